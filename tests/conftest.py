@@ -1,0 +1,24 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_bin():
+    """Path of the CPU oracle binary (test infrastructure only); built on demand with g++."""
+    d = os.path.join(ROOT, "oracle")
+    exe = os.path.join(d, "modkit_oracle")
+    srcs = [os.path.join(d, f) for f in ("modkit_oracle.cpp", "oracle_core.hpp", "oracle_pileup.hpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.check_call(["make", "-C", d, "modkit_oracle"])
+    return exe

@@ -1,0 +1,52 @@
+"""The reference's own pileup integration cases (/root/reference/tests/test_pileup.rs), as
+(name, flags, input BAM, golden bedMethyl) over the data fixtures in tests/golden/modkit_fixtures.
+Shared by the oracle pinning tests (CPU) and the HIP parity tests (GPU)."""
+import os
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "modkit_fixtures")
+_CG = "CG_5mC_20230207_1700_6A_PAG66026_3c0abf27_oligo_741_adapters_modcalls_0th_sort_10_reads"
+BC = "bc_anchored_10_reads.sorted.bam"
+REF = os.path.join(FIX, "CGI_ladder_3.6kb_ref.fa")
+BED = os.path.join(FIX, "CGI_ladder_3.6kb_ref_include_positions.bed")
+_MOT = ["--motif", "CG", "0", "--motif", "CGCG", "2", "--mixed-delim", "--no-filtering", "--ref", REF,
+        "--region", "oligo_741_adapters:22-62"]
+
+# (test name in tests/test_pileup.rs : line) -> case
+GOLDEN_CASES = [
+    ("test_pileup_no_filt:23", ["-i", "25", "--no-filtering", "--only-tabs"], BC, "modbam.modpileup_nofilt.methyl.bed"),
+    ("test_pileup_with_header:900", ["-i", "25", "--no-filtering", "--with-header"], BC, "pileup_with_header.bed"),
+    ("test_pileup_with_filt:44", ["-i", "25", "-f", "1.0", "-p", "0.25", "--only-tabs", "--seed", "42",
+                                  "--include-unmapped"], BC, "modbam.modpileup_filt025.methyl.bed"),
+    ("test_pileup_combine:71", ["--combine-mods", "--no-filtering", "--only-tabs"], BC,
+     "modbam.modpileup_combined.methyl.bed"),
+    ("test_pileup_with_region:194", ["--region", "oligo_1512_adapters:0-50", "--no-filtering", "--mixed-delim"], BC,
+     "modbam.modpileup_nofilt_oligo_1512_adapters_10_50.bed"),
+    ("test_pileup_duplex_reads:217", ["--region", "chr17", "--no-filtering", "--mixed-delim"],
+     "duplex_modbam.sorted.bam", "duplex_modbam_pileup_nofilt.bed"),
+    ("test_pileup_cpg_motif_filtering:237", ["--no-filtering", "--mixed-delim", "--cpg", "--ref", REF], BC,
+     "bc_anchored_10_reads_nofilt_cg_motif.bed"),
+    ("test_pileup_edge_filter_regression:360", ["--no-filtering", "--mixed-delim", "--edge-filter", "50"], BC,
+     "bc_anchored_10_reads_edge_filter50.bed"),
+    ("test_pileup_edge_filter_asymmetric_regression:418", ["--no-filtering", "--mixed-delim", "--edge-filter", "50,0"],
+     BC, "bc_anchored_10_reads_edge_filter50-0.bed"),
+    ("test_pileup_with_filt_position_filter:639", ["--mixed-delim", "-i", "25", "-p", "0.25", "--include-positions", BED],
+     BC, "modbam.modpileup_filt_positions_025.methyl.bed"),
+    ("test_pileup_with_filter_positions_and_traditional:663",
+     ["--mixed-delim", "-i", "25", "-p", "0.25", "--include-positions", BED, "--preset", "traditional", "--ref", REF],
+     BC, "modbam.modpileup_filt_positions_025_traditional.methyl.bed"),
+    ("test_pileup_motifs_cg0_cgcg2:738a", _MOT, _CG + ".bam", "cgcg2_cg0_test1.bed"),
+    ("test_pileup_motifs_cg0_cgcg2:738b", _MOT, _CG + "-2.bam", "cgcg2_cg0_test2.bed"),
+    ("test_pileup_motifs_cg0_cgcg2_combined:779a", _MOT + ["--combine-strands"], _CG + ".bam",
+     "cgcg2_cg0_test1_combine_strands.bed"),
+    ("test_pileup_motifs_cg0_cgcg2_combined:779b", _MOT + ["--combine-strands"], _CG + "-2.bam",
+     "cgcg2_cg0_test2_combine_strands.bed"),
+] + [
+    ("test_pileup_cpg_motif_filtering_strand_combine:257[i=%s]" % isz,
+     ["--no-filtering", "--mixed-delim", "-i", isz, "--cpg", "--combine-strands", "--ref", REF], BC,
+     "bc_anchored_10_reads_nofilt_cg_motif_strand_combine.bed")
+    for isz in ["10", "88", "89", "90", "91", "92", "93", "94", "10000"]
+]
+
+
+def fixture(name):
+    return os.path.join(FIX, name)

@@ -1,0 +1,52 @@
+"""Pins the CPU oracle (oracle/, test infrastructure) against the reference's own golden bedMethyl
+files: every case of /root/reference/tests/test_pileup.rs whose inputs ship with the reference and that
+does not need another subcommand.  Whole-file byte comparison, as check_against_expected_text_file does
+(/root/reference/tests/common/mod.rs:113-135)."""
+import subprocess
+
+import pytest
+
+from pileup_cases import BC, GOLDEN_CASES, REF, fixture
+
+
+def run_oracle(oracle_bin, bam, out, flags):
+    p = subprocess.run([oracle_bin, "pileup", bam, out] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    return p.stderr
+
+
+@pytest.mark.parametrize("name,flags,bam,golden", GOLDEN_CASES, ids=[c[0] for c in GOLDEN_CASES])
+def test_oracle_reproduces_reference_golden(oracle_bin, tmp_path, name, flags, bam, golden):
+    out = str(tmp_path / "out.bed")
+    run_oracle(oracle_bin, fixture(bam), out, flags)
+    assert open(out).read() == open(fixture(golden)).read()
+
+
+def test_duplicated_reads_ignored(oracle_bin, tmp_path):
+    # tests/test_pileup.rs:326 — DUP / secondary / supplementary records do not contribute
+    a, b = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
+    run_oracle(oracle_bin, fixture("duplicated.marked.fixed.bam"), a, ["--no-filtering"])
+    run_oracle(oracle_bin, fixture(BC), b, ["--no-filtering"])
+    assert open(a).read() == open(b).read() and len(open(a).read()) > 0
+
+
+def test_no_mod_calls(oracle_bin, tmp_path):
+    # tests/test_pileup.rs:143 — reads without usable tags are coverage-only: no rows
+    out = str(tmp_path / "o.bed")
+    run_oracle(oracle_bin, fixture("empty-tags.sorted.bam"), out, ["--no-filtering"])
+    assert open(out).read() == ""
+
+
+def test_preset_traditional_same_as_options(oracle_bin, tmp_path):
+    # tests/test_pileup.rs:286
+    a, b = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
+    run_oracle(oracle_bin, fixture(BC), a, ["--preset", "traditional", "--ref", REF, "--no-filtering"])
+    run_oracle(oracle_bin, fixture(BC), b, ["--cpg", "--ignore", "h", "--combine-strands", "--ref", REF, "--no-filtering"])
+    assert open(a).read() == open(b).read() and len(open(a).read().splitlines()) == 11
+
+
+def test_estimated_thresholds_match_reference_values(oracle_bin, tmp_path):
+    # thresholds the reference derives for its goldens (SURVEY.md verification note): f32-exact
+    err = run_oracle(oracle_bin, fixture(BC), str(tmp_path / "o.bed"),
+                     ["-i", "25", "-f", "1.0", "-p", "0.25", "--include-unmapped"])
+    assert "threshold C 0.662109375 (n=109)" in err
