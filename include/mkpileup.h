@@ -1,0 +1,175 @@
+/* mkpileup.h — C ABI of libmkpileup: the MI355X (gfx950) implementation of modkit's `pileup`
+ * hot path (MM/ML decode -> threshold caller -> per-position aggregation -> bedMethyl rows).
+ *
+ * The reference (nanoporetech/modkit v0.4.4, pure Rust) has no FFI on this path.  The seam this
+ * library replaces is the Rust function
+ *     pub fn process_region_batch(&MultiChromCoordinates, bam_fp, &MultipleThresholdModCaller,
+ *                                 &PileupNumericOptions, force_allow, combine_strands, max_depth,
+ *                                 Option<&EdgeFilter>, Option<&Vec<SamTag>>)
+ *         -> Vec<Result<ModBasePileup, String>>                       (src/pileup/mod.rs:684-716)
+ * called from ModBamPileup::run (src/pileup/subcommand.rs:733-753) and consumed by
+ * PileupWriter::write (src/writers.rs:159-183).  Each entry point below names the reference item
+ * it stands in for.  INTEGRATION.md shows the Rust `extern "C"` binding.
+ *
+ * Conventions: every function returns MKP_OK (0) or a negative mkp_status and never unwinds;
+ * mkp_last_error() gives the message.  A mkp_ctx is NOT thread-safe (one per host worker thread,
+ * any number per GPU).  Input buffers stay owned by the caller and may be freed as soon as the
+ * call that read them returns.  Output arrays (mkp_rows) are owned by the ctx and stay valid
+ * until the next mkp_shard_run/mkp_process_region on that ctx or mkp_ctx_destroy.
+ * There is no CPU fallback: inputs the device path does not cover fail with MKP_E_UNSUPPORTED.
+ */
+#ifndef MKPILEUP_H
+#define MKPILEUP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MKP_OK = 0,
+  MKP_E_INVALID = -1,     /* bad argument / call order */
+  MKP_E_IO = -2,          /* file open / parse failure */
+  MKP_E_UNSUPPORTED = -3, /* input outside the device path's coverage */
+  MKP_E_DEVICE = -4,      /* HIP runtime error, or no gfx950 device */
+  MKP_E_NOMEM = -5,
+  MKP_E_THRESHOLD = -6    /* threshold estimation failed (e.g. < 2 datapoints, thresholds.rs:18) */
+} mkp_status;
+
+typedef struct mkp_ctx mkp_ctx;
+
+typedef struct {
+  int32_t device;          /* HIP device ordinal */
+  uint32_t tile_positions; /* reference positions per LDS tile; 0 = derive from the LDS budget */
+  uint32_t reserved[6];
+} mkp_config;
+
+/* mod code encoding = ModCodeRepr (src/mod_base_code.rs:105-109):
+ *   Code(char)  -> the code point (e.g. 'm' = 0x6d);  ChEbi(id) -> 0x80000000 | id.
+ * Numeric order of this encoding is the reference's row order (derived Ord: Code < ChEbi). */
+#define MKP_CODE_CHAR(c) ((uint32_t)(unsigned char)(c))
+#define MKP_CODE_CHEBI(id) (0x80000000u | (uint32_t)(id))
+
+typedef struct { uint32_t code_repr; float threshold; } mkp_mod_threshold;
+
+/* Replaces MultipleThresholdModCaller (src/threshold_mod_caller.rs:8-13) + PileupNumericOptions
+ * (src/pileup/mod.rs:667-671) + EdgeFilter (src/mod_bam.rs:1634-1639) + the force_allow /
+ * combine_strands / max_depth arguments of process_region_batch. Bases are indexed A,C,G,T = 0..3. */
+typedef struct {
+  float default_threshold;
+  float per_base_threshold[4];
+  uint8_t has_per_base[4];
+  const mkp_mod_threshold* per_mod;
+  uint32_t n_per_mod;
+  uint32_t numeric_mode;   /* 0 Passthrough, 1 Combine (--combine-mods), 2 Collapse(ReDistribute(collapse_code)) */
+  uint32_t collapse_code;  /* code_repr, used when numeric_mode == 2 (--ignore / --preset traditional) */
+  uint32_t edge_filter;    /* 0/1 */
+  uint32_t edge_start, edge_end, edge_inverted;
+  uint32_t force_allow_implicit;
+  uint32_t combine_strands;
+  uint32_t max_depth;      /* columns deeper than this fail loudly (htslib maxcnt is not restated) */
+} mkp_caller;
+
+/* One alignment record = the fields of htslib's bam1_t the path reads
+ * (rust-htslib Record: tid/pos/flags/cigar/seq/aux — src/pileup/mod.rs:783-862, src/mod_bam.rs:1388-1470).
+ * `data` is bam1_t::data: qname | cigar u32[n_cigar] | 4-bit seq | qual | aux. */
+typedef struct {
+  int32_t tid;
+  int32_t pos;
+  uint16_t flag;
+  uint16_t l_qname; /* including the NUL, as bam1_core_t.l_qname */
+  uint32_t n_cigar;
+  int32_t l_qseq;
+  int32_t l_data;
+  const uint8_t* data;
+} mkp_record;
+
+/* Focus positions of a shard = FocusPositions (src/interval_chunks.rs:32-59) flattened:
+ * one byte per reference position of [start,end): bits 0-1 = strand rule (1 = '+' tally only,
+ * 2 = '-' tally only, 3 = both, 0 = position not in focus); bits 2-7 = index into `combos`
+ * (0 = no motif ids).  focus == NULL means FocusPositions::AllPositions. */
+#define MKP_MAX_MOTIF_IDS 4
+typedef struct {
+  uint8_t n_pos;                          /* motif ids attached to '+' rows (get_positive_strand_motif_ids) */
+  uint8_t n_neg;                          /* motif ids attached to '-' rows (get_negative_strand_motif_ids) */
+  uint8_t pos_ids[MKP_MAX_MOTIF_IDS];
+  uint8_t neg_ids[MKP_MAX_MOTIF_IDS];
+  int8_t pos_delta[MKP_MAX_MOTIF_IDS];    /* combine-strands: MotifInfo::negative_strand_position offset; -128 = none */
+  uint8_t pad[2];
+} mkp_motif_combo;
+
+typedef struct {
+  int32_t tid;
+  uint32_t start, end;          /* reference window; rows are produced for positions in [start,end) */
+  const uint8_t* focus;         /* (end-start) bytes or NULL */
+  const mkp_motif_combo* combos;
+  uint32_t n_combos;
+} mkp_shard;
+
+/* Result rows = PileupFeatureCounts (src/pileup/mod.rs:54-68) as SoA, already in the order
+ * ModBasePileup::iter_counts_sorted + the per-position (strand, code) sort would give
+ * (src/pileup/mod.rs:440-443, 659-664).  fraction_modified is n_mod as f32 / n_valid as f32. */
+typedef struct {
+  uint64_t n_rows;
+  const uint32_t* pos;
+  const uint8_t* strand;      /* '+', '-' or '.' */
+  const uint32_t* code_repr;
+  const int32_t* motif_idx;   /* -1 = None */
+  const uint32_t* n_valid;    /* filtered_coverage */
+  const uint32_t* n_mod;
+  const uint32_t* n_canonical;
+  const uint32_t* n_other;
+  const uint32_t* n_delete;
+  const uint32_t* n_fail;     /* n_filtered */
+  const uint32_t* n_diff;
+  const uint32_t* n_nocall;
+  uint64_t processed_records; /* reads that yielded mod calls (read_cache.rs:357-365) */
+  uint64_t skipped_records;   /* coverage-only reads (skip_set) */
+} mkp_rows;
+
+typedef struct {
+  double pack_ms, h2d_ms, kernel_ms, d2h_ms;  /* last shard */
+  double decode_kernel_ms, pileup_kernel_ms, gather_kernel_ms;
+  uint64_t n_reads, n_events, n_rows, n_tiles, n_positions;
+  uint64_t alg_bytes_decode, alg_bytes_pileup; /* SURVEY.md §8(d) algorithmic bytes for the two kernels */
+} mkp_stats;
+
+/* ---- lifecycle */
+int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out);
+void mkp_ctx_destroy(mkp_ctx* ctx);
+const char* mkp_last_error(const mkp_ctx* ctx);
+const char* mkp_version(void);
+
+/* ---- caller / options: stands in for the `caller`, `pileup_numeric_options`, `force_allow`,
+ *      `combine_strands`, `max_depth`, `edge_filter` arguments of process_region_batch */
+int mkp_set_caller(mkp_ctx* ctx, const mkp_caller* caller);
+
+/* ---- the hot path on records the host already holds (rust-htslib fetch()+records()):
+ * begin a shard, append its records in coordinate order, run.  Replaces the body of
+ * process_region (src/pileup/mod.rs:718-1020) for every interval inside the shard. */
+int mkp_shard_begin(mkp_ctx* ctx, const mkp_shard* shard);
+int mkp_shard_add_records(mkp_ctx* ctx, const mkp_record* recs, uint32_t n);
+int mkp_shard_run(mkp_ctx* ctx, mkp_rows* out);
+
+/* Re-run the device pipeline on the shard that is already resident in HBM (no pack, no H2D):
+ * what bench.py times.  `iters` launches; rows of the last one are returned. */
+int mkp_shard_rerun(mkp_ctx* ctx, uint32_t iters, mkp_rows* out);
+int mkp_get_stats(const mkp_ctx* ctx, mkp_stats* out);
+
+/* ---- same, reading the BAM itself: direct stand-in for process_region_batch(bam_fp, ...) */
+int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shard, mkp_rows* out);
+
+/* ---- whole subcommand: `modkit pileup` (ModBamPileup::run, src/pileup/subcommand.rs:382-816).
+ * argv carries the reference's own flags (in.bam out.bed --cpg --ref ... ), see DESIGN.md for the
+ * covered set; plus --device N, --gpus-rank R --gpus-world W for interval sharding. */
+int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
+
+/* ---- threshold arithmetic: percentile_linear_interp (src/thresholds.rs:17-38) over values the
+ * device histogrammed; and the f32 histogram itself for multi-GPU all-reduce. */
+int mkp_percentile(const float* sorted, uint64_t n, float q, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKPILEUP_H */

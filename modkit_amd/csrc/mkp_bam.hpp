@@ -1,0 +1,144 @@
+// Host-side ingest for libmkpileup: BGZF/BAM reader (block-parallel inflate), FASTA (+.fai not
+// required), BED.  This is the IO substrate the reference gets from rust-htslib / bio
+// (src/pileup/mod.rs:732-743, src/fasta.rs:34,106-111, src/position_filter.rs:230-347); it feeds
+// mkp_record views to the packer.  Whole-file residency (decompressed BAM kept in host RAM) is the
+// round-1 design; BAI-indexed streaming is listed under "next" in DESIGN.md.
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mkpileup.h"
+
+namespace mkp {
+
+struct Error : std::runtime_error {
+  int status;
+  Error(int st, const std::string& m) : std::runtime_error(m), status(st) {}
+};
+
+struct BamIndexEntry {  // one alignment record inside `raw`
+  uint64_t off;         // offset of the record's 32-byte core (after block_size)
+  int32_t tid, pos, end;  // end = bam_endpos (pos+1 for records without reference length)
+  int32_t reflen;
+  uint16_t flag;
+};
+
+struct BamData {
+  std::vector<std::string> ref_names;
+  std::vector<uint32_t> ref_lens;
+  std::vector<uint8_t> raw;  // decompressed stream
+  std::vector<BamIndexEntry> recs;
+  std::vector<size_t> tid_first;  // first record index per tid (+ sentinel), records are coordinate sorted
+
+  int tid_of(const std::string& n) const { for (size_t i = 0; i < ref_names.size(); i++) if (ref_names[i] == n) return (int)i; return -1; }
+
+  mkp_record view(const BamIndexEntry& e) const {
+    const uint8_t* c = &raw[e.off];
+    mkp_record r;
+    memcpy(&r.tid, c, 4); memcpy(&r.pos, c + 4, 4);
+    r.l_qname = c[8];
+    uint16_t nc; memcpy(&nc, c + 12, 2); r.n_cigar = nc;
+    memcpy(&r.flag, c + 14, 2);
+    memcpy(&r.l_qseq, c + 16, 4);
+    uint32_t bs; memcpy(&bs, c - 4, 4);
+    r.l_data = (int32_t)bs - 32;
+    r.data = c + 32;
+    return r;
+  }
+};
+
+static inline void inflate_block(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
+  z_stream zs; memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, -15) != Z_OK) throw Error(MKP_E_IO, "zlib init failed");
+  zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = (uInt)dlen;
+  int rc = inflate(&zs, Z_FINISH);
+  inflateEnd(&zs);
+  if (rc != Z_STREAM_END || zs.avail_out != 0) throw Error(MKP_E_IO, "corrupt BGZF block");
+}
+
+static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) throw Error(MKP_E_IO, "cannot open " + path);
+  fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+  std::vector<uint8_t> comp((size_t)sz);
+  if (sz && fread(comp.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); throw Error(MKP_E_IO, "short read " + path); }
+  fclose(f);
+  struct Blk { size_t coff, clen, doff, dlen; };
+  std::vector<Blk> blks; size_t o = 0, dtotal = 0;
+  while (o + 18 <= comp.size()) {
+    if (comp[o] != 31 || comp[o + 1] != 139) throw Error(MKP_E_IO, "not BGZF: " + path);
+    uint16_t xlen; memcpy(&xlen, &comp[o + 10], 2);
+    size_t x = o + 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &comp[x + 2], 2); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2) { uint16_t b; memcpy(&b, &comp[x + 4], 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + sl; }
+    if (!found || o + bsize > comp.size()) throw Error(MKP_E_IO, "bad BGZF block in " + path);
+    uint32_t isize; memcpy(&isize, &comp[o + bsize - 4], 4);
+    blks.push_back({o + 12 + xlen, bsize - xlen - 20, dtotal, isize});
+    dtotal += isize; o += bsize;
+  }
+  BamData bd; bd.raw.resize(dtotal);
+  if (!threads) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::atomic<size_t> next{0}; std::atomic<bool> bad{false};
+  auto work = [&]() { for (;;) { size_t i = next++; if (i >= blks.size()) break; if (!blks[i].dlen) continue; try { inflate_block(&comp[blks[i].coff], blks[i].clen, &bd.raw[blks[i].doff], blks[i].dlen); } catch (...) { bad = true; } } };
+  if (threads <= 1 || blks.size() < 4) work(); else { std::vector<std::thread> th; for (unsigned t = 0; t < threads; t++) th.emplace_back(work); for (auto& t : th) t.join(); }
+  if (bad) throw Error(MKP_E_IO, "corrupt BGZF data in " + path);
+  comp.clear(); comp.shrink_to_fit();
+  const std::vector<uint8_t>& d = bd.raw; o = 0;
+  auto need = [&](size_t n) { if (o + n > d.size()) throw Error(MKP_E_IO, "truncated BAM " + path); };
+  need(12);
+  if (memcmp(&d[0], "BAM\1", 4) != 0) throw Error(MKP_E_IO, "not a BAM file: " + path);
+  int32_t l_text; memcpy(&l_text, &d[4], 4); o = 8; need((size_t)l_text + 4); o += (size_t)l_text;
+  int32_t n_ref; memcpy(&n_ref, &d[o], 4); o += 4;
+  for (int i = 0; i < n_ref; i++) {
+    need(4); int32_t ln; memcpy(&ln, &d[o], 4); o += 4; need((size_t)ln + 4);
+    bd.ref_names.push_back(std::string((const char*)&d[o], ln > 0 ? (size_t)ln - 1 : 0)); o += (size_t)ln;
+    uint32_t lr; memcpy(&lr, &d[o], 4); o += 4; bd.ref_lens.push_back(lr);
+  }
+  while (o + 4 <= d.size()) {
+    int32_t bs; memcpy(&bs, &d[o], 4); o += 4; need((size_t)bs);
+    if (bs < 32) throw Error(MKP_E_IO, "corrupt BAM record");
+    BamIndexEntry e; e.off = o;
+    memcpy(&e.tid, &d[o], 4); memcpy(&e.pos, &d[o + 4], 4);
+    uint8_t lq = d[o + 8]; uint16_t nc; memcpy(&nc, &d[o + 12], 2); memcpy(&e.flag, &d[o + 14], 2);
+    int64_t rl = 0; const uint8_t* cg = &d[o + 32 + lq];
+    if ((size_t)32 + lq + 4 * (size_t)nc > (size_t)bs) throw Error(MKP_E_IO, "corrupt BAM record");
+    for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4; }
+    e.reflen = (int32_t)rl; e.end = e.pos + (rl > 0 ? (int32_t)rl : 1);
+    bd.recs.push_back(e); o += (size_t)bs;
+  }
+  bd.tid_first.assign(bd.ref_names.size() + 1, bd.recs.size());
+  for (size_t i = bd.recs.size(); i-- > 0;) { int t = bd.recs[i].tid; if (t >= 0 && (size_t)t < bd.ref_names.size()) bd.tid_first[(size_t)t] = i; }
+  for (size_t t = bd.ref_names.size(); t-- > 0;) if (bd.tid_first[t] == bd.recs.size() && t + 1 <= bd.ref_names.size()) bd.tid_first[t] = bd.tid_first[t + 1];
+  return bd;
+}
+
+// ------------------------------------------------------------------------------------ FASTA
+struct Fasta {
+  std::map<std::string, std::string> seqs;
+  static Fasta load(const std::string& path) {
+    Fasta f; std::ifstream in(path);
+    if (!in) throw Error(MKP_E_IO, "cannot open fasta " + path);
+    std::string line; std::string* cur = nullptr;
+    while (std::getline(in, line)) {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (line.empty()) continue;
+      if (line[0] == '>') { std::string n = line.substr(1); size_t sp = n.find_first_of(" \t"); if (sp != std::string::npos) n.resize(sp); cur = &f.seqs[n]; }
+      else if (cur) cur->append(line);
+    }
+    return f;
+  }
+  const std::string* get(const std::string& name) const { auto it = seqs.find(name); return it == seqs.end() ? nullptr : &it->second; }
+};
+
+}  // namespace mkp

@@ -1,0 +1,55 @@
+// Internal (not installed): the context behind the opaque mkp_ctx handle, shared by mkp_api.cpp and
+// mkp_driver.cpp.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+
+#include "mkp_pack.hpp"
+
+namespace mkp {
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; throw Error(MKP_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed"); }
+    cap = want;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+inline void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+inline double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+
+struct SampleOut {  // one entry per packed read, in input order
+  std::vector<uint32_t> ok, n, off; std::vector<float> vals; std::vector<uint8_t> base;
+};
+}  // namespace mkp
+
+struct mkp_ctx {
+  int device = 0; hipStream_t stream = nullptr; std::string err; mkp_config cfg;
+  mkp::CallerCfg caller; bool caller_set = false;
+  mkp::Packer packer; mkp::ShardHost shard; mkp::LayoutTables tables; bool shard_open = false, resident = false;
+  std::vector<uint8_t> focus; bool has_focus = false; std::vector<mkp_motif_combo> combos;
+  MkpRunParams prm; uint32_t lds_bytes = 0, n_tiles = 0; uint64_t row_cap = 0;
+  mkp::DevBuf d_hdr, d_vals, d_cigar, d_seq, d_tagref, d_ranks, d_ml, d_layouts, d_events, d_readout, d_focus, d_combos, d_tile_ids, d_tile_first, d_tile_last,
+      d_tile_row_off, d_tile_row_cnt, d_tile_dst, d_misc, d_rows_src, d_rows_dst;
+  MkpRowsDev rows_src, rows_dst;
+  std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif;
+  uint64_t n_ok = 0, n_bad = 0;
+  mkp_stats stats;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// threshold sampling pass on the device (decode kernel in sample mode); `recs` need not pass Packer::keep
+int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,
+                        uint32_t n, bool only_mapped, mkp::SampleOut* out);

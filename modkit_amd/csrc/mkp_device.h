@@ -1,0 +1,120 @@
+// Structures shared by the host packer and the gfx950 kernels.
+// Data layout in HBM for one shard (a reference window of one contig):
+//   MkpReadHdr  hdr[n_reads]        48 B each, coordinate order
+//   uint32      cigar[]             BAM cigar words (len<<4|op)
+//   uint8       seq[]               BAM 4-bit packed bases, each read 4-byte aligned
+//   MkpTagRef   tagref[]            one per MM tag of each read
+//   uint32      ranks[]             per call: cumulative occurrence index of the tag's fundamental
+//                                   base in the as-sequenced read (Σ(delta+1)-1, mod_bam.rs:697-733),
+//                                   or the absolute forward position for `N` tags (735-767)
+//   uint8       ml[]                ML qualities (bytes of the B:C array)
+//   MkpLayout   layout[]            interned MM header structure + caller tables (host-built)
+//   MkpEvent    events[]            written by mkp_decode_reads, read by mkp_pileup_tiles
+//   MkpReadOut  readout[n_reads]    per-read decode summary
+#pragma once
+#include <stdint.h>
+
+#define MKP_MAX_TAGS 8        // MM tags per read
+#define MKP_KMAX 4            // distinct mod codes per (mod strand, base) group
+#define MKP_MAX_MEMBERS 4     // tags per (mod strand, base) group
+#define MKP_MAX_SLOTS 12      // distinct (primary base, code) pairs per run
+#define MKP_MAX_COUNTERS (6 + 4 + MKP_MAX_SLOTS)
+#define MKP_PAT_INFERRED 16   // pattern index of the all-inferred ('.' mode) case
+#define MKP_HALO 16           // tile halo for strand combining (motif length <= 16)
+
+// counter ids inside one strand tally (Tally, pileup/mod.rs:167-174)
+#define MKP_C_NC 0            // NoCall(base) 0..3
+#define MKP_C_DEL 4
+#define MKP_C_FAIL 5
+#define MKP_C_CAN 6           // + index of primary base among the run's primary bases; MOD ids follow
+
+struct MkpReadHdr {
+  int32_t ref_start, ref_end;
+  uint32_t l_seq, n_cigar;
+  uint32_t cigar_off;   // index into cigar[]
+  uint32_t seq_off;     // byte offset into seq[]
+  uint32_t tag_off;     // index into tagref[]
+  uint16_t n_tags;
+  uint16_t layout;
+  uint32_t flags;       // bit0 reverse; bit1 host-detected tag error (coverage-only read)
+  uint32_t event_off;   // index into events[]
+  uint32_t event_cap;
+  uint32_t pad;
+};
+#define MKP_RF_REVERSE 1u
+#define MKP_RF_BAD 2u
+
+struct MkpTagRef { uint32_t rank_off, n, ml_off, pad; };
+
+struct MkpEvent {  // the packed (ref_pos, strand, class, base) event of BASELINE.json's north_star
+  uint32_t pos;
+  uint32_t info;   // [0:7] counter id of the call class, [8] tally strand of the call,
+                   // [9:10] read base, [11] alignment strand, [12] decrement NoCall(read base)
+};
+
+struct MkpReadOut { uint32_t n_events; uint32_t ok; uint32_t obs[2]; };  // obs: slot bitmask per tally strand
+
+struct MkpTagDesc { uint8_t fb /*0..3, 4 = N*/, neg, mode /*0 ? 1 . 2 default*/, n_codes; };
+
+struct MkpGroupDesc {          // one (mod strand σ, read base b) group; index σ*4+b
+  uint8_t n_members, n_codes, threshold_base, implicit_members;  // implicit_members: bitmask of members in '.'/default mode with fb != N
+  int8_t collapse_local;       // local idx of the code removed by ReDistribute, or -1
+  uint8_t cid_can;             // counter id of Canonical(threshold_base)
+  uint8_t pad[2];
+  uint8_t members[MKP_MAX_MEMBERS];                      // tag indices, MM order
+  uint8_t member_code_local[MKP_MAX_MEMBERS][MKP_KMAX];  // tag's i-th code -> local code idx
+  uint8_t slot[MKP_KMAX];                                // local code -> global slot
+  uint8_t cid_mod[MKP_KMAX];                             // local code -> counter id of Modified(code)
+  uint8_t n_pre[17], n_post[17];                         // per hit pattern: map sizes before / after collapse
+  uint8_t order_pre[17][MKP_KMAX];                       // FxHashMap iteration order (local idx) before collapse
+  uint8_t order_post[17][MKP_KMAX];                      // ... of the map the caller iterates
+  float thr_mod[MKP_KMAX];
+  float thr_can;
+};
+
+struct MkpLayout {
+  uint8_t n_tags;
+  uint8_t default_mask;   // tags whose mode is DefaultImplicitUnmodified
+  uint8_t pad[2];
+  MkpTagDesc tags[MKP_MAX_TAGS];
+  MkpGroupDesc groups[8];
+};
+
+struct MkpSlot { uint32_t code_repr; uint8_t pb; uint8_t cid; uint8_t can_cid; uint8_t pad; };
+
+struct MkpCombo {  // == mkp_motif_combo
+  uint8_t n_pos, n_neg;
+  uint8_t pos_ids[4], neg_ids[4];
+  int8_t pos_delta[4];
+  uint8_t pad[2];
+};
+
+struct MkpRunParams {
+  // reference window
+  int32_t win_start, win_end;
+  uint32_t tile, n_tiles_total;
+  // counters
+  uint32_t n_counters;      // per strand tally
+  uint32_t n_slots;
+  uint32_t n_pb;            // distinct primary bases with CAN counters
+  uint32_t numeric_mode;    // 0 passthrough / 2 collapse (same row logic), 1 combine
+  uint32_t combine_strands;
+  uint32_t edge_filter, edge_start, edge_end, edge_inverted;
+  uint32_t force_allow;
+  uint32_t max_depth;
+  uint32_t has_focus;
+  uint32_t n_combos;
+  uint32_t row_capacity;
+  uint32_t sample_mode;     // 1: threshold sampling pass — emit argmax probabilities instead of call events
+  uint32_t only_mapped;     // sampling: keep only calls with an aligned reference position
+  uint8_t pb_of_can[4];     // CAN counter k -> primary base
+  uint8_t can_of_pb[4];     // primary base -> CAN counter k or 0xff
+  uint8_t slot_order[MKP_MAX_SLOTS];   // slots sorted by (code_repr, pb)
+  MkpSlot slots[MKP_MAX_SLOTS];
+};
+
+struct MkpRowsDev {  // SoA row buffers (44 B / row)
+  uint32_t* pos; uint32_t* info; uint32_t* code;
+  uint32_t* n_valid; uint32_t* n_mod; uint32_t* n_can; uint32_t* n_other;
+  uint32_t* n_del; uint32_t* n_fail; uint32_t* n_diff; uint32_t* n_nocall;
+};

@@ -1,0 +1,381 @@
+// `modkit pileup` as a library call: mkp_pileup_main mirrors ModBamPileup::run
+// (src/pileup/subcommand.rs:382-816) — same flags, same option resolution, same bedMethyl text —
+// with process_region_batch replaced by shards on the GPU.  Host work here is scheduling only:
+// BAM ingest, the interval grid + focus positions, choosing which reads the threshold sampler takes
+// (reads_sampler/*, sampling_schedule.rs), and formatting rows (writers.rs:87-156).
+#include <set>
+
+#include "mkp_ctx.hpp"
+#include "mkp_focus.hpp"
+
+using namespace mkp;
+
+namespace {
+
+struct Args {
+  std::string in_bam, out_bed, region, sample_region, include_bed, ignore, ref_fasta, edge_filter, preset;
+  uint32_t max_depth = 8000, interval_size = 100000, sampling_interval_size = 1000000;
+  size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
+  std::vector<std::string> filter_threshold, mod_thresholds, motif_parts;
+  bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
+  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false;
+};
+
+struct RegionSpec { std::string name; uint32_t start, end; };
+
+RegionSpec parse_region(const std::string& raw, const BamData& bam) {  // Region::parse_str (util.rs:463-524)
+  auto bad = [&]() { return Error(MKP_E_INVALID, "invalid region, " + raw + ", should be 'chrom' or 'chrom:start-stop'"); };
+  size_t c = raw.find(':');
+  if (c == std::string::npos) { int tid = bam.tid_of(raw); if (tid < 0) throw Error(MKP_E_INVALID, "contig-missing"); return {raw, 0, bam.ref_lens[(size_t)tid]}; }
+  if (raw.find(':', c + 1) != std::string::npos) throw bad();
+  std::string se = raw.substr(c + 1); std::vector<uint32_t> v; size_t s = 0;
+  for (;;) { size_t d = se.find('-', s); std::string part = se.substr(s, d == std::string::npos ? std::string::npos : d - s), cl; for (char ch : part) if (ch != ',') cl += ch; if (cl.empty()) throw bad(); uint64_t x = 0; for (char ch : cl) { if (ch < '0' || ch > '9') throw bad(); x = x * 10 + (uint64_t)(ch - '0'); if (x > 0xffffffffull) throw bad(); } v.push_back((uint32_t)x); if (d == std::string::npos) break; s = d + 1; }
+  if (v.size() != 2 || v[1] <= v[0]) throw bad();
+  return {raw.substr(0, c), v[0], v[1]};
+}
+
+bool parse_code(const std::string& s, uint32_t* out) {  // ModCodeRepr::parse (mod_base_code.rs:112-122)
+  if (s.size() == 1) { *out = (uint32_t)(unsigned char)s[0]; return true; }
+  if (s.empty()) return false;
+  uint64_t v = 0; for (char c : s) { if (c < '0' || c > '9') return false; v = v * 10 + (uint64_t)(c - '0'); if (v > 0x7fffffffull) return false; }
+  *out = 0x80000000u | (uint32_t)v; return true;
+}
+
+std::vector<Contig> targets(const BamData& bam, const RegionSpec* r) {  // get_targets (util.rs:409-446)
+  std::vector<Contig> out;
+  for (size_t t = 0; t < bam.ref_names.size(); t++) { if (r) { if (bam.ref_names[t] == r->name) out.push_back({(uint32_t)t, r->start, r->end - r->start, bam.ref_names[t]}); } else out.push_back({(uint32_t)t, 0, bam.ref_lens[t], bam.ref_names[t]}); }
+  return out;
+}
+
+struct IdxStats { std::map<int64_t, uint64_t> mapped_by_tid; uint64_t mapped = 0, unmapped = 0; };
+IdxStats idxstats(const BamData& bam, const RegionSpec* region, const BedFilter* bf) {  // IdxStats::new_from_reader (sampling_schedule.rs:649-716)
+  IdxStats st; int rt = region ? bam.tid_of(region->name) : -1;
+  if (region && rt < 0) throw Error(MKP_E_INVALID, "did not find target_id for region");
+  std::vector<uint64_t> m(bam.ref_names.size(), 0), u(bam.ref_names.size(), 0); uint64_t nocoor = 0;
+  for (auto& r : bam.recs) { if (r.tid < 0) nocoor++; else if (r.flag & 4) u[(size_t)r.tid]++; else m[(size_t)r.tid]++; }
+  auto keep = [&](int64_t t) { if (region) return t == rt; if (bf) return bf->has_chrom(t); return true; };
+  for (size_t t = 0; t < m.size(); t++) if (keep((int64_t)t)) { st.mapped += m[t]; st.unmapped += u[t]; st.mapped_by_tid[(int64_t)t] = m[t]; }
+  if (keep(-1)) st.unmapped += nocoor;
+  return st;
+}
+
+// records of `tid` overlapping [start,end) in file order (IndexedReader::fetch)
+void fetch(const BamData& bam, uint32_t tid, uint32_t start, uint32_t end, std::vector<size_t>* out) {
+  out->clear();
+  if (tid >= bam.ref_names.size()) return;
+  for (size_t i = bam.tid_first[tid]; i < bam.tid_first[tid + 1] && i < bam.recs.size(); i++) {
+    const BamIndexEntry& e = bam.recs[i];
+    if (e.tid != (int32_t)tid) continue;
+    if ((int64_t)e.pos >= (int64_t)end) break;
+    if ((int64_t)e.end > (int64_t)start) out->push_back(i);
+  }
+}
+
+struct Quota { bool all = false; size_t n = 0; };
+
+// Default threshold estimation: the reference's deterministic "first N qualifying reads per interval" schedule
+// (reads_sampler/mod.rs:30-257, sampling_schedule.rs:171-615); the per-call probabilities come from the decode kernel.
+std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
+  const bool only_mapped = !a.include_unmapped;
+  IdxStats st = idxstats(bam, region, bf);
+  const uint64_t total_u = only_mapped ? st.mapped : st.mapped + st.unmapped;
+  if (total_u == 0) throw Error(MKP_E_THRESHOLD, "zero reads found in bam index");
+  std::map<uint32_t, Quota> quota; bool sched_unmapped = !only_mapped;
+  if (a.have_frac) {  // from_sample_frac (321-381)
+    if (a.sampling_frac > 1.0) throw Error(MKP_E_INVALID, "sample fraction must be <= 1");
+    const float f = (float)a.sampling_frac;
+    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; if (f == 1.0f) q.all = true; else q.n = (size_t)ceilf((float)kv.second * f); quota[(uint32_t)kv.first] = q; }
+  } else {  // from_num_reads (171-273)
+    const float total = (float)total_u; size_t sum = 0;
+    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; q.n = std::min<size_t>((size_t)ceilf((float)a.num_reads * ((float)kv.second / total)), (size_t)kv.second); sum += q.n; quota[(uint32_t)kv.first] = q; }
+    if (!only_mapped) sum += (size_t)ceilf((float)a.num_reads * ((float)st.unmapped / total));
+    size_t floor = 1;
+    while ((double)sum / (double)a.num_reads > 1.5) {  // pruning walks an FxHashMap in the reference; ascending tid here (order unpinned)
+      for (auto& kv : quota) { if (kv.second.n <= floor) { sum -= kv.second.n; kv.second.n = 0; } if (sum <= a.num_reads) break; }
+      sum = 0; for (auto& kv : quota) sum += kv.second.n; floor++;
+    }
+    for (auto it = quota.begin(); it != quota.end();) { if (!it->second.all && it->second.n == 0) it = quota.erase(it); else ++it; }
+  }
+  const size_t batch_size = (size_t)floorf((float)a.threads * 1.5f);
+  std::vector<Contig> contigs; for (auto& c : targets(bam, region)) if (quota.count(c.tid)) contigs.push_back(c);
+  std::map<uint32_t, uint32_t> contig_size; for (auto& c : contigs) contig_size[c.tid] = c.length;
+  std::map<int, std::vector<float>> per_base; std::set<std::string> taken; std::map<uint32_t, size_t> sampled_so_far;
+  std::map<uint32_t, std::vector<uint8_t>> bedmasks;
+  auto bedmask_for = [&](uint32_t tid) -> const uint8_t* {
+    if (!bf) return nullptr;
+    auto it = bedmasks.find(tid); if (it != bedmasks.end()) return it->second.data();
+    std::vector<uint8_t> m(bam.ref_lens[tid], 0);
+    auto mark = [&](const std::map<uint32_t, std::vector<Span>>& mp, uint8_t bit) { auto f = mp.find(tid); if (f == mp.end()) return; for (auto& s : f->second) for (uint64_t p = s.s; p < std::min<uint64_t>(s.e, m.size()); p++) m[p] |= bit; };
+    mark(bf->pos, 1); mark(bf->neg, 2);
+    return bedmasks.emplace(tid, std::move(m)).first->second.data();
+  };
+  auto qname = [&](const BamIndexEntry& e) { const uint8_t* c = &bam.raw[e.off]; return std::string((const char*)c + 32, c[8] ? (size_t)c[8] - 1 : 0); };
+  // process_records (read_ids_to_base_mod_probs.rs:223-362) over the candidate records, first-N semantics
+  auto take = [&](const std::vector<size_t>& cand, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen) -> size_t {
+    size_t used = 0, next = 0, n_reads_out = 0;
+    while (next < cand.size() && (limit < 0 || used < (size_t)limit)) {
+      size_t want = limit < 0 ? cand.size() - next : std::max<size_t>(256, 2 * ((size_t)limit - used));
+      size_t hi = std::min(cand.size(), next + want);
+      std::vector<mkp_record> recs; for (size_t i = next; i < hi; i++) recs.push_back(bam.view(bam.recs[cand[i]]));
+      SampleOut so; uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1;
+      int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(), only_mapped, &so);
+      if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+      for (size_t i = next; i < hi; i++) {
+        if (limit >= 0 && used >= (size_t)limit) break;   // RecordSampler::ask -> Done
+        const size_t k = i - next;
+        if (!so.ok[k] && so.n[k] == 0) { /* tag error or nothing kept */ }
+        std::string name = qname(bam.recs[cand[i]]);
+        // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
+        // but keeps no position is asked, not counted, and not recorded
+        if (interval_seen->count(name)) continue;
+        if (so.n[k] == 0) continue;
+        interval_seen->insert(name); used++; n_reads_out++;
+        if (taken.count(name)) continue;  // Moniod::op_mut keeps the first occurrence of a read id
+        taken.insert(name);
+        for (uint32_t j = 0; j < so.n[k]; j++) per_base[so.base[so.off[k] + j]].push_back(so.vals[so.off[k] + j]);
+      }
+      next = hi;
+    }
+    return n_reads_out;
+  };
+  auto candidates = [&](const std::vector<size_t>& in, std::vector<size_t>* out) {
+    out->clear();
+    for (size_t i : in) { const BamIndexEntry& e = bam.recs[i]; uint32_t lq; memcpy(&lq, &bam.raw[e.off + 16], 4); if ((e.flag & (256 | 1024 | 2048)) || lq == 0) continue; if ((only_mapped || a.edge_filter.size()) && (e.flag & 4)) continue; out->push_back(i); }
+  };
+  if (!contigs.empty()) {
+    // ReferenceIntervalsFeeder over the sampling grid, batch_size super-batches (interval_chunks.rs:563-643)
+    struct Iv { uint32_t tid, start, end; };
+    std::vector<std::vector<Iv>> groups;  // MultiChromCoordinates in feeder order
+    { std::vector<Iv> batch; uint32_t blen = 0;
+      for (auto& c : contigs) for (uint32_t p = c.start; p < c.end();) { uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.sampling_interval_size, c.end()); batch.push_back({c.tid, p, e}); blen += e - p; if (blen >= a.sampling_interval_size) { groups.push_back(batch); batch.clear(); blen = 0; } p = e; }
+      if (!batch.empty()) groups.push_back(batch); }
+    for (size_t g0 = 0; g0 < groups.size(); g0 += std::max<size_t>(batch_size, 1)) {
+      std::vector<Iv> all; for (size_t g = g0; g < std::min(groups.size(), g0 + std::max<size_t>(batch_size, 1)); g++) for (auto& iv : groups[g]) all.push_back(iv);
+      std::stable_sort(all.begin(), all.end(), [](const Iv& x, const Iv& y) { return x.tid != y.tid ? x.tid < y.tid : x.start < y.start; });
+      // accumulate_sample_counts (sampling_schedule.rs:440-615)
+      std::map<uint32_t, uint32_t> len_per; for (auto& iv : all) len_per[iv.tid] += iv.end - iv.start;
+      std::map<uint32_t, Quota> per_chrom;
+      for (auto& kv : len_per) { auto cs = contig_size.find(kv.first); auto q = quota.find(kv.first); if (cs == contig_size.end() || q == quota.end()) continue; size_t so_far = sampled_so_far.count(kv.first) ? sampled_so_far[kv.first] : 0; float f = (float)kv.second / (float)cs->second;
+        if (q->second.all) per_chrom[kv.first] = q->second; else if (q->second.n > so_far) { Quota x; x.n = (size_t)ceilf(f * (float)(q->second.n - so_far)); per_chrom[kv.first] = x; } }
+      struct G { Iv iv; Quota q; }; std::vector<G> grouped; bool have_slack = false; Iv slack{0, 0, 0}; size_t slack_n = 0;
+      auto merged = [](const Iv& x, const Iv& y) { return Iv{x.tid, std::min(x.start, y.start), std::max(x.end, y.end)}; };
+      for (auto& iv : all) {
+        auto pc = per_chrom.find(iv.tid); if (pc == per_chrom.end()) continue;
+        if (pc->second.all) { grouped.push_back({iv, pc->second}); continue; }
+        float f = (float)(iv.end - iv.start) / (float)len_per[iv.tid]; size_t x = (size_t)ceilf((float)pc->second.n * f); Quota qx; qx.n = x;
+        if (x < 50) {
+          if (have_slack) { if (slack.tid == iv.tid) { Iv m = merged(slack, iv); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot; } else { Quota q; q.n = tot; grouped.push_back({m, q}); have_slack = false; } } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); slack = iv; slack_n = x; } }
+          else { have_slack = true; slack = iv; slack_n = x; }
+        } else if (have_slack) { have_slack = false; if (slack.tid == iv.tid) { Quota q; q.n = slack_n + x; grouped.push_back({merged(slack, iv), q}); } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); grouped.push_back({iv, qx}); } }
+        else grouped.push_back({iv, qx});
+      }
+      if (have_slack) { Quota q; q.n = slack_n; grouped.push_back({slack, q}); }
+      std::map<uint32_t, size_t> batch_counts;
+      for (auto& g : grouped) {  // run_batch (reads_sampler/mod.rs:259-338)
+        if (bf && !bf->overlaps(g.iv.tid, g.iv.start, g.iv.end)) continue;
+        std::vector<size_t> ov, cand; fetch(bam, g.iv.tid, g.iv.start, g.iv.end, &ov); candidates(ov, &cand);
+        std::set<std::string> seen;
+        batch_counts[g.iv.tid] += take(cand, g.q.all ? -1 : (long)g.q.n, g.iv.tid, true, &seen);
+      }
+      for (auto& kv : batch_counts) sampled_so_far[kv.first] += kv.second;
+    }
+  }
+  if ((sched_unmapped || taken.size() < 100) && !only_mapped) {  // reads_sampler/mod.rs:89-125
+    std::vector<size_t> un, cand; for (size_t i = 0; i < bam.recs.size(); i++) if (bam.recs[i].tid < 0) un.push_back(i);
+    candidates(un, &cand);
+    long limit;
+    if (!a.have_frac) limit = (long)(a.num_reads > taken.size() ? a.num_reads - taken.size() : 0);
+    else if (a.sampling_frac >= 1.0) limit = -1;
+    else { if (!cand.empty()) throw Error(MKP_E_UNSUPPORTED, "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible"); limit = -1; }
+    std::set<std::string> seen; take(cand, limit, 0, false, &seen);
+  }
+  return per_base;
+}
+
+void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) {  // parse_per_base_thresholds (command_utils.rs:136-206)
+  bool have_default = false;
+  for (auto& raw : raws) {
+    size_t c = raw.find(':');
+    if (c != std::string::npos) {
+      if (raw.find(':', c + 1) != std::string::npos || c == 0) throw Error(MKP_E_INVALID, "encountered illegal per-base threshold " + raw);
+      int b = (int)std::string("ACGT").find(raw[0]); if (b < 0 || b > 3) throw Error(MKP_E_INVALID, "failed to parse base in " + raw);
+      if (k->has_per_base[b]) throw Error(MKP_E_INVALID, "repeated threshold for base");
+      k->has_per_base[b] = 1; k->per_base_threshold[b] = strtof(raw.c_str() + c + 1, nullptr);
+    } else { if (have_default) throw Error(MKP_E_INVALID, "default threshold encountered more than once"); have_default = true; k->default_threshold = strtof(raw.c_str(), nullptr); }
+  }
+}
+
+// {:.2} of an f32 (writers.rs:140): exact decimal expansion of the value, ties to even — glibc's printf does the same
+struct RowWriter {
+  FILE* f; bool mixed; std::vector<std::string> labels; uint64_t n = 0;
+  void write(const std::string& chrom, const mkp_rows& r) {
+    const char sp = mixed ? ' ' : '\t';
+    for (uint64_t i = 0; i < r.n_rows; i++) {
+      char name[96]; uint32_t code = r.code_repr[i];
+      int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
+      if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
+      const float frac = (float)r.n_mod[i] / (float)r.n_valid[i];
+      const float pct = frac * 100.0f;
+      fprintf(f, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos[i], r.pos[i] + 1, name, r.n_valid[i], (char)r.strand[i], r.pos[i],
+              r.pos[i] + 1, r.n_valid[i], sp, (double)pct, sp, r.n_mod[i], sp, r.n_canonical[i], sp, r.n_other[i], sp, r.n_delete[i], sp, r.n_fail[i], sp, r.n_diff[i], sp, r.n_nocall[i]);
+    }
+    n += r.n_rows;
+  }
+};
+
+int run(const Args& a, std::string* msg) {
+  auto t_all = std::chrono::steady_clock::now();
+  BamData bam = load_bam(a.in_bam, (unsigned)std::max<size_t>(a.threads, 1));
+  double load_ms = ms_since(t_all);
+  RegionSpec region, sregion; const bool have_region = !a.region.empty(), have_sregion = !a.sample_region.empty();
+  if (have_region) region = parse_region(a.region, bam);
+  if (have_sregion) sregion = parse_region(a.sample_region, bam);
+  mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth; kc.force_allow_implicit = a.force_allow;
+  if (!a.edge_filter.empty()) {  // parse_edge_filter_input (command_utils.rs:243-277)
+    kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(',');
+    if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); }
+    else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10);
+  }
+  std::vector<mkp_mod_threshold> per_mod;
+  for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code; if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID, "encountered illegal per-mod threshold: " + raw); per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
+  std::vector<Contig> records = targets(bam, have_region ? &region : nullptr);
+  BedFilter bed_store; const BedFilter* bf = nullptr;
+  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
+  if (idxstats(bam, have_region ? &region : nullptr, bf).mapped == 0) throw Error(MKP_E_INVALID, "did not find any mapped reads, perform alignment first or use modkit extract and/or modkit summary to inspect unaligned modBAMs");
+  if (a.filter_percentile > 1.0f) throw Error(MKP_E_INVALID, "filter percentile must be <= 1.0");
+  if (a.combine_strands && !(a.cpg || !a.motif_parts.empty())) throw Error(MKP_E_INVALID, "need to specify either --motif or --cpg to combine strands");
+  bool combine_strands = a.combine_strands;  // option resolution (subcommand.rs:484-523)
+  if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; combine_strands = true; }
+  else if (!a.preset.empty()) throw Error(MKP_E_INVALID, "unknown preset " + a.preset);
+  else if (a.combine_mods) kc.numeric_mode = 1;
+  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+  kc.combine_strands = combine_strands;
+  FocusBuilder fb; fb.combine = combine_strands; fb.mask = a.mask; fb.bed = bf;
+  Fasta fasta;
+  if (!a.motif_parts.empty()) {  // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
+    if (!a.preset.empty()) throw Error(MKP_E_INVALID, "cannot use presets and motifs together");
+    std::vector<std::string> parts = a.motif_parts;
+    for (size_t i = 0; i + 1 < parts.size(); i += 2) for (size_t j = i + 2; j + 1 < parts.size(); j += 2) if (parts[i] == parts[j] && parts[i + 1] == parts[j + 1]) throw Error(MKP_E_INVALID, "cannot have the same motif more than once");
+    if (a.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true; if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
+    for (size_t i = 0; i + 1 < parts.size(); i += 2) fb.motifs.push_back(Motif::parse(parts[i], strtoul(parts[i + 1].c_str(), nullptr, 10)));
+  } else if (a.preset == "traditional" || a.cpg) fb.motifs.push_back(Motif::parse("CG", 0));
+  RowWriter wr; wr.mixed = a.mixed_delim; for (auto& m : fb.motifs) wr.labels.push_back(m.label());
+  if (!fb.motifs.empty()) {
+    if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "reference fasta is required for using --motif or --cpg options");
+    if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID, "cannot combine strands with a motif that is not a palindrome");
+    fasta = Fasta::load(a.ref_fasta); fb.fasta = &fasta;
+  }
+  mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
+  mkp_ctx* ctx = nullptr;
+  int rc = mkp_ctx_create(&cfg, &ctx);
+  if (rc != MKP_OK) throw Error(rc, "no usable gfx950 device (libmkpileup has no CPU path)");
+  struct Guard { mkp_ctx* c; ~Guard() { mkp_ctx_destroy(c); } } guard{ctx};
+  auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
+  // thresholds (subcommand.rs:615-638)
+  kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
+  double thr_ms = 0;
+  if (!a.filter_threshold.empty()) parse_base_thresholds(a.filter_threshold, &kc);
+  else if (a.no_filtering) { kc.n_per_mod = 0; }  // MultipleThresholdModCaller::new_passthrough
+  else {
+    auto t0 = std::chrono::steady_clock::now();
+    must(mkp_set_caller(ctx, &kc));  // collapse + edge filter apply to the sampled probabilities too
+    const RegionSpec* sr = have_sregion ? &sregion : (have_region ? &region : nullptr);
+    auto per_base = sample_probabilities(ctx, bam, a, sr, bf);
+    for (auto& kv : per_base) {
+      std::sort(kv.second.begin(), kv.second.end()); float t;
+      if (mkp_percentile(kv.second.data(), kv.second.size(), a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size()));
+      kc.has_per_base[kv.first] = 1; kc.per_base_threshold[kv.first] = t;
+      if (a.stats) fprintf(stderr, "[mkpileup] threshold %c %.9g (n=%zu)\n", "ACGT"[kv.first], (double)t, kv.second.size());
+    }
+    thr_ms = ms_since(t0);
+  }
+  must(mkp_set_caller(ctx, &kc));
+  if (bf) records = bed_contigs(*bf, records, a.interval_size);
+  wr.f = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w");
+  if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
+  if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", wr.f);
+  // shard plan: one shard per contig record, or pieces of it cut at interval boundaries; ranks take contiguous runs
+  uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
+  uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, (total_bp + a.world * 8 - 1) / (a.world * 8)) : (1ull << 30));
+  uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0;
+  for (auto& rec : records) {
+    std::vector<uint8_t> focus; const bool hf = fb.has_focus();
+    std::vector<Interval> ivs = fb.walk(rec, a.interval_size, hf ? &focus : nullptr);
+    size_t i0 = 0;
+    while (i0 < ivs.size()) {
+      size_t i1 = i0; uint64_t bp = 0; while (i1 < ivs.size() && (bp == 0 || bp + (ivs[i1].end - ivs[i1].start) <= shard_bp)) { bp += ivs[i1].end - ivs[i1].start; i1++; }
+      const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
+      const uint64_t mid = bp_done + bp / 2; bp_done += bp;
+      const uint32_t owner = total_bp ? (uint32_t)std::min<uint64_t>(a.world - 1, mid * a.world / total_bp) : 0;
+      i0 = i1;
+      if (owner != a.rank) continue;
+      mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
+      if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+      must(mkp_shard_begin(ctx, &sh));
+      std::vector<size_t> ov; fetch(bam, rec.tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, &ov);
+      std::vector<mkp_record> recs; recs.reserve(ov.size()); for (size_t i : ov) recs.push_back(bam.view(bam.recs[i]));
+      must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
+      mkp_rows rows; must(mkp_shard_run(ctx, &rows));
+      wr.write(rec.name, rows);
+      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
+      positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
+    }
+  }
+  if (wr.f != stdout) fclose(wr.f);
+  if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f d2h_ms=%.1f total_ms=%.1f\n",
+                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, pack_ms, h2d_ms, kernel_ms, d2h_ms, ms_since(t_all));
+  (void)msg;
+  return MKP_OK;
+}
+
+}  // namespace
+
+extern "C" int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len) {
+  auto fail = [&](int st, const std::string& m) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return st; };
+  try {
+    Args a; std::vector<std::string> pos;
+    for (int i = 0; i < argc; i++) {
+      std::string s = argv[i];
+      auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
+      if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
+      else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
+      else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath" || s == "--seed") val();
+      else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true; a.sampling_frac = std::stod(val()); }
+      else if (s == "--no-filtering") a.no_filtering = true; else if (s == "-p" || s == "--filter-percentile") a.filter_percentile = std::stof(val());
+      else if (s == "--filter-threshold") a.filter_threshold.push_back(val()); else if (s == "--mod-thresholds" || s == "--mod-threshold") a.mod_thresholds.push_back(val());
+      else if (s == "--sample-region") a.sample_region = val(); else if (s == "--sampling-interval-size") a.sampling_interval_size = (uint32_t)std::stoul(val());
+      else if (s == "--include-bed" || s == "--include-positions") a.include_bed = val(); else if (s == "--include-unmapped") a.include_unmapped = true;
+      else if (s == "--ignore") a.ignore = val(); else if (s == "--force-allow-implicit") a.force_allow = true;
+      else if (s == "--motif") { a.motif_parts.push_back(val()); a.motif_parts.push_back(val()); } else if (s == "--cpg") a.cpg = true;
+      else if (s == "--ref" || s == "-r") a.ref_fasta = val(); else if (s == "--mask" || s == "-k") a.mask = true; else if (s == "--preset") a.preset = val();
+      else if (s == "--combine-mods") a.combine_mods = true; else if (s == "--combine-strands") a.combine_strands = true;
+      else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
+      else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
+      else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
+      else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
+      else if (s == "--partition-tag" || s == "--bedgraph" || s == "--prefix") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
+      else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
+      else pos.push_back(s);
+    }
+    if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]");
+    if (a.world == 0 || a.rank >= a.world) throw Error(MKP_E_INVALID, "bad --gpus-rank/--gpus-world");
+    a.in_bam = pos[0]; a.out_bed = pos[1];
+    std::string msg;
+    return run(a, &msg);
+  } catch (const Error& e) { return fail(e.status, e.what()); }
+  catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }
+}
+
+// process_region_batch stand-in reading the BAM itself (whole-file residency, see mkp_bam.hpp)
+extern "C" int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shard, mkp_rows* out) {
+  if (!ctx || !bam_path || !shard || !out) return MKP_E_INVALID;
+  try {
+    BamData bam = load_bam(bam_path);
+    int rc = mkp_shard_begin(ctx, shard); if (rc != MKP_OK) return rc;
+    std::vector<size_t> ov; fetch(bam, (uint32_t)shard->tid, shard->start > MKP_HALO ? shard->start - MKP_HALO : 0, shard->end + MKP_HALO, &ov);
+    std::vector<mkp_record> recs; for (size_t i : ov) recs.push_back(bam.view(bam.recs[i]));
+    rc = mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()); if (rc != MKP_OK) return rc;
+    return mkp_shard_run(ctx, out);
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
+}

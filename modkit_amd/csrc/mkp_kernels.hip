@@ -1,0 +1,696 @@
+// gfx950 (CDNA4, wave64) kernels of the modkit-pileup hot path.  Integer / byte work bound by HBM
+// and LDS atomics — no MFMA.  Three kernels:
+//
+//   mkp_decode_reads   one wave per read.  Walks the CIGAR 64 ops at a time (wave prefix sums),
+//                      expands query positions 64 per step, ranks each base with ballot+popcount
+//                      (DeltaListConverter's cumulative counts, mod_bam.rs:667-684), finds the read's
+//                      MM calls at that base, rebuilds BaseModProbs in MM order, applies edge filter,
+//                      ReDistribute collapse and MultipleThresholdModCaller::call in f32, and appends
+//                      a packed 8-byte event per mapped call (coalesced, ballot-compacted).
+//   mkp_pileup_tiles   one workgroup per reference tile.  LDS holds the tile's strand tallies
+//                      ([strand][counter][position] u32, consecutive positions on consecutive banks).
+//                      Waves take the tile's reads: depth walk (one LDS atomic per aligned/deleted
+//                      base), observed-code difference arrays, and the read's event slice.  Then an
+//                      in-LDS prefix scan of the observed-code arrays and row emission with a
+//                      block-wide scan for compaction.
+//   mkp_gather_rows    orders the per-tile row segments by tile (device exclusive scan + copy).
+//
+// Semantics follow /root/reference/src (cited inline); arithmetic that must be bit-exact is f32
+// with contraction off (-ffp-contract=off) and IEEE division.
+#include <hip/hip_runtime.h>
+
+#include "mkp_device.h"
+
+#define ERR_EVENT_CAP 1u
+#define ERR_ROW_CAP 2u
+#define ERR_DEPTH 4u
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ unsigned long long lanemask_le() { int l = lane_id(); return l == 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
+  return v;
+}
+
+// BAM 4-bit code -> A,C,G,T = 0..3, anything else -1 (DnaBase::parse, mod_base_code.rs:188-196)
+__device__ __forceinline__ int nib2base(uint32_t n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : -1; }
+__device__ __forceinline__ uint32_t seq_nibble(const uint8_t* __restrict__ s, uint32_t q) {
+  uint32_t b = s[q >> 1];
+  return (q & 1u) ? (b & 15u) : (b >> 4);
+}
+__device__ __forceinline__ bool op_consumes_query(uint32_t op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
+__device__ __forceinline__ bool op_consumes_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+__device__ __forceinline__ bool op_is_match(uint32_t op) { return op == 0 || op == 7 || op == 8; }
+
+// number of lanes whose (non-decreasing) inclusive prefix `incl` is <= j  == index of the op holding element j
+__device__ __forceinline__ int find_op(uint32_t incl, uint32_t j) {
+  int idx = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    uint32_t v = __shfl(incl, idx + step - 1, 64);
+    if (v <= j) idx += step;
+  }
+  return idx;
+}
+
+__device__ __forceinline__ uint32_t sel4(const uint32_t* a, int x) { return x == 0 ? a[0] : x == 1 ? a[1] : x == 2 ? a[2] : a[3]; }
+__device__ __forceinline__ unsigned long long sel4b(const unsigned long long* a, int x) { return x == 0 ? a[0] : x == 1 ? a[1] : x == 2 ? a[2] : a[3]; }
+
+__device__ __forceinline__ int find_rank(const uint32_t* __restrict__ a, uint32_t n, uint32_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && a[lo] == key) ? (int)lo : -1;
+}
+
+// ----------------------------------------------------------------------------------------------
+// BaseModProbs -> BaseModCall for one (mod strand, base) group at one read position.
+// pk[k] = summed probability of local code k; `pat` = which member tags listed this position
+// (or MKP_PAT_INFERRED).  Returns 0 Filtered, 1 Canonical, 2+k Modified(local code k);
+// *obs gets the slots of the codes left in the map the caller sees (read_cache.rs:171-179).
+//   collapse:  BaseModProbs::into_collapsed / ReDistribute   (mod_bam.rs:558-600)
+//   call:      MultipleThresholdModCaller::call              (threshold_mod_caller.rs:28-63)
+__device__ __forceinline__ int call_group(const MkpGroupDesc* __restrict__ g, int pat, float* pk, bool collapse, uint32_t* obs) {
+  int n_pre = g->n_pre[pat];
+  if (collapse) {
+    int x = g->collapse_local;
+    bool present = false;
+    for (int i = 0; i < n_pre; i++) present |= ((int)g->order_pre[pat][i] == x);
+    float marginal = present ? pk[x] : 0.0f;
+    float n_other = (float)(present ? n_pre : n_pre + 1);  // other_mods.len() + 1
+    float redistribute = marginal / n_other;
+    for (int i = 0; i < n_pre; i++) {
+      int k = g->order_pre[pat][i];
+      if (k != x) pk[k] = pk[k] + redistribute;
+    }
+  }
+  int n_post = g->n_post[pat];
+  int best = 0;
+  float best_p = 0.0f;
+  float s = 0.0f;
+  uint32_t ob = 0;
+  for (int i = 0; i < n_post; i++) {
+    int k = g->order_post[pat][i];
+    float p = pk[k];
+    ob |= 1u << g->slot[k];
+    s = s + p;  // probs.values().sum() in map order
+    if (p >= g->thr_mod[k]) {
+      if (best == 0 || !(p < best_p)) { best = 2 + k; best_p = p; }  // Iterator::max keeps the last maximum
+    }
+  }
+  float pc = 1.0f - s;  // canonical_prob, pushed last
+  if (pc >= g->thr_can) {
+    if (best == 0 || !(pc < best_p)) { best = 1; best_p = pc; }
+  }
+  *obs |= ob;
+  return best;
+}
+
+// Threshold sampling: value of BaseModProbs::argmax_base_mod_call after the optional collapse
+// (mod_bam.rs:489-505; read_ids_to_base_mod_probs.rs:67-101, 324-328).
+__device__ __forceinline__ float argmax_group(const MkpGroupDesc* __restrict__ g, int pat, float* pk, bool collapse) {
+  int n_pre = g->n_pre[pat];
+  if (collapse) {
+    int x = g->collapse_local;
+    bool present = false;
+    for (int i = 0; i < n_pre; i++) present |= ((int)g->order_pre[pat][i] == x);
+    float marginal = present ? pk[x] : 0.0f;
+    float redistribute = marginal / (float)(present ? n_pre : n_pre + 1);
+    for (int i = 0; i < n_pre; i++) { int k = g->order_pre[pat][i]; if (k != x) pk[k] = pk[k] + redistribute; }
+  }
+  int n_post = g->n_post[pat];
+  float s = 0.0f, best = 0.0f; bool have = false;
+  for (int i = 0; i < n_post; i++) { float p = pk[g->order_post[pat][i]]; s = s + p; if (!have || !(p < best)) { best = p; have = true; } }
+  float can = 1.0f - s;
+  return (have && best > can) ? best : can;
+}
+
+// ----------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
+                 const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
+                 const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, MkpRunParams prm,
+                 MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals) {
+  const int lane = lane_id();
+  const uint32_t rid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (rid >= n_reads) return;
+  const MkpReadHdr h = hdrs[rid];
+  MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
+  if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
+  const MkpLayout* __restrict__ lay = &layouts[h.layout];
+  const uint8_t* __restrict__ seq = seqs + h.seq_off;
+  const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
+  const uint32_t L = h.l_seq;
+  const uint32_t aln = rev ? 1u : 0u;
+
+  // pass 1: totals of each base over the read (as stored)
+  uint32_t tot[4] = {0, 0, 0, 0};
+  for (uint32_t q0 = 0; q0 < L; q0 += 64) {
+    uint32_t q = q0 + lane;
+    int x = (q < L) ? nib2base(seq_nibble(seq, q)) : -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tot[k] += (uint32_t)__popcll(__ballot(x == k));
+  }
+  bool err = false;
+  // delta list must not run past the last occurrence of its base (mod_bam.rs:705-727)
+  bool has_n_tag = false;
+  for (int t = 0; t < (int)h.n_tags; t++) {
+    MkpTagDesc d = lay->tags[t];
+    MkpTagRef tr = tagref[h.tag_off + t];
+    if (d.fb == 4) { has_n_tag = true; continue; }
+    if (tr.n) {
+      uint32_t total = sel4(tot, rev ? 3 - d.fb : d.fb);
+      if (ranks[tr.rank_off + tr.n - 1] >= total) err = true;
+    }
+  }
+  // edge filter: read_can_be_trimmed (mod_bam.rs:1668-1671)
+  const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);
+  const bool collapse = prm.numeric_mode == 2;
+
+  uint32_t obs0 = 0, obs1 = 0, contrib_lo = 0, contrib_hi = 0;  // contrib: 8 groups x 8 tag bits
+  bool any_surviving = false;
+  uint32_t n_ev = 0;
+  uint32_t q_run = 0, cum[4] = {0, 0, 0, 0};
+  int32_t r_run = h.ref_start;
+
+  for (uint32_t c0 = 0; c0 < h.n_cigar && !err; c0 += 64) {
+    uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u /*0H*/;
+    uint32_t op = w & 15u, len = w >> 4;
+    uint32_t qlen = op_consumes_query(op) ? len : 0u;
+    uint32_t rlen = op_consumes_ref(op) ? len : 0u;
+    uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
+    uint32_t qs = q_run + qe - qlen;
+    int32_t rs = r_run + (int32_t)(re - rlen);
+    uint32_t Qtot = __shfl(qe, 63, 64), Rtot = __shfl(re, 63, 64);
+    for (uint32_t base = 0; base < Qtot; base += 64) {
+      uint32_t j = base + lane;
+      bool active = j < Qtot;
+      int oi = find_op(qe, active ? j : 0u);
+      uint32_t my_qs = __shfl(qs, oi, 64);
+      int32_t my_rs = __shfl(rs, oi, 64);
+      uint32_t my_op = __shfl(op, oi, 64);
+      uint32_t q = q_run + j;
+      active = active && q < L;
+      int x = active ? nib2base(seq_nibble(seq, q)) : -1;
+      unsigned long long bal[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) bal[k] = __ballot(x == k);
+      uint32_t ev_info[2]; float sv[2] = {0.f, 0.f}; uint32_t ev_cnt = 0; int32_t ev_pos = 0;
+      if (active) {
+        const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
+        const bool mapped = op_is_match(my_op);
+        const int32_t rpos = my_rs + (int32_t)(q - my_qs);
+        if (x < 0) {
+          // a call listed on a non-ACGT base is an error (DnaBase::try_from, mod_bam.rs:1245)
+          if (has_n_tag) for (int t = 0; t < (int)h.n_tags; t++) if (lay->tags[t].fb == 4) {
+            MkpTagRef tr = tagref[h.tag_off + t];
+            if (find_rank(ranks + tr.rank_off, tr.n, f) >= 0) err = true;
+          }
+        } else {
+          const int b = rev ? 3 - x : x;  // base in the as-sequenced orientation
+          const uint32_t incl = sel4(cum, x) + (uint32_t)__popcll(sel4b(bal, x) & lanemask_le());
+          const uint32_t rank = rev ? (sel4(tot, x) - incl) : (incl - 1u);
+          const bool edge_keep = !prm.edge_filter ||
+              (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
+          bool dec_done = false;
+          for (int sg = 0; sg < 2; sg++) {
+            const MkpGroupDesc* __restrict__ g = &lay->groups[sg * 4 + b];
+            const int nm = g->n_members;
+            if (nm == 0) continue;
+            float pk[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+            uint32_t H = 0, setmask = 0;
+            for (int mi = 0; mi < nm; mi++) {
+              const int t = g->members[mi];
+              const MkpTagDesc d = lay->tags[t];
+              const MkpTagRef tr = tagref[h.tag_off + t];
+              const int jx = find_rank(ranks + tr.rank_off, tr.n, d.fb == 4 ? f : rank);
+              if (jx < 0) continue;
+              // get_base_mod_probs (mod_bam.rs:1242-1263): stride = #codes of the tag
+              float ts[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+              uint32_t seen = 0;
+              for (int i = 0; i < (int)d.n_codes; i++) {
+                const float p = ((float)ml[tr.ml_off + (uint32_t)jx * d.n_codes + i] + 0.5f) / 256.0f;  // quals_to_probs 808-816
+                const int k = g->member_code_local[mi][i];
+                if (seen & (1u << k)) { if (ts[k] + p > 1.01f) err = true; ts[k] = ts[k] + p; }
+                else { ts[k] = p; seen |= 1u << k; }
+              }
+              for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) {
+                if (setmask & (1u << k)) pk[k] = pk[k] + ts[k]; else pk[k] = ts[k];
+              }
+              setmask |= seen;
+              if (H) {  // combine_checked -> check (mod_bam.rs:629-656)
+                float s = 0.f;
+                for (int k = 0; k < MKP_KMAX; k++) if (setmask & (1u << k)) s = s + pk[k];
+                if (s > 1.01f) err = true;
+              }
+              H |= 1u << mi;
+            }
+            int pat;
+            uint32_t member_contrib;
+            if (H) {
+              if (g->implicit_members & ~H) err = true;  // ExplicitConflictInferred
+              pat = (int)H; member_contrib = H;
+            } else if (g->implicit_members) {
+              pat = MKP_PAT_INFERRED; member_contrib = g->implicit_members;  // implicit fill (mod_bam.rs:1265-1292)
+            } else continue;
+            uint32_t tagbits = 0;
+            for (int mi = 0; mi < nm; mi++) if (member_contrib & (1u << mi)) tagbits |= 1u << g->members[mi];
+            const int gi = sg * 4 + b;
+            if (gi < 4) contrib_lo |= tagbits << (8 * gi); else contrib_hi |= tagbits << (8 * (gi - 4));
+            if (!trimmable || !edge_keep) continue;
+            if (prm.sample_mode) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
+              bool keep = !prm.only_mapped || mapped;
+              if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
+              if (!keep) continue;
+              any_surviving = true;
+              sv[ev_cnt] = argmax_group(g, pat, pk, collapse);
+              ev_info[ev_cnt++] = g->threshold_base;
+              continue;
+            }
+            any_surviving = true;
+            uint32_t ob = 0;
+            const int cls = call_group(g, pat, pk, collapse, &ob);
+            const uint32_t tally = aln ^ (uint32_t)sg;  // read_cache.rs:181-188 / FeatureVector::add_feature
+            if (tally) obs1 |= ob; else obs0 |= ob;
+            if (mapped) {
+              const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? (uint32_t)g->cid_can : (uint32_t)g->cid_mod[cls - 2];
+              ev_info[ev_cnt++] = cid | (tally << 8) | ((uint32_t)b << 9) | (aln << 11) | (dec_done ? 0u : (1u << 12));
+              dec_done = true;
+              ev_pos = rpos;
+            }
+          }
+        }
+      }
+      // ballot-compacted, position-ordered append of this step's events
+      unsigned long long b1 = __ballot(ev_cnt >= 1), b2 = __ballot(ev_cnt >= 2);
+      uint32_t step_total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+      if (step_total) {
+        unsigned long long mlt = lanemask_lt();
+        uint32_t off = n_ev + (uint32_t)__popcll(b1 & mlt) + (uint32_t)__popcll(b2 & mlt);
+        if (n_ev + step_total > h.event_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
+        else for (uint32_t e = 0; e < ev_cnt; e++) {
+          MkpEvent ev; ev.pos = (uint32_t)ev_pos; ev.info = ev_info[e]; events[h.event_off + off + e] = ev;
+          if (prm.sample_mode) sample_vals[h.event_off + off + e] = sv[e];
+        }
+        n_ev += step_total;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) cum[k] += (uint32_t)__popcll(bal[k]);
+      err = __any(err);
+      if (err) break;
+    }
+    q_run += Qtot; r_run += (int32_t)Rtot;
+  }
+  err = __any(err);
+  obs0 = wave_or(obs0); obs1 = wave_or(obs1);
+  contrib_lo = wave_or(contrib_lo); contrib_hi = wave_or(contrib_hi);
+  any_surviving = __any(any_surviving);
+  // InvalidImplicitMode: a group all of whose contributing tags have no mode character (read_cache.rs:122-137)
+  if (!prm.force_allow && !prm.sample_mode) {
+    for (int gi = 0; gi < 8; gi++) {
+      uint32_t m = ((gi < 4 ? contrib_lo >> (8 * gi) : contrib_hi >> (8 * (gi - 4)))) & 0xffu;
+      if (m && (m & ~(uint32_t)lay->default_mask) == 0) err = true;
+    }
+  }
+  if (lane == 0) {
+    if (!err && any_surviving) { out.ok = 1; out.n_events = n_ev; out.obs[0] = obs0; out.obs[1] = obs1; }
+    readout[rid] = out;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
+
+struct TileView {
+  uint32_t* cnt;    // [2][n_counters][TH]
+  int32_t* obs;     // [2][n_slots][TH]
+  uint32_t TH, n_counters, n_slots;
+  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return cnt[(s * n_counters + cid) * TH + i]; }
+  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return obs[(s * n_slots + sl) * TH + i]; }
+};
+
+// one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
+// sl < 0: --combine-mods row (code = base letter).  Returns false when the reference emits nothing.
+__device__ __forceinline__ bool tally_row(const TileView& tv, const MkpRunParams& prm, uint32_t s, uint32_t i, int sl, int pb, RowAcc* r) {
+  const uint32_t ck = prm.can_of_pb[pb];
+  if (ck == 0xffu) return false;
+  uint32_t n_can = tv.c(s, MKP_C_CAN + ck, i), mods = 0;
+  for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == pb) mods += tv.c(s, prm.slots[t].cid, i);
+  const uint32_t cov = n_can + mods;
+  if (cov == 0) return false;
+  uint32_t n_mod;
+  if (sl >= 0) { if (tv.o(s, (uint32_t)sl, i) <= 0) return false; n_mod = tv.c(s, prm.slots[sl].cid, i); }
+  else n_mod = mods;
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < prm.n_counters; k++) if (k != MKP_C_DEL && k != MKP_C_FAIL) total += tv.c(s, k, i);
+  const uint32_t nocall = tv.c(s, MKP_C_NC + pb, i);
+  r->n_valid = cov; r->n_mod = n_mod; r->n_can = n_can; r->n_other = sl >= 0 ? mods - n_mod : 0u;
+  r->n_del = tv.c(s, MKP_C_DEL, i); r->n_fail = tv.c(s, MKP_C_FAIL, i);
+  r->n_diff = total - (nocall + cov); r->n_nocall = nocall;
+  return true;
+}
+
+template <bool WRITE>
+__device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
+                                            const MkpCombo* __restrict__ combos, int32_t T0h, uint32_t i, const MkpRowsDev& rows,
+                                            uint32_t wr) {
+  const int32_t p = T0h + (int32_t)i;
+  uint32_t rule = 3, combo = 0;
+  if (prm.has_focus) { uint32_t fv = focus[p - prm.win_start]; rule = fv & 3u; combo = fv >> 2; }
+  if (!rule) return 0;
+  uint32_t n = 0;
+  auto put = [&](const RowAcc& r, uint32_t strand, uint32_t code, int motif) {
+    if (WRITE) {
+      uint32_t k = wr + n;
+      rows.pos[k] = (uint32_t)p; rows.info[k] = strand | ((uint32_t)(motif + 1) << 8); rows.code[k] = code;
+      rows.n_valid[k] = r.n_valid; rows.n_mod[k] = r.n_mod; rows.n_can[k] = r.n_can; rows.n_other[k] = r.n_other;
+      rows.n_del[k] = r.n_del; rows.n_fail[k] = r.n_fail; rows.n_diff[k] = r.n_diff; rows.n_nocall[k] = r.n_nocall;
+    }
+    n++;
+  };
+  static const char LETTER[4] = {'A', 'C', 'G', 'T'};
+  if (!prm.combine_strands) {
+    for (uint32_t s = 0; s < 2; s++) {
+      if (!((rule >> s) & 1u)) continue;
+      uint32_t n_ids = 0; const uint8_t* ids = nullptr;
+      if (combo) { n_ids = s ? combos[combo].n_neg : combos[combo].n_pos; ids = s ? combos[combo].neg_ids : combos[combo].pos_ids; }
+      RowAcc r;
+      if (prm.numeric_mode == 1) {
+        for (int pb = 0; pb < 4; pb++) if (tally_row(tv, prm, s, i, -1, pb, &r)) {
+          if (n_ids) for (uint32_t k = 0; k < n_ids; k++) put(r, s, (uint32_t)LETTER[pb], ids[k]); else put(r, s, (uint32_t)LETTER[pb], -1);
+        }
+      } else {
+        for (uint32_t oi = 0; oi < prm.n_slots; oi++) {
+          const int sl = prm.slot_order[oi];
+          if (tally_row(tv, prm, s, i, sl, prm.slots[sl].pb, &r)) {
+            if (n_ids) for (uint32_t k = 0; k < n_ids; k++) put(r, s, prm.slots[sl].code_repr, ids[k]); else put(r, s, prm.slots[sl].code_repr, -1);
+          }
+        }
+      }
+    }
+  } else {
+    // combine_strand_features (pileup/mod.rs:469-561): only '+' motif positions produce rows
+    if (!combo) return 0;
+    const MkpCombo cb = combos[combo];
+    for (uint32_t m = 0; m < cb.n_pos; m++) {
+      const int idx = cb.pos_ids[m];
+      const int delta = cb.pos_delta[m];
+      if (delta == -128) continue;  // not a palindrome / negative_strand_position() == None
+      const int32_t qpos = p + delta;
+      bool neg_ok = false; uint32_t iq = 0;
+      if (delta != -127 && qpos >= prm.win_start && qpos < prm.win_end) {  // -127: mate position is in another interval
+        uint32_t fq = focus[qpos - prm.win_start];
+        if ((fq & 2u) && (fq >> 2)) {
+          const MkpCombo cq = combos[fq >> 2];
+          for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx);
+        }
+        iq = (uint32_t)(qpos - T0h);
+      }
+      const bool pos_ok = (rule & 1u) != 0;
+      auto add = [](RowAcc& a, const RowAcc& b) { a.n_valid += b.n_valid; a.n_mod += b.n_mod; a.n_can += b.n_can; a.n_other += b.n_other;
+                                                  a.n_del += b.n_del; a.n_fail += b.n_fail; a.n_diff += b.n_diff; a.n_nocall += b.n_nocall; };
+      if (prm.numeric_mode == 1) {
+        for (int pb = 0; pb < 4; pb++) {
+          RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0}, r; bool any = false;
+          if (pos_ok && tally_row(tv, prm, 0, i, -1, pb, &r)) { add(acc, r); any = true; }
+          if (neg_ok && tally_row(tv, prm, 1, iq, -1, pb, &r)) { add(acc, r); any = true; }
+          if (any) put(acc, 2, (uint32_t)LETTER[pb], idx);
+        }
+      } else {
+        for (uint32_t oi = 0; oi < prm.n_slots; oi++) {
+          const uint32_t code = prm.slots[prm.slot_order[oi]].code_repr;
+          if (oi && prm.slots[prm.slot_order[oi - 1]].code_repr == code) continue;  // grouped by code (BTreeMap)
+          RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0}, r; bool any = false;
+          for (uint32_t oj = oi; oj < prm.n_slots && prm.slots[prm.slot_order[oj]].code_repr == code; oj++) {
+            const int sl = prm.slot_order[oj];
+            if (pos_ok && tally_row(tv, prm, 0, i, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
+          }
+          for (uint32_t oj = oi; oj < prm.n_slots && prm.slots[prm.slot_order[oj]].code_repr == code; oj++) {
+            const int sl = prm.slot_order[oj];
+            if (neg_ok && tally_row(tv, prm, 1, iq, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
+          }
+          if (any) put(acc, 2, code, idx);
+        }
+      }
+    }
+  }
+  return n;
+}
+
+#define PILEUP_THREADS 512
+
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS)
+mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
+                 const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
+                 const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
+                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, MkpRunParams prm, MkpRowsDev rows,
+                 uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
+                 uint32_t* __restrict__ dev_err) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t wave_tot[PILEUP_THREADS / 64];
+  __shared__ uint32_t tile_base;
+  // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
+  // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
+  uint32_t bid = blockIdx.x;
+  {
+    const uint32_t per = n_tiles / 8u;
+    if (per && bid < per * 8u) bid = (bid & 7u) * per + (bid >> 3);
+  }
+  const uint32_t tix = bid;
+  const uint32_t tile = tile_ids[tix];
+  const uint32_t T = prm.tile, TH = T + 2 * MKP_HALO;
+  const int32_t T0 = prm.win_start + (int32_t)(tile * T);
+  const int32_t T0h = T0 - MKP_HALO, T1h = T0 + (int32_t)T + MKP_HALO;
+  TileView tv; tv.TH = TH; tv.n_counters = prm.n_counters; tv.n_slots = prm.n_slots;
+  tv.cnt = lds; tv.obs = (int32_t*)(lds + 2u * prm.n_counters * TH);
+  const uint32_t lds_words = 2u * (prm.n_counters + prm.n_slots) * TH;
+  for (uint32_t k = threadIdx.x; k < lds_words; k += blockDim.x) lds[k] = 0;
+  __syncthreads();
+
+  const int lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (uint32_t rid = tile_first[tix] + wave; rid < tile_last[tix]; rid += n_waves) {
+    const MkpReadHdr h = hdrs[rid];
+    if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
+    const MkpReadOut ro = readout[rid];
+    const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u;
+    const uint8_t* __restrict__ seq = seqs + h.seq_off;
+    // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
+    if (ro.ok && lane < 2) {
+      uint32_t m = ro.obs[lane];
+      const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
+      while (m) {
+        const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+        atomicAdd(&tv.obs[((uint32_t)lane * prm.n_slots + sl) * TH + (uint32_t)(a - T0h)], 1);
+        if (b < T1h) atomicAdd(&tv.obs[((uint32_t)lane * prm.n_slots + sl) * TH + (uint32_t)(b - T0h)], -1);
+      }
+    }
+    // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip)
+    uint32_t q_run = 0; int32_t r_run = h.ref_start;
+    for (uint32_t c0 = 0; c0 < h.n_cigar; c0 += 64) {
+      if (r_run >= T1h) break;
+      uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
+      uint32_t op = w & 15u, len = w >> 4;
+      uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
+      uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
+      uint32_t qs = q_run + qe - qlen;
+      int32_t rs = r_run + (int32_t)(re - rlen);
+      uint32_t Qtot = __shfl(qe, 63, 64), Rtot = __shfl(re, 63, 64);
+      const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
+      if (c_lo < c_hi) {
+        if (op == 3 && ro.ok) {  // ref-skip: the read is not in these columns (alignment.is_refskip())
+          const int32_t a = min(max(rs, T0h), T1h), b = min(max(rs + (int32_t)rlen, T0h), T1h);
+          if (a < b) for (uint32_t s = 0; s < 2; s++) {
+            uint32_t m = ro.obs[s];
+            while (m) {
+              const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+              atomicAdd(&tv.obs[(s * prm.n_slots + sl) * TH + (uint32_t)(a - T0h)], -1);
+              if (b < T1h) atomicAdd(&tv.obs[(s * prm.n_slots + sl) * TH + (uint32_t)(b - T0h)], 1);
+            }
+          }
+        }
+        for (int32_t pb0 = c_lo; pb0 < c_hi; pb0 += 64) {
+          const int32_t pos = pb0 + lane;
+          const bool active = pos < c_hi;
+          const uint32_t rel = (uint32_t)((active ? pos : c_lo) - r_run);
+          const int oi = find_op(re, rel);
+          const uint32_t my_op = __shfl(op, oi, 64), my_qs = __shfl(qs, oi, 64);
+          const int32_t my_rs = __shfl(rs, oi, 64);
+          if (active) {
+            const uint32_t i = (uint32_t)(pos - T0h);
+            if (op_is_match(my_op)) {
+              const uint32_t q = my_qs + (uint32_t)(pos - my_rs);
+              const int x = q < h.l_seq ? nib2base(seq_nibble(seq, q)) : -1;
+              if (x >= 0) atomicAdd(&tv.cnt[(aln * prm.n_counters + MKP_C_NC + (uint32_t)(aln ? 3 - x : x)) * TH + i], 1u);
+            } else if (my_op == 2) {
+              atomicAdd(&tv.cnt[(aln * prm.n_counters + MKP_C_DEL) * TH + i], 1u);
+            }
+          }
+        }
+      }
+      q_run += Qtot; r_run += (int32_t)Rtot;
+    }
+    // the read's call events inside the tile (sorted by position)
+    if (ro.ok && ro.n_events) {
+      const MkpEvent* __restrict__ ev = events + h.event_off;
+      uint32_t lo = 0, hi = ro.n_events;
+      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((int32_t)ev[mid].pos < T0h) lo = mid + 1; else hi = mid; }
+      for (uint32_t k = lo + lane;; k += 64) {
+        bool in = k < ro.n_events;
+        MkpEvent e; e.pos = 0; e.info = 0;
+        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
+        if (in) {
+          const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
+          atomicAdd(&tv.cnt[(((e.info >> 8) & 1u) * prm.n_counters + (e.info & 0xffu)) * TH + i], 1u);
+          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
+            atomicAdd(&tv.cnt[(((e.info >> 11) & 1u) * prm.n_counters + MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0xffffffffu);
+        }
+        if (!__any(in)) break;
+      }
+    }
+  }
+  __syncthreads();
+  // observed-code difference arrays -> coverage counts (one wave per array)
+  {
+    const uint32_t n_arr = 2u * prm.n_slots;
+    for (uint32_t a = wave; a < n_arr; a += n_waves) {
+      int32_t* arr = tv.obs + a * TH;
+      uint32_t carry = 0;
+      for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
+        uint32_t v = (b0 + lane < TH) ? (uint32_t)arr[b0 + lane] : 0u;
+        uint32_t inc = wave_incl_scan(v);
+        if (b0 + lane < TH) arr[b0 + lane] = (int32_t)(inc + carry);
+        carry += __shfl(inc, 63, 64);
+      }
+    }
+  }
+  __syncthreads();
+  // rows: each thread owns a contiguous run of positions so row order == position order
+  const uint32_t per = (T + blockDim.x - 1) / blockDim.x;
+  const uint32_t i0 = threadIdx.x * per;
+  uint32_t my_rows = 0;
+  bool deep = false;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t li = i0 + k;
+    if (li >= T) break;
+    const int32_t p = T0 + (int32_t)li;
+    if (p < prm.win_start || p >= prm.win_end) continue;
+    const uint32_t i = li + MKP_HALO;
+    uint32_t depth = 0;
+    for (uint32_t s = 0; s < 2; s++) for (uint32_t c = 0; c < prm.n_counters; c++) depth += tv.c(s, c, i);
+    if (depth > prm.max_depth) deep = true;
+    my_rows += rows_at<false>(tv, prm, focus, combos, T0h, i, rows, 0);
+  }
+  if (deep) atomicOr(dev_err, ERR_DEPTH);
+  uint32_t inc = wave_incl_scan(my_rows);
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+    for (uint32_t w2 = 0; w2 < n_waves; w2++) { uint32_t t = wave_tot[w2]; wave_tot[w2] = s; s += t; }
+    uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+    if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+    tile_base = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s;
+  }
+  __syncthreads();
+  if (tile_row_cnt[tix] == 0) return;
+  uint32_t wr = tile_base + wave_tot[wave] + inc - my_rows;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t li = i0 + k;
+    if (li >= T) break;
+    const int32_t p = T0 + (int32_t)li;
+    if (p < prm.win_start || p >= prm.win_end) continue;
+    wr += rows_at<true>(tv, prm, focus, combos, T0h, li + MKP_HALO, rows, wr);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Order the per-tile row segments by tile index.  Block 0 computes the exclusive scan of the
+// tile counts (n_tiles is small), then every block copies its tiles' segments.
+extern "C" __global__ void __launch_bounds__(256)
+mkp_scan_tiles(const uint32_t* __restrict__ tile_row_cnt, uint32_t n_tiles, uint32_t* __restrict__ tile_dst_off, uint32_t* __restrict__ total_rows) {
+  __shared__ uint32_t carry_s;
+  __shared__ uint32_t wtot[4];
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < n_tiles; b0 += 256) {
+    uint32_t k = b0 + threadIdx.x;
+    uint32_t v = k < n_tiles ? tile_row_cnt[k] : 0u;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane_id() == 63) wtot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w2 = 0; w2 < (threadIdx.x >> 6); w2++) woff += wtot[w2];
+    if (k < n_tiles) tile_dst_off[k] = carry_s + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s += woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_rows = carry_s;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mkp_gather_rows(const uint32_t* __restrict__ tile_row_off, const uint32_t* __restrict__ tile_row_cnt, const uint32_t* __restrict__ tile_dst_off,
+                uint32_t n_tiles, MkpRowsDev src, MkpRowsDev dst) {
+  for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint32_t n = tile_row_cnt[t], so = tile_row_off[t], d0 = tile_dst_off[t];
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+      dst.pos[d0 + k] = src.pos[so + k]; dst.info[d0 + k] = src.info[so + k]; dst.code[d0 + k] = src.code[so + k];
+      dst.n_valid[d0 + k] = src.n_valid[so + k]; dst.n_mod[d0 + k] = src.n_mod[so + k]; dst.n_can[d0 + k] = src.n_can[so + k];
+      dst.n_other[d0 + k] = src.n_other[so + k]; dst.n_del[d0 + k] = src.n_del[so + k]; dst.n_fail[d0 + k] = src.n_fail[so + k];
+      dst.n_diff[d0 + k] = src.n_diff[so + k]; dst.n_nocall[d0 + k] = src.n_nocall[so + k];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// host-side launchers (called from mkp_api.cpp)
+extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, uint32_t n_reads, const uint32_t* cigar, const uint8_t* seqs,
+                                        const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts,
+                                        const MkpRunParams* prm, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err,
+                                        const uint8_t* bedmask, float* sample_vals) {
+  if (!n_reads) return hipSuccess;
+  const uint32_t waves_per_block = 4;
+  dim3 grid((n_reads + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
+  hipLaunchKernelGGL(mkp_decode_reads, grid, block, 0, st, hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mkp_pileup_set_lds(uint32_t bytes) {
+  return hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
+                                        const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
+                                        const uint32_t* tile_last, uint32_t n_tiles, const uint8_t* focus, const MkpCombo* combos,
+                                        const MkpRunParams* prm, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
+                                        uint32_t* tile_row_cnt, uint32_t* dev_err) {
+  if (!n_tiles) return hipSuccess;
+  hipLaunchKernelGGL(mkp_pileup_tiles, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
+                     tile_last, n_tiles, focus, combos, *prm, *rows, row_cursor, tile_row_off, tile_row_cnt, dev_err);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mkp_launch_gather(hipStream_t st, const uint32_t* tile_row_off, const uint32_t* tile_row_cnt, uint32_t* tile_dst_off,
+                                        uint32_t n_tiles, uint32_t* total_rows, const MkpRowsDev* src, const MkpRowsDev* dst) {
+  hipLaunchKernelGGL(mkp_scan_tiles, dim3(1), dim3(256), 0, st, tile_row_cnt, n_tiles, tile_dst_off, total_rows);
+  if (n_tiles) {
+    uint32_t grid = n_tiles < 2048u ? n_tiles : 2048u;
+    hipLaunchKernelGGL(mkp_gather_rows, dim3(grid), dim3(256), 0, st, tile_row_off, tile_row_cnt, tile_dst_off, n_tiles, *src, *dst);
+  }
+  return hipGetLastError();
+}
