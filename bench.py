@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py — `modkit pileup` hot path on MI355X: genomic positions/s (and bedMethyl rows/s).
+
+A step = one pass of the device pipeline (mkp_decode_reads -> mkp_pileup_tiles -> mkp_scan/gather) over one
+HBM-resident shard.  Workload at every N (weak scaling: one shard of this shape per GPU, disjoint contigs, no
+data-path collective): BASELINE.json configs[1] "C2" — synthetic 1 contig of 5 Mb, 100 000 reads (mean ~4.8 kb,
+~96x), 5mC-only `C+m?` MM/ML on every CpG of each read, default 10th-percentile threshold (rank 0 estimates it
+with the reference's sampling schedule; broadcast to the other ranks when N>1).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONTIG_LEN = 5_000_000
+N_READS = 100_000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def gen_bam(prefix, contig_len, n_reads, seed):
+    tool = os.path.join(ROOT, "tools", "gen_modbam")
+    if not os.path.exists(tool):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+    meta = prefix + ".json"
+    if not (os.path.exists(prefix + ".bam") and os.path.exists(meta)):
+        out = subprocess.check_output([tool, "--out", prefix, "--contig", "synth5m:%d" % contig_len, "--reads", str(n_reads), "--seed", str(seed), "--style", "m"])
+        with open(meta, "w") as f:
+            f.write(out.decode())
+    return prefix + ".bam", json.load(open(meta))
+
+
+def cpu_baseline(sample_bam, sample_len, workers):
+    """The oracle (CPU restatement of the reference's path, NOT the reference binary) on a bounded sample."""
+    oracle = os.path.join(ROOT, "oracle", "modkit_oracle")
+    if not os.path.exists(oracle):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "modkit_oracle"], stdout=subprocess.DEVNULL)
+    out = sample_bam + ".oracle.bed"
+    p = subprocess.run([oracle, "pileup", sample_bam, out, "--oracle-workers", str(workers), "-i", "50000"], capture_output=True, text=True, check=True)
+    m = re.search(r"rows=(\d+) positions=(\d+).*pileup_s=([0-9.]+) total_s=([0-9.]+)", p.stderr)
+    rows, positions, pileup_s, total_s = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+    return out, {"value": positions / pileup_s, "unit": "positions/s", "cores": workers, "kind": "port",
+                 "sample": "C2 generator at 1/5 scale (1 contig of %d bp, %d reads, same depth), interval-parallel restated CPU path, BAM already decoded in RAM (pileup_s=%.2f of total_s=%.2f)" % (sample_len, N_READS // 5, pileup_s, total_s),
+                 "rows_per_s": rows / pileup_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; the JSON says so)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import modkit_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d ranks: launch with python -m torch.distributed.run --nproc-per-node %d ..." % (a.gpus, a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists in libmkpileup)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    contig_len, n_reads = int(CONTIG_LEN * a.scale), int(N_READS * a.scale)
+    tmp = os.environ.get("MKP_BENCH_DIR", "/tmp")
+    bam, meta = gen_bam(os.path.join(tmp, "mkp_c2_L%d_N%d_seed%d" % (contig_len, n_reads, 1 + rank)), contig_len, n_reads, 1 + rank)
+
+    ctx = modkit_amd.Context(device=local_rank)
+    # default 10th-percentile pass threshold from the reference's sampling schedule (-n 10042, --threads 4)
+    thr = torch.zeros(4, dtype=torch.float32, device="cuda")
+    if rank == 0:
+        t = ctx.estimate_thresholds(bam)
+        for b, v in t.items():
+            thr["ACGT".index(b)] = v
+    if dist:
+        dist.broadcast(thr, src=0)  # the one collective of the path: the global threshold (RCCL over xGMI)
+    thr_h = thr.cpu().tolist()
+    ctx.set_caller(per_base={"ACGT"[i]: thr_h[i] for i in range(4) if thr_h[i] > 0})
+
+    t0 = time.time()
+    rows = ctx.process_region(bam, 0, 0, contig_len)  # ingest + pack + H2D + first run (untimed)
+    ingest_s = time.time() - t0
+    n_rows = int(rows.n_rows)
+    ctx.rerun(a.warmup)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.rerun(a.steps)  # K passes; each launch sequence ends with a stream sync inside the library
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    st = ctx.stats()
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    totals = torch.tensor([float(contig_len), float(n_rows)], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    total_positions, total_rows = float(totals[0].item()), float(totals[1].item())
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        kernels = {"mkp_decode_reads": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_ms, dom_bytes = kernels[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile) and a.scale == 1.0:
+            traffic = json.load(open(tfile)).get(dom)
+        result = {
+            "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": total_positions * a.steps / elapsed, "unit": "positions/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 counters / f32 caller", "data": "synthetic",
+            "config": {"workload": "C2: synthetic 1 contig x %d bp, %d reads (mean %.0f bp, ~%.0fx), C+m? at every read CpG, default 10th-percentile threshold; one such shard per GPU" % (
+                contig_len, n_reads, meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / contig_len),
+                "scale": a.scale, "rows_per_s": total_rows * a.steps / elapsed, "rows_per_step": total_rows, "reads": int(st.n_reads), "call_events": int(st.n_events),
+                "tiles": int(st.n_tiles), "threshold_C": thr_h[1], "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "gather": st.gather_kernel_ms},
+                "untimed_ingest_pack_h2d_s": ingest_s, "pcie_inclusive_note": "see DESIGN.md"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            sample_len, sample_reads = contig_len // 5, n_reads // 5
+            sbam, _ = gen_bam(os.path.join(tmp, "mkp_c2_L%d_N%d_seed%d" % (sample_len, sample_reads, 101)), sample_len, sample_reads, 101)
+            workers = min(os.cpu_count() or 1, 8)
+            obed, base = cpu_baseline(sbam, sample_len, workers)
+            dbed = sbam + ".device.bed"
+            modkit_amd.pileup([sbam, dbed, "--device", str(local_rank), "-i", "50000"])
+            base["bedmethyl_sha256_equal"] = hashlib.sha256(open(dbed, "rb").read()).hexdigest() == hashlib.sha256(open(obed, "rb").read()).hexdigest()
+            result["cpu_baseline"] = base
+        print(json.dumps(result))
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,13 @@ int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shar
  * covered set; plus --device N, --gpus-rank R --gpus-world W for interval sharding. */
 int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
+/* ---- threshold estimation: get_threshold_from_options (src/command_utils.rs:74-134) ->
+ * calc_threshold_from_bam (src/thresholds.rs:121-159).  Which reads are sampled follows the reference's
+ * schedule (reads_sampler/, sampling_schedule.rs); their call probabilities are decoded on the GPU.
+ * argv = the sampling flags of `modkit pileup` (-n -f -p -t --sampling-interval-size --region --sample-region
+ * --include-bed --include-unmapped --edge-filter --ignore --preset). thr/has are indexed A,C,G,T. */
+int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float thr[4], uint8_t has[4]);
+
 /* ---- threshold arithmetic: percentile_linear_interp (src/thresholds.rs:17-38) over values the
  * device histogrammed; and the f32 histogram itself for multi-GPU all-reduce. */
 int mkp_percentile(const float* sorted, uint64_t n, float q, float* out);

@@ -51,13 +51,18 @@ def lib():
         L.mkp_pileup_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
         L.mkp_ctx_create.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         L.mkp_ctx_destroy.argtypes = [ctypes.c_void_p]
+        L.mkp_set_caller.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.mkp_estimate_thresholds.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p, ctypes.c_void_p]
+        L.mkp_process_region.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.mkp_shard_rerun.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        L.mkp_get_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
 
 
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
-           "mkp_percentile"]
+           "mkp_percentile", "mkp_estimate_thresholds"]
 
 
 def pileup(argv):
@@ -70,3 +75,109 @@ def pileup(argv):
     if rc != MKP_OK:
         raise MkpError(rc, err.value.decode(errors="replace"))
     return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# ctypes mirror of include/mkpileup.h for callers that drive shards directly (bench.py, tests)
+class Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("tile_positions", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 6)]
+
+
+class ModThreshold(ctypes.Structure):
+    _fields_ = [("code_repr", ctypes.c_uint32), ("threshold", ctypes.c_float)]
+
+
+class Caller(ctypes.Structure):
+    _fields_ = [("default_threshold", ctypes.c_float), ("per_base_threshold", ctypes.c_float * 4), ("has_per_base", ctypes.c_uint8 * 4),
+                ("per_mod", ctypes.POINTER(ModThreshold)), ("n_per_mod", ctypes.c_uint32), ("numeric_mode", ctypes.c_uint32),
+                ("collapse_code", ctypes.c_uint32), ("edge_filter", ctypes.c_uint32), ("edge_start", ctypes.c_uint32),
+                ("edge_end", ctypes.c_uint32), ("edge_inverted", ctypes.c_uint32), ("force_allow_implicit", ctypes.c_uint32),
+                ("combine_strands", ctypes.c_uint32), ("max_depth", ctypes.c_uint32)]
+
+
+class Shard(ctypes.Structure):
+    _fields_ = [("tid", ctypes.c_int32), ("start", ctypes.c_uint32), ("end", ctypes.c_uint32), ("focus", ctypes.c_void_p),
+                ("combos", ctypes.c_void_p), ("n_combos", ctypes.c_uint32)]
+
+
+class Rows(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_uint64), ("pos", ctypes.POINTER(ctypes.c_uint32)), ("strand", ctypes.POINTER(ctypes.c_uint8)),
+                ("code_repr", ctypes.POINTER(ctypes.c_uint32)), ("motif_idx", ctypes.POINTER(ctypes.c_int32)),
+                ("n_valid", ctypes.POINTER(ctypes.c_uint32)), ("n_mod", ctypes.POINTER(ctypes.c_uint32)),
+                ("n_canonical", ctypes.POINTER(ctypes.c_uint32)), ("n_other", ctypes.POINTER(ctypes.c_uint32)),
+                ("n_delete", ctypes.POINTER(ctypes.c_uint32)), ("n_fail", ctypes.POINTER(ctypes.c_uint32)),
+                ("n_diff", ctypes.POINTER(ctypes.c_uint32)), ("n_nocall", ctypes.POINTER(ctypes.c_uint32)),
+                ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("pack_ms", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
+                ("decode_kernel_ms", ctypes.c_double), ("pileup_kernel_ms", ctypes.c_double), ("gather_kernel_ms", ctypes.c_double),
+                ("n_reads", ctypes.c_uint64), ("n_events", ctypes.c_uint64), ("n_rows", ctypes.c_uint64), ("n_tiles", ctypes.c_uint64),
+                ("n_positions", ctypes.c_uint64), ("alg_bytes_decode", ctypes.c_uint64), ("alg_bytes_pileup", ctypes.c_uint64)]
+
+
+class Context:
+    """One mkp_ctx (one per host thread; binds to one GPU)."""
+
+    def __init__(self, device=0, tile_positions=0):
+        self.L = lib()
+        self.h = ctypes.c_void_p()
+        cfg = Config(device=device, tile_positions=tile_positions)
+        rc = self.L.mkp_ctx_create(ctypes.byref(cfg), ctypes.byref(self.h))
+        if rc != MKP_OK:
+            raise MkpError(rc, "mkp_ctx_create failed (no gfx950 device visible?)")
+
+    def _check(self, rc):
+        if rc != MKP_OK:
+            raise MkpError(rc, self.L.mkp_last_error(self.h).decode(errors="replace"))
+
+    def close(self):
+        if self.h:
+            self.L.mkp_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def set_caller(self, default_threshold=0.0, per_base=None, per_mod=None, numeric_mode=0, collapse_code=0, combine_strands=False,
+                   force_allow_implicit=False, edge=None, max_depth=8000):
+        c = Caller()
+        c.default_threshold = default_threshold
+        for b, t in (per_base or {}).items():
+            i = "ACGT".index(b) if isinstance(b, str) else int(b)
+            c.per_base_threshold[i] = t
+            c.has_per_base[i] = 1
+        pm = list((per_mod or {}).items())
+        arr = (ModThreshold * max(1, len(pm)))()
+        for i, (code, t) in enumerate(pm):
+            arr[i].code_repr = ord(code) if isinstance(code, str) else int(code)
+            arr[i].threshold = t
+        c.per_mod = arr
+        c.n_per_mod = len(pm)
+        c.numeric_mode, c.collapse_code, c.combine_strands = numeric_mode, collapse_code, int(combine_strands)
+        c.force_allow_implicit, c.max_depth = int(force_allow_implicit), max_depth
+        if edge:
+            c.edge_filter, c.edge_start, c.edge_end, c.edge_inverted = 1, edge[0], edge[1], int(edge[2]) if len(edge) > 2 else 0
+        self._check(self.L.mkp_set_caller(self.h, ctypes.byref(c)))
+
+    def estimate_thresholds(self, bam, argv=()):
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * max(1, len(args)))(*args)
+        thr = (ctypes.c_float * 4)()
+        has = (ctypes.c_uint8 * 4)()
+        self._check(self.L.mkp_estimate_thresholds(self.h, str(bam).encode(), len(args), arr, thr, has))
+        return {"ACGT"[i]: float(thr[i]) for i in range(4) if has[i]}
+
+    def process_region(self, bam, tid, start, end):
+        sh = Shard(tid=tid, start=start, end=end, focus=None, combos=None, n_combos=0)
+        rows = Rows()
+        self._check(self.L.mkp_process_region(self.h, str(bam).encode(), ctypes.byref(sh), ctypes.byref(rows)))
+        return rows
+
+    def rerun(self, iters, fetch=False):
+        rows = Rows()
+        self._check(self.L.mkp_shard_rerun(self.h, int(iters), ctypes.byref(rows) if fetch else None))
+        return rows
+
+    def stats(self):
+        s = Stats()
+        self._check(self.L.mkp_get_stats(self.h, ctypes.byref(s)))
+        return s

@@ -328,42 +328,73 @@ int run(const Args& a, std::string* msg) {
   return MKP_OK;
 }
 
+void parse_args(int argc, const char* const* argv, Args* out, bool need_positional) {
+  Args& a = *out; std::vector<std::string> pos;
+  for (int i = 0; i < argc; i++) {
+    std::string s = argv[i];
+    auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
+    if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
+    else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
+    else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath" || s == "--seed") val();
+    else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true; a.sampling_frac = std::stod(val()); }
+    else if (s == "--no-filtering") a.no_filtering = true; else if (s == "-p" || s == "--filter-percentile") a.filter_percentile = std::stof(val());
+    else if (s == "--filter-threshold") a.filter_threshold.push_back(val()); else if (s == "--mod-thresholds" || s == "--mod-threshold") a.mod_thresholds.push_back(val());
+    else if (s == "--sample-region") a.sample_region = val(); else if (s == "--sampling-interval-size") a.sampling_interval_size = (uint32_t)std::stoul(val());
+    else if (s == "--include-bed" || s == "--include-positions") a.include_bed = val(); else if (s == "--include-unmapped") a.include_unmapped = true;
+    else if (s == "--ignore") a.ignore = val(); else if (s == "--force-allow-implicit") a.force_allow = true;
+    else if (s == "--motif") { a.motif_parts.push_back(val()); a.motif_parts.push_back(val()); } else if (s == "--cpg") a.cpg = true;
+    else if (s == "--ref" || s == "-r") a.ref_fasta = val(); else if (s == "--mask" || s == "-k") a.mask = true; else if (s == "--preset") a.preset = val();
+    else if (s == "--combine-mods") a.combine_mods = true; else if (s == "--combine-strands") a.combine_strands = true;
+    else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
+    else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
+    else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
+    else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
+    else if (s == "--partition-tag" || s == "--bedgraph" || s == "--prefix") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
+    else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
+    else pos.push_back(s);
+  }
+  if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]"); a.in_bam = pos[0]; a.out_bed = pos[1]; }
+  else if (!pos.empty()) throw Error(MKP_E_INVALID, "unexpected positional argument " + pos[0]);
+  if (a.world == 0 || a.rank >= a.world) throw Error(MKP_E_INVALID, "bad --gpus-rank/--gpus-world");
+}
+
 }  // namespace
 
 extern "C" int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len) {
   auto fail = [&](int st, const std::string& m) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return st; };
   try {
-    Args a; std::vector<std::string> pos;
-    for (int i = 0; i < argc; i++) {
-      std::string s = argv[i];
-      auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
-      if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
-      else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
-      else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath" || s == "--seed") val();
-      else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true; a.sampling_frac = std::stod(val()); }
-      else if (s == "--no-filtering") a.no_filtering = true; else if (s == "-p" || s == "--filter-percentile") a.filter_percentile = std::stof(val());
-      else if (s == "--filter-threshold") a.filter_threshold.push_back(val()); else if (s == "--mod-thresholds" || s == "--mod-threshold") a.mod_thresholds.push_back(val());
-      else if (s == "--sample-region") a.sample_region = val(); else if (s == "--sampling-interval-size") a.sampling_interval_size = (uint32_t)std::stoul(val());
-      else if (s == "--include-bed" || s == "--include-positions") a.include_bed = val(); else if (s == "--include-unmapped") a.include_unmapped = true;
-      else if (s == "--ignore") a.ignore = val(); else if (s == "--force-allow-implicit") a.force_allow = true;
-      else if (s == "--motif") { a.motif_parts.push_back(val()); a.motif_parts.push_back(val()); } else if (s == "--cpg") a.cpg = true;
-      else if (s == "--ref" || s == "-r") a.ref_fasta = val(); else if (s == "--mask" || s == "-k") a.mask = true; else if (s == "--preset") a.preset = val();
-      else if (s == "--combine-mods") a.combine_mods = true; else if (s == "--combine-strands") a.combine_strands = true;
-      else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
-      else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
-      else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
-      else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
-      else if (s == "--partition-tag" || s == "--bedgraph" || s == "--prefix") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
-      else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
-      else pos.push_back(s);
-    }
-    if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]");
-    if (a.world == 0 || a.rank >= a.world) throw Error(MKP_E_INVALID, "bad --gpus-rank/--gpus-world");
-    a.in_bam = pos[0]; a.out_bed = pos[1];
+    Args a; parse_args(argc, argv, &a, true);
     std::string msg;
     return run(a, &msg);
   } catch (const Error& e) { return fail(e.status, e.what()); }
   catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }
+}
+
+// get_threshold_from_options (command_utils.rs:74-134) as a call: per-base pass thresholds from the
+// reference's sampling schedule; argv takes the sampling flags of `modkit pileup`
+// (-n -f -p -t --sampling-interval-size --region --sample-region --include-bed --include-unmapped --edge-filter --ignore --preset).
+extern "C" int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float thr[4], uint8_t has[4]) {
+  if (!ctx || !bam_path || !thr || !has) return MKP_E_INVALID;
+  try {
+    Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
+    BamData bam = load_bam(a.in_bam, (unsigned)std::max<size_t>(a.threads, 1));
+    RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
+    if (hr) region = parse_region(a.region, bam);
+    if (hs) sregion = parse_region(a.sample_region, bam);
+    mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
+    if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(','); if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); }
+    if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; }
+    else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+    std::vector<Contig> records = targets(bam, hr ? &region : nullptr);
+    BedFilter bed_store; const BedFilter* bf = nullptr;
+    if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
+    int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) return rc;
+    auto per_base = sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
+    for (int b = 0; b < 4; b++) { thr[b] = 0.f; has[b] = 0; }
+    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); float t; if (mkp_percentile(kv.second.data(), kv.second.size(), a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size())); thr[kv.first] = t; has[kv.first] = 1; }
+    return MKP_OK;
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
 }
 
 // process_region_batch stand-in reading the BAM itself (whole-file residency, see mkp_bam.hpp)
