@@ -56,29 +56,41 @@ struct MkpReadOut { uint32_t n_events; uint32_t ok; uint32_t obs[2]; };  // obs:
 
 struct MkpTagDesc { uint8_t fb /*0..3, 4 = N*/, neg, mode /*0 ? 1 . 2 default*/, n_codes; };
 
-struct MkpGroupDesc {          // one (mod strand σ, read base b) group; index σ*4+b
-  uint8_t n_members, n_codes, threshold_base, implicit_members;  // implicit_members: bitmask of members in '.'/default mode with fb != N
-  int8_t collapse_local;       // local idx of the code removed by ReDistribute, or -1
-  uint8_t cid_can;             // counter id of Canonical(threshold_base)
-  uint8_t pad[2];
-  uint8_t members[MKP_MAX_MEMBERS];                      // tag indices, MM order
-  uint8_t member_code_local[MKP_MAX_MEMBERS][MKP_KMAX];  // tag's i-th code -> local code idx
-  uint8_t slot[MKP_KMAX];                                // local code -> global slot
-  uint8_t cid_mod[MKP_KMAX];                             // local code -> counter id of Modified(code)
-  uint8_t n_pre[17], n_post[17];                         // per hit pattern: map sizes before / after collapse
-  uint8_t order_pre[17][MKP_KMAX];                       // FxHashMap iteration order (local idx) before collapse
-  uint8_t order_post[17][MKP_KMAX];                      // ... of the map the caller iterates
-  float thr_mod[MKP_KMAX];
+struct MkpGroupDesc {          // one (mod strand σ, read base b) group; index σ*4+b.  128 bytes, dword-packed so a
+                               // lane fetches everything it needs with a handful of independent LDS reads.
+  uint32_t misc;               // [0:2] n_members, [3:6] implicit members (modes '.'/none, fb != N), [7:9] collapse local+1 (0 = none),
+                               // [10:14] counter id of Canonical(threshold_base), [16:17] threshold_base, [20:22] n_codes
+  uint32_t slots;              // 4 x 8 bit: local code -> global slot
+  uint32_t cids;               // 4 x 8 bit: local code -> counter id of Modified(code)
+  uint32_t member_tags;        // 4 x 4 bit: member -> tag index
+  float thr_mod[MKP_KMAX];     // pass threshold per local code (threshold_mod_caller.rs:36-43)
   float thr_can;
+  uint32_t pad[3];
+  uint32_t pat[20];            // per hit pattern (1..15, 16 = all-inferred): [0:2] n_pre, [3:5] n_post,
+                               // [8:15] FxHashMap iteration order before collapse (4 x 2 bit local idx), [16:23] after collapse
 };
+#define MKP_G_NMEM(m) ((m) & 7u)
+#define MKP_G_IMPL(m) (((m) >> 3) & 15u)
+#define MKP_G_COLL(m) ((int)(((m) >> 7) & 7u) - 1)
+#define MKP_G_CIDCAN(m) (((m) >> 10) & 31u)
+#define MKP_G_TB(m) (((m) >> 16) & 3u)
 
 struct MkpLayout {
   uint8_t n_tags;
   uint8_t default_mask;   // tags whose mode is DefaultImplicitUnmodified
   uint8_t pad[2];
   MkpTagDesc tags[MKP_MAX_TAGS];
+  uint32_t tagmap[MKP_MAX_TAGS][4];  // per (tag, read base): [0:3] member index in its group, [4+4i..] local code idx of the tag's i-th code
+  uint32_t pad2[7];                  // groups start 16-byte aligned (offset 192)
   MkpGroupDesc groups[8];
 };
+
+#define MKP_LAYOUT_DWORDS 304
+#define MKP_LAYOUT_GROUP_DW 48
+#ifdef __cplusplus
+static_assert(sizeof(MkpGroupDesc) == 128, "group desc is 32 dwords");
+static_assert(sizeof(MkpLayout) == 4 * MKP_LAYOUT_DWORDS, "layout is 304 dwords");
+#endif
 
 struct MkpSlot { uint32_t code_repr; uint8_t pb; uint8_t cid; uint8_t can_cid; uint8_t pad; };
 

@@ -76,69 +76,97 @@ __device__ __forceinline__ int find_rank(const uint32_t* __restrict__ a, uint32_
   return (lo < n && a[lo] == key) ? (int)lo : -1;
 }
 
+__device__ __forceinline__ float getk(const float* p, int k) { return k == 0 ? p[0] : k == 1 ? p[1] : k == 2 ? p[2] : p[3]; }
+__device__ __forceinline__ void addk(float* p, int k, float v) { p[0] = k == 0 ? p[0] + v : p[0]; p[1] = k == 1 ? p[1] + v : p[1]; p[2] = k == 2 ? p[2] + v : p[2]; p[3] = k == 3 ? p[3] + v : p[3]; }
+
 // ----------------------------------------------------------------------------------------------
-// BaseModProbs -> BaseModCall for one (mod strand, base) group at one read position.
-// pk[k] = summed probability of local code k; `pat` = which member tags listed this position
-// (or MKP_PAT_INFERRED).  Returns 0 Filtered, 1 Canonical, 2+k Modified(local code k);
-// *obs gets the slots of the codes left in the map the caller sees (read_cache.rs:171-179).
-//   collapse:  BaseModProbs::into_collapsed / ReDistribute   (mod_bam.rs:558-600)
-//   call:      MultipleThresholdModCaller::call              (threshold_mod_caller.rs:28-63)
-__device__ __forceinline__ int call_group(const MkpGroupDesc* __restrict__ g, int pat, float* pk, bool collapse, uint32_t* obs) {
-  int n_pre = g->n_pre[pat];
-  if (collapse) {
-    int x = g->collapse_local;
-    bool present = false;
-    for (int i = 0; i < n_pre; i++) present |= ((int)g->order_pre[pat][i] == x);
-    float marginal = present ? pk[x] : 0.0f;
-    float n_other = (float)(present ? n_pre : n_pre + 1);  // other_mods.len() + 1
-    float redistribute = marginal / n_other;
-    for (int i = 0; i < n_pre; i++) {
-      int k = g->order_pre[pat][i];
-      if (k != x) pk[k] = pk[k] + redistribute;
-    }
-  }
-  int n_post = g->n_post[pat];
+// One (mod strand, base) group descriptor as the lane sees it (fetched from the LDS copy of the layout).
+struct GroupRegs { uint32_t misc, slots, cids, member_tags; float thr[MKP_KMAX]; float thr_can; };
+__device__ __forceinline__ GroupRegs load_group(const uint32_t* g) {
+  GroupRegs r;
+  const uint4 a = *reinterpret_cast<const uint4*>(g);
+  const float4 t = *reinterpret_cast<const float4*>(g + 4);
+  r.misc = a.x; r.slots = a.y; r.cids = a.z; r.member_tags = a.w;
+  r.thr[0] = t.x; r.thr[1] = t.y; r.thr[2] = t.z; r.thr[3] = t.w;
+  r.thr_can = __uint_as_float(g[8]);
+  return r;
+}
+
+// ReDistribute collapse (BaseModProbs::into_collapsed, mod_bam.rs:558-600) in the map's iteration order.
+__device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32_t pv, float* pk) {
+  const int n_pre = (int)(pv & 7u);
+  const int x = MKP_G_COLL(g.misc);
+  bool present = false;
+  for (int i = 0; i < n_pre; i++) present |= ((int)((pv >> (8 + 2 * i)) & 3u) == x);
+  const float marginal = present ? getk(pk, x) : 0.0f;
+  const float n_other = (float)(present ? n_pre : n_pre + 1);  // other_mods.len() + 1
+  const float redistribute = marginal / n_other;
+  for (int i = 0; i < n_pre; i++) { const int k = (int)((pv >> (8 + 2 * i)) & 3u); if (k != x) addk(pk, k, redistribute); }
+}
+
+// BaseModProbs -> BaseModCall: MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63).
+// Returns 0 Filtered, 1 Canonical, 2+k Modified(local code k); *obs gets the slots of the codes in the map the
+// caller sees (read_cache.rs:171-179).  pv = the group's entry for this hit pattern.
+__device__ __forceinline__ int call_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse, uint32_t* obs) {
+  if (collapse) collapse_redistribute(g, pv, pk);
+  const int n_post = (int)((pv >> 3) & 7u);
   int best = 0;
-  float best_p = 0.0f;
-  float s = 0.0f;
+  float best_p = 0.0f, s = 0.0f;
   uint32_t ob = 0;
   for (int i = 0; i < n_post; i++) {
-    int k = g->order_post[pat][i];
-    float p = pk[k];
-    ob |= 1u << g->slot[k];
+    const int k = (int)((pv >> (16 + 2 * i)) & 3u);
+    const float p = getk(pk, k);
+    ob |= 1u << ((g.slots >> (8 * k)) & 0xffu);
     s = s + p;  // probs.values().sum() in map order
-    if (p >= g->thr_mod[k]) {
-      if (best == 0 || !(p < best_p)) { best = 2 + k; best_p = p; }  // Iterator::max keeps the last maximum
-    }
+    if (p >= getk(g.thr, k)) { if (best == 0 || !(p < best_p)) { best = 2 + k; best_p = p; } }  // Iterator::max keeps the last maximum
   }
-  float pc = 1.0f - s;  // canonical_prob, pushed last
-  if (pc >= g->thr_can) {
-    if (best == 0 || !(pc < best_p)) { best = 1; best_p = pc; }
-  }
+  const float pc = 1.0f - s;  // canonical_prob, pushed last
+  if (pc >= g.thr_can) { if (best == 0 || !(pc < best_p)) { best = 1; best_p = pc; } }
   *obs |= ob;
   return best;
 }
 
 // Threshold sampling: value of BaseModProbs::argmax_base_mod_call after the optional collapse
 // (mod_bam.rs:489-505; read_ids_to_base_mod_probs.rs:67-101, 324-328).
-__device__ __forceinline__ float argmax_group(const MkpGroupDesc* __restrict__ g, int pat, float* pk, bool collapse) {
-  int n_pre = g->n_pre[pat];
-  if (collapse) {
-    int x = g->collapse_local;
-    bool present = false;
-    for (int i = 0; i < n_pre; i++) present |= ((int)g->order_pre[pat][i] == x);
-    float marginal = present ? pk[x] : 0.0f;
-    float redistribute = marginal / (float)(present ? n_pre : n_pre + 1);
-    for (int i = 0; i < n_pre; i++) { int k = g->order_pre[pat][i]; if (k != x) pk[k] = pk[k] + redistribute; }
-  }
-  int n_post = g->n_post[pat];
+__device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse) {
+  if (collapse) collapse_redistribute(g, pv, pk);
+  const int n_post = (int)((pv >> 3) & 7u);
   float s = 0.0f, best = 0.0f; bool have = false;
-  for (int i = 0; i < n_post; i++) { float p = pk[g->order_post[pat][i]]; s = s + p; if (!have || !(p < best)) { best = p; have = true; } }
-  float can = 1.0f - s;
+  for (int i = 0; i < n_post; i++) { const float p = getk(pk, (int)((pv >> (16 + 2 * i)) & 3u)); s = s + p; if (!have || !(p < best)) { best = p; have = true; } }
+  const float can = 1.0f - s;
   return (have && best > can) ? best : can;
 }
 
-// ----------------------------------------------------------------------------------------------
+// Per (mod strand) BaseModProbs under construction at one read position.
+struct GState { float pk[MKP_KMAX]; uint32_t H, setmask; };
+
+// combine_positions_to_probs for one more tag at this position (mod_bam.rs:1037-1054, 629-656)
+__device__ __forceinline__ bool merge_tag(GState& S, const float* ts, uint32_t seen, uint32_t mi) {
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) { if (S.setmask & (1u << k)) S.pk[k] = S.pk[k] + ts[k]; else S.pk[k] = ts[k]; }
+  S.setmask |= seen;
+  if (S.H) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MKP_KMAX; k++) if (S.setmask & (1u << k)) s = s + S.pk[k];
+    if (s > 1.01f) bad = true;
+  }
+  S.H |= 1u << mi;
+  return bad;
+}
+
+// index of the lane holding `key` among the wave's sorted entries `e` (or 64): 6 bpermutes, no memory traffic
+__device__ __forceinline__ int find_sorted(uint32_t e, uint32_t key) {
+  int idx = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    uint32_t v = __shfl(e, idx + step - 1, 64);
+    if (v < key) idx += step;
+  }
+  return idx;
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
@@ -146,39 +174,43 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
                  const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals) {
   const int lane = lane_id();
-  const uint32_t rid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // wave-uniform values are made provably uniform (readfirstlane) so they live in SGPRs and load through the scalar cache
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (rid >= n_reads) return;
   const MkpReadHdr h = hdrs[rid];
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
-  const MkpLayout* __restrict__ lay = &layouts[h.layout];
+  // the read's layout (1216 B) goes to LDS once; every per-base table lookup below is an LDS read
+  __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
+  uint32_t* __restrict__ lds_lay = lds_layouts[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
+    for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
+  __builtin_amdgcn_wave_barrier();
+  const MkpLayout* lay = reinterpret_cast<const MkpLayout*>(lds_lay);
   const uint8_t* __restrict__ seq = seqs + h.seq_off;
   const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
   const uint32_t L = h.l_seq;
   const uint32_t aln = rev ? 1u : 0u;
+  const int n_tags = (int)h.n_tags;
 
-  // pass 1: totals of each base over the read (as stored)
+  // reverse reads need the totals up front (forward rank = total - inclusive count in stored order)
   uint32_t tot[4] = {0, 0, 0, 0};
-  for (uint32_t q0 = 0; q0 < L; q0 += 64) {
+  if (rev) for (uint32_t q0 = 0; q0 < L; q0 += 64) {
     uint32_t q = q0 + lane;
     int x = (q < L) ? nib2base(seq_nibble(seq, q)) : -1;
 #pragma unroll
     for (int k = 0; k < 4; k++) tot[k] += (uint32_t)__popcll(__ballot(x == k));
   }
-  bool err = false;
-  // delta list must not run past the last occurrence of its base (mod_bam.rs:705-727)
-  bool has_n_tag = false;
-  for (int t = 0; t < (int)h.n_tags; t++) {
-    MkpTagDesc d = lay->tags[t];
-    MkpTagRef tr = tagref[h.tag_off + t];
-    if (d.fb == 4) { has_n_tag = true; continue; }
-    if (tr.n) {
-      uint32_t total = sel4(tot, rev ? 3 - d.fb : d.fb);
-      if (ranks[tr.rank_off + tr.n - 1] >= total) err = true;
-    }
+  // per-tag cursors into the sorted rank lists: a merge join against the read's bases, 64 at a time
+  uint32_t t_off[MKP_MAX_TAGS], t_n[MKP_MAX_TAGS], t_ml[MKP_MAX_TAGS], t_cur[MKP_MAX_TAGS];
+  MkpTagDesc t_desc[MKP_MAX_TAGS];
+#pragma unroll
+  for (int t = 0; t < MKP_MAX_TAGS; t++) {
+    t_off[t] = 0; t_n[t] = 0; t_ml[t] = 0; t_cur[t] = 0; t_desc[t] = lay->tags[t];
+    if (t < n_tags) { const MkpTagRef tr = tagref[h.tag_off + t]; t_off[t] = tr.rank_off; t_n[t] = tr.n; t_ml[t] = tr.ml_off; t_cur[t] = rev ? tr.n : 0u; }
   }
-  // edge filter: read_can_be_trimmed (mod_bam.rs:1668-1671)
-  const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);
+  bool err = false;
+  const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);  // read_can_be_trimmed (mod_bam.rs:1668-1671)
   const bool collapse = prm.numeric_mode == 2;
 
   uint32_t obs0 = 0, obs1 = 0, contrib_lo = 0, contrib_hi = 0;  // contrib: 8 groups x 8 tag bits
@@ -203,95 +235,110 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
       uint32_t my_qs = __shfl(qs, oi, 64);
       int32_t my_rs = __shfl(rs, oi, 64);
       uint32_t my_op = __shfl(op, oi, 64);
-      uint32_t q = q_run + j;
+      const uint32_t q = q_run + j;
       active = active && q < L;
-      int x = active ? nib2base(seq_nibble(seq, q)) : -1;
-      unsigned long long bal[4];
+      const int x = active ? nib2base(seq_nibble(seq, q)) : -1;
+      unsigned long long bal[4]; uint32_t cnt[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) bal[k] = __ballot(x == k);
+      for (int k = 0; k < 4; k++) { bal[k] = __ballot(x == k); cnt[k] = (uint32_t)__popcll(bal[k]); }
+      const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
+      const uint32_t q_lo = q_run + base;
+      const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
+      const int b = x < 0 ? -1 : (rev ? 3 - x : x);
+      uint32_t rank = 0;
+      if (x >= 0) { const uint32_t incl = sel4(cum, x) + (uint32_t)__popcll(sel4b(bal, x) & lanemask_le()); rank = rev ? (sel4(tot, x) - incl) : (incl - 1u); }
+      GState S0, S1;
+#pragma unroll
+      for (int k = 0; k < MKP_KMAX; k++) { S0.pk[k] = 0.f; S1.pk[k] = 0.f; }
+      S0.H = S0.setmask = S1.H = S1.setmask = 0;
+#pragma unroll
+      for (int t = 0; t < MKP_MAX_TAGS; t++) {
+        if (t >= n_tags) break;
+        const MkpTagDesc d = t_desc[t];
+        // window of keys this step can ask for (keys of successive steps tile the key space, so entries below it are spent)
+        uint32_t wlo, whi;
+        if (d.fb == 4) { wlo = rev ? (L - q_lo - n_act) : q_lo; whi = wlo + n_act; }
+        else { const int xb = rev ? 3 - d.fb : d.fb; const uint32_t c = sel4(cum, xb), n = sel4(cnt, xb); wlo = rev ? (sel4(tot, xb) - c - n) : c; whi = wlo + n; }
+        uint32_t e; bool valid; uint32_t idx0;
+        if (!rev) { idx0 = t_cur[t]; const uint32_t i = idx0 + lane; valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; const uint32_t nh = (uint32_t)__popcll(__ballot(valid && e < whi)); t_cur[t] += nh; }
+        else { idx0 = t_cur[t] - 64u; const uint32_t i = idx0 + lane; valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; const uint32_t nh = (uint32_t)__popcll(__ballot(valid && e >= wlo && e < whi)); t_cur[t] -= nh; }  // an entry >= whi is past the last occurrence: never consumed -> error at the end
+        const unsigned long long vmask = __ballot(valid);
+        const bool member = active && (d.fb == 4 || (int)d.fb == b);
+        const uint32_t key = d.fb == 4 ? f : rank;
+        // search on e+1 so the empty lanes (0 at the low end when walking a reverse read) can never tie with rank 0
+        const uint32_t e1 = valid ? e + 1u : (rev ? 0u : 0xffffffffu);
+        const int fi = find_sorted(e1, member ? key + 1u : 0u);
+        const uint32_t ef = __shfl(e1, fi & 63, 64);
+        const bool found = member && fi < 64 && ef == key + 1u && ((vmask >> (fi & 63)) & 1ull);
+        if (!found) continue;
+        if (x < 0) { err = true; continue; }  // a call listed on a non-ACGT base (DnaBase::try_from, mod_bam.rs:1245)
+        const uint32_t jx = idx0 + (uint32_t)fi;
+        const uint32_t tm = lay->tagmap[t][b];  // [0:3] member index, [4+4i : 8+4i) local code of the tag's i-th code
+        const uint32_t mi = tm & 15u;
+        // get_base_mod_probs (mod_bam.rs:1242-1263): stride = #codes of the tag
+        float ts[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t seen = 0;
+        for (int i = 0; i < (int)d.n_codes; i++) {
+          const float p = ((float)ml[t_ml[t] + jx * d.n_codes + i] + 0.5f) / 256.0f;  // quals_to_probs 808-816
+          const uint32_t kk = (tm >> (4 + 4 * i)) & 15u;
+#pragma unroll
+          for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k == kk) {
+            if (seen & (1u << k)) { if (ts[k] + p > 1.01f) err = true; ts[k] = ts[k] + p; } else { ts[k] = p; seen |= 1u << k; }
+          }
+        }
+        if (d.neg) { if (merge_tag(S1, ts, seen, mi)) err = true; } else { if (merge_tag(S0, ts, seen, mi)) err = true; }
+      }
       uint32_t ev_info[2]; float sv[2] = {0.f, 0.f}; uint32_t ev_cnt = 0; int32_t ev_pos = 0;
-      if (active) {
-        const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
+      if (active && x >= 0) {
         const bool mapped = op_is_match(my_op);
         const int32_t rpos = my_rs + (int32_t)(q - my_qs);
-        if (x < 0) {
-          // a call listed on a non-ACGT base is an error (DnaBase::try_from, mod_bam.rs:1245)
-          if (has_n_tag) for (int t = 0; t < (int)h.n_tags; t++) if (lay->tags[t].fb == 4) {
-            MkpTagRef tr = tagref[h.tag_off + t];
-            if (find_rank(ranks + tr.rank_off, tr.n, f) >= 0) err = true;
-          }
-        } else {
-          const int b = rev ? 3 - x : x;  // base in the as-sequenced orientation
-          const uint32_t incl = sel4(cum, x) + (uint32_t)__popcll(sel4b(bal, x) & lanemask_le());
-          const uint32_t rank = rev ? (sel4(tot, x) - incl) : (incl - 1u);
-          const bool edge_keep = !prm.edge_filter ||
-              (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
-          bool dec_done = false;
-          for (int sg = 0; sg < 2; sg++) {
-            const MkpGroupDesc* __restrict__ g = &lay->groups[sg * 4 + b];
-            const int nm = g->n_members;
-            if (nm == 0) continue;
-            float pk[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
-            uint32_t H = 0, setmask = 0;
-            for (int mi = 0; mi < nm; mi++) {
-              const int t = g->members[mi];
-              const MkpTagDesc d = lay->tags[t];
-              const MkpTagRef tr = tagref[h.tag_off + t];
-              const int jx = find_rank(ranks + tr.rank_off, tr.n, d.fb == 4 ? f : rank);
-              if (jx < 0) continue;
-              // get_base_mod_probs (mod_bam.rs:1242-1263): stride = #codes of the tag
-              float ts[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
-              uint32_t seen = 0;
-              for (int i = 0; i < (int)d.n_codes; i++) {
-                const float p = ((float)ml[tr.ml_off + (uint32_t)jx * d.n_codes + i] + 0.5f) / 256.0f;  // quals_to_probs 808-816
-                const int k = g->member_code_local[mi][i];
-                if (seen & (1u << k)) { if (ts[k] + p > 1.01f) err = true; ts[k] = ts[k] + p; }
-                else { ts[k] = p; seen |= 1u << k; }
-              }
-              for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) {
-                if (setmask & (1u << k)) pk[k] = pk[k] + ts[k]; else pk[k] = ts[k];
-              }
-              setmask |= seen;
-              if (H) {  // combine_checked -> check (mod_bam.rs:629-656)
-                float s = 0.f;
-                for (int k = 0; k < MKP_KMAX; k++) if (setmask & (1u << k)) s = s + pk[k];
-                if (s > 1.01f) err = true;
-              }
-              H |= 1u << mi;
-            }
-            int pat;
-            uint32_t member_contrib;
-            if (H) {
-              if (g->implicit_members & ~H) err = true;  // ExplicitConflictInferred
-              pat = (int)H; member_contrib = H;
-            } else if (g->implicit_members) {
-              pat = MKP_PAT_INFERRED; member_contrib = g->implicit_members;  // implicit fill (mod_bam.rs:1265-1292)
-            } else continue;
-            uint32_t tagbits = 0;
-            for (int mi = 0; mi < nm; mi++) if (member_contrib & (1u << mi)) tagbits |= 1u << g->members[mi];
-            const int gi = sg * 4 + b;
-            if (gi < 4) contrib_lo |= tagbits << (8 * gi); else contrib_hi |= tagbits << (8 * (gi - 4));
-            if (!trimmable || !edge_keep) continue;
-            if (prm.sample_mode) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
-              bool keep = !prm.only_mapped || mapped;
-              if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
-              if (!keep) continue;
-              any_surviving = true;
-              sv[ev_cnt] = argmax_group(g, pat, pk, collapse);
-              ev_info[ev_cnt++] = g->threshold_base;
-              continue;
-            }
+        const bool edge_keep = !prm.edge_filter ||
+            (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
+        bool dec_done = false;
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) {
+          const uint32_t* gp = lds_lay + MKP_LAYOUT_GROUP_DW + (sg * 4 + b) * 32;
+          const uint32_t gmisc = gp[0];
+          const int nm = (int)MKP_G_NMEM(gmisc);
+          if (nm == 0) continue;
+          float* spk = sg ? S1.pk : S0.pk;
+          const uint32_t SH = sg ? S1.H : S0.H;
+          const uint32_t impl = MKP_G_IMPL(gmisc);
+          int pat;
+          uint32_t member_contrib;
+          if (SH) {
+            if (impl & ~SH) err = true;  // ExplicitConflictInferred
+            pat = (int)SH; member_contrib = SH;
+          } else if (impl) {
+            pat = MKP_PAT_INFERRED; member_contrib = impl;  // implicit fill (mod_bam.rs:1265-1292)
+          } else continue;
+          const GroupRegs g = load_group(gp);
+          const uint32_t pv = gp[12 + pat];
+          uint32_t tagbits = 0;
+#pragma unroll
+          for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (member_contrib & (1u << mi)) tagbits |= 1u << ((g.member_tags >> (4 * mi)) & 15u);
+          const int gi = sg * 4 + b;
+          if (gi < 4) contrib_lo |= tagbits << (8 * gi); else contrib_hi |= tagbits << (8 * (gi - 4));
+          if (!trimmable || !edge_keep) continue;
+          if (prm.sample_mode) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
+            bool keep = !prm.only_mapped || mapped;
+            if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
+            if (!keep) continue;
             any_surviving = true;
-            uint32_t ob = 0;
-            const int cls = call_group(g, pat, pk, collapse, &ob);
-            const uint32_t tally = aln ^ (uint32_t)sg;  // read_cache.rs:181-188 / FeatureVector::add_feature
-            if (tally) obs1 |= ob; else obs0 |= ob;
-            if (mapped) {
-              const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? (uint32_t)g->cid_can : (uint32_t)g->cid_mod[cls - 2];
-              ev_info[ev_cnt++] = cid | (tally << 8) | ((uint32_t)b << 9) | (aln << 11) | (dec_done ? 0u : (1u << 12));
-              dec_done = true;
-              ev_pos = rpos;
-            }
+            sv[ev_cnt] = argmax_group(g, pv, spk, collapse);
+            ev_info[ev_cnt++] = MKP_G_TB(g.misc);
+            continue;
+          }
+          any_surviving = true;
+          uint32_t ob = 0;
+          const int cls = call_group(g, pv, spk, collapse, &ob);
+          const uint32_t tally = aln ^ (uint32_t)sg;  // read_cache.rs:181-188 / FeatureVector::add_feature
+          if (tally) obs1 |= ob; else obs0 |= ob;
+          if (mapped) {
+            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(g.misc) : ((g.cids >> (8 * (cls - 2))) & 0xffu);
+            ev_info[ev_cnt++] = cid | (tally << 8) | ((uint32_t)b << 9) | (aln << 11) | (dec_done ? 0u : (1u << 12));
+            dec_done = true;
+            ev_pos = rpos;
           }
         }
       }
@@ -302,19 +349,23 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
         unsigned long long mlt = lanemask_lt();
         uint32_t off = n_ev + (uint32_t)__popcll(b1 & mlt) + (uint32_t)__popcll(b2 & mlt);
         if (n_ev + step_total > h.event_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
-        else for (uint32_t e = 0; e < ev_cnt; e++) {
-          MkpEvent ev; ev.pos = (uint32_t)ev_pos; ev.info = ev_info[e]; events[h.event_off + off + e] = ev;
-          if (prm.sample_mode) sample_vals[h.event_off + off + e] = sv[e];
+        else for (uint32_t e2 = 0; e2 < ev_cnt; e2++) {
+          MkpEvent ev; ev.pos = (uint32_t)ev_pos; ev.info = ev_info[e2]; events[h.event_off + off + e2] = ev;
+          if (prm.sample_mode) sample_vals[h.event_off + off + e2] = sv[e2];
         }
         n_ev += step_total;
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) cum[k] += (uint32_t)__popcll(bal[k]);
+      for (int k = 0; k < 4; k++) cum[k] += cnt[k];
       err = __any(err);
       if (err) break;
     }
     q_run += Qtot; r_run += (int32_t)Rtot;
   }
+  // a delta list must not run past the last occurrence of its base / the end of the read: every entry must have
+  // been consumed by the join (mod_bam.rs:705-727, 750-756)
+#pragma unroll
+  for (int t = 0; t < MKP_MAX_TAGS; t++) if (t < n_tags) { if (rev ? (t_cur[t] != 0u) : (t_cur[t] != t_n[t])) err = true; }
   err = __any(err);
   obs0 = wave_or(obs0); obs1 = wave_or(obs1);
   contrib_lo = wave_or(contrib_lo); contrib_hi = wave_or(contrib_hi);
@@ -482,7 +533,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   __syncthreads();
 
   const int lane = lane_id();
-  const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
   for (uint32_t rid = tile_first[tix] + wave; rid < tile_last[tix]; rid += n_waves) {
     const MkpReadHdr h = hdrs[rid];
     if (h.ref_end <= T0h || h.ref_start >= T1h) continue;

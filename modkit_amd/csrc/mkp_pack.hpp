@@ -106,13 +106,12 @@ struct LayoutTables {
         if (mem.size() > MKP_MAX_MEMBERS) throw Error(MKP_E_UNSUPPORTED, "more than 4 MM tags on one (strand, base)");
         if (uni.size() > MKP_KMAX) throw Error(MKP_E_UNSUPPORTED, "more than 4 mod codes on one (strand, base)");
         int pb = sg ? 3 - b : b;
-        G.n_members = (uint8_t)mem.size(); G.n_codes = (uint8_t)uni.size(); G.threshold_base = (uint8_t)pb;
-        G.cid_can = (uint8_t)(6 + st.find_can(pb)); G.collapse_local = -1;
+        int collapse_local = -1; uint32_t implicit = 0;
         auto local_of = [&](uint32_t c) { return (int)(std::find(uni.begin(), uni.end(), c) - uni.begin()); };
         for (size_t k = 0; k < uni.size(); k++) {
           bool gone = collapse && uni[k] == cc.collapse_code;
-          if (gone) { G.collapse_local = (int8_t)k; G.slot[k] = 0; G.cid_mod[k] = MKP_C_FAIL; }
-          else { int s = st.find_slot(pb, uni[k]); G.slot[k] = (uint8_t)s; G.cid_mod[k] = st.slots[(size_t)s].cid; }
+          if (gone) { collapse_local = (int)k; G.cids |= (uint32_t)MKP_C_FAIL << (8 * k); }
+          else { int s = st.find_slot(pb, uni[k]); G.slots |= (uint32_t)s << (8 * k); G.cids |= (uint32_t)st.slots[(size_t)s].cid << (8 * k); }
           // threshold resolution (threshold_mod_caller.rs:36-43)
           float thr; auto a = cc.per_mod.find(uni[k]);
           if (a != cc.per_mod.end()) thr = a->second;
@@ -122,10 +121,13 @@ struct LayoutTables {
         G.thr_can = cc.has_per_base[pb] ? cc.per_base[pb] : cc.default_threshold;
         for (size_t mi = 0; mi < mem.size(); mi++) {
           const TagHeader& h = L.tags[(size_t)mem[mi]];
-          G.members[mi] = (uint8_t)mem[mi];
-          for (size_t i = 0; i < h.codes.size(); i++) G.member_code_local[mi][i] = (uint8_t)local_of(h.codes[i]);
-          if (h.mode != 0 && h.fb != 4) G.implicit_members |= (uint8_t)(1u << mi);
+          G.member_tags |= (uint32_t)mem[mi] << (4 * mi);
+          uint32_t tm = (uint32_t)mi;
+          for (size_t i = 0; i < h.codes.size(); i++) tm |= (uint32_t)local_of(h.codes[i]) << (4 + 4 * i);
+          D.tagmap[mem[mi]][b] = tm;
+          if (h.mode != 0 && h.fb != 4) implicit |= 1u << mi;
         }
+        G.misc = (uint32_t)mem.size() | (implicit << 3) | ((uint32_t)(collapse_local + 1) << 7) | ((uint32_t)(6 + st.find_can(pb)) << 10) | ((uint32_t)pb << 16) | ((uint32_t)uni.size() << 20);
         auto fill = [&](int pat, const std::vector<int>& hit_members, bool inferred) {
           // maps as the reference builds them: each tag's own map first (new_init / new_inferred_canonical),
           // then merged into the aggregate in MM order (combine_checked iterates the incoming map)
@@ -140,12 +142,13 @@ struct LayoutTables {
           std::vector<int> pre = agg.order(); std::vector<uint32_t> prec = agg.codes();
           std::vector<int> post = pre;
           if (collapse) { FxOrder nm; for (size_t i = 0; i < pre.size(); i++) if (prec[i] != cc.collapse_code) nm.insert(prec[i], pre[i]); post = nm.order(); }
-          G.n_pre[pat] = (uint8_t)pre.size(); G.n_post[pat] = (uint8_t)post.size();
-          for (size_t i = 0; i < pre.size(); i++) G.order_pre[pat][i] = (uint8_t)pre[i];
-          for (size_t i = 0; i < post.size(); i++) G.order_post[pat][i] = (uint8_t)post[i];
+          uint32_t v = (uint32_t)pre.size() | ((uint32_t)post.size() << 3);
+          for (size_t i = 0; i < pre.size(); i++) v |= (uint32_t)pre[i] << (8 + 2 * i);
+          for (size_t i = 0; i < post.size(); i++) v |= (uint32_t)post[i] << (16 + 2 * i);
+          G.pat[pat] = v;
         };
         for (int pat = 1; pat < (1 << mem.size()); pat++) { std::vector<int> hm; for (size_t mi = 0; mi < mem.size(); mi++) if (pat & (1 << mi)) hm.push_back((int)mi); fill(pat, hm, false); }
-        if (G.implicit_members) { std::vector<int> hm; for (size_t mi = 0; mi < mem.size(); mi++) if (G.implicit_members & (1u << mi)) hm.push_back((int)mi); fill(MKP_PAT_INFERRED, hm, true); }
+        if (implicit) { std::vector<int> hm; for (size_t mi = 0; mi < mem.size(); mi++) if (implicit & (1u << mi)) hm.push_back((int)mi); fill(MKP_PAT_INFERRED, hm, true); }
       }
       dev.push_back(D);
     }
