@@ -18,6 +18,7 @@
 // Semantics follow /root/reference/src (cited inline); arithmetic that must be bit-exact is f32
 // with contraction off (-ffp-contract=off) and IEEE division.
 #include <hip/hip_runtime.h>
+#include <rocprim/warp/warp_scan.hpp>
 
 #include "mkp_device.h"
 
@@ -29,13 +30,12 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ unsigned long long lanemask_le() { int l = lane_id(); return l == 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane_id() >= d) v += t;
-  }
-  return v;
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {  // DPP row_shr / row_bcast scan, no LDS traffic
+  using WS = rocprim::warp_scan<uint32_t, 64>;
+  WS::storage_type st;
+  uint32_t o;
+  WS().inclusive_scan(v, o, st);
+  return o;
 }
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 #pragma unroll
@@ -167,47 +167,99 @@ __device__ __forceinline__ int find_sorted(uint32_t e, uint32_t key) {
   return idx;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
+// ---- packed-base helpers: a dword of BAM SEQ holds 8 bases, high nibble of each byte first.
+// linearize() swaps the nibbles of every byte so that base i of the dword sits at bits [4i, 4i+4).
+__device__ __forceinline__ uint32_t linearize(uint32_t x) { return ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu); }
+// 8-bit mask (bit i = base i of the dword) of the nibbles equal to the BAM code of base k (A,C,G,T = 1,2,4,8)
+__device__ __forceinline__ uint32_t match8(uint32_t xl, int k) {
+  uint32_t t = xl ^ (0x11111111u << k);
+  t |= t >> 1; t |= t >> 2;
+  const uint32_t m = (t & 0x11111111u) ^ 0x11111111u;          // bit 4i set where nibble i matches
+  return ((((m | (m >> 3)) & 0x03030303u) * 0x01041040u) >> 24);  // gather bits 4i -> i
+}
+// position of the r-th (0-based) set bit of an 8-bit mask
+__device__ __forceinline__ uint32_t select8(uint32_t m, uint32_t r) {
+  for (uint32_t k = 0; k < r; k++) m &= m - 1u;
+  return (uint32_t)__ffs((int)m) - 1u;
+}
+
+// One wave per read.  The read is walked 512 bases at a time (one SEQ dword = 8 bases per lane):
+//   1. per lane: match masks of the stored bases the read's MM tags count, popcounts, wave prefix sums
+//      (DeltaListConverter's cumulative counts, mod_bam.rs:667-684, 8 bases per instruction);
+//   2. per tag: the calls whose rank falls into the chunk's rank window are located (prefix search + select)
+//      and marked in a per-lane 8-bit "call here" mask held in LDS;
+//   3. the union of the masks (plus every occurrence of an implicit-mode base) is enumerated, 64 positions
+//      per batch: BaseModProbs are rebuilt in MM order, edge filter, ReDistribute collapse and
+//      MultipleThresholdModCaller::call in f32, CIGAR mapping through a 64-op window, and one packed
+//      8-byte event per mapped call is appended (ballot-compacted, position order).
+// SAMPLE = threshold-sampling pass: emits argmax probabilities instead of call events.
+template <bool SAMPLE>
+__device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
-                 const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, MkpRunParams prm,
+                 const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
                  const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals) {
   const int lane = lane_id();
   // wave-uniform values are made provably uniform (readfirstlane) so they live in SGPRs and load through the scalar cache
-  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
   if (rid >= n_reads) return;
   const MkpReadHdr h = hdrs[rid];
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
-  // the read's layout (1216 B) goes to LDS once; every per-base table lookup below is an LDS read
+  // the read's layout (1216 B) goes to LDS once; every table lookup below is an LDS read
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
-  uint32_t* __restrict__ lds_lay = lds_layouts[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  __shared__ uint32_t lds_marks[4][MKP_MAX_TAGS][64];
+  uint32_t* __restrict__ lds_lay = lds_layouts[wib];
+  uint32_t (*__restrict__ marks)[64] = lds_marks[wib];
   { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
     for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
   __builtin_amdgcn_wave_barrier();
   const MkpLayout* lay = reinterpret_cast<const MkpLayout*>(lds_lay);
-  const uint8_t* __restrict__ seq = seqs + h.seq_off;
+  const uint32_t* __restrict__ seqw = reinterpret_cast<const uint32_t*>(seqs + h.seq_off);  // reads start 4-byte aligned
   const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
   const uint32_t L = h.l_seq;
+  const uint32_t nd = (L + 7u) >> 3;
   const uint32_t aln = rev ? 1u : 0u;
   const int n_tags = (int)h.n_tags;
 
-  // reverse reads need the totals up front (forward rank = total - inclusive count in stored order)
-  uint32_t tot[4] = {0, 0, 0, 0};
-  if (rev) for (uint32_t q0 = 0; q0 < L; q0 += 64) {
-    uint32_t q = q0 + lane;
-    int x = (q < L) ? nib2base(seq_nibble(seq, q)) : -1;
-#pragma unroll
-    for (int k = 0; k < 4; k++) tot[k] += (uint32_t)__popcll(__ballot(x == k));
-  }
-  // per-tag cursors into the sorted rank lists: a merge join against the read's bases, 64 at a time
+  // per-tag cursors into the sorted rank lists: a merge join against the read's bases, 512 at a time
   uint32_t t_off[MKP_MAX_TAGS], t_n[MKP_MAX_TAGS], t_ml[MKP_MAX_TAGS], t_cur[MKP_MAX_TAGS];
   MkpTagDesc t_desc[MKP_MAX_TAGS];
+  uint32_t needmask = 0;   // stored bases (A,C,G,T = bit 0..3) some tag counts
 #pragma unroll
   for (int t = 0; t < MKP_MAX_TAGS; t++) {
     t_off[t] = 0; t_n[t] = 0; t_ml[t] = 0; t_cur[t] = 0; t_desc[t] = lay->tags[t];
-    if (t < n_tags) { const MkpTagRef tr = tagref[h.tag_off + t]; t_off[t] = tr.rank_off; t_n[t] = tr.n; t_ml[t] = tr.ml_off; t_cur[t] = rev ? tr.n : 0u; }
+    if (t < n_tags) {
+      const MkpTagRef tr = tagref[h.tag_off + t]; t_off[t] = tr.rank_off; t_n[t] = tr.n; t_ml[t] = tr.ml_off; t_cur[t] = rev ? tr.n : 0u;
+      if (t_desc[t].fb != 4) needmask |= 1u << (rev ? 3 - t_desc[t].fb : t_desc[t].fb);
+    }
+  }
+  needmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)needmask);
+  // stored bases every occurrence of which is a call: groups with implicit-mode members (mod_bam.rs:1265-1292)
+  uint32_t implmask = 0;
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int b = rev ? 3 - x : x;
+    const uint32_t m0 = lds_lay[MKP_LAYOUT_GROUP_DW + b * 32], m1 = lds_lay[MKP_LAYOUT_GROUP_DW + (4 + b) * 32];
+    if (MKP_G_IMPL(m0) | MKP_G_IMPL(m1)) implmask |= 1u << x;
+  }
+  implmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)implmask);
+
+  // reverse reads need the totals up front (forward rank = total - inclusive count in stored order)
+  uint32_t tot[4] = {0, 0, 0, 0};
+  if (rev) {
+    uint32_t acc[4] = {0, 0, 0, 0};
+    for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
+      const uint32_t d = d0 + lane;
+      const uint32_t xl = linearize(d < nd ? seqw[d] : 0u);
+      const int nv = min(max((int)L - (int)(8u * d), 0), 8);
+      const uint32_t vmask = (1u << nv) - 1u;
+#pragma unroll
+      for (int k = 0; k < 4; k++) if ((needmask >> k) & 1u) acc[k] += (uint32_t)__popc(match8(xl, k) & vmask);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if ((needmask >> k) & 1u) tot[k] = __shfl(wave_incl_scan(acc[k]), 63, 64);
   }
   bool err = false;
   const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);  // read_can_be_trimmed (mod_bam.rs:1668-1671)
@@ -216,37 +268,83 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
   uint32_t obs0 = 0, obs1 = 0, contrib_lo = 0, contrib_hi = 0;  // contrib: 8 groups x 8 tag bits
   bool any_surviving = false;
   uint32_t n_ev = 0;
-  uint32_t q_run = 0, cum[4] = {0, 0, 0, 0};
-  int32_t r_run = h.ref_start;
+  uint32_t cum[4] = {0, 0, 0, 0};
+  // CIGAR window: 64 ops in registers, advanced as the walk moves along the read
+  uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
+  uint32_t w_op = 5u, w_qe = 0, w_qs = 0; int32_t w_rs = 0; uint32_t w_rtot = 0;
+  bool win_loaded = false;
 
-  for (uint32_t c0 = 0; c0 < h.n_cigar && !err; c0 += 64) {
-    uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u /*0H*/;
-    uint32_t op = w & 15u, len = w >> 4;
-    uint32_t qlen = op_consumes_query(op) ? len : 0u;
-    uint32_t rlen = op_consumes_ref(op) ? len : 0u;
-    uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
-    uint32_t qs = q_run + qe - qlen;
-    int32_t rs = r_run + (int32_t)(re - rlen);
-    uint32_t Qtot = __shfl(qe, 63, 64), Rtot = __shfl(re, 63, 64);
-    for (uint32_t base = 0; base < Qtot; base += 64) {
-      uint32_t j = base + lane;
-      bool active = j < Qtot;
-      int oi = find_op(qe, active ? j : 0u);
-      uint32_t my_qs = __shfl(qs, oi, 64);
-      int32_t my_rs = __shfl(rs, oi, 64);
-      uint32_t my_op = __shfl(op, oi, 64);
-      const uint32_t q = q_run + j;
-      active = active && q < L;
-      const int x = active ? nib2base(seq_nibble(seq, q)) : -1;
-      unsigned long long bal[4]; uint32_t cnt[4];
+  for (uint32_t d0 = 0; d0 < nd && !err; d0 += 64) {
+    const uint32_t d = d0 + lane;
+    const uint32_t xl = linearize(d < nd ? seqw[d] : 0u);
+    const int nv = min(max((int)L - (int)(8u * d), 0), 8);
+    const uint32_t vmask = (1u << nv) - 1u;
+    uint32_t m8[4], incl[4], cnt[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) { bal[k] = __ballot(x == k); cnt[k] = (uint32_t)__popcll(bal[k]); }
-      const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
-      const uint32_t q_lo = q_run + base;
+    for (int k = 0; k < 4; k++) {
+      m8[k] = 0; incl[k] = 0; cnt[k] = 0;
+      if ((needmask >> k) & 1u) { m8[k] = match8(xl, k) & vmask; incl[k] = wave_incl_scan((uint32_t)__popc(m8[k])); cnt[k] = __shfl(incl[k], 63, 64); }
+    }
+    uint32_t U = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if ((implmask >> k) & 1u) U |= m8[k];
+    const uint32_t qa = 8u * d0, qb = min(qa + 512u, L);
+    uint32_t cur_before[MKP_MAX_TAGS];
+#pragma unroll
+    for (int t = 0; t < MKP_MAX_TAGS; t++) { cur_before[t] = t_cur[t]; if (t < n_tags) marks[t][lane] = 0; }
+    // ---- 2. mark the calls of every tag that fall into this chunk
+#pragma unroll
+    for (int t = 0; t < MKP_MAX_TAGS; t++) {
+      if (t >= n_tags) break;
+      const MkpTagDesc dsc = t_desc[t];
+      const int xb = dsc.fb == 4 ? 0 : (rev ? 3 - dsc.fb : dsc.fb);
+      uint32_t wlo, whi;   // window of keys this chunk can ask for (windows of successive chunks tile the key space)
+      if (dsc.fb == 4) { wlo = rev ? (L - qb) : qa; whi = rev ? (L - qa) : qb; }
+      else { const uint32_t c = sel4(cum, xb), n = sel4(cnt, xb); wlo = rev ? (sel4(tot, xb) - c - n) : c; whi = wlo + n; }
+      const uint32_t my_incl = sel4(incl, xb);
+      const uint32_t pk = my_incl | (sel4(m8, xb) << 16);
+      for (;;) {
+        uint32_t e; bool hit; uint32_t nh;
+        if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
+        else { const uint32_t i = t_cur[t] - 64u + lane; const bool valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }  // an entry >= whi is past the last occurrence: never consumed -> error at the end
+        if (nh == 0) break;
+        uint32_t owner, bit;
+        if (dsc.fb == 4) { const uint32_t q = (rev ? (L - 1u - e) : e) - qa; owner = q >> 3; bit = q & 7u; }
+        else {
+          const uint32_t s = hit ? ((rev ? (sel4(tot, xb) - 1u - e) : e) - sel4(cum, xb)) : 0u;  // chunk-relative stored ordinal
+          owner = (uint32_t)find_op(my_incl, s);
+          const uint32_t po = __shfl(pk, (int)(owner & 63u), 64);
+          const uint32_t mo = po >> 16;
+          bit = hit ? select8(mo, s - ((po & 0xffffu) - (uint32_t)__popc(mo))) : 0u;
+        }
+        if (hit) atomicOr(&marks[t][owner & 63u], 1u << bit);
+        if (nh < 64) break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t pack_t[MKP_MAX_TAGS];
+#pragma unroll
+    for (int t = 0; t < MKP_MAX_TAGS; t++) {
+      pack_t[t] = 0;
+      if (t < n_tags) { const uint32_t bm = marks[t][lane]; U |= bm; const uint32_t c = (uint32_t)__popc(bm); pack_t[t] = bm | ((wave_incl_scan(c) - c) << 8); }
+    }
+    const uint32_t ucnt = (uint32_t)__popc(U);
+    const uint32_t uincl = wave_incl_scan(ucnt);
+    const uint32_t H = __shfl(uincl, 63, 64);
+    const uint32_t packU = U | ((uincl - ucnt) << 8);
+    // ---- 3. the called positions, 64 per batch, in read order
+    for (uint32_t g0 = 0; g0 < H && !err; g0 += 64) {
+      const uint32_t g = g0 + lane;
+      const bool active = g < H;
+      const int owner = find_op(uincl, active ? g : 0u) & 63;
+      const uint32_t pu = __shfl(packU, owner, 64), xo = __shfl(xl, owner, 64);
+      const uint32_t bit = active ? select8(pu & 0xffu, g - (pu >> 8)) : 0u;
+      const uint32_t q = 8u * (d0 + (uint32_t)owner) + bit;
+      const int x = active ? nib2base((xo >> (4u * bit)) & 15u) : -1;
       const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
       const int b = x < 0 ? -1 : (rev ? 3 - x : x);
-      uint32_t rank = 0;
-      if (x >= 0) { const uint32_t incl = sel4(cum, x) + (uint32_t)__popcll(sel4b(bal, x) & lanemask_le()); rank = rev ? (sel4(tot, x) - incl) : (incl - 1u); }
       GState S0, S1;
 #pragma unroll
       for (int k = 0; k < MKP_KMAX; k++) { S0.pk[k] = 0.f; S1.pk[k] = 0.f; }
@@ -254,44 +352,56 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
 #pragma unroll
       for (int t = 0; t < MKP_MAX_TAGS; t++) {
         if (t >= n_tags) break;
-        const MkpTagDesc d = t_desc[t];
-        // window of keys this step can ask for (keys of successive steps tile the key space, so entries below it are spent)
-        uint32_t wlo, whi;
-        if (d.fb == 4) { wlo = rev ? (L - q_lo - n_act) : q_lo; whi = wlo + n_act; }
-        else { const int xb = rev ? 3 - d.fb : d.fb; const uint32_t c = sel4(cum, xb), n = sel4(cnt, xb); wlo = rev ? (sel4(tot, xb) - c - n) : c; whi = wlo + n; }
-        uint32_t e; bool valid; uint32_t idx0;
-        if (!rev) { idx0 = t_cur[t]; const uint32_t i = idx0 + lane; valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; const uint32_t nh = (uint32_t)__popcll(__ballot(valid && e < whi)); t_cur[t] += nh; }
-        else { idx0 = t_cur[t] - 64u; const uint32_t i = idx0 + lane; valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; const uint32_t nh = (uint32_t)__popcll(__ballot(valid && e >= wlo && e < whi)); t_cur[t] -= nh; }  // an entry >= whi is past the last occurrence: never consumed -> error at the end
-        const unsigned long long vmask = __ballot(valid);
-        const bool member = active && (d.fb == 4 || (int)d.fb == b);
-        const uint32_t key = d.fb == 4 ? f : rank;
-        // search on e+1 so the empty lanes (0 at the low end when walking a reverse read) can never tie with rank 0
-        const uint32_t e1 = valid ? e + 1u : (rev ? 0u : 0xffffffffu);
-        const int fi = find_sorted(e1, member ? key + 1u : 0u);
-        const uint32_t ef = __shfl(e1, fi & 63, 64);
-        const bool found = member && fi < 64 && ef == key + 1u && ((vmask >> (fi & 63)) & 1ull);
+        const MkpTagDesc dsc = t_desc[t];
+        const uint32_t pt = __shfl(pack_t[t], owner, 64);
+        const bool found = active && ((pt >> bit) & 1u);
         if (!found) continue;
         if (x < 0) { err = true; continue; }  // a call listed on a non-ACGT base (DnaBase::try_from, mod_bam.rs:1245)
-        const uint32_t jx = idx0 + (uint32_t)fi;
+        const uint32_t idx = (pt >> 8) + (uint32_t)__popc(pt & ((1u << bit) - 1u));  // index among the tag's calls of this chunk, read order
+        const uint32_t jx = rev ? (cur_before[t] - 1u - idx) : (cur_before[t] + idx);
         const uint32_t tm = lay->tagmap[t][b];  // [0:3] member index, [4+4i : 8+4i) local code of the tag's i-th code
         const uint32_t mi = tm & 15u;
         // get_base_mod_probs (mod_bam.rs:1242-1263): stride = #codes of the tag
         float ts[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
         uint32_t seen = 0;
-        for (int i = 0; i < (int)d.n_codes; i++) {
-          const float p = ((float)ml[t_ml[t] + jx * d.n_codes + i] + 0.5f) / 256.0f;  // quals_to_probs 808-816
+        for (int i = 0; i < (int)dsc.n_codes; i++) {
+          const float p = ((float)ml[t_ml[t] + jx * dsc.n_codes + i] + 0.5f) / 256.0f;  // quals_to_probs 808-816
           const uint32_t kk = (tm >> (4 + 4 * i)) & 15u;
 #pragma unroll
           for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k == kk) {
             if (seen & (1u << k)) { if (ts[k] + p > 1.01f) err = true; ts[k] = ts[k] + p; } else { ts[k] = p; seen |= 1u << k; }
           }
         }
-        if (d.neg) { if (merge_tag(S1, ts, seen, mi)) err = true; } else { if (merge_tag(S0, ts, seen, mi)) err = true; }
+        if (dsc.neg) { if (merge_tag(S1, ts, seen, mi)) err = true; } else { if (merge_tag(S0, ts, seen, mi)) err = true; }
+      }
+      // reference position through the CIGAR window (aligned pairs: M/=/X only, util.rs:122-145)
+      bool mapped = false; int32_t rpos = 0;
+      {
+        bool pending = active && x >= 0;
+        for (;;) {
+          if (!win_loaded || (__any(pending && q >= wq1) && !__any(pending && q < wq1))) {
+            // load / advance the window
+            if (win_loaded) { c0 += 64; wq0 = wq1; wr0 += (int32_t)w_rtot; }
+            if (c0 >= h.n_cigar) break;
+            const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u /*0H*/;
+            w_op = w & 15u; const uint32_t len = w >> 4;
+            const uint32_t qlen = op_consumes_query(w_op) ? len : 0u, rlen = op_consumes_ref(w_op) ? len : 0u;
+            w_qe = wave_incl_scan(qlen); const uint32_t re = wave_incl_scan(rlen);
+            w_qs = wq0 + w_qe - qlen; w_rs = wr0 + (int32_t)(re - rlen);
+            wq1 = wq0 + __shfl(w_qe, 63, 64); w_rtot = __shfl(re, 63, 64);
+            win_loaded = true;
+            continue;
+          }
+          const bool ready = pending && q < wq1;
+          const int oi = find_op(w_qe, ready ? q - wq0 : 0u) & 63;
+          const uint32_t my_qs = __shfl(w_qs, oi, 64), my_op = __shfl(w_op, oi, 64);
+          const int32_t my_rs = __shfl(w_rs, oi, 64);
+          if (ready) { mapped = op_is_match(my_op); rpos = my_rs + (int32_t)(q - my_qs); pending = false; }
+          if (!__any(pending)) break;
+        }
       }
       uint32_t ev_info[2]; float sv[2] = {0.f, 0.f}; uint32_t ev_cnt = 0; int32_t ev_pos = 0;
       if (active && x >= 0) {
-        const bool mapped = op_is_match(my_op);
-        const int32_t rpos = my_rs + (int32_t)(q - my_qs);
         const bool edge_keep = !prm.edge_filter ||
             (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
         bool dec_done = false;
@@ -312,37 +422,37 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
           } else if (impl) {
             pat = MKP_PAT_INFERRED; member_contrib = impl;  // implicit fill (mod_bam.rs:1265-1292)
           } else continue;
-          const GroupRegs g = load_group(gp);
+          const GroupRegs gr = load_group(gp);
           const uint32_t pv = gp[12 + pat];
           uint32_t tagbits = 0;
 #pragma unroll
-          for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (member_contrib & (1u << mi)) tagbits |= 1u << ((g.member_tags >> (4 * mi)) & 15u);
+          for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (member_contrib & (1u << mi)) tagbits |= 1u << ((gr.member_tags >> (4 * mi)) & 15u);
           const int gi = sg * 4 + b;
           if (gi < 4) contrib_lo |= tagbits << (8 * gi); else contrib_hi |= tagbits << (8 * (gi - 4));
           if (!trimmable || !edge_keep) continue;
-          if (prm.sample_mode) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
+          if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
             bool keep = !prm.only_mapped || mapped;
             if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
             if (!keep) continue;
             any_surviving = true;
-            sv[ev_cnt] = argmax_group(g, pv, spk, collapse);
-            ev_info[ev_cnt++] = MKP_G_TB(g.misc);
+            sv[ev_cnt] = argmax_group(gr, pv, spk, collapse);
+            ev_info[ev_cnt++] = MKP_G_TB(gr.misc);
             continue;
           }
           any_surviving = true;
           uint32_t ob = 0;
-          const int cls = call_group(g, pv, spk, collapse, &ob);
+          const int cls = call_group(gr, pv, spk, collapse, &ob);
           const uint32_t tally = aln ^ (uint32_t)sg;  // read_cache.rs:181-188 / FeatureVector::add_feature
           if (tally) obs1 |= ob; else obs0 |= ob;
           if (mapped) {
-            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(g.misc) : ((g.cids >> (8 * (cls - 2))) & 0xffu);
+            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(gr.misc) : ((gr.cids >> (8 * (cls - 2))) & 0xffu);
             ev_info[ev_cnt++] = cid | (tally << 8) | ((uint32_t)b << 9) | (aln << 11) | (dec_done ? 0u : (1u << 12));
             dec_done = true;
             ev_pos = rpos;
           }
         }
       }
-      // ballot-compacted, position-ordered append of this step's events
+      // ballot-compacted, position-ordered append of this batch's events
       unsigned long long b1 = __ballot(ev_cnt >= 1), b2 = __ballot(ev_cnt >= 2);
       uint32_t step_total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
       if (step_total) {
@@ -351,16 +461,15 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
         if (n_ev + step_total > h.event_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
         else for (uint32_t e2 = 0; e2 < ev_cnt; e2++) {
           MkpEvent ev; ev.pos = (uint32_t)ev_pos; ev.info = ev_info[e2]; events[h.event_off + off + e2] = ev;
-          if (prm.sample_mode) sample_vals[h.event_off + off + e2] = sv[e2];
+          if (SAMPLE) sample_vals[h.event_off + off + e2] = sv[e2];
         }
         n_ev += step_total;
       }
-#pragma unroll
-      for (int k = 0; k < 4; k++) cum[k] += cnt[k];
       err = __any(err);
-      if (err) break;
     }
-    q_run += Qtot; r_run += (int32_t)Rtot;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cum[k] += cnt[k];
+    err = __any(err);
   }
   // a delta list must not run past the last occurrence of its base / the end of the read: every entry must have
   // been consumed by the join (mod_bam.rs:705-727, 750-756)
@@ -371,7 +480,7 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
   contrib_lo = wave_or(contrib_lo); contrib_hi = wave_or(contrib_hi);
   any_surviving = __any(any_surviving);
   // InvalidImplicitMode: a group all of whose contributing tags have no mode character (read_cache.rs:122-137)
-  if (!prm.force_allow && !prm.sample_mode) {
+  if (!prm.force_allow && !SAMPLE) {
     for (int gi = 0; gi < 8; gi++) {
       uint32_t m = ((gi < 4 ? contrib_lo >> (8 * gi) : contrib_hi >> (8 * (gi - 4)))) & 0xffu;
       if (m && (m & ~(uint32_t)lay->default_mask) == 0) err = true;
@@ -381,6 +490,18 @@ mkp_decode_reads(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const ui
     if (!err && any_surviving) { out.ok = 1; out.n_events = n_ev; out.obs[0] = obs0; out.obs[1] = obs1; }
     readout[rid] = out;
   }
+}
+
+#define DECODE_ARGS const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
+                    const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
+                    const MkpLayout* __restrict__ layouts, MkpRunParams prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
+                    uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_ARGS) {
+  decode_read_body<false>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
+}
+// the same walk in threshold-sampling mode (reads_sampler / thresholds.rs:121-159): a separate kernel so profiles keep the two apart
+extern "C" __global__ void __launch_bounds__(256) mkp_sample_reads(DECODE_ARGS) {
+  decode_read_body<true>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -717,7 +838,8 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
   if (!n_reads) return hipSuccess;
   const uint32_t waves_per_block = 4;
   dim3 grid((n_reads + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
-  hipLaunchKernelGGL(mkp_decode_reads, grid, block, 0, st, hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals);
+  if (prm->sample_mode) hipLaunchKernelGGL(mkp_sample_reads, grid, block, 0, st, hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals);
+  else hipLaunchKernelGGL(mkp_decode_reads, grid, block, 0, st, hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals);
   return hipGetLastError();
 }
 
