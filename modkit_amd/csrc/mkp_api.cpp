@@ -11,7 +11,7 @@ hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, uint32_t, const uin
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
 hipError_t mkp_pileup_set_lds(uint32_t);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
-                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, const MkpCombo*, const MkpRunParams*,
+                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
                              const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
@@ -55,10 +55,12 @@ void make_resident(mkp_ctx* c) {
   const uint32_t words_per_pos = 2u * (P.n_counters + P.n_slots);
   uint32_t T = c->cfg.tile_positions;
   const uint32_t budget = 160u * 1024u - 512u;
-  uint32_t maxT = budget / 4u / words_per_pos; maxT = maxT > 2 * MKP_HALO + 64 ? maxT - 2 * MKP_HALO : 64; maxT &= ~63u;
+  uint32_t maxT = 0;
+  for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;
+  if (maxT < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
   if (!T || T > maxT) T = std::min<uint32_t>(maxT, 4096u);
-  if (T < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
-  P.tile = T; c->lds_bytes = words_per_pos * (T + 2 * MKP_HALO) * 4u;
+  T = std::max<uint32_t>(64u, T & ~63u);
+  P.tile = T; c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_pos, T + 2 * MKP_HALO) * 4u;
   const uint64_t win = (uint64_t)(S.win_end - S.win_start);
   P.n_tiles_total = (uint32_t)((win + T - 1) / T);
   // tile -> [first,last) reads.  Reads are coordinate sorted; prefix-max of ends bounds the first candidate.
@@ -110,12 +112,14 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
     uint32_t* misc = c->d_misc.as<uint32_t>();  // [0] row cursor, [1] total rows, [2] error bits
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
+    c->d_prm.ensure(sizeof(MkpRunParams));
+    hip_check(hipMemcpyAsync(c->d_prm.p, &P, sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), (uint32_t)S.hdr.size(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &P,
+                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
                                 &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
     hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_tiles, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
@@ -194,7 +198,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tile_ids,
-                    &c->d_tile_first, &c->d_tile_last, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
+                    &c->d_tile_first, &c->d_tile_last, &c->d_prm, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -125,6 +125,13 @@ struct MkpRunParams {
   MkpSlot slots[MKP_MAX_SLOTS];
 };
 
+// mkp_pileup_tiles geometry: 16 waves per tile; behind the tallies every wave owns an op-start bitmap over the
+// tile's positions (even number of dwords, 2 spare for the 96-bit window read) and a 64 x 8-byte compaction buffer
+#define MKP_PILEUP_THREADS 1024
+#define MKP_PILEUP_WAVE_SCRATCH 128
+#define MKP_PILEUP_BM_WORDS(TH) (((((TH) + 31u) >> 5) + 3u) & ~1u)
+#define MKP_PILEUP_LDS_WORDS(words_per_pos, TH) ((words_per_pos) * (TH) + (MKP_PILEUP_THREADS / 64) * (MKP_PILEUP_BM_WORDS(TH) + MKP_PILEUP_WAVE_SCRATCH))
+
 struct MkpRowsDev {  // SoA row buffers (44 B / row)
   uint32_t* pos; uint32_t* info; uint32_t* code;
   uint32_t* n_valid; uint32_t* n_mod; uint32_t* n_can; uint32_t* n_other;

@@ -623,18 +623,42 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
   return n;
 }
 
-#define PILEUP_THREADS 512
+#define PILEUP_THREADS MKP_PILEUP_THREADS
+#define PILEUP_WAVES (PILEUP_THREADS / 64)
+#define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
+
+// first index in the position-sorted event list `ev[0..n)` whose pos is >= key: 64-way probes, two dependent
+// loads for up to 4096 events instead of a 12-step bisection
+__device__ __forceinline__ uint32_t event_lower_bound(const MkpEvent* __restrict__ ev, uint32_t n, int32_t key) {
+  const uint32_t lane = (uint32_t)lane_id();
+  uint32_t lo = 0, span = n;
+  while (span > 64) {
+    const uint32_t stride = (span + 63u) >> 6;
+    const uint32_t k = lo + lane * stride;
+    const bool valid = k < lo + span;
+    const int32_t p = valid ? (int32_t)ev[k].pos : 0x7fffffff;
+    const uint32_t c = (uint32_t)__popcll(__ballot(valid && p < key));
+    if (c == 0) return lo;
+    const uint32_t nlo = lo + (c - 1u) * stride + 1u;
+    const uint32_t nhi = min(lo + c * stride, lo + span);
+    lo = nlo; span = nhi - nlo;
+  }
+  const bool valid = lane < span;
+  const int32_t p = valid ? (int32_t)ev[lo + lane].pos : 0x7fffffff;
+  return lo + (uint32_t)__popcll(__ballot(valid && p < key));
+}
 
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS)
 mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
-                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, MkpRunParams prm, MkpRowsDev rows,
+                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
                  uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
                  uint32_t* __restrict__ dev_err) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t wave_tot[PILEUP_THREADS / 64];
+  __shared__ uint32_t wave_tot[PILEUP_WAVES];
   __shared__ uint32_t tile_base;
+  const MkpRunParams& prm = *prmp;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
   uint32_t bid = blockIdx.x;
@@ -645,17 +669,22 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   const uint32_t tix = bid;
   const uint32_t tile = tile_ids[tix];
   const uint32_t T = prm.tile, TH = T + 2 * MKP_HALO;
+  const uint32_t n_counters = prm.n_counters, n_slots = prm.n_slots;
   const int32_t T0 = prm.win_start + (int32_t)(tile * T);
   const int32_t T0h = T0 - MKP_HALO, T1h = T0 + (int32_t)T + MKP_HALO;
-  TileView tv; tv.TH = TH; tv.n_counters = prm.n_counters; tv.n_slots = prm.n_slots;
-  tv.cnt = lds; tv.obs = (int32_t*)(lds + 2u * prm.n_counters * TH);
-  const uint32_t lds_words = 2u * (prm.n_counters + prm.n_slots) * TH;
-  for (uint32_t k = threadIdx.x; k < lds_words; k += blockDim.x) lds[k] = 0;
+  TileView tv; tv.TH = TH; tv.n_counters = n_counters; tv.n_slots = n_slots;
+  tv.cnt = lds; tv.obs = (int32_t*)(lds + 2u * n_counters * TH);
+  const uint32_t lds_words = 2u * (n_counters + n_slots) * TH;
+  const int lane = lane_id();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // per-wave scratch behind the tallies: op-start bitmap over the tile's positions + CIGAR compaction buffer
+  const uint32_t bm_words = MKP_PILEUP_BM_WORDS(TH);
+  uint32_t* __restrict__ bm = lds + lds_words + wave * (bm_words + PILEUP_WAVE_SCRATCH);
+  uint2* __restrict__ comp = reinterpret_cast<uint2*>(bm + bm_words);
+  for (uint32_t k = threadIdx.x; k < lds_words + PILEUP_WAVES * (bm_words + PILEUP_WAVE_SCRATCH); k += PILEUP_THREADS) lds[k] = 0;
   __syncthreads();
 
-  const int lane = lane_id();
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
-  for (uint32_t rid = tile_first[tix] + wave; rid < tile_last[tix]; rid += n_waves) {
+  for (uint32_t rid = tile_first[tix] + wave; rid < tile_last[tix]; rid += PILEUP_WAVES) {
     const MkpReadHdr h = hdrs[rid];
     if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
     const MkpReadOut ro = readout[rid];
@@ -667,21 +696,41 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
       const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
       while (m) {
         const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-        atomicAdd(&tv.obs[((uint32_t)lane * prm.n_slots + sl) * TH + (uint32_t)(a - T0h)], 1);
-        if (b < T1h) atomicAdd(&tv.obs[((uint32_t)lane * prm.n_slots + sl) * TH + (uint32_t)(b - T0h)], -1);
+        atomicAdd(&tv.obs[((uint32_t)lane * n_slots + sl) * TH + (uint32_t)(a - T0h)], 1);
+        if (b < T1h) atomicAdd(&tv.obs[((uint32_t)lane * n_slots + sl) * TH + (uint32_t)(b - T0h)], -1);
       }
     }
-    // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip)
+    // the read's call events inside the tile (sorted by position); issued first so their loads overlap the depth walk
+    if (ro.ok && ro.n_events) {
+      const MkpEvent* __restrict__ ev = events + h.event_off;
+      const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
+      for (uint32_t k = lo + lane;; k += 64) {
+        bool in = k < ro.n_events;
+        MkpEvent e; e.pos = 0; e.info = 0;
+        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
+        if (in) {
+          const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
+          atomicAdd(&tv.cnt[(((e.info >> 8) & 1u) * n_counters + (e.info & 0xffu)) * TH + i], 1u);
+          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
+            atomicAdd(&tv.cnt[(((e.info >> 11) & 1u) * n_counters + MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0xffffffffu);
+        }
+        if (!__any(in)) break;
+      }
+    }
+    // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
+    // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
+    uint32_t* __restrict__ nc_base = tv.cnt + (aln * n_counters + MKP_C_NC) * TH;
+    uint32_t* __restrict__ del_base = tv.cnt + (aln * n_counters + MKP_C_DEL) * TH;
     uint32_t q_run = 0; int32_t r_run = h.ref_start;
     for (uint32_t c0 = 0; c0 < h.n_cigar; c0 += 64) {
       if (r_run >= T1h) break;
-      uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
-      uint32_t op = w & 15u, len = w >> 4;
-      uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
-      uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
-      uint32_t qs = q_run + qe - qlen;
-      int32_t rs = r_run + (int32_t)(re - rlen);
-      uint32_t Qtot = __shfl(qe, 63, 64), Rtot = __shfl(re, 63, 64);
+      const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
+      const uint32_t op = w & 15u, len = w >> 4;
+      const uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
+      const uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
+      const uint32_t qs = q_run + qe - qlen;
+      const int32_t rs = r_run + (int32_t)(re - rlen);
+      const uint32_t Qtot = __shfl(qe, 63, 64), Rtot = __shfl(re, 63, 64);
       const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
       if (c_lo < c_hi) {
         if (op == 3 && ro.ok) {  // ref-skip: the read is not in these columns (alignment.is_refskip())
@@ -690,56 +739,64 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
             uint32_t m = ro.obs[s];
             while (m) {
               const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-              atomicAdd(&tv.obs[(s * prm.n_slots + sl) * TH + (uint32_t)(a - T0h)], -1);
-              if (b < T1h) atomicAdd(&tv.obs[(s * prm.n_slots + sl) * TH + (uint32_t)(b - T0h)], 1);
+              atomicAdd(&tv.obs[(s * n_slots + sl) * TH + (uint32_t)(a - T0h)], -1);
+              if (b < T1h) atomicAdd(&tv.obs[(s * n_slots + sl) * TH + (uint32_t)(b - T0h)], 1);
             }
           }
         }
+        // compact the window's reference-consuming ops to the low lanes: {start, packed(query offset, kind)}
+        const bool isref = rlen > 0;
+        const unsigned long long refbal = __ballot(isref);
+        const uint32_t nref = (uint32_t)__popcll(refbal);
+        const uint32_t ci = (uint32_t)__popcll(refbal & lanemask_lt());
+        const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
+        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 28)) << 2) | kind;  // q = (pos - ref_start) + D
+        if (isref) comp[ci] = make_uint2((uint32_t)rs, pk);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint2 cc = comp[lane];
+        const bool cvalid = (uint32_t)lane < nref;
+        const int32_t c_rs = (int32_t)cc.x; const uint32_t c_pk = cc.y;
+        const uint32_t cb = (uint32_t)__popcll(__ballot(cvalid && c_rs <= c_lo)) - 1u;  // op covering c_lo
+        const bool mark = cvalid && c_rs > c_lo && c_rs < c_hi;
+        const uint32_t mrel = (uint32_t)(c_rs - T0h);
+        if (mark) atomicOr(&bm[mrel >> 5], 1u << (mrel & 31u));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t R = cb;
         for (int32_t pb0 = c_lo; pb0 < c_hi; pb0 += 64) {
+          const uint32_t rel = (uint32_t)(pb0 - T0h), wi = rel >> 5, sh = rel & 31u;
+          const uint32_t d0 = bm[wi], d1 = bm[wi + 1], d2 = bm[wi + 2];
+          const uint32_t wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
+          const uint32_t own = ((lane < 32 ? (wlo >> lane) : (whi >> (lane - 32))) & 1u);
+          const uint32_t idx = R + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u)) + own;
+          const uint32_t pkv = __shfl(c_pk, (int)(idx & 63u), 64);
+          R += (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
           const int32_t pos = pb0 + lane;
-          const bool active = pos < c_hi;
-          const uint32_t rel = (uint32_t)((active ? pos : c_lo) - r_run);
-          const int oi = find_op(re, rel);
-          const uint32_t my_op = __shfl(op, oi, 64), my_qs = __shfl(qs, oi, 64);
-          const int32_t my_rs = __shfl(rs, oi, 64);
-          if (active) {
+          if (pos < c_hi) {
             const uint32_t i = (uint32_t)(pos - T0h);
-            if (op_is_match(my_op)) {
-              const uint32_t q = my_qs + (uint32_t)(pos - my_rs);
+            const uint32_t kd = pkv & 3u;
+            if (kd == 0) {
+              const uint32_t q = (uint32_t)((pos - h.ref_start) + ((int32_t)(pkv >> 2) - (1 << 28)));
               const int x = q < h.l_seq ? nib2base(seq_nibble(seq, q)) : -1;
-              if (x >= 0) atomicAdd(&tv.cnt[(aln * prm.n_counters + MKP_C_NC + (uint32_t)(aln ? 3 - x : x)) * TH + i], 1u);
-            } else if (my_op == 2) {
-              atomicAdd(&tv.cnt[(aln * prm.n_counters + MKP_C_DEL) * TH + i], 1u);
+              if (x >= 0) atomicAdd(&nc_base[(uint32_t)(aln ? 3 - x : x) * TH + i], 1u);
+            } else if (kd == 1) {
+              atomicAdd(&del_base[i], 1u);
             }
           }
         }
+        if (mark) bm[mrel >> 5] = 0;
       }
       q_run += Qtot; r_run += (int32_t)Rtot;
-    }
-    // the read's call events inside the tile (sorted by position)
-    if (ro.ok && ro.n_events) {
-      const MkpEvent* __restrict__ ev = events + h.event_off;
-      uint32_t lo = 0, hi = ro.n_events;
-      while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if ((int32_t)ev[mid].pos < T0h) lo = mid + 1; else hi = mid; }
-      for (uint32_t k = lo + lane;; k += 64) {
-        bool in = k < ro.n_events;
-        MkpEvent e; e.pos = 0; e.info = 0;
-        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
-        if (in) {
-          const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
-          atomicAdd(&tv.cnt[(((e.info >> 8) & 1u) * prm.n_counters + (e.info & 0xffu)) * TH + i], 1u);
-          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
-            atomicAdd(&tv.cnt[(((e.info >> 11) & 1u) * prm.n_counters + MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0xffffffffu);
-        }
-        if (!__any(in)) break;
-      }
     }
   }
   __syncthreads();
   // observed-code difference arrays -> coverage counts (one wave per array)
   {
-    const uint32_t n_arr = 2u * prm.n_slots;
-    for (uint32_t a = wave; a < n_arr; a += n_waves) {
+    const uint32_t n_arr = 2u * n_slots;
+    for (uint32_t a = wave; a < n_arr; a += PILEUP_WAVES) {
       int32_t* arr = tv.obs + a * TH;
       uint32_t carry = 0;
       for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
@@ -752,7 +809,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   }
   __syncthreads();
   // rows: each thread owns a contiguous run of positions so row order == position order
-  const uint32_t per = (T + blockDim.x - 1) / blockDim.x;
+  const uint32_t per = (T + PILEUP_THREADS - 1) / PILEUP_THREADS;
   const uint32_t i0 = threadIdx.x * per;
   uint32_t my_rows = 0;
   bool deep = false;
@@ -763,7 +820,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     if (p < prm.win_start || p >= prm.win_end) continue;
     const uint32_t i = li + MKP_HALO;
     uint32_t depth = 0;
-    for (uint32_t s = 0; s < 2; s++) for (uint32_t c = 0; c < prm.n_counters; c++) depth += tv.c(s, c, i);
+    for (uint32_t s = 0; s < 2; s++) for (uint32_t c = 0; c < n_counters; c++) depth += tv.c(s, c, i);
     if (depth > prm.max_depth) deep = true;
     my_rows += rows_at<false>(tv, prm, focus, combos, T0h, i, rows, 0);
   }
@@ -773,7 +830,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t s = 0;
-    for (uint32_t w2 = 0; w2 < n_waves; w2++) { uint32_t t = wave_tot[w2]; wave_tot[w2] = s; s += t; }
+    for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) { uint32_t t = wave_tot[w2]; wave_tot[w2] = s; s += t; }
     uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
     if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
     tile_base = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s;
@@ -850,11 +907,11 @@ extern "C" hipError_t mkp_pileup_set_lds(uint32_t bytes) {
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
                                         const uint32_t* tile_last, uint32_t n_tiles, const uint8_t* focus, const MkpCombo* combos,
-                                        const MkpRunParams* prm, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
+                                        const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
                                         uint32_t* tile_row_cnt, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
   hipLaunchKernelGGL(mkp_pileup_tiles, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
-                     tile_last, n_tiles, focus, combos, *prm, *rows, row_cursor, tile_row_off, tile_row_cnt, dev_err);
+                     tile_last, n_tiles, focus, combos, prm_dev, *rows, row_cursor, tile_row_off, tile_row_cnt, dev_err);
   return hipGetLastError();
 }
 
