@@ -45,6 +45,7 @@ void make_resident(mkp_ctx* c) {
   P.numeric_mode = c->caller.numeric_mode; P.combine_strands = c->caller.combine_strands; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
   P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = c->caller.force_allow; P.max_depth = c->caller.max_depth;
   P.has_focus = c->has_focus; P.n_combos = (uint32_t)c->combos.size();
+  if (const char* dbg = getenv("MKP_DEBUG_SKIP")) P.debug_skip = (uint32_t)strtoul(dbg, nullptr, 0);
   for (int b = 0; b < 4; b++) { P.can_of_pb[b] = 0xff; P.pb_of_can[b] = 0; }
   for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) { P.can_of_pb[c->tables.st.can_pbs[k]] = (uint8_t)k; P.pb_of_can[k] = (uint8_t)c->tables.st.can_pbs[k]; }
   std::vector<int> order(P.n_slots); for (uint32_t i = 0; i < P.n_slots; i++) order[i] = (int)i;

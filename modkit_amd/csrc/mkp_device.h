@@ -119,6 +119,7 @@ struct MkpRunParams {
   uint32_t row_capacity;
   uint32_t sample_mode;     // 1: threshold sampling pass — emit argmax probabilities instead of call events
   uint32_t only_mapped;     // sampling: keep only calls with an aligned reference position
+  uint32_t debug_skip;      // ablation only (env MKP_DEBUG_SKIP): 1 depth walk, 2 events, 4 rows, 8 zero+obs scan
   uint8_t pb_of_can[4];     // CAN counter k -> primary base
   uint8_t can_of_pb[4];     // primary base -> CAN counter k or 0xff
   uint8_t slot_order[MKP_MAX_SLOTS];   // slots sorted by (code_repr, pb)

@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 }
 
 // BAM 4-bit code -> A,C,G,T = 0..3, anything else -1 (DnaBase::parse, mod_base_code.rs:188-196)
-__device__ __forceinline__ int nib2base(uint32_t n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : -1; }
+__device__ __forceinline__ int nib2base(uint32_t n) { const int x = (int)__ffs((int)n) - 1; return (n & (n - 1u)) ? -1 : x; }  // one-hot nibble -> bit index; 0 -> -1
 __device__ __forceinline__ uint32_t seq_nibble(const uint8_t* __restrict__ s, uint32_t q) {
   uint32_t b = s[q >> 1];
   return (q & 1u) ? (b & 15u) : (b >> 4);
@@ -626,6 +626,7 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
 #define PILEUP_THREADS MKP_PILEUP_THREADS
 #define PILEUP_WAVES (PILEUP_THREADS / 64)
 #define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
+#define PILEUP_UNROLL 4
 
 // first index in the position-sorted event list `ev[0..n)` whose pos is >= key: 64-way probes, two dependent
 // loads for up to 4096 events instead of a 12-step bisection
@@ -701,7 +702,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
       }
     }
     // the read's call events inside the tile (sorted by position); issued first so their loads overlap the depth walk
-    if (ro.ok && ro.n_events) {
+    if (ro.ok && ro.n_events && !(prm.debug_skip & 2u)) {
       const MkpEvent* __restrict__ ev = events + h.event_off;
       const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
       for (uint32_t k = lo + lane;; k += 64) {
@@ -719,18 +720,16 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     }
     // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
     // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
-    uint32_t* __restrict__ nc_base = tv.cnt + (aln * n_counters + MKP_C_NC) * TH;
-    uint32_t* __restrict__ del_base = tv.cnt + (aln * n_counters + MKP_C_DEL) * TH;
     uint32_t q_run = 0; int32_t r_run = h.ref_start;
     for (uint32_t c0 = 0; c0 < h.n_cigar; c0 += 64) {
-      if (r_run >= T1h) break;
+      if (r_run >= T1h || (prm.debug_skip & 1u)) break;
       const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
       const uint32_t op = w & 15u, len = w >> 4;
       const uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
       const uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
       const uint32_t qs = q_run + qe - qlen;
       const int32_t rs = r_run + (int32_t)(re - rlen);
-      const uint32_t Qtot = __shfl(qe, 63, 64), Rtot = __shfl(re, 63, 64);
+      const uint32_t Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63), Rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
       const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
       if (c_lo < c_hi) {
         if (op == 3 && ro.ok) {  // ref-skip: the read is not in these columns (alignment.is_refskip())
@@ -760,31 +759,38 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         const int32_t c_rs = (int32_t)cc.x; const uint32_t c_pk = cc.y;
         const uint32_t cb = (uint32_t)__popcll(__ballot(cvalid && c_rs <= c_lo)) - 1u;  // op covering c_lo
         const bool mark = cvalid && c_rs > c_lo && c_rs < c_hi;
-        const uint32_t mrel = (uint32_t)(c_rs - T0h);
+        const uint32_t mrel = (uint32_t)(c_rs - 1 - T0h);   // bit m set <=> an op starts at T0h+m+1: "starts at or before p" = bits strictly below p-T0h
         if (mark) atomicOr(&bm[mrel >> 5], 1u << (mrel & 31u));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 64 positions per step, aligned to the tile so a step reads one aligned 64-bit window of the bitmap;
+        // PILEUP_UNROLL steps are issued together (bitmap read -> bpermute -> SEQ byte load) before any tally update
         uint32_t R = cb;
-        for (int32_t pb0 = c_lo; pb0 < c_hi; pb0 += 64) {
-          const uint32_t rel = (uint32_t)(pb0 - T0h), wi = rel >> 5, sh = rel & 31u;
-          const uint32_t d0 = bm[wi], d1 = bm[wi + 1], d2 = bm[wi + 2];
-          const uint32_t wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
-          const uint32_t own = ((lane < 32 ? (wlo >> lane) : (whi >> (lane - 32))) & 1u);
-          const uint32_t idx = R + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u)) + own;
-          const uint32_t pkv = __shfl(c_pk, (int)(idx & 63u), 64);
-          R += (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
-          const int32_t pos = pb0 + lane;
-          if (pos < c_hi) {
-            const uint32_t i = (uint32_t)(pos - T0h);
-            const uint32_t kd = pkv & 3u;
-            if (kd == 0) {
-              const uint32_t q = (uint32_t)((pos - h.ref_start) + ((int32_t)(pkv >> 2) - (1 << 28)));
-              const int x = q < h.l_seq ? nib2base(seq_nibble(seq, q)) : -1;
-              if (x >= 0) atomicAdd(&nc_base[(uint32_t)(aln ? 3 - x : x) * TH + i], 1u);
-            } else if (kd == 1) {
-              atomicAdd(&del_base[i], 1u);
-            }
+        uint32_t* __restrict__ strand_base = tv.cnt + aln * n_counters * TH;   // rows NC[0..3], DEL of this alignment strand
+        const unsigned long long LUT = aln ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;  // BAM nibble -> NoCall row (complemented on '-'), f = not ACGT
+        const uint32_t k0 = (uint32_t)(c_lo - T0h) >> 6, k1 = (uint32_t)(c_hi - 1 - T0h) >> 6;
+        for (uint32_t kb = k0; kb <= k1; kb += PILEUP_UNROLL) {
+          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL], rl[PILEUP_UNROLL]; bool inb[PILEUP_UNROLL];
+#pragma unroll
+          for (int j = 0; j < PILEUP_UNROLL; j++) {
+            const uint32_t kk = min(kb + (uint32_t)j, k1);
+            const uint2 W = *reinterpret_cast<const uint2*>(bm + 2u * kk);
+            const uint32_t idx = R + __builtin_amdgcn_mbcnt_hi(W.y, __builtin_amdgcn_mbcnt_lo(W.x, 0u));
+            pkv[j] = __shfl(c_pk, (int)(idx & 63u), 64);
+            R += (uint32_t)__popc((uint32_t)__builtin_amdgcn_readfirstlane((int)W.x)) + (uint32_t)__popc((uint32_t)__builtin_amdgcn_readfirstlane((int)W.y));
+            rl[j] = 64u * kk + (uint32_t)lane;
+            const int32_t pos = T0h + (int32_t)rl[j];
+            inb[j] = pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1;
+            qq[j] = (uint32_t)(pos - h.ref_start) + (pkv[j] >> 2) - (1u << 28);
+            byte[j] = seq[(inb[j] && (pkv[j] & 3u) == 0) ? (qq[j] >> 1) : 0u];
+          }
+#pragma unroll
+          for (int j = 0; j < PILEUP_UNROLL; j++) {
+            const uint32_t kd = pkv[j] & 3u;
+            const uint32_t nb = (byte[j] >> ((qq[j] & 1u) ? 0u : 4u)) & 15u;
+            const uint32_t row = kd ? (uint32_t)MKP_C_DEL : (uint32_t)(LUT >> (4u * nb)) & 15u;
+            if (inb[j] && kd < 2u && row < 8u) atomicAdd(&strand_base[__umul24(row, TH) + rl[j]], 1u);
           }
         }
         if (mark) bm[mrel >> 5] = 0;
@@ -809,6 +815,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   }
   __syncthreads();
   // rows: each thread owns a contiguous run of positions so row order == position order
+  if (prm.debug_skip & 4u) { if (threadIdx.x == 0) { tile_row_off[tix] = 0; tile_row_cnt[tix] = 0; } return; }
   const uint32_t per = (T + PILEUP_THREADS - 1) / PILEUP_THREADS;
   const uint32_t i0 = threadIdx.x * per;
   uint32_t my_rows = 0;
