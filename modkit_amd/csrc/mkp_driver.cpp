@@ -18,7 +18,7 @@ struct Args {
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
-  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false;
+  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false, plan_only = false;
 };
 
 struct RegionSpec { std::string name; uint32_t start, end; };
@@ -267,7 +267,7 @@ int run(const Args& a, std::string* msg) {
   }
   mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
   mkp_ctx* ctx = nullptr;
-  int rc = mkp_ctx_create(&cfg, &ctx);
+  int rc = a.plan_only ? MKP_OK : mkp_ctx_create(&cfg, &ctx);   // --plan-only: shard plan of this rank, no device work
   if (rc != MKP_OK) throw Error(rc, "no usable gfx950 device (libmkpileup has no CPU path)");
   struct Guard { mkp_ctx* c; ~Guard() { mkp_ctx_destroy(c); } } guard{ctx};
   auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
@@ -275,7 +275,7 @@ int run(const Args& a, std::string* msg) {
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
   double thr_ms = 0;
   if (!a.filter_threshold.empty()) parse_base_thresholds(a.filter_threshold, &kc);
-  else if (a.no_filtering) { kc.n_per_mod = 0; }  // MultipleThresholdModCaller::new_passthrough
+  else if (a.no_filtering || a.plan_only) { kc.n_per_mod = 0; }  // MultipleThresholdModCaller::new_passthrough
   else {
     auto t0 = std::chrono::steady_clock::now();
     must(mkp_set_caller(ctx, &kc));  // collapse + edge filter apply to the sampled probabilities too
@@ -289,7 +289,7 @@ int run(const Args& a, std::string* msg) {
     }
     thr_ms = ms_since(t0);
   }
-  must(mkp_set_caller(ctx, &kc));
+  if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
   if (bf) records = bed_contigs(*bf, records, a.interval_size);
   wr.f = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w");
   if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
@@ -309,6 +309,7 @@ int run(const Args& a, std::string* msg) {
       const uint32_t owner = total_bp ? (uint32_t)std::min<uint64_t>(a.world - 1, mid * a.world / total_bp) : 0;
       i0 = i1;
       if (owner != a.rank) continue;
+      if (a.plan_only) { fprintf(wr.f, "%s\t%u\t%u\n", rec.name.c_str(), s0, s1); positions += bp; continue; }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
       must(mkp_shard_begin(ctx, &sh));
@@ -348,7 +349,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
     else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
     else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
-    else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
+    else if (s == "--plan-only") a.plan_only = true; else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag" || s == "--bedgraph" || s == "--prefix") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);

@@ -295,7 +295,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     // ---- 2. mark the calls of every tag that fall into this chunk
 #pragma unroll
     for (int t = 0; t < MKP_MAX_TAGS; t++) {
-      if (t >= n_tags) break;
+      if (t >= n_tags || (prm.debug_skip & 32u)) break;
       const MkpTagDesc dsc = t_desc[t];
       const int xb = dsc.fb == 4 ? 0 : (rev ? 3 - dsc.fb : dsc.fb);
       uint32_t wlo, whi;   // window of keys this chunk can ask for (windows of successive chunks tile the key space)
@@ -335,7 +335,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     const uint32_t H = __shfl(uincl, 63, 64);
     const uint32_t packU = U | ((uincl - ucnt) << 8);
     // ---- 3. the called positions, 64 per batch, in read order
-    for (uint32_t g0 = 0; g0 < H && !err; g0 += 64) {
+    for (uint32_t g0 = 0; g0 < H && !err && !(prm.debug_skip & 16u); g0 += 64) {
       const uint32_t g = g0 + lane;
       const bool active = g < H;
       const int owner = find_op(uincl, active ? g : 0u) & 63;
