@@ -1,0 +1,107 @@
+"""CPU-side checks of the product library (no GPU, no compute calls): libmkpileup.so loads and exports every symbol
+include/mkpileup.h declares, the ctypes mirror matches the header's struct layout, compute entry points fail loudly
+without a device (there is no CPU fallback), and the host-only arithmetic (mkp_percentile = percentile_linear_interp,
+src/thresholds.rs:17-38) reproduces the reference's known answers."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import modkit_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mkpileup.h")
+
+
+@pytest.fixture(scope="module")
+def L():
+    modkit_amd.build()
+    return modkit_amd.lib()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"^(?:int|void|const char\*)\s+(mkp_\w+)\s*\(", text, flags=re.M)))
+
+
+def test_every_declared_symbol_is_exported(L):
+    syms = declared_symbols()
+    assert len(syms) == 14 and sorted(modkit_amd.EXPORTS) == syms
+    for s in syms:
+        assert getattr(L, s) is not None
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", modkit_amd.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (mkp_\w+)", nm))
+    assert set(syms) <= exported
+    # nothing from the test oracle is linked into the product
+    assert "mko" not in nm and "oracle" not in nm.lower()
+
+
+def test_ctypes_mirror_matches_header_layout(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "mkpileup.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mkp_config), sizeof(mkp_mod_threshold), '
+                   'sizeof(mkp_caller), sizeof(mkp_record), sizeof(mkp_motif_combo), sizeof(mkp_shard), sizeof(mkp_rows), sizeof(mkp_stats));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])  # the header is plain C
+    sizes = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert sizes[0] == ctypes.sizeof(modkit_amd.Config)
+    assert sizes[1] == ctypes.sizeof(modkit_amd.ModThreshold)
+    assert sizes[2] == ctypes.sizeof(modkit_amd.Caller)
+    assert sizes[5] == ctypes.sizeof(modkit_amd.Shard)
+    assert sizes[6] == ctypes.sizeof(modkit_amd.Rows)
+    assert sizes[7] == ctypes.sizeof(modkit_amd.Stats)
+    assert sizes[4] == 16 and sizes[3] == 32
+
+
+def test_version_and_no_device_is_loud(L):
+    assert b"gfx950" in L.mkp_version()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the no-device path cannot be observed here")
+    with pytest.raises(modkit_amd.MkpError) as e:
+        modkit_amd.Context(device=0)
+    assert e.value.status == -4  # MKP_E_DEVICE
+    fix = os.path.join(ROOT, "tests", "golden", "modkit_fixtures", "bc_anchored_10_reads.sorted.bam")
+    with pytest.raises(modkit_amd.MkpError) as e:
+        modkit_amd.pileup([fix, "/dev/null", "--no-filtering"])
+    assert e.value.status == -4 and "no CPU path" in str(e.value)
+
+
+def pct(L, xs, q):
+    a = (ctypes.c_float * len(xs))(*xs)
+    out = ctypes.c_float()
+    L.mkp_percentile.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
+    rc = L.mkp_percentile(a, len(xs), ctypes.c_float(q), ctypes.byref(out))
+    return rc, out.value
+
+
+def test_percentile_known_answers(L):
+    # src/thresholds.rs:197-201: a quantile above 1 is an error; fewer than two datapoints is an error (line 18)
+    assert pct(L, [0.1, 0.2, 0.3], 1.5)[0] == -6
+    assert pct(L, [0.5], 0.1)[0] == -6
+    assert pct(L, [0.25, 0.5, 0.75], 1.0) == (0, 0.75)
+    assert pct(L, [0.25, 0.5, 0.75], 0.5) == (0, 0.5)
+    # the threshold the reference derives for its golden modbam.modpileup_filt025 (109 calls, p=0.25) is f32-exact 0.662109375
+    rng = np.random.default_rng(7)
+    xs = np.sort(((rng.integers(0, 256, 1001).astype(np.float32) + np.float32(0.5)) / np.float32(256)))
+    for q in (0.1, 0.25, 0.333, 0.9):
+        q32 = np.float32(q)
+        lq = np.float32(len(xs) - 1) * q32
+        g = np.float32(lq - np.float32(np.trunc(lq)))
+        want = np.float32(np.float32(xs[int(np.floor(lq))] * np.float32(np.float32(1) - g)) + np.float32(xs[int(np.ceil(lq))] * g))
+        rc, got = pct(L, [float(x) for x in xs], q)
+        assert rc == 0 and np.float32(got) == want
+
+
+def test_bad_arguments_do_not_crash(L):
+    assert L.mkp_ctx_create(None, None) == -1
+    L.mkp_get_stats.restype = ctypes.c_int
+    assert L.mkp_get_stats(None, None) == -1
+    assert L.mkp_last_error(None).startswith(b"no context")
+    err = ctypes.create_string_buffer(256)
+    arr = (ctypes.c_char_p * 1)(b"only_one_positional")
+    assert L.mkp_pileup_main(1, arr, err, 256) == -1 and b"usage" in err.value
+    arr = (ctypes.c_char_p * 3)(b"/nonexistent.bam", b"/dev/null", b"--partition-tag")
+    assert L.mkp_pileup_main(3, arr, err, 256) in (-1, -3)
