@@ -78,7 +78,8 @@ struct MkpGroupDesc {          // one (mod strand σ, read base b) group; index 
 struct MkpLayout {
   uint8_t n_tags;
   uint8_t default_mask;   // tags whose mode is DefaultImplicitUnmodified
-  uint8_t pad[2];
+  uint8_t fast;           // 1: all tags share one specific base and mod strand and no code is listed twice (single group, distinct codes)
+  uint8_t pad;
   MkpTagDesc tags[MKP_MAX_TAGS];
   uint32_t tagmap[MKP_MAX_TAGS][4];  // per (tag, read base): [0:3] member index in its group, [4+4i..] local code idx of the tag's i-th code
   uint32_t pad2[7];                  // groups start 16-byte aligned (offset 192)

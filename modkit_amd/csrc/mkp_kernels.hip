@@ -193,12 +193,22 @@ __device__ __forceinline__ uint32_t select8(uint32_t m, uint32_t r) {
 //      MultipleThresholdModCaller::call in f32, CIGAR mapping through a 64-op window, and one packed
 //      8-byte event per mapped call is appended (ballot-compacted, position order).
 // SAMPLE = threshold-sampling pass: emits argmax probabilities instead of call events.
-template <bool SAMPLE>
+// arr[j] for a wave-uniform j < N (N is tiny: a select chain, no scratch)
+template <int N> __device__ __forceinline__ uint32_t selN(const uint32_t* a, uint32_t j) {
+  uint32_t r = a[0];
+#pragma unroll
+  for (int i = 1; i < N; i++) r = (j == (uint32_t)i) ? a[i] : r;
+  return r;
+}
+
+// NT = compile-time bound on the read's MM tag count (the entry point dispatches on it): every per-tag loop and
+// register array below is sized for the layout actually present instead of NT.
+template <bool SAMPLE, int NT, bool FAST>
 __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
-                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals) {
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64]) {
   const int lane = lane_id();
   // wave-uniform values are made provably uniform (readfirstlane) so they live in SGPRs and load through the scalar cache
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -208,10 +218,9 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
   // the read's layout (1216 B) goes to LDS once; every table lookup below is an LDS read
-  __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
-  __shared__ uint32_t lds_marks[4][MKP_MAX_TAGS][64];
-  uint32_t* __restrict__ lds_lay = lds_layouts[wib];
-  uint32_t (*__restrict__ marks)[64] = lds_marks[wib];
+  constexpr int NB = NT < 4 ? NT : 4;   // distinct stored bases the tags can count
+  uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
+  uint32_t (*__restrict__ marks)[64] = lds_marks + wib * MKP_MAX_TAGS;
   { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
     for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
   __builtin_amdgcn_wave_barrier();
@@ -224,42 +233,78 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   const int n_tags = (int)h.n_tags;
 
   // per-tag cursors into the sorted rank lists: a merge join against the read's bases, 512 at a time
-  uint32_t t_off[MKP_MAX_TAGS], t_n[MKP_MAX_TAGS], t_ml[MKP_MAX_TAGS], t_cur[MKP_MAX_TAGS];
-  MkpTagDesc t_desc[MKP_MAX_TAGS];
-  uint32_t needmask = 0;   // stored bases (A,C,G,T = bit 0..3) some tag counts
+  uint32_t t_off[NT], t_n[NT], t_ml[NT], t_cur[NT];
+  MkpTagDesc t_desc[NT];
+  uint32_t sbase[NB], tslot[NT], nb = 0;   // base slots: the distinct stored bases (A,C,G,T = 0..3) some tag counts
 #pragma unroll
-  for (int t = 0; t < MKP_MAX_TAGS; t++) {
-    t_off[t] = 0; t_n[t] = 0; t_ml[t] = 0; t_cur[t] = 0; t_desc[t] = lay->tags[t];
+  for (int j = 0; j < NB; j++) sbase[j] = 0;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    t_off[t] = 0; t_n[t] = 0; t_ml[t] = 0; t_cur[t] = 0; tslot[t] = 0; t_desc[t] = lay->tags[t];
     if (t < n_tags) {
       const MkpTagRef tr = tagref[h.tag_off + t]; t_off[t] = tr.rank_off; t_n[t] = tr.n; t_ml[t] = tr.ml_off; t_cur[t] = rev ? tr.n : 0u;
-      if (t_desc[t].fb != 4) needmask |= 1u << (rev ? 3 - t_desc[t].fb : t_desc[t].fb);
+      if (t_desc[t].fb != 4) {
+        const uint32_t xb = (uint32_t)(rev ? 3 - t_desc[t].fb : t_desc[t].fb);
+        uint32_t found = nb;
+#pragma unroll
+        for (int j = 0; j < NB; j++) if ((uint32_t)j < nb && sbase[j] == xb) found = (uint32_t)j;
+        if (found == nb) {
+#pragma unroll
+          for (int j = 0; j < NB; j++) if ((uint32_t)j == nb) sbase[j] = xb;
+          nb++;
+        }
+        tslot[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)found);
+      }
     }
   }
-  needmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)needmask);
-  // stored bases every occurrence of which is a call: groups with implicit-mode members (mod_bam.rs:1265-1292)
-  uint32_t implmask = 0;
+  nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+  // slots every occurrence of whose base is a call: groups with implicit-mode members (mod_bam.rs:1265-1292)
+  uint32_t implslots = 0;
 #pragma unroll
-  for (int x = 0; x < 4; x++) {
-    const int b = rev ? 3 - x : x;
+  for (int j = 0; j < NB; j++) {
+    sbase[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sbase[j]);
+    const uint32_t b = rev ? 3u - sbase[j] : sbase[j];
     const uint32_t m0 = lds_lay[MKP_LAYOUT_GROUP_DW + b * 32], m1 = lds_lay[MKP_LAYOUT_GROUP_DW + (4 + b) * 32];
-    if (MKP_G_IMPL(m0) | MKP_G_IMPL(m1)) implmask |= 1u << x;
+    if ((uint32_t)j < nb && (MKP_G_IMPL(m0) | MKP_G_IMPL(m1))) implslots |= 1u << j;
   }
-  implmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)implmask);
+  implslots = (uint32_t)__builtin_amdgcn_readfirstlane((int)implslots);
+  // FAST: the one group of the read, held in SGPRs
+  const int b0 = (int)t_desc[0].fb & 3, sg0 = (int)t_desc[0].neg & 1;
+  const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
+  GroupRegs grp0; uint32_t tmu[NT], codes_t[NT], contribH = 0;
+  if (FAST) {
+    grp0 = load_group(gp0);
+    grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
+    grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
+#pragma unroll
+    for (int kq = 0; kq < MKP_KMAX; kq++) grp0.thr[kq] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr[kq])));
+    grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      tmu[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tagmap[t][b0]);
+      codes_t[t] = 0;
+      for (int i = 0; i < (int)t_desc[t].n_codes; i++) codes_t[t] |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
+    }
+  }
 
   // reverse reads need the totals up front (forward rank = total - inclusive count in stored order)
-  uint32_t tot[4] = {0, 0, 0, 0};
-  if (rev) {
-    uint32_t acc[4] = {0, 0, 0, 0};
+  uint32_t tot[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) tot[j] = 0;
+  if (rev && nb) {
+    uint32_t acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; j++) acc[j] = 0;
     for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
       const uint32_t d = d0 + lane;
       const uint32_t xl = linearize(d < nd ? seqw[d] : 0u);
       const int nv = min(max((int)L - (int)(8u * d), 0), 8);
       const uint32_t vmask = (1u << nv) - 1u;
 #pragma unroll
-      for (int k = 0; k < 4; k++) if ((needmask >> k) & 1u) acc[k] += (uint32_t)__popc(match8(xl, k) & vmask);
+      for (int j = 0; j < NB; j++) if ((uint32_t)j < nb) acc[j] += (uint32_t)__popc(match8(xl, (int)sbase[j]) & vmask);
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) if ((needmask >> k) & 1u) tot[k] = __shfl(wave_incl_scan(acc[k]), 63, 64);
+    for (int j = 0; j < NB; j++) if ((uint32_t)j < nb) tot[j] = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc[j]), 63);
   }
   bool err = false;
   const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);  // read_can_be_trimmed (mod_bam.rs:1668-1671)
@@ -268,7 +313,10 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   uint32_t obs0 = 0, obs1 = 0, contrib_lo = 0, contrib_hi = 0;  // contrib: 8 groups x 8 tag bits
   bool any_surviving = false;
   uint32_t n_ev = 0;
-  uint32_t cum[4] = {0, 0, 0, 0};
+  uint32_t cum[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) cum[j] = 0;
+  uint32_t x_next = (uint32_t)lane < nd ? seqw[lane] : 0u;   // the next step's SEQ dword is always in flight
   // CIGAR window: 64 ops in registers, advanced as the walk moves along the read
   uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
   uint32_t w_op = 5u, w_qe = 0, w_qs = 0; int32_t w_rs = 0; uint32_t w_rtot = 0;
@@ -276,33 +324,35 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
 
   for (uint32_t d0 = 0; d0 < nd && !err; d0 += 64) {
     const uint32_t d = d0 + lane;
-    const uint32_t xl = linearize(d < nd ? seqw[d] : 0u);
+    const uint32_t xl = linearize(x_next);
+    { const uint32_t dn = d + 64u; x_next = dn < nd ? seqw[dn] : 0u; }
     const int nv = min(max((int)L - (int)(8u * d), 0), 8);
     const uint32_t vmask = (1u << nv) - 1u;
-    uint32_t m8[4], incl[4], cnt[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      m8[k] = 0; incl[k] = 0; cnt[k] = 0;
-      if ((needmask >> k) & 1u) { m8[k] = match8(xl, k) & vmask; incl[k] = wave_incl_scan((uint32_t)__popc(m8[k])); cnt[k] = __shfl(incl[k], 63, 64); }
-    }
+    uint32_t m8[NB], incl[NB], cnt[NB];
     uint32_t U = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) if ((implmask >> k) & 1u) U |= m8[k];
+    for (int j = 0; j < NB; j++) {
+      m8[j] = 0; incl[j] = 0; cnt[j] = 0;
+      if ((uint32_t)j < nb) {
+        m8[j] = match8(xl, (int)sbase[j]) & vmask; incl[j] = wave_incl_scan((uint32_t)__popc(m8[j])); cnt[j] = (uint32_t)__builtin_amdgcn_readlane((int)incl[j], 63);
+        if ((implslots >> j) & 1u) U |= m8[j];
+      }
+    }
     const uint32_t qa = 8u * d0, qb = min(qa + 512u, L);
-    uint32_t cur_before[MKP_MAX_TAGS];
+    uint32_t cur_before[NT];
 #pragma unroll
-    for (int t = 0; t < MKP_MAX_TAGS; t++) { cur_before[t] = t_cur[t]; if (t < n_tags) marks[t][lane] = 0; }
+    for (int t = 0; t < NT; t++) { cur_before[t] = t_cur[t]; if (t < n_tags) marks[t][lane] = 0; }
     // ---- 2. mark the calls of every tag that fall into this chunk
 #pragma unroll
-    for (int t = 0; t < MKP_MAX_TAGS; t++) {
+    for (int t = 0; t < NT; t++) {
       if (t >= n_tags || (prm.debug_skip & 32u)) break;
       const MkpTagDesc dsc = t_desc[t];
-      const int xb = dsc.fb == 4 ? 0 : (rev ? 3 - dsc.fb : dsc.fb);
+      const uint32_t sj = tslot[t];
       uint32_t wlo, whi;   // window of keys this chunk can ask for (windows of successive chunks tile the key space)
       if (dsc.fb == 4) { wlo = rev ? (L - qb) : qa; whi = rev ? (L - qa) : qb; }
-      else { const uint32_t c = sel4(cum, xb), n = sel4(cnt, xb); wlo = rev ? (sel4(tot, xb) - c - n) : c; whi = wlo + n; }
-      const uint32_t my_incl = sel4(incl, xb);
-      const uint32_t pk = my_incl | (sel4(m8, xb) << 16);
+      else { const uint32_t c = selN<NB>(cum, sj), n = selN<NB>(cnt, sj); wlo = rev ? (selN<NB>(tot, sj) - c - n) : c; whi = wlo + n; }
+      const uint32_t my_incl = selN<NB>(incl, sj);
+      const uint32_t pk = my_incl | (selN<NB>(m8, sj) << 16);
       for (;;) {
         uint32_t e; bool hit; uint32_t nh;
         if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
@@ -311,7 +361,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
         uint32_t owner, bit;
         if (dsc.fb == 4) { const uint32_t q = (rev ? (L - 1u - e) : e) - qa; owner = q >> 3; bit = q & 7u; }
         else {
-          const uint32_t s = hit ? ((rev ? (sel4(tot, xb) - 1u - e) : e) - sel4(cum, xb)) : 0u;  // chunk-relative stored ordinal
+          const uint32_t s = hit ? ((rev ? (selN<NB>(tot, sj) - 1u - e) : e) - selN<NB>(cum, sj)) : 0u;  // chunk-relative stored ordinal
           owner = (uint32_t)find_op(my_incl, s);
           const uint32_t po = __shfl(pk, (int)(owner & 63u), 64);
           const uint32_t mo = po >> 16;
@@ -324,15 +374,15 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t pack_t[MKP_MAX_TAGS];
+    uint32_t pack_t[NT];
 #pragma unroll
-    for (int t = 0; t < MKP_MAX_TAGS; t++) {
+    for (int t = 0; t < NT; t++) {
       pack_t[t] = 0;
       if (t < n_tags) { const uint32_t bm = marks[t][lane]; U |= bm; const uint32_t c = (uint32_t)__popc(bm); pack_t[t] = bm | ((wave_incl_scan(c) - c) << 8); }
     }
     const uint32_t ucnt = (uint32_t)__popc(U);
     const uint32_t uincl = wave_incl_scan(ucnt);
-    const uint32_t H = __shfl(uincl, 63, 64);
+    const uint32_t H = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 63);
     const uint32_t packU = U | ((uincl - ucnt) << 8);
     // ---- 3. the called positions, 64 per batch, in read order
     for (uint32_t g0 = 0; g0 < H && !err && !(prm.debug_skip & 16u); g0 += 64) {
@@ -349,8 +399,34 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
 #pragma unroll
       for (int k = 0; k < MKP_KMAX; k++) { S0.pk[k] = 0.f; S1.pk[k] = 0.f; }
       S0.H = S0.setmask = S1.H = S1.setmask = 0;
+      if constexpr (FAST) {
+        // one group, distinct codes: every local code is written at most once, straight from ML (quals_to_probs 808-816)
 #pragma unroll
-      for (int t = 0; t < MKP_MAX_TAGS; t++) {
+        for (int t = 0; t < NT; t++) {
+          if (t >= n_tags) break;
+          const uint32_t pt = __shfl(pack_t[t], owner, 64);
+          const bool found = active && ((pt >> bit) & 1u);
+          const uint32_t idx = (pt >> 8) + (uint32_t)__popc(pt & ((1u << bit) - 1u));
+          const uint32_t jx = rev ? (cur_before[t] - 1u - idx) : (cur_before[t] + idx);
+          const uint32_t nc = t_desc[t].n_codes;
+          for (uint32_t i = 0; i < nc; i++) {
+            const float p = ((float)ml[found ? (t_ml[t] + jx * nc + i) : 0u] + 0.5f) / 256.0f;
+            const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform
+#pragma unroll
+            for (int k2 = 0; k2 < MKP_KMAX; k2++) if (kk == (uint32_t)k2) S0.pk[k2] = found ? p : S0.pk[k2];
+          }
+          S0.H |= found ? (1u << (tmu[t] & 15u)) : 0u;
+          S0.setmask |= found ? codes_t[t] : 0u;
+        }
+        if (__popc(S0.H) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
+          float s = 0.f;
+#pragma unroll
+          for (int k2 = 0; k2 < MKP_KMAX; k2++) if (S0.setmask & (1u << k2)) s = s + S0.pk[k2];
+          if (s > 1.01f) err = true;
+        }
+      } else {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
         if (t >= n_tags) break;
         const MkpTagDesc dsc = t_desc[t];
         const uint32_t pt = __shfl(pack_t[t], owner, 64);
@@ -374,6 +450,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
         }
         if (dsc.neg) { if (merge_tag(S1, ts, seen, mi)) err = true; } else { if (merge_tag(S0, ts, seen, mi)) err = true; }
       }
+      }
       // reference position through the CIGAR window (aligned pairs: M/=/X only, util.rs:122-145)
       bool mapped = false; int32_t rpos = 0;
       {
@@ -388,7 +465,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
             const uint32_t qlen = op_consumes_query(w_op) ? len : 0u, rlen = op_consumes_ref(w_op) ? len : 0u;
             w_qe = wave_incl_scan(qlen); const uint32_t re = wave_incl_scan(rlen);
             w_qs = wq0 + w_qe - qlen; w_rs = wr0 + (int32_t)(re - rlen);
-            wq1 = wq0 + __shfl(w_qe, 63, 64); w_rtot = __shfl(re, 63, 64);
+            wq1 = wq0 + (uint32_t)__builtin_amdgcn_readlane((int)w_qe, 63); w_rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
             win_loaded = true;
             continue;
           }
@@ -401,6 +478,36 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
         }
       }
       uint32_t ev_info[2]; float sv[2] = {0.f, 0.f}; uint32_t ev_cnt = 0; int32_t ev_pos = 0;
+      if constexpr (FAST) {
+        if (active && (S0.H | MKP_G_IMPL(grp0.misc))) {
+          const bool edge_keep = !prm.edge_filter ||
+              (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
+          const uint32_t impl = MKP_G_IMPL(grp0.misc);
+          int pat; uint32_t member_contrib;
+          if (S0.H) { if (impl & ~S0.H) err = true; pat = (int)S0.H; member_contrib = S0.H; }   // ExplicitConflictInferred
+          else { pat = MKP_PAT_INFERRED; member_contrib = impl; }                                // implicit fill (mod_bam.rs:1265-1292)
+          const uint32_t pv = gp0[12 + pat];
+          contribH |= member_contrib;
+          if (trimmable && edge_keep) {
+            if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
+              bool keep = !prm.only_mapped || mapped;
+              if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
+              if (keep) { any_surviving = true; sv[ev_cnt] = argmax_group(grp0, pv, S0.pk, collapse); ev_info[ev_cnt++] = MKP_G_TB(grp0.misc); }
+            } else {
+              any_surviving = true;
+              uint32_t ob = 0;
+              const int cls = call_group(grp0, pv, S0.pk, collapse, &ob);
+              const uint32_t tally = aln ^ (uint32_t)sg0;  // read_cache.rs:181-188 / FeatureVector::add_feature
+              if (tally) obs1 |= ob; else obs0 |= ob;
+              if (mapped) {
+                const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
+                ev_info[ev_cnt++] = cid | (tally << 8) | ((uint32_t)b0 << 9) | (aln << 11) | (1u << 12);
+                ev_pos = rpos;
+              }
+            }
+          }
+        }
+      } else
       if (active && x >= 0) {
         const bool edge_keep = !prm.edge_filter ||
             (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
@@ -468,15 +575,22 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
       err = __any(err);
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) cum[k] += cnt[k];
+    for (int j = 0; j < NB; j++) cum[j] += cnt[j];
     err = __any(err);
   }
   // a delta list must not run past the last occurrence of its base / the end of the read: every entry must have
   // been consumed by the join (mod_bam.rs:705-727, 750-756)
 #pragma unroll
-  for (int t = 0; t < MKP_MAX_TAGS; t++) if (t < n_tags) { if (rev ? (t_cur[t] != 0u) : (t_cur[t] != t_n[t])) err = true; }
+  for (int t = 0; t < NT; t++) if (t < n_tags) { if (rev ? (t_cur[t] != 0u) : (t_cur[t] != t_n[t])) err = true; }
   err = __any(err);
   obs0 = wave_or(obs0); obs1 = wave_or(obs1);
+  if (FAST) {
+    const uint32_t mc = wave_or(contribH); uint32_t tagbits = 0;
+#pragma unroll
+    for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (mc & (1u << mi)) tagbits |= 1u << ((grp0.member_tags >> (4 * mi)) & 15u);
+    const int gi = sg0 * 4 + b0;
+    if (gi < 4) contrib_lo |= tagbits << (8 * gi); else contrib_hi |= tagbits << (8 * (gi - 4));
+  }
   contrib_lo = wave_or(contrib_lo); contrib_hi = wave_or(contrib_hi);
   any_surviving = __any(any_surviving);
   // InvalidImplicitMode: a group all of whose contributing tags have no mode character (read_cache.rs:122-137)
@@ -492,16 +606,31 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   }
 }
 
+#define DECODE_ARGS_REF const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
+                    const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
+                    const MkpLayout* __restrict__ layouts, const MkpRunParams& prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
+                    uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
 #define DECODE_ARGS const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
                     const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
                     const MkpLayout* __restrict__ layouts, MkpRunParams prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
                     uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
+#define DECODE_CALL(S, N, F) decode_read_body<S, N, F>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks)
+template <bool SAMPLE> __device__ __forceinline__ void decode_dispatch(DECODE_ARGS_REF) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
+  __shared__ uint32_t lds_marks[4 * MKP_MAX_TAGS][64];
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (rid >= n_reads) return;
+  const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[rid].n_tags);
+  const bool fast = nt && __builtin_amdgcn_readfirstlane((int)layouts[hdrs[rid].layout].fast) != 0;
+  if (fast && nt == 1) DECODE_CALL(SAMPLE, 1, true); else if (fast && nt == 2) DECODE_CALL(SAMPLE, 2, true);
+  else if (nt <= 2) DECODE_CALL(SAMPLE, 2, false); else if (nt <= 4) DECODE_CALL(SAMPLE, 4, false); else DECODE_CALL(SAMPLE, MKP_MAX_TAGS, false);
+}
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_ARGS) {
-  decode_read_body<false>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
+  decode_dispatch<false>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
 }
 // the same walk in threshold-sampling mode (reads_sampler / thresholds.rs:121-159): a separate kernel so profiles keep the two apart
 extern "C" __global__ void __launch_bounds__(256) mkp_sample_reads(DECODE_ARGS) {
-  decode_read_body<true>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
+  decode_dispatch<true>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
 }
 
 // ----------------------------------------------------------------------------------------------

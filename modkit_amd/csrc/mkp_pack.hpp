@@ -95,6 +95,10 @@ struct LayoutTables {
     for (const LayoutHost& L : layouts) {
       MkpLayout D; memset(&D, 0, sizeof(D));
       D.n_tags = (uint8_t)L.tags.size();
+      { bool fast = !L.tags.empty(); std::vector<uint32_t> seen_codes;
+        for (auto& th : L.tags) { if (th.fb == 4 || th.fb != L.tags[0].fb || th.neg != L.tags[0].neg || th.codes.empty()) fast = false;
+          for (uint32_t c : th.codes) { if (std::find(seen_codes.begin(), seen_codes.end(), c) != seen_codes.end()) fast = false; seen_codes.push_back(c); } }
+        D.fast = fast ? 1 : 0; }
       for (size_t t = 0; t < L.tags.size(); t++) {
         D.tags[t].fb = L.tags[t].fb; D.tags[t].neg = L.tags[t].neg; D.tags[t].mode = L.tags[t].mode; D.tags[t].n_codes = (uint8_t)L.tags[t].codes.size();
         if (L.tags[t].mode == 2) D.default_mask |= (uint8_t)(1u << t);
