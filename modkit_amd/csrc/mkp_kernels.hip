@@ -788,6 +788,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
   __shared__ uint32_t tile_base;
+  __shared__ uint32_t next_read;
   const MkpRunParams& prm = *prmp;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
@@ -812,9 +813,16 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   uint32_t* __restrict__ bm = lds + lds_words + wave * (bm_words + PILEUP_WAVE_SCRATCH);
   uint2* __restrict__ comp = reinterpret_cast<uint2*>(bm + bm_words);
   for (uint32_t k = threadIdx.x; k < lds_words + PILEUP_WAVES * (bm_words + PILEUP_WAVE_SCRATCH); k += PILEUP_THREADS) lds[k] = 0;
+  if (threadIdx.x == 0) next_read = tile_first[tix];
   __syncthreads();
 
-  for (uint32_t rid = tile_first[tix] + wave; rid < tile_last[tix]; rid += PILEUP_WAVES) {
+  // reads are handed out one at a time (LDS ticket) so waves finish the tile together whatever the reads' spans
+  const uint32_t rid_end = tile_last[tix];
+  for (;;) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&next_read, 1u);
+    const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (rid >= rid_end) break;
     const MkpReadHdr h = hdrs[rid];
     if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
     const MkpReadOut ro = readout[rid];
@@ -850,6 +858,10 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
     // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
     uint32_t q_run = 0; int32_t r_run = h.ref_start;
+    uint32_t* __restrict__ strand_base = tv.cnt + aln * n_counters * TH;   // rows NC[0..3], DEL of this alignment strand
+    const unsigned long long LUT = aln ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;  // BAM nibble -> NoCall row (complemented on '-'), f = not ACGT
+    const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 28) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
+    const uint32_t last_byte = (h.l_seq - 1u) >> 1;
     for (uint32_t c0 = 0; c0 < h.n_cigar; c0 += 64) {
       if (r_run >= T1h || (prm.debug_skip & 1u)) break;
       const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
@@ -894,32 +906,34 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // 64 positions per step, aligned to the tile so a step reads one aligned 64-bit window of the bitmap;
-        // PILEUP_UNROLL steps are issued together (bitmap read -> bpermute -> SEQ byte load) before any tally update
-        uint32_t R = cb;
-        uint32_t* __restrict__ strand_base = tv.cnt + aln * n_counters * TH;   // rows NC[0..3], DEL of this alignment strand
-        const unsigned long long LUT = aln ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;  // BAM nibble -> NoCall row (complemented on '-'), f = not ACGT
+        // PILEUP_UNROLL steps are issued together (bitmap read -> bpermute -> SEQ byte load) before any tally update.
+        // ops started at or before the first position of window kk: a ballot over the compacted starts (no LDS dependency)
         const uint32_t k0 = (uint32_t)(c_lo - T0h) >> 6, k1 = (uint32_t)(c_hi - 1 - T0h) >> 6;
         for (uint32_t kb = k0; kb <= k1; kb += PILEUP_UNROLL) {
-          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL], rl[PILEUP_UNROLL]; bool inb[PILEUP_UNROLL];
+          const bool edge = kb == k0 || kb + PILEUP_UNROLL > k1;   // only the first and last groups hold out-of-range lanes
+          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL];
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
             const uint32_t kk = min(kb + (uint32_t)j, k1);
             const uint2 W = *reinterpret_cast<const uint2*>(bm + 2u * kk);
+            const int32_t wfirst = max(c_lo, T0h + (int32_t)(64u * kk));
+            const uint32_t R = (uint32_t)__popcll(__ballot(cvalid && c_rs <= wfirst)) - 1u;
             const uint32_t idx = R + __builtin_amdgcn_mbcnt_hi(W.y, __builtin_amdgcn_mbcnt_lo(W.x, 0u));
-            pkv[j] = __shfl(c_pk, (int)(idx & 63u), 64);
-            R += (uint32_t)__popc((uint32_t)__builtin_amdgcn_readfirstlane((int)W.x)) + (uint32_t)__popc((uint32_t)__builtin_amdgcn_readfirstlane((int)W.y));
-            rl[j] = 64u * kk + (uint32_t)lane;
-            const int32_t pos = T0h + (int32_t)rl[j];
-            inb[j] = pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1;
-            qq[j] = (uint32_t)(pos - h.ref_start) + (pkv[j] >> 2) - (1u << 28);
-            byte[j] = seq[(inb[j] && (pkv[j] & 3u) == 0) ? (qq[j] >> 1) : 0u];
+            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)c_pk);
+            qq[j] = qlane + 64u * kk + (pkv[j] >> 2);
+            byte[j] = seq[min(qq[j] >> 1, last_byte)];   // lanes on D/N ops or outside the span read a clamped (ignored) byte
           }
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
+            const uint32_t kk = min(kb + (uint32_t)j, k1);
             const uint32_t kd = pkv[j] & 3u;
-            const uint32_t nb = (byte[j] >> ((qq[j] & 1u) ? 0u : 4u)) & 15u;
-            const uint32_t row = kd ? (uint32_t)MKP_C_DEL : (uint32_t)(LUT >> (4u * nb)) & 15u;
-            if (inb[j] && kd < 2u && row < 8u) atomicAdd(&strand_base[__umul24(row, TH) + rl[j]], 1u);
+            const uint32_t x60 = ((byte[j] << ((qq[j] & 1u) << 2)) >> 2) & 60u;          // 4 * BAM nibble of base qq
+            const uint32_t rown = (uint32_t)(LUT >> x60) & 15u;
+            const uint32_t row = kd ? kd * 11u - 7u : rown;                                 // D -> row 4 (MKP_C_DEL), N/other -> 15
+            const uint32_t rl = 64u * kk + (uint32_t)lane;
+            bool ok = row < 8u;
+            if (edge) { const int32_t pos = T0h + (int32_t)rl; ok = ok && pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1; }
+            if (ok) atomicAdd(&strand_base[__umul24(row, TH) + rl], 1u);
           }
         }
         if (mark) bm[mrel >> 5] = 0;
