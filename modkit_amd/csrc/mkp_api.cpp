@@ -55,6 +55,7 @@ void make_resident(mkp_ctx* c) {
   // tile geometry from the LDS budget (160 KiB per CU on gfx950)
   const uint32_t words_per_pos = 2u * (P.n_counters + P.n_slots);
   uint32_t T = c->cfg.tile_positions;
+  if (const char* te = getenv("MKP_TILE")) T = (uint32_t)strtoul(te, nullptr, 0);   // experiments only
   const uint32_t budget = 160u * 1024u - 512u;
   uint32_t maxT = 0;
   for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;

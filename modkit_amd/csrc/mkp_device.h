@@ -129,7 +129,9 @@ struct MkpRunParams {
 
 // mkp_pileup_tiles geometry: 16 waves per tile; behind the tallies every wave owns an op-start bitmap over the
 // tile's positions (even number of dwords, 2 spare for the 96-bit window read) and a 64 x 8-byte compaction buffer
+#ifndef MKP_PILEUP_THREADS
 #define MKP_PILEUP_THREADS 1024
+#endif
 #define MKP_PILEUP_WAVE_SCRATCH 128
 #define MKP_PILEUP_BM_WORDS(TH) (((((TH) + 31u) >> 5) + 3u) & ~1u)
 #define MKP_PILEUP_LDS_WORDS(words_per_pos, TH) ((words_per_pos) * (TH) + (MKP_PILEUP_THREADS / 64) * (MKP_PILEUP_BM_WORDS(TH) + MKP_PILEUP_WAVE_SCRATCH))

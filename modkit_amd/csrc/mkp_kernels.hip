@@ -884,6 +884,13 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
             }
           }
         }
+        if (op == 2) {  // deletion columns (alignment.is_del()): +1/-1 on the strand's DEL row, summed after the barrier
+          const int32_t a = min(max(rs, T0h), T1h), b = min(max(rs + (int32_t)rlen, T0h), T1h);
+          if (a < b) {
+            atomicAdd(&strand_base[MKP_C_DEL * TH + (uint32_t)(a - T0h)], 1u);
+            if (b < T1h) atomicAdd(&strand_base[MKP_C_DEL * TH + (uint32_t)(b - T0h)], 0xffffffffu);
+          }
+        }
         // compact the window's reference-consuming ops to the low lanes: {start, packed(query offset, kind)}
         const bool isref = rlen > 0;
         const unsigned long long refbal = __ballot(isref);
@@ -911,29 +918,32 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         const uint32_t k0 = (uint32_t)(c_lo - T0h) >> 6, k1 = (uint32_t)(c_hi - 1 - T0h) >> 6;
         for (uint32_t kb = k0; kb <= k1; kb += PILEUP_UNROLL) {
           const bool edge = kb == k0 || kb + PILEUP_UNROLL > k1;   // only the first and last groups hold out-of-range lanes
-          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL];
+          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL], idx[PILEUP_UNROLL]; uint2 W[PILEUP_UNROLL];
+          // stage by stage across the PILEUP_UNROLL windows, so the LDS reads, the bpermutes and the global loads of the group overlap
+#pragma unroll
+          for (int j = 0; j < PILEUP_UNROLL; j++) W[j] = *reinterpret_cast<const uint2*>(bm + 2u * min(kb + (uint32_t)j, k1));
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
-            const uint32_t kk = min(kb + (uint32_t)j, k1);
-            const uint2 W = *reinterpret_cast<const uint2*>(bm + 2u * kk);
-            const int32_t wfirst = max(c_lo, T0h + (int32_t)(64u * kk));
-            const uint32_t R = (uint32_t)__popcll(__ballot(cvalid && c_rs <= wfirst)) - 1u;
-            const uint32_t idx = R + __builtin_amdgcn_mbcnt_hi(W.y, __builtin_amdgcn_mbcnt_lo(W.x, 0u));
-            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)c_pk);
-            qq[j] = qlane + 64u * kk + (pkv[j] >> 2);
+            const int32_t wfirst = max(c_lo, T0h + (int32_t)(64u * min(kb + (uint32_t)j, k1)));
+            idx[j] = (uint32_t)__popcll(__ballot(cvalid && c_rs <= wfirst)) - 1u;
+          }
+#pragma unroll
+          for (int j = 0; j < PILEUP_UNROLL; j++)
+            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(W[j].y, __builtin_amdgcn_mbcnt_lo(W[j].x, 0u))) << 2), (int)c_pk);
+#pragma unroll
+          for (int j = 0; j < PILEUP_UNROLL; j++) {
+            qq[j] = qlane + 64u * min(kb + (uint32_t)j, k1) + (pkv[j] >> 2);
             byte[j] = seq[min(qq[j] >> 1, last_byte)];   // lanes on D/N ops or outside the span read a clamped (ignored) byte
           }
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
             const uint32_t kk = min(kb + (uint32_t)j, k1);
-            const uint32_t kd = pkv[j] & 3u;
             const uint32_t x60 = ((byte[j] << ((qq[j] & 1u) << 2)) >> 2) & 60u;          // 4 * BAM nibble of base qq
-            const uint32_t rown = (uint32_t)(LUT >> x60) & 15u;
-            const uint32_t row = kd ? kd * 11u - 7u : rown;                                 // D -> row 4 (MKP_C_DEL), N/other -> 15
+            const uint32_t rowt = ((uint32_t)(LUT >> x60) & 15u) | ((pkv[j] & 3u) << 3);   // >= 8: not ACGT, or the lane sits on a D/N op
             const uint32_t rl = 64u * kk + (uint32_t)lane;
-            bool ok = row < 8u;
+            bool ok = rowt < 8u;
             if (edge) { const int32_t pos = T0h + (int32_t)rl; ok = ok && pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1; }
-            if (ok) atomicAdd(&strand_base[__umul24(row, TH) + rl], 1u);
+            if (ok) atomicAdd(&strand_base[__umul24(rowt, TH) + rl], 1u);
           }
         }
         if (mark) bm[mrel >> 5] = 0;
@@ -942,11 +952,11 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     }
   }
   __syncthreads();
-  // observed-code difference arrays -> coverage counts (one wave per array)
+  // difference arrays -> counts (one wave per array): observed codes per (strand, slot), deletions per strand
   {
-    const uint32_t n_arr = 2u * n_slots;
+    const uint32_t n_arr = 2u * n_slots + 2u;
     for (uint32_t a = wave; a < n_arr; a += PILEUP_WAVES) {
-      int32_t* arr = tv.obs + a * TH;
+      int32_t* arr = a < 2u * n_slots ? tv.obs + a * TH : (int32_t*)tv.cnt + ((a - 2u * n_slots) * n_counters + MKP_C_DEL) * TH;
       uint32_t carry = 0;
       for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
         uint32_t v = (b0 + lane < TH) ? (uint32_t)arr[b0 + lane] : 0u;
