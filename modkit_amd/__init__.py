@@ -181,3 +181,17 @@ class Context:
         s = Stats()
         self._check(self.L.mkp_get_stats(self.h, ctypes.byref(s)))
         return s
+
+
+ROW_FIELDS = ("pos", "strand", "code_repr", "motif_idx", "n_valid", "n_mod", "n_canonical", "n_other", "n_delete", "n_fail", "n_diff", "n_nocall")
+
+
+def rows_to_numpy(rows):
+    """Copy an mkp_rows view (owned by the ctx until its next run) into a dict of numpy arrays."""
+    import numpy as np
+    n = int(rows.n_rows)
+    out = {}
+    for f in ROW_FIELDS:
+        p = getattr(rows, f)
+        out[f] = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)
+    return out

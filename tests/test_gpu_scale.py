@@ -1,0 +1,121 @@
+"""GPU parity, part 3: the BASELINE.json configs.  Scaled-down C2..C5 against the oracle (whole bedMethyl text,
+bit-exact), and the full-size C2 workload through size-independent properties: row invariants, idempotence of a
+re-run on the resident shard, and shard-split invariance (two half-contig shards == one whole-contig shard)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import modkit_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gen(tmp, name, contigs, reads, style, seed, extra=()):
+    tool = os.path.join(ROOT, "tools", "gen_modbam")
+    if not os.path.exists(tool):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+    prefix = os.path.join(str(tmp), name)
+    args = [tool, "--out", prefix, "--reads", str(reads), "--seed", str(seed), "--style", style] + list(extra)
+    for c in contigs:
+        args += ["--contig", "%s:%d" % c]
+    meta = json.loads(subprocess.check_output(args).decode())
+    return prefix + ".bam", prefix + ".fa", meta
+
+
+def both(oracle_bin, tmp, bam, flags):
+    dev, ora = os.path.join(str(tmp), "dev.bed"), os.path.join(str(tmp), "ora.bed")
+    modkit_amd.pileup([bam, dev] + flags)
+    p = subprocess.run([oracle_bin, "pileup", bam, ora, "--oracle-workers", "8"] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-400:]
+    a, b = open(dev).read(), open(ora).read()
+    if a != b:
+        al, bl = a.splitlines(), b.splitlines()
+        for i in range(max(len(al), len(bl))):
+            x, y = (al[i] if i < len(al) else "<none>"), (bl[i] if i < len(bl) else "<none>")
+            assert x == y, "row %d differs\n device: %s\n oracle: %s (%d vs %d rows)" % (i, x, y, len(al), len(bl))
+    return a
+
+
+def test_c2_scaled_defaults(oracle_bin, tmp_path):
+    # C2 at 1/10: one contig, `C+m?` on every read CpG, default sampled 10th-percentile threshold
+    bam, fa, meta = gen(tmp_path, "c2", [("synth5m", 500_000)], 10_000, "m", 11)
+    out = both(oracle_bin, tmp_path, bam, [])
+    assert len(out.splitlines()) > 100_000
+
+
+def test_c3_scaled_cpg_hm_ties(oracle_bin, tmp_path):
+    # C3 scaled: CpG-depleted contig, mean-10 kb reads, `C+hm?` / `C+h?;C+m?` alternating with forced h==m ties, --cpg --ref,
+    # default -i 100000 (boundary CpGs are lost exactly as the reference loses them)
+    bam, fa, meta = gen(tmp_path, "c3", [("chr20", 1_000_000)], 3_000, "hm", 20, ["--cpg-depleted", "--mean-len", "10000"])
+    out = both(oracle_bin, tmp_path, bam, ["--cpg", "--ref", fa])
+    assert len(out.splitlines()) > 10_000
+
+
+def test_c4_scaled_traditional_two_ranks(oracle_bin, tmp_path):
+    # C4 scaled: several contigs, --preset traditional; interval-sharded over 2 ranks (run back to back on this GPU):
+    # concatenating the rank outputs in rank order reproduces the single-GPU bedMethyl and the oracle's
+    bam, fa, meta = gen(tmp_path, "c4", [("chr1", 400_000), ("chr2", 300_000), ("chrX", 150_000)], 4_000, "hm", 4, ["--cpg-depleted", "--mean-len", "8000"])
+    flags = ["--preset", "traditional", "--ref", fa, "-f", "1.0", "-p", "0.1"]
+    whole = both(oracle_bin, tmp_path, bam, flags)
+    parts = []
+    for r in range(2):
+        o = os.path.join(str(tmp_path), "rank%d.bed" % r)
+        modkit_amd.pileup([bam, o] + flags + ["--gpus-rank", str(r), "--gpus-world", "2"])
+        parts.append(open(o).read())
+    assert all(parts) and "".join(parts) == whole
+
+
+def test_c5_scaled_multimod_bed(oracle_bin, tmp_path):
+    # C5 scaled: `C+h?;C+m?;A+a?` (6mA on every A), per-mod thresholds on top of estimated per-base ones, --include-bed
+    bam, fa, meta = gen(tmp_path, "c5", [("chr1", 200_000), ("chr2", 100_000)], 1_500, "hma", 5, ["--mean-len", "6000"])
+    rng = np.random.default_rng(5)
+    bed = os.path.join(str(tmp_path), "inc.bed")
+    with open(bed, "w") as f:
+        for i in range(60):
+            c, ln = ("chr1", 200_000) if i % 3 else ("chr2", 100_000)
+            s = int(rng.integers(0, ln - 2000))
+            kind = i % 4
+            f.write("%s\t%d\t%d\n" % (c, s, s + 2000) if kind == 0 else "%s\t%d\t%d\tx\t0\t%s\n" % (c, s, s + 2000, "+-."[kind - 1]))
+    out = both(oracle_bin, tmp_path, bam, ["--mod-thresholds", "m:0.8", "--mod-thresholds", "h:0.9", "--mod-thresholds", "a:0.7", "--include-bed", bed])
+    assert len(out.splitlines()) > 10_000
+
+
+def _digest(r):
+    h = hashlib.sha256()
+    for f in modkit_amd.ROW_FIELDS:
+        h.update(np.ascontiguousarray(r[f]).tobytes())
+    return h.hexdigest()
+
+
+def test_c2_full_size_properties(tmp_path):
+    # the bench workload itself: 5 Mb contig, 100 000 reads (~96x)
+    bam, fa, meta = gen(tmp_path, "c2full", [("synth5m", 5_000_000)], 100_000, "m", 1)
+    ctx = modkit_amd.Context(device=0)
+    try:
+        ctx.set_caller(per_base={"C": 0.802734375})
+        whole = modkit_amd.rows_to_numpy(ctx.process_region(bam, 0, 0, 5_000_000))
+        n = len(whole["pos"])
+        assert n > 1_500_000
+        # rows ordered by (position, strand '+' < '-'); one mod code here
+        key = whole["pos"].astype(np.int64) * 2 + (whole["strand"] == ord("-"))
+        assert np.all(np.diff(key) > 0)
+        # PileupFeatureCounts invariants (pileup/mod.rs:283-410)
+        assert np.array_equal(whole["n_valid"], whole["n_mod"] + whole["n_canonical"] + whole["n_other"])
+        assert np.all(whole["n_valid"] > 0) and np.all(whole["n_other"] == 0) and np.all(whole["code_repr"] == ord("m"))
+        depth = whole["n_valid"].astype(np.int64) + whole["n_fail"] + whole["n_diff"] + whole["n_nocall"] + whole["n_delete"]
+        assert depth.max() <= 8000 and 20 < depth.mean() < 80  # per-strand column depth of a ~96x pileup
+        # idempotence: re-running the resident shard reproduces the rows bit for bit
+        again = modkit_amd.rows_to_numpy(ctx.rerun(2, fetch=True))
+        assert _digest(again) == _digest(whole)
+        # shard-split invariance: rows are independent of where the shard boundary falls
+        left = modkit_amd.rows_to_numpy(ctx.process_region(bam, 0, 0, 2_345_678))
+        right = modkit_amd.rows_to_numpy(ctx.process_region(bam, 0, 2_345_678, 5_000_000))
+        joined = {f: np.concatenate([left[f], right[f]]) for f in modkit_amd.ROW_FIELDS}
+        assert _digest(joined) == _digest(whole)
+    finally:
+        ctx.close()
