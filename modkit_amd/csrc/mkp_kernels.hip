@@ -208,7 +208,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
-                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64]) {
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4) {
   const int lane = lane_id();
   // wave-uniform values are made provably uniform (readfirstlane) so they live in SGPRs and load through the scalar cache
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -220,7 +220,8 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   // the read's layout (1216 B) goes to LDS once; every table lookup below is an LDS read
   constexpr int NB = NT < 4 ? NT : 4;   // distinct stored bases the tags can count
   uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
-  uint32_t (*__restrict__ marks)[64] = lds_marks + wib * MKP_MAX_TAGS;
+  uint32_t* __restrict__ ordb = &lds_marks[wib * MKP_MAX_TAGS][0];                        // [NT][18] ordinal / position bitmaps of the chunk
+  uint16_t* __restrict__ slots = reinterpret_cast<uint16_t*>(ordb + 192);                 // 512 compacted {lane, bit} entries
   { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
     for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
   __builtin_amdgcn_wave_barrier();
@@ -341,7 +342,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     const uint32_t qa = 8u * d0, qb = min(qa + 512u, L);
     uint32_t cur_before[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) { cur_before[t] = t_cur[t]; if (t < n_tags) marks[t][lane] = 0; }
+    for (int t = 0; t < NT; t++) { cur_before[t] = t_cur[t]; if (t < n_tags && lane < 18) ordb[t * 18 + lane] = 0; }
     // ---- 2. mark the calls of every tag that fall into this chunk
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -351,23 +352,15 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
       uint32_t wlo, whi;   // window of keys this chunk can ask for (windows of successive chunks tile the key space)
       if (dsc.fb == 4) { wlo = rev ? (L - qb) : qa; whi = rev ? (L - qa) : qb; }
       else { const uint32_t c = selN<NB>(cum, sj), n = selN<NB>(cnt, sj); wlo = rev ? (selN<NB>(tot, sj) - c - n) : c; whi = wlo + n; }
-      const uint32_t my_incl = selN<NB>(incl, sj);
-      const uint32_t pk = my_incl | (selN<NB>(m8, sj) << 16);
+      const uint32_t kbase = dsc.fb == 4 ? qa : selN<NB>(cum, sj), ktot = dsc.fb == 4 ? L : selN<NB>(tot, sj);
       for (;;) {
         uint32_t e; bool hit; uint32_t nh;
         if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
         else { const uint32_t i = t_cur[t] - 64u + lane; const bool valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }  // an entry >= whi is past the last occurrence: never consumed -> error at the end
         if (nh == 0) break;
-        uint32_t owner, bit;
-        if (dsc.fb == 4) { const uint32_t q = (rev ? (L - 1u - e) : e) - qa; owner = q >> 3; bit = q & 7u; }
-        else {
-          const uint32_t s = hit ? ((rev ? (selN<NB>(tot, sj) - 1u - e) : e) - selN<NB>(cum, sj)) : 0u;  // chunk-relative stored ordinal
-          owner = (uint32_t)find_op(my_incl, s);
-          const uint32_t po = __shfl(pk, (int)(owner & 63u), 64);
-          const uint32_t mo = po >> 16;
-          bit = hit ? select8(mo, s - ((po & 0xffffu) - (uint32_t)__popc(mo))) : 0u;
-        }
-        if (hit) atomicOr(&marks[t][owner & 63u], 1u << bit);
+        // chunk-relative stored ordinal of the call's base (specific-base tags) or stored position (`N` tags): one bit in LDS
+        const uint32_t ib = (rev ? (ktot - 1u - e) : e) - kbase;
+        if (hit) atomicOr(&ordb[t * 18 + (ib >> 5)], 1u << (ib & 31u));
         if (nh < 64) break;
       }
     }
@@ -378,19 +371,36 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       pack_t[t] = 0;
-      if (t < n_tags) { const uint32_t bm = marks[t][lane]; U |= bm; const uint32_t c = (uint32_t)__popc(bm); pack_t[t] = bm | ((wave_incl_scan(c) - c) << 8); }
+      if (t < n_tags) {
+        uint32_t bm;
+        if (t_desc[t].fb == 4) bm = (ordb[t * 18 + (lane >> 2)] >> ((lane & 3) * 8)) & 0xffu & vmask;
+        else {  // bits [excl, excl+cnt) of the ordinal bitmap deposited onto the set bits of the lane's match mask
+          const uint32_t m = selN<NB>(m8, tslot[t]), c = (uint32_t)__popc(m), ex = selN<NB>(incl, tslot[t]) - c;
+          const uint32_t w0 = ordb[t * 18 + (ex >> 5)], w1 = ordb[t * 18 + (ex >> 5) + 1];
+          const uint32_t f = __builtin_amdgcn_alignbit(w1, w0, ex & 31u) & ((1u << c) - 1u);
+          const uint32_t clo = (uint32_t)__popc(m & 15u);
+          bm = (uint32_t)pdep4[((m & 15u) << 4) | (f & 15u)] | ((uint32_t)pdep4[(m & 0xf0u) | ((f >> clo) & 15u)] << 4);
+        }
+        U |= bm; const uint32_t c2 = (uint32_t)__popc(bm); pack_t[t] = bm | ((wave_incl_scan(c2) - c2) << 8);
+      }
     }
     const uint32_t ucnt = (uint32_t)__popc(U);
     const uint32_t uincl = wave_incl_scan(ucnt);
     const uint32_t H = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 63);
-    const uint32_t packU = U | ((uincl - ucnt) << 8);
+    // compaction: every lane writes {lane, bit} of its called positions into the wave's slot list, in read order
+    { uint32_t ut = U, sidx = uincl - ucnt;
+      while (ut) { slots[sidx++] = (uint16_t)(((uint32_t)lane << 3) | ((uint32_t)__ffs((int)ut) - 1u)); ut &= ut - 1u; } }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- 3. the called positions, 64 per batch, in read order
     for (uint32_t g0 = 0; g0 < H && !err && !(prm.debug_skip & 16u); g0 += 64) {
       const uint32_t g = g0 + lane;
       const bool active = g < H;
-      const int owner = find_op(uincl, active ? g : 0u) & 63;
-      const uint32_t pu = __shfl(packU, owner, 64), xo = __shfl(xl, owner, 64);
-      const uint32_t bit = active ? select8(pu & 0xffu, g - (pu >> 8)) : 0u;
+      const uint32_t slot = active ? (uint32_t)slots[g] : 0u;
+      const int owner = (int)(slot >> 3);
+      const uint32_t bit = slot & 7u;
+      const uint32_t xo = __shfl(xl, owner, 64);
       const uint32_t q = 8u * (d0 + (uint32_t)owner) + bit;
       const int x = active ? nib2base((xo >> (4u * bit)) & 15u) : -1;
       const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
@@ -614,10 +624,15 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
                     const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
                     const MkpLayout* __restrict__ layouts, MkpRunParams prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
                     uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
-#define DECODE_CALL(S, N, F) decode_read_body<S, N, F>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks)
+#define DECODE_CALL(S, N, F) decode_read_body<S, N, F>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks, pdep4)
 template <bool SAMPLE> __device__ __forceinline__ void decode_dispatch(DECODE_ARGS_REF) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
   __shared__ uint32_t lds_marks[4 * MKP_MAX_TAGS][64];
+  __shared__ uint8_t pdep4[256];   // pdep4[(mask << 4) | bits]: the low bits of `bits` deposited onto the set bits of a 4-bit mask
+  { const uint32_t m = threadIdx.x >> 4; uint32_t f = threadIdx.x & 15u, o = 0;
+    for (uint32_t i = 0; i < 4; i++) if ((m >> i) & 1u) { o |= (f & 1u) << i; f >>= 1; }
+    pdep4[threadIdx.x & 255u] = (uint8_t)o; }
+  __syncthreads();
   const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (rid >= n_reads) return;
   const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[rid].n_tags);
