@@ -220,7 +220,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   // the read's layout (1216 B) goes to LDS once; every table lookup below is an LDS read
   constexpr int NB = NT < 4 ? NT : 4;   // distinct stored bases the tags can count
   uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
-  uint32_t* __restrict__ ordb = &lds_marks[wib * MKP_MAX_TAGS][0];                        // [NT][18] ordinal / position bitmaps of the chunk
+  uint32_t* __restrict__ ordb = &lds_marks[wib * 7][0];                        // [NT][18] ordinal / position bitmaps of the chunk
   uint16_t* __restrict__ slots = reinterpret_cast<uint16_t*>(ordb + 192);                 // 512 compacted {lane, bit} entries
   { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
     for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
@@ -616,6 +616,278 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Decode, FAST layouts (MkpLayout::fast: every tag on the same specific base and mod strand, no code listed twice —
+// `C+m?`, `C+hm?`, `C+h?;C+m?`, ...; NT <= 2 tags).  Same semantics as decode_read_body, restructured as a
+// producer/consumer inside the wave: the 512-base steps only *locate* calls and append {stored position, ML index per
+// tag} to a queue in LDS; whenever 64 calls are queued one full batch runs the per-call work (ML -> f32, collapse,
+// threshold caller, CIGAR mapping, event append).  With CpG data a step finds ~13 calls, so batches run at full
+// lane occupancy instead of ~20 %.  The group descriptor, thresholds and code maps are wave-uniform (SGPRs).
+#define MKP_QCAP 576   // 63 left over + up to 512 from one step
+template <bool SAMPLE, int NT>
+__device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
+                 const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
+                 const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
+                 MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts,
+                 uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4, uint32_t* __restrict__ lds_queue) {
+  static_assert(NT <= 2, "the call queue holds two ML indices per entry");
+  const int lane = lane_id();
+  const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
+  if (rid >= n_reads) return;
+  const MkpReadHdr h = hdrs[rid];
+  MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
+  if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
+  uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
+  uint32_t* __restrict__ ordb = &lds_marks[wib * 7][0];   // [NT][18] ordinal bitmaps of the step
+  uint32_t* __restrict__ q_pos = lds_queue + wib * (3 * MKP_QCAP);   // queue, SoA: stored position, ML call index of tag 0 / 1 (~0 = not listed)
+  uint32_t* __restrict__ q_j0 = q_pos + MKP_QCAP;
+  uint32_t* __restrict__ q_j1 = q_pos + 2 * MKP_QCAP;
+  { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
+    for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
+  __builtin_amdgcn_wave_barrier();
+  const MkpLayout* lay = reinterpret_cast<const MkpLayout*>(lds_lay);
+  const uint32_t* __restrict__ seqw = reinterpret_cast<const uint32_t*>(seqs + h.seq_off);
+  const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
+  const uint32_t L = h.l_seq, nd = (L + 7u) >> 3, aln = rev ? 1u : 0u;
+  const int n_tags = (int)h.n_tags;
+  const int b0 = (int)lay->tags[0].fb & 3, sg0 = (int)lay->tags[0].neg & 1;
+  const int xs = rev ? 3 - b0 : b0;                                   // the stored base the tags count
+  const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
+  GroupRegs grp0 = load_group(gp0);
+  grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
+  grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
+#pragma unroll
+  for (int kq = 0; kq < MKP_KMAX; kq++) grp0.thr[kq] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr[kq])));
+  grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
+  const uint32_t impl0 = MKP_G_IMPL(grp0.misc);
+  uint32_t t_off[NT], t_n[NT], t_ml[NT], t_cur[NT], t_nc[NT], tmu[NT], codes_t[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    t_off[t] = 0; t_n[t] = 0; t_ml[t] = 0; t_cur[t] = 0; t_nc[t] = 0; tmu[t] = 0; codes_t[t] = 0;
+    if (t < n_tags) {
+      const MkpTagRef tr = tagref[h.tag_off + t]; t_off[t] = tr.rank_off; t_n[t] = tr.n; t_ml[t] = tr.ml_off; t_cur[t] = rev ? tr.n : 0u;
+      t_nc[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tags[t].n_codes);
+      tmu[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tagmap[t][b0]);
+      for (uint32_t i = 0; i < t_nc[t]; i++) codes_t[t] |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
+    }
+  }
+  // reverse reads need the total up front (forward rank = total - inclusive count in stored order); 4 loads in flight
+  uint32_t tot = 0;
+  if (rev) {
+    uint32_t acc = 0;
+    for (uint32_t d0 = 0; d0 < nd; d0 += 256) {
+      uint32_t xw[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const uint32_t dd = d0 + 64u * j + lane; xw[j] = dd < nd ? seqw[dd] : 0u; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t dd = d0 + 64u * j + lane;
+        const int nv = min(max((int)L - (int)(8u * dd), 0), 8);
+        acc += (uint32_t)__popc(match8(linearize(xw[j]), xs) & ((1u << nv) - 1u));
+      }
+    }
+    tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
+  }
+  bool err = false;
+  const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);  // read_can_be_trimmed (mod_bam.rs:1668-1671)
+  const bool collapse = prm.numeric_mode == 2;
+  uint32_t obs0 = 0, obs1 = 0, contribH = 0, n_ev = 0, cum = 0;
+  bool any_surviving = false;
+  // CIGAR window: 64 ops in registers, advanced as the batches move along the read
+  uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
+  uint32_t w_op = 5u, w_qe = 0; int32_t w_dl = 0; uint32_t w_rtot = 0;
+  bool win_loaded = false;
+  uint32_t qhead = 0, qcount = 0, d0 = 0;
+  uint32_t x_next = (uint32_t)lane < nd ? seqw[lane] : 0u;   // the next step's SEQ dword is always in flight
+
+  for (;;) {
+    if (err) break;
+    if (qcount - qhead < 64u && d0 < nd) {
+      // ---- producer: one 512-base step appends its calls to the queue
+      if (qhead) {  // move the (< 64) unconsumed entries to the front
+        const uint32_t n_left = qcount - qhead;
+        const bool mv = (uint32_t)lane < n_left;
+        const uint32_t a = mv ? q_pos[qhead + lane] : 0u, b = mv ? q_j0[qhead + lane] : 0u, c = (NT > 1 && mv) ? q_j1[qhead + lane] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (mv) { q_pos[lane] = a; q_j0[lane] = b; if (NT > 1) q_j1[lane] = c; }
+        qcount = n_left; qhead = 0;
+      }
+      const uint32_t d = d0 + lane;
+      const uint32_t xl = linearize(x_next);
+      { const uint32_t dn = d + 64u; x_next = dn < nd ? seqw[dn] : 0u; }
+      const int nv = min(max((int)L - (int)(8u * d), 0), 8);
+      const uint32_t m8 = match8(xl, xs) & ((1u << nv) - 1u);
+      const uint32_t c = (uint32_t)__popc(m8), incl = wave_incl_scan(c);
+      const uint32_t cntT = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const uint32_t wlo = rev ? (tot - cum - cntT) : cum, whi = wlo + cntT;   // rank window of this step
+      uint32_t cur_before[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) { cur_before[t] = t_cur[t]; if (t < n_tags && lane < 18) ordb[t * 18 + lane] = 0; }
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        if (t >= n_tags) break;
+        for (;;) {
+          uint32_t e; bool hit; uint32_t nh;
+          if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
+          else { const uint32_t i = t_cur[t] - 64u + lane; const bool valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }
+          if (nh == 0) break;
+          const uint32_t ib = (rev ? (tot - 1u - e) : e) - cum;   // step-relative stored ordinal of the called base
+          if (hit) atomicOr(&ordb[t * 18 + (ib >> 5)], 1u << (ib & 31u));
+          if (nh < 64) break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint32_t bm[NT], texcl[NT], U = impl0 ? m8 : 0u, uincl = 0, ucnt = 0;
+      const uint32_t ex = incl - c, clo = (uint32_t)__popc(m8 & 15u);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        bm[t] = 0; texcl[t] = 0;
+        if (t < n_tags) {  // bits [excl, excl+cnt) of the ordinal bitmap deposited onto the set bits of the lane's match mask
+          const uint32_t w0 = ordb[t * 18 + (ex >> 5)], w1 = ordb[t * 18 + (ex >> 5) + 1];
+          const uint32_t f = __builtin_amdgcn_alignbit(w1, w0, ex & 31u) & ((1u << c) - 1u);
+          bm[t] = (uint32_t)pdep4[((m8 & 15u) << 4) | (f & 15u)] | ((uint32_t)pdep4[(m8 & 0xf0u) | ((f >> clo) & 15u)] << 4);
+          U |= bm[t];
+          const uint32_t c2 = (uint32_t)__popc(bm[t]);
+          uincl = wave_incl_scan(c2); ucnt = c2; texcl[t] = uincl - c2;
+        }
+      }
+      if (NT > 1 || impl0) { ucnt = (uint32_t)__popc(U); uincl = wave_incl_scan(ucnt); }   // else U == bm[0]: its scan is already there
+      const uint32_t H = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 63);
+      { uint32_t ut = U, sidx = qcount + uincl - ucnt;
+        while (ut) {
+          const uint32_t bit = (uint32_t)__ffs((int)ut) - 1u, below = (1u << bit) - 1u;
+          q_pos[sidx] = 8u * d + bit;
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            const uint32_t idx = texcl[t] + (uint32_t)__popc(bm[t] & below);
+            const uint32_t jx = rev ? (cur_before[t] - 1u - idx) : (cur_before[t] + idx);
+            (t == 0 ? q_j0 : q_j1)[sidx] = ((bm[t] >> bit) & 1u) ? jx : 0xffffffffu;
+          }
+          sidx++; ut &= ut - 1u;
+        } }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      qcount += H; cum += cntT; d0 += 64;
+      continue;
+    }
+    if (qcount == qhead) break;
+    // ---- consumer: up to 64 queued calls, in read order
+    const uint32_t nb = min(64u, qcount - qhead);
+    const bool active = (uint32_t)lane < nb;
+    const uint32_t q = active ? q_pos[qhead + lane] : 0u;
+    const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
+    float pk[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t SH = 0, setmask = 0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (t >= n_tags) break;
+      const uint32_t jx = active ? (t == 0 ? q_j0 : q_j1)[qhead + lane] : 0xffffffffu;
+      const bool found = jx != 0xffffffffu;
+      const uint32_t nc = t_nc[t];
+      for (uint32_t i = 0; i < nc; i++) {
+        const float p = ((float)ml[found ? (t_ml[t] + jx * nc + i) : 0u] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
+        const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
+#pragma unroll
+        for (int k2 = 0; k2 < MKP_KMAX; k2++) if (kk == (uint32_t)k2) pk[k2] = found ? p : pk[k2];
+      }
+      SH |= found ? (1u << (tmu[t] & 15u)) : 0u;
+      setmask |= found ? codes_t[t] : 0u;
+    }
+    if (NT > 1 && __popc(SH) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
+      float s = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask & (1u << k2)) s = s + pk[k2];
+      if (s > 1.01f) err = true;
+    }
+    // reference position through the CIGAR window (aligned pairs: M/=/X only, util.rs:122-145)
+    bool mapped = false; int32_t rpos = 0;
+    {
+      bool pending = active;
+      for (;;) {
+        if (!win_loaded || (__any(pending && q >= wq1) && !__any(pending && q < wq1))) {
+          if (win_loaded) { c0 += 64; wq0 = wq1; wr0 += (int32_t)w_rtot; }
+          if (c0 >= h.n_cigar) break;
+          const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u /*0H*/;
+          w_op = w & 15u; const uint32_t len = w >> 4;
+          const uint32_t qlen = op_consumes_query(w_op) ? len : 0u, rlen = op_consumes_ref(w_op) ? len : 0u;
+          w_qe = wave_incl_scan(qlen); const uint32_t re = wave_incl_scan(rlen);
+          w_dl = (wr0 + (int32_t)(re - rlen)) - (int32_t)(wq0 + w_qe - qlen);   // ref start - query start of the op
+          wq1 = wq0 + (uint32_t)__builtin_amdgcn_readlane((int)w_qe, 63); w_rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
+          win_loaded = true;
+          continue;
+        }
+        const bool ready = pending && q < wq1;
+        const int oi = find_op(w_qe, ready ? q - wq0 : 0u) & 63;
+        const uint32_t my_op = __shfl(w_op, oi, 64);
+        const int32_t my_dl = __shfl(w_dl, oi, 64);
+        if (ready) { mapped = op_is_match(my_op); rpos = (int32_t)q + my_dl; pending = false; }
+        if (!__any(pending)) break;
+      }
+    }
+    uint32_t ev_info = 0; float sv = 0.f; bool has_ev = false;
+    if (active && (SH | impl0)) {
+      const bool edge_keep = !prm.edge_filter ||
+          (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
+      int pat; uint32_t member_contrib;
+      if (SH) { if (impl0 & ~SH) err = true; pat = (int)SH; member_contrib = SH; }      // ExplicitConflictInferred
+      else { pat = MKP_PAT_INFERRED; member_contrib = impl0; }                          // implicit fill (mod_bam.rs:1265-1292)
+      const uint32_t pv = gp0[12 + pat];
+      contribH |= member_contrib;
+      if (trimmable && edge_keep) {
+        if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
+          bool keep = !prm.only_mapped || mapped;
+          if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
+          if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
+        } else {
+          any_surviving = true;
+          uint32_t ob = 0;
+          const int cls = call_group(grp0, pv, pk, collapse, &ob);
+          const uint32_t tally = aln ^ (uint32_t)sg0;  // read_cache.rs:181-188 / FeatureVector::add_feature
+          if (tally) obs1 |= ob; else obs0 |= ob;
+          if (mapped) {
+            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
+            ev_info = cid | (tally << 8) | ((uint32_t)b0 << 9) | (aln << 11) | (1u << 12);
+            has_ev = true;
+          }
+        }
+      }
+    }
+    // ballot-compacted, position-ordered append of this batch's events
+    const unsigned long long b1 = __ballot(has_ev);
+    const uint32_t step_total = (uint32_t)__popcll(b1);
+    if (step_total) {
+      const uint32_t off = n_ev + (uint32_t)__popcll(b1 & lanemask_lt());
+      if (n_ev + step_total > h.event_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
+      else if (has_ev) {
+        MkpEvent ev; ev.pos = (uint32_t)rpos; ev.info = ev_info; events[h.event_off + off] = ev;
+        if (SAMPLE) sample_vals[h.event_off + off] = sv;
+      }
+      n_ev += step_total;
+    }
+    err = __any(err);
+    qhead += nb;
+  }
+  // a delta list must not run past the last occurrence of its base: every entry must have been consumed (mod_bam.rs:705-727)
+#pragma unroll
+  for (int t = 0; t < NT; t++) if (t < n_tags) { if (rev ? (t_cur[t] != 0u) : (t_cur[t] != t_n[t])) err = true; }
+  err = __any(err);
+  obs0 = wave_or(obs0); obs1 = wave_or(obs1);
+  any_surviving = __any(any_surviving);
+  // InvalidImplicitMode: the group's contributing tags all lack a mode character (read_cache.rs:122-137)
+  if (!prm.force_allow && !SAMPLE) {
+    const uint32_t mc = wave_or(contribH); uint32_t tagbits = 0;
+#pragma unroll
+    for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (mc & (1u << mi)) tagbits |= 1u << ((grp0.member_tags >> (4 * mi)) & 15u);
+    if (tagbits && (tagbits & ~(uint32_t)lay->default_mask) == 0) err = true;
+  }
+  if (lane == 0) {
+    if (!err && any_surviving) { out.ok = 1; out.n_events = n_ev; out.obs[0] = obs0; out.obs[1] = obs1; }
+    readout[rid] = out;
+  }
+}
+
 #define DECODE_ARGS_REF const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
                     const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
                     const MkpLayout* __restrict__ layouts, const MkpRunParams& prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
@@ -625,9 +897,11 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
                     const MkpLayout* __restrict__ layouts, MkpRunParams prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
                     uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
 #define DECODE_CALL(S, N, F) decode_read_body<S, N, F>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks, pdep4)
+#define DECODE_FAST(S, N) decode_read_fast<S, N>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks, pdep4, &lds_queue[0][0])
 template <bool SAMPLE> __device__ __forceinline__ void decode_dispatch(DECODE_ARGS_REF) {
+  __shared__ uint32_t lds_queue[4][3 * MKP_QCAP];
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
-  __shared__ uint32_t lds_marks[4 * MKP_MAX_TAGS][64];
+  __shared__ uint32_t lds_marks[4 * 7][64];   // per wave 448 dwords: ordinal bitmaps [<=8][18] at 0, 512 u16 slots at 192
   __shared__ uint8_t pdep4[256];   // pdep4[(mask << 4) | bits]: the low bits of `bits` deposited onto the set bits of a 4-bit mask
   { const uint32_t m = threadIdx.x >> 4; uint32_t f = threadIdx.x & 15u, o = 0;
     for (uint32_t i = 0; i < 4; i++) if ((m >> i) & 1u) { o |= (f & 1u) << i; f >>= 1; }
@@ -637,7 +911,7 @@ template <bool SAMPLE> __device__ __forceinline__ void decode_dispatch(DECODE_AR
   if (rid >= n_reads) return;
   const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[rid].n_tags);
   const bool fast = nt && __builtin_amdgcn_readfirstlane((int)layouts[hdrs[rid].layout].fast) != 0;
-  if (fast && nt == 1) DECODE_CALL(SAMPLE, 1, true); else if (fast && nt == 2) DECODE_CALL(SAMPLE, 2, true);
+  if (fast && nt == 1) DECODE_FAST(SAMPLE, 1); else if (fast && nt == 2) DECODE_FAST(SAMPLE, 2);
   else if (nt <= 2) DECODE_CALL(SAMPLE, 2, false); else if (nt <= 4) DECODE_CALL(SAMPLE, 4, false); else DECODE_CALL(SAMPLE, MKP_MAX_TAGS, false);
 }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_ARGS) {
