@@ -7,7 +7,7 @@
 using namespace mkp;
 
 extern "C" {
-hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
+hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
 hipError_t mkp_pileup_set_lds(uint32_t);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
@@ -24,6 +24,18 @@ MkpRowsDev carve_rows(DevBuf& b, uint64_t cap) {
   r.pos = p; r.info = p + cap; r.code = p + 2 * cap; r.n_valid = p + 3 * cap; r.n_mod = p + 4 * cap; r.n_can = p + 5 * cap; r.n_other = p + 6 * cap;
   r.n_del = p + 7 * cap; r.n_fail = p + 8 * cap; r.n_diff = p + 9 * cap; r.n_nocall = p + 10 * cap;
   return r;
+}
+
+// reads by decode kernel: [FAST layouts with one tag | FAST layouts with two tags | everything else]
+void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[3]) {
+  std::vector<uint32_t> cls[3];
+  for (size_t i = 0; i < S.hdr.size(); i++) {
+    const MkpReadHdr& h = S.hdr[i]; int c = 2;
+    if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast && h.n_tags <= 2) c = h.n_tags - 1;
+    cls[c].push_back((uint32_t)i);
+  }
+  ids->clear();
+  for (int c = 0; c < 3; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
 }
 
 template <class T> void upload(DevBuf& b, const std::vector<T>& v) {
@@ -86,6 +98,7 @@ void make_resident(mkp_ctx* c) {
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
   upload(c->d_layouts, c->tables.dev); upload(c->d_tile_ids, tile_ids); upload(c->d_tile_first, tf); upload(c->d_tile_last, tl);
+  { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class); upload(c->d_read_ids, ids); }
   if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
@@ -117,7 +130,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     c->d_prm.ensure(sizeof(MkpRunParams));
     hip_check(hipMemcpyAsync(c->d_prm.p, &P, sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), (uint32_t)S.hdr.size(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
+    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
@@ -200,7 +213,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tile_ids,
-                    &c->d_tile_first, &c->d_tile_last, &c->d_prm, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
+                    &c->d_tile_first, &c->d_tile_last, &c->d_prm, &c->d_read_ids, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -304,12 +317,13 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
     upload(c->d_layouts, c->tables.dev);
+    { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class); upload(c->d_read_ids, ids); }
     if (bedmask) { c->d_focus.ensure((size_t)(win_end - win_start)); hip_check(hipMemcpy(c->d_focus.p, bedmask, (size_t)(win_end - win_start), hipMemcpyHostToDevice), "H2D"); } else c->d_focus.ensure(16);
     const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
     c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut)); c->d_misc.ensure(64);
     uint32_t* misc = c->d_misc.as<uint32_t>();
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), (uint32_t)S.hdr.size(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
+    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
                                 c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), c->d_vals.as<float>()), "decode(sample) launch");
     hip_check(hipStreamSynchronize(c->stream), "sample sync");
     uint32_t h[4]; hip_check(hipMemcpy(h, misc, 16, hipMemcpyDeviceToHost), "D2H");

@@ -49,9 +49,10 @@ __device__ __forceinline__ uint32_t seq_nibble(const uint8_t* __restrict__ s, ui
   uint32_t b = s[q >> 1];
   return (q & 1u) ? (b & 15u) : (b >> 4);
 }
-__device__ __forceinline__ bool op_consumes_query(uint32_t op) { return op == 0 || op == 1 || op == 4 || op == 7 || op == 8; }
-__device__ __forceinline__ bool op_consumes_ref(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
-__device__ __forceinline__ bool op_is_match(uint32_t op) { return op == 0 || op == 7 || op == 8; }
+// CIGAR op classes as bit tables over the op code (MIDNSHP=X = 0..8): no branches
+__device__ __forceinline__ bool op_consumes_query(uint32_t op) { return (0x193u >> op) & 1u; }  // M I S = X
+__device__ __forceinline__ bool op_consumes_ref(uint32_t op) { return (0x18du >> op) & 1u; }    // M D N = X
+__device__ __forceinline__ bool op_is_match(uint32_t op) { return (0x181u >> op) & 1u; }        // M = X
 
 // number of lanes whose (non-decreasing) inclusive prefix `incl` is <= j  == index of the op holding element j
 __device__ __forceinline__ int find_op(uint32_t incl, uint32_t j) {
@@ -76,7 +77,11 @@ __device__ __forceinline__ int find_rank(const uint32_t* __restrict__ a, uint32_
   return (lo < n && a[lo] == key) ? (int)lo : -1;
 }
 
-__device__ __forceinline__ float getk(const float* p, int k) { return k == 0 ? p[0] : k == 1 ? p[1] : k == 2 ? p[2] : p[3]; }
+__device__ __forceinline__ float getk(const float* p, int k) {  // select chain (kept as v_cndmask, not a switch)
+  float r = p[0];
+  r = (k == 1) ? p[1] : r; r = (k == 2) ? p[2] : r; r = (k == 3) ? p[3] : r;
+  return r;
+}
 __device__ __forceinline__ void addk(float* p, int k, float v) { p[0] = k == 0 ? p[0] + v : p[0]; p[1] = k == 1 ? p[1] + v : p[1]; p[2] = k == 2 ? p[2] + v : p[2]; p[3] = k == 3 ? p[3] + v : p[3]; }
 
 // ----------------------------------------------------------------------------------------------
@@ -93,46 +98,62 @@ __device__ __forceinline__ GroupRegs load_group(const uint32_t* g) {
 }
 
 // ReDistribute collapse (BaseModProbs::into_collapsed, mod_bam.rs:558-600) in the map's iteration order.
-__device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32_t pv, float* pk) {
+__device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32_t pv, float* pk, int kmax) {
   const int n_pre = (int)(pv & 7u);
   const int x = MKP_G_COLL(g.misc);
   bool present = false;
-  for (int i = 0; i < n_pre; i++) present |= ((int)((pv >> (8 + 2 * i)) & 3u) == x);
+#pragma unroll
+  for (int i = 0; i < MKP_KMAX; i++) { if (i >= kmax) break; present |= (i < n_pre) && ((int)((pv >> (8 + 2 * i)) & 3u) == x); }
   const float marginal = present ? getk(pk, x) : 0.0f;
   const float n_other = (float)(present ? n_pre : n_pre + 1);  // other_mods.len() + 1
   const float redistribute = marginal / n_other;
-  for (int i = 0; i < n_pre; i++) { const int k = (int)((pv >> (8 + 2 * i)) & 3u); if (k != x) addk(pk, k, redistribute); }
+#pragma unroll
+  for (int i = 0; i < MKP_KMAX; i++) { if (i >= kmax) break; const int kq = (int)((pv >> (8 + 2 * i)) & 3u); addk(pk, (i < n_pre && kq != x) ? kq : -1, redistribute); }
 }
 
 // BaseModProbs -> BaseModCall: MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63).
 // Returns 0 Filtered, 1 Canonical, 2+k Modified(local code k); *obs gets the slots of the codes in the map the
 // caller sees (read_cache.rs:171-179).  pv = the group's entry for this hit pattern.
-__device__ __forceinline__ int call_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse, uint32_t* obs) {
-  if (collapse) collapse_redistribute(g, pv, pk);
+// kmax: wave-uniform bound on the number of codes in the map (MKP_KMAX when the group differs per lane)
+__device__ __forceinline__ int call_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX) {
+  if (collapse) collapse_redistribute(g, pv, pk, kmax);
   const int n_post = (int)((pv >> 3) & 7u);
   int best = 0;
   float best_p = 0.0f, s = 0.0f;
   uint32_t ob = 0;
-  for (int i = 0; i < n_post; i++) {
-    const int k = (int)((pv >> (16 + 2 * i)) & 3u);
-    const float p = getk(pk, k);
-    ob |= 1u << ((g.slots >> (8 * k)) & 0xffu);
-    s = s + p;  // probs.values().sum() in map order
-    if (p >= getk(g.thr, k)) { if (best == 0 || !(p < best_p)) { best = 2 + k; best_p = p; } }  // Iterator::max keeps the last maximum
+#pragma unroll
+  for (int i = 0; i < MKP_KMAX; i++) {   // predicated, uniform trip count
+    if (i >= kmax) break;
+    const bool valid = i < n_post;
+    const int kq = (int)((pv >> (16 + 2 * i)) & 3u);
+    const float p = getk(pk, kq);
+    ob |= valid ? (1u << ((g.slots >> (8 * kq)) & 0xffu)) : 0u;
+    s = valid ? s + p : s;  // probs.values().sum() in map order
+    const bool take = valid && p >= getk(g.thr, kq) && (best == 0 || !(p < best_p));  // Iterator::max keeps the last maximum
+    best = take ? 2 + kq : best; best_p = take ? p : best_p;
   }
   const float pc = 1.0f - s;  // canonical_prob, pushed last
-  if (pc >= g.thr_can) { if (best == 0 || !(pc < best_p)) { best = 1; best_p = pc; } }
+  const bool takec = pc >= g.thr_can && (best == 0 || !(pc < best_p));
+  best = takec ? 1 : best;
   *obs |= ob;
   return best;
 }
 
 // Threshold sampling: value of BaseModProbs::argmax_base_mod_call after the optional collapse
 // (mod_bam.rs:489-505; read_ids_to_base_mod_probs.rs:67-101, 324-328).
-__device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse) {
-  if (collapse) collapse_redistribute(g, pv, pk);
+__device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse, int kmax = MKP_KMAX) {
+  if (collapse) collapse_redistribute(g, pv, pk, kmax);
   const int n_post = (int)((pv >> 3) & 7u);
   float s = 0.0f, best = 0.0f; bool have = false;
-  for (int i = 0; i < n_post; i++) { const float p = getk(pk, (int)((pv >> (16 + 2 * i)) & 3u)); s = s + p; if (!have || !(p < best)) { best = p; have = true; } }
+#pragma unroll
+  for (int i = 0; i < MKP_KMAX; i++) {
+    if (i >= kmax) break;
+    const bool valid = i < n_post;
+    const float p = getk(pk, (int)((pv >> (16 + 2 * i)) & 3u));
+    s = valid ? s + p : s;
+    const bool take = valid && (!have || !(p < best));
+    best = take ? p : best; have = have || valid;
+  }
   const float can = 1.0f - s;
   return (have && best > can) ? best : can;
 }
@@ -208,12 +229,13 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
-                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4) {
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, const uint32_t* __restrict__ read_ids, uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4) {
   const int lane = lane_id();
   // wave-uniform values are made provably uniform (readfirstlane) so they live in SGPRs and load through the scalar cache
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
-  if (rid >= n_reads) return;
+  const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
+  if (widx >= n_reads) return;
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)read_ids[widx]);
   const MkpReadHdr h = hdrs[rid];
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
@@ -631,20 +653,21 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
                  const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts,
-                 uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4, uint32_t* __restrict__ lds_queue) {
+                 const uint32_t* __restrict__ read_ids, uint32_t* __restrict__ lds_ord, const uint8_t* __restrict__ pdep4, uint32_t* __restrict__ lds_queue) {
   static_assert(NT <= 2, "the call queue holds two ML indices per entry");
   const int lane = lane_id();
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
-  if (rid >= n_reads) return;
+  const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
+  if (widx >= n_reads) return;
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)read_ids[widx]);
   const MkpReadHdr h = hdrs[rid];
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
   uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
-  uint32_t* __restrict__ ordb = &lds_marks[wib * 7][0];   // [NT][18] ordinal bitmaps of the step
-  uint32_t* __restrict__ q_pos = lds_queue + wib * (3 * MKP_QCAP);   // queue, SoA: stored position, ML call index of tag 0 / 1 (~0 = not listed)
+  uint32_t* __restrict__ ordb = lds_ord + wib * (NT * 18);            // [NT][18] ordinal bitmaps of the step
+  uint32_t* __restrict__ q_pos = lds_queue + wib * ((1 + NT) * MKP_QCAP);   // queue, SoA: stored position, ML call index of tag 0 / 1 (~0 = not listed)
   uint32_t* __restrict__ q_j0 = q_pos + MKP_QCAP;
-  uint32_t* __restrict__ q_j1 = q_pos + 2 * MKP_QCAP;
+  uint32_t* __restrict__ q_j1 = q_pos + (NT > 1 ? 2 : 1) * MKP_QCAP;
   { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
     for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
   __builtin_amdgcn_wave_barrier();
@@ -663,6 +686,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   for (int kq = 0; kq < MKP_KMAX; kq++) grp0.thr[kq] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr[kq])));
   grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
   const uint32_t impl0 = MKP_G_IMPL(grp0.misc);
+  const int kcodes0 = (int)((grp0.misc >> 20) & 7u);   // codes of the group: bounds every per-code loop
   uint32_t t_off[NT], t_n[NT], t_ml[NT], t_cur[NT], t_nc[NT], tmu[NT], codes_t[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
@@ -773,6 +797,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
       continue;
     }
     if (qcount == qhead) break;
+    if (prm.debug_skip & 16u) { qhead = qcount; continue; }
     // ---- consumer: up to 64 queued calls, in read order
     const uint32_t nb = min(64u, qcount - qhead);
     const bool active = (uint32_t)lane < nb;
@@ -839,11 +864,11 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
+          if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
         } else {
           any_surviving = true;
           uint32_t ob = 0;
-          const int cls = call_group(grp0, pv, pk, collapse, &ob);
+          const int cls = call_group(grp0, pv, pk, collapse, &ob, kcodes0);
           const uint32_t tally = aln ^ (uint32_t)sg0;  // read_cache.rs:181-188 / FeatureVector::add_feature
           if (tally) obs1 |= ob; else obs0 |= ob;
           if (mapped) {
@@ -888,39 +913,48 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   }
 }
 
-#define DECODE_ARGS_REF const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
+#define DECODE_PARAMS(PRM) const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
                     const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
-                    const MkpLayout* __restrict__ layouts, const MkpRunParams& prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
-                    uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
-#define DECODE_ARGS const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
-                    const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
-                    const MkpLayout* __restrict__ layouts, MkpRunParams prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
-                    uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals
-#define DECODE_CALL(S, N, F) decode_read_body<S, N, F>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks, pdep4)
-#define DECODE_FAST(S, N) decode_read_fast<S, N>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], lds_marks, pdep4, &lds_queue[0][0])
-template <bool SAMPLE> __device__ __forceinline__ void decode_dispatch(DECODE_ARGS_REF) {
-  __shared__ uint32_t lds_queue[4][3 * MKP_QCAP];
+                    const MkpLayout* __restrict__ layouts, PRM prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
+                    uint32_t* __restrict__ dev_err, const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, const uint32_t* __restrict__ read_ids
+#define DECODE_PASS hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, read_ids
+// pdep4[(mask << 4) | bits]: the low bits of `bits` deposited onto the set bits of a 4-bit mask
+__device__ __forceinline__ void init_pdep4(uint8_t* pdep4) {
+  const uint32_t m = (threadIdx.x >> 4) & 15u; uint32_t f = threadIdx.x & 15u, o = 0;
+  for (uint32_t i = 0; i < 4; i++) if ((m >> i) & 1u) { o |= (f & 1u) << i; f >>= 1; }
+  pdep4[threadIdx.x & 255u] = (uint8_t)o;
+  __syncthreads();
+}
+// Reads are split by the host into three lists (read_ids): FAST layouts with one tag, FAST layouts with two tags, and
+// everything else; each list has its own kernel so the common `C+m?` / `C+h?;C+m?` reads run with few registers and
+// little LDS (more waves per SIMD) while the general decoder keeps its full generality.
+template <bool SAMPLE, int NT> __device__ __forceinline__ void decode_fast_entry(DECODE_PARAMS(const MkpRunParams&)) {
+  __shared__ uint32_t lds_queue[4][(1 + NT) * MKP_QCAP];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
+  __shared__ uint32_t lds_ord[4][NT * 18];
+  __shared__ uint8_t pdep4[256];
+  init_pdep4(pdep4);
+  decode_read_fast<SAMPLE, NT>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals,
+                               &lds_layouts[0][0], read_ids, &lds_ord[0][0], pdep4, &lds_queue[0][0]);
+}
+template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECODE_PARAMS(const MkpRunParams&)) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
   __shared__ uint32_t lds_marks[4 * 7][64];   // per wave 448 dwords: ordinal bitmaps [<=8][18] at 0, 512 u16 slots at 192
-  __shared__ uint8_t pdep4[256];   // pdep4[(mask << 4) | bits]: the low bits of `bits` deposited onto the set bits of a 4-bit mask
-  { const uint32_t m = threadIdx.x >> 4; uint32_t f = threadIdx.x & 15u, o = 0;
-    for (uint32_t i = 0; i < 4; i++) if ((m >> i) & 1u) { o |= (f & 1u) << i; f >>= 1; }
-    pdep4[threadIdx.x & 255u] = (uint8_t)o; }
-  __syncthreads();
-  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-  if (rid >= n_reads) return;
-  const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[rid].n_tags);
-  const bool fast = nt && __builtin_amdgcn_readfirstlane((int)layouts[hdrs[rid].layout].fast) != 0;
-  if (fast && nt == 1) DECODE_FAST(SAMPLE, 1); else if (fast && nt == 2) DECODE_FAST(SAMPLE, 2);
-  else if (nt <= 2) DECODE_CALL(SAMPLE, 2, false); else if (nt <= 4) DECODE_CALL(SAMPLE, 4, false); else DECODE_CALL(SAMPLE, MKP_MAX_TAGS, false);
+  __shared__ uint8_t pdep4[256];
+  init_pdep4(pdep4);
+  const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (widx >= n_reads) return;
+  const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[read_ids[widx]].n_tags);
+#define DECODE_CALL(S, N) decode_read_body<S, N, false>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, read_ids, &lds_layouts[0][0], lds_marks, pdep4)
+  if (nt <= 2) DECODE_CALL(SAMPLE, 2); else if (nt <= 4) DECODE_CALL(SAMPLE, 4); else DECODE_CALL(SAMPLE, MKP_MAX_TAGS);
 }
-extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_ARGS) {
-  decode_dispatch<false>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
-}
-// the same walk in threshold-sampling mode (reads_sampler / thresholds.rs:121-159): a separate kernel so profiles keep the two apart
-extern "C" __global__ void __launch_bounds__(256) mkp_sample_reads(DECODE_ARGS) {
-  decode_dispatch<true>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals);
-}
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<false>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 1>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast2(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 2>(DECODE_PASS); }
+// the same walks in threshold-sampling mode (reads_sampler / thresholds.rs:121-159): separate kernels so profiles keep the two apart
+extern "C" __global__ void __launch_bounds__(256) mkp_sample_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<true>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<true, 1>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast2(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<true, 2>(DECODE_PASS); }
 
 // ----------------------------------------------------------------------------------------------
 struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
@@ -1337,15 +1371,23 @@ mkp_gather_rows(const uint32_t* __restrict__ tile_row_off, const uint32_t* __res
 
 // ----------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
-extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, uint32_t n_reads, const uint32_t* cigar, const uint8_t* seqs,
+// read_ids = [FAST one-tag reads | FAST two-tag reads | all other reads], n_class = the three list lengths
+extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* read_ids, const uint32_t* n_class, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts,
                                         const MkpRunParams* prm, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err,
                                         const uint8_t* bedmask, float* sample_vals) {
-  if (!n_reads) return hipSuccess;
   const uint32_t waves_per_block = 4;
-  dim3 grid((n_reads + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
-  if (prm->sample_mode) hipLaunchKernelGGL(mkp_sample_reads, grid, block, 0, st, hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals);
-  else hipLaunchKernelGGL(mkp_decode_reads, grid, block, 0, st, hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals);
+  const uint32_t* ids = read_ids;
+  for (int cls = 0; cls < 3; cls++) {
+    const uint32_t n = n_class[cls];
+    if (n) {
+      dim3 grid((n + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
+#define MKP_DECODE_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids)
+      if (prm->sample_mode) { if (cls == 0) MKP_DECODE_LAUNCH(mkp_sample_fast1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_sample_fast2); else MKP_DECODE_LAUNCH(mkp_sample_reads); }
+      else { if (cls == 0) MKP_DECODE_LAUNCH(mkp_decode_fast1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_decode_fast2); else MKP_DECODE_LAUNCH(mkp_decode_reads); }
+    }
+    ids += n;
+  }
   return hipGetLastError();
 }
 
