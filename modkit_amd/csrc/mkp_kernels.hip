@@ -1115,7 +1115,10 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   const MkpRunParams& prm = *prmp;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
-  uint32_t bid = blockIdx.x;
+  // Persistent workgroups: the grid is one workgroup per CU and each walks its tiles (v = b, b + grid, ...), so there
+  // is no workgroup launch/drain gap between tiles.
+  for (uint32_t vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
+  uint32_t bid = vb;
   {
     const uint32_t per = n_tiles / 8u;
     if (per && bid < per * 8u) bid = (bid & 7u) * per + (bid >> 3);
@@ -1291,7 +1294,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   }
   __syncthreads();
   // rows: each thread owns a contiguous run of positions so row order == position order
-  if (prm.debug_skip & 4u) { if (threadIdx.x == 0) { tile_row_off[tix] = 0; tile_row_cnt[tix] = 0; } return; }
+  if (prm.debug_skip & 4u) { if (threadIdx.x == 0) { tile_row_off[tix] = 0; tile_row_cnt[tix] = 0; } __syncthreads(); continue; }
   const uint32_t per = (T + PILEUP_THREADS - 1) / PILEUP_THREADS;
   const uint32_t i0 = threadIdx.x * per;
   uint32_t my_rows = 0;
@@ -1319,7 +1322,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     tile_base = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s;
   }
   __syncthreads();
-  if (tile_row_cnt[tix] == 0) return;
+  if (tile_row_cnt[tix] != 0) {
   uint32_t wr = tile_base + wave_tot[wave] + inc - my_rows;
   for (uint32_t k = 0; k < per; k++) {
     const uint32_t li = i0 + k;
@@ -1327,6 +1330,9 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     const int32_t p = T0 + (int32_t)li;
     if (p < prm.win_start || p >= prm.win_end) continue;
     wr += rows_at<true>(tv, prm, focus, combos, T0h, li + MKP_HALO, rows, wr);
+  }
+  }
+  __syncthreads();   // the tallies are re-zeroed for the next tile
   }
 }
 
@@ -1401,7 +1407,9 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, cons
                                         const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
                                         uint32_t* tile_row_cnt, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
-  hipLaunchKernelGGL(mkp_pileup_tiles, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
+  // n_tiles/8 must stay the XCD remap's unit: the grid is a multiple of 8 (one workgroup per CU, 256 CUs)
+  const uint32_t grid = n_tiles < 256u ? n_tiles : 256u;
+  hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
                      tile_last, n_tiles, focus, combos, prm_dev, *rows, row_cursor, tile_row_off, tile_row_cnt, dev_err);
   return hipGetLastError();
 }
