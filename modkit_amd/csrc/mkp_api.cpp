@@ -34,6 +34,8 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
     if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast && h.n_tags <= 2) c = h.n_tags - 1;
     cls[c].push_back((uint32_t)i);
   }
+  // one wave decodes one read start to end: launch the longest reads first so they do not form the kernel's tail
+  for (int c = 0; c < 3; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; });
   ids->clear();
   for (int c = 0; c < 3; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
 }

@@ -297,7 +297,7 @@ int run(const Args& a, std::string* msg) {
   // shard plan: one shard per contig record, or pieces of it cut at interval boundaries; ranks take contiguous runs
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
   uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, (total_bp + a.world * 8 - 1) / (a.world * 8)) : (1ull << 30));
-  uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0;
+  uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0;
   for (auto& rec : records) {
     std::vector<uint8_t> focus; const bool hf = fb.has_focus();
     std::vector<Interval> ivs = fb.walk(rec, a.interval_size, hf ? &focus : nullptr);
@@ -318,13 +318,13 @@ int run(const Args& a, std::string* msg) {
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       mkp_rows rows; must(mkp_shard_run(ctx, &rows));
       wr.write(rec.name, rows);
-      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
+      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
   if (wr.f != stdout) fclose(wr.f);
-  if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f d2h_ms=%.1f total_ms=%.1f\n",
-                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, pack_ms, h2d_ms, kernel_ms, d2h_ms, ms_since(t_all));
+  if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f) d2h_ms=%.1f total_ms=%.1f\n",
+                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, d2h_ms, ms_since(t_all));
   (void)msg;
   return MKP_OK;
 }
