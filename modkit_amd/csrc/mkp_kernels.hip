@@ -742,6 +742,17 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
       const uint32_t d = d0 + lane;
       const uint32_t xl = linearize(x_next);
       { const uint32_t dn = d + 64u; x_next = dn < nd ? seqw[dn] : 0u; }
+      // the first 64 ranks at every tag's cursor are requested now, ahead of the match/scan work that decides how many are used
+      uint32_t e_pre[NT]; bool v_pre[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        e_pre[t] = rev ? 0u : 0xffffffffu; v_pre[t] = false;
+        if (t < n_tags) {
+          const uint32_t i = rev ? (t_cur[t] - 64u + lane) : (t_cur[t] + lane);
+          v_pre[t] = rev ? ((int32_t)i >= 0 && i < t_cur[t]) : (i < t_n[t]);
+          if (v_pre[t]) e_pre[t] = ranks[t_off[t] + i];
+        }
+      }
       const int nv = min(max((int)L - (int)(8u * d), 0), 8);
       const uint32_t m8 = match8(xl, xs) & ((1u << nv) - 1u);
       const uint32_t c = (uint32_t)__popc(m8), incl = wave_incl_scan(c);
@@ -753,10 +764,13 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         if (t >= n_tags) break;
-        for (;;) {
-          uint32_t e; bool hit; uint32_t nh;
-          if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
-          else { const uint32_t i = t_cur[t] - 64u + lane; const bool valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }
+        for (bool first = true;; first = false) {
+          uint32_t e; bool hit, valid; uint32_t nh;
+          if (first) { e = e_pre[t]; valid = v_pre[t]; }
+          else if (!rev) { const uint32_t i = t_cur[t] + lane; valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; }
+          else { const uint32_t i = t_cur[t] - 64u + lane; valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; }
+          if (!rev) { hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
+          else { hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }   // an entry >= whi is past the last occurrence: never consumed -> error at the end
           if (nh == 0) break;
           const uint32_t ib = (rev ? (tot - 1u - e) : e) - cum;   // step-relative stored ordinal of the called base
           if (hit) atomicOr(&ordb[t * 18 + (ib >> 5)], 1u << (ib & 31u));
@@ -803,28 +817,20 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
     const bool active = (uint32_t)lane < nb;
     const uint32_t q = active ? q_pos[qhead + lane] : 0u;
     const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
-    float pk[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
-    uint32_t SH = 0, setmask = 0;
+    // the ML bytes are requested first (up to MKP_KMAX per tag) and converted after the CIGAR mapping, whose latency they overlap
+    uint32_t mlq[NT][MKP_KMAX]; bool found_t[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      if (t >= n_tags) break;
-      const uint32_t jx = active ? (t == 0 ? q_j0 : q_j1)[qhead + lane] : 0xffffffffu;
-      const bool found = jx != 0xffffffffu;
-      const uint32_t nc = t_nc[t];
-      for (uint32_t i = 0; i < nc; i++) {
-        const float p = ((float)ml[found ? (t_ml[t] + jx * nc + i) : 0u] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
-        const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
+      found_t[t] = false;
 #pragma unroll
-        for (int k2 = 0; k2 < MKP_KMAX; k2++) if (kk == (uint32_t)k2) pk[k2] = found ? p : pk[k2];
+      for (int i = 0; i < MKP_KMAX; i++) mlq[t][i] = 0;
+      if (t < n_tags) {
+        const uint32_t jx = active ? (t == 0 ? q_j0 : q_j1)[qhead + lane] : 0xffffffffu;
+        found_t[t] = jx != 0xffffffffu;
+        const uint32_t nc = t_nc[t], base = found_t[t] ? (t_ml[t] + jx * nc) : 0u;
+#pragma unroll
+        for (int i = 0; i < MKP_KMAX; i++) if ((uint32_t)i < nc) mlq[t][i] = ml[base + (found_t[t] ? (uint32_t)i : 0u)];
       }
-      SH |= found ? (1u << (tmu[t] & 15u)) : 0u;
-      setmask |= found ? codes_t[t] : 0u;
-    }
-    if (NT > 1 && __popc(SH) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
-      float s = 0.f;
-#pragma unroll
-      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask & (1u << k2)) s = s + pk[k2];
-      if (s > 1.01f) err = true;
     }
     // reference position through the CIGAR window (aligned pairs: M/=/X only, util.rs:122-145)
     bool mapped = false; int32_t rpos = 0;
@@ -850,6 +856,29 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (ready) { mapped = op_is_match(my_op); rpos = (int32_t)q + my_dl; pending = false; }
         if (!__any(pending)) break;
       }
+    }
+    float pk[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t SH = 0, setmask = 0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (t >= n_tags) break;
+      const bool found = found_t[t];
+#pragma unroll
+      for (int i = 0; i < MKP_KMAX; i++) {
+        if ((uint32_t)i >= t_nc[t]) break;
+        const float p = ((float)mlq[t][i] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
+        const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
+#pragma unroll
+        for (int k2 = 0; k2 < MKP_KMAX; k2++) if (kk == (uint32_t)k2) pk[k2] = found ? p : pk[k2];
+      }
+      SH |= found ? (1u << (tmu[t] & 15u)) : 0u;
+      setmask |= found ? codes_t[t] : 0u;
+    }
+    if (NT > 1 && __popc(SH) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
+      float s = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask & (1u << k2)) s = s + pk[k2];
+      if (s > 1.01f) err = true;
     }
     uint32_t ev_info = 0; float sv = 0.f; bool has_ev = false;
     if (active && (SH | impl0)) {
