@@ -122,7 +122,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         # C2 reads are all `C+m?`: the decode work runs in mkp_decode_fast1 (the FAST one-tag kernel of the decode family)
-        kernels = {"mkp_decode_fast1": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
+        kernels = {"mkp_decode_fast1": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup),
+                   "mkp_emit_rows": (st.rows_kernel_ms, st.alg_bytes_rows)}
         dom = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -137,7 +138,7 @@ def main():
             "config": {"workload": "C2: synthetic 1 contig x %d bp, %d reads (mean %.0f bp, ~%.0fx), C+m? at every read CpG, default 10th-percentile threshold; one such shard per GPU" % (
                 contig_len, n_reads, meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / contig_len),
                 "scale": a.scale, "rows_per_s": total_rows * a.steps / elapsed, "rows_per_step": total_rows, "reads": int(st.n_reads), "call_events": int(st.n_events),
-                "tiles": int(st.n_tiles), "threshold_C": thr_h[1], "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "gather": st.gather_kernel_ms},
+                "tiles": int(st.n_tiles), "threshold_C": thr_h[1], "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
                 "untimed_ingest_pack_h2d_s": ingest_s, "pcie_inclusive_note": "see DESIGN.md", "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
                 "roofline_all_kernels": {k: {"achieved_GBps": v[1] / (v[0] * 1e-3) / 1e9, "algorithmic_bytes": int(v[1]), "avg_launch_ms": v[0]} for k, v in kernels.items()}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -132,7 +132,9 @@ typedef struct {
   double pack_ms, h2d_ms, kernel_ms, d2h_ms;  /* last shard */
   double decode_kernel_ms, pileup_kernel_ms, gather_kernel_ms;
   uint64_t n_reads, n_events, n_rows, n_tiles, n_positions;
-  uint64_t alg_bytes_decode, alg_bytes_pileup; /* SURVEY.md §8(d) algorithmic bytes for the two kernels */
+  uint64_t alg_bytes_decode, alg_bytes_pileup; /* SURVEY.md §8(d) algorithmic bytes of the decode and pileup kernels */
+  double rows_kernel_ms;                       /* mkp_emit_rows (tallies -> rows) */
+  uint64_t alg_bytes_rows;                     /* 44 B per row */
 } mkp_stats;
 
 /* ---- lifecycle */

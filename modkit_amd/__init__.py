@@ -114,7 +114,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("pack_ms", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
                 ("decode_kernel_ms", ctypes.c_double), ("pileup_kernel_ms", ctypes.c_double), ("gather_kernel_ms", ctypes.c_double),
                 ("n_reads", ctypes.c_uint64), ("n_events", ctypes.c_uint64), ("n_rows", ctypes.c_uint64), ("n_tiles", ctypes.c_uint64),
-                ("n_positions", ctypes.c_uint64), ("alg_bytes_decode", ctypes.c_uint64), ("alg_bytes_pileup", ctypes.c_uint64)]
+                ("n_positions", ctypes.c_uint64), ("alg_bytes_decode", ctypes.c_uint64), ("alg_bytes_pileup", ctypes.c_uint64),
+                ("rows_kernel_ms", ctypes.c_double), ("alg_bytes_rows", ctypes.c_uint64)]
 
 
 class Context:

@@ -9,10 +9,11 @@ using namespace mkp;
 extern "C" {
 hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
-hipError_t mkp_pileup_set_lds(uint32_t);
+hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, uint32_t rows_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
-                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
-                             const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/);
+hipError_t mkp_launch_rows(hipStream_t, uint32_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
+                           const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
 
@@ -66,17 +67,20 @@ void make_resident(mkp_ctx* c) {
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a], &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
   for (uint32_t i = 0; i < P.n_slots; i++) { P.slot_order[i] = (uint8_t)order[i]; P.slots[i] = c->tables.st.slots[i]; }
   if (P.combine_strands && !P.has_focus) throw Error(MKP_E_INVALID, "combine_strands needs motif focus positions");
-  // tile geometry from the LDS budget (160 KiB per CU on gfx950)
-  const uint32_t words_per_pos = 2u * (P.n_counters + P.n_slots);
+  // tile geometry from the LDS budget (160 KiB per CU on gfx950): the accumulate kernel runs two workgroups per CU, each
+  // holding one tile of packed tallies (one dword per counter / slot and position) plus its waves' scratch in 80 KiB;
+  // the row kernel unpacks one tile into twice that
+  const uint32_t words_per_pos = P.n_counters + P.n_slots;
   uint32_t T = c->cfg.tile_positions;
   if (const char* te = getenv("MKP_TILE")) T = (uint32_t)strtoul(te, nullptr, 0);   // experiments only
-  const uint32_t budget = 160u * 1024u - 512u;
+  const uint32_t budget = 80u * 1024u - 256u;
   uint32_t maxT = 0;
   for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;
   if (maxT < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
   if (!T || T > maxT) T = std::min<uint32_t>(maxT, 4096u);
   T = std::max<uint32_t>(64u, T & ~63u);
   P.tile = T; c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_pos, T + 2 * MKP_HALO) * 4u;
+  c->lds_rows_bytes = 2u * words_per_pos * (T + 2 * MKP_HALO) * 4u;
   const uint64_t win = (uint64_t)(S.win_end - S.win_start);
   P.n_tiles_total = (uint32_t)((win + T - 1) / T);
   // tile -> [first,last) reads.  Reads are coordinate sorted; prefix-max of ends bounds the first candidate.
@@ -92,6 +96,8 @@ void make_resident(mkp_ctx* c) {
       while (last < n && S.hdr[last].ref_start < hi) last++;
       bool any = false; for (size_t i = first; i < last && !any; i++) any = S.hdr[i].ref_end > lo;
       if (any) { tile_ids.push_back(t); tf.push_back((uint32_t)first); tl.push_back((uint32_t)last); }
+      // the packed tallies hold 16 bits per strand: no column may be deeper than 65535 (every column's reads are among the tile's)
+      if (last - first > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one tile: columns this deep are outside the device path");
     }
   }
   c->n_tiles = (uint32_t)tile_ids.size();
@@ -106,7 +112,8 @@ void make_resident(mkp_ctx* c) {
   c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
   c->d_tile_row_off.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_tiles + 1) * 4);
   c->d_misc.ensure(64);
-  hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
+  c->d_tally.ensure(std::max<size_t>((size_t)c->n_tiles * words_per_pos * (T + 2 * MKP_HALO) * 4u, 16));
+  hip_check(mkp_pileup_set_lds(c->lds_bytes, c->lds_rows_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
   c->resident = true;
@@ -114,12 +121,11 @@ void make_resident(mkp_ctx* c) {
   uint64_t b_reads = 0; for (auto& h : S.hdr) b_reads += 16 + 4ull * h.n_cigar + (h.l_seq + 1) / 2;
   c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = win;
   c->stats.alg_bytes_decode = b_reads + S.ranks.size() * 2ull + S.ml.size();  // + 8*events added after the run
-  c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events + 44*rows added after the run
+  c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events added after the run; rows: 44 B each
 }
 
 void run_kernels(mkp_ctx* c, bool time_kernels) {
   MkpRunParams& P = c->prm;
-  ShardHost& S = c->shard;
   if (c->row_cap == 0) {
     uint64_t guess = c->has_focus ? 1u << 20 : (uint64_t)c->stats.n_positions * 2 + 1024;
     c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess, 1ull << 28));
@@ -136,11 +142,13 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
-                                &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2), "pileup launch");
+                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>()), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_tiles, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
+    hip_check(mkp_launch_rows(c->stream, c->lds_rows_bytes, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
+                              &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2), "rows launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
+    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_tiles, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
+    if (time_kernels) hip_check(hipEventRecord(c->ev[4], c->stream), "event");
     uint32_t h[4];
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     hip_check(hipStreamSynchronize(c->stream), "kernel sync");
@@ -149,8 +157,9 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     if (h[2] & 4u) throw Error(MKP_E_UNSUPPORTED, "a pileup column is deeper than max_depth; htslib's maxcnt read-dropping is not reproduced");
     c->stats.n_rows = h[1];
     if (time_kernels) {
-      float a = 0, b = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event"); hip_check(hipEventElapsedTime(&d, c->ev[2], c->ev[3]), "event");
-      c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.gather_kernel_ms = d; c->stats.kernel_ms = a + b + d;
+      float a = 0, b = 0, r = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
+      hip_check(hipEventElapsedTime(&r, c->ev[2], c->ev[3]), "event"); hip_check(hipEventElapsedTime(&d, c->ev[3], c->ev[4]), "event");
+      c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.rows_kernel_ms = r; c->stats.gather_kernel_ms = d; c->stats.kernel_ms = a + b + r + d;
     }
     return;
   }
@@ -215,7 +224,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tile_ids,
-                    &c->d_tile_first, &c->d_tile_last, &c->d_prm, &c->d_read_ids, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
+                    &c->d_tile_first, &c->d_tile_last, &c->d_prm, &c->d_read_ids, &c->d_tally, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -278,7 +287,8 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
     run_kernels(c, true);
     fetch_rows(c, out);
     c->stats.alg_bytes_decode += 8ull * c->stats.n_events;
-    c->stats.alg_bytes_pileup += 8ull * c->stats.n_events + 44ull * c->stats.n_rows;
+    c->stats.alg_bytes_pileup += 8ull * c->stats.n_events;
+    c->stats.alg_bytes_rows = 44ull * c->stats.n_rows;
   });
 }
 
@@ -286,9 +296,9 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
   if (!c) return MKP_E_INVALID;
   return guarded(c, [&]() {
     if (!c->resident) throw Error(MKP_E_INVALID, "no resident shard: call mkp_shard_run once first");
-    double d = 0, p = 0, g = 0;
-    for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; g += c->stats.gather_kernel_ms; }
-    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.gather_kernel_ms = g / iters; c->stats.kernel_ms = (d + p + g) / iters; }
+    double d = 0, p = 0, r = 0, g = 0;
+    for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; r += c->stats.rows_kernel_ms; g += c->stats.gather_kernel_ms; }
+    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = r / iters; c->stats.gather_kernel_ms = g / iters; c->stats.kernel_ms = (d + p + r + g) / iters; }
     if (out) fetch_rows(c, out);
   });
 }

@@ -318,7 +318,7 @@ int run(const Args& a, std::string* msg) {
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       mkp_rows rows; must(mkp_shard_run(ctx, &rows));
       wr.write(rec.name, rows);
-      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
+      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms + st.rows_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }

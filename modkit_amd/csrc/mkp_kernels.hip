@@ -1130,22 +1130,22 @@ __device__ __forceinline__ uint32_t event_lower_bound(const MkpEvent* __restrict
   return lo + (uint32_t)__popcll(__ballot(valid && p < key));
 }
 
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS)
+// mkp_pileup_tiles — accumulate.  Two 1024-thread workgroups per CU (8 waves per SIMD).  LDS holds the tile's tallies as
+// [row][position] u32 with the '+' strand tally in the low and the '-' strand tally in the high 16 bits (column depth
+// < 65536 is checked by the host), rows = the strand tally's counters followed by the observed-code slots; consecutive
+// positions sit on consecutive banks.  After the tile's reads are in, the packed tallies are streamed to HBM and
+// mkp_emit_rows turns them into rows.  (Sums are exact in 32-bit arithmetic whatever the order of +/- updates.)
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8)
 mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
-                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
-                 uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
-                 uint32_t* __restrict__ dev_err) {
+                 const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t wave_tot[PILEUP_WAVES];
-  __shared__ uint32_t tile_base;
   __shared__ uint32_t next_read;
   const MkpRunParams& prm = *prmp;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
-  // Persistent workgroups: the grid is one workgroup per CU and each walks its tiles (v = b, b + grid, ...), so there
-  // is no workgroup launch/drain gap between tiles.
+  // Persistent workgroups: each walks its tiles (v = b, b + grid, ...).
   for (uint32_t vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
   uint32_t bid = vb;
   {
@@ -1158,9 +1158,9 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   const uint32_t n_counters = prm.n_counters, n_slots = prm.n_slots;
   const int32_t T0 = prm.win_start + (int32_t)(tile * T);
   const int32_t T0h = T0 - MKP_HALO, T1h = T0 + (int32_t)T + MKP_HALO;
-  TileView tv; tv.TH = TH; tv.n_counters = n_counters; tv.n_slots = n_slots;
-  tv.cnt = lds; tv.obs = (int32_t*)(lds + 2u * n_counters * TH);
-  const uint32_t lds_words = 2u * (n_counters + n_slots) * TH;
+  uint32_t* __restrict__ tal = lds;                       // [n_counters + n_slots][TH], packed
+  uint32_t* __restrict__ obs = lds + n_counters * TH;     // observed-code difference arrays
+  const uint32_t lds_words = (n_counters + n_slots) * TH;
   const int lane = lane_id();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // per-wave scratch behind the tallies: op-start bitmap over the tile's positions + CIGAR compaction buffer
@@ -1189,8 +1189,8 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
       const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
       while (m) {
         const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-        atomicAdd(&tv.obs[((uint32_t)lane * n_slots + sl) * TH + (uint32_t)(a - T0h)], 1);
-        if (b < T1h) atomicAdd(&tv.obs[((uint32_t)lane * n_slots + sl) * TH + (uint32_t)(b - T0h)], -1);
+        atomicAdd(&obs[sl * TH + (uint32_t)(a - T0h)], lane ? 0x10000u : 1u);
+        if (b < T1h) atomicAdd(&obs[sl * TH + (uint32_t)(b - T0h)], 0u - (lane ? 0x10000u : 1u));
       }
     }
     // the read's call events inside the tile (sorted by position); issued first so their loads overlap the depth walk
@@ -1203,9 +1203,9 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
         if (in) {
           const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
-          atomicAdd(&tv.cnt[(((e.info >> 8) & 1u) * n_counters + (e.info & 0xffu)) * TH + i], 1u);
+          atomicAdd(&tal[(e.info & 0xffu) * TH + i], (e.info & 0x100u) ? 0x10000u : 1u);
           if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
-            atomicAdd(&tv.cnt[(((e.info >> 11) & 1u) * n_counters + MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0xffffffffu);
+            atomicAdd(&tal[(MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0u - ((e.info & 0x800u) ? 0x10000u : 1u));
         }
         if (!__any(in)) break;
       }
@@ -1213,7 +1213,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
     // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
     uint32_t q_run = 0; int32_t r_run = h.ref_start;
-    uint32_t* __restrict__ strand_base = tv.cnt + aln * n_counters * TH;   // rows NC[0..3], DEL of this alignment strand
+    const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
     const unsigned long long LUT = aln ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;  // BAM nibble -> NoCall row (complemented on '-'), f = not ACGT
     const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 28) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
@@ -1234,16 +1234,16 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
             uint32_t m = ro.obs[s];
             while (m) {
               const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-              atomicAdd(&tv.obs[(s * n_slots + sl) * TH + (uint32_t)(a - T0h)], -1);
-              if (b < T1h) atomicAdd(&tv.obs[(s * n_slots + sl) * TH + (uint32_t)(b - T0h)], 1);
+              atomicAdd(&obs[sl * TH + (uint32_t)(a - T0h)], 0u - (s ? 0x10000u : 1u));
+              if (b < T1h) atomicAdd(&obs[sl * TH + (uint32_t)(b - T0h)], s ? 0x10000u : 1u);
             }
           }
         }
         if (op == 2) {  // deletion columns (alignment.is_del()): +1/-1 on the strand's DEL row, summed after the barrier
           const int32_t a = min(max(rs, T0h), T1h), b = min(max(rs + (int32_t)rlen, T0h), T1h);
           if (a < b) {
-            atomicAdd(&strand_base[MKP_C_DEL * TH + (uint32_t)(a - T0h)], 1u);
-            if (b < T1h) atomicAdd(&strand_base[MKP_C_DEL * TH + (uint32_t)(b - T0h)], 0xffffffffu);
+            atomicAdd(&tal[MKP_C_DEL * TH + (uint32_t)(a - T0h)], inc);
+            if (b < T1h) atomicAdd(&tal[MKP_C_DEL * TH + (uint32_t)(b - T0h)], 0u - inc);
           }
         }
         // compact the window's reference-consuming ops to the low lanes: {start, packed(query offset, kind)}
@@ -1298,7 +1298,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
             const uint32_t rl = 64u * kk + (uint32_t)lane;
             bool ok = rowt < 8u;
             if (edge) { const int32_t pos = T0h + (int32_t)rl; ok = ok && pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1; }
-            if (ok) atomicAdd(&strand_base[__umul24(rowt, TH) + rl], 1u);
+            if (ok) atomicAdd(&tal[__umul24(rowt, TH) + rl], inc);
           }
         }
         if (mark) bm[mrel >> 5] = 0;
@@ -1307,23 +1307,65 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     }
   }
   __syncthreads();
-  // difference arrays -> counts (one wave per array): observed codes per (strand, slot), deletions per strand
+  // the tile's packed tallies go to HBM (coalesced); mkp_emit_rows reads them back
   {
-    const uint32_t n_arr = 2u * n_slots + 2u;
-    for (uint32_t a = wave; a < n_arr; a += PILEUP_WAVES) {
-      int32_t* arr = a < 2u * n_slots ? tv.obs + a * TH : (int32_t*)tv.cnt + ((a - 2u * n_slots) * n_counters + MKP_C_DEL) * TH;
-      uint32_t carry = 0;
-      for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
-        uint32_t v = (b0 + lane < TH) ? (uint32_t)arr[b0 + lane] : 0u;
-        uint32_t inc = wave_incl_scan(v);
-        if (b0 + lane < TH) arr[b0 + lane] = (int32_t)(inc + carry);
-        carry += __shfl(inc, 63, 64);
-      }
+    uint32_t* __restrict__ dst = tally_out + (size_t)tix * lds_words;
+    for (uint32_t k = threadIdx.x; k < lds_words; k += PILEUP_THREADS) dst[k] = lds[k];
+  }
+  __syncthreads();   // the tallies are re-zeroed for the next tile
+  }
+}
+
+// mkp_emit_rows — one workgroup per tile: unpack the tile's tallies into LDS ([strand][counter][position] u32),
+// prefix-sum the difference arrays (observed codes, deletions; packed sums are exact, so they are summed packed and then
+// split), and emit rows (FeatureVector::decode 412-446, add_tally_to_counts 283-410, combine_strand_features 469-561)
+// with a block-wide scan for compaction; each thread owns a contiguous run of positions so row order = position order.
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS)
+mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
+              const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
+              uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
+              uint32_t* __restrict__ dev_err) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t wave_tot[PILEUP_WAVES];
+  __shared__ uint32_t tile_base;
+  const MkpRunParams& prm = *prmp;
+  const uint32_t tix = blockIdx.x;
+  const uint32_t tile = tile_ids[tix];
+  const uint32_t T = prm.tile, TH = T + 2 * MKP_HALO;
+  const uint32_t n_counters = prm.n_counters, n_slots = prm.n_slots;
+  const int32_t T0 = prm.win_start + (int32_t)(tile * T);
+  const int32_t T0h = T0 - MKP_HALO;
+  TileView tv; tv.TH = TH; tv.n_counters = n_counters; tv.n_slots = n_slots;
+  tv.cnt = lds; tv.obs = (int32_t*)(lds + 2u * n_counters * TH);
+  const int lane = lane_id();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t* __restrict__ src = tally_in + (size_t)tix * (n_counters + n_slots) * TH;
+  for (uint32_t r = 0; r < n_counters + n_slots; r++) {
+    const bool diff = r == MKP_C_DEL || r >= n_counters;   // difference arrays stay packed (in the '+' array) until they are summed
+    uint32_t* __restrict__ plus = r < n_counters ? tv.cnt + r * TH : (uint32_t*)tv.obs + (r - n_counters) * TH;
+    uint32_t* __restrict__ minus = r < n_counters ? tv.cnt + (n_counters + r) * TH : (uint32_t*)tv.obs + (n_slots + r - n_counters) * TH;
+    for (uint32_t i = threadIdx.x; i < TH; i += PILEUP_THREADS) {
+      const uint32_t v = src[r * TH + i];
+      if (diff) plus[i] = v; else { plus[i] = v & 0xffffu; minus[i] = v >> 16; }
+    }
+  }
+  __syncthreads();
+  // difference arrays -> counts (one wave per array): deletions, then observed codes per slot
+  for (uint32_t a = wave; a < n_slots + 1u; a += PILEUP_WAVES) {
+    uint32_t* __restrict__ plus = a == 0 ? tv.cnt + MKP_C_DEL * TH : (uint32_t*)tv.obs + (a - 1u) * TH;
+    uint32_t* __restrict__ minus = a == 0 ? tv.cnt + (n_counters + MKP_C_DEL) * TH : (uint32_t*)tv.obs + (n_slots + a - 1u) * TH;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
+      const uint32_t v = (b0 + lane < TH) ? plus[b0 + lane] : 0u;
+      const uint32_t inc = wave_incl_scan(v);
+      const uint32_t val = inc + carry;
+      if (b0 + lane < TH) { plus[b0 + lane] = val & 0xffffu; minus[b0 + lane] = val >> 16; }
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
   }
   __syncthreads();
   // rows: each thread owns a contiguous run of positions so row order == position order
-  if (prm.debug_skip & 4u) { if (threadIdx.x == 0) { tile_row_off[tix] = 0; tile_row_cnt[tix] = 0; } __syncthreads(); continue; }
+  if (prm.debug_skip & 4u) { if (threadIdx.x == 0) { tile_row_off[tix] = 0; tile_row_cnt[tix] = 0; } return; }
   const uint32_t per = (T + PILEUP_THREADS - 1) / PILEUP_THREADS;
   const uint32_t i0 = threadIdx.x * per;
   uint32_t my_rows = 0;
@@ -1360,8 +1402,6 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     if (p < prm.win_start || p >= prm.win_end) continue;
     wr += rows_at<true>(tv, prm, focus, combos, T0h, li + MKP_HALO, rows, wr);
   }
-  }
-  __syncthreads();   // the tallies are re-zeroed for the next tile
   }
 }
 
@@ -1426,20 +1466,28 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_pileup_set_lds(uint32_t bytes) {
-  return hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, uint32_t rows_bytes) {
+  hipError_t e = hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_bytes);
 }
 
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
-                                        const uint32_t* tile_last, uint32_t n_tiles, const uint8_t* focus, const MkpCombo* combos,
-                                        const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
-                                        uint32_t* tile_row_cnt, uint32_t* dev_err) {
+                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally) {
   if (!n_tiles) return hipSuccess;
-  // n_tiles/8 must stay the XCD remap's unit: the grid is a multiple of 8 (one workgroup per CU, 256 CUs)
-  const uint32_t grid = n_tiles < 256u ? n_tiles : 256u;
+  const uint32_t grid = n_tiles < 512u ? n_tiles : 512u;   // two persistent workgroups per CU
   hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
-                     tile_last, n_tiles, focus, combos, prm_dev, *rows, row_cursor, tile_row_off, tile_row_cnt, dev_err);
+                     tile_last, n_tiles, prm_dev, tally);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mkp_launch_rows(hipStream_t st, uint32_t lds_bytes, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, const uint8_t* focus,
+                                      const MkpCombo* combos, const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
+                                      uint32_t* tile_row_cnt, uint32_t* dev_err) {
+  if (!n_tiles) return hipSuccess;
+  hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, tally, tile_ids, n_tiles, focus, combos, prm_dev, *rows, row_cursor,
+                     tile_row_off, tile_row_cnt, dev_err);
   return hipGetLastError();
 }
 
