@@ -9,10 +9,11 @@ using namespace mkp;
 extern "C" {
 hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
-hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, uint32_t rows_bytes);
+hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
+uint32_t mkp_rows_segments(uint32_t tile);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
                              const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/);
-hipError_t mkp_launch_rows(hipStream_t, uint32_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
+hipError_t mkp_launch_rows(hipStream_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, uint32_t /*tile*/, uint32_t /*arrays*/, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
                            const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
@@ -80,7 +81,6 @@ void make_resident(mkp_ctx* c) {
   if (!T || T > maxT) T = std::min<uint32_t>(maxT, 4096u);
   T = std::max<uint32_t>(64u, T & ~63u);
   P.tile = T; c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_pos, T + 2 * MKP_HALO) * 4u;
-  c->lds_rows_bytes = 2u * words_per_pos * (T + 2 * MKP_HALO) * 4u;
   const uint64_t win = (uint64_t)(S.win_end - S.win_start);
   P.n_tiles_total = (uint32_t)((win + T - 1) / T);
   // tile -> [first,last) reads.  Reads are coordinate sorted; prefix-max of ends bounds the first candidate.
@@ -110,10 +110,11 @@ void make_resident(mkp_ctx* c) {
   if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
-  c->d_tile_row_off.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_tiles + 1) * 4);
+  c->n_segs = c->n_tiles * mkp_rows_segments(P.tile);   // row segments: 256 positions each, in genome order
+  c->d_tile_row_off.ensure((size_t)(c->n_segs + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_segs + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_segs + 1) * 4);
   c->d_misc.ensure(64);
   c->d_tally.ensure(std::max<size_t>((size_t)c->n_tiles * words_per_pos * (T + 2 * MKP_HALO) * 4u, 16));
-  hip_check(mkp_pileup_set_lds(c->lds_bytes, c->lds_rows_bytes), "hipFuncSetAttribute(max dynamic LDS)");
+  hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
   c->resident = true;
@@ -144,10 +145,10 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                 c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>()), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_rows(c->stream, c->lds_rows_bytes, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
+    hip_check(mkp_launch_rows(c->stream, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, P.tile, P.n_counters + P.n_slots, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
                               &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2), "rows launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
-    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_tiles, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
+    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_segs, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[4], c->stream), "event");
     uint32_t h[4];
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");

@@ -988,12 +988,12 @@ extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast2(DECODE_PARAMS
 // ----------------------------------------------------------------------------------------------
 struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
 
-struct TileView {
-  uint32_t* cnt;    // [2][n_counters][TH]
-  int32_t* obs;     // [2][n_slots][TH]
-  uint32_t TH, n_counters, n_slots;
-  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return cnt[(s * n_counters + cid) * TH + i]; }
-  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return obs[(s * n_slots + sl) * TH + i]; }
+struct TileView {   // packed tallies of a run of positions staged in LDS: [counter | slot][W], '+' tally in the low, '-' in the high 16 bits;
+                    // position index i (tile-relative, halo included) lives at column i - i0
+  const uint32_t* pk;
+  uint32_t W, i0, n_counters, n_slots;
+  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return (pk[cid * W + (i - i0)] >> (16u * s)) & 0xffffu; }
+  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return (int32_t)((pk[(n_counters + sl) * W + (i - i0)] >> (16u * s)) & 0xffffu); }
 };
 
 // one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
@@ -1307,6 +1307,18 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     }
   }
   __syncthreads();
+  // difference arrays -> counts, in place and still packed (the sums are exact): deletions, then observed codes per slot
+  for (uint32_t a = wave; a < n_slots + 1u; a += PILEUP_WAVES) {
+    uint32_t* __restrict__ arr = a == 0 ? tal + MKP_C_DEL * TH : obs + (a - 1u) * TH;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
+      const uint32_t v = (b0 + lane < TH) ? arr[b0 + lane] : 0u;
+      const uint32_t sc = wave_incl_scan(v);
+      if (b0 + lane < TH) arr[b0 + lane] = sc + carry;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    }
+  }
+  __syncthreads();
   // the tile's packed tallies go to HBM (coalesced); mkp_emit_rows reads them back
   {
     uint32_t* __restrict__ dst = tally_out + (size_t)tix * lds_words;
@@ -1316,115 +1328,103 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
   }
 }
 
-// mkp_emit_rows — one workgroup per tile: unpack the tile's tallies into LDS ([strand][counter][position] u32),
-// prefix-sum the difference arrays (observed codes, deletions; packed sums are exact, so they are summed packed and then
-// split), and emit rows (FeatureVector::decode 412-446, add_tally_to_counts 283-410, combine_strand_features 469-561)
-// with a block-wide scan for compaction; each thread owns a contiguous run of positions so row order = position order.
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS)
-mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_tiles,
+// mkp_emit_rows — one 256-thread workgroup per segment of ROWS_SEG consecutive positions of a tile.  The segment's packed
+// tallies (plus a 16-position halo each side for strand combining) and the run parameters are staged in LDS with all
+// loads in flight together; every thread then owns ROWS_PER_THREAD consecutive positions: rows of FeatureVector::decode
+// (412-446), add_tally_to_counts (283-410) and combine_strand_features (469-561), compacted with a block scan.
+// Segment order = position order; mkp_gather_rows concatenates the segments.
+#define ROWS_THREADS 256
+#define ROWS_PER_THREAD 4
+#define ROWS_SEG (ROWS_THREADS * ROWS_PER_THREAD)
+extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
+mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
               const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
-              uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
+              uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
               uint32_t* __restrict__ dev_err) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t wave_tot[PILEUP_WAVES];
-  __shared__ uint32_t tile_base;
-  const MkpRunParams& prm = *prmp;
-  const uint32_t tix = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint32_t seg_lds[];
+  __shared__ uint32_t wave_tot[ROWS_THREADS / 64];
+  __shared__ uint32_t seg_base;
+  // the run parameters (slot / counter tables the row logic indexes per lane) are read from an LDS copy, not from global memory
+  __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
+  for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += ROWS_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
+  const uint32_t seg = blockIdx.x;
+  const uint32_t tix = seg / segs_per_tile;
   const uint32_t tile = tile_ids[tix];
-  const uint32_t T = prm.tile, TH = T + 2 * MKP_HALO;
-  const uint32_t n_counters = prm.n_counters, n_slots = prm.n_slots;
+  const uint32_t T = prmp->tile, TH = T + 2 * MKP_HALO;
+  const uint32_t n_arr = prmp->n_counters + prmp->n_slots;
+  const uint32_t SEGW = ROWS_SEG + 2 * MKP_HALO;
+  const uint32_t i_first = (seg % segs_per_tile) * ROWS_SEG;   // tile-relative index (halo included) of the first staged column
+  {
+    const uint32_t* __restrict__ src = tally_in + (size_t)tix * n_arr * TH;
+    for (uint32_t r = 0; r < n_arr; r++)
+      for (uint32_t cidx = threadIdx.x; cidx < SEGW; cidx += ROWS_THREADS) { const uint32_t gi = i_first + cidx; seg_lds[r * SEGW + cidx] = gi < TH ? src[r * TH + gi] : 0u; }
+  }
+  __syncthreads();
+  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
+  const uint32_t n_counters = prm.n_counters;
   const int32_t T0 = prm.win_start + (int32_t)(tile * T);
   const int32_t T0h = T0 - MKP_HALO;
-  TileView tv; tv.TH = TH; tv.n_counters = n_counters; tv.n_slots = n_slots;
-  tv.cnt = lds; tv.obs = (int32_t*)(lds + 2u * n_counters * TH);
+  TileView tv; tv.W = SEGW; tv.i0 = i_first; tv.n_counters = n_counters; tv.n_slots = prm.n_slots; tv.pk = seg_lds;
   const int lane = lane_id();
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t* __restrict__ src = tally_in + (size_t)tix * (n_counters + n_slots) * TH;
-  for (uint32_t r = 0; r < n_counters + n_slots; r++) {
-    const bool diff = r == MKP_C_DEL || r >= n_counters;   // difference arrays stay packed (in the '+' array) until they are summed
-    uint32_t* __restrict__ plus = r < n_counters ? tv.cnt + r * TH : (uint32_t*)tv.obs + (r - n_counters) * TH;
-    uint32_t* __restrict__ minus = r < n_counters ? tv.cnt + (n_counters + r) * TH : (uint32_t*)tv.obs + (n_slots + r - n_counters) * TH;
-    for (uint32_t i = threadIdx.x; i < TH; i += PILEUP_THREADS) {
-      const uint32_t v = src[r * TH + i];
-      if (diff) plus[i] = v; else { plus[i] = v & 0xffffu; minus[i] = v >> 16; }
-    }
-  }
-  __syncthreads();
-  // difference arrays -> counts (one wave per array): deletions, then observed codes per slot
-  for (uint32_t a = wave; a < n_slots + 1u; a += PILEUP_WAVES) {
-    uint32_t* __restrict__ plus = a == 0 ? tv.cnt + MKP_C_DEL * TH : (uint32_t*)tv.obs + (a - 1u) * TH;
-    uint32_t* __restrict__ minus = a == 0 ? tv.cnt + (n_counters + MKP_C_DEL) * TH : (uint32_t*)tv.obs + (n_slots + a - 1u) * TH;
-    uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
-      const uint32_t v = (b0 + lane < TH) ? plus[b0 + lane] : 0u;
-      const uint32_t inc = wave_incl_scan(v);
-      const uint32_t val = inc + carry;
-      if (b0 + lane < TH) { plus[b0 + lane] = val & 0xffffu; minus[b0 + lane] = val >> 16; }
-      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    }
-  }
-  __syncthreads();
-  // rows: each thread owns a contiguous run of positions so row order == position order
-  if (prm.debug_skip & 4u) { if (threadIdx.x == 0) { tile_row_off[tix] = 0; tile_row_cnt[tix] = 0; } return; }
-  const uint32_t per = (T + PILEUP_THREADS - 1) / PILEUP_THREADS;
-  const uint32_t i0 = threadIdx.x * per;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t li0 = i_first + threadIdx.x * ROWS_PER_THREAD;   // first of this thread's positions, tile-relative (no halo)
   uint32_t my_rows = 0;
   bool deep = false;
-  for (uint32_t k = 0; k < per; k++) {
-    const uint32_t li = i0 + k;
-    if (li >= T) break;
+#pragma unroll
+  for (uint32_t j = 0; j < ROWS_PER_THREAD; j++) {
+    const uint32_t li = li0 + j;
     const int32_t p = T0 + (int32_t)li;
-    if (p < prm.win_start || p >= prm.win_end) continue;
+    if (!(li < T && p >= prm.win_start && p < prm.win_end) || (prm.debug_skip & (4u | 512u))) continue;
     const uint32_t i = li + MKP_HALO;
     uint32_t depth = 0;
     for (uint32_t s = 0; s < 2; s++) for (uint32_t c = 0; c < n_counters; c++) depth += tv.c(s, c, i);
-    if (depth > prm.max_depth) deep = true;
+    deep |= depth > prm.max_depth;
     my_rows += rows_at<false>(tv, prm, focus, combos, T0h, i, rows, 0);
   }
   if (deep) atomicOr(dev_err, ERR_DEPTH);
-  uint32_t inc = wave_incl_scan(my_rows);
+  const uint32_t inc = wave_incl_scan(my_rows);
   if (lane == 63) wave_tot[wave] = inc;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t s = 0;
-    for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) { uint32_t t = wave_tot[w2]; wave_tot[w2] = s; s += t; }
-    uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+    for (uint32_t w2 = 0; w2 < ROWS_THREADS / 64; w2++) { const uint32_t t = wave_tot[w2]; wave_tot[w2] = s; s += t; }
+    const uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
     if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
-    tile_base = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s;
+    seg_base = base; seg_row_off[seg] = base; seg_row_cnt[seg] = s;
   }
   __syncthreads();
-  if (tile_row_cnt[tix] != 0) {
-  uint32_t wr = tile_base + wave_tot[wave] + inc - my_rows;
-  for (uint32_t k = 0; k < per; k++) {
-    const uint32_t li = i0 + k;
-    if (li >= T) break;
-    const int32_t p = T0 + (int32_t)li;
-    if (p < prm.win_start || p >= prm.win_end) continue;
-    wr += rows_at<true>(tv, prm, focus, combos, T0h, li + MKP_HALO, rows, wr);
-  }
+  if (seg_row_cnt[seg] != 0 && my_rows && !(prm.debug_skip & 256u)) {
+    uint32_t wr = seg_base + wave_tot[wave] + inc - my_rows;
+#pragma unroll
+    for (uint32_t j = 0; j < ROWS_PER_THREAD; j++) {
+      const uint32_t li = li0 + j;
+      const int32_t p = T0 + (int32_t)li;
+      if (!(li < T && p >= prm.win_start && p < prm.win_end)) continue;
+      wr += rows_at<true>(tv, prm, focus, combos, T0h, li + MKP_HALO, rows, wr);
+    }
   }
 }
 
 // ----------------------------------------------------------------------------------------------
 // Order the per-tile row segments by tile index.  Block 0 computes the exclusive scan of the
 // tile counts (n_tiles is small), then every block copies its tiles' segments.
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(1024)
 mkp_scan_tiles(const uint32_t* __restrict__ tile_row_cnt, uint32_t n_tiles, uint32_t* __restrict__ tile_dst_off, uint32_t* __restrict__ total_rows) {
   __shared__ uint32_t carry_s;
-  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t wtot[16];
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t b0 = 0; b0 < n_tiles; b0 += 256) {
-    uint32_t k = b0 + threadIdx.x;
-    uint32_t v = k < n_tiles ? tile_row_cnt[k] : 0u;
-    uint32_t inc = wave_incl_scan(v);
+  for (uint32_t b0 = 0; b0 < n_tiles; b0 += 1024) {
+    const uint32_t k = b0 + threadIdx.x;
+    const uint32_t v = k < n_tiles ? tile_row_cnt[k] : 0u;
+    const uint32_t inc = wave_incl_scan(v);
     if (lane_id() == 63) wtot[threadIdx.x >> 6] = inc;
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t w2 = 0; w2 < (threadIdx.x >> 6); w2++) woff += wtot[w2];
     if (k < n_tiles) tile_dst_off[k] = carry_s + woff + inc - v;
     __syncthreads();
-    if (threadIdx.x == 255) carry_s += woff + inc;
+    if (threadIdx.x == 1023) carry_s += woff + inc;
     __syncthreads();
   }
   if (threadIdx.x == 0) *total_rows = carry_s;
@@ -1466,10 +1466,8 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, uint32_t rows_bytes) {
-  hipError_t e = hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_bytes);
+extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
+  return hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
 }
 
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
@@ -1482,18 +1480,24 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, cons
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_launch_rows(hipStream_t st, uint32_t lds_bytes, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, const uint8_t* focus,
-                                      const MkpCombo* combos, const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* tile_row_off,
-                                      uint32_t* tile_row_cnt, uint32_t* dev_err) {
+extern "C" uint32_t mkp_rows_segments(uint32_t tile) { return (tile + ROWS_SEG - 1) / ROWS_SEG; }
+
+extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, uint32_t tile, uint32_t n_arr, const uint8_t* focus,
+                                      const MkpCombo* combos, const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* seg_row_off,
+                                      uint32_t* seg_row_cnt, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
-  hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, tally, tile_ids, n_tiles, focus, combos, prm_dev, *rows, row_cursor,
-                     tile_row_off, tile_row_cnt, dev_err);
+  const uint32_t spt = mkp_rows_segments(tile);
+  const uint32_t lds_bytes = n_arr * (ROWS_SEG + 2 * MKP_HALO) * 4u;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+  hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
+                     seg_row_off, seg_row_cnt, dev_err);
   return hipGetLastError();
 }
 
 extern "C" hipError_t mkp_launch_gather(hipStream_t st, const uint32_t* tile_row_off, const uint32_t* tile_row_cnt, uint32_t* tile_dst_off,
                                         uint32_t n_tiles, uint32_t* total_rows, const MkpRowsDev* src, const MkpRowsDev* dst) {
-  hipLaunchKernelGGL(mkp_scan_tiles, dim3(1), dim3(256), 0, st, tile_row_cnt, n_tiles, tile_dst_off, total_rows);
+  hipLaunchKernelGGL(mkp_scan_tiles, dim3(1), dim3(1024), 0, st, tile_row_cnt, n_tiles, tile_dst_off, total_rows);
   if (n_tiles) {
     uint32_t grid = n_tiles < 2048u ? n_tiles : 2048u;
     hipLaunchKernelGGL(mkp_gather_rows, dim3(grid), dim3(256), 0, st, tile_row_off, tile_row_cnt, tile_dst_off, n_tiles, *src, *dst);
