@@ -77,28 +77,38 @@ __device__ __forceinline__ int find_rank(const uint32_t* __restrict__ a, uint32_
   return (lo < n && a[lo] == key) ? (int)lo : -1;
 }
 
-__device__ __forceinline__ float getk(const float* p, int k) {  // select chain (kept as v_cndmask, not a switch)
-  float r = p[0];
-  r = (k == 1) ? p[1] : r; r = (k == 2) ? p[2] : r; r = (k == 3) ? p[3] : r;
-  return r;
+// Four f32 values addressed by a small index, kept as named scalars: a `float[4]` indexed by a lane-varying value is
+// demoted to scratch memory by the compiler (a select chain over array elements becomes an indexed load), which put
+// scratch loads into the per-call path.  With scalars the selects stay v_cndmask.
+struct F4 { float v0, v1, v2, v3; };
+__device__ __forceinline__ float& at(F4& f, int k) { return k == 0 ? f.v0 : k == 1 ? f.v1 : k == 2 ? f.v2 : f.v3; }   // k is a compile-time constant at every call site (unrolled loops)
+__device__ __forceinline__ float at(const F4& f, int k) { return k == 0 ? f.v0 : k == 1 ? f.v1 : k == 2 ? f.v2 : f.v3; }
+__device__ __forceinline__ float getk(const F4& p, int k) {   // OR of masked bit patterns: cannot be folded into an indexed (scratch) load
+  const uint32_t r = (k == 0 ? __float_as_uint(p.v0) : 0u) | (k == 1 ? __float_as_uint(p.v1) : 0u) | (k == 2 ? __float_as_uint(p.v2) : 0u) | (k == 3 ? __float_as_uint(p.v3) : 0u);
+  return __uint_as_float(r);
 }
-__device__ __forceinline__ void addk(float* p, int k, float v) { p[0] = k == 0 ? p[0] + v : p[0]; p[1] = k == 1 ? p[1] + v : p[1]; p[2] = k == 2 ? p[2] + v : p[2]; p[3] = k == 3 ? p[3] + v : p[3]; }
+// p[kk] = cond ? v : p[kk], as bit-field inserts under an all-ones / all-zeros mask (again: nothing the compiler can turn into an indexed store)
+__device__ __forceinline__ float bsel(bool c, float a, float b) { const uint32_t m = c ? 0xffffffffu : 0u; return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m)); }
+__device__ __forceinline__ void setk(F4& p, uint32_t kk, bool cond, float v) {
+  p.v0 = bsel(cond && kk == 0u, v, p.v0); p.v1 = bsel(cond && kk == 1u, v, p.v1); p.v2 = bsel(cond && kk == 2u, v, p.v2); p.v3 = bsel(cond && kk == 3u, v, p.v3);
+}
+__device__ __forceinline__ void addk(F4& p, int k, float v) { p.v0 = k == 0 ? p.v0 + v : p.v0; p.v1 = k == 1 ? p.v1 + v : p.v1; p.v2 = k == 2 ? p.v2 + v : p.v2; p.v3 = k == 3 ? p.v3 + v : p.v3; }
 
 // ----------------------------------------------------------------------------------------------
 // One (mod strand, base) group descriptor as the lane sees it (fetched from the LDS copy of the layout).
-struct GroupRegs { uint32_t misc, slots, cids, member_tags; float thr[MKP_KMAX]; float thr_can; };
+struct GroupRegs { uint32_t misc, slots, cids, member_tags; F4 thr; float thr_can; };
 __device__ __forceinline__ GroupRegs load_group(const uint32_t* g) {
   GroupRegs r;
   const uint4 a = *reinterpret_cast<const uint4*>(g);
   const float4 t = *reinterpret_cast<const float4*>(g + 4);
   r.misc = a.x; r.slots = a.y; r.cids = a.z; r.member_tags = a.w;
-  r.thr[0] = t.x; r.thr[1] = t.y; r.thr[2] = t.z; r.thr[3] = t.w;
+  r.thr.v0 = t.x; r.thr.v1 = t.y; r.thr.v2 = t.z; r.thr.v3 = t.w;
   r.thr_can = __uint_as_float(g[8]);
   return r;
 }
 
 // ReDistribute collapse (BaseModProbs::into_collapsed, mod_bam.rs:558-600) in the map's iteration order.
-__device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32_t pv, float* pk, int kmax) {
+__device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32_t pv, F4& pk, int kmax) {
   const int n_pre = (int)(pv & 7u);
   const int x = MKP_G_COLL(g.misc);
   bool present = false;
@@ -115,7 +125,7 @@ __device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32
 // Returns 0 Filtered, 1 Canonical, 2+k Modified(local code k); *obs gets the slots of the codes in the map the
 // caller sees (read_cache.rs:171-179).  pv = the group's entry for this hit pattern.
 // kmax: wave-uniform bound on the number of codes in the map (MKP_KMAX when the group differs per lane)
-__device__ __forceinline__ int call_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX) {
+__device__ __forceinline__ int call_group(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX) {
   if (collapse) collapse_redistribute(g, pv, pk, kmax);
   const int n_post = (int)((pv >> 3) & 7u);
   int best = 0;
@@ -141,7 +151,7 @@ __device__ __forceinline__ int call_group(const GroupRegs& g, uint32_t pv, float
 
 // Threshold sampling: value of BaseModProbs::argmax_base_mod_call after the optional collapse
 // (mod_bam.rs:489-505; read_ids_to_base_mod_probs.rs:67-101, 324-328).
-__device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, float* pk, bool collapse, int kmax = MKP_KMAX) {
+__device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, int kmax = MKP_KMAX) {
   if (collapse) collapse_redistribute(g, pv, pk, kmax);
   const int n_post = (int)((pv >> 3) & 7u);
   float s = 0.0f, best = 0.0f; bool have = false;
@@ -159,18 +169,18 @@ __device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, f
 }
 
 // Per (mod strand) BaseModProbs under construction at one read position.
-struct GState { float pk[MKP_KMAX]; uint32_t H, setmask; };
+struct GState { F4 pk; uint32_t H, setmask; };
 
 // combine_positions_to_probs for one more tag at this position (mod_bam.rs:1037-1054, 629-656)
-__device__ __forceinline__ bool merge_tag(GState& S, const float* ts, uint32_t seen, uint32_t mi) {
+__device__ __forceinline__ bool merge_tag(GState& S, const F4& ts, uint32_t seen, uint32_t mi) {
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) { if (S.setmask & (1u << k)) S.pk[k] = S.pk[k] + ts[k]; else S.pk[k] = ts[k]; }
+  for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) { if (S.setmask & (1u << k)) at(S.pk, k) = at(S.pk, k) + at(ts, k); else at(S.pk, k) = at(ts, k); }
   S.setmask |= seen;
   if (S.H) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < MKP_KMAX; k++) if (S.setmask & (1u << k)) s = s + S.pk[k];
+    for (int k = 0; k < MKP_KMAX; k++) if (S.setmask & (1u << k)) s = s + at(S.pk, k);
     if (s > 1.01f) bad = true;
   }
   S.H |= 1u << mi;
@@ -300,7 +310,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
     grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
 #pragma unroll
-    for (int kq = 0; kq < MKP_KMAX; kq++) grp0.thr[kq] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr[kq])));
+    for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
     grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -429,7 +439,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
       const int b = x < 0 ? -1 : (rev ? 3 - x : x);
       GState S0, S1;
 #pragma unroll
-      for (int k = 0; k < MKP_KMAX; k++) { S0.pk[k] = 0.f; S1.pk[k] = 0.f; }
+      for (int k = 0; k < MKP_KMAX; k++) { at(S0.pk, k) = 0.f; at(S1.pk, k) = 0.f; }
       S0.H = S0.setmask = S1.H = S1.setmask = 0;
       if constexpr (FAST) {
         // one group, distinct codes: every local code is written at most once, straight from ML (quals_to_probs 808-816)
@@ -444,8 +454,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
           for (uint32_t i = 0; i < nc; i++) {
             const float p = ((float)ml[found ? (t_ml[t] + jx * nc + i) : 0u] + 0.5f) / 256.0f;
             const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform
-#pragma unroll
-            for (int k2 = 0; k2 < MKP_KMAX; k2++) if (kk == (uint32_t)k2) S0.pk[k2] = found ? p : S0.pk[k2];
+            setk(S0.pk, kk, found, p);
           }
           S0.H |= found ? (1u << (tmu[t] & 15u)) : 0u;
           S0.setmask |= found ? codes_t[t] : 0u;
@@ -453,7 +462,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
         if (__popc(S0.H) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
           float s = 0.f;
 #pragma unroll
-          for (int k2 = 0; k2 < MKP_KMAX; k2++) if (S0.setmask & (1u << k2)) s = s + S0.pk[k2];
+          for (int k2 = 0; k2 < MKP_KMAX; k2++) if (S0.setmask & (1u << k2)) s = s + at(S0.pk, k2);
           if (s > 1.01f) err = true;
         }
       } else {
@@ -470,14 +479,14 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
         const uint32_t tm = lay->tagmap[t][b];  // [0:3] member index, [4+4i : 8+4i) local code of the tag's i-th code
         const uint32_t mi = tm & 15u;
         // get_base_mod_probs (mod_bam.rs:1242-1263): stride = #codes of the tag
-        float ts[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+        F4 ts = {0.f, 0.f, 0.f, 0.f};
         uint32_t seen = 0;
         for (int i = 0; i < (int)dsc.n_codes; i++) {
           const float p = ((float)ml[t_ml[t] + jx * dsc.n_codes + i] + 0.5f) / 256.0f;  // quals_to_probs 808-816
           const uint32_t kk = (tm >> (4 + 4 * i)) & 15u;
 #pragma unroll
           for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k == kk) {
-            if (seen & (1u << k)) { if (ts[k] + p > 1.01f) err = true; ts[k] = ts[k] + p; } else { ts[k] = p; seen |= 1u << k; }
+            if (seen & (1u << k)) { if (at(ts, k) + p > 1.01f) err = true; at(ts, k) = at(ts, k) + p; } else { at(ts, k) = p; seen |= 1u << k; }
           }
         }
         if (dsc.neg) { if (merge_tag(S1, ts, seen, mi)) err = true; } else { if (merge_tag(S0, ts, seen, mi)) err = true; }
@@ -550,7 +559,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
           const uint32_t gmisc = gp[0];
           const int nm = (int)MKP_G_NMEM(gmisc);
           if (nm == 0) continue;
-          float* spk = sg ? S1.pk : S0.pk;
+          F4& spk = sg ? S1.pk : S0.pk;
           const uint32_t SH = sg ? S1.H : S0.H;
           const uint32_t impl = MKP_G_IMPL(gmisc);
           int pat;
@@ -683,7 +692,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
   grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
 #pragma unroll
-  for (int kq = 0; kq < MKP_KMAX; kq++) grp0.thr[kq] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr[kq])));
+  for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
   grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
   const uint32_t impl0 = MKP_G_IMPL(grp0.misc);
   const int kcodes0 = (int)((grp0.misc >> 20) & 7u);   // codes of the group: bounds every per-code loop
@@ -857,7 +866,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (!__any(pending)) break;
       }
     }
-    float pk[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f};
+    F4 pk = {0.f, 0.f, 0.f, 0.f};
     uint32_t SH = 0, setmask = 0;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -868,8 +877,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if ((uint32_t)i >= t_nc[t]) break;
         const float p = ((float)mlq[t][i] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
         const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
-#pragma unroll
-        for (int k2 = 0; k2 < MKP_KMAX; k2++) if (kk == (uint32_t)k2) pk[k2] = found ? p : pk[k2];
+        setk(pk, kk, found, p);
       }
       SH |= found ? (1u << (tmu[t] & 15u)) : 0u;
       setmask |= found ? codes_t[t] : 0u;
@@ -877,7 +885,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
     if (NT > 1 && __popc(SH) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
       float s = 0.f;
 #pragma unroll
-      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask & (1u << k2)) s = s + pk[k2];
+      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask & (1u << k2)) s = s + at(pk, k2);
       if (s > 1.01f) err = true;
     }
     uint32_t ev_info = 0; float sv = 0.f; bool has_ev = false;
@@ -1107,7 +1115,9 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
 #define PILEUP_THREADS MKP_PILEUP_THREADS
 #define PILEUP_WAVES (PILEUP_THREADS / 64)
 #define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
+#ifndef PILEUP_UNROLL
 #define PILEUP_UNROLL 4
+#endif
 
 // first index in the position-sorted event list `ev[0..n)` whose pos is >= key: 64-way probes, two dependent
 // loads for up to 4096 events instead of a 12-step bisection
@@ -1185,7 +1195,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     const uint8_t* __restrict__ seq = seqs + h.seq_off;
     // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
     if (ro.ok && lane < 2) {
-      uint32_t m = ro.obs[lane];
+      uint32_t m = lane ? ro.obs[1] : ro.obs[0];
       const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
       while (m) {
         const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
@@ -1260,7 +1270,6 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         const uint2 cc = comp[lane];
         const bool cvalid = (uint32_t)lane < nref;
         const int32_t c_rs = (int32_t)cc.x; const uint32_t c_pk = cc.y;
-        const uint32_t cb = (uint32_t)__popcll(__ballot(cvalid && c_rs <= c_lo)) - 1u;  // op covering c_lo
         const bool mark = cvalid && c_rs > c_lo && c_rs < c_hi;
         const uint32_t mrel = (uint32_t)(c_rs - 1 - T0h);   // bit m set <=> an op starts at T0h+m+1: "starts at or before p" = bits strictly below p-T0h
         if (mark) atomicOr(&bm[mrel >> 5], 1u << (mrel & 31u));
