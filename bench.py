@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py — `modkit pileup` hot path on MI355X: genomic positions/s (and bedMethyl rows/s).
 
-A step = one pass of the device pipeline (mkp_decode_reads -> mkp_pileup_tiles -> mkp_scan/gather) over one
-HBM-resident shard.  Workload at every N (weak scaling: one shard of this shape per GPU, disjoint contigs, no
+A step = one pass of the device pipeline (decode kernels -> mkp_pileup_tiles -> mkp_emit_rows -> mkp_scan/gather) over
+one HBM-resident shard.  Workload at every N (weak scaling: one shard of this shape per GPU, disjoint contigs, no
 data-path collective): BASELINE.json configs[1] "C2" — synthetic 1 contig of 5 Mb, 100 000 reads (mean ~4.8 kb,
 ~96x), 5mC-only `C+m?` MM/ML on every CpG of each read, default 10th-percentile threshold (rank 0 estimates it
 with the reference's sampling schedule; broadcast to the other ranks when N>1).
