@@ -2,6 +2,8 @@
 // Data layout in HBM for one shard (a reference window of one contig):
 //   MkpReadHdr  hdr[n_reads]        48 B each, coordinate order
 //   uint32      cigar[]             BAM cigar words (len<<4|op)
+//   uint2       chunk_pfx[]         per read, per 64 CIGAR ops: query / reference offsets at the chunk start (the host walks the
+//                                   CIGAR anyway to get the read's reference span), so a tile starts its walk at the right chunk
 //   uint8       seq[]               BAM 4-bit packed bases, each read 4-byte aligned
 //   MkpTagRef   tagref[]            one per MM tag of each read
 //   uint32      ranks[]             per call: cumulative occurrence index of the tag's fundamental
@@ -39,7 +41,7 @@ struct MkpReadHdr {
   uint32_t flags;       // bit0 reverse; bit1 host-detected tag error (coverage-only read)
   uint32_t event_off;   // index into events[]
   uint32_t event_cap;
-  uint32_t pad;
+  uint32_t chunk_off;   // index into chunk_pfx[]: one {query offset, reference offset} per 64 CIGAR ops of this read
 };
 #define MKP_RF_REVERSE 1u
 #define MKP_RF_BAD 2u

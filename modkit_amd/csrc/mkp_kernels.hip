@@ -1149,7 +1149,7 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8)
 mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
-                 const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out) {
+                 const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
   const MkpRunParams& prm = *prmp;
@@ -1222,12 +1222,29 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     }
     // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
     // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
-    uint32_t q_run = 0; int32_t r_run = h.ref_start;
+    uint32_t q_run = 0; int32_t r_run = h.ref_start; uint32_t c_first = 0;
+    {  // skip the 64-op CIGAR chunks that end before the tile: the host's per-chunk offsets say where the walk starts
+      const uint32_t nch = (h.n_cigar + 63u) >> 6;
+      if (nch > 1 && T0h > h.ref_start) {
+        const uint32_t rel = (uint32_t)(T0h - h.ref_start);
+        for (uint32_t b0 = 0; b0 < nch; b0 += 64) {
+          const uint32_t kidx = b0 + (uint32_t)lane;
+          const uint2 e = kidx < nch ? chunk_pfx[h.chunk_off + kidx] : make_uint2(0u, 0xffffffffu);
+          const uint32_t cnt = (uint32_t)__popcll(__ballot(kidx < nch && e.y <= rel));   // offsets ascend: a prefix of the lanes
+          if (cnt) {
+            q_run = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)(cnt - 1u));
+            r_run = h.ref_start + (int32_t)__builtin_amdgcn_readlane((int)e.y, (int)(cnt - 1u));
+            c_first = 64u * (b0 + cnt - 1u);
+          }
+          if (cnt < 64u) break;
+        }
+      }
+    }
     const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
     const unsigned long long LUT = aln ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;  // BAM nibble -> NoCall row (complemented on '-'), f = not ACGT
     const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 28) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
-    for (uint32_t c0 = 0; c0 < h.n_cigar; c0 += 64) {
+    for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
       if (r_run >= T1h || (prm.debug_skip & 1u)) break;
       const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
       const uint32_t op = w & 15u, len = w >> 4;
@@ -1481,11 +1498,11 @@ extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
 
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
-                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally) {
+                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally, const uint32_t* chunk_pfx) {
   if (!n_tiles) return hipSuccess;
   const uint32_t grid = n_tiles < 512u ? n_tiles : 512u;   // two persistent workgroups per CU
   hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
-                     tile_last, n_tiles, prm_dev, tally);
+                     tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx));
   return hipGetLastError();
 }
 

@@ -162,11 +162,11 @@ struct LayoutTables {
 // ------------------------------------------------------------------------------------------
 struct ShardHost {
   int32_t tid = -1; int32_t win_start = 0, win_end = 0;
-  std::vector<MkpReadHdr> hdr; std::vector<uint32_t> cigar; std::vector<uint8_t> seq; std::vector<MkpTagRef> tagref;
+  std::vector<MkpReadHdr> hdr; std::vector<uint32_t> cigar; std::vector<uint32_t> chunk_pfx; std::vector<uint8_t> seq; std::vector<MkpTagRef> tagref;
   std::vector<uint32_t> ranks; std::vector<uint8_t> ml;
   uint64_t n_events_cap = 0, n_calls = 0;
   std::vector<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
-  void clear() { hdr.clear(); cigar.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); }
+  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); }
 };
 
 class Packer {
@@ -211,7 +211,10 @@ class Packer {
     h.cigar_off = (uint32_t)S.cigar.size();
     uint32_t n_cigar = r.n_cigar;
     if (n_cigar == 0) { S.cigar.push_back(((uint32_t)r.l_qseq << 4) | 4u); n_cigar = 1; qlen = r.l_qseq; }  // unaligned record (sampling only): one soft clip
-    for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); S.cigar.push_back(w); uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += w >> 4; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += w >> 4; }
+    h.chunk_off = (uint32_t)(S.chunk_pfx.size() / 2);
+    if (r.n_cigar == 0) { S.chunk_pfx.push_back(0); S.chunk_pfx.push_back(0); }
+    for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); S.cigar.push_back(w); uint32_t op = w & 15;
+      if ((k & 63u) == 0) { S.chunk_pfx.push_back((uint32_t)qlen); S.chunk_pfx.push_back((uint32_t)reflen); } if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += w >> 4; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += w >> 4; }
     if (qlen != r.l_qseq) throw Error(MKP_E_INVALID, "CIGAR query length does not match SEQ length");
     h.ref_start = r.pos; h.ref_end = r.pos + (int32_t)reflen; h.l_seq = (uint32_t)r.l_qseq; h.n_cigar = n_cigar;
     if (S.seq.size() + (size_t)r.l_qseq / 2 + 8 > 0xfffffff0ull || S.cigar.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
