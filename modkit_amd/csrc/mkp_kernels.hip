@@ -1006,6 +1006,8 @@ struct TileView {   // packed tallies of a run of positions staged in LDS: [coun
 
 // one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
 // sl < 0: --combine-mods row (code = base letter).  Returns false when the reference emits nothing.
+// FILL = false: only decide whether the row exists (the counting pass)
+template <bool FILL>
 __device__ __forceinline__ bool tally_row(const TileView& tv, const MkpRunParams& prm, uint32_t s, uint32_t i, int sl, int pb, RowAcc* r) {
   const uint32_t ck = prm.can_of_pb[pb];
   if (ck == 0xffu) return false;
@@ -1016,6 +1018,7 @@ __device__ __forceinline__ bool tally_row(const TileView& tv, const MkpRunParams
   uint32_t n_mod;
   if (sl >= 0) { if (tv.o(s, (uint32_t)sl, i) <= 0) return false; n_mod = tv.c(s, prm.slots[sl].cid, i); }
   else n_mod = mods;
+  if (!FILL) return true;
   uint32_t total = 0;
   for (uint32_t k = 0; k < prm.n_counters; k++) if (k != MKP_C_DEL && k != MKP_C_FAIL) total += tv.c(s, k, i);
   const uint32_t nocall = tv.c(s, MKP_C_NC + pb, i);
@@ -1051,13 +1054,13 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
       if (combo) { n_ids = s ? combos[combo].n_neg : combos[combo].n_pos; ids = s ? combos[combo].neg_ids : combos[combo].pos_ids; }
       RowAcc r;
       if (prm.numeric_mode == 1) {
-        for (int pb = 0; pb < 4; pb++) if (tally_row(tv, prm, s, i, -1, pb, &r)) {
+        for (int pb = 0; pb < 4; pb++) if (tally_row<WRITE>(tv, prm, s, i, -1, pb, &r)) {
           if (n_ids) for (uint32_t k = 0; k < n_ids; k++) put(r, s, (uint32_t)LETTER[pb], ids[k]); else put(r, s, (uint32_t)LETTER[pb], -1);
         }
       } else {
         for (uint32_t oi = 0; oi < prm.n_slots; oi++) {
           const int sl = prm.slot_order[oi];
-          if (tally_row(tv, prm, s, i, sl, prm.slots[sl].pb, &r)) {
+          if (tally_row<WRITE>(tv, prm, s, i, sl, prm.slots[sl].pb, &r)) {
             if (n_ids) for (uint32_t k = 0; k < n_ids; k++) put(r, s, prm.slots[sl].code_repr, ids[k]); else put(r, s, prm.slots[sl].code_repr, -1);
           }
         }
@@ -1087,8 +1090,8 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
       if (prm.numeric_mode == 1) {
         for (int pb = 0; pb < 4; pb++) {
           RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0}, r; bool any = false;
-          if (pos_ok && tally_row(tv, prm, 0, i, -1, pb, &r)) { add(acc, r); any = true; }
-          if (neg_ok && tally_row(tv, prm, 1, iq, -1, pb, &r)) { add(acc, r); any = true; }
+          if (pos_ok && tally_row<WRITE>(tv, prm, 0, i, -1, pb, &r)) { add(acc, r); any = true; }
+          if (neg_ok && tally_row<WRITE>(tv, prm, 1, iq, -1, pb, &r)) { add(acc, r); any = true; }
           if (any) put(acc, 2, (uint32_t)LETTER[pb], idx);
         }
       } else {
@@ -1098,11 +1101,11 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
           RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0}, r; bool any = false;
           for (uint32_t oj = oi; oj < prm.n_slots && prm.slots[prm.slot_order[oj]].code_repr == code; oj++) {
             const int sl = prm.slot_order[oj];
-            if (pos_ok && tally_row(tv, prm, 0, i, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
+            if (pos_ok && tally_row<WRITE>(tv, prm, 0, i, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
           }
           for (uint32_t oj = oi; oj < prm.n_slots && prm.slots[prm.slot_order[oj]].code_repr == code; oj++) {
             const int sl = prm.slot_order[oj];
-            if (neg_ok && tally_row(tv, prm, 1, iq, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
+            if (neg_ok && tally_row<WRITE>(tv, prm, 1, iq, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
           }
           if (any) put(acc, 2, code, idx);
         }
@@ -1382,8 +1385,21 @@ mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict_
   const uint32_t i_first = (seg % segs_per_tile) * ROWS_SEG;   // tile-relative index (halo included) of the first staged column
   {
     const uint32_t* __restrict__ src = tally_in + (size_t)tix * n_arr * TH;
-    for (uint32_t r = 0; r < n_arr; r++)
-      for (uint32_t cidx = threadIdx.x; cidx < SEGW; cidx += ROWS_THREADS) { const uint32_t gi = i_first + cidx; seg_lds[r * SEGW + cidx] = gi < TH ? src[r * TH + gi] : 0u; }
+    // 8 independent loads per thread in flight before the first LDS store (a load-store-per-iteration loop waits for every load)
+    const uint32_t per_row = (SEGW + ROWS_THREADS - 1) / ROWS_THREADS, n_it = n_arr * per_row;
+    for (uint32_t it0 = 0; it0 < n_it; it0 += 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) {
+        const uint32_t it = it0 + u, r = it / per_row, cidx = (it % per_row) * ROWS_THREADS + threadIdx.x, gi = i_first + cidx;
+        v[u] = (it < n_it && cidx < SEGW && gi < TH) ? src[r * TH + gi] : 0u;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) {
+        const uint32_t it = it0 + u, r = it / per_row, cidx = (it % per_row) * ROWS_THREADS + threadIdx.x;
+        if (it < n_it && cidx < SEGW) seg_lds[r * SEGW + cidx] = v[u];
+      }
+    }
   }
   __syncthreads();
   const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
