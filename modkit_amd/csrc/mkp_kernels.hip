@@ -1155,6 +1155,15 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
                  const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
+  // SEQ byte -> NoCall row of the base a query index selects: rowlut[strand][query parity][byte]; 15 = not A/C/G/T.
+  // (BAM packs two bases per byte, high nibble first; on the '-' strand the tallied base is the complement.)
+  __shared__ uint8_t rowlut[2][2][256];
+  {
+    const uint32_t t = threadIdx.x, byte = t & 255u, par = (t >> 8) & 1u, st = (t >> 9) & 1u;
+    const uint32_t nib = par ? (byte & 15u) : (byte >> 4);
+    const unsigned long long LUT = st ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;
+    rowlut[st][par][byte] = (uint8_t)((LUT >> (4u * nib)) & 15u);
+  }
   const MkpRunParams& prm = *prmp;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
@@ -1244,8 +1253,8 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
       }
     }
     const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
-    const unsigned long long LUT = aln ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;  // BAM nibble -> NoCall row (complemented on '-'), f = not ACGT
-    const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 28) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
+    const uint8_t* __restrict__ lut = &rowlut[aln][0][0];
+    const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 26) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
     for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
       if (r_run >= T1h || (prm.debug_skip & 1u)) break;
@@ -1282,7 +1291,7 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         const uint32_t nref = (uint32_t)__popcll(refbal);
         const uint32_t ci = (uint32_t)__popcll(refbal & lanemask_lt());
         const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
-        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 28)) << 2) | kind;  // q = (pos - ref_start) + D
+        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);  // q = (pos - ref_start) + D; kind sits where it ORs into the row
         if (isref) comp[ci] = make_uint2((uint32_t)rs, pk);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1316,14 +1325,13 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
             pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(W[j].y, __builtin_amdgcn_mbcnt_lo(W[j].x, 0u))) << 2), (int)c_pk);
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
-            qq[j] = qlane + 64u * min(kb + (uint32_t)j, k1) + (pkv[j] >> 2);
+            qq[j] = qlane + 64u * min(kb + (uint32_t)j, k1) + (pkv[j] >> 5);
             byte[j] = seq[min(qq[j] >> 1, last_byte)];   // lanes on D/N ops or outside the span read a clamped (ignored) byte
           }
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
             const uint32_t kk = min(kb + (uint32_t)j, k1);
-            const uint32_t x60 = ((byte[j] << ((qq[j] & 1u) << 2)) >> 2) & 60u;          // 4 * BAM nibble of base qq
-            const uint32_t rowt = ((uint32_t)(LUT >> x60) & 15u) | ((pkv[j] & 3u) << 3);   // >= 8: not ACGT, or the lane sits on a D/N op
+            const uint32_t rowt = (uint32_t)lut[((qq[j] & 1u) << 8) + byte[j]] | (pkv[j] & 0x18u);   // >= 8: not ACGT, or the lane sits on a D/N op
             const uint32_t rl = 64u * kk + (uint32_t)lane;
             bool ok = rowt < 8u;
             if (edge) { const int32_t pos = T0h + (int32_t)rl; ok = ok && pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1; }

@@ -216,6 +216,7 @@ class Packer {
     for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); S.cigar.push_back(w); uint32_t op = w & 15;
       if ((k & 63u) == 0) { S.chunk_pfx.push_back((uint32_t)qlen); S.chunk_pfx.push_back((uint32_t)reflen); } if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += w >> 4; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += w >> 4; }
     if (qlen != r.l_qseq) throw Error(MKP_E_INVALID, "CIGAR query length does not match SEQ length");
+    if (qlen >= (1 << 26) || reflen >= (1 << 26)) throw Error(MKP_E_UNSUPPORTED, "a read or its alignment spans 2^26 bases or more (the depth walk packs query offsets in 27 bits)");
     h.ref_start = r.pos; h.ref_end = r.pos + (int32_t)reflen; h.l_seq = (uint32_t)r.l_qseq; h.n_cigar = n_cigar;
     if (S.seq.size() + (size_t)r.l_qseq / 2 + 8 > 0xfffffff0ull || S.cigar.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
     h.seq_off = (uint32_t)S.seq.size();
