@@ -12,8 +12,8 @@ hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*r
 hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 uint32_t mkp_rows_segments(uint32_t tile);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
-                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/, const uint32_t* /*chunk offsets*/);
-hipError_t mkp_launch_rows(hipStream_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, uint32_t /*tile*/, uint32_t /*arrays*/, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
+                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/);
+hipError_t mkp_launch_rows(hipStream_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, uint32_t /*tile*/, uint32_t /*arrays*/, int /*has focus*/, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
                            const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
@@ -74,7 +74,9 @@ void make_resident(mkp_ctx* c) {
   const uint32_t words_per_pos = P.n_counters + P.n_slots;
   uint32_t T = c->cfg.tile_positions;
   if (const char* te = getenv("MKP_TILE")) T = (uint32_t)strtoul(te, nullptr, 0);   // experiments only
-  const uint32_t budget = 80u * 1024u - 256u;
+  // two workgroups must be co-resident per CU: 76 KiB each including the kernel's ~1 KiB of static LDS leaves 8 KiB of
+  // slack for the allocation granule (at 80 KiB each one GPU box ran them one per CU and the kernel took 1.9x as long)
+  const uint32_t budget = 76u * 1024u - 1280u;
   uint32_t maxT = 0;
   for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;
   if (maxT < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
@@ -143,9 +145,9 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>(), c->d_chunk.as<uint32_t>()), "pileup launch");
+                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_rows(c->stream, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, P.tile, P.n_counters + P.n_slots, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
+    hip_check(mkp_launch_rows(c->stream, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, P.tile, P.n_counters + P.n_slots, (int)P.has_focus, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
                               &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2), "rows launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_segs, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");

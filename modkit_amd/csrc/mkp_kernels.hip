@@ -1030,11 +1030,10 @@ __device__ __forceinline__ bool tally_row(const TileView& tv, const MkpRunParams
 
 template <bool WRITE>
 __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
-                                            const MkpCombo* __restrict__ combos, int32_t T0h, uint32_t i, const MkpRowsDev& rows,
-                                            uint32_t wr) {
+                                            const MkpCombo* combos, int32_t T0h, uint32_t i, const MkpRowsDev& rows,
+                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */) {
   const int32_t p = T0h + (int32_t)i;
-  uint32_t rule = 3, combo = 0;
-  if (prm.has_focus) { uint32_t fv = focus[p - prm.win_start]; rule = fv & 3u; combo = fv >> 2; }
+  const uint32_t rule = fv & 3u, combo = fv >> 2;
   if (!rule) return 0;
   uint32_t n = 0;
   auto put = [&](const RowAcc& r, uint32_t strand, uint32_t code, int motif) {
@@ -1152,7 +1151,7 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8)
 mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
-                 const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx) {
+                 const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
   // SEQ byte -> NoCall row of the base a query index selects: rowlut[strand][query parity][byte]; 15 = not A/C/G/T.
@@ -1361,6 +1360,18 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     uint32_t* __restrict__ dst = tally_out + (size_t)tix * lds_words;
     for (uint32_t k = threadIdx.x; k < lds_words; k += PILEUP_THREADS) dst[k] = lds[k];
   }
+  // column depth against --max-depth (htslib would start dropping reads: not restated, so the run must fail loudly)
+  {
+    bool deep = false;
+    for (uint32_t i = MKP_HALO + threadIdx.x; i < MKP_HALO + T; i += PILEUP_THREADS) {
+      const int32_t p = T0h + (int32_t)i;
+      if (p < prm.win_start || p >= prm.win_end) continue;
+      uint32_t depth = 0;
+      for (uint32_t c = 0; c < n_counters; c++) { const uint32_t v = tal[c * TH + i]; depth += (v & 0xffffu) + (v >> 16); }
+      deep |= depth > prm.max_depth;
+    }
+    if (deep) atomicOr(dev_err, ERR_DEPTH);
+  }
   __syncthreads();   // the tallies are re-zeroed for the next tile
   }
 }
@@ -1373,8 +1384,10 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
 #define ROWS_THREADS 256
 #define ROWS_PER_THREAD 4
 #define ROWS_SEG (ROWS_THREADS * ROWS_PER_THREAD)
-extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
-mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
+// STAGE = false (runs with focus positions, e.g. --cpg: rows exist at ~1 % of the positions): the tallies are read
+// straight from HBM for the few positions in focus instead of staging the whole segment.
+template <bool STAGE>
+__device__ __forceinline__ void emit_rows_body(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
               const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
               uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
               uint32_t* __restrict__ dev_err) {
@@ -1383,7 +1396,9 @@ mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict_
   __shared__ uint32_t seg_base;
   // the run parameters (slot / counter tables the row logic indexes per lane) are read from an LDS copy, not from global memory
   __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];   // <= 64 motif-id combos (checked at mkp_shard_begin)
   for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += ROWS_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
+  if (prmp->has_focus) for (uint32_t kq = threadIdx.x; kq < prmp->n_combos * (sizeof(MkpCombo) / 4); kq += ROWS_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
   const uint32_t seg = blockIdx.x;
   const uint32_t tix = seg / segs_per_tile;
   const uint32_t tile = tile_ids[tix];
@@ -1391,19 +1406,19 @@ mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict_
   const uint32_t n_arr = prmp->n_counters + prmp->n_slots;
   const uint32_t SEGW = ROWS_SEG + 2 * MKP_HALO;
   const uint32_t i_first = (seg % segs_per_tile) * ROWS_SEG;   // tile-relative index (halo included) of the first staged column
-  {
-    const uint32_t* __restrict__ src = tally_in + (size_t)tix * n_arr * TH;
-    // 8 independent loads per thread in flight before the first LDS store (a load-store-per-iteration loop waits for every load)
+  const uint32_t* __restrict__ src = tally_in + (size_t)tix * n_arr * TH;
+  if (STAGE) {
+    // 16 independent loads per thread in flight before the first LDS store (a load-store-per-iteration loop waits for every load)
     const uint32_t per_row = (SEGW + ROWS_THREADS - 1) / ROWS_THREADS, n_it = n_arr * per_row;
-    for (uint32_t it0 = 0; it0 < n_it; it0 += 8) {
-      uint32_t v[8];
+    for (uint32_t it0 = 0; it0 < n_it; it0 += 16) {
+      uint32_t v[16];
 #pragma unroll
-      for (uint32_t u = 0; u < 8; u++) {
+      for (uint32_t u = 0; u < 16; u++) {
         const uint32_t it = it0 + u, r = it / per_row, cidx = (it % per_row) * ROWS_THREADS + threadIdx.x, gi = i_first + cidx;
         v[u] = (it < n_it && cidx < SEGW && gi < TH) ? src[r * TH + gi] : 0u;
       }
 #pragma unroll
-      for (uint32_t u = 0; u < 8; u++) {
+      for (uint32_t u = 0; u < 16; u++) {
         const uint32_t it = it0 + u, r = it / per_row, cidx = (it % per_row) * ROWS_THREADS + threadIdx.x;
         if (it < n_it && cidx < SEGW) seg_lds[r * SEGW + cidx] = v[u];
       }
@@ -1414,24 +1429,26 @@ mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict_
   const uint32_t n_counters = prm.n_counters;
   const int32_t T0 = prm.win_start + (int32_t)(tile * T);
   const int32_t T0h = T0 - MKP_HALO;
-  TileView tv; tv.W = SEGW; tv.i0 = i_first; tv.n_counters = n_counters; tv.n_slots = prm.n_slots; tv.pk = seg_lds;
+  TileView tv; tv.n_counters = n_counters; tv.n_slots = prm.n_slots;
+  if (STAGE) { tv.W = SEGW; tv.i0 = i_first; tv.pk = seg_lds; } else { tv.W = TH; tv.i0 = 0; tv.pk = src; }
   const int lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t li0 = i_first + threadIdx.x * ROWS_PER_THREAD;   // first of this thread's positions, tile-relative (no halo)
+  // the four focus bytes of this thread's positions: one aligned dword (tiles start on multiples of 64 from win_start)
+  uint32_t fv4 = 0x03030303u;
+  if (prm.has_focus) { const int32_t p0 = T0 + (int32_t)li0; fv4 = (li0 < T && p0 >= prm.win_start && p0 + 3 < prm.win_end) ? *reinterpret_cast<const uint32_t*>(focus + (p0 - prm.win_start)) : 0xffffffffu; }
+  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
   uint32_t my_rows = 0;
-  bool deep = false;
 #pragma unroll
   for (uint32_t j = 0; j < ROWS_PER_THREAD; j++) {
     const uint32_t li = li0 + j;
     const int32_t p = T0 + (int32_t)li;
     if (!(li < T && p >= prm.win_start && p < prm.win_end) || (prm.debug_skip & (4u | 512u))) continue;
+    if (!STAGE && (focus[p - prm.win_start] & 3u) == 0) continue;   // not in focus: no rows, and its depth is not looked at either way
     const uint32_t i = li + MKP_HALO;
-    uint32_t depth = 0;
-    for (uint32_t s = 0; s < 2; s++) for (uint32_t c = 0; c < n_counters; c++) depth += tv.c(s, c, i);
-    deep |= depth > prm.max_depth;
-    my_rows += rows_at<false>(tv, prm, focus, combos, T0h, i, rows, 0);
+    const uint32_t fv = fv4 == 0xffffffffu ? (uint32_t)focus[p - prm.win_start] : (fv4 >> (8u * j)) & 0xffu;   // (segment edge: byte loads)
+    my_rows += rows_at<false>(tv, prm, focus, combos_l, T0h, i, rows, 0, fv);
   }
-  if (deep) atomicOr(dev_err, ERR_DEPTH);
   const uint32_t inc = wave_incl_scan(my_rows);
   if (lane == 63) wave_tot[wave] = inc;
   __syncthreads();
@@ -1450,9 +1467,23 @@ mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict_
       const uint32_t li = li0 + j;
       const int32_t p = T0 + (int32_t)li;
       if (!(li < T && p >= prm.win_start && p < prm.win_end)) continue;
-      wr += rows_at<true>(tv, prm, focus, combos, T0h, li + MKP_HALO, rows, wr);
+      const uint32_t fv = fv4 == 0xffffffffu ? (uint32_t)focus[p - prm.win_start] : (fv4 >> (8u * j)) & 0xffu;
+      wr += rows_at<true>(tv, prm, focus, combos_l, T0h, li + MKP_HALO, rows, wr, fv);
     }
   }
+}
+
+extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
+mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
+              const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
+              uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt, uint32_t* __restrict__ dev_err) {
+  emit_rows_body<true>(tally_in, tile_ids, n_segs, segs_per_tile, focus, combos, prmp, rows, row_cursor, seg_row_off, seg_row_cnt, dev_err);
+}
+extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
+mkp_emit_rows_focus(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
+                    const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
+                    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt, uint32_t* __restrict__ dev_err) {
+  emit_rows_body<false>(tally_in, tile_ids, n_segs, segs_per_tile, focus, combos, prmp, rows, row_cursor, seg_row_off, seg_row_cnt, dev_err);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1522,17 +1553,17 @@ extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
 
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
-                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally, const uint32_t* chunk_pfx) {
+                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally, const uint32_t* chunk_pfx, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
   const uint32_t grid = n_tiles < 512u ? n_tiles : 512u;   // two persistent workgroups per CU
   hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
-                     tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx));
+                     tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
   return hipGetLastError();
 }
 
 extern "C" uint32_t mkp_rows_segments(uint32_t tile) { return (tile + ROWS_SEG - 1) / ROWS_SEG; }
 
-extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, uint32_t tile, uint32_t n_arr, const uint8_t* focus,
+extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, uint32_t tile, uint32_t n_arr, int has_focus, const uint8_t* focus,
                                       const MkpCombo* combos, const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* seg_row_off,
                                       uint32_t* seg_row_cnt, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
@@ -1540,8 +1571,9 @@ extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, con
   const uint32_t lds_bytes = n_arr * (ROWS_SEG + 2 * MKP_HALO) * 4u;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+  (void)has_focus;   // the unstaged variant (mkp_emit_rows_focus) lost: its per-row chains of dependent HBM loads cost more than staging
   hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
-                     seg_row_off, seg_row_cnt, dev_err);
+                       seg_row_off, seg_row_cnt, dev_err);
   return hipGetLastError();
 }
 
