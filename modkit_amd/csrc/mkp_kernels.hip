@@ -1,19 +1,21 @@
-// gfx950 (CDNA4, wave64) kernels of the modkit-pileup hot path.  Integer / byte work bound by HBM
-// and LDS atomics — no MFMA.  Three kernels:
+// gfx950 (CDNA4, wave64) kernels of the modkit-pileup hot path.  Integer / byte work bound by instruction issue, LDS
+// atomics and HBM — no MFMA.  One device pass = the launches below, in order (DESIGN.md §3 has the details):
 //
-//   mkp_decode_reads   one wave per read.  Walks the CIGAR 64 ops at a time (wave prefix sums),
-//                      expands query positions 64 per step, ranks each base with ballot+popcount
-//                      (DeltaListConverter's cumulative counts, mod_bam.rs:667-684), finds the read's
-//                      MM calls at that base, rebuilds BaseModProbs in MM order, applies edge filter,
-//                      ReDistribute collapse and MultipleThresholdModCaller::call in f32, and appends
-//                      a packed 8-byte event per mapped call (coalesced, ballot-compacted).
-//   mkp_pileup_tiles   one workgroup per reference tile.  LDS holds the tile's strand tallies
-//                      ([strand][counter][position] u32, consecutive positions on consecutive banks).
-//                      Waves take the tile's reads: depth walk (one LDS atomic per aligned/deleted
-//                      base), observed-code difference arrays, and the read's event slice.  Then an
-//                      in-LDS prefix scan of the observed-code arrays and row emission with a
-//                      block-wide scan for compaction.
-//   mkp_gather_rows    orders the per-tile row segments by tile (device exclusive scan + copy).
+//   mkp_decode_fast1 / _fast2 / mkp_decode_reads   one wave per read (three read classes, host-built id lists).  512
+//                      bases per step (8 per lane): nibble-parallel match masks + DPP prefix sums give the rank of every
+//                      base (DeltaListConverter's cumulative counts, mod_bam.rs:667-684); the calls of each MM tag are
+//                      located through an ordinal bitmap in LDS; per call: BaseModProbs in f32 from ML, edge filter,
+//                      ReDistribute collapse, MultipleThresholdModCaller::call, CIGAR mapping; one packed 8-byte event
+//                      per mapped call (coalesced, position order).  mkp_sample_* = the same walks emitting argmax
+//                      probabilities for threshold estimation.
+//   mkp_pileup_tiles   accumulate: persistent workgroups, two per CU, one reference tile each in LDS as 16-bit-packed
+//                      strand tallies ([counter | slot][position], consecutive positions on consecutive banks).  Waves draw
+//                      the tile's reads from an LDS ticket: observed-code difference arrays, the read's event slice,
+//                      and the depth walk (one LDS atomic per aligned base, one lane per reference position).  The
+//                      tallies are prefix-summed where needed and streamed to HBM.
+//   mkp_emit_rows      one workgroup per 1024 positions: tallies staged in LDS, rows of FeatureVector::decode /
+//                      combine_strand_features compacted with a block scan.
+//   mkp_scan_tiles, mkp_gather_rows   order the row segments (exclusive scan of the counts + coalesced copy).
 //
 // Semantics follow /root/reference/src (cited inline); arithmetic that must be bit-exact is f32
 // with contraction off (-ffp-contract=off) and IEEE division.
@@ -234,7 +236,7 @@ template <int N> __device__ __forceinline__ uint32_t selN(const uint32_t* a, uin
 
 // NT = compile-time bound on the read's MM tag count (the entry point dispatches on it): every per-tag loop and
 // register array below is sized for the layout actually present instead of NT.
-template <bool SAMPLE, int NT, bool FAST>
+template <bool SAMPLE, int NT>
 __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
@@ -301,25 +303,6 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     if ((uint32_t)j < nb && (MKP_G_IMPL(m0) | MKP_G_IMPL(m1))) implslots |= 1u << j;
   }
   implslots = (uint32_t)__builtin_amdgcn_readfirstlane((int)implslots);
-  // FAST: the one group of the read, held in SGPRs
-  const int b0 = (int)t_desc[0].fb & 3, sg0 = (int)t_desc[0].neg & 1;
-  const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
-  GroupRegs grp0; uint32_t tmu[NT], codes_t[NT], contribH = 0;
-  if (FAST) {
-    grp0 = load_group(gp0);
-    grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
-    grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
-#pragma unroll
-    for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
-    grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      tmu[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tagmap[t][b0]);
-      codes_t[t] = 0;
-      for (int i = 0; i < (int)t_desc[t].n_codes; i++) codes_t[t] |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
-    }
-  }
-
   // reverse reads need the totals up front (forward rank = total - inclusive count in stored order)
   uint32_t tot[NB];
 #pragma unroll
@@ -441,31 +424,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
 #pragma unroll
       for (int k = 0; k < MKP_KMAX; k++) { at(S0.pk, k) = 0.f; at(S1.pk, k) = 0.f; }
       S0.H = S0.setmask = S1.H = S1.setmask = 0;
-      if constexpr (FAST) {
-        // one group, distinct codes: every local code is written at most once, straight from ML (quals_to_probs 808-816)
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          if (t >= n_tags) break;
-          const uint32_t pt = __shfl(pack_t[t], owner, 64);
-          const bool found = active && ((pt >> bit) & 1u);
-          const uint32_t idx = (pt >> 8) + (uint32_t)__popc(pt & ((1u << bit) - 1u));
-          const uint32_t jx = rev ? (cur_before[t] - 1u - idx) : (cur_before[t] + idx);
-          const uint32_t nc = t_desc[t].n_codes;
-          for (uint32_t i = 0; i < nc; i++) {
-            const float p = ((float)ml[found ? (t_ml[t] + jx * nc + i) : 0u] + 0.5f) / 256.0f;
-            const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform
-            setk(S0.pk, kk, found, p);
-          }
-          S0.H |= found ? (1u << (tmu[t] & 15u)) : 0u;
-          S0.setmask |= found ? codes_t[t] : 0u;
-        }
-        if (__popc(S0.H) >= 2) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
-          float s = 0.f;
-#pragma unroll
-          for (int k2 = 0; k2 < MKP_KMAX; k2++) if (S0.setmask & (1u << k2)) s = s + at(S0.pk, k2);
-          if (s > 1.01f) err = true;
-        }
-      } else {
+      {
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         if (t >= n_tags) break;
@@ -519,36 +478,6 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
         }
       }
       uint32_t ev_info[2]; float sv[2] = {0.f, 0.f}; uint32_t ev_cnt = 0; int32_t ev_pos = 0;
-      if constexpr (FAST) {
-        if (active && (S0.H | MKP_G_IMPL(grp0.misc))) {
-          const bool edge_keep = !prm.edge_filter ||
-              (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
-          const uint32_t impl = MKP_G_IMPL(grp0.misc);
-          int pat; uint32_t member_contrib;
-          if (S0.H) { if (impl & ~S0.H) err = true; pat = (int)S0.H; member_contrib = S0.H; }   // ExplicitConflictInferred
-          else { pat = MKP_PAT_INFERRED; member_contrib = impl; }                                // implicit fill (mod_bam.rs:1265-1292)
-          const uint32_t pv = gp0[12 + pat];
-          contribH |= member_contrib;
-          if (trimmable && edge_keep) {
-            if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
-              bool keep = !prm.only_mapped || mapped;
-              if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-              if (keep) { any_surviving = true; sv[ev_cnt] = argmax_group(grp0, pv, S0.pk, collapse); ev_info[ev_cnt++] = MKP_G_TB(grp0.misc); }
-            } else {
-              any_surviving = true;
-              uint32_t ob = 0;
-              const int cls = call_group(grp0, pv, S0.pk, collapse, &ob);
-              const uint32_t tally = aln ^ (uint32_t)sg0;  // read_cache.rs:181-188 / FeatureVector::add_feature
-              if (tally) obs1 |= ob; else obs0 |= ob;
-              if (mapped) {
-                const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
-                ev_info[ev_cnt++] = cid | (tally << 8) | ((uint32_t)b0 << 9) | (aln << 11) | (1u << 12);
-                ev_pos = rpos;
-              }
-            }
-          }
-        }
-      } else
       if (active && x >= 0) {
         const bool edge_keep = !prm.edge_filter ||
             (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
@@ -625,13 +554,6 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
   for (int t = 0; t < NT; t++) if (t < n_tags) { if (rev ? (t_cur[t] != 0u) : (t_cur[t] != t_n[t])) err = true; }
   err = __any(err);
   obs0 = wave_or(obs0); obs1 = wave_or(obs1);
-  if (FAST) {
-    const uint32_t mc = wave_or(contribH); uint32_t tagbits = 0;
-#pragma unroll
-    for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (mc & (1u << mi)) tagbits |= 1u << ((grp0.member_tags >> (4 * mi)) & 15u);
-    const int gi = sg0 * 4 + b0;
-    if (gi < 4) contrib_lo |= tagbits << (8 * gi); else contrib_hi |= tagbits << (8 * (gi - 4));
-  }
   contrib_lo = wave_or(contrib_lo); contrib_hi = wave_or(contrib_hi);
   any_surviving = __any(any_surviving);
   // InvalidImplicitMode: a group all of whose contributing tags have no mode character (read_cache.rs:122-137)
@@ -982,7 +904,7 @@ template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECO
   const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (widx >= n_reads) return;
   const uint32_t nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[read_ids[widx]].n_tags);
-#define DECODE_CALL(S, N) decode_read_body<S, N, false>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, read_ids, &lds_layouts[0][0], lds_marks, pdep4)
+#define DECODE_CALL(S, N) decode_read_body<S, N>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, read_ids, &lds_layouts[0][0], lds_marks, pdep4)
   if (nt <= 2) DECODE_CALL(SAMPLE, 2); else if (nt <= 4) DECODE_CALL(SAMPLE, 4); else DECODE_CALL(SAMPLE, MKP_MAX_TAGS);
 }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<false>(DECODE_PASS); }
@@ -1384,10 +1306,10 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
 #define ROWS_THREADS 256
 #define ROWS_PER_THREAD 4
 #define ROWS_SEG (ROWS_THREADS * ROWS_PER_THREAD)
-// STAGE = false (runs with focus positions, e.g. --cpg: rows exist at ~1 % of the positions): the tallies are read
-// straight from HBM for the few positions in focus instead of staging the whole segment.
-template <bool STAGE>
-__device__ __forceinline__ void emit_rows_body(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
+// (Reading the tallies straight from HBM for the few positions in focus of a --cpg run was tried instead of staging: the
+// per-row chains of dependent HBM loads cost 2x the staged version.)
+extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
+mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
               const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
               uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
               uint32_t* __restrict__ dev_err) {
@@ -1407,7 +1329,7 @@ __device__ __forceinline__ void emit_rows_body(const uint32_t* __restrict__ tall
   const uint32_t SEGW = ROWS_SEG + 2 * MKP_HALO;
   const uint32_t i_first = (seg % segs_per_tile) * ROWS_SEG;   // tile-relative index (halo included) of the first staged column
   const uint32_t* __restrict__ src = tally_in + (size_t)tix * n_arr * TH;
-  if (STAGE) {
+  {
     // 16 independent loads per thread in flight before the first LDS store (a load-store-per-iteration loop waits for every load)
     const uint32_t per_row = (SEGW + ROWS_THREADS - 1) / ROWS_THREADS, n_it = n_arr * per_row;
     for (uint32_t it0 = 0; it0 < n_it; it0 += 16) {
@@ -1430,7 +1352,7 @@ __device__ __forceinline__ void emit_rows_body(const uint32_t* __restrict__ tall
   const int32_t T0 = prm.win_start + (int32_t)(tile * T);
   const int32_t T0h = T0 - MKP_HALO;
   TileView tv; tv.n_counters = n_counters; tv.n_slots = prm.n_slots;
-  if (STAGE) { tv.W = SEGW; tv.i0 = i_first; tv.pk = seg_lds; } else { tv.W = TH; tv.i0 = 0; tv.pk = src; }
+  tv.W = SEGW; tv.i0 = i_first; tv.pk = seg_lds;
   const int lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t li0 = i_first + threadIdx.x * ROWS_PER_THREAD;   // first of this thread's positions, tile-relative (no halo)
@@ -1444,7 +1366,6 @@ __device__ __forceinline__ void emit_rows_body(const uint32_t* __restrict__ tall
     const uint32_t li = li0 + j;
     const int32_t p = T0 + (int32_t)li;
     if (!(li < T && p >= prm.win_start && p < prm.win_end) || (prm.debug_skip & (4u | 512u))) continue;
-    if (!STAGE && (focus[p - prm.win_start] & 3u) == 0) continue;   // not in focus: no rows, and its depth is not looked at either way
     const uint32_t i = li + MKP_HALO;
     const uint32_t fv = fv4 == 0xffffffffu ? (uint32_t)focus[p - prm.win_start] : (fv4 >> (8u * j)) & 0xffu;   // (segment edge: byte loads)
     my_rows += rows_at<false>(tv, prm, focus, combos_l, T0h, i, rows, 0, fv);
@@ -1471,19 +1392,6 @@ __device__ __forceinline__ void emit_rows_body(const uint32_t* __restrict__ tall
       wr += rows_at<true>(tv, prm, focus, combos_l, T0h, li + MKP_HALO, rows, wr, fv);
     }
   }
-}
-
-extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
-mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
-              const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
-              uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt, uint32_t* __restrict__ dev_err) {
-  emit_rows_body<true>(tally_in, tile_ids, n_segs, segs_per_tile, focus, combos, prmp, rows, row_cursor, seg_row_off, seg_row_cnt, dev_err);
-}
-extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
-mkp_emit_rows_focus(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
-                    const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
-                    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt, uint32_t* __restrict__ dev_err) {
-  emit_rows_body<false>(tally_in, tile_ids, n_segs, segs_per_tile, focus, combos, prmp, rows, row_cursor, seg_row_off, seg_row_cnt, dev_err);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1571,7 +1479,7 @@ extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, con
   const uint32_t lds_bytes = n_arr * (ROWS_SEG + 2 * MKP_HALO) * 4u;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-  (void)has_focus;   // the unstaged variant (mkp_emit_rows_focus) lost: its per-row chains of dependent HBM loads cost more than staging
+  (void)has_focus;
   hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
                        seg_row_off, seg_row_cnt, dev_err);
   return hipGetLastError();
