@@ -2,6 +2,9 @@
 // row read-back.  No CPU fallback lives here: the only way rows are produced is the three HIP
 // kernels of mkp_kernels.hip; without a gfx950 device every compute entry point fails with
 // MKP_E_DEVICE.
+#include <memory>
+#include <thread>
+
 #include "mkp_ctx.hpp"
 
 using namespace mkp;
@@ -272,10 +275,28 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
   return guarded(c, [&]() {
     if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
     auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t i = 0; i < n; i++) {
-      const mkp_record& r = recs[i];
-      if (r.tid != c->shard.tid || !Packer::keep(r)) continue;
-      c->packer.add(r, c->shard);
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned n_thr = n >= 4096 ? hw : 1;
+    if (n_thr == 1) {
+      for (uint32_t i = 0; i < n; i++) {
+        const mkp_record& r = recs[i];
+        if (r.tid != c->shard.tid || !Packer::keep(r)) continue;
+        c->packer.add(r, c->shard);
+      }
+    } else {
+      // MM tokenising dominates packing: contiguous record ranges are packed independently and appended in order (same
+      // layout ids and offsets as the sequential pass)
+      std::vector<Packer> pk(n_thr); std::vector<ShardHost> sh(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr); std::vector<std::thread> th;
+      const int32_t tid = c->shard.tid;
+      for (unsigned t = 0; t < n_thr; t++) th.emplace_back([&, t]() {
+        const uint32_t lo = (uint32_t)((uint64_t)n * t / n_thr), hi = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
+        sh[t].tid = tid;
+        try { for (uint32_t i = lo; i < hi; i++) { const mkp_record& r = recs[i]; if (r.tid != tid || !Packer::keep(r)) continue; pk[t].add(r, sh[t]); } }
+        catch (const Error& e) { errs[t].reset(new Error(e)); }
+        catch (const std::exception& e) { errs[t].reset(new Error(MKP_E_INVALID, e.what())); }
+      });
+      for (auto& x : th) x.join();
+      for (unsigned t = 0; t < n_thr; t++) { if (errs[t]) throw *errs[t]; c->shard.append(sh[t], c->packer.adopt(pk[t])); sh[t] = ShardHost(); }
     }
     c->stats.pack_ms += ms_since(t0);
   });

@@ -7,6 +7,7 @@
 
 #include "mkp_ctx.hpp"
 #include "mkp_focus.hpp"
+#include "mkp_format.hpp"
 
 using namespace mkp;
 
@@ -192,6 +193,22 @@ std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamDa
   return per_base;
 }
 
+// percentile_linear_interp (thresholds.rs:17-38) needs two order statistics of the sample, not the sorted sample: select
+// them (O(n)) and let mkp_percentile do the f32 interpolation on a 2-element view with the same fractional rank.
+int percentile_select(std::vector<float>& xs, float q, float* out) {
+  const uint64_t n = xs.size();
+  if (n < 2 || q > 1.0f) return MKP_E_THRESHOLD;
+  if (q == 1.0f) { *out = *std::max_element(xs.begin(), xs.end()); return MKP_OK; }
+  const float lq = (float)(n - 1) * q;
+  const uint64_t left = (uint64_t)floorf(lq), right = (uint64_t)ceilf(lq);
+  std::nth_element(xs.begin(), xs.begin() + (std::ptrdiff_t)left, xs.end());
+  float two[2] = {xs[left], xs[left]};
+  if (right != left) two[1] = *std::min_element(xs.begin() + (std::ptrdiff_t)left + 1, xs.end());
+  const float g = lq - truncf(lq);
+  if (right == left) { *out = two[0] * (1.0f - g) + two[0] * g; return MKP_OK; }   // g == 0 here: same expression as the reference
+  return mkp_percentile(two, 2, g, out);   // l = 1, l*q = g: xs[0]*(1-g) + xs[1]*g
+}
+
 void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) {  // parse_per_base_thresholds (command_utils.rs:136-206)
   bool have_default = false;
   for (auto& raw : raws) {
@@ -205,27 +222,29 @@ void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) 
   }
 }
 
-// {:.2} of an f32 (writers.rs:140): exact decimal expansion of the value, ties to even — glibc's printf does the same
+// bedMethyl text (writers.rs:87-156) through mkp_format.hpp, buffered
 struct RowWriter {
-  FILE* f; bool mixed; std::vector<std::string> labels; uint64_t n = 0;
+  FILE* f; bool mixed; std::vector<std::string> labels; uint64_t n = 0; std::vector<char> buf;
   void write(const std::string& chrom, const mkp_rows& r) {
     const char sp = mixed ? ' ' : '\t';
+    if (buf.empty()) buf.resize(1 << 20);
+    char* p = buf.data(); char* const hi = buf.data() + buf.size() - 512 - chrom.size();
     for (uint64_t i = 0; i < r.n_rows; i++) {
       char name[96]; uint32_t code = r.code_repr[i];
-      int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
-      if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
-      const float frac = (float)r.n_mod[i] / (float)r.n_valid[i];
-      const float pct = frac * 100.0f;
-      fprintf(f, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos[i], r.pos[i] + 1, name, r.n_valid[i], (char)r.strand[i], r.pos[i],
-              r.pos[i] + 1, r.n_valid[i], sp, (double)pct, sp, r.n_mod[i], sp, r.n_canonical[i], sp, r.n_other[i], sp, r.n_delete[i], sp, r.n_fail[i], sp, r.n_diff[i], sp, r.n_nocall[i]);
+      int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : (name[0] = (char)code, name[1] = 0, 1);
+      if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) k += snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
+      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)std::min<int>(k, (int)sizeof(name) - 1), sp, r.pos[i], (char)r.strand[i], r.n_valid[i], r.n_mod[i], r.n_canonical[i], r.n_other[i],
+                     r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
+      if (p > hi) { fwrite(buf.data(), 1, (size_t)(p - buf.data()), f); p = buf.data(); }
     }
+    if (p > buf.data()) fwrite(buf.data(), 1, (size_t)(p - buf.data()), f);
     n += r.n_rows;
   }
 };
 
 int run(const Args& a, std::string* msg) {
   auto t_all = std::chrono::steady_clock::now();
-  BamData bam = load_bam(a.in_bam, (unsigned)std::max<size_t>(a.threads, 1));
+  BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
   double load_ms = ms_since(t_all);
   RegionSpec region, sregion; const bool have_region = !a.region.empty(), have_sregion = !a.sample_region.empty();
   if (have_region) region = parse_region(a.region, bam);
@@ -282,8 +301,8 @@ int run(const Args& a, std::string* msg) {
     const RegionSpec* sr = have_sregion ? &sregion : (have_region ? &region : nullptr);
     auto per_base = sample_probabilities(ctx, bam, a, sr, bf);
     for (auto& kv : per_base) {
-      std::sort(kv.second.begin(), kv.second.end()); float t;
-      if (mkp_percentile(kv.second.data(), kv.second.size(), a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size()));
+      float t;
+      if (percentile_select(kv.second, a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size()));
       kc.has_per_base[kv.first] = 1; kc.per_base_threshold[kv.first] = t;
       if (a.stats) fprintf(stderr, "[mkpileup] threshold %c %.9g (n=%zu)\n", "ACGT"[kv.first], (double)t, kv.second.size());
     }
@@ -379,7 +398,7 @@ extern "C" int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int a
   if (!ctx || !bam_path || !thr || !has) return MKP_E_INVALID;
   try {
     Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
-    BamData bam = load_bam(a.in_bam, (unsigned)std::max<size_t>(a.threads, 1));
+    BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
     RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
     if (hr) region = parse_region(a.region, bam);
     if (hs) sregion = parse_region(a.sample_region, bam);
@@ -393,7 +412,7 @@ extern "C" int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int a
     int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) return rc;
     auto per_base = sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
     for (int b = 0; b < 4; b++) { thr[b] = 0.f; has[b] = 0; }
-    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); float t; if (mkp_percentile(kv.second.data(), kv.second.size(), a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size())); thr[kv.first] = t; has[kv.first] = 1; }
+    for (auto& kv : per_base) { float t; if (percentile_select(kv.second, a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size())); thr[kv.first] = t; has[kv.first] = 1; }
     return MKP_OK;
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }

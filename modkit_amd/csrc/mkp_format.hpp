@@ -1,0 +1,51 @@
+// bedMethyl row text for mkp_pileup_main, byte-identical to BedMethylWriter::write_feature_counts
+// (src/writers.rs:87-156): 18 columns, `{:.2}` of `fraction_modified * 100f32`.  The reference keeps this in Rust; the
+// library formats rows only so that its whole-subcommand entry point can be checked against golden files.  Plain C++,
+// no device code: tests/test_format_cpu.py compiles it against snprintf for every (n_mod, n_valid) pair up to 4096.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+namespace mkp {
+
+inline char* put_u32(char* p, uint32_t v) {
+  char tmp[10]; int n = 0;
+  do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+
+// "{:.2}" of an f32: the exact decimal expansion of the value rounded to 2 places, ties to even (Rust's float
+// formatting and glibc's printf agree on this).  pct has a 24-bit significand, so pct * 100 is exact in double and
+// nearbyint (round-to-nearest-even) of it is the correctly rounded number of hundredths.
+inline char* put_pct2(char* p, float pct) {
+  const double x = (double)pct * 100.0;
+  const uint64_t h = (uint64_t)std::nearbyint(x);
+  p = put_u32(p, (uint32_t)(h / 100u));
+  *p++ = '.';
+  *p++ = (char)('0' + (h / 10u) % 10u);
+  *p++ = (char)('0' + h % 10u);
+  return p;
+}
+
+// one row; `name` = mod code (or `code,MOTIF,offset`); returns the end of the written text (at most ~200 bytes + chrom + name)
+inline char* format_row(char* p, const char* chrom, size_t chrom_n, const char* name, size_t name_n, char sp, uint32_t pos, char strand,
+                        uint32_t n_valid, uint32_t n_mod, uint32_t n_can, uint32_t n_other, uint32_t n_del, uint32_t n_fail, uint32_t n_diff, uint32_t n_nocall) {
+  memcpy(p, chrom, chrom_n); p += chrom_n; *p++ = '\t';
+  p = put_u32(p, pos); *p++ = '\t'; p = put_u32(p, pos + 1u); *p++ = '\t';
+  memcpy(p, name, name_n); p += name_n; *p++ = '\t';
+  p = put_u32(p, n_valid); *p++ = '\t'; *p++ = strand; *p++ = '\t';
+  p = put_u32(p, pos); *p++ = '\t'; p = put_u32(p, pos + 1u); *p++ = '\t';
+  memcpy(p, "255,0,0\t", 8); p += 8;
+  p = put_u32(p, n_valid); *p++ = sp;
+  const float frac = (float)n_mod / (float)n_valid;   // fraction_modified (pileup/mod.rs:401), f32
+  p = put_pct2(p, frac * 100.0f); *p++ = sp;
+  p = put_u32(p, n_mod); *p++ = sp; p = put_u32(p, n_can); *p++ = sp; p = put_u32(p, n_other); *p++ = sp;
+  p = put_u32(p, n_del); *p++ = sp; p = put_u32(p, n_fail); *p++ = sp; p = put_u32(p, n_diff); *p++ = sp;
+  p = put_u32(p, n_nocall); *p++ = '\n';
+  return p;
+}
+
+}  // namespace mkp

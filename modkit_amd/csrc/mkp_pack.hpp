@@ -166,13 +166,49 @@ struct ShardHost {
   std::vector<uint32_t> ranks; std::vector<uint8_t> ml;
   uint64_t n_events_cap = 0, n_calls = 0;
   std::vector<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
+  // append another shard piece packed independently (parallel packing): offsets of `o` are rebased, layout ids remapped
+  void append(const ShardHost& o, const std::vector<uint16_t>& layout_map) {
+    const uint32_t b_cigar = (uint32_t)cigar.size(), b_chunk = (uint32_t)(chunk_pfx.size() / 2), b_seq = (uint32_t)seq.size(), b_tag = (uint32_t)tagref.size(),
+                   b_rank = (uint32_t)ranks.size(), b_ml = (uint32_t)ml.size();
+    if ((uint64_t)b_seq + o.seq.size() > 0xfffffff0ull || (uint64_t)b_cigar + o.cigar.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
+    if (n_events_cap + o.n_events_cap > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
+    const size_t h0 = hdr.size(), t0 = tagref.size();
+    hdr.insert(hdr.end(), o.hdr.begin(), o.hdr.end());
+    for (size_t i = h0; i < hdr.size(); i++) {
+      MkpReadHdr& h = hdr[i];
+      h.cigar_off += b_cigar; h.chunk_off += b_chunk; h.seq_off += b_seq; h.tag_off += b_tag; h.event_off += (uint32_t)n_events_cap;
+      if (h.n_tags) h.layout = layout_map[h.layout];
+    }
+    tagref.insert(tagref.end(), o.tagref.begin(), o.tagref.end());
+    for (size_t i = t0; i < tagref.size(); i++) { tagref[i].rank_off += b_rank; tagref[i].ml_off += b_ml; }
+    cigar.insert(cigar.end(), o.cigar.begin(), o.cigar.end()); chunk_pfx.insert(chunk_pfx.end(), o.chunk_pfx.begin(), o.chunk_pfx.end());
+    seq.insert(seq.end(), o.seq.begin(), o.seq.end()); ranks.insert(ranks.end(), o.ranks.begin(), o.ranks.end()); ml.insert(ml.end(), o.ml.begin(), o.ml.end());
+    name_hash.insert(name_hash.end(), o.name_hash.begin(), o.name_hash.end());
+    n_events_cap += o.n_events_cap; n_calls += o.n_calls;
+  }
   void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); }
 };
 
 class Packer {
  public:
   std::vector<LayoutHost> layouts;
+  std::vector<std::string> layout_keys;   // key of layouts[i]
   std::unordered_map<std::string, uint16_t> layout_ids;
+
+  // intern the layouts of an independently used packer; returns its id -> this packer's id (first-appearance order is kept)
+  std::vector<uint16_t> adopt(const Packer& o) {
+    std::vector<uint16_t> map(o.layouts.size());
+    for (size_t i = 0; i < o.layouts.size(); i++) {
+      auto it = layout_ids.find(o.layout_keys[i]);
+      if (it == layout_ids.end()) {
+        if (layouts.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "too many distinct MM header structures");
+        layouts.push_back(o.layouts[i]); layout_keys.push_back(o.layout_keys[i]);
+        it = layout_ids.emplace(o.layout_keys[i], (uint16_t)(layouts.size() - 1)).first;
+      }
+      map[i] = it->second;
+    }
+    return map;
+  }
 
   // aux scan (bam_aux_get: first occurrence); returns pointer at the type byte or null
   static const uint8_t* aux_find(const uint8_t* aux, size_t n, char t0, char t1) {
@@ -314,7 +350,7 @@ class Packer {
     auto it = layout_ids.find(key);
     if (it == layout_ids.end()) {
       if (layouts.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "too many distinct MM header structures");
-      LayoutHost L; L.tags = hdrs; layouts.push_back(std::move(L));
+      LayoutHost L; L.tags = hdrs; layouts.push_back(std::move(L)); layout_keys.push_back(key);
       it = layout_ids.emplace(key, (uint16_t)(layouts.size() - 1)).first;
     }
     h->layout = it->second; h->n_tags = (uint16_t)hdrs.size();
