@@ -11,8 +11,11 @@
 //                                   or the absolute forward position for `N` tags (735-767)
 //   uint8       ml[]                ML qualities (bytes of the B:C array)
 //   MkpLayout   layout[]            interned MM header structure + caller tables (host-built)
-//   MkpEvent    events[]            written by mkp_decode_reads, read by mkp_pileup_tiles
+//   uint32      read_ids[]          reads by decode kernel class (FAST 1 tag | FAST 2 tags | general), longest first in a class
+//   MkpEvent    events[]            written by the decode kernels, read by mkp_pileup_tiles
 //   MkpReadOut  readout[n_reads]    per-read decode summary
+//   uint32      tally[n_tiles][counters + slots][tile + 2*halo]   16-bit-packed strand tallies, mkp_pileup_tiles -> mkp_emit_rows
+//   MkpRowsDev  rows                SoA row buffers (per 1024-position segment, then gathered into genome order)
 #pragma once
 #include <stdint.h>
 
