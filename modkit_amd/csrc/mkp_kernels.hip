@@ -228,9 +228,9 @@ __device__ __forceinline__ uint32_t select8(uint32_t m, uint32_t r) {
 // SAMPLE = threshold-sampling pass: emits argmax probabilities instead of call events.
 // arr[j] for a wave-uniform j < N (N is tiny: a select chain, no scratch)
 template <int N> __device__ __forceinline__ uint32_t selN(const uint32_t* a, uint32_t j) {
-  uint32_t r = a[0];
+  uint32_t r = 0;   // OR of masked elements: a select chain over array elements is folded into an indexed (scratch) load
 #pragma unroll
-  for (int i = 1; i < N; i++) r = (j == (uint32_t)i) ? a[i] : r;
+  for (int i = 0; i < N; i++) r |= (j == (uint32_t)i) ? a[i] : 0u;
   return r;
 }
 
