@@ -1,6 +1,7 @@
 """GPU parity, part 2: differential tests oracle vs device on seeded fuzzed modBAMs (tests/bamfuzz.py).
 Contigs are longer than one LDS tile so tile seams, halos and multi-tile reads are exercised; `--tile 256`
 forces many small tiles.  Bit-exact comparison of the whole bedMethyl text."""
+import os
 import subprocess
 
 import pytest
@@ -57,7 +58,11 @@ def run_both(oracle_bin, tmp_path, bam, flags, extra_dev=()):
     return a
 
 
-@pytest.mark.parametrize("seed", range(6))
+# MKP_FUZZ_SEEDS=a:b widens the sweep for one-off soak runs (default: the 6 seeds the suite pins)
+_S = os.environ.get("MKP_FUZZ_SEEDS", "0:6").split(":")
+
+
+@pytest.mark.parametrize("seed", range(int(_S[0]), int(_S[1])))
 @pytest.mark.parametrize("fi", range(len(FLAG_SETS)))
 def test_fuzz_mixed(oracle_bin, tmp_path, seed, fi):
     bam, fa, bed = Fuzz(1000 + seed).write(str(tmp_path / "fz"), bed=True)
