@@ -315,7 +315,8 @@ int run(const Args& a, std::string* msg) {
   if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", wr.f);
   // shard plan: one shard per contig record, or pieces of it cut at interval boundaries; ranks take contiguous runs
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
-  uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, (total_bp + a.world * 8 - 1) / (a.world * 8)) : (1ull << 30));
+  uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
+  // 2^27 positions per shard keeps the per-shard tally buffer (4 B x (counters + slots) per position, plus halos) at a few GB
   uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0;
   for (auto& rec : records) {
     std::vector<uint8_t> focus; const bool hf = fb.has_focus();
