@@ -178,6 +178,17 @@ int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int argc, const 
  * device histogrammed; and the f32 histogram itself for multi-GPU all-reduce. */
 int mkp_percentile(const float* sorted, uint64_t n, float q, float* out);
 
+/* ---- host-side pieces exposed for tests (no device needed):
+ * mkp_host_mm_ranks: the packer's MM tokeniser (MmTagInfo::parse, src/mod_bam.rs:909-1000) on one MM string: for every tag its
+ *   header (fundamental base A,C,G,T,N = 0..4; strand; mode 0 '?', 1 '.', 2 none; codes as code_repr) and its delta list turned into
+ *   the cumulative occurrence ranks sum(d+1)-1 the device consumes (DeltaListConverter::to_positions_specific, 697-733, is rank ->
+ *   position).  Returns the number of tags, or a negative status (MKP_E_INVALID = the reference would reject the tag).
+ * mkp_host_map_order: iteration order of a small FxHashMap<ModCodeRepr, _> filled in the given insertion order (rustc-hash 1.1 +
+ *   hashbrown), which decides probability ties in MultipleThresholdModCaller::call (src/threshold_mod_caller.rs:28-63). */
+typedef struct { uint8_t base, negative_strand, mode, n_codes; uint32_t codes[4]; uint32_t rank_off, n_ranks; } mkp_host_tag;
+int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_tag* tags, uint32_t tags_cap, uint32_t* ranks, uint32_t ranks_cap);
+int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,7 @@ def lib():
 
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
-           "mkp_percentile", "mkp_estimate_thresholds"]
+           "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order"]
 
 
 def pileup(argv):

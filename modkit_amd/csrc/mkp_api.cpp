@@ -338,6 +338,37 @@ int mkp_percentile(const float* xs, uint64_t n, float q, float* out) {  // perce
   return MKP_OK;
 }
 
+int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_tag* tags, uint32_t tags_cap, uint32_t* ranks, uint32_t ranks_cap) {
+  if (!mm || (!tags && tags_cap) || (!ranks && ranks_cap)) return MKP_E_INVALID;
+  try {
+    // a synthetic one-record shard: qname "r", one M op, all-A SEQ, aux = MM:Z + ML:B:C (n_ml zero bytes)
+    std::vector<uint8_t> data; data.push_back('r'); data.push_back(0);
+    const uint32_t cg = (l_seq << 4) | 0u; data.insert(data.end(), (const uint8_t*)&cg, (const uint8_t*)&cg + 4);
+    data.insert(data.end(), (l_seq + 1) / 2, 0x11); data.insert(data.end(), l_seq, 0xff);
+    data.push_back('M'); data.push_back('M'); data.push_back('Z'); data.insert(data.end(), mm, mm + strlen(mm) + 1);
+    data.push_back('M'); data.push_back('L'); data.push_back('B'); data.push_back('C'); data.insert(data.end(), (const uint8_t*)&n_ml, (const uint8_t*)&n_ml + 4); data.insert(data.end(), n_ml, 0);
+    mkp_record r; memset(&r, 0, sizeof(r)); r.tid = 0; r.pos = 0; r.l_qname = 2; r.n_cigar = 1; r.l_qseq = (int32_t)l_seq; r.l_data = (int32_t)data.size(); r.data = data.data();
+    Packer pk; ShardHost S; S.tid = 0; pk.add(r, S);
+    if (S.hdr.empty() || (S.hdr[0].flags & MKP_RF_BAD)) return MKP_E_INVALID;
+    const LayoutHost& L = pk.layouts[S.hdr[0].layout];
+    if (L.tags.size() > tags_cap || S.ranks.size() > ranks_cap) return MKP_E_NOMEM;
+    for (size_t t = 0; t < L.tags.size(); t++) {
+      mkp_host_tag& o = tags[t]; memset(&o, 0, sizeof(o));
+      o.base = L.tags[t].fb; o.negative_strand = L.tags[t].neg; o.mode = L.tags[t].mode; o.n_codes = (uint8_t)L.tags[t].codes.size();
+      for (size_t i = 0; i < L.tags[t].codes.size() && i < 4; i++) o.codes[i] = L.tags[t].codes[i];
+      o.rank_off = S.tagref[t].rank_off; o.n_ranks = S.tagref[t].n;
+    }
+    for (size_t i = 0; i < S.ranks.size(); i++) ranks[i] = S.ranks[i];
+    return (int)L.tags.size();
+  } catch (const Error& e) { return e.status; } catch (...) { return MKP_E_INVALID; }
+}
+
+int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_out) {
+  if (!code_reprs || !order_out || n > 14) return MKP_E_INVALID;
+  try { FxOrder m; for (uint32_t i = 0; i < n; i++) m.insert(code_reprs[i], (int)i); auto c = m.codes(); for (size_t i = 0; i < c.size(); i++) order_out[i] = c[i]; return (int)c.size(); }
+  catch (...) { return MKP_E_INVALID; }
+}
+
 }  // extern "C"
 
 int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,

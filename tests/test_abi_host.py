@@ -29,7 +29,7 @@ def declared_symbols():
 
 def test_every_declared_symbol_is_exported(L):
     syms = declared_symbols()
-    assert len(syms) == 14 and sorted(modkit_amd.EXPORTS) == syms
+    assert len(syms) == 16 and sorted(modkit_amd.EXPORTS) == syms
     for s in syms:
         assert getattr(L, s) is not None
     nm = subprocess.check_output(["nm", "-D", "--defined-only", modkit_amd.LIB_PATH], text=True)
@@ -105,3 +105,56 @@ def test_bad_arguments_do_not_crash(L):
     assert L.mkp_pileup_main(1, arr, err, 256) == -1 and b"usage" in err.value
     arr = (ctypes.c_char_p * 3)(b"/nonexistent.bam", b"/dev/null", b"--partition-tag")
     assert L.mkp_pileup_main(3, arr, err, 256) in (-1, -3)
+
+
+class HostTag(ctypes.Structure):
+    _fields_ = [("base", ctypes.c_uint8), ("negative_strand", ctypes.c_uint8), ("mode", ctypes.c_uint8), ("n_codes", ctypes.c_uint8),
+                ("codes", ctypes.c_uint32 * 4), ("rank_off", ctypes.c_uint32), ("n_ranks", ctypes.c_uint32)]
+
+
+def mm_ranks(L, mm, l_seq, n_ml):
+    tags = (HostTag * 8)()
+    ranks = (ctypes.c_uint32 * 256)()
+    L.mkp_host_mm_ranks.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HostTag), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32]
+    n = L.mkp_host_mm_ranks(mm.encode(), l_seq, n_ml, tags, 8, ranks, 256)
+    if n < 0:
+        return n
+    return [dict(base="ACGTN"[t.base], neg=bool(t.negative_strand), mode="?. "[t.mode], codes=[t.codes[i] for i in range(t.n_codes)],
+                 ranks=[ranks[t.rank_off + i] for i in range(t.n_ranks)]) for t in tags[:n]]
+
+
+def test_mm_tokeniser_known_answers(L):
+    # src/mod_bam.rs:1924-1953 (test_delta_list_to_positions): read ACCGCCGTCGTCG, the C's sit at 1,2,4,5,8,11.
+    # delta lists -> k-th occurrence ranks; positions = occurrence[rank], checked here against the reference's expected positions
+    cpos = [i for i, c in enumerate("ACCGCCGTCGTCG") if c == "C"]
+    for ds, expected in (([1, 1, 0], [2, 5, 8]), ([3, 0, 0], [5, 8, 11]), ([3, 1], [5, 11])):
+        tags = mm_ranks(L, "C+m?,%s;" % ",".join(map(str, ds)), 13, len(ds))
+        assert len(tags) == 1 and tags[0]["base"] == "C" and tags[0]["mode"] == "?" and tags[0]["codes"] == [ord("m")]
+        assert [cpos[r] for r in tags[0]["ranks"]] == expected
+    # header forms (MmTagInfo::parse, 909-1000): combined codes, ChEBI, strands, modes, whitespace, several tags
+    tags = mm_ranks(L, "C+hm?,0,1,0;A-a.,2 ,0;N+76792,5;T+g;", 40, 6 + 2 + 1)
+    assert [t["base"] for t in tags] == ["C", "A", "N", "T"] and [t["neg"] for t in tags] == [False, True, False, False]
+    assert [t["mode"] for t in tags] == ["?", ".", " ", " "]
+    assert tags[0]["codes"] == [ord("h"), ord("m")] and tags[2]["codes"] == [0x80000000 | 76792] and tags[3]["ranks"] == []
+    assert tags[0]["ranks"] == [0, 2, 3] and tags[1]["ranks"] == [2, 3] and tags[2]["ranks"] == [5]
+    # rejected by the reference: bad base, missing strand, ML shorter than the calls (1222-1228), N-tag position past the read end
+    assert mm_ranks(L, "X+m?,1;", 10, 1) == -1
+    assert mm_ranks(L, "Cm?,1;", 10, 1) == -1
+    assert mm_ranks(L, "C+m?,1,2,3;", 10, 2) == -1
+    assert mm_ranks(L, "N+m?,4,5;", 10, 2) == -1
+
+
+def test_fxhashmap_iteration_order(L):
+    # src/mod_bam.rs:2250-2258 pins h before m whatever the insertion order (FxHasher: Code(c) -> bucket c & 3 in a 4-bucket table)
+    L.mkp_host_map_order.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+
+    def order(codes):
+        a = (ctypes.c_uint32 * len(codes))(*codes)
+        o = (ctypes.c_uint32 * 16)()
+        n = L.mkp_host_map_order(a, len(codes), o)
+        return [o[i] for i in range(n)]
+    h, m, a_, c_ = ord("h"), ord("m"), ord("a"), ord("c")
+    assert order([h, m]) == [h, m] and order([m, h]) == [h, m]
+    assert order([m]) == [m] and order([c_, h]) == [h, c_]          # buckets: h -> 0, m -> 1, a -> 1, c -> 3
+    assert order([m, a_]) == [m, a_] and order([a_, m]) == [a_, m]  # same bucket: linear probing keeps insertion order
+    assert len(order([h, m, a_, c_])) == 4                          # fourth insert grows the table to 8 buckets
