@@ -329,7 +329,12 @@ int run(const Args& a, std::string* msg) {
       const uint32_t owner = total_bp ? (uint32_t)std::min<uint64_t>(a.world - 1, mid * a.world / total_bp) : 0;
       i0 = i1;
       if (owner != a.rank) continue;
-      if (a.plan_only) { fprintf(wr.f, "%s\t%u\t%u\n", rec.name.c_str(), s0, s1); positions += bp; continue; }
+      if (a.plan_only) {  // host-only dry run: the shard plan, plus the packer over the shard's records (no device)
+        std::vector<size_t> ov; fetch(bam, rec.tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, &ov);
+        Packer pk; ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1; size_t kept = 0;
+        for (size_t i : ov) { mkp_record r = bam.view(bam.recs[i]); if (r.tid == (int32_t)rec.tid && Packer::keep(r)) { pk.add(r, S); kept++; } }
+        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\n", rec.name.c_str(), s0, s1, kept, (unsigned long long)S.n_calls); positions += bp; continue;
+      }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
       must(mkp_shard_begin(ctx, &sh));

@@ -124,4 +124,4 @@ def shard_plan(argv, rank, world):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "plan.tsv")
         pileup([argv[0], out] + list(argv[2:]) + ["--plan-only", "--gpus-rank", str(rank), "--gpus-world", str(world)])
-        return [(c, int(s), int(e)) for c, s, e in (l.split("\t") for l in open(out).read().splitlines())]
+        return [(l[0], int(l[1]), int(l[2])) for l in (x.split("\t") for x in open(out).read().splitlines())]
