@@ -71,9 +71,13 @@ def test_fuzz_mixed(oracle_bin, tmp_path, seed, fi):
     assert out is None or isinstance(out, str)
 
 
+_PS = os.environ.get("MKP_FUZZ_PROFILE_SEEDS", "77:78").split(":")
+
+
+@pytest.mark.parametrize("pseed", range(int(_PS[0]), int(_PS[1])))
 @pytest.mark.parametrize("profile", ["m", "hm_comb", "hm_split", "hm_split_diff", "hma", "implicit", "default", "duplex", "nbase", "chebi"])
-def test_fuzz_profiles(oracle_bin, tmp_path, profile):
-    bam, fa, bed = Fuzz(77, profile=profile, n_reads=400, tie_rate=0.2).write(str(tmp_path / "fz"), bed=True)
+def test_fuzz_profiles(oracle_bin, tmp_path, profile, pseed):
+    bam, fa, bed = Fuzz(pseed, profile=profile, n_reads=400, tie_rate=0.2).write(str(tmp_path / "fz"), bed=True)
     rows = 0
     for flags in (["--no-filtering", "--force-allow-implicit"], ["--filter-threshold", "0.7", "--force-allow-implicit", "--cpg", "--ref", fa],
                   ["--preset", "traditional", "--ref", fa, "-p", "0.2", "--force-allow-implicit"]):
