@@ -573,11 +573,12 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
 // ----------------------------------------------------------------------------------------------
 // Decode, FAST layouts (MkpLayout::fast: every tag on the same specific base and mod strand, no code listed twice —
 // `C+m?`, `C+hm?`, `C+h?;C+m?`, ...; NT <= 2 tags).  Same semantics as decode_read_body, restructured as a
-// producer/consumer inside the wave: the 512-base steps only *locate* calls and append {stored position, ML index per
+// producer/consumer inside the wave: the 1024-base steps (16 bases per lane) only *locate* calls and append {stored position, ML index per
 // tag} to a queue in LDS; whenever 64 calls are queued one full batch runs the per-call work (ML -> f32, collapse,
 // threshold caller, CIGAR mapping, event append).  With CpG data a step finds ~13 calls, so batches run at full
 // lane occupancy instead of ~20 %.  The group descriptor, thresholds and code maps are wave-uniform (SGPRs).
-#define MKP_QCAP 576   // 63 left over + up to 512 from one step
+#define MKP_QCAP 576   // 63 left over + up to 512 from half a step (32 lanes x 16 bases)
+#define MKP_ORD_WORDS 34   // ordinal bitmap of a 1024-base step: 32 words + 2 for the 64-bit window read
 template <bool SAMPLE, int NT>
 __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
@@ -595,7 +596,7 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
   uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
-  uint32_t* __restrict__ ordb = lds_ord + wib * (NT * 18);            // [NT][18] ordinal bitmaps of the step
+  uint32_t* __restrict__ ordb = lds_ord + wib * (NT * MKP_ORD_WORDS);   // [NT][MKP_ORD_WORDS] ordinal bitmaps of the step
   uint32_t* __restrict__ q_pos = lds_queue + wib * ((1 + NT) * MKP_QCAP);   // queue, SoA: stored position, ML call index of tag 0 / 1 (~0 = not listed)
   uint32_t* __restrict__ q_j0 = q_pos + MKP_QCAP;
   uint32_t* __restrict__ q_j1 = q_pos + (NT > 1 ? 2 : 1) * MKP_QCAP;
@@ -656,12 +657,20 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   uint32_t w_op = 5u, w_qe = 0; int32_t w_dl = 0; uint32_t w_rtot = 0;
   bool win_loaded = false;
   uint32_t qhead = 0, qcount = 0, d0 = 0;
-  uint32_t x_next = (uint32_t)lane < nd ? seqw[lane] : 0u;   // the next step's SEQ dword is always in flight
+  // the next step's SEQ dwords (two per lane = 16 bases) are always in flight
+  uint32_t x_next0 = 2u * (uint32_t)lane < nd ? seqw[2u * lane] : 0u, x_next1 = 2u * (uint32_t)lane + 1u < nd ? seqw[2u * lane + 1u] : 0u;
+  // a step's located calls are appended in two halves (lanes 0-31, then 32-63) so the queue never has to take more than
+  // 512 entries at once; these hold the step's state between the halves
+  bool pend = false;
+  uint32_t st_U = 0, st_uincl = 0, st_ucnt = 0, st_HA = 0, st_H = 0, st_cntT = 0, st_d = 0;
+  uint32_t st_bm[NT], st_texcl[NT], st_cur[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { st_bm[t] = 0; st_texcl[t] = 0; st_cur[t] = 0; }
 
   for (;;) {
     if (err) break;
-    if (qcount - qhead < 64u && d0 < nd) {
-      // ---- producer: one 512-base step appends its calls to the queue
+    if (qcount - qhead < 64u && (pend || d0 < nd)) {
+      // ---- producer: one 1024-base step locates its calls; each half of the lanes appends them to the queue
       if (qhead) {  // move the (< 64) unconsumed entries to the front
         const uint32_t n_left = qcount - qhead;
         const bool mv = (uint32_t)lane < n_left;
@@ -670,75 +679,85 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (mv) { q_pos[lane] = a; q_j0[lane] = b; if (NT > 1) q_j1[lane] = c; }
         qcount = n_left; qhead = 0;
       }
-      const uint32_t d = d0 + lane;
-      const uint32_t xl = linearize(x_next);
-      { const uint32_t dn = d + 64u; x_next = dn < nd ? seqw[dn] : 0u; }
-      // the first 64 ranks at every tag's cursor are requested now, ahead of the match/scan work that decides how many are used
-      uint32_t e_pre[NT]; bool v_pre[NT];
+      if (!pend) {
+        const uint32_t d = d0 + 2u * (uint32_t)lane;          // this lane's first dword: bases [8d, 8d+16)
+        const uint32_t xl0 = linearize(x_next0), xl1 = linearize(x_next1);
+        { const uint32_t dn = d + 128u; x_next0 = dn < nd ? seqw[dn] : 0u; x_next1 = dn + 1u < nd ? seqw[dn + 1u] : 0u; }
+        // the first 64 ranks at every tag's cursor are requested now, ahead of the match/scan work that decides how many are used
+        uint32_t e_pre[NT]; bool v_pre[NT];
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        e_pre[t] = rev ? 0u : 0xffffffffu; v_pre[t] = false;
-        if (t < n_tags) {
-          const uint32_t i = rev ? (t_cur[t] - 64u + lane) : (t_cur[t] + lane);
-          v_pre[t] = rev ? ((int32_t)i >= 0 && i < t_cur[t]) : (i < t_n[t]);
-          if (v_pre[t]) e_pre[t] = ranks[t_off[t] + i];
+        for (int t = 0; t < NT; t++) {
+          e_pre[t] = rev ? 0u : 0xffffffffu; v_pre[t] = false;
+          if (t < n_tags) {
+            const uint32_t i = rev ? (t_cur[t] - 64u + lane) : (t_cur[t] + lane);
+            v_pre[t] = rev ? ((int32_t)i >= 0 && i < t_cur[t]) : (i < t_n[t]);
+            if (v_pre[t]) e_pre[t] = ranks[t_off[t] + i];
+          }
         }
-      }
-      const int nv = min(max((int)L - (int)(8u * d), 0), 8);
-      const uint32_t m8 = match8(xl, xs) & ((1u << nv) - 1u);
-      const uint32_t c = (uint32_t)__popc(m8), incl = wave_incl_scan(c);
-      const uint32_t cntT = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      const uint32_t wlo = rev ? (tot - cum - cntT) : cum, whi = wlo + cntT;   // rank window of this step
-      uint32_t cur_before[NT];
+        const int nv = min(max((int)L - (int)(8u * d), 0), 16);
+        const uint32_t m16 = (match8(xl0, xs) | (match8(xl1, xs) << 8)) & ((1u << nv) - 1u);
+        const uint32_t c = (uint32_t)__popc(m16), incl = wave_incl_scan(c);
+        const uint32_t cntT = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t wlo = rev ? (tot - cum - cntT) : cum, whi = wlo + cntT;   // rank window of this step
 #pragma unroll
-      for (int t = 0; t < NT; t++) { cur_before[t] = t_cur[t]; if (t < n_tags && lane < 18) ordb[t * 18 + lane] = 0; }
+        for (int t = 0; t < NT; t++) { st_cur[t] = t_cur[t]; if (t < n_tags && lane < MKP_ORD_WORDS) ordb[t * MKP_ORD_WORDS + lane] = 0; }
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        if (t >= n_tags) break;
-        for (bool first = true;; first = false) {
-          uint32_t e; bool hit, valid; uint32_t nh;
-          if (first) { e = e_pre[t]; valid = v_pre[t]; }
-          else if (!rev) { const uint32_t i = t_cur[t] + lane; valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; }
-          else { const uint32_t i = t_cur[t] - 64u + lane; valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; }
-          if (!rev) { hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
-          else { hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }   // an entry >= whi is past the last occurrence: never consumed -> error at the end
-          if (nh == 0) break;
-          const uint32_t ib = (rev ? (tot - 1u - e) : e) - cum;   // step-relative stored ordinal of the called base
-          if (hit) atomicOr(&ordb[t * 18 + (ib >> 5)], 1u << (ib & 31u));
-          if (nh < 64) break;
+        for (int t = 0; t < NT; t++) {
+          if (t >= n_tags) break;
+          for (bool first = true;; first = false) {
+            uint32_t e; bool hit, valid; uint32_t nh;
+            if (first) { e = e_pre[t]; valid = v_pre[t]; }
+            else if (!rev) { const uint32_t i = t_cur[t] + lane; valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; }
+            else { const uint32_t i = t_cur[t] - 64u + lane; valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; }
+            if (!rev) { hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
+            else { hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }   // an entry >= whi is past the last occurrence: never consumed -> error at the end
+            if (nh == 0) break;
+            const uint32_t ib = (rev ? (tot - 1u - e) : e) - cum;   // step-relative stored ordinal of the called base (< 1024)
+            if (hit) atomicOr(&ordb[t * MKP_ORD_WORDS + (ib >> 5)], 1u << (ib & 31u));
+            if (nh < 64) break;
+          }
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      uint32_t bm[NT], texcl[NT], U = impl0 ? m8 : 0u, uincl = 0, ucnt = 0;
-      const uint32_t ex = incl - c, clo = (uint32_t)__popc(m8 & 15u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t U = impl0 ? m16 : 0u, uincl = 0, ucnt = 0;
+        const uint32_t ex = incl - c;
+        const uint32_t n0 = m16 & 15u, n1 = (m16 >> 4) & 15u, n2 = (m16 >> 8) & 15u, n3 = m16 >> 12;
+        const uint32_t c0n = (uint32_t)__popc(n0), c1n = c0n + (uint32_t)__popc(n1), c2n = c1n + (uint32_t)__popc(n2);
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        bm[t] = 0; texcl[t] = 0;
-        if (t < n_tags) {  // bits [excl, excl+cnt) of the ordinal bitmap deposited onto the set bits of the lane's match mask
-          const uint32_t w0 = ordb[t * 18 + (ex >> 5)], w1 = ordb[t * 18 + (ex >> 5) + 1];
-          const uint32_t f = __builtin_amdgcn_alignbit(w1, w0, ex & 31u) & ((1u << c) - 1u);
-          bm[t] = (uint32_t)pdep4[((m8 & 15u) << 4) | (f & 15u)] | ((uint32_t)pdep4[(m8 & 0xf0u) | ((f >> clo) & 15u)] << 4);
-          U |= bm[t];
-          const uint32_t c2 = (uint32_t)__popc(bm[t]);
-          uincl = wave_incl_scan(c2); ucnt = c2; texcl[t] = uincl - c2;
+        for (int t = 0; t < NT; t++) {
+          st_bm[t] = 0; st_texcl[t] = 0;
+          if (t < n_tags) {  // bits [excl, excl+cnt) of the ordinal bitmap deposited onto the set bits of the lane's 16-base match mask
+            const uint32_t w0 = ordb[t * MKP_ORD_WORDS + (ex >> 5)], w1 = ordb[t * MKP_ORD_WORDS + (ex >> 5) + 1];
+            const uint32_t f = __builtin_amdgcn_alignbit(w1, w0, ex & 31u) & ((1u << c) - 1u);
+            st_bm[t] = (uint32_t)pdep4[(n0 << 4) | (f & 15u)] | ((uint32_t)pdep4[(n1 << 4) | ((f >> c0n) & 15u)] << 4) |
+                       ((uint32_t)pdep4[(n2 << 4) | ((f >> c1n) & 15u)] << 8) | ((uint32_t)pdep4[(n3 << 4) | ((f >> c2n) & 15u)] << 12);
+            U |= st_bm[t];
+            const uint32_t c2 = (uint32_t)__popc(st_bm[t]);
+            uincl = wave_incl_scan(c2); ucnt = c2; st_texcl[t] = uincl - c2;
+          }
         }
+        if (NT > 1 || impl0) { ucnt = (uint32_t)__popc(U); uincl = wave_incl_scan(ucnt); }   // else U == bm[0]: its scan is already there
+        st_U = U; st_uincl = uincl; st_ucnt = ucnt; st_d = d; st_cntT = cntT;
+        st_H = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 63); st_HA = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 31);
       }
-      if (NT > 1 || impl0) { ucnt = (uint32_t)__popc(U); uincl = wave_incl_scan(ucnt); }   // else U == bm[0]: its scan is already there
-      const uint32_t H = (uint32_t)__builtin_amdgcn_readlane((int)uincl, 63);
-      { uint32_t ut = U, sidx = qcount + uincl - ucnt;
+      {  // append this half's calls: lanes 0-31 first, lanes 32-63 on the next visit
+        const bool mine = pend ? (lane >= 32) : (lane < 32);
+        uint32_t ut = mine ? st_U : 0u, sidx = qcount + st_uincl - st_ucnt - (pend ? st_HA : 0u);
         while (ut) {
           const uint32_t bit = (uint32_t)__ffs((int)ut) - 1u, below = (1u << bit) - 1u;
-          q_pos[sidx] = 8u * d + bit;
+          q_pos[sidx] = 8u * st_d + bit;
 #pragma unroll
           for (int t = 0; t < NT; t++) {
-            const uint32_t idx = texcl[t] + (uint32_t)__popc(bm[t] & below);
-            const uint32_t jx = rev ? (cur_before[t] - 1u - idx) : (cur_before[t] + idx);
-            (t == 0 ? q_j0 : q_j1)[sidx] = ((bm[t] >> bit) & 1u) ? jx : 0xffffffffu;
+            const uint32_t idx = st_texcl[t] + (uint32_t)__popc(st_bm[t] & below);
+            const uint32_t jx = rev ? (st_cur[t] - 1u - idx) : (st_cur[t] + idx);
+            (t == 0 ? q_j0 : q_j1)[sidx] = ((st_bm[t] >> bit) & 1u) ? jx : 0xffffffffu;
           }
           sidx++; ut &= ut - 1u;
-        } }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      qcount += H; cum += cntT; d0 += 64;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        qcount += pend ? (st_H - st_HA) : st_HA;
+        if (!pend && st_H > st_HA) pend = true;                  // the upper lanes still hold calls
+        else { pend = false; cum += st_cntT; d0 += 128; }        // step done
+      }
       continue;
     }
     if (qcount == qhead) break;
@@ -890,7 +909,7 @@ __device__ __forceinline__ void init_pdep4(uint8_t* pdep4) {
 template <bool SAMPLE, int NT> __device__ __forceinline__ void decode_fast_entry(DECODE_PARAMS(const MkpRunParams&)) {
   __shared__ uint32_t lds_queue[4][(1 + NT) * MKP_QCAP];
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
-  __shared__ uint32_t lds_ord[4][NT * 18];
+  __shared__ uint32_t lds_ord[4][NT * MKP_ORD_WORDS];
   __shared__ uint8_t pdep4[256];
   init_pdep4(pdep4);
   decode_read_fast<SAMPLE, NT>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals,
