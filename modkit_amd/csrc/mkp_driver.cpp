@@ -3,7 +3,9 @@
 // with process_region_batch replaced by shards on the GPU.  Host work here is scheduling only:
 // BAM ingest, the interval grid + focus positions, choosing which reads the threshold sampler takes
 // (reads_sampler/*, sampling_schedule.rs), and formatting rows (writers.rs:87-156).
+#include <memory>
 #include <set>
+#include <thread>
 
 #include "mkp_ctx.hpp"
 #include "mkp_focus.hpp"
@@ -222,22 +224,33 @@ void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) 
   }
 }
 
-// bedMethyl text (writers.rs:87-156) through mkp_format.hpp, buffered
+// bedMethyl text (writers.rs:87-156) through mkp_format.hpp: row ranges are formatted by all host cores into per-thread
+// buffers and written out in order
 struct RowWriter {
-  FILE* f; bool mixed; std::vector<std::string> labels; uint64_t n = 0; std::vector<char> buf;
-  void write(const std::string& chrom, const mkp_rows& r) {
+  struct TextBuf { std::unique_ptr<char[]> mem; size_t n = 0; };
+  FILE* f; bool mixed; std::vector<std::string> labels; uint64_t n = 0;
+  static size_t row_bound(size_t chrom_n) { return chrom_n + 96 + 14 * 11 + 32; }   // chrom + name + 14 numbers + separators
+  void format_range(const std::string& chrom, const mkp_rows& r, uint64_t lo, uint64_t hi, TextBuf* out) const {
     const char sp = mixed ? ' ' : '\t';
-    if (buf.empty()) buf.resize(1 << 20);
-    char* p = buf.data(); char* const hi = buf.data() + buf.size() - 512 - chrom.size();
-    for (uint64_t i = 0; i < r.n_rows; i++) {
+    out->mem.reset(new char[(size_t)(hi - lo) * row_bound(chrom.size()) + 1]);   // uninitialised: only the written pages get touched
+    char* p = out->mem.get();
+    for (uint64_t i = lo; i < hi; i++) {
       char name[96]; uint32_t code = r.code_repr[i];
       int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : (name[0] = (char)code, name[1] = 0, 1);
       if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) k += snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
       p = format_row(p, chrom.data(), chrom.size(), name, (size_t)std::min<int>(k, (int)sizeof(name) - 1), sp, r.pos[i], (char)r.strand[i], r.n_valid[i], r.n_mod[i], r.n_canonical[i], r.n_other[i],
                      r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
-      if (p > hi) { fwrite(buf.data(), 1, (size_t)(p - buf.data()), f); p = buf.data(); }
     }
-    if (p > buf.data()) fwrite(buf.data(), 1, (size_t)(p - buf.data()), f);
+    out->n = (size_t)(p - out->mem.get());
+  }
+  void write(const std::string& chrom, const mkp_rows& r) {
+    if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
+    const unsigned n_thr = r.n_rows >= 65536 ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<TextBuf> bufs(n_thr); std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_thr; t++) th.emplace_back([&, t]() { format_range(chrom, r, r.n_rows * t / n_thr, r.n_rows * (t + 1) / n_thr, &bufs[t]); });
+    format_range(chrom, r, 0, r.n_rows / n_thr, &bufs[0]);
+    for (auto& x : th) x.join();
+    for (auto& b : bufs) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) throw Error(MKP_E_IO, "short write on the bedMethyl output");
     n += r.n_rows;
   }
 };
