@@ -93,3 +93,14 @@ def test_deep_long_reads_many_tiles(oracle_bin, tmp_path):
     assert out and len(out.splitlines()) > 500
     out = run_both(oracle_bin, tmp_path, bam, ["--filter-threshold", "0.75"], extra_dev=["--tile", "1024"])
     assert out and len(out.splitlines()) > 30000
+
+
+@pytest.mark.parametrize("shard_bp", [2000, 6000, 14000])
+def test_driver_shards_cut_inside_a_contig(oracle_bin, tmp_path, shard_bp):
+    # the driver cuts contigs longer than 2^27 bp into shards at interval boundaries; --shard-bp forces that on a 60 kb contig:
+    # rows (and the strand-combined rows whose partner sits across the cut) must not depend on where the shards end
+    bam, fa, bed = Fuzz(11, contigs=(("long", 60000), ("short", 3000)), n_reads=600, mean_len=5000, profile="hm_split", weird_rate=0.05).write(str(tmp_path / "fz"), bed=True)
+    for flags in (["-i", "2000", "--preset", "traditional", "--ref", fa, "--filter-threshold", "0.7"], ["-i", "2000", "--filter-threshold", "0.8", "--include-bed", bed],
+                  ["-i", "1000", "--cpg", "--ref", fa, "--combine-strands", "--no-filtering"]):
+        out = run_both(oracle_bin, tmp_path, bam, flags, extra_dev=["--shard-bp", str(shard_bp)])
+        assert out and len(out.splitlines()) > 100
