@@ -104,3 +104,14 @@ def test_driver_shards_cut_inside_a_contig(oracle_bin, tmp_path, shard_bp):
                   ["-i", "1000", "--cpg", "--ref", fa, "--combine-strands", "--no-filtering"]):
         out = run_both(oracle_bin, tmp_path, bam, flags, extra_dev=["--shard-bp", str(shard_bp)])
         assert out and len(out.splitlines()) > 100
+
+
+@pytest.mark.parametrize("profile", ["m", "hm_split", "hma"])
+def test_ultra_long_reads(oracle_bin, tmp_path, profile):
+    # reads of ~10^5 bases: hundreds of decode steps per read, CIGARs of tens of thousands of ops (many 64-op chunks), every
+    # tile of the contig crossed by every read
+    bam, fa, bed = Fuzz(21, contigs=(("ul", 250000),), n_reads=14, mean_len=120000, profile=profile, weird_rate=0.0).write(str(tmp_path / "fz"))
+    out = run_both(oracle_bin, tmp_path, bam, ["--filter-threshold", "0.75"])
+    assert out and len(out.splitlines()) > 10000
+    out = run_both(oracle_bin, tmp_path, bam, ["--cpg", "--ref", fa, "--combine-strands", "-p", "0.2", "--force-allow-implicit"])
+    assert out and len(out.splitlines()) > 1000
