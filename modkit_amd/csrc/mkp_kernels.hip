@@ -1062,6 +1062,11 @@ __device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunPara
 #define PILEUP_UNROLL 4
 #endif
 
+// LDS byte addresses as integers: a tally update is then `lane base + 256*window + row*4*TH`, two VALU instructions
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // first index in the position-sorted event list `ev[0..n)` whose pos is >= key: 64-way probes, two dependent
 // loads for up to 4096 events instead of a 12-step bisection
 __device__ __forceinline__ uint32_t event_lower_bound(const MkpEvent* __restrict__ ev, uint32_t n, int32_t key) {
@@ -1193,7 +1198,10 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
       }
     }
     const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
-    const uint8_t* __restrict__ lut = &rowlut[aln][0][0];
+    const uint8_t* __restrict__ lut = &rowlut[0][0][0];
+    const uint32_t aln2 = aln << 1;
+    const uint32_t TH4 = TH * 4u;
+    const uint32_t lanebase = lds_addr(tal) + 4u * (uint32_t)lane;   // LDS byte address of (row 0, position `lane`)
     const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 26) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
     for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
@@ -1239,6 +1247,8 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         const uint2 cc = comp[lane];
         const bool cvalid = (uint32_t)lane < nref;
         const int32_t c_rs = (int32_t)cc.x; const uint32_t c_pk = cc.y;
+        const int32_t c_key = cvalid ? c_rs : 0x7fffffff;
+        const uint32_t e_lo = lds_addr(tal) + 4u * (uint32_t)(c_lo - T0h), e_span = 4u * (uint32_t)(c_hi - c_lo);
         const bool mark = cvalid && c_rs > c_lo && c_rs < c_hi;
         const uint32_t mrel = (uint32_t)(c_rs - 1 - T0h);   // bit m set <=> an op starts at T0h+m+1: "starts at or before p" = bits strictly below p-T0h
         if (mark) atomicOr(&bm[mrel >> 5], 1u << (mrel & 31u));
@@ -1249,34 +1259,41 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         // PILEUP_UNROLL steps are issued together (bitmap read -> bpermute -> SEQ byte load) before any tally update.
         // ops started at or before the first position of window kk: a ballot over the compacted starts (no LDS dependency)
         const uint32_t k0 = (uint32_t)(c_lo - T0h) >> 6, k1 = (uint32_t)(c_hi - 1 - T0h) >> 6;
-        for (uint32_t kb = k0; kb <= k1; kb += PILEUP_UNROLL) {
-          const bool edge = kb == k0 || kb + PILEUP_UNROLL > k1;   // only the first and last groups hold out-of-range lanes
-          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL], idx[PILEUP_UNROLL]; uint2 W[PILEUP_UNROLL];
+        // Only the first and the last group of a chunk hold out-of-range lanes or repeated (clamped) windows; the groups in
+        // between run a version without the clamps and the range check.
+        auto group = [&](uint32_t kb, auto edge_c) {
+          constexpr bool EDGE = decltype(edge_c)::value;
+          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL], idx[PILEUP_UNROLL], kk[PILEUP_UNROLL]; uint2 W[PILEUP_UNROLL];
           // stage by stage across the PILEUP_UNROLL windows, so the LDS reads, the bpermutes and the global loads of the group overlap
 #pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++) W[j] = *reinterpret_cast<const uint2*>(bm + 2u * min(kb + (uint32_t)j, k1));
+          for (int j = 0; j < PILEUP_UNROLL; j++) kk[j] = EDGE ? min(kb + (uint32_t)j, k1) : kb + (uint32_t)j;
+#pragma unroll
+          for (int j = 0; j < PILEUP_UNROLL; j++) W[j] = *reinterpret_cast<const uint2*>(bm + 2u * kk[j]);
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
-            const int32_t wfirst = max(c_lo, T0h + (int32_t)(64u * min(kb + (uint32_t)j, k1)));
-            idx[j] = (uint32_t)__popcll(__ballot(cvalid && c_rs <= wfirst)) - 1u;
+            const int32_t wstart = T0h + (int32_t)(64u * kk[j]);
+            idx[j] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c_key <= (EDGE ? max(c_lo, wstart) : wstart))) - 1u;
           }
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++)
             pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(W[j].y, __builtin_amdgcn_mbcnt_lo(W[j].x, 0u))) << 2), (int)c_pk);
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
-            qq[j] = qlane + 64u * min(kb + (uint32_t)j, k1) + (pkv[j] >> 5);
+            qq[j] = qlane + 64u * kk[j] + (pkv[j] >> 5);
             byte[j] = seq[min(qq[j] >> 1, last_byte)];   // lanes on D/N ops or outside the span read a clamped (ignored) byte
           }
 #pragma unroll
           for (int j = 0; j < PILEUP_UNROLL; j++) {
-            const uint32_t kk = min(kb + (uint32_t)j, k1);
-            const uint32_t rowt = (uint32_t)lut[((qq[j] & 1u) << 8) + byte[j]] | (pkv[j] & 0x18u);   // >= 8: not ACGT, or the lane sits on a D/N op
-            const uint32_t rl = 64u * kk + (uint32_t)lane;
+            const uint32_t t = (qq[j] & 1u) | aln2;
+            const uint32_t rowt = (uint32_t)lut[(t << 8) | byte[j]] | (pkv[j] & 0x18u);   // >= 8: not ACGT, or the lane sits on a D/N op
+            const uint32_t la = lanebase + 256u * kk[j];
             bool ok = rowt < 8u;
-            if (edge) { const int32_t pos = T0h + (int32_t)rl; ok = ok && pos >= c_lo && pos < c_hi && kb + (uint32_t)j <= k1; }
-            if (ok) atomicAdd(&tal[__umul24(rowt, TH) + rl], inc);
+            if (EDGE) ok = ok && (la - e_lo) < e_span && kb + (uint32_t)j <= k1;
+            if (ok) lds_add(la + __umul24(rowt, TH4), inc);
           }
+        };
+        for (uint32_t kb = k0; kb <= k1; kb += PILEUP_UNROLL) {
+          if (kb == k0 || kb + PILEUP_UNROLL > k1) group(kb, std::true_type{}); else group(kb, std::false_type{});
         }
         if (mark) bm[mrel >> 5] = 0;
       }
