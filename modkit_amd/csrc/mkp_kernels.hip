@@ -20,7 +20,6 @@
 // Semantics follow /root/reference/src (cited inline); arithmetic that must be bit-exact is f32
 // with contraction off (-ffp-contract=off) and IEEE division.
 #include <hip/hip_runtime.h>
-#include <rocprim/warp/warp_scan.hpp>
 
 #include "mkp_device.h"
 
@@ -32,12 +31,16 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ unsigned long long lanemask_le() { int l = lane_id(); return l == 63 ? ~0ull : ((1ull << (l + 1)) - 1ull); }
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {  // DPP row_shr / row_bcast scan, no LDS traffic
-  using WS = rocprim::warp_scan<uint32_t, 64>;
-  WS::storage_type st;
-  uint32_t o;
-  WS().inclusive_scan(v, o, st);
-  return o;
+// Inclusive prefix sum over the wave: four row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31
+// carry the row totals across (lanes without a source add 0).  Six v_add_u32_dpp, no LDS traffic.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /*row_shr:4*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /*row_shr:8*/, 0xf, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);
+  return v;
 }
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 #pragma unroll
