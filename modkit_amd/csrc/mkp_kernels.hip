@@ -1153,33 +1153,6 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     const MkpReadOut ro = readout[rid];
     const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u;
     const uint8_t* __restrict__ seq = seqs + h.seq_off;
-    // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
-    if (ro.ok && lane < 2) {
-      uint32_t m = lane ? ro.obs[1] : ro.obs[0];
-      const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
-      while (m) {
-        const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-        atomicAdd(&obs[sl * TH + (uint32_t)(a - T0h)], lane ? 0x10000u : 1u);
-        if (b < T1h) atomicAdd(&obs[sl * TH + (uint32_t)(b - T0h)], 0u - (lane ? 0x10000u : 1u));
-      }
-    }
-    // the read's call events inside the tile (sorted by position); issued first so their loads overlap the depth walk
-    if (ro.ok && ro.n_events && !(prm.debug_skip & 2u)) {
-      const MkpEvent* __restrict__ ev = events + h.event_off;
-      const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
-      for (uint32_t k = lo + lane;; k += 64) {
-        bool in = k < ro.n_events;
-        MkpEvent e; e.pos = 0; e.info = 0;
-        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
-        if (in) {
-          const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
-          atomicAdd(&tal[(e.info & 0xffu) * TH + i], (e.info & 0x100u) ? 0x10000u : 1u);
-          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
-            atomicAdd(&tal[(MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0u - ((e.info & 0x800u) ? 0x10000u : 1u));
-        }
-        if (!__any(in)) break;
-      }
-    }
     // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
     // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
     uint32_t q_run = 0; int32_t r_run = h.ref_start; uint32_t c_first = 0;
@@ -1200,6 +1173,35 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
         }
       }
     }
+    // the first chunk's CIGAR words are requested now, ahead of the event work; every later chunk is requested one chunk ahead
+    uint32_t w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
+    // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
+    if (ro.ok && lane < 2) {
+      uint32_t m = lane ? ro.obs[1] : ro.obs[0];
+      const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
+      while (m) {
+        const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+        atomicAdd(&obs[sl * TH + (uint32_t)(a - T0h)], lane ? 0x10000u : 1u);
+        if (b < T1h) atomicAdd(&obs[sl * TH + (uint32_t)(b - T0h)], 0u - (lane ? 0x10000u : 1u));
+      }
+    }
+    // the read's call events inside the tile (sorted by position)
+    if (ro.ok && ro.n_events && !(prm.debug_skip & 2u)) {
+      const MkpEvent* __restrict__ ev = events + h.event_off;
+      const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
+      for (uint32_t k = lo + lane;; k += 64) {
+        bool in = k < ro.n_events;
+        MkpEvent e; e.pos = 0; e.info = 0;
+        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
+        if (in) {
+          const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
+          atomicAdd(&tal[(e.info & 0xffu) * TH + i], (e.info & 0x100u) ? 0x10000u : 1u);
+          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
+            atomicAdd(&tal[(MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0u - ((e.info & 0x800u) ? 0x10000u : 1u));
+        }
+        if (!__any(in)) break;
+      }
+    }
     const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
     const uint8_t* __restrict__ lut = &rowlut[0][0][0];
     const uint32_t aln2 = aln << 1;
@@ -1209,7 +1211,8 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
     for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
       if (r_run >= T1h || (prm.debug_skip & 1u)) break;
-      const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u;
+      const uint32_t w = w_next;
+      if (c0 + 64u < h.n_cigar) w_next = (c0 + 64u + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c0 + 64u + lane] : 5u;
       const uint32_t op = w & 15u, len = w >> 4;
       const uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
       const uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
