@@ -45,9 +45,10 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   for (int c = 0; c < 3; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
 }
 
-template <class T> void upload(DevBuf& b, const std::vector<T>& v) {
-  b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
-  if (!v.empty()) hip_check(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "H2D");
+template <class V> void upload(DevBuf& b, const V& v) {
+  const size_t bytes = v.size() * sizeof(v[0]);
+  b.ensure(std::max<size_t>(bytes, 16));
+  if (!v.empty()) hip_check(hipMemcpy(b.p, v.data(), bytes, hipMemcpyHostToDevice), "H2D");
 }
 
 // derive tile geometry, tile read ranges and the run parameters; upload everything
@@ -56,7 +57,7 @@ void make_resident(mkp_ctx* c) {
   ShardHost& S = c->shard;
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
-  { std::vector<uint64_t> h = S.name_hash; std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
+  { std::vector<uint64_t> h(S.name_hash.begin(), S.name_hash.end()); std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
   c->tables.build(c->packer.layouts, c->caller);
   MkpRunParams& P = c->prm; memset(&P, 0, sizeof(P));
   P.win_start = S.win_start; P.win_end = S.win_end;
@@ -275,29 +276,8 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
   return guarded(c, [&]() {
     if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
     auto t0 = std::chrono::steady_clock::now();
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const unsigned n_thr = n >= 4096 ? hw : 1;
-    if (n_thr == 1) {
-      for (uint32_t i = 0; i < n; i++) {
-        const mkp_record& r = recs[i];
-        if (r.tid != c->shard.tid || !Packer::keep(r)) continue;
-        c->packer.add(r, c->shard);
-      }
-    } else {
-      // MM tokenising dominates packing: contiguous record ranges are packed independently and appended in order (same
-      // layout ids and offsets as the sequential pass)
-      std::vector<Packer> pk(n_thr); std::vector<ShardHost> sh(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr); std::vector<std::thread> th;
-      const int32_t tid = c->shard.tid;
-      for (unsigned t = 0; t < n_thr; t++) th.emplace_back([&, t]() {
-        const uint32_t lo = (uint32_t)((uint64_t)n * t / n_thr), hi = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
-        sh[t].tid = tid;
-        try { for (uint32_t i = lo; i < hi; i++) { const mkp_record& r = recs[i]; if (r.tid != tid || !Packer::keep(r)) continue; pk[t].add(r, sh[t]); } }
-        catch (const Error& e) { errs[t].reset(new Error(e)); }
-        catch (const std::exception& e) { errs[t].reset(new Error(MKP_E_INVALID, e.what())); }
-      });
-      for (auto& x : th) x.join();
-      for (unsigned t = 0; t < n_thr; t++) { if (errs[t]) throw *errs[t]; c->shard.append(sh[t], c->packer.adopt(pk[t])); sh[t] = ShardHost(); }
-    }
+    const int32_t tid = c->shard.tid;
+    pack_records(c->packer, c->shard, recs, n, [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); });
     c->stats.pack_ms += ms_since(t0);
   });
 }
@@ -376,7 +356,7 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
   if (!c || !out) return MKP_E_INVALID;
   return guarded(c, [&]() {
     ShardHost S; S.tid = tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end;
-    for (uint32_t i = 0; i < n; i++) c->packer.add(recs[i], S);
+    pack_records(c->packer, S, recs, n, [](const mkp_record&) { return true; });
     c->tables.build(c->packer.layouts, c->caller);
     MkpRunParams P; memset(&P, 0, sizeof(P));
     P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
@@ -399,9 +379,15 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     if (!ro.empty()) hip_check(hipMemcpy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost), "D2H");
     if (!ev.empty()) { hip_check(hipMemcpy(ev.data(), c->d_events.p, ev.size() * sizeof(MkpEvent), hipMemcpyDeviceToHost), "D2H"); hip_check(hipMemcpy(vals.data(), c->d_vals.p, vals.size() * 4, hipMemcpyDeviceToHost), "D2H"); }
     out->ok.clear(); out->n.clear(); out->off.clear(); out->vals.clear(); out->base.clear();
+    size_t total = 0; for (size_t i = 0; i < S.hdr.size(); i++) if (ro[i].ok) total += ro[i].n_events;
+    out->vals.reserve(total); out->base.reserve(total);
     for (size_t i = 0; i < S.hdr.size(); i++) {
       out->ok.push_back(ro[i].ok); out->n.push_back(ro[i].ok ? ro[i].n_events : 0); out->off.push_back((uint32_t)out->vals.size());
-      if (ro[i].ok) for (uint32_t k = 0; k < ro[i].n_events; k++) { out->vals.push_back(vals[S.hdr[i].event_off + k]); out->base.push_back((uint8_t)ev[S.hdr[i].event_off + k].info); }
+      if (ro[i].ok && ro[i].n_events) {
+        const size_t e0 = S.hdr[i].event_off;
+        out->vals.insert(out->vals.end(), vals.begin() + (std::ptrdiff_t)e0, vals.begin() + (std::ptrdiff_t)(e0 + ro[i].n_events));
+        for (uint32_t k = 0; k < ro[i].n_events; k++) out->base.push_back((uint8_t)ev[e0 + k].info);
+      }
     }
     c->resident = false;
   });

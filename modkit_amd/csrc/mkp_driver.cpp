@@ -3,7 +3,10 @@
 // with process_region_batch replaced by shards on the GPU.  Host work here is scheduling only:
 // BAM ingest, the interval grid + focus positions, choosing which reads the threshold sampler takes
 // (reads_sampler/*, sampling_schedule.rs), and formatting rows (writers.rs:87-156).
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <thread>
 
@@ -21,7 +24,7 @@ struct Args {
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
-  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0;
+  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
 };
 
 struct RegionSpec { std::string name; uint32_t start, end; };
@@ -135,7 +138,10 @@ std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamDa
         interval_seen->insert(name); used++; n_reads_out++;
         if (taken.count(name)) continue;  // Moniod::op_mut keeps the first occurrence of a read id
         taken.insert(name);
-        for (uint32_t j = 0; j < so.n[k]; j++) per_base[so.base[so.off[k] + j]].push_back(so.vals[so.off[k] + j]);
+        {  // one map lookup per run of equal bases, not per value
+          const uint8_t* bs = &so.base[so.off[k]]; const float* vs = &so.vals[so.off[k]];
+          for (uint32_t j = 0; j < so.n[k];) { uint32_t e = j + 1; while (e < so.n[k] && bs[e] == bs[j]) e++; std::vector<float>& dst = per_base[bs[j]]; dst.insert(dst.end(), vs + j, vs + e); j = e; }
+        }
       }
       next = hi;
     }
@@ -225,10 +231,11 @@ void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) 
 }
 
 // bedMethyl text (writers.rs:87-156) through mkp_format.hpp: row ranges are formatted by all host cores into per-thread
-// buffers and written out in order
+// buffers; a writer thread puts the buffers of one shard on disk, in order, while the next shard is packed and run
 struct RowWriter {
   struct TextBuf { std::unique_ptr<char[]> mem; size_t n = 0; };
-  FILE* f; bool mixed; std::vector<std::string> labels; uint64_t n = 0;
+  FILE* f = nullptr; bool mixed = false; std::vector<std::string> labels; uint64_t n = 0;
+  std::thread io; std::mutex mu; std::condition_variable cv; std::deque<std::vector<TextBuf>> pending; bool closing = false, io_failed = false, io_started = false;
   static size_t row_bound(size_t chrom_n) { return chrom_n + 96 + 14 * 11 + 32; }   // chrom + name + 14 numbers + separators
   void format_range(const std::string& chrom, const mkp_rows& r, uint64_t lo, uint64_t hi, TextBuf* out) const {
     const char sp = mixed ? ' ' : '\t';
@@ -243,16 +250,41 @@ struct RowWriter {
     }
     out->n = (size_t)(p - out->mem.get());
   }
+  void io_loop() {
+    for (;;) {
+      std::vector<TextBuf> job;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closing || !pending.empty(); }); if (pending.empty()) return; job = std::move(pending.front()); }
+      bool ok = true;
+      for (auto& b : job) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) ok = false;
+      { std::lock_guard<std::mutex> lk(mu); pending.pop_front(); if (!ok) io_failed = true; }   // popped after the write: `pending` bounds the text held in memory
+      cv.notify_all();
+    }
+  }
   void write(const std::string& chrom, const mkp_rows& r) {
     if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
+    if (r.n_rows == 0) return;
     const unsigned n_thr = r.n_rows >= 65536 ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
     std::vector<TextBuf> bufs(n_thr); std::vector<std::thread> th;
     for (unsigned t = 1; t < n_thr; t++) th.emplace_back([&, t]() { format_range(chrom, r, r.n_rows * t / n_thr, r.n_rows * (t + 1) / n_thr, &bufs[t]); });
     format_range(chrom, r, 0, r.n_rows / n_thr, &bufs[0]);
     for (auto& x : th) x.join();
-    for (auto& b : bufs) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) throw Error(MKP_E_IO, "short write on the bedMethyl output");
     n += r.n_rows;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (!io_started) { io_started = true; io = std::thread([this] { io_loop(); }); }
+      cv.wait(lk, [&] { return pending.size() < 2 || io_failed; });
+      if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+      pending.push_back(std::move(bufs));
+    }
+    cv.notify_all();
   }
+  // waits for the writer thread; throws if any write came up short
+  void finish() {
+    if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); io_started = false; }
+    if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+    if (f && fflush(f) != 0) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+  }
+  ~RowWriter() { if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); } }
 };
 
 int run(const Args& a, std::string* msg) {
@@ -344,9 +376,18 @@ int run(const Args& a, std::string* msg) {
       if (owner != a.rank) continue;
       if (a.plan_only) {  // host-only dry run: the shard plan, plus the packer over the shard's records (no device)
         std::vector<size_t> ov; fetch(bam, rec.tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, &ov);
-        Packer pk; ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1; size_t kept = 0;
-        for (size_t i : ov) { mkp_record r = bam.view(bam.recs[i]); if (r.tid == (int32_t)rec.tid && Packer::keep(r)) { pk.add(r, S); kept++; } }
-        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\n", rec.name.c_str(), s0, s1, kept, (unsigned long long)S.n_calls); positions += bp; continue;
+        Packer pk; ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1;
+        std::vector<mkp_record> recs; recs.reserve(ov.size()); for (size_t i : ov) recs.push_back(bam.view(bam.recs[i]));
+        const int32_t tid = (int32_t)rec.tid;
+        // --plan-pack-min N: records from which the packer runs on all cores (0 = always; default as in mkp_shard_add_records)
+        pack_records(pk, S, recs.data(), (uint32_t)recs.size(), [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); }, a.plan_pack_min);
+        // digest of everything the packer hands to the device: a parallel pack must equal the sequential one byte for byte
+        uint64_t dg = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { dg ^= b[i]; dg *= 1099511628211ull; } };
+        mix(S.hdr.data(), S.hdr.size() * sizeof(MkpReadHdr)); mix(S.cigar.data(), S.cigar.size() * 4); mix(S.chunk_pfx.data(), S.chunk_pfx.size() * 4); mix(S.seq.data(), S.seq.size());
+        mix(S.tagref.data(), S.tagref.size() * sizeof(MkpTagRef)); mix(S.ranks.data(), S.ranks.size() * 4); mix(S.ml.data(), S.ml.size()); mix(S.name_hash.data(), S.name_hash.size() * 8);
+        for (auto& k : pk.layout_keys) mix(k.data(), k.size());
+        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\t%016llx\n", rec.name.c_str(), s0, s1, S.hdr.size(), (unsigned long long)S.n_calls, (unsigned long long)dg); positions += bp; continue;
       }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
@@ -361,6 +402,7 @@ int run(const Args& a, std::string* msg) {
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
+  wr.finish();
   if (wr.f != stdout) fclose(wr.f);
   if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f total_ms=%.1f\n",
                        (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, ms_since(t_all));
@@ -388,7 +430,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
     else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
     else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
-    else if (s == "--plan-only") a.plan_only = true; else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
+    else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val()); else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag" || s == "--bedgraph" || s == "--prefix") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);

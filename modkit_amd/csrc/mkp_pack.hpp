@@ -8,6 +8,8 @@
 // structure instead of once per call.  Everything per base and per call happens on the GPU.
 #pragma once
 #include <cmath>
+#include <memory>
+#include <thread>
 #include <unordered_map>
 
 #include "mkp_bam.hpp"
@@ -160,31 +162,53 @@ struct LayoutTables {
 };
 
 // ------------------------------------------------------------------------------------------
+// std::vector whose resize() leaves new elements uninitialised (the caller fills them; pages are first touched by the writer)
+template <class T> struct DefaultInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+  template <class U, class... A> void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+template <class T> using PodVec = std::vector<T, DefaultInitAlloc<T>>;
+
 struct ShardHost {
   int32_t tid = -1; int32_t win_start = 0, win_end = 0;
-  std::vector<MkpReadHdr> hdr; std::vector<uint32_t> cigar; std::vector<uint32_t> chunk_pfx; std::vector<uint8_t> seq; std::vector<MkpTagRef> tagref;
-  std::vector<uint32_t> ranks; std::vector<uint8_t> ml;
+  PodVec<MkpReadHdr> hdr; PodVec<uint32_t> cigar; PodVec<uint32_t> chunk_pfx; PodVec<uint8_t> seq; PodVec<MkpTagRef> tagref;
+  PodVec<uint32_t> ranks; PodVec<uint8_t> ml;
   uint64_t n_events_cap = 0, n_calls = 0;
-  std::vector<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
-  // append another shard piece packed independently (parallel packing): offsets of `o` are rebased, layout ids remapped
-  void append(const ShardHost& o, const std::vector<uint16_t>& layout_map) {
-    const uint32_t b_cigar = (uint32_t)cigar.size(), b_chunk = (uint32_t)(chunk_pfx.size() / 2), b_seq = (uint32_t)seq.size(), b_tag = (uint32_t)tagref.size(),
-                   b_rank = (uint32_t)ranks.size(), b_ml = (uint32_t)ml.size();
-    if ((uint64_t)b_seq + o.seq.size() > 0xfffffff0ull || (uint64_t)b_cigar + o.cigar.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
-    if (n_events_cap + o.n_events_cap > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
-    const size_t h0 = hdr.size(), t0 = tagref.size();
-    hdr.insert(hdr.end(), o.hdr.begin(), o.hdr.end());
-    for (size_t i = h0; i < hdr.size(); i++) {
-      MkpReadHdr& h = hdr[i];
-      h.cigar_off += b_cigar; h.chunk_off += b_chunk; h.seq_off += b_seq; h.tag_off += b_tag; h.event_off += (uint32_t)n_events_cap;
-      if (h.n_tags) h.layout = layout_map[h.layout];
+  PodVec<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
+  // append shard pieces packed independently (parallel packing), in order: offsets are rebased, layout ids remapped.  Sizes
+  // are fixed first, then every piece is copied into place by its own thread.
+  void append_all(const std::vector<ShardHost>& ps, const std::vector<std::vector<uint16_t>>& layout_maps) {
+    struct Base { size_t hdr, cigar, chunk, seq, tag, rank, ml, name; uint64_t ev; };
+    std::vector<Base> b(ps.size() + 1);
+    b[0] = {hdr.size(), cigar.size(), chunk_pfx.size(), seq.size(), tagref.size(), ranks.size(), ml.size(), name_hash.size(), n_events_cap};
+    uint64_t calls = n_calls;
+    for (size_t i = 0; i < ps.size(); i++) {
+      const ShardHost& o = ps[i];
+      b[i + 1] = {b[i].hdr + o.hdr.size(), b[i].cigar + o.cigar.size(), b[i].chunk + o.chunk_pfx.size(), b[i].seq + o.seq.size(), b[i].tag + o.tagref.size(),
+                  b[i].rank + o.ranks.size(), b[i].ml + o.ml.size(), b[i].name + o.name_hash.size(), b[i].ev + o.n_events_cap};
+      calls += o.n_calls;
     }
-    tagref.insert(tagref.end(), o.tagref.begin(), o.tagref.end());
-    for (size_t i = t0; i < tagref.size(); i++) { tagref[i].rank_off += b_rank; tagref[i].ml_off += b_ml; }
-    cigar.insert(cigar.end(), o.cigar.begin(), o.cigar.end()); chunk_pfx.insert(chunk_pfx.end(), o.chunk_pfx.begin(), o.chunk_pfx.end());
-    seq.insert(seq.end(), o.seq.begin(), o.seq.end()); ranks.insert(ranks.end(), o.ranks.begin(), o.ranks.end()); ml.insert(ml.end(), o.ml.begin(), o.ml.end());
-    name_hash.insert(name_hash.end(), o.name_hash.begin(), o.name_hash.end());
-    n_events_cap += o.n_events_cap; n_calls += o.n_calls;
+    const Base& e = b[ps.size()];
+    if (e.seq > 0xfffffff0ull || e.cigar > 0xfffffff0ull || e.rank > 0xfffffff0ull || e.ml > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
+    if (e.ev > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
+    hdr.resize(e.hdr); cigar.resize(e.cigar); chunk_pfx.resize(e.chunk); seq.resize(e.seq); tagref.resize(e.tag); ranks.resize(e.rank); ml.resize(e.ml); name_hash.resize(e.name);
+    auto place = [&](size_t i) {
+      const ShardHost& o = ps[i]; const Base& at = b[i]; const std::vector<uint16_t>& lm = layout_maps[i];
+      auto cp = [](auto& dst, size_t off, const auto& src) { if (!src.empty()) memcpy(dst.data() + off, src.data(), src.size() * sizeof(src[0])); };
+      cp(cigar, at.cigar, o.cigar); cp(chunk_pfx, at.chunk, o.chunk_pfx); cp(seq, at.seq, o.seq); cp(ranks, at.rank, o.ranks); cp(ml, at.ml, o.ml); cp(name_hash, at.name, o.name_hash);
+      for (size_t k = 0; k < o.hdr.size(); k++) {
+        MkpReadHdr h = o.hdr[k];
+        h.cigar_off += (uint32_t)at.cigar; h.chunk_off += (uint32_t)(at.chunk / 2); h.seq_off += (uint32_t)at.seq; h.tag_off += (uint32_t)at.tag; h.event_off += (uint32_t)at.ev;
+        if (h.n_tags) h.layout = lm[h.layout];
+        hdr[at.hdr + k] = h;
+      }
+      for (size_t k = 0; k < o.tagref.size(); k++) { MkpTagRef t = o.tagref[k]; t.rank_off += (uint32_t)at.rank; t.ml_off += (uint32_t)at.ml; tagref[at.tag + k] = t; }
+    };
+    if (ps.size() <= 1) { for (size_t i = 0; i < ps.size(); i++) place(i); }
+    else { std::vector<std::thread> th; for (size_t i = 0; i < ps.size(); i++) th.emplace_back(place, i); for (auto& t : th) t.join(); }
+    n_events_cap = e.ev; n_calls = calls;
   }
   void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); }
 };
@@ -361,5 +385,26 @@ class Packer {
     return true;
   }
 };
+
+// Pack `recs` (those `keep` accepts) behind `dst`.  MM tokenising dominates packing: above a few thousand records contiguous
+// record ranges are packed independently by all host cores and appended in order (same layout ids and offsets as one
+// sequential pass).
+template <class Keep> void pack_records(Packer& packer, ShardHost& dst, const mkp_record* recs, uint32_t n, Keep keep, uint32_t min_parallel = 1024) {
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned n_thr = n >= min_parallel ? std::max(1u, std::min(hw, n)) : 1;
+  if (n_thr == 1) { for (uint32_t i = 0; i < n; i++) if (keep(recs[i])) packer.add(recs[i], dst); return; }
+  std::vector<Packer> pk(n_thr); std::vector<ShardHost> sh(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr); std::vector<std::thread> th;
+  for (unsigned t = 0; t < n_thr; t++) th.emplace_back([&, t]() {
+    const uint32_t lo = (uint32_t)((uint64_t)n * t / n_thr), hi = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
+    sh[t].tid = dst.tid; sh[t].win_start = dst.win_start; sh[t].win_end = dst.win_end;
+    try { for (uint32_t i = lo; i < hi; i++) if (keep(recs[i])) pk[t].add(recs[i], sh[t]); }
+    catch (const Error& e) { errs[t].reset(new Error(e)); }
+    catch (const std::exception& e) { errs[t].reset(new Error(MKP_E_INVALID, e.what())); }
+  });
+  for (auto& x : th) x.join();
+  std::vector<std::vector<uint16_t>> maps(n_thr);
+  for (unsigned t = 0; t < n_thr; t++) { if (errs[t]) throw *errs[t]; maps[t] = packer.adopt(pk[t]); }
+  dst.append_all(sh, maps);
+}
 
 }  // namespace mkp

@@ -47,3 +47,20 @@ def test_other_fixtures_pack(tmp_path, bam):
         assert sum(r[4] for r in rows) == 0   # reads without usable tags: coverage only
     else:
         assert sum(r[4] for r in rows) > 1000
+
+
+def test_parallel_pack_equals_sequential_pack(tmp_path):
+    """mkp_shard_add_records packs large record batches on all cores (per-thread pieces, then ShardHost::append_all):
+    the digest of everything handed to the device must equal the one-thread pack's, byte for byte."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bamfuzz import Fuzz
+    modkit_amd.build()
+    bam, fa, bed = Fuzz(4242, contigs=(("ctgA", 20000), ("ctgB", 5000)), n_reads=700, mean_len=600, profile="mixed").write(str(tmp_path / "fz"))
+    outs = []
+    for pack_min in ("0", "1000000"):
+        out = str(tmp_path / ("plan_%s.tsv" % pack_min))
+        modkit_amd.pileup([bam, out, "--plan-only", "--plan-pack-min", pack_min])
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") >= 2
+    assert all(len(l.split("\t")) == 6 for l in outs[0].splitlines())

@@ -13,4 +13,8 @@ for b in $F/*.bam "$@"; do
     ASAN_OPTIONS=detect_leaks=0 /tmp/mkpileup_asan pileup $b /tmp/asan_plan.tsv --plan-only $fl 2>&1 | grep -E "ERROR: AddressSanitizer|runtime error" && exit 1
   done
 done
+# the all-cores packer (per-thread pieces + ShardHost::append_all), forced on for every batch size
+for b in $F/*.bam "$@"; do
+  ASAN_OPTIONS=detect_leaks=0 /tmp/mkpileup_asan pileup $b /tmp/asan_plan.tsv --plan-only --plan-pack-min 0 2>&1 | grep -E "ERROR: AddressSanitizer|runtime error" && exit 1
+done
 echo "asan/ubsan: clean"
