@@ -81,6 +81,11 @@ def main():
 
     contig_len, n_reads = int(CONTIG_LEN * a.scale), int(N_READS * a.scale)
     tmp = os.environ.get("MKP_BENCH_DIR", "/tmp")
+    # the generator binary normally ships prebuilt (__graft_entry__.build()); if it has to be compiled, one rank does it
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "tools", "gen_modbam")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+    if dist:
+        dist.barrier()
     bam, meta = gen_bam(os.path.join(tmp, "mkp_c2_L%d_N%d_seed%d" % (contig_len, n_reads, 1 + rank)), contig_len, n_reads, 1 + rank)
 
     ctx = modkit_amd.Context(device=local_rank)
