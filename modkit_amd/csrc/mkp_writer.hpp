@@ -1,0 +1,77 @@
+// bedMethyl output of mkp_pileup_main: rows -> text (mkp_format.hpp) on all host cores, text -> file on a writer thread.
+// Host-only C++ (no device code); tests/test_format_cpu.py drives it against a one-thread formulation.
+#pragma once
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mkpileup.h"
+#include "mkp_bam.hpp"
+#include "mkp_format.hpp"
+
+namespace mkp {
+
+// bedMethyl text (writers.rs:87-156) through mkp_format.hpp: row ranges are formatted by all host cores into per-thread
+// buffers; a writer thread puts the buffers of one shard on disk, in order, while the next shard is packed and run
+struct RowWriter {
+  struct TextBuf { std::unique_ptr<char[]> mem; size_t n = 0; };
+  FILE* f = nullptr; bool mixed = false; std::vector<std::string> labels; uint64_t n = 0;
+  std::thread io; std::mutex mu; std::condition_variable cv; std::deque<std::vector<TextBuf>> pending; bool closing = false, io_failed = false, io_started = false;
+  static size_t row_bound(size_t chrom_n) { return chrom_n + 96 + 14 * 11 + 32; }   // chrom + name + 14 numbers + separators
+  void format_range(const std::string& chrom, const mkp_rows& r, uint64_t lo, uint64_t hi, TextBuf* out) const {
+    const char sp = mixed ? ' ' : '\t';
+    out->mem.reset(new char[(size_t)(hi - lo) * row_bound(chrom.size()) + 1]);   // uninitialised: only the written pages get touched
+    char* p = out->mem.get();
+    for (uint64_t i = lo; i < hi; i++) {
+      char name[96]; uint32_t code = r.code_repr[i];
+      int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : (name[0] = (char)code, name[1] = 0, 1);
+      if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) k += snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
+      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)std::min<int>(k, (int)sizeof(name) - 1), sp, r.pos[i], (char)r.strand[i], r.n_valid[i], r.n_mod[i], r.n_canonical[i], r.n_other[i],
+                     r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
+    }
+    out->n = (size_t)(p - out->mem.get());
+  }
+  void io_loop() {
+    for (;;) {
+      std::vector<TextBuf> job;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closing || !pending.empty(); }); if (pending.empty()) return; job = std::move(pending.front()); }
+      bool ok = true;
+      for (auto& b : job) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) ok = false;
+      { std::lock_guard<std::mutex> lk(mu); pending.pop_front(); if (!ok) io_failed = true; }   // popped after the write: `pending` bounds the text held in memory
+      cv.notify_all();
+    }
+  }
+  void write(const std::string& chrom, const mkp_rows& r) {
+    if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
+    if (r.n_rows == 0) return;
+    const unsigned n_thr = r.n_rows >= 65536 ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<TextBuf> bufs(n_thr); std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_thr; t++) th.emplace_back([&, t]() { format_range(chrom, r, r.n_rows * t / n_thr, r.n_rows * (t + 1) / n_thr, &bufs[t]); });
+    format_range(chrom, r, 0, r.n_rows / n_thr, &bufs[0]);
+    for (auto& x : th) x.join();
+    n += r.n_rows;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (!io_started) { io_started = true; io = std::thread([this] { io_loop(); }); }
+      cv.wait(lk, [&] { return pending.size() < 2 || io_failed; });
+      if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+      pending.push_back(std::move(bufs));
+    }
+    cv.notify_all();
+  }
+  // waits for the writer thread; throws if any write came up short
+  void finish() {
+    if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); io_started = false; }
+    if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+    if (f && fflush(f) != 0) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+  }
+  ~RowWriter() { if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); } }
+};
+
+}  // namespace mkp

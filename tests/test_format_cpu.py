@@ -42,3 +42,73 @@ def test_percent_formatting_matches_printf_exhaustively(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-o", str(exe), str(src)])
     out = subprocess.check_output([str(exe)], text=True)
     assert out.startswith("ok 8394752"), out
+
+
+WRITER_SRC = r'''
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "mkp_writer.hpp"
+using namespace mkp;
+// three "shards" of rows through RowWriter (format on all cores + writer thread) against the one-thread formulation
+int main(int argc, char** argv) {
+  std::mt19937 rng(7);
+  std::string ref;
+  RowWriter wr; wr.mixed = argc > 3; wr.labels = {"CG,0", "CHH,0"};
+  wr.f = fopen(argv[1], "w"); if (!wr.f) return 2;
+  const size_t sizes[3] = {200000, 10, 70001};
+  const char* chroms[3] = {"chr1", "chrUn_KI270742v1", "chrM"};
+  for (int s = 0; s < 3; s++) {
+    const size_t n = sizes[s];
+    std::vector<uint32_t> pos(n), code(n), nv(n), nm(n), nc(n), no(n), nd(n), nf(n), ndf(n), nn(n); std::vector<uint8_t> st(n); std::vector<int32_t> mi(n);
+    for (size_t i = 0; i < n; i++) {
+      pos[i] = (uint32_t)(i * 3 + rng() % 3); code[i] = (rng() % 5 == 0) ? (0x80000000u | (rng() % 100000u)) : (uint32_t)"mhac"[rng() % 4];
+      nm[i] = rng() % 50; nc[i] = rng() % 50; no[i] = rng() % 3; nv[i] = nm[i] + nc[i] + no[i]; if (!nv[i]) { nc[i] = 1; nv[i] = 1; }
+      nd[i] = rng() % 4; nf[i] = rng() % 9; ndf[i] = rng() % 5; nn[i] = rng() % 7; st[i] = (uint8_t)"+-."[rng() % 3]; mi[i] = (int32_t)(rng() % 3) - 1;
+    }
+    mkp_rows r; memset(&r, 0, sizeof(r));
+    r.n_rows = n; r.pos = pos.data(); r.strand = st.data(); r.code_repr = code.data(); r.motif_idx = mi.data(); r.n_valid = nv.data(); r.n_mod = nm.data();
+    r.n_canonical = nc.data(); r.n_other = no.data(); r.n_delete = nd.data(); r.n_fail = nf.data(); r.n_diff = ndf.data(); r.n_nocall = nn.data();
+    wr.write(chroms[s], r);
+    // reference formulation: one thread, one row at a time
+    const char sp = wr.mixed ? ' ' : '\t';
+    for (size_t i = 0; i < n; i++) {
+      char name[96]; int k = (code[i] & 0x80000000u) ? snprintf(name, sizeof name, "%u", code[i] & 0x7fffffffu) : snprintf(name, sizeof name, "%c", (char)code[i]);
+      if (mi[i] >= 0) k += snprintf(name + k, sizeof(name) - (size_t)k, ",%s", wr.labels[(size_t)mi[i]].c_str());
+      char buf[512]; char* e = format_row(buf, chroms[s], strlen(chroms[s]), name, (size_t)k, sp, pos[i], (char)st[i], nv[i], nm[i], nc[i], no[i], nd[i], nf[i], ndf[i], nn[i]);
+      ref.append(buf, (size_t)(e - buf));
+    }
+  }
+  wr.finish(); fclose(wr.f);
+  FILE* g = fopen(argv[2], "w"); fwrite(ref.data(), 1, ref.size(), g); fclose(g);
+  printf("rows %llu bytes %zu\n", (unsigned long long)wr.n, ref.size());
+  return 0;
+}
+'''
+
+
+def _writer_harness(tmp_path, extra_flags, mixed):
+    src = tmp_path / "wr.cpp"
+    src.write_text(WRITER_SRC)
+    exe = tmp_path / "wr"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread"] + extra_flags + ["-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-o", str(exe), str(src)])
+    a, b = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
+    out = subprocess.run([str(exe), a, b] + (["mixed"] if mixed else []), capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("rows 270011"), out.stdout + out.stderr
+    assert "ThreadSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-2000:]
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_row_writer_threads_keep_order_and_bytes(tmp_path):
+    _writer_harness(tmp_path, [], mixed=False)
+    _writer_harness(tmp_path, [], mixed=True)
+
+
+def test_row_writer_under_thread_sanitizer(tmp_path):
+    probe = subprocess.run(["g++", "-fsanitize=thread", "-x", "c++", "-", "-o", str(tmp_path / "probe")], input="int main(){return 0;}", capture_output=True, text=True)
+    if probe.returncode != 0:
+        import pytest
+        pytest.skip("no libtsan in this image")
+    _writer_harness(tmp_path, ["-fsanitize=thread"], mixed=False)
