@@ -159,24 +159,28 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
     BamIndexEntry e; e.off = o;
     memcpy(&e.tid, &d[o], 4); memcpy(&e.pos, &d[o + 4], 4);
     uint8_t lq = d[o + 8]; uint16_t nc; memcpy(&nc, &d[o + 12], 2); memcpy(&e.flag, &d[o + 14], 2);
-    if ((size_t)32 + lq + 4 * (size_t)nc > (size_t)bs) throw Error(MKP_E_IO, "corrupt BAM record");
+    int32_t lseq; memcpy(&lseq, &d[o + 16], 4);
+    if (lseq < 0 || (uint64_t)32 + lq + 4ull * nc + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) throw Error(MKP_E_IO, "corrupt BAM record");
+    if (e.tid < -1 || e.tid >= n_ref || e.pos < -1 || e.pos >= 0x7ffffff0) throw Error(MKP_E_IO, "corrupt BAM record: reference id or position out of range");
     e.reflen = 0; e.end = e.pos + 1;
     bd.recs.push_back(e); o += (size_t)bs;
   }
   {  // reference spans (bam_endpos): CIGAR walks, all cores
-    const size_t n = bd.recs.size();
+    const size_t n = bd.recs.size(); std::atomic<bool> span_bad{false};
     auto span = [&](size_t lo, size_t hi) {
       for (size_t i = lo; i < hi; i++) {
         BamIndexEntry& e = bd.recs[i];
         const uint8_t* c = &d[e.off]; uint16_t nc; memcpy(&nc, c + 12, 2);
         const uint8_t* cg = c + 32 + c[8]; int64_t rl = 0;
         for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4; }
+        if ((int64_t)e.pos + rl > 0x7ffffff0ll) { span_bad = true; rl = 0; }   // alignment runs past 2^31: corrupt record
         e.reflen = (int32_t)rl; e.end = e.pos + (rl > 0 ? (int32_t)rl : 1);
       }
     };
     const unsigned nt = n >= 4096 ? threads : 1u;
     if (nt <= 1) span(0, n);
     else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(span, n * t / nt, n * (t + 1) / nt); for (auto& t : th) t.join(); }
+    if (span_bad) throw Error(MKP_E_IO, "corrupt BAM record: alignment runs past 2^31");
   }
   bd.tid_first.assign(bd.ref_names.size() + 1, bd.recs.size());
   for (size_t i = bd.recs.size(); i-- > 0;) { int t = bd.recs[i].tid; if (t >= 0 && (size_t)t < bd.ref_names.size()) bd.tid_first[(size_t)t] = i; }

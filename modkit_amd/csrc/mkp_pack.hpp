@@ -262,6 +262,8 @@ class Packer {
 
   void add(const mkp_record& r, ShardHost& S) {
     MkpReadHdr h; memset(&h, 0, sizeof(h));
+    if (!r.data || r.l_data < 0 || r.l_qseq < 0 || (uint64_t)r.l_qname + 4ull * r.n_cigar + ((uint64_t)r.l_qseq + 1) / 2 + (uint64_t)r.l_qseq > (uint64_t)r.l_data)
+      throw Error(MKP_E_INVALID, "record data shorter than its fields");
     const uint8_t* cg = r.data + r.l_qname;
     const uint8_t* sq = cg + 4 * (size_t)r.n_cigar;
     const uint8_t* aux = sq + ((size_t)r.l_qseq + 1) / 2 + (size_t)r.l_qseq;

@@ -64,3 +64,32 @@ def test_parallel_pack_equals_sequential_pack(tmp_path):
         outs.append(open(out).read())
     assert outs[0] == outs[1] and outs[0].count("\n") >= 2
     assert all(len(l.split("\t")) == 6 for l in outs[0].splitlines())
+
+
+def test_corrupt_bams_end_in_clean_errors(tmp_path):
+    """tools/mutate_bam.py (random bytes, truncation, record core fields, bytes near MM/ML/MN) against the plain build: every
+    mutated file is either processed or refused with an error code — no crash.  (The same tool runs against the ASan/UBSan build
+    of tools/asan_host.sh outside the suite.)"""
+    import subprocess
+    import sys
+    modkit_amd.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "mutate_bam.py"), os.path.join(FIX, "bc_anchored_10_reads.sorted.bam"), "40", "5",
+                        os.path.join(root, "modkit_amd", "csrc", "mkpileup")], capture_output=True, text=True)
+    assert p.returncode == 0 and "done: bad 0" in p.stdout, p.stdout[-800:] + p.stderr[-800:]
+
+
+def test_out_of_range_reference_id_is_refused(tmp_path):
+    import struct
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bamfuzz import bam_header, bam_record, bgzf_write
+    data = bam_header((("c", 1000),)) + bam_record(0, 10, 0, "r1", [(20, "M")], "ACGT" * 5, b"")
+    rec0 = len(bam_header((("c", 1000),)))
+    bad = bytearray(data)
+    struct.pack_into("<i", bad, rec0 + 4, 7)          # refID 7 of 1
+    path = str(tmp_path / "bad.bam")
+    bgzf_write(path, bytes(bad))
+    with pytest.raises(modkit_amd.MkpError) as e:
+        modkit_amd.pileup([path, str(tmp_path / "o.tsv"), "--plan-only"])
+    assert e.value.status == -2 and "corrupt BAM record" in str(e.value)
