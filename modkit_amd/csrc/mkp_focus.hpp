@@ -10,6 +10,7 @@
 // is lost by the reference, and bit-exact output has to lose it too.
 #pragma once
 #include "mkp_bam.hpp"
+#include "mkp_device.h"
 
 namespace mkp {
 

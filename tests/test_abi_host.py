@@ -137,6 +137,16 @@ def test_mm_tokeniser_known_answers(L):
     assert [t["mode"] for t in tags] == ["?", ".", " ", " "]
     assert tags[0]["codes"] == [ord("h"), ord("m")] and tags[2]["codes"] == [0x80000000 | 76792] and tags[3]["ranks"] == []
     assert tags[0]["ranks"] == [0, 2, 3] and tags[1]["ranks"] == [2, 3] and tags[2]["ranks"] == [5]
+    # the reference's duplex and N-base vectors (test_duplex_modbase_info 2512-2569, test_delta_list_converter_n_base 2776-2785)
+    d2 = "GACTCGACTGGACGTCGA"
+    tags = mm_ranks(L, "C+h?,1,1,0;C+m?,1,1,0;G-h?,1,2,0;G-m?,1,2,0", len(d2), 12)
+    occ = {b: [i for i, c in enumerate(d2) if c == b] for b in "CG"}
+    assert [[occ[t["base"]][r] for r in t["ranks"]] for t in tags] == [[4, 12, 15], [4, 12, 15], [5, 13, 16], [5, 13, 16]]
+    assert [t["neg"] for t in tags] == [False, False, True, True]
+    tags = mm_ranks(L, "N+b?,5,0,0,1,3,0,0;", 17, 7)
+    assert tags[0]["ranks"] == [5, 6, 7, 9, 13, 14, 15]          # N tags: absolute forward positions
+    tags = mm_ranks(L, "C+h?;C+m?;", 15, 0)
+    assert [t["ranks"] for t in tags] == [[], []]                  # test_mod_bam_modbase_info_empty: headers without calls
     # rejected by the reference: bad base, missing strand, ML shorter than the calls (1222-1228), N-tag position past the read end
     assert mm_ranks(L, "X+m?,1;", 10, 1) == -1
     assert mm_ranks(L, "Cm?,1;", 10, 1) == -1
