@@ -12,12 +12,12 @@ using namespace mkp;
 extern "C" {
 hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
-hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
+hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, int tally8);
 uint32_t mkp_rows_segments(uint32_t tile);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
-                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/);
+                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, int /*8-bit tally layout*/);
 hipError_t mkp_launch_rows(hipStream_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, uint32_t /*tile*/, uint32_t /*arrays*/, int /*has focus*/, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
-                           const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+                           const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int /*8-bit tally layout*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
 
@@ -75,37 +75,59 @@ void make_resident(mkp_ctx* c) {
   // tile geometry from the LDS budget (160 KiB per CU on gfx950): the accumulate kernel runs two workgroups per CU, each
   // holding one tile of packed tallies (one dword per counter / slot and position) plus its waves' scratch in 80 KiB;
   // the row kernel unpacks one tile into twice that
-  const uint32_t words_per_pos = P.n_counters + P.n_slots;
-  uint32_t T = c->cfg.tile_positions;
-  if (const char* te = getenv("MKP_TILE")) T = (uint32_t)strtoul(te, nullptr, 0);   // experiments only
-  // two workgroups must be co-resident per CU: 76 KiB each including the kernel's ~1 KiB of static LDS leaves 8 KiB of
-  // slack for the allocation granule (at 80 KiB each one GPU box ran them one per CU and the kernel took 1.9x as long)
-  const uint32_t budget = 76u * 1024u - 1280u;
-  uint32_t maxT = 0;
-  for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;
-  if (maxT < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
-  if (!T || T > maxT) T = std::min<uint32_t>(maxT, 4096u);
-  T = std::max<uint32_t>(64u, T & ~63u);
-  P.tile = T; c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_pos, T + 2 * MKP_HALO) * 4u;
-  const uint64_t win = (uint64_t)(S.win_end - S.win_start);
-  P.n_tiles_total = (uint32_t)((win + T - 1) / T);
-  // tile -> [first,last) reads.  Reads are coordinate sorted; prefix-max of ends bounds the first candidate.
-  std::vector<uint32_t> tile_ids, tf, tl;
-  {
+  // tile plan for a given number of packed dwords per position: tile length from the LDS budget, then tile -> [first,last) reads
+  // (reads are coordinate sorted; the prefix-max of ends bounds the first candidate)
+  struct TilePlan { uint32_t T = 0, n_total = 0; size_t max_reads = 0; std::vector<uint32_t> ids, first, last; };
+  auto plan_tiles = [&](uint32_t words_per_pos) {
+    TilePlan tp;
+    uint32_t T = c->cfg.tile_positions;
+    if (const char* te = getenv("MKP_TILE")) T = (uint32_t)strtoul(te, nullptr, 0);   // experiments only
+    // two workgroups must be co-resident per CU: 76 KiB each including the kernel's ~1 KiB of static LDS leaves 8 KiB of
+    // slack for the allocation granule (at 80 KiB each one GPU box ran them one per CU and the kernel took 1.9x as long)
+    const uint32_t budget = 76u * 1024u - 1280u;
+    uint32_t maxT = 0;
+    for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;
+    if (maxT < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
+    if (!T || T > maxT) T = std::min<uint32_t>(maxT, 4096u);
+    T = std::max<uint32_t>(64u, T & ~63u);
+    tp.T = T;
+    const uint64_t win = (uint64_t)(S.win_end - S.win_start);
+    tp.n_total = (uint32_t)((win + T - 1) / T);
     const size_t n = S.hdr.size(); std::vector<int32_t> pmax(n); int32_t m = INT32_MIN;
     for (size_t i = 0; i < n; i++) { if (i && S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted"); m = std::max(m, S.hdr[i].ref_end); pmax[i] = m; }
     size_t first = 0, last = 0;
-    for (uint32_t t = 0; t < P.n_tiles_total; t++) {
+    for (uint32_t t = 0; t < tp.n_total; t++) {
       const int64_t lo = (int64_t)S.win_start + (int64_t)t * T - MKP_HALO, hi = (int64_t)S.win_start + (int64_t)(t + 1) * T + MKP_HALO;
       while (first < n && pmax[first] <= lo) first++;
       if (last < first) last = first;
       while (last < n && S.hdr[last].ref_start < hi) last++;
       bool any = false; for (size_t i = first; i < last && !any; i++) any = S.hdr[i].ref_end > lo;
-      if (any) { tile_ids.push_back(t); tf.push_back((uint32_t)first); tl.push_back((uint32_t)last); }
-      // the packed tallies hold 16 bits per strand: no column may be deeper than 65535 (every column's reads are among the tile's)
-      if (last - first > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one tile: columns this deep are outside the device path");
+      if (any) { tp.ids.push_back(t); tp.first.push_back((uint32_t)first); tp.last.push_back((uint32_t)last); }
+      tp.max_reads = std::max(tp.max_reads, last - first);   // every column's reads are among the tile's
     }
+    return tp;
+  };
+  // tile geometry from the LDS budget (160 KiB per CU on gfx950): the accumulate kernel runs two workgroups per CU, each
+  // holding one tile of packed tallies plus its waves' scratch.  Default layout: one dword per counter / slot and position
+  // (16 bits per strand).  MKP_TALLY8=1 (opt-in until validated on the GPU): four 8-bit fields per dword when no tile sees
+  // more than 255 reads — fewer dwords per position, longer tiles, fewer (read, tile) visits.
+  uint32_t words_per_pos = P.n_counters + P.n_slots;
+  c->tally8 = 0;
+  TilePlan tp;
+  if (const char* t8 = getenv("MKP_TALLY8")) if (atoi(t8) == 1 && P.n_counters >= 5) {
+    const uint32_t words8 = 2u + ((2u + 2u * P.n_slots + 3u) >> 2) + ((2u * (P.n_counters - 5u) + 3u) >> 2);
+    tp = plan_tiles(words8);
+    if (tp.max_reads <= 255) { c->tally8 = 1; words_per_pos = words8; }
   }
+  if (!c->tally8) tp = plan_tiles(words_per_pos);
+  // the packed tallies hold 16 bits per strand: no column may be deeper than 65535
+  if (tp.max_reads > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one tile: columns this deep are outside the device path");
+  const uint32_t T = tp.T;
+  P.tile = T; c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_pos, T + 2 * MKP_HALO) * 4u;
+  c->words_per_pos = words_per_pos;
+  const uint64_t win = (uint64_t)(S.win_end - S.win_start);
+  P.n_tiles_total = tp.n_total;
+  std::vector<uint32_t>& tile_ids = tp.ids; std::vector<uint32_t>& tf = tp.first; std::vector<uint32_t>& tl = tp.last;
   c->n_tiles = (uint32_t)tile_ids.size();
   c->stats.pack_ms += ms_since(t0);
   auto t1 = std::chrono::steady_clock::now();
@@ -120,7 +142,7 @@ void make_resident(mkp_ctx* c) {
   c->d_tile_row_off.ensure((size_t)(c->n_segs + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_segs + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_segs + 1) * 4);
   c->d_misc.ensure(64);
   c->d_tally.ensure(std::max<size_t>((size_t)c->n_tiles * words_per_pos * (T + 2 * MKP_HALO) * 4u, 16));
-  hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
+  hip_check(mkp_pileup_set_lds(c->lds_bytes, c->tally8), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
   c->resident = true;
@@ -149,10 +171,10 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2), "pileup launch");
+                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->tally8), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_rows(c->stream, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, P.tile, P.n_counters + P.n_slots, (int)P.has_focus, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
-                              &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2), "rows launch");
+    hip_check(mkp_launch_rows(c->stream, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, P.tile, c->words_per_pos, (int)P.has_focus, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
+                              &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2, c->tally8), "rows launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_segs, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[4], c->stream), "event");

@@ -15,6 +15,7 @@
 //   MkpEvent    events[]            written by the decode kernels, read by mkp_pileup_tiles
 //   MkpReadOut  readout[n_reads]    per-read decode summary
 //   uint32      tally[n_tiles][counters + slots][tile + 2*halo]   16-bit-packed strand tallies, mkp_pileup_tiles -> mkp_emit_rows
+//                                   (opt-in MKP_TALLY8=1: four 8-bit fields per dword, see mkp_pileup_body.inc)
 //   MkpRowsDev  rows                SoA row buffers (per 1024-position segment, then gathered into genome order)
 #pragma once
 #include <stdint.h>

@@ -947,12 +947,26 @@ struct TileView {   // packed tallies of a run of positions staged in LDS: [coun
   __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return (pk[cid * W + (i - i0)] >> (16u * s)) & 0xffffu; }
   __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return (int32_t)((pk[(n_counters + sl) * W + (i - i0)] >> (16u * s)) & 0xffffu); }
 };
+// the 8-bit layout of mkp_pileup_tiles8 (mkp_pileup_body.inc): rows [0]/[1] NoCall '+'/'-' (field = base), then ND difference rows
+// (fields DEL+, DEL-, slot0+, slot0-, ...), then the direct counters (field (counter-5)*2 + strand)
+struct TileView8 {
+  const uint32_t* pk;
+  uint32_t W, i0, n_counters, n_slots;
+  __device__ __forceinline__ uint32_t fld(uint32_t row, uint32_t f, uint32_t i) const { return (pk[row * W + (i - i0)] >> (8u * (f & 3u))) & 0xffu; }
+  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const {
+    if (cid < 4u) return fld(s, cid, i);
+    if (cid == 4u) return fld(2u, s, i);
+    const uint32_t nd = (2u + 2u * n_slots + 3u) >> 2, g = (cid - 5u) * 2u + s;
+    return fld(2u + nd + (g >> 2), g, i);
+  }
+  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { const uint32_t dd = 2u + 2u * sl + s; return (int32_t)fld(2u + (dd >> 2), dd, i); }
+};
 
 // one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
 // sl < 0: --combine-mods row (code = base letter).  Returns false when the reference emits nothing.
 // FILL = false: only decide whether the row exists (the counting pass)
-template <bool FILL>
-__device__ __forceinline__ bool tally_row(const TileView& tv, const MkpRunParams& prm, uint32_t s, uint32_t i, int sl, int pb, RowAcc* r) {
+template <bool FILL, class TV>
+__device__ __forceinline__ bool tally_row(const TV& tv, const MkpRunParams& prm, uint32_t s, uint32_t i, int sl, int pb, RowAcc* r) {
   const uint32_t ck = prm.can_of_pb[pb];
   if (ck == 0xffu) return false;
   uint32_t n_can = tv.c(s, MKP_C_CAN + ck, i), mods = 0;
@@ -972,8 +986,8 @@ __device__ __forceinline__ bool tally_row(const TileView& tv, const MkpRunParams
   return true;
 }
 
-template <bool WRITE>
-__device__ __forceinline__ uint32_t rows_at(const TileView& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
+template <bool WRITE, class TV>
+__device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
                                             const MkpCombo* combos, int32_t T0h, uint32_t i, const MkpRowsDev& rows,
                                             uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */) {
   const int32_t p = T0h + (int32_t)i;
@@ -1101,243 +1115,22 @@ mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
                  const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t next_read;
-  // SEQ byte -> NoCall row of the base a query index selects: rowlut[strand][query parity][byte]; 15 = not A/C/G/T.
-  // (BAM packs two bases per byte, high nibble first; on the '-' strand the tallied base is the complement.)
-  __shared__ uint8_t rowlut[2][2][256];
-  {
-    const uint32_t t = threadIdx.x, byte = t & 255u, par = (t >> 8) & 1u, st = (t >> 9) & 1u;
-    const uint32_t nib = par ? (byte & 15u) : (byte >> 4);
-    const unsigned long long LUT = st ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;
-    rowlut[st][par][byte] = (uint8_t)((LUT >> (4u * nib)) & 15u);
-  }
-  const MkpRunParams& prm = *prmp;
-  // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
-  // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
-  // Persistent workgroups: each walks its tiles (v = b, b + grid, ...).
-  for (uint32_t vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
-  uint32_t bid = vb;
-  {
-    const uint32_t per = n_tiles / 8u;
-    if (per && bid < per * 8u) bid = (bid & 7u) * per + (bid >> 3);
-  }
-  const uint32_t tix = bid;
-  const uint32_t tile = tile_ids[tix];
-  const uint32_t T = prm.tile, TH = T + 2 * MKP_HALO;
-  const uint32_t n_counters = prm.n_counters, n_slots = prm.n_slots;
-  const int32_t T0 = prm.win_start + (int32_t)(tile * T);
-  const int32_t T0h = T0 - MKP_HALO, T1h = T0 + (int32_t)T + MKP_HALO;
-  uint32_t* __restrict__ tal = lds;                       // [n_counters + n_slots][TH], packed
-  uint32_t* __restrict__ obs = lds + n_counters * TH;     // observed-code difference arrays
-  const uint32_t lds_words = (n_counters + n_slots) * TH;
-  const int lane = lane_id();
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // per-wave scratch behind the tallies: op-start bitmap over the tile's positions + CIGAR compaction buffer
-  const uint32_t bm_words = MKP_PILEUP_BM_WORDS(TH);
-  uint32_t* __restrict__ bm = lds + lds_words + wave * (bm_words + PILEUP_WAVE_SCRATCH);
-  uint2* __restrict__ comp = reinterpret_cast<uint2*>(bm + bm_words);
-  for (uint32_t k = threadIdx.x; k < lds_words + PILEUP_WAVES * (bm_words + PILEUP_WAVE_SCRATCH); k += PILEUP_THREADS) lds[k] = 0;
-  if (threadIdx.x == 0) next_read = tile_first[tix];
-  __syncthreads();
-
-  // reads are handed out one at a time (LDS ticket) so waves finish the tile together whatever the reads' spans
-  const uint32_t rid_end = tile_last[tix];
-  for (;;) {
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&next_read, 1u);
-    const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-    if (rid >= rid_end) break;
-    const MkpReadHdr h = hdrs[rid];
-    if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
-    const MkpReadOut ro = readout[rid];
-    const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u;
-    const uint8_t* __restrict__ seq = seqs + h.seq_off;
-    // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per reference position;
-    // the op covering a position = (ops starting at or before it) - 1, counted with the wave's op-start bitmap.
-    uint32_t q_run = 0; int32_t r_run = h.ref_start; uint32_t c_first = 0;
-    {  // skip the 64-op CIGAR chunks that end before the tile: the host's per-chunk offsets say where the walk starts
-      const uint32_t nch = (h.n_cigar + 63u) >> 6;
-      if (nch > 1 && T0h > h.ref_start) {
-        const uint32_t rel = (uint32_t)(T0h - h.ref_start);
-        for (uint32_t b0 = 0; b0 < nch; b0 += 64) {
-          const uint32_t kidx = b0 + (uint32_t)lane;
-          const uint2 e = kidx < nch ? chunk_pfx[h.chunk_off + kidx] : make_uint2(0u, 0xffffffffu);
-          const uint32_t cnt = (uint32_t)__popcll(__ballot(kidx < nch && e.y <= rel));   // offsets ascend: a prefix of the lanes
-          if (cnt) {
-            q_run = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)(cnt - 1u));
-            r_run = h.ref_start + (int32_t)__builtin_amdgcn_readlane((int)e.y, (int)(cnt - 1u));
-            c_first = 64u * (b0 + cnt - 1u);
-          }
-          if (cnt < 64u) break;
-        }
-      }
-    }
-    // the first chunk's CIGAR words are requested now, ahead of the event work; every later chunk is requested one chunk ahead
-    uint32_t w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
-    // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
-    if (ro.ok && lane < 2) {
-      uint32_t m = lane ? ro.obs[1] : ro.obs[0];
-      const int32_t a = max(h.ref_start, T0h), b = min(h.ref_end, T1h);
-      while (m) {
-        const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-        atomicAdd(&obs[sl * TH + (uint32_t)(a - T0h)], lane ? 0x10000u : 1u);
-        if (b < T1h) atomicAdd(&obs[sl * TH + (uint32_t)(b - T0h)], 0u - (lane ? 0x10000u : 1u));
-      }
-    }
-    // the read's call events inside the tile (sorted by position)
-    if (ro.ok && ro.n_events && !(prm.debug_skip & 2u)) {
-      const MkpEvent* __restrict__ ev = events + h.event_off;
-      const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
-      for (uint32_t k = lo + lane;; k += 64) {
-        bool in = k < ro.n_events;
-        MkpEvent e; e.pos = 0; e.info = 0;
-        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
-        if (in) {
-          const uint32_t i = (uint32_t)((int32_t)e.pos - T0h);
-          atomicAdd(&tal[(e.info & 0xffu) * TH + i], (e.info & 0x100u) ? 0x10000u : 1u);
-          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
-            atomicAdd(&tal[(MKP_C_NC + ((e.info >> 9) & 3u)) * TH + i], 0u - ((e.info & 0x800u) ? 0x10000u : 1u));
-        }
-        if (!__any(in)) break;
-      }
-    }
-    const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
-    const uint8_t* __restrict__ lut = &rowlut[0][0][0];
-    const uint32_t aln2 = aln << 1;
-    const uint32_t TH4 = TH * 4u;
-    const uint32_t lanebase = lds_addr(tal) + 4u * (uint32_t)lane;   // LDS byte address of (row 0, position `lane`)
-    const uint32_t qlane = (uint32_t)(T0h - h.ref_start) - (1u << 26) + (uint32_t)lane;   // query index = qlane + 64*window + packed offset
-    const uint32_t last_byte = (h.l_seq - 1u) >> 1;
-    for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
-      if (r_run >= T1h || (prm.debug_skip & 1u)) break;
-      const uint32_t w = w_next;
-      if (c0 + 64u < h.n_cigar) w_next = (c0 + 64u + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c0 + 64u + lane] : 5u;
-      const uint32_t op = w & 15u, len = w >> 4;
-      const uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
-      const uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
-      const uint32_t qs = q_run + qe - qlen;
-      const int32_t rs = r_run + (int32_t)(re - rlen);
-      const uint32_t Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63), Rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
-      const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
-      if (c_lo < c_hi) {
-        if (op == 3 && ro.ok) {  // ref-skip: the read is not in these columns (alignment.is_refskip())
-          const int32_t a = min(max(rs, T0h), T1h), b = min(max(rs + (int32_t)rlen, T0h), T1h);
-          if (a < b) for (uint32_t s = 0; s < 2; s++) {
-            uint32_t m = ro.obs[s];
-            while (m) {
-              const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-              atomicAdd(&obs[sl * TH + (uint32_t)(a - T0h)], 0u - (s ? 0x10000u : 1u));
-              if (b < T1h) atomicAdd(&obs[sl * TH + (uint32_t)(b - T0h)], s ? 0x10000u : 1u);
-            }
-          }
-        }
-        if (op == 2) {  // deletion columns (alignment.is_del()): +1/-1 on the strand's DEL row, summed after the barrier
-          const int32_t a = min(max(rs, T0h), T1h), b = min(max(rs + (int32_t)rlen, T0h), T1h);
-          if (a < b) {
-            atomicAdd(&tal[MKP_C_DEL * TH + (uint32_t)(a - T0h)], inc);
-            if (b < T1h) atomicAdd(&tal[MKP_C_DEL * TH + (uint32_t)(b - T0h)], 0u - inc);
-          }
-        }
-        // compact the window's reference-consuming ops to the low lanes: {start, packed(query offset, kind)}
-        const bool isref = rlen > 0;
-        const unsigned long long refbal = __ballot(isref);
-        const uint32_t nref = (uint32_t)__popcll(refbal);
-        const uint32_t ci = (uint32_t)__popcll(refbal & lanemask_lt());
-        const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
-        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);  // q = (pos - ref_start) + D; kind sits where it ORs into the row
-        if (isref) comp[ci] = make_uint2((uint32_t)rs, pk);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint2 cc = comp[lane];
-        const bool cvalid = (uint32_t)lane < nref;
-        const int32_t c_rs = (int32_t)cc.x; const uint32_t c_pk = cc.y;
-        const int32_t c_key = cvalid ? c_rs : 0x7fffffff;
-        const uint32_t e_lo = lds_addr(tal) + 4u * (uint32_t)(c_lo - T0h), e_span = 4u * (uint32_t)(c_hi - c_lo);
-        const bool mark = cvalid && c_rs > c_lo && c_rs < c_hi;
-        const uint32_t mrel = (uint32_t)(c_rs - 1 - T0h);   // bit m set <=> an op starts at T0h+m+1: "starts at or before p" = bits strictly below p-T0h
-        if (mark) atomicOr(&bm[mrel >> 5], 1u << (mrel & 31u));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // 64 positions per step, aligned to the tile so a step reads one aligned 64-bit window of the bitmap;
-        // PILEUP_UNROLL steps are issued together (bitmap read -> bpermute -> SEQ byte load) before any tally update.
-        // ops started at or before the first position of window kk: a ballot over the compacted starts (no LDS dependency)
-        const uint32_t k0 = (uint32_t)(c_lo - T0h) >> 6, k1 = (uint32_t)(c_hi - 1 - T0h) >> 6;
-        // Only the first and the last group of a chunk hold out-of-range lanes or repeated (clamped) windows; the groups in
-        // between run a version without the clamps and the range check.
-        auto group = [&](uint32_t kb, auto edge_c) {
-          constexpr bool EDGE = decltype(edge_c)::value;
-          uint32_t pkv[PILEUP_UNROLL], byte[PILEUP_UNROLL], qq[PILEUP_UNROLL], idx[PILEUP_UNROLL], kk[PILEUP_UNROLL]; uint2 W[PILEUP_UNROLL];
-          // stage by stage across the PILEUP_UNROLL windows, so the LDS reads, the bpermutes and the global loads of the group overlap
-#pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++) kk[j] = EDGE ? min(kb + (uint32_t)j, k1) : kb + (uint32_t)j;
-#pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++) W[j] = *reinterpret_cast<const uint2*>(bm + 2u * kk[j]);
-#pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++) {
-            const int32_t wstart = T0h + (int32_t)(64u * kk[j]);
-            idx[j] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c_key <= (EDGE ? max(c_lo, wstart) : wstart))) - 1u;
-          }
-#pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++)
-            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(W[j].y, __builtin_amdgcn_mbcnt_lo(W[j].x, 0u))) << 2), (int)c_pk);
-#pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++) {
-            qq[j] = qlane + 64u * kk[j] + (pkv[j] >> 5);
-            byte[j] = seq[min(qq[j] >> 1, last_byte)];   // lanes on D/N ops or outside the span read a clamped (ignored) byte
-          }
-#pragma unroll
-          for (int j = 0; j < PILEUP_UNROLL; j++) {
-            const uint32_t t = (qq[j] & 1u) | aln2;
-            const uint32_t rowt = (uint32_t)lut[(t << 8) | byte[j]] | (pkv[j] & 0x18u);   // >= 8: not ACGT, or the lane sits on a D/N op
-            const uint32_t la = lanebase + 256u * kk[j];
-            bool ok = rowt < 8u;
-            if (EDGE) ok = ok && (la - e_lo) < e_span && kb + (uint32_t)j <= k1;
-            if (ok) lds_add(la + __umul24(rowt, TH4), inc);
-          }
-        };
-        for (uint32_t kb = k0; kb <= k1; kb += PILEUP_UNROLL) {
-          if (kb == k0 || kb + PILEUP_UNROLL > k1) group(kb, std::true_type{}); else group(kb, std::false_type{});
-        }
-        if (mark) bm[mrel >> 5] = 0;
-      }
-      q_run += Qtot; r_run += (int32_t)Rtot;
-    }
-  }
-  __syncthreads();
-  // difference arrays -> counts, in place and still packed (the sums are exact): deletions, then observed codes per slot
-  for (uint32_t a = wave; a < n_slots + 1u; a += PILEUP_WAVES) {
-    uint32_t* __restrict__ arr = a == 0 ? tal + MKP_C_DEL * TH : obs + (a - 1u) * TH;
-    uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < TH; b0 += 64) {
-      const uint32_t v = (b0 + lane < TH) ? arr[b0 + lane] : 0u;
-      const uint32_t sc = wave_incl_scan(v);
-      if (b0 + lane < TH) arr[b0 + lane] = sc + carry;
-      carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
-    }
-  }
-  __syncthreads();
-  // the tile's packed tallies go to HBM (coalesced); mkp_emit_rows reads them back
-  {
-    uint32_t* __restrict__ dst = tally_out + (size_t)tix * lds_words;
-    for (uint32_t k = threadIdx.x; k < lds_words; k += PILEUP_THREADS) dst[k] = lds[k];
-  }
-  // column depth against --max-depth (htslib would start dropping reads: not restated, so the run must fail loudly)
-  {
-    bool deep = false;
-    for (uint32_t i = MKP_HALO + threadIdx.x; i < MKP_HALO + T; i += PILEUP_THREADS) {
-      const int32_t p = T0h + (int32_t)i;
-      if (p < prm.win_start || p >= prm.win_end) continue;
-      uint32_t depth = 0;
-      for (uint32_t c = 0; c < n_counters; c++) { const uint32_t v = tal[c * TH + i]; depth += (v & 0xffffu) + (v >> 16); }
-      deep |= depth > prm.max_depth;
-    }
-    if (deep) atomicOr(dev_err, ERR_DEPTH);
-  }
-  __syncthreads();   // the tallies are re-zeroed for the next tile
-  }
+#define TALLY_BITS 16
+#include "mkp_pileup_body.inc"
+#undef TALLY_BITS
+}
+// the same kernel over the 8-bit tally layout (see mkp_pileup_body.inc); selected by the host for tiles of <= 255 reads when MKP_TALLY8=1
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8)
+mkp_pileup_tiles8(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
+                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
+                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
+                  const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
+#define TALLY_BITS 8
+#include "mkp_pileup_body.inc"
+#undef TALLY_BITS
+#undef T8_DIFF_ADDR
+#undef T8_DIR_ADDR
+#undef T8_INC
 }
 
 // mkp_emit_rows — one 256-thread workgroup per segment of ROWS_SEG consecutive positions of a tile.  The segment's packed
@@ -1355,85 +1148,19 @@ mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict_
               const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
               uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
               uint32_t* __restrict__ dev_err) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t seg_lds[];
-  __shared__ uint32_t wave_tot[ROWS_THREADS / 64];
-  __shared__ uint32_t seg_base;
-  // the run parameters (slot / counter tables the row logic indexes per lane) are read from an LDS copy, not from global memory
-  __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
-  __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];   // <= 64 motif-id combos (checked at mkp_shard_begin)
-  for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += ROWS_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
-  if (prmp->has_focus) for (uint32_t kq = threadIdx.x; kq < prmp->n_combos * (sizeof(MkpCombo) / 4); kq += ROWS_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
-  const uint32_t seg = blockIdx.x;
-  const uint32_t tix = seg / segs_per_tile;
-  const uint32_t tile = tile_ids[tix];
-  const uint32_t T = prmp->tile, TH = T + 2 * MKP_HALO;
-  const uint32_t n_arr = prmp->n_counters + prmp->n_slots;
-  const uint32_t SEGW = ROWS_SEG + 2 * MKP_HALO;
-  const uint32_t i_first = (seg % segs_per_tile) * ROWS_SEG;   // tile-relative index (halo included) of the first staged column
-  const uint32_t* __restrict__ src = tally_in + (size_t)tix * n_arr * TH;
-  {
-    // 16 independent loads per thread in flight before the first LDS store (a load-store-per-iteration loop waits for every load)
-    const uint32_t per_row = (SEGW + ROWS_THREADS - 1) / ROWS_THREADS, n_it = n_arr * per_row;
-    for (uint32_t it0 = 0; it0 < n_it; it0 += 16) {
-      uint32_t v[16];
-#pragma unroll
-      for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t it = it0 + u, r = it / per_row, cidx = (it % per_row) * ROWS_THREADS + threadIdx.x, gi = i_first + cidx;
-        v[u] = (it < n_it && cidx < SEGW && gi < TH) ? src[r * TH + gi] : 0u;
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < 16; u++) {
-        const uint32_t it = it0 + u, r = it / per_row, cidx = (it % per_row) * ROWS_THREADS + threadIdx.x;
-        if (it < n_it && cidx < SEGW) seg_lds[r * SEGW + cidx] = v[u];
-      }
-    }
-  }
-  __syncthreads();
-  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
-  const uint32_t n_counters = prm.n_counters;
-  const int32_t T0 = prm.win_start + (int32_t)(tile * T);
-  const int32_t T0h = T0 - MKP_HALO;
-  TileView tv; tv.n_counters = n_counters; tv.n_slots = prm.n_slots;
-  tv.W = SEGW; tv.i0 = i_first; tv.pk = seg_lds;
-  const int lane = lane_id();
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t li0 = i_first + threadIdx.x * ROWS_PER_THREAD;   // first of this thread's positions, tile-relative (no halo)
-  // the four focus bytes of this thread's positions: one aligned dword (tiles start on multiples of 64 from win_start)
-  uint32_t fv4 = 0x03030303u;
-  if (prm.has_focus) { const int32_t p0 = T0 + (int32_t)li0; fv4 = (li0 < T && p0 >= prm.win_start && p0 + 3 < prm.win_end) ? *reinterpret_cast<const uint32_t*>(focus + (p0 - prm.win_start)) : 0xffffffffu; }
-  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
-  uint32_t my_rows = 0;
-#pragma unroll
-  for (uint32_t j = 0; j < ROWS_PER_THREAD; j++) {
-    const uint32_t li = li0 + j;
-    const int32_t p = T0 + (int32_t)li;
-    if (!(li < T && p >= prm.win_start && p < prm.win_end) || (prm.debug_skip & (4u | 512u))) continue;
-    const uint32_t i = li + MKP_HALO;
-    const uint32_t fv = fv4 == 0xffffffffu ? (uint32_t)focus[p - prm.win_start] : (fv4 >> (8u * j)) & 0xffu;   // (segment edge: byte loads)
-    my_rows += rows_at<false>(tv, prm, focus, combos_l, T0h, i, rows, 0, fv);
-  }
-  const uint32_t inc = wave_incl_scan(my_rows);
-  if (lane == 63) wave_tot[wave] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t s = 0;
-    for (uint32_t w2 = 0; w2 < ROWS_THREADS / 64; w2++) { const uint32_t t = wave_tot[w2]; wave_tot[w2] = s; s += t; }
-    const uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
-    if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
-    seg_base = base; seg_row_off[seg] = base; seg_row_cnt[seg] = s;
-  }
-  __syncthreads();
-  if (seg_row_cnt[seg] != 0 && my_rows && !(prm.debug_skip & 256u)) {
-    uint32_t wr = seg_base + wave_tot[wave] + inc - my_rows;
-#pragma unroll
-    for (uint32_t j = 0; j < ROWS_PER_THREAD; j++) {
-      const uint32_t li = li0 + j;
-      const int32_t p = T0 + (int32_t)li;
-      if (!(li < T && p >= prm.win_start && p < prm.win_end)) continue;
-      const uint32_t fv = fv4 == 0xffffffffu ? (uint32_t)focus[p - prm.win_start] : (fv4 >> (8u * j)) & 0xffu;
-      wr += rows_at<true>(tv, prm, focus, combos_l, T0h, li + MKP_HALO, rows, wr, fv);
-    }
-  }
+#define TALLY_BITS 16
+#include "mkp_rows_body.inc"
+#undef TALLY_BITS
+}
+// the same kernel reading the 8-bit tally layout of mkp_pileup_tiles8
+extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
+mkp_emit_rows8(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
+               const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
+               uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
+               uint32_t* __restrict__ dev_err) {
+#define TALLY_BITS 8
+#include "mkp_rows_body.inc"
+#undef TALLY_BITS
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1497,15 +1224,19 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
-  return hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
+extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, int tally8) {
+  return hipFuncSetAttribute(tally8 ? (const void*)mkp_pileup_tiles8 : (const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
 }
 
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
-                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally, const uint32_t* chunk_pfx, uint32_t* dev_err) {
+                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally, const uint32_t* chunk_pfx, uint32_t* dev_err, int tally8) {
   if (!n_tiles) return hipSuccess;
   const uint32_t grid = n_tiles < 512u ? n_tiles : 512u;   // two persistent workgroups per CU
+  if (tally8)
+    hipLaunchKernelGGL(mkp_pileup_tiles8, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
+                       tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
+  else
   hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
                      tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
   return hipGetLastError();
@@ -1515,13 +1246,21 @@ extern "C" uint32_t mkp_rows_segments(uint32_t tile) { return (tile + ROWS_SEG -
 
 extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, uint32_t tile, uint32_t n_arr, int has_focus, const uint8_t* focus,
                                       const MkpCombo* combos, const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* seg_row_off,
-                                      uint32_t* seg_row_cnt, uint32_t* dev_err) {
+                                      uint32_t* seg_row_cnt, uint32_t* dev_err, int tally8) {
   if (!n_tiles) return hipSuccess;
   const uint32_t spt = mkp_rows_segments(tile);
   const uint32_t lds_bytes = n_arr * (ROWS_SEG + 2 * MKP_HALO) * 4u;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    (void)hipFuncSetAttribute((const void*)mkp_emit_rows8, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_set = true;
+  }
   (void)has_focus;
+  if (tally8)
+    hipLaunchKernelGGL(mkp_emit_rows8, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
+                       seg_row_off, seg_row_cnt, dev_err);
+  else
   hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
                        seg_row_off, seg_row_cnt, dev_err);
   return hipGetLastError();
