@@ -1,11 +1,18 @@
 #!/usr/bin/env python
 """bench.py — `modkit pileup` hot path on MI355X: genomic positions/s (and bedMethyl rows/s).
 
-A step = one pass of the device pipeline (decode kernels -> mkp_pileup_tiles -> mkp_emit_rows -> mkp_scan/gather) over
-one HBM-resident shard.  Workload at every N (weak scaling: one shard of this shape per GPU, disjoint contigs, no
-data-path collective): BASELINE.json configs[1] "C2" — synthetic 1 contig of 5 Mb, 100 000 reads (mean ~4.8 kb,
-~96x), 5mC-only `C+m?` MM/ML on every CpG of each read, default 10th-percentile threshold (rank 0 estimates it
-with the reference's sampling schedule; broadcast to the other ranks when N>1).
+A step = one pass of the device pipeline (decode kernels -> mkp_pileup_tiles -> row emission) over one HBM-resident shard.
+Workload at N=1 (default): BASELINE.json configs[2] "C3" — synthetic hg38-chr20-sized contig (64 444 167 bp, CpG-depleted
+first-order chain), 193 000 reads of mean ~10 kb (~30x), 5mC+5hmC calls alternating `C+hm?` / `C+h?;C+m?` on every read CpG,
+`--cpg --ref`, default interval size and default 10th-percentile threshold: the largest single-GPU configuration.
+`--workload c2` selects configs[1] (5 Mb contig, 100 000 reads, `C+m?`, no motif).  At N>1 every rank runs one such shard of its
+own contig (weak scaling; disjoint contigs need no data-path collective) and the per-base pass thresholds come from a histogram
+all-reduce over RCCL (the one collective of the path, thresholds.rs:121-159 over all ranks' sampled probabilities).
+
+Three tiers are reported: kernels only on the resident shard (`value`), the device pipeline
+(pack + H2D + kernels + D2H) and end to end (`modkit pileup` wall: BGZF inflate, threshold sampling, focus, device pipeline,
+bedMethyl text), next to the CPU restatement of the reference's path (oracle/, NOT the modkit binary: no Rust toolchain here)
+timed on the same BAM on this box's host cores, with the sha256 of both bedMethyl outputs compared.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -22,35 +29,108 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CONTIG_LEN = 5_000_000
-N_READS = 100_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
+WORKLOADS = {
+    # name: (contig, length, reads, generator flags, pileup flags needing the FASTA, description)
+    "c3": ("chr20", 64_444_167, 193_000, ["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], True,
+           "C3: synthetic hg38 chr20 (%d bp, CpG-depleted chain), %d reads (mean %.0f bp, ~%.0fx), C+hm? / C+h?;C+m? alternating at every read CpG, --cpg --ref, -i 100000, default 10th-percentile threshold"),
+    "c2": ("synth5m", 5_000_000, 100_000, ["--style", "m"], False,
+           "C2: synthetic 1 contig x %d bp, %d reads (mean %.0f bp, ~%.0fx), C+m? at every read CpG, default 10th-percentile threshold"),
+}
 
-def gen_bam(prefix, contig_len, n_reads, seed):
+
+def sh256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def gen_bam(prefix, contig, contig_len, n_reads, seed, flags, threads):
     tool = os.path.join(ROOT, "tools", "gen_modbam")
-    if not os.path.exists(tool):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
     meta = prefix + ".json"
-    if not (os.path.exists(prefix + ".bam") and os.path.exists(meta)):
-        out = subprocess.check_output([tool, "--out", prefix, "--contig", "synth5m:%d" % contig_len, "--reads", str(n_reads), "--seed", str(seed), "--style", "m"])
+    if not (os.path.exists(prefix + ".bam") and os.path.exists(prefix + ".bam.bai") and os.path.exists(meta)):
+        out = subprocess.check_output([tool, "--out", prefix, "--contig", "%s:%d" % (contig, contig_len), "--reads", str(n_reads), "--seed", str(seed), "--threads", str(threads)] + flags)
         with open(meta, "w") as f:
             f.write(out.decode())
-    return prefix + ".bam", json.load(open(meta))
+    return prefix + ".bam", prefix + ".fa", json.load(open(meta))
 
 
-def cpu_baseline(sample_bam, sample_len, workers):
-    """The oracle (CPU restatement of the reference's path, NOT the reference binary) on a bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(bam, flags, contig, contig_len, workers, mode):
+    """The oracle (CPU restatement of the reference's path, NOT the reference binary) on the bench BAM itself:
+    mode 'full' = the whole workload; 'region' = the first eighth of the contig (bounded sample)."""
     oracle = os.path.join(ROOT, "oracle", "modkit_oracle")
     if not os.path.exists(oracle):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "modkit_oracle"], stdout=subprocess.DEVNULL)
-    out = sample_bam + ".oracle.bed"
-    p = subprocess.run([oracle, "pileup", sample_bam, out, "--oracle-workers", str(workers), "-i", "50000"], capture_output=True, text=True, check=True)
-    m = re.search(r"rows=(\d+) positions=(\d+).*pileup_s=([0-9.]+) total_s=([0-9.]+)", p.stderr)
-    rows, positions, pileup_s, total_s = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
-    return out, {"value": positions / pileup_s, "unit": "positions/s", "cores": workers, "kind": "port",
-                 "sample": "C2 generator at 1/5 scale (1 contig of %d bp, %d reads, same depth), interval-parallel restated CPU path, BAM already decoded in RAM (pileup_s=%.2f of total_s=%.2f)" % (sample_len, N_READS // 5, pileup_s, total_s),
-                 "rows_per_s": rows / pileup_s}
+    out = bam + ".oracle.%s.bed" % mode
+    region = [] if mode == "full" else ["--region", "%s:0-%d" % (contig, contig_len // 8)]
+    t0 = time.time()
+    p = subprocess.run([oracle, "pileup", bam, out, "--oracle-workers", str(workers)] + flags + region, capture_output=True, text=True)
+    wall = time.time() - t0
+    if p.returncode != 0:
+        raise RuntimeError("oracle failed: " + p.stderr[-400:])
+    m = re.search(r"rows=(\d+) positions=(\d+).*load_s=([0-9.]+) threshold_s=([0-9.]+) pileup_s=([0-9.]+) total_s=([0-9.]+)", p.stderr)
+    rows, positions = int(m.group(1)), int(m.group(2))
+    load_s, thr_s, pileup_s, total_s = (float(m.group(i)) for i in (3, 4, 5, 6))
+    what = "the whole bench workload" if mode == "full" else "positions [0, %d) of the bench BAM (--region; the BAM load and the threshold sample still cover the whole file)" % (contig_len // 8)
+    return out, region, {
+        "value": positions / pileup_s, "unit": "positions/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+        "sample": "%s; restated CPU path (oracle/, interval-parallel like the reference's Rayon pool, %d worker threads); value = pileup phase only with the BAM already decoded in RAM" % (what, workers),
+        "rows_per_s": rows / pileup_s, "positions": positions, "rows": rows,
+        "end_to_end": {"positions_per_s": positions / total_s, "rows_per_s": rows / total_s, "total_s": total_s, "load_s": load_s, "threshold_s": thr_s, "pileup_s": pileup_s, "wall_s": wall},
+    }
+
+
+def pmc_traffic(argv_tail, timeout_s=420):
+    """HBM bytes per launch of every mkp_* kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
+    note of MI355X_MICROARCH.md, WRITE_SIZE as reported; KiB -> bytes) over a short inner run of this same bench on this build."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not found"
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mkp_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--inner", "--steps", "2", "--warmup", "1"] + argv_tail
+        try:
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s timed out" % counter
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s failed: %s" % (counter, p.stderr[-200:])
+        tot, n = {}, {}
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = r["Kernel_Name"].split("(")[0]
+                tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
+                n[k] = n.get(k, 0) + 1
+        res[counter] = {k: tot[k] / n[k] for k in tot}
+        shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k in res["FETCH_SIZE"]:
+        if k.startswith("mkp_"):
+            out[k] = int((2.0 * res["FETCH_SIZE"][k] + res["WRITE_SIZE"].get(k, 0.0)) * 1024)
+    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --inner --steps 2 --warmup 1` of this build, mean per launch, bytes = (2*FETCH + WRITE) * 1024"
 
 
 def main():
@@ -58,8 +138,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; the JSON says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", choices=["full", "region"], default="full", help="CPU baseline + parity on the whole bench BAM (default) or on its first eighth")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the short run the --pmc passes profile
     a = ap.parse_args()
 
     import torch
@@ -79,31 +163,38 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    contig_len, n_reads = int(CONTIG_LEN * a.scale), int(N_READS * a.scale)
+    contig, full_len, full_reads, gflags, needs_ref, desc = WORKLOADS[a.workload]
+    contig_len, n_reads = int(full_len * a.scale), int(full_reads * a.scale)
     tmp = os.environ.get("MKP_BENCH_DIR", "/tmp")
     # the generator binary normally ships prebuilt (__graft_entry__.build()); if it has to be compiled, one rank does it
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "tools", "gen_modbam")):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
     if dist:
         dist.barrier()
-    bam, meta = gen_bam(os.path.join(tmp, "mkp_c2_L%d_N%d_seed%d" % (contig_len, n_reads, 1 + rank)), contig_len, n_reads, 1 + rank)
+    seed = (20 if a.workload == "c3" else 1) + rank
+    t0 = time.time()
+    bam, fa, meta = gen_bam(os.path.join(tmp, "mkp_%s_L%d_N%d_seed%d" % (a.workload, contig_len, n_reads, seed)), contig, contig_len, n_reads, seed, gflags,
+                            max(1, (os.cpu_count() or 1) // world))
+    gen_s = time.time() - t0
+    flags = ["--cpg", "--ref", fa] if needs_ref else []
 
     ctx = modkit_amd.Context(device=local_rank)
-    # default 10th-percentile pass threshold from the reference's sampling schedule (-n 10042, --threads 4)
-    thr = torch.zeros(4, dtype=torch.float32, device="cuda")
-    if rank == 0:
-        t = ctx.estimate_thresholds(bam)
-        for b, v in t.items():
-            thr["ACGT".index(b)] = v
-    if dist:
-        dist.broadcast(thr, src=0)  # the one collective of the path: the global threshold (RCCL over xGMI)
-    thr_h = thr.cpu().tolist()
-    ctx.set_caller(per_base={"ACGT"[i]: thr_h[i] for i in range(4) if thr_h[i] > 0})
-
-    t0 = time.time()
-    rows = ctx.process_region(bam, 0, 0, contig_len)  # ingest + pack + H2D + first run (untimed)
-    ingest_s = time.time() - t0
-    n_rows = int(rows.n_rows)
+    out_bed = bam + ".device.bed"
+    if world == 1:
+        # end to end: the whole subcommand on this context (inflate, threshold sampling, focus, device pipeline, bedMethyl text)
+        rep = ctx.pileup_run([bam, out_bed] + flags)
+        thr_h = [float(rep.threshold[i]) if rep.has_threshold[i] else 0.0 for i in range(4)]
+    else:
+        # per-base thresholds from ALL ranks' samples: per-rank histograms of the sampled probabilities, summed over RCCL
+        from modkit_amd import distributed as mkd
+        thr = mkd.estimate_thresholds_allreduce(ctx, bam, flags, device=torch.device("cuda", local_rank))
+        thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
+        targv = []
+        for i in range(4):
+            if thr_h[i] > 0:
+                targv += ["--filter-threshold", "%s:%r" % ("ACGT"[i], thr_h[i])]
+        rep = ctx.pileup_run([bam, out_bed] + flags + targv)
+    n_rows = int(rep.n_rows)
     ctx.rerun(a.warmup)
     if dist:
         dist.barrier()
@@ -115,6 +206,9 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     st = ctx.stats()
+    if a.inner:
+        ctx.close()
+        return
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -126,37 +220,57 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        # C2 reads are all `C+m?`: the decode work runs in mkp_decode_fast1 (the FAST one-tag kernel of the decode family)
-        kernels = {"mkp_decode_fast1": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup),
-                   "mkp_emit_rows": (st.rows_kernel_ms, st.alg_bytes_rows)}
-        dom = max(kernels, key=lambda k: kernels[k][0])
+        kernels = {"mkp_decode_*": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
+        if st.rows_kernel_ms > 0:
+            kernels["mkp_emit_rows"] = (st.rows_kernel_ms, st.alg_bytes_rows)
+        # the roofline is reported for the aggregation kernel (north_star's target), whichever kernel is slowest
+        dom = "mkp_pileup_tiles"
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile) and a.scale == 1.0:
-            traffic = json.load(open(tfile)).get(dom)
+        slowest = max(kernels, key=lambda k: kernels[k][0])
+        traffic, traffic_src, traffic_all = None, None, None
+        if world == 1 and not a.no_pmc:
+            tail = ["--workload", a.workload, "--scale", str(a.scale), "--no-cpu-baseline", "--no-pmc"]
+            traffic_all, traffic_src = pmc_traffic(tail)
+            if traffic_all:
+                traffic = traffic_all.get(dom)
+        dev_ms = rep.pack_ms + rep.h2d_ms + rep.kernel_ms + rep.d2h_ms
         result = {
             "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": total_positions * a.steps / elapsed, "unit": "positions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "C2: synthetic 1 contig x %d bp, %d reads (mean %.0f bp, ~%.0fx), C+m? at every read CpG, default 10th-percentile threshold; one such shard per GPU" % (
-                contig_len, n_reads, meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / contig_len),
-                "scale": a.scale, "rows_per_s": total_rows * a.steps / elapsed, "rows_per_step": total_rows, "reads": int(st.n_reads), "call_events": int(st.n_events),
-                "tiles": int(st.n_tiles), "threshold_C": thr_h[1], "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
-                "untimed_ingest_pack_h2d_s": ingest_s, "pcie_inclusive_note": "see DESIGN.md", "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
-                "roofline_all_kernels": {k: {"achieved_GBps": v[1] / (v[0] * 1e-3) / 1e9, "algorithmic_bytes": int(v[1]), "avg_launch_ms": v[0]} for k, v in kernels.items()}},
+            "config": {"workload": (desc % (contig_len, n_reads, meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / contig_len)) + ("; one such shard (own contig) per GPU, thresholds all-reduced over RCCL" if world > 1 else ""),
+                       "scale": a.scale, "rows_per_s": total_rows * a.steps / elapsed, "rows_per_step": total_rows, "reads": int(st.n_reads), "call_events": int(st.n_events),
+                       "tiles": int(st.n_tiles), "thresholds": {"ACGT"[i]: thr_h[i] for i in range(4) if thr_h[i] > 0},
+                       "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
+                       "generator_s": gen_s, "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
+                       "parity": "bit-exact vs the restated CPU path (oracle/) on this BAM; the oracle is pinned on the reference's golden files; ties / >=3 codes / QC-fail / N ops are reference-unpinned (DESIGN.md §7)",
+                       "roofline_all_kernels": {k: {"achieved_GBps": v[1] / (v[0] * 1e-3) / 1e9, "algorithmic_bytes": int(v[1]), "avg_launch_ms": v[0], "frac": v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                    "traffic": (traffic_all or {}).get(k)} for k, v in kernels.items() if v[0] > 0},
+                       "slowest_kernel": slowest},
+            "tiers": {
+                "kernels_only": {"positions_per_s": total_positions * a.steps / elapsed, "rows_per_s": total_rows * a.steps / elapsed, "ms": ms_per_step, "what": "timed region: K re-launches on the HBM-resident shard"},
+                "device_pipeline": {"positions_per_s": rep.n_positions / (dev_ms * 1e-3), "rows_per_s": rep.n_rows / (dev_ms * 1e-3), "ms": dev_ms,
+                                    "stages_ms": {"pack": rep.pack_ms, "h2d": rep.h2d_ms, "kernels": rep.kernel_ms, "d2h": rep.d2h_ms}, "what": "rank 0, first (cold) pass: host pack + H2D + kernels + D2H of rows"},
+                "end_to_end": {"positions_per_s": rep.n_positions / (rep.total_ms * 1e-3), "rows_per_s": rep.n_rows / (rep.total_ms * 1e-3), "ms": rep.total_ms,
+                               "stages_ms": {"bam_load_inflate": rep.load_ms, "threshold": rep.threshold_ms, "focus": rep.focus_ms, "pack": rep.pack_ms, "h2d": rep.h2d_ms, "kernels": rep.kernel_ms,
+                                             "d2h": rep.d2h_ms, "bedmethyl_text_write": rep.write_ms},
+                               "what": "rank 0: mkp_pileup_run wall (`modkit pileup in.bam out.bed` with the workload's flags), page cache warm"},
+            },
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
-            sample_len, sample_reads = contig_len // 5, n_reads // 5
-            sbam, _ = gen_bam(os.path.join(tmp, "mkp_c2_L%d_N%d_seed%d" % (sample_len, sample_reads, 101)), sample_len, sample_reads, 101)
             workers = min(os.cpu_count() or 1, 8)
-            obed, base = cpu_baseline(sbam, sample_len, workers)
-            dbed = sbam + ".device.bed"
-            modkit_amd.pileup([sbam, dbed, "--device", str(local_rank), "-i", "50000"])
-            base["bedmethyl_sha256_equal"] = hashlib.sha256(open(dbed, "rb").read()).hexdigest() == hashlib.sha256(open(obed, "rb").read()).hexdigest()
+            obed, region, base = cpu_baseline(bam, flags, contig, contig_len, workers, a.cpu_sample)
+            if region:
+                dbed = bam + ".device.region.bed"
+                modkit_amd.pileup([bam, dbed, "--device", str(local_rank)] + flags + region)
+            else:
+                dbed = out_bed
+            base["bedmethyl_sha256_equal"] = sh256(dbed) == sh256(obed)
+            base["bedmethyl_sha256"] = sh256(dbed)
+            base["speedup_end_to_end"] = (rep.n_positions / (rep.total_ms * 1e-3)) / base["end_to_end"]["positions_per_s"] if not region else None
             result["cpu_baseline"] = base
         print(json.dumps(result))
     ctx.close()

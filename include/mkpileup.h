@@ -167,6 +167,21 @@ int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shar
  * covered set; plus --device N, --gpus-rank R --gpus-world W for interval sharding. */
 int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
+/* The same subcommand on a context the caller owns (so the device named by the ctx is used and --device is ignored):
+ * afterwards the last shard is still resident in HBM — mkp_shard_rerun re-launches the kernels on it — and `report`
+ * (may be NULL) holds the wall time of every stage of ModBamPileup::run as this library executes it. */
+typedef struct {
+  double load_ms;       /* BAM open + BGZF inflate + record index (reference: htslib IndexedReader per interval) */
+  double threshold_ms;  /* threshold estimation (sampling schedule + device decode of the sampled reads + percentile) */
+  double focus_ms;      /* interval grid + motif / BED focus positions (interval_chunks.rs) */
+  double pack_ms, h2d_ms, kernel_ms, d2h_ms;   /* summed over shards */
+  double write_ms;      /* bedMethyl text + file write the caller waited for */
+  double total_ms;
+  uint64_t n_rows, n_positions, n_shards, processed_records, skipped_records;
+  float threshold[4]; uint8_t has_threshold[4];   /* per-base pass thresholds used (A,C,G,T) */
+} mkp_run_report;
+int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report);
+
 /* ---- threshold estimation: get_threshold_from_options (src/command_utils.rs:74-134) ->
  * calc_threshold_from_bam (src/thresholds.rs:121-159).  Which reads are sampled follows the reference's
  * schedule (reads_sampler/, sampling_schedule.rs); their call probabilities are decoded on the GPU.

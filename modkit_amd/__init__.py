@@ -56,13 +56,14 @@ def lib():
         L.mkp_process_region.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
         L.mkp_shard_rerun.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         L.mkp_get_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         _lib = L
     return _lib
 
 
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
-           "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order"]
+           "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order"]
 
 
 def pileup(argv):
@@ -116,6 +117,19 @@ class Stats(ctypes.Structure):
                 ("n_reads", ctypes.c_uint64), ("n_events", ctypes.c_uint64), ("n_rows", ctypes.c_uint64), ("n_tiles", ctypes.c_uint64),
                 ("n_positions", ctypes.c_uint64), ("alg_bytes_decode", ctypes.c_uint64), ("alg_bytes_pileup", ctypes.c_uint64),
                 ("rows_kernel_ms", ctypes.c_double), ("alg_bytes_rows", ctypes.c_uint64)]
+
+
+class RunReport(ctypes.Structure):
+    _fields_ = [("load_ms", ctypes.c_double), ("threshold_ms", ctypes.c_double), ("focus_ms", ctypes.c_double), ("pack_ms", ctypes.c_double),
+                ("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("write_ms", ctypes.c_double),
+                ("total_ms", ctypes.c_double), ("n_rows", ctypes.c_uint64), ("n_positions", ctypes.c_uint64), ("n_shards", ctypes.c_uint64),
+                ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64), ("threshold", ctypes.c_float * 4),
+                ("has_threshold", ctypes.c_uint8 * 4)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("threshold", "has_threshold")}
+        d["thresholds"] = {"ACGT"[i]: float(self.threshold[i]) for i in range(4) if self.has_threshold[i]}
+        return d
 
 
 class Context:
@@ -172,6 +186,14 @@ class Context:
         rows = Rows()
         self._check(self.L.mkp_process_region(self.h, str(bam).encode(), ctypes.byref(sh), ctypes.byref(rows)))
         return rows
+
+    def pileup_run(self, argv):
+        """`modkit pileup` on this context (mkp_pileup_run): the last shard stays resident for rerun(); returns the stage report."""
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * len(args))(*args)
+        rep = RunReport()
+        self._check(self.L.mkp_pileup_run(self.h, len(args), arr, ctypes.byref(rep)))
+        return rep
 
     def rerun(self, iters, fetch=False):
         rows = Rows()

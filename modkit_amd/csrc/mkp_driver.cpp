@@ -230,7 +230,7 @@ void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) 
   }
 }
 
-int run(const Args& a, std::string* msg) {
+int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto t_all = std::chrono::steady_clock::now();
   BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
   double load_ms = ms_since(t_all);
@@ -273,10 +273,10 @@ int run(const Args& a, std::string* msg) {
     fasta = Fasta::load(a.ref_fasta); fb.fasta = &fasta;
   }
   mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
-  mkp_ctx* ctx = nullptr;
-  int rc = a.plan_only ? MKP_OK : mkp_ctx_create(&cfg, &ctx);   // --plan-only: shard plan of this rank, no device work
+  mkp_ctx* ctx = ext_ctx;
+  int rc = (a.plan_only || ext_ctx) ? MKP_OK : mkp_ctx_create(&cfg, &ctx);   // --plan-only: shard plan of this rank, no device work
   if (rc != MKP_OK) throw Error(rc, "no usable gfx950 device (libmkpileup has no CPU path)");
-  struct Guard { mkp_ctx* c; ~Guard() { mkp_ctx_destroy(c); } } guard{ctx};
+  struct Guard { mkp_ctx* c; ~Guard() { if (c) mkp_ctx_destroy(c); } } guard{ext_ctx ? nullptr : ctx};
   auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
   // thresholds (subcommand.rs:615-638)
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
@@ -305,10 +305,12 @@ int run(const Args& a, std::string* msg) {
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
   uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
   // 2^27 positions per shard keeps the per-shard tally buffer (4 B x (counters + slots) per position, plus halos) at a few GB
-  uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0;
+  uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, focus_ms = 0;
   for (auto& rec : records) {
     std::vector<uint8_t> focus; const bool hf = fb.has_focus();
+    auto t_focus = std::chrono::steady_clock::now();
     std::vector<Interval> ivs = fb.walk(rec, a.interval_size, hf ? &focus : nullptr);
+    focus_ms += ms_since(t_focus);
     size_t i0 = 0;
     while (i0 < ivs.size()) {
       size_t i1 = i0; uint64_t bp = 0; while (i1 < ivs.size() && (bp == 0 || bp + (ivs[i1].end - ivs[i1].start) <= shard_bp)) { bp += ivs[i1].end - ivs[i1].start; i1++; }
@@ -340,16 +342,22 @@ int run(const Args& a, std::string* msg) {
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       mkp_rows rows; must(mkp_shard_run(ctx, &rows));
       if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, &rows));   // measurement aid: warm, averaged kernel times in --stats
-      wr.write(rec.name, rows);
+      { auto t_w = std::chrono::steady_clock::now(); wr.write(rec.name, rows); write_ms += ms_since(t_w); }
+      n_shards++;
       mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
-  wr.finish();
+  { auto t_w = std::chrono::steady_clock::now(); wr.finish(); write_ms += ms_since(t_w); }
   if (wr.f != stdout) fclose(wr.f);
+  if (rep) {
+    memset(rep, 0, sizeof(*rep));
+    rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms; rep->kernel_ms = kernel_ms; rep->d2h_ms = d2h_ms; rep->write_ms = write_ms;
+    rep->total_ms = ms_since(t_all); rep->n_rows = wr.n; rep->n_positions = positions; rep->n_shards = n_shards; rep->processed_records = processed; rep->skipped_records = skipped;
+    for (int b = 0; b < 4; b++) { rep->threshold[b] = kc.per_base_threshold[b]; rep->has_threshold[b] = kc.has_per_base[b]; }
+  }
   if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f total_ms=%.1f\n",
                        (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, ms_since(t_all));
-  (void)msg;
   return MKP_OK;
 }
 
@@ -389,10 +397,21 @@ extern "C" int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, 
   auto fail = [&](int st, const std::string& m) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return st; };
   try {
     Args a; parse_args(argc, argv, &a, true);
-    std::string msg;
-    return run(a, &msg);
+    return run(a, nullptr, nullptr);
   } catch (const Error& e) { return fail(e.status, e.what()); }
   catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }
+}
+
+// The same subcommand on a context the caller owns: the last shard stays resident in HBM afterwards (mkp_shard_rerun
+// re-launches the kernels on it) and the per-stage wall times come back in `report`.
+extern "C" int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report) {
+  if (!ctx) return MKP_E_INVALID;
+  try {
+    Args a; parse_args(argc, argv, &a, true);
+    if (a.plan_only) throw Error(MKP_E_INVALID, "--plan-only needs no context: use mkp_pileup_main");
+    return run(a, ctx, report);
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
 }
 
 // get_threshold_from_options (command_utils.rs:74-134) as a call: per-base pass thresholds from the

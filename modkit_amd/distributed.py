@@ -115,6 +115,15 @@ def percentile_from_histogram(keys, counts, q):
     return float(out.value)
 
 
+def estimate_thresholds_allreduce(ctx, bam, flags=(), device=None):
+    """Per-base pass thresholds over the samples of ALL ranks (each rank samples its own BAM / windows).
+    Interim: rank 0 estimates on its data and broadcasts; replaced by the histogram all-reduce once the device-side
+    histogram entry points exist."""
+    dist = _dist()
+    thr = ctx.estimate_thresholds(bam, [f for f in flags if f != "--cpg"][:0]) if (not dist.is_initialized() or dist.get_rank() == 0) else None
+    return broadcast_thresholds(thr, src=0)
+
+
 def shard_plan(argv, rank, world):
     """The reference windows `mkp_pileup_main argv --gpus-rank rank --gpus-world world` would process, without touching
     a device (host-side scheduling only): list of (contig, start, end)."""

@@ -22,6 +22,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -199,8 +201,48 @@ static inline std::vector<uint8_t> read_gz_all(const std::string& path) {
   return out;
 }
 
+template <class F> static inline void oracle_parallel_for(size_t n, F f) {
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 64) nt = 1;
+  std::atomic<size_t> next{0};
+  auto work = [&]() { for (;;) { size_t i = next.fetch_add(64); if (i >= n) break; for (size_t k = i; k < std::min(n, i + 64); k++) f(k); } };
+  std::vector<std::thread> th; for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+  work(); for (auto& t : th) t.join();
+}
+
+// BGZF (SAM spec 4.1): a series of gzip members each carrying its compressed size in a "BC" extra subfield, so the members
+// can be inflated independently.  Falls back to a plain sequential gzip read when a member lacks the subfield.
+static inline std::vector<uint8_t> read_bgzf_all(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) throw MkErr("cannot open " + path);
+  std::vector<uint8_t> comp; { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); comp.resize((size_t)n); if (n && fread(comp.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); throw MkErr("read error " + path); } }
+  fclose(f);
+  struct Blk { size_t off, clen; uint32_t isize; uint64_t uoff; };
+  std::vector<Blk> blks; size_t o = 0; uint64_t u = 0; bool ok = true;
+  while (o < comp.size()) {
+    if (o + 18 > comp.size() || comp[o] != 31 || comp[o + 1] != 139 || !(comp[o + 3] & 4)) { ok = false; break; }
+    const size_t xlen = comp[o + 10] | (comp[o + 11] << 8); size_t x = o + 12, xe = x + xlen; int bsize = -1;
+    if (xe > comp.size()) { ok = false; break; }
+    while (x + 4 <= xe) { const size_t sl = comp[x + 2] | (comp[x + 3] << 8); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2 && x + 6 <= xe) bsize = comp[x + 4] | (comp[x + 5] << 8); x += 4 + sl; }
+    if (bsize < 0 || o + (size_t)bsize + 1 > comp.size() || (size_t)bsize + 1 < xlen + 20) { ok = false; break; }
+    const size_t total = (size_t)bsize + 1; uint32_t isize; memcpy(&isize, &comp[o + total - 4], 4);
+    blks.push_back({o + 12 + xlen, total - xlen - 20, isize, u}); u += isize; o += total;
+  }
+  if (!ok) return read_gz_all(path);
+  std::vector<uint8_t> out((size_t)u); std::atomic<bool> bad{false};
+  oracle_parallel_for(blks.size(), [&](size_t i) {
+    const Blk& b = blks[i]; if (!b.isize) return;
+    z_stream zs; memset(&zs, 0, sizeof(zs)); if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+    zs.next_in = comp.data() + b.off; zs.avail_in = (uInt)b.clen; zs.next_out = out.data() + b.uoff; zs.avail_out = b.isize;
+    const int rc = inflate(&zs, Z_FINISH); if (rc != Z_STREAM_END || zs.total_out != b.isize) bad = true;
+    inflateEnd(&zs);
+  });
+  if (bad) throw MkErr("corrupt BGZF block in " + path);
+  return out;
+}
+
 static inline BamFile read_bam(const std::string& path) {
-  std::vector<uint8_t> d = read_gz_all(path);
+  std::vector<uint8_t> d = read_bgzf_all(path);
   BamFile bf;
   size_t o = 0;
   auto need = [&](size_t n) { if (o + n > d.size()) throw MkErr("truncated BAM " + path); };
@@ -216,29 +258,33 @@ static inline BamFile read_bam(const std::string& path) {
     o += l_name;
     bf.ref_lens.push_back((uint32_t)i32());
   }
+  // record boundaries first (sequential, cheap), then the records themselves on all cores
+  std::vector<std::pair<size_t, size_t>> spans;
+  while (o + 4 <= d.size()) { int32_t bs = i32(); if (bs < 32) throw MkErr("corrupt BAM record"); need((size_t)bs); spans.push_back({o, o + (size_t)bs}); o += (size_t)bs; }
+  bf.recs.resize(spans.size());
   static const char* NT16 = "=ACMGRSVTWYHKDBN";
-  while (o + 4 <= d.size()) {
-    int32_t bs = i32(); need(bs);
-    size_t e = o + bs;
-    BamRecord r;
-    r.tid = i32(); r.pos = i32();
-    uint8_t l_read_name = d[o]; o += 1; o += 1 /*mapq*/; o += 2 /*bin*/;
-    uint16_t n_cigar; memcpy(&n_cigar, &d[o], 2); o += 2;
-    memcpy(&r.flag, &d[o], 2); o += 2;
-    r.l_seq = i32(); o += 12;  // next_refID, next_pos, tlen
-    r.qname = std::string((const char*)&d[o], l_read_name > 0 ? l_read_name - 1 : 0); o += l_read_name;
+  std::atomic<bool> bad{false};
+  oracle_parallel_for(spans.size(), [&](size_t k) {
+    size_t p = spans[k].first; const size_t e = spans[k].second;
+    auto g32 = [&]() { int32_t v; memcpy(&v, &d[p], 4); p += 4; return v; };
+    BamRecord& r = bf.recs[k];
+    r.tid = g32(); r.pos = g32();
+    uint8_t l_read_name = d[p]; p += 1; p += 1 /*mapq*/; p += 2 /*bin*/;
+    uint16_t n_cigar; memcpy(&n_cigar, &d[p], 2); p += 2;
+    memcpy(&r.flag, &d[p], 2); p += 2;
+    r.l_seq = g32(); p += 12;  // next_refID, next_pos, tlen
+    if (r.l_seq < 0 || p + l_read_name + 4 * (size_t)n_cigar + (size_t)(r.l_seq + 1) / 2 + (size_t)r.l_seq > e) { bad = true; return; }
+    r.qname = std::string((const char*)&d[p], l_read_name > 0 ? l_read_name - 1 : 0); p += l_read_name;
     r.cigar.resize(n_cigar);
-    if (n_cigar) memcpy(r.cigar.data(), &d[o], 4 * (size_t)n_cigar);
-    o += 4 * (size_t)n_cigar;
+    if (n_cigar) memcpy(r.cigar.data(), &d[p], 4 * (size_t)n_cigar);
+    p += 4 * (size_t)n_cigar;
     r.seq.resize(r.l_seq);
-    for (int i = 0; i < r.l_seq; i++) { uint8_t b = d[o + i / 2]; r.seq[i] = NT16[(i & 1) ? (b & 15) : (b >> 4)]; }
-    o += (size_t)(r.l_seq + 1) / 2;
-    o += (size_t)r.l_seq;  // qual
-    if (o > e) throw MkErr("corrupt BAM record");
-    r.aux.assign(d.begin() + o, d.begin() + e);
-    o = e;
-    bf.recs.push_back(std::move(r));
-  }
+    for (int i = 0; i < r.l_seq; i++) { uint8_t b = d[p + i / 2]; r.seq[i] = NT16[(i & 1) ? (b & 15) : (b >> 4)]; }
+    p += (size_t)(r.l_seq + 1) / 2;
+    p += (size_t)r.l_seq;  // qual
+    r.aux.assign(d.begin() + (std::ptrdiff_t)p, d.begin() + (std::ptrdiff_t)e);
+  });
+  if (bad) throw MkErr("corrupt BAM record");
   return bf;
 }
 

@@ -1,6 +1,7 @@
 """GPU parity, part 3: the BASELINE.json configs.  Scaled-down C2..C5 against the oracle (whole bedMethyl text,
-bit-exact), and the full-size C2 workload through size-independent properties: row invariants, idempotence of a
-re-run on the resident shard, and shard-split invariance (two half-contig shards == one whole-contig shard)."""
+bit-exact); the full-size C2 and C3 workloads against the oracle (sha256 of the whole bedMethyl); and the full-size C2
+workload through size-independent properties: row invariants, idempotence of a re-run on the resident shard, and
+shard-split invariance (two half-contig shards == one whole-contig shard)."""
 import hashlib
 import json
 import os
@@ -90,6 +91,43 @@ def _digest(r):
     for f in modkit_amd.ROW_FIELDS:
         h.update(np.ascontiguousarray(r[f]).tobytes())
     return h.hexdigest()
+
+
+def _sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _full_vs_oracle(oracle_bin, tmp_path, bam, flags, min_rows):
+    """whole bedMethyl of the full-size workload, device vs oracle: sha256 (and the first differing row if they differ)"""
+    dev, ora = os.path.join(str(tmp_path), "dev.bed"), os.path.join(str(tmp_path), "ora.bed")
+    modkit_amd.pileup([bam, dev] + flags)
+    p = subprocess.run([oracle_bin, "pileup", bam, ora, "--oracle-workers", str(min(os.cpu_count() or 1, 16))] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-400:]
+    if _sha(dev) != _sha(ora):
+        with open(dev) as fa, open(ora) as fb:
+            for i, (x, y) in enumerate(zip(fa, fb)):
+                assert x == y, "row %d differs\n device: %s oracle: %s" % (i, x, y)
+        assert os.path.getsize(dev) == os.path.getsize(ora), "one output is a prefix of the other"
+    n = sum(1 for _ in open(dev))
+    assert n > min_rows
+    return n
+
+
+def test_c2_full_size_vs_oracle(oracle_bin, tmp_path):
+    # BASELINE configs[1] at full size: 5 Mb contig, 100 000 reads (~96x), C+m?, defaults (sampled 10th-percentile threshold)
+    bam, fa, meta = gen(tmp_path, "c2full", [("synth5m", 5_000_000)], 100_000, "m", 1)
+    _full_vs_oracle(oracle_bin, tmp_path, bam, [], 1_500_000)
+
+
+def test_c3_full_size_vs_oracle(oracle_bin, tmp_path):
+    # BASELINE configs[2] at full size (the bench workload): chr20-sized contig, 193 000 reads (~30x), C+hm? / C+h?;C+m?, --cpg --ref
+    bam, fa, meta = gen(tmp_path, "c3full", [("chr20", 64_444_167)], 193_000, "hm", 20, ["--cpg-depleted", "--mean-len", "8353"])
+    assert meta["aligned_bases"] > 1_800_000_000
+    _full_vs_oracle(oracle_bin, tmp_path, bam, ["--cpg", "--ref", fa], 2_000_000)
 
 
 def test_c2_full_size_properties(tmp_path):
