@@ -2,6 +2,8 @@
 // row read-back.  No CPU fallback lives here: the only way rows are produced is the three HIP
 // kernels of mkp_kernels.hip; without a gfx950 device every compute entry point fails with
 // MKP_E_DEVICE.
+#include <atomic>
+#include <climits>
 #include <memory>
 #include <thread>
 
@@ -12,12 +14,10 @@ using namespace mkp;
 extern "C" {
 hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
-hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, int tally8);
-uint32_t mkp_rows_segments(uint32_t tile);
-hipError_t mkp_launch_pileup(hipStream_t, uint32_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*,
-                             const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, const MkpRunParams* /*device*/, uint32_t* /*tallies*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, int /*8-bit tally layout*/);
-hipError_t mkp_launch_rows(hipStream_t, const uint32_t* /*tallies*/, const uint32_t*, uint32_t, uint32_t /*tile*/, uint32_t /*arrays*/, int /*has focus*/, const uint8_t*, const MkpCombo*, const MkpRunParams* /*device*/,
-                           const MkpRowsDev*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int /*8-bit tally layout*/);
+hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
+hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
+                             const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
+                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
 
@@ -51,6 +51,33 @@ template <class V> void upload(DevBuf& b, const V& v) {
   if (!v.empty()) hip_check(hipMemcpy(b.p, v.data(), bytes, hipMemcpyHostToDevice), "H2D");
 }
 
+template <class F> void host_parallel(size_t n, size_t grain, F f) {   // f(lo, hi) over [0, n) in `grain`-sized pieces on all host cores
+  const size_t pieces = (n + grain - 1) / grain;
+  const unsigned n_thr = (unsigned)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), std::max<size_t>(pieces, 1));
+  if (n_thr <= 1) { if (n) f((size_t)0, n); return; }
+  std::atomic<size_t> next{0}; std::vector<std::thread> th;
+  auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pieces) break; f(i * grain, std::min(n, (i + 1) * grain)); } };
+  for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work);
+  work(); for (auto& x : th) x.join();
+}
+
+// htslib's pileup engine stops buffering reads once more than max_depth of them overlap (bam_plp_push, maxcnt); which reads it
+// would drop is not restated, so a shard in which that could happen is refused.  The population is htslib's: every record
+// passing BAM_DEF_MASK (kept reads and supplementary ones), by reference span (ref-skips included).  While no position has
+// more than max_depth such records over it, nothing is ever dropped and the device result is exact.
+void depth_guard(const ShardHost& S, uint32_t max_depth) {
+  const size_t n = S.hdr.size() + S.extra_spans.size();
+  if (n <= max_depth) return;
+  std::vector<int32_t> st, en; st.reserve(n); en.reserve(n);
+  for (auto& h : S.hdr) { st.push_back(h.ref_start); en.push_back(std::max(h.ref_end, h.ref_start + 1)); }
+  for (auto& x : S.extra_spans) { st.push_back(x.first); en.push_back(std::max(x.second, x.first + 1)); }
+  std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+  size_t j = 0, cur = 0, best = 0;
+  for (size_t i = 0; i < n; i++) { while (j < n && en[j] <= st[i]) { j++; cur--; } cur++; best = std::max(best, cur); }
+  if (best > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
+  if (best > max_depth) throw Error(MKP_E_UNSUPPORTED, "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
+}
+
 // derive tile geometry, tile read ranges and the run parameters; upload everything
 void make_resident(mkp_ctx* c) {
   auto t0 = std::chrono::steady_clock::now();
@@ -58,105 +85,119 @@ void make_resident(mkp_ctx* c) {
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
   { std::vector<uint64_t> h(S.name_hash.begin(), S.name_hash.end()); std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
-  c->tables.build(c->packer.layouts, c->caller);
+  // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
+  { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1; c->tables.build(c->packer.layouts, c->caller, &used); }
   MkpRunParams& P = c->prm; memset(&P, 0, sizeof(P));
   P.win_start = S.win_start; P.win_end = S.win_end;
   P.n_counters = c->tables.n_counters; P.n_slots = (uint32_t)c->tables.st.slots.size(); P.n_pb = (uint32_t)c->tables.st.can_pbs.size();
   P.numeric_mode = c->caller.numeric_mode; P.combine_strands = c->caller.combine_strands; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
   P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = c->caller.force_allow; P.max_depth = c->caller.max_depth;
   P.has_focus = c->has_focus; P.n_combos = (uint32_t)c->combos.size();
+#ifdef MKP_DEBUG
   if (const char* dbg = getenv("MKP_DEBUG_SKIP")) P.debug_skip = (uint32_t)strtoul(dbg, nullptr, 0);
+#endif
   for (int b = 0; b < 4; b++) { P.can_of_pb[b] = 0xff; P.pb_of_can[b] = 0; }
   for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) { P.can_of_pb[c->tables.st.can_pbs[k]] = (uint8_t)k; P.pb_of_can[k] = (uint8_t)c->tables.st.can_pbs[k]; }
   std::vector<int> order(P.n_slots); for (uint32_t i = 0; i < P.n_slots; i++) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a], &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
   for (uint32_t i = 0; i < P.n_slots; i++) { P.slot_order[i] = (uint8_t)order[i]; P.slots[i] = c->tables.st.slots[i]; }
   if (P.combine_strands && !P.has_focus) throw Error(MKP_E_INVALID, "combine_strands needs motif focus positions");
-  // tile geometry from the LDS budget (160 KiB per CU on gfx950): the accumulate kernel runs two workgroups per CU, each
-  // holding one tile of packed tallies (one dword per counter / slot and position) plus its waves' scratch in 80 KiB;
-  // the row kernel unpacks one tile into twice that
-  // tile plan for a given number of packed dwords per position: tile length from the LDS budget, then tile -> [first,last) reads
-  // (reads are coordinate sorted; the prefix-max of ends bounds the first candidate)
-  struct TilePlan { uint32_t T = 0, n_total = 0; size_t max_reads = 0; std::vector<uint32_t> ids, first, last; };
-  auto plan_tiles = [&](uint32_t words_per_pos) {
-    TilePlan tp;
-    uint32_t T = c->cfg.tile_positions;
-    if (const char* te = getenv("MKP_TILE")) T = (uint32_t)strtoul(te, nullptr, 0);   // experiments only
-    // two workgroups must be co-resident per CU: 76 KiB each including the kernel's ~1 KiB of static LDS leaves 8 KiB of
-    // slack for the allocation granule (at 80 KiB each one GPU box ran them one per CU and the kernel took 1.9x as long)
-    const uint32_t budget = 76u * 1024u - 1280u;
-    uint32_t maxT = 0;
-    for (uint32_t t = 64; t <= 8192; t += 64) if (MKP_PILEUP_LDS_WORDS(words_per_pos, t + 2 * MKP_HALO) * 4u <= budget) maxT = t;
-    if (maxT < 64) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
-    if (!T || T > maxT) T = std::min<uint32_t>(maxT, 4096u);
-    T = std::max<uint32_t>(64u, T & ~63u);
-    tp.T = T;
-    const uint64_t win = (uint64_t)(S.win_end - S.win_start);
-    tp.n_total = (uint32_t)((win + T - 1) / T);
-    const size_t n = S.hdr.size(); std::vector<int32_t> pmax(n); int32_t m = INT32_MIN;
-    for (size_t i = 0; i < n; i++) { if (i && S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted"); m = std::max(m, S.hdr[i].ref_end); pmax[i] = m; }
-    size_t first = 0, last = 0;
-    for (uint32_t t = 0; t < tp.n_total; t++) {
-      const int64_t lo = (int64_t)S.win_start + (int64_t)t * T - MKP_HALO, hi = (int64_t)S.win_start + (int64_t)(t + 1) * T + MKP_HALO;
+  const size_t n = S.hdr.size();
+  for (size_t i = 1; i < n; i++) if (S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted");
+  depth_guard(S, c->caller.max_depth);
+
+  // ---- tile plan.  The accumulate kernel runs two 1024-thread workgroups per CU, each holding one tile in LDS: 76 KiB per
+  // workgroup including ~3.5 KiB of static LDS leaves slack for the allocation granule (at 80 KiB each one GPU box ran them one
+  // per CU and the kernel took 1.9x as long).  A tile = a run of reference positions; its tally columns ("slots") are all of
+  // its positions, or — when the run has focus positions — only those, so a --cpg tile spans ~50x more reference.
+  const uint32_t words_per_slot = P.n_counters + P.n_slots;
+  const uint32_t budget_words = (76u * 1024u - 3584u) / 4u;
+  const int64_t win = (int64_t)S.win_end - (int64_t)S.win_start;
+  std::vector<MkpTile> tiles; std::vector<uint32_t> slotbm; uint32_t Scap = 0, Wcap = 0;
+  auto max_slots_for = [&](uint32_t W) { uint32_t best = 0; for (uint32_t s = 64; s <= 4160; s += 64) if (MKP_PILEUP_LDS_WORDS(words_per_slot, s, W) <= budget_words) best = s; return best; };
+  if (!c->has_focus) {
+    uint32_t Smax = max_slots_for(0);
+    if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
+    uint32_t T = Smax - 2 * MKP_HALO;
+    if (c->cfg.tile_positions) T = std::min(T, std::max<uint32_t>(32u, c->cfg.tile_positions));
+    Scap = (T + 2 * MKP_HALO + 63u) & ~63u;
+    for (int64_t r0 = S.win_start; r0 < S.win_end; r0 += T) tiles.push_back({(int32_t)r0, (int32_t)std::min<int64_t>(r0 + T, S.win_end), 0, 0});
+  } else {
+    // slot bitmap: bit (p - win_start + margin) set where position p is in focus
+    const size_t nbits = (size_t)win + 2 * MKP_SLOTBM_MARGIN, nwords = (nbits + 31) / 32 + 2;
+    slotbm.assign(nwords, 0);
+    const uint8_t* fz = c->focus.data();
+    host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {   // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
+      for (size_t p = lo; p < hi; p++) if (fz[p] & 3u) { const size_t b = p + MKP_SLOTBM_MARGIN; slotbm[b >> 5] |= 1u << (b & 31); }
+    });
+    std::vector<uint32_t> wpfx(nwords + 1, 0);
+    for (size_t w = 0; w < nwords; w++) wpfx[w + 1] = wpfx[w] + (uint32_t)__builtin_popcount(slotbm[w]);
+    auto rank = [&](int64_t p) { const size_t b = (size_t)(p - S.win_start + MKP_SLOTBM_MARGIN); return wpfx[b >> 5] + (uint32_t)__builtin_popcount(slotbm[b >> 5] & ((1u << (b & 31)) - 1u)); };
+    // span: enough tiles to balance 512 persistent workgroups, bounded by the bitmap the tile keeps in LDS
+    const uint32_t span_max = 32768 - 128;
+    uint32_t span = (uint32_t)std::min<int64_t>(span_max, std::max<int64_t>(1024, ((win / 4096) + 63) & ~63ll));
+    if (c->cfg.tile_positions) span = std::max<uint32_t>(64u, std::min(span, c->cfg.tile_positions & ~63u));
+    Wcap = (span + 2 * MKP_HALO + 31 + 31) / 32 + 2;
+    const uint32_t Smax = max_slots_for(Wcap);
+    if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
+    uint32_t most = 0;
+    for (int64_t r0 = S.win_start; r0 < S.win_end;) {
+      int64_t r1 = std::min<int64_t>(r0 + span, S.win_end);
+      auto halo_slots = [&](int64_t a, int64_t b) { return rank(std::min<int64_t>(b + MKP_HALO, (int64_t)S.win_end + MKP_SLOTBM_MARGIN)) - rank(std::max<int64_t>(a - MKP_HALO, (int64_t)S.win_start - MKP_SLOTBM_MARGIN)); };
+      while (halo_slots(r0, r1) > Smax && r1 - r0 > 32) r1 = r0 + std::max<int64_t>(32, (r1 - r0) / 2);   // dense focus: shorter tile
+      if (halo_slots(r0, r1) > Smax) throw Error(MKP_E_UNSUPPORTED, "internal: focus tile does not fit the LDS budget");
+      if (rank(r1) > rank(r0)) { tiles.push_back({(int32_t)r0, (int32_t)r1, 0, 0}); most = std::max(most, halo_slots(r0, r1)); }   // a tile without focus positions emits nothing
+      r0 = r1;
+    }
+    Scap = std::max<uint32_t>(64u, (most + 63u) & ~63u);
+  }
+  // tile -> [first, last) candidate reads (coordinate sorted; the prefix-max of ends bounds the first candidate)
+  {
+    std::vector<int32_t> pmax(n); int32_t m = INT32_MIN;
+    for (size_t i = 0; i < n; i++) { m = std::max(m, S.hdr[i].ref_end); pmax[i] = m; }
+    size_t first = 0, last = 0; std::vector<MkpTile> kept;
+    for (auto& tl : tiles) {
+      const int64_t lo = (int64_t)tl.r0 - MKP_HALO, hi = (int64_t)tl.r1 + MKP_HALO;
       while (first < n && pmax[first] <= lo) first++;
       if (last < first) last = first;
       while (last < n && S.hdr[last].ref_start < hi) last++;
       bool any = false; for (size_t i = first; i < last && !any; i++) any = S.hdr[i].ref_end > lo;
-      if (any) { tp.ids.push_back(t); tp.first.push_back((uint32_t)first); tp.last.push_back((uint32_t)last); }
-      tp.max_reads = std::max(tp.max_reads, last - first);   // every column's reads are among the tile's
+      if (any) { tl.first = (uint32_t)first; tl.last = (uint32_t)last; kept.push_back(tl); }
     }
-    return tp;
-  };
-  // tile geometry from the LDS budget (160 KiB per CU on gfx950): the accumulate kernel runs two workgroups per CU, each
-  // holding one tile of packed tallies plus its waves' scratch.  Default layout: one dword per counter / slot and position
-  // (16 bits per strand).  MKP_TALLY8=1 (opt-in until validated on the GPU): four 8-bit fields per dword when no tile sees
-  // more than 255 reads — fewer dwords per position, longer tiles, fewer (read, tile) visits.
-  uint32_t words_per_pos = P.n_counters + P.n_slots;
-  c->tally8 = 0;
-  TilePlan tp;
-  if (const char* t8 = getenv("MKP_TALLY8")) if (atoi(t8) == 1 && P.n_counters >= 5) {
-    const uint32_t words8 = 2u + ((2u + 2u * P.n_slots + 3u) >> 2) + ((2u * (P.n_counters - 5u) + 3u) >> 2);
-    tp = plan_tiles(words8);
-    if (tp.max_reads <= 255) { c->tally8 = 1; words_per_pos = words8; }
+    tiles.swap(kept);
   }
-  if (!c->tally8) tp = plan_tiles(words_per_pos);
-  // the packed tallies hold 16 bits per strand: no column may be deeper than 65535
-  if (tp.max_reads > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one tile: columns this deep are outside the device path");
-  const uint32_t T = tp.T;
-  P.tile = T; c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_pos, T + 2 * MKP_HALO) * 4u;
-  c->words_per_pos = words_per_pos;
-  const uint64_t win = (uint64_t)(S.win_end - S.win_start);
-  P.n_tiles_total = tp.n_total;
-  std::vector<uint32_t>& tile_ids = tp.ids; std::vector<uint32_t>& tf = tp.first; std::vector<uint32_t>& tl = tp.last;
-  c->n_tiles = (uint32_t)tile_ids.size();
+  P.slot_cap = Scap; P.focus_words = Wcap;
+  c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_slot, Scap, Wcap) * 4u;
+  c->n_tiles = (uint32_t)tiles.size();
+  c->n_slots_total = 0;
+  if (c->has_focus) { for (size_t w = 0; w < slotbm.size(); w++) c->n_slots_total += (uint64_t)__builtin_popcount(slotbm[w]); }
   c->stats.pack_ms += ms_since(t0);
   auto t1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
-  upload(c->d_layouts, c->tables.dev); upload(c->d_tile_ids, tile_ids); upload(c->d_tile_first, tf); upload(c->d_tile_last, tl);
+  upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
   { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class); upload(c->d_read_ids, ids); }
-  if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); }
+  if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
-  c->n_segs = c->n_tiles * mkp_rows_segments(P.tile);   // row segments: 256 positions each, in genome order
-  c->d_tile_row_off.ensure((size_t)(c->n_segs + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_segs + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_segs + 1) * 4);
+  c->d_tile_row_off.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_tiles + 1) * 4);
   c->d_misc.ensure(64);
-  c->d_tally.ensure(std::max<size_t>((size_t)c->n_tiles * words_per_pos * (T + 2 * MKP_HALO) * 4u, 16));
-  hip_check(mkp_pileup_set_lds(c->lds_bytes, c->tally8), "hipFuncSetAttribute(max dynamic LDS)");
+  hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
   c->resident = true;
   // algorithmic bytes
   uint64_t b_reads = 0; for (auto& h : S.hdr) b_reads += 16 + 4ull * h.n_cigar + (h.l_seq + 1) / 2;
-  c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = win;
+  c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = (uint64_t)win;
   c->stats.alg_bytes_decode = b_reads + S.ranks.size() * 2ull + S.ml.size();  // + 8*events added after the run
-  c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events added after the run; rows: 44 B each
+  c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events + 44*rows added after the run
 }
 
 void run_kernels(mkp_ctx* c, bool time_kernels) {
   MkpRunParams& P = c->prm;
   if (c->row_cap == 0) {
-    uint64_t guess = c->has_focus ? 1u << 20 : (uint64_t)c->stats.n_positions * 2 + 1024;
+    // focus runs: usually one strand rule per focus position and one row per observed code; otherwise two strands per position
+    uint64_t guess = c->has_focus ? c->n_slots_total * std::max<uint32_t>(1u, P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
     c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess, 1ull << 28));
   }
   for (;;) {
@@ -170,25 +211,22 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
-    hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                c->d_tile_ids.as<uint32_t>(), c->d_tile_first.as<uint32_t>(), c->d_tile_last.as<uint32_t>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_tally.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->tally8), "pileup launch");
+    hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+                                c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
+                                c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_rows(c->stream, c->d_tally.as<uint32_t>(), c->d_tile_ids.as<uint32_t>(), c->n_tiles, P.tile, c->words_per_pos, (int)P.has_focus, c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), c->d_prm.as<MkpRunParams>(),
-                              &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2, c->tally8), "rows launch");
+    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_tiles, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
-    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_segs, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
-    if (time_kernels) hip_check(hipEventRecord(c->ev[4], c->stream), "event");
     uint32_t h[4];
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     hip_check(hipStreamSynchronize(c->stream), "kernel sync");
     if (h[2] & 2u) { c->row_cap *= 2; if (c->row_cap > (1ull << 31)) throw Error(MKP_E_NOMEM, "row buffer would exceed 2^31 rows"); continue; }
     if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
-    if (h[2] & 4u) throw Error(MKP_E_UNSUPPORTED, "a pileup column is deeper than max_depth; htslib's maxcnt read-dropping is not reproduced");
     c->stats.n_rows = h[1];
     if (time_kernels) {
-      float a = 0, b = 0, r = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
-      hip_check(hipEventElapsedTime(&r, c->ev[2], c->ev[3]), "event"); hip_check(hipEventElapsedTime(&d, c->ev[3], c->ev[4]), "event");
-      c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.rows_kernel_ms = r; c->stats.gather_kernel_ms = d; c->stats.kernel_ms = a + b + r + d;
+      float a = 0, b = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
+      hip_check(hipEventElapsedTime(&d, c->ev[2], c->ev[3]), "event");
+      c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = d; c->stats.kernel_ms = a + b + d;
     }
     return;
   }
@@ -252,8 +290,8 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
 void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tile_ids,
-                    &c->d_tile_first, &c->d_tile_last, &c->d_prm, &c->d_read_ids, &c->d_tally, &c->d_chunk, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
+  for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -300,6 +338,14 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
     auto t0 = std::chrono::steady_clock::now();
     const int32_t tid = c->shard.tid;
     pack_records(c->packer, c->shard, recs, n, [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); });
+    // supplementary records are not tallied but htslib buffers them (BAM_DEF_MASK lets 0x800 through): their spans count for the max-depth guard
+    for (uint32_t i = 0; i < n; i++) {
+      const mkp_record& r = recs[i];
+      if (r.tid != tid || !(r.flag & 2048) || (r.flag & (4 | 256 | 512 | 1024)) || !r.n_cigar || !r.data || (uint64_t)r.l_qname + 4ull * r.n_cigar > (uint64_t)std::max(r.l_data, 0)) continue;
+      int64_t len = 0; for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, r.data + r.l_qname + 4 * (size_t)k, 4); if ((0x18du >> (w & 15u)) & 1u) len += w >> 4; }
+      c->shard.extra_spans.push_back({r.pos, (int32_t)std::min<int64_t>((int64_t)r.pos + std::max<int64_t>(len, 1), INT32_MAX)});
+    }
+    c->resident = false; c->row_cap = 0;   // the HBM copy and the tile plan belong to the previous record set
     c->stats.pack_ms += ms_since(t0);
   });
 }
@@ -313,8 +359,8 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
     run_kernels(c, true);
     fetch_rows(c, out);
     c->stats.alg_bytes_decode += 8ull * c->stats.n_events;
-    c->stats.alg_bytes_pileup += 8ull * c->stats.n_events;
-    c->stats.alg_bytes_rows = 44ull * c->stats.n_rows;
+    c->stats.alg_bytes_pileup += 8ull * c->stats.n_events + 44ull * c->stats.n_rows;   // rows leave the accumulate kernel directly
+    c->stats.alg_bytes_rows = 0;
   });
 }
 
@@ -322,9 +368,9 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
   if (!c) return MKP_E_INVALID;
   return guarded(c, [&]() {
     if (!c->resident) throw Error(MKP_E_INVALID, "no resident shard: call mkp_shard_run once first");
-    double d = 0, p = 0, r = 0, g = 0;
-    for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; r += c->stats.rows_kernel_ms; g += c->stats.gather_kernel_ms; }
-    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = r / iters; c->stats.gather_kernel_ms = g / iters; c->stats.kernel_ms = (d + p + r + g) / iters; }
+    double d = 0, p = 0, g = 0;
+    for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; g += c->stats.gather_kernel_ms; }
+    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = g / iters; c->stats.kernel_ms = (d + p + g) / iters; }
     if (out) fetch_rows(c, out);
   });
 }

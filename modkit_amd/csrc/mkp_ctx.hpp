@@ -40,9 +40,9 @@ struct mkp_ctx {
   mkp::CallerCfg caller; bool caller_set = false;
   mkp::Packer packer; mkp::ShardHost shard; mkp::LayoutTables tables; bool shard_open = false, resident = false;
   std::vector<uint8_t> focus; bool has_focus = false; std::vector<mkp_motif_combo> combos;
-  MkpRunParams prm; uint32_t lds_bytes = 0, n_tiles = 0, n_segs = 0, words_per_pos = 0; int tally8 = 0; uint64_t row_cap = 0;
-  mkp::DevBuf d_hdr, d_vals, d_cigar, d_seq, d_tagref, d_ranks, d_ml, d_layouts, d_events, d_readout, d_focus, d_combos, d_tile_ids, d_tile_first, d_tile_last,
-      d_tile_row_off, d_tile_row_cnt, d_tile_dst, d_misc, d_rows_src, d_rows_dst, d_prm, d_read_ids, d_tally, d_chunk;
+  MkpRunParams prm; uint32_t lds_bytes = 0, n_tiles = 0; uint64_t row_cap = 0, n_slots_total = 0;
+  mkp::DevBuf d_hdr, d_vals, d_cigar, d_seq, d_tagref, d_ranks, d_ml, d_layouts, d_events, d_readout, d_focus, d_combos, d_tiles, d_slotbm,
+      d_tile_row_off, d_tile_row_cnt, d_tile_dst, d_misc, d_rows_src, d_rows_dst, d_prm, d_read_ids, d_chunk;
   uint32_t n_class[3] = {0, 0, 0};
   MkpRowsDev rows_src, rows_dst;
   std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif;

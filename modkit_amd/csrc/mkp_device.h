@@ -14,9 +14,10 @@
 //   uint32      read_ids[]          reads by decode kernel class (FAST 1 tag | FAST 2 tags | general), longest first in a class
 //   MkpEvent    events[]            written by the decode kernels, read by mkp_pileup_tiles
 //   MkpReadOut  readout[n_reads]    per-read decode summary
-//   uint32      tally[n_tiles][counters + slots][tile + 2*halo]   16-bit-packed strand tallies, mkp_pileup_tiles -> mkp_emit_rows
-//                                   (opt-in MKP_TALLY8=1: four 8-bit fields per dword, see mkp_pileup_body.inc)
-//   MkpRowsDev  rows                SoA row buffers (per 1024-position segment, then gathered into genome order)
+//   MkpTile     tiles[n_tiles]      reference range + read range of every tile, genome order (host tile planner)
+//   uint32      slotbm[]            focus runs only: one bit per reference position of the window (+64 positions of margin each
+//                                   side), set where the position is in focus — the positions that get a tally column ("slot")
+//   MkpRowsDev  rows                SoA row buffers (per tile, then gathered into genome order)
 #pragma once
 #include <stdint.h>
 
@@ -111,7 +112,7 @@ struct MkpCombo {  // == mkp_motif_combo
 struct MkpRunParams {
   // reference window
   int32_t win_start, win_end;
-  uint32_t tile, n_tiles_total;
+  uint32_t slot_cap, focus_words;   // S: tally columns per tile; W: bitmap words per tile (0 = no focus: slot = position)
   // counters
   uint32_t n_counters;      // per strand tally
   uint32_t n_slots;
@@ -126,21 +127,31 @@ struct MkpRunParams {
   uint32_t row_capacity;
   uint32_t sample_mode;     // 1: threshold sampling pass — emit argmax probabilities instead of call events
   uint32_t only_mapped;     // sampling: keep only calls with an aligned reference position
-  uint32_t debug_skip;      // ablation only (env MKP_DEBUG_SKIP): 1 depth walk, 2 events, 4 rows, 8 zero+obs scan
+  uint32_t debug_skip;      // ablation only (-DMKP_DEBUG builds, env MKP_DEBUG_SKIP): 1 depth walk, 2 events, 4 rows
   uint8_t pb_of_can[4];     // CAN counter k -> primary base
   uint8_t can_of_pb[4];     // primary base -> CAN counter k or 0xff
   uint8_t slot_order[MKP_MAX_SLOTS];   // slots sorted by (code_repr, pb)
   MkpSlot slots[MKP_MAX_SLOTS];
 };
 
-// mkp_pileup_tiles geometry: 16 waves per tile; behind the tallies every wave owns an op-start bitmap over the
-// tile's positions (even number of dwords, 2 spare for the 96-bit window read) and a 64 x 8-byte compaction buffer
+// One tile of mkp_pileup_tiles: rows are emitted for reference positions [r0, r1) (inside the shard window); tallies are kept
+// for the slots of [r0 - MKP_HALO, r1 + MKP_HALO) (strand combining reads a partner up to MKP_HALO away); reads [first, last)
+// are the candidates overlapping that range.  A "slot" is a position that owns a tally column in LDS: every position of
+// the range when the run has no focus, the focus positions only (--cpg / --motif / --include-bed) when it has.
+struct MkpTile { int32_t r0, r1; uint32_t first, last; };
+#define MKP_SLOTBM_MARGIN 64   // slot bitmap origin = win_start - MKP_SLOTBM_MARGIN
+
+// mkp_pileup_tiles geometry: 16 waves per tile.  Dynamic LDS, in dwords:
+//   tallies  [words_per_slot][S]            S = slot capacity of a tile (multiple of 64), 16-bit-packed strand tallies
+//   focus runs: bm[W] + pfx[W] (slot bitmap of the tile's reference range and its running popcount), fpos[S] (slot -> position)
+//   per wave: an op-start bitmap over the tile's slots (even number of dwords, 2 spare for the 64-bit window read) and a
+//   64 x 8-byte compaction buffer
 #ifndef MKP_PILEUP_THREADS
 #define MKP_PILEUP_THREADS 1024
 #endif
 #define MKP_PILEUP_WAVE_SCRATCH 128
-#define MKP_PILEUP_BM_WORDS(TH) (((((TH) + 31u) >> 5) + 3u) & ~1u)
-#define MKP_PILEUP_LDS_WORDS(words_per_pos, TH) ((words_per_pos) * (TH) + (MKP_PILEUP_THREADS / 64) * (MKP_PILEUP_BM_WORDS(TH) + MKP_PILEUP_WAVE_SCRATCH))
+#define MKP_PILEUP_BM_WORDS(S) (((((S) + 31u) >> 5) + 3u) & ~1u)
+#define MKP_PILEUP_LDS_WORDS(words_per_slot, S, focus_words) ((words_per_slot) * (S) + ((focus_words) ? 2u * (focus_words) + (S) : 0u) + (MKP_PILEUP_THREADS / 64) * (MKP_PILEUP_BM_WORDS(S) + MKP_PILEUP_WAVE_SCRATCH))
 
 struct MkpRowsDev {  // SoA row buffers (44 B / row)
   uint32_t* pos; uint32_t* info; uint32_t* code;

@@ -940,26 +940,11 @@ extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast2(DECODE_PARAMS
 // ----------------------------------------------------------------------------------------------
 struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
 
-struct TileView {   // packed tallies of a run of positions staged in LDS: [counter | slot][W], '+' tally in the low, '-' in the high 16 bits;
-                    // position index i (tile-relative, halo included) lives at column i - i0
+struct TileView {   // packed tallies of a tile in LDS: [counter | observed-code slot][S], '+' tally in the low, '-' in the high 16 bits; column = tally slot
   const uint32_t* pk;
-  uint32_t W, i0, n_counters, n_slots;
-  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return (pk[cid * W + (i - i0)] >> (16u * s)) & 0xffffu; }
-  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return (int32_t)((pk[(n_counters + sl) * W + (i - i0)] >> (16u * s)) & 0xffffu); }
-};
-// the 8-bit layout of mkp_pileup_tiles8 (mkp_pileup_body.inc): rows [0]/[1] NoCall '+'/'-' (field = base), then ND difference rows
-// (fields DEL+, DEL-, slot0+, slot0-, ...), then the direct counters (field (counter-5)*2 + strand)
-struct TileView8 {
-  const uint32_t* pk;
-  uint32_t W, i0, n_counters, n_slots;
-  __device__ __forceinline__ uint32_t fld(uint32_t row, uint32_t f, uint32_t i) const { return (pk[row * W + (i - i0)] >> (8u * (f & 3u))) & 0xffu; }
-  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const {
-    if (cid < 4u) return fld(s, cid, i);
-    if (cid == 4u) return fld(2u, s, i);
-    const uint32_t nd = (2u + 2u * n_slots + 3u) >> 2, g = (cid - 5u) * 2u + s;
-    return fld(2u + nd + (g >> 2), g, i);
-  }
-  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { const uint32_t dd = 2u + 2u * sl + s; return (int32_t)fld(2u + (dd >> 2), dd, i); }
+  uint32_t W, n_counters;
+  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return (pk[cid * W + i] >> (16u * s)) & 0xffffu; }
+  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return (int32_t)((pk[(n_counters + sl) * W + i] >> (16u * s)) & 0xffffu); }
 };
 
 // one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
@@ -986,11 +971,12 @@ __device__ __forceinline__ bool tally_row(const TV& tv, const MkpRunParams& prm,
   return true;
 }
 
-template <bool WRITE, class TV>
+// Rows of one reference position p whose tallies sit in column i.  slot_of(q) = column of a nearby position q (the strand-
+// combining partner: always a focus position of the same tile's halo'd range).
+template <bool WRITE, class TV, class SlotOf>
 __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
-                                            const MkpCombo* combos, int32_t T0h, uint32_t i, const MkpRowsDev& rows,
-                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */) {
-  const int32_t p = T0h + (int32_t)i;
+                                            const MkpCombo* combos, int32_t p, uint32_t i, const MkpRowsDev& rows,
+                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */, SlotOf slot_of) {
   const uint32_t rule = fv & 3u, combo = fv >> 2;
   if (!rule) return 0;
   uint32_t n = 0;
@@ -1039,7 +1025,7 @@ __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& pr
           const MkpCombo cq = combos[fq >> 2];
           for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx);
         }
-        iq = (uint32_t)(qpos - T0h);
+        if (neg_ok) iq = slot_of(qpos);
       }
       const bool pos_ok = (rule & 1u) != 0;
       auto add = [](RowAcc& a, const RowAcc& b) { a.n_valid += b.n_valid; a.n_mod += b.n_mod; a.n_can += b.n_can; a.n_other += b.n_other;
@@ -1075,11 +1061,8 @@ __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& pr
 #define PILEUP_THREADS MKP_PILEUP_THREADS
 #define PILEUP_WAVES (PILEUP_THREADS / 64)
 #define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
-#ifndef PILEUP_UNROLL
-#define PILEUP_UNROLL 4
-#endif
 
-// LDS byte addresses as integers: a tally update is then `lane base + 256*window + row*4*TH`, two VALU instructions
+// LDS byte addresses as integers: a tally update is then `lane base + 256*window + row*4*S`, two VALU instructions
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 __device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1105,67 +1088,391 @@ __device__ __forceinline__ uint32_t event_lower_bound(const MkpEvent* __restrict
   return lo + (uint32_t)__popcll(__ballot(valid && p < key));
 }
 
-// mkp_pileup_tiles — accumulate.  Two 1024-thread workgroups per CU (8 waves per SIMD).  LDS holds the tile's tallies as
-// [row][position] u32 with the '+' strand tally in the low and the '-' strand tally in the high 16 bits (column depth
-// < 65536 is checked by the host), rows = the strand tally's counters followed by the observed-code slots; consecutive
-// positions sit on consecutive banks.  After the tile's reads are in, the packed tallies are streamed to HBM and
-// mkp_emit_rows turns them into rows.  (Sums are exact in 32-bit arithmetic whatever the order of +/- updates.)
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8)
-mkp_pileup_tiles(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
-                 const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
-                 const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
-                 const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
-#define TALLY_BITS 16
-#include "mkp_pileup_body.inc"
-#undef TALLY_BITS
-}
-// the same kernel over the 8-bit tally layout (see mkp_pileup_body.inc); selected by the host for tiles of <= 255 reads when MKP_TALLY8=1
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8)
-mkp_pileup_tiles8(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
-                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const uint32_t* __restrict__ tile_ids,
-                  const uint32_t* __restrict__ tile_first, const uint32_t* __restrict__ tile_last, uint32_t n_tiles,
-                  const MkpRunParams* __restrict__ prmp, uint32_t* __restrict__ tally_out, const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
-#define TALLY_BITS 8
-#include "mkp_pileup_body.inc"
-#undef TALLY_BITS
-#undef T8_DIFF_ADDR
-#undef T8_DIR_ADDR
-#undef T8_INC
+// Position <-> tally column of a tile.  Without focus positions every position of the tile's (halo'd) range owns a column.
+// With them only the focus positions do: a bitmap of the range plus its running popcount (both in LDS) give
+// rank(p) = number of focus positions below p, which is the column of p when p is one, and the first column at or after p
+// when it is not (what the ends of a read span, a deletion or a CIGAR op need).
+template <bool FOCUS> struct SlotMap {
+  const uint32_t* bm; const uint32_t* pfx; const int32_t* fpos; int32_t lbase, T0h;
+  __device__ __forceinline__ uint32_t rank(int32_t p) const {
+    if (!FOCUS) return (uint32_t)(p - T0h);
+    const uint32_t lb = (uint32_t)(p - lbase), w = lb >> 5;
+    return pfx[w] + (uint32_t)__popc(bm[w] & ((1u << (lb & 31u)) - 1u));
+  }
+  __device__ __forceinline__ bool is_slot(int32_t p) const { if (!FOCUS) return true; const uint32_t lb = (uint32_t)(p - lbase); return (bm[lb >> 5] >> (lb & 31u)) & 1u; }
+  __device__ __forceinline__ int32_t pos_of(uint32_t c) const { return FOCUS ? fpos[c] : T0h + (int32_t)c; }
+};
+
+// Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
+// run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
+template <bool FOCUS>
+__device__ __noinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SlotMap<FOCUS> sm, uint32_t n_tslots, MkpTile tl, uint32_t tix, const MkpRunParams* __restrict__ prmp,
+                                            const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
+                                            uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
+                                            uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p) {
+  const MkpRunParams& prm = *prmp;
+  const int lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  MkpRowsDev rows;
+  { const size_t cap = prm.row_capacity; uint32_t* p = rows_base;
+    rows.pos = p; rows.info = p + cap; rows.code = p + 2 * cap; rows.n_valid = p + 3 * cap; rows.n_mod = p + 4 * cap; rows.n_can = p + 5 * cap; rows.n_other = p + 6 * cap;
+    rows.n_del = p + 7 * cap; rows.n_fail = p + 8 * cap; rows.n_diff = p + 9 * cap; rows.n_nocall = p + 10 * cap; }
+  TileView tv; tv.pk = tal; tv.W = prm.slot_cap; tv.n_counters = prm.n_counters;
+  auto slot_of = [&](int32_t q) { return sm.rank(q); };
+  // pass 1: rows per slot, summed over the tile
+  uint32_t mine = 0;
+  for (uint32_t i = threadIdx.x; i < n_tslots; i += PILEUP_THREADS) {
+    const int32_t p = sm.pos_of(i);
+    if (p < tl.r0 || p >= tl.r1) continue;
+    const uint32_t fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u;
+    mine += rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of);
+  }
+  { const uint32_t inc2 = wave_incl_scan(mine); if (lane == 63) wave_tot[wave] = inc2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+    for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
+    uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+    if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+    *row_base_p = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s; *scan_carry_p = s ? 0u : 0xffffffffu;
+  }
+  __syncthreads();
+  // pass 2: write, 1024 slots at a time
+  if (*scan_carry_p != 0xffffffffu) {
+    const uint32_t row_base = *row_base_p;
+    for (uint32_t i0 = 0; i0 < n_tslots; i0 += PILEUP_THREADS) {
+      const uint32_t i = i0 + threadIdx.x;
+      uint32_t cnt = 0, fv = 0; int32_t p = 0;
+      if (i < n_tslots) {
+        p = sm.pos_of(i);
+        if (p >= tl.r0 && p < tl.r1) { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+      }
+      const uint32_t inc2 = wave_incl_scan(cnt);
+      __syncthreads();   // wave_tot / scan_carry of the previous round are consumed
+      if (lane == 63) wave_tot[wave] = inc2;
+      __syncthreads();
+      uint32_t woff = *scan_carry_p;
+      for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
+      if (cnt) rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of);
+      __syncthreads();
+      if (threadIdx.x == PILEUP_THREADS - 1) *scan_carry_p = woff + inc2;
+    }
+  }
 }
 
-// mkp_emit_rows — one 256-thread workgroup per segment of ROWS_SEG consecutive positions of a tile.  The segment's packed
-// tallies (plus a 16-position halo each side for strand combining) and the run parameters are staged in LDS with all
-// loads in flight together; every thread then owns ROWS_PER_THREAD consecutive positions: rows of FeatureVector::decode
-// (412-446), add_tally_to_counts (283-410) and combine_strand_features (469-561), compacted with a block scan.
-// Segment order = position order; mkp_gather_rows concatenates the segments.
-#define ROWS_THREADS 256
-#define ROWS_PER_THREAD 4
-#define ROWS_SEG (ROWS_THREADS * ROWS_PER_THREAD)
-// (Reading the tallies straight from HBM for the few positions in focus of a --cpg run was tried instead of staging: the
-// per-row chains of dependent HBM loads cost 2x the staged version.)
-extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
-mkp_emit_rows(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
-              const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
-              uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
-              uint32_t* __restrict__ dev_err) {
-#define TALLY_BITS 16
-#include "mkp_rows_body.inc"
-#undef TALLY_BITS
+// mkp_pileup_tiles — accumulate + emit.  Persistent 1024-thread workgroups, two per CU (8 waves per SIMD).  LDS holds one
+// tile's tallies as [row][slot] u32 with the '+' strand tally in the low and the '-' strand tally in the high 16 bits (the host
+// refuses shards in which more than 65535 reads overlap one position); rows = the strand tally's counters followed by the
+// observed-code slots; consecutive slots sit on consecutive banks.  Waves draw the tile's reads from an LDS ticket:
+//   * observed codes: +1 / -1 at the slots bounding the read's span (and around ref-skips) — an interval-OR as a difference array;
+//   * the read's call events inside the tile (position-sorted slice): one LDS atomic on the call's counter and -1 on NoCall(read base);
+//   * depth walk (htslib pileup columns, pileup/mod.rs:783-939): per 64-op CIGAR window the reference-consuming ops that
+//     cover at least one slot are compacted through LDS and their first slots marked in the wave's bitmap; deletions are
+//     +1 / -1 on a difference array; then one lane per slot, 64 slots per step: op index = ballot over the compacted starts
+//     + mbcnt of the aligned 64-bit bitmap window, one ds_bpermute fetches the op's packed (query offset, kind), one byte load
+//     fetches the base, a 1 KB table in LDS maps (strand, query parity, SEQ byte) to the NoCall row, one LDS atomic.
+// With focus positions (FOCUS) the walk touches only the focus slots of each op — a --cpg run visits ~2 % of the aligned bases
+// and a tile covers ~50x more reference for the same LDS.  After a barrier the difference arrays are prefix-summed in place and
+// the rows of FeatureVector::decode (412-446) / add_tally_to_counts (283-410) / combine_strand_features (469-561) are produced
+// straight from LDS: counted, reserved in the row buffer with one atomic per tile, written.  mkp_scan_tiles / mkp_gather_rows
+// put the tiles' row runs in genome order.
+template <bool FOCUS, int UNROLL>
+__device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
+                 const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles,
+                 const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos,
+                 uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
+                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t next_read;
+  __shared__ uint32_t wave_tot[PILEUP_WAVES];
+  __shared__ uint32_t row_base, scan_carry;
+  // SEQ byte -> NoCall row of the base a query index selects: rowlut[strand][query parity][byte]; 15 = not A/C/G/T.
+  // (BAM packs two bases per byte, high nibble first; on the '-' strand the tallied base is the complement.)
+  __shared__ uint8_t rowlut[2][2][256];
+  __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];   // <= 64 motif-id combos (checked at mkp_shard_begin)
+  {
+    const uint32_t t = threadIdx.x, byte = t & 255u, par = (t >> 8) & 1u, st = (t >> 9) & 1u;
+    const uint32_t nib = par ? (byte & 15u) : (byte >> 4);
+    const unsigned long long LUT = st ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;
+    rowlut[st][par][byte] = (uint8_t)((LUT >> (4u * nib)) & 15u);
+    for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += PILEUP_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
+    if (prmp->has_focus) for (uint32_t kq = threadIdx.x; kq < prmp->n_combos * (sizeof(MkpCombo) / 4); kq += PILEUP_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
+  }
+  __syncthreads();
+  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
+  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
+  const uint32_t S = prm.slot_cap, W = prm.focus_words;
+  const uint32_t n_counters = prm.n_counters, n_oslots = prm.n_slots;
+  const uint32_t tal_words = (n_counters + n_oslots) * S;
+  uint32_t* __restrict__ tal = lds;                       // [n_counters + n_oslots][S], packed
+  uint32_t* __restrict__ obs = lds + n_counters * S;      // observed-code difference arrays
+  uint32_t* __restrict__ fbm = lds + tal_words;           // FOCUS: bitmap words [W], running popcount [W], slot -> position [S]
+  uint32_t* __restrict__ fpfx = fbm + W;
+  int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(fpfx + W);
+  const uint32_t focus_total = FOCUS ? 2u * W + S : 0u;
+  const int lane = lane_id();
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // per-wave scratch behind that: op-start bitmap over the tile's slots + CIGAR compaction buffer
+  const uint32_t bm_words = MKP_PILEUP_BM_WORDS(S);
+  uint32_t* __restrict__ bm = lds + tal_words + focus_total + wave * (bm_words + PILEUP_WAVE_SCRATCH);
+  uint2* __restrict__ comp = reinterpret_cast<uint2*>(bm + bm_words);
+  const uint32_t TS4 = S * 4u;
+  // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
+  // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
+  // Persistent workgroups: each walks its tiles (v = b, b + grid, ...).
+  for (uint32_t vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
+  uint32_t tix = vb;
+  { const uint32_t per = n_tiles / 8u; if (per && tix < per * 8u) tix = (tix & 7u) * per + (tix >> 3); }
+  const MkpTile tl = tiles[tix];
+  const int32_t T0h = tl.r0 - MKP_HALO, T1h = tl.r1 + MKP_HALO;
+  // zero the tallies and the per-wave scratch (the focus arrays are rewritten below)
+  for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
+  for (uint32_t k = threadIdx.x; k < PILEUP_WAVES * (bm_words + PILEUP_WAVE_SCRATCH); k += PILEUP_THREADS) lds[tal_words + focus_total + k] = 0;
+  if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }
+  SlotMap<FOCUS> sm; sm.bm = fbm; sm.pfx = fpfx; sm.fpos = fpos; sm.T0h = T0h; sm.lbase = T0h;
+  uint32_t n_tslots = (uint32_t)(T1h - T0h);   // tally columns in use
+  if (FOCUS) {
+    // the tile's slice of the slot bitmap: words masked to [T0h, T1h), their running popcount, and the slot -> position list
+    const uint32_t g0 = (uint32_t)(T0h - (prm.win_start - MKP_SLOTBM_MARGIN)), sh = g0 & 31u, nbits = (uint32_t)(T1h - T0h);
+    const uint32_t nw = (sh + nbits + 31u) >> 5;
+    sm.lbase = T0h - (int32_t)sh;
+    __syncthreads();   // scan_carry = 0 visible; previous tile's readers of the focus arrays are done
+    for (uint32_t k0 = 0; k0 < nw + 1u; k0 += PILEUP_THREADS) {
+      const uint32_t k = k0 + threadIdx.x;
+      uint32_t w = 0;
+      if (k < nw) {
+        w = slotbm[(g0 >> 5) + k];
+        if (k == 0) w &= ~((1u << sh) - 1u);
+        const uint32_t endb = sh + nbits - 32u * k;   // bits of this word below the range end
+        if (endb < 32u) w &= (1u << endb) - 1u;
+      }
+      const uint32_t cnt = (uint32_t)__popc(w), inc = wave_incl_scan(cnt);
+      if (lane == 63) wave_tot[wave] = inc;
+      __syncthreads();
+      uint32_t woff = scan_carry;
+      for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
+      const uint32_t excl = woff + inc - cnt;
+      if (k <= nw) { fbm[k] = w; fpfx[k] = excl; }
+      for (uint32_t ww = w, j = 0; ww; ww &= ww - 1u, j++) fpos[excl + j] = sm.lbase + (int32_t)(32u * k) + (__ffs((int)ww) - 1);
+      __syncthreads();
+      if (threadIdx.x == PILEUP_THREADS - 1) scan_carry = woff + inc;
+    }
+    __syncthreads();
+    n_tslots = scan_carry;
+  }
+  __syncthreads();
+
+  // reads are handed out one at a time (LDS ticket) so waves finish the tile together whatever the reads' spans
+  const uint32_t rid_end = tl.last;
+  if (n_tslots) for (;;) {
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&next_read, 1u);
+    const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (rid >= rid_end) break;
+    const MkpReadHdr h = hdrs[rid];
+    if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
+    // the read's slot range in this tile; a read that covers no slot leaves nothing here
+    const int32_t span_a = max(h.ref_start, T0h), span_b = min(h.ref_end, T1h);
+    const uint32_t rs_a = sm.rank(span_a), rs_b = sm.rank(span_b);
+    if (FOCUS && rs_a == rs_b) continue;
+    const MkpReadOut ro = readout[rid];
+    const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u;
+    const uint8_t* __restrict__ seq = seqs + h.seq_off;
+    // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per slot;
+    // the op covering a slot = (ops whose first slot is at or before it) - 1, counted with the wave's op-start bitmap.
+    uint32_t q_run = 0; int32_t r_run = h.ref_start; uint32_t c_first = 0;
+    {  // skip the 64-op CIGAR chunks that end before the tile: the host's per-chunk offsets say where the walk starts
+      const uint32_t nch = (h.n_cigar + 63u) >> 6;
+      if (nch > 1 && T0h > h.ref_start) {
+        const uint32_t rel = (uint32_t)(T0h - h.ref_start);
+        for (uint32_t b0 = 0; b0 < nch; b0 += 64) {
+          const uint32_t kidx = b0 + (uint32_t)lane;
+          const uint2 e = kidx < nch ? chunk_pfx[h.chunk_off + kidx] : make_uint2(0u, 0xffffffffu);
+          const uint32_t cnt = (uint32_t)__popcll(__ballot(kidx < nch && e.y <= rel));   // offsets ascend: a prefix of the lanes
+          if (cnt) {
+            q_run = (uint32_t)__builtin_amdgcn_readlane((int)e.x, (int)(cnt - 1u));
+            r_run = h.ref_start + (int32_t)__builtin_amdgcn_readlane((int)e.y, (int)(cnt - 1u));
+            c_first = 64u * (b0 + cnt - 1u);
+          }
+          if (cnt < 64u) break;
+        }
+      }
+    }
+    // the first chunk's CIGAR words are requested now, ahead of the event work; every later chunk is requested one chunk ahead
+    uint32_t w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
+    // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
+    if (ro.ok && lane < 2) {
+      uint32_t m = lane ? ro.obs[1] : ro.obs[0];
+      while (m) {
+        const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+        atomicAdd(&obs[sl * S + rs_a], lane ? 0x10000u : 1u);
+        if (rs_b < n_tslots) atomicAdd(&obs[sl * S + rs_b], 0u - (lane ? 0x10000u : 1u));
+      }
+    }
+    // the read's call events inside the tile (sorted by position)
+    if (ro.ok && ro.n_events) {
+      const MkpEvent* __restrict__ ev = events + h.event_off;
+      const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
+      for (uint32_t k = lo + lane;; k += 64) {
+        bool in = k < ro.n_events;
+        MkpEvent e; e.pos = 0; e.info = 0;
+        if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
+        if (in && sm.is_slot((int32_t)e.pos)) {
+          const uint32_t i = sm.rank((int32_t)e.pos);
+          atomicAdd(&tal[(e.info & 0xffu) * S + i], (e.info & 0x100u) ? 0x10000u : 1u);
+          if (e.info & (1u << 12))  // the base is a call, not a NoCall (pileup/mod.rs:889-938)
+            atomicAdd(&tal[(MKP_C_NC + ((e.info >> 9) & 3u)) * S + i], 0u - ((e.info & 0x800u) ? 0x10000u : 1u));
+        }
+        if (!__any(in)) break;
+      }
+    }
+    const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
+    const uint8_t* __restrict__ lut = &rowlut[0][0][0];
+    const uint32_t aln2 = aln << 1;
+    const uint32_t lanebase = lds_addr(tal) + 4u * (uint32_t)lane;   // LDS byte address of (row 0, slot `lane`)
+    const uint32_t fposbase = lds_addr(fpos) + 4u * (uint32_t)lane;
+    const uint32_t qbase = (uint32_t)(0 - h.ref_start) - (1u << 26);   // query index = position + qbase + packed offset
+    const uint32_t last_byte = (h.l_seq - 1u) >> 1;
+    for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
+      if (r_run >= T1h) break;
+      const uint32_t w = w_next;
+      if (c0 + 64u < h.n_cigar) w_next = (c0 + 64u + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c0 + 64u + lane] : 5u;
+      const uint32_t op = w & 15u, len = w >> 4;
+      const uint32_t qlen = op_consumes_query(op) ? len : 0u, rlen = op_consumes_ref(op) ? len : 0u;
+      const uint32_t qe = wave_incl_scan(qlen), re = wave_incl_scan(rlen);
+      const uint32_t qs = q_run + qe - qlen;
+      const int32_t rs = r_run + (int32_t)(re - rlen);
+      const uint32_t Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63), Rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
+      const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
+      if (c_lo < c_hi) {
+        // the op's slots inside the tile: [sa, sb)
+        const int32_t pa = min(max(rs, c_lo), c_hi), pb = min(max(rs + (int32_t)rlen, c_lo), c_hi);
+        const uint32_t sa = sm.rank(pa), sb = sm.rank(pb);
+        const bool covers = rlen > 0 && sa < sb;
+        if (op == 3 && ro.ok && covers) {  // ref-skip: the read is not in these columns (alignment.is_refskip())
+          for (uint32_t s = 0; s < 2; s++) {
+            uint32_t m = ro.obs[s];
+            while (m) {
+              const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+              atomicAdd(&obs[sl * S + sa], 0u - (s ? 0x10000u : 1u));
+              if (sb < n_tslots) atomicAdd(&obs[sl * S + sb], s ? 0x10000u : 1u);
+            }
+          }
+        }
+        if (op == 2 && covers) {  // deletion columns (alignment.is_del()): +1/-1 on the strand's DEL row, summed after the barrier
+          atomicAdd(&tal[MKP_C_DEL * S + sa], inc);
+          if (sb < n_tslots) atomicAdd(&tal[MKP_C_DEL * S + sb], 0u - inc);
+        }
+        const uint32_t S_lo = sm.rank(c_lo), S_hi = sm.rank(c_hi);   // the chunk's slots
+        if (S_lo < S_hi) {
+        // compact the window's slot-covering ops to the low lanes: {first slot, packed(query offset, kind)}
+        const unsigned long long refbal = __ballot(covers);
+        const uint32_t nref = (uint32_t)__popcll(refbal);
+        const uint32_t ci = (uint32_t)__popcll(refbal & lanemask_lt());
+        const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
+        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);  // q = (pos - ref_start) + D; kind sits where it ORs into the row
+        if (covers) comp[ci] = make_uint2(sa, pk);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint2 cc = comp[lane];
+        const bool cvalid = (uint32_t)lane < nref;
+        const uint32_t c_sa = cc.x; const uint32_t c_pk = cc.y;
+        const uint32_t c_key = cvalid ? c_sa : 0x7fffffffu;
+        const uint32_t e_lo = lds_addr(tal) + 4u * S_lo, e_span = 4u * (S_hi - S_lo);
+        const bool mark = cvalid && c_sa > S_lo;
+        const uint32_t mrel = c_sa - 1u;   // bit m set <=> an op's first slot is m+1: "starts at or before slot c" = bits strictly below c
+        if (mark) atomicOr(&bm[mrel >> 5], 1u << (mrel & 31u));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 64 slots per step, aligned so a step reads one aligned 64-bit window of the bitmap;
+        // UNROLL steps are issued together (bitmap read -> bpermute -> SEQ byte load) before any tally update.
+        // ops started at or before the first slot of window kk: a ballot over the compacted starts (no LDS dependency)
+        const uint32_t k0 = S_lo >> 6, k1 = (S_hi - 1u) >> 6;
+        // Only the first and the last group of a chunk hold out-of-range lanes or repeated (clamped) windows; the groups in
+        // between run a version without the clamps and the range check.
+        auto group = [&](uint32_t kb, auto edge_c) {
+          constexpr bool EDGE = decltype(edge_c)::value;
+          uint32_t pkv[UNROLL], byte[UNROLL], qq[UNROLL], idx[UNROLL], kk[UNROLL]; uint2 Wd[UNROLL]; int32_t pp[UNROLL];
+          // stage by stage across the UNROLL windows, so the LDS reads, the bpermutes and the global loads of the group overlap
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++) kk[j] = EDGE ? min(kb + (uint32_t)j, k1) : kb + (uint32_t)j;
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++) Wd[j] = *reinterpret_cast<const uint2*>(bm + 2u * kk[j]);
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++) {
+            if (FOCUS) pp[j] = (64u * kk[j] + (uint32_t)lane < n_tslots) ? *(const __attribute__((address_space(3))) int32_t*)(uintptr_t)(fposbase + 256u * kk[j]) : T0h;
+            else pp[j] = T0h + (int32_t)(64u * kk[j]) + lane;
+          }
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++) {
+            const uint32_t wstart = 64u * kk[j];
+            idx[j] = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(c_key <= (EDGE ? max(S_lo, wstart) : wstart))) - 1u;
+          }
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++)
+            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(Wd[j].y, __builtin_amdgcn_mbcnt_lo(Wd[j].x, 0u))) << 2), (int)c_pk);
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++) {
+            qq[j] = (uint32_t)pp[j] + qbase + (pkv[j] >> 5);
+            byte[j] = seq[min(qq[j] >> 1, last_byte)];   // lanes on D/N ops or outside the span read a clamped (ignored) byte
+          }
+#pragma unroll
+          for (int j = 0; j < UNROLL; j++) {
+            const uint32_t t = (qq[j] & 1u) | aln2;
+            const uint32_t rowt = (uint32_t)lut[(t << 8) | byte[j]] | (pkv[j] & 0x18u);   // >= 8: not ACGT, or the lane sits on a D/N op
+            const uint32_t la = lanebase + 256u * kk[j];
+            bool ok = rowt < 8u;
+            if (EDGE) ok = ok && (la - e_lo) < e_span && kb + (uint32_t)j <= k1;
+            if (ok) lds_add(la + __umul24(rowt, TS4), inc);
+          }
+        };
+        for (uint32_t kb = k0; kb <= k1; kb += UNROLL) {
+          if (kb == k0 || kb + UNROLL > k1) group(kb, std::true_type{}); else group(kb, std::false_type{});
+        }
+        if (mark) bm[mrel >> 5] = 0;
+        }
+      }
+      q_run += Qtot; r_run += (int32_t)Rtot;
+    }
+  }
+  __syncthreads();
+  // difference arrays -> counts, in place and still packed (the sums are exact): deletions, then observed codes per slot
+  for (uint32_t a = wave; a < n_oslots + 1u; a += PILEUP_WAVES) {
+    uint32_t* __restrict__ arr = a == 0 ? tal + MKP_C_DEL * S : obs + (a - 1u) * S;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_tslots; b0 += 64) {
+      const uint32_t v = (b0 + lane < n_tslots) ? arr[b0 + lane] : 0u;
+      const uint32_t sc = wave_incl_scan(v);
+      if (b0 + lane < n_tslots) arr[b0 + lane] = sc + carry;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    }
+  }
+  if (threadIdx.x == 0) scan_carry = 0;
+  __syncthreads();
+  // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  Out of line: its register needs
+  // (row assembly, motif tables) stay out of the accumulate loops' allocation
+  emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, tix, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  __syncthreads();   // the tallies are re-zeroed for the next tile
+  }
 }
-// the same kernel reading the 8-bit tally layout of mkp_pileup_tiles8
-extern "C" __global__ void __launch_bounds__(ROWS_THREADS)
-mkp_emit_rows8(const uint32_t* __restrict__ tally_in, const uint32_t* __restrict__ tile_ids, uint32_t n_segs, uint32_t segs_per_tile,
-               const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, const MkpRunParams* __restrict__ prmp, MkpRowsDev rows,
-               uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ seg_row_off, uint32_t* __restrict__ seg_row_cnt,
-               uint32_t* __restrict__ dev_err) {
-#define TALLY_BITS 8
-#include "mkp_rows_body.inc"
-#undef TALLY_BITS
-}
+
+#define PILEUP_PARAMS const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
+                 const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles, \
+                 const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, \
+                 uint32_t* __restrict__ rows_base /* 11 SoA arrays of row_capacity entries */, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, \
+                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err
+#define PILEUP_PASS hdrs, cigar, seqs, events, readout, tiles, n_tiles, prmp, slotbm, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, chunk_pfx, dev_err
+// every position owns a tally column (no focus positions): the dense walk, 4 windows of 64 positions in flight
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles(PILEUP_PARAMS) { pileup_tiles_body<false, 4>(PILEUP_PASS); }
+// focus positions only (--cpg / --motif / --include-bed): tally columns, events and the depth walk are restricted to them
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus(PILEUP_PARAMS) { pileup_tiles_body<true, 1>(PILEUP_PASS); }
 
 // ----------------------------------------------------------------------------------------------
-// Order the per-tile row segments by tile index.  Block 0 computes the exclusive scan of the
-// tile counts (n_tiles is small), then every block copies its tiles' segments.
+// Order the per-tile row runs by tile index.  Block 0 computes the exclusive scan of the
+// tile counts (n_tiles is small), then every block copies its tiles' runs.
 extern "C" __global__ void __launch_bounds__(1024)
 mkp_scan_tiles(const uint32_t* __restrict__ tile_row_cnt, uint32_t n_tiles, uint32_t* __restrict__ tile_dst_off, uint32_t* __restrict__ total_rows) {
   __shared__ uint32_t carry_s;
@@ -1224,45 +1531,25 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes, int tally8) {
-  return hipFuncSetAttribute(tally8 ? (const void*)mkp_pileup_tiles8 : (const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
+// per device: both accumulate kernels may use the whole per-workgroup LDS budget the host planned for
+extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
+  hipError_t e = hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)mkp_pileup_tiles_focus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
 }
 
-extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
-                                        const MkpEvent* events, const MkpReadOut* readout, const uint32_t* tile_ids, const uint32_t* tile_first,
-                                        const uint32_t* tile_last, uint32_t n_tiles, const MkpRunParams* prm_dev, uint32_t* tally, const uint32_t* chunk_pfx, uint32_t* dev_err, int tally8) {
+extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int focus_mode, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
+                                        const MkpEvent* events, const MkpReadOut* readout, const MkpTile* tiles, uint32_t n_tiles, const MkpRunParams* prm_dev,
+                                        const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
   const uint32_t grid = n_tiles < 512u ? n_tiles : 512u;   // two persistent workgroups per CU
-  if (tally8)
-    hipLaunchKernelGGL(mkp_pileup_tiles8, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
-                       tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
+  if (focus_mode)
+    hipLaunchKernelGGL(mkp_pileup_tiles_focus, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
+                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
   else
-  hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tile_ids, tile_first,
-                     tile_last, n_tiles, prm_dev, tally, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
-  return hipGetLastError();
-}
-
-extern "C" uint32_t mkp_rows_segments(uint32_t tile) { return (tile + ROWS_SEG - 1) / ROWS_SEG; }
-
-extern "C" hipError_t mkp_launch_rows(hipStream_t st, const uint32_t* tally, const uint32_t* tile_ids, uint32_t n_tiles, uint32_t tile, uint32_t n_arr, int has_focus, const uint8_t* focus,
-                                      const MkpCombo* combos, const MkpRunParams* prm_dev, const MkpRowsDev* rows, uint32_t* row_cursor, uint32_t* seg_row_off,
-                                      uint32_t* seg_row_cnt, uint32_t* dev_err, int tally8) {
-  if (!n_tiles) return hipSuccess;
-  const uint32_t spt = mkp_rows_segments(tile);
-  const uint32_t lds_bytes = n_arr * (ROWS_SEG + 2 * MKP_HALO) * 4u;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mkp_emit_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    (void)hipFuncSetAttribute((const void*)mkp_emit_rows8, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_set = true;
-  }
-  (void)has_focus;
-  if (tally8)
-    hipLaunchKernelGGL(mkp_emit_rows8, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
-                       seg_row_off, seg_row_cnt, dev_err);
-  else
-  hipLaunchKernelGGL(mkp_emit_rows, dim3(n_tiles * spt), dim3(ROWS_THREADS), lds_bytes, st, tally, tile_ids, n_tiles * spt, spt, focus, combos, prm_dev, *rows, row_cursor,
-                       seg_row_off, seg_row_cnt, dev_err);
+    hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
+                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
   return hipGetLastError();
 }
 

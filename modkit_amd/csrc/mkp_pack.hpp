@@ -78,11 +78,16 @@ struct LayoutTables {
     }
   }
 
-  void build(const std::vector<LayoutHost>& layouts, const CallerCfg& cc) {
+  // `used` (optional): layout ids the current shard's reads refer to; the counters / slots and the LDS tile size then depend on
+  // the shard only, not on what the packer interned earlier (e.g. for the threshold sampler).  Unused ids get an empty entry.
+  void build(const std::vector<LayoutHost>& layouts, const CallerCfg& cc, const std::vector<uint8_t>* used = nullptr) {
     dev.clear(); st = SlotTable();
     const bool collapse = cc.numeric_mode == 2;
+    auto is_used = [&](size_t li) { return !used || (li < used->size() && (*used)[li]); };
     // pass 1: slots and CAN counters over every group of every layout
-    for (const LayoutHost& L : layouts) for (int sg = 0; sg < 2; sg++) for (int b = 0; b < 4; b++) {
+    for (size_t li = 0; li < layouts.size(); li++) for (int sg = 0; sg < 2; sg++) for (int b = 0; b < 4; b++) {
+      if (!is_used(li)) continue;
+      const LayoutHost& L = layouts[li];
       std::vector<int> mem; std::vector<uint32_t> uni; group_members(L, sg, b, &mem, &uni);
       if (mem.empty()) continue;
       int pb = sg ? 3 - b : b;  // threshold_base (read_cache.rs:147-150)
@@ -94,8 +99,10 @@ struct LayoutTables {
     n_counters = 6 + (uint32_t)st.can_pbs.size() + (uint32_t)st.slots.size();
     for (size_t i = 0; i < st.slots.size(); i++) { st.slots[i].cid = (uint8_t)(6 + st.can_pbs.size() + i); st.slots[i].can_cid = (uint8_t)(6 + st.find_can(st.slots[i].pb)); }
     // pass 2: per-layout tables
-    for (const LayoutHost& L : layouts) {
+    for (size_t li = 0; li < layouts.size(); li++) {
+      const LayoutHost& L = layouts[li];
       MkpLayout D; memset(&D, 0, sizeof(D));
+      if (!is_used(li)) { dev.push_back(D); continue; }
       D.n_tags = (uint8_t)L.tags.size();
       { bool fast = !L.tags.empty(); std::vector<uint32_t> seen_codes;
         for (auto& th : L.tags) { if (th.fb == 4 || th.fb != L.tags[0].fb || th.neg != L.tags[0].neg || th.codes.empty()) fast = false;
@@ -177,6 +184,7 @@ struct ShardHost {
   PodVec<uint32_t> ranks; PodVec<uint8_t> ml;
   uint64_t n_events_cap = 0, n_calls = 0;
   PodVec<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
+  std::vector<std::pair<int32_t, int32_t>> extra_spans;   // reference spans of records htslib's pileup buffers but the path drops (supplementary): max-depth guard only
   // append shard pieces packed independently (parallel packing), in order: offsets are rebased, layout ids remapped.  Sizes
   // are fixed first, then every piece is copied into place by its own thread.
   void append_all(const std::vector<ShardHost>& ps, const std::vector<std::vector<uint16_t>>& layout_maps) {
@@ -210,7 +218,7 @@ struct ShardHost {
     else { std::vector<std::thread> th; for (size_t i = 0; i < ps.size(); i++) th.emplace_back(place, i); for (auto& t : th) t.join(); }
     n_events_cap = e.ev; n_calls = calls;
   }
-  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); }
+  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); extra_spans.clear(); }
 };
 
 class Packer {
