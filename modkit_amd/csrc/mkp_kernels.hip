@@ -1012,7 +1012,7 @@ __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& pr
   } else {
     // combine_strand_features (pileup/mod.rs:469-561): only '+' motif positions produce rows
     if (!combo) return 0;
-    const MkpCombo cb = combos[combo];
+    const MkpCombo& cb = combos[combo];
     for (uint32_t m = 0; m < cb.n_pos; m++) {
       const int idx = cb.pos_ids[m];
       const int delta = cb.pos_delta[m];
@@ -1022,7 +1022,7 @@ __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& pr
       if (delta != -127 && qpos >= prm.win_start && qpos < prm.win_end) {  // -127: mate position is in another interval
         uint32_t fq = focus[qpos - prm.win_start];
         if ((fq & 2u) && (fq >> 2)) {
-          const MkpCombo cq = combos[fq >> 2];
+          const MkpCombo& cq = combos[fq >> 2];
           for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx);
         }
         if (neg_ok) iq = slot_of(qpos);
@@ -1106,7 +1106,7 @@ template <bool FOCUS> struct SlotMap {
 // Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
 // run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
 template <bool FOCUS>
-__device__ __noinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SlotMap<FOCUS> sm, uint32_t n_tslots, MkpTile tl, uint32_t tix, const MkpRunParams* __restrict__ prmp,
+__device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SlotMap<FOCUS> sm, uint32_t n_tslots, MkpTile tl, uint32_t tix, const MkpRunParams* __restrict__ prmp,
                                             const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
                                             uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
                                             uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p) {
@@ -1220,9 +1220,9 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   const uint32_t TS4 = S * 4u;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
-  // Persistent workgroups: each walks its tiles (v = b, b + grid, ...).
-  for (uint32_t vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
-  uint32_t tix = vb;
+  // One workgroup per tile; the dispatcher hands tiles to CUs as workgroups retire (two fit a CU).
+  {
+  uint32_t tix = blockIdx.x;
   { const uint32_t per = n_tiles / 8u; if (per && tix < per * 8u) tix = (tix & 7u) * per + (tix >> 3); }
   const MkpTile tl = tiles[tix];
   const int32_t T0h = tl.r0 - MKP_HALO, T1h = tl.r1 + MKP_HALO;
@@ -1452,10 +1452,9 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   }
   if (threadIdx.x == 0) scan_carry = 0;
   __syncthreads();
-  // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  Out of line: its register needs
-  // (row assembly, motif tables) stay out of the accumulate loops' allocation
+  // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
+  // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
   emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, tix, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
-  __syncthreads();   // the tallies are re-zeroed for the next tile
   }
 }
 
@@ -1543,7 +1542,7 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int 
                                         const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
                                         uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err) {
   if (!n_tiles) return hipSuccess;
-  const uint32_t grid = n_tiles < 512u ? n_tiles : 512u;   // two persistent workgroups per CU
+  const uint32_t grid = n_tiles;   // one workgroup per tile
   if (focus_mode)
     hipLaunchKernelGGL(mkp_pileup_tiles_focus, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
                        row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
