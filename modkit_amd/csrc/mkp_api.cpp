@@ -12,7 +12,7 @@
 using namespace mkp;
 
 extern "C" {
-hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
+hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[5]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
 hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
@@ -31,18 +31,30 @@ MkpRowsDev carve_rows(DevBuf& b, uint64_t cap) {
   return r;
 }
 
-// reads by decode kernel: [FAST layouts with one tag | FAST layouts with two tags | everything else]
-void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[3]) {
-  std::vector<uint32_t> cls[3];
+// reads by decode kernel: [SPARSE one tag | SPARSE two tags | FAST one tag | FAST two tags | everything else].
+// FAST = one (strand, base) group, no code listed twice, at most two tags.  SPARSE = FAST with explicit ('?') tags only and,
+// for two tags, identical rank lists (`C+h?,d..;C+m?,d..` as basecallers write them): the calls are located per call, not per base.
+void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[5]) {
+  std::vector<uint32_t> cls[5];
   for (size_t i = 0; i < S.hdr.size(); i++) {
-    const MkpReadHdr& h = S.hdr[i]; int c = 2;
-    if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast && h.n_tags <= 2) c = h.n_tags - 1;
+    const MkpReadHdr& h = S.hdr[i]; int c = 4;
+    if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast && h.n_tags <= 2) {
+      c = 2 + (h.n_tags - 1);
+      const MkpLayout& L = T.dev[h.layout];
+      bool sparse = true;
+      for (uint32_t t = 0; t < h.n_tags; t++) if (L.tags[t].mode != 0) sparse = false;
+      if (sparse && h.n_tags == 2) {
+        const MkpTagRef &a = S.tagref[h.tag_off], &b = S.tagref[h.tag_off + 1];
+        sparse = a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0);
+      }
+      if (sparse) c -= 2;
+    }
     cls[c].push_back((uint32_t)i);
   }
   // one wave decodes one read start to end: launch the longest reads first so they do not form the kernel's tail
-  for (int c = 0; c < 3; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; });
+  for (int c = 0; c < 5; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; });
   ids->clear();
-  for (int c = 0; c < 3; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
+  for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
 }
 
 template <class V> void upload(DevBuf& b, const V& v) {

@@ -43,7 +43,7 @@ struct mkp_ctx {
   MkpRunParams prm; uint32_t lds_bytes = 0, n_tiles = 0; uint64_t row_cap = 0, n_slots_total = 0;
   mkp::DevBuf d_hdr, d_vals, d_cigar, d_seq, d_tagref, d_ranks, d_ml, d_layouts, d_events, d_readout, d_focus, d_combos, d_tiles, d_slotbm,
       d_tile_row_off, d_tile_row_cnt, d_tile_dst, d_misc, d_rows_src, d_rows_dst, d_prm, d_read_ids, d_chunk;
-  uint32_t n_class[3] = {0, 0, 0};
+  uint32_t n_class[5] = {0, 0, 0, 0, 0};
   MkpRowsDev rows_src, rows_dst;
   std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif;
   uint64_t n_ok = 0, n_bad = 0;

@@ -894,6 +894,325 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Decode, SPARSE layouts: FAST layouts whose tags are all explicit ('?': only the listed bases are calls) and, when there are
+// two tags, list the same bases (`C+h?,..;C+m?,..` with one delta list — checked by the host).  The calls are then a few
+// percent of the bases, and locating them must not cost per base.  Per 4096-base step (64 bases = 8 SEQ dwords per lane) the
+// wave only counts: per dword a nibble-equality flag word (7 VALU for 8 bases) and its popcount, byte-packed running counts
+// inside the lane, one wave prefix sum; the flag words go to LDS.  The ranks that fall into the step's window are taken 64 at a
+// time from the sorted rank list; every lane owning one finds the lane whose bases contain that occurrence (6 ds_bpermute steps
+// over the prefix sums), the dword inside that lane (one SWAR compare over the packed counts) and the base inside the dword
+// (select on the flag word read back from LDS) — {stored position, call index} goes straight into the call queue, in read
+// order.  No per-base marks, no bitmap deposit, no per-bit loops.  The consumer (per-call work on full batches of 64) is the
+// one of the FAST kernels.
+// flag word of a SEQ dword: bit 4i set where nibble i equals the BAM code of base k (A,C,G,T = 1,2,4,8)
+__device__ __forceinline__ uint32_t nibble_eq(uint32_t x, uint32_t pat) {
+  uint32_t t = x ^ pat;
+  t |= t >> 1; t |= t >> 2;
+  return ~t & 0x11111111u;
+}
+#define MKP_SQCAP 128   // call queue of the SPARSE kernels: < 64 left over + one round of <= 64
+template <bool SAMPLE, int NT>
+__device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
+                 const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
+                 const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
+                 MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts,
+                 const uint32_t* __restrict__ read_ids, uint32_t* __restrict__ lds_queue, uint32_t* __restrict__ lds_flags) {
+  static_assert(NT <= 2, "one or two tags");
+  const int lane = lane_id();
+  const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
+  if (widx >= n_reads) return;
+  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)read_ids[widx]);
+  const MkpReadHdr h = hdrs[rid];
+  MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
+  if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
+  uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
+  uint32_t* __restrict__ q_pos = lds_queue + wib * (2 * MKP_SQCAP);   // queue, SoA: stored position, call index (the same for both tags)
+  uint32_t* __restrict__ q_j = q_pos + MKP_SQCAP;
+  uint32_t* __restrict__ flg = lds_flags + wib * 512u;                 // the step's 512 flag words
+  { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
+    for (int i = lane; i < MKP_LAYOUT_DWORDS; i += 64) lds_lay[i] = src[i]; }
+  __builtin_amdgcn_wave_barrier();
+  const MkpLayout* lay = reinterpret_cast<const MkpLayout*>(lds_lay);
+  const uint32_t* __restrict__ seqw = reinterpret_cast<const uint32_t*>(seqs + h.seq_off);
+  const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
+  const uint32_t L = h.l_seq, nd = (L + 7u) >> 3, aln = rev ? 1u : 0u;
+  const int n_tags = (int)h.n_tags;
+  const int b0 = (int)lay->tags[0].fb & 3, sg0 = (int)lay->tags[0].neg & 1;
+  const int xs = rev ? 3 - b0 : b0;                                   // the stored base the tags count
+  const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
+  GroupRegs grp0 = load_group(gp0);
+  grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
+  grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
+#pragma unroll
+  for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
+  grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
+  const int kcodes0 = (int)((grp0.misc >> 20) & 7u);   // codes of the group: bounds every per-code loop
+  uint32_t t_ml[NT], t_nc[NT], tmu[NT], codes_t[NT];
+  uint32_t t_off = 0, t_n = 0, t_cur = 0;   // the (shared) rank list
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    t_ml[t] = 0; t_nc[t] = 0; tmu[t] = 0; codes_t[t] = 0;
+    if (t < n_tags) {
+      const MkpTagRef tr = tagref[h.tag_off + t]; t_ml[t] = tr.ml_off;
+      if (t == 0) { t_off = tr.rank_off; t_n = tr.n; t_cur = rev ? tr.n : 0u; }
+      t_nc[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tags[t].n_codes);
+      tmu[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tagmap[t][b0]);
+      for (uint32_t i = 0; i < t_nc[t]; i++) codes_t[t] |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
+    }
+  }
+  uint32_t SH_all = 0, setmask_all = 0;   // every call is listed by every tag: hit pattern and code set are wave constants
+#pragma unroll
+  for (int t = 0; t < NT; t++) if (t < n_tags) { SH_all |= 1u << (tmu[t] & 15u); setmask_all |= codes_t[t]; }
+  const uint32_t pat = 0x11111111u << xs;
+  // the low nibble of the last byte is not a base when L is odd: its flag is cleared wherever that dword is looked at
+  const uint32_t odd_dw = (L & 1u) ? ((L - 1u) >> 3) : 0xffffffffu, odd_clear = ~(1u << (8u * (((L - 1u) >> 1) & 3u)));
+  // reverse reads need the total up front (forward rank = total - inclusive count in stored order); 4 loads in flight.
+  // (SEQ is zero-padded to a dword per read and code 0 matches no base; dwords past the read are not loaded.)
+  uint32_t tot = 0;
+  if (rev) {
+    uint32_t acc = 0;
+    for (uint32_t d0 = 0; d0 < nd; d0 += 256) {
+      uint32_t xw[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const uint32_t dd = d0 + 64u * j + lane; xw[j] = dd < nd ? seqw[dd] : 0u; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t dd = d0 + 64u * j + lane;
+        uint32_t F = nibble_eq(xw[j], pat); if (dd == odd_dw) F &= odd_clear;
+        acc += (uint32_t)__popc(F);
+      }
+    }
+    tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
+  }
+  bool err = false;
+  // reverse reads consume the (ascending) rank list from its end: a last entry past the last occurrence of the base
+  // (mod_bam.rs:705-727) would never be consumed — the read is rejected here so that hits always form a suffix of the cursor window
+  if (rev && t_n && ranks[t_off + t_n - 1u] >= tot) err = true;
+  const bool trimmable = !prm.edge_filter || !(L <= prm.edge_start || L <= prm.edge_end);  // read_can_be_trimmed (mod_bam.rs:1668-1671)
+  const bool collapse = prm.numeric_mode == 2;
+  uint32_t obs0 = 0, obs1 = 0, contribH = 0, n_ev = 0, cum = 0;
+  bool any_surviving = false;
+  // CIGAR window: 64 ops in registers, advanced as the batches move along the read
+  uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
+  uint32_t w_op = 5u, w_qe = 0; int32_t w_dl = 0; uint32_t w_rtot = 0;
+  bool win_loaded = false;
+  uint32_t qhead = 0, qcount = 0, d0 = 0;
+  // the next step's SEQ dwords (eight per lane = 64 bases, two 16-byte loads) are always in flight; SEQ buffers end with
+  // slack, so whole vectors are loaded and the dwords past the read are discarded when the flags are made
+  const uint4* __restrict__ seqv = reinterpret_cast<const uint4*>(seqw);   // reads start 4-byte aligned: vector loads may be unaligned (fine on global memory)
+  uint4 xa = make_uint4(0, 0, 0, 0), xb = make_uint4(0, 0, 0, 0);
+  auto load_step = [&](uint32_t dstep) {
+    const uint32_t d = dstep + 8u * (uint32_t)lane;
+    if (d + 4u <= nd) xa = *reinterpret_cast<const uint4*>(seqw + d);
+    else { xa.x = d < nd ? seqw[d] : 0u; xa.y = d + 1u < nd ? seqw[d + 1u] : 0u; xa.z = d + 2u < nd ? seqw[d + 2u] : 0u; xa.w = 0u; }
+    if (d + 8u <= nd) xb = *reinterpret_cast<const uint4*>(seqw + d + 4u);
+    else { xb.x = d + 4u < nd ? seqw[d + 4u] : 0u; xb.y = d + 5u < nd ? seqw[d + 5u] : 0u; xb.z = d + 6u < nd ? seqw[d + 6u] : 0u; xb.w = 0u; }
+  };
+  (void)seqv;
+  load_step(0);
+  // the current step: per-lane counts (byte-packed running counts of its 8 dwords), wave prefix sums, the step's rank window
+  bool step_loaded = false;
+  uint32_t st_incl = 0, st_excl = 0, st_cumlo = 0, st_cumhi = 0, st_cntT = 0, st_wlo = 0, st_whi = 0;
+
+  for (;;) {
+    if (err) break;
+    if (qcount - qhead < 64u && (step_loaded || d0 < nd)) {
+      // ---- producer
+      // the next 64 ranks at the cursor are requested first: the flag / scan work below hides the load
+      uint32_t e; bool valid;
+      if (!rev) { const uint32_t i = t_cur + lane; valid = i < t_n; e = valid ? ranks[t_off + i] : 0xffffffffu; }
+      else { const uint32_t i = t_cur - 64u + lane; valid = (int32_t)i >= 0 && i < t_cur; e = valid ? ranks[t_off + i] : 0u; }
+      if (!step_loaded) {
+        const uint32_t d = d0 + 8u * (uint32_t)lane;          // this lane's first dword: bases [8d, 8d+64)
+        uint32_t F[8] = {nibble_eq(xa.x, pat), nibble_eq(xa.y, pat), nibble_eq(xa.z, pat), nibble_eq(xa.w, pat),
+                         nibble_eq(xb.x, pat), nibble_eq(xb.y, pat), nibble_eq(xb.z, pat), nibble_eq(xb.w, pat)};
+        if (odd_dw - d < 8u) {   // the read's last dword sits in this lane and L is odd
+#pragma unroll
+          for (int j = 0; j < 8; j++) if (d + (uint32_t)j == odd_dw) F[j] &= odd_clear;
+        }
+        load_step(d0 + 512u);
+        __builtin_amdgcn_wave_barrier();   // the previous step's readers of the flag words are done (same wave: program order)
+        *reinterpret_cast<uint4*>(flg + 8u * (uint32_t)lane) = make_uint4(F[0], F[1], F[2], F[3]);
+        *reinterpret_cast<uint4*>(flg + 8u * (uint32_t)lane + 4u) = make_uint4(F[4], F[5], F[6], F[7]);
+        // byte-packed counts, then running counts inside the lane (byte k = count of the dwords before k)
+        const uint32_t clo = (uint32_t)__popc(F[0]) | ((uint32_t)__popc(F[1]) << 8) | ((uint32_t)__popc(F[2]) << 16) | ((uint32_t)__popc(F[3]) << 24);
+        const uint32_t chi = (uint32_t)__popc(F[4]) | ((uint32_t)__popc(F[5]) << 8) | ((uint32_t)__popc(F[6]) << 16) | ((uint32_t)__popc(F[7]) << 24);
+        const uint32_t plo = clo + (clo << 8) + (clo << 16) + (clo << 24);   // inclusive prefix per byte (sums stay below 256)
+        const uint32_t tlo = plo >> 24;                                     // count of dwords 0..3
+        const uint32_t phi = chi + (chi << 8) + (chi << 16) + (chi << 24) + tlo * 0x01010101u;
+        st_cumlo = plo << 8; st_cumhi = (phi << 8) | tlo;                    // exclusive
+        const uint32_t c = phi >> 24;                                       // the lane's 64 bases
+        st_incl = wave_incl_scan(c); st_excl = st_incl - c;
+        st_cntT = (uint32_t)__builtin_amdgcn_readlane((int)st_incl, 63);
+        st_wlo = rev ? (tot - cum - st_cntT) : cum; st_whi = st_wlo + st_cntT;   // rank window of this step
+        step_loaded = true;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      // (reverse reads: the list's last entry was checked against the total, so every entry is below the first window's end)
+      const bool hit = valid && (rev ? (e >= st_wlo) : (e < st_whi));
+      const unsigned long long hb = __ballot(hit);
+      const uint32_t nh = (uint32_t)__popcll(hb);
+      if (nh) {
+        if (qhead) {  // move the (< 64) unconsumed entries to the front
+          const uint32_t n_left = qcount - qhead;
+          const bool mv = (uint32_t)lane < n_left;
+          const uint32_t a = mv ? q_pos[qhead + lane] : 0u, b = mv ? q_j[qhead + lane] : 0u;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (mv) { q_pos[lane] = a; q_j[lane] = b; }
+          qcount = n_left; qhead = 0;
+        }
+        const uint32_t ib = hit ? ((rev ? (tot - 1u - e) : e) - cum) : 0u;   // step-relative stored ordinal of the called base (< cntT)
+        const int owner = find_op(st_incl, ib) & 63;                          // the lane whose 64 bases hold that occurrence
+        const uint32_t o_excl = (uint32_t)__shfl((int)st_excl, owner, 64), o_lo = (uint32_t)__shfl((int)st_cumlo, owner, 64), o_hi = (uint32_t)__shfl((int)st_cumhi, owner, 64);
+        const uint32_t k = ib - o_excl;                                       // occurrence inside the owner's 64 bases
+        // dword: the last of the 8 running counts that is <= k (SWAR: byte i of t keeps 0x80 where count_i > k; counts < 128)
+        const uint32_t kk1 = (k + 1u) * 0x01010101u;
+        const uint32_t t_lo = ((o_lo | 0x80808080u) - kk1) & 0x80808080u, t_hi = ((o_hi | 0x80808080u) - kk1) & 0x80808080u;
+        const uint32_t jd = 7u - (uint32_t)__popc(t_lo) - (uint32_t)__popc(t_hi);
+        const uint32_t cj = ((jd < 4u ? o_lo : o_hi) >> (8u * (jd & 3u))) & 0xffu;
+        uint32_t r = k - cj;
+        uint32_t Fw = hit ? flg[8u * (uint32_t)owner + jd] : 1u;
+        Fw = ((Fw & 0x01010101u) << 4) | ((Fw >> 4) & 0x01010101u);         // base order: bit 4b = base b of the dword
+        uint32_t bpos = 0, cc;
+        cc = (uint32_t)__popc(Fw & 0xffffu); if (r >= cc) { r -= cc; bpos += 4u; Fw >>= 16; }
+        cc = (uint32_t)__popc(Fw & 0xffu);   if (r >= cc) { r -= cc; bpos += 2u; Fw >>= 8; }
+        cc = Fw & 1u;                         if (r >= cc) { bpos += 1u; }
+        // read order: forward reads hit on the low lanes with ascending positions, reverse reads on the high lanes with descending ones
+        const uint32_t slot = qcount + (uint32_t)__popcll(rev ? (hb & ~lanemask_le()) : (hb & lanemask_lt()));
+        if (hit) { q_pos[slot] = 8u * (d0 + 8u * (uint32_t)owner + jd) + bpos; q_j[slot] = rev ? (t_cur - 64u + (uint32_t)lane) : (t_cur + (uint32_t)lane); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        qcount += nh;
+        if (rev) t_cur -= nh; else t_cur += nh;
+      }
+      if (nh < 64u) {   // the window holds no further rank: step done; nothing left in the list: the rest of the read holds no call
+        cum += st_cntT; d0 += 512; step_loaded = false;
+        if (rev ? (t_cur == 0u) : (t_cur == t_n)) d0 = nd;
+      }
+      continue;
+    }
+    if (qcount == qhead) break;
+    // ---- consumer: up to 64 queued calls, in read order
+    const uint32_t nb = min(64u, qcount - qhead);
+    const bool active = (uint32_t)lane < nb;
+    const uint32_t q = active ? q_pos[qhead + lane] : 0u;
+    const uint32_t jx = active ? q_j[qhead + lane] : 0u;
+    const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
+    // the ML bytes are requested first (up to MKP_KMAX per tag) and converted after the CIGAR mapping, whose latency they overlap
+    uint32_t mlq[NT][MKP_KMAX];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+#pragma unroll
+      for (int i = 0; i < MKP_KMAX; i++) mlq[t][i] = 0;
+      if (t < n_tags) {
+        const uint32_t nc = t_nc[t], base = active ? (t_ml[t] + jx * nc) : 0u;
+#pragma unroll
+        for (int i = 0; i < MKP_KMAX; i++) if ((uint32_t)i < nc) mlq[t][i] = ml[base + (active ? (uint32_t)i : 0u)];
+      }
+    }
+    // reference position through the CIGAR window (aligned pairs: M/=/X only, util.rs:122-145)
+    bool mapped = false; int32_t rpos = 0;
+    {
+      bool pending = active;
+      for (;;) {
+        if (!win_loaded || (__any(pending && q >= wq1) && !__any(pending && q < wq1))) {
+          if (win_loaded) { c0 += 64; wq0 = wq1; wr0 += (int32_t)w_rtot; }
+          if (c0 >= h.n_cigar) break;
+          const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u /*0H*/;
+          w_op = w & 15u; const uint32_t len = w >> 4;
+          const uint32_t qlen = op_consumes_query(w_op) ? len : 0u, rlen = op_consumes_ref(w_op) ? len : 0u;
+          w_qe = wave_incl_scan(qlen); const uint32_t re = wave_incl_scan(rlen);
+          w_dl = (wr0 + (int32_t)(re - rlen)) - (int32_t)(wq0 + w_qe - qlen);   // ref start - query start of the op
+          wq1 = wq0 + (uint32_t)__builtin_amdgcn_readlane((int)w_qe, 63); w_rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
+          win_loaded = true;
+          continue;
+        }
+        const bool ready = pending && q < wq1;
+        const int oi = find_op(w_qe, ready ? q - wq0 : 0u) & 63;
+        const uint32_t my_op = __shfl(w_op, oi, 64);
+        const int32_t my_dl = __shfl(w_dl, oi, 64);
+        if (ready) { mapped = op_is_match(my_op); rpos = (int32_t)q + my_dl; pending = false; }
+        if (!__any(pending)) break;
+      }
+    }
+    F4 pk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (t >= n_tags) break;
+#pragma unroll
+      for (int i = 0; i < MKP_KMAX; i++) {
+        if ((uint32_t)i >= t_nc[t]) break;
+        const float p = ((float)mlq[t][i] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
+        const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
+        setk(pk, kk, true, p);
+      }
+    }
+    if (NT > 1 && n_tags > 1) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
+      float s = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask_all & (1u << k2)) s = s + at(pk, k2);
+      if (active && s > 1.01f) err = true;
+    }
+    uint32_t ev_info = 0; float sv = 0.f; bool has_ev = false;
+    if (active) {
+      const bool edge_keep = !prm.edge_filter ||
+          (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
+      const uint32_t pv = gp0[12 + SH_all];
+      contribH |= SH_all;
+      if (trimmable && edge_keep) {
+        if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
+          bool keep = !prm.only_mapped || mapped;
+          if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
+          if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
+        } else {
+          any_surviving = true;
+          uint32_t ob = 0;
+          const int cls = call_group(grp0, pv, pk, collapse, &ob, kcodes0);
+          const uint32_t tally = aln ^ (uint32_t)sg0;  // read_cache.rs:181-188 / FeatureVector::add_feature
+          if (tally) obs1 |= ob; else obs0 |= ob;
+          if (mapped) {
+            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
+            ev_info = cid | (tally << 8) | ((uint32_t)b0 << 9) | (aln << 11) | (1u << 12);
+            has_ev = true;
+          }
+        }
+      }
+    }
+    // ballot-compacted, position-ordered append of this batch's events
+    const unsigned long long b1 = __ballot(has_ev);
+    const uint32_t step_total = (uint32_t)__popcll(b1);
+    if (step_total) {
+      const uint32_t off = n_ev + (uint32_t)__popcll(b1 & lanemask_lt());
+      if (n_ev + step_total > h.event_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
+      else if (has_ev) {
+        MkpEvent ev; ev.pos = (uint32_t)rpos; ev.info = ev_info; events[h.event_off + off] = ev;
+        if (SAMPLE) sample_vals[h.event_off + off] = sv;
+      }
+      n_ev += step_total;
+    }
+    err = __any(err);
+    qhead += nb;
+  }
+  // a delta list must not run past the last occurrence of its base: every entry must have been consumed (mod_bam.rs:705-727)
+  if (rev ? (t_cur != 0u) : (t_cur != t_n)) err = true;
+  err = __any(err);
+  obs0 = wave_or(obs0); obs1 = wave_or(obs1);
+  any_surviving = __any(any_surviving);
+  // InvalidImplicitMode cannot arise (every tag carries '?'), kept for symmetry with the FAST kernels (read_cache.rs:122-137)
+  if (!prm.force_allow && !SAMPLE) {
+    const uint32_t mc = wave_or(contribH); uint32_t tagbits = 0;
+#pragma unroll
+    for (int mi = 0; mi < MKP_MAX_MEMBERS; mi++) if (mc & (1u << mi)) tagbits |= 1u << ((grp0.member_tags >> (4 * mi)) & 15u);
+    if (tagbits && (tagbits & ~(uint32_t)lay->default_mask) == 0) err = true;
+  }
+  if (lane == 0) {
+    if (!err && any_surviving) { out.ok = 1; out.n_events = n_ev; out.obs[0] = obs0; out.obs[1] = obs1; }
+    readout[rid] = out;
+  }
+}
+
 #define DECODE_PARAMS(PRM) const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
                     const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
                     const MkpLayout* __restrict__ layouts, PRM prm, MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, \
@@ -918,6 +1237,12 @@ template <bool SAMPLE, int NT> __device__ __forceinline__ void decode_fast_entry
   decode_read_fast<SAMPLE, NT>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals,
                                &lds_layouts[0][0], read_ids, &lds_ord[0][0], pdep4, &lds_queue[0][0]);
 }
+template <bool SAMPLE, int NT> __device__ __forceinline__ void decode_sparse_entry(DECODE_PARAMS(const MkpRunParams&)) {
+  __shared__ uint32_t lds_queue[4][2 * MKP_SQCAP];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_flags[4][512];
+  decode_read_sparse<SAMPLE, NT>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], read_ids, &lds_queue[0][0], &lds_flags[0][0]);
+}
 template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECODE_PARAMS(const MkpRunParams&)) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
   __shared__ uint32_t lds_marks[4 * 7][64];   // per wave 448 dwords: ordinal bitmaps [<=8][18] at 0, 512 u16 slots at 192
@@ -932,10 +1257,14 @@ template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECO
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<false>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 1>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast2(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 2>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_sparse1(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 1>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_sparse2(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 2>(DECODE_PASS); }
 // the same walks in threshold-sampling mode (reads_sampler / thresholds.rs:121-159): separate kernels so profiles keep the two apart
 extern "C" __global__ void __launch_bounds__(256) mkp_sample_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<true>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<true, 1>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast2(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<true, 2>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_sample_sparse1(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<true, 1>(DECODE_PASS); }
+extern "C" __global__ void __launch_bounds__(256) mkp_sample_sparse2(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<true, 2>(DECODE_PASS); }
 
 // ----------------------------------------------------------------------------------------------
 struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
@@ -1510,20 +1839,20 @@ mkp_gather_rows(const uint32_t* __restrict__ tile_row_off, const uint32_t* __res
 
 // ----------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
-// read_ids = [FAST one-tag reads | FAST two-tag reads | all other reads], n_class = the three list lengths
+// read_ids = [SPARSE one tag | SPARSE two tags | FAST one tag | FAST two tags | all other reads], n_class = the five list lengths
 extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* read_ids, const uint32_t* n_class, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts,
                                         const MkpRunParams* prm, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err,
                                         const uint8_t* bedmask, float* sample_vals) {
   const uint32_t waves_per_block = 4;
   const uint32_t* ids = read_ids;
-  for (int cls = 0; cls < 3; cls++) {
+  for (int cls = 0; cls < 5; cls++) {
     const uint32_t n = n_class[cls];
     if (n) {
       dim3 grid((n + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
 #define MKP_DECODE_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids)
-      if (prm->sample_mode) { if (cls == 0) MKP_DECODE_LAUNCH(mkp_sample_fast1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_sample_fast2); else MKP_DECODE_LAUNCH(mkp_sample_reads); }
-      else { if (cls == 0) MKP_DECODE_LAUNCH(mkp_decode_fast1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_decode_fast2); else MKP_DECODE_LAUNCH(mkp_decode_reads); }
+      if (prm->sample_mode) { if (cls == 0) MKP_DECODE_LAUNCH(mkp_sample_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_sample_sparse2); else if (cls == 2) MKP_DECODE_LAUNCH(mkp_sample_fast1); else if (cls == 3) MKP_DECODE_LAUNCH(mkp_sample_fast2); else MKP_DECODE_LAUNCH(mkp_sample_reads); }
+      else { if (cls == 0) MKP_DECODE_LAUNCH(mkp_decode_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_decode_sparse2); else if (cls == 2) MKP_DECODE_LAUNCH(mkp_decode_fast1); else if (cls == 3) MKP_DECODE_LAUNCH(mkp_decode_fast2); else MKP_DECODE_LAUNCH(mkp_decode_reads); }
     }
     ids += n;
   }
