@@ -187,7 +187,7 @@ def main():
     else:
         # per-base thresholds from ALL ranks' samples: per-rank histograms of the sampled probabilities, summed over RCCL
         from modkit_amd import distributed as mkd
-        thr = mkd.estimate_thresholds_allreduce(ctx, bam, flags, device=torch.device("cuda", local_rank))
+        thr = mkd.estimate_thresholds_allreduce(ctx, bam, [])   # every rank samples its own BAM in full; histograms summed over RCCL
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
         targv = []
         for i in range(4):

@@ -189,9 +189,26 @@ int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_repo
  * --include-bed --include-unmapped --edge-filter --ignore --preset). thr/has are indexed A,C,G,T. */
 int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float thr[4], uint8_t has[4]);
 
-/* ---- threshold arithmetic: percentile_linear_interp (src/thresholds.rs:17-38) over values the
- * device histogrammed; and the f32 histogram itself for multi-GPU all-reduce. */
+/* ---- threshold arithmetic: percentile_linear_interp (src/thresholds.rs:17-38) on a sorted array */
 int mkp_percentile(const float* sorted, uint64_t n, float q, float* out);
+
+/* ---- the same estimate split for multi-GPU runs: calc_threshold_from_bam (src/thresholds.rs:121-159) sorts the
+ * sampled argmax probabilities of each canonical base and interpolates between two order statistics.  Here the sample stays in
+ * HBM and is summarised by two-level histograms of the values' f32 bit patterns (positive floats order like unsigned integers):
+ * level 0 counts the top 16 bits, level 1 the low 16 bits of the values whose top 16 bits equal `prefix`.  Histograms add, so
+ * W ranks that each sampled their own reference windows sum them (ncclAllReduce(sum, u64) over xGMI — the path's one
+ * collective) and every rank finds the exact order statistics of the union.  Sequence per rank:
+ *   mkp_histogram_begin; mkp_histogram_add_bam(..., "--gpus-rank R --gpus-world W -f 1.0 ...");
+ *   per base: get(level 0) -> all-reduce -> mkp_histogram_locate -> get(level 1, bins) -> all-reduce -> mkp_histogram_resolve
+ *             -> mkp_percentile_from_histogram.                 (mkp_estimate_thresholds does all of it for one rank.)
+ * Histogram arrays are uint64_t[65536]. */
+int mkp_histogram_begin(mkp_ctx* ctx);
+int mkp_histogram_add_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv);
+int mkp_histogram_get(mkp_ctx* ctx, uint32_t base /*A,C,G,T = 0..3*/, uint32_t level, uint32_t prefix, uint64_t* out);
+int mkp_histogram_from_values(const float* vals, uint64_t n, uint32_t level, uint32_t prefix, uint64_t* out);  /* host values, no device */
+int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint64_t ranks_in_bin[2], uint64_t* n);
+int mkp_histogram_resolve(uint32_t prefix, const uint64_t* hist1, uint64_t rank_in_bin, float* value);
+int mkp_percentile_from_histogram(uint64_t n, float q, float y_floor, float y_ceil, float* out);
 
 /* ---- host-side pieces exposed for tests (no device needed):
  * mkp_host_mm_ranks: the packer's MM tokeniser (MmTagInfo::parse, src/mod_bam.rs:909-1000) on one MM string: for every tag its

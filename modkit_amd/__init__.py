@@ -57,13 +57,23 @@ def lib():
         L.mkp_shard_rerun.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         L.mkp_get_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+        u64p, f32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)
+        L.mkp_histogram_begin.argtypes = [ctypes.c_void_p]
+        L.mkp_histogram_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+        L.mkp_histogram_get.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p]
+        L.mkp_histogram_from_values.argtypes = [f32p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, u64p]
+        L.mkp_histogram_locate.argtypes = [u64p, ctypes.c_float, ctypes.POINTER(ctypes.c_uint32), u64p, u64p]
+        L.mkp_histogram_resolve.argtypes = [ctypes.c_uint32, u64p, ctypes.c_uint64, f32p]
+        L.mkp_percentile_from_histogram.argtypes = [ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float, f32p]
         _lib = L
     return _lib
 
 
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
-           "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order"]
+           "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
+           "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
+           "mkp_histogram_resolve", "mkp_percentile_from_histogram"]
 
 
 def pileup(argv):
@@ -180,6 +190,23 @@ class Context:
         has = (ctypes.c_uint8 * 4)()
         self._check(self.L.mkp_estimate_thresholds(self.h, str(bam).encode(), len(args), arr, thr, has))
         return {"ACGT"[i]: float(thr[i]) for i in range(4) if has[i]}
+
+    def histogram_begin(self):
+        self._check(self.L.mkp_histogram_begin(self.h))
+
+    def histogram_add_bam(self, bam, argv=()):
+        """Sample this rank's windows of `bam` (argv: sampling flags, --gpus-rank/--gpus-world) into the HBM-resident sample."""
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * max(1, len(args)))(*args)
+        self._check(self.L.mkp_histogram_add_bam(self.h, str(bam).encode(), len(args), arr))
+
+    def histogram_get(self, base, level, prefix=0):
+        """uint64[65536] numpy array: level 0 = top 16 bits of the f32 patterns of `base`'s sample, level 1 = low 16 bits under `prefix`."""
+        import numpy as np
+        out = np.zeros(65536, dtype=np.uint64)
+        i = "ACGT".index(base) if isinstance(base, str) else int(base)
+        self._check(self.L.mkp_histogram_get(self.h, i, level, prefix, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out
 
     def process_region(self, bam, tid, start, end):
         sh = Shard(tid=tid, start=start, end=end, focus=None, combos=None, n_combos=0)

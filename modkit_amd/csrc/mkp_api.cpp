@@ -303,7 +303,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -390,9 +390,9 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
 int mkp_get_stats(const mkp_ctx* c, mkp_stats* out) { if (!c || !out) return MKP_E_INVALID; *out = c->stats; return MKP_OK; }
 
 int mkp_percentile(const float* xs, uint64_t n, float q, float* out) {  // percentile_linear_interp (thresholds.rs:17-38)
-  if (!xs || !out || n < 2 || q > 1.0f) return MKP_E_THRESHOLD;
+  if (!xs || !out || n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;   // negative / NaN quantiles would index out of bounds (Rust's `as usize` saturates; here they are refused)
   if (q == 1.0f) { *out = xs[n - 1]; return MKP_OK; }
-  float l = (float)(n - 1), lq = l * q, left = floorf(lq); uint64_t right = (uint64_t)ceilf(lq);
+  float l = (float)(n - 1), lq = l * q, left = floorf(lq); uint64_t right = std::min<uint64_t>((uint64_t)ceilf(lq), n - 1);
   float g = lq - truncf(lq), a = xs[(uint64_t)left] * (1.0f - g), b = xs[right] * g;
   *out = a + b;
   return MKP_OK;
@@ -431,11 +431,19 @@ int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_o
 
 }  // extern "C"
 
+// ---- threshold sampling on the device (decode kernels in sampling mode; the values stay in HBM)
+extern "C" {
+hipError_t mkp_launch_sample_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const float*, const MkpEvent*, uint32_t*, unsigned long long, unsigned long long*, uint32_t*, uint32_t*);
+hipError_t mkp_launch_sample_hist1(hipStream_t, const uint32_t*, unsigned long long, uint32_t, uint32_t, uint32_t*);
+}
+
+// Decode `recs` in sampling mode.  n_vals[i] = number of argmax probabilities record i yields after the filters (0: rejected or
+// nothing kept).  The values themselves stay on the device until mkp_internal_sample_take says which reads the schedule took.
 int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,
-                        uint32_t n, bool only_mapped, mkp::SampleOut* out) {
-  if (!c || !out) return MKP_E_INVALID;
+                        uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals) {
+  if (!c || !n_vals) return MKP_E_INVALID;
   return guarded(c, [&]() {
-    ShardHost S; S.tid = tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end;
+    ShardHost& S = c->sample_shard; S.clear(); S.tid = tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end;
     pack_records(c->packer, S, recs, n, [](const mkp_record&) { return true; });
     c->tables.build(c->packer.layouts, c->caller);
     MkpRunParams P; memset(&P, 0, sizeof(P));
@@ -452,23 +460,119 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
                                 c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), c->d_vals.as<float>()), "decode(sample) launch");
+    uint32_t h[4]; hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+    c->sample_ro.resize(S.hdr.size());
+    if (!S.hdr.empty()) hip_check(hipMemcpyAsync(c->sample_ro.data(), c->d_readout.p, S.hdr.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost, c->stream), "D2H");
     hip_check(hipStreamSynchronize(c->stream), "sample sync");
-    uint32_t h[4]; hip_check(hipMemcpy(h, misc, 16, hipMemcpyDeviceToHost), "D2H");
     if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
-    std::vector<MkpReadOut> ro(S.hdr.size()); std::vector<MkpEvent> ev(S.n_events_cap); std::vector<float> vals(S.n_events_cap);
-    if (!ro.empty()) hip_check(hipMemcpy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost), "D2H");
-    if (!ev.empty()) { hip_check(hipMemcpy(ev.data(), c->d_events.p, ev.size() * sizeof(MkpEvent), hipMemcpyDeviceToHost), "D2H"); hip_check(hipMemcpy(vals.data(), c->d_vals.p, vals.size() * 4, hipMemcpyDeviceToHost), "D2H"); }
-    out->ok.clear(); out->n.clear(); out->off.clear(); out->vals.clear(); out->base.clear();
-    size_t total = 0; for (size_t i = 0; i < S.hdr.size(); i++) if (ro[i].ok) total += ro[i].n_events;
-    out->vals.reserve(total); out->base.reserve(total);
-    for (size_t i = 0; i < S.hdr.size(); i++) {
-      out->ok.push_back(ro[i].ok); out->n.push_back(ro[i].ok ? ro[i].n_events : 0); out->off.push_back((uint32_t)out->vals.size());
-      if (ro[i].ok && ro[i].n_events) {
-        const size_t e0 = S.hdr[i].event_off;
-        out->vals.insert(out->vals.end(), vals.begin() + (std::ptrdiff_t)e0, vals.begin() + (std::ptrdiff_t)(e0 + ro[i].n_events));
-        for (uint32_t k = 0; k < ro[i].n_events; k++) out->base.push_back((uint8_t)ev[e0 + k].info);
-      }
-    }
+    if (S.hdr.size() != n) throw Error(MKP_E_INVALID, "internal: sampler packed a different number of records");
+    n_vals->resize(n);
+    for (uint32_t i = 0; i < n; i++) (*n_vals)[i] = c->sample_ro[i].ok ? c->sample_ro[i].n_events : 0u;
     c->resident = false;
   });
 }
+
+// Add the values of the marked records of the last mkp_internal_sample batch to the resident sample and its level-0 histogram.
+int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
+  if (!c) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    const size_t n = c->sample_shard.hdr.size();
+    if (take.size() != n) throw Error(MKP_E_INVALID, "internal: take mask size");
+    uint64_t add = 0; for (size_t i = 0; i < n; i++) if (take[i] && c->sample_ro[i].ok) add += c->sample_ro[i].n_events;
+    if (!add) return;
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    if (!c->d_hist0.p) { c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16); hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset"); hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
+    const uint64_t need = c->sample_n + add;
+    if (need * 4 > c->d_store.cap) {   // grow the resident sample, keeping what is there
+      DevBuf nb; nb.ensure(std::max<uint64_t>(need * 4 * 2, 1u << 20));
+      if (c->sample_n) hip_check(hipMemcpyAsync(nb.p, c->d_store.p, c->sample_n * 4, hipMemcpyDeviceToDevice, c->stream), "D2D");
+      hip_check(hipStreamSynchronize(c->stream), "sync"); c->d_store.release(); c->d_store = nb; nb.p = nullptr; nb.cap = 0;
+    }
+    c->d_take.ensure(std::max<size_t>(n, 16));
+    hip_check(hipMemcpyAsync(c->d_take.p, take.data(), n, hipMemcpyHostToDevice, c->stream), "H2D");
+    uint32_t* misc = c->d_misc.as<uint32_t>();
+    hip_check(mkp_launch_sample_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n, c->d_vals.as<float>(), c->d_events.as<MkpEvent>(),
+                                           c->d_store.as<uint32_t>(), c->d_store.cap / 4, c->d_sample_cursor.as<unsigned long long>(), c->d_hist0.as<uint32_t>(), misc + 2), "sample accumulate launch");
+    hip_check(hipStreamSynchronize(c->stream), "sample accumulate sync");
+    c->sample_n = need;
+  });
+}
+
+namespace {
+void require_sample(mkp_ctx* c) { if (!c->d_hist0.p) { hip_check(hipSetDevice(c->device), "hipSetDevice"); c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16); hip_check(hipMemset(c->d_hist0.p, 0, 4 * 65536 * 4), "memset"); hip_check(hipMemset(c->d_sample_cursor.p, 0, 16), "memset"); } }
+}
+
+extern "C" {
+
+int mkp_histogram_begin(mkp_ctx* c) {
+  if (!c) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    require_sample(c);
+    hip_check(hipMemset(c->d_hist0.p, 0, 4 * 65536 * 4), "memset"); hip_check(hipMemset(c->d_sample_cursor.p, 0, 16), "memset");
+    c->sample_n = 0;
+  });
+}
+
+int mkp_histogram_get(mkp_ctx* c, uint32_t base, uint32_t level, uint32_t prefix, uint64_t* out) {
+  if (!c || !out || base > 3 || level > 1 || prefix > 0xffffu) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    require_sample(c);
+    std::vector<uint32_t> h(65536);
+    if (level == 0) hip_check(hipMemcpy(h.data(), c->d_hist0.as<uint32_t>() + (size_t)base * 65536, 65536 * 4, hipMemcpyDeviceToHost), "D2H");
+    else {
+      hip_check(hipMemsetAsync(c->d_hist1.p, 0, 65536 * 4, c->stream), "memset");
+      hip_check(mkp_launch_sample_hist1(c->stream, c->d_store.as<uint32_t>(), c->sample_n, base, prefix, c->d_hist1.as<uint32_t>()), "hist1 launch");
+      hip_check(hipMemcpyAsync(h.data(), c->d_hist1.p, 65536 * 4, hipMemcpyDeviceToHost, c->stream), "D2H");
+      hip_check(hipStreamSynchronize(c->stream), "hist1 sync");
+    }
+    for (size_t i = 0; i < 65536; i++) out[i] = h[i];
+  });
+}
+
+// the same histograms over values the caller holds on the host (tests, and callers that sample elsewhere)
+int mkp_histogram_from_values(const float* vals, uint64_t n, uint32_t level, uint32_t prefix, uint64_t* out) {
+  if ((!vals && n) || !out || level > 1 || prefix > 0xffffu) return MKP_E_INVALID;
+  memset(out, 0, 65536 * sizeof(uint64_t));
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t b; memcpy(&b, &vals[i], 4);
+    if (b >> 30) return MKP_E_INVALID;   // probabilities are in [0, 2)
+    if (level == 0) out[b >> 16]++; else if ((b >> 16) == prefix) out[b & 0xffffu]++;
+  }
+  return MKP_OK;
+}
+
+// percentile_linear_interp (thresholds.rs:17-38) needs xs[floor((n-1)q)] and xs[ceil((n-1)q)] of the sorted sample: which
+// level-0 bins hold them, and at which rank inside the bin
+int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint64_t ranks_in_bin[2], uint64_t* n_out) {
+  if (!hist0 || !bins || !ranks_in_bin) return MKP_E_INVALID;
+  uint64_t n = 0; for (size_t i = 0; i < 65536; i++) n += hist0[i];
+  if (n_out) *n_out = n;
+  if (n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;
+  uint64_t want[2];
+  if (q == 1.0f) want[0] = want[1] = n - 1;
+  else { const float l = (float)(n - 1), lq = l * q; want[0] = (uint64_t)floorf(lq); want[1] = (uint64_t)ceilf(lq); if (want[1] > n - 1) want[1] = n - 1; if (want[0] > n - 1) want[0] = n - 1; }
+  for (int k = 0; k < 2; k++) {
+    uint64_t cum = 0; bool found = false;
+    for (uint32_t b = 0; b < 65536 && !found; b++) { if (want[k] < cum + hist0[b]) { bins[k] = b; ranks_in_bin[k] = want[k] - cum; found = true; } cum += hist0[b]; }
+    if (!found) return MKP_E_THRESHOLD;
+  }
+  return MKP_OK;
+}
+
+int mkp_histogram_resolve(uint32_t prefix, const uint64_t* hist1, uint64_t rank_in_bin, float* value) {
+  if (!hist1 || !value || prefix > 0xffffu) return MKP_E_INVALID;
+  uint64_t cum = 0;
+  for (uint32_t b = 0; b < 65536; b++) { if (rank_in_bin < cum + hist1[b]) { const uint32_t bits = (prefix << 16) | b; memcpy(value, &bits, 4); return MKP_OK; } cum += hist1[b]; }
+  return MKP_E_THRESHOLD;
+}
+
+// the interpolation itself, on the two order statistics: y0 * (1 - g) + y1 * g with g = fract((n-1) q), in f32 as the reference does
+int mkp_percentile_from_histogram(uint64_t n, float q, float y0, float y1, float* out) {
+  if (!out || n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;
+  if (q == 1.0f) { *out = y1; return MKP_OK; }
+  const float l = (float)(n - 1), lq = l * q, g = lq - truncf(lq);
+  *out = y0 * (1.0f - g) + y1 * g;
+  return MKP_OK;
+}
+
+}  // extern "C"

@@ -30,9 +30,6 @@ inline void hip_check(hipError_t e, const char* what) {
 inline double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 
 
-struct SampleOut {  // one entry per packed read, in input order
-  std::vector<uint32_t> ok, n, off; std::vector<float> vals; std::vector<uint8_t> base;
-};
 }  // namespace mkp
 
 struct mkp_ctx {
@@ -44,6 +41,9 @@ struct mkp_ctx {
   mkp::DevBuf d_hdr, d_vals, d_cigar, d_seq, d_tagref, d_ranks, d_ml, d_layouts, d_events, d_readout, d_focus, d_combos, d_tiles, d_slotbm,
       d_tile_row_off, d_tile_row_cnt, d_tile_dst, d_misc, d_rows_src, d_rows_dst, d_prm, d_read_ids, d_chunk;
   uint32_t n_class[5] = {0, 0, 0, 0, 0};
+  // threshold sample, resident in HBM: keys = base << 30 | f32 bit pattern of an argmax probability; level-0 histogram per base
+  mkp::ShardHost sample_shard; std::vector<MkpReadOut> sample_ro; uint64_t sample_n = 0;
+  mkp::DevBuf d_store, d_hist0, d_hist1, d_sample_cursor, d_take;
   MkpRowsDev rows_src, rows_dst;
   std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif;
   uint64_t n_ok = 0, n_bad = 0;
@@ -53,4 +53,5 @@ struct mkp_ctx {
 
 // threshold sampling pass on the device (decode kernel in sample mode); `recs` need not pass Packer::keep
 int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,
-                        uint32_t n, bool only_mapped, mkp::SampleOut* out);
+                        uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals);
+int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take);

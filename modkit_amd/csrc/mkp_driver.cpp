@@ -81,8 +81,13 @@ struct Quota { bool all = false; size_t n = 0; };
 
 // Default threshold estimation: the reference's deterministic "first N qualifying reads per interval" schedule
 // (reads_sampler/mod.rs:30-257, sampling_schedule.rs:171-615); the per-call probabilities come from the decode kernel.
-std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
+// The values are accumulated in the context's HBM-resident sample (mkp_internal_sample_take); nothing but per-read counts
+// comes back to the host.  With --gpus-world W > 1 (full-data mode `-f 1.0` only) a rank walks just its own sampling intervals:
+// a read is taken in the first processed interval it overlaps, so the union over ranks is the single-rank sample.
+void sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
   const bool only_mapped = !a.include_unmapped;
+  const bool sharded = a.world > 1;
+  if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED, "rank-sharded threshold sampling needs the full-data mode (-f 1.0): the count-based schedule carries quotas from interval to interval");
   IdxStats st = idxstats(bam, region, bf);
   const uint64_t total_u = only_mapped ? st.mapped : st.mapped + st.unmapped;
   if (total_u == 0) throw Error(MKP_E_THRESHOLD, "zero reads found in bam index");
@@ -105,7 +110,8 @@ std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamDa
   const size_t batch_size = (size_t)floorf((float)a.threads * 1.5f);
   std::vector<Contig> contigs; for (auto& c : targets(bam, region)) if (quota.count(c.tid)) contigs.push_back(c);
   std::map<uint32_t, uint32_t> contig_size; for (auto& c : contigs) contig_size[c.tid] = c.length;
-  std::map<int, std::vector<float>> per_base; std::set<std::string> taken; std::map<uint32_t, size_t> sampled_so_far;
+  std::map<uint32_t, uint64_t> contig_base, contig_start; uint64_t grid_bp = 0; for (auto& c : contigs) { contig_base[c.tid] = grid_bp; contig_start[c.tid] = c.start; grid_bp += c.length; }
+  std::set<std::string> taken; std::map<uint32_t, size_t> sampled_so_far;
   std::map<uint32_t, std::vector<uint8_t>> bedmasks;
   auto bedmask_for = [&](uint32_t tid) -> const uint8_t* {
     if (!bf) return nullptr;
@@ -117,32 +123,33 @@ std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamDa
   };
   auto qname = [&](const BamIndexEntry& e) { const uint8_t* c = &bam.raw[e.off]; return std::string((const char*)c + 32, c[8] ? (size_t)c[8] - 1 : 0); };
   // process_records (read_ids_to_base_mod_probs.rs:223-362) over the candidate records, first-N semantics
-  auto take = [&](const std::vector<size_t>& cand, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen) -> size_t {
+  // `skip` (rank-sharded mode): candidates an earlier interval already took
+  auto take = [&](const std::vector<size_t>& cand, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen, const std::vector<uint8_t>* skip = nullptr) -> size_t {
     size_t used = 0, next = 0, n_reads_out = 0;
     while (next < cand.size() && (limit < 0 || used < (size_t)limit)) {
-      size_t want = limit < 0 ? cand.size() - next : std::max<size_t>(256, 2 * ((size_t)limit - used));
+      size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - used));
       size_t hi = std::min(cand.size(), next + want);
       std::vector<mkp_record> recs; for (size_t i = next; i < hi; i++) recs.push_back(bam.view(bam.recs[cand[i]]));
-      SampleOut so; uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1;
-      int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(), only_mapped, &so);
+      std::vector<uint32_t> nv; uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1;
+      int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(), only_mapped, &nv);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+      std::vector<uint8_t> mask(recs.size(), 0);
       for (size_t i = next; i < hi; i++) {
         if (limit >= 0 && used >= (size_t)limit) break;   // RecordSampler::ask -> Done
         const size_t k = i - next;
-        if (!so.ok[k] && so.n[k] == 0) { /* tag error or nothing kept */ }
+        if (skip && (*skip)[i]) continue;
         std::string name = qname(bam.recs[cand[i]]);
         // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
         // but keeps no position is asked, not counted, and not recorded
         if (interval_seen->count(name)) continue;
-        if (so.n[k] == 0) continue;
+        if (nv[k] == 0) continue;
         interval_seen->insert(name); used++; n_reads_out++;
         if (taken.count(name)) continue;  // Moniod::op_mut keeps the first occurrence of a read id
         taken.insert(name);
-        {  // one map lookup per run of equal bases, not per value
-          const uint8_t* bs = &so.base[so.off[k]]; const float* vs = &so.vals[so.off[k]];
-          for (uint32_t j = 0; j < so.n[k];) { uint32_t e = j + 1; while (e < so.n[k] && bs[e] == bs[j]) e++; std::vector<float>& dst = per_base[bs[j]]; dst.insert(dst.end(), vs + j, vs + e); j = e; }
-        }
+        mask[k] = 1;
       }
+      rc = mkp_internal_sample_take(ctx, mask);
+      if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       next = hi;
     }
     return n_reads_out;
@@ -182,14 +189,31 @@ std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamDa
       std::map<uint32_t, size_t> batch_counts;
       for (auto& g : grouped) {  // run_batch (reads_sampler/mod.rs:259-338)
         if (bf && !bf->overlaps(g.iv.tid, g.iv.start, g.iv.end)) continue;
+        std::vector<uint8_t> skip;
+        if (sharded) {
+          // owner of the interval: contiguous runs of the sampling grid by base pairs (as the pileup shards are dealt)
+          const uint64_t mid = contig_base[g.iv.tid] + (g.iv.start - contig_start[g.iv.tid]) + (g.iv.end - g.iv.start) / 2;
+          if (std::min<uint64_t>(a.world - 1, mid * a.world / std::max<uint64_t>(grid_bp, 1)) != a.rank) continue;
+        }
         std::vector<size_t> ov, cand; fetch(bam, g.iv.tid, g.iv.start, g.iv.end, &ov); candidates(ov, &cand);
+        if (sharded) {   // a read that reaches back into an earlier processed interval of this contig was taken there
+          skip.assign(cand.size(), 0);
+          for (size_t i = 0; i < cand.size(); i++) {
+            const BamIndexEntry& e = bam.recs[cand[i]];
+            for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && (int64_t)e.pos < s1;) {   // grid intervals before this one, nearest first
+              const int64_t s0 = std::max<int64_t>((int64_t)contig_start[g.iv.tid], s1 - (int64_t)a.sampling_interval_size);
+              if (!bf || bf->overlaps(g.iv.tid, (uint64_t)s0, (uint64_t)s1)) { skip[i] = 1; break; }
+              s1 = s0;
+            }
+          }
+        }
         std::set<std::string> seen;
-        batch_counts[g.iv.tid] += take(cand, g.q.all ? -1 : (long)g.q.n, g.iv.tid, true, &seen);
+        batch_counts[g.iv.tid] += take(cand, g.q.all ? -1 : (long)g.q.n, g.iv.tid, true, &seen, sharded ? &skip : nullptr);
       }
       for (auto& kv : batch_counts) sampled_so_far[kv.first] += kv.second;
     }
   }
-  if ((sched_unmapped || taken.size() < 100) && !only_mapped) {  // reads_sampler/mod.rs:89-125
+  if ((sched_unmapped || taken.size() < 100) && !only_mapped && a.rank == 0) {  // reads_sampler/mod.rs:89-125 (rank-sharded: rank 0 takes the unmapped reads)
     std::vector<size_t> un, cand; for (size_t i = 0; i < bam.recs.size(); i++) if (bam.recs[i].tid < 0) un.push_back(i);
     candidates(un, &cand);
     long limit;
@@ -198,23 +222,28 @@ std::map<int, std::vector<float>> sample_probabilities(mkp_ctx* ctx, const BamDa
     else { if (!cand.empty()) throw Error(MKP_E_UNSUPPORTED, "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible"); limit = -1; }
     std::set<std::string> seen; take(cand, limit, 0, false, &seen);
   }
-  return per_base;
 }
 
-// percentile_linear_interp (thresholds.rs:17-38) needs two order statistics of the sample, not the sorted sample: select
-// them (O(n)) and let mkp_percentile do the f32 interpolation on a 2-element view with the same fractional rank.
-int percentile_select(std::vector<float>& xs, float q, float* out) {
-  const uint64_t n = xs.size();
-  if (n < 2 || q > 1.0f) return MKP_E_THRESHOLD;
-  if (q == 1.0f) { *out = *std::max_element(xs.begin(), xs.end()); return MKP_OK; }
-  const float lq = (float)(n - 1) * q;
-  const uint64_t left = (uint64_t)floorf(lq), right = (uint64_t)ceilf(lq);
-  std::nth_element(xs.begin(), xs.begin() + (std::ptrdiff_t)left, xs.end());
-  float two[2] = {xs[left], xs[left]};
-  if (right != left) two[1] = *std::min_element(xs.begin() + (std::ptrdiff_t)left + 1, xs.end());
-  const float g = lq - truncf(lq);
-  if (right == left) { *out = two[0] * (1.0f - g) + two[0] * g; return MKP_OK; }   // g == 0 here: same expression as the reference
-  return mkp_percentile(two, 2, g, out);   // l = 1, l*q = g: xs[0]*(1-g) + xs[1]*g
+// per-base pass thresholds from the context's resident sample: two-level histogram -> the two order statistics -> interpolation
+void thresholds_from_sample(mkp_ctx* ctx, float q, float thr[4], uint8_t has[4], bool verbose) {
+  std::vector<uint64_t> h0(65536), h1(65536);
+  for (uint32_t b = 0; b < 4; b++) {
+    thr[b] = 0.f; has[b] = 0;
+    int rc = mkp_histogram_get(ctx, b, 0, 0, h0.data()); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+    uint32_t bins[2]; uint64_t rk[2], n = 0;
+    rc = mkp_histogram_locate(h0.data(), q, bins, rk, &n);
+    if (n == 0) continue;   // no calls on this base
+    if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(n));
+    float y[2];
+    for (int k = 0; k < 2; k++) {
+      if (k == 1 && bins[1] == bins[0] && rk[1] == rk[0]) { y[1] = y[0]; break; }
+      if (k == 0 || bins[1] != bins[0]) { rc = mkp_histogram_get(ctx, b, 1, bins[k], h1.data()); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx)); }
+      rc = mkp_histogram_resolve(bins[k], h1.data(), rk[k], &y[k]); if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "internal: histogram levels disagree");
+    }
+    float t; rc = mkp_percentile_from_histogram(n, q, y[0], y[1], &t); if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(n));
+    thr[b] = t; has[b] = 1;
+    if (verbose) fprintf(stderr, "[mkpileup] threshold %c %.9g (n=%llu)\n", "ACGT"[b], (double)t, (unsigned long long)n);
+  }
 }
 
 void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) {  // parse_per_base_thresholds (command_utils.rs:136-206)
@@ -287,13 +316,12 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     auto t0 = std::chrono::steady_clock::now();
     must(mkp_set_caller(ctx, &kc));  // collapse + edge filter apply to the sampled probabilities too
     const RegionSpec* sr = have_sregion ? &sregion : (have_region ? &region : nullptr);
-    auto per_base = sample_probabilities(ctx, bam, a, sr, bf);
-    for (auto& kv : per_base) {
-      float t;
-      if (percentile_select(kv.second, a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size()));
-      kc.has_per_base[kv.first] = 1; kc.per_base_threshold[kv.first] = t;
-      if (a.stats) fprintf(stderr, "[mkpileup] threshold %c %.9g (n=%zu)\n", "ACGT"[kv.first], (double)t, kv.second.size());
-    }
+    // a rank of a multi-GPU run that was not handed thresholds (--filter-threshold from the all-reduced histograms, see
+    // modkit_amd.distributed) estimates them alone over the whole file: correct, but every rank repeats the work
+    Args as = a; as.world = 1; as.rank = 0;
+    must(mkp_histogram_begin(ctx));
+    sample_probabilities(ctx, bam, as, sr, bf);
+    { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; } }
     thr_ms = ms_since(t0);
   }
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
@@ -417,27 +445,49 @@ extern "C" int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, m
 // get_threshold_from_options (command_utils.rs:74-134) as a call: per-base pass thresholds from the
 // reference's sampling schedule; argv takes the sampling flags of `modkit pileup`
 // (-n -f -p -t --sampling-interval-size --region --sample-region --include-bed --include-unmapped --edge-filter --ignore --preset).
+namespace {
+// the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
+void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out) {
+  Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
+  BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
+  RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
+  if (hr) region = parse_region(a.region, bam);
+  if (hs) sregion = parse_region(a.sample_region, bam);
+  if (!(a.filter_percentile >= 0.0f) || a.filter_percentile > 1.0f) throw Error(MKP_E_INVALID, "filter percentile must be in [0, 1]");
+  mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
+  if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(','); if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); }
+  if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; }
+  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+  std::vector<Contig> records = targets(bam, hr ? &region : nullptr);
+  BedFilter bed_store; const BedFilter* bf = nullptr;
+  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
+  int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+  sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
+  if (q_out) *q_out = a.filter_percentile;
+}
+}  // namespace
+
+// get_threshold_from_options (command_utils.rs:74-134) as a call: per-base pass thresholds from the
+// reference's sampling schedule; argv takes the sampling flags of `modkit pileup`
+// (-n -f -p -t --sampling-interval-size --region --sample-region --include-bed --include-unmapped --edge-filter --ignore --preset).
 extern "C" int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float thr[4], uint8_t has[4]) {
   if (!ctx || !bam_path || !thr || !has) return MKP_E_INVALID;
   try {
-    Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
-    BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
-    RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
-    if (hr) region = parse_region(a.region, bam);
-    if (hs) sregion = parse_region(a.sample_region, bam);
-    mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
-    if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(','); if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); }
-    if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; }
-    else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
-    std::vector<Contig> records = targets(bam, hr ? &region : nullptr);
-    BedFilter bed_store; const BedFilter* bf = nullptr;
-    if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
-    int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) return rc;
-    auto per_base = sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
-    for (int b = 0; b < 4; b++) { thr[b] = 0.f; has[b] = 0; }
-    for (auto& kv : per_base) { float t; if (percentile_select(kv.second, a.filter_percentile, &t) != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(kv.second.size())); thr[kv.first] = t; has[kv.first] = 1; }
+    int rc = mkp_histogram_begin(ctx); if (rc != MKP_OK) return rc;
+    float q = 0.1f; sample_bam(ctx, bam_path, argc, argv, &q);
+    thresholds_from_sample(ctx, q, thr, has, false);
     return MKP_OK;
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
+}
+
+// The sampling half alone, for multi-GPU runs: add this rank's share of the sample (argv carries --gpus-rank R --gpus-world W
+// next to the sampling flags; W > 1 needs -f 1.0) to the context's histograms.  The caller then sums mkp_histogram_get's arrays
+// over the ranks (RCCL all-reduce) and finishes with mkp_histogram_locate / _resolve / mkp_percentile_from_histogram.
+extern "C" int mkp_histogram_add_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv) {
+  if (!ctx || !bam_path) return MKP_E_INVALID;
+  try { sample_bam(ctx, bam_path, argc, argv, nullptr); return MKP_OK; }
+  catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
 }
 

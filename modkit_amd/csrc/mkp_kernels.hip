@@ -21,6 +21,9 @@
 // with contraction off (-ffp-contract=off) and IEEE division.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "mkp_device.h"
 
 #define ERR_EVENT_CAP 1u
@@ -1835,6 +1838,74 @@ mkp_gather_rows(const uint32_t* __restrict__ tile_row_off, const uint32_t* __res
       dst.n_diff[d0 + k] = src.n_diff[so + k]; dst.n_nocall[d0 + k] = src.n_nocall[so + k];
     }
   }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Threshold estimation (thresholds.rs:121-159) without shipping the sample to the host: the argmax probabilities the
+// mkp_sample_* kernels wrote stay in HBM.  The f32 bit pattern of a probability is its sort key (positive floats order like
+// unsigned integers); patterns are below 2^30, so the canonical base of a value rides in the top two bits.
+//   mkp_sample_accumulate  for the reads the host's sampling schedule took: append {base, pattern} keys to the resident sample
+//                          and count the top 16 bits of every pattern per base (level-0 histogram: LDS-privatised window of the
+//                          patterns probabilities actually have, global atomics for the rest)
+//   mkp_sample_hist1       level-1 histogram: the low 16 bits of the keys of one base whose top 16 bits equal `prefix`
+// Two levels give the exact order statistics percentile_linear_interp needs (a 2 x 16 bit radix select); both histograms are
+// plain integer arrays that add across GPUs (the path's one collective).
+#define MKP_HIST_LO 0x3800u     // top-16 patterns [0x3800, 0x4000) = values in [2^-15, 2) are counted in LDS
+#define MKP_HIST_LDS 2048u
+extern "C" __global__ void __launch_bounds__(256)
+mkp_sample_accumulate(const MkpReadHdr* __restrict__ hdrs, const MkpReadOut* __restrict__ readout, const uint8_t* __restrict__ take, uint32_t n_reads,
+                      const float* __restrict__ vals, const MkpEvent* __restrict__ events, uint32_t* __restrict__ store, unsigned long long store_cap,
+                      unsigned long long* __restrict__ store_cursor, uint32_t* __restrict__ hist0, uint32_t* __restrict__ dev_err) {
+  __shared__ uint32_t lh[4][MKP_HIST_LDS];
+  for (uint32_t k = threadIdx.x; k < 4u * MKP_HIST_LDS; k += 256) (&lh[0][0])[k] = 0;
+  __syncthreads();
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  for (uint32_t r = wave; r < n_reads; r += n_waves) {
+    if (!take[r]) continue;
+    const MkpReadOut ro = readout[r];
+    if (!ro.ok || !ro.n_events) continue;
+    const uint32_t e0 = hdrs[r].event_off;
+    for (uint32_t k0 = 0; k0 < ro.n_events; k0 += 64) {
+      const uint32_t k = k0 + (uint32_t)lane;
+      const bool v = k < ro.n_events;
+      uint32_t key = 0;
+      if (v) { const uint32_t bits = __float_as_uint(vals[e0 + k]), base = events[e0 + k].info & 3u; key = (base << 30) | (bits & 0x3fffffffu);
+               const uint32_t top = (bits >> 16) & 0x3fffu;
+               if (top - MKP_HIST_LO < MKP_HIST_LDS) atomicAdd(&lh[base][top - MKP_HIST_LO], 1u); else atomicAdd(&hist0[base * 65536u + top], 1u); }
+      const unsigned long long b = __ballot(v);
+      unsigned long long at = 0;
+      if (lane == 0) at = atomicAdd(store_cursor, (unsigned long long)__popcll(b));
+      at = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at);
+      const unsigned long long idx = at + (unsigned long long)__popcll(b & lanemask_lt());
+      if (v) { if (idx < store_cap) store[idx] = key; else atomicOr(dev_err, ERR_EVENT_CAP); }
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < 4u * MKP_HIST_LDS; k += 256) { const uint32_t c = (&lh[0][0])[k]; if (c) atomicAdd(&hist0[(k / MKP_HIST_LDS) * 65536u + MKP_HIST_LO + (k % MKP_HIST_LDS)], c); }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mkp_sample_hist1(const uint32_t* __restrict__ store, unsigned long long n, uint32_t base, uint32_t prefix, uint32_t* __restrict__ hist1) {
+  const uint32_t want = (base << 14) | (prefix & 0x3fffu);   // key >> 16
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256u) {
+    const uint32_t key = store[i];
+    if ((key >> 16) == want) atomicAdd(&hist1[key & 0xffffu], 1u);
+  }
+}
+
+extern "C" hipError_t mkp_launch_sample_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take, uint32_t n_reads, const float* vals,
+                                                   const MkpEvent* events, uint32_t* store, unsigned long long store_cap, unsigned long long* store_cursor, uint32_t* hist0, uint32_t* dev_err) {
+  if (!n_reads) return hipSuccess;
+  const uint32_t grid = std::min<uint32_t>((n_reads + 3u) / 4u, 1024u);
+  hipLaunchKernelGGL(mkp_sample_accumulate, dim3(grid), dim3(256), 0, st, hdrs, readout, take, n_reads, vals, events, store, store_cap, store_cursor, hist0, dev_err);
+  return hipGetLastError();
+}
+extern "C" hipError_t mkp_launch_sample_hist1(hipStream_t st, const uint32_t* store, unsigned long long n, uint32_t base, uint32_t prefix, uint32_t* hist1) {
+  if (!n) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<unsigned long long>((n + 255u) / 256u, 4096ull);
+  hipLaunchKernelGGL(mkp_sample_hist1, dim3(grid), dim3(256), 0, st, store, n, base, prefix, hist1);
+  return hipGetLastError();
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -3,10 +3,13 @@ GPU box, "gloo" in the CPU tests).  The pileup path itself shards by reference w
 (mkp_pileup_main --gpus-rank R --gpus-world W); the only thing ranks ever share is the pass threshold:
 
 * broadcast_thresholds  — default sampled mode: rank 0 estimates (mkp_estimate_thresholds), everyone receives it.
-* allreduce_histograms + percentile_from_histogram — full-data percentile (`-f 1.0`, thresholds.rs:121-159) when every
-  rank has decoded only its own windows: histograms keyed by the f32 *bit pattern* of the probabilities are summed
-  across ranks (int64 all-reduce) and each rank evaluates percentile_linear_interp (thresholds.rs:17-38) on the merged
-  histogram — bit-identical to sorting the union of all values.
+* estimate_thresholds_allreduce / percentile_from_histograms — full-data percentile (`-f 1.0`, thresholds.rs:121-159) when
+  every rank has decoded only its own windows: the sample stays in each GPU's HBM, two-level histograms of the f32 *bit
+  patterns* (top 16 bits, then the low 16 bits inside the bins that hold the wanted order statistics) are summed across ranks
+  (int64 all-reduce, 512 KiB each) and each rank evaluates percentile_linear_interp (thresholds.rs:17-38) — bit-identical to
+  sorting the union of all values.
+* pileup_sharded — the launcher: thresholds as above, then `mkp_pileup_main --gpus-rank R --gpus-world W` per rank and an
+  ordered concatenation of the rank outputs.
 """
 import ctypes
 
@@ -46,82 +49,136 @@ def broadcast_thresholds(thresholds, src=0):
     return {BASES[i]: float(h[i]) for i in range(4) if h[4 + i] > 0}
 
 
-def local_histogram(values):
-    """f32 values -> (sorted distinct bit patterns as uint32, counts as int64).  Probabilities are positive, so the
-    unsigned order of the bit patterns is the numeric order."""
-    v = np.ascontiguousarray(values, dtype=np.float32).view(np.uint32)
-    keys, counts = np.unique(v, return_counts=True)
-    return keys.astype(np.uint32), counts.astype(np.int64)
+def _u64p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
 
 
-def allreduce_histograms(values):
-    """values: this rank's f32 probabilities for one canonical base -> (keys f32 ascending, counts int64) of the union
-    over all ranks.  Two collectives: all-gather of the (few, <= 2^16) distinct keys, all-reduce(SUM) of the counts."""
+def _allreduce_u64(h):
+    """SUM all-reduce of a uint64 numpy array over the ranks (int64 on the wire: counts stay far below 2^63)."""
     import torch
     dist = _dist()
-    keys, counts = local_histogram(values)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return keys.view(np.float32), counts
-    dev = _device()
-    world = dist.get_world_size()
-    n = torch.tensor([len(keys)], dtype=torch.int64, device=dev)
-    ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(ns, n)
-    cap = int(max(int(x.item()) for x in ns))
-    pad = torch.full((max(cap, 1),), -1, dtype=torch.int64, device=dev)
-    pad[:len(keys)] = torch.from_numpy(keys.astype(np.int64)).to(dev)
-    gathered = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(gathered, pad)
-    allk = torch.cat(gathered).cpu().numpy()
-    union = np.unique(allk[allk >= 0]).astype(np.uint32)
-    merged = np.zeros(len(union), dtype=np.int64)
-    merged[np.searchsorted(union, keys)] = counts
-    t = torch.from_numpy(merged).to(dev)
+        return h
+    t = torch.from_numpy(h.astype(np.int64)).to(_device())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return union.view(np.float32), t.cpu().numpy()
+    return t.cpu().numpy().astype(np.uint64)
 
 
-def percentile_from_histogram(keys, counts, q):
-    """percentile_linear_interp (thresholds.rs:17-38) on a histogram: only xs[floor(x)] and xs[ceil(x)] of the sorted
-    multiset are needed; they are found by walking the cumulative counts, and the interpolation itself is done by the
-    library (mkp_percentile) on those two values so the f32 arithmetic is the product's, not numpy's."""
-    n = int(counts.sum())
-    if n < 2:
-        raise ValueError("not enough datapoints, got %d" % n)
-    q32 = np.float32(q)
-    if q32 > np.float32(1.0):
-        raise ValueError("quantile greater than 1.0")
-    cum = np.cumsum(counts)
-
-    def at(rank):
-        return np.float32(keys[int(np.searchsorted(cum, rank, side="right"))])
-    if q32 == np.float32(1.0):
-        return float(at(n - 1))
-    lq = np.float32(n - 1) * q32
-    left, right = int(np.floor(lq)), int(np.ceil(lq))
-    # rebuild a 2..3 element sorted array whose percentile at the same fractional rank equals the full one:
-    # mkp_percentile(xs, n, q) reads xs[left] and xs[right] only, so hand it a sparse view through an index shift
-    xs = (ctypes.c_float * 2)(float(at(left)), float(at(right)))
-    frac = np.float32(lq - np.float32(np.trunc(lq)))
-    out = ctypes.c_float()
+def percentile_from_histograms(get, q):
+    """percentile_linear_interp (thresholds.rs:17-38) of the union of all ranks' samples of one base.
+    get(level, prefix) -> this rank's uint64[65536] histogram (Context.histogram_get or mkp_histogram_from_values);
+    every call is followed by a SUM all-reduce, so all ranks must call this function in the same order.
+    Returns (value or None when the union is empty, n)."""
     L = lib()
-    L.mkp_percentile.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_uint64, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
-    if left == right:
-        return float(at(left))
-    # two points, rank 1*frac: l = 1, lq' = frac, floor 0, ceil 1 -> xs[0]*(1-frac) + xs[1]*frac, the same f32 expression
-    rc = L.mkp_percentile(xs, 2, ctypes.c_float(float(frac)), ctypes.byref(out))
-    if rc != 0:
-        raise ValueError("mkp_percentile failed (%d)" % rc)
-    return float(out.value)
+    h0 = _allreduce_u64(np.ascontiguousarray(get(0, 0), dtype=np.uint64))
+    n = int(h0.sum())
+    if n == 0:
+        return None, 0
+    bins = (ctypes.c_uint32 * 2)()
+    rk = (ctypes.c_uint64 * 2)()
+    nn = ctypes.c_uint64()
+    if L.mkp_histogram_locate(_u64p(h0), ctypes.c_float(q), bins, rk, ctypes.byref(nn)) != 0:
+        raise ValueError("not enough datapoints, got %d" % n)
+    ys = []
+    h1 = None
+    for k in range(2):
+        if k == 0 or bins[1] != bins[0]:
+            h1 = _allreduce_u64(np.ascontiguousarray(get(1, int(bins[k])), dtype=np.uint64))
+        y = ctypes.c_float()
+        if L.mkp_histogram_resolve(int(bins[k]), _u64p(h1), int(rk[k]), ctypes.byref(y)) != 0:
+            raise ValueError("histogram levels disagree")
+        ys.append(y.value)
+    out = ctypes.c_float()
+    if L.mkp_percentile_from_histogram(n, ctypes.c_float(q), ctypes.c_float(ys[0]), ctypes.c_float(ys[1]), ctypes.byref(out)) != 0:
+        raise ValueError("not enough datapoints, got %d" % n)
+    return float(out.value), n
 
 
-def estimate_thresholds_allreduce(ctx, bam, flags=(), device=None):
-    """Per-base pass thresholds over the samples of ALL ranks (each rank samples its own BAM / windows).
-    Interim: rank 0 estimates on its data and broadcasts; replaced by the histogram all-reduce once the device-side
-    histogram entry points exist."""
+def host_histogram(values):
+    """get(level, prefix) over f32 values held on the host (mkp_histogram_from_values): for callers that sampled elsewhere, and tests."""
+    v = np.ascontiguousarray(values, dtype=np.float32)
+
+    def get(level, prefix):
+        out = np.zeros(65536, dtype=np.uint64)
+        rc = lib().mkp_histogram_from_values(v.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), len(v), level, prefix, _u64p(out))
+        if rc != 0:
+            raise ValueError("mkp_histogram_from_values failed (%d)" % rc)
+        return out
+    return get
+
+
+def estimate_thresholds_allreduce(ctx, bam, flags=(), q=0.1, rank=None, world=None):
+    """Per-base pass thresholds over the samples of ALL ranks (full-data mode, `-f 1.0`): each rank decodes only the reads of its
+    own sampling intervals on its GPU (mkp_histogram_add_bam --gpus-rank R --gpus-world W), the two-level histograms are summed
+    over the ranks (RCCL all-reduce on GPUs, gloo in the CPU tests) and every rank evaluates the exact percentile of the union.
+    With rank/world given explicitly the ranks shard ONE BAM; by default (torch.distributed rank/world when initialised and each
+    rank holding its own BAM, as in bench.py) every rank samples its whole file."""
     dist = _dist()
-    thr = ctx.estimate_thresholds(bam, [f for f in flags if f != "--cpg"][:0]) if (not dist.is_initialized() or dist.get_rank() == 0) else None
-    return broadcast_thresholds(thr, src=0)
+    shard = rank is not None and world is not None and world > 1
+    ctx.histogram_begin()
+    argv = list(flags) + ["-f", "1.0", "-p", repr(float(q))]
+    if shard:
+        argv += ["--gpus-rank", str(rank), "--gpus-world", str(world)]
+    ctx.histogram_add_bam(bam, argv)
+    out = {}
+    for b in BASES:
+        t, n = percentile_from_histograms(lambda level, prefix, b=b: ctx.histogram_get(b, level, prefix), q)
+        if t is not None:
+            out[b] = t
+    return out
+
+
+SAMPLING_FLAGS_WITH_VALUE = ("--region", "--sample-region", "--include-bed", "--include-positions", "--edge-filter", "--ignore", "--preset",
+                             "--sampling-interval-size", "-t", "--threads")
+SAMPLING_FLAGS_BARE = ("--include-unmapped", "--invert-edge-filter")
+
+
+def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1):
+    """`modkit pileup` with ONE BAM sharded over the ranks of the current torch.distributed job (one process per GPU):
+    thresholds from the all-reduced histograms of rank-sharded sampling, then every rank runs its contiguous run of the
+    reference's interval grid (mkp_pileup_main --gpus-rank/--gpus-world) into `<out>.rank<R>`, and rank 0 concatenates the parts
+    in rank order into `<out>` — byte-identical to the single-GPU output.  argv = [in.bam, out.bed, flags...] (no threshold flags)."""
+    import os
+    import shutil
+    from . import Context, pileup
+    dist = _dist()
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    bam, out, flags = argv[0], argv[1], list(argv[2:])
+    sflags, i = [], 0
+    while i < len(flags):
+        if flags[i] in SAMPLING_FLAGS_WITH_VALUE:
+            sflags += flags[i:i + 2]
+            i += 2
+        else:
+            if flags[i] in SAMPLING_FLAGS_BARE:
+                sflags.append(flags[i])
+            i += 1
+    ctx = Context(device=0 if device is None else device)
+    try:
+        thr = estimate_thresholds_allreduce(ctx, bam, sflags, q=q, rank=rank, world=world)
+    finally:
+        ctx.close()
+    targv = []
+    for b, v in sorted(thr.items()):
+        targv += ["--filter-threshold", "%s:%r" % (b, v)]
+    if not targv:
+        raise ValueError("no mod calls sampled on any rank")
+    part = "%s.rank%d" % (out, rank)
+    pileup([bam, part] + flags + targv + ["--gpus-rank", str(rank), "--gpus-world", str(world)] + (["--device", str(device)] if device is not None else []))
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
+        with open(out, "wb") as f:
+            for r in range(world):
+                with open("%s.rank%d" % (out, r), "rb") as g:
+                    shutil.copyfileobj(g, f)
+                os.remove("%s.rank%d" % (out, r))
+    if dist.is_initialized():
+        dist.barrier()
+    return thr
 
 
 def shard_plan(argv, rank, world):

@@ -27,7 +27,12 @@ def percentile_linear_interp_f32(xs, q):
 def _values(rank):
     rng = np.random.default_rng(100 + rank)
     q = rng.integers(0, 256, size=5000 + 777 * rank)
-    return ((q.astype(np.float32) + np.float32(0.5)) / np.float32(256.0)).astype(np.float32)  # quals_to_probs (mod_bam.rs:808-816)
+    v = ((q.astype(np.float32) + np.float32(0.5)) / np.float32(256.0)).astype(np.float32)  # quals_to_probs (mod_bam.rs:808-816)
+    # a third of them as ReDistribute would leave them (p + m/2, m/3: not multiples of 1/512), so the low 16 pattern bits matter
+    k = len(v) // 3
+    v[:k] = (v[:k] / np.float32(3.0)).astype(np.float32)
+    v[k:2 * k] = (v[k:2 * k] + v[:k] / np.float32(2.0)).astype(np.float32)
+    return np.minimum(v, np.float32(1.0))
 
 
 def _worker(rank, world, port, q):
@@ -40,9 +45,11 @@ def _worker(rank, world, port, q):
         from modkit_amd import distributed as mkd
         res = {}
         res["thr"] = mkd.broadcast_thresholds({"C": 0.802734375, "A": 0.5} if rank == 0 else None)
-        keys, counts = mkd.allreduce_histograms(_values(rank))
-        res["n"] = int(counts.sum())
-        res["pct"] = [mkd.percentile_from_histogram(keys, counts, p) for p in (0.1, 0.25, 0.5, 0.999, 1.0)]
+        # the path's one collective: two-level histograms of the f32 bit patterns, summed over the ranks (mkp_histogram_* C ABI)
+        get = mkd.host_histogram(_values(rank))
+        pn = [mkd.percentile_from_histograms(get, p) for p in (0.1, 0.25, 0.5, 0.999, 1.0, 0.0)]
+        res["n"] = pn[0][1]
+        res["pct"] = [t for t, _ in pn]
         bam = os.path.join(FIX, "bc_anchored_10_reads.sorted.bam")
         res["plan"] = mkd.shard_plan([bam, "-", "-i", "25", "--no-filtering"], rank, world)
         q.put((rank, res))
@@ -81,7 +88,7 @@ def test_threshold_broadcast(two_ranks):
 def test_histogram_allreduce_percentile_equals_sorting_the_union(two_ranks):
     union = np.concatenate([_values(0), _values(1)])
     assert two_ranks[0]["n"] == two_ranks[1]["n"] == len(union)
-    want = [float(percentile_linear_interp_f32(union, p)) for p in (0.1, 0.25, 0.5, 0.999, 1.0)]
+    want = [float(percentile_linear_interp_f32(union, p)) for p in (0.1, 0.25, 0.5, 0.999, 1.0, 0.0)]
     assert two_ranks[0]["pct"] == want and two_ranks[1]["pct"] == want  # bit-exact f32
 
 

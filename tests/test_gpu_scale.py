@@ -157,3 +157,41 @@ def test_c2_full_size_properties(tmp_path):
         assert _digest(joined) == _digest(whole)
     finally:
         ctx.close()
+
+
+def _sharded_worker(rank, world, port, argv, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both processes share this box's one GPU: RCCL needs one device per rank
+    try:
+        from modkit_amd import distributed as mkd
+        thr = mkd.pileup_sharded(argv, device=0)
+        q.put((rank, thr))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c4_scaled_two_processes_sharded_sampling_allreduce(oracle_bin, tmp_path):
+    # C4 scaled, two processes: each rank samples ONLY its own sampling intervals on the GPU (-f 1.0), the two-level histograms
+    # are summed over the ranks (torch.distributed all-reduce; gloo here because both ranks sit on one GPU, RCCL on a node),
+    # each rank runs its run of the interval grid, rank 0 concatenates: byte-identical to the single-rank run and to the oracle
+    import socket
+    import torch.multiprocessing as mp
+    bam, fa, meta = gen(tmp_path, "c4s", [("chr1", 2_600_000), ("chr2", 1_700_000), ("chrX", 900_000)], 9_000, "hm", 44, ["--cpg-depleted", "--mean-len", "8000"])
+    flags = ["--preset", "traditional", "--ref", fa, "--sampling-interval-size", "400000"]
+    whole = both(oracle_bin, tmp_path, bam, flags + ["-f", "1.0", "-p", "0.1"])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = os.path.join(str(tmp_path), "sharded.bed")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, [bam, out] + flags, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == res[1] and "C" in res[0]
+    assert open(out).read() == whole
