@@ -126,6 +126,13 @@ typedef struct {
   const uint32_t* n_nocall;
   uint64_t processed_records; /* reads that yielded mod calls (read_cache.rs:357-365) */
   uint64_t skipped_records;   /* coverage-only reads (skip_set) */
+  /* --partition-tag (PartitionKey, src/pileup/mod.rs:607-610, 795-815): rows are grouped by key (all rows of key 0, then key 1, ..),
+   * genome order inside a key.  partition_key[i] indexes partition_key_names; name 0 is "ungrouped" (PartitionKey::NoKey: no
+   * partition tags set, or the read carries none of them); the others are the tag values joined by '_' ("missing" for an absent
+   * tag), which is the file stem PartitioningBedMethylWriter uses (src/writers.rs:1029-1080). */
+  const uint32_t* partition_key;
+  uint32_t n_partition_keys;
+  const char* const* partition_key_names;
 } mkp_rows;
 
 typedef struct {
@@ -146,6 +153,10 @@ const char* mkp_version(void);
 /* ---- caller / options: stands in for the `caller`, `pileup_numeric_options`, `force_allow`,
  *      `combine_strands`, `max_depth`, `edge_filter` arguments of process_region_batch */
 int mkp_set_caller(mkp_ctx* ctx, const mkp_caller* caller);
+
+/* ---- partition tags: the `partition_tags: Option<&Vec<SamTag>>` argument of process_region_batch (src/pileup/mod.rs:693).
+ * tags = two-character SAM tag names (e.g. "HP", "RG"); n = 0 clears.  Applies to the shards begun afterwards. */
+int mkp_set_partition_tags(mkp_ctx* ctx, const char* const* tags, uint32_t n);
 
 /* ---- the hot path on records the host already holds (rust-htslib fetch()+records()):
  * begin a shard, append its records in coordinate order, run.  Replaces the body of

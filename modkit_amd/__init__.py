@@ -72,7 +72,7 @@ def lib():
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
-           "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
+           "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
            "mkp_histogram_resolve", "mkp_percentile_from_histogram"]
 
 
@@ -118,7 +118,9 @@ class Rows(ctypes.Structure):
                 ("n_canonical", ctypes.POINTER(ctypes.c_uint32)), ("n_other", ctypes.POINTER(ctypes.c_uint32)),
                 ("n_delete", ctypes.POINTER(ctypes.c_uint32)), ("n_fail", ctypes.POINTER(ctypes.c_uint32)),
                 ("n_diff", ctypes.POINTER(ctypes.c_uint32)), ("n_nocall", ctypes.POINTER(ctypes.c_uint32)),
-                ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64)]
+                ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64),
+                ("partition_key", ctypes.POINTER(ctypes.c_uint32)), ("n_partition_keys", ctypes.c_uint32),
+                ("partition_key_names", ctypes.POINTER(ctypes.c_char_p))]
 
 
 class Stats(ctypes.Structure):

@@ -17,7 +17,7 @@ hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*r
 hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
-                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/);
+                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 }
 
@@ -96,7 +96,8 @@ void make_resident(mkp_ctx* c) {
   ShardHost& S = c->shard;
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
-  { std::vector<uint64_t> h(S.name_hash.begin(), S.name_hash.end()); std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
+  { std::vector<std::pair<uint32_t, uint64_t>> h(S.name_hash.size()); for (size_t i = 0; i < h.size(); i++) h[i] = {i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u, S.name_hash[i]};   // per partition key: tallies of different keys never meet
+    std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
   // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
   { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1; c->tables.build(c->packer.layouts, c->caller, &used); }
   MkpRunParams& P = c->prm; memset(&P, 0, sizeof(P));
@@ -192,8 +193,11 @@ void make_resident(mkp_ctx* c) {
   if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
-  c->d_tile_row_off.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(c->n_tiles + 1) * 4); c->d_tile_dst.ensure((size_t)(c->n_tiles + 1) * 4);
   c->d_misc.ensure(64);
+  // partition keys present in this shard: one accumulate pass each
+  c->key_passes.clear();
+  if (c->partition_tags.empty()) c->key_passes.push_back(MKP_NO_KEY_FILTER);
+  else { std::vector<uint8_t> seen(c->key_names.size(), 0); for (auto& h : S.hdr) { const uint32_t k = h.flags >> MKP_RF_KEY_SHIFT; if (k < seen.size()) seen[k] = 1; } for (uint32_t k = 0; k < seen.size(); k++) if (seen[k]) c->key_passes.push_back(k); if (c->key_passes.empty()) c->key_passes.push_back(0); }
   hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
@@ -210,8 +214,10 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
   if (c->row_cap == 0) {
     // focus runs: usually one strand rule per focus position and one row per observed code; otherwise two strands per position
     uint64_t guess = c->has_focus ? c->n_slots_total * std::max<uint32_t>(1u, P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
-    c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess, 1ull << 28));
+    c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess * c->key_passes.size(), 1ull << 28));
   }
+  const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
+  c->d_tile_row_off.ensure((size_t)(n_runs + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);
   for (;;) {
     P.row_capacity = (uint32_t)c->row_cap;
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
@@ -223,11 +229,12 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
-    hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
-                                c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2), "pileup launch");
+    for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
+      hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+                                  c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
+                                  c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), c->n_tiles, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
+    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     uint32_t h[4];
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
@@ -251,8 +258,9 @@ void fetch_rows(mkp_ctx* c, mkp_rows* out) {
                              c->rows_dst.n_del, c->rows_dst.n_fail, c->rows_dst.n_diff, c->rows_dst.n_nocall};
   (void)cap;
   for (int k = 0; k < 11; k++) { c->h_rows[k].resize(n); if (n) hip_check(hipMemcpy(c->h_rows[k].data(), src[k], n * 4, hipMemcpyDeviceToHost), "rows D2H"); }
-  c->h_strand.resize(n); c->h_motif.resize(n);
-  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)(inf >> 8) - 1; }
+  c->h_strand.resize(n); c->h_motif.resize(n); c->h_key.resize(n);
+  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1; c->h_key[i] = inf >> 16; }
+  c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
   // per-read outcome counts
   std::vector<MkpReadOut> ro(c->shard.hdr.size());
   if (!ro.empty()) hip_check(hipMemcpy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost), "readout D2H");
@@ -265,7 +273,40 @@ void fetch_rows(mkp_ctx* c, mkp_rows* out) {
     out->n_valid = c->h_rows[3].data(); out->n_mod = c->h_rows[4].data(); out->n_canonical = c->h_rows[5].data(); out->n_other = c->h_rows[6].data();
     out->n_delete = c->h_rows[7].data(); out->n_fail = c->h_rows[8].data(); out->n_diff = c->h_rows[9].data(); out->n_nocall = c->h_rows[10].data();
     out->processed_records = c->n_ok; out->skipped_records = c->n_bad;
+    out->partition_key = c->h_key.data(); out->n_partition_keys = (uint32_t)c->key_name_ptrs.size(); out->partition_key_names = c->key_name_ptrs.data();
   }
+}
+
+// get_stringable_aux (util.rs:670-688): the value of an aux field as the text the reference partitions by
+bool aux_stringable(const mkp_record& r, const char* tag, std::string* out) {
+  if (!r.data || r.l_data <= 0) return false;
+  const size_t fixed = (size_t)r.l_qname + 4 * (size_t)r.n_cigar + ((size_t)std::max(r.l_qseq, 0) + 1) / 2 + (size_t)std::max(r.l_qseq, 0);
+  if (fixed > (size_t)r.l_data) return false;
+  const uint8_t* a = r.data + fixed; const uint8_t* e = r.data + r.l_data;
+  auto width = [](uint8_t ty) -> int { switch (ty) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; default: return -1; } };
+  while (a + 3 <= e) {
+    const uint8_t ty = a[2]; const uint8_t* v = a + 3; const uint8_t* nx;
+    if (ty == 'Z' || ty == 'H') { const uint8_t* z = v; while (z < e && *z) z++; if (z >= e) return false; nx = z + 1; }
+    else if (ty == 'B') { if (v + 5 > e) return false; const int w = width(v[0]); uint32_t cnt; memcpy(&cnt, v + 1, 4); if (w < 0 || (uint64_t)cnt * (uint64_t)w > (uint64_t)(e - v - 5)) return false; nx = v + 5 + (size_t)cnt * (size_t)w; }
+    else { const int w = width(ty); if (w < 0 || v + w > e) return false; nx = v + w; }
+    if (a[0] == (uint8_t)tag[0] && a[1] == (uint8_t)tag[1]) {   // first occurrence (bam_aux_get)
+      char buf[64];
+      switch (ty) {
+        case 'Z': case 'H': out->assign((const char*)v, (size_t)(nx - 1 - v)); return true;
+        case 'A': out->assign(1, (char)v[0]); return true;
+        case 'c': snprintf(buf, sizeof(buf), "%d", (int)(int8_t)v[0]); break;
+        case 'C': snprintf(buf, sizeof(buf), "%u", (unsigned)v[0]); break;
+        case 's': { int16_t x; memcpy(&x, v, 2); snprintf(buf, sizeof(buf), "%d", (int)x); break; }
+        case 'S': { uint16_t x; memcpy(&x, v, 2); snprintf(buf, sizeof(buf), "%u", (unsigned)x); break; }
+        case 'i': { int32_t x; memcpy(&x, v, 4); snprintf(buf, sizeof(buf), "%d", x); break; }
+        case 'I': { uint32_t x; memcpy(&x, v, 4); snprintf(buf, sizeof(buf), "%u", x); break; }
+        default: return false;   // floats print through Rust's Display (shortest round-trip form): not restated; arrays are not stringable
+      }
+      *out = buf; return true;
+    }
+    a = nx;
+  }
+  return false;
 }
 
 template <class F> int guarded(mkp_ctx* c, F f) {
@@ -325,6 +366,15 @@ int mkp_set_caller(mkp_ctx* c, const mkp_caller* k) {
   });
 }
 
+int mkp_set_partition_tags(mkp_ctx* c, const char* const* tags, uint32_t n) {
+  if (!c || (!tags && n)) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    std::vector<std::string> v;
+    for (uint32_t i = 0; i < n; i++) { if (!tags[i] || strlen(tags[i]) != 2) throw Error(MKP_E_INVALID, "SAM tags are two characters"); if (std::find(v.begin(), v.end(), tags[i]) != v.end()) throw Error(MKP_E_INVALID, "partition tag given twice"); v.push_back(tags[i]); }
+    c->partition_tags = v; c->resident = false;
+  });
+}
+
 int mkp_shard_begin(mkp_ctx* c, const mkp_shard* s) {
   if (!c || !s) return MKP_E_INVALID;
   return guarded(c, [&]() {
@@ -339,6 +389,7 @@ int mkp_shard_begin(mkp_ctx* c, const mkp_shard* s) {
       if (c->combos.empty()) { mkp_motif_combo z; memset(&z, 0, sizeof(z)); c->combos.push_back(z); }
     } else { c->focus.clear(); c->combos.clear(); }
     c->shard_open = true; c->resident = false; c->row_cap = 0;
+    c->key_names.assign(1, "ungrouped");
     memset(&c->stats, 0, sizeof(c->stats));
   });
 }
@@ -349,6 +400,7 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
     if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
     auto t0 = std::chrono::steady_clock::now();
     const int32_t tid = c->shard.tid;
+    const size_t hdr_before = c->shard.hdr.size();
     pack_records(c->packer, c->shard, recs, n, [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); });
     // supplementary records are not tallied but htslib buffers them (BAM_DEF_MASK lets 0x800 through): their spans count for the max-depth guard
     for (uint32_t i = 0; i < n; i++) {
@@ -356,6 +408,21 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
       if (r.tid != tid || !(r.flag & 2048) || (r.flag & (4 | 256 | 512 | 1024)) || !r.n_cigar || !r.data || (uint64_t)r.l_qname + 4ull * r.n_cigar > (uint64_t)std::max(r.l_data, 0)) continue;
       int64_t len = 0; for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, r.data + r.l_qname + 4 * (size_t)k, 4); if ((0x18du >> (w & 15u)) & 1u) len += w >> 4; }
       c->shard.extra_spans.push_back({r.pos, (int32_t)std::min<int64_t>((int64_t)r.pos + std::max<int64_t>(len, 1), INT32_MAX)});
+    }
+    if (!c->partition_tags.empty()) {   // PartitionKey per kept record (parse_tags_from_record, pileup/mod.rs:626-643): values joined by '_', "missing" for an absent tag
+      size_t at = hdr_before;
+      for (uint32_t i = 0; i < n; i++) {
+        const mkp_record& r = recs[i];
+        if (!(r.tid == tid && Packer::keep(r))) continue;
+        if (at >= c->shard.hdr.size()) throw Error(MKP_E_INVALID, "internal: packer dropped a kept record");
+        std::string key; bool any = false;
+        for (size_t t = 0; t < c->partition_tags.size(); t++) { std::string v; const bool got = aux_stringable(r, c->partition_tags[t].c_str(), &v); any |= got; if (t) key += '_'; key += got ? v : std::string("missing"); }
+        uint32_t id = 0;
+        if (any) { auto it = std::find(c->key_names.begin() + 1, c->key_names.end(), key); id = (uint32_t)(it - c->key_names.begin()); if (it == c->key_names.end()) { if (c->key_names.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65534 partition keys in one shard"); c->key_names.push_back(key); } }
+        c->shard.hdr[at].flags |= id << MKP_RF_KEY_SHIFT;
+        at++;
+      }
+      if (at != c->shard.hdr.size()) throw Error(MKP_E_INVALID, "internal: packer added records that were not kept");
     }
     c->resident = false; c->row_cap = 0;   // the HBM copy and the tile plan belong to the previous record set
     c->stats.pack_ms += ms_since(t0);

@@ -45,7 +45,9 @@ struct mkp_ctx {
   mkp::ShardHost sample_shard; std::vector<MkpReadOut> sample_ro; uint64_t sample_n = 0;
   mkp::DevBuf d_store, d_hist0, d_hist1, d_sample_cursor, d_take;
   MkpRowsDev rows_src, rows_dst;
-  std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif;
+  std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif; std::vector<uint32_t> h_key;
+  // --partition-tag: tag names, the shard's key names (index = key id, 0 = "ungrouped"), the key ids present (one accumulate pass each)
+  std::vector<std::string> partition_tags, key_names{"ungrouped"}; std::vector<const char*> key_name_ptrs; std::vector<uint32_t> key_passes{0xffffffffu};
   uint64_t n_ok = 0, n_bad = 0;
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -43,13 +43,15 @@ struct MkpReadHdr {
   uint32_t tag_off;     // index into tagref[]
   uint16_t n_tags;
   uint16_t layout;
-  uint32_t flags;       // bit0 reverse; bit1 host-detected tag error (coverage-only read)
+  uint32_t flags;       // bit0 reverse; bit1 host-detected tag error (coverage-only read); bits 8.. partition key id (0 = ungrouped)
   uint32_t event_off;   // index into events[]
   uint32_t event_cap;
   uint32_t chunk_off;   // index into chunk_pfx[]: one {query offset, reference offset} per 64 CIGAR ops of this read
 };
 #define MKP_RF_REVERSE 1u
 #define MKP_RF_BAD 2u
+#define MKP_RF_KEY_SHIFT 8
+#define MKP_NO_KEY_FILTER 0xffffffffu
 
 struct MkpTagRef { uint32_t rank_off, n, ml_off, pad; };
 

@@ -3,6 +3,9 @@
 // with process_region_batch replaced by shards on the GPU.  Host work here is scheduling only:
 // BAM ingest, the interval grid + focus positions, choosing which reads the threshold sampler takes
 // (reads_sampler/*, sampling_schedule.rs), and formatting rows (writers.rs:87-156).
+#include <sys/stat.h>
+
+#include <cerrno>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -22,7 +25,7 @@ struct Args {
   std::string in_bam, out_bed, region, sample_region, include_bed, ignore, ref_fasta, edge_filter, preset;
   uint32_t max_depth = 8000, interval_size = 100000, sampling_interval_size = 1000000;
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
-  std::vector<std::string> filter_threshold, mod_thresholds, motif_parts;
+  std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
   int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
 };
@@ -326,8 +329,28 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   }
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
   if (bf) records = bed_contigs(*bf, records, a.interval_size);
+  // --partition-tag: the output path is a directory with one bedMethyl per key, `[<prefix>_]<key>.bed` (PartitioningBedMethylWriter, writers.rs:1005-1082)
+  const bool partitioned = !a.partition_tags.empty();
+  std::map<std::string, std::unique_ptr<RowWriter>> key_writers;
+  if (partitioned) {
+    if (a.with_header) throw Error(MKP_E_INVALID, "--with-header cannot be combined with --partition-tag");
+    if (a.plan_only) throw Error(MKP_E_INVALID, "--plan-only has no partitioned form");
+    { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
+    if (mkdir(a.out_bed.c_str(), 0777) != 0 && errno != EEXIST) throw Error(MKP_E_IO, "failed to make output directory " + a.out_bed);
+  } else {
   wr.f = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w");
   if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
+  }
+  auto writer_for = [&](const std::string& key) -> RowWriter& {
+    auto it = key_writers.find(key);
+    if (it == key_writers.end()) {
+      std::unique_ptr<RowWriter> w(new RowWriter()); w->mixed = a.mixed_delim; w->labels = wr.labels;
+      const std::string path = a.out_bed + "/" + (a.prefix.empty() ? key : a.prefix + "_" + key) + ".bed";
+      w->f = fopen(path.c_str(), "w"); if (!w->f) throw Error(MKP_E_IO, "failed to make output file " + path);
+      it = key_writers.emplace(key, std::move(w)).first;
+    }
+    return *it->second;
+  };
   if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", wr.f);
   // shard plan: one shard per contig record, or pieces of it cut at interval boundaries; ranks take contiguous runs
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
@@ -370,14 +393,24 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       mkp_rows rows; must(mkp_shard_run(ctx, &rows));
       if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, &rows));   // measurement aid: warm, averaged kernel times in --stats
-      { auto t_w = std::chrono::steady_clock::now(); wr.write(rec.name, rows); write_ms += ms_since(t_w); }
+      { auto t_w = std::chrono::steady_clock::now();
+        if (!partitioned) wr.write(rec.name, rows);
+        else for (uint64_t i0r = 0; i0r < rows.n_rows;) {   // rows come grouped by key: one slice per key
+          uint64_t i1r = i0r; while (i1r < rows.n_rows && rows.partition_key[i1r] == rows.partition_key[i0r]) i1r++;
+          mkp_rows v = rows; v.n_rows = i1r - i0r; v.pos += i0r; v.strand += i0r; v.code_repr += i0r; v.motif_idx += i0r; v.n_valid += i0r; v.n_mod += i0r; v.n_canonical += i0r; v.n_other += i0r;
+          v.n_delete += i0r; v.n_fail += i0r; v.n_diff += i0r; v.n_nocall += i0r; v.partition_key += i0r;
+          const uint32_t k = rows.partition_key[i0r];
+          RowWriter& kw = writer_for(k < rows.n_partition_keys ? rows.partition_key_names[k] : "not_found"); kw.write(rec.name, v); wr.n += v.n_rows;
+          i0r = i1r;
+        }
+        write_ms += ms_since(t_w); }
       n_shards++;
       mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
-  { auto t_w = std::chrono::steady_clock::now(); wr.finish(); write_ms += ms_since(t_w); }
-  if (wr.f != stdout) fclose(wr.f);
+  { auto t_w = std::chrono::steady_clock::now(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f); } write_ms += ms_since(t_w); }
+  if (wr.f && wr.f != stdout) fclose(wr.f);
   if (rep) {
     memset(rep, 0, sizeof(*rep));
     rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms; rep->kernel_ms = kernel_ms; rep->d2h_ms = d2h_ms; rep->write_ms = write_ms;
@@ -410,7 +443,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
     else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
     else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val()); else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
-    else if (s == "--partition-tag" || s == "--bedgraph" || s == "--prefix") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
+    else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
+    else if (s == "--bedgraph") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);
   }

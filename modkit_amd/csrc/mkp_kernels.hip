@@ -1308,14 +1308,14 @@ __device__ __forceinline__ bool tally_row(const TV& tv, const MkpRunParams& prm,
 template <bool WRITE, class TV, class SlotOf>
 __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
                                             const MkpCombo* combos, int32_t p, uint32_t i, const MkpRowsDev& rows,
-                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */, SlotOf slot_of) {
+                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */, SlotOf slot_of, uint32_t key = 0) {
   const uint32_t rule = fv & 3u, combo = fv >> 2;
   if (!rule) return 0;
   uint32_t n = 0;
   auto put = [&](const RowAcc& r, uint32_t strand, uint32_t code, int motif) {
     if (WRITE) {
       uint32_t k = wr + n;
-      rows.pos[k] = (uint32_t)p; rows.info[k] = strand | ((uint32_t)(motif + 1) << 8); rows.code[k] = code;
+      rows.pos[k] = (uint32_t)p; rows.info[k] = strand | ((uint32_t)(motif + 1) << 8) | (key << 16); rows.code[k] = code;
       rows.n_valid[k] = r.n_valid; rows.n_mod[k] = r.n_mod; rows.n_can[k] = r.n_can; rows.n_other[k] = r.n_other;
       rows.n_del[k] = r.n_del; rows.n_fail[k] = r.n_fail; rows.n_diff[k] = r.n_diff; rows.n_nocall[k] = r.n_nocall;
     }
@@ -1438,7 +1438,7 @@ template <bool FOCUS> struct SlotMap {
 // Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
 // run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
 template <bool FOCUS>
-__device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SlotMap<FOCUS> sm, uint32_t n_tslots, MkpTile tl, uint32_t tix, const MkpRunParams* __restrict__ prmp,
+__device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SlotMap<FOCUS> sm, uint32_t n_tslots, MkpTile tl, uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
                                             const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
                                             uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
                                             uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p) {
@@ -1485,7 +1485,7 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       __syncthreads();
       uint32_t woff = *scan_carry_p;
       for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
-      if (cnt) rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of);
+      if (cnt) rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of, key);
       __syncthreads();
       if (threadIdx.x == PILEUP_THREADS - 1) *scan_carry_p = woff + inc2;
     }
@@ -1513,7 +1513,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles,
                  const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos,
                  uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
-                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err) {
+                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_filter, uint32_t key_slot) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
@@ -1604,6 +1604,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
     if (rid >= rid_end) break;
     const MkpReadHdr h = hdrs[rid];
     if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
+    if (key_filter != MKP_NO_KEY_FILTER && (h.flags >> MKP_RF_KEY_SHIFT) != key_filter) continue;   // --partition-tag: one pass per key
     // the read's slot range in this tile; a read that covers no slot leaves nothing here
     const int32_t span_a = max(h.ref_start, T0h), span_b = min(h.ref_end, T1h);
     const uint32_t rs_a = sm.rank(span_a), rs_b = sm.rank(span_b);
@@ -1786,7 +1787,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __syncthreads();
   // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
   // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
-  emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, tix, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, key_slot * n_tiles + tix, key_filter == MKP_NO_KEY_FILTER ? 0u : key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
   }
 }
 
@@ -1794,8 +1795,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles, \
                  const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, \
                  uint32_t* __restrict__ rows_base /* 11 SoA arrays of row_capacity entries */, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, \
-                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err
-#define PILEUP_PASS hdrs, cigar, seqs, events, readout, tiles, n_tiles, prmp, slotbm, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, chunk_pfx, dev_err
+                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_filter /* partition key to tally, or MKP_NO_KEY_FILTER */, uint32_t key_slot /* index of this key pass */
+#define PILEUP_PASS hdrs, cigar, seqs, events, readout, tiles, n_tiles, prmp, slotbm, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, chunk_pfx, dev_err, key_filter, key_slot
 // every position owns a tally column (no focus positions): the dense walk, 4 windows of 64 positions in flight
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles(PILEUP_PARAMS) { pileup_tiles_body<false, 4>(PILEUP_PASS); }
 // focus positions only (--cpg / --motif / --include-bed): tally columns, events and the depth walk are restricted to them
@@ -1940,15 +1941,15 @@ extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int focus_mode, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const MkpTile* tiles, uint32_t n_tiles, const MkpRunParams* prm_dev,
                                         const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot) {
   if (!n_tiles) return hipSuccess;
   const uint32_t grid = n_tiles;   // one workgroup per tile
   if (focus_mode)
     hipLaunchKernelGGL(mkp_pileup_tiles_focus, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
-                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
+                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_filter, key_slot);
   else
     hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
-                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err);
+                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_filter, key_slot);
   return hipGetLastError();
 }
 

@@ -22,7 +22,8 @@ for f in bc_anchored_10_reads.sorted.bam bc_anchored_10_reads.sorted.bam.bai \
   bc_anchored_10_reads_edge_filter50-0.bed modbam.modpileup_filt_positions_025.methyl.bed \
   modbam.modpileup_filt_positions_025_traditional.methyl.bed cgcg2_cg0_test1.bed cgcg2_cg0_test2.bed \
   cgcg2_cg0_test1_combine_strands.bed cgcg2_cg0_test2_combine_strands.bed \
-  pileup-old-tags-regressiontest.methyl.bed; do
+  pileup-old-tags-regressiontest.methyl.bed \
+  bc_anchored_10_reads.haplotyped.sorted.bam bc_anchored_10_reads.haplotyped.sorted.bam.bai; do
   cp "$SRC/$f" "$DST/$f"
 done
 echo "copied $(ls "$DST" | wc -l) files"

@@ -50,3 +50,58 @@ GOLDEN_CASES = [
 
 def fixture(name):
     return os.path.join(FIX, name)
+
+
+def update_tags_ambiguous(src_bam, dst_bam):
+    """What `modkit update-tags --mode ambiguous --no-implicit-probs` (src/commands.rs:1239-1282) does to a record whose
+    tags are old-style `Mm:Z:C+m,d..;` / `Ml:B:C`: the explicitly listed calls are kept with their qualities, the mode
+    becomes explicit ('?'), and the tags are written under the current names `MM` / `ML` at the end of the aux block
+    (remove_aux + push_aux).  Only that tag shape is handled (it is the only one in the fixture this serves,
+    tests/test_pileup.rs:161-192); anything else raises."""
+    import gzip
+    import struct
+    from bamfuzz import bgzf_write
+    d = gzip.open(src_bam).read()
+    o = 4
+    lt, = struct.unpack_from("<i", d, o); o += 4 + lt
+    nr, = struct.unpack_from("<i", d, o); o += 4
+    for _ in range(nr):
+        ln, = struct.unpack_from("<i", d, o); o += 4 + ln + 4
+    out = bytearray(d[:o])
+    width = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+    while o < len(d):
+        bs, = struct.unpack_from("<i", d, o)
+        rec = d[o + 4:o + 4 + bs]; o += 4 + bs
+        lrn, ncig, lseq = rec[8], struct.unpack_from("<H", rec, 12)[0], struct.unpack_from("<i", rec, 16)[0]
+        a = 32 + lrn + 4 * ncig + (lseq + 1) // 2 + lseq
+        aux, keep, mm, ml, p = rec[a:], bytearray(), None, None, 0
+        while p < len(aux):
+            tag, ty, q = aux[p:p + 2], chr(aux[p + 2]), p + 3
+            if ty in width:
+                q += width[ty]
+            elif ty in "ZH":
+                q = aux.index(b"\0", q) + 1
+            elif ty == "B":
+                cnt, = struct.unpack_from("<i", aux, q + 1)
+                q += 5 + cnt * width[chr(aux[q])]
+            else:
+                raise ValueError("aux type " + ty)
+            if tag in (b"Mm", b"MM"):
+                mm = aux[p + 3:q - 1].decode()
+            elif tag in (b"Ml", b"ML"):
+                assert aux[p + 2:p + 4] == b"BC"
+                ml = aux[p + 8:q]
+            else:
+                keep += aux[p:q]
+            p = q
+        assert mm is not None and ml is not None
+        new_mm = ""
+        for part in [x for x in mm.split(";") if x]:
+            head, _, rest = part.partition(",")
+            assert head == "C+m", head   # default mode, one code: the explicit positions stay, the mode becomes '?'
+            new_mm += "C+m?" + ("," + rest if rest else "") + ";"
+        keep += b"MMZ" + new_mm.encode() + b"\0" + b"MLBC" + struct.pack("<I", len(ml)) + ml
+        body = rec[:a] + bytes(keep)
+        out += struct.pack("<i", len(body)) + body
+    bgzf_write(dst_bam, bytes(out))
+    return dst_bam

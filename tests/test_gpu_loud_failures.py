@@ -34,7 +34,7 @@ def test_duplicate_read_names_are_refused(tmp_path):
     assert e.value.status == -3 and "read name" in str(e.value)
 
 
-@pytest.mark.parametrize("flag", [["--partition-tag", "HP"], ["--bedgraph"], ["--prefix", "x"]])
+@pytest.mark.parametrize("flag", [["--bedgraph"]])
 def test_writer_side_flags_are_refused(tmp_path, flag):
     with pytest.raises(modkit_amd.MkpError) as e:
         modkit_amd.pileup([BC, str(tmp_path / "o.bed"), "--no-filtering"] + flag)

@@ -6,7 +6,7 @@ import subprocess
 import pytest
 
 import modkit_amd
-from pileup_cases import BC, GOLDEN_CASES, REF, fixture
+from pileup_cases import BC, GOLDEN_CASES, REF, fixture, update_tags_ambiguous
 
 pytestmark = pytest.mark.gpu
 
@@ -16,6 +16,14 @@ def test_device_reproduces_reference_golden(tmp_path, name, flags, bam, golden):
     out = str(tmp_path / "out.bed")
     modkit_amd.pileup([fixture(bam), out] + flags)
     assert open(out).read() == open(fixture(golden)).read()
+
+
+def test_pileup_old_tags(tmp_path):
+    # tests/test_pileup.rs:161-192: the reference's regression golden on a real PacBio BAM (old-style tags updated to `C+m?`, =/X CIGARs)
+    bam = update_tags_ambiguous(fixture("HG002_small.ch20._other.sorted.bam"), str(tmp_path / "updated.bam"))
+    out = str(tmp_path / "out.bed")
+    modkit_amd.pileup([bam, out, "--no-filtering", "--only-tabs"])
+    assert open(out).read() == open(fixture("pileup-old-tags-regressiontest.methyl.bed")).read()
 
 
 def _both(oracle_bin, tmp_path, bam, flags):
@@ -70,3 +78,63 @@ def test_device_equals_oracle_old_tags_rejected(oracle_bin, tmp_path):
 def test_device_equals_oracle_duplex_defaults(oracle_bin, tmp_path):
     dev, ora = _both(oracle_bin, tmp_path, "duplex_modbam.sorted.bam", ["--region", "chr17"])
     assert dev == ora and len(dev) > 0
+
+
+def _bed_files(d):
+    import os
+    return sorted(f for f in os.listdir(d) if f.endswith(".bed"))
+
+
+@pytest.mark.parametrize("flags", [["--no-filtering"], ["--combine-strands", "--ref", REF, "--cpg", "--no-filtering"]], ids=["partitioned", "combine_strands"])
+def test_pileup_partition_tags(tmp_path, flags):
+    # tests/test_pileup.rs:501-545 and 692-736: the haplotyped fixture holds every read six times, once per (RG, HP) pair;
+    # partitioning on RG and HP must give 6 files, each equal to the unpartitioned pileup of the plain fixture
+    control, out_dir = str(tmp_path / "control.bed"), str(tmp_path / "parts")
+    modkit_amd.pileup([fixture(BC), control] + flags)
+    modkit_amd.pileup([fixture("bc_anchored_10_reads.haplotyped.sorted.bam"), out_dir, "--partition-tag", "RG", "--partition-tag", "HP"] + flags)
+    files = _bed_files(out_dir)
+    assert files == ["A_1.bed", "A_2.bed", "B_1.bed", "B_2.bed", "C_1.bed", "C_2.bed"]
+    want = open(control).read()
+    assert want
+    for f in files:
+        assert open(str(tmp_path / "parts" / f)).read() == want, f
+
+
+def test_partition_tags_vs_oracle_on_split_bams(oracle_bin, tmp_path):
+    # generator reads carry HP:i in {1,2,3} or no HP tag: every partition file must equal the oracle's unpartitioned pileup of
+    # the reads of that key alone (split test-side), "ungrouped" holding the untagged reads; --prefix names the files
+    import gzip
+    import json
+    import os
+    import struct
+    from bamfuzz import bgzf_write
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = str(tmp_path / "p")
+    subprocess.check_output([os.path.join(root, "tools", "gen_modbam"), "--out", prefix, "--contig", "chrP:300000", "--reads", "3000", "--seed", "77", "--style", "hm",
+                             "--mean-len", "5000", "--partition-tag", "HP:3"])
+    d = gzip.open(prefix + ".bam").read()
+    o = 4
+    lt, = struct.unpack_from("<i", d, o); o += 4 + lt
+    nr, = struct.unpack_from("<i", d, o); o += 4
+    for _ in range(nr):
+        ln, = struct.unpack_from("<i", d, o); o += 4 + ln + 4
+    header, groups = d[:o], {}
+    while o < len(d):
+        bs, = struct.unpack_from("<i", d, o)
+        rec = d[o:o + 4 + bs]; o += 4 + bs
+        k = rec.rfind(b"HPi")   # the generator appends the tag last
+        key = str(struct.unpack_from("<i", rec, k + 3)[0]) if k == len(rec) - 7 else "ungrouped"
+        groups.setdefault(key, bytearray(header)).extend(rec)
+    assert sorted(groups) == ["1", "2", "3", "ungrouped"]
+    flags = ["--filter-threshold", "0.7", "--cpg", "--ref", prefix + ".fa"]
+    out_dir = str(tmp_path / "parts")
+    modkit_amd.pileup([prefix + ".bam", out_dir, "--partition-tag", "HP", "--prefix", "hap"] + flags)
+    assert _bed_files(out_dir) == ["hap_1.bed", "hap_2.bed", "hap_3.bed", "hap_ungrouped.bed"]
+    for key, data in groups.items():
+        sub = str(tmp_path / ("sub_%s.bam" % key))
+        bgzf_write(sub, bytes(data))
+        ora = str(tmp_path / ("ora_%s.bed" % key))
+        p = subprocess.run([oracle_bin, "pileup", sub, ora] + flags, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        got, want = open(os.path.join(out_dir, "hap_%s.bed" % key)).read(), open(ora).read()
+        assert want and got == want, key

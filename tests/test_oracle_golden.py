@@ -6,7 +6,7 @@ import subprocess
 
 import pytest
 
-from pileup_cases import BC, GOLDEN_CASES, REF, fixture
+from pileup_cases import BC, GOLDEN_CASES, REF, fixture, update_tags_ambiguous
 
 
 def run_oracle(oracle_bin, bam, out, flags):
@@ -50,3 +50,12 @@ def test_estimated_thresholds_match_reference_values(oracle_bin, tmp_path):
     err = run_oracle(oracle_bin, fixture(BC), str(tmp_path / "o.bed"),
                      ["-i", "25", "-f", "1.0", "-p", "0.25", "--include-unmapped"])
     assert "threshold C 0.662109375 (n=109)" in err
+
+
+def test_pileup_old_tags(oracle_bin, tmp_path):
+    # tests/test_pileup.rs:161-192 — HG002_small (PacBio, old-style `Mm`/`Ml`, =/X CIGARs) through `update-tags --mode ambiguous
+    # --no-implicit-probs` (restated test-side), then `pileup --no-filtering --only-tabs`: the reference's regression golden
+    bam = update_tags_ambiguous(fixture("HG002_small.ch20._other.sorted.bam"), str(tmp_path / "updated.bam"))
+    out = str(tmp_path / "out.bed")
+    run_oracle(oracle_bin, bam, out, ["--no-filtering", "--only-tabs"])
+    assert open(out).read() == open(fixture("pileup-old-tags-regressiontest.methyl.bed")).read()
