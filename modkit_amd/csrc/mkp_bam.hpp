@@ -188,6 +188,295 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
   return bd;
 }
 
+// ------------------------------------------------------------------------------------ indexed, bounded ingest
+// What the reference gets from htslib's IndexedReader::fetch (src/pileup/mod.rs:732-743): only the BGZF blocks the BAI (SAM spec
+// 5.2) lists for a region are read (pread: no whole-file mapping) and inflated, so memory follows the shard, not the file, and a
+// rank of a multi-GPU run touches only its own part of the file.  Without a .bai next to the BAM the whole file is loaded once
+// (load_bam) and fetches are views into it.
+struct BamBatch {               // the records of one fetch, in file order
+  const uint8_t* base = nullptr;   // record offsets are relative to this (resident file), or absolute addresses when null
+  std::vector<ByteBuf> owned;      // the inflated ingest windows (indexed source); empty when `base` points into a resident file
+  std::vector<BamIndexEntry> recs;
+  const uint8_t* at(const BamIndexEntry& e) const { return reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(base) + (uintptr_t)e.off); }
+  void clear() { recs.clear(); for (auto& b : owned) b.release(); owned.clear(); base = nullptr; }
+  mkp_record view(const BamIndexEntry& e) const {
+    const uint8_t* c = at(e);
+    mkp_record r;
+    memcpy(&r.tid, c, 4); memcpy(&r.pos, c + 4, 4);
+    r.l_qname = c[8];
+    uint16_t nc; memcpy(&nc, c + 12, 2); r.n_cigar = nc;
+    memcpy(&r.flag, c + 14, 2);
+    memcpy(&r.l_qseq, c + 16, 4);
+    uint32_t bs; memcpy(&bs, c - 4, 4);
+    r.l_data = (int32_t)bs - 32;
+    r.data = c + 32;
+    return r;
+  }
+  std::string qname(const BamIndexEntry& e) const { const uint8_t* c = at(e); return std::string((const char*)c + 32, c[8] ? (size_t)c[8] - 1 : 0); }
+  uint32_t l_seq(const BamIndexEntry& e) const { uint32_t lq; memcpy(&lq, at(e) + 16, 4); return lq; }
+};
+
+// one record header at d[o] (after its block_size) -> index entry; false when the record is malformed
+static inline bool index_record(const uint8_t* d, size_t o, int32_t bs, int32_t n_ref, BamIndexEntry* e) {
+  if (bs < 32) return false;
+  e->off = o; memcpy(&e->tid, d + o, 4); memcpy(&e->pos, d + o + 4, 4);
+  const uint8_t lq = d[o + 8]; uint16_t nc; memcpy(&nc, d + o + 12, 2); memcpy(&e->flag, d + o + 14, 2);
+  int32_t lseq; memcpy(&lseq, d + o + 16, 4);
+  if (lseq < 0 || (uint64_t)32 + lq + 4ull * nc + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) return false;
+  if (e->tid < -1 || e->tid >= n_ref || e->pos < -1 || e->pos >= 0x7ffffff0) return false;
+  const uint8_t* cg = d + o + 32 + lq; int64_t rl = 0;
+  for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); const uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4; }
+  if ((int64_t)e->pos + rl > 0x7ffffff0ll) return false;
+  e->reflen = (int32_t)rl; e->end = e->pos + (rl > 0 ? (int32_t)rl : 1);
+  return true;
+}
+
+struct BaiIndex {
+  struct Chunk { uint64_t beg, end; };
+  struct Ref { std::map<uint32_t, std::vector<Chunk>> bins; std::vector<uint64_t> lin; uint64_t mapped = 0, unmapped = 0, off_beg = 0, off_end = 0; bool has_counts = false; };
+  std::vector<Ref> refs; uint64_t no_coor = 0; bool has_no_coor = false;
+  static bool load(const std::string& path, BaiIndex* out) {
+    FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
+    std::vector<uint8_t> b; { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize((size_t)std::max(n, 0l)); if (n > 0 && fread(b.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); return false; } }
+    fclose(f);
+    size_t o = 0; auto need = [&](size_t n) { if (o + n > b.size()) throw Error(MKP_E_IO, "truncated BAM index " + path); };
+    auto u32 = [&]() { need(4); uint32_t v; memcpy(&v, &b[o], 4); o += 4; return v; }; auto u64 = [&]() { need(8); uint64_t v; memcpy(&v, &b[o], 8); o += 8; return v; };
+    need(4); if (memcmp(b.data(), "BAI\1", 4) != 0) throw Error(MKP_E_IO, "not a BAI index: " + path); o = 4;
+    const uint32_t n_ref = u32(); if (n_ref > (1u << 24)) throw Error(MKP_E_IO, "corrupt BAM index " + path);
+    out->refs.assign(n_ref, Ref());
+    for (uint32_t r = 0; r < n_ref; r++) {
+      Ref& R = out->refs[r]; const uint32_t n_bin = u32();
+      for (uint32_t k = 0; k < n_bin; k++) {
+        const uint32_t bin = u32(), n_chunk = u32(); need((size_t)n_chunk * 16);
+        if (bin == 37450 && n_chunk == 2) { R.off_beg = u64(); R.off_end = u64(); R.mapped = u64(); R.unmapped = u64(); R.has_counts = true; continue; }   // htslib's metadata pseudo-bin
+        std::vector<Chunk>& v = R.bins[bin]; for (uint32_t c = 0; c < n_chunk; c++) { Chunk ch; ch.beg = u64(); ch.end = u64(); v.push_back(ch); }
+      }
+      const uint32_t n_intv = u32(); need((size_t)n_intv * 8); R.lin.resize(n_intv); for (uint32_t i = 0; i < n_intv; i++) R.lin[i] = u64();
+    }
+    if (o + 8 <= b.size()) { out->no_coor = u64(); out->has_no_coor = true; }
+    return true;
+  }
+  static void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t>* bins) {  // SAM spec 5.3
+    bins->clear(); --end; bins->push_back(0);
+    for (int64_t k = 1 + (beg >> 26); k <= 1 + (end >> 26); k++) bins->push_back((uint32_t)k);
+    for (int64_t k = 9 + (beg >> 23); k <= 9 + (end >> 23); k++) bins->push_back((uint32_t)k);
+    for (int64_t k = 73 + (beg >> 20); k <= 73 + (end >> 20); k++) bins->push_back((uint32_t)k);
+    for (int64_t k = 585 + (beg >> 17); k <= 585 + (end >> 17); k++) bins->push_back((uint32_t)k);
+    for (int64_t k = 4681 + (beg >> 14); k <= 4681 + (end >> 14); k++) bins->push_back((uint32_t)k);
+  }
+  // merged virtual-offset ranges that can hold records of `tid` overlapping [beg, end)
+  std::vector<Chunk> query(uint32_t tid, int64_t beg, int64_t end) const {
+    std::vector<Chunk> out; if (tid >= refs.size() || end <= beg) return out;
+    const Ref& R = refs[tid]; std::vector<uint32_t> bins; reg2bins(beg, end, &bins);
+    uint64_t min_off = 0; { const size_t w = (size_t)(beg >> 14); if (!R.lin.empty()) min_off = R.lin[std::min(w, R.lin.size() - 1)]; }
+    for (uint32_t b : bins) { auto it = R.bins.find(b); if (it == R.bins.end()) continue; for (auto& c : it->second) if (c.end > min_off) out.push_back(c); }
+    std::sort(out.begin(), out.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+    // chunks are record-granular and those of neighbouring bins interleave in the file: ranges that overlap, touch, or lie within
+    // one block (64 KiB compressed) of each other are read as one — the records in between belong to other bins of the same
+    // region or are dropped by the position test, and reading through the gap beats re-reading the same blocks chunk by chunk
+    std::vector<Chunk> m; for (auto& c : out) { if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end); else m.push_back(c); }
+    return m;
+  }
+};
+
+class BamSource {
+ public:
+  std::vector<std::string> ref_names; std::vector<uint32_t> ref_lens;
+  mutable std::atomic<uint64_t> bytes_read{0}, bytes_inflated{0};   // compressed bytes pread / bytes inflated so far
+  int tid_of(const std::string& n) const { for (size_t i = 0; i < ref_names.size(); i++) if (ref_names[i] == n) return (int)i; return -1; }
+  bool indexed() const { return fd_ >= 0; }
+  ~BamSource() { if (fd_ >= 0) close(fd_); }
+
+  // `use_index`: read through <path>.bai when it exists; otherwise (or when there is none) load the whole file
+  static std::unique_ptr<BamSource> open(const std::string& path, unsigned threads, bool use_index = true) {
+    std::unique_ptr<BamSource> s(new BamSource()); s->path_ = path; s->threads_ = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (use_index && BaiIndex::load(path + ".bai", &s->bai_)) {
+      s->fd_ = ::open(path.c_str(), O_RDONLY); if (s->fd_ < 0) throw Error(MKP_E_IO, "cannot open " + path);
+      struct stat st; if (fstat(s->fd_, &st) != 0) throw Error(MKP_E_IO, "cannot stat " + path); s->fsize_ = (uint64_t)st.st_size;
+      s->read_header();
+      if (s->bai_.refs.size() != s->ref_names.size()) throw Error(MKP_E_IO, "BAM index does not match the BAM header: " + path + ".bai");
+      // an index without htslib's per-reference counts (metadata pseudo-bins) cannot drive the sampling schedule: load the file instead
+      bool complete = s->bai_.has_no_coor; for (auto& R : s->bai_.refs) if (!R.has_counts && !R.bins.empty()) complete = false;
+      if (!complete) { close(s->fd_); s->fd_ = -1; s->ref_names.clear(); s->ref_lens.clear(); s->bai_ = BaiIndex(); }
+    }
+    if (s->fd_ < 0) {
+      s->resident_ = load_bam(path, s->threads_); s->ref_names = s->resident_.ref_names; s->ref_lens = s->resident_.ref_lens;
+      s->bytes_inflated += s->resident_.raw.size();
+    }
+    return s;
+  }
+
+  // records of `tid` overlapping [beg, end), file order (IndexedReader::fetch + records()); at most about `max_records` of them
+  // when the caller only needs the first ones (the threshold sampler's first-N schedule)
+  void fetch(uint32_t tid, uint32_t beg, uint32_t end, BamBatch* out, size_t max_records = SIZE_MAX) const {
+    out->clear();
+    if (tid >= ref_names.size() || end <= beg) return;
+    if (!indexed()) {
+      const BamData& bam = resident_; out->base = bam.raw.data();
+      for (size_t i = bam.tid_first[tid]; i < bam.tid_first[tid + 1] && i < bam.recs.size(); i++) {
+        const BamIndexEntry& e = bam.recs[i];
+        if (e.tid != (int32_t)tid) continue;
+        if ((int64_t)e.pos >= (int64_t)end) break;
+        if ((int64_t)e.end > (int64_t)beg) { out->recs.push_back(e); if (out->recs.size() >= max_records) break; }
+      }
+      return;
+    }
+    read_chunks(bai_.query(tid, beg, end), (int32_t)tid, (int64_t)beg, (int64_t)end, out, max_records);
+  }
+
+  // the records without coordinates (tid < 0), at the end of a sorted file
+  void fetch_unmapped(BamBatch* out) const {
+    out->clear();
+    if (!indexed()) { out->base = resident_.raw.data(); for (auto& e : resident_.recs) if (e.tid < 0) out->recs.push_back(e); return; }
+    uint64_t from = first_record_voff_;
+    for (auto& R : bai_.refs) { for (auto& kv : R.bins) for (auto& c : kv.second) from = std::max(from, c.end); if (R.has_counts) from = std::max(from, R.off_end); }
+    std::vector<BaiIndex::Chunk> ch(1); ch[0].beg = from; ch[0].end = fsize_ << 16;
+    read_chunks(ch, -1, 0, 0, out, SIZE_MAX);
+  }
+
+  // per-reference counts as htslib's idxstats gives them (sampling_schedule.rs:685-710)
+  void counts(std::vector<uint64_t>* mapped, std::vector<uint64_t>* unmapped, uint64_t* no_coor) const {
+    mapped->assign(ref_names.size(), 0); unmapped->assign(ref_names.size(), 0); *no_coor = 0;
+    if (!indexed()) { for (auto& r : resident_.recs) { if (r.tid < 0) (*no_coor)++; else if (r.flag & 4) (*unmapped)[(size_t)r.tid]++; else (*mapped)[(size_t)r.tid]++; } return; }
+    bool complete = bai_.has_no_coor; for (auto& R : bai_.refs) if (!R.has_counts && !R.bins.empty()) complete = false;
+    if (!complete) throw Error(MKP_E_UNSUPPORTED, "the BAM index carries no per-reference read counts (metadata pseudo-bin): re-index the file with samtools index");
+    for (size_t t = 0; t < bai_.refs.size(); t++) { (*mapped)[t] = bai_.refs[t].mapped; (*unmapped)[t] = bai_.refs[t].unmapped; }
+    *no_coor = bai_.no_coor;
+  }
+
+  // Where in the (compressed) file the data of position `pos` of `tid` starts, by the index's 16 kb linear windows: monotone in
+  // (tid, pos) for a sorted file, so differences measure the bytes under a reference range.  Without an index: a base-pair
+  // coordinate over the concatenated references (shards are then balanced by length).
+  uint64_t offset_at(uint32_t tid, uint64_t pos) const {
+    if (!indexed()) { uint64_t o = 0; for (uint32_t t = 0; t < tid && t < ref_lens.size(); t++) o += ref_lens[t]; return o + std::min<uint64_t>(pos, tid < ref_lens.size() ? ref_lens[tid] : 0); }
+    if (tid >= bai_.refs.size()) return fsize_;
+    // references without records take the offset of the next one that has any
+    for (uint32_t t = tid; t < bai_.refs.size(); t++) {
+      const BaiIndex::Ref& R = bai_.refs[t];
+      if (R.lin.empty() && !R.has_counts) continue;
+      if (t != tid) return R.has_counts ? R.off_beg >> 16 : (R.lin.empty() ? fsize_ : R.lin[0] >> 16);
+      const size_t w = (size_t)(pos >> 14);
+      if (w < R.lin.size()) { const uint64_t v = R.lin[w] >> 16; if (v || w == 0) return v ? v : (R.has_counts ? R.off_beg >> 16 : 0); }
+      return R.has_counts ? R.off_end >> 16 : (R.lin.empty() ? fsize_ : R.lin.back() >> 16);
+    }
+    return fsize_;
+  }
+
+ private:
+  std::string path_; unsigned threads_ = 1; int fd_ = -1; uint64_t fsize_ = 0, first_record_voff_ = 0; BaiIndex bai_; BamData resident_;
+
+  void pread_all(uint64_t off, uint8_t* dst, size_t n) const {
+    size_t got = 0; while (got < n) { const ssize_t r = ::pread(fd_, dst + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; }
+    bytes_read += n;
+  }
+  struct Blk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
+  // BGZF block at compressed offset `coff` inside buf (which starts at file offset buf_off): sizes from its header / trailer
+  bool block_at(const std::vector<uint8_t>& buf, uint64_t buf_off, uint64_t coff, Blk* b) const {
+    const size_t o = (size_t)(coff - buf_off);
+    if (o + 18 > buf.size()) return false;
+    if (buf[o] != 31 || buf[o + 1] != 139 || !(buf[o + 3] & 4)) throw Error(MKP_E_IO, "not BGZF: " + path_);
+    uint16_t xlen; memcpy(&xlen, &buf[o + 10], 2);
+    size_t x = o + 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
+    if (xe > buf.size()) return false;
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &buf[x + 2], 2); if (buf[x] == 'B' && buf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t v; memcpy(&v, &buf[x + 4], 2); bsize = (uint32_t)v + 1; found = true; } x += 4 + (size_t)sl; }
+    if (!found || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path_);
+    if (o + bsize > buf.size()) return false;
+    b->coff = coff; b->hdr = 12u + xlen; b->clen = bsize - xlen - 20u; memcpy(&b->isize, &buf[o + bsize - 4], 4); b->doff = 0;
+    return true;
+  }
+
+  void read_header() {
+    // the header sits in the first blocks: inflate block by block until it is complete
+    std::vector<uint8_t> d; std::vector<std::pair<uint64_t, uint32_t>> blocks; uint64_t coff = 0;
+    auto ensure = [&](size_t n) {
+      while (d.size() < n) {
+        if (coff >= fsize_) throw Error(MKP_E_IO, "truncated BAM " + path_);
+        std::vector<uint8_t> buf((size_t)std::min<uint64_t>((1u << 16) + 64, fsize_ - coff)); pread_all(coff, buf.data(), buf.size());
+        Blk b; if (!block_at(buf, coff, coff, &b)) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
+        const size_t at = d.size(); d.resize(at + b.isize); if (b.isize) inflate_block(&buf[b.hdr], b.clen, &d[at], b.isize);
+        blocks.push_back({coff, b.isize}); coff += (uint64_t)b.hdr + b.clen + 8;
+      }
+    };
+    ensure(12);
+    if (memcmp(d.data(), "BAM\1", 4) != 0) throw Error(MKP_E_IO, "not a BAM file: " + path_);
+    int32_t l_text; memcpy(&l_text, &d[4], 4); if (l_text < 0) throw Error(MKP_E_IO, "corrupt BAM header: negative text length");
+    size_t o = 8 + (size_t)l_text; ensure(o + 4);
+    int32_t n_ref; memcpy(&n_ref, &d[o], 4); o += 4; if (n_ref < 0) throw Error(MKP_E_IO, "corrupt BAM header: negative reference count");
+    for (int32_t i = 0; i < n_ref; i++) {
+      ensure(o + 4); int32_t ln; memcpy(&ln, &d[o], 4); if (ln <= 0) throw Error(MKP_E_IO, "corrupt BAM header: reference name length");
+      ensure(o + 4 + (size_t)ln + 4);
+      ref_names.push_back(std::string((const char*)&d[o + 4], (size_t)ln - 1)); uint32_t lr; memcpy(&lr, &d[o + 4 + (size_t)ln], 4); ref_lens.push_back(lr); o += 8 + (size_t)ln;
+    }
+    // virtual offset of the first record: `o` bytes into the inflated stream
+    uint64_t acc = 0; first_record_voff_ = coff << 16;
+    for (auto& b : blocks) { if (o < acc + b.second) { first_record_voff_ = (b.first << 16) | (uint64_t)(o - acc); break; } acc += b.second; }
+  }
+
+  // inflate the blocks under the (merged, ascending) virtual-offset ranges and index their records that pass the region test
+  void read_chunks(const std::vector<BaiIndex::Chunk>& chunks, int32_t tid, int64_t beg, int64_t end, BamBatch* out, size_t max_records) const {
+    const int32_t n_ref = (int32_t)ref_names.size();
+    // groups of chunks are processed until enough records are in hand; each group: pread, block walk, parallel inflate, record scan
+    bool stop = false;
+    for (size_t ci = 0; ci < chunks.size() && !stop; ci++) {
+      uint64_t cb = chunks[ci].beg >> 16; const uint64_t ce = chunks[ci].end >> 16, ue = chunks[ci].end & 0xffff; uint32_t ub = (uint32_t)(chunks[ci].beg & 0xffff);
+      // a bounded window of compressed bytes at a time (a chunk may be the whole contig): 64 MiB, or — when the caller wants only
+      // the first records of the region — 4 MiB growing to that
+      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (4u << 20);
+      while (cb < fsize_ && (cb < ce || (cb == ce && ue > 0)) && !stop) {
+        const uint64_t want_end = std::min<uint64_t>(fsize_, std::min<uint64_t>(ce + (1u << 16) + 64, cb + window));
+        window = std::min<uint64_t>(window * 2, 64u << 20);
+        std::vector<uint8_t> buf((size_t)(want_end - cb)); pread_all(cb, buf.data(), buf.size());
+        std::vector<Blk> blks; uint64_t c = cb, dtotal = 0;
+        for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; b.doff = dtotal; dtotal += b.isize; blks.push_back(b); c += b.hdr + b.clen + 8; }
+        if (blks.empty()) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
+        ByteBuf d; d.alloc((size_t)dtotal + 8);
+        { std::atomic<size_t> next{0}; std::atomic<bool> bad{false};
+          auto work = [&]() { for (;;) { const size_t i = next++; if (i >= blks.size()) break; if (!blks[i].isize) continue; try { inflate_block(&buf[(size_t)(blks[i].coff - cb) + blks[i].hdr], blks[i].clen, &d[(size_t)blks[i].doff], blks[i].isize); } catch (...) { bad = true; } } };
+          const unsigned nt = blks.size() < 4 ? 1u : std::min<unsigned>(threads_, (unsigned)blks.size());
+          if (nt <= 1) work(); else { std::vector<std::thread> th; for (unsigned t = 1; t < nt; t++) th.emplace_back(work); work(); for (auto& t : th) t.join(); }
+          if (bad) throw Error(MKP_E_IO, "corrupt BGZF data in " + path_); }
+        bytes_inflated += dtotal;
+        // records: from `ub` in the first block to the chunk end (or the end of this window's last complete record)
+        const bool last_window = c > ce || (c == ce && ue == 0) || c >= fsize_;
+        uint64_t o = ub, limit = dtotal;
+        if (last_window) { for (auto& b : blks) if (b.coff == ce) limit = b.doff + ue; }
+        // record boundaries: one hop per record; then the per-record work (field checks, CIGAR walk for the end) on all cores
+        std::vector<uint64_t> starts; uint64_t consumed = o;
+        while (o + 4 <= limit) {
+          int32_t bs; memcpy(&bs, &d[(size_t)o], 4);
+          if (bs < 32) throw Error(MKP_E_IO, "corrupt BAM record");
+          if (o + 4 + (uint64_t)bs > dtotal) break;   // the record continues in the next window
+          starts.push_back(o); o += 4 + (uint64_t)bs; consumed = o;
+        }
+        std::vector<BamIndexEntry> all(starts.size()); std::atomic<bool> rec_bad{false};
+        { auto idx = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { int32_t bs; memcpy(&bs, &d[(size_t)starts[i]], 4); if (!index_record(d.data(), (size_t)starts[i] + 4, bs, n_ref, &all[i])) rec_bad = true; } };
+          const unsigned nt = starts.size() < 4096 ? 1u : threads_;
+          if (nt <= 1) idx(0, starts.size()); else { std::vector<std::thread> th; for (unsigned t = 1; t < nt; t++) th.emplace_back(idx, starts.size() * t / nt, starts.size() * (t + 1) / nt); idx(0, starts.size() / nt); for (auto& t : th) t.join(); } }
+        if (rec_bad) throw Error(MKP_E_IO, "corrupt BAM record");
+        std::vector<BamIndexEntry> recs;
+        for (size_t i = 0; i < all.size(); i++) {
+          const BamIndexEntry& e = all[i];
+          if (tid >= 0) { if (e.tid != tid || (int64_t)e.pos >= end) { if (e.tid > tid || e.tid < 0 || (e.tid == tid && (int64_t)e.pos >= end)) { stop = true; break; } continue; } if ((int64_t)e.end <= beg) continue; }
+          else if (e.tid >= 0) continue;
+          recs.push_back(e);
+          if (recs.size() + out->recs.size() >= max_records) { stop = true; break; }
+        }
+        if (!recs.empty()) {   // the window stays alive with the batch; its records are addressed absolutely
+          const uintptr_t wbase = reinterpret_cast<uintptr_t>(d.data());
+          for (auto& e : recs) { e.off += (uint64_t)wbase; out->recs.push_back(e); }
+          out->owned.push_back(std::move(d));
+        }
+        if (stop || last_window) break;
+        // next window starts at the block holding the first unconsumed byte
+        size_t bi = blks.size() - 1; while (bi > 0 && blks[bi].doff > consumed) bi--;
+        if (blks[bi].coff == cb && consumed - blks[bi].doff == ub && blks.size() == 1) throw Error(MKP_E_IO, "BAM record larger than the ingest window");
+        cb = blks[bi].coff; ub = (uint32_t)(consumed - blks[bi].doff);
+      }
+    }
+    out->base = nullptr;
+  }
+};
+
 // ------------------------------------------------------------------------------------ FASTA
 struct Fasta {
   std::map<std::string, std::string> seqs;

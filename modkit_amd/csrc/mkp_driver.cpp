@@ -8,6 +8,7 @@
 #include <cerrno>
 #include <condition_variable>
 #include <deque>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -27,12 +28,18 @@ struct Args {
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
-  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
+  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0, shard_bytes = 1ull << 30; bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
 };
 
 struct RegionSpec { std::string name; uint32_t start, end; };
 
-RegionSpec parse_region(const std::string& raw, const BamData& bam) {  // Region::parse_str (util.rs:463-524)
+uint64_t peak_rss_kb() {   // VmHWM of this process (--stats)
+  std::ifstream f("/proc/self/status"); std::string line;
+  while (std::getline(f, line)) if (line.compare(0, 6, "VmHWM:") == 0) return strtoull(line.c_str() + 6, nullptr, 10);
+  return 0;
+}
+
+RegionSpec parse_region(const std::string& raw, const BamSource& bam) {  // Region::parse_str (util.rs:463-524)
   auto bad = [&]() { return Error(MKP_E_INVALID, "invalid region, " + raw + ", should be 'chrom' or 'chrom:start-stop'"); };
   size_t c = raw.find(':');
   if (c == std::string::npos) { int tid = bam.tid_of(raw); if (tid < 0) throw Error(MKP_E_INVALID, "contig-missing"); return {raw, 0, bam.ref_lens[(size_t)tid]}; }
@@ -50,34 +57,22 @@ bool parse_code(const std::string& s, uint32_t* out) {  // ModCodeRepr::parse (m
   *out = 0x80000000u | (uint32_t)v; return true;
 }
 
-std::vector<Contig> targets(const BamData& bam, const RegionSpec* r) {  // get_targets (util.rs:409-446)
+std::vector<Contig> targets(const BamSource& bam, const RegionSpec* r) {  // get_targets (util.rs:409-446)
   std::vector<Contig> out;
   for (size_t t = 0; t < bam.ref_names.size(); t++) { if (r) { if (bam.ref_names[t] == r->name) out.push_back({(uint32_t)t, r->start, r->end - r->start, bam.ref_names[t]}); } else out.push_back({(uint32_t)t, 0, bam.ref_lens[t], bam.ref_names[t]}); }
   return out;
 }
 
 struct IdxStats { std::map<int64_t, uint64_t> mapped_by_tid; uint64_t mapped = 0, unmapped = 0; };
-IdxStats idxstats(const BamData& bam, const RegionSpec* region, const BedFilter* bf) {  // IdxStats::new_from_reader (sampling_schedule.rs:649-716)
+IdxStats idxstats(const BamSource& bam, const RegionSpec* region, const BedFilter* bf) {  // IdxStats::new_from_reader (sampling_schedule.rs:649-716)
   IdxStats st; int rt = region ? bam.tid_of(region->name) : -1;
   if (region && rt < 0) throw Error(MKP_E_INVALID, "did not find target_id for region");
-  std::vector<uint64_t> m(bam.ref_names.size(), 0), u(bam.ref_names.size(), 0); uint64_t nocoor = 0;
-  for (auto& r : bam.recs) { if (r.tid < 0) nocoor++; else if (r.flag & 4) u[(size_t)r.tid]++; else m[(size_t)r.tid]++; }
+  std::vector<uint64_t> m, u; uint64_t nocoor = 0;
+  bam.counts(&m, &u, &nocoor);   // the index's per-reference counts (htslib idxstats), or a count over the resident file
   auto keep = [&](int64_t t) { if (region) return t == rt; if (bf) return bf->has_chrom(t); return true; };
   for (size_t t = 0; t < m.size(); t++) if (keep((int64_t)t)) { st.mapped += m[t]; st.unmapped += u[t]; st.mapped_by_tid[(int64_t)t] = m[t]; }
   if (keep(-1)) st.unmapped += nocoor;
   return st;
-}
-
-// records of `tid` overlapping [start,end) in file order (IndexedReader::fetch)
-void fetch(const BamData& bam, uint32_t tid, uint32_t start, uint32_t end, std::vector<size_t>* out) {
-  out->clear();
-  if (tid >= bam.ref_names.size()) return;
-  for (size_t i = bam.tid_first[tid]; i < bam.tid_first[tid + 1] && i < bam.recs.size(); i++) {
-    const BamIndexEntry& e = bam.recs[i];
-    if (e.tid != (int32_t)tid) continue;
-    if ((int64_t)e.pos >= (int64_t)end) break;
-    if ((int64_t)e.end > (int64_t)start) out->push_back(i);
-  }
 }
 
 struct Quota { bool all = false; size_t n = 0; };
@@ -87,7 +82,7 @@ struct Quota { bool all = false; size_t n = 0; };
 // The values are accumulated in the context's HBM-resident sample (mkp_internal_sample_take); nothing but per-read counts
 // comes back to the host.  With --gpus-world W > 1 (full-data mode `-f 1.0` only) a rank walks just its own sampling intervals:
 // a read is taken in the first processed interval it overlaps, so the union over ranks is the single-rank sample.
-void sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
+void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
   if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED, "rank-sharded threshold sampling needs the full-data mode (-f 1.0): the count-based schedule carries quotas from interval to interval");
@@ -124,29 +119,30 @@ void sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const
     mark(bf->pos, 1); mark(bf->neg, 2);
     return bedmasks.emplace(tid, std::move(m)).first->second.data();
   };
-  auto qname = [&](const BamIndexEntry& e) { const uint8_t* c = &bam.raw[e.off]; return std::string((const char*)c + 32, c[8] ? (size_t)c[8] - 1 : 0); };
   // process_records (read_ids_to_base_mod_probs.rs:223-362) over the candidate records, first-N semantics
-  // `skip` (rank-sharded mode): candidates an earlier interval already took
-  auto take = [&](const std::vector<size_t>& cand, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen, const std::vector<uint8_t>* skip = nullptr) -> size_t {
-    size_t used = 0, next = 0, n_reads_out = 0;
-    while (next < cand.size() && (limit < 0 || used < (size_t)limit)) {
-      size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - used));
+  // One fetched batch of an interval: `cand` = indices into batch.recs that pass `candidates`, processed from cand[from] on.
+  // `skip` (rank-sharded mode): candidates an earlier interval already took.  State across calls: used / n_reads_out.
+  struct TakeState { size_t used = 0, n_reads_out = 0; };
+  auto take = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen, TakeState* ts, const std::vector<uint8_t>* skip = nullptr) {
+    size_t next = from;
+    while (next < cand.size() && (limit < 0 || ts->used < (size_t)limit)) {
+      size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - ts->used));
       size_t hi = std::min(cand.size(), next + want);
-      std::vector<mkp_record> recs; for (size_t i = next; i < hi; i++) recs.push_back(bam.view(bam.recs[cand[i]]));
+      std::vector<mkp_record> recs; for (size_t i = next; i < hi; i++) recs.push_back(batch.view(batch.recs[cand[i]]));
       std::vector<uint32_t> nv; uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1;
       int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(), only_mapped, &nv);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       std::vector<uint8_t> mask(recs.size(), 0);
       for (size_t i = next; i < hi; i++) {
-        if (limit >= 0 && used >= (size_t)limit) break;   // RecordSampler::ask -> Done
+        if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
         const size_t k = i - next;
         if (skip && (*skip)[i]) continue;
-        std::string name = qname(bam.recs[cand[i]]);
+        std::string name = batch.qname(batch.recs[cand[i]]);
         // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
         // but keeps no position is asked, not counted, and not recorded
         if (interval_seen->count(name)) continue;
         if (nv[k] == 0) continue;
-        interval_seen->insert(name); used++; n_reads_out++;
+        interval_seen->insert(name); ts->used++; ts->n_reads_out++;
         if (taken.count(name)) continue;  // Moniod::op_mut keeps the first occurrence of a read id
         taken.insert(name);
         mask[k] = 1;
@@ -155,11 +151,10 @@ void sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       next = hi;
     }
-    return n_reads_out;
   };
-  auto candidates = [&](const std::vector<size_t>& in, std::vector<size_t>* out) {
+  auto candidates = [&](const BamBatch& batch, std::vector<size_t>* out) {
     out->clear();
-    for (size_t i : in) { const BamIndexEntry& e = bam.recs[i]; uint32_t lq; memcpy(&lq, &bam.raw[e.off + 16], 4); if ((e.flag & (256 | 1024 | 2048)) || lq == 0) continue; if ((only_mapped || a.edge_filter.size()) && (e.flag & 4)) continue; out->push_back(i); }
+    for (size_t i = 0; i < batch.recs.size(); i++) { const BamIndexEntry& e = batch.recs[i]; if ((e.flag & (256 | 1024 | 2048)) || batch.l_seq(e) == 0) continue; if ((only_mapped || a.edge_filter.size()) && (e.flag & 4)) continue; out->push_back(i); }
   };
   if (!contigs.empty()) {
     // ReferenceIntervalsFeeder over the sampling grid, batch_size super-batches (interval_chunks.rs:563-643)
@@ -192,38 +187,50 @@ void sample_probabilities(mkp_ctx* ctx, const BamData& bam, const Args& a, const
       std::map<uint32_t, size_t> batch_counts;
       for (auto& g : grouped) {  // run_batch (reads_sampler/mod.rs:259-338)
         if (bf && !bf->overlaps(g.iv.tid, g.iv.start, g.iv.end)) continue;
-        std::vector<uint8_t> skip;
         if (sharded) {
           // owner of the interval: contiguous runs of the sampling grid by base pairs (as the pileup shards are dealt)
           const uint64_t mid = contig_base[g.iv.tid] + (g.iv.start - contig_start[g.iv.tid]) + (g.iv.end - g.iv.start) / 2;
           if (std::min<uint64_t>(a.world - 1, mid * a.world / std::max<uint64_t>(grid_bp, 1)) != a.rank) continue;
         }
-        std::vector<size_t> ov, cand; fetch(bam, g.iv.tid, g.iv.start, g.iv.end, &ov); candidates(ov, &cand);
-        if (sharded) {   // a read that reaches back into an earlier processed interval of this contig was taken there
-          skip.assign(cand.size(), 0);
-          for (size_t i = 0; i < cand.size(); i++) {
-            const BamIndexEntry& e = bam.recs[cand[i]];
-            for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && (int64_t)e.pos < s1;) {   // grid intervals before this one, nearest first
-              const int64_t s0 = std::max<int64_t>((int64_t)contig_start[g.iv.tid], s1 - (int64_t)a.sampling_interval_size);
-              if (!bf || bf->overlaps(g.iv.tid, (uint64_t)s0, (uint64_t)s1)) { skip[i] = 1; break; }
-              s1 = s0;
+        // the first-N schedule needs only the head of an interval: fetch a bounded number of records first, everything only if
+        // that was not enough (records already processed are skipped on the second pass)
+        const long limit = g.q.all ? -1 : (long)g.q.n;
+        std::set<std::string> seen; TakeState ts; size_t done = 0;
+        for (int pass = 0; pass < 2; pass++) {
+          const size_t cap = (limit < 0 || pass == 1) ? SIZE_MAX : 16 * (size_t)limit + 4096;
+          BamBatch batch; bam.fetch(g.iv.tid, g.iv.start, g.iv.end, &batch, cap);
+          std::vector<size_t> cand; candidates(batch, &cand);
+          std::vector<uint8_t> skip;
+          if (sharded) {   // a read that reaches back into an earlier processed interval of this contig was taken there
+            skip.assign(cand.size(), 0);
+            for (size_t i = 0; i < cand.size(); i++) {
+              const BamIndexEntry& e = batch.recs[cand[i]];
+              for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && (int64_t)e.pos < s1;) {   // grid intervals before this one, nearest first
+                const int64_t s0 = std::max<int64_t>((int64_t)contig_start[g.iv.tid], s1 - (int64_t)a.sampling_interval_size);
+                if (!bf || bf->overlaps(g.iv.tid, (uint64_t)s0, (uint64_t)s1)) { skip[i] = 1; break; }
+                s1 = s0;
+              }
             }
           }
+          size_t from = 0; while (from < cand.size() && cand[from] < done) from++;
+          take(batch, cand, from, limit, g.iv.tid, true, &seen, &ts, sharded ? &skip : nullptr);
+          const bool truncated = batch.recs.size() >= cap;
+          done = batch.recs.size();
+          if (!truncated || (limit >= 0 && ts.used >= (size_t)limit)) break;
         }
-        std::set<std::string> seen;
-        batch_counts[g.iv.tid] += take(cand, g.q.all ? -1 : (long)g.q.n, g.iv.tid, true, &seen, sharded ? &skip : nullptr);
+        batch_counts[g.iv.tid] += ts.n_reads_out;
       }
       for (auto& kv : batch_counts) sampled_so_far[kv.first] += kv.second;
     }
   }
   if ((sched_unmapped || taken.size() < 100) && !only_mapped && a.rank == 0) {  // reads_sampler/mod.rs:89-125 (rank-sharded: rank 0 takes the unmapped reads)
-    std::vector<size_t> un, cand; for (size_t i = 0; i < bam.recs.size(); i++) if (bam.recs[i].tid < 0) un.push_back(i);
-    candidates(un, &cand);
+    BamBatch batch; bam.fetch_unmapped(&batch);
+    std::vector<size_t> cand; candidates(batch, &cand);
     long limit;
     if (!a.have_frac) limit = (long)(a.num_reads > taken.size() ? a.num_reads - taken.size() : 0);
     else if (a.sampling_frac >= 1.0) limit = -1;
     else { if (!cand.empty()) throw Error(MKP_E_UNSUPPORTED, "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible"); limit = -1; }
-    std::set<std::string> seen; take(cand, limit, 0, false, &seen);
+    std::set<std::string> seen; TakeState ts; take(batch, cand, 0, limit, 0, false, &seen, &ts);
   }
 }
 
@@ -264,7 +271,10 @@ void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) 
 
 int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto t_all = std::chrono::steady_clock::now();
-  BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
+  // BAI next to the BAM: only the blocks of the shards (and sampling intervals) this run touches are read and inflated; otherwise
+  // the whole file is loaded once.  (inflate threads: --threads only steers the sampling schedule)
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())), !a.no_index);
+  const BamSource& bam = *src;
   double load_ms = ms_since(t_all);
   RegionSpec region, sregion; const bool have_region = !a.region.empty(), have_sregion = !a.sample_region.empty();
   if (have_region) region = parse_region(a.region, bam);
@@ -352,28 +362,53 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     return *it->second;
   };
   if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", wr.f);
-  // shard plan: one shard per contig record, or pieces of it cut at interval boundaries; ranks take contiguous runs
+  // ---- shard plan: pieces of the contig records cut at interval boundaries, bounded in positions (tally / focus buffers) and in
+  // BAM bytes (host memory: a shard's blocks are inflated and packed as a unit); ranks take contiguous runs, balanced by the
+  // bytes the index puts under them (by length without an index)
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
-  uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
-  // 2^27 positions per shard keeps the per-shard tally buffer (4 B x (counters + slots) per position, plus halos) at a few GB
-  uint64_t bp_done = 0, positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, focus_ms = 0;
-  for (auto& rec : records) {
-    std::vector<uint8_t> focus; const bool hf = fb.has_focus();
-    auto t_focus = std::chrono::steady_clock::now();
-    std::vector<Interval> ivs = fb.walk(rec, a.interval_size, hf ? &focus : nullptr);
-    focus_ms += ms_since(t_focus);
-    size_t i0 = 0;
-    while (i0 < ivs.size()) {
-      size_t i1 = i0; uint64_t bp = 0; while (i1 < ivs.size() && (bp == 0 || bp + (ivs[i1].end - ivs[i1].start) <= shard_bp)) { bp += ivs[i1].end - ivs[i1].start; i1++; }
-      const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
-      const uint64_t mid = bp_done + bp / 2; bp_done += bp;
-      const uint32_t owner = total_bp ? (uint32_t)std::min<uint64_t>(a.world - 1, mid * a.world / total_bp) : 0;
-      i0 = i1;
-      if (owner != a.rank) continue;
+  const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
+  // 2^27 positions per shard keeps the per-shard focus / slot buffers small
+  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; };
+  std::vector<ShardPlan> plan; std::vector<std::vector<uint8_t>> focus_of(records.size()); std::vector<char> focus_done(records.size(), 0);
+  const bool hf = fb.has_focus();
+  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, focus_ms = 0, fetch_wait_ms = 0;
+  {
+    const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid, records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
+    for (size_t ri = 0; ri < records.size(); ri++) {
+      const Contig& rec = records[ri];
+      auto t_focus = std::chrono::steady_clock::now();
+      // the grid; with one rank the focus bytes are filled in the same walk, otherwise only for the contigs this rank owns (below)
+      std::vector<Interval> ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr);
+      if (hf && a.world == 1) focus_done[ri] = 1;
+      focus_ms += ms_since(t_focus);
+      size_t i0 = 0;
+      while (i0 < ivs.size()) {
+        size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
+        while (i1 < ivs.size() && (bp == 0 || (bp + (ivs[i1].end - ivs[i1].start) <= shard_bp && (!bam.indexed() || bam.offset_at(rec.tid, ivs[i1].end) - o0 <= a.shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
+        const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
+        const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
+        const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
+        i0 = i1;
+        if (owner == a.rank) plan.push_back({ri, s0, s1, bp});
+      }
+    }
+  }
+  auto fetch_shard = [&](const ShardPlan& sp) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(records[sp.rec].tid, sp.s0 > MKP_HALO ? sp.s0 - MKP_HALO : 0, sp.s1 + MKP_HALO, b.get()); return b; };
+  // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
+  std::future<std::unique_ptr<BamBatch>> next_batch;
+  if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]);
+  for (size_t pi = 0; pi < plan.size(); pi++) {
+    const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
+    std::unique_ptr<BamBatch> batch;
+    { auto t_f = std::chrono::steady_clock::now(); batch = next_batch.get(); fetch_wait_ms += ms_since(t_f); }
+    if (pi + 1 < plan.size()) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
+    if (hf && !focus_done[sp.rec]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(rec, a.interval_size, &focus_of[sp.rec]); focus_done[sp.rec] = 1; focus_ms += ms_since(t_focus); }
+    if (sp.rec > 0 && (pi == 0 || plan[pi - 1].rec != sp.rec)) for (size_t r2 = 0; r2 < sp.rec; r2++) { std::vector<uint8_t>().swap(focus_of[r2]); }   // earlier contigs are done
+    const std::vector<uint8_t>& focus = focus_of[sp.rec];
+    std::vector<mkp_record> recs; recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e));
+    {
       if (a.plan_only) {  // host-only dry run: the shard plan, plus the packer over the shard's records (no device)
-        std::vector<size_t> ov; fetch(bam, rec.tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, &ov);
         Packer pk; ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1;
-        std::vector<mkp_record> recs; recs.reserve(ov.size()); for (size_t i : ov) recs.push_back(bam.view(bam.recs[i]));
         const int32_t tid = (int32_t)rec.tid;
         // --plan-pack-min N: records from which the packer runs on all cores (0 = always; default as in mkp_shard_add_records)
         pack_records(pk, S, recs.data(), (uint32_t)recs.size(), [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); }, a.plan_pack_min);
@@ -388,9 +423,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
       must(mkp_shard_begin(ctx, &sh));
-      std::vector<size_t> ov; fetch(bam, rec.tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, &ov);
-      std::vector<mkp_record> recs; recs.reserve(ov.size()); for (size_t i : ov) recs.push_back(bam.view(bam.recs[i]));
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
+      batch.reset();   // packed: the inflated blocks are no longer needed
       mkp_rows rows; must(mkp_shard_run(ctx, &rows));
       if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, &rows));   // measurement aid: warm, averaged kernel times in --stats
       { auto t_w = std::chrono::steady_clock::now();
@@ -409,6 +443,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
+  load_ms += fetch_wait_ms;   // what the shard loop waited for blocks to be read and inflated (the rest overlapped with pack / run / write)
   { auto t_w = std::chrono::steady_clock::now(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f); } write_ms += ms_since(t_w); }
   if (wr.f && wr.f != stdout) fclose(wr.f);
   if (rep) {
@@ -417,8 +452,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     rep->total_ms = ms_since(t_all); rep->n_rows = wr.n; rep->n_positions = positions; rep->n_shards = n_shards; rep->processed_records = processed; rep->skipped_records = skipped;
     for (int b = 0; b < 4; b++) { rep->threshold[b] = kc.per_base_threshold[b]; rep->has_threshold[b] = kc.has_per_base[b]; }
   }
-  if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f total_ms=%.1f\n",
-                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, ms_since(t_all));
+  if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu peak_rss_kb=%llu\n",
+                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
+                       (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)peak_rss_kb());
   return MKP_OK;
 }
 
@@ -442,7 +478,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
     else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
     else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
-    else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val()); else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
+    else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val()); else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--shard-bytes") a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); else if (s == "--no-index") a.no_index = true; else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
     else if (s == "--bedgraph") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
@@ -483,7 +519,8 @@ namespace {
 // the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
 void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out) {
   Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
-  BamData bam = load_bam(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())));   // inflate threads: --threads only steers the sampling schedule
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())), !a.no_index);   // inflate threads: --threads only steers the sampling schedule
+  const BamSource& bam = *src;
   RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
   if (hr) region = parse_region(a.region, bam);
   if (hs) sregion = parse_region(a.sample_region, bam);
@@ -529,10 +566,10 @@ extern "C" int mkp_histogram_add_bam(mkp_ctx* ctx, const char* bam_path, int arg
 extern "C" int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shard, mkp_rows* out) {
   if (!ctx || !bam_path || !shard || !out) return MKP_E_INVALID;
   try {
-    BamData bam = load_bam(bam_path);
+    std::unique_ptr<BamSource> src = BamSource::open(bam_path, 0);
     int rc = mkp_shard_begin(ctx, shard); if (rc != MKP_OK) return rc;
-    std::vector<size_t> ov; fetch(bam, (uint32_t)shard->tid, shard->start > MKP_HALO ? shard->start - MKP_HALO : 0, shard->end + MKP_HALO, &ov);
-    std::vector<mkp_record> recs; for (size_t i : ov) recs.push_back(bam.view(bam.recs[i]));
+    BamBatch batch; src->fetch((uint32_t)shard->tid, shard->start > MKP_HALO ? shard->start - MKP_HALO : 0, shard->end + MKP_HALO, &batch);
+    std::vector<mkp_record> recs; for (auto& e : batch.recs) recs.push_back(batch.view(e));
     rc = mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()); if (rc != MKP_OK) return rc;
     return mkp_shard_run(ctx, out);
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }

@@ -146,13 +146,51 @@ class FocusBuilder {
   // indexed from rec.start) when non-null.
   std::vector<Interval> walk(const Contig& rec, uint32_t interval_size, std::vector<uint8_t>* focus) {
     std::vector<Interval> ivs;
+    if (interval_size == 0) throw Error(MKP_E_INVALID, "interval size must be positive");
     if (focus) focus->assign(rec.length, 0);
     const std::string* seq = nullptr; std::string upper;
     if (!motifs.empty()) {
       seq = fasta->get(rec.name);
       if (!seq) throw Error(MKP_E_IO, "contig " + rec.name + " missing from reference FASTA");
       if (rec.end() > seq->size()) throw Error(MKP_E_IO, "contig " + rec.name + " shorter in FASTA than in the BAM header");
-      if (!mask) { upper.resize(rec.end()); for (size_t i = rec.start; i < rec.end(); i++) upper[i] = (char)toupper((unsigned char)(*seq)[i]); seq = &upper; }
+      if (!mask) {
+        upper.resize(rec.end());
+        parallel_ranges(rec.start, rec.end(), 1u << 22, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) upper[i] = (char)toupper((unsigned char)(*seq)[i]); });
+        seq = &upper;
+      }
+    }
+    if (!motifs.empty() && !combine) {
+      // Without strand combining the grid is fixed (start + k * interval_size) and every interval's motif hits depend on its own
+      // slice of the reference only: intervals are filled by all host cores, each block of intervals with its own motif-id
+      // combo table; the tables are then interned into the shared one in interval order (the ids a sequential walk would give)
+      // and a block whose local ids differ has its bytes renumbered.
+      for (uint32_t pos = rec.start; pos < rec.end();) { const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end()); ivs.push_back({rec.tid, pos, end}); pos = end; }
+      if (focus) {
+        const size_t per_block = std::max<size_t>(1, (4u << 20) / interval_size), n_blocks = (ivs.size() + per_block - 1) / per_block;
+        std::vector<FocusBuilder> local(n_blocks);
+        std::vector<std::unique_ptr<Error>> errs(n_blocks);
+        parallel_ranges(0, n_blocks, 1, [&](uint64_t b0, uint64_t b1) {
+          for (uint64_t b = b0; b < b1; b++) {
+            FocusBuilder& L = local[b]; L.fasta = fasta; L.mask = mask; L.motifs = motifs; L.bed = bed; L.combine = false;
+            try {
+              for (size_t k = b * per_block; k < std::min(ivs.size(), (b + 1) * per_block); k++) {
+                std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
+                for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + ivs[k].start, ivs[k].end - ivs[k].start, motifs[i], ivs[k].start, rec.tid, bed, &locs[i]);
+                L.fill_motif(locs, rec, ivs[k].start, ivs[k].end, focus);
+              }
+            } catch (const Error& e) { errs[b].reset(new Error(e)); }
+          }
+        });
+        for (size_t b = 0; b < n_blocks; b++) {
+          if (errs[b]) throw *errs[b];
+          std::vector<uint8_t> remap(local[b].combos.size(), 0); bool identity = true;
+          for (size_t i = 1; i < local[b].combos.size(); i++) { remap[i] = combo_id(local[b].combos[i]); identity = identity && remap[i] == i; }
+          if (identity) continue;
+          const size_t k0 = b * per_block, k1 = std::min(ivs.size(), (b + 1) * per_block);
+          for (uint64_t p = ivs[k0].start; p < ivs[k1 - 1].end; p++) { uint8_t& f = (*focus)[p - rec.start]; if (f >> 2) f = (uint8_t)((f & 3u) | (remap[f >> 2] << 2)); }
+        }
+      }
+      return ivs;
     }
     size_t longest = 0; for (auto& m : motifs) longest = std::max(longest, m.len());
     uint32_t pos = rec.start;
@@ -160,9 +198,7 @@ class FocusBuilder {
       uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end());
       if (!motifs.empty()) {
         std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
-        if (!combine) {
-          for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + pos, end - pos, motifs[i], pos, rec.tid, bed, &locs[i]);
-        } else {  // get_motif_positions_combine_strands (fasta.rs:92-188)
+        {  // get_motif_positions_combine_strands (fasta.rs:92-188): the interval end moves past a motif hit that straddles it
           uint64_t ref_end = rec.end(), buffer = longest * 5, e = end, end_w = std::min<uint64_t>((uint64_t)end + buffer, ref_end);
           for (;;) {
             if (end_w > seq->size()) throw Error(MKP_E_UNSUPPORTED, "motif run reaches past the contig end while extending an interval (the reference never terminates here)");
@@ -188,6 +224,16 @@ class FocusBuilder {
       pos = end;
     }
     return ivs;
+  }
+
+  template <class F> static void parallel_ranges(uint64_t lo, uint64_t hi, uint64_t grain, F f) {   // f(a, b) over [lo, hi) on all host cores
+    const uint64_t n = hi > lo ? hi - lo : 0, pieces = (n + grain - 1) / std::max<uint64_t>(grain, 1);
+    const unsigned n_thr = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), std::max<uint64_t>(pieces, 1));
+    if (n_thr <= 1) { if (n) f(lo, hi); return; }
+    std::atomic<uint64_t> next{0}; std::vector<std::thread> th;
+    auto work = [&]() { for (;;) { const uint64_t i = next.fetch_add(1); if (i >= pieces) break; f(lo + i * grain, std::min(hi, lo + (i + 1) * grain)); } };
+    for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work);
+    work(); for (auto& x : th) x.join();
   }
 
  private:

@@ -1,0 +1,87 @@
+"""Host ingest without a device (`--plan-only`): the BAI-indexed, bounded reader (mkp_bam.hpp: BaiIndex / BamSource) against the
+whole-file loader — same shard plan and the same packed bytes (digest) on the reference's fixtures (indexes written by samtools)
+and on generated BAMs (index written by tools/gen_modbam); peak memory that follows the shard, not the file; and a 2-rank plan in
+which each rank reads about half of the file."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+import modkit_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIX = os.path.join(ROOT, "tests", "golden", "modkit_fixtures")
+CLI = os.path.join(ROOT, "modkit_amd", "csrc", "mkpileup")
+
+
+def gen(tmp, name, contigs, reads, extra=()):
+    tool = os.path.join(ROOT, "tools", "gen_modbam")
+    if not os.path.exists(tool):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+    prefix = os.path.join(str(tmp), name)
+    args = [tool, "--out", prefix, "--reads", str(reads), "--seed", "5", "--style", "hm"] + list(extra)
+    for c in contigs:
+        args += ["--contig", "%s:%d" % c]
+    json.loads(subprocess.check_output(args).decode())
+    return prefix + ".bam", prefix + ".fa"
+
+
+def plan(bam, flags, out):
+    """runs the CLI; returns (plan text, stats dict from the --stats line, peak RSS of that process in KiB)"""
+    modkit_amd.build()
+    p = subprocess.run([CLI, "pileup", bam, out, "--plan-only", "--stats"] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    st = {k: int(v) for k, v in re.findall(r"(\w+)=(\d+)(?=\s|$)", p.stderr)}
+    return open(out).read(), st, st["peak_rss_kb"]
+
+
+@pytest.mark.parametrize("bam,flags", [
+    ("bc_anchored_10_reads.sorted.bam", ["-i", "25"]),
+    ("bc_anchored_10_reads.sorted.bam", ["--cpg", "--ref", os.path.join(FIX, "CGI_ladder_3.6kb_ref.fa"), "--region", "oligo_1512_adapters:10-120"]),
+    ("duplex_modbam.sorted.bam", ["--region", "chr17"]),
+    ("HG002_small.ch20._other.sorted.bam", []),
+    ("bc_anchored_10_reads.haplotyped.sorted.bam", []),
+])
+def test_indexed_fetch_equals_whole_file_on_reference_fixtures(tmp_path, bam, flags):
+    a, sa, _ = plan(os.path.join(FIX, bam), flags, str(tmp_path / "a.tsv"))
+    b, sb, _ = plan(os.path.join(FIX, bam), flags + ["--no-index"], str(tmp_path / "b.tsv"))
+    assert a == b and a
+    assert sa["indexed"] == 1 and sb["indexed"] == 0
+
+
+def test_indexed_fetch_equals_whole_file_on_generated_bam(tmp_path):
+    bam, fa = gen(tmp_path, "g", [("chrA", 700_000), ("chrB", 300_000), ("chrC", 120_000)], 6_000, ["--mean-len", "5000"])
+    for flags in ([], ["--shard-bp", "100000"], ["--cpg", "--ref", fa, "--shard-bp", "250000"], ["--region", "chrB:100000-250000"]):
+        a, sa, _ = plan(bam, flags, str(tmp_path / "a.tsv"))
+        b, sb, _ = plan(bam, flags + ["--no-index"], str(tmp_path / "b.tsv"))
+        assert a == b and a, flags
+        assert sa["indexed"] == 1 and sa["bam_bytes_read"] > 0 and sb["bam_bytes_read"] == 0
+
+
+def test_peak_memory_follows_the_shard_not_the_file(tmp_path):
+    # the same contig shape once and eight times over: with the index the peak RSS stays put, without it it grows with the file
+    one, _ = gen(tmp_path, "one", [("c0", 400_000)], 8_000, ["--mean-len", "5000"])
+    many, _ = gen(tmp_path, "many", [("c%d" % i, 400_000) for i in range(8)], 64_000, ["--mean-len", "5000"])
+    assert os.path.getsize(many) > 6 * os.path.getsize(one)
+    _, s1, rss_one = plan(one, [], str(tmp_path / "p1.tsv"))
+    t8, s8, rss_many = plan(many, [], str(tmp_path / "p8.tsv"))
+    _, s8w, rss_many_whole = plan(many, ["--no-index"], str(tmp_path / "p8w.tsv"))
+    assert len(t8.splitlines()) == 8 and s8["bam_bytes_inflated"] > 6 * s1["bam_bytes_inflated"]
+    assert rss_many < 1.6 * rss_one + 65536, (rss_one, rss_many)             # two shards' worth in flight (double buffering), not eight
+    assert rss_many_whole > 1.7 * rss_many, (rss_many, rss_many_whole)      # the whole-file loader holds everything
+
+
+def test_two_ranks_each_read_about_half_of_the_file(tmp_path):
+    bam, _ = gen(tmp_path, "r2", [("c%d" % i, 300_000) for i in range(6)], 18_000, ["--mean-len", "4000"])
+    whole, s, _ = plan(bam, ["--shard-bp", "100000"], str(tmp_path / "w.tsv"))
+    parts, reads = [], []
+    for r in range(2):
+        t, st, _ = plan(bam, ["--shard-bp", "100000", "--gpus-rank", str(r), "--gpus-world", "2"], str(tmp_path / ("r%d.tsv" % r)))
+        parts.append(t)
+        reads.append(st["bam_bytes_read"])
+    assert "".join(parts) == whole                                           # contiguous runs, in order, nothing lost
+    size = os.path.getsize(bam)
+    assert all(0.3 * size < x < 0.7 * size for x in reads), (size, reads)   # balanced by the bytes the index puts under each run
+    assert sum(reads) < 1.25 * s["bam_bytes_read"]
