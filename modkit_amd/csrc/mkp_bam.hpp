@@ -370,8 +370,24 @@ class BamSource {
     bytes_read += n;
   }
   struct Blk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
+  // a read-only view of file bytes [off, off + n): mapped (no copy out of the page cache), page-aligned underneath
+  struct Window {
+    const uint8_t* p = nullptr; size_t n = 0; void* map = nullptr; size_t map_len = 0;
+    Window() = default; Window(const Window&) = delete; Window& operator=(const Window&) = delete;
+    ~Window() { if (map) munmap(map, map_len); }
+    size_t size() const { return n; }
+    const uint8_t& operator[](size_t i) const { return p[i]; }
+  };
+  void map_window(uint64_t off, size_t n, Window* w) const {
+    const uint64_t page = 4096, a0 = off & ~(page - 1);
+    w->map_len = (size_t)(off - a0) + n;
+    w->map = mmap(nullptr, w->map_len, PROT_READ, MAP_PRIVATE, fd_, (off_t)a0);
+    if (w->map == MAP_FAILED) { w->map = nullptr; throw Error(MKP_E_IO, "cannot map " + path_); }
+    madvise(w->map, w->map_len, MADV_WILLNEED);
+    w->p = (const uint8_t*)w->map + (off - a0); w->n = n; bytes_read += n;
+  }
   // BGZF block at compressed offset `coff` inside buf (which starts at file offset buf_off): sizes from its header / trailer
-  bool block_at(const std::vector<uint8_t>& buf, uint64_t buf_off, uint64_t coff, Blk* b) const {
+  template <class Buf> bool block_at(const Buf& buf, uint64_t buf_off, uint64_t coff, Blk* b) const {
     const size_t o = (size_t)(coff - buf_off);
     if (o + 18 > buf.size()) return false;
     if (buf[o] != 31 || buf[o + 1] != 139 || !(buf[o + 3] & 4)) throw Error(MKP_E_IO, "not BGZF: " + path_);
@@ -421,11 +437,11 @@ class BamSource {
       uint64_t cb = chunks[ci].beg >> 16; const uint64_t ce = chunks[ci].end >> 16, ue = chunks[ci].end & 0xffff; uint32_t ub = (uint32_t)(chunks[ci].beg & 0xffff);
       // a bounded window of compressed bytes at a time (a chunk may be the whole contig): 64 MiB, or — when the caller wants only
       // the first records of the region — 4 MiB growing to that
-      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (4u << 20);
+      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (1u << 20);
       while (cb < fsize_ && (cb < ce || (cb == ce && ue > 0)) && !stop) {
         const uint64_t want_end = std::min<uint64_t>(fsize_, std::min<uint64_t>(ce + (1u << 16) + 64, cb + window));
         window = std::min<uint64_t>(window * 2, 64u << 20);
-        std::vector<uint8_t> buf((size_t)(want_end - cb)); pread_all(cb, buf.data(), buf.size());
+        Window buf; map_window(cb, (size_t)(want_end - cb), &buf);
         std::vector<Blk> blks; uint64_t c = cb, dtotal = 0;
         for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; b.doff = dtotal; dtotal += b.isize; blks.push_back(b); c += b.hdr + b.clen + 8; }
         if (blks.empty()) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);

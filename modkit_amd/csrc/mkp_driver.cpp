@@ -185,20 +185,34 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       }
       if (have_slack) { Quota q; q.n = slack_n; grouped.push_back({slack, q}); }
       std::map<uint32_t, size_t> batch_counts;
-      for (auto& g : grouped) {  // run_batch (reads_sampler/mod.rs:259-338)
+      // intervals this rank samples, in order; the head of the next one is fetched while the current one is decoded
+      std::vector<size_t> mine;
+      for (size_t gi = 0; gi < grouped.size(); gi++) {
+        const G& g = grouped[gi];
         if (bf && !bf->overlaps(g.iv.tid, g.iv.start, g.iv.end)) continue;
         if (sharded) {
           // owner of the interval: contiguous runs of the sampling grid by base pairs (as the pileup shards are dealt)
           const uint64_t mid = contig_base[g.iv.tid] + (g.iv.start - contig_start[g.iv.tid]) + (g.iv.end - g.iv.start) / 2;
           if (std::min<uint64_t>(a.world - 1, mid * a.world / std::max<uint64_t>(grid_bp, 1)) != a.rank) continue;
         }
+        mine.push_back(gi);
+      }
+      auto cap_of = [&](const G& g) { return g.q.all ? SIZE_MAX : 2 * g.q.n + 128; };
+      auto head_of = [&](size_t gi) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, b.get(), cap_of(grouped[gi])); return b; };
+      std::future<std::unique_ptr<BamBatch>> next_head;
+      if (!mine.empty()) next_head = std::async(std::launch::async, head_of, mine[0]);
+      for (size_t mi = 0; mi < mine.size(); mi++) {  // run_batch (reads_sampler/mod.rs:259-338)
+        const G& g = grouped[mine[mi]];
+        std::unique_ptr<BamBatch> head = next_head.get();
+        if (mi + 1 < mine.size()) next_head = std::async(std::launch::async, head_of, mine[mi + 1]);
         // the first-N schedule needs only the head of an interval: fetch a bounded number of records first, everything only if
         // that was not enough (records already processed are skipped on the second pass)
         const long limit = g.q.all ? -1 : (long)g.q.n;
         std::set<std::string> seen; TakeState ts; size_t done = 0;
         for (int pass = 0; pass < 2; pass++) {
-          const size_t cap = (limit < 0 || pass == 1) ? SIZE_MAX : 16 * (size_t)limit + 4096;
-          BamBatch batch; bam.fetch(g.iv.tid, g.iv.start, g.iv.end, &batch, cap);
+          const size_t cap = pass == 0 ? cap_of(g) : SIZE_MAX;
+          BamBatch whole; if (pass == 1) bam.fetch(g.iv.tid, g.iv.start, g.iv.end, &whole, cap);
+          const BamBatch& batch = pass == 0 ? *head : whole;
           std::vector<size_t> cand; candidates(batch, &cand);
           std::vector<uint8_t> skip;
           if (sharded) {   // a read that reaches back into an earlier processed interval of this contig was taken there
@@ -273,7 +287,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto t_all = std::chrono::steady_clock::now();
   // BAI next to the BAM: only the blocks of the shards (and sampling intervals) this run touches are read and inflated; otherwise
   // the whole file is loaded once.  (inflate threads: --threads only steers the sampling schedule)
-  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())), !a.no_index);
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(64u, std::thread::hardware_concurrency())), !a.no_index);
   const BamSource& bam = *src;
   double load_ms = ms_since(t_all);
   RegionSpec region, sregion; const bool have_region = !a.region.empty(), have_sregion = !a.sample_region.empty();

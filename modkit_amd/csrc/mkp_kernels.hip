@@ -1508,12 +1508,14 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
 // the rows of FeatureVector::decode (412-446) / add_tally_to_counts (283-410) / combine_strand_features (469-561) are produced
 // straight from LDS: counted, reserved in the row buffer with one atomic per tile, written.  mkp_scan_tiles / mkp_gather_rows
 // put the tiles' row runs in genome order.
-template <bool FOCUS, int UNROLL>
+template <bool FOCUS, int UNROLL, bool KEYED>
 __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles,
                  const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos,
                  uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
-                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_filter, uint32_t key_slot) {
+                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_arg) {
+  // --partition-tag (KEYED kernels): low 16 bits = the key this pass tallies, high 16 bits = index of the pass; otherwise unused
+  const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = KEYED ? (key_arg >> 16) : 0u;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
@@ -1604,7 +1606,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
     if (rid >= rid_end) break;
     const MkpReadHdr h = hdrs[rid];
     if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
-    if (key_filter != MKP_NO_KEY_FILTER && (h.flags >> MKP_RF_KEY_SHIFT) != key_filter) continue;   // --partition-tag: one pass per key
+    if (KEYED && (h.flags >> MKP_RF_KEY_SHIFT) != key_filter) continue;   // --partition-tag: one pass per key
     // the read's slot range in this tile; a read that covers no slot leaves nothing here
     const int32_t span_a = max(h.ref_start, T0h), span_b = min(h.ref_end, T1h);
     const uint32_t rs_a = sm.rank(span_a), rs_b = sm.rank(span_b);
@@ -1787,7 +1789,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __syncthreads();
   // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
   // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
-  emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, key_slot * n_tiles + tix, key_filter == MKP_NO_KEY_FILTER ? 0u : key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
   }
 }
 
@@ -1795,12 +1797,15 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles, \
                  const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, \
                  uint32_t* __restrict__ rows_base /* 11 SoA arrays of row_capacity entries */, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, \
-                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_filter /* partition key to tally, or MKP_NO_KEY_FILTER */, uint32_t key_slot /* index of this key pass */
-#define PILEUP_PASS hdrs, cigar, seqs, events, readout, tiles, n_tiles, prmp, slotbm, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, chunk_pfx, dev_err, key_filter, key_slot
+                 const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_arg /* KEYED kernels: partition key to tally | index of this key pass << 16 */
+#define PILEUP_PASS hdrs, cigar, seqs, events, readout, tiles, n_tiles, prmp, slotbm, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, chunk_pfx, dev_err, key_arg
 // every position owns a tally column (no focus positions): the dense walk, 4 windows of 64 positions in flight
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles(PILEUP_PARAMS) { pileup_tiles_body<false, 4>(PILEUP_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles(PILEUP_PARAMS) { pileup_tiles_body<false, 4, false>(PILEUP_PASS); }
 // focus positions only (--cpg / --motif / --include-bed): tally columns, events and the depth walk are restricted to them
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus(PILEUP_PARAMS) { pileup_tiles_body<true, 1>(PILEUP_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false>(PILEUP_PASS); }
+// --partition-tag: the same two kernels tallying only the reads of one partition key per launch
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_keyed(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus_keyed(PILEUP_PARAMS) { pileup_tiles_body<true, 1, true>(PILEUP_PASS); }
 
 // ----------------------------------------------------------------------------------------------
 // Order the per-tile row runs by tile index.  Block 0 computes the exclusive scan of the
@@ -1933,9 +1938,11 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
 
 // per device: both accumulate kernels may use the whole per-workgroup LDS budget the host planned for
 extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
-  hipError_t e = hipFuncSetAttribute((const void*)mkp_pileup_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)mkp_pileup_tiles_focus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
+  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_focus, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_focus_keyed}) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int focus_mode, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
@@ -1943,13 +1950,13 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int 
                                         const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
                                         uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot) {
   if (!n_tiles) return hipSuccess;
+  const bool keyed = key_filter != MKP_NO_KEY_FILTER;
+  const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
   const uint32_t grid = n_tiles;   // one workgroup per tile
-  if (focus_mode)
-    hipLaunchKernelGGL(mkp_pileup_tiles_focus, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
-                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_filter, key_slot);
-  else
-    hipLaunchKernelGGL(mkp_pileup_tiles, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos,
-                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_filter, key_slot);
+#define MKP_PILEUP_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos, \
+                       row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_arg)
+  if (focus_mode) { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus); }
+  else { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles); }
   return hipGetLastError();
 }
 

@@ -61,16 +61,17 @@ def test_indexed_fetch_equals_whole_file_on_generated_bam(tmp_path):
 
 
 def test_peak_memory_follows_the_shard_not_the_file(tmp_path):
-    # the same contig shape once and eight times over: with the index the peak RSS stays put, without it it grows with the file
-    one, _ = gen(tmp_path, "one", [("c0", 400_000)], 8_000, ["--mean-len", "5000"])
-    many, _ = gen(tmp_path, "many", [("c%d" % i, 400_000) for i in range(8)], 64_000, ["--mean-len", "5000"])
-    assert os.path.getsize(many) > 6 * os.path.getsize(one)
-    _, s1, rss_one = plan(one, [], str(tmp_path / "p1.tsv"))
-    t8, s8, rss_many = plan(many, [], str(tmp_path / "p8.tsv"))
-    _, s8w, rss_many_whole = plan(many, ["--no-index"], str(tmp_path / "p8w.tsv"))
-    assert len(t8.splitlines()) == 8 and s8["bam_bytes_inflated"] > 6 * s1["bam_bytes_inflated"]
-    assert rss_many < 1.6 * rss_one + 65536, (rss_one, rss_many)             # two shards' worth in flight (double buffering), not eight
-    assert rss_many_whole > 1.7 * rss_many, (rss_many, rss_many_whole)      # the whole-file loader holds everything
+    # the same contig shape three times and twelve times over (one shard per contig; two shards are in flight at any time: the next
+    # one is fetched while the current one is packed): with the index the peak RSS stays put, without it it grows with the file
+    few, _ = gen(tmp_path, "few", [("c%d" % i, 400_000) for i in range(3)], 24_000, ["--mean-len", "5000"])
+    many, _ = gen(tmp_path, "many", [("c%d" % i, 400_000) for i in range(12)], 96_000, ["--mean-len", "5000"])
+    assert os.path.getsize(many) > 3.5 * os.path.getsize(few)
+    t3, s3, rss_few = plan(few, [], str(tmp_path / "p3.tsv"))
+    t12, s12, rss_many = plan(many, [], str(tmp_path / "p12.tsv"))
+    _, s12w, rss_many_whole = plan(many, ["--no-index"], str(tmp_path / "p12w.tsv"))
+    assert len(t3.splitlines()) == 3 and len(t12.splitlines()) == 12 and s12["bam_bytes_inflated"] > 3.5 * s3["bam_bytes_inflated"]
+    assert rss_many < 1.3 * rss_few + 32768, (rss_few, rss_many)
+    assert rss_many_whole > 2.0 * rss_many, (rss_many, rss_many_whole)      # the whole-file loader holds everything
 
 
 def test_two_ranks_each_read_about_half_of_the_file(tmp_path):
