@@ -130,7 +130,7 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
     uint16_t xlen; memcpy(&xlen, &comp[o + 10], 2);
     size_t x = o + 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
     if (xe > comp.size()) throw Error(MKP_E_IO, "bad BGZF block in " + path);
-    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &comp[x + 2], 2); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2) { uint16_t b; memcpy(&b, &comp[x + 4], 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + sl; }
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &comp[x + 2], 2); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b; memcpy(&b, &comp[x + 4], 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (size_t)sl; }
     if (!found || o + bsize > comp.size() || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path);
     uint32_t isize; memcpy(&isize, &comp[o + bsize - 4], 4);
     blks.push_back({o + 12 + xlen, bsize - xlen - 20, dtotal, isize});
@@ -146,10 +146,15 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
   auto need = [&](size_t n) { if (o + n > d.size()) throw Error(MKP_E_IO, "truncated BAM " + path); };
   need(12);
   if (memcmp(&d[0], "BAM\1", 4) != 0) throw Error(MKP_E_IO, "not a BAM file: " + path);
-  int32_t l_text; memcpy(&l_text, &d[4], 4); o = 8; need((size_t)l_text + 4); o += (size_t)l_text;
+  int32_t l_text; memcpy(&l_text, &d[4], 4); o = 8;
+  if (l_text < 0) throw Error(MKP_E_IO, "corrupt BAM header: negative text length");
+  need((size_t)l_text + 4); o += (size_t)l_text;
   int32_t n_ref; memcpy(&n_ref, &d[o], 4); o += 4;
+  if (n_ref < 0) throw Error(MKP_E_IO, "corrupt BAM header: negative reference count");
   for (int i = 0; i < n_ref; i++) {
-    need(4); int32_t ln; memcpy(&ln, &d[o], 4); o += 4; need((size_t)ln + 4);
+    need(4); int32_t ln; memcpy(&ln, &d[o], 4); o += 4;
+    if (ln <= 0) throw Error(MKP_E_IO, "corrupt BAM header: reference name length");
+    need((size_t)ln + 4);
     bd.ref_names.push_back(std::string((const char*)&d[o], ln > 0 ? (size_t)ln - 1 : 0)); o += (size_t)ln;
     uint32_t lr; memcpy(&lr, &d[o], 4); o += 4; bd.ref_lens.push_back(lr);
   }
@@ -163,6 +168,9 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
     if (lseq < 0 || (uint64_t)32 + lq + 4ull * nc + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) throw Error(MKP_E_IO, "corrupt BAM record");
     if (e.tid < -1 || e.tid >= n_ref || e.pos < -1 || e.pos >= 0x7ffffff0) throw Error(MKP_E_IO, "corrupt BAM record: reference id or position out of range");
     e.reflen = 0; e.end = e.pos + 1;
+    // fetches assume a coordinate-sorted file (reference ids ascending, unplaced records last, positions ascending inside a reference)
+    if (!bd.recs.empty()) { const BamIndexEntry& q = bd.recs.back(); const uint32_t ta = (uint32_t)q.tid, tb = (uint32_t)e.tid;   // -1 sorts last as unsigned
+      if (tb < ta || (tb == ta && e.tid >= 0 && e.pos < q.pos)) throw Error(MKP_E_INVALID, "the BAM is not coordinate sorted: " + path); }
     bd.recs.push_back(e); o += (size_t)bs;
   }
   {  // reference spans (bam_endpos): CIGAR walks, all cores
