@@ -223,8 +223,10 @@ def main():
         kernels = {"mkp_decode_*": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
         if st.rows_kernel_ms > 0:
             kernels["mkp_emit_rows"] = (st.rows_kernel_ms, st.alg_bytes_rows)
-        # the roofline is reported for the aggregation kernel (north_star's target), whichever kernel is slowest
+        # the roofline is reported for the aggregation kernel (north_star's target), whichever kernel is slowest; its name in the
+        # rocprof summaries: mkp_pileup_tiles_focus for runs with focus positions (--cpg), mkp_pileup_tiles otherwise
         dom = "mkp_pileup_tiles"
+        dom_kernel = "mkp_pileup_tiles_focus" if needs_ref else "mkp_pileup_tiles"
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         slowest = max(kernels, key=lambda k: kernels[k][0])
@@ -233,7 +235,9 @@ def main():
             tail = ["--workload", a.workload, "--scale", str(a.scale), "--no-cpu-baseline", "--no-pmc"]
             traffic_all, traffic_src = pmc_traffic(tail)
             if traffic_all:
-                traffic = traffic_all.get(dom)
+                traffic = traffic_all.get(dom_kernel)
+                traffic_all["mkp_pileup_tiles"] = traffic
+                traffic_all["mkp_decode_*"] = sum(v for k, v in traffic_all.items() if k.startswith("mkp_decode_")) or None
         dev_ms = rep.pack_ms + rep.h2d_ms + rep.kernel_ms + rep.d2h_ms
         result = {
             "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": total_positions * a.steps / elapsed, "unit": "positions/s",
@@ -257,7 +261,7 @@ def main():
                                              "d2h": rep.d2h_ms, "bedmethyl_text_write": rep.write_ms},
                                "what": "rank 0: mkp_pileup_run wall (`modkit pileup in.bam out.bed` with the workload's flags), page cache warm"},
             },
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -271,6 +275,11 @@ def main():
             base["bedmethyl_sha256_equal"] = sh256(dbed) == sh256(obed)
             base["bedmethyl_sha256"] = sh256(dbed)
             base["speedup_end_to_end"] = (rep.n_positions / (rep.total_ms * 1e-3)) / base["end_to_end"]["positions_per_s"] if not region else None
+            if (os.cpu_count() or 1) > 8:   # the same run on more of this box's cores (the reference's --threads is the user's choice)
+                w2 = min(os.cpu_count(), 32)
+                _, _, b2 = cpu_baseline(bam, flags, contig, contig_len, w2, a.cpu_sample)
+                base["more_cores"] = {"cores": w2, "positions_per_s": b2["value"], "end_to_end": b2["end_to_end"],
+                                      "speedup_end_to_end": (rep.n_positions / (rep.total_ms * 1e-3)) / b2["end_to_end"]["positions_per_s"] if not region else None}
             result["cpu_baseline"] = base
         print(json.dumps(result))
     ctx.close()
