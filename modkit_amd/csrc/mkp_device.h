@@ -153,7 +153,10 @@ struct MkpTile { int32_t r0, r1; uint32_t first, last; };
 #endif
 #define MKP_PILEUP_WAVE_SCRATCH 128
 #define MKP_PILEUP_BM_WORDS(S) (((((S) + 31u) >> 5) + 3u) & ~1u)
-#define MKP_PILEUP_LDS_WORDS(words_per_slot, S, focus_words) ((words_per_slot) * (S) + ((focus_words) ? 2u * (focus_words) + (S) : 0u) + (MKP_PILEUP_THREADS / 64) * (MKP_PILEUP_BM_WORDS(S) + MKP_PILEUP_WAVE_SCRATCH))
+// per-wave scratch: dense kernel = op-start bitmap + compaction buffer; focus kernel = one word per slot of a read's visit
+// (the packed query index / kind the CIGAR phase leaves for the SEQ phase)
+#define MKP_PILEUP_WAVE_WORDS(S, focus_words) ((focus_words) && (S) > MKP_PILEUP_BM_WORDS(S) + MKP_PILEUP_WAVE_SCRATCH ? (S) : MKP_PILEUP_BM_WORDS(S) + MKP_PILEUP_WAVE_SCRATCH)
+#define MKP_PILEUP_LDS_WORDS(words_per_slot, S, focus_words) ((words_per_slot) * (S) + ((focus_words) ? 2u * (focus_words) + (S) : 0u) + (MKP_PILEUP_THREADS / 64) * MKP_PILEUP_WAVE_WORDS(S, focus_words))
 
 struct MkpRowsDev {  // SoA row buffers (44 B / row)
   uint32_t* pos; uint32_t* info; uint32_t* code;

@@ -1548,9 +1548,10 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   const int lane = lane_id();
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // per-wave scratch behind that: op-start bitmap over the tile's slots + CIGAR compaction buffer
-  const uint32_t bm_words = MKP_PILEUP_BM_WORDS(S);
-  uint32_t* __restrict__ bm = lds + tal_words + focus_total + wave * (bm_words + PILEUP_WAVE_SCRATCH);
+  const uint32_t bm_words = MKP_PILEUP_BM_WORDS(S), wave_words = MKP_PILEUP_WAVE_WORDS(S, W);
+  uint32_t* __restrict__ bm = lds + tal_words + focus_total + wave * wave_words;
   uint2* __restrict__ comp = reinterpret_cast<uint2*>(bm + bm_words);
+  uint32_t* __restrict__ qk = bm;   // focus kernel: per slot of the current read's visit, (query index << 2) | kind
   const uint32_t TS4 = S * 4u;
   // XCD-aware mapping: consecutive workgroups land on different XCDs (b % 8); give each XCD a
   // contiguous run of tiles so the reads shared by neighbouring tiles stay in one L2.
@@ -1562,7 +1563,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   const int32_t T0h = tl.r0 - MKP_HALO, T1h = tl.r1 + MKP_HALO;
   // zero the tallies and the per-wave scratch (the focus arrays are rewritten below)
   for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
-  for (uint32_t k = threadIdx.x; k < PILEUP_WAVES * (bm_words + PILEUP_WAVE_SCRATCH); k += PILEUP_THREADS) lds[tal_words + focus_total + k] = 0;
+  for (uint32_t k = threadIdx.x; k < PILEUP_WAVES * wave_words; k += PILEUP_THREADS) lds[tal_words + focus_total + k] = FOCUS ? 3u : 0u;   // focus: kind 3 = no base
   if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }
   SlotMap<FOCUS> sm; sm.bm = fbm; sm.pfx = fpfx; sm.fpos = fpos; sm.T0h = T0h; sm.lbase = T0h;
   uint32_t n_tslots = (uint32_t)(T1h - T0h);   // tally columns in use
@@ -1648,7 +1649,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
     // the read's call events inside the tile (sorted by position)
     if (ro.ok && ro.n_events) {
       const MkpEvent* __restrict__ ev = events + h.event_off;
-      const uint32_t lo = event_lower_bound(ev, ro.n_events, T0h);
+      const uint32_t lo = h.ref_start >= T0h ? 0u : event_lower_bound(ev, ro.n_events, T0h);   // a read that starts in the tile: no search
       for (uint32_t k = lo + lane;; k += 64) {
         bool in = k < ro.n_events;
         MkpEvent e; e.pos = 0; e.info = 0;
@@ -1680,6 +1681,43 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       const int32_t rs = r_run + (int32_t)(re - rlen);
       const uint32_t Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63), Rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
       const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
+      if (FOCUS) {
+        // Focus runs: the walk is driven by the slots, not by the ops.  The window's slots [S_lo, S_hi) are enumerated 64 at a
+        // time (lane = slot, position from the tile's slot list); the op holding a position is the number of ops whose inclusive
+        // reference end is at or before it (6 ds_bpermute steps over the prefix sums the window has anyway); its packed
+        // (query offset, kind) comes with one more bpermute.  No per-op rank queries, no compaction, no op-start bitmap;
+        // deletions are counted directly.  (~20 slots per window on a --cpg run.)
+        if (c_lo < c_hi) {
+          const uint32_t S_lo = sm.rank(c_lo), S_hi = sm.rank(c_hi);
+          if (S_lo < S_hi) {
+            const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
+            const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);  // q = (pos - ref_start) + D
+            if (ro.ok && __any(op == 3 && rlen > 0)) {  // ref-skips: the read is not in these columns (alignment.is_refskip())
+              const int32_t pa = min(max(rs, c_lo), c_hi), pb = min(max(rs + (int32_t)rlen, c_lo), c_hi);
+              const uint32_t sa = sm.rank(pa), sb = sm.rank(pb);
+              if (op == 3 && sa < sb) for (uint32_t s = 0; s < 2; s++) {
+                uint32_t m = ro.obs[s];
+                while (m) {
+                  const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+                  atomicAdd(&obs[sl * S + sa], 0u - (s ? 0x10000u : 1u));
+                  if (sb < n_tslots) atomicAdd(&obs[sl * S + sb], s ? 0x10000u : 1u);
+                }
+              }
+            }
+            // phase 1 (here): the window's slots get their packed (query index, kind); phase 2 (after the CIGAR loop) fetches the
+            // bases of all the read's slots with several loads in flight — the SEQ loads no longer sit in the CIGAR dependency chain
+            for (uint32_t s0 = S_lo; s0 < S_hi; s0 += 64) {
+              const uint32_t c = s0 + (uint32_t)lane;
+              const bool valid = c < S_hi;
+              const int32_t p = valid ? fpos[c] : c_lo;
+              const int oi = find_op(re, (uint32_t)(p - r_run)) & 63;
+              const uint32_t my_pk = (uint32_t)__shfl((int)pk, oi, 64);
+              const uint32_t qq = (uint32_t)p + qbase + (my_pk >> 5);
+              if (valid) qk[c - rs_a] = (qq << 2) | ((my_pk >> 3) & 3u);
+            }
+          }
+        }
+      } else
       if (c_lo < c_hi) {
         // the op's slots inside the tile: [sa, sb)
         const int32_t pa = min(max(rs, c_lo), c_hi), pb = min(max(rs + (int32_t)rlen, c_lo), c_hi);
@@ -1772,10 +1810,34 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       }
       q_run += Qtot; r_run += (int32_t)Rtot;
     }
+    if (FOCUS) {
+      // phase 2: bases of the read's slots [rs_a, rs_b) in this tile, 4 x 64 slots per round with their SEQ loads in flight together
+      // (slots the CIGAR phase did not reach — a read whose CIGAR ends early — keep kind 3 = nothing)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t nsl = rs_b - rs_a;
+      for (uint32_t g0 = 0; g0 < nsl; g0 += 256) {
+        uint32_t v[4], byte[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t i = g0 + 64u * j + (uint32_t)lane; v[j] = i < nsl ? qk[i] : 3u; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) byte[j] = seq[min(v[j] >> 3, last_byte)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t i = g0 + 64u * j + (uint32_t)lane, kind = v[j] & 3u;
+          const uint32_t t = ((v[j] >> 2) & 1u) | aln2;
+          const uint32_t rowt = (uint32_t)lut[(t << 8) | byte[j]];
+          const uint32_t a0 = lds_addr(tal) + 4u * (rs_a + i);
+          if (kind == 0u && rowt < 8u) lds_add(a0 + __umul24(rowt, TS4), inc);
+          if (kind == 1u) lds_add(a0 + __umul24((uint32_t)MKP_C_DEL, TS4), inc);   // alignment.is_del()
+          if (i < nsl) qk[i] = 3u;   // left clean for the wave's next read
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
   }
   __syncthreads();
   // difference arrays -> counts, in place and still packed (the sums are exact): deletions, then observed codes per slot
-  for (uint32_t a = wave; a < n_oslots + 1u; a += PILEUP_WAVES) {
+  for (uint32_t a = wave + (FOCUS ? 1u : 0u); a < n_oslots + 1u; a += PILEUP_WAVES) {   // (focus runs count deletions directly)
     uint32_t* __restrict__ arr = a == 0 ? tal + MKP_C_DEL * S : obs + (a - 1u) * S;
     uint32_t carry = 0;
     for (uint32_t b0 = 0; b0 < n_tslots; b0 += 64) {
