@@ -1598,21 +1598,24 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   }
   __syncthreads();
 
-  // reads are handed out one at a time (LDS ticket) so waves finish the tile together whatever the reads' spans
+  // reads are handed out one at a time (LDS ticket) so waves finish the tile together whatever the reads' spans; the next
+  // read's header and decode summary are requested while the current read is processed (one global round trip less per read)
   const uint32_t rid_end = tl.last;
+  uint32_t rid_nx; MkpReadHdr h_nx; MkpReadOut ro_nx;
+  { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 1u); rid_nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket); }
+  { const uint32_t r0 = min(rid_nx, rid_end - 1u); h_nx = hdrs[r0]; ro_nx = readout[r0]; }   // (tiles hold at least one candidate read)
   if (n_tslots) for (;;) {
-    uint32_t ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&next_read, 1u);
-    const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    const uint32_t rid = rid_nx;
     if (rid >= rid_end) break;
-    const MkpReadHdr h = hdrs[rid];
+    const MkpReadHdr h = h_nx; const MkpReadOut ro = ro_nx;
+    { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 1u); rid_nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket); }
+    { const uint32_t r0 = min(rid_nx, rid_end - 1u); h_nx = hdrs[r0]; ro_nx = readout[r0]; }
     if (h.ref_end <= T0h || h.ref_start >= T1h) continue;
     if (KEYED && (h.flags >> MKP_RF_KEY_SHIFT) != key_filter) continue;   // --partition-tag: one pass per key
     // the read's slot range in this tile; a read that covers no slot leaves nothing here
     const int32_t span_a = max(h.ref_start, T0h), span_b = min(h.ref_end, T1h);
     const uint32_t rs_a = sm.rank(span_a), rs_b = sm.rank(span_b);
     if (FOCUS && rs_a == rs_b) continue;
-    const MkpReadOut ro = readout[rid];
     const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u;
     const uint8_t* __restrict__ seq = seqs + h.seq_off;
     // depth walk: htslib pileup columns (match -> base, D -> delete, N -> ref-skip).  One lane per slot;
