@@ -1639,7 +1639,9 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       }
     }
     // the first chunk's CIGAR words are requested now, ahead of the event work; every later chunk is requested one chunk ahead
-    uint32_t w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
+    auto load2 = [&](uint32_t c) { uint2 r; const uint32_t i = c + 2u * (uint32_t)lane; r.x = i < h.n_cigar ? cigar[h.cigar_off + i] : 5u; r.y = i + 1u < h.n_cigar ? cigar[h.cigar_off + i + 1u] : 5u; return r; };
+    uint32_t w_next = 5u; uint2 w2_next = make_uint2(5u, 5u);   // focus kernel: two ops per lane
+    if (FOCUS) w2_next = load2(c_first); else w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
     // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
     if (ro.ok && lane < 2) {
       uint32_t m = lane ? ro.obs[1] : ro.obs[0];
@@ -1673,6 +1675,65 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
     const uint32_t fposbase = lds_addr(fpos) + 4u * (uint32_t)lane;
     const uint32_t qbase = (uint32_t)(0 - h.ref_start) - (1u << 26);   // query index = position + qbase + packed offset
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
+    if (FOCUS) {
+      // Focus runs: the walk is driven by the slots, not by the ops, 128 CIGAR ops per window (two per lane).  The window's slots
+      // [S_lo, S_hi) are enumerated 64 at a time (lane = slot, position from the tile's slot list); the lane holding a position's
+      // op is the number of lanes whose inclusive reference end is at or before it (6 ds_bpermute steps over the prefix sums the
+      // window has anyway), three more bpermutes bring that lane's split point and the packed (query offset, kind) of its two
+      // ops.  No per-op rank queries, no compaction, no op-start bitmap; deletions are counted directly.
+      // Phase 1 (here): the slots get their packed (query index, kind); phase 2 (after the loop) fetches the bases of all the
+      // read's slots with several loads in flight — the SEQ loads do not sit in the CIGAR dependency chain.
+      for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 128) {
+        if (r_run >= T1h) break;
+        const uint2 w2 = w2_next;
+        if (c0 + 128u < h.n_cigar) w2_next = load2(c0 + 128u);
+        const uint32_t op0 = w2.x & 15u, len0 = w2.x >> 4, op1 = w2.y & 15u, len1 = w2.y >> 4;
+        const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
+        const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
+        const uint32_t qe = wave_incl_scan(ql0 + ql1), re = wave_incl_scan(rl0 + rl1);
+        const uint32_t Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63), Rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
+        const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
+        if (c_lo < c_hi) {
+          const uint32_t S_lo = sm.rank(c_lo), S_hi = sm.rank(c_hi);
+          if (S_lo < S_hi) {
+            const uint32_t qs0 = q_run + qe - (ql0 + ql1), qs1 = qs0 + ql0;
+            const uint32_t mid = re - rl1;                                     // window-relative reference offset where the lane's second op starts
+            const int32_t rs0 = r_run + (int32_t)(re - (rl0 + rl1)), rs1 = r_run + (int32_t)mid;
+            const uint32_t kind0 = op_is_match(op0) ? 0u : (op0 == 2 ? 1u : 2u), kind1 = op_is_match(op1) ? 0u : (op1 == 2 ? 1u : 2u);
+            const uint32_t pk0 = ((uint32_t)((int32_t)qs0 - (rs0 - h.ref_start) + (1 << 26)) << 5) | (kind0 << 3);  // q = (pos - ref_start) + D
+            const uint32_t pk1 = ((uint32_t)((int32_t)qs1 - (rs1 - h.ref_start) + (1 << 26)) << 5) | (kind1 << 3);
+            if (ro.ok && __any((op0 == 3 && rl0 > 0) || (op1 == 3 && rl1 > 0))) {  // ref-skips: the read is not in these columns (alignment.is_refskip())
+              for (int j = 0; j < 2; j++) {
+                const bool skipop = j ? (op1 == 3 && rl1 > 0) : (op0 == 3 && rl0 > 0);
+                const int32_t a0 = j ? rs1 : rs0, b0 = a0 + (int32_t)(j ? rl1 : rl0);
+                const int32_t pa = min(max(a0, c_lo), c_hi), pb = min(max(b0, c_lo), c_hi);
+                const uint32_t sa = sm.rank(pa), sb = sm.rank(pb);
+                if (skipop && sa < sb) for (uint32_t s = 0; s < 2; s++) {
+                  uint32_t m = ro.obs[s];
+                  while (m) {
+                    const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+                    atomicAdd(&obs[sl * S + sa], 0u - (s ? 0x10000u : 1u));
+                    if (sb < n_tslots) atomicAdd(&obs[sl * S + sb], s ? 0x10000u : 1u);
+                  }
+                }
+              }
+            }
+            for (uint32_t s0 = S_lo; s0 < S_hi; s0 += 64) {
+              const uint32_t c = s0 + (uint32_t)lane;
+              const bool valid = c < S_hi;
+              const int32_t p = valid ? fpos[c] : c_lo;
+              const uint32_t rel = (uint32_t)(p - r_run);
+              const int ol = find_op(re, rel) & 63;
+              const uint32_t o_mid = (uint32_t)__shfl((int)mid, ol, 64), o_pk0 = (uint32_t)__shfl((int)pk0, ol, 64), o_pk1 = (uint32_t)__shfl((int)pk1, ol, 64);
+              const uint32_t my_pk = rel < o_mid ? o_pk0 : o_pk1;
+              const uint32_t qq = (uint32_t)p + qbase + (my_pk >> 5);
+              if (valid) qk[c - rs_a] = (qq << 2) | ((my_pk >> 3) & 3u);
+            }
+          }
+        }
+        q_run += Qtot; r_run += (int32_t)Rtot;
+      }
+    } else
     for (uint32_t c0 = c_first; c0 < h.n_cigar; c0 += 64) {
       if (r_run >= T1h) break;
       const uint32_t w = w_next;
@@ -1684,43 +1745,6 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       const int32_t rs = r_run + (int32_t)(re - rlen);
       const uint32_t Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63), Rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
       const int32_t c_lo = max(r_run, T0h), c_hi = min(r_run + (int32_t)Rtot, T1h);
-      if (FOCUS) {
-        // Focus runs: the walk is driven by the slots, not by the ops.  The window's slots [S_lo, S_hi) are enumerated 64 at a
-        // time (lane = slot, position from the tile's slot list); the op holding a position is the number of ops whose inclusive
-        // reference end is at or before it (6 ds_bpermute steps over the prefix sums the window has anyway); its packed
-        // (query offset, kind) comes with one more bpermute.  No per-op rank queries, no compaction, no op-start bitmap;
-        // deletions are counted directly.  (~20 slots per window on a --cpg run.)
-        if (c_lo < c_hi) {
-          const uint32_t S_lo = sm.rank(c_lo), S_hi = sm.rank(c_hi);
-          if (S_lo < S_hi) {
-            const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
-            const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);  // q = (pos - ref_start) + D
-            if (ro.ok && __any(op == 3 && rlen > 0)) {  // ref-skips: the read is not in these columns (alignment.is_refskip())
-              const int32_t pa = min(max(rs, c_lo), c_hi), pb = min(max(rs + (int32_t)rlen, c_lo), c_hi);
-              const uint32_t sa = sm.rank(pa), sb = sm.rank(pb);
-              if (op == 3 && sa < sb) for (uint32_t s = 0; s < 2; s++) {
-                uint32_t m = ro.obs[s];
-                while (m) {
-                  const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-                  atomicAdd(&obs[sl * S + sa], 0u - (s ? 0x10000u : 1u));
-                  if (sb < n_tslots) atomicAdd(&obs[sl * S + sb], s ? 0x10000u : 1u);
-                }
-              }
-            }
-            // phase 1 (here): the window's slots get their packed (query index, kind); phase 2 (after the CIGAR loop) fetches the
-            // bases of all the read's slots with several loads in flight — the SEQ loads no longer sit in the CIGAR dependency chain
-            for (uint32_t s0 = S_lo; s0 < S_hi; s0 += 64) {
-              const uint32_t c = s0 + (uint32_t)lane;
-              const bool valid = c < S_hi;
-              const int32_t p = valid ? fpos[c] : c_lo;
-              const int oi = find_op(re, (uint32_t)(p - r_run)) & 63;
-              const uint32_t my_pk = (uint32_t)__shfl((int)pk, oi, 64);
-              const uint32_t qq = (uint32_t)p + qbase + (my_pk >> 5);
-              if (valid) qk[c - rs_a] = (qq << 2) | ((my_pk >> 3) & 3u);
-            }
-          }
-        }
-      } else
       if (c_lo < c_hi) {
         // the op's slots inside the tile: [sa, sb)
         const int32_t pa = min(max(rs, c_lo), c_hi), pb = min(max(rs + (int32_t)rlen, c_lo), c_hi);
