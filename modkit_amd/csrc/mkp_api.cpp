@@ -63,14 +63,9 @@ template <class V> void upload(DevBuf& b, const V& v) {
   if (!v.empty()) hip_check(hipMemcpy(b.p, v.data(), bytes, hipMemcpyHostToDevice), "H2D");
 }
 
-template <class F> void host_parallel(size_t n, size_t grain, F f) {   // f(lo, hi) over [0, n) in `grain`-sized pieces on all host cores
+template <class F> void host_parallel(size_t n, size_t grain, F f) {   // f(lo, hi) over [0, n) in `grain`-sized pieces on the host pool
   const size_t pieces = (n + grain - 1) / grain;
-  const unsigned n_thr = (unsigned)std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), std::max<size_t>(pieces, 1));
-  if (n_thr <= 1) { if (n) f((size_t)0, n); return; }
-  std::atomic<size_t> next{0}; std::vector<std::thread> th;
-  auto work = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= pieces) break; f(i * grain, std::min(n, (i + 1) * grain)); } };
-  for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work);
-  work(); for (auto& x : th) x.join();
+  HostPool::get().parallel(pieces, [&](size_t i) { f(i * grain, std::min(n, (i + 1) * grain)); });
 }
 
 // htslib's pileup engine stops buffering reads once more than max_depth of them overlap (bam_plp_push, maxcnt); which reads it

@@ -12,6 +12,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +37,51 @@ struct Error : std::runtime_error {
   Error(int st, const std::string& m) : std::runtime_error(m), status(st) {}
 };
 
+// A process-wide pool of host worker threads for the ingest's short parallel sections (block inflate, record indexing).
+// Spawning threads per section costs a stack mapping each — with many sections running concurrently (sampler heads, shard
+// prefetch) that serialises on the address-space lock; pooled workers are created once.
+class HostPool {
+ public:
+  static HostPool& get() { static HostPool p; return p; }
+  // f(i) for every i in [0, n), on the pool's workers and the calling thread; returns when all are done.  Re-entrant and
+  // callable from several threads at once.
+  template <class F> void parallel(size_t n, F f) {
+    if (n == 0) return;
+    if (n == 1 || workers_.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
+    Job job; job.n = n; job.fn = [&f](size_t i) { f(i); };
+    { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(&job); }
+    cv_.notify_all();
+    for (;;) { const size_t i = job.next.fetch_add(1); if (i >= n) break; job.fn(i); job.done.fetch_add(1); }
+    { std::unique_lock<std::mutex> lk(mu_);
+      for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (*it == &job) { jobs_.erase(it); break; }   // no new claims from now on
+      done_cv_.wait(lk, [&] { return job.done.load() + job.skipped.load() >= std::min(n, job.next.load()); }); }
+  }
+ private:
+  struct Job { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}, skipped{0}; };
+  std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Job*> jobs_; bool stop_ = false;
+  HostPool() {
+    const unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    for (unsigned t = 1; t < n; t++) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : workers_) t.join(); }
+  void loop() {
+    for (;;) {
+      Job* job = nullptr; size_t i = 0;
+      { std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+          if (stop_) return;
+          for (Job* j : jobs_) { const size_t k = j->next.fetch_add(1); if (k < j->n) { job = j; i = k; break; } }   // claimed under the lock: the job cannot be retired in between
+          if (job) break;
+          cv_.wait(lk);
+        } }
+      job->fn(i);
+      job->done.fetch_add(1);
+      { std::lock_guard<std::mutex> lk(mu_); }   // pairs with the waiter's predicate check
+      done_cv_.notify_all();
+    }
+  }
+};
+
 struct BamIndexEntry {  // one alignment record inside `raw`
   uint64_t off;         // offset of the record's 32-byte core (after block_size)
   int32_t tid, pos, end;  // end = bam_endpos (pos+1 for records without reference length)
@@ -43,15 +92,17 @@ struct BamIndexEntry {  // one alignment record inside `raw`
 // A byte buffer whose pages are first touched by whoever writes them (the inflate workers), not zero-filled up front;
 // anonymous mapping with transparent huge pages requested (one fault per 2 MiB instead of per 4 KiB where the host allows it)
 struct ByteBuf {
-  uint8_t* p = nullptr; size_t n = 0, cap = 0;
+  uint8_t* p = nullptr; size_t n = 0, cap = 0; bool heap = false;
   ByteBuf() = default;
-  ByteBuf(ByteBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
-  ByteBuf& operator=(ByteBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+  ByteBuf(ByteBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), heap(o.heap) { o.p = nullptr; o.n = o.cap = 0; }
+  ByteBuf& operator=(ByteBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; heap = o.heap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
   ByteBuf(const ByteBuf&) = delete; ByteBuf& operator=(const ByteBuf&) = delete;
   ~ByteBuf() { release(); }
-  void release() { if (p) munmap(p, cap); p = nullptr; n = cap = 0; }
+  void release() { if (p) { if (heap) free(p); else munmap(p, cap); } p = nullptr; n = cap = 0; heap = false; }
+  // small buffers come from the heap: many threads mapping, faulting and unmapping small regions serialise on the address-space lock
   void alloc(size_t bytes) {
     release();
+    if (bytes < (32u << 20)) { p = (uint8_t*)malloc(std::max<size_t>(bytes, 1)); if (!p) throw Error(MKP_E_NOMEM, "out of host memory for the decompressed BAM"); n = cap = bytes; heap = true; return; }
     cap = (std::max<size_t>(bytes, 1) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
     void* m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) { cap = 0; throw Error(MKP_E_NOMEM, "out of host memory for the decompressed BAM"); }
@@ -137,7 +188,7 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
     dtotal += isize; o += bsize;
   }
   BamData bd; bd.raw.alloc(dtotal);
-  if (!threads) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (!threads) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   std::atomic<size_t> next{0}; std::atomic<bool> bad{false};
   auto work = [&]() { for (;;) { size_t i = next++; if (i >= blks.size()) break; if (!blks[i].dlen) continue; try { inflate_block(&comp[blks[i].coff], blks[i].clen, &bd.raw[blks[i].doff], blks[i].dlen); } catch (...) { bad = true; } } };
   if (threads <= 1 || blks.size() < 4) work(); else { std::vector<std::thread> th; for (unsigned t = 0; t < threads; t++) th.emplace_back(work); for (auto& t : th) t.join(); }
@@ -297,7 +348,7 @@ class BamSource {
 
   // `use_index`: read through <path>.bai when it exists; otherwise (or when there is none) load the whole file
   static std::unique_ptr<BamSource> open(const std::string& path, unsigned threads, bool use_index = true) {
-    std::unique_ptr<BamSource> s(new BamSource()); s->path_ = path; s->threads_ = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::unique_ptr<BamSource> s(new BamSource()); s->path_ = path; s->threads_ = threads ? threads : std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (use_index && BaiIndex::load(path + ".bai", &s->bai_)) {
       s->fd_ = ::open(path.c_str(), O_RDONLY); if (s->fd_ < 0) throw Error(MKP_E_IO, "cannot open " + path);
       struct stat st; if (fstat(s->fd_, &st) != 0) throw Error(MKP_E_IO, "cannot stat " + path); s->fsize_ = (uint64_t)st.st_size;
@@ -380,13 +431,14 @@ class BamSource {
   struct Blk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
   // a read-only view of file bytes [off, off + n): mapped (no copy out of the page cache), page-aligned underneath
   struct Window {
-    const uint8_t* p = nullptr; size_t n = 0; void* map = nullptr; size_t map_len = 0;
+    const uint8_t* p = nullptr; size_t n = 0; void* map = nullptr; size_t map_len = 0; std::vector<uint8_t> copy;
     Window() = default; Window(const Window&) = delete; Window& operator=(const Window&) = delete;
     ~Window() { if (map) munmap(map, map_len); }
     size_t size() const { return n; }
     const uint8_t& operator[](size_t i) const { return p[i]; }
   };
   void map_window(uint64_t off, size_t n, Window* w) const {
+    if (n < (16u << 20)) { w->copy.resize(n); pread_all(off, w->copy.data(), n); w->p = w->copy.data(); w->n = n; return; }   // small: a plain read (no mapping churn)
     const uint64_t page = 4096, a0 = off & ~(page - 1);
     w->map_len = (size_t)(off - a0) + n;
     w->map = mmap(nullptr, w->map_len, PROT_READ, MAP_PRIVATE, fd_, (off_t)a0);
@@ -445,7 +497,7 @@ class BamSource {
       uint64_t cb = chunks[ci].beg >> 16; const uint64_t ce = chunks[ci].end >> 16, ue = chunks[ci].end & 0xffff; uint32_t ub = (uint32_t)(chunks[ci].beg & 0xffff);
       // a bounded window of compressed bytes at a time (a chunk may be the whole contig): 64 MiB, or — when the caller wants only
       // the first records of the region — 4 MiB growing to that
-      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (1u << 20);
+      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (2u << 20);   // (heads: ~2 MiB hold the few hundred records the sampler asks for)
       while (cb < fsize_ && (cb < ce || (cb == ce && ue > 0)) && !stop) {
         const uint64_t want_end = std::min<uint64_t>(fsize_, std::min<uint64_t>(ce + (1u << 16) + 64, cb + window));
         window = std::min<uint64_t>(window * 2, 64u << 20);
@@ -454,10 +506,8 @@ class BamSource {
         for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; b.doff = dtotal; dtotal += b.isize; blks.push_back(b); c += b.hdr + b.clen + 8; }
         if (blks.empty()) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
         ByteBuf d; d.alloc((size_t)dtotal + 8);
-        { std::atomic<size_t> next{0}; std::atomic<bool> bad{false};
-          auto work = [&]() { for (;;) { const size_t i = next++; if (i >= blks.size()) break; if (!blks[i].isize) continue; try { inflate_block(&buf[(size_t)(blks[i].coff - cb) + blks[i].hdr], blks[i].clen, &d[(size_t)blks[i].doff], blks[i].isize); } catch (...) { bad = true; } } };
-          const unsigned nt = blks.size() < 4 ? 1u : std::min<unsigned>(threads_, (unsigned)blks.size());
-          if (nt <= 1) work(); else { std::vector<std::thread> th; for (unsigned t = 1; t < nt; t++) th.emplace_back(work); work(); for (auto& t : th) t.join(); }
+        { std::atomic<bool> bad{false};
+          HostPool::get().parallel(blks.size(), [&](size_t i) { if (!blks[i].isize) return; try { inflate_block(&buf[(size_t)(blks[i].coff - cb) + blks[i].hdr], blks[i].clen, &d[(size_t)blks[i].doff], blks[i].isize); } catch (...) { bad = true; } });
           if (bad) throw Error(MKP_E_IO, "corrupt BGZF data in " + path_); }
         bytes_inflated += dtotal;
         // records: from `ub` in the first block to the chunk end (or the end of this window's last complete record)
@@ -473,9 +523,8 @@ class BamSource {
           starts.push_back(o); o += 4 + (uint64_t)bs; consumed = o;
         }
         std::vector<BamIndexEntry> all(starts.size()); std::atomic<bool> rec_bad{false};
-        { auto idx = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { int32_t bs; memcpy(&bs, &d[(size_t)starts[i]], 4); if (!index_record(d.data(), (size_t)starts[i] + 4, bs, n_ref, &all[i])) rec_bad = true; } };
-          const unsigned nt = starts.size() < 4096 ? 1u : threads_;
-          if (nt <= 1) idx(0, starts.size()); else { std::vector<std::thread> th; for (unsigned t = 1; t < nt; t++) th.emplace_back(idx, starts.size() * t / nt, starts.size() * (t + 1) / nt); idx(0, starts.size() / nt); for (auto& t : th) t.join(); } }
+        { const size_t grain = 512, pieces = (starts.size() + grain - 1) / grain;
+          HostPool::get().parallel(pieces, [&](size_t pc) { for (size_t i = pc * grain; i < std::min(starts.size(), (pc + 1) * grain); i++) { int32_t bs; memcpy(&bs, &d[(size_t)starts[i]], 4); if (!index_record(d.data(), (size_t)starts[i] + 4, bs, n_ref, &all[i])) rec_bad = true; } }); }
         if (rec_bad) throw Error(MKP_E_IO, "corrupt BAM record");
         std::vector<BamIndexEntry> recs;
         for (size_t i = 0; i < all.size(); i++) {
@@ -505,14 +554,20 @@ class BamSource {
 struct Fasta {
   std::map<std::string, std::string> seqs;
   static Fasta load(const std::string& path) {
-    Fasta f; std::ifstream in(path);
-    if (!in) throw Error(MKP_E_IO, "cannot open fasta " + path);
-    std::string line; std::string* cur = nullptr;
-    while (std::getline(in, line)) {
-      if (!line.empty() && line.back() == '\r') line.pop_back();
-      if (line.empty()) continue;
-      if (line[0] == '>') { std::string n = line.substr(1); size_t sp = n.find_first_of(" \t"); if (sp != std::string::npos) n.resize(sp); cur = &f.seqs[n]; }
-      else if (cur) cur->append(line);
+    // the whole file in one read, lines found with memchr (a 3 Gb reference is read at memory speed, not getline speed)
+    Fasta f; FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) throw Error(MKP_E_IO, "cannot open fasta " + path);
+    std::string buf; { fseek(fp, 0, SEEK_END); const long n = ftell(fp); fseek(fp, 0, SEEK_SET); buf.resize((size_t)std::max(n, 0l)); if (n > 0 && fread(&buf[0], 1, (size_t)n, fp) != (size_t)n) { fclose(fp); throw Error(MKP_E_IO, "read error on " + path); } }
+    fclose(fp);
+    std::string* cur = nullptr; size_t o = 0; const size_t n = buf.size();
+    while (o < n) {
+      const char* nl = (const char*)memchr(buf.data() + o, '\n', n - o); size_t e = nl ? (size_t)(nl - buf.data()) : n, le = e;
+      if (le > o && buf[le - 1] == '\r') le--;
+      if (le > o) {
+        if (buf[o] == '>') { std::string name(buf.data() + o + 1, le - o - 1); const size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name.resize(sp); cur = &f.seqs[name]; if (cur->empty()) cur->reserve(std::min<size_t>(n - o, (size_t)1 << 28)); }
+        else if (cur) cur->append(buf.data() + o, le - o);
+      }
+      o = e + 1;
     }
     return f;
   }

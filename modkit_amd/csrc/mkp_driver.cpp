@@ -28,7 +28,7 @@ struct Args {
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
-  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0, shard_bytes = 1ull << 30; bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
+  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */; bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
 };
 
 struct RegionSpec { std::string name; uint32_t start, end; };
@@ -76,6 +76,8 @@ IdxStats idxstats(const BamSource& bam, const RegionSpec* region, const BedFilte
 }
 
 struct Quota { bool all = false; size_t n = 0; };
+struct SampleTimes { double fetch_ms = 0, device_ms = 0, decide_ms = 0; uint64_t rounds = 0, reads = 0; };
+SampleTimes g_sample_times;   // --stats: where the threshold estimate's time went (last run in this process)
 
 // Default threshold estimation: the reference's deterministic "first N qualifying reads per interval" schedule
 // (reads_sampler/mod.rs:30-257, sampling_schedule.rs:171-615); the per-call probabilities come from the decode kernel.
@@ -123,6 +125,23 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   // One fetched batch of an interval: `cand` = indices into batch.recs that pass `candidates`, processed from cand[from] on.
   // `skip` (rank-sharded mode): candidates an earlier interval already took.  State across calls: used / n_reads_out.
   struct TakeState { size_t used = 0, n_reads_out = 0; };
+  // the sampler's verdict on candidates cand[lo, hi) whose value counts are nv[0 ..): mask[k] = 1 where the read's values enter the sample
+  auto decide = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen, TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask) {
+    for (size_t i = lo; i < hi; i++) {
+      if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
+      const size_t k = i - lo;
+      if (skip && (*skip)[i]) continue;
+      std::string name = batch.qname(batch.recs[cand[i]]);
+      // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
+      // but keeps no position is asked, not counted, and not recorded
+      if (interval_seen->count(name)) continue;
+      if (nv[k] == 0) continue;
+      interval_seen->insert(name); ts->used++; ts->n_reads_out++;
+      if (taken.count(name)) continue;  // Moniod::op_mut keeps the first occurrence of a read id
+      taken.insert(name);
+      mask[k] = 1;
+    }
+  };
   auto take = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen, TakeState* ts, const std::vector<uint8_t>* skip = nullptr) {
     size_t next = from;
     while (next < cand.size() && (limit < 0 || ts->used < (size_t)limit)) {
@@ -133,20 +152,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(), only_mapped, &nv);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       std::vector<uint8_t> mask(recs.size(), 0);
-      for (size_t i = next; i < hi; i++) {
-        if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
-        const size_t k = i - next;
-        if (skip && (*skip)[i]) continue;
-        std::string name = batch.qname(batch.recs[cand[i]]);
-        // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
-        // but keeps no position is asked, not counted, and not recorded
-        if (interval_seen->count(name)) continue;
-        if (nv[k] == 0) continue;
-        interval_seen->insert(name); ts->used++; ts->n_reads_out++;
-        if (taken.count(name)) continue;  // Moniod::op_mut keeps the first occurrence of a read id
-        taken.insert(name);
-        mask[k] = 1;
-      }
+      decide(batch, cand, next, hi, nv.data(), limit, interval_seen, ts, skip, mask.data());
       rc = mkp_internal_sample_take(ctx, mask);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       next = hi;
@@ -199,40 +205,81 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       }
       auto cap_of = [&](const G& g) { return g.q.all ? SIZE_MAX : 2 * g.q.n + 128; };
       auto head_of = [&](size_t gi) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, b.get(), cap_of(grouped[gi])); return b; };
-      std::future<std::unique_ptr<BamBatch>> next_head;
-      if (!mine.empty()) next_head = std::async(std::launch::async, head_of, mine[0]);
-      for (size_t mi = 0; mi < mine.size(); mi++) {  // run_batch (reads_sampler/mod.rs:259-338)
-        const G& g = grouped[mine[mi]];
-        std::unique_ptr<BamBatch> head = next_head.get();
-        if (mi + 1 < mine.size()) next_head = std::async(std::launch::async, head_of, mine[mi + 1]);
-        // the first-N schedule needs only the head of an interval: fetch a bounded number of records first, everything only if
-        // that was not enough (records already processed are skipped on the second pass)
-        const long limit = g.q.all ? -1 : (long)g.q.n;
-        std::set<std::string> seen; TakeState ts; size_t done = 0;
-        for (int pass = 0; pass < 2; pass++) {
-          const size_t cap = pass == 0 ? cap_of(g) : SIZE_MAX;
-          BamBatch whole; if (pass == 1) bam.fetch(g.iv.tid, g.iv.start, g.iv.end, &whole, cap);
-          const BamBatch& batch = pass == 0 ? *head : whole;
-          std::vector<size_t> cand; candidates(batch, &cand);
-          std::vector<uint8_t> skip;
-          if (sharded) {   // a read that reaches back into an earlier processed interval of this contig was taken there
-            skip.assign(cand.size(), 0);
-            for (size_t i = 0; i < cand.size(); i++) {
-              const BamIndexEntry& e = batch.recs[cand[i]];
-              for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && (int64_t)e.pos < s1;) {   // grid intervals before this one, nearest first
-                const int64_t s0 = std::max<int64_t>((int64_t)contig_start[g.iv.tid], s1 - (int64_t)a.sampling_interval_size);
-                if (!bf || bf->overlaps(g.iv.tid, (uint64_t)s0, (uint64_t)s1)) { skip[i] = 1; break; }
-                s1 = s0;
-              }
-            }
+      auto skip_for = [&](const G& g, const BamBatch& batch, const std::vector<size_t>& cand, std::vector<uint8_t>* skip) {
+        skip->assign(cand.size(), 0);   // rank-sharded mode: a read that reaches back into an earlier processed interval of this contig was taken there
+        for (size_t i = 0; i < cand.size(); i++) {
+          const BamIndexEntry& e = batch.recs[cand[i]];
+          for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && (int64_t)e.pos < s1;) {   // grid intervals before this one, nearest first
+            const int64_t s0 = std::max<int64_t>((int64_t)contig_start[g.iv.tid], s1 - (int64_t)a.sampling_interval_size);
+            if (!bf || bf->overlaps(g.iv.tid, (uint64_t)s0, (uint64_t)s1)) { (*skip)[i] = 1; break; }
+            s1 = s0;
           }
-          size_t from = 0; while (from < cand.size() && cand[from] < done) from++;
-          take(batch, cand, from, limit, g.iv.tid, true, &seen, &ts, sharded ? &skip : nullptr);
-          const bool truncated = batch.recs.size() >= cap;
-          done = batch.recs.size();
-          if (!truncated || (limit >= 0 && ts.used >= (size_t)limit)) break;
         }
-        batch_counts[g.iv.tid] += ts.n_reads_out;
+      };
+      // the rest of an interval after its head (or all of it in full-data mode): sequential device rounds
+      auto finish_interval = [&](const G& g, std::unique_ptr<BamBatch>& head, const std::vector<size_t>& head_cand, size_t head_done, const std::vector<uint8_t>& head_skip, std::set<std::string>* seen, TakeState* ts) {
+        const long limit = g.q.all ? -1 : (long)g.q.n;
+        take(*head, head_cand, head_done, limit, g.iv.tid, true, seen, ts, sharded ? &head_skip : nullptr);
+        const bool truncated = head->recs.size() >= cap_of(g);
+        if (!truncated || (limit >= 0 && ts->used >= (size_t)limit)) return;
+        const size_t done = head->recs.size();
+        head.reset();
+        BamBatch whole; bam.fetch(g.iv.tid, g.iv.start, g.iv.end, &whole, SIZE_MAX);   // the head was not enough: the whole interval, records already seen skipped
+        std::vector<size_t> cand; candidates(whole, &cand);
+        std::vector<uint8_t> skip; if (sharded) skip_for(g, whole, cand, &skip);
+        size_t from = 0; while (from < cand.size() && cand[from] < done) from++;
+        take(whole, cand, from, limit, g.iv.tid, true, seen, ts, sharded ? &skip : nullptr);
+      };
+      // run_batch (reads_sampler/mod.rs:259-338).  The count-based schedule needs only the head of every interval: the heads of up to
+      // 8 consecutive intervals of one contig are fetched concurrently and decoded in ONE device round; the sampler's first-N logic
+      // then runs over them in interval order.  An interval its head does not satisfy is finished sequentially before the
+      // following ones are judged (their reads may already be taken by it), and the remaining heads are decoded again.
+      struct Pending { size_t gi; std::unique_ptr<BamBatch> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen; TakeState ts; };
+      for (size_t mi = 0; mi < mine.size();) {
+        const G& g0 = grouped[mine[mi]];
+        size_t mj = mi + 1;
+        if (!g0.q.all) while (mj < mine.size() && mj - mi < 8 && !grouped[mine[mj]].q.all && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;
+        std::vector<std::future<std::unique_ptr<BamBatch>>> futs;
+        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(std::launch::async, head_of, mine[k]));
+        std::vector<Pending> pend(mj - mi);
+        for (size_t k = mi; k < mj; k++) {
+          Pending& P = pend[k - mi]; P.gi = mine[k];
+          { auto t_f = std::chrono::steady_clock::now(); P.head = futs[k - mi].get(); g_sample_times.fetch_ms += ms_since(t_f); }
+          candidates(*P.head, &P.cand); if (sharded) skip_for(grouped[P.gi], *P.head, P.cand, &P.skip);
+          const G& g = grouped[P.gi];
+          P.n_first = g.q.all ? 0 : std::min(P.cand.size(), std::max<size_t>(256, 2 * g.q.n));
+        }
+        if (g0.q.all) { finish_interval(g0, pend[0].head, pend[0].cand, 0, pend[0].skip, &pend[0].seen, &pend[0].ts); batch_counts[g0.iv.tid] += pend[0].ts.n_reads_out; mi = mj; continue; }
+        for (size_t k0 = 0; k0 < pend.size();) {
+          std::vector<mkp_record> recs; std::vector<size_t> at(pend.size() + 1, 0);
+          for (size_t k = k0; k < pend.size(); k++) { at[k] = recs.size(); for (size_t i = 0; i < pend[k].n_first; i++) recs.push_back(pend[k].head->view(pend[k].head->recs[pend[k].cand[i]])); }
+          at[pend.size()] = recs.size();
+          std::vector<uint32_t> nv;
+          auto t_d = std::chrono::steady_clock::now();
+          int rc = mkp_internal_sample(ctx, (int32_t)g0.iv.tid, 0, bam.ref_lens[g0.iv.tid], bedmask_for(g0.iv.tid), recs.data(), (uint32_t)recs.size(), only_mapped, &nv);
+          if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+          g_sample_times.device_ms += ms_since(t_d); g_sample_times.rounds++; g_sample_times.reads += recs.size();
+          auto t_h = std::chrono::steady_clock::now();
+          std::vector<uint8_t> mask(recs.size(), 0);
+          size_t unsatisfied = pend.size();
+          for (size_t k = k0; k < pend.size(); k++) {
+            Pending& P = pend[k]; const G& g = grouped[P.gi];
+            decide(*P.head, P.cand, 0, P.n_first, nv.data() + at[k], (long)g.q.n, &P.seen, &P.ts, sharded ? &P.skip : nullptr, mask.data() + at[k]);
+            const bool more = P.n_first < P.cand.size() || P.head->recs.size() >= cap_of(g);
+            if (P.ts.used < g.q.n && more) { unsatisfied = k; break; }   // the judgement of the later heads waits for this interval
+          }
+          g_sample_times.decide_ms += ms_since(t_h);
+          t_d = std::chrono::steady_clock::now();
+          rc = mkp_internal_sample_take(ctx, mask);
+          if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+          g_sample_times.device_ms += ms_since(t_d);
+          if (unsatisfied == pend.size()) break;
+          Pending& P = pend[unsatisfied];
+          finish_interval(grouped[P.gi], P.head, P.cand, P.n_first, P.skip, &P.seen, &P.ts);
+          k0 = unsatisfied + 1;
+        }
+        for (auto& P : pend) batch_counts[grouped[P.gi].iv.tid] += P.ts.n_reads_out;
+        mi = mj;
       }
       for (auto& kv : batch_counts) sampled_so_far[kv.first] += kv.second;
     }
@@ -347,7 +394,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     // modkit_amd.distributed) estimates them alone over the whole file: correct, but every rank repeats the work
     Args as = a; as.world = 1; as.rank = 0;
     must(mkp_histogram_begin(ctx));
+    g_sample_times = SampleTimes();
     sample_probabilities(ctx, bam, as, sr, bf);
+    if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n", g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms, g_sample_times.decide_ms);
     { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; } }
     thr_ms = ms_since(t0);
   }

@@ -226,14 +226,9 @@ class FocusBuilder {
     return ivs;
   }
 
-  template <class F> static void parallel_ranges(uint64_t lo, uint64_t hi, uint64_t grain, F f) {   // f(a, b) over [lo, hi) on all host cores
-    const uint64_t n = hi > lo ? hi - lo : 0, pieces = (n + grain - 1) / std::max<uint64_t>(grain, 1);
-    const unsigned n_thr = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), std::max<uint64_t>(pieces, 1));
-    if (n_thr <= 1) { if (n) f(lo, hi); return; }
-    std::atomic<uint64_t> next{0}; std::vector<std::thread> th;
-    auto work = [&]() { for (;;) { const uint64_t i = next.fetch_add(1); if (i >= pieces) break; f(lo + i * grain, std::min(hi, lo + (i + 1) * grain)); } };
-    for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work);
-    work(); for (auto& x : th) x.join();
+  template <class F> static void parallel_ranges(uint64_t lo, uint64_t hi, uint64_t grain, F f) {   // f(a, b) over [lo, hi) on the host pool
+    const uint64_t n = hi > lo ? hi - lo : 0, g = std::max<uint64_t>(grain, 1), pieces = (n + g - 1) / g;
+    HostPool::get().parallel((size_t)pieces, [&](size_t i) { f(lo + i * g, std::min(hi, lo + (i + 1) * g)); });
   }
 
  private:

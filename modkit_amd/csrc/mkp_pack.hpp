@@ -214,8 +214,7 @@ struct ShardHost {
       }
       for (size_t k = 0; k < o.tagref.size(); k++) { MkpTagRef t = o.tagref[k]; t.rank_off += (uint32_t)at.rank; t.ml_off += (uint32_t)at.ml; tagref[at.tag + k] = t; }
     };
-    if (ps.size() <= 1) { for (size_t i = 0; i < ps.size(); i++) place(i); }
-    else { std::vector<std::thread> th; for (size_t i = 0; i < ps.size(); i++) th.emplace_back(place, i); for (auto& t : th) t.join(); }
+    HostPool::get().parallel(ps.size(), place);
     n_events_cap = e.ev; n_calls = calls;
   }
   void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); extra_spans.clear(); }
@@ -400,18 +399,17 @@ class Packer {
 // record ranges are packed independently by all host cores and appended in order (same layout ids and offsets as one
 // sequential pass).
 template <class Keep> void pack_records(Packer& packer, ShardHost& dst, const mkp_record* recs, uint32_t n, Keep keep, uint32_t min_parallel = 1024) {
-  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   const unsigned n_thr = n >= min_parallel ? std::max(1u, std::min(hw, n)) : 1;
   if (n_thr == 1) { for (uint32_t i = 0; i < n; i++) if (keep(recs[i])) packer.add(recs[i], dst); return; }
-  std::vector<Packer> pk(n_thr); std::vector<ShardHost> sh(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr); std::vector<std::thread> th;
-  for (unsigned t = 0; t < n_thr; t++) th.emplace_back([&, t]() {
+  std::vector<Packer> pk(n_thr); std::vector<ShardHost> sh(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr);
+  HostPool::get().parallel(n_thr, [&](size_t t) {
     const uint32_t lo = (uint32_t)((uint64_t)n * t / n_thr), hi = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
     sh[t].tid = dst.tid; sh[t].win_start = dst.win_start; sh[t].win_end = dst.win_end;
     try { for (uint32_t i = lo; i < hi; i++) if (keep(recs[i])) pk[t].add(recs[i], sh[t]); }
     catch (const Error& e) { errs[t].reset(new Error(e)); }
     catch (const std::exception& e) { errs[t].reset(new Error(MKP_E_INVALID, e.what())); }
   });
-  for (auto& x : th) x.join();
   std::vector<std::vector<uint16_t>> maps(n_thr);
   for (unsigned t = 0; t < n_thr; t++) { if (errs[t]) throw *errs[t]; maps[t] = packer.adopt(pk[t]); }
   dst.append_all(sh, maps);

@@ -50,11 +50,9 @@ struct RowWriter {
   void write(const std::string& chrom, const mkp_rows& r) {
     if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
     if (r.n_rows == 0) return;
-    const unsigned n_thr = r.n_rows >= 65536 ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
-    std::vector<TextBuf> bufs(n_thr); std::vector<std::thread> th;
-    for (unsigned t = 1; t < n_thr; t++) th.emplace_back([&, t]() { format_range(chrom, r, r.n_rows * t / n_thr, r.n_rows * (t + 1) / n_thr, &bufs[t]); });
-    format_range(chrom, r, 0, r.n_rows / n_thr, &bufs[0]);
-    for (auto& x : th) x.join();
+    const unsigned n_thr = r.n_rows >= 65536 ? std::max(1u, std::min(64u, std::thread::hardware_concurrency())) : 1u;
+    std::vector<TextBuf> bufs(n_thr);
+    HostPool::get().parallel(n_thr, [&](size_t t) { format_range(chrom, r, r.n_rows * t / n_thr, r.n_rows * (t + 1) / n_thr, &bufs[t]); });
     n += r.n_rows;
     {
       std::unique_lock<std::mutex> lk(mu);
