@@ -1002,6 +1002,7 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
   uint32_t w_op = 5u, w_qe = 0; int32_t w_dl = 0; uint32_t w_rtot = 0;
   bool win_loaded = false;
+  uint32_t w_pref = ((uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + lane] : 5u /*0H*/;   // the first CIGAR window, requested before the read is walked
   uint32_t qhead = 0, qcount = 0, d0 = 0;
   // the next step's SEQ dwords (eight per lane = 64 bases, two 16-byte loads) are always in flight; SEQ buffers end with
   // slack, so whole vectors are loaded and the dwords past the read are discarded when the flags are made
@@ -1123,7 +1124,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         if (!win_loaded || (__any(pending && q >= wq1) && !__any(pending && q < wq1))) {
           if (win_loaded) { c0 += 64; wq0 = wq1; wr0 += (int32_t)w_rtot; }
           if (c0 >= h.n_cigar) break;
-          const uint32_t w = (c0 + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + lane] : 5u /*0H*/;
+          const uint32_t w = w_pref;   // requested one window ahead: the load is off the mapping's dependency chain
+          w_pref = (c0 + 64u + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + 64u + lane] : 5u /*0H*/;
           w_op = w & 15u; const uint32_t len = w >> 4;
           const uint32_t qlen = op_consumes_query(w_op) ? len : 0u, rlen = op_consumes_ref(w_op) ? len : 0u;
           w_qe = wave_incl_scan(qlen); const uint32_t re = wave_incl_scan(rlen);
