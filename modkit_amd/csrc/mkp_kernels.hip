@@ -999,10 +999,13 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   uint32_t obs0 = 0, obs1 = 0, contribH = 0, n_ev = 0, cum = 0;
   bool any_surviving = false;
   // CIGAR window: 64 ops in registers, advanced as the batches move along the read
+  // (128 ops per window, two per lane: w_qe = inclusive query end of the lane's pair, w_mid = where its second op starts,
+  //  w_a / w_b = (reference start - query start) << 1 | is-match of the two ops)
   uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
-  uint32_t w_op = 5u, w_qe = 0; int32_t w_dl = 0; uint32_t w_rtot = 0;
+  uint32_t w_qe = 0, w_mid = 0, w_a = 0, w_b = 0, w_rtot = 0;
   bool win_loaded = false;
-  uint32_t w_pref = ((uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + lane] : 5u /*0H*/;   // the first CIGAR window, requested before the read is walked
+  auto cigar2 = [&](uint32_t c) { uint2 r; const uint32_t k = c + 2u * (uint32_t)lane; r.x = k < h.n_cigar ? cigar[h.cigar_off + k] : 5u /*0H*/; r.y = k + 1u < h.n_cigar ? cigar[h.cigar_off + k + 1u] : 5u; return r; };
+  uint2 w_pref = cigar2(0);   // the first CIGAR window, requested before the read is walked
   uint32_t qhead = 0, qcount = 0, d0 = 0;
   // the next step's SEQ dwords (eight per lane = 64 bases, two 16-byte loads) are always in flight; SEQ buffers end with
   // slack, so whole vectors are loaded and the dwords past the read are discarded when the flags are made
@@ -1122,23 +1125,28 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
       bool pending = active;
       for (;;) {
         if (!win_loaded || (__any(pending && q >= wq1) && !__any(pending && q < wq1))) {
-          if (win_loaded) { c0 += 64; wq0 = wq1; wr0 += (int32_t)w_rtot; }
+          if (win_loaded) { c0 += 128; wq0 = wq1; wr0 += (int32_t)w_rtot; }
           if (c0 >= h.n_cigar) break;
-          const uint32_t w = w_pref;   // requested one window ahead: the load is off the mapping's dependency chain
-          w_pref = (c0 + 64u + lane < h.n_cigar) ? cigar[h.cigar_off + c0 + 64u + lane] : 5u /*0H*/;
-          w_op = w & 15u; const uint32_t len = w >> 4;
-          const uint32_t qlen = op_consumes_query(w_op) ? len : 0u, rlen = op_consumes_ref(w_op) ? len : 0u;
-          w_qe = wave_incl_scan(qlen); const uint32_t re = wave_incl_scan(rlen);
-          w_dl = (wr0 + (int32_t)(re - rlen)) - (int32_t)(wq0 + w_qe - qlen);   // ref start - query start of the op
+          const uint2 w = w_pref;   // requested one window ahead: the load is off the mapping's dependency chain
+          w_pref = cigar2(c0 + 128u);
+          const uint32_t op0 = w.x & 15u, len0 = w.x >> 4, op1 = w.y & 15u, len1 = w.y >> 4;
+          const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
+          const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
+          w_qe = wave_incl_scan(ql0 + ql1); const uint32_t re = wave_incl_scan(rl0 + rl1);
+          w_mid = w_qe - ql1;                                                       // window-relative query offset of the second op
+          const int32_t dl0 = (wr0 + (int32_t)(re - rl0 - rl1)) - (int32_t)(wq0 + w_qe - ql0 - ql1);   // ref start - query start of the first op
+          const int32_t dl1 = (wr0 + (int32_t)(re - rl1)) - (int32_t)(wq0 + w_mid);
+          w_a = ((uint32_t)dl0 << 1) | (op_is_match(op0) ? 1u : 0u); w_b = ((uint32_t)dl1 << 1) | (op_is_match(op1) ? 1u : 0u);
           wq1 = wq0 + (uint32_t)__builtin_amdgcn_readlane((int)w_qe, 63); w_rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
           win_loaded = true;
           continue;
         }
         const bool ready = pending && q < wq1;
-        const int oi = find_op(w_qe, ready ? q - wq0 : 0u) & 63;
-        const uint32_t my_op = __shfl(w_op, oi, 64);
-        const int32_t my_dl = __shfl(w_dl, oi, 64);
-        if (ready) { mapped = op_is_match(my_op); rpos = (int32_t)q + my_dl; pending = false; }
+        const uint32_t qrel = ready ? q - wq0 : 0u;
+        const int oi = find_op(w_qe, qrel) & 63;
+        const uint32_t o_mid = (uint32_t)__shfl((int)w_mid, oi, 64), o_a = (uint32_t)__shfl((int)w_a, oi, 64), o_b = (uint32_t)__shfl((int)w_b, oi, 64);
+        const uint32_t pick = qrel < o_mid ? o_a : o_b;
+        if (ready) { mapped = (pick & 1u) != 0u; rpos = (int32_t)q + ((int32_t)pick >> 1); pending = false; }
         if (!__any(pending)) break;
       }
     }
