@@ -176,7 +176,9 @@ def main():
     bam, fa, meta = gen_bam(os.path.join(tmp, "mkp_%s_L%d_N%d_seed%d" % (a.workload, contig_len, n_reads, seed)), contig, contig_len, n_reads, seed, gflags,
                             max(1, (os.cpu_count() or 1) // world))
     gen_s = time.time() - t0
-    flags = ["--cpg", "--ref", fa] if needs_ref else []
+    # `-t 8`: the reference's --threads (8 here, its default is 4) sets how many intervals are in flight (chunk size floor(1.5 t)) and how
+    # the sampling schedule batches its intervals; the device run and the CPU baseline get the same value so that they sample the same reads
+    flags = (["--cpg", "--ref", fa] if needs_ref else []) + ["-t", "8"]
 
     ctx = modkit_amd.Context(device=local_rank)
     out_bed = bam + ".device.bed"
@@ -285,7 +287,7 @@ def main():
             base["speedup_end_to_end"] = (rep.n_positions / (rep.total_ms * 1e-3)) / base["end_to_end"]["positions_per_s"] if not region else None
             if (os.cpu_count() or 1) > 8:   # the same run on more of this box's cores (the reference's --threads is the user's choice)
                 w2 = min(os.cpu_count(), 32)
-                _, _, b2 = cpu_baseline(bam, flags, contig, contig_len, w2, a.cpu_sample)
+                _, _, b2 = cpu_baseline(bam, [f for f in flags if f not in ("-t", "8")] + ["-t", str(w2)], contig, contig_len, w2, a.cpu_sample)   # (-t steers its sampling schedule too: timing only, no sha comparison)
                 base["more_cores"] = {"cores": w2, "positions_per_s": b2["value"], "end_to_end": b2["end_to_end"],
                                       "speedup_end_to_end": (rep.n_positions / (rep.total_ms * 1e-3)) / b2["end_to_end"]["positions_per_s"] if not region else None}
             result["cpu_baseline"] = base
