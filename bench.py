@@ -144,7 +144,10 @@ def main():
     ap.add_argument("--cpu-sample", choices=["full", "region"], default="full", help="CPU baseline + parity on the whole bench BAM (default) or on its first eighth")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the short run the --pmc passes profile
+    ap.add_argument("--skip-e2e", action="store_true", help="profiling runs: skip the sharded end-to-end pass so that every kernel launch is the full-size one the timed region repeats")
     a = ap.parse_args()
+    if a.skip_e2e or a.inner:
+        a.no_cpu_baseline = True   # no sharded output to compare with
 
     import torch
     import modkit_amd
@@ -182,17 +185,20 @@ def main():
 
     ctx = modkit_amd.Context(device=local_rank)
     out_bed = bam + ".device.bed"
-    if world == 1:
+    rep = None
+    if world == 1 and not (a.inner or a.skip_e2e):
         # end to end: the whole subcommand on this context (block reads + inflate, threshold sampling, focus, device pipeline,
         # bedMethyl text), with the driver's default sharding (the next shard's blocks inflate while this one is packed and run)
         rep = ctx.pileup_run([bam, out_bed] + flags)
         thr_h = [float(rep.threshold[i]) if rep.has_threshold[i] else 0.0 for i in range(4)]
+    elif world == 1:
+        thr = ctx.estimate_thresholds(bam, ["-t", "8"])
+        thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
     else:
         # per-base thresholds from ALL ranks' samples: per-rank histograms of the sampled probabilities, summed over RCCL
         from modkit_amd import distributed as mkd
         thr = mkd.estimate_thresholds_allreduce(ctx, bam, [])   # every rank samples its own BAM in full; histograms summed over RCCL
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
-        rep = None
     # kernels-only tier: the whole contig as ONE HBM-resident shard (same thresholds), re-launched K times
     targv = []
     for i in range(4):

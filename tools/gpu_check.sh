@@ -20,6 +20,6 @@ fi
 timeout 1200 python bench.py --steps 20 --warmup 3 "$@" > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
 cat $OUT/bench.json; tail -5 $OUT/bench.err
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pmc "$@" > $OUT/bench_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --skip-e2e "$@" > $OUT/bench_rocprof.json 2> $OUT/rocprof.err; echo "rocprof exit $?"
 for f in $(find /tmp/prof_$TAG -name '*kernel_stats.csv'); do cp $f $OUT/kernel_stats.csv; done
 cat $OUT/kernel_stats.csv 2>/dev/null | head -14
