@@ -327,6 +327,7 @@ struct Options {
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false;
   bool invert_edge = false, mixed_delim = false, with_header = false;
   size_t workers = 1;  // oracle-only: interval-parallel std::thread workers for the CPU baseline
+  bool hemi = false;   // `pileup-hemi` (DuplexModBamPileup, src/pileup/subcommand.rs:827-1514)
 };
 
 struct Region { std::string name; uint32_t start, end; };
@@ -569,6 +570,20 @@ static void write_rows(FILE* f, const std::string& chrom, const std::map<uint32_
   }
 }
 
+// PileupWriter<DuplexModBasePileup> for BedMethylWriter (writers.rs:185-258)
+static void write_duplex_rows(FILE* f, const std::string& chrom, const std::map<uint32_t, std::vector<DuplexRow>>& rows, bool mixed, uint64_t* n_rows) {
+  char sp = mixed ? ' ' : '\t';
+  auto el = [](ModCode c) { return c == 0 ? std::string("-") : code_str(c); };
+  for (auto& kv : rows) for (const DuplexRow& r : kv.second) {
+    uint32_t cov = r.count + r.n_other;
+    float pct = ((float)r.count / (float)cov) * 100.0f;
+    std::string name = el(r.pat[0]) + "," + el(r.pat[1]) + "," + std::string(1, r.base);
+    fprintf(f, "%s\t%u\t%u\t%s\t%u\t.\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos, r.pos + 1, name.c_str(), cov, r.pos, r.pos + 1,
+            cov, sp, (double)pct, sp, r.count, sp, r.n_can, sp, r.n_other, sp, r.n_delete, sp, r.n_fail, sp, r.n_diff, sp, r.n_nocall);
+    (*n_rows)++;
+  }
+}
+
 static int run_pileup(const Options& o) {
   auto t0 = std::chrono::steady_clock::now();
   BamFile bam = read_bam(o.in_bam);
@@ -592,7 +607,13 @@ static int run_pileup(const Options& o) {
   size_t chunk_size = o.have_chunk ? o.chunk_size : (size_t)floorf((float)o.threads * 1.5f);
   if (o.filter_percentile > 1.0f) throw MkErr("filter percentile must be <= 1.0");
   if (o.combine_strands && !(o.cpg || !o.motif_parts.empty())) throw MkErr("need to specify either --motif or --cpg to combine strands");
-  CollapseMethod thr_collapse; bool combine_strands = o.combine_strands;
+  if (o.hemi) {  // subcommand.rs:1247-1276: one palindromic motif, --cpg xor --motif
+    if (!o.cpg && o.motif_parts.empty()) throw MkErr("either --cpg or a --motif must be provided for pileup-hemi");
+    if (o.cpg && !o.motif_parts.empty()) throw MkErr("--cpg cannot be used with --motif");
+    if (o.motif_parts.size() > 2) throw MkErr("motif arg should be length 2, eg. CG 0");
+    if (o.ref_fasta.empty()) throw MkErr("--ref is required");
+  }
+  CollapseMethod thr_collapse; bool combine_strands = o.combine_strands || o.hemi;  // the feeder runs with combine_strands = true (1383-1390)
   if (o.preset == "traditional") { po.numeric = NUM_COLLAPSE; po.collapse.active = true; po.collapse.code = code_char('h'); combine_strands = true; thr_collapse = po.collapse; }
   else if (!o.preset.empty()) throw MkErr("unknown preset");
   else if (o.combine_mods) po.numeric = NUM_COMBINE;
@@ -610,7 +631,7 @@ static int run_pileup(const Options& o) {
   MotifLookup lookup; const MotifLookup* lk = nullptr;
   if (have_motifs) {
     if (o.ref_fasta.empty()) throw MkErr("reference fasta is required for using --motif or --cpg options");
-    if (combine_strands) for (auto& m : motifs) if (!m.info.is_palindrome) throw MkErr("cannot combine strands with a motif that is not a palindrome");
+    if (combine_strands) for (auto& m : motifs) if (!m.info.is_palindrome) throw MkErr(o.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
     lookup.fasta = Fasta::load(o.ref_fasta); lookup.mask = o.mask; lookup.motifs = motifs; for (auto& m : motifs) lookup.longest = std::max<uint64_t>(lookup.longest, m.info.length);
     lk = &lookup;
   }
@@ -625,7 +646,7 @@ static int run_pileup(const Options& o) {
   }
   auto t_thr = std::chrono::steady_clock::now();
   if (pf) reference_records = optimize_reference_records(*pf, reference_records, o.interval_size);
-  FILE* out = (o.out_bed == "-" || o.out_bed == "stdout") ? stdout : fopen(o.out_bed.c_str(), "w");
+  FILE* out = (o.out_bed.empty() || o.out_bed == "-" || o.out_bed == "stdout") ? stdout : fopen(o.out_bed.c_str(), "w");
   if (!out) throw MkErr("failed to make output file");
   if (o.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", out);
   uint64_t n_rows = 0, n_positions = 0, n_proc = 0, n_skip = 0;
@@ -634,14 +655,20 @@ static int run_pileup(const Options& o) {
     std::vector<MultiChromCoordinates> super_batch;
     while (feeder.next_batch(&super_batch)) {
       std::vector<const ChromCoordinates*> work; for (auto& m : super_batch) for (auto& c : m) work.push_back(&c);
-      std::vector<IntervalResult> results(work.size()); std::vector<std::string> errs(work.size());
-      auto job = [&](size_t i) { try { results[i] = process_region(bam, work[i]->tid, work[i]->start, work[i]->end, caller, po, work[i]->focus); } catch (const MkErr& e) { errs[i] = e.what(); } };
+      std::vector<IntervalResult> results(work.size()); std::vector<DuplexIntervalResult> dresults(o.hemi ? work.size() : 0); std::vector<std::string> errs(work.size());
+      auto job = [&](size_t i) {
+        try {
+          if (o.hemi) dresults[i] = process_region_duplex(bam, work[i]->tid, work[i]->start, work[i]->end, caller, po, work[i]->focus);
+          else results[i] = process_region(bam, work[i]->tid, work[i]->start, work[i]->end, caller, po, work[i]->focus);
+        } catch (const MkErr& e) { errs[i] = e.what(); }
+      };
       if (o.workers <= 1) for (size_t i = 0; i < work.size(); i++) job(i);
       else { std::vector<std::thread> th; std::atomic<size_t> nxt{0}; for (size_t w = 0; w < o.workers; w++) th.emplace_back([&]() { for (;;) { size_t i = nxt++; if (i >= work.size()) break; job(i); } }); for (auto& t : th) t.join(); }
       for (size_t i = 0; i < work.size(); i++) {
         if (!errs[i].empty()) { fprintf(stderr, "[oracle] interval error: %s\n", errs[i].c_str()); if (errs[i].find("max-depth") != std::string::npos) throw MkErr(errs[i]); continue; }
-        write_rows(out, bam.ref_names[work[i]->tid], results[i].rows, o.mixed_delim, labels, &n_rows);
-        n_positions += work[i]->len(); n_proc += results[i].processed; n_skip += results[i].skipped;
+        if (o.hemi) { write_duplex_rows(out, bam.ref_names[work[i]->tid], dresults[i].rows, o.mixed_delim, &n_rows); n_proc += dresults[i].processed; n_skip += dresults[i].skipped; }
+        else { write_rows(out, bam.ref_names[work[i]->tid], results[i].rows, o.mixed_delim, labels, &n_rows); n_proc += results[i].processed; n_skip += results[i].skipped; }
+        n_positions += work[i]->len();
       }
     }
   }
@@ -654,12 +681,18 @@ static int run_pileup(const Options& o) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2 || std::string(argv[1]) != "pileup") { fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n"); return 2; }
+  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi")) {
+    fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n");
+    return 2;
+  }
   Options o; std::vector<std::string> pos;
+  o.hemi = std::string(argv[1]) == "pileup-hemi";
   try {
     for (int i = 2; i < argc; i++) {
       std::string a = argv[i];
       auto val = [&]() { if (i + 1 >= argc) throw MkErr("missing value for " + a); return std::string(argv[++i]); };
+      if (o.hemi && (a == "--preset" || a == "--combine-strands" || a == "--with-header" || a == "--header")) throw MkErr("unknown flag " + a + " for pileup-hemi");
+      if (o.hemi && (a == "-o" || a == "--out-bed")) { o.out_bed = val(); continue; }
       if (a == "--region") o.region = val(); else if (a == "--max-depth") o.max_depth = (uint32_t)std::stoul(val());
       else if (a == "-t" || a == "--threads") o.threads = std::stoul(val()); else if (a == "-i" || a == "--interval-size") o.interval_size = (uint32_t)std::stoul(val());
       else if (a == "--chunk-size") { o.have_chunk = true; o.chunk_size = std::stoul(val()); }
@@ -679,8 +712,8 @@ int main(int argc, char** argv) {
       else if (!a.empty() && a[0] == '-' && a != "-") throw MkErr("unknown flag " + a);
       else pos.push_back(a);
     }
-    if (pos.size() != 2) throw MkErr("need <in.bam> <out.bed>");
-    o.in_bam = pos[0]; o.out_bed = pos[1];
+    if (o.hemi) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; }
+    else { if (pos.size() != 2) throw MkErr("need <in.bam> <out.bed>"); o.in_bam = pos[0]; o.out_bed = pos[1]; }
     return run_pileup(o);
   } catch (const std::exception& e) { fprintf(stderr, "Error! %s\n", e.what()); return 1; }
 }

@@ -3,6 +3,7 @@
 // strand combine.  Follows /root/reference/src/read_cache.rs and src/pileup/mod.rs.
 #pragma once
 #include "oracle_core.hpp"
+#include <tuple>
 
 namespace mko {
 
@@ -276,13 +277,10 @@ struct ReadSpan {
   std::vector<int32_t> state;
 };
 
-// process_region (pileup/mod.rs:718-1020).  `recs` = records of the BAM in file order.
-static inline IntervalResult process_region(const BamFile& bam, uint32_t tid, uint32_t start, uint32_t end,
-                                            const ThresholdCaller& caller, const PileupOptions& opts,
-                                            const FocusPositions& focus) {
-  IntervalResult res;
-  ReadCache cache; cache.caller = &caller; cache.opts = &opts;
-  // fetch(tid,start,end) + htslib pileup default mask (UNMAP|SECONDARY|QCFAIL|DUP)
+// fetch(tid,start,end) + the htslib pileup engine (default mask UNMAP|SECONDARY|QCFAIL|DUP; reads stay in push = file order):
+// calls col(P, spans, active) for every column of [start,end) that has at least one read.
+template <class ColFn>
+static inline void sweep_columns(const BamFile& bam, uint32_t tid, uint32_t start, uint32_t end, uint32_t max_depth, ColFn&& col) {
   std::vector<ReadSpan> spans;
   for (const BamRecord& r : bam.recs) {
     if (r.tid != (int32_t)tid) continue;
@@ -302,13 +300,10 @@ static inline IntervalResult process_region(const BamFile& bam, uint32_t tid, ui
     }
     spans.push_back(std::move(sp));
   }
-  if (spans.empty()) return res;
-  // sweep columns; htslib keeps reads in push (file) order
+  if (spans.empty()) return;
   std::vector<size_t> active;
   size_t next = 0;
   int64_t P = std::max<int64_t>(start, spans[0].beg);
-  std::map<uint32_t, std::vector<Row>> pfc;
-  std::vector<size_t> tmp_ids;
   for (; P < (int64_t)end; P++) {
     while (next < spans.size() && spans[next].beg <= P) { active.push_back(next); next++; }
     size_t w = 0;
@@ -320,10 +315,23 @@ static inline IntervalResult process_region(const BamFile& bam, uint32_t tid, ui
       if (P + 1 < (int64_t)start) P = (int64_t)start - 1;
       continue;
     }
-    if (active.size() > opts.max_depth)
+    if (active.size() > max_depth)
       throw MkErr("depth exceeds --max-depth: htslib maxcnt semantics are not restated (parity unpinned)");
+    col((uint32_t)P, spans, active);
+  }
+}
+
+// process_region (pileup/mod.rs:718-1020).  `recs` = records of the BAM in file order.
+static inline IntervalResult process_region(const BamFile& bam, uint32_t tid, uint32_t start, uint32_t end,
+                                            const ThresholdCaller& caller, const PileupOptions& opts,
+                                            const FocusPositions& focus) {
+  IntervalResult res;
+  ReadCache cache; cache.caller = &caller; cache.opts = &opts;
+  std::map<uint32_t, std::vector<Row>> pfc;
+  std::vector<size_t> tmp_ids;
+  sweep_columns(bam, tid, start, end, opts.max_depth, [&](uint32_t P, const std::vector<ReadSpan>& spans, const std::vector<size_t>& active) {
     StrandRule rule;
-    if (!focus.check_position((uint32_t)P, &rule)) continue;
+    if (!focus.check_position((uint32_t)P, &rule)) return;
     Tally pos_tally, neg_tally;
     std::set<ModCode> pos_obs[4], neg_obs[4];
     for (size_t ai : active) {
@@ -379,9 +387,108 @@ static inline IntervalResult process_region(const BamFile& bam, uint32_t tid, ui
       return a.code < b.code;
     });
     pfc[(uint32_t)P] = std::move(counts);
-  }
+  });
   if (opts.combine_strands && focus.kind == FocusPositions::MOTIF_COMBINE) res.rows = combine_strand_features(focus.positive_motifs, pfc);
   else res.rows = std::move(pfc);
+  res.processed = cache.reads.size();
+  res.skipped = cache.skip_set.size();
+  return res;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pileup-hemi: duplex pattern counts (src/pileup/duplex.rs, DuplexReadCache src/read_cache.rs:368-468, DuplexModCall
+// src/mod_bam.rs:1674-1830).  A pattern element is 0 for a canonical call ('-') or the ModCode: DuplexModCodeRepr's derived order
+// (Canonical < Code(char) < ChEbi(u32)) is then the unsigned order of the elements.
+struct DuplexRow {  // DuplexPatternCounts + n_delete of the position (duplex.rs:32-85)
+  uint32_t pos = 0;
+  char base = 'C';            // primary base = the record's SEQ base at the position (reference orientation)
+  ModCode pat[2] = {0, 0};
+  uint32_t count = 0, n_other = 0, n_diff = 0, n_can = 0, n_fail = 0, n_nocall = 0, n_delete = 0;
+};
+struct DuplexIntervalResult {
+  std::map<uint32_t, std::vector<DuplexRow>> rows;  // rows of a position in writer order: base, then pattern (writers.rs:196-207)
+  size_t processed = 0, skipped = 0;
+};
+
+// process_region_duplex (duplex.rs:241-339)
+static inline DuplexIntervalResult process_region_duplex(const BamFile& bam, uint32_t tid, uint32_t start, uint32_t end,
+                                                         const ThresholdCaller& caller, const PileupOptions& opts,
+                                                         const FocusPositions& focus) {
+  if (focus.kind != FocusPositions::MOTIF_COMBINE) throw MkErr("duplex requires a motif");
+  DuplexIntervalResult res;
+  ReadCache cache; cache.caller = &caller; cache.opts = &opts;
+  auto lookup = [](const ReadCacheEntry* e, int s, int base, uint64_t pos) -> const BaseModCall* {  // get_mod_call, read_cache.rs:232-297
+    if (!e) return nullptr;
+    if (!(s ? e->have_neg : e->have_pos) || !e->have_calls[s][base]) return nullptr;
+    auto it = e->calls[s][base].find(pos);
+    return it == e->calls[s][base].end() ? nullptr : &it->second;
+  };
+  sweep_columns(bam, tid, start, end, opts.max_depth, [&](uint32_t P, const std::vector<ReadSpan>& spans, const std::vector<size_t>& active) {
+    StrandRule rule;
+    if (!focus.check_position(P, &rule)) return;        // PileupIter
+    auto mit = focus.positive_motifs.find(P);            // positions_to_motifs.get(&pos)? (duplex.rs:289-296)
+    if (mit == focus.positive_motifs.end()) return;
+    const MotifInfo& motif = mit->second[0].first;
+    // DuplexFeatureVector (duplex.rs:90-122): kind 0 = ModCall(pattern), 1 = Filtered, 2 = NoCall; key (kind, base, a, b)
+    struct Key { int kind; int base; ModCode a, b; bool operator<(const Key& o) const { return std::tie(kind, base, a, b) < std::tie(o.kind, o.base, o.a, o.b); } };
+    std::map<Key, uint32_t> counts;
+    uint32_t n_delete = 0;
+    for (size_t ai : active) {
+      const ReadSpan& sp = spans[ai];
+      int32_t st = sp.state[(size_t)(P - (uint32_t)sp.beg)];
+      if (st == -2) continue;  // is_refskip
+      const BamRecord& r = *sp.rec;
+      if ((r.flag & (2048 | 256 | 1024)) || r.l_seq == 0) continue;
+      if (st == -1) { n_delete++; continue; }
+      if (st >= r.l_seq) continue;
+      int x = base_from_char(r.seq[(size_t)st]);           // get_forward_read_base: NOT complemented here (duplex.rs:308-313)
+      if (x < 0) continue;
+      // get_duplex_mod_call (read_cache.rs:422-462)
+      if (cache.skip_set.count(r.qname)) continue;          // -> None: no feature at all
+      bool rev = r.is_reverse();
+      int pos_base = rev ? complement(x) : x, neg_base = rev ? x : complement(x);
+      const ReadCacheEntry* e = cache.ensure(r);            // a record that fails here still yields one NoCall below
+      const BaseModCall* pc = lookup(e, rev ? 1 : 0, pos_base, (uint64_t)P);
+      uint32_t npos;
+      Key k; k.kind = 2; k.base = x; k.a = 0; k.b = 0;
+      if (motif.negative_strand_position(P, &npos)) {
+        const BaseModCall* nc = lookup(e, rev ? 0 : 1, neg_base, (uint64_t)npos);
+        if (pc && nc) {  // DuplexModCall::from_base_mod_calls (mod_bam.rs:1718-1752)
+          if (pc->kind == BaseModCall::FILTERED || nc->kind == BaseModCall::FILTERED) k.kind = 1;
+          else {
+            k.kind = 0;
+            k.a = pc->kind == BaseModCall::CANONICAL ? 0 : pc->code;
+            k.b = nc->kind == BaseModCall::CANONICAL ? 0 : nc->code;
+            if (opts.numeric == NUM_COMBINE) {  // into_combined (1797-1829)
+              if (k.a) k.a = code_char(base_char(x));
+              if (k.b) k.b = code_char(base_char(x));
+            }
+          }
+        }
+      }
+      counts[k]++;
+    }
+    // DuplexFeatureVector::decode (duplex.rs:124-205)
+    std::vector<DuplexRow>& out = res.rows[P];             // position_feature_counts.insert even when nothing is emitted
+    for (int pb = 0; pb < 4; pb++) {                       // writer: bases sorted by char = A,C,G,T
+      uint32_t total = 0, n_can = 0, n_fail = 0, n_nocall = 0, n_diff = 0;
+      for (auto& kv : counts) {
+        const Key& k = kv.first;
+        if (k.base == pb) {
+          if (k.kind == 0) { total += kv.second; if (k.a == 0 && k.b == 0) n_can += kv.second; }
+          else if (k.kind == 1) n_fail += kv.second; else n_nocall += kv.second;
+        } else if (k.kind == 0) n_diff += kv.second;      // is_mod_call() || is_canonical()
+      }
+      for (auto& kv : counts) {                            // std::map order = (a, b) ascending = patterns.iter().sorted()
+        const Key& k = kv.first;
+        if (k.base != pb || k.kind != 0) continue;
+        DuplexRow row; row.pos = P; row.base = base_char(pb); row.pat[0] = k.a; row.pat[1] = k.b;
+        row.count = kv.second; row.n_other = total - kv.second; row.n_diff = n_diff; row.n_can = n_can; row.n_fail = n_fail;
+        row.n_nocall = n_nocall; row.n_delete = n_delete;
+        out.push_back(row);
+      }
+    }
+  });
   res.processed = cache.reads.size();
   res.skipped = cache.skip_set.size();
   return res;

@@ -23,7 +23,11 @@ for f in bc_anchored_10_reads.sorted.bam bc_anchored_10_reads.sorted.bam.bai \
   modbam.modpileup_filt_positions_025_traditional.methyl.bed cgcg2_cg0_test1.bed cgcg2_cg0_test2.bed \
   cgcg2_cg0_test1_combine_strands.bed cgcg2_cg0_test2_combine_strands.bed \
   pileup-old-tags-regressiontest.methyl.bed \
-  bc_anchored_10_reads.haplotyped.sorted.bam bc_anchored_10_reads.haplotyped.sorted.bam.bai; do
+  bc_anchored_10_reads.haplotyped.sorted.bam bc_anchored_10_reads.haplotyped.sorted.bam.bai \
+  duplex_modcalls_sort.bam duplex_modcalls_sort.bam.bai duplex_hemi_nofilt.bed duplex_hemi.bed; do
   cp "$SRC/$f" "$DST/$f"
 done
+# pileup-hemi (tests/test_pileup_hemi.rs) needs GRCh38_chr20.fa, which the checkout does not ship: the slice the test region
+# touches is rebuilt from the MD tags of the test BAM (exact at every covered position)
+python3 "$(dirname "$0")/make_hemi_reference.py" "$SRC/duplex_modcalls_sort.bam" "$DST/chr20_hemi_slice.txt"
 echo "copied $(ls "$DST" | wc -l) files"

@@ -52,6 +52,34 @@ def fixture(name):
     return os.path.join(FIX, name)
 
 
+# /root/reference/tests/test_pileup_hemi.rs: (name, flags without -r/-o, input BAM, golden)
+HEMI_BAM = "duplex_modcalls_sort.bam"
+_HEMI_REGION = ["--region", "chr20:22,613,835-22,640,468"]
+HEMI_GOLDEN_CASES = [
+    ("test_pileup_hemi_hm:13", ["--motif", "CG", "0"] + _HEMI_REGION + ["--no-filtering", "--mixed-delim"], HEMI_BAM,
+     "duplex_hemi_nofilt.bed"),
+    ("test_pileup_hemi_preset:42", ["--cpg"] + _HEMI_REGION + ["--mixed-delim"], HEMI_BAM, "duplex_hemi.bed"),
+]
+
+
+def hemi_reference_fasta(directory):
+    """GRCh38_chr20.fa stand-in for the pileup-hemi cases: chr20 at its full length, N everywhere except the slice that
+    tests/golden/make_hemi_reference.py rebuilt from the MD tags of the test BAM.  Written once per directory."""
+    path = os.path.join(str(directory), "chr20_hemi.fa")
+    if not os.path.exists(path):
+        with open(fixture("chr20_hemi_slice.txt")) as f:
+            name, length, start = f.readline().split()
+            seq = f.readline().strip().encode()
+        full = bytearray(b"N" * int(length))
+        full[int(start):int(start) + len(seq)] = seq
+        with open(path + ".tmp", "wb") as f:
+            f.write(b">" + name.encode() + b"\n")
+            for i in range(0, len(full), 100000):
+                f.write(full[i:i + 100000] + b"\n")
+        os.replace(path + ".tmp", path)
+    return path
+
+
 def update_tags_ambiguous(src_bam, dst_bam):
     """What `modkit update-tags --mode ambiguous --no-implicit-probs` (src/commands.rs:1239-1282) does to a record whose
     tags are old-style `Mm:Z:C+m,d..;` / `Ml:B:C`: the explicitly listed calls are kept with their qualities, the mode

@@ -6,7 +6,7 @@ import subprocess
 
 import pytest
 
-from pileup_cases import BC, GOLDEN_CASES, REF, fixture, update_tags_ambiguous
+from pileup_cases import BC, GOLDEN_CASES, HEMI_BAM, HEMI_GOLDEN_CASES, REF, fixture, hemi_reference_fasta, update_tags_ambiguous
 
 
 def run_oracle(oracle_bin, bam, out, flags):
@@ -59,3 +59,54 @@ def test_pileup_old_tags(oracle_bin, tmp_path):
     out = str(tmp_path / "out.bed")
     run_oracle(oracle_bin, bam, out, ["--no-filtering", "--only-tabs"])
     assert open(out).read() == open(fixture("pileup-old-tags-regressiontest.methyl.bed")).read()
+
+
+# ---- pileup-hemi (tests/test_pileup_hemi.rs)
+@pytest.fixture(scope="module")
+def hemi_ref(tmp_path_factory):
+    return hemi_reference_fasta(tmp_path_factory.mktemp("hemi_ref"))
+
+
+def run_oracle_hemi(oracle_bin, bam, out, flags, ok=True):
+    p = subprocess.run([oracle_bin, "pileup-hemi", bam, "-o", out] + flags, capture_output=True, text=True)
+    assert (p.returncode == 0) == ok, p.stderr
+    return p.stderr
+
+
+@pytest.mark.parametrize("name,flags,bam,golden", HEMI_GOLDEN_CASES, ids=[c[0] for c in HEMI_GOLDEN_CASES])
+def test_oracle_reproduces_reference_hemi_golden(oracle_bin, tmp_path, hemi_ref, name, flags, bam, golden):
+    out = str(tmp_path / "out.bed")
+    run_oracle_hemi(oracle_bin, fixture(bam), out, flags + ["-r", hemi_ref])
+    assert open(out).read() == open(fixture(golden)).read()
+
+
+def test_hemi_combine_mods_folds_patterns(oracle_bin, tmp_path, hemi_ref):
+    # DuplexModCall::into_combined (src/mod_bam.rs:1797-1829): every modified element becomes the base's any-mod code; the
+    # per-position pattern total is unchanged
+    a, b = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
+    common = ["--cpg", "--region", "chr20:22,613,835-22,640,468", "--no-filtering", "-r", hemi_ref]
+    run_oracle_hemi(oracle_bin, fixture(HEMI_BAM), a, common)
+    run_oracle_hemi(oracle_bin, fixture(HEMI_BAM), b, common + ["--combine-mods"])
+    def by_pos(path):
+        d = {}
+        for ln in open(path):
+            f = ln.split("\t")
+            d.setdefault(int(f[1]), []).append((f[3], int(f[11])))
+        return d
+    pa, pb = by_pos(a), by_pos(b)
+    assert pa.keys() == pb.keys() and len(pa) == 191
+    fold = lambda e: "-" if e == "-" else "C"
+    for pos, rows in pa.items():
+        want = {}
+        for name, cnt in rows:
+            x, y, base = name.split(",")
+            k = "%s,%s,%s" % (fold(x), fold(y), base)
+            want[k] = want.get(k, 0) + cnt
+        assert dict(pb[pos]) == want
+
+
+def test_hemi_requires_a_palindromic_motif(oracle_bin, tmp_path, hemi_ref):
+    err = run_oracle_hemi(oracle_bin, fixture(HEMI_BAM), str(tmp_path / "o.bed"), ["--motif", "CGT", "0", "-r", hemi_ref], ok=False)
+    assert "palindromic" in err
+    err = run_oracle_hemi(oracle_bin, fixture(HEMI_BAM), str(tmp_path / "o.bed"), ["-r", hemi_ref], ok=False)
+    assert "--cpg or a --motif" in err
