@@ -221,6 +221,42 @@ int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint6
 int mkp_histogram_resolve(uint32_t prefix, const uint64_t* hist1, uint64_t rank_in_bin, float* value);
 int mkp_percentile_from_histogram(uint64_t n, float q, float y_floor, float y_ceil, float* out);
 
+/* ---- pileup-hemi: duplex (hemi-methylation) pattern counts.  Stands in for process_region_duplex_batch
+ * (src/pileup/duplex.rs:209-339) over every interval inside a shard, with DuplexReadCache::get_duplex_mod_call
+ * (src/read_cache.rs:422-462) and DuplexFeatureVector::decode (duplex.rs:124-205) on the device.
+ * Rows = DuplexPatternCounts (duplex.rs:32-56) + the position's n_delete, SoA, in the order the reference's writer emits them
+ * (position, primary base by letter, pattern — src/writers.rs:185-258).  A pattern element is MKP_HEMI_CANONICAL for '-'
+ * (a canonical call) or the mod code (code_repr encoding above); DuplexModCodeRepr's order is the numeric order of that. */
+#define MKP_HEMI_CANONICAL 0u
+typedef struct {
+  uint64_t n_rows;
+  const uint32_t* pos;
+  const uint8_t* primary_base;      /* 'A','C','G','T': the record's SEQ base at the position, reference orientation */
+  const uint32_t* pattern_pos;      /* call on the positive strand at `pos` */
+  const uint32_t* pattern_neg;      /* call on the negative strand at the partner position */
+  const uint32_t* n_valid;          /* valid_coverage = count + n_other_pattern */
+  const uint32_t* count;
+  const uint32_t* n_canonical;
+  const uint32_t* n_other_pattern;
+  const uint32_t* n_delete;
+  const uint32_t* n_fail;
+  const uint32_t* n_diff;
+  const uint32_t* n_nocall;
+  uint64_t processed_records, skipped_records;
+} mkp_hemi_rows;
+/* Run the shard begun with mkp_shard_begin / mkp_shard_add_records as pileup-hemi.  The shard's focus bytes must be those of
+ * FocusPositions::MotifCombineStrands for ONE palindromic motif (rule bit 0 + a combo with a positive motif id mark the positions
+ * that get rows).  partner_offset = MotifInfo::negative_strand_position(p) - p (src/motif_bed.rs:124-140; 1 for CG,0).
+ * interval_starts = ascending start positions of the reference's intervals inside [start,end) (ReferenceIntervalsFeeder,
+ * src/interval_chunks.rs:497-652): the reference keeps one read cache per interval, which shows in the output only through
+ * records whose tags fail to parse (one NoCall per such record and interval); NULL / 0 = the shard is one interval.
+ * mkp_shard_rerun re-launches the hemi kernels afterwards (pass out = NULL there). */
+int mkp_hemi_shard_run(mkp_ctx* ctx, int32_t partner_offset, const uint32_t* interval_starts, uint32_t n_intervals, mkp_hemi_rows* out);
+/* `modkit pileup-hemi <in.bam> -o <out.bed> [flags]` (DuplexModBamPileup::run, src/pileup/subcommand.rs:1122-1514):
+ * argv = the arguments after the subcommand name; without -o the rows go to stdout. */
+int mkp_pileup_hemi_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
+int mkp_pileup_hemi_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report);
+
 /* ---- host-side pieces exposed for tests (no device needed):
  * mkp_host_mm_ranks: the packer's MM tokeniser (MmTagInfo::parse, src/mod_bam.rs:909-1000) on one MM string: for every tag its
  *   header (fundamental base A,C,G,T,N = 0..4; strand; mode 0 '?', 1 '.', 2 none; codes as code_repr) and its delta list turned into

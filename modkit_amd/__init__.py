@@ -57,6 +57,9 @@ def lib():
         L.mkp_shard_rerun.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         L.mkp_get_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+        L.mkp_pileup_hemi_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
+        L.mkp_pileup_hemi_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+        L.mkp_hemi_shard_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_void_p]
         u64p, f32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)
         L.mkp_histogram_begin.argtypes = [ctypes.c_void_p]
         L.mkp_histogram_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
@@ -73,7 +76,7 @@ EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
-           "mkp_histogram_resolve", "mkp_percentile_from_histogram"]
+           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run"]
 
 
 def pileup(argv):
@@ -83,6 +86,18 @@ def pileup(argv):
     arr = (ctypes.c_char_p * len(args))(*args)
     err = ctypes.create_string_buffer(2048)
     rc = L.mkp_pileup_main(len(args), arr, err, len(err))
+    if rc != MKP_OK:
+        raise MkpError(rc, err.value.decode(errors="replace"))
+    return rc
+
+
+def pileup_hemi(argv):
+    """`modkit pileup-hemi` (DuplexModBamPileup::run, src/pileup/subcommand.rs:1122): argv = [in_bam, "-o", out_bed, flags...]."""
+    L = lib()
+    args = [str(a).encode() for a in argv]
+    arr = (ctypes.c_char_p * len(args))(*args)
+    err = ctypes.create_string_buffer(2048)
+    rc = L.mkp_pileup_hemi_main(len(args), arr, err, len(err))
     if rc != MKP_OK:
         raise MkpError(rc, err.value.decode(errors="replace"))
     return rc
@@ -121,6 +136,19 @@ class Rows(ctypes.Structure):
                 ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64),
                 ("partition_key", ctypes.POINTER(ctypes.c_uint32)), ("n_partition_keys", ctypes.c_uint32),
                 ("partition_key_names", ctypes.POINTER(ctypes.c_char_p))]
+
+
+class HemiRows(ctypes.Structure):
+    """mkp_hemi_rows: duplex pattern counts (DuplexPatternCounts, src/pileup/duplex.rs:32-56)."""
+    _u32p = ctypes.POINTER(ctypes.c_uint32)
+    _fields_ = [("n_rows", ctypes.c_uint64), ("pos", _u32p), ("primary_base", ctypes.POINTER(ctypes.c_uint8)), ("pattern_pos", _u32p),
+                ("pattern_neg", _u32p), ("n_valid", _u32p), ("count", _u32p), ("n_canonical", _u32p), ("n_other_pattern", _u32p),
+                ("n_delete", _u32p), ("n_fail", _u32p), ("n_diff", _u32p), ("n_nocall", _u32p),
+                ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64)]
+
+
+HEMI_ROW_FIELDS = ("pos", "primary_base", "pattern_pos", "pattern_neg", "n_valid", "count", "n_canonical", "n_other_pattern", "n_delete",
+                   "n_fail", "n_diff", "n_nocall")
 
 
 class Stats(ctypes.Structure):
@@ -223,6 +251,25 @@ class Context:
         rep = RunReport()
         self._check(self.L.mkp_pileup_run(self.h, len(args), arr, ctypes.byref(rep)))
         return rep
+
+    def pileup_hemi_run(self, argv):
+        """`modkit pileup-hemi` on this context (mkp_pileup_hemi_run); returns the stage report."""
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * len(args))(*args)
+        rep = RunReport()
+        self._check(self.L.mkp_pileup_hemi_run(self.h, len(args), arr, ctypes.byref(rep)))
+        return rep
+
+    def hemi_shard_run(self, partner_offset, interval_starts=()):
+        """mkp_hemi_shard_run on the shard begun with shard_begin / add_records; returns a dict of numpy arrays."""
+        import numpy as np
+        iv = (ctypes.c_uint32 * max(1, len(interval_starts)))(*[int(x) for x in interval_starts])
+        rows = HemiRows()
+        self._check(self.L.mkp_hemi_shard_run(self.h, int(partner_offset), iv if len(interval_starts) else None, len(interval_starts), ctypes.byref(rows)))
+        n = int(rows.n_rows)
+        out = {f: (np.ctypeslib.as_array(getattr(rows, f), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)) for f in HEMI_ROW_FIELDS}
+        out["processed_records"], out["skipped_records"] = int(rows.processed_records), int(rows.skipped_records)
+        return out
 
     def rerun(self, iters, fetch=False):
         rows = Rows()

@@ -19,6 +19,8 @@ hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mo
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
                              uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
+hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/, const uint32_t* /*interval starts*/,
+                                  uint32_t, int32_t, int32_t, uint32_t* /*error bits*/);
 }
 
 namespace {
@@ -110,6 +112,46 @@ void make_resident(mkp_ctx* c) {
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a], &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
   for (uint32_t i = 0; i < P.n_slots; i++) { P.slot_order[i] = (uint8_t)order[i]; P.slots[i] = c->tables.st.slots[i]; }
   if (P.combine_strands && !P.has_focus) throw Error(MKP_E_INVALID, "combine_strands needs motif focus positions");
+  if (c->hemi) {
+    // pileup-hemi counters: a pattern block of (1 + codes)^2 counters per primary base that has calls, elements in DuplexModCodeRepr
+    // order (Canonical < Code(char) < ChEbi(id) = 0 < the code_repr encoding's numeric order)
+    if (!c->has_focus) throw Error(MKP_E_INVALID, "pileup-hemi needs the focus positions of a palindromic motif");
+    if (!c->partition_tags.empty()) throw Error(MKP_E_INVALID, "pileup-hemi has no partition tags");
+    P.hemi = 1; P.hemi_off = c->hemi_off;
+    memset(P.hemi_el, 0xff, sizeof(P.hemi_el)); memset(c->hemi_codes, 0, sizeof(c->hemi_codes));
+    uint32_t next = MKP_H_PAT;
+    for (int b = 0; b < 4; b++) { P.hemi_pat_base[b] = 0xff; P.hemi_nel[b] = 0; }
+    for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) {
+      const int pb = c->tables.st.can_pbs[k];
+      std::vector<int> mine; for (size_t i = 0; i < c->tables.st.slots.size(); i++) if (c->tables.st.slots[i].pb == pb) mine.push_back((int)i);
+      std::sort(mine.begin(), mine.end(), [&](int x, int y) { return c->tables.st.slots[(size_t)x].code_repr < c->tables.st.slots[(size_t)y].code_repr; });
+      const bool comb = P.numeric_mode == 1;   // DuplexModCall::into_combined: every modified element becomes the base's any-mod code
+      const uint32_t nel = comb ? (mine.empty() ? 1u : 2u) : 1u + (uint32_t)mine.size();
+      if (nel > MKP_KMAX + 1) throw Error(MKP_E_UNSUPPORTED, "more mod codes on one base than a pileup-hemi pattern block holds");
+      P.hemi_pat_base[pb] = (uint8_t)next; P.hemi_nel[pb] = (uint8_t)nel; next += nel * nel;
+      P.hemi_el[MKP_C_CAN + k] = 0;
+      for (size_t r = 0; r < mine.size(); r++) {
+        const MkpSlot& sl = c->tables.st.slots[(size_t)mine[r]];
+        P.hemi_el[sl.cid] = (uint8_t)(comb ? 1u : 1u + r);
+        c->hemi_codes[pb][comb ? 1u : 1u + r] = comb ? (uint32_t)"ACGT"[pb] : sl.code_repr;
+      }
+    }
+    if (next > MKP_H_MAX_COUNTERS) throw Error(MKP_E_UNSUPPORTED, "too many pileup-hemi pattern counters for one LDS tile");
+    P.hemi_counters = next;
+    // a record whose tags fail leaves one NoCall per interval it crosses (mkp_hemi_failed_reads), written into its own event slice:
+    // make every slice at least that long
+    if (c->hemi_iv.empty()) c->hemi_iv.push_back((uint32_t)S.win_start);
+    if (!std::is_sorted(c->hemi_iv.begin(), c->hemi_iv.end())) throw Error(MKP_E_INVALID, "interval starts must ascend");
+    uint64_t off = 0;
+    for (auto& h : S.hdr) {
+      auto iv_of = [&](int64_t p) { return (int64_t)(std::upper_bound(c->hemi_iv.begin(), c->hemi_iv.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->hemi_iv.begin()); };
+      const int64_t need = iv_of((int64_t)h.ref_end - 1) - iv_of(h.ref_start) + 1;
+      h.event_cap = (uint32_t)std::max<int64_t>(h.event_cap, need);
+      if (off > 0xffffffffull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "more than 2^32 call events in one shard");
+      h.event_off = (uint32_t)off; off += h.event_cap;
+    }
+    S.n_events_cap = off;
+  }
   const size_t n = S.hdr.size();
   for (size_t i = 1; i < n; i++) if (S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted");
   depth_guard(S, c->caller.max_depth);
@@ -118,7 +160,7 @@ void make_resident(mkp_ctx* c) {
   // workgroup including ~3.5 KiB of static LDS leaves slack for the allocation granule (at 80 KiB each one GPU box ran them one
   // per CU and the kernel took 1.9x as long).  A tile = a run of reference positions; its tally columns ("slots") are all of
   // its positions, or — when the run has focus positions — only those, so a --cpg tile spans ~50x more reference.
-  const uint32_t words_per_slot = P.n_counters + P.n_slots;
+  const uint32_t words_per_slot = c->hemi ? P.hemi_counters : P.n_counters + P.n_slots;
   const uint32_t budget_words = (76u * 1024u - 3584u) / 4u;
   const int64_t win = (int64_t)S.win_end - (int64_t)S.win_start;
   std::vector<MkpTile> tiles; std::vector<uint32_t> slotbm; uint32_t Scap = 0, Wcap = 0;
@@ -135,8 +177,11 @@ void make_resident(mkp_ctx* c) {
     const size_t nbits = (size_t)win + 2 * MKP_SLOTBM_MARGIN, nwords = (nbits + 31) / 32 + 2;
     slotbm.assign(nwords, 0);
     const uint8_t* fz = c->focus.data();
+    // pileup-hemi: only the positions with a positive-strand motif hit own a column (positions_to_motifs.get(pos), duplex.rs:289-296)
+    uint8_t hemi_ok[64]; for (size_t k = 0; k < 64; k++) hemi_ok[k] = (k < c->combos.size() && c->combos[k].n_pos > 0) ? 1 : 0;
+    const bool hemi = c->hemi;
     host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {   // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
-      for (size_t p = lo; p < hi; p++) if (fz[p] & 3u) { const size_t b = p + MKP_SLOTBM_MARGIN; slotbm[b >> 5] |= 1u << (b & 31); }
+      for (size_t p = lo; p < hi; p++) if (hemi ? ((fz[p] & 1u) && hemi_ok[fz[p] >> 2]) : (fz[p] & 3u)) { const size_t b = p + MKP_SLOTBM_MARGIN; slotbm[b >> 5] |= 1u << (b & 31); }
     });
     std::vector<uint32_t> wpfx(nwords + 1, 0);
     for (size_t w = 0; w < nwords; w++) wpfx[w + 1] = wpfx[w] + (uint32_t)__builtin_popcount(slotbm[w]);
@@ -189,6 +234,7 @@ void make_resident(mkp_ctx* c) {
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
   c->d_misc.ensure(64);
+  if (c->hemi) upload(c->d_hemi_iv, c->hemi_iv);
   // partition keys present in this shard: one accumulate pass each
   c->key_passes.clear();
   if (c->partition_tags.empty()) c->key_passes.push_back(MKP_NO_KEY_FILTER);
@@ -196,7 +242,7 @@ void make_resident(mkp_ctx* c) {
   hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
-  c->resident = true;
+  c->resident = true; c->resident_hemi = c->hemi;
   // algorithmic bytes
   uint64_t b_reads = 0; for (auto& h : S.hdr) b_reads += 16 + 4ull * h.n_cigar + (h.l_seq + 1) / 2;
   c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = (uint64_t)win;
@@ -208,7 +254,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
   MkpRunParams& P = c->prm;
   if (c->row_cap == 0) {
     // focus runs: usually one strand rule per focus position and one row per observed code; otherwise two strands per position
-    uint64_t guess = c->has_focus ? c->n_slots_total * std::max<uint32_t>(1u, P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
+    uint64_t guess = c->hemi ? c->n_slots_total * 3 + 4096 : c->has_focus ? c->n_slots_total * std::max<uint32_t>(1u, P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
     c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess * c->key_passes.size(), 1ull << 28));
   }
   const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
@@ -223,9 +269,11 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
+    if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+                                                  (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
-      hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+      hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
                                   c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
@@ -246,22 +294,45 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
   }
 }
 
-void fetch_rows(mkp_ctx* c, mkp_rows* out) {
-  auto t0 = std::chrono::steady_clock::now();
-  const uint64_t n = c->stats.n_rows, cap = c->row_cap;
+// row columns and per-read outcome counts, device -> host
+void fetch_row_columns(mkp_ctx* c) {
+  const uint64_t n = c->stats.n_rows;
   const uint32_t* src[11] = {c->rows_dst.pos, c->rows_dst.info, c->rows_dst.code, c->rows_dst.n_valid, c->rows_dst.n_mod, c->rows_dst.n_can, c->rows_dst.n_other,
                              c->rows_dst.n_del, c->rows_dst.n_fail, c->rows_dst.n_diff, c->rows_dst.n_nocall};
-  (void)cap;
   for (int k = 0; k < 11; k++) { c->h_rows[k].resize(n); if (n) hip_check(hipMemcpy(c->h_rows[k].data(), src[k], n * 4, hipMemcpyDeviceToHost), "rows D2H"); }
-  c->h_strand.resize(n); c->h_motif.resize(n); c->h_key.resize(n);
-  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1; c->h_key[i] = inf >> 16; }
-  c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
-  // per-read outcome counts
   std::vector<MkpReadOut> ro(c->shard.hdr.size());
   if (!ro.empty()) hip_check(hipMemcpy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost), "readout D2H");
   c->n_ok = 0; c->n_bad = 0; uint64_t ev = 0;
   for (auto& r : ro) { if (r.ok) { c->n_ok++; ev += r.n_events; } else c->n_bad++; }
   c->stats.n_events = ev;
+}
+
+void fetch_hemi_rows(mkp_ctx* c, mkp_hemi_rows* out) {
+  auto t0 = std::chrono::steady_clock::now();
+  fetch_row_columns(c);
+  const uint64_t n = c->stats.n_rows;
+  c->h_hemi_base.resize(n); c->h_hemi_pat[0].resize(n); c->h_hemi_pat[1].resize(n);
+  for (uint64_t i = 0; i < n; i++) {   // rows.info = primary base, rows.code = pattern elements a | b << 8
+    const uint32_t pb = c->h_rows[1][i] & 3u, a = c->h_rows[2][i] & 0xffu, b = (c->h_rows[2][i] >> 8) & 0xffu;
+    c->h_hemi_base[i] = (uint8_t)"ACGT"[pb];
+    c->h_hemi_pat[0][i] = a <= MKP_KMAX + 1 ? c->hemi_codes[pb][a] : 0u; c->h_hemi_pat[1][i] = b <= MKP_KMAX + 1 ? c->hemi_codes[pb][b] : 0u;
+  }
+  c->stats.d2h_ms = ms_since(t0);
+  if (out) {
+    out->n_rows = n; out->pos = c->h_rows[0].data(); out->primary_base = c->h_hemi_base.data(); out->pattern_pos = c->h_hemi_pat[0].data(); out->pattern_neg = c->h_hemi_pat[1].data();
+    out->n_valid = c->h_rows[3].data(); out->count = c->h_rows[4].data(); out->n_canonical = c->h_rows[5].data(); out->n_other_pattern = c->h_rows[6].data();
+    out->n_delete = c->h_rows[7].data(); out->n_fail = c->h_rows[8].data(); out->n_diff = c->h_rows[9].data(); out->n_nocall = c->h_rows[10].data();
+    out->processed_records = c->n_ok; out->skipped_records = c->n_bad;
+  }
+}
+
+void fetch_rows(mkp_ctx* c, mkp_rows* out) {
+  auto t0 = std::chrono::steady_clock::now();
+  fetch_row_columns(c);
+  const uint64_t n = c->stats.n_rows;
+  c->h_strand.resize(n); c->h_motif.resize(n); c->h_key.resize(n);
+  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1; c->h_key[i] = inf >> 16; }
+  c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
   c->stats.d2h_ms = ms_since(t0);
   if (out) {
     out->n_rows = n; out->pos = c->h_rows[0].data(); out->strand = c->h_strand.data(); out->code_repr = c->h_rows[2].data(); out->motif_idx = c->h_motif.data();
@@ -339,7 +410,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -429,7 +500,8 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
   return guarded(c, [&]() {
     if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
     if (!c->caller_set) throw Error(MKP_E_INVALID, "mkp_set_caller first");
-    if (!c->resident) make_resident(c);
+    c->hemi = false;
+    if (!c->resident || c->resident_hemi) { c->row_cap = 0; make_resident(c); }
     run_kernels(c, true);
     fetch_rows(c, out);
     c->stats.alg_bytes_decode += 8ull * c->stats.n_events;
@@ -438,10 +510,30 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
   });
 }
 
+int mkp_hemi_shard_run(mkp_ctx* c, int32_t partner_offset, const uint32_t* interval_starts, uint32_t n_intervals, mkp_hemi_rows* out) {
+  if (!c || (n_intervals && !interval_starts)) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
+    if (!c->caller_set) throw Error(MKP_E_INVALID, "mkp_set_caller first");
+    if (partner_offset < -MKP_HALO || partner_offset > MKP_HALO) throw Error(MKP_E_UNSUPPORTED, "motif longer than the tile halo");
+    std::vector<uint32_t> iv(interval_starts, interval_starts + n_intervals);
+    if (iv.empty()) iv.push_back((uint32_t)std::max(c->shard.win_start, 0));
+    const bool same = c->resident && c->resident_hemi && c->hemi_off == partner_offset && c->hemi_iv == iv;
+    c->hemi = true; c->hemi_off = partner_offset;
+    if (!same) { c->hemi_iv = std::move(iv); c->row_cap = 0; make_resident(c); }
+    run_kernels(c, true);
+    fetch_hemi_rows(c, out);
+    c->stats.alg_bytes_decode += 8ull * c->stats.n_events;
+    c->stats.alg_bytes_pileup += 8ull * c->stats.n_events + 44ull * c->stats.n_rows;
+    c->stats.alg_bytes_rows = 0;
+  });
+}
+
 int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
   if (!c) return MKP_E_INVALID;
   return guarded(c, [&]() {
     if (!c->resident) throw Error(MKP_E_INVALID, "no resident shard: call mkp_shard_run once first");
+    if (c->resident_hemi && out) throw Error(MKP_E_INVALID, "the resident shard ran as pileup-hemi: pass out = NULL here and read rows with mkp_hemi_shard_run");
     double d = 0, p = 0, g = 0;
     for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; g += c->stats.gather_kernel_ms; }
     if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = g / iters; c->stats.kernel_ms = (d + p + g) / iters; }

@@ -49,6 +49,9 @@ struct mkp_ctx {
   // --partition-tag: tag names, the shard's key names (index = key id, 0 = "ungrouped"), the key ids present (one accumulate pass each)
   std::vector<std::string> partition_tags, key_names{"ungrouped"}; std::vector<const char*> key_name_ptrs; std::vector<uint32_t> key_passes{0xffffffffu};
   uint64_t n_ok = 0, n_bad = 0;
+  // pileup-hemi (mkp_hemi_shard_run): mode of the resident plan, partner offset, interval starts, pattern element -> mod code
+  bool hemi = false, resident_hemi = false; int32_t hemi_off = 0; std::vector<uint32_t> hemi_iv; mkp::DevBuf d_hemi_iv;
+  uint32_t hemi_codes[4][MKP_KMAX + 2] = {}; std::vector<uint8_t> h_hemi_base; std::vector<uint32_t> h_hemi_pat[2];
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -134,7 +134,21 @@ struct MkpRunParams {
   uint8_t can_of_pb[4];     // primary base -> CAN counter k or 0xff
   uint8_t slot_order[MKP_MAX_SLOTS];   // slots sorted by (code_repr, pb)
   MkpSlot slots[MKP_MAX_SLOTS];
+  // pileup-hemi (duplex.rs): per '+' motif position and primary base, one counter per (positive-strand call, negative-strand call)
+  // pattern.  A pattern element is 0 for a canonical call, 1.. for the base's mod codes in DuplexModCodeRepr order.
+  uint32_t hemi;                          // 1: mkp_pileup_tiles_hemi tallies
+  int32_t hemi_off;                       // MotifInfo::negative_strand_position: partner position = position + hemi_off
+  uint32_t hemi_counters;                 // counters per tally column (MKP_H_* layout below)
+  uint8_t hemi_pat_base[4];               // primary base -> its first pattern counter (0xff: the base has no calls in this run)
+  uint8_t hemi_nel[4];                    // primary base -> pattern elements (1 + mod codes; 2 with --combine-mods)
+  uint8_t hemi_el[MKP_MAX_COUNTERS + 2];  // call-event counter id -> pattern element; 0xff = Filtered
 };
+// pileup-hemi counters of one tally column: NoCall(base) 0..3, deletions, Filtered(base) 5..8, then the pattern blocks
+#define MKP_H_NC 0
+#define MKP_H_DEL 4
+#define MKP_H_FAIL 5
+#define MKP_H_PAT 9
+#define MKP_H_MAX_COUNTERS 64
 
 // One tile of mkp_pileup_tiles: rows are emitted for reference positions [r0, r1) (inside the shard window); tallies are kept
 // for the slots of [r0 - MKP_HALO, r1 + MKP_HALO) (strand combining reads a partner up to MKP_HALO away); reads [first, last)

@@ -29,6 +29,7 @@ struct Args {
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
   int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */; bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
+  bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
 };
 
 struct RegionSpec { std::string name; uint32_t start, end; };
@@ -354,12 +355,20 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (idxstats(bam, have_region ? &region : nullptr, bf).mapped == 0) throw Error(MKP_E_INVALID, "did not find any mapped reads, perform alignment first or use modkit extract and/or modkit summary to inspect unaligned modBAMs");
   if (a.filter_percentile > 1.0f) throw Error(MKP_E_INVALID, "filter percentile must be <= 1.0");
   if (a.combine_strands && !(a.cpg || !a.motif_parts.empty())) throw Error(MKP_E_INVALID, "need to specify either --motif or --cpg to combine strands");
+  if (a.hemi) {  // subcommand.rs:1247-1276: one motif, --cpg or --motif (a clap argument group: not both), palindromic; the reference FASTA is required
+    if (!a.cpg && a.motif_parts.empty()) throw Error(MKP_E_INVALID, "either --cpg or a --motif must be provided for pileup-hemi");
+    if (a.cpg && !a.motif_parts.empty()) throw Error(MKP_E_INVALID, "the argument '--cpg' cannot be used with '--motif'");
+    if (a.motif_parts.size() > 2) throw Error(MKP_E_INVALID, "motif arg should be length 2, eg. CG 0");
+    if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "the following required arguments were not provided: --ref <REFERENCE_FASTA>");
+    if (a.world > 1) throw Error(MKP_E_UNSUPPORTED, "pileup-hemi runs on one GPU");
+  }
   bool combine_strands = a.combine_strands;  // option resolution (subcommand.rs:484-523)
   if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; combine_strands = true; }
   else if (!a.preset.empty()) throw Error(MKP_E_INVALID, "unknown preset " + a.preset);
   else if (a.combine_mods) kc.numeric_mode = 1;
   else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
   kc.combine_strands = combine_strands;
+  if (a.hemi) combine_strands = true;   // the interval feeder runs with combine_strands = true ("must be true for duplex", subcommand.rs:1383-1390); the caller's flag stays off
   FocusBuilder fb; fb.combine = combine_strands; fb.mask = a.mask; fb.bed = bf;
   Fasta fasta;
   if (!a.motif_parts.empty()) {  // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
@@ -372,7 +381,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   RowWriter wr; wr.mixed = a.mixed_delim; for (auto& m : fb.motifs) wr.labels.push_back(m.label());
   if (!fb.motifs.empty()) {
     if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "reference fasta is required for using --motif or --cpg options");
-    if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID, "cannot combine strands with a motif that is not a palindrome");
+    if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID, a.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
     fasta = Fasta::load(a.ref_fasta); fb.fasta = &fasta;
   }
   mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
@@ -411,7 +420,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
     if (mkdir(a.out_bed.c_str(), 0777) != 0 && errno != EEXIST) throw Error(MKP_E_IO, "failed to make output directory " + a.out_bed);
   } else {
-  wr.f = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w");
+  wr.f = (a.out_bed == "-" || a.out_bed == "stdout" || (a.hemi && a.out_bed.empty())) ? stdout : fopen(a.out_bed.c_str(), "w");
   if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
   }
   auto writer_for = [&](const std::string& key) -> RowWriter& {
@@ -431,7 +440,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
   const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
   // 2^27 positions per shard keeps the per-shard focus / slot buffers small
-  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; };
+  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */ };
   std::vector<ShardPlan> plan; std::vector<std::vector<uint8_t>> focus_of(records.size()); std::vector<char> focus_done(records.size(), 0);
   const bool hf = fb.has_focus();
   uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, focus_ms = 0, fetch_wait_ms = 0;
@@ -451,8 +460,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
         const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
         const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
+        std::vector<uint32_t> iv_starts; if (a.hemi) for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);
         i0 = i1;
-        if (owner == a.rank) plan.push_back({ri, s0, s1, bp});
+        if (owner == a.rank) plan.push_back({ri, s0, s1, bp, std::move(iv_starts)});
       }
     }
   }
@@ -488,7 +498,17 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       must(mkp_shard_begin(ctx, &sh));
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       batch.reset();   // packed: the inflated blocks are no longer needed
-      mkp_rows rows; must(mkp_shard_run(ctx, &rows));
+      mkp_rows rows; memset(&rows, 0, sizeof(rows));
+      if (a.hemi) {
+        int hoff = 0; fb.motifs[0].neg_delta(&hoff);
+        mkp_hemi_rows hrows; must(mkp_hemi_shard_run(ctx, hoff, sp.iv_starts.data(), (uint32_t)sp.iv_starts.size(), &hrows));
+        if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, nullptr));
+        auto t_w = std::chrono::steady_clock::now();
+        wr.write_hemi(rec.name, hrows);
+        write_ms += ms_since(t_w);
+        rows.processed_records = hrows.processed_records; rows.skipped_records = hrows.skipped_records;
+      } else {
+      must(mkp_shard_run(ctx, &rows));
       if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, &rows));   // measurement aid: warm, averaged kernel times in --stats
       { auto t_w = std::chrono::steady_clock::now();
         if (!partitioned) wr.write(rec.name, rows);
@@ -501,6 +521,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           i0r = i1r;
         }
         write_ms += ms_since(t_w); }
+      }
       n_shards++;
       mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
@@ -521,11 +542,15 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   return MKP_OK;
 }
 
-void parse_args(int argc, const char* const* argv, Args* out, bool need_positional) {
+void parse_args(int argc, const char* const* argv, Args* out, bool need_positional, bool hemi = false) {
   Args& a = *out; std::vector<std::string> pos;
+  a.hemi = hemi;
   for (int i = 0; i < argc; i++) {
     std::string s = argv[i];
     auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
+    if (hemi && (s == "--preset" || s == "--combine-strands" || s == "--with-header" || s == "--header" || s == "--partition-tag" || s == "--prefix" || s == "--bedgraph" || s == "--plan-only"))
+      throw Error(MKP_E_INVALID, "unexpected argument '" + s + "' for pileup-hemi");
+    if (hemi && (s == "-o" || s == "--out-bed")) { a.out_bed = val(); continue; }
     if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
     else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
     else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath" || s == "--seed") val();
@@ -547,7 +572,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);
   }
-  if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]"); a.in_bam = pos[0]; a.out_bed = pos[1]; }
+  if (need_positional && hemi) { if (pos.size() != 1) throw Error(MKP_E_INVALID, "usage: <in.bam> -o <out.bed> [flags of `modkit pileup-hemi`]"); a.in_bam = pos[0]; }
+  else if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]"); a.in_bam = pos[0]; a.out_bed = pos[1]; }
   else if (!pos.empty()) throw Error(MKP_E_INVALID, "unexpected positional argument " + pos[0]);
   if (a.world == 0 || a.rank >= a.world) throw Error(MKP_E_INVALID, "bad --gpus-rank/--gpus-world");
 }
@@ -561,6 +587,24 @@ extern "C" int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, 
     return run(a, nullptr, nullptr);
   } catch (const Error& e) { return fail(e.status, e.what()); }
   catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }
+}
+
+extern "C" int mkp_pileup_hemi_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len) {
+  auto fail = [&](int st, const std::string& m) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return st; };
+  try {
+    Args a; parse_args(argc, argv, &a, true, true);
+    return run(a, nullptr, nullptr);
+  } catch (const Error& e) { return fail(e.status, e.what()); }
+  catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }
+}
+
+extern "C" int mkp_pileup_hemi_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report) {
+  if (!ctx) return MKP_E_INVALID;
+  try {
+    Args a; parse_args(argc, argv, &a, true, true);
+    return run(a, ctx, report);
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
 }
 
 // The same subcommand on a context the caller owns: the last shard stays resident in HBM afterwards (mkp_shard_rerun

@@ -1400,6 +1400,36 @@ __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& pr
   return n;
 }
 
+// pileup-hemi rows of one '+' motif position whose counters sit in column i (DuplexFeatureVector::decode, duplex.rs:124-205, in the
+// writer's order: primary base, then pattern — writers.rs:196-207).  The pattern goes out as its two element indices
+// (rows.code = a | b << 8), the primary base in rows.info; the host turns the elements into mod codes.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t hemi_rows_at(const uint32_t* __restrict__ tal, uint32_t S, const MkpRunParams& prm, int32_t p, uint32_t i, const MkpRowsDev& rows, uint32_t wr) {
+  uint32_t tot[4], n = 0;
+  for (int pb = 0; pb < 4; pb++) {
+    tot[pb] = 0;
+    const uint32_t base = prm.hemi_pat_base[pb], nel = prm.hemi_nel[pb];
+    if (base != 0xffu) for (uint32_t k = 0; k < nel * nel; k++) tot[pb] += tal[(base + k) * S + i];
+  }
+  for (int pb = 0; pb < 4; pb++) {
+    if (!tot[pb]) continue;
+    const uint32_t base = prm.hemi_pat_base[pb], nel = prm.hemi_nel[pb];
+    for (uint32_t k = 0; k < nel * nel; k++) {
+      const uint32_t cnt = tal[(base + k) * S + i];
+      if (!cnt) continue;
+      if (WRITE) {
+        const uint32_t r = wr + n;
+        rows.pos[r] = (uint32_t)p; rows.info[r] = (uint32_t)pb; rows.code[r] = (k / nel) | ((k % nel) << 8);
+        rows.n_valid[r] = tot[pb]; rows.n_mod[r] = cnt; rows.n_can[r] = tal[base * S + i]; rows.n_other[r] = tot[pb] - cnt;
+        rows.n_del[r] = tal[MKP_H_DEL * S + i]; rows.n_fail[r] = tal[(MKP_H_FAIL + pb) * S + i];
+        rows.n_diff[r] = tot[0] + tot[1] + tot[2] + tot[3] - tot[pb]; rows.n_nocall[r] = tal[(MKP_H_NC + pb) * S + i];
+      }
+      n++;
+    }
+  }
+  return n;
+}
+
 #define PILEUP_THREADS MKP_PILEUP_THREADS
 #define PILEUP_WAVES (PILEUP_THREADS / 64)
 #define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
@@ -1447,7 +1477,7 @@ template <bool FOCUS> struct SlotMap {
 
 // Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
 // run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
-template <bool FOCUS>
+template <bool FOCUS, bool HEMI>
 __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SlotMap<FOCUS> sm, uint32_t n_tslots, MkpTile tl, uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
                                             const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
                                             uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
@@ -1466,6 +1496,7 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
   for (uint32_t i = threadIdx.x; i < n_tslots; i += PILEUP_THREADS) {
     const int32_t p = sm.pos_of(i);
     if (p < tl.r0 || p >= tl.r1) continue;
+    if (HEMI) { mine += hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0); continue; }
     const uint32_t fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u;
     mine += rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of);
   }
@@ -1487,7 +1518,10 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       uint32_t cnt = 0, fv = 0; int32_t p = 0;
       if (i < n_tslots) {
         p = sm.pos_of(i);
-        if (p >= tl.r0 && p < tl.r1) { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+        if (p >= tl.r0 && p < tl.r1) {
+          if (HEMI) cnt = hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0);
+          else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+        }
       }
       const uint32_t inc2 = wave_incl_scan(cnt);
       __syncthreads();   // wave_tot / scan_carry of the previous round are consumed
@@ -1495,7 +1529,7 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       __syncthreads();
       uint32_t woff = *scan_carry_p;
       for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
-      if (cnt) rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of, key);
+      if (cnt) { if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, row_base + woff + inc2 - cnt); else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of, key); }
       __syncthreads();
       if (threadIdx.x == PILEUP_THREADS - 1) *scan_carry_p = woff + inc2;
     }
@@ -1518,7 +1552,9 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
 // the rows of FeatureVector::decode (412-446) / add_tally_to_counts (283-410) / combine_strand_features (469-561) are produced
 // straight from LDS: counted, reserved in the row buffer with one atomic per tile, written.  mkp_scan_tiles / mkp_gather_rows
 // put the tiles' row runs in genome order.
-template <bool FOCUS, int UNROLL, bool KEYED>
+// HEMI (pileup-hemi, duplex.rs:241-339): the tally columns are the '+' motif positions; a read's '+' tally call at such a position
+// and its '-' tally call at the partner position form one pattern count; everything else about the walk is the focus kernel's.
+template <bool FOCUS, int UNROLL, bool KEYED, bool HEMI = false>
 __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles,
                  const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos,
@@ -1547,7 +1583,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
   const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
   const uint32_t S = prm.slot_cap, W = prm.focus_words;
-  const uint32_t n_counters = prm.n_counters, n_oslots = prm.n_slots;
+  const uint32_t n_counters = HEMI ? prm.hemi_counters : prm.n_counters, n_oslots = HEMI ? 0u : prm.n_slots;
   const uint32_t tal_words = (n_counters + n_oslots) * S;
   uint32_t* __restrict__ tal = lds;                       // [n_counters + n_oslots][S], packed
   uint32_t* __restrict__ obs = lds + n_counters * S;      // observed-code difference arrays
@@ -1653,7 +1689,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
     uint32_t w_next = 5u; uint2 w2_next = make_uint2(5u, 5u);   // focus kernel: two ops per lane
     if (FOCUS) w2_next = load2(c_first); else w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
     // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
-    if (ro.ok && lane < 2) {
+    if (!HEMI && ro.ok && lane < 2) {
       uint32_t m = lane ? ro.obs[1] : ro.obs[0];
       while (m) {
         const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
@@ -1661,6 +1697,50 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
         if (rs_b < n_tslots) atomicAdd(&obs[sl * S + rs_b], 0u - (lane ? 0x10000u : 1u));
       }
     }
+    if (HEMI) {
+      // get_duplex_mod_call (read_cache.rs:422-462) over the read's call events inside the tile (sorted by position): a '+' tally
+      // call at a slot = the positive-strand half; its partner is the read's '-' tally call on the same primary base at
+      // position + hemi_off (a few events away).  Both present -> one pattern (or Filtered) count and the NoCall the walk below
+      // adds for this base is taken back; otherwise the base stays a NoCall.  A record whose tags failed carries, instead of
+      // calls, the one NoCall per interval the reference's cache leaves for it (mkp_hemi_failed_reads).
+      if (ro.n_events) {
+        const MkpEvent* __restrict__ ev = events + h.event_off;
+        const uint32_t lo = h.ref_start >= T0h ? 0u : event_lower_bound(ev, ro.n_events, T0h);
+        const int32_t hoff = prm.hemi_off;
+        auto pb_of = [](uint32_t info) { const uint32_t b = (info >> 9) & 3u; return (((info >> 11) ^ (info >> 8)) & 1u) ? 3u - b : b; };   // threshold base of the call (read_cache.rs:147-150)
+        for (uint32_t k = lo + lane;; k += 64) {
+          bool in = k < ro.n_events;
+          MkpEvent e; e.pos = 0; e.info = 0;
+          if (in) { e = ev[k]; in = (int32_t)e.pos < T1h; }
+          if (in && sm.is_slot((int32_t)e.pos)) {
+            const uint32_t i = sm.rank((int32_t)e.pos);
+            if (!ro.ok) atomicAdd(&tal[(e.info & 0xffu) * S + i], 1u);
+            else if (!(e.info & 0x100u)) {
+              const uint32_t pbA = pb_of(e.info);
+              const int32_t q = (int32_t)e.pos + hoff;
+              uint32_t binfo = 0xffffffffu;
+              if (hoff >= 0) for (uint32_t j = k + 1u; j < ro.n_events; j++) {
+                const MkpEvent f = ev[j];
+                if ((int32_t)f.pos > q) break;
+                if ((int32_t)f.pos == q && (f.info & 0x100u) && pb_of(f.info) == pbA) { binfo = f.info; break; }
+              }
+              if (hoff <= 0 && binfo == 0xffffffffu) for (uint32_t j = k; j-- > 0u;) {
+                const MkpEvent f = ev[j];
+                if ((int32_t)f.pos < q) break;
+                if ((int32_t)f.pos == q && (f.info & 0x100u) && pb_of(f.info) == pbA) { binfo = f.info; break; }
+              }
+              if (binfo != 0xffffffffu && q >= 0) {
+                const uint32_t elA = prm.hemi_el[e.info & 0xffu], elB = prm.hemi_el[binfo & 0xffu];
+                const uint32_t cid = (elA == 0xffu || elB == 0xffu) ? (uint32_t)MKP_H_FAIL + pbA : (uint32_t)prm.hemi_pat_base[pbA] + elA * prm.hemi_nel[pbA] + elB;
+                atomicAdd(&tal[cid * S + i], 1u);
+                atomicAdd(&tal[(MKP_H_NC + pbA) * S + i], 0u - 1u);
+              }
+            }
+          }
+          if (!__any(in)) break;
+        }
+      }
+    } else
     // the read's call events inside the tile (sorted by position)
     if (ro.ok && ro.n_events) {
       const MkpEvent* __restrict__ ev = events + h.event_off;
@@ -1678,9 +1758,9 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
         if (!__any(in)) break;
       }
     }
-    const uint32_t inc = aln ? 0x10000u : 1u;   // this alignment strand's half of the packed tallies
+    const uint32_t inc = HEMI ? 1u : (aln ? 0x10000u : 1u);   // this alignment strand's half of the packed tallies (hemi: plain counters)
     const uint8_t* __restrict__ lut = &rowlut[0][0][0];
-    const uint32_t aln2 = aln << 1;
+    const uint32_t aln2 = HEMI ? 0u : aln << 1;   // hemi: the primary base is the SEQ base as stored, whatever the strand (duplex.rs:308-313)
     const uint32_t lanebase = lds_addr(tal) + 4u * (uint32_t)lane;   // LDS byte address of (row 0, slot `lane`)
     const uint32_t fposbase = lds_addr(fpos) + 4u * (uint32_t)lane;
     const uint32_t qbase = (uint32_t)(0 - h.ref_start) - (1u << 26);   // query index = position + qbase + packed offset
@@ -1712,7 +1792,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
             const uint32_t kind0 = op_is_match(op0) ? 0u : (op0 == 2 ? 1u : 2u), kind1 = op_is_match(op1) ? 0u : (op1 == 2 ? 1u : 2u);
             const uint32_t pk0 = ((uint32_t)((int32_t)qs0 - (rs0 - h.ref_start) + (1 << 26)) << 5) | (kind0 << 3);  // q = (pos - ref_start) + D
             const uint32_t pk1 = ((uint32_t)((int32_t)qs1 - (rs1 - h.ref_start) + (1 << 26)) << 5) | (kind1 << 3);
-            if (ro.ok && __any((op0 == 3 && rl0 > 0) || (op1 == 3 && rl1 > 0))) {  // ref-skips: the read is not in these columns (alignment.is_refskip())
+            if (!HEMI && ro.ok && __any((op0 == 3 && rl0 > 0) || (op1 == 3 && rl1 > 0))) {  // ref-skips: the read is not in these columns (alignment.is_refskip())
               for (int j = 0; j < 2; j++) {
                 const bool skipop = j ? (op1 == 3 && rl1 > 0) : (op0 == 3 && rl0 > 0);
                 const int32_t a0 = j ? rs1 : rs0, b0 = a0 + (int32_t)(j ? rl1 : rl0);
@@ -1864,7 +1944,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
           const uint32_t t = ((v[j] >> 2) & 1u) | aln2;
           const uint32_t rowt = (uint32_t)lut[(t << 8) | byte[j]];
           const uint32_t a0 = lds_addr(tal) + 4u * (rs_a + i);
-          if (kind == 0u && rowt < 8u) lds_add(a0 + __umul24(rowt, TS4), inc);
+          if (kind == 0u && rowt < 8u && (!HEMI || ro.ok)) lds_add(a0 + __umul24(rowt, TS4), inc);   // hemi: a failed record gives no feature (its one NoCall came in as an event)
           if (kind == 1u) lds_add(a0 + __umul24((uint32_t)MKP_C_DEL, TS4), inc);   // alignment.is_del()
           if (i < nsl) qk[i] = 3u;   // left clean for the wave's next read
         }
@@ -1888,7 +1968,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __syncthreads();
   // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
   // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
-  emit_tile_rows<FOCUS>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
   }
 }
 
@@ -1905,6 +1985,62 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles
 // --partition-tag: the same two kernels tallying only the reads of one partition key per launch
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_keyed(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus_keyed(PILEUP_PARAMS) { pileup_tiles_body<true, 1, true>(PILEUP_PASS); }
+// pileup-hemi: the focus kernel with duplex pattern tallies
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_hemi(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false, true>(PILEUP_PASS); }
+
+// pileup-hemi, records whose tags failed (readout.ok == 0): DuplexReadCache::get_duplex_mod_call (read_cache.rs:422-462) finds such a
+// record in no map the first time it is asked about it, fails to add it, and answers NoCall(primary base) for that one position;
+// from then on the record is in the skip set and yields no feature.  The cache lives for one interval (process_region_duplex,
+// duplex.rs:241-339), so the record leaves one NoCall per interval it crosses: at its first '+' motif position there that it
+// covers with an A/C/G/T base (not a deletion or ref-skip).  One thread per record writes those as events into the record's own
+// (unused) event slice, where mkp_pileup_tiles_hemi picks them up.  iv_start = ascending starts of the shard's intervals.
+extern "C" __global__ void __launch_bounds__(256)
+mkp_hemi_failed_reads(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, MkpEvent* __restrict__ events,
+                      MkpReadOut* __restrict__ readout, uint32_t n_reads, const uint32_t* __restrict__ slotbm, const uint32_t* __restrict__ iv_start, uint32_t n_iv,
+                      int32_t win_start, int32_t win_end, uint32_t* __restrict__ dev_err) {
+  const uint32_t rid = blockIdx.x * 256u + threadIdx.x;
+  if (rid >= n_reads) return;
+  if (readout[rid].ok) return;
+  const MkpReadHdr h = hdrs[rid];
+  const uint8_t* __restrict__ seq = seqs + h.seq_off;
+  MkpEvent* __restrict__ ev = events + h.event_off;
+  auto next_slot = [&](int32_t a, int32_t b) -> int32_t {   // first slot in [a, b), or -1
+    uint32_t bit = (uint32_t)(a - (win_start - MKP_SLOTBM_MARGIN));
+    const uint32_t end = (uint32_t)(b - (win_start - MKP_SLOTBM_MARGIN));
+    uint32_t w = slotbm[bit >> 5] & ~((1u << (bit & 31u)) - 1u);
+    for (;;) {
+      if (w) { const uint32_t f = (bit & ~31u) + (uint32_t)__ffs((int)w) - 1u; return f < end ? (int32_t)f + (win_start - MKP_SLOTBM_MARGIN) : -1; }
+      bit = (bit & ~31u) + 32u;
+      if (bit >= end) return -1;
+      w = slotbm[bit >> 5];
+    }
+  };
+  uint32_t n = 0, q = 0; bool overflow = false;
+  int32_t rp = h.ref_start, served = max(h.ref_start, win_start);   // positions below `served` lie in intervals that have their NoCall
+  for (uint32_t c = 0; c < h.n_cigar && rp < win_end && served < win_end; c++) {
+    const uint32_t w = cigar[h.cigar_off + c], op = w & 15u, len = w >> 4;
+    if (op_is_match(op)) {
+      int32_t a = max(rp, served); const int32_t b = min(rp + (int32_t)len, win_end);
+      while (a < b) {
+        const int32_t p = next_slot(a, b);
+        if (p < 0) break;
+        const uint32_t qq = q + (uint32_t)(p - rp);
+        const int x = qq < h.l_seq ? nib2base(seq_nibble(seq, qq)) : -1;
+        if (x < 0) { a = p + 1; continue; }
+        if (n < h.event_cap) { ev[n].pos = (uint32_t)p; ev[n].info = (uint32_t)(MKP_H_NC + x); } else overflow = true;
+        n++;
+        uint32_t lo = 0, hi = n_iv;   // first interval starting after p
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (iv_start[mid] <= (uint32_t)p) lo = mid + 1u; else hi = mid; }
+        served = lo < n_iv ? (int32_t)iv_start[lo] : win_end;
+        a = served;
+      }
+    }
+    if (op_consumes_query(op)) q += len;
+    if (op_consumes_ref(op)) rp += (int32_t)len;
+  }
+  if (overflow) { atomicOr(dev_err, ERR_EVENT_CAP); n = 0; }
+  readout[rid].n_events = n;
+}
 
 // ----------------------------------------------------------------------------------------------
 // Order the per-tile row runs by tile index.  Block 0 computes the exclusive scan of the
@@ -2037,7 +2173,7 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
 
 // per device: both accumulate kernels may use the whole per-workgroup LDS budget the host planned for
 extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
-  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_focus, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_focus_keyed}) {
+  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_focus, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_focus_keyed, (const void*)mkp_pileup_tiles_hemi}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
     if (e != hipSuccess) return e;
   }
@@ -2054,8 +2190,16 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int 
   const uint32_t grid = n_tiles;   // one workgroup per tile
 #define MKP_PILEUP_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos, \
                        row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_arg)
-  if (focus_mode) { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus); }
+  if (focus_mode == 2) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_hemi);   // pileup-hemi
+  else if (focus_mode) { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus); }
   else { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles); }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mkp_launch_hemi_failed(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs, MkpEvent* events, MkpReadOut* readout, uint32_t n_reads,
+                                             const uint32_t* slotbm, const uint32_t* iv_start, uint32_t n_iv, int32_t win_start, int32_t win_end, uint32_t* dev_err) {
+  if (!n_reads) return hipSuccess;
+  hipLaunchKernelGGL(mkp_hemi_failed_reads, dim3((n_reads + 255u) / 256u), dim3(256), 0, st, hdrs, cigar, seqs, events, readout, n_reads, slotbm, iv_start, n_iv, win_start, win_end, dev_err);
   return hipGetLastError();
 }
 

@@ -37,6 +37,20 @@ struct RowWriter {
     }
     out->n = (size_t)(p - out->mem.get());
   }
+  // pileup-hemi rows (PileupWriter<DuplexModBasePileup>, writers.rs:185-258): the same 18 columns with name = "<pos>,<neg>,<base>",
+  // strand '.', count / canonical / other-pattern in the modified / canonical / other columns
+  void format_range_hemi(const std::string& chrom, const mkp_hemi_rows& r, uint64_t lo, uint64_t hi, TextBuf* out) const {
+    const char sp = mixed ? ' ' : '\t';
+    out->mem.reset(new char[(size_t)(hi - lo) * row_bound(chrom.size()) + 1]);
+    char* p = out->mem.get();
+    auto element = [](char* q, uint32_t code) { if (code == MKP_HEMI_CANONICAL) { *q++ = '-'; return q; } if (code & 0x80000000u) return put_u32(q, code & 0x7fffffffu); *q++ = (char)code; return q; };
+    for (uint64_t i = lo; i < hi; i++) {
+      char name[32]; char* q = element(name, r.pattern_pos[i]); *q++ = ','; q = element(q, r.pattern_neg[i]); *q++ = ','; *q++ = (char)r.primary_base[i];
+      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)(q - name), sp, r.pos[i], '.', r.n_valid[i], r.count[i], r.n_canonical[i], r.n_other_pattern[i],
+                     r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
+    }
+    out->n = (size_t)(p - out->mem.get());
+  }
   void io_loop() {
     for (;;) {
       std::vector<TextBuf> job;
@@ -48,12 +62,18 @@ struct RowWriter {
     }
   }
   void write(const std::string& chrom, const mkp_rows& r) {
+    write_rows(chrom, r.n_rows, [&](uint64_t lo, uint64_t hi, TextBuf* out) { format_range(chrom, r, lo, hi, out); });
+  }
+  void write_hemi(const std::string& chrom, const mkp_hemi_rows& r) {
+    write_rows(chrom, r.n_rows, [&](uint64_t lo, uint64_t hi, TextBuf* out) { format_range_hemi(chrom, r, lo, hi, out); });
+  }
+  template <class Fmt> void write_rows(const std::string& chrom, uint64_t n_rows, Fmt fmt) {
     if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
-    if (r.n_rows == 0) return;
-    const unsigned n_thr = r.n_rows >= 65536 ? std::max(1u, std::min(64u, std::thread::hardware_concurrency())) : 1u;
+    if (n_rows == 0) return;
+    const unsigned n_thr = n_rows >= 65536 ? std::max(1u, std::min(64u, std::thread::hardware_concurrency())) : 1u;
     std::vector<TextBuf> bufs(n_thr);
-    HostPool::get().parallel(n_thr, [&](size_t t) { format_range(chrom, r, r.n_rows * t / n_thr, r.n_rows * (t + 1) / n_thr, &bufs[t]); });
-    n += r.n_rows;
+    HostPool::get().parallel(n_thr, [&](size_t t) { fmt(n_rows * t / n_thr, n_rows * (t + 1) / n_thr, &bufs[t]); });
+    n += n_rows;
     {
       std::unique_lock<std::mutex> lk(mu);
       if (!io_started) { io_started = true; io = std::thread([this] { io_loop(); }); }

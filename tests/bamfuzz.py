@@ -165,6 +165,17 @@ class Fuzz:
         elif prof == "duplex":
             add("C+m?", positions("C", 0.9, cpg=True), 1)
             add("G-m?", positions("G", 0.5), 1)
+        elif prof == "duplex_hm":   # both strands of a duplex read, two codes each (pileup-hemi patterns like h,m / m,- / -,-)
+            add("C+hm?", positions("C", 0.9, cpg=True), 2)
+            add("G-hm?", positions("G", 0.7), 2)
+        elif prof == "duplex_split":  # the same calls as separate tags per code, plus 6mA on one strand
+            rk = positions("C", 0.9, cpg=True)
+            header("C+h?", rk)
+            ml.extend(r.randrange(0, 128) for _ in rk)
+            header("C+m?", rk)
+            ml.extend(r.randrange(0, 128) for _ in rk)
+            add("G-m?", positions("G", 0.8), 1)
+            add("A+a?", positions("A", 0.5), 1)
         elif prof == "nbase":
             n = len(fwd)
             pos = sorted(r.sample(range(n), min(n, r.randrange(0, 25))))
