@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--cpu-sample", choices=["full", "region"], default="full", help="CPU baseline + parity on the whole bench BAM (default) or on its first eighth")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the short run the --pmc passes profile
+    ap.add_argument("--tile", type=int, default=0, help="experiments: reference positions per accumulate tile (0 = the library's plan)")
     ap.add_argument("--skip-e2e", action="store_true", help="profiling runs: skip the sharded end-to-end pass so that every kernel launch is the full-size one the timed region repeats")
     a = ap.parse_args()
     if a.skip_e2e or a.inner:
@@ -183,7 +184,7 @@ def main():
     # the sampling schedule batches its intervals; the device run and the CPU baseline get the same value so that they sample the same reads
     flags = (["--cpg", "--ref", fa] if needs_ref else []) + ["-t", "8"]
 
-    ctx = modkit_amd.Context(device=local_rank)
+    ctx = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
     out_bed = bam + ".device.bed"
     rep = None
     if world == 1 and not (a.inner or a.skip_e2e):

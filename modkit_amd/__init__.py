@@ -14,7 +14,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmkpileup.so")
+LIB_PATH = os.environ.get("MKP_LIB_PATH") or os.path.join(CSRC, "libmkpileup.so")   # MKP_LIB_PATH: another build of the same library (e.g. -DMKP_DEBUG ablations)
 
 MKP_OK = 0
 STATUS = {0: "MKP_OK", -1: "MKP_E_INVALID", -2: "MKP_E_IO", -3: "MKP_E_UNSUPPORTED", -4: "MKP_E_DEVICE", -5: "MKP_E_NOMEM",

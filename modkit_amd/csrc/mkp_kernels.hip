@@ -1491,6 +1491,37 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
     rows.n_del = p + 7 * cap; rows.n_fail = p + 8 * cap; rows.n_diff = p + 9 * cap; rows.n_nocall = p + 10 * cap; }
   TileView tv; tv.pk = tal; tv.W = prm.slot_cap; tv.n_counters = prm.n_counters;
   auto slot_of = [&](int32_t q) { return sm.rank(q); };
+  if (FOCUS) {
+    // focus tiles hold at most one slot per thread (the host planner caps them at MKP_PILEUP_THREADS): every thread counts its
+    // slot's rows once, the block scans, thread 0 reserves the tile's run, and the same threads write — position, focus byte and
+    // count stay in registers
+    const uint32_t i = threadIdx.x;
+    uint32_t cnt = 0, fv = 0; int32_t p = 0;
+    if (i < n_tslots) {
+      p = sm.pos_of(i);
+      if (p >= tl.r0 && p < tl.r1) {
+        if (HEMI) cnt = hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0);
+        else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+      }
+    }
+    const uint32_t inc2 = wave_incl_scan(cnt);
+    if (lane == 63) wave_tot[wave] = inc2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t s = 0;
+      for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
+      uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+      if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+      *row_base_p = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s; *scan_carry_p = s ? 0u : 0xffffffffu;
+    }
+    __syncthreads();
+    if (*scan_carry_p != 0xffffffffu && cnt) {
+      uint32_t woff = *row_base_p + inc2 - cnt;
+      for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
+      if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, woff); else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, woff, fv, slot_of, key);
+    }
+    return;
+  }
   // pass 1: rows per slot, summed over the tile
   uint32_t mine = 0;
   for (uint32_t i = threadIdx.x; i < n_tslots; i += PILEUP_THREADS) {
@@ -1583,6 +1614,11 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
   const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
   const uint32_t S = prm.slot_cap, W = prm.focus_words;
+#ifdef MKP_DEBUG
+  const uint32_t dbg = prm.debug_skip;   // ablation runs (env MKP_DEBUG_SKIP): 1 depth walk, 2 events, 4 row emission, 8 SEQ phase of the focus walk
+#else
+  constexpr uint32_t dbg = 0;
+#endif
   const uint32_t n_counters = HEMI ? prm.hemi_counters : prm.n_counters, n_oslots = HEMI ? 0u : prm.n_slots;
   const uint32_t tal_words = (n_counters + n_oslots) * S;
   uint32_t* __restrict__ tal = lds;                       // [n_counters + n_oslots][S], packed
@@ -1742,7 +1778,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       }
     } else
     // the read's call events inside the tile (sorted by position)
-    if (ro.ok && ro.n_events) {
+    if (ro.ok && ro.n_events && !(dbg & 2u)) {
       const MkpEvent* __restrict__ ev = events + h.event_off;
       const uint32_t lo = h.ref_start >= T0h ? 0u : event_lower_bound(ev, ro.n_events, T0h);   // a read that starts in the tile: no search
       for (uint32_t k = lo + lane;; k += 64) {
@@ -1765,6 +1801,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
     const uint32_t fposbase = lds_addr(fpos) + 4u * (uint32_t)lane;
     const uint32_t qbase = (uint32_t)(0 - h.ref_start) - (1u << 26);   // query index = position + qbase + packed offset
     const uint32_t last_byte = (h.l_seq - 1u) >> 1;
+    if (FOCUS && (dbg & 1u)) {} else
     if (FOCUS) {
       // Focus runs: the walk is driven by the slots, not by the ops, 128 CIGAR ops per window (two per lane).  The window's slots
       // [S_lo, S_hi) are enumerated 64 at a time (lane = slot, position from the tile's slot list); the lane holding a position's
@@ -1927,7 +1964,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       }
       q_run += Qtot; r_run += (int32_t)Rtot;
     }
-    if (FOCUS) {
+    if (FOCUS && !(dbg & 9u)) {
       // phase 2: bases of the read's slots [rs_a, rs_b) in this tile, 4 x 64 slots per round with their SEQ loads in flight together
       // (slots the CIGAR phase did not reach — a read whose CIGAR ends early — keep kind 3 = nothing)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1968,7 +2005,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __syncthreads();
   // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
   // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
-  emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  if (!(dbg & 4u)) emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
   }
 }
 
