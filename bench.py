@@ -35,6 +35,8 @@ WORKLOADS = {
     # name: (contig, length, reads, generator flags, pileup flags needing the FASTA, description)
     "c3": ("chr20", 64_444_167, 193_000, ["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], True,
            "C3: synthetic hg38 chr20 (%d bp, CpG-depleted chain), %d reads (mean %.0f bp, ~%.0fx), C+hm? / C+h?;C+m? alternating at every read CpG, --cpg --ref, -i 100000, default 10th-percentile threshold"),
+    "hemi": ("chr20", 64_444_167, 193_000, ["--style", "duplex", "--cpg-depleted", "--mean-len", "8353"], True,
+             "pileup-hemi on the C3 geometry: synthetic hg38 chr20 (%d bp, CpG-depleted chain), %d duplex reads (mean %.0f bp, ~%.0fx), C+hm?;G-hm? / C+h?;C+m?;G-h?;G-m? alternating at every read CpG, --cpg -r, -i 100000, default 10th-percentile threshold"),
     "c2": ("synth5m", 5_000_000, 100_000, ["--style", "m"], False,
            "C2: synthetic 1 contig x %d bp, %d reads (mean %.0f bp, ~%.0fx), C+m? at every read CpG, default 10th-percentile threshold"),
 }
@@ -68,7 +70,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(bam, flags, contig, contig_len, workers, mode):
+def cpu_baseline(bam, flags, contig, contig_len, workers, mode, hemi=False):
     """The oracle (CPU restatement of the reference's path, NOT the reference binary) on the bench BAM itself:
     mode 'full' = the whole workload; 'region' = the first eighth of the contig (bounded sample)."""
     oracle = os.path.join(ROOT, "oracle", "modkit_oracle")
@@ -77,7 +79,7 @@ def cpu_baseline(bam, flags, contig, contig_len, workers, mode):
     out = bam + ".oracle.%s.bed" % mode
     region = [] if mode == "full" else ["--region", "%s:0-%d" % (contig, contig_len // 8)]
     t0 = time.time()
-    p = subprocess.run([oracle, "pileup", bam, out, "--oracle-workers", str(workers)] + flags + region, capture_output=True, text=True)
+    p = subprocess.run([oracle] + (["pileup-hemi", bam, "-o", out] if hemi else ["pileup", bam, out]) + ["--oracle-workers", str(workers)] + flags + region, capture_output=True, text=True)
     wall = time.time() - t0
     if p.returncode != 0:
         raise RuntimeError("oracle failed: " + p.stderr[-400:])
@@ -175,7 +177,8 @@ def main():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
     if dist:
         dist.barrier()
-    seed = (20 if a.workload == "c3" else 1) + rank
+    hemi = a.workload == "hemi"
+    seed = {"c3": 20, "hemi": 30}.get(a.workload, 1) + rank
     t0 = time.time()
     bam, fa, meta = gen_bam(os.path.join(tmp, "mkp_%s_L%d_N%d_seed%d" % (a.workload, contig_len, n_reads, seed)), contig, contig_len, n_reads, seed, gflags,
                             max(1, (os.cpu_count() or 1) // world))
@@ -184,13 +187,16 @@ def main():
     # the sampling schedule batches its intervals; the device run and the CPU baseline get the same value so that they sample the same reads
     flags = (["--cpg", "--ref", fa] if needs_ref else []) + ["-t", "8"]
 
+    def run_subcommand(out, extra):   # `modkit pileup` / `modkit pileup-hemi` on the bench context
+        return ctx.pileup_hemi_run([bam, "-o", out] + flags + extra) if hemi else ctx.pileup_run([bam, out] + flags + extra)
+
     ctx = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
     out_bed = bam + ".device.bed"
     rep = None
     if world == 1 and not (a.inner or a.skip_e2e):
         # end to end: the whole subcommand on this context (block reads + inflate, threshold sampling, focus, device pipeline,
         # bedMethyl text), with the driver's default sharding (the next shard's blocks inflate while this one is packed and run)
-        rep = ctx.pileup_run([bam, out_bed] + flags)
+        rep = run_subcommand(out_bed, [])
         thr_h = [float(rep.threshold[i]) if rep.has_threshold[i] else 0.0 for i in range(4)]
     elif world == 1:
         thr = ctx.estimate_thresholds(bam, ["-t", "8"])
@@ -205,7 +211,7 @@ def main():
     for i in range(4):
         if thr_h[i] > 0:
             targv += ["--filter-threshold", "%s:%r" % ("ACGT"[i], thr_h[i])]
-    rep1 = ctx.pileup_run([bam, out_bed + ".oneshard"] + flags + targv + ["--shard-bytes", str(1 << 40)])
+    rep1 = run_subcommand(out_bed + ".oneshard", targv + ["--shard-bytes", str(1 << 40)])
     if rep is None:
         rep = rep1
     elif sh256(out_bed) != sh256(out_bed + ".oneshard"):
@@ -243,7 +249,7 @@ def main():
         # the roofline is reported for the aggregation kernel (north_star's target), whichever kernel is slowest; its name in the
         # rocprof summaries: mkp_pileup_tiles_focus for runs with focus positions (--cpg), mkp_pileup_tiles otherwise
         dom = "mkp_pileup_tiles"
-        dom_kernel = "mkp_pileup_tiles_focus" if needs_ref else "mkp_pileup_tiles"
+        dom_kernel = "mkp_pileup_tiles_hemi" if hemi else "mkp_pileup_tiles_focus" if needs_ref else "mkp_pileup_tiles"
         dom_ms, dom_bytes = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         slowest = max(kernels, key=lambda k: kernels[k][0])
@@ -283,10 +289,13 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             workers = min(os.cpu_count() or 1, 8)
-            obed, region, base = cpu_baseline(bam, flags, contig, contig_len, workers, a.cpu_sample)
+            obed, region, base = cpu_baseline(bam, flags, contig, contig_len, workers, a.cpu_sample, hemi)
             if region:
                 dbed = bam + ".device.region.bed"
-                modkit_amd.pileup([bam, dbed, "--device", str(local_rank)] + flags + region)
+                if hemi:
+                    modkit_amd.pileup_hemi([bam, "-o", dbed, "--device", str(local_rank)] + flags + region)
+                else:
+                    modkit_amd.pileup([bam, dbed, "--device", str(local_rank)] + flags + region)
             else:
                 dbed = out_bed
             base["bedmethyl_sha256_equal"] = sh256(dbed) == sh256(obed)
@@ -294,7 +303,7 @@ def main():
             base["speedup_end_to_end"] = (rep.n_positions / (rep.total_ms * 1e-3)) / base["end_to_end"]["positions_per_s"] if not region else None
             if (os.cpu_count() or 1) > 8:   # the same run on more of this box's cores (the reference's --threads is the user's choice)
                 w2 = min(os.cpu_count(), 32)
-                _, _, b2 = cpu_baseline(bam, [f for f in flags if f not in ("-t", "8")] + ["-t", str(w2)], contig, contig_len, w2, a.cpu_sample)   # (-t steers its sampling schedule too: timing only, no sha comparison)
+                _, _, b2 = cpu_baseline(bam, [f for f in flags if f not in ("-t", "8")] + ["-t", str(w2)], contig, contig_len, w2, a.cpu_sample, hemi)   # (-t steers its sampling schedule too: timing only, no sha comparison)
                 base["more_cores"] = {"cores": w2, "positions_per_s": b2["value"], "end_to_end": b2["end_to_end"],
                                       "speedup_end_to_end": (rep.n_positions / (rep.total_ms * 1e-3)) / b2["end_to_end"]["positions_per_s"] if not region else None}
             result["cpu_baseline"] = base

@@ -159,23 +159,54 @@ class FocusBuilder {
         seq = &upper;
       }
     }
-    if (!motifs.empty() && !combine) {
-      // Without strand combining the grid is fixed (start + k * interval_size) and every interval's motif hits depend on its own
-      // slice of the reference only: intervals are filled by all host cores, each block of intervals with its own motif-id
-      // combo table; the tables are then interned into the shared one in interval order (the ids a sequential walk would give)
-      // and a block whose local ids differ has its bytes renumbered.
-      for (uint32_t pos = rec.start; pos < rec.end();) { const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end()); ivs.push_back({rec.tid, pos, end}); pos = end; }
+    size_t longest = 0; for (auto& m : motifs) longest = std::max(longest, m.len());
+    if (!motifs.empty()) {
+      // The grid.  Without strand combining it is fixed (start + k * interval_size).  With it the end of an interval moves past a
+      // motif hit that straddles it (get_motif_positions_combine_strands, fasta.rs:92-188) and the next interval starts there, so
+      // the ends are found one after the other — but each needs only the hits around the nominal end: a merged run of hits that
+      // covers position e-1 is chained hit by hit, and every hit that can chain to e-1 or beyond starts after e - 2 * longest.
+      uint32_t pos = rec.start;
+      while (pos < rec.end()) {
+        uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end());
+        if (combine) {
+          uint64_t ref_end = rec.end(), buffer = longest * 5, e = end, end_w = std::min<uint64_t>((uint64_t)end + buffer, ref_end);
+          std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
+          for (;;) {
+            if (end_w > seq->size()) throw Error(MKP_E_UNSUPPORTED, "motif run reaches past the contig end while extending an interval (the reference never terminates here)");
+            const uint64_t from = std::max<uint64_t>(pos, e > 2 * longest + 2 ? e - 2 * longest - 2 : 0);
+            for (auto& l : locs) l.clear();
+            for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + from, (size_t)(end_w - from), motifs[i], (uint32_t)from, rec.tid, bed, &locs[i]);
+            std::vector<Span> sp;
+            for (size_t i = 0; i < motifs.size(); i++) { uint64_t adj = motifs[i].len() >= motifs[i].fwd_off ? motifs[i].len() - motifs[i].fwd_off : motifs[i].len(); for (auto& kv : locs[i]) sp.push_back({kv.first, kv.first + adj}); }
+            merge_spans(sp);
+            uint64_t search_end = e, qs = e ? e - 1 : 0;
+            for (auto& s2 : sp) if (s2.s < e && s2.e > qs) { search_end = s2.e; break; }
+            uint64_t too_close = end_w >= longest ? end_w - longest : 0;
+            if (search_end < too_close || end_w >= ref_end) { end = (uint32_t)std::min<uint64_t>(search_end, rec.end()); break; }
+            e = end_w; end_w += buffer;
+          }
+        }
+        ivs.push_back({rec.tid, pos, end});
+        if (end <= pos) throw Error(MKP_E_INVALID, "interval size must be positive");
+        pos = end;
+      }
+      // The focus bytes: every interval's motif hits depend on its own slice of the reference only (with strand combining the
+      // slice runs `longest` past the interval end, so that a hit that starts inside it is seen whole): intervals are filled by all
+      // host cores, each block of intervals with its own motif-id combo table; the tables are then interned into the shared one in
+      // interval order (the ids a sequential walk would give) and a block whose local ids differ has its bytes renumbered.
       if (focus) {
         const size_t per_block = std::max<size_t>(1, (4u << 20) / interval_size), n_blocks = (ivs.size() + per_block - 1) / per_block;
         std::vector<FocusBuilder> local(n_blocks);
         std::vector<std::unique_ptr<Error>> errs(n_blocks);
+        const bool comb = combine;
         parallel_ranges(0, n_blocks, 1, [&](uint64_t b0, uint64_t b1) {
           for (uint64_t b = b0; b < b1; b++) {
-            FocusBuilder& L = local[b]; L.fasta = fasta; L.mask = mask; L.motifs = motifs; L.bed = bed; L.combine = false;
+            FocusBuilder& L = local[b]; L.fasta = fasta; L.mask = mask; L.motifs = motifs; L.bed = bed; L.combine = comb;
             try {
               for (size_t k = b * per_block; k < std::min(ivs.size(), (b + 1) * per_block); k++) {
                 std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
-                for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + ivs[k].start, ivs[k].end - ivs[k].start, motifs[i], ivs[k].start, rec.tid, bed, &locs[i]);
+                const uint64_t slice_end = comb ? std::min<uint64_t>((uint64_t)ivs[k].end + longest, rec.end()) : ivs[k].end;
+                for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + ivs[k].start, (size_t)(slice_end - ivs[k].start), motifs[i], ivs[k].start, rec.tid, bed, &locs[i]);
                 L.fill_motif(locs, rec, ivs[k].start, ivs[k].end, focus);
               }
             } catch (const Error& e) { errs[b].reset(new Error(e)); }
@@ -192,35 +223,13 @@ class FocusBuilder {
       }
       return ivs;
     }
-    size_t longest = 0; for (auto& m : motifs) longest = std::max(longest, m.len());
-    uint32_t pos = rec.start;
-    while (pos < rec.end()) {
-      uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end());
-      if (!motifs.empty()) {
-        std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
-        {  // get_motif_positions_combine_strands (fasta.rs:92-188): the interval end moves past a motif hit that straddles it
-          uint64_t ref_end = rec.end(), buffer = longest * 5, e = end, end_w = std::min<uint64_t>((uint64_t)end + buffer, ref_end);
-          for (;;) {
-            if (end_w > seq->size()) throw Error(MKP_E_UNSUPPORTED, "motif run reaches past the contig end while extending an interval (the reference never terminates here)");
-            for (auto& l : locs) l.clear();
-            for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + pos, (size_t)(end_w - pos), motifs[i], pos, rec.tid, bed, &locs[i]);
-            std::vector<Span> sp;
-            for (size_t i = 0; i < motifs.size(); i++) { uint64_t adj = motifs[i].len() >= motifs[i].fwd_off ? motifs[i].len() - motifs[i].fwd_off : motifs[i].len(); for (auto& kv : locs[i]) sp.push_back({kv.first, kv.first + adj}); }
-            merge_spans(sp);
-            uint64_t search_end = e, qs = e ? e - 1 : 0;
-            for (auto& s : sp) if (s.s < e && s.e > qs) { search_end = s.e; break; }
-            uint64_t too_close = end_w >= longest ? end_w - longest : 0;
-            if (search_end < too_close || end_w >= ref_end) { for (auto& l : locs) for (auto it = l.begin(); it != l.end();) { if (it->first <= search_end) ++it; else it = l.erase(it); } end = (uint32_t)std::min<uint64_t>(search_end, rec.end()); break; }
-            e = end_w; end_w += buffer;
-          }
-        }
-        if (focus) fill_motif(locs, rec, pos, end, focus);
-      } else if (bed && focus) {
-        auto mark = [&](const std::map<uint32_t, std::vector<Span>>& m, uint8_t bit) { auto it = m.find(rec.tid); if (it == m.end()) return; for (auto& s : it->second) { uint64_t a = std::max<uint64_t>(s.s, pos), b = std::min<uint64_t>(s.e, end); for (uint64_t p = a; p < b; p++) (*focus)[p - rec.start] |= bit; } };
+    for (uint32_t pos = rec.start; pos < rec.end();) {   // no motifs: the fixed grid; BED focus bytes per interval
+      const uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end());
+      if (bed && focus) {
+        auto mark = [&](const std::map<uint32_t, std::vector<Span>>& m, uint8_t bit) { auto it = m.find(rec.tid); if (it == m.end()) return; for (auto& s2 : it->second) { uint64_t a = std::max<uint64_t>(s2.s, pos), b = std::min<uint64_t>(s2.e, end); for (uint64_t p = a; p < b; p++) (*focus)[p - rec.start] |= bit; } };
         mark(bed->pos, 1); mark(bed->neg, 2);
       }
       ivs.push_back({rec.tid, pos, end});
-      if (end <= pos) throw Error(MKP_E_INVALID, "interval size must be positive");
       pos = end;
     }
     return ivs;

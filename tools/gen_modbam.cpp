@@ -1,5 +1,5 @@
 // gen_modbam — seeded synthetic modBAM generator for the BASELINE.json configs.
-//   gen_modbam --out PREFIX --contig NAME:LEN [--contig ...] --reads N [--style m|hm|hma]
+//   gen_modbam --out PREFIX --contig NAME:LEN [--contig ...] --reads N [--style m|hm|hma|duplex]
 //              [--seed S] [--mean-len 4000] [--sigma 0.6] [--min-len 500] [--max-len 50000] [--cpg-depleted] [--threads T]
 //              [--partition-tag HP:3]
 // Writes PREFIX.bam (coordinate sorted BGZF), PREFIX.bam.bai (bins, linear index, idxstats pseudo-bin), PREFIX.fa,
@@ -182,6 +182,20 @@ int main(int argc, char** argv) {
       auto qual = [&](bool meth) -> uint8_t { if (r.uni() < 0.1) return (uint8_t)r.below(256); int v = (int)std::floor(std::fabs(r.normal() * 25.0)); if (v > 255) v = 255; return (uint8_t)(meth ? 255 - v : v); };
       std::string mm; std::vector<uint8_t> ml; char num[16];
       std::vector<uint32_t> cpos; std::string deltas; { uint32_t skipped = 0; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'C') { if (f + 1 < L && fwd[f + 1] == 'G') { cpos.push_back(f); snprintf(num, sizeof(num), ",%u", skipped); deltas += num; skipped = 0; } else skipped++; } }
+      if (style == "duplex") {
+        // duplex basecalls: the read's own strand as C+h / C+m at its CpG C's, the opposite strand as G-h / G-m at the G's of the same
+        // CpGs; the two strands of a site are drawn independently from the site's methylation level (mostly concordant, some hemi)
+        std::vector<uint32_t> gpos; std::string gdeltas; { uint32_t skipped = 0; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'G') { if (f > 0 && fwd[f - 1] == 'C') { gpos.push_back(f); snprintf(num, sizeof(num), ",%u", skipped); gdeltas += num; skipped = 0; } else skipped++; } }
+        auto gsite = [&](uint32_t f) -> double { uint32_t q = rev ? L - 1 - f : f; uint32_t rp = qref[q]; return rp == ~0u ? 0.5 : site_beta(beta_seed, tid, rev ? rp : rp - 1); };
+        std::vector<uint8_t> hv[2], mv[2];
+        for (int sd = 0; sd < 2; sd++) for (uint32_t f : (sd ? gpos : cpos)) {
+          double b = sd ? gsite(f) : site(f); bool meth = r.uni() < b; uint8_t qm = qual(meth); uint32_t rest = 255u - qm; uint8_t qh = (uint8_t)(r.uni() < 0.15 ? r.below(rest + 1) : r.below(rest / 4 + 1));
+          hv[sd].push_back(qh); mv[sd].push_back(qm);
+        }
+        if (rid & 1) { mm = "C+hm?" + deltas + ";G-hm?" + gdeltas + ";"; for (int sd = 0; sd < 2; sd++) for (size_t i = 0; i < hv[sd].size(); i++) { ml.push_back(hv[sd][i]); ml.push_back(mv[sd][i]); } }
+        else { mm = "C+h?" + deltas + ";C+m?" + deltas + ";G-h?" + gdeltas + ";G-m?" + gdeltas + ";"; for (int sd = 0; sd < 2; sd++) { ml.insert(ml.end(), hv[sd].begin(), hv[sd].end()); ml.insert(ml.end(), mv[sd].begin(), mv[sd].end()); } }
+        blk_calls[bi] += gpos.size();
+      } else {
       const bool hm = style == "hm" || style == "hma";
       if (!hm) { mm = "C+m?" + deltas + ";"; for (uint32_t f : cpos) ml.push_back(qual(r.uni() < site(f))); }
       else {
@@ -195,6 +209,7 @@ int main(int argc, char** argv) {
         if (combined) { mm = "C+hm?" + deltas + ";"; for (size_t i = 0; i < hv.size(); i++) { ml.push_back(hv[i]); ml.push_back(mv[i]); } }
         else { mm = "C+h?" + deltas + ";C+m?" + deltas + ";"; ml.insert(ml.end(), hv.begin(), hv.end()); ml.insert(ml.end(), mv.begin(), mv.end()); }
         if (style == "hma") { mm += "A+a?"; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'A') { mm += ",0"; ml.push_back(qual(r.uni() < 0.05)); } mm += ";"; }
+      }
       }
       blk_calls[bi] += cpos.size();
       // record
