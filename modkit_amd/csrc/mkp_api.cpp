@@ -12,7 +12,7 @@
 using namespace mkp;
 
 extern "C" {
-hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[5]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
+hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[7]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
 hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
@@ -36,11 +36,23 @@ MkpRowsDev carve_rows(DevBuf& b, uint64_t cap) {
 // reads by decode kernel: [SPARSE one tag | SPARSE two tags | FAST one tag | FAST two tags | everything else].
 // FAST = one (strand, base) group, no code listed twice, at most two tags.  SPARSE = FAST with explicit ('?') tags only and,
 // for two tags, identical rank lists (`C+h?,d..;C+m?,d..` as basecallers write them): the calls are located per call, not per base.
-void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[5]) {
-  std::vector<uint32_t> cls[5];
+// With `duplex` (never for the threshold sampler): [.. | duplex one tag per group | duplex two]: reads whose layout has two groups on
+// different bases (`C+h?;C+m?;G-h?;G-m?`), every tag explicit and the tags of a group sharing one rank list; such a read is listed
+// twice (bit 31 = its second group), each listing decoded by a SPARSE wave, and mkp_merge_duplex interleaves the two event lists.
+void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[7], bool duplex) {
+  std::vector<uint32_t> cls[7];
   for (size_t i = 0; i < S.hdr.size(); i++) {
     const MkpReadHdr& h = S.hdr[i]; int c = 4;
-    if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast && h.n_tags <= 2) {
+    if (duplex && !(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast == 2) {
+      const MkpLayout& L = T.dev[h.layout]; const uint32_t nA = L.pad;
+      bool ok = true;
+      for (uint32_t t = 0; t < h.n_tags; t++) if (L.tags[t].mode != 0) ok = false;
+      auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1]; return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
+      if (ok && nA == 2) ok = same(0, 1);
+      if (ok && h.n_tags - nA == 2) ok = same(nA, nA + 1);
+      if (ok) { cls[(nA == 1 && h.n_tags - nA == 1) ? 5 : 6].push_back((uint32_t)i); continue; }
+    }
+    if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast == 1 && h.n_tags <= 2) {
       c = 2 + (h.n_tags - 1);
       const MkpLayout& L = T.dev[h.layout];
       bool sparse = true;
@@ -54,9 +66,10 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
     cls[c].push_back((uint32_t)i);
   }
   // one wave decodes one read start to end: launch the longest reads first so they do not form the kernel's tail
-  for (int c = 0; c < 5; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; });
+  for (int c = 0; c < 7; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; });
   ids->clear();
   for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
+  for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r); ids->push_back(r | 0x80000000u); } }
 }
 
 template <class V> void upload(DevBuf& b, const V& v) {
@@ -142,16 +155,25 @@ void make_resident(mkp_ctx* c) {
     // make every slice at least that long
     if (c->hemi_iv.empty()) c->hemi_iv.push_back((uint32_t)S.win_start);
     if (!std::is_sorted(c->hemi_iv.begin(), c->hemi_iv.end())) throw Error(MKP_E_INVALID, "interval starts must ascend");
-    uint64_t off = 0;
     for (auto& h : S.hdr) {
       auto iv_of = [&](int64_t p) { return (int64_t)(std::upper_bound(c->hemi_iv.begin(), c->hemi_iv.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->hemi_iv.begin()); };
       const int64_t need = iv_of((int64_t)h.ref_end - 1) - iv_of(h.ref_start) + 1;
       h.event_cap = (uint32_t)std::max<int64_t>(h.event_cap, need);
-      if (off > 0xffffffffull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "more than 2^32 call events in one shard");
-      h.event_off = (uint32_t)off; off += h.event_cap;
     }
-    S.n_events_cap = off;
   }
+  // decode kernel classes; a duplex read decoded one group per wave needs room for both groups' lists behind the merged one
+  std::vector<uint32_t> class_list; class_ids(S, c->tables, &class_list, c->n_class, true);
+  { size_t at = 0; for (int k = 0; k < 5; k++) at += c->n_class[k];
+    for (; at < class_list.size(); at += 2) {
+      MkpReadHdr& h = S.hdr[class_list[at]];
+      const uint64_t need = 2ull * ((uint64_t)S.tagref[h.tag_off].n + S.tagref[h.tag_off + c->tables.dev[h.layout].pad].n);
+      if (need > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED, "more than 2^32 call events in one read");
+      h.event_cap = std::max(h.event_cap, (uint32_t)need);
+    } }
+  { uint64_t off = 0;   // event slices laid out again (capacities may have grown above)
+    for (auto& h : S.hdr) { if (off > 0xfffffff0ull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards"); h.event_off = (uint32_t)off; off += h.event_cap; }
+    S.n_events_cap = off; }
+  P.readout_b_off = (uint32_t)S.hdr.size();
   const size_t n = S.hdr.size();
   for (size_t i = 1; i < n; i++) if (S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted");
   depth_guard(S, c->caller.max_depth);
@@ -232,10 +254,10 @@ void make_resident(mkp_ctx* c) {
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
   upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
-  { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class); upload(c->d_read_ids, ids); }
+  upload(c->d_read_ids, class_list);
   if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
-  c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
+  c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
   if (c->hemi) upload(c->d_hemi_iv, c->hemi_iv);
   // partition keys present in this shard: one accumulate pass each
@@ -609,7 +631,7 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
     upload(c->d_layouts, c->tables.dev);
-    { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class); upload(c->d_read_ids, ids); }
+    { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class, false); upload(c->d_read_ids, ids); }
     if (bedmask) { c->d_focus.ensure((size_t)(win_end - win_start)); hip_check(hipMemcpy(c->d_focus.p, bedmask, (size_t)(win_end - win_start), hipMemcpyHostToDevice), "H2D"); } else c->d_focus.ensure(16);
     const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
     c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut)); c->d_misc.ensure(64);

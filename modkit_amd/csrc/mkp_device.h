@@ -88,7 +88,8 @@ struct MkpLayout {
   uint8_t n_tags;
   uint8_t default_mask;   // tags whose mode is DefaultImplicitUnmodified
   uint8_t fast;           // 1: all tags share one specific base and mod strand and no code is listed twice (single group, distinct codes)
-  uint8_t pad;
+                          // 2: duplex — two such groups on different bases (`C+h?;C+m?;G-h?;G-m?`): the first `pad` tags form one, the rest the other
+  uint8_t pad;            // fast == 2: tags in the first group
   MkpTagDesc tags[MKP_MAX_TAGS];
   uint32_t tagmap[MKP_MAX_TAGS][4];  // per (tag, read base): [0:3] member index in its group, [4+4i..] local code idx of the tag's i-th code
   uint32_t pad2[7];                  // groups start 16-byte aligned (offset 192)
@@ -142,6 +143,7 @@ struct MkpRunParams {
   uint8_t hemi_pat_base[4];               // primary base -> its first pattern counter (0xff: the base has no calls in this run)
   uint8_t hemi_nel[4];                    // primary base -> pattern elements (1 + mod codes; 2 with --combine-mods)
   uint8_t hemi_el[MKP_MAX_COUNTERS + 2];  // call-event counter id -> pattern element; 0xff = Filtered
+  uint32_t readout_b_off;                 // duplex reads decoded one group per wave: the second group's summary sits at readout[readout_b_off + read]
 };
 // pileup-hemi counters of one tally column: NoCall(base) 0..3, deletions, Filtered(base) 5..8, then the pattern blocks
 #define MKP_H_NC 0

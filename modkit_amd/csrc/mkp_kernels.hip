@@ -927,7 +927,11 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6))) + wib;
   if (widx >= n_reads) return;
-  const uint32_t rid = (uint32_t)__builtin_amdgcn_readfirstlane((int)read_ids[widx]);
+  // Duplex reads (layout.fast == 2: two (strand, base) groups on different bases) are listed twice, once per group (bit 31 = the
+  // second); each listing decodes its group's tags exactly like a single-group read, into its own half of the read's event slice
+  // behind the room for the merged list, with its own summary; mkp_merge_duplex interleaves the two by position afterwards.
+  const uint32_t rid_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)read_ids[widx]);
+  const uint32_t rid = rid_raw & 0x7fffffffu; const bool half_b = (rid_raw >> 31) != 0u;
   const MkpReadHdr h = hdrs[rid];
   MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
@@ -942,8 +946,17 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   const uint32_t* __restrict__ seqw = reinterpret_cast<const uint32_t*>(seqs + h.seq_off);
   const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
   const uint32_t L = h.l_seq, nd = (L + 7u) >> 3, aln = rev ? 1u : 0u;
-  const int n_tags = (int)h.n_tags;
-  const int b0 = (int)lay->tags[0].fb & 3, sg0 = (int)lay->tags[0].neg & 1;
+  const bool duplex = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->fast) == 2u;
+  const int n_first = (int)__builtin_amdgcn_readfirstlane((int)lay->pad);
+  const int tb = (duplex && half_b) ? n_first : 0;                     // first tag of the group this wave decodes
+  const int n_tags = duplex ? (half_b ? (int)h.n_tags - n_first : n_first) : (int)h.n_tags;
+  uint32_t ev_base = h.event_off, ev_cap = h.event_cap, ro_idx = rid;
+  if (duplex) {
+    const uint32_t nA = tagref[h.tag_off].n, nB = tagref[h.tag_off + n_first].n;   // calls listed per group (one shared rank list each)
+    ev_base = h.event_off + nA + nB + (half_b ? nA : 0u); ev_cap = half_b ? nB : nA;
+    if (half_b) ro_idx = prm.readout_b_off + rid;
+  }
+  const int b0 = (int)lay->tags[tb].fb & 3, sg0 = (int)lay->tags[tb].neg & 1;
   const int xs = rev ? 3 - b0 : b0;                                   // the stored base the tags count
   const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
   GroupRegs grp0 = load_group(gp0);
@@ -959,10 +972,10 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   for (int t = 0; t < NT; t++) {
     t_ml[t] = 0; t_nc[t] = 0; tmu[t] = 0; codes_t[t] = 0;
     if (t < n_tags) {
-      const MkpTagRef tr = tagref[h.tag_off + t]; t_ml[t] = tr.ml_off;
+      const MkpTagRef tr = tagref[h.tag_off + tb + t]; t_ml[t] = tr.ml_off;
       if (t == 0) { t_off = tr.rank_off; t_n = tr.n; t_cur = rev ? tr.n : 0u; }
-      t_nc[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tags[t].n_codes);
-      tmu[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tagmap[t][b0]);
+      t_nc[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tags[tb + t].n_codes);
+      tmu[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lay->tagmap[tb + t][b0]);
       for (uint32_t i = 0; i < t_nc[t]; i++) codes_t[t] |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
     }
   }
@@ -1198,10 +1211,10 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
     const uint32_t step_total = (uint32_t)__popcll(b1);
     if (step_total) {
       const uint32_t off = n_ev + (uint32_t)__popcll(b1 & lanemask_lt());
-      if (n_ev + step_total > h.event_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
+      if (n_ev + step_total > ev_cap) { err = true; if (lane == 0) atomicOr(dev_err, ERR_EVENT_CAP); }
       else if (has_ev) {
-        MkpEvent ev; ev.pos = (uint32_t)rpos; ev.info = ev_info; events[h.event_off + off] = ev;
-        if (SAMPLE) sample_vals[h.event_off + off] = sv;
+        MkpEvent ev; ev.pos = (uint32_t)rpos; ev.info = ev_info; events[ev_base + off] = ev;
+        if (SAMPLE) sample_vals[ev_base + off] = sv;
       }
       n_ev += step_total;
     }
@@ -1222,7 +1235,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   }
   if (lane == 0) {
     if (!err && any_surviving) { out.ok = 1; out.n_events = n_ev; out.obs[0] = obs0; out.obs[1] = obs1; }
-    readout[rid] = out;
+    else if (!err && duplex) out.ok = 2;   // this group added nothing (all of it edge-filtered): the record still stands if the other group did
+    readout[ro_idx] = out;
   }
 }
 
@@ -2025,6 +2039,43 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles
 // pileup-hemi: the focus kernel with duplex pattern tallies
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_hemi(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false, true>(PILEUP_PASS); }
 
+// Duplex reads decoded one group per wave (decode_read_sparse): interleave the two position-sorted event lists of a read into the
+// front of its slice and combine the two summaries.  The record fails if either group failed (add_record returns at the first
+// error, read_cache.rs:111-211) and counts as "no modified base information" if neither group added anything.
+extern "C" __global__ void __launch_bounds__(256)
+mkp_merge_duplex(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ read_ids, uint32_t n, const MkpTagRef* __restrict__ tagref, const MkpLayout* __restrict__ layouts,
+                 MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t roff) {
+  const uint32_t lane = (uint32_t)lane_id();
+  const uint32_t widx = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (widx >= n) return;
+  const uint32_t rid_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)read_ids[widx]);
+  if (rid_raw >> 31) return;   // the listing of the second group
+  const uint32_t rid = rid_raw;
+  const MkpReadHdr h = hdrs[rid];
+  const uint32_t n_first = layouts[h.layout].pad;
+  const uint32_t capA = tagref[h.tag_off].n, capB = tagref[h.tag_off + n_first].n;
+  const MkpReadOut a = readout[rid], b = readout[roff + rid];
+  MkpReadOut out; out.n_events = 0; out.ok = 0; out.obs[0] = 0; out.obs[1] = 0;
+  if (a.ok && b.ok && (a.ok == 1u || b.ok == 1u)) {
+    const MkpEvent* __restrict__ eA = events + h.event_off + capA + capB; const MkpEvent* __restrict__ eB = eA + capA;
+    MkpEvent* __restrict__ dst = events + h.event_off;
+    const uint32_t nA = a.ok == 1u ? a.n_events : 0u, nB = b.ok == 1u ? b.n_events : 0u;
+    for (uint32_t i = lane; i < nA; i += 64) {   // an event of the first group goes after the second group's events at lower positions
+      const MkpEvent e = eA[i]; uint32_t lo = 0, hi = nB;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (eB[mid].pos < e.pos) lo = mid + 1u; else hi = mid; }
+      dst[i + lo] = e;
+    }
+    for (uint32_t i = lane; i < nB; i += 64) {   // and one of the second group after the first group's events at lower or equal positions
+      const MkpEvent e = eB[i]; uint32_t lo = 0, hi = nA;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (eA[mid].pos <= e.pos) lo = mid + 1u; else hi = mid; }
+      dst[i + lo] = e;
+    }
+    out.ok = 1; out.n_events = nA + nB;
+    out.obs[0] = (a.ok == 1u ? a.obs[0] : 0u) | (b.ok == 1u ? b.obs[0] : 0u); out.obs[1] = (a.ok == 1u ? a.obs[1] : 0u) | (b.ok == 1u ? b.obs[1] : 0u);
+  }
+  if (lane == 0) readout[rid] = out;
+}
+
 // pileup-hemi, records whose tags failed (readout.ok == 0): DuplexReadCache::get_duplex_mod_call (read_cache.rs:422-462) finds such a
 // record in no map the first time it is asked about it, fails to add it, and answers NoCall(primary base) for that one position;
 // from then on the record is in the skip set and yields no feature.  The cache lives for one interval (process_region_duplex,
@@ -2189,16 +2240,24 @@ extern "C" hipError_t mkp_launch_sample_hist1(hipStream_t st, const uint32_t* st
 // ----------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
 // read_ids = [SPARSE one tag | SPARSE two tags | FAST one tag | FAST two tags | all other reads], n_class = the five list lengths
-extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* read_ids, const uint32_t* n_class, const uint32_t* cigar, const uint8_t* seqs,
+extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* read_ids, const uint32_t* n_class /* [7] */, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts,
                                         const MkpRunParams* prm, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err,
                                         const uint8_t* bedmask, float* sample_vals) {
   const uint32_t waves_per_block = 4;
   const uint32_t* ids = read_ids;
-  for (int cls = 0; cls < 5; cls++) {
+  for (int cls = 0; cls < 7; cls++) {
     const uint32_t n = n_class[cls];
     if (n) {
       dim3 grid((n + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
+      if (cls >= 5) {   // duplex reads, listed once per group (never in sampling mode): SPARSE decode per group, then the merge
+        if (prm->sample_mode) return hipErrorInvalidValue;
+        if (cls == 5) hipLaunchKernelGGL(mkp_decode_sparse1, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids);
+        else hipLaunchKernelGGL(mkp_decode_sparse2, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids);
+        hipLaunchKernelGGL(mkp_merge_duplex, grid, block, 0, st, hdrs, ids, n, tagref, layouts, events, readout, prm->readout_b_off);
+        ids += n;
+        continue;
+      }
 #define MKP_DECODE_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids)
       if (prm->sample_mode) { if (cls == 0) MKP_DECODE_LAUNCH(mkp_sample_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_sample_sparse2); else if (cls == 2) MKP_DECODE_LAUNCH(mkp_sample_fast1); else if (cls == 3) MKP_DECODE_LAUNCH(mkp_sample_fast2); else MKP_DECODE_LAUNCH(mkp_sample_reads); }
       else { if (cls == 0) MKP_DECODE_LAUNCH(mkp_decode_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_decode_sparse2); else if (cls == 2) MKP_DECODE_LAUNCH(mkp_decode_fast1); else if (cls == 3) MKP_DECODE_LAUNCH(mkp_decode_fast2); else MKP_DECODE_LAUNCH(mkp_decode_reads); }

@@ -107,7 +107,16 @@ struct LayoutTables {
       { bool fast = !L.tags.empty(); std::vector<uint32_t> seen_codes;
         for (auto& th : L.tags) { if (th.fb == 4 || th.fb != L.tags[0].fb || th.neg != L.tags[0].neg || th.codes.empty()) fast = false;
           for (uint32_t c : th.codes) { if (std::find(seen_codes.begin(), seen_codes.end(), c) != seen_codes.end()) fast = false; seen_codes.push_back(c); } }
-        D.fast = fast ? 1 : 0; }
+        D.fast = fast ? 1 : 0;
+        // duplex: a leading run of tags on one (strand, base) and the rest on another one, different base, at most two tags each and no
+        // code listed twice inside a group (`C+h?;C+m?;G-h?;G-m?`, `C+hm?;G-hm?`): each group decodes like a single-group read
+        if (!fast && L.tags.size() >= 2 && L.tags.size() <= 4) {
+          size_t nA = 1; while (nA < L.tags.size() && L.tags[nA].fb == L.tags[0].fb && L.tags[nA].neg == L.tags[0].neg) nA++;
+          bool ok = nA < L.tags.size() && nA <= 2 && L.tags.size() - nA <= 2 && L.tags[0].fb < 4 && L.tags[nA].fb < 4 && L.tags[nA].fb != L.tags[0].fb;
+          for (size_t t = nA; ok && t < L.tags.size(); t++) ok = L.tags[t].fb == L.tags[nA].fb && L.tags[t].neg == L.tags[nA].neg;
+          for (size_t g = 0; ok && g < 2; g++) { std::vector<uint32_t> seen; for (size_t t = g ? nA : 0; t < (g ? L.tags.size() : nA); t++) { if (L.tags[t].codes.empty()) ok = false; for (uint32_t c : L.tags[t].codes) { if (std::find(seen.begin(), seen.end(), c) != seen.end()) ok = false; seen.push_back(c); } } }
+          if (ok) { D.fast = 2; D.pad = (uint8_t)nA; }
+        } }
       for (size_t t = 0; t < L.tags.size(); t++) {
         D.tags[t].fb = L.tags[t].fb; D.tags[t].neg = L.tags[t].neg; D.tags[t].mode = L.tags[t].mode; D.tags[t].n_codes = (uint8_t)L.tags[t].codes.size();
         if (L.tags[t].mode == 2) D.default_mask |= (uint8_t)(1u << t);
