@@ -360,7 +360,6 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (a.cpg && !a.motif_parts.empty()) throw Error(MKP_E_INVALID, "the argument '--cpg' cannot be used with '--motif'");
     if (a.motif_parts.size() > 2) throw Error(MKP_E_INVALID, "motif arg should be length 2, eg. CG 0");
     if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "the following required arguments were not provided: --ref <REFERENCE_FASTA>");
-    if (a.world > 1) throw Error(MKP_E_UNSUPPORTED, "pileup-hemi runs on one GPU");
   }
   bool combine_strands = a.combine_strands;  // option resolution (subcommand.rs:484-523)
   if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; combine_strands = true; }

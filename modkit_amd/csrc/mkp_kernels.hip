@@ -1116,6 +1116,9 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
     if (qcount == qhead) break;
     // ---- consumer: up to 64 queued calls, in read order
     const uint32_t nb = min(64u, qcount - qhead);
+#ifdef MKP_DEBUG
+    if (prm.debug_skip & 16u) { qhead += nb; any_surviving = true; continue; }   // ablation: producer only
+#endif
     const bool active = (uint32_t)lane < nb;
     const uint32_t q = active ? q_pos[qhead + lane] : 0u;
     const uint32_t jx = active ? q_j[qhead + lane] : 0u;
@@ -1134,6 +1137,9 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
     }
     // reference position through the CIGAR window (aligned pairs: M/=/X only, util.rs:122-145)
     bool mapped = false; int32_t rpos = 0;
+#ifdef MKP_DEBUG
+    if (prm.debug_skip & 32u) { mapped = active; rpos = h.ref_start + (int32_t)q; } else   // ablation: no CIGAR mapping
+#endif
     {
       bool pending = active;
       for (;;) {

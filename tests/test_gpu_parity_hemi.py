@@ -121,3 +121,17 @@ def test_hemi_shard_api_and_mode_switch(tmp_path, hemi_ref):
         assert len(open(out2).read().splitlines()) > 300
     finally:
         ctx.close()
+
+
+def test_hemi_rank_sharded_equals_single(oracle_bin, tmp_path):
+    """--gpus-rank R --gpus-world W deals runs of shards to the ranks (the plain pileup's plan): the ranks' outputs, concatenated in
+    rank order, are the single-rank output."""
+    bam, fa, _ = Fuzz(4311, profile="duplex_hm", n_reads=500, contigs=(("ctgA", 30000), ("ctgB", 9000), ("ctgC", 4000))).write(str(tmp_path / "fz"))
+    flags = ["--cpg", "-r", fa, "--filter-threshold", "0.7", "-i", "1000"]
+    single = run_both(oracle_bin, tmp_path, bam, flags, extra_dev=["--shard-bp", "3000"])
+    parts = []
+    for r in range(3):
+        out = str(tmp_path / ("rank%d.bed" % r))
+        modkit_amd.pileup_hemi([bam, "-o", out] + flags + ["--shard-bp", "3000", "--gpus-rank", str(r), "--gpus-world", "3"])
+        parts.append(open(out).read())
+    assert all(parts) and "".join(parts) == single
