@@ -132,7 +132,10 @@ def pmc_traffic(argv_tail, timeout_s=420):
     for k in res["FETCH_SIZE"]:
         if k.startswith("mkp_"):
             out[k] = int((2.0 * res["FETCH_SIZE"][k] + res["WRITE_SIZE"].get(k, 0.0)) * 1024)
-    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --inner --steps 2 --warmup 1` of this build, mean per launch, bytes = (2*FETCH + WRITE) * 1024"
+            out[k + ":read"] = int(2.0 * res["FETCH_SIZE"][k] * 1024)
+            out[k + ":write"] = int(res["WRITE_SIZE"].get(k, 0.0) * 1024)
+    return out, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --inner --steps 2 --warmup 1` of this build, mean per launch, "
+                 "bytes = (2*FETCH + WRITE) * 1024; the factor 2 is calibrated on this GPU for streams and byte walks alike (profiles/r02_pmc_calibration.txt)")
 
 
 def main():
@@ -260,7 +263,7 @@ def main():
             if traffic_all:
                 traffic = traffic_all.get(dom_kernel)
                 traffic_all["mkp_pileup_tiles"] = traffic
-                traffic_all["mkp_decode_*"] = sum(v for k, v in traffic_all.items() if k.startswith("mkp_decode_")) or None
+                traffic_all["mkp_decode_*"] = sum(v for k, v in traffic_all.items() if k.startswith("mkp_decode_") and ":" not in k) or None
         dev_ms = rep1.pack_ms + rep1.h2d_ms + rep1.kernel_ms + rep1.d2h_ms
         result = {
             "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": total_positions * a.steps / elapsed, "unit": "positions/s",
@@ -285,7 +288,7 @@ def main():
                                "shards": int(rep.n_shards), "what": "rank 0: mkp_pileup_run wall (`modkit pileup in.bam out.bed` with the workload's flags, default sharding), page cache warm; bam_load_inflate = what the shard loop waited for blocks (the rest overlaps with pack / run / write)"},
             },
             "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
+                         "traffic": traffic, "traffic_read": (traffic_all or {}).get(dom_kernel + ":read"), "traffic_write": (traffic_all or {}).get(dom_kernel + ":write"), "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
             workers = min(os.cpu_count() or 1, 8)
