@@ -240,7 +240,7 @@ class FocusBuilder {
     HostPool::get().parallel((size_t)pieces, [&](size_t i) { f(lo + i * g, std::min(hi, lo + (i + 1) * g)); });
   }
 
- private:
+  // (public for tests/test_host_focus_kats.py, which walks a contig interval by interval with these and compares with walk())
   uint8_t combo_id(const mkp_motif_combo& c) {
     if (c.n_pos == 0 && c.n_neg == 0) return 0;
     for (size_t i = 1; i < combos.size(); i++) if (memcmp(&combos[i], &c, sizeof(c)) == 0) return (uint8_t)i;

@@ -68,3 +68,86 @@ def test_library_motif_code_matches_reference_unit_tests(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-lz", "-pthread"])
     p = subprocess.run([str(exe)], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip() == "ok", p.stdout + p.stderr
+
+
+# The strand-combining interval walk (get_motif_positions_combine_strands, src/fasta.rs:92-188 + FocusPositions::
+# new_motif_combine_strands, src/interval_chunks.rs:250-297): the library finds the interval ends in one sequential pass that looks
+# at the hits around each nominal end only and fills the focus bytes on all cores; here the contig is walked the plain way, one
+# interval after the other over the whole slice, and intervals, focus bytes and combo tables must be identical.
+WALK_SRC = r'''
+#include <cstdio>
+#include <random>
+#include "mkp_focus.hpp"
+using namespace mkp;
+static std::vector<Interval> walk_plain(FocusBuilder& fb, const Contig& rec, uint32_t interval_size, std::vector<uint8_t>* focus, const std::string& seq) {
+  std::vector<Interval> ivs; focus->assign(rec.length, 0);
+  size_t longest = 0; for (auto& m : fb.motifs) longest = std::max(longest, m.len());
+  uint32_t pos = rec.start;
+  while (pos < rec.end()) {
+    uint32_t end = (uint32_t)std::min<uint64_t>((uint64_t)pos + interval_size, rec.end());
+    std::vector<std::map<uint32_t, Rule>> locs(fb.motifs.size());
+    uint64_t ref_end = rec.end(), buffer = longest * 5, e = end, end_w = std::min<uint64_t>((uint64_t)end + buffer, ref_end);
+    for (;;) {
+      if (end_w > seq.size()) throw Error(MKP_E_UNSUPPORTED, "past the contig end");
+      for (auto& l : locs) l.clear();
+      for (size_t i = 0; i < fb.motifs.size(); i++) motif_hits(seq.data() + pos, (size_t)(end_w - pos), fb.motifs[i], pos, rec.tid, nullptr, &locs[i]);
+      std::vector<Span> sp;
+      for (size_t i = 0; i < fb.motifs.size(); i++) { uint64_t adj = fb.motifs[i].len() >= fb.motifs[i].fwd_off ? fb.motifs[i].len() - fb.motifs[i].fwd_off : fb.motifs[i].len(); for (auto& kv : locs[i]) sp.push_back({kv.first, kv.first + adj}); }
+      merge_spans(sp);
+      uint64_t search_end = e, qs = e ? e - 1 : 0;
+      for (auto& s : sp) if (s.s < e && s.e > qs) { search_end = s.e; break; }
+      uint64_t too_close = end_w >= longest ? end_w - longest : 0;
+      if (search_end < too_close || end_w >= ref_end) { for (auto& l : locs) for (auto it = l.begin(); it != l.end();) { if (it->first <= search_end) ++it; else it = l.erase(it); } end = (uint32_t)std::min<uint64_t>(search_end, rec.end()); break; }
+      e = end_w; end_w += buffer;
+    }
+    fb.fill_motif(locs, rec, pos, end, focus);
+    ivs.push_back({rec.tid, pos, end});
+    pos = end;
+  }
+  return ivs;
+}
+int main() {
+  std::mt19937_64 rng(11); int bad = 0, cases = 0;
+  for (int it = 0; it < 60; it++) {
+    uint32_t L = 2000 + rng() % 30000; std::string seq(L, 'A');
+    for (uint32_t i = 0; i < L; i++) seq[i] = "ACGT"[rng() & 3];
+    if (it % 3) for (int k = 0; k < 40; k++) { uint32_t p = rng() % (L - 200), n = 2 + rng() % 90; for (uint32_t j = 0; j < n && p + j < L; j++) seq[p + j] = (it % 3 == 2 ? "GATC"[j & 3] : "CG"[j & 1]); }
+    Fasta fa; fa.seqs["c"] = seq;
+    for (int mset = 0; mset < 3; mset++) for (uint32_t isz : {37u, 100u, 501u, 4096u, 100000u}) {
+      FocusBuilder a, b;
+      for (FocusBuilder* f : {&a, &b}) {
+        f->fasta = &fa; f->combine = true; f->mask = true;   // mask: the sequence is used as it is
+        if (mset == 0) f->motifs.push_back(Motif::parse("CG", 0));
+        else if (mset == 1) { f->motifs.push_back(Motif::parse("CG", 0)); f->motifs.push_back(Motif::parse("GATC", 1)); }
+        else { f->motifs.push_back(Motif::parse("CCGG", 1)); f->motifs.push_back(Motif::parse("CG", 0)); f->motifs.push_back(Motif::parse("GC", 1)); }
+      }
+      Contig rec; rec.tid = 0; rec.name = "c"; rec.start = (it % 5 == 0) ? 123 : 0; rec.length = L - rec.start - ((it % 7 == 0) ? 57 : 0);
+      std::vector<uint8_t> fa_bytes, fb_bytes; std::vector<Interval> ia, ib; bool ea = false, eb = false;
+      try { ia = a.walk(rec, isz, &fa_bytes); } catch (const Error&) { ea = true; }
+      try { ib = walk_plain(b, rec, isz, &fb_bytes, seq); } catch (const Error&) { eb = true; }
+      cases++;
+      bool same = ea == eb;
+      if (same && !ea) {
+        same = ia.size() == ib.size() && fa_bytes == fb_bytes && a.combos.size() == b.combos.size();
+        for (size_t k = 0; same && k < ia.size(); k++) same = ia[k].start == ib[k].start && ia[k].end == ib[k].end;
+        for (size_t k = 0; same && k < a.combos.size(); k++) same = memcmp(&a.combos[k], &b.combos[k], sizeof(mkp_motif_combo)) == 0;
+        FocusBuilder c2; c2.fasta = &fa; c2.combine = true; c2.mask = true; c2.motifs = a.motifs;   // the grid alone (what ranks that do not own a contig compute)
+        auto ic = c2.walk(rec, isz, nullptr); same = same && ic.size() == ia.size(); for (size_t k = 0; same && k < ia.size(); k++) same = ic[k].end == ia[k].end;
+      }
+      if (!same) { bad++; if (bad < 5) printf("MISMATCH it=%d mset=%d isz=%u errs=%d/%d n=%zu/%zu\n", it, mset, isz, ea, eb, ia.size(), ib.size()); }
+    }
+  }
+  printf(bad ? "FAILED %d of %d\n" : "ok %d\n", bad ? bad : cases, cases);
+  return bad != 0;
+}
+'''
+
+
+def test_combine_strands_walk_matches_interval_by_interval_walk(tmp_path):
+    src = tmp_path / "walk.cpp"
+    src.write_text(WALK_SRC)
+    exe = tmp_path / "walk"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           "-o", str(exe), str(src), "-lz", "-pthread"])
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip().startswith("ok"), p.stdout + p.stderr
