@@ -234,6 +234,9 @@ class Packer {
   std::vector<LayoutHost> layouts;
   std::vector<std::string> layout_keys;   // key of layouts[i]
   std::unordered_map<std::string, uint16_t> layout_ids;
+  // pieces of the all-cores pack (pack_records): kept between shards so that their buffers — as large as a shard, together — are
+  // mapped and faulted in once instead of once per shard (fresh mappings cost page faults on 64 threads and TLB shootdowns on unmap)
+  std::vector<ShardHost> pieces;
 
   // intern the layouts of an independently used packer; returns its id -> this packer's id (first-appearance order is kept)
   std::vector<uint16_t> adopt(const Packer& o) {
@@ -411,8 +414,11 @@ template <class Keep> void pack_records(Packer& packer, ShardHost& dst, const mk
   const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
   const unsigned n_thr = n >= min_parallel ? std::max(1u, std::min(hw, n)) : 1;
   if (n_thr == 1) { for (uint32_t i = 0; i < n; i++) if (keep(recs[i])) packer.add(recs[i], dst); return; }
-  std::vector<Packer> pk(n_thr); std::vector<ShardHost> sh(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr);
+  std::vector<Packer> pk(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr);
+  if (packer.pieces.size() != n_thr) { packer.pieces.clear(); packer.pieces.resize(n_thr); }
+  std::vector<ShardHost>& sh = packer.pieces;
   HostPool::get().parallel(n_thr, [&](size_t t) {
+    sh[t].clear();
     const uint32_t lo = (uint32_t)((uint64_t)n * t / n_thr), hi = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
     sh[t].tid = dst.tid; sh[t].win_start = dst.win_start; sh[t].win_end = dst.win_end;
     try { for (uint32_t i = lo; i < hi; i++) if (keep(recs[i])) pk[t].add(recs[i], sh[t]); }
