@@ -39,34 +39,33 @@ MkpRowsDev carve_rows(DevBuf& b, uint64_t cap) {
 // With `duplex` (never for the threshold sampler): [.. | duplex one tag per group | duplex two]: reads whose layout has two groups on
 // different bases (`C+h?;C+m?;G-h?;G-m?`), every tag explicit and the tags of a group sharing one rank list; such a read is listed
 // twice (bit 31 = its second group), each listing decoded by a SPARSE wave, and mkp_merge_duplex interleaves the two event lists.
+template <class F> void host_parallel(size_t n, size_t grain, F f);
 void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[7], bool duplex) {
+  auto class_of = [&](size_t i) -> int {
+    const MkpReadHdr& h = S.hdr[i];
+    auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1]; return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
+    if ((h.flags & MKP_RF_BAD) || !h.n_tags || h.layout >= T.dev.size()) return 4;
+    const MkpLayout& L = T.dev[h.layout];
+    bool explicit_tags = true;
+    for (uint32_t t = 0; t < h.n_tags; t++) if (L.tags[t].mode != 0) explicit_tags = false;
+    if (duplex && L.fast == 2) {
+      const uint32_t nA = L.pad;
+      if (explicit_tags && (nA != 2 || same(0, 1)) && (h.n_tags - nA != 2 || same(nA, nA + 1))) return (nA == 1 && h.n_tags - nA == 1) ? 5 : 6;
+      return 4;
+    }
+    if (L.fast == 1 && h.n_tags <= 2) {
+      const bool sparse = explicit_tags && (h.n_tags == 1 || same(0, 1));
+      return (sparse ? 0 : 2) + (int)(h.n_tags - 1);
+    }
+    return 4;
+  };
+  // classified on all cores (the rank-list comparisons touch every call of a two-tag read); then one list per class,
+  // one wave decodes one read start to end: the longest reads are launched first so that they do not form the kernel's tail
+  std::vector<uint8_t> cl(S.hdr.size());
+  host_parallel(S.hdr.size(), 4096, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cl[i] = (uint8_t)class_of(i); });
   std::vector<uint32_t> cls[7];
-  for (size_t i = 0; i < S.hdr.size(); i++) {
-    const MkpReadHdr& h = S.hdr[i]; int c = 4;
-    if (duplex && !(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast == 2) {
-      const MkpLayout& L = T.dev[h.layout]; const uint32_t nA = L.pad;
-      bool ok = true;
-      for (uint32_t t = 0; t < h.n_tags; t++) if (L.tags[t].mode != 0) ok = false;
-      auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1]; return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
-      if (ok && nA == 2) ok = same(0, 1);
-      if (ok && h.n_tags - nA == 2) ok = same(nA, nA + 1);
-      if (ok) { cls[(nA == 1 && h.n_tags - nA == 1) ? 5 : 6].push_back((uint32_t)i); continue; }
-    }
-    if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < T.dev.size() && T.dev[h.layout].fast == 1 && h.n_tags <= 2) {
-      c = 2 + (h.n_tags - 1);
-      const MkpLayout& L = T.dev[h.layout];
-      bool sparse = true;
-      for (uint32_t t = 0; t < h.n_tags; t++) if (L.tags[t].mode != 0) sparse = false;
-      if (sparse && h.n_tags == 2) {
-        const MkpTagRef &a = S.tagref[h.tag_off], &b = S.tagref[h.tag_off + 1];
-        sparse = a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0);
-      }
-      if (sparse) c -= 2;
-    }
-    cls[c].push_back((uint32_t)i);
-  }
-  // one wave decodes one read start to end: launch the longest reads first so they do not form the kernel's tail
-  for (int c = 0; c < 7; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; });
+  for (size_t i = 0; i < cl.size(); i++) cls[cl[i]].push_back((uint32_t)i);
+  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; }); });
   ids->clear();
   for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
   for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r); ids->push_back(r | 0x80000000u); } }
@@ -104,10 +103,13 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
 void make_resident(mkp_ctx* c) {
   auto t0 = std::chrono::steady_clock::now();
   ShardHost& S = c->shard;
+  const bool trace = getenv("MKP_TRACE_PLAN") != nullptr;   // host planning stages on stderr
+  auto lap = [&, last = t0](const char* what) mutable { if (trace) { auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
   { std::vector<std::pair<uint32_t, uint64_t>> h(S.name_hash.size()); for (size_t i = 0; i < h.size(); i++) h[i] = {i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u, S.name_hash[i]};   // per partition key: tallies of different keys never meet
     std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
+  lap("duplicate-name check");
   // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
   { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1; c->tables.build(c->packer.layouts, c->caller, &used); }
   MkpRunParams& P = c->prm; memset(&P, 0, sizeof(P));
@@ -124,6 +126,7 @@ void make_resident(mkp_ctx* c) {
   std::vector<int> order(P.n_slots); for (uint32_t i = 0; i < P.n_slots; i++) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a], &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
   for (uint32_t i = 0; i < P.n_slots; i++) { P.slot_order[i] = (uint8_t)order[i]; P.slots[i] = c->tables.st.slots[i]; }
+  lap("caller tables + params");
   if (P.combine_strands && !P.has_focus) throw Error(MKP_E_INVALID, "combine_strands needs motif focus positions");
   if (c->hemi) {
     // pileup-hemi counters: a pattern block of (1 + codes)^2 counters per primary base that has calls, elements in DuplexModCodeRepr
@@ -174,9 +177,11 @@ void make_resident(mkp_ctx* c) {
     for (auto& h : S.hdr) { if (off > 0xfffffff0ull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards"); h.event_off = (uint32_t)off; off += h.event_cap; }
     S.n_events_cap = off; }
   P.readout_b_off = (uint32_t)S.hdr.size();
+  lap("decode classes + event slices");
   const size_t n = S.hdr.size();
   for (size_t i = 1; i < n; i++) if (S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted");
   depth_guard(S, c->caller.max_depth);
+  lap("sortedness + depth guard");
 
   // ---- tile plan.  The accumulate kernel runs two 1024-thread workgroups per CU, each holding one tile in LDS: 76 KiB per
   // workgroup including ~3.5 KiB of static LDS leaves slack for the allocation granule (at 80 KiB each one GPU box ran them one
@@ -229,6 +234,7 @@ void make_resident(mkp_ctx* c) {
     }
     Scap = std::max<uint32_t>(64u, (most + 63u) & ~63u);
   }
+  lap("slot bitmap + tiles");
   // tile -> [first, last) candidate reads (coordinate sorted; the prefix-max of ends bounds the first candidate)
   {
     std::vector<int32_t> pmax(n); int32_t m = INT32_MIN;
@@ -249,6 +255,7 @@ void make_resident(mkp_ctx* c) {
   c->n_tiles = (uint32_t)tiles.size();
   c->n_slots_total = 0;
   if (c->has_focus) { for (size_t w = 0; w < slotbm.size(); w++) c->n_slots_total += (uint64_t)__builtin_popcount(slotbm[w]); }
+  lap("candidate reads per tile");
   c->stats.pack_ms += ms_since(t0);
   auto t1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");

@@ -60,7 +60,8 @@ class HostPool {
   struct Job { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}, skipped{0}; };
   std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Job*> jobs_; bool stop_ = false;
   HostPool() {
-    const unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("MKP_POOL_THREADS")) n = std::max(1u, std::min(512u, (unsigned)strtoul(e, nullptr, 10)));   // experiments
     for (unsigned t = 1; t < n; t++) workers_.emplace_back([this] { loop(); });
   }
   ~HostPool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : workers_) t.join(); }

@@ -480,10 +480,12 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     std::vector<mkp_record> recs; recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e));
     {
       if (a.plan_only) {  // host-only dry run: the shard plan, plus the packer over the shard's records (no device)
-        Packer pk; ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1;
-        const int32_t tid = (int32_t)rec.tid;
+        static std::vector<ShardHost> kept_pieces;   // the all-cores pack's per-thread buffers persist across shards, as they do in a context
+        Packer pk; pk.pieces.swap(kept_pieces); ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1;
+        const int32_t tid = (int32_t)rec.tid; auto t_pk = std::chrono::steady_clock::now();
         // --plan-pack-min N: records from which the packer runs on all cores (0 = always; default as in mkp_shard_add_records)
         pack_records(pk, S, recs.data(), (uint32_t)recs.size(), [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); }, a.plan_pack_min);
+        pack_ms += ms_since(t_pk); kept_pieces.swap(pk.pieces);
         // digest of everything the packer hands to the device: a parallel pack must equal the sequential one byte for byte
         uint64_t dg = 1469598103934665603ull;
         auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { dg ^= b[i]; dg *= 1099511628211ull; } };

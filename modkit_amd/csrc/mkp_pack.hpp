@@ -411,7 +411,8 @@ class Packer {
 // record ranges are packed independently by all host cores and appended in order (same layout ids and offsets as one
 // sequential pass).
 template <class Keep> void pack_records(Packer& packer, ShardHost& dst, const mkp_record* recs, uint32_t n, Keep keep, uint32_t min_parallel = 1024) {
-  const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("MKP_PACK_PIECES")) hw = std::max(1u, std::min(4096u, (unsigned)strtoul(e, nullptr, 10)));   // experiments
   const unsigned n_thr = n >= min_parallel ? std::max(1u, std::min(hw, n)) : 1;
   if (n_thr == 1) { for (uint32_t i = 0; i < n; i++) if (keep(recs[i])) packer.add(recs[i], dst); return; }
   std::vector<Packer> pk(n_thr); std::vector<std::unique_ptr<Error>> errs(n_thr);

@@ -176,6 +176,20 @@ class Fuzz:
             ml.extend(r.randrange(0, 128) for _ in rk)
             add("G-m?", positions("G", 0.8), 1)
             add("A+a?", positions("A", 0.5), 1)
+        elif prof == "duplex_chebi":  # a ChEBI-numbered code next to a letter code on both strands (pattern names like 76792,m,C)
+            rk = positions("C", 0.9, cpg=True)
+            header("C+76792?", rk)
+            ml.extend(r.randrange(0, 128) for _ in rk)
+            header("C+m?", rk)
+            ml.extend(r.randrange(0, 128) for _ in rk)
+            rg = positions("G", 0.7)
+            header("G-76792?", rg)
+            ml.extend(r.randrange(0, 128) for _ in rg)
+            header("G-m?", rg)
+            ml.extend(r.randrange(0, 128) for _ in rg)
+        elif prof == "duplex_3codes":  # three codes per strand: 16 patterns per base
+            add("C+hmf?", positions("C", 0.9, cpg=True), 3)
+            add("G-hmf?", positions("G", 0.7), 3)
         elif prof == "nbase":
             n = len(fwd)
             pos = sorted(r.sample(range(n), min(n, r.randrange(0, 25))))

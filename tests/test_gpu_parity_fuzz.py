@@ -75,7 +75,7 @@ _PS = os.environ.get("MKP_FUZZ_PROFILE_SEEDS", "77:78").split(":")
 
 
 @pytest.mark.parametrize("pseed", range(int(_PS[0]), int(_PS[1])))
-@pytest.mark.parametrize("profile", ["m", "hm_comb", "hm_split", "hm_split_diff", "hma", "implicit", "default", "duplex", "nbase", "chebi"])
+@pytest.mark.parametrize("profile", ["m", "hm_comb", "hm_split", "hm_split_diff", "hma", "implicit", "default", "duplex", "nbase", "chebi", "duplex_hm", "duplex_split", "duplex_chebi", "duplex_3codes"])
 def test_fuzz_profiles(oracle_bin, tmp_path, profile, pseed):
     bam, fa, bed = Fuzz(pseed, profile=profile, n_reads=400, tie_rate=0.2).write(str(tmp_path / "fz"), bed=True)
     rows = 0
@@ -106,7 +106,7 @@ def test_driver_shards_cut_inside_a_contig(oracle_bin, tmp_path, shard_bp):
         assert out and len(out.splitlines()) > 100
 
 
-@pytest.mark.parametrize("profile", ["m", "hm_split", "hma"])
+@pytest.mark.parametrize("profile", ["m", "hm_split", "hma", "duplex_split"])
 def test_ultra_long_reads(oracle_bin, tmp_path, profile):
     # reads of ~10^5 bases: hundreds of decode steps per read, CIGARs of tens of thousands of ops (many 64-op chunks), every
     # tile of the contig crossed by every read

@@ -89,7 +89,7 @@ FUZZ_FLAGS = [
 ]
 
 
-@pytest.mark.parametrize("profile", ["duplex", "duplex_hm", "duplex_split", "mixed"])
+@pytest.mark.parametrize("profile", ["duplex", "duplex_hm", "duplex_split", "duplex_chebi", "duplex_3codes", "mixed"])
 @pytest.mark.parametrize("fi", range(len(FUZZ_FLAGS)))
 def test_fuzz_hemi(oracle_bin, tmp_path, profile, fi):
     bam, fa, bed = Fuzz(4200 + fi, profile=profile, n_reads=300, tie_rate=0.1).write(str(tmp_path / "fz"), bed=True)
