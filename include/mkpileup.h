@@ -257,6 +257,15 @@ int mkp_hemi_shard_run(mkp_ctx* ctx, int32_t partner_offset, const uint32_t* int
 int mkp_pileup_hemi_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 int mkp_pileup_hemi_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report);
 
+/* ---- BGZF inflate on the device: first stage of moving BAM ingest onto the GPU.  Not on the pileup path yet — the
+ * driver still inflates on the host, where the step overlaps with packing; this entry point exists so that the kernel is tested and
+ * measured on its own.  Stands in for what htslib does under rust-htslib's IndexedReader (src/pileup/mod.rs:732-743): BGZF blocks
+ * (SAM spec 4.1) of raw DEFLATE (RFC 1951) — neither htslib nor zlib is part of the reference checkout, the decoder follows the RFC.
+ * bgzf = n_bytes of whole BGZF blocks in host memory (a file image).  One device thread decodes one block; every block's CRC32 and
+ * ISIZE are checked on the host before the call returns.  *out = the inflated bytes, owned by the ctx until its next inflate call;
+ * *kernel_ms (may be NULL) = device time of the decode kernel. */
+int mkp_bgzf_inflate(mkp_ctx* ctx, const uint8_t* bgzf, uint64_t n_bytes, const uint8_t** out, uint64_t* out_len, double* kernel_ms);
+
 /* ---- host-side pieces exposed for tests (no device needed):
  * mkp_host_mm_ranks: the packer's MM tokeniser (MmTagInfo::parse, src/mod_bam.rs:909-1000) on one MM string: for every tag its
  *   header (fundamental base A,C,G,T,N = 0..4; strand; mode 0 '?', 1 '.', 2 none; codes as code_repr) and its delta list turned into

@@ -59,6 +59,7 @@ def lib():
         L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         L.mkp_pileup_hemi_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
         L.mkp_pileup_hemi_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+        L.mkp_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
         L.mkp_hemi_shard_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_void_p]
         u64p, f32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)
         L.mkp_histogram_begin.argtypes = [ctypes.c_void_p]
@@ -76,7 +77,7 @@ EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
-           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run"]
+           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate"]
 
 
 def pileup(argv):
@@ -270,6 +271,12 @@ class Context:
         out = {f: (np.ctypeslib.as_array(getattr(rows, f), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)) for f in HEMI_ROW_FIELDS}
         out["processed_records"], out["skipped_records"] = int(rows.processed_records), int(rows.skipped_records)
         return out
+
+    def bgzf_inflate(self, data):
+        """mkp_bgzf_inflate: inflate a BGZF file image (bytes) on the device; returns (inflated bytes, kernel ms)."""
+        out, n, ms = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_double()
+        self._check(self.L.mkp_bgzf_inflate(self.h, data, len(data), ctypes.byref(out), ctypes.byref(n), ctypes.byref(ms)))
+        return ctypes.string_at(out, n.value) if n.value else b"", ms.value
 
     def rerun(self, iters, fetch=False):
         rows = Rows()

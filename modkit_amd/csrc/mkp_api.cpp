@@ -19,6 +19,7 @@ hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mo
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
                              uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
+hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/, const uint32_t* /*interval starts*/,
                                   uint32_t, int32_t, int32_t, uint32_t* /*error bits*/);
 }
@@ -442,7 +443,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -582,6 +583,50 @@ int mkp_percentile(const float* xs, uint64_t n, float q, float* out) {  // perce
   float g = lq - truncf(lq), a = xs[(uint64_t)left] * (1.0f - g), b = xs[right] * g;
   *out = a + b;
   return MKP_OK;
+}
+
+int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const uint8_t** out, uint64_t* out_len, double* kernel_ms) {
+  if (!c || (!bgzf && n_bytes) || !out || !out_len) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    struct Blk { unsigned long long in_off, out_off; uint32_t in_len, out_len; };   // == MkpBgzfBlock (mkp_inflate.hip)
+    std::vector<Blk> blks; std::vector<uint32_t> crcs; uint64_t o = 0, total = 0;
+    while (o < n_bytes) {   // header walk, as in load_bam (mkp_bam.hpp): gzip magic, FEXTRA with a BC subfield holding BSIZE
+      if (o + 18 > n_bytes || bgzf[o] != 31 || bgzf[o + 1] != 139 || bgzf[o + 2] != 8 || !(bgzf[o + 3] & 4)) throw Error(MKP_E_IO, "not BGZF");
+      uint16_t xlen; memcpy(&xlen, bgzf + o + 10, 2);
+      uint64_t x = o + 12; const uint64_t xe = x + xlen; uint32_t bsize = 0; bool found = false;
+      if (xe > n_bytes) throw Error(MKP_E_IO, "bad BGZF block");
+      while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, bgzf + x + 2, 2); if (bgzf[x] == 'B' && bgzf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b; memcpy(&b, bgzf + x + 4, 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (uint64_t)sl; }
+      if (!found || o + bsize > n_bytes || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block");
+      uint32_t crc, isize; memcpy(&crc, bgzf + o + bsize - 8, 4); memcpy(&isize, bgzf + o + bsize - 4, 4);
+      if (isize > 65536u) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB");
+      blks.push_back({o + 12 + xlen, total, bsize - xlen - 20, isize}); crcs.push_back(crc);
+      total += isize; o += bsize;
+    }
+    if (blks.size() > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED, "too many BGZF blocks");
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    c->d_zin.ensure(std::max<uint64_t>(n_bytes, 16)); c->d_zout.ensure(std::max<uint64_t>(total, 16)); c->d_zblk.ensure(std::max<size_t>(blks.size(), 1) * sizeof(Blk)); c->d_zstat.ensure(std::max<size_t>(blks.size(), 1) * 4);
+    if (n_bytes) hip_check(hipMemcpyAsync(c->d_zin.p, bgzf, n_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+    if (!blks.empty()) hip_check(hipMemcpyAsync(c->d_zblk.p, blks.data(), blks.size() * sizeof(Blk), hipMemcpyHostToDevice, c->stream), "H2D");
+    hip_check(hipMemsetAsync(c->d_zstat.p, 0xff, std::max<size_t>(blks.size(), 1) * 4, c->stream), "memset");
+    hip_check(hipEventRecord(c->ev[0], c->stream), "event");
+    hip_check(mkp_launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()), "inflate launch");
+    hip_check(hipEventRecord(c->ev[1], c->stream), "event");
+    std::vector<uint32_t> st(blks.size());
+    c->h_inflated.resize(total);
+    if (!blks.empty()) hip_check(hipMemcpyAsync(st.data(), c->d_zstat.p, blks.size() * 4, hipMemcpyDeviceToHost, c->stream), "D2H");
+    if (total) hip_check(hipMemcpyAsync(c->h_inflated.data(), c->d_zout.p, total, hipMemcpyDeviceToHost, c->stream), "D2H");
+    hip_check(hipStreamSynchronize(c->stream), "inflate sync");
+    if (kernel_ms) { float ms = 0; hip_check(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]), "event"); *kernel_ms = ms; }
+    std::atomic<long> bad{-1};
+    host_parallel(blks.size(), 64, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) {
+        const bool ok = st[i] == 0 && (uint32_t)crc32(crc32(0L, Z_NULL, 0), c->h_inflated.data() + blks[i].out_off, blks[i].out_len) == crcs[i];
+        if (!ok) { long exp = -1; bad.compare_exchange_strong(exp, (long)i); }
+      }
+    });
+    if (bad.load() >= 0) throw Error(MKP_E_IO, "corrupt BGZF data: block " + std::to_string(bad.load()) + " (decoder status " + std::to_string(st[(size_t)bad.load()]) + ")");
+    *out = c->h_inflated.data(); *out_len = total;
+  });
 }
 
 int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_tag* tags, uint32_t tags_cap, uint32_t* ranks, uint32_t ranks_cap) {

@@ -52,6 +52,7 @@ struct mkp_ctx {
   // pileup-hemi (mkp_hemi_shard_run): mode of the resident plan, partner offset, interval starts, pattern element -> mod code
   bool hemi = false, resident_hemi = false; int32_t hemi_off = 0; std::vector<uint32_t> hemi_iv; mkp::DevBuf d_hemi_iv;
   uint32_t hemi_codes[4][MKP_KMAX + 2] = {}; std::vector<uint8_t> h_hemi_base; std::vector<uint32_t> h_hemi_pat[2];
+  mkp::DevBuf d_zin, d_zout, d_zblk, d_zstat; std::vector<uint8_t> h_inflated;   // mkp_bgzf_inflate
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -1,0 +1,52 @@
+"""Device BGZF inflate (mkp_bgzf_inflate -> mkp_inflate_blocks, one thread per block; SURVEY §8 f1 first stage) against Python's gzip
+on the reference's BAM fixtures and on generated BAMs; corrupt input must come back as an error."""
+import glob
+import gzip
+import os
+
+import pytest
+
+import modkit_amd
+from bamfuzz import Fuzz
+from pileup_cases import FIX
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = modkit_amd.Context()
+    yield c
+    c.close()
+
+
+def test_fixture_bams_inflate_like_gzip(ctx):
+    bams = sorted(glob.glob(os.path.join(FIX, "*.bam")))
+    assert len(bams) >= 8
+    for b in bams:
+        data = open(b, "rb").read()
+        got, ms = ctx.bgzf_inflate(data)
+        assert got == gzip.decompress(data), b
+        assert ms >= 0
+
+
+def test_generated_bam_and_empty_input(ctx, tmp_path):
+    bam, _, _ = Fuzz(77, contigs=(("c", 400000),), n_reads=4000, mean_len=3000, profile="hm_split", weird_rate=0.0).write(str(tmp_path / "big"))
+    data = open(bam, "rb").read()
+    got, ms = ctx.bgzf_inflate(data)
+    want = gzip.decompress(data)
+    assert got == want and len(want) > 20_000_000
+    assert ctx.bgzf_inflate(b"")[0] == b""
+
+
+def test_corrupt_blocks_are_refused(ctx):
+    data = bytearray(open(os.path.join(FIX, "bc_anchored_10_reads.sorted.bam"), "rb").read())
+    for at in (40, 200, 1500, 3000):   # payload bytes of the first block
+        bad = bytearray(data)
+        bad[at] ^= 0x5A
+        with pytest.raises(modkit_amd.MkpError):
+            ctx.bgzf_inflate(bytes(bad))
+    with pytest.raises(modkit_amd.MkpError):
+        ctx.bgzf_inflate(bytes(data[:len(data) // 2]))   # cut inside a block
+    with pytest.raises(modkit_amd.MkpError):
+        ctx.bgzf_inflate(b"not a bgzf file at all.." * 4)
