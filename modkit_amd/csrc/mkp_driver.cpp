@@ -389,6 +389,20 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (rc != MKP_OK) throw Error(rc, "no usable gfx950 device (libmkpileup has no CPU path)");
   struct Guard { mkp_ctx* c; ~Guard() { if (c) mkp_ctx_destroy(c); } } guard{ext_ctx ? nullptr : ctx};
   auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
+  // The interval grid and the focus bytes need the reference and the BED only: with one rank they are built on a second thread
+  // while the thresholds are being estimated (both are all-cores work in short bursts; neither waits for the other's results).
+  if (bf) records = bed_contigs(*bf, records, a.interval_size);
+  std::vector<std::vector<uint8_t>> focus_of(records.size()); std::vector<char> focus_done(records.size(), 0);
+  std::vector<std::vector<Interval>> grid_of(records.size()); std::vector<char> grid_done(records.size(), 0);
+  double focus_ms = 0;
+  std::future<void> early_walk;
+  if (fb.has_focus() && a.world == 1 && !a.plan_only && a.filter_threshold.empty() && !a.no_filtering)
+    early_walk = std::async(std::launch::async, [&]() {
+      auto t_focus = std::chrono::steady_clock::now();
+      for (size_t ri = 0; ri < records.size(); ri++) { grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1; }
+      focus_ms += ms_since(t_focus);
+    });
+  struct JoinWalk { std::future<void>* f; ~JoinWalk() { if (f->valid()) f->wait(); } } join_walk{&early_walk};   // (an exception below must not leave the walker running on dead locals)
   // thresholds (subcommand.rs:615-638)
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
   double thr_ms = 0;
@@ -409,7 +423,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     thr_ms = ms_since(t0);
   }
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
-  if (bf) records = bed_contigs(*bf, records, a.interval_size);
+  if (early_walk.valid()) early_walk.get();   // rethrows what the walk threw
   // --partition-tag: the output path is a directory with one bedMethyl per key, `[<prefix>_]<key>.bed` (PartitioningBedMethylWriter, writers.rs:1005-1082)
   const bool partitioned = !a.partition_tags.empty();
   std::map<std::string, std::unique_ptr<RowWriter>> key_writers;
@@ -440,18 +454,18 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
   // 2^27 positions per shard keeps the per-shard focus / slot buffers small
   struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */ };
-  std::vector<ShardPlan> plan; std::vector<std::vector<uint8_t>> focus_of(records.size()); std::vector<char> focus_done(records.size(), 0);
+  std::vector<ShardPlan> plan;
   const bool hf = fb.has_focus();
-  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, focus_ms = 0, fetch_wait_ms = 0;
+  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, fetch_wait_ms = 0;
   {
     const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid, records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
     for (size_t ri = 0; ri < records.size(); ri++) {
       const Contig& rec = records[ri];
       auto t_focus = std::chrono::steady_clock::now();
       // the grid; with one rank the focus bytes are filled in the same walk, otherwise only for the contigs this rank owns (below)
-      std::vector<Interval> ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr);
-      if (hf && a.world == 1) focus_done[ri] = 1;
-      focus_ms += ms_since(t_focus);
+      std::vector<Interval> ivs;
+      if (grid_done[ri]) ivs.swap(grid_of[ri]);
+      else { ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr); if (hf && a.world == 1) focus_done[ri] = 1; focus_ms += ms_since(t_focus); }
       size_t i0 = 0;
       while (i0 < ivs.size()) {
         size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
