@@ -257,6 +257,16 @@ int mkp_hemi_shard_run(mkp_ctx* ctx, int32_t partner_offset, const uint32_t* int
 int mkp_pileup_hemi_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 int mkp_pileup_hemi_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report);
 
+/* ---- `modkit sample-probs` (SampleModBaseProbs, src/commands.rs:549-887), the percentiles table: the reads the reference's schedule
+ * samples are decoded on the device (the sampling kernels of the threshold estimate); per canonical base the requested percentiles of
+ * their argmax probabilities come out of the HBM-resident sample exactly (Percentiles::new -> percentile_linear_interp,
+ * src/thresholds.rs:17-38).  argv = the subcommand's sampling flags (-n -f --no-sampling --region -i --include-bed --only-mapped
+ * --ignore --edge-filter --invert-edge-filter -t); values[b * n_percentiles + k] for bases A,C,G,T; has[b] = 0 when the sample holds
+ * no call on base b; n_values[b] = sampled calls on base b.  A base with fewer than two values fails with MKP_E_THRESHOLD, as the
+ * reference does.  (The histogram / plot outputs of the subcommand are outside this path.) */
+int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, const float* percentiles, uint32_t n_percentiles,
+                     float* values, uint8_t has[4], uint64_t n_values[4]);
+
 /* ---- BGZF inflate on the device: first stage of moving BAM ingest onto the GPU.  Not on the pileup path yet — the
  * driver still inflates on the host, where the step overlaps with packing; this entry point exists so that the kernel is tested and
  * measured on its own.  Stands in for what htslib does under rust-htslib's IndexedReader (src/pileup/mod.rs:732-743): BGZF blocks

@@ -62,6 +62,7 @@ def lib():
         L.mkp_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
         L.mkp_hemi_shard_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_void_p]
         u64p, f32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)
+        L.mkp_sample_probs.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), f32p, ctypes.c_uint32, f32p, ctypes.c_void_p, u64p]
         L.mkp_histogram_begin.argtypes = [ctypes.c_void_p]
         L.mkp_histogram_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
         L.mkp_histogram_get.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p]
@@ -77,7 +78,7 @@ EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
-           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate"]
+           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs"]
 
 
 def pileup(argv):
@@ -271,6 +272,19 @@ class Context:
         out = {f: (np.ctypeslib.as_array(getattr(rows, f), shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)) for f in HEMI_ROW_FIELDS}
         out["processed_records"], out["skipped_records"] = int(rows.processed_records), int(rows.skipped_records)
         return out
+
+    def sample_probs(self, bam, percentiles=(0.1, 0.5, 0.9), argv=()):
+        """`modkit sample-probs` percentiles (mkp_sample_probs): {base: {"n": sampled calls, "percentiles": {q: value}}}; values are f32."""
+        import numpy as np
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * max(1, len(args)))(*args)
+        qs = np.asarray(percentiles, dtype=np.float32)
+        vals = np.zeros((4, len(qs)), dtype=np.float32)
+        has = (ctypes.c_uint8 * 4)()
+        n = (ctypes.c_uint64 * 4)()
+        f32p = ctypes.POINTER(ctypes.c_float)
+        self._check(self.L.mkp_sample_probs(self.h, str(bam).encode(), len(args), arr, qs.ctypes.data_as(f32p), len(qs), vals.ctypes.data_as(f32p), has, n))
+        return {"ACGT"[b]: {"n": int(n[b]), "percentiles": {float(qs[k]): vals[b, k] for k in range(len(qs))}} for b in range(4) if has[b]}
 
     def bgzf_inflate(self, data):
         """mkp_bgzf_inflate: inflate a BGZF file image (bytes) on the device; returns (inflated bytes, kernel ms)."""

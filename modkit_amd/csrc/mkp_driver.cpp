@@ -297,13 +297,14 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
 }
 
 // per-base pass thresholds from the context's resident sample: two-level histogram -> the two order statistics -> interpolation
-void thresholds_from_sample(mkp_ctx* ctx, float q, float thr[4], uint8_t has[4], bool verbose) {
+void thresholds_from_sample(mkp_ctx* ctx, float q, float thr[4], uint8_t has[4], bool verbose, uint64_t* n_out = nullptr) {
   std::vector<uint64_t> h0(65536), h1(65536);
   for (uint32_t b = 0; b < 4; b++) {
     thr[b] = 0.f; has[b] = 0;
     int rc = mkp_histogram_get(ctx, b, 0, 0, h0.data()); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
     uint32_t bins[2]; uint64_t rk[2], n = 0;
     rc = mkp_histogram_locate(h0.data(), q, bins, rk, &n);
+    if (n_out) n_out[b] = n;
     if (n == 0) continue;   // no calls on this base
     if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(n));
     float y[2];
@@ -677,6 +678,42 @@ extern "C" int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int a
 // The sampling half alone, for multi-GPU runs: add this rank's share of the sample (argv carries --gpus-rank R --gpus-world W
 // next to the sampling flags; W > 1 needs -f 1.0) to the context's histograms.  The caller then sums mkp_histogram_get's arrays
 // over the ranks (RCCL all-reduce) and finishes with mkp_histogram_locate / _resolve / mkp_percentile_from_histogram.
+// `modkit sample-probs` (SampleModBaseProbs::run, src/commands.rs:680-887), the percentiles table: the schedule's sample, per canonical
+// base the requested percentiles of the argmax probabilities (Percentiles::new -> percentile_linear_interp).  The subcommand's own
+// flag names: -i is the sampling interval (default 1 000 000), unmapped reads are sampled unless --only-mapped (or --include-bed).
+extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, const float* percentiles, uint32_t n_percentiles,
+                                float* values /* [4][n_percentiles], bases A,C,G,T */, uint8_t has[4], uint64_t n_values[4]) {
+  if (!ctx || !bam_path || (!percentiles && n_percentiles) || !values || !has || !n_values) return MKP_E_INVALID;
+  try {
+    std::vector<std::string> tr; bool only_mapped = false, have_i = false;
+    for (int i = 0; i < argc; i++) {
+      const std::string s = argv[i];
+      if (s == "-i" || s == "--interval-size") { tr.push_back("--sampling-interval-size"); have_i = true; }
+      else if (s == "--no-sampling") { tr.push_back("-f"); tr.push_back("1.0"); }
+      else if (s == "--only-mapped") only_mapped = true;
+      else if (s == "--include-bed" || s == "--include-positions") { only_mapped = true; tr.push_back(s); }
+      else if (s == "-p" || s == "--percentiles" || s == "--filter-percentile") throw Error(MKP_E_INVALID, "percentiles are an argument of this call, not a flag");
+      else tr.push_back(s);
+    }
+    if (!have_i) { tr.push_back("--sampling-interval-size"); tr.push_back("1000000"); }
+    if (!only_mapped) tr.push_back("--include-unmapped");
+    std::vector<const char*> av; for (auto& x : tr) av.push_back(x.c_str());
+    int rc = mkp_histogram_begin(ctx); if (rc != MKP_OK) return rc;
+    sample_bam(ctx, bam_path, (int)av.size(), av.data(), nullptr);
+    for (int b = 0; b < 4; b++) { has[b] = 0; n_values[b] = 0; }
+    for (uint32_t k = 0; k < n_percentiles; k++) {
+      const float q = percentiles[k];
+      if (!(q >= 0.0f) || q > 1.0f) throw Error(MKP_E_INVALID, "percentiles must be in [0, 1]");
+      float thr[4]; uint8_t h[4]; uint64_t n[4] = {0, 0, 0, 0};
+      thresholds_from_sample(ctx, q, thr, h, false, n);
+      for (int b = 0; b < 4; b++) { values[(size_t)b * n_percentiles + k] = thr[b]; has[b] = h[b]; n_values[b] = n[b]; }
+    }
+    if (n_percentiles == 0) { float thr[4]; uint64_t n[4] = {0, 0, 0, 0}; try { thresholds_from_sample(ctx, 0.5f, thr, has, false, n); } catch (const Error&) {} for (int b = 0; b < 4; b++) n_values[b] = n[b]; }
+    return MKP_OK;
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
+}
+
 extern "C" int mkp_histogram_add_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv) {
   if (!ctx || !bam_path) return MKP_E_INVALID;
   try { sample_bam(ctx, bam_path, argc, argv, nullptr); return MKP_OK; }

@@ -328,6 +328,7 @@ struct Options {
   bool invert_edge = false, mixed_delim = false, with_header = false;
   size_t workers = 1;  // oracle-only: interval-parallel std::thread workers for the CPU baseline
   bool hemi = false;   // `pileup-hemi` (DuplexModBamPileup, src/pileup/subcommand.rs:827-1514)
+  bool sample_probs_cmd = false; std::string percentiles = "0.1,0.5,0.9";   // `sample-probs` (SampleModBaseProbs, src/commands.rs:549-887): the percentiles table only
 };
 
 struct Region { std::string name; uint32_t start, end; };
@@ -680,19 +681,55 @@ static int run_pileup(const Options& o) {
   return 0;
 }
 
+// `modkit sample-probs` (src/commands.rs:680-887), the percentile table: sample as the schedule says, per canonical base sort the argmax
+// probabilities and interpolate (Percentiles::new -> percentile_linear_interp, src/thresholds.rs:17-38).  One line per (base, percentile):
+// base, percentile, value (%.9g), number of values.  The reference prints through prettytable / f32 Display; the numbers are what is pinned.
+static int run_sample_probs(const Options& o) {
+  BamFile bam = read_bam(o.in_bam);
+  Region region; const bool have_region = !o.region.empty();
+  if (have_region) region = parse_region(o.region, bam);
+  EdgeFilter edge;
+  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
+  CollapseMethod collapse;
+  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true; collapse.code = mc; }
+  std::vector<ReferenceRecord> reference_records = get_targets(bam, have_region ? &region : nullptr);
+  PositionFilter pf_store; const PositionFilter* pf = nullptr;
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
+  auto per_base = sample_probs(bam, o, have_region ? &region : nullptr, collapse, edge, pf);
+  std::vector<float> qs; { size_t a = 0; while (a <= o.percentiles.size()) { size_t c = o.percentiles.find(',', a); if (c == std::string::npos) c = o.percentiles.size(); if (c > a) qs.push_back(strtof(o.percentiles.substr(a, c - a).c_str(), nullptr)); a = c + 1; } }
+  FILE* out = (o.out_bed.empty() || o.out_bed == "-") ? stdout : fopen(o.out_bed.c_str(), "w");
+  if (!out) throw MkErr("failed to make output file");
+  for (auto& kv : per_base) {
+    std::sort(kv.second.begin(), kv.second.end());
+    for (float q : qs) fprintf(out, "%c\t%.9g\t%.9g\t%zu\n", base_char(kv.first), (double)q, (double)percentile_linear_interp(kv.second, q), kv.second.size());
+  }
+  if (out != stdout) fclose(out);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi")) {
-    fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n");
+  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs")) {
+    fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n"
+                    "       modkit_oracle sample-probs <in.bam> [-o table.tsv] [-p 0.1,0.5,0.9] [sampling flags of `modkit sample-probs`]\n");
     return 2;
   }
   Options o; std::vector<std::string> pos;
   o.hemi = std::string(argv[1]) == "pileup-hemi";
+  o.sample_probs_cmd = std::string(argv[1]) == "sample-probs";
+  if (o.sample_probs_cmd) { o.include_unmapped = true; o.sampling_interval_size = 1000000; }   // --only-mapped is off by default; -i is the sampling interval
   try {
     for (int i = 2; i < argc; i++) {
       std::string a = argv[i];
       auto val = [&]() { if (i + 1 >= argc) throw MkErr("missing value for " + a); return std::string(argv[++i]); };
       if (o.hemi && (a == "--preset" || a == "--combine-strands" || a == "--with-header" || a == "--header")) throw MkErr("unknown flag " + a + " for pileup-hemi");
       if (o.hemi && (a == "-o" || a == "--out-bed")) { o.out_bed = val(); continue; }
+      if (o.sample_probs_cmd) {
+        if (a == "-o") { o.out_bed = val(); continue; }
+        if (a == "-p" || a == "--percentiles") { o.percentiles = val(); continue; }
+        if (a == "-i" || a == "--interval-size") { o.sampling_interval_size = (uint32_t)std::stoul(val()); continue; }
+        if (a == "--only-mapped") { o.include_unmapped = false; continue; }
+        if (a == "--no-sampling") { o.have_frac = true; o.sampling_frac = 1.0; continue; }
+      }
       if (a == "--region") o.region = val(); else if (a == "--max-depth") o.max_depth = (uint32_t)std::stoul(val());
       else if (a == "-t" || a == "--threads") o.threads = std::stoul(val()); else if (a == "-i" || a == "--interval-size") o.interval_size = (uint32_t)std::stoul(val());
       else if (a == "--chunk-size") { o.have_chunk = true; o.chunk_size = std::stoul(val()); }
@@ -712,6 +749,7 @@ int main(int argc, char** argv) {
       else if (!a.empty() && a[0] == '-' && a != "-") throw MkErr("unknown flag " + a);
       else pos.push_back(a);
     }
+    if (o.sample_probs_cmd) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; if (!o.include_bed.empty()) o.include_unmapped = false; return run_sample_probs(o); }
     if (o.hemi) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; }
     else { if (pos.size() != 2) throw MkErr("need <in.bam> <out.bed>"); o.in_bam = pos[0]; o.out_bed = pos[1]; }
     return run_pileup(o);
