@@ -267,6 +267,25 @@ int mkp_pileup_hemi_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run
 int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, const float* percentiles, uint32_t n_percentiles,
                      float* values, uint8_t has[4], uint64_t n_values[4]);
 
+/* ---- `modkit summary` (ModSummarize, src/commands.rs:888-1189 -> summarize_modbam / sampled_reads_to_summary, src/summarize.rs:59-262):
+ * ModSummary as counts.  The sampled reads are decoded twice by the sampling kernels: once to estimate the pass thresholds (skipped with
+ * --no-filtering / --filter-threshold), once to count every sampled call under its thresholded call — or, when that is Filtered, under
+ * its argmax call.  argv = the subcommand's flags (-n -f --no-sampling --region -i --include-bed --only-mapped --ignore --edge-filter
+ * --invert-edge-filter -p --no-filtering --filter-threshold --mod-thresholds -t).  Rows: for every canonical base with sampled calls
+ * the canonical state (code_repr = MKP_HEMI_CANONICAL) then every observed mod code in code order; arrays owned by the ctx until its
+ * next summary call.  (The table / TSV writers iterate std HashMaps and print through f32 Display: they stay in Rust.) */
+typedef struct {
+  uint64_t total_reads_used;
+  uint64_t reads_with_mod_calls[4];     /* per canonical base A,C,G,T */
+  float threshold[4]; uint8_t has_threshold[4];
+  uint32_t n_rows;
+  const uint8_t* base;                  /* 0..3 */
+  const uint32_t* code_repr;
+  const uint64_t* pass_count;           /* mod_call_counts */
+  const uint64_t* fail_count;           /* filtered_mod_call_counts */
+} mkp_summary_out;
+int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, mkp_summary_out* out);
+
 /* ---- BGZF inflate on the device: first stage of moving BAM ingest onto the GPU.  Not on the pileup path yet — the
  * driver still inflates on the host, where the step overlaps with packing; this entry point exists so that the kernel is tested and
  * measured on its own.  Stands in for what htslib does under rust-htslib's IndexedReader (src/pileup/mod.rs:732-743): BGZF blocks

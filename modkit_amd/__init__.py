@@ -59,6 +59,7 @@ def lib():
         L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         L.mkp_pileup_hemi_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
         L.mkp_pileup_hemi_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+        L.mkp_summary.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         L.mkp_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
         L.mkp_hemi_shard_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_void_p]
         u64p, f32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_float)
@@ -78,7 +79,7 @@ EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
-           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs"]
+           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs", "mkp_summary"]
 
 
 def pileup(argv):
@@ -151,6 +152,13 @@ class HemiRows(ctypes.Structure):
 
 HEMI_ROW_FIELDS = ("pos", "primary_base", "pattern_pos", "pattern_neg", "n_valid", "count", "n_canonical", "n_other_pattern", "n_delete",
                    "n_fail", "n_diff", "n_nocall")
+
+
+class SummaryOut(ctypes.Structure):
+    """mkp_summary_out: ModSummary (src/summarize.rs:21-46) as counts."""
+    _fields_ = [("total_reads_used", ctypes.c_uint64), ("reads_with_mod_calls", ctypes.c_uint64 * 4), ("threshold", ctypes.c_float * 4),
+                ("has_threshold", ctypes.c_uint8 * 4), ("n_rows", ctypes.c_uint32), ("base", ctypes.POINTER(ctypes.c_uint8)),
+                ("code_repr", ctypes.POINTER(ctypes.c_uint32)), ("pass_count", ctypes.POINTER(ctypes.c_uint64)), ("fail_count", ctypes.POINTER(ctypes.c_uint64))]
 
 
 class Stats(ctypes.Structure):
@@ -285,6 +293,19 @@ class Context:
         f32p = ctypes.POINTER(ctypes.c_float)
         self._check(self.L.mkp_sample_probs(self.h, str(bam).encode(), len(args), arr, qs.ctypes.data_as(f32p), len(qs), vals.ctypes.data_as(f32p), has, n))
         return {"ACGT"[b]: {"n": int(n[b]), "percentiles": {float(qs[k]): vals[b, k] for k in range(len(qs))}} for b in range(4) if has[b]}
+
+    def summary(self, bam, argv=()):
+        """`modkit summary` as counts (mkp_summary): {"total", "reads_with": {base: n}, "threshold": {base: f32}, "rows": {(base, code): (pass, fail)}};
+        code "-" = canonical, a letter, or a ChEBI number as text."""
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * max(1, len(args)))(*args)
+        o = SummaryOut()
+        self._check(self.L.mkp_summary(self.h, str(bam).encode(), len(args), arr, ctypes.byref(o)))
+        def code(c):
+            return "-" if c == 0 else str(c & 0x7fffffff) if c & 0x80000000 else chr(c)
+        return {"total": int(o.total_reads_used), "reads_with": {"ACGT"[b]: int(o.reads_with_mod_calls[b]) for b in range(4) if o.reads_with_mod_calls[b]},
+                "threshold": {"ACGT"[b]: float(o.threshold[b]) for b in range(4) if o.has_threshold[b]},
+                "rows": {("ACGT"[o.base[i]], code(o.code_repr[i])): (int(o.pass_count[i]), int(o.fail_count[i])) for i in range(o.n_rows)}}
 
     def bgzf_inflate(self, data):
         """mkp_bgzf_inflate: inflate a BGZF file image (bytes) on the device; returns (inflated bytes, kernel ms)."""

@@ -443,7 +443,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -666,6 +666,7 @@ int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_o
 extern "C" {
 hipError_t mkp_launch_sample_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const float*, const MkpEvent*, uint32_t*, unsigned long long, unsigned long long*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_sample_hist1(hipStream_t, const uint32_t*, unsigned long long, uint32_t, uint32_t, uint32_t*);
+hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const MkpEvent*, unsigned long long*, unsigned long long*);
 }
 
 // Decode `recs` in sampling mode.  n_vals[i] = number of argmax probabilities record i yields after the filters (0: rejected or
@@ -679,7 +680,7 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     c->tables.build(c->packer.layouts, c->caller);
     MkpRunParams P; memset(&P, 0, sizeof(P));
     P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
-    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = 1; P.only_mapped = only_mapped; P.has_focus = bedmask != nullptr;
+    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->summary_mode ? 2 : 1; P.only_mapped = only_mapped; P.has_focus = bedmask != nullptr;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
     upload(c->d_layouts, c->tables.dev);
@@ -704,6 +705,23 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
 }
 
 // Add the values of the marked records of the last mkp_internal_sample batch to the resident sample and its level-0 histogram.
+int mkp_internal_summary_begin(mkp_ctx* c) {
+  if (!c) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    c->d_summary.ensure(134 * 8);
+    hip_check(hipMemsetAsync(c->d_summary.p, 0, 134 * 8, c->stream), "memset");
+    hip_check(hipStreamSynchronize(c->stream), "sync");
+  });
+}
+int mkp_internal_summary_get(mkp_ctx* c, uint64_t out[134], std::vector<MkpSlot>* slots) {
+  if (!c || !out || !slots) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!c->d_summary.p) throw Error(MKP_E_INVALID, "internal: summary table not set up");
+    hip_check(hipMemcpy(out, c->d_summary.p, 134 * 8, hipMemcpyDeviceToHost), "D2H");
+    *slots = c->tables.st.slots;   // class 2 + s = Modified(slots[s].code_repr) on primary base slots[s].pb
+  });
+}
 int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
   if (!c) return MKP_E_INVALID;
   return guarded(c, [&]() {
@@ -712,6 +730,15 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
     uint64_t add = 0; for (size_t i = 0; i < n; i++) if (take[i] && c->sample_ro[i].ok) add += c->sample_ro[i].n_events;
     if (!add) return;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
+    if (c->summary_mode) {   // `modkit summary`: count the taken reads' calls
+      if (!c->d_summary.p) throw Error(MKP_E_INVALID, "internal: summary table not set up");
+      c->d_take.ensure(std::max<size_t>(n, 16));
+      hip_check(hipMemcpyAsync(c->d_take.p, take.data(), n, hipMemcpyHostToDevice, c->stream), "H2D");
+      hip_check(mkp_launch_summary_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n, c->d_events.as<MkpEvent>(),
+                                              c->d_summary.as<unsigned long long>(), c->d_summary.as<unsigned long long>() + 128), "summary accumulate launch");
+      hip_check(hipStreamSynchronize(c->stream), "summary accumulate sync");
+      return;
+    }
     if (!c->d_hist0.p) { c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16); hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset"); hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
     const uint64_t need = c->sample_n + add;
     if (need * 4 > c->d_store.cap) {   // grow the resident sample, keeping what is there

@@ -640,7 +640,7 @@ extern "C" int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, m
 // (-n -f -p -t --sampling-interval-size --region --sample-region --include-bed --include-unmapped --edge-filter --ignore --preset).
 namespace {
 // the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
-void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out) {
+void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out, const mkp_caller* thresholds = nullptr) {
   Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
   std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())), !a.no_index);   // inflate threads: --threads only steers the sampling schedule
   const BamSource& bam = *src;
@@ -655,6 +655,8 @@ void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
   std::vector<Contig> records = targets(bam, hr ? &region : nullptr);
   BedFilter bed_store; const BedFilter* bf = nullptr;
   if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
+  if (thresholds) { kc.default_threshold = thresholds->default_threshold; kc.per_mod = thresholds->per_mod; kc.n_per_mod = thresholds->n_per_mod;
+                    for (int b = 0; b < 4; b++) { kc.per_base_threshold[b] = thresholds->per_base_threshold[b]; kc.has_per_base[b] = thresholds->has_per_base[b]; } }
   int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
   sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
   if (q_out) *q_out = a.filter_percentile;
@@ -709,6 +711,63 @@ extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, co
       for (int b = 0; b < 4; b++) { values[(size_t)b * n_percentiles + k] = thr[b]; has[b] = h[b]; n_values[b] = n[b]; }
     }
     if (n_percentiles == 0) { float thr[4]; uint64_t n[4] = {0, 0, 0, 0}; try { thresholds_from_sample(ctx, 0.5f, thr, has, false, n); } catch (const Error&) {} for (int b = 0; b < 4; b++) n_values[b] = n[b]; }
+    return MKP_OK;
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
+}
+
+// `modkit summary` (ModSummarize::run, src/commands.rs:1035-1189): ModSummary as counts.  Two walks of the same sampling schedule on the
+// device: the first estimates the pass thresholds (calc_thresholds_per_base) unless the flags give them, the second counts every sampled
+// call under its thresholded call, or under its argmax call when that is Filtered (sampled_reads_to_summary, src/summarize.rs:117-262).
+extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, mkp_summary_out* out) {
+  if (!ctx || !bam_path || !out) return MKP_E_INVALID;
+  struct ModeGuard { mkp_ctx* c; ~ModeGuard() { c->summary_mode = false; } } guard{ctx};
+  try {
+    std::vector<std::string> tr; bool only_mapped = false, have_i = false;
+    for (int i = 0; i < argc; i++) {
+      const std::string s = argv[i];
+      if (s == "-i" || s == "--interval-size") { tr.push_back("--sampling-interval-size"); have_i = true; }
+      else if (s == "--no-sampling") { tr.push_back("-f"); tr.push_back("1.0"); }
+      else if (s == "--only-mapped") only_mapped = true;
+      else if (s == "--include-bed" || s == "--include-positions") { only_mapped = true; tr.push_back(s); }
+      else if (s == "--tsv" || s == "--table") {}
+      else tr.push_back(s);
+    }
+    if (!have_i) { tr.push_back("--sampling-interval-size"); tr.push_back("1000000"); }
+    if (!only_mapped) tr.push_back("--include-unmapped");
+    std::vector<const char*> av; for (auto& x : tr) av.push_back(x.c_str());
+    Args a; parse_args((int)av.size(), av.data(), &a, false);
+    mkp_caller kt; memset(&kt, 0, sizeof(kt));
+    std::vector<mkp_mod_threshold> per_mod;
+    for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code; if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID, "encountered illegal per-mod threshold: " + raw); per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
+    if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kt); kt.per_mod = per_mod.data(); kt.n_per_mod = (uint32_t)per_mod.size(); }
+    else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
+    else {
+      int rc = mkp_histogram_begin(ctx); if (rc != MKP_OK) return rc;
+      float q = 0.1f; sample_bam(ctx, bam_path, (int)av.size(), av.data(), &q);
+      float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, q, thr, has, false);
+      for (int b = 0; b < 4; b++) if (has[b]) { kt.has_per_base[b] = 1; kt.per_base_threshold[b] = thr[b]; }
+      kt.per_mod = per_mod.data(); kt.n_per_mod = (uint32_t)per_mod.size();
+    }
+    ctx->summary_mode = true;
+    int rc = mkp_internal_summary_begin(ctx); if (rc != MKP_OK) return rc;
+    sample_bam(ctx, bam_path, (int)av.size(), av.data(), nullptr, &kt);
+    uint64_t t[134]; std::vector<MkpSlot> slots;
+    rc = mkp_internal_summary_get(ctx, t, &slots); if (rc != MKP_OK) return rc;
+    ctx->h_sum_base.clear(); ctx->h_sum_code.clear(); ctx->h_sum_pass.clear(); ctx->h_sum_fail.clear();
+    const uint64_t obs = t[128 + 5];
+    for (uint32_t b = 0; b < 4; b++) {
+      out->reads_with_mod_calls[b] = t[128 + b]; out->threshold[b] = kt.per_base_threshold[b]; out->has_threshold[b] = kt.has_per_base[b];
+      if (!t[128 + b]) continue;
+      auto row = [&](uint32_t code, uint32_t cls) { ctx->h_sum_base.push_back((uint8_t)b); ctx->h_sum_code.push_back(code); ctx->h_sum_pass.push_back(t[b * 32 + cls]); ctx->h_sum_fail.push_back(t[b * 32 + 16 + cls]); };
+      row(MKP_HEMI_CANONICAL, 1);
+      std::vector<std::pair<uint32_t, uint32_t>> codes;
+      for (size_t si = 0; si < slots.size() && si < 14; si++) if (slots[si].pb == b && ((obs >> si) & 1ull)) codes.push_back({slots[si].code_repr, (uint32_t)si});
+      std::sort(codes.begin(), codes.end());
+      for (auto& cs : codes) row(cs.first, 2 + cs.second);
+    }
+    out->total_reads_used = t[128 + 4];
+    out->n_rows = (uint32_t)ctx->h_sum_base.size(); out->base = ctx->h_sum_base.data(); out->code_repr = ctx->h_sum_code.data(); out->pass_count = ctx->h_sum_pass.data(); out->fail_count = ctx->h_sum_fail.data();
     return MKP_OK;
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }

@@ -176,6 +176,30 @@ __device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, F
   return (have && best > can) ? best : can;
 }
 
+// `modkit summary` (sampled_reads_to_summary, src/summarize.rs:117-262): per sampled call the thresholded call and the argmax call.
+// Returns the sample "event" info: [0:1] canonical base, [4:7] thresholded class, [8:11] argmax class; class 0 = Filtered,
+// 1 = Canonical, 2 + s = Modified(code of global slot s).  *obs gets the slots of the codes in the map (observed_mods).
+__device__ __forceinline__ uint32_t summary_info(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX) {
+  if (collapse) collapse_redistribute(g, pv, pk, kmax);
+  const int n_post = (int)((pv >> 3) & 7u);
+  float s = 0.0f, best = 0.0f; bool have = false; int bk = 0;
+#pragma unroll
+  for (int i = 0; i < MKP_KMAX; i++) {   // argmax_base_mod_call (mod_bam.rs:489-505): max_by keeps the last maximum
+    if (i >= kmax) break;
+    const bool valid = i < n_post;
+    const int kq = (int)((pv >> (16 + 2 * i)) & 3u);
+    const float p = getk(pk, kq);
+    s = valid ? s + p : s;
+    const bool take = valid && (!have || !(p < best));
+    best = take ? p : best; bk = take ? kq : bk; have = have || valid;
+  }
+  const float can = 1.0f - s;
+  const uint32_t arg_cls = (have && best > can) ? 2u + ((g.slots >> (8 * bk)) & 0xffu) : 1u;
+  const int cls = call_group(g, pv, pk, false, obs, kmax);   // on the collapsed map
+  const uint32_t thr_cls = cls < 2 ? (uint32_t)cls : 2u + ((g.slots >> (8 * (cls - 2))) & 0xffu);
+  return MKP_G_TB(g.misc) | (thr_cls << 4) | (arg_cls << 8);
+}
+
 // Per (mod strand) BaseModProbs under construction at one read position.
 struct GState { F4 pk; uint32_t H, setmask; };
 
@@ -518,6 +542,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
             if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
             if (!keep) continue;
             any_surviving = true;
+            if (prm.sample_mode == 2) { uint32_t ob = 0; sv[ev_cnt] = 0.f; ev_info[ev_cnt++] = summary_info(gr, pv, spk, collapse, &ob); obs0 |= ob; continue; }
             sv[ev_cnt] = argmax_group(gr, pv, spk, collapse);
             ev_info[ev_cnt++] = MKP_G_TB(gr.misc);
             continue;
@@ -848,7 +873,8 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
+          if (keep && prm.sample_mode == 2) { any_surviving = true; uint32_t ob = 0; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0); obs0 |= ob; has_ev = true; }
+          else if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
         } else {
           any_surviving = true;
           uint32_t ob = 0;
@@ -1197,7 +1223,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
+          if (keep && prm.sample_mode == 2) { any_surviving = true; uint32_t ob = 0; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0); obs0 |= ob; has_ev = true; }
+          else if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
         } else {
           any_surviving = true;
           uint32_t ob = 0;
@@ -2227,6 +2254,49 @@ mkp_sample_hist1(const uint32_t* __restrict__ store, unsigned long long n, uint3
     const uint32_t key = store[i];
     if ((key >> 16) == want) atomicAdd(&hist1[key & 0xffffu], 1u);
   }
+}
+
+// `modkit summary`: counts of the sampled calls of the reads the schedule took.  table[base][0 pass | 1 filtered][class] (class as in
+// summary_info; filtered calls are counted under their argmax class), reads_with[base] = taken reads with a call on that base,
+// reads_with[4] = taken reads with any call, reads_with[5] = OR of the reads' observed-code slot masks.
+extern "C" __global__ void __launch_bounds__(256)
+mkp_summary_accumulate(const MkpReadHdr* __restrict__ hdrs, const MkpReadOut* __restrict__ readout, const uint8_t* __restrict__ take, uint32_t n_reads,
+                       const MkpEvent* __restrict__ events, unsigned long long* __restrict__ table /*[4][2][16]*/, unsigned long long* __restrict__ reads_with /*[6]*/) {
+  __shared__ uint32_t lt[128];
+  __shared__ uint32_t lr[6];
+  for (uint32_t k = threadIdx.x; k < 128; k += 256) lt[k] = 0;
+  if (threadIdx.x < 6) lr[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+  for (uint32_t r = wave; r < n_reads; r += n_waves) {
+    if (!take[r]) continue;
+    const MkpReadOut ro = readout[r];
+    if (!ro.ok || !ro.n_events) continue;
+    const uint32_t e0 = hdrs[r].event_off;
+    uint32_t bases = 0;
+    for (uint32_t k0 = 0; k0 < ro.n_events; k0 += 64) {
+      const uint32_t k = k0 + (uint32_t)lane;
+      if (k < ro.n_events) {
+        const uint32_t info = events[e0 + k].info, tb = info & 3u, thr = (info >> 4) & 15u, arg = (info >> 8) & 15u;
+        atomicAdd(&lt[tb * 32u + (thr ? thr : 16u + arg)], 1u);
+        bases |= 1u << tb;
+      }
+    }
+    bases = wave_or(bases);
+    if (lane == 0) { for (uint32_t b = 0; b < 4; b++) if (bases & (1u << b)) atomicAdd(&lr[b], 1u); atomicAdd(&lr[4], 1u); atomicOr(&lr[5], ro.obs[0] | ro.obs[1]); }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < 128; k += 256) if (lt[k]) atomicAdd(&table[k], (unsigned long long)lt[k]);
+  if (threadIdx.x < 5 && lr[threadIdx.x]) atomicAdd(&reads_with[threadIdx.x], (unsigned long long)lr[threadIdx.x]);
+  if (threadIdx.x == 5 && lr[5]) atomicOr(&reads_with[5], (unsigned long long)lr[5]);
+}
+extern "C" hipError_t mkp_launch_summary_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take, uint32_t n_reads, const MkpEvent* events,
+                                                    unsigned long long* table, unsigned long long* reads_with) {
+  if (!n_reads) return hipSuccess;
+  const uint32_t grid = std::min<uint32_t>((n_reads + 3u) / 4u, 1024u);
+  hipLaunchKernelGGL(mkp_summary_accumulate, dim3(grid), dim3(256), 0, st, hdrs, readout, take, n_reads, events, table, reads_with);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t mkp_launch_sample_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take, uint32_t n_reads, const float* vals,

@@ -412,11 +412,14 @@ struct SamplingSchedule {  // sampling_schedule.rs:73-76
 // ReadIdsToBaseModProbs (read_ids_to_base_mod_probs.rs:39-363): read id -> base -> argmax probabilities
 struct SampledProbs {
   std::map<std::string, std::map<int, std::vector<float>>> inner;
-  void merge(SampledProbs&& o) { for (auto& kv : o.inner) if (!inner.count(kv.first)) inner.emplace(kv.first, std::move(kv.second)); }  // op_mut 205-213
+  std::map<std::string, std::map<int, std::vector<BaseModProbs>>> calls;   // `summary` only: the sampled maps themselves
+  void merge(SampledProbs&& o) {  // op_mut 205-213: the first occurrence of a read id wins
+    for (auto& kv : o.inner) if (!inner.count(kv.first)) { auto c = o.calls.find(kv.first); if (c != o.calls.end()) calls.emplace(kv.first, std::move(c->second)); inner.emplace(kv.first, std::move(kv.second)); }
+  }
   size_t len() const { return inner.size(); }
 };
 
-struct SampleCtx { const BamFile* bam; const CollapseMethod* collapse; const EdgeFilter* edge; const PositionFilter* pf; bool only_mapped; };
+struct SampleCtx { const BamFile* bam; const CollapseMethod* collapse; const EdgeFilter* edge; const PositionFilter* pf; bool only_mapped; bool keep_calls = false; };
 
 // process_records (223-362) over an iterator of records; limit: -1 = passthrough, else first-N
 static SampledProbs process_records(const std::vector<const BamRecord*>& recs, long limit, const SampleCtx& cx) {
@@ -443,17 +446,18 @@ static SampledProbs process_records(const std::vector<const BamRecord*>& recs, l
       int canonical_base = s ? complement(kv.first) : kv.first;
       // filter_positions (966-1070)
       if (cx.edge->active && !cx.edge->read_can_be_trimmed((size_t)r.l_seq)) continue;
-      std::vector<float> vals;
+      std::vector<float> vals; std::vector<BaseModProbs> kept;
       for (auto& pp : kv.second.pos) {
         bool keep = !cx.edge->active || cx.edge->keep_position(pp.first, (size_t)r.l_seq);
         if (cx.only_mapped && !pairs.count(pp.first)) keep = false;
         if (cx.pf) { auto ap = pairs.find(pp.first); bool ref_neg = (s == 1) != r.is_reverse(); if (ap == pairs.end() || !cx.pf->contains(r.tid, ap->second, ref_neg)) keep = false; }
         if (!keep) continue;
-        if (cx.collapse->active) vals.push_back(collapse_redistribute(pp.second, cx.collapse->code).argmax_value());
-        else vals.push_back(pp.second.argmax_value());
+        if (cx.collapse->active) { BaseModProbs c2 = collapse_redistribute(pp.second, cx.collapse->code); vals.push_back(c2.argmax_value()); if (cx.keep_calls) kept.push_back(c2); }
+        else { vals.push_back(pp.second.argmax_value()); if (cx.keep_calls) kept.push_back(pp.second); }
       }
       if (vals.empty()) continue;
       auto& dst = out.inner[r.qname][canonical_base]; dst.insert(dst.end(), vals.begin(), vals.end());
+      if (cx.keep_calls) { auto& dc = out.calls[r.qname][canonical_base]; dc.insert(dc.end(), kept.begin(), kept.end()); }
       added = true;
     }
     if (added) used++;
@@ -467,8 +471,8 @@ static std::vector<const BamRecord*> fetch(const BamFile& bam, uint32_t tid, uin
 }
 
 // get_sampled_read_ids_to_base_mod_probs + sample_reads_base_mod_calls_over_regions (reads_sampler/mod.rs:30-257)
-static std::map<int, std::vector<float>> sample_probs(const BamFile& bam, const Options& o, const Region* region, const CollapseMethod& collapse,
-                                                      const EdgeFilter& edge, const PositionFilter* pf) {
+static SampledProbs sample_reads(const BamFile& bam, const Options& o, const Region* region, const CollapseMethod& collapse,
+                                 const EdgeFilter& edge, const PositionFilter* pf, bool keep_calls) {
   bool only_mapped = !o.include_unmapped;
   IdxStats st = IdxStats::make(bam, region, pf);
   SamplingSchedule sched = o.have_frac ? SamplingSchedule::from_sample_frac(st, (float)o.sampling_frac, !only_mapped)
@@ -476,7 +480,7 @@ static std::map<int, std::vector<float>> sample_probs(const BamFile& bam, const 
   size_t batch_size = (size_t)floorf((float)o.threads * 1.5f);
   std::vector<ReferenceRecord> contigs; for (auto& r : get_targets(bam, region)) if (sched.counts.count(r.tid)) contigs.push_back(r);
   std::map<uint32_t, uint32_t> contig_sizes; for (auto& r : contigs) contig_sizes[r.tid] = r.length;
-  SampleCtx cx{&bam, &collapse, &edge, pf, only_mapped};
+  SampleCtx cx{&bam, &collapse, &edge, pf, only_mapped, keep_calls};
   SampledProbs agg; std::map<uint32_t, size_t> sampled_per_chr;
   if (!contigs.empty()) {
     Feeder feeder(contigs, batch_size, o.sampling_interval_size, false, nullptr, nullptr);
@@ -539,9 +543,16 @@ static std::map<int, std::vector<float>> sample_probs(const BamFile& bam, const 
     else { if (!un.empty()) throw MkErr("unmapped-read sampling with --sampling-frac < 1 uses rand::StdRng: parity unpinned, unsupported"); limit = -1; }
     agg.merge(process_records(un, limit, cx));
   }
-  std::map<int, std::vector<float>> per_base;  // mle_probs_per_base 67-101
+  return agg;
+}
+static std::map<int, std::vector<float>> flatten_probs(const SampledProbs& agg) {  // mle_probs_per_base 67-101
+  std::map<int, std::vector<float>> per_base;
   for (auto& kv : agg.inner) for (auto& bv : kv.second) { auto& d = per_base[bv.first]; d.insert(d.end(), bv.second.begin(), bv.second.end()); }
   return per_base;
+}
+static std::map<int, std::vector<float>> sample_probs(const BamFile& bam, const Options& o, const Region* region, const CollapseMethod& collapse,
+                                                      const EdgeFilter& edge, const PositionFilter* pf) {
+  return flatten_probs(sample_reads(bam, o, region, collapse, edge, pf, false));
 }
 
 // parse_thresholds / parse_per_base_thresholds (command_utils.rs:47-206)
@@ -707,15 +718,63 @@ static int run_sample_probs(const Options& o) {
   return 0;
 }
 
+// `modkit summary` (ModSummarize::run, src/commands.rs:1035-1189; summarize_modbam / sampled_reads_to_summary, src/summarize.rs:59-262) as
+// counts.  Lines: `total_reads_used N`, `reads_with B N`, `threshold B %.9g`, then `row B code pass fail` per base: canonical ("-") then
+// the observed codes in code order.  (The reference's writers iterate std HashMaps and print f32 through Display: not restated.)
+static int run_summary(const Options& o) {
+  BamFile bam = read_bam(o.in_bam);
+  Region region; const bool have_region = !o.region.empty();
+  if (have_region) region = parse_region(o.region, bam);
+  EdgeFilter edge;
+  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
+  CollapseMethod collapse;
+  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true; collapse.code = mc; }
+  std::map<ModCode, float> per_mod;
+  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc; if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code"); per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
+  std::vector<ReferenceRecord> reference_records = get_targets(bam, have_region ? &region : nullptr);
+  PositionFilter pf_store; const PositionFilter* pf = nullptr;
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
+  SampledProbs agg = sample_reads(bam, o, have_region ? &region : nullptr, collapse, edge, pf, true);
+  ThresholdCaller caller;
+  if (!o.filter_threshold.empty()) { caller.per_mod = per_mod; parse_thresholds(o.filter_threshold, &caller); }
+  else if (o.no_filtering) {}
+  else { caller.per_mod = per_mod; auto per_base = flatten_probs(agg); for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); } }
+  std::map<int, uint64_t> reads_with; std::map<int, std::map<ModCode, uint64_t>> pass, fail; std::map<int, std::set<ModCode>> observed;   // code 0 = canonical
+  for (auto& rk : agg.calls) for (auto& bk : rk.second) {
+    const int base = bk.first; reads_with[base]++;
+    for (const BaseModProbs& bmp : bk.second) {
+      const BaseModCall am = argmax_call(bmp), th = caller.call(base, bmp);
+      bmp.probs.for_each([&](ModCode c, float) { observed[base].insert(c); });
+      if (th.kind == BaseModCall::CANONICAL) pass[base][0]++; else if (th.kind == BaseModCall::MODIFIED) pass[base][th.code]++;
+      else if (am.kind == BaseModCall::CANONICAL) fail[base][0]++; else fail[base][am.code]++;
+    }
+  }
+  FILE* out = (o.out_bed.empty() || o.out_bed == "-") ? stdout : fopen(o.out_bed.c_str(), "w");
+  if (!out) throw MkErr("failed to make output file");
+  fprintf(out, "total_reads_used\t%zu\n", agg.inner.size());
+  for (auto& kv : reads_with) fprintf(out, "reads_with\t%c\t%llu\n", base_char(kv.first), (unsigned long long)kv.second);
+  for (auto& kv : caller.per_base) fprintf(out, "threshold\t%c\t%.9g\n", base_char(kv.first), (double)kv.second);
+  for (auto& kv : reads_with) {
+    const int b = kv.first;
+    std::vector<ModCode> codes(observed[b].begin(), observed[b].end()); std::sort(codes.begin(), codes.end());
+    fprintf(out, "row\t%c\t-\t%llu\t%llu\n", base_char(b), (unsigned long long)pass[b][0], (unsigned long long)fail[b][0]);
+    for (ModCode c : codes) fprintf(out, "row\t%c\t%s\t%llu\t%llu\n", base_char(b), code_str(c).c_str(), (unsigned long long)pass[b][c], (unsigned long long)fail[b][c]);
+  }
+  if (out != stdout) fclose(out);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs")) {
+  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs" && std::string(argv[1]) != "summary")) {
     fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n"
-                    "       modkit_oracle sample-probs <in.bam> [-o table.tsv] [-p 0.1,0.5,0.9] [sampling flags of `modkit sample-probs`]\n");
+                    "       modkit_oracle sample-probs <in.bam> [-o table.tsv] [-p 0.1,0.5,0.9] [sampling flags of `modkit sample-probs`]\n"
+                    "       modkit_oracle summary <in.bam> [-o counts.tsv] [flags of `modkit summary`]\n");
     return 2;
   }
   Options o; std::vector<std::string> pos;
   o.hemi = std::string(argv[1]) == "pileup-hemi";
-  o.sample_probs_cmd = std::string(argv[1]) == "sample-probs";
+  const bool summary_cmd = std::string(argv[1]) == "summary";
+  o.sample_probs_cmd = std::string(argv[1]) == "sample-probs" || summary_cmd;
   if (o.sample_probs_cmd) { o.include_unmapped = true; o.sampling_interval_size = 1000000; }   // --only-mapped is off by default; -i is the sampling interval
   try {
     for (int i = 2; i < argc; i++) {
@@ -725,7 +784,8 @@ int main(int argc, char** argv) {
       if (o.hemi && (a == "-o" || a == "--out-bed")) { o.out_bed = val(); continue; }
       if (o.sample_probs_cmd) {
         if (a == "-o") { o.out_bed = val(); continue; }
-        if (a == "-p" || a == "--percentiles") { o.percentiles = val(); continue; }
+        if (!summary_cmd && (a == "-p" || a == "--percentiles")) { o.percentiles = val(); continue; }
+        if (summary_cmd && (a == "--tsv" || a == "--table")) continue;
         if (a == "-i" || a == "--interval-size") { o.sampling_interval_size = (uint32_t)std::stoul(val()); continue; }
         if (a == "--only-mapped") { o.include_unmapped = false; continue; }
         if (a == "--no-sampling") { o.have_frac = true; o.sampling_frac = 1.0; continue; }
@@ -749,7 +809,7 @@ int main(int argc, char** argv) {
       else if (!a.empty() && a[0] == '-' && a != "-") throw MkErr("unknown flag " + a);
       else pos.push_back(a);
     }
-    if (o.sample_probs_cmd) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; if (!o.include_bed.empty()) o.include_unmapped = false; return run_sample_probs(o); }
+    if (o.sample_probs_cmd) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; if (!o.include_bed.empty()) o.include_unmapped = false; return summary_cmd ? run_summary(o) : run_sample_probs(o); }
     if (o.hemi) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; }
     else { if (pos.size() != 2) throw MkErr("need <in.bam> <out.bed>"); o.in_bam = pos[0]; o.out_bed = pos[1]; }
     return run_pileup(o);

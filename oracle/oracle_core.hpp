@@ -630,6 +630,16 @@ struct BaseModCall {  // mod_bam.rs:370-375
   ModCode code = 0;
 };
 
+// BaseModProbs::argmax_base_mod_call (mod_bam.rs:489-505): max_by keeps the LAST maximum; a tie with the canonical probability is canonical
+static inline BaseModCall argmax_call(const BaseModProbs& bmp) {
+  const float can = bmp.canonical_prob();
+  bool have = false; float best = 0.0f; ModCode bc = 0;
+  bmp.probs.for_each([&](ModCode c, float p) { if (!have || !(p < best)) { best = p; bc = c; have = true; } });
+  BaseModCall m;
+  if (have && best > can) { m.kind = BaseModCall::MODIFIED; m.p = best; m.code = bc; } else { m.kind = BaseModCall::CANONICAL; m.p = can; }
+  return m;
+}
+
 struct ThresholdCaller {  // threshold_mod_caller.rs:8-13
   std::map<int, float> per_base;
   std::map<ModCode, float> per_mod;

@@ -110,3 +110,44 @@ def test_hemi_requires_a_palindromic_motif(oracle_bin, tmp_path, hemi_ref):
     assert "palindromic" in err
     err = run_oracle_hemi(oracle_bin, fixture(HEMI_BAM), str(tmp_path / "o.bed"), ["-r", hemi_ref], ok=False)
     assert "--cpg or a --motif" in err
+
+
+# ---- summary (tests/test_summary.rs): the reference's tests assert on the ModSummary struct, not on text
+def run_oracle_summary(oracle_bin, bam, flags):
+    p = subprocess.run([oracle_bin, "summary", bam] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = {"rows": {}, "reads_with": {}, "threshold": {}}
+    for ln in p.stdout.splitlines():
+        f = ln.split("\t")
+        if f[0] == "total_reads_used":
+            out["total"] = int(f[1])
+        elif f[0] == "reads_with":
+            out["reads_with"][f[1]] = int(f[2])
+        elif f[0] == "threshold":
+            out["threshold"][f[1]] = float(f[2])
+        elif f[0] == "row":
+            out["rows"][(f[1], f[2])] = (int(f[3]), int(f[4]))
+    return out
+
+
+def test_summary_implicit_calls(oracle_bin):
+    # tests/test_summary.rs:133-172: passthrough caller, BED of 8 positions on an implicit-mode `A+a.` read -> 8 canonical A calls
+    s = run_oracle_summary(oracle_bin, fixture("single_read.bam"), ["--include-bed", fixture("include_bed_summary_test.bed"), "--no-filtering", "-i", "32", "--no-sampling"])
+    assert s["total"] == 1 and s["reads_with"] == {"A": 1}
+    assert s["rows"][("A", "-")] == (8, 0) and all(v == (0, 0) for k, v in s["rows"].items() if k != ("A", "-"))
+
+
+def test_summary_ignore(oracle_bin):
+    # tests/test_summary.rs:31-68: the states counted without / with ReDistribute('h')
+    a = run_oracle_summary(oracle_bin, fixture(BC), ["-i", "25", "--no-sampling"])
+    b = run_oracle_summary(oracle_bin, fixture(BC), ["-i", "25", "--no-sampling", "--ignore", "h"])
+    assert {k for k, v in a["rows"].items() if v[0]} == {("C", "-"), ("C", "h"), ("C", "m")}
+    assert {k for k, v in b["rows"].items() if v[0]} == {("C", "-"), ("C", "m")}
+
+
+def test_summary_edge_filter(oracle_bin):
+    # tests/test_summary.rs:70-131 (the part that needs no adjust-mods): same reads, fewer calls
+    a = run_oracle_summary(oracle_bin, fixture(BC), ["-i", "25", "--no-sampling"])
+    b = run_oracle_summary(oracle_bin, fixture(BC), ["-i", "25", "--no-sampling", "--edge-filter", "50"])
+    assert a["reads_with"]["C"] == b["reads_with"]["C"] and a["total"] == b["total"]
+    assert sum(v[0] for v in a["rows"].values()) > sum(v[0] for v in b["rows"].values())
