@@ -30,6 +30,7 @@ struct Args {
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
   int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */; bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
+  bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */
 };
 
 struct RegionSpec { std::string name; uint32_t start, end; };
@@ -436,7 +437,12 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   } else {
   wr.f = (a.out_bed == "-" || a.out_bed == "stdout" || (a.hemi && a.out_bed.empty())) ? stdout : fopen(a.out_bed.c_str(), "w");
   if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
+  if (a.bgzf) {
+    if (wr.f == stdout || a.with_header || a.plan_only) throw Error(MKP_E_INVALID, "--bgzf writes a file and its index: it needs an output path and goes without --with-header");
+    wr.bz.reset(new BgzfTabixSink()); wr.bz->f = wr.f; wr.bz->index_path = a.out_bed + ".tbi";
   }
+  }
+  if (a.bgzf && partitioned) throw Error(MKP_E_INVALID, "--bgzf has no partitioned form");
   auto writer_for = [&](const std::string& key) -> RowWriter& {
     auto it = key_writers.find(key);
     if (it == key_writers.end()) {
@@ -584,6 +590,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
     else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val()); else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--shard-bytes") a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); else if (s == "--no-index") a.no_index = true; else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
+    else if (s == "--bgzf") a.bgzf = true;
     else if (s == "--bedgraph") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);

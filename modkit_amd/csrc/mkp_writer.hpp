@@ -14,28 +14,35 @@
 #include "../../include/mkpileup.h"
 #include "mkp_bam.hpp"
 #include "mkp_format.hpp"
+#include "mkp_bgzf_out.hpp"
 
 namespace mkp {
 
 // bedMethyl text (writers.rs:87-156) through mkp_format.hpp: row ranges are formatted by all host cores into per-thread
 // buffers; a writer thread puts the buffers of one shard on disk, in order, while the next shard is packed and run
 struct RowWriter {
-  struct TextBuf { std::unique_ptr<char[]> mem; size_t n = 0; };
+  struct TextBuf { std::unique_ptr<char[]> mem; size_t n = 0; std::string chrom; BgzfPiece piece; };
+  std::unique_ptr<BgzfTabixSink> bz;   // --bgzf: BGZF blocks + TBI index instead of plain text
   FILE* f = nullptr; bool mixed = false; std::vector<std::string> labels; uint64_t n = 0;
+  bool bz_finished = false;
   std::thread io; std::mutex mu; std::condition_variable cv; std::deque<std::vector<TextBuf>> pending; bool closing = false, io_failed = false, io_started = false;
   static size_t row_bound(size_t chrom_n) { return chrom_n + 96 + 14 * 11 + 32; }   // chrom + name + 14 numbers + separators
   void format_range(const std::string& chrom, const mkp_rows& r, uint64_t lo, uint64_t hi, TextBuf* out) const {
     const char sp = mixed ? ' ' : '\t';
     out->mem.reset(new char[(size_t)(hi - lo) * row_bound(chrom.size()) + 1]);   // uninitialised: only the written pages get touched
     char* p = out->mem.get();
+    std::vector<uint32_t> lens; if (bz) lens.reserve((size_t)(hi - lo));
     for (uint64_t i = lo; i < hi; i++) {
+      const char* p_line = p;
       char name[96]; uint32_t code = r.code_repr[i];
       int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : (name[0] = (char)code, name[1] = 0, 1);
       if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) k += snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
       p = format_row(p, chrom.data(), chrom.size(), name, (size_t)std::min<int>(k, (int)sizeof(name) - 1), sp, r.pos[i], (char)r.strand[i], r.n_valid[i], r.n_mod[i], r.n_canonical[i], r.n_other[i],
                      r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
+      if (bz) lens.push_back((uint32_t)(p - p_line));
     }
     out->n = (size_t)(p - out->mem.get());
+    if (bz) { out->chrom = chrom; out->piece.build(out->mem.get(), lens.data(), r.pos + lo, (size_t)(hi - lo)); out->mem.reset(); }
   }
   // pileup-hemi rows (PileupWriter<DuplexModBasePileup>, writers.rs:185-258): the same 18 columns with name = "<pos>,<neg>,<base>",
   // strand '.', count / canonical / other-pattern in the modified / canonical / other columns
@@ -43,20 +50,25 @@ struct RowWriter {
     const char sp = mixed ? ' ' : '\t';
     out->mem.reset(new char[(size_t)(hi - lo) * row_bound(chrom.size()) + 1]);
     char* p = out->mem.get();
+    std::vector<uint32_t> lens; if (bz) lens.reserve((size_t)(hi - lo));
     auto element = [](char* q, uint32_t code) { if (code == MKP_HEMI_CANONICAL) { *q++ = '-'; return q; } if (code & 0x80000000u) return put_u32(q, code & 0x7fffffffu); *q++ = (char)code; return q; };
     for (uint64_t i = lo; i < hi; i++) {
+      const char* p_line = p;
       char name[32]; char* q = element(name, r.pattern_pos[i]); *q++ = ','; q = element(q, r.pattern_neg[i]); *q++ = ','; *q++ = (char)r.primary_base[i];
       p = format_row(p, chrom.data(), chrom.size(), name, (size_t)(q - name), sp, r.pos[i], '.', r.n_valid[i], r.count[i], r.n_canonical[i], r.n_other_pattern[i],
                      r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
+      if (bz) lens.push_back((uint32_t)(p - p_line));
     }
     out->n = (size_t)(p - out->mem.get());
+    if (bz) { out->chrom = chrom; out->piece.build(out->mem.get(), lens.data(), r.pos + lo, (size_t)(hi - lo)); out->mem.reset(); }
   }
   void io_loop() {
     for (;;) {
       std::vector<TextBuf> job;
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closing || !pending.empty(); }); if (pending.empty()) return; job = std::move(pending.front()); }
       bool ok = true;
-      for (auto& b : job) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) ok = false;
+      if (bz) { for (auto& b : job) bz->write(b.chrom, b.piece); ok = !bz->failed; }
+      else for (auto& b : job) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) ok = false;
       { std::lock_guard<std::mutex> lk(mu); pending.pop_front(); if (!ok) io_failed = true; }   // popped after the write: `pending` bounds the text held in memory
       cv.notify_all();
     }
@@ -87,6 +99,7 @@ struct RowWriter {
   void finish() {
     if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); io_started = false; }
     if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+    if (bz && !bz_finished) { bz_finished = true; bz->finish(); if (bz->failed) throw Error(MKP_E_IO, "short write on the bedMethyl output or its index"); }
     if (f && fflush(f) != 0) throw Error(MKP_E_IO, "short write on the bedMethyl output");
   }
   ~RowWriter() { if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); } }

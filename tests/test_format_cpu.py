@@ -56,8 +56,9 @@ using namespace mkp;
 int main(int argc, char** argv) {
   std::mt19937 rng(7);
   std::string ref;
-  RowWriter wr; wr.mixed = argc > 3; wr.labels = {"CG,0", "CHH,0"};
+  RowWriter wr; wr.mixed = argc > 3 && !strcmp(argv[3], "mixed"); wr.labels = {"CG,0", "CHH,0"};
   wr.f = fopen(argv[1], "w"); if (!wr.f) return 2;
+  if (argc > 3 && !strcmp(argv[3], "bgzf")) { wr.bz.reset(new BgzfTabixSink()); wr.bz->f = wr.f; wr.bz->index_path = std::string(argv[1]) + ".tbi"; }
   const size_t sizes[3] = {200000, 10, 70001};
   const char* chroms[3] = {"chr1", "chrUn_KI270742v1", "chrM"};
   for (int s = 0; s < 3; s++) {
@@ -93,12 +94,14 @@ def _writer_harness(tmp_path, extra_flags, mixed):
     src = tmp_path / "wr.cpp"
     src.write_text(WRITER_SRC)
     exe = tmp_path / "wr"
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread"] + extra_flags + ["-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-o", str(exe), str(src)])
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread"] + extra_flags + ["-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-o", str(exe), str(src), "-lz"])
     a, b = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
-    out = subprocess.run([str(exe), a, b] + (["mixed"] if mixed else []), capture_output=True, text=True)
+    out = subprocess.run([str(exe), a, b] + ([mixed] if isinstance(mixed, str) else ["mixed"] if mixed else []), capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("rows 270011"), out.stdout + out.stderr
     assert "ThreadSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-2000:]
-    assert open(a, "rb").read() == open(b, "rb").read()
+    if mixed != "bgzf":
+        assert open(a, "rb").read() == open(b, "rb").read()
+    return a, b
 
 
 def test_row_writer_threads_keep_order_and_bytes(tmp_path):
@@ -112,3 +115,92 @@ def test_row_writer_under_thread_sanitizer(tmp_path):
         import pytest
         pytest.skip("no libtsan in this image")
     _writer_harness(tmp_path, ["-fsanitize=thread"], mixed=False)
+
+
+# ---- --bgzf: BGZF blocks + TBI index (mkp_bgzf_out.hpp)
+def _bgzf_blocks(data):
+    import struct
+    import zlib
+    o, blocks = 0, []
+    while o < len(data):
+        assert data[o:o + 4] == b"\x1f\x8b\x08\x04"
+        xlen = struct.unpack_from("<H", data, o + 10)[0]
+        assert data[o + 12:o + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", data, o + 16)[0] + 1
+        payload = zlib.decompress(data[o + 12 + xlen:o + bsize - 8], -15)
+        crc, isize = struct.unpack_from("<II", data, o + bsize - 8)
+        assert isize == len(payload) <= 65536 and crc == (zlib.crc32(payload) & 0xffffffff)
+        blocks.append((o, payload))
+        o += bsize
+    return blocks
+
+
+def _reg2bins(beg, end):
+    end -= 1
+    bins = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins.extend(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return bins
+
+
+def test_bgzf_output_and_tabix_index(tmp_path):
+    import gzip
+    import random
+    import struct
+    a, b = _writer_harness(tmp_path, [], mixed="bgzf")
+    raw = open(a, "rb").read()
+    text = open(b, "rb").read()
+    assert gzip.decompress(raw) == text                    # a gzip reader sees the plain bedMethyl
+    blocks = _bgzf_blocks(raw)
+    assert blocks[-1][1] == b"" and all(len(p) <= 0xff00 for _, p in blocks)   # EOF marker; bgzip's block size
+    by_off = {o: p for o, p in blocks}
+    ix = b"".join(p for _, p in _bgzf_blocks(open(a + ".tbi", "rb").read()))
+    magic, n_ref, fmt, sc, bc, ec, meta, skip, l_nm = struct.unpack_from("<4siiiiiiii", ix, 0)
+    assert (magic, fmt, sc, bc, ec, meta, skip) == (b"TBI\x01", 0x10000, 1, 2, 3, ord("#"), 0)   # tabix -p bed
+    names = ix[36:36 + l_nm].split(b"\0")[:-1]
+    assert names == [b"chr1", b"chrUn_KI270742v1", b"chrM"] and n_ref == 3
+    o = 36 + l_nm
+    index = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", ix, o)[0]; o += 4
+        bins = {}
+        for _ in range(n_bin):
+            bn, n_chunk = struct.unpack_from("<Ii", ix, o); o += 8
+            bins[bn] = [struct.unpack_from("<QQ", ix, o + 16 * k) for k in range(n_chunk)]; o += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", ix, o)[0]; o += 4
+        lidx = list(struct.unpack_from("<%dQ" % n_intv, ix, o)); o += 8 * n_intv
+        index.append((bins, lidx))
+    assert len(ix) - o == 8                                 # n_no_coor
+    lines = text.split(b"\n")[:-1]
+    per_ref = {nm: [] for nm in names}
+    for ln in lines:
+        f = ln.split(b"\t")
+        per_ref[f[0]].append((int(f[1]), int(f[2]), ln))
+    for ri, nm in enumerate(names):
+        bins, lidx = index[ri]
+        assert bins[37450][1] == (len(per_ref[nm]), 0)      # pseudo-bin: line count
+        rng = random.Random(ri)
+        span = per_ref[nm][-1][1]
+        for _ in range(60):                                 # region queries through the index == a scan of the text
+            beg = rng.randrange(0, span); end = min(span + 5, beg + rng.choice([1, 7, 300, 20000, 400000]))
+            want = [ln for s0, e0, ln in per_ref[nm] if s0 < end and e0 > beg]
+            min_off = lidx[beg >> 14] if (beg >> 14) < len(lidx) else 0
+            got = []
+            for bn in _reg2bins(beg, end):
+                for c0, c1 in bins.get(bn, []):
+                    if c1 <= min_off:
+                        continue
+                    v = c0
+                    while v < c1:                           # read lines from virtual offset v
+                        coff, uoff = v >> 16, v & 0xffff
+                        payload = by_off[coff]
+                        nl = payload.index(b"\n", uoff)
+                        ln = payload[uoff:nl]
+                        f = ln.split(b"\t")
+                        if f[0] == nm and int(f[1]) < end and int(f[2]) > beg:
+                            got.append((v, ln))
+                        if nl + 1 < len(payload):
+                            v = (coff << 16) | (nl + 1)
+                        else:
+                            v = (coff + len(raw[coff:coff + 18]) - 18 + struct.unpack_from("<H", raw, coff + 16)[0] + 1) << 16
+            assert [ln for _, ln in sorted(set(got))] == want, (nm, beg, end)

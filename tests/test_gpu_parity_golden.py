@@ -138,3 +138,21 @@ def test_partition_tags_vs_oracle_on_split_bams(oracle_bin, tmp_path):
         assert p.returncode == 0, p.stderr
         got, want = open(os.path.join(out_dir, "hap_%s.bed" % key)).read(), open(ora).read()
         assert want and got == want, key
+
+
+def test_bgzf_output_holds_the_golden_text(tmp_path):
+    # --bgzf: what `bgzip` + `tabix -p bed` would make of the reference's output — the gzip stream is the golden bedMethyl, the
+    # .tbi is there (its contents are checked against region scans in tests/test_format_cpu.py)
+    import gzip
+    from pileup_cases import HEMI_GOLDEN_CASES, hemi_reference_fasta
+    name, flags, bam, golden = GOLDEN_CASES[0]
+    out = str(tmp_path / "out.bed.gz")
+    modkit_amd.pileup([fixture(bam), out] + flags + ["--bgzf"])
+    assert gzip.decompress(open(out, "rb").read()) == open(fixture(golden), "rb").read()
+    assert open(out + ".tbi", "rb").read()[:4] == b"\x1f\x8b\x08\x04"
+    name, flags, bam, golden = HEMI_GOLDEN_CASES[0]
+    out = str(tmp_path / "hemi.bed.gz")
+    modkit_amd.pileup_hemi([fixture(bam), "-o", out] + flags + ["-r", hemi_reference_fasta(tmp_path), "--bgzf"])
+    assert gzip.decompress(open(out, "rb").read()) == open(fixture(golden), "rb").read()
+    with pytest.raises(modkit_amd.MkpError):
+        modkit_amd.pileup([fixture(bam), str(tmp_path / "x.gz"), "--no-filtering", "--bgzf", "--with-header"])
