@@ -340,6 +340,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(64u, std::thread::hardware_concurrency())), !a.no_index);
   const BamSource& bam = *src;
   double load_ms = ms_since(t_all);
+  const bool trace = getenv("MKP_TRACE_PLAN") != nullptr;   // wall-clock marks of the subcommand's phases on stderr
+  auto mark = [&](const char* what) { if (trace) fprintf(stderr, "[mkpileup run] %-36s at %.1f ms\n", what, ms_since(t_all)); };
+  mark("BAM opened (header, index)");
   RegionSpec region, sregion; const bool have_region = !a.region.empty(), have_sregion = !a.sample_region.empty();
   if (have_region) region = parse_region(a.region, bam);
   if (have_sregion) sregion = parse_region(a.sample_region, bam);
@@ -384,6 +387,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "reference fasta is required for using --motif or --cpg options");
     if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID, a.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
     fasta = Fasta::load(a.ref_fasta); fb.fasta = &fasta;
+    mark("reference FASTA loaded");
   }
   mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
   mkp_ctx* ctx = ext_ctx;
@@ -424,6 +428,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; } }
     thr_ms = ms_since(t0);
   }
+  mark("thresholds done");
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
   if (early_walk.valid()) early_walk.get();   // rethrows what the walk threw
   // --partition-tag: the output path is a directory with one bedMethyl per key, `[<prefix>_]<key>.bed` (PartitioningBedMethylWriter, writers.rs:1005-1082)
@@ -487,6 +492,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     }
   }
   auto fetch_shard = [&](const ShardPlan& sp) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(records[sp.rec].tid, sp.s0 > MKP_HALO ? sp.s0 - MKP_HALO : 0, sp.s1 + MKP_HALO, b.get()); return b; };
+  mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<std::unique_ptr<BamBatch>> next_batch;
   if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]);
@@ -517,8 +523,10 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+      mark("shard blocks in hand");
       must(mkp_shard_begin(ctx, &sh));
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
+      mark("shard packed");
       batch.reset();   // packed: the inflated blocks are no longer needed
       mkp_rows rows; memset(&rows, 0, sizeof(rows));
       if (a.hemi) {
@@ -545,6 +553,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         write_ms += ms_since(t_w); }
       }
       n_shards++;
+      mark("shard run, rows with the writer");
       mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
@@ -552,6 +561,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   load_ms += fetch_wait_ms;   // what the shard loop waited for blocks to be read and inflated (the rest overlapped with pack / run / write)
   { auto t_w = std::chrono::steady_clock::now(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f); } write_ms += ms_since(t_w); }
   if (wr.f && wr.f != stdout) fclose(wr.f);
+  mark("output closed");
   if (rep) {
     memset(rep, 0, sizeof(*rep));
     rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms; rep->kernel_ms = kernel_ms; rep->d2h_ms = d2h_ms; rep->write_ms = write_ms;
