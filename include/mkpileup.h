@@ -142,6 +142,10 @@ typedef struct {
   uint64_t alg_bytes_decode, alg_bytes_pileup; /* SURVEY.md §8(d) algorithmic bytes of the decode and pileup kernels */
   double rows_kernel_ms;                       /* mkp_emit_rows (tallies -> rows) */
   uint64_t alg_bytes_rows;                     /* 44 B per row */
+  /* focus runs on the slot pipeline: feature-stream bytes (one per read and focus position in its span) and
+   * SURVEY §8(d)'s literal B_agg = 8 B per coverage / call event + 44 B per row for the aggregation kernel */
+  uint64_t stream_bytes, alg_bytes_agg_survey;
+  uint32_t slot_pipeline, reserved;
 } mkp_stats;
 
 /* ---- lifecycle */

@@ -166,7 +166,8 @@ class Stats(ctypes.Structure):
                 ("decode_kernel_ms", ctypes.c_double), ("pileup_kernel_ms", ctypes.c_double), ("gather_kernel_ms", ctypes.c_double),
                 ("n_reads", ctypes.c_uint64), ("n_events", ctypes.c_uint64), ("n_rows", ctypes.c_uint64), ("n_tiles", ctypes.c_uint64),
                 ("n_positions", ctypes.c_uint64), ("alg_bytes_decode", ctypes.c_uint64), ("alg_bytes_pileup", ctypes.c_uint64),
-                ("rows_kernel_ms", ctypes.c_double), ("alg_bytes_rows", ctypes.c_uint64)]
+                ("rows_kernel_ms", ctypes.c_double), ("alg_bytes_rows", ctypes.c_uint64),
+                ("stream_bytes", ctypes.c_uint64), ("alg_bytes_agg_survey", ctypes.c_uint64), ("slot_pipeline", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class RunReport(ctypes.Structure):

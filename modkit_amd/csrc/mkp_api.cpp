@@ -18,6 +18,11 @@ hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
                              uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
+hipError_t mkp_launch_slots(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids: fused 1 | fused 2 | cover*/, const uint32_t* /*n[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*,
+                            const uint32_t*, const uint8_t*, const MkpLayout*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
+hipError_t mkp_stream_set_lds(uint32_t bytes);
+hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t, const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/, const uint32_t* /*interval starts*/,
@@ -192,6 +197,11 @@ void make_resident(mkp_ctx* c) {
   const uint32_t budget_words = (76u * 1024u - 3584u) / 4u;
   const int64_t win = (int64_t)S.win_end - (int64_t)S.win_start;
   std::vector<MkpTile> tiles; std::vector<uint32_t> slotbm; uint32_t Scap = 0, Wcap = 0;
+  // focus runs take the slot pipeline (mkp_slots.hip) unless MKP_PIPELINE=tiles asks for the tile walk of mkp_kernels.hip (A/B runs);
+  // pileup-hemi keeps the tile walk
+  const bool stream = c->has_focus && !c->hemi && !(getenv("MKP_PIPELINE") && !strcmp(getenv("MKP_PIPELINE"), "tiles"));
+  std::vector<uint32_t> slot_pos_h; std::vector<MkpSTile> stiles;
+  c->slot_mode = stream; P.slot_stream = stream ? 1u : 0u; c->cov_bytes = 0;
   auto max_slots_for = [&](uint32_t W) { uint32_t best = 0; for (uint32_t s = 64; s <= 4160; s += 64) if (MKP_PILEUP_LDS_WORDS(words_per_slot, s, W) <= budget_words) best = s; return best; };
   if (!c->has_focus) {
     uint32_t Smax = max_slots_for(0);
@@ -214,6 +224,39 @@ void make_resident(mkp_ctx* c) {
     std::vector<uint32_t> wpfx(nwords + 1, 0);
     for (size_t w = 0; w < nwords; w++) wpfx[w + 1] = wpfx[w] + (uint32_t)__builtin_popcount(slotbm[w]);
     auto rank = [&](int64_t p) { const size_t b = (size_t)(p - S.win_start + MKP_SLOTBM_MARGIN); return wpfx[b >> 5] + (uint32_t)__builtin_popcount(slotbm[b >> 5] & ((1u << (b & 31)) - 1u)); };
+    if (stream) {
+      // ---- slot pipeline plan (mkp_slots.hip): global slot numbering, per-read slot ranges and feature-stream offsets, tiles of slots
+      const int64_t lo_clamp = (int64_t)S.win_start - MKP_SLOTBM_MARGIN, hi_clamp = (int64_t)S.win_end + MKP_SLOTBM_MARGIN;
+      auto crank = [&](int64_t p) { return rank(std::min(std::max(p, lo_clamp), hi_clamp)); };
+      const uint32_t total = wpfx[nwords];
+      slot_pos_h.resize(total);
+      host_parallel(nwords, (size_t)1 << 15, [&](size_t lo, size_t hi) {
+        for (size_t w = lo; w < hi; w++) { uint32_t at = wpfx[w]; for (uint32_t bits = slotbm[w]; bits; bits &= bits - 1u) slot_pos_h[at++] = (uint32_t)((int64_t)(w * 32 + (size_t)__builtin_ctz(bits)) - MKP_SLOTBM_MARGIN + S.win_start); }
+      });
+      uint64_t off = 0;
+      for (auto& h : S.hdr) {
+        const uint32_t a = crank(h.ref_start), b = std::max(a, crank(h.ref_end));
+        h.gs0 = a; h.n_sl = b - a; h.cov_off = (uint32_t)off; h.pad = 0;
+        off += ((uint64_t)h.n_sl + 3u) & ~3ull;
+        if (off > 0xffffff00ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of per-read focus positions; use smaller shards");
+      }
+      c->cov_bytes = off;
+      // tile = a run of slots: rows for [g0, g1), tally columns for the slots within MKP_HALO positions of them (strand combining)
+      const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, (budget_words / (words_per_slot + 1u)) & ~63u);   // + the tile's slot positions; row emission: one thread per slot
+      if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
+      uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 2048u + 63u) & ~63u));   // about 2000 tiles over 512 resident workgroups
+      if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));   // tests: many small tiles
+      if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));   // experiments
+      uint32_t most = 0;
+      for (uint32_t g0 = 0; g0 < total; g0 += Te) {
+        MkpSTile t; t.g0 = g0; t.g1 = std::min(total, g0 + Te);
+        t.r0 = (int32_t)slot_pos_h[t.g0]; t.r1 = (int32_t)slot_pos_h[t.g1 - 1u] + 1;
+        t.gh0 = crank((int64_t)t.r0 - MKP_HALO); t.gh1 = crank((int64_t)t.r1 + MKP_HALO); t.first = t.last = 0;
+        stiles.push_back(t); most = std::max(most, t.gh1 - t.gh0);
+      }
+      if (most > Smax) throw Error(MKP_E_UNSUPPORTED, "internal: slot tile does not fit the LDS budget");
+      Scap = std::max<uint32_t>(64u, (most + 63u) & ~63u); Wcap = 0;
+    } else {
     // span: enough tiles to balance 512 persistent workgroups, bounded by the bitmap the tile keeps in LDS
     const uint32_t span_max = 32768 - 128;
     // A read is visited once per tile it crosses: longer tiles mean fewer visits (10 kb reads: 1.64 per read at 16 kb, 1.41 at 24 kb),
@@ -234,6 +277,7 @@ void make_resident(mkp_ctx* c) {
       r0 = r1;
     }
     Scap = std::max<uint32_t>(64u, (most + 63u) & ~63u);
+    }
   }
   lap("slot bitmap + tiles");
   // tile -> [first, last) candidate reads (coordinate sorted; the prefix-max of ends bounds the first candidate)
@@ -251,9 +295,43 @@ void make_resident(mkp_ctx* c) {
     }
     tiles.swap(kept);
   }
+  if (stream) {   // slot tiles: reads are coordinate sorted, so their first slots ascend; the prefix-max of their slot ends bounds the first candidate
+    std::vector<uint32_t> pmax(n); uint32_t m = 0;
+    for (size_t i = 0; i < n; i++) { m = std::max(m, S.hdr[i].gs0 + S.hdr[i].n_sl); pmax[i] = m; }
+    size_t first = 0, last = 0; std::vector<MkpSTile> kept;
+    for (auto& tl : stiles) {
+      while (first < n && pmax[first] <= tl.gh0) first++;
+      if (last < first) last = first;
+      while (last < n && S.hdr[last].gs0 < tl.gh1) last++;
+      bool any = false; for (size_t i = first; i < last && !any; i++) any = S.hdr[i].gs0 + S.hdr[i].n_sl > tl.gh0 && S.hdr[i].n_sl > 0;
+      if (any) { tl.first = (uint32_t)first; tl.last = (uint32_t)last; kept.push_back(tl); }
+    }
+    stiles.swap(kept);
+  }
+  // reads by kernel on the slot pipeline: the fused slot decoder takes the SPARSE classes when no edge filter is set (it never locates
+  // calls off the focus positions, which the edge filter's "any call left" test would need); every other read is decoded into events
+  // by its class kernel and then covered
+  c->read_ids_dec_off = 0; c->n_slot_class[0] = c->n_slot_class[1] = c->n_slot_class[2] = 0;
+  std::vector<uint32_t> slot_ids;
+  if (stream) {
+    const bool fused = !P.edge_filter && !(getenv("MKP_FUSED") && !strcmp(getenv("MKP_FUSED"), "0"));
+    std::vector<uint8_t> is_fused(n, 0);
+    if (fused) {
+      const uint32_t nf = c->n_class[0] + c->n_class[1];
+      for (uint32_t k = 0; k < nf; k++) is_fused[class_list[k]] = 1;
+      slot_ids.assign(class_list.begin(), class_list.begin() + nf);
+      c->n_slot_class[0] = c->n_class[0]; c->n_slot_class[1] = c->n_class[1];
+      c->read_ids_dec_off = nf; c->n_class[0] = c->n_class[1] = 0;
+    }
+    std::vector<uint32_t> rest; rest.reserve(n);
+    for (size_t i = 0; i < n; i++) if (!is_fused[i]) rest.push_back((uint32_t)i);
+    std::stable_sort(rest.begin(), rest.end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].n_sl > S.hdr[y].n_sl; });
+    c->n_slot_class[2] = (uint32_t)rest.size();
+    slot_ids.insert(slot_ids.end(), rest.begin(), rest.end());
+  }
   P.slot_cap = Scap; P.focus_words = Wcap;
-  c->lds_bytes = MKP_PILEUP_LDS_WORDS(words_per_slot, Scap, Wcap) * 4u;
-  c->n_tiles = (uint32_t)tiles.size();
+  c->lds_bytes = stream ? (words_per_slot + 1u) * Scap * 4u : MKP_PILEUP_LDS_WORDS(words_per_slot, Scap, Wcap) * 4u;
+  c->n_tiles = stream ? (uint32_t)stiles.size() : (uint32_t)tiles.size();
   c->n_slots_total = 0;
   if (c->has_focus) { for (size_t w = 0; w < slotbm.size(); w++) c->n_slots_total += (uint64_t)__builtin_popcount(slotbm[w]); }
   lap("candidate reads per tile");
@@ -267,6 +345,11 @@ void make_resident(mkp_ctx* c) {
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
+  if (stream) {
+    upload(c->d_slot_pos, slot_pos_h); upload(c->d_stiles, stiles); upload(c->d_slot_ids, slot_ids);
+    c->d_cov.ensure(c->cov_bytes + 256); c->d_visits.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpVisit));
+    hip_check(mkp_stream_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS, stream)");
+  }
   if (c->hemi) upload(c->d_hemi_iv, c->hemi_iv);
   // partition keys present in this shard: one accumulate pass each
   c->key_passes.clear();
@@ -281,6 +364,16 @@ void make_resident(mkp_ctx* c) {
   c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = (uint64_t)win;
   c->stats.alg_bytes_decode = b_reads + S.ranks.size() * 2ull + S.ml.size();  // + 8*events added after the run
   c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events + 44*rows added after the run
+  c->stats.slot_pipeline = stream ? 1u : 0u; c->stats.stream_bytes = 0; c->stats.alg_bytes_agg_survey = 0;
+  if (stream) {
+    // slot pipeline: the decode side also reads the slot positions of every read's span and writes one feature byte per slot and a
+    // 32-byte visit record per read; the aggregation kernel reads exactly those (SEQ and CIGAR are read once per pass)
+    uint64_t n_rs = 0; for (auto& h : S.hdr) n_rs += h.n_sl;
+    c->stats.stream_bytes = n_rs;
+    c->stats.alg_bytes_decode += 4ull * n_rs + n_rs + 32ull * S.hdr.size();
+    c->stats.alg_bytes_pileup = n_rs + 32ull * S.hdr.size();               // + 44*rows added after the run
+    c->stats.alg_bytes_agg_survey = 8ull * n_rs;                            // 8 B per coverage event at a candidate position (+ call events, + 44*rows)
+  }
 }
 
 void run_kernels(mkp_ctx* c, bool time_kernels) {
@@ -300,13 +393,19 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     c->d_prm.ensure(sizeof(MkpRunParams));
     hip_check(hipMemcpyAsync(c->d_prm.p, &P, sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
+    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                                   (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
+    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_slot_ids.as<uint32_t>(), c->n_slot_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
+                                              c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(), c->d_visits.as<MkpVisit>(),
+                                              c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2), "slot decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
-      hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+      if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
+                                                 c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
+                                                 c->key_passes[kp], kp), "stream pileup launch");
+      else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
                                   c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
@@ -443,7 +542,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -537,8 +636,13 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
     if (!c->resident || c->resident_hemi) { c->row_cap = 0; make_resident(c); }
     run_kernels(c, true);
     fetch_rows(c, out);
-    c->stats.alg_bytes_decode += 8ull * c->stats.n_events;
-    c->stats.alg_bytes_pileup += 8ull * c->stats.n_events + 44ull * c->stats.n_rows;   // rows leave the accumulate kernel directly
+    if (c->slot_mode) {   // n_events = call features + events of the reads the event decoders took
+      c->stats.alg_bytes_pileup += 44ull * c->stats.n_rows;
+      c->stats.alg_bytes_agg_survey += 44ull * c->stats.n_rows;
+    } else {
+      c->stats.alg_bytes_decode += 8ull * c->stats.n_events;
+      c->stats.alg_bytes_pileup += 8ull * c->stats.n_events + 44ull * c->stats.n_rows;   // rows leave the accumulate kernel directly
+    }
     c->stats.alg_bytes_rows = 0;
   });
 }

@@ -1,0 +1,291 @@
+// Row emission from a tile's LDS tallies (FeatureVector::decode / add_tally_to_counts / combine_strand_features, pileup/mod.rs:283-561;
+// DuplexFeatureVector::decode, duplex.rs:124-205), shared by the accumulate kernels of mkp_kernels.hip and mkp_slots.hip.
+#pragma once
+#include "mkp_dev_common.hpp"
+
+struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
+
+struct TileView {   // packed tallies of a tile in LDS: [counter | observed-code slot][S], '+' tally in the low, '-' in the high 16 bits; column = tally slot
+  const uint32_t* pk;
+  uint32_t W, n_counters;
+  __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return (pk[cid * W + i] >> (16u * s)) & 0xffffu; }
+  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return (int32_t)((pk[(n_counters + sl) * W + i] >> (16u * s)) & 0xffffu); }
+};
+
+// one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
+// sl < 0: --combine-mods row (code = base letter).  Returns false when the reference emits nothing.
+// FILL = false: only decide whether the row exists (the counting pass)
+template <bool FILL, class TV>
+__device__ __forceinline__ bool tally_row(const TV& tv, const MkpRunParams& prm, uint32_t s, uint32_t i, int sl, int pb, RowAcc* r) {
+  const uint32_t ck = prm.can_of_pb[pb];
+  if (ck == 0xffu) return false;
+  uint32_t n_can = tv.c(s, MKP_C_CAN + ck, i), mods = 0;
+  for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == pb) mods += tv.c(s, prm.slots[t].cid, i);
+  const uint32_t cov = n_can + mods;
+  if (cov == 0) return false;
+  uint32_t n_mod;
+  if (sl >= 0) { if (tv.o(s, (uint32_t)sl, i) <= 0) return false; n_mod = tv.c(s, prm.slots[sl].cid, i); }
+  else n_mod = mods;
+  if (!FILL) return true;
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < prm.n_counters; k++) if (k != MKP_C_DEL && k != MKP_C_FAIL) total += tv.c(s, k, i);
+  const uint32_t nocall = tv.c(s, MKP_C_NC + pb, i);
+  r->n_valid = cov; r->n_mod = n_mod; r->n_can = n_can; r->n_other = sl >= 0 ? mods - n_mod : 0u;
+  r->n_del = tv.c(s, MKP_C_DEL, i); r->n_fail = tv.c(s, MKP_C_FAIL, i);
+  r->n_diff = total - (nocall + cov); r->n_nocall = nocall;
+  return true;
+}
+
+// Rows of one reference position p whose tallies sit in column i.  slot_of(q) = column of a nearby position q (the strand-
+// combining partner: always a focus position of the same tile's halo'd range).
+template <bool WRITE, class TV, class SlotOf>
+__device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
+                                            const MkpCombo* combos, int32_t p, uint32_t i, const MkpRowsDev& rows,
+                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */, SlotOf slot_of, uint32_t key = 0) {
+  const uint32_t rule = fv & 3u, combo = fv >> 2;
+  if (!rule) return 0;
+  uint32_t n = 0;
+  auto put = [&](const RowAcc& r, uint32_t strand, uint32_t code, int motif) {
+    if (WRITE) {
+      uint32_t k = wr + n;
+      rows.pos[k] = (uint32_t)p; rows.info[k] = strand | ((uint32_t)(motif + 1) << 8) | (key << 16); rows.code[k] = code;
+      rows.n_valid[k] = r.n_valid; rows.n_mod[k] = r.n_mod; rows.n_can[k] = r.n_can; rows.n_other[k] = r.n_other;
+      rows.n_del[k] = r.n_del; rows.n_fail[k] = r.n_fail; rows.n_diff[k] = r.n_diff; rows.n_nocall[k] = r.n_nocall;
+    }
+    n++;
+  };
+  static const char LETTER[4] = {'A', 'C', 'G', 'T'};
+  if (!prm.combine_strands) {
+    for (uint32_t s = 0; s < 2; s++) {
+      if (!((rule >> s) & 1u)) continue;
+      uint32_t n_ids = 0; const uint8_t* ids = nullptr;
+      if (combo) { n_ids = s ? combos[combo].n_neg : combos[combo].n_pos; ids = s ? combos[combo].neg_ids : combos[combo].pos_ids; }
+      RowAcc r;
+      if (prm.numeric_mode == 1) {
+        for (int pb = 0; pb < 4; pb++) if (tally_row<WRITE>(tv, prm, s, i, -1, pb, &r)) {
+          if (n_ids) for (uint32_t k = 0; k < n_ids; k++) put(r, s, (uint32_t)LETTER[pb], ids[k]); else put(r, s, (uint32_t)LETTER[pb], -1);
+        }
+      } else {
+        for (uint32_t oi = 0; oi < prm.n_slots; oi++) {
+          const int sl = prm.slot_order[oi];
+          if (tally_row<WRITE>(tv, prm, s, i, sl, prm.slots[sl].pb, &r)) {
+            if (n_ids) for (uint32_t k = 0; k < n_ids; k++) put(r, s, prm.slots[sl].code_repr, ids[k]); else put(r, s, prm.slots[sl].code_repr, -1);
+          }
+        }
+      }
+    }
+  } else {
+    // combine_strand_features (pileup/mod.rs:469-561): only '+' motif positions produce rows
+    if (!combo) return 0;
+    const MkpCombo& cb = combos[combo];
+    for (uint32_t m = 0; m < cb.n_pos; m++) {
+      const int idx = cb.pos_ids[m];
+      const int delta = cb.pos_delta[m];
+      if (delta == -128) continue;  // not a palindrome / negative_strand_position() == None
+      const int32_t qpos = p + delta;
+      bool neg_ok = false; uint32_t iq = 0;
+      if (delta != -127 && qpos >= prm.win_start && qpos < prm.win_end) {  // -127: mate position is in another interval
+        uint32_t fq = focus[qpos - prm.win_start];
+        if ((fq & 2u) && (fq >> 2)) {
+          const MkpCombo& cq = combos[fq >> 2];
+          for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx);
+        }
+        if (neg_ok) iq = slot_of(qpos);
+      }
+      const bool pos_ok = (rule & 1u) != 0;
+      auto add = [](RowAcc& a, const RowAcc& b) { a.n_valid += b.n_valid; a.n_mod += b.n_mod; a.n_can += b.n_can; a.n_other += b.n_other;
+                                                  a.n_del += b.n_del; a.n_fail += b.n_fail; a.n_diff += b.n_diff; a.n_nocall += b.n_nocall; };
+      if (prm.numeric_mode == 1) {
+        for (int pb = 0; pb < 4; pb++) {
+          RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0}, r; bool any = false;
+          if (pos_ok && tally_row<WRITE>(tv, prm, 0, i, -1, pb, &r)) { add(acc, r); any = true; }
+          if (neg_ok && tally_row<WRITE>(tv, prm, 1, iq, -1, pb, &r)) { add(acc, r); any = true; }
+          if (any) put(acc, 2, (uint32_t)LETTER[pb], idx);
+        }
+      } else {
+        for (uint32_t oi = 0; oi < prm.n_slots; oi++) {
+          const uint32_t code = prm.slots[prm.slot_order[oi]].code_repr;
+          if (oi && prm.slots[prm.slot_order[oi - 1]].code_repr == code) continue;  // grouped by code (BTreeMap)
+          RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0}, r; bool any = false;
+          for (uint32_t oj = oi; oj < prm.n_slots && prm.slots[prm.slot_order[oj]].code_repr == code; oj++) {
+            const int sl = prm.slot_order[oj];
+            if (pos_ok && tally_row<WRITE>(tv, prm, 0, i, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
+          }
+          for (uint32_t oj = oi; oj < prm.n_slots && prm.slots[prm.slot_order[oj]].code_repr == code; oj++) {
+            const int sl = prm.slot_order[oj];
+            if (neg_ok && tally_row<WRITE>(tv, prm, 1, iq, sl, prm.slots[sl].pb, &r)) { add(acc, r); any = true; }
+          }
+          if (any) put(acc, 2, code, idx);
+        }
+      }
+    }
+  }
+  return n;
+}
+
+// pileup-hemi rows of one '+' motif position whose counters sit in column i (DuplexFeatureVector::decode, duplex.rs:124-205, in the
+// writer's order: primary base, then pattern — writers.rs:196-207).  The pattern goes out as its two element indices
+// (rows.code = a | b << 8), the primary base in rows.info; the host turns the elements into mod codes.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t hemi_rows_at(const uint32_t* __restrict__ tal, uint32_t S, const MkpRunParams& prm, int32_t p, uint32_t i, const MkpRowsDev& rows, uint32_t wr) {
+  uint32_t tot[4], n = 0;
+  for (int pb = 0; pb < 4; pb++) {
+    tot[pb] = 0;
+    const uint32_t base = prm.hemi_pat_base[pb], nel = prm.hemi_nel[pb];
+    if (base != 0xffu) for (uint32_t k = 0; k < nel * nel; k++) tot[pb] += tal[(base + k) * S + i];
+  }
+  for (int pb = 0; pb < 4; pb++) {
+    if (!tot[pb]) continue;
+    const uint32_t base = prm.hemi_pat_base[pb], nel = prm.hemi_nel[pb];
+    for (uint32_t k = 0; k < nel * nel; k++) {
+      const uint32_t cnt = tal[(base + k) * S + i];
+      if (!cnt) continue;
+      if (WRITE) {
+        const uint32_t r = wr + n;
+        rows.pos[r] = (uint32_t)p; rows.info[r] = (uint32_t)pb; rows.code[r] = (k / nel) | ((k % nel) << 8);
+        rows.n_valid[r] = tot[pb]; rows.n_mod[r] = cnt; rows.n_can[r] = tal[base * S + i]; rows.n_other[r] = tot[pb] - cnt;
+        rows.n_del[r] = tal[MKP_H_DEL * S + i]; rows.n_fail[r] = tal[(MKP_H_FAIL + pb) * S + i];
+        rows.n_diff[r] = tot[0] + tot[1] + tot[2] + tot[3] - tot[pb]; rows.n_nocall[r] = tal[(MKP_H_NC + pb) * S + i];
+      }
+      n++;
+    }
+  }
+  return n;
+}
+
+#define PILEUP_THREADS MKP_PILEUP_THREADS
+#define PILEUP_WAVES (PILEUP_THREADS / 64)
+#define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
+
+// LDS byte addresses as integers: a tally update is then `lane base + 256*window + row*4*S`, two VALU instructions
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// first index in the position-sorted event list `ev[0..n)` whose pos is >= key: 64-way probes, two dependent
+// loads for up to 4096 events instead of a 12-step bisection
+__device__ __forceinline__ uint32_t event_lower_bound(const MkpEvent* __restrict__ ev, uint32_t n, int32_t key) {
+  const uint32_t lane = (uint32_t)lane_id();
+  uint32_t lo = 0, span = n;
+  while (span > 64) {
+    const uint32_t stride = (span + 63u) >> 6;
+    const uint32_t k = lo + lane * stride;
+    const bool valid = k < lo + span;
+    const int32_t p = valid ? (int32_t)ev[k].pos : 0x7fffffff;
+    const uint32_t c = (uint32_t)__popcll(__ballot(valid && p < key));
+    if (c == 0) return lo;
+    const uint32_t nlo = lo + (c - 1u) * stride + 1u;
+    const uint32_t nhi = min(lo + c * stride, lo + span);
+    lo = nlo; span = nhi - nlo;
+  }
+  const bool valid = lane < span;
+  const int32_t p = valid ? (int32_t)ev[lo + lane].pos : 0x7fffffff;
+  return lo + (uint32_t)__popcll(__ballot(valid && p < key));
+}
+
+// Position <-> tally column of a tile.  Without focus positions every position of the tile's (halo'd) range owns a column.
+// With them only the focus positions do: a bitmap of the range plus its running popcount (both in LDS) give
+// rank(p) = number of focus positions below p, which is the column of p when p is one, and the first column at or after p
+// when it is not (what the ends of a read span, a deletion or a CIGAR op need).
+template <bool FOCUS> struct SlotMap {
+  const uint32_t* bm; const uint32_t* pfx; const int32_t* fpos; int32_t lbase, T0h;
+  __device__ __forceinline__ uint32_t rank(int32_t p) const {
+    if (!FOCUS) return (uint32_t)(p - T0h);
+    const uint32_t lb = (uint32_t)(p - lbase), w = lb >> 5;
+    return pfx[w] + (uint32_t)__popc(bm[w] & ((1u << (lb & 31u)) - 1u));
+  }
+  __device__ __forceinline__ bool is_slot(int32_t p) const { if (!FOCUS) return true; const uint32_t lb = (uint32_t)(p - lbase); return (bm[lb >> 5] >> (lb & 31u)) & 1u; }
+  __device__ __forceinline__ int32_t pos_of(uint32_t c) const { return FOCUS ? fpos[c] : T0h + (int32_t)c; }
+};
+
+// Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
+// run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
+template <bool FOCUS, bool HEMI, class SM>
+__device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SM sm, uint32_t n_tslots, MkpTile tl, uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
+                                            const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
+                                            uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
+                                            uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p) {
+  const MkpRunParams& prm = *prmp;
+  const int lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  MkpRowsDev rows;
+  { const size_t cap = prm.row_capacity; uint32_t* p = rows_base;
+    rows.pos = p; rows.info = p + cap; rows.code = p + 2 * cap; rows.n_valid = p + 3 * cap; rows.n_mod = p + 4 * cap; rows.n_can = p + 5 * cap; rows.n_other = p + 6 * cap;
+    rows.n_del = p + 7 * cap; rows.n_fail = p + 8 * cap; rows.n_diff = p + 9 * cap; rows.n_nocall = p + 10 * cap; }
+  TileView tv; tv.pk = tal; tv.W = prm.slot_cap; tv.n_counters = prm.n_counters;
+  auto slot_of = [&](int32_t q) { return sm.rank(q); };
+  if (FOCUS) {
+    // focus tiles hold at most one slot per thread (the host planner caps them at MKP_PILEUP_THREADS): every thread counts its
+    // slot's rows once, the block scans, thread 0 reserves the tile's run, and the same threads write — position, focus byte and
+    // count stay in registers
+    const uint32_t i = threadIdx.x;
+    uint32_t cnt = 0, fv = 0; int32_t p = 0;
+    if (i < n_tslots) {
+      p = sm.pos_of(i);
+      if (p >= tl.r0 && p < tl.r1) {
+        if (HEMI) cnt = hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0);
+        else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+      }
+    }
+    const uint32_t inc2 = wave_incl_scan(cnt);
+    if (lane == 63) wave_tot[wave] = inc2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t s = 0;
+      for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
+      uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+      if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+      *row_base_p = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s; *scan_carry_p = s ? 0u : 0xffffffffu;
+    }
+    __syncthreads();
+    if (*scan_carry_p != 0xffffffffu && cnt) {
+      uint32_t woff = *row_base_p + inc2 - cnt;
+      for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
+      if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, woff); else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, woff, fv, slot_of, key);
+    }
+    return;
+  }
+  // pass 1: rows per slot, summed over the tile
+  uint32_t mine = 0;
+  for (uint32_t i = threadIdx.x; i < n_tslots; i += PILEUP_THREADS) {
+    const int32_t p = sm.pos_of(i);
+    if (p < tl.r0 || p >= tl.r1) continue;
+    if (HEMI) { mine += hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0); continue; }
+    const uint32_t fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u;
+    mine += rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of);
+  }
+  { const uint32_t inc2 = wave_incl_scan(mine); if (lane == 63) wave_tot[wave] = inc2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+    for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
+    uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+    if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+    *row_base_p = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s; *scan_carry_p = s ? 0u : 0xffffffffu;
+  }
+  __syncthreads();
+  // pass 2: write, 1024 slots at a time
+  if (*scan_carry_p != 0xffffffffu) {
+    const uint32_t row_base = *row_base_p;
+    for (uint32_t i0 = 0; i0 < n_tslots; i0 += PILEUP_THREADS) {
+      const uint32_t i = i0 + threadIdx.x;
+      uint32_t cnt = 0, fv = 0; int32_t p = 0;
+      if (i < n_tslots) {
+        p = sm.pos_of(i);
+        if (p >= tl.r0 && p < tl.r1) {
+          if (HEMI) cnt = hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0);
+          else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+        }
+      }
+      const uint32_t inc2 = wave_incl_scan(cnt);
+      __syncthreads();   // wave_tot / scan_carry of the previous round are consumed
+      if (lane == 63) wave_tot[wave] = inc2;
+      __syncthreads();
+      uint32_t woff = *scan_carry_p;
+      for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
+      if (cnt) { if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, row_base + woff + inc2 - cnt); else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of, key); }
+      __syncthreads();
+      if (threadIdx.x == PILEUP_THREADS - 1) *scan_carry_p = woff + inc2;
+    }
+  }
+}

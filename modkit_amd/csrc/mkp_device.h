@@ -1,6 +1,6 @@
 // Structures shared by the host packer and the gfx950 kernels.
 // Data layout in HBM for one shard (a reference window of one contig):
-//   MkpReadHdr  hdr[n_reads]        48 B each, coordinate order
+//   MkpReadHdr  hdr[n_reads]        64 B each, coordinate order
 //   uint32      cigar[]             BAM cigar words (len<<4|op)
 //   uint2       chunk_pfx[]         per read, per 64 CIGAR ops: query / reference offsets at the chunk start (the host walks the
 //                                   CIGAR anyway to get the read's reference span), so a tile starts its walk at the right chunk
@@ -47,6 +47,10 @@ struct MkpReadHdr {
   uint32_t event_off;   // index into events[]
   uint32_t event_cap;
   uint32_t chunk_off;   // index into chunk_pfx[]: one {query offset, reference offset} per 64 CIGAR ops of this read
+  // focus runs (slot pipeline, mkp_slots.hip): the read's focus positions ("slots") are the global slots [gs0, gs0 + n_sl) of
+  // slot_pos[]; its features go to cov[cov_off .. cov_off + n_sl) (4-byte aligned).  Filled by the host planner (make_resident).
+  uint32_t gs0, n_sl, cov_off;
+  uint32_t pad;
 };
 #define MKP_RF_REVERSE 1u
 #define MKP_RF_BAD 2u
@@ -99,6 +103,7 @@ struct MkpLayout {
 #define MKP_LAYOUT_DWORDS 304
 #define MKP_LAYOUT_GROUP_DW 48
 #ifdef __cplusplus
+static_assert(sizeof(MkpReadHdr) == 64, "read header is 16 dwords");
 static_assert(sizeof(MkpGroupDesc) == 128, "group desc is 32 dwords");
 static_assert(sizeof(MkpLayout) == 4 * MKP_LAYOUT_DWORDS, "layout is 304 dwords");
 #endif
@@ -144,6 +149,7 @@ struct MkpRunParams {
   uint8_t hemi_nel[4];                    // primary base -> pattern elements (1 + mod codes; 2 with --combine-mods)
   uint8_t hemi_el[MKP_MAX_COUNTERS + 2];  // call-event counter id -> pattern element; 0xff = Filtered
   uint32_t readout_b_off;                 // duplex reads decoded one group per wave: the second group's summary sits at readout[readout_b_off + read]
+  uint32_t slot_stream;                   // 1: focus run on the slot pipeline (feature stream + mkp_pileup_stream)
 };
 // pileup-hemi counters of one tally column: NoCall(base) 0..3, deletions, Filtered(base) 5..8, then the pattern blocks
 #define MKP_H_NC 0
@@ -173,6 +179,28 @@ struct MkpTile { int32_t r0, r1; uint32_t first, last; };
 // (the packed query index / kind the CIGAR phase leaves for the SEQ phase)
 #define MKP_PILEUP_WAVE_WORDS(S, focus_words) ((focus_words) && (S) > MKP_PILEUP_BM_WORDS(S) + MKP_PILEUP_WAVE_SCRATCH ? (S) : MKP_PILEUP_BM_WORDS(S) + MKP_PILEUP_WAVE_SCRATCH)
 #define MKP_PILEUP_LDS_WORDS(words_per_slot, S, focus_words) ((words_per_slot) * (S) + ((focus_words) ? 2u * (focus_words) + (S) : 0u) + (MKP_PILEUP_THREADS / 64) * MKP_PILEUP_WAVE_WORDS(S, focus_words))
+
+// ---- slot pipeline (focus runs: --cpg / --motif / --include-bed; mkp_slots.hip) -------------------------------------------
+// The decode side leaves one FEATURE BYTE per (read, focus position in the read's reference span) — position-implicit: byte k
+// of a read belongs to global slot gs0 + k — and one MkpVisit per read; mkp_pileup_stream is then a pure histogram of that
+// stream into LDS tallies.  Feature byte = what FeatureVector::add_feature receives for this alignment at this column
+// (pileup/mod.rs:783-939): [0:4] counter id (MKP_C_*), [5] tally strand, [6:7] the read base as tallied (so that a call of a
+// record that later fails can be counted as NoCall(base)).
+#define MKP_FB_NONE 0xffu    // the read is not in this column (ref-skip)
+#define MKP_FB_BLANK 0xfeu   // in the column, no feature (non-ACGT base: pileup/mod.rs:864-874)
+struct MkpVisit {            // 32 B, written by the decode / cover kernels, read by mkp_pileup_stream
+  uint32_t gs0, n_sl, cov_off;
+  uint32_t flags;            // bit0 record yielded calls (observed-code masks valid), bit1 alignment strand, bit2 stream holds NONE bytes,
+                             // bits 8.. partition key id
+  uint32_t obs0, obs1;       // observed-code slot masks per tally strand (read_cache.rs:171-194)
+  uint32_t over_off, n_over; // second features on one column (pos_call and neg_call at one base): {global slot, feature byte} pairs in events[]
+};
+#define MKP_VF_OK 1u
+#define MKP_VF_REV 2u
+#define MKP_VF_GAPS 4u
+// one tile of mkp_pileup_stream: rows for the global slots [g0, g1) (positions [r0, r1)), tally columns for [gh0, gh1) (+- MKP_HALO
+// positions for strand combining), candidate reads [first, last)
+struct MkpSTile { uint32_t g0, g1, gh0, gh1; int32_t r0, r1; uint32_t first, last; };
 
 struct MkpRowsDev {  // SoA row buffers (44 B / row)
   uint32_t* pos; uint32_t* info; uint32_t* code;

@@ -1,0 +1,651 @@
+// gfx950 (CDNA4, wave64) kernels of the SLOT PIPELINE: the modkit-pileup hot path for runs with focus positions (--cpg, --motif,
+// --include-bed — FocusPositions::{Motif, MotifCombineStrands, Regions}, interval_chunks.rs:32-59).  A "slot" is a focus position;
+// the host numbers the window's slots in genome order (slot_pos[g] = position of global slot g) and gives every read the slot
+// range [gs0, gs0 + n_sl) of its reference span.  One device pass:
+//
+//   mkp_decode_slots1/2   one wave per read, reads whose MM tags form one explicit-mode ('?') group with one shared delta list
+//                         (`C+m?`, `C+hm?`, `C+h?;C+m?` as basecallers write them), no edge filter.  The walk is driven by the
+//                         read's SLOTS, not by its calls: the SEQ is swept once into LDS (a flag bit per base "is the fundamental
+//                         base" + a running count per 32 bases), the delta list is marked into a bitmap over the base's
+//                         occurrences, and then, 64 slots per step: CIGAR (128-op register window, reference -> query), the base,
+//                         its occurrence number (2 LDS reads), whether that occurrence is listed and as which call (2 LDS reads),
+//                         ML -> f32 probabilities -> MultipleThresholdModCaller::call, and ONE FEATURE BYTE per slot goes to the
+//                         read's run of the feature stream.  Calls on non-focus positions are never located (their rows would be
+//                         dropped, pileup/mod.rs:570-604); SEQ and CIGAR are read once per pass.
+//   mkp_cover_reads       every other read (implicit-mode / multi-group / duplex / `N` tags / failed tags, or any read when an edge
+//                         filter is set): the decode kernels of mkp_kernels.hip leave position-sorted call events; this kernel walks
+//                         the read's slots (coverage features) and merges the events into the stream.
+//   mkp_pileup_stream     accumulate + emit: one workgroup per tile of <= 1024 slots; the tile's reads' feature bytes are a
+//                         position-implicit stream (byte k of a read = global slot gs0 + k): four bytes per lane, one LDS atomic per
+//                         feature on 16-bit-packed strand tallies; observed codes as difference arrays; rows straight from LDS
+//                         (mkp_dev_rows.hpp).  This is the packed-event-stream histogram of BASELINE.json's north_star.
+//   (mkp_scan_tiles + mkp_gather_rows of mkp_kernels.hip order the row runs.)
+//
+// Semantics follow /root/reference/src (cited inline).  f32 arithmetic is the reference's (contraction off, IEEE division).
+#include "mkp_dev_common.hpp"
+#include "mkp_dev_rows.hpp"
+
+#define SL_WB 16384u           // stored bases per base window of the fused decoder
+#define SL_FW (SL_WB / 32u)    // words of the window's flag bitmaps
+
+// per-wave LDS of mkp_decode_slots*: F = "base is the fundamental base" (bit = nibble index inside the dword, dword k of a word at
+// bits 8k..), P = occurrences before the word (inside the window), B = "occurrence is listed" over the window's occurrences,
+// WP = listed occurrences before the B word
+struct SlotLds { uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+// flag word of a SEQ dword: bit 4n set where nibble n equals the BAM code in `pat`
+__device__ __forceinline__ uint32_t nib_eq(uint32_t x, uint32_t pat) { uint32_t t = x ^ pat; t |= t >> 1; t |= t >> 2; return ~t & 0x11111111u; }
+// the eight flags (bits 4n) gathered into bits n
+__device__ __forceinline__ uint32_t gather8(uint32_t t) { return (((t | (t >> 3)) & 0x03030303u) * 0x01041040u) >> 24; }
+__device__ __forceinline__ uint32_t feat(uint32_t cid, uint32_t tally) { return cid | (tally << 5); }
+
+#define SLOT_PARAMS(PRM) const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ read_ids, const uint32_t* __restrict__ cigar, \
+    const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
+    const MkpLayout* __restrict__ layouts, PRM prm, const uint32_t* __restrict__ slot_pos, uint8_t* __restrict__ cov, MkpVisit* __restrict__ visits, \
+    MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err
+#define SLOT_PASS hdrs, n_reads, read_ids, cigar, seqs, tagref, ranks, ml, layouts, prm, slot_pos, cov, visits, events, readout, dev_err
+
+// The CIGAR as the slot walk sees it: 128 ops per window (two per lane), reference -> query.  re = inclusive reference end of the
+// lane's pair (window-relative), mid = where its second op starts, pk0 / pk1 = ((query start - (reference start - ref_start)) << 2)
+// | kind (0 match: M = X, 1 deletion, 2 ref-skip / nothing) of the two ops.
+struct RefWin {
+  uint32_t c0, q_run, Rtot, Qtot, re, mid, pk0, pk1; int32_t r_run; uint2 pref; bool loaded;
+};
+__device__ __forceinline__ uint2 cigar_pair(const uint32_t* __restrict__ cg, uint32_t n_cigar, uint32_t c) {
+  uint2 r; const uint32_t k = c + 2u * (uint32_t)lane_id();
+  r.x = k < n_cigar ? cg[k] : 5u /* 0H */; r.y = k + 1u < n_cigar ? cg[k + 1u] : 5u;
+  return r;
+}
+__device__ __forceinline__ void refwin_load(RefWin& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start) {
+  const uint2 v = w.pref;
+  w.pref = cigar_pair(cg, n_cigar, w.c0 + 128u);   // requested one window ahead
+  const uint32_t op0 = v.x & 15u, len0 = v.x >> 4, op1 = v.y & 15u, len1 = v.y >> 4;
+  const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
+  const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
+  const uint32_t qe = wave_incl_scan(ql0 + ql1);
+  w.re = wave_incl_scan(rl0 + rl1);
+  w.Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63); w.Rtot = (uint32_t)__builtin_amdgcn_readlane((int)w.re, 63);
+  const uint32_t qs0 = w.q_run + qe - (ql0 + ql1), qs1 = qs0 + ql0;
+  w.mid = w.re - rl1;
+  const int32_t rs0 = w.r_run + (int32_t)(w.re - (rl0 + rl1)), rs1 = w.r_run + (int32_t)w.mid;
+  const uint32_t kind0 = op_is_match(op0) ? 0u : (op0 == 2u ? 1u : 2u), kind1 = op_is_match(op1) ? 0u : (op1 == 2u ? 1u : 2u);
+  w.pk0 = ((uint32_t)((int32_t)qs0 - (rs0 - ref_start)) << 2) | kind0;
+  w.pk1 = ((uint32_t)((int32_t)qs1 - (rs1 - ref_start)) << 2) | kind1;
+  w.loaded = true;
+}
+// (kind, query index) of the reference positions p (ascending over the lanes and from call to call; `valid` lanes lie inside the
+// read's reference span).  htslib pileup columns: M = X -> the base, D -> is_del, N -> is_refskip (pileup/mod.rs:783-851).
+__device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start, bool valid, int32_t p, uint32_t* kind, uint32_t* q) {
+  bool pending = valid; *kind = 2u; *q = 0u;
+  for (;;) {
+    if (!__any(pending)) break;
+    const bool inw = pending && w.loaded && (uint32_t)(p - w.r_run) < w.Rtot;
+    if (!__any(inw)) {
+      if (w.loaded) { w.c0 += 128u; w.q_run += w.Qtot; w.r_run += (int32_t)w.Rtot; }
+      if (w.c0 >= n_cigar) break;   // (cannot happen for positions inside the span)
+      refwin_load(w, cg, n_cigar, ref_start);
+      continue;
+    }
+    const uint32_t rel = inw ? (uint32_t)(p - w.r_run) : 0u;
+    const int ol = find_op(w.re, rel) & 63;
+    const uint32_t o_mid = (uint32_t)__shfl((int)w.mid, ol, 64), o_pk0 = (uint32_t)__shfl((int)w.pk0, ol, 64), o_pk1 = (uint32_t)__shfl((int)w.pk1, ol, 64);
+    const uint32_t pk = rel < o_mid ? o_pk0 : o_pk1;
+    if (inw) { *kind = pk & 3u; *q = (uint32_t)((p - ref_start) + ((int32_t)pk >> 2)); pending = false; }
+  }
+}
+
+// coverage feature of a slot: NoCall(base) on the alignment strand (the base complemented on '-': get_forward_read_base,
+// pileup/mod.rs:612-624), Delete, nothing on a ref-skip, and no feature for a base that is not A/C/G/T (864-874)
+__device__ __forceinline__ uint32_t cover_feature(uint32_t kind, uint32_t nib, uint32_t aln) {
+  if (kind == 1u) return feat(MKP_C_DEL, aln);
+  if (kind != 0u) return MKP_FB_NONE;
+  const int sb = nib2base(nib);
+  if (sb < 0) return MKP_FB_BLANK;
+  return feat((uint32_t)MKP_C_NC + (aln ? 3u - (uint32_t)sb : (uint32_t)sb), aln);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// mkp_decode_slots: MM/ML decode + threshold caller + coverage, slot-driven (see the head of the file).
+// Reference: DeltaListConverter (mod_bam.rs:667-733), get_base_mod_probs (1213-1295), combine_checked (629-656),
+// into_collapsed (530-627), MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63), ReadCache::add_record
+// (read_cache.rs:111-211), get_aligned_pairs_forward (util.rs:122-145), process_region's alignment loop (pileup/mod.rs:783-939).
+template <int NT>
+__device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams&), SlotLds* __restrict__ lds_all) {
+  static_assert(NT <= 2, "one or two tags");
+  const int lane = lane_id();
+  const uint32_t wib = rfl(threadIdx.x >> 6);
+  const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6)) + wib;
+  if (widx >= n_reads) return;
+  const uint32_t rid = rfl(read_ids[widx]);
+  const MkpReadHdr h = hdrs[rid];
+  SlotLds& W = lds_all[wib];
+  const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
+  const uint32_t aln = rev ? 1u : 0u;
+  const uint32_t L = h.l_seq, nd = (L + 7u) >> 3;
+  const uint32_t* __restrict__ seqw = reinterpret_cast<const uint32_t*>(seqs + h.seq_off);   // reads start 4-byte aligned, zero-padded to a dword
+  const uint8_t* __restrict__ seqb = seqs + h.seq_off;
+  const uint32_t* __restrict__ cg = cigar + h.cigar_off;
+  bool have_calls = !(h.flags & MKP_RF_BAD) && h.n_tags != 0;
+  bool err = false;
+
+  // ---- the read's one (mod strand, base) group: wave-uniform tables straight from the layout (scalar loads)
+  const int n_tags = have_calls ? (int)h.n_tags : 0;
+  const uint32_t* __restrict__ layw = reinterpret_cast<const uint32_t*>(&layouts[have_calls ? h.layout : 0u]);
+  const MkpLayout* __restrict__ lay = reinterpret_cast<const MkpLayout*>(layw);
+  int b0 = 0, sg0 = 0; uint32_t xs = 0;
+  GroupRegs grp0; grp0.misc = grp0.slots = grp0.cids = grp0.member_tags = 0; grp0.thr = F4{0.f, 0.f, 0.f, 0.f}; grp0.thr_can = 0.f;
+  uint32_t t_ml[NT], t_nc[NT], tmu[NT];
+  uint32_t t_off = 0, t_n = 0, setmask_all = 0, SH_all = 0, pv = 0, ob_const = 0;
+  int kcodes0 = 0;
+#pragma unroll
+  for (int t = 0; t < NT; t++) { t_ml[t] = 0; t_nc[t] = 0; tmu[t] = 0; }
+  if (have_calls) {
+    b0 = (int)rfl((uint32_t)lay->tags[0].fb) & 3; sg0 = (int)rfl((uint32_t)lay->tags[0].neg) & 1;
+    xs = (uint32_t)(rev ? 3 - b0 : b0);                                    // the stored base the tags count
+    const uint32_t* gp0 = layw + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
+    grp0 = load_group(gp0);
+    grp0.misc = rfl(grp0.misc); grp0.slots = rfl(grp0.slots); grp0.cids = rfl(grp0.cids); grp0.member_tags = rfl(grp0.member_tags);
+#pragma unroll
+    for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float(rfl(__float_as_uint(at(grp0.thr, kq))));
+    grp0.thr_can = __uint_as_float(rfl(__float_as_uint(grp0.thr_can)));
+    kcodes0 = (int)((grp0.misc >> 20) & 7u);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (t < n_tags) {
+        const MkpTagRef tr = tagref[h.tag_off + t]; t_ml[t] = tr.ml_off;
+        if (t == 0) { t_off = tr.rank_off; t_n = tr.n; }
+        t_nc[t] = rfl((uint32_t)lay->tags[t].n_codes);
+        tmu[t] = rfl(lay->tagmap[t][b0]);
+        SH_all |= 1u << (tmu[t] & 15u);
+        for (uint32_t i = 0; i < t_nc[t]; i++) setmask_all |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
+      }
+    }
+    pv = rfl(gp0[12 + SH_all]);       // every call is listed by every tag: one hit pattern
+    { const uint32_t n_post = (pv >> 3) & 7u;   // the codes the caller sees (read_cache.rs:171-179), the same for every call
+      for (uint32_t i = 0; i < n_post && i < MKP_KMAX; i++) ob_const |= 1u << ((grp0.slots >> (8u * ((pv >> (16 + 2 * i)) & 3u))) & 0xffu); }
+    if (t_n == 0) have_calls = false;   // a tag without calls: the record has no modified-base information
+  }
+  const bool collapse = prm.numeric_mode == 2;
+  const uint32_t pat = 0x11111111u << xs;
+  // the low nibble of the last byte is not a base when L is odd
+  const uint32_t odd_dw = (L & 1u) ? ((L - 1u) >> 3) : 0xffffffffu, odd_clear = ~(1u << (8u * (((L - 1u) >> 1) & 3u)));
+
+  // ---- combine_checked's sum test over every listed call (two tags on one base: the second tag's probabilities are added)
+  if (have_calls && NT > 1 && n_tags > 1) {
+    bool bad = false;
+    for (uint32_t j0 = 0; j0 < t_n; j0 += 64) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      if (j < t_n) {
+        F4 pk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+          for (int i = 0; i < MKP_KMAX; i++) {
+            if ((uint32_t)i >= t_nc[t]) break;
+            const float p = ((float)ml[t_ml[t] + j * t_nc[t] + (uint32_t)i] + 0.5f) / 256.0f;
+            setk(pk, (tmu[t] >> (4 + 4 * i)) & 15u, true, p);
+          }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask_all & (1u << k2)) s = s + at(pk, k2);
+        if (s > 1.01f) bad = true;
+      }
+    }
+    if (__any(bad)) err = true;
+  }
+
+  // ---- base windows: stored bases [w0, w0 + SL_WB) swept into F / P
+  uint32_t w0 = 0, cntW = 0, cum = 0, tot = 0, t_cur = 0, t_base = 0;
+  bool bw_loaded = false;
+  auto load4 = [&](uint32_t d) {
+    uint4 x;
+    if (d + 4u <= nd) x = *reinterpret_cast<const uint4*>(seqw + d);
+    else { x.x = d < nd ? seqw[d] : 0u; x.y = d + 1u < nd ? seqw[d + 1u] : 0u; x.z = d + 2u < nd ? seqw[d + 2u] : 0u; x.w = d + 3u < nd ? seqw[d + 3u] : 0u; }
+    return x;
+  };
+  auto flags4 = [&](const uint4& x, uint32_t d, uint32_t* cnt) {
+    uint32_t t0 = nib_eq(x.x, pat), t1 = nib_eq(x.y, pat), t2 = nib_eq(x.z, pat), t3 = nib_eq(x.w, pat);
+    if (odd_dw - d < 4u) { if (d == odd_dw) t0 &= odd_clear; if (d + 1u == odd_dw) t1 &= odd_clear; if (d + 2u == odd_dw) t2 &= odd_clear; if (d + 3u == odd_dw) t3 &= odd_clear; }
+    if (d >= nd) t0 = 0; if (d + 1u >= nd) t1 = 0; if (d + 2u >= nd) t2 = 0; if (d + 3u >= nd) t3 = 0;   // (zero dwords match nothing anyway)
+    *cnt = (uint32_t)__popc(t0) + (uint32_t)__popc(t1) + (uint32_t)__popc(t2) + (uint32_t)__popc(t3);
+    return gather8(t0) | (gather8(t1) << 8) | (gather8(t2) << 16) | (gather8(t3) << 24);
+  };
+  auto sweep = [&]() {   // F, P, cntW of the window at w0
+    const uint32_t nwords = min(SL_FW, (L - w0 + 31u) >> 5);
+    const uint32_t dbase = w0 >> 3;
+    uint32_t carry = 0;
+    uint4 xn = load4(dbase + 4u * (uint32_t)lane);
+    wave_lds_fence();   // the previous window's readers are done (same wave)
+    for (uint32_t i0 = 0; i0 < nwords; i0 += 64) {
+      const uint32_t wi = i0 + (uint32_t)lane, d = dbase + 4u * wi;
+      const uint4 x = xn;
+      if (i0 + 64u < nwords) xn = load4(d + 256u);
+      uint32_t c; const uint32_t Fw = flags4(x, d, &c);
+      const uint32_t inc = wave_incl_scan(c);
+      if (wi < nwords) { W.F[wi] = Fw; W.P[wi] = (uint16_t)(carry + inc - c); }
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    cntW = carry; bw_loaded = true;
+    wave_lds_fence();
+  };
+  auto mark = [&]() {   // B, WP of the window: the listed ranks among its occurrences (stored-order ordinals cum .. cum + cntW)
+    const uint32_t nbw = (cntW + 31u) >> 5;
+    for (uint32_t k = (uint32_t)lane; k < nbw + 1u; k += 64) W.B[k] = 0;
+    wave_lds_fence();
+    t_base = t_cur;
+    if (!rev) {
+      const uint32_t whi = cum + cntW;
+      for (;;) {
+        const uint32_t i = t_cur + (uint32_t)lane; const bool valid = i < t_n;
+        const uint32_t e = valid ? ranks[t_off + i] : 0xffffffffu;
+        const bool hit = valid && e < whi;
+        const uint32_t o = e - cum;
+        if (hit) atomicOr(&W.B[o >> 5], 1u << (o & 31u));
+        const uint32_t nh = (uint32_t)__popcll(__ballot(hit));
+        t_cur += nh;
+        if (nh < 64u) break;
+      }
+    } else {   // forward rank of a stored ordinal o: tot - 1 - o; the list is consumed from its end
+      const uint32_t wlo = tot - cum - cntW;
+      for (;;) {
+        const uint32_t i = t_cur - 64u + (uint32_t)lane; const bool valid = (int32_t)i >= 0 && i < t_cur;
+        const uint32_t e = valid ? ranks[t_off + i] : 0u;
+        const bool hit = valid && e >= wlo;
+        const uint32_t o = (tot - 1u - e) - cum;
+        if (hit) atomicOr(&W.B[o >> 5], 1u << (o & 31u));
+        const uint32_t nh = (uint32_t)__popcll(__ballot(hit));
+        t_cur -= nh;
+        if (nh < 64u) break;
+      }
+    }
+    wave_lds_fence();
+    uint32_t carry = 0;
+    for (uint32_t k0 = 0; k0 < nbw; k0 += 64) {
+      const uint32_t k = k0 + (uint32_t)lane;
+      const uint32_t c = k < nbw ? (uint32_t)__popc(W.B[k]) : 0u;
+      const uint32_t inc = wave_incl_scan(c);
+      if (k < nbw) W.WP[k] = (uint16_t)(carry + inc - c);
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    wave_lds_fence();
+  };
+  if (have_calls && !err) {
+    if (L > SL_WB) {   // several windows: the total is needed up front (reverse reads; the list's last entry)
+      uint32_t acc = 0;
+      for (uint32_t d0 = 0; d0 < nd; d0 += 256) {
+        const uint32_t d = d0 + 4u * (uint32_t)lane;
+        const uint4 x = load4(d);
+        uint32_t c; (void)flags4(x, d, &c); acc += c;
+      }
+      tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
+    } else { sweep(); tot = cntW; }
+    // a delta list must not run past the last occurrence of its base (mod_bam.rs:705-727)
+    if (rfl(ranks[t_off + t_n - 1u]) >= tot) err = true;
+    else { t_cur = rev ? t_n : 0u; if (bw_loaded) mark(); }
+  }
+  if (err) have_calls = false;   // the record only contributes coverage (skip_set, read_cache.rs:272-277)
+
+  // ---- the read's slots, 64 per step
+  const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
+  uint8_t* __restrict__ covp = cov + h.cov_off;
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
+  rw.pref = cigar_pair(cg, h.n_cigar, 0);
+  uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
+  bool gaps = false; uint32_t n_callfeat = 0;
+  for (uint32_t s0 = 0; s0 < n_sl; s0 += 64) {
+    const uint32_t i = s0 + (uint32_t)lane; const bool valid = i < n_sl;
+    const int32_t p = (int32_t)p_next;
+    { const uint32_t in = i + 64u; p_next = in < n_sl ? slot_pos[gs0 + in] : 0u; }
+    uint32_t kind, q;
+    refwin_map(rw, cg, h.n_cigar, h.ref_start, valid, p, &kind, &q);
+    const bool is_match = valid && kind == 0u && q < L;
+    const uint32_t byte = is_match ? (uint32_t)seqb[q >> 1] : 0u;
+    uint32_t call_fb = 0xffffffffu;
+    if (have_calls) {
+      bool pend = is_match;
+      for (;;) {
+        if (!__any(pend)) break;
+        const bool inw = pend && bw_loaded && (q - w0) < SL_WB;
+        if (!__any(inw)) {   // the next base window (never skipped: the occurrence counts run on)
+          if (bw_loaded) { w0 += SL_WB; cum += cntW; }
+          if (w0 >= L) break;
+          sweep(); mark();
+          continue;
+        }
+        const uint32_t qr = inw ? q - w0 : 0u, wv = qr >> 5;
+        const uint32_t Fw = W.F[wv], Pw = W.P[wv];
+        const uint32_t r = qr & 7u, bi = (qr & 24u) | (r ^ 1u);
+        const bool cand = inw && ((Fw >> bi) & 1u);
+        // occurrences before q inside the word: whole dwords below, then the nibbles of the bases before q (base 2j sits in nibble 2j+1)
+        const uint32_t inb = (r & 1u) ? (((1u << (r - 1u)) - 1u) | (1u << r)) : ((1u << r) - 1u);
+        const uint32_t below = ((1u << (qr & 24u)) - 1u) | (inb << (qr & 24u));
+        const uint32_t ord = Pw + (uint32_t)__popc(Fw & below);               // ordinal inside the window, stored order
+        const uint32_t Bw = cand ? W.B[ord >> 5] : 0u;
+        const bool listed = cand && ((Bw >> (ord & 31u)) & 1u);
+        if (__any(listed)) {
+          const uint32_t jrel = (uint32_t)W.WP[listed ? (ord >> 5) : 0u] + (uint32_t)__popc(Bw & ((1u << (ord & 31u)) - 1u));
+          const uint32_t jx = listed ? (rev ? (t_base - 1u - jrel) : (t_base + jrel)) : 0u;
+          uint32_t mlq[NT][MKP_KMAX];
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int k = 0; k < MKP_KMAX; k++) mlq[t][k] = 0;
+            if (t < n_tags) {
+              const uint32_t nc = t_nc[t], base = listed ? (t_ml[t] + jx * nc) : 0u;
+#pragma unroll
+              for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k < nc) mlq[t][k] = ml[base + (listed ? (uint32_t)k : 0u)];
+            }
+          }
+          F4 pk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            if (t >= n_tags) break;
+#pragma unroll
+            for (int k = 0; k < MKP_KMAX; k++) {
+              if ((uint32_t)k >= t_nc[t]) break;
+              const float pr = ((float)mlq[t][k] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
+              setk(pk, (tmu[t] >> (4 + 4 * k)) & 15u, true, pr);
+            }
+          }
+          uint32_t ob = 0;
+          const int cls = call_group(grp0, pv, pk, collapse, &ob, kcodes0);
+          const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
+          if (listed) call_fb = feat(cid, aln ^ (uint32_t)sg0);   // FeatureVector::add_feature's tally (pileup/mod.rs:238-281)
+        }
+        pend = pend && !inw;
+      }
+    }
+    const uint32_t nib = (q & 1u) ? (byte & 15u) : (byte >> 4);
+    uint32_t fb = cover_feature(valid ? kind : 2u, nib, aln);
+    if (valid && kind == 0u && q >= L) fb = MKP_FB_NONE;   // (a CIGAR longer than SEQ is refused by the packer)
+    if (call_fb != 0xffffffffu) { fb = call_fb; n_callfeat++; }
+    if (valid) covp[i] = (uint8_t)fb;
+    gaps = gaps || (valid && fb == MKP_FB_NONE);
+  }
+  gaps = __any(gaps);
+  const bool ok = have_calls;
+  const uint32_t tally = aln ^ (uint32_t)sg0;
+  const uint32_t n_cf = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(n_callfeat), 63);
+  if (lane == 0) {
+    MkpVisit v; v.gs0 = gs0; v.n_sl = n_sl; v.cov_off = h.cov_off;
+    v.flags = (ok ? MKP_VF_OK : 0u) | (rev ? MKP_VF_REV : 0u) | (gaps ? MKP_VF_GAPS : 0u) | ((h.flags >> MKP_RF_KEY_SHIFT) << 8);
+    v.obs0 = (ok && tally == 0u) ? ob_const : 0u; v.obs1 = (ok && tally == 1u) ? ob_const : 0u;
+    v.over_off = 0; v.n_over = 0;
+    visits[rid] = v;
+    MkpReadOut out; out.n_events = ok ? n_cf : 0u; out.ok = ok ? 1u : 0u; out.obs[0] = v.obs0; out.obs[1] = v.obs1;
+    readout[rid] = out;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_slots1(SLOT_PARAMS(MkpRunParams)) {
+  __shared__ __attribute__((aligned(16))) SlotLds lds_all[4];
+  decode_slots_body<1>(SLOT_PASS, lds_all);
+}
+extern "C" __global__ void __launch_bounds__(256) mkp_decode_slots2(SLOT_PARAMS(MkpRunParams)) {
+  __shared__ __attribute__((aligned(16))) SlotLds lds_all[4];
+  decode_slots_body<2>(SLOT_PASS, lds_all);
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// mkp_cover_reads: coverage features of the reads the event-producing decode kernels handled, with their call events merged in.
+// An event's counter id / tally strand are those the decode kernels computed; the first event on a position (bit 12) replaces the
+// NoCall of the base, a second one (pos_call and neg_call on one base, pileup/mod.rs:889-938) goes to the read's overflow list —
+// written over the front of its own event slice, which holds only events already consumed.
+extern "C" __global__ void __launch_bounds__(256) mkp_cover_reads(SLOT_PARAMS(MkpRunParams)) {
+  __shared__ uint32_t stage_all[4][64];
+  const int lane = lane_id();
+  const uint32_t wib = rfl(threadIdx.x >> 6);
+  const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6)) + wib;
+  if (widx >= n_reads) return;
+  const uint32_t rid = rfl(read_ids[widx]);
+  const MkpReadHdr h = hdrs[rid];
+  const MkpReadOut ro = readout[rid];
+  uint32_t* __restrict__ stage = stage_all[wib];
+  const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
+  const uint32_t aln = rev ? 1u : 0u, L = h.l_seq;
+  const uint8_t* __restrict__ seqb = seqs + h.seq_off;
+  const uint32_t* __restrict__ cg = cigar + h.cigar_off;
+  const bool ok = ro.ok == 1u;
+  const uint32_t n_ev = ok ? ro.n_events : 0u;
+  MkpEvent* __restrict__ ev = events + h.event_off;
+  const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
+  uint8_t* __restrict__ covp = cov + h.cov_off;
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
+  rw.pref = cigar_pair(cg, h.n_cigar, 0);
+  uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
+  uint32_t ec = 0, n_over = 0; bool gaps = false;
+  stage[lane] = 0xffffffffu;
+  for (uint32_t s0 = 0; s0 < n_sl; s0 += 64) {
+    const uint32_t i = s0 + (uint32_t)lane; const bool valid = i < n_sl;
+    const int32_t p = (int32_t)p_next;
+    { const uint32_t in = i + 64u; p_next = in < n_sl ? slot_pos[gs0 + in] : 0u; }
+    uint32_t kind, q;
+    refwin_map(rw, cg, h.n_cigar, h.ref_start, valid, p, &kind, &q);
+    const bool is_match = valid && kind == 0u && q < L;
+    const uint32_t byte = is_match ? (uint32_t)seqb[q >> 1] : 0u;
+    const uint32_t nib = (q & 1u) ? (byte & 15u) : (byte >> 4);
+    uint32_t fb = cover_feature(valid ? kind : 2u, nib, aln);
+    if (valid && kind == 0u && q >= L) fb = MKP_FB_NONE;
+    if (ec < n_ev) {
+      // the read's events up to the step's last slot position, 64 at a time; each finds the lane holding its position
+      const uint32_t nval = min(64u, n_sl - s0);
+      const uint32_t pkey = valid ? (uint32_t)p : 0xffffffffu;
+      const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readlane((int)pkey, (int)(nval - 1u));
+      wave_lds_fence();
+      for (;;) {
+        const uint32_t k = ec + (uint32_t)lane; const bool in = k < n_ev;
+        MkpEvent e; e.pos = 0xffffffffu; e.info = 0;
+        if (in) e = ev[k];
+        const bool take = in && e.pos <= p_hi;
+        const int tgt = find_sorted(pkey, take ? e.pos : 0u);
+        const uint32_t tp = (uint32_t)__shfl((int)pkey, tgt & 63, 64);
+        const bool match = take && tgt < 64 && tp == e.pos;
+        const uint32_t eb = feat(e.info & 0x1fu, (e.info >> 8) & 1u);
+        const bool prim = match && (e.info & (1u << 12)), over = match && !(e.info & (1u << 12));
+        if (prim) stage[tgt] = eb;
+        const unsigned long long ob = __ballot(over);
+        if (over) { MkpEvent o; o.pos = gs0 + s0 + (uint32_t)tgt; o.info = eb; ev[n_over + (uint32_t)__popcll(ob & lanemask_lt())] = o; }
+        n_over += (uint32_t)__popcll(ob);
+        const uint32_t nt = (uint32_t)__popcll(__ballot(take));
+        ec += nt;
+        if (nt < 64u) break;
+      }
+      wave_lds_fence();
+      const uint32_t sv = stage[lane];
+      if (sv != 0xffffffffu) { fb = sv; stage[lane] = 0xffffffffu; }
+    }
+    if (valid) covp[i] = (uint8_t)fb;
+    gaps = gaps || (valid && fb == MKP_FB_NONE);
+  }
+  gaps = __any(gaps);
+  if (lane == 0) {
+    MkpVisit v; v.gs0 = gs0; v.n_sl = n_sl; v.cov_off = h.cov_off;
+    v.flags = (ok ? MKP_VF_OK : 0u) | (rev ? MKP_VF_REV : 0u) | (gaps ? MKP_VF_GAPS : 0u) | ((h.flags >> MKP_RF_KEY_SHIFT) << 8);
+    v.obs0 = ok ? ro.obs[0] : 0u; v.obs1 = ok ? ro.obs[1] : 0u;
+    v.over_off = h.event_off; v.n_over = n_over;
+    visits[rid] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// mkp_pileup_stream: accumulate + emit over the feature stream.  LDS: [counter | observed-code slot][S] packed tallies ('+' tally
+// in the low, '-' in the high 16 bits; the host refuses shards with more than 65535 records over one position) + the tile's slot
+// positions.  Waves draw the tile's candidate reads from an LDS ticket; a visit = the read's MkpVisit (scalar loads, the next one
+// requested ahead), its bytes for the tile's slots (a dword per lane), one LDS atomic per feature.  Observed codes: +1 / -1 at
+// the ends of the read's slot range (and at every change between covered and not covered when the read holds ref-skips).
+struct StreamSlotMap {
+  const int32_t* fpos; uint32_t n;
+  __device__ __forceinline__ int32_t pos_of(uint32_t c) const { return fpos[c]; }
+  __device__ __forceinline__ uint32_t rank(int32_t p) const {   // first column whose position is >= p
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fpos[mid] < p) lo = mid + 1u; else hi = mid; }
+    return lo;
+  }
+};
+
+template <bool KEYED>
+__device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events,
+                 const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
+                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
+                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg) {
+  const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = KEYED ? (key_arg >> 16) : 0u;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t next_read;
+  __shared__ uint32_t wave_tot[PILEUP_WAVES];
+  __shared__ uint32_t row_base, scan_carry;
+  __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];
+  for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += PILEUP_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
+  for (uint32_t kq = threadIdx.x; kq < prmp->n_combos * (sizeof(MkpCombo) / 4); kq += PILEUP_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
+  __syncthreads();
+  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
+  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
+  const uint32_t S = prm.slot_cap;
+  const uint32_t n_counters = prm.n_counters, n_oslots = prm.n_slots;
+  const uint32_t tal_words = (n_counters + n_oslots) * S;
+  uint32_t* __restrict__ tal = lds;
+  uint32_t* __restrict__ obs = lds + n_counters * S;
+  int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(lds + tal_words);
+  const int lane = lane_id();
+  const uint32_t wave = rfl(threadIdx.x >> 6);
+  // XCD-aware mapping: consecutive workgroups land on different XCDs; give each XCD a contiguous run of tiles so that the reads
+  // neighbouring tiles share stay in one L2
+  uint32_t tix = blockIdx.x;
+  { const uint32_t per = n_tiles / 8u; if (per && tix < per * 8u) tix = (tix & 7u) * per + (tix >> 3); }
+  const MkpSTile tl = tiles[tix];
+  const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
+  for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
+  for (uint32_t k = threadIdx.x; k < n_tslots; k += PILEUP_THREADS) fpos[k] = (int32_t)slot_pos[gh0 + k];
+  if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }
+  __syncthreads();
+
+  const uint32_t rid_end = tl.last;
+  const uint32_t talbase = lds_addr(tal), S4 = S * 4u;
+  uint32_t rid_nx; MkpVisit v_nx;
+  { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 1u); rid_nx = rfl(ticket); }
+  v_nx = visits[min(rid_nx, rid_end - 1u)];   // (tiles hold at least one candidate read)
+  for (;;) {
+    const uint32_t rid = rid_nx;
+    if (rid >= rid_end) break;
+    const MkpVisit v = v_nx;
+    { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 1u); rid_nx = rfl(ticket); }
+    v_nx = visits[min(rid_nx, rid_end - 1u)];
+    const uint32_t a = max(v.gs0, gh0), b = min(v.gs0 + v.n_sl, gh1);
+    if (a >= b) continue;
+    if (KEYED && (v.flags >> 8) != key_filter) continue;   // --partition-tag: one pass per key
+    const uint32_t k_lo = a - v.gs0, k_hi = b - v.gs0;      // the read's bytes for this tile
+    const uint32_t col0 = v.gs0 - gh0;                      // column of byte k = col0 + k (mod 2^32)
+    const uint8_t* __restrict__ cp = cov + v.cov_off;
+    // the stream: a dword (four slots) per lane, requested before the observed-code updates
+    const uint32_t kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
+    uint32_t wcur = kfirst < k_hi ? *reinterpret_cast<const uint32_t*>(cp + kfirst) : 0xffffffffu;
+    // observed mod codes over the columns the read is in (add_mod_codes_for_record, pileup/mod.rs:831-835)
+    if ((v.flags & MKP_VF_OK) && (v.obs0 | v.obs1)) {
+      if (!(v.flags & MKP_VF_GAPS)) {
+        if (lane < 2) {
+          uint32_t m = lane ? v.obs1 : v.obs0;
+          const uint32_t inc = lane ? 0x10000u : 1u;
+          while (m) {
+            const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
+            atomicAdd(&obs[sl * S + (a - gh0)], inc);
+            if (b - gh0 < n_tslots) atomicAdd(&obs[sl * S + (b - gh0)], 0u - inc);
+          }
+        }
+      } else {   // ref-skips: the read is not in those columns (alignment.is_refskip()) — a change of state per boundary
+        for (uint32_t k = k_lo + (uint32_t)lane; k <= k_hi; k += 64) {
+          const bool cur = k < k_hi && cp[k] != MKP_FB_NONE, prev = k > k_lo && cp[k - 1u] != MKP_FB_NONE;
+          const uint32_t col = col0 + k;
+          if (cur != prev && col < n_tslots) for (uint32_t s = 0; s < 2; s++) {
+            uint32_t m = s ? v.obs1 : v.obs0;
+            const uint32_t inc = s ? 0x10000u : 1u;
+            while (m) { const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u; atomicAdd(&obs[sl * S + col], cur ? inc : 0u - inc); }
+          }
+        }
+      }
+    }
+    for (uint32_t k = kfirst;; k += 256u) {
+      const uint32_t w = wcur;
+      const uint32_t kn = k + 256u;
+      wcur = kn < k_hi ? *reinterpret_cast<const uint32_t*>(cp + kn) : 0xffffffffu;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t fb = (w >> (8u * j)) & 0xffu, kk = k + j;
+        if (fb < 0x40u && kk >= k_lo && kk < k_hi)
+          lds_add(talbase + 4u * (col0 + kk) + __umul24(fb & 31u, S4), (fb & 32u) ? 0x10000u : 1u);
+      }
+      if (!__any(kn < k_hi)) break;
+    }
+    if (v.n_over) {   // second features on one column
+      for (uint32_t k = (uint32_t)lane; k < v.n_over; k += 64) {
+        const MkpEvent e = events[v.over_off + k];
+        if (e.pos >= gh0 && e.pos < gh1) lds_add(talbase + 4u * (e.pos - gh0) + __umul24(e.info & 31u, S4), (e.info & 32u) ? 0x10000u : 1u);
+      }
+    }
+  }
+  __syncthreads();
+  // observed-code difference arrays -> counts, in place and still packed
+  for (uint32_t a = wave; a < n_oslots; a += PILEUP_WAVES) {
+    uint32_t* __restrict__ arr = obs + a * S;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < n_tslots; b0 += 64) {
+      const uint32_t vv = (b0 + lane < n_tslots) ? arr[b0 + lane] : 0u;
+      const uint32_t sc = wave_incl_scan(vv);
+      if (b0 + lane < n_tslots) arr[b0 + lane] = sc + carry;
+      carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
+    }
+  }
+  if (threadIdx.x == 0) scan_carry = 0;
+  __syncthreads();
+  StreamSlotMap sm; sm.fpos = fpos; sm.n = n_tslots;
+  MkpTile tl2; tl2.r0 = tl.r0; tl2.r1 = tl.r1; tl2.first = tl.first; tl2.last = tl.last;
+  emit_tile_rows<true, false>(tal, sm, n_tslots, tl2, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+}
+
+#define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \
+    const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, \
+    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg
+#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true>(STREAM_PASS); }
+
+// ----------------------------------------------------------------------------------------------------------------------
+// host-side launchers (called from mkp_api.cpp)
+// slot_ids = [fused one tag | fused two tags | cover], n_slot_class = the three list lengths
+extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* slot_ids, const uint32_t* n_slot_class /* [3] */, const uint32_t* cigar,
+                                       const uint8_t* seqs, const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts, const MkpRunParams* prm,
+                                       const uint32_t* slot_pos, uint8_t* cov, MkpVisit* visits, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err) {
+  const uint32_t* ids = slot_ids;
+  for (int cls = 0; cls < 3; cls++) {
+    const uint32_t n = n_slot_class[cls];
+    if (n) {
+      dim3 grid((n + 3u) / 4u), block(256);
+#define MKP_SLOT_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, ids, cigar, seqs, tagref, ranks, ml, layouts, *prm, slot_pos, cov, visits, events, readout, dev_err)
+      if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1); else if (cls == 1) MKP_SLOT_LAUNCH(mkp_decode_slots2); else MKP_SLOT_LAUNCH(mkp_cover_reads);
+    }
+    ids += n;
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
+  for (const void* k : {(const void*)mkp_pileup_stream, (const void*)mkp_pileup_stream_keyed}) {
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
+                                        const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot) {
+  if (!n_tiles) return hipSuccess;
+  const bool keyed = key_filter != MKP_NO_KEY_FILTER;
+  const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
+#define MKP_STREAM_LAUNCH(K) hipLaunchKernelGGL(K, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, visits, cov, events, tiles, n_tiles, prm_dev, slot_pos, focus, combos, rows->pos, row_cursor, \
+                                                tile_row_off, tile_row_cnt, dev_err, key_arg)
+  if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed); else MKP_STREAM_LAUNCH(mkp_pileup_stream);
+  return hipGetLastError();
+}
