@@ -172,6 +172,25 @@ void make_resident(mkp_ctx* c) {
   }
   // decode kernel classes; a duplex read decoded one group per wave needs room for both groups' lists behind the merged one
   std::vector<uint32_t> class_list; class_ids(S, c->tables, &class_list, c->n_class, true);
+  // SPARSE reads with two tags: combine_checked's test (mod_bam.rs:629-656) that a call's probabilities over both tags do not add up
+  // to more than 1.01 — every term is (2q + 1) / 512, so the f32 sum is exact and `> 1.01f` is "the numerators reach 518" — is made
+  // here over the ML bytes, on all cores, and handed to the slot decoder as a header flag
+  host_parallel(c->n_class[1], 2048, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; k++) {
+      MkpReadHdr& h = S.hdr[class_list[c->n_class[0] + k]];
+      const MkpLayout& L = c->tables.dev[h.layout];
+      const MkpTagRef &t0 = S.tagref[h.tag_off], &t1 = S.tagref[h.tag_off + 1];
+      const uint32_t nc0 = L.tags[0].n_codes, nc1 = L.tags[1].n_codes;
+      bool bad = false;
+      for (uint32_t j = 0; j < t0.n && !bad; j++) {
+        uint32_t num = 0;
+        for (uint32_t i = 0; i < nc0; i++) num += 2u * S.ml[t0.ml_off + j * nc0 + i] + 1u;
+        for (uint32_t i = 0; i < nc1; i++) num += 2u * S.ml[t1.ml_off + j * nc1 + i] + 1u;
+        bad = num >= 518u;
+      }
+      if (bad) h.flags |= MKP_RF_SUMERR; else h.flags &= ~MKP_RF_SUMERR;
+    }
+  });
   { size_t at = 0; for (int k = 0; k < 5; k++) at += c->n_class[k];
     for (; at < class_list.size(); at += 2) {
       MkpReadHdr& h = S.hdr[class_list[at]];

@@ -43,7 +43,7 @@ struct MkpReadHdr {
   uint32_t tag_off;     // index into tagref[]
   uint16_t n_tags;
   uint16_t layout;
-  uint32_t flags;       // bit0 reverse; bit1 host-detected tag error (coverage-only read); bits 8.. partition key id (0 = ungrouped)
+  uint32_t flags;       // bit0 reverse; bit1 host-detected tag error (coverage-only read); bit2 MKP_RF_SUMERR; bits 8.. partition key id (0 = ungrouped)
   uint32_t event_off;   // index into events[]
   uint32_t event_cap;
   uint32_t chunk_off;   // index into chunk_pfx[]: one {query offset, reference offset} per 64 CIGAR ops of this read
@@ -54,6 +54,7 @@ struct MkpReadHdr {
 };
 #define MKP_RF_REVERSE 1u
 #define MKP_RF_BAD 2u
+#define MKP_RF_SUMERR 4u   // host planner: some call's probabilities over the read's two tags add up to more than 1.01 (combine_checked, mod_bam.rs:629-656)
 #define MKP_RF_KEY_SHIFT 8
 #define MKP_NO_KEY_FILTER 0xffffffffu
 

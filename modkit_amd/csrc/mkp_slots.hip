@@ -22,6 +22,8 @@
 //   (mkp_scan_tiles + mkp_gather_rows of mkp_kernels.hip order the row runs.)
 //
 // Semantics follow /root/reference/src (cited inline).  f32 arithmetic is the reference's (contraction off, IEEE division).
+#include <cstdlib>
+
 #include "mkp_dev_common.hpp"
 #include "mkp_dev_rows.hpp"
 
@@ -31,7 +33,8 @@
 // per-wave LDS of mkp_decode_slots*: F = "base is the fundamental base" (bit = nibble index inside the dword, dword k of a word at
 // bits 8k..), P = occurrences before the word (inside the window), B = "occurrence is listed" over the window's occurrences,
 // WP = listed occurrences before the B word
-struct SlotLds { uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
+#define SL_BCAP (SL_WB / 2u)   // occurrences of the fundamental base a window's B bitmap holds (half-size windows beyond that)
+struct SlotLds { uint32_t F[SL_FW]; uint32_t B[SL_BCAP / 32u + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_BCAP / 32u + 2]; };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -111,6 +114,11 @@ __device__ __forceinline__ uint32_t cover_feature(uint32_t kind, uint32_t nib, u
 // Reference: DeltaListConverter (mod_bam.rs:667-733), get_base_mod_probs (1213-1295), combine_checked (629-656),
 // into_collapsed (530-627), MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63), ReadCache::add_record
 // (read_cache.rs:111-211), get_aligned_pairs_forward (util.rs:122-145), process_region's alignment loop (pileup/mod.rs:783-939).
+// One wave runs one read start to end, so what bounds the kernel is the chain of dependent memory round trips per read, not
+// instruction issue: everything that depends only on the header (first slots, first CIGAR window, the first 8192 bases) is
+// requested before the layout tables are looked at and the sweep issues four 16-byte loads per lane at a time.  Measured (SQ
+// counters, C3): the kernel is VALU-issue bound (~80 % of the SIMD cycles), so the per-base and per-slot instruction counts matter:
+// three VALU per SEQ dword for the flags, one popcount per 32 bases, the caller resolved to a fixed walk per read.
 template <int NT>
 __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams&), SlotLds* __restrict__ lds_all) {
   static_assert(NT <= 2, "one or two tags");
@@ -128,7 +136,27 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   const uint8_t* __restrict__ seqb = seqs + h.seq_off;
   const uint32_t* __restrict__ cg = cigar + h.cigar_off;
   bool have_calls = !(h.flags & MKP_RF_BAD) && h.n_tags != 0;
-  bool err = false;
+  // combine_checked's sum test (mod_bam.rs:629-656) — two tags on one base: the probabilities of a call add up to more than 1.01 —
+  // is made by the host planner over the ML bytes (the f32 sums are exact multiples of 1/512: an integer comparison)
+  const bool err_sum = (h.flags & MKP_RF_SUMERR) != 0;
+  const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
+  uint8_t* __restrict__ covp = cov + h.cov_off;
+
+  // ---- requests that depend on the header alone
+  // 16 bytes of SEQ at dword d.  The address is clamped to the read's last dword (the SEQ buffer has slack behind the last read)
+  // and dwords past the read come back as zero: no divergent tail path.
+  auto load4 = [&](uint32_t d) {
+    uint4 x = *reinterpret_cast<const uint4*>(seqw + min(d, nd - 1u));
+    if (__any(d + 4u > nd)) { if (d >= nd) x.x = 0u; if (d + 1u >= nd) x.y = 0u; if (d + 2u >= nd) x.z = 0u; if (d + 3u >= nd) x.w = 0u; }
+    return x;
+  };
+  uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
+  rw.pref = cigar_pair(cg, h.n_cigar, 0);
+  uint4 xpre[4];   // stored bases [0, 8192): a 16-byte vector per lane and 2048 bases
+#pragma unroll
+  for (int j = 0; j < 4; j++) xpre[j] = (have_calls && 2048u * (uint32_t)j < L) ? load4(4u * (64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t pad_nib = (L & 1u) ? ((uint32_t)seqb[L >> 1] & 15u) : 0u;   // the low nibble of the last byte is not a base when L is odd
 
   // ---- the read's one (mod strand, base) group: wave-uniform tables straight from the layout (scalar loads)
   const int n_tags = have_calls ? (int)h.n_tags : 0;
@@ -137,11 +165,26 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   int b0 = 0, sg0 = 0; uint32_t xs = 0;
   GroupRegs grp0; grp0.misc = grp0.slots = grp0.cids = grp0.member_tags = 0; grp0.thr = F4{0.f, 0.f, 0.f, 0.f}; grp0.thr_can = 0.f;
   uint32_t t_ml[NT], t_nc[NT], tmu[NT];
-  uint32_t t_off = 0, t_n = 0, setmask_all = 0, SH_all = 0, pv = 0, ob_const = 0;
+  uint32_t t_off = 0, t_n = 0, SH_all = 0, pv = 0, ob_const = 0;
   int kcodes0 = 0;
 #pragma unroll
   for (int t = 0; t < NT; t++) { t_ml[t] = 0; t_nc[t] = 0; tmu[t] = 0; }
+  uint32_t e_pre = 0, e_last = 0;   // the first 64 entries of the rank list as the first window consumes it, and its last entry
+  // the caller's walk over the call's map in iteration order, resolved once per read: where the ML byte of the i-th code sits
+  // (offset + stride per call), its pass threshold and the counter of Modified(code)
+  uint32_t it_off[MKP_KMAX], it_stride[MKP_KMAX], it_cid[MKP_KMAX]; float it_thr[MKP_KMAX]; uint32_t n_post = 0;
+#pragma unroll
+  for (int i = 0; i < MKP_KMAX; i++) { it_off[i] = 0; it_stride[i] = 0; it_cid[i] = 0; it_thr[i] = 0.f; }
   if (have_calls) {
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      if (t < n_tags) { const MkpTagRef tr = tagref[h.tag_off + t]; t_ml[t] = tr.ml_off; if (t == 0) { t_off = tr.rank_off; t_n = tr.n; } }
+    }
+    if (t_n) {
+      const uint32_t i = rev ? t_n - 64u + (uint32_t)lane : (uint32_t)lane;
+      e_pre = ((int32_t)i >= 0 && i < t_n) ? ranks[t_off + i] : (rev ? 0u : 0xffffffffu);
+      e_last = ranks[t_off + t_n - 1u];
+    }
     b0 = (int)rfl((uint32_t)lay->tags[0].fb) & 3; sg0 = (int)rfl((uint32_t)lay->tags[0].neg) & 1;
     xs = (uint32_t)(rev ? 3 - b0 : b0);                                    // the stored base the tags count
     const uint32_t* gp0 = layw + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
@@ -154,82 +197,75 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       if (t < n_tags) {
-        const MkpTagRef tr = tagref[h.tag_off + t]; t_ml[t] = tr.ml_off;
-        if (t == 0) { t_off = tr.rank_off; t_n = tr.n; }
         t_nc[t] = rfl((uint32_t)lay->tags[t].n_codes);
         tmu[t] = rfl(lay->tagmap[t][b0]);
         SH_all |= 1u << (tmu[t] & 15u);
-        for (uint32_t i = 0; i < t_nc[t]; i++) setmask_all |= 1u << ((tmu[t] >> (4 + 4 * i)) & 15u);
       }
     }
     pv = rfl(gp0[12 + SH_all]);       // every call is listed by every tag: one hit pattern
-    { const uint32_t n_post = (pv >> 3) & 7u;   // the codes the caller sees (read_cache.rs:171-179), the same for every call
-      for (uint32_t i = 0; i < n_post && i < MKP_KMAX; i++) ob_const |= 1u << ((grp0.slots >> (8u * ((pv >> (16 + 2 * i)) & 3u))) & 0xffu); }
-    if (t_n == 0) have_calls = false;   // a tag without calls: the record has no modified-base information
-  }
-  const bool collapse = prm.numeric_mode == 2;
-  const uint32_t pat = 0x11111111u << xs;
-  // the low nibble of the last byte is not a base when L is odd
-  const uint32_t odd_dw = (L & 1u) ? ((L - 1u) >> 3) : 0xffffffffu, odd_clear = ~(1u << (8u * (((L - 1u) >> 1) & 3u)));
-
-  // ---- combine_checked's sum test over every listed call (two tags on one base: the second tag's probabilities are added)
-  if (have_calls && NT > 1 && n_tags > 1) {
-    bool bad = false;
-    for (uint32_t j0 = 0; j0 < t_n; j0 += 64) {
-      const uint32_t j = j0 + (uint32_t)lane;
-      if (j < t_n) {
-        F4 pk = {0.f, 0.f, 0.f, 0.f};
+    n_post = min((pv >> 3) & 7u, (uint32_t)MKP_KMAX);
+#pragma unroll
+    for (int i = 0; i < MKP_KMAX; i++) {
+      if ((uint32_t)i < n_post) {
+        const uint32_t kq = (pv >> (16 + 2 * i)) & 3u;      // local code of the i-th entry of the map as the caller iterates it
+        ob_const |= 1u << ((grp0.slots >> (8u * kq)) & 0xffu);   // the codes the caller sees (read_cache.rs:171-179), the same for every call
+        it_cid[i] = (grp0.cids >> (8u * kq)) & 0xffu; it_thr[i] = getk(grp0.thr, (int)kq);
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-#pragma unroll
-          for (int i = 0; i < MKP_KMAX; i++) {
-            if ((uint32_t)i >= t_nc[t]) break;
-            const float p = ((float)ml[t_ml[t] + j * t_nc[t] + (uint32_t)i] + 0.5f) / 256.0f;
-            setk(pk, (tmu[t] >> (4 + 4 * i)) & 15u, true, p);
-          }
+          if (t < n_tags) for (uint32_t k = 0; k < t_nc[t]; k++) if (((tmu[t] >> (4 + 4 * k)) & 15u) == kq) { it_off[i] = t_ml[t] + k; it_stride[i] = t_nc[t]; }
         }
-        float s = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask_all & (1u << k2)) s = s + at(pk, k2);
-        if (s > 1.01f) bad = true;
       }
     }
-    if (__any(bad)) err = true;
+    if (t_n == 0) have_calls = false;   // a tag without calls: the record has no modified-base information
   }
+  bool err = have_calls && err_sum;
+  const bool collapse = prm.numeric_mode == 2;
+  const uint32_t pat = 0x11111111u << xs;
+  const bool pad_hit = (L & 1u) && pad_nib == (1u << xs);
 
-  // ---- base windows: stored bases [w0, w0 + SL_WB) swept into F / P
-  uint32_t w0 = 0, cntW = 0, cum = 0, tot = 0, t_cur = 0, t_base = 0;
-  bool bw_loaded = false;
-  auto load4 = [&](uint32_t d) {
-    uint4 x;
-    if (d + 4u <= nd) x = *reinterpret_cast<const uint4*>(seqw + d);
-    else { x.x = d < nd ? seqw[d] : 0u; x.y = d + 1u < nd ? seqw[d + 1u] : 0u; x.z = d + 2u < nd ? seqw[d + 2u] : 0u; x.w = d + 3u < nd ? seqw[d + 3u] : 0u; }
-    return x;
+  // ---- base windows: stored bases [w0, w0 + wb) swept into F / P.  wb = SL_WB unless a window holds more occurrences of the
+  // base than the B bitmap has bits (more than half of 16384 bases one base): then the read goes on with half-size windows.
+  // F word = 32 bases = 4 SEQ dwords: the flag of nibble n of dword k sits at bit 4n + 3 - k (base 2j of a dword is nibble 2j+1).
+  uint32_t w0 = 0, wb = SL_WB, cntW = 0, cum = 0, tot = 0, t_cur = 0, t_base = 0;
+  bool bw_loaded = false, first_mark = true, xpre_live = true;
+  auto flags4 = [&](const uint4& x) {   // "nibble != base" lands on bit 3 of the nibble after two shift-ors; the four dwords interleave
+    uint32_t n0 = x.x ^ pat, n1 = x.y ^ pat, n2 = x.z ^ pat, n3 = x.w ^ pat;
+    n0 |= n0 << 1; n1 |= n1 << 1; n2 |= n2 << 1; n3 |= n3 << 1;
+    n0 |= n0 << 2; n1 |= n1 << 2; n2 |= n2 << 2; n3 |= n3 << 2;
+    const uint32_t a = (n0 & 0x88888888u) | ((n1 >> 1) & ~0x88888888u), b = ((n2 >> 2) & 0x22222222u) | ((n3 >> 3) & ~0x22222222u);
+    return ~((a & 0xccccccccu) | (b & ~0xccccccccu));
   };
-  auto flags4 = [&](const uint4& x, uint32_t d, uint32_t* cnt) {
-    uint32_t t0 = nib_eq(x.x, pat), t1 = nib_eq(x.y, pat), t2 = nib_eq(x.z, pat), t3 = nib_eq(x.w, pat);
-    if (odd_dw - d < 4u) { if (d == odd_dw) t0 &= odd_clear; if (d + 1u == odd_dw) t1 &= odd_clear; if (d + 2u == odd_dw) t2 &= odd_clear; if (d + 3u == odd_dw) t3 &= odd_clear; }
-    if (d >= nd) t0 = 0; if (d + 1u >= nd) t1 = 0; if (d + 2u >= nd) t2 = 0; if (d + 3u >= nd) t3 = 0;   // (zero dwords match nothing anyway)
-    *cnt = (uint32_t)__popc(t0) + (uint32_t)__popc(t1) + (uint32_t)__popc(t2) + (uint32_t)__popc(t3);
-    return gather8(t0) | (gather8(t1) << 8) | (gather8(t2) << 16) | (gather8(t3) << 24);
-  };
-  auto sweep = [&]() {   // F, P, cntW of the window at w0
-    const uint32_t nwords = min(SL_FW, (L - w0 + 31u) >> 5);
+  auto sweep = [&]() {   // F, P, cntW of the window at w0; four vectors per lane (8192 bases) in flight at a time
+    const uint32_t nwords = min(wb >> 5, (L - w0 + 31u) >> 5);
     const uint32_t dbase = w0 >> 3;
     uint32_t carry = 0;
-    uint4 xn = load4(dbase + 4u * (uint32_t)lane);
     wave_lds_fence();   // the previous window's readers are done (same wave)
-    for (uint32_t i0 = 0; i0 < nwords; i0 += 64) {
-      const uint32_t wi = i0 + (uint32_t)lane, d = dbase + 4u * wi;
-      const uint4 x = xn;
-      if (i0 + 64u < nwords) xn = load4(d + 256u);
-      uint32_t c; const uint32_t Fw = flags4(x, d, &c);
-      const uint32_t inc = wave_incl_scan(c);
-      if (wi < nwords) { W.F[wi] = Fw; W.P[wi] = (uint16_t)(carry + inc - c); }
-      carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    for (uint32_t i0 = 0; i0 < nwords; i0 += 256) {
+      uint4* x = xpre;   // (the vectors requested at the top serve the first 8192 bases)
+      if (!(w0 == 0 && i0 == 0 && xpre_live)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = (i0 + 64u * (uint32_t)j < nwords) ? load4(dbase + 4u * (i0 + 64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (i0 + 64u * (uint32_t)j < nwords) {
+          const uint32_t wi = i0 + 64u * (uint32_t)j + (uint32_t)lane;
+          const uint32_t Fw = flags4(x[j]), c = (uint32_t)__popc(Fw);
+          const uint32_t inc = wave_incl_scan(c);
+          if (wi < nwords) { W.F[wi] = Fw; W.P[wi] = (uint16_t)(carry + inc - c); }
+          carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        }
+      }
+    }
+    xpre_live = w0 == 0u && nwords <= 256u;
+    wave_lds_fence();
+    if (pad_hit && L - w0 < (nwords << 5)) {   // the pad nibble matched: take its flag back (it lies behind every base)
+      const uint32_t qr = L - w0;
+      if (lane == 0) W.F[qr >> 5] &= ~(1u << (4u * ((qr & 7u) ^ 1u) + 3u - ((qr >> 3) & 3u)));
+      carry -= 1u;
+      wave_lds_fence();
     }
     cntW = carry; bw_loaded = true;
-    wave_lds_fence();
   };
   auto mark = [&]() {   // B, WP of the window: the listed ranks among its occurrences (stored-order ordinals cum .. cum + cntW)
     const uint32_t nbw = (cntW + 31u) >> 5;
@@ -240,7 +276,8 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
       const uint32_t whi = cum + cntW;
       for (;;) {
         const uint32_t i = t_cur + (uint32_t)lane; const bool valid = i < t_n;
-        const uint32_t e = valid ? ranks[t_off + i] : 0xffffffffu;
+        const uint32_t e = first_mark ? e_pre : (valid ? ranks[t_off + i] : 0xffffffffu);
+        first_mark = false;
         const bool hit = valid && e < whi;
         const uint32_t o = e - cum;
         if (hit) atomicOr(&W.B[o >> 5], 1u << (o & 31u));
@@ -252,7 +289,8 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
       const uint32_t wlo = tot - cum - cntW;
       for (;;) {
         const uint32_t i = t_cur - 64u + (uint32_t)lane; const bool valid = (int32_t)i >= 0 && i < t_cur;
-        const uint32_t e = valid ? ranks[t_off + i] : 0u;
+        const uint32_t e = first_mark ? e_pre : (valid ? ranks[t_off + i] : 0u);
+        first_mark = false;
         const bool hit = valid && e >= wlo;
         const uint32_t o = (tot - 1u - e) - cum;
         if (hit) atomicOr(&W.B[o >> 5], 1u << (o & 31u));
@@ -275,28 +313,29 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   if (have_calls && !err) {
     if (L > SL_WB) {   // several windows: the total is needed up front (reverse reads; the list's last entry)
       uint32_t acc = 0;
-      for (uint32_t d0 = 0; d0 < nd; d0 += 256) {
-        const uint32_t d = d0 + 4u * (uint32_t)lane;
-        const uint4 x = load4(d);
-        uint32_t c; (void)flags4(x, d, &c); acc += c;
+      for (uint32_t d0 = 0; d0 < nd; d0 += 1024) {
+        uint4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = d0 == 0 ? xpre[j] : load4(d0 + 256u * (uint32_t)j + 4u * (uint32_t)lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc += (uint32_t)__popc(flags4(x[j]));
       }
-      tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63);
+      tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(acc), 63) - (pad_hit ? 1u : 0u);
     } else { sweep(); tot = cntW; }
     // a delta list must not run past the last occurrence of its base (mod_bam.rs:705-727)
-    if (rfl(ranks[t_off + t_n - 1u]) >= tot) err = true;
-    else { t_cur = rev ? t_n : 0u; if (bw_loaded) mark(); }
+    if (rfl(e_last) >= tot) err = true;
+    else {
+      t_cur = rev ? t_n : 0u;
+      if (bw_loaded) { if (cntW > SL_BCAP) { wb = SL_WB / 2u; sweep(); } mark(); }
+    }
   }
   if (err) have_calls = false;   // the record only contributes coverage (skip_set, read_cache.rs:272-277)
 
   // ---- the read's slots, 64 per step
-  const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
-  uint8_t* __restrict__ covp = cov + h.cov_off;
-  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
-  rw.pref = cigar_pair(cg, h.n_cigar, 0);
-  uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
   bool gaps = false; uint32_t n_callfeat = 0;
-  for (uint32_t s0 = 0; s0 < n_sl; s0 += 64) {
-    const uint32_t i = s0 + (uint32_t)lane; const bool valid = i < n_sl;
+  for (uint32_t s0 = 0; s0 < n_sl; s0 += 64u) {
+    const uint32_t i = s0 + (uint32_t)lane;
+    const bool valid = i < n_sl;
     const int32_t p = (int32_t)p_next;
     { const uint32_t in = i + 64u; p_next = in < n_sl ? slot_pos[gs0 + in] : 0u; }
     uint32_t kind, q;
@@ -308,51 +347,76 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
       bool pend = is_match;
       for (;;) {
         if (!__any(pend)) break;
-        const bool inw = pend && bw_loaded && (q - w0) < SL_WB;
+        const bool inw = pend && bw_loaded && (q - w0) < wb;
         if (!__any(inw)) {   // the next base window (never skipped: the occurrence counts run on)
-          if (bw_loaded) { w0 += SL_WB; cum += cntW; }
+          if (bw_loaded) { w0 += wb; cum += cntW; }
           if (w0 >= L) break;
-          sweep(); mark();
+          sweep();
+          if (cntW > SL_BCAP) { wb = SL_WB / 2u; sweep(); }
+          mark();
           continue;
         }
         const uint32_t qr = inw ? q - w0 : 0u, wv = qr >> 5;
         const uint32_t Fw = W.F[wv], Pw = W.P[wv];
-        const uint32_t r = qr & 7u, bi = (qr & 24u) | (r ^ 1u);
-        const bool cand = inw && ((Fw >> bi) & 1u);
-        // occurrences before q inside the word: whole dwords below, then the nibbles of the bases before q (base 2j sits in nibble 2j+1)
-        const uint32_t inb = (r & 1u) ? (((1u << (r - 1u)) - 1u) | (1u << r)) : ((1u << r) - 1u);
-        const uint32_t below = ((1u << (qr & 24u)) - 1u) | (inb << (qr & 24u));
-        const uint32_t ord = Pw + (uint32_t)__popc(Fw & below);               // ordinal inside the window, stored order
+        const uint32_t r = qr & 7u, kd = (qr >> 3) & 3u, sh = 3u - kd;
+        const bool cand = inw && ((Fw >> (4u * (r ^ 1u) + sh)) & 1u);
+        // occurrences before q inside the word: the dwords below (bit offsets above 3 - kd in every nibble), then the nibbles of
+        // the bases before q in its own dword (base 2j sits in nibble 2j+1)
+        const uint32_t m_dw = ~((0x11111111u << (4u - kd)) - 0x11111111u);
+        const uint32_t re4 = (r & 6u) << 2;
+        const uint32_t m_in = (((1u << re4) - 1u) & 0x11111111u) | ((r & 1u) << (4u * r));
+        const uint32_t ord = Pw + (uint32_t)__popc(Fw & (m_dw | (m_in << sh)));               // ordinal inside the window, stored order
         const uint32_t Bw = cand ? W.B[ord >> 5] : 0u;
         const bool listed = cand && ((Bw >> (ord & 31u)) & 1u);
         if (__any(listed)) {
           const uint32_t jrel = (uint32_t)W.WP[listed ? (ord >> 5) : 0u] + (uint32_t)__popc(Bw & ((1u << (ord & 31u)) - 1u));
           const uint32_t jx = listed ? (rev ? (t_base - 1u - jrel) : (t_base + jrel)) : 0u;
-          uint32_t mlq[NT][MKP_KMAX];
+          uint32_t cid;
+          if (!collapse) {
+            // MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63) on the map of this call, entries in the map's
+            // iteration order: pass threshold, Iterator::max keeps the last maximum, canonical pushed last
+            uint32_t mlb[MKP_KMAX];
 #pragma unroll
-          for (int t = 0; t < NT; t++) {
-#pragma unroll
-            for (int k = 0; k < MKP_KMAX; k++) mlq[t][k] = 0;
-            if (t < n_tags) {
-              const uint32_t nc = t_nc[t], base = listed ? (t_ml[t] + jx * nc) : 0u;
-#pragma unroll
-              for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k < nc) mlq[t][k] = ml[base + (listed ? (uint32_t)k : 0u)];
-            }
-          }
-          F4 pk = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int t = 0; t < NT; t++) {
-            if (t >= n_tags) break;
+            for (int k = 0; k < MKP_KMAX; k++) mlb[k] = ((uint32_t)k < n_post) ? (uint32_t)ml[listed ? it_off[k] + jx * it_stride[k] : 0u] : 0u;
+            float s = 0.f, best_p = 0.f; bool have = false; cid = MKP_C_FAIL;
 #pragma unroll
             for (int k = 0; k < MKP_KMAX; k++) {
-              if ((uint32_t)k >= t_nc[t]) break;
-              const float pr = ((float)mlq[t][k] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
-              setk(pk, (tmu[t] >> (4 + 4 * k)) & 15u, true, pr);
+              if ((uint32_t)k < n_post) {
+                const float pr = ((float)mlb[k] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
+                s = s + pr;
+                const bool take = pr >= it_thr[k] && (!have || !(pr < best_p));
+                cid = take ? it_cid[k] : cid; best_p = take ? pr : best_p; have = have || take;
+              }
             }
+            const float pc = 1.0f - s;
+            if (pc >= grp0.thr_can && (!have || !(pc < best_p))) cid = MKP_G_CIDCAN(grp0.misc);
+          } else {
+            uint32_t mlq[NT][MKP_KMAX];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+              for (int k = 0; k < MKP_KMAX; k++) mlq[t][k] = 0;
+              if (t < n_tags) {
+                const uint32_t nc = t_nc[t], base = listed ? (t_ml[t] + jx * nc) : 0u;
+#pragma unroll
+                for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k < nc) mlq[t][k] = ml[base + (listed ? (uint32_t)k : 0u)];
+              }
+            }
+            F4 pk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+              if (t >= n_tags) break;
+#pragma unroll
+              for (int k = 0; k < MKP_KMAX; k++) {
+                if ((uint32_t)k >= t_nc[t]) break;
+                const float pr = ((float)mlq[t][k] + 0.5f) / 256.0f;
+                setk(pk, (tmu[t] >> (4 + 4 * k)) & 15u, true, pr);
+              }
+            }
+            uint32_t ob = 0;
+            const int cls = call_group(grp0, pv, pk, true, &ob, kcodes0);
+            cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
           }
-          uint32_t ob = 0;
-          const int cls = call_group(grp0, pv, pk, collapse, &ob, kcodes0);
-          const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
           if (listed) call_fb = feat(cid, aln ^ (uint32_t)sg0);   // FeatureVector::add_feature's tally (pileup/mod.rs:238-281)
         }
         pend = pend && !inw;
@@ -380,14 +444,14 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256) mkp_decode_slots1(SLOT_PARAMS(MkpRunParams)) {
-  __shared__ __attribute__((aligned(16))) SlotLds lds_all[4];
-  decode_slots_body<1>(SLOT_PASS, lds_all);
-}
-extern "C" __global__ void __launch_bounds__(256) mkp_decode_slots2(SLOT_PARAMS(MkpRunParams)) {
-  __shared__ __attribute__((aligned(16))) SlotLds lds_all[4];
-  decode_slots_body<2>(SLOT_PASS, lds_all);
-}
+#define MKP_SLOT_KERNEL(NAME, NT, ...) extern "C" __global__ void __launch_bounds__(256 __VA_ARGS__) NAME(SLOT_PARAMS(MkpRunParams)) { \
+    __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<NT>(SLOT_PASS, lds_all); }
+MKP_SLOT_KERNEL(mkp_decode_slots1, 1)
+MKP_SLOT_KERNEL(mkp_decode_slots2, 2)
+MKP_SLOT_KERNEL(mkp_decode_slots1_o6, 1, , 6)
+MKP_SLOT_KERNEL(mkp_decode_slots2_o6, 2, , 6)
+MKP_SLOT_KERNEL(mkp_decode_slots1_o8, 1, , 8)
+MKP_SLOT_KERNEL(mkp_decode_slots2_o8, 2, , 8)
 
 // ----------------------------------------------------------------------------------------------------------------------
 // mkp_cover_reads: coverage features of the reads the event-producing decode kernels handled, with their call events merged in.
@@ -623,7 +687,11 @@ extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpReadHdr* hdrs, c
     if (n) {
       dim3 grid((n + 3u) / 4u), block(256);
 #define MKP_SLOT_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, ids, cigar, seqs, tagref, ranks, ml, layouts, *prm, slot_pos, cov, visits, events, readout, dev_err)
-      if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1); else if (cls == 1) MKP_SLOT_LAUNCH(mkp_decode_slots2); else MKP_SLOT_LAUNCH(mkp_cover_reads);
+      static const int variant = getenv("MKP_SLOT_VARIANT") ? atoi(getenv("MKP_SLOT_VARIANT")) : 0;   // experiments: 1 six, 2 eight waves per SIMD (register cap)
+      if (cls == 2) MKP_SLOT_LAUNCH(mkp_cover_reads);
+      else if (variant == 1) { if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1_o6); else MKP_SLOT_LAUNCH(mkp_decode_slots2_o6); }
+      else if (variant == 2) { if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1_o8); else MKP_SLOT_LAUNCH(mkp_decode_slots2_o8); }
+      else { if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1); else MKP_SLOT_LAUNCH(mkp_decode_slots2); }
     }
     ids += n;
   }
