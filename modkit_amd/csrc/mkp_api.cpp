@@ -18,8 +18,8 @@ hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
                              uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
-hipError_t mkp_launch_slots(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids: fused 1 | fused 2 | cover*/, const uint32_t* /*n[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*,
-                            const uint32_t*, const uint8_t*, const MkpLayout*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
+hipError_t mkp_launch_slots(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids: fused long | fused | cover*/, const uint32_t* /*n[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*,
+                            const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t, const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
                              const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
@@ -75,6 +75,35 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   ids->clear();
   for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
   for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r); ids->push_back(r | 0x80000000u); } }
+}
+
+// MkpFusedDesc of a layout whose tags form one explicit-mode group (decode class SPARSE): the walk of
+// MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63) over a call's map, resolved from the layout's caller tables
+MkpFusedDesc fused_desc(const MkpLayout& D) {
+  MkpFusedDesc f; memset(&f, 0, sizeof(f));
+  if (D.fast != 1 || D.n_tags == 0 || D.n_tags > 2) return f;
+  const uint32_t b0 = D.tags[0].fb & 3u, sg0 = D.tags[0].neg & 1u;
+  const MkpGroupDesc& G = D.groups[sg0 * 4 + b0];
+  uint32_t hit = 0; for (uint32_t t = 0; t < D.n_tags; t++) hit |= 1u << (D.tagmap[t][b0] & 15u);
+  const uint32_t pv = G.pat[hit < 20u ? hit : 0u], n_post = std::min<uint32_t>((pv >> 3) & 7u, MKP_KMAX);
+  uint32_t ob = 0;
+  for (uint32_t i = 0; i < n_post; i++) {
+    const uint32_t kq = (pv >> (16 + 2 * i)) & 3u;
+    ob |= 1u << ((G.slots >> (8 * kq)) & 0xffu);
+    f.it_cid |= ((G.cids >> (8 * kq)) & 0xffu) << (8 * i); f.it_thr[i] = G.thr_mod[kq];
+    for (uint32_t t = 0; t < D.n_tags; t++) for (uint32_t k = 0; k < D.tags[t].n_codes; k++)
+      if (((D.tagmap[t][b0] >> (4 + 4 * k)) & 15u) == kq) f.it_src |= (t | (k << 1)) << (4 * i);
+  }
+  f.misc = b0 | (sg0 << 2) | (n_post << 3) | (MKP_G_CIDCAN(G.misc) << 8) | (ob << 16);
+  f.nc = (uint32_t)D.tags[0].n_codes | ((D.n_tags > 1 ? (uint32_t)D.tags[1].n_codes : 0u) << 8);
+  f.thr_can = G.thr_can;
+  const int x = MKP_G_COLL(G.misc); const uint32_t n_pre = pv & 7u;   // collapse_redistribute's inputs (only looked at in collapse runs)
+  for (uint32_t i = 0; i < n_pre && i < MKP_KMAX; i++) if ((int)((pv >> (8 + 2 * i)) & 3u) == x) {
+    f.col = 1u; f.n_other = (float)n_pre;
+    for (uint32_t t = 0; t < D.n_tags; t++) for (uint32_t k = 0; k < D.tags[t].n_codes; k++)
+      if ((int)((D.tagmap[t][b0] >> (4 + 4 * k)) & 15u) == x) f.col |= (t | (k << 1)) << 1;
+  }
+  return f;
 }
 
 template <class V> void upload(DevBuf& b, const V& v) {
@@ -330,7 +359,7 @@ void make_resident(mkp_ctx* c) {
   // reads by kernel on the slot pipeline: the fused slot decoder takes the SPARSE classes when no edge filter is set (it never locates
   // calls off the focus positions, which the edge filter's "any call left" test would need); every other read is decoded into events
   // by its class kernel and then covered
-  c->read_ids_dec_off = 0; c->n_slot_class[0] = c->n_slot_class[1] = c->n_slot_class[2] = 0;
+  c->read_ids_dec_off = 0; for (auto& x : c->n_slot_class) x = 0;
   std::vector<uint32_t> slot_ids;
   if (stream) {
     const bool fused = !P.edge_filter && !(getenv("MKP_FUSED") && !strcmp(getenv("MKP_FUSED"), "0"));
@@ -338,8 +367,12 @@ void make_resident(mkp_ctx* c) {
     if (fused) {
       const uint32_t nf = c->n_class[0] + c->n_class[1];
       for (uint32_t k = 0; k < nf; k++) is_fused[class_list[k]] = 1;
-      slot_ids.assign(class_list.begin(), class_list.begin() + nf);
-      c->n_slot_class[0] = c->n_class[0]; c->n_slot_class[1] = c->n_class[1];
+      // one list for both SPARSE classes, longest first; the reads of more than one base window (mkp_decode_slots_long) lead it
+      slot_ids.resize(nf);
+      auto longer = [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; };
+      std::merge(class_list.begin(), class_list.begin() + c->n_class[0], class_list.begin() + c->n_class[0], class_list.begin() + nf, slot_ids.begin(), longer);
+      uint32_t n_long = 0; while (n_long < nf && S.hdr[slot_ids[n_long]].l_seq > MKP_SLOT_WB) n_long++;
+      c->n_slot_class[0] = n_long; c->n_slot_class[1] = nf - n_long;
       c->read_ids_dec_off = nf; c->n_class[0] = c->n_class[1] = 0;
     }
     std::vector<uint32_t> rest; rest.reserve(n);
@@ -366,6 +399,7 @@ void make_resident(mkp_ctx* c) {
   c->d_misc.ensure(64);
   if (stream) {
     upload(c->d_slot_pos, slot_pos_h); upload(c->d_stiles, stiles); upload(c->d_slot_ids, slot_ids);
+    { std::vector<MkpFusedDesc> fd(c->tables.dev.size()); for (size_t i = 0; i < fd.size(); i++) fd[i] = fused_desc(c->tables.dev[i]); upload(c->d_fdesc, fd); }
     c->d_cov.ensure(c->cov_bytes + 256); c->d_visits.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpVisit));
     hip_check(mkp_stream_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS, stream)");
   }
@@ -417,7 +451,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                                   (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
     if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_slot_ids.as<uint32_t>(), c->n_slot_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
-                                              c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(), c->d_visits.as<MkpVisit>(),
+                                              c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), c->d_fdesc.as<MkpFusedDesc>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(), c->d_visits.as<MkpVisit>(),
                                               c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2), "slot decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
@@ -561,7 +595,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

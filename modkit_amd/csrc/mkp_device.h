@@ -187,6 +187,7 @@ struct MkpTile { int32_t r0, r1; uint32_t first, last; };
 // stream into LDS tallies.  Feature byte = what FeatureVector::add_feature receives for this alignment at this column
 // (pileup/mod.rs:783-939): [0:4] counter id (MKP_C_*), [5] tally strand, [6:7] the read base as tallied (so that a call of a
 // record that later fails can be counted as NoCall(base)).
+#define MKP_SLOT_WB 16384u   // mkp_decode_slots*: stored bases per base window; longer reads take the *_long instances
 #define MKP_FB_NONE 0xffu    // the read is not in this column (ref-skip)
 #define MKP_FB_BLANK 0xfeu   // in the column, no feature (non-ACGT base: pileup/mod.rs:864-874)
 struct MkpVisit {            // 32 B, written by the decode / cover kernels, read by mkp_pileup_stream
@@ -195,6 +196,21 @@ struct MkpVisit {            // 32 B, written by the decode / cover kernels, rea
                              // bits 8.. partition key id
   uint32_t obs0, obs1;       // observed-code slot masks per tally strand (read_cache.rs:171-194)
   uint32_t over_off, n_over; // second features on one column (pos_call and neg_call at one base): {global slot, feature byte} pairs in events[]
+};
+// what mkp_decode_slots* needs of a layout whose tags form one explicit-mode group (decode class SPARSE), resolved by the host from
+// the MkpLayout so that a wave gets it with one scalar load: the caller's walk over a call's map in iteration order
+struct MkpFusedDesc {        // 64 B
+  uint32_t misc;             // [0:1] fundamental base, [2] mod strand, [3:5] codes the caller sees (n_post), [8:15] counter of Canonical, [16:31] observed-code slot mask
+  uint32_t it_cid;           // 4 x 8 bit: counter of Modified(i-th code)
+  uint32_t it_src;           // 4 x 4 bit: where the i-th code's ML byte sits: [0] tag, [1:3] index among the tag's codes
+  uint32_t nc;               // codes per call of tag 0 | tag 1 << 8 (the tags' ML strides)
+  float it_thr[4];           // pass threshold of the i-th code
+  float thr_can;
+  // --ignore / --preset traditional: ReDistribute(x) (BaseModProbs::into_collapsed, mod_bam.rs:558-600) — when the map holds x, every
+  // other code gets p_x / n_other added (n_other = number of codes before the collapse; x is no longer among the it_* entries)
+  uint32_t col;              // [0] the map holds x, [1:4] where x's ML byte sits (tag | index << 1)
+  float n_other;
+  uint32_t pad[5];
 };
 #define MKP_VF_OK 1u
 #define MKP_VF_REV 2u

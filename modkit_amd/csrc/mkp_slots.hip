@@ -3,7 +3,7 @@
 // the host numbers the window's slots in genome order (slot_pos[g] = position of global slot g) and gives every read the slot
 // range [gs0, gs0 + n_sl) of its reference span.  One device pass:
 //
-//   mkp_decode_slots1/2   one wave per read, reads whose MM tags form one explicit-mode ('?') group with one shared delta list
+//   mkp_decode_slots[_long]  one wave per read, reads whose MM tags form one explicit-mode ('?') group with one shared delta list
 //                         (`C+m?`, `C+hm?`, `C+h?;C+m?` as basecallers write them), no edge filter.  The walk is driven by the
 //                         read's SLOTS, not by its calls: the SEQ is swept once into LDS (a flag bit per base "is the fundamental
 //                         base" + a running count per 32 bases), the delta list is marked into a bitmap over the base's
@@ -27,14 +27,13 @@
 #include "mkp_dev_common.hpp"
 #include "mkp_dev_rows.hpp"
 
-#define SL_WB 16384u           // stored bases per base window of the fused decoder
+#define SL_WB MKP_SLOT_WB      // stored bases per base window of the fused decoder
 #define SL_FW (SL_WB / 32u)    // words of the window's flag bitmaps
 
 // per-wave LDS of mkp_decode_slots*: F = "base is the fundamental base" (bit = nibble index inside the dword, dword k of a word at
 // bits 8k..), P = occurrences before the word (inside the window), B = "occurrence is listed" over the window's occurrences,
 // WP = listed occurrences before the B word
-#define SL_BCAP (SL_WB / 2u)   // occurrences of the fundamental base a window's B bitmap holds (half-size windows beyond that)
-struct SlotLds { uint32_t F[SL_FW]; uint32_t B[SL_BCAP / 32u + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_BCAP / 32u + 2]; };
+struct SlotLds { uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -46,9 +45,9 @@ __device__ __forceinline__ uint32_t feat(uint32_t cid, uint32_t tally) { return 
 
 #define SLOT_PARAMS(PRM) const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ read_ids, const uint32_t* __restrict__ cigar, \
     const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, \
-    const MkpLayout* __restrict__ layouts, PRM prm, const uint32_t* __restrict__ slot_pos, uint8_t* __restrict__ cov, MkpVisit* __restrict__ visits, \
+    const MkpLayout* __restrict__ layouts, const MkpFusedDesc* __restrict__ fdesc, PRM prm, const uint32_t* __restrict__ slot_pos, uint8_t* __restrict__ cov, MkpVisit* __restrict__ visits, \
     MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err
-#define SLOT_PASS hdrs, n_reads, read_ids, cigar, seqs, tagref, ranks, ml, layouts, prm, slot_pos, cov, visits, events, readout, dev_err
+#define SLOT_PASS hdrs, n_reads, read_ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, prm, slot_pos, cov, visits, events, readout, dev_err
 
 // The CIGAR as the slot walk sees it: 128 ops per window (two per lane), reference -> query.  re = inclusive reference end of the
 // lane's pair (window-relative), mid = where its second op starts, pk0 / pk1 = ((query start - (reference start - ref_start)) << 2)
@@ -56,9 +55,14 @@ __device__ __forceinline__ uint32_t feat(uint32_t cid, uint32_t tally) { return 
 struct RefWin {
   uint32_t c0, q_run, Rtot, Qtot, re, mid, pk0, pk1; int32_t r_run; uint2 pref; bool loaded;
 };
+// loads as `uniform base + 32-bit byte offset`: the address is one VALU instruction (global saddr form), not 64-bit arithmetic
+template <class T> __device__ __forceinline__ T ldo(const void* __restrict__ base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+// two CIGAR words per lane; the address is clamped to the read's last op (the buffer has slack behind it), ops past the end read as 0H
 __device__ __forceinline__ uint2 cigar_pair(const uint32_t* __restrict__ cg, uint32_t n_cigar, uint32_t c) {
-  uint2 r; const uint32_t k = c + 2u * (uint32_t)lane_id();
-  r.x = k < n_cigar ? cg[k] : 5u /* 0H */; r.y = k + 1u < n_cigar ? cg[k + 1u] : 5u;
+  const uint32_t k = c + 2u * (uint32_t)lane_id();
+  uint2 r = ldo<uint2>(cg, 4u * min(k, n_cigar - 1u));
+  if (k >= n_cigar) r.x = 5u;
+  if (k + 1u >= n_cigar) r.y = 5u;
   return r;
 }
 __device__ __forceinline__ void refwin_load(RefWin& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start) {
@@ -67,8 +71,11 @@ __device__ __forceinline__ void refwin_load(RefWin& w, const uint32_t* __restric
   const uint32_t op0 = v.x & 15u, len0 = v.x >> 4, op1 = v.y & 15u, len1 = v.y >> 4;
   const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
   const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
-  const uint32_t qe = wave_incl_scan(ql0 + ql1);
-  w.re = wave_incl_scan(rl0 + rl1);
+  uint32_t qe;
+  if (!__any((v.x | v.y) >= (256u << 4))) {   // ops shorter than 256: both running sums fit 16 bits, one scan serves both
+    const uint32_t sc = wave_incl_scan((ql0 + ql1) | ((rl0 + rl1) << 16));
+    qe = sc & 0xffffu; w.re = sc >> 16;
+  } else { qe = wave_incl_scan(ql0 + ql1); w.re = wave_incl_scan(rl0 + rl1); }
   w.Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63); w.Rtot = (uint32_t)__builtin_amdgcn_readlane((int)w.re, 63);
   const uint32_t qs0 = w.q_run + qe - (ql0 + ql1), qs1 = qs0 + ql0;
   w.mid = w.re - rl1;
@@ -119,9 +126,12 @@ __device__ __forceinline__ uint32_t cover_feature(uint32_t kind, uint32_t nib, u
 // requested before the layout tables are looked at and the sweep issues four 16-byte loads per lane at a time.  Measured (SQ
 // counters, C3): the kernel is VALU-issue bound (~80 % of the SIMD cycles), so the per-base and per-slot instruction counts matter:
 // three VALU per SEQ dword for the flags, one popcount per 32 bases, the caller resolved to a fixed walk per read.
-template <int NT>
+// MULTI = false: reads of at most SL_WB bases — one base window, swept before the slot loop, and a straight-line slot step;
+// MULTI = true: longer reads — the windows are swept as the slots reach them.  (Two instances: the window-advance code inside the
+// slot loop costs the short-read kernel registers it never uses, and uniform values that do not fit the SGPR file are spilled to
+// VGPR lanes — VALU instructions in a VALU-bound kernel.)
+template <bool MULTI>
 __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams&), SlotLds* __restrict__ lds_all) {
-  static_assert(NT <= 2, "one or two tags");
   const int lane = lane_id();
   const uint32_t wib = rfl(threadIdx.x >> 6);
   const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6)) + wib;
@@ -132,25 +142,24 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
   const uint32_t aln = rev ? 1u : 0u;
   const uint32_t L = h.l_seq, nd = (L + 7u) >> 3;
-  const uint32_t* __restrict__ seqw = reinterpret_cast<const uint32_t*>(seqs + h.seq_off);   // reads start 4-byte aligned, zero-padded to a dword
-  const uint8_t* __restrict__ seqb = seqs + h.seq_off;
+  const uint8_t* __restrict__ seqb = seqs + h.seq_off;   // reads start 4-byte aligned, zero-padded to a dword
   const uint32_t* __restrict__ cg = cigar + h.cigar_off;
   bool have_calls = !(h.flags & MKP_RF_BAD) && h.n_tags != 0;
   // combine_checked's sum test (mod_bam.rs:629-656) — two tags on one base: the probabilities of a call add up to more than 1.01 —
   // is made by the host planner over the ML bytes (the f32 sums are exact multiples of 1/512: an integer comparison)
   const bool err_sum = (h.flags & MKP_RF_SUMERR) != 0;
-  const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
-  uint8_t* __restrict__ covp = cov + h.cov_off;
+  const uint32_t n_sl = h.n_sl;
+  const uint32_t* __restrict__ spos = slot_pos + h.gs0;
 
-  // ---- requests that depend on the header alone
+  // ---- requests that depend on the header alone (per-read bases are uniform: scalar base + 32-bit lane offset)
   // 16 bytes of SEQ at dword d.  The address is clamped to the read's last dword (the SEQ buffer has slack behind the last read)
   // and dwords past the read come back as zero: no divergent tail path.
   auto load4 = [&](uint32_t d) {
-    uint4 x = *reinterpret_cast<const uint4*>(seqw + min(d, nd - 1u));
+    uint4 x = ldo<uint4>(seqb, 4u * min(d, nd - 1u));
     if (__any(d + 4u > nd)) { if (d >= nd) x.x = 0u; if (d + 1u >= nd) x.y = 0u; if (d + 2u >= nd) x.z = 0u; if (d + 3u >= nd) x.w = 0u; }
     return x;
   };
-  uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
+  uint32_t p_next = (uint32_t)lane < n_sl ? ldo<uint32_t>(spos, 4u * (uint32_t)lane) : 0u;
   RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
   rw.pref = cigar_pair(cg, h.n_cigar, 0);
   uint4 xpre[4];   // stored bases [0, 8192): a 16-byte vector per lane and 2048 bases
@@ -158,76 +167,44 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   for (int j = 0; j < 4; j++) xpre[j] = (have_calls && 2048u * (uint32_t)j < L) ? load4(4u * (64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
   const uint32_t pad_nib = (L & 1u) ? ((uint32_t)seqb[L >> 1] & 15u) : 0u;   // the low nibble of the last byte is not a base when L is odd
 
-  // ---- the read's one (mod strand, base) group: wave-uniform tables straight from the layout (scalar loads)
+  // ---- the read's one (mod strand, base) group.  The caller's walk over a call's map in iteration order is resolved once per
+  // layout by the host (MkpFusedDesc: one scalar load): where the ML byte of the i-th code sits (tag + index: offset and stride
+  // per call), its pass threshold and the counter of Modified(code).  --ignore / --preset traditional (ReDistribute) keep the
+  // general tables.
   const int n_tags = have_calls ? (int)h.n_tags : 0;
-  const uint32_t* __restrict__ layw = reinterpret_cast<const uint32_t*>(&layouts[have_calls ? h.layout : 0u]);
-  const MkpLayout* __restrict__ lay = reinterpret_cast<const MkpLayout*>(layw);
-  int b0 = 0, sg0 = 0; uint32_t xs = 0;
-  GroupRegs grp0; grp0.misc = grp0.slots = grp0.cids = grp0.member_tags = 0; grp0.thr = F4{0.f, 0.f, 0.f, 0.f}; grp0.thr_can = 0.f;
-  uint32_t t_ml[NT], t_nc[NT], tmu[NT];
-  uint32_t t_off = 0, t_n = 0, SH_all = 0, pv = 0, ob_const = 0;
-  int kcodes0 = 0;
-#pragma unroll
-  for (int t = 0; t < NT; t++) { t_ml[t] = 0; t_nc[t] = 0; tmu[t] = 0; }
+  const bool collapse = prm.numeric_mode == 2;
+  uint32_t fmisc = 0, f_cid = 0, f_src = 0, f_nc = 0, f_col = 0; float f_thr[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f}, thr_can = 0.f, n_other = 1.f;
+  uint32_t t_ml[2] = {0, 0};
+  uint32_t t_n = 0;
   uint32_t e_pre = 0, e_last = 0;   // the first 64 entries of the rank list as the first window consumes it, and its last entry
-  // the caller's walk over the call's map in iteration order, resolved once per read: where the ML byte of the i-th code sits
-  // (offset + stride per call), its pass threshold and the counter of Modified(code)
-  uint32_t it_off[MKP_KMAX], it_stride[MKP_KMAX], it_cid[MKP_KMAX]; float it_thr[MKP_KMAX]; uint32_t n_post = 0;
-#pragma unroll
-  for (int i = 0; i < MKP_KMAX; i++) { it_off[i] = 0; it_stride[i] = 0; it_cid[i] = 0; it_thr[i] = 0.f; }
+  const uint32_t* __restrict__ rk = ranks;
   if (have_calls) {
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      if (t < n_tags) { const MkpTagRef tr = tagref[h.tag_off + t]; t_ml[t] = tr.ml_off; if (t == 0) { t_off = tr.rank_off; t_n = tr.n; } }
-    }
+    const MkpTagRef tr0 = tagref[h.tag_off];
+    t_ml[0] = tr0.ml_off; t_n = tr0.n;
+    if (n_tags > 1) t_ml[1] = tagref[h.tag_off + 1u].ml_off;
+    rk = ranks + tr0.rank_off;
     if (t_n) {
       const uint32_t i = rev ? t_n - 64u + (uint32_t)lane : (uint32_t)lane;
-      e_pre = ((int32_t)i >= 0 && i < t_n) ? ranks[t_off + i] : (rev ? 0u : 0xffffffffu);
-      e_last = ranks[t_off + t_n - 1u];
+      e_pre = ((int32_t)i >= 0 && i < t_n) ? ldo<uint32_t>(rk, 4u * i) : (rev ? 0u : 0xffffffffu);
+      e_last = rk[t_n - 1u];
     }
-    b0 = (int)rfl((uint32_t)lay->tags[0].fb) & 3; sg0 = (int)rfl((uint32_t)lay->tags[0].neg) & 1;
-    xs = (uint32_t)(rev ? 3 - b0 : b0);                                    // the stored base the tags count
-    const uint32_t* gp0 = layw + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
-    grp0 = load_group(gp0);
-    grp0.misc = rfl(grp0.misc); grp0.slots = rfl(grp0.slots); grp0.cids = rfl(grp0.cids); grp0.member_tags = rfl(grp0.member_tags);
+    const MkpFusedDesc fd = fdesc[h.layout];
+    fmisc = fd.misc; f_cid = fd.it_cid; f_src = fd.it_src; f_nc = fd.nc; thr_can = fd.thr_can;
 #pragma unroll
-    for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float(rfl(__float_as_uint(at(grp0.thr, kq))));
-    grp0.thr_can = __uint_as_float(rfl(__float_as_uint(grp0.thr_can)));
-    kcodes0 = (int)((grp0.misc >> 20) & 7u);
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      if (t < n_tags) {
-        t_nc[t] = rfl((uint32_t)lay->tags[t].n_codes);
-        tmu[t] = rfl(lay->tagmap[t][b0]);
-        SH_all |= 1u << (tmu[t] & 15u);
-      }
-    }
-    pv = rfl(gp0[12 + SH_all]);       // every call is listed by every tag: one hit pattern
-    n_post = min((pv >> 3) & 7u, (uint32_t)MKP_KMAX);
-#pragma unroll
-    for (int i = 0; i < MKP_KMAX; i++) {
-      if ((uint32_t)i < n_post) {
-        const uint32_t kq = (pv >> (16 + 2 * i)) & 3u;      // local code of the i-th entry of the map as the caller iterates it
-        ob_const |= 1u << ((grp0.slots >> (8u * kq)) & 0xffu);   // the codes the caller sees (read_cache.rs:171-179), the same for every call
-        it_cid[i] = (grp0.cids >> (8u * kq)) & 0xffu; it_thr[i] = getk(grp0.thr, (int)kq);
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          if (t < n_tags) for (uint32_t k = 0; k < t_nc[t]; k++) if (((tmu[t] >> (4 + 4 * k)) & 15u) == kq) { it_off[i] = t_ml[t] + k; it_stride[i] = t_nc[t]; }
-        }
-      }
-    }
+    for (int i = 0; i < MKP_KMAX; i++) f_thr[i] = fd.it_thr[i];
+    if (collapse) { f_col = fd.col; n_other = fd.n_other; }
     if (t_n == 0) have_calls = false;   // a tag without calls: the record has no modified-base information
   }
+  const uint32_t sg0u = (fmisc >> 2) & 1u, n_post = (fmisc >> 3) & 7u;
+  const uint32_t xs = rev ? 3u - (fmisc & 3u) : (fmisc & 3u);     // the stored base the tags count
   bool err = have_calls && err_sum;
-  const bool collapse = prm.numeric_mode == 2;
   const uint32_t pat = 0x11111111u << xs;
   const bool pad_hit = (L & 1u) && pad_nib == (1u << xs);
 
-  // ---- base windows: stored bases [w0, w0 + wb) swept into F / P.  wb = SL_WB unless a window holds more occurrences of the
-  // base than the B bitmap has bits (more than half of 16384 bases one base): then the read goes on with half-size windows.
+  // ---- base windows: stored bases [w0, w0 + SL_WB) swept into F / P.
   // F word = 32 bases = 4 SEQ dwords: the flag of nibble n of dword k sits at bit 4n + 3 - k (base 2j of a dword is nibble 2j+1).
-  uint32_t w0 = 0, wb = SL_WB, cntW = 0, cum = 0, tot = 0, t_cur = 0, t_base = 0;
-  bool bw_loaded = false, first_mark = true, xpre_live = true;
+  uint32_t w0 = 0, cntW = 0, cum = 0, tot = 0, t_cur = 0, t_base = 0;
+  bool bw_loaded = false, first_mark = true;
   auto flags4 = [&](const uint4& x) {   // "nibble != base" lands on bit 3 of the nibble after two shift-ors; the four dwords interleave
     uint32_t n0 = x.x ^ pat, n1 = x.y ^ pat, n2 = x.z ^ pat, n3 = x.w ^ pat;
     n0 |= n0 << 1; n1 |= n1 << 1; n2 |= n2 << 1; n3 |= n3 << 1;
@@ -236,13 +213,13 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
     return ~((a & 0xccccccccu) | (b & ~0xccccccccu));
   };
   auto sweep = [&]() {   // F, P, cntW of the window at w0; four vectors per lane (8192 bases) in flight at a time
-    const uint32_t nwords = min(wb >> 5, (L - w0 + 31u) >> 5);
+    const uint32_t nwords = min(SL_FW, (L - w0 + 31u) >> 5);
     const uint32_t dbase = w0 >> 3;
     uint32_t carry = 0;
-    wave_lds_fence();   // the previous window's readers are done (same wave)
+    if (MULTI) wave_lds_fence();   // the previous window's readers are done (same wave)
     for (uint32_t i0 = 0; i0 < nwords; i0 += 256) {
       uint4* x = xpre;   // (the vectors requested at the top serve the first 8192 bases)
-      if (!(w0 == 0 && i0 == 0 && xpre_live)) {
+      if (!(w0 == 0 && i0 == 0)) {
 #pragma unroll
         for (int j = 0; j < 4; j++) x[j] = (i0 + 64u * (uint32_t)j < nwords) ? load4(dbase + 4u * (i0 + 64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
       }
@@ -257,7 +234,6 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
         }
       }
     }
-    xpre_live = w0 == 0u && nwords <= 256u;
     wave_lds_fence();
     if (pad_hit && L - w0 < (nwords << 5)) {   // the pad nibble matched: take its flag back (it lies behind every base)
       const uint32_t qr = L - w0;
@@ -276,7 +252,7 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
       const uint32_t whi = cum + cntW;
       for (;;) {
         const uint32_t i = t_cur + (uint32_t)lane; const bool valid = i < t_n;
-        const uint32_t e = first_mark ? e_pre : (valid ? ranks[t_off + i] : 0xffffffffu);
+        const uint32_t e = first_mark ? e_pre : (valid ? ldo<uint32_t>(rk, 4u * i) : 0xffffffffu);
         first_mark = false;
         const bool hit = valid && e < whi;
         const uint32_t o = e - cum;
@@ -289,7 +265,7 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
       const uint32_t wlo = tot - cum - cntW;
       for (;;) {
         const uint32_t i = t_cur - 64u + (uint32_t)lane; const bool valid = (int32_t)i >= 0 && i < t_cur;
-        const uint32_t e = first_mark ? e_pre : (valid ? ranks[t_off + i] : 0u);
+        const uint32_t e = first_mark ? e_pre : (valid ? ldo<uint32_t>(rk, 4u * i) : 0u);
         first_mark = false;
         const bool hit = valid && e >= wlo;
         const uint32_t o = (tot - 1u - e) - cum;
@@ -310,8 +286,11 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
     }
     wave_lds_fence();
   };
+#ifdef MKP_DEBUG
+  if (prm.debug_skip & 256u) have_calls = false;   // ablation: no sweep, no calls
+#endif
   if (have_calls && !err) {
-    if (L > SL_WB) {   // several windows: the total is needed up front (reverse reads; the list's last entry)
+    if (MULTI) {   // several windows: the total is needed up front (reverse reads; the list's last entry)
       uint32_t acc = 0;
       for (uint32_t d0 = 0; d0 < nd; d0 += 1024) {
         uint4 x[4];
@@ -324,37 +303,47 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
     } else { sweep(); tot = cntW; }
     // a delta list must not run past the last occurrence of its base (mod_bam.rs:705-727)
     if (rfl(e_last) >= tot) err = true;
-    else {
-      t_cur = rev ? t_n : 0u;
-      if (bw_loaded) { if (cntW > SL_BCAP) { wb = SL_WB / 2u; sweep(); } mark(); }
-    }
+    else { t_cur = rev ? t_n : 0u; if (!MULTI) mark(); }
   }
   if (err) have_calls = false;   // the record only contributes coverage (skip_set, read_cache.rs:272-277)
 
   // ---- the read's slots, 64 per step
   bool gaps = false; uint32_t n_callfeat = 0;
-  for (uint32_t s0 = 0; s0 < n_sl; s0 += 64u) {
+#ifdef MKP_DEBUG
+  const uint32_t n_sl_walk = (prm.debug_skip & 512u) ? 0u : n_sl;   // ablation: no slot loop
+#else
+  const uint32_t n_sl_walk = n_sl;
+#endif
+  for (uint32_t s0 = 0; s0 < n_sl_walk; s0 += 64u) {
     const uint32_t i = s0 + (uint32_t)lane;
     const bool valid = i < n_sl;
     const int32_t p = (int32_t)p_next;
-    { const uint32_t in = i + 64u; p_next = in < n_sl ? slot_pos[gs0 + in] : 0u; }
+    { const uint32_t in = i + 64u; p_next = in < n_sl ? ldo<uint32_t>(spos, 4u * in) : 0u; }
     uint32_t kind, q;
+#ifdef MKP_DEBUG
+    if (prm.debug_skip & 64u) { kind = 0u; q = min((uint32_t)(p - h.ref_start), L - 1u); } else   // ablation: no CIGAR mapping
+#endif
     refwin_map(rw, cg, h.n_cigar, h.ref_start, valid, p, &kind, &q);
     const bool is_match = valid && kind == 0u && q < L;
-    const uint32_t byte = is_match ? (uint32_t)seqb[q >> 1] : 0u;
+    const uint32_t byte = is_match ? (uint32_t)ldo<uint8_t>(seqb, q >> 1) : 0u;
     uint32_t call_fb = 0xffffffffu;
+#ifdef MKP_DEBUG
+    if (have_calls && !(prm.debug_skip & 128u)) {   // ablation: no rank lookups, no calls
+#else
     if (have_calls) {
+#endif
       bool pend = is_match;
       for (;;) {
-        if (!__any(pend)) break;
-        const bool inw = pend && bw_loaded && (q - w0) < wb;
-        if (!__any(inw)) {   // the next base window (never skipped: the occurrence counts run on)
-          if (bw_loaded) { w0 += wb; cum += cntW; }
-          if (w0 >= L) break;
-          sweep();
-          if (cntW > SL_BCAP) { wb = SL_WB / 2u; sweep(); }
-          mark();
-          continue;
+        bool inw = pend;
+        if (MULTI) {
+          if (!__any(pend)) break;
+          inw = pend && bw_loaded && (q - w0) < SL_WB;
+          if (!__any(inw)) {   // the next base window (never skipped: the occurrence counts run on)
+            if (bw_loaded) { w0 += SL_WB; cum += cntW; }
+            if (w0 >= L) break;
+            sweep(); mark();
+            continue;
+          }
         }
         const uint32_t qr = inw ? q - w0 : 0u, wv = qr >> 5;
         const uint32_t Fw = W.F[wv], Pw = W.P[wv];
@@ -371,54 +360,35 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
         if (__any(listed)) {
           const uint32_t jrel = (uint32_t)W.WP[listed ? (ord >> 5) : 0u] + (uint32_t)__popc(Bw & ((1u << (ord & 31u)) - 1u));
           const uint32_t jx = listed ? (rev ? (t_base - 1u - jrel) : (t_base + jrel)) : 0u;
-          uint32_t cid;
-          if (!collapse) {
-            // MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63) on the map of this call, entries in the map's
-            // iteration order: pass threshold, Iterator::max keeps the last maximum, canonical pushed last
-            uint32_t mlb[MKP_KMAX];
+          // MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63) on the map of this call, entries in the map's
+          // iteration order: pass threshold, Iterator::max keeps the last maximum, canonical pushed last.  ReDistribute runs
+          // (--ignore, --preset traditional) first add the collapsed code's share to every entry (mod_bam.rs:558-600).
+          auto ml_at = [&](uint32_t src) {
+            const uint32_t tg = src & 1u, off = (tg ? t_ml[1] : t_ml[0]) + (src >> 1), stride = (f_nc >> (8u * tg)) & 0xffu;
+            return (uint32_t)ldo<uint8_t>(ml + off, listed ? jx * stride : 0u);
+          };
+          uint32_t mlb[MKP_KMAX], mlx = 0;
 #pragma unroll
-            for (int k = 0; k < MKP_KMAX; k++) mlb[k] = ((uint32_t)k < n_post) ? (uint32_t)ml[listed ? it_off[k] + jx * it_stride[k] : 0u] : 0u;
-            float s = 0.f, best_p = 0.f; bool have = false; cid = MKP_C_FAIL;
+          for (int k = 0; k < MKP_KMAX; k++) mlb[k] = ((uint32_t)k < n_post) ? ml_at((f_src >> (4 * k)) & 15u) : 0u;
+          if (f_col & 1u) mlx = ml_at((f_col >> 1) & 15u);
+          float red = 0.f;
+          if (f_col & 1u) red = (((float)mlx + 0.5f) / 256.0f) / n_other;
+          float s = 0.f, best_p = 0.f; bool have = false; uint32_t cid = MKP_C_FAIL;
 #pragma unroll
-            for (int k = 0; k < MKP_KMAX; k++) {
-              if ((uint32_t)k < n_post) {
-                const float pr = ((float)mlb[k] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
-                s = s + pr;
-                const bool take = pr >= it_thr[k] && (!have || !(pr < best_p));
-                cid = take ? it_cid[k] : cid; best_p = take ? pr : best_p; have = have || take;
-              }
+          for (int k = 0; k < MKP_KMAX; k++) {
+            if ((uint32_t)k < n_post) {
+              float pr = ((float)mlb[k] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
+              if (f_col & 1u) pr = pr + red;
+              s = s + pr;
+              const bool take = pr >= f_thr[k] && (!have || !(pr < best_p));
+              cid = take ? ((f_cid >> (8 * k)) & 0xffu) : cid; best_p = take ? pr : best_p; have = have || take;
             }
-            const float pc = 1.0f - s;
-            if (pc >= grp0.thr_can && (!have || !(pc < best_p))) cid = MKP_G_CIDCAN(grp0.misc);
-          } else {
-            uint32_t mlq[NT][MKP_KMAX];
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-#pragma unroll
-              for (int k = 0; k < MKP_KMAX; k++) mlq[t][k] = 0;
-              if (t < n_tags) {
-                const uint32_t nc = t_nc[t], base = listed ? (t_ml[t] + jx * nc) : 0u;
-#pragma unroll
-                for (int k = 0; k < MKP_KMAX; k++) if ((uint32_t)k < nc) mlq[t][k] = ml[base + (listed ? (uint32_t)k : 0u)];
-              }
-            }
-            F4 pk = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-              if (t >= n_tags) break;
-#pragma unroll
-              for (int k = 0; k < MKP_KMAX; k++) {
-                if ((uint32_t)k >= t_nc[t]) break;
-                const float pr = ((float)mlq[t][k] + 0.5f) / 256.0f;
-                setk(pk, (tmu[t] >> (4 + 4 * k)) & 15u, true, pr);
-              }
-            }
-            uint32_t ob = 0;
-            const int cls = call_group(grp0, pv, pk, true, &ob, kcodes0);
-            cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
           }
-          if (listed) call_fb = feat(cid, aln ^ (uint32_t)sg0);   // FeatureVector::add_feature's tally (pileup/mod.rs:238-281)
+          const float pc = 1.0f - s;
+          if (pc >= thr_can && (!have || !(pc < best_p))) cid = (fmisc >> 8) & 0xffu;
+          if (listed) call_fb = feat(cid, aln ^ sg0u);   // FeatureVector::add_feature's tally (pileup/mod.rs:238-281)
         }
+        if (!MULTI) break;
         pend = pend && !inw;
       }
     }
@@ -426,15 +396,15 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
     uint32_t fb = cover_feature(valid ? kind : 2u, nib, aln);
     if (valid && kind == 0u && q >= L) fb = MKP_FB_NONE;   // (a CIGAR longer than SEQ is refused by the packer)
     if (call_fb != 0xffffffffu) { fb = call_fb; n_callfeat++; }
-    if (valid) covp[i] = (uint8_t)fb;
+    if (valid) cov[h.cov_off + i] = (uint8_t)fb;
     gaps = gaps || (valid && fb == MKP_FB_NONE);
   }
   gaps = __any(gaps);
   const bool ok = have_calls;
-  const uint32_t tally = aln ^ (uint32_t)sg0;
+  const uint32_t tally = aln ^ sg0u, ob_const = fmisc >> 16;
   const uint32_t n_cf = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(n_callfeat), 63);
   if (lane == 0) {
-    MkpVisit v; v.gs0 = gs0; v.n_sl = n_sl; v.cov_off = h.cov_off;
+    MkpVisit v; v.gs0 = h.gs0; v.n_sl = n_sl; v.cov_off = h.cov_off;
     v.flags = (ok ? MKP_VF_OK : 0u) | (rev ? MKP_VF_REV : 0u) | (gaps ? MKP_VF_GAPS : 0u) | ((h.flags >> MKP_RF_KEY_SHIFT) << 8);
     v.obs0 = (ok && tally == 0u) ? ob_const : 0u; v.obs1 = (ok && tally == 1u) ? ob_const : 0u;
     v.over_off = 0; v.n_over = 0;
@@ -444,14 +414,11 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   }
 }
 
-#define MKP_SLOT_KERNEL(NAME, NT, ...) extern "C" __global__ void __launch_bounds__(256 __VA_ARGS__) NAME(SLOT_PARAMS(MkpRunParams)) { \
-    __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<NT>(SLOT_PASS, lds_all); }
-MKP_SLOT_KERNEL(mkp_decode_slots1, 1)
-MKP_SLOT_KERNEL(mkp_decode_slots2, 2)
-MKP_SLOT_KERNEL(mkp_decode_slots1_o6, 1, , 6)
-MKP_SLOT_KERNEL(mkp_decode_slots2_o6, 2, , 6)
-MKP_SLOT_KERNEL(mkp_decode_slots1_o8, 1, , 8)
-MKP_SLOT_KERNEL(mkp_decode_slots2_o8, 2, , 8)
+#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __launch_bounds__(256 __VA_ARGS__) NAME(SLOT_PARAMS(MkpRunParams)) { \
+    __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<MULTI>(SLOT_PASS, lds_all); }
+MKP_SLOT_KERNEL(mkp_decode_slots, false)
+MKP_SLOT_KERNEL(mkp_decode_slots_long, true)
+MKP_SLOT_KERNEL(mkp_decode_slots_o6, false, , 6)
 
 // ----------------------------------------------------------------------------------------------------------------------
 // mkp_cover_reads: coverage features of the reads the event-producing decode kernels handled, with their call events merged in.
@@ -677,21 +644,20 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_strea
 
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
-// slot_ids = [fused one tag | fused two tags | cover], n_slot_class = the three list lengths
+// slot_ids = [fused, reads longer than one base window | fused | cover], n_slot_class = the three list lengths
 extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* slot_ids, const uint32_t* n_slot_class /* [3] */, const uint32_t* cigar,
-                                       const uint8_t* seqs, const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts, const MkpRunParams* prm,
+                                       const uint8_t* seqs, const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts, const MkpFusedDesc* fdesc, const MkpRunParams* prm,
                                        const uint32_t* slot_pos, uint8_t* cov, MkpVisit* visits, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err) {
   const uint32_t* ids = slot_ids;
+  static const int variant = getenv("MKP_SLOT_VARIANT") ? atoi(getenv("MKP_SLOT_VARIANT")) : 0;   // experiments: 1 = register cap for six waves per SIMD
   for (int cls = 0; cls < 3; cls++) {
     const uint32_t n = n_slot_class[cls];
     if (n) {
       dim3 grid((n + 3u) / 4u), block(256);
-#define MKP_SLOT_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, ids, cigar, seqs, tagref, ranks, ml, layouts, *prm, slot_pos, cov, visits, events, readout, dev_err)
-      static const int variant = getenv("MKP_SLOT_VARIANT") ? atoi(getenv("MKP_SLOT_VARIANT")) : 0;   // experiments: 1 six, 2 eight waves per SIMD (register cap)
-      if (cls == 2) MKP_SLOT_LAUNCH(mkp_cover_reads);
-      else if (variant == 1) { if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1_o6); else MKP_SLOT_LAUNCH(mkp_decode_slots2_o6); }
-      else if (variant == 2) { if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1_o8); else MKP_SLOT_LAUNCH(mkp_decode_slots2_o8); }
-      else { if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots1); else MKP_SLOT_LAUNCH(mkp_decode_slots2); }
+#define MKP_SLOT_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, *prm, slot_pos, cov, visits, events, readout, dev_err)
+      if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots_long);
+      else if (cls == 1) { if (variant == 1) MKP_SLOT_LAUNCH(mkp_decode_slots_o6); else MKP_SLOT_LAUNCH(mkp_decode_slots); }
+      else MKP_SLOT_LAUNCH(mkp_cover_reads);
     }
     ids += n;
   }
