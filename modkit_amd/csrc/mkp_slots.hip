@@ -49,40 +49,48 @@ __device__ __forceinline__ uint32_t feat(uint32_t cid, uint32_t tally) { return 
     MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err
 #define SLOT_PASS hdrs, n_reads, read_ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, prm, slot_pos, cov, visits, events, readout, dev_err
 
-// The CIGAR as the slot walk sees it: 128 ops per window (two per lane), reference -> query.  re = inclusive reference end of the
-// lane's pair (window-relative), mid = where its second op starts, pk0 / pk1 = ((query start - (reference start - ref_start)) << 2)
-// | kind (0 match: M = X, 1 deletion, 2 ref-skip / nothing) of the two ops.
+// The CIGAR as the slot walk sees it: 256 ops per window (four per lane), reference -> query.  re = inclusive reference end of the
+// lane's four ops (window-relative), m1..m3 = where its second..fourth op start, pk[j] = ((query start - (reference start -
+// ref_start)) << 2) | kind (0 match: M = X, 1 deletion, 2 ref-skip / nothing) of op j.
 struct RefWin {
-  uint32_t c0, q_run, Rtot, Qtot, re, mid, pk0, pk1; int32_t r_run; uint2 pref; bool loaded;
+  uint32_t c0, q_run, Rtot, Qtot, re, m1, m2, m3, pk[4]; int32_t r_run; uint4 pref; bool loaded;
 };
 // loads as `uniform base + 32-bit byte offset`: the address is one VALU instruction (global saddr form), not 64-bit arithmetic
 template <class T> __device__ __forceinline__ T ldo(const void* __restrict__ base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
-// two CIGAR words per lane; the address is clamped to the read's last op (the buffer has slack behind it), ops past the end read as 0H
-__device__ __forceinline__ uint2 cigar_pair(const uint32_t* __restrict__ cg, uint32_t n_cigar, uint32_t c) {
-  const uint32_t k = c + 2u * (uint32_t)lane_id();
-  uint2 r = ldo<uint2>(cg, 4u * min(k, n_cigar - 1u));
-  if (k >= n_cigar) r.x = 5u;
-  if (k + 1u >= n_cigar) r.y = 5u;
+// four CIGAR words per lane; the address is clamped to the read's last op (the buffer has slack behind it), ops past the end read as 0H
+__device__ __forceinline__ uint4 cigar_quad(const uint32_t* __restrict__ cg, uint32_t n_cigar, uint32_t c) {
+  const uint32_t k = c + 4u * (uint32_t)lane_id();
+  uint4 r = ldo<uint4>(cg, 4u * min(k, n_cigar - 1u));
+  if (__any(k + 4u > n_cigar)) { if (k >= n_cigar) r.x = 5u; if (k + 1u >= n_cigar) r.y = 5u; if (k + 2u >= n_cigar) r.z = 5u; if (k + 3u >= n_cigar) r.w = 5u; }
   return r;
 }
+// per op code (MIDNSHP=X): bit 0 consumes query, bit 1 consumes reference, bits 2-3 kind
+#define MKP_CIGAR_LUT 0x888888833889a693ull
 __device__ __forceinline__ void refwin_load(RefWin& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start) {
-  const uint2 v = w.pref;
-  w.pref = cigar_pair(cg, n_cigar, w.c0 + 128u);   // requested one window ahead
-  const uint32_t op0 = v.x & 15u, len0 = v.x >> 4, op1 = v.y & 15u, len1 = v.y >> 4;
-  const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
-  const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
+  const uint4 v = w.pref;
+  w.pref = cigar_quad(cg, n_cigar, w.c0 + 256u);   // requested one window ahead
+  const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+  uint32_t ql[4], rl[4], kind[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t f = (uint32_t)(MKP_CIGAR_LUT >> ((wd[j] & 15u) << 2)), len = wd[j] >> 4;
+    ql[j] = len & (0u - (f & 1u)); rl[j] = len & (0u - ((f >> 1) & 1u)); kind[j] = (f >> 2) & 3u;
+  }
+  const uint32_t qsum = ql[0] + ql[1] + ql[2] + ql[3], rsum = rl[0] + rl[1] + rl[2] + rl[3];
   uint32_t qe;
-  if (!__any((v.x | v.y) >= (256u << 4))) {   // ops shorter than 256: both running sums fit 16 bits, one scan serves both
-    const uint32_t sc = wave_incl_scan((ql0 + ql1) | ((rl0 + rl1) << 16));
+  if (!__any((v.x | v.y | v.z | v.w) >= (128u << 4))) {   // ops shorter than 128: both running sums fit 16 bits, one scan serves both
+    const uint32_t sc = wave_incl_scan(qsum | (rsum << 16));
     qe = sc & 0xffffu; w.re = sc >> 16;
-  } else { qe = wave_incl_scan(ql0 + ql1); w.re = wave_incl_scan(rl0 + rl1); }
+  } else { qe = wave_incl_scan(qsum); w.re = wave_incl_scan(rsum); }
   w.Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63); w.Rtot = (uint32_t)__builtin_amdgcn_readlane((int)w.re, 63);
-  const uint32_t qs0 = w.q_run + qe - (ql0 + ql1), qs1 = qs0 + ql0;
-  w.mid = w.re - rl1;
-  const int32_t rs0 = w.r_run + (int32_t)(w.re - (rl0 + rl1)), rs1 = w.r_run + (int32_t)w.mid;
-  const uint32_t kind0 = op_is_match(op0) ? 0u : (op0 == 2u ? 1u : 2u), kind1 = op_is_match(op1) ? 0u : (op1 == 2u ? 1u : 2u);
-  w.pk0 = ((uint32_t)((int32_t)qs0 - (rs0 - ref_start)) << 2) | kind0;
-  w.pk1 = ((uint32_t)((int32_t)qs1 - (rs1 - ref_start)) << 2) | kind1;
+  uint32_t qs = w.q_run + qe - qsum, rs = w.re - rsum;   // query offset / window-relative reference offset of the lane's first op
+  const int32_t rbase = w.r_run - ref_start;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    w.pk[j] = ((uint32_t)((int32_t)qs - (rbase + (int32_t)rs)) << 2) | kind[j];
+    qs += ql[j]; rs += rl[j];
+    if (j == 0) w.m1 = rs; else if (j == 1) w.m2 = rs; else if (j == 2) w.m3 = rs;
+  }
   w.loaded = true;
 }
 // (kind, query index) of the reference positions p (ascending over the lanes and from call to call; `valid` lanes lie inside the
@@ -93,15 +101,25 @@ __device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict
     if (!__any(pending)) break;
     const bool inw = pending && w.loaded && (uint32_t)(p - w.r_run) < w.Rtot;
     if (!__any(inw)) {
-      if (w.loaded) { w.c0 += 128u; w.q_run += w.Qtot; w.r_run += (int32_t)w.Rtot; }
+      if (w.loaded) { w.c0 += 256u; w.q_run += w.Qtot; w.r_run += (int32_t)w.Rtot; }
       if (w.c0 >= n_cigar) break;   // (cannot happen for positions inside the span)
       refwin_load(w, cg, n_cigar, ref_start);
       continue;
     }
     const uint32_t rel = inw ? (uint32_t)(p - w.r_run) : 0u;
-    const int ol = find_op(w.re, rel) & 63;
-    const uint32_t o_mid = (uint32_t)__shfl((int)w.mid, ol, 64), o_pk0 = (uint32_t)__shfl((int)w.pk0, ol, 64), o_pk1 = (uint32_t)__shfl((int)w.pk1, ol, 64);
-    const uint32_t pk = rel < o_mid ? o_pk0 : o_pk1;
+    // the lane whose four ops hold `rel`: the number of lanes whose inclusive end is <= rel (six probes; the probe address is carried)
+    uint32_t probe = 31u << 2;
+#pragma unroll
+    for (int hstep = 16; hstep >= 1; hstep >>= 1) {
+      const uint32_t vv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)probe, (int)w.re);
+      probe = vv <= rel ? probe + 4u * (uint32_t)hstep : probe - 4u * (uint32_t)hstep;
+    }
+    { const uint32_t vv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)probe, (int)w.re); probe = vv <= rel ? probe + 4u : probe; }
+    const int oa = (int)(probe & 255u);
+    const uint32_t o_m1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m1), o_m2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m2), o_m3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m3);
+    const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[0]), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[1]);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[2]), o3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[3]);
+    const uint32_t pk = rel < o_m1 ? o0 : rel < o_m2 ? o1 : rel < o_m3 ? o2 : o3;
     if (inw) { *kind = pk & 3u; *q = (uint32_t)((p - ref_start) + ((int32_t)pk >> 2)); pending = false; }
   }
 }
@@ -160,8 +178,8 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
     return x;
   };
   uint32_t p_next = (uint32_t)lane < n_sl ? ldo<uint32_t>(spos, 4u * (uint32_t)lane) : 0u;
-  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
-  rw.pref = cigar_pair(cg, h.n_cigar, 0);
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0; rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
+  rw.pref = cigar_quad(cg, h.n_cigar, 0);
   uint4 xpre[4];   // stored bases [0, 8192): a 16-byte vector per lane and 2048 bases
 #pragma unroll
   for (int j = 0; j < 4; j++) xpre[j] = (have_calls && 2048u * (uint32_t)j < L) ? load4(4u * (64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
@@ -444,8 +462,8 @@ extern "C" __global__ void __launch_bounds__(256) mkp_cover_reads(SLOT_PARAMS(Mk
   MkpEvent* __restrict__ ev = events + h.event_off;
   const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
   uint8_t* __restrict__ covp = cov + h.cov_off;
-  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.mid = rw.pk0 = rw.pk1 = 0; rw.loaded = false;
-  rw.pref = cigar_pair(cg, h.n_cigar, 0);
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0; rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
+  rw.pref = cigar_quad(cg, h.n_cigar, 0);
   uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
   uint32_t ec = 0, n_over = 0; bool gaps = false;
   stage[lane] = 0xffffffffu;
