@@ -18,7 +18,7 @@ hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
                              uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
-hipError_t mkp_launch_slots(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids: fused long | fused | cover*/, const uint32_t* /*n[3]*/, const uint32_t*, const uint8_t*, const MkpTagRef*,
+hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*, const uint32_t* /*cover read ids*/, uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
                             const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t, const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
@@ -398,7 +398,21 @@ void make_resident(mkp_ctx* c) {
   c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
   if (stream) {
-    upload(c->d_slot_pos, slot_pos_h); upload(c->d_stiles, stiles); upload(c->d_slot_ids, slot_ids);
+    upload(c->d_slot_pos, slot_pos_h); upload(c->d_stiles, stiles);
+    {   // the fused decoder's work records, in launch order; the cover kernel keeps a read-id list
+      const uint32_t nf = c->n_slot_class[0] + c->n_slot_class[1];
+      std::vector<MkpWork> work(nf);
+      host_parallel(nf, 8192, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) {
+          const MkpReadHdr& h = S.hdr[slot_ids[k]]; MkpWork& w = work[k]; memset(&w, 0, sizeof(w));
+          w.ref_start = h.ref_start; w.l_seq = h.l_seq; w.n_cigar = h.n_cigar; w.cigar_off = h.cigar_off; w.seq_off = h.seq_off; w.flags = h.flags; w.gs0 = h.gs0; w.n_sl = h.n_sl;
+          w.cov_off = h.cov_off; w.n_tags = h.n_tags; w.layout = h.layout; w.rid = slot_ids[k];
+          if (!(h.flags & MKP_RF_BAD) && h.n_tags) { const MkpTagRef& t0 = S.tagref[h.tag_off]; w.rank_off = t0.rank_off; w.n_calls = t0.n; w.ml_off0 = t0.ml_off; if (h.n_tags > 1) w.ml_off1 = S.tagref[h.tag_off + 1].ml_off; }
+        }
+      });
+      upload(c->d_work, work);
+      std::vector<uint32_t> cover(slot_ids.begin() + nf, slot_ids.end()); upload(c->d_slot_ids, cover);
+    }
     { std::vector<MkpFusedDesc> fd(c->tables.dev.size()); for (size_t i = 0; i < fd.size(); i++) fd[i] = fused_desc(c->tables.dev[i]); upload(c->d_fdesc, fd); }
     c->d_cov.ensure(c->cov_bytes + 256); c->d_visits.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpVisit));
     hip_check(mkp_stream_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS, stream)");
@@ -450,7 +464,8 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                                   (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
-    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_slot_ids.as<uint32_t>(), c->n_slot_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
+    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_work.as<MkpWork>(), c->n_slot_class[0], c->n_slot_class[1], c->d_hdr.as<MkpReadHdr>(), c->d_slot_ids.as<uint32_t>(), c->n_slot_class[2],
+                                              c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                               c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), c->d_fdesc.as<MkpFusedDesc>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(), c->d_visits.as<MkpVisit>(),
                                               c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2), "slot decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
@@ -595,7 +610,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

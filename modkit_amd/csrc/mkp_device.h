@@ -212,6 +212,14 @@ struct MkpFusedDesc {        // 64 B
   float n_other;
   uint32_t pad[5];
 };
+// one read as mkp_decode_slots* takes it: the header and tag fields the kernel needs, in launch order (longest reads first), so that a
+// wave starts from ONE 64-byte scalar load instead of the chain read id -> header -> tag table
+struct MkpWork {             // 64 B
+  int32_t ref_start; uint32_t l_seq, n_cigar, cigar_off, seq_off, flags, gs0, n_sl, cov_off;
+  uint16_t n_tags, layout;
+  uint32_t rank_off, n_calls, ml_off0, ml_off1;   // the shared rank list, the tags' ML bytes
+  uint32_t rid, pad;
+};
 #define MKP_VF_OK 1u
 #define MKP_VF_REV 2u
 #define MKP_VF_GAPS 4u
@@ -224,3 +232,7 @@ struct MkpRowsDev {  // SoA row buffers (44 B / row)
   uint32_t* n_valid; uint32_t* n_mod; uint32_t* n_can; uint32_t* n_other;
   uint32_t* n_del; uint32_t* n_fail; uint32_t* n_diff; uint32_t* n_nocall;
 };
+#ifdef __cplusplus
+static_assert(sizeof(MkpWork) == 64, "work record is 16 dwords");
+static_assert(sizeof(MkpFusedDesc) == 64 && sizeof(MkpVisit) == 32, "slot pipeline records");
+#endif

@@ -148,14 +148,18 @@ __device__ __forceinline__ uint32_t cover_feature(uint32_t kind, uint32_t nib, u
 // MULTI = true: longer reads — the windows are swept as the slots reach them.  (Two instances: the window-advance code inside the
 // slot loop costs the short-read kernel registers it never uses, and uniform values that do not fit the SGPR file are spilled to
 // VGPR lanes — VALU instructions in a VALU-bound kernel.)
+#define FUSED_PARAMS(PRM) const MkpWork* __restrict__ work, uint32_t n_reads, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, \
+    const uint32_t* __restrict__ ranks, const uint8_t* __restrict__ ml, const MkpFusedDesc* __restrict__ fdesc, PRM prm, const uint32_t* __restrict__ slot_pos, \
+    uint8_t* __restrict__ cov, MkpVisit* __restrict__ visits, MkpReadOut* __restrict__ readout
+#define FUSED_PASS work, n_reads, cigar, seqs, ranks, ml, fdesc, prm, slot_pos, cov, visits, readout
 template <bool MULTI>
-__device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams&), SlotLds* __restrict__ lds_all) {
+__device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParams&), SlotLds* __restrict__ lds_all) {
   const int lane = lane_id();
   const uint32_t wib = rfl(threadIdx.x >> 6);
   const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6)) + wib;
   if (widx >= n_reads) return;
-  const uint32_t rid = rfl(read_ids[widx]);
-  const MkpReadHdr h = hdrs[rid];
+  const MkpWork h = work[widx];
+  const uint32_t rid = h.rid;
   SlotLds& W = lds_all[wib];
   const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
   const uint32_t aln = rev ? 1u : 0u;
@@ -189,7 +193,6 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   // layout by the host (MkpFusedDesc: one scalar load): where the ML byte of the i-th code sits (tag + index: offset and stride
   // per call), its pass threshold and the counter of Modified(code).  --ignore / --preset traditional (ReDistribute) keep the
   // general tables.
-  const int n_tags = have_calls ? (int)h.n_tags : 0;
   const bool collapse = prm.numeric_mode == 2;
   uint32_t fmisc = 0, f_cid = 0, f_src = 0, f_nc = 0, f_col = 0; float f_thr[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f}, thr_can = 0.f, n_other = 1.f;
   uint32_t t_ml[2] = {0, 0};
@@ -197,10 +200,8 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   uint32_t e_pre = 0, e_last = 0;   // the first 64 entries of the rank list as the first window consumes it, and its last entry
   const uint32_t* __restrict__ rk = ranks;
   if (have_calls) {
-    const MkpTagRef tr0 = tagref[h.tag_off];
-    t_ml[0] = tr0.ml_off; t_n = tr0.n;
-    if (n_tags > 1) t_ml[1] = tagref[h.tag_off + 1u].ml_off;
-    rk = ranks + tr0.rank_off;
+    t_ml[0] = h.ml_off0; t_ml[1] = h.ml_off1; t_n = h.n_calls;
+    rk = ranks + h.rank_off;
     if (t_n) {
       const uint32_t i = rev ? t_n - 64u + (uint32_t)lane : (uint32_t)lane;
       e_pre = ((int32_t)i >= 0 && i < t_n) ? ldo<uint32_t>(rk, 4u * i) : (rev ? 0u : 0xffffffffu);
@@ -432,11 +433,10 @@ __device__ __forceinline__ void decode_slots_body(SLOT_PARAMS(const MkpRunParams
   }
 }
 
-#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __launch_bounds__(256 __VA_ARGS__) NAME(SLOT_PARAMS(MkpRunParams)) { \
-    __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<MULTI>(SLOT_PASS, lds_all); }
+#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __launch_bounds__(256 __VA_ARGS__) NAME(FUSED_PARAMS(MkpRunParams)) { \
+    __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<MULTI>(FUSED_PASS, lds_all); }
 MKP_SLOT_KERNEL(mkp_decode_slots, false)
 MKP_SLOT_KERNEL(mkp_decode_slots_long, true)
-MKP_SLOT_KERNEL(mkp_decode_slots_o6, false, , 6)
 
 // ----------------------------------------------------------------------------------------------------------------------
 // mkp_cover_reads: coverage features of the reads the event-producing decode kernels handled, with their call events merged in.
@@ -662,23 +662,14 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_strea
 
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
-// slot_ids = [fused, reads longer than one base window | fused | cover], n_slot_class = the three list lengths
-extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* slot_ids, const uint32_t* n_slot_class /* [3] */, const uint32_t* cigar,
+// work = the fused decoder's reads [longer than one base window | the others], cover_ids = the reads of mkp_cover_reads
+extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint32_t n_long, uint32_t n_short, const MkpReadHdr* hdrs, const uint32_t* cover_ids, uint32_t n_cover, const uint32_t* cigar,
                                        const uint8_t* seqs, const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts, const MkpFusedDesc* fdesc, const MkpRunParams* prm,
                                        const uint32_t* slot_pos, uint8_t* cov, MkpVisit* visits, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err) {
-  const uint32_t* ids = slot_ids;
-  static const int variant = getenv("MKP_SLOT_VARIANT") ? atoi(getenv("MKP_SLOT_VARIANT")) : 0;   // experiments: 1 = register cap for six waves per SIMD
-  for (int cls = 0; cls < 3; cls++) {
-    const uint32_t n = n_slot_class[cls];
-    if (n) {
-      dim3 grid((n + 3u) / 4u), block(256);
-#define MKP_SLOT_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, *prm, slot_pos, cov, visits, events, readout, dev_err)
-      if (cls == 0) MKP_SLOT_LAUNCH(mkp_decode_slots_long);
-      else if (cls == 1) { if (variant == 1) MKP_SLOT_LAUNCH(mkp_decode_slots_o6); else MKP_SLOT_LAUNCH(mkp_decode_slots); }
-      else MKP_SLOT_LAUNCH(mkp_cover_reads);
-    }
-    ids += n;
-  }
+#define MKP_FUSED_LAUNCH(K, W, N) hipLaunchKernelGGL(K, dim3(((N) + 3u) / 4u), dim3(256), 0, st, W, N, cigar, seqs, ranks, ml, fdesc, *prm, slot_pos, cov, visits, readout)
+  if (n_long) MKP_FUSED_LAUNCH(mkp_decode_slots_long, work, n_long);
+  if (n_short) MKP_FUSED_LAUNCH(mkp_decode_slots, work + n_long, n_short);
+  if (n_cover) hipLaunchKernelGGL(mkp_cover_reads, dim3((n_cover + 3u) / 4u), dim3(256), 0, st, hdrs, n_cover, cover_ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, *prm, slot_pos, cov, visits, events, readout, dev_err);
   return hipGetLastError();
 }
 
