@@ -913,6 +913,9 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
     }
     if (!c->d_hist0.p) { c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16); hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset"); hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
     const uint64_t need = c->sample_n + add;
+    // the device histograms count in 32 bits: with 2^32 or more sampled values one bin could wrap (ML bytes put most values on a handful
+    // of f32 patterns) — refused rather than estimated wrongly
+    if (need > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED, "more than 2^32 - 1 sampled probabilities on one GPU (32-bit histogram counters); shard the estimate over more ranks");
     if (need * 4 > c->d_store.cap) {   // grow the resident sample, keeping what is there
       DevBuf nb; nb.ensure(std::max<uint64_t>(need * 4 * 2, 1u << 20));
       if (c->sample_n) hip_check(hipMemcpyAsync(nb.p, c->d_store.p, c->sample_n * 4, hipMemcpyDeviceToDevice, c->stream), "D2D");

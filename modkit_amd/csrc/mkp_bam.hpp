@@ -4,6 +4,7 @@
 // mkp_record views to the packer.  Whole-file residency (decompressed BAM kept in host RAM) is the
 // round-1 design; BAI-indexed streaming is listed under "next" in DESIGN.md.
 #pragma once
+#include <exception>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -51,13 +52,20 @@ class HostPool {
     Job job; job.n = n; job.fn = [&f](size_t i) { f(i); };
     { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(&job); }
     cv_.notify_all();
-    for (;;) { const size_t i = job.next.fetch_add(1); if (i >= n) break; job.fn(i); job.done.fetch_add(1); }
+    for (;;) { const size_t i = job.next.fetch_add(1); if (i >= n) break; run_one(&job, i); }
     { std::unique_lock<std::mutex> lk(mu_);
       for (auto it = jobs_.begin(); it != jobs_.end(); ++it) if (*it == &job) { jobs_.erase(it); break; }   // no new claims from now on
       done_cv_.wait(lk, [&] { return job.done.load() + job.skipped.load() >= std::min(n, job.next.load()); }); }
+    // an exception thrown by f on any thread: every index is still accounted for and the job retired before it reaches the caller
+    if (job.failed.load()) std::rethrow_exception(job.error);
   }
  private:
-  struct Job { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}, skipped{0}; };
+  struct Job { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}, skipped{0}; std::atomic<bool> failed{false}; std::exception_ptr error; std::mutex emu; };
+  static void run_one(Job* job, size_t i) {   // never lets an exception escape: the first one is kept for the caller, the index counts as done
+    try { if (!job->failed.load()) job->fn(i); }
+    catch (...) { std::lock_guard<std::mutex> lk(job->emu); if (!job->failed.load()) { job->error = std::current_exception(); job->failed.store(true); } }
+    job->done.fetch_add(1);
+  }
   std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Job*> jobs_; bool stop_ = false;
   HostPool() {
     unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
@@ -75,8 +83,7 @@ class HostPool {
           if (job) break;
           cv_.wait(lk);
         } }
-      job->fn(i);
-      job->done.fetch_add(1);
+      run_one(job, i);
       { std::lock_guard<std::mutex> lk(mu_); }   // pairs with the waiter's predicate check
       done_cv_.notify_all();
     }
@@ -501,6 +508,7 @@ class BamSource {
       uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (2u << 20);   // (heads: ~2 MiB hold the few hundred records the sampler asks for)
       while (cb < fsize_ && (cb < ce || (cb == ce && ue > 0)) && !stop) {
         const uint64_t want_end = std::min<uint64_t>(fsize_, std::min<uint64_t>(ce + (1u << 16) + 64, cb + window));
+        const bool window_at_max = window >= (64u << 20) || want_end < cb + window;   // this window cannot be made larger
         window = std::min<uint64_t>(window * 2, 64u << 20);
         Window buf; map_window(cb, (size_t)(want_end - cb), &buf);
         std::vector<Blk> blks; uint64_t c = cb, dtotal = 0;
@@ -520,7 +528,11 @@ class BamSource {
         while (o + 4 <= limit) {
           int32_t bs; memcpy(&bs, &d[(size_t)o], 4);
           if (bs < 32) throw Error(MKP_E_IO, "corrupt BAM record");
-          if (o + 4 + (uint64_t)bs > dtotal) break;   // the record continues in the next window
+          if (o + 4 + (uint64_t)bs > dtotal) {   // the record continues in the next window — unless there is none, or no window could hold it
+            if (last_window) throw Error(MKP_E_IO, "truncated BAM record at the end of " + path_);
+            if ((uint64_t)bs > (64u << 20)) throw Error(MKP_E_IO, "BAM record larger than the ingest window (corrupt block_size?)");
+            break;
+          }
           starts.push_back(o); o += 4 + (uint64_t)bs; consumed = o;
         }
         std::vector<BamIndexEntry> all(starts.size()); std::atomic<bool> rec_bad{false};
@@ -543,7 +555,8 @@ class BamSource {
         if (stop || last_window) break;
         // next window starts at the block holding the first unconsumed byte
         size_t bi = blks.size() - 1; while (bi > 0 && blks[bi].doff > consumed) bi--;
-        if (blks[bi].coff == cb && consumed - blks[bi].doff == ub && blks.size() == 1) throw Error(MKP_E_IO, "BAM record larger than the ingest window");
+        // no progress: the same first record again.  A larger window may hold it; the largest one did not
+        if (blks[bi].coff == cb && consumed - blks[bi].doff == ub && window_at_max) throw Error(MKP_E_IO, "BAM record larger than the ingest window (corrupt block_size?)");
         cb = blks[bi].coff; ub = (uint32_t)(consumed - blks[bi].doff);
       }
     }

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -17,14 +18,15 @@ namespace mkp {
 
 static const size_t MKP_BGZF_BLOCK = 0xff00;   // uncompressed bytes per block, as bgzip cuts them
 
-// text[0..n) -> one BGZF block appended to `out`; returns its compressed size
+// text[0..n) -> one BGZF block appended to `out`; returns its compressed size.  A zlib failure (or a block that does not fit the
+// 64 KiB BGZF limit) leaves `out` as it was and throws: a half-written block must never reach the file or the index.
 static inline uint32_t bgzf_block(const uint8_t* text, size_t n, std::vector<uint8_t>* out, int level = 6) {
   const size_t at = out->size(); out->resize(at + n + n / 8 + 64);
   z_stream zs; memset(&zs, 0, sizeof(zs));
-  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { out->resize(at); throw std::runtime_error("bgzf: deflateInit2 failed"); }
   zs.next_in = const_cast<Bytef*>(text); zs.avail_in = (uInt)n; zs.next_out = out->data() + at + 18; zs.avail_out = (uInt)(out->size() - at - 26);
   const int rc = deflate(&zs, Z_FINISH); const size_t clen = zs.total_out; deflateEnd(&zs);
-  if (rc != Z_STREAM_END || clen + 26 > 65536) return 0;
+  if (rc != Z_STREAM_END || clen + 26 > 65536) { out->resize(at); throw std::runtime_error("bgzf: block does not compress into 64 KiB"); }
   static const uint8_t hdr[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0};
   memcpy(out->data() + at, hdr, 16);
   const uint16_t bsize = (uint16_t)(clen + 25); memcpy(out->data() + at + 16, &bsize, 2);
@@ -112,7 +114,8 @@ class BgzfTabixSink {
     FILE* fi = fopen(index_path.c_str(), "wb");
     if (!fi) { failed = true; return; }
     std::vector<uint8_t> comp;
-    for (size_t o = 0; o < ix.size(); o += MKP_BGZF_BLOCK) bgzf_block(ix.data() + o, std::min(MKP_BGZF_BLOCK, ix.size() - o), &comp);
+    try { for (size_t o = 0; o < ix.size(); o += MKP_BGZF_BLOCK) bgzf_block(ix.data() + o, std::min(MKP_BGZF_BLOCK, ix.size() - o), &comp); }
+    catch (const std::exception&) { failed = true; fclose(fi); remove(index_path.c_str()); return; }
     comp.insert(comp.end(), eof, eof + 28);
     if (fwrite(comp.data(), 1, comp.size(), fi) != comp.size()) failed = true;
     fclose(fi);

@@ -133,11 +133,16 @@ SAMPLING_FLAGS_WITH_VALUE = ("--region", "--sample-region", "--include-bed", "--
 SAMPLING_FLAGS_BARE = ("--include-unmapped", "--invert-edge-filter")
 
 
-def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1):
+def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1, stats=None):
     """`modkit pileup` with ONE BAM sharded over the ranks of the current torch.distributed job (one process per GPU):
     thresholds from the all-reduced histograms of rank-sharded sampling, then every rank runs its contiguous run of the
     reference's interval grid (mkp_pileup_main --gpus-rank/--gpus-world) into `<out>.rank<R>`, and rank 0 concatenates the parts
-    in rank order into `<out>` — byte-identical to the single-GPU output.  argv = [in.bam, out.bed, flags...] (no threshold flags)."""
+    in rank order into `<out>`.  argv = [in.bam, out.bed, flags...] (no threshold flags).
+    Parity: the thresholds are the FULL-DATA percentile (`-f 1.0`; the count-based default sampler carries quotas from interval
+    to interval and does not shard), so the output is byte-identical to a single-GPU run with `-f 1.0 -p q` — or with the explicit
+    `--filter-threshold` values this function returns — not to a default (`-n 10042`) run.
+    `--with-header` is written by rank 0 only; `--bgzf` (one BGZF stream + one index) and `--partition-tag` (one file per key)
+    do not concatenate and are refused.  `stats` (a dict) receives this rank's wall times."""
     import os
     import shutil
     from . import Context, pileup
@@ -147,6 +152,11 @@ def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1):
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     bam, out, flags = argv[0], argv[1], list(argv[2:])
+    for bad in ("--bgzf", "--partition-tag", "--bedgraph"):
+        if bad in flags:
+            raise ValueError("pileup_sharded: %s output does not concatenate over ranks; run it on one GPU" % bad)
+    if rank > 0:   # one header, from rank 0
+        flags = [f for f in flags if f not in ("--with-header", "--header")]
     sflags, i = [], 0
     while i < len(flags):
         if flags[i] in SAMPLING_FLAGS_WITH_VALUE:
@@ -156,11 +166,14 @@ def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1):
             if flags[i] in SAMPLING_FLAGS_BARE:
                 sflags.append(flags[i])
             i += 1
+    import time
+    t0 = time.time()
     ctx = Context(device=0 if device is None else device)
     try:
         thr = estimate_thresholds_allreduce(ctx, bam, sflags, q=q, rank=rank, world=world)
     finally:
         ctx.close()
+    t1 = time.time()
     targv = []
     for b, v in sorted(thr.items()):
         targv += ["--filter-threshold", "%s:%r" % (b, v)]
@@ -168,6 +181,8 @@ def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1):
         raise ValueError("no mod calls sampled on any rank")
     part = "%s.rank%d" % (out, rank)
     pileup([bam, part] + flags + targv + ["--gpus-rank", str(rank), "--gpus-world", str(world)] + (["--device", str(device)] if device is not None else []))
+    if stats is not None:
+        stats.update({"threshold_s": t1 - t0, "pileup_s": time.time() - t1, "part_bytes": os.path.getsize(part)})
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:

@@ -86,3 +86,40 @@ def test_two_ranks_each_read_about_half_of_the_file(tmp_path):
     size = os.path.getsize(bam)
     assert all(0.3 * size < x < 0.7 * size for x in reads), (size, reads)   # balanced by the bytes the index puts under each run
     assert sum(reads) < 1.25 * s["bam_bytes_read"]
+
+
+def _bgzf_block(data):
+    import struct
+    import zlib
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    return (bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0]) + struct.pack("<H", len(comp) + 25) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def test_oversized_block_size_in_an_indexed_bam_fails_loudly(tmp_path):
+    """A record whose block_size runs past the end of the data, reached through the BAI (the bounded reader of mkp_bam.hpp): the old
+    reader dropped it silently in the last window (and re-inflated the same window forever in an earlier one); it is an I/O error."""
+    import struct
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:c\tLN:100000\n"
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1) + struct.pack("<i", 2) + b"c\0" + struct.pack("<i", 100000)
+
+    def rec(pos, block_size=None):
+        name = b"r%d\0" % pos
+        core = struct.pack("<iiBBHHHiiii", 0, pos, len(name), 30, 4681, 1, 0, 10, -1, -1, 0)
+        body = core + name + struct.pack("<I", (10 << 4) | 0) + bytes([0x12] * 5) + bytes([30] * 10)
+        return struct.pack("<i", len(body) if block_size is None else block_size) + body
+    recs = rec(10) + rec(20, 0x7fffff00) + rec(30)
+    b1, b2 = _bgzf_block(hdr), _bgzf_block(recs)
+    eof = bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    bam = str(tmp_path / "bad.bam")
+    open(bam, "wb").write(b1 + b2 + eof)
+    beg, end = len(b1) << 16, (len(b1) + len(b2)) << 16
+    bai = (b"BAI\1" + struct.pack("<i", 1) + struct.pack("<i", 2) + struct.pack("<Ii", 4681, 1) + struct.pack("<QQ", beg, end) +
+           struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", beg, end, 3, 0) +      # htslib's metadata pseudo-bin: without it the reader loads the whole file
+           struct.pack("<i", 1) + struct.pack("<Q", beg) + struct.pack("<Q", 0))
+    open(bam + ".bai", "wb").write(bai)
+    modkit_amd.build()
+    p = subprocess.run([CLI, "pileup", bam, str(tmp_path / "o.tsv"), "--plan-only", "--stats"], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0, p.stderr
+    assert "BAM record" in p.stderr or "corrupt" in p.stderr, p.stderr
