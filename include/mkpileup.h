@@ -124,8 +124,11 @@ typedef struct {
   const uint32_t* n_fail;     /* n_filtered */
   const uint32_t* n_diff;
   const uint32_t* n_nocall;
-  uint64_t processed_records; /* reads that yielded mod calls (read_cache.rs:357-365) */
-  uint64_t skipped_records;   /* coverage-only reads (skip_set) */
+  /* Log-only counters (the reference prints them at debug level).  Here: kept records of the SHARD whose tags yielded calls /
+   * that only contribute coverage.  The reference counts per INTERVAL cache, distinct read names (read_cache.rs:357-365): a read
+   * spanning k intervals is counted k times there, once here; the sums over a run differ, the rows do not. */
+  uint64_t processed_records;
+  uint64_t skipped_records;
   /* --partition-tag (PartitionKey, src/pileup/mod.rs:607-610, 795-815): rows are grouped by key (all rows of key 0, then key 1, ..),
    * genome order inside a key.  partition_key[i] indexes partition_key_names; name 0 is "ungrouped" (PartitionKey::NoKey: no
    * partition tags set, or the read carries none of them); the others are the tag values joined by '_' ("missing" for an absent

@@ -12,20 +12,25 @@
 using namespace mkp;
 
 extern "C" {
-hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[7]*/, const uint32_t*, const uint8_t*, const MkpTagRef*, const uint32_t*,
+hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[7]*/, const uint32_t*, const uint8_t*,
+    const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
 hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
-hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*, const MkpReadOut*, const MkpTile*, uint32_t,
+hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*,
+    const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
                              uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
-hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*, const uint32_t* /*cover read ids*/, uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
+hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*, const uint32_t* /*cover read ids*/,
+    uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
                             const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
-hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t, const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
+hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
+    const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
                              const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);
-hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/, const uint32_t* /*interval starts*/,
+hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
+    const uint32_t* /*interval starts*/,
                                   uint32_t, int32_t, int32_t, uint32_t* /*error bits*/);
 }
 
@@ -49,7 +54,8 @@ template <class F> void host_parallel(size_t n, size_t grain, F f);
 void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[7], bool duplex) {
   auto class_of = [&](size_t i) -> int {
     const MkpReadHdr& h = S.hdr[i];
-    auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1]; return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
+    auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1];
+        return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
     if ((h.flags & MKP_RF_BAD) || !h.n_tags || h.layout >= T.dev.size()) return 4;
     const MkpLayout& L = T.dev[h.layout];
     bool explicit_tags = true;
@@ -71,7 +77,8 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   host_parallel(S.hdr.size(), 4096, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cl[i] = (uint8_t)class_of(i); });
   std::vector<uint32_t> cls[7];
   for (size_t i = 0; i < cl.size(); i++) cls[cl[i]].push_back((uint32_t)i);
-  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; }); });
+  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x,
+      uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; }); });
   ids->clear();
   for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
   for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r); ids->push_back(r | 0x80000000u); } }
@@ -131,7 +138,8 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
   size_t j = 0, cur = 0, best = 0;
   for (size_t i = 0; i < n; i++) { while (j < n && en[j] <= st[i]) { j++; cur--; } cur++; best = std::max(best, cur); }
   if (best > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
-  if (best > max_depth) throw Error(MKP_E_UNSUPPORTED, "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
+  if (best > max_depth) throw Error(MKP_E_UNSUPPORTED,
+      "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
 }
 
 // derive tile geometry, tile read ranges and the run parameters; upload everything
@@ -139,14 +147,20 @@ void make_resident(mkp_ctx* c) {
   auto t0 = std::chrono::steady_clock::now();
   ShardHost& S = c->shard;
   const bool trace = getenv("MKP_TRACE_PLAN") != nullptr;   // host planning stages on stderr
-  auto lap = [&, last = t0](const char* what) mutable { if (trace) { auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
+  auto lap = [&, last = t0](const char* what) mutable { if (trace) { auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
-  { std::vector<std::pair<uint32_t, uint64_t>> h(S.name_hash.size()); for (size_t i = 0; i < h.size(); i++) h[i] = {i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u, S.name_hash[i]};   // per partition key: tallies of different keys never meet
-    std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED, "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device"); }
+  { std::vector<std::pair<uint32_t, uint64_t>> h(S.name_hash.size());
+      for (size_t i = 0; i < h.size(); i++) h[i] = {i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u, S.name_hash[i]};
+      // per partition key: tallies of different keys never meet
+    std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED,
+        "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device");
+        }
   lap("duplicate-name check");
   // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
-  { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1; c->tables.build(c->packer.layouts, c->caller, &used); }
+  { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1;
+      c->tables.build(c->packer.layouts, c->caller, &used); }
   MkpRunParams& P = c->prm; memset(&P, 0, sizeof(P));
   P.win_start = S.win_start; P.win_end = S.win_end;
   P.n_counters = c->tables.n_counters; P.n_slots = (uint32_t)c->tables.st.slots.size(); P.n_pb = (uint32_t)c->tables.st.can_pbs.size();
@@ -159,7 +173,8 @@ void make_resident(mkp_ctx* c) {
   for (int b = 0; b < 4; b++) { P.can_of_pb[b] = 0xff; P.pb_of_can[b] = 0; }
   for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) { P.can_of_pb[c->tables.st.can_pbs[k]] = (uint8_t)k; P.pb_of_can[k] = (uint8_t)c->tables.st.can_pbs[k]; }
   std::vector<int> order(P.n_slots); for (uint32_t i = 0; i < P.n_slots; i++) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a], &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a],
+      &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
   for (uint32_t i = 0; i < P.n_slots; i++) { P.slot_order[i] = (uint8_t)order[i]; P.slots[i] = c->tables.st.slots[i]; }
   lap("caller tables + params");
   if (P.combine_strands && !P.has_focus) throw Error(MKP_E_INVALID, "combine_strands needs motif focus positions");
@@ -228,7 +243,8 @@ void make_resident(mkp_ctx* c) {
       h.event_cap = std::max(h.event_cap, (uint32_t)need);
     } }
   { uint64_t off = 0;   // event slices laid out again (capacities may have grown above)
-    for (auto& h : S.hdr) { if (off > 0xfffffff0ull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards"); h.event_off = (uint32_t)off; off += h.event_cap; }
+    for (auto& h : S.hdr) { if (off > 0xfffffff0ull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
+        h.event_off = (uint32_t)off; off += h.event_cap; }
     S.n_events_cap = off; }
   P.readout_b_off = (uint32_t)S.hdr.size();
   lap("decode classes + event slices");
@@ -250,7 +266,9 @@ void make_resident(mkp_ctx* c) {
   const bool stream = c->has_focus && !c->hemi && !(getenv("MKP_PIPELINE") && !strcmp(getenv("MKP_PIPELINE"), "tiles"));
   std::vector<uint32_t> slot_pos_h; std::vector<MkpSTile> stiles;
   c->slot_mode = stream; P.slot_stream = stream ? 1u : 0u; c->cov_bytes = 0;
-  auto max_slots_for = [&](uint32_t W) { uint32_t best = 0; for (uint32_t s = 64; s <= 4160; s += 64) if (MKP_PILEUP_LDS_WORDS(words_per_slot, s, W) <= budget_words) best = s; return best; };
+  auto max_slots_for = [&](uint32_t W) { uint32_t best = 0; for (uint32_t s = 64; s <= 4160; s += 64) if (MKP_PILEUP_LDS_WORDS(words_per_slot, s,
+      W) <= budget_words) best = s;
+  return best; };
   if (!c->has_focus) {
     uint32_t Smax = max_slots_for(0);
     if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
@@ -267,11 +285,13 @@ void make_resident(mkp_ctx* c) {
     uint8_t hemi_ok[64]; for (size_t k = 0; k < 64; k++) hemi_ok[k] = (k < c->combos.size() && c->combos[k].n_pos > 0) ? 1 : 0;
     const bool hemi = c->hemi;
     host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {   // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
-      for (size_t p = lo; p < hi; p++) if (hemi ? ((fz[p] & 1u) && hemi_ok[fz[p] >> 2]) : (fz[p] & 3u)) { const size_t b = p + MKP_SLOTBM_MARGIN; slotbm[b >> 5] |= 1u << (b & 31); }
+      for (size_t p = lo; p < hi; p++) if (hemi ? ((fz[p] & 1u) && hemi_ok[fz[p] >> 2]) : (fz[p] & 3u)) { const size_t b = p + MKP_SLOTBM_MARGIN;
+          slotbm[b >> 5] |= 1u << (b & 31); }
     });
     std::vector<uint32_t> wpfx(nwords + 1, 0);
     for (size_t w = 0; w < nwords; w++) wpfx[w + 1] = wpfx[w] + (uint32_t)__builtin_popcount(slotbm[w]);
-    auto rank = [&](int64_t p) { const size_t b = (size_t)(p - S.win_start + MKP_SLOTBM_MARGIN); return wpfx[b >> 5] + (uint32_t)__builtin_popcount(slotbm[b >> 5] & ((1u << (b & 31)) - 1u)); };
+    auto rank = [&](int64_t p) { const size_t b = (size_t)(p - S.win_start + MKP_SLOTBM_MARGIN);
+        return wpfx[b >> 5] + (uint32_t)__builtin_popcount(slotbm[b >> 5] & ((1u << (b & 31)) - 1u)); };
     if (stream) {
       // ---- slot pipeline plan (mkp_slots.hip): global slot numbering, per-read slot ranges and feature-stream offsets, tiles of slots
       const int64_t lo_clamp = (int64_t)S.win_start - MKP_SLOTBM_MARGIN, hi_clamp = (int64_t)S.win_end + MKP_SLOTBM_MARGIN;
@@ -279,7 +299,9 @@ void make_resident(mkp_ctx* c) {
       const uint32_t total = wpfx[nwords];
       slot_pos_h.resize(total);
       host_parallel(nwords, (size_t)1 << 15, [&](size_t lo, size_t hi) {
-        for (size_t w = lo; w < hi; w++) { uint32_t at = wpfx[w]; for (uint32_t bits = slotbm[w]; bits; bits &= bits - 1u) slot_pos_h[at++] = (uint32_t)((int64_t)(w * 32 + (size_t)__builtin_ctz(bits)) - MKP_SLOTBM_MARGIN + S.win_start); }
+        for (size_t w = lo; w < hi; w++) { uint32_t at = wpfx[w];
+            for (uint32_t bits = slotbm[w]; bits; bits &= bits - 1u) slot_pos_h[at++] = (uint32_t)((int64_t)(w * 32 + (size_t)__builtin_ctz(bits)) - MKP_SLOTBM_MARGIN + S.win_start);
+            }
       });
       uint64_t off = 0;
       for (auto& h : S.hdr) {
@@ -290,11 +312,13 @@ void make_resident(mkp_ctx* c) {
       }
       c->cov_bytes = off;
       // tile = a run of slots: rows for [g0, g1), tally columns for the slots within MKP_HALO positions of them (strand combining)
-      const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, (budget_words / (words_per_slot + 1u)) & ~63u);   // + the tile's slot positions; row emission: one thread per slot
+      const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, (budget_words / (words_per_slot + 1u)) & ~63u);
+          // + the tile's slot positions; row emission: one thread per slot
       if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
       uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 2048u + 63u) & ~63u));   // about 2000 tiles over 512 resident workgroups
       if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));   // tests: many small tiles
-      if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));   // experiments
+      if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));
+          // experiments
       uint32_t most = 0;
       for (uint32_t g0 = 0; g0 < total; g0 += Te) {
         MkpSTile t; t.g0 = g0; t.g1 = std::min(total, g0 + Te);
@@ -311,17 +335,20 @@ void make_resident(mkp_ctx* c) {
     // fewer tiles mean a coarser balance over the 512 resident workgroups.  Measured on C3: 2 600 tiles of 24 kb beat 4 100 of 16 kb by 9 %
     // and 7 900 of 8 kb by 31 %.  Small windows keep >= 16 kb tiles (a handful of workgroups of little work each).
     uint32_t span = (uint32_t)std::min<int64_t>(span_max, std::max<int64_t>(16384, ((win / 2600) + 63) & ~63ll));
-    if (c->cfg.tile_positions) span = std::max<uint32_t>(64u, std::min(span_max & ~63u, c->cfg.tile_positions & ~63u));   // explicit tile span (tests: many small tiles; experiments: larger ones)
+    if (c->cfg.tile_positions) span = std::max<uint32_t>(64u, std::min(span_max & ~63u, c->cfg.tile_positions & ~63u));
+        // explicit tile span (tests: many small tiles; experiments: larger ones)
     Wcap = (span + 2 * MKP_HALO + 31 + 31) / 32 + 2;
     const uint32_t Smax = std::min<uint32_t>(max_slots_for(Wcap), MKP_PILEUP_THREADS);   // row emission of a focus tile: one thread per slot
     if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
     uint32_t most = 0;
     for (int64_t r0 = S.win_start; r0 < S.win_end;) {
       int64_t r1 = std::min<int64_t>(r0 + span, S.win_end);
-      auto halo_slots = [&](int64_t a, int64_t b) { return rank(std::min<int64_t>(b + MKP_HALO, (int64_t)S.win_end + MKP_SLOTBM_MARGIN)) - rank(std::max<int64_t>(a - MKP_HALO, (int64_t)S.win_start - MKP_SLOTBM_MARGIN)); };
+      auto halo_slots = [&](int64_t a, int64_t b) { return rank(std::min<int64_t>(b + MKP_HALO,
+          (int64_t)S.win_end + MKP_SLOTBM_MARGIN)) - rank(std::max<int64_t>(a - MKP_HALO, (int64_t)S.win_start - MKP_SLOTBM_MARGIN)); };
       while (halo_slots(r0, r1) > Smax && r1 - r0 > 32) r1 = r0 + std::max<int64_t>(32, (r1 - r0) / 2);   // dense focus: shorter tile
       if (halo_slots(r0, r1) > Smax) throw Error(MKP_E_UNSUPPORTED, "internal: focus tile does not fit the LDS budget");
-      if (rank(r1) > rank(r0)) { tiles.push_back({(int32_t)r0, (int32_t)r1, 0, 0}); most = std::max(most, halo_slots(r0, r1)); }   // a tile without focus positions emits nothing
+      if (rank(r1) > rank(r0)) { tiles.push_back({(int32_t)r0, (int32_t)r1, 0, 0}); most = std::max(most, halo_slots(r0, r1));
+          }   // a tile without focus positions emits nothing
       r0 = r1;
     }
     Scap = std::max<uint32_t>(64u, (most + 63u) & ~63u);
@@ -390,10 +417,12 @@ void make_resident(mkp_ctx* c) {
   c->stats.pack_ms += ms_since(t0);
   auto t1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");
-  upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
+  upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref);
+      upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
   upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
   upload(c->d_read_ids, class_list);
-  if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64); c->d_slotbm.ensure(16); }
+  if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64);
+      c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
@@ -405,9 +434,11 @@ void make_resident(mkp_ctx* c) {
       host_parallel(nf, 8192, [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; k++) {
           const MkpReadHdr& h = S.hdr[slot_ids[k]]; MkpWork& w = work[k]; memset(&w, 0, sizeof(w));
-          w.ref_start = h.ref_start; w.l_seq = h.l_seq; w.n_cigar = h.n_cigar; w.cigar_off = h.cigar_off; w.seq_off = h.seq_off; w.flags = h.flags; w.gs0 = h.gs0; w.n_sl = h.n_sl;
+          w.ref_start = h.ref_start; w.l_seq = h.l_seq; w.n_cigar = h.n_cigar; w.cigar_off = h.cigar_off; w.seq_off = h.seq_off; w.flags = h.flags; w.gs0 = h.gs0;
+              w.n_sl = h.n_sl;
           w.cov_off = h.cov_off; w.n_tags = h.n_tags; w.layout = h.layout; w.rid = slot_ids[k];
-          if (!(h.flags & MKP_RF_BAD) && h.n_tags) { const MkpTagRef& t0 = S.tagref[h.tag_off]; w.rank_off = t0.rank_off; w.n_calls = t0.n; w.ml_off0 = t0.ml_off; if (h.n_tags > 1) w.ml_off1 = S.tagref[h.tag_off + 1].ml_off; }
+          if (!(h.flags & MKP_RF_BAD) && h.n_tags) { const MkpTagRef& t0 = S.tagref[h.tag_off]; w.rank_off = t0.rank_off; w.n_calls = t0.n; w.ml_off0 = t0.ml_off;
+              if (h.n_tags > 1) w.ml_off1 = S.tagref[h.tag_off + 1].ml_off; }
         }
       });
       upload(c->d_work, work);
@@ -421,7 +452,8 @@ void make_resident(mkp_ctx* c) {
   // partition keys present in this shard: one accumulate pass each
   c->key_passes.clear();
   if (c->partition_tags.empty()) c->key_passes.push_back(MKP_NO_KEY_FILTER);
-  else { std::vector<uint8_t> seen(c->key_names.size(), 0); for (auto& h : S.hdr) { const uint32_t k = h.flags >> MKP_RF_KEY_SHIFT; if (k < seen.size()) seen[k] = 1; } for (uint32_t k = 0; k < seen.size(); k++) if (seen[k]) c->key_passes.push_back(k); if (c->key_passes.empty()) c->key_passes.push_back(0); }
+  else { std::vector<uint8_t> seen(c->key_names.size(), 0); for (auto& h : S.hdr) { const uint32_t k = h.flags >> MKP_RF_KEY_SHIFT; if (k < seen.size()) seen[k] = 1;
+      } for (uint32_t k = 0; k < seen.size(); k++) if (seen[k]) c->key_passes.push_back(k); if (c->key_passes.empty()) c->key_passes.push_back(0); }
   hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
   c->stats.h2d_ms = ms_since(t1);
@@ -447,7 +479,8 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
   MkpRunParams& P = c->prm;
   if (c->row_cap == 0) {
     // focus runs: usually one strand rule per focus position and one row per observed code; otherwise two strands per position
-    uint64_t guess = c->hemi ? c->n_slots_total * 3 + 4096 : c->has_focus ? c->n_slots_total * std::max<uint32_t>(1u, P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
+    uint64_t guess = c->hemi ? c->n_slots_total * 3 + 4096 : c->has_focus ? c->n_slots_total * std::max<uint32_t>(1u,
+        P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
     c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess * c->key_passes.size(), 1ull << 28));
   }
   const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
@@ -460,24 +493,30 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     c->d_prm.ensure(sizeof(MkpRunParams));
     hip_check(hipMemcpyAsync(c->d_prm.p, &P, sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
+    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class, c->d_cigar.as<uint32_t>(),
+        c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
-    if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+    if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(),
+        c->d_readout.as<MkpReadOut>(),
                                                   (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
-    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_work.as<MkpWork>(), c->n_slot_class[0], c->n_slot_class[1], c->d_hdr.as<MkpReadHdr>(), c->d_slot_ids.as<uint32_t>(), c->n_slot_class[2],
+    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_work.as<MkpWork>(), c->n_slot_class[0], c->n_slot_class[1], c->d_hdr.as<MkpReadHdr>(),
+        c->d_slot_ids.as<uint32_t>(), c->n_slot_class[2],
                                               c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                               c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), c->d_fdesc.as<MkpFusedDesc>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(), c->d_visits.as<MkpVisit>(),
                                               c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2), "slot decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
-      if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
+      if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
+          c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
                                                  c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
                                                  c->key_passes[kp], kp), "stream pileup launch");
-      else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+      else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
+          c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
                                   c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1, &c->rows_src, &c->rows_dst), "gather launch");
+    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
+        &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     uint32_t h[4];
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
@@ -519,7 +558,8 @@ void fetch_hemi_rows(mkp_ctx* c, mkp_hemi_rows* out) {
   }
   c->stats.d2h_ms = ms_since(t0);
   if (out) {
-    out->n_rows = n; out->pos = c->h_rows[0].data(); out->primary_base = c->h_hemi_base.data(); out->pattern_pos = c->h_hemi_pat[0].data(); out->pattern_neg = c->h_hemi_pat[1].data();
+    out->n_rows = n; out->pos = c->h_rows[0].data(); out->primary_base = c->h_hemi_base.data(); out->pattern_pos = c->h_hemi_pat[0].data();
+        out->pattern_neg = c->h_hemi_pat[1].data();
     out->n_valid = c->h_rows[3].data(); out->count = c->h_rows[4].data(); out->n_canonical = c->h_rows[5].data(); out->n_other_pattern = c->h_rows[6].data();
     out->n_delete = c->h_rows[7].data(); out->n_fail = c->h_rows[8].data(); out->n_diff = c->h_rows[9].data(); out->n_nocall = c->h_rows[10].data();
     out->processed_records = c->n_ok; out->skipped_records = c->n_bad;
@@ -531,7 +571,8 @@ void fetch_rows(mkp_ctx* c, mkp_rows* out) {
   fetch_row_columns(c);
   const uint64_t n = c->stats.n_rows;
   c->h_strand.resize(n); c->h_motif.resize(n); c->h_key.resize(n);
-  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1; c->h_key[i] = inf >> 16; }
+  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1;
+      c->h_key[i] = inf >> 16; }
   c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
   c->stats.d2h_ms = ms_since(t0);
   if (out) {
@@ -549,11 +590,13 @@ bool aux_stringable(const mkp_record& r, const char* tag, std::string* out) {
   const size_t fixed = (size_t)r.l_qname + 4 * (size_t)r.n_cigar + ((size_t)std::max(r.l_qseq, 0) + 1) / 2 + (size_t)std::max(r.l_qseq, 0);
   if (fixed > (size_t)r.l_data) return false;
   const uint8_t* a = r.data + fixed; const uint8_t* e = r.data + r.l_data;
-  auto width = [](uint8_t ty) -> int { switch (ty) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; default: return -1; } };
+  auto width = [](uint8_t ty) -> int { switch (ty) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4;
+      case 'd': return 8; default: return -1; } };
   while (a + 3 <= e) {
     const uint8_t ty = a[2]; const uint8_t* v = a + 3; const uint8_t* nx;
     if (ty == 'Z' || ty == 'H') { const uint8_t* z = v; while (z < e && *z) z++; if (z >= e) return false; nx = z + 1; }
-    else if (ty == 'B') { if (v + 5 > e) return false; const int w = width(v[0]); uint32_t cnt; memcpy(&cnt, v + 1, 4); if (w < 0 || (uint64_t)cnt * (uint64_t)w > (uint64_t)(e - v - 5)) return false; nx = v + 5 + (size_t)cnt * (size_t)w; }
+    else if (ty == 'B') { if (v + 5 > e) return false; const int w = width(v[0]); uint32_t cnt; memcpy(&cnt, v + 1, 4);
+        if (w < 0 || (uint64_t)cnt * (uint64_t)w > (uint64_t)(e - v - 5)) return false; nx = v + 5 + (size_t)cnt * (size_t)w; }
     else { const int w = width(ty); if (w < 0 || v + w > e) return false; nx = v + w; }
     if (a[0] == (uint8_t)tag[0] && a[1] == (uint8_t)tag[1]) {   // first occurrence (bam_aux_get)
       char buf[64];
@@ -636,7 +679,8 @@ int mkp_set_partition_tags(mkp_ctx* c, const char* const* tags, uint32_t n) {
   if (!c || (!tags && n)) return MKP_E_INVALID;
   return guarded(c, [&]() {
     std::vector<std::string> v;
-    for (uint32_t i = 0; i < n; i++) { if (!tags[i] || strlen(tags[i]) != 2) throw Error(MKP_E_INVALID, "SAM tags are two characters"); if (std::find(v.begin(), v.end(), tags[i]) != v.end()) throw Error(MKP_E_INVALID, "partition tag given twice"); v.push_back(tags[i]); }
+    for (uint32_t i = 0; i < n; i++) { if (!tags[i] || strlen(tags[i]) != 2) throw Error(MKP_E_INVALID, "SAM tags are two characters");
+        if (std::find(v.begin(), v.end(), tags[i]) != v.end()) throw Error(MKP_E_INVALID, "partition tag given twice"); v.push_back(tags[i]); }
     c->partition_tags = v; c->resident = false;
   });
 }
@@ -671,8 +715,10 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
     // supplementary records are not tallied but htslib buffers them (BAM_DEF_MASK lets 0x800 through): their spans count for the max-depth guard
     for (uint32_t i = 0; i < n; i++) {
       const mkp_record& r = recs[i];
-      if (r.tid != tid || !(r.flag & 2048) || (r.flag & (4 | 256 | 512 | 1024)) || !r.n_cigar || !r.data || (uint64_t)r.l_qname + 4ull * r.n_cigar > (uint64_t)std::max(r.l_data, 0)) continue;
-      int64_t len = 0; for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, r.data + r.l_qname + 4 * (size_t)k, 4); if ((0x18du >> (w & 15u)) & 1u) len += w >> 4; }
+      if (r.tid != tid || !(r.flag & 2048) || (r.flag & (4 | 256 | 512 | 1024)) || !r.n_cigar || !r.data || (uint64_t)r.l_qname + 4ull * r.n_cigar > (uint64_t)std::max(r.l_data,
+          0)) continue;
+      int64_t len = 0; for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, r.data + r.l_qname + 4 * (size_t)k, 4);
+          if ((0x18du >> (w & 15u)) & 1u) len += w >> 4; }
       c->shard.extra_spans.push_back({r.pos, (int32_t)std::min<int64_t>((int64_t)r.pos + std::max<int64_t>(len, 1), INT32_MAX)});
     }
     if (!c->partition_tags.empty()) {   // PartitionKey per kept record (parse_tags_from_record, pileup/mod.rs:626-643): values joined by '_', "missing" for an absent tag
@@ -682,9 +728,12 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
         if (!(r.tid == tid && Packer::keep(r))) continue;
         if (at >= c->shard.hdr.size()) throw Error(MKP_E_INVALID, "internal: packer dropped a kept record");
         std::string key; bool any = false;
-        for (size_t t = 0; t < c->partition_tags.size(); t++) { std::string v; const bool got = aux_stringable(r, c->partition_tags[t].c_str(), &v); any |= got; if (t) key += '_'; key += got ? v : std::string("missing"); }
+        for (size_t t = 0; t < c->partition_tags.size(); t++) { std::string v; const bool got = aux_stringable(r, c->partition_tags[t].c_str(), &v); any |= got;
+            if (t) key += '_'; key += got ? v : std::string("missing"); }
         uint32_t id = 0;
-        if (any) { auto it = std::find(c->key_names.begin() + 1, c->key_names.end(), key); id = (uint32_t)(it - c->key_names.begin()); if (it == c->key_names.end()) { if (c->key_names.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65534 partition keys in one shard"); c->key_names.push_back(key); } }
+        if (any) { auto it = std::find(c->key_names.begin() + 1, c->key_names.end(), key); id = (uint32_t)(it - c->key_names.begin());
+            if (it == c->key_names.end()) { if (c->key_names.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65534 partition keys in one shard");
+            c->key_names.push_back(key); } }
         c->shard.hdr[at].flags |= id << MKP_RF_KEY_SHIFT;
         at++;
       }
@@ -741,7 +790,8 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
     if (c->resident_hemi && out) throw Error(MKP_E_INVALID, "the resident shard ran as pileup-hemi: pass out = NULL here and read rows with mkp_hemi_shard_run");
     double d = 0, p = 0, g = 0;
     for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; g += c->stats.gather_kernel_ms; }
-    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = g / iters; c->stats.kernel_ms = (d + p + g) / iters; }
+    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = g / iters;
+        c->stats.kernel_ms = (d + p + g) / iters; }
     if (out) fetch_rows(c, out);
   });
 }
@@ -749,7 +799,8 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
 int mkp_get_stats(const mkp_ctx* c, mkp_stats* out) { if (!c || !out) return MKP_E_INVALID; *out = c->stats; return MKP_OK; }
 
 int mkp_percentile(const float* xs, uint64_t n, float q, float* out) {  // percentile_linear_interp (thresholds.rs:17-38)
-  if (!xs || !out || n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;   // negative / NaN quantiles would index out of bounds (Rust's `as usize` saturates; here they are refused)
+  if (!xs || !out || n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;
+      // negative / NaN quantiles would index out of bounds (Rust's `as usize` saturates; here they are refused)
   if (q == 1.0f) { *out = xs[n - 1]; return MKP_OK; }
   float l = (float)(n - 1), lq = l * q, left = floorf(lq); uint64_t right = std::min<uint64_t>((uint64_t)ceilf(lq), n - 1);
   float g = lq - truncf(lq), a = xs[(uint64_t)left] * (1.0f - g), b = xs[right] * g;
@@ -767,7 +818,8 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
       uint16_t xlen; memcpy(&xlen, bgzf + o + 10, 2);
       uint64_t x = o + 12; const uint64_t xe = x + xlen; uint32_t bsize = 0; bool found = false;
       if (xe > n_bytes) throw Error(MKP_E_IO, "bad BGZF block");
-      while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, bgzf + x + 2, 2); if (bgzf[x] == 'B' && bgzf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b; memcpy(&b, bgzf + x + 4, 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (uint64_t)sl; }
+      while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, bgzf + x + 2, 2); if (bgzf[x] == 'B' && bgzf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b;
+          memcpy(&b, bgzf + x + 4, 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (uint64_t)sl; }
       if (!found || o + bsize > n_bytes || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block");
       uint32_t crc, isize; memcpy(&crc, bgzf + o + bsize - 8, 4); memcpy(&isize, bgzf + o + bsize - 4, 4);
       if (isize > 65536u) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB");
@@ -776,12 +828,14 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
     }
     if (blks.size() > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED, "too many BGZF blocks");
     hip_check(hipSetDevice(c->device), "hipSetDevice");
-    c->d_zin.ensure(std::max<uint64_t>(n_bytes, 16)); c->d_zout.ensure(std::max<uint64_t>(total, 16)); c->d_zblk.ensure(std::max<size_t>(blks.size(), 1) * sizeof(Blk)); c->d_zstat.ensure(std::max<size_t>(blks.size(), 1) * 4);
+    c->d_zin.ensure(std::max<uint64_t>(n_bytes, 16)); c->d_zout.ensure(std::max<uint64_t>(total, 16)); c->d_zblk.ensure(std::max<size_t>(blks.size(), 1) * sizeof(Blk));
+        c->d_zstat.ensure(std::max<size_t>(blks.size(), 1) * 4);
     if (n_bytes) hip_check(hipMemcpyAsync(c->d_zin.p, bgzf, n_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
     if (!blks.empty()) hip_check(hipMemcpyAsync(c->d_zblk.p, blks.data(), blks.size() * sizeof(Blk), hipMemcpyHostToDevice, c->stream), "H2D");
     hip_check(hipMemsetAsync(c->d_zstat.p, 0xff, std::max<size_t>(blks.size(), 1) * 4, c->stream), "memset");
     hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    hip_check(mkp_launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()), "inflate launch");
+    hip_check(mkp_launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()),
+        "inflate launch");
     hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     std::vector<uint32_t> st(blks.size());
     c->h_inflated.resize(total);
@@ -796,7 +850,8 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
         if (!ok) { long exp = -1; bad.compare_exchange_strong(exp, (long)i); }
       }
     });
-    if (bad.load() >= 0) throw Error(MKP_E_IO, "corrupt BGZF data: block " + std::to_string(bad.load()) + " (decoder status " + std::to_string(st[(size_t)bad.load()]) + ")");
+    if (bad.load() >= 0) throw Error(MKP_E_IO,
+        "corrupt BGZF data: block " + std::to_string(bad.load()) + " (decoder status " + std::to_string(st[(size_t)bad.load()]) + ")");
     *out = c->h_inflated.data(); *out_len = total;
   });
 }
@@ -809,8 +864,10 @@ int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_ta
     const uint32_t cg = (l_seq << 4) | 0u; data.insert(data.end(), (const uint8_t*)&cg, (const uint8_t*)&cg + 4);
     data.insert(data.end(), (l_seq + 1) / 2, 0x11); data.insert(data.end(), l_seq, 0xff);
     data.push_back('M'); data.push_back('M'); data.push_back('Z'); data.insert(data.end(), mm, mm + strlen(mm) + 1);
-    data.push_back('M'); data.push_back('L'); data.push_back('B'); data.push_back('C'); data.insert(data.end(), (const uint8_t*)&n_ml, (const uint8_t*)&n_ml + 4); data.insert(data.end(), n_ml, 0);
-    mkp_record r; memset(&r, 0, sizeof(r)); r.tid = 0; r.pos = 0; r.l_qname = 2; r.n_cigar = 1; r.l_qseq = (int32_t)l_seq; r.l_data = (int32_t)data.size(); r.data = data.data();
+    data.push_back('M'); data.push_back('L'); data.push_back('B'); data.push_back('C'); data.insert(data.end(), (const uint8_t*)&n_ml, (const uint8_t*)&n_ml + 4);
+        data.insert(data.end(), n_ml, 0);
+    mkp_record r; memset(&r, 0, sizeof(r)); r.tid = 0; r.pos = 0; r.l_qname = 2; r.n_cigar = 1; r.l_qseq = (int32_t)l_seq; r.l_data = (int32_t)data.size();
+        r.data = data.data();
     Packer pk; ShardHost S; S.tid = 0; pk.add(r, S);
     if (S.hdr.empty() || (S.hdr[0].flags & MKP_RF_BAD)) return MKP_E_INVALID;
     const LayoutHost& L = pk.layouts[S.hdr[0].layout];
@@ -828,7 +885,8 @@ int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_ta
 
 int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_out) {
   if (!code_reprs || !order_out || n > 14) return MKP_E_INVALID;
-  try { FxOrder m; for (uint32_t i = 0; i < n; i++) m.insert(code_reprs[i], (int)i); auto c = m.codes(); for (size_t i = 0; i < c.size(); i++) order_out[i] = c[i]; return (int)c.size(); }
+  try { FxOrder m; for (uint32_t i = 0; i < n; i++) m.insert(code_reprs[i], (int)i); auto c = m.codes(); for (size_t i = 0; i < c.size(); i++) order_out[i] = c[i];
+      return (int)c.size(); }
   catch (...) { return MKP_E_INVALID; }
 }
 
@@ -836,9 +894,11 @@ int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_o
 
 // ---- threshold sampling on the device (decode kernels in sampling mode; the values stay in HBM)
 extern "C" {
-hipError_t mkp_launch_sample_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const float*, const MkpEvent*, uint32_t*, unsigned long long, unsigned long long*, uint32_t*, uint32_t*);
+hipError_t mkp_launch_sample_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const float*, const MkpEvent*, uint32_t*,
+    unsigned long long, unsigned long long*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_sample_hist1(hipStream_t, const uint32_t*, unsigned long long, uint32_t, uint32_t, uint32_t*);
-hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const MkpEvent*, unsigned long long*, unsigned long long*);
+hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const MkpEvent*, unsigned long long*,
+    unsigned long long*);
 }
 
 // Decode `recs` in sampling mode.  n_vals[i] = number of argmax probabilities record i yields after the filters (0: rejected or
@@ -852,17 +912,21 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     c->tables.build(c->packer.layouts, c->caller);
     MkpRunParams P; memset(&P, 0, sizeof(P));
     P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
-    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->summary_mode ? 2 : 1; P.only_mapped = only_mapped; P.has_focus = bedmask != nullptr;
+    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
+        P.has_focus = bedmask != nullptr;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
     upload(c->d_layouts, c->tables.dev);
     { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class, false); upload(c->d_read_ids, ids); }
-    if (bedmask) { c->d_focus.ensure((size_t)(win_end - win_start)); hip_check(hipMemcpy(c->d_focus.p, bedmask, (size_t)(win_end - win_start), hipMemcpyHostToDevice), "H2D"); } else c->d_focus.ensure(16);
+    if (bedmask) { c->d_focus.ensure((size_t)(win_end - win_start)); hip_check(hipMemcpy(c->d_focus.p, bedmask, (size_t)(win_end - win_start), hipMemcpyHostToDevice),
+        "H2D"); } else c->d_focus.ensure(16);
     const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
-    c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut)); c->d_misc.ensure(64);
+    c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
+        c->d_misc.ensure(64);
     uint32_t* misc = c->d_misc.as<uint32_t>();
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
+    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
+        c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
                                 c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), c->d_vals.as<float>()), "decode(sample) launch");
     uint32_t h[4]; hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     c->sample_ro.resize(S.hdr.size());
@@ -906,16 +970,19 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
       if (!c->d_summary.p) throw Error(MKP_E_INVALID, "internal: summary table not set up");
       c->d_take.ensure(std::max<size_t>(n, 16));
       hip_check(hipMemcpyAsync(c->d_take.p, take.data(), n, hipMemcpyHostToDevice, c->stream), "H2D");
-      hip_check(mkp_launch_summary_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n, c->d_events.as<MkpEvent>(),
+      hip_check(mkp_launch_summary_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n,
+          c->d_events.as<MkpEvent>(),
                                               c->d_summary.as<unsigned long long>(), c->d_summary.as<unsigned long long>() + 128), "summary accumulate launch");
       hip_check(hipStreamSynchronize(c->stream), "summary accumulate sync");
       return;
     }
-    if (!c->d_hist0.p) { c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16); hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset"); hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
+    if (!c->d_hist0.p) { c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16);
+        hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset"); hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
     const uint64_t need = c->sample_n + add;
     // the device histograms count in 32 bits: with 2^32 or more sampled values one bin could wrap (ML bytes put most values on a handful
     // of f32 patterns) — refused rather than estimated wrongly
-    if (need > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED, "more than 2^32 - 1 sampled probabilities on one GPU (32-bit histogram counters); shard the estimate over more ranks");
+    if (need > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED,
+        "more than 2^32 - 1 sampled probabilities on one GPU (32-bit histogram counters); shard the estimate over more ranks");
     if (need * 4 > c->d_store.cap) {   // grow the resident sample, keeping what is there
       DevBuf nb; nb.ensure(std::max<uint64_t>(need * 4 * 2, 1u << 20));
       if (c->sample_n) hip_check(hipMemcpyAsync(nb.p, c->d_store.p, c->sample_n * 4, hipMemcpyDeviceToDevice, c->stream), "D2D");
@@ -924,7 +991,8 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
     c->d_take.ensure(std::max<size_t>(n, 16));
     hip_check(hipMemcpyAsync(c->d_take.p, take.data(), n, hipMemcpyHostToDevice, c->stream), "H2D");
     uint32_t* misc = c->d_misc.as<uint32_t>();
-    hip_check(mkp_launch_sample_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n, c->d_vals.as<float>(), c->d_events.as<MkpEvent>(),
+    hip_check(mkp_launch_sample_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n,
+        c->d_vals.as<float>(), c->d_events.as<MkpEvent>(),
                                            c->d_store.as<uint32_t>(), c->d_store.cap / 4, c->d_sample_cursor.as<unsigned long long>(), c->d_hist0.as<uint32_t>(), misc + 2), "sample accumulate launch");
     hip_check(hipStreamSynchronize(c->stream), "sample accumulate sync");
     c->sample_n = need;
@@ -932,7 +1000,8 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
 }
 
 namespace {
-void require_sample(mkp_ctx* c) { if (!c->d_hist0.p) { hip_check(hipSetDevice(c->device), "hipSetDevice"); c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16); hip_check(hipMemset(c->d_hist0.p, 0, 4 * 65536 * 4), "memset"); hip_check(hipMemset(c->d_sample_cursor.p, 0, 16), "memset"); } }
+void require_sample(mkp_ctx* c) { if (!c->d_hist0.p) { hip_check(hipSetDevice(c->device), "hipSetDevice"); c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4);
+    c->d_sample_cursor.ensure(16); hip_check(hipMemset(c->d_hist0.p, 0, 4 * 65536 * 4), "memset"); hip_check(hipMemset(c->d_sample_cursor.p, 0, 16), "memset"); } }
 }
 
 extern "C" {
@@ -983,7 +1052,8 @@ int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint6
   if (n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;
   uint64_t want[2];
   if (q == 1.0f) want[0] = want[1] = n - 1;
-  else { const float l = (float)(n - 1), lq = l * q; want[0] = (uint64_t)floorf(lq); want[1] = (uint64_t)ceilf(lq); if (want[1] > n - 1) want[1] = n - 1; if (want[0] > n - 1) want[0] = n - 1; }
+  else { const float l = (float)(n - 1), lq = l * q; want[0] = (uint64_t)floorf(lq); want[1] = (uint64_t)ceilf(lq); if (want[1] > n - 1) want[1] = n - 1;
+      if (want[0] > n - 1) want[0] = n - 1; }
   for (int k = 0; k < 2; k++) {
     uint64_t cum = 0; bool found = false;
     for (uint32_t b = 0; b < 65536 && !found; b++) { if (want[k] < cum + hist0[b]) { bins[k] = b; ranks_in_bin[k] = want[k] - cum; found = true; } cum += hist0[b]; }
@@ -995,7 +1065,8 @@ int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint6
 int mkp_histogram_resolve(uint32_t prefix, const uint64_t* hist1, uint64_t rank_in_bin, float* value) {
   if (!hist1 || !value || prefix > 0xffffu) return MKP_E_INVALID;
   uint64_t cum = 0;
-  for (uint32_t b = 0; b < 65536; b++) { if (rank_in_bin < cum + hist1[b]) { const uint32_t bits = (prefix << 16) | b; memcpy(value, &bits, 4); return MKP_OK; } cum += hist1[b]; }
+  for (uint32_t b = 0; b < 65536; b++) { if (rank_in_bin < cum + hist1[b]) { const uint32_t bits = (prefix << 16) | b; memcpy(value, &bits, 4); return MKP_OK;
+      } cum += hist1[b]; }
   return MKP_E_THRESHOLD;
 }
 

@@ -28,7 +28,9 @@ struct Args {
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
-  int device = 0; uint32_t rank = 0, world = 1; uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */; bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
+  int device = 0; uint32_t rank = 0, world = 1;
+      uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
+      bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
   bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */
 };
@@ -47,7 +49,9 @@ RegionSpec parse_region(const std::string& raw, const BamSource& bam) {  // Regi
   if (c == std::string::npos) { int tid = bam.tid_of(raw); if (tid < 0) throw Error(MKP_E_INVALID, "contig-missing"); return {raw, 0, bam.ref_lens[(size_t)tid]}; }
   if (raw.find(':', c + 1) != std::string::npos) throw bad();
   std::string se = raw.substr(c + 1); std::vector<uint32_t> v; size_t s = 0;
-  for (;;) { size_t d = se.find('-', s); std::string part = se.substr(s, d == std::string::npos ? std::string::npos : d - s), cl; for (char ch : part) if (ch != ',') cl += ch; if (cl.empty()) throw bad(); uint64_t x = 0; for (char ch : cl) { if (ch < '0' || ch > '9') throw bad(); x = x * 10 + (uint64_t)(ch - '0'); if (x > 0xffffffffull) throw bad(); } v.push_back((uint32_t)x); if (d == std::string::npos) break; s = d + 1; }
+  for (;;) { size_t d = se.find('-', s); std::string part = se.substr(s, d == std::string::npos ? std::string::npos : d - s), cl;
+      for (char ch : part) if (ch != ',') cl += ch; if (cl.empty()) throw bad(); uint64_t x = 0; for (char ch : cl) { if (ch < '0' || ch > '9') throw bad();
+      x = x * 10 + (uint64_t)(ch - '0'); if (x > 0xffffffffull) throw bad(); } v.push_back((uint32_t)x); if (d == std::string::npos) break; s = d + 1; }
   if (v.size() != 2 || v[1] <= v[0]) throw bad();
   return {raw.substr(0, c), v[0], v[1]};
 }
@@ -61,7 +65,8 @@ bool parse_code(const std::string& s, uint32_t* out) {  // ModCodeRepr::parse (m
 
 std::vector<Contig> targets(const BamSource& bam, const RegionSpec* r) {  // get_targets (util.rs:409-446)
   std::vector<Contig> out;
-  for (size_t t = 0; t < bam.ref_names.size(); t++) { if (r) { if (bam.ref_names[t] == r->name) out.push_back({(uint32_t)t, r->start, r->end - r->start, bam.ref_names[t]}); } else out.push_back({(uint32_t)t, 0, bam.ref_lens[t], bam.ref_names[t]}); }
+  for (size_t t = 0; t < bam.ref_names.size(); t++) { if (r) { if (bam.ref_names[t] == r->name) out.push_back({(uint32_t)t, r->start, r->end - r->start,
+      bam.ref_names[t]}); } else out.push_back({(uint32_t)t, 0, bam.ref_lens[t], bam.ref_names[t]}); }
   return out;
 }
 
@@ -89,7 +94,8 @@ SampleTimes g_sample_times;   // --stats: where the threshold estimate's time we
 void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
-  if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED, "rank-sharded threshold sampling needs the full-data mode (-f 1.0): the count-based schedule carries quotas from interval to interval");
+  if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED,
+      "rank-sharded threshold sampling needs the full-data mode (-f 1.0): the count-based schedule carries quotas from interval to interval");
   IdxStats st = idxstats(bam, region, bf);
   const uint64_t total_u = only_mapped ? st.mapped : st.mapped + st.unmapped;
   if (total_u == 0) throw Error(MKP_E_THRESHOLD, "zero reads found in bam index");
@@ -97,10 +103,12 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   if (a.have_frac) {  // from_sample_frac (321-381)
     if (a.sampling_frac > 1.0) throw Error(MKP_E_INVALID, "sample fraction must be <= 1");
     const float f = (float)a.sampling_frac;
-    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; if (f == 1.0f) q.all = true; else q.n = (size_t)ceilf((float)kv.second * f); quota[(uint32_t)kv.first] = q; }
+    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; if (f == 1.0f) q.all = true; else q.n = (size_t)ceilf((float)kv.second * f);
+        quota[(uint32_t)kv.first] = q; }
   } else {  // from_num_reads (171-273)
     const float total = (float)total_u; size_t sum = 0;
-    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; q.n = std::min<size_t>((size_t)ceilf((float)a.num_reads * ((float)kv.second / total)), (size_t)kv.second); sum += q.n; quota[(uint32_t)kv.first] = q; }
+    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; q.n = std::min<size_t>((size_t)ceilf((float)a.num_reads * ((float)kv.second / total)), (size_t)kv.second);
+        sum += q.n; quota[(uint32_t)kv.first] = q; }
     if (!only_mapped) sum += (size_t)ceilf((float)a.num_reads * ((float)st.unmapped / total));
     size_t floor = 1;
     while ((double)sum / (double)a.num_reads > 1.5) {  // pruning walks an FxHashMap in the reference; ascending tid here (order unpinned)
@@ -112,14 +120,16 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   const size_t batch_size = (size_t)floorf((float)a.threads * 1.5f);
   std::vector<Contig> contigs; for (auto& c : targets(bam, region)) if (quota.count(c.tid)) contigs.push_back(c);
   std::map<uint32_t, uint32_t> contig_size; for (auto& c : contigs) contig_size[c.tid] = c.length;
-  std::map<uint32_t, uint64_t> contig_base, contig_start; uint64_t grid_bp = 0; for (auto& c : contigs) { contig_base[c.tid] = grid_bp; contig_start[c.tid] = c.start; grid_bp += c.length; }
+  std::map<uint32_t, uint64_t> contig_base, contig_start; uint64_t grid_bp = 0; for (auto& c : contigs) { contig_base[c.tid] = grid_bp; contig_start[c.tid] = c.start;
+      grid_bp += c.length; }
   std::set<std::string> taken; std::map<uint32_t, size_t> sampled_so_far;
   std::map<uint32_t, std::vector<uint8_t>> bedmasks;
   auto bedmask_for = [&](uint32_t tid) -> const uint8_t* {
     if (!bf) return nullptr;
     auto it = bedmasks.find(tid); if (it != bedmasks.end()) return it->second.data();
     std::vector<uint8_t> m(bam.ref_lens[tid], 0);
-    auto mark = [&](const std::map<uint32_t, std::vector<Span>>& mp, uint8_t bit) { auto f = mp.find(tid); if (f == mp.end()) return; for (auto& s : f->second) for (uint64_t p = s.s; p < std::min<uint64_t>(s.e, m.size()); p++) m[p] |= bit; };
+    auto mark = [&](const std::map<uint32_t, std::vector<Span>>& mp, uint8_t bit) { auto f = mp.find(tid); if (f == mp.end()) return;
+        for (auto& s : f->second) for (uint64_t p = s.s; p < std::min<uint64_t>(s.e, m.size()); p++) m[p] |= bit; };
     mark(bf->pos, 1); mark(bf->neg, 2);
     return bedmasks.emplace(tid, std::move(m)).first->second.data();
   };
@@ -128,7 +138,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   // `skip` (rank-sharded mode): candidates an earlier interval already took.  State across calls: used / n_reads_out.
   struct TakeState { size_t used = 0, n_reads_out = 0; };
   // the sampler's verdict on candidates cand[lo, hi) whose value counts are nv[0 ..): mask[k] = 1 where the read's values enter the sample
-  auto decide = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen, TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask) {
+  auto decide = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen,
+      TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask) {
     for (size_t i = lo; i < hi; i++) {
       if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
       const size_t k = i - lo;
@@ -144,14 +155,16 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       mask[k] = 1;
     }
   };
-  auto take = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen, TakeState* ts, const std::vector<uint8_t>* skip = nullptr) {
+  auto take = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen,
+      TakeState* ts, const std::vector<uint8_t>* skip = nullptr) {
     size_t next = from;
     while (next < cand.size() && (limit < 0 || ts->used < (size_t)limit)) {
       size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - ts->used));
       size_t hi = std::min(cand.size(), next + want);
       std::vector<mkp_record> recs; for (size_t i = next; i < hi; i++) recs.push_back(batch.view(batch.recs[cand[i]]));
       std::vector<uint32_t> nv; uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1;
-      int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(), only_mapped, &nv);
+      int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(),
+          only_mapped, &nv);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       std::vector<uint8_t> mask(recs.size(), 0);
       decide(batch, cand, next, hi, nv.data(), limit, interval_seen, ts, skip, mask.data());
@@ -162,14 +175,16 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   };
   auto candidates = [&](const BamBatch& batch, std::vector<size_t>* out) {
     out->clear();
-    for (size_t i = 0; i < batch.recs.size(); i++) { const BamIndexEntry& e = batch.recs[i]; if ((e.flag & (256 | 1024 | 2048)) || batch.l_seq(e) == 0) continue; if ((only_mapped || a.edge_filter.size()) && (e.flag & 4)) continue; out->push_back(i); }
+    for (size_t i = 0; i < batch.recs.size(); i++) { const BamIndexEntry& e = batch.recs[i]; if ((e.flag & (256 | 1024 | 2048)) || batch.l_seq(e) == 0) continue;
+        if ((only_mapped || a.edge_filter.size()) && (e.flag & 4)) continue; out->push_back(i); }
   };
   if (!contigs.empty()) {
     // ReferenceIntervalsFeeder over the sampling grid, batch_size super-batches (interval_chunks.rs:563-643)
     struct Iv { uint32_t tid, start, end; };
     std::vector<std::vector<Iv>> groups;  // MultiChromCoordinates in feeder order
     { std::vector<Iv> batch; uint32_t blen = 0;
-      for (auto& c : contigs) for (uint32_t p = c.start; p < c.end();) { uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.sampling_interval_size, c.end()); batch.push_back({c.tid, p, e}); blen += e - p; if (blen >= a.sampling_interval_size) { groups.push_back(batch); batch.clear(); blen = 0; } p = e; }
+      for (auto& c : contigs) for (uint32_t p = c.start; p < c.end();) { uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.sampling_interval_size, c.end());
+          batch.push_back({c.tid, p, e}); blen += e - p; if (blen >= a.sampling_interval_size) { groups.push_back(batch); batch.clear(); blen = 0; } p = e; }
       if (!batch.empty()) groups.push_back(batch); }
     for (size_t g0 = 0; g0 < groups.size(); g0 += std::max<size_t>(batch_size, 1)) {
       std::vector<Iv> all; for (size_t g = g0; g < std::min(groups.size(), g0 + std::max<size_t>(batch_size, 1)); g++) for (auto& iv : groups[g]) all.push_back(iv);
@@ -177,8 +192,10 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       // accumulate_sample_counts (sampling_schedule.rs:440-615)
       std::map<uint32_t, uint32_t> len_per; for (auto& iv : all) len_per[iv.tid] += iv.end - iv.start;
       std::map<uint32_t, Quota> per_chrom;
-      for (auto& kv : len_per) { auto cs = contig_size.find(kv.first); auto q = quota.find(kv.first); if (cs == contig_size.end() || q == quota.end()) continue; size_t so_far = sampled_so_far.count(kv.first) ? sampled_so_far[kv.first] : 0; float f = (float)kv.second / (float)cs->second;
-        if (q->second.all) per_chrom[kv.first] = q->second; else if (q->second.n > so_far) { Quota x; x.n = (size_t)ceilf(f * (float)(q->second.n - so_far)); per_chrom[kv.first] = x; } }
+      for (auto& kv : len_per) { auto cs = contig_size.find(kv.first); auto q = quota.find(kv.first); if (cs == contig_size.end() || q == quota.end()) continue;
+          size_t so_far = sampled_so_far.count(kv.first) ? sampled_so_far[kv.first] : 0; float f = (float)kv.second / (float)cs->second;
+        if (q->second.all) per_chrom[kv.first] = q->second; else if (q->second.n > so_far) { Quota x; x.n = (size_t)ceilf(f * (float)(q->second.n - so_far));
+            per_chrom[kv.first] = x; } }
       struct G { Iv iv; Quota q; }; std::vector<G> grouped; bool have_slack = false; Iv slack{0, 0, 0}; size_t slack_n = 0;
       auto merged = [](const Iv& x, const Iv& y) { return Iv{x.tid, std::min(x.start, y.start), std::max(x.end, y.end)}; };
       for (auto& iv : all) {
@@ -186,9 +203,11 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         if (pc->second.all) { grouped.push_back({iv, pc->second}); continue; }
         float f = (float)(iv.end - iv.start) / (float)len_per[iv.tid]; size_t x = (size_t)ceilf((float)pc->second.n * f); Quota qx; qx.n = x;
         if (x < 50) {
-          if (have_slack) { if (slack.tid == iv.tid) { Iv m = merged(slack, iv); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot; } else { Quota q; q.n = tot; grouped.push_back({m, q}); have_slack = false; } } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); slack = iv; slack_n = x; } }
+          if (have_slack) { if (slack.tid == iv.tid) { Iv m = merged(slack, iv); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot; } else { Quota q;
+              q.n = tot; grouped.push_back({m, q}); have_slack = false; } } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); slack = iv; slack_n = x; } }
           else { have_slack = true; slack = iv; slack_n = x; }
-        } else if (have_slack) { have_slack = false; if (slack.tid == iv.tid) { Quota q; q.n = slack_n + x; grouped.push_back({merged(slack, iv), q}); } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); grouped.push_back({iv, qx}); } }
+        } else if (have_slack) { have_slack = false; if (slack.tid == iv.tid) { Quota q; q.n = slack_n + x; grouped.push_back({merged(slack, iv), q}); } else { Quota q;
+            q.n = slack_n; grouped.push_back({slack, q}); grouped.push_back({iv, qx}); } }
         else grouped.push_back({iv, qx});
       }
       if (have_slack) { Quota q; q.n = slack_n; grouped.push_back({slack, q}); }
@@ -206,7 +225,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         mine.push_back(gi);
       }
       auto cap_of = [&](const G& g) { return g.q.all ? SIZE_MAX : 2 * g.q.n + 128; };
-      auto head_of = [&](size_t gi) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, b.get(), cap_of(grouped[gi])); return b; };
+      auto head_of = [&](size_t gi) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, b.get(),
+          cap_of(grouped[gi])); return b; };
       auto skip_for = [&](const G& g, const BamBatch& batch, const std::vector<size_t>& cand, std::vector<uint8_t>* skip) {
         skip->assign(cand.size(), 0);   // rank-sharded mode: a read that reaches back into an earlier processed interval of this contig was taken there
         for (size_t i = 0; i < cand.size(); i++) {
@@ -219,7 +239,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         }
       };
       // the rest of an interval after its head (or all of it in full-data mode): sequential device rounds
-      auto finish_interval = [&](const G& g, std::unique_ptr<BamBatch>& head, const std::vector<size_t>& head_cand, size_t head_done, const std::vector<uint8_t>& head_skip, std::set<std::string>* seen, TakeState* ts) {
+      auto finish_interval = [&](const G& g, std::unique_ptr<BamBatch>& head, const std::vector<size_t>& head_cand, size_t head_done,
+          const std::vector<uint8_t>& head_skip, std::set<std::string>* seen, TakeState* ts) {
         const long limit = g.q.all ? -1 : (long)g.q.n;
         take(*head, head_cand, head_done, limit, g.iv.tid, true, seen, ts, sharded ? &head_skip : nullptr);
         const bool truncated = head->recs.size() >= cap_of(g);
@@ -236,7 +257,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       // 8 consecutive intervals of one contig are fetched concurrently and decoded in ONE device round; the sampler's first-N logic
       // then runs over them in interval order.  An interval its head does not satisfy is finished sequentially before the
       // following ones are judged (their reads may already be taken by it), and the remaining heads are decoded again.
-      struct Pending { size_t gi; std::unique_ptr<BamBatch> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen; TakeState ts; };
+      struct Pending { size_t gi; std::unique_ptr<BamBatch> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen;
+          TakeState ts; };
       for (size_t mi = 0; mi < mine.size();) {
         const G& g0 = grouped[mine[mi]];
         size_t mj = mi + 1;
@@ -251,10 +273,12 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
           const G& g = grouped[P.gi];
           P.n_first = g.q.all ? 0 : std::min(P.cand.size(), std::max<size_t>(256, 2 * g.q.n));
         }
-        if (g0.q.all) { finish_interval(g0, pend[0].head, pend[0].cand, 0, pend[0].skip, &pend[0].seen, &pend[0].ts); batch_counts[g0.iv.tid] += pend[0].ts.n_reads_out; mi = mj; continue; }
+        if (g0.q.all) { finish_interval(g0, pend[0].head, pend[0].cand, 0, pend[0].skip, &pend[0].seen, &pend[0].ts); batch_counts[g0.iv.tid] += pend[0].ts.n_reads_out;
+            mi = mj; continue; }
         for (size_t k0 = 0; k0 < pend.size();) {
           std::vector<mkp_record> recs; std::vector<size_t> at(pend.size() + 1, 0);
-          for (size_t k = k0; k < pend.size(); k++) { at[k] = recs.size(); for (size_t i = 0; i < pend[k].n_first; i++) recs.push_back(pend[k].head->view(pend[k].head->recs[pend[k].cand[i]])); }
+          for (size_t k = k0; k < pend.size(); k++) { at[k] = recs.size();
+              for (size_t i = 0; i < pend[k].n_first; i++) recs.push_back(pend[k].head->view(pend[k].head->recs[pend[k].cand[i]])); }
           at[pend.size()] = recs.size();
           std::vector<uint32_t> nv;
           auto t_d = std::chrono::steady_clock::now();
@@ -292,7 +316,9 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     long limit;
     if (!a.have_frac) limit = (long)(a.num_reads > taken.size() ? a.num_reads - taken.size() : 0);
     else if (a.sampling_frac >= 1.0) limit = -1;
-    else { if (!cand.empty()) throw Error(MKP_E_UNSUPPORTED, "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible"); limit = -1; }
+    else { if (!cand.empty()) throw Error(MKP_E_UNSUPPORTED,
+        "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible");
+    limit = -1; }
     std::set<std::string> seen; TakeState ts; take(batch, cand, 0, limit, 0, false, &seen, &ts);
   }
 }
@@ -329,7 +355,8 @@ void parse_base_thresholds(const std::vector<std::string>& raws, mkp_caller* k) 
       int b = (int)std::string("ACGT").find(raw[0]); if (b < 0 || b > 3) throw Error(MKP_E_INVALID, "failed to parse base in " + raw);
       if (k->has_per_base[b]) throw Error(MKP_E_INVALID, "repeated threshold for base");
       k->has_per_base[b] = 1; k->per_base_threshold[b] = strtof(raw.c_str() + c + 1, nullptr);
-    } else { if (have_default) throw Error(MKP_E_INVALID, "default threshold encountered more than once"); have_default = true; k->default_threshold = strtof(raw.c_str(), nullptr); }
+    } else { if (have_default) throw Error(MKP_E_INVALID, "default threshold encountered more than once"); have_default = true;
+        k->default_threshold = strtof(raw.c_str(), nullptr); }
   }
 }
 
@@ -337,7 +364,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto t_all = std::chrono::steady_clock::now();
   // BAI next to the BAM: only the blocks of the shards (and sampling intervals) this run touches are read and inflated; otherwise
   // the whole file is loaded once.  (inflate threads: --threads only steers the sampling schedule)
-  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(64u, std::thread::hardware_concurrency())), !a.no_index);
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(64u, std::thread::hardware_concurrency())),
+      !a.no_index);
   const BamSource& bam = *src;
   double load_ms = ms_since(t_all);
   const bool trace = getenv("MKP_TRACE_PLAN") != nullptr;   // wall-clock marks of the subcommand's phases on stderr
@@ -349,15 +377,21 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth; kc.force_allow_implicit = a.force_allow;
   if (!a.edge_filter.empty()) {  // parse_edge_filter_input (command_utils.rs:243-277)
     kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(',');
-    if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); }
+    if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10);
+        kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); }
     else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10);
   }
   std::vector<mkp_mod_threshold> per_mod;
-  for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code; if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID, "encountered illegal per-mod threshold: " + raw); per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
+  for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code;
+      if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID,
+      "encountered illegal per-mod threshold: " + raw);
+      per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
   std::vector<Contig> records = targets(bam, have_region ? &region : nullptr);
   BedFilter bed_store; const BedFilter* bf = nullptr;
-  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
-  if (idxstats(bam, have_region ? &region : nullptr, bf).mapped == 0) throw Error(MKP_E_INVALID, "did not find any mapped reads, perform alignment first or use modkit extract and/or modkit summary to inspect unaligned modBAMs");
+  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t);
+      bf = &bed_store; }
+  if (idxstats(bam, have_region ? &region : nullptr, bf).mapped == 0) throw Error(MKP_E_INVALID,
+      "did not find any mapped reads, perform alignment first or use modkit extract and/or modkit summary to inspect unaligned modBAMs");
   if (a.filter_percentile > 1.0f) throw Error(MKP_E_INVALID, "filter percentile must be <= 1.0");
   if (a.combine_strands && !(a.cpg || !a.motif_parts.empty())) throw Error(MKP_E_INVALID, "need to specify either --motif or --cpg to combine strands");
   if (a.hemi) {  // subcommand.rs:1247-1276: one motif, --cpg or --motif (a clap argument group: not both), palindromic; the reference FASTA is required
@@ -370,22 +404,27 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; combine_strands = true; }
   else if (!a.preset.empty()) throw Error(MKP_E_INVALID, "unknown preset " + a.preset);
   else if (a.combine_mods) kc.numeric_mode = 1;
-  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2;
+      kc.collapse_code = code; }
   kc.combine_strands = combine_strands;
-  if (a.hemi) combine_strands = true;   // the interval feeder runs with combine_strands = true ("must be true for duplex", subcommand.rs:1383-1390); the caller's flag stays off
+  if (a.hemi) combine_strands = true;
+      // the interval feeder runs with combine_strands = true ("must be true for duplex", subcommand.rs:1383-1390); the caller's flag stays off
   FocusBuilder fb; fb.combine = combine_strands; fb.mask = a.mask; fb.bed = bf;
   Fasta fasta;
   if (!a.motif_parts.empty()) {  // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
     if (!a.preset.empty()) throw Error(MKP_E_INVALID, "cannot use presets and motifs together");
     std::vector<std::string> parts = a.motif_parts;
-    for (size_t i = 0; i + 1 < parts.size(); i += 2) for (size_t j = i + 2; j + 1 < parts.size(); j += 2) if (parts[i] == parts[j] && parts[i + 1] == parts[j + 1]) throw Error(MKP_E_INVALID, "cannot have the same motif more than once");
-    if (a.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true; if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
+    for (size_t i = 0; i + 1 < parts.size(); i += 2) for (size_t j = i + 2; j + 1 < parts.size(); j += 2) if (parts[i] == parts[j] && parts[i + 1] == parts[j + 1]) throw Error(MKP_E_INVALID,
+        "cannot have the same motif more than once");
+    if (a.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true;
+        if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
     for (size_t i = 0; i + 1 < parts.size(); i += 2) fb.motifs.push_back(Motif::parse(parts[i], strtoul(parts[i + 1].c_str(), nullptr, 10)));
   } else if (a.preset == "traditional" || a.cpg) fb.motifs.push_back(Motif::parse("CG", 0));
   RowWriter wr; wr.mixed = a.mixed_delim; for (auto& m : fb.motifs) wr.labels.push_back(m.label());
   if (!fb.motifs.empty()) {
     if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "reference fasta is required for using --motif or --cpg options");
-    if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID, a.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
+    if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID,
+        a.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
     fasta = Fasta::load(a.ref_fasta); fb.fasta = &fasta;
     mark("reference FASTA loaded");
   }
@@ -408,7 +447,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       for (size_t ri = 0; ri < records.size(); ri++) { grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1; }
       focus_ms += ms_since(t_focus);
     });
-  struct JoinWalk { std::future<void>* f; ~JoinWalk() { if (f->valid()) f->wait(); } } join_walk{&early_walk};   // (an exception below must not leave the walker running on dead locals)
+  struct JoinWalk { std::future<void>* f; ~JoinWalk() { if (f->valid()) f->wait(); } } join_walk{&early_walk};
+      // (an exception below must not leave the walker running on dead locals)
   // thresholds (subcommand.rs:615-638)
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
   double thr_ms = 0;
@@ -424,8 +464,11 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     must(mkp_histogram_begin(ctx));
     g_sample_times = SampleTimes();
     sample_probabilities(ctx, bam, as, sr, bf);
-    if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n", g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms, g_sample_times.decide_ms);
-    { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; } }
+    if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n",
+        g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms,
+        g_sample_times.decide_ms);
+    { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1;
+        kc.per_base_threshold[b] = thr[b]; } }
     thr_ms = ms_since(t0);
   }
   mark("thresholds done");
@@ -443,7 +486,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   wr.f = (a.out_bed == "-" || a.out_bed == "stdout" || (a.hemi && a.out_bed.empty())) ? stdout : fopen(a.out_bed.c_str(), "w");
   if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
   if (a.bgzf) {
-    if (wr.f == stdout || a.with_header || a.plan_only) throw Error(MKP_E_INVALID, "--bgzf writes a file and its index: it needs an output path and goes without --with-header");
+    if (wr.f == stdout || a.with_header || a.plan_only) throw Error(MKP_E_INVALID,
+        "--bgzf writes a file and its index: it needs an output path and goes without --with-header");
     wr.bz.reset(new BgzfTabixSink()); wr.bz->f = wr.f; wr.bz->index_path = a.out_bed + ".tbi";
   }
   }
@@ -458,30 +502,36 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     }
     return *it->second;
   };
-  if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", wr.f);
+  if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n",
+      wr.f);
   // ---- shard plan: pieces of the contig records cut at interval boundaries, bounded in positions (tally / focus buffers) and in
   // BAM bytes (host memory: a shard's blocks are inflated and packed as a unit); ranks take contiguous runs, balanced by the
   // bytes the index puts under them (by length without an index)
   uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
-  const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27, (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
+  const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27,
+      (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
   // 2^27 positions per shard keeps the per-shard focus / slot buffers small
   struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */ };
   std::vector<ShardPlan> plan;
   const bool hf = fb.has_focus();
-  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0; double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, fetch_wait_ms = 0;
+  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0;
+      double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, fetch_wait_ms = 0;
   {
-    const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid, records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
+    const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid,
+        records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
     for (size_t ri = 0; ri < records.size(); ri++) {
       const Contig& rec = records[ri];
       auto t_focus = std::chrono::steady_clock::now();
       // the grid; with one rank the focus bytes are filled in the same walk, otherwise only for the contigs this rank owns (below)
       std::vector<Interval> ivs;
       if (grid_done[ri]) ivs.swap(grid_of[ri]);
-      else { ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr); if (hf && a.world == 1) focus_done[ri] = 1; focus_ms += ms_since(t_focus); }
+      else { ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr); if (hf && a.world == 1) focus_done[ri] = 1;
+          focus_ms += ms_since(t_focus); }
       size_t i0 = 0;
       while (i0 < ivs.size()) {
         size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
-        while (i1 < ivs.size() && (bp == 0 || (bp + (ivs[i1].end - ivs[i1].start) <= shard_bp && (!bam.indexed() || bam.offset_at(rec.tid, ivs[i1].end) - o0 <= a.shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
+        while (i1 < ivs.size() && (bp == 0 || (bp + (ivs[i1].end - ivs[i1].start) <= shard_bp && (!bam.indexed() || bam.offset_at(rec.tid,
+            ivs[i1].end) - o0 <= a.shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
         const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
         const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
         const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
@@ -491,7 +541,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
     }
   }
-  auto fetch_shard = [&](const ShardPlan& sp) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(records[sp.rec].tid, sp.s0 > MKP_HALO ? sp.s0 - MKP_HALO : 0, sp.s1 + MKP_HALO, b.get()); return b; };
+  auto fetch_shard = [&](const ShardPlan& sp) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(records[sp.rec].tid, sp.s0 > MKP_HALO ? sp.s0 - MKP_HALO : 0,
+      sp.s1 + MKP_HALO, b.get()); return b; };
   mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<std::unique_ptr<BamBatch>> next_batch;
@@ -501,8 +552,10 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     std::unique_ptr<BamBatch> batch;
     { auto t_f = std::chrono::steady_clock::now(); batch = next_batch.get(); fetch_wait_ms += ms_since(t_f); }
     if (pi + 1 < plan.size()) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
-    if (hf && !focus_done[sp.rec]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(rec, a.interval_size, &focus_of[sp.rec]); focus_done[sp.rec] = 1; focus_ms += ms_since(t_focus); }
-    if (sp.rec > 0 && (pi == 0 || plan[pi - 1].rec != sp.rec)) for (size_t r2 = 0; r2 < sp.rec; r2++) { std::vector<uint8_t>().swap(focus_of[r2]); }   // earlier contigs are done
+    if (hf && !focus_done[sp.rec]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(rec, a.interval_size, &focus_of[sp.rec]); focus_done[sp.rec] = 1;
+        focus_ms += ms_since(t_focus); }
+    if (sp.rec > 0 && (pi == 0 || plan[pi - 1].rec != sp.rec)) for (size_t r2 = 0; r2 < sp.rec; r2++) { std::vector<uint8_t>().swap(focus_of[r2]);
+        }   // earlier contigs are done
     const std::vector<uint8_t>& focus = focus_of[sp.rec];
     std::vector<mkp_record> recs; recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e));
     {
@@ -516,10 +569,13 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         // digest of everything the packer hands to the device: a parallel pack must equal the sequential one byte for byte
         uint64_t dg = 1469598103934665603ull;
         auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { dg ^= b[i]; dg *= 1099511628211ull; } };
-        mix(S.hdr.data(), S.hdr.size() * sizeof(MkpReadHdr)); mix(S.cigar.data(), S.cigar.size() * 4); mix(S.chunk_pfx.data(), S.chunk_pfx.size() * 4); mix(S.seq.data(), S.seq.size());
-        mix(S.tagref.data(), S.tagref.size() * sizeof(MkpTagRef)); mix(S.ranks.data(), S.ranks.size() * 4); mix(S.ml.data(), S.ml.size()); mix(S.name_hash.data(), S.name_hash.size() * 8);
+        mix(S.hdr.data(), S.hdr.size() * sizeof(MkpReadHdr)); mix(S.cigar.data(), S.cigar.size() * 4); mix(S.chunk_pfx.data(), S.chunk_pfx.size() * 4);
+            mix(S.seq.data(), S.seq.size());
+        mix(S.tagref.data(), S.tagref.size() * sizeof(MkpTagRef)); mix(S.ranks.data(), S.ranks.size() * 4); mix(S.ml.data(), S.ml.size());
+            mix(S.name_hash.data(), S.name_hash.size() * 8);
         for (auto& k : pk.layout_keys) mix(k.data(), k.size());
-        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\t%016llx\n", rec.name.c_str(), s0, s1, S.hdr.size(), (unsigned long long)S.n_calls, (unsigned long long)dg); positions += bp; continue;
+        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\t%016llx\n", rec.name.c_str(), s0, s1, S.hdr.size(), (unsigned long long)S.n_calls, (unsigned long long)dg); positions += bp;
+            continue;
       }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
@@ -544,7 +600,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         if (!partitioned) wr.write(rec.name, rows);
         else for (uint64_t i0r = 0; i0r < rows.n_rows;) {   // rows come grouped by key: one slice per key
           uint64_t i1r = i0r; while (i1r < rows.n_rows && rows.partition_key[i1r] == rows.partition_key[i0r]) i1r++;
-          mkp_rows v = rows; v.n_rows = i1r - i0r; v.pos += i0r; v.strand += i0r; v.code_repr += i0r; v.motif_idx += i0r; v.n_valid += i0r; v.n_mod += i0r; v.n_canonical += i0r; v.n_other += i0r;
+          mkp_rows v = rows; v.n_rows = i1r - i0r; v.pos += i0r; v.strand += i0r; v.code_repr += i0r; v.motif_idx += i0r; v.n_valid += i0r; v.n_mod += i0r;
+              v.n_canonical += i0r; v.n_other += i0r;
           v.n_delete += i0r; v.n_fail += i0r; v.n_diff += i0r; v.n_nocall += i0r; v.partition_key += i0r;
           const uint32_t k = rows.partition_key[i0r];
           RowWriter& kw = writer_for(k < rows.n_partition_keys ? rows.partition_key_names[k] : "not_found"); kw.write(rec.name, v); wr.n += v.n_rows;
@@ -554,7 +611,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
       n_shards++;
       mark("shard run, rows with the writer");
-      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms; pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
+      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms;
+          pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
@@ -564,11 +622,14 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   mark("output closed");
   if (rep) {
     memset(rep, 0, sizeof(*rep));
-    rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms; rep->kernel_ms = kernel_ms; rep->d2h_ms = d2h_ms; rep->write_ms = write_ms;
-    rep->total_ms = ms_since(t_all); rep->n_rows = wr.n; rep->n_positions = positions; rep->n_shards = n_shards; rep->processed_records = processed; rep->skipped_records = skipped;
+    rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms; rep->kernel_ms = kernel_ms;
+        rep->d2h_ms = d2h_ms; rep->write_ms = write_ms;
+    rep->total_ms = ms_since(t_all); rep->n_rows = wr.n; rep->n_positions = positions; rep->n_shards = n_shards; rep->processed_records = processed;
+        rep->skipped_records = skipped;
     for (int b = 0; b < 4; b++) { rep->threshold[b] = kc.per_base_threshold[b]; rep->has_threshold[b] = kc.has_per_base[b]; }
   }
-  if (a.stats) fprintf(stderr, "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu peak_rss_kb=%llu\n",
+  if (a.stats) fprintf(stderr,
+      "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu peak_rss_kb=%llu\n",
                        (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
                        (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)peak_rss_kb());
   return MKP_OK;
@@ -586,9 +647,11 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
     else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
     else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath" || s == "--seed") val();
-    else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true; a.sampling_frac = std::stod(val()); }
+    else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true;
+        a.sampling_frac = std::stod(val()); }
     else if (s == "--no-filtering") a.no_filtering = true; else if (s == "-p" || s == "--filter-percentile") a.filter_percentile = std::stof(val());
-    else if (s == "--filter-threshold") a.filter_threshold.push_back(val()); else if (s == "--mod-thresholds" || s == "--mod-threshold") a.mod_thresholds.push_back(val());
+    else if (s == "--filter-threshold") a.filter_threshold.push_back(val());
+        else if (s == "--mod-thresholds" || s == "--mod-threshold") a.mod_thresholds.push_back(val());
     else if (s == "--sample-region") a.sample_region = val(); else if (s == "--sampling-interval-size") a.sampling_interval_size = (uint32_t)std::stoul(val());
     else if (s == "--include-bed" || s == "--include-positions") a.include_bed = val(); else if (s == "--include-unmapped") a.include_unmapped = true;
     else if (s == "--ignore") a.ignore = val(); else if (s == "--force-allow-implicit") a.force_allow = true;
@@ -596,9 +659,14 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--ref" || s == "-r") a.ref_fasta = val(); else if (s == "--mask" || s == "-k") a.mask = true; else if (s == "--preset") a.preset = val();
     else if (s == "--combine-mods") a.combine_mods = true; else if (s == "--combine-strands") a.combine_strands = true;
     else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
-    else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true; else if (s == "--with-header" || s == "--header") a.with_header = true;
-    else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val()); else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
-    else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val()); else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val()); else if (s == "--shard-bytes") a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); else if (s == "--no-index") a.no_index = true; else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
+    else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true;
+        else if (s == "--with-header" || s == "--header") a.with_header = true;
+    else if (s == "--device") a.device = std::stoi(val()); else if (s == "--gpus-rank") a.rank = (uint32_t)std::stoul(val());
+        else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
+    else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val());
+        else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val());
+        else if (s == "--shard-bytes") a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); else if (s == "--no-index") a.no_index = true;
+        else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
     else if (s == "--bgzf") a.bgzf = true;
     else if (s == "--bedgraph") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
@@ -606,7 +674,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else pos.push_back(s);
   }
   if (need_positional && hemi) { if (pos.size() != 1) throw Error(MKP_E_INVALID, "usage: <in.bam> -o <out.bed> [flags of `modkit pileup-hemi`]"); a.in_bam = pos[0]; }
-  else if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]"); a.in_bam = pos[0]; a.out_bed = pos[1]; }
+  else if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]"); a.in_bam = pos[0];
+      a.out_bed = pos[1]; }
   else if (!pos.empty()) throw Error(MKP_E_INVALID, "unexpected positional argument " + pos[0]);
   if (a.world == 0 || a.rank >= a.world) throw Error(MKP_E_INVALID, "bad --gpus-rank/--gpus-world");
 }
@@ -659,19 +728,25 @@ namespace {
 // the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
 void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out, const mkp_caller* thresholds = nullptr) {
   Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
-  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())), !a.no_index);   // inflate threads: --threads only steers the sampling schedule
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())),
+      !a.no_index);   // inflate threads: --threads only steers the sampling schedule
   const BamSource& bam = *src;
   RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
   if (hr) region = parse_region(a.region, bam);
   if (hs) sregion = parse_region(a.sample_region, bam);
   if (!(a.filter_percentile >= 0.0f) || a.filter_percentile > 1.0f) throw Error(MKP_E_INVALID, "filter percentile must be in [0, 1]");
   mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
-  if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(','); if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); }
+  if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(',');
+      if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10);
+      kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr,
+      10); }
   if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; }
-  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2;
+      kc.collapse_code = code; }
   std::vector<Contig> records = targets(bam, hr ? &region : nullptr);
   BedFilter bed_store; const BedFilter* bf = nullptr;
-  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t); bf = &bed_store; }
+  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t);
+      bf = &bed_store; }
   if (thresholds) { kc.default_threshold = thresholds->default_threshold; kc.per_mod = thresholds->per_mod; kc.n_per_mod = thresholds->n_per_mod;
                     for (int b = 0; b < 4; b++) { kc.per_base_threshold[b] = thresholds->per_base_threshold[b]; kc.has_per_base[b] = thresholds->has_per_base[b]; } }
   int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
@@ -727,7 +802,8 @@ extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, co
       thresholds_from_sample(ctx, q, thr, h, false, n);
       for (int b = 0; b < 4; b++) { values[(size_t)b * n_percentiles + k] = thr[b]; has[b] = h[b]; n_values[b] = n[b]; }
     }
-    if (n_percentiles == 0) { float thr[4]; uint64_t n[4] = {0, 0, 0, 0}; try { thresholds_from_sample(ctx, 0.5f, thr, has, false, n); } catch (const Error&) {} for (int b = 0; b < 4; b++) n_values[b] = n[b]; }
+    if (n_percentiles == 0) { float thr[4]; uint64_t n[4] = {0, 0, 0, 0}; try { thresholds_from_sample(ctx, 0.5f, thr, has, false, n);
+        } catch (const Error&) {} for (int b = 0; b < 4; b++) n_values[b] = n[b]; }
     return MKP_OK;
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
@@ -756,7 +832,10 @@ extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const c
     Args a; parse_args((int)av.size(), av.data(), &a, false);
     mkp_caller kt; memset(&kt, 0, sizeof(kt));
     std::vector<mkp_mod_threshold> per_mod;
-    for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code; if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID, "encountered illegal per-mod threshold: " + raw); per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
+    for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code;
+        if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID,
+        "encountered illegal per-mod threshold: " + raw);
+        per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
     if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kt); kt.per_mod = per_mod.data(); kt.n_per_mod = (uint32_t)per_mod.size(); }
     else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
     else {
@@ -776,7 +855,8 @@ extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const c
     for (uint32_t b = 0; b < 4; b++) {
       out->reads_with_mod_calls[b] = t[128 + b]; out->threshold[b] = kt.per_base_threshold[b]; out->has_threshold[b] = kt.has_per_base[b];
       if (!t[128 + b]) continue;
-      auto row = [&](uint32_t code, uint32_t cls) { ctx->h_sum_base.push_back((uint8_t)b); ctx->h_sum_code.push_back(code); ctx->h_sum_pass.push_back(t[b * 32 + cls]); ctx->h_sum_fail.push_back(t[b * 32 + 16 + cls]); };
+      auto row = [&](uint32_t code, uint32_t cls) { ctx->h_sum_base.push_back((uint8_t)b); ctx->h_sum_code.push_back(code); ctx->h_sum_pass.push_back(t[b * 32 + cls]);
+          ctx->h_sum_fail.push_back(t[b * 32 + 16 + cls]); };
       row(MKP_HEMI_CANONICAL, 1);
       std::vector<std::pair<uint32_t, uint32_t>> codes;
       for (size_t si = 0; si < slots.size() && si < 14; si++) if (slots[si].pb == b && ((obs >> si) & 1ull)) codes.push_back({slots[si].code_repr, (uint32_t)si});
@@ -784,7 +864,8 @@ extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const c
       for (auto& cs : codes) row(cs.first, 2 + cs.second);
     }
     out->total_reads_used = t[128 + 4];
-    out->n_rows = (uint32_t)ctx->h_sum_base.size(); out->base = ctx->h_sum_base.data(); out->code_repr = ctx->h_sum_code.data(); out->pass_count = ctx->h_sum_pass.data(); out->fail_count = ctx->h_sum_fail.data();
+    out->n_rows = (uint32_t)ctx->h_sum_base.size(); out->base = ctx->h_sum_base.data(); out->code_repr = ctx->h_sum_code.data(); out->pass_count = ctx->h_sum_pass.data();
+        out->fail_count = ctx->h_sum_fail.data();
     return MKP_OK;
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }

@@ -2,7 +2,9 @@
 // rust-htslib's IndexedReader (src/pileup/mod.rs:732-743); the block format is BGZF (SAM spec 4.1: gzip members of at most 64 KiB
 // with a BC extra field) and the payload is raw DEFLATE (RFC 1951), which htslib hands to zlib.  Neither library is part of the
 // reference checkout: the decoder below restates RFC 1951 section 3.2 directly (stored / fixed / dynamic blocks, canonical
-// Huffman codes decoded length by length as in section 3.2.2).
+// Huffman codes decoded length by length as in section 3.2.2).  The length-by-length walk of decode_sym (`code - count < first`, with
+// running `first` / `index`) is the canonical-code decoder of Mark Adler's puff.c (zlib's contrib/puff, zlib licence) — the algorithm
+// is his; the code here is written for one GPU thread per block (packed tables in LDS, 64-bit bit buffer, 8-byte match copies).
 //
 // One THREAD per BGZF block: blocks are independent, a 1 GB BAM has ~17 000 of them, and a bit-serial decoder has no parallelism
 // inside a block worth the bookkeeping.  Every thread keeps its two code tables (counts per length + symbols in canonical order)

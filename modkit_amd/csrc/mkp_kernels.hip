@@ -1,21 +1,24 @@
-// gfx950 (CDNA4, wave64) kernels of the modkit-pileup hot path.  Integer / byte work bound by instruction issue, LDS
-// atomics and HBM — no MFMA.  One device pass = the launches below, in order (DESIGN.md §3 has the details):
+// gfx950 (CDNA4, wave64) kernels of the modkit-pileup hot path, part 1: the event pipeline.  Integer / byte work bound by
+// instruction issue, LDS atomics and HBM — no MFMA.  (Part 2, mkp_slots.hip, is the slot pipeline focus runs take; it reuses the
+// decode kernels below for the read classes its fused decoder does not cover.)  One device pass here, in order:
 //
-//   mkp_decode_fast1 / _fast2 / mkp_decode_reads   one wave per read (three read classes, host-built id lists).  512
-//                      bases per step (8 per lane): nibble-parallel match masks + DPP prefix sums give the rank of every
-//                      base (DeltaListConverter's cumulative counts, mod_bam.rs:667-684); the calls of each MM tag are
-//                      located through an ordinal bitmap in LDS; per call: BaseModProbs in f32 from ML, edge filter,
-//                      ReDistribute collapse, MultipleThresholdModCaller::call, CIGAR mapping; one packed 8-byte event
-//                      per mapped call (coalesced, position order).  mkp_sample_* = the same walks emitting argmax
-//                      probabilities for threshold estimation.
-//   mkp_pileup_tiles   accumulate: persistent workgroups, two per CU, one reference tile each in LDS as 16-bit-packed
-//                      strand tallies ([counter | slot][position], consecutive positions on consecutive banks).  Waves draw
-//                      the tile's reads from an LDS ticket: observed-code difference arrays, the read's event slice,
-//                      and the depth walk (one LDS atomic per aligned base, one lane per reference position).  The
-//                      tallies are prefix-summed where needed and streamed to HBM.
-//   mkp_emit_rows      one workgroup per 1024 positions: tallies staged in LDS, rows of FeatureVector::decode /
-//                      combine_strand_features compacted with a block scan.
-//   mkp_scan_tiles, mkp_gather_rows   order the row segments (exclusive scan of the counts + coalesced copy).
+//   decode, one wave per read, one kernel per read class (host-built id lists, longest reads first):
+//     mkp_decode_sparse1/2   one explicit-mode ('?') group, one shared delta list: 4096-base steps that only count (nibble flags,
+//                            byte-packed popcounts, DPP scan); the listed ranks are located per call (lane search + SWAR select)
+//     mkp_decode_fast1/2     one group, any mode / differing delta lists: 1024-base steps, ordinal bitmap in LDS + 4-bit deposit
+//     mkp_decode_reads       everything else (<= 8 tags, `N` tags, duplex, repeated codes): combine_positions_to_probs per group
+//     mkp_merge_duplex       duplex reads decoded one group per wave: interleave the two position-sorted event lists
+//   all share the consumer: per 64 queued calls ML -> f32 BaseModProbs, edge filter, ReDistribute collapse,
+//   MultipleThresholdModCaller::call, CIGAR mapping (register window) and one packed 8-byte event per mapped call.
+//   mkp_sample_* = the same walks emitting argmax probabilities / summary classes (threshold estimate, sample-probs, summary).
+//
+//   mkp_pileup_tiles[_focus|_hemi][_keyed]   accumulate + emit: one 1024-thread workgroup per tile, two per CU; LDS holds the
+//                            tile's 16-bit-packed strand tallies; waves draw the tile's reads from an LDS ticket (observed-code
+//                            difference arrays, the read's event slice, the depth walk over its CIGAR); rows are produced straight
+//                            from LDS (mkp_dev_rows.hpp).  Used for runs without focus positions and for pileup-hemi.
+//   mkp_hemi_failed_reads    pileup-hemi: the one NoCall per interval a record with failing tags leaves
+//   mkp_scan_tiles, mkp_gather_rows   order the tiles' row runs (exclusive scan of the counts + coalesced copy).
+//   mkp_sample_accumulate / _hist1, mkp_summary_accumulate   summaries of the threshold sample (two-level histograms), summary counts.
 //
 // Semantics follow /root/reference/src (cited inline); arithmetic that must be bit-exact is f32
 // with contraction off (-ffp-contract=off) and IEEE division.
