@@ -1,18 +1,29 @@
 #!/usr/bin/env python
 """bench.py — `modkit pileup` hot path on MI355X: genomic positions/s (and bedMethyl rows/s).
 
-A step = one pass of the device pipeline (decode kernels -> mkp_pileup_tiles -> row emission) over one HBM-resident shard.
+A step = one pass of the device pipeline over HBM-resident shards: decode (focus runs: the slot decoder mkp_decode_slots* writing
+the per-read feature stream; otherwise the event decoders) -> accumulate + emit (mkp_pileup_stream / mkp_pileup_tiles*) ->
+mkp_scan_tiles + mkp_gather_rows.
+
 Workload at N=1 (default): BASELINE.json configs[2] "C3" — synthetic hg38-chr20-sized contig (64 444 167 bp, CpG-depleted
 first-order chain), 193 000 reads of mean ~10 kb (~30x), 5mC+5hmC calls alternating `C+hm?` / `C+h?;C+m?` on every read CpG,
 `--cpg --ref`, default interval size and default 10th-percentile threshold: the largest single-GPU configuration.
-`--workload c2` selects configs[1] (5 Mb contig, 100 000 reads, `C+m?`, no motif).  At N>1 every rank runs one such shard of its
-own contig (weak scaling; disjoint contigs need no data-path collective) and the per-base pass thresholds come from a histogram
-all-reduce over RCCL (the one collective of the path, thresholds.rs:121-159 over all ranks' sampled probabilities).
+Other workloads (not the headline line): `--workload c2` (configs[1]: 5 Mb contig, 100 000 reads, `C+m?`, all positions), `hemi`
+(pileup-hemi on duplex reads), `c4` / `c5` (configs[3] / [4] as scale models of the 24-contig genome: `--genome-scale`, default
+1/10 of the hg38 lengths; c4 = 30x `--preset traditional`, c5 = 60x `C+h?;C+m?;A+a?` + per-mod thresholds + `--include-bed`).
 
-Three tiers are reported: kernels only on the resident shard (`value`), the device pipeline
-(pack + H2D + kernels + D2H) and end to end (`modkit pileup` wall: BGZF inflate, threshold sampling, focus, device pipeline,
-bedMethyl text), next to the CPU restatement of the reference's path (oracle/, NOT the modkit binary: no Rust toolchain here)
-timed on the same BAM on this box's host cores, with the sha256 of both bedMethyl outputs compared.
+N > 1 (`--gpus N`, one process per GPU): ONE BAM of N chr20-sized contigs (C3's generator, N x the reads) is sharded over the ranks
+by modkit_amd.distributed.pileup_sharded — contiguous runs of the reference's interval grid balanced by the bytes the BAI puts under
+them, every rank reading only its own BGZF blocks, thresholds from the histogram all-reduce over RCCL (the path's one collective,
+thresholds.rs:121-159) — and the timed region re-launches every rank's HBM-resident windows.  Per-GPU work is fixed as N grows
+("scaling": "weak"), the file and the sharding are north_star's.  The concatenated output is sha256-compared with a single-GPU
+run of the same file.
+
+Tiers: kernels only on the resident shard (`value`), the device pipeline (pack + H2D + kernels + D2H), end to end
+(`modkit pileup` wall: BGZF inflate, threshold sampling, focus, device pipeline, bedMethyl text) and the per-interval C-ABI seam
+(tests/abi_client.c: one mkp_shard_begin/add_records/run per 100 kb interval), next to the CPU restatement of the reference's path
+(oracle/, NOT the modkit binary: no Rust toolchain here) timed on the same BAM on this box's host cores, sha256 of both outputs
+compared, with the host thread counts of both sides stated and a matched-thread comparison.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -21,6 +32,7 @@ import argparse
 import hashlib
 import json
 import os
+import random
 import re
 import subprocess
 import sys
@@ -30,15 +42,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HG38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979), ("chr7", 159345973),
+        ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309), ("chr13", 114364328), ("chr14", 107043718),
+        ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983),
+        ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+MEAN_ALIGNED = 9994.0   # aligned bases per read of the generator at --mean-len 8353 (median of the log-normal)
 
 WORKLOADS = {
-    # name: (contig, length, reads, generator flags, pileup flags needing the FASTA, description)
-    "c3": ("chr20", 64_444_167, 193_000, ["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], True,
-           "C3: synthetic hg38 chr20 (%d bp, CpG-depleted chain), %d reads (mean %.0f bp, ~%.0fx), C+hm? / C+h?;C+m? alternating at every read CpG, --cpg --ref, -i 100000, default 10th-percentile threshold"),
-    "hemi": ("chr20", 64_444_167, 193_000, ["--style", "duplex", "--cpg-depleted", "--mean-len", "8353"], True,
-             "pileup-hemi on the C3 geometry: synthetic hg38 chr20 (%d bp, CpG-depleted chain), %d duplex reads (mean %.0f bp, ~%.0fx), C+hm?;G-hm? / C+h?;C+m?;G-h?;G-m? alternating at every read CpG, --cpg -r, -i 100000, default 10th-percentile threshold"),
-    "c2": ("synth5m", 5_000_000, 100_000, ["--style", "m"], False,
-           "C2: synthetic 1 contig x %d bp, %d reads (mean %.0f bp, ~%.0fx), C+m? at every read CpG, default 10th-percentile threshold"),
+    # name: (style flags of the generator, pileup flags (FASTA / BED substituted), description)
+    "c3": (["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], ["--cpg", "--ref", "{fa}"],
+           "C3: synthetic hg38 chr20 (CpG-depleted chain), ~30x reads of mean ~10 kb, C+hm? / C+h?;C+m? alternating at every read CpG, --cpg --ref, -i 100000, default 10th-percentile threshold"),
+    "hemi": (["--style", "duplex", "--cpg-depleted", "--mean-len", "8353"], ["--cpg", "--ref", "{fa}"],
+             "pileup-hemi on the C3 geometry: duplex reads, C+hm?;G-hm? / C+h?;C+m?;G-h?;G-m? alternating at every read CpG, --cpg -r, -i 100000, default 10th-percentile threshold"),
+    "c2": (["--style", "m"], [],
+           "C2: synthetic 1 contig x 5 Mb, 100 000 reads (~96x), C+m? at every read CpG, all positions, default 10th-percentile threshold"),
+    "c4": (["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], ["--preset", "traditional", "--ref", "{fa}"],
+           "C4 scale model: 24 contigs at {gs} of the hg38 lengths (CpG-depleted chain), 30x, C+hm? / C+h?;C+m?, --preset traditional (= --cpg --combine-strands --ignore h) --ref"),
+    "c5": (["--style", "hma", "--cpg-depleted", "--mean-len", "8353"],
+           ["--mod-thresholds", "m:0.8", "--mod-thresholds", "h:0.9", "--mod-thresholds", "a:0.7", "--include-bed", "{bed}"],
+           "C5 scale model: 24 contigs at {gs} of the hg38 lengths, 60x, C+h?;C+m?;A+a? (6mA at every A), --mod-thresholds m:0.8 h:0.9 a:0.7 over estimated per-base thresholds, --include-bed = seeded random 2 kb intervals (seed 5, mixed BED3 / BED6) at the full genome's density"),
 }
 
 
@@ -50,14 +72,34 @@ def sh256(path):
     return h.hexdigest()
 
 
-def gen_bam(prefix, contig, contig_len, n_reads, seed, flags, threads):
+def gen_bam(prefix, contigs, n_reads, seed, flags, threads):
     tool = os.path.join(ROOT, "tools", "gen_modbam")
     meta = prefix + ".json"
     if not (os.path.exists(prefix + ".bam") and os.path.exists(prefix + ".bam.bai") and os.path.exists(meta)):
-        out = subprocess.check_output([tool, "--out", prefix, "--contig", "%s:%d" % (contig, contig_len), "--reads", str(n_reads), "--seed", str(seed), "--threads", str(threads)] + flags)
+        cmd = [tool, "--out", prefix, "--reads", str(n_reads), "--seed", str(seed), "--threads", str(threads)] + flags
+        for name, ln in contigs:
+            cmd += ["--contig", "%s:%d" % (name, ln)]
+        out = subprocess.check_output(cmd)
         with open(meta, "w") as f:
             f.write(out.decode())
     return prefix + ".bam", prefix + ".fa", json.load(open(meta))
+
+
+def gen_bed(path, contigs, n, seed=5, width=2000):
+    """BASELINE configs[4]: seeded random 2 kb intervals, mixed BED3 / BED6 (+ / - / .)"""
+    rng = random.Random(seed)
+    total = sum(l for _, l in contigs)
+    with open(path, "w") as f:
+        for i in range(n):
+            x = rng.randrange(total)
+            for name, ln in contigs:
+                if x < ln:
+                    break
+                x -= ln
+            s = max(0, min(x, ln - width))
+            kind = rng.randrange(4)
+            f.write("%s\t%d\t%d\n" % (name, s, s + width) if kind == 0 else "%s\t%d\t%d\tiv%d\t0\t%s\n" % (name, s, s + width, i, "+-."[kind - 1]))
+    return path
 
 
 def cpu_model():
@@ -70,29 +112,64 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(bam, flags, contig, contig_len, workers, mode, hemi=False):
-    """The oracle (CPU restatement of the reference's path, NOT the reference binary) on the bench BAM itself:
-    mode 'full' = the whole workload; 'region' = the first eighth of the contig (bounded sample)."""
+def cpu_baseline(bam, flags, workers, region=None, hemi=False, tag="full"):
+    """The oracle (CPU restatement of the reference's path, NOT the reference binary) on the bench BAM itself; `region` bounds the sample."""
     oracle = os.path.join(ROOT, "oracle", "modkit_oracle")
     if not os.path.exists(oracle):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "modkit_oracle"], stdout=subprocess.DEVNULL)
-    out = bam + ".oracle.%s.bed" % mode
-    region = [] if mode == "full" else ["--region", "%s:0-%d" % (contig, contig_len // 8)]
+    out = bam + ".oracle.%s.bed" % tag
+    rflags = ["--region", region] if region else []
     t0 = time.time()
-    p = subprocess.run([oracle] + (["pileup-hemi", bam, "-o", out] if hemi else ["pileup", bam, out]) + ["--oracle-workers", str(workers)] + flags + region, capture_output=True, text=True)
+    p = subprocess.run([oracle] + (["pileup-hemi", bam, "-o", out] if hemi else ["pileup", bam, out]) + ["--oracle-workers", str(workers)] + flags + rflags, capture_output=True, text=True)
     wall = time.time() - t0
     if p.returncode != 0:
         raise RuntimeError("oracle failed: " + p.stderr[-400:])
     m = re.search(r"rows=(\d+) positions=(\d+).*load_s=([0-9.]+) threshold_s=([0-9.]+) pileup_s=([0-9.]+) total_s=([0-9.]+)", p.stderr)
     rows, positions = int(m.group(1)), int(m.group(2))
     load_s, thr_s, pileup_s, total_s = (float(m.group(i)) for i in (3, 4, 5, 6))
-    what = "the whole bench workload" if mode == "full" else "positions [0, %d) of the bench BAM (--region; the BAM load and the threshold sample still cover the whole file)" % (contig_len // 8)
-    return out, region, {
+    what = "the whole bench workload" if not region else "region %s of the bench BAM (the BAM load and the threshold sample still cover the whole file)" % region
+    return out, {
         "value": positions / pileup_s, "unit": "positions/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
         "sample": "%s; restated CPU path (oracle/, interval-parallel like the reference's Rayon pool, %d worker threads); value = pileup phase only with the BAM already decoded in RAM" % (what, workers),
         "rows_per_s": rows / pileup_s, "positions": positions, "rows": rows,
         "end_to_end": {"positions_per_s": positions / total_s, "rows_per_s": rows / total_s, "total_s": total_s, "load_s": load_s, "threshold_s": thr_s, "pileup_s": pileup_s, "wall_s": wall},
     }
+
+
+def device_e2e_subprocess(bam, out, flags, pool_threads, hemi=False):
+    """`modkit pileup` end to end in a fresh process with the library's host pool capped at `pool_threads` (MKP_POOL_THREADS is read
+    once per process): wall of mkp_pileup_main as the CLI reports it."""
+    cli = os.path.join(ROOT, "modkit_amd", "csrc", "mkpileup")
+    env = dict(os.environ, MKP_POOL_THREADS=str(pool_threads), MKP_PACK_PIECES=str(pool_threads))
+    t0 = time.time()
+    p = subprocess.run([cli, "pileup-hemi" if hemi else "pileup", bam] + (["-o", out] if hemi else [out]) + flags + ["--stats"], capture_output=True, text=True, env=env)
+    wall = time.time() - t0
+    if p.returncode != 0:
+        return {"error": p.stderr[-300:]}
+    m = re.search(r"total_ms=([0-9.]+)", p.stderr)
+    return {"host_threads": pool_threads, "total_ms": float(m.group(1)) if m else None, "process_wall_s": wall}
+
+
+def seam_per_interval(bam, fa, out, thr):
+    """The seam a Rust maintainer would call: tests/abi_client.c drives mkp_shard_begin / add_records / run once per
+    100 kb interval on the bench BAM; its own stderr line carries intervals, rows and the time inside the API calls."""
+    exe = os.path.join(os.environ.get("MKP_BENCH_DIR", "/tmp"), "mkp_abi_client")
+    lib_dir = os.path.join(ROOT, "modkit_amd", "csrc")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "abi_client.c"),
+                                   "-L", lib_dir, "-lmkpileup", "-lz", "-Wl,-rpath," + lib_dir])
+        t0 = time.time()
+        p = subprocess.run([exe, bam, fa, out, "cpg", repr(float(thr))], capture_output=True, text=True, timeout=600)
+        wall = time.time() - t0
+        if p.returncode != 0:
+            return {"error": p.stderr[-300:]}
+        kv = dict(re.findall(r"(\w+)=([0-9.eE+-]+)", p.stderr))
+        return {"intervals": int(float(kv.get("intervals", 0))), "rows": int(float(kv.get("rows", 0))), "rows_per_s_api": float(kv.get("rows_per_s_api", 0)),
+                "api_s": float(kv.get("api_s", 0)), "process_wall_s": wall,
+                "what": "tests/abi_client.c: own BGZF/BAM/FASTA readers, one mkp_shard_begin / mkp_shard_add_records / mkp_shard_run per 100 kb interval with a fixed pass threshold; rates over the time spent inside the three API calls"}
+    except Exception as e:  # noqa: BLE001 — the seam tier is informative, never fatal
+        return {"error": str(e)[-300:]}
 
 
 def pmc_traffic(argv_tail, timeout_s=420):
@@ -138,13 +215,22 @@ def pmc_traffic(argv_tail, timeout_s=420):
                  "bytes = (2*FETCH + WRITE) * 1024; the factor 2 is calibrated on this GPU for streams and byte walks alike (profiles/r02_pmc_calibration.txt)")
 
 
+def threshold_argv(thr_h):
+    t = []
+    for i in range(4):
+        if thr_h[i] > 0:
+            t += ["--filter-threshold", "%s:%r" % ("ACGT"[i], thr_h[i])]
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; the JSON says so)")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink a single-contig workload (debug only; the JSON says so)")
+    ap.add_argument("--genome-scale", type=float, default=0.1, help="c4 / c5: fraction of the hg38 contig lengths (the JSON states it next to every number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", choices=["full", "region"], default="full", help="CPU baseline + parity on the whole bench BAM (default) or on its first eighth")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
@@ -172,146 +258,269 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    contig, full_len, full_reads, gflags, needs_ref, desc = WORKLOADS[a.workload]
-    contig_len, n_reads = int(full_len * a.scale), int(full_reads * a.scale)
+    gflags, pflags, desc = WORKLOADS[a.workload]
+    multi = a.workload in ("c4", "c5")
+    hemi = a.workload == "hemi"
+    if multi and world > 1:
+        raise SystemExit("--workload %s is a single-process run (the multi-GPU line shards the C3 generator's BAM)" % a.workload)
     tmp = os.environ.get("MKP_BENCH_DIR", "/tmp")
-    # the generator binary normally ships prebuilt (__graft_entry__.build()); if it has to be compiled, one rank does it
-    if rank == 0 and not os.path.exists(os.path.join(ROOT, "tools", "gen_modbam")):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+    # ---- the workload's BAM (rank 0 generates; the generator binary normally ships prebuilt, __graft_entry__.build())
+    if multi:
+        contigs = [(n, max(100_000, int(l * a.genome_scale))) for n, l in HG38]
+        cov = 30 if a.workload == "c4" else 60
+        n_reads = int(cov * sum(l for _, l in contigs) / MEAN_ALIGNED)
+        seed = 40 if a.workload == "c4" else 50
+        tag = "mkp_%s_g%g" % (a.workload, a.genome_scale)
+    else:
+        base_len, base_reads = (5_000_000, 100_000) if a.workload == "c2" else (64_444_167, 193_000)
+        cl, nr = int(base_len * a.scale), int(base_reads * a.scale)
+        name = "synth5m" if a.workload == "c2" else "chr20"
+        contigs = [(name, cl)] if world == 1 else [("%s_%d" % (name, k), cl) for k in range(world)]   # N > 1: one BAM, N contigs, sharded over the ranks
+        n_reads = nr * world
+        seed = {"c3": 20, "hemi": 30}.get(a.workload, 1)
+        tag = "mkp_%s_L%d_N%d_x%d" % (a.workload, cl, nr, world)
+    prefix = os.path.join(tmp, "%s_seed%d" % (tag, seed))
+    t0 = time.time()
+    if rank == 0:
+        if not os.path.exists(os.path.join(ROOT, "tools", "gen_modbam")):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+        gen_bam(prefix, contigs, n_reads, seed, gflags, os.cpu_count() or 1)
+        if a.workload == "c5":
+            gen_bed(prefix + ".bed", contigs, max(50, int(20000 * a.genome_scale)))
     if dist:
         dist.barrier()
-    hemi = a.workload == "hemi"
-    seed = {"c3": 20, "hemi": 30}.get(a.workload, 1) + rank
-    t0 = time.time()
-    bam, fa, meta = gen_bam(os.path.join(tmp, "mkp_%s_L%d_N%d_seed%d" % (a.workload, contig_len, n_reads, seed)), contig, contig_len, n_reads, seed, gflags,
-                            max(1, (os.cpu_count() or 1) // world))
+    bam, fa, meta = gen_bam(prefix, contigs, n_reads, seed, gflags, 1)
     gen_s = time.time() - t0
+    total_len = sum(l for _, l in contigs)
     # `-t 8`: the reference's --threads (8 here, its default is 4) sets how many intervals are in flight (chunk size floor(1.5 t)) and how
     # the sampling schedule batches its intervals; the device run and the CPU baseline get the same value so that they sample the same reads
-    flags = (["--cpg", "--ref", fa] if needs_ref else []) + ["-t", "8"]
+    flags = [f.format(fa=fa, bed=prefix + ".bed") for f in pflags] + ["-t", "8"]
+    desc = desc.format(gs="%g" % a.genome_scale) + "; %d contig(s), %d bp, %d reads (mean %.0f aligned bp, ~%.1fx)" % (len(contigs), total_len, meta["reads"], meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / total_len)
+    host_threads = min(64, os.cpu_count() or 1) if "MKP_POOL_THREADS" not in os.environ else int(os.environ["MKP_POOL_THREADS"])
 
-    def run_subcommand(out, extra):   # `modkit pileup` / `modkit pileup-hemi` on the bench context
+    def run_subcommand(ctx, out, extra):   # `modkit pileup` / `modkit pileup-hemi` on a bench context
         return ctx.pileup_hemi_run([bam, "-o", out] + flags + extra) if hemi else ctx.pileup_run([bam, out] + flags + extra)
 
-    ctx = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
     out_bed = bam + ".device.bed"
-    rep = None
-    if world == 1 and not (a.inner or a.skip_e2e):
-        # end to end: the whole subcommand on this context (block reads + inflate, threshold sampling, focus, device pipeline,
-        # bedMethyl text), with the driver's default sharding (the next shard's blocks inflate while this one is packed and run)
-        rep = run_subcommand(out_bed, [])
+    extra_cfg, tiers = {}, {}
+    if multi:
+        # ---- multi-shard workloads: K passes of the whole subcommand; device times are the library's HIP-event sums over the shards
+        ctx = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
+        rep = run_subcommand(ctx, out_bed, [])
         thr_h = [float(rep.threshold[i]) if rep.has_threshold[i] else 0.0 for i in range(4)]
+        kms, walls = [], []
+        for k in range(a.warmup + a.steps):
+            r = run_subcommand(ctx, out_bed + ".rep", threshold_argv(thr_h))
+            if k >= a.warmup:
+                kms.append(r.kernel_ms); walls.append(r.total_ms)
+        if a.steps and sh256(out_bed + ".rep") != sh256(out_bed):
+            raise SystemExit("repeat pass with explicit thresholds differs from the sampled run")
+        st = ctx.stats()
+        ms_per_step = sum(kms) / max(1, len(kms))
+        n_rows, total_positions, total_rows = int(rep.n_rows), float(rep.n_positions), float(rep.n_rows)
+        value = total_positions / (ms_per_step * 1e-3)
+        extra_cfg = {"genome_scale": a.genome_scale, "shards": int(rep.n_shards), "timing": "multi-shard workload: value = positions / device kernel time summed over the shards of one pass (HIP events inside the library, mean over the timed passes), NOT a wall-clock bracket; walls are in tiers.end_to_end",
+                     "pass_wall_ms_mean": sum(walls) / max(1, len(walls)), "kernel_ms_last_shard": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "gather": st.gather_kernel_ms}}
+        if a.workload == "c4":   # the full-data percentile (-f 1.0) next to the default sampled threshold
+            rf = run_subcommand(ctx, out_bed + ".f1", ["-f", "1.0"])
+            extra_cfg["full_data_threshold_run"] = {"flag": "-f 1.0", "total_ms": rf.total_ms, "threshold_ms": rf.threshold_ms, "thresholds": {"ACGT"[i]: float(rf.threshold[i]) for i in range(4) if rf.has_threshold[i]}, "rows": int(rf.n_rows)}
+        rep1, elapsed = rep, ms_per_step * 1e-3 * a.steps
+        ctxs = [ctx]
     elif world == 1:
-        thr = ctx.estimate_thresholds(bam, ["-t", "8"])
-        thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
+        ctx = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
+        rep = None
+        if not (a.inner or a.skip_e2e):
+            # end to end: the whole subcommand on this context (block reads + inflate, threshold sampling, focus, device pipeline,
+            # bedMethyl text), with the driver's default sharding (the next shard's blocks inflate while this one is packed and run)
+            rep = run_subcommand(ctx, out_bed, [])
+            thr_h = [float(rep.threshold[i]) if rep.has_threshold[i] else 0.0 for i in range(4)]
+        else:
+            thr = ctx.estimate_thresholds(bam, ["-t", "8"])
+            thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
+        # kernels-only tier: the whole contig as ONE HBM-resident shard (same thresholds), re-launched K times
+        rep1 = run_subcommand(ctx, out_bed + ".oneshard", threshold_argv(thr_h) + ["--shard-bytes", str(1 << 40)])
+        if rep is None:
+            rep = rep1
+        elif sh256(out_bed) != sh256(out_bed + ".oneshard"):
+            raise SystemExit("sharded and single-shard bedMethyl differ")
+        os.remove(out_bed + ".oneshard")
+        ctxs = [ctx]
     else:
-        # per-base thresholds from ALL ranks' samples: per-rank histograms of the sampled probabilities, summed over RCCL
+        # ---- N ranks, ONE BAM: thresholds from the all-reduced histograms, every rank runs its contiguous run of the interval grid
         from modkit_amd import distributed as mkd
-        thr = mkd.estimate_thresholds_allreduce(ctx, bam, [])   # every rank samples its own BAM in full; histograms summed over RCCL
+        shard_stats = {}
+        thr = mkd.pileup_sharded([bam, out_bed] + flags, rank=rank, world=world, device=local_rank, stats=shard_stats)
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
-    # kernels-only tier: the whole contig as ONE HBM-resident shard (same thresholds), re-launched K times
-    targv = []
-    for i in range(4):
-        if thr_h[i] > 0:
-            targv += ["--filter-threshold", "%s:%r" % ("ACGT"[i], thr_h[i])]
-    rep1 = run_subcommand(out_bed + ".oneshard", targv + ["--shard-bytes", str(1 << 40)])
-    if rep is None:
+        # the rank's windows, each resident in HBM on its own context (a window = a piece of one contig; cuts sit on the interval grid)
+        plan = mkd.shard_plan([bam, out_bed] + flags, rank, world)
+        ctxs, rep1, n_rows_rank, parts = [], None, 0, []
+        for k, (cname, s, e) in enumerate(plan):
+            c = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
+            part = "%s.rank%d.win%d" % (out_bed, rank, k)
+            r = run_subcommand(c, part, threshold_argv(thr_h) + ["--region", "%s:%d-%d" % (cname, s, e), "--shard-bytes", str(1 << 40)])
+            n_rows_rank += int(r.n_rows); parts.append(part); ctxs.append(c)
+            rep1 = r if rep1 is None else rep1
         rep = rep1
-    elif sh256(out_bed) != sh256(out_bed + ".oneshard"):
-        raise SystemExit("sharded and single-shard bedMethyl differ")
-    os.remove(out_bed + ".oneshard")
-    n_rows = int(rep.n_rows)
-    ctx.rerun(a.warmup)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.rerun(a.steps)  # K passes; each launch sequence ends with a stream sync inside the library
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    st = ctx.stats()
-    if a.inner:
-        ctx.close()
-        return
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    totals = torch.tensor([float(contig_len), float(n_rows)], dtype=torch.float64, device="cuda")
-    if dist:
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-    total_positions, total_rows = float(totals[0].item()), float(totals[1].item())
+        # the windows' rows = the rank's part of the sharded run (validated below through the concatenation)
+        with open("%s.rank%d.windows" % (out_bed, rank), "wb") as f:
+            for p_ in parts:
+                with open(p_, "rb") as g:
+                    f.write(g.read())
+                os.remove(p_)
+        n_rows = n_rows_rank
+
+    if not multi:
+        for c in ctxs:
+            c.rerun(a.warmup)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if len(ctxs) == 1:
+            ctxs[0].rerun(a.steps)  # K passes; each launch sequence ends with a stream sync inside the library
+        else:
+            for _ in range(a.steps):
+                for c in ctxs:
+                    c.rerun(1)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        st = ctxs[0].stats()
+        if a.inner:
+            for c in ctxs:
+                c.close()
+            return
+        if world == 1:
+            n_rows = int(rep.n_rows)
+        my_positions = float(total_len) if world == 1 else float(sum(e - s for _, s, e in plan))
+        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        totals = torch.tensor([my_positions, float(n_rows)], dtype=torch.float64, device="cuda")
+        if dist:
+            dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        total_positions, total_rows = float(totals[0].item()), float(totals[1].item())
+        ms_per_step = elapsed / a.steps * 1e3
+        value = total_positions * a.steps / elapsed
+        if world > 1:
+            # per-rank figures (gathered to rank 0): windows, positions, reads, BAM bytes under the rank's run, kernel ms per step, walls
+            mine = {"rank": rank, "windows": len(plan), "positions": my_positions, "rows": n_rows, "reads_first_window": int(st.n_reads), "ms_per_step": elapsed / a.steps * 1e3,
+                    "threshold_s": shard_stats.get("threshold_s"), "pileup_s": shard_stats.get("pileup_s"), "part_bytes": shard_stats.get("part_bytes")}
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            if rank == 0:
+                # parity of the split: concatenation of the ranks' parts == a single-GPU run of the same file with the same thresholds;
+                # and the per-window resident runs reproduce the parts
+                single = out_bed + ".single"
+                modkit_amd.pileup([bam, single, "--device", str(local_rank)] + flags + threshold_argv(thr_h))
+                win_cat = hashlib.sha256()
+                for r_ in range(world):
+                    with open("%s.rank%d.windows" % (out_bed, r_), "rb") as g:
+                        win_cat.update(g.read())
+                walls = [g_["pileup_s"] for g_ in gathered if g_["pileup_s"]]
+                extra_cfg = {"sharding": "ONE BAM (%d contigs), contiguous runs of the interval grid per rank balanced by BAI bytes (mkp_pileup_main --gpus-rank/--gpus-world via modkit_amd.distributed.pileup_sharded), thresholds: two-level histogram all-reduce over RCCL (-f 1.0)" % len(contigs),
+                             "per_rank": gathered, "imbalance_pileup_wall_max_over_mean": (max(walls) / (sum(walls) / len(walls))) if walls else None,
+                             "sharded_sha256": sh256(out_bed), "sharded_equals_single_gpu": sh256(out_bed) == sh256(single), "resident_windows_equal_sharded": win_cat.hexdigest() == sh256(out_bed)}
+                os.remove(single)
+            dist.barrier()
 
     if rank == 0:
-        ms_per_step = elapsed / a.steps * 1e3
-        kernels = {"mkp_decode_*": (st.decode_kernel_ms, st.alg_bytes_decode), "mkp_pileup_tiles": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
-        if st.rows_kernel_ms > 0:
-            kernels["mkp_emit_rows"] = (st.rows_kernel_ms, st.alg_bytes_rows)
-        # the roofline is reported for the aggregation kernel (north_star's target), whichever kernel is slowest; its name in the
-        # rocprof summaries: mkp_pileup_tiles_focus for runs with focus positions (--cpg), mkp_pileup_tiles otherwise
-        dom = "mkp_pileup_tiles"
-        dom_kernel = "mkp_pileup_tiles_hemi" if hemi else "mkp_pileup_tiles_focus" if needs_ref else "mkp_pileup_tiles"
-        dom_ms, dom_bytes = kernels[dom]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        slowest = max(kernels, key=lambda k: kernels[k][0])
-        traffic, traffic_src, traffic_all = None, None, None
-        if world == 1 and not a.no_pmc:
+        focus_run = bool(st.slot_pipeline)
+        agg_kernel = "mkp_pileup_tiles_hemi" if hemi else "mkp_pileup_stream" if focus_run else "mkp_pileup_tiles_focus" if "--ref" in flags else "mkp_pileup_tiles"
+        kernels = {"decode": (st.decode_kernel_ms, st.alg_bytes_decode), "aggregate": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
+        # SURVEY §8(d) one-pass algorithmic bytes of the whole pass: reads (16 + 4 n_cigar + L/2) + calls (2 + K) + 44 per row
+        if focus_run:
+            b_alg = st.alg_bytes_decode - 5 * st.stream_bytes - 32 * st.n_reads + 44 * st.n_rows
+        else:
+            b_alg = st.alg_bytes_decode - 8 * st.n_events + 44 * st.n_rows
+        traffic_all, traffic_src = None, None
+        if world == 1 and not a.no_pmc and not multi:
             tail = ["--workload", a.workload, "--scale", str(a.scale), "--no-cpu-baseline", "--no-pmc"]
             traffic_all, traffic_src = pmc_traffic(tail)
-            if traffic_all:
-                traffic = traffic_all.get(dom_kernel)
-                traffic_all["mkp_pileup_tiles"] = traffic
-                traffic_all["mkp_decode_*"] = sum(v for k, v in traffic_all.items() if k.startswith("mkp_decode_") and ":" not in k) or None
+        def kernel_traffic(prefixes):
+            if not traffic_all:
+                return None
+            return sum(v for k, v in traffic_all.items() if ":" not in k and any(k.startswith(p) for p in prefixes)) or None
+        dec_prefixes = ("mkp_decode_", "mkp_cover_reads", "mkp_merge_duplex", "mkp_hemi_failed")
+        def roof(name, ms, nbytes, traffic):
+            ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_ms": ms, "traffic": traffic}
+        agg = roof(agg_kernel, st.pileup_kernel_ms, st.alg_bytes_pileup, (traffic_all or {}).get(agg_kernel))
+        agg.update({"traffic_read": (traffic_all or {}).get(agg_kernel + ":read"), "traffic_write": (traffic_all or {}).get(agg_kernel + ":write"), "traffic_source": traffic_src,
+                    "accounting": ("feature stream (1 B per read and focus position) + 32 B visit record per read + 44 B per row" if focus_run else "reads (16 + 4 n_cigar + L/2) + 8 B per call event + 44 B per row")})
+        if focus_run:   # SURVEY §8(d)'s literal B_agg: 8 B per coverage event at a candidate position + 44 B per row
+            s_ach = st.alg_bytes_agg_survey / (st.pileup_kernel_ms * 1e-3) / 1e9
+            agg["survey_B_agg"] = {"bytes": int(st.alg_bytes_agg_survey), "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS, "what": "SURVEY §8(d): 8 B x (read, candidate position) coverage events + 44 B x rows over the same launch time; the kernel itself reads the events as 1-byte features"}
+        slowest_name = "decode" if st.decode_kernel_ms >= st.pileup_kernel_ms else "aggregate"
+        slow = roof("mkp_decode_slots* (+ mkp_cover_reads)" if focus_run else "mkp_decode_*", st.decode_kernel_ms, st.alg_bytes_decode, kernel_traffic(dec_prefixes)) if slowest_name == "decode" else dict(agg)
+        whole = None
+        if not multi:
+            whole = roof("whole pass: decode + aggregate + gather", ms_per_step, b_alg, None)
+            whole["what"] = "SURVEY §8(d) one-pass B_alg (reads + calls + 44 B rows, every byte counted once) over the driver-timed step"
         dev_ms = rep1.pack_ms + rep1.h2d_ms + rep1.kernel_ms + rep1.d2h_ms
+        tiers.update({
+            "kernels_only": {"positions_per_s": value, "rows_per_s": total_rows * a.steps / elapsed if elapsed else 0.0, "ms": ms_per_step, "what": "timed region: K re-launches on the HBM-resident shard(s)"},
+            "device_pipeline": {"positions_per_s": rep1.n_positions / (dev_ms * 1e-3), "rows_per_s": rep1.n_rows / (dev_ms * 1e-3), "ms": dev_ms,
+                                "stages_ms": {"pack": rep1.pack_ms, "h2d": rep1.h2d_ms, "kernels": rep1.kernel_ms, "d2h": rep1.d2h_ms},
+                                "what": "rank 0, first (cold) pass: host pack + H2D + kernels + D2H of rows" + ("" if multi else ", one shard")},
+            "end_to_end": {"positions_per_s": rep.n_positions / (rep.total_ms * 1e-3), "rows_per_s": rep.n_rows / (rep.total_ms * 1e-3), "ms": rep.total_ms, "host_threads": host_threads,
+                           "stages_ms": {"bam_load_inflate": rep.load_ms, "threshold": rep.threshold_ms, "focus": rep.focus_ms, "pack": rep.pack_ms, "h2d": rep.h2d_ms, "kernels": rep.kernel_ms,
+                                         "d2h": rep.d2h_ms, "bedmethyl_text_write": rep.write_ms},
+                           "shards": int(rep.n_shards), "what": "rank 0: mkp_pileup_run wall (`modkit pileup in.bam out.bed` with the workload's flags, default sharding), page cache warm, the library's host pool at host_threads threads; bam_load_inflate = what the shard loop waited for blocks (the rest overlaps with pack / run / write)"},
+        })
+        if world == 1 and a.workload == "c3" and not (a.inner or a.skip_e2e):
+            tiers["seam_per_interval"] = seam_per_interval(bam, fa, bam + ".seam.bed", thr_h[1] if thr_h[1] > 0 else 0.7)
         result = {
-            "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": total_positions * a.steps / elapsed, "unit": "positions/s",
+            "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": value, "unit": "positions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": (desc % (contig_len, n_reads, meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / contig_len)) + ("; one such shard (own contig) per GPU, thresholds all-reduced over RCCL" if world > 1 else ""),
-                       "scale": a.scale, "rows_per_s": total_rows * a.steps / elapsed, "rows_per_step": total_rows, "reads": int(st.n_reads), "call_events": int(st.n_events),
-                       "tiles": int(st.n_tiles), "thresholds": {"ACGT"[i]: thr_h[i] for i in range(4) if thr_h[i] > 0},
-                       "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
-                       "generator_s": gen_s, "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
-                       "parity": "bit-exact vs the restated CPU path (oracle/) on this BAM; the oracle is pinned on the reference's golden files; ties / >=3 codes / QC-fail / N ops are reference-unpinned (DESIGN.md §7)",
-                       "roofline_all_kernels": {k: {"achieved_GBps": v[1] / (v[0] * 1e-3) / 1e9, "algorithmic_bytes": int(v[1]), "avg_launch_ms": v[0], "frac": v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                    "traffic": (traffic_all or {}).get(k)} for k, v in kernels.items() if v[0] > 0},
-                       "slowest_kernel": slowest},
-            "tiers": {
-                "kernels_only": {"positions_per_s": total_positions * a.steps / elapsed, "rows_per_s": total_rows * a.steps / elapsed, "ms": ms_per_step, "what": "timed region: K re-launches on the HBM-resident shard"},
-                "device_pipeline": {"positions_per_s": rep1.n_positions / (dev_ms * 1e-3), "rows_per_s": rep1.n_rows / (dev_ms * 1e-3), "ms": dev_ms,
-                                    "stages_ms": {"pack": rep1.pack_ms, "h2d": rep1.h2d_ms, "kernels": rep1.kernel_ms, "d2h": rep1.d2h_ms}, "what": "rank 0, the contig as one shard, first (cold) pass: host pack + H2D + kernels + D2H of rows"},
-                "end_to_end": {"positions_per_s": rep.n_positions / (rep.total_ms * 1e-3), "rows_per_s": rep.n_rows / (rep.total_ms * 1e-3), "ms": rep.total_ms,
-                               "stages_ms": {"bam_load_inflate": rep.load_ms, "threshold": rep.threshold_ms, "focus": rep.focus_ms, "pack": rep.pack_ms, "h2d": rep.h2d_ms, "kernels": rep.kernel_ms,
-                                             "d2h": rep.d2h_ms, "bedmethyl_text_write": rep.write_ms},
-                               "shards": int(rep.n_shards), "what": "rank 0: mkp_pileup_run wall (`modkit pileup in.bam out.bed` with the workload's flags, default sharding), page cache warm; bam_load_inflate = what the shard loop waited for blocks (the rest overlaps with pack / run / write)"},
-            },
-            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_read": (traffic_all or {}).get(dom_kernel + ":read"), "traffic_write": (traffic_all or {}).get(dom_kernel + ":write"), "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": dom_ms},
+            "config": dict({"workload": desc + ("; ONE BAM of %d such contigs sharded over %d ranks" % (world, world) if world > 1 else ""),
+                            "scale": a.scale, "rows_per_s": total_rows * a.steps / elapsed if elapsed else 0.0, "rows_per_step": total_rows, "reads": int(st.n_reads), "call_events": int(st.n_events),
+                            "tiles": int(st.n_tiles), "thresholds": {"ACGT"[i]: thr_h[i] for i in range(4) if thr_h[i] > 0},
+                            "pipeline": "slot pipeline (feature stream)" if focus_run else "event pipeline (tile walk)",
+                            "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
+                            "generator_s": gen_s, "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
+                            "parity": "bit-exact vs the restated CPU path (oracle/) on this BAM; the oracle is pinned on the reference's golden files; ties / >=3 codes / QC-fail / N ops are reference-unpinned and sample-probs has no reference pin (DESIGN.md §7)",
+                            "slowest_kernel": slowest_name}, **extra_cfg),
+            "tiers": tiers,
+            "roofline": dict(agg, slowest=slow, whole_pass=whole),
         }
         if world == 1 and not a.no_cpu_baseline:
             workers = min(os.cpu_count() or 1, 8)
-            obed, region, base = cpu_baseline(bam, flags, contig, contig_len, workers, a.cpu_sample, hemi)
+            region = None
+            if multi:
+                region = "%s:0-%d" % (contigs[-1][0], contigs[-1][1])   # bounded sample: the last (shortest-but-one) contig
+            elif a.cpu_sample == "region":
+                region = "%s:0-%d" % (contigs[0][0], contigs[0][1] // 8)
+            obed, base = cpu_baseline(bam, flags, workers, region, hemi, "s" if region else "full")
             if region:
                 dbed = bam + ".device.region.bed"
-                if hemi:
-                    modkit_amd.pileup_hemi([bam, "-o", dbed, "--device", str(local_rank)] + flags + region)
-                else:
-                    modkit_amd.pileup([bam, dbed, "--device", str(local_rank)] + flags + region)
+                (modkit_amd.pileup_hemi if hemi else modkit_amd.pileup)(([bam, "-o", dbed] if hemi else [bam, dbed]) + ["--device", str(local_rank)] + flags + ["--region", region])
             else:
                 dbed = out_bed
             base["bedmethyl_sha256_equal"] = sh256(dbed) == sh256(obed)
             base["bedmethyl_sha256"] = sh256(dbed)
-            base["speedup_end_to_end"] = (rep.n_positions / (rep.total_ms * 1e-3)) / base["end_to_end"]["positions_per_s"] if not region else None
-            if (os.cpu_count() or 1) > 8:   # the same run on more of this box's cores (the reference's --threads is the user's choice)
-                w2 = min(os.cpu_count(), 32)
-                _, _, b2 = cpu_baseline(bam, [f for f in flags if f not in ("-t", "8")] + ["-t", str(w2)], contig, contig_len, w2, a.cpu_sample, hemi)   # (-t steers its sampling schedule too: timing only, no sha comparison)
-                base["more_cores"] = {"cores": w2, "positions_per_s": b2["value"], "end_to_end": b2["end_to_end"],
-                                      "speedup_end_to_end": (rep.n_positions / (rep.total_ms * 1e-3)) / b2["end_to_end"]["positions_per_s"] if not region else None}
+            dev_pps = rep.n_positions / (rep.total_ms * 1e-3)
+            base["speedup_end_to_end"] = dev_pps / base["end_to_end"]["positions_per_s"] if not region else None
+            base["device_host_threads"] = host_threads
+            if not region and not hemi:
+                # matched host thread counts: the device run's host side capped at 8 threads against the oracle on 8; both at 64 (or all cores)
+                m8 = device_e2e_subprocess(bam, bam + ".device.t8.bed", flags, 8)
+                matched = {"8_threads": {"device": m8, "oracle_total_s": base["end_to_end"]["total_s"],
+                                         "speedup_end_to_end": (base["end_to_end"]["total_s"] * 1e3 / m8["total_ms"]) if m8.get("total_ms") else None}}
+                if (os.cpu_count() or 1) > 8:
+                    w2 = min(os.cpu_count(), 64)
+                    _, b2 = cpu_baseline(bam, [f for f in flags if f not in ("-t", "8")] + ["-t", str(w2)], w2, None, hemi, "t%d" % w2)   # (-t steers its sampling schedule too: timing only, no sha comparison)
+                    mN = device_e2e_subprocess(bam, bam + ".device.t%d.bed" % w2, flags, w2)
+                    matched["%d_threads" % w2] = {"device": mN, "oracle_total_s": b2["end_to_end"]["total_s"], "oracle_positions_per_s": b2["value"],
+                                                  "speedup_end_to_end": (b2["end_to_end"]["total_s"] * 1e3 / mN["total_ms"]) if mN.get("total_ms") else None}
+                base["matched_host_threads"] = matched
             result["cpu_baseline"] = base
         print(json.dumps(result))
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist:
         dist.destroy_process_group()
 

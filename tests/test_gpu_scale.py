@@ -86,6 +86,44 @@ def test_c5_scaled_multimod_bed(oracle_bin, tmp_path):
     assert len(out.splitlines()) > 10_000
 
 
+HG38 = [("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259), ("chr6", 170805979), ("chr7", 159345973),
+        ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422), ("chr11", 135086622), ("chr12", 133275309), ("chr13", 114364328), ("chr14", 107043718),
+        ("chr15", 101991189), ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167), ("chr21", 46709983),
+        ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415)]
+
+
+def test_c4_genome_scale_model_vs_oracle(oracle_bin, tmp_path):
+    # BASELINE configs[3] as a declared scale model: all 24 hg38 contigs at 1/100 of their lengths (31 Mb), 30x, --preset traditional
+    # --ref; the default sampled threshold and the full-data percentile (-f 1.0), whole output sha256 against the oracle
+    contigs = [(n, l // 100) for n, l in HG38]
+    total = sum(l for _, l in contigs)
+    bam, fa, meta = gen(tmp_path, "c4g", contigs, int(30 * total / 9994), "hm", 40, ["--cpg-depleted", "--mean-len", "8353"])
+    assert meta["aligned_bases"] > 25 * total
+    n = _full_vs_oracle(oracle_bin, tmp_path, bam, ["--preset", "traditional", "--ref", fa], 250_000)
+    assert n == _full_vs_oracle(oracle_bin, tmp_path, bam, ["--preset", "traditional", "--ref", fa, "-f", "1.0"], 250_000)
+
+
+def test_c5_genome_scale_model_vs_oracle(oracle_bin, tmp_path):
+    # BASELINE configs[4] as a declared scale model: 24 contigs at 1/400 (7.7 Mb), 60x, C+h?;C+m?;A+a? (6mA at every A), per-mod thresholds over
+    # estimated per-base ones, --include-bed = seeded random 2 kb intervals at the full genome's density (seed 5, mixed BED3 / BED6)
+    contigs = [(n, max(100_000, l // 400)) for n, l in HG38]
+    total = sum(l for _, l in contigs)
+    bam, fa, meta = gen(tmp_path, "c5g", contigs, int(60 * total / 9994), "hma", 50, ["--cpg-depleted", "--mean-len", "8353"])
+    import random
+    rng = random.Random(5)
+    bed = os.path.join(str(tmp_path), "inc.bed")
+    with open(bed, "w") as f:
+        for i in range(50):
+            x = rng.randrange(total)
+            for name, ln in contigs:
+                if x < ln:
+                    break
+                x -= ln
+            s = max(0, min(x, ln - 2000)); kind = rng.randrange(4)
+            f.write("%s\t%d\t%d\n" % (name, s, s + 2000) if kind == 0 else "%s\t%d\t%d\tiv%d\t0\t%s\n" % (name, s, s + 2000, i, "+-."[kind - 1]))
+    _full_vs_oracle(oracle_bin, tmp_path, bam, ["--mod-thresholds", "m:0.8", "--mod-thresholds", "h:0.9", "--mod-thresholds", "a:0.7", "--include-bed", bed], 50_000)
+
+
 def _digest(r):
     h = hashlib.sha256()
     for f in modkit_amd.ROW_FIELDS:
