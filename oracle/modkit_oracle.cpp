@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "oracle_pileup.hpp"
+#include "oracle_extract.hpp"
 
 using namespace mko;
 
@@ -764,14 +765,52 @@ static int run_summary(const Options& o) {
   return 0;
 }
 
+// `modkit extract calls` (EntryExtractCalls::run, src/extract/subcommand.rs:452-761), the serial file-order path
+static int run_extract_calls(const Options& o, const ExtractOptions& xo) {
+  BamFile bam = read_bam(o.in_bam);
+  EdgeFilter edge;
+  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
+  CollapseMethod collapse;
+  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true; collapse.code = mc; }
+  std::map<ModCode, float> per_mod;
+  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc; if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code"); per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
+  ThresholdCaller caller;
+  if (o.no_filtering) {}
+  else if (!o.filter_threshold.empty()) { caller.per_mod = per_mod; parse_thresholds(o.filter_threshold, &caller); }
+  else {   // get_threshold_from_options (command_utils.rs:74-134): the pileup's estimate; positions without a reference position count unless --mapped-only
+    Options so = o; so.include_unmapped = !xo.mapped_only;
+    caller.per_mod = per_mod;
+    auto per_base = sample_probs(bam, so, nullptr, collapse, edge, nullptr);
+    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); }
+  }
+  std::map<std::string, std::string> ref_seqs;
+  if (!xo.ref_fasta.empty()) { Fasta fa = Fasta::load(xo.ref_fasta); for (auto& kv : fa.seqs) if (bam.tid_of(kv.first) >= 0) ref_seqs[kv.first] = kv.second; }
+  FILE* out = (xo.out_tsv.empty() || xo.out_tsv == "-" || xo.out_tsv == "stdout") ? stdout : fopen(xo.out_tsv.c_str(), "w");
+  if (!out) throw MkErr("failed to make output file");
+  if (!xo.no_headers) fputs(extract_calls_header(), out);
+  uint64_t n_used = 0, n_skipped = 0, n_failed = 0, n_rows = 0;
+  for (const BamRecord& r : bam.recs) {
+    std::string rows; bool skipped = false;
+    if (!extract_calls_of_record(bam, r, xo, collapse, edge, caller, ref_seqs, &rows, &skipped)) { n_failed++; continue; }
+    if (skipped) { n_skipped++; continue; }
+    n_used++; for (char c : rows) if (c == '\n') n_rows++;
+    fputs(rows.c_str(), out);
+  }
+  if (out != stdout) fclose(out);
+  fprintf(stderr, "[oracle] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used, (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs" && std::string(argv[1]) != "summary")) {
+  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs" && std::string(argv[1]) != "summary" && std::string(argv[1]) != "extract-calls")) {
     fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n"
                     "       modkit_oracle sample-probs <in.bam> [-o table.tsv] [-p 0.1,0.5,0.9] [sampling flags of `modkit sample-probs`]\n"
-                    "       modkit_oracle summary <in.bam> [-o counts.tsv] [flags of `modkit summary`]\n");
+                    "       modkit_oracle summary <in.bam> [-o counts.tsv] [flags of `modkit summary`]\n"
+                    "       modkit_oracle extract-calls <in.bam> <out.tsv> [--ref fa] [--allow-non-primary] [--mapped-only] [--pass-only] [threshold / sampling flags of `modkit extract calls`]\n");
     return 2;
   }
   Options o; std::vector<std::string> pos;
+  const bool extract_cmd = std::string(argv[1]) == "extract-calls"; ExtractOptions xo;
   o.hemi = std::string(argv[1]) == "pileup-hemi";
   const bool summary_cmd = std::string(argv[1]) == "summary";
   o.sample_probs_cmd = std::string(argv[1]) == "sample-probs" || summary_cmd;
@@ -782,6 +821,15 @@ int main(int argc, char** argv) {
       auto val = [&]() { if (i + 1 >= argc) throw MkErr("missing value for " + a); return std::string(argv[++i]); };
       if (o.hemi && (a == "--preset" || a == "--combine-strands" || a == "--with-header" || a == "--header")) throw MkErr("unknown flag " + a + " for pileup-hemi");
       if (o.hemi && (a == "-o" || a == "--out-bed")) { o.out_bed = val(); continue; }
+      if (extract_cmd) {
+        if (a == "--ref" || a == "--reference") { xo.ref_fasta = val(); continue; }
+        if (a == "--allow-non-primary") { xo.allow_non_primary = true; continue; }
+        if (a == "--mapped-only") { xo.mapped_only = true; continue; }
+        if (a == "--pass-only" || a == "--pass") { xo.pass_only = true; continue; }
+        if (a == "--no-headers") { xo.no_headers = true; continue; }
+        if (a == "--kmer-size") { xo.kmer_size = std::stoul(val()); continue; }
+        if (a == "--force") continue;
+      }
       if (o.sample_probs_cmd) {
         if (a == "-o") { o.out_bed = val(); continue; }
         if (!summary_cmd && (a == "-p" || a == "--percentiles")) { o.percentiles = val(); continue; }
@@ -809,6 +857,7 @@ int main(int argc, char** argv) {
       else if (!a.empty() && a[0] == '-' && a != "-") throw MkErr("unknown flag " + a);
       else pos.push_back(a);
     }
+    if (extract_cmd) { if (pos.size() != 2) throw MkErr("need <in.bam> <out.tsv>"); o.in_bam = pos[0]; xo.in_bam = pos[0]; xo.out_tsv = pos[1]; return run_extract_calls(o, xo); }
     if (o.sample_probs_cmd) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; if (!o.include_bed.empty()) o.include_unmapped = false; return summary_cmd ? run_summary(o) : run_sample_probs(o); }
     if (o.hemi) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; }
     else { if (pos.size() != 2) throw MkErr("need <in.bam> <out.bed>"); o.in_bam = pos[0]; o.out_bed = pos[1]; }

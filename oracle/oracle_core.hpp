@@ -163,6 +163,7 @@ struct BamRecord {
   std::string qname;
   std::vector<uint32_t> cigar;  // len<<4|op  (MIDNSHP=X)
   std::string seq;              // ASCII, as stored (reference orientation)
+  std::vector<uint8_t> qual;    // base qualities, as stored
   std::vector<uint8_t> aux;
   int32_t ref_len() const {
     int64_t l = 0;
@@ -281,7 +282,8 @@ static inline BamFile read_bam(const std::string& path) {
     r.seq.resize(r.l_seq);
     for (int i = 0; i < r.l_seq; i++) { uint8_t b = d[p + i / 2]; r.seq[i] = NT16[(i & 1) ? (b & 15) : (b >> 4)]; }
     p += (size_t)(r.l_seq + 1) / 2;
-    p += (size_t)r.l_seq;  // qual
+    r.qual.assign(d.begin() + (std::ptrdiff_t)p, d.begin() + (std::ptrdiff_t)(p + (size_t)r.l_seq));
+    p += (size_t)r.l_seq;
     r.aux.assign(d.begin() + (std::ptrdiff_t)p, d.begin() + (std::ptrdiff_t)e);
   });
   if (bad) throw MkErr("corrupt BAM record");

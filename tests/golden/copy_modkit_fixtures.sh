@@ -25,7 +25,8 @@ for f in bc_anchored_10_reads.sorted.bam bc_anchored_10_reads.sorted.bam.bai \
   pileup-old-tags-regressiontest.methyl.bed \
   bc_anchored_10_reads.haplotyped.sorted.bam bc_anchored_10_reads.haplotyped.sorted.bam.bai \
   duplex_modcalls_sort.bam duplex_modcalls_sort.bam.bai duplex_hemi_nofilt.bed duplex_hemi.bed \
-  single_read.bam include_bed_summary_test.bed; do
+  single_read.bam include_bed_summary_test.bed \
+  2_reads_all_context.bam supplementary_and_secondary_read.bam test_read_calls_estimate_thresh.tsv test_supplementary_calls.tsv; do
   cp "$SRC/$f" "$DST/$f"
 done
 # pileup-hemi (tests/test_pileup_hemi.rs) needs GRCh38_chr20.fa, which the checkout does not ship: the slice the test region

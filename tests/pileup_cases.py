@@ -133,3 +133,9 @@ def update_tags_ambiguous(src_bam, dst_bam):
         out += struct.pack("<i", len(body)) + body
     bgzf_write(dst_bam, bytes(out))
     return dst_bam
+
+# `modkit extract calls` (tests/test_extract.rs:499-560): (name, flags, bam, golden tsv)
+EXTRACT_CALLS_CASES = [
+    ("extract_calls_regression", ["--ref", "{ref}"], "2_reads_all_context.bam", "test_read_calls_estimate_thresh.tsv"),
+    ("extract_supplementary_secondary_calls", ["--allow-non-primary"], "supplementary_and_secondary_read.bam", "test_supplementary_calls.tsv"),
+]
