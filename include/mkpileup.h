@@ -293,6 +293,18 @@ typedef struct {
 } mkp_summary_out;
 int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, mkp_summary_out* out);
 
+/* ---- `modkit extract calls <in.bam> <out.tsv> [flags]` (EntryExtractCalls::run, src/extract/subcommand.rs:452-761): the per-read call table
+ * (PositionModCalls::header / to_row, src/extract/writer.rs:12-132) — 21 tab-separated columns per call: read id, forward and reference
+ * position, strands, soft clips, read length, call_prob / call_code (BaseModProbs::argmax_base_mod_call), base quality, reference and
+ * query k-mers, canonical / modified primary base, fail (MultipleThresholdModCaller::call == Filtered), inferred, within_alignment, flag.
+ * The calls (MM / ML decode, edge filter, --ignore collapse, argmax and thresholded call) are computed on the device; ids, positions,
+ * qualities, k-mers and the text on the host.  argv = in.bam out.tsv + --ref fa, --allow-non-primary, --mapped-only, --pass-only,
+ * --no-headers, --kmer-size k, --no-filtering | --filter-threshold .. | the sampling flags of the threshold estimate (-n -f -p -t
+ * --sampling-interval-size), --mod-thresholds, --ignore, --edge-filter, --invert-edge-filter, --device N.  Records go out in FILE order
+ * (the reference's serial path, which its golden tests pin; its indexed path emits interval batches in Rayon completion order).
+ * --region, --include-bed / --exclude-bed, --motif, --num-reads, --ignore-implicit, --bgzf fail with MKP_E_UNSUPPORTED. */
+int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
+
 /* ---- BGZF inflate on the device: first stage of moving BAM ingest onto the GPU.  Not on the pileup path yet — the
  * driver still inflates on the host, where the step overlaps with packing; this entry point exists so that the kernel is tested and
  * measured on its own.  Stands in for what htslib does under rust-htslib's IndexedReader (src/pileup/mod.rs:732-743): BGZF blocks

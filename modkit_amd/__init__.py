@@ -58,6 +58,7 @@ def lib():
         L.mkp_get_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         L.mkp_pileup_hemi_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
+        L.mkp_extract_calls_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
         L.mkp_pileup_hemi_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         L.mkp_summary.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
         L.mkp_bgzf_inflate.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
@@ -79,7 +80,7 @@ EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
-           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs", "mkp_summary"]
+           "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs", "mkp_summary", "mkp_extract_calls_main"]
 
 
 def pileup(argv):
@@ -101,6 +102,18 @@ def pileup_hemi(argv):
     arr = (ctypes.c_char_p * len(args))(*args)
     err = ctypes.create_string_buffer(2048)
     rc = L.mkp_pileup_hemi_main(len(args), arr, err, len(err))
+    if rc != MKP_OK:
+        raise MkpError(rc, err.value.decode(errors="replace"))
+    return rc
+
+
+def extract_calls(argv):
+    """`modkit extract calls` (EntryExtractCalls::run, src/extract/subcommand.rs:452): argv = [in_bam, out_tsv, flags...]."""
+    L = lib()
+    args = [str(a).encode() for a in argv]
+    arr = (ctypes.c_char_p * len(args))(*args)
+    err = ctypes.create_string_buffer(2048)
+    rc = L.mkp_extract_calls_main(len(args), arr, err, len(err))
     if rc != MKP_OK:
         raise MkpError(rc, err.value.decode(errors="replace"))
     return rc

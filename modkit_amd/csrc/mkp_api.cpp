@@ -912,7 +912,7 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     c->tables.build(c->packer.layouts, c->caller);
     MkpRunParams P; memset(&P, 0, sizeof(P));
     P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
-    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
+    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->extract_mode ? 3 : c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
         P.has_focus = bedmask != nullptr;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
@@ -937,6 +937,24 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     n_vals->resize(n);
     for (uint32_t i = 0; i < n; i++) (*n_vals)[i] = c->sample_ro[i].ok ? c->sample_ro[i].n_events : 0u;
     c->resident = false;
+  });
+}
+
+int mkp_internal_set_extract(mkp_ctx* c, bool on) {
+  if (!c) return MKP_E_INVALID;
+  c->extract_mode = on; c->caller.read_base_caller = on; c->resident = false;
+  return MKP_OK;
+}
+
+int mkp_internal_extract_fetch(mkp_ctx* c, std::vector<MkpEvent>* events, std::vector<float>* vals) {
+  if (!c || !events || !vals) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    const uint64_t n = c->sample_shard.n_events_cap;
+    events->resize(n); vals->resize(n);
+    if (!n) return;
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    hip_check(hipMemcpy(events->data(), c->d_events.p, n * sizeof(MkpEvent), hipMemcpyDeviceToHost), "events D2H");
+    hip_check(hipMemcpy(vals->data(), c->d_vals.p, n * sizeof(float), hipMemcpyDeviceToHost), "values D2H");
   });
 }
 

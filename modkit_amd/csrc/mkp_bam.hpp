@@ -180,7 +180,8 @@ static inline void inflate_block(const uint8_t* src, size_t clen, uint8_t* dst, 
   if (rc != Z_STREAM_END || zs.avail_out != 0) throw Error(MKP_E_IO, "corrupt BGZF block");
 }
 
-static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
+// require_sorted = false: file order is all the caller needs (`extract calls` walks records one by one; fetches are not valid then)
+static inline BamData load_bam(const std::string& path, unsigned threads = 0, bool require_sorted = true) {
   FileMap comp(path);
   struct Blk { size_t coff, clen, doff, dlen; };
   std::vector<Blk> blks; size_t o = 0, dtotal = 0;
@@ -228,7 +229,7 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0) {
     if (e.tid < -1 || e.tid >= n_ref || e.pos < -1 || e.pos >= 0x7ffffff0) throw Error(MKP_E_IO, "corrupt BAM record: reference id or position out of range");
     e.reflen = 0; e.end = e.pos + 1;
     // fetches assume a coordinate-sorted file (reference ids ascending, unplaced records last, positions ascending inside a reference)
-    if (!bd.recs.empty()) { const BamIndexEntry& q = bd.recs.back(); const uint32_t ta = (uint32_t)q.tid, tb = (uint32_t)e.tid;   // -1 sorts last as unsigned
+    if (require_sorted && !bd.recs.empty()) { const BamIndexEntry& q = bd.recs.back(); const uint32_t ta = (uint32_t)q.tid, tb = (uint32_t)e.tid;   // -1 sorts last as unsigned
       if (tb < ta || (tb == ta && e.tid >= 0 && e.pos < q.pos)) throw Error(MKP_E_INVALID, "the BAM is not coordinate sorted: " + path); }
     bd.recs.push_back(e); o += (size_t)bs;
   }

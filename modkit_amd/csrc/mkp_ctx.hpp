@@ -58,6 +58,7 @@ struct mkp_ctx {
   uint32_t hemi_codes[4][MKP_KMAX + 2] = {}; std::vector<uint8_t> h_hemi_base; std::vector<uint32_t> h_hemi_pat[2];
   mkp::DevBuf d_zin, d_zout, d_zblk, d_zstat; std::vector<uint8_t> h_inflated;   // mkp_bgzf_inflate
   // `modkit summary` (mkp_summary): sampling rounds count calls instead of storing probabilities; device table [4][2][16] + reads_with[6] (u64)
+  bool extract_mode = false;   // `extract calls`: the sampling kernels emit one record per call (forward position, classes, call_prob)
   bool summary_mode = false; mkp::DevBuf d_summary; std::vector<uint8_t> h_sum_base; std::vector<uint32_t> h_sum_code; std::vector<uint64_t> h_sum_pass, h_sum_fail;
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -69,4 +70,8 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
 int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take);
 // summary mode: zero the device table / read it back (134 u64: table[4][2][16] then reads_with[6])
 int mkp_internal_summary_begin(mkp_ctx* c);
+// `extract calls`: switch the sampling kernels to per-call records (and the caller tables to read-base thresholds); fetch the records of the
+// last mkp_internal_sample batch: per packed record its header (event_off), readout, and the events / call_prob values
+int mkp_internal_set_extract(mkp_ctx* c, bool on);
+int mkp_internal_extract_fetch(mkp_ctx* c, std::vector<MkpEvent>* events, std::vector<float>* vals);
 int mkp_internal_summary_get(mkp_ctx* c, uint64_t out[134], std::vector<MkpSlot>* slots);

@@ -161,7 +161,8 @@ __device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, F
 // `modkit summary` (sampled_reads_to_summary, src/summarize.rs:117-262): per sampled call the thresholded call and the argmax call.
 // Returns the sample "event" info: [0:1] canonical base, [4:7] thresholded class, [8:11] argmax class; class 0 = Filtered,
 // 1 = Canonical, 2 + s = Modified(code of global slot s).  *obs gets the slots of the codes in the map (observed_mods).
-__device__ __forceinline__ uint32_t summary_info(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX) {
+// *amax (optional): the probability of the argmax call (`extract calls`: call_prob)
+__device__ __forceinline__ uint32_t summary_info(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX, float* amax = nullptr) {
   if (collapse) collapse_redistribute(g, pv, pk, kmax);
   const int n_post = (int)((pv >> 3) & 7u);
   float s = 0.0f, best = 0.0f; bool have = false; int bk = 0;
@@ -177,6 +178,7 @@ __device__ __forceinline__ uint32_t summary_info(const GroupRegs& g, uint32_t pv
   }
   const float can = 1.0f - s;
   const uint32_t arg_cls = (have && best > can) ? 2u + ((g.slots >> (8 * bk)) & 0xffu) : 1u;
+  if (amax) *amax = (have && best > can) ? best : can;
   const int cls = call_group(g, pv, pk, false, obs, kmax);   // on the collapsed map
   const uint32_t thr_cls = cls < 2 ? (uint32_t)cls : 2u + ((g.slots >> (8 * (cls - 2))) & 0xffu);
   return MKP_G_TB(g.misc) | (thr_cls << 4) | (arg_cls << 8);

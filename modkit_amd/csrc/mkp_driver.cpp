@@ -891,3 +891,203 @@ extern "C" int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// `modkit extract calls` (EntryExtractCalls::run, src/extract/subcommand.rs:452-761): the per-read call table.  The reads are decoded
+// on the device by the sampling kernels in per-call mode (MM / ML -> BaseModProbs, edge filter, ReDistribute collapse, the argmax call
+// and the thresholded call — mkp_kernels.hip, sample_mode 3); what is left for the host is what the table is made of besides the
+// call: read ids, soft clips, reference positions (aligned_pairs_full), base qualities, k-mers, and the text
+// (PositionModCalls::to_row, src/extract/writer.rs:46-132).  Records are taken in FILE order — the reference's serial path
+// (process_records_to_chan, src/extract/util.rs:519-575), which its golden tests pin; its indexed path hands interval batches to the
+// writer in whatever order the Rayon pool finishes them.
+namespace {
+// f32 through Rust's Display: the shortest decimal that parses back to the same f32, positional notation
+std::string f32_display(float v) {
+  if (v == 0.0f) return std::signbit(v) ? "-0" : "0";
+  char buf[64]; int prec = 1;
+  for (; prec <= 9; prec++) { snprintf(buf, sizeof(buf), "%.*e", prec - 1, (double)v); if (strtof(buf, nullptr) == v) break; }
+  std::string s(buf); const size_t e = s.find('e'); const int ex = atoi(s.c_str() + e + 1);
+  std::string mant = s.substr(0, e); bool neg = false;
+  if (!mant.empty() && mant[0] == '-') { neg = true; mant.erase(0, 1); }
+  std::string digits; for (char c : mant) if (c != '.') digits.push_back(c);
+  while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+  std::string out;
+  if (ex >= 0) { if ((int)digits.size() <= ex + 1) out = digits + std::string((size_t)(ex + 1 - (int)digits.size()), '0'); else out = digits.substr(0, (size_t)ex + 1) + "." + digits.substr((size_t)ex + 1); }
+  else out = "0." + std::string((size_t)(-ex - 1), '0') + digits;
+  return neg ? "-" + out : out;
+}
+char comp_char(char c) {   // bio::alphabets::dna::revcomp
+  switch (c) {
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
+    case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K'; case 'B': return 'V'; case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D';
+    default: return c;
+  }
+}
+// Kmer::new (util.rs:750-777) as text; '-' where the sequence has no base
+std::string kmer_at(const char* seq, size_t n, size_t position, size_t size) {
+  const size_t before = size % 2 == 0 ? size / 2 - 1 : size / 2, after = size / 2;
+  std::string k;
+  for (size_t off = before; off >= 1; off--) k.push_back(position >= off && position - off < n ? seq[position - off] : '-');
+  k.push_back(position < n ? seq[position] : '-');
+  for (size_t off = 1; off <= after; off++) k.push_back(position + off < n ? seq[position + off] : '-');
+  return k;
+}
+}  // namespace
+
+extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len) {
+  auto fail = [&](int st, const std::string& m) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return st; };
+  mkp_ctx* ctx = nullptr;
+  struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
+  try {
+    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false; size_t kmer = 5; int device = 0;
+    std::vector<std::string> rest;
+    for (int i = 0; i < argc; i++) {
+      const std::string s = argv[i];
+      auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
+      if (s == "--ref" || s == "--reference") ref_path = val(); else if (s == "--allow-non-primary") allow_np = true; else if (s == "--mapped-only") mapped_only = true;
+      else if (s == "--pass-only" || s == "--pass") pass_only = true; else if (s == "--no-headers") no_headers = true; else if (s == "--kmer-size") kmer = std::stoul(val());
+      else if (s == "--force" || s == "--suppress-progress") {} else if (s == "--device") device = std::stoi(val()); else if (s == "--stats") stats = true;
+      else if (s == "--region" || s == "--include-bed" || s == "--include-positions" || s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--num-reads" ||
+               s == "--ignore-index" || s == "--ignore-implicit" || s == "--bgzf" || s == "--cpg" || s == "--seed")
+        throw Error(MKP_E_UNSUPPORTED, "extract calls: " + s + " is outside what this library restates (whole-file, file-order table; see include/mkpileup.h)");
+      else rest.push_back(s);
+    }
+    if (kmer == 0 || kmer > 50) throw Error(MKP_E_INVALID, "kmer size must be less than or equal to 50");
+    if (pass_only && std::find(rest.begin(), rest.end(), "--no-filtering") != rest.end()) throw Error(MKP_E_INVALID, "the argument '--no-filtering' cannot be used with '--pass-only'");
+    std::vector<const char*> av; for (auto& x : rest) av.push_back(x.c_str());
+    Args a; parse_args((int)av.size(), av.data(), &a, true);
+    // the flags of the threshold estimate (get_threshold_from_options, command_utils.rs:74-134): calls without a reference position count
+    // unless --mapped-only (ReferencePositionFilter::only_mapped_positions, src/extract/util.rs:39-41)
+    std::vector<std::string> sf;
+    for (size_t i = 0; i < rest.size(); i++) if (rest[i] != a.in_bam && rest[i] != a.out_bed) sf.push_back(rest[i]);
+    if (!mapped_only) sf.push_back("--include-unmapped");
+    std::vector<const char*> sav; for (auto& x : sf) sav.push_back(x.c_str());
+    mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = device;
+    int rc = mkp_ctx_create(&cfg, &ctx);
+    if (rc != MKP_OK) throw Error(rc, "no usable gfx950 device (libmkpileup has no CPU path)");
+    auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
+    mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
+    std::vector<mkp_mod_threshold> per_mod;
+    for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code;
+      if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID, "encountered illegal per-mod threshold: " + raw);
+      per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
+    if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kc); kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size(); }
+    else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
+    else {
+      must(mkp_histogram_begin(ctx));
+      float q = 0.1f; sample_bam(ctx, a.in_bam.c_str(), (int)sav.size(), sav.data(), &q);
+      float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, q, thr, has, false);
+      for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; }
+      kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
+    }
+    if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(',');
+      if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); }
+      else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); }
+    if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+    must(mkp_set_caller(ctx, &kc));
+    must(mkp_internal_set_extract(ctx, true));
+    const BamData bd = load_bam(a.in_bam, 0, false);
+    Fasta fasta; if (!ref_path.empty()) fasta = Fasta::load(ref_path);
+    FILE* out = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w");
+    if (!out) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
+    struct Close { FILE* f; ~Close() { if (f && f != stdout) fclose(f); } } closer{out};
+    if (!no_headers) fputs("read_id\tforward_read_position\tref_position\tchrom\tmod_strand\tref_strand\tref_mod_strand\tfw_soft_clipped_start\tfw_soft_clipped_end\tread_length\tcall_prob\tcall_code\t"
+                           "base_qual\tref_kmer\tquery_kmer\tcanonical_base\tmodified_primary_base\tfail\tinferred\twithin_alignment\tflag\n", out);
+    BamBatch view; view.base = bd.raw.data();
+    uint64_t n_used = 0, n_skipped = 0, n_failed = 0, n_rows = 0;
+    static const char NT16[] = "=ACMGRSVTWYHKDBN";
+    const size_t BATCH = 1 << 15;
+    std::vector<MkpEvent> ev; std::vector<float> vals; std::vector<uint32_t> n_vals;
+    for (size_t r0 = 0; r0 < bd.recs.size(); r0 += BATCH) {
+      const size_t r1 = std::min(bd.recs.size(), r0 + BATCH);
+      std::vector<mkp_record> recs;
+      for (size_t i = r0; i < r1; i++) {   // TrackingModRecordIter (mod_bam.rs:53-122) + process_records_to_chan's --mapped-only
+        const mkp_record r = view.view(bd.recs[i]);
+        if ((r.flag & (2048 | 256 | 1024)) && !allow_np) { n_skipped++; continue; }
+        if (r.l_qseq <= 0) { n_failed++; continue; }
+        if ((r.flag & 4) && mapped_only) { n_skipped++; continue; }
+        recs.push_back(r);
+      }
+      if (recs.empty()) continue;
+      must(mkp_internal_sample(ctx, 0, 0, 1, nullptr, recs.data(), (uint32_t)recs.size(), false, &n_vals));
+      must(mkp_internal_extract_fetch(ctx, &ev, &vals));
+      const std::vector<MkpSlot>& slots = ctx->tables.st.slots;
+      std::string text;
+      for (size_t i = 0; i < recs.size(); i++) {
+        const mkp_record& r = recs[i];
+        const MkpReadHdr& h = ctx->sample_shard.hdr[i]; const MkpReadOut& ro = ctx->sample_ro[i];
+        if (!ro.ok || !ro.n_events) { if (h.flags & MKP_RF_BAD) n_failed++; else n_skipped++; continue; }
+        const bool unmapped = (r.flag & 4) != 0, rev = (r.flag & 16) != 0;
+        const size_t L = (size_t)r.l_qseq;
+        const uint8_t* cg = r.data + r.l_qname; const uint8_t* sq = cg + 4 * (size_t)r.n_cigar; const uint8_t* ql = sq + (L + 1) / 2;
+        auto cig = [&](uint32_t k) { uint32_t w; memcpy(&w, cg + 4 * (size_t)k, 4); return w; };
+        size_t sc_start = 0, sc_end = 0; bool cigar_ok = true;   // get_soft_clipped (read_ids_to_base_mod_probs.rs:803-824)
+        if (!unmapped) {
+          bool broke = false; for (uint32_t k = 0; k < r.n_cigar; k++) { const uint32_t w = cig(k); if ((w & 15u) == 4u) sc_start += w >> 4; else { broke = true; break; } }
+          if (!broke) cigar_ok = false;
+          broke = false; for (uint32_t k = r.n_cigar; k-- > 0;) { const uint32_t w = cig(k); if ((w & 15u) == 4u) sc_end += w >> 4; else { broke = true; break; } }
+          if (!broke) cigar_ok = false;
+        }
+        if (!cigar_ok) { n_failed++; continue; }
+        const size_t clip_start = rev ? sc_end : sc_start, clip_end = rev ? sc_start : sc_end;
+        auto within = [&](size_t qp) { return L >= clip_end && qp >= clip_start && qp < L - clip_end; };
+        // forward sequence and qualities
+        std::string fwd(L, 'N');
+        for (size_t k = 0; k < L; k++) { const uint8_t b = sq[k >> 1]; const char c = NT16[(k & 1) ? (b & 15) : (b >> 4)]; if (rev) fwd[L - 1 - k] = comp_char(c); else fwd[k] = c; }
+        const std::string chrom = (!unmapped && r.tid >= 0 && (size_t)r.tid < bd.ref_names.size()) ? bd.ref_names[(size_t)r.tid] : std::string();
+        const bool have_chrom = !unmapped && r.tid >= 0 && (size_t)r.tid < bd.ref_names.size();
+        const std::string* ref_seq = have_chrom ? fasta.get(chrom) : nullptr;
+        const bool primary_or_unmapped = r.flag == 0 || r.flag == 16 || r.flag == 4;
+        const std::string qname((const char*)r.data, r.l_qname ? (size_t)r.l_qname - 1 : 0);
+        // the record's calls come in stored order (ascending stored index): one CIGAR walk gives their reference positions
+        struct Row { size_t f; long ref; uint32_t info; float p; };
+        std::vector<Row> rows; rows.reserve(ro.n_events);
+        uint32_t ck = 0; size_t q_at = 0; long r_at = r.pos;   // op ck starts at stored index q_at / reference position r_at
+        for (uint32_t k = 0; k < ro.n_events; k++) {
+          const MkpEvent& e = ev[(size_t)h.event_off + k];
+          const size_t f = e.pos, q = rev ? L - 1 - f : f;
+          long ref = -1;
+          if (!unmapped) {
+            while (ck < r.n_cigar) {
+              const uint32_t w = cig(ck), op = w & 15u, len = w >> 4;
+              const bool cq = op == 0 || op == 1 || op == 4 || op == 7 || op == 8, cr = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+              if (cq && q < q_at + len) { if (op == 0 || op == 7 || op == 8) ref = r_at + (long)(q - q_at); break; }
+              if (cq) q_at += len;
+              if (cr) r_at += len;
+              ck++;
+            }
+          }
+          rows.push_back({f, ref, e.info, vals[(size_t)h.event_off + k]});
+        }
+        if (unmapped && rev) std::reverse(rows.begin(), rows.end());   // no alignment strand: ascending forward position
+        bool any = false;
+        for (const Row& w : rows) {
+          if (mapped_only && (unmapped || w.ref < 0)) continue;                 // filter_read_base_mod_probs (src/extract/util.rs:71-124)
+          if (!primary_or_unmapped && !within(w.f)) continue;                   // iter_profiles (read_ids_to_base_mod_probs.rs:785-800)
+          any = true;
+          const uint32_t tb = w.info & 3u, sg = (w.info >> 2) & 1u, inferred = (w.info >> 3) & 1u, thr_cls = (w.info >> 4) & 15u, arg_cls = (w.info >> 8) & 15u;
+          const bool filtered = thr_cls == 0;
+          if (filtered && pass_only) continue;
+          std::string code = "-";
+          if (arg_cls >= 2) { const uint32_t cr = arg_cls - 2 < slots.size() ? slots[arg_cls - 2].code_repr : 0u; code = (cr & 0x80000000u) ? std::to_string(cr & 0x7fffffffu) : std::string(1, (char)cr); }
+          std::string qk = kmer_at(fwd.data(), L, w.f, kmer);
+          if (sg) { std::string t; for (size_t k = qk.size(); k-- > 0;) t.push_back(qk[k] == '-' ? '-' : comp_char(qk[k])); qk.swap(t); }
+          std::string rk = ".";
+          if (w.ref >= 0 && ref_seq) rk = kmer_at(ref_seq->data(), ref_seq->size(), (size_t)w.ref, kmer);
+          const unsigned bq = ql[rev ? L - 1 - w.f : w.f];
+          char line[1200];
+          snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n", qname.c_str(), w.f, w.ref >= 0 ? w.ref : -1L,
+                   have_chrom ? chrom.c_str() : ".", sg ? '-' : '+', unmapped ? '.' : (rev ? '-' : '+'), unmapped ? '.' : ((sg != 0) != rev ? '-' : '+'), clip_start, clip_end, L,
+                   f32_display(w.p).c_str(), code.c_str(), bq, rk.c_str(), qk.c_str(), "ACGT"[tb], "ACGT"[sg ? 3 - tb : tb], filtered ? "true" : "false", inferred ? "true" : "false",
+                   (have_chrom && within(w.f)) ? "true" : "false", (unsigned)r.flag);
+          text.append(line); n_rows++;
+        }
+        if (any) n_used++; else n_skipped++;
+      }
+      if (!text.empty() && fwrite(text.data(), 1, text.size(), out) != text.size()) throw Error(MKP_E_IO, "write error on " + a.out_bed);
+    }
+    if (stats) fprintf(stderr, "[mkpileup] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used, (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);
+    return MKP_OK;
+  } catch (const Error& e) { return fail(e.status, e.what()); }
+  catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }
+}

@@ -322,7 +322,11 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
             if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
             if (!keep) continue;
             any_surviving = true;
-            if (prm.sample_mode == 2) { uint32_t ob = 0; sv[ev_cnt] = 0.f; ev_info[ev_cnt++] = summary_info(gr, pv, spk, collapse, &ob); obs0 |= ob; continue; }
+            if (prm.sample_mode >= 2) {   // 2 `summary`: thresholded + argmax class; 3 `extract calls`: + forward position, mod strand, inferred, call_prob
+              uint32_t ob = 0; float am = 0.f; uint32_t inf = summary_info(gr, pv, spk, collapse, &ob, MKP_KMAX, &am);
+              if (prm.sample_mode == 3) { inf |= ((uint32_t)sg << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); ev_pos = (int32_t)f; }
+              sv[ev_cnt] = prm.sample_mode == 3 ? am : 0.f; ev_info[ev_cnt++] = inf; obs0 |= ob; continue;
+            }
             sv[ev_cnt] = argmax_group(gr, pv, spk, collapse);
             ev_info[ev_cnt++] = MKP_G_TB(gr.misc);
             continue;
@@ -653,7 +657,10 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep && prm.sample_mode == 2) { any_surviving = true; uint32_t ob = 0; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0); obs0 |= ob; has_ev = true; }
+          if (keep && prm.sample_mode >= 2) {
+            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob; has_ev = true;
+            if (prm.sample_mode == 3) { ev_info |= ((uint32_t)sg0 << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position
+          }
           else if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
         } else {
           any_surviving = true;
@@ -1003,7 +1010,10 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep && prm.sample_mode == 2) { any_surviving = true; uint32_t ob = 0; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0); obs0 |= ob; has_ev = true; }
+          if (keep && prm.sample_mode >= 2) {
+            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob; has_ev = true;
+            if (prm.sample_mode == 3) { ev_info |= (uint32_t)sg0 << 2; sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position (explicit tags: never inferred)
+          }
           else if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
         } else {
           any_surviving = true;

@@ -56,6 +56,9 @@ struct CallerCfg {  // mkp_caller, owned copy
   std::map<uint32_t, float> per_mod;
   uint32_t numeric_mode = 0, collapse_code = 0; bool edge = false; uint32_t edge_start = 0, edge_end = 0; bool edge_inverted = false;
   bool force_allow = false, combine_strands = false; uint32_t max_depth = 8000;
+  // `extract calls`: PositionModCalls::to_row asks the caller with the READ base of the call (src/extract/writer.rs:61), where the pileup's
+  // read cache asks with the complement for negative-strand tags (read_cache.rs:147-150)
+  bool read_base_caller = false;
 };
 
 struct SlotTable {
@@ -90,7 +93,7 @@ struct LayoutTables {
       const LayoutHost& L = layouts[li];
       std::vector<int> mem; std::vector<uint32_t> uni; group_members(L, sg, b, &mem, &uni);
       if (mem.empty()) continue;
-      int pb = sg ? 3 - b : b;  // threshold_base (read_cache.rs:147-150)
+      int pb = (sg && !cc.read_base_caller) ? 3 - b : b;  // threshold_base (read_cache.rs:147-150)
       if (st.find_can(pb) < 0) st.can_pbs.push_back(pb);
       for (uint32_t c : uni) { if (collapse && c == cc.collapse_code) continue; if (st.find_slot(pb, c) < 0) { MkpSlot s; memset(&s, 0, sizeof(s)); s.code_repr = c; s.pb = (uint8_t)pb; st.slots.push_back(s); } }
     }
@@ -127,7 +130,7 @@ struct LayoutTables {
         if (mem.empty()) continue;
         if (mem.size() > MKP_MAX_MEMBERS) throw Error(MKP_E_UNSUPPORTED, "more than 4 MM tags on one (strand, base)");
         if (uni.size() > MKP_KMAX) throw Error(MKP_E_UNSUPPORTED, "more than 4 mod codes on one (strand, base)");
-        int pb = sg ? 3 - b : b;
+        int pb = (sg && !cc.read_base_caller) ? 3 - b : b;
         int collapse_local = -1; uint32_t implicit = 0;
         auto local_of = [&](uint32_t c) { return (int)(std::find(uni.begin(), uni.end(), c) - uni.begin()); };
         for (size_t k = 0; k < uni.size(); k++) {

@@ -1,0 +1,55 @@
+"""GPU parity, part 7: `extract calls` (mkp_extract_calls_main: calls decoded on the device, the table assembled on the host) against the
+reference's own golden tables (tests/test_extract.rs:499-560) byte for byte, and against the oracle on fuzzed modBAMs (every tag
+layout of tests/bamfuzz.py, filters, thresholds)."""
+import subprocess
+
+import pytest
+
+import modkit_amd
+from bamfuzz import Fuzz
+from pileup_cases import EXTRACT_CALLS_CASES, REF, fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,flags,bam,golden", EXTRACT_CALLS_CASES, ids=[c[0] for c in EXTRACT_CALLS_CASES])
+def test_device_reproduces_extract_calls_golden(tmp_path, name, flags, bam, golden):
+    out = str(tmp_path / "calls.tsv")
+    modkit_amd.extract_calls([fixture(bam), out] + [f.format(ref=REF) for f in flags])
+    assert open(out).read() == open(fixture(golden)).read()
+
+
+FLAG_SETS = [
+    ["--no-filtering"],
+    ["--filter-threshold", "0.75", "--mod-thresholds", "m:0.9"],
+    ["--filter-threshold", "C:0.7", "--filter-threshold", "0.6", "--pass-only"],
+    ["--ignore", "h", "--filter-threshold", "0.7"],
+    ["--edge-filter", "12,30", "--no-filtering"],
+    ["--mapped-only", "--no-filtering", "--kmer-size", "8"],
+    ["--allow-non-primary", "--no-filtering", "--ref", "{fa}"],
+    ["-p", "0.2", "--ref", "{fa}"],
+    [],
+]
+
+
+@pytest.mark.parametrize("profile", ["m", "hm_comb", "hm_split", "hm_split_diff", "hma", "implicit", "default", "nbase", "chebi", "mixed"])
+def test_extract_calls_fuzz_vs_oracle(oracle_bin, tmp_path, profile):
+    bam, fa, bed = Fuzz(900, profile=profile, n_reads=300).write(str(tmp_path / "fz"))
+    for fi, fl in enumerate(FLAG_SETS):
+        flags = [f.format(fa=fa) for f in fl]
+        dev, ora = str(tmp_path / ("dev%d.tsv" % fi)), str(tmp_path / ("ora%d.tsv" % fi))
+        p = subprocess.run([oracle_bin, "extract-calls", bam, ora] + flags, capture_output=True, text=True)
+        try:
+            modkit_amd.extract_calls([bam, dev] + flags)
+            err = None
+        except modkit_amd.MkpError as e:
+            err = e
+        if p.returncode != 0:
+            assert err is not None, "oracle failed (%s) but the device run succeeded" % p.stderr[-200:]
+            continue
+        assert err is None, "device failed: %s (flags %s)" % (err, flags)
+        a, b = open(dev).read().splitlines(), open(ora).read().splitlines()
+        for i in range(max(len(a), len(b))):
+            x, y = (a[i] if i < len(a) else "<none>"), (b[i] if i < len(b) else "<none>")
+            assert x == y, "profile %s flags %s row %d differs\n device: %s\n oracle: %s (%d vs %d rows)" % (profile, flags, i, x, y, len(a), len(b))
+        assert len(a) > 1
