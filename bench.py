@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the short run the --pmc passes profile
     ap.add_argument("--tile", type=int, default=0, help="experiments: reference positions per accumulate tile (0 = the library's plan)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help="nccl (= RCCL over xGMI, one GPU per rank) or gloo (tests: several ranks may share a GPU)")
     ap.add_argument("--skip-e2e", action="store_true", help="profiling runs: skip the sharded end-to-end pass so that every kernel launch is the full-size one the timed region repeats")
     a = ap.parse_args()
     if a.skip_e2e or a.inner:
@@ -251,12 +252,18 @@ def main():
         raise SystemExit("--gpus %d needs WORLD_SIZE=%d ranks: launch with python -m torch.distributed.run --nproc-per-node %d ..." % (a.gpus, a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in libmkpileup)")
+    if a.dist_backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()   # tests: ranks share the GPUs there are
     torch.cuda.set_device(local_rank)
+    tdev = "cuda" if a.dist_backend == "nccl" else "cpu"      # where the few scalars that cross ranks live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     gflags, pflags, desc = WORKLOADS[a.workload]
     multi = a.workload in ("c4", "c5")
@@ -349,6 +356,7 @@ def main():
         # ---- N ranks, ONE BAM: thresholds from the all-reduced histograms, every rank runs its contiguous run of the interval grid
         from modkit_amd import distributed as mkd
         shard_stats = {}
+        flags = flags + ["--shard-bp", str(1 << 27)]   # one shard per contig piece a rank owns (the default cuts 8 pieces per rank to balance small files)
         thr = mkd.pileup_sharded([bam, out_bed] + flags, rank=rank, world=world, device=local_rank, stats=shard_stats)
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
         # the rank's windows, each resident in HBM on its own context (a window = a piece of one contig; cuts sit on the interval grid)
@@ -394,11 +402,11 @@ def main():
         if world == 1:
             n_rows = int(rep.n_rows)
         my_positions = float(total_len) if world == 1 else float(sum(e - s for _, s, e in plan))
-        el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        el = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         if dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
-        totals = torch.tensor([my_positions, float(n_rows)], dtype=torch.float64, device="cuda")
+        totals = torch.tensor([my_positions, float(n_rows)], dtype=torch.float64, device=tdev)
         if dist:
             dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         total_positions, total_rows = float(totals[0].item()), float(totals[1].item())

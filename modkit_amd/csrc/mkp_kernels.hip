@@ -323,6 +323,7 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
             if (!keep) continue;
             any_surviving = true;
             if (prm.sample_mode >= 2) {   // 2 `summary`: thresholded + argmax class; 3 `extract calls`: + forward position, mod strand, inferred, call_prob
+              if (prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) continue;   // the collapse left no code in the map: no profile row (iter_probs is empty)
               uint32_t ob = 0; float am = 0.f; uint32_t inf = summary_info(gr, pv, spk, collapse, &ob, MKP_KMAX, &am);
               if (prm.sample_mode == 3) { inf |= ((uint32_t)sg << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); ev_pos = (int32_t)f; }
               sv[ev_cnt] = prm.sample_mode == 3 ? am : 0.f; ev_info[ev_cnt++] = inf; obs0 |= ob; continue;
@@ -657,7 +658,8 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep && prm.sample_mode >= 2) {
+          if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;   // `extract calls`: the collapse left no code in the map: no profile row
+          else if (keep && prm.sample_mode >= 2) {
             any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob; has_ev = true;
             if (prm.sample_mode == 3) { ev_info |= ((uint32_t)sg0 << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position
           }
@@ -1010,7 +1012,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep && prm.sample_mode >= 2) {
+          if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;   // `extract calls`: the collapse left no code in the map: no profile row
+          else if (keep && prm.sample_mode >= 2) {
             any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob; has_ev = true;
             if (prm.sample_mode == 3) { ev_info |= (uint32_t)sg0 << 2; sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position (explicit tags: never inferred)
           }

@@ -343,7 +343,7 @@ class Packer {
         default: return false;
       }
       if ((uint64_t)v != (uint64_t)(uint32_t)r.l_qseq) return false;  // check_mn_tag_correct (mod_bam.rs:1431-1449)
-    }
+    } else if (r.flag & (256 | 1024 | 2048)) return false;             // NonPrimaryMissingMn: a secondary / supplementary / duplicate record needs MN (1444-1446)
     const char* s = (const char*)mm + 1;
     std::string key; std::vector<TagHeader> hdrs; std::vector<MkpTagRef> refs;
     uint32_t ml_base = (uint32_t)S.ml.size(); uint64_t pointer = 0; uint64_t calls = 0; bool implicit_strand[2] = {false, false};
