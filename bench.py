@@ -64,6 +64,18 @@ WORKLOADS = {
 }
 
 
+def usable_cpus():
+    """CPUs this process may use: affinity mask cut by the cgroup CPU quota (the GPU box's container: 256 hardware threads, cpu.max = 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def sh256(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -129,7 +141,7 @@ def cpu_baseline(bam, flags, workers, region=None, hemi=False, tag="full"):
     load_s, thr_s, pileup_s, total_s = (float(m.group(i)) for i in (3, 4, 5, 6))
     what = "the whole bench workload" if not region else "region %s of the bench BAM (the BAM load and the threshold sample still cover the whole file)" % region
     return out, {
-        "value": positions / pileup_s, "unit": "positions/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+        "value": positions / pileup_s, "unit": "positions/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(), "host_cores": os.cpu_count(), "usable_cpus": usable_cpus(),
         "sample": "%s; restated CPU path (oracle/, interval-parallel like the reference's Rayon pool, %d worker threads); value = pileup phase only with the BAM already decoded in RAM" % (what, workers),
         "rows_per_s": rows / pileup_s, "positions": positions, "rows": rows,
         "end_to_end": {"positions_per_s": positions / total_s, "rows_per_s": rows / total_s, "total_s": total_s, "load_s": load_s, "threshold_s": thr_s, "pileup_s": pileup_s, "wall_s": wall},
@@ -291,7 +303,7 @@ def main():
     if rank == 0:
         if not os.path.exists(os.path.join(ROOT, "tools", "gen_modbam")):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
-        gen_bam(prefix, contigs, n_reads, seed, gflags, os.cpu_count() or 1)
+        gen_bam(prefix, contigs, n_reads, seed, gflags, usable_cpus())
         if a.workload == "c5":
             gen_bed(prefix + ".bed", contigs, max(50, int(20000 * a.genome_scale)))
     if dist:
@@ -303,7 +315,7 @@ def main():
     # the sampling schedule batches its intervals; the device run and the CPU baseline get the same value so that they sample the same reads
     flags = [f.format(fa=fa, bed=prefix + ".bed") for f in pflags] + ["-t", "8"]
     desc = desc.format(gs="%g" % a.genome_scale) + "; %d contig(s), %d bp, %d reads (mean %.0f aligned bp, ~%.1fx)" % (len(contigs), total_len, meta["reads"], meta["aligned_bases"] / max(1, meta["reads"]), meta["aligned_bases"] / total_len)
-    host_threads = min(64, os.cpu_count() or 1) if "MKP_POOL_THREADS" not in os.environ else int(os.environ["MKP_POOL_THREADS"])
+    host_threads = int(modkit_amd.lib().mkp_host_threads())   # the library's pool: usable CPUs (affinity, cgroup quota) capped at 64, or MKP_POOL_THREADS
 
     def run_subcommand(ctx, out, extra):   # `modkit pileup` / `modkit pileup-hemi` on a bench context
         return ctx.pileup_hemi_run([bam, "-o", out] + flags + extra) if hemi else ctx.pileup_run([bam, out] + flags + extra)
@@ -496,7 +508,7 @@ def main():
             "roofline": dict(agg, slowest=slow, whole_pass=whole),
         }
         if world == 1 and not a.no_cpu_baseline:
-            workers = min(os.cpu_count() or 1, 8)
+            workers = min(usable_cpus(), 8)
             region = None
             if multi:
                 region = "%s:0-%d" % (contigs[-1][0], contigs[-1][1])   # bounded sample: the last (shortest-but-one) contig
@@ -514,12 +526,12 @@ def main():
             base["speedup_end_to_end"] = dev_pps / base["end_to_end"]["positions_per_s"] if not region else None
             base["device_host_threads"] = host_threads
             if not region and not hemi:
-                # matched host thread counts: the device run's host side capped at 8 threads against the oracle on 8; both at 64 (or all cores)
+                # matched host thread counts: the device run's host side capped at 8 threads against the oracle on 8; both at all usable CPUs (at most 64)
                 m8 = device_e2e_subprocess(bam, bam + ".device.t8.bed", flags, 8)
                 matched = {"8_threads": {"device": m8, "oracle_total_s": base["end_to_end"]["total_s"],
                                          "speedup_end_to_end": (base["end_to_end"]["total_s"] * 1e3 / m8["total_ms"]) if m8.get("total_ms") else None}}
-                if (os.cpu_count() or 1) > 8:
-                    w2 = min(os.cpu_count(), 64)
+                if usable_cpus() > 8:
+                    w2 = min(usable_cpus(), 64)
                     _, b2 = cpu_baseline(bam, [f for f in flags if f not in ("-t", "8")] + ["-t", str(w2)], w2, None, hemi, "t%d" % w2)   # (-t steers its sampling schedule too: timing only, no sha comparison)
                     mN = device_e2e_subprocess(bam, bam + ".device.t%d.bed" % w2, flags, w2)
                     matched["%d_threads" % w2] = {"device": mN, "oracle_total_s": b2["end_to_end"]["total_s"], "oracle_positions_per_s": b2["value"],

@@ -156,6 +156,10 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out);
 void mkp_ctx_destroy(mkp_ctx* ctx);
 const char* mkp_last_error(const mkp_ctx* ctx);
 const char* mkp_version(void);
+/* Threads of the library's host pool (BGZF inflate, packing, planning, text): the CPUs this process may use — affinity mask and
+   cgroup CPU quota — capped at 64; MKP_POOL_THREADS in the environment overrides it.  Rayon's `-t` in the reference
+   (subcommand.rs:486-489) is the matching knob. */
+unsigned mkp_host_threads(void);
 
 /* ---- caller / options: stands in for the `caller`, `pileup_numeric_options`, `force_allow`,
  *      `combine_strands`, `max_depth`, `edge_filter` arguments of process_region_batch */

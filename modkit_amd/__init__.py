@@ -46,6 +46,7 @@ def lib():
             raise MkpError(-4, "libmkpileup.so is not built (run modkit_amd.build() / __graft_entry__.build())")
         L = ctypes.CDLL(LIB_PATH)
         L.mkp_version.restype = ctypes.c_char_p
+        L.mkp_host_threads.restype = ctypes.c_uint
         L.mkp_last_error.restype = ctypes.c_char_p
         L.mkp_last_error.argtypes = [ctypes.c_void_p]
         L.mkp_pileup_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
@@ -76,7 +77,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_set_caller", "mkp_shard_begin",
+EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_host_threads", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",

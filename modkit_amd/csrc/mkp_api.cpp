@@ -216,6 +216,7 @@ void make_resident(mkp_ctx* c) {
   }
   // decode kernel classes; a duplex read decoded one group per wave needs room for both groups' lists behind the merged one
   std::vector<uint32_t> class_list; class_ids(S, c->tables, &class_list, c->n_class, true);
+  lap("decode classes");
   // SPARSE reads with two tags: combine_checked's test (mod_bam.rs:629-656) that a call's probabilities over both tags do not add up
   // to more than 1.01 — every term is (2q + 1) / 512, so the f32 sum is exact and `> 1.01f` is "the numerators reach 518" — is made
   // here over the ML bytes, on all cores, and handed to the slot decoder as a header flag
@@ -235,6 +236,7 @@ void make_resident(mkp_ctx* c) {
       if (bad) h.flags |= MKP_RF_SUMERR; else h.flags &= ~MKP_RF_SUMERR;
     }
   });
+  lap("probability-sum test");
   { size_t at = 0; for (int k = 0; k < 5; k++) at += c->n_class[k];
     for (; at < class_list.size(); at += 2) {
       MkpReadHdr& h = S.hdr[class_list[at]];
@@ -419,6 +421,7 @@ void make_resident(mkp_ctx* c) {
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref);
       upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
+  lap("upload: packed reads");
   upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
   upload(c->d_read_ids, class_list);
   if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64);
@@ -426,6 +429,7 @@ void make_resident(mkp_ctx* c) {
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
+  lap("upload: focus + event buffers");
   if (stream) {
     upload(c->d_slot_pos, slot_pos_h); upload(c->d_stiles, stiles);
     {   // the fused decoder's work records, in launch order; the cover kernel keeps a read-id list
@@ -456,6 +460,7 @@ void make_resident(mkp_ctx* c) {
       } for (uint32_t k = 0; k < seen.size(); k++) if (seen[k]) c->key_passes.push_back(k); if (c->key_passes.empty()) c->key_passes.push_back(0); }
   hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
+  lap("upload: slot plan + sync");
   c->stats.h2d_ms = ms_since(t1);
   c->resident = true; c->resident_hemi = c->hemi;
   // algorithmic bytes
@@ -630,6 +635,12 @@ template <class F> int guarded(mkp_ctx* c, F f) {
 extern "C" {
 
 const char* mkp_version(void) { return "libmkpileup 0.1 (gfx950)"; }
+unsigned mkp_host_threads(void) { return HostPool::get().size(); }
+// test hook (tests/test_host_inflate.py; not part of include/mkpileup.h): the host DEFLATE decoder alone, 1 = decoded, 0 = declined
+int mkp_internal_host_inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
+  std::vector<uint8_t> padded(clen + 8, 0); if (clen) memcpy(padded.data(), src, clen);
+  return hostinf::inflate(padded.data(), clen, dst, dlen) ? 1 : 0;
+}
 
 int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
   if (!out) return MKP_E_INVALID;
@@ -750,9 +761,16 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
     if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
     if (!c->caller_set) throw Error(MKP_E_INVALID, "mkp_set_caller first");
     c->hemi = false;
+    const bool trace = getenv("MKP_TRACE_PLAN") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&, last = t0](const char* what) mutable { if (trace) { auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
     if (!c->resident || c->resident_hemi) { c->row_cap = 0; make_resident(c); }
+    lap("run: make_resident");
     run_kernels(c, true);
+    lap("run: kernels");
     fetch_rows(c, out);
+    lap("run: fetch rows");
     if (c->slot_mode) {   // n_events = call features + events of the reads the event decoders took
       c->stats.alg_bytes_pileup += 44ull * c->stats.n_rows;
       c->stats.alg_bytes_agg_survey += 44ull * c->stats.n_rows;

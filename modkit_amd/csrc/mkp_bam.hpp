@@ -17,6 +17,8 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include "mkp_inflate_host.hpp"
+#include <sched.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -46,11 +48,31 @@ class HostPool {
   static HostPool& get() { static HostPool p; return p; }
   // f(i) for every i in [0, n), on the pool's workers and the calling thread; returns when all are done.  Re-entrant and
   // callable from several threads at once.
+  // CPUs this process may actually use: the scheduler affinity mask, cut by the cgroup's CPU quota (a container on a 256-thread
+  // host with `cpu.max = 1600000 100000` runs 16 threads' worth; 64 pool threads there spend their time being throttled), capped at 64
+  static unsigned host_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set; if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
+      char q[32]; unsigned long long period = 0;
+      if (fscanf(f, "%31s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min(n, (unsigned)std::max(1ull, (strtoull(q, nullptr, 10) + period - 1) / period));
+      fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      long long quota = -1, period = 0; if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g);
+      if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+      if (quota > 0 && period > 0) n = std::min(n, (unsigned)std::max(1ll, (quota + period - 1) / period));
+    }
+    return std::max(1u, std::min(64u, n));
+  }
+  unsigned size() const { return (unsigned)workers_.size() + 1u; }   // the calling thread works too
+  static bool& background() { static thread_local bool b = false; return b; }
   template <class F> void parallel(size_t n, F f) {
     if (n == 0) return;
     if (n == 1 || workers_.empty()) { for (size_t i = 0; i < n; i++) f(i); return; }
     Job job; job.n = n; job.fn = [&f](size_t i) { f(i); };
-    { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(&job); }
+    // workers claim from the front: a job of a thread that declared itself background work (the next shard's prefetch) queues behind
+    // everything else, so the steps of the shard in hand are never starved by a thousand queued inflate tasks
+    { std::lock_guard<std::mutex> lk(mu_); if (background()) jobs_.push_back(&job); else jobs_.push_front(&job); }
     cv_.notify_all();
     for (;;) { const size_t i = job.next.fetch_add(1); if (i >= n) break; run_one(&job, i); }
     { std::unique_lock<std::mutex> lk(mu_);
@@ -68,7 +90,7 @@ class HostPool {
   }
   std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Job*> jobs_; bool stop_ = false;
   HostPool() {
-    unsigned n = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    unsigned n = host_cpus();
     if (const char* e = getenv("MKP_POOL_THREADS")) n = std::max(1u, std::min(512u, (unsigned)strtoul(e, nullptr, 10)));   // experiments
     for (unsigned t = 1; t < n; t++) workers_.emplace_back([this] { loop(); });
   }
@@ -106,12 +128,38 @@ struct ByteBuf {
   ByteBuf& operator=(ByteBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; heap = o.heap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
   ByteBuf(const ByteBuf&) = delete; ByteBuf& operator=(const ByteBuf&) = delete;
   ~ByteBuf() { release(); }
-  void release() { if (p) { if (heap) free(p); else munmap(p, cap); } p = nullptr; n = cap = 0; heap = false; }
+  // Large mappings are recycled through a process-wide spare list: a shard's inflated windows are ~1 GB, and unmapping them after the
+  // pack (~45 ms per shard, the address-space lock held against every other thread's faults) plus faulting fresh ones for the next
+  // shard cost more than the copy itself.  At most kSpareBytes stay parked; trim_spares() (BamSource destructor) returns them.
+  struct Spares { std::mutex mu; std::vector<std::pair<uint8_t*, size_t>> free; size_t bytes = 0; };
+  static Spares& spares() { static Spares s; return s; }
+  static constexpr size_t kSpareBytes = (size_t)6 << 30;
+  static void trim_spares() { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu); for (auto& f : s.free) munmap(f.first, f.second); s.free.clear(); s.bytes = 0; }
+  void release() {
+    if (p) {
+      if (heap) free(p);
+      else {
+        Spares& s = spares(); bool parked = false;
+        { std::lock_guard<std::mutex> g(s.mu); if (s.bytes + cap <= kSpareBytes && s.free.size() < 64) { s.free.push_back({p, cap}); s.bytes += cap; parked = true; } }
+        if (!parked) munmap(p, cap);
+      }
+    }
+    p = nullptr; n = cap = 0; heap = false;
+  }
   // small buffers come from the heap: many threads mapping, faulting and unmapping small regions serialise on the address-space lock
   void alloc(size_t bytes) {
     release();
     if (bytes < (32u << 20)) { p = (uint8_t*)malloc(std::max<size_t>(bytes, 1)); if (!p) throw Error(MKP_E_NOMEM, "out of host memory for the decompressed BAM"); n = cap = bytes; heap = true; return; }
-    cap = (std::max<size_t>(bytes, 1) + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    // sizes in 32 MiB steps: the windows of one file inflate to similar sizes and then land in the same step
+    const size_t want = (std::max<size_t>(bytes, 1) + (32u << 20) - 1) & ~(size_t)((32u << 20) - 1);
+    { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu);   // the smallest parked mapping that holds it without wasting more than its size again
+      size_t best = SIZE_MAX;
+      for (size_t i = 0; i < s.free.size(); i++) if (s.free[i].second >= want && s.free[i].second <= 2 * want && (best == SIZE_MAX || s.free[i].second < s.free[best].second)) best = i;
+      if (best != SIZE_MAX) { p = s.free[best].first; cap = s.free[best].second; n = bytes; s.bytes -= cap; s.free.erase(s.free.begin() + (ptrdiff_t)best); return; }
+      // nothing parked fits: the parked ones belong to a shape of work that is over; give them back so that the peak follows the shard in hand
+      for (auto& f : s.free) munmap(f.first, f.second);
+      s.free.clear(); s.bytes = 0; }
+    cap = want;
     void* m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) { cap = 0; throw Error(MKP_E_NOMEM, "out of host memory for the decompressed BAM"); }
     madvise(m, cap, MADV_HUGEPAGE);
@@ -171,7 +219,11 @@ struct BamData {
   }
 };
 
+// one BGZF block's deflate payload -> dst[0, dlen).  The payload is followed by the block's CRC32 + ISIZE (8 readable bytes).
+// The library's own decoder (mkp_inflate_host.hpp) first; zlib when it declines, which is also where the error comes from.
 static inline void inflate_block(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
+  static const bool use_zlib = getenv("MKP_HOST_INFLATE") && !strcmp(getenv("MKP_HOST_INFLATE"), "zlib");   // A/B timing
+  if (!use_zlib && hostinf::inflate(src, clen, dst, dlen)) return;
   z_stream zs; memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, -15) != Z_OK) throw Error(MKP_E_IO, "zlib init failed");
   zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = (uInt)dlen;
@@ -197,7 +249,7 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0, bo
     dtotal += isize; o += bsize;
   }
   BamData bd; bd.raw.alloc(dtotal);
-  if (!threads) threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  if (!threads) threads = HostPool::host_cpus();
   std::atomic<size_t> next{0}; std::atomic<bool> bad{false};
   auto work = [&]() { for (;;) { size_t i = next++; if (i >= blks.size()) break; if (!blks[i].dlen) continue; try { inflate_block(&comp[blks[i].coff], blks[i].clen, &bd.raw[blks[i].doff], blks[i].dlen); } catch (...) { bad = true; } } };
   if (threads <= 1 || blks.size() < 4) work(); else { std::vector<std::thread> th; for (unsigned t = 0; t < threads; t++) th.emplace_back(work); for (auto& t : th) t.join(); }
@@ -353,11 +405,11 @@ class BamSource {
   mutable std::atomic<uint64_t> bytes_read{0}, bytes_inflated{0};   // compressed bytes pread / bytes inflated so far
   int tid_of(const std::string& n) const { for (size_t i = 0; i < ref_names.size(); i++) if (ref_names[i] == n) return (int)i; return -1; }
   bool indexed() const { return fd_ >= 0; }
-  ~BamSource() { if (fd_ >= 0) close(fd_); }
+  ~BamSource() { if (fd_ >= 0) close(fd_); ByteBuf::trim_spares(); }
 
   // `use_index`: read through <path>.bai when it exists; otherwise (or when there is none) load the whole file
   static std::unique_ptr<BamSource> open(const std::string& path, unsigned threads, bool use_index = true) {
-    std::unique_ptr<BamSource> s(new BamSource()); s->path_ = path; s->threads_ = threads ? threads : std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    std::unique_ptr<BamSource> s(new BamSource()); s->path_ = path; s->threads_ = threads ? threads : HostPool::host_cpus();
     if (use_index && BaiIndex::load(path + ".bai", &s->bai_)) {
       s->fd_ = ::open(path.c_str(), O_RDONLY); if (s->fd_ < 0) throw Error(MKP_E_IO, "cannot open " + path);
       struct stat st; if (fstat(s->fd_, &st) != 0) throw Error(MKP_E_IO, "cannot stat " + path); s->fsize_ = (uint64_t)st.st_size;

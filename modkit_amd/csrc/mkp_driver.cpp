@@ -364,7 +364,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto t_all = std::chrono::steady_clock::now();
   // BAI next to the BAM: only the blocks of the shards (and sampling intervals) this run touches are read and inflated; otherwise
   // the whole file is loaded once.  (inflate threads: --threads only steers the sampling schedule)
-  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(64u, std::thread::hardware_concurrency())),
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), HostPool::host_cpus()),
       !a.no_index);
   const BamSource& bam = *src;
   double load_ms = ms_since(t_all);
@@ -440,11 +440,35 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   std::vector<std::vector<uint8_t>> focus_of(records.size()); std::vector<char> focus_done(records.size(), 0);
   std::vector<std::vector<Interval>> grid_of(records.size()); std::vector<char> grid_done(records.size(), 0);
   double focus_ms = 0;
+  // shards: pieces of the contig records cut at interval boundaries, bounded in positions (tally / focus buffers) and in BAM bytes
+  // (host memory: a shard's blocks are inflated and packed as a unit)
+  uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
+  const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27,
+      (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
+  // 2^27 positions per shard keeps the per-shard focus / slot buffers small
+  auto shard_cut = [&](const Contig& rec, const std::vector<Interval>& ivs, size_t i0, uint64_t* bp_out) {   // -> one past the shard's last interval
+    size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
+    while (i1 < ivs.size() && (bp == 0 || (bp + (ivs[i1].end - ivs[i1].start) <= shard_bp && (!bam.indexed() || bam.offset_at(rec.tid,
+        ivs[i1].end) - o0 <= a.shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
+    *bp_out = bp; return i1;
+  };
+  auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) { HostPool::background() = true; std::unique_ptr<BamBatch> b(new BamBatch());
+      bam.fetch(tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, b.get()); return b; };
+  // The first shard's blocks are read and inflated behind the threshold estimate (background priority on the host pool: the estimate's
+  // own bursts go first), as soon as the first contig's grid is known.
+  std::future<std::unique_ptr<BamBatch>> early_fetch; uint32_t early_s0 = 0, early_s1 = 0; bool early_set = false;
   std::future<void> early_walk;
   if (fb.has_focus() && a.world == 1 && !a.plan_only && a.filter_threshold.empty() && !a.no_filtering)
     early_walk = std::async(std::launch::async, [&]() {
       auto t_focus = std::chrono::steady_clock::now();
-      for (size_t ri = 0; ri < records.size(); ri++) { grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1; }
+      for (size_t ri = 0; ri < records.size(); ri++) {
+        grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1;
+        if (ri == 0 && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {
+          uint64_t bp; const size_t i1 = shard_cut(records[0], grid_of[0], 0, &bp);
+          early_s0 = grid_of[0][0].start; early_s1 = grid_of[0][i1 - 1].end; early_set = true;
+          early_fetch = std::async(std::launch::async, fetch_range, records[0].tid, early_s0, early_s1);
+        }
+      }
       focus_ms += ms_since(t_focus);
     });
   struct JoinWalk { std::future<void>* f; ~JoinWalk() { if (f->valid()) f->wait(); } } join_walk{&early_walk};
@@ -504,13 +528,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   };
   if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n",
       wr.f);
-  // ---- shard plan: pieces of the contig records cut at interval boundaries, bounded in positions (tally / focus buffers) and in
-  // BAM bytes (host memory: a shard's blocks are inflated and packed as a unit); ranks take contiguous runs, balanced by the
-  // bytes the index puts under them (by length without an index)
-  uint64_t total_bp = 0; for (auto& r : records) total_bp += r.length;
-  const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27,
-      (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
-  // 2^27 positions per shard keeps the per-shard focus / slot buffers small
+  // ---- shard plan (shard_cut above); ranks take contiguous runs, balanced by the bytes the index puts under them (by length
+  // without an index)
   struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */ };
   std::vector<ShardPlan> plan;
   const bool hf = fb.has_focus();
@@ -529,9 +548,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           focus_ms += ms_since(t_focus); }
       size_t i0 = 0;
       while (i0 < ivs.size()) {
-        size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
-        while (i1 < ivs.size() && (bp == 0 || (bp + (ivs[i1].end - ivs[i1].start) <= shard_bp && (!bam.indexed() || bam.offset_at(rec.tid,
-            ivs[i1].end) - o0 <= a.shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
+        uint64_t bp = 0; const size_t i1 = shard_cut(rec, ivs, i0, &bp); const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
         const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
         const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
         const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
@@ -541,12 +558,13 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
     }
   }
-  auto fetch_shard = [&](const ShardPlan& sp) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(records[sp.rec].tid, sp.s0 > MKP_HALO ? sp.s0 - MKP_HALO : 0,
-      sp.s1 + MKP_HALO, b.get()); return b; };
+  auto fetch_shard = [&](const ShardPlan& sp) { return fetch_range(records[sp.rec].tid, sp.s0, sp.s1); };
   mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<std::unique_ptr<BamBatch>> next_batch;
-  if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]);
+  const bool early_ok = early_set && early_fetch.valid() && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
+  if (early_ok) next_batch = std::move(early_fetch);
+  else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }
   for (size_t pi = 0; pi < plan.size(); pi++) {
     const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
     std::unique_ptr<BamBatch> batch;
@@ -583,7 +601,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       must(mkp_shard_begin(ctx, &sh));
       must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       mark("shard packed");
-      batch.reset();   // packed: the inflated blocks are no longer needed
+      batch.reset();   // packed: the inflated blocks are no longer needed (their mappings are parked for the next fetch, ByteBuf::spares)
       mkp_rows rows; memset(&rows, 0, sizeof(rows));
       if (a.hemi) {
         int hoff = 0; fb.motifs[0].neg_delta(&hoff);
@@ -595,6 +613,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         rows.processed_records = hrows.processed_records; rows.skipped_records = hrows.skipped_records;
       } else {
       must(mkp_shard_run(ctx, &rows));
+      mark("  mkp_shard_run returned");
       if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, &rows));   // measurement aid: warm, averaged kernel times in --stats
       { auto t_w = std::chrono::steady_clock::now();
         if (!partitioned) wr.write(rec.name, rows);
@@ -728,7 +747,7 @@ namespace {
 // the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
 void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out, const mkp_caller* thresholds = nullptr) {
   Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
-  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, std::thread::hardware_concurrency())),
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, HostPool::host_cpus())),
       !a.no_index);   // inflate threads: --threads only steers the sampling schedule
   const BamSource& bam = *src;
   RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();

@@ -8,6 +8,7 @@
 // structure instead of once per call.  Everything per base and per call happens on the GPU.
 #pragma once
 #include <cmath>
+#include <sys/mman.h>
 #include <memory>
 #include <thread>
 #include <unordered_map>
@@ -182,8 +183,22 @@ struct LayoutTables {
 
 // ------------------------------------------------------------------------------------------
 // std::vector whose resize() leaves new elements uninitialised (the caller fills them; pages are first touched by the writer)
+// Buffers of 8 MiB and more are mapped directly and advised to use huge pages: a shard's arrays are hundreds of MB that all cores touch
+// for the first time at once, and with 4 KiB pages the first shard of a run spent more time in page faults than in packing.
 template <class T> struct DefaultInitAlloc : std::allocator<T> {
   template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+  static constexpr size_t kMapFrom = (size_t)8 << 20, kHuge = (size_t)2 << 20;
+  static size_t mapped_len(size_t n) { return (n * sizeof(T) + kHuge - 1) & ~(kHuge - 1); }
+  T* allocate(size_t n) {
+    if (n * sizeof(T) < kMapFrom) return std::allocator<T>::allocate(n);
+    void* m = mmap(nullptr, mapped_len(n), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    madvise(m, mapped_len(n), MADV_HUGEPAGE);
+    return (T*)m;
+  }
+  void deallocate(T* p, size_t n) {
+    if (n * sizeof(T) < kMapFrom) std::allocator<T>::deallocate(p, n); else munmap((void*)p, mapped_len(n));
+  }
   template <class U, class... A> void construct(U* p, A&&... a) {
     if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
   }
@@ -414,7 +429,7 @@ class Packer {
 // record ranges are packed independently by all host cores and appended in order (same layout ids and offsets as one
 // sequential pass).
 template <class Keep> void pack_records(Packer& packer, ShardHost& dst, const mkp_record* recs, uint32_t n, Keep keep, uint32_t min_parallel = 1024) {
-  unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  unsigned hw = HostPool::host_cpus();
   if (const char* e = getenv("MKP_PACK_PIECES")) hw = std::max(1u, std::min(4096u, (unsigned)strtoul(e, nullptr, 10)));   // experiments
   const unsigned n_thr = n >= min_parallel ? std::max(1u, std::min(hw, n)) : 1;
   if (n_thr == 1) { for (uint32_t i = 0; i < n; i++) if (keep(recs[i])) packer.add(recs[i], dst); return; }
@@ -425,6 +440,11 @@ template <class Keep> void pack_records(Packer& packer, ShardHost& dst, const mk
     sh[t].clear();
     const uint32_t lo = (uint32_t)((uint64_t)n * t / n_thr), hi = (uint32_t)((uint64_t)n * (t + 1) / n_thr);
     sh[t].tid = dst.tid; sh[t].win_start = dst.win_start; sh[t].win_end = dst.win_end;
+    {   // room for the piece's bases and CIGARs up front (known from the record cores): no regrowth copies while packing
+      size_t seq_b = 0, cig = 0;
+      for (uint32_t i = lo; i < hi; i++) { seq_b += (((size_t)std::max(recs[i].l_qseq, 0) + 1) / 2 + 3) & ~(size_t)3; cig += recs[i].n_cigar; }
+      sh[t].seq.reserve(seq_b + 64); sh[t].cigar.reserve(cig + 64); sh[t].hdr.reserve(hi - lo); sh[t].name_hash.reserve(hi - lo);
+    }
     try { for (uint32_t i = lo; i < hi; i++) if (keep(recs[i])) pk[t].add(recs[i], sh[t]); }
     catch (const Error& e) { errs[t].reset(new Error(e)); }
     catch (const std::exception& e) { errs[t].reset(new Error(MKP_E_INVALID, e.what())); }

@@ -82,7 +82,7 @@ struct RowWriter {
   template <class Fmt> void write_rows(const std::string& chrom, uint64_t n_rows, Fmt fmt) {
     if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
     if (n_rows == 0) return;
-    const unsigned n_thr = n_rows >= 65536 ? std::max(1u, std::min(64u, std::thread::hardware_concurrency())) : 1u;
+    const unsigned n_thr = n_rows >= 65536 ? HostPool::host_cpus() : 1u;
     std::vector<TextBuf> bufs(n_thr);
     HostPool::get().parallel(n_thr, [&](size_t t) { fmt(n_rows * t / n_thr, n_rows * (t + 1) / n_thr, &bufs[t]); });
     n += n_rows;

@@ -24,7 +24,7 @@ def L():
 
 def declared_symbols():
     text = open(HEADER).read()
-    return sorted(set(re.findall(r"^(?:int|void|const char\*)\s+(mkp_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|unsigned|void|const char\*)\s+(mkp_\w+)\s*\(", text, flags=re.M)))
 
 
 def test_every_declared_symbol_is_exported(L):
