@@ -399,9 +399,17 @@ struct BaiIndex {
   }
 };
 
+// Optional device stage of the indexed fetch (--device-inflate): one window's BGZF blocks inflated on the GPU (mkp_inflate.hip) straight
+// into the window's host buffer.  false = not done (any block failed, or no device): the host decoder then runs and reports.
+struct InflateBlk { unsigned long long in_off, out_off; uint32_t in_len, out_len; };   // == MkpBgzfBlock
+struct InflateJob { const uint8_t* comp; size_t comp_len; const InflateBlk* blks; size_t n_blks; uint8_t* dst; size_t dtotal; };
+using DeviceInflateFn = bool (*)(void* user, const InflateJob& job);
+
 class BamSource {
  public:
   std::vector<std::string> ref_names; std::vector<uint32_t> ref_lens;
+  DeviceInflateFn dev_inflate = nullptr; void* dev_inflate_user = nullptr;   // set by the driver for --device-inflate
+  mutable std::atomic<uint64_t> bytes_inflated_device{0};
   mutable std::atomic<uint64_t> bytes_read{0}, bytes_inflated{0};   // compressed bytes pread / bytes inflated so far
   int tid_of(const std::string& n) const { for (size_t i = 0; i < ref_names.size(); i++) if (ref_names[i] == n) return (int)i; return -1; }
   bool indexed() const { return fd_ >= 0; }
@@ -568,6 +576,15 @@ class BamSource {
         for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; b.doff = dtotal; dtotal += b.isize; blks.push_back(b); c += b.hdr + b.clen + 8; }
         if (blks.empty()) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
         ByteBuf d; d.alloc((size_t)dtotal + 8);
+        bool on_device = false;
+        if (dev_inflate && dtotal >= (32u << 20)) {   // big windows only: a sampler's 2 MiB head is not worth a round trip
+          std::vector<InflateBlk> jb(blks.size());
+          for (size_t i = 0; i < blks.size(); i++) jb[i] = {(unsigned long long)((blks[i].coff - cb) + blks[i].hdr), (unsigned long long)blks[i].doff, blks[i].clen, blks[i].isize};
+          InflateJob job{&buf[0], buf.size(), jb.data(), jb.size(), d.data(), (size_t)dtotal};
+          on_device = dev_inflate(dev_inflate_user, job);
+          if (on_device) bytes_inflated_device += dtotal;
+        }
+        if (!on_device)
         { std::atomic<bool> bad{false};
           HostPool::get().parallel(blks.size(), [&](size_t i) { if (!blks[i].isize) return; try { inflate_block(&buf[(size_t)(blks[i].coff - cb) + blks[i].hdr], blks[i].clen, &d[(size_t)blks[i].doff], blks[i].isize); } catch (...) { bad = true; } });
           if (bad) throw Error(MKP_E_IO, "corrupt BGZF data in " + path_); }

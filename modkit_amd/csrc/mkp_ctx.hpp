@@ -75,3 +75,8 @@ int mkp_internal_summary_begin(mkp_ctx* c);
 int mkp_internal_set_extract(mkp_ctx* c, bool on);
 int mkp_internal_extract_fetch(mkp_ctx* c, std::vector<MkpEvent>* events, std::vector<float>* vals);
 int mkp_internal_summary_get(mkp_ctx* c, uint64_t out[134], std::vector<MkpSlot>* slots);
+// --device-inflate: the indexed fetch's inflate stage on the GPU (own stream and buffers; BamSource::dev_inflate = mkp_internal_device_inflate)
+struct mkp_dev_inflater;
+mkp_dev_inflater* mkp_internal_inflater_create(int device);
+void mkp_internal_inflater_destroy(mkp_dev_inflater* d);
+bool mkp_internal_device_inflate(void* user, const mkp::InflateJob& job);

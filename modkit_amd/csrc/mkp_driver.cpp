@@ -32,6 +32,7 @@ struct Args {
       uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
       bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
+  bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate.hip) instead of the host pool */
   bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */
 };
 
@@ -434,6 +435,14 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (rc != MKP_OK) throw Error(rc, "no usable gfx950 device (libmkpileup has no CPU path)");
   struct Guard { mkp_ctx* c; ~Guard() { if (c) mkp_ctx_destroy(c); } } guard{ext_ctx ? nullptr : ctx};
   auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
+  // --device-inflate (or MKP_DEVICE_INFLATE=1): the shard windows' BGZF blocks are inflated on the GPU; destroyed after the last fetch (declared
+  // before everything that fetches, so it outlives the prefetch threads on every path out of here)
+  struct InflaterGuard { mkp_dev_inflater* d = nullptr; BamSource* src = nullptr; ~InflaterGuard() { if (src) { src->dev_inflate = nullptr; src->dev_inflate_user = nullptr; } mkp_internal_inflater_destroy(d); } } inflater;
+  if ((a.device_inflate || (getenv("MKP_DEVICE_INFLATE") && !strcmp(getenv("MKP_DEVICE_INFLATE"), "1"))) && !a.plan_only && bam.indexed()) {
+    inflater.d = mkp_internal_inflater_create(a.device);
+    if (!inflater.d) throw Error(MKP_E_DEVICE, "--device-inflate: cannot create a stream on the device");
+    inflater.src = src.get(); src->dev_inflate = mkp_internal_device_inflate; src->dev_inflate_user = inflater.d;
+  }
   // The interval grid and the focus bytes need the reference and the BED only: with one rank they are built on a second thread
   // while the thresholds are being estimated (both are all-cores work in short bursts; neither waits for the other's results).
   if (bf) records = bed_contigs(*bf, records, a.interval_size);
@@ -648,9 +657,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     for (int b = 0; b < 4; b++) { rep->threshold[b] = kc.per_base_threshold[b]; rep->has_threshold[b] = kc.has_per_base[b]; }
   }
   if (a.stats) fprintf(stderr,
-      "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu peak_rss_kb=%llu\n",
+      "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu (on the device %llu) peak_rss_kb=%llu\n",
                        (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
-                       (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)peak_rss_kb());
+                       (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)bam.bytes_inflated_device.load(), (unsigned long long)peak_rss_kb());
   return MKP_OK;
 }
 
@@ -685,6 +694,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val());
         else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val());
         else if (s == "--shard-bytes") a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); else if (s == "--no-index") a.no_index = true;
+        else if (s == "--device-inflate") a.device_inflate = true;
         else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
     else if (s == "--bgzf") a.bgzf = true;

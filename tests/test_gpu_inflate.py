@@ -50,3 +50,21 @@ def test_corrupt_blocks_are_refused(ctx):
         ctx.bgzf_inflate(bytes(data[:len(data) // 2]))   # cut inside a block
     with pytest.raises(modkit_amd.MkpError):
         ctx.bgzf_inflate(b"not a bgzf file at all.." * 4)
+
+
+def test_device_inflate_on_the_fetch_path(tmp_path):
+    """`pileup --device-inflate`: the shard windows' blocks go through the device decoder (mkp_internal_device_inflate) instead of the host
+    pool; the bedMethyl must not change and the --stats line must say how many bytes took the device route."""
+    import re
+    import subprocess
+    bam, fa, _ = Fuzz(78, contigs=(("c", 600000),), n_reads=12000, mean_len=4000, profile="hm_split", weird_rate=0.0).write(str(tmp_path / "dv"))
+    modkit_amd.build()
+    cli = os.path.join(os.path.dirname(modkit_amd.LIB_PATH), "mkpileup")
+    outs = []
+    for extra in ([], ["--device-inflate"]):
+        out = str(tmp_path / ("o%d.bed" % len(outs)))
+        p = subprocess.run([cli, "pileup", bam, out, "--cpg", "--ref", fa, "--stats"] + extra, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs.append((open(out, "rb").read(), int(re.search(r"on the device (\d+)", p.stderr).group(1)), int(re.search(r"bam_bytes_inflated=(\d+)", p.stderr).group(1))))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 100000
+    assert outs[0][1] == 0 and outs[1][1] > 0.9 * outs[1][2] > 32 << 20
