@@ -57,7 +57,8 @@ def test_device_inflate_on_the_fetch_path(tmp_path):
     pool; the bedMethyl must not change and the --stats line must say how many bytes took the device route."""
     import re
     import subprocess
-    bam, fa, _ = Fuzz(78, contigs=(("c", 600000),), n_reads=12000, mean_len=4000, profile="hm_split", weird_rate=0.0).write(str(tmp_path / "dv"))
+    from test_host_ingest import gen   # tools/gen_modbam: writes the BAI the indexed fetch needs
+    bam, fa = gen(tmp_path, "dv", [("c", 600000)], 12000, ["--mean-len", "4000"])
     modkit_amd.build()
     cli = os.path.join(os.path.dirname(modkit_amd.LIB_PATH), "mkpileup")
     outs = []
@@ -67,4 +68,4 @@ def test_device_inflate_on_the_fetch_path(tmp_path):
         assert p.returncode == 0, p.stderr
         outs.append((open(out, "rb").read(), int(re.search(r"on the device (\d+)", p.stderr).group(1)), int(re.search(r"bam_bytes_inflated=(\d+)", p.stderr).group(1))))
     assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 100000
-    assert outs[0][1] == 0 and outs[1][1] > 0.9 * outs[1][2] > 32 << 20
+    assert outs[0][1] == 0 and outs[1][1] > 0.5 * outs[1][2] and outs[1][1] > 32 << 20   # (the threshold sampler's 2 MiB heads stay on the host)
