@@ -636,7 +636,7 @@ extern "C" {
 
 const char* mkp_version(void) { return "libmkpileup 0.1 (gfx950)"; }
 unsigned mkp_host_threads(void) { return HostPool::get().size(); }
-// test hook (tests/test_host_inflate.py; not part of include/mkpileup.h): the host DEFLATE decoder alone, 1 = decoded, 0 = declined
+// test hook (tests/test_host_deflate.py; not part of include/mkpileup.h): the host DEFLATE decoder alone, 1 = decoded, 0 = declined
 int mkp_internal_host_inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
   std::vector<uint8_t> padded(clen + 8, 0); if (clen) memcpy(padded.data(), src, clen);
   return hostinf::inflate(padded.data(), clen, dst, dlen) ? 1 : 0;
