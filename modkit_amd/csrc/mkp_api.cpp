@@ -28,7 +28,8 @@ hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
                              const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
-hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);
+hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);        // one thread per block
+hipError_t mkp_launch_inflate_wave(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);   // one wave per block
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
                                   uint32_t, int32_t, int32_t, uint32_t* /*error bits*/);
@@ -140,6 +141,15 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
   if (best > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
   if (best > max_depth) throw Error(MKP_E_UNSUPPORTED,
       "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
+}
+
+// BGZF inflate on the device.  Two kernels: one wave per block (mkp_inflate_wave.hip: ~4 ms for any launch of up to 1 024 blocks —
+// what a shard window needs) and one thread per block (mkp_inflate.hip: ~100 ms per launch whatever its size, but 2.4x the throughput
+// once a launch has tens of thousands of blocks — a whole file).  MKP_INFLATE_KERNEL=wave|thread forces one (A/B runs).
+static hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
+  static const char* force = getenv("MKP_INFLATE_KERNEL");
+  const bool per_thread = force ? !strcmp(force, "thread") : n >= 24576u;
+  return per_thread ? mkp_launch_inflate(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
 }
 
 // derive tile geometry, tile read ranges and the run parameters; upload everything
@@ -852,7 +862,7 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
     if (!blks.empty()) hip_check(hipMemcpyAsync(c->d_zblk.p, blks.data(), blks.size() * sizeof(Blk), hipMemcpyHostToDevice, c->stream), "H2D");
     hip_check(hipMemsetAsync(c->d_zstat.p, 0xff, std::max<size_t>(blks.size(), 1) * 4, c->stream), "memset");
     hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    hip_check(mkp_launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()),
+    hip_check(launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()),
         "inflate launch");
     hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     std::vector<uint32_t> st(blks.size());
@@ -910,7 +920,7 @@ bool mkp_internal_device_inflate(void* user, const InflateJob& j) {
     ok(hipMemcpyAsync(d->zin.p, pin, j.comp_len, hipMemcpyHostToDevice, d->stream));
     ok(hipMemcpyAsync(d->zblk.p, pin + j.comp_len, j.n_blks * sizeof(InflateBlk), hipMemcpyHostToDevice, d->stream));
     ok(hipMemsetAsync(d->zstat.p, 0xff, j.n_blks * 4, d->stream));
-    ok(mkp_launch_inflate(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)j.n_blks, d->zout.as<uint8_t>(), d->zstat.as<uint32_t>()));
+    ok(launch_inflate(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)j.n_blks, d->zout.as<uint8_t>(), d->zstat.as<uint32_t>()));
     uint8_t* pout = (uint8_t*)d->pin_out.p;
     ok(hipMemcpyAsync(pout, d->zout.p, j.dtotal, hipMemcpyDeviceToHost, d->stream));
     ok(hipMemcpyAsync(pout + j.dtotal, d->zstat.p, j.n_blks * 4, hipMemcpyDeviceToHost, d->stream));

@@ -69,3 +69,22 @@ def test_device_inflate_on_the_fetch_path(tmp_path):
         outs.append((open(out, "rb").read(), int(re.search(r"on the device (\d+)", p.stderr).group(1)), int(re.search(r"bam_bytes_inflated=(\d+)", p.stderr).group(1))))
     assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 100000
     assert outs[0][1] == 0 and outs[1][1] > 0.5 * outs[1][2] and outs[1][1] > 32 << 20   # (the threshold sampler's 2 MiB heads stay on the host)
+
+
+def test_both_device_kernels(tmp_path):
+    """mkp_bgzf_inflate picks its kernel by launch size (one wave per block below 24 576 blocks, one thread per block above); both are
+    forced here through MKP_INFLATE_KERNEL in fresh processes (the variable is read once) and checked against gzip."""
+    import subprocess
+    import sys
+    script = (
+        "import glob, gzip, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import modkit_amd\n"
+        "c = modkit_amd.Context()\n"
+        "n = 0\n"
+        "for b in sorted(glob.glob(os.path.join(%r, '*.bam'))):\n"
+        "    d = open(b, 'rb').read(); got, _ = c.bgzf_inflate(d); assert got == gzip.decompress(d), b; n += 1\n"
+        "c.close(); print('ok', n)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), FIX)
+    for kernel in ("wave", "thread"):
+        p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, MKP_INFLATE_KERNEL=kernel))
+        assert p.returncode == 0 and p.stdout.startswith("ok"), (kernel, p.stderr[-400:])
