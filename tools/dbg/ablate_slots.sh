@@ -1,6 +1,6 @@
 #!/bin/bash
 # ablations of mkp_decode_slots* (debug build, MKP_DEBUG_SKIP: 64 no CIGAR mapping, 128 no calls, 256 no sweep/calls, 512 no slot loop) + SQ counters
-cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r3d; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT; OUT=gpurun_out/ablate_slots; mkdir -p $OUT
 export MKP_SLOT_VARIANT=2
 export MKP_LIB_PATH=$GRAFT_REPO_ROOT/tools/dbg/lib/libmkpileup_debug.so
 for K in 0 64 128 192 256 512 768; do

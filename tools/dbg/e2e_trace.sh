@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-to-end C3 run of the CLI with the plan/run traces on: where does the host second go?  INF="own zlib" A/Bs the host inflate.
-cd $GRAFT_REPO_ROOT; OUT=gpurun_out/r3j; mkdir -p $OUT
+cd $GRAFT_REPO_ROOT; OUT=gpurun_out/e2e_trace; mkdir -p $OUT
 P=/tmp/mkp_c3_L64444167_N193000_x1_seed20
 tools/gen_modbam --out $P --reads 193000 --seed 20 --threads 16 $GEN --contig chr20:64444167 > /dev/null
 for I in ${INF:-own}; do for T in ${POOLS:-0}; do for i in 1 2 3; do
