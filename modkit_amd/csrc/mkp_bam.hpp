@@ -426,6 +426,7 @@ class BamSource {
       // an index without htslib's per-reference counts (metadata pseudo-bins) cannot drive the sampling schedule: load the file instead
       bool complete = s->bai_.has_no_coor; for (auto& R : s->bai_.refs) if (!R.has_counts && !R.bins.empty()) complete = false;
       if (!complete) { close(s->fd_); s->fd_ = -1; s->ref_names.clear(); s->ref_lens.clear(); s->bai_ = BaiIndex(); }
+      else { uint64_t n = s->bai_.no_coor; for (auto& R : s->bai_.refs) n += R.mapped + R.unmapped; if (n) s->avg_rec_bytes_ = (double)s->fsize_ / (double)n; }
     }
     if (s->fd_ < 0) {
       s->resident_ = load_bam(path, s->threads_); s->ref_names = s->resident_.ref_names; s->ref_lens = s->resident_.ref_lens;
@@ -492,6 +493,7 @@ class BamSource {
 
  private:
   std::string path_; unsigned threads_ = 1; int fd_ = -1; uint64_t fsize_ = 0, first_record_voff_ = 0; BaiIndex bai_; BamData resident_;
+  double avg_rec_bytes_ = 0;   // compressed bytes per record over the whole file (indexed source: the index's counts)
 
   void pread_all(uint64_t off, uint8_t* dst, size_t n) const {
     size_t got = 0; while (got < n) { const ssize_t r = ::pread(fd_, dst + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; }
@@ -566,7 +568,10 @@ class BamSource {
       uint64_t cb = chunks[ci].beg >> 16; const uint64_t ce = chunks[ci].end >> 16, ue = chunks[ci].end & 0xffff; uint32_t ub = (uint32_t)(chunks[ci].beg & 0xffff);
       // a bounded window of compressed bytes at a time (a chunk may be the whole contig): 64 MiB, or — when the caller wants only
       // the first records of the region — 4 MiB growing to that
-      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : (2u << 20);   // (heads: ~2 MiB hold the few hundred records the sampler asks for)
+      // (heads: sized from the file's mean compressed record — index counts over file size — plus slack for the records of the first
+      // chunk that end before the region; a fixed 2 MiB start was short for 10 kb reads and its doubling then inflated 2.4x what was needed)
+      uint64_t window = max_records == SIZE_MAX ? (64u << 20) : avg_rec_bytes_ > 0
+          ? std::min<uint64_t>(64u << 20, std::max<uint64_t>(256u << 10, (uint64_t)((double)max_records * avg_rec_bytes_ * 1.2) + (192u << 10))) : (2u << 20);
       while (cb < fsize_ && (cb < ce || (cb == ce && ue > 0)) && !stop) {
         const uint64_t want_end = std::min<uint64_t>(fsize_, std::min<uint64_t>(ce + (1u << 16) + 64, cb + window));
         const bool window_at_max = window >= (64u << 20) || want_end < cb + window;   // this window cannot be made larger
