@@ -674,7 +674,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask}) b->release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -995,8 +995,16 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
     upload(c->d_layouts, c->tables.dev);
     { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class, false); upload(c->d_read_ids, ids); }
-    if (bedmask) { c->d_focus.ensure((size_t)(win_end - win_start)); hip_check(hipMemcpy(c->d_focus.p, bedmask, (size_t)(win_end - win_start), hipMemcpyHostToDevice),
-        "H2D"); } else c->d_focus.ensure(16);
+    // the --include-bed mask of the contig: one upload per contig and sampling session, not per round (a 25 MB mask per round was most of
+    // the 11.6 s a BED-filtered threshold estimate took on the C5 scale model); mkp_internal_bedmask_reset() starts a session
+    const uint8_t* d_mask;
+    if (bedmask) {
+      const size_t len = (size_t)(win_end - win_start);
+      if (bedmask != c->bedmask_src || len != c->bedmask_len) {
+        c->d_bedmask.ensure(len); hip_check(hipMemcpy(c->d_bedmask.p, bedmask, len, hipMemcpyHostToDevice), "H2D"); c->bedmask_src = bedmask; c->bedmask_len = len;
+      }
+      d_mask = c->d_bedmask.as<uint8_t>();
+    } else { c->d_focus.ensure(16); d_mask = c->d_focus.as<uint8_t>(); }
     const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
     c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
         c->d_misc.ensure(64);
@@ -1004,7 +1012,7 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
         c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
-                                c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), c->d_vals.as<float>()), "decode(sample) launch");
+                                c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, d_mask, c->d_vals.as<float>()), "decode(sample) launch");
     uint32_t h[4]; hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     c->sample_ro.resize(S.hdr.size());
     if (!S.hdr.empty()) hip_check(hipMemcpyAsync(c->sample_ro.data(), c->d_readout.p, S.hdr.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost, c->stream), "D2H");
@@ -1016,6 +1024,8 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
     c->resident = false;
   });
 }
+
+void mkp_internal_bedmask_reset(mkp_ctx* c) { if (c) { c->bedmask_src = nullptr; c->bedmask_len = 0; } }
 
 int mkp_internal_set_extract(mkp_ctx* c, bool on) {
   if (!c) return MKP_E_INVALID;

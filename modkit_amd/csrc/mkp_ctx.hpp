@@ -57,6 +57,7 @@ struct mkp_ctx {
   bool hemi = false, resident_hemi = false; int32_t hemi_off = 0; std::vector<uint32_t> hemi_iv; mkp::DevBuf d_hemi_iv;
   uint32_t hemi_codes[4][MKP_KMAX + 2] = {}; std::vector<uint8_t> h_hemi_base; std::vector<uint32_t> h_hemi_pat[2];
   mkp::DevBuf d_zin, d_zout, d_zblk, d_zstat; std::vector<uint8_t> h_inflated;   // mkp_bgzf_inflate
+  mkp::DevBuf d_bedmask; const uint8_t* bedmask_src = nullptr; size_t bedmask_len = 0;   // sampling: the contig's --include-bed mask last uploaded (host pointer + length identify it within a session)
   // `modkit summary` (mkp_summary): sampling rounds count calls instead of storing probabilities; device table [4][2][16] + reads_with[6] (u64)
   bool extract_mode = false;   // `extract calls`: the sampling kernels emit one record per call (forward position, classes, call_prob)
   bool summary_mode = false; mkp::DevBuf d_summary; std::vector<uint8_t> h_sum_base; std::vector<uint32_t> h_sum_code; std::vector<uint64_t> h_sum_pass, h_sum_fail;
@@ -68,6 +69,7 @@ struct mkp_ctx {
 int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,
                         uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals);
 int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take);
+void mkp_internal_bedmask_reset(mkp_ctx* c);   // a new sampling session: host mask pointers of the last one mean nothing any more
 // summary mode: zero the device table / read it back (134 u64: table[4][2][16] then reads_with[6])
 int mkp_internal_summary_begin(mkp_ctx* c);
 // `extract calls`: switch the sampling kernels to per-call records (and the caller tables to read-base thresholds); fetch the records of the

@@ -95,6 +95,8 @@ SampleTimes g_sample_times;   // --stats: where the threshold estimate's time we
 void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
+  mkp_internal_bedmask_reset(ctx);
+  struct MaskSession { mkp_ctx* c; ~MaskSession() { mkp_internal_bedmask_reset(c); } } mask_session{ctx};   // the host masks below die with this call
   if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED,
       "rank-sharded threshold sampling needs the full-data mode (-f 1.0): the count-based schedule carries quotas from interval to interval");
   IdxStats st = idxstats(bam, region, bf);
