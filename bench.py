@@ -368,7 +368,9 @@ def main():
         # ---- N ranks, ONE BAM: thresholds from the all-reduced histograms, every rank runs its contiguous run of the interval grid
         from modkit_amd import distributed as mkd
         shard_stats = {}
-        flags = flags + ["--shard-bp", str(1 << 27)]   # one shard per contig piece a rank owns (the default cuts 8 pieces per rank to balance small files)
+        # one shard per contig piece a rank owns, as the single-GPU line's one resident shard: the default cuts 8 pieces per rank (balance
+        # for small files) and 256 MiB of BAM per shard (host memory), which only adds launch and tile-edge overhead to a resident re-run
+        flags = flags + ["--shard-bp", str(1 << 27), "--shard-bytes", str(1 << 40)]
         thr = mkd.pileup_sharded([bam, out_bed] + flags, rank=rank, world=world, device=local_rank, stats=shard_stats)
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
         # the rank's windows, each resident in HBM on its own context (a window = a piece of one contig; cuts sit on the interval grid)
