@@ -120,15 +120,20 @@ struct Motif {
   bool neg_delta(int* d) const { if (!palindrome) return false; *d = (int)rev_off - (int)fwd_off; return true; }  // MotifInfo::negative_strand_position
 };
 
-static inline uint8_t base_bit(char c) { switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8; default: return 0; } }
+// base -> bit (A1 C2 G4 T8), by table: [0] upper case only (--mask-reference: soft-masked bases never match), [1] either case (the
+// reference upper-cases the sequence first, fasta.rs; reading through this table saves a copy of every contig)
+struct BaseBits { uint8_t t[2][256]; BaseBits() { memset(t, 0, sizeof(t)); const char* b = "ACGT"; for (int i = 0; i < 4; i++) { t[0][(uint8_t)b[i]] = t[1][(uint8_t)b[i]] = (uint8_t)(1 << i); t[1][(uint8_t)(b[i] | 0x20)] = (uint8_t)(1 << i); } } };
+static inline const uint8_t* base_bits(bool any_case) { static const BaseBits B; return B.t[any_case ? 1 : 0]; }
+static inline uint8_t base_bit(char c) { return base_bits(false)[(uint8_t)c]; }
 
 // find_motif_hits (motif_bed.rs:288-337) folded straight into a position -> rule map relative to `off`
-static inline void motif_hits(const char* seq, size_t n, const Motif& m, uint64_t off, uint32_t tid, const BedFilter* bf, std::map<uint32_t, Rule>* out) {
+static inline void motif_hits(const char* seq, size_t n, const Motif& m, uint64_t off, uint32_t tid, const BedFilter* bf, std::map<uint32_t, Rule>* out, bool any_case = false) {
+  const uint8_t* bb = base_bits(any_case);
   auto add = [&](size_t p, bool neg) { uint64_t g = off + p; if (bf && !bf->contains(tid, g, neg)) return; auto it = out->find((uint32_t)g); if (it != out->end()) it->second = rule_absorb(it->second, neg); else (*out)[(uint32_t)g] = neg ? R_NEG : R_POS; };
   size_t L = m.len();
-  auto match = [&](const std::vector<uint8_t>& cls, size_t i) { for (size_t j = 0; j < L; j++) if (!(cls[j] & base_bit(seq[i + j]))) return false; return true; };
+  auto match = [&](const std::vector<uint8_t>& cls, size_t i) { for (size_t j = 0; j < L; j++) if (!(cls[j] & bb[(uint8_t)seq[i + j]])) return false; return true; };
   if (m.palindrome) { for (size_t i = 0; i + L <= n; i++) if (match(m.fwd, i)) { add(i + m.fwd_off, false); add(i + m.rev_off, true); } }
-  else if (L == 1) { char fw = m.raw[0], rv = fw == 'A' ? 'T' : fw == 'C' ? 'G' : fw == 'G' ? 'C' : 'A'; for (size_t i = 0; i < n; i++) { if (seq[i] == fw) add(i, false); else if (seq[i] == rv) add(i, true); } }
+  else if (L == 1) { const uint8_t fw = bb[(uint8_t)m.raw[0]], rv = (uint8_t)(fw == 1 ? 8 : fw == 2 ? 4 : fw == 4 ? 2 : 1); for (size_t i = 0; i < n; i++) { const uint8_t x = bb[(uint8_t)seq[i]]; if (x == fw) add(i, false); else if (x == rv) add(i, true); } }
   else { for (size_t i = 0; i + L <= n; i++) { if (match(m.fwd, i)) add(i + m.fwd_off, false); if (match(m.rev, i)) add(i + m.rev_off, true); } }
 }
 
@@ -139,7 +144,8 @@ class FocusBuilder {
  public:
   const Fasta* fasta = nullptr; bool mask = false; std::vector<Motif> motifs; const BedFilter* bed = nullptr; bool combine = false;
   std::vector<mkp_motif_combo> combos;  // [0] = none
-  FocusBuilder() { mkp_motif_combo z; memset(&z, 0, sizeof(z)); combos.push_back(z); }
+  bool fast_single = true;   // one motif: fill_single instead of motif_hits + fill_motif (tests switch it off to compare the two)
+  FocusBuilder() { mkp_motif_combo z; memset(&z, 0, sizeof(z)); combos.push_back(z); if (getenv("MKP_FOCUS_MAPS")) fast_single = false; /* A/B timing */ }
   bool has_focus() const { return !motifs.empty() || bed != nullptr; }
 
   // Interval list of one contig record, in feeder order; fills `focus` (size end-start of the record,
@@ -148,16 +154,12 @@ class FocusBuilder {
     std::vector<Interval> ivs;
     if (interval_size == 0) throw Error(MKP_E_INVALID, "interval size must be positive");
     if (focus) focus->assign(rec.length, 0);
-    const std::string* seq = nullptr; std::string upper;
+    const std::string* seq = nullptr;
+    const bool any_case = !mask;   // without --mask-reference the reference upper-cases the contig: read it through the either-case table instead of copying it
     if (!motifs.empty()) {
       seq = fasta->get(rec.name);
       if (!seq) throw Error(MKP_E_IO, "contig " + rec.name + " missing from reference FASTA");
       if (rec.end() > seq->size()) throw Error(MKP_E_IO, "contig " + rec.name + " shorter in FASTA than in the BAM header");
-      if (!mask) {
-        upper.resize(rec.end());
-        parallel_ranges(rec.start, rec.end(), 1u << 22, [&](uint64_t a, uint64_t b) { for (uint64_t i = a; i < b; i++) upper[i] = (char)toupper((unsigned char)(*seq)[i]); });
-        seq = &upper;
-      }
     }
     size_t longest = 0; for (auto& m : motifs) longest = std::max(longest, m.len());
     if (!motifs.empty()) {
@@ -175,7 +177,7 @@ class FocusBuilder {
             if (end_w > seq->size()) throw Error(MKP_E_UNSUPPORTED, "motif run reaches past the contig end while extending an interval (the reference never terminates here)");
             const uint64_t from = std::max<uint64_t>(pos, e > 2 * longest + 2 ? e - 2 * longest - 2 : 0);
             for (auto& l : locs) l.clear();
-            for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + from, (size_t)(end_w - from), motifs[i], (uint32_t)from, rec.tid, bed, &locs[i]);
+            for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + from, (size_t)(end_w - from), motifs[i], (uint32_t)from, rec.tid, bed, &locs[i], any_case);
             std::vector<Span> sp;
             for (size_t i = 0; i < motifs.size(); i++) { uint64_t adj = motifs[i].len() >= motifs[i].fwd_off ? motifs[i].len() - motifs[i].fwd_off : motifs[i].len(); for (auto& kv : locs[i]) sp.push_back({kv.first, kv.first + adj}); }
             merge_spans(sp);
@@ -203,10 +205,12 @@ class FocusBuilder {
           for (uint64_t b = b0; b < b1; b++) {
             FocusBuilder& L = local[b]; L.fasta = fasta; L.mask = mask; L.motifs = motifs; L.bed = bed; L.combine = comb;
             try {
+              std::vector<uint8_t> scratch;
               for (size_t k = b * per_block; k < std::min(ivs.size(), (b + 1) * per_block); k++) {
-                std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
                 const uint64_t slice_end = comb ? std::min<uint64_t>((uint64_t)ivs[k].end + longest, rec.end()) : ivs[k].end;
-                for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + ivs[k].start, (size_t)(slice_end - ivs[k].start), motifs[i], ivs[k].start, rec.tid, bed, &locs[i]);
+                if (motifs.size() == 1 && fast_single) { L.fill_single(seq->data(), rec, ivs[k].start, ivs[k].end, slice_end, focus, scratch, any_case); continue; }
+                std::vector<std::map<uint32_t, Rule>> locs(motifs.size());
+                for (size_t i = 0; i < motifs.size(); i++) motif_hits(seq->data() + ivs[k].start, (size_t)(slice_end - ivs[k].start), motifs[i], ivs[k].start, rec.tid, bed, &locs[i], any_case);
                 L.fill_motif(locs, rec, ivs[k].start, ivs[k].end, focus);
               }
             } catch (const Error& e) { errs[b].reset(new Error(e)); }
@@ -246,6 +250,38 @@ class FocusBuilder {
     for (size_t i = 1; i < combos.size(); i++) if (memcmp(&combos[i], &c, sizeof(c)) == 0) return (uint8_t)i;
     if (combos.size() >= 64) throw Error(MKP_E_UNSUPPORTED, "more than 63 distinct motif-id combinations");
     combos.push_back(c); return (uint8_t)(combos.size() - 1);
+  }
+  // One motif (the usual run: --cpg, one --motif): the focus bytes of interval [start, end) from the slice [start, slice_end) of `seq`
+  // (whole contig, offset 0) without the per-hit maps below — a rule-bit array over the slice, then one ascending pass.  Same hits as
+  // motif_hits (a match must lie inside the slice: the boundary-CpG loss of the reference's per-interval search, SURVEY hazard 3), same
+  // combos in the same first-appearance order as fill_motif (positions ascending), hence the same bytes; walk() falls back to the maps
+  // for several motifs.  A 3 Gb genome's --cpg focus bytes took 13 s of std::map work on 16 cores.
+  void fill_single(const char* seq, const Contig& rec, uint32_t start, uint32_t end, uint64_t slice_end, std::vector<uint8_t>* focus, std::vector<uint8_t>& rule, bool any_case) {
+    const Motif& m = motifs[0]; const size_t L = m.len(), n = (size_t)(slice_end - start); const char* s = seq + start; const uint8_t* bb = base_bits(any_case);
+    rule.assign(n, 0);
+    auto add = [&](size_t p, bool neg) { if (bed && !bed->contains(rec.tid, (uint64_t)start + p, neg)) return; rule[p] |= neg ? (uint8_t)R_NEG : (uint8_t)R_POS; };
+    const uint8_t* f0 = m.fwd.data(); const uint8_t* r0 = m.rev.data();
+    auto match = [&](const uint8_t* cls, size_t i) { for (size_t j = 0; j < L; j++) if (!(cls[j] & bb[(uint8_t)s[i + j]])) return false; return true; };
+    if (m.palindrome) { for (size_t i = 0; i + L <= n; i++) if (match(f0, i)) { add(i + m.fwd_off, false); add(i + m.rev_off, true); } }
+    else if (L == 1) { const uint8_t fw = bb[(uint8_t)m.raw[0]], rv = (uint8_t)(fw == 1 ? 8 : fw == 2 ? 4 : fw == 4 ? 2 : 1); for (size_t i = 0; i < n; i++) { const uint8_t x = bb[(uint8_t)s[i]]; if (x == fw) add(i, false); else if (x == rv) add(i, true); } }
+    else { for (size_t i = 0; i + L <= n; i++) { if (match(f0, i)) add(i + m.fwd_off, false); if (match(r0, i)) add(i + m.rev_off, true); } }
+    int d = 0; const bool has_d = m.neg_delta(&d);
+    const size_t upto = std::min<size_t>(n, (size_t)(end - start));
+    for (size_t p = 0; p < upto; p++) {
+      const uint8_t r = rule[p]; if (!r) continue;
+      mkp_motif_combo c; memset(&c, 0, sizeof(c)); for (auto& x : c.pos_delta) x = -128;
+      if (combine) {   // FocusPositions::new_motif_combine_strands: a '+' (or both-strand) hit carries the offset of its '-' mate, see fill_motif
+        if (r == R_POS || r == R_BOTH) {
+          int8_t dd = -128;
+          if (has_d) { const int64_t q = (int64_t)start + (int64_t)p + d; dd = (q < 0) ? (int8_t)-128 : (q >= (int64_t)start && q < (int64_t)end) ? (int8_t)d : (int8_t)-127; }
+          c.pos_ids[0] = 0; c.pos_delta[0] = dd; c.n_pos = 1;
+        } else { c.neg_ids[0] = 0; c.n_neg = 1; }
+      } else {
+        if (r & R_POS) { c.pos_ids[0] = 0; c.n_pos = 1; }
+        if (r & R_NEG) { c.neg_ids[0] = 0; c.n_neg = 1; }
+      }
+      (*focus)[(size_t)start + p - rec.start] = (uint8_t)(r | (combo_id(c) << 2));
+    }
   }
   void fill_motif(const std::vector<std::map<uint32_t, Rule>>& locs, const Contig& rec, uint32_t start, uint32_t end, std::vector<uint8_t>* focus) {
     if (motifs.size() > MKP_MAX_MOTIF_IDS) throw Error(MKP_E_UNSUPPORTED, "more than 4 motifs");

@@ -151,3 +151,76 @@ def test_combine_strands_walk_matches_interval_by_interval_walk(tmp_path):
                            "-o", str(exe), str(src), "-lz", "-pthread"])
     p = subprocess.run([str(exe)], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip().startswith("ok"), p.stdout + p.stderr
+
+
+FAST_SRC = r"""
+#include <cstdio>
+#include <random>
+#include "mkp_focus.hpp"
+using namespace mkp;
+// FocusBuilder::walk with the one-motif fast path (fill_single) against the same walk through motif_hits + fill_motif: focus bytes, grid
+// and combo tables must be identical for every motif shape (palindromic, IUPAC, single base, off-centre focus), with and without strand
+// combining and a BED filter, at interval sizes that cut through motif runs.
+int main() {
+  std::mt19937_64 rng(29); int bad = 0, cases = 0;
+  const char* specs[][2] = {{"CG", "0"}, {"GATC", "1"}, {"CHH", "0"}, {"C", "0"}, {"CCWGG", "1"}, {"A", "0"}, {"GC", "1"}, {"CGCG", "2"}, {"DRACH", "2"}};
+  for (int it = 0; it < 40; it++) {
+    uint32_t L = 1500 + rng() % 20000; std::string seq(L, 'A');
+    for (uint32_t i = 0; i < L; i++) seq[i] = "ACGT"[rng() & 3];
+    if (it % 3) for (int k = 0; k < 30; k++) { uint32_t p = rng() % (L - 200), n = 2 + rng() % 90; for (uint32_t j = 0; j < n && p + j < L; j++) seq[p + j] = (it % 3 == 2 ? "GATC"[j & 3] : "CG"[j & 1]); }
+    if (it % 4 == 1) for (int k = 0; k < 20; k++) seq[rng() % L] = 'N';
+    Fasta fa; fa.seqs["c"] = seq;
+    BedFilter bf; { std::vector<Span> p, n; for (int k = 0; k < 25; k++) { uint64_t a = rng() % L, b = a + 1 + rng() % 400; (k & 1 ? p : n).push_back({a, b}); if (k % 5 == 0) { p.push_back({a, b}); n.push_back({a, b}); } }
+      merge_spans(p); merge_spans(n); bf.pos[0] = p; bf.neg[0] = n; }
+    for (auto& sp : specs) for (int comb = 0; comb < 2; comb++) for (int with_bed = 0; with_bed < 2; with_bed++) for (uint32_t isz : {37u, 100u, 501u, 4096u, 100000u}) {
+      Motif m = Motif::parse(sp[0], (size_t)atoi(sp[1]));
+      if (comb && !m.palindrome) continue;   // --combine-strands needs a palindromic motif
+      FocusBuilder a, b;
+      for (FocusBuilder* f : {&a, &b}) { f->fasta = &fa; f->combine = comb; f->mask = true; f->motifs.push_back(m); f->bed = with_bed ? &bf : nullptr; }
+      b.fast_single = false;
+      Contig rec; rec.tid = 0; rec.name = "c"; rec.start = (it % 5 == 0) ? 123 : 0; rec.length = L - rec.start - ((it % 7 == 0) ? 57 : 0);
+      std::vector<uint8_t> xa, xb; std::vector<Interval> ia, ib; bool ea = false, eb = false;
+      try { ia = a.walk(rec, isz, &xa); } catch (const Error&) { ea = true; }
+      try { ib = b.walk(rec, isz, &xb); } catch (const Error&) { eb = true; }
+      cases++;
+      bool same = ea == eb;
+      if (same && !ea) {
+        same = ia.size() == ib.size() && xa == xb && a.combos.size() == b.combos.size();
+        for (size_t k = 0; same && k < ia.size(); k++) same = ia[k].start == ib[k].start && ia[k].end == ib[k].end;
+        for (size_t k = 0; same && k < a.combos.size(); k++) same = memcmp(&a.combos[k], &b.combos[k], sizeof(mkp_motif_combo)) == 0;
+      }
+      if (!same) { bad++; if (bad < 6) printf("MISMATCH it=%d motif=%s comb=%d bed=%d isz=%u errs=%d/%d\n", it, sp[0], comb, with_bed, isz, ea, eb); }
+    }
+  }
+  // soft-masked (lower-case) reference: without --mask-reference the contig counts as upper-cased, with it lower-case bases never match
+  for (int it = 0; it < 12; it++) {
+    uint32_t L = 3000 + rng() % 9000; std::string mixed(L, 'A');
+    for (uint32_t i = 0; i < L; i++) mixed[i] = "ACGTacgt"[rng() & 7];
+    std::string upper = mixed, masked = mixed;
+    for (auto& ch : upper) ch = (char)toupper((unsigned char)ch);
+    for (auto& ch : masked) if (ch >= 'a' && ch <= 'z') ch = 'N';
+    for (auto& sp : specs) for (int nm = 1; nm <= 2; nm++) for (int mk = 0; mk < 2; mk++) {
+      Fasta f1, f2; f1.seqs["c"] = mixed; f2.seqs["c"] = mk ? masked : upper;
+      FocusBuilder a, b;
+      a.fasta = &f1; b.fasta = &f2; a.mask = mk; b.mask = true;
+      for (FocusBuilder* f : {&a, &b}) { f->motifs.push_back(Motif::parse(sp[0], (size_t)atoi(sp[1]))); if (nm == 2) f->motifs.push_back(Motif::parse("CG", 0)); f->combine = false; }
+      Contig rec; rec.tid = 0; rec.name = "c"; rec.start = 0; rec.length = L;
+      std::vector<uint8_t> xa, xb; a.walk(rec, 777, &xa); b.walk(rec, 777, &xb);
+      cases++;
+      if (xa != xb) { bad++; if (bad < 6) printf("CASE MISMATCH it=%d motif=%s motifs=%d mask=%d\n", it, sp[0], nm, mk); }
+    }
+  }
+  printf(bad ? "FAILED %d of %d\n" : "ok %d\n", bad ? bad : cases, cases);
+  return bad != 0;
+}
+"""
+
+
+def test_single_motif_fast_path_equals_the_map_path(tmp_path):
+    src = tmp_path / "fast.cpp"
+    src.write_text(FAST_SRC)
+    exe = tmp_path / "fast"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           "-o", str(exe), str(src), "-lz", "-pthread"])
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip().startswith("ok"), p.stdout + p.stderr
