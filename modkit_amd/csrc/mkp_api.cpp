@@ -143,8 +143,8 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
       "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
 }
 
-// BGZF inflate on the device.  Two kernels: one wave per block (mkp_inflate_wave.hip: ~4 ms for any launch of up to 1 024 blocks —
-// what a shard window needs) and one thread per block (mkp_inflate.hip: ~100 ms per launch whatever its size, but 2.4x the throughput
+// BGZF inflate on the device.  Two kernels: one wave per block (mkp_inflate_wave.hip: ~4 ms per block, 1 024 at a time — a shard
+// window of 5 000 blocks in 26 ms) and one thread per block (mkp_inflate.hip: ~100 ms per launch whatever its size, but 2.4x the throughput
 // once a launch has tens of thousands of blocks — a whole file).  MKP_INFLATE_KERNEL=wave|thread forces one (A/B runs).
 static hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
   static const char* force = getenv("MKP_INFLATE_KERNEL");
