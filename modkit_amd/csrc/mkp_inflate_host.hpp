@@ -22,7 +22,10 @@ constexpr uint32_t LIT_CAP = 4096, DIST_CAP = 1024;
 
 struct Tables { uint32_t lit[LIT_CAP]; uint32_t dist[DIST_CAP]; };
 
-static inline uint32_t rev_bits(uint32_t c, int n) { uint32_t r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (c & 1u); c >>= 1; } return r; }
+static inline uint32_t rev_bits(uint32_t c, int n) {   // the low n (<= 16) bits of c, reversed
+  c = ((c & 0x5555u) << 1) | ((c >> 1) & 0x5555u); c = ((c & 0x3333u) << 2) | ((c >> 2) & 0x3333u); c = ((c & 0x0f0fu) << 4) | ((c >> 4) & 0x0f0fu);
+  return (((c & 0xffu) << 8) | ((c >> 8) & 0xffu)) >> (16 - n);
+}
 
 // Canonical code of `n` symbols with lengths lens[] (0 = unused) into a two-level table; sym_entry(s) gives the entry without its
 // code_bits.  Returns false for an over-subscribed code, an incomplete literal/length code, or a table that does not fit.
@@ -47,10 +50,11 @@ static inline bool build_table(const uint8_t* lens, int n, int root, uint32_t* t
   for (int s = 0; s < n; s++) if (lens[s]) codes[s] = rev_bits(next_code[lens[s]]++, lens[s]);
   uint32_t used = root_size;
   if (any_long) {
+    uint16_t prefixes[320]; int n_prefixes = 0;   // first-level slots that lead to a second-level table (at most one per long code)
     memset(submax, 0, root_size);
-    for (int s = 0; s < n; s++) if (lens[s] > root) { const uint32_t p = codes[s] & (root_size - 1); if (lens[s] > submax[p]) submax[p] = lens[s]; }
-    for (uint32_t p = 0; p < root_size; p++) if (submax[p]) {
-      const uint32_t sb = (uint32_t)submax[p] - (uint32_t)root;
+    for (int s = 0; s < n; s++) if (lens[s] > root) { const uint32_t p = codes[s] & (root_size - 1); if (!submax[p]) prefixes[n_prefixes++] = (uint16_t)p; if (lens[s] > submax[p]) submax[p] = lens[s]; }
+    for (int k = 0; k < n_prefixes; k++) {
+      const uint32_t p = prefixes[k], sb = (uint32_t)submax[p] - (uint32_t)root;
       if (used + (1u << sb) > cap) return false;
       tab[p] = F_SUB | (used << 12) | (sb << 8) | (uint32_t)root;
       used += 1u << sb;
@@ -71,18 +75,18 @@ static inline bool build_table(const uint8_t* lens, int n, int root, uint32_t* t
   return true;
 }
 
-// first-level literal slots whose remaining index bits determine a second literal become pair entries
+// first-level literal slots whose remaining index bits determine a second literal become pair entries.  Slot i of a literal with an
+// l1-bit code is code | k << l1; the second symbol is whatever slot k (zero-extended) decodes, when its code fits the 11 - l1 bits k has.
 static inline void pair_literals(uint32_t* tab) {
   constexpr uint32_t N = 1u << LIT_BITS;
-  for (uint32_t i = N; i-- > 0;) {   // descending: slot i >> l1 (< i) is still a single literal when slot i looks at it
-    const uint32_t e = tab[i];
+  uint32_t orig[N]; memcpy(orig, tab, sizeof(orig));
+  for (uint32_t i = 0; i < N; i++) {
+    const uint32_t e = orig[i];
     if (!(e & F_LIT)) continue;
     const uint32_t l1 = e & 0xffu; if (l1 >= (uint32_t)LIT_BITS) continue;
-    const uint32_t e2 = tab[i >> l1];   // the index bits after the first code, zero-extended: right whenever the second code fits in them
-    if (!(e2 & F_LIT)) continue;
-    const uint32_t l2 = e2 & 0xffu;
-    if (l1 + l2 > (uint32_t)LIT_BITS) continue;
-    tab[i] = F_LIT | F_LIT2 | (((e >> 12) & 0xffu) << 12) | (((e2 >> 12) & 0xffu) << 20) | (l1 + l2);
+    const uint32_t e2 = orig[i >> l1];
+    if (!(e2 & F_LIT) || l1 + (e2 & 0xffu) > (uint32_t)LIT_BITS) continue;
+    tab[i] = F_LIT | F_LIT2 | (((e >> 12) & 0xffu) << 12) | (((e2 >> 12) & 0xffu) << 20) | (l1 + (e2 & 0xffu));
   }
 }
 
