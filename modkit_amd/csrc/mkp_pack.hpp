@@ -292,6 +292,29 @@ class Packer {
     return nullptr;
   }
 
+  // The same answers as aux_find for several tags from ONE walk over the aux block (the MM string of a 10 kb read is a kilobyte that
+  // five separate lookups each stepped through byte by byte): out[k] = first occurrence of tags[k] reached before any malformed
+  // field, else null — exactly what aux_find returns for each of them.
+  static void aux_find_all(const uint8_t* aux, size_t n, const char (*tags)[2], int n_tags, const uint8_t** out) {
+    for (int k = 0; k < n_tags; k++) out[k] = nullptr;
+    int missing = n_tags; size_t o = 0;
+    while (o + 3 <= n && missing) {
+      const char ty = (char)aux[o + 2]; const size_t v = o + 3; size_t len;
+      switch (ty) {
+        case 'A': case 'c': case 'C': len = 1; break;
+        case 's': case 'S': len = 2; break;
+        case 'i': case 'I': case 'f': len = 4; break;
+        case 'd': len = 8; break;
+        case 'Z': case 'H': { const void* z = v < n ? memchr(aux + v, 0, n - v) : nullptr; len = z ? (size_t)((const uint8_t*)z - (aux + v)) + 1 : n - v + 1; break; }   // (no terminator: runs past the end, malformed below)
+        case 'B': { if (v + 5 > n) return; const char st = (char)aux[v]; uint32_t c; memcpy(&c, aux + v + 1, 4); const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; len = 5 + es * (size_t)c; break; }
+        default: return;
+      }
+      if (v + len > n) return;
+      for (int k = 0; k < n_tags; k++) if (!out[k] && (char)aux[o] == tags[k][0] && (char)aux[o + 1] == tags[k][1]) { out[k] = aux + o + 2; missing--; }
+      o = v + len;
+    }
+  }
+
   // Appends one record.  Records the packer never needs (flag mask of the htslib pileup engine,
   // supplementary, empty SEQ — pileup/mod.rs:783-791 & BAM_DEF_MASK) must be filtered by the caller
   // with `keep()`.
@@ -342,13 +365,15 @@ class Packer {
 
   bool tokenise(const mkp_record& r, const uint8_t* aux, size_t aux_n, ShardHost& S, MkpReadHdr* h, uint64_t* cap) {
     // get_tag: new style wins, each looked up independently (util.rs:174-188)
-    const uint8_t* mm = aux_find(aux, aux_n, 'M', 'M'); if (!mm) mm = aux_find(aux, aux_n, 'M', 'm');
-    const uint8_t* mlp = aux_find(aux, aux_n, 'M', 'L'); if (!mlp) mlp = aux_find(aux, aux_n, 'M', 'l');
+    static const char want[5][2] = {{'M', 'M'}, {'M', 'm'}, {'M', 'L'}, {'M', 'l'}, {'M', 'N'}};
+    const uint8_t* at[5]; aux_find_all(aux, aux_n, want, 5, at);
+    const uint8_t* mm = at[0] ? at[0] : at[1];
+    const uint8_t* mlp = at[2] ? at[2] : at[3];
     if (!mm || !mlp) return false;
     if ((char)mm[0] != 'Z') return false;
     if (!((char)mlp[0] == 'B' && (char)mlp[1] == 'C')) return false;
     uint32_t ml_n; memcpy(&ml_n, mlp + 2, 4);
-    const uint8_t* mn = aux_find(aux, aux_n, 'M', 'N');
+    const uint8_t* mn = at[4];
     if (mn) {
       int64_t v;
       switch ((char)mn[0]) {
