@@ -139,3 +139,77 @@ EXTRACT_CALLS_CASES = [
     ("extract_calls_regression", ["--ref", "{ref}"], "2_reads_all_context.bam", "test_read_calls_estimate_thresh.tsv"),
     ("extract_supplementary_secondary_calls", ["--allow-non-primary"], "supplementary_and_secondary_read.bam", "test_supplementary_calls.tsv"),
 ]
+
+
+def convert_mod_code(src_bam, dst_bam, from_code, to_code):
+    """What `modkit adjust-mods --convert <from> <to>` writes for a record whose tags are `C+h?,d;C+m?,d;` (src/adjust.rs ->
+    format_mm_ml_tag, src/mod_bam.rs:1299-1387): one tag per code in ModCodeRepr order (letters by code point, then ChEBI numbers), each
+    with the same delta list, the ML blocks in tag order; probabilities survive the f32 round trip ((q + 0.5) / 256 -> q).  Only that
+    tag shape is handled (the fixture of tests/test_pileup.rs:373-444); anything else raises."""
+    import gzip
+    import struct
+    from bamfuzz import bgzf_write
+    d = gzip.open(src_bam).read()
+    o = 4
+    lt, = struct.unpack_from("<i", d, o); o += 4 + lt
+    nr, = struct.unpack_from("<i", d, o); o += 4
+    for _ in range(nr):
+        ln, = struct.unpack_from("<i", d, o); o += 4 + ln + 4
+    out = bytearray(d[:o])
+    width = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+    order = lambda code: (1, int(code)) if code.isdigit() else (0, ord(code))   # derive(Ord) on enum ModCodeRepr { Code(char), ChEbi(u32) }
+    while o < len(d):
+        bs, = struct.unpack_from("<i", d, o)
+        rec = d[o + 4:o + 4 + bs]; o += 4 + bs
+        lrn, ncig, lseq = rec[8], struct.unpack_from("<H", rec, 12)[0], struct.unpack_from("<i", rec, 16)[0]
+        a = 32 + lrn + 4 * ncig + (lseq + 1) // 2 + lseq
+        aux, keep, mm, ml, p = rec[a:], bytearray(), None, None, 0
+        while p < len(aux):
+            tag, ty, q = aux[p:p + 2], chr(aux[p + 2]), p + 3
+            if ty in width:
+                q += width[ty]
+            elif ty in "ZH":
+                q = aux.index(b"\0", q) + 1
+            elif ty == "B":
+                cnt, = struct.unpack_from("<i", aux, q + 1)
+                q += 5 + cnt * width[chr(aux[q])]
+            else:
+                raise ValueError("aux type " + ty)
+            if tag == b"MM":
+                mm = aux[p + 3:q - 1].decode()
+            elif tag == b"ML":
+                assert aux[p + 2:p + 4] == b"BC"
+                ml = aux[p + 8:q]
+            else:
+                keep += aux[p:q]
+            p = q
+        if mm is None:   # a record without tags stays as it is
+            out += struct.pack("<i", len(rec)) + rec
+            continue
+        tags, at = [], 0
+        for part in [x for x in mm.split(";") if x]:
+            head, _, rest = part.partition(",")
+            assert len(head) == 4 and head[:2] == "C+" and head[3] == "?", head
+            n = len(rest.split(",")) if rest else 0
+            code = to_code if head[2] == from_code else head[2]
+            tags.append((code, rest, ml[at:at + n])); at += n
+        assert at == len(ml) and len({t[0] for t in tags}) == len(tags)
+        tags.sort(key=lambda t: order(t[0]))
+        new_mm = "".join("C+%s?%s;" % (c, "," + r if r else "") for c, r, _ in tags)
+        new_ml = b"".join(bytes(m) for _, _, m in tags)
+        keep += b"MMZ" + new_mm.encode() + b"\0" + b"MLBC" + struct.pack("<I", len(new_ml)) + new_ml
+        body = rec[:a] + bytes(keep)
+        out += struct.pack("<i", len(body)) + body
+    bgzf_write(dst_bam, bytes(out))
+    return dst_bam
+
+
+def chebi_case_expected_rows(golden_path, to_code):
+    """tests/test_pileup.rs:373-444: the no-filter golden with `h` renamed, both sides sorted by (chrom, start, code) as the test does
+    (ModCodeRepr order: letters before ChEBI numbers)."""
+    key = lambda f: (f[0], int(f[1]), (1, int(f[3])) if f[3].isdigit() else (0, ord(f[3])))
+    rows = [l.split("\t") for l in open(golden_path).read().splitlines()]
+    for f in rows:
+        if f[3] == "h":
+            f[3] = to_code
+    return ["\t".join(f) for f in sorted(rows, key=key)], key

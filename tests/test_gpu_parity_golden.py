@@ -26,6 +26,23 @@ def test_pileup_old_tags(tmp_path):
     assert open(out).read() == open(fixture("pileup-old-tags-regressiontest.methyl.bed")).read()
 
 
+@pytest.mark.parametrize("to_code", ["76792", "c"])
+def test_pileup_chebi_code_same_output(oracle_bin, tmp_path, to_code):
+    # tests/test_pileup.rs:373-444: 5hmC renamed to a ChEBI number / another letter (`adjust-mods --convert`, restated test-side): the
+    # no-filter golden with the code renamed (sorted as the reference's test sorts), and — unsorted — the oracle's row order
+    from pileup_cases import convert_mod_code, chebi_case_expected_rows
+    bam = convert_mod_code(fixture(BC), str(tmp_path / "conv.bam"), "h", to_code)
+    out, ora = str(tmp_path / "out.bed"), str(tmp_path / "oracle.bed")
+    flags = ["-i", "25", "--no-filtering", "--only-tabs"]
+    modkit_amd.pileup([bam, out] + flags)
+    want, key = chebi_case_expected_rows(fixture("modbam.modpileup_nofilt.methyl.bed"), to_code)
+    got = ["\t".join(f) for f in sorted((l.split("\t") for l in open(out).read().splitlines()), key=key)]
+    assert got == want
+    p = subprocess.run([oracle_bin, "pileup", bam, ora] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(out).read() == open(ora).read()
+
+
 def _both(oracle_bin, tmp_path, bam, flags):
     a, b = str(tmp_path / "dev.bed"), str(tmp_path / "oracle.bed")
     modkit_amd.pileup([fixture(bam), a] + flags)

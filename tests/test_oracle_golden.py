@@ -61,6 +61,19 @@ def test_pileup_old_tags(oracle_bin, tmp_path):
     assert open(out).read() == open(fixture("pileup-old-tags-regressiontest.methyl.bed")).read()
 
 
+@pytest.mark.parametrize("to_code", ["76792", "c"])
+def test_pileup_chebi_code_same_output(oracle_bin, tmp_path, to_code):
+    # tests/test_pileup.rs:373-444 — 5hmC renamed to a ChEBI number (and to another letter) by `adjust-mods --convert` (restated
+    # test-side): the pileup must be the no-filter golden with the code renamed.  Pins ChEBI codes through tags, tallies and rows.
+    from pileup_cases import convert_mod_code, chebi_case_expected_rows
+    bam = convert_mod_code(fixture(BC), str(tmp_path / "conv.bam"), "h", to_code)
+    out = str(tmp_path / "out.bed")
+    run_oracle(oracle_bin, bam, out, ["-i", "25", "--no-filtering", "--only-tabs"])
+    want, key = chebi_case_expected_rows(fixture("modbam.modpileup_nofilt.methyl.bed"), to_code)
+    got = ["\t".join(f) for f in sorted((l.split("\t") for l in open(out).read().splitlines()), key=key)]
+    assert got == want
+
+
 # ---- pileup-hemi (tests/test_pileup_hemi.rs)
 @pytest.fixture(scope="module")
 def hemi_ref(tmp_path_factory):
