@@ -45,6 +45,19 @@ def test_fixture_summary_matches_oracle(oracle_bin, fi):
         ctx.close()
 
 
+def test_summary_with_and_without_index(tmp_path):
+    # tests/test_summary.rs:174-186 (test_summary_with_regions): the same BAM read through its index and — a copy without one — whole
+    import shutil
+    bare = str(tmp_path / "no_index.bam")
+    shutil.copy(fixture(BC), bare)
+    ctx = modkit_amd.Context()
+    try:
+        for flags in (["-i", "25"], ["-i", "25", "--no-sampling"]):
+            same(ctx.summary(fixture(BC), flags), ctx.summary(bare, flags))
+    finally:
+        ctx.close()
+
+
 def test_summary_implicit_calls_on_device(oracle_bin):
     # the reference's test_summary_implicit_calls numbers (tests/test_summary.rs:133-172), on the device
     ctx = modkit_amd.Context()
