@@ -43,6 +43,14 @@ def test_pileup_chebi_code_same_output(oracle_bin, tmp_path, to_code):
     assert open(out).read() == open(ora).read()
 
 
+def test_preset_traditional_same_as_options(tmp_path):
+    # tests/test_pileup.rs:446-487: `--preset traditional` is `--cpg --ignore h --combine-strands`
+    a, b = str(tmp_path / "preset.bed"), str(tmp_path / "options.bed")
+    modkit_amd.pileup([fixture(BC), a, "--no-filtering", "--mixed-delim", "--preset", "traditional", "--ref", REF])
+    modkit_amd.pileup([fixture(BC), b, "--cpg", "--no-filtering", "--mixed-delim", "--ignore", "h", "--combine-strands", "--ref", REF])
+    assert open(a).read() == open(b).read() and open(a).read()
+
+
 def _both(oracle_bin, tmp_path, bam, flags):
     a, b = str(tmp_path / "dev.bed"), str(tmp_path / "oracle.bed")
     modkit_amd.pileup([fixture(bam), a] + flags)
