@@ -64,3 +64,55 @@ def test_plan_and_pack_do_not_depend_on_the_pool_size(tmp_path, threads):
         assert re.search(r"shards=\d+", p.stderr)
         outs.append(open(out).read())
     assert outs[0] == outs[1] and outs[0].count("\n") >= 5
+
+
+POOL_SRC = r"""
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <future>
+#include <thread>
+#include "mkp_bam.hpp"
+using namespace mkp;
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL line %d: %s\n", __LINE__, #c); fails++; } } while (0)
+int main() {
+  HostPool& P = HostPool::get();
+  CHECK(P.size() == 4);   // MKP_POOL_THREADS=4 from the test
+  // every index exactly once, from several submitting threads at a time
+  { std::vector<std::atomic<int>> hit(10000); for (auto& h : hit) h = 0;
+    auto job = [&](size_t lo) { P.parallel(2500, [&](size_t i) { hit[lo + i]++; }); };
+    std::thread a(job, 0), b(job, 2500), c(job, 5000); job(7500); a.join(); b.join(); c.join();
+    for (auto& h : hit) CHECK(h == 1); }
+  // an exception in a task reaches the caller after the job is retired; the pool keeps working
+  { bool threw = false; try { P.parallel(64, [&](size_t i) { if (i == 13) throw Error(MKP_E_IO, "boom"); }); } catch (const Error& e) { threw = e.status == MKP_E_IO; } CHECK(threw);
+    std::atomic<int> n{0}; P.parallel(100, [&](size_t) { n++; }); CHECK(n == 100); }
+  // foreground before background: with a long background job queued, a foreground job submitted later still finishes first
+  { std::atomic<bool> bg_done{false}; std::atomic<int> bg_ran{0};
+    auto bg = std::async(std::launch::async, [&]() { HostPool::background() = true;
+        P.parallel(400, [&](size_t) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); bg_ran++; }); bg_done = true; });
+    while (bg_ran < 8) std::this_thread::yield();            // the background job has the workers
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int> fg{0}; P.parallel(40, [&](size_t) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); fg++; });
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(fg == 40); CHECK(!bg_done);                          // 400 ms of background sleep on 3 workers is not over ...
+    CHECK(ms < 60.0);                                          // ... and the foreground job did not queue behind it (40 x 1 ms over 4 threads + slack)
+    bg.get(); CHECK(bg_ran == 400); }
+  // inflate windows are recycled: a released large buffer comes back for a request of a similar size, and trim gives it up
+  { ByteBuf a; a.alloc((size_t)70 << 20); uint8_t* p = a.data(); a[0] = 1; a.release();
+    ByteBuf b; b.alloc((size_t)66 << 20); CHECK(b.data() == p); b.release();
+    ByteBuf c; c.alloc((size_t)200 << 20); CHECK(c.data() != p);   // nothing parked fits: the parked one is returned to the system
+    c.release(); ByteBuf::trim_spares(); ByteBuf d; d.alloc((size_t)200 << 20); d[0] = 2; }
+  printf(fails ? "FAILED %d\n" : "ok\n", fails);
+  return fails ? 1 : 0;
+}
+"""
+
+
+def test_pool_priority_exceptions_and_buffer_recycling(tmp_path):
+    src = tmp_path / "pool.cpp"
+    src.write_text(POOL_SRC)
+    exe = tmp_path / "pool"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "modkit_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-lz", "-pthread"])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, MKP_POOL_THREADS="4"))
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stdout + p.stderr
