@@ -652,6 +652,9 @@ int mkp_internal_host_inflate(const uint8_t* src, size_t clen, uint8_t* dst, siz
   return hostinf::inflate(padded.data(), clen, dst, dlen) ? 1 : 0;
 }
 
+// test hook (tests/test_host_deflate.py): the CRC-32 every inflate path checks a block's bytes with (mkp_crc32.hpp)
+uint32_t mkp_internal_crc32(const uint8_t* p, size_t n) { return crc32_of(p, n); }
+
 int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
   if (!out) return MKP_E_INVALID;
   *out = nullptr;
@@ -928,6 +931,12 @@ bool mkp_internal_device_inflate(void* user, const InflateJob& j) {
     const uint32_t* st = (const uint32_t*)(pout + j.dtotal);   // (dtotal is a sum of block sizes; the status words may sit unaligned)
     for (size_t i = 0; i < j.n_blks; i++) { uint32_t v; memcpy(&v, (const uint8_t*)st + 4 * i, 4); if (v != 0) return false; }   // the host decoder takes the window and names the error
     HostPool::get().parallel((j.dtotal + piece - 1) / piece, [&](size_t i) { const size_t lo = i * piece, n = std::min(piece, j.dtotal - lo); memcpy(j.dst + lo, pout + lo, n); });
+    // the blocks' CRC32s (trailer word behind each payload), as the host decoder checks them: a mismatch hands the window to the host path,
+    // which names the error
+    std::atomic<bool> crc_bad{false};
+    HostPool::get().parallel((j.n_blks + 63) / 64, [&](size_t g) { for (size_t i = g * 64; i < std::min(j.n_blks, (g + 1) * 64); i++) { const InflateBlk& b = j.blks[i];
+        uint32_t want; memcpy(&want, j.comp + b.in_off + b.in_len, 4); if (crc32_of(j.dst + b.out_off, b.out_len) != want) crc_bad = true; } });
+    if (crc_bad) return false;
     return true;
   } catch (const Error&) { return false; }
 }

@@ -18,6 +18,7 @@
 #include <functional>
 #include <mutex>
 #include "mkp_inflate_host.hpp"
+#include "mkp_crc32.hpp"
 #include <sched.h>
 #include <cstdint>
 #include <cstdio>
@@ -221,15 +222,22 @@ struct BamData {
 
 // one BGZF block's deflate payload -> dst[0, dlen).  The payload is followed by the block's CRC32 + ISIZE (8 readable bytes).
 // The library's own decoder (mkp_inflate_host.hpp) first; zlib when it declines, which is also where the error comes from.
+// Either way the inflated bytes must carry the CRC32 the block's trailer names (as htslib's bgzf reader demands): a decoder bug or a
+// flipped bit that still yields ISIZE bytes is an error, not data.
+static inline void check_block_crc(const uint8_t* src, size_t clen, const uint8_t* dst, size_t dlen) {
+  uint32_t want; memcpy(&want, src + clen, 4);
+  if (crc32_of(dst, dlen) != want) throw Error(MKP_E_IO, "corrupt BGZF block (CRC32 mismatch)");
+}
 static inline void inflate_block(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
   static const bool use_zlib = getenv("MKP_HOST_INFLATE") && !strcmp(getenv("MKP_HOST_INFLATE"), "zlib");   // A/B timing
-  if (!use_zlib && hostinf::inflate(src, clen, dst, dlen)) return;
+  if (!use_zlib && hostinf::inflate(src, clen, dst, dlen)) { check_block_crc(src, clen, dst, dlen); return; }
   z_stream zs; memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, -15) != Z_OK) throw Error(MKP_E_IO, "zlib init failed");
   zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = (uInt)dlen;
   int rc = inflate(&zs, Z_FINISH);
   inflateEnd(&zs);
   if (rc != Z_STREAM_END || zs.avail_out != 0) throw Error(MKP_E_IO, "corrupt BGZF block");
+  check_block_crc(src, clen, dst, dlen);
 }
 
 // require_sorted = false: file order is all the caller needs (`extract calls` walks records one by one; fetches are not valid then)

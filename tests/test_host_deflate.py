@@ -130,3 +130,18 @@ def test_every_block_of_the_golden_bams():
             o += bsize
             n += 1
     assert n > 50
+
+
+def test_crc32_equals_zlib():
+    """mkp_crc32.hpp (PCLMULQDQ folding where the host has it) against zlib.crc32: every length around the 16 / 64-byte step sizes, random
+    offsets (unaligned starts), block-sized inputs."""
+    L = modkit_amd.lib()
+    L.mkp_internal_crc32.restype = ctypes.c_uint32
+    L.mkp_internal_crc32.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    rng = np.random.default_rng(11)
+    buf = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    lens = list(range(0, 300)) + [1023, 1024, 1025, 65279, 65280, 65281, 65536] + [int(x) for x in rng.integers(300, 66000, 200)]
+    for n in lens:
+        off = int(rng.integers(0, 64))
+        piece = buf[off:off + n]
+        assert L.mkp_internal_crc32(piece, len(piece)) == (zlib.crc32(piece) & 0xffffffff), (n, off)

@@ -123,3 +123,27 @@ def test_oversized_block_size_in_an_indexed_bam_fails_loudly(tmp_path):
     p = subprocess.run([CLI, "pileup", bam, str(tmp_path / "o.tsv"), "--plan-only", "--stats"], capture_output=True, text=True, timeout=60)
     assert p.returncode != 0, p.stderr
     assert "BAM record" in p.stderr or "corrupt" in p.stderr, p.stderr
+
+
+@pytest.mark.parametrize("indexed", [True, False])
+def test_crc_mismatch_in_a_block_fails_loudly(tmp_path, indexed):
+    """A BGZF block whose payload still inflates to ISIZE bytes but whose CRC32 word does not match (htslib's reader rejects it): an I/O
+    error on the indexed reader and on the whole-file loader, never rows."""
+    bam, _ = gen(tmp_path, "crc", [("c1", 60000)], 300)
+    data = bytearray(open(bam, "rb").read())
+    o, k = 0, 0
+    while o + 18 <= len(data):   # the CRC word of the third block
+        bsize = int.from_bytes(data[o + 16:o + 18], "little") + 1
+        if k == 2:
+            data[o + bsize - 8] ^= 0x40
+            break
+        o += bsize
+        k += 1
+    bad = str(tmp_path / "crc_bad.bam")
+    open(bad, "wb").write(bytes(data))
+    if indexed:
+        open(bad + ".bai", "wb").write(open(bam + ".bai", "rb").read())
+    modkit_amd.build()
+    p = subprocess.run([CLI, "pileup", bad, str(tmp_path / "o.tsv"), "--plan-only"] + ([] if indexed else ["--no-index"]), capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert "corrupt BGZF" in p.stderr, p.stderr
