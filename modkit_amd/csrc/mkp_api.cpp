@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "mkp_ctx.hpp"
+#include "mkp_ingest_host.hpp"
 
 using namespace mkp;
 
@@ -56,6 +57,7 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   auto class_of = [&](size_t i) -> int {
     const MkpReadHdr& h = S.hdr[i];
     auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1];
+        if (S.dev_packed) return t1 == t0 + 1 && b.pad != 0;   // compared on the device while the lists were written (only neighbours are ever asked about)
         return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
     if ((h.flags & MKP_RF_BAD) || !h.n_tags || h.layout >= T.dev.size()) return 4;
     const MkpLayout& L = T.dev[h.layout];
@@ -233,6 +235,7 @@ void make_resident(mkp_ctx* c) {
   host_parallel(c->n_class[1], 2048, [&](size_t lo, size_t hi) {
     for (size_t k = lo; k < hi; k++) {
       MkpReadHdr& h = S.hdr[class_list[c->n_class[0] + k]];
+      if (S.dev_packed) { if (S.dev_sum2[class_list[c->n_class[0] + k]]) h.flags |= MKP_RF_SUMERR; else h.flags &= ~MKP_RF_SUMERR; continue; }
       const MkpLayout& L = c->tables.dev[h.layout];
       const MkpTagRef &t0 = S.tagref[h.tag_off], &t1 = S.tagref[h.tag_off + 1];
       const uint32_t nc0 = L.tags[0].n_codes, nc1 = L.tags[1].n_codes;
@@ -429,8 +432,9 @@ void make_resident(mkp_ctx* c) {
   c->stats.pack_ms += ms_since(t0);
   auto t1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");
-  upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref);
-      upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
+  upload(c->d_hdr, S.hdr);
+  if (!S.dev_packed) { upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml); }
+  // (device ingest: those arrays were written in HBM by mkp_ingest_pack and handed over by mkp_internal_shard_attach)
   lap("upload: packed reads");
   upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
   upload(c->d_read_ids, class_list);
@@ -476,7 +480,7 @@ void make_resident(mkp_ctx* c) {
   // algorithmic bytes
   uint64_t b_reads = 0; for (auto& h : S.hdr) b_reads += 16 + 4ull * h.n_cigar + (h.l_seq + 1) / 2;
   c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = (uint64_t)win;
-  c->stats.alg_bytes_decode = b_reads + S.ranks.size() * 2ull + S.ml.size();  // + 8*events added after the run
+  c->stats.alg_bytes_decode = b_reads + (S.dev_packed ? S.dev_n_ranks : S.ranks.size()) * 2ull + (S.dev_packed ? S.dev_n_ml : S.ml.size());  // + 8*events added after the run
   c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events + 44*rows added after the run
   c->stats.slot_pipeline = stream ? 1u : 0u; c->stats.stream_bytes = 0; c->stats.alg_bytes_agg_survey = 0;
   if (stream) {
@@ -678,6 +682,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
                     &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask}) b->release();
+  mkp_internal_ingest_destroy(c->ingest); c->ingest = nullptr;
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -767,6 +772,30 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
     c->stats.pack_ms += ms_since(t0);
   });
 }
+
+}   // extern "C"
+// Device ingest hand-over (mkp_ingest_host.cpp): the open shard takes the records the device packed.  Their big arrays are swapped into
+// the context's device buffers (what those held goes back with `sh`), the digest becomes the host shard, layout ids are mapped into the
+// context's table (shared with the threshold sampler).
+int mkp_internal_shard_attach(mkp_ctx* c, DevShard* sh) {
+  if (!c || !sh) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
+    if (!c->partition_tags.empty()) throw Error(MKP_E_INVALID, "internal: device ingest does not read partition tags");
+    if (!c->shard.hdr.empty()) throw Error(MKP_E_INVALID, "internal: the shard already holds host-packed records");
+    auto t0 = std::chrono::steady_clock::now();
+    const std::vector<uint16_t> map = c->packer.adopt(sh->layouts);
+    for (auto& h : sh->S.hdr) if (h.n_tags && !(h.flags & MKP_RF_BAD)) { if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range"); h.layout = map[h.layout]; }
+    const int32_t tid = c->shard.tid, ws = c->shard.win_start, we = c->shard.win_end;
+    c->shard = std::move(sh->S); c->shard.tid = tid; c->shard.win_start = ws; c->shard.win_end = we; c->shard.dev_packed = true;
+    std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref); std::swap(c->d_ranks, sh->d_ranks);
+        std::swap(c->d_ml, sh->d_ml);
+    for (DevBuf* b : {&c->d_cigar, &c->d_chunk, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml}) b->ensure(16);   // (an empty shard: the kernels still take valid pointers)
+    c->resident = false; c->row_cap = 0;
+    c->stats.pack_ms += ms_since(t0);
+  });
+}
+extern "C" {
 
 int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
   if (!c) return MKP_E_INVALID;

@@ -499,6 +499,48 @@ class BamSource {
     return fsize_;
   }
 
+  // ---- device ingest (mkp_ingest_host.cpp): what the indexed fetch of [beg, end) would read and inflate, as a plan — the file
+  // ranges holding the region's BGZF blocks, the block table with each block's place in the inflated window, and the record starts the
+  // index knows (chunk starts + the 16 kb linear index) from which the device walks the `block_size` chains in parallel.
+  struct IngestBlk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
+  struct IngestRange { uint64_t file_off, file_len; size_t blk0, blk1; uint64_t raw_start, raw_limit; size_t entry0, entry1; };
+  struct IngestPlan { std::vector<IngestRange> ranges; std::vector<IngestBlk> blks; std::vector<uint64_t> entries; uint64_t raw_total = 0, comp_total = 0; };
+  int fd() const { return fd_; }
+  const std::string& path() const { return path_; }
+  void ingest_plan(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const {
+    *out = IngestPlan();
+    if (!indexed() || tid >= ref_names.size() || end <= beg) return;
+    const std::vector<BaiIndex::Chunk> chunks = bai_.query(tid, beg, end);
+    const BaiIndex::Ref& R = bai_.refs[tid];
+    for (auto& ch : chunks) {
+      const uint64_t cb = ch.beg >> 16, ce = ch.end >> 16, ue = ch.end & 0xffff; const uint32_t ub = (uint32_t)(ch.beg & 0xffff);
+      if (cb >= fsize_ || !(cb < ce || (cb == ce && ue > 0))) continue;
+      const uint64_t want_end = std::min<uint64_t>(fsize_, ce + (1u << 16) + 64);
+      Window buf; map_window(cb, (size_t)(want_end - cb), &buf);   // (only the headers are touched here; the upload preads the same bytes)
+      IngestRange rg; rg.file_off = cb; rg.blk0 = out->blks.size(); uint64_t c = cb; const uint64_t d0 = out->raw_total;
+      for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; out->blks.push_back({b.coff, b.hdr, b.clen, b.isize, out->raw_total}); out->raw_total += b.isize; c += (uint64_t)b.hdr + b.clen + 8; }
+      rg.blk1 = out->blks.size();
+      if (rg.blk1 == rg.blk0) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
+      rg.file_len = c - cb; out->comp_total += rg.file_len;
+      rg.raw_start = d0 + ub; rg.raw_limit = out->raw_total;
+      for (size_t k = rg.blk0; k < rg.blk1; k++) if (out->blks[k].coff == ce) rg.raw_limit = out->blks[k].doff + ue;
+      // entry points: the chunk start, then every linear-index offset that falls inside the chunk
+      rg.entry0 = out->entries.size(); out->entries.push_back(rg.raw_start);
+      uint64_t last_v = 0;
+      for (uint64_t v : R.lin) {
+        if (v == last_v || v <= ch.beg || v >= ch.end) continue;
+        last_v = v;
+        const uint64_t vc = v >> 16; size_t lo = rg.blk0, hi = rg.blk1;
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (out->blks[mid].coff < vc) lo = mid + 1; else hi = mid; }
+        if (lo >= rg.blk1 || out->blks[lo].coff != vc || (v & 0xffff) >= out->blks[lo].isize) continue;   // not a block start of this range: the chain does without it
+        const uint64_t at = out->blks[lo].doff + (v & 0xffff);
+        if (at > out->entries.back() && at + 4 <= rg.raw_limit) out->entries.push_back(at);
+      }
+      rg.entry1 = out->entries.size();
+      out->ranges.push_back(rg);
+    }
+  }
+
  private:
   std::string path_; unsigned threads_ = 1; int fd_ = -1; uint64_t fsize_ = 0, first_record_voff_ = 0; BaiIndex bai_; BamData resident_;
   double avg_rec_bytes_ = 0;   // compressed bytes per record over the whole file (indexed source: the index's counts)

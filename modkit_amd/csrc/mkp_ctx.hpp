@@ -61,6 +61,7 @@ struct mkp_ctx {
   // `modkit summary` (mkp_summary): sampling rounds count calls instead of storing probabilities; device table [4][2][16] + reads_with[6] (u64)
   bool extract_mode = false;   // `extract calls`: the sampling kernels emit one record per call (forward position, classes, call_prob)
   bool summary_mode = false; mkp::DevBuf d_summary; std::vector<uint8_t> h_sum_base; std::vector<uint32_t> h_sum_code; std::vector<uint64_t> h_sum_pass, h_sum_fail;
+  struct mkp_dev_ingest* ingest = nullptr;   // device ingest of indexed BAMs (mkp_ingest_host.cpp): created on first use, lives with the context (staging + window buffers are reused)
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

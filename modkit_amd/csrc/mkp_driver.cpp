@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "mkp_ctx.hpp"
+#include "mkp_ingest_host.hpp"
 #include "mkp_focus.hpp"
 #include "mkp_writer.hpp"
 
@@ -32,7 +33,8 @@ struct Args {
       uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
       bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
-  bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate.hip) instead of the host pool */
+  bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate.hip) instead of the host pool, records back to the host packer */
+  bool host_ingest = false, shard_bytes_set = false;   /* --host-ingest (or MKP_HOST_INGEST=1): inflate, cut and pack the shards on the host instead of the device (mkp_ingest.hip) */
   bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */
 };
 
@@ -457,17 +459,31 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   const uint64_t shard_bp = a.shard_bp ? a.shard_bp : (a.world > 1 ? std::max<uint64_t>(a.interval_size, std::min<uint64_t>(1ull << 27,
       (total_bp + a.world * 8 - 1) / (a.world * 8))) : (1ull << 27));
   // 2^27 positions per shard keeps the per-shard focus / slot buffers small
+  // BAM bytes per shard: the device ingest's inflate pays a fixed latency per launch and HBM holds the window many times over — 1 GiB of
+  // compressed blocks at a time; the host path keeps 256 MiB (its inflated window lives in host memory)
+  const bool dev_ingest_plan = !a.no_index && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !a.device_inflate && !(getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1"));
+  const uint64_t shard_bytes = (a.shard_bytes_set || !dev_ingest_plan) ? a.shard_bytes : (1ull << 30);
   auto shard_cut = [&](const Contig& rec, const std::vector<Interval>& ivs, size_t i0, uint64_t* bp_out) {   // -> one past the shard's last interval
     size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
     while (i1 < ivs.size() && (bp == 0 || (bp + (ivs[i1].end - ivs[i1].start) <= shard_bp && (!bam.indexed() || bam.offset_at(rec.tid,
-        ivs[i1].end) - o0 <= a.shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
+        ivs[i1].end) - o0 <= shard_bytes)))) { bp += ivs[i1].end - ivs[i1].start; i1++; }
     *bp_out = bp; return i1;
   };
-  auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) { HostPool::background() = true; std::unique_ptr<BamBatch> b(new BamBatch());
-      bam.fetch(tid, s0 > MKP_HALO ? s0 - MKP_HALO : 0, s1 + MKP_HALO, b.get()); return b; };
+  // Shard records come from the device ingest (mkp_ingest_host.cpp: compressed blocks up, inflate + record cut + tag tokeniser + packing in
+  // HBM, a digest back) whenever the BAM is indexed; --host-ingest / MKP_HOST_INGEST=1, --partition-tag (keys are read from aux fields on
+  // the host) and --plan-only keep the host reader + packer.
+  struct ShardInput { std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev; };
+  const bool host_ingest_env = getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1");
+  const bool dev_ingest = bam.indexed() && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !inflater.d && !host_ingest_env;
+  if (dev_ingest && !ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
+  double ingest_ms[5] = {0, 0, 0, 0, 0}; uint64_t ingest_blocks = 0, ingest_records = 0;
+  auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) {
+    ShardInput in; const uint32_t lo = s0 > MKP_HALO ? s0 - MKP_HALO : 0, hi = s1 + MKP_HALO;
+    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ctx->ingest, bam, tid, lo, hi); return in; }   // foreground: the upload feeds the GPU's longest job of the run
+    HostPool::background() = true; in.batch.reset(new BamBatch()); bam.fetch(tid, lo, hi, in.batch.get()); return in; };
   // The first shard's blocks are read and inflated behind the threshold estimate (background priority on the host pool: the estimate's
   // own bursts go first), as soon as the first contig's grid is known.
-  std::future<std::unique_ptr<BamBatch>> early_fetch; uint32_t early_s0 = 0, early_s1 = 0; bool early_set = false;
+  std::future<ShardInput> early_fetch; uint32_t early_s0 = 0, early_s1 = 0; bool early_set = false;
   std::future<void> early_walk;
   if (fb.has_focus() && a.world == 1 && !a.plan_only && a.filter_threshold.empty() && !a.no_filtering)
     early_walk = std::async(std::launch::async, [&]() {
@@ -572,21 +588,23 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto fetch_shard = [&](const ShardPlan& sp) { return fetch_range(records[sp.rec].tid, sp.s0, sp.s1); };
   mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
-  std::future<std::unique_ptr<BamBatch>> next_batch;
+  std::future<ShardInput> next_batch;
   const bool early_ok = early_set && early_fetch.valid() && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
   if (early_ok) next_batch = std::move(early_fetch);
   else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }
   for (size_t pi = 0; pi < plan.size(); pi++) {
     const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
-    std::unique_ptr<BamBatch> batch;
-    { auto t_f = std::chrono::steady_clock::now(); batch = next_batch.get(); fetch_wait_ms += ms_since(t_f); }
+    std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev;
+    { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev); fetch_wait_ms += ms_since(t_f); }
+    if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack; ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
+               ingest_records += dev->n_records; }
     if (pi + 1 < plan.size()) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
     if (hf && !focus_done[sp.rec]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(rec, a.interval_size, &focus_of[sp.rec]); focus_done[sp.rec] = 1;
         focus_ms += ms_since(t_focus); }
     if (sp.rec > 0 && (pi == 0 || plan[pi - 1].rec != sp.rec)) for (size_t r2 = 0; r2 < sp.rec; r2++) { std::vector<uint8_t>().swap(focus_of[r2]);
         }   // earlier contigs are done
     const std::vector<uint8_t>& focus = focus_of[sp.rec];
-    std::vector<mkp_record> recs; recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e));
+    std::vector<mkp_record> recs; if (batch) { recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e)); }
     {
       if (a.plan_only) {  // host-only dry run: the shard plan, plus the packer over the shard's records (no device)
         static std::vector<ShardHost> kept_pieces;   // the all-cores pack's per-thread buffers persist across shards, as they do in a context
@@ -610,7 +628,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
       mark("shard blocks in hand");
       must(mkp_shard_begin(ctx, &sh));
-      must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
+      if (dev) { must(mkp_internal_shard_attach(ctx, dev.get())); mkp_internal_ingest_recycle(ctx->ingest, dev.get()); dev.reset(); }
+      else must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       mark("shard packed");
       batch.reset();   // packed: the inflated blocks are no longer needed (their mappings are parked for the next fetch, ByteBuf::spares)
       mkp_rows rows; memset(&rows, 0, sizeof(rows));
@@ -662,6 +681,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu (on the device %llu) peak_rss_kb=%llu\n",
                        (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
                        (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)bam.bytes_inflated_device.load(), (unsigned long long)peak_rss_kb());
+  if (a.stats && dev_ingest) fprintf(stderr, "[mkpileup] device ingest: %llu BGZF blocks, %llu records; block plan %.1f ms, upload %.1f, inflate + CRC + chains %.1f, parse + pack %.1f, digest %.1f (overlapped with the threshold estimate / the shard in hand)\n",
+      (unsigned long long)ingest_blocks, (unsigned long long)ingest_records, ingest_ms[0], ingest_ms[1], ingest_ms[2], ingest_ms[3], ingest_ms[4]);
   return MKP_OK;
 }
 
@@ -695,8 +716,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
         else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
     else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val());
         else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val());
-        else if (s == "--shard-bytes") a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); else if (s == "--no-index") a.no_index = true;
-        else if (s == "--device-inflate") a.device_inflate = true;
+        else if (s == "--shard-bytes") { a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); a.shard_bytes_set = true; } else if (s == "--no-index") a.no_index = true;
+        else if (s == "--device-inflate") a.device_inflate = true; else if (s == "--host-ingest") a.host_ingest = true;
         else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
     else if (s == "--bgzf") a.bgzf = true;

@@ -1,0 +1,245 @@
+// Device ingest, host side: one shard window of an indexed BAM goes to the GPU COMPRESSED and comes back as a digest.
+// Stands in for htslib's IndexedReader::fetch + records() (src/pileup/mod.rs:732-759) and for the tag getters / MmTagInfo::parse
+// (src/mod_bam.rs:1388-1470, 900-1000) on the shard path: the BGZF blocks the index lists are uploaded as they sit in the file,
+// inflated (mkp_inflate*.hip), CRC-checked, cut into records, filtered and packed into the shard arrays (mkp_ingest.hip) — the
+// inflated bytes never exist on the host.  What returns: one MkpReadHdr + tag table + two hashes per kept record (the planner's input),
+// the spans of supplementary records (max-depth guard), block status words and error bits.  MM header structures ("layouts") are
+// interned on the host from the key hash of each record; the text of a structure seen for the first time is fetched from HBM and
+// parsed by the host packer itself.
+#include <atomic>
+#include <memory>
+#include <thread>
+
+#include "mkp_ingest_dev.hpp"
+#include "mkp_ingest_host.hpp"
+
+using namespace mkp;
+
+extern "C" {
+hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);
+hipError_t mkp_launch_inflate_wave(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);
+hipError_t mkp_launch_crc32(hipStream_t, const uint8_t*, const void*, uint32_t, const uint8_t*, uint32_t*);
+hipError_t mkp_launch_ingest_count(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, uint32_t*, MkpIngestTotals*);
+hipError_t mkp_launch_ingest_parse(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, const uint32_t*, unsigned long long*, MkpRecInfo*, uint32_t*, int32_t*, MkpIngestTotals*);
+hipError_t mkp_launch_ingest_pack(hipStream_t, const uint8_t*, uint32_t, const MkpRecInfo*, const uint32_t*, MkpReadHdr*, uint32_t*, uint32_t*, uint8_t*, MkpTagRef*, uint32_t*, uint8_t*, MkpRecDigest*, MkpIngestTotals*);
+}
+
+namespace {
+struct Pinned {
+  void* p = nullptr; size_t cap = 0;
+  void ensure(size_t n) { if (n <= cap) return; release(); if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); } cap = n; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+struct BgzfBlk { unsigned long long in_off, out_off; uint32_t in_len, out_len; };   // == MkpBgzfBlock
+uint64_t fnv64(const std::string& s) { uint64_t h = 1469598103934665603ull; for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; } return h; }
+}  // namespace
+
+struct mkp_dev_ingest {
+  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr;
+  static constexpr size_t kPiece = (size_t)4 << 20, kSlots = 16;   // upload staging: two halves of kSlots pieces
+  Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
+  DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig;
+  std::mutex mu;                                                   // one ingest at a time per object
+  std::mutex spare_mu; std::vector<DevBuf> spares;                 // buffers the contexts handed back (mkp_internal_ingest_recycle)
+  DevBuf take(size_t bytes) {
+    DevBuf b;
+    { std::lock_guard<std::mutex> g(spare_mu); size_t best = SIZE_MAX; for (size_t i = 0; i < spares.size(); i++) if (spares[i].cap >= bytes && (best == SIZE_MAX || spares[i].cap < spares[best].cap)) best = i;
+      if (best != SIZE_MAX) { b = spares[best]; spares.erase(spares.begin() + (ptrdiff_t)best); return b; } }
+    b.ensure(std::max<size_t>(bytes, 256)); return b;
+  }
+};
+
+mkp_dev_ingest* mkp_internal_ingest_create(int device) {
+  std::unique_ptr<mkp_dev_ingest> d(new mkp_dev_ingest()); d->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return d.release();
+}
+
+void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig}) b->release();
+  for (auto& b : d->spares) b.release();
+  d->stage.release(); d->small.release();
+  for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
+  if (d->up_done) (void)hipEventDestroy(d->up_done);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
+  delete d;
+}
+
+DevShard::~DevShard() { for (DevBuf* b : {&d_cigar, &d_chunk, &d_seq, &d_tagref, &d_ranks, &d_ml}) b->release(); }
+
+void mkp_internal_ingest_recycle(mkp_dev_ingest* d, DevShard* sh) {
+  if (!d || !sh) return;
+  std::lock_guard<std::mutex> g(d->spare_mu);
+  for (DevBuf* b : {&sh->d_cigar, &sh->d_chunk, &sh->d_seq, &sh->d_tagref, &sh->d_ranks, &sh->d_ml}) { if (b->p && d->spares.size() < 16) { d->spares.push_back(*b); b->p = nullptr; b->cap = 0; } }
+}
+
+std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSource& bam, uint32_t tid, uint32_t beg, uint32_t end) {
+  if (!d) throw Error(MKP_E_DEVICE, "device ingest: no ingest object");
+  std::lock_guard<std::mutex> lock(d->mu);
+  auto t0 = std::chrono::steady_clock::now();
+  std::unique_ptr<DevShard> out(new DevShard());
+  ShardHost& S = out->S; S.tid = (int32_t)tid; S.dev_packed = true;
+  BamSource::IngestPlan plan; bam.ingest_plan(tid, beg, end, &plan);
+  out->ms_plan = ms_since(t0);
+  if (plan.ranges.empty() || plan.raw_total == 0) return out;   // nothing under the region: an empty shard
+  if (plan.blks.size() > 0xfffffff0ull || plan.entries.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");
+  auto ok = [](hipError_t e, const char* what) { if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string("device ingest: ") + what + ": " + hipGetErrorString(e)); };
+  ok(hipSetDevice(d->device), "hipSetDevice");
+  // ---- the compressed ranges go up piece by piece: pread into page-locked staging on all cores, async H2D behind them
+  auto t_up = std::chrono::steady_clock::now();
+  std::vector<uint64_t> zbase(plan.ranges.size()); uint64_t zbytes = 0;
+  for (size_t r = 0; r < plan.ranges.size(); r++) { zbase[r] = zbytes; zbytes += (plan.ranges[r].file_len + 63) & ~63ull; }
+  d->zin.ensure(zbytes + 64);
+  struct Piece { uint64_t file_off, z_off; size_t n; };
+  std::vector<Piece> pieces;
+  for (size_t r = 0; r < plan.ranges.size(); r++) for (uint64_t o = 0; o < plan.ranges[r].file_len; o += mkp_dev_ingest::kPiece)
+    pieces.push_back({plan.ranges[r].file_off + o, zbase[r] + o, (size_t)std::min<uint64_t>(mkp_dev_ingest::kPiece, plan.ranges[r].file_len - o)});
+  d->stage.ensure(2 * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece);
+  const int fd = bam.fd();
+  std::atomic<bool> read_bad{false};
+  for (size_t p0 = 0, round = 0; p0 < pieces.size(); p0 += mkp_dev_ingest::kSlots, round++) {
+    const size_t half = round & 1, n = std::min(mkp_dev_ingest::kSlots, pieces.size() - p0);
+    if (round >= 2) ok(hipEventSynchronize(d->slot_ev[half]), "staging wait");   // the copies that last used this half are done
+    uint8_t* base = (uint8_t*)d->stage.p + half * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece;
+    HostPool::get().parallel(n, [&](size_t k) {
+      const Piece& pc = pieces[p0 + k]; uint8_t* dst = base + k * mkp_dev_ingest::kPiece; size_t got = 0;
+      while (got < pc.n) { const ssize_t r = ::pread(fd, dst + got, pc.n - got, (off_t)(pc.file_off + got)); if (r <= 0) { read_bad = true; return; } got += (size_t)r; }
+    });
+    if (read_bad) throw Error(MKP_E_IO, "read error on " + bam.path());
+    for (size_t k = 0; k < n; k++) ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, pieces[p0 + k].n, hipMemcpyHostToDevice, d->up_stream), "H2D");
+    ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
+  }
+  ok(hipEventRecord(d->up_done, d->up_stream), "event");
+  bam.bytes_read += plan.comp_total;
+  // ---- tables: BGZF blocks, chain segments
+  const size_t nb = plan.blks.size(), ns = plan.entries.size();
+  std::vector<BgzfBlk> blks(nb);
+  for (size_t r = 0; r < plan.ranges.size(); r++) for (size_t k = plan.ranges[r].blk0; k < plan.ranges[r].blk1; k++) {
+    const BamSource::IngestBlk& b = plan.blks[k];
+    if (b.isize > 65536u) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB in " + bam.path());
+    blks[k] = {zbase[r] + (b.coff - plan.ranges[r].file_off) + b.hdr, b.doff, b.clen, b.isize};
+  }
+  const std::vector<MkpSeg> segs = mkp_plan_segments<MkpSeg>(plan);
+  d->zblk.ensure(nb * sizeof(BgzfBlk)); d->zstat.ensure(nb * 4 + 16); d->raw.ensure(plan.raw_total + 64); d->segs.ensure(ns * sizeof(MkpSeg)); d->seg_cnt.ensure((ns + 1) * 4); d->tot.ensure(sizeof(MkpIngestTotals));
+  const size_t small_need = nb * sizeof(BgzfBlk) + ns * sizeof(MkpSeg) + nb * 4 + sizeof(MkpIngestTotals) + 256;
+  d->small.ensure(small_need + small_need / 4);
+  uint8_t* sm = (uint8_t*)d->small.p; uint8_t* sm_blk = sm; uint8_t* sm_seg = sm + nb * sizeof(BgzfBlk); uint8_t* sm_tot = sm_seg + ns * sizeof(MkpSeg); uint8_t* sm_stat = sm_tot + 64;
+  memcpy(sm_blk, blks.data(), nb * sizeof(BgzfBlk)); memcpy(sm_seg, segs.data(), ns * sizeof(MkpSeg));
+  ok(hipMemcpyAsync(d->zblk.p, sm_blk, nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, d->stream), "H2D");
+  ok(hipMemcpyAsync(d->segs.p, sm_seg, ns * sizeof(MkpSeg), hipMemcpyHostToDevice, d->stream), "H2D");
+  ok(hipMemsetAsync(d->zstat.p, 0xff, nb * 4, d->stream), "memset");
+  ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
+  ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
+  out->ms_upload = ms_since(t_up);
+  // ---- inflate + CRC, record chains
+  auto t_inf = std::chrono::steady_clock::now();
+  { static const char* force = getenv("MKP_INFLATE_KERNEL");
+    const bool per_thread = force ? !strcmp(force, "thread") : nb >= 24576u;
+    ok(per_thread ? mkp_launch_inflate(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>())
+                  : mkp_launch_inflate_wave(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch"); }
+  ok(mkp_launch_crc32(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
+  MkpIngestParams P; memset(&P, 0, sizeof(P));
+  P.raw_len = plan.raw_total; P.tid = (int32_t)tid; P.beg = (int32_t)std::min<uint32_t>(beg, 0x7fffffffu); P.end = (int32_t)std::min<uint32_t>(end, 0x7fffffffu); P.n_ref = (int32_t)bam.ref_names.size(); P.n_seg = (uint32_t)ns;
+  ok(mkp_launch_ingest_count(d->stream, d->raw.as<uint8_t>(), &P, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->tot.as<MkpIngestTotals>()), "count launch");
+  MkpIngestTotals* tot = (MkpIngestTotals*)sm_tot;
+  ok(hipMemcpyAsync(sm_stat, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+  ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
+  ok(hipStreamSynchronize(d->stream), "inflate sync");
+  out->ms_inflate = ms_since(t_inf);
+  bam.bytes_inflated += plan.raw_total; bam.bytes_inflated_device += plan.raw_total;
+  { const uint32_t* st = (const uint32_t*)sm_stat; for (size_t i = 0; i < nb; i++) if (st[i] != 0) throw Error(MKP_E_IO, "corrupt BGZF data in " + bam.path() +
+        ((st[i] & 0x100u) ? " (CRC32 mismatch" : " (decoder status " + std::to_string(st[i] & 0xffu)) + ", block at " + std::to_string(plan.blks[i].coff) + ")"); }
+  auto check = [&](uint32_t err) {
+    if (err & MKP_IE_TRUNCATED) throw Error(MKP_E_IO, "truncated BAM record at the end of " + bam.path());
+    if (err & MKP_IE_CORRUPT) throw Error(MKP_E_IO, "corrupt BAM record");
+    if (err & MKP_IE_CHAIN) throw Error(MKP_E_IO, "the BAM index does not match the file (a record chain misses an indexed record start): " + bam.path() + ".bai");
+    if (err & (MKP_IE_TABLE | MKP_IE_4G)) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
+    if (err & MKP_IE_QLEN) throw Error(MKP_E_INVALID, "CIGAR query length does not match SEQ length");
+    if (err & MKP_IE_SPAN) throw Error(MKP_E_UNSUPPORTED, "a read or its alignment spans 2^26 bases or more (the depth walk packs query offsets in 27 bits)");
+    if (err & MKP_IE_NONASCII) throw Error(MKP_E_UNSUPPORTED, "non-ASCII mod code");
+    if (err & MKP_IE_CODES) throw Error(MKP_E_UNSUPPORTED, "more than 4 mod codes in one MM tag");
+    if (err & MKP_IE_TAGS) throw Error(MKP_E_UNSUPPORTED, "more than 8 MM tags in one read");
+  };
+  check(tot->err);
+  // ---- records: offsets, checks + region test + aux walk, sizes -> offsets
+  auto t_scan = std::chrono::steady_clock::now();
+  const uint32_t n_all = tot->n_all;
+  P.rec_cap = std::max<uint32_t>(n_all, 1u);
+  d->rec_off.ensure((size_t)P.rec_cap * 8); d->info.ensure((size_t)P.rec_cap * sizeof(MkpRecInfo)); d->sz.ensure(5 * (size_t)P.rec_cap * 4); d->extra.ensure(2 * (size_t)P.rec_cap * 4);
+  ok(mkp_launch_ingest_parse(d->stream, d->raw.as<uint8_t>(), &P, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->rec_off.as<unsigned long long>(), d->info.as<MkpRecInfo>(), d->sz.as<uint32_t>(),
+                             d->extra.as<int32_t>(), d->tot.as<MkpIngestTotals>()), "parse launch");
+  ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
+  ok(hipStreamSynchronize(d->stream), "parse sync");
+  check(tot->err);
+  const uint32_t n = tot->n_kept;
+  // ---- pack
+  out->d_cigar = d->take((tot->cigar_words + 16) * 4); out->d_chunk = d->take((tot->chunk_pairs + 4) * 8); out->d_seq = d->take(tot->seq_bytes + 64);
+  out->d_tagref = d->take(((size_t)n * MKP_MAX_TAGS + 1) * sizeof(MkpTagRef)); out->d_ranks = d->take((tot->ml_bytes + 16) * 4); out->d_ml = d->take(tot->ml_bytes + 64);
+  DevBuf d_hdr = d->take(((size_t)n + 1) * sizeof(MkpReadHdr));
+  struct Back { mkp_dev_ingest* d; DevBuf b; ~Back() { std::lock_guard<std::mutex> g(d->spare_mu); if (b.p) { if (d->spares.size() < 16) d->spares.push_back(b); else b.release(); } } } back{d, d_hdr};
+  d->dig.ensure(((size_t)n + 1) * sizeof(MkpRecDigest));
+  ok(mkp_launch_ingest_pack(d->stream, d->raw.as<uint8_t>(), P.rec_cap, d->info.as<MkpRecInfo>(), d->sz.as<uint32_t>(), d_hdr.as<MkpReadHdr>(), out->d_cigar.as<uint32_t>(), out->d_chunk.as<uint32_t>(),
+                            out->d_seq.as<uint8_t>(), out->d_tagref.as<MkpTagRef>(), out->d_ranks.as<uint32_t>(), out->d_ml.as<uint8_t>(), d->dig.as<MkpRecDigest>(), d->tot.as<MkpIngestTotals>()), "pack launch");
+  S.hdr.resize(n); S.tagref.resize((size_t)n * MKP_MAX_TAGS); S.name_hash.resize(n);
+  std::vector<MkpRecDigest> dig(n); std::vector<int32_t> extra(2 * (size_t)tot->n_extra);
+  if (n) { ok(hipMemcpyAsync(S.hdr.data(), d_hdr.p, (size_t)n * sizeof(MkpReadHdr), hipMemcpyDeviceToHost, d->stream), "D2H");
+           ok(hipMemcpyAsync(S.tagref.data(), out->d_tagref.p, (size_t)n * MKP_MAX_TAGS * sizeof(MkpTagRef), hipMemcpyDeviceToHost, d->stream), "D2H");
+           ok(hipMemcpyAsync(dig.data(), d->dig.p, (size_t)n * sizeof(MkpRecDigest), hipMemcpyDeviceToHost, d->stream), "D2H"); }
+  if (!extra.empty()) ok(hipMemcpyAsync(extra.data(), d->extra.p, extra.size() * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+  ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
+  ok(hipStreamSynchronize(d->stream), "pack sync");
+  check(tot->err);
+  out->ms_pack = ms_since(t_scan);
+  // ---- digest -> what the planner reads: layout ids (this shard's own table; mkp_internal_shard_attach maps them into the context's), flags
+  auto t_dig = std::chrono::steady_clock::now();
+  S.n_calls = tot->n_calls; S.dev_n_ranks = tot->n_calls; S.dev_n_ml = tot->n_ml_used;
+  S.dev_sum2.resize(n);
+  for (size_t k = 0; k < extra.size(); k += 2) S.extra_spans.push_back({extra[k], extra[k + 1]});
+  std::unordered_map<uint64_t, uint16_t> by_hash; std::vector<uint8_t> recbuf;
+  uint64_t ev_cap = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    MkpReadHdr& h = S.hdr[j];
+    S.name_hash[j] = dig[j].name_hash; S.dev_sum2[j] = (uint8_t)(h.pad & 1u); h.pad = 0;
+    ev_cap += h.event_cap;
+    if (!h.n_tags || (h.flags & MKP_RF_BAD)) continue;
+    auto it = by_hash.find(dig[j].key_hash);
+    if (it == by_hash.end()) {
+      // a structure not seen in this shard yet: its record comes back from HBM and goes through the host packer, which interns the layout
+      // (and must arrive at the same key: a colliding hash would otherwise attach the wrong caller tables)
+      MkpRecInfo ri;
+      // the record's place in the window: find it through the info table (kept records are in window order; j-th kept one)
+      // -- the scan offsets are on the device; one small search kernel would do, but first sightings are rare: read info[] once per shard
+      if (out->info_host.empty()) { out->info_host.resize(n_all); ok(hipMemcpyAsync(out->info_host.data(), d->info.p, (size_t)n_all * sizeof(MkpRecInfo), hipMemcpyDeviceToHost, d->stream), "D2H (record table)"); ok(hipStreamSynchronize(d->stream), "sync");
+        out->kept_index.reserve(n); for (uint32_t i = 0; i < n_all; i++) if (out->info_host[i].kind == 1) out->kept_index.push_back(i); }
+      if (out->kept_index.size() != n) throw Error(MKP_E_DEVICE, "internal: device ingest kept-record count disagrees with its record table");
+      ri = out->info_host[out->kept_index[j]];
+      recbuf.resize((size_t)ri.bs + 4);
+      ok(hipMemcpyAsync(recbuf.data(), d->raw.as<uint8_t>() + (ri.core - 4), recbuf.size(), hipMemcpyDeviceToHost, d->stream), "D2H (record)"); ok(hipStreamSynchronize(d->stream), "sync");
+      mkp_record r; const uint8_t* c = recbuf.data() + 4;
+      memcpy(&r.tid, c, 4); memcpy(&r.pos, c + 4, 4); r.l_qname = c[8]; uint16_t nc; memcpy(&nc, c + 12, 2); r.n_cigar = nc; memcpy(&r.flag, c + 14, 2); memcpy(&r.l_qseq, c + 16, 4);
+      r.l_data = (int32_t)ri.bs - 32; r.data = c + 32;
+      ShardHost scratch; scratch.tid = (int32_t)tid;
+      const size_t before = out->layouts.layouts.size();
+      out->layouts.add(r, scratch);
+      if (scratch.hdr.size() != 1 || (scratch.hdr[0].flags & MKP_RF_BAD) || !scratch.hdr[0].n_tags) throw Error(MKP_E_DEVICE, "internal: device and host tokenisers disagree on a record's tags");
+      const uint16_t id = scratch.hdr[0].layout;
+      if (fnv64(out->layouts.layout_keys[id]) != dig[j].key_hash) throw Error(MKP_E_DEVICE, "internal: device and host tokenisers disagree on a record's MM header structure");
+      if (id < before) throw Error(MKP_E_DEVICE, "internal: two MM header structures share a 64-bit key hash");
+      it = by_hash.emplace(dig[j].key_hash, id).first;
+    }
+    h.layout = it->second;
+  }
+  S.n_events_cap = ev_cap;
+  std::vector<MkpRecInfo>().swap(out->info_host); std::vector<uint32_t>().swap(out->kept_index);
+  out->ms_digest = ms_since(t_dig);
+  out->n_blocks = nb; out->n_segments = ns; out->n_records = n_all; out->raw_bytes = plan.raw_total; out->comp_bytes = plan.comp_total;
+  out->ms_total = ms_since(t0);
+  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f parse+pack %.1f digest %.1f total %.1f ms\n",
+      tid, beg, end, nb, ns, n_all, n, plan.comp_total / 1e6, plan.raw_total / 1e6, out->ms_plan, out->ms_upload, out->ms_inflate, out->ms_pack, out->ms_digest, out->ms_total);
+  return out;
+}

@@ -212,6 +212,10 @@ struct ShardHost {
   uint64_t n_events_cap = 0, n_calls = 0;
   PodVec<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
   std::vector<std::pair<int32_t, int32_t>> extra_spans;   // reference spans of records htslib's pileup buffers but the path drops (supplementary): max-depth guard only
+  // Device ingest (mkp_ingest.hip): cigar / chunk_pfx / seq / ranks / ml were written in HBM and never existed on the host; hdr, tagref
+  // (MKP_MAX_TAGS entries per read, pad = "same delta list as the tag before") and name_hash are the digest the planner works from.
+  bool dev_packed = false; std::vector<uint8_t> dev_sum2;   // per read: the probability-sum test of a two-tag read (what make_resident computes from S.ml otherwise)
+  uint64_t dev_n_ranks = 0, dev_n_ml = 0;
   // append shard pieces packed independently (parallel packing), in order: offsets are rebased, layout ids remapped.  Sizes
   // are fixed first, then every piece is copied into place by its own thread.
   void append_all(const std::vector<ShardHost>& ps, const std::vector<std::vector<uint16_t>>& layout_maps) {
@@ -244,7 +248,8 @@ struct ShardHost {
     HostPool::get().parallel(ps.size(), place);
     n_events_cap = e.ev; n_calls = calls;
   }
-  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); extra_spans.clear(); }
+  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); extra_spans.clear();
+               dev_packed = false; dev_sum2.clear(); dev_n_ranks = dev_n_ml = 0; }
 };
 
 class Packer {

@@ -17,16 +17,80 @@ def revcomp(s):
 
 
 def bgzf_write(path, data):
+    """-> file offset of every BGZF block (each holds 0xff00 inflated bytes, the last one fewer)"""
+    offs = []
     with open(path, "wb") as f:
         for off in range(0, len(data), 0xff00):
             chunk = data[off:off + 0xff00]
             co = zlib.compressobj(1, zlib.DEFLATED, -15)
             comp = co.compress(chunk) + co.flush()
             bsize = len(comp) + 25
+            offs.append(f.tell())
             f.write(struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, bsize))
             f.write(comp)
             f.write(struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+        offs.append(f.tell())
         f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return offs
+
+
+def reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def write_bai(path, n_ref, block_offs, records):
+    """BAI (SAM spec 5.2) as `samtools index` writes it: bins with chunk lists, the 16 kb linear index, htslib's metadata pseudo-bin 37450
+    (file range + mapped / unmapped counts) and the count of records without coordinates.
+    records = (tid, pos, reflen, flag, inflated offset of the record, its inflated length), file order."""
+    def voff(u):
+        return (block_offs[u // 0xff00] << 16) | (u % 0xff00)
+    refs = [dict(bins={}, lin=[], beg=None, end=0, mapped=0, unmapped=0) for _ in range(n_ref)]
+    no_coor = 0
+    for tid, pos, reflen, flag, u0, ulen in records:
+        if tid < 0:
+            no_coor += 1
+            continue
+        R = refs[tid]
+        vb, ve = voff(u0), voff(u0 + ulen)
+        end = pos + (reflen if reflen > 0 else 1)
+        chunks = R["bins"].setdefault(reg2bin(pos, end), [])
+        if chunks and chunks[-1][1] == vb:
+            chunks[-1][1] = ve
+        else:
+            chunks.append([vb, ve])
+        for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+            while len(R["lin"]) <= w:
+                R["lin"].append(0)
+            if R["lin"][w] == 0:
+                R["lin"][w] = vb
+        if R["beg"] is None:
+            R["beg"] = vb
+        R["end"] = ve
+        if flag & 4:
+            R["unmapped"] += 1
+        else:
+            R["mapped"] += 1
+    out = bytearray(b"BAI\1" + struct.pack("<i", n_ref))
+    for R in refs:
+        for i in range(1, len(R["lin"])):
+            if R["lin"][i] == 0:
+                R["lin"][i] = R["lin"][i - 1]
+        has = R["beg"] is not None
+        out += struct.pack("<i", len(R["bins"]) + (1 if has else 0))
+        for b in sorted(R["bins"]):
+            out += struct.pack("<Ii", b, len(R["bins"][b]))
+            for vb, ve in R["bins"][b]:
+                out += struct.pack("<QQ", vb, ve)
+        if has:
+            out += struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", R["beg"], R["end"], R["mapped"], R["unmapped"])
+        out += struct.pack("<i", len(R["lin"])) + b"".join(struct.pack("<Q", v) for v in R["lin"])
+    out += struct.pack("<Q", no_coor)
+    with open(path, "wb") as f:
+        f.write(bytes(out))
 
 
 def bam_record(tid, pos, flag, qname, cigar, seq, aux):
@@ -60,7 +124,8 @@ def bam_header(contigs):
 
 
 class Fuzz:
-    def __init__(self, seed, contigs=(("ctgA", 12000), ("ctgB", 3000)), n_reads=250, mean_len=900, profile="mixed", tie_rate=0.05, weird_rate=0.08):
+    def __init__(self, seed, contigs=(("ctgA", 12000), ("ctgB", 3000)), n_reads=250, mean_len=900, profile="mixed", tie_rate=0.05, weird_rate=0.08, index=None):
+        self.index = (seed % 3 != 2) if index is None else index   # two of three seeds write a BAI
         self.r = random.Random(seed)
         self.contigs = contigs
         self.n_reads = n_reads
@@ -305,6 +370,7 @@ class Fuzz:
     def write(self, prefix, bed=False):
         data = bam_header(self.contigs)
         k = 0
+        index = []
         total = sum(c[1] for c in self.contigs)
         for tid, (name, ln) in enumerate(self.contigs):
             reads = []
@@ -314,9 +380,13 @@ class Fuzz:
                     reads.append(rd)
             reads.sort(key=lambda t: t[0])
             for start, flag, cigar, seq, aux in reads:
-                data += bam_record(tid, start, flag, "read%06d" % k, cigar, seq, aux)
+                rec = bam_record(tid, start, flag, "read%06d" % k, cigar, seq, aux)
+                index.append((tid, start, sum(n for n, op in cigar if op in "MDN=X"), flag, len(data), len(rec)))
+                data += rec
                 k += 1
-        bgzf_write(prefix + ".bam", bytes(data))
+        offs = bgzf_write(prefix + ".bam", bytes(data))
+        if self.index:   # an indexed BAM goes through the device ingest (linear-index entry points), an unindexed one through the host loader
+            write_bai(prefix + ".bam.bai", len(self.contigs), offs, index)
         with open(prefix + ".fa", "w") as f:
             for name, _ in self.contigs:
                 s = self.refs[name]

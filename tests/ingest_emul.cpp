@@ -7,6 +7,7 @@
 #define MKP_INGEST_HOST_SHIM
 #include "../modkit_amd/csrc/mkp_pack.hpp"
 #include "../modkit_amd/csrc/mkp_ingest_dev.hpp"
+#include "../modkit_amd/csrc/mkp_ingest_host.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -36,8 +37,46 @@ static uint32_t crc_sliced(const uint8_t* p, uint32_t len) {
   return c[0] ^ 0xffffffffu;
 }
 
+// --plan: the indexed side.  BamSource::ingest_plan (block table, window layout, entry points from the BAI) + the chain walk + the region
+// test must select exactly the records BamSource::fetch returns, for whole contigs and for sub-regions, and no chain may miss its entry point.
+static int plan_mode(const char* path) {
+  std::unique_ptr<BamSource> src = BamSource::open(path, 4, true);
+  if (!src->indexed()) { printf("ok (no usable index)\n"); return 0; }
+  size_t n_cmp = 0, n_seg = 0;
+  for (uint32_t t = 0; t < src->ref_names.size(); t++) {
+    const uint32_t L = src->ref_lens[t];
+    const uint32_t regions[4][2] = {{0, L + 16}, {L / 3, 2 * L / 3 + 1}, {L / 2, L / 2 + 50}, {L > 20000 ? L - 20000 : 0, L}};
+    for (auto& rg : regions) {
+      BamSource::IngestPlan plan; src->ingest_plan(t, rg[0], rg[1], &plan);
+      std::vector<uint8_t> raw(plan.raw_total + 8, 0);
+      for (auto& r : plan.ranges) {
+        std::vector<uint8_t> comp(r.file_len + 8, 0);
+        if (::pread(src->fd(), comp.data(), r.file_len, (off_t)r.file_off) != (ssize_t)r.file_len) { fprintf(stderr, "pread failed\n"); return 2; }
+        for (size_t k = r.blk0; k < r.blk1; k++) { const auto& b = plan.blks[k]; if (b.isize) inflate_block(comp.data() + (b.coff - r.file_off) + b.hdr, b.clen, raw.data() + b.doff, b.isize); }
+      }
+      const std::vector<MkpSeg> segs = mkp_plan_segments<MkpSeg>(plan); n_seg += segs.size();
+      MkpIngestParams P; memset(&P, 0, sizeof(P)); P.raw_len = plan.raw_total; P.tid = (int32_t)t; P.beg = (int32_t)rg[0]; P.end = (int32_t)rg[1]; P.n_ref = (int32_t)src->ref_names.size(); P.n_seg = (uint32_t)segs.size();
+      uint32_t err = 0; std::vector<unsigned long long> offs;
+      for (auto& sg : segs) { const uint32_t n = ingest_walk_segment(raw.data(), plan.raw_total, sg, nullptr, &err); const size_t at = offs.size(); offs.resize(at + n); ingest_walk_segment(raw.data(), plan.raw_total, sg, offs.data() + at, &err); }
+      if (err) return fail("chain error bits", t, err, 0);
+      for (size_t i = 1; i < offs.size(); i++) if (offs[i] <= offs[i - 1]) return fail("record offsets not ascending", i, (long long)offs[i], (long long)offs[i - 1]);
+      std::vector<std::string> dev_names;
+      for (auto o : offs) { MkpRecInfo R; ingest_parse_record(raw.data(), o, P, &R, &err); if (R.kind == 1) dev_names.push_back(std::string((const char*)raw.data() + R.core + 32) + ":" + std::to_string(R.pos) + ":" + std::to_string(R.flag)); }
+      if (err) return fail("record error bits", t, err, 0);
+      BamBatch batch; src->fetch(t, rg[0], rg[1], &batch);
+      std::vector<std::string> host_names;
+      for (auto& e : batch.recs) { const mkp_record r = batch.view(e); if (Packer::keep(r)) host_names.push_back(batch.qname(e) + ":" + std::to_string(e.pos) + ":" + std::to_string(e.flag)); }
+      if (dev_names != host_names) return fail("kept records of a region", t, (long long)dev_names.size(), (long long)host_names.size());
+      n_cmp += host_names.size();
+    }
+  }
+  printf("ok plan compared=%zu segments=%zu\n", n_cmp, n_seg);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: ingest_emul in.bam [entry_every]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: ingest_emul in.bam [entry_every] | ingest_emul --plan in.bam\n"); return 2; }
+  if (argc > 2 && !strcmp(argv[1], "--plan")) { try { return plan_mode(argv[2]); } catch (const Error& e) { fprintf(stderr, "plan: %s\n", e.what()); return 2; } }
   const size_t every = argc > 2 ? std::max(1, atoi(argv[2])) : 7;
   BamData bd;
   try { bd = load_bam(argv[1], 4, true); } catch (const Error& e) { fprintf(stderr, "load: %s\n", e.what()); return 2; }

@@ -147,3 +147,18 @@ def test_crc_mismatch_in_a_block_fails_loudly(tmp_path, indexed):
     p = subprocess.run([CLI, "pileup", bad, str(tmp_path / "o.tsv"), "--plan-only"] + ([] if indexed else ["--no-index"]), capture_output=True, text=True, timeout=120)
     assert p.returncode != 0
     assert "corrupt BGZF" in p.stderr, p.stderr
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3])
+def test_indexed_fetch_equals_whole_file_on_fuzzed_bams(tmp_path, seed):
+    """tests/bamfuzz.py writes its own BAI (bins, linear index, metadata pseudo-bin): reading through it gives the packed bytes of the
+    whole-file loader, whole contigs and regions."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from bamfuzz import Fuzz
+    bam, fa, _ = Fuzz(seed, contigs=(("ctgA", 60000), ("ctgB", 20000)), n_reads=600, mean_len=2500, index=True).write(str(tmp_path / "fz"))
+    for flags in ([], ["--shard-bp", "7000"], ["--region", "ctgA:20000-41000"], ["--cpg", "--ref", fa, "-i", "3000", "--shard-bp", "9000"]):
+        a, sa, _ = plan(bam, flags, str(tmp_path / "a.tsv"))
+        b, sb, _ = plan(bam, flags + ["--no-index"], str(tmp_path / "b.tsv"))
+        assert a == b and a, flags
+        assert sa["indexed"] == 1 and sb["indexed"] == 0

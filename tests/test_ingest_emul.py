@@ -18,8 +18,8 @@ FIX = os.path.join(ROOT, "tests", "golden", "modkit_fixtures")
 @pytest.fixture(scope="module")
 def emul(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("emul") / "ingest_emul")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(ROOT, "tests", "ingest_emul.cpp"), "-lz", "-lpthread"])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           "-o", exe, os.path.join(ROOT, "tests", "ingest_emul.cpp"), "-lz", "-lpthread"])
     return exe
 
 
@@ -110,3 +110,25 @@ def test_refusals_match_the_host_packer(emul, tmp_path, mm):
     # with a short ML array the broken tag is reached after the "ML array too short" answer of an earlier tag in some cases: still the same verdict on both sides
     _mm_bam(bam, ["C+m?,1,2;", mm], "short", 0)
     run(emul, bam, 1)
+
+
+def run_plan(emul, bam):
+    p = subprocess.run([emul, "--plan", bam], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.startswith("ok"), p.stdout
+    return p.stdout
+
+
+def test_index_plans_select_the_fetch_records(emul, tmp_path):
+    """BamSource::ingest_plan (block table + entry points from the BAI: samtools-written, generator-written, fuzzer-written) + chain walk +
+    region test == BamSource::fetch, for whole contigs and sub-regions."""
+    for f in sorted(os.listdir(FIX)):
+        if f.endswith(".bam") and os.path.exists(os.path.join(FIX, f + ".bai")):
+            run_plan(emul, os.path.join(FIX, f))
+    from test_host_ingest import gen
+    bam, _ = gen(tmp_path, "g", [("c1", 900000), ("c2", 250000)], 4000, ["--mean-len", "6000"])
+    out = run_plan(emul, bam)
+    assert int(out.split("segments=")[1]) > 50      # the linear index supplied entry points
+    for seed in (0, 1):
+        bam, _, _ = Fuzz(seed, contigs=(("ctgA", 90000), ("ctgB", 20000)), n_reads=900, mean_len=2500, index=True).write(str(tmp_path / ("fz%d" % seed)))
+        run_plan(emul, bam)
