@@ -53,6 +53,34 @@ MkpRowsDev carve_rows(DevBuf& b, uint64_t cap) {
 // different bases (`C+h?;C+m?;G-h?;G-m?`), every tag explicit and the tags of a group sharing one rank list; such a read is listed
 // twice (bit 31 = its second group), each listing decoded by a SPARSE wave, and mkp_merge_duplex interleaves the two event lists.
 template <class F> void host_parallel(size_t n, size_t grain, F f);
+// ids reordered by key(id) DESCENDING, equal keys keeping their order (what std::stable_sort with `>` gives): three 11-bit counting passes
+// — the planner sorts a shard's 200 000 reads by length three times, and comparison sorts were a third of its time
+template <class Key> void stable_sort_desc(std::vector<uint32_t>& ids, Key key) {
+  const size_t n = ids.size(); if (n < 2) return;
+  if (n < 2048) { std::stable_sort(ids.begin(), ids.end(), [&](uint32_t x, uint32_t y) { return key(x) > key(y); }); return; }
+  std::vector<uint32_t> k(n), tmp(n), ktmp(n);
+  for (size_t i = 0; i < n; i++) k[i] = ~key(ids[i]);   // ascending in the complement = descending in the key
+  for (int pass = 0; pass < 3; pass++) {
+    const int sh = 11 * pass; size_t cnt[2049] = {0};
+    for (size_t i = 0; i < n; i++) cnt[((k[i] >> sh) & 2047u) + 1]++;
+    bool trivial = false; for (size_t b = 1; b <= 2048; b++) if (cnt[b] == n) trivial = true;
+    if (trivial) continue;
+    for (size_t b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+    for (size_t i = 0; i < n; i++) { const size_t at = cnt[(k[i] >> sh) & 2047u]++; tmp[at] = ids[i]; ktmp[at] = k[i]; }
+    ids.swap(tmp); k.swap(ktmp);
+  }
+}
+inline void sort_u32(std::vector<uint32_t>& v) {   // ascending, three 11-bit counting passes
+  const size_t n = v.size(); if (n < 4096) { std::sort(v.begin(), v.end()); return; }
+  std::vector<uint32_t> tmp(n);
+  for (int pass = 0; pass < 3; pass++) {
+    const int sh = 11 * pass; const uint32_t mask = pass == 2 ? 1023u : 2047u; size_t cnt[2049] = {0};
+    for (size_t i = 0; i < n; i++) cnt[((v[i] >> sh) & mask) + 1]++;
+    for (size_t b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+    for (size_t i = 0; i < n; i++) tmp[cnt[(v[i] >> sh) & mask]++] = v[i];
+    v.swap(tmp);
+  }
+}
 void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>* ids, uint32_t n_class[7], bool duplex) {
   auto class_of = [&](size_t i) -> int {
     const MkpReadHdr& h = S.hdr[i];
@@ -80,8 +108,7 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   host_parallel(S.hdr.size(), 4096, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cl[i] = (uint8_t)class_of(i); });
   std::vector<uint32_t> cls[7];
   for (size_t i = 0; i < cl.size(); i++) cls[cl[i]].push_back((uint32_t)i);
-  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) std::stable_sort(cls[c].begin(), cls[c].end(), [&](uint32_t x,
-      uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; }); });
+  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) stable_sort_desc(cls[c], [&](uint32_t x) { return S.hdr[x].l_seq; }); });
   ids->clear();
   for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
   for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r); ids->push_back(r | 0x80000000u); } }
@@ -137,7 +164,8 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
   std::vector<int32_t> st, en; st.reserve(n); en.reserve(n);
   for (auto& h : S.hdr) { st.push_back(h.ref_start); en.push_back(std::max(h.ref_end, h.ref_start + 1)); }
   for (auto& x : S.extra_spans) { st.push_back(x.first); en.push_back(std::max(x.second, x.first + 1)); }
-  std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+  // (alignment starts and ends are non-negative: they sort as unsigned)
+  { std::vector<uint32_t> a(st.begin(), st.end()), b(en.begin(), en.end()); if (!std::is_sorted(a.begin(), a.end())) sort_u32(a); sort_u32(b); std::copy(a.begin(), a.end(), st.begin()); std::copy(b.begin(), b.end(), en.begin()); }
   size_t j = 0, cur = 0, best = 0;
   for (size_t i = 0; i < n; i++) { while (j < n && en[j] <= st[i]) { j++; cur--; } cur++; best = std::max(best, cur); }
   if (best > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
@@ -148,11 +176,17 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
 // BGZF inflate on the device.  Two kernels: one wave per block (mkp_inflate_wave.hip: ~4 ms per block, 1 024 at a time — a shard
 // window of 5 000 blocks in 26 ms) and one thread per block (mkp_inflate.hip: ~100 ms per launch whatever its size, but 2.4x the throughput
 // once a launch has tens of thousands of blocks — a whole file).  MKP_INFLATE_KERNEL=wave|thread forces one (A/B runs).
-static hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
+}  // namespace
+extern "C" hipError_t mkp_launch_inflate2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one thread per block, second edition
+hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
   static const char* force = getenv("MKP_INFLATE_KERNEL");
-  const bool per_thread = force ? !strcmp(force, "thread") : n >= 24576u;
-  return per_thread ? mkp_launch_inflate(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
+  if (force && !strcmp(force, "wave")) return mkp_launch_inflate_wave(st, in, blks, n, out, status);
+  if (force && !strcmp(force, "thread")) return mkp_launch_inflate(st, in, blks, n, out, status);
+  if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
+  return n >= 24576u ? mkp_launch_inflate(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
 }
+namespace {
+hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
 
 // derive tile geometry, tile read ranges and the run parameters; upload everything
 void make_resident(mkp_ctx* c) {
@@ -163,12 +197,22 @@ void make_resident(mkp_ctx* c) {
       fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
-  { std::vector<std::pair<uint32_t, uint64_t>> h(S.name_hash.size());
-      for (size_t i = 0; i < h.size(); i++) h[i] = {i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u, S.name_hash[i]};
-      // per partition key: tallies of different keys never meet
-    std::sort(h.begin(), h.end()); for (size_t i = 1; i < h.size(); i++) if (h[i] == h[i - 1]) throw Error(MKP_E_UNSUPPORTED,
+  { const size_t nn = S.name_hash.size();
+    // every thread takes the names whose hash falls into its sixteenth and looks for a repeat in an open-addressing table of its own
+    std::atomic<bool> dup{false};
+    host_parallel(16, 1, [&](size_t lo, size_t hi) { for (size_t part = lo; part < hi; part++) {
+      size_t mine = 0; for (size_t i = 0; i < nn; i++) if ((S.name_hash[i] >> 60) == part) mine++;
+      if (mine < 2) continue;
+      size_t cap = 64; while (cap < 2 * mine) cap <<= 1;
+      std::vector<uint64_t> tab(cap, 0), key(cap, 0); std::vector<uint8_t> used(cap, 0);
+      for (size_t i = 0; i < nn; i++) { const uint64_t hh = S.name_hash[i]; if ((hh >> 60) != part) continue;
+        const uint64_t kk = i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u;   // per partition key: tallies of different keys never meet
+        size_t at = (size_t)((hh * 0x9e3779b97f4a7c15ull) >> 20) & (cap - 1);
+        for (;;) { if (!used[at]) { used[at] = 1; tab[at] = hh; key[at] = kk; break; } if (tab[at] == hh && key[at] == kk) { dup = true; break; } at = (at + 1) & (cap - 1); } }
+    } });
+    if (dup) throw Error(MKP_E_UNSUPPORTED,
         "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device");
-        }
+  }
   lap("duplicate-name check");
   // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
   { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1;
@@ -419,7 +463,7 @@ void make_resident(mkp_ctx* c) {
     }
     std::vector<uint32_t> rest; rest.reserve(n);
     for (size_t i = 0; i < n; i++) if (!is_fused[i]) rest.push_back((uint32_t)i);
-    std::stable_sort(rest.begin(), rest.end(), [&](uint32_t x, uint32_t y) { return S.hdr[x].n_sl > S.hdr[y].n_sl; });
+    stable_sort_desc(rest, [&](uint32_t x) { return S.hdr[x].n_sl; });
     c->n_slot_class[2] = (uint32_t)rest.size();
     slot_ids.insert(slot_ids.end(), rest.begin(), rest.end());
   }
@@ -557,7 +601,8 @@ void fetch_row_columns(mkp_ctx* c) {
   const uint64_t n = c->stats.n_rows;
   const uint32_t* src[11] = {c->rows_dst.pos, c->rows_dst.info, c->rows_dst.code, c->rows_dst.n_valid, c->rows_dst.n_mod, c->rows_dst.n_can, c->rows_dst.n_other,
                              c->rows_dst.n_del, c->rows_dst.n_fail, c->rows_dst.n_diff, c->rows_dst.n_nocall};
-  for (int k = 0; k < 11; k++) { c->h_rows[k].resize(n); if (n) hip_check(hipMemcpy(c->h_rows[k].data(), src[k], n * 4, hipMemcpyDeviceToHost), "rows D2H"); }
+  c->h_rows.ensure(std::max<uint64_t>(n, 1));
+  if (n) { for (int k = 0; k < 11; k++) hip_check(hipMemcpyAsync(c->h_rows.col[k], src[k], n * 4, hipMemcpyDeviceToHost, c->stream), "rows D2H"); hip_check(hipStreamSynchronize(c->stream), "rows D2H sync"); }
   std::vector<MkpReadOut> ro(c->shard.hdr.size());
   if (!ro.empty()) hip_check(hipMemcpy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost), "readout D2H");
   c->n_ok = 0; c->n_bad = 0; uint64_t ev = 0;
@@ -571,16 +616,16 @@ void fetch_hemi_rows(mkp_ctx* c, mkp_hemi_rows* out) {
   const uint64_t n = c->stats.n_rows;
   c->h_hemi_base.resize(n); c->h_hemi_pat[0].resize(n); c->h_hemi_pat[1].resize(n);
   for (uint64_t i = 0; i < n; i++) {   // rows.info = primary base, rows.code = pattern elements a | b << 8
-    const uint32_t pb = c->h_rows[1][i] & 3u, a = c->h_rows[2][i] & 0xffu, b = (c->h_rows[2][i] >> 8) & 0xffu;
+    const uint32_t pb = c->h_rows.col[1][i] & 3u, a = c->h_rows.col[2][i] & 0xffu, b = (c->h_rows.col[2][i] >> 8) & 0xffu;
     c->h_hemi_base[i] = (uint8_t)"ACGT"[pb];
     c->h_hemi_pat[0][i] = a <= MKP_KMAX + 1 ? c->hemi_codes[pb][a] : 0u; c->h_hemi_pat[1][i] = b <= MKP_KMAX + 1 ? c->hemi_codes[pb][b] : 0u;
   }
   c->stats.d2h_ms = ms_since(t0);
   if (out) {
-    out->n_rows = n; out->pos = c->h_rows[0].data(); out->primary_base = c->h_hemi_base.data(); out->pattern_pos = c->h_hemi_pat[0].data();
+    out->n_rows = n; out->pos = c->h_rows.col[0]; out->primary_base = c->h_hemi_base.data(); out->pattern_pos = c->h_hemi_pat[0].data();
         out->pattern_neg = c->h_hemi_pat[1].data();
-    out->n_valid = c->h_rows[3].data(); out->count = c->h_rows[4].data(); out->n_canonical = c->h_rows[5].data(); out->n_other_pattern = c->h_rows[6].data();
-    out->n_delete = c->h_rows[7].data(); out->n_fail = c->h_rows[8].data(); out->n_diff = c->h_rows[9].data(); out->n_nocall = c->h_rows[10].data();
+    out->n_valid = c->h_rows.col[3]; out->count = c->h_rows.col[4]; out->n_canonical = c->h_rows.col[5]; out->n_other_pattern = c->h_rows.col[6];
+    out->n_delete = c->h_rows.col[7]; out->n_fail = c->h_rows.col[8]; out->n_diff = c->h_rows.col[9]; out->n_nocall = c->h_rows.col[10];
     out->processed_records = c->n_ok; out->skipped_records = c->n_bad;
   }
 }
@@ -590,14 +635,14 @@ void fetch_rows(mkp_ctx* c, mkp_rows* out) {
   fetch_row_columns(c);
   const uint64_t n = c->stats.n_rows;
   c->h_strand.resize(n); c->h_motif.resize(n); c->h_key.resize(n);
-  for (uint64_t i = 0; i < n; i++) { uint32_t inf = c->h_rows[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1;
-      c->h_key[i] = inf >> 16; }
+  host_parallel(n, (size_t)1 << 17, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { const uint32_t inf = c->h_rows.col[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1;
+      c->h_key[i] = inf >> 16; } });
   c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
   c->stats.d2h_ms = ms_since(t0);
   if (out) {
-    out->n_rows = n; out->pos = c->h_rows[0].data(); out->strand = c->h_strand.data(); out->code_repr = c->h_rows[2].data(); out->motif_idx = c->h_motif.data();
-    out->n_valid = c->h_rows[3].data(); out->n_mod = c->h_rows[4].data(); out->n_canonical = c->h_rows[5].data(); out->n_other = c->h_rows[6].data();
-    out->n_delete = c->h_rows[7].data(); out->n_fail = c->h_rows[8].data(); out->n_diff = c->h_rows[9].data(); out->n_nocall = c->h_rows[10].data();
+    out->n_rows = n; out->pos = c->h_rows.col[0]; out->strand = c->h_strand.data(); out->code_repr = c->h_rows.col[2]; out->motif_idx = c->h_motif.data();
+    out->n_valid = c->h_rows.col[3]; out->n_mod = c->h_rows.col[4]; out->n_canonical = c->h_rows.col[5]; out->n_other = c->h_rows.col[6];
+    out->n_delete = c->h_rows.col[7]; out->n_fail = c->h_rows.col[8]; out->n_diff = c->h_rows.col[9]; out->n_nocall = c->h_rows.col[10];
     out->processed_records = c->n_ok; out->skipped_records = c->n_bad;
     out->partition_key = c->h_key.data(); out->n_partition_keys = (uint32_t)c->key_name_ptrs.size(); out->partition_key_names = c->key_name_ptrs.data();
   }
@@ -683,6 +728,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
                     &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask}) b->release();
   mkp_internal_ingest_destroy(c->ingest); c->ingest = nullptr;
+  c->h_rows.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1018,48 +1064,80 @@ hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const M
 
 // Decode `recs` in sampling mode.  n_vals[i] = number of argmax probabilities record i yields after the filters (0: rejected or
 // nothing kept).  The values themselves stay on the device until mkp_internal_sample_take says which reads the schedule took.
+namespace {
+// the sampling pass over the packed reads of S (host-packed: everything goes up; resident: the arrays of the attached shard are in HBM
+// already and S.hdr is the round's selection of its headers)
+void sample_decode(mkp_ctx* c, ShardHost& S, bool resident, const uint8_t* bedmask, bool only_mapped, size_t n_expected, std::vector<uint32_t>* n_vals) {
+  c->tables.build(c->packer.layouts, c->caller);
+  MkpRunParams P; memset(&P, 0, sizeof(P));
+  P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
+  P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->extract_mode ? 3 : c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
+      P.has_focus = bedmask != nullptr;
+  hip_check(hipSetDevice(c->device), "hipSetDevice");
+  upload(c->d_hdr, S.hdr);
+  if (!resident) { upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml); }
+  upload(c->d_layouts, c->tables.dev);
+  { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class, false); upload(c->d_read_ids, ids); }
+  // the --include-bed mask of the contig: one upload per contig and sampling session, not per round (a 25 MB mask per round was most of
+  // the 11.6 s a BED-filtered threshold estimate took on the C5 scale model); mkp_internal_bedmask_reset() starts a session
+  const uint8_t* d_mask;
+  if (bedmask) {
+    const size_t len = (size_t)(S.win_end - S.win_start);
+    if (bedmask != c->bedmask_src || len != c->bedmask_len) {
+      c->d_bedmask.ensure(len); hip_check(hipMemcpy(c->d_bedmask.p, bedmask, len, hipMemcpyHostToDevice), "H2D"); c->bedmask_src = bedmask; c->bedmask_len = len;
+    }
+    d_mask = c->d_bedmask.as<uint8_t>();
+  } else { c->d_focus.ensure(16); d_mask = c->d_focus.as<uint8_t>(); }
+  const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
+  c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
+      c->d_misc.ensure(64);
+  uint32_t* misc = c->d_misc.as<uint32_t>();
+  hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
+  hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
+      c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
+                              c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, d_mask, c->d_vals.as<float>()), "decode(sample) launch");
+  uint32_t h[4]; hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
+  c->sample_ro.resize(S.hdr.size());
+  if (!S.hdr.empty()) hip_check(hipMemcpyAsync(c->sample_ro.data(), c->d_readout.p, S.hdr.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost, c->stream), "D2H");
+  hip_check(hipStreamSynchronize(c->stream), "sample sync");
+  if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
+  if (S.hdr.size() != n_expected) throw Error(MKP_E_INVALID, "internal: sampler packed a different number of records");
+  n_vals->resize(n_expected);
+  for (size_t i = 0; i < n_expected; i++) (*n_vals)[i] = c->sample_ro[i].ok ? c->sample_ro[i].n_events : 0u;
+  c->resident = false;
+}
+}  // namespace
+
 int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,
                         uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals) {
   if (!c || !n_vals) return MKP_E_INVALID;
   return guarded(c, [&]() {
+    if (c->shard.dev_packed) { c->shard.clear(); c->shard_open = false; c->resident = false; }   // a device-packed shard of an earlier run: its HBM arrays are about to be reused
     ShardHost& S = c->sample_shard; S.clear(); S.tid = tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end;
     pack_records(c->packer, S, recs, n, [](const mkp_record&) { return true; });
-    c->tables.build(c->packer.layouts, c->caller);
-    MkpRunParams P; memset(&P, 0, sizeof(P));
-    P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
-    P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->extract_mode ? 3 : c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
-        P.has_focus = bedmask != nullptr;
-    hip_check(hipSetDevice(c->device), "hipSetDevice");
-    upload(c->d_hdr, S.hdr); upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml);
-    upload(c->d_layouts, c->tables.dev);
-    { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class, false); upload(c->d_read_ids, ids); }
-    // the --include-bed mask of the contig: one upload per contig and sampling session, not per round (a 25 MB mask per round was most of
-    // the 11.6 s a BED-filtered threshold estimate took on the C5 scale model); mkp_internal_bedmask_reset() starts a session
-    const uint8_t* d_mask;
-    if (bedmask) {
-      const size_t len = (size_t)(win_end - win_start);
-      if (bedmask != c->bedmask_src || len != c->bedmask_len) {
-        c->d_bedmask.ensure(len); hip_check(hipMemcpy(c->d_bedmask.p, bedmask, len, hipMemcpyHostToDevice), "H2D"); c->bedmask_src = bedmask; c->bedmask_len = len;
-      }
-      d_mask = c->d_bedmask.as<uint8_t>();
-    } else { c->d_focus.ensure(16); d_mask = c->d_focus.as<uint8_t>(); }
-    const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
-    c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
-        c->d_misc.ensure(64);
-    uint32_t* misc = c->d_misc.as<uint32_t>();
-    hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
-        c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
-                                c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, d_mask, c->d_vals.as<float>()), "decode(sample) launch");
-    uint32_t h[4]; hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
-    c->sample_ro.resize(S.hdr.size());
-    if (!S.hdr.empty()) hip_check(hipMemcpyAsync(c->sample_ro.data(), c->d_readout.p, S.hdr.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost, c->stream), "D2H");
-    hip_check(hipStreamSynchronize(c->stream), "sample sync");
-    if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
-    if (S.hdr.size() != n) throw Error(MKP_E_INVALID, "internal: sampler packed a different number of records");
-    n_vals->resize(n);
-    for (uint32_t i = 0; i < n; i++) (*n_vals)[i] = c->sample_ro[i].ok ? c->sample_ro[i].n_events : 0u;
-    c->resident = false;
+    sample_decode(c, S, false, bedmask, only_mapped, n, n_vals);
+  });
+}
+
+// The same pass over reads of the shard the device ingest attached (mkp_internal_shard_attach): `reads` index that shard's records; their
+// CIGARs, bases and tags are in HBM already, only the round's headers (with their slices of the event buffer) go up.
+int mkp_internal_sample_resident(mkp_ctx* c, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const uint32_t* reads, uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals) {
+  if (!c || !n_vals || (!reads && n)) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    ShardHost& R = c->shard;
+    if (!c->shard_open || !R.dev_packed) throw Error(MKP_E_INVALID, "internal: no device-packed shard attached");
+    ShardHost& S = c->sample_shard; S.clear(); S.tid = R.tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end; S.dev_packed = true;
+    S.hdr.resize(n); uint64_t off = 0;
+    for (uint32_t k = 0; k < n; k++) {
+      if (reads[k] >= R.hdr.size()) throw Error(MKP_E_INVALID, "internal: sampled read index out of range");
+      MkpReadHdr h = R.hdr[reads[k]]; h.event_off = (uint32_t)off; off += h.event_cap;
+      if (off > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "sampling round exceeds 4 Gi call events");
+      S.hdr[k] = h;
+    }
+    S.n_events_cap = off;
+    S.tagref.swap(R.tagref);   // the headers' tag_off index the shard's tag table
+    struct Back { ShardHost& a; ShardHost& b; ~Back() { a.tagref.swap(b.tagref); } } back{S, R};
+    sample_decode(c, S, true, bedmask, only_mapped, n, n_vals);
   });
 }
 

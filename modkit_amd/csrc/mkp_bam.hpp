@@ -503,32 +503,79 @@ class BamSource {
   // ranges holding the region's BGZF blocks, the block table with each block's place in the inflated window, and the record starts the
   // index knows (chunk starts + the 16 kb linear index) from which the device walks the `block_size` chains in parallel.
   struct IngestBlk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
-  struct IngestRange { uint64_t file_off, file_len; size_t blk0, blk1; uint64_t raw_start, raw_limit; size_t entry0, entry1; };
-  struct IngestPlan { std::vector<IngestRange> ranges; std::vector<IngestBlk> blks; std::vector<uint64_t> entries; uint64_t raw_total = 0, comp_total = 0; };
+  struct IngestRange { uint64_t file_off = 0, file_len = 0, vbeg = 0, vend = 0; size_t blk0 = 0, blk1 = 0; uint64_t raw_start = 0, raw_limit = 0; size_t entry0 = 0, entry1 = 0; };
+  struct IngestPlan { uint32_t tid = 0; std::vector<IngestRange> ranges; std::vector<IngestBlk> blks; std::vector<uint64_t> entries; uint64_t raw_total = 0, comp_total = 0; };
   int fd() const { return fd_; }
   const std::string& path() const { return path_; }
-  void ingest_plan(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const {
-    *out = IngestPlan();
+  // phase 1: the file ranges (what has to go up) — the chunk list of the index and one header read at each chunk's end block
+  void ingest_ranges(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const {
+    *out = IngestPlan(); out->tid = tid;
     if (!indexed() || tid >= ref_names.size() || end <= beg) return;
-    const std::vector<BaiIndex::Chunk> chunks = bai_.query(tid, beg, end);
-    const BaiIndex::Ref& R = bai_.refs[tid];
-    for (auto& ch : chunks) {
-      const uint64_t cb = ch.beg >> 16, ce = ch.end >> 16, ue = ch.end & 0xffff; const uint32_t ub = (uint32_t)(ch.beg & 0xffff);
+    for (auto& ch : bai_.query(tid, beg, end)) {
+      const uint64_t cb = ch.beg >> 16, ce = ch.end >> 16, ue = ch.end & 0xffff;
       if (cb >= fsize_ || !(cb < ce || (cb == ce && ue > 0))) continue;
-      const uint64_t want_end = std::min<uint64_t>(fsize_, ce + (1u << 16) + 64);
-      Window buf; map_window(cb, (size_t)(want_end - cb), &buf);   // (only the headers are touched here; the upload preads the same bytes)
-      IngestRange rg; rg.file_off = cb; rg.blk0 = out->blks.size(); uint64_t c = cb; const uint64_t d0 = out->raw_total;
-      for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; out->blks.push_back({b.coff, b.hdr, b.clen, b.isize, out->raw_total}); out->raw_total += b.isize; c += (uint64_t)b.hdr + b.clen + 8; }
+      IngestRange rg; rg.file_off = cb; rg.vbeg = ch.beg; rg.vend = ch.end;
+      uint64_t stop = std::min<uint64_t>(ce, fsize_);
+      if (ue > 0 && ce < fsize_) {   // the end block is part of the chunk: its size from its header
+        std::vector<uint8_t> hb((size_t)std::min<uint64_t>(512, fsize_ - ce)); pread_all(ce, hb.data(), hb.size()); bytes_read -= hb.size();
+        Blk b; if (!block_at_header(hb, ce, &b)) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
+        stop = std::min<uint64_t>(fsize_, ce + b.hdr + b.clen + 8);
+      }
+      rg.file_len = stop - cb; out->comp_total += rg.file_len;
+      out->ranges.push_back(rg);
+    }
+  }
+  // phase 2: block table (headers walked on all cores from the block starts the index knows), window layout, entry points
+  void ingest_blocks(IngestPlan* out) const {
+    const uint32_t tid = out->tid; if (tid >= bai_.refs.size()) return;
+    const BaiIndex::Ref& R = bai_.refs[tid];
+    // block starts the index knows: every chunk boundary of the reference's bins and every linear-index offset
+    std::vector<uint64_t> known_all; known_all.reserve(R.lin.size() + 64);
+    for (auto& kv : R.bins) for (auto& c : kv.second) { known_all.push_back(c.beg >> 16); known_all.push_back(c.end >> 16); }
+    for (uint64_t v : R.lin) known_all.push_back(v >> 16);
+    std::sort(known_all.begin(), known_all.end()); known_all.erase(std::unique(known_all.begin(), known_all.end()), known_all.end());
+    for (auto& rg : out->ranges) {
+      const uint64_t cb = rg.file_off, ce = rg.vend >> 16, ue = rg.vend & 0xffff; const uint32_t ub = (uint32_t)(rg.vbeg & 0xffff);
+      const uint64_t range_end = cb + rg.file_len;
+      std::vector<uint64_t> known; known.push_back(cb);
+      for (auto it = std::upper_bound(known_all.begin(), known_all.end(), cb); it != known_all.end() && *it < range_end; ++it) known.push_back(*it);
+      std::vector<std::vector<IngestBlk>> parts(known.size()); std::atomic<bool> bad{false};
+      // headers through pread (a mapping of the range costs a page fault per block, all of them on one address-space lock): one read per
+      // block brings the trailer of the block in hand (ISIZE) and the header of the next
+      HostPool::get().parallel(known.size(), [&](size_t i) {
+        uint64_t c = known[i]; const uint64_t stop = i + 1 < known.size() ? known[i + 1] : UINT64_MAX;
+        try {
+          std::vector<uint8_t> hb(600); Blk b; bool have = false;
+          auto read_at = [&](uint64_t off, size_t n) { n = (size_t)std::min<uint64_t>(n, range_end > off ? range_end - off : 0); hb.resize(n); size_t got = 0;
+            while (got < n) { const ssize_t r = ::pread(fd_, hb.data() + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; } };
+          for (;;) {
+            if (c >= stop || c > ce || (c == ce && ue == 0) || c + 18 > range_end) break;
+            if (!have) { read_at(c, 600); if (!block_at_header(hb, c, &b)) break; }
+            const uint64_t next = c + b.hdr + b.clen + 8;
+            if (next > range_end) break;
+            // [next - 8, next): CRC32 + ISIZE of this block; [next, ..): the next block's header
+            read_at(next - 8, 8 + 600);
+            if (hb.size() < 8) break;
+            uint32_t isize; memcpy(&isize, hb.data() + 4, 4);
+            parts[i].push_back({c, b.hdr, b.clen, isize, 0});
+            c = next; have = false;
+            if (hb.size() >= 8 + 18 && !(c >= stop || c > ce || (c == ce && ue == 0))) { Blk nb; if (block_at_header(hb.data() + 8, hb.size() - 8, c, &nb)) { b = nb; have = true; } }
+          }
+        } catch (...) { bad = true; return; }
+        if (stop != UINT64_MAX && c != stop && !(c > ce || (c == ce && ue == 0))) bad = true;   // the chain of block sizes misses a block start the index names
+      });
+      if (bad) throw Error(MKP_E_IO, "bad BGZF block in " + path_ + " (or the index does not match the file)");
+      rg.blk0 = out->blks.size(); const uint64_t d0 = out->raw_total; uint64_t expect = cb;
+      for (auto& pt : parts) for (auto& b : pt) { if (b.coff != expect) throw Error(MKP_E_IO, "the BAM index does not match the file: " + path_ + ".bai"); b.doff = out->raw_total; out->raw_total += b.isize; expect = b.coff + b.hdr + b.clen + 8; out->blks.push_back(b); }
       rg.blk1 = out->blks.size();
-      if (rg.blk1 == rg.blk0) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
-      rg.file_len = c - cb; out->comp_total += rg.file_len;
+      if (rg.blk1 == rg.blk0 || expect != cb + rg.file_len) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
       rg.raw_start = d0 + ub; rg.raw_limit = out->raw_total;
       for (size_t k = rg.blk0; k < rg.blk1; k++) if (out->blks[k].coff == ce) rg.raw_limit = out->blks[k].doff + ue;
       // entry points: the chunk start, then every linear-index offset that falls inside the chunk
       rg.entry0 = out->entries.size(); out->entries.push_back(rg.raw_start);
       uint64_t last_v = 0;
       for (uint64_t v : R.lin) {
-        if (v == last_v || v <= ch.beg || v >= ch.end) continue;
+        if (v == last_v || v <= rg.vbeg || v >= rg.vend) continue;
         last_v = v;
         const uint64_t vc = v >> 16; size_t lo = rg.blk0, hi = rg.blk1;
         while (lo < hi) { const size_t mid = (lo + hi) / 2; if (out->blks[mid].coff < vc) lo = mid + 1; else hi = mid; }
@@ -537,9 +584,9 @@ class BamSource {
         if (at > out->entries.back() && at + 4 <= rg.raw_limit) out->entries.push_back(at);
       }
       rg.entry1 = out->entries.size();
-      out->ranges.push_back(rg);
     }
   }
+  void ingest_plan(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const { ingest_ranges(tid, beg, end, out); ingest_blocks(out); }
 
  private:
   std::string path_; unsigned threads_ = 1; int fd_ = -1; uint64_t fsize_ = 0, first_record_voff_ = 0; BaiIndex bai_; BamData resident_;
@@ -579,6 +626,20 @@ class BamSource {
     if (!found || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path_);
     if (o + bsize > buf.size()) return false;
     b->coff = coff; b->hdr = 12u + xlen; b->clen = bsize - xlen - 20u; memcpy(&b->isize, &buf[o + bsize - 4], 4); b->doff = 0;
+    return true;
+  }
+
+  // sizes of the BGZF block whose header sits at the start of `hb` (file offset coff); false when the header itself is cut short
+  bool block_at_header(const std::vector<uint8_t>& v, uint64_t coff, Blk* b) const { return block_at_header(v.data(), v.size(), coff, b); }
+  bool block_at_header(const uint8_t* hb, size_t hn, uint64_t coff, Blk* b) const {
+    if (hn < 18) return false;
+    if (hb[0] != 31 || hb[1] != 139 || !(hb[3] & 4)) throw Error(MKP_E_IO, "not BGZF: " + path_);
+    uint16_t xlen; memcpy(&xlen, &hb[10], 2);
+    size_t x = 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
+    if (xe > hn) return false;
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &hb[x + 2], 2); if (hb[x] == 'B' && hb[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t v; memcpy(&v, &hb[x + 4], 2); bsize = (uint32_t)v + 1; found = true; } x += 4 + (size_t)sl; }
+    if (!found || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path_);
+    b->coff = coff; b->hdr = 12u + xlen; b->clen = bsize - xlen - 20u; b->isize = 0; b->doff = 0;
     return true;
   }
 

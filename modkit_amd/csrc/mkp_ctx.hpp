@@ -49,7 +49,13 @@ struct mkp_ctx {
   mkp::ShardHost sample_shard; std::vector<MkpReadOut> sample_ro; uint64_t sample_n = 0;
   mkp::DevBuf d_store, d_hist0, d_hist1, d_sample_cursor, d_take;
   MkpRowsDev rows_src, rows_dst;
-  std::vector<uint32_t> h_rows[11]; std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif; std::vector<uint32_t> h_key;
+  // row columns on the host: one page-locked arena (pageable D2H of a chromosome's 120 MB of rows ran at under 5 GB/s), kept across shards
+  struct RowArena { void* p = nullptr; size_t cap = 0; uint32_t* col[11] = {};
+    void ensure(size_t n_rows) { const size_t need = 11 * n_rows * 4 + 64; if (need > cap) { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; const size_t want = need + need / 4;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw mkp::Error(MKP_E_NOMEM, "hipHostMalloc of the row arena failed"); } cap = want; }
+      for (int k = 0; k < 11; k++) col[k] = (uint32_t*)p + (size_t)k * n_rows; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; } } h_rows;
+  std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif; std::vector<uint32_t> h_key;
   // --partition-tag: tag names, the shard's key names (index = key id, 0 = "ungrouped"), the key ids present (one accumulate pass each)
   std::vector<std::string> partition_tags, key_names{"ungrouped"}; std::vector<const char*> key_name_ptrs; std::vector<uint32_t> key_passes{0xffffffffu};
   uint64_t n_ok = 0, n_bad = 0;
@@ -69,6 +75,8 @@ struct mkp_ctx {
 // threshold sampling pass on the device (decode kernel in sample mode); `recs` need not pass Packer::keep
 int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const mkp_record* recs,
                         uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals);
+int mkp_internal_sample_resident(mkp_ctx* c, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const uint32_t* reads, uint32_t n, bool only_mapped,
+                                 std::vector<uint32_t>* n_vals);   // the same pass over reads of the device-packed shard attached to the context
 int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take);
 void mkp_internal_bedmask_reset(mkp_ctx* c);   // a new sampling session: host mask pointers of the last one mean nothing any more
 // summary mode: zero the device table / read it back (134 u64: table[4][2][16] then reads_with[6])

@@ -94,9 +94,43 @@ SampleTimes g_sample_times;   // --stats: where the threshold estimate's time we
 // The values are accumulated in the context's HBM-resident sample (mkp_internal_sample_take); nothing but per-read counts
 // comes back to the host.  With --gpus-world W > 1 (full-data mode `-f 1.0` only) a rank walks just its own sampling intervals:
 // a read is taken in the first processed interval it overlaps, so the union over ranks is the single-rank sample.
-void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
+// The records of one fetch as the sampler sees them: a BamBatch of the indexed / whole-file reader, or — `res`: the shard the device ingest
+// attached to the context covers the contig — indices into that shard's digest (every kept record is a candidate; names are compared
+// through their two 64-bit hashes; the reads' bases and tags are in HBM already, mkp_internal_sample_resident).
+struct RecSet {
+  std::unique_ptr<BamBatch> b; const ShardHost* S = nullptr; std::vector<uint32_t> idx;
+  size_t size() const { return S ? idx.size() : b->recs.size(); }
+  bool truncated(size_t cap) const { return !S && b->recs.size() >= cap; }
+  std::string name(size_t i) const {
+    if (S) { char k[16]; memcpy(k, &S->name_hash[idx[i]], 8); memcpy(k + 8, &S->dev_name_hash2[idx[i]], 8); return std::string(k, 16); }
+    return b->qname(b->recs[i]);
+  }
+  int32_t pos(size_t i) const { return S ? S->hdr[idx[i]].ref_start : b->recs[i].pos; }
+  bool candidate(size_t i, bool drop_unmapped) const {
+    if (S) return true;
+    const BamIndexEntry& e = b->recs[i];
+    if ((e.flag & (256 | 1024 | 2048)) || b->l_seq(e) == 0) return false;
+    return !(drop_unmapped && (e.flag & 4));
+  }
+};
+
+void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf, const ShardHost* res = nullptr) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
+  if (res && (!only_mapped || sharded || res->dev_sample_only)) throw Error(MKP_E_INVALID, "internal: resident sampling needs mapped-only, single-rank sampling and no sampler-only records");
+  std::vector<int32_t> res_pmax;   // resident shard: prefix maximum of the alignment ends (first record that can reach an interval)
+  if (res) { res_pmax.resize(res->hdr.size()); int32_t m = INT32_MIN; for (size_t i = 0; i < res->hdr.size(); i++) { m = std::max(m, std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1)); res_pmax[i] = m; } }
+  auto fetch_set = [&](uint32_t tid, uint32_t s, uint32_t e, size_t cap) {
+    RecSet r;
+    if (res) {
+      if ((int32_t)tid != res->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the attached contig");
+      r.S = res;
+      size_t first = (size_t)(std::upper_bound(res_pmax.begin(), res_pmax.end(), (int32_t)std::min<uint32_t>(s, 0x7fffffffu)) - res_pmax.begin());
+      for (size_t i = first; i < res->hdr.size() && (int64_t)res->hdr[i].ref_start < (int64_t)e; i++) if ((int64_t)std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1) > (int64_t)s) r.idx.push_back((uint32_t)i);
+      return r;
+    }
+    r.b.reset(new BamBatch()); bam.fetch(tid, s, e, r.b.get(), cap); return r;
+  };
   mkp_internal_bedmask_reset(ctx);
   struct MaskSession { mkp_ctx* c; ~MaskSession() { mkp_internal_bedmask_reset(c); } } mask_session{ctx};   // the host masks below die with this call
   if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED,
@@ -143,13 +177,13 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   // `skip` (rank-sharded mode): candidates an earlier interval already took.  State across calls: used / n_reads_out.
   struct TakeState { size_t used = 0, n_reads_out = 0; };
   // the sampler's verdict on candidates cand[lo, hi) whose value counts are nv[0 ..): mask[k] = 1 where the read's values enter the sample
-  auto decide = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen,
+  auto decide = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen,
       TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask) {
     for (size_t i = lo; i < hi; i++) {
       if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
       const size_t k = i - lo;
       if (skip && (*skip)[i]) continue;
-      std::string name = batch.qname(batch.recs[cand[i]]);
+      std::string name = batch.name(cand[i]);
       // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
       // but keeps no position is asked, not counted, and not recorded
       if (interval_seen->count(name)) continue;
@@ -160,28 +194,34 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       mask[k] = 1;
     }
   };
-  auto take = [&](const BamBatch& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen,
+  // decode the records `which` (indices into the sets' records, set by set) in sampling mode: one device round
+  auto sample_round = [&](const std::vector<std::pair<const RecSet*, size_t>>& which, uint32_t tid, bool mapped_contig, std::vector<uint32_t>* nv) {
+    const uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1; const uint8_t* mask = mapped_contig ? bedmask_for(tid) : nullptr;
+    int rc;
+    if (res) { std::vector<uint32_t> ids; ids.reserve(which.size()); for (auto& w : which) ids.push_back(w.first->idx[w.second]);
+      rc = mkp_internal_sample_resident(ctx, ws, we, mask, ids.data(), (uint32_t)ids.size(), only_mapped, nv); }
+    else { std::vector<mkp_record> recs; recs.reserve(which.size()); for (auto& w : which) recs.push_back(w.first->b->view(w.first->b->recs[w.second]));
+      rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mask, recs.data(), (uint32_t)recs.size(), only_mapped, nv); }
+    if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+  };
+  auto take = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen,
       TakeState* ts, const std::vector<uint8_t>* skip = nullptr) {
     size_t next = from;
     while (next < cand.size() && (limit < 0 || ts->used < (size_t)limit)) {
       size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - ts->used));
       size_t hi = std::min(cand.size(), next + want);
-      std::vector<mkp_record> recs; for (size_t i = next; i < hi; i++) recs.push_back(batch.view(batch.recs[cand[i]]));
-      std::vector<uint32_t> nv; uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1;
-      int rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mapped_contig ? bedmask_for(tid) : nullptr, recs.data(), (uint32_t)recs.size(),
-          only_mapped, &nv);
-      if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
-      std::vector<uint8_t> mask(recs.size(), 0);
+      std::vector<std::pair<const RecSet*, size_t>> which; which.reserve(hi - next); for (size_t i = next; i < hi; i++) which.push_back({&batch, cand[i]});
+      std::vector<uint32_t> nv; sample_round(which, tid, mapped_contig, &nv);
+      std::vector<uint8_t> mask(which.size(), 0);
       decide(batch, cand, next, hi, nv.data(), limit, interval_seen, ts, skip, mask.data());
-      rc = mkp_internal_sample_take(ctx, mask);
+      int rc = mkp_internal_sample_take(ctx, mask);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       next = hi;
     }
   };
-  auto candidates = [&](const BamBatch& batch, std::vector<size_t>* out) {
+  auto candidates = [&](const RecSet& batch, std::vector<size_t>* out) {
     out->clear();
-    for (size_t i = 0; i < batch.recs.size(); i++) { const BamIndexEntry& e = batch.recs[i]; if ((e.flag & (256 | 1024 | 2048)) || batch.l_seq(e) == 0) continue;
-        if ((only_mapped || a.edge_filter.size()) && (e.flag & 4)) continue; out->push_back(i); }
+    for (size_t i = 0; i < batch.size(); i++) if (batch.candidate(i, only_mapped || a.edge_filter.size())) out->push_back(i);
   };
   if (!contigs.empty()) {
     // ReferenceIntervalsFeeder over the sampling grid, batch_size super-batches (interval_chunks.rs:563-643)
@@ -230,13 +270,12 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         mine.push_back(gi);
       }
       auto cap_of = [&](const G& g) { return g.q.all ? SIZE_MAX : 2 * g.q.n + 128; };
-      auto head_of = [&](size_t gi) { std::unique_ptr<BamBatch> b(new BamBatch()); bam.fetch(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, b.get(),
-          cap_of(grouped[gi])); return b; };
-      auto skip_for = [&](const G& g, const BamBatch& batch, const std::vector<size_t>& cand, std::vector<uint8_t>* skip) {
+      auto head_of = [&](size_t gi) { return std::unique_ptr<RecSet>(new RecSet(fetch_set(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, cap_of(grouped[gi])))); };
+      auto skip_for = [&](const G& g, const RecSet& batch, const std::vector<size_t>& cand, std::vector<uint8_t>* skip) {
         skip->assign(cand.size(), 0);   // rank-sharded mode: a read that reaches back into an earlier processed interval of this contig was taken there
         for (size_t i = 0; i < cand.size(); i++) {
-          const BamIndexEntry& e = batch.recs[cand[i]];
-          for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && (int64_t)e.pos < s1;) {   // grid intervals before this one, nearest first
+          const int64_t e_pos = batch.pos(cand[i]);
+          for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && e_pos < s1;) {   // grid intervals before this one, nearest first
             const int64_t s0 = std::max<int64_t>((int64_t)contig_start[g.iv.tid], s1 - (int64_t)a.sampling_interval_size);
             if (!bf || bf->overlaps(g.iv.tid, (uint64_t)s0, (uint64_t)s1)) { (*skip)[i] = 1; break; }
             s1 = s0;
@@ -244,15 +283,15 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         }
       };
       // the rest of an interval after its head (or all of it in full-data mode): sequential device rounds
-      auto finish_interval = [&](const G& g, std::unique_ptr<BamBatch>& head, const std::vector<size_t>& head_cand, size_t head_done,
+      auto finish_interval = [&](const G& g, std::unique_ptr<RecSet>& head, const std::vector<size_t>& head_cand, size_t head_done,
           const std::vector<uint8_t>& head_skip, std::set<std::string>* seen, TakeState* ts) {
         const long limit = g.q.all ? -1 : (long)g.q.n;
         take(*head, head_cand, head_done, limit, g.iv.tid, true, seen, ts, sharded ? &head_skip : nullptr);
-        const bool truncated = head->recs.size() >= cap_of(g);
+        const bool truncated = head->truncated(cap_of(g));
         if (!truncated || (limit >= 0 && ts->used >= (size_t)limit)) return;
-        const size_t done = head->recs.size();
+        const size_t done = head->size();
         head.reset();
-        BamBatch whole; bam.fetch(g.iv.tid, g.iv.start, g.iv.end, &whole, SIZE_MAX);   // the head was not enough: the whole interval, records already seen skipped
+        const RecSet whole = fetch_set(g.iv.tid, g.iv.start, g.iv.end, SIZE_MAX);   // the head was not enough: the whole interval, records already seen skipped
         std::vector<size_t> cand; candidates(whole, &cand);
         std::vector<uint8_t> skip; if (sharded) skip_for(g, whole, cand, &skip);
         size_t from = 0; while (from < cand.size() && cand[from] < done) from++;
@@ -262,14 +301,14 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       // 8 consecutive intervals of one contig are fetched concurrently and decoded in ONE device round; the sampler's first-N logic
       // then runs over them in interval order.  An interval its head does not satisfy is finished sequentially before the
       // following ones are judged (their reads may already be taken by it), and the remaining heads are decoded again.
-      struct Pending { size_t gi; std::unique_ptr<BamBatch> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen;
+      struct Pending { size_t gi; std::unique_ptr<RecSet> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen;
           TakeState ts; };
       for (size_t mi = 0; mi < mine.size();) {
         const G& g0 = grouped[mine[mi]];
         size_t mj = mi + 1;
         if (!g0.q.all) while (mj < mine.size() && mj - mi < 8 && !grouped[mine[mj]].q.all && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;
-        std::vector<std::future<std::unique_ptr<BamBatch>>> futs;
-        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(std::launch::async, head_of, mine[k]));
+        std::vector<std::future<std::unique_ptr<RecSet>>> futs;
+        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(res ? std::launch::deferred : std::launch::async, head_of, mine[k]));   // (resident: a scan of the digest, no fetch to overlap)
         std::vector<Pending> pend(mj - mi);
         for (size_t k = mi; k < mj; k++) {
           Pending& P = pend[k - mi]; P.gi = mine[k];
@@ -281,14 +320,13 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         if (g0.q.all) { finish_interval(g0, pend[0].head, pend[0].cand, 0, pend[0].skip, &pend[0].seen, &pend[0].ts); batch_counts[g0.iv.tid] += pend[0].ts.n_reads_out;
             mi = mj; continue; }
         for (size_t k0 = 0; k0 < pend.size();) {
-          std::vector<mkp_record> recs; std::vector<size_t> at(pend.size() + 1, 0);
+          std::vector<std::pair<const RecSet*, size_t>> recs; std::vector<size_t> at(pend.size() + 1, 0);
           for (size_t k = k0; k < pend.size(); k++) { at[k] = recs.size();
-              for (size_t i = 0; i < pend[k].n_first; i++) recs.push_back(pend[k].head->view(pend[k].head->recs[pend[k].cand[i]])); }
+              for (size_t i = 0; i < pend[k].n_first; i++) recs.push_back({pend[k].head.get(), pend[k].cand[i]}); }
           at[pend.size()] = recs.size();
           std::vector<uint32_t> nv;
           auto t_d = std::chrono::steady_clock::now();
-          int rc = mkp_internal_sample(ctx, (int32_t)g0.iv.tid, 0, bam.ref_lens[g0.iv.tid], bedmask_for(g0.iv.tid), recs.data(), (uint32_t)recs.size(), only_mapped, &nv);
-          if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+          sample_round(recs, g0.iv.tid, true, &nv);
           g_sample_times.device_ms += ms_since(t_d); g_sample_times.rounds++; g_sample_times.reads += recs.size();
           auto t_h = std::chrono::steady_clock::now();
           std::vector<uint8_t> mask(recs.size(), 0);
@@ -296,13 +334,12 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
           for (size_t k = k0; k < pend.size(); k++) {
             Pending& P = pend[k]; const G& g = grouped[P.gi];
             decide(*P.head, P.cand, 0, P.n_first, nv.data() + at[k], (long)g.q.n, &P.seen, &P.ts, sharded ? &P.skip : nullptr, mask.data() + at[k]);
-            const bool more = P.n_first < P.cand.size() || P.head->recs.size() >= cap_of(g);
+            const bool more = P.n_first < P.cand.size() || P.head->truncated(cap_of(g));
             if (P.ts.used < g.q.n && more) { unsatisfied = k; break; }   // the judgement of the later heads waits for this interval
           }
           g_sample_times.decide_ms += ms_since(t_h);
           t_d = std::chrono::steady_clock::now();
-          rc = mkp_internal_sample_take(ctx, mask);
-          if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+          { const int rc = mkp_internal_sample_take(ctx, mask); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx)); }
           g_sample_times.device_ms += ms_since(t_d);
           if (unsatisfied == pend.size()) break;
           Pending& P = pend[unsatisfied];
@@ -316,7 +353,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     }
   }
   if ((sched_unmapped || taken.size() < 100) && !only_mapped && a.rank == 0) {  // reads_sampler/mod.rs:89-125 (rank-sharded: rank 0 takes the unmapped reads)
-    BamBatch batch; bam.fetch_unmapped(&batch);
+    RecSet batch; batch.b.reset(new BamBatch()); bam.fetch_unmapped(batch.b.get());
     std::vector<size_t> cand; candidates(batch, &cand);
     long limit;
     if (!a.have_frac) limit = (long)(a.num_reads > taken.size() ? a.num_reads - taken.size() : 0);
@@ -415,7 +452,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (a.hemi) combine_strands = true;
       // the interval feeder runs with combine_strands = true ("must be true for duplex", subcommand.rs:1383-1390); the caller's flag stays off
   FocusBuilder fb; fb.combine = combine_strands; fb.mask = a.mask; fb.bed = bf;
-  Fasta fasta;
+  Fasta fasta; std::future<Fasta> fasta_load;
+  struct JoinFasta { std::future<Fasta>* f; ~JoinFasta() { if (f->valid()) f->wait(); } } join_fasta{&fasta_load};
   if (!a.motif_parts.empty()) {  // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
     if (!a.preset.empty()) throw Error(MKP_E_INVALID, "cannot use presets and motifs together");
     std::vector<std::string> parts = a.motif_parts;
@@ -430,8 +468,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "reference fasta is required for using --motif or --cpg options");
     if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID,
         a.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
-    fasta = Fasta::load(a.ref_fasta); fb.fasta = &fasta;
-    mark("reference FASTA loaded");
+    fasta_load = std::async(std::launch::async, [&]() { return Fasta::load(a.ref_fasta); });   // joined where the grid walk needs it: the device ingest of the first shard starts meanwhile
   }
   mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
   mkp_ctx* ctx = ext_ctx;
@@ -484,13 +521,25 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // The first shard's blocks are read and inflated behind the threshold estimate (background priority on the host pool: the estimate's
   // own bursts go first), as soon as the first contig's grid is known.
   std::future<ShardInput> early_fetch; uint32_t early_s0 = 0, early_s1 = 0; bool early_set = false;
+  // One target contig that fits one shard whatever its grid turns out to be: the device ingest of that window starts now, before the
+  // reference is read and the grid walked (if the grid's one shard is not this window after all, the ingest is repeated for the plan's)
+  bool early_whole = false;
+  if (dev_ingest && a.world == 1 && records.size() == 1 && records[0].length > 0 && !getenv("MKP_NO_EARLY_FETCH")) {
+    const Contig& r0 = records[0];
+    if (r0.length <= shard_bp && bam.offset_at(r0.tid, r0.end()) - bam.offset_at(r0.tid, r0.start) <= shard_bytes) {
+      early_s0 = r0.start; early_s1 = r0.end(); early_set = true; early_whole = true;
+      early_fetch = std::async(std::launch::async, fetch_range, r0.tid, early_s0, early_s1);
+    }
+  }
+  struct JoinFetch { std::future<ShardInput>* f; ~JoinFetch() { if (f->valid()) f->wait(); } } join_fetch{&early_fetch};
+  if (fasta_load.valid()) { fasta = fasta_load.get(); fb.fasta = &fasta; mark("reference FASTA loaded"); }
   std::future<void> early_walk;
   if (fb.has_focus() && a.world == 1 && !a.plan_only && a.filter_threshold.empty() && !a.no_filtering)
     early_walk = std::async(std::launch::async, [&]() {
       auto t_focus = std::chrono::steady_clock::now();
       for (size_t ri = 0; ri < records.size(); ri++) {
         grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1;
-        if (ri == 0 && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {
+        if (ri == 0 && !early_whole && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {
           uint64_t bp; const size_t i1 = shard_cut(records[0], grid_of[0], 0, &bp);
           early_s0 = grid_of[0][0].start; early_s1 = grid_of[0][i1 - 1].end; early_set = true;
           early_fetch = std::async(std::launch::async, fetch_range, records[0].tid, early_s0, early_s1);
@@ -502,7 +551,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       // (an exception below must not leave the walker running on dead locals)
   // thresholds (subcommand.rs:615-638)
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
-  double thr_ms = 0;
+  double thr_ms = 0, fetch_wait_early_ms = 0;
+  ShardInput early_in; bool early_in_ready = false, pre_attached = false; std::unique_ptr<DevShard> pre_dev;   // the first shard's records, taken before the loop
   if (!a.filter_threshold.empty()) parse_base_thresholds(a.filter_threshold, &kc);
   else if (a.no_filtering || a.plan_only) { kc.n_per_mod = 0; }  // MultipleThresholdModCaller::new_passthrough
   else {
@@ -514,13 +564,44 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     Args as = a; as.world = 1; as.rank = 0;
     must(mkp_histogram_begin(ctx));
     g_sample_times = SampleTimes();
-    sample_probabilities(ctx, bam, as, sr, bf);
+    // The one shard of the run is being ingested on the device and every read the schedule can ask for lies in it: the estimate waits for
+    // it and samples from HBM (the heads are scans of the shard's digest, a round is one launch over reads that are already packed)
+    // instead of fetching, inflating and packing interval heads on the host next to the ingest.
+    const ShardHost* resident = nullptr;
+    if (early_whole && !have_sregion && !a.include_unmapped && !getenv("MKP_NO_RESIDENT_SAMPLING")) {
+      bool only_this = true; { const IdxStats stx = idxstats(bam, sr, bf); for (auto& kv : stx.mapped_by_tid) if (kv.second && kv.first != (int64_t)records[0].tid) only_this = false; }
+      if (only_this) {
+        mark("resident sampling: waiting for the grid");
+        if (early_walk.valid()) early_walk.get();
+        else if (!grid_done[0]) { auto t_focus = std::chrono::steady_clock::now(); grid_of[0] = fb.walk(records[0], a.interval_size, fb.has_focus() ? &focus_of[0] : nullptr); grid_done[0] = 1;
+          if (fb.has_focus()) focus_done[0] = 1; focus_ms += ms_since(t_focus); }
+        const std::vector<Interval>& ivs = grid_of[0]; uint64_t bp = 0;
+        if (!ivs.empty() && shard_cut(records[0], ivs, 0, &bp) == ivs.size() && ivs.front().start == early_s0 && ivs.back().end == early_s1) {
+          auto t_w = std::chrono::steady_clock::now();
+          mark("resident sampling: waiting for the ingest");
+          early_in = early_fetch.get(); early_in_ready = true;
+          fetch_wait_early_ms = ms_since(t_w);
+          mark("resident sampling: ingest in hand");
+          if (early_in.dev && early_in.dev->S.dev_sample_only == 0) {
+            mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)records[0].tid; sh.start = early_s0; sh.end = early_s1;
+            if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+            must(mkp_shard_begin(ctx, &sh));
+            pre_dev = std::move(early_in.dev); early_in_ready = false;
+            must(mkp_internal_shard_attach(ctx, pre_dev.get())); mkp_internal_ingest_recycle(ctx->ingest, pre_dev.get());
+            pre_attached = true; resident = &ctx->shard;
+            mark("first shard attached (resident sampling)");
+          }
+        }
+      }
+    }
+    sample_probabilities(ctx, bam, as, sr, bf, resident);
+    mark("schedule walked, sample in HBM");
     if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n",
         g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms,
         g_sample_times.decide_ms);
     { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1;
         kc.per_base_threshold[b] = thr[b]; } }
-    thr_ms = ms_since(t0);
+    thr_ms = ms_since(t0) - fetch_wait_early_ms;
   }
   mark("thresholds done");
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
@@ -589,13 +670,18 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<ShardInput> next_batch;
-  const bool early_ok = early_set && early_fetch.valid() && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
-  if (early_ok) next_batch = std::move(early_fetch);
+  const bool early_match = early_set && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
+  if (pre_attached && !(early_match && plan.size() == 1)) throw Error(MKP_E_INVALID, "internal: the shard attached for resident sampling is not the plan's");
+  if (pre_attached) { fetch_wait_ms += fetch_wait_early_ms; }
+  else if (early_match && early_in_ready) { fetch_wait_ms += fetch_wait_early_ms; next_batch = std::async(std::launch::deferred, [&]() { return std::move(early_in); }); }
+  else if (early_match && early_fetch.valid()) next_batch = std::move(early_fetch);
   else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }
   for (size_t pi = 0; pi < plan.size(); pi++) {
     const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
     std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev;
-    { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev); fetch_wait_ms += ms_since(t_f); }
+    const bool attached_already = pre_attached && pi == 0;
+    if (attached_already) dev = std::move(pre_dev);
+    else { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev); fetch_wait_ms += ms_since(t_f); }
     if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack; ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
                ingest_records += dev->n_records; }
     if (pi + 1 < plan.size()) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
@@ -627,9 +713,12 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
       if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
       mark("shard blocks in hand");
-      must(mkp_shard_begin(ctx, &sh));
-      if (dev) { must(mkp_internal_shard_attach(ctx, dev.get())); mkp_internal_ingest_recycle(ctx->ingest, dev.get()); dev.reset(); }
-      else must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
+      if (attached_already) dev.reset();   // begun and attached before the threshold estimate, which sampled from it
+      else {
+        must(mkp_shard_begin(ctx, &sh));
+        if (dev) { must(mkp_internal_shard_attach(ctx, dev.get())); mkp_internal_ingest_recycle(ctx->ingest, dev.get()); dev.reset(); }
+        else must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
+      }
       mark("shard packed");
       batch.reset();   // packed: the inflated blocks are no longer needed (their mappings are parked for the next fetch, ByteBuf::spares)
       mkp_rows rows; memset(&rows, 0, sizeof(rows));

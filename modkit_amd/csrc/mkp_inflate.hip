@@ -192,6 +192,201 @@ mkp_inflate_blocks(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restric
   status[bi] = err;
 }
 
+// ---- second edition of the one-thread-per-block decoder (round 4).  Same tables and symbol decode; what changed is the memory traffic of
+// a lane, which is what a block's 100 ms were made of (every global access of the first edition is a round trip of one lane with nothing
+// else to run meanwhile):
+//   * input: the next aligned qword is always in flight (two-qword window), a refill is register work;
+//   * literals gather in a register and leave as one store per eight (loads and stores share vmcnt on gfx9: a wait for a load also drains
+//     every store behind it);
+//   * LZ77 copies never read what the same copy wrote: dist >= len reads its source four qwords at a time ahead of the stores;
+//     dist < 8 builds the repeating pattern in a register once and only stores; 8 <= dist < len reads the `dist` source bytes cyclically.
+//     Tails are byte stores out of a register, not byte round trips.
+// Reads may run up to 7 bytes past a block's output slice (never written there): the output buffer carries that slack at its end.
+namespace {
+struct Bits2 {
+  const uint8_t* p; uint32_t n; uint32_t at;        // block input; next unread byte
+  unsigned long long cur, nxt; uint32_t q;           // qwords q and q + 1 of the input (zero past the end)
+  unsigned long long buf; uint32_t cnt; bool over;
+  __device__ __forceinline__ unsigned long long load_q(uint32_t qi) const {
+    const uint32_t off = qi * 8u;
+    if (off + 8u <= n) { unsigned long long v; __builtin_memcpy(&v, p + off, 8); return v; }
+    unsigned long long v = 0; for (uint32_t k = 0; k < 8u; k++) if (off + k < n) v |= (unsigned long long)p[off + k] << (8u * k);
+    return v;
+  }
+  __device__ __forceinline__ void init() { at = 0; q = 0; cur = load_q(0); nxt = load_q(1); buf = 0; cnt = 0; over = false; }
+  __device__ __forceinline__ void fill() {            // whole bytes that fit above the `cnt` bits held
+    const uint32_t avail = at < n ? n - at : 0u;
+    uint32_t take = (63u - cnt) >> 3; if (take > avail) take = avail;
+    if (!take) return;
+    const uint32_t sh = (at & 7u) * 8u;
+    unsigned long long v = cur >> sh; if (sh) v |= nxt << (64u - sh);
+    if (take < 8u) v &= (1ull << (8u * take)) - 1ull;
+    buf |= v << cnt; cnt += take * 8u; at += take;
+    if ((at >> 3) != q) { q++; cur = nxt; nxt = load_q(q + 1u); }   // (take <= 7: at most one qword boundary is crossed)
+  }
+  __device__ __forceinline__ uint32_t get(uint32_t k) {   // k <= 16
+    if (cnt < k) { fill(); if (cnt < k) { over = true; return 0; } }
+    const uint32_t v = (uint32_t)(buf & ((1ull << k) - 1ull)); buf >>= k; cnt -= k; return v;
+  }
+};
+__device__ __forceinline__ int decode_sym2(Bits2& b, const Code& h) {
+  if (b.cnt < 15u) b.fill();
+  uint32_t bits = (uint32_t)b.buf; const uint32_t avail = b.cnt;
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; len++) {
+    code |= (int)(bits & 1u); bits >>= 1;
+    const int count = h.count[len];
+    if (code - count < first) {
+      if ((uint32_t)len > avail) { b.over = true; return -1; }
+      b.buf >>= len; b.cnt -= (uint32_t)len;
+      return h.sym(index + (code - first));
+    }
+    index += count; first += count; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+__device__ __forceinline__ unsigned long long ld8(const uint8_t* p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ void st8(uint8_t* p, unsigned long long v) { __builtin_memcpy(p, &v, 8); }
+__device__ __forceinline__ void st_tail(uint8_t* p, unsigned long long v, uint32_t n) { for (uint32_t j = 0; j < n; j++) p[j] = (uint8_t)(v >> (8u * j)); }   // n < 8
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(MKP_INFLATE_THREADS)
+mkp_inflate_blocks2(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) uint8_t tab[MKP_INFLATE_THREADS][MKP_INFLATE_TAB_BYTES];
+  const uint32_t bi = blockIdx.x * MKP_INFLATE_THREADS + threadIdx.x;
+  if (bi >= n_blocks) return;
+  const MkpBgzfBlock bk = blocks[bi];
+  uint8_t* t = tab[threadIdx.x];
+  const Code lencode{reinterpret_cast<uint16_t*>(t), t + 112, reinterpret_cast<uint32_t*>(t + 64)};
+  const Code distcode{reinterpret_cast<uint16_t*>(t + 32), t + 400, reinterpret_cast<uint32_t*>(t + 104)};
+  uint8_t lengths[320];
+  Bits2 b; b.p = in + bk.in_off; b.n = bk.in_len; b.init();
+  uint8_t* o = out + bk.out_off;
+  const uint32_t cap = bk.out_len;
+  uint32_t w = 0, err = 0;
+  unsigned long long lit = 0; uint32_t nlit = 0;   // literals not stored yet: output bytes [w - nlit, w)
+  for (uint32_t guard = 0; guard <= bk.in_len && !err; guard++) {
+    const uint32_t last = b.get(1), type = b.get(2);
+    if (b.over) { err = 1; break; }
+    if (type == 0) {   // stored
+      const uint32_t drop = b.cnt & 7u; b.buf >>= drop; b.cnt -= drop;
+      const uint32_t len = b.get(16), nlen = b.get(16);
+      if (b.over) { err = 1; break; }
+      if ((len ^ 0xffffu) != nlen || w + len > cap) { err = 2; break; }
+      for (uint32_t k = 0; k < len; k++) { const uint32_t v = b.get(8); if (b.over) { err = 1; break; } o[w++] = (uint8_t)v; }
+    } else if (type == 1 || type == 2) {
+      if (type == 1) {
+        int s = 0;
+        for (; s < 144; s++) lengths[s] = 8;
+        for (; s < 256; s++) lengths[s] = 9;
+        for (; s < 280; s++) lengths[s] = 7;
+        for (; s < 288; s++) lengths[s] = 8;
+        construct(lencode, lengths, 288);
+        for (s = 0; s < 30; s++) lengths[s] = 5;
+        construct(distcode, lengths, 30);
+      } else {
+        const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
+        if (b.over) { err = 1; break; }
+        if (nlen > 286 || ndist > 30) { err = 3; break; }
+        int idx = 0;
+        for (; idx < ncode; idx++) lengths[cl_order(idx)] = (uint8_t)b.get(3);
+        for (; idx < 19; idx++) lengths[cl_order(idx)] = 0;
+        if (b.over) { err = 1; break; }
+        if (construct(lencode, lengths, 19) != 0) { err = 3; break; }
+        idx = 0;
+        while (idx < nlen + ndist) {
+          int sym = decode_sym2(b, lencode);
+          if (sym < 0) { err = b.over ? 1 : 4; break; }
+          if (sym < 16) lengths[idx++] = (uint8_t)sym;
+          else {
+            int len = 0, rep;
+            if (sym == 16) { if (idx == 0) { err = 3; break; } len = lengths[idx - 1]; rep = 3 + (int)b.get(2); }
+            else if (sym == 17) rep = 3 + (int)b.get(3);
+            else rep = 11 + (int)b.get(7);
+            if (b.over) { err = 1; break; }
+            if (idx + rep > nlen + ndist) { err = 3; break; }
+            while (rep--) lengths[idx++] = (uint8_t)len;
+          }
+        }
+        if (err) break;
+        if (lengths[256] == 0) { err = 3; break; }
+        int e1 = construct(lencode, lengths, nlen);
+        if (e1 < 0 || (e1 > 0 && nlen - lencode.count[0] != 1)) { err = 3; break; }
+        int e2 = construct(distcode, lengths + nlen, ndist);
+        if (e2 < 0 || (e2 > 0 && ndist - distcode.count[0] != 1)) { err = 3; break; }
+      }
+      for (uint32_t g2 = 0; g2 <= cap + 1u; g2++) {
+        const int sym = decode_sym2(b, lencode);
+        if (sym < 0) { err = b.over ? 1 : 4; break; }
+        if (sym < 256) {
+          if (w >= cap) { err = 6; break; }
+          lit |= (unsigned long long)(uint32_t)sym << (8u * nlit); nlit++; w++;
+          if (nlit == 8u) { st8(o + w - 8u, lit); lit = 0; nlit = 0; }
+        } else {
+          if (nlit) { st_tail(o + w - nlit, lit, nlit); lit = 0; nlit = 0; }
+          if (sym == 256) break;
+          const int ls = sym - 257;
+          if (ls >= 29) { err = 4; break; }
+          const uint32_t len = len_base(ls) + b.get(len_extra(ls));
+          const int ds = decode_sym2(b, distcode);
+          if (ds < 0 || ds >= 30) { err = b.over ? 1 : 4; break; }
+          const uint32_t dist = dist_base(ds) + b.get(dist_extra(ds));
+          if (b.over) { err = 1; break; }
+          if (dist > w) { err = 5; break; }
+          if (w + len > cap) { err = 6; break; }
+          const uint8_t* src = o + w - dist; uint8_t* dst = o + w;
+          if (dist >= len) {
+            uint32_t k = 0;
+            for (; k + 32u <= len; k += 32u) { const unsigned long long a0 = ld8(src + k), a1 = ld8(src + k + 8u), a2 = ld8(src + k + 16u), a3 = ld8(src + k + 24u);
+                                                st8(dst + k, a0); st8(dst + k + 8u, a1); st8(dst + k + 16u, a2); st8(dst + k + 24u, a3); }
+            if (k < len) {   // up to 31 bytes: all loads first (the last one may run past the source's end, into bytes that are not used)
+              const uint32_t r = len - k; unsigned long long a0 = ld8(src + k), a1 = 0, a2 = 0, a3 = 0;
+              if (r > 8u) a1 = ld8(src + k + 8u);
+              if (r > 16u) a2 = ld8(src + k + 16u);
+              if (r > 24u) a3 = ld8(src + k + 24u);
+              if (r >= 8u) st8(dst + k, a0); else st_tail(dst + k, a0, r);
+              if (r >= 16u) st8(dst + k + 8u, a1); else if (r > 8u) st_tail(dst + k + 8u, a1, r - 8u);
+              if (r >= 24u) st8(dst + k + 16u, a2); else if (r > 16u) st_tail(dst + k + 16u, a2, r - 16u);
+              if (r > 24u) st_tail(dst + k + 24u, a3, r - 24u);
+            }
+          } else if (dist < 8u) {
+            // the `dist` bytes before w repeat: eight bytes of that pattern in a register, stored at every multiple of the period
+            unsigned long long pat = ld8(src) & ((1ull << (8u * dist)) - 1ull);
+            for (uint32_t sft = dist; sft < 8u; sft <<= 1) pat |= pat << (8u * sft);
+            const uint32_t step = dist * (8u / dist);   // the largest multiple of the period within eight bytes
+            uint32_t k = 0;
+            for (; k + 8u <= len; k += step) st8(dst + k, pat);
+            if (k < len) st_tail(dst + k, pat, len - k);
+          } else {
+            // 8 <= dist < len: output byte k is source byte k mod dist; the source bytes are final, so no load waits for a store of this copy
+            uint32_t off = 0, k = 0;
+            for (; k < len; k += 8u) {
+              unsigned long long v;
+              if (off + 8u <= dist) v = ld8(src + off);
+              else { const uint32_t head = dist - off; v = (ld8(src + off) & ((1ull << (8u * head)) - 1ull)) | (ld8(src) << (8u * head)); }
+              if (k + 8u <= len) st8(dst + k, v); else st_tail(dst + k, v, len - k);
+              off += 8u; if (off >= dist) off -= dist;
+            }
+          }
+          w += len;
+        }
+      }
+      if (nlit) { st_tail(o + w - nlit, lit, nlit); lit = 0; nlit = 0; }
+    } else { err = 2; break; }
+    if (last) break;
+  }
+  if (!err && w != cap) err = 6;
+  status[bi] = err;
+}
+
+#ifndef MKP_INFLATE_HOST_SHIM
+extern "C" hipError_t mkp_launch_inflate2(hipStream_t st, const uint8_t* in, const MkpBgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status) {
+  if (!n_blocks) return hipSuccess;
+  hipLaunchKernelGGL(mkp_inflate_blocks2, dim3((n_blocks + MKP_INFLATE_THREADS - 1) / MKP_INFLATE_THREADS), dim3(MKP_INFLATE_THREADS), 0, st, in, blocks, n_blocks, out, status);
+  return hipGetLastError();
+}
+#endif
+
 #ifndef MKP_INFLATE_HOST_SHIM
 extern "C" hipError_t mkp_launch_inflate(hipStream_t st, const uint8_t* in, const MkpBgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status) {
   if (!n_blocks) return hipSuccess;

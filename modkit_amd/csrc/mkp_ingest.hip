@@ -91,6 +91,7 @@ mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const unsig
     sz[2 * (size_t)P.rec_cap + i] = k ? ingest_chunk_pairs(R.n_cigar) : 0u;
     sz[3 * (size_t)P.rec_cap + i] = k ? ingest_seq_bytes(R.l_seq) : 0u;
     sz[4 * (size_t)P.rec_cap + i] = k ? R.ml_n : 0u;
+    if (R.kind == 3) atomicAdd(&tot->n_sample_only, 1u);
     if (R.kind == 2) { const uint32_t at = atomicAdd(&tot->n_extra, 1u); extra[2 * (size_t)at] = R.pos;
       const long long e = (long long)R.pos + (R.reflen > 0 ? R.reflen : 1); extra[2 * (size_t)at + 1] = (int32_t)(e > 0x7fffffffll ? 0x7fffffffll : e); }
   }

@@ -52,7 +52,7 @@ struct MkpRecInfo {             // 48 B
   unsigned long long core;      // offset of the 32-byte core in the window (block_size sits 4 bytes before it)
   int32_t pos, reflen;
   uint32_t l_seq, bs;           // block_size
-  uint16_t n_cigar, flag; uint8_t l_qname, kind, pad0, pad1;   // kind: 0 dropped, 1 kept, 2 span only (supplementary: max-depth guard)
+  uint16_t n_cigar, flag; uint8_t l_qname, kind, pad0, pad1;   // kind: 0 dropped, 1 kept, 2 span only (supplementary: max-depth guard), 3 sampler-only
   uint32_t mm, ml, mn;          // offsets of the aux values' TYPE bytes from the core (0 = absent): MM|Mm, ML|Ml, MN
   uint32_t ml_n;                // elements of the ML array when it is B:C
 };
@@ -62,6 +62,7 @@ struct MkpIngestTotals {
   uint32_t err, n_all, n_kept, n_extra;
   unsigned long long cigar_words, chunk_pairs, seq_bytes, ml_bytes;   // capacities of the packed arrays (exclusive-scan totals)
   unsigned long long n_calls, n_ml_used;
+  uint32_t n_sample_only, pad;   // records of the region the threshold sampler would consider but the pileup drops (QC-fail, no CIGAR)
 };
 
 // ---- CRC-32 joins (mkp_crc32_blocks): GF(2) polynomial arithmetic mod the gzip polynomial, bit-reflected operands (bit 31 = x^0)
@@ -117,7 +118,9 @@ MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, cons
   if (!in_region) { *out = R; return; }
   const bool masked = (R.flag & (4u | 256u | 512u | 1024u)) != 0;
   if (!masked && (R.flag & 2048u) && R.n_cigar) { R.kind = 2; *out = R; return; }
-  if (masked || (R.flag & 2048u) || lseq <= 0 || R.n_cigar == 0) { *out = R; return; }
+  if (masked || (R.flag & 2048u) || lseq <= 0 || R.n_cigar == 0) {
+    if (!(R.flag & (4u | 256u | 1024u | 2048u)) && lseq > 0) R.kind = 3;   // QC-fail or CIGAR-less: not in the pileup, but a candidate of the threshold sampler (reads_sampler: only secondary / duplicate / supplementary are dropped)
+    *out = R; return; }
   R.kind = 1;
   // aux walk
   const uint32_t aux0 = (uint32_t)fixed, aux_n = (uint32_t)bs - aux0;   // offsets from the core
@@ -263,7 +266,7 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
 }
 
 // per-record digest the host plans with (next to the record's MkpReadHdr and tag table)
-struct MkpRecDigest { unsigned long long name_hash, key_hash; };
+struct MkpRecDigest { unsigned long long name_hash, key_hash, name_hash2, pad; };   // name_hash2: a second, independent hash of the read name (128 bits identify a name in the sampler's sets)
 
 // Packer::add for one kept record: CIGAR words + chunk prefixes, SEQ bytes, tags; writes the header with the offsets the scan gave.
 MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t j, uint32_t cigar_off, uint32_t chunk_off, uint32_t seq_off, uint32_t ml_off,
@@ -288,7 +291,8 @@ MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32
   for (uint32_t k = 0; k < nb; k++) seq[seq_off + k] = sq[k];
   for (uint32_t k = nb; k < nbp; k++) seq[seq_off + k] = 0;
   h.flags = (R.flag & 16u) ? MKP_RF_REVERSE : 0u;
-  { unsigned long long hh = 1469598103934665603ull; for (int i = 0; i + 1 < (int)R.l_qname; i++) { hh ^= c[32 + i]; hh *= 1099511628211ull; } dig[j].name_hash = hh; }
+  { unsigned long long hh = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull; for (int i = 0; i + 1 < (int)R.l_qname; i++) { hh ^= c[32 + i]; hh *= 1099511628211ull; h2 = (h2 ^ c[32 + i]) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 29; }
+    dig[j].name_hash = hh; dig[j].name_hash2 = h2; dig[j].pad = 0; }
   MkpTokOut t;
   for (uint32_t k = 0; k < MKP_MAX_TAGS; k++) { MkpTagRef z; z.rank_off = 0; z.n = 0; z.ml_off = 0; z.pad = 0; tagref[h.tag_off + k] = z; }
   const bool ok = ingest_tokenise(c, R, ranks + ml_off, ml + ml_off, tagref + h.tag_off, ml_off, ml_off, &t, &tot->err);

@@ -84,14 +84,12 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   auto t0 = std::chrono::steady_clock::now();
   std::unique_ptr<DevShard> out(new DevShard());
   ShardHost& S = out->S; S.tid = (int32_t)tid; S.dev_packed = true;
-  BamSource::IngestPlan plan; bam.ingest_plan(tid, beg, end, &plan);
-  out->ms_plan = ms_since(t0);
-  if (plan.ranges.empty() || plan.raw_total == 0) return out;   // nothing under the region: an empty shard
-  if (plan.blks.size() > 0xfffffff0ull || plan.entries.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");
+  BamSource::IngestPlan plan; bam.ingest_ranges(tid, beg, end, &plan);
+  if (plan.ranges.empty()) return out;   // nothing under the region: an empty shard
   auto ok = [](hipError_t e, const char* what) { if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string("device ingest: ") + what + ": " + hipGetErrorString(e)); };
   ok(hipSetDevice(d->device), "hipSetDevice");
-  // ---- the compressed ranges go up piece by piece: pread into page-locked staging on all cores, async H2D behind them
-  auto t_up = std::chrono::steady_clock::now();
+  // ---- the compressed ranges go up piece by piece — pread into page-locked staging on all cores, async H2D behind them — on a helper
+  // thread, while this one walks the block headers (the upload needs the file ranges only)
   std::vector<uint64_t> zbase(plan.ranges.size()); uint64_t zbytes = 0;
   for (size_t r = 0; r < plan.ranges.size(); r++) { zbase[r] = zbytes; zbytes += (plan.ranges[r].file_len + 63) & ~63ull; }
   d->zin.ensure(zbytes + 64);
@@ -101,21 +99,37 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     pieces.push_back({plan.ranges[r].file_off + o, zbase[r] + o, (size_t)std::min<uint64_t>(mkp_dev_ingest::kPiece, plan.ranges[r].file_len - o)});
   d->stage.ensure(2 * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece);
   const int fd = bam.fd();
-  std::atomic<bool> read_bad{false};
-  for (size_t p0 = 0, round = 0; p0 < pieces.size(); p0 += mkp_dev_ingest::kSlots, round++) {
-    const size_t half = round & 1, n = std::min(mkp_dev_ingest::kSlots, pieces.size() - p0);
-    if (round >= 2) ok(hipEventSynchronize(d->slot_ev[half]), "staging wait");   // the copies that last used this half are done
-    uint8_t* base = (uint8_t*)d->stage.p + half * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece;
-    HostPool::get().parallel(n, [&](size_t k) {
-      const Piece& pc = pieces[p0 + k]; uint8_t* dst = base + k * mkp_dev_ingest::kPiece; size_t got = 0;
-      while (got < pc.n) { const ssize_t r = ::pread(fd, dst + got, pc.n - got, (off_t)(pc.file_off + got)); if (r <= 0) { read_bad = true; return; } got += (size_t)r; }
-    });
-    if (read_bad) throw Error(MKP_E_IO, "read error on " + bam.path());
-    for (size_t k = 0; k < n; k++) ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, pieces[p0 + k].n, hipMemcpyHostToDevice, d->up_stream), "H2D");
-    ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
-  }
-  ok(hipEventRecord(d->up_done, d->up_stream), "event");
+  std::unique_ptr<Error> up_err; double up_ms = 0;
+  std::thread uploader([&]() {
+    auto t_up = std::chrono::steady_clock::now();
+    try {
+      ok(hipSetDevice(d->device), "hipSetDevice");
+      std::atomic<bool> read_bad{false};
+      for (size_t p0 = 0, round = 0; p0 < pieces.size(); p0 += mkp_dev_ingest::kSlots, round++) {
+        const size_t half = round & 1, n = std::min(mkp_dev_ingest::kSlots, pieces.size() - p0);
+        if (round >= 2) ok(hipEventSynchronize(d->slot_ev[half]), "staging wait");   // the copies that last used this half are done
+        uint8_t* base = (uint8_t*)d->stage.p + half * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece;
+        HostPool::get().parallel(n, [&](size_t k) {
+          const Piece& pc = pieces[p0 + k]; uint8_t* dst = base + k * mkp_dev_ingest::kPiece; size_t got = 0;
+          while (got < pc.n) { const ssize_t r = ::pread(fd, dst + got, pc.n - got, (off_t)(pc.file_off + got)); if (r <= 0) { read_bad = true; return; } got += (size_t)r; }
+        });
+        if (read_bad) throw Error(MKP_E_IO, "read error on " + bam.path());
+        for (size_t k = 0; k < n; k++) ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, pieces[p0 + k].n, hipMemcpyHostToDevice, d->up_stream), "H2D");
+        ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
+      }
+      ok(hipEventRecord(d->up_done, d->up_stream), "event");
+    } catch (const Error& e) { up_err.reset(new Error(e)); }
+    up_ms = ms_since(t_up);
+  });
+  struct JoinUp { std::thread& t; ~JoinUp() { if (t.joinable()) t.join(); } } join_up{uploader};
+  bam.ingest_blocks(&plan);
+  out->ms_plan = ms_since(t0);
+  uploader.join();
+  if (up_err) throw *up_err;
+  out->ms_upload = up_ms;
   bam.bytes_read += plan.comp_total;
+  if (plan.raw_total == 0) return out;
+  if (plan.blks.size() > 0xfffffff0ull || plan.entries.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");
   // ---- tables: BGZF blocks, chain segments
   const size_t nb = plan.blks.size(), ns = plan.entries.size();
   std::vector<BgzfBlk> blks(nb);
@@ -128,20 +142,16 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   d->zblk.ensure(nb * sizeof(BgzfBlk)); d->zstat.ensure(nb * 4 + 16); d->raw.ensure(plan.raw_total + 64); d->segs.ensure(ns * sizeof(MkpSeg)); d->seg_cnt.ensure((ns + 1) * 4); d->tot.ensure(sizeof(MkpIngestTotals));
   const size_t small_need = nb * sizeof(BgzfBlk) + ns * sizeof(MkpSeg) + nb * 4 + sizeof(MkpIngestTotals) + 256;
   d->small.ensure(small_need + small_need / 4);
-  uint8_t* sm = (uint8_t*)d->small.p; uint8_t* sm_blk = sm; uint8_t* sm_seg = sm + nb * sizeof(BgzfBlk); uint8_t* sm_tot = sm_seg + ns * sizeof(MkpSeg); uint8_t* sm_stat = sm_tot + 64;
+  uint8_t* sm = (uint8_t*)d->small.p; uint8_t* sm_blk = sm; uint8_t* sm_seg = sm + nb * sizeof(BgzfBlk); uint8_t* sm_tot = sm_seg + ns * sizeof(MkpSeg); uint8_t* sm_stat = sm_tot + ((sizeof(MkpIngestTotals) + 63) & ~(size_t)63);
   memcpy(sm_blk, blks.data(), nb * sizeof(BgzfBlk)); memcpy(sm_seg, segs.data(), ns * sizeof(MkpSeg));
   ok(hipMemcpyAsync(d->zblk.p, sm_blk, nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, d->stream), "H2D");
   ok(hipMemcpyAsync(d->segs.p, sm_seg, ns * sizeof(MkpSeg), hipMemcpyHostToDevice, d->stream), "H2D");
   ok(hipMemsetAsync(d->zstat.p, 0xff, nb * 4, d->stream), "memset");
   ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
   ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
-  out->ms_upload = ms_since(t_up);
   // ---- inflate + CRC, record chains
   auto t_inf = std::chrono::steady_clock::now();
-  { static const char* force = getenv("MKP_INFLATE_KERNEL");
-    const bool per_thread = force ? !strcmp(force, "thread") : nb >= 24576u;
-    ok(per_thread ? mkp_launch_inflate(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>())
-                  : mkp_launch_inflate_wave(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch"); }
+  ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch");
   ok(mkp_launch_crc32(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
   MkpIngestParams P; memset(&P, 0, sizeof(P));
   P.raw_len = plan.raw_total; P.tid = (int32_t)tid; P.beg = (int32_t)std::min<uint32_t>(beg, 0x7fffffffu); P.end = (int32_t)std::min<uint32_t>(end, 0x7fffffffu); P.n_ref = (int32_t)bam.ref_names.size(); P.n_seg = (uint32_t)ns;
@@ -198,13 +208,13 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   // ---- digest -> what the planner reads: layout ids (this shard's own table; mkp_internal_shard_attach maps them into the context's), flags
   auto t_dig = std::chrono::steady_clock::now();
   S.n_calls = tot->n_calls; S.dev_n_ranks = tot->n_calls; S.dev_n_ml = tot->n_ml_used;
-  S.dev_sum2.resize(n);
+  S.dev_sum2.resize(n); S.dev_name_hash2.resize(n); S.dev_sample_only = tot->n_sample_only;
   for (size_t k = 0; k < extra.size(); k += 2) S.extra_spans.push_back({extra[k], extra[k + 1]});
   std::unordered_map<uint64_t, uint16_t> by_hash; std::vector<uint8_t> recbuf;
   uint64_t ev_cap = 0;
   for (uint32_t j = 0; j < n; j++) {
     MkpReadHdr& h = S.hdr[j];
-    S.name_hash[j] = dig[j].name_hash; S.dev_sum2[j] = (uint8_t)(h.pad & 1u); h.pad = 0;
+    S.name_hash[j] = dig[j].name_hash; S.dev_name_hash2[j] = dig[j].name_hash2; S.dev_sum2[j] = (uint8_t)(h.pad & 1u); h.pad = 0;
     ev_cap += h.event_cap;
     if (!h.n_tags || (h.flags & MKP_RF_BAD)) continue;
     auto it = by_hash.find(dig[j].key_hash);

@@ -26,6 +26,9 @@ template <class Seg> inline std::vector<Seg> mkp_plan_segments(const mkp::BamSou
   return segs;
 }
 
+// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block below 24 576 blocks, one thread per block from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
+hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status);
+
 mkp_dev_ingest* mkp_internal_ingest_create(int device);
 void mkp_internal_ingest_destroy(mkp_dev_ingest* d);
 // the indexed fetch of [beg, end) on `tid` — every record overlapping it — inflated, cut, filtered and packed on the device; throws mkp::Error

@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
       std::vector<MkpRecInfo> info(tot.n_all); std::vector<uint32_t> sz(5 * (size_t)tot.n_all); std::vector<std::pair<int32_t, int32_t>> extra;
       for (uint32_t i = 0; i < tot.n_all; i++) {
         ingest_parse_record(raw, rec_off[i], P, &info[i], &tot.err);
-        const MkpRecInfo& R = info[i]; const bool k = R.kind == 1;
+        const MkpRecInfo& R = info[i]; const bool k = R.kind == 1; if (R.kind == 3) tot.n_sample_only++;
         sz[i] = k; sz[(size_t)tot.n_all + i] = k ? R.n_cigar : 0; sz[2 * (size_t)tot.n_all + i] = k ? ingest_chunk_pairs(R.n_cigar) : 0; sz[3 * (size_t)tot.n_all + i] = k ? ingest_seq_bytes(R.l_seq) : 0;
         sz[4 * (size_t)tot.n_all + i] = k ? R.ml_n : 0;
         if (R.kind == 2) { const long long e = (long long)R.pos + (R.reflen > 0 ? R.reflen : 1); extra.push_back({R.pos, (int32_t)std::min<long long>(e, 0x7fffffffll)}); }
@@ -140,6 +140,10 @@ int main(int argc, char** argv) {
       if (host_err) { if (!(tot.err & host_err)) return fail("error bits (host threw)", 0, tot.err, host_err); continue; }
       if (tot.err) return fail("error bits (host did not throw)", 0, tot.err, 0);
       if (S.hdr.size() != tot.n_kept) return fail("kept records", 0, tot.n_kept, (long long)S.hdr.size());
+      { uint32_t so = 0;   // the sampler's candidates (sample_probabilities: candidates()) that Packer::keep drops
+        for (auto& e : bd.recs) { if (e.tid != (int32_t)t || (int64_t)e.pos >= P.end || (int64_t)e.end <= P.beg) continue; const mkp_record r = bd.view(e);
+          if (!(e.flag & (4 | 256 | 1024 | 2048)) && r.l_qseq > 0 && !Packer::keep(r)) so++; }
+        if (so != tot.n_sample_only) return fail("sampler-only records", 0, tot.n_sample_only, so); }
       std::sort(extra.begin(), extra.end()); std::sort(hextra.begin(), hextra.end());
       if (extra != hextra) return fail("supplementary spans", 0, (long long)extra.size(), (long long)hextra.size());
       uint64_t calls = 0, ml_used = 0;

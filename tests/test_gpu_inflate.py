@@ -62,7 +62,7 @@ def test_device_inflate_on_the_fetch_path(tmp_path):
     modkit_amd.build()
     cli = os.path.join(os.path.dirname(modkit_amd.LIB_PATH), "mkpileup")
     outs = []
-    for extra in ([], ["--device-inflate"]):
+    for extra in (["--host-ingest"], ["--device-inflate"]):
         out = str(tmp_path / ("o%d.bed" % len(outs)))
         p = subprocess.run([cli, "pileup", bam, out, "--cpg", "--ref", fa, "--stats"] + extra, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
@@ -72,8 +72,9 @@ def test_device_inflate_on_the_fetch_path(tmp_path):
 
 
 def test_both_device_kernels(tmp_path):
-    """mkp_bgzf_inflate picks its kernel by launch size (one wave per block below 24 576 blocks, one thread per block above); both are
-    forced here through MKP_INFLATE_KERNEL in fresh processes (the variable is read once) and checked against gzip."""
+    """mkp_bgzf_inflate picks its kernel by launch size (one wave per block below 24 576 blocks, one thread per block above); all three
+    (wave, thread, thread2 = the second edition of the per-thread decoder) are forced here through MKP_INFLATE_KERNEL in fresh processes
+    (the variable is read once) and checked against gzip."""
     import subprocess
     import sys
     script = (
@@ -85,6 +86,6 @@ def test_both_device_kernels(tmp_path):
         "for b in sorted(glob.glob(os.path.join(%r, '*.bam'))):\n"
         "    d = open(b, 'rb').read(); got, _ = c.bgzf_inflate(d); assert got == gzip.decompress(d), b; n += 1\n"
         "c.close(); print('ok', n)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), FIX)
-    for kernel in ("wave", "thread"):
+    for kernel in ("wave", "thread", "thread2"):
         p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, MKP_INFLATE_KERNEL=kernel))
         assert p.returncode == 0 and p.stdout.startswith("ok"), (kernel, p.stderr[-400:])
