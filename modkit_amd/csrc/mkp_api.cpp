@@ -183,7 +183,7 @@ hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void
   if (force && !strcmp(force, "wave")) return mkp_launch_inflate_wave(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread")) return mkp_launch_inflate(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
-  return n >= 24576u ? mkp_launch_inflate(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
+  return n >= 24576u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
 }
 namespace {
 hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
@@ -831,7 +831,7 @@ int mkp_internal_shard_attach(mkp_ctx* c, DevShard* sh) {
     if (!c->shard.hdr.empty()) throw Error(MKP_E_INVALID, "internal: the shard already holds host-packed records");
     auto t0 = std::chrono::steady_clock::now();
     const std::vector<uint16_t> map = c->packer.adopt(sh->layouts);
-    for (auto& h : sh->S.hdr) if (h.n_tags && !(h.flags & MKP_RF_BAD)) { if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range"); h.layout = map[h.layout]; }
+    for (auto* hv : {&sh->S.hdr, &sh->S.so_hdr}) for (auto& h : *hv) if (h.n_tags && !(h.flags & MKP_RF_BAD)) { if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range"); h.layout = map[h.layout]; }
     const int32_t tid = c->shard.tid, ws = c->shard.win_start, we = c->shard.win_end;
     c->shard = std::move(sh->S); c->shard.tid = tid; c->shard.win_start = ws; c->shard.win_end = we; c->shard.dev_packed = true;
     std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref); std::swap(c->d_ranks, sh->d_ranks);
@@ -1129,8 +1129,8 @@ int mkp_internal_sample_resident(mkp_ctx* c, uint32_t win_start, uint32_t win_en
     ShardHost& S = c->sample_shard; S.clear(); S.tid = R.tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end; S.dev_packed = true;
     S.hdr.resize(n); uint64_t off = 0;
     for (uint32_t k = 0; k < n; k++) {
-      if (reads[k] >= R.hdr.size()) throw Error(MKP_E_INVALID, "internal: sampled read index out of range");
-      MkpReadHdr h = R.hdr[reads[k]]; h.event_off = (uint32_t)off; off += h.event_cap;
+      if (reads[k] >= R.hdr.size() + R.so_hdr.size()) throw Error(MKP_E_INVALID, "internal: sampled read index out of range");
+      MkpReadHdr h = reads[k] < R.hdr.size() ? R.hdr[reads[k]] : R.so_hdr[reads[k] - R.hdr.size()]; h.event_off = (uint32_t)off; off += h.event_cap;
       if (off > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "sampling round exceeds 4 Gi call events");
       S.hdr[k] = h;
     }

@@ -405,7 +405,23 @@ struct BaiIndex {
     std::vector<Chunk> m; for (auto& c : out) { if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end); else m.push_back(c); }
     return m;
   }
+  // the same for several disjoint ascending windows of one reference at once (a shard made of BED spans): one merged list
+  std::vector<Chunk> query_parts(uint32_t tid, const std::vector<std::pair<int64_t, int64_t>>& parts) const {
+    if (parts.size() == 1) return query(tid, parts[0].first, parts[0].second);
+    std::vector<Chunk> all; for (auto& pr : parts) { const std::vector<Chunk> q = query(tid, pr.first, pr.second); all.insert(all.end(), q.begin(), q.end()); }
+    std::sort(all.begin(), all.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
+    std::vector<Chunk> m; for (auto& c : all) { if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end); else m.push_back(c); }
+    return m;
+  }
 };
+
+// windows of a multi-part fetch: ascending, disjoint; a record belongs to the fetch when its [pos, end) meets one of them
+using FetchParts = std::vector<std::pair<int64_t, int64_t>>;
+static inline bool overlaps_parts(const FetchParts& parts, int64_t pos, int64_t end) {
+  size_t lo = 0, hi = parts.size();   // first part that ends behind pos
+  while (lo < hi) { const size_t mid = (lo + hi) / 2; if (parts[mid].second > pos) hi = mid; else lo = mid + 1; }
+  return lo < parts.size() && parts[lo].first < end;
+}
 
 // Optional device stage of the indexed fetch (--device-inflate): one window's BGZF blocks inflated on the GPU (mkp_inflate.hip) straight
 // into the window's host buffer.  false = not done (any block failed, or no device): the host decoder then runs and reports.
@@ -461,6 +477,26 @@ class BamSource {
     read_chunks(bai_.query(tid, beg, end), (int32_t)tid, (int64_t)beg, (int64_t)end, out, max_records);
   }
 
+  // records of `tid` overlapping any of the windows (ascending, disjoint), file order, each once: what one fetch per window would
+  // return, without reading the blocks between far-apart windows and without the duplicates of a read that spans two windows
+  void fetch_parts(uint32_t tid, const FetchParts& parts, BamBatch* out) const {
+    out->clear();
+    if (tid >= ref_names.size() || parts.empty()) return;
+    if (parts.size() == 1) { fetch(tid, (uint32_t)std::max<int64_t>(parts[0].first, 0), (uint32_t)std::min<int64_t>(parts[0].second, 0xffffffffll), out); return; }
+    const int64_t beg = parts.front().first, end = parts.back().second;
+    if (!indexed()) {
+      const BamData& bam = resident_; out->base = bam.raw.data();
+      for (size_t i = bam.tid_first[tid]; i < bam.tid_first[tid + 1] && i < bam.recs.size(); i++) {
+        const BamIndexEntry& e = bam.recs[i];
+        if (e.tid != (int32_t)tid) continue;
+        if ((int64_t)e.pos >= end) break;
+        if ((int64_t)e.end > beg && overlaps_parts(parts, e.pos, e.end)) out->recs.push_back(e);
+      }
+      return;
+    }
+    read_chunks(bai_.query_parts(tid, parts), (int32_t)tid, beg, end, out, SIZE_MAX, &parts);
+  }
+
   // the records without coordinates (tid < 0), at the end of a sorted file
   void fetch_unmapped(BamBatch* out) const {
     out->clear();
@@ -508,10 +544,11 @@ class BamSource {
   int fd() const { return fd_; }
   const std::string& path() const { return path_; }
   // phase 1: the file ranges (what has to go up) — the chunk list of the index and one header read at each chunk's end block
-  void ingest_ranges(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const {
+  void ingest_ranges(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const { ingest_ranges(tid, FetchParts{{(int64_t)beg, (int64_t)end}}, out); }
+  void ingest_ranges(uint32_t tid, const FetchParts& parts, IngestPlan* out) const {
     *out = IngestPlan(); out->tid = tid;
-    if (!indexed() || tid >= ref_names.size() || end <= beg) return;
-    for (auto& ch : bai_.query(tid, beg, end)) {
+    if (!indexed() || tid >= ref_names.size() || parts.empty() || parts.back().second <= parts.front().first) return;
+    for (auto& ch : bai_.query_parts(tid, parts)) {
       const uint64_t cb = ch.beg >> 16, ce = ch.end >> 16, ue = ch.end & 0xffff;
       if (cb >= fsize_ || !(cb < ce || (cb == ce && ue > 0))) continue;
       IngestRange rg; rg.file_off = cb; rg.vbeg = ch.beg; rg.vend = ch.end;
@@ -671,7 +708,7 @@ class BamSource {
   }
 
   // inflate the blocks under the (merged, ascending) virtual-offset ranges and index their records that pass the region test
-  void read_chunks(const std::vector<BaiIndex::Chunk>& chunks, int32_t tid, int64_t beg, int64_t end, BamBatch* out, size_t max_records) const {
+  void read_chunks(const std::vector<BaiIndex::Chunk>& chunks, int32_t tid, int64_t beg, int64_t end, BamBatch* out, size_t max_records, const FetchParts* parts = nullptr) const {
     const int32_t n_ref = (int32_t)ref_names.size();
     // groups of chunks are processed until enough records are in hand; each group: pread, block walk, parallel inflate, record scan
     bool stop = false;
@@ -728,7 +765,7 @@ class BamSource {
         std::vector<BamIndexEntry> recs;
         for (size_t i = 0; i < all.size(); i++) {
           const BamIndexEntry& e = all[i];
-          if (tid >= 0) { if (e.tid != tid || (int64_t)e.pos >= end) { if (e.tid > tid || e.tid < 0 || (e.tid == tid && (int64_t)e.pos >= end)) { stop = true; break; } continue; } if ((int64_t)e.end <= beg) continue; }
+          if (tid >= 0) { if (e.tid != tid || (int64_t)e.pos >= end) { if (e.tid > tid || e.tid < 0 || (e.tid == tid && (int64_t)e.pos >= end)) { stop = true; break; } continue; } if ((int64_t)e.end <= beg) continue; if (parts && !overlaps_parts(*parts, e.pos, e.end)) continue; }
           else if (e.tid >= 0) continue;
           recs.push_back(e);
           if (recs.size() + out->recs.size() >= max_records) { stop = true; break; }

@@ -98,14 +98,15 @@ SampleTimes g_sample_times;   // --stats: where the threshold estimate's time we
 // attached to the context covers the contig — indices into that shard's digest (every kept record is a candidate; names are compared
 // through their two 64-bit hashes; the reads' bases and tags are in HBM already, mkp_internal_sample_resident).
 struct RecSet {
-  std::unique_ptr<BamBatch> b; const ShardHost* S = nullptr; std::vector<uint32_t> idx;
+  std::unique_ptr<BamBatch> b; const ShardHost* S = nullptr; std::vector<uint32_t> idx;   // resident: index < S->hdr.size() = a kept read, above = sampler-only read (index - hdr.size())
   size_t size() const { return S ? idx.size() : b->recs.size(); }
   bool truncated(size_t cap) const { return !S && b->recs.size() >= cap; }
   std::string name(size_t i) const {
-    if (S) { char k[16]; memcpy(k, &S->name_hash[idx[i]], 8); memcpy(k + 8, &S->dev_name_hash2[idx[i]], 8); return std::string(k, 16); }
+    if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size(); char key[16]; memcpy(key, k < n ? &S->name_hash[k] : &S->so_name_hash[k - n], 8); memcpy(key + 8, k < n ? &S->dev_name_hash2[k] : &S->so_name_hash2[k - n], 8);
+      return std::string(key, 16); }
     return b->qname(b->recs[i]);
   }
-  int32_t pos(size_t i) const { return S ? S->hdr[idx[i]].ref_start : b->recs[i].pos; }
+  int32_t pos(size_t i) const { if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size(); return k < n ? S->hdr[k].ref_start : S->so_hdr[k - n].ref_start; } return b->recs[i].pos; }
   bool candidate(size_t i, bool drop_unmapped) const {
     if (S) return true;
     const BamIndexEntry& e = b->recs[i];
@@ -117,7 +118,7 @@ struct RecSet {
 void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf, const ShardHost* res = nullptr) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
-  if (res && (!only_mapped || sharded || res->dev_sample_only)) throw Error(MKP_E_INVALID, "internal: resident sampling needs mapped-only, single-rank sampling and no sampler-only records");
+  if (res && (!only_mapped || sharded)) throw Error(MKP_E_INVALID, "internal: resident sampling needs mapped-only, single-rank sampling");
   std::vector<int32_t> res_pmax;   // resident shard: prefix maximum of the alignment ends (first record that can reach an interval)
   if (res) { res_pmax.resize(res->hdr.size()); int32_t m = INT32_MIN; for (size_t i = 0; i < res->hdr.size(); i++) { m = std::max(m, std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1)); res_pmax[i] = m; } }
   auto fetch_set = [&](uint32_t tid, uint32_t s, uint32_t e, size_t cap) {
@@ -125,8 +126,14 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     if (res) {
       if ((int32_t)tid != res->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the attached contig");
       r.S = res;
-      size_t first = (size_t)(std::upper_bound(res_pmax.begin(), res_pmax.end(), (int32_t)std::min<uint32_t>(s, 0x7fffffffu)) - res_pmax.begin());
+      const size_t first = (size_t)(std::upper_bound(res_pmax.begin(), res_pmax.end(), (int32_t)std::min<uint32_t>(s, 0x7fffffffu)) - res_pmax.begin());
       for (size_t i = first; i < res->hdr.size() && (int64_t)res->hdr[i].ref_start < (int64_t)e; i++) if ((int64_t)std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1) > (int64_t)s) r.idx.push_back((uint32_t)i);
+      // the sampler-only records of the window (QC-fail ...: few), merged in by their place in the file
+      bool any_so = false;
+      for (size_t k = 0; k < res->so_hdr.size(); k++) { const MkpReadHdr& h = res->so_hdr[k];
+        if ((int64_t)h.ref_start < (int64_t)e && (int64_t)std::max(h.ref_end, h.ref_start + 1) > (int64_t)s) { r.idx.push_back((uint32_t)(res->hdr.size() + k)); any_so = true; } }
+      if (any_so) { const size_t n = res->hdr.size(); auto wi = [&](uint32_t k) { return k < n ? res->dev_win_idx[k] : res->so_win_idx[k - n]; };
+        std::stable_sort(r.idx.begin(), r.idx.end(), [&](uint32_t x, uint32_t y) { return wi(x) < wi(y); }); }
       return r;
     }
     r.b.reset(new BamBatch()); bam.fetch(tid, s, e, r.b.get(), cap); return r;
@@ -582,7 +589,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           early_in = early_fetch.get(); early_in_ready = true;
           fetch_wait_early_ms = ms_since(t_w);
           mark("resident sampling: ingest in hand");
-          if (early_in.dev && early_in.dev->S.dev_sample_only == 0) {
+          if (early_in.dev) {
             mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)records[0].tid; sh.start = early_s0; sh.end = early_s1;
             if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
             must(mkp_shard_begin(ctx, &sh));

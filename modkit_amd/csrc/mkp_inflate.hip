@@ -201,7 +201,18 @@ mkp_inflate_blocks(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restric
 //   * LZ77 copies never read what the same copy wrote: dist >= len reads its source four qwords at a time ahead of the stores;
 //     dist < 8 builds the repeating pattern in a register once and only stores; 8 <= dist < len reads the `dist` source bytes cyclically.
 //     Tails are byte stores out of a register, not byte round trips.
-// Reads may run up to 7 bytes past a block's output slice (never written there): the output buffer carries that slack at its end.
+//   * the codes-per-length counts of both tables in registers: the canonical walk touches LDS only for the symbol itself.
+// Reads may run up to 7 bytes past a block's output slice and 8 past its input (never written there): both buffers carry that slack.
+// Measured on the C3 BAM (54 450 blocks; tools/dbg/inflate_variants.hip): 117 ms first edition, 89 ms this one — 55 ms of it decode, 34 ms
+// copies (literal stores: nothing); 6 000 blocks take 78 ms: a block is a serial chain and the kernel's time is one lane's time.  A
+// three-state machine (one decode site per pass for literal/length and distance codes, copies in 32-byte steps) was 146 ms: the extra
+// passes and table selects cost more than the second decode site.
+#ifdef MKP_INFLATE_DBG   // ablation builds only (tools/dbg/inflate_variants.hip): 1 = no LZ77 copies, 2 = no literal stores
+__device__ uint32_t mkp_inflate_dbg;
+#define MKP_DBG(bit) (mkp_inflate_dbg & (bit))
+#else
+#define MKP_DBG(bit) 0
+#endif
 namespace {
 struct Bits2 {
   const uint8_t* p; uint32_t n; uint32_t at;        // block input; next unread byte
@@ -209,8 +220,9 @@ struct Bits2 {
   unsigned long long buf; uint32_t cnt; bool over;
   __device__ __forceinline__ unsigned long long load_q(uint32_t qi) const {
     const uint32_t off = qi * 8u;
-    if (off + 8u <= n) { unsigned long long v; __builtin_memcpy(&v, p + off, 8); return v; }
-    unsigned long long v = 0; for (uint32_t k = 0; k < 8u; k++) if (off + k < n) v |= (unsigned long long)p[off + k] << (8u * k);
+    if (off >= n) return 0ull;
+    unsigned long long v; __builtin_memcpy(&v, p + off, 8);   // (may run into the block's trailer / the buffer's slack: masked below)
+    if (off + 8u > n) v &= (1ull << (8u * (n - off))) - 1ull;
     return v;
   }
   __device__ __forceinline__ void init() { at = 0; q = 0; cur = load_q(0); nxt = load_q(1); buf = 0; cnt = 0; over = false; }
@@ -229,13 +241,17 @@ struct Bits2 {
     const uint32_t v = (uint32_t)(buf & ((1ull << k) - 1ull)); buf >>= k; cnt -= k; return v;
   }
 };
-__device__ __forceinline__ int decode_sym2(Bits2& b, const Code& h) {
+// the codes-per-length counts of one table in registers (two per dword): the length-by-length walk is then register work, only the
+// final symbol fetch touches LDS (the first edition read count[len] from LDS at every step: ten dependent round trips per symbol)
+struct Counts { uint32_t w[8]; __device__ __forceinline__ void load(const uint16_t* c) { for (int i = 0; i < 8; i++) w[i] = (uint32_t)c[2 * i] | ((uint32_t)c[2 * i + 1] << 16); } };
+__device__ __forceinline__ int decode_sym2(Bits2& b, const Code& h, const Counts& cn) {
   if (b.cnt < 15u) b.fill();
   uint32_t bits = (uint32_t)b.buf; const uint32_t avail = b.cnt;
   int code = 0, first = 0, index = 0;
+#pragma unroll
   for (int len = 1; len <= 15; len++) {
     code |= (int)(bits & 1u); bits >>= 1;
-    const int count = h.count[len];
+    const int count = (int)((cn.w[len >> 1] >> (16 * (len & 1))) & 0xffffu);
     if (code - count < first) {
       if ((uint32_t)len > avail) { b.over = true; return -1; }
       b.buf >>= len; b.cnt -= (uint32_t)len;
@@ -260,6 +276,7 @@ mkp_inflate_blocks2(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restri
   const Code lencode{reinterpret_cast<uint16_t*>(t), t + 112, reinterpret_cast<uint32_t*>(t + 64)};
   const Code distcode{reinterpret_cast<uint16_t*>(t + 32), t + 400, reinterpret_cast<uint32_t*>(t + 104)};
   uint8_t lengths[320];
+  Counts lc, dc;
   Bits2 b; b.p = in + bk.in_off; b.n = bk.in_len; b.init();
   uint8_t* o = out + bk.out_off;
   const uint32_t cap = bk.out_len;
@@ -293,9 +310,10 @@ mkp_inflate_blocks2(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restri
         for (; idx < 19; idx++) lengths[cl_order(idx)] = 0;
         if (b.over) { err = 1; break; }
         if (construct(lencode, lengths, 19) != 0) { err = 3; break; }
+        lc.load(lencode.count);
         idx = 0;
         while (idx < nlen + ndist) {
-          int sym = decode_sym2(b, lencode);
+          int sym = decode_sym2(b, lencode, lc);
           if (sym < 0) { err = b.over ? 1 : 4; break; }
           if (sym < 16) lengths[idx++] = (uint8_t)sym;
           else {
@@ -315,27 +333,29 @@ mkp_inflate_blocks2(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restri
         int e2 = construct(distcode, lengths + nlen, ndist);
         if (e2 < 0 || (e2 > 0 && ndist - distcode.count[0] != 1)) { err = 3; break; }
       }
+      lc.load(lencode.count); dc.load(distcode.count);
       for (uint32_t g2 = 0; g2 <= cap + 1u; g2++) {
-        const int sym = decode_sym2(b, lencode);
+        const int sym = decode_sym2(b, lencode, lc);
         if (sym < 0) { err = b.over ? 1 : 4; break; }
         if (sym < 256) {
           if (w >= cap) { err = 6; break; }
           lit |= (unsigned long long)(uint32_t)sym << (8u * nlit); nlit++; w++;
-          if (nlit == 8u) { st8(o + w - 8u, lit); lit = 0; nlit = 0; }
+          if (nlit == 8u) { if (!MKP_DBG(2)) st8(o + w - 8u, lit); lit = 0; nlit = 0; }
         } else {
           if (nlit) { st_tail(o + w - nlit, lit, nlit); lit = 0; nlit = 0; }
           if (sym == 256) break;
           const int ls = sym - 257;
           if (ls >= 29) { err = 4; break; }
           const uint32_t len = len_base(ls) + b.get(len_extra(ls));
-          const int ds = decode_sym2(b, distcode);
+          const int ds = decode_sym2(b, distcode, dc);
           if (ds < 0 || ds >= 30) { err = b.over ? 1 : 4; break; }
           const uint32_t dist = dist_base(ds) + b.get(dist_extra(ds));
           if (b.over) { err = 1; break; }
           if (dist > w) { err = 5; break; }
           if (w + len > cap) { err = 6; break; }
           const uint8_t* src = o + w - dist; uint8_t* dst = o + w;
-          if (dist >= len) {
+          if (MKP_DBG(1)) { /* ablation: the copy is skipped, the decode goes on */ }
+          else if (dist >= len) {
             uint32_t k = 0;
             for (; k + 32u <= len; k += 32u) { const unsigned long long a0 = ld8(src + k), a1 = ld8(src + k + 8u), a2 = ld8(src + k + 16u), a3 = ld8(src + k + 24u);
                                                 st8(dst + k, a0); st8(dst + k + 8u, a1); st8(dst + k + 16u, a2); st8(dst + k + 24u, a3); }

@@ -77,33 +77,33 @@ mkp_ingest_write(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSe
   ingest_walk_segment(raw, P.raw_len, segs[i], rec_off + seg_base[i], &tot->err);
 }
 
-// per record: checks, region test, aux walk; sizes of the kept ones into sz[5][rec_cap] (kept, CIGAR words, chunk pairs, SEQ bytes, ML bytes)
+// per record: checks, region test, aux walk; sizes of the packed ones into sz[6][rec_cap] (kept, CIGAR words, chunk pairs, SEQ bytes, ML bytes, sampler-only)
 extern "C" __global__ void __launch_bounds__(256)
-mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const unsigned long long* __restrict__ rec_off, MkpRecInfo* __restrict__ info, uint32_t* __restrict__ sz,
-                 int32_t* __restrict__ extra, MkpIngestTotals* tot) {
+mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const int32_t* __restrict__ parts, const unsigned long long* __restrict__ rec_off, MkpRecInfo* __restrict__ info,
+                 uint32_t* __restrict__ sz, int32_t* __restrict__ extra, MkpIngestTotals* tot) {
   const uint32_t n = min(tot->n_all, P.rec_cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    MkpRecInfo R; ingest_parse_record(raw, rec_off[i], P, &R, &tot->err);
+    MkpRecInfo R; ingest_parse_record(raw, rec_off[i], P, parts, &R, &tot->err);
     info[i] = R;
-    const bool k = R.kind == 1;
+    const bool k = R.kind == 1, pk = R.kind == 1 || R.kind == 3;   // kept by the pileup; packed (the sampler-only records go behind the kept ones)
     sz[i] = k ? 1u : 0u;
-    sz[(size_t)P.rec_cap + i] = k ? (uint32_t)R.n_cigar : 0u;
-    sz[2 * (size_t)P.rec_cap + i] = k ? ingest_chunk_pairs(R.n_cigar) : 0u;
-    sz[3 * (size_t)P.rec_cap + i] = k ? ingest_seq_bytes(R.l_seq) : 0u;
-    sz[4 * (size_t)P.rec_cap + i] = k ? R.ml_n : 0u;
-    if (R.kind == 3) atomicAdd(&tot->n_sample_only, 1u);
+    sz[(size_t)P.rec_cap + i] = pk ? ingest_cigar_words(R.n_cigar) : 0u;
+    sz[2 * (size_t)P.rec_cap + i] = pk ? ingest_chunk_pairs(R.n_cigar) : 0u;
+    sz[3 * (size_t)P.rec_cap + i] = pk ? ingest_seq_bytes(R.l_seq) : 0u;
+    sz[4 * (size_t)P.rec_cap + i] = pk ? R.ml_n : 0u;
+    sz[5 * (size_t)P.rec_cap + i] = R.kind == 3 ? 1u : 0u;
     if (R.kind == 2) { const uint32_t at = atomicAdd(&tot->n_extra, 1u); extra[2 * (size_t)at] = R.pos;
       const long long e = (long long)R.pos + (R.reflen > 0 ? R.reflen : 1); extra[2 * (size_t)at + 1] = (int32_t)(e > 0x7fffffffll ? 0x7fffffffll : e); }
   }
 }
 
-// exclusive scans of the five size arrays in place, one workgroup; totals into tot
+// exclusive scans of the six size arrays in place, one workgroup; totals into tot
 extern "C" __global__ void __launch_bounds__(1024)
 mkp_ingest_scan_sizes(uint32_t* __restrict__ sz, uint32_t rec_cap, MkpIngestTotals* tot) {
   __shared__ unsigned long long part[1025];
   const uint32_t n = min(tot->n_all, rec_cap);
   const uint32_t t = threadIdx.x, chunk = (n + 1023u) / 1024u, lo = min(n, t * chunk), hi = min(n, lo + chunk);
-  for (uint32_t q = 0; q < 5u; q++) {
+  for (uint32_t q = 0; q < 6u; q++) {
     uint32_t* a = sz + (size_t)q * rec_cap;
     unsigned long long s = 0; for (uint32_t i = lo; i < hi; i++) s += a[i];
     __syncthreads();
@@ -115,7 +115,7 @@ mkp_ingest_scan_sizes(uint32_t* __restrict__ sz, uint32_t rec_cap, MkpIngestTota
     if (t == 0) {
       const unsigned long long total = part[1024];
       if (total > 0xfffffff0ull) atomicOr(&tot->err, MKP_IE_4G);
-      if (q == 0) tot->n_kept = (uint32_t)total; else if (q == 1) tot->cigar_words = total; else if (q == 2) tot->chunk_pairs = total; else if (q == 3) tot->seq_bytes = total; else tot->ml_bytes = total;
+      if (q == 0) tot->n_kept = (uint32_t)total; else if (q == 1) tot->cigar_words = total; else if (q == 2) tot->chunk_pairs = total; else if (q == 3) tot->seq_bytes = total; else if (q == 4) tot->ml_bytes = total; else tot->n_sample_only = (uint32_t)total;
     }
   }
 }
@@ -127,8 +127,9 @@ mkp_ingest_pack(const uint8_t* __restrict__ raw, uint32_t rec_cap, const MkpRecI
   const uint32_t n = min(tot->n_all, rec_cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const MkpRecInfo R = info[i];
-    if (R.kind != 1) continue;
-    ingest_pack_record(raw, R, sz[i], sz[(size_t)rec_cap + i], sz[2 * (size_t)rec_cap + i], sz[3 * (size_t)rec_cap + i], sz[4 * (size_t)rec_cap + i],
+    if (R.kind != 1 && R.kind != 3) continue;
+    const uint32_t j = R.kind == 1 ? sz[i] : tot->n_kept + sz[5 * (size_t)rec_cap + i];   // headers: the kept records in file order, then the sampler-only ones
+    ingest_pack_record(raw, R, i, j, sz[(size_t)rec_cap + i], sz[2 * (size_t)rec_cap + i], sz[3 * (size_t)rec_cap + i], sz[4 * (size_t)rec_cap + i],
                        hdr, cigar, chunk_pfx, seq, tagref, ranks, ml, dig, tot);
   }
 }
@@ -144,11 +145,11 @@ hipError_t mkp_launch_ingest_count(hipStream_t st, const uint8_t* raw, const Mkp
   hipLaunchKernelGGL(mkp_ingest_scan_segs, dim3(1), dim3(1024), 0, st, seg_cnt, P->n_seg, tot);
   return hipGetLastError();
 }
-hipError_t mkp_launch_ingest_parse(hipStream_t st, const uint8_t* raw, const MkpIngestParams* P, const MkpSeg* segs, const uint32_t* seg_base, unsigned long long* rec_off,
+hipError_t mkp_launch_ingest_parse(hipStream_t st, const uint8_t* raw, const MkpIngestParams* P, const int32_t* parts, const MkpSeg* segs, const uint32_t* seg_base, unsigned long long* rec_off,
                                    MkpRecInfo* info, uint32_t* sz, int32_t* extra, MkpIngestTotals* tot) {
   if (P->n_seg) hipLaunchKernelGGL(mkp_ingest_write, dim3((P->n_seg + 255u) / 256u), dim3(256), 0, st, raw, *P, segs, seg_base, rec_off, tot);
   const uint32_t grid = P->rec_cap ? (uint32_t)((P->rec_cap + 255u) / 256u < 8192u ? (P->rec_cap + 255u) / 256u : 8192u) : 1u;
-  hipLaunchKernelGGL(mkp_ingest_parse, dim3(grid), dim3(256), 0, st, raw, *P, rec_off, info, sz, extra, tot);
+  hipLaunchKernelGGL(mkp_ingest_parse, dim3(grid), dim3(256), 0, st, raw, *P, parts, rec_off, info, sz, extra, tot);
   hipLaunchKernelGGL(mkp_ingest_scan_sizes, dim3(1), dim3(1024), 0, st, sz, P->rec_cap, tot);
   return hipGetLastError();
 }

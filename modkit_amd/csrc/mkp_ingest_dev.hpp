@@ -45,6 +45,7 @@ struct MkpIngestParams {
   int32_t tid, beg, end;        // region test of the fetch: records of `tid` with pos < end and endpos > beg
   int32_t n_ref;
   uint32_t n_seg, rec_cap;
+  uint32_t n_parts, pad;        // > 1: the fetch is the union of n_parts windows (ascending, disjoint {beg, end} pairs, passed next to the params); beg / end is their hull
 };
 
 // one record of the window after mkp_ingest_parse
@@ -62,7 +63,7 @@ struct MkpIngestTotals {
   uint32_t err, n_all, n_kept, n_extra;
   unsigned long long cigar_words, chunk_pairs, seq_bytes, ml_bytes;   // capacities of the packed arrays (exclusive-scan totals)
   unsigned long long n_calls, n_ml_used;
-  uint32_t n_sample_only, pad;   // records of the region the threshold sampler would consider but the pileup drops (QC-fail, no CIGAR)
+  uint32_t n_sample_only, pad;   // records of the region only the threshold sampler takes (QC-fail, no CIGAR): packed behind the kept ones
 };
 
 // ---- CRC-32 joins (mkp_crc32_blocks): GF(2) polynomial arithmetic mod the gzip polynomial, bit-reflected operands (bit 31 = x^0)
@@ -100,7 +101,12 @@ MKP_IDEV uint32_t ingest_walk_segment(const uint8_t* raw, unsigned long long raw
 
 // ---- one record: field checks and reference span (index_record, mkp_bam.hpp), region test and flag mask (BamSource::read_chunks,
 // Packer::keep), aux walk (Packer::aux_find_all: first occurrence of each tag reached before any malformed field)
-MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, const MkpIngestParams& P, MkpRecInfo* out, uint32_t* err) {
+MKP_IDEV bool ingest_overlaps_parts(const int32_t* parts, uint32_t n, long long pos, long long end) {   // overlaps_parts (mkp_bam.hpp)
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if ((long long)parts[2 * mid + 1] > pos) hi = mid; else lo = mid + 1; }
+  return lo < n && (long long)parts[2 * lo] < end;
+}
+MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, const MkpIngestParams& P, const int32_t* parts, MkpRecInfo* out, uint32_t* err) {
   MkpRecInfo R; R.core = o + 4; R.kind = 0; R.pad0 = R.pad1 = 0; R.mm = R.ml = R.mn = 0; R.ml_n = 0;
   const uint8_t* c = raw + o + 4;
   const int32_t bs = ld_i32(raw + o); R.bs = (uint32_t)bs;
@@ -114,14 +120,15 @@ MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, cons
   if ((long long)R.pos + rl > 0x7ffffff0ll) { MKP_ATOMIC_OR(err, MKP_IE_CORRUPT); *out = R; return; }
   R.reflen = (int32_t)rl;
   const long long endpos = (long long)R.pos + (rl > 0 ? rl : 1);
-  const bool in_region = tid == P.tid && (long long)R.pos < (long long)P.end && endpos > (long long)P.beg;
+  const bool in_region = tid == P.tid && (long long)R.pos < (long long)P.end && endpos > (long long)P.beg && (P.n_parts < 2 || ingest_overlaps_parts(parts, P.n_parts, R.pos, endpos));
   if (!in_region) { *out = R; return; }
   const bool masked = (R.flag & (4u | 256u | 512u | 1024u)) != 0;
   if (!masked && (R.flag & 2048u) && R.n_cigar) { R.kind = 2; *out = R; return; }
   if (masked || (R.flag & 2048u) || lseq <= 0 || R.n_cigar == 0) {
-    if (!(R.flag & (4u | 256u | 1024u | 2048u)) && lseq > 0) R.kind = 3;   // QC-fail or CIGAR-less: not in the pileup, but a candidate of the threshold sampler (reads_sampler: only secondary / duplicate / supplementary are dropped)
-    *out = R; return; }
-  R.kind = 1;
+    // QC-fail or CIGAR-less: not in the pileup, but a candidate of the threshold sampler (reads_sampler: only secondary / duplicate /
+    // supplementary records are dropped there) — packed like a kept record, behind them
+    if (!(R.flag & (4u | 256u | 1024u | 2048u)) && lseq > 0) R.kind = 3; else { *out = R; return; }
+  } else R.kind = 1;
   // aux walk
   const uint32_t aux0 = (uint32_t)fixed, aux_n = (uint32_t)bs - aux0;   // offsets from the core
   const uint8_t* a = c + aux0;
@@ -155,7 +162,8 @@ MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, cons
 
 // sizes a kept record takes in the packed arrays (scanned into offsets before mkp_ingest_pack)
 MKP_IDEV uint32_t ingest_seq_bytes(uint32_t l_seq) { return (((l_seq + 1u) / 2u) + 3u) & ~3u; }
-MKP_IDEV uint32_t ingest_chunk_pairs(uint32_t n_cigar) { return (n_cigar + 63u) / 64u; }
+MKP_IDEV uint32_t ingest_chunk_pairs(uint32_t n_cigar) { return n_cigar ? (n_cigar + 63u) / 64u : 1u; }   // (a record without a CIGAR is packed with one soft clip over its bases, as Packer::add does)
+MKP_IDEV uint32_t ingest_cigar_words(uint32_t n_cigar) { return n_cigar ? n_cigar : 1u; }
 
 // what the packer's tokeniser leaves for one record
 struct MkpTokOut { uint32_t n_tags; uint32_t n_calls; uint32_t ml_used; unsigned long long cap; unsigned long long key_hash; uint32_t sum2; };
@@ -266,10 +274,10 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
 }
 
 // per-record digest the host plans with (next to the record's MkpReadHdr and tag table)
-struct MkpRecDigest { unsigned long long name_hash, key_hash, name_hash2, pad; };   // name_hash2: a second, independent hash of the read name (128 bits identify a name in the sampler's sets)
+struct MkpRecDigest { unsigned long long name_hash, key_hash, name_hash2, win_idx; };   // name_hash2: a second, independent hash of the read name (128 bits identify a name in the sampler's sets); win_idx: the record's place in the window (file order across kept and sampler-only records)
 
 // Packer::add for one kept record: CIGAR words + chunk prefixes, SEQ bytes, tags; writes the header with the offsets the scan gave.
-MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t j, uint32_t cigar_off, uint32_t chunk_off, uint32_t seq_off, uint32_t ml_off,
+MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t win_idx, uint32_t j, uint32_t cigar_off, uint32_t chunk_off, uint32_t seq_off, uint32_t ml_off,
                                  MkpReadHdr* hdr, uint32_t* cigar, uint32_t* chunk_pfx, uint8_t* seq, MkpTagRef* tagref, uint32_t* ranks, uint8_t* ml, MkpRecDigest* dig,
                                  MkpIngestTotals* tot) {
   const uint8_t* c = raw + R.core;
@@ -284,15 +292,16 @@ MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32
     if ((0x18du >> op) & 1u) reflen += w >> 4;
     if ((0x193u >> op) & 1u) qlen += w >> 4;   // M I S = X consume the query
   }
+  if (R.n_cigar == 0) { cigar[cigar_off] = (R.l_seq << 4) | 4u; chunk_pfx[2 * chunk_off] = 0; chunk_pfx[2 * chunk_off + 1] = 0; qlen = R.l_seq; }   // sampler-only record without alignment ops
   if (qlen != (long long)R.l_seq) MKP_ATOMIC_OR(&tot->err, MKP_IE_QLEN);
   if (qlen >= (1 << 26) || reflen >= (1 << 26)) MKP_ATOMIC_OR(&tot->err, MKP_IE_SPAN);
-  h.ref_start = R.pos; h.ref_end = R.pos + (int32_t)reflen; h.l_seq = R.l_seq; h.n_cigar = R.n_cigar;
+  h.ref_start = R.pos; h.ref_end = R.pos + (int32_t)reflen; h.l_seq = R.l_seq; h.n_cigar = ingest_cigar_words(R.n_cigar);
   const uint32_t nb = (R.l_seq + 1u) / 2u, nbp = ingest_seq_bytes(R.l_seq);
   for (uint32_t k = 0; k < nb; k++) seq[seq_off + k] = sq[k];
   for (uint32_t k = nb; k < nbp; k++) seq[seq_off + k] = 0;
   h.flags = (R.flag & 16u) ? MKP_RF_REVERSE : 0u;
   { unsigned long long hh = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull; for (int i = 0; i + 1 < (int)R.l_qname; i++) { hh ^= c[32 + i]; hh *= 1099511628211ull; h2 = (h2 ^ c[32 + i]) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 29; }
-    dig[j].name_hash = hh; dig[j].name_hash2 = h2; dig[j].pad = 0; }
+    dig[j].name_hash = hh; dig[j].name_hash2 = h2; dig[j].win_idx = win_idx; }
   MkpTokOut t;
   for (uint32_t k = 0; k < MKP_MAX_TAGS; k++) { MkpTagRef z; z.rank_off = 0; z.n = 0; z.ml_off = 0; z.pad = 0; tagref[h.tag_off + k] = z; }
   const bool ok = ingest_tokenise(c, R, ranks + ml_off, ml + ml_off, tagref + h.tag_off, ml_off, ml_off, &t, &tot->err);

@@ -20,7 +20,7 @@ hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void*, uint32_t
 hipError_t mkp_launch_inflate_wave(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);
 hipError_t mkp_launch_crc32(hipStream_t, const uint8_t*, const void*, uint32_t, const uint8_t*, uint32_t*);
 hipError_t mkp_launch_ingest_count(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, uint32_t*, MkpIngestTotals*);
-hipError_t mkp_launch_ingest_parse(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, const uint32_t*, unsigned long long*, MkpRecInfo*, uint32_t*, int32_t*, MkpIngestTotals*);
+hipError_t mkp_launch_ingest_parse(hipStream_t, const uint8_t*, const MkpIngestParams*, const int32_t*, const MkpSeg*, const uint32_t*, unsigned long long*, MkpRecInfo*, uint32_t*, int32_t*, MkpIngestTotals*);
 hipError_t mkp_launch_ingest_pack(hipStream_t, const uint8_t*, uint32_t, const MkpRecInfo*, const uint32_t*, MkpReadHdr*, uint32_t*, uint32_t*, uint8_t*, MkpTagRef*, uint32_t*, uint8_t*, MkpRecDigest*, MkpIngestTotals*);
 }
 
@@ -38,7 +38,7 @@ struct mkp_dev_ingest {
   int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr;
   static constexpr size_t kPiece = (size_t)4 << 20, kSlots = 16;   // upload staging: two halves of kSlots pieces
   Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
-  DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig;
+  DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig, parts;
   std::mutex mu;                                                   // one ingest at a time per object
   std::mutex spare_mu; std::vector<DevBuf> spares;                 // buffers the contexts handed back (mkp_internal_ingest_recycle)
   DevBuf take(size_t bytes) {
@@ -60,7 +60,7 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
 void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig}) b->release();
+  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig, &d->parts}) b->release();
   for (auto& b : d->spares) b.release();
   d->stage.release(); d->small.release();
   for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
@@ -78,13 +78,15 @@ void mkp_internal_ingest_recycle(mkp_dev_ingest* d, DevShard* sh) {
   for (DevBuf* b : {&sh->d_cigar, &sh->d_chunk, &sh->d_seq, &sh->d_tagref, &sh->d_ranks, &sh->d_ml}) { if (b->p && d->spares.size() < 16) { d->spares.push_back(*b); b->p = nullptr; b->cap = 0; } }
 }
 
-std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSource& bam, uint32_t tid, uint32_t beg, uint32_t end) {
+std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSource& bam, uint32_t tid, const FetchParts& parts) {
+  if (parts.empty()) throw Error(MKP_E_INVALID, "device ingest: no fetch window");
+  const uint32_t beg = (uint32_t)std::max<int64_t>(parts.front().first, 0), end = (uint32_t)std::min<int64_t>(parts.back().second, 0x7fffffffll);
   if (!d) throw Error(MKP_E_DEVICE, "device ingest: no ingest object");
   std::lock_guard<std::mutex> lock(d->mu);
   auto t0 = std::chrono::steady_clock::now();
   std::unique_ptr<DevShard> out(new DevShard());
   ShardHost& S = out->S; S.tid = (int32_t)tid; S.dev_packed = true;
-  BamSource::IngestPlan plan; bam.ingest_ranges(tid, beg, end, &plan);
+  BamSource::IngestPlan plan; bam.ingest_ranges(tid, parts, &plan);
   if (plan.ranges.empty()) return out;   // nothing under the region: an empty shard
   auto ok = [](hipError_t e, const char* what) { if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string("device ingest: ") + what + ": " + hipGetErrorString(e)); };
   ok(hipSetDevice(d->device), "hipSetDevice");
@@ -180,26 +182,33 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   auto t_scan = std::chrono::steady_clock::now();
   const uint32_t n_all = tot->n_all;
   P.rec_cap = std::max<uint32_t>(n_all, 1u);
-  d->rec_off.ensure((size_t)P.rec_cap * 8); d->info.ensure((size_t)P.rec_cap * sizeof(MkpRecInfo)); d->sz.ensure(5 * (size_t)P.rec_cap * 4); d->extra.ensure(2 * (size_t)P.rec_cap * 4);
-  ok(mkp_launch_ingest_parse(d->stream, d->raw.as<uint8_t>(), &P, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->rec_off.as<unsigned long long>(), d->info.as<MkpRecInfo>(), d->sz.as<uint32_t>(),
+  d->rec_off.ensure((size_t)P.rec_cap * 8); d->info.ensure((size_t)P.rec_cap * sizeof(MkpRecInfo)); d->sz.ensure(6 * (size_t)P.rec_cap * 4); d->extra.ensure(2 * (size_t)P.rec_cap * 4);
+  const int32_t* d_parts = nullptr;
+  if (parts.size() > 1) {   // the windows of a multi-part fetch, next to the params
+    std::vector<int32_t> pv; pv.reserve(2 * parts.size()); for (auto& pr : parts) { pv.push_back((int32_t)std::max<int64_t>(pr.first, 0)); pv.push_back((int32_t)std::min<int64_t>(pr.second, 0x7fffffffll)); }
+    d->parts.ensure(pv.size() * 4); ok(hipMemcpyAsync(d->parts.p, pv.data(), pv.size() * 4, hipMemcpyHostToDevice, d->stream), "H2D"); ok(hipStreamSynchronize(d->stream), "sync");
+    P.n_parts = (uint32_t)parts.size(); d_parts = d->parts.as<int32_t>();
+  }
+  ok(mkp_launch_ingest_parse(d->stream, d->raw.as<uint8_t>(), &P, d_parts, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->rec_off.as<unsigned long long>(), d->info.as<MkpRecInfo>(), d->sz.as<uint32_t>(),
                              d->extra.as<int32_t>(), d->tot.as<MkpIngestTotals>()), "parse launch");
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "parse sync");
   check(tot->err);
-  const uint32_t n = tot->n_kept;
+  const uint32_t n = tot->n_kept, n_so = tot->n_sample_only, n_pk = n + n_so;
   // ---- pack
   out->d_cigar = d->take((tot->cigar_words + 16) * 4); out->d_chunk = d->take((tot->chunk_pairs + 4) * 8); out->d_seq = d->take(tot->seq_bytes + 64);
-  out->d_tagref = d->take(((size_t)n * MKP_MAX_TAGS + 1) * sizeof(MkpTagRef)); out->d_ranks = d->take((tot->ml_bytes + 16) * 4); out->d_ml = d->take(tot->ml_bytes + 64);
-  DevBuf d_hdr = d->take(((size_t)n + 1) * sizeof(MkpReadHdr));
+  out->d_tagref = d->take(((size_t)n_pk * MKP_MAX_TAGS + 1) * sizeof(MkpTagRef)); out->d_ranks = d->take((tot->ml_bytes + 16) * 4); out->d_ml = d->take(tot->ml_bytes + 64);
+  DevBuf d_hdr = d->take(((size_t)n_pk + 1) * sizeof(MkpReadHdr));
   struct Back { mkp_dev_ingest* d; DevBuf b; ~Back() { std::lock_guard<std::mutex> g(d->spare_mu); if (b.p) { if (d->spares.size() < 16) d->spares.push_back(b); else b.release(); } } } back{d, d_hdr};
-  d->dig.ensure(((size_t)n + 1) * sizeof(MkpRecDigest));
+  d->dig.ensure(((size_t)n_pk + 1) * sizeof(MkpRecDigest));
   ok(mkp_launch_ingest_pack(d->stream, d->raw.as<uint8_t>(), P.rec_cap, d->info.as<MkpRecInfo>(), d->sz.as<uint32_t>(), d_hdr.as<MkpReadHdr>(), out->d_cigar.as<uint32_t>(), out->d_chunk.as<uint32_t>(),
                             out->d_seq.as<uint8_t>(), out->d_tagref.as<MkpTagRef>(), out->d_ranks.as<uint32_t>(), out->d_ml.as<uint8_t>(), d->dig.as<MkpRecDigest>(), d->tot.as<MkpIngestTotals>()), "pack launch");
-  S.hdr.resize(n); S.tagref.resize((size_t)n * MKP_MAX_TAGS); S.name_hash.resize(n);
-  std::vector<MkpRecDigest> dig(n); std::vector<int32_t> extra(2 * (size_t)tot->n_extra);
-  if (n) { ok(hipMemcpyAsync(S.hdr.data(), d_hdr.p, (size_t)n * sizeof(MkpReadHdr), hipMemcpyDeviceToHost, d->stream), "D2H");
-           ok(hipMemcpyAsync(S.tagref.data(), out->d_tagref.p, (size_t)n * MKP_MAX_TAGS * sizeof(MkpTagRef), hipMemcpyDeviceToHost, d->stream), "D2H");
-           ok(hipMemcpyAsync(dig.data(), d->dig.p, (size_t)n * sizeof(MkpRecDigest), hipMemcpyDeviceToHost, d->stream), "D2H"); }
+  S.hdr.resize(n); S.so_hdr.resize(n_so); S.tagref.resize((size_t)n_pk * MKP_MAX_TAGS); S.name_hash.resize(n);
+  std::vector<MkpRecDigest> dig(n_pk); std::vector<int32_t> extra(2 * (size_t)tot->n_extra);
+  if (n) ok(hipMemcpyAsync(S.hdr.data(), d_hdr.p, (size_t)n * sizeof(MkpReadHdr), hipMemcpyDeviceToHost, d->stream), "D2H");
+  if (n_so) ok(hipMemcpyAsync(S.so_hdr.data(), d_hdr.as<MkpReadHdr>() + n, (size_t)n_so * sizeof(MkpReadHdr), hipMemcpyDeviceToHost, d->stream), "D2H");
+  if (n_pk) { ok(hipMemcpyAsync(S.tagref.data(), out->d_tagref.p, (size_t)n_pk * MKP_MAX_TAGS * sizeof(MkpTagRef), hipMemcpyDeviceToHost, d->stream), "D2H");
+              ok(hipMemcpyAsync(dig.data(), d->dig.p, (size_t)n_pk * sizeof(MkpRecDigest), hipMemcpyDeviceToHost, d->stream), "D2H"); }
   if (!extra.empty()) ok(hipMemcpyAsync(extra.data(), d->extra.p, extra.size() * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "pack sync");
@@ -208,26 +217,24 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   // ---- digest -> what the planner reads: layout ids (this shard's own table; mkp_internal_shard_attach maps them into the context's), flags
   auto t_dig = std::chrono::steady_clock::now();
   S.n_calls = tot->n_calls; S.dev_n_ranks = tot->n_calls; S.dev_n_ml = tot->n_ml_used;
-  S.dev_sum2.resize(n); S.dev_name_hash2.resize(n); S.dev_sample_only = tot->n_sample_only;
+  S.dev_sum2.resize(n); S.dev_name_hash2.resize(n); S.dev_win_idx.resize(n); S.so_name_hash.resize(n_so); S.so_name_hash2.resize(n_so); S.so_win_idx.resize(n_so);
   for (size_t k = 0; k < extra.size(); k += 2) S.extra_spans.push_back({extra[k], extra[k + 1]});
   std::unordered_map<uint64_t, uint16_t> by_hash; std::vector<uint8_t> recbuf;
   uint64_t ev_cap = 0;
-  for (uint32_t j = 0; j < n; j++) {
-    MkpReadHdr& h = S.hdr[j];
-    S.name_hash[j] = dig[j].name_hash; S.dev_name_hash2[j] = dig[j].name_hash2; S.dev_sum2[j] = (uint8_t)(h.pad & 1u); h.pad = 0;
-    ev_cap += h.event_cap;
+  for (uint32_t j = 0; j < n_pk; j++) {
+    const bool so = j >= n;
+    MkpReadHdr& h = so ? S.so_hdr[j - n] : S.hdr[j];
+    if (so) { S.so_name_hash[j - n] = dig[j].name_hash; S.so_name_hash2[j - n] = dig[j].name_hash2; S.so_win_idx[j - n] = (uint32_t)dig[j].win_idx; h.pad = 0; }
+    else { S.name_hash[j] = dig[j].name_hash; S.dev_name_hash2[j] = dig[j].name_hash2; S.dev_win_idx[j] = (uint32_t)dig[j].win_idx; S.dev_sum2[j] = (uint8_t)(h.pad & 1u); h.pad = 0; ev_cap += h.event_cap; }
     if (!h.n_tags || (h.flags & MKP_RF_BAD)) continue;
     auto it = by_hash.find(dig[j].key_hash);
     if (it == by_hash.end()) {
       // a structure not seen in this shard yet: its record comes back from HBM and goes through the host packer, which interns the layout
       // (and must arrive at the same key: a colliding hash would otherwise attach the wrong caller tables)
-      MkpRecInfo ri;
-      // the record's place in the window: find it through the info table (kept records are in window order; j-th kept one)
-      // -- the scan offsets are on the device; one small search kernel would do, but first sightings are rare: read info[] once per shard
-      if (out->info_host.empty()) { out->info_host.resize(n_all); ok(hipMemcpyAsync(out->info_host.data(), d->info.p, (size_t)n_all * sizeof(MkpRecInfo), hipMemcpyDeviceToHost, d->stream), "D2H (record table)"); ok(hipStreamSynchronize(d->stream), "sync");
-        out->kept_index.reserve(n); for (uint32_t i = 0; i < n_all; i++) if (out->info_host[i].kind == 1) out->kept_index.push_back(i); }
-      if (out->kept_index.size() != n) throw Error(MKP_E_DEVICE, "internal: device ingest kept-record count disagrees with its record table");
-      ri = out->info_host[out->kept_index[j]];
+      if (out->info_host.empty()) { out->info_host.resize(n_all); ok(hipMemcpyAsync(out->info_host.data(), d->info.p, (size_t)n_all * sizeof(MkpRecInfo), hipMemcpyDeviceToHost, d->stream), "D2H (record table)"); ok(hipStreamSynchronize(d->stream), "sync"); }
+      const uint64_t wi = dig[j].win_idx;
+      if (wi >= n_all || (out->info_host[wi].kind != 1 && out->info_host[wi].kind != 3)) throw Error(MKP_E_DEVICE, "internal: device ingest digest points at a record it did not pack");
+      const MkpRecInfo ri = out->info_host[wi];
       recbuf.resize((size_t)ri.bs + 4);
       ok(hipMemcpyAsync(recbuf.data(), d->raw.as<uint8_t>() + (ri.core - 4), recbuf.size(), hipMemcpyDeviceToHost, d->stream), "D2H (record)"); ok(hipStreamSynchronize(d->stream), "sync");
       mkp_record r; const uint8_t* c = recbuf.data() + 4;
@@ -245,11 +252,11 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     h.layout = it->second;
   }
   S.n_events_cap = ev_cap;
-  std::vector<MkpRecInfo>().swap(out->info_host); std::vector<uint32_t>().swap(out->kept_index);
+  std::vector<MkpRecInfo>().swap(out->info_host);
   out->ms_digest = ms_since(t_dig);
   out->n_blocks = nb; out->n_segments = ns; out->n_records = n_all; out->raw_bytes = plan.raw_total; out->comp_bytes = plan.comp_total;
   out->ms_total = ms_since(t0);
-  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f parse+pack %.1f digest %.1f total %.1f ms\n",
-      tid, beg, end, nb, ns, n_all, n, plan.comp_total / 1e6, plan.raw_total / 1e6, out->ms_plan, out->ms_upload, out->ms_inflate, out->ms_pack, out->ms_digest, out->ms_total);
+  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u) in %zu window(s): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f parse+pack %.1f digest %.1f total %.1f ms\n",
+      tid, beg, end, parts.size(), nb, ns, n_all, n, plan.comp_total / 1e6, plan.raw_total / 1e6, out->ms_plan, out->ms_upload, out->ms_inflate, out->ms_pack, out->ms_digest, out->ms_total);
   return out;
 }

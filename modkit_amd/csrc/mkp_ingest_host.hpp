@@ -11,7 +11,7 @@ struct DevShard {
   ShardHost S;                 // hdr, tagref (MKP_MAX_TAGS per read), name_hash, extra_spans, dev_sum2; dev_packed = true; hdr[i].layout indexes `layouts`
   Packer layouts;              // MM header structures of this shard, in order of first appearance
   DevBuf d_cigar, d_chunk, d_seq, d_tagref, d_ranks, d_ml;
-  std::vector<MkpRecInfo> info_host; std::vector<uint32_t> kept_index;   // scratch of the layout interning
+  std::vector<MkpRecInfo> info_host;   // scratch of the layout interning
   uint64_t n_blocks = 0, n_segments = 0, n_records = 0, raw_bytes = 0, comp_bytes = 0;
   double ms_plan = 0, ms_upload = 0, ms_inflate = 0, ms_pack = 0, ms_digest = 0, ms_total = 0;
   DevShard() = default; DevShard(const DevShard&) = delete; DevShard& operator=(const DevShard&) = delete;
@@ -26,13 +26,17 @@ template <class Seg> inline std::vector<Seg> mkp_plan_segments(const mkp::BamSou
   return segs;
 }
 
-// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block below 24 576 blocks, one thread per block from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
+// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block below 24 576 blocks, one thread per block (second edition) from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
 hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status);
 
 mkp_dev_ingest* mkp_internal_ingest_create(int device);
 void mkp_internal_ingest_destroy(mkp_dev_ingest* d);
 // the indexed fetch of [beg, end) on `tid` — every record overlapping it — inflated, cut, filtered and packed on the device; throws mkp::Error
-std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const mkp::BamSource& bam, uint32_t tid, uint32_t beg, uint32_t end);
+// (several windows — ascending, disjoint: a shard made of BED spans — select the union of their fetches, every record once)
+std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const mkp::BamSource& bam, uint32_t tid, const mkp::FetchParts& parts);
+inline std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const mkp::BamSource& bam, uint32_t tid, uint32_t beg, uint32_t end) {
+  return mkp_internal_ingest_run(d, bam, tid, mkp::FetchParts{{(int64_t)beg, (int64_t)end}});
+}
 // the shard begun with mkp_shard_begin takes these records instead of mkp_shard_add_records: device arrays swapped into the context
 // (what the context held before stays in `sh` and goes back to the ingest object with mkp_internal_ingest_recycle)
 int mkp_internal_shard_attach(mkp_ctx* c, mkp::DevShard* sh);

@@ -216,7 +216,10 @@ struct ShardHost {
   // (MKP_MAX_TAGS entries per read, pad = "same delta list as the tag before") and name_hash are the digest the planner works from.
   bool dev_packed = false; std::vector<uint8_t> dev_sum2;   // per read: the probability-sum test of a two-tag read (what make_resident computes from S.ml otherwise)
   uint64_t dev_n_ranks = 0, dev_n_ml = 0;
-  std::vector<uint64_t> dev_name_hash2; uint32_t dev_sample_only = 0;   // second name hash; records of the window only the threshold sampler would take
+  std::vector<uint64_t> dev_name_hash2; std::vector<uint32_t> dev_win_idx;   // second name hash; place in the window (file order)
+  // records of the window only the threshold sampler takes (QC-fail, CIGAR-less): packed behind the kept ones in the same HBM arrays; their
+  // tag table entries follow the kept reads' in `tagref` (tag_off = MKP_MAX_TAGS * (hdr.size() + k))
+  PodVec<MkpReadHdr> so_hdr; std::vector<uint64_t> so_name_hash, so_name_hash2; std::vector<uint32_t> so_win_idx;
   // append shard pieces packed independently (parallel packing), in order: offsets are rebased, layout ids remapped.  Sizes
   // are fixed first, then every piece is copied into place by its own thread.
   void append_all(const std::vector<ShardHost>& ps, const std::vector<std::vector<uint16_t>>& layout_maps) {
@@ -250,7 +253,7 @@ struct ShardHost {
     n_events_cap = e.ev; n_calls = calls;
   }
   void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); extra_spans.clear();
-               dev_packed = false; dev_sum2.clear(); dev_n_ranks = dev_n_ml = 0; dev_name_hash2.clear(); dev_sample_only = 0; }
+               dev_packed = false; dev_sum2.clear(); dev_n_ranks = dev_n_ml = 0; dev_name_hash2.clear(); dev_win_idx.clear(); so_hdr.clear(); so_name_hash.clear(); so_name_hash2.clear(); so_win_idx.clear(); }
 };
 
 class Packer {

@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <set>
 
 using namespace mkp;
 
@@ -61,7 +62,7 @@ static int plan_mode(const char* path) {
       if (err) return fail("chain error bits", t, err, 0);
       for (size_t i = 1; i < offs.size(); i++) if (offs[i] <= offs[i - 1]) return fail("record offsets not ascending", i, (long long)offs[i], (long long)offs[i - 1]);
       std::vector<std::string> dev_names;
-      for (auto o : offs) { MkpRecInfo R; ingest_parse_record(raw.data(), o, P, &R, &err); if (R.kind == 1) dev_names.push_back(std::string((const char*)raw.data() + R.core + 32) + ":" + std::to_string(R.pos) + ":" + std::to_string(R.flag)); }
+      for (auto o : offs) { MkpRecInfo R; ingest_parse_record(raw.data(), o, P, nullptr, &R, &err); if (R.kind == 1) dev_names.push_back(std::string((const char*)raw.data() + R.core + 32) + ":" + std::to_string(R.pos) + ":" + std::to_string(R.flag)); }
       if (err) return fail("record error bits", t, err, 0);
       BamBatch batch; src->fetch(t, rg[0], rg[1], &batch);
       std::vector<std::string> host_names;
@@ -70,7 +71,37 @@ static int plan_mode(const char* path) {
       n_cmp += host_names.size();
     }
   }
-  printf("ok plan compared=%zu segments=%zu\n", n_cmp, n_seg);
+  // multi-part fetches (a shard made of BED spans): the union of the windows' fetches, every record once, against fetch_parts and
+  // against the windows fetched one by one
+  size_t n_parts_cmp = 0;
+  for (uint32_t t = 0; t < src->ref_names.size(); t++) {
+    const int64_t L = src->ref_lens[t]; if (L < 4000) continue;
+    const FetchParts layouts[3] = {{{L / 10, L / 10 + 300}, {L / 2, L / 2 + 1200}, {L - 1500, L - 200}}, {{0, 50}, {60, 61}, {L / 3, 2 * L / 3}}, {{100, 101}, {L / 4, L / 4 + 16}, {L / 4 + 16, L / 4 + 5000}, {L - 50, L + 16}}};
+    for (auto& parts : layouts) {
+      BamSource::IngestPlan plan; src->ingest_ranges(t, parts, &plan); src->ingest_blocks(&plan);
+      std::vector<uint8_t> raw(plan.raw_total + 8, 0);
+      for (auto& r : plan.ranges) { std::vector<uint8_t> comp(r.file_len + 8, 0); if (::pread(src->fd(), comp.data(), r.file_len, (off_t)r.file_off) != (ssize_t)r.file_len) return 2;
+        for (size_t k = r.blk0; k < r.blk1; k++) { const auto& b = plan.blks[k]; if (b.isize) inflate_block(comp.data() + (b.coff - r.file_off) + b.hdr, b.clen, raw.data() + b.doff, b.isize); } }
+      const std::vector<MkpSeg> segs = mkp_plan_segments<MkpSeg>(plan);
+      std::vector<int32_t> pv; for (auto& pr : parts) { pv.push_back((int32_t)pr.first); pv.push_back((int32_t)pr.second); }
+      MkpIngestParams P; memset(&P, 0, sizeof(P)); P.raw_len = plan.raw_total; P.tid = (int32_t)t; P.beg = (int32_t)parts.front().first; P.end = (int32_t)parts.back().second; P.n_ref = (int32_t)src->ref_names.size();
+      P.n_seg = (uint32_t)segs.size(); P.n_parts = (uint32_t)parts.size();
+      uint32_t err = 0; std::vector<std::string> dev_names;
+      for (auto& sg : segs) { const uint32_t n = ingest_walk_segment(raw.data(), plan.raw_total, sg, nullptr, &err); std::vector<unsigned long long> offs(n); ingest_walk_segment(raw.data(), plan.raw_total, sg, offs.data(), &err);
+        for (auto o : offs) { MkpRecInfo R; ingest_parse_record(raw.data(), o, P, pv.data(), &R, &err); if (R.kind == 1) dev_names.push_back(std::string((const char*)raw.data() + R.core + 32) + ":" + std::to_string(R.pos)); } }
+      if (err) return fail("multi-part error bits", t, err, 0);
+      BamBatch batch; src->fetch_parts(t, parts, &batch);
+      std::vector<std::string> host_names; for (auto& e : batch.recs) { const mkp_record r = batch.view(e); if (Packer::keep(r)) host_names.push_back(batch.qname(e) + ":" + std::to_string(e.pos)); }
+      if (dev_names != host_names) return fail("kept records of a multi-part fetch", t, (long long)dev_names.size(), (long long)host_names.size());
+      // one by one: the union, first sighting kept
+      std::vector<std::string> uni; std::set<std::string> seen;
+      for (auto& pr : parts) { BamBatch b1; src->fetch(t, (uint32_t)pr.first, (uint32_t)pr.second, &b1); for (auto& e : b1.recs) { const mkp_record r = b1.view(e); if (!Packer::keep(r)) continue; const std::string k = b1.qname(e) + ":" + std::to_string(e.pos);
+          if (seen.insert(k).second) uni.push_back(k); } }
+      if (uni != host_names) return fail("multi-part fetch vs the windows one by one", t, (long long)host_names.size(), (long long)uni.size());
+      n_parts_cmp += host_names.size();
+    }
+  }
+  printf("ok plan compared=%zu multipart=%zu segments=%zu\n", n_cmp, n_parts_cmp, n_seg);
   return 0;
 }
 
@@ -106,32 +137,35 @@ int main(int argc, char** argv) {
       std::vector<unsigned long long> rec_off(tot.n_all);
       for (size_t i = 0; i < segs.size(); i++) ingest_walk_segment(raw, raw_len, segs[i], rec_off.data() + seg_cnt[i], &tot.err);
       for (size_t i = 0; i < rec_off.size(); i++) if (rec_off[i] + 4 != bd.recs[i].off) return fail("record offset", i, (long long)rec_off[i] + 4, (long long)bd.recs[i].off);
-      std::vector<MkpRecInfo> info(tot.n_all); std::vector<uint32_t> sz(5 * (size_t)tot.n_all); std::vector<std::pair<int32_t, int32_t>> extra;
+      std::vector<MkpRecInfo> info(tot.n_all); std::vector<uint32_t> sz(6 * (size_t)tot.n_all); std::vector<std::pair<int32_t, int32_t>> extra;
       for (uint32_t i = 0; i < tot.n_all; i++) {
-        ingest_parse_record(raw, rec_off[i], P, &info[i], &tot.err);
-        const MkpRecInfo& R = info[i]; const bool k = R.kind == 1; if (R.kind == 3) tot.n_sample_only++;
-        sz[i] = k; sz[(size_t)tot.n_all + i] = k ? R.n_cigar : 0; sz[2 * (size_t)tot.n_all + i] = k ? ingest_chunk_pairs(R.n_cigar) : 0; sz[3 * (size_t)tot.n_all + i] = k ? ingest_seq_bytes(R.l_seq) : 0;
-        sz[4 * (size_t)tot.n_all + i] = k ? R.ml_n : 0;
+        ingest_parse_record(raw, rec_off[i], P, nullptr, &info[i], &tot.err);
+        const MkpRecInfo& R = info[i]; const bool k = R.kind == 1, pk = R.kind == 1 || R.kind == 3;
+        sz[i] = k; sz[(size_t)tot.n_all + i] = pk ? ingest_cigar_words(R.n_cigar) : 0; sz[2 * (size_t)tot.n_all + i] = pk ? ingest_chunk_pairs(R.n_cigar) : 0; sz[3 * (size_t)tot.n_all + i] = pk ? ingest_seq_bytes(R.l_seq) : 0;
+        sz[4 * (size_t)tot.n_all + i] = pk ? R.ml_n : 0; sz[5 * (size_t)tot.n_all + i] = R.kind == 3;
         if (R.kind == 2) { const long long e = (long long)R.pos + (R.reflen > 0 ? R.reflen : 1); extra.push_back({R.pos, (int32_t)std::min<long long>(e, 0x7fffffffll)}); }
       }
-      uint64_t totals[5];
-      for (int q = 0; q < 5; q++) { uint64_t run = 0; for (uint32_t i = 0; i < tot.n_all; i++) { uint32_t& a = sz[(size_t)q * tot.n_all + i]; const uint32_t v = a; a = (uint32_t)run; run += v; } totals[q] = run; }
-      tot.n_kept = (uint32_t)totals[0];
-      std::vector<MkpReadHdr> hdr(tot.n_kept); std::vector<uint32_t> cigar(totals[1] + 1), chunk(2 * totals[2] + 2), ranks(totals[4] + 1); std::vector<uint8_t> seq(totals[3] + 4), ml(totals[4] + 1);
-      std::vector<MkpTagRef> tagref((size_t)tot.n_kept * MKP_MAX_TAGS + 1); std::vector<MkpRecDigest> dig(tot.n_kept + 1);
-      for (uint32_t i = 0; i < tot.n_all; i++) if (info[i].kind == 1)
-        ingest_pack_record(raw, info[i], sz[i], sz[(size_t)tot.n_all + i], sz[2 * (size_t)tot.n_all + i], sz[3 * (size_t)tot.n_all + i], sz[4 * (size_t)tot.n_all + i],
+      uint64_t totals[6];
+      for (int q = 0; q < 6; q++) { uint64_t run = 0; for (uint32_t i = 0; i < tot.n_all; i++) { uint32_t& a = sz[(size_t)q * tot.n_all + i]; const uint32_t v = a; a = (uint32_t)run; run += v; } totals[q] = run; }
+      tot.n_kept = (uint32_t)totals[0]; tot.n_sample_only = (uint32_t)totals[5];
+      const uint32_t n_pk = tot.n_kept + tot.n_sample_only;
+      std::vector<MkpReadHdr> hdr(n_pk); std::vector<uint32_t> cigar(totals[1] + 1), chunk(2 * totals[2] + 2), ranks(totals[4] + 1); std::vector<uint8_t> seq(totals[3] + 4), ml(totals[4] + 1);
+      std::vector<MkpTagRef> tagref((size_t)n_pk * MKP_MAX_TAGS + 1); std::vector<MkpRecDigest> dig(n_pk + 1);
+      for (uint32_t i = 0; i < tot.n_all; i++) if (info[i].kind == 1 || info[i].kind == 3)
+        ingest_pack_record(raw, info[i], i, info[i].kind == 1 ? sz[i] : tot.n_kept + sz[5 * (size_t)tot.n_all + i], sz[(size_t)tot.n_all + i], sz[2 * (size_t)tot.n_all + i], sz[3 * (size_t)tot.n_all + i], sz[4 * (size_t)tot.n_all + i],
                            hdr.data(), cigar.data(), chunk.data(), seq.data(), tagref.data(), ranks.data(), ml.data(), dig.data(), &tot);
       // ---- the host path over the same region: the fetch's region test, Packer::keep, Packer::add
-      std::vector<mkp_record> recs; std::vector<std::pair<int32_t, int32_t>> hextra;
+      std::vector<mkp_record> recs, so_recs; std::vector<std::pair<int32_t, int32_t>> hextra;
       for (auto& e : bd.recs) {
         if (e.tid != (int32_t)t || (int64_t)e.pos >= P.end || (int64_t)e.end <= P.beg) continue;
         const mkp_record r = bd.view(e);
         if (Packer::keep(r)) recs.push_back(r);
+        else if (!(r.flag & (4 | 256 | 1024 | 2048)) && r.l_qseq > 0) so_recs.push_back(r);   // the sampler's candidates that the pileup drops
         else if ((r.flag & 2048) && !(r.flag & (4 | 256 | 512 | 1024)) && r.n_cigar) hextra.push_back({e.pos, (int32_t)std::min<int64_t>((int64_t)e.pos + std::max<int64_t>(e.reflen, 1), INT32_MAX)});
       }
       Packer pk; ShardHost S; S.tid = (int32_t)t; uint32_t host_err = 0;
-      try { for (auto& r : recs) pk.add(r, S); }
+      const size_t n_keep_host = recs.size();
+      try { for (auto& r : recs) pk.add(r, S); for (auto& r : so_recs) pk.add(r, S); }   // (one host shard: the kept records, then the sampler-only ones — the order of the device headers)
       catch (const Error& e) {
         const std::string m = e.what();
         host_err = m.find("non-ASCII") != std::string::npos ? MKP_IE_NONASCII : m.find("more than 4 mod codes") != std::string::npos ? MKP_IE_CODES : m.find("more than 8 MM tags") != std::string::npos ? MKP_IE_TAGS
@@ -139,13 +173,11 @@ int main(int argc, char** argv) {
       }
       if (host_err) { if (!(tot.err & host_err)) return fail("error bits (host threw)", 0, tot.err, host_err); continue; }
       if (tot.err) return fail("error bits (host did not throw)", 0, tot.err, 0);
-      if (S.hdr.size() != tot.n_kept) return fail("kept records", 0, tot.n_kept, (long long)S.hdr.size());
-      { uint32_t so = 0;   // the sampler's candidates (sample_probabilities: candidates()) that Packer::keep drops
-        for (auto& e : bd.recs) { if (e.tid != (int32_t)t || (int64_t)e.pos >= P.end || (int64_t)e.end <= P.beg) continue; const mkp_record r = bd.view(e);
-          if (!(e.flag & (4 | 256 | 1024 | 2048)) && r.l_qseq > 0 && !Packer::keep(r)) so++; }
-        if (so != tot.n_sample_only) return fail("sampler-only records", 0, tot.n_sample_only, so); }
+      if (n_keep_host != tot.n_kept) return fail("kept records", 0, tot.n_kept, (long long)n_keep_host);
+      if (so_recs.size() != tot.n_sample_only) return fail("sampler-only records", 0, tot.n_sample_only, (long long)so_recs.size());
       std::sort(extra.begin(), extra.end()); std::sort(hextra.begin(), hextra.end());
       if (extra != hextra) return fail("supplementary spans", 0, (long long)extra.size(), (long long)hextra.size());
+      for (uint32_t j = 1; j < n_pk; j++) if (j != tot.n_kept && dig[j].win_idx <= dig[j - 1].win_idx) return fail("window order of the packed records", j, (long long)dig[j].win_idx, (long long)dig[j - 1].win_idx);
       uint64_t calls = 0, ml_used = 0;
       for (size_t j = 0; j < S.hdr.size(); j++) {
         const MkpReadHdr &d = hdr[j], &h = S.hdr[j]; total_cmp++;

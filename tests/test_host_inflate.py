@@ -84,6 +84,18 @@ int main(int argc, char** argv) {
       if (k >= 3 && st2 == 0) { printf("FAIL corrupt %d/%d decoded cleanly\n", it, k); fails++; }
     }
   }
+  // periodic data: matches at every short distance, 258 bytes long, chained (the second edition's pattern / cyclic / stepwise copies)
+  for (int d = 1; d <= 48; d++) for (int lvl : {1, 6, 9}) {
+    const uint32_t n = 3000 + (uint32_t)(rand() % 60000); std::vector<uint8_t> raw(n), per((size_t)d);
+    for (auto& x : per) x = (uint8_t)rand();
+    for (uint32_t i = 0; i < n; i++) raw[i] = per[i % (uint32_t)d];
+    for (int k = 0; k < 40; k++) raw[(size_t)rand() % n] = (uint8_t)rand();   // a few breaks: literal runs and fresh matches in between
+    z_stream zs; memset(&zs, 0, sizeof(zs)); deflateInit2(&zs, lvl, Z_DEFLATED, -15, 9, Z_DEFAULT_STRATEGY);
+    std::vector<uint8_t> comp(n + 1024); zs.next_in = raw.data(); zs.avail_in = n; zs.next_out = comp.data(); zs.avail_out = (uInt)comp.size();
+    deflate(&zs, Z_FINISH); const uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
+    std::vector<uint8_t> got; const uint32_t st = run_block(comp.data(), clen, got, n);
+    if (st != 0 || got != raw) { printf("FAIL periodic d=%d level %d: status %u\n", d, lvl, st); fails++; }
+  }
   if (fails) printf("FAILED %d\n", fails); else printf("ok %zu blocks %zu bytes\n", blocks, bytes);
   return fails ? 1 : 0;
 }
