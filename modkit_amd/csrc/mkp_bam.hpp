@@ -397,7 +397,12 @@ struct BaiIndex {
     std::vector<Chunk> out; if (tid >= refs.size() || end <= beg) return out;
     const Ref& R = refs[tid]; std::vector<uint32_t> bins; reg2bins(beg, end, &bins);
     uint64_t min_off = 0; { const size_t w = (size_t)(beg >> 14); if (!R.lin.empty()) min_off = R.lin[std::min(w, R.lin.size() - 1)]; }
-    for (uint32_t b : bins) { auto it = R.bins.find(b); if (it == R.bins.end()) continue; for (auto& c : it->second) if (c.end > min_off) out.push_back(c); }
+    // upper bound: a record that lies wholly inside a 16 kb window past `end` starts behind every record the region can hold (the file is
+    // coordinate sorted), so the first chunk of that window's own bin ends the search — what htslib gets by stopping at the first
+    // record with pos >= end, known here before anything is read (the device ingest uploads whole ranges; a sparse BED asks for hundreds)
+    uint64_t max_off = UINT64_MAX;
+    for (int64_t w = ((end - 1) >> 14) + 1, tries = 0; tries < 256 && w < (1 << 15); w++, tries++) { auto it = R.bins.find((uint32_t)(4681 + w)); if (it != R.bins.end() && !it->second.empty()) { max_off = it->second.front().beg; break; } }
+    for (uint32_t b : bins) { auto it = R.bins.find(b); if (it == R.bins.end()) continue; for (auto c : it->second) if (c.end > min_off && c.beg < max_off) { c.end = std::min(c.end, max_off); out.push_back(c); } }
     std::sort(out.begin(), out.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
     // chunks are record-granular and those of neighbouring bins interleave in the file: ranges that overlap, touch, or lie within
     // one block (64 KiB compressed) of each other are read as one — the records in between belong to other bins of the same

@@ -521,10 +521,14 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   const bool dev_ingest = bam.indexed() && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !inflater.d && !host_ingest_env;
   if (dev_ingest && !ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
   double ingest_ms[5] = {0, 0, 0, 0, 0}; uint64_t ingest_blocks = 0, ingest_records = 0;
-  auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) {
-    ShardInput in; const uint32_t lo = s0 > MKP_HALO ? s0 - MKP_HALO : 0, hi = s1 + MKP_HALO;
-    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ctx->ingest, bam, tid, lo, hi); return in; }   // foreground: the upload feeds the GPU's longest job of the run
-    HostPool::background() = true; in.batch.reset(new BamBatch()); bam.fetch(tid, lo, hi, in.batch.get()); return in; };
+  // the records of a shard: those overlapping any of its windows (one window, or the BED spans of a merged shard), each +- the halo
+  auto fetch_windows = [&](uint32_t tid, const std::vector<std::pair<uint32_t, uint32_t>>& wins) {
+    ShardInput in; FetchParts parts;
+    for (auto& w : wins) { const int64_t lo = w.first > MKP_HALO ? (int64_t)w.first - MKP_HALO : 0, hi = (int64_t)w.second + MKP_HALO;
+      if (!parts.empty() && lo <= parts.back().second) parts.back().second = std::max(parts.back().second, hi); else parts.push_back({lo, hi}); }
+    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ctx->ingest, bam, tid, parts); return in; }   // foreground: the upload feeds the GPU's longest job of the run
+    HostPool::background() = true; in.batch.reset(new BamBatch()); bam.fetch_parts(tid, parts, in.batch.get()); return in; };
+  auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) { return fetch_windows(tid, {{s0, s1}}); };
   // The first shard's blocks are read and inflated behind the threshold estimate (background priority on the host pool: the estimate's
   // own bursts go first), as soon as the first contig's grid is known.
   std::future<ShardInput> early_fetch; uint32_t early_s0 = 0, early_s1 = 0; bool early_set = false;
@@ -546,7 +550,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       auto t_focus = std::chrono::steady_clock::now();
       for (size_t ri = 0; ri < records.size(); ri++) {
         grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1;
-        if (ri == 0 && !early_whole && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {
+        if (ri == 0 && !early_whole && !bf && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {   // (--include-bed: the first shard is a merge of records, known only with the plan)
           uint64_t bp; const size_t i1 = shard_cut(records[0], grid_of[0], 0, &bp);
           early_s0 = grid_of[0][0].start; early_s1 = grid_of[0][i1 - 1].end; early_set = true;
           early_fetch = std::async(std::launch::async, fetch_range, records[0].tid, early_s0, early_s1);
@@ -645,7 +649,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       wr.f);
   // ---- shard plan (shard_cut above); ranks take contiguous runs, balanced by the bytes the index puts under them (by length
   // without an index)
-  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */ };
+  struct ShardPart { size_t rec; uint32_t s0, s1; };
+  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */
+                     std::vector<ShardPart> parts; /* --include-bed: the BED-span records merged into this shard (empty: one window) */ };
   std::vector<ShardPlan> plan;
   const bool hf = fb.has_focus();
   uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0;
@@ -673,7 +679,27 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
     }
   }
-  auto fetch_shard = [&](const ShardPlan& sp) { return fetch_range(records[sp.rec].tid, sp.s0, sp.s1); };
+  // --include-bed: optimize_reference_records (position_filter.rs:103-210) turns every run of BED spans into a reference record of its own —
+  // hundreds per contig for a sparse BED.  Rows only depend on the focus bytes (BED positions inside the records), not on how records are
+  // grouped, so consecutive records of one contig share a shard: one hull window whose focus is zero between the records, fed by a
+  // multi-window fetch of the records' spans only (what lies between them is neither read nor inflated).
+  if (bf && plan.size() > 1 && !getenv("MKP_NO_BED_MERGE")) {
+    std::vector<ShardPlan> merged; uint64_t bytes = 0;
+    for (auto& sp : plan) {
+      const uint32_t tid = records[sp.rec].tid;
+      const uint64_t sp_bytes = bam.indexed() ? bam.offset_at(tid, sp.s1) - bam.offset_at(tid, sp.s0) + (1u << 16) : 0;
+      const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1 && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp && bytes + sp_bytes <= shard_bytes &&
+                        merged.back().parts.size() < 65536;
+      if (!join) { ShardPlan m = sp; m.parts.assign(1, {sp.rec, sp.s0, sp.s1}); merged.push_back(std::move(m)); bytes = sp_bytes; continue; }
+      ShardPlan& m = merged.back(); m.s1 = sp.s1; m.bp += sp.bp; m.iv_starts.insert(m.iv_starts.end(), sp.iv_starts.begin(), sp.iv_starts.end()); m.parts.push_back({sp.rec, sp.s0, sp.s1}); bytes += sp_bytes;
+    }
+    for (auto& m : merged) if (m.parts.size() == 1) m.parts.clear();
+    plan.swap(merged);
+  }
+  auto fetch_shard = [&](const ShardPlan& sp) {
+    if (sp.parts.empty()) return fetch_range(records[sp.rec].tid, sp.s0, sp.s1);
+    std::vector<std::pair<uint32_t, uint32_t>> wins; for (auto& pt : sp.parts) wins.push_back({pt.s0, pt.s1});
+    return fetch_windows(records[sp.rec].tid, wins); };
   mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<ShardInput> next_batch;
@@ -692,10 +718,13 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack; ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
                ingest_records += dev->n_records; }
     if (pi + 1 < plan.size()) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
-    if (hf && !focus_done[sp.rec]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(rec, a.interval_size, &focus_of[sp.rec]); focus_done[sp.rec] = 1;
-        focus_ms += ms_since(t_focus); }
+    std::vector<uint8_t> merged_focus;   // a merged shard: its records' focus bytes at their places in the hull, zero in between
+    if (hf) for (size_t k = 0; k < std::max<size_t>(sp.parts.size(), 1); k++) { const size_t ri = sp.parts.empty() ? sp.rec : sp.parts[k].rec;
+      if (!focus_done[ri]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(records[ri], a.interval_size, &focus_of[ri]); focus_done[ri] = 1; focus_ms += ms_since(t_focus); } }
     if (sp.rec > 0 && (pi == 0 || plan[pi - 1].rec != sp.rec)) for (size_t r2 = 0; r2 < sp.rec; r2++) { std::vector<uint8_t>().swap(focus_of[r2]);
         }   // earlier contigs are done
+    if (hf && !sp.parts.empty()) { merged_focus.assign((size_t)(s1 - s0), 0);
+      for (auto& pt : sp.parts) memcpy(merged_focus.data() + (pt.s0 - s0), focus_of[pt.rec].data() + (pt.s0 - records[pt.rec].start), (size_t)(pt.s1 - pt.s0)); }
     const std::vector<uint8_t>& focus = focus_of[sp.rec];
     std::vector<mkp_record> recs; if (batch) { recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e)); }
     {
@@ -718,7 +747,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
             continue;
       }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
-      if (hf) { sh.focus = focus.data() + (s0 - rec.start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+      if (hf) { sh.focus = sp.parts.empty() ? focus.data() + (s0 - rec.start) : merged_focus.data(); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
       mark("shard blocks in hand");
       if (attached_already) dev.reset();   // begun and attached before the threshold estimate, which sampled from it
       else {

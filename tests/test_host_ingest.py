@@ -162,3 +162,32 @@ def test_indexed_fetch_equals_whole_file_on_fuzzed_bams(tmp_path, seed):
         b, sb, _ = plan(bam, flags + ["--no-index"], str(tmp_path / "b.tsv"))
         assert a == b and a, flags
         assert sa["indexed"] == 1 and sb["indexed"] == 0
+
+
+def test_bed_spans_of_a_contig_share_a_shard(tmp_path):
+    """--include-bed: the reference turns every run of BED spans into its own reference record; here the records of one contig share a
+    shard (multi-window fetch).  The plan must hold one shard per contig, name the same records through the index and through the
+    whole-file loader, and read only a fraction of the file."""
+    import random
+    bam, fa = gen(tmp_path, "bedm", [("chrA", 3_000_000), ("chrB", 2_000_000)], 12_000, ["--mean-len", "3000"])
+    rng = random.Random(3)
+    bed = str(tmp_path / "spans.bed")
+    with open(bed, "w") as f:
+        for name, ln in (("chrA", 3_000_000), ("chrB", 2_000_000)):
+            for s in sorted(rng.randrange(0, ln - 3000) for _ in range(10)):
+                f.write("%s\t%d\t%d\n" % (name, s, s + 2000))
+    a, sa, _ = plan(bam, ["--include-bed", bed], str(tmp_path / "a.tsv"))
+    b, sb, _ = plan(bam, ["--include-bed", bed, "--no-index"], str(tmp_path / "b.tsv"))
+    assert a == b
+    lines = a.strip().split("\n")
+    assert len(lines) == 2, lines                       # one merged shard per contig, not one per BED record
+    assert sa["bam_bytes_inflated"] < 0.6 * sb["bam_bytes_inflated"]   # the gaps between the spans were not read
+    # the same records as one shard per BED record would pack (MKP_NO_BED_MERGE): total kept reads can only differ by reads spanning two records
+    env = dict(os.environ, MKP_NO_BED_MERGE="1")
+    p = subprocess.run([CLI, "pileup", bam, str(tmp_path / "c.tsv"), "--plan-only", "--include-bed", bed], capture_output=True, text=True, env=env)
+    assert p.returncode == 0
+    unmerged = open(str(tmp_path / "c.tsv")).read().strip().split("\n")
+    assert len(unmerged) > 5
+    n_merged = sum(int(l.split("\t")[3]) for l in lines)
+    n_unmerged = sum(int(l.split("\t")[3]) for l in unmerged)
+    assert n_merged <= n_unmerged and n_merged > 0.5 * n_unmerged
