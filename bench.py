@@ -505,9 +505,12 @@ def main():
                             "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
                             "generator_s": gen_s, "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
                             "parity": "bit-exact vs the restated CPU path (oracle/) on this BAM; the oracle is pinned on the reference's golden files; ties / >=3 codes / QC-fail / N ops are reference-unpinned and sample-probs has no reference pin (DESIGN.md §7)",
-                            "slowest_kernel": slowest_name}, **extra_cfg),
+                            "slowest_kernel": slowest_name,
+                            "ingest": "device (compressed BGZF blocks up; inflate, record cut, MM/ML tokeniser and packing in HBM)" if not os.environ.get("MKP_HOST_INGEST") == "1" else "host",
+                            "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MKP_") and k != "MKP_BENCH_DIR"}}, **extra_cfg),
             "tiers": tiers,
-            "roofline": dict(agg, slowest=slow, whole_pass=whole),
+            # `roofline` itself = the aggregation kernel (north_star's target); `dominant` = the kernel that takes most of the step
+            "roofline": dict(agg, slowest=slow, dominant=dict(slow, share_of_step=(slow["avg_launch_ms"] / ms_per_step) if ms_per_step else None), whole_pass=whole),
         }
         if world == 1 and not a.no_cpu_baseline:
             workers = min(usable_cpus(), 8)

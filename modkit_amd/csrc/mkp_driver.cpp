@@ -14,6 +14,8 @@
 #include <set>
 #include <thread>
 
+#include <unistd.h>
+
 #include "mkp_ctx.hpp"
 #include "mkp_ingest_host.hpp"
 #include "mkp_focus.hpp"
@@ -98,9 +100,9 @@ SampleTimes g_sample_times;   // --stats: where the threshold estimate's time we
 // attached to the context covers the contig — indices into that shard's digest (every kept record is a candidate; names are compared
 // through their two 64-bit hashes; the reads' bases and tags are in HBM already, mkp_internal_sample_resident).
 struct RecSet {
-  std::unique_ptr<BamBatch> b; const ShardHost* S = nullptr; std::vector<uint32_t> idx;   // resident: index < S->hdr.size() = a kept read, above = sampler-only read (index - hdr.size())
+  std::unique_ptr<BamBatch> b; bool complete = false; const ShardHost* S = nullptr; std::vector<uint32_t> idx;   // complete: nothing was left out for a later fetch; resident: index < S->hdr.size() = a kept read, above = sampler-only read (index - hdr.size())
   size_t size() const { return S ? idx.size() : b->recs.size(); }
-  bool truncated(size_t cap) const { return !S && b->recs.size() >= cap; }
+  bool truncated(size_t cap) const { return !S && !complete && b->recs.size() >= cap; }
   std::string name(size_t i) const {
     if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size(); char key[16]; memcpy(key, k < n ? &S->name_hash[k] : &S->so_name_hash[k - n], 8); memcpy(key + 8, k < n ? &S->dev_name_hash2[k] : &S->so_name_hash2[k - n], 8);
       return std::string(key, 16); }
@@ -136,7 +138,19 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         std::stable_sort(r.idx.begin(), r.idx.end(), [&](uint32_t x, uint32_t y) { return wi(x) < wi(y); }); }
       return r;
     }
-    r.b.reset(new BamBatch()); bam.fetch(tid, s, e, r.b.get(), cap); return r;
+    r.b.reset(new BamBatch());
+    if (bf && !getenv("MKP_NO_BED_SAMPLING")) {
+      // under --include-bed a read counts only through calls on BED positions (the kernel masks the rest): a read that meets no BED span of
+      // the interval yields nothing, is not counted and not recorded — so only the records over the interval's spans are fetched (a sparse
+      // BED used to make the estimate inflate every sampling interval whole), all of them: there is no head to extend afterwards
+      std::vector<Span> sp;
+      for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue; for (auto& x : it->second) if (x.e > s && x.s < e) sp.push_back({std::max<uint64_t>(x.s, s), std::min<uint64_t>(x.e, e)}); }
+      merge_spans(sp);
+      FetchParts parts; for (auto& x : sp) parts.push_back({(int64_t)x.s, (int64_t)x.e});
+      if (!parts.empty()) bam.fetch_parts(tid, parts, r.b.get());
+      r.complete = true; return r;
+    }
+    bam.fetch(tid, s, e, r.b.get(), cap); return r;
   };
   mkp_internal_bedmask_reset(ctx);
   struct MaskSession { mkp_ctx* c; ~MaskSession() { mkp_internal_bedmask_reset(c); } } mask_session{ctx};   // the host masks below die with this call
@@ -806,6 +820,10 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu (on the device %llu) peak_rss_kb=%llu\n",
                        (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
                        (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)bam.bytes_inflated_device.load(), (unsigned long long)peak_rss_kb());
+  if (a.stats) {   // every MKP_* variable that is set: they pick kernels and paths and would otherwise leave no trace in a measurement
+    std::string ov; for (char** e = ::environ; e && *e; e++) if (!strncmp(*e, "MKP_", 4)) { ov += ' '; ov += *e; }
+    fprintf(stderr, "[mkpileup] ingest=%s resident_sampling=%d env overrides:%s\n", dev_ingest ? "device" : "host", pre_attached ? 1 : 0, ov.empty() ? " none" : ov.c_str());
+  }
   if (a.stats && dev_ingest) fprintf(stderr, "[mkpileup] device ingest: %llu BGZF blocks, %llu records; block plan %.1f ms, upload %.1f, inflate + CRC + chains %.1f, parse + pack %.1f, digest %.1f (overlapped with the threshold estimate / the shard in hand)\n",
       (unsigned long long)ingest_blocks, (unsigned long long)ingest_records, ingest_ms[0], ingest_ms[1], ingest_ms[2], ingest_ms[3], ingest_ms[4]);
   return MKP_OK;
