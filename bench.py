@@ -371,7 +371,7 @@ def main():
         # one shard per contig piece a rank owns, as the single-GPU line's one resident shard: the default cuts 8 pieces per rank (balance
         # for small files) and 256 MiB of BAM per shard (host memory), which only adds launch and tile-edge overhead to a resident re-run
         flags = flags + ["--shard-bp", str(1 << 27), "--shard-bytes", str(1 << 40)]
-        thr = mkd.pileup_sharded([bam, out_bed] + flags, rank=rank, world=world, device=local_rank, stats=shard_stats)
+        thr = mkd.pileup_sharded([bam, out_bed] + flags, rank=rank, world=world, device=local_rank, stats=shard_stats, mode="full")   # the all-reduce mode (BASELINE configs[3]); the default-mode (broadcast) path is covered by tests/test_gpu_scale.py
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
         # the rank's windows, each resident in HBM on its own context (a window = a piece of one contig; cuts sit on the interval grid)
         plan = mkd.shard_plan([bam, out_bed] + flags, rank, world)

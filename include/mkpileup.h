@@ -227,6 +227,12 @@ int mkp_percentile(const float* sorted, uint64_t n, float q, float* out);
 int mkp_histogram_begin(mkp_ctx* ctx);
 int mkp_histogram_add_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv);
 int mkp_histogram_get(mkp_ctx* ctx, uint32_t base /*A,C,G,T = 0..3*/, uint32_t level, uint32_t prefix, uint64_t* out);
+/* mkp_histogram_get + the all-reduce in one call, on the device: the histogram is widened to u64 in HBM and summed over the ranks of
+ * `nccl_comm` (an ncclComm_t the caller created with ncclCommInitRank, one rank per GPU) with ncclAllReduce(ncclUint64, ncclSum) over
+ * xGMI on the context's stream; `out` receives the sum.  Every rank must make the same calls in the same order.  librccl.so is loaded
+ * at run time.  (modkit_amd.distributed uses it when the job runs on the nccl backend; torch.distributed's all_reduce is the test
+ * double on gloo.) */
+int mkp_histogram_allreduce(mkp_ctx* ctx, void* nccl_comm, uint32_t base, uint32_t level, uint32_t prefix, uint64_t* out);
 int mkp_histogram_from_values(const float* vals, uint64_t n, uint32_t level, uint32_t prefix, uint64_t* out);  /* host values, no device */
 int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint64_t ranks_in_bin[2], uint64_t* n);
 int mkp_histogram_resolve(uint32_t prefix, const uint64_t* hist1, uint64_t rank_in_bin, float* value);

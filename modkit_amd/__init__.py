@@ -69,6 +69,7 @@ def lib():
         L.mkp_histogram_begin.argtypes = [ctypes.c_void_p]
         L.mkp_histogram_add_bam.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
         L.mkp_histogram_get.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p]
+        L.mkp_histogram_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u64p]
         L.mkp_histogram_from_values.argtypes = [f32p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, u64p]
         L.mkp_histogram_locate.argtypes = [u64p, ctypes.c_float, ctypes.POINTER(ctypes.c_uint32), u64p, u64p]
         L.mkp_histogram_resolve.argtypes = [ctypes.c_uint32, u64p, ctypes.c_uint64, f32p]
@@ -80,7 +81,7 @@ def lib():
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_host_threads", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
-           "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_from_values", "mkp_histogram_locate",
+           "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_allreduce", "mkp_histogram_from_values", "mkp_histogram_locate",
            "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs", "mkp_summary", "mkp_extract_calls_main"]
 
 
@@ -254,6 +255,14 @@ class Context:
         args = [str(a).encode() for a in argv]
         arr = (ctypes.c_char_p * max(1, len(args)))(*args)
         self._check(self.L.mkp_histogram_add_bam(self.h, str(bam).encode(), len(args), arr))
+
+    def histogram_allreduce(self, comm, base, level, prefix=0):
+        """histogram_get summed over the ranks of an RCCL communicator (modkit_amd.distributed.RcclComm), in HBM over xGMI."""
+        import numpy as np
+        out = np.zeros(65536, dtype=np.uint64)
+        i = "ACGT".index(base) if isinstance(base, str) else int(base)
+        self._check(self.L.mkp_histogram_allreduce(self.h, comm.handle, i, level, prefix, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+        return out
 
     def histogram_get(self, base, level, prefix=0):
         """uint64[65536] numpy array: level 0 = top 16 bits of the f32 patterns of `base`'s sample, level 1 = low 16 bits under `prefix`."""

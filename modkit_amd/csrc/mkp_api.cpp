@@ -726,7 +726,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask}) b->release();
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask, &c->d_hist64}) b->release();
   mkp_internal_ingest_destroy(c->ingest); c->ingest = nullptr;
   c->h_rows.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -768,7 +768,8 @@ int mkp_shard_begin(mkp_ctx* c, const mkp_shard* s) {
     c->shard.clear(); c->shard.tid = s->tid; c->shard.win_start = (int32_t)s->start; c->shard.win_end = (int32_t)s->end;
     c->has_focus = s->focus != nullptr;
     if (c->has_focus) {
-      c->focus.assign(s->focus, s->focus + (s->end - s->start));
+      { const size_t nf = (size_t)(s->end - s->start); c->focus.resize(nf); const uint8_t* src = s->focus; uint8_t* dst = c->focus.data();
+        host_parallel(nf, (size_t)4 << 20, [&](size_t lo, size_t hi) { memcpy(dst + lo, src + lo, hi - lo); }); }
       if (s->n_combos > 64) throw Error(MKP_E_UNSUPPORTED, "more than 64 motif combos");
       c->combos.assign(s->combos, s->combos + s->n_combos);
       if (c->combos.empty()) { mkp_motif_combo z; memset(&z, 0, sizeof(z)); c->combos.push_back(z); }
@@ -1249,6 +1250,44 @@ int mkp_histogram_get(mkp_ctx* c, uint32_t base, uint32_t level, uint32_t prefix
       hip_check(hipStreamSynchronize(c->stream), "hist1 sync");
     }
     for (size_t i = 0; i < 65536; i++) out[i] = h[i];
+  });
+}
+
+// The path's one collective behind the C ABI: the histogram is summed over the ranks of an RCCL communicator where it sits — widened to
+// u64 in HBM, ncclAllReduce(ncclUint64, ncclSum) over xGMI on the context's stream, one D2H of the result.  librccl is looked up at
+// run time (dlopen): a single-GPU build of the caller needs no RCCL.
+}  // extern "C"
+#include <dlfcn.h>
+extern "C" hipError_t mkp_launch_widen(hipStream_t, const uint32_t*, unsigned long long*, uint32_t);
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+nccl_allreduce_fn rccl_allreduce() {
+  static nccl_allreduce_fn fn = []() -> nccl_allreduce_fn {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f; } }
+    return nullptr; }();
+  return fn;
+}
+}  // namespace
+extern "C" {
+int mkp_histogram_allreduce(mkp_ctx* c, void* nccl_comm, uint32_t base, uint32_t level, uint32_t prefix, uint64_t* out) {
+  if (!c || !nccl_comm || !out || base > 3 || level > 1 || prefix > 0xffffu) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    nccl_allreduce_fn ar = rccl_allreduce();
+    if (!ar) throw Error(MKP_E_DEVICE, "librccl.so not found (ncclAllReduce)");
+    require_sample(c);
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    c->d_hist64.ensure(65536 * 8);
+    const uint32_t* src = c->d_hist0.as<uint32_t>() + (size_t)base * 65536;
+    if (level == 1) {
+      hip_check(hipMemsetAsync(c->d_hist1.p, 0, 65536 * 4, c->stream), "memset");
+      hip_check(mkp_launch_sample_hist1(c->stream, c->d_store.as<uint32_t>(), c->sample_n, base, prefix, c->d_hist1.as<uint32_t>()), "hist1 launch");
+      src = c->d_hist1.as<uint32_t>();
+    }
+    hip_check(mkp_launch_widen(c->stream, src, c->d_hist64.as<unsigned long long>(), 65536u), "widen launch");
+    const int rc = ar(c->d_hist64.p, c->d_hist64.p, 65536, /*ncclUint64*/ 5, /*ncclSum*/ 0, nccl_comm, c->stream);
+    if (rc != 0) throw Error(MKP_E_DEVICE, "ncclAllReduce failed (" + std::to_string(rc) + ")");
+    hip_check(hipMemcpyAsync(out, c->d_hist64.p, 65536 * 8, hipMemcpyDeviceToHost, c->stream), "D2H");
+    hip_check(hipStreamSynchronize(c->stream), "all-reduce sync");
   });
 }
 

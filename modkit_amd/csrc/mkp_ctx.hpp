@@ -36,7 +36,7 @@ struct mkp_ctx {
   int device = 0; hipStream_t stream = nullptr; std::string err; mkp_config cfg;
   mkp::CallerCfg caller; bool caller_set = false;
   mkp::Packer packer; mkp::ShardHost shard; mkp::LayoutTables tables; bool shard_open = false, resident = false;
-  std::vector<uint8_t> focus; bool has_focus = false; std::vector<mkp_motif_combo> combos;
+  mkp::PodVec<uint8_t> focus; bool has_focus = false; std::vector<mkp_motif_combo> combos;   // (focus: a byte per position of the shard window, copied on all cores)
   MkpRunParams prm; uint32_t lds_bytes = 0, n_tiles = 0; uint64_t row_cap = 0, n_slots_total = 0;
   mkp::DevBuf d_hdr, d_vals, d_cigar, d_seq, d_tagref, d_ranks, d_ml, d_layouts, d_events, d_readout, d_focus, d_combos, d_tiles, d_slotbm,
       d_tile_row_off, d_tile_row_cnt, d_tile_dst, d_misc, d_rows_src, d_rows_dst, d_prm, d_read_ids, d_chunk;
@@ -47,7 +47,7 @@ struct mkp_ctx {
   mkp::DevBuf d_slot_pos, d_cov, d_visits, d_stiles, d_slot_ids, d_fdesc, d_work;
   // threshold sample, resident in HBM: keys = base << 30 | f32 bit pattern of an argmax probability; level-0 histogram per base
   mkp::ShardHost sample_shard; std::vector<MkpReadOut> sample_ro; uint64_t sample_n = 0;
-  mkp::DevBuf d_store, d_hist0, d_hist1, d_sample_cursor, d_take;
+  mkp::DevBuf d_store, d_hist0, d_hist1, d_sample_cursor, d_take, d_hist64;
   MkpRowsDev rows_src, rows_dst;
   // row columns on the host: one page-locked arena (pageable D2H of a chromosome's 120 MB of rows ran at under 5 GB/s), kept across shards
   struct RowArena { void* p = nullptr; size_t cap = 0; uint32_t* col[11] = {};

@@ -140,11 +140,14 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     }
     r.b.reset(new BamBatch());
     if (bf && !getenv("MKP_NO_BED_SAMPLING")) {
-      // under --include-bed a read counts only through calls on BED positions (the kernel masks the rest): a read that meets no BED span of
-      // the interval yields nothing, is not counted and not recorded — so only the records over the interval's spans are fetched (a sparse
-      // BED used to make the estimate inflate every sampling interval whole), all of them: there is no head to extend afterwards
+      // under --include-bed a read counts only through calls on BED positions (the kernel masks the rest): a read that meets no BED span
+      // yields nothing, is not counted and not recorded — so only the records that can meet one are fetched (a sparse BED used to make
+      // the estimate inflate every sampling interval whole), all of them: there is no head to extend afterwards.  A record of the interval
+      // meets a span inside it, or reaches a span outside it — then it crosses the interval's first or last position.
       std::vector<Span> sp;
       for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue; for (auto& x : it->second) if (x.e > s && x.s < e) sp.push_back({std::max<uint64_t>(x.s, s), std::min<uint64_t>(x.e, e)}); }
+      sp.push_back({s, (uint64_t)s + 1}); if (e > s + 1) sp.push_back({(uint64_t)e - 1, e});
+      std::sort(sp.begin(), sp.end(), [](const Span& x, const Span& y) { return x.s < y.s; });
       merge_spans(sp);
       FetchParts parts; for (auto& x : sp) parts.push_back({(int64_t)x.s, (int64_t)x.e});
       if (!parts.empty()) bam.fetch_parts(tid, parts, r.b.get());
@@ -640,7 +643,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
     if (mkdir(a.out_bed.c_str(), 0777) != 0 && errno != EEXIST) throw Error(MKP_E_IO, "failed to make output directory " + a.out_bed);
   } else {
-  wr.f = (a.out_bed == "-" || a.out_bed == "stdout" || (a.hemi && a.out_bed.empty())) ? stdout : fopen(a.out_bed.c_str(), "w");
+  wr.f = (a.out_bed == "-" || a.out_bed == "stdout" || (a.hemi && a.out_bed.empty())) ? stdout : fopen(a.out_bed.c_str(), "w+");
   if (!wr.f) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
   if (a.bgzf) {
     if (wr.f == stdout || a.with_header || a.plan_only) throw Error(MKP_E_INVALID,
@@ -654,7 +657,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (it == key_writers.end()) {
       std::unique_ptr<RowWriter> w(new RowWriter()); w->mixed = a.mixed_delim; w->labels = wr.labels;
       const std::string path = a.out_bed + "/" + (a.prefix.empty() ? key : a.prefix + "_" + key) + ".bed";
-      w->f = fopen(path.c_str(), "w"); if (!w->f) throw Error(MKP_E_IO, "failed to make output file " + path);
+      w->f = fopen(path.c_str(), "w+"); if (!w->f) throw Error(MKP_E_IO, "failed to make output file " + path);
       it = key_writers.emplace(key, std::move(w)).first;
     }
     return *it->second;
@@ -1183,7 +1186,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     must(mkp_internal_set_extract(ctx, true));
     const BamData bd = load_bam(a.in_bam, 0, false);
     Fasta fasta; if (!ref_path.empty()) fasta = Fasta::load(ref_path);
-    FILE* out = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w");
+    FILE* out = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w+");
     if (!out) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
     struct Close { FILE* f; ~Close() { if (f && f != stdout) fclose(f); } } closer{out};
     if (!no_headers) fputs("read_id\tforward_read_position\tref_position\tchrom\tmod_strand\tref_strand\tref_mod_strand\tfw_soft_clipped_start\tfw_soft_clipped_end\tread_length\tcall_prob\tcall_code\t"

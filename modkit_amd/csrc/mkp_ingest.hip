@@ -134,7 +134,17 @@ mkp_ingest_pack(const uint8_t* __restrict__ raw, uint32_t rec_cap, const MkpRecI
   }
 }
 
+// u32 counters -> u64 (the threshold histograms count in 32 bits per GPU; their sum over the ranks of a node may not fit)
+extern "C" __global__ void __launch_bounds__(256)
+mkp_widen_u32_u64(const uint32_t* __restrict__ in, unsigned long long* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = in[i];
+}
+
 extern "C" {
+hipError_t mkp_launch_widen(hipStream_t st, const uint32_t* in, unsigned long long* out, uint32_t n) {
+  if (n) hipLaunchKernelGGL(mkp_widen_u32_u64, dim3((n + 255u) / 256u), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
 hipError_t mkp_launch_crc32(hipStream_t st, const uint8_t* zin, const void* blocks, uint32_t n_blocks, const uint8_t* raw, uint32_t* status) {
   if (!n_blocks) return hipSuccess;
   hipLaunchKernelGGL(mkp_crc32_blocks, dim3((n_blocks + 3u) / 4u), dim3(256), 0, st, zin, (const MkpBgzfBlock*)blocks, n_blocks, raw, status);

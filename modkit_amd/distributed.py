@@ -2,7 +2,7 @@
 GPU box, "gloo" in the CPU tests).  The pileup path itself shards by reference windows with no data-path collective
 (mkp_pileup_main --gpus-rank R --gpus-world W); the only thing ranks ever share is the pass threshold:
 
-* broadcast_thresholds  — default sampled mode: rank 0 estimates (mkp_estimate_thresholds), everyone receives it.
+* broadcast_thresholds  — default sampled mode (`-n 10042` / `-f x`): rank 0 estimates (mkp_estimate_thresholds), everyone receives it.
 * estimate_thresholds_allreduce / percentile_from_histograms — full-data percentile (`-f 1.0`, thresholds.rs:121-159) when
   every rank has decoded only its own windows: the sample stays in each GPU's HBM, two-level histograms of the f32 *bit
   patterns* (top 16 bits, then the low 16 bits inside the bins that hold the wanted order statistics) are summed across ranks
@@ -49,6 +49,52 @@ def broadcast_thresholds(thresholds, src=0):
     return {BASES[i]: float(h[i]) for i in range(4) if h[4 + i] > 0}
 
 
+class RcclComm:
+    """An RCCL communicator of this job's ranks (one GPU each), created through librccl's C API — ncclGetUniqueId on rank 0, the id
+    handed round with torch.distributed, ncclCommInitRank — so that the C ABI's mkp_histogram_allreduce can run ncclAllReduce on the
+    histograms in HBM.  (torch's own NCCL communicator is not reachable from outside; a Rust host would make the same three calls.)"""
+
+    def __init__(self, rank=None, world=None, device=None):
+        import torch
+        dist = _dist()
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.lib = None
+        for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+            try:
+                self.lib = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise OSError("librccl.so not found")
+        uid = (ctypes.c_char * 128)()
+        if self.rank == 0 and self.lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(_device())
+            dist.broadcast(t, src=0)
+            ctypes.memmove(uid, bytes(t.cpu().numpy().tobytes()), 128)
+        if device is not None:
+            torch.cuda.set_device(device)
+
+        class _Uid(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_char * 128)]
+        u = _Uid()
+        ctypes.memmove(ctypes.byref(u), uid, 128)
+        self.handle = ctypes.c_void_p()
+        self.lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _Uid, ctypes.c_int]
+        rc = self.lib.ncclCommInitRank(ctypes.byref(self.handle), self.world, u, self.rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+
+    def close(self):
+        if self.lib is not None and self.handle:
+            self.lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self.lib.ncclCommDestroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
 def _u64p(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
 
@@ -64,13 +110,15 @@ def _allreduce_u64(h):
     return t.cpu().numpy().astype(np.uint64)
 
 
-def percentile_from_histograms(get, q):
+def percentile_from_histograms(get, q, reduced=False):
     """percentile_linear_interp (thresholds.rs:17-38) of the union of all ranks' samples of one base.
     get(level, prefix) -> this rank's uint64[65536] histogram (Context.histogram_get or mkp_histogram_from_values);
     every call is followed by a SUM all-reduce, so all ranks must call this function in the same order.
+    reduced=True: get already returns the sum over the ranks (Context.histogram_allreduce: RCCL on the device buffers).
     Returns (value or None when the union is empty, n)."""
     L = lib()
-    h0 = _allreduce_u64(np.ascontiguousarray(get(0, 0), dtype=np.uint64))
+    _red = (lambda h: h) if reduced else _allreduce_u64
+    h0 = _red(np.ascontiguousarray(get(0, 0), dtype=np.uint64))
     n = int(h0.sum())
     if n == 0:
         return None, 0
@@ -83,7 +131,7 @@ def percentile_from_histograms(get, q):
     h1 = None
     for k in range(2):
         if k == 0 or bins[1] != bins[0]:
-            h1 = _allreduce_u64(np.ascontiguousarray(get(1, int(bins[k])), dtype=np.uint64))
+            h1 = _red(np.ascontiguousarray(get(1, int(bins[k])), dtype=np.uint64))
         y = ctypes.c_float()
         if L.mkp_histogram_resolve(int(bins[k]), _u64p(h1), int(rk[k]), ctypes.byref(y)) != 0:
             raise ValueError("histogram levels disagree")
@@ -121,11 +169,28 @@ def estimate_thresholds_allreduce(ctx, bam, flags=(), q=0.1, rank=None, world=No
         argv += ["--gpus-rank", str(rank), "--gpus-world", str(world)]
     ctx.histogram_add_bam(bam, argv)
     out = {}
-    for b in BASES:
-        t, n = percentile_from_histograms(lambda level, prefix, b=b: ctx.histogram_get(b, level, prefix), q)
-        if t is not None:
-            out[b] = t
+    # on the nccl backend (one GPU per rank) the sum runs where the histograms sit: ncclAllReduce(u64) through the C ABI on a communicator
+    # of this job's ranks; torch.distributed's all_reduce on host copies is the test double (gloo: several ranks may share a GPU)
+    comm = None
+    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl" and not _env_flag("MKP_TORCH_ALLREDUCE"):
+        comm = RcclComm()
+    try:
+        for b in BASES:
+            if comm is not None:
+                t, n = percentile_from_histograms(lambda level, prefix, b=b: ctx.histogram_allreduce(comm, b, level, prefix), q, reduced=True)
+            else:
+                t, n = percentile_from_histograms(lambda level, prefix, b=b: ctx.histogram_get(b, level, prefix), q)
+            if t is not None:
+                out[b] = t
+    finally:
+        if comm is not None:
+            comm.close()
     return out
+
+
+def _env_flag(name):
+    import os
+    return os.environ.get(name, "") == "1"
 
 
 SAMPLING_FLAGS_WITH_VALUE = ("--region", "--sample-region", "--include-bed", "--include-positions", "--edge-filter", "--ignore", "--preset",
@@ -133,14 +198,56 @@ SAMPLING_FLAGS_WITH_VALUE = ("--region", "--sample-region", "--include-bed", "--
 SAMPLING_FLAGS_BARE = ("--include-unmapped", "--invert-edge-filter")
 
 
-def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1, stats=None):
+ESTIMATE_FLAGS_WITH_VALUE = ("-n", "--num-reads", "-f", "--sampling-frac", "-p", "--filter-percentile")
+
+
+def split_threshold_flags(flags, q=None, mode=None):
+    """`modkit pileup` flags -> (sampling flags [region, BED, collapse, edge filter ...], estimate flags [-n -f -p], the flags the sharded
+    runs keep [everything but the estimate flags], threshold mode, percentile).  Mode as the subcommand itself decides: thresholds given
+    (`--filter-threshold` / `--no-filtering`), full-data percentile (`-f 1.0`), else the count-based sampled estimate."""
+    sflags, eflags, rest, i = [], [], [], 0
+    frac, given = None, False
+    flags = list(flags)
+    while i < len(flags):
+        f = flags[i]
+        if f in SAMPLING_FLAGS_WITH_VALUE and i + 1 < len(flags):
+            sflags += flags[i:i + 2]; rest += flags[i:i + 2]; i += 2
+        elif f in ESTIMATE_FLAGS_WITH_VALUE and i + 1 < len(flags):
+            eflags += flags[i:i + 2]
+            if f in ("-f", "--sampling-frac"):
+                frac = float(flags[i + 1])
+            if f in ("-p", "--filter-percentile") and q is None:
+                q = float(flags[i + 1])
+            i += 2
+        else:
+            if f in SAMPLING_FLAGS_BARE:
+                sflags.append(f)
+            if f in ("--filter-threshold", "--no-filtering"):
+                given = True
+            rest.append(f); i += 1
+    if q is None:
+        q = 0.1
+    if mode is None:
+        mode = "given" if given else "full" if (frac is not None and frac >= 1.0) else "sampled"
+    if mode not in ("sampled", "full", "given"):
+        raise ValueError("pileup_sharded: mode must be 'sampled', 'full' or 'given'")
+    return sflags, eflags, rest, mode, q
+
+
+def pileup_sharded(argv, rank=None, world=None, device=None, q=None, stats=None, mode=None):
     """`modkit pileup` with ONE BAM sharded over the ranks of the current torch.distributed job (one process per GPU):
     thresholds from the all-reduced histograms of rank-sharded sampling, then every rank runs its contiguous run of the
     reference's interval grid (mkp_pileup_main --gpus-rank/--gpus-world) into `<out>.rank<R>`, and rank 0 concatenates the parts
     in rank order into `<out>`.  argv = [in.bam, out.bed, flags...] (no threshold flags).
-    Parity: the thresholds are the FULL-DATA percentile (`-f 1.0`; the count-based default sampler carries quotas from interval
-    to interval and does not shard), so the output is byte-identical to a single-GPU run with `-f 1.0 -p q` — or with the explicit
-    `--filter-threshold` values this function returns — not to a default (`-n 10042`) run.
+    Threshold modes (`mode`, default: by the flags, as `modkit pileup` itself decides):
+      "sampled" — the reference's default: the count-based schedule (`-n 10042`, or `-f x < 1`) carries quotas from interval to interval
+                  and does not shard; it reads only interval heads, so rank 0 estimates (mkp_estimate_thresholds) and broadcasts four
+                  floats.  The output is byte-identical to a single-GPU run with the same flags.
+      "full"    — `-f 1.0` (thresholds.rs:121-159): every rank samples its own sampling intervals, the two-level histograms are summed
+                  over the ranks (the path's one collective) and every rank evaluates the percentile of the union.  Byte-identical to a
+                  single-GPU run with `-f 1.0`.
+      "given"   — `--filter-threshold` / `--no-filtering` in argv: nothing to estimate.
+    Returns the thresholds used ({base: f32}; empty for "given").
     `--with-header` is written by rank 0 only; `--bgzf` (one BGZF stream + one index) and `--partition-tag` (one file per key)
     do not concatenate and are refused.  `stats` (a dict) receives this rank's wall times."""
     import os
@@ -157,28 +264,32 @@ def pileup_sharded(argv, rank=None, world=None, device=None, q=0.1, stats=None):
             raise ValueError("pileup_sharded: %s output does not concatenate over ranks; run it on one GPU" % bad)
     if rank > 0:   # one header, from rank 0
         flags = [f for f in flags if f not in ("--with-header", "--header")]
-    sflags, i = [], 0
-    while i < len(flags):
-        if flags[i] in SAMPLING_FLAGS_WITH_VALUE:
-            sflags += flags[i:i + 2]
-            i += 2
-        else:
-            if flags[i] in SAMPLING_FLAGS_BARE:
-                sflags.append(flags[i])
-            i += 1
+    sflags, eflags, rest, mode, q = split_threshold_flags(flags, q, mode)
     import time
     t0 = time.time()
-    ctx = Context(device=0 if device is None else device)
-    try:
-        thr = estimate_thresholds_allreduce(ctx, bam, sflags, q=q, rank=rank, world=world)
-    finally:
-        ctx.close()
+    thr = {}
+    if mode == "full":
+        ctx = Context(device=0 if device is None else device)
+        try:
+            thr = estimate_thresholds_allreduce(ctx, bam, sflags, q=q, rank=rank, world=world)
+        finally:
+            ctx.close()
+    elif mode == "sampled":
+        if rank == 0:   # heads of the sampling intervals only: one rank's work, the others wait for four floats
+            ctx = Context(device=0 if device is None else device)
+            try:
+                thr = ctx.estimate_thresholds(bam, sflags + eflags)
+            finally:
+                ctx.close()
+        thr = broadcast_thresholds(thr, src=0)
     t1 = time.time()
     targv = []
-    for b, v in sorted(thr.items()):
-        targv += ["--filter-threshold", "%s:%r" % (b, v)]
-    if not targv:
-        raise ValueError("no mod calls sampled on any rank")
+    if mode != "given":
+        for b, v in sorted(thr.items()):
+            targv += ["--filter-threshold", "%s:%r" % (b, v)]
+        if not targv:
+            raise ValueError("no mod calls sampled on any rank")
+    flags = rest
     part = "%s.rank%d" % (out, rank)
     pileup([bam, part] + flags + targv + ["--gpus-rank", str(rank), "--gpus-world", str(world)] + (["--device", str(device)] if device is not None else []))
     if stats is not None:

@@ -105,3 +105,20 @@ def test_shard_plans_partition_the_genome(two_ranks):
     order = {c: i for i, c in enumerate(dict.fromkeys(w[0] for w in whole))}
     assert [order[w[0]] for w in a + b] == sorted(order[w[0]] for w in a + b)
     assert max(order[w[0]] for w in a) <= min(order[w[0]] for w in b)
+
+
+def test_threshold_mode_follows_the_flags():
+    """pileup_sharded decides like the subcommand: thresholds given, the full-data percentile (`-f 1.0`: sharded sampling + all-reduce), or
+    the default count-based estimate (rank 0 walks the schedule, four floats are broadcast); the estimate flags leave the sharded runs'
+    argv, the sampling flags stay in both."""
+    from modkit_amd.distributed import split_threshold_flags as sp
+    s, e, rest, mode, q = sp(["--cpg", "--ref", "x.fa", "-t", "8"])
+    assert mode == "sampled" and q == 0.1 and e == [] and s == ["-t", "8"] and rest == ["--cpg", "--ref", "x.fa", "-t", "8"]
+    s, e, rest, mode, q = sp(["-n", "500", "-p", "0.25", "--ignore", "h", "--region", "chr1:1-20", "--include-unmapped"])
+    assert mode == "sampled" and q == 0.25 and e == ["-n", "500", "-p", "0.25"] and s == ["--ignore", "h", "--region", "chr1:1-20", "--include-unmapped"]
+    assert rest == ["--ignore", "h", "--region", "chr1:1-20", "--include-unmapped"]
+    assert sp(["-f", "1.0"])[3] == "full" and sp(["--sampling-frac", "0.5"])[3] == "sampled"
+    assert sp(["--filter-threshold", "C:0.8", "-f", "1.0"])[3] == "given" and sp(["--no-filtering"])[3] == "given"
+    assert sp(["-f", "0.3"], mode="full")[3] == "full"
+    with pytest.raises(ValueError):
+        sp([], mode="median")

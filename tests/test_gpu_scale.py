@@ -224,6 +224,30 @@ def test_c4_scaled_two_processes_sharded_sampling_allreduce(oracle_bin, tmp_path
     out = os.path.join(str(tmp_path), "sharded.bed")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, [bam, out] + flags + ["-f", "1.0", "-p", "0.1"], q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == res[1] and "C" in res[0]
+    assert open(out).read() == whole
+
+
+@pytest.mark.parametrize("extra", [[], ["-n", "800", "-p", "0.2"], ["-f", "0.4"]])
+def test_two_processes_default_sampled_thresholds_equal_single_gpu(oracle_bin, tmp_path, extra):
+    # `modkit pileup` defaults on two ranks: the count-based estimate does not shard — rank 0 walks the schedule (interval heads), the
+    # thresholds are broadcast, every rank runs its windows: byte-identical to the single-GPU run with the same flags (and to the oracle)
+    import socket
+    import torch.multiprocessing as mp
+    bam, fa, meta = gen(tmp_path, "c4d", [("chr1", 1_900_000), ("chr2", 1_200_000), ("chrX", 600_000)], 7_000, "hm", 45, ["--cpg-depleted", "--mean-len", "6000"])
+    flags = ["--cpg", "--ref", fa, "--sampling-interval-size", "300000"] + extra
+    whole = both(oracle_bin, tmp_path, bam, flags)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = os.path.join(str(tmp_path), "sharded.bed")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
     procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, [bam, out] + flags, q)) for r in range(2)]
     for p in procs:
         p.start()
