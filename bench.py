@@ -162,7 +162,7 @@ def device_e2e_subprocess(bam, out, flags, pool_threads, hemi=False):
     return {"host_threads": pool_threads, "total_ms": float(m.group(1)) if m else None, "process_wall_s": wall}
 
 
-def seam_per_interval(bam, fa, out, thr):
+def seam_per_interval(bam, fa, out, thr, per_batch=None):
     """The seam a Rust maintainer would call: tests/abi_client.c drives mkp_shard_begin / add_records / run once per
     100 kb interval on the bench BAM; its own stderr line carries intervals, rows and the time inside the API calls."""
     exe = os.path.join(os.environ.get("MKP_BENCH_DIR", "/tmp"), "mkp_abi_client")
@@ -172,14 +172,15 @@ def seam_per_interval(bam, fa, out, thr):
             subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "abi_client.c"),
                                    "-L", lib_dir, "-lmkpileup", "-lz", "-Wl,-rpath," + lib_dir])
         t0 = time.time()
-        p = subprocess.run([exe, bam, fa, out, "cpg", repr(float(thr))], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, bam, fa, out, "cpg", repr(float(thr))] + (["100000", str(per_batch)] if per_batch else []), capture_output=True, text=True, timeout=600)
         wall = time.time() - t0
         if p.returncode != 0:
             return {"error": p.stderr[-300:]}
         kv = dict(re.findall(r"(\w+)=([0-9.eE+-]+)", p.stderr))
         return {"intervals": int(float(kv.get("intervals", 0))), "rows": int(float(kv.get("rows", 0))), "rows_per_s_api": float(kv.get("rows_per_s_api", 0)),
                 "api_s": float(kv.get("api_s", 0)), "process_wall_s": wall,
-                "what": "tests/abi_client.c: own BGZF/BAM/FASTA readers, one mkp_shard_begin / mkp_shard_add_records / mkp_shard_run per 100 kb interval with a fixed pass threshold; rates over the time spent inside the three API calls"}
+                "what": ("tests/abi_client.c: own BGZF/BAM/FASTA readers, one mkp_batch_run per %d consecutive 100 kb intervals (process_region_batch's MultiChromCoordinates) with a fixed pass threshold; rates over the time spent inside the API call" % per_batch) if per_batch else
+                        "tests/abi_client.c: own BGZF/BAM/FASTA readers, one mkp_shard_begin / mkp_shard_add_records / mkp_shard_run per 100 kb interval with a fixed pass threshold; rates over the time spent inside the three API calls"}
     except Exception as e:  # noqa: BLE001 — the seam tier is informative, never fatal
         return {"error": str(e)[-300:]}
 
@@ -494,6 +495,8 @@ def main():
         })
         if world == 1 and a.workload == "c3" and not (a.inner or a.skip_e2e):
             tiers["seam_per_interval"] = seam_per_interval(bam, fa, bam + ".seam.bed", thr_h[1] if thr_h[1] > 0 else 0.7)
+            # the batch seam (mkp_batch_run): the reference's default chunk of floor(1.5 * threads) intervals at 8 and 64 threads, and a whole contig per call
+            tiers["seam_batch"] = {str(n): seam_per_interval(bam, fa, bam + ".seam.bed", thr_h[1] if thr_h[1] > 0 else 0.7, per_batch=n) for n in (12, 96, 1000)}
         result = {
             "metric": "genomic positions/sec pileup (bedMethyl rows/s); bit-exact vs ref", "value": value, "unit": "positions/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",

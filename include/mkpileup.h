@@ -143,7 +143,7 @@ typedef struct {
   double decode_kernel_ms, pileup_kernel_ms, gather_kernel_ms;
   uint64_t n_reads, n_events, n_rows, n_tiles, n_positions;
   uint64_t alg_bytes_decode, alg_bytes_pileup; /* SURVEY.md §8(d) algorithmic bytes of the decode and pileup kernels */
-  double rows_kernel_ms;                       /* mkp_emit_rows (tallies -> rows) */
+  double rows_kernel_ms;                       /* always 0: rows are emitted by the aggregation kernels straight from LDS (kept for layout compatibility) */
   uint64_t alg_bytes_rows;                     /* 44 B per row */
   /* focus runs on the slot pipeline: feature-stream bytes (one per read and focus position in its span) and
    * SURVEY §8(d)'s literal B_agg = 8 B per coverage / call event + 44 B per row for the aggregation kernel */
@@ -174,7 +174,23 @@ int mkp_set_partition_tags(mkp_ctx* ctx, const char* const* tags, uint32_t n);
  * process_region (src/pileup/mod.rs:718-1020) for every interval inside the shard. */
 int mkp_shard_begin(mkp_ctx* ctx, const mkp_shard* shard);
 int mkp_shard_add_records(mkp_ctx* ctx, const mkp_record* recs, uint32_t n);
+/* Optional, between begin and run: the ascending start positions of the reference's intervals inside the shard (the last one ends with
+ * the window).  The reference keeps one read cache per interval, keyed by read NAME (src/read_cache.rs:28-35): two kept records with one
+ * name interfere only when they overlap a common interval — that case is refused (MKP_E_UNSUPPORTED); mates / split alignments lying
+ * in different intervals are independent reads.  Without this call the whole shard counts as one interval. */
+int mkp_shard_set_intervals(mkp_ctx* ctx, const uint32_t* interval_starts, uint32_t n_intervals);
 int mkp_shard_run(mkp_ctx* ctx, mkp_rows* out);
+
+/* ---- the same seam one level up: process_region_batch(&MultiChromCoordinates, ...) (src/pileup/mod.rs:684-716, called per batch from
+ * ModBamPileup::run, src/pileup/subcommand.rs:733-753) in ONE call.  intervals = the batch's ChromCoordinates (each a mkp_shard: window +
+ * focus bytes of that interval), in the order the feeder produced them; recs = the records the caller fetched for the batch — every
+ * record overlapping any of the intervals once, coordinate order per contig.  Intervals that follow each other on one contig
+ * (start == previous end, same kind of focus, same combo table) are merged into ONE resident shard — one pack, one plan, one launch
+ * sequence, one read-back instead of one per interval — and cut apart again at their ends: out[k] = the rows of intervals[k], arrays
+ * owned by the ctx until its next run.  processed / skipped_records are reported on the first interval of each merged run.  With
+ * partition tags set every interval runs alone (its rows come grouped by key).  Per-interval calls cost ~1.7 ms of launch and planning
+ * latency each (bench.py: tiers.seam_per_interval); a batch pays it once per contig run. */
+int mkp_batch_run(mkp_ctx* ctx, const mkp_shard* intervals, uint32_t n_intervals, const mkp_record* recs, uint32_t n_recs, mkp_rows* out);
 
 /* Re-run the device pipeline on the shard that is already resident in HBM (no pack, no H2D):
  * what bench.py times.  `iters` launches; rows of the last one are returned. */
@@ -315,13 +331,14 @@ int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
  * --region, --include-bed / --exclude-bed, --motif, --num-reads, --ignore-implicit, --bgzf fail with MKP_E_UNSUPPORTED. */
 int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
-/* ---- BGZF inflate on the device: first stage of moving BAM ingest onto the GPU.  Not on the pileup path yet — the
- * driver still inflates on the host, where the step overlaps with packing; this entry point exists so that the kernel is tested and
- * measured on its own.  Stands in for what htslib does under rust-htslib's IndexedReader (src/pileup/mod.rs:732-743): BGZF blocks
- * (SAM spec 4.1) of raw DEFLATE (RFC 1951) — neither htslib nor zlib is part of the reference checkout, the decoder follows the RFC.
- * bgzf = n_bytes of whole BGZF blocks in host memory (a file image).  One device thread decodes one block; every block's CRC32 and
- * ISIZE are checked on the host before the call returns.  *out = the inflated bytes, owned by the ctx until its next inflate call;
- * *kernel_ms (may be NULL) = device time of the decode kernel. */
+/* ---- BGZF inflate on the device as a call of its own.  On the pileup path the same kernels run inside the device ingest
+ * (`mkp_pileup_main` on an indexed BAM: compressed blocks up, inflate + CRC-32 + record cut + MM/ML tokeniser + packing in HBM, a digest
+ * back — DESIGN.md §3.6); this entry point exists so that the decoders are tested and measured alone.  Stands in for what htslib does
+ * under rust-htslib's IndexedReader (src/pileup/mod.rs:732-743): BGZF blocks (SAM spec 4.1) of raw DEFLATE (RFC 1951) — neither htslib
+ * nor zlib is part of the reference checkout, the decoders follow the RFC.  bgzf = n_bytes of whole BGZF blocks in host memory (a file
+ * image).  One wave (small launches) or one thread (large ones) decodes a block; every block's CRC32 and ISIZE are checked before the
+ * call returns.  *out = the inflated bytes, owned by the ctx until its next inflate call; *kernel_ms (may be NULL) = device time of the
+ * decode kernel. */
 int mkp_bgzf_inflate(mkp_ctx* ctx, const uint8_t* bgzf, uint64_t n_bytes, const uint8_t** out, uint64_t* out_len, double* kernel_ms);
 
 /* ---- host-side pieces exposed for tests (no device needed):

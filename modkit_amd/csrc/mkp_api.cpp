@@ -199,19 +199,35 @@ void make_resident(mkp_ctx* c) {
   // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
   { const size_t nn = S.name_hash.size();
     // every thread takes the names whose hash falls into its sixteenth and looks for a repeat in an open-addressing table of its own
-    std::atomic<bool> dup{false};
+    // (value = the first record carrying the name); repeats are rare, so they are only collected here and judged below
+    std::mutex dmu; std::vector<std::pair<uint32_t, uint32_t>> dups;   // (first record with the name, a later one)
     host_parallel(16, 1, [&](size_t lo, size_t hi) { for (size_t part = lo; part < hi; part++) {
       size_t mine = 0; for (size_t i = 0; i < nn; i++) if ((S.name_hash[i] >> 60) == part) mine++;
       if (mine < 2) continue;
       size_t cap = 64; while (cap < 2 * mine) cap <<= 1;
-      std::vector<uint64_t> tab(cap, 0), key(cap, 0); std::vector<uint8_t> used(cap, 0);
+      std::vector<uint64_t> tab(cap, 0), key(cap, 0); std::vector<uint32_t> who(cap, 0); std::vector<uint8_t> used(cap, 0);
       for (size_t i = 0; i < nn; i++) { const uint64_t hh = S.name_hash[i]; if ((hh >> 60) != part) continue;
         const uint64_t kk = i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u;   // per partition key: tallies of different keys never meet
         size_t at = (size_t)((hh * 0x9e3779b97f4a7c15ull) >> 20) & (cap - 1);
-        for (;;) { if (!used[at]) { used[at] = 1; tab[at] = hh; key[at] = kk; break; } if (tab[at] == hh && key[at] == kk) { dup = true; break; } at = (at + 1) & (cap - 1); } }
+        for (;;) { if (!used[at]) { used[at] = 1; tab[at] = hh; key[at] = kk; who[at] = (uint32_t)i; break; }
+                   if (tab[at] == hh && key[at] == kk) { std::lock_guard<std::mutex> g(dmu); dups.push_back({who[at], (uint32_t)i}); break; } at = (at + 1) & (cap - 1); } }
     } });
-    if (dup) throw Error(MKP_E_UNSUPPORTED,
-        "two primary records share a read name in one shard (unmarked duplicates / paired or split reads); the reference keys its per-interval cache by name and this is not reproduced on the device");
+    // The reference keys its read cache by NAME, one cache per interval (read_cache.rs:28-35, pileup/mod.rs:718-760): two kept records
+    // with one name meet only if they overlap a common interval — then the later one is answered from the earlier one's calls, which the
+    // device path does not reproduce.  Mates / split alignments that lie in different intervals never share a cache and are simply two reads.
+    // (No interval grid given: the shard is one interval.)
+    for (auto& d : dups) {
+      if (d.first >= S.hdr.size() || d.second >= S.hdr.size()) continue;
+      auto iv_range = [&](const MkpReadHdr& h, int64_t* a, int64_t* b) {
+        const int64_t s0 = h.ref_start, e0 = std::max<int64_t>(h.ref_end, (int64_t)h.ref_start + 1);
+        if (c->iv_starts.empty()) { *a = 0; *b = 0; return; }
+        auto idx = [&](int64_t p) { return (int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1; };
+        *a = std::max<int64_t>(idx(s0), 0); *b = std::max<int64_t>(idx(e0 - 1), 0);
+      };
+      int64_t a0, a1, b0, b1; iv_range(S.hdr[d.first], &a0, &a1); iv_range(S.hdr[d.second], &b0, &b1);
+      if (a0 <= b1 && b0 <= a1) throw Error(MKP_E_UNSUPPORTED,
+        "two primary records share a read name inside one interval (unmarked duplicates, or mates / split reads that overlap the same interval); the reference answers the later record from the earlier one's calls (its per-interval cache is keyed by name) and this is not reproduced on the device");
+    }
   }
   lap("duplicate-name check");
   // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
@@ -774,9 +790,21 @@ int mkp_shard_begin(mkp_ctx* c, const mkp_shard* s) {
       c->combos.assign(s->combos, s->combos + s->n_combos);
       if (c->combos.empty()) { mkp_motif_combo z; memset(&z, 0, sizeof(z)); c->combos.push_back(z); }
     } else { c->focus.clear(); c->combos.clear(); }
-    c->shard_open = true; c->resident = false; c->row_cap = 0;
+    c->shard_open = true; c->resident = false; c->row_cap = 0; c->iv_starts.clear();
     c->key_names.assign(1, "ungrouped");
     memset(&c->stats, 0, sizeof(c->stats));
+  });
+}
+
+// The reference's interval grid inside the open shard (ascending interval starts; the last interval ends with the window): only read by the
+// duplicate-name rule of the planner — records with one name matter only when they overlap a common interval.  Without it the shard counts
+// as one interval.
+int mkp_shard_set_intervals(mkp_ctx* c, const uint32_t* starts, uint32_t n) {
+  if (!c || (!starts && n)) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
+    c->iv_starts.assign(starts, starts + n);
+    if (!std::is_sorted(c->iv_starts.begin(), c->iv_starts.end())) throw Error(MKP_E_INVALID, "interval starts must ascend");
   });
 }
 
@@ -868,6 +896,62 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
       c->stats.alg_bytes_pileup += 8ull * c->stats.n_events + 44ull * c->stats.n_rows;   // rows leave the accumulate kernel directly
     }
     c->stats.alg_bytes_rows = 0;
+  });
+}
+
+// process_region_batch (src/pileup/mod.rs:684-716) as ONE call: the intervals of a MultiChromCoordinates with the records the caller's
+// reader fetched for them.  Runs of intervals that follow each other on one contig become one resident shard (one pack, one plan, one
+// launch sequence, one read-back); the rows come back per interval.
+int mkp_batch_run(mkp_ctx* c, const mkp_shard* ivs, uint32_t n_ivs, const mkp_record* recs, uint32_t n_recs, mkp_rows* out) {
+  if (!c || (!ivs && n_ivs) || (!recs && n_recs) || (!out && n_ivs)) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!c->caller_set) throw Error(MKP_E_INVALID, "mkp_set_caller first");
+    for (auto& v : c->batch_cols) v.clear();
+    c->batch_strand.clear(); c->batch_motif.clear(); c->batch_key.clear();
+    struct Slice { uint64_t lo, hi, processed, skipped; }; std::vector<Slice> slice(n_ivs, Slice{0, 0, 0, 0});
+    mkp_stats acc; memset(&acc, 0, sizeof(acc));
+    for (uint32_t i0 = 0; i0 < n_ivs;) {
+      // a group: intervals i0 .. i1-1 follow each other on one contig with the same kind of focus (with partition keys every interval runs alone: rows come grouped by key)
+      uint32_t i1 = i0 + 1;
+      while (c->partition_tags.empty() && i1 < n_ivs && ivs[i1].tid == ivs[i0].tid && ivs[i1].start == ivs[i1 - 1].end && (ivs[i1].focus != nullptr) == (ivs[i0].focus != nullptr) &&
+             ivs[i1].combos == ivs[i0].combos && ivs[i1].n_combos == ivs[i0].n_combos && (uint64_t)ivs[i1].end - ivs[i0].start <= (1ull << 27)) i1++;
+      mkp_shard sh = ivs[i0]; sh.end = ivs[i1 - 1].end;
+      std::vector<uint8_t> focus;
+      if (sh.focus && i1 > i0 + 1) { focus.resize((size_t)(sh.end - sh.start)); for (uint32_t k = i0; k < i1; k++) memcpy(focus.data() + (ivs[k].start - sh.start), ivs[k].focus, (size_t)(ivs[k].end - ivs[k].start)); sh.focus = focus.data(); }
+      int rc = mkp_shard_begin(c, &sh); if (rc != MKP_OK) throw Error(rc, c->err);
+      c->iv_starts.clear(); for (uint32_t k = i0; k < i1; k++) c->iv_starts.push_back(ivs[k].start);   // the duplicate-name rule is per interval
+      // the group's records: its contig, starting before the window's end (the packer drops the other contigs itself; a record that ends
+      // before the window only costs its packing)
+      std::vector<mkp_record> mine; mine.reserve(n_recs);
+      const int64_t hi = (int64_t)sh.end + MKP_HALO;
+      for (uint32_t r = 0; r < n_recs; r++) if (recs[r].tid == sh.tid && (int64_t)recs[r].pos < hi) mine.push_back(recs[r]);
+      rc = mkp_shard_add_records(c, mine.data(), (uint32_t)mine.size()); if (rc != MKP_OK) throw Error(rc, c->err);
+      mkp_rows rows; memset(&rows, 0, sizeof(rows));
+      rc = mkp_shard_run(c, &rows); if (rc != MKP_OK) throw Error(rc, c->err);
+      // rows are in genome order (by key first with partition tags: then the group is one interval): cut at the interval ends
+      const uint64_t base = c->batch_cols[0].size();
+      const uint32_t* src[11] = {rows.pos, nullptr, rows.code_repr, rows.n_valid, rows.n_mod, rows.n_canonical, rows.n_other, rows.n_delete, rows.n_fail, rows.n_diff, rows.n_nocall};
+      for (int k = 0; k < 11; k++) if (src[k]) c->batch_cols[k].insert(c->batch_cols[k].end(), src[k], src[k] + rows.n_rows);
+      c->batch_strand.insert(c->batch_strand.end(), rows.strand, rows.strand + rows.n_rows); c->batch_motif.insert(c->batch_motif.end(), rows.motif_idx, rows.motif_idx + rows.n_rows);
+      c->batch_key.insert(c->batch_key.end(), rows.partition_key, rows.partition_key + rows.n_rows);
+      uint64_t at = 0;
+      for (uint32_t k = i0; k < i1; k++) {
+        uint64_t e = at; if (i1 == i0 + 1) e = rows.n_rows; else while (e < rows.n_rows && rows.pos[e] < ivs[k].end) e++;
+        slice[k] = {base + at, base + e, k == i0 ? rows.processed_records : 0, k == i0 ? rows.skipped_records : 0}; at = e;
+      }
+      acc.pack_ms += c->stats.pack_ms; acc.h2d_ms += c->stats.h2d_ms; acc.kernel_ms += c->stats.kernel_ms; acc.d2h_ms += c->stats.d2h_ms; acc.n_rows += c->stats.n_rows; acc.n_reads += c->stats.n_reads;
+      i0 = i1;
+    }
+    c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
+    for (uint32_t k = 0; k < n_ivs; k++) {
+      mkp_rows& o = out[k]; memset(&o, 0, sizeof(o)); const Slice& sl = slice[k]; const uint64_t lo = sl.lo;
+      o.n_rows = sl.hi - sl.lo; o.pos = c->batch_cols[0].data() + lo; o.strand = c->batch_strand.data() + lo; o.code_repr = c->batch_cols[2].data() + lo; o.motif_idx = c->batch_motif.data() + lo;
+      o.n_valid = c->batch_cols[3].data() + lo; o.n_mod = c->batch_cols[4].data() + lo; o.n_canonical = c->batch_cols[5].data() + lo; o.n_other = c->batch_cols[6].data() + lo;
+      o.n_delete = c->batch_cols[7].data() + lo; o.n_fail = c->batch_cols[8].data() + lo; o.n_diff = c->batch_cols[9].data() + lo; o.n_nocall = c->batch_cols[10].data() + lo;
+      o.processed_records = sl.processed; o.skipped_records = sl.skipped;
+      o.partition_key = c->batch_key.data() + lo; o.n_partition_keys = (uint32_t)c->key_name_ptrs.size(); o.partition_key_names = c->key_name_ptrs.data();
+    }
+    c->stats.pack_ms = acc.pack_ms; c->stats.h2d_ms = acc.h2d_ms; c->stats.kernel_ms = acc.kernel_ms; c->stats.d2h_ms = acc.d2h_ms;   // the batch's sums (the other fields: its last group)
   });
 }
 

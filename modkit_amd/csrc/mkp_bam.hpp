@@ -131,17 +131,25 @@ struct ByteBuf {
   ~ByteBuf() { release(); }
   // Large mappings are recycled through a process-wide spare list: a shard's inflated windows are ~1 GB, and unmapping them after the
   // pack (~45 ms per shard, the address-space lock held against every other thread's faults) plus faulting fresh ones for the next
-  // shard cost more than the copy itself.  At most kSpareBytes stay parked; trim_spares() (BamSource destructor) returns them.
+  // shard cost more than the copy itself.  At most spare_limit() bytes stay parked (recycled mappings are not zeroed: callers write what they read, including the 8 spare bytes behind a window); trim_spares() (BamSource destructor) returns them.
   struct Spares { std::mutex mu; std::vector<std::pair<uint8_t*, size_t>> free; size_t bytes = 0; };
   static Spares& spares() { static Spares s; return s; }
-  static constexpr size_t kSpareBytes = (size_t)6 << 30;
+  // at most 6 GiB parked, and never more than a quarter of what this process may use (the cgroup's memory limit where there is one):
+  // parked mappings are resident pages nobody is using
+  static size_t spare_limit() {
+    static const size_t lim = []() { size_t v = (size_t)6 << 30;
+      if (FILE* f = fopen("/sys/fs/cgroup/memory.max", "r")) { char q[64]; if (fscanf(f, "%63s", q) == 1 && strcmp(q, "max") != 0) { const unsigned long long m = strtoull(q, nullptr, 10); if (m) v = std::min<size_t>(v, (size_t)(m / 4)); } fclose(f); }
+      else if (FILE* g = fopen("/sys/fs/cgroup/memory/memory.limit_in_bytes", "r")) { unsigned long long m = 0; if (fscanf(g, "%llu", &m) == 1 && m && m < (1ull << 60)) v = std::min<size_t>(v, (size_t)(m / 4)); fclose(g); }
+      return v; }();
+    return lim;
+  }
   static void trim_spares() { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu); for (auto& f : s.free) munmap(f.first, f.second); s.free.clear(); s.bytes = 0; }
   void release() {
     if (p) {
       if (heap) free(p);
       else {
         Spares& s = spares(); bool parked = false;
-        { std::lock_guard<std::mutex> g(s.mu); if (s.bytes + cap <= kSpareBytes && s.free.size() < 64) { s.free.push_back({p, cap}); s.bytes += cap; parked = true; } }
+        { std::lock_guard<std::mutex> g(s.mu); if (s.bytes + cap <= spare_limit() && s.free.size() < 64) { s.free.push_back({p, cap}); s.bytes += cap; parked = true; } }
         if (!parked) munmap(p, cap);
       }
     }

@@ -56,7 +56,9 @@ struct mkp_ctx {
       for (int k = 0; k < 11; k++) col[k] = (uint32_t*)p + (size_t)k * n_rows; }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; } } h_rows;
   std::vector<uint8_t> h_strand; std::vector<int32_t> h_motif; std::vector<uint32_t> h_key;
+  std::vector<uint32_t> batch_cols[11]; std::vector<uint8_t> batch_strand; std::vector<int32_t> batch_motif; std::vector<uint32_t> batch_key;   // mkp_batch_run: the rows of all groups of the batch
   // --partition-tag: tag names, the shard's key names (index = key id, 0 = "ungrouped"), the key ids present (one accumulate pass each)
+  std::vector<uint32_t> iv_starts;   // the reference's interval grid inside the open shard (duplicate-name rule); empty = one interval
   std::vector<std::string> partition_tags, key_names{"ungrouped"}; std::vector<const char*> key_name_ptrs; std::vector<uint32_t> key_passes{0xffffffffu};
   uint64_t n_ok = 0, n_bad = 0;
   // pileup-hemi (mkp_hemi_shard_run): mode of the resident plan, partner offset, interval starts, pattern element -> mod code

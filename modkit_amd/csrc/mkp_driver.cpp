@@ -614,6 +614,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
             mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)records[0].tid; sh.start = early_s0; sh.end = early_s1;
             if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
             must(mkp_shard_begin(ctx, &sh));
+            { std::vector<uint32_t> st; st.reserve(ivs.size()); for (auto& iv : ivs) st.push_back(iv.start); must(mkp_shard_set_intervals(ctx, st.data(), (uint32_t)st.size())); }
             pre_dev = std::move(early_in.dev); early_in_ready = false;
             must(mkp_internal_shard_attach(ctx, pre_dev.get())); mkp_internal_ingest_recycle(ctx->ingest, pre_dev.get());
             pre_attached = true; resident = &ctx->shard;
@@ -690,7 +691,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
         const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
         const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
-        std::vector<uint32_t> iv_starts; if (a.hemi) for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);
+        std::vector<uint32_t> iv_starts; for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);   // the shard's intervals (pileup-hemi: per-interval NoCalls; always: the duplicate-name rule)
         i0 = i1;
         if (owner == a.rank) plan.push_back({ri, s0, s1, bp, std::move(iv_starts)});
       }
@@ -769,6 +770,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       if (attached_already) dev.reset();   // begun and attached before the threshold estimate, which sampled from it
       else {
         must(mkp_shard_begin(ctx, &sh));
+        must(mkp_shard_set_intervals(ctx, sp.iv_starts.data(), (uint32_t)sp.iv_starts.size()));
         if (dev) { must(mkp_internal_shard_attach(ctx, dev.get())); mkp_internal_ingest_recycle(ctx->ingest, dev.get()); dev.reset(); }
         else must(mkp_shard_add_records(ctx, recs.data(), (uint32_t)recs.size()));
       }
@@ -1246,6 +1248,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           const size_t f = e.pos, q = rev ? L - 1 - f : f;
           long ref = -1;
           if (!unmapped) {
+            if (q < q_at) { ck = 0; q_at = 0; r_at = r.pos; }   // an event behind the walk (the kernels emit a record's events in stored order; should that ever change, start over instead of underflowing)
             while (ck < r.n_cigar) {
               const uint32_t w = cig(ck), op = w & 15u, len = w >> 4;
               const bool cq = op == 0 || op == 1 || op == 4 || op == 7 || op == 8, cr = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
@@ -1274,11 +1277,12 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           if (w.ref >= 0 && ref_seq) rk = kmer_at(ref_seq->data(), ref_seq->size(), (size_t)w.ref, kmer);
           const unsigned bq = ql[rev ? L - 1 - w.f : w.f];
           char line[1200];
-          snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n", qname.c_str(), w.f, w.ref >= 0 ? w.ref : -1L,
+          const int ln = snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n", qname.c_str(), w.f, w.ref >= 0 ? w.ref : -1L,
                    have_chrom ? chrom.c_str() : ".", sg ? '-' : '+', unmapped ? '.' : (rev ? '-' : '+'), unmapped ? '.' : ((sg != 0) != rev ? '-' : '+'), clip_start, clip_end, L,
                    f32_display(w.p).c_str(), code.c_str(), bq, rk.c_str(), qk.c_str(), "ACGT"[tb], "ACGT"[sg ? 3 - tb : tb], filtered ? "true" : "false", inferred ? "true" : "false",
                    (have_chrom && within(w.f)) ? "true" : "false", (unsigned)r.flag);
-          text.append(line); n_rows++;
+          if (ln < 0 || (size_t)ln >= sizeof(line)) throw Error(MKP_E_UNSUPPORTED, "extract calls: a row is longer than " + std::to_string(sizeof(line)) + " bytes (read or contig name of unusual length)");
+          text.append(line, (size_t)ln); n_rows++;
         }
         if (any) n_used++; else n_skipped++;
       }

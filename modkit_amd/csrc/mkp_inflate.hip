@@ -154,10 +154,10 @@ mkp_inflate_blocks(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restric
         if (lengths[256] == 0) { err = 3; break; }   // no end-of-block code
         // the distance lengths follow the literal/length ones in the same array: build the length code first, then move on
         int e1 = construct(lencode, lengths, nlen);
-        if (e1 < 0 || (e1 > 0 && nlen - lencode.count[0] != 1)) { err = 3; break; }
+        if (e1 != 0) { err = 3; break; }   // an incomplete literal/length code is never valid (the host decoder's and zlib's rule)
         // (lengths of the distance code start at lengths[nlen]; construct reads them in place)
         int e2 = construct(distcode, lengths + nlen, ndist);
-        if (e2 < 0 || (e2 > 0 && ndist - distcode.count[0] != 1)) { err = 3; break; }
+        if (e2 < 0 || (e2 > 0 && !(ndist - distcode.count[0] == 1 && distcode.count[1] == 1))) { err = 3; break; }   // incomplete distance code: only a single one-bit code
       }
       // literal / length + distance symbols until end of block (3.2.5)
       for (uint32_t g2 = 0; g2 <= cap + 1u; g2++) {   // every symbol but the last emits at least one byte
@@ -329,9 +329,9 @@ mkp_inflate_blocks2(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restri
         if (err) break;
         if (lengths[256] == 0) { err = 3; break; }
         int e1 = construct(lencode, lengths, nlen);
-        if (e1 < 0 || (e1 > 0 && nlen - lencode.count[0] != 1)) { err = 3; break; }
+        if (e1 != 0) { err = 3; break; }   // an incomplete literal/length code is never valid (the host decoder's and zlib's rule)
         int e2 = construct(distcode, lengths + nlen, ndist);
-        if (e2 < 0 || (e2 > 0 && ndist - distcode.count[0] != 1)) { err = 3; break; }
+        if (e2 < 0 || (e2 > 0 && !(ndist - distcode.count[0] == 1 && distcode.count[1] == 1))) { err = 3; break; }   // incomplete distance code: only a single one-bit code
       }
       lc.load(lencode.count); dc.load(distcode.count);
       for (uint32_t g2 = 0; g2 <= cap + 1u; g2++) {

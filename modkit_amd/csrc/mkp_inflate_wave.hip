@@ -205,10 +205,10 @@ mkp_inflate_wave(const uint8_t* __restrict__ in, const MkpBgzfBlock* __restrict_
       {
         const int e1 = build(L.lens, nlen_codes, L.lit, LIT_BITS, L.lcount, L.lsym, lane);
         uint32_t used1 = 0; for (int l = 1; l <= 15; l++) used1 += sgpr(L.lcount[l]);
-        if (e1 < 0 || (e1 > 0 && used1 != 1u)) { err = 3; break; }
+        (void)used1; if (e1 != 0) { err = 3; break; }   // an incomplete literal/length code is never valid (the host decoder's and zlib's rule)
         const int e2 = build(L.lens + 288, ndist_codes, L.dist, DIST_BITS, L.dcount, L.dsym, lane);
         uint32_t used2 = 0; for (int l = 1; l <= 15; l++) used2 += sgpr(L.dcount[l]);
-        if (e2 < 0 || (e2 > 0 && used2 != 1u)) { err = 3; break; }
+        if (e2 < 0 || (e2 > 0 && !(used2 == 1u && sgpr(L.dcount[1]) == 1u))) { err = 3; break; }   // incomplete distance code: only a single one-bit code
       }
       // literal / length + distance symbols until end of block (§3.2.5)
       for (uint32_t g2 = 0; g2 <= cap + 1u; g2++) {   // every symbol but the last emits at least one byte

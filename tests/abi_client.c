@@ -97,8 +97,10 @@ static void build_focus(const char* seq, uint32_t s, uint32_t e, const motif_t* 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 int main(int argc, char** argv) {
-  if (argc < 6) die("usage: abi_client <in.bam> <ref.fa|-> <out.bed> <all|cpg|cg_cgcg> <default_threshold|none> [interval_size]");
+  if (argc < 6) die("usage: abi_client <in.bam> <ref.fa|-> <out.bed> <all|cpg|cg_cgcg> <default_threshold|none> [interval_size [intervals_per_batch]]");
   const char* mode = argv[4]; uint32_t interval = argc > 6 ? (uint32_t)strtoul(argv[6], NULL, 10) : 100000u;
+  /* intervals_per_batch > 1: the batch seam — mkp_batch_run takes that many consecutive intervals (a MultiChromCoordinates) per call */
+  uint32_t per_batch = argc > 7 ? (uint32_t)strtoul(argv[7], NULL, 10) : 1u; if (per_batch < 1) per_batch = 1;
   size_t cn, n; uint8_t* comp = read_file(argv[1], &cn); uint8_t* d = bgzf_inflate_all(comp, cn, &n); free(comp);
   if (n < 12 || memcmp(d, "BAM\1", 4) != 0) die("not a BAM");
   size_t o = 4; int32_t l_text; memcpy(&l_text, d + o, 4); o += 4 + (size_t)l_text;
@@ -129,7 +131,8 @@ int main(int argc, char** argv) {
   if (mkp_set_caller(ctx, &kc) != MKP_OK) die(mkp_last_error(ctx));
 
   FILE* out = fopen(argv[3], "w"); if (!out) die("cannot open output");
-  uint8_t* focus = n_motifs ? malloc(interval) : NULL; combos_t combos; memset(&combos, 0, sizeof(combos)); combos.n = 1;
+  uint8_t* focus = n_motifs ? malloc((size_t)interval * per_batch) : NULL; combos_t combos; memset(&combos, 0, sizeof(combos)); combos.n = 1;
+  mkp_shard* ivs = malloc(per_batch * sizeof(*ivs)); mkp_rows* brows = malloc(per_batch * sizeof(*brows));
   size_t first = 0; uint64_t total_rows = 0, n_calls = 0; double t_api = 0, t0 = now_s();
   mkp_record* batch = malloc(nr * sizeof(*batch) + sizeof(*batch));
   for (int tid = 0; tid < n_ref; tid++) {
@@ -137,7 +140,37 @@ int main(int argc, char** argv) {
     if (n_motifs) { for (int c = 0; c < n_contigs; c++) if (strcmp(fa[c].name, names[tid]) == 0) { if (fa[c].len < lens[tid]) die("FASTA contig shorter than BAM header says"); seq = fa[c].seq; } if (!seq) die("contig missing from FASTA"); }
     while (first < nr && recs[first].tid >= 0 && recs[first].tid < tid) first++;
     size_t lo = first;
-    for (uint32_t s = 0; s < lens[tid]; s += interval) {
+    for (uint32_t s = 0; per_batch > 1 && s < lens[tid];) {
+      /* the batch seam: `per_batch` consecutive intervals, their records fetched once, one call */
+      uint32_t nb_iv = 0, s0 = s;
+      for (; nb_iv < per_batch && s < lens[tid]; nb_iv++) {
+        uint32_t e = s + interval < lens[tid] ? s + interval : lens[tid];
+        memset(&ivs[nb_iv], 0, sizeof(ivs[nb_iv])); ivs[nb_iv].tid = tid; ivs[nb_iv].start = s; ivs[nb_iv].end = e;
+        if (n_motifs) { build_focus(seq, s, e, motifs, n_motifs, focus + (size_t)nb_iv * interval, &combos); ivs[nb_iv].focus = focus + (size_t)nb_iv * interval; ivs[nb_iv].combos = combos.c; }
+        s = e;
+      }
+      for (uint32_t k = 0; k < nb_iv; k++) if (n_motifs) ivs[k].n_combos = combos.n;   /* one table for the batch */
+      int64_t fs = (int64_t)s0 - 16, fe = (int64_t)s + 16;
+      while (lo < nr && recs[lo].tid == tid && (int64_t)ends[lo] <= fs) lo++;
+      size_t nb = 0;
+      for (size_t i = lo; i < nr && recs[i].tid == tid && (int64_t)recs[i].pos < fe; i++) if ((int64_t)ends[i] > fs) batch[nb++] = recs[i];
+      double ta = now_s();
+      if (mkp_batch_run(ctx, ivs, nb_iv, batch, (uint32_t)nb, brows) != MKP_OK) die(mkp_last_error(ctx));
+      t_api += now_s() - ta; n_calls++;
+      for (uint32_t k = 0; k < nb_iv; k++) {
+        const mkp_rows rows = brows[k];
+        for (uint64_t i = 0; i < rows.n_rows; i++) {
+          char name[64]; uint32_t code = rows.code_repr[i];
+          int kk = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
+          if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + kk, sizeof(name) - (size_t)kk, ",%s,%d", motifs[rows.motif_idx[i]].pat, motifs[rows.motif_idx[i]].off);
+          float frac = (float)rows.n_mod[i] / (float)rows.n_valid[i];
+          fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1, name, rows.n_valid[i], (char)rows.strand[i],
+                  rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i], rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
+        }
+        total_rows += rows.n_rows;
+      }
+    }
+    for (uint32_t s = 0; per_batch == 1 && s < lens[tid]; s += interval) {
       uint32_t e = s + interval < lens[tid] ? s + interval : lens[tid];
       int64_t fs = (int64_t)s - 16, fe = (int64_t)e + 16;
       /* records of this contig overlapping [s-16, e+16), file order (what IndexedReader::fetch returns) */
@@ -165,7 +198,7 @@ int main(int argc, char** argv) {
   }
   fclose(out);
   double wall = now_s() - t0;
-  fprintf(stderr, "[abi_client] intervals=%llu rows=%llu api_s=%.3f wall_s=%.3f rows_per_s_api=%.0f\n", (unsigned long long)n_calls, (unsigned long long)total_rows, t_api, wall, t_api > 0 ? (double)total_rows / t_api : 0.0);
+  fprintf(stderr, "[abi_client] per_batch=%u intervals=%llu rows=%llu api_s=%.3f wall_s=%.3f rows_per_s_api=%.0f\n", per_batch, (unsigned long long)n_calls, (unsigned long long)total_rows, t_api, wall, t_api > 0 ? (double)total_rows / t_api : 0.0);
   mkp_ctx_destroy(ctx);
   return 0;
 }

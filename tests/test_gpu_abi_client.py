@@ -25,8 +25,8 @@ def client(tmp_path_factory):
     return exe
 
 
-def run_client(client, bam, ref, out, mode, thr, interval=None):
-    p = subprocess.run([client, bam, ref or "-", out, mode, thr] + ([str(interval)] if interval else []), capture_output=True, text=True)
+def run_client(client, bam, ref, out, mode, thr, interval=None, per_batch=None):
+    p = subprocess.run([client, bam, ref or "-", out, mode, thr] + ([str(interval or 100000)] if (interval or per_batch) else []) + ([str(per_batch)] if per_batch else []), capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     return p.stderr
 
@@ -57,4 +57,33 @@ def test_client_per_interval_calls_on_a_cpg_workload(client, oracle_bin, tmp_pat
     ta, tb, tc = open(a).read(), open(b).read(), open(c).read()
     assert len(ta.splitlines()) > 100_000 and ta == tb == tc
     assert "intervals=40 " in err
+    print(err.strip())
+
+
+@pytest.mark.parametrize("mode,flags", [
+    ("all", ["--no-filtering"]),
+    ("cpg", ["--no-filtering", "--cpg", "--ref", REF]),
+    ("cg_cgcg", ["--no-filtering", "--motif", "CG", "0", "--motif", "CGCG", "2", "--ref", REF]),
+], ids=["all_positions", "cpg", "two_motifs"])
+@pytest.mark.parametrize("per_batch", [2, 7, 1000])
+def test_batch_seam_equals_driver_on_the_reference_fixture(client, tmp_path, mode, flags, per_batch):
+    """mkp_batch_run: `per_batch` consecutive 25 bp intervals (a MultiChromCoordinates) per call — merged into one resident shard
+    inside, rows cut apart at the interval ends — must print what the per-interval calls and the driver print."""
+    a, b = str(tmp_path / "client.bed"), str(tmp_path / "driver.bed")
+    err = run_client(client, fixture(BC), REF, a, mode, "none", 25, per_batch)
+    assert "per_batch=%d " % per_batch in err
+    modkit_amd.pileup([fixture(BC), b, "-i", "25"] + flags)
+    assert open(a).read() == open(b).read() and open(a).read()
+
+
+def test_batch_seam_on_a_cpg_workload(client, oracle_bin, tmp_path):
+    # the same C3-shaped data through mkp_batch_run, 12 intervals (1.2 Mb) per call: 4 calls instead of 40, the same rows
+    bam, fa, meta = gen(tmp_path, "c3b", [("chr20", 4_000_000)], 12_000, "hm", 21, ["--cpg-depleted", "--mean-len", "8353"])
+    a, c = str(tmp_path / "client.bed"), str(tmp_path / "oracle.bed")
+    err = run_client(client, bam, fa, a, "cpg", "0.7", 100000, 12)
+    flags = ["--filter-threshold", "0.7", "--cpg", "--ref", fa]
+    p = subprocess.run([oracle_bin, "pileup", bam, c, "--oracle-workers", "8"] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(a).read() == open(c).read()
+    assert "intervals=4 " in err
     print(err.strip())

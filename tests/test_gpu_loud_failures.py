@@ -34,6 +34,39 @@ def test_duplicate_read_names_are_refused(tmp_path):
     assert e.value.status == -3 and "read name" in str(e.value)
 
 
+def test_same_name_in_different_intervals_is_two_reads(oracle_bin, tmp_path):
+    """The reference's read cache is per interval and keyed by name: mates / split alignments with one name that lie in different intervals
+    never meet — the device takes them as two reads (== oracle, which keys its cache the same way); the same two records under an interval
+    size that puts them into one interval are still refused."""
+    import random
+    import subprocess
+    rng = random.Random(5)
+    ref_len = 6000
+    recs = []
+    for i in range(60):
+        seq = "".join(rng.choice("ACGT") for _ in range(200))
+        cs = [k for k, ch in enumerate(seq) if ch == "C"]
+        picks = cs[::3][:20]
+        deltas, prev = [], -1
+        for k, pidx in enumerate(cs):
+            if pidx in picks:
+                deltas.append(sum(1 for x in cs if prev < x < pidx)); prev = pidx
+        aux = aux_z("MM", "C+m?," + ",".join(map(str, deltas)) + ";") + aux_bc("ML", [rng.randrange(256) for _ in deltas])
+        pos = rng.randrange(0, 1500) if i % 2 == 0 else rng.randrange(3200, ref_len - 250)
+        recs.append((pos, bam_record(0, pos, 0, "pair%02d" % (i // 2), [(len(seq), "M")], seq, aux)))   # mates: one name, far apart
+    recs.sort(key=lambda t: t[0])
+    bam = str(tmp_path / "mates.bam")
+    bgzf_write(bam, bytes(bam_header([("ctg", ref_len)])) + b"".join(r for _, r in recs))
+    dev, ora = str(tmp_path / "dev.bed"), str(tmp_path / "ora.bed")
+    flags = ["--no-filtering", "-i", "1600"]      # mates sit in intervals 0 and 2-3
+    modkit_amd.pileup([bam, dev] + flags)
+    assert subprocess.run([oracle_bin, "pileup", bam, ora] + flags, capture_output=True).returncode == 0
+    assert open(dev).read() == open(ora).read() and len(open(dev).read()) > 1000
+    with pytest.raises(modkit_amd.MkpError) as e:   # one interval for the whole contig: the mates would share a cache entry
+        modkit_amd.pileup([bam, dev, "--no-filtering", "-i", "100000"])
+    assert e.value.status == -3 and "read name" in str(e.value)
+
+
 @pytest.mark.parametrize("flag", [["--bedgraph"]])
 def test_writer_side_flags_are_refused(tmp_path, flag):
     with pytest.raises(modkit_amd.MkpError) as e:
