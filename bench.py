@@ -348,12 +348,17 @@ def main():
         ctxs = [ctx]
     elif world == 1:
         ctx = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
-        rep = None
+        rep = rep_warm = None
         if not (a.inner or a.skip_e2e):
             # end to end: the whole subcommand on this context (block reads + inflate, threshold sampling, focus, device pipeline,
             # bedMethyl text), with the driver's default sharding (the next shard's blocks inflate while this one is packed and run)
             rep = run_subcommand(ctx, out_bed, [])
             thr_h = [float(rep.threshold[i]) if rep.has_threshold[i] else 0.0 for i in range(4)]
+            # the same call again on the same context: staging, window and row buffers exist now (what a long-lived caller pays per file)
+            rep_warm = run_subcommand(ctx, out_bed + ".warm", [])
+            if sh256(out_bed) != sh256(out_bed + ".warm"):
+                raise SystemExit("second end-to-end pass on the same context differs from the first")
+            os.remove(out_bed + ".warm")
         else:
             thr = ctx.estimate_thresholds(bam, ["-t", "8"])
             thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
@@ -493,6 +498,11 @@ def main():
                                          "d2h": rep.d2h_ms, "bedmethyl_text_write": rep.write_ms},
                            "shards": int(rep.n_shards), "what": "rank 0: mkp_pileup_run wall (`modkit pileup in.bam out.bed` with the workload's flags, default sharding), page cache warm, the library's host pool at host_threads threads; bam_load_inflate = what the shard loop waited for blocks (the rest overlaps with pack / run / write)"},
         })
+        if world == 1 and not multi and locals().get("rep_warm") is not None:
+            rw = rep_warm
+            tiers["end_to_end_warm_context"] = {"positions_per_s": rw.n_positions / (rw.total_ms * 1e-3), "rows_per_s": rw.n_rows / (rw.total_ms * 1e-3), "ms": rw.total_ms,
+                                                "stages_ms": {"bam_load_inflate": rw.load_ms, "threshold": rw.threshold_ms, "focus": rw.focus_ms, "pack": rw.pack_ms, "h2d": rw.h2d_ms, "kernels": rw.kernel_ms, "d2h": rw.d2h_ms, "bedmethyl_text_write": rw.write_ms},
+                                                "what": "the same mkp_pileup_run again on the same context (page-locked staging, ingest windows and row buffers already allocated); tiers.end_to_end is the first call on a fresh context"}
         if world == 1 and a.workload == "c3" and not (a.inner or a.skip_e2e):
             tiers["seam_per_interval"] = seam_per_interval(bam, fa, bam + ".seam.bed", thr_h[1] if thr_h[1] > 0 else 0.7)
             # the batch seam (mkp_batch_run): the reference's default chunk of floor(1.5 * threads) intervals at 8 and 64 threads, and a whole contig per call

@@ -364,7 +364,13 @@ void make_resident(mkp_ctx* c) {
           slotbm[b >> 5] |= 1u << (b & 31); }
     });
     std::vector<uint32_t> wpfx(nwords + 1, 0);
-    for (size_t w = 0; w < nwords; w++) wpfx[w + 1] = wpfx[w] + (uint32_t)__builtin_popcount(slotbm[w]);
+    {   // running popcount over the bitmap words: block sums on all cores, a short serial pass over the blocks, then the blocks again
+      const size_t blk = (size_t)1 << 16, nblk = (nwords + blk - 1) / blk; std::vector<uint32_t> bsum(nblk + 1, 0);
+      host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t t = 0; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) t += (uint32_t)__builtin_popcount(slotbm[w]); bsum[b + 1] = t; } });
+      for (size_t b = 0; b < nblk; b++) bsum[b + 1] += bsum[b];
+      host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t run = bsum[b]; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) { wpfx[w] = run; run += (uint32_t)__builtin_popcount(slotbm[w]); } } });
+      wpfx[nwords] = bsum[nblk];
+    }
     auto rank = [&](int64_t p) { const size_t b = (size_t)(p - S.win_start + MKP_SLOTBM_MARGIN);
         return wpfx[b >> 5] + (uint32_t)__builtin_popcount(slotbm[b >> 5] & ((1u << (b & 31)) - 1u)); };
     if (stream) {
@@ -378,10 +384,10 @@ void make_resident(mkp_ctx* c) {
             for (uint32_t bits = slotbm[w]; bits; bits &= bits - 1u) slot_pos_h[at++] = (uint32_t)((int64_t)(w * 32 + (size_t)__builtin_ctz(bits)) - MKP_SLOTBM_MARGIN + S.win_start);
             }
       });
+      host_parallel(S.hdr.size(), 8192, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { MkpReadHdr& h = S.hdr[i]; const uint32_t a = crank(h.ref_start), b = std::max(a, crank(h.ref_end)); h.gs0 = a; h.n_sl = b - a; h.pad = 0; } });
       uint64_t off = 0;
-      for (auto& h : S.hdr) {
-        const uint32_t a = crank(h.ref_start), b = std::max(a, crank(h.ref_end));
-        h.gs0 = a; h.n_sl = b - a; h.cov_off = (uint32_t)off; h.pad = 0;
+      for (auto& h : S.hdr) {   // (the stream offsets are a running sum: serial, but nothing else is left in the loop)
+        h.cov_off = (uint32_t)off;
         off += ((uint64_t)h.n_sl + 3u) & ~3ull;
         if (off > 0xffffff00ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of per-read focus positions; use smaller shards");
       }
@@ -563,12 +569,16 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess * c->key_passes.size(), 1ull << 28));
   }
   const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
-  c->d_tile_row_off.ensure((size_t)(n_runs + 1) * 4); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);
+  c->d_tile_row_off.ensure((size_t)(n_runs + 1) * 8); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);   // (slot pipeline: row_off holds the runs' 64-bit look-back words)
   for (;;) {
     P.row_capacity = (uint32_t)c->row_cap;
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
     uint32_t* misc = c->d_misc.as<uint32_t>();  // [0] row cursor, [1] total rows, [2] error bits
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
+    if (c->slot_mode) {   // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, misc[3] = number of runs
+      hip_check(hipMemsetAsync(c->d_tile_row_off.p, 0, (size_t)(n_runs + 1) * 8, c->stream), "memset");
+      hip_check(hipMemcpyAsync(misc + 3, &n_runs, 4, hipMemcpyHostToDevice, c->stream), "H2D");
+    }
     c->d_prm.ensure(sizeof(MkpRunParams));
     hip_check(hipMemcpyAsync(c->d_prm.p, &P, sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
@@ -594,7 +604,8 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
                                   c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
-    hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
+    if (c->slot_mode) c->rows_dst = c->rows_src;   // already in genome order
+    else hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
         &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     uint32_t h[4];

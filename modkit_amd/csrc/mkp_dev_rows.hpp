@@ -200,7 +200,26 @@ template <bool FOCUS> struct SlotMap {
 
 // Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
 // run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
-template <bool FOCUS, bool HEMI, class SM>
+// Row runs in genome order without a second pass: a tile's place in the row buffer is the number of rows of the tiles before it, found by
+// a decoupled look-back over one 64-bit word per run (bits 62-63: 1 = this run's own count is known, 2 = the count of everything up to
+// and including it; low bits: the value).  Tile t runs as workgroup t (dispatch order = genome order), so the run a workgroup waits for
+// is always one that started before it.  One thread per workgroup walks back; flag and value travel in one atomic word.
+__device__ __forceinline__ uint32_t lookback_reserve(unsigned long long* __restrict__ state, uint32_t run, uint32_t s) {
+  __hip_atomic_store(&state[run], (1ull << 62) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long excl = 0;
+  for (long long i = (long long)run - 1; i >= 0;) {
+    const unsigned long long v = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t flag = (uint32_t)(v >> 62);
+    if (flag == 0u) { __builtin_amdgcn_s_sleep(2); continue; }
+    excl += v & 0xffffffffull;
+    if (flag == 2u) break;
+    i--;
+  }
+  __hip_atomic_store(&state[run], (2ull << 62) | ((excl + s) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (uint32_t)excl;
+}
+
+template <bool FOCUS, bool HEMI, class SM, bool ORDERED = false>
 __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SM sm, uint32_t n_tslots, MkpTile tl, uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
                                             const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
                                             uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
@@ -233,9 +252,13 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
     if (threadIdx.x == 0) {
       uint32_t s = 0;
       for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
-      uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+      uint32_t base;
+      if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); row_cursor[3] = number of runs (host), row_cursor[1] = total rows, written by the last run
+        base = lookback_reserve(reinterpret_cast<unsigned long long*>(tile_row_off), tix, s);
+        if (tix + 1u == row_cursor[3]) row_cursor[1] = base + s;
+      } else base = s ? atomicAdd(row_cursor, s) : 0u;
       if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
-      *row_base_p = base; tile_row_off[tix] = base; tile_row_cnt[tix] = s; *scan_carry_p = s ? 0u : 0xffffffffu;
+      *row_base_p = base; if (!ORDERED) { tile_row_off[tix] = base; tile_row_cnt[tix] = s; } *scan_carry_p = s ? 0u : 0xffffffffu;
     }
     __syncthreads();
     if (*scan_carry_p != 0xffffffffu && cnt) {

@@ -36,7 +36,7 @@ uint64_t fnv64(const std::string& s) { uint64_t h = 1469598103934665603ull; for 
 
 struct mkp_dev_ingest {
   int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr;
-  static constexpr size_t kPiece = (size_t)4 << 20, kSlots = 16;   // upload staging: two halves of kSlots pieces
+  static constexpr size_t kPiece = (size_t)2 << 20, kSlots = 16;   // 64 MiB page-locked in all (allocating it is part of a fresh context's first ingest)   // upload staging: two halves of kSlots pieces
   Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
   DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig, parts;
   std::mutex mu;                                                   // one ingest at a time per object

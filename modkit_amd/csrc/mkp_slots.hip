@@ -562,8 +562,10 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   const uint32_t wave = rfl(threadIdx.x >> 6);
   // XCD-aware mapping: consecutive workgroups land on different XCDs; give each XCD a contiguous run of tiles so that the reads
   // neighbouring tiles share stay in one L2
-  uint32_t tix = blockIdx.x;
-  { const uint32_t per = n_tiles / 8u; if (per && tix < per * 8u) tix = (tix & 7u) * per + (tix >> 3); }
+  // tile t = workgroup t: rows leave in genome order through a look-back over the tiles before (mkp_dev_rows.hpp), which needs the
+  // dispatch order to be the genome order (an XCD-aware permutation was tried in round 3: it kept neighbouring tiles' shared reads in one
+  // L2, but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need)
+  const uint32_t tix = blockIdx.x;
   const MkpSTile tl = tiles[tix];
   const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
   for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
@@ -650,7 +652,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   __syncthreads();
   StreamSlotMap sm; sm.fpos = fpos; sm.n = n_tslots;
   MkpTile tl2; tl2.r0 = tl.r0; tl2.r1 = tl.r1; tl2.first = tl.first; tl2.last = tl.last;
-  emit_tile_rows<true, false>(tal, sm, n_tslots, tl2, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
 }
 
 #define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \
