@@ -155,7 +155,7 @@ def host_histogram(values):
     return get
 
 
-def estimate_thresholds_allreduce(ctx, bam, flags=(), q=0.1, rank=None, world=None):
+def estimate_thresholds_allreduce(ctx, bam, flags=(), q=0.1, rank=None, world=None, rccl_direct=None):
     """Per-base pass thresholds over the samples of ALL ranks (full-data mode, `-f 1.0`): each rank decodes only the reads of its
     own sampling intervals on its GPU (mkp_histogram_add_bam --gpus-rank R --gpus-world W), the two-level histograms are summed
     over the ranks (RCCL all-reduce on GPUs, gloo in the CPU tests) and every rank evaluates the exact percentile of the union.
@@ -169,10 +169,14 @@ def estimate_thresholds_allreduce(ctx, bam, flags=(), q=0.1, rank=None, world=No
         argv += ["--gpus-rank", str(rank), "--gpus-world", str(world)]
     ctx.histogram_add_bam(bam, argv)
     out = {}
-    # on the nccl backend (one GPU per rank) the sum runs where the histograms sit: ncclAllReduce(u64) through the C ABI on a communicator
-    # of this job's ranks; torch.distributed's all_reduce on host copies is the test double (gloo: several ranks may share a GPU)
+    # rccl_direct (or MKP_RCCL_DIRECT=1; nccl backend, one GPU per rank): the sum runs where the histograms sit — ncclAllReduce(u64) through
+    # the C ABI (mkp_histogram_allreduce) on a communicator of this job's ranks.  Default: mkp_histogram_get + torch.distributed's
+    # all_reduce, the path every multi-rank test here exercises (gloo: several ranks share the box's one GPU, which RCCL refuses); the
+    # direct path has run on one rank only (tests/test_gpu_scale.py) until a multi-GPU node confirms it.
     comm = None
-    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl" and not _env_flag("MKP_TORCH_ALLREDUCE"):
+    if rccl_direct is None:
+        rccl_direct = _env_flag("MKP_RCCL_DIRECT")
+    if rccl_direct and dist.is_initialized() and dist.get_backend() == "nccl":
         comm = RcclComm()
     try:
         for b in BASES:

@@ -257,3 +257,33 @@ def test_two_processes_default_sampled_thresholds_equal_single_gpu(oracle_bin, t
         assert p.exitcode == 0
     assert res[0] == res[1] and "C" in res[0]
     assert open(out).read() == whole
+
+
+def test_histogram_allreduce_through_rccl_on_one_rank(tmp_path):
+    """mkp_histogram_allreduce: the device histograms widened to u64 and summed with ncclAllReduce on a communicator made through
+    librccl's C API (modkit_amd.distributed.RcclComm).  One rank here (the box has one GPU): the sum is the histogram itself; what is
+    checked is the call path — communicator, u64 device buffers, stream order, D2H — for both levels."""
+    import numpy as np
+    from modkit_amd import distributed as mkd
+    bam, fa, meta = gen(tmp_path, "rc", [("chr1", 900_000)], 3_000, "hm", 46, ["--mean-len", "5000"])
+    ctx = modkit_amd.Context()
+    try:
+        ctx.histogram_begin()
+        ctx.histogram_add_bam(bam, ["-f", "1.0"])
+        comm = mkd.RcclComm(rank=0, world=1)
+        try:
+            for b in "AC":
+                h0 = ctx.histogram_get(b, 0, 0)
+                r0 = ctx.histogram_allreduce(comm, b, 0, 0)
+                assert np.array_equal(h0, r0)
+                if h0.sum():
+                    top = int(np.argmax(h0))
+                    assert np.array_equal(ctx.histogram_get(b, 1, top), ctx.histogram_allreduce(comm, b, 1, top))
+            assert ctx.histogram_get("C", 0, 0).sum() > 1000
+            t_direct, n1 = mkd.percentile_from_histograms(lambda level, prefix: ctx.histogram_allreduce(comm, "C", level, prefix), 0.1, reduced=True)
+            t_host, n2 = mkd.percentile_from_histograms(lambda level, prefix: ctx.histogram_get("C", level, prefix), 0.1)
+            assert n1 == n2 and t_direct == t_host
+        finally:
+            comm.close()
+    finally:
+        ctx.close()
