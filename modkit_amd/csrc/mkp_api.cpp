@@ -188,6 +188,40 @@ hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void
 namespace {
 hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
 
+// slot bitmap of a focus window (bit p - win_start + margin set where position p owns a tally column), its running popcount per word and —
+// slot pipeline — the slot positions.  Depends on the focus bytes only.
+void window_slots(mkp_ctx* c, bool hemi, bool stream, std::vector<uint32_t>& slotbm, std::vector<uint32_t>& wpfx, std::vector<uint32_t>& slot_pos_h) {
+  const ShardHost& S = c->shard;
+  const int64_t win = (int64_t)S.win_end - (int64_t)S.win_start;
+  const size_t nbits = (size_t)win + 2 * MKP_SLOTBM_MARGIN, nwords = (nbits + 31) / 32 + 2;
+  slotbm.assign(nwords, 0);
+  const uint8_t* fz = c->focus.data();
+  // pileup-hemi: only the positions with a positive-strand motif hit own a column (positions_to_motifs.get(pos), duplex.rs:289-296)
+  uint8_t hemi_ok[64]; for (size_t k = 0; k < 64; k++) hemi_ok[k] = (k < c->combos.size() && c->combos[k].n_pos > 0) ? 1 : 0;
+  host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {   // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
+    for (size_t p = lo; p < hi; p++) if (hemi ? ((fz[p] & 1u) && hemi_ok[fz[p] >> 2]) : (fz[p] & 3u)) { const size_t b = p + MKP_SLOTBM_MARGIN;
+        slotbm[b >> 5] |= 1u << (b & 31); }
+  });
+  wpfx.assign(nwords + 1, 0);
+  {   // running popcount over the bitmap words: block sums on all cores, a short serial pass over the blocks, then the blocks again
+    const size_t blk = (size_t)1 << 16, nblk = (nwords + blk - 1) / blk; std::vector<uint32_t> bsum(nblk + 1, 0);
+    host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t t = 0; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) t += (uint32_t)__builtin_popcount(slotbm[w]); bsum[b + 1] = t; } });
+    for (size_t b = 0; b < nblk; b++) bsum[b + 1] += bsum[b];
+    host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t run = bsum[b]; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) { wpfx[w] = run; run += (uint32_t)__builtin_popcount(slotbm[w]); } } });
+    wpfx[nwords] = bsum[nblk];
+  }
+  slot_pos_h.clear();
+  if (stream) {
+    slot_pos_h.resize(wpfx[nwords]);
+    host_parallel(nwords, (size_t)1 << 15, [&](size_t lo, size_t hi) {
+      for (size_t w = lo; w < hi; w++) { uint32_t at = wpfx[w];
+          for (uint32_t bits = slotbm[w]; bits; bits &= bits - 1u) slot_pos_h[at++] = (uint32_t)((int64_t)(w * 32 + (size_t)__builtin_ctz(bits)) - MKP_SLOTBM_MARGIN + S.win_start);
+          }
+    });
+  }
+}
+bool stream_pipeline(const mkp_ctx* c, bool hemi) { return c->has_focus && !hemi && !(getenv("MKP_PIPELINE") && !strcmp(getenv("MKP_PIPELINE"), "tiles")); }
+
 // derive tile geometry, tile read ranges and the run parameters; upload everything
 void make_resident(mkp_ctx* c) {
   auto t0 = std::chrono::steady_clock::now();
@@ -338,8 +372,8 @@ void make_resident(mkp_ctx* c) {
   std::vector<MkpTile> tiles; std::vector<uint32_t> slotbm; uint32_t Scap = 0, Wcap = 0;
   // focus runs take the slot pipeline (mkp_slots.hip) unless MKP_PIPELINE=tiles asks for the tile walk of mkp_kernels.hip (A/B runs);
   // pileup-hemi keeps the tile walk
-  const bool stream = c->has_focus && !c->hemi && !(getenv("MKP_PIPELINE") && !strcmp(getenv("MKP_PIPELINE"), "tiles"));
-  std::vector<uint32_t> slot_pos_h; std::vector<MkpSTile> stiles;
+  const bool stream = stream_pipeline(c, c->hemi);
+  std::vector<uint32_t> slot_pos_h, wpfx; std::vector<MkpSTile> stiles; bool preplanned = false;
   c->slot_mode = stream; P.slot_stream = stream ? 1u : 0u; c->cov_bytes = 0;
   auto max_slots_for = [&](uint32_t W) { uint32_t best = 0; for (uint32_t s = 64; s <= 4160; s += 64) if (MKP_PILEUP_LDS_WORDS(words_per_slot, s,
       W) <= budget_words) best = s;
@@ -352,25 +386,11 @@ void make_resident(mkp_ctx* c) {
     Scap = (T + 2 * MKP_HALO + 63u) & ~63u;
     for (int64_t r0 = S.win_start; r0 < S.win_end; r0 += T) tiles.push_back({(int32_t)r0, (int32_t)std::min<int64_t>(r0 + T, S.win_end), 0, 0});
   } else {
-    // slot bitmap: bit (p - win_start + margin) set where position p is in focus
+    // slot bitmap + running popcount + slot positions: made ahead of the reads when the driver asked for it (mkp_internal_shard_preplan)
     const size_t nbits = (size_t)win + 2 * MKP_SLOTBM_MARGIN, nwords = (nbits + 31) / 32 + 2;
-    slotbm.assign(nwords, 0);
-    const uint8_t* fz = c->focus.data();
-    // pileup-hemi: only the positions with a positive-strand motif hit own a column (positions_to_motifs.get(pos), duplex.rs:289-296)
-    uint8_t hemi_ok[64]; for (size_t k = 0; k < 64; k++) hemi_ok[k] = (k < c->combos.size() && c->combos[k].n_pos > 0) ? 1 : 0;
-    const bool hemi = c->hemi;
-    host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {   // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
-      for (size_t p = lo; p < hi; p++) if (hemi ? ((fz[p] & 1u) && hemi_ok[fz[p] >> 2]) : (fz[p] & 3u)) { const size_t b = p + MKP_SLOTBM_MARGIN;
-          slotbm[b >> 5] |= 1u << (b & 31); }
-    });
-    std::vector<uint32_t> wpfx(nwords + 1, 0);
-    {   // running popcount over the bitmap words: block sums on all cores, a short serial pass over the blocks, then the blocks again
-      const size_t blk = (size_t)1 << 16, nblk = (nwords + blk - 1) / blk; std::vector<uint32_t> bsum(nblk + 1, 0);
-      host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t t = 0; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) t += (uint32_t)__builtin_popcount(slotbm[w]); bsum[b + 1] = t; } });
-      for (size_t b = 0; b < nblk; b++) bsum[b + 1] += bsum[b];
-      host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t run = bsum[b]; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) { wpfx[w] = run; run += (uint32_t)__builtin_popcount(slotbm[w]); } } });
-      wpfx[nwords] = bsum[nblk];
-    }
+    preplanned = c->wplan.valid && stream && !c->hemi && c->wplan.slotbm.size() == nwords;
+    if (preplanned) { slotbm.swap(c->wplan.slotbm); wpfx.swap(c->wplan.wpfx); slot_pos_h.swap(c->wplan.slot_pos); c->wplan.valid = false; }
+    else window_slots(c, c->hemi, stream, slotbm, wpfx, slot_pos_h);
     auto rank = [&](int64_t p) { const size_t b = (size_t)(p - S.win_start + MKP_SLOTBM_MARGIN);
         return wpfx[b >> 5] + (uint32_t)__builtin_popcount(slotbm[b >> 5] & ((1u << (b & 31)) - 1u)); };
     if (stream) {
@@ -378,12 +398,6 @@ void make_resident(mkp_ctx* c) {
       const int64_t lo_clamp = (int64_t)S.win_start - MKP_SLOTBM_MARGIN, hi_clamp = (int64_t)S.win_end + MKP_SLOTBM_MARGIN;
       auto crank = [&](int64_t p) { return rank(std::min(std::max(p, lo_clamp), hi_clamp)); };
       const uint32_t total = wpfx[nwords];
-      slot_pos_h.resize(total);
-      host_parallel(nwords, (size_t)1 << 15, [&](size_t lo, size_t hi) {
-        for (size_t w = lo; w < hi; w++) { uint32_t at = wpfx[w];
-            for (uint32_t bits = slotbm[w]; bits; bits &= bits - 1u) slot_pos_h[at++] = (uint32_t)((int64_t)(w * 32 + (size_t)__builtin_ctz(bits)) - MKP_SLOTBM_MARGIN + S.win_start);
-            }
-      });
       host_parallel(S.hdr.size(), 8192, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { MkpReadHdr& h = S.hdr[i]; const uint32_t a = crank(h.ref_start), b = std::max(a, crank(h.ref_end)); h.gs0 = a; h.n_sl = b - a; h.pad = 0; } });
       uint64_t off = 0;
       for (auto& h : S.hdr) {   // (the stream offsets are a running sum: serial, but nothing else is left in the loop)
@@ -504,14 +518,16 @@ void make_resident(mkp_ctx* c) {
   lap("upload: packed reads");
   upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
   upload(c->d_read_ids, class_list);
-  if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64);
+  if (c->has_focus && preplanned) { /* focus bytes, combos, slot bitmap and slot positions went up with the pre-plan */ }
+  else if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64);
       c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
   lap("upload: focus + event buffers");
   if (stream) {
-    upload(c->d_slot_pos, slot_pos_h); upload(c->d_stiles, stiles);
+    if (!preplanned) upload(c->d_slot_pos, slot_pos_h);
+    upload(c->d_stiles, stiles);
     {   // the fused decoder's work records, in launch order; the cover kernel keeps a read-id list
       const uint32_t nf = c->n_slot_class[0] + c->n_slot_class[1];
       std::vector<MkpWork> work(nf);
@@ -801,11 +817,27 @@ int mkp_shard_begin(mkp_ctx* c, const mkp_shard* s) {
       c->combos.assign(s->combos, s->combos + s->n_combos);
       if (c->combos.empty()) { mkp_motif_combo z; memset(&z, 0, sizeof(z)); c->combos.push_back(z); }
     } else { c->focus.clear(); c->combos.clear(); }
-    c->shard_open = true; c->resident = false; c->row_cap = 0; c->iv_starts.clear();
+    c->shard_open = true; c->resident = false; c->row_cap = 0; c->iv_starts.clear(); c->wplan.valid = false;
     c->key_names.assign(1, "ungrouped");
     memset(&c->stats, 0, sizeof(c->stats));
   });
 }
+
+// Ahead of the reads (the device ingest of this shard is still running): everything of the plan that depends on the window alone.
+}   // extern "C"
+int mkp_internal_shard_preplan(mkp_ctx* c) {
+  if (!c) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!c->shard_open) throw Error(MKP_E_INVALID, "mkp_shard_begin first");
+    c->wplan.valid = false;
+    if (!stream_pipeline(c, false)) return;
+    window_slots(c, false, true, c->wplan.slotbm, c->wplan.wpfx, c->wplan.slot_pos);
+    hip_check(hipSetDevice(c->device), "hipSetDevice");
+    upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, c->wplan.slotbm); upload(c->d_slot_pos, c->wplan.slot_pos);
+    c->wplan.valid = true;
+  });
+}
+extern "C" {
 
 // The reference's interval grid inside the open shard (ascending interval starts; the last interval ends with the window): only read by the
 // duplicate-name rule of the planner — records with one name matter only when they overlap a common interval.  Without it the shard counts

@@ -69,6 +69,9 @@ struct mkp_ctx {
   // `modkit summary` (mkp_summary): sampling rounds count calls instead of storing probabilities; device table [4][2][16] + reads_with[6] (u64)
   bool extract_mode = false;   // `extract calls`: the sampling kernels emit one record per call (forward position, classes, call_prob)
   bool summary_mode = false; mkp::DevBuf d_summary; std::vector<uint8_t> h_sum_base; std::vector<uint32_t> h_sum_code; std::vector<uint64_t> h_sum_pass, h_sum_fail;
+  // the read-independent part of a focus shard's plan (slot bitmap, its running popcount, the slot positions, their uploads), made ahead
+  // of the reads by mkp_internal_shard_preplan while the device ingest of the same shard is still running
+  struct WindowPlan { bool valid = false; std::vector<uint32_t> slotbm, wpfx, slot_pos; } wplan;
   struct mkp_dev_ingest* ingest = nullptr;   // device ingest of indexed BAMs (mkp_ingest_host.cpp): created on first use, lives with the context (staging + window buffers are reused)
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -80,6 +83,7 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
 int mkp_internal_sample_resident(mkp_ctx* c, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const uint32_t* reads, uint32_t n, bool only_mapped,
                                  std::vector<uint32_t>* n_vals);   // the same pass over reads of the device-packed shard attached to the context
 int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take);
+int mkp_internal_shard_preplan(mkp_ctx* c);   // between mkp_shard_begin and the records: the window's slot bitmap / positions computed and uploaded ahead (plain pileup focus shards)
 void mkp_internal_bedmask_reset(mkp_ctx* c);   // a new sampling session: host mask pointers of the last one mean nothing any more
 // summary mode: zero the device table / read it back (134 u64: table[4][2][16] then reads_with[6])
 int mkp_internal_summary_begin(mkp_ctx* c);

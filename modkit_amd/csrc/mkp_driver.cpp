@@ -605,16 +605,19 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           if (fb.has_focus()) focus_done[0] = 1; focus_ms += ms_since(t_focus); }
         const std::vector<Interval>& ivs = grid_of[0]; uint64_t bp = 0;
         if (!ivs.empty() && shard_cut(records[0], ivs, 0, &bp) == ivs.size() && ivs.front().start == early_s0 && ivs.back().end == early_s1) {
+          // the shard is begun and everything of its plan that needs the window alone (slot bitmap, slot positions, their uploads) is
+          // made now, while the ingest is still running
+          mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)records[0].tid; sh.start = early_s0; sh.end = early_s1;
+          if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+          must(mkp_shard_begin(ctx, &sh));
+          { std::vector<uint32_t> st; st.reserve(ivs.size()); for (auto& iv : ivs) st.push_back(iv.start); must(mkp_shard_set_intervals(ctx, st.data(), (uint32_t)st.size())); }
+          if (fb.has_focus() && !a.hemi) must(mkp_internal_shard_preplan(ctx));
           auto t_w = std::chrono::steady_clock::now();
           mark("resident sampling: waiting for the ingest");
           early_in = early_fetch.get(); early_in_ready = true;
           fetch_wait_early_ms = ms_since(t_w);
           mark("resident sampling: ingest in hand");
           if (early_in.dev) {
-            mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)records[0].tid; sh.start = early_s0; sh.end = early_s1;
-            if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
-            must(mkp_shard_begin(ctx, &sh));
-            { std::vector<uint32_t> st; st.reserve(ivs.size()); for (auto& iv : ivs) st.push_back(iv.start); must(mkp_shard_set_intervals(ctx, st.data(), (uint32_t)st.size())); }
             pre_dev = std::move(early_in.dev); early_in_ready = false;
             must(mkp_internal_shard_attach(ctx, pre_dev.get())); mkp_internal_ingest_recycle(ctx->ingest, pre_dev.get());
             pre_attached = true; resident = &ctx->shard;

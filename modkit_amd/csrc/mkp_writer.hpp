@@ -102,17 +102,22 @@ struct RowWriter {
     if (chrom.size() > 4096) throw Error(MKP_E_UNSUPPORTED, "contig name longer than 4096 bytes");
     if (n_rows == 0) return;
     const unsigned n_thr = n_rows >= 65536 ? HostPool::host_cpus() : 1u;
-    std::vector<TextBuf> bufs(n_thr);
-    HostPool::get().parallel(n_thr, [&](size_t t) { fmt(n_rows * t / n_thr, n_rows * (t + 1) / n_thr, &bufs[t]); });
-    n += n_rows;
-    {
-      std::unique_lock<std::mutex> lk(mu);
-      if (!io_started) { io_started = true; io = std::thread([this] { io_loop(); }); }
-      cv.wait(lk, [&] { return pending.size() < 2 || io_failed; });
-      if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
-      pending.push_back(std::move(bufs));
+    // a large shard goes to the writer thread in pieces: the first piece is on its way to the file while the next is formatted
+    const uint64_t n_pieces = n_rows >= (1u << 20) ? 4 : 1;
+    for (uint64_t pc = 0; pc < n_pieces; pc++) {
+      const uint64_t p_lo = n_rows * pc / n_pieces, p_n = n_rows * (pc + 1) / n_pieces - p_lo;
+      std::vector<TextBuf> bufs(n_thr);
+      HostPool::get().parallel(n_thr, [&](size_t t) { fmt(p_lo + p_n * t / n_thr, p_lo + p_n * (t + 1) / n_thr, &bufs[t]); });
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!io_started) { io_started = true; io = std::thread([this] { io_loop(); }); }
+        cv.wait(lk, [&] { return pending.size() < 2 || io_failed; });
+        if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
+        pending.push_back(std::move(bufs));
+      }
+      cv.notify_all();
     }
-    cv.notify_all();
+    n += n_rows;
   }
   // waits for the writer thread; throws if any write came up short
   void finish() {
