@@ -892,6 +892,25 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
 }
 
 }   // extern "C"
+namespace {
+void adopt_layouts(mkp_ctx* c, DevShard* sh) {   // the shard's own layout ids -> the context's table (shared with the threshold sampler); once per shard
+  if (sh->layouts_adopted) return;
+  const std::vector<uint16_t> map = c->packer.adopt(sh->layouts);
+  for (auto* hv : {&sh->S.hdr, &sh->S.so_hdr}) for (auto& h : *hv) if (h.n_tags && !(h.flags & MKP_RF_BAD)) { if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range"); h.layout = map[h.layout]; }
+  sh->layouts_adopted = true;
+}
+}  // namespace
+int mkp_internal_sample_bind(mkp_ctx* c, DevShard* sh) {
+  if (!c || !sh) return MKP_E_INVALID;
+  return guarded(c, [&]() {
+    if (!sh->bound) adopt_layouts(c, sh);
+    std::swap(c->shard, sh->S);
+    std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref); std::swap(c->d_ranks, sh->d_ranks); std::swap(c->d_ml, sh->d_ml);
+    sh->bound = !sh->bound;
+    c->shard_open = sh->bound; c->resident = false; c->wplan.valid = false;
+    if (sh->bound) for (DevBuf* b : {&c->d_cigar, &c->d_chunk, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml}) b->ensure(16);
+  });
+}
 // Device ingest hand-over (mkp_ingest_host.cpp): the open shard takes the records the device packed.  Their big arrays are swapped into
 // the context's device buffers (what those held goes back with `sh`), the digest becomes the host shard, layout ids are mapped into the
 // context's table (shared with the threshold sampler).
@@ -902,8 +921,8 @@ int mkp_internal_shard_attach(mkp_ctx* c, DevShard* sh) {
     if (!c->partition_tags.empty()) throw Error(MKP_E_INVALID, "internal: device ingest does not read partition tags");
     if (!c->shard.hdr.empty()) throw Error(MKP_E_INVALID, "internal: the shard already holds host-packed records");
     auto t0 = std::chrono::steady_clock::now();
-    const std::vector<uint16_t> map = c->packer.adopt(sh->layouts);
-    for (auto* hv : {&sh->S.hdr, &sh->S.so_hdr}) for (auto& h : *hv) if (h.n_tags && !(h.flags & MKP_RF_BAD)) { if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range"); h.layout = map[h.layout]; }
+    if (sh->bound) throw Error(MKP_E_INVALID, "internal: the shard is still bound for sampling");
+    adopt_layouts(c, sh);
     const int32_t tid = c->shard.tid, ws = c->shard.win_start, we = c->shard.win_end;
     c->shard = std::move(sh->S); c->shard.tid = tid; c->shard.win_start = ws; c->shard.win_end = we; c->shard.dev_packed = true;
     std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref); std::swap(c->d_ranks, sh->d_ranks);

@@ -117,16 +117,26 @@ struct RecSet {
   }
 };
 
-void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf, const ShardHost* res = nullptr) {
+// `resident_of` (optional): the device-packed shard holding contig `tid`, bound to the context (mkp_internal_sample_bind) — the estimate then
+// samples from HBM; called whenever the schedule moves to another contig.
+using ResidentOf = std::function<const ShardHost*(uint32_t tid)>;
+void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf, const ResidentOf& resident_of = ResidentOf()) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
-  if (res && (!only_mapped || sharded)) throw Error(MKP_E_INVALID, "internal: resident sampling needs mapped-only, single-rank sampling");
+  const bool resident_mode = (bool)resident_of;
+  if (resident_mode && (!only_mapped || sharded)) throw Error(MKP_E_INVALID, "internal: resident sampling needs mapped-only, single-rank sampling");
+  const ShardHost* res = nullptr; uint32_t res_tid = 0xffffffffu;
   std::vector<int32_t> res_pmax;   // resident shard: prefix maximum of the alignment ends (first record that can reach an interval)
-  if (res) { res_pmax.resize(res->hdr.size()); int32_t m = INT32_MIN; for (size_t i = 0; i < res->hdr.size(); i++) { m = std::max(m, std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1)); res_pmax[i] = m; } }
+  auto use_contig = [&](uint32_t tid) {   // the shard of contig `tid` becomes the one sampled from
+    if (res && res_tid == tid) return;
+    res = resident_of(tid); res_tid = tid;
+    if (!res || (int32_t)tid != res->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
+    res_pmax.resize(res->hdr.size()); int32_t m = INT32_MIN; for (size_t i = 0; i < res->hdr.size(); i++) { m = std::max(m, std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1)); res_pmax[i] = m; }
+  };
   auto fetch_set = [&](uint32_t tid, uint32_t s, uint32_t e, size_t cap) {
     RecSet r;
-    if (res) {
-      if ((int32_t)tid != res->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the attached contig");
+    if (resident_mode) {
+      use_contig(tid);
       r.S = res;
       const size_t first = (size_t)(std::upper_bound(res_pmax.begin(), res_pmax.end(), (int32_t)std::min<uint32_t>(s, 0x7fffffffu)) - res_pmax.begin());
       for (size_t i = first; i < res->hdr.size() && (int64_t)res->hdr[i].ref_start < (int64_t)e; i++) if ((int64_t)std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1) > (int64_t)s) r.idx.push_back((uint32_t)i);
@@ -222,7 +232,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   auto sample_round = [&](const std::vector<std::pair<const RecSet*, size_t>>& which, uint32_t tid, bool mapped_contig, std::vector<uint32_t>* nv) {
     const uint32_t ws = 0, we = mapped_contig ? bam.ref_lens[tid] : 1; const uint8_t* mask = mapped_contig ? bedmask_for(tid) : nullptr;
     int rc;
-    if (res) { std::vector<uint32_t> ids; ids.reserve(which.size()); for (auto& w : which) ids.push_back(w.first->idx[w.second]);
+    if (resident_mode) { std::vector<uint32_t> ids; ids.reserve(which.size()); for (auto& w : which) ids.push_back(w.first->idx[w.second]);
       rc = mkp_internal_sample_resident(ctx, ws, we, mask, ids.data(), (uint32_t)ids.size(), only_mapped, nv); }
     else { std::vector<mkp_record> recs; recs.reserve(which.size()); for (auto& w : which) recs.push_back(w.first->b->view(w.first->b->recs[w.second]));
       rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mask, recs.data(), (uint32_t)recs.size(), only_mapped, nv); }
@@ -332,7 +342,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         size_t mj = mi + 1;
         if (!g0.q.all) while (mj < mine.size() && mj - mi < 8 && !grouped[mine[mj]].q.all && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;
         std::vector<std::future<std::unique_ptr<RecSet>>> futs;
-        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(res ? std::launch::deferred : std::launch::async, head_of, mine[k]));   // (resident: a scan of the digest, no fetch to overlap)
+        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(resident_mode ? std::launch::deferred : std::launch::async, head_of, mine[k]));   // (resident: a scan of the digest, no fetch to overlap)
         std::vector<Pending> pend(mj - mi);
         for (size_t k = mi; k < mj; k++) {
           Pending& P = pend[k - mi]; P.gi = mine[k];
@@ -546,6 +556,10 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (dev_ingest) { in.dev = mkp_internal_ingest_run(ctx->ingest, bam, tid, parts); return in; }   // foreground: the upload feeds the GPU's longest job of the run
     HostPool::background() = true; in.batch.reset(new BamBatch()); bam.fetch_parts(tid, parts, in.batch.get()); return in; };
   auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) { return fetch_windows(tid, {{s0, s1}}); };
+  // compressed bytes a set of fetch windows stands for (the index's 16 kb granularity: a short window costs at least its blocks)
+  auto win_bytes = [&](uint32_t tid, const std::vector<std::pair<uint32_t, uint32_t>>& wins) { uint64_t b = 0;
+    for (auto& w : wins) b += bam.offset_at(tid, (uint64_t)w.second + 16384) - bam.offset_at(tid, w.first > 16384 ? w.first - 16384 : 0) + (1u << 16);
+    return b; };
   // The first shard's blocks are read and inflated behind the threshold estimate (background priority on the host pool: the estimate's
   // own bursts go first), as soon as the first contig's grid is known.
   std::future<ShardInput> early_fetch; uint32_t early_s0 = 0, early_s1 = 0; bool early_set = false;
@@ -560,6 +574,51 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     }
   }
   struct JoinFetch { std::future<ShardInput>* f; ~JoinFetch() { if (f->valid()) f->wait(); } } join_fetch{&early_fetch};
+  // Several target contigs (or the BED records of several contigs), each fitting one shard: all of them are ingested AHEAD, one after the
+  // other on a worker thread, and stay packed in HBM (288 GB hold a 30x genome's packed reads) — the threshold estimate then samples from
+  // them (every contig's interval heads are scans of a digest, no second read of the file), and the pileup pass finds its shards already
+  // there.  Budget: the compressed bytes under the shards; beyond it the shards are fetched as the loop reaches them (host sampler).
+  struct Ahead { size_t rec0 = 0, rec1 = 0; uint32_t tid = 0, s0 = 0, s1 = 0; std::vector<std::pair<uint32_t, uint32_t>> wins; ShardInput in; bool ready = false; std::exception_ptr err; uint64_t bytes = 0; };
+  std::vector<Ahead> ahead; std::mutex amu; std::condition_variable acv; std::thread aworker; std::atomic<bool> astop{false};
+  struct JoinAhead { std::thread* t; std::atomic<bool>* stop; ~JoinAhead() { stop->store(true); if (t->joinable()) t->join(); } } join_ahead{&aworker, &astop};
+  // the fetch windows of a shard made of BED records [r0, r1) of one contig: the BED spans inside them (rows exist at BED positions only,
+  // so only records reaching a span matter), not the records, which run from one span to the next
+  auto bed_windows = [&](size_t r0, size_t r1) {
+    std::vector<std::pair<uint32_t, uint32_t>> w; const uint32_t tid = records[r0].tid; std::vector<Span> sp;
+    for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
+      for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, records[r0].start), hi = std::min<uint64_t>(x.e, records[r1 - 1].end()); if (lo < hi) sp.push_back({lo, hi}); } }
+    merge_spans(sp);
+    // keep what lies inside the records (sorted, disjoint): one sweep
+    { std::vector<Span> in; size_t r = r0;
+      for (auto& x : sp) { while (r < r1 && records[r].end() <= x.s) r++;
+        for (size_t q = r; q < r1 && records[q].start < x.e; q++) { const uint64_t lo = std::max<uint64_t>(x.s, records[q].start), hi = std::min<uint64_t>(x.e, records[q].end()); if (lo < hi) in.push_back({lo, hi}); } }
+      sp.swap(in); merge_spans(sp); } for (auto& x : sp) w.push_back({(uint32_t)x.s, (uint32_t)x.e});
+    return w;
+  };
+  if (dev_ingest && !early_whole && a.world == 1 && !records.empty() && !getenv("MKP_NO_EARLY_FETCH") && !getenv("MKP_NO_AHEAD")) {
+    uint64_t total = 0; bool fits = true;
+    for (size_t r0 = 0; r0 < records.size() && fits;) {
+      size_t r1 = r0 + 1; if (bf) while (r1 < records.size() && records[r1].tid == records[r0].tid) r1++;
+      Ahead A; A.rec0 = r0; A.rec1 = r1; A.tid = records[r0].tid; A.s0 = records[r0].start; A.s1 = records[r1 - 1].end();
+      if (bf) A.wins = bed_windows(r0, r1); else A.wins.push_back({A.s0, A.s1});
+      A.bytes = bf ? win_bytes(A.tid, A.wins) : bam.offset_at(A.tid, A.s1) - bam.offset_at(A.tid, A.s0);
+      if ((uint64_t)A.s1 - A.s0 > shard_bp || A.bytes > shard_bytes || (bf && r1 - r0 > 65536) || records[r0].length == 0 || A.wins.empty()) fits = false;
+      total += A.bytes; ahead.push_back(std::move(A)); r0 = r1;
+    }
+    if (!fits || total > (24ull << 30)) ahead.clear();
+    if (!ahead.empty()) aworker = std::thread([&]() {
+      for (size_t k = 0; k < ahead.size() && !astop.load(); k++) {
+        ShardInput in; std::exception_ptr err;
+        try { in = fetch_windows(ahead[k].tid, ahead[k].wins); } catch (...) { err = std::current_exception(); }
+        { std::lock_guard<std::mutex> g(amu); ahead[k].in = std::move(in); ahead[k].err = err; ahead[k].ready = true; }
+        acv.notify_all();
+        if (err) { std::lock_guard<std::mutex> g(amu); for (size_t j = k + 1; j < ahead.size(); j++) { ahead[j].err = err; ahead[j].ready = true; } acv.notify_all(); break; }
+      }
+      std::lock_guard<std::mutex> g(amu); for (auto& A : ahead) if (!A.ready) { A.err = std::make_exception_ptr(Error(MKP_E_INVALID, "internal: shard ingest cancelled")); A.ready = true; }
+      acv.notify_all();
+    });
+  }
+  auto ahead_wait = [&](size_t k) -> Ahead& { std::unique_lock<std::mutex> lk(amu); acv.wait(lk, [&] { return ahead[k].ready; }); if (ahead[k].err) std::rethrow_exception(ahead[k].err); return ahead[k]; };
   if (fasta_load.valid()) { fasta = fasta_load.get(); fb.fasta = &fasta; mark("reference FASTA loaded"); }
   std::future<void> early_walk;
   if (fb.has_focus() && a.world == 1 && !a.plan_only && a.filter_threshold.empty() && !a.no_filtering)
@@ -567,7 +626,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       auto t_focus = std::chrono::steady_clock::now();
       for (size_t ri = 0; ri < records.size(); ri++) {
         grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1;
-        if (ri == 0 && !early_whole && !bf && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {   // (--include-bed: the first shard is a merge of records, known only with the plan)
+        if (ri == 0 && !early_whole && !bf && ahead.empty() && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {   // (--include-bed: the first shard is a merge of records, known only with the plan)
           uint64_t bp; const size_t i1 = shard_cut(records[0], grid_of[0], 0, &bp);
           early_s0 = grid_of[0][0].start; early_s1 = grid_of[0][i1 - 1].end; early_set = true;
           early_fetch = std::async(std::launch::async, fetch_range, records[0].tid, early_s0, early_s1);
@@ -626,7 +685,28 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         }
       }
     }
-    sample_probabilities(ctx, bam, as, sr, bf, resident);
+    ResidentOf resident_of;
+    DevShard* bound = nullptr;   // multi-shard resident sampling: the shard currently swapped into the context
+    if (resident) resident_of = [&](uint32_t) { return resident; };
+    else if (!ahead.empty() && !have_sregion && !a.include_unmapped && !getenv("MKP_NO_RESIDENT_SAMPLING")) {
+      // every contig the schedule can visit must be among the shards ingested ahead
+      std::map<uint32_t, size_t> by_tid; for (size_t k = 0; k < ahead.size(); k++) by_tid[ahead[k].tid] = k;
+      bool covered = true; { const IdxStats stx = idxstats(bam, sr, bf); for (auto& kv : stx.mapped_by_tid) if (kv.second && !by_tid.count((uint32_t)kv.first)) covered = false; }
+      // (a region run: the one record is the region; a BED run: a contig's shard holds the records reaching its BED spans, which are the only ones that can yield a value)
+      if (covered) resident_of = [&, by_tid](uint32_t tid) -> const ShardHost* {
+        auto it = by_tid.find(tid); if (it == by_tid.end()) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
+        auto t_w = std::chrono::steady_clock::now();
+        Ahead& A = ahead_wait(it->second);
+        fetch_wait_early_ms += ms_since(t_w);
+        if (!A.in.dev) throw Error(MKP_E_INVALID, "internal: shard ingested ahead without device records");
+        if (bound != A.in.dev.get()) { if (bound) must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; must(mkp_internal_sample_bind(ctx, A.in.dev.get())); bound = A.in.dev.get(); }
+        return &ctx->shard;
+      };
+    }
+    struct Unbind { mkp_ctx* c; DevShard** b; ~Unbind() { if (*b) { (void)mkp_internal_sample_bind(c, *b); *b = nullptr; } } } unbind{ctx, &bound};
+    sample_probabilities(ctx, bam, as, sr, bf, resident_of);
+    if (bound) { must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; }
+    if (a.stats && resident_of && !resident) fprintf(stderr, "[mkpileup] threshold estimate sampled from %zu shards ingested ahead (resident)\n", ahead.size());
     mark("schedule walked, sample in HBM");
     if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n",
         g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms,
@@ -709,7 +789,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     for (auto& sp : plan) {
       const uint32_t tid = records[sp.rec].tid;
       const uint64_t sp_bytes = bam.indexed() ? bam.offset_at(tid, sp.s1) - bam.offset_at(tid, sp.s0) + (1u << 16) : 0;
-      const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1 && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp && bytes + sp_bytes <= shard_bytes &&
+      const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1 && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp && (bytes + sp_bytes <= shard_bytes || !ahead.empty() /* its spans were sized when it was ingested ahead */) &&
                         merged.back().parts.size() < 65536;
       if (!join) { ShardPlan m = sp; m.parts.assign(1, {sp.rec, sp.s0, sp.s1}); merged.push_back(std::move(m)); bytes = sp_bytes; continue; }
       ShardPlan& m = merged.back(); m.s1 = sp.s1; m.bp += sp.bp; m.iv_starts.insert(m.iv_starts.end(), sp.iv_starts.begin(), sp.iv_starts.end()); m.parts.push_back({sp.rec, sp.s0, sp.s1}); bytes += sp_bytes;
@@ -717,10 +797,24 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     for (auto& m : merged) if (m.parts.size() == 1) m.parts.clear();
     plan.swap(merged);
   }
-  auto fetch_shard = [&](const ShardPlan& sp) {
-    if (sp.parts.empty()) return fetch_range(records[sp.rec].tid, sp.s0, sp.s1);
-    std::vector<std::pair<uint32_t, uint32_t>> wins; for (auto& pt : sp.parts) wins.push_back({pt.s0, pt.s1});
-    return fetch_windows(records[sp.rec].tid, wins); };
+  // the fetch windows of a shard: its window — or, under --include-bed, the BED spans inside its pieces (rows exist at BED positions only;
+  // the records of optimize_reference_records run from one span to the next, most of what lies under them is never looked at)
+  auto plan_windows = [&](const ShardPlan& sp) {
+    std::vector<std::pair<uint32_t, uint32_t>> w;
+    if (!bf) { w.push_back({sp.s0, sp.s1}); return w; }
+    const uint32_t tid = records[sp.rec].tid; std::vector<Span> spn;
+    auto clip = [&](uint32_t a0, uint32_t a1) { for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
+        for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, a0), hi = std::min<uint64_t>(x.e, a1); if (lo < hi) spn.push_back({lo, hi}); } } };
+    if (sp.parts.empty()) clip(sp.s0, sp.s1); else for (auto& pt : sp.parts) clip(pt.s0, pt.s1);
+    merge_spans(spn); for (auto& x : spn) w.push_back({(uint32_t)x.s, (uint32_t)x.e});
+    if (w.empty()) w.push_back({sp.s0, sp.s0 + 1});   // (no BED position inside: nothing to fetch but an empty window)
+    return w;
+  };
+  auto fetch_shard = [&](const ShardPlan& sp) { return fetch_windows(records[sp.rec].tid, plan_windows(sp)); };
+  // shards that were ingested ahead: same contig, same hull, same windows
+  std::vector<long> plan_ahead(plan.size(), -1);
+  for (size_t pi = 0; pi < plan.size(); pi++) for (size_t k = 0; k < ahead.size(); k++)
+    if (ahead[k].tid == records[plan[pi].rec].tid && ahead[k].s0 == plan[pi].s0 && ahead[k].s1 == plan[pi].s1 && ahead[k].wins == plan_windows(plan[pi])) { plan_ahead[pi] = (long)k; break; }
   mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<ShardInput> next_batch;
@@ -729,16 +823,17 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (pre_attached) { fetch_wait_ms += fetch_wait_early_ms; }
   else if (early_match && early_in_ready) { fetch_wait_ms += fetch_wait_early_ms; next_batch = std::async(std::launch::deferred, [&]() { return std::move(early_in); }); }
   else if (early_match && early_fetch.valid()) next_batch = std::move(early_fetch);
-  else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty()) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }
+  else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty() && plan_ahead[0] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }
   for (size_t pi = 0; pi < plan.size(); pi++) {
     const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
     std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev;
     const bool attached_already = pre_attached && pi == 0;
     if (attached_already) dev = std::move(pre_dev);
+    else if (plan_ahead[pi] >= 0) { auto t_f = std::chrono::steady_clock::now(); Ahead& A = ahead_wait((size_t)plan_ahead[pi]); batch = std::move(A.in.batch); dev = std::move(A.in.dev); fetch_wait_ms += ms_since(t_f); }
     else { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev); fetch_wait_ms += ms_since(t_f); }
     if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack; ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
                ingest_records += dev->n_records; }
-    if (pi + 1 < plan.size()) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
+    if (pi + 1 < plan.size() && plan_ahead[pi + 1] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
     std::vector<uint8_t> merged_focus;   // a merged shard: its records' focus bytes at their places in the hull, zero in between
     if (hf) for (size_t k = 0; k < std::max<size_t>(sp.parts.size(), 1); k++) { const size_t ri = sp.parts.empty() ? sp.rec : sp.parts[k].rec;
       if (!focus_done[ri]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(records[ri], a.interval_size, &focus_of[ri]); focus_done[ri] = 1; focus_ms += ms_since(t_focus); } }

@@ -12,6 +12,7 @@ struct DevShard {
   Packer layouts;              // MM header structures of this shard, in order of first appearance
   DevBuf d_cigar, d_chunk, d_seq, d_tagref, d_ranks, d_ml;
   std::vector<MkpRecInfo> info_host;   // scratch of the layout interning
+  bool layouts_adopted = false, bound = false;   // layout ids already mapped into a context's table; currently swapped into a context for sampling
   uint64_t n_blocks = 0, n_segments = 0, n_records = 0, raw_bytes = 0, comp_bytes = 0;
   double ms_plan = 0, ms_upload = 0, ms_inflate = 0, ms_pack = 0, ms_digest = 0, ms_total = 0;
   DevShard() = default; DevShard(const DevShard&) = delete; DevShard& operator=(const DevShard&) = delete;
@@ -41,3 +42,7 @@ inline std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d,
 // (what the context held before stays in `sh` and goes back to the ingest object with mkp_internal_ingest_recycle)
 int mkp_internal_shard_attach(mkp_ctx* c, mkp::DevShard* sh);
 void mkp_internal_ingest_recycle(mkp_dev_ingest* d, mkp::DevShard* sh);
+// Resident sampling over several shards: swap `sh`'s digest and device arrays into the context (its layouts are mapped into the context's
+// table the first time) so that mkp_internal_sample_resident reads them; the same call again swaps them back out.  The shard stays owned
+// by `sh` and can be attached for its pileup later.
+int mkp_internal_sample_bind(mkp_ctx* c, mkp::DevShard* sh);
