@@ -178,11 +178,13 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
 // once a launch has tens of thousands of blocks — a whole file).  MKP_INFLATE_KERNEL=wave|thread forces one (A/B runs).
 }  // namespace
 extern "C" hipError_t mkp_launch_inflate2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one thread per block, second edition
+extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one wave per block, speculative symbol decode
 hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
   static const char* force = getenv("MKP_INFLATE_KERNEL");
   if (force && !strcmp(force, "wave")) return mkp_launch_inflate_wave(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread")) return mkp_launch_inflate(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
+  if (force && !strcmp(force, "wave2")) return mkp_launch_inflate_wave2(st, in, blks, n, out, status);
   return n >= 24576u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
 }
 namespace {
@@ -1409,7 +1411,8 @@ namespace {
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 nccl_allreduce_fn rccl_allreduce() {
   static nccl_allreduce_fn fn = []() -> nccl_allreduce_fn {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f; } }
+    const char* forced = getenv("MKP_RCCL_LIB");   // (the library the caller made its communicator with, when it is not the first on the search path)
+    for (const char* name : {forced ? forced : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f; } }
     return nullptr; }();
   return fn;
 }

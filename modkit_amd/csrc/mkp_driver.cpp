@@ -549,11 +549,11 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (dev_ingest && !ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
   double ingest_ms[5] = {0, 0, 0, 0, 0}; uint64_t ingest_blocks = 0, ingest_records = 0;
   // the records of a shard: those overlapping any of its windows (one window, or the BED spans of a merged shard), each +- the halo
-  auto fetch_windows = [&](uint32_t tid, const std::vector<std::pair<uint32_t, uint32_t>>& wins) {
+  auto fetch_windows = [&](uint32_t tid, const std::vector<std::pair<uint32_t, uint32_t>>& wins, mkp_dev_ingest* ing = nullptr) {
     ShardInput in; FetchParts parts;
     for (auto& w : wins) { const int64_t lo = w.first > MKP_HALO ? (int64_t)w.first - MKP_HALO : 0, hi = (int64_t)w.second + MKP_HALO;
       if (!parts.empty() && lo <= parts.back().second) parts.back().second = std::max(parts.back().second, hi); else parts.push_back({lo, hi}); }
-    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ctx->ingest, bam, tid, parts); return in; }   // foreground: the upload feeds the GPU's longest job of the run
+    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ing ? ing : ctx->ingest, bam, tid, parts); return in; }   // foreground: the upload feeds the GPU's longest job of the run
     HostPool::background() = true; in.batch.reset(new BamBatch()); bam.fetch_parts(tid, parts, in.batch.get()); return in; };
   auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) { return fetch_windows(tid, {{s0, s1}}); };
   // compressed bytes a set of fetch windows stands for (the index's 16 kb granularity: a short window costs at least its blocks)
@@ -579,8 +579,13 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // them (every contig's interval heads are scans of a digest, no second read of the file), and the pileup pass finds its shards already
   // there.  Budget: the compressed bytes under the shards; beyond it the shards are fetched as the loop reaches them (host sampler).
   struct Ahead { size_t rec0 = 0, rec1 = 0; uint32_t tid = 0, s0 = 0, s1 = 0; std::vector<std::pair<uint32_t, uint32_t>> wins; ShardInput in; bool ready = false; std::exception_ptr err; uint64_t bytes = 0; };
-  std::vector<Ahead> ahead; std::mutex amu; std::condition_variable acv; std::thread aworker; std::atomic<bool> astop{false};
-  struct JoinAhead { std::thread* t; std::atomic<bool>* stop; ~JoinAhead() { stop->store(true); if (t->joinable()) t->join(); } } join_ahead{&aworker, &astop};
+  // Several shards are in flight at once, each on an ingest object of its own (its streams, staging and scratch): one shard's inflate is a
+  // latency-bound launch that fills a fraction of the chip, and its host half (header walk, pread into staging) leaves the GPU idle —
+  // shards side by side fill both.
+  std::vector<Ahead> ahead; std::mutex amu; std::condition_variable acv; std::vector<std::thread> aworkers; std::atomic<bool> astop{false}; std::atomic<size_t> anext{0};
+  std::vector<mkp_dev_ingest*> aingest;
+  struct FreeIngest { std::vector<mkp_dev_ingest*>* v; ~FreeIngest() { for (auto* d : *v) mkp_internal_ingest_destroy(d); } } free_ingest{&aingest};
+  struct JoinAhead { std::vector<std::thread>* t; std::atomic<bool>* stop; ~JoinAhead() { stop->store(true); for (auto& x : *t) if (x.joinable()) x.join(); } } join_ahead{&aworkers, &astop};
   // the fetch windows of a shard made of BED records [r0, r1) of one contig: the BED spans inside them (rows exist at BED positions only,
   // so only records reaching a span matter), not the records, which run from one span to the next
   auto bed_windows = [&](size_t r0, size_t r1) {
@@ -606,17 +611,23 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       total += A.bytes; ahead.push_back(std::move(A)); r0 = r1;
     }
     if (!fits || total > (24ull << 30)) ahead.clear();
-    if (!ahead.empty()) aworker = std::thread([&]() {
-      for (size_t k = 0; k < ahead.size() && !astop.load(); k++) {
-        ShardInput in; std::exception_ptr err;
-        try { in = fetch_windows(ahead[k].tid, ahead[k].wins); } catch (...) { err = std::current_exception(); }
-        { std::lock_guard<std::mutex> g(amu); ahead[k].in = std::move(in); ahead[k].err = err; ahead[k].ready = true; }
-        acv.notify_all();
-        if (err) { std::lock_guard<std::mutex> g(amu); for (size_t j = k + 1; j < ahead.size(); j++) { ahead[j].err = err; ahead[j].ready = true; } acv.notify_all(); break; }
-      }
-      std::lock_guard<std::mutex> g(amu); for (auto& A : ahead) if (!A.ready) { A.err = std::make_exception_ptr(Error(MKP_E_INVALID, "internal: shard ingest cancelled")); A.ready = true; }
-      acv.notify_all();
-    });
+    if (!ahead.empty()) {
+      size_t nw = 4; if (const char* e = getenv("MKP_AHEAD_WORKERS")) nw = (size_t)std::max(1, atoi(e));
+      nw = std::min(nw, ahead.size());
+      for (size_t w = 1; w < nw; w++) { mkp_dev_ingest* d = mkp_internal_ingest_create(ctx->device); if (!d) break; aingest.push_back(d); }
+      nw = aingest.size() + 1;
+      for (size_t w = 0; w < nw; w++) aworkers.emplace_back([&, w]() {
+        mkp_dev_ingest* ing = w == 0 ? ctx->ingest : aingest[w - 1];
+        for (;;) {
+          const size_t k = anext.fetch_add(1); if (k >= ahead.size()) break;
+          ShardInput in; std::exception_ptr err;
+          if (astop.load()) err = std::make_exception_ptr(Error(MKP_E_INVALID, "internal: shard ingest cancelled"));
+          else try { in = fetch_windows(ahead[k].tid, ahead[k].wins, ing); } catch (...) { err = std::current_exception(); astop.store(true); }
+          { std::lock_guard<std::mutex> g(amu); ahead[k].in = std::move(in); ahead[k].err = err; ahead[k].ready = true; }
+          acv.notify_all();
+        }
+      });
+    }
   }
   auto ahead_wait = [&](size_t k) -> Ahead& { std::unique_lock<std::mutex> lk(amu); acv.wait(lk, [&] { return ahead[k].ready; }); if (ahead[k].err) std::rethrow_exception(ahead[k].err); return ahead[k]; };
   if (fasta_load.valid()) { fasta = fasta_load.get(); fb.fasta = &fasta; mark("reference FASTA loaded"); }
@@ -820,7 +831,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   std::future<ShardInput> next_batch;
   const bool early_match = early_set && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
   if (pre_attached && !(early_match && plan.size() == 1)) throw Error(MKP_E_INVALID, "internal: the shard attached for resident sampling is not the plan's");
-  if (pre_attached) { fetch_wait_ms += fetch_wait_early_ms; }
+  if (pre_attached || !ahead.empty()) { fetch_wait_ms += fetch_wait_early_ms; }   // (what the estimate waited for shards ingested ahead is load time too)
   else if (early_match && early_in_ready) { fetch_wait_ms += fetch_wait_early_ms; next_batch = std::async(std::launch::deferred, [&]() { return std::move(early_in); }); }
   else if (early_match && early_fetch.valid()) next_batch = std::move(early_fetch);
   else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty() && plan_ahead[0] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }

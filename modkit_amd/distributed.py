@@ -12,6 +12,7 @@ GPU box, "gloo" in the CPU tests).  The pileup path itself shards by reference w
   ordered concatenation of the rank outputs.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -60,7 +61,10 @@ class RcclComm:
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.lib = None
-        for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        names = ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so")
+        if os.environ.get("MKP_RCCL_LIB"):   # the same override mkp_histogram_allreduce reads
+            names = (os.environ["MKP_RCCL_LIB"],) + names
+        for name in names:
             try:
                 self.lib = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
                 break

@@ -1,0 +1,311 @@
+// CPU emulation of mkp_inflate_wave2 (modkit_amd/csrc/mkp_inflate_wave2.hip): the kernel's control flow restated over 64 emulated lanes,
+// with the per-lane code — the stream window and the token decode of mkp_inflate_tok.hpp — being the very functions the kernel compiles.
+// Test infrastructure: checks the algorithm (speculative decode + chain walk + deferred match stores + input window refills) against zlib
+// where no GPU is at hand.
+//   inflate_wave2_emul bgzf FILE...      every BGZF block of the files: output and acceptance must equal zlib's
+//   inflate_wave2_emul corpus FILE       records of [u32 in_len][u32 out_len][in bytes]: raw DEFLATE streams; acceptance (and output when
+//                                        accepted) must equal zlib's with the record's out_len as the expected size
+// Prints "ok <blocks> <bytes> <accepted> <rejected>"; exits 1 at the first difference.
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../modkit_amd/csrc/mkp_inflate_tok.hpp"
+
+namespace {
+constexpr uint32_t RING = 32768u, LIT_BITS = 11u, DIST_BITS = 9u;
+constexpr int W = 64;
+
+struct Lds {
+  uint8_t ring[RING];
+  uint16_t lit[1u << LIT_BITS], dist[1u << DIST_BITS];
+  uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
+  uint8_t lens[320];
+  uint32_t inw[256];
+};
+
+// mkp_inflate_wave_common.hpp: build()
+int build(const uint8_t* lens, int n, uint16_t* tab, uint32_t tab_bits, uint16_t* count, uint16_t* syms) {
+  for (int i = 0; i < 16; i++) count[i] = 0;
+  for (uint32_t i = 0; i < (1u << tab_bits); i++) tab[i] = 0;
+  for (int s = 0; s < n; s++) if (lens[s]) count[lens[s]]++;
+  uint32_t next_code[16], offs[16]; int left = 1; uint32_t code = 0, off = 0, used = 0;
+  next_code[0] = 0; offs[0] = 0;
+  for (int l = 1; l <= 15; l++) { const uint32_t c = count[l]; left = (left << 1) - (int)c; code = (code + (l > 1 ? count[l - 1] : 0u)) << 1; next_code[l] = code; offs[l] = off; off += c; used += c; }
+  if (left < 0) return left;
+  if (used == 0) return 0;
+  for (int s = 0; s < n; s++) {
+    const uint32_t l = lens[s]; if (!l) continue;
+    const uint32_t c = next_code[l]++, o = offs[l]++;
+    syms[o] = (uint16_t)s;
+    if (l <= tab_bits) {
+      uint32_t rev = 0; for (uint32_t k = 0; k < l; k++) if (c & (1u << k)) rev |= 1u << (l - 1 - k);
+      const uint16_t ent = (uint16_t)(l | ((uint32_t)s << 4));
+      for (uint32_t k = rev; k < (1u << tab_bits); k += 1u << l) tab[k] = ent;
+    }
+  }
+  return left;
+}
+uint32_t cl_order(int i) { static const uint8_t o[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15}; return o[i]; }
+
+struct In2 {
+  const uint8_t* p; uint32_t n, lo; uint32_t pf0[W], pf1[W]; uint32_t* w;
+  uint64_t refills = 0, seeks = 0;
+  uint32_t load_word(uint32_t off) const { uint32_t v = 0; for (uint32_t k = 0; k < 4u; k++) if (off + k < n) v |= (uint32_t)p[off + k] << (8u * k); return v; }
+  void seek(uint32_t byte) {
+    lo = byte & ~511u; seeks++;
+    for (uint32_t k = 0; k < 4u; k++) for (uint32_t lane = 0; lane < W; lane++) w[(((lo >> 2) + 64u * k) + lane) & 255u] = load_word(lo + 256u * k + 4u * lane);
+    for (uint32_t lane = 0; lane < W; lane++) { pf0[lane] = load_word(lo + 1024u + 4u * lane); pf1[lane] = load_word(lo + 1280u + 4u * lane); }
+  }
+  void ensure(uint32_t pos_bits) {
+    const uint32_t byte = pos_bits >> 3;
+    if (byte >= lo + 4096u) { seek(byte); return; }
+    while (byte >= lo + 512u) {
+      const uint32_t base = (lo >> 2) & 255u; refills++;
+      for (uint32_t lane = 0; lane < W; lane++) { w[base + lane] = pf0[lane]; w[base + 64u + lane] = pf1[lane]; }
+      lo += 512u;
+      for (uint32_t lane = 0; lane < W; lane++) { pf0[lane] = load_word(lo + 1024u + 4u * lane); pf1[lane] = load_word(lo + 1280u + 4u * lane); }
+    }
+  }
+  unsigned long long peek(uint32_t pos_bits) const {
+    // the window must hold what is read: bytes [4 * (q >> 5), + 12)
+    const uint32_t b0 = 4u * (pos_bits >> 5);
+    if (b0 < lo || b0 + 12u > lo + 1024u) { fprintf(stderr, "window miss: byte %u, window [%u, %u)\n", b0, lo, lo + 1024u); exit(3); }
+    return mkp_tok_window(w, pos_bits);
+  }
+};
+struct Hdr {
+  unsigned long long cb; uint32_t cpos;
+  void load(In2& in, uint32_t pos) { in.ensure(pos); cb = in.peek(pos); cpos = pos; }
+  uint32_t get(In2& in, uint32_t& pos, uint32_t k) { if (pos + k > cpos + 64u) load(in, pos); const uint32_t v = (uint32_t)(cb >> (pos - cpos)) & ((1u << k) - 1u); pos += k; return v; }
+  uint32_t peek16(In2& in, uint32_t pos) { if (pos + 16u > cpos + 64u) load(in, pos); return (uint32_t)(cb >> (pos - cpos)) & 0xffffu; }
+};
+int canon_sym(uint32_t bits, const uint16_t* count, const uint16_t* syms, uint32_t* l) {
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; len++) {
+    code |= (int)(bits & 1u); bits >>= 1;
+    const int c = (int)count[len];
+    if (code - c < first) { *l = (uint32_t)len; return (int)syms[index + (code - first)]; }
+    index += c; first += c; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+uint32_t slow_token(const In2& in, const Lds& L, uint32_t q, uint32_t* a, uint32_t* b) {
+  const unsigned long long bits = in.peek(q);
+  uint32_t e = L.lit[(uint32_t)bits & ((1u << LIT_BITS) - 1u)], l = e & 15u; int sym = (int)(e >> 4);
+  if (!l) { sym = canon_sym((uint32_t)bits, L.lcount, L.lsym, &l); if (sym < 0) return 4u; }
+  if (sym < 256) { *a = l | (MKP_TK_LIT << 6) | ((uint32_t)sym << 8); *b = 0; return 0u; }
+  if (sym == 256) { *a = l | (MKP_TK_EOB << 6); *b = 0; return 0u; }
+  const int ls = sym - 257;
+  if (ls >= 29) return 4u;
+  const uint32_t ex = len_extra(ls), len = len_base(ls) + ((uint32_t)(bits >> l) & ((1u << ex) - 1u));
+  uint32_t n = l + ex;
+  const uint32_t d = L.dist[(uint32_t)(bits >> n) & ((1u << DIST_BITS) - 1u)]; uint32_t dl = d & 15u; int ds = (int)(d >> 4);
+  if (!dl) { ds = canon_sym((uint32_t)(bits >> n), L.dcount, L.dsym, &dl); if (ds < 0) return 4u; }
+  if (ds >= 30) return 4u;
+  const uint32_t dx = dist_extra(ds);
+  *b = dist_base(ds) + ((uint32_t)(bits >> (n + dl)) & ((1u << dx) - 1u));
+  n += dl + dx;
+  *a = n | (MKP_TK_MATCH << 6) | (len << 8);
+  return 0u;
+}
+
+struct Stats { uint64_t passes = 0, tokens = 0, slow = 0, matches = 0, long_matches = 0, early_out = 0, refills = 0, seeks = 0; } g_stats;
+
+// the kernel, one block; returns the status, fills `out` (cap bytes)
+uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t cap) {
+  static Lds L;
+  In2 in; in.p = inp; in.n = in_len; in.w = L.inw; in.seek(0);
+  Hdr h; uint32_t pos = 0, w = 0, err = 0, flushed = 0;
+  const uint32_t in_bits = 8u * in_len;
+  uint32_t pv[W] = {0}, pa[W] = {0}, plen = 0, pw = 0;
+  auto pending_out = [&]() { if (plen) { for (uint32_t lane = 0; lane < W; lane++) if (lane < plen) L.ring[pa[lane]] = (uint8_t)pv[lane]; plen = 0; } };
+  auto flush = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) o[k] = L.ring[k & (RING - 1u)]; };
+  for (uint32_t guard = 0; guard <= in_len && !err; guard++) {
+    h.load(in, pos);
+    const uint32_t last = h.get(in, pos, 1), type = h.get(in, pos, 2);
+    if (type == 0) {
+      pos = (pos + 7u) & ~7u;
+      const uint32_t len = h.get(in, pos, 16), nlen = h.get(in, pos, 16);
+      if ((len ^ 0xffffu) != nlen || w + len > cap) { err = 2; break; }
+      const uint32_t at = pos >> 3;
+      if ((unsigned long long)at + len > in_len) { err = 1; break; }
+      pending_out(); flush(flushed, w);
+      for (uint32_t k = 0; k < len; k++) { const uint8_t v = inp[at + k]; o[w + k] = v; L.ring[(w + k) & (RING - 1u)] = v; }
+      w += len; flushed = w; pos = 8u * (at + len);
+    } else if (type == 1 || type == 2) {
+      int nlen_codes = 288, ndist_codes = 30;
+      if (type == 1) {
+        for (int s = 0; s < 288; s++) L.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+        for (int s = 0; s < 32; s++) L.lens[288 + s] = 5;
+        ndist_codes = 32;
+      } else {
+        const int nlen = (int)h.get(in, pos, 5) + 257, ndist = (int)h.get(in, pos, 5) + 1, ncode = (int)h.get(in, pos, 4) + 4;
+        if (nlen > 286 || ndist > 30) { err = 3; break; }
+        for (int k = 0; k < 19; k++) L.lens[k] = 0;
+        for (int idx = 0; idx < ncode; idx++) { const uint32_t v = h.get(in, pos, 3); L.lens[cl_order(idx)] = (uint8_t)v; }
+        if (build(L.lens, 19, L.dist, DIST_BITS, L.dcount, L.dsym) != 0) { err = 3; break; }
+        int idx = 0;
+        while (idx < nlen + ndist) {
+          const uint32_t e = L.dist[h.peek16(in, pos) & ((1u << DIST_BITS) - 1u)];
+          if (!(e & 15u)) { err = 4; break; }
+          pos += (e & 15u);
+          const int sym = (int)(e >> 4);
+          if (sym < 16) { L.lens[idx] = (uint8_t)sym; idx++; }
+          else {
+            int len = 0, rep;
+            if (sym == 16) { if (idx == 0) { err = 3; break; } len = L.lens[idx - 1]; rep = 3 + (int)h.get(in, pos, 2); }
+            else if (sym == 17) rep = 3 + (int)h.get(in, pos, 3);
+            else rep = 11 + (int)h.get(in, pos, 7);
+            if (idx + rep > nlen + ndist) { err = 3; break; }
+            for (int k = 0; k < rep; k++) L.lens[idx + k] = (uint8_t)len;
+            idx += rep;
+          }
+        }
+        if (err) break;
+        uint8_t mine[32]; for (int k = 0; k < 32; k++) mine[k] = k < ndist ? L.lens[nlen + k] : 0;
+        for (int k = 0; k < ndist; k++) L.lens[288 + k] = mine[k];
+        nlen_codes = nlen; ndist_codes = ndist;
+        if (L.lens[256] == 0u) { err = 3; break; }
+      }
+      {
+        const int e1 = build(L.lens, nlen_codes, L.lit, LIT_BITS, L.lcount, L.lsym);
+        if (e1 != 0) { err = 3; break; }
+        const int e2 = build(L.lens + 288, ndist_codes, L.dist, DIST_BITS, L.dcount, L.dsym);
+        uint32_t used2 = 0; for (int l = 1; l <= 15; l++) used2 += L.dcount[l];
+        if (e2 < 0 || (e2 > 0 && !(used2 == 1u && L.dcount[1] == 1u))) { err = 3; break; }
+      }
+      bool eob = false;
+      while (!eob && !err) {
+        if (pos > in_bits + 64u) { err = 1; break; }
+        in.ensure(pos);
+        MkpTok t[W];
+        for (uint32_t lane = 0; lane < W; lane++) t[lane] = mkp_tok_decode(in.peek(pos + lane), L.lit, L.dist);
+        g_stats.passes++;
+        uint32_t i = 0;
+        while (i < 64u) {
+          uint32_t a = t[i].a, b;
+          if (mkp_tok_kind(a) == MKP_TK_SLOW) { g_stats.slow++; err = slow_token(in, L, pos + i, &a, &b); if (err) break; }
+          else b = t[i].b;
+          i += mkp_tok_bits(a); g_stats.tokens++;
+          const uint32_t kind = mkp_tok_kind(a);
+          if (kind == MKP_TK_LIT) {
+            if (w >= cap) { err = 6; break; }
+            L.ring[w & (RING - 1u)] = (uint8_t)mkp_tok_val(a);
+            w++;
+          } else if (kind == MKP_TK_MATCH) {
+            const uint32_t len = mkp_tok_val(a), dist = b; g_stats.matches++;
+            if (dist > w) { err = 5; break; }
+            if (w + len > cap) { err = 6; break; }
+            const uint32_t src0 = w - dist, span = dist < len ? dist : len;
+            if (len <= 64u) {
+              if (plen && src0 < pw + plen && src0 + span > pw) { g_stats.early_out++; pending_out(); }
+              uint32_t v[W];
+              for (uint32_t k = 0; k < W; k++) { const uint32_t soff = dist >= len ? k : dist == 1u ? 0u : k % dist; v[k] = k < len ? L.ring[(src0 + soff) & (RING - 1u)] : 0; }
+              pending_out();
+              for (uint32_t k = 0; k < W; k++) { pv[k] = v[k]; pa[k] = (w + k) & (RING - 1u); }
+              plen = len; pw = w;
+            } else {
+              g_stats.long_matches++;
+              pending_out();
+              // lanes in steps of 64: all loads of a step before its stores
+              for (uint32_t k0 = 0; k0 < len; k0 += 64u) {
+                uint8_t v[W];
+                for (uint32_t k = k0; k < k0 + 64u && k < len; k++) v[k - k0] = dist >= len ? L.ring[(src0 + k) & (RING - 1u)] : dist == 1u ? L.ring[src0 & (RING - 1u)] : L.ring[(src0 + k % dist) & (RING - 1u)];
+                for (uint32_t k = k0; k < k0 + 64u && k < len; k++) L.ring[(w + k) & (RING - 1u)] = v[k - k0];
+              }
+              if (((w + len) & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = (w + len) & ~(RING / 2u - 1u); flush(flushed, upto); flushed = upto; }
+            }
+            w += len;
+          } else { eob = true; break; }
+        }
+        pos += i;
+        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); pending_out(); flush(flushed, upto); flushed = upto; }
+        if (w - flushed > RING) { fprintf(stderr, "ring overrun: %u bytes unflushed\n", w - flushed); exit(3); }
+      }
+    } else { err = 2; break; }
+    if (err || last) break;
+  }
+  pending_out(); flush(flushed, w);
+  if (!err && w != cap) err = 6;
+  if (!err && pos > in_bits) err = 1;
+  g_stats.refills += in.refills; g_stats.seeks += in.seeks;
+  return err;
+}
+
+// zlib on a raw DEFLATE stream that must produce exactly `cap` bytes and end inside the input: 0 accepted
+int zlib_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t cap) {
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, -15) != Z_OK) return -100;
+  std::vector<uint8_t> spill(16);
+  z.next_in = const_cast<uint8_t*>(inp); z.avail_in = in_len; z.next_out = o; z.avail_out = cap;
+  int rc = inflate(&z, Z_FINISH);
+  if (rc == Z_BUF_ERROR && z.avail_out == 0) {   // the expected size is full: a stream that goes on is a size mismatch
+    z.next_out = spill.data(); z.avail_out = (uInt)spill.size(); rc = inflate(&z, Z_FINISH);
+    if (rc == Z_STREAM_END && z.total_out == cap) { inflateEnd(&z); return 0; }
+    inflateEnd(&z); return 1;
+  }
+  const bool ok = rc == Z_STREAM_END && z.total_out == cap;
+  inflateEnd(&z);
+  return ok ? 0 : 1;
+}
+
+std::vector<uint8_t> slurp(const char* path) {
+  FILE* f = fopen(path, "rb"); if (!f) { perror(path); exit(2); }
+  std::vector<uint8_t> v; uint8_t buf[1 << 16]; size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + n);
+  fclose(f); return v;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: inflate_wave2_emul bgzf FILE... | corpus FILE\n"); return 2; }
+  const std::string mode = argv[1];
+  uint64_t blocks = 0, bytes = 0, accepted = 0, rejected = 0;
+  auto one = [&](const uint8_t* inp, uint32_t in_len, uint32_t cap, const char* what, uint64_t at) {
+    std::vector<uint8_t> a(cap + 64, 0xAA), b(cap + 64, 0xBB);
+    const uint32_t st = wave2_block(inp, in_len, a.data(), cap);
+    const int zr = zlib_block(inp, in_len, b.data(), cap);
+    if ((st == 0) != (zr == 0)) { fprintf(stderr, "%s @%llu: kernel status %u, zlib %s (in %u bytes, out %u)\n", what, (unsigned long long)at, st, zr == 0 ? "accepts" : "rejects", in_len, cap); exit(1); }
+    if (st == 0 && memcmp(a.data(), b.data(), cap) != 0) {
+      uint32_t k = 0; while (k < cap && a[k] == b[k]) k++;
+      fprintf(stderr, "%s @%llu: output differs at byte %u of %u\n", what, (unsigned long long)at, k, cap); exit(1);
+    }
+    blocks++; bytes += cap; if (st == 0) accepted++; else rejected++;
+  };
+  if (mode == "bgzf") {
+    for (int f = 2; f < argc; f++) {
+      const std::vector<uint8_t> d = slurp(argv[f]);
+      size_t off = 0;
+      while (off + 18 <= d.size()) {
+        if (d[off] != 0x1f || d[off + 1] != 0x8b) { fprintf(stderr, "%s: not BGZF at %zu\n", argv[f], off); return 2; }
+        const uint32_t xlen = d[off + 10] | (d[off + 11] << 8);
+        uint32_t bsize = 0; for (uint32_t x = 0; x + 4 <= xlen;) { const uint8_t* e = &d[off + 12 + x]; const uint32_t sl = e[2] | (e[3] << 8); if (e[0] == 'B' && e[1] == 'C') bsize = (e[4] | (e[5] << 8)) + 1u; x += 4 + sl; }
+        if (!bsize || off + bsize > d.size()) { fprintf(stderr, "%s: bad block at %zu\n", argv[f], off); return 2; }
+        const uint32_t hdr = 12 + xlen, clen = bsize - hdr - 8;
+        uint32_t isize; memcpy(&isize, &d[off + bsize - 4], 4);
+        one(&d[off + hdr], clen, isize, argv[f], off);
+        off += bsize;
+      }
+    }
+  } else if (mode == "corpus") {
+    const std::vector<uint8_t> d = slurp(argv[2]);
+    size_t off = 0; uint64_t rec = 0;
+    while (off + 8 <= d.size()) {
+      uint32_t in_len, out_len; memcpy(&in_len, &d[off], 4); memcpy(&out_len, &d[off + 4], 4); off += 8;
+      if (off + in_len > d.size()) { fprintf(stderr, "corpus truncated\n"); return 2; }
+      one(&d[off], in_len, out_len, "record", rec++);
+      off += in_len;
+    }
+  } else return 2;
+  printf("ok %llu %llu %llu %llu\n", (unsigned long long)blocks, (unsigned long long)bytes, (unsigned long long)accepted, (unsigned long long)rejected);
+  fprintf(stderr, "passes %llu tokens %llu (%.2f per pass) matches %llu long %llu early-out %llu slow %llu refills %llu seeks %llu\n", (unsigned long long)g_stats.passes, (unsigned long long)g_stats.tokens,
+          g_stats.passes ? (double)g_stats.tokens / (double)g_stats.passes : 0.0, (unsigned long long)g_stats.matches, (unsigned long long)g_stats.long_matches, (unsigned long long)g_stats.early_out,
+          (unsigned long long)g_stats.slow, (unsigned long long)g_stats.refills, (unsigned long long)g_stats.seeks);
+  return 0;
+}

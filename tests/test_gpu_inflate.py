@@ -71,21 +71,65 @@ def test_device_inflate_on_the_fetch_path(tmp_path):
     assert outs[0][1] == 0 and outs[1][1] > 0.5 * outs[1][2] and outs[1][1] > 32 << 20   # (the threshold sampler's 2 MiB heads stay on the host)
 
 
-def test_both_device_kernels(tmp_path):
-    """mkp_bgzf_inflate picks its kernel by launch size (one wave per block below 24 576 blocks, one thread per block above); all three
-    (wave, thread, thread2 = the second edition of the per-thread decoder) are forced here through MKP_INFLATE_KERNEL in fresh processes
-    (the variable is read once) and checked against gzip."""
+def bgzf_block(payload: bytes, isize: int, crc: int) -> bytes:
+    import struct
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(payload) + 25) + payload + struct.pack("<II", crc & 0xffffffff, isize))
+
+
+KERNEL_SCRIPT = """
+import glob, gzip, os, pickle, sys, zlib
+sys.path.insert(0, %r)
+import modkit_amd
+from test_gpu_inflate import bgzf_block
+c = modkit_amd.Context()
+n = 0
+for b in sorted(glob.glob(os.path.join(%r, '*.bam'))):
+    d = open(b, 'rb').read(); got, _ = c.bgzf_inflate(d); assert got == gzip.decompress(d), b; n += 1
+recs = pickle.load(open(%r, 'rb'))
+good, want, bad = [], [], 0
+for z, size in recs:
+    if len(z) + 26 > 65536 or size > 65536:
+        continue
+    try:
+        w = zlib.decompress(z, -15)
+        if len(w) != size:
+            w = None
+    except zlib.error:
+        w = None
+    if w is not None:
+        good.append(bgzf_block(z, size, zlib.crc32(w))); want.append(w)
+    else:   # what zlib refuses (as a stream of this size) must be refused here, whatever the CRC field says
+        try:
+            c.bgzf_inflate(bgzf_block(z, size, 0))
+        except modkit_amd.MkpError:
+            bad += 1
+        else:
+            raise AssertionError('accepted a stream zlib refuses: %%d bytes -> %%d' %% (len(z), size))
+got, _ = c.bgzf_inflate(b''.join(good))
+assert got == b''.join(want)
+for k in (0, len(good) // 2, len(good) - 1):   # and one at a time
+    assert c.bgzf_inflate(good[k])[0] == want[k]
+c.close(); print('ok', n, len(good), bad)
+"""
+
+
+def test_all_device_kernels(tmp_path):
+    """mkp_bgzf_inflate picks its kernel by launch size; all four — wave, thread, thread2 (the second edition of the per-thread decoder),
+    wave2 (one wave per block, speculative symbol decode) — are forced here through MKP_INFLATE_KERNEL in fresh processes (the variable
+    is read once) and checked against gzip on the reference's BAMs and against zlib on the DEFLATE corpus of
+    tests/test_inflate_wave2_emul.py: every block type, level and strategy, multi-block streams, long stored blocks, and ~500 corrupted
+    or random streams whose acceptance must be zlib's."""
+    import pickle
     import subprocess
     import sys
-    script = (
-        "import glob, gzip, os, sys\n"
-        "sys.path.insert(0, %r)\n"
-        "import modkit_amd\n"
-        "c = modkit_amd.Context()\n"
-        "n = 0\n"
-        "for b in sorted(glob.glob(os.path.join(%r, '*.bam'))):\n"
-        "    d = open(b, 'rb').read(); got, _ = c.bgzf_inflate(d); assert got == gzip.decompress(d), b; n += 1\n"
-        "c.close(); print('ok', n)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), FIX)
-    for kernel in ("wave", "thread", "thread2"):
-        p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, MKP_INFLATE_KERNEL=kernel))
-        assert p.returncode == 0 and p.stdout.startswith("ok"), (kernel, p.stderr[-400:])
+    from test_inflate_wave2_emul import deflate_corpus
+    recs = deflate_corpus()
+    pk = str(tmp_path / "corpus.pkl")
+    pickle.dump(recs, open(pk, "wb"))
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = KERNEL_SCRIPT % (os.path.dirname(here), FIX, pk)
+    for kernel in ("wave2", "wave", "thread", "thread2"):
+        p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, MKP_INFLATE_KERNEL=kernel, PYTHONPATH=here + os.pathsep + os.environ.get("PYTHONPATH", "")))
+        assert p.returncode == 0 and p.stdout.startswith("ok"), (kernel, p.stdout[-200:], p.stderr[-600:])
+        n, good, bad = map(int, p.stdout.split()[1:4])
+        assert n >= 8 and good > 700 and bad > 200, (kernel, p.stdout)

@@ -13,6 +13,11 @@ else:
         subprocess.check_call([os.path.join(ROOT, "tools", "gen_modbam"), "--out", "/tmp/inflate_c3", "--contig", "chr20:64444167", "--reads", "193000", "--seed", "20", "--style", "hm",
                                "--cpg-depleted", "--mean-len", "8353", "--threads", str(os.cpu_count() or 8)], stdout=subprocess.DEVNULL)
 data = open(bam, "rb").read()
+if os.environ.get("INFLATE_BLOCKS"):   # the first N blocks only (launch-size sweeps)
+    o, k = 0, 0
+    while o < len(data) and k < int(os.environ["INFLATE_BLOCKS"]):
+        o += int.from_bytes(data[o + 16:o + 18], "little") + 1; k += 1
+    data = data[:o]
 ctx = modkit_amd.Context()
 res = []
 for rep in range(3):
