@@ -173,9 +173,10 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
       "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
 }
 
-// BGZF inflate on the device.  Two kernels: one wave per block (mkp_inflate_wave.hip: ~4 ms per block, 1 024 at a time — a shard
-// window of 5 000 blocks in 26 ms) and one thread per block (mkp_inflate.hip: ~100 ms per launch whatever its size, but 2.4x the throughput
-// once a launch has tens of thousands of blocks — a whole file).  MKP_INFLATE_KERNEL=wave|thread forces one (A/B runs).
+// BGZF inflate on the device.  One wave per block with speculative token decode (mkp_inflate_wave2.hip: 3.2 ms per block, 1 024 at a
+// time — 16 000 blocks in 52 ms, 4 000 in 14 ms) for shard-sized launches, one thread per block (mkp_inflate.hip, second edition: ~80 ms
+// per launch whatever its size, 89 ms for a whole file of 54 000 blocks) from 28 000 blocks up.  MKP_INFLATE_KERNEL=wave2|thread2|wave|thread
+// forces one (A/B runs; --stats names it).
 }  // namespace
 extern "C" hipError_t mkp_launch_inflate2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one thread per block, second edition
 extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one wave per block, speculative symbol decode
@@ -185,7 +186,7 @@ hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void
   if (force && !strcmp(force, "thread")) return mkp_launch_inflate(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
   if (force && !strcmp(force, "wave2")) return mkp_launch_inflate_wave2(st, in, blks, n, out, status);
-  return n >= 24576u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave(st, in, blks, n, out, status);
+  return n >= 28000u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave2(st, in, blks, n, out, status);
 }
 namespace {
 hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }

@@ -9,17 +9,20 @@
 
 namespace mkp {
 
+inline double& mkp_tl_alloc_ms() { static thread_local double v = 0; return v; }   // what this thread spent in hipMalloc / hipFree (traces)
 struct DevBuf {
   void* p = nullptr; size_t cap = 0;
+  struct Clock { std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now(); ~Clock() { mkp_tl_alloc_ms() += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); } };
   void ensure(size_t bytes) {
     if (bytes <= cap) return;
+    Clock clk;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     size_t want = bytes + bytes / 8 + 256;
     if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; throw Error(MKP_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed"); }
     cap = want;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) { Clock clk; (void)hipFree(p); } p = nullptr; cap = 0; }
   template <class T> T* as() const { return (T*)p; }
 };
 

@@ -17,12 +17,14 @@ MKP_TOK_HD uint32_t len_base(int ls) { return ls < 8 ? 3u + (uint32_t)ls : ls ==
 MKP_TOK_HD uint32_t dist_extra(int ds) { return ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u; }
 MKP_TOK_HD uint32_t dist_base(int ds) { return ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << ((uint32_t)(ds >> 1) - 1u)); }
 
-// a token: `a` = [0:5] bits it takes (1..48), [6:7] kind, [8:16] match length | [8:15] literal byte; `b` = match distance
-enum : uint32_t { MKP_TK_LIT = 0u, MKP_TK_MATCH = 1u, MKP_TK_EOB = 2u, MKP_TK_SLOW = 3u };   // SLOW: not decodable from the direct tables (a longer code, or no valid code): the walk decodes it on its own if the chain gets there
+// What a lane reports for its bit position: `a` = [0:5] bits the token takes, [6] WIN: a token the output window takes as it is — a
+// literal, or a match no longer than a window (64 bytes) that does not overlap itself (dist >= len) — [7] LIT, [8:16] output bytes
+// (1 | match length); `b` = the window entry of a literal (MKP_SV_LITERAL | byte) | the distance of a match.  Everything else — end of
+// block, codes longer than the direct tables, long or self-overlapping matches, invalid codes — has WIN clear: the walk stops there and
+// decodes that one token on its own.
+enum : uint32_t { MKP_TA_WIN = 64u, MKP_TA_LIT = 128u, MKP_SV_LITERAL = 0x80000000u };
+enum : uint32_t { MKP_TK_LIT = 0u, MKP_TK_MATCH = 1u, MKP_TK_EOB = 2u };
 struct MkpTok { uint32_t a, b; };
-MKP_TOK_HD uint32_t mkp_tok_bits(uint32_t a) { return a & 63u; }
-MKP_TOK_HD uint32_t mkp_tok_kind(uint32_t a) { return (a >> 6) & 3u; }
-MKP_TOK_HD uint32_t mkp_tok_val(uint32_t a) { return a >> 8; }
 
 // 64 stream bits starting at bit `q` of the block input, from the 1 KiB circular LDS window (256 dwords; dword i holds input bytes
 // [4i, 4i + 4) mod 1024).  Reads 12 bytes from byte 4 * (q >> 5) on.
@@ -36,22 +38,22 @@ MKP_TOK_HD unsigned long long mkp_tok_window(const uint32_t* inw, uint32_t q) {
 
 // lit: 2^11 entries, [0:3] code length (0: none this short), [4:12] symbol; dist: 2^9 entries, [0:3] code length, [4:8] symbol
 MKP_TOK_HD MkpTok mkp_tok_decode(unsigned long long bits, const uint16_t* lit, const uint16_t* dist) {
-  MkpTok t; t.b = 0;
+  MkpTok t; t.a = 0; t.b = 0;
   const uint32_t e = lit[(uint32_t)bits & 2047u], l = e & 15u, sym = e >> 4;
-  if (!l) { t.a = MKP_TK_SLOW << 6; return t; }
-  if (sym < 256u) { t.a = l | (MKP_TK_LIT << 6) | (sym << 8); return t; }
-  if (sym == 256u) { t.a = l | (MKP_TK_EOB << 6); return t; }
+  if (!l || sym == 256u) return t;
+  if (sym < 256u) { t.a = l | MKP_TA_WIN | MKP_TA_LIT | (1u << 8); t.b = MKP_SV_LITERAL | sym; return t; }
   const int ls = (int)sym - 257;
-  if (ls >= 29) { t.a = MKP_TK_SLOW << 6; return t; }   // 286 / 287: the walk reports it
+  if (ls >= 29) return t;
   const uint32_t ex = len_extra(ls);
   const uint32_t len = len_base(ls) + ((uint32_t)(bits >> l) & ((1u << ex) - 1u));
   uint32_t n = l + ex;
   const uint32_t d = dist[(uint32_t)(bits >> n) & 511u], dl = d & 15u; const int ds = (int)(d >> 4);
-  if (!dl || ds >= 30) { t.a = MKP_TK_SLOW << 6; return t; }
+  if (!dl || ds >= 30) return t;
   const uint32_t dx = dist_extra(ds);
   t.b = dist_base(ds) + ((uint32_t)(bits >> (n + dl)) & ((1u << dx) - 1u));
   n += dl + dx;   // <= 11 + 5 + 9 + 13 = 38
-  t.a = n | (MKP_TK_MATCH << 6) | (len << 8);
+  if (len > 64u || t.b < len) return t;
+  t.a = n | MKP_TA_WIN | (len << 8);
   return t;
 }
 }  // namespace

@@ -4,12 +4,15 @@
 // ~440 cycles of dependent latency per symbol with 63 lanes watching.  Here the lanes decode AHEAD of the chain: lane k decodes the
 // token (literal | length + distance | end of block) that starts at bit `pos + k` as if one started there — two LDS table probes per
 // lane, all 64 at once (mkp_inflate_tok.hpp) — and a scalar walk then follows the real chain 0 -> n(0) -> n(0) + n(n(0)) -> ...
-// through the 64 answers with v_readlane, ~6 tokens per pass on BAM data (10 bits per token).  The walk does the output:
-//   * a literal is one LDS byte store by lane 0;
-//   * a match is one step of the whole wave (lane k copies byte k; overlapping matches through k mod dist) — and its LDS store is
-//     DEFERRED until the next match's load has been issued, so the load -> store latency of one match hides behind the next (LDS
-//     executes a wave's instructions in order; a match that reads what the pending store writes flushes it first);
-//   * codes longer than the direct tables, and everything invalid, are re-decoded by the walk itself if the chain gets there.
+// through the 64 answers with v_readlane, ~6 tokens per pass on BAM data (10 bits per token).  A wave alone on its SIMD pays ~10
+// cycles per instruction whatever it is (SQ counters: 1.0 M instructions = 10 M cycles per block for the first version of this walk), so
+// the walk is kept to one exit and a few dozen instructions per token:
+//   * output bytes are not written token by token: lane j of a 64-byte OUTPUT WINDOW notes where byte j comes from — a literal value,
+//     or a ring position for a match byte — with a handful of VALU per token, and the window goes out in one LDS load + one LDS store
+//     when it is full (or when a match needs bytes that are still in it).  No LDS round trip sits on the per-token path;
+//   * the lanes pre-digest their tokens (output length, literal already in window form, "the window can take this" flag); anything
+//     else — end of block, codes longer than the direct tables, matches that overlap themselves or are longer than a window, anything
+//     invalid or out of bounds — ends the pass, is decoded by the wave as one token (one_token) and handled the plain way.
 // The compressed bytes reach the lanes through a 1 KiB circular LDS window (512 bytes ahead in registers, loaded a refill early);
 // the output ring, the tables and the table builder are mkp_inflate_wave's.  LDS 39.0 KiB per wave: four waves per CU.
 #include <hip/hip_runtime.h>
@@ -91,25 +94,28 @@ __device__ __forceinline__ int canon_sym(uint32_t bits, const uint16_t* count, c
   return -1;
 }
 
-// the token at bit q, decoded by the wave as one (uniform): 0 or the error status
-__device__ __forceinline__ uint32_t slow_token(const In2& in, const Wave2Lds& L, uint32_t q, uint32_t* a, uint32_t* b) {
+// the token at bit q, decoded by the wave as one (uniform; any code length): err = 0 or the status to report
+struct OneTok { uint32_t err, bits, kind, val, dist; };   // kind MKP_TK_*; val = literal byte | match length
+__device__ __forceinline__ OneTok one_token(const In2& in, const Wave2Lds& L, uint32_t q) {
+  OneTok r; r.err = 0; r.bits = 0; r.kind = MKP_TK_EOB; r.val = 0; r.dist = 0;
   const unsigned long long bits = in.peek(q);
   uint32_t e = sgpr(L.lit[(uint32_t)bits & ((1u << LIT_BITS) - 1u)]), l = e & 15u; int sym = (int)(e >> 4);
-  if (!l) { sym = canon_sym((uint32_t)bits, L.lcount, L.lsym, &l); if (sym < 0) return 4u; }
-  if (sym < 256) { *a = l | (MKP_TK_LIT << 6) | ((uint32_t)sym << 8); *b = 0; return 0u; }
-  if (sym == 256) { *a = l | (MKP_TK_EOB << 6); *b = 0; return 0u; }
+  if (!l) { sym = canon_sym((uint32_t)bits, L.lcount, L.lsym, &l); if (sym < 0) { r.err = 4u; return r; } }
+  r.bits = l;
+  if (sym < 256) { r.kind = MKP_TK_LIT; r.val = (uint32_t)sym; return r; }
+  if (sym == 256) return r;
   const int ls = sym - 257;
-  if (ls >= 29) return 4u;
-  const uint32_t ex = len_extra(ls), len = len_base(ls) + ((uint32_t)(bits >> l) & ((1u << ex) - 1u));
+  if (ls >= 29) { r.err = 4u; return r; }
+  const uint32_t ex = len_extra(ls);
+  r.kind = MKP_TK_MATCH; r.val = len_base(ls) + ((uint32_t)(bits >> l) & ((1u << ex) - 1u));
   uint32_t n = l + ex;
   const uint32_t d = sgpr(L.dist[(uint32_t)(bits >> n) & ((1u << DIST_BITS) - 1u)]); uint32_t dl = d & 15u; int ds = (int)(d >> 4);
-  if (!dl) { ds = canon_sym((uint32_t)(bits >> n), L.dcount, L.dsym, &dl); if (ds < 0) return 4u; }
-  if (ds >= 30) return 4u;
+  if (!dl) { ds = canon_sym((uint32_t)(bits >> n), L.dcount, L.dsym, &dl); if (ds < 0) { r.err = 4u; return r; } }
+  if (ds >= 30) { r.err = 4u; return r; }
   const uint32_t dx = dist_extra(ds);
-  *b = dist_base(ds) + ((uint32_t)(bits >> (n + dl)) & ((1u << dx) - 1u));
-  n += dl + dx;   // <= 15 + 5 + 15 + 13 = 48
-  *a = n | (MKP_TK_MATCH << 6) | (len << 8);
-  return 0u;
+  r.dist = dist_base(ds) + ((uint32_t)(bits >> (n + dl)) & ((1u << dx) - 1u));
+  r.bits = n + dl + dx;   // <= 15 + 5 + 15 + 13 = 48
+  return r;
 }
 }  // namespace
 
@@ -127,9 +133,10 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
   Hdr h;
   uint32_t pos = 0;                       // bit position in the block input (uniform)
   uint32_t w = 0, err = 0, flushed = 0;   // uniform; output bytes [flushed, w) are in the ring only
-  // the deferred store of the last match: lane k owes ring[pa] = pv when k < plen
-  uint32_t pv = 0, pa = 0, plen = 0, pw = 0;
-#define PENDING_OUT() do { if (plen) { if ((uint32_t)lane < plen) L.ring[pa] = (uint8_t)pv; plen = 0; } } while (0)
+  // the output window: lane j < fill owes ring[(w - fill + j) & M] its byte — sv = LITERAL | value, or the ring position it is copied from
+  constexpr uint32_t LITERAL = MKP_SV_LITERAL, M = RING - 1u;
+  uint32_t sv = 0, fill = 0;
+#define WINDOW_OUT() do { if (fill) { const uint32_t r_ = L.ring[sv & M]; if ((uint32_t)lane < fill) L.ring[(w - fill + (uint32_t)lane) & M] = (uint8_t)((sv & LITERAL) ? sv : r_); fill = 0; } } while (0)
   for (uint32_t guard = 0; guard <= bk.in_len && !err; guard++) {
     h.load(in, pos, lane);
     const uint32_t last = h.get(in, pos, 1, lane), type = h.get(in, pos, 2, lane);
@@ -139,7 +146,7 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
       if ((len ^ 0xffffu) != nlen || w + len > cap) { err = 2; break; }
       const uint32_t at = pos >> 3;
       if ((unsigned long long)at + len > bk.in_len) { err = 1; break; }
-      PENDING_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, w, lane);
+      WINDOW_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, w, lane);
       for (uint32_t k = (uint32_t)lane; k < len; k += 64u) { const uint8_t v = in.p[at + k]; o[w + k] = v; L.ring[(w + k) & (RING - 1u)] = v; }
       w += len; flushed = w; pos = 8u * (at + len);
     } else if (type == 1 || type == 2) {
@@ -200,58 +207,59 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
         if (pos > in_bits + 64u) { err = 1; break; }   // ran off the input (zeros follow it in the window)
         in.ensure(pos, lane);
         const MkpTok t = mkp_tok_decode(mkp_tok_window(L.inw, pos + (uint32_t)lane), L.lit, L.dist);
-        uint32_t i = 0;
-        while (i < 64u) {
-          uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)t.a, (int)i), b;
-          if (mkp_tok_kind(a) == MKP_TK_SLOW) { err = slow_token(in, L, pos + i, &a, &b); if (err) break; }
-          else b = (uint32_t)__builtin_amdgcn_readlane((int)t.b, (int)i);
-          i += mkp_tok_bits(a);
-          const uint32_t kind = mkp_tok_kind(a);
-          if (kind == MKP_TK_LIT) {
+        uint32_t i = 0; bool special = false;
+        do {
+          const uint32_t f0 = sgpr(fill);   // (uniform by construction; said so, the walk's arithmetic stays scalar)
+          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)t.a, (int)i), b = (uint32_t)__builtin_amdgcn_readlane((int)t.b, (int)i);
+          const uint32_t ol = a >> 8; const bool lit = (a & MKP_TA_LIT) != 0u;
+          if (!((a & MKP_TA_WIN) && w + ol <= cap && (lit || b <= w))) { special = true; break; }
+          const bool out = f0 + ol > 64u || (!lit && b < f0 + ol);   // no room — or the match reads bytes that are still in the window (f0 > 0 either way)
+          if (out) { const uint32_t r_ = L.ring[sv & M]; if ((uint32_t)lane < f0) L.ring[(w - f0 + (uint32_t)lane) & M] = (uint8_t)((sv & LITERAL) ? sv : r_); }
+          const uint32_t f1 = out ? 0u : f0;
+          const uint32_t rel = (uint32_t)lane - f1;
+          const uint32_t nsv = lit ? b : ((w - b + rel) & M);
+          if (rel < ol) sv = nsv;
+          fill = f1 + ol; w += ol; i += a & 63u;
+        } while (i < 64u);
+        pos += i;
+        if (special) {   // the token at pos, on its own
+          const OneTok k = one_token(in, L, pos);
+          if (k.err) { err = k.err; break; }
+          pos += k.bits;
+          if (k.kind == MKP_TK_EOB) eob = true;
+          else if (k.kind == MKP_TK_LIT) {
             if (w >= cap) { err = 6; break; }
-            if (lane == 0) L.ring[w & (RING - 1u)] = (uint8_t)mkp_tok_val(a);
-            w++;
-          } else if (kind == MKP_TK_MATCH) {
-            const uint32_t len = mkp_tok_val(a), dist = b;
+            if (fill == 64u) WINDOW_OUT();
+            if ((uint32_t)lane == fill) sv = MKP_SV_LITERAL | k.val;
+            fill++; w++;
+          } else {
+            const uint32_t len = k.val, dist = k.dist;
             if (dist > w) { err = 5; break; }
             if (w + len > cap) { err = 6; break; }
-            const uint32_t src0 = w - dist, span = dist < len ? dist : len;   // the bytes read: [src0, src0 + span), all written before this match
-            if (len <= 64u) {
-              if (plen && src0 < pw + plen && src0 + span > pw) PENDING_OUT();   // it reads what the pending store writes
-              const uint32_t k = (uint32_t)lane;
-              const uint32_t soff = dist >= len ? k : dist == 1u ? 0u : k % dist;
-              uint32_t v = 0;
-              if (k < len) v = L.ring[(src0 + soff) & (RING - 1u)];
-              PENDING_OUT();   // the previous match's store goes out behind this match's load
-              pv = v; pa = (w + k) & (RING - 1u); plen = len; pw = w;
+            const uint32_t src0 = w - dist;
+            WINDOW_OUT();
+            if (dist >= len) {
+              for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) L.ring[(w + k2) & M] = L.ring[(src0 + k2) & M];
+            } else if (dist == 1u) {
+              const uint8_t v = L.ring[src0 & M];
+              for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) L.ring[(w + k2) & M] = v;
             } else {
-              PENDING_OUT();
-              if (dist >= len) {
-                for (uint32_t k = (uint32_t)lane; k < len; k += 64u) L.ring[(w + k) & (RING - 1u)] = L.ring[(src0 + k) & (RING - 1u)];
-              } else if (dist == 1u) {
-                const uint8_t v = L.ring[src0 & (RING - 1u)];
-                for (uint32_t k = (uint32_t)lane; k < len; k += 64u) L.ring[(w + k) & (RING - 1u)] = v;
-              } else {
-                for (uint32_t k = (uint32_t)lane; k < len; k += 64u) L.ring[(w + k) & (RING - 1u)] = L.ring[(src0 + k % dist) & (RING - 1u)];
-              }
-              // (long matches could fill the ring within one pass: the half-ring flush is checked behind each of them as well)
-              if (((w + len) & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = (w + len) & ~(RING / 2u - 1u); LDS_SYNC(); flush(L.ring, o, flushed, upto, lane); flushed = upto; }
+              for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) L.ring[(w + k2) & M] = L.ring[(src0 + k2 % dist) & M];
             }
             w += len;
-          } else { eob = true; break; }
+          }
         }
-        pos += i;
         // a 16 KiB half of the ring is complete: it goes out in one coalesced sweep, long before the write position comes round to it again
-        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); PENDING_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, upto, lane); flushed = upto; }
+        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); WINDOW_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, upto, lane); flushed = upto; }
       }
     } else { err = 2; break; }
     if (err || last) break;
   }
-  PENDING_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, w, lane);
+  WINDOW_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, w, lane);
   if (!err && w != cap) err = 6;
   if (!err && pos > in_bits) err = 1;
   if (lane == 0) status[bi] = err;
-#undef PENDING_OUT
+#undef WINDOW_OUT
 }
 
 extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t st, const uint8_t* in, const void* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status) {

@@ -12,6 +12,7 @@
 
 #include "mkp_ingest_dev.hpp"
 #include "mkp_ingest_host.hpp"
+#include <cmath>
 
 using namespace mkp;
 
@@ -35,7 +36,7 @@ uint64_t fnv64(const std::string& s) { uint64_t h = 1469598103934665603ull; for 
 }  // namespace
 
 struct mkp_dev_ingest {
-  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr;
+  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr};
   static constexpr size_t kPiece = (size_t)2 << 20, kSlots = 16;   // 64 MiB page-locked in all (allocating it is part of a fresh context's first ingest)   // upload staging: two halves of kSlots pieces
   Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
   DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig, parts;
@@ -54,6 +55,7 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + CRC + chain kernels, for the trace)
   return d.release();
 }
 
@@ -65,6 +67,7 @@ void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   d->stage.release(); d->small.release();
   for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
   if (d->up_done) (void)hipEventDestroy(d->up_done);
+  for (auto& e : d->kev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
   delete d;
@@ -82,8 +85,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   if (parts.empty()) throw Error(MKP_E_INVALID, "device ingest: no fetch window");
   const uint32_t beg = (uint32_t)std::max<int64_t>(parts.front().first, 0), end = (uint32_t)std::min<int64_t>(parts.back().second, 0x7fffffffll);
   if (!d) throw Error(MKP_E_DEVICE, "device ingest: no ingest object");
+  auto t_lock = std::chrono::steady_clock::now();
   std::lock_guard<std::mutex> lock(d->mu);
-  auto t0 = std::chrono::steady_clock::now();
+  auto t0 = std::chrono::steady_clock::now(); const double wait_ms = std::chrono::duration<double, std::milli>(t0 - t_lock).count(), alloc0 = mkp_tl_alloc_ms();
   std::unique_ptr<DevShard> out(new DevShard());
   ShardHost& S = out->S; S.tid = (int32_t)tid; S.dev_packed = true;
   BamSource::IngestPlan plan; bam.ingest_ranges(tid, parts, &plan);
@@ -153,16 +157,19 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
   // ---- inflate + CRC, record chains
   auto t_inf = std::chrono::steady_clock::now();
+  ok(hipEventRecord(d->kev[0], d->stream), "event");
   ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch");
   ok(mkp_launch_crc32(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
   MkpIngestParams P; memset(&P, 0, sizeof(P));
   P.raw_len = plan.raw_total; P.tid = (int32_t)tid; P.beg = (int32_t)std::min<uint32_t>(beg, 0x7fffffffu); P.end = (int32_t)std::min<uint32_t>(end, 0x7fffffffu); P.n_ref = (int32_t)bam.ref_names.size(); P.n_seg = (uint32_t)ns;
   ok(mkp_launch_ingest_count(d->stream, d->raw.as<uint8_t>(), &P, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->tot.as<MkpIngestTotals>()), "count launch");
   MkpIngestTotals* tot = (MkpIngestTotals*)sm_tot;
+  ok(hipEventRecord(d->kev[1], d->stream), "event");
   ok(hipMemcpyAsync(sm_stat, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "inflate sync");
   out->ms_inflate = ms_since(t_inf);
+  { float kms = 0; if (hipEventElapsedTime(&kms, d->kev[0], d->kev[1]) == hipSuccess) out->ms_kernel = kms; }
   bam.bytes_inflated += plan.raw_total; bam.bytes_inflated_device += plan.raw_total;
   { const uint32_t* st = (const uint32_t*)sm_stat; for (size_t i = 0; i < nb; i++) if (st[i] != 0) throw Error(MKP_E_IO, "corrupt BGZF data in " + bam.path() +
         ((st[i] & 0x100u) ? " (CRC32 mismatch" : " (decoder status " + std::to_string(st[i] & 0xffu)) + ", block at " + std::to_string(plan.blks[i].coff) + ")"); }
@@ -255,8 +262,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   std::vector<MkpRecInfo>().swap(out->info_host);
   out->ms_digest = ms_since(t_dig);
   out->n_blocks = nb; out->n_segments = ns; out->n_records = n_all; out->raw_bytes = plan.raw_total; out->comp_bytes = plan.comp_total;
-  out->ms_total = ms_since(t0);
-  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u) in %zu window(s): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f parse+pack %.1f digest %.1f total %.1f ms\n",
-      tid, beg, end, parts.size(), nb, ns, n_all, n, plan.comp_total / 1e6, plan.raw_total / 1e6, out->ms_plan, out->ms_upload, out->ms_inflate, out->ms_pack, out->ms_digest, out->ms_total);
+  out->ms_total = ms_since(t0); out->ms_alloc = mkp_tl_alloc_ms() - alloc0; out->ms_wait = wait_ms;
+  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u) in %zu window(s): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f (kernels %.1f) parse+pack %.1f digest %.1f total %.1f ms, of which hipMalloc/hipFree %.1f; began at %.1f\n",
+      tid, beg, end, parts.size(), nb, ns, n_all, n, plan.comp_total / 1e6, plan.raw_total / 1e6, out->ms_plan, out->ms_upload, out->ms_inflate, out->ms_kernel, out->ms_pack, out->ms_digest, out->ms_total, out->ms_alloc,
+      std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count() - 1000.0 * std::floor(std::chrono::duration<double>(t0.time_since_epoch()).count() / 100.0) * 100.0);
   return out;
 }

@@ -14,7 +14,7 @@ struct DevShard {
   std::vector<MkpRecInfo> info_host;   // scratch of the layout interning
   bool layouts_adopted = false, bound = false;   // layout ids already mapped into a context's table; currently swapped into a context for sampling
   uint64_t n_blocks = 0, n_segments = 0, n_records = 0, raw_bytes = 0, comp_bytes = 0;
-  double ms_plan = 0, ms_upload = 0, ms_inflate = 0, ms_pack = 0, ms_digest = 0, ms_total = 0;
+  double ms_plan = 0, ms_upload = 0, ms_inflate = 0, ms_pack = 0, ms_digest = 0, ms_total = 0, ms_alloc = 0, ms_wait = 0, ms_kernel = 0;
   DevShard() = default; DevShard(const DevShard&) = delete; DevShard& operator=(const DevShard&) = delete;
   ~DevShard();
 };
@@ -27,7 +27,7 @@ template <class Seg> inline std::vector<Seg> mkp_plan_segments(const mkp::BamSou
   return segs;
 }
 
-// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block below 24 576 blocks, one thread per block (second edition) from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
+// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block (speculative token decode) below 28 000 blocks, one thread per block (second edition) from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
 hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status);
 
 mkp_dev_ingest* mkp_internal_ingest_create(int device);

@@ -61,17 +61,33 @@ class RcclComm:
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.lib = None
-        names = ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so")
-        if os.environ.get("MKP_RCCL_LIB"):   # the same override mkp_histogram_allreduce reads
-            names = (os.environ["MKP_RCCL_LIB"],) + names
+        # The librccl that sits next to the HIP runtime this process already runs on (libmkpileup's): RCCL looks for "libhsa-runtime64.so"
+        # by that name, and a copy from another directory (torch ships its own ROCm libraries) would be a second, uninitialised HSA
+        # runtime ("no ROCm-capable device is detected").
+        names = []
+        if os.environ.get("MKP_RCCL_LIB"):
+            names.append(os.environ["MKP_RCCL_LIB"])
+        try:
+            for line in open("/proc/self/maps"):
+                path = line.split(None, 5)[-1].strip() if line.count("/") else ""
+                if os.path.basename(path).startswith("libamdhip64.so"):
+                    for cand in ("librccl.so.1", "librccl.so"):
+                        full = os.path.join(os.path.dirname(os.path.realpath(path)), cand)
+                        if os.path.exists(full) and full not in names:
+                            names.append(full)
+        except OSError:
+            pass
+        names += ["librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"]
         for name in names:
             try:
                 self.lib = ctypes.CDLL(name, mode=ctypes.RTLD_GLOBAL)
+                self.lib_path = name
                 break
             except OSError:
                 continue
         if self.lib is None:
             raise OSError("librccl.so not found")
+        os.environ["MKP_RCCL_LIB"] = self.lib_path   # mkp_histogram_allreduce must call into the same copy the communicator lives in
         uid = (ctypes.c_char * 128)()
         if self.rank == 0 and self.lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
             raise RuntimeError("ncclGetUniqueId failed")

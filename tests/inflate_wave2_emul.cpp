@@ -1,6 +1,6 @@
 // CPU emulation of mkp_inflate_wave2 (modkit_amd/csrc/mkp_inflate_wave2.hip): the kernel's control flow restated over 64 emulated lanes,
 // with the per-lane code — the stream window and the token decode of mkp_inflate_tok.hpp — being the very functions the kernel compiles.
-// Test infrastructure: checks the algorithm (speculative decode + chain walk + deferred match stores + input window refills) against zlib
+// Test infrastructure: checks the algorithm (speculative decode + chain walk + the 64-byte output window + input window refills) against zlib
 // where no GPU is at hand.
 //   inflate_wave2_emul bgzf FILE...      every BGZF block of the files: output and acceptance must equal zlib's
 //   inflate_wave2_emul corpus FILE       records of [u32 in_len][u32 out_len][in bytes]: raw DEFLATE streams; acceptance (and output when
@@ -95,27 +95,30 @@ int canon_sym(uint32_t bits, const uint16_t* count, const uint16_t* syms, uint32
   }
   return -1;
 }
-uint32_t slow_token(const In2& in, const Lds& L, uint32_t q, uint32_t* a, uint32_t* b) {
+struct OneTok { uint32_t err, bits, kind, val, dist; };
+OneTok one_token(const In2& in, const Lds& L, uint32_t q) {
+  OneTok r; r.err = 0; r.bits = 0; r.kind = MKP_TK_EOB; r.val = 0; r.dist = 0;
   const unsigned long long bits = in.peek(q);
   uint32_t e = L.lit[(uint32_t)bits & ((1u << LIT_BITS) - 1u)], l = e & 15u; int sym = (int)(e >> 4);
-  if (!l) { sym = canon_sym((uint32_t)bits, L.lcount, L.lsym, &l); if (sym < 0) return 4u; }
-  if (sym < 256) { *a = l | (MKP_TK_LIT << 6) | ((uint32_t)sym << 8); *b = 0; return 0u; }
-  if (sym == 256) { *a = l | (MKP_TK_EOB << 6); *b = 0; return 0u; }
+  if (!l) { sym = canon_sym((uint32_t)bits, L.lcount, L.lsym, &l); if (sym < 0) { r.err = 4u; return r; } }
+  r.bits = l;
+  if (sym < 256) { r.kind = MKP_TK_LIT; r.val = (uint32_t)sym; return r; }
+  if (sym == 256) return r;
   const int ls = sym - 257;
-  if (ls >= 29) return 4u;
-  const uint32_t ex = len_extra(ls), len = len_base(ls) + ((uint32_t)(bits >> l) & ((1u << ex) - 1u));
+  if (ls >= 29) { r.err = 4u; return r; }
+  const uint32_t ex = len_extra(ls);
+  r.kind = MKP_TK_MATCH; r.val = len_base(ls) + ((uint32_t)(bits >> l) & ((1u << ex) - 1u));
   uint32_t n = l + ex;
   const uint32_t d = L.dist[(uint32_t)(bits >> n) & ((1u << DIST_BITS) - 1u)]; uint32_t dl = d & 15u; int ds = (int)(d >> 4);
-  if (!dl) { ds = canon_sym((uint32_t)(bits >> n), L.dcount, L.dsym, &dl); if (ds < 0) return 4u; }
-  if (ds >= 30) return 4u;
+  if (!dl) { ds = canon_sym((uint32_t)(bits >> n), L.dcount, L.dsym, &dl); if (ds < 0) { r.err = 4u; return r; } }
+  if (ds >= 30) { r.err = 4u; return r; }
   const uint32_t dx = dist_extra(ds);
-  *b = dist_base(ds) + ((uint32_t)(bits >> (n + dl)) & ((1u << dx) - 1u));
-  n += dl + dx;
-  *a = n | (MKP_TK_MATCH << 6) | (len << 8);
-  return 0u;
+  r.dist = dist_base(ds) + ((uint32_t)(bits >> (n + dl)) & ((1u << dx) - 1u));
+  r.bits = n + dl + dx;
+  return r;
 }
 
-struct Stats { uint64_t passes = 0, tokens = 0, slow = 0, matches = 0, long_matches = 0, early_out = 0, refills = 0, seeks = 0; } g_stats;
+struct Stats { uint64_t windows = 0, window_bytes = 0, passes = 0, tokens = 0, slow = 0, matches = 0, long_matches = 0, early_out = 0, refills = 0, seeks = 0; } g_stats;
 
 // the kernel, one block; returns the status, fills `out` (cap bytes)
 uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t cap) {
@@ -123,8 +126,16 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
   In2 in; in.p = inp; in.n = in_len; in.w = L.inw; in.seek(0);
   Hdr h; uint32_t pos = 0, w = 0, err = 0, flushed = 0;
   const uint32_t in_bits = 8u * in_len;
-  uint32_t pv[W] = {0}, pa[W] = {0}, plen = 0, pw = 0;
-  auto pending_out = [&]() { if (plen) { for (uint32_t lane = 0; lane < W; lane++) if (lane < plen) L.ring[pa[lane]] = (uint8_t)pv[lane]; plen = 0; } };
+  constexpr uint32_t LITERAL = MKP_SV_LITERAL, M = RING - 1u;
+  uint32_t sv[W] = {0}, fill = 0;
+  auto window_out = [&]() {
+    if (fill) {
+      g_stats.windows++; g_stats.window_bytes += fill;
+      uint32_t r[W]; for (uint32_t lane = 0; lane < W; lane++) r[lane] = L.ring[sv[lane] & M];
+      for (uint32_t lane = 0; lane < W; lane++) if (lane < fill) L.ring[(w - fill + lane) & M] = (uint8_t)((sv[lane] & LITERAL) ? sv[lane] : r[lane]);
+      fill = 0;
+    }
+  };
   auto flush = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) o[k] = L.ring[k & (RING - 1u)]; };
   for (uint32_t guard = 0; guard <= in_len && !err; guard++) {
     h.load(in, pos);
@@ -135,7 +146,7 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
       if ((len ^ 0xffffu) != nlen || w + len > cap) { err = 2; break; }
       const uint32_t at = pos >> 3;
       if ((unsigned long long)at + len > in_len) { err = 1; break; }
-      pending_out(); flush(flushed, w);
+      window_out(); flush(flushed, w);
       for (uint32_t k = 0; k < len; k++) { const uint8_t v = inp[at + k]; o[w + k] = v; L.ring[(w + k) & (RING - 1u)] = v; }
       w += len; flushed = w; pos = 8u * (at + len);
     } else if (type == 1 || type == 2) {
@@ -187,51 +198,49 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
         MkpTok t[W];
         for (uint32_t lane = 0; lane < W; lane++) t[lane] = mkp_tok_decode(in.peek(pos + lane), L.lit, L.dist);
         g_stats.passes++;
-        uint32_t i = 0;
-        while (i < 64u) {
-          uint32_t a = t[i].a, b;
-          if (mkp_tok_kind(a) == MKP_TK_SLOW) { g_stats.slow++; err = slow_token(in, L, pos + i, &a, &b); if (err) break; }
-          else b = t[i].b;
-          i += mkp_tok_bits(a); g_stats.tokens++;
-          const uint32_t kind = mkp_tok_kind(a);
-          if (kind == MKP_TK_LIT) {
+        uint32_t i = 0; bool special = false;
+        do {
+          const uint32_t a = t[i].a, b = t[i].b;
+          const uint32_t ol = a >> 8; const bool lit = (a & MKP_TA_LIT) != 0u;
+          if (!((a & MKP_TA_WIN) && w + ol <= cap && (lit || b <= w))) { special = true; break; }
+          g_stats.tokens++; if (!lit) g_stats.matches++;
+          if (fill + ol > 64u || (!lit && b < fill + ol)) { if (!lit && b < fill + ol) g_stats.early_out++; window_out(); }
+          for (uint32_t lane = 0; lane < W; lane++) { const uint32_t rel = lane - fill; const uint32_t nsv = lit ? b : ((w - b + rel) & M); if (rel < ol) sv[lane] = nsv; }
+          fill += ol; w += ol; i += a & 63u;
+        } while (i < 64u);
+        pos += i;
+        if (special) {
+          g_stats.slow++; g_stats.tokens++;
+          const OneTok k = one_token(in, L, pos);
+          if (k.err) { err = k.err; break; }
+          pos += k.bits;
+          if (k.kind == MKP_TK_EOB) eob = true;
+          else if (k.kind == MKP_TK_LIT) {
             if (w >= cap) { err = 6; break; }
-            L.ring[w & (RING - 1u)] = (uint8_t)mkp_tok_val(a);
-            w++;
-          } else if (kind == MKP_TK_MATCH) {
-            const uint32_t len = mkp_tok_val(a), dist = b; g_stats.matches++;
+            if (fill == 64u) window_out();
+            for (uint32_t lane = 0; lane < W; lane++) if (lane == fill) sv[lane] = LITERAL | k.val;
+            fill++; w++;
+          } else {
+            const uint32_t len = k.val, dist = k.dist; g_stats.matches++; g_stats.long_matches++;
             if (dist > w) { err = 5; break; }
             if (w + len > cap) { err = 6; break; }
-            const uint32_t src0 = w - dist, span = dist < len ? dist : len;
-            if (len <= 64u) {
-              if (plen && src0 < pw + plen && src0 + span > pw) { g_stats.early_out++; pending_out(); }
-              uint32_t v[W];
-              for (uint32_t k = 0; k < W; k++) { const uint32_t soff = dist >= len ? k : dist == 1u ? 0u : k % dist; v[k] = k < len ? L.ring[(src0 + soff) & (RING - 1u)] : 0; }
-              pending_out();
-              for (uint32_t k = 0; k < W; k++) { pv[k] = v[k]; pa[k] = (w + k) & (RING - 1u); }
-              plen = len; pw = w;
-            } else {
-              g_stats.long_matches++;
-              pending_out();
-              // lanes in steps of 64: all loads of a step before its stores
-              for (uint32_t k0 = 0; k0 < len; k0 += 64u) {
-                uint8_t v[W];
-                for (uint32_t k = k0; k < k0 + 64u && k < len; k++) v[k - k0] = dist >= len ? L.ring[(src0 + k) & (RING - 1u)] : dist == 1u ? L.ring[src0 & (RING - 1u)] : L.ring[(src0 + k % dist) & (RING - 1u)];
-                for (uint32_t k = k0; k < k0 + 64u && k < len; k++) L.ring[(w + k) & (RING - 1u)] = v[k - k0];
-              }
-              if (((w + len) & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = (w + len) & ~(RING / 2u - 1u); flush(flushed, upto); flushed = upto; }
+            const uint32_t src0 = w - dist;
+            window_out();
+            for (uint32_t k0 = 0; k0 < len; k0 += 64u) {   // lanes in steps of 64: all loads of a step before its stores
+              uint8_t v[W];
+              for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) v[k2 - k0] = dist >= len ? L.ring[(src0 + k2) & M] : dist == 1u ? L.ring[src0 & M] : L.ring[(src0 + k2 % dist) & M];
+              for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) L.ring[(w + k2) & M] = v[k2 - k0];
             }
             w += len;
-          } else { eob = true; break; }
+          }
         }
-        pos += i;
-        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); pending_out(); flush(flushed, upto); flushed = upto; }
+        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); window_out(); flush(flushed, upto); flushed = upto; }
         if (w - flushed > RING) { fprintf(stderr, "ring overrun: %u bytes unflushed\n", w - flushed); exit(3); }
       }
     } else { err = 2; break; }
     if (err || last) break;
   }
-  pending_out(); flush(flushed, w);
+  window_out(); flush(flushed, w);
   if (!err && w != cap) err = 6;
   if (!err && pos > in_bits) err = 1;
   g_stats.refills += in.refills; g_stats.seeks += in.seeks;
@@ -304,7 +313,8 @@ int main(int argc, char** argv) {
     }
   } else return 2;
   printf("ok %llu %llu %llu %llu\n", (unsigned long long)blocks, (unsigned long long)bytes, (unsigned long long)accepted, (unsigned long long)rejected);
-  fprintf(stderr, "passes %llu tokens %llu (%.2f per pass) matches %llu long %llu early-out %llu slow %llu refills %llu seeks %llu\n", (unsigned long long)g_stats.passes, (unsigned long long)g_stats.tokens,
+  fprintf(stderr, "windows %llu (%.1f bytes each) ", (unsigned long long)g_stats.windows, g_stats.windows ? (double)g_stats.window_bytes / (double)g_stats.windows : 0.0);
+  fprintf(stderr, "passes %llu tokens %llu (%.2f per pass) matches %llu long %llu early-out %llu special %llu refills %llu seeks %llu\n", (unsigned long long)g_stats.passes, (unsigned long long)g_stats.tokens,
           g_stats.passes ? (double)g_stats.tokens / (double)g_stats.passes : 0.0, (unsigned long long)g_stats.matches, (unsigned long long)g_stats.long_matches, (unsigned long long)g_stats.early_out,
           (unsigned long long)g_stats.slow, (unsigned long long)g_stats.refills, (unsigned long long)g_stats.seeks);
   return 0;

@@ -1,4 +1,4 @@
-"""Device BGZF inflate (mkp_bgzf_inflate -> mkp_inflate_blocks, one thread per block; SURVEY §8 f1 first stage) against Python's gzip
+"""Device BGZF inflate (mkp_bgzf_inflate -> mkp_inflate_wave2 / mkp_inflate_blocks2 by launch size; SURVEY §8 f1 first stage) against Python's gzip
 on the reference's BAM fixtures and on generated BAMs; corrupt input must come back as an error."""
 import glob
 import gzip
