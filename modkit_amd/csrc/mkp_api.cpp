@@ -1410,14 +1410,19 @@ int mkp_histogram_get(mkp_ctx* c, uint32_t base, uint32_t level, uint32_t prefix
 extern "C" hipError_t mkp_launch_widen(hipStream_t, const uint32_t*, unsigned long long*, uint32_t);
 namespace {
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+// the HIP runtime this library is bound to (its device pointers mean something to that copy only): a process that also imports torch
+// can hold a second copy of the ROCm libraries, with a librccl of its own next to it
+std::string hip_runtime_path() { Dl_info i; if (dladdr((void*)&hipGetDeviceCount, &i) && i.dli_fname) return std::string(i.dli_fname); return std::string(); }
 nccl_allreduce_fn rccl_allreduce() {
   static nccl_allreduce_fn fn = []() -> nccl_allreduce_fn {
-    const char* forced = getenv("MKP_RCCL_LIB");   // (the library the caller made its communicator with, when it is not the first on the search path)
-    for (const char* name : {forced ? forced : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f; } }
+    const char* forced = getenv("MKP_RCCL_LIB");   // (the library the caller made its communicator with)
+    std::string beside = hip_runtime_path(); { const size_t sl = beside.rfind('/'); beside = sl == std::string::npos ? std::string("librccl.so.1") : beside.substr(0, sl + 1) + "librccl.so.1"; }
+    for (const char* name : {forced ? forced : beside.c_str(), beside.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f; } }
     return nullptr; }();
   return fn;
 }
 }  // namespace
+extern "C" const char* mkp_internal_hip_runtime_path() { static const std::string p = hip_runtime_path(); return p.c_str(); }
 extern "C" {
 int mkp_histogram_allreduce(mkp_ctx* c, void* nccl_comm, uint32_t base, uint32_t level, uint32_t prefix, uint64_t* out) {
   if (!c || !nccl_comm || !out || base > 3 || level > 1 || prefix > 0xffffu) return MKP_E_INVALID;

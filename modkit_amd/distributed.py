@@ -61,21 +61,22 @@ class RcclComm:
         self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.lib = None
-        # The librccl that sits next to the HIP runtime this process already runs on (libmkpileup's): RCCL looks for "libhsa-runtime64.so"
-        # by that name, and a copy from another directory (torch ships its own ROCm libraries) would be a second, uninitialised HSA
-        # runtime ("no ROCm-capable device is detected").
+        # The librccl that sits next to the HIP runtime libmkpileup is bound to: the histograms are device pointers of THAT runtime, and
+        # a process that imports torch may hold a second copy of the ROCm libraries (torch ships its own) whose HSA runtime nobody has
+        # initialised ("no ROCm-capable device is detected" from ncclCommInitRank).
         names = []
         if os.environ.get("MKP_RCCL_LIB"):
             names.append(os.environ["MKP_RCCL_LIB"])
         try:
-            for line in open("/proc/self/maps"):
-                path = line.split(None, 5)[-1].strip() if line.count("/") else ""
-                if os.path.basename(path).startswith("libamdhip64.so"):
-                    for cand in ("librccl.so.1", "librccl.so"):
-                        full = os.path.join(os.path.dirname(os.path.realpath(path)), cand)
-                        if os.path.exists(full) and full not in names:
-                            names.append(full)
-        except OSError:
+            L = lib()
+            L.mkp_internal_hip_runtime_path.restype = ctypes.c_char_p
+            hip_path = (L.mkp_internal_hip_runtime_path() or b"").decode()
+            if hip_path:
+                for cand in ("librccl.so.1", "librccl.so"):
+                    full = os.path.join(os.path.dirname(os.path.realpath(hip_path)), cand)
+                    if os.path.exists(full) and full not in names:
+                        names.append(full)
+        except (OSError, AttributeError):
             pass
         names += ["librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"]
         for name in names:
