@@ -197,7 +197,12 @@ int mkp_batch_run(mkp_ctx* ctx, const mkp_shard* intervals, uint32_t n_intervals
 int mkp_shard_rerun(mkp_ctx* ctx, uint32_t iters, mkp_rows* out);
 int mkp_get_stats(const mkp_ctx* ctx, mkp_stats* out);
 
-/* ---- same, reading the BAM itself: direct stand-in for process_region_batch(bam_fp, ...) */
+/* ---- same, reading the BAM itself: direct stand-in for process_region_batch(bam_fp, ...)
+ * (src/pileup/mod.rs:684-716; the IndexedReader fetch + pileup of :732-759).  With a .bai next to the file the window's
+ * compressed BGZF blocks are uploaded and inflated, cut into records, tokenised and packed ON THE DEVICE: nothing
+ * but the index and the block headers is read on the host, and this is the fast seam — the record-level calls above pay the
+ * host packer and the upload of packed records.  Without an index (or with partition tags, or MKP_HOST_INGEST=1) the library's
+ * host reader + packer feed the same kernels.  One call = one shard: keep the window to ~1 GiB of BAM. */
 int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shard, mkp_rows* out);
 
 /* ---- whole subcommand: `modkit pileup` (ModBamPileup::run, src/pileup/subcommand.rs:382-816).

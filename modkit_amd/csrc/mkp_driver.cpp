@@ -1187,11 +1187,20 @@ extern "C" int mkp_histogram_add_bam(mkp_ctx* ctx, const char* bam_path, int arg
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
 }
 
-// process_region_batch stand-in reading the BAM itself (whole-file residency, see mkp_bam.hpp)
+// process_region_batch stand-in reading the BAM itself: an indexed BAM goes through the device ingest (compressed blocks up, records cut and
+// packed in HBM — what mkp_pileup_run does per shard), anything else through the host reader + packer
 extern "C" int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_shard* shard, mkp_rows* out) {
   if (!ctx || !bam_path || !shard || !out) return MKP_E_INVALID;
   try {
     std::unique_ptr<BamSource> src = BamSource::open(bam_path, 0);
+    const bool host_ingest_env = getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1");
+    if (src->indexed() && ctx->partition_tags.empty() && !host_ingest_env && shard->tid >= 0 && shard->end > shard->start) {
+      if (!ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
+      std::unique_ptr<DevShard> dev = mkp_internal_ingest_run(ctx->ingest, *src, (uint32_t)shard->tid, shard->start > MKP_HALO ? (uint32_t)shard->start - MKP_HALO : 0u, (uint32_t)shard->end + MKP_HALO);
+      int rc = mkp_shard_begin(ctx, shard); if (rc != MKP_OK) return rc;
+      rc = mkp_internal_shard_attach(ctx, dev.get()); mkp_internal_ingest_recycle(ctx->ingest, dev.get()); if (rc != MKP_OK) return rc;
+      return mkp_shard_run(ctx, out);
+    }
     int rc = mkp_shard_begin(ctx, shard); if (rc != MKP_OK) return rc;
     BamBatch batch; src->fetch((uint32_t)shard->tid, shard->start > MKP_HALO ? shard->start - MKP_HALO : 0, shard->end + MKP_HALO, &batch);
     std::vector<mkp_record> recs; for (auto& e : batch.recs) recs.push_back(batch.view(e));

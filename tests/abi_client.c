@@ -97,10 +97,12 @@ static void build_focus(const char* seq, uint32_t s, uint32_t e, const motif_t* 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
 int main(int argc, char** argv) {
-  if (argc < 6) die("usage: abi_client <in.bam> <ref.fa|-> <out.bed> <all|cpg|cg_cgcg> <default_threshold|none> [interval_size [intervals_per_batch]]");
+  if (argc < 6) die("usage: abi_client <in.bam> <ref.fa|-> <out.bed> <all|cpg|cg_cgcg> <default_threshold|none> [interval_size [intervals_per_batch|file]]");
   const char* mode = argv[4]; uint32_t interval = argc > 6 ? (uint32_t)strtoul(argv[6], NULL, 10) : 100000u;
   /* intervals_per_batch > 1: the batch seam — mkp_batch_run takes that many consecutive intervals (a MultiChromCoordinates) per call */
-  uint32_t per_batch = argc > 7 ? (uint32_t)strtoul(argv[7], NULL, 10) : 1u; if (per_batch < 1) per_batch = 1;
+  /* intervals_per_batch = "file": the file seam — one mkp_process_region per contig, the library reads the BAM itself (device ingest with a .bai) */
+  const int file_seam = argc > 7 && strcmp(argv[7], "file") == 0;
+  uint32_t per_batch = (argc > 7 && !file_seam) ? (uint32_t)strtoul(argv[7], NULL, 10) : 1u; if (per_batch < 1) per_batch = 1;
   size_t cn, n; uint8_t* comp = read_file(argv[1], &cn); uint8_t* d = bgzf_inflate_all(comp, cn, &n); free(comp);
   if (n < 12 || memcmp(d, "BAM\1", 4) != 0) die("not a BAM");
   size_t o = 4; int32_t l_text; memcpy(&l_text, d + o, 4); o += 4 + (size_t)l_text;
@@ -131,7 +133,9 @@ int main(int argc, char** argv) {
   if (mkp_set_caller(ctx, &kc) != MKP_OK) die(mkp_last_error(ctx));
 
   FILE* out = fopen(argv[3], "w"); if (!out) die("cannot open output");
-  uint8_t* focus = n_motifs ? malloc((size_t)interval * per_batch) : NULL; combos_t combos; memset(&combos, 0, sizeof(combos)); combos.n = 1;
+  size_t focus_cap = (size_t)interval * per_batch;
+  if (file_seam) for (int t = 0; t < n_ref; t++) if (lens[t] > focus_cap) focus_cap = lens[t];
+  uint8_t* focus = n_motifs ? malloc(focus_cap) : NULL; combos_t combos; memset(&combos, 0, sizeof(combos)); combos.n = 1;
   mkp_shard* ivs = malloc(per_batch * sizeof(*ivs)); mkp_rows* brows = malloc(per_batch * sizeof(*brows));
   size_t first = 0; uint64_t total_rows = 0, n_calls = 0; double t_api = 0, t0 = now_s();
   mkp_record* batch = malloc(nr * sizeof(*batch) + sizeof(*batch));
@@ -140,6 +144,24 @@ int main(int argc, char** argv) {
     if (n_motifs) { for (int c = 0; c < n_contigs; c++) if (strcmp(fa[c].name, names[tid]) == 0) { if (fa[c].len < lens[tid]) die("FASTA contig shorter than BAM header says"); seq = fa[c].seq; } if (!seq) die("contig missing from FASTA"); }
     while (first < nr && recs[first].tid >= 0 && recs[first].tid < tid) first++;
     size_t lo = first;
+    if (file_seam && lens[tid] > 0) {
+      mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = tid; sh.start = 0; sh.end = lens[tid];
+      if (n_motifs) { build_focus(seq, 0, lens[tid], motifs, n_motifs, focus, &combos); sh.focus = focus; sh.combos = combos.c; sh.n_combos = combos.n; }
+      mkp_rows rows; memset(&rows, 0, sizeof(rows));
+      double ta = now_s();
+      if (mkp_process_region(ctx, argv[1], &sh, &rows) != MKP_OK) die(mkp_last_error(ctx));
+      t_api += now_s() - ta; n_calls++;
+      for (uint64_t i = 0; i < rows.n_rows; i++) {
+        char name[64]; uint32_t code = rows.code_repr[i];
+        int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
+        if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + k, sizeof(name) - (size_t)k, ",%s,%d", motifs[rows.motif_idx[i]].pat, motifs[rows.motif_idx[i]].off);
+        float frac = (float)rows.n_mod[i] / (float)rows.n_valid[i];
+        fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1, name, rows.n_valid[i], (char)rows.strand[i],
+                rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i], rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
+      }
+      total_rows += rows.n_rows;
+      continue;
+    }
     for (uint32_t s = 0; per_batch > 1 && s < lens[tid];) {
       /* the batch seam: `per_batch` consecutive intervals, their records fetched once, one call */
       uint32_t nb_iv = 0, s0 = s;

@@ -87,3 +87,30 @@ def test_batch_seam_on_a_cpg_workload(client, oracle_bin, tmp_path):
     assert open(a).read() == open(c).read()
     assert "intervals=4 " in err
     print(err.strip())
+
+
+@pytest.mark.parametrize("mode,flags", [
+    ("all", ["--no-filtering"]),
+    ("cpg", ["--no-filtering", "--cpg", "--ref", REF]),
+], ids=["all_positions", "cpg"])
+def test_file_seam_equals_driver_on_the_reference_fixture(client, tmp_path, mode, flags):
+    """mkp_process_region: the client hands over the BAM's path and one shard per contig; with the fixture's .bai the records reach the
+    kernels through the device ingest.  Same rows as the driver."""
+    a, b = str(tmp_path / "client.bed"), str(tmp_path / "driver.bed")
+    err = run_client(client, fixture(BC), REF, a, mode, "none", 100000, "file")
+    assert "intervals=" in err
+    modkit_amd.pileup([fixture(BC), b] + flags)
+    assert open(a).read() == open(b).read() and open(a).read()
+
+
+def test_file_seam_on_a_cpg_workload(client, oracle_bin, tmp_path):
+    # the C3-shaped data of the batch test, one mkp_process_region for the contig (indexed BAM: device ingest) against the oracle
+    bam, fa, meta = gen(tmp_path, "c3f", [("chr20", 4_000_000)], 12_000, "hm", 21, ["--cpg-depleted", "--mean-len", "8353"])
+    a, c = str(tmp_path / "client.bed"), str(tmp_path / "oracle.bed")
+    err = run_client(client, bam, fa, a, "cpg", "0.7", 100000, "file")
+    flags = ["--filter-threshold", "0.7", "--cpg", "--ref", fa]
+    p = subprocess.run([oracle_bin, "pileup", bam, c, "--oracle-workers", "8"] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(a).read() == open(c).read()
+    assert "intervals=1 " in err
+    print(err.strip())
