@@ -20,14 +20,14 @@ hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*,
     const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
-                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
+                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/);
 hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*, const uint32_t* /*cover read ids*/,
     uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
                             const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
-                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);        // one thread per block
 hipError_t mkp_launch_inflate_wave(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);   // one wave per block
@@ -579,7 +579,7 @@ void make_resident(mkp_ctx* c) {
   }
 }
 
-void run_kernels(mkp_ctx* c, bool time_kernels) {
+void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
   MkpRunParams& P = c->prm;
   if (c->row_cap == 0) {
     // focus runs: usually one strand rule per focus position and one row per observed code; otherwise two strands per position
@@ -587,11 +587,15 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
         P.numeric_mode == 1 ? P.n_pb : P.n_slots) + 4096 : (uint64_t)c->stats.n_positions * 2 + 1024;
     c->row_cap = std::max<uint64_t>(1u << 16, std::min<uint64_t>(guess * c->key_passes.size(), 1ull << 28));
   }
+  const bool trace = time_kernels && getenv("MKP_TRACE_PLAN") != nullptr;
+  auto t_rk = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (trace) { auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[mkpileup plan]   kernels: %-20s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_rk).count()); t_rk = now; } };
   const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
   c->d_tile_row_off.ensure((size_t)(n_runs + 1) * 8); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);   // (slot pipeline: row_off holds the runs' 64-bit look-back words)
   for (;;) {
     P.row_capacity = (uint32_t)c->row_cap;
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
+    lap("row buffers");
     uint32_t* misc = c->d_misc.as<uint32_t>();  // [0] row cursor, [1] total rows, [2] error bits
     hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
     if (c->slot_mode) {   // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, misc[3] = number of runs
@@ -617,19 +621,21 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
       if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
                                                  c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
-                                                 c->key_passes[kp], kp), "stream pileup launch");
+                                                 c->key_passes[kp], kp, one_shot ? 1 : 0), "stream pileup launch");
       else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
-                                  c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
+                                  c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp, one_shot ? 1 : 0), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
     if (c->slot_mode) c->rows_dst = c->rows_src;   // already in genome order
     else hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
         &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
+    lap("launches");
     uint32_t h[4];
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     hip_check(hipStreamSynchronize(c->stream), "kernel sync");
+    lap("sync");
     if (h[2] & 2u) { c->row_cap *= 2; if (c->row_cap > (1ull << 31)) throw Error(MKP_E_NOMEM, "row buffer would exceed 2^31 rows"); continue; }
     if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
     c->stats.n_rows = h[1];
@@ -838,6 +844,9 @@ int mkp_internal_shard_preplan(mkp_ctx* c) {
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, c->wplan.slotbm); upload(c->d_slot_pos, c->wplan.slot_pos);
     c->wplan.valid = true;
+    // a fresh context's first shard: page-locking the row arena costs ~25 ms per 100 MB — here it hides behind the ingest (the caller is
+    // about to wait for it); two rows per focus position is what a two-code run can produce at most per strand rule
+    if (c->h_rows.cap == 0 && !c->wplan.slot_pos.empty()) c->h_rows.ensure(std::min<size_t>(c->wplan.slot_pos.size() * 2, (size_t)1 << 26));
   });
 }
 extern "C" {
@@ -949,7 +958,7 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
         fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
     if (!c->resident || c->resident_hemi) { c->row_cap = 0; make_resident(c); }
     lap("run: make_resident");
-    run_kernels(c, true);
+    run_kernels(c, true, true);   // one launch on this shard, then its rows: the scratch-free build of the accumulate kernel
     lap("run: kernels");
     fetch_rows(c, out);
     lap("run: fetch rows");

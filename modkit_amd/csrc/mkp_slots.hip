@@ -661,6 +661,9 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
 #define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false>(STREAM_PASS); }
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true>(STREAM_PASS); }
+// the same bodies with 128 VGPRs (four waves per SIMD, one workgroup per CU): no register spills, no scratch (MKP_PILEUP_WAVES=4; A/B runs)
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_w4(STREAM_PARAMS) { pileup_stream_body<false>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_keyed_w4(STREAM_PARAMS) { pileup_stream_body<true>(STREAM_PASS); }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
@@ -676,7 +679,7 @@ extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint
 }
 
 extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
-  for (const void* k : {(const void*)mkp_pileup_stream, (const void*)mkp_pileup_stream_keyed}) {
+  for (const void* k : {(const void*)mkp_pileup_stream, (const void*)mkp_pileup_stream_keyed, (const void*)mkp_pileup_stream_w4, (const void*)mkp_pileup_stream_keyed_w4}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
   }
@@ -685,12 +688,19 @@ extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
 
 extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
                                         const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot) {
   if (!n_tiles) return hipSuccess;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
 #define MKP_STREAM_LAUNCH(K) hipLaunchKernelGGL(K, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, visits, cov, events, tiles, n_tiles, prm_dev, slot_pos, focus, combos, rows->pos, row_cursor, \
                                                 tile_row_off, tile_row_cnt, dev_err, key_arg)
-  if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed); else MKP_STREAM_LAUNCH(mkp_pileup_stream);
+  // The 64-VGPR build (two workgroups per CU) spills into 220 bytes of scratch per lane.  It is the faster kernel (0.154 against 0.234 ms
+  // on C3) — but a queue that has been idle pays 9-13 ms for the scratch allocation around its first such dispatch, which is all a
+  // one-shot run (one launch per shard, then rows) ever sees.  One-shot launches take the 128-VGPR build (no spills, no scratch); re-launches
+  // on a resident shard, where the allocation is long paid for, the 64-VGPR one.  MKP_PILEUP_WAVES=4|8 forces either.
+  static const int forced = getenv("MKP_PILEUP_WAVES") ? atoi(getenv("MKP_PILEUP_WAVES")) : 0;
+  const bool w4 = forced == 4 || (forced != 8 && one_shot);
+  if (w4) { if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed_w4); else MKP_STREAM_LAUNCH(mkp_pileup_stream_w4); }
+  else if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed); else MKP_STREAM_LAUNCH(mkp_pileup_stream);
   return hipGetLastError();
 }
