@@ -25,6 +25,39 @@ using namespace mkp;
 
 namespace {
 
+std::string f32_display(float v);   // (Rust's `{}` of an f32; defined with the extract-calls writer below)
+
+// --bedgraph (BedGraphWriter, writers.rs:264-381): one file per (partition key, strand, mod code[, motif]) in the output directory,
+// `[<prefix>_][<key>_]<code>[_<motif label without commas>]_<positive|negative|combined>.bedgraph`, rows
+// `chrom <tab> pos <tab> pos + 1 <tab> fraction_modified <tab> filtered_coverage` with the fraction as an f32 through `{}`
+// (n_modified as f32 / filtered_coverage as f32, pileup/mod.rs:327-331).  A projection of the bedMethyl rows: same rows, same order per file.
+struct BedGraphOut {
+  std::string dir, prefix; bool groupings = false; std::vector<std::string> labels; uint64_t n = 0;
+  struct File { FILE* f = nullptr; std::string buf; };
+  std::map<std::string, File> files;
+  void write(const std::string& chrom, const mkp_rows& r) {
+    char line[160];
+    for (uint64_t i = 0; i < r.n_rows; i++) {
+      std::string name;
+      if (!prefix.empty()) name = prefix + "_";
+      if (groupings) { const uint32_t k = r.partition_key ? r.partition_key[i] : 0u; name += (k < r.n_partition_keys ? r.partition_key_names[k] : "not_found"); name += "_"; }
+      const uint32_t code = r.code_repr[i];
+      if (code & 0x80000000u) name += std::to_string(code & 0x7fffffffu); else name += (char)code;
+      if (r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) { name += "_"; for (char ch : labels[(size_t)r.motif_idx[i]]) if (ch != ',') name += ch; }
+      name += r.strand[i] == '+' ? "_positive" : r.strand[i] == '-' ? "_negative" : r.strand[i] == '.' ? "_combined" : "__unknown";
+      File& fl = files[name];
+      if (!fl.f) { const std::string path = dir + "/" + name + ".bedgraph"; fl.f = fopen(path.c_str(), "w"); if (!fl.f) throw Error(MKP_E_IO, "failed to make output file " + path); }
+      const float frac = (float)r.n_mod[i] / (float)r.n_valid[i];
+      const int k = snprintf(line, sizeof(line), "\t%u\t%u\t%s\t%u\n", r.pos[i], r.pos[i] + 1, f32_display(frac).c_str(), r.n_valid[i]);
+      fl.buf += chrom; fl.buf.append(line, (size_t)k);
+      if (fl.buf.size() > ((size_t)1 << 20)) { if (fwrite(fl.buf.data(), 1, fl.buf.size(), fl.f) != fl.buf.size()) throw Error(MKP_E_IO, "write error in " + dir); fl.buf.clear(); }
+      n++;
+    }
+  }
+  void finish() { for (auto& kv : files) { File& fl = kv.second; if (fl.f) { if (!fl.buf.empty() && fwrite(fl.buf.data(), 1, fl.buf.size(), fl.f) != fl.buf.size()) throw Error(MKP_E_IO, "write error in " + dir); fclose(fl.f); fl.f = nullptr; } } }
+  ~BedGraphOut() { for (auto& kv : files) if (kv.second.f) fclose(kv.second.f); }
+};
+
 struct Args {
   std::string in_bam, out_bed, region, sample_region, include_bed, ignore, ref_fasta, edge_filter, preset;
   uint32_t max_depth = 8000, interval_size = 100000, sampling_interval_size = 1000000;
@@ -37,6 +70,7 @@ struct Args {
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
   bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate.hip) instead of the host pool, records back to the host packer */
   bool host_ingest = false, shard_bytes_set = false;   /* --host-ingest (or MKP_HOST_INGEST=1): inflate, cut and pack the shards on the host instead of the device (mkp_ingest.hip) */
+  bool bedgraph = false;   /* --bedgraph: the output path is a directory of <code>[_<motif>]_<strand>.bedgraph files (BedGraphWriter, writers.rs:264-381) */
   bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */
 };
 
@@ -732,7 +766,14 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // --partition-tag: the output path is a directory with one bedMethyl per key, `[<prefix>_]<key>.bed` (PartitioningBedMethylWriter, writers.rs:1005-1082)
   const bool partitioned = !a.partition_tags.empty();
   std::map<std::string, std::unique_ptr<RowWriter>> key_writers;
-  if (partitioned) {
+  BedGraphOut bg;
+  if (a.bedgraph) {   // (subcommand.rs:328-363: no header, no mixed delimiters; the path is a directory)
+    if (a.with_header || a.mixed_delim || a.bgzf || a.hemi || a.plan_only) throw Error(MKP_E_INVALID, "--bedgraph cannot be combined with --with-header, --mixed-delim, --bgzf or --plan-only");
+    if (a.out_bed.empty() || a.out_bed == "-" || a.out_bed == "stdout") throw Error(MKP_E_INVALID, "--bedgraph needs an output directory");
+    if (partitioned) { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
+    if (mkdir(a.out_bed.c_str(), 0777) != 0 && errno != EEXIST) throw Error(MKP_E_IO, "failed to make output directory " + a.out_bed);
+    bg.dir = a.out_bed; bg.prefix = a.prefix; bg.groupings = partitioned; bg.labels = wr.labels;
+  } else if (partitioned) {
     if (a.with_header) throw Error(MKP_E_INVALID, "--with-header cannot be combined with --partition-tag");
     if (a.plan_only) throw Error(MKP_E_INVALID, "--plan-only has no partitioned form");
     { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
@@ -899,7 +940,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       mark("  mkp_shard_run returned");
       if (a.rerun) must(mkp_shard_rerun(ctx, a.rerun, &rows));   // measurement aid: warm, averaged kernel times in --stats
       { auto t_w = std::chrono::steady_clock::now();
-        if (!partitioned) wr.write(rec.name, rows);
+        if (a.bedgraph) { bg.write(rec.name, rows); wr.n += rows.n_rows; }
+        else if (!partitioned) wr.write(rec.name, rows);
         else for (uint64_t i0r = 0; i0r < rows.n_rows;) {   // rows come grouped by key: one slice per key
           uint64_t i1r = i0r; while (i1r < rows.n_rows && rows.partition_key[i1r] == rows.partition_key[i0r]) i1r++;
           mkp_rows v = rows; v.n_rows = i1r - i0r; v.pos += i0r; v.strand += i0r; v.code_repr += i0r; v.motif_idx += i0r; v.n_valid += i0r; v.n_mod += i0r;
@@ -919,7 +961,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     }
   }
   load_ms += fetch_wait_ms;   // what the shard loop waited for blocks to be read and inflated (the rest overlapped with pack / run / write)
-  { auto t_w = std::chrono::steady_clock::now(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f); } write_ms += ms_since(t_w); }
+  { auto t_w = std::chrono::steady_clock::now(); bg.finish(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f); } write_ms += ms_since(t_w); }
   if (wr.f && wr.f != stdout) fclose(wr.f);
   mark("output closed");
   if (rep) {
@@ -978,7 +1020,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
         else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
     else if (s == "--bgzf") a.bgzf = true;
-    else if (s == "--bedgraph") throw Error(MKP_E_UNSUPPORTED, s + " is handled by the reference's Rust writers and is outside the device path");
+    else if (s == "--bedgraph") a.bedgraph = true;
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);
   }
