@@ -36,7 +36,7 @@ uint64_t fnv64(const std::string& s) { uint64_t h = 1469598103934665603ull; for 
 }  // namespace
 
 struct mkp_dev_ingest {
-  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr};
+  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr}, inf_done = nullptr, crc_done = nullptr;
   static constexpr size_t kPiece = (size_t)2 << 20, kSlots = 16;   // 64 MiB page-locked in all (allocating it is part of a fresh context's first ingest)   // upload staging: two halves of kSlots pieces
   Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
   DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig, parts;
@@ -55,7 +55,8 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-  for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + CRC + chain kernels, for the trace)
+  for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + chain kernels, for the trace)
+  if (hipEventCreateWithFlags(&d->inf_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->crc_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   return d.release();
 }
 
@@ -68,6 +69,8 @@ void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
   if (d->up_done) (void)hipEventDestroy(d->up_done);
   for (auto& e : d->kev) if (e) (void)hipEventDestroy(e);
+  if (d->inf_done) (void)hipEventDestroy(d->inf_done);
+  if (d->crc_done) (void)hipEventDestroy(d->crc_done);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
   delete d;
@@ -146,9 +149,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   }
   const std::vector<MkpSeg> segs = mkp_plan_segments<MkpSeg>(plan);
   d->zblk.ensure(nb * sizeof(BgzfBlk)); d->zstat.ensure(nb * 4 + 16); d->raw.ensure(plan.raw_total + 64); d->segs.ensure(ns * sizeof(MkpSeg)); d->seg_cnt.ensure((ns + 1) * 4); d->tot.ensure(sizeof(MkpIngestTotals));
-  const size_t small_need = nb * sizeof(BgzfBlk) + ns * sizeof(MkpSeg) + nb * 4 + sizeof(MkpIngestTotals) + 256;
+  const size_t small_need = nb * sizeof(BgzfBlk) + ns * sizeof(MkpSeg) + 2 * (nb * 4 + 64) + sizeof(MkpIngestTotals) + 256;
   d->small.ensure(small_need + small_need / 4);
-  uint8_t* sm = (uint8_t*)d->small.p; uint8_t* sm_blk = sm; uint8_t* sm_seg = sm + nb * sizeof(BgzfBlk); uint8_t* sm_tot = sm_seg + ns * sizeof(MkpSeg); uint8_t* sm_stat = sm_tot + ((sizeof(MkpIngestTotals) + 63) & ~(size_t)63);
+  uint8_t* sm = (uint8_t*)d->small.p; uint8_t* sm_blk = sm; uint8_t* sm_seg = sm + nb * sizeof(BgzfBlk); uint8_t* sm_tot = sm_seg + ns * sizeof(MkpSeg); uint8_t* sm_stat = sm_tot + ((sizeof(MkpIngestTotals) + 63) & ~(size_t)63); uint8_t* sm_stat0 = sm_stat + ((nb * 4 + 63) & ~(size_t)63);
   memcpy(sm_blk, blks.data(), nb * sizeof(BgzfBlk)); memcpy(sm_seg, segs.data(), ns * sizeof(MkpSeg));
   ok(hipMemcpyAsync(d->zblk.p, sm_blk, nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, d->stream), "H2D");
   ok(hipMemcpyAsync(d->segs.p, sm_seg, ns * sizeof(MkpSeg), hipMemcpyHostToDevice, d->stream), "H2D");
@@ -159,21 +162,33 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   auto t_inf = std::chrono::steady_clock::now();
   ok(hipEventRecord(d->kev[0], d->stream), "event");
   ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch");
-  ok(mkp_launch_crc32(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
+  // the CRC-32 of every block runs on the upload stream (idle by now), beside the record kernels below: its verdict — and the decoders'
+  // status words it is OR-ed into — is only read when something has gone wrong, or at the very end (corrupt())
+  ok(hipEventRecord(d->inf_done, d->stream), "event");
+  ok(hipStreamWaitEvent(d->up_stream, d->inf_done, 0), "wait for the inflate");
+  ok(mkp_launch_crc32(d->up_stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
   MkpIngestParams P; memset(&P, 0, sizeof(P));
   P.raw_len = plan.raw_total; P.tid = (int32_t)tid; P.beg = (int32_t)std::min<uint32_t>(beg, 0x7fffffffu); P.end = (int32_t)std::min<uint32_t>(end, 0x7fffffffu); P.n_ref = (int32_t)bam.ref_names.size(); P.n_seg = (uint32_t)ns;
   ok(mkp_launch_ingest_count(d->stream, d->raw.as<uint8_t>(), &P, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->tot.as<MkpIngestTotals>()), "count launch");
   MkpIngestTotals* tot = (MkpIngestTotals*)sm_tot;
   ok(hipEventRecord(d->kev[1], d->stream), "event");
-  ok(hipMemcpyAsync(sm_stat, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+  ok(hipMemcpyAsync(sm_stat, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->up_stream), "D2H");
+  ok(hipEventRecord(d->crc_done, d->up_stream), "event");
+  ok(hipMemcpyAsync(sm_stat0, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->stream), "D2H");   // the decoders' own status (low byte; the CRC kernel may be OR-ing bit 8 in meanwhile)
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "inflate sync");
   out->ms_inflate = ms_since(t_inf);
   { float kms = 0; if (hipEventElapsedTime(&kms, d->kev[0], d->kev[1]) == hipSuccess) out->ms_kernel = kms; }
   bam.bytes_inflated += plan.raw_total; bam.bytes_inflated_device += plan.raw_total;
-  { const uint32_t* st = (const uint32_t*)sm_stat; for (size_t i = 0; i < nb; i++) if (st[i] != 0) throw Error(MKP_E_IO, "corrupt BGZF data in " + bam.path() +
-        ((st[i] & 0x100u) ? " (CRC32 mismatch" : " (decoder status " + std::to_string(st[i] & 0xffu)) + ", block at " + std::to_string(plan.blks[i].coff) + ")"); }
+  // whatever leaves this function early must not leave the CRC kernel reading buffers the next ingest rewrites
+  struct CrcJoin { hipEvent_t ev; ~CrcJoin() { (void)hipEventSynchronize(ev); } } crc_join{d->crc_done};
+  auto corrupt = [&]() {   // block decoder status / CRC verdict: a corrupt block is what gets reported, whatever the record kernels made of its bytes
+    ok(hipEventSynchronize(d->crc_done), "crc sync");
+    const uint32_t* st = (const uint32_t*)sm_stat; for (size_t i = 0; i < nb; i++) if (st[i] != 0) throw Error(MKP_E_IO, "corrupt BGZF data in " + bam.path() +
+        ((st[i] & 0x100u) ? " (CRC32 mismatch" : " (decoder status " + std::to_string(st[i] & 0xffu)) + ", block at " + std::to_string(plan.blks[i].coff) + ")"); };
+  { const uint32_t* st0 = (const uint32_t*)sm_stat0; bool bad = false; for (size_t i = 0; i < nb && !bad; i++) bad = (st0[i] & 0xffu) != 0; if (bad) corrupt(); }   // a block that did not inflate: nothing behind it is worth parsing
   auto check = [&](uint32_t err) {
+    if (err) corrupt();
     if (err & MKP_IE_TRUNCATED) throw Error(MKP_E_IO, "truncated BAM record at the end of " + bam.path());
     if (err & MKP_IE_CORRUPT) throw Error(MKP_E_IO, "corrupt BAM record");
     if (err & MKP_IE_CHAIN) throw Error(MKP_E_IO, "the BAM index does not match the file (a record chain misses an indexed record start): " + bam.path() + ".bai");
@@ -220,6 +235,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "pack sync");
   check(tot->err);
+  corrupt();
   out->ms_pack = ms_since(t_scan);
   // ---- digest -> what the planner reads: layout ids (this shard's own table; mkp_internal_shard_attach maps them into the context's), flags
   auto t_dig = std::chrono::steady_clock::now();

@@ -67,8 +67,9 @@ def test_same_name_in_different_intervals_is_two_reads(oracle_bin, tmp_path):
     assert e.value.status == -3 and "read name" in str(e.value)
 
 
-@pytest.mark.parametrize("flag", [["--bedgraph"]])
-def test_writer_side_flags_are_refused(tmp_path, flag):
-    with pytest.raises(modkit_amd.MkpError) as e:
-        modkit_amd.pileup([BC, str(tmp_path / "o.bed"), "--no-filtering"] + flag)
-    assert e.value.status == -3
+def test_writer_side_flag_combinations_are_refused(tmp_path):
+    # --bedgraph writes a directory of files: no header line, no stdout (subcommand.rs:328-363); the files themselves: tests/test_gpu_bedgraph.py
+    for flags in (["--bedgraph", "--with-header"], ["--bedgraph", "--mixed-delim"], ["--bedgraph", "--bgzf"]):
+        with pytest.raises(modkit_amd.MkpError) as e:
+            modkit_amd.pileup([BC, str(tmp_path / "o"), "--no-filtering"] + flags)
+        assert e.value.status == -1, flags
