@@ -1033,6 +1033,17 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
 
 }  // namespace
 
+// (tests) the --bedgraph writer alone: rows in, files out — no device involved
+extern "C" int mkp_internal_bedgraph_write(const char* dir, const char* prefix, int groupings, const char* const* motif_labels, uint32_t n_labels, const char* chrom, const mkp_rows* rows) {
+  if (!dir || !chrom || !rows) return MKP_E_INVALID;
+  try {
+    BedGraphOut bg; bg.dir = dir; bg.prefix = prefix ? prefix : ""; bg.groupings = groupings != 0;
+    for (uint32_t k = 0; k < n_labels; k++) bg.labels.push_back(motif_labels[k]);
+    bg.write(chrom, *rows); bg.finish();
+    return MKP_OK;
+  } catch (const Error& e) { return e.status; } catch (const std::exception&) { return MKP_E_INVALID; }
+}
+
 extern "C" int mkp_pileup_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len) {
   auto fail = [&](int st, const std::string& m) { if (errbuf && errbuf_len) { snprintf(errbuf, errbuf_len, "%s", m.c_str()); } return st; };
   try {
