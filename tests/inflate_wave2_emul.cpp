@@ -36,7 +36,7 @@ int build(const uint8_t* lens, int n, uint16_t* tab, uint32_t tab_bits, uint16_t
   for (int s = 0; s < n; s++) if (lens[s]) count[lens[s]]++;
   uint32_t next_code[16], offs[16]; int left = 1; uint32_t code = 0, off = 0, used = 0;
   next_code[0] = 0; offs[0] = 0;
-  for (int l = 1; l <= 15; l++) { const uint32_t c = count[l]; left = (left << 1) - (int)c; code = (code + (l > 1 ? count[l - 1] : 0u)) << 1; next_code[l] = code; offs[l] = off; off += c; used += c; }
+  for (int l = 1; l <= 15; l++) { const uint32_t c = count[l]; left = left * 2 - (int)c; code = (code + (l > 1 ? count[l - 1] : 0u)) << 1; next_code[l] = code; offs[l] = off; off += c; used += c; }
   if (left < 0) return left;
   if (used == 0) return 0;
   for (int s = 0; s < n; s++) {
