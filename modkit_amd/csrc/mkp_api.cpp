@@ -180,12 +180,14 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
 }  // namespace
 extern "C" hipError_t mkp_launch_inflate2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one thread per block, second edition
 extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one wave per block, speculative symbol decode
+extern "C" hipError_t mkp_launch_inflate_wave3(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // the same with an 8 KiB ring (ten waves per CU), far matches from the flushed output
 hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
   static const char* force = getenv("MKP_INFLATE_KERNEL");
   if (force && !strcmp(force, "wave")) return mkp_launch_inflate_wave(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread")) return mkp_launch_inflate(st, in, blks, n, out, status);
   if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
   if (force && !strcmp(force, "wave2")) return mkp_launch_inflate_wave2(st, in, blks, n, out, status);
+  if (force && !strcmp(force, "wave3")) return mkp_launch_inflate_wave3(st, in, blks, n, out, status);
   return n >= 28000u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave2(st, in, blks, n, out, status);
 }
 namespace {

@@ -22,8 +22,9 @@
 struct MkpBgzfBlock { unsigned long long in_off; unsigned long long out_off; uint32_t in_len; uint32_t out_len; };
 
 namespace {
-struct Wave2Lds {
-  uint8_t ring[RING];
+template <uint32_t RINGSZ>
+struct SpecLds {
+  uint8_t ring[RINGSZ];
   uint16_t lit[1u << LIT_BITS];
   uint16_t dist[1u << DIST_BITS];
   uint16_t lcount[16], dcount[16];
@@ -31,6 +32,20 @@ struct Wave2Lds {
   uint8_t lens[320];
   uint32_t inw[256];   // input bytes [lo, lo + 1024), byte x at inw-byte x mod 1024
 };
+
+// ring -> global, output bytes [from, to): 16 bytes per lane and step (mkp_inflate_wave_common.hpp's flush for a ring of RINGSZ bytes)
+template <uint32_t RINGSZ>
+__device__ __forceinline__ void flush_ring(const uint8_t* ring, uint8_t* __restrict__ o, uint32_t from, uint32_t to, int lane) {
+  uint32_t a = from;
+  if (a & 15u) { const uint32_t head = min(to, (a + 15u) & ~15u); for (uint32_t k = a + (uint32_t)lane; k < head; k += 64u) o[k] = ring[k & (RINGSZ - 1u)]; a = head; }
+  const uint32_t units = (to - a) >> 4;
+  for (uint32_t u = (uint32_t)lane; u < units; u += 64u) { const uint32_t at = a + 16u * u; uint4 v = *reinterpret_cast<const uint4*>(ring + (at & (RINGSZ - 1u))); __builtin_memcpy(o + at, &v, 16); }
+  for (uint32_t k = a + 16u * units + (uint32_t)lane; k < to; k += 64u) o[k] = ring[k & (RINGSZ - 1u)];
+}
+
+// an output byte this wave flushed earlier, read back from global memory past the vector L1 (the flush's stores are write-through; an
+// agent-scope load does not look at L1 lines that may predate them)
+__device__ __forceinline__ uint32_t far_byte(const uint8_t* p) { return (uint32_t)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ unsigned long long sgpr64(unsigned long long v) {
   return (unsigned long long)sgpr((uint32_t)v) | ((unsigned long long)sgpr((uint32_t)(v >> 32)) << 32);
@@ -96,7 +111,8 @@ __device__ __forceinline__ int canon_sym(uint32_t bits, const uint16_t* count, c
 
 // the token at bit q, decoded by the wave as one (uniform; any code length): err = 0 or the status to report
 struct OneTok { uint32_t err, bits, kind, val, dist; };   // kind MKP_TK_*; val = literal byte | match length
-__device__ __forceinline__ OneTok one_token(const In2& in, const Wave2Lds& L, uint32_t q) {
+template <class LDS>
+__device__ __forceinline__ OneTok one_token(const In2& in, const LDS& L, uint32_t q) {
   OneTok r; r.err = 0; r.bits = 0; r.kind = MKP_TK_EOB; r.val = 0; r.dist = 0;
   const unsigned long long bits = in.peek(q);
   uint32_t e = sgpr(L.lit[(uint32_t)bits & ((1u << LIT_BITS) - 1u)]), l = e & 15u; int sym = (int)(e >> 4);
@@ -120,9 +136,15 @@ __device__ __forceinline__ OneTok one_token(const In2& in, const Wave2Lds& L, ui
 }  // namespace
 
 // status[i]: as mkp_inflate_wave — 0 ok, 1 input exhausted, 2 bad block type / stored length, 3 bad code lengths, 4 bad symbol, 5 distance too far, 6 output size mismatch
-extern "C" __global__ void __launch_bounds__(64)
-mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) Wave2Lds L;
+//
+// RINGSZ = 32768, FARM = false: the whole DEFLATE window in LDS, four waves per CU (mkp_inflate_wave2).
+// RINGSZ = 8192, FARM = true (mkp_inflate_wave3, MKP_INFLATE_KERNEL=wave3): ten waves per CU; the ring goes out a quarter at a time, a match
+// further back than the ring takes its bytes from the flushed output (always flushed: it lies more than RINGSZ - 128 back, the unflushed
+// tail is at most a quarter + one pass), one agent-scope load for all such lanes of a window.
+template <uint32_t RINGSZ, bool FARM>
+__device__ __forceinline__ void inflate_wave_spec(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) SpecLds<RINGSZ> L;
+  constexpr uint32_t RING = RINGSZ, FLQ = RINGSZ >= 32768u ? RINGSZ / 2u : RINGSZ / 4u, NEAR = RINGSZ - 128u, FARBIT = 0x40000000u;
   const uint32_t bi = blockIdx.x;
   if (bi >= n_blocks) return;
   const int lane = (int)threadIdx.x;
@@ -136,7 +158,10 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
   // the output window: lane j < fill owes ring[(w - fill + j) & M] its byte — sv = LITERAL | value, or the ring position it is copied from
   constexpr uint32_t LITERAL = MKP_SV_LITERAL, M = RING - 1u;
   uint32_t sv = 0, fill = 0;
-#define WINDOW_OUT() do { if (fill) { const uint32_t r_ = L.ring[sv & M]; if ((uint32_t)lane < fill) L.ring[(w - fill + (uint32_t)lane) & M] = (uint8_t)((sv & LITERAL) ? sv : r_); fill = 0; } } while (0)
+#define WINDOW_BYTES(N) do { uint32_t r_ = L.ring[sv & M]; \
+    if (FARM) { const bool far_ = (uint32_t)lane < (N) && (sv & (LITERAL | FARBIT)) == FARBIT; if (__builtin_amdgcn_ballot_w64(far_)) { if (far_) r_ = far_byte(o + (sv & 0xfffffu)); } } \
+    if ((uint32_t)lane < (N)) L.ring[(w - (N) + (uint32_t)lane) & M] = (uint8_t)((sv & LITERAL) ? sv : r_); } while (0)
+#define WINDOW_OUT() do { if (fill) { WINDOW_BYTES(fill); fill = 0; } } while (0)
   for (uint32_t guard = 0; guard <= bk.in_len && !err; guard++) {
     h.load(in, pos, lane);
     const uint32_t last = h.get(in, pos, 1, lane), type = h.get(in, pos, 2, lane);
@@ -146,9 +171,10 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
       if ((len ^ 0xffffu) != nlen || w + len > cap) { err = 2; break; }
       const uint32_t at = pos >> 3;
       if ((unsigned long long)at + len > bk.in_len) { err = 1; break; }
-      WINDOW_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, w, lane);
+      WINDOW_OUT(); LDS_SYNC(); flush_ring<RINGSZ>(L.ring, o, flushed, w, lane);
       for (uint32_t k = (uint32_t)lane; k < len; k += 64u) { const uint8_t v = in.p[at + k]; o[w + k] = v; L.ring[(w + k) & (RING - 1u)] = v; }
       w += len; flushed = w; pos = 8u * (at + len);
+      if (FARM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (later far reads may want these bytes)
     } else if (type == 1 || type == 2) {
       int nlen_codes = 288, ndist_codes = 30;
       if (type == 1) {   // fixed codes (§3.2.6)
@@ -214,10 +240,10 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
           const uint32_t ol = a >> 8; const bool lit = (a & MKP_TA_LIT) != 0u;
           if (!((a & MKP_TA_WIN) && w + ol <= cap && (lit || b <= w))) { special = true; break; }
           const bool out = f0 + ol > 64u || (!lit && b < f0 + ol);   // no room — or the match reads bytes that are still in the window (f0 > 0 either way)
-          if (out) { const uint32_t r_ = L.ring[sv & M]; if ((uint32_t)lane < f0) L.ring[(w - f0 + (uint32_t)lane) & M] = (uint8_t)((sv & LITERAL) ? sv : r_); }
+          if (out) WINDOW_BYTES(f0);
           const uint32_t f1 = out ? 0u : f0;
           const uint32_t rel = (uint32_t)lane - f1;
-          const uint32_t nsv = lit ? b : ((w - b + rel) & M);
+          const uint32_t nsv = lit ? b : (FARM && b > NEAR) ? (FARBIT | (w - b + rel)) : ((w - b + rel) & M);
           if (rel < ol) sv = nsv;
           fill = f1 + ol; w += ol; i += a & 63u;
         } while (i < 64u);
@@ -238,7 +264,9 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
             if (w + len > cap) { err = 6; break; }
             const uint32_t src0 = w - dist;
             WINDOW_OUT();
-            if (dist >= len) {
+            if (FARM && dist > NEAR) {   // (dist >= len here: the flushed output is the source)
+              for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) L.ring[(w + k2) & M] = (uint8_t)far_byte(o + src0 + k2);
+            } else if (dist >= len) {
               for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) L.ring[(w + k2) & M] = L.ring[(src0 + k2) & M];
             } else if (dist == 1u) {
               const uint8_t v = L.ring[src0 & M];
@@ -250,16 +278,33 @@ mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __re
           }
         }
         // a 16 KiB half of the ring is complete: it goes out in one coalesced sweep, long before the write position comes round to it again
-        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); WINDOW_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, upto, lane); flushed = upto; }
+        if ((w & ~(FLQ - 1u)) > flushed) { const uint32_t upto = w & ~(FLQ - 1u); WINDOW_OUT(); LDS_SYNC(); flush_ring<RINGSZ>(L.ring, o, flushed, upto, lane); flushed = upto;
+          if (FARM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
       }
     } else { err = 2; break; }
     if (err || last) break;
   }
-  WINDOW_OUT(); LDS_SYNC(); flush(L.ring, o, flushed, w, lane);
+  WINDOW_OUT(); LDS_SYNC(); flush_ring<RINGSZ>(L.ring, o, flushed, w, lane);
   if (!err && w != cap) err = 6;
   if (!err && pos > in_bits) err = 1;
   if (lane == 0) status[bi] = err;
 #undef WINDOW_OUT
+#undef WINDOW_BYTES
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+mkp_inflate_wave2(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+  inflate_wave_spec<32768u, false>(in_bytes, blocks, n_blocks, out, status);
+}
+extern "C" __global__ void __launch_bounds__(64)
+mkp_inflate_wave3(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+  inflate_wave_spec<8192u, true>(in_bytes, blocks, n_blocks, out, status);
+}
+
+extern "C" hipError_t mkp_launch_inflate_wave3(hipStream_t st, const uint8_t* in, const void* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status) {
+  if (!n_blocks) return hipSuccess;
+  hipLaunchKernelGGL(mkp_inflate_wave3, dim3(n_blocks), dim3(64), 0, st, in, (const MkpBgzfBlock*)blocks, n_blocks, out, status);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t st, const uint8_t* in, const void* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status) {

@@ -18,11 +18,14 @@
 #include "../modkit_amd/csrc/mkp_inflate_tok.hpp"
 
 namespace {
-constexpr uint32_t RING = 32768u, LIT_BITS = 11u, DIST_BITS = 9u;
+constexpr uint32_t RING_MAX = 32768u, LIT_BITS = 11u, DIST_BITS = 9u;
 constexpr int W = 64;
+// the two instantiations of the kernel body: wave2 = the whole 32 KiB window in the ring; wave3 (WAVE=3 in the environment) = an 8 KiB ring
+// flushed a quarter at a time, matches further back than the ring read from the flushed output
+uint32_t RING = 32768u; bool FARM = false;
 
 struct Lds {
-  uint8_t ring[RING];
+  uint8_t ring[RING_MAX];
   uint16_t lit[1u << LIT_BITS], dist[1u << DIST_BITS];
   uint16_t lcount[16], dcount[16], lsym[288], dsym[32];
   uint8_t lens[320];
@@ -118,7 +121,7 @@ OneTok one_token(const In2& in, const Lds& L, uint32_t q) {
   return r;
 }
 
-struct Stats { uint64_t windows = 0, window_bytes = 0, passes = 0, tokens = 0, slow = 0, matches = 0, long_matches = 0, early_out = 0, refills = 0, seeks = 0; } g_stats;
+struct Stats { uint64_t far_reads = 0, far_windows = 0, windows = 0, window_bytes = 0, passes = 0, tokens = 0, slow = 0, matches = 0, long_matches = 0, early_out = 0, refills = 0, seeks = 0; } g_stats;
 
 // the kernel, one block; returns the status, fills `out` (cap bytes)
 uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t cap) {
@@ -126,17 +129,24 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
   In2 in; in.p = inp; in.n = in_len; in.w = L.inw; in.seek(0);
   Hdr h; uint32_t pos = 0, w = 0, err = 0, flushed = 0;
   const uint32_t in_bits = 8u * in_len;
-  constexpr uint32_t LITERAL = MKP_SV_LITERAL, M = RING - 1u;
+  constexpr uint32_t LITERAL = MKP_SV_LITERAL, FARBIT = 0x40000000u;
+  const uint32_t M = RING - 1u, FLQ = RING >= 32768u ? RING / 2u : RING / 4u, NEAR = RING - 128u;
   uint32_t sv[W] = {0}, fill = 0;
+  auto far_byte = [&](uint32_t at) -> uint32_t {   // the flushed output: what has not been flushed is not there yet
+    if (at >= flushed) { fprintf(stderr, "far read of byte %u, flushed %u, w %u\n", at, flushed, w); exit(3); }
+    g_stats.far_reads++; return o[at]; };
   auto window_out = [&]() {
     if (fill) {
       g_stats.windows++; g_stats.window_bytes += fill;
-      uint32_t r[W]; for (uint32_t lane = 0; lane < W; lane++) r[lane] = L.ring[sv[lane] & M];
+      uint32_t r[W]; bool anyfar = false;
+      for (uint32_t lane = 0; lane < W; lane++) r[lane] = L.ring[sv[lane] & M];
+      if (FARM) for (uint32_t lane = 0; lane < fill; lane++) if ((sv[lane] & (LITERAL | FARBIT)) == FARBIT) { r[lane] = far_byte(sv[lane] & 0xfffffu); anyfar = true; }
+      if (anyfar) g_stats.far_windows++;
       for (uint32_t lane = 0; lane < W; lane++) if (lane < fill) L.ring[(w - fill + lane) & M] = (uint8_t)((sv[lane] & LITERAL) ? sv[lane] : r[lane]);
       fill = 0;
     }
   };
-  auto flush = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) o[k] = L.ring[k & (RING - 1u)]; };
+  auto flush = [&](uint32_t from, uint32_t to) { for (uint32_t k = from; k < to; k++) o[k] = L.ring[k & M]; };
   for (uint32_t guard = 0; guard <= in_len && !err; guard++) {
     h.load(in, pos);
     const uint32_t last = h.get(in, pos, 1), type = h.get(in, pos, 2);
@@ -147,7 +157,7 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
       const uint32_t at = pos >> 3;
       if ((unsigned long long)at + len > in_len) { err = 1; break; }
       window_out(); flush(flushed, w);
-      for (uint32_t k = 0; k < len; k++) { const uint8_t v = inp[at + k]; o[w + k] = v; L.ring[(w + k) & (RING - 1u)] = v; }
+      for (uint32_t k = 0; k < len; k++) { const uint8_t v = inp[at + k]; o[w + k] = v; L.ring[(w + k) & M] = v; }
       w += len; flushed = w; pos = 8u * (at + len);
     } else if (type == 1 || type == 2) {
       int nlen_codes = 288, ndist_codes = 30;
@@ -205,7 +215,7 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
           if (!((a & MKP_TA_WIN) && w + ol <= cap && (lit || b <= w))) { special = true; break; }
           g_stats.tokens++; if (!lit) g_stats.matches++;
           if (fill + ol > 64u || (!lit && b < fill + ol)) { if (!lit && b < fill + ol) g_stats.early_out++; window_out(); }
-          for (uint32_t lane = 0; lane < W; lane++) { const uint32_t rel = lane - fill; const uint32_t nsv = lit ? b : ((w - b + rel) & M); if (rel < ol) sv[lane] = nsv; }
+          for (uint32_t lane = 0; lane < W; lane++) { const uint32_t rel = lane - fill; const uint32_t nsv = lit ? b : (FARM && b > NEAR) ? (FARBIT | (w - b + rel)) : ((w - b + rel) & M); if (rel < ol) sv[lane] = nsv; }
           fill += ol; w += ol; i += a & 63u;
         } while (i < 64u);
         pos += i;
@@ -228,13 +238,13 @@ uint32_t wave2_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
             window_out();
             for (uint32_t k0 = 0; k0 < len; k0 += 64u) {   // lanes in steps of 64: all loads of a step before its stores
               uint8_t v[W];
-              for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) v[k2 - k0] = dist >= len ? L.ring[(src0 + k2) & M] : dist == 1u ? L.ring[src0 & M] : L.ring[(src0 + k2 % dist) & M];
+              for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) v[k2 - k0] = (FARM && dist > NEAR) ? (uint8_t)far_byte(src0 + k2) : dist >= len ? L.ring[(src0 + k2) & M] : dist == 1u ? L.ring[src0 & M] : L.ring[(src0 + k2 % dist) & M];
               for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) L.ring[(w + k2) & M] = v[k2 - k0];
             }
             w += len;
           }
         }
-        if ((w & ~(RING / 2u - 1u)) > flushed) { const uint32_t upto = w & ~(RING / 2u - 1u); window_out(); flush(flushed, upto); flushed = upto; }
+        if ((w & ~(FLQ - 1u)) > flushed) { const uint32_t upto = w & ~(FLQ - 1u); window_out(); flush(flushed, upto); flushed = upto; }
         if (w - flushed > RING) { fprintf(stderr, "ring overrun: %u bytes unflushed\n", w - flushed); exit(3); }
       }
     } else { err = 2; break; }
@@ -273,6 +283,7 @@ std::vector<uint8_t> slurp(const char* path) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  if (getenv("WAVE") && atoi(getenv("WAVE")) == 3) { RING = 8192u; FARM = true; }
   if (argc < 3) { fprintf(stderr, "usage: inflate_wave2_emul bgzf FILE... | corpus FILE\n"); return 2; }
   const std::string mode = argv[1];
   uint64_t blocks = 0, bytes = 0, accepted = 0, rejected = 0;
@@ -313,6 +324,7 @@ int main(int argc, char** argv) {
     }
   } else return 2;
   printf("ok %llu %llu %llu %llu\n", (unsigned long long)blocks, (unsigned long long)bytes, (unsigned long long)accepted, (unsigned long long)rejected);
+  if (FARM) fprintf(stderr, "ring %u: far reads %llu in %llu windows; ", RING, (unsigned long long)g_stats.far_reads, (unsigned long long)g_stats.far_windows);
   fprintf(stderr, "windows %llu (%.1f bytes each) ", (unsigned long long)g_stats.windows, g_stats.windows ? (double)g_stats.window_bytes / (double)g_stats.windows : 0.0);
   fprintf(stderr, "passes %llu tokens %llu (%.2f per pass) matches %llu long %llu early-out %llu special %llu refills %llu seeks %llu\n", (unsigned long long)g_stats.passes, (unsigned long long)g_stats.tokens,
           g_stats.passes ? (double)g_stats.tokens / (double)g_stats.passes : 0.0, (unsigned long long)g_stats.matches, (unsigned long long)g_stats.long_matches, (unsigned long long)g_stats.early_out,

@@ -114,8 +114,9 @@ c.close(); print('ok', n, len(good), bad)
 
 
 def test_all_device_kernels(tmp_path):
-    """mkp_bgzf_inflate picks its kernel by launch size; all four — wave, thread, thread2 (the second edition of the per-thread decoder),
-    wave2 (one wave per block, speculative symbol decode) — are forced here through MKP_INFLATE_KERNEL in fresh processes (the variable
+    """mkp_bgzf_inflate picks its kernel by launch size; all five — wave, thread, thread2 (the second edition of the per-thread decoder),
+    wave2 (one wave per block, speculative symbol decode), wave3 (the same with an 8 KiB ring and far matches read from the flushed
+    output; opt-in) — are forced here through MKP_INFLATE_KERNEL in fresh processes (the variable
     is read once) and checked against gzip on the reference's BAMs and against zlib on the DEFLATE corpus of
     tests/test_inflate_wave2_emul.py: every block type, level and strategy, multi-block streams, long stored blocks, and ~500 corrupted
     or random streams whose acceptance must be zlib's."""
@@ -128,7 +129,7 @@ def test_all_device_kernels(tmp_path):
     pickle.dump(recs, open(pk, "wb"))
     here = os.path.dirname(os.path.abspath(__file__))
     script = KERNEL_SCRIPT % (os.path.dirname(here), FIX, pk)
-    for kernel in ("wave2", "wave", "thread", "thread2"):
+    for kernel in ("wave2", "wave3", "wave", "thread", "thread2"):
         p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, MKP_INFLATE_KERNEL=kernel, PYTHONPATH=here + os.pathsep + os.environ.get("PYTHONPATH", "")))
         assert p.returncode == 0 and p.stdout.startswith("ok"), (kernel, p.stdout[-200:], p.stderr[-600:])
         n, good, bad = map(int, p.stdout.split()[1:4])

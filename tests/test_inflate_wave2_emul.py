@@ -1,4 +1,4 @@
-"""mkp_inflate_wave2 (one wave per BGZF block, speculative symbol decode) checked on the CPU: tests/inflate_wave2_emul.cpp restates the
+"""mkp_inflate_wave2 / mkp_inflate_wave3 (one wave per BGZF block, speculative symbol decode; 32 KiB ring | 8 KiB ring + far reads) checked on the CPU: tests/inflate_wave2_emul.cpp restates the
 kernel's control flow over 64 emulated lanes around the per-lane functions the kernel itself compiles (mkp_inflate_tok.hpp) and compares
 every block with zlib — output and acceptance.  The GPU run of the same corpus is tests/test_gpu_inflate.py."""
 import os
@@ -69,26 +69,36 @@ def write_corpus(path, recs):
             f.write(z)
 
 
-def test_every_block_of_the_golden_bams(emul):
+MODES = pytest.mark.parametrize("wave", ["2", "3"], ids=["wave2_ring32k", "wave3_ring8k_far"])   # the two instantiations of the kernel body
+
+
+def run_emul(emul, args, wave):
+    return subprocess.run([emul] + args, capture_output=True, text=True, env=dict(os.environ, WAVE=wave))
+
+
+@MODES
+def test_every_block_of_the_golden_bams(emul, wave):
     import glob
     bams = sorted(glob.glob(os.path.join(HERE, "golden", "**", "*.bam"), recursive=True))
-    p = subprocess.run([emul, "bgzf"] + bams, capture_output=True, text=True)
+    p = run_emul(emul, ["bgzf"] + bams, wave)
     assert p.returncode == 0 and p.stdout.startswith("ok "), p.stderr[-500:]
     blocks, nbytes, acc, rej = map(int, p.stdout.split()[1:5])
     assert blocks > 100 and rej == 0
 
 
-def test_deflate_corpus_and_corruptions(emul, tmp_path):
+@MODES
+def test_deflate_corpus_and_corruptions(emul, tmp_path, wave):
     recs = deflate_corpus()
     path = str(tmp_path / "corpus.bin")
     write_corpus(path, recs)
-    p = subprocess.run([emul, "corpus", path], capture_output=True, text=True)
+    p = run_emul(emul, ["corpus", path], wave)
     assert p.returncode == 0 and p.stdout.startswith("ok "), p.stderr[-800:]
     blocks, nbytes, acc, rej = map(int, p.stdout.split()[1:5])
     assert blocks == len(recs) and acc > 700 and rej > 200, p.stdout
 
 
-def test_fuzzed_bams(emul, tmp_path):
+@MODES
+def test_fuzzed_bams(emul, tmp_path, wave):
     from bamfuzz import Fuzz
     paths = []
     for seed, prof in ((3, "hm_split"), (4, "duplex_hm"), (5, "a_only")):
@@ -97,5 +107,7 @@ def test_fuzzed_bams(emul, tmp_path):
         except Exception:
             bam, _, _ = Fuzz(seed, contigs=(("c", 300000),), n_reads=1500, mean_len=3000, profile="hm_split").write(str(tmp_path / ("f%d" % seed)))
         paths.append(bam)
-    p = subprocess.run([emul, "bgzf"] + paths, capture_output=True, text=True)
+    p = run_emul(emul, ["bgzf"] + paths, wave)
     assert p.returncode == 0 and p.stdout.startswith("ok "), p.stderr[-500:]
+    if wave == "3":
+        assert "far reads" in p.stderr and int(p.stderr.split("far reads ")[1].split()[0]) > 1000   # (the far path is exercised)
