@@ -173,10 +173,10 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
       "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
 }
 
-// BGZF inflate on the device.  One wave per block with speculative token decode (mkp_inflate_wave2.hip: 3.2 ms per block, 1 024 at a
-// time — 16 000 blocks in 52 ms, 4 000 in 14 ms) for shard-sized launches, one thread per block (mkp_inflate.hip, second edition: ~80 ms
-// per launch whatever its size, 89 ms for a whole file of 54 000 blocks) from 28 000 blocks up.  MKP_INFLATE_KERNEL=wave2|thread2|wave|thread
-// forces one (A/B runs; --stats names it).
+// BGZF inflate on the device.  One wave per block with speculative token decode, 8 KiB ring (mkp_inflate_wave3: ten waves per CU,
+// 16 000 blocks in 27 ms, 4 000 in 9 ms) for shard-sized launches; one thread per block (mkp_inflate.hip, second edition: ~80 ms per launch
+// whatever its size, 91-95 ms for a whole file of 54 000 blocks — wave3 takes 85 ms for that, measured at the very end of round 4) from
+// 28 000 blocks up.  MKP_INFLATE_KERNEL=wave3|wave2|thread2|wave|thread forces one (A/B runs; --stats names it).
 }  // namespace
 extern "C" hipError_t mkp_launch_inflate2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one thread per block, second edition
 extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one wave per block, speculative symbol decode
@@ -188,7 +188,7 @@ hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void
   if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
   if (force && !strcmp(force, "wave2")) return mkp_launch_inflate_wave2(st, in, blks, n, out, status);
   if (force && !strcmp(force, "wave3")) return mkp_launch_inflate_wave3(st, in, blks, n, out, status);
-  return n >= 28000u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave2(st, in, blks, n, out, status);
+  return n >= 28000u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave3(st, in, blks, n, out, status);
 }
 namespace {
 hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
