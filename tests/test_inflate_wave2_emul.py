@@ -22,7 +22,7 @@ def emul(tmp_path_factory):
     return exe
 
 
-def deflate_corpus(seed=5, corrupt=400):
+def deflate_corpus(seed=5, corrupt=400, full_block=False):
     """(payload, expected size) records: every corpus of test_host_deflate at every level and strategy, multi-block streams, long stored
     blocks (the input window's seek path), and corrupted copies."""
     recs = []
@@ -44,6 +44,12 @@ def deflate_corpus(seed=5, corrupt=400):
     mid = nprng.integers(0, 256, 20000, dtype=np.uint8).tobytes()
     recs.append((raw_deflate(a + mid + a, 6), len(a) * 2 + len(mid)))
     recs.append((raw_deflate(mid * 3, 0), len(mid) * 3))
+    if full_block:   # (CPU emulation only) the largest block BGZF allows, 65 536 bytes out: records far apart that repeat, so that matches reach back past an 8 KiB ring
+        rec = nprng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+        big = b"".join(rec[:2000 + 37 * k] + b"%06d" % k for k in range(40))
+        big = (big * 3)[:65536]
+        recs.append((raw_deflate(big, 9), len(big)))
+        recs.append((raw_deflate(big, 1, zlib.Z_FIXED), len(big)))
     base = [r for r in recs if len(r[0]) > 40]
     for trial in range(corrupt):
         z, n = base[rng.randrange(len(base))]
@@ -88,7 +94,7 @@ def test_every_block_of_the_golden_bams(emul, wave):
 
 @MODES
 def test_deflate_corpus_and_corruptions(emul, tmp_path, wave):
-    recs = deflate_corpus()
+    recs = deflate_corpus(full_block=True)
     path = str(tmp_path / "corpus.bin")
     write_corpus(path, recs)
     p = run_emul(emul, ["corpus", path], wave)
