@@ -29,8 +29,6 @@ hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
                              const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
-hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);        // one thread per block
-hipError_t mkp_launch_inflate_wave(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*);   // one wave per block
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
                                   uint32_t, int32_t, int32_t, uint32_t* /*error bits*/);
@@ -173,22 +171,16 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
       "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
 }
 
-// BGZF inflate on the device.  One wave per block with speculative token decode, 8 KiB ring (mkp_inflate_wave3: ten waves per CU,
-// 16 000 blocks in 27 ms, 4 000 in 9 ms) for shard-sized launches; one thread per block (mkp_inflate.hip, second edition: ~80 ms per launch
-// whatever its size, 91-95 ms for a whole file of 54 000 blocks — wave3 takes 85 ms for that, measured at the very end of round 4) from
-// 28 000 blocks up.  MKP_INFLATE_KERNEL=wave3|wave2|thread2|wave|thread forces one (A/B runs; --stats names it).
+// BGZF inflate on the device: mkp_inflate_wave4, one wave per block — speculative token decode, a scalar walk that only marks the chain,
+// all output of a pass placed at once; 4 KiB ring, sixteen waves per CU (round 5; it replaced the five kernels of rounds 2-4 at every
+// launch size).  MKP_INFLATE_KERNEL=wave4_8k|wave4_2k picks another ring size (A/B runs; --stats names it).
 }  // namespace
-extern "C" hipError_t mkp_launch_inflate2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one thread per block, second edition
-extern "C" hipError_t mkp_launch_inflate_wave2(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // one wave per block, speculative symbol decode
-extern "C" hipError_t mkp_launch_inflate_wave3(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);   // the same with an 8 KiB ring (ten waves per CU), far matches from the flushed output
+extern "C" hipError_t mkp_launch_inflate_wave4(hipStream_t, const uint8_t*, const void* /*MkpBgzfBlock[]*/, uint32_t, uint8_t*, uint32_t*, int);
 hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
   static const char* force = getenv("MKP_INFLATE_KERNEL");
-  if (force && !strcmp(force, "wave")) return mkp_launch_inflate_wave(st, in, blks, n, out, status);
-  if (force && !strcmp(force, "thread")) return mkp_launch_inflate(st, in, blks, n, out, status);
-  if (force && !strcmp(force, "thread2")) return mkp_launch_inflate2(st, in, blks, n, out, status);
-  if (force && !strcmp(force, "wave2")) return mkp_launch_inflate_wave2(st, in, blks, n, out, status);
-  if (force && !strcmp(force, "wave3")) return mkp_launch_inflate_wave3(st, in, blks, n, out, status);
-  return n >= 28000u ? mkp_launch_inflate2(st, in, blks, n, out, status) : mkp_launch_inflate_wave3(st, in, blks, n, out, status);
+  if (force && !strcmp(force, "wave4_8k")) return mkp_launch_inflate_wave4(st, in, blks, n, out, status, 8);
+  if (force && !strcmp(force, "wave4_2k")) return mkp_launch_inflate_wave4(st, in, blks, n, out, status, 2);
+  return mkp_launch_inflate_wave4(st, in, blks, n, out, status, 4);
 }
 namespace {
 hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
@@ -1085,7 +1077,7 @@ int mkp_percentile(const float* xs, uint64_t n, float q, float* out) {  // perce
 int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const uint8_t** out, uint64_t* out_len, double* kernel_ms) {
   if (!c || (!bgzf && n_bytes) || !out || !out_len) return MKP_E_INVALID;
   return guarded(c, [&]() {
-    struct Blk { unsigned long long in_off, out_off; uint32_t in_len, out_len; };   // == MkpBgzfBlock (mkp_inflate.hip)
+    struct Blk { unsigned long long in_off, out_off; uint32_t in_len, out_len; };   // == MkpBgzfBlock (mkp_inflate_wave4.hip)
     std::vector<Blk> blks; std::vector<uint32_t> crcs; uint64_t o = 0, total = 0;
     while (o < n_bytes) {   // header walk, as in load_bam (mkp_bam.hpp): gzip magic, FEXTRA with a BC subfield holding BSIZE
       if (o + 18 > n_bytes || bgzf[o] != 31 || bgzf[o + 1] != 139 || bgzf[o + 2] != 8 || !(bgzf[o + 3] & 4)) throw Error(MKP_E_IO, "not BGZF");

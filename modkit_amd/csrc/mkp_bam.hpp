@@ -436,7 +436,7 @@ static inline bool overlaps_parts(const FetchParts& parts, int64_t pos, int64_t 
   return lo < parts.size() && parts[lo].first < end;
 }
 
-// Optional device stage of the indexed fetch (--device-inflate): one window's BGZF blocks inflated on the GPU (mkp_inflate.hip) straight
+// Optional device stage of the indexed fetch (--device-inflate): one window's BGZF blocks inflated on the GPU (mkp_inflate_wave4.hip) straight
 // into the window's host buffer.  false = not done (any block failed, or no device): the host decoder then runs and reports.
 struct InflateBlk { unsigned long long in_off, out_off; uint32_t in_len, out_len; };   // == MkpBgzfBlock
 struct InflateJob { const uint8_t* comp; size_t comp_len; const InflateBlk* blks; size_t n_blks; uint8_t* dst; size_t dtotal; };

@@ -68,7 +68,7 @@ struct Args {
       uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
       bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
-  bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate.hip) instead of the host pool, records back to the host packer */
+  bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate_wave4.hip) instead of the host pool, records back to the host packer */
   bool host_ingest = false, shard_bytes_set = false;   /* --host-ingest (or MKP_HOST_INGEST=1): inflate, cut and pack the shards on the host instead of the device (mkp_ingest.hip) */
   bool bedgraph = false;   /* --bedgraph: the output path is a directory of <code>[_<motif>]_<strand>.bedgraph files (BedGraphWriter, writers.rs:264-381) */
   bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */

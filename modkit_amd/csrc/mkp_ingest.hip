@@ -3,7 +3,7 @@
 // into offsets, and the CRC-32 of the inflated BGZF blocks (htslib checks it on every block the reference reads).
 //
 // Order on the ingest stream, per shard window (host side: mkp_ingest_host.cpp):
-//   inflate (mkp_inflate*.hip) -> mkp_crc32_blocks -> mkp_ingest_count -> mkp_ingest_scan_segs            [host reads n_all]
+//   inflate (mkp_inflate_wave4.hip) -> mkp_crc32_blocks -> mkp_ingest_count -> mkp_ingest_scan_segs            [host reads n_all]
 //   -> mkp_ingest_write -> mkp_ingest_parse -> mkp_ingest_scan_sizes                                       [host reads the array sizes]
 //   -> mkp_ingest_pack                                                                                     [host reads headers + digests]
 #include <hip/hip_runtime.h>
@@ -14,33 +14,79 @@
 struct MkpBgzfBlock { unsigned long long in_off; unsigned long long out_off; uint32_t in_len; uint32_t out_len; };
 
 
-// One wave per BGZF block: the block's bytes split into 64 slices, every lane runs the byte-wise table CRC over its slice (table in LDS),
-// and the slices are joined left to right — crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in the raw (unconditioned) register domain — in six
-// butterfly steps.  Lane 0 takes the odd-sized first slice so that every right-hand operand of a join has the same length per level.
-// status[i] |= 0x100 on a mismatch with the CRC word stored behind the block's payload.
+// CRC-32 of every inflated block against the word behind its payload.  One wave per BGZF block: the block's bytes split into 64 slices, every
+// lane runs a slicing-by-4 table CRC over its slice — one dword per step: four independent LDS probes instead of four dependent ones; the
+// slice may start at any byte, so dwords are loaded aligned, 16 bytes at a time, and brought into place by v_alignbyte — and the slices
+// are joined left to right — crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in the raw (unconditioned) register domain — in six butterfly steps.
+// Lane 0 takes the odd-sized first slice so that every right-hand operand of a join has the same length per level; x^(8 S 2^L) mod P for
+// every slice length S a block can have comes from a table built at compile time (round 4 spent a third of the kernel raising x to that
+// power bit by bit).  status[i] |= 0x100 on a mismatch.
+namespace {
+constexpr uint32_t cx_mulmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+  for (int i = 0; i < 32; i++) { if (a & (0x80000000u >> i)) p ^= b; b = (b & 1u) ? (b >> 1) ^ MKP_CRC_POLY : b >> 1; }
+  return p;
+}
+struct XpowTab { uint32_t v[6][257]; };   // v[L][k] = x^(8 * 4k * 2^L) mod P
+constexpr XpowTab make_xpow() {
+  XpowTab t{};
+  uint32_t step = 0x00000001u;   // x^31 ... the reflected representation has bit 31 = x^0: x^32 = P's low terms; built below from x^8 by squaring
+  uint32_t x8 = 0x00800000u, x16 = cx_mulmod(x8, x8); step = cx_mulmod(x16, x16);   // x^32
+  for (int L = 0; L < 6; L++) {
+    t.v[L][0] = 0x80000000u;   // 1
+    for (int k = 1; k <= 256; k++) t.v[L][k] = cx_mulmod(t.v[L][k - 1], step);
+    step = cx_mulmod(step, step);
+  }
+  return t;
+}
+__device__ const XpowTab kXpow = make_xpow();
+
+// raw CRC register after n bytes from p (any alignment), starting from c; slicing-by-4 tables T[4][256] in LDS
+__device__ __forceinline__ uint32_t crc_slice(const uint8_t* __restrict__ p, uint32_t n, uint32_t c, const uint32_t* __restrict__ T) {
+  const uintptr_t A = (uintptr_t)p; const uint32_t off = (uint32_t)(A & 3u);
+  const uint32_t* __restrict__ q = (const uint32_t*)(A & ~(uintptr_t)3);
+  const uint32_t nd = n >> 2;   // whole dwords of the slice
+  uint4 w; __builtin_memcpy(&w, q, 16);   // (reads up to 19 bytes past the slice: the inflated window has 64 bytes of slack)
+  uint32_t k = 0;
+  for (; k + 4u <= nd; k += 4u) {
+    uint4 nx; __builtin_memcpy(&nx, q + k + 4u, 16);
+    const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, off), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, off), d2 = __builtin_amdgcn_alignbyte(w.w, w.z, off), d3 = __builtin_amdgcn_alignbyte(nx.x, w.w, off);
+    c ^= d0; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
+    c ^= d1; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
+    c ^= d2; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
+    c ^= d3; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
+    w = nx;
+  }
+  // up to three dwords and three bytes left, all inside w and the dword behind it
+  const uint32_t e = q[k + 4u];
+  const uint32_t r[4] = {__builtin_amdgcn_alignbyte(w.y, w.x, off), __builtin_amdgcn_alignbyte(w.z, w.y, off), __builtin_amdgcn_alignbyte(w.w, w.z, off), __builtin_amdgcn_alignbyte(e, w.w, off)};
+  uint32_t j = 0;
+  for (; k < nd; k++, j++) { const uint32_t d = j == 0 ? r[0] : j == 1 ? r[1] : r[2]; c ^= d; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24]; }
+  uint32_t tail = j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
+  for (uint32_t b = 0; b < (n & 3u); b++) { c = T[(c ^ tail) & 0xffu] ^ (c >> 8); tail >>= 8; }
+  return c;
+}
+}  // namespace
+
 extern "C" __global__ void __launch_bounds__(256)
 mkp_crc32_blocks(const uint8_t* __restrict__ zin, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, const uint8_t* __restrict__ raw, uint32_t* __restrict__ status) {
-  __shared__ uint32_t tab[256];
-  { uint32_t c = threadIdx.x; for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ MKP_CRC_POLY : c >> 1; tab[threadIdx.x] = c; }
+  __shared__ uint32_t T[1024];   // T[0..255]: the byte table; T[256 k + i] = the CRC register after byte i followed by k zero bytes
+  { uint32_t c = threadIdx.x; for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ MKP_CRC_POLY : c >> 1; T[threadIdx.x] = c; }
   __syncthreads();
+  for (uint32_t k = 1; k < 4u; k++) { const uint32_t v = T[256u * (k - 1u) + threadIdx.x]; T[256u * k + threadIdx.x] = (v >> 8) ^ T[v & 0xffu]; __syncthreads(); }
   const uint32_t bi = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (bi >= n_blocks) return;
   const MkpBgzfBlock bk = blocks[bi];
   const uint32_t len = bk.out_len;
-  const uint32_t S = (len / 64u) & ~3u;                 // slice of lanes 1..63
+  const uint32_t S = (len / 64u) & ~3u;                 // slice of lanes 1..63 (<= 1024)
   const uint32_t first = len - 63u * S;                 // lane 0
-  const uint8_t* p = raw + bk.out_off + (lane ? first + (lane - 1u) * S : 0u);
-  const uint32_t n = lane ? S : first;
-  uint32_t c = lane ? 0u : 0xffffffffu;                 // the conditioning (initial all-ones) belongs to the first slice only
-  for (uint32_t k = 0; k < n; k++) c = tab[(c ^ p[k]) & 0xffu] ^ (c >> 8);
+  uint32_t c = crc_slice(raw + bk.out_off + (lane ? first + (lane - 1u) * S : 0u), lane ? S : first, lane ? 0u : 0xffffffffu, T);   // the conditioning (initial all-ones) belongs to the first slice only
   // join: at level L lanes with bit L clear hold a left operand whose right neighbour covers S << L bytes
-  uint32_t sh = gf2_xpow8n(S);
   for (uint32_t L = 0; L < 6u; L++) {
+    const uint32_t sh = kXpow.v[L][S >> 2];
     const uint32_t other = (uint32_t)__shfl_xor((int)c, 1 << L);
     const bool left = ((lane >> L) & 1u) == 0u;
-    const uint32_t joined = gf2_mulmod(left ? c : other, sh) ^ (left ? other : c);
-    c = joined;   // both lanes of a pair now hold the pair's CRC; only lanes with the low L+1 bits clear matter from here on
-    sh = gf2_mulmod(sh, sh);
+    c = gf2_mulmod(left ? c : other, sh) ^ (left ? other : c);   // both lanes of a pair now hold the pair's CRC; only lanes with the low L+1 bits clear matter from here on
   }
   if (lane == 0) {
     uint32_t want; __builtin_memcpy(&want, zin + bk.in_off + bk.in_len, 4);
@@ -55,18 +101,41 @@ mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSe
   seg_cnt[i] = ingest_walk_segment(raw, P.raw_len, segs[i], nullptr, &tot->err);
 }
 
+// Exclusive scan of a[0, n) in place by one 1024-thread workgroup; returns the total to every thread.  Tiles of 4096 elements, four
+// consecutive ones per thread (coalesced), a shuffle scan per wave, the 16 wave totals through LDS, a running 64-bit carry.  (Round 4 gave
+// every thread one contiguous chunk — 64 different cache lines per load instruction — and let thread 0 add the 1024 partial sums.)
+__device__ __forceinline__ unsigned long long block_scan_inplace(uint32_t* __restrict__ a, uint32_t n) {
+  __shared__ unsigned long long wtot[16];
+  __shared__ unsigned long long tile_total;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  unsigned long long carry = 0;
+  for (uint32_t base = 0; base < n; base += 4096u) {
+    const uint32_t i0 = base + 4u * t;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) v[k] = i0 + k < n ? a[i0 + k] : 0u;
+    const unsigned long long mine = (unsigned long long)v[0] + v[1] + v[2] + v[3];
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+    if (lane == 63u) wtot[wv] = incl;
+    __syncthreads();
+    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x; } tile_total = run; }
+    __syncthreads();
+    unsigned long long run = carry + wtot[wv] + incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) { if (i0 + k < n) a[i0 + k] = (uint32_t)run; run += v[k]; }
+    carry += tile_total;
+    __syncthreads();
+  }
+  return carry;
+}
+
 // exclusive scan of seg_cnt[0, n) in place (+ the total behind it), one workgroup; tot->n_all = records of the window
 extern "C" __global__ void __launch_bounds__(1024)
 mkp_ingest_scan_segs(uint32_t* __restrict__ seg_cnt, uint32_t n, MkpIngestTotals* tot) {
-  __shared__ unsigned long long part[1025];
-  const uint32_t t = threadIdx.x, chunk = (n + 1023u) / 1024u, lo = min(n, t * chunk), hi = min(n, lo + chunk);
-  unsigned long long s = 0; for (uint32_t i = lo; i < hi; i++) s += seg_cnt[i];
-  part[t] = s; __syncthreads();
-  if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 1024u; k++) { const unsigned long long v = part[k]; part[k] = run; run += v; } part[1024] = run; }
-  __syncthreads();
-  unsigned long long run = part[t];
-  for (uint32_t i = lo; i < hi; i++) { const uint32_t v = seg_cnt[i]; seg_cnt[i] = (uint32_t)run; run += v; }
-  if (t == 0) { const unsigned long long total = part[1024]; if (total > 0xfffffff0ull) { atomicOr(&tot->err, MKP_IE_TABLE); tot->n_all = 0; } else tot->n_all = (uint32_t)total; seg_cnt[n] = (uint32_t)total; }
+  const unsigned long long total = block_scan_inplace(seg_cnt, n);
+  if (threadIdx.x == 0) { if (total > 0xfffffff0ull) { atomicOr(&tot->err, MKP_IE_TABLE); tot->n_all = 0; } else tot->n_all = (uint32_t)total; seg_cnt[n] = (uint32_t)total; }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -97,40 +166,42 @@ mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const int32
   }
 }
 
-// exclusive scans of the six size arrays in place, one workgroup; totals into tot
+// exclusive scans of the six size arrays in place, one workgroup per array; totals into tot
 extern "C" __global__ void __launch_bounds__(1024)
 mkp_ingest_scan_sizes(uint32_t* __restrict__ sz, uint32_t rec_cap, MkpIngestTotals* tot) {
-  __shared__ unsigned long long part[1025];
-  const uint32_t n = min(tot->n_all, rec_cap);
-  const uint32_t t = threadIdx.x, chunk = (n + 1023u) / 1024u, lo = min(n, t * chunk), hi = min(n, lo + chunk);
-  for (uint32_t q = 0; q < 6u; q++) {
-    uint32_t* a = sz + (size_t)q * rec_cap;
-    unsigned long long s = 0; for (uint32_t i = lo; i < hi; i++) s += a[i];
-    __syncthreads();
-    part[t] = s; __syncthreads();
-    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 1024u; k++) { const unsigned long long v = part[k]; part[k] = run; run += v; } part[1024] = run; }
-    __syncthreads();
-    unsigned long long run = part[t];
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = a[i]; a[i] = (uint32_t)run; run += v; }
-    if (t == 0) {
-      const unsigned long long total = part[1024];
-      if (total > 0xfffffff0ull) atomicOr(&tot->err, MKP_IE_4G);
-      if (q == 0) tot->n_kept = (uint32_t)total; else if (q == 1) tot->cigar_words = total; else if (q == 2) tot->chunk_pairs = total; else if (q == 3) tot->seq_bytes = total; else if (q == 4) tot->ml_bytes = total; else tot->n_sample_only = (uint32_t)total;
-    }
+  const uint32_t n = min(tot->n_all, rec_cap), q = blockIdx.x;
+  const unsigned long long total = block_scan_inplace(sz + (size_t)q * rec_cap, n);
+  if (threadIdx.x == 0) {
+    if (total > 0xfffffff0ull) atomicOr(&tot->err, MKP_IE_4G);
+    if (q == 0) tot->n_kept = (uint32_t)total; else if (q == 1) tot->cigar_words = total; else if (q == 2) tot->chunk_pairs = total; else if (q == 3) tot->seq_bytes = total; else if (q == 4) tot->ml_bytes = total; else tot->n_sample_only = (uint32_t)total;
   }
 }
 
+// the serial half of the packing, one thread per record: chunk prefixes, name hashes, the MM tokeniser, header and digest
 extern "C" __global__ void __launch_bounds__(256)
 mkp_ingest_pack(const uint8_t* __restrict__ raw, uint32_t rec_cap, const MkpRecInfo* __restrict__ info, const uint32_t* __restrict__ sz,
-                MkpReadHdr* __restrict__ hdr, uint32_t* __restrict__ cigar, uint32_t* __restrict__ chunk_pfx, uint8_t* __restrict__ seq, MkpTagRef* __restrict__ tagref,
-                uint32_t* __restrict__ ranks, uint8_t* __restrict__ ml, MkpRecDigest* __restrict__ dig, MkpIngestTotals* tot) {
+                MkpReadHdr* __restrict__ hdr, uint32_t* __restrict__ chunk_pfx, MkpTagRef* __restrict__ tagref,
+                uint32_t* __restrict__ ranks, MkpRecDigest* __restrict__ dig, MkpIngestTotals* tot) {
   const uint32_t n = min(tot->n_all, rec_cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const MkpRecInfo R = info[i];
     if (R.kind != 1 && R.kind != 3) continue;
     const uint32_t j = R.kind == 1 ? sz[i] : tot->n_kept + sz[5 * (size_t)rec_cap + i];   // headers: the kept records in file order, then the sampler-only ones
     ingest_pack_record(raw, R, i, j, sz[(size_t)rec_cap + i], sz[2 * (size_t)rec_cap + i], sz[3 * (size_t)rec_cap + i], sz[4 * (size_t)rec_cap + i],
-                       hdr, cigar, chunk_pfx, seq, tagref, ranks, ml, dig, tot);
+                       hdr, chunk_pfx, tagref, ranks, dig, tot);
+  }
+}
+
+// the bulk half, one wave per record: CIGAR words, SEQ and ML bytes, a dword per lane and step (round 4 moved them byte by byte inside
+// the thread above: the longest read's 25 000 SEQ bytes were the kernel's 10 ms)
+extern "C" __global__ void __launch_bounds__(256)
+mkp_ingest_copy(const uint8_t* __restrict__ raw, uint32_t rec_cap, const MkpRecInfo* __restrict__ info, const uint32_t* __restrict__ sz,
+                uint32_t* __restrict__ cigar, uint8_t* __restrict__ seq, uint8_t* __restrict__ ml, const MkpIngestTotals* tot) {
+  const uint32_t n = min(tot->n_all, rec_cap), lane = threadIdx.x & 63u, waves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += waves) {
+    const MkpRecInfo R = info[i];
+    if (R.kind != 1 && R.kind != 3) continue;
+    ingest_copy_record(raw, R, sz[(size_t)rec_cap + i], sz[3 * (size_t)rec_cap + i], sz[4 * (size_t)rec_cap + i], cigar, seq, ml, lane, 64u);
   }
 }
 
@@ -160,13 +231,15 @@ hipError_t mkp_launch_ingest_parse(hipStream_t st, const uint8_t* raw, const Mkp
   if (P->n_seg) hipLaunchKernelGGL(mkp_ingest_write, dim3((P->n_seg + 255u) / 256u), dim3(256), 0, st, raw, *P, segs, seg_base, rec_off, tot);
   const uint32_t grid = P->rec_cap ? (uint32_t)((P->rec_cap + 255u) / 256u < 8192u ? (P->rec_cap + 255u) / 256u : 8192u) : 1u;
   hipLaunchKernelGGL(mkp_ingest_parse, dim3(grid), dim3(256), 0, st, raw, *P, parts, rec_off, info, sz, extra, tot);
-  hipLaunchKernelGGL(mkp_ingest_scan_sizes, dim3(1), dim3(1024), 0, st, sz, P->rec_cap, tot);
+  hipLaunchKernelGGL(mkp_ingest_scan_sizes, dim3(6), dim3(1024), 0, st, sz, P->rec_cap, tot);
   return hipGetLastError();
 }
 hipError_t mkp_launch_ingest_pack(hipStream_t st, const uint8_t* raw, uint32_t rec_cap, const MkpRecInfo* info, const uint32_t* sz, MkpReadHdr* hdr, uint32_t* cigar,
                                   uint32_t* chunk_pfx, uint8_t* seq, MkpTagRef* tagref, uint32_t* ranks, uint8_t* ml, MkpRecDigest* dig, MkpIngestTotals* tot) {
   const uint32_t grid = rec_cap ? (uint32_t)((rec_cap + 255u) / 256u < 8192u ? (rec_cap + 255u) / 256u : 8192u) : 1u;
-  hipLaunchKernelGGL(mkp_ingest_pack, dim3(grid), dim3(256), 0, st, raw, rec_cap, info, sz, hdr, cigar, chunk_pfx, seq, tagref, ranks, ml, dig, tot);
+  hipLaunchKernelGGL(mkp_ingest_pack, dim3(grid), dim3(256), 0, st, raw, rec_cap, info, sz, hdr, chunk_pfx, tagref, ranks, dig, tot);
+  const uint32_t cgrid = rec_cap ? (uint32_t)((rec_cap + 3u) / 4u < 16384u ? (rec_cap + 3u) / 4u : 16384u) : 1u;
+  hipLaunchKernelGGL(mkp_ingest_copy, dim3(cgrid), dim3(256), 0, st, raw, rec_cap, info, sz, cigar, seq, ml, tot);
   return hipGetLastError();
 }
 }

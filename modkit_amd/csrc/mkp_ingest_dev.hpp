@@ -175,10 +175,10 @@ MKP_IDEV void fnv_decimal(unsigned long long* h, uint32_t v) {   // the digits s
   while (n) fnv_byte(h, d[--n]);
 }
 
-// Packer::tokenise (mkp_pack.hpp) for one record: MM header structure -> key hash, delta lists -> cumulative ranks, ML bytes copied.
-// ranks / ml: the record's slices (capacity ml_n each); tagref: MKP_MAX_TAGS entries; rank_base / ml_base: their offsets in the shard.
+// Packer::tokenise (mkp_pack.hpp) for one record: MM header structure -> key hash, delta lists -> cumulative ranks (the ML bytes are moved
+// by ingest_copy_record).  ranks: the record's slice (capacity ml_n); tagref: MKP_MAX_TAGS entries; rank_base / ml_base: their offsets in the shard.
 // false = the read only contributes coverage (tag error).  `err` collects the conditions the host packer throws on.
-MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* ranks, uint8_t* ml, MkpTagRef* tagref, uint32_t rank_base, uint32_t ml_base, MkpTokOut* out, uint32_t* err) {
+MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* ranks, MkpTagRef* tagref, uint32_t rank_base, uint32_t ml_base, MkpTokOut* out, uint32_t* err) {
   out->n_tags = 0; out->n_calls = 0; out->ml_used = 0; out->cap = 0; out->key_hash = 1469598103934665603ull; out->sum2 = 0;
   if (!R.mm || !R.ml) return false;
   if (c[R.mm] != 'Z') return false;
@@ -260,11 +260,10 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
   }
   if (n_hdr == 0) return false;   // no tags -> ModBaseInfo::is_empty -> NoModifiedBaseInformation
   if (n_hdr > MKP_MAX_TAGS) { MKP_ATOMIC_OR(err, MKP_IE_TAGS); return false; }
-  for (unsigned long long k = 0; k < pointer; k++) ml[k] = mlp[6 + k];
   // two tags over one delta list: combine_checked's "> 1.01" test (mod_bam.rs:629-656) as an integer test on the ML bytes — every
   // term is (2q + 1) / 512, so the f32 sum is exact and the test is "the numerators reach 518"
   if (n_hdr == 2 && tagref[1].pad) {
-    const uint32_t n = tagref[0].n; const uint8_t* m0 = ml; const uint8_t* m1 = ml + (tagref[1].ml_off - ml_base); bool bad = false;
+    const uint32_t n = tagref[0].n; const uint8_t* m0 = mlp + 6; const uint8_t* m1 = mlp + 6 + (tagref[1].ml_off - ml_base); bool bad = false;
     for (uint32_t j = 0; j < n && !bad; j++) { uint32_t num = 0; for (uint32_t i = 0; i < nc[0]; i++) num += 2u * m0[j * nc[0] + i] + 1u; for (uint32_t i = 0; i < nc[1]; i++) num += 2u * m1[j * nc[1] + i] + 1u; bad = num >= 518u; }
     out->sum2 = bad ? 1u : 0u;
   }
@@ -276,35 +275,31 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
 // per-record digest the host plans with (next to the record's MkpReadHdr and tag table)
 struct MkpRecDigest { unsigned long long name_hash, key_hash, name_hash2, win_idx; };   // name_hash2: a second, independent hash of the read name (128 bits identify a name in the sampler's sets); win_idx: the record's place in the window (file order across kept and sampler-only records)
 
-// Packer::add for one kept record: CIGAR words + chunk prefixes, SEQ bytes, tags; writes the header with the offsets the scan gave.
+// Packer::add for one kept record, the serial half (one thread): chunk prefixes of the CIGAR, name hashes, the tags; writes the header with
+// the offsets the scan gave.  The bulk copies are ingest_copy_record's.
 MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t win_idx, uint32_t j, uint32_t cigar_off, uint32_t chunk_off, uint32_t seq_off, uint32_t ml_off,
-                                 MkpReadHdr* hdr, uint32_t* cigar, uint32_t* chunk_pfx, uint8_t* seq, MkpTagRef* tagref, uint32_t* ranks, uint8_t* ml, MkpRecDigest* dig,
-                                 MkpIngestTotals* tot) {
+                                 MkpReadHdr* hdr, uint32_t* chunk_pfx, MkpTagRef* tagref, uint32_t* ranks, MkpRecDigest* dig, MkpIngestTotals* tot) {
   const uint8_t* c = raw + R.core;
   const uint8_t* cg = c + 32 + R.l_qname;
-  const uint8_t* sq = cg + 4 * (uint32_t)R.n_cigar;
   MkpReadHdr h;
   h.cigar_off = cigar_off; h.chunk_off = chunk_off; h.seq_off = seq_off; h.tag_off = j * MKP_MAX_TAGS;
   long long reflen = 0, qlen = 0;
   for (uint32_t k = 0; k < R.n_cigar; k++) {
-    const uint32_t w = ld_u32(cg + 4 * k), op = w & 15u; cigar[cigar_off + k] = w;
+    const uint32_t w = ld_u32(cg + 4 * k), op = w & 15u;
     if ((k & 63u) == 0) { chunk_pfx[2 * (chunk_off + (k >> 6))] = (uint32_t)qlen; chunk_pfx[2 * (chunk_off + (k >> 6)) + 1] = (uint32_t)reflen; }
     if ((0x18du >> op) & 1u) reflen += w >> 4;
     if ((0x193u >> op) & 1u) qlen += w >> 4;   // M I S = X consume the query
   }
-  if (R.n_cigar == 0) { cigar[cigar_off] = (R.l_seq << 4) | 4u; chunk_pfx[2 * chunk_off] = 0; chunk_pfx[2 * chunk_off + 1] = 0; qlen = R.l_seq; }   // sampler-only record without alignment ops
+  if (R.n_cigar == 0) { chunk_pfx[2 * chunk_off] = 0; chunk_pfx[2 * chunk_off + 1] = 0; qlen = R.l_seq; }   // sampler-only record without alignment ops
   if (qlen != (long long)R.l_seq) MKP_ATOMIC_OR(&tot->err, MKP_IE_QLEN);
   if (qlen >= (1 << 26) || reflen >= (1 << 26)) MKP_ATOMIC_OR(&tot->err, MKP_IE_SPAN);
   h.ref_start = R.pos; h.ref_end = R.pos + (int32_t)reflen; h.l_seq = R.l_seq; h.n_cigar = ingest_cigar_words(R.n_cigar);
-  const uint32_t nb = (R.l_seq + 1u) / 2u, nbp = ingest_seq_bytes(R.l_seq);
-  for (uint32_t k = 0; k < nb; k++) seq[seq_off + k] = sq[k];
-  for (uint32_t k = nb; k < nbp; k++) seq[seq_off + k] = 0;
   h.flags = (R.flag & 16u) ? MKP_RF_REVERSE : 0u;
   { unsigned long long hh = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull; for (int i = 0; i + 1 < (int)R.l_qname; i++) { hh ^= c[32 + i]; hh *= 1099511628211ull; h2 = (h2 ^ c[32 + i]) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 29; }
     dig[j].name_hash = hh; dig[j].name_hash2 = h2; dig[j].win_idx = win_idx; }
   MkpTokOut t;
   for (uint32_t k = 0; k < MKP_MAX_TAGS; k++) { MkpTagRef z; z.rank_off = 0; z.n = 0; z.ml_off = 0; z.pad = 0; tagref[h.tag_off + k] = z; }
-  const bool ok = ingest_tokenise(c, R, ranks + ml_off, ml + ml_off, tagref + h.tag_off, ml_off, ml_off, &t, &tot->err);
+  const bool ok = ingest_tokenise(c, R, ranks + ml_off, tagref + h.tag_off, ml_off, ml_off, &t, &tot->err);
   if (!ok) { h.flags |= MKP_RF_BAD; t.n_tags = 0; t.cap = 0; t.n_calls = 0; t.ml_used = 0; t.sum2 = 0; t.key_hash = 0; }
   if (t.cap > 0xfffffff0ull) { MKP_ATOMIC_OR(&tot->err, MKP_IE_4G); t.cap = 0; }
   h.n_tags = (uint16_t)t.n_tags; h.layout = 0;
@@ -314,4 +309,33 @@ MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32
   hdr[j] = h;
   if (t.n_calls) MKP_ATOMIC_ADD64(&tot->n_calls, (unsigned long long)t.n_calls);
   if (t.ml_used) MKP_ATOMIC_ADD64(&tot->n_ml_used, (unsigned long long)t.ml_used);
+}
+
+// Packer::add for one kept record, the bulk half: CIGAR words, SEQ bytes (zero-padded to a dword), the ML array — by `nlanes` lanes that
+// share the record (a wave on the device; the test harness calls it lane after lane).  No lane reads what another wrote.  The whole B:C
+// array is moved (the record's slice has room for it; the tags only ever point at the bytes their calls use).
+MKP_IDEV void ingest_copy_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t cigar_off, uint32_t seq_off, uint32_t ml_off, uint32_t* cigar, uint8_t* seq, uint8_t* ml,
+                                 uint32_t lane, uint32_t nlanes) {
+  const uint8_t* c = raw + R.core;
+  const uint8_t* cg = c + 32 + R.l_qname;
+  const uint8_t* sq = cg + 4 * (uint32_t)R.n_cigar;
+  for (uint32_t k = lane; k < R.n_cigar; k += nlanes) cigar[cigar_off + k] = ld_u32(cg + 4 * k);
+  if (R.n_cigar == 0 && lane == 0) cigar[cigar_off] = (R.l_seq << 4) | 4u;   // one soft clip over the bases, as Packer::add does
+  const uint32_t nb = (R.l_seq + 1u) / 2u, nd = ingest_seq_bytes(R.l_seq) / 4u;
+  uint32_t* sd = (uint32_t*)(seq + seq_off);   // (seq_off is a multiple of 4: every record's room is)
+  for (uint32_t k = lane; k < nd; k += nlanes) {
+    uint32_t v;
+    if (4u * k + 4u <= nb) v = ld_u32(sq + 4u * k);
+    else { v = 0; for (uint32_t b = 0; b < 4u; b++) if (4u * k + b < nb) v |= (uint32_t)sq[4u * k + b] << (8u * b); }
+    sd[k] = v;
+  }
+  if (R.ml && c[R.ml] == 'B' && c[R.ml + 1] == 'C') {
+    const uint8_t* mlp = c + R.ml + 6; uint8_t* md = ml + ml_off; const uint32_t n = R.ml_n;
+    // dwords where source and destination allow (the destination decides; the source is read unaligned)
+    const uint32_t head = (uint32_t)((4u - ((uintptr_t)md & 3u)) & 3u) < n ? (uint32_t)((4u - ((uintptr_t)md & 3u)) & 3u) : n;
+    for (uint32_t k = lane; k < head; k += nlanes) md[k] = mlp[k];
+    const uint32_t nw = (n - head) / 4u;
+    for (uint32_t k = lane; k < nw; k += nlanes) { const uint32_t v = ld_u32(mlp + head + 4u * k); __builtin_memcpy(md + head + 4u * k, &v, 4); }
+    for (uint32_t k = head + 4u * nw + lane; k < n; k += nlanes) md[k] = mlp[k];
+  }
 }

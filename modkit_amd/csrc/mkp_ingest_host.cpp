@@ -1,7 +1,7 @@
 // Device ingest, host side: one shard window of an indexed BAM goes to the GPU COMPRESSED and comes back as a digest.
 // Stands in for htslib's IndexedReader::fetch + records() (src/pileup/mod.rs:732-759) and for the tag getters / MmTagInfo::parse
 // (src/mod_bam.rs:1388-1470, 900-1000) on the shard path: the BGZF blocks the index lists are uploaded as they sit in the file,
-// inflated (mkp_inflate*.hip), CRC-checked, cut into records, filtered and packed into the shard arrays (mkp_ingest.hip) — the
+// inflated (mkp_inflate_wave4.hip), CRC-checked, cut into records, filtered and packed into the shard arrays (mkp_ingest.hip) — the
 // inflated bytes never exist on the host.  What returns: one MkpReadHdr + tag table + two hashes per kept record (the planner's input),
 // the spans of supplementary records (max-depth guard), block status words and error bits.  MM header structures ("layouts") are
 // interned on the host from the key hash of each record; the text of a structure seen for the first time is fetched from HBM and
@@ -17,8 +17,6 @@
 using namespace mkp;
 
 extern "C" {
-hipError_t mkp_launch_inflate(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);
-hipError_t mkp_launch_inflate_wave(hipStream_t, const uint8_t*, const void*, uint32_t, uint8_t*, uint32_t*);
 hipError_t mkp_launch_crc32(hipStream_t, const uint8_t*, const void*, uint32_t, const uint8_t*, uint32_t*);
 hipError_t mkp_launch_ingest_count(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, uint32_t*, MkpIngestTotals*);
 hipError_t mkp_launch_ingest_parse(hipStream_t, const uint8_t*, const MkpIngestParams*, const int32_t*, const MkpSeg*, const uint32_t*, unsigned long long*, MkpRecInfo*, uint32_t*, int32_t*, MkpIngestTotals*);

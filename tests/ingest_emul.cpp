@@ -153,7 +153,9 @@ int main(int argc, char** argv) {
       std::vector<MkpTagRef> tagref((size_t)n_pk * MKP_MAX_TAGS + 1); std::vector<MkpRecDigest> dig(n_pk + 1);
       for (uint32_t i = 0; i < tot.n_all; i++) if (info[i].kind == 1 || info[i].kind == 3)
         ingest_pack_record(raw, info[i], i, info[i].kind == 1 ? sz[i] : tot.n_kept + sz[5 * (size_t)tot.n_all + i], sz[(size_t)tot.n_all + i], sz[2 * (size_t)tot.n_all + i], sz[3 * (size_t)tot.n_all + i], sz[4 * (size_t)tot.n_all + i],
-                           hdr.data(), cigar.data(), chunk.data(), seq.data(), tagref.data(), ranks.data(), ml.data(), dig.data(), &tot);
+                           hdr.data(), chunk.data(), tagref.data(), ranks.data(), dig.data(), &tot);
+      for (uint32_t i = 0; i < tot.n_all; i++) if (info[i].kind == 1 || info[i].kind == 3)   // the bulk half, as the 64 lanes of its wave (any order: no lane reads what another wrote)
+        for (uint32_t lane = 64; lane-- > 0;) ingest_copy_record(raw, info[i], sz[(size_t)tot.n_all + i], sz[3 * (size_t)tot.n_all + i], sz[4 * (size_t)tot.n_all + i], cigar.data(), seq.data(), ml.data(), lane, 64u);
       // ---- the host path over the same region: the fetch's region test, Packer::keep, Packer::add
       std::vector<mkp_record> recs, so_recs; std::vector<std::pair<int32_t, int32_t>> hextra;
       for (auto& e : bd.recs) {

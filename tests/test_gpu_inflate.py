@@ -1,4 +1,4 @@
-"""Device BGZF inflate (mkp_bgzf_inflate -> mkp_inflate_wave2 / mkp_inflate_blocks2 by launch size; SURVEY §8 f1 first stage) against Python's gzip
+"""Device BGZF inflate (mkp_bgzf_inflate -> mkp_inflate_wave4; SURVEY §8 f1 first stage) against Python's gzip
 on the reference's BAM fixtures and on generated BAMs; corrupt input must come back as an error."""
 import glob
 import gzip
@@ -114,22 +114,20 @@ c.close(); print('ok', n, len(good), bad)
 
 
 def test_all_device_kernels(tmp_path):
-    """mkp_bgzf_inflate picks its kernel by launch size; all five — wave, thread, thread2 (the second edition of the per-thread decoder),
-    wave2 (one wave per block, speculative symbol decode), wave3 (the same with an 8 KiB ring and far matches read from the flushed
-    output; opt-in) — are forced here through MKP_INFLATE_KERNEL in fresh processes (the variable
-    is read once) and checked against gzip on the reference's BAMs and against zlib on the DEFLATE corpus of
-    tests/test_inflate_wave2_emul.py: every block type, level and strategy, multi-block streams, long stored blocks, and ~500 corrupted
+    """mkp_inflate_wave4 and its ring-size variants (4 KiB: the product's; 8 KiB, 2 KiB: A/B builds), forced through MKP_INFLATE_KERNEL in
+    fresh processes (the variable is read once) and checked against gzip on the reference's BAMs and against zlib on the DEFLATE corpus of
+    tests/test_inflate_wave4_emul.py: every block type, level and strategy, multi-block streams, long stored blocks, and ~500 corrupted
     or random streams whose acceptance must be zlib's."""
     import pickle
     import subprocess
     import sys
-    from test_inflate_wave2_emul import deflate_corpus
+    from test_inflate_wave4_emul import deflate_corpus
     recs = deflate_corpus()
     pk = str(tmp_path / "corpus.pkl")
     pickle.dump(recs, open(pk, "wb"))
     here = os.path.dirname(os.path.abspath(__file__))
     script = KERNEL_SCRIPT % (os.path.dirname(here), FIX, pk)
-    for kernel in ("wave2", "wave3", "wave", "thread", "thread2"):
+    for kernel in ("wave4", "wave4_8k", "wave4_2k"):
         p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=dict(os.environ, MKP_INFLATE_KERNEL=kernel, PYTHONPATH=here + os.pathsep + os.environ.get("PYTHONPATH", "")))
         assert p.returncode == 0 and p.stdout.startswith("ok"), (kernel, p.stdout[-200:], p.stderr[-600:])
         n, good, bad = map(int, p.stdout.split()[1:4])

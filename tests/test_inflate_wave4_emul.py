@@ -1,6 +1,7 @@
-"""mkp_inflate_wave2 / mkp_inflate_wave3 (one wave per BGZF block, speculative symbol decode; 32 KiB ring | 8 KiB ring + far reads) checked on the CPU: tests/inflate_wave2_emul.cpp restates the
-kernel's control flow over 64 emulated lanes around the per-lane functions the kernel itself compiles (mkp_inflate_tok.hpp) and compares
-every block with zlib — output and acceptance.  The GPU run of the same corpus is tests/test_gpu_inflate.py."""
+"""mkp_inflate_wave4 (one wave per BGZF block: speculative token decode, a scalar walk that marks the chain, a parallel output step with in-pass
+pointer jumping; 4 KiB ring + far reads) checked on the CPU: tests/inflate_wave4_emul.cpp restates the kernel's control flow over 64 emulated
+lanes around the per-lane functions the kernel itself compiles (mkp_inflate_tok.hpp) and compares every block with zlib — output and
+acceptance.  The GPU run of the same corpus is tests/test_gpu_inflate.py."""
 import os
 import random
 import struct
@@ -17,8 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope="module")
 def emul(tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("w2") / "inflate_wave2_emul")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(HERE, "inflate_wave2_emul.cpp"), "-lz"], check=True)
+    exe = str(tmp_path_factory.mktemp("w4") / "inflate_wave4_emul")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(HERE, "inflate_wave4_emul.cpp"), "-lz"], check=True)
     return exe
 
 
@@ -75,11 +76,11 @@ def write_corpus(path, recs):
             f.write(z)
 
 
-MODES = pytest.mark.parametrize("wave", ["2", "3"], ids=["wave2_ring32k", "wave3_ring8k_far"])   # the two instantiations of the kernel body
+MODES = pytest.mark.parametrize("wave", ["4096", "2048", "8192", "32768"], ids=["ring4k_the_kernel", "ring2k", "ring8k", "ring32k_no_far_reads"])   # ring sizes of the kernel body
 
 
 def run_emul(emul, args, wave):
-    return subprocess.run([emul] + args, capture_output=True, text=True, env=dict(os.environ, WAVE=wave))
+    return subprocess.run([emul] + args, capture_output=True, text=True, env=dict(os.environ, RING=wave))
 
 
 @MODES
@@ -115,5 +116,5 @@ def test_fuzzed_bams(emul, tmp_path, wave):
         paths.append(bam)
     p = run_emul(emul, ["bgzf"] + paths, wave)
     assert p.returncode == 0 and p.stdout.startswith("ok "), p.stderr[-500:]
-    if wave == "3":
+    if wave != "32768":
         assert "far reads" in p.stderr and int(p.stderr.split("far reads ")[1].split()[0]) > 1000   # (the far path is exercised)

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp; OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmci}; mkdir -p $OUT; cd /tmp
 export INFLATE_BLOCKS=16000
 python $GRAFT_REPO_ROOT/tools/dbg/inflate_bench.py > /dev/null 2>&1   # (writes the BAM)
-for K in ${KERNELS:-wave2 wave}; do
+for K in ${KERNELS:-wave4}; do
   export MKP_INFLATE_KERNEL=$K
   for P in 1 2 3; do
     case $P in
