@@ -222,8 +222,28 @@ typedef struct {
   double total_ms;
   uint64_t n_rows, n_positions, n_shards, processed_records, skipped_records;
   float threshold[4]; uint8_t has_threshold[4];   /* per-base pass thresholds used (A,C,G,T) */
+  /* round 5 — where the wall went that the stages above do not own, so that they add up; and the device ingest's own figures */
+  double grid_wait_ms;          /* the threshold estimate waiting for the reference FASTA and the interval grid (not part of threshold_ms) */
+  double callback_ms;           /* mkp_pileup_run_cb: inside the caller's threshold callback (all-reduce / broadcast; not part of threshold_ms) */
+  double ingest_kernel_ms;      /* device ingest, summed over the shards: the inflate launch + record chains (HIP events) */
+  double ingest_upload_ms, ingest_table_ms, ingest_pack_ms;   /* ... the uploads, the block tables, parse + scans + pack incl. their syncs (host clocks) */
+  uint64_t ingest_comp_bytes, ingest_raw_bytes, ingest_blocks, ingest_records;   /* compressed bytes uploaded, bytes they inflated to */
 } mkp_run_report;
 int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report);
+
+/* The same run with the pass thresholds decided by the CALLER at the point where `modkit pileup` estimates them (subcommand.rs:615-638) —
+ * the multi-GPU form: every rank calls this with --gpus-rank / --gpus-world and no threshold flags.  The library ingests this rank's shards
+ * ahead from the first moment, then calls `fn` once:
+ *   have_sample = 1  (`-f 1.0`, thresholds.rs:121-159): the context's histograms hold the sample of THIS rank's shards, taken from HBM;
+ *                    the callback sums them over the ranks (mkp_histogram_allreduce, or mkp_histogram_get + its own collective) and
+ *                    evaluates the percentile (mkp_histogram_locate / _resolve / mkp_percentile_from_histogram);
+ *   have_sample = 0  (the count-based default, `-n`, `-f x < 1`): nothing was sampled — the schedule carries quotas from interval to
+ *                    interval and is one rank's job (mkp_estimate_thresholds on a context of its own) — the callback hands over the
+ *                    values it received from that rank.
+ * The callback fills thresholds[b] / has[b] for b = A, C, G, T and returns MKP_OK; the shards are still resident when it returns and the
+ * pileup pass runs on them.  With fn == NULL this is mkp_pileup_run. */
+typedef int (*mkp_threshold_fn)(void* user, mkp_ctx* ctx, int have_sample, float thresholds[4], uint8_t has[4]);
+int mkp_pileup_run_cb(mkp_ctx* ctx, int argc, const char* const* argv, mkp_threshold_fn fn, void* user, mkp_run_report* report);
 
 /* ---- threshold estimation: get_threshold_from_options (src/command_utils.rs:74-134) ->
  * calc_threshold_from_bam (src/thresholds.rs:121-159).  Which reads are sampled follows the reference's

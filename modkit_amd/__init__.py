@@ -58,6 +58,7 @@ def lib():
         L.mkp_shard_rerun.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
         L.mkp_get_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.mkp_pileup_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
+        L.mkp_pileup_run_cb.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), THRESHOLD_FN, ctypes.c_void_p, ctypes.c_void_p]
         L.mkp_pileup_hemi_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
         L.mkp_extract_calls_main.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_char_p, ctypes.c_size_t]
         L.mkp_pileup_hemi_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.c_void_p]
@@ -78,9 +79,12 @@ def lib():
     return _lib
 
 
+# mkp_threshold_fn (include/mkpileup.h): int fn(void* user, mkp_ctx* ctx, int have_sample, float thresholds[4], uint8_t has[4])
+THRESHOLD_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint8))
+
 EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_host_threads", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_set_intervals", "mkp_shard_run", "mkp_batch_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
-           "mkp_pileup_run", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
+           "mkp_pileup_run", "mkp_pileup_run_cb", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_allreduce", "mkp_histogram_from_values", "mkp_histogram_locate",
            "mkp_histogram_resolve", "mkp_percentile_from_histogram", "mkp_hemi_shard_run", "mkp_pileup_hemi_main", "mkp_pileup_hemi_run", "mkp_bgzf_inflate", "mkp_sample_probs", "mkp_summary", "mkp_extract_calls_main"]
 
@@ -190,7 +194,10 @@ class RunReport(ctypes.Structure):
                 ("h2d_ms", ctypes.c_double), ("kernel_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("write_ms", ctypes.c_double),
                 ("total_ms", ctypes.c_double), ("n_rows", ctypes.c_uint64), ("n_positions", ctypes.c_uint64), ("n_shards", ctypes.c_uint64),
                 ("processed_records", ctypes.c_uint64), ("skipped_records", ctypes.c_uint64), ("threshold", ctypes.c_float * 4),
-                ("has_threshold", ctypes.c_uint8 * 4)]
+                ("has_threshold", ctypes.c_uint8 * 4),
+                ("grid_wait_ms", ctypes.c_double), ("callback_ms", ctypes.c_double), ("ingest_kernel_ms", ctypes.c_double), ("ingest_upload_ms", ctypes.c_double),
+                ("ingest_table_ms", ctypes.c_double), ("ingest_pack_ms", ctypes.c_double), ("ingest_comp_bytes", ctypes.c_uint64), ("ingest_raw_bytes", ctypes.c_uint64),
+                ("ingest_blocks", ctypes.c_uint64), ("ingest_records", ctypes.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("threshold", "has_threshold")}
@@ -284,6 +291,35 @@ class Context:
         arr = (ctypes.c_char_p * len(args))(*args)
         rep = RunReport()
         self._check(self.L.mkp_pileup_run(self.h, len(args), arr, ctypes.byref(rep)))
+        return rep
+
+    def pileup_run_cb(self, argv, thresholds):
+        """`modkit pileup` with the pass thresholds decided by the caller (mkp_pileup_run_cb — the multi-GPU form: argv carries --gpus-rank /
+        --gpus-world and no threshold flags).  The library ingests this rank's shards ahead, then calls `thresholds(have_sample)` once:
+        have_sample True (`-f 1.0`): this context's histograms hold the sample of this rank's shards — reduce them over the ranks and
+        evaluate the percentile; False: nothing was sampled, supply the values.  It returns {base letter: f32}.  Returns the stage report."""
+        args = [str(a).encode() for a in argv]
+        arr = (ctypes.c_char_p * len(args))(*args)
+        rep = RunReport()
+        failure = []
+
+        def _cb(user, ctx, have_sample, thr, has):
+            try:
+                got = thresholds(bool(have_sample))
+                for i, b in enumerate("ACGT"):
+                    if b in got:
+                        thr[i] = float(got[b]); has[i] = 1
+                    else:
+                        thr[i] = 0.0; has[i] = 0
+                return MKP_OK
+            except BaseException as e:   # (must not unwind through the C frames)
+                failure.append(e)
+                return -2
+        fn = THRESHOLD_FN(_cb)
+        rc = self.L.mkp_pileup_run_cb(self.h, len(args), arr, fn, None, ctypes.byref(rep))
+        if failure:
+            raise failure[0]
+        self._check(rc)
         return rep
 
     def pileup_hemi_run(self, argv):

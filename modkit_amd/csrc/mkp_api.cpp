@@ -247,17 +247,25 @@ void make_resident(mkp_ctx* c) {
     // with one name meet only if they overlap a common interval — then the later one is answered from the earlier one's calls, which the
     // device path does not reproduce.  Mates / split alignments that lie in different intervals never share a cache and are simply two reads.
     // (No interval grid given: the shard is one interval.)
-    for (auto& d : dups) {
-      if (d.first >= S.hdr.size() || d.second >= S.hdr.size()) continue;
-      auto iv_range = [&](const MkpReadHdr& h, int64_t* a, int64_t* b) {
-        const int64_t s0 = h.ref_start, e0 = std::max<int64_t>(h.ref_end, (int64_t)h.ref_start + 1);
-        if (c->iv_starts.empty()) { *a = 0; *b = 0; return; }
-        auto idx = [&](int64_t p) { return (int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1; };
-        *a = std::max<int64_t>(idx(s0), 0); *b = std::max<int64_t>(idx(e0 - 1), 0);
-      };
-      int64_t a0, a1, b0, b1; iv_range(S.hdr[d.first], &a0, &a1); iv_range(S.hdr[d.second], &b0, &b1);
-      if (a0 <= b1 && b0 <= a1) throw Error(MKP_E_UNSUPPORTED,
-        "two primary records share a read name inside one interval (unmarked duplicates, or mates / split reads that overlap the same interval); the reference answers the later record from the earlier one's calls (its per-interval cache is keyed by name) and this is not reproduced on the device");
+    // Every pair of records of one name is judged (three records A, B, C: the table above names (A, B) and (A, C); B and C can meet too).
+    // A record that lies wholly outside the shard window — a halo record of the fetch — belongs to none of its intervals.
+    std::map<uint32_t, std::vector<uint32_t>> groups;
+    for (auto& d : dups) { if (d.first >= S.hdr.size() || d.second >= S.hdr.size()) continue; auto& g = groups[d.first]; if (g.empty()) g.push_back(d.first); g.push_back(d.second); }
+    auto iv_range = [&](const MkpReadHdr& h, int64_t* a, int64_t* b) -> bool {   // false: outside the window
+      const int64_t s0 = h.ref_start, e0 = std::max<int64_t>(h.ref_end, (int64_t)h.ref_start + 1);
+      if (e0 <= (int64_t)S.win_start || s0 >= (int64_t)S.win_end) return false;
+      if (c->iv_starts.empty()) { *a = 0; *b = 0; return true; }
+      auto idx = [&](int64_t p) { return (int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1; };
+      *a = std::max<int64_t>(idx(std::max<int64_t>(s0, S.win_start)), 0); *b = std::max<int64_t>(idx(std::min<int64_t>(e0, S.win_end) - 1), 0);
+      return true;
+    };
+    for (auto& kv : groups) {
+      const std::vector<uint32_t>& g = kv.second;
+      std::vector<std::pair<int64_t, int64_t>> rg; rg.reserve(g.size());
+      for (uint32_t r : g) { int64_t a, b; if (iv_range(S.hdr[r], &a, &b)) rg.push_back({a, b}); }
+      for (size_t x = 0; x < rg.size(); x++) for (size_t y = x + 1; y < rg.size(); y++)
+        if (rg[x].first <= rg[y].second && rg[y].first <= rg[x].second) throw Error(MKP_E_UNSUPPORTED,
+          "two primary records share a read name inside one interval (unmarked duplicates, or mates / split reads that overlap the same interval); the reference answers the later record from the earlier one's calls (its per-interval cache is keyed by name) and this is not reproduced on the device");
     }
   }
   lap("duplicate-name check");

@@ -408,8 +408,8 @@ struct BaiIndex {
     // upper bound: a record that lies wholly inside a 16 kb window past `end` starts behind every record the region can hold (the file is
     // coordinate sorted), so the first chunk of that window's own bin ends the search — what htslib gets by stopping at the first
     // record with pos >= end, known here before anything is read (the device ingest uploads whole ranges; a sparse BED asks for hundreds)
-    uint64_t max_off = UINT64_MAX;
-    for (int64_t w = ((end - 1) >> 14) + 1, tries = 0; tries < 256 && w < (1 << 15); w++, tries++) { auto it = R.bins.find((uint32_t)(4681 + w)); if (it != R.bins.end() && !it->second.empty()) { max_off = it->second.front().beg; break; } }
+    uint64_t max_off = UINT64_MAX;   // (the smallest chunk start of that bin: the BAI format does not promise a bin's chunks sorted)
+    for (int64_t w = ((end - 1) >> 14) + 1, tries = 0; tries < 256 && w < (1 << 15); w++, tries++) { auto it = R.bins.find((uint32_t)(4681 + w)); if (it != R.bins.end() && !it->second.empty()) { max_off = UINT64_MAX; for (auto& ck : it->second) max_off = std::min<uint64_t>(max_off, ck.beg); break; } }
     for (uint32_t b : bins) { auto it = R.bins.find(b); if (it == R.bins.end()) continue; for (auto c : it->second) if (c.end > min_off && c.beg < max_off) { c.end = std::min(c.end, max_off); out.push_back(c); } }
     std::sort(out.begin(), out.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
     // chunks are record-granular and those of neighbouring bins interleave in the file: ranges that overlap, touch, or lie within
@@ -575,48 +575,61 @@ class BamSource {
       out->ranges.push_back(rg);
     }
   }
-  // phase 2: block table (headers walked on all cores from the block starts the index knows), window layout, entry points
-  void ingest_blocks(IngestPlan* out) const {
-    const uint32_t tid = out->tid; if (tid >= bai_.refs.size()) return;
+  // phase 2: block table, window layout, entry points.  The table is walked in CHAINS — runs of blocks between block starts the index
+  // knows (every chunk boundary of the reference's bins, every linear-index offset) — by the device over the uploaded bytes
+  // (mkp_ingest_host.cpp; round 5: 54 000 preads of the host walk below were the longest step of a whole-contig ingest) or by the host pool.
+  struct IngestChain { size_t range; uint64_t start, stop; };   // file offsets; stop = the next known block start inside the range, UINT64_MAX for the range's last chain
+  void ingest_chains(const IngestPlan& plan, std::vector<IngestChain>* out) const {
+    out->clear();
+    const uint32_t tid = plan.tid; if (tid >= bai_.refs.size()) return;
     const BaiIndex::Ref& R = bai_.refs[tid];
-    // block starts the index knows: every chunk boundary of the reference's bins and every linear-index offset
     std::vector<uint64_t> known_all; known_all.reserve(R.lin.size() + 64);
     for (auto& kv : R.bins) for (auto& c : kv.second) { known_all.push_back(c.beg >> 16); known_all.push_back(c.end >> 16); }
     for (uint64_t v : R.lin) known_all.push_back(v >> 16);
     std::sort(known_all.begin(), known_all.end()); known_all.erase(std::unique(known_all.begin(), known_all.end()), known_all.end());
-    for (auto& rg : out->ranges) {
+    for (size_t r = 0; r < plan.ranges.size(); r++) {
+      const IngestRange& rg = plan.ranges[r]; const uint64_t cb = rg.file_off, range_end = cb + rg.file_len;
+      const size_t first = out->size();
+      out->push_back({r, cb, UINT64_MAX});
+      for (auto it = std::upper_bound(known_all.begin(), known_all.end(), cb); it != known_all.end() && *it < range_end; ++it) { out->back().stop = *it; out->push_back({r, *it, UINT64_MAX}); }
+      (void)first;
+    }
+  }
+  // the host walk of one chain: one pread per block brings the trailer of the block in hand (ISIZE) and the header of the next
+  // (a mapping of the range costs a page fault per block, all of them on one address-space lock); false = bad block / the chain misses `stop`
+  bool ingest_walk_chain_host(const IngestPlan& plan, const IngestChain& ch, std::vector<IngestBlk>* blks) const {
+    const IngestRange& rg = plan.ranges[ch.range];
+    const uint64_t ce = rg.vend >> 16, ue = rg.vend & 0xffff, range_end = rg.file_off + rg.file_len, stop = ch.stop;
+    uint64_t c = ch.start;
+    try {
+      std::vector<uint8_t> hb(600); Blk b; bool have = false;
+      auto read_at = [&](uint64_t off, size_t n) { n = (size_t)std::min<uint64_t>(n, range_end > off ? range_end - off : 0); hb.resize(n); size_t got = 0;
+        while (got < n) { const ssize_t r = ::pread(fd_, hb.data() + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; } };
+      for (;;) {
+        if (c >= stop || c > ce || (c == ce && ue == 0) || c + 18 > range_end) break;
+        if (!have) { read_at(c, 600); if (!block_at_header(hb, c, &b)) break; }
+        const uint64_t next = c + b.hdr + b.clen + 8;
+        if (next > range_end) break;
+        // [next - 8, next): CRC32 + ISIZE of this block; [next, ..): the next block's header
+        read_at(next - 8, 8 + 600);
+        if (hb.size() < 8) break;
+        uint32_t isize; memcpy(&isize, hb.data() + 4, 4);
+        blks->push_back({c, b.hdr, b.clen, isize, 0});
+        c = next; have = false;
+        if (hb.size() >= 8 + 18 && !(c >= stop || c > ce || (c == ce && ue == 0))) { Blk nb; if (block_at_header(hb.data() + 8, hb.size() - 8, c, &nb)) { b = nb; have = true; } }
+      }
+    } catch (...) { return false; }
+    return !(stop != UINT64_MAX && c != stop && !(c > ce || (c == ce && ue == 0)));   // the chain of block sizes must land on the block start the index names
+  }
+  // window layout and entry points from the chains' blocks (parts[i] = the blocks of chain i, in file order)
+  void ingest_layout(IngestPlan* out, const std::vector<IngestChain>& chains, std::vector<std::vector<IngestBlk>>& parts) const {
+    const BaiIndex::Ref& R = bai_.refs[out->tid];
+    size_t ci = 0;
+    for (size_t r = 0; r < out->ranges.size(); r++) {
+      IngestRange& rg = out->ranges[r];
       const uint64_t cb = rg.file_off, ce = rg.vend >> 16, ue = rg.vend & 0xffff; const uint32_t ub = (uint32_t)(rg.vbeg & 0xffff);
-      const uint64_t range_end = cb + rg.file_len;
-      std::vector<uint64_t> known; known.push_back(cb);
-      for (auto it = std::upper_bound(known_all.begin(), known_all.end(), cb); it != known_all.end() && *it < range_end; ++it) known.push_back(*it);
-      std::vector<std::vector<IngestBlk>> parts(known.size()); std::atomic<bool> bad{false};
-      // headers through pread (a mapping of the range costs a page fault per block, all of them on one address-space lock): one read per
-      // block brings the trailer of the block in hand (ISIZE) and the header of the next
-      HostPool::get().parallel(known.size(), [&](size_t i) {
-        uint64_t c = known[i]; const uint64_t stop = i + 1 < known.size() ? known[i + 1] : UINT64_MAX;
-        try {
-          std::vector<uint8_t> hb(600); Blk b; bool have = false;
-          auto read_at = [&](uint64_t off, size_t n) { n = (size_t)std::min<uint64_t>(n, range_end > off ? range_end - off : 0); hb.resize(n); size_t got = 0;
-            while (got < n) { const ssize_t r = ::pread(fd_, hb.data() + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; } };
-          for (;;) {
-            if (c >= stop || c > ce || (c == ce && ue == 0) || c + 18 > range_end) break;
-            if (!have) { read_at(c, 600); if (!block_at_header(hb, c, &b)) break; }
-            const uint64_t next = c + b.hdr + b.clen + 8;
-            if (next > range_end) break;
-            // [next - 8, next): CRC32 + ISIZE of this block; [next, ..): the next block's header
-            read_at(next - 8, 8 + 600);
-            if (hb.size() < 8) break;
-            uint32_t isize; memcpy(&isize, hb.data() + 4, 4);
-            parts[i].push_back({c, b.hdr, b.clen, isize, 0});
-            c = next; have = false;
-            if (hb.size() >= 8 + 18 && !(c >= stop || c > ce || (c == ce && ue == 0))) { Blk nb; if (block_at_header(hb.data() + 8, hb.size() - 8, c, &nb)) { b = nb; have = true; } }
-          }
-        } catch (...) { bad = true; return; }
-        if (stop != UINT64_MAX && c != stop && !(c > ce || (c == ce && ue == 0))) bad = true;   // the chain of block sizes misses a block start the index names
-      });
-      if (bad) throw Error(MKP_E_IO, "bad BGZF block in " + path_ + " (or the index does not match the file)");
       rg.blk0 = out->blks.size(); const uint64_t d0 = out->raw_total; uint64_t expect = cb;
-      for (auto& pt : parts) for (auto& b : pt) { if (b.coff != expect) throw Error(MKP_E_IO, "the BAM index does not match the file: " + path_ + ".bai"); b.doff = out->raw_total; out->raw_total += b.isize; expect = b.coff + b.hdr + b.clen + 8; out->blks.push_back(b); }
+      for (; ci < chains.size() && chains[ci].range == r; ci++) for (auto& b : parts[ci]) { if (b.coff != expect) throw Error(MKP_E_IO, "the BAM index does not match the file: " + path_ + ".bai"); b.doff = out->raw_total; out->raw_total += b.isize; expect = b.coff + b.hdr + b.clen + 8; out->blks.push_back(b); }
       rg.blk1 = out->blks.size();
       if (rg.blk1 == rg.blk0 || expect != cb + rg.file_len) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
       rg.raw_start = d0 + ub; rg.raw_limit = out->raw_total;
@@ -635,6 +648,14 @@ class BamSource {
       }
       rg.entry1 = out->entries.size();
     }
+  }
+  void ingest_blocks(IngestPlan* out) const {   // the host form: chains on all cores
+    if (out->tid >= bai_.refs.size()) return;
+    std::vector<IngestChain> chains; ingest_chains(*out, &chains);
+    std::vector<std::vector<IngestBlk>> parts(chains.size()); std::atomic<bool> bad{false};
+    HostPool::get().parallel(chains.size(), [&](size_t i) { if (!ingest_walk_chain_host(*out, chains[i], &parts[i])) bad = true; });
+    if (bad) throw Error(MKP_E_IO, "bad BGZF block in " + path_ + " (or the index does not match the file)");
+    ingest_layout(out, chains, parts);
   }
   void ingest_plan(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const { ingest_ranges(tid, beg, end, out); ingest_blocks(out); }
 

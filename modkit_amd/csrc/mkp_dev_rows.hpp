@@ -200,23 +200,32 @@ template <bool FOCUS> struct SlotMap {
 
 // Row emission of one tile from its LDS tallies (the tail of mkp_pileup_tiles): count the rows of every slot, reserve the tile's
 // run in the row buffer with one atomic, write.  Slot order = position order, so a block scan of the per-slot counts keeps it.
-// Row runs in genome order without a second pass: a tile's place in the row buffer is the number of rows of the tiles before it, found by
+// Row runs in genome order without a second pass: a run's place in the row buffer is the number of rows of the runs before it, found by
 // a decoupled look-back over one 64-bit word per run (bits 62-63: 1 = this run's own count is known, 2 = the count of everything up to
-// and including it; low bits: the value).  Tile t runs as workgroup t (dispatch order = genome order), so the run a workgroup waits for
-// is always one that started before it.  One thread per workgroup walks back; flag and value travel in one atomic word.
-__device__ __forceinline__ uint32_t lookback_reserve(unsigned long long* __restrict__ state, uint32_t run, uint32_t s) {
-  __hip_atomic_store(&state[run], (1ull << 62) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned long long excl = 0;
-  for (long long i = (long long)run - 1; i >= 0;) {
-    const unsigned long long v = __hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// and including it; low bits: the value).  Run numbers are TICKETS drawn from an atomic counter when a workgroup starts (round 5; round 4
+// took blockIdx and relied on dispatch order), so the runs a workgroup waits for belong to workgroups that are already running, whatever
+// the dispatch order and whoever else shares the device.  The look-back is made by a whole wave, 64 words per step (round 4: one thread,
+// one dependent global load per run before it — with 512 workgroups in flight that walk was most of a tile's tail).
+__device__ __forceinline__ uint32_t lookback_reserve_wave(unsigned long long* __restrict__ state, uint32_t run, uint32_t s) {
+  const int lane = lane_id();
+  if (lane == 0) __hip_atomic_store(&state[run], (1ull << 62) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t excl = 0;
+  for (long long hi = (long long)run - 1; hi >= 0;) {
+    const long long idx = hi - lane;
+    const unsigned long long v = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);   // (before the first run: everything so far = 0)
     const uint32_t flag = (uint32_t)(v >> 62);
-    if (flag == 0u) { __builtin_amdgcn_s_sleep(2); continue; }
-    excl += v & 0xffffffffull;
-    if (flag == 2u) break;
-    i--;
+    const unsigned long long m2 = __ballot(flag == 2u), m0 = __ballot(flag == 0u);
+    const uint32_t first2 = m2 ? (uint32_t)__builtin_ctzll(m2) : 64u, first0 = m0 ? (uint32_t)__builtin_ctzll(m0) : 64u;
+    // the words nearest to this run, up to the first inclusive one or to the first that is not written yet
+    const uint32_t take = first0 < first2 ? first0 : (first2 < 64u ? first2 + 1u : 64u);
+    const uint32_t part = wave_incl_scan((uint32_t)lane < take ? (uint32_t)v : 0u);
+    excl += (uint32_t)__builtin_amdgcn_readlane((int)part, 63);
+    if (first2 < first0) break;          // reached a run that knows everything before it
+    hi -= take;
+    if (first0 < 64u) __builtin_amdgcn_s_sleep(2);   // the next word is still being counted
   }
-  __hip_atomic_store(&state[run], (2ull << 62) | ((excl + s) & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return (uint32_t)excl;
+  if (lane == 0) __hip_atomic_store(&state[run], (2ull << 62) | (unsigned long long)(excl + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
 }
 
 template <bool FOCUS, bool HEMI, class SM, bool ORDERED = false>
@@ -249,16 +258,18 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
     const uint32_t inc2 = wave_incl_scan(cnt);
     if (lane == 63) wave_tot[wave] = inc2;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (ORDERED ? threadIdx.x < 64u : threadIdx.x == 0) {
       uint32_t s = 0;
       for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
       uint32_t base;
       if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); row_cursor[3] = number of runs (host), row_cursor[1] = total rows, written by the last run
-        base = lookback_reserve(reinterpret_cast<unsigned long long*>(tile_row_off), tix, s);
-        if (tix + 1u == row_cursor[3]) row_cursor[1] = base + s;
+        base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), tix, s);
+        if (threadIdx.x == 0 && tix + 1u == row_cursor[3]) row_cursor[1] = base + s;
       } else base = s ? atomicAdd(row_cursor, s) : 0u;
-      if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
-      *row_base_p = base; if (!ORDERED) { tile_row_off[tix] = base; tile_row_cnt[tix] = s; } *scan_carry_p = s ? 0u : 0xffffffffu;
+      if (threadIdx.x == 0) {
+        if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+        *row_base_p = base; if (!ORDERED) { tile_row_off[tix] = base; tile_row_cnt[tix] = s; } *scan_carry_p = s ? 0u : 0xffffffffu;
+      }
     }
     __syncthreads();
     if (*scan_carry_p != 0xffffffffu && cnt) {

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <set>
+#include <unordered_set>
 #include <thread>
 
 #include <unistd.h>
@@ -68,6 +69,8 @@ struct Args {
       uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
       bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
+  mkp_threshold_fn thr_cb = nullptr; void* thr_cb_user = nullptr;   /* mkp_pileup_run_cb: the pass thresholds come from the caller (multi-GPU: all-reduced histograms / a broadcast) */
+  uint64_t hbm_budget_mb = 0;   /* --hbm-budget-mb: device memory the shards ingested ahead may hold (0: 55 % of the device) */
   bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate_wave4.hip) instead of the host pool, records back to the host packer */
   bool host_ingest = false, shard_bytes_set = false;   /* --host-ingest (or MKP_HOST_INGEST=1): inflate, cut and pack the shards on the host instead of the device (mkp_ingest.hip) */
   bool bedgraph = false;   /* --bedgraph: the output path is a directory of <code>[_<motif>]_<strand>.bedgraph files (BedGraphWriter, writers.rs:264-381) */
@@ -366,7 +369,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         take(whole, cand, from, limit, g.iv.tid, true, seen, ts, sharded ? &skip : nullptr);
       };
       // run_batch (reads_sampler/mod.rs:259-338).  The count-based schedule needs only the head of every interval: the heads of up to
-      // 8 consecutive intervals of one contig are fetched concurrently and decoded in ONE device round; the sampler's first-N logic
+      // 8 consecutive intervals of one contig (32 when they are scans of a resident shard's digest) are fetched concurrently and decoded in ONE device round; the sampler's first-N logic
       // then runs over them in interval order.  An interval its head does not satisfy is finished sequentially before the
       // following ones are judged (their reads may already be taken by it), and the remaining heads are decoded again.
       struct Pending { size_t gi; std::unique_ptr<RecSet> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen;
@@ -374,7 +377,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       for (size_t mi = 0; mi < mine.size();) {
         const G& g0 = grouped[mine[mi]];
         size_t mj = mi + 1;
-        if (!g0.q.all) while (mj < mine.size() && mj - mi < 8 && !grouped[mine[mj]].q.all && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;
+        if (!g0.q.all) while (mj < mine.size() && mj - mi < (resident_mode ? 32u : 8u) && !grouped[mine[mj]].q.all && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;   // (resident: a head is a scan of the digest — more intervals per device round)
         std::vector<std::future<std::unique_ptr<RecSet>>> futs;
         for (size_t k = mi; k < mj; k++) futs.push_back(std::async(resident_mode ? std::launch::deferred : std::launch::async, head_of, mine[k]));   // (resident: a scan of the digest, no fetch to overlap)
         std::vector<Pending> pend(mj - mi);
@@ -430,6 +433,64 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible");
     limit = -1; }
     std::set<std::string> seen; TakeState ts; take(batch, cand, 0, limit, 0, false, &seen, &ts);
+  }
+}
+
+// Full-data mode (`-f 1.0`, thresholds.rs:121-159) over shards that are resident in HBM.  sample_probabilities' schedule degenerates there
+// to "every candidate read whose tags yield a value, once" — each sampling interval takes all of its reads, a read counts in the first
+// interval it overlaps — so the shards are sampled directly, read by read in file order, without the interval machinery (and without its
+// per-read std::set<std::string> lookups: 2.0 s of a 2.4 s run on the C4 scale model in round 4).  A read that lies in two shards of a
+// contig belongs to the first one (`own_from`: the end of the previous shard's fetch), so the union over the shards — of one rank or of
+// all ranks — is the single-rank sample; names seen before are skipped as the reference's Moniod keeps the first occurrence of a read id.
+struct FullShard { uint32_t tid; int64_t own_from, ext_lo, ext_hi; std::function<const ShardHost*()> bind; };
+struct NameKey { uint64_t a, b; bool operator==(const NameKey& o) const { return a == o.a && b == o.b; } };
+struct NameKeyHash { size_t operator()(const NameKey& k) const { return (size_t)(k.a ^ (k.b * 0x9e3779b97f4a7c15ull)); } };
+void sample_resident_full(mkp_ctx* ctx, const BamSource& bam, const BedFilter* bf, std::vector<FullShard>& shards) {
+  mkp_internal_bedmask_reset(ctx);
+  struct MaskSession { mkp_ctx* c; ~MaskSession() { mkp_internal_bedmask_reset(c); } } mask_session{ctx};
+  std::map<uint32_t, std::vector<uint8_t>> bedmasks;
+  auto bedmask_for = [&](uint32_t tid) -> const uint8_t* {
+    if (!bf) return nullptr;
+    auto it = bedmasks.find(tid); if (it != bedmasks.end()) return it->second.data();
+    std::vector<uint8_t> m(bam.ref_lens[tid], 0);
+    auto mark = [&](const std::map<uint32_t, std::vector<Span>>& mp, uint8_t bit) { auto f = mp.find(tid); if (f == mp.end()) return;
+        for (auto& sp : f->second) for (uint64_t p = sp.s; p < std::min<uint64_t>(sp.e, m.size()); p++) m[p] |= bit; };
+    mark(bf->pos, 1); mark(bf->neg, 2);
+    return bedmasks.emplace(tid, std::move(m)).first->second.data();
+  };
+  std::unordered_set<NameKey, NameKeyHash> taken;
+  for (auto& fs : shards) {
+    auto t_f = std::chrono::steady_clock::now();
+    const ShardHost* S = fs.bind();
+    g_sample_times.fetch_ms += ms_since(t_f);
+    if (!S || (int32_t)fs.tid != S->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
+    const size_t n = S->hdr.size(), n_so = S->so_hdr.size();
+    auto owned = [&](const MkpReadHdr& h) { const int64_t pos = h.ref_start, end = std::max(h.ref_end, h.ref_start + 1); return pos >= fs.own_from && pos < fs.ext_hi && end > fs.ext_lo; };
+    std::vector<uint32_t> ids; ids.reserve(n + n_so);
+    for (size_t i = 0; i < n; i++) if (owned(S->hdr[i])) ids.push_back((uint32_t)i);
+    { bool any_so = false; for (size_t k = 0; k < n_so; k++) if (owned(S->so_hdr[k])) { ids.push_back((uint32_t)(n + k)); any_so = true; }
+      if (any_so) { auto wi = [&](uint32_t k) { return k < n ? S->dev_win_idx[k] : S->so_win_idx[k - n]; }; std::stable_sort(ids.begin(), ids.end(), [&](uint32_t x, uint32_t y) { return wi(x) < wi(y); }); } }
+    const uint8_t* mask = bedmask_for(fs.tid);
+    for (size_t at = 0; at < ids.size();) {
+      const size_t hi = std::min(ids.size(), at + ((size_t)1 << 18));
+      std::vector<uint32_t> nv;
+      auto t_d = std::chrono::steady_clock::now();
+      int rc = mkp_internal_sample_resident(ctx, 0, bam.ref_lens[fs.tid], mask, ids.data() + at, (uint32_t)(hi - at), true, &nv);
+      if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+      g_sample_times.device_ms += ms_since(t_d); g_sample_times.rounds++; g_sample_times.reads += hi - at;
+      auto t_h = std::chrono::steady_clock::now();
+      std::vector<uint8_t> take(hi - at, 0);
+      for (size_t i = at; i < hi; i++) {
+        if (nv[i - at] == 0) continue;   // a read that keeps no position is asked, not counted and not recorded
+        const uint32_t k = ids[i]; NameKey key{k < n ? S->name_hash[k] : S->so_name_hash[k - n], k < n ? S->dev_name_hash2[k] : S->so_name_hash2[k - n]};
+        if (taken.insert(key).second) take[i - at] = 1;
+      }
+      g_sample_times.decide_ms += ms_since(t_h);
+      t_d = std::chrono::steady_clock::now();
+      rc = mkp_internal_sample_take(ctx, take); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+      g_sample_times.device_ms += ms_since(t_d);
+      at = hi;
+    }
   }
 }
 
@@ -581,7 +642,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   const bool host_ingest_env = getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1");
   const bool dev_ingest = bam.indexed() && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !inflater.d && !host_ingest_env;
   if (dev_ingest && !ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
-  double ingest_ms[5] = {0, 0, 0, 0, 0}; uint64_t ingest_blocks = 0, ingest_records = 0;
+  double ingest_ms[5] = {0, 0, 0, 0, 0}, ingest_kernel_ms = 0; uint64_t ingest_blocks = 0, ingest_records = 0, ingest_comp = 0, ingest_raw = 0;
   // the records of a shard: those overlapping any of its windows (one window, or the BED spans of a merged shard), each +- the halo
   auto fetch_windows = [&](uint32_t tid, const std::vector<std::pair<uint32_t, uint32_t>>& wins, mkp_dev_ingest* ing = nullptr) {
     ShardInput in; FetchParts parts;
@@ -612,14 +673,50 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // other on a worker thread, and stay packed in HBM (288 GB hold a 30x genome's packed reads) — the threshold estimate then samples from
   // them (every contig's interval heads are scans of a digest, no second read of the file), and the pileup pass finds its shards already
   // there.  Budget: the compressed bytes under the shards; beyond it the shards are fetched as the loop reaches them (host sampler).
-  struct Ahead { size_t rec0 = 0, rec1 = 0; uint32_t tid = 0, s0 = 0, s1 = 0; std::vector<std::pair<uint32_t, uint32_t>> wins; ShardInput in; bool ready = false; std::exception_ptr err; uint64_t bytes = 0; };
+  struct Ahead { size_t rec0 = 0, rec1 = 0; uint32_t tid = 0, s0 = 0, s1 = 0; std::vector<std::pair<uint32_t, uint32_t>> wins; ShardInput in; bool ready = false; std::exception_ptr err; uint64_t bytes = 0, est = 0; };
   // Several shards are in flight at once, each on an ingest object of its own (its streams, staging and scratch): one shard's inflate is a
-  // latency-bound launch that fills a fraction of the chip, and its host half (header walk, pread into staging) leaves the GPU idle —
-  // shards side by side fill both.
+  // launch that fills a fraction of the chip for most of its time, and its host half (pread into staging) leaves the GPU idle —
+  // shards side by side fill both.  What they may hold is bounded by an HBM BUDGET (round 5; round 4 had an all-or-nothing 24 GiB gate on
+  // the compressed size): a shard is admitted — in plan order — while the estimated bytes of the admitted, not yet consumed shards fit the
+  // budget (one shard is always admitted), and the shard loop gives a shard's bytes back when it is through with it.  A run whose shards
+  // fit together keeps them all (and may sample its threshold estimate from them); a larger one streams.
   std::vector<Ahead> ahead; std::mutex amu; std::condition_variable acv; std::vector<std::thread> aworkers; std::atomic<bool> astop{false}; std::atomic<size_t> anext{0};
+  size_t admit_next = 0; uint64_t hbm_used = 0, hbm_budget = 0, ahead_est_total = 0;   // (under amu)
   std::vector<mkp_dev_ingest*> aingest;
   struct FreeIngest { std::vector<mkp_dev_ingest*>* v; ~FreeIngest() { for (auto* d : *v) mkp_internal_ingest_destroy(d); } } free_ingest{&aingest};
-  struct JoinAhead { std::vector<std::thread>* t; std::atomic<bool>* stop; ~JoinAhead() { stop->store(true); for (auto& x : *t) if (x.joinable()) x.join(); } } join_ahead{&aworkers, &astop};
+  struct JoinAhead { std::vector<std::thread>* t; std::atomic<bool>* stop; std::condition_variable* cv; ~JoinAhead() { stop->store(true); cv->notify_all(); for (auto& x : *t) if (x.joinable()) x.join(); } } join_ahead{&aworkers, &astop, &acv};
+  if (dev_ingest) {
+    uint64_t mb = a.hbm_budget_mb; if (const char* e = getenv("MKP_HBM_BUDGET_MB")) mb = strtoull(e, nullptr, 10);
+    if (mb) hbm_budget = mb << 20;
+    else { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) tot = (size_t)64 << 30; hbm_budget = (uint64_t)((double)tot * 0.55); }
+  }
+  // packed arrays of a shard ~ 1.9 x its compressed blocks on ONT-like data (SEQ nibbles + CIGAR words + 5 bytes per call; names and
+  // qualities are not kept), the inflated window of the ingest object in flight on top: 2.5 x as the estimate
+  auto est_of = [](uint64_t comp_bytes) { return comp_bytes * 5 / 2 + (64ull << 20); };
+  auto start_ahead = [&]() {
+    if (ahead.empty() || !aworkers.empty()) return;
+    ahead_est_total = 0; for (auto& A : ahead) { A.est = est_of(A.bytes); ahead_est_total += A.est; }
+    size_t nw = 4; if (const char* e = getenv("MKP_AHEAD_WORKERS")) nw = (size_t)std::max(1, atoi(e));
+    nw = std::min(nw, ahead.size());
+    for (size_t w = 1; w < nw; w++) { mkp_dev_ingest* d = mkp_internal_ingest_create(ctx->device); if (!d) break; aingest.push_back(d); }
+    nw = aingest.size() + 1;
+    for (size_t w = 0; w < nw; w++) aworkers.emplace_back([&, w]() {
+      mkp_dev_ingest* ing = w == 0 ? ctx->ingest : aingest[w - 1];
+      for (;;) {
+        const size_t k = anext.fetch_add(1); if (k >= ahead.size()) break;
+        { std::unique_lock<std::mutex> lk(amu);   // admission in plan order, under the budget
+          acv.wait(lk, [&] { return astop.load() || (admit_next == k && (hbm_used == 0 || hbm_used + ahead[k].est <= hbm_budget)); });
+          if (!astop.load()) { hbm_used += ahead[k].est; admit_next = k + 1; } }
+        acv.notify_all();
+        ShardInput in; std::exception_ptr err;
+        if (astop.load()) err = std::make_exception_ptr(Error(MKP_E_INVALID, "internal: shard ingest cancelled"));
+        else try { in = fetch_windows(ahead[k].tid, ahead[k].wins, ing); } catch (...) { err = std::current_exception(); astop.store(true); }
+        { std::lock_guard<std::mutex> g(amu); ahead[k].in = std::move(in); ahead[k].err = err; ahead[k].ready = true; }
+        acv.notify_all();
+      }
+    });
+  };
+  auto ahead_release = [&](size_t k) { { std::lock_guard<std::mutex> g(amu); hbm_used -= std::min(hbm_used, ahead[k].est); } acv.notify_all(); };   // the shard loop is through with shard k
   // the fetch windows of a shard made of BED records [r0, r1) of one contig: the BED spans inside them (rows exist at BED positions only,
   // so only records reaching a span matter), not the records, which run from one span to the next
   auto bed_windows = [&](size_t r0, size_t r1) {
@@ -644,24 +741,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       if ((uint64_t)A.s1 - A.s0 > shard_bp || A.bytes > shard_bytes || (bf && r1 - r0 > 65536) || records[r0].length == 0 || A.wins.empty()) fits = false;
       total += A.bytes; ahead.push_back(std::move(A)); r0 = r1;
     }
-    if (!fits || total > (24ull << 30)) ahead.clear();
-    if (!ahead.empty()) {
-      size_t nw = 4; if (const char* e = getenv("MKP_AHEAD_WORKERS")) nw = (size_t)std::max(1, atoi(e));
-      nw = std::min(nw, ahead.size());
-      for (size_t w = 1; w < nw; w++) { mkp_dev_ingest* d = mkp_internal_ingest_create(ctx->device); if (!d) break; aingest.push_back(d); }
-      nw = aingest.size() + 1;
-      for (size_t w = 0; w < nw; w++) aworkers.emplace_back([&, w]() {
-        mkp_dev_ingest* ing = w == 0 ? ctx->ingest : aingest[w - 1];
-        for (;;) {
-          const size_t k = anext.fetch_add(1); if (k >= ahead.size()) break;
-          ShardInput in; std::exception_ptr err;
-          if (astop.load()) err = std::make_exception_ptr(Error(MKP_E_INVALID, "internal: shard ingest cancelled"));
-          else try { in = fetch_windows(ahead[k].tid, ahead[k].wins, ing); } catch (...) { err = std::current_exception(); astop.store(true); }
-          { std::lock_guard<std::mutex> g(amu); ahead[k].in = std::move(in); ahead[k].err = err; ahead[k].ready = true; }
-          acv.notify_all();
-        }
-      });
-    }
+    (void)total;
+    if (!fits) ahead.clear();   // a contig larger than a shard: the shards are cut on the grid and ingested ahead once the plan is known (below)
+    start_ahead();
   }
   auto ahead_wait = [&](size_t k) -> Ahead& { std::unique_lock<std::mutex> lk(amu); acv.wait(lk, [&] { return ahead[k].ready; }); if (ahead[k].err) std::rethrow_exception(ahead[k].err); return ahead[k]; };
   if (fasta_load.valid()) { fasta = fasta_load.get(); fb.fasta = &fasta; mark("reference FASTA loaded"); }
@@ -681,10 +763,106 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     });
   struct JoinWalk { std::future<void>* f; ~JoinWalk() { if (f->valid()) f->wait(); } } join_walk{&early_walk};
       // (an exception below must not leave the walker running on dead locals)
+  // ---- shard plan (shard_cut above); ranks take contiguous runs, balanced by the bytes the index puts under them (by length
+  // without an index)
+  struct ShardPart { size_t rec; uint32_t s0, s1; };
+  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */
+                     std::vector<ShardPart> parts; /* --include-bed: the BED-span records merged into this shard (empty: one window) */
+                     int64_t own_from = INT64_MIN; /* full-data sampling from the shards: reads starting before this position lie in the previous shard of the contig too, and are sampled there */ };
+  std::vector<ShardPlan> plan;
+  const bool hf = fb.has_focus();
+  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0;
+      double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, fetch_wait_ms = 0;
+  bool plan_built = false;
+  auto build_plan = [&]() {
+    if (plan_built) return; plan_built = true;
+    if (early_walk.valid()) early_walk.get();   // (the walker owns grid_of / focus_of until it is done; rethrows what it threw)
+  {
+      const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid,
+          records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
+      bool have_prev = false; uint32_t prev_tid = 0; int64_t prev_fetch_hi = 0;   // the shard before, over ALL ranks' shards: where its fetch ends
+      auto last_window_end = [&](uint32_t tid, uint32_t w0, uint32_t w1) -> int64_t {   // end of the last fetch window of a shard [w0, w1) (plan_windows below, before the halo)
+        if (!bf) return w1;
+        uint64_t last = 0; for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
+          for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, w0), hi = std::min<uint64_t>(x.e, w1); if (lo < hi) last = std::max(last, hi); } }
+        return last ? (int64_t)last : (int64_t)w0 + 1;
+      };
+      for (size_t ri = 0; ri < records.size(); ri++) {
+        const Contig& rec = records[ri];
+        auto t_focus = std::chrono::steady_clock::now();
+        // the grid; with one rank the focus bytes are filled in the same walk, otherwise only for the contigs this rank owns (below)
+        std::vector<Interval> ivs;
+        if (grid_done[ri]) ivs.swap(grid_of[ri]);
+        else { ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr); if (hf && a.world == 1) focus_done[ri] = 1;
+            focus_ms += ms_since(t_focus); }
+        size_t i0 = 0;
+        while (i0 < ivs.size()) {
+          uint64_t bp = 0; const size_t i1 = shard_cut(rec, ivs, i0, &bp); const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
+          const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
+          const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
+          const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
+          std::vector<uint32_t> iv_starts; for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);   // the shard's intervals (pileup-hemi: per-interval NoCalls; always: the duplicate-name rule)
+          i0 = i1;
+          const int64_t own_from = have_prev && prev_tid == rec.tid ? prev_fetch_hi : INT64_MIN;
+          have_prev = true; prev_tid = rec.tid; prev_fetch_hi = last_window_end(rec.tid, s0, s1) + MKP_HALO;
+          if (owner == a.rank) { plan.push_back({ri, s0, s1, bp, std::move(iv_starts)}); plan.back().own_from = own_from; }
+        }
+      }
+    }
+    // --include-bed: optimize_reference_records (position_filter.rs:103-210) turns every run of BED spans into a reference record of its own —
+    // hundreds per contig for a sparse BED.  Rows only depend on the focus bytes (BED positions inside the records), not on how records are
+    // grouped, so consecutive records of one contig share a shard: one hull window whose focus is zero between the records, fed by a
+    // multi-window fetch of the records' spans only (what lies between them is neither read nor inflated).
+    if (bf && plan.size() > 1 && !getenv("MKP_NO_BED_MERGE")) {
+      std::vector<ShardPlan> merged; uint64_t bytes = 0;
+      for (auto& sp : plan) {
+        const uint32_t tid = records[sp.rec].tid;
+        const uint64_t sp_bytes = bam.indexed() ? bam.offset_at(tid, sp.s1) - bam.offset_at(tid, sp.s0) + (1u << 16) : 0;
+        const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1 && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp && (bytes + sp_bytes <= shard_bytes || !ahead.empty() /* its spans were sized when it was ingested ahead */) &&
+                          merged.back().parts.size() < 65536;
+        if (!join) { ShardPlan m = sp; m.parts.assign(1, {sp.rec, sp.s0, sp.s1}); merged.push_back(std::move(m)); bytes = sp_bytes; continue; }
+        ShardPlan& m = merged.back(); m.s1 = sp.s1; m.bp += sp.bp; m.iv_starts.insert(m.iv_starts.end(), sp.iv_starts.begin(), sp.iv_starts.end()); m.parts.push_back({sp.rec, sp.s0, sp.s1}); bytes += sp_bytes;
+      }
+      for (auto& m : merged) if (m.parts.size() == 1) m.parts.clear();
+      plan.swap(merged);
+    }
+    mark("shard plan done");
+  };
+  // the fetch windows of a shard: its window — or, under --include-bed, the BED spans inside its pieces (rows exist at BED positions only;
+  // the records of optimize_reference_records run from one span to the next, most of what lies under them is never looked at)
+  auto plan_windows = [&](const ShardPlan& sp) {
+    std::vector<std::pair<uint32_t, uint32_t>> w;
+    if (!bf) { w.push_back({sp.s0, sp.s1}); return w; }
+    const uint32_t tid = records[sp.rec].tid; std::vector<Span> spn;
+    auto clip = [&](uint32_t a0, uint32_t a1) { for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
+        for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, a0), hi = std::min<uint64_t>(x.e, a1); if (lo < hi) spn.push_back({lo, hi}); } } };
+    if (sp.parts.empty()) clip(sp.s0, sp.s1); else for (auto& pt : sp.parts) clip(pt.s0, pt.s1);
+    merge_spans(spn); for (auto& x : spn) w.push_back({(uint32_t)x.s, (uint32_t)x.e});
+    if (w.empty()) w.push_back({sp.s0, sp.s0 + 1});   // (no BED position inside: nothing to fetch but an empty window)
+    return w;
+  };
+  auto fetch_shard = [&](const ShardPlan& sp) { return fetch_windows(records[sp.rec].tid, plan_windows(sp)); };
+  // the plan's shards as the list ingested ahead (several ranks, contigs larger than a shard, full-data sampling from the shards): same
+  // workers, same budget as the contig list above
+  auto ahead_from_plan = [&]() {
+    if (!dev_ingest || !ahead.empty() || plan.empty()) return;
+    for (auto& sp : plan) { Ahead A; A.rec0 = sp.rec; A.rec1 = sp.rec + 1; A.tid = records[sp.rec].tid; A.s0 = sp.s0; A.s1 = sp.s1; A.wins = plan_windows(sp);
+      A.bytes = bf ? win_bytes(A.tid, A.wins) : bam.offset_at(A.tid, A.s1) - bam.offset_at(A.tid, A.s0) + (1u << 16); ahead.push_back(std::move(A)); }
+    start_ahead();
+  };
   // thresholds (subcommand.rs:615-638)
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
-  double thr_ms = 0, fetch_wait_early_ms = 0;
+  double thr_ms = 0, fetch_wait_early_ms = 0, grid_wait_ms = 0, callback_ms = 0;
   ShardInput early_in; bool early_in_ready = false, pre_attached = false; std::unique_ptr<DevShard> pre_dev;   // the first shard's records, taken before the loop
+  const bool full_mode = a.have_frac && a.sampling_frac >= 1.0;
+  const bool want_estimate = a.filter_threshold.empty() && !a.no_filtering && !a.plan_only;
+  const bool resident_ok = !have_sregion && !a.include_unmapped && !getenv("MKP_NO_RESIDENT_SAMPLING");
+  const bool ahead_whole_contigs = !ahead.empty();   // (the list made above holds whole contigs; the plan's shards may be pieces of them)
+  bool resident_used = pre_attached;
+  // The plan comes before the thresholds — and its shards go ahead — when nothing is gained by waiting for them: several ranks (a rank needs
+  // its own shards whatever the thresholds turn out to be, and the others' estimate or all-reduce is time to ingest in), thresholds given,
+  // or a full-data estimate, which samples from the shards themselves.
+  if (dev_ingest && !early_whole && ahead.empty() && !getenv("MKP_NO_AHEAD") && (a.world > 1 || !want_estimate || (full_mode && resident_ok))) { build_plan(); ahead_from_plan(); }
   if (!a.filter_threshold.empty()) parse_base_thresholds(a.filter_threshold, &kc);
   else if (a.no_filtering || a.plan_only) { kc.n_per_mod = 0; }  // MultipleThresholdModCaller::new_passthrough
   else {
@@ -696,6 +874,11 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     Args as = a; as.world = 1; as.rank = 0;
     must(mkp_histogram_begin(ctx));
     g_sample_times = SampleTimes();
+    // mkp_pileup_run_cb: in the count-based modes the caller supplies the thresholds (one rank estimates, all ranks receive: the schedule
+    // carries quotas from interval to interval and does not shard) — nothing is sampled here, and this rank's shards are being ingested
+    // meanwhile; in the full-data mode this rank samples its own shards and the caller reduces the histograms over the ranks
+    const bool cb_supplies = a.thr_cb && !full_mode;
+    if (!cb_supplies) {
     // The one shard of the run is being ingested on the device and every read the schedule can ask for lies in it: the estimate waits for
     // it and samples from HBM (the heads are scans of the shard's digest, a round is one launch over reads that are already packed)
     // instead of fetching, inflating and packing interval heads on the host next to the ingest.
@@ -704,9 +887,11 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       bool only_this = true; { const IdxStats stx = idxstats(bam, sr, bf); for (auto& kv : stx.mapped_by_tid) if (kv.second && kv.first != (int64_t)records[0].tid) only_this = false; }
       if (only_this) {
         mark("resident sampling: waiting for the grid");
+        auto t_gw = std::chrono::steady_clock::now();
         if (early_walk.valid()) early_walk.get();
         else if (!grid_done[0]) { auto t_focus = std::chrono::steady_clock::now(); grid_of[0] = fb.walk(records[0], a.interval_size, fb.has_focus() ? &focus_of[0] : nullptr); grid_done[0] = 1;
           if (fb.has_focus()) focus_done[0] = 1; focus_ms += ms_since(t_focus); }
+        grid_wait_ms += ms_since(t_gw);
         const std::vector<Interval>& ivs = grid_of[0]; uint64_t bp = 0;
         if (!ivs.empty() && shard_cut(records[0], ivs, 0, &bp) == ivs.size() && ivs.front().start == early_s0 && ivs.back().end == early_s1) {
           // the shard is begun and everything of its plan that needs the window alone (slot bitmap, slot positions, their uploads) is
@@ -732,33 +917,58 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     }
     ResidentOf resident_of;
     DevShard* bound = nullptr;   // multi-shard resident sampling: the shard currently swapped into the context
+    struct Unbind { mkp_ctx* c; DevShard** b; ~Unbind() { if (*b) { (void)mkp_internal_sample_bind(c, *b); *b = nullptr; } } } unbind{ctx, &bound};
+    auto bind_ahead = [&](size_t k) -> const ShardHost* {
+      auto t_w = std::chrono::steady_clock::now();
+      Ahead& A = ahead_wait(k);
+      fetch_wait_early_ms += ms_since(t_w);
+      if (!A.in.dev) throw Error(MKP_E_INVALID, "internal: shard ingested ahead without device records");
+      if (bound != A.in.dev.get()) { if (bound) must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; must(mkp_internal_sample_bind(ctx, A.in.dev.get())); bound = A.in.dev.get(); }
+      return &ctx->shard;
+    };
+    const bool ahead_fits = !ahead.empty() && ahead_est_total <= hbm_budget;   // every shard stays in HBM until the loop takes it: the sample can come from them
+    // the extent the sampler covers on a contig: the region, or all of it
+    auto ext_of = [&](uint32_t tid, int64_t* lo, int64_t* hi) { if (have_region) { *lo = region.start; *hi = region.end; } else { *lo = 0; *hi = bam.ref_lens[tid]; } };
+    if (full_mode && resident_ok && (resident || (ahead_fits && (a.world == 1 || a.thr_cb)))) {
+      // full-data mode: the shards themselves are the sample's source, whatever their cut — with several ranks (mkp_pileup_run_cb) each
+      // rank its own, the caller sums the histograms
+      std::vector<FullShard> fs;
+      if (resident) { FullShard f; f.tid = records[0].tid; f.own_from = INT64_MIN; ext_of(f.tid, &f.ext_lo, &f.ext_hi); f.bind = [&]() { return resident; }; fs.push_back(std::move(f)); }
+      else for (size_t k = 0; k < ahead.size(); k++) { FullShard f; f.tid = ahead[k].tid; f.own_from = ahead_whole_contigs ? INT64_MIN : plan[k].own_from; ext_of(f.tid, &f.ext_lo, &f.ext_hi);
+          f.bind = [&, k]() { return bind_ahead(k); }; fs.push_back(std::move(f)); }
+      sample_resident_full(ctx, bam, bf, fs);
+      resident_used = true;
+      if (a.stats) fprintf(stderr, "[mkpileup] full-data threshold sample taken from %zu resident shard(s)%s\n", fs.size(), a.world > 1 ? " of this rank" : "");
+    } else {
     if (resident) resident_of = [&](uint32_t) { return resident; };
-    else if (!ahead.empty() && !have_sregion && !a.include_unmapped && !getenv("MKP_NO_RESIDENT_SAMPLING")) {
+    else if (ahead_fits && ahead_whole_contigs && resident_ok && a.world == 1) {
       // every contig the schedule can visit must be among the shards ingested ahead
       std::map<uint32_t, size_t> by_tid; for (size_t k = 0; k < ahead.size(); k++) by_tid[ahead[k].tid] = k;
       bool covered = true; { const IdxStats stx = idxstats(bam, sr, bf); for (auto& kv : stx.mapped_by_tid) if (kv.second && !by_tid.count((uint32_t)kv.first)) covered = false; }
       // (a region run: the one record is the region; a BED run: a contig's shard holds the records reaching its BED spans, which are the only ones that can yield a value)
       if (covered) resident_of = [&, by_tid](uint32_t tid) -> const ShardHost* {
         auto it = by_tid.find(tid); if (it == by_tid.end()) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
-        auto t_w = std::chrono::steady_clock::now();
-        Ahead& A = ahead_wait(it->second);
-        fetch_wait_early_ms += ms_since(t_w);
-        if (!A.in.dev) throw Error(MKP_E_INVALID, "internal: shard ingested ahead without device records");
-        if (bound != A.in.dev.get()) { if (bound) must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; must(mkp_internal_sample_bind(ctx, A.in.dev.get())); bound = A.in.dev.get(); }
-        return &ctx->shard;
+        return bind_ahead(it->second);
       };
     }
-    struct Unbind { mkp_ctx* c; DevShard** b; ~Unbind() { if (*b) { (void)mkp_internal_sample_bind(c, *b); *b = nullptr; } } } unbind{ctx, &bound};
-    sample_probabilities(ctx, bam, as, sr, bf, resident_of);
-    if (bound) { must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; }
+    // (a rank of mkp_pileup_run_cb's full-data mode whose shards are not resident — an unindexed BAM, a budget too small — samples its own
+    // sampling intervals through the host reader, as round 4 did)
+    sample_probabilities(ctx, bam, (a.thr_cb && full_mode) ? a : as, sr, bf, resident_of);
+    if (resident_of) resident_used = true;
     if (a.stats && resident_of && !resident) fprintf(stderr, "[mkpileup] threshold estimate sampled from %zu shards ingested ahead (resident)\n", ahead.size());
+    }
+    if (bound) { must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; }
     mark("schedule walked, sample in HBM");
     if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n",
         g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms,
         g_sample_times.decide_ms);
-    { float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats); for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1;
-        kc.per_base_threshold[b] = thr[b]; } }
-    thr_ms = ms_since(t0) - fetch_wait_early_ms;
+    }
+    { float thr[4] = {0, 0, 0, 0}; uint8_t has[4] = {0, 0, 0, 0};
+      if (a.thr_cb) { auto t_cb = std::chrono::steady_clock::now(); const int rc = a.thr_cb(a.thr_cb_user, ctx, cb_supplies ? 0 : 1, thr, has); callback_ms = ms_since(t_cb);
+        if (rc != MKP_OK) throw Error(rc, "the threshold callback failed"); mark("thresholds from the callback"); }
+      else thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats);
+      for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; } }
+    thr_ms = ms_since(t0) - fetch_wait_early_ms - grid_wait_ms - callback_ms;
   }
   mark("thresholds done");
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
@@ -800,74 +1010,12 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   };
   if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n",
       wr.f);
-  // ---- shard plan (shard_cut above); ranks take contiguous runs, balanced by the bytes the index puts under them (by length
-  // without an index)
-  struct ShardPart { size_t rec; uint32_t s0, s1; };
-  struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */
-                     std::vector<ShardPart> parts; /* --include-bed: the BED-span records merged into this shard (empty: one window) */ };
-  std::vector<ShardPlan> plan;
-  const bool hf = fb.has_focus();
-  uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0;
-      double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, fetch_wait_ms = 0;
-  {
-    const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid,
-        records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
-    for (size_t ri = 0; ri < records.size(); ri++) {
-      const Contig& rec = records[ri];
-      auto t_focus = std::chrono::steady_clock::now();
-      // the grid; with one rank the focus bytes are filled in the same walk, otherwise only for the contigs this rank owns (below)
-      std::vector<Interval> ivs;
-      if (grid_done[ri]) ivs.swap(grid_of[ri]);
-      else { ivs = fb.walk(rec, a.interval_size, (hf && a.world == 1) ? &focus_of[ri] : nullptr); if (hf && a.world == 1) focus_done[ri] = 1;
-          focus_ms += ms_since(t_focus); }
-      size_t i0 = 0;
-      while (i0 < ivs.size()) {
-        uint64_t bp = 0; const size_t i1 = shard_cut(rec, ivs, i0, &bp); const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
-        const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
-        const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
-        const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
-        std::vector<uint32_t> iv_starts; for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);   // the shard's intervals (pileup-hemi: per-interval NoCalls; always: the duplicate-name rule)
-        i0 = i1;
-        if (owner == a.rank) plan.push_back({ri, s0, s1, bp, std::move(iv_starts)});
-      }
-    }
-  }
-  // --include-bed: optimize_reference_records (position_filter.rs:103-210) turns every run of BED spans into a reference record of its own —
-  // hundreds per contig for a sparse BED.  Rows only depend on the focus bytes (BED positions inside the records), not on how records are
-  // grouped, so consecutive records of one contig share a shard: one hull window whose focus is zero between the records, fed by a
-  // multi-window fetch of the records' spans only (what lies between them is neither read nor inflated).
-  if (bf && plan.size() > 1 && !getenv("MKP_NO_BED_MERGE")) {
-    std::vector<ShardPlan> merged; uint64_t bytes = 0;
-    for (auto& sp : plan) {
-      const uint32_t tid = records[sp.rec].tid;
-      const uint64_t sp_bytes = bam.indexed() ? bam.offset_at(tid, sp.s1) - bam.offset_at(tid, sp.s0) + (1u << 16) : 0;
-      const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1 && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp && (bytes + sp_bytes <= shard_bytes || !ahead.empty() /* its spans were sized when it was ingested ahead */) &&
-                        merged.back().parts.size() < 65536;
-      if (!join) { ShardPlan m = sp; m.parts.assign(1, {sp.rec, sp.s0, sp.s1}); merged.push_back(std::move(m)); bytes = sp_bytes; continue; }
-      ShardPlan& m = merged.back(); m.s1 = sp.s1; m.bp += sp.bp; m.iv_starts.insert(m.iv_starts.end(), sp.iv_starts.begin(), sp.iv_starts.end()); m.parts.push_back({sp.rec, sp.s0, sp.s1}); bytes += sp_bytes;
-    }
-    for (auto& m : merged) if (m.parts.size() == 1) m.parts.clear();
-    plan.swap(merged);
-  }
-  // the fetch windows of a shard: its window — or, under --include-bed, the BED spans inside its pieces (rows exist at BED positions only;
-  // the records of optimize_reference_records run from one span to the next, most of what lies under them is never looked at)
-  auto plan_windows = [&](const ShardPlan& sp) {
-    std::vector<std::pair<uint32_t, uint32_t>> w;
-    if (!bf) { w.push_back({sp.s0, sp.s1}); return w; }
-    const uint32_t tid = records[sp.rec].tid; std::vector<Span> spn;
-    auto clip = [&](uint32_t a0, uint32_t a1) { for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
-        for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, a0), hi = std::min<uint64_t>(x.e, a1); if (lo < hi) spn.push_back({lo, hi}); } } };
-    if (sp.parts.empty()) clip(sp.s0, sp.s1); else for (auto& pt : sp.parts) clip(pt.s0, pt.s1);
-    merge_spans(spn); for (auto& x : spn) w.push_back({(uint32_t)x.s, (uint32_t)x.e});
-    if (w.empty()) w.push_back({sp.s0, sp.s0 + 1});   // (no BED position inside: nothing to fetch but an empty window)
-    return w;
-  };
-  auto fetch_shard = [&](const ShardPlan& sp) { return fetch_windows(records[sp.rec].tid, plan_windows(sp)); };
+  build_plan();
+  if (ahead.empty() && plan.size() > 1 && !getenv("MKP_NO_AHEAD")) ahead_from_plan();   // (thresholds known before the plan: the shards go ahead of the loop from here)
   // shards that were ingested ahead: same contig, same hull, same windows
   std::vector<long> plan_ahead(plan.size(), -1);
   for (size_t pi = 0; pi < plan.size(); pi++) for (size_t k = 0; k < ahead.size(); k++)
     if (ahead[k].tid == records[plan[pi].rec].tid && ahead[k].s0 == plan[pi].s0 && ahead[k].s1 == plan[pi].s1 && ahead[k].wins == plan_windows(plan[pi])) { plan_ahead[pi] = (long)k; break; }
-  mark("shard plan done");
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<ShardInput> next_batch;
   const bool early_match = early_set && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
@@ -880,11 +1028,12 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
     std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev;
     const bool attached_already = pre_attached && pi == 0;
+    struct Release { decltype(ahead_release)& rel; long k; ~Release() { if (k >= 0) rel((size_t)k); } } release_shard{ahead_release, plan_ahead[pi]};   // the shard's bytes go back to the budget when this iteration is over
     if (attached_already) dev = std::move(pre_dev);
     else if (plan_ahead[pi] >= 0) { auto t_f = std::chrono::steady_clock::now(); Ahead& A = ahead_wait((size_t)plan_ahead[pi]); batch = std::move(A.in.batch); dev = std::move(A.in.dev); fetch_wait_ms += ms_since(t_f); }
     else { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev); fetch_wait_ms += ms_since(t_f); }
     if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack; ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
-               ingest_records += dev->n_records; }
+               ingest_records += dev->n_records; ingest_kernel_ms += dev->ms_kernel; ingest_comp += dev->comp_bytes; ingest_raw += dev->raw_bytes; }
     if (pi + 1 < plan.size() && plan_ahead[pi + 1] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
     std::vector<uint8_t> merged_focus;   // a merged shard: its records' focus bytes at their places in the hull, zero in between
     if (hf) for (size_t k = 0; k < std::max<size_t>(sp.parts.size(), 1); k++) { const size_t ri = sp.parts.empty() ? sp.rec : sp.parts[k].rec;
@@ -971,6 +1120,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     rep->total_ms = ms_since(t_all); rep->n_rows = wr.n; rep->n_positions = positions; rep->n_shards = n_shards; rep->processed_records = processed;
         rep->skipped_records = skipped;
     for (int b = 0; b < 4; b++) { rep->threshold[b] = kc.per_base_threshold[b]; rep->has_threshold[b] = kc.has_per_base[b]; }
+    rep->grid_wait_ms = grid_wait_ms; rep->callback_ms = callback_ms; rep->ingest_kernel_ms = ingest_kernel_ms; rep->ingest_upload_ms = ingest_ms[1]; rep->ingest_table_ms = ingest_ms[0];
+    rep->ingest_pack_ms = ingest_ms[3]; rep->ingest_comp_bytes = ingest_comp; rep->ingest_raw_bytes = ingest_raw; rep->ingest_blocks = ingest_blocks; rep->ingest_records = ingest_records;
   }
   if (a.stats) fprintf(stderr,
       "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu (on the device %llu) peak_rss_kb=%llu\n",
@@ -978,7 +1129,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
                        (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)bam.bytes_inflated_device.load(), (unsigned long long)peak_rss_kb());
   if (a.stats) {   // every MKP_* variable that is set: they pick kernels and paths and would otherwise leave no trace in a measurement
     std::string ov; for (char** e = ::environ; e && *e; e++) if (!strncmp(*e, "MKP_", 4)) { ov += ' '; ov += *e; }
-    fprintf(stderr, "[mkpileup] ingest=%s resident_sampling=%d env overrides:%s\n", dev_ingest ? "device" : "host", pre_attached ? 1 : 0, ov.empty() ? " none" : ov.c_str());
+    fprintf(stderr, "[mkpileup] ingest=%s resident_sampling=%d ahead=%zu shards (estimated %.0f MB, HBM budget %.0f MB) rank=%u/%u env overrides:%s\n", dev_ingest ? "device" : "host", (pre_attached || resident_used) ? 1 : 0,
+        ahead.size(), (double)ahead_est_total / 1048576.0, (double)hbm_budget / 1048576.0, a.rank, a.world, ov.empty() ? " none" : ov.c_str());
   }
   if (a.stats && dev_ingest) fprintf(stderr, "[mkpileup] device ingest: %llu BGZF blocks, %llu records; block plan %.1f ms, upload %.1f, inflate + CRC + chains %.1f, parse + pack %.1f, digest %.1f (overlapped with the threshold estimate / the shard in hand)\n",
       (unsigned long long)ingest_blocks, (unsigned long long)ingest_records, ingest_ms[0], ingest_ms[1], ingest_ms[2], ingest_ms[3], ingest_ms[4]);
@@ -1017,6 +1169,7 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
         else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val());
         else if (s == "--shard-bytes") { a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); a.shard_bytes_set = true; } else if (s == "--no-index") a.no_index = true;
         else if (s == "--device-inflate") a.device_inflate = true; else if (s == "--host-ingest") a.host_ingest = true;
+        else if (s == "--hbm-budget-mb") a.hbm_budget_mb = std::stoull(val());
         else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
     else if (s == "--partition-tag") a.partition_tags.push_back(val()); else if (s == "--prefix") a.prefix = val();
     else if (s == "--bgzf") a.bgzf = true;
@@ -1078,6 +1231,17 @@ extern "C" int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, m
   try {
     Args a; parse_args(argc, argv, &a, true);
     if (a.plan_only) throw Error(MKP_E_INVALID, "--plan-only needs no context: use mkp_pileup_main");
+    return run(a, ctx, report);
+  } catch (const Error& e) { ctx->err = e.what(); return e.status; }
+  catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }
+}
+
+extern "C" int mkp_pileup_run_cb(mkp_ctx* ctx, int argc, const char* const* argv, mkp_threshold_fn fn, void* user, mkp_run_report* report) {
+  if (!ctx) return MKP_E_INVALID;
+  try {
+    Args a; parse_args(argc, argv, &a, true);
+    if (a.plan_only) throw Error(MKP_E_INVALID, "--plan-only needs no context: use mkp_pileup_main");
+    a.thr_cb = fn; a.thr_cb_user = user;
     return run(a, ctx, report);
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
   catch (const std::exception& e) { ctx->err = e.what(); return MKP_E_INVALID; }

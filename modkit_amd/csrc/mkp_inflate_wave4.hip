@@ -283,7 +283,10 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
       LDS_SYNC();
       {
         const int e1 = build(L.lens, nlen_codes, L.lit, LIT_BITS, L.lcount, L.lsym, lane, mkp_w4_lit_entry);
-        if (e1 != 0) { err = 3; break; }   // an incomplete literal/length code is never valid (the host decoder's and zlib's rule)
+        // an incomplete literal/length code is only valid as a single one-bit code (zlib's inflate_table: max == 1 — a block that holds
+        // nothing but its end-of-block symbol); the unused code then decodes to nothing and is an error where it is met
+        { uint32_t used1 = 0; for (int l = 1; l <= 15; l++) used1 += sgpr(L.lcount[l]);
+          if (e1 < 0 || (e1 > 0 && !(used1 == 1u && sgpr(L.lcount[1]) == 1u))) { err = 3; break; } }
         const int e2 = build(L.lens + 288, ndist_codes, L.dist, DIST_BITS, L.dcount, L.dsym, lane, mkp_w4_dist_entry);
         uint32_t used2 = 0; for (int l = 1; l <= 15; l++) used2 += sgpr(L.dcount[l]);
         if (e2 < 0 || (e2 > 0 && !(used2 == 1u && sgpr(L.dcount[1]) == 1u))) { err = 3; break; }   // incomplete distance code: only a single one-bit code

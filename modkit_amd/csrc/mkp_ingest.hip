@@ -94,13 +94,6 @@ mkp_crc32_blocks(const uint8_t* __restrict__ zin, const MkpBgzfBlock* __restrict
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, uint32_t* __restrict__ seg_cnt, MkpIngestTotals* tot) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n_seg) return;
-  seg_cnt[i] = ingest_walk_segment(raw, P.raw_len, segs[i], nullptr, &tot->err);
-}
-
 // Exclusive scan of a[0, n) in place by one 1024-thread workgroup; returns the total to every thread.  Tiles of 4096 elements, four
 // consecutive ones per thread (coalesced), a shuffle scan per wave, the 16 wave totals through LDS, a running 64-bit carry.  (Round 4 gave
 // every thread one contiguous chunk — 64 different cache lines per load instruction — and let thread 0 add the 1024 partial sums.)
@@ -129,6 +122,32 @@ __device__ __forceinline__ unsigned long long block_scan_inplace(uint32_t* __res
     __syncthreads();
   }
   return carry;
+}
+
+// BGZF block table of the uploaded window: one thread per chain (ingest_walk_blocks), counts -> offsets -> {offset, header, payload, ISIZE}
+extern "C" __global__ void __launch_bounds__(256)
+mkp_bgzf_chain_count(const uint8_t* __restrict__ z, const MkpZChain* __restrict__ chains, uint32_t n, uint32_t* __restrict__ cnt, uint32_t* err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cnt[i] = ingest_walk_blocks(z, chains[i], nullptr, err);
+}
+extern "C" __global__ void __launch_bounds__(1024)
+mkp_bgzf_chain_scan(uint32_t* __restrict__ cnt, uint32_t n, uint32_t* err) {
+  const unsigned long long total = block_scan_inplace(cnt, n);
+  if (threadIdx.x == 0) { if (total > 0xfffffff0ull) { atomicOr(err, MKP_ZE_BAD); cnt[n] = 0; } else cnt[n] = (uint32_t)total; }
+}
+extern "C" __global__ void __launch_bounds__(256)
+mkp_bgzf_chain_write(const uint8_t* __restrict__ z, const MkpZChain* __restrict__ chains, uint32_t n, const uint32_t* __restrict__ base, uint32_t cap, MkpZBlk* __restrict__ out, uint32_t* err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (base[i + 1] > cap) { atomicOr(err, MKP_ZE_BAD); return; }
+  ingest_walk_blocks(z, chains[i], out + base[i], err);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, uint32_t* __restrict__ seg_cnt, MkpIngestTotals* tot) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_seg) return;
+  seg_cnt[i] = ingest_walk_segment(raw, P.raw_len, segs[i], nullptr, &tot->err);
 }
 
 // exclusive scan of seg_cnt[0, n) in place (+ the total behind it), one workgroup; tot->n_all = records of the window
@@ -214,6 +233,15 @@ mkp_widen_u32_u64(const uint32_t* __restrict__ in, unsigned long long* __restric
 extern "C" {
 hipError_t mkp_launch_widen(hipStream_t st, const uint32_t* in, unsigned long long* out, uint32_t n) {
   if (n) hipLaunchKernelGGL(mkp_widen_u32_u64, dim3((n + 255u) / 256u), dim3(256), 0, st, in, out, n);
+  return hipGetLastError();
+}
+hipError_t mkp_launch_bgzf_chain_count(hipStream_t st, const uint8_t* z, const MkpZChain* chains, uint32_t n, uint32_t* cnt, uint32_t* err) {
+  if (n) hipLaunchKernelGGL(mkp_bgzf_chain_count, dim3((n + 255u) / 256u), dim3(256), 0, st, z, chains, n, cnt, err);
+  hipLaunchKernelGGL(mkp_bgzf_chain_scan, dim3(1), dim3(1024), 0, st, cnt, n, err);
+  return hipGetLastError();
+}
+hipError_t mkp_launch_bgzf_chain_write(hipStream_t st, const uint8_t* z, const MkpZChain* chains, uint32_t n, const uint32_t* base, uint32_t cap, MkpZBlk* out, uint32_t* err) {
+  if (n) hipLaunchKernelGGL(mkp_bgzf_chain_write, dim3((n + 255u) / 256u), dim3(256), 0, st, z, chains, n, base, cap, out, err);
   return hipGetLastError();
 }
 hipError_t mkp_launch_crc32(hipStream_t st, const uint8_t* zin, const void* blocks, uint32_t n_blocks, const uint8_t* raw, uint32_t* status) {

@@ -83,6 +83,33 @@ MKP_IDEV uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p,
 MKP_IDEV int32_t ld_i32(const uint8_t* p) { int32_t v; __builtin_memcpy(&v, p, 4); return v; }
 MKP_IDEV uint16_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
+// ---- BGZF block table (BamSource::ingest_walk_chain_host on the uploaded bytes).  One thread walks one chain: the blocks from a block
+// start the index knows to the next one.  Offsets are positions in the uploaded buffer `z` (the window's file ranges, each 64-byte aligned).
+// Pass 1 (out == nullptr) counts, pass 2 writes {offset, header bytes, payload bytes, ISIZE}.
+struct MkpZChain { unsigned long long start, stop, range_end, ce; uint32_t ue, pad; };   // stop: the next known block start (~0: none); ce / ue: block offset and in-block offset of the chunk's end
+struct MkpZBlk { unsigned long long coff; uint32_t hdr, clen, isize, pad; };
+#define MKP_ZE_BAD 1u      // not BGZF, or a block without a usable BC field
+#define MKP_ZE_CHAIN 2u    // the chain of block sizes misses the block start the index names
+MKP_IDEV uint32_t ingest_walk_blocks(const uint8_t* z, const MkpZChain ch, MkpZBlk* out, uint32_t* err) {
+  unsigned long long c = ch.start; uint32_t n = 0;
+  for (;;) {
+    if (c >= ch.stop || c > ch.ce || (c == ch.ce && ch.ue == 0) || c + 18 > ch.range_end) break;
+    const uint8_t* hb = z + c; const unsigned long long hn = ch.range_end - c < 600ull ? ch.range_end - c : 600ull;   // (the host reads 600 bytes of header at most)
+    if (hb[0] != 31 || hb[1] != 139 || !(hb[3] & 4)) { MKP_ATOMIC_OR(err, MKP_ZE_BAD); return n; }
+    const uint32_t xlen = ld_u16(hb + 10); unsigned long long x = 12; const unsigned long long xe = 12ull + xlen; uint32_t bsize = 0; bool found = false;
+    if (xe > hn) break;
+    while (x + 4 <= xe) { const uint32_t sl = ld_u16(hb + x + 2); if (hb[x] == 'B' && hb[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { bsize = (uint32_t)ld_u16(hb + x + 4) + 1u; found = true; } x += 4ull + sl; }
+    if (!found || bsize < xlen + 20u) { MKP_ATOMIC_OR(err, MKP_ZE_BAD); return n; }
+    const uint32_t hdr = 12u + xlen, clen = bsize - xlen - 20u;
+    const unsigned long long next = c + hdr + clen + 8ull;
+    if (next > ch.range_end) break;
+    if (out) { MkpZBlk b; b.coff = c; b.hdr = hdr; b.clen = clen; b.isize = ld_u32(z + next - 4); b.pad = 0; out[n] = b; }
+    n++; c = next;
+  }
+  if (ch.stop != ~0ull && c != ch.stop && !(c > ch.ce || (c == ch.ce && ch.ue == 0))) MKP_ATOMIC_OR(err, MKP_ZE_CHAIN);
+  return n;
+}
+
 // ---- record chains.  One thread walks one segment: entry points are record starts the host knows (chunk starts and the BAI's 16 kb
 // linear index), `block_size` links the records in between.  Pass 1 (out == nullptr) counts, pass 2 writes the starts.
 MKP_IDEV uint32_t ingest_walk_segment(const uint8_t* raw, unsigned long long raw_len, const MkpSeg sg, unsigned long long* out, uint32_t* err) {
@@ -168,6 +195,12 @@ MKP_IDEV uint32_t ingest_cigar_words(uint32_t n_cigar) { return n_cigar ? n_ciga
 // what the packer's tokeniser leaves for one record
 struct MkpTokOut { uint32_t n_tags; uint32_t n_calls; uint32_t ml_used; unsigned long long cap; unsigned long long key_hash; uint32_t sum2; };
 
+// eight text bytes from q on, zero past `lim` (never reads past it)
+MKP_IDEV unsigned long long ingest_ld8(const uint8_t* q, const uint8_t* lim) {
+  if (q + 8 <= lim) { unsigned long long v; __builtin_memcpy(&v, q, 8); return v; }
+  unsigned long long v = 0; for (int k = 0; k < 8 && q + k < lim; k++) v |= (unsigned long long)q[k] << (8 * k);
+  return v;
+}
 MKP_IDEV bool ingest_ws(uint8_t ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\f' || ch == '\v'; }
 MKP_IDEV void fnv_byte(unsigned long long* h, uint8_t b) { *h ^= b; *h *= 1099511628211ull; }
 MKP_IDEV void fnv_decimal(unsigned long long* h, uint32_t v) {   // the digits std::to_string(v) would append
@@ -221,14 +254,18 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
       // ---- delta list -> cumulative ranks (to_positions_specific / to_positions, mod_bam.rs:697-767)
       const uint32_t first_rank = n_rank; uint32_t tn = 0;
       if (offset + 1 <= (uint32_t)(e - s)) {
+        // (the hot loop of the tokeniser — a 50 kb read carries ~30 KB of digits and commas: the text is read eight bytes at a time into a
+        // register and taken apart there; a byte load per character made the longest read's serial chain the whole kernel)
         const uint8_t* d = s + offset + 1; bool first = true; unsigned long long acc = 0;
+        const uint8_t* wb = d; unsigned long long wv = ingest_ld8(d, e);   // window: the eight bytes at wb
+#define MKP_CH(q) ((uint8_t)(((q) >= wb && (q) < wb + 8) ? (wv >> (8 * (int)((q) - wb))) : ((wb = (q)), (wv = ingest_ld8((q), e)))))
         for (;;) {
           const uint8_t* save = d;
-          if (!first) { if (d >= e || *d != ',') break; d++; }
-          while (d < e && ingest_ws(*d)) d++;
-          if (!(d < e && *d >= '0' && *d <= '9')) { if (first) return false; d = save; break; }
-          unsigned long long v = 0; while (d < e && *d >= '0' && *d <= '9') { v = v * 10 + (unsigned long long)(*d - '0'); if (v > 0xffffffffull) return false; d++; }
-          while (d < e && ingest_ws(*d)) d++;
+          if (!first) { if (d >= e || MKP_CH(d) != ',') break; d++; }
+          while (d < e && ingest_ws(MKP_CH(d))) d++;
+          if (!(d < e && MKP_CH(d) >= '0' && MKP_CH(d) <= '9')) { if (first) return false; d = save; break; }
+          unsigned long long v = 0; while (d < e) { const uint8_t ch = MKP_CH(d); if (ch < '0' || ch > '9') break; v = v * 10 + (unsigned long long)(ch - '0'); if (v > 0xffffffffull) return false; d++; }
+          while (d < e && ingest_ws(MKP_CH(d))) d++;
           acc = first ? v : acc + v + 1;   // sum(d + 1) - 1
           if (acc >= (fb == 4 ? (unsigned long long)R.l_seq : 0xffffffffull)) { if (fb == 4 || acc >= 0xffffffffull) return false; }
           // the host packer stores the whole list and then finds the ML array too short; the answer is the same as soon as it is known
@@ -236,6 +273,7 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
           if (pointer + ((unsigned long long)tn + 1) * n_codes > ml_n) return false;       // "ML array too short" (mod_bam.rs:1222-1228)
           ranks[n_rank++] = (uint32_t)acc; tn++; first = false;
         }
+#undef MKP_CH
       }
       const unsigned long long need = pointer + (unsigned long long)tn * n_codes;
       if (n_hdr < MKP_MAX_TAGS) {

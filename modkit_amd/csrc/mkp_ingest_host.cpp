@@ -18,6 +18,8 @@ using namespace mkp;
 
 extern "C" {
 hipError_t mkp_launch_crc32(hipStream_t, const uint8_t*, const void*, uint32_t, const uint8_t*, uint32_t*);
+hipError_t mkp_launch_bgzf_chain_count(hipStream_t, const uint8_t*, const MkpZChain*, uint32_t, uint32_t*, uint32_t*);
+hipError_t mkp_launch_bgzf_chain_write(hipStream_t, const uint8_t*, const MkpZChain*, uint32_t, const uint32_t*, uint32_t, MkpZBlk*, uint32_t*);
 hipError_t mkp_launch_ingest_count(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, uint32_t*, MkpIngestTotals*);
 hipError_t mkp_launch_ingest_parse(hipStream_t, const uint8_t*, const MkpIngestParams*, const int32_t*, const MkpSeg*, const uint32_t*, unsigned long long*, MkpRecInfo*, uint32_t*, int32_t*, MkpIngestTotals*);
 hipError_t mkp_launch_ingest_pack(hipStream_t, const uint8_t*, uint32_t, const MkpRecInfo*, const uint32_t*, MkpReadHdr*, uint32_t*, uint32_t*, uint8_t*, MkpTagRef*, uint32_t*, uint8_t*, MkpRecDigest*, MkpIngestTotals*);
@@ -50,7 +52,11 @@ struct mkp_dev_ingest {
 
 mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   std::unique_ptr<mkp_dev_ingest> d(new mkp_dev_ingest()); d->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  // the record kernels' stream goes before the upload stream, which also runs the CRC kernel beside them: the CRC's thirteen thousand
+  // workgroups otherwise hold up the one-workgroup scans that the host waits for (2.6 ms for a 15 us kernel)
+  int prio_lo = 0, prio_hi = 0;
+  if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return nullptr;
+  if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
   for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + chain kernels, for the trace)
@@ -129,11 +135,49 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     up_ms = ms_since(t_up);
   });
   struct JoinUp { std::thread& t; ~JoinUp() { if (t.joinable()) t.join(); } } join_up{uploader};
-  bam.ingest_blocks(&plan);
-  out->ms_plan = ms_since(t0);
-  uploader.join();
-  if (up_err) throw *up_err;
-  out->ms_upload = up_ms;
+  // ---- block table.  The device walks the BGZF headers of the uploaded bytes, one thread per chain between block starts the index knows
+  // (round 4 walked them on the host with one pread per block: 54 000 preads, 40-90 ms beside an upload that wants the same cores);
+  // MKP_HOST_BLOCK_TABLE=1 keeps the host walk (A/B runs).
+  static const bool host_table = getenv("MKP_HOST_BLOCK_TABLE") && !strcmp(getenv("MKP_HOST_BLOCK_TABLE"), "1");
+  if (host_table) { bam.ingest_blocks(&plan); out->ms_plan = ms_since(t0); uploader.join(); if (up_err) throw *up_err; out->ms_upload = up_ms; }
+  else {
+    std::vector<BamSource::IngestChain> chains; bam.ingest_chains(plan, &chains);
+    std::vector<MkpZChain> zc(chains.size());
+    for (size_t i = 0; i < chains.size(); i++) { const BamSource::IngestRange& rg = plan.ranges[chains[i].range]; const uint64_t zb = zbase[chains[i].range], fo = rg.file_off;
+      MkpZChain c; c.start = zb + (chains[i].start - fo); c.stop = chains[i].stop == UINT64_MAX ? ~0ull : zb + (chains[i].stop - fo); c.range_end = zb + rg.file_len;
+      c.ce = (rg.vend >> 16) >= fo ? zb + ((rg.vend >> 16) - fo) : 0; c.ue = (uint32_t)(rg.vend & 0xffff); c.pad = 0; zc[i] = c; }
+    out->ms_plan = ms_since(t0);
+    uploader.join();
+    if (up_err) throw *up_err;
+    out->ms_upload = up_ms;
+    auto t_tab = std::chrono::steady_clock::now();
+    const size_t nc = zc.size();
+    if (nc > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF chains; use smaller shards");
+    d->segs.ensure(nc * sizeof(MkpZChain)); d->seg_cnt.ensure((nc + 2) * 4); d->tot.ensure(sizeof(MkpIngestTotals));
+    d->small.ensure(256);
+    uint32_t* h_small = (uint32_t*)d->small.p;   // [0] error bits, [1] number of blocks
+    ok(hipMemcpyAsync(d->segs.p, zc.data(), nc * sizeof(MkpZChain), hipMemcpyHostToDevice, d->stream), "H2D");
+    ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
+    ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
+    ok(mkp_launch_bgzf_chain_count(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>(), (uint32_t)nc, d->seg_cnt.as<uint32_t>(), d->tot.as<uint32_t>()), "block table launch");
+    ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 1, d->seg_cnt.as<uint32_t>() + nc, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipStreamSynchronize(d->stream), "block table sync");
+    if (h_small[0]) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+    const uint32_t nblk = h_small[1];
+    d->zblk.ensure(((size_t)nblk + 1) * sizeof(MkpZBlk));
+    std::vector<MkpZBlk> zb(nblk); std::vector<uint32_t> cbase(nc + 1);
+    ok(mkp_launch_bgzf_chain_write(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>(), (uint32_t)nc, d->seg_cnt.as<uint32_t>(), nblk, d->zblk.as<MkpZBlk>(), d->tot.as<uint32_t>()), "block table launch");
+    if (nblk) ok(hipMemcpyAsync(zb.data(), d->zblk.p, (size_t)nblk * sizeof(MkpZBlk), hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipMemcpyAsync(cbase.data(), d->seg_cnt.p, (nc + 1) * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipStreamSynchronize(d->stream), "block table sync");
+    if (h_small[0]) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+    std::vector<std::vector<BamSource::IngestBlk>> parts(nc);
+    for (size_t i = 0; i < nc; i++) { const uint64_t zbs = zbase[chains[i].range], fo = plan.ranges[chains[i].range].file_off; parts[i].reserve(cbase[i + 1] - cbase[i]);
+      for (uint32_t k = cbase[i]; k < cbase[i + 1]; k++) parts[i].push_back({fo + (zb[k].coff - zbs), zb[k].hdr, zb[k].clen, zb[k].isize, 0}); }
+    bam.ingest_layout(&plan, chains, parts);
+    out->ms_plan += ms_since(t_tab);
+  }
   bam.bytes_read += plan.comp_total;
   if (plan.raw_total == 0) return out;
   if (plan.blks.size() > 0xfffffff0ull || plan.entries.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");

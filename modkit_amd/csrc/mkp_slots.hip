@@ -560,39 +560,35 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(lds + tal_words);
   const int lane = lane_id();
   const uint32_t wave = rfl(threadIdx.x >> 6);
-  // XCD-aware mapping: consecutive workgroups land on different XCDs; give each XCD a contiguous run of tiles so that the reads
-  // neighbouring tiles share stay in one L2
-  // tile t = workgroup t: rows leave in genome order through a look-back over the tiles before (mkp_dev_rows.hpp), which needs the
-  // dispatch order to be the genome order (an XCD-aware permutation was tried in round 3: it kept neighbouring tiles' shared reads in one
-  // L2, but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need)
-  const uint32_t tix = blockIdx.x;
+  // A workgroup takes the next TILE from an atomic ticket (row_cursor[0]; the host zeroes it before the first pass), not from blockIdx: rows
+  // leave in genome order through a look-back over the runs before (mkp_dev_rows.hpp), and a run may only wait for runs whose workgroups
+  // are already running — true for tickets whatever the dispatch order, with any number of contexts on the device.  (Tiles in ticket
+  // order also start in genome order; an XCD-aware permutation was tried in round 3: it kept neighbouring tiles' shared reads in one L2,
+  // but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need.)
+  __shared__ uint32_t run_ticket;
+  if (threadIdx.x == 0) run_ticket = atomicAdd(row_cursor, 1u);
+  __syncthreads();
+  const uint32_t run = run_ticket;                                  // row-run index: key pass * tiles + tile (passes run one after the other on the stream)
+  const uint32_t tix = KEYED ? run - key_run * n_tiles : run;
+  if (tix >= n_tiles) { if (threadIdx.x == 0) atomicOr(dev_err, ERR_ROW_CAP); return; }   // (cannot happen: one ticket per workgroup)
   const MkpSTile tl = tiles[tix];
   const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
   for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
   for (uint32_t k = threadIdx.x; k < n_tslots; k += PILEUP_THREADS) fpos[k] = (int32_t)slot_pos[gh0 + k];
-  if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }
+  if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }   // (tiles hold at least one candidate read)
   __syncthreads();
 
   const uint32_t rid_end = tl.last;
   const uint32_t talbase = lds_addr(tal), S4 = S * 4u;
-  uint32_t rid_nx; MkpVisit v_nx;
-  { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 1u); rid_nx = rfl(ticket); }
-  v_nx = visits[min(rid_nx, rid_end - 1u)];   // (tiles hold at least one candidate read)
-  for (;;) {
-    const uint32_t rid = rid_nx;
-    if (rid >= rid_end) break;
-    const MkpVisit v = v_nx;
-    { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 1u); rid_nx = rfl(ticket); }
-    v_nx = visits[min(rid_nx, rid_end - 1u)];
+  // one visit: the read's bytes for this tile's slots (first dword per lane already in `wcur`), its observed codes, its overflow events
+  auto visit = [&](const MkpVisit& v, uint32_t wcur) {
     const uint32_t a = max(v.gs0, gh0), b = min(v.gs0 + v.n_sl, gh1);
-    if (a >= b) continue;
-    if (KEYED && (v.flags >> 8) != key_filter) continue;   // --partition-tag: one pass per key
+    if (a >= b) return;
+    if (KEYED && (v.flags >> 8) != key_filter) return;   // --partition-tag: one pass per key
     const uint32_t k_lo = a - v.gs0, k_hi = b - v.gs0;      // the read's bytes for this tile
     const uint32_t col0 = v.gs0 - gh0;                      // column of byte k = col0 + k (mod 2^32)
     const uint8_t* __restrict__ cp = cov + v.cov_off;
-    // the stream: a dword (four slots) per lane, requested before the observed-code updates
     const uint32_t kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
-    uint32_t wcur = kfirst < k_hi ? *reinterpret_cast<const uint32_t*>(cp + kfirst) : 0xffffffffu;
     // observed mod codes over the columns the read is in (add_mod_codes_for_record, pileup/mod.rs:831-835)
     if ((v.flags & MKP_VF_OK) && (v.obs0 | v.obs1)) {
       if (!(v.flags & MKP_VF_GAPS)) {
@@ -635,6 +631,25 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
         if (e.pos >= gh0 && e.pos < gh1) lds_add(talbase + 4u * (e.pos - gh0) + __umul24(e.info & 31u, S4), (e.info & 32u) ? 0x10000u : 1u);
       }
     }
+  };
+  // Reads are drawn FOUR at a time: their visit records and the first stream dword of each are requested before any of them is used.  A visit
+  // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics, ~1.5 us of memory latency for ~150 bytes; with one visit in
+  // flight per wave (round 4) a CU's 32 waves retired ~20 visits per microsecond, and 1 000 visits per CU were the kernel (SQ: 73 % of the
+  // wave cycles waiting).
+  for (;;) {
+    uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 4u); base = rfl(ticket); }
+    if (base >= rid_end) break;
+    MkpVisit vv[4]; uint32_t ww[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) vv[j] = visits[min(base + j, rid_end - 1u)];   // (uniform: scalar loads)
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) {
+      const uint32_t a = max(vv[j].gs0, gh0), b = min(vv[j].gs0 + vv[j].n_sl, gh1);
+      const uint32_t k_lo = a - vv[j].gs0, k_hi = b - vv[j].gs0, kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
+      ww[j] = (a < b && kfirst < k_hi) ? *reinterpret_cast<const uint32_t*>(cov + vv[j].cov_off + kfirst) : 0xffffffffu;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) if (base + j < rid_end) visit(vv[j], ww[j]);
   }
   __syncthreads();
   // observed-code difference arrays -> counts, in place and still packed
@@ -652,7 +667,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   __syncthreads();
   StreamSlotMap sm; sm.fpos = fpos; sm.n = n_tslots;
   MkpTile tl2; tl2.r0 = tl.r0; tl2.r1 = tl.r1; tl2.first = tl.first; tl2.last = tl.last;
-  emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, run, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
 }
 
 #define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \

@@ -259,25 +259,54 @@ def split_threshold_flags(flags, q=None, mode=None):
     return sflags, eflags, rest, mode, q
 
 
+def reduce_thresholds(ctx, q, rccl_direct=None):
+    """Per-base pass thresholds from the histograms every rank's context holds (mkp_histogram_*): summed over the ranks — RCCL on the
+    device buffers behind the C ABI (rccl_direct / MKP_RCCL_DIRECT=1, nccl backend), else mkp_histogram_get + torch.distributed — then the
+    exact percentile of the union.  All ranks call this in step."""
+    dist = _dist()
+    comm = None
+    if rccl_direct is None:
+        rccl_direct = _env_flag("MKP_RCCL_DIRECT")
+    if rccl_direct and dist.is_initialized() and dist.get_backend() == "nccl":
+        comm = RcclComm()
+    out = {}
+    try:
+        for b in BASES:
+            if comm is not None:
+                t, n = percentile_from_histograms(lambda level, prefix, b=b: ctx.histogram_allreduce(comm, b, level, prefix), q, reduced=True)
+            else:
+                t, n = percentile_from_histograms(lambda level, prefix, b=b: ctx.histogram_get(b, level, prefix), q)
+            if t is not None:
+                out[b] = t
+    finally:
+        if comm is not None:
+            comm.close()
+    return out
+
+
 def pileup_sharded(argv, rank=None, world=None, device=None, q=None, stats=None, mode=None):
-    """`modkit pileup` with ONE BAM sharded over the ranks of the current torch.distributed job (one process per GPU):
-    thresholds from the all-reduced histograms of rank-sharded sampling, then every rank runs its contiguous run of the
-    reference's interval grid (mkp_pileup_main --gpus-rank/--gpus-world) into `<out>.rank<R>`, and rank 0 concatenates the parts
-    in rank order into `<out>`.  argv = [in.bam, out.bed, flags...] (no threshold flags).
+    """`modkit pileup` with ONE BAM sharded over the ranks of the current torch.distributed job (one process per GPU): every rank runs
+    its contiguous run of the reference's interval grid into `<out>.rank<R>` and rank 0 concatenates the parts in rank order into `<out>`.
+    argv = [in.bam, out.bed, flags...].  Each rank makes ONE call into the library (mkp_pileup_run_cb): its shards are ingested on the
+    device from the first moment — several in flight, kept in HBM under a budget — and the pass thresholds arrive through a callback.
     Threshold modes (`mode`, default: by the flags, as `modkit pileup` itself decides):
       "sampled" — the reference's default: the count-based schedule (`-n 10042`, or `-f x < 1`) carries quotas from interval to interval
-                  and does not shard; it reads only interval heads, so rank 0 estimates (mkp_estimate_thresholds) and broadcasts four
-                  floats.  The output is byte-identical to a single-GPU run with the same flags.
-      "full"    — `-f 1.0` (thresholds.rs:121-159): every rank samples its own sampling intervals, the two-level histograms are summed
-                  over the ranks (the path's one collective) and every rank evaluates the percentile of the union.  Byte-identical to a
-                  single-GPU run with `-f 1.0`.
+                  and does not shard; it reads only interval heads, so rank 0 estimates (mkp_estimate_thresholds on a context of its own,
+                  beside its ingest) and broadcasts four floats, while every rank's shards are already on their way into HBM.
+                  The output is byte-identical to a single-GPU run with the same flags.
+      "full"    — `-f 1.0` (thresholds.rs:121-159): every rank samples the shards it has just ingested, FROM HBM (each read belongs to the
+                  shard that holds its start, so the union over ranks is the single-rank sample), the two-level histograms are summed
+                  over the ranks (the path's one collective) and every rank evaluates the percentile of the union; then the pileup pass
+                  runs on the same resident shards — every block of the file is read, uploaded and inflated once, by one rank.
+                  Byte-identical to a single-GPU run with `-f 1.0`.
       "given"   — `--filter-threshold` / `--no-filtering` in argv: nothing to estimate.
     Returns the thresholds used ({base: f32}; empty for "given").
     `--with-header` is written by rank 0 only; `--bgzf` (one BGZF stream + one index) and `--partition-tag` (one file per key)
     do not concatenate and are refused.  `stats` (a dict) receives this rank's wall times."""
     import os
     import shutil
-    from . import Context, pileup
+    import time
+    from . import Context
     dist = _dist()
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -290,35 +319,38 @@ def pileup_sharded(argv, rank=None, world=None, device=None, q=None, stats=None,
     if rank > 0:   # one header, from rank 0
         flags = [f for f in flags if f not in ("--with-header", "--header")]
     sflags, eflags, rest, mode, q = split_threshold_flags(flags, q, mode)
-    import time
     t0 = time.time()
-    thr = {}
-    if mode == "full":
-        ctx = Context(device=0 if device is None else device)
-        try:
-            thr = estimate_thresholds_allreduce(ctx, bam, sflags, q=q, rank=rank, world=world)
-        finally:
-            ctx.close()
-    elif mode == "sampled":
-        if rank == 0:   # heads of the sampling intervals only: one rank's work, the others wait for four floats
-            ctx = Context(device=0 if device is None else device)
-            try:
-                thr = ctx.estimate_thresholds(bam, sflags + eflags)
-            finally:
-                ctx.close()
-        thr = broadcast_thresholds(thr, src=0)
-    t1 = time.time()
-    targv = []
-    if mode != "given":
-        for b, v in sorted(thr.items()):
-            targv += ["--filter-threshold", "%s:%r" % (b, v)]
-        if not targv:
+    used, t_thr = {}, [0.0]
+
+    def thresholds(have_sample):
+        t1 = time.time()
+        if have_sample:   # full-data mode: this rank's sample is in ctx's histograms
+            thr = reduce_thresholds(ctx, q)
+        else:             # count-based estimate: one rank's job
+            thr = {}
+            if rank == 0:
+                c2 = Context(device=0 if device is None else device)
+                try:
+                    thr = c2.estimate_thresholds(bam, sflags + eflags)
+                finally:
+                    c2.close()
+            thr = broadcast_thresholds(thr, src=0)
+        if not thr:
             raise ValueError("no mod calls sampled on any rank")
-    flags = rest
+        used.update(thr)
+        t_thr[0] = time.time() - t1
+        return thr
+
     part = "%s.rank%d" % (out, rank)
-    pileup([bam, part] + flags + targv + ["--gpus-rank", str(rank), "--gpus-world", str(world)] + (["--device", str(device)] if device is not None else []))
+    run_flags = rest + (["-f", "1.0", "-p", repr(float(q))] if mode == "full" else []) + ["--gpus-rank", str(rank), "--gpus-world", str(world)]
+    ctx = Context(device=0 if device is None else device)
+    try:
+        rep = ctx.pileup_run_cb([bam, part] + run_flags, thresholds)
+    finally:
+        ctx.close()
     if stats is not None:
-        stats.update({"threshold_s": t1 - t0, "pileup_s": time.time() - t1, "part_bytes": os.path.getsize(part)})
+        stats.update({"threshold_s": t_thr[0], "pileup_s": time.time() - t0 - t_thr[0], "total_s": time.time() - t0, "part_bytes": os.path.getsize(part),
+                      "report": rep.as_dict()})
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
@@ -329,7 +361,7 @@ def pileup_sharded(argv, rank=None, world=None, device=None, q=None, stats=None,
                 os.remove("%s.rank%d" % (out, r))
     if dist.is_initialized():
         dist.barrier()
-    return thr
+    return dict(used)
 
 
 def shard_plan(argv, rank, world):

@@ -191,7 +191,8 @@ uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
       }
       {
         const int e1 = build(L.lens, nlen_codes, L.lit, LIT_BITS, L.lcount, L.lsym, mkp_w4_lit_entry);
-        if (e1 != 0) { err = 3; break; }
+        { uint32_t used1 = 0; for (int l = 1; l <= 15; l++) used1 += L.lcount[l];
+          if (e1 < 0 || (e1 > 0 && !(used1 == 1u && L.lcount[1] == 1u))) { err = 3; break; } }
         const int e2 = build(L.lens + 288, ndist_codes, L.dist, DIST_BITS, L.dcount, L.dsym, mkp_w4_dist_entry);
         uint32_t used2 = 0; for (int l = 1; l <= 15; l++) used2 += L.dcount[l];
         if (e2 < 0 || (e2 > 0 && !(used2 == 1u && L.dcount[1] == 1u))) { err = 3; break; }

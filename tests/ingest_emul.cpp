@@ -38,6 +38,35 @@ static uint32_t crc_sliced(const uint8_t* p, uint32_t len) {
   return c[0] ^ 0xffffffffu;
 }
 
+// The block table as the device builds it (mkp_ingest_host.cpp): the ranges' bytes laid out as the upload lays them out, one
+// ingest_walk_blocks per chain, the host's layout over the result — must be the plan the host's pread walk arrives at.
+static int device_block_table(const BamSource& src, uint32_t t, const FetchParts& parts, const BamSource::IngestPlan& want) {
+  BamSource::IngestPlan plan; src.ingest_ranges(t, parts, &plan);
+  if (plan.ranges.empty()) return want.blks.empty() ? 0 : fail("device block table: ranges", t, 0, (long long)want.blks.size());
+  std::vector<uint64_t> zbase(plan.ranges.size()); uint64_t zbytes = 0;
+  for (size_t r = 0; r < plan.ranges.size(); r++) { zbase[r] = zbytes; zbytes += (plan.ranges[r].file_len + 63) & ~63ull; }
+  std::vector<uint8_t> z(zbytes + 64, 0xA5);
+  for (size_t r = 0; r < plan.ranges.size(); r++) if (::pread(src.fd(), z.data() + zbase[r], plan.ranges[r].file_len, (off_t)plan.ranges[r].file_off) != (ssize_t)plan.ranges[r].file_len) { fprintf(stderr, "pread failed\n"); return 2; }
+  std::vector<BamSource::IngestChain> chains; src.ingest_chains(plan, &chains);
+  std::vector<std::vector<BamSource::IngestBlk>> bparts(chains.size()); uint32_t err = 0;
+  for (size_t i = 0; i < chains.size(); i++) {
+    const BamSource::IngestRange& rg = plan.ranges[chains[i].range]; const uint64_t zb = zbase[chains[i].range], fo = rg.file_off;
+    MkpZChain c; c.start = zb + (chains[i].start - fo); c.stop = chains[i].stop == UINT64_MAX ? ~0ull : zb + (chains[i].stop - fo); c.range_end = zb + rg.file_len;
+    c.ce = (rg.vend >> 16) >= fo ? zb + ((rg.vend >> 16) - fo) : 0; c.ue = (uint32_t)(rg.vend & 0xffff); c.pad = 0;
+    const uint32_t n = ingest_walk_blocks(z.data(), c, nullptr, &err); std::vector<MkpZBlk> out(n + 1);
+    if (ingest_walk_blocks(z.data(), c, out.data(), &err) != n) return fail("device block table: the two passes disagree", i, n, 0);
+    for (uint32_t k = 0; k < n; k++) bparts[i].push_back({fo + (out[k].coff - zb), out[k].hdr, out[k].clen, out[k].isize, 0});
+  }
+  if (err) return fail("device block table: error bits", t, err, 0);
+  src.ingest_layout(&plan, chains, bparts);
+  if (plan.blks.size() != want.blks.size() || plan.raw_total != want.raw_total || plan.entries != want.entries) return fail("device block table: size / entries", t, (long long)plan.blks.size(), (long long)want.blks.size());
+  for (size_t k = 0; k < plan.blks.size(); k++) { const auto& a = plan.blks[k]; const auto& b = want.blks[k];
+    if (a.coff != b.coff || a.hdr != b.hdr || a.clen != b.clen || a.isize != b.isize || a.doff != b.doff) return fail("device block table: block", k, (long long)a.coff, (long long)b.coff); }
+  for (size_t r = 0; r < plan.ranges.size(); r++) { const auto& a = plan.ranges[r]; const auto& b = want.ranges[r];
+    if (a.blk0 != b.blk0 || a.blk1 != b.blk1 || a.raw_start != b.raw_start || a.raw_limit != b.raw_limit || a.entry0 != b.entry0 || a.entry1 != b.entry1) return fail("device block table: range", r, (long long)a.raw_limit, (long long)b.raw_limit); }
+  return 0;
+}
+
 // --plan: the indexed side.  BamSource::ingest_plan (block table, window layout, entry points from the BAI) + the chain walk + the region
 // test must select exactly the records BamSource::fetch returns, for whole contigs and for sub-regions, and no chain may miss its entry point.
 static int plan_mode(const char* path) {
@@ -49,6 +78,7 @@ static int plan_mode(const char* path) {
     const uint32_t regions[4][2] = {{0, L + 16}, {L / 3, 2 * L / 3 + 1}, {L / 2, L / 2 + 50}, {L > 20000 ? L - 20000 : 0, L}};
     for (auto& rg : regions) {
       BamSource::IngestPlan plan; src->ingest_plan(t, rg[0], rg[1], &plan);
+      if (int rc = device_block_table(*src, t, FetchParts{{(int64_t)rg[0], (int64_t)rg[1]}}, plan)) return rc;
       std::vector<uint8_t> raw(plan.raw_total + 8, 0);
       for (auto& r : plan.ranges) {
         std::vector<uint8_t> comp(r.file_len + 8, 0);
@@ -79,6 +109,7 @@ static int plan_mode(const char* path) {
     const FetchParts layouts[3] = {{{L / 10, L / 10 + 300}, {L / 2, L / 2 + 1200}, {L - 1500, L - 200}}, {{0, 50}, {60, 61}, {L / 3, 2 * L / 3}}, {{100, 101}, {L / 4, L / 4 + 16}, {L / 4 + 16, L / 4 + 5000}, {L - 50, L + 16}}};
     for (auto& parts : layouts) {
       BamSource::IngestPlan plan; src->ingest_ranges(t, parts, &plan); src->ingest_blocks(&plan);
+      if (int rc = device_block_table(*src, t, parts, plan)) return rc;
       std::vector<uint8_t> raw(plan.raw_total + 8, 0);
       for (auto& r : plan.ranges) { std::vector<uint8_t> comp(r.file_len + 8, 0); if (::pread(src->fd(), comp.data(), r.file_len, (off_t)r.file_off) != (ssize_t)r.file_len) return 2;
         for (size_t k = r.blk0; k < r.blk1; k++) { const auto& b = plan.blks[k]; if (b.isize) inflate_block(comp.data() + (b.coff - r.file_off) + b.hdr, b.clen, raw.data() + b.doff, b.isize); } }

@@ -259,6 +259,58 @@ def test_two_processes_default_sampled_thresholds_equal_single_gpu(oracle_bin, t
     assert open(out).read() == whole
 
 
+def _dev_vs(text, tmp, bam, flags, name):
+    out = os.path.join(str(tmp), name)
+    p = subprocess.run([os.path.join(ROOT, "modkit_amd", "csrc", "mkpileup"), "pileup", bam, out] + flags + ["--stats"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-600:]
+    assert open(out).read() == text, name
+    return p.stderr
+
+
+def test_shards_ahead_as_pieces_of_contigs_and_under_a_budget(oracle_bin, tmp_path):
+    """Round 5: the shards of a run are ingested ahead of the loop whatever their cut — whole contigs, or pieces of contigs (a contig larger
+    than a shard; here forced with --shard-bp) — several in flight under an HBM budget, and the full-data estimate (-f 1.0) samples from them
+    in HBM: a read that lies in two pieces belongs to the first.  Every variant must write what the default run writes (== the oracle)."""
+    bam, fa, meta = gen(tmp_path, "pc", [("chr1", 2_300_000), ("chr2", 1_500_000), ("chrX", 700_000)], 8_000, "hm", 47, ["--cpg-depleted", "--mean-len", "7000"])
+    flags = ["--cpg", "--ref", fa, "--sampling-interval-size", "350000"]
+    full = both(oracle_bin, tmp_path, bam, flags + ["-f", "1.0"])                          # whole contigs ahead, sampled from HBM
+    err = _dev_vs(full, tmp_path, bam, flags + ["-f", "1.0", "--shard-bp", "450000"], "pieces_full.bed")   # pieces of contigs, sampled from HBM
+    assert "resident_sampling=1" in err and "full-data threshold sample taken from" in err and "ahead=" in err and "ahead=0 " not in err and "ahead=3 " not in err, err[-400:]
+    err = _dev_vs(full, tmp_path, bam, flags + ["-f", "1.0", "--shard-bp", "450000", "--hbm-budget-mb", "1"], "pieces_full_budget.bed")   # too small to hold them: host sampler, streamed shards
+    assert "resident_sampling=0" in err, err[-400:]
+    dflt = both(oracle_bin, tmp_path, bam, flags)                                          # the count-based default
+    err = _dev_vs(dflt, tmp_path, bam, flags + ["--hbm-budget-mb", "1"], "default_budget.bed")           # whole contigs, one admitted at a time
+    assert "resident_sampling=0" in err, err[-400:]
+    err = _dev_vs(dflt, tmp_path, bam, flags + ["--shard-bp", "450000"], "pieces_default.bed")           # pieces: estimate from the host reader, then the pieces ahead of the loop
+    assert "ahead=" in err and "ahead=0 " not in err, err[-400:]
+
+
+@pytest.mark.parametrize("extra,run_extra", [(["-f", "1.0", "-p", "0.1"], ["--shard-bp", "400000"]), ([], ["--shard-bp", "400000", "--hbm-budget-mb", "1"])],
+                         ids=["full_resident_pieces", "sampled_streamed"])
+def test_two_processes_several_shards_per_rank(oracle_bin, tmp_path, extra, run_extra):
+    """pileup_sharded = one mkp_pileup_run_cb per rank: each rank's shards (here several pieces per rank) are ingested ahead; in the full-data
+    mode the rank samples them from HBM and the callback all-reduces the histograms, in the count-based mode the callback waits for rank 0's
+    broadcast while the shards come in.  Byte-identical to the single-GPU run and the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    bam, fa, meta = gen(tmp_path, "c4m", [("chr1", 2_100_000), ("chr2", 1_300_000), ("chrX", 800_000)], 7_500, "hm", 48, ["--cpg-depleted", "--mean-len", "6500"])
+    flags = ["--preset", "traditional", "--ref", fa, "--sampling-interval-size", "300000"] + extra
+    whole = both(oracle_bin, tmp_path, bam, flags)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = os.path.join(str(tmp_path), "sharded.bed")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, [bam, out] + flags + run_extra, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0] == res[1] and "C" in res[0]
+    assert open(out).read() == whole
+
+
 def test_histogram_allreduce_through_rccl_on_one_rank(tmp_path):
     """mkp_histogram_allreduce: the device histograms widened to u64 and summed with ncclAllReduce on a communicator made through
     librccl's C API (modkit_amd.distributed.RcclComm).  One rank here (the box has one GPU): the sum is the histogram itself; what is

@@ -66,6 +66,11 @@ def deflate_corpus(seed=5, corrupt=400, full_block=False):
         recs.append((nprng.integers(0, 256, int(nprng.integers(1, 400)), dtype=np.uint8).tobytes(), int(nprng.integers(0, 70000))))
     recs.append((b"", 10))
     recs.append((b"\x07", 0))
+    # a dynamic block that holds nothing but its end-of-block symbol: ONE literal/length code, one bit long — an incomplete code zlib accepts
+    # (inflate_table: max == 1); with a distance code of length 0 and of length 1.  And the same block asked to decode its unused code.
+    recs.append((bytes.fromhex("05e081080000000020f85b1f"), 0))
+    recs.append((bytes.fromhex("05e081080000000020f85b3f"), 0))
+    recs.append((bytes.fromhex("05e081080000000020f85b5f"), 0))   # (first data bit 1: the code that does not exist)
     return recs
 
 
