@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--genome-scale", type=float, default=0.1, help="c4 / c5: fraction of the hg38 contig lengths (the JSON states it next to every number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", choices=["full", "region"], default="full", help="CPU baseline + parity on the whole bench BAM (default) or on its first eighth")
+    ap.add_argument("--cpu-whole", action="store_true", help="c4 / c5: CPU baseline + sha256 parity on the WHOLE scale model (all usable CPUs; minutes), not on its last contig")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the short run the --pmc passes profile
     ap.add_argument("--tile", type=int, default=0, help="experiments: reference positions per accumulate tile (0 = the library's plan)")
@@ -495,7 +496,7 @@ def main():
 
     if rank == 0:
         focus_run = bool(st.slot_pipeline)
-        agg_kernel = "mkp_pileup_tiles_hemi" if hemi else "mkp_pileup_stream" if focus_run else "mkp_pileup_tiles_focus" if "--ref" in flags else "mkp_pileup_tiles"
+        agg_kernel = "mkp_pileup_tiles_hemi" if hemi else "mkp_pileup_stream" if focus_run else "mkp_pileup_tiles"
         kernels = {"decode": (st.decode_kernel_ms, st.alg_bytes_decode), "aggregate": (st.pileup_kernel_ms, st.alg_bytes_pileup)}
         # SURVEY §8(d) one-pass algorithmic bytes of the whole pass: reads (16 + 4 n_cigar + L/2) + calls (2 + K) + 44 per row
         if focus_run:
@@ -571,7 +572,9 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             workers = min(usable_cpus(), 8)
             region = None
-            if multi:
+            if multi and a.cpu_whole:
+                workers = usable_cpus()   # the whole scale model: every contig's rows compared (sha256), the oracle on all usable CPUs
+            elif multi:
                 region = "%s:0-%d" % (contigs[-1][0], contigs[-1][1])   # bounded sample: the last (shortest-but-one) contig
             elif a.cpu_sample == "region":
                 region = "%s:0-%d" % (contigs[0][0], contigs[0][1] // 8)
@@ -586,7 +589,7 @@ def main():
             dev_pps = rep.n_positions / (rep.total_ms * 1e-3)
             base["speedup_end_to_end"] = dev_pps / base["end_to_end"]["positions_per_s"] if not region else None
             base["device_host_threads"] = host_threads
-            if not region and not hemi:
+            if not region and not hemi and not multi:
                 # matched host thread counts: the device run's host side capped at 8 threads against the oracle on 8; both at all usable CPUs (at most 64)
                 m8 = device_e2e_subprocess(bam, bam + ".device.t8.bed", flags, 8)
                 matched = {"8_threads": {"device": m8, "oracle_total_s": base["end_to_end"]["total_s"],

@@ -27,7 +27,7 @@ hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | sh
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
-                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/);
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/, uint32_t /*motif combos*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
@@ -217,7 +217,7 @@ void window_slots(mkp_ctx* c, bool hemi, bool stream, std::vector<uint32_t>& slo
     });
   }
 }
-bool stream_pipeline(const mkp_ctx* c, bool hemi) { return c->has_focus && !hemi && !(getenv("MKP_PIPELINE") && !strcmp(getenv("MKP_PIPELINE"), "tiles")); }
+bool stream_pipeline(const mkp_ctx* c, bool hemi) { return c->has_focus && !hemi; }
 
 // derive tile geometry, tile read ranges and the run parameters; upload everything
 void make_resident(mkp_ctx* c) {
@@ -375,8 +375,7 @@ void make_resident(mkp_ctx* c) {
   const uint32_t budget_words = (76u * 1024u - 3584u) / 4u;
   const int64_t win = (int64_t)S.win_end - (int64_t)S.win_start;
   std::vector<MkpTile> tiles; std::vector<uint32_t> slotbm; uint32_t Scap = 0, Wcap = 0;
-  // focus runs take the slot pipeline (mkp_slots.hip) unless MKP_PIPELINE=tiles asks for the tile walk of mkp_kernels.hip (A/B runs);
-  // pileup-hemi keeps the tile walk
+  // focus runs take the slot pipeline (mkp_slots.hip); pileup-hemi keeps the tile walk
   const bool stream = stream_pipeline(c, c->hemi);
   std::vector<uint32_t> slot_pos_h, wpfx; std::vector<MkpSTile> stiles; bool preplanned = false;
   c->slot_mode = stream; P.slot_stream = stream ? 1u : 0u; c->cov_bytes = 0;
@@ -623,7 +622,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
       if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
                                                  c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
-                                                 c->key_passes[kp], kp, one_shot ? 1 : 0), "stream pileup launch");
+                                                 c->key_passes[kp], kp, one_shot ? 1 : 0, (uint32_t)c->combos.size()), "stream pileup launch");
       else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
@@ -769,7 +768,10 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete c; return MKP_E_DEVICE; }
   if (c->device < 0 || c->device >= n) { delete c; return MKP_E_DEVICE; }
-  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MKP_E_DEVICE; }
+  // the context's stream runs the short kernels a caller waits for — sampling rounds, the pileup pass — often beside an ingest that fills the
+  // chip for tens of milliseconds: it goes first when workgroup slots free up
+  { int plo = 0, phi = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamDefault, phi) != hipSuccess) { delete c; return MKP_E_DEVICE; } }
   for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MKP_E_DEVICE; }
   c->caller = CallerCfg();
   *out = c;

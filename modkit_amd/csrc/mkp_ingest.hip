@@ -143,6 +143,36 @@ mkp_bgzf_chain_write(const uint8_t* __restrict__ z, const MkpZChain* __restrict_
   ingest_walk_blocks(z, chains[i], out + base[i], err);
 }
 
+// the inflate's block table of one upload stage from its MkpZBlk entries: payload offsets and sizes, and each block's place in the inflated
+// window — an exclusive scan of ISIZE behind *raw_cursor, which moves on by the stage's total.  One workgroup.  A block that claims more than
+// 64 KiB, or a window that would not fit raw_cap, raises the error bits (the host then falls back to an exact allocation).
+#define MKP_ZE_ISIZE 4u
+#define MKP_ZE_RAWCAP 8u
+extern "C" __global__ void __launch_bounds__(1024)
+mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap, MkpBgzfBlock* __restrict__ out, uint32_t* err) {
+  __shared__ unsigned long long wtot[16];
+  __shared__ unsigned long long tile_total;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  const unsigned long long base0 = *raw_cursor;
+  unsigned long long carry = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += 1024u) {
+    const uint32_t i = b0 + t;
+    MkpZBlk z; z.coff = 0; z.hdr = 0; z.clen = 0; z.isize = 0; z.pad = 0; if (i < n) z = zb[i];
+    if (z.isize > 65536u) { atomicOr(err, MKP_ZE_ISIZE); z.isize = 0; }
+    unsigned long long incl = z.isize;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
+    if (lane == 63u) wtot[wv] = incl;
+    __syncthreads();
+    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x; } tile_total = run; }
+    __syncthreads();
+    if (i < n) { MkpBgzfBlock b; b.in_off = z.coff + z.hdr; b.out_off = base0 + carry + wtot[wv] + incl - z.isize; b.in_len = z.clen; b.out_len = z.isize; out[i] = b; }
+    carry += tile_total;
+    __syncthreads();
+  }
+  if (t == 0) { if (base0 + carry + 64ull > raw_cap) atomicOr(err, MKP_ZE_RAWCAP); *raw_cursor = base0 + carry; }
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, uint32_t* __restrict__ seg_cnt, MkpIngestTotals* tot) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,6 +272,10 @@ hipError_t mkp_launch_bgzf_chain_count(hipStream_t st, const uint8_t* z, const M
 }
 hipError_t mkp_launch_bgzf_chain_write(hipStream_t st, const uint8_t* z, const MkpZChain* chains, uint32_t n, const uint32_t* base, uint32_t cap, MkpZBlk* out, uint32_t* err) {
   if (n) hipLaunchKernelGGL(mkp_bgzf_chain_write, dim3((n + 255u) / 256u), dim3(256), 0, st, z, chains, n, base, cap, out, err);
+  return hipGetLastError();
+}
+hipError_t mkp_launch_bgzf_layout(hipStream_t st, const MkpZBlk* zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap, void* out, uint32_t* err) {
+  hipLaunchKernelGGL(mkp_bgzf_layout, dim3(1), dim3(1024), 0, st, zb, n, raw_cursor, raw_cap, (MkpBgzfBlock*)out, err);
   return hipGetLastError();
 }
 hipError_t mkp_launch_crc32(hipStream_t st, const uint8_t* zin, const void* blocks, uint32_t n_blocks, const uint8_t* raw, uint32_t* status) {

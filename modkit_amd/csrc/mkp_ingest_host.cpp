@@ -20,6 +20,7 @@ extern "C" {
 hipError_t mkp_launch_crc32(hipStream_t, const uint8_t*, const void*, uint32_t, const uint8_t*, uint32_t*);
 hipError_t mkp_launch_bgzf_chain_count(hipStream_t, const uint8_t*, const MkpZChain*, uint32_t, uint32_t*, uint32_t*);
 hipError_t mkp_launch_bgzf_chain_write(hipStream_t, const uint8_t*, const MkpZChain*, uint32_t, const uint32_t*, uint32_t, MkpZBlk*, uint32_t*);
+hipError_t mkp_launch_bgzf_layout(hipStream_t, const MkpZBlk*, uint32_t, unsigned long long*, unsigned long long, void*, uint32_t*);
 hipError_t mkp_launch_ingest_count(hipStream_t, const uint8_t*, const MkpIngestParams*, const MkpSeg*, uint32_t*, MkpIngestTotals*);
 hipError_t mkp_launch_ingest_parse(hipStream_t, const uint8_t*, const MkpIngestParams*, const int32_t*, const MkpSeg*, const uint32_t*, unsigned long long*, MkpRecInfo*, uint32_t*, int32_t*, MkpIngestTotals*);
 hipError_t mkp_launch_ingest_pack(hipStream_t, const uint8_t*, uint32_t, const MkpRecInfo*, const uint32_t*, MkpReadHdr*, uint32_t*, uint32_t*, uint8_t*, MkpTagRef*, uint32_t*, uint8_t*, MkpRecDigest*, MkpIngestTotals*);
@@ -36,7 +37,11 @@ uint64_t fnv64(const std::string& s) { uint64_t h = 1469598103934665603ull; for 
 }  // namespace
 
 struct mkp_dev_ingest {
-  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr}, inf_done = nullptr, crc_done = nullptr;
+  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr, crc_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr}, inf_done = nullptr, crc_done = nullptr;
+  std::vector<hipEvent_t> stage_ev;      // upload stages: recorded on up_stream behind a stage's last copy
+  std::vector<hipEvent_t> tev;           // timed pairs around the inflate launches of the stages
+  static constexpr size_t kStageRounds = 4;   // an upload stage = 4 rounds of kSlots pieces = 128 MiB: inflated while the next stage is on its way up
+  DevBuf ztab, rawcur;
   static constexpr size_t kPiece = (size_t)2 << 20, kSlots = 16;   // 64 MiB page-locked in all (allocating it is part of a fresh context's first ingest)   // upload staging: two halves of kSlots pieces
   Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
   DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig, parts;
@@ -52,11 +57,13 @@ struct mkp_dev_ingest {
 
 mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   std::unique_ptr<mkp_dev_ingest> d(new mkp_dev_ingest()); d->device = device;
-  // the record kernels' stream goes before the upload stream, which also runs the CRC kernel beside them: the CRC's thirteen thousand
+  // the record kernels' stream goes before the upload and CRC streams: the CRC's thirteen thousand
   // workgroups otherwise hold up the one-workgroup scans that the host waits for (2.6 ms for a 15 us kernel)
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return nullptr;
-  if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_hi) != hipSuccess || hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
+  const int prio_mid = (prio_lo + prio_hi) / 2 != prio_hi ? (prio_lo + prio_hi) / 2 : prio_hi;   // (below the contexts' own streams, above the uploads and the CRC)
+  if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_mid) != hipSuccess || hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+      hipStreamCreateWithPriority(&d->crc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
   for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + chain kernels, for the trace)
@@ -67,7 +74,10 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
 void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig, &d->parts}) b->release();
+  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig, &d->parts, &d->ztab, &d->rawcur}) b->release();
+  for (auto& e : d->stage_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : d->tev) if (e) (void)hipEventDestroy(e);
+  if (d->crc_stream) (void)hipStreamDestroy(d->crc_stream);
   for (auto& b : d->spares) b.release();
   d->stage.release(); d->small.release();
   for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
@@ -113,6 +123,12 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   d->stage.ensure(2 * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece);
   const int fd = bam.fd();
   std::unique_ptr<Error> up_err; double up_ms = 0;
+  // upload stages (the staged path below): stage j = rounds [j * kStageRounds, (j + 1) * kStageRounds); stage_end_z[j] = where its bytes end in zin
+  const size_t n_rounds = (pieces.size() + mkp_dev_ingest::kSlots - 1) / mkp_dev_ingest::kSlots, n_stages = std::max<size_t>(1, (n_rounds + mkp_dev_ingest::kStageRounds - 1) / mkp_dev_ingest::kStageRounds);
+  std::vector<uint64_t> stage_end_z(n_stages, zbytes);
+  for (size_t j = 0; j + 1 < n_stages; j++) { const size_t last = std::min(pieces.size(), (j + 1) * mkp_dev_ingest::kStageRounds * mkp_dev_ingest::kSlots) - 1; stage_end_z[j] = pieces[last].z_off + pieces[last].n; }
+  while (d->stage_ev.size() < n_stages) { hipEvent_t e = nullptr; ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"); d->stage_ev.push_back(e); }
+  std::mutex st_mu; std::condition_variable st_cv; size_t stages_issued = 0; bool up_finished = false;   // (an event that has not been recorded yet does not hold a stream back: the consumer waits for the record call itself)
   std::thread uploader([&]() {
     auto t_up = std::chrono::steady_clock::now();
     try {
@@ -129,9 +145,16 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
         if (read_bad) throw Error(MKP_E_IO, "read error on " + bam.path());
         for (size_t k = 0; k < n; k++) ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, pieces[p0 + k].n, hipMemcpyHostToDevice, d->up_stream), "H2D");
         ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
+        if ((round + 1) % mkp_dev_ingest::kStageRounds == 0 && (round + 1) / mkp_dev_ingest::kStageRounds < n_stages) {
+          const size_t j = (round + 1) / mkp_dev_ingest::kStageRounds - 1;
+          ok(hipEventRecord(d->stage_ev[j], d->up_stream), "event");
+          { std::lock_guard<std::mutex> g(st_mu); stages_issued = j + 1; } st_cv.notify_all();
+        }
       }
+      ok(hipEventRecord(d->stage_ev[n_stages - 1], d->up_stream), "event");
       ok(hipEventRecord(d->up_done, d->up_stream), "event");
     } catch (const Error& e) { up_err.reset(new Error(e)); }
+    { std::lock_guard<std::mutex> g(st_mu); stages_issued = n_stages; up_finished = true; } st_cv.notify_all();
     up_ms = ms_since(t_up);
   });
   struct JoinUp { std::thread& t; ~JoinUp() { if (t.joinable()) t.join(); } } join_up{uploader};
@@ -140,43 +163,94 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   // MKP_HOST_BLOCK_TABLE=1 keeps the host walk (A/B runs).
   static const bool host_table = getenv("MKP_HOST_BLOCK_TABLE") && !strcmp(getenv("MKP_HOST_BLOCK_TABLE"), "1");
   if (host_table) { bam.ingest_blocks(&plan); out->ms_plan = ms_since(t0); uploader.join(); if (up_err) throw *up_err; out->ms_upload = up_ms; }
-  else {
+  bool staged_done = false; double staged_kernel_ms = 0; std::chrono::steady_clock::time_point t_inf_staged;
+  if (!host_table) {
+    // ---- the STAGED path: the window goes up in stages of 128 MiB, and a stage's blocks are found, laid out and inflated while the next
+    // stage is still on its way (round 4: whole upload, then block table, then one inflate launch — the GPU idle for the 40-90 ms of the
+    // upload, the host idle for the inflate).  Per stage, on the ingest stream: wait for the stage's last copy; walk its chains
+    // (count -> scan; ONE host sync for the block count, which sizes the launches); write its MkpZBlk entries; mkp_bgzf_layout turns them
+    // into the inflate's table behind a device-side cursor of the inflated window; inflate; CRC on a stream of its own.  The inflated
+    // size is not known before the last stage: the window buffer is sized at 6 x the compressed bytes and the layout kernel reports an
+    // overflow, on which the whole window is inflated again into an exact allocation (below).
+    struct Drain { mkp_dev_ingest* d; int n = std::uncaught_exceptions(); ~Drain() { if (std::uncaught_exceptions() > n) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->crc_stream); } } } drain{d};   // (whatever leaves this block by exception must not leave kernels reading buffers the next ingest rewrites)
     std::vector<BamSource::IngestChain> chains; bam.ingest_chains(plan, &chains);
-    std::vector<MkpZChain> zc(chains.size());
-    for (size_t i = 0; i < chains.size(); i++) { const BamSource::IngestRange& rg = plan.ranges[chains[i].range]; const uint64_t zb = zbase[chains[i].range], fo = rg.file_off;
-      MkpZChain c; c.start = zb + (chains[i].start - fo); c.stop = chains[i].stop == UINT64_MAX ? ~0ull : zb + (chains[i].stop - fo); c.range_end = zb + rg.file_len;
-      c.ce = (rg.vend >> 16) >= fo ? zb + ((rg.vend >> 16) - fo) : 0; c.ue = (uint32_t)(rg.vend & 0xffff); c.pad = 0; zc[i] = c; }
-    out->ms_plan = ms_since(t0);
-    uploader.join();
-    if (up_err) throw *up_err;
-    out->ms_upload = up_ms;
-    auto t_tab = std::chrono::steady_clock::now();
-    const size_t nc = zc.size();
+    const size_t nc = chains.size();
     if (nc > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF chains; use smaller shards");
-    d->segs.ensure(nc * sizeof(MkpZChain)); d->seg_cnt.ensure((nc + 2) * 4); d->tot.ensure(sizeof(MkpIngestTotals));
-    d->small.ensure(256);
-    uint32_t* h_small = (uint32_t*)d->small.p;   // [0] error bits, [1] number of blocks
+    std::vector<MkpZChain> zc(nc); std::vector<size_t> stage_c0(n_stages + 1, nc);
+    { size_t j = 0; stage_c0[0] = 0;
+      for (size_t i = 0; i < nc; i++) { const BamSource::IngestRange& rg = plan.ranges[chains[i].range]; const uint64_t zb = zbase[chains[i].range], fo = rg.file_off;
+        MkpZChain c; c.start = zb + (chains[i].start - fo); c.stop = chains[i].stop == UINT64_MAX ? ~0ull : zb + (chains[i].stop - fo); c.range_end = zb + rg.file_len;
+        c.ce = (rg.vend >> 16) >= fo ? zb + ((rg.vend >> 16) - fo) : 0; c.ue = (uint32_t)(rg.vend & 0xffff); c.pad = 0; zc[i] = c;
+        const uint64_t zend = c.stop == ~0ull ? c.range_end : std::min<uint64_t>(c.stop, c.range_end);   // the chain reads nothing at or behind this
+        while (j + 1 < n_stages && zend > stage_end_z[j]) { j++; stage_c0[j] = i; } }
+      for (size_t k = j + 1; k <= n_stages; k++) stage_c0[k] = nc; }
+    out->ms_plan = ms_since(t0);
+    const uint64_t raw_cap = std::max<uint64_t>(d->raw.cap, plan.comp_total * 6 + (64ull << 20));
+    d->raw.ensure(raw_cap); d->segs.ensure(nc * sizeof(MkpZChain)); d->seg_cnt.ensure((nc + n_stages + 2) * 4); d->tot.ensure(sizeof(MkpIngestTotals)); d->rawcur.ensure(16);
+    d->small.ensure(4096);
+    uint32_t* h_small = (uint32_t*)d->small.p;   // [0] error bits, [1] blocks of the stage; [2..3] the cursor of the inflated window (at the end)
+    while (d->tev.size() < 2 * n_stages) { hipEvent_t e = nullptr; ok(hipEventCreate(&e), "event"); d->tev.push_back(e); }
     ok(hipMemcpyAsync(d->segs.p, zc.data(), nc * sizeof(MkpZChain), hipMemcpyHostToDevice, d->stream), "H2D");
     ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
-    ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
-    ok(mkp_launch_bgzf_chain_count(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>(), (uint32_t)nc, d->seg_cnt.as<uint32_t>(), d->tot.as<uint32_t>()), "block table launch");
-    ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 1, d->seg_cnt.as<uint32_t>() + nc, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
-    ok(hipStreamSynchronize(d->stream), "block table sync");
-    if (h_small[0]) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
-    const uint32_t nblk = h_small[1];
-    d->zblk.ensure(((size_t)nblk + 1) * sizeof(MkpZBlk));
-    std::vector<MkpZBlk> zb(nblk); std::vector<uint32_t> cbase(nc + 1);
-    ok(mkp_launch_bgzf_chain_write(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>(), (uint32_t)nc, d->seg_cnt.as<uint32_t>(), nblk, d->zblk.as<MkpZBlk>(), d->tot.as<uint32_t>()), "block table launch");
-    if (nblk) ok(hipMemcpyAsync(zb.data(), d->zblk.p, (size_t)nblk * sizeof(MkpZBlk), hipMemcpyDeviceToHost, d->stream), "D2H");
-    ok(hipMemcpyAsync(cbase.data(), d->seg_cnt.p, (nc + 1) * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
-    ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
-    ok(hipStreamSynchronize(d->stream), "block table sync");
-    if (h_small[0]) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+    ok(hipMemsetAsync(d->rawcur.p, 0, 16, d->stream), "memset");
+    size_t blk_cap = std::max<size_t>({d->zblk.cap / sizeof(BgzfBlk), d->ztab.cap / sizeof(MkpZBlk), (size_t)(plan.comp_total / 8192 + 4096)});
+    d->zblk.ensure(blk_cap * sizeof(BgzfBlk)); d->ztab.ensure(blk_cap * sizeof(MkpZBlk)); d->zstat.ensure(blk_cap * 4 + 16);
+    blk_cap = std::min({d->zblk.cap / sizeof(BgzfBlk), d->ztab.cap / sizeof(MkpZBlk), (d->zstat.cap - 16) / 4});
+    auto grow = [&](DevBuf& b, size_t need, size_t keep) {   // (a window of unusually small blocks: the tables grow, keeping what the stages before wrote)
+      DevBuf nb; nb.ensure(need); ok(hipStreamSynchronize(d->stream), "sync"); ok(hipStreamSynchronize(d->crc_stream), "sync");
+      if (keep) ok(hipMemcpy(nb.p, b.p, keep, hipMemcpyDeviceToDevice), "D2D"); b.release(); b = nb; nb.p = nullptr; nb.cap = 0; };
+    size_t blkbase = 0; std::vector<uint32_t> stage_nblk(n_stages, 0);
+    t_inf_staged = std::chrono::steady_clock::now();
+    for (size_t j = 0; j < n_stages; j++) {
+      { std::unique_lock<std::mutex> lk(st_mu); st_cv.wait(lk, [&] { return stages_issued > j || up_finished; }); }
+      if (up_err) break;
+      ok(hipStreamWaitEvent(d->stream, d->stage_ev[j], 0), "wait for the upload stage");
+      const size_t c0 = stage_c0[j], c1 = stage_c0[j + 1], n = c1 - c0;
+      uint32_t* cnt = d->seg_cnt.as<uint32_t>() + c0 + j;   // the stage's counts -> offsets, its total behind them
+      ok(mkp_launch_bgzf_chain_count(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>() + c0, (uint32_t)n, cnt, d->tot.as<uint32_t>()), "block table launch");
+      ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 1, cnt + n, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+      ok(hipStreamSynchronize(d->stream), "block table sync");
+      if (h_small[0]) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+      const uint32_t nblk = h_small[1]; stage_nblk[j] = nblk;
+      if (blkbase + nblk > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");
+      if (blkbase + nblk > blk_cap) { const size_t want = std::max<size_t>(2 * blk_cap, blkbase + nblk + 4096);
+        grow(d->zblk, want * sizeof(BgzfBlk), blkbase * sizeof(BgzfBlk)); grow(d->ztab, want * sizeof(MkpZBlk), blkbase * sizeof(MkpZBlk)); grow(d->zstat, want * 4 + 16, blkbase * 4); blk_cap = want; }
+      if (!nblk) continue;
+      MkpZBlk* ztab = d->ztab.as<MkpZBlk>() + blkbase; BgzfBlk* zblk = d->zblk.as<BgzfBlk>() + blkbase; uint32_t* zst = d->zstat.as<uint32_t>() + blkbase;
+      ok(mkp_launch_bgzf_chain_write(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>() + c0, (uint32_t)n, cnt, nblk, ztab, d->tot.as<uint32_t>()), "block table launch");
+      ok(mkp_launch_bgzf_layout(d->stream, ztab, nblk, d->rawcur.as<unsigned long long>(), raw_cap, zblk, d->tot.as<uint32_t>()), "layout launch");
+      ok(hipMemsetAsync(zst, 0xff, (size_t)nblk * 4, d->stream), "memset");
+      ok(hipEventRecord(d->tev[2 * j], d->stream), "event");
+      ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "inflate launch");
+      ok(hipEventRecord(d->tev[2 * j + 1], d->stream), "event");
+      ok(hipEventRecord(d->inf_done, d->stream), "event");
+      ok(hipStreamWaitEvent(d->crc_stream, d->inf_done, 0), "wait for the inflate");
+      ok(mkp_launch_crc32(d->crc_stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "crc launch");
+      blkbase += nblk;
+    }
+    uploader.join();
+    if (up_err) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->crc_stream); throw *up_err; }
+    out->ms_upload = up_ms;
+    // the whole table comes back for the window layout the record kernels need (entry points of the chains) and for error reports
+    std::vector<MkpZBlk> zb(blkbase); std::vector<uint32_t> cbase(nc + n_stages + 2);
+    if (blkbase) ok(hipMemcpyAsync(zb.data(), d->ztab.p, blkbase * sizeof(MkpZBlk), hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipMemcpyAsync(cbase.data(), d->seg_cnt.p, (nc + n_stages + 1) * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 2, d->rawcur.p, 8, hipMemcpyDeviceToHost, d->stream), "D2H");
+    ok(hipStreamSynchronize(d->stream), "inflate sync");
+    for (size_t j = 0; j < n_stages; j++) if (stage_nblk[j]) { float ms = 0; if (hipEventElapsedTime(&ms, d->tev[2 * j], d->tev[2 * j + 1]) == hipSuccess) staged_kernel_ms += ms; }
+    const uint32_t zerr = h_small[0];
+    if (zerr & (MKP_ZE_BAD | MKP_ZE_CHAIN)) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+    if (zerr & 4u) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB in " + bam.path());
     std::vector<std::vector<BamSource::IngestBlk>> parts(nc);
-    for (size_t i = 0; i < nc; i++) { const uint64_t zbs = zbase[chains[i].range], fo = plan.ranges[chains[i].range].file_off; parts[i].reserve(cbase[i + 1] - cbase[i]);
-      for (uint32_t k = cbase[i]; k < cbase[i + 1]; k++) parts[i].push_back({fo + (zb[k].coff - zbs), zb[k].hdr, zb[k].clen, zb[k].isize, 0}); }
+    { size_t base = 0;
+      for (size_t j = 0; j < n_stages; j++) { const size_t c0 = stage_c0[j], c1 = stage_c0[j + 1]; const uint32_t* cb = cbase.data() + c0 + j;
+        for (size_t i = c0; i < c1; i++) { const uint64_t zbs = zbase[chains[i].range], fo = plan.ranges[chains[i].range].file_off; parts[i].reserve(cb[i - c0 + 1] - cb[i - c0]);
+          for (uint32_t k = cb[i - c0]; k < cb[i - c0 + 1]; k++) { const MkpZBlk& z = zb[base + k]; parts[i].push_back({fo + (z.coff - zbs), z.hdr, z.clen, z.isize, 0}); } }
+        base += stage_nblk[j]; } }
     bam.ingest_layout(&plan, chains, parts);
-    out->ms_plan += ms_since(t_tab);
+    unsigned long long cur; memcpy(&cur, h_small + 2, 8);
+    staged_done = !(zerr & 8u) && cur == plan.raw_total && plan.blks.size() == blkbase;   // (a window larger than the estimate: inflated again below, into an exact allocation)
+    if (!staged_done) { ok(hipStreamSynchronize(d->crc_stream), "sync"); if (!(zerr & 8u)) throw Error(MKP_E_DEVICE, "internal: the device's window layout differs from the host's"); }
   }
   bam.bytes_read += plan.comp_total;
   if (plan.raw_total == 0) return out;
@@ -195,32 +269,35 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   d->small.ensure(small_need + small_need / 4);
   uint8_t* sm = (uint8_t*)d->small.p; uint8_t* sm_blk = sm; uint8_t* sm_seg = sm + nb * sizeof(BgzfBlk); uint8_t* sm_tot = sm_seg + ns * sizeof(MkpSeg); uint8_t* sm_stat = sm_tot + ((sizeof(MkpIngestTotals) + 63) & ~(size_t)63); uint8_t* sm_stat0 = sm_stat + ((nb * 4 + 63) & ~(size_t)63);
   memcpy(sm_blk, blks.data(), nb * sizeof(BgzfBlk)); memcpy(sm_seg, segs.data(), ns * sizeof(MkpSeg));
-  ok(hipMemcpyAsync(d->zblk.p, sm_blk, nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, d->stream), "H2D");
   ok(hipMemcpyAsync(d->segs.p, sm_seg, ns * sizeof(MkpSeg), hipMemcpyHostToDevice, d->stream), "H2D");
-  ok(hipMemsetAsync(d->zstat.p, 0xff, nb * 4, d->stream), "memset");
   ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
-  ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
-  // ---- inflate + CRC, record chains
-  auto t_inf = std::chrono::steady_clock::now();
-  ok(hipEventRecord(d->kev[0], d->stream), "event");
-  ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch");
-  // the CRC-32 of every block runs on the upload stream (idle by now), beside the record kernels below: its verdict — and the decoders'
-  // status words it is OR-ed into — is only read when something has gone wrong, or at the very end (corrupt())
-  ok(hipEventRecord(d->inf_done, d->stream), "event");
-  ok(hipStreamWaitEvent(d->up_stream, d->inf_done, 0), "wait for the inflate");
-  ok(mkp_launch_crc32(d->up_stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
+  auto t_inf = staged_done ? t_inf_staged : std::chrono::steady_clock::now();
+  if (!staged_done) {   // the whole window in one launch: the host-table path, or a window that outgrew the staged path's estimate
+    ok(hipMemcpyAsync(d->zblk.p, sm_blk, nb * sizeof(BgzfBlk), hipMemcpyHostToDevice, d->stream), "H2D");
+    ok(hipMemsetAsync(d->zstat.p, 0xff, nb * 4, d->stream), "memset");
+    ok(hipStreamWaitEvent(d->stream, d->up_done, 0), "wait for the upload");
+    // ---- inflate + CRC
+    ok(hipEventRecord(d->kev[0], d->stream), "event");
+    ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "inflate launch");
+    // the CRC-32 of every block runs on a stream of its own, beside the record kernels below: its verdict — and the decoders'
+    // status words it is OR-ed into — is only read when something has gone wrong, or at the very end (corrupt())
+    ok(hipEventRecord(d->inf_done, d->stream), "event");
+    ok(hipStreamWaitEvent(d->crc_stream, d->inf_done, 0), "wait for the inflate");
+    ok(mkp_launch_crc32(d->crc_stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
+  } else ok(hipEventRecord(d->kev[0], d->stream), "event");
+  // ---- record chains
   MkpIngestParams P; memset(&P, 0, sizeof(P));
   P.raw_len = plan.raw_total; P.tid = (int32_t)tid; P.beg = (int32_t)std::min<uint32_t>(beg, 0x7fffffffu); P.end = (int32_t)std::min<uint32_t>(end, 0x7fffffffu); P.n_ref = (int32_t)bam.ref_names.size(); P.n_seg = (uint32_t)ns;
   ok(mkp_launch_ingest_count(d->stream, d->raw.as<uint8_t>(), &P, d->segs.as<MkpSeg>(), d->seg_cnt.as<uint32_t>(), d->tot.as<MkpIngestTotals>()), "count launch");
   MkpIngestTotals* tot = (MkpIngestTotals*)sm_tot;
   ok(hipEventRecord(d->kev[1], d->stream), "event");
-  ok(hipMemcpyAsync(sm_stat, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->up_stream), "D2H");
-  ok(hipEventRecord(d->crc_done, d->up_stream), "event");
+  ok(hipMemcpyAsync(sm_stat, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->crc_stream), "D2H");
+  ok(hipEventRecord(d->crc_done, d->crc_stream), "event");
   ok(hipMemcpyAsync(sm_stat0, d->zstat.p, nb * 4, hipMemcpyDeviceToHost, d->stream), "D2H");   // the decoders' own status (low byte; the CRC kernel may be OR-ing bit 8 in meanwhile)
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "inflate sync");
   out->ms_inflate = ms_since(t_inf);
-  { float kms = 0; if (hipEventElapsedTime(&kms, d->kev[0], d->kev[1]) == hipSuccess) out->ms_kernel = kms; }
+  { float kms = 0; if (hipEventElapsedTime(&kms, d->kev[0], d->kev[1]) == hipSuccess) out->ms_kernel = kms + staged_kernel_ms; }   // (staged: the stages' inflate launches + the chain kernels)
   bam.bytes_inflated += plan.raw_total; bam.bytes_inflated_device += plan.raw_total;
   // whatever leaves this function early must not leave the CRC kernel reading buffers the next ingest rewrites
   struct CrcJoin { hipEvent_t ev; ~CrcJoin() { (void)hipEventSynchronize(ev); } } crc_join{d->crc_done};

@@ -1571,14 +1571,13 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
 #define PILEUP_PASS hdrs, cigar, seqs, events, readout, tiles, n_tiles, prmp, slotbm, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, chunk_pfx, dev_err, key_arg
 // every position owns a tally column (no focus positions): the dense walk, 4 windows of 64 positions in flight
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles(PILEUP_PARAMS) { pileup_tiles_body<false, 4, false>(PILEUP_PASS); }
-// focus positions only (--cpg / --motif / --include-bed): tally columns, events and the depth walk are restricted to them
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false>(PILEUP_PASS); }
-// --partition-tag: the same two kernels tallying only the reads of one partition key per launch
+// (focus positions — --cpg / --motif / --include-bed — go through the slot pipeline of mkp_slots.hip; the FOCUS instantiation of this body
+// serves pileup-hemi below)
+// --partition-tag: the same kernel tallying only the reads of one partition key per launch
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_keyed(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
 // the same bodies with 128 VGPRs (four waves per SIMD, one workgroup per CU): no register spills, no scratch (MKP_PILEUP_WAVES=4; A/B runs)
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_tiles_w4(PILEUP_PARAMS) { pileup_tiles_body<false, 4, false>(PILEUP_PASS); }
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_tiles_keyed_w4(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_focus_keyed(PILEUP_PARAMS) { pileup_tiles_body<true, 1, true>(PILEUP_PASS); }
 // pileup-hemi: the focus kernel with duplex pattern tallies
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_hemi(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false, true>(PILEUP_PASS); }
 
@@ -1855,7 +1854,7 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
 
 // per device: both accumulate kernels may use the whole per-workgroup LDS budget the host planned for
 extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
-  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_focus, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_focus_keyed, (const void*)mkp_pileup_tiles_hemi, (const void*)mkp_pileup_tiles_w4, (const void*)mkp_pileup_tiles_keyed_w4}) {
+  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_hemi, (const void*)mkp_pileup_tiles_w4, (const void*)mkp_pileup_tiles_keyed_w4}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
     if (e != hipSuccess) return e;
   }
@@ -1876,7 +1875,7 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int 
 #define MKP_PILEUP_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos, \
                        row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_arg)
   if (focus_mode == 2) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_hemi);   // pileup-hemi
-  else if (focus_mode) { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles_focus); }
+  else if (focus_mode) return hipErrorInvalidValue;   // (focus runs are the slot pipeline's: mkp_launch_stream)
   else if (w4) { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_keyed_w4); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles_w4); }
   else { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles); }
   return hipGetLastError();

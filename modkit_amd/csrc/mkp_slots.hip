@@ -535,11 +535,11 @@ struct StreamSlotMap {
   }
 };
 
-template <bool KEYED>
+template <bool KEYED, uint32_t VB /* visits drawn per ticket, their records and first stream dwords requested together */>
 __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events,
                  const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
                  const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
-                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg) {
+                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos) {
   const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = KEYED ? (key_arg >> 16) : 0u;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
@@ -547,8 +547,18 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   __shared__ uint32_t row_base, scan_carry;
   __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
   __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];
+  // A workgroup takes the next TILE from an atomic ticket (row_cursor[0]; the host zeroes it before the first pass), not from blockIdx: rows
+  // leave in genome order through a look-back over the runs before (mkp_dev_rows.hpp), and a run may only wait for runs whose workgroups
+  // are already running — true for tickets whatever the dispatch order, with any number of contexts on the device.  (Tiles in ticket
+  // order also start in genome order; an XCD-aware permutation was tried in round 3: it kept neighbouring tiles' shared reads in one L2,
+  // but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need.)
+  // The prologue is a chain of memory round trips in front of the first tally — ticket, tile record, slot positions, first visit, first
+  // stream dword — and there are four tiles per workgroup slot: what does not depend on the ticket (parameters, combos, clearing the
+  // tallies) is issued beside it, under one barrier.
+  __shared__ uint32_t run_ticket;
+  if (threadIdx.x == 0) run_ticket = atomicAdd(row_cursor, 1u);
   for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += PILEUP_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
-  for (uint32_t kq = threadIdx.x; kq < prmp->n_combos * (sizeof(MkpCombo) / 4); kq += PILEUP_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
+  for (uint32_t kq = threadIdx.x; kq < n_combos * (sizeof(MkpCombo) / 4); kq += PILEUP_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
   __syncthreads();
   const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
   const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
@@ -560,20 +570,14 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(lds + tal_words);
   const int lane = lane_id();
   const uint32_t wave = rfl(threadIdx.x >> 6);
-  // A workgroup takes the next TILE from an atomic ticket (row_cursor[0]; the host zeroes it before the first pass), not from blockIdx: rows
-  // leave in genome order through a look-back over the runs before (mkp_dev_rows.hpp), and a run may only wait for runs whose workgroups
-  // are already running — true for tickets whatever the dispatch order, with any number of contexts on the device.  (Tiles in ticket
-  // order also start in genome order; an XCD-aware permutation was tried in round 3: it kept neighbouring tiles' shared reads in one L2,
-  // but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need.)
-  __shared__ uint32_t run_ticket;
-  if (threadIdx.x == 0) run_ticket = atomicAdd(row_cursor, 1u);
-  __syncthreads();
   const uint32_t run = run_ticket;                                  // row-run index: key pass * tiles + tile (passes run one after the other on the stream)
   const uint32_t tix = KEYED ? run - key_run * n_tiles : run;
   if (tix >= n_tiles) { if (threadIdx.x == 0) atomicOr(dev_err, ERR_ROW_CAP); return; }   // (cannot happen: one ticket per workgroup)
-  const MkpSTile tl = tiles[tix];
+  const MkpSTile tl = tiles[tix];   // (in flight while the tallies are cleared)
+  { const uint32_t nv = tal_words >> 2; uint4* l4 = reinterpret_cast<uint4*>(lds);
+    for (uint32_t k = threadIdx.x; k < nv; k += PILEUP_THREADS) l4[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t k = (nv << 2) + threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0; }
   const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
-  for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
   for (uint32_t k = threadIdx.x; k < n_tslots; k += PILEUP_THREADS) fpos[k] = (int32_t)slot_pos[gh0 + k];
   if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }   // (tiles hold at least one candidate read)
   __syncthreads();
@@ -632,26 +636,36 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
       }
     }
   };
-  // Reads are drawn FOUR at a time: their visit records and the first stream dword of each are requested before any of them is used.  A visit
-  // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics, ~1.5 us of memory latency for ~150 bytes; with one visit in
-  // flight per wave (round 4) a CU's 32 waves retired ~20 visits per microsecond, and 1 000 visits per CU were the kernel (SQ: 73 % of the
-  // wave cycles waiting).
+  // Reads are drawn FOUR at a time: their visit records and the first stream dword of each are requested before any of them is used (a visit
+  // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics).  Measured on C3 (MKP_DEBUG_SKIP ablations, round 5): the
+  // visits are 0.03 of the kernel's 0.17 ms — one, two or four in flight make no difference that shows; 0.05-0.07 are the prologue and the
+  // scans, 0.07 the rows, 0.04 the ordered hand-over of the row offsets (the look-back: a tile cannot write before every tile in front of
+  // it has counted).
   for (;;) {
-    uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, 4u); base = rfl(ticket); }
+#ifdef MKP_DEBUG
+    if (prm.debug_skip & 1024u) break;   // ablation: no visits (prologue + scans + emission only)
+#endif
+    uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, VB); base = rfl(ticket); }
     if (base >= rid_end) break;
-    MkpVisit vv[4]; uint32_t ww[4];
+    MkpVisit vv[VB]; uint32_t ww[VB];
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) vv[j] = visits[min(base + j, rid_end - 1u)];   // (uniform: scalar loads)
+    for (uint32_t j = 0; j < VB; j++) vv[j] = visits[min(base + j, rid_end - 1u)];   // (uniform: scalar loads)
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) {
+    for (uint32_t j = 0; j < VB; j++) {
       const uint32_t a = max(vv[j].gs0, gh0), b = min(vv[j].gs0 + vv[j].n_sl, gh1);
       const uint32_t k_lo = a - vv[j].gs0, k_hi = b - vv[j].gs0, kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
       ww[j] = (a < b && kfirst < k_hi) ? *reinterpret_cast<const uint32_t*>(cov + vv[j].cov_off + kfirst) : 0xffffffffu;
     }
 #pragma unroll
-    for (uint32_t j = 0; j < 4; j++) if (base + j < rid_end) visit(vv[j], ww[j]);
+    for (uint32_t j = 0; j < VB; j++) if (base + j < rid_end) visit(vv[j], ww[j]);
   }
   __syncthreads();
+#ifdef MKP_DEBUG
+  if (prm.debug_skip & 2048u) {   // ablation: no scans, no rows (the look-back word is still published so that nothing waits)
+    if (threadIdx.x < 64u) { lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, 0u); if (threadIdx.x == 0 && run + 1u == row_cursor[3]) row_cursor[1] = 0; }
+    return;
+  }
+#endif
   // observed-code difference arrays -> counts, in place and still packed
   for (uint32_t a = wave; a < n_oslots; a += PILEUP_WAVES) {
     uint32_t* __restrict__ arr = obs + a * S;
@@ -672,13 +686,13 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
 
 #define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \
     const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, \
-    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg
-#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false>(STREAM_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true>(STREAM_PASS); }
+    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos
+#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
 // the same bodies with 128 VGPRs (four waves per SIMD, one workgroup per CU): no register spills, no scratch (MKP_PILEUP_WAVES=4; A/B runs)
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_w4(STREAM_PARAMS) { pileup_stream_body<false>(STREAM_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_keyed_w4(STREAM_PARAMS) { pileup_stream_body<true>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_w4(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_keyed_w4(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
@@ -703,12 +717,12 @@ extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
 
 extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
                                         const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot, uint32_t n_combos) {
   if (!n_tiles) return hipSuccess;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
 #define MKP_STREAM_LAUNCH(K) hipLaunchKernelGGL(K, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, visits, cov, events, tiles, n_tiles, prm_dev, slot_pos, focus, combos, rows->pos, row_cursor, \
-                                                tile_row_off, tile_row_cnt, dev_err, key_arg)
+                                                tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos > 64u ? 64u : n_combos)
   // The 64-VGPR build (two workgroups per CU) spills into 220 bytes of scratch per lane.  It is the faster kernel (0.154 against 0.234 ms
   // on C3) — but a queue that has been idle pays 9-13 ms for the scratch allocation around its first such dispatch, which is all a
   // one-shot run (one launch per shard, then rows) ever sees.  One-shot launches take the 128-VGPR build (no spills, no scratch); re-launches

@@ -204,6 +204,79 @@ def convert_mod_code(src_bam, dst_bam, from_code, to_code):
     return dst_bam
 
 
+def collapse_ignore(src_bam, dst_bam, ignore="h"):
+    """What `modkit adjust-mods --ignore <code>` writes for a record whose tags are `C+h?,d;C+m?,d;` over ONE delta list (src/adjust.rs ->
+    BaseModProbs::into_collapsed, CollapseMethod::ReDistribute, src/mod_bam.rs:559-597; format_mm_ml_tag, 1299-1387; prob_to_qual,
+    798-806): per call the ignored code's probability is split evenly between the other codes and the canonical base
+    (p' = p + p_ignored / (others + 1), in f32), the ignored tag disappears, and the survivors are written back with ML = floor(256 p')
+    (255 for p' == 1).  Only that tag shape is handled (the fixture of tests/test_pileup.rs:91-141); anything else raises."""
+    import gzip
+    import struct
+    import numpy as np
+    from bamfuzz import bgzf_write
+    d = gzip.open(src_bam).read()
+    o = 4
+    lt, = struct.unpack_from("<i", d, o); o += 4 + lt
+    nr, = struct.unpack_from("<i", d, o); o += 4
+    for _ in range(nr):
+        ln, = struct.unpack_from("<i", d, o); o += 4 + ln + 4
+    out = bytearray(d[:o])
+    width = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}
+    f32 = np.float32
+    while o < len(d):
+        bs, = struct.unpack_from("<i", d, o)
+        rec = d[o + 4:o + 4 + bs]; o += 4 + bs
+        lrn, ncig, lseq = rec[8], struct.unpack_from("<H", rec, 12)[0], struct.unpack_from("<i", rec, 16)[0]
+        a = 32 + lrn + 4 * ncig + (lseq + 1) // 2 + lseq
+        aux, keep, mm, ml, p = rec[a:], bytearray(), None, None, 0
+        while p < len(aux):
+            tag, ty, q = aux[p:p + 2], chr(aux[p + 2]), p + 3
+            if ty in width:
+                q += width[ty]
+            elif ty in "ZH":
+                q = aux.index(b"\0", q) + 1
+            elif ty == "B":
+                cnt, = struct.unpack_from("<i", aux, q + 1)
+                q += 5 + cnt * width[chr(aux[q])]
+            else:
+                raise ValueError("aux type " + ty)
+            if tag == b"MM":
+                mm = aux[p + 3:q - 1].decode()
+            elif tag == b"ML":
+                assert aux[p + 2:p + 4] == b"BC"
+                ml = aux[p + 8:q]
+            else:
+                keep += aux[p:q]
+            p = q
+        if mm is None:
+            out += struct.pack("<i", len(rec)) + rec
+            continue
+        tags, at = [], 0
+        for part in [x for x in mm.split(";") if x]:
+            head, _, rest = part.partition(",")
+            assert len(head) == 4 and head[:2] == "C+" and head[3] == "?", head
+            n = len(rest.split(",")) if rest else 0
+            tags.append((head[2], rest, ml[at:at + n])); at += n
+        assert at == len(ml) and len({t[1] for t in tags}) == 1, "one delta list expected"
+        gone = [t for t in tags if t[0] == ignore]
+        stay = sorted((t for t in tags if t[0] != ignore), key=lambda t: ord(t[0]))
+        assert len(gone) == 1 and stay
+        share = f32(len(stay) + 1)
+        new_ml = bytearray()
+        for code, rest, quals in stay:
+            for k, qv in enumerate(quals):
+                prob = (f32(qv) + f32(0.5)) / f32(256)
+                pig = (f32(gone[0][2][k]) + f32(0.5)) / f32(256)
+                newp = f32(prob + f32(pig / share))
+                new_ml.append(255 if newp == f32(1.0) else int(np.floor(f32(newp * f32(256)))))
+        new_mm = "".join("C+%s?%s;" % (c, "," + r if r else "") for c, r, _ in stay)
+        keep += b"MMZ" + new_mm.encode() + b"\0" + b"MLBC" + struct.pack("<I", len(new_ml)) + bytes(new_ml)
+        body = rec[:a] + bytes(keep)
+        out += struct.pack("<i", len(body)) + body
+    bgzf_write(dst_bam, bytes(out))
+    return dst_bam
+
+
 def chebi_case_expected_rows(golden_path, to_code):
     """tests/test_pileup.rs:373-444: the no-filter golden with `h` renamed, both sides sorted by (chrom, start, code) as the test does
     (ModCodeRepr order: letters before ChEBI numbers)."""

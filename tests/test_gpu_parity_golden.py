@@ -43,6 +43,20 @@ def test_pileup_chebi_code_same_output(oracle_bin, tmp_path, to_code):
     assert open(out).read() == open(ora).read()
 
 
+def test_pileup_collapse(oracle_bin, tmp_path):
+    # tests/test_pileup.rs:91-141: `pileup --ignore h` == `adjust-mods --ignore h` (restated test-side) + plain pileup, -i 25 —
+    # on the device, and both against the oracle
+    from pileup_cases import collapse_ignore
+    bam = collapse_ignore(fixture(BC), str(tmp_path / "collapsed.bam"), "h")
+    a, b, ora = str(tmp_path / "collapsed.bed"), str(tmp_path / "restricted.bed"), str(tmp_path / "oracle.bed")
+    modkit_amd.pileup([bam, a, "-i", "25", "--no-filtering"])
+    modkit_amd.pileup([fixture(BC), b, "-i", "25", "--ignore", "h", "--no-filtering"])
+    assert open(a).read() and open(a).read() == open(b).read()
+    p = subprocess.run([oracle_bin, "pileup", fixture(BC), ora, "-i", "25", "--ignore", "h", "--no-filtering"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(b).read() == open(ora).read()
+
+
 def test_preset_traditional_same_as_options(tmp_path):
     # tests/test_pileup.rs:446-487: `--preset traditional` is `--cpg --ignore h --combine-strands`
     a, b = str(tmp_path / "preset.bed"), str(tmp_path / "options.bed")

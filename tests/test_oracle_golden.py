@@ -74,6 +74,17 @@ def test_pileup_chebi_code_same_output(oracle_bin, tmp_path, to_code):
     assert got == want
 
 
+def test_pileup_collapse(oracle_bin, tmp_path):
+    # tests/test_pileup.rs:91-141 — `pileup --ignore h` on the fixture == `adjust-mods --ignore h` (restated test-side: the collapse
+    # written back into the tags, ML re-quantised) followed by a plain pileup; -i 25 so that the interval chunking is exercised
+    from pileup_cases import collapse_ignore
+    bam = collapse_ignore(fixture(BC), str(tmp_path / "collapsed.bam"), "h")
+    a, b = str(tmp_path / "collapsed.bed"), str(tmp_path / "restricted.bed")
+    run_oracle(oracle_bin, bam, a, ["-i", "25", "--no-filtering"])
+    run_oracle(oracle_bin, fixture(BC), b, ["-i", "25", "--ignore", "h", "--no-filtering"])
+    assert open(a).read() and open(a).read() == open(b).read()
+
+
 # ---- pileup-hemi (tests/test_pileup_hemi.rs)
 @pytest.fixture(scope="module")
 def hemi_ref(tmp_path_factory):

@@ -1,4 +1,4 @@
-"""A/B of the two focus pipelines on fuzzed BAMs (GPU box): slot pipeline (default) vs tile walk (MKP_PIPELINE=tiles) vs fused off
+"""A/B of the two focus pipelines on fuzzed BAMs (GPU box): slot pipeline (default) vs fused off
 (MKP_FUSED=0).  Prints the first differing rows of every case so one gpurun call says where a divergence starts."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
@@ -16,8 +16,8 @@ with tempfile.TemporaryDirectory() as td:
         for fi, fl in enumerate(FLAGS):
             flags = [f.format(fa=fa, bed=bed) for f in fl]
             outs = {}
-            for name, env in (("slots", {}), ("cover", {"MKP_FUSED": "0"}), ("tiles", {"MKP_PIPELINE": "tiles"})):
-                for k in ("MKP_FUSED", "MKP_PIPELINE"): os.environ.pop(k, None)
+            for name, env in (("slots", {}), ("cover", {"MKP_FUSED": "0"})):
+                for k in ("MKP_FUSED",): os.environ.pop(k, None)
                 os.environ.update(env)
                 o = os.path.join(td, "o_%s.bed" % name)
                 try:

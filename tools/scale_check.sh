@@ -21,7 +21,9 @@ for N in 1 2 4 8; do
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); n = int(sys.argv[2])
 c = d["config"]
-print("N=%d value %.4g %s ms/step %.3f" % (d["n_gpus"], d["value"], d["unit"], d["ms_per_step"]), "sharded_equals_single_gpu:", c.get("sharded_equals_single_gpu"), "imbalance:", c.get("imbalance_pileup_wall_max_over_mean"))
+e2e = d["tiers"].get("end_to_end_sharded") or d["tiers"].get("end_to_end") or {}
+print("N=%d value %.4g %s ms/step %.3f | end to end %.4g %s in %.0f ms" % (d["n_gpus"], d["value"], d["unit"], d["ms_per_step"], d.get("value_end_to_end", 0.0), d["unit"], e2e.get("ms", 0.0)),
+      "sharded_equals_single_gpu:", c.get("sharded_equals_single_gpu"), "imbalance:", c.get("imbalance_pileup_wall_max_over_mean"), "per-rank total s:", e2e.get("per_rank_total_s"))
 assert d["n_gpus"] == n
 if n > 1:
     assert c.get("sharded_equals_single_gpu") is True and c.get("resident_windows_equal_sharded") is True, "sharded output differs from the single-GPU run"
