@@ -381,11 +381,7 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
   if (lane == 0) status[bi] = err;
 }
 
-// At most three waves per SIMD (twelve per CU, 120 of the 160 KiB of LDS): the kernel is instruction-issue bound and runs the same 57-58 ms
-// with 11 or with 16 waves per CU — but with sixteen it holds EVERY byte of LDS for the ~4 ms a block takes, and the small kernels that run
-// beside an ingest (the threshold estimate's sampling rounds, the pileup pass of the shard in hand while later shards come in) waited for a
-// block to finish before their workgroups found room: 6 ms per sampling round on the C4 scale model.
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 3)))
+extern "C" __global__ void __launch_bounds__(64)
 mkp_inflate_wave4(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
   inflate_wave_par<4096u, true>(in_bytes, blocks, n_blocks, out, status);
 }
