@@ -157,7 +157,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     { std::lock_guard<std::mutex> g(st_mu); stages_issued = n_stages; up_finished = true; } st_cv.notify_all();
     up_ms = ms_since(t_up);
   });
-  struct JoinUp { std::thread& t; ~JoinUp() { if (t.joinable()) t.join(); } } join_up{uploader};
+  // (whatever way this function is left: the uploader has stopped and the copies it queued out of the page-locked staging have landed — the
+  // next ingest on this object rewrites that staging from its first round on)
+  struct JoinUp { std::thread& t; hipStream_t up; ~JoinUp() { if (t.joinable()) t.join(); (void)hipStreamSynchronize(up); } } join_up{uploader, d->up_stream};
   // ---- block table.  The device walks the BGZF headers of the uploaded bytes, one thread per chain between block starts the index knows
   // (round 4 walked them on the host with one pread per block: 54 000 preads, 40-90 ms beside an upload that wants the same cores);
   // MKP_HOST_BLOCK_TABLE=1 keeps the host walk (A/B runs).

@@ -4,7 +4,7 @@
 # `mkpileup pileup` run (the device-ingest kernels), SQ counters of the c3 step kernels and of the inflate kernels.
 # Usage: [SKIP_PYTEST=1] tools/gpu_final.sh <tag>     -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r04}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+TAG=${1:-r05}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 nproc > $OUT/host.txt; free -g >> $OUT/host.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>/dev/null
 if [ -z "${SKIP_PYTEST:-}" ]; then
   ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
@@ -27,5 +27,7 @@ if [ -n "$P" ]; then
   for f in $(find /tmp/prof_cli -name '*kernel_stats.csv'); do cp $f $OUT/ingest_kernel_stats.csv; done
   head -14 $OUT/ingest_kernel_stats.csv | cut -c1-160; grep -E "ingest|total_ms|MKP_" $OUT/ingest_cli.err | cut -c1-300 | head
 fi
+# the 2-rank form of the bench on this box's one GPU (gloo): the sharded path end to end, its parity flags
+( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 $GRAFT_REPO_ROOT/bench.py --gpus 2 --steps 5 --warmup 2 --dist-backend gloo ) > $OUT/n2_gloo_bench.json 2> $OUT/n2_gloo_bench.err; echo "n2 gloo exit $?"
 cd $GRAFT_REPO_ROOT; PASSES="1 2" bash tools/dbg/pmc_wide.sh $TAG/sq > /dev/null 2>&1; cat $OUT/sq/pmc.txt | cut -c1-400
-KERNELS=wave2 bash tools/dbg/pmc_inflate.sh $TAG/sqi > /dev/null 2>&1; cat $OUT/sqi/sq_inflate.txt | cut -c1-500
+KERNELS=wave4 bash tools/dbg/pmc_inflate.sh $TAG/sqi > /dev/null 2>&1; cat $OUT/sqi/sq_inflate.txt | cut -c1-500
