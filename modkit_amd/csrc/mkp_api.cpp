@@ -592,19 +592,23 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
   auto t_rk = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (trace) { auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[mkpileup plan]   kernels: %-20s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_rk).count()); t_rk = now; } };
   const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
-  c->d_tile_row_off.ensure((size_t)(n_runs + 1) * 8); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);   // (slot pipeline: row_off holds the runs' 64-bit look-back words)
+  // (slot pipeline: row_off holds the runs' 64-bit look-back words behind a 64-byte header — the pass's cursor / total / error words — so that
+  //  ONE memset readies a pass: between two kernels of a 1 ms step every extra fill or copy is a 5-10 us launch of its own)
+  c->d_tile_row_off.ensure(64 + (size_t)(n_runs + 1) * 8); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);
   for (;;) {
     P.row_capacity = (uint32_t)c->row_cap;
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
     lap("row buffers");
-    uint32_t* misc = c->d_misc.as<uint32_t>();  // [0] row cursor, [1] total rows, [2] error bits
-    hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
-    if (c->slot_mode) {   // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, misc[3] = number of runs
-      hip_check(hipMemsetAsync(c->d_tile_row_off.p, 0, (size_t)(n_runs + 1) * 8, c->stream), "memset");
-      hip_check(hipMemcpyAsync(misc + 3, &n_runs, 4, hipMemcpyHostToDevice, c->stream), "H2D");
-    }
+    uint32_t* misc = c->d_tile_row_off.as<uint32_t>();  // [0] row cursor / tile ticket, [1] total rows, [2] error bits; the look-back words (slot pipeline) or row offsets start at +16 dwords
+    uint32_t* row_off = misc + 16;
+    // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, P.n_runs = number of runs
+    hip_check(hipMemsetAsync(misc, 0, c->slot_mode ? 64 + (size_t)(n_runs + 1) * 8 : 64, c->stream), "memset");
+    P.n_runs = n_runs;
     c->d_prm.ensure(sizeof(MkpRunParams));
-    hip_check(hipMemcpyAsync(c->d_prm.p, &P, sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
+    if (c->prm_uploaded.size() != sizeof(MkpRunParams) || c->prm_uploaded_to != c->d_prm.p || memcmp(c->prm_uploaded.data(), &P, sizeof(MkpRunParams)) != 0) {   // (re-launches on a resident shard: unchanged)
+      c->prm_uploaded.assign(reinterpret_cast<const uint8_t*>(&P), reinterpret_cast<const uint8_t*>(&P) + sizeof(MkpRunParams)); c->prm_uploaded_to = c->d_prm.p;
+      hip_check(hipMemcpyAsync(c->d_prm.p, c->prm_uploaded.data(), sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
+    }
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class, c->d_cigar.as<uint32_t>(),
         c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
@@ -621,15 +625,15 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
     for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
       if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
-                                                 c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
+                                                 c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, row_off, c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
                                                  c->key_passes[kp], kp, one_shot ? 1 : 0, (uint32_t)c->combos.size()), "stream pileup launch");
       else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
-                                  c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp, one_shot ? 1 : 0), "pileup launch");
+                                  row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp, one_shot ? 1 : 0), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
     if (c->slot_mode) c->rows_dst = c->rows_src;   // already in genome order
-    else hip_check(mkp_launch_gather(c->stream, c->d_tile_row_off.as<uint32_t>(), c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
+    else hip_check(mkp_launch_gather(c->stream, row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
         &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     lap("launches");

@@ -262,13 +262,13 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       uint32_t s = 0;
       for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
       uint32_t base;
-      if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); row_cursor[3] = number of runs (host), row_cursor[1] = total rows, written by the last run
+      if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); prm.n_runs = number of runs, row_cursor[1] = total rows, written by the last run
 #ifdef MKP_DEBUG
         if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (threadIdx.x == 0) b0 = atomicAdd(row_cursor + 1, s); base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); } else   // ablation: no look-back (rows in completion order)
 #endif
         {
         base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), tix, s);
-        if (threadIdx.x == 0 && tix + 1u == row_cursor[3]) row_cursor[1] = base + s;
+        if (threadIdx.x == 0 && tix + 1u == prm.n_runs) row_cursor[1] = base + s;
         }
       } else base = s ? atomicAdd(row_cursor, s) : 0u;
       if (threadIdx.x == 0) {

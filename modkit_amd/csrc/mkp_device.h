@@ -151,6 +151,7 @@ struct MkpRunParams {
   uint8_t hemi_el[MKP_MAX_COUNTERS + 2];  // call-event counter id -> pattern element; 0xff = Filtered
   uint32_t readout_b_off;                 // duplex reads decoded one group per wave: the second group's summary sits at readout[readout_b_off + read]
   uint32_t slot_stream;                   // 1: focus run on the slot pipeline (feature stream + mkp_pileup_stream)
+  uint32_t n_runs;                        // slot pipeline: row runs of the launch sequence (key passes * tiles); the last one writes the row total
 };
 // pileup-hemi counters of one tally column: NoCall(base) 0..3, deletions, Filtered(base) 5..8, then the pattern blocks
 #define MKP_H_NC 0

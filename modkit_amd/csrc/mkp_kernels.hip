@@ -1157,6 +1157,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
   __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];   // <= 64 motif-id combos (checked at mkp_shard_begin)
   {
+    static_assert(PILEUP_THREADS == 1024, "the row table below is filled one entry per thread");
     const uint32_t t = threadIdx.x, byte = t & 255u, par = (t >> 8) & 1u, st = (t >> 9) & 1u;
     const uint32_t nib = par ? (byte & 15u) : (byte >> 4);
     const unsigned long long LUT = st ? 0xfffffff0fff1f23fULL : 0xfffffff3fff2f10fULL;

@@ -540,7 +540,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
                  const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
                  const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
                  uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos) {
-  const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = KEYED ? (key_arg >> 16) : 0u;
+  const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = key_arg >> 16;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
@@ -554,36 +554,49 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   // but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need.)
   // The prologue is a chain of memory round trips in front of the first tally — ticket, tile record, slot positions, first visit, first
   // stream dword — and there are four tiles per workgroup slot: what does not depend on the ticket (parameters, combos, clearing the
-  // tallies) is issued beside it, under one barrier.
+  // tallies) is issued beside it.  The tile record then goes through LDS and comes back as SCALAR values: it is uniform, and eight VGPRs
+  // that live to the last row are what the 64-VGPR build spills first (87 spilled registers before, 29 now: the rest belong to the
+  // row emission).  (Round 5 also tried persistent workgroups — two per CU drawing tickets until none is left, the last wave making the
+  // next tile's chain beside the current tile's visits: no faster at equal register use, and the loop's live values cost more spills.)
   __shared__ uint32_t run_ticket;
+  __shared__ MkpSTile tile_s;
   if (threadIdx.x == 0) run_ticket = atomicAdd(row_cursor, 1u);
   for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += PILEUP_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
   for (uint32_t kq = threadIdx.x; kq < n_combos * (sizeof(MkpCombo) / 4); kq += PILEUP_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
   __syncthreads();
-  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
-  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
-  const uint32_t S = prm.slot_cap;
-  const uint32_t n_counters = prm.n_counters, n_oslots = prm.n_slots;
+  const MkpRunParams& prm0 = *reinterpret_cast<const MkpRunParams*>(prm_lds);
+  const uint32_t S = rfl(prm0.slot_cap);
+  const uint32_t n_counters = rfl(prm0.n_counters), n_oslots = rfl(prm0.n_slots);
   const uint32_t tal_words = (n_counters + n_oslots) * S;
   uint32_t* __restrict__ tal = lds;
   uint32_t* __restrict__ obs = lds + n_counters * S;
   int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(lds + tal_words);
   const int lane = lane_id();
   const uint32_t wave = rfl(threadIdx.x >> 6);
-  const uint32_t run = run_ticket;                                  // row-run index: key pass * tiles + tile (passes run one after the other on the stream)
-  const uint32_t tix = KEYED ? run - key_run * n_tiles : run;
+  const uint32_t run = rfl(run_ticket);                               // row-run index: key pass * tiles + tile (passes run one after the other on the stream)
+  // (key_run is a kernel argument in both builds — zero without --partition-tag — and not folded away in the unkeyed one: with `tix` and
+  //  `run` one and the same value the register allocator ends at 91 spilled VGPRs in the 64-VGPR build, with the subtraction at 29)
+  const uint32_t tix = run - key_run * n_tiles;
   if (tix >= n_tiles) { if (threadIdx.x == 0) atomicOr(dev_err, ERR_ROW_CAP); return; }   // (cannot happen: one ticket per workgroup)
-  const MkpSTile tl = tiles[tix];   // (in flight while the tallies are cleared)
-  { const uint32_t nv = tal_words >> 2; uint4* l4 = reinterpret_cast<uint4*>(lds);
+  { const MkpSTile tl0 = tiles[tix];   // (in flight while the tallies are cleared)
+    const uint32_t nv = tal_words >> 2; uint4* l4 = reinterpret_cast<uint4*>(lds);
     for (uint32_t k = threadIdx.x; k < nv; k += PILEUP_THREADS) l4[k] = make_uint4(0u, 0u, 0u, 0u);
-    for (uint32_t k = (nv << 2) + threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0; }
-  const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
-  for (uint32_t k = threadIdx.x; k < n_tslots; k += PILEUP_THREADS) fpos[k] = (int32_t)slot_pos[gh0 + k];
-  if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }   // (tiles hold at least one candidate read)
+    for (uint32_t k = (nv << 2) + threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
+    if (threadIdx.x == 0) { tile_s = tl0; next_read = tl0.first; scan_carry = 0; }   // (tiles hold at least one candidate read)
+    for (uint32_t k = threadIdx.x; k < tl0.gh1 - tl0.gh0; k += PILEUP_THREADS) fpos[k] = (int32_t)slot_pos[tl0.gh0 + k];
+  }
   __syncthreads();
-
-  const uint32_t rid_end = tl.last;
   const uint32_t talbase = lds_addr(tal), S4 = S * 4u;
+  // (from here on the parameter block and the combos are read through an offset the compiler cannot see through: fields it would otherwise
+  //  load early and keep in registers to the last row are read where they are used)
+  uint32_t zofs = 0; asm volatile("" : "+s"(zofs));
+  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds + zofs);
+  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds + zofs);
+  MkpSTile tl;
+  tl.gh0 = rfl(tile_s.gh0); tl.gh1 = rfl(tile_s.gh1); tl.r0 = (int32_t)rfl((uint32_t)tile_s.r0); tl.r1 = (int32_t)rfl((uint32_t)tile_s.r1);
+  tl.first = rfl(tile_s.first); tl.last = rfl(tile_s.last); tl.g0 = 0; tl.g1 = 0;
+  const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
+  const uint32_t rid_end = tl.last;
   // one visit: the read's bytes for this tile's slots (first dword per lane already in `wcur`), its observed codes, its overflow events
   auto visit = [&](const MkpVisit& v, uint32_t wcur) {
     const uint32_t a = max(v.gs0, gh0), b = min(v.gs0 + v.n_sl, gh1);
@@ -662,10 +675,10 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   __syncthreads();
 #ifdef MKP_DEBUG
   if (prm.debug_skip & 2048u) {   // ablation: no scans, no rows (the look-back word is still published so that nothing waits)
-    if (threadIdx.x < 64u) { lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, 0u); if (threadIdx.x == 0 && run + 1u == row_cursor[3]) row_cursor[1] = 0; }
-    return;
-  }
+    if (threadIdx.x < 64u) { lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, 0u); if (threadIdx.x == 0 && run + 1u == prm.n_runs) row_cursor[1] = 0; }
+  } else
 #endif
+  {
   // observed-code difference arrays -> counts, in place and still packed
   for (uint32_t a = wave; a < n_oslots; a += PILEUP_WAVES) {
     uint32_t* __restrict__ arr = obs + a * S;
@@ -682,6 +695,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   StreamSlotMap sm; sm.fpos = fpos; sm.n = n_tslots;
   MkpTile tl2; tl2.r0 = tl.r0; tl2.r1 = tl.r1; tl2.first = tl.first; tl2.last = tl.last;
   emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, run, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  }
 }
 
 #define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \
