@@ -27,7 +27,7 @@ hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | sh
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
-                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/, uint32_t /*motif combos*/);
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
@@ -601,9 +601,8 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
     lap("row buffers");
     uint32_t* misc = c->d_tile_row_off.as<uint32_t>();  // [0] row cursor / tile ticket, [1] total rows, [2] error bits; the look-back words (slot pipeline) or row offsets start at +16 dwords
     uint32_t* row_off = misc + 16;
-    // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, P.n_runs = number of runs
+    // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, the number of runs is a kernel argument
     hip_check(hipMemsetAsync(misc, 0, c->slot_mode ? 64 + (size_t)(n_runs + 1) * 8 : 64, c->stream), "memset");
-    P.n_runs = n_runs;
     c->d_prm.ensure(sizeof(MkpRunParams));
     if (c->prm_uploaded.size() != sizeof(MkpRunParams) || c->prm_uploaded_to != c->d_prm.p || memcmp(c->prm_uploaded.data(), &P, sizeof(MkpRunParams)) != 0) {   // (re-launches on a resident shard: unchanged)
       c->prm_uploaded.assign(reinterpret_cast<const uint8_t*>(&P), reinterpret_cast<const uint8_t*>(&P) + sizeof(MkpRunParams)); c->prm_uploaded_to = c->d_prm.p;
@@ -626,7 +625,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
       if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
                                                  c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, row_off, c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
-                                                 c->key_passes[kp], kp, one_shot ? 1 : 0, (uint32_t)c->combos.size()), "stream pileup launch");
+                                                 c->key_passes[kp], kp, one_shot ? 1 : 0, (uint32_t)c->combos.size(), n_runs), "stream pileup launch");
       else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
@@ -637,7 +636,8 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
         &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     lap("launches");
-    uint32_t h[4];
+    if (!c->h_words && hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 64, hipHostMallocDefault) != hipSuccess) { c->h_words = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); }
+    uint32_t* h = c->h_words;
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     hip_check(hipStreamSynchronize(c->stream), "kernel sync");
     lap("sync");
@@ -790,6 +790,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   mkp_internal_ingest_destroy(c->ingest); c->ingest = nullptr;
   c->h_rows.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->h_words) (void)hipHostFree(c->h_words);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

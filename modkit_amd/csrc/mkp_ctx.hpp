@@ -78,6 +78,7 @@ struct mkp_ctx {
   struct mkp_dev_ingest* ingest = nullptr;   // device ingest of indexed BAMs (mkp_ingest_host.cpp): created on first use, lives with the context (staging + window buffers are reused)
   mkp_stats stats;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t* h_words = nullptr;   // 64 page-locked bytes: the pass's cursor / total / error words come back into these (a D2H into pageable memory is staged and synchronised by the runtime)
   std::vector<uint8_t> prm_uploaded; const void* prm_uploaded_to = nullptr;   // the parameter block as last sent to d_prm (kept alive for the async copy; re-launches skip an unchanged one)
 };
 

@@ -232,7 +232,7 @@ template <bool FOCUS, bool HEMI, class SM, bool ORDERED = false>
 __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SM sm, uint32_t n_tslots, MkpTile tl, uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
                                             const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
                                             uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
-                                            uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p) {
+                                            uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p, uint32_t n_runs = 0 /* ORDERED: runs of the launch sequence */) {
   const MkpRunParams& prm = *prmp;
   const int lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
@@ -262,13 +262,13 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       uint32_t s = 0;
       for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
       uint32_t base;
-      if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); prm.n_runs = number of runs, row_cursor[1] = total rows, written by the last run
+      if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); n_runs = number of runs (a kernel argument), row_cursor[1] = total rows, written by the last run
 #ifdef MKP_DEBUG
         if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (threadIdx.x == 0) b0 = atomicAdd(row_cursor + 1, s); base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); } else   // ablation: no look-back (rows in completion order)
 #endif
         {
         base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), tix, s);
-        if (threadIdx.x == 0 && tix + 1u == prm.n_runs) row_cursor[1] = base + s;
+        if (threadIdx.x == 0 && tix + 1u == n_runs) row_cursor[1] = base + s;
         }
       } else base = s ? atomicAdd(row_cursor, s) : 0u;
       if (threadIdx.x == 0) {

@@ -151,7 +151,6 @@ struct MkpRunParams {
   uint8_t hemi_el[MKP_MAX_COUNTERS + 2];  // call-event counter id -> pattern element; 0xff = Filtered
   uint32_t readout_b_off;                 // duplex reads decoded one group per wave: the second group's summary sits at readout[readout_b_off + read]
   uint32_t slot_stream;                   // 1: focus run on the slot pipeline (feature stream + mkp_pileup_stream)
-  uint32_t n_runs;                        // slot pipeline: row runs of the launch sequence (key passes * tiles); the last one writes the row total
 };
 // pileup-hemi counters of one tally column: NoCall(base) 0..3, deletions, Filtered(base) 5..8, then the pattern blocks
 #define MKP_H_NC 0
@@ -188,7 +187,9 @@ struct MkpTile { int32_t r0, r1; uint32_t first, last; };
 // stream into LDS tallies.  Feature byte = what FeatureVector::add_feature receives for this alignment at this column
 // (pileup/mod.rs:783-939): [0:4] counter id (MKP_C_*), [5] tally strand, [6:7] the read base as tallied (so that a call of a
 // record that later fails can be counted as NoCall(base)).
+#ifndef MKP_SLOT_WB
 #define MKP_SLOT_WB 16384u   // mkp_decode_slots*: stored bases per base window; longer reads take the *_long instances
+#endif
 #define MKP_FB_NONE 0xffu    // the read is not in this column (ref-skip)
 #define MKP_FB_BLANK 0xfeu   // in the column, no feature (non-ACGT base: pileup/mod.rs:864-874)
 struct MkpVisit {            // 32 B, written by the decode / cover kernels, read by mkp_pileup_stream

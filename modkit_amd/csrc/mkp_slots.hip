@@ -539,7 +539,7 @@ template <bool KEYED, uint32_t VB /* visits drawn per ticket, their records and 
 __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events,
                  const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
                  const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
-                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos) {
+                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs) {
   const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = key_arg >> 16;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   __syncthreads();
 #ifdef MKP_DEBUG
   if (prm.debug_skip & 2048u) {   // ablation: no scans, no rows (the look-back word is still published so that nothing waits)
-    if (threadIdx.x < 64u) { lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, 0u); if (threadIdx.x == 0 && run + 1u == prm.n_runs) row_cursor[1] = 0; }
+    if (threadIdx.x < 64u) { lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, 0u); if (threadIdx.x == 0 && run + 1u == n_runs) row_cursor[1] = 0; }
   } else
 #endif
   {
@@ -694,14 +694,14 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   __syncthreads();
   StreamSlotMap sm; sm.fpos = fpos; sm.n = n_tslots;
   MkpTile tl2; tl2.r0 = tl.r0; tl2.r1 = tl.r1; tl2.first = tl.first; tl2.last = tl.last;
-  emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, run, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, run, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry, n_runs);
   }
 }
 
 #define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \
     const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, \
-    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos
-#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos
+    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs
+#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos, n_runs
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
 // the same bodies with 128 VGPRs (four waves per SIMD, one workgroup per CU): no register spills, no scratch (MKP_PILEUP_WAVES=4; A/B runs)
@@ -731,12 +731,12 @@ extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
 
 extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
                                         const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot, uint32_t n_combos) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot, uint32_t n_combos, uint32_t n_runs) {
   if (!n_tiles) return hipSuccess;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
 #define MKP_STREAM_LAUNCH(K) hipLaunchKernelGGL(K, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, visits, cov, events, tiles, n_tiles, prm_dev, slot_pos, focus, combos, rows->pos, row_cursor, \
-                                                tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos > 64u ? 64u : n_combos)
+                                                tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos > 64u ? 64u : n_combos, n_runs)
   // The 64-VGPR build (two workgroups per CU) spills into 220 bytes of scratch per lane.  It is the faster kernel (0.154 against 0.234 ms
   // on C3) — but a queue that has been idle pays 9-13 ms for the scratch allocation around its first such dispatch, which is all a
   // one-shot run (one launch per shard, then rows) ever sees.  One-shot launches take the 128-VGPR build (no spills, no scratch); re-launches
