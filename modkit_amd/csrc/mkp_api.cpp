@@ -634,7 +634,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
     if (c->slot_mode) c->rows_dst = c->rows_src;   // already in genome order
     else hip_check(mkp_launch_gather(c->stream, row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
         &c->rows_src, &c->rows_dst), "gather launch");
-    if (time_kernels) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
+    if (time_kernels && !c->slot_mode) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     lap("launches");
     if (!c->h_words && hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 64, hipHostMallocDefault) != hipSuccess) { c->h_words = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); }
     uint32_t* h = c->h_words;
@@ -646,7 +646,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
     c->stats.n_rows = h[1];
     if (time_kernels) {
       float a = 0, b = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
-      hip_check(hipEventElapsedTime(&d, c->ev[2], c->ev[3]), "event");
+      if (!c->slot_mode) hip_check(hipEventElapsedTime(&d, c->ev[2], c->ev[3]), "event");   // (the slot pipeline has no gather pass)
       c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = d; c->stats.kernel_ms = a + b + d;
     }
     return;
@@ -776,7 +776,9 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
   // chip for tens of milliseconds: it goes first when workgroup slots free up
   { int plo = 0, phi = 0;
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamDefault, phi) != hipSuccess) { delete c; return MKP_E_DEVICE; } }
-  for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return MKP_E_DEVICE; }
+  // timing events between the kernels of a pass: no system-scope fence when they are recorded (its cache write-back and invalidation sat
+  // between the decoder and the kernel that reads what it just wrote; nothing on the host looks at device memory through these events)
+  for (auto& e : c->ev) if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { delete c; return MKP_E_DEVICE; }
   c->caller = CallerCfg();
   *out = c;
   return MKP_OK;
