@@ -144,7 +144,7 @@ MkpFusedDesc fused_desc(const MkpLayout& D) {
 template <class V> void upload(DevBuf& b, const V& v) {
   const size_t bytes = v.size() * sizeof(v[0]);
   b.ensure(std::max<size_t>(bytes, 16));
-  if (!v.empty()) hip_check(hipMemcpy(b.p, v.data(), bytes, hipMemcpyHostToDevice), "H2D");
+  if (!v.empty()) h2d_copy(b.p, v.data(), bytes);   // (through the library's page-locked staging: mkp_ctx.hpp)
 }
 
 template <class F> void host_parallel(size_t n, size_t grain, F f) {   // f(lo, hi) over [0, n) in `grain`-sized pieces on the host pool
@@ -599,6 +599,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
     P.row_capacity = (uint32_t)c->row_cap;
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
     lap("row buffers");
+    if (trace) { hip_check(hipStreamSynchronize(c->stream), "sync"); lap("stream drained"); }   // (trace runs: what the stream still had queued shows up here, not in the kernels' sync)
     uint32_t* misc = c->d_tile_row_off.as<uint32_t>();  // [0] row cursor / tile ticket, [1] total rows, [2] error bits; the look-back words (slot pipeline) or row offsets start at +16 dwords
     uint32_t* row_off = misc + 16;
     // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, the number of runs is a kernel argument
@@ -636,6 +637,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
         &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels && !c->slot_mode) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     lap("launches");
+    if (trace && time_kernels) { hip_check(hipEventSynchronize(c->ev[0]), "sync"); lap("first event reached"); hip_check(hipEventSynchronize(c->ev[2]), "sync"); lap("kernels done (event)"); }
     if (!c->h_words && hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 64, hipHostMallocDefault) != hipSuccess) { c->h_words = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); }
     uint32_t* h = c->h_words;
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
@@ -1261,7 +1263,7 @@ void sample_decode(mkp_ctx* c, ShardHost& S, bool resident, const uint8_t* bedma
   if (bedmask) {
     const size_t len = (size_t)(S.win_end - S.win_start);
     if (bedmask != c->bedmask_src || len != c->bedmask_len) {
-      c->d_bedmask.ensure(len); hip_check(hipMemcpy(c->d_bedmask.p, bedmask, len, hipMemcpyHostToDevice), "H2D"); c->bedmask_src = bedmask; c->bedmask_len = len;
+      c->d_bedmask.ensure(len); h2d_copy(c->d_bedmask.p, bedmask, len); c->bedmask_src = bedmask; c->bedmask_len = len;
     }
     d_mask = c->d_bedmask.as<uint8_t>();
   } else { c->d_focus.ensure(16); d_mask = c->d_focus.as<uint8_t>(); }

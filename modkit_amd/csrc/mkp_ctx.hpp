@@ -30,6 +30,44 @@ inline void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Host -> device copies of plan data (read headers, work records, focus bytes, tiles) go through page-locked staging owned by the library.
+// Handed a large PAGEABLE buffer, the HIP runtime pins the caller's pages in place (a userptr mapping) for the DMA; when that memory is
+// later freed or remapped — the planner's vectors are temporaries — the kernel driver evicts every queue of the process and restores
+// them after a delay: measured as 10-25 ms between the first launch of the next pass and its first event (round 5; with
+// GPU_PINNED_MIN_XFER_SIZE raised so that the runtime never pins in place the wait is 0.00 ms).  So the library never hands the
+// runtime a large pageable buffer: two 8 MiB halves per calling thread, filled on the host pool while the other half is in flight.
+struct H2DStage {
+  static constexpr size_t kHalf = 8u << 20;
+  uint8_t* p = nullptr; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; int dev = -1;
+  ~H2DStage() { if (st) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(st); } if (p) (void)hipHostFree(p); }
+};
+inline void h2d_copy(void* dst, const void* src, size_t bytes) {   // synchronous, like the hipMemcpy it replaces
+  if (!bytes) return;
+  if (bytes <= 4096) { hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "H2D"); return; }   // (small copies take the runtime's own staging buffer)
+  static thread_local H2DStage S;
+  int dev = 0; hip_check(hipGetDevice(&dev), "hipGetDevice");
+  if (!S.p && hipHostMalloc(reinterpret_cast<void**>(&S.p), 2 * H2DStage::kHalf, hipHostMallocPortable) != hipSuccess) { S.p = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc of the upload staging failed"); }
+  if (S.dev != dev) {   // the stream and events belong to a device
+    if (S.st) { for (auto& e : S.ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(S.st); S.st = nullptr; S.ev[0] = S.ev[1] = nullptr; }
+    hip_check(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto& e : S.ev) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    S.dev = dev;
+  }
+  const uint8_t* s = static_cast<const uint8_t*>(src); uint8_t* d = static_cast<uint8_t*>(dst);
+  size_t k = 0;
+  for (size_t off = 0; off < bytes; off += H2DStage::kHalf, k++) {
+    const size_t n = std::min(H2DStage::kHalf, bytes - off), h = k & 1u;
+    if (k >= 2) hip_check(hipEventSynchronize(S.ev[h]), "event sync");   // the copy that last used this half is done
+    uint8_t* stage = S.p + h * H2DStage::kHalf;
+    const size_t grain = 1u << 20, pieces = (n + grain - 1) / grain;
+    if (pieces > 1) HostPool::get().parallel(pieces, [&](size_t i) { memcpy(stage + i * grain, s + off + i * grain, std::min(grain, n - i * grain)); });
+    else memcpy(stage, s + off, n);
+    hip_check(hipMemcpyAsync(d + off, stage, n, hipMemcpyHostToDevice, S.st), "H2D");
+    hip_check(hipEventRecord(S.ev[h], S.st), "event");
+  }
+  hip_check(hipStreamSynchronize(S.st), "H2D sync");
+}
+
 inline double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 
 

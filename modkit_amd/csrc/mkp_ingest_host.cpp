@@ -192,7 +192,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     d->small.ensure(4096);
     uint32_t* h_small = (uint32_t*)d->small.p;   // [0] error bits, [1] blocks of the stage; [2..3] the cursor of the inflated window (at the end)
     while (d->tev.size() < 2 * n_stages) { hipEvent_t e = nullptr; ok(hipEventCreate(&e), "event"); d->tev.push_back(e); }
-    ok(hipMemcpyAsync(d->segs.p, zc.data(), nc * sizeof(MkpZChain), hipMemcpyHostToDevice, d->stream), "H2D");
+    h2d_copy(d->segs.p, zc.data(), nc * sizeof(MkpZChain));   // (a temporary: through the library's page-locked staging, mkp_ctx.hpp)
     ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
     ok(hipMemsetAsync(d->rawcur.p, 0, 16, d->stream), "memset");
     size_t blk_cap = std::max<size_t>({d->zblk.cap / sizeof(BgzfBlk), d->ztab.cap / sizeof(MkpZBlk), (size_t)(plan.comp_total / 8192 + 4096)});
