@@ -663,7 +663,7 @@ void fetch_row_columns(mkp_ctx* c) {
   c->h_rows.ensure(std::max<uint64_t>(n, 1));
   if (n) { for (int k = 0; k < 11; k++) hip_check(hipMemcpyAsync(c->h_rows.col[k], src[k], n * 4, hipMemcpyDeviceToHost, c->stream), "rows D2H"); hip_check(hipStreamSynchronize(c->stream), "rows D2H sync"); }
   std::vector<MkpReadOut> ro(c->shard.hdr.size());
-  if (!ro.empty()) hip_check(hipMemcpy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost), "readout D2H");
+  d2h_copy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), c->stream);
   c->n_ok = 0; c->n_bad = 0; uint64_t ev = 0;
   for (auto& r : ro) { if (r.ok) { c->n_ok++; ev += r.n_events; } else c->n_bad++; }
   c->stats.n_events = ev;
@@ -1115,8 +1115,8 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
     hip_check(hipSetDevice(c->device), "hipSetDevice");
     c->d_zin.ensure(std::max<uint64_t>(n_bytes, 16)); c->d_zout.ensure(std::max<uint64_t>(total, 16)); c->d_zblk.ensure(std::max<size_t>(blks.size(), 1) * sizeof(Blk));
         c->d_zstat.ensure(std::max<size_t>(blks.size(), 1) * 4);
-    if (n_bytes) hip_check(hipMemcpyAsync(c->d_zin.p, bgzf, n_bytes, hipMemcpyHostToDevice, c->stream), "H2D");
-    if (!blks.empty()) hip_check(hipMemcpyAsync(c->d_zblk.p, blks.data(), blks.size() * sizeof(Blk), hipMemcpyHostToDevice, c->stream), "H2D");
+    h2d_copy(c->d_zin.p, bgzf, n_bytes);   // (caller memory and a temporary: through the library's page-locked staging, mkp_ctx.hpp)
+    h2d_copy(c->d_zblk.p, blks.data(), blks.size() * sizeof(Blk));
     hip_check(hipMemsetAsync(c->d_zstat.p, 0xff, std::max<size_t>(blks.size(), 1) * 4, c->stream), "memset");
     hip_check(hipEventRecord(c->ev[0], c->stream), "event");
     hip_check(launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()),
@@ -1124,8 +1124,8 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
     hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     std::vector<uint32_t> st(blks.size());
     c->h_inflated.resize(total);
-    if (!blks.empty()) hip_check(hipMemcpyAsync(st.data(), c->d_zstat.p, blks.size() * 4, hipMemcpyDeviceToHost, c->stream), "D2H");
-    if (total) hip_check(hipMemcpyAsync(c->h_inflated.data(), c->d_zout.p, total, hipMemcpyDeviceToHost, c->stream), "D2H");
+    d2h_copy(st.data(), c->d_zstat.p, blks.size() * 4, c->stream);
+    d2h_copy(c->h_inflated.data(), c->d_zout.p, total, c->stream);
     hip_check(hipStreamSynchronize(c->stream), "inflate sync");
     if (kernel_ms) { float ms = 0; hip_check(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]), "event"); *kernel_ms = ms; }
     std::atomic<long> bad{-1};
@@ -1335,8 +1335,8 @@ int mkp_internal_extract_fetch(mkp_ctx* c, std::vector<MkpEvent>* events, std::v
     events->resize(n); vals->resize(n);
     if (!n) return;
     hip_check(hipSetDevice(c->device), "hipSetDevice");
-    hip_check(hipMemcpy(events->data(), c->d_events.p, n * sizeof(MkpEvent), hipMemcpyDeviceToHost), "events D2H");
-    hip_check(hipMemcpy(vals->data(), c->d_vals.p, n * sizeof(float), hipMemcpyDeviceToHost), "values D2H");
+    d2h_copy(events->data(), c->d_events.p, n * sizeof(MkpEvent), c->stream);
+    d2h_copy(vals->data(), c->d_vals.p, n * sizeof(float), c->stream);
   });
 }
 

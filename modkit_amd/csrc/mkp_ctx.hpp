@@ -41,27 +41,55 @@ struct H2DStage {
   uint8_t* p = nullptr; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; int dev = -1;
   ~H2DStage() { if (st) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(st); } if (p) (void)hipHostFree(p); }
 };
-inline void h2d_copy(void* dst, const void* src, size_t bytes) {   // synchronous, like the hipMemcpy it replaces
-  if (!bytes) return;
-  if (bytes <= 4096) { hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "H2D"); return; }   // (small copies take the runtime's own staging buffer)
+inline H2DStage& copy_stage() {   // this thread's staging, its stream and events on the current device
   static thread_local H2DStage S;
   int dev = 0; hip_check(hipGetDevice(&dev), "hipGetDevice");
-  if (!S.p && hipHostMalloc(reinterpret_cast<void**>(&S.p), 2 * H2DStage::kHalf, hipHostMallocPortable) != hipSuccess) { S.p = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc of the upload staging failed"); }
+  if (!S.p && hipHostMalloc(reinterpret_cast<void**>(&S.p), 2 * H2DStage::kHalf, hipHostMallocPortable) != hipSuccess) { S.p = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc of the copy staging failed"); }
   if (S.dev != dev) {   // the stream and events belong to a device
     if (S.st) { for (auto& e : S.ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(S.st); S.st = nullptr; S.ev[0] = S.ev[1] = nullptr; }
     hip_check(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking), "hipStreamCreate");
     for (auto& e : S.ev) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     S.dev = dev;
   }
+  return S;
+}
+inline void staged_memcpy(uint8_t* dst, const uint8_t* src, size_t n) {
+  const size_t grain = 1u << 20, pieces = (n + grain - 1) / grain;
+  if (pieces > 1) HostPool::get().parallel(pieces, [&](size_t i) { memcpy(dst + i * grain, src + i * grain, std::min(grain, n - i * grain)); });
+  else memcpy(dst, src, n);
+}
+// device -> host into pageable memory (digests, read headers, readout): the same staging the other way.  Ordered after the work already
+// queued on `stream`; returns when the bytes are in `dst`.
+inline void d2h_copy(void* dst, const void* src_dev, size_t bytes, hipStream_t stream) {
+  if (!bytes) return;
+  if (bytes <= 4096) { hip_check(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream), "D2H"); hip_check(hipStreamSynchronize(stream), "D2H sync"); return; }
+  H2DStage& S = copy_stage();
+  const uint8_t* s = static_cast<const uint8_t*>(src_dev); uint8_t* d = static_cast<uint8_t*>(dst);
+  const size_t n_chunks = (bytes + H2DStage::kHalf - 1) / H2DStage::kHalf;
+  for (size_t k = 0; k <= n_chunks; k++) {
+    if (k < n_chunks) {   // chunk k into half k & 1 (drained of chunk k - 2 one iteration ago)
+      const size_t off = k * H2DStage::kHalf, n = std::min(H2DStage::kHalf, bytes - off), h = k & 1u;
+      hip_check(hipMemcpyAsync(S.p + h * H2DStage::kHalf, s + off, n, hipMemcpyDeviceToHost, stream), "D2H");
+      hip_check(hipEventRecord(S.ev[h], stream), "event");
+    }
+    if (k >= 1) {
+      const size_t j = k - 1, off = j * H2DStage::kHalf, n = std::min(H2DStage::kHalf, bytes - off), h = j & 1u;
+      hip_check(hipEventSynchronize(S.ev[h]), "event sync");
+      staged_memcpy(d + off, S.p + h * H2DStage::kHalf, n);
+    }
+  }
+}
+inline void h2d_copy(void* dst, const void* src, size_t bytes) {   // synchronous, like the hipMemcpy it replaces
+  if (!bytes) return;
+  if (bytes <= 4096) { hip_check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "H2D"); return; }   // (small copies take the runtime's own staging buffer)
+  H2DStage& S = copy_stage();
   const uint8_t* s = static_cast<const uint8_t*>(src); uint8_t* d = static_cast<uint8_t*>(dst);
   size_t k = 0;
   for (size_t off = 0; off < bytes; off += H2DStage::kHalf, k++) {
     const size_t n = std::min(H2DStage::kHalf, bytes - off), h = k & 1u;
     if (k >= 2) hip_check(hipEventSynchronize(S.ev[h]), "event sync");   // the copy that last used this half is done
     uint8_t* stage = S.p + h * H2DStage::kHalf;
-    const size_t grain = 1u << 20, pieces = (n + grain - 1) / grain;
-    if (pieces > 1) HostPool::get().parallel(pieces, [&](size_t i) { memcpy(stage + i * grain, s + off + i * grain, std::min(grain, n - i * grain)); });
-    else memcpy(stage, s + off, n);
+    staged_memcpy(stage, s + off, n);
     hip_check(hipMemcpyAsync(d + off, stage, n, hipMemcpyHostToDevice, S.st), "H2D");
     hip_check(hipEventRecord(S.ev[h], S.st), "event");
   }

@@ -235,8 +235,8 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     out->ms_upload = up_ms;
     // the whole table comes back for the window layout the record kernels need (entry points of the chains) and for error reports
     std::vector<MkpZBlk> zb(blkbase); std::vector<uint32_t> cbase(nc + n_stages + 2);
-    if (blkbase) ok(hipMemcpyAsync(zb.data(), d->ztab.p, blkbase * sizeof(MkpZBlk), hipMemcpyDeviceToHost, d->stream), "D2H");
-    ok(hipMemcpyAsync(cbase.data(), d->seg_cnt.p, (nc + n_stages + 1) * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+    d2h_copy(zb.data(), d->ztab.p, blkbase * sizeof(MkpZBlk), d->stream);
+    d2h_copy(cbase.data(), d->seg_cnt.p, (nc + n_stages + 1) * 4, d->stream);
     ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 2, d->rawcur.p, 8, hipMemcpyDeviceToHost, d->stream), "D2H");
     ok(hipStreamSynchronize(d->stream), "inflate sync");
     for (size_t j = 0; j < n_stages; j++) if (stage_nblk[j]) { float ms = 0; if (hipEventElapsedTime(&ms, d->tev[2 * j], d->tev[2 * j + 1]) == hipSuccess) staged_kernel_ms += ms; }
@@ -348,11 +348,13 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
                             out->d_seq.as<uint8_t>(), out->d_tagref.as<MkpTagRef>(), out->d_ranks.as<uint32_t>(), out->d_ml.as<uint8_t>(), d->dig.as<MkpRecDigest>(), d->tot.as<MkpIngestTotals>()), "pack launch");
   S.hdr.resize(n); S.so_hdr.resize(n_so); S.tagref.resize((size_t)n_pk * MKP_MAX_TAGS); S.name_hash.resize(n);
   std::vector<MkpRecDigest> dig(n_pk); std::vector<int32_t> extra(2 * (size_t)tot->n_extra);
-  if (n) ok(hipMemcpyAsync(S.hdr.data(), d_hdr.p, (size_t)n * sizeof(MkpReadHdr), hipMemcpyDeviceToHost, d->stream), "D2H");
-  if (n_so) ok(hipMemcpyAsync(S.so_hdr.data(), d_hdr.as<MkpReadHdr>() + n, (size_t)n_so * sizeof(MkpReadHdr), hipMemcpyDeviceToHost, d->stream), "D2H");
-  if (n_pk) { ok(hipMemcpyAsync(S.tagref.data(), out->d_tagref.p, (size_t)n_pk * MKP_MAX_TAGS * sizeof(MkpTagRef), hipMemcpyDeviceToHost, d->stream), "D2H");
-              ok(hipMemcpyAsync(dig.data(), d->dig.p, (size_t)n_pk * sizeof(MkpRecDigest), hipMemcpyDeviceToHost, d->stream), "D2H"); }
-  if (!extra.empty()) ok(hipMemcpyAsync(extra.data(), d->extra.p, extra.size() * 4, hipMemcpyDeviceToHost, d->stream), "D2H");
+  // (into pageable vectors through the library's page-locked staging: handed these directly, the runtime pins them in place, and their
+  //  release — with the shard — stalls every queue of the process; mkp_ctx.hpp)
+  d2h_copy(S.hdr.data(), d_hdr.p, (size_t)n * sizeof(MkpReadHdr), d->stream);
+  d2h_copy(S.so_hdr.data(), d_hdr.as<MkpReadHdr>() + n, (size_t)n_so * sizeof(MkpReadHdr), d->stream);
+  if (n_pk) { d2h_copy(S.tagref.data(), out->d_tagref.p, (size_t)n_pk * MKP_MAX_TAGS * sizeof(MkpTagRef), d->stream);
+              d2h_copy(dig.data(), d->dig.p, (size_t)n_pk * sizeof(MkpRecDigest), d->stream); }
+  d2h_copy(extra.data(), d->extra.p, extra.size() * 4, d->stream);
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "pack sync");
   check(tot->err);
@@ -375,7 +377,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     if (it == by_hash.end()) {
       // a structure not seen in this shard yet: its record comes back from HBM and goes through the host packer, which interns the layout
       // (and must arrive at the same key: a colliding hash would otherwise attach the wrong caller tables)
-      if (out->info_host.empty()) { out->info_host.resize(n_all); ok(hipMemcpyAsync(out->info_host.data(), d->info.p, (size_t)n_all * sizeof(MkpRecInfo), hipMemcpyDeviceToHost, d->stream), "D2H (record table)"); ok(hipStreamSynchronize(d->stream), "sync"); }
+      if (out->info_host.empty()) { out->info_host.resize(n_all); d2h_copy(out->info_host.data(), d->info.p, (size_t)n_all * sizeof(MkpRecInfo), d->stream); }
       const uint64_t wi = dig[j].win_idx;
       if (wi >= n_all || (out->info_host[wi].kind != 1 && out->info_host[wi].kind != 3)) throw Error(MKP_E_DEVICE, "internal: device ingest digest points at a record it did not pack");
       const MkpRecInfo ri = out->info_host[wi];
