@@ -859,14 +859,7 @@ int mkp_internal_shard_preplan(mkp_ctx* c) {
     c->wplan.valid = true;
     // a fresh context's first shard: page-locking the row arena costs ~25 ms per 100 MB — here it hides behind the ingest (the caller is
     // about to wait for it); two rows per focus position is what a two-code run can produce at most per strand rule
-    static const int prealloc = getenv("MKP_ARENA_PREALLOC") ? atoi(getenv("MKP_ARENA_PREALLOC")) : 1;   // (0 / 1 / 2: A/B runs)
-    if (prealloc && c->h_rows.cap == 0 && !c->wplan.slot_pos.empty()) {
-      c->h_rows.ensure(std::min<size_t>(c->wplan.slot_pos.size() * 2, (size_t)1 << 26));
-      if (prealloc == 2) {   // and have the device touch it once, on this (idle) stream
-        hip_check(hipMemcpyAsync(c->h_rows.p, c->d_slot_pos.p, std::min<size_t>(c->h_rows.cap, c->wplan.slot_pos.size() * 4), hipMemcpyDeviceToHost, c->stream), "arena touch");
-        hip_check(hipStreamSynchronize(c->stream), "arena touch sync");
-      }
-    }
+    if (c->h_rows.cap == 0 && !c->wplan.slot_pos.empty()) c->h_rows.ensure(std::min<size_t>(c->wplan.slot_pos.size() * 2, (size_t)1 << 26));
   });
 }
 extern "C" {

@@ -237,8 +237,7 @@ static inline void check_block_crc(const uint8_t* src, size_t clen, const uint8_
   if (crc32_of(dst, dlen) != want) throw Error(MKP_E_IO, "corrupt BGZF block (CRC32 mismatch)");
 }
 static inline void inflate_block(const uint8_t* src, size_t clen, uint8_t* dst, size_t dlen) {
-  static const bool use_zlib = getenv("MKP_HOST_INFLATE") && !strcmp(getenv("MKP_HOST_INFLATE"), "zlib");   // A/B timing
-  if (!use_zlib && hostinf::inflate(src, clen, dst, dlen)) { check_block_crc(src, clen, dst, dlen); return; }
+  if (hostinf::inflate(src, clen, dst, dlen)) { check_block_crc(src, clen, dst, dlen); return; }   // (blocks the table decoder declines go to zlib)
   z_stream zs; memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, -15) != Z_OK) throw Error(MKP_E_IO, "zlib init failed");
   zs.next_in = const_cast<Bytef*>(src); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = (uInt)dlen;

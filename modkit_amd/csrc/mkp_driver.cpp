@@ -186,7 +186,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       return r;
     }
     r.b.reset(new BamBatch());
-    if (bf && !getenv("MKP_NO_BED_SAMPLING")) {
+    if (bf) {
       // under --include-bed a read counts only through calls on BED positions (the kernel masks the rest): a read that meets no BED span
       // yields nothing, is not counted and not recorded — so only the records that can meet one are fetched (a sparse BED used to make
       // the estimate inflate every sampling interval whole), all of them: there is no head to extend afterwards.  A record of the interval

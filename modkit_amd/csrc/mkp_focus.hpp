@@ -145,7 +145,7 @@ class FocusBuilder {
   const Fasta* fasta = nullptr; bool mask = false; std::vector<Motif> motifs; const BedFilter* bed = nullptr; bool combine = false;
   std::vector<mkp_motif_combo> combos;  // [0] = none
   bool fast_single = true;   // one motif: fill_single instead of motif_hits + fill_motif (tests switch it off to compare the two)
-  FocusBuilder() { mkp_motif_combo z; memset(&z, 0, sizeof(z)); combos.push_back(z); if (getenv("MKP_FOCUS_MAPS")) fast_single = false; /* A/B timing */ }
+  FocusBuilder() { mkp_motif_combo z; memset(&z, 0, sizeof(z)); combos.push_back(z); }
   bool has_focus() const { return !motifs.empty() || bed != nullptr; }
 
   // Interval list of one contig record, in feeder order; fills `focus` (size end-start of the record,
