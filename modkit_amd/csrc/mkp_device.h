@@ -118,6 +118,9 @@ struct MkpCombo {  // == mkp_motif_combo
   uint8_t pad[2];
 };
 
+// (Every kernel that takes this block — by value or through LDS — is compiled against its size: in round 5 one more dword here re-rolled
+//  the register allocation of mkp_pileup_tiles into a build 8 % slower on the C2 workload.  After changing it, A/B the accumulate kernels
+//  against the previous build on one box: tools/dbg/build_variant.sh + tools/dbg/r5_ab_lib.sh.)
 struct MkpRunParams {
   // reference window
   int32_t win_start, win_end;
