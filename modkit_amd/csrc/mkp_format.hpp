@@ -10,11 +10,17 @@
 
 namespace mkp {
 
+// decimal digits of v, two at a time from a pair table; counts are mostly below 100 and take one of the two short paths
 inline char* put_u32(char* p, uint32_t v) {
-  char tmp[10]; int n = 0;
-  do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
-  while (n) *p++ = tmp[--n];
-  return p;
+  static const char kPairs[201] =
+      "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+  if (v < 10u) { *p++ = (char)('0' + v); return p; }
+  if (v < 100u) { memcpy(p, kPairs + 2u * v, 2); return p + 2; }
+  char tmp[10]; int n = 10;
+  while (v >= 100u) { const uint32_t q = v / 100u, r = v - q * 100u; n -= 2; memcpy(tmp + n, kPairs + 2u * r, 2); v = q; }
+  if (v >= 10u) { n -= 2; memcpy(tmp + n, kPairs + 2u * v, 2); } else tmp[--n] = (char)('0' + v);
+  memcpy(p, tmp + n, (size_t)(10 - n));
+  return p + (10 - n);
 }
 
 // "{:.2}" of an f32: the exact decimal expansion of the value rounded to 2 places, ties to even (Rust's float
@@ -34,12 +40,13 @@ inline char* put_pct2(char* p, float pct) {
 inline char* format_row(char* p, const char* chrom, size_t chrom_n, const char* name, size_t name_n, char sp, uint32_t pos, char strand,
                         uint32_t n_valid, uint32_t n_mod, uint32_t n_can, uint32_t n_other, uint32_t n_del, uint32_t n_fail, uint32_t n_diff, uint32_t n_nocall) {
   memcpy(p, chrom, chrom_n); p += chrom_n; *p++ = '\t';
-  p = put_u32(p, pos); *p++ = '\t'; p = put_u32(p, pos + 1u); *p++ = '\t';
+  // start, end and the coverage appear twice in a row (columns 2-3 = 7-8, 5 = 10): converted once, copied the second time
+  char* const se = p; p = put_u32(p, pos); *p++ = '\t'; p = put_u32(p, pos + 1u); *p++ = '\t'; const size_t se_n = (size_t)(p - se);
   memcpy(p, name, name_n); p += name_n; *p++ = '\t';
-  p = put_u32(p, n_valid); *p++ = '\t'; *p++ = strand; *p++ = '\t';
-  p = put_u32(p, pos); *p++ = '\t'; p = put_u32(p, pos + 1u); *p++ = '\t';
+  char* const cv = p; p = put_u32(p, n_valid); const size_t cv_n = (size_t)(p - cv); *p++ = '\t'; *p++ = strand; *p++ = '\t';
+  memcpy(p, se, se_n); p += se_n;
   memcpy(p, "255,0,0\t", 8); p += 8;
-  p = put_u32(p, n_valid); *p++ = sp;
+  memcpy(p, cv, cv_n); p += cv_n; *p++ = sp;
   const float frac = (float)n_mod / (float)n_valid;   // fraction_modified (pileup/mod.rs:401), f32
   p = put_pct2(p, frac * 100.0f); *p++ = sp;
   p = put_u32(p, n_mod); *p++ = sp; p = put_u32(p, n_can); *p++ = sp; p = put_u32(p, n_other); *p++ = sp;

@@ -29,6 +29,27 @@ int main() {
   snprintf(b, sizeof b, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", "chr20", 1234567u, 1234568u, "m,CG,0", 37u, '-', 1234567u, 1234568u, 37u, ' ',
            (double)pct, ' ', 11u, ' ', 26u, ' ', 0u, ' ', 2u, ' ', 5u, ' ', 1u, ' ', 3u);
   if (strcmp(a, b)) { printf("MISMATCH row:\n%s%s", a, b); return 1; }
+  // the decimal writer over every digit count and both short paths (pair table), alone and inside whole rows whose repeated columns
+  // (start / end / coverage) are copied rather than converted twice
+  unsigned long long x = 88172645463325252ull; auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (unsigned v = 0; v < 200000; v++) { char* q = mkp::put_u32(a, v); *q = 0; snprintf(b, sizeof b, "%u", v); if (strcmp(a, b)) { printf("MISMATCH u32 %u: %s vs %s\n", v, a, b); return 1; } }
+  for (int k = 0; k < 200000; k++) {
+    const unsigned v = (unsigned)(rnd() >> (rnd() % 33u + 31u)); char* q = mkp::put_u32(a, v); *q = 0; snprintf(b, sizeof b, "%u", v);
+    if (strcmp(a, b)) { printf("MISMATCH u32 %u: %s vs %s\n", v, a, b); return 1; }
+  }
+  for (unsigned v : {0u, 9u, 10u, 99u, 100u, 999u, 1000u, 65535u, 99999u, 100000u, 999999999u, 1000000000u, 4294967294u, 4294967295u}) {
+    char* q = mkp::put_u32(a, v); *q = 0; snprintf(b, sizeof b, "%u", v); if (strcmp(a, b)) { printf("MISMATCH u32 %u: %s vs %s\n", v, a, b); return 1; }
+  }
+  for (int k = 0; k < 100000; k++) {
+    const unsigned pos = (unsigned)(rnd() % 4294967295ull), nv = 1u + (unsigned)(rnd() % (k & 1 ? 70000u : 60u)), nm = (unsigned)(rnd() % (nv + 1u));
+    const unsigned c[6] = {(unsigned)(rnd() % 100u), (unsigned)(rnd() % 12u), (unsigned)(rnd() % 1000u), (unsigned)(rnd() % 3u), (unsigned)(rnd() % 70000u), (unsigned)(rnd() % 10u)};
+    const char sp = (k & 2) ? ' ' : '\t', strand = (k & 4) ? '+' : '-';
+    char* q = mkp::format_row(a, "chrUn_KI270742v1", 16, "21839,CG,0", 10, sp, pos, strand, nv, nm, nv - nm, c[0], c[1], c[2], c[3], c[4]); *q = 0;
+    const float f = ((float)nm / (float)nv) * 100.0f;
+    snprintf(b, sizeof b, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", "chrUn_KI270742v1", pos, pos + 1u, "21839,CG,0", nv, strand, pos, pos + 1u, nv, sp,
+             (double)f, sp, nm, sp, nv - nm, sp, c[0], sp, c[1], sp, c[2], sp, c[3], sp, c[4]);
+    if (strcmp(a, b)) { printf("MISMATCH row %d:\n%s%s", k, a, b); return 1; }
+  }
   printf("ok %llu\n", n);
   return 0;
 }
