@@ -1573,7 +1573,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         for (size_t k = 0; k < L; k++) { const uint8_t b = sq[k >> 1]; const char c = NT16[(k & 1) ? (b & 15) : (b >> 4)]; if (rev) fwd[L - 1 - k] = comp_char(c); else fwd[k] = c; }
         const std::string chrom = (!unmapped && r.tid >= 0 && (size_t)r.tid < bd.ref_names.size()) ? bd.ref_names[(size_t)r.tid] : std::string();
         const bool have_chrom = !unmapped && r.tid >= 0 && (size_t)r.tid < bd.ref_names.size();
-        const std::string* ref_seq = have_chrom ? fasta.get(chrom) : nullptr;
+        const FastaSeq* ref_seq = have_chrom ? fasta.get(chrom) : nullptr;
         const bool primary_or_unmapped = r.flag == 0 || r.flag == 16 || r.flag == 4;
         const std::string qname((const char*)r.data, r.l_qname ? (size_t)r.l_qname - 1 : 0);
         // the record's calls come in stored order (ascending stored index): one CIGAR walk gives their reference positions

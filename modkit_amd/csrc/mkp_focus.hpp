@@ -154,7 +154,7 @@ class FocusBuilder {
     std::vector<Interval> ivs;
     if (interval_size == 0) throw Error(MKP_E_INVALID, "interval size must be positive");
     if (focus) focus->assign(rec.length, 0);
-    const std::string* seq = nullptr;
+    const FastaSeq* seq = nullptr;
     const bool any_case = !mask;   // without --mask-reference the reference upper-cases the contig: read it through the either-case table instead of copying it
     if (!motifs.empty()) {
       seq = fasta->get(rec.name);
