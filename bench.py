@@ -395,7 +395,12 @@ def main():
             rep = rep1
         elif sh256(out_bed) != sh256(out_bed + ".oneshard"):
             raise SystemExit("sharded and single-shard bedMethyl differ")
-        os.remove(out_bed + ".oneshard")
+        # the rows the timed re-launches must reproduce: the one-shard output (sha256-equal to the end-to-end file, which the CPU baseline leg compares with the oracle's)
+        expected_row_digests = None if hemi else [modkit_amd.rows_digest(modkit_amd.read_bedmethyl(out_bed + ".oneshard"))]
+        if rep is rep1:
+            os.replace(out_bed + ".oneshard", out_bed)
+        else:
+            os.remove(out_bed + ".oneshard")
         ctxs = [ctx]
     else:
         # ---- N ranks, ONE BAM: thresholds from the all-reduced histograms, every rank runs its contiguous run of the interval grid
@@ -416,12 +421,13 @@ def main():
         thr_h = [float(thr.get(b, 0.0)) for b in "ACGT"]
         # the rank's windows, each resident in HBM on its own context (a window = a piece of one contig; cuts sit on the interval grid)
         plan = mkd.shard_plan([bam, out_bed] + flags, rank, world)
-        ctxs, rep1, n_rows_rank, parts = [], None, 0, []
+        ctxs, rep1, n_rows_rank, parts, expected_row_digests = [], None, 0, [], []
         for k, (cname, s, e) in enumerate(plan):
             c = modkit_amd.Context(device=local_rank, tile_positions=a.tile)
             part = "%s.rank%d.win%d" % (out_bed, rank, k)
             r = run_subcommand(c, part, threshold_argv(thr_h) + ["--region", "%s:%d-%d" % (cname, s, e), "--shard-bytes", str(1 << 40)])
             n_rows_rank += int(r.n_rows); parts.append(part); ctxs.append(c)
+            expected_row_digests.append(modkit_amd.rows_digest(modkit_amd.read_bedmethyl(part)))
             rep1 = r if rep1 is None else rep1
         rep = rep1
         # the windows' rows = the rank's part of the sharded run (validated below through the concatenation)
@@ -450,6 +456,16 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         st = ctxs[0].stats()
+        # the rows the LAST timed re-launch left in HBM, fetched now (rerun(0): no further launch) and compared with the checked output: the
+        # kernels the timed region ran are the kernels whose rows are bit-exact, on this very pass
+        timed_rows_checked = None
+        if expected_row_digests is not None and a.steps > 0:
+            for c, want in zip(ctxs, expected_row_digests):
+                got = modkit_amd.rows_digest(modkit_amd.rows_to_numpy(c.rerun(0, fetch=True)))
+                if got != want:
+                    raise SystemExit("rows of the last timed re-launch differ from the checked bedMethyl output (digest %s vs %s)" % (got, want))
+            timed_rows_checked = {"equal": True, "contexts": len(ctxs), "sha256_of_row_columns": expected_row_digests[0],
+                                  "what": "mkp_shard_rerun(0, fetch): the row columns left by the last timed launch == the columns of the bedMethyl file this run checked (sha256 over pos, strand, code, n_valid .. n_nocall)"}
         if a.inner:
             for c in ctxs:
                 c.close()
@@ -562,7 +578,7 @@ def main():
                             "kernel_ms": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "rows": st.rows_kernel_ms, "gather": st.gather_kernel_ms},
                             "generator_s": gen_s, "arithmetic": "u32 tallies in LDS; f32 threshold caller (bit-exact vs the reference's f32)",
                             "parity": "bit-exact vs the restated CPU path (oracle/) on this BAM; the oracle is pinned on the reference's golden files; ties / >=3 codes / QC-fail / N ops are reference-unpinned and sample-probs has no reference pin (DESIGN.md §7)",
-                            "slowest_kernel": slowest_name,
+                            "slowest_kernel": slowest_name, "timed_rows_checked": locals().get("timed_rows_checked"),
                             "ingest": "device (compressed BGZF blocks up; inflate, record cut, MM/ML tokeniser and packing in HBM)" if not os.environ.get("MKP_HOST_INGEST") == "1" else "host",
                             "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MKP_") and k != "MKP_BENCH_DIR"}}, **extra_cfg),
             "tiers": tiers,

@@ -387,6 +387,32 @@ class Context:
 ROW_FIELDS = ("pos", "strand", "code_repr", "motif_idx", "n_valid", "n_mod", "n_canonical", "n_other", "n_delete", "n_fail", "n_diff", "n_nocall")
 
 
+def read_bedmethyl(path):
+    """The count columns of a bedMethyl file (writers.rs:87-156) as the row arrays mkp_rows carries: pos, strand, code_repr (a letter's
+    code point, or the ChEBI number | 1 << 31), n_valid, n_mod, n_canonical, n_other, n_delete, n_fail, n_diff, n_nocall — so that rows
+    fetched from the device can be compared with a file that was itself compared with the oracle's."""
+    import numpy as np
+    import pandas as pd
+    cols = {1: "pos", 3: "code", 5: "strand", 9: "n_valid", 11: "n_mod", 12: "n_canonical", 13: "n_other", 14: "n_delete", 15: "n_fail", 16: "n_diff", 17: "n_nocall"}
+    if os.path.getsize(path) == 0:
+        return {f: np.zeros(0, dtype=np.uint32) for f in ROW_FIELDS if f != "motif_idx"}
+    df = pd.read_csv(path, sep=r"\s+", header=None, usecols=sorted(cols), dtype={3: str, 5: str}, engine="c")
+    out = {name: df[k].to_numpy().astype(np.uint32) for k, name in cols.items() if name not in ("code", "strand")}
+    out["strand"] = df[5].map(ord).to_numpy().astype(np.uint8)
+    out["code_repr"] = df[3].map(lambda c: (int(c) | (1 << 31)) if c.isdigit() else ord(c)).to_numpy().astype(np.uint32)
+    return out
+
+
+def rows_digest(r, fields=("pos", "strand", "code_repr", "n_valid", "n_mod", "n_canonical", "n_other", "n_delete", "n_fail", "n_diff", "n_nocall")):
+    """sha256 over the row arrays (numpy dicts from rows_to_numpy / read_bedmethyl), field by field, widths normalised."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for f in fields:
+        h.update(np.ascontiguousarray(np.asarray(r[f]).astype(np.uint32)).tobytes())
+    return h.hexdigest()
+
+
 def rows_to_numpy(rows):
     """Copy an mkp_rows view (owned by the ctx until its next run) into a dict of numpy arrays."""
     import numpy as np

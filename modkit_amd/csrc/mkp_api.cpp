@@ -20,14 +20,14 @@ hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
 hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*,
     const MkpReadOut*, const MkpTile*, uint32_t,
                              const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
-                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/);
+                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
 hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*, const uint32_t* /*cover read ids*/,
     uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
                             const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
-                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, int /*one launch, then rows: the scratch-free build*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/);
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
@@ -132,12 +132,20 @@ MkpFusedDesc fused_desc(const MkpLayout& D) {
   f.misc = b0 | (sg0 << 2) | (n_post << 3) | (MKP_G_CIDCAN(G.misc) << 8) | (ob << 16);
   f.nc = (uint32_t)D.tags[0].n_codes | ((D.n_tags > 1 ? (uint32_t)D.tags[1].n_codes : 0u) << 8);
   f.thr_can = G.thr_can;
+  // the thresholds of the integer caller: least T with T / 2048 >= threshold (exact in double: a float times 2^11)
+  auto i_of = [](float thr) -> int32_t { if (!(thr == thr)) return INT32_MAX; const double t = std::ceil((double)thr * 2048.0); return (int32_t)std::max(-1073741824.0, std::min(1073741824.0, t)); };
+  for (uint32_t i = 0; i < MKP_KMAX; i++) f.i_thr[i] = i_of(f.it_thr[i]);
+  f.i_can = i_of(f.thr_can);
+  f.misc |= 1u << 6;
   const int x = MKP_G_COLL(G.misc); const uint32_t n_pre = pv & 7u;   // collapse_redistribute's inputs (only looked at in collapse runs)
+  bool col_exact = true;
   for (uint32_t i = 0; i < n_pre && i < MKP_KMAX; i++) if ((int)((pv >> (8 + 2 * i)) & 3u) == x) {
     f.col = 1u; f.n_other = (float)n_pre;
     for (uint32_t t = 0; t < D.n_tags; t++) for (uint32_t k = 0; k < D.tags[t].n_codes; k++)
       if ((int)((D.tagmap[t][b0] >> (4 + 4 * k)) & 15u) == x) f.col |= (t | (k << 1)) << 1;
+    if (n_pre == 1 || n_pre == 2 || n_pre == 4) f.col |= (n_pre == 1 ? 0u : n_pre == 2 ? 1u : 2u) << 5; else col_exact = false;   // (a share over three codes is rounded: the f32 walk stays)
   }
+  if (col_exact) f.misc |= 1u << 7;
   return f;
 }
 
@@ -580,7 +588,7 @@ void make_resident(mkp_ctx* c) {
   }
 }
 
-void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
+void run_kernels(mkp_ctx* c, bool time_kernels) {
   MkpRunParams& P = c->prm;
   if (c->row_cap == 0) {
     // focus runs: usually one strand rule per focus position and one row per observed code; otherwise two strands per position
@@ -626,11 +634,11 @@ void run_kernels(mkp_ctx* c, bool time_kernels, bool one_shot = false) {
       if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
                                                  c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, row_off, c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
-                                                 c->key_passes[kp], kp, one_shot ? 1 : 0, (uint32_t)c->combos.size(), n_runs), "stream pileup launch");
+                                                 c->key_passes[kp], kp, (uint32_t)c->combos.size(), n_runs), "stream pileup launch");
       else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
-                                  row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp, one_shot ? 1 : 0), "pileup launch");
+                                  row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
     if (c->slot_mode) c->rows_dst = c->rows_src;   // already in genome order
     else hip_check(mkp_launch_gather(c->stream, row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
@@ -971,7 +979,7 @@ int mkp_shard_run(mkp_ctx* c, mkp_rows* out) {
         fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
     if (!c->resident || c->resident_hemi) { c->row_cap = 0; make_resident(c); }
     lap("run: make_resident");
-    run_kernels(c, true, true);   // one launch on this shard, then its rows: the scratch-free build of the accumulate kernel
+    run_kernels(c, true);
     lap("run: kernels");
     fetch_rows(c, out);
     lap("run: fetch rows");

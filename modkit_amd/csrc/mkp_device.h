@@ -205,7 +205,8 @@ struct MkpVisit {            // 32 B, written by the decode / cover kernels, rea
 // what mkp_decode_slots* needs of a layout whose tags form one explicit-mode group (decode class SPARSE), resolved by the host from
 // the MkpLayout so that a wave gets it with one scalar load: the caller's walk over a call's map in iteration order
 struct MkpFusedDesc {        // 64 B
-  uint32_t misc;             // [0:1] fundamental base, [2] mod strand, [3:5] codes the caller sees (n_post), [8:15] counter of Canonical, [16:31] observed-code slot mask
+  uint32_t misc;             // [0:1] fundamental base, [2] mod strand, [3:5] codes the caller sees (n_post), [6] / [7] the integer form of the caller is exact
+                             // without / with the collapse, [8:15] counter of Canonical, [16:31] observed-code slot mask
   uint32_t it_cid;           // 4 x 8 bit: counter of Modified(i-th code)
   uint32_t it_src;           // 4 x 4 bit: where the i-th code's ML byte sits: [0] tag, [1:3] index among the tag's codes
   uint32_t nc;               // codes per call of tag 0 | tag 1 << 8 (the tags' ML strides)
@@ -213,10 +214,15 @@ struct MkpFusedDesc {        // 64 B
   float thr_can;
   // --ignore / --preset traditional: ReDistribute(x) (BaseModProbs::into_collapsed, mod_bam.rs:558-600) — when the map holds x, every
   // other code gets p_x / n_other added (n_other = number of codes before the collapse; x is no longer among the it_* entries)
-  uint32_t col;              // [0] the map holds x, [1:4] where x's ML byte sits (tag | index << 1)
+  uint32_t col;              // [0] the map holds x, [1:4] where x's ML byte sits (tag | index << 1), [5:6] log2(n_other) when it is 1, 2 or 4
   float n_other;
-  uint32_t pad[5];
+  // The caller in integers (round 6).  (q + 0.5) / 256 is a multiple of 2^-9 and, when n_other is a power of two, so is every value the
+  // f32 walk forms — shares, sums, 1 - sum — a multiple of 2^-11 that f32 holds exactly: `p >= threshold` is `p * 2048 >= i_thr` with
+  // i_thr = the least integer T such that T / 2048 >= threshold (INT32_MAX for a NaN threshold: never passed).
+  int32_t i_can;
+  int32_t i_thr[4];          // (16-byte aligned: one LDS vector read per slot batch)
 };
+static_assert(sizeof(MkpFusedDesc) == 64, "MkpFusedDesc is one 64-byte scalar load");
 // one read as mkp_decode_slots* takes it: the header and tag fields the kernel needs, in launch order (longest reads first), so that a
 // wave starts from ONE 64-byte scalar load instead of the chain read id -> header -> tag table
 struct MkpWork {             // 64 B

@@ -772,6 +772,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
                      std::vector<ShardPart> parts; /* --include-bed: the BED-span records merged into this shard (empty: one window) */
                      int64_t own_from = INT64_MIN; /* full-data sampling from the shards: reads starting before this position lie in the previous shard of the contig too, and are sampled there */ };
   std::vector<ShardPlan> plan;
+  // what every rank's shards would hold in HBM if they were all ingested ahead (est_of of each shard's bytes under the index), computed by
+  // every rank for every rank: the one thing a rank of a multi-GPU run may base a choice on that the other ranks must make the same way
+  std::vector<uint64_t> est_by_rank(std::max<uint32_t>(a.world, 1u), 0);
   const bool hf = fb.has_focus();
   uint64_t positions = 0, processed = 0, skipped = 0, n_shards = 0;
       double kernel_ms = 0, pack_ms = 0, h2d_ms = 0, d2h_ms = 0, dec_ms = 0, pil_ms = 0, row_ms = 0, write_ms = 0, fetch_wait_ms = 0;
@@ -807,6 +810,7 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           i0 = i1;
           const int64_t own_from = have_prev && prev_tid == rec.tid ? prev_fetch_hi : INT64_MIN;
           have_prev = true; prev_tid = rec.tid; prev_fetch_hi = last_window_end(rec.tid, s0, s1) + MKP_HALO;
+          est_by_rank[owner] += est_of(bam.indexed() ? bam.offset_at(rec.tid, s1) - o0 + (1u << 16) : 0);
           if (owner == a.rank) { plan.push_back({ri, s0, s1, bp, std::move(iv_starts)}); plan.back().own_from = own_from; }
         }
       }
@@ -931,7 +935,16 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     const bool ahead_fits = !ahead.empty() && ahead_est_total <= hbm_budget;   // every shard stays in HBM until the loop takes it: the sample can come from them
     // the extent the sampler covers on a contig: the region, or all of it
     auto ext_of = [&](uint32_t tid, int64_t* lo, int64_t* hi) { if (have_region) { *lo = region.start; *hi = region.end; } else { *lo = 0; *hi = bam.ref_lens[tid]; } };
-    if (full_mode && resident_ok && (resident || (ahead_fits && (a.world == 1 || a.thr_cb)))) {
+    // Several ranks in the full-data mode (mkp_pileup_run_cb): the ranks' samples are summed by the caller, so every rank must cut the reads the
+    // same way — by shard ownership (own_from) when the shards are the source, by sampling intervals when the host reader is.  The two cuts do
+    // not coincide, so the choice is one every rank arrives at alike without talking: the shards are the source iff EVERY rank's shards fit
+    // its budget (est_by_rank: the same arithmetic on the same index on every rank; the budget and MKP_NO_AHEAD must be the ranks' common
+    // setting, like the flags).  A rank without shards then contributes an empty sample (it used to sample its bp-share of the
+    // sampling intervals, reads the other ranks' shards had already counted).
+    bool all_ranks_resident = dev_ingest && plan_built && !getenv("MKP_NO_AHEAD") && !early_whole;
+    for (uint64_t e : est_by_rank) if (e > hbm_budget) all_ranks_resident = false;
+    const bool shards_are_the_sample = a.world > 1 ? (a.thr_cb && all_ranks_resident) : ahead_fits;
+    if (full_mode && resident_ok && (resident || shards_are_the_sample)) {
       // full-data mode: the shards themselves are the sample's source, whatever their cut — with several ranks (mkp_pileup_run_cb) each
       // rank its own, the caller sums the histograms
       std::vector<FullShard> fs;

@@ -146,8 +146,6 @@ mkp_bgzf_chain_write(const uint8_t* __restrict__ z, const MkpZChain* __restrict_
 // the inflate's block table of one upload stage from its MkpZBlk entries: payload offsets and sizes, and each block's place in the inflated
 // window — an exclusive scan of ISIZE behind *raw_cursor, which moves on by the stage's total.  One workgroup.  A block that claims more than
 // 64 KiB, or a window that would not fit raw_cap, raises the error bits (the host then falls back to an exact allocation).
-#define MKP_ZE_ISIZE 4u
-#define MKP_ZE_RAWCAP 8u
 extern "C" __global__ void __launch_bounds__(1024)
 mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap, MkpBgzfBlock* __restrict__ out, uint32_t* err) {
   __shared__ unsigned long long wtot[16];
@@ -166,7 +164,13 @@ mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* 
     __syncthreads();
     if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x; } tile_total = run; }
     __syncthreads();
-    if (i < n) { MkpBgzfBlock b; b.in_off = z.coff + z.hdr; b.out_off = base0 + carry + wtot[wv] + incl - z.isize; b.in_len = z.clen; b.out_len = z.isize; out[i] = b; }
+    if (i < n) {
+      MkpBgzfBlock b; b.in_off = z.coff + z.hdr; b.out_off = base0 + carry + wtot[wv] + incl - z.isize; b.in_len = z.clen; b.out_len = z.isize;
+      // a block that would end behind the window's capacity gets no room: the inflate and the CRC of this stage write and read nothing for it
+      // (both are bounded by out_len); the host sees MKP_ZE_RAWCAP below and inflates the whole window again into an exact allocation
+      if (b.out_off + z.isize + 64ull > raw_cap) { b.out_off = 0; b.out_len = 0; }
+      out[i] = b;
+    }
     carry += tile_total;
     __syncthreads();
   }

@@ -90,6 +90,8 @@ struct MkpZChain { unsigned long long start, stop, range_end, ce; uint32_t ue, p
 struct MkpZBlk { unsigned long long coff; uint32_t hdr, clen, isize, pad; };
 #define MKP_ZE_BAD 1u      // not BGZF, or a block without a usable BC field
 #define MKP_ZE_CHAIN 2u    // the chain of block sizes misses the block start the index names
+#define MKP_ZE_ISIZE 4u    // a block's trailer claims more than 64 KiB (mkp_bgzf_layout)
+#define MKP_ZE_RAWCAP 8u   // the inflated window outgrew its buffer: blocks from there on got no room (mkp_bgzf_layout)
 MKP_IDEV uint32_t ingest_walk_blocks(const uint8_t* z, const MkpZChain ch, MkpZBlk* out, uint32_t* err) {
   unsigned long long c = ch.start; uint32_t n = 0;
   for (;;) {

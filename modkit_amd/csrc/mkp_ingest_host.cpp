@@ -55,6 +55,18 @@ struct mkp_dev_ingest {
   }
 };
 
+// Test hooks (tests/test_gpu_ingest.py; not part of the ABI): smaller upload pieces / stages and a forced capacity of the inflated window, so
+// that a few-MB BAM goes through several stages and outgrows its window in the middle of them.  0 = the product's value.
+namespace { struct IngestTune { size_t piece = mkp_dev_ingest::kPiece, stage_rounds = mkp_dev_ingest::kStageRounds; uint64_t raw_cap = 0; } g_tune;
+            std::atomic<uint64_t> g_reinflated{0}, g_staged_windows{0}; }
+extern "C" uint64_t mkp_internal_ingest_reinflated() { return g_reinflated.load(); }   // windows that outgrew their buffer and were inflated again
+extern "C" uint64_t mkp_internal_ingest_staged() { return g_staged_windows.load(); }   // windows whose staged inflate stood
+extern "C" void mkp_internal_ingest_tune(uint64_t piece_bytes, uint64_t stage_rounds, uint64_t raw_cap_bytes) {
+  g_tune.piece = piece_bytes ? std::min<size_t>((size_t)((piece_bytes + 63) & ~63ull), mkp_dev_ingest::kPiece) : mkp_dev_ingest::kPiece;
+  g_tune.stage_rounds = stage_rounds ? (size_t)stage_rounds : mkp_dev_ingest::kStageRounds;
+  g_tune.raw_cap = raw_cap_bytes;
+}
+
 mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   std::unique_ptr<mkp_dev_ingest> d(new mkp_dev_ingest()); d->device = device;
   // the record kernels' stream goes before the upload and CRC streams: the CRC's thirteen thousand
@@ -118,15 +130,16 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   d->zin.ensure(zbytes + 64);
   struct Piece { uint64_t file_off, z_off; size_t n; };
   std::vector<Piece> pieces;
-  for (size_t r = 0; r < plan.ranges.size(); r++) for (uint64_t o = 0; o < plan.ranges[r].file_len; o += mkp_dev_ingest::kPiece)
-    pieces.push_back({plan.ranges[r].file_off + o, zbase[r] + o, (size_t)std::min<uint64_t>(mkp_dev_ingest::kPiece, plan.ranges[r].file_len - o)});
+  const size_t piece_bytes = g_tune.piece, stage_rounds = g_tune.stage_rounds;   // (kPiece / kStageRounds unless a test shrank them)
+  for (size_t r = 0; r < plan.ranges.size(); r++) for (uint64_t o = 0; o < plan.ranges[r].file_len; o += piece_bytes)
+    pieces.push_back({plan.ranges[r].file_off + o, zbase[r] + o, (size_t)std::min<uint64_t>(piece_bytes, plan.ranges[r].file_len - o)});
   d->stage.ensure(2 * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece);
   const int fd = bam.fd();
   std::unique_ptr<Error> up_err; double up_ms = 0;
   // upload stages (the staged path below): stage j = rounds [j * kStageRounds, (j + 1) * kStageRounds); stage_end_z[j] = where its bytes end in zin
-  const size_t n_rounds = (pieces.size() + mkp_dev_ingest::kSlots - 1) / mkp_dev_ingest::kSlots, n_stages = std::max<size_t>(1, (n_rounds + mkp_dev_ingest::kStageRounds - 1) / mkp_dev_ingest::kStageRounds);
+  const size_t n_rounds = (pieces.size() + mkp_dev_ingest::kSlots - 1) / mkp_dev_ingest::kSlots, n_stages = std::max<size_t>(1, (n_rounds + stage_rounds - 1) / stage_rounds);
   std::vector<uint64_t> stage_end_z(n_stages, zbytes);
-  for (size_t j = 0; j + 1 < n_stages; j++) { const size_t last = std::min(pieces.size(), (j + 1) * mkp_dev_ingest::kStageRounds * mkp_dev_ingest::kSlots) - 1; stage_end_z[j] = pieces[last].z_off + pieces[last].n; }
+  for (size_t j = 0; j + 1 < n_stages; j++) { const size_t last = std::min(pieces.size(), (j + 1) * stage_rounds * mkp_dev_ingest::kSlots) - 1; stage_end_z[j] = pieces[last].z_off + pieces[last].n; }
   while (d->stage_ev.size() < n_stages) { hipEvent_t e = nullptr; ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"); d->stage_ev.push_back(e); }
   std::mutex st_mu; std::condition_variable st_cv; size_t stages_issued = 0; bool up_finished = false;   // (an event that has not been recorded yet does not hold a stream back: the consumer waits for the record call itself)
   std::thread uploader([&]() {
@@ -145,8 +158,8 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
         if (read_bad) throw Error(MKP_E_IO, "read error on " + bam.path());
         for (size_t k = 0; k < n; k++) ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, pieces[p0 + k].n, hipMemcpyHostToDevice, d->up_stream), "H2D");
         ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
-        if ((round + 1) % mkp_dev_ingest::kStageRounds == 0 && (round + 1) / mkp_dev_ingest::kStageRounds < n_stages) {
-          const size_t j = (round + 1) / mkp_dev_ingest::kStageRounds - 1;
+        if ((round + 1) % stage_rounds == 0 && (round + 1) / stage_rounds < n_stages) {
+          const size_t j = (round + 1) / stage_rounds - 1;
           ok(hipEventRecord(d->stage_ev[j], d->up_stream), "event");
           { std::lock_guard<std::mutex> g(st_mu); stages_issued = j + 1; } st_cv.notify_all();
         }
@@ -187,7 +200,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
         while (j + 1 < n_stages && zend > stage_end_z[j]) { j++; stage_c0[j] = i; } }
       for (size_t k = j + 1; k <= n_stages; k++) stage_c0[k] = nc; }
     out->ms_plan = ms_since(t0);
-    const uint64_t raw_cap = std::max<uint64_t>(d->raw.cap, plan.comp_total * 6 + (64ull << 20));
+    // the window's capacity as the layout kernel enforces it: a block that would end behind it gets no room at all (out_len 0: the inflate and
+    // the CRC of its stage touch nothing), the overflow bit goes up, and the stages after it only build their tables
+    const uint64_t raw_cap = g_tune.raw_cap ? g_tune.raw_cap : std::max<uint64_t>(d->raw.cap, plan.comp_total * 6 + (64ull << 20));
     d->raw.ensure(raw_cap); d->segs.ensure(nc * sizeof(MkpZChain)); d->seg_cnt.ensure((nc + n_stages + 2) * 4); d->tot.ensure(sizeof(MkpIngestTotals)); d->rawcur.ensure(16);
     d->small.ensure(4096);
     uint32_t* h_small = (uint32_t*)d->small.p;   // [0] error bits, [1] blocks of the stage; [2..3] the cursor of the inflated window (at the end)
@@ -212,7 +227,8 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
       ok(mkp_launch_bgzf_chain_count(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>() + c0, (uint32_t)n, cnt, d->tot.as<uint32_t>()), "block table launch");
       ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 1, cnt + n, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
       ok(hipStreamSynchronize(d->stream), "block table sync");
-      if (h_small[0]) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+      if (h_small[0] & (MKP_ZE_BAD | MKP_ZE_CHAIN)) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
+      const bool outgrown = (h_small[0] & MKP_ZE_RAWCAP) != 0;   // an earlier stage ran out of window: the rest is inflated below, into an exact allocation
       const uint32_t nblk = h_small[1]; stage_nblk[j] = nblk;
       if (blkbase + nblk > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");
       if (blkbase + nblk > blk_cap) { const size_t want = std::max<size_t>(2 * blk_cap, blkbase + nblk + 4096);
@@ -223,11 +239,13 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
       ok(mkp_launch_bgzf_layout(d->stream, ztab, nblk, d->rawcur.as<unsigned long long>(), raw_cap, zblk, d->tot.as<uint32_t>()), "layout launch");
       ok(hipMemsetAsync(zst, 0xff, (size_t)nblk * 4, d->stream), "memset");
       ok(hipEventRecord(d->tev[2 * j], d->stream), "event");
-      ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "inflate launch");
+      if (!outgrown) ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "inflate launch");
       ok(hipEventRecord(d->tev[2 * j + 1], d->stream), "event");
-      ok(hipEventRecord(d->inf_done, d->stream), "event");
-      ok(hipStreamWaitEvent(d->crc_stream, d->inf_done, 0), "wait for the inflate");
-      ok(mkp_launch_crc32(d->crc_stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "crc launch");
+      if (!outgrown) {
+        ok(hipEventRecord(d->inf_done, d->stream), "event");
+        ok(hipStreamWaitEvent(d->crc_stream, d->inf_done, 0), "wait for the inflate");
+        ok(mkp_launch_crc32(d->crc_stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "crc launch");
+      }
       blkbase += nblk;
     }
     uploader.join();
@@ -242,7 +260,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     for (size_t j = 0; j < n_stages; j++) if (stage_nblk[j]) { float ms = 0; if (hipEventElapsedTime(&ms, d->tev[2 * j], d->tev[2 * j + 1]) == hipSuccess) staged_kernel_ms += ms; }
     const uint32_t zerr = h_small[0];
     if (zerr & (MKP_ZE_BAD | MKP_ZE_CHAIN)) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
-    if (zerr & 4u) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB in " + bam.path());
+    if (zerr & MKP_ZE_ISIZE) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB in " + bam.path());
     std::vector<std::vector<BamSource::IngestBlk>> parts(nc);
     { size_t base = 0;
       for (size_t j = 0; j < n_stages; j++) { const size_t c0 = stage_c0[j], c1 = stage_c0[j + 1]; const uint32_t* cb = cbase.data() + c0 + j;
@@ -251,8 +269,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
         base += stage_nblk[j]; } }
     bam.ingest_layout(&plan, chains, parts);
     unsigned long long cur; memcpy(&cur, h_small + 2, 8);
-    staged_done = !(zerr & 8u) && cur == plan.raw_total && plan.blks.size() == blkbase;   // (a window larger than the estimate: inflated again below, into an exact allocation)
-    if (!staged_done) { ok(hipStreamSynchronize(d->crc_stream), "sync"); if (!(zerr & 8u)) throw Error(MKP_E_DEVICE, "internal: the device's window layout differs from the host's"); }
+    staged_done = !(zerr & MKP_ZE_RAWCAP) && cur == plan.raw_total && plan.blks.size() == blkbase;   // (a window larger than the estimate: inflated again below, into an exact allocation)
+    if (!staged_done) { ok(hipStreamSynchronize(d->crc_stream), "sync"); if (!(zerr & MKP_ZE_RAWCAP)) throw Error(MKP_E_DEVICE, "internal: the device's window layout differs from the host's"); g_reinflated++; }
+    else g_staged_windows++;
   }
   bam.bytes_read += plan.comp_total;
   if (plan.raw_total == 0) return out;

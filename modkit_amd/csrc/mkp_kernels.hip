@@ -1576,9 +1576,6 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles
 // serves pileup-hemi below)
 // --partition-tag: the same kernel tallying only the reads of one partition key per launch
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_keyed(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
-// the same bodies with 128 VGPRs (four waves per SIMD, one workgroup per CU): no register spills, no scratch (MKP_PILEUP_WAVES=4; A/B runs)
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_tiles_w4(PILEUP_PARAMS) { pileup_tiles_body<false, 4, false>(PILEUP_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_tiles_keyed_w4(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
 // pileup-hemi: the focus kernel with duplex pattern tallies
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_hemi(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false, true>(PILEUP_PASS); }
 
@@ -1855,7 +1852,7 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
 
 // per device: both accumulate kernels may use the whole per-workgroup LDS budget the host planned for
 extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
-  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_hemi, (const void*)mkp_pileup_tiles_w4, (const void*)mkp_pileup_tiles_keyed_w4}) {
+  for (const void* k : {(const void*)mkp_pileup_tiles, (const void*)mkp_pileup_tiles_keyed, (const void*)mkp_pileup_tiles_hemi}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)accum_bytes);
     if (e != hipSuccess) return e;
   }
@@ -1865,19 +1862,16 @@ extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
 extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int focus_mode, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpEvent* events, const MkpReadOut* readout, const MkpTile* tiles, uint32_t n_tiles, const MkpRunParams* prm_dev,
                                         const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot) {
   if (!n_tiles) return hipSuccess;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
   const uint32_t grid = n_tiles;   // one workgroup per tile
-  // (as mkp_launch_stream: the 64-VGPR build spills into scratch, whose allocation costs a one-shot launch ~10 ms; one-shot launches take the 128-VGPR build)
-  static const int forced = getenv("MKP_PILEUP_WAVES") ? atoi(getenv("MKP_PILEUP_WAVES")) : 0;
-  const bool w4 = forced == 4 || (forced != 8 && one_shot);
+  // ONE build of each accumulate kernel: what a one-shot shard pass launches is what a re-launch on the resident shard launches
 #define MKP_PILEUP_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(PILEUP_THREADS), lds_bytes, st, hdrs, cigar, seqs, events, readout, tiles, n_tiles, prm_dev, slotbm, focus, combos, rows->pos, \
                        row_cursor, tile_row_off, tile_row_cnt, reinterpret_cast<const uint2*>(chunk_pfx), dev_err, key_arg)
   if (focus_mode == 2) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_hemi);   // pileup-hemi
   else if (focus_mode) return hipErrorInvalidValue;   // (focus runs are the slot pipeline's: mkp_launch_stream)
-  else if (w4) { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_keyed_w4); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles_w4); }
   else { if (keyed) MKP_PILEUP_LAUNCH(mkp_pileup_tiles_keyed); else MKP_PILEUP_LAUNCH(mkp_pileup_tiles); }
   return hipGetLastError();
 }

@@ -33,7 +33,9 @@
 // per-wave LDS of mkp_decode_slots*: F = "base is the fundamental base" (bit = nibble index inside the dword, dword k of a word at
 // bits 8k..), P = occurrences before the word (inside the window), B = "occurrence is listed" over the window's occurrences,
 // WP = listed occurrences before the B word
-struct SlotLds { uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
+// ck_* = the read's caller constants per code (integer pass threshold, offset and stride of its ML bytes): uniform, but the kernel is short of
+// scalar registers — every lane reads them back as vectors once per slot batch
+struct SlotLds { int32_t ck_thr[4]; uint32_t ck_off[4]; uint32_t ck_str[4]; uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -194,13 +196,15 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
   // per call), its pass threshold and the counter of Modified(code).  --ignore / --preset traditional (ReDistribute) keep the
   // general tables.
   const bool collapse = prm.numeric_mode == 2;
-  uint32_t fmisc = 0, f_cid = 0, f_src = 0, f_nc = 0, f_col = 0; float f_thr[MKP_KMAX] = {0.f, 0.f, 0.f, 0.f}, thr_can = 0.f, n_other = 1.f;
-  uint32_t t_ml[2] = {0, 0};
+  uint32_t fmisc = 0, f_cid = 0, f_col = 0;
+  int32_t i_can = 0;   // Canonical's threshold in units of 2^-11 (the exact integer form of the caller, below); the codes' are in W.ck_thr
+  // where the ML byte of the i-th code of call j sits: ml[W.ck_off[i] + j * W.ck_str[i]] (tag + index inside the tag: offset and stride)
+  uint32_t mlx_o = 0, mlx_s = 0;
   uint32_t t_n = 0;
   uint32_t e_pre = 0, e_last = 0;   // the first 64 entries of the rank list as the first window consumes it, and its last entry
   const uint32_t* __restrict__ rk = ranks;
   if (have_calls) {
-    t_ml[0] = h.ml_off0; t_ml[1] = h.ml_off1; t_n = h.n_calls;
+    t_n = h.n_calls;
     rk = ranks + h.rank_off;
     if (t_n) {
       const uint32_t i = rev ? t_n - 64u + (uint32_t)lane : (uint32_t)lane;
@@ -208,13 +212,22 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
       e_last = rk[t_n - 1u];
     }
     const MkpFusedDesc fd = fdesc[h.layout];
-    fmisc = fd.misc; f_cid = fd.it_cid; f_src = fd.it_src; f_nc = fd.nc; thr_can = fd.thr_can;
-#pragma unroll
-    for (int i = 0; i < MKP_KMAX; i++) f_thr[i] = fd.it_thr[i];
-    if (collapse) { f_col = fd.col; n_other = fd.n_other; }
+    fmisc = fd.misc; f_cid = fd.it_cid; i_can = fd.i_can;
+    if (lane < MKP_KMAX) {
+      const uint32_t src = (fd.it_src >> (4 * lane)) & 15u, tg = src & 1u;
+      W.ck_off[lane] = (tg ? h.ml_off1 : h.ml_off0) + (src >> 1); W.ck_str[lane] = (fd.nc >> (8u * tg)) & 0xffu;
+      W.ck_thr[lane] = lane == 0 ? fd.i_thr[0] : lane == 1 ? fd.i_thr[1] : lane == 2 ? fd.i_thr[2] : fd.i_thr[3];
+    }
+    if (collapse) {
+      f_col = fd.col;
+      const uint32_t src = (fd.col >> 1) & 15u, tg = src & 1u;
+      mlx_o = (tg ? h.ml_off1 : h.ml_off0) + (src >> 1); mlx_s = (fd.nc >> (8u * tg)) & 0xffu;
+    }
     if (t_n == 0) have_calls = false;   // a tag without calls: the record has no modified-base information
   }
   const uint32_t sg0u = (fmisc >> 2) & 1u, n_post = (fmisc >> 3) & 7u;
+  const bool int_caller = (fmisc >> (collapse ? 7 : 6)) & 1u;     // the exact integer form of the caller applies (fused_desc)
+  const uint32_t red_shift = (f_col >> 5) & 3u;                   // log2 of the number of codes a collapsed code's probability is shared among
   const uint32_t xs = rev ? 3u - (fmisc & 3u) : (fmisc & 3u);     // the stored base the tags count
   bool err = have_calls && err_sum;
   const uint32_t pat = 0x11111111u << xs;
@@ -382,17 +395,44 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
           // MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63) on the map of this call, entries in the map's
           // iteration order: pass threshold, Iterator::max keeps the last maximum, canonical pushed last.  ReDistribute runs
           // (--ignore, --preset traditional) first add the collapsed code's share to every entry (mod_bam.rs:558-600).
-          auto ml_at = [&](uint32_t src) {
-            const uint32_t tg = src & 1u, off = (tg ? t_ml[1] : t_ml[0]) + (src >> 1), stride = (f_nc >> (8u * tg)) & 0xffu;
-            return (uint32_t)ldo<uint8_t>(ml + off, listed ? jx * stride : 0u);
-          };
+          // All ML bytes of the call are requested before any is looked at (round 5 waited for each in turn: two to five dependent
+          // memory round trips per 64 slots, the longest chain of the wave's life).
+          const uint32_t jl = listed ? jx : 0u;
+          const uint4 off4 = *reinterpret_cast<const uint4*>(W.ck_off), str4 = *reinterpret_cast<const uint4*>(W.ck_str);
+          const uint32_t ml_o[MKP_KMAX] = {off4.x, off4.y, off4.z, off4.w}, ml_s[MKP_KMAX] = {str4.x, str4.y, str4.z, str4.w};
           uint32_t mlb[MKP_KMAX], mlx = 0;
 #pragma unroll
-          for (int k = 0; k < MKP_KMAX; k++) mlb[k] = ((uint32_t)k < n_post) ? ml_at((f_src >> (4 * k)) & 15u) : 0u;
-          if (f_col & 1u) mlx = ml_at((f_col >> 1) & 15u);
+          for (int k = 0; k < MKP_KMAX; k++) mlb[k] = ((uint32_t)k < n_post) ? (uint32_t)ldo<uint8_t>(ml, __umul24(jl, ml_s[k]) + ml_o[k]) : 0u;
+          if (f_col & 1u) mlx = (uint32_t)ldo<uint8_t>(ml, __umul24(jl, mlx_s) + mlx_o);
+          uint32_t cid = MKP_C_FAIL;
+          if (int_caller) {
+            // The same walk in integers, exactly: q -> (q + 0.5) / 256 is a multiple of 2^-9, the share of a collapsed code (its
+            // probability over 1, 2 or 4 codes) a multiple of 2^-11, every sum of up to five of them and 1 - sum are exact in f32 — so
+            // the f32 comparisons of the reference are comparisons of integers in units of 2^-11, thresholds rounded up to the next
+            // multiple by the host (fused_desc: the least integer T with T / 2048 >= threshold).
+            const int4 thr4 = *reinterpret_cast<const int4*>(W.ck_thr);
+            const int32_t i_thr[MKP_KMAX] = {thr4.x, thr4.y, thr4.z, thr4.w};
+            const int32_t red4 = (f_col & 1u) ? (int32_t)(((2u * mlx + 1u) << 2) >> red_shift) + 4 : 4;
+            int32_t sum = 0, best = INT32_MIN;
+#pragma unroll
+            for (int k = 0; k < MKP_KMAX; k++) {
+              if ((uint32_t)k < n_post) {
+                const int32_t v = (int32_t)(mlb[k] << 3) + red4;
+                sum += v;
+                const bool take = v >= max(i_thr[k], best);   // passes, and no entry before it is larger (the last maximum wins)
+                cid = take ? ((f_cid >> (8 * k)) & 0xffu) : cid; best = take ? v : best;
+              }
+            }
+            const int32_t pc = 2048 - sum;
+            if (pc >= max(i_can, best)) cid = (fmisc >> 8) & 0xffu;
+          } else {   // (a share over three codes: the f32 walk; its thresholds are read here — this is the rare path — not held in registers by every read)
+          const MkpFusedDesc& fdr = fdesc[h.layout];
+          float f_thr[MKP_KMAX]; const float thr_can = fdr.thr_can;
+#pragma unroll
+          for (int k = 0; k < MKP_KMAX; k++) f_thr[k] = fdr.it_thr[k];
           float red = 0.f;
-          if (f_col & 1u) red = (((float)mlx + 0.5f) / 256.0f) / n_other;
-          float s = 0.f, best_p = 0.f; bool have = false; uint32_t cid = MKP_C_FAIL;
+          if (f_col & 1u) red = (((float)mlx + 0.5f) / 256.0f) / fdr.n_other;
+          float s = 0.f, best_p = 0.f; bool have = false;
 #pragma unroll
           for (int k = 0; k < MKP_KMAX; k++) {
             if ((uint32_t)k < n_post) {
@@ -405,6 +445,7 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
           }
           const float pc = 1.0f - s;
           if (pc >= thr_can && (!have || !(pc < best_p))) cid = (fmisc >> 8) & 0xffu;
+          }
           if (listed) call_fb = feat(cid, aln ^ sg0u);   // FeatureVector::add_feature's tally (pileup/mod.rs:238-281)
         }
         if (!MULTI) break;
@@ -704,9 +745,6 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
 #define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos, n_runs
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
-// the same bodies with 128 VGPRs (four waves per SIMD, one workgroup per CU): no register spills, no scratch (MKP_PILEUP_WAVES=4; A/B runs)
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_w4(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 4) mkp_pileup_stream_keyed_w4(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
@@ -722,7 +760,7 @@ extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint
 }
 
 extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
-  for (const void* k : {(const void*)mkp_pileup_stream, (const void*)mkp_pileup_stream_keyed, (const void*)mkp_pileup_stream_w4, (const void*)mkp_pileup_stream_keyed_w4}) {
+  for (const void* k : {(const void*)mkp_pileup_stream, (const void*)mkp_pileup_stream_keyed}) {
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
   }
@@ -731,19 +769,13 @@ extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
 
 extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
                                         const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, int one_shot, uint32_t n_combos, uint32_t n_runs) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, uint32_t n_combos, uint32_t n_runs) {
   if (!n_tiles) return hipSuccess;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
 #define MKP_STREAM_LAUNCH(K) hipLaunchKernelGGL(K, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, visits, cov, events, tiles, n_tiles, prm_dev, slot_pos, focus, combos, rows->pos, row_cursor, \
                                                 tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos > 64u ? 64u : n_combos, n_runs)
-  // The 64-VGPR build (two workgroups per CU) spills into 220 bytes of scratch per lane.  It is the faster kernel (0.154 against 0.234 ms
-  // on C3) — but a queue that has been idle pays 9-13 ms for the scratch allocation around its first such dispatch, which is all a
-  // one-shot run (one launch per shard, then rows) ever sees.  One-shot launches take the 128-VGPR build (no spills, no scratch); re-launches
-  // on a resident shard, where the allocation is long paid for, the 64-VGPR one.  MKP_PILEUP_WAVES=4|8 forces either.
-  static const int forced = getenv("MKP_PILEUP_WAVES") ? atoi(getenv("MKP_PILEUP_WAVES")) : 0;
-  const bool w4 = forced == 4 || (forced != 8 && one_shot);
-  if (w4) { if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed_w4); else MKP_STREAM_LAUNCH(mkp_pileup_stream_w4); }
-  else if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed); else MKP_STREAM_LAUNCH(mkp_pileup_stream);
+  // ONE build per kernel: a one-shot shard pass and a re-launch on the resident shard run the same code object
+  if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed); else MKP_STREAM_LAUNCH(mkp_pileup_stream);
   return hipGetLastError();
 }

@@ -136,3 +136,40 @@ def test_reference_fixtures_through_the_device_ingest(tmp_path):
         assert dev == host, f
         m = re.search(r"device ingest: (\d+) BGZF blocks, (\d+) records", err)
         assert m and int(m.group(1)) >= 1
+
+
+def test_window_that_outgrows_its_buffer_is_inflated_again(oracle_bin, tmp_path):
+    """the staged ingest sizes the inflated window before it knows its size (6 x the compressed bytes).  A window that outgrows the
+    buffer must not be written past it: blocks behind the capacity get no room on the device (mkp_bgzf_layout), later stages only build their
+    tables, and the whole window is inflated again into an exact allocation — whichever stage the overflow is in.  The test shrinks the
+    upload pieces / stages and forces the capacity (mkp_internal_ingest_tune) so that a few-MB BAM has several stages and overflows in the
+    first, a middle and the last of them; rows must equal the host ingest's and the oracle's."""
+    import ctypes
+    bam, fa = gen(tmp_path, "grow", [("c1", 600000)], 9000, ["--mean-len", "3000"])
+    size = os.path.getsize(bam)
+    assert size > 5 * (1 << 20)
+    flags = ["--cpg", "--ref", fa, "--filter-threshold", "0.7"]
+    host = str(tmp_path / "host.bed")
+    modkit_amd.pileup([bam, host] + flags + ["--host-ingest"])
+    ora = str(tmp_path / "ora.bed")
+    assert subprocess.run([oracle_bin, "pileup", bam, ora] + flags, capture_output=True).returncode == 0
+    want = open(host, "rb").read()
+    assert want == open(ora, "rb").read() and len(want) > 100000
+    L = modkit_amd.lib()
+    L.mkp_internal_ingest_tune.argtypes = [ctypes.c_uint64] * 3
+    L.mkp_internal_ingest_tune.restype = None
+    L.mkp_internal_ingest_reinflated.restype = ctypes.c_uint64
+    L.mkp_internal_ingest_staged.restype = ctypes.c_uint64
+    try:
+        # 64 KiB pieces x 16 slots x 1 round = 1 MiB stages: >= 5 stages.  Capacities: below the first stage's output, in the middle of the
+        # window, just short of its end (the inflated window of these BAMs is ~3.5 x the file), and one that holds it all (staged path stands)
+        for cap, overflow in ((1 << 20, True), (int(1.7 * size), True), (int(3.0 * size), True), (8 * size, False)):
+            before, staged = L.mkp_internal_ingest_reinflated(), L.mkp_internal_ingest_staged()
+            L.mkp_internal_ingest_tune(65536, 1, cap)
+            out = str(tmp_path / ("dev_%d.bed" % cap))
+            modkit_amd.pileup([bam, out] + flags)
+            assert open(out, "rb").read() == want, cap
+            assert (L.mkp_internal_ingest_reinflated() > before) == overflow, cap
+            assert (L.mkp_internal_ingest_staged() > staged) == (not overflow), cap
+    finally:
+        L.mkp_internal_ingest_tune(0, 0, 0)

@@ -155,10 +155,30 @@ def _full_vs_oracle(oracle_bin, tmp_path, bam, flags, min_rows):
     return n
 
 
+def _relaunch_vs_oracle(tmp_path, bam, flags):
+    """The kernels the bench times are the kernels whose rows are checked: `modkit pileup` on a context with the whole contig as ONE resident
+    shard (file == the oracle's, sha256), then the row columns left in HBM by that one-shot launch and by two RE-LAUNCHES on the resident
+    shard (mkp_shard_rerun, what bench.py's timed region calls) == the columns of the ORACLE's bedMethyl.  (_full_vs_oracle left ora.bed.)"""
+    ora, dev = os.path.join(str(tmp_path), "ora.bed"), os.path.join(str(tmp_path), "dev_resident.bed")
+    want = modkit_amd.rows_digest(modkit_amd.read_bedmethyl(ora))
+    ctx = modkit_amd.Context(device=0)
+    try:
+        rep = ctx.pileup_run([bam, dev] + flags + ["--shard-bytes", str(1 << 40)])
+        assert rep.n_shards == 1 and _sha(dev) == _sha(ora)
+        one_shot = modkit_amd.rows_to_numpy(ctx.rerun(0, fetch=True))     # no launch: the rows of the shard pass itself
+        assert modkit_amd.rows_digest(one_shot) == want
+        again = modkit_amd.rows_to_numpy(ctx.rerun(2, fetch=True))        # two re-launches, rows of the second
+        assert modkit_amd.rows_digest(again) == want
+        assert np.array_equal(again["motif_idx"], one_shot["motif_idx"])
+    finally:
+        ctx.close()
+
+
 def test_c2_full_size_vs_oracle(oracle_bin, tmp_path):
     # BASELINE configs[1] at full size: 5 Mb contig, 100 000 reads (~96x), C+m?, defaults (sampled 10th-percentile threshold)
     bam, fa, meta = gen(tmp_path, "c2full", [("synth5m", 5_000_000)], 100_000, "m", 1)
     _full_vs_oracle(oracle_bin, tmp_path, bam, [], 1_500_000)
+    _relaunch_vs_oracle(tmp_path, bam, [])
 
 
 def test_c3_full_size_vs_oracle(oracle_bin, tmp_path):
@@ -166,6 +186,7 @@ def test_c3_full_size_vs_oracle(oracle_bin, tmp_path):
     bam, fa, meta = gen(tmp_path, "c3full", [("chr20", 64_444_167)], 193_000, "hm", 20, ["--cpg-depleted", "--mean-len", "8353"])
     assert meta["aligned_bases"] > 1_800_000_000
     _full_vs_oracle(oracle_bin, tmp_path, bam, ["--cpg", "--ref", fa], 2_000_000)
+    _relaunch_vs_oracle(tmp_path, bam, ["--cpg", "--ref", fa])
 
 
 def test_c2_full_size_properties(tmp_path):
