@@ -459,7 +459,9 @@ def main():
         # the rows the LAST timed re-launch left in HBM, fetched now (rerun(0): no further launch) and compared with the checked output: the
         # kernels the timed region ran are the kernels whose rows are bit-exact, on this very pass
         timed_rows_checked = None
-        if expected_row_digests is not None and a.steps > 0:
+        if os.environ.get("MKP_DEBUG_SKIP", "0") not in ("", "0"):
+            timed_rows_checked = {"equal": None, "what": "skipped: MKP_DEBUG_SKIP ablation run of a -DMKP_DEBUG build (the kernels leave parts out on purpose)"}
+        elif expected_row_digests is not None and a.steps > 0:
             for c, want in zip(ctxs, expected_row_digests):
                 got = modkit_amd.rows_digest(modkit_amd.rows_to_numpy(c.rerun(0, fetch=True)))
                 if got != want:

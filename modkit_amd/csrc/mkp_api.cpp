@@ -27,7 +27,8 @@ hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | sh
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
-                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/);
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/,
+                             uint32_t /*slot capacity of a tile*/, uint32_t /*tally words per slot*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
 hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
@@ -419,8 +420,8 @@ void make_resident(mkp_ctx* c) {
       }
       c->cov_bytes = off;
       // tile = a run of slots: rows for [g0, g1), tally columns for the slots within MKP_HALO positions of them (strand combining)
-      const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, (budget_words / (words_per_slot + 1u)) & ~63u);
-          // + the tile's slot positions; row emission: one thread per slot
+      // LDS of mkp_pileup_stream: tallies + per slot its position and an emission word, + the row map (one thread per slot decides the rows)
+      const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, ((budget_words - MKP_STREAM_ROWMAP_WORDS) / (words_per_slot + 2u)) & ~63u);
       if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
       uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 2048u + 63u) & ~63u));   // about 2000 tiles over 512 resident workgroups
       if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));   // tests: many small tiles
@@ -516,7 +517,7 @@ void make_resident(mkp_ctx* c) {
     slot_ids.insert(slot_ids.end(), rest.begin(), rest.end());
   }
   P.slot_cap = Scap; P.focus_words = Wcap;
-  c->lds_bytes = stream ? (words_per_slot + 1u) * Scap * 4u : MKP_PILEUP_LDS_WORDS(words_per_slot, Scap, Wcap) * 4u;
+  c->lds_bytes = stream ? ((words_per_slot + 2u) * Scap + MKP_STREAM_ROWMAP_WORDS) * 4u : MKP_PILEUP_LDS_WORDS(words_per_slot, Scap, Wcap) * 4u;
   c->n_tiles = stream ? (uint32_t)stiles.size() : (uint32_t)tiles.size();
   c->n_slots_total = 0;
   if (c->has_focus) { for (size_t w = 0; w < slotbm.size(); w++) c->n_slots_total += (uint64_t)__builtin_popcount(slotbm[w]); }
@@ -634,7 +635,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
       if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
                                                  c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, row_off, c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
-                                                 c->key_passes[kp], kp, (uint32_t)c->combos.size(), n_runs), "stream pileup launch");
+                                                 c->key_passes[kp], kp, (uint32_t)c->combos.size(), n_runs, P.slot_cap, P.n_counters + P.n_slots), "stream pileup launch");
       else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
                                   c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,

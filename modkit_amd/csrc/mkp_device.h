@@ -191,8 +191,12 @@ struct MkpTile { int32_t r0, r1; uint32_t first, last; };
 // (pileup/mod.rs:783-939): [0:4] counter id (MKP_C_*), [5] tally strand, [6:7] the read base as tallied (so that a call of a
 // record that later fails can be counted as NoCall(base)).
 #ifndef MKP_SLOT_WB
-#define MKP_SLOT_WB 16384u   // mkp_decode_slots*: stored bases per base window; longer reads take the *_long instances
+// mkp_decode_slots*: stored bases per base window; longer reads take the *_long instances.  13 312 bases = 5 052 bytes of LDS per wave: eight
+// 4-wave workgroups per CU (16 384: six), which — together with the 80-SGPR cap of the short-read kernel, see mkp_slots.hip — is what lets the
+// hardware keep eight waves per SIMD resident (round 6: 0.75 -> 0.70 ms on C3)
+#define MKP_SLOT_WB 13312u
 #endif
+#define MKP_STREAM_ROWMAP_WORDS 2048u   // mkp_pileup_stream: rows of a tile placed per emission round (a dword of LDS each)
 #define MKP_FB_NONE 0xffu    // the read is not in this column (ref-skip)
 #define MKP_FB_BLANK 0xfeu   // in the column, no feature (non-ACGT base: pileup/mod.rs:864-874)
 struct MkpVisit {            // 32 B, written by the decode / cover kernels, read by mkp_pileup_stream

@@ -474,9 +474,17 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
   }
 }
 
-#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __launch_bounds__(256 __VA_ARGS__) NAME(FUSED_PARAMS(MkpRunParams)) { \
+// Residency on gfx950 is also bounded by the SIMD's 800 scalar registers: a wave is charged ceil(sgprs / 16) * 16 + 16 of them
+// (MI355X_MICROARCH.md, "Residency and cooperative launch"), so the 105 the compiler takes when left alone admit six waves per SIMD whatever
+// the LDS and VGPR budgets say (the compiler's own occupancy figure says eight).  The short-read kernel is capped at 80 — eight waves; the
+// spilled scalars cost ~26 v_readlane / v_writelane per slot batch (+7 % VALU) against +33 % resident waves: 0.75 -> 0.70 ms on C3
+// (A/B on one box: tools/dbg/ab.sh, MKP_DECODE_SGPRS=96 gives seven waves and 0.705).  The long-read kernel keeps its 85 VGPRs (five waves).
+#ifndef MKP_DECODE_SGPRS
+#define MKP_DECODE_SGPRS 80
+#endif
+#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __VA_ARGS__ __launch_bounds__(256) NAME(FUSED_PARAMS(MkpRunParams)) { \
     __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<MULTI>(FUSED_PASS, lds_all); }
-MKP_SLOT_KERNEL(mkp_decode_slots, false)
+MKP_SLOT_KERNEL(mkp_decode_slots, false, __attribute__((amdgpu_num_sgpr(MKP_DECODE_SGPRS))))
 MKP_SLOT_KERNEL(mkp_decode_slots_long, true)
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -562,82 +570,117 @@ extern "C" __global__ void __launch_bounds__(256) mkp_cover_reads(SLOT_PARAMS(Mk
 
 // ----------------------------------------------------------------------------------------------------------------------
 // mkp_pileup_stream: accumulate + emit over the feature stream.  LDS: [counter | observed-code slot][S] packed tallies ('+' tally
-// in the low, '-' in the high 16 bits; the host refuses shards with more than 65535 records over one position) + the tile's slot
-// positions.  Waves draw the tile's candidate reads from an LDS ticket; a visit = the read's MkpVisit (scalar loads, the next one
-// requested ahead), its bytes for the tile's slots (a dword per lane), one LDS atomic per feature.  Observed codes: +1 / -1 at
-// the ends of the read's slot range (and at every change between covered and not covered when the read holds ref-skips).
-struct StreamSlotMap {
-  const int32_t* fpos; uint32_t n;
-  __device__ __forceinline__ int32_t pos_of(uint32_t c) const { return fpos[c]; }
-  __device__ __forceinline__ uint32_t rank(int32_t p) const {   // first column whose position is >= p
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fpos[mid] < p) lo = mid + 1u; else hi = mid; }
-    return lo;
-  }
+// in the low, '-' in the high 16 bits; the host refuses shards with more than 65535 records over one position), the tile's slot
+// positions, a word per slot for the emission (focus byte | strand-combining partners) and the row map.  Waves draw the tile's candidate
+// reads from an LDS ticket; a visit = the read's MkpVisit (scalar loads), its bytes for the tile's slots (a dword per lane), one LDS
+// atomic per feature.  Observed codes: +1 / -1 at the ends of the read's slot range (and at every change between covered and not
+// covered when the read holds ref-skips).
+//
+// Row emission (round 6; rounds 2-5 ran the parameter-driven interpreter of mkp_dev_rows.hpp twice per slot — count, then write — with one
+// thread per slot: ~800 VALU instructions per thread, 29 spilled registers, rows of a slot written with stride-2 stores):
+//   E1  one thread per SLOT decides which rows exist: a bit per (strand | motif, code group) candidate — existence needs the coverage of
+//       the candidate's primary base and its observed-code count, a handful of LDS reads — and counts them;
+//   E2  block scan of the counts; wave 0 reserves the tile's run in the row buffer (decoupled look-back over the runs before, in ticket
+//       order) while every thread scatters (slot, candidate) words of its rows into the ROW MAP in LDS;
+//   E3  one thread per ROW fills its row from the tallies and stores it: every store instruction writes 64 consecutive rows of one column.
+// MkpRunParams is resolved once per workgroup into a small table (StreamProg) so that neither pass walks slot lists.
+struct StreamProg {
+  uint32_t n_groups;       // row candidates per strand (or per motif when strands combine): observed-code slots in row order, or the four primary bases (--combine-mods)
+  uint32_t totmask;        // counters that add up to a column's total (all but Delete and Filtered)
+  uint32_t modmask[4];     // primary base -> the counters of its mod codes
+  uint32_t code[16];       // group -> code of its rows
+  uint32_t info[16];       // group -> [0:1] primary base, [2:6] observed-code slot + 1 (0: a --combine-mods row), [7:11] counter of the code, [12:16] counter of
+                           //          Canonical(base), [17] the base has one, [18] first group of its code (strand combining adds up the groups of a code)
 };
+#define STREAM_ROWMAP MKP_STREAM_ROWMAP_WORDS   // rows per emission round (dwords of LDS)
+
+__device__ __forceinline__ uint32_t col_get(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t k) { return (tal[k * S + i] >> (16u * s)) & 0xffffu; }
+__device__ __forceinline__ uint32_t col_sum(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t mask) {
+  uint32_t t = 0;
+  while (mask) { const uint32_t k = (uint32_t)__ffs((int)mask) - 1u; mask &= mask - 1u; t += col_get(tal, S, i, s, k); }
+  return t;
+}
+// does (strand tally s, column i, group g) yield a row — add_tally_to_counts's early returns (pileup/mod.rs:283-410): the primary base has
+// filtered coverage, and (per-code rows) the code was observed in a record over this column
+__device__ __forceinline__ bool stream_row_exists(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g) {
+  const uint32_t inf = P.info[g];
+  if (!((inf >> 17) & 1u)) return false;
+  const uint32_t cov = col_get(tal, S, i, s, (inf >> 12) & 31u) + col_sum(tal, S, i, s, P.modmask[inf & 3u]);
+  if (!cov) return false;
+  const uint32_t osl = (inf >> 2) & 31u;
+  return !osl || col_get(tal, S, i, s, n_counters + osl - 1u) != 0u;
+}
+// the row itself, added into `r`
+__device__ __forceinline__ void stream_row_add(const uint32_t* __restrict__ tal, uint32_t S, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g, RowAcc& r) {
+  const uint32_t inf = P.info[g], pb = inf & 3u;
+  const uint32_t n_can = col_get(tal, S, i, s, (inf >> 12) & 31u), mods = col_sum(tal, S, i, s, P.modmask[pb]);
+  const uint32_t n_mod = ((inf >> 2) & 31u) ? col_get(tal, S, i, s, (inf >> 7) & 31u) : mods;
+  const uint32_t total = col_sum(tal, S, i, s, P.totmask), nocall = col_get(tal, S, i, s, MKP_C_NC + pb), cov = n_can + mods;
+  r.n_valid += cov; r.n_mod += n_mod; r.n_can += n_can; r.n_other += mods - n_mod;
+  r.n_del += col_get(tal, S, i, s, MKP_C_DEL); r.n_fail += col_get(tal, S, i, s, MKP_C_FAIL);
+  r.n_diff += total - (nocall + cov); r.n_nocall += nocall;
+}
 
 template <bool KEYED, uint32_t VB /* visits drawn per ticket, their records and first stream dwords requested together */>
 __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events,
                  const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
                  const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
-                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs) {
+                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs, uint32_t S, uint32_t tal_words) {
   const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = key_arg >> 16;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t next_read;
+  __shared__ uint32_t next_read, run_ticket, row_base_s, row_total_s;
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
-  __shared__ uint32_t row_base, scan_carry;
   __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
   __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];
+  __shared__ StreamProg prog;
   // A workgroup takes the next TILE from an atomic ticket (row_cursor[0]; the host zeroes it before the first pass), not from blockIdx: rows
   // leave in genome order through a look-back over the runs before (mkp_dev_rows.hpp), and a run may only wait for runs whose workgroups
-  // are already running — true for tickets whatever the dispatch order, with any number of contexts on the device.  (Tiles in ticket
-  // order also start in genome order; an XCD-aware permutation was tried in round 3: it kept neighbouring tiles' shared reads in one L2,
-  // but the stream is 1 byte per feature — the second L2's copy costs less than the gather pass it would need.)
-  // The prologue is a chain of memory round trips in front of the first tally — ticket, tile record, slot positions, first visit, first
-  // stream dword — and there are four tiles per workgroup slot: what does not depend on the ticket (parameters, combos, clearing the
-  // tallies) is issued beside it.  The tile record then goes through LDS and comes back as SCALAR values: it is uniform, and eight VGPRs
-  // that live to the last row are what the 64-VGPR build spills first (87 spilled registers before, 29 now: the rest belong to the
-  // row emission).  (Round 5 also tried persistent workgroups — two per CU drawing tickets until none is left, the last wave making the
-  // next tile's chain beside the current tile's visits: no faster at equal register use, and the loop's live values cost more spills.)
-  __shared__ uint32_t run_ticket;
-  __shared__ MkpSTile tile_s;
-  if (threadIdx.x == 0) run_ticket = atomicAdd(row_cursor, 1u);
+  // are already running — true for tickets whatever the dispatch order, with any number of contexts on the device.
+  // The prologue is a chain of memory round trips in front of the first tally — ticket, tile record, visit records, stream dwords.  What does
+  // not hang on it starts beside the ticket: the tallies are cleared at once (their size is a kernel argument), the parameter block and the
+  // combos come in; the slot positions and focus bytes (needed by the emission only) are requested when the tile is known and land in LDS
+  // behind the visits.  ONE barrier stands between a workgroup's start and its first visit (round 5: two, the second behind the positions).
+  if (threadIdx.x == 0) { run_ticket = atomicAdd(row_cursor, 1u); next_read = 0; }
+  { const uint32_t nv = tal_words >> 2; uint4* l4 = reinterpret_cast<uint4*>(lds);
+    for (uint32_t k = threadIdx.x; k < nv; k += PILEUP_THREADS) l4[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t k = (nv << 2) + threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0; }
   for (uint32_t kq = threadIdx.x; kq < sizeof(MkpRunParams) / 4; kq += PILEUP_THREADS) prm_lds[kq] = reinterpret_cast<const uint32_t*>(prmp)[kq];
   for (uint32_t kq = threadIdx.x; kq < n_combos * (sizeof(MkpCombo) / 4); kq += PILEUP_THREADS) combo_lds[kq] = reinterpret_cast<const uint32_t*>(combos)[kq];
   __syncthreads();
-  const MkpRunParams& prm0 = *reinterpret_cast<const MkpRunParams*>(prm_lds);
-  const uint32_t S = rfl(prm0.slot_cap);
-  const uint32_t n_counters = rfl(prm0.n_counters), n_oslots = rfl(prm0.n_slots);
-  const uint32_t tal_words = (n_counters + n_oslots) * S;
+  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds);
+  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds);
+  const uint32_t n_counters = rfl(prm.n_counters), n_oslots = rfl(prm.n_slots);
   uint32_t* __restrict__ tal = lds;
   uint32_t* __restrict__ obs = lds + n_counters * S;
   int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(lds + tal_words);
+  uint32_t* __restrict__ aux = lds + tal_words + S;            // per slot: [0:7] focus byte, [8 + 6m ..] partner column of the m-th '+' motif (strand combining)
+  uint32_t* __restrict__ rowmap = lds + tal_words + 2u * S;
   const int lane = lane_id();
   const uint32_t wave = rfl(threadIdx.x >> 6);
   const uint32_t run = rfl(run_ticket);                               // row-run index: key pass * tiles + tile (passes run one after the other on the stream)
-  // (key_run is a kernel argument in both builds — zero without --partition-tag — and not folded away in the unkeyed one: with `tix` and
-  //  `run` one and the same value the register allocator ends at 91 spilled VGPRs in the 64-VGPR build, with the subtraction at 29)
   const uint32_t tix = run - key_run * n_tiles;
   if (tix >= n_tiles) { if (threadIdx.x == 0) atomicOr(dev_err, ERR_ROW_CAP); return; }   // (cannot happen: one ticket per workgroup)
-  { const MkpSTile tl0 = tiles[tix];   // (in flight while the tallies are cleared)
-    const uint32_t nv = tal_words >> 2; uint4* l4 = reinterpret_cast<uint4*>(lds);
-    for (uint32_t k = threadIdx.x; k < nv; k += PILEUP_THREADS) l4[k] = make_uint4(0u, 0u, 0u, 0u);
-    for (uint32_t k = (nv << 2) + threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
-    if (threadIdx.x == 0) { tile_s = tl0; next_read = tl0.first; scan_carry = 0; }   // (tiles hold at least one candidate read)
-    for (uint32_t k = threadIdx.x; k < tl0.gh1 - tl0.gh0; k += PILEUP_THREADS) fpos[k] = (int32_t)slot_pos[tl0.gh0 + k];
-  }
-  __syncthreads();
-  const uint32_t talbase = lds_addr(tal), S4 = S * 4u;
-  // (from here on the parameter block and the combos are read through an offset the compiler cannot see through: fields it would otherwise
-  //  load early and keep in registers to the last row are read where they are used)
-  uint32_t zofs = 0; asm volatile("" : "+s"(zofs));
-  const MkpRunParams& prm = *reinterpret_cast<const MkpRunParams*>(prm_lds + zofs);
-  const MkpCombo* combos_l = reinterpret_cast<const MkpCombo*>(combo_lds + zofs);
-  MkpSTile tl;
-  tl.gh0 = rfl(tile_s.gh0); tl.gh1 = rfl(tile_s.gh1); tl.r0 = (int32_t)rfl((uint32_t)tile_s.r0); tl.r1 = (int32_t)rfl((uint32_t)tile_s.r1);
-  tl.first = rfl(tile_s.first); tl.last = rfl(tile_s.last); tl.g0 = 0; tl.g1 = 0;
+  const MkpSTile tl = tiles[tix];   // (uniform: scalar loads)
   const uint32_t gh0 = tl.gh0, gh1 = tl.gh1, n_tslots = gh1 - gh0;
-  const uint32_t rid_end = tl.last;
+  const uint32_t rid_first = tl.first, rid_end = tl.last;
+  // this thread's slot: position now, focus byte behind the visits
+  int32_t my_pos = 0;
+  if (threadIdx.x < n_tslots) my_pos = (int32_t)slot_pos[gh0 + threadIdx.x];
+  if (threadIdx.x < 16u) {   // the row program (read after the visits' barrier)
+    const uint32_t g = threadIdx.x, combine_mods = prm.numeric_mode == 1 ? 1u : 0u;
+    const uint32_t ng = combine_mods ? 4u : prm.n_slots;
+    uint32_t code = 0, inf = 0;
+    if (g < ng) {
+      const uint32_t sl = combine_mods ? 0u : prm.slot_order[g], pb = combine_mods ? g : prm.slots[sl].pb, ck = prm.can_of_pb[pb];
+      code = combine_mods ? (uint32_t)"ACGT"[g] : prm.slots[sl].code_repr;
+      const bool first = combine_mods || g == 0u || prm.slots[prm.slot_order[g - 1u]].code_repr != code;
+      inf = pb | ((combine_mods ? 0u : sl + 1u) << 2) | ((combine_mods ? 0u : (uint32_t)prm.slots[sl].cid) << 7) | (((MKP_C_CAN + ck) & 31u) << 12) | ((ck != 0xffu ? 1u : 0u) << 17) | ((first ? 1u : 0u) << 18);
+    }
+    prog.code[g] = code; prog.info[g] = inf;
+    if (g < 4u) { uint32_t m = 0; for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == g) m |= 1u << prm.slots[t].cid; prog.modmask[g] = m; }
+    if (g == 0u) { prog.n_groups = ng; prog.totmask = ((1u << n_counters) - 1u) & ~((1u << MKP_C_DEL) | (1u << MKP_C_FAIL)); }
+  }
+  const uint32_t talbase = lds_addr(tal), S4 = S * 4u;
   // one visit: the read's bytes for this tile's slots (first dword per lane already in `wcur`), its observed codes, its overflow events
   auto visit = [&](const MkpVisit& v, uint32_t wcur) {
     const uint32_t a = max(v.gs0, gh0), b = min(v.gs0 + v.n_sl, gh1);
@@ -672,14 +715,17 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
       }
     }
     for (uint32_t k = kfirst;; k += 256u) {
-      const uint32_t w = wcur;
+      uint32_t w = wcur;
       const uint32_t kn = k + 256u;
       wcur = kn < k_hi ? *reinterpret_cast<const uint32_t*>(cp + kn) : 0xffffffffu;
+      // bytes outside [k_lo, k_hi) — the ends of the read's first and last dword in this tile — become "no feature" once per dword
+      if (k < k_lo) w |= k + 4u <= k_lo ? 0xffffffffu : ~(0xffffffffu << (8u * (k_lo - k)));
+      if (k + 4u > k_hi) w |= k >= k_hi ? 0xffffffffu : 0xffffffffu << (8u * (k_hi - k));
+      const uint32_t lane_base = talbase + 4u * (col0 + k);
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t fb = (w >> (8u * j)) & 0xffu, kk = k + j;
-        if (fb < 0x40u && kk >= k_lo && kk < k_hi)
-          lds_add(talbase + 4u * (col0 + kk) + __umul24(fb & 31u, S4), (fb & 32u) ? 0x10000u : 1u);
+        const uint32_t fb = (w >> (8u * j)) & 0xffu;
+        if (fb < 0x40u) lds_add(lane_base + 4u * j + __umul24(fb & 31u, S4), (fb & 32u) ? 0x10000u : 1u);
       }
       if (!__any(kn < k_hi)) break;
     }
@@ -691,15 +737,9 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
     }
   };
   // Reads are drawn FOUR at a time: their visit records and the first stream dword of each are requested before any of them is used (a visit
-  // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics).  Measured on C3 (MKP_DEBUG_SKIP ablations, round 5): the
-  // visits are 0.03 of the kernel's 0.17 ms — one, two or four in flight make no difference that shows; 0.05-0.07 are the prologue and the
-  // scans, 0.07 the rows, 0.04 the ordered hand-over of the row offsets (the look-back: a tile cannot write before every tile in front of
-  // it has counted).
+  // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics).
   for (;;) {
-#ifdef MKP_DEBUG
-    if (prm.debug_skip & 1024u) break;   // ablation: no visits (prologue + scans + emission only)
-#endif
-    uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, VB); base = rfl(ticket); }
+    uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, VB); base = rid_first + rfl(ticket); }
     if (base >= rid_end) break;
     MkpVisit vv[VB]; uint32_t ww[VB];
 #pragma unroll
@@ -713,13 +753,10 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
 #pragma unroll
     for (uint32_t j = 0; j < VB; j++) if (base + j < rid_end) visit(vv[j], ww[j]);
   }
+  // the emission's per-slot words: position and focus byte (the byte's load overlaps the barrier and the scans below)
+  uint32_t my_fv = 0;
+  if (threadIdx.x < n_tslots) { fpos[threadIdx.x] = my_pos; my_fv = prm.has_focus ? (uint32_t)focus[my_pos - prm.win_start] : 3u; }
   __syncthreads();
-#ifdef MKP_DEBUG
-  if (prm.debug_skip & 2048u) {   // ablation: no scans, no rows (the look-back word is still published so that nothing waits)
-    if (threadIdx.x < 64u) { lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, 0u); if (threadIdx.x == 0 && run + 1u == n_runs) row_cursor[1] = 0; }
-  } else
-#endif
-  {
   // observed-code difference arrays -> counts, in place and still packed
   for (uint32_t a = wave; a < n_oslots; a += PILEUP_WAVES) {
     uint32_t* __restrict__ arr = obs + a * S;
@@ -731,18 +768,121 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
       carry += (uint32_t)__builtin_amdgcn_readlane((int)sc, 63);
     }
   }
-  if (threadIdx.x == 0) scan_carry = 0;
+  if (threadIdx.x < n_tslots) aux[threadIdx.x] = my_fv;
   __syncthreads();
-  StreamSlotMap sm; sm.fpos = fpos; sm.n = n_tslots;
-  MkpTile tl2; tl2.r0 = tl.r0; tl2.r1 = tl.r1; tl2.first = tl.first; tl2.last = tl.last;
-  emit_tile_rows<true, false, StreamSlotMap, true>(tal, sm, n_tslots, tl2, run, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry, n_runs);
+
+  // ---- E1: which rows does this thread's slot yield (FeatureVector::decode, pileup/mod.rs:412-446; combine_strand_features 469-561)
+  const StreamProg& P = prog;
+  const uint32_t n_groups = P.n_groups;
+  const bool combine = prm.combine_strands != 0;
+  const uint32_t i = threadIdx.x;
+  unsigned long long em = 0; uint32_t cnt = 0, mult0 = 1, mult1 = 1;
+  if (i < n_tslots && my_pos >= tl.r0 && my_pos < tl.r1 && (my_fv & 3u)) {
+    const uint32_t rule = my_fv & 3u, combo = my_fv >> 2;
+    if (!combine) {
+      if (combo) { const MkpCombo& cb = combos_l[combo]; mult0 = cb.n_pos ? cb.n_pos : 1u; mult1 = cb.n_neg ? cb.n_neg : 1u; }
+      for (uint32_t s = 0; s < 2; s++) {
+        if (!((rule >> s) & 1u)) continue;
+        for (uint32_t g = 0; g < n_groups; g++) if (stream_row_exists(tal, S, n_counters, P, s, i, g)) em |= 1ull << (16u * s + g);
+      }
+      cnt = (uint32_t)__popc((uint32_t)em & 0xffffu) * mult0 + (uint32_t)__popc((uint32_t)(em >> 16) & 0xffffu) * mult1;
+    } else if (combo) {   // only '+' motif positions produce rows
+      const MkpCombo& cb = combos_l[combo];
+      const bool pos_ok = (rule & 1u) != 0;
+      uint32_t part = 0;
+      for (uint32_t m = 0; m < cb.n_pos; m++) {
+        const int delta = cb.pos_delta[m];
+        if (delta == -128) continue;   // not a palindrome / negative_strand_position() == None
+        const int idx = cb.pos_ids[m];
+        const int32_t qpos = my_pos + delta;
+        bool neg_ok = false; uint32_t iq = i;
+        if (delta != -127 && qpos >= prm.win_start && qpos < prm.win_end) {   // -127: the mate position is in another interval
+          // the partner's column: a focus position at most MKP_HALO away — a few columns up or down
+          if (delta > 0) { while (iq + 1u < n_tslots && fpos[iq + 1u] <= qpos) iq++; } else { while (iq > 0u && fpos[iq - 1u] >= qpos) iq--; }
+          if (fpos[iq] == qpos) {
+            const uint32_t fq = aux[iq] & 0xffu;
+            if ((fq & 2u) && (fq >> 2)) { const MkpCombo& cq = combos_l[fq >> 2]; for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx); }
+          }
+        }
+        if (neg_ok) part |= ((iq - i + 32u) & 63u) << (8u + 6u * m);
+        for (uint32_t g = 0; g < n_groups; g++) {
+          if (!((P.info[g] >> 18) & 1u)) continue;   // grouped by code (BTreeMap)
+          bool any = false;
+          for (uint32_t gj = g; gj < n_groups && (gj == g || !((P.info[gj] >> 18) & 1u)); gj++)
+            any = any || (pos_ok && stream_row_exists(tal, S, n_counters, P, 0, i, gj)) || (neg_ok && stream_row_exists(tal, S, n_counters, P, 1, iq, gj));
+          if (any) { em |= 1ull << (16u * m + g); cnt++; }
+        }
+      }
+      if (part) aux[i] = my_fv | part;   // (own word; the other threads only look at the focus byte, which stays)
+    }
+  }
+  // ---- E2: place of every slot's rows inside the tile, the tile's place in the row buffer
+  const uint32_t inc2 = wave_incl_scan(cnt);
+  if (lane == 63) wave_tot[wave] = inc2;
+  __syncthreads();
+  uint32_t off = inc2 - cnt, tile_rows = 0;
+  for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) { const uint32_t t = wave_tot[w2]; if (w2 < wave) off += t; tile_rows += t; }
+  MkpRowsDev rows;
+  { const size_t cap = prm.row_capacity; uint32_t* q = rows_base;
+    rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap; rows.n_other = q + 6 * cap;
+    rows.n_del = q + 7 * cap; rows.n_fail = q + 8 * cap; rows.n_diff = q + 9 * cap; rows.n_nocall = q + 10 * cap; }
+  for (uint32_t r0 = 0; r0 == 0u || r0 < tile_rows; r0 += STREAM_ROWMAP) {
+    if (r0) __syncthreads();   // the round before has read the map
+    // (slot, candidate) of every row of this round: [0:9] slot, [10:13] group, [14:15] strand | motif, [16:17] which of the position's motif ids
+    if (cnt && off < r0 + STREAM_ROWMAP && off + cnt > r0) {
+      uint32_t r = off;
+      for (uint32_t sm = 0; sm < 4u; sm++) {
+        uint32_t bits = (uint32_t)(em >> (16u * sm)) & 0xffffu;
+        const uint32_t mult = combine ? 1u : (sm ? mult1 : mult0);
+        while (bits) {
+          const uint32_t g = (uint32_t)__ffs((int)bits) - 1u; bits &= bits - 1u;
+          for (uint32_t k = 0; k < mult; k++, r++) if (r >= r0 && r < r0 + STREAM_ROWMAP) rowmap[r - r0] = i | (g << 10) | (sm << 14) | (k << 16);
+        }
+      }
+    }
+    if (r0 == 0u && wave == 0u) {   // tile_row_off = the runs' look-back words (two dwords each); row_cursor[1] = total rows, written by the last run
+      const uint32_t base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, tile_rows);
+      if (lane == 0) {
+        if (run + 1u == n_runs) row_cursor[1] = base + tile_rows;
+        uint32_t s = tile_rows;
+        if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+        row_base_s = base; row_total_s = s;
+      }
+    }
+    __syncthreads();
+    // ---- E3: one thread per row
+    const uint32_t n_here = min(row_total_s, r0 + STREAM_ROWMAP) > r0 ? min(row_total_s, r0 + STREAM_ROWMAP) - r0 : 0u;
+    for (uint32_t rr = threadIdx.x; rr < n_here; rr += PILEUP_THREADS) {
+      const uint32_t e = rowmap[rr], si = e & 1023u, g = (e >> 10) & 15u, sm = (e >> 14) & 3u, k = (e >> 16) & 3u;
+      const uint32_t ax = aux[si], combo = (ax & 0xffu) >> 2;
+      RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t strand, motif1;   // motif1 = motif id + 1 (0: none)
+      if (!combine) {
+        stream_row_add(tal, S, P, sm, si, g, acc);
+        strand = sm; motif1 = 0;
+        if (combo) { const MkpCombo& cb = combos_l[combo]; const uint32_t n_ids = sm ? cb.n_neg : cb.n_pos; if (n_ids) motif1 = (uint32_t)(sm ? cb.neg_ids[k] : cb.pos_ids[k]) + 1u; }
+      } else {
+        const MkpCombo& cb = combos_l[combo];
+        const uint32_t pd = (ax >> (8u + 6u * sm)) & 63u, iq = si + pd - 32u;
+        const bool pos_ok = (ax & 1u) != 0, neg_ok = pd != 0u;
+        for (uint32_t gj = g; gj < n_groups && (gj == g || !((P.info[gj] >> 18) & 1u)); gj++) {
+          if (pos_ok && stream_row_exists(tal, S, n_counters, P, 0, si, gj)) stream_row_add(tal, S, P, 0, si, gj, acc);
+          if (neg_ok && stream_row_exists(tal, S, n_counters, P, 1, iq, gj)) stream_row_add(tal, S, P, 1, iq, gj, acc);
+        }
+        strand = 2; motif1 = (uint32_t)cb.pos_ids[sm] + 1u;
+      }
+      const size_t at = (size_t)row_base_s + r0 + rr;
+      rows.pos[at] = (uint32_t)fpos[si]; rows.info[at] = strand | (motif1 << 8) | (key_filter << 16); rows.code[at] = P.code[g];
+      rows.n_valid[at] = acc.n_valid; rows.n_mod[at] = acc.n_mod; rows.n_can[at] = acc.n_can; rows.n_other[at] = acc.n_other;
+      rows.n_del[at] = acc.n_del; rows.n_fail[at] = acc.n_fail; rows.n_diff[at] = acc.n_diff; rows.n_nocall[at] = acc.n_nocall;
+    }
   }
 }
 
 #define STREAM_PARAMS const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events, const MkpSTile* __restrict__ tiles, uint32_t n_tiles, \
     const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, \
-    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs
-#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos, n_runs
+    uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs, uint32_t S, uint32_t tal_words
+#define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, dev_err, key_arg, n_combos, n_runs, S, tal_words
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
 
@@ -769,12 +909,13 @@ extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
 
 extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
                                         const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, uint32_t n_combos, uint32_t n_runs) {
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, uint32_t n_combos, uint32_t n_runs, uint32_t slot_cap, uint32_t words_per_slot) {
   if (!n_tiles) return hipSuccess;
+  (void)tile_row_cnt;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
 #define MKP_STREAM_LAUNCH(K) hipLaunchKernelGGL(K, dim3(n_tiles), dim3(PILEUP_THREADS), lds_bytes, st, visits, cov, events, tiles, n_tiles, prm_dev, slot_pos, focus, combos, rows->pos, row_cursor, \
-                                                tile_row_off, tile_row_cnt, dev_err, key_arg, n_combos > 64u ? 64u : n_combos, n_runs)
+                                                tile_row_off, dev_err, key_arg, n_combos > 64u ? 64u : n_combos, n_runs, slot_cap, words_per_slot * slot_cap)
   // ONE build per kernel: a one-shot shard pass and a re-launch on the resident shard run the same code object
   if (keyed) MKP_STREAM_LAUNCH(mkp_pileup_stream_keyed); else MKP_STREAM_LAUNCH(mkp_pileup_stream);
   return hipGetLastError();
