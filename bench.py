@@ -56,6 +56,8 @@ WORKLOADS = {
              "pileup-hemi on the C3 geometry: duplex reads, C+hm?;G-hm? / C+h?;C+m?;G-h?;G-m? alternating at every read CpG, --cpg -r, -i 100000, default 10th-percentile threshold"),
     "c2": (["--style", "m"], [],
            "C2: synthetic 1 contig x 5 Mb, 100 000 reads (~96x), C+m? at every read CpG, all positions, default 10th-percentile threshold"),
+    "chr1": (["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], ["--cpg", "--ref", "{fa}"],
+             "chr1: ONE contig of hg38 chr1's length x {gs} (a contig longer than a shard: 2^27 positions / 1 GiB of BAM), CpG-depleted chain, 30x, C+hm? / C+h?;C+m?, --cpg --ref, default sharding"),
     "c4": (["--style", "hm", "--cpg-depleted", "--mean-len", "8353"], ["--preset", "traditional", "--ref", "{fa}"],
            "C4 scale model: 24 contigs at {gs} of the hg38 lengths (CpG-depleted chain), 30x, C+hm? / C+h?;C+m?, --preset traditional (= --cpg --combine-strands --ignore h) --ref"),
     "c5": (["--style", "hma", "--cpg-depleted", "--mean-len", "8353"],
@@ -306,17 +308,19 @@ def main():
             dist.init_process_group("gloo")
 
     gflags, pflags, desc = WORKLOADS[a.workload]
-    multi = a.workload in ("c4", "c5")
+    multi = a.workload in ("c4", "c5", "chr1")
+    if a.workload == "chr1" and a.genome_scale == 0.1:
+        a.genome_scale = 1.0   # (the point of this workload is the real length; --genome-scale < 1 only for dry runs)
     hemi = a.workload == "hemi"
     if multi and world > 1:
         raise SystemExit("--workload %s is a single-process run (the multi-GPU line shards the C3 generator's BAM)" % a.workload)
     tmp = os.environ.get("MKP_BENCH_DIR", "/tmp")
     # ---- the workload's BAM (rank 0 generates; the generator binary normally ships prebuilt, __graft_entry__.build())
     if multi:
-        contigs = [(n, max(100_000, int(l * a.genome_scale))) for n, l in HG38]
-        cov = 30 if a.workload == "c4" else 60
+        contigs = [(n, max(100_000, int(l * a.genome_scale))) for n, l in (HG38[:1] if a.workload == "chr1" else HG38)]
+        cov = 60 if a.workload == "c5" else 30
         n_reads = int(cov * sum(l for _, l in contigs) / MEAN_ALIGNED)
-        seed = 40 if a.workload == "c4" else 50
+        seed = {"c4": 40, "c5": 50, "chr1": 60}[a.workload]
         tag = "mkp_%s_g%g" % (a.workload, a.genome_scale)
     else:
         base_len, base_reads = (5_000_000, 100_000) if a.workload == "c2" else (64_444_167, 193_000)
@@ -368,7 +372,7 @@ def main():
         value = total_positions / (ms_per_step * 1e-3)
         extra_cfg = {"genome_scale": a.genome_scale, "shards": int(rep.n_shards), "timing": "multi-shard workload: value = positions / device kernel time summed over the shards of one pass (HIP events inside the library, mean over the timed passes), NOT a wall-clock bracket; walls are in tiers.end_to_end",
                      "pass_wall_ms_mean": sum(walls) / max(1, len(walls)), "kernel_ms_last_shard": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "gather": st.gather_kernel_ms}}
-        if a.workload == "c4":   # the full-data percentile (-f 1.0) next to the default sampled threshold
+        if a.workload in ("c4", "chr1"):   # the full-data percentile (-f 1.0) next to the default sampled threshold
             rf = run_subcommand(ctx, out_bed + ".f1", ["-f", "1.0"])
             extra_cfg["full_data_threshold_run"] = {"flag": "-f 1.0", "total_ms": rf.total_ms, "threshold_ms": rf.threshold_ms, "thresholds": {"ACGT"[i]: float(rf.threshold[i]) for i in range(4) if rf.has_threshold[i]}, "rows": int(rf.n_rows)}
         rep1, elapsed = rep, ms_per_step * 1e-3 * a.steps
@@ -604,6 +608,10 @@ def main():
                 dbed = out_bed
             base["bedmethyl_sha256_equal"] = sh256(dbed) == sh256(obed)
             base["bedmethyl_sha256"] = sh256(dbed)
+            if multi and a.cpu_whole and os.path.exists(out_bed + ".f1"):
+                # the full-data estimate (-f 1.0: sampled from the shards resident in HBM) against the oracle's -f 1.0 run, whole output
+                obed1, base1 = cpu_baseline(bam, flags + ["-f", "1.0"], workers, None, hemi, "full_f1")
+                base["full_data_threshold_run"] = {"flag": "-f 1.0", "bedmethyl_sha256_equal": sh256(out_bed + ".f1") == sh256(obed1), "oracle_total_s": base1["end_to_end"]["total_s"], "oracle_threshold_s": base1["end_to_end"]["threshold_s"]}
             dev_pps = rep.n_positions / (rep.total_ms * 1e-3)
             base["speedup_end_to_end"] = dev_pps / base["end_to_end"]["positions_per_s"] if not region else None
             base["device_host_threads"] = host_threads

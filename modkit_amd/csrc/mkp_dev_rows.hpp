@@ -153,9 +153,131 @@ __device__ __forceinline__ uint32_t hemi_rows_at(const uint32_t* __restrict__ ta
   return n;
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Row emission, row-major (round 6): MkpRunParams resolved once per workgroup into a small table (the "row program"), existence of a
+// row decided from a handful of tallies, one thread per ROW filling and storing it (mkp_pileup_stream, mkp_pileup_tiles).
+struct StreamProg {
+  uint32_t n_groups;       // row candidates per strand (or per motif when strands combine): observed-code slots in row order, or the four primary bases (--combine-mods)
+  uint32_t totmask;        // counters that add up to a column's total (all but Delete and Filtered)
+  uint32_t modmask[4];     // primary base -> the counters of its mod codes
+  uint32_t code[16];       // group -> code of its rows
+  uint32_t info[16];       // group -> [0:1] primary base, [2:6] observed-code slot + 1 (0: a --combine-mods row), [7:11] counter of the code, [12:16] counter of
+                           //          Canonical(base), [17] the base has one, [18] first group of its code (strand combining adds up the groups of a code)
+};
+
+__device__ __forceinline__ uint32_t col_get(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t k) { return (tal[k * S + i] >> (16u * s)) & 0xffffu; }
+__device__ __forceinline__ uint32_t col_sum(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t mask) {
+  uint32_t t = 0;
+  while (mask) { const uint32_t k = (uint32_t)__ffs((int)mask) - 1u; mask &= mask - 1u; t += col_get(tal, S, i, s, k); }
+  return t;
+}
+// does (strand tally s, column i, group g) yield a row — add_tally_to_counts's early returns (pileup/mod.rs:283-410): the primary base has
+// filtered coverage, and (per-code rows) the code was observed in a record over this column
+__device__ __forceinline__ bool stream_row_exists(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g) {
+  const uint32_t inf = P.info[g];
+  if (!((inf >> 17) & 1u)) return false;
+  const uint32_t cov = col_get(tal, S, i, s, (inf >> 12) & 31u) + col_sum(tal, S, i, s, P.modmask[inf & 3u]);
+  if (!cov) return false;
+  const uint32_t osl = (inf >> 2) & 31u;
+  return !osl || col_get(tal, S, i, s, n_counters + osl - 1u) != 0u;
+}
+// the row itself, added into `r`
+__device__ __forceinline__ void stream_row_add(const uint32_t* __restrict__ tal, uint32_t S, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g, RowAcc& r) {
+  const uint32_t inf = P.info[g], pb = inf & 3u;
+  const uint32_t n_can = col_get(tal, S, i, s, (inf >> 12) & 31u), mods = col_sum(tal, S, i, s, P.modmask[pb]);
+  const uint32_t n_mod = ((inf >> 2) & 31u) ? col_get(tal, S, i, s, (inf >> 7) & 31u) : mods;
+  const uint32_t total = col_sum(tal, S, i, s, P.totmask), nocall = col_get(tal, S, i, s, MKP_C_NC + pb), cov = n_can + mods;
+  r.n_valid += cov; r.n_mod += n_mod; r.n_can += n_can; r.n_other += mods - n_mod;
+  r.n_del += col_get(tal, S, i, s, MKP_C_DEL); r.n_fail += col_get(tal, S, i, s, MKP_C_FAIL);
+  r.n_diff += total - (nocall + cov); r.n_nocall += nocall;
+}
+
+// the row program, built by threads 0..15 of the workgroup (callers put a barrier before its first use)
+__device__ __forceinline__ void rowprog_build(const MkpRunParams& prm, uint32_t n_counters, StreamProg& prog) {
+  if (threadIdx.x >= 16u) return;
+  const uint32_t g = threadIdx.x, combine_mods = prm.numeric_mode == 1 ? 1u : 0u;
+  const uint32_t ng = combine_mods ? 4u : prm.n_slots;
+  uint32_t code = 0, inf = 0;
+  if (g < ng) {
+    const uint32_t sl = combine_mods ? 0u : prm.slot_order[g], pb = combine_mods ? g : prm.slots[sl].pb, ck = prm.can_of_pb[pb];
+    code = combine_mods ? (uint32_t)"ACGT"[g] : prm.slots[sl].code_repr;
+    const bool first = combine_mods || g == 0u || prm.slots[prm.slot_order[g - 1u]].code_repr != code;
+    inf = pb | ((combine_mods ? 0u : sl + 1u) << 2) | ((combine_mods ? 0u : (uint32_t)prm.slots[sl].cid) << 7) | (((MKP_C_CAN + ck) & 31u) << 12) | ((ck != 0xffu ? 1u : 0u) << 17) | ((first ? 1u : 0u) << 18);
+  }
+  prog.code[g] = code; prog.info[g] = inf;
+  if (g < 4u) { uint32_t m = 0; for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == g) m |= 1u << prm.slots[t].cid; prog.modmask[g] = m; }
+  if (g == 0u) { prog.n_groups = ng; prog.totmask = ((1u << n_counters) - 1u) & ~((1u << MKP_C_DEL) | (1u << MKP_C_FAIL)); }
+}
+
 #define PILEUP_THREADS MKP_PILEUP_THREADS
 #define PILEUP_WAVES (PILEUP_THREADS / 64)
 #define PILEUP_WAVE_SCRATCH MKP_PILEUP_WAVE_SCRATCH
+
+// Rows of a DENSE tile (mkp_pileup_tiles without focus positions: every position of the tile's range owns a column, both strands of every
+// position are candidates, strands never combine): each thread takes a contiguous run of columns — rows keep position order — counts its
+// rows, the block scans, thread 0 reserves the tile's run of the row buffer (mkp_scan_tiles + mkp_gather_rows order the runs afterwards),
+// the threads scatter (column, strand, group) words into `rowmap` (LDS, `map_words` dwords: the accumulate phase's per-wave scratch, dead
+// by now) and then every thread fills and stores whole rows.  Existence is evaluated twice (count, scatter) — a handful of LDS reads —
+// instead of keeping a mask per column.  (Rounds 1-5: the interpreter of rows_at three times per column, 119 spilled registers.)
+__device__ __forceinline__ void emit_dense_rows(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, uint32_t n_tslots, int32_t T0h, const MkpTile& tl, uint32_t run, uint32_t key,
+                                                const MkpRunParams& prm, StreamProg& prog, uint32_t* __restrict__ rowmap, uint32_t map_words, uint32_t* __restrict__ rows_base,
+                                                uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
+                                                uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* row_total_p) {
+  const int lane = lane_id();
+  const uint32_t wave = threadIdx.x >> 6;
+  rowprog_build(prm, n_counters, prog);
+  __syncthreads();
+  const StreamProg& P = prog;
+  const uint32_t n_groups = prm.combine_strands ? 0u : P.n_groups;   // (strands combine at motif positions only: a run without focus positions has none)
+  const uint32_t per = (n_tslots + PILEUP_THREADS - 1u) / PILEUP_THREADS;
+  const uint32_t i0 = min(n_tslots, threadIdx.x * per), i1 = min(n_tslots, i0 + per);
+  auto in_rows = [&](uint32_t i) { const int32_t p = T0h + (int32_t)i; return p >= tl.r0 && p < tl.r1; };
+  uint32_t cnt = 0;
+  for (uint32_t i = i0; i < i1; i++) {
+    if (!in_rows(i)) continue;
+    for (uint32_t s = 0; s < 2; s++) for (uint32_t g = 0; g < n_groups; g++) cnt += stream_row_exists(tal, S, n_counters, P, s, i, g) ? 1u : 0u;
+  }
+  const uint32_t inc2 = wave_incl_scan(cnt);
+  if (lane == 63) wave_tot[wave] = inc2;
+  __syncthreads();
+  uint32_t off = inc2 - cnt, tile_rows = 0;
+  for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) { const uint32_t t = wave_tot[w2]; if (w2 < wave) off += t; tile_rows += t; }
+  if (threadIdx.x == 0) {
+    uint32_t s = tile_rows;
+    const uint32_t base = s ? atomicAdd(row_cursor, s) : 0u;
+    if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
+    *row_base_p = base; *row_total_p = s; tile_row_off[run] = base; tile_row_cnt[run] = s;
+  }
+  MkpRowsDev rows;
+  { const size_t cap = prm.row_capacity; uint32_t* q = rows_base;
+    rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap; rows.n_other = q + 6 * cap;
+    rows.n_del = q + 7 * cap; rows.n_fail = q + 8 * cap; rows.n_diff = q + 9 * cap; rows.n_nocall = q + 10 * cap; }
+  for (uint32_t r0 = 0; r0 < tile_rows; r0 += map_words) {
+    if (r0) __syncthreads();   // the round before has read the map
+    if (cnt && off < r0 + map_words && off + cnt > r0) {
+      uint32_t r = off;
+      for (uint32_t i = i0; i < i1; i++) {
+        if (!in_rows(i)) continue;
+        for (uint32_t s = 0; s < 2; s++) for (uint32_t g = 0; g < n_groups; g++) {
+          if (!stream_row_exists(tal, S, n_counters, P, s, i, g)) continue;
+          if (r >= r0 && r < r0 + map_words) rowmap[r - r0] = i | (g << 13) | (s << 17);
+          r++;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t total = *row_total_p, n_here = min(total, r0 + map_words) > r0 ? min(total, r0 + map_words) - r0 : 0u;
+    for (uint32_t rr = threadIdx.x; rr < n_here; rr += PILEUP_THREADS) {
+      const uint32_t e = rowmap[rr], si = e & 8191u, g = (e >> 13) & 15u, s = (e >> 17) & 1u;
+      RowAcc acc = {0, 0, 0, 0, 0, 0, 0, 0};
+      stream_row_add(tal, S, P, s, si, g, acc);
+      const size_t at = (size_t)*row_base_p + r0 + rr;
+      rows.pos[at] = (uint32_t)(T0h + (int32_t)si); rows.info[at] = s | (key << 16); rows.code[at] = P.code[g];   // (no motif: info[8:15] = 0)
+      rows.n_valid[at] = acc.n_valid; rows.n_mod[at] = acc.n_mod; rows.n_can[at] = acc.n_can; rows.n_other[at] = acc.n_other;
+      rows.n_del[at] = acc.n_del; rows.n_fail[at] = acc.n_fail; rows.n_diff[at] = acc.n_diff; rows.n_nocall[at] = acc.n_nocall;
+    }
+  }
+}
 
 // LDS byte addresses as integers: a tally update is then `lane base + 256*window + row*4*S`, two VALU instructions
 typedef __attribute__((address_space(3))) uint32_t lds_u32;

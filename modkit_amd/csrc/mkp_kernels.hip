@@ -1151,6 +1151,7 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __shared__ uint32_t next_read;
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
   __shared__ uint32_t row_base, scan_carry;
+  __shared__ StreamProg rowprog;   // dense tiles: the row program of the emission (mkp_dev_rows.hpp)
   // SEQ byte -> NoCall row of the base a query index selects: rowlut[strand][query parity][byte]; 15 = not A/C/G/T.
   // (BAM packs two bases per byte, high nibble first; on the '-' strand the tallied base is the complement.)
   __shared__ uint8_t rowlut[2][2][256];
@@ -1560,7 +1561,11 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   __syncthreads();
   // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
   // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
-  if (!(dbg & 4u)) emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  if (dbg & 4u) {}
+  else if (!FOCUS && !HEMI)   // dense tiles: row-major emission; the row map lives in the per-wave scratch of the accumulate phase (dead behind the barrier above)
+    emit_dense_rows(tal, S, n_counters, n_tslots, T0h, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, prm, rowprog, lds + tal_words + focus_total, min(8192u, PILEUP_WAVES * wave_words),
+                    rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  else emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
   }
 }
 

@@ -33,9 +33,10 @@
 // per-wave LDS of mkp_decode_slots*: F = "base is the fundamental base" (bit = nibble index inside the dword, dword k of a word at
 // bits 8k..), P = occurrences before the word (inside the window), B = "occurrence is listed" over the window's occurrences,
 // WP = listed occurrences before the B word
-// ck_* = the read's caller constants per code (integer pass threshold, offset and stride of its ML bytes): uniform, but the kernel is short of
+// ck_* = the read's caller constants per code (integer pass threshold, offset and stride of its ML bytes, counter of Modified(code)):
+// uniform, but the kernel is short of
 // scalar registers — every lane reads them back as vectors once per slot batch
-struct SlotLds { int32_t ck_thr[4]; uint32_t ck_off[4]; uint32_t ck_str[4]; uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
+struct SlotLds { int32_t ck_thr[4]; uint32_t ck_off[4]; uint32_t ck_str[4]; uint32_t ck_cid[4]; uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
@@ -161,7 +162,6 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
   const uint32_t widx = rfl(blockIdx.x * (blockDim.x >> 6)) + wib;
   if (widx >= n_reads) return;
   const MkpWork h = work[widx];
-  const uint32_t rid = h.rid;
   SlotLds& W = lds_all[wib];
   const bool rev = (h.flags & MKP_RF_REVERSE) != 0;
   const uint32_t aln = rev ? 1u : 0u;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
   // per call), its pass threshold and the counter of Modified(code).  --ignore / --preset traditional (ReDistribute) keep the
   // general tables.
   const bool collapse = prm.numeric_mode == 2;
-  uint32_t fmisc = 0, f_cid = 0, f_col = 0;
+  uint32_t fmisc = 0, f_col = 0;
   int32_t i_can = 0;   // Canonical's threshold in units of 2^-11 (the exact integer form of the caller, below); the codes' are in W.ck_thr
   // where the ML byte of the i-th code of call j sits: ml[W.ck_off[i] + j * W.ck_str[i]] (tag + index inside the tag: offset and stride)
   uint32_t mlx_o = 0, mlx_s = 0;
@@ -212,11 +212,12 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
       e_last = rk[t_n - 1u];
     }
     const MkpFusedDesc fd = fdesc[h.layout];
-    fmisc = fd.misc; f_cid = fd.it_cid; i_can = fd.i_can;
+    fmisc = fd.misc; i_can = fd.i_can;
     if (lane < MKP_KMAX) {
       const uint32_t src = (fd.it_src >> (4 * lane)) & 15u, tg = src & 1u;
       W.ck_off[lane] = (tg ? h.ml_off1 : h.ml_off0) + (src >> 1); W.ck_str[lane] = (fd.nc >> (8u * tg)) & 0xffu;
       W.ck_thr[lane] = lane == 0 ? fd.i_thr[0] : lane == 1 ? fd.i_thr[1] : lane == 2 ? fd.i_thr[2] : fd.i_thr[3];
+      W.ck_cid[lane] = (fd.it_cid >> (8 * lane)) & 0xffu;
     }
     if (collapse) {
       f_col = fd.col;
@@ -259,7 +260,7 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
       for (int j = 0; j < 4; j++) {
         if (i0 + 64u * (uint32_t)j < nwords) {
           const uint32_t wi = i0 + 64u * (uint32_t)j + (uint32_t)lane;
-          const uint32_t Fw = flags4(x[j]), c = (uint32_t)__popc(Fw);
+          const uint32_t Fw = flags4(x[j]), c = wi < nwords ? (uint32_t)__popc(Fw) : 0u;   // (a window of 416 words ends inside a vector: the words behind it belong to the next window)
           const uint32_t inc = wave_incl_scan(c);
           if (wi < nwords) { W.F[wi] = Fw; W.P[wi] = (uint16_t)(carry + inc - c); }
           carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -400,28 +401,39 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
           const uint32_t jl = listed ? jx : 0u;
           const uint4 off4 = *reinterpret_cast<const uint4*>(W.ck_off), str4 = *reinterpret_cast<const uint4*>(W.ck_str);
           const uint32_t ml_o[MKP_KMAX] = {off4.x, off4.y, off4.z, off4.w}, ml_s[MKP_KMAX] = {str4.x, str4.y, str4.z, str4.w};
-          uint32_t mlb[MKP_KMAX], mlx = 0;
-#pragma unroll
-          for (int k = 0; k < MKP_KMAX; k++) mlb[k] = ((uint32_t)k < n_post) ? (uint32_t)ldo<uint8_t>(ml, __umul24(jl, ml_s[k]) + ml_o[k]) : 0u;
+          uint32_t mlb[MKP_KMAX] = {0u, 0u, 0u, 0u}, mlx = 0;
+          auto mlq = [&](int k) { return (uint32_t)ldo<uint8_t>(ml, __umul24(jl, ml_s[k]) + ml_o[k]); };
+          switch (n_post) {   // (uniform)
+            case 1: mlb[0] = mlq(0); break;
+            case 2: mlb[0] = mlq(0); mlb[1] = mlq(1); break;
+            case 3: mlb[0] = mlq(0); mlb[1] = mlq(1); mlb[2] = mlq(2); break;
+            case 4: mlb[0] = mlq(0); mlb[1] = mlq(1); mlb[2] = mlq(2); mlb[3] = mlq(3); break;
+            default: break;
+          }
           if (f_col & 1u) mlx = (uint32_t)ldo<uint8_t>(ml, __umul24(jl, mlx_s) + mlx_o);
           uint32_t cid = MKP_C_FAIL;
           if (int_caller) {
             // The same walk in integers, exactly: q -> (q + 0.5) / 256 is a multiple of 2^-9, the share of a collapsed code (its
             // probability over 1, 2 or 4 codes) a multiple of 2^-11, every sum of up to five of them and 1 - sum are exact in f32 — so
             // the f32 comparisons of the reference are comparisons of integers in units of 2^-11, thresholds rounded up to the next
-            // multiple by the host (fused_desc: the least integer T with T / 2048 >= threshold).
+            // multiple by the host (fused_desc: the least integer T with T / 2048 >= threshold).  One straight-line instance per number
+            // of codes (uniform switch): no per-code masks held in scalar registers.
             const int4 thr4 = *reinterpret_cast<const int4*>(W.ck_thr);
-            const int32_t i_thr[MKP_KMAX] = {thr4.x, thr4.y, thr4.z, thr4.w};
+            const uint4 cid4 = *reinterpret_cast<const uint4*>(W.ck_cid);
             const int32_t red4 = (f_col & 1u) ? (int32_t)(((2u * mlx + 1u) << 2) >> red_shift) + 4 : 4;
             int32_t sum = 0, best = INT32_MIN;
-#pragma unroll
-            for (int k = 0; k < MKP_KMAX; k++) {
-              if ((uint32_t)k < n_post) {
-                const int32_t v = (int32_t)(mlb[k] << 3) + red4;
-                sum += v;
-                const bool take = v >= max(i_thr[k], best);   // passes, and no entry before it is larger (the last maximum wins)
-                cid = take ? ((f_cid >> (8 * k)) & 0xffu) : cid; best = take ? v : best;
-              }
+            auto step = [&](uint32_t b, int32_t thr, uint32_t c) {
+              const int32_t v = (int32_t)(b << 3) + red4;
+              sum += v;
+              const bool take = v >= max(thr, best);   // passes, and no entry before it is larger (the last maximum wins)
+              cid = take ? c : cid; best = take ? v : best;
+            };
+            switch (n_post) {
+              case 1: step(mlb[0], thr4.x, cid4.x); break;
+              case 2: step(mlb[0], thr4.x, cid4.x); step(mlb[1], thr4.y, cid4.y); break;
+              case 3: step(mlb[0], thr4.x, cid4.x); step(mlb[1], thr4.y, cid4.y); step(mlb[2], thr4.z, cid4.z); break;
+              case 4: step(mlb[0], thr4.x, cid4.x); step(mlb[1], thr4.y, cid4.y); step(mlb[2], thr4.z, cid4.z); step(mlb[3], thr4.w, cid4.w); break;
+              default: break;
             }
             const int32_t pc = 2048 - sum;
             if (pc >= max(i_can, best)) cid = (fmisc >> 8) & 0xffu;
@@ -440,7 +452,7 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
               if (f_col & 1u) pr = pr + red;
               s = s + pr;
               const bool take = pr >= f_thr[k] && (!have || !(pr < best_p));
-              cid = take ? ((f_cid >> (8 * k)) & 0xffu) : cid; best_p = take ? pr : best_p; have = have || take;
+              cid = take ? W.ck_cid[k] : cid; best_p = take ? pr : best_p; have = have || take;
             }
           }
           const float pc = 1.0f - s;
@@ -464,13 +476,16 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
   const uint32_t tally = aln ^ sg0u, ob_const = fmisc >> 16;
   const uint32_t n_cf = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(n_callfeat), 63);
   if (lane == 0) {
-    MkpVisit v; v.gs0 = h.gs0; v.n_sl = n_sl; v.cov_off = h.cov_off;
-    v.flags = (ok ? MKP_VF_OK : 0u) | (rev ? MKP_VF_REV : 0u) | (gaps ? MKP_VF_GAPS : 0u) | ((h.flags >> MKP_RF_KEY_SHIFT) << 8);
+    // (what the records below need of the work record is read again here rather than held in scalar registers through the slot loop)
+    const MkpWork* hp = work + widx; asm volatile("" : "+s"(hp));
+    const uint32_t h_gs0 = hp->gs0, h_flags = hp->flags, h_cov_off = hp->cov_off, h_rid = hp->rid;
+    MkpVisit v; v.gs0 = h_gs0; v.n_sl = n_sl; v.cov_off = h_cov_off;
+    v.flags = (ok ? MKP_VF_OK : 0u) | (rev ? MKP_VF_REV : 0u) | (gaps ? MKP_VF_GAPS : 0u) | ((h_flags >> MKP_RF_KEY_SHIFT) << 8);
     v.obs0 = (ok && tally == 0u) ? ob_const : 0u; v.obs1 = (ok && tally == 1u) ? ob_const : 0u;
     v.over_off = 0; v.n_over = 0;
-    visits[rid] = v;
+    visits[h_rid] = v;
     MkpReadOut out; out.n_events = ok ? n_cf : 0u; out.ok = ok ? 1u : 0u; out.obs[0] = v.obs0; out.obs[1] = v.obs1;
-    readout[rid] = out;
+    readout[h_rid] = out;
   }
 }
 
@@ -584,43 +599,6 @@ extern "C" __global__ void __launch_bounds__(256) mkp_cover_reads(SLOT_PARAMS(Mk
 //       order) while every thread scatters (slot, candidate) words of its rows into the ROW MAP in LDS;
 //   E3  one thread per ROW fills its row from the tallies and stores it: every store instruction writes 64 consecutive rows of one column.
 // MkpRunParams is resolved once per workgroup into a small table (StreamProg) so that neither pass walks slot lists.
-struct StreamProg {
-  uint32_t n_groups;       // row candidates per strand (or per motif when strands combine): observed-code slots in row order, or the four primary bases (--combine-mods)
-  uint32_t totmask;        // counters that add up to a column's total (all but Delete and Filtered)
-  uint32_t modmask[4];     // primary base -> the counters of its mod codes
-  uint32_t code[16];       // group -> code of its rows
-  uint32_t info[16];       // group -> [0:1] primary base, [2:6] observed-code slot + 1 (0: a --combine-mods row), [7:11] counter of the code, [12:16] counter of
-                           //          Canonical(base), [17] the base has one, [18] first group of its code (strand combining adds up the groups of a code)
-};
-#define STREAM_ROWMAP MKP_STREAM_ROWMAP_WORDS   // rows per emission round (dwords of LDS)
-
-__device__ __forceinline__ uint32_t col_get(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t k) { return (tal[k * S + i] >> (16u * s)) & 0xffffu; }
-__device__ __forceinline__ uint32_t col_sum(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t mask) {
-  uint32_t t = 0;
-  while (mask) { const uint32_t k = (uint32_t)__ffs((int)mask) - 1u; mask &= mask - 1u; t += col_get(tal, S, i, s, k); }
-  return t;
-}
-// does (strand tally s, column i, group g) yield a row — add_tally_to_counts's early returns (pileup/mod.rs:283-410): the primary base has
-// filtered coverage, and (per-code rows) the code was observed in a record over this column
-__device__ __forceinline__ bool stream_row_exists(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g) {
-  const uint32_t inf = P.info[g];
-  if (!((inf >> 17) & 1u)) return false;
-  const uint32_t cov = col_get(tal, S, i, s, (inf >> 12) & 31u) + col_sum(tal, S, i, s, P.modmask[inf & 3u]);
-  if (!cov) return false;
-  const uint32_t osl = (inf >> 2) & 31u;
-  return !osl || col_get(tal, S, i, s, n_counters + osl - 1u) != 0u;
-}
-// the row itself, added into `r`
-__device__ __forceinline__ void stream_row_add(const uint32_t* __restrict__ tal, uint32_t S, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g, RowAcc& r) {
-  const uint32_t inf = P.info[g], pb = inf & 3u;
-  const uint32_t n_can = col_get(tal, S, i, s, (inf >> 12) & 31u), mods = col_sum(tal, S, i, s, P.modmask[pb]);
-  const uint32_t n_mod = ((inf >> 2) & 31u) ? col_get(tal, S, i, s, (inf >> 7) & 31u) : mods;
-  const uint32_t total = col_sum(tal, S, i, s, P.totmask), nocall = col_get(tal, S, i, s, MKP_C_NC + pb), cov = n_can + mods;
-  r.n_valid += cov; r.n_mod += n_mod; r.n_can += n_can; r.n_other += mods - n_mod;
-  r.n_del += col_get(tal, S, i, s, MKP_C_DEL); r.n_fail += col_get(tal, S, i, s, MKP_C_FAIL);
-  r.n_diff += total - (nocall + cov); r.n_nocall += nocall;
-}
-
 template <bool KEYED, uint32_t VB /* visits drawn per ticket, their records and first stream dwords requested together */>
 __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events,
                  const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
@@ -666,20 +644,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   // this thread's slot: position now, focus byte behind the visits
   int32_t my_pos = 0;
   if (threadIdx.x < n_tslots) my_pos = (int32_t)slot_pos[gh0 + threadIdx.x];
-  if (threadIdx.x < 16u) {   // the row program (read after the visits' barrier)
-    const uint32_t g = threadIdx.x, combine_mods = prm.numeric_mode == 1 ? 1u : 0u;
-    const uint32_t ng = combine_mods ? 4u : prm.n_slots;
-    uint32_t code = 0, inf = 0;
-    if (g < ng) {
-      const uint32_t sl = combine_mods ? 0u : prm.slot_order[g], pb = combine_mods ? g : prm.slots[sl].pb, ck = prm.can_of_pb[pb];
-      code = combine_mods ? (uint32_t)"ACGT"[g] : prm.slots[sl].code_repr;
-      const bool first = combine_mods || g == 0u || prm.slots[prm.slot_order[g - 1u]].code_repr != code;
-      inf = pb | ((combine_mods ? 0u : sl + 1u) << 2) | ((combine_mods ? 0u : (uint32_t)prm.slots[sl].cid) << 7) | (((MKP_C_CAN + ck) & 31u) << 12) | ((ck != 0xffu ? 1u : 0u) << 17) | ((first ? 1u : 0u) << 18);
-    }
-    prog.code[g] = code; prog.info[g] = inf;
-    if (g < 4u) { uint32_t m = 0; for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == g) m |= 1u << prm.slots[t].cid; prog.modmask[g] = m; }
-    if (g == 0u) { prog.n_groups = ng; prog.totmask = ((1u << n_counters) - 1u) & ~((1u << MKP_C_DEL) | (1u << MKP_C_FAIL)); }
-  }
+  rowprog_build(prm, n_counters, prog);   // (threads 0..15; read after the visits' barrier)
   const uint32_t talbase = lds_addr(tal), S4 = S * 4u;
   // one visit: the read's bytes for this tile's slots (first dword per lane already in `wcur`), its observed codes, its overflow events
   auto visit = [&](const MkpVisit& v, uint32_t wcur) {
@@ -739,6 +704,9 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   // Reads are drawn FOUR at a time: their visit records and the first stream dword of each are requested before any of them is used (a visit
   // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics).
   for (;;) {
+#ifdef MKP_DEBUG
+    if (prm.debug_skip & 1024u) break;   // ablation: no visits (prologue + scans + emission only)
+#endif
     uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, VB); base = rid_first + rfl(ticket); }
     if (base >= rid_end) break;
     MkpVisit vv[VB]; uint32_t ww[VB];
@@ -777,7 +745,12 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   const bool combine = prm.combine_strands != 0;
   const uint32_t i = threadIdx.x;
   unsigned long long em = 0; uint32_t cnt = 0, mult0 = 1, mult1 = 1;
-  if (i < n_tslots && my_pos >= tl.r0 && my_pos < tl.r1 && (my_fv & 3u)) {
+#ifdef MKP_DEBUG
+  const bool dbg_norows = (prm.debug_skip & 2048u) != 0;   // ablation: no rows (the look-back word is still published so that nothing waits)
+#else
+  constexpr bool dbg_norows = false;
+#endif
+  if (!dbg_norows && i < n_tslots && my_pos >= tl.r0 && my_pos < tl.r1 && (my_fv & 3u)) {
     const uint32_t rule = my_fv & 3u, combo = my_fv >> 2;
     if (!combine) {
       if (combo) { const MkpCombo& cb = combos_l[combo]; mult0 = cb.n_pos ? cb.n_pos : 1u; mult1 = cb.n_neg ? cb.n_neg : 1u; }
@@ -826,23 +799,32 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   { const size_t cap = prm.row_capacity; uint32_t* q = rows_base;
     rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap; rows.n_other = q + 6 * cap;
     rows.n_del = q + 7 * cap; rows.n_fail = q + 8 * cap; rows.n_diff = q + 9 * cap; rows.n_nocall = q + 10 * cap; }
-  for (uint32_t r0 = 0; r0 == 0u || r0 < tile_rows; r0 += STREAM_ROWMAP) {
+  for (uint32_t r0 = 0; r0 == 0u || r0 < tile_rows; r0 += MKP_STREAM_ROWMAP_WORDS) {
     if (r0) __syncthreads();   // the round before has read the map
     // (slot, candidate) of every row of this round: [0:9] slot, [10:13] group, [14:15] strand | motif, [16:17] which of the position's motif ids
-    if (cnt && off < r0 + STREAM_ROWMAP && off + cnt > r0) {
+    if (cnt && off < r0 + MKP_STREAM_ROWMAP_WORDS && off + cnt > r0) {
       uint32_t r = off;
       for (uint32_t sm = 0; sm < 4u; sm++) {
         uint32_t bits = (uint32_t)(em >> (16u * sm)) & 0xffffu;
         const uint32_t mult = combine ? 1u : (sm ? mult1 : mult0);
         while (bits) {
           const uint32_t g = (uint32_t)__ffs((int)bits) - 1u; bits &= bits - 1u;
-          for (uint32_t k = 0; k < mult; k++, r++) if (r >= r0 && r < r0 + STREAM_ROWMAP) rowmap[r - r0] = i | (g << 10) | (sm << 14) | (k << 16);
+          for (uint32_t k = 0; k < mult; k++, r++) if (r >= r0 && r < r0 + MKP_STREAM_ROWMAP_WORDS) rowmap[r - r0] = i | (g << 10) | (sm << 14) | (k << 16);
         }
       }
     }
     if (r0 == 0u && wave == 0u) {   // tile_row_off = the runs' look-back words (two dwords each); row_cursor[1] = total rows, written by the last run
+#ifdef MKP_DEBUG
+      uint32_t base;
+      if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (lane == 0) b0 = atomicAdd(row_cursor + 1, tile_rows); base = rfl(b0); }   // ablation: no look-back (rows in completion order)
+      else base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, tile_rows);
+#else
       const uint32_t base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, tile_rows);
+#endif
       if (lane == 0) {
+#ifdef MKP_DEBUG
+        if (!(prm.debug_skip & 4096u))
+#endif
         if (run + 1u == n_runs) row_cursor[1] = base + tile_rows;
         uint32_t s = tile_rows;
         if (base + s > prm.row_capacity) { atomicOr(dev_err, ERR_ROW_CAP); s = 0; }
@@ -851,7 +833,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
     }
     __syncthreads();
     // ---- E3: one thread per row
-    const uint32_t n_here = min(row_total_s, r0 + STREAM_ROWMAP) > r0 ? min(row_total_s, r0 + STREAM_ROWMAP) - r0 : 0u;
+    const uint32_t n_here = min(row_total_s, r0 + MKP_STREAM_ROWMAP_WORDS) > r0 ? min(row_total_s, r0 + MKP_STREAM_ROWMAP_WORDS) - r0 : 0u;
     for (uint32_t rr = threadIdx.x; rr < n_here; rr += PILEUP_THREADS) {
       const uint32_t e = rowmap[rr], si = e & 1023u, g = (e >> 10) & 15u, sm = (e >> 14) & 3u, k = (e >> 16) & 3u;
       const uint32_t ax = aux[si], combo = (ax & 0xffu) >> 2;
@@ -883,8 +865,11 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
     const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, \
     uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs, uint32_t S, uint32_t tal_words
 #define STREAM_PASS visits, cov, events, tiles, n_tiles, prmp, slot_pos, focus, combos, rows_base, row_cursor, tile_row_off, dev_err, key_arg, n_combos, n_runs, S, tal_words
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, 4>(STREAM_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, 4>(STREAM_PASS); }
+#ifndef MKP_STREAM_VB
+#define MKP_STREAM_VB 4
+#endif
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, MKP_STREAM_VB>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, MKP_STREAM_VB>(STREAM_PASS); }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)

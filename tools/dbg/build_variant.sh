@@ -1,5 +1,5 @@
 #!/bin/bash
-# another build of the library with extra compile flags -> tools/dbg/lib/libmkpileup_<name>.so; used through MKP_LIB_PATH (tools/dbg/r5_ab_lib.sh)
+# another build of the library with extra compile flags -> tools/dbg/lib/libmkpileup_<name>.so; used through MKP_LIB_PATH (tools/dbg/ab.sh)
 # usage: tools/dbg/build_variant.sh wb12k "-DMKP_SLOT_WB=12288u"
 set -e
 NAME=$1; EXTRA=$2

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel times of one workload under a list of environment settings, on one box
-# usage: tools/dbg/r5_env_sweep.sh <tag> <workload> "VAR=a" "VAR=b" ...
+# usage: tools/dbg/env_sweep.sh <tag> <workload> "VAR=a" "VAR=b" ...
 TAG=${1:-r5z}; W=${2:-c3}; shift 2
 cd "$(dirname "$0")/../.." && OUT=$PWD/gpurun_out/$TAG && mkdir -p $OUT
 export PYTHONPATH=$PWD TMPDIR=/tmp GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$PWD} MKP_BENCH_DIR=/tmp
