@@ -608,7 +608,10 @@ def main():
                 dbed = out_bed
             base["bedmethyl_sha256_equal"] = sh256(dbed) == sh256(obed)
             base["bedmethyl_sha256"] = sh256(dbed)
-            if multi and a.cpu_whole and os.path.exists(out_bed + ".f1"):
+            if a.workload == "chr1" and os.path.exists(out_bed + ".f1"):
+                # (the oracle's -f 1.0 run reads and sorts the whole contig's probabilities on one thread: > 700 s at this size, profiles/r06_chr1.txt)
+                base["full_data_threshold_run"] = {"flag": "-f 1.0", "equals_default_threshold_output": sh256(out_bed + ".f1") == sh256(out_bed)}
+            elif multi and a.cpu_whole and os.path.exists(out_bed + ".f1"):
                 # the full-data estimate (-f 1.0: sampled from the shards resident in HBM) against the oracle's -f 1.0 run, whole output
                 obed1, base1 = cpu_baseline(bam, flags + ["-f", "1.0"], workers, None, hemi, "full_f1")
                 base["full_data_threshold_run"] = {"flag": "-f 1.0", "bedmethyl_sha256_equal": sh256(out_bed + ".f1") == sh256(obed1), "oracle_total_s": base1["end_to_end"]["total_s"], "oracle_threshold_s": base1["end_to_end"]["threshold_s"]}

@@ -156,6 +156,13 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out);
 void mkp_ctx_destroy(mkp_ctx* ctx);
 const char* mkp_last_error(const mkp_ctx* ctx);
 const char* mkp_version(void);
+/* ABI revision of THIS header: bumped whenever a struct the caller allocates changes size or layout (mkp_run_report grew in round 5:
+ * revision 2; round 6 = 3).  The library writes whole structs of its own revision, so a caller built against another header must not
+ * hand it its structs: compare once at start-up —  `mkp_abi_version() == MKP_ABI_VERSION && mkp_run_report_size() == sizeof(mkp_run_report)`
+ * (the Rust binding asserts the same on its #[repr(C)] mirror). */
+#define MKP_ABI_VERSION 3u
+uint32_t mkp_abi_version(void);
+size_t mkp_run_report_size(void);
 /* Threads of the library's host pool (BGZF inflate, packing, planning, text): the CPUs this process may use — affinity mask and
    cgroup CPU quota — capped at 64; MKP_POOL_THREADS in the environment overrides it.  Rayon's `-t` in the reference
    (subcommand.rs:486-489) is the matching knob. */

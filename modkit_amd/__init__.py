@@ -75,14 +75,23 @@ def lib():
         L.mkp_histogram_locate.argtypes = [u64p, ctypes.c_float, ctypes.POINTER(ctypes.c_uint32), u64p, u64p]
         L.mkp_histogram_resolve.argtypes = [ctypes.c_uint32, u64p, ctypes.c_uint64, f32p]
         L.mkp_percentile_from_histogram.argtypes = [ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float, f32p]
+        # the structs this binding allocates mirror ONE revision of include/mkpileup.h: a library of another revision would write past them
+        L.mkp_abi_version.restype = ctypes.c_uint32
+        L.mkp_run_report_size.restype = ctypes.c_size_t
+        if L.mkp_abi_version() != ABI_VERSION or L.mkp_run_report_size() != ctypes.sizeof(RunReport):
+            raise MkpError(-1, "libmkpileup.so has ABI revision %d (mkp_run_report %d bytes), this binding %d (%d bytes): rebuild" %
+                           (L.mkp_abi_version(), L.mkp_run_report_size(), ABI_VERSION, ctypes.sizeof(RunReport)))
         _lib = L
     return _lib
+
+
+ABI_VERSION = 3   # MKP_ABI_VERSION of include/mkpileup.h
 
 
 # mkp_threshold_fn (include/mkpileup.h): int fn(void* user, mkp_ctx* ctx, int have_sample, float thresholds[4], uint8_t has[4])
 THRESHOLD_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint8))
 
-EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_host_threads", "mkp_set_caller", "mkp_shard_begin",
+EXPORTS = ["mkp_ctx_create", "mkp_ctx_destroy", "mkp_last_error", "mkp_version", "mkp_abi_version", "mkp_run_report_size", "mkp_host_threads", "mkp_set_caller", "mkp_shard_begin",
            "mkp_shard_add_records", "mkp_shard_set_intervals", "mkp_shard_run", "mkp_batch_run", "mkp_shard_rerun", "mkp_get_stats", "mkp_process_region", "mkp_pileup_main",
            "mkp_pileup_run", "mkp_pileup_run_cb", "mkp_percentile", "mkp_estimate_thresholds", "mkp_host_mm_ranks", "mkp_host_map_order",
            "mkp_set_partition_tags", "mkp_histogram_begin", "mkp_histogram_add_bam", "mkp_histogram_get", "mkp_histogram_allreduce", "mkp_histogram_from_values", "mkp_histogram_locate",

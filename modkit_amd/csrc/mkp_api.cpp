@@ -25,6 +25,8 @@ hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | sh
     uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
                             const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
+hipError_t mkp_launch_dup_restore(hipStream_t, MkpReadHdr*, const MkpDupCons*, uint32_t);
+hipError_t mkp_launch_dup_events(hipStream_t, MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, MkpDupCons*, const MkpDupSeg*, uint32_t, uint32_t* /*error bits*/);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
                              const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/,
@@ -236,7 +238,9 @@ void make_resident(mkp_ctx* c) {
   auto lap = [&, last = t0](const char* what) mutable { if (trace) { auto now = std::chrono::steady_clock::now();
       fprintf(stderr, "[mkpileup plan] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now; } };
   // hazard: the reference's ReadCache is keyed by read NAME (read_cache.rs:28-35); two kept records with
-  // one name in one interval share a cache entry there.  Not reproduced -> refuse loudly.
+  // one name in one interval share a cache entry there: the later one is answered from the earlier one's calls.  Found here, planned
+  // behind the tile plan (it needs the focus positions), reproduced by mkp_dup_events (mkp_slots.hip).
+  std::vector<std::vector<uint32_t>> dup_groups;   // records of one name (and partition key) that meet inside an interval: planned below (plan_dups)
   { const size_t nn = S.name_hash.size();
     // every thread takes the names whose hash falls into its sixteenth and looks for a repeat in an open-addressing table of its own
     // (value = the first record carrying the name); repeats are rare, so they are only collected here and judged below
@@ -269,12 +273,16 @@ void make_resident(mkp_ctx* c) {
       return true;
     };
     for (auto& kv : groups) {
-      const std::vector<uint32_t>& g = kv.second;
+      std::vector<uint32_t> g = kv.second; std::sort(g.begin(), g.end()); g.erase(std::unique(g.begin(), g.end()), g.end());
       std::vector<std::pair<int64_t, int64_t>> rg; rg.reserve(g.size());
       for (uint32_t r : g) { int64_t a, b; if (iv_range(S.hdr[r], &a, &b)) rg.push_back({a, b}); }
-      for (size_t x = 0; x < rg.size(); x++) for (size_t y = x + 1; y < rg.size(); y++)
-        if (rg[x].first <= rg[y].second && rg[y].first <= rg[x].second) throw Error(MKP_E_UNSUPPORTED,
-          "two primary records share a read name inside one interval (unmarked duplicates, or mates / split reads that overlap the same interval); the reference answers the later record from the earlier one's calls (its per-interval cache is keyed by name) and this is not reproduced on the device");
+      bool meet = false;
+      for (size_t x = 0; x < rg.size() && !meet; x++) for (size_t y = x + 1; y < rg.size(); y++) if (rg[x].first <= rg[y].second && rg[y].first <= rg[x].second) { meet = true; break; }
+      if (!meet) continue;
+      // pileup-hemi keys its DuplexReadCache by name as well (read_cache.rs:368-468); that form is not reproduced
+      if (c->hemi) throw Error(MKP_E_UNSUPPORTED,
+          "two primary records share a read name inside one interval (unmarked duplicates, or mates / split reads that overlap the same interval); pileup-hemi answers the later record from the earlier one's calls (its per-interval cache is keyed by name) and this is not reproduced on the device");
+      dup_groups.push_back(std::move(g));
     }
   }
   lap("duplicate-name check");
@@ -423,7 +431,7 @@ void make_resident(mkp_ctx* c) {
       // LDS of mkp_pileup_stream: tallies + per slot its position and an emission word, + the row map (one thread per slot decides the rows)
       const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, ((budget_words - MKP_STREAM_ROWMAP_WORDS) / (words_per_slot + 2u)) & ~63u);
       if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
-      uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 2048u + 63u) & ~63u));   // about 2000 tiles over 512 resident workgroups
+      uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 2304u + 63u) & ~63u));   // about 2300 tiles over 512 resident workgroups (C3, round 6 kernel: 448 / 640 / 768 / 896 / 992 slots: 0.153 / 0.136 / 0.132 / 0.125 / 0.128 ms)
       if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));   // tests: many small tiles
       if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));
           // experiments
@@ -491,6 +499,75 @@ void make_resident(mkp_ctx* c) {
     }
     stiles.swap(kept);
   }
+  // ---- records sharing a name inside an interval (dup_groups, found above): who answers for the name in which interval.
+  // The reference asks its per-interval cache about a record the first time the record shows up in a focus column of the interval as
+  // something other than a reference skip (add_mod_codes_for_record is called before the deletion check, pileup/mod.rs:783-835); columns
+  // ascend, records inside a column come in file order.  The first record asked OWNS the name in that interval: its tags are parsed, its
+  // calls (by reference position and read base), its codes and its failure answer for every record of the name (read_cache.rs:232-355).
+  std::vector<MkpDupCons> dup_cons; std::vector<MkpDupSeg> dup_segs; std::vector<uint8_t> dup_member(n, 0);
+  if (!dup_groups.empty()) {
+    auto cigar_of = [&](uint32_t r) {
+      const MkpReadHdr& h = S.hdr[r]; std::vector<uint32_t> cg(h.n_cigar);
+      if (!S.dev_packed) { for (uint32_t k = 0; k < h.n_cigar; k++) cg[k] = S.cigar[h.cigar_off + k]; }
+      else if (h.n_cigar) { hip_check(hipSetDevice(c->device), "hipSetDevice"); d2h_copy(cg.data(), c->d_cigar.as<uint32_t>() + h.cigar_off, (size_t)h.n_cigar * 4, c->stream); }
+      return cg;
+    };
+    const int64_t W0 = S.win_start, W1 = S.win_end;
+    auto iv_bounds = [&](int64_t k, int64_t* a, int64_t* b) {   // interval k of the shard's grid, clipped to the window
+      if (c->iv_starts.empty()) { *a = W0; *b = W1; return; }
+      *a = std::max<int64_t>(W0, k == 0 ? W0 : (int64_t)c->iv_starts[(size_t)k]); *b = (size_t)k + 1 < c->iv_starts.size() ? std::min<int64_t>(W1, (int64_t)c->iv_starts[(size_t)k + 1]) : W1;
+    };
+    auto iv_index = [&](int64_t p) -> int64_t { if (c->iv_starts.empty()) return 0;
+      return std::max<int64_t>((int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1, 0); };
+    uint64_t ev_off = S.n_events_cap;
+    for (auto& g : dup_groups) {
+      struct Mem { uint32_t r; int64_t beg, end; std::vector<std::pair<int64_t, int64_t>> skips; };
+      std::vector<Mem> ms;
+      for (uint32_t r : g) {
+        const MkpReadHdr& h = S.hdr[r]; Mem m; m.r = r; m.beg = h.ref_start; m.end = std::max<int64_t>(h.ref_end, (int64_t)h.ref_start + 1);
+        if (m.end <= W0 || m.beg >= W1) continue;   // a halo record of the fetch: in none of the shard's intervals
+        int64_t p = h.ref_start;
+        for (uint32_t w : cigar_of(r)) { const uint32_t op = w & 15u, len = w >> 4; if (op == 3u) m.skips.push_back({p, p + len}); if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) p += len; }
+        ms.push_back(std::move(m)); dup_member[r] = 1;
+      }
+      // first column of [lo, hi) in which member m is asked about: a focus position that is not inside one of its reference skips
+      auto first_col = [&](const Mem& m, int64_t lo, int64_t hi) -> int64_t {
+        lo = std::max(lo, m.beg); hi = std::min(hi, m.end);
+        auto in_skip = [&](int64_t p, int64_t* e) { for (auto& sk : m.skips) if (p >= sk.first && p < sk.second) { *e = sk.second; return true; } return false; };
+        if (!c->has_focus) { int64_t p = lo, e; while (p < hi && in_skip(p, &e)) p = e; return p < hi ? p : -1; }
+        for (size_t k = (size_t)(std::lower_bound(slot_pos_h.begin(), slot_pos_h.end(), (uint32_t)std::max<int64_t>(lo, 0)) - slot_pos_h.begin()); k < slot_pos_h.size() && (int64_t)slot_pos_h[k] < hi; k++) {
+          int64_t e; if (!in_skip((int64_t)slot_pos_h[k], &e)) return (int64_t)slot_pos_h[k]; }
+        return -1;
+      };
+      int64_t k_lo = INT64_MAX, k_hi = -1;
+      for (auto& m : ms) { k_lo = std::min(k_lo, iv_index(std::max(m.beg, W0))); k_hi = std::max(k_hi, iv_index(std::min(m.end, W1) - 1)); }
+      std::vector<std::vector<MkpDupSeg>> segs_of(ms.size());
+      for (int64_t k = k_lo; k <= k_hi; k++) {
+        int64_t a, b; iv_bounds(k, &a, &b);
+        int64_t best_p = -1; size_t best = 0; std::vector<uint8_t> present(ms.size(), 0);
+        for (size_t x = 0; x < ms.size(); x++) { const int64_t fc = first_col(ms[x], a, b); if (fc < 0) continue; present[x] = 1;
+          if (best_p < 0 || fc < best_p) { best_p = fc; best = x; } }   // (members are in file order: the first of equal columns stays)
+        if (best_p < 0) continue;
+        for (size_t x = 0; x < ms.size(); x++) if (present[x]) {
+          auto& sv = segs_of[x]; const uint32_t owner = ms[best].r;
+          if (!sv.empty() && sv.back().owner == owner && sv.back().p_hi == (int32_t)a) sv.back().p_hi = (int32_t)b;
+          else sv.push_back({(int32_t)a, (int32_t)b, S.hdr[owner].event_off, owner});
+        }
+      }
+      for (size_t x = 0; x < ms.size(); x++) {
+        bool foreign = false; for (auto& sg : segs_of[x]) if (sg.owner != ms[x].r) foreign = true;
+        if (!foreign) continue;   // asked about first wherever it shows up: an ordinary record (whose events others may read)
+        MkpDupCons dc; memset(&dc, 0, sizeof(dc)); dc.rid = ms[x].r; dc.seg_off = (uint32_t)dup_segs.size(); dc.n_seg = (uint32_t)segs_of[x].size(); dc.own_off = S.hdr[ms[x].r].event_off;
+        uint64_t cap = 0; for (auto& sg : segs_of[x]) { cap += S.hdr[sg.owner].event_cap; dup_segs.push_back(sg); }
+        if (ev_off + cap > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
+        dc.eff_off = (uint32_t)ev_off; dc.eff_cap = (uint32_t)cap; ev_off += cap;
+        dup_cons.push_back(dc);
+      }
+    }
+    S.n_events_cap = ev_off;
+    lap("records sharing a name: owners per interval");
+  }
+  c->n_dup_cons = (uint32_t)dup_cons.size();
   // reads by kernel on the slot pipeline: the fused slot decoder takes the SPARSE classes when no edge filter is set (it never locates
   // calls off the focus positions, which the edge filter's "any call left" test would need); every other read is decoded into events
   // by its class kernel and then covered
@@ -498,8 +575,17 @@ void make_resident(mkp_ctx* c) {
   std::vector<uint32_t> slot_ids;
   if (stream) {
     const bool fused = !P.edge_filter && !(getenv("MKP_FUSED") && !strcmp(getenv("MKP_FUSED"), "0"));
+    uint32_t dup_forced[2] = {0, 0};
     std::vector<uint8_t> is_fused(n, 0);
     if (fused) {
+      // (records sharing a name inside an interval keep their event decoder: their events are what the others are answered from; they move
+      //  behind the fused reads of the class list, where the decode launch starts)
+      if (!dup_groups.empty()) {
+        std::vector<uint32_t> keep, f0, f1; const uint32_t n0 = c->n_class[0], n01 = c->n_class[0] + c->n_class[1]; uint32_t k0 = 0;
+        for (uint32_t k = 0; k < n01; k++) { const uint32_t r = class_list[k]; if (dup_member[r]) (k < n0 ? f0 : f1).push_back(r); else { keep.push_back(r); if (k < n0) k0++; } }
+        std::vector<uint32_t> nl(keep); nl.insert(nl.end(), f0.begin(), f0.end()); nl.insert(nl.end(), f1.begin(), f1.end()); nl.insert(nl.end(), class_list.begin() + n01, class_list.end());
+        class_list.swap(nl); c->n_class[0] = k0; c->n_class[1] = (uint32_t)keep.size() - k0; dup_forced[0] = (uint32_t)f0.size(); dup_forced[1] = (uint32_t)f1.size();
+      }
       const uint32_t nf = c->n_class[0] + c->n_class[1];
       for (uint32_t k = 0; k < nf; k++) is_fused[class_list[k]] = 1;
       // one list for both SPARSE classes, longest first; the reads of more than one base window (mkp_decode_slots_long) lead it
@@ -508,7 +594,7 @@ void make_resident(mkp_ctx* c) {
       std::merge(class_list.begin(), class_list.begin() + c->n_class[0], class_list.begin() + c->n_class[0], class_list.begin() + nf, slot_ids.begin(), longer);
       uint32_t n_long = 0; while (n_long < nf && S.hdr[slot_ids[n_long]].l_seq > MKP_SLOT_WB) n_long++;
       c->n_slot_class[0] = n_long; c->n_slot_class[1] = nf - n_long;
-      c->read_ids_dec_off = nf; c->n_class[0] = c->n_class[1] = 0;
+      c->read_ids_dec_off = nf; c->n_class[0] = dup_forced[0]; c->n_class[1] = dup_forced[1];
     }
     std::vector<uint32_t> rest; rest.reserve(n);
     for (size_t i = 0; i < n; i++) if (!is_fused[i]) rest.push_back((uint32_t)i);
@@ -535,6 +621,7 @@ void make_resident(mkp_ctx* c) {
   else if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64);
       c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
+  if (c->n_dup_cons) { upload(c->d_dupcons, dup_cons); upload(c->d_dupsegs, dup_segs); }
   c->d_readout.ensure(std::max<size_t>(2 * S.hdr.size(), 1) * sizeof(MkpReadOut));   // second half: second-group summaries of duplex reads
   c->d_misc.ensure(64);
   lap("upload: focus + event buffers");
@@ -619,12 +706,17 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
       hip_check(hipMemcpyAsync(c->d_prm.p, c->prm_uploaded.data(), sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     }
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
+    if (c->n_dup_cons) hip_check(mkp_launch_dup_restore(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_dupcons.as<MkpDupCons>(), c->n_dup_cons), "dup restore launch");
     hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class, c->d_cigar.as<uint32_t>(),
         c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
                                 c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
     if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(),
         c->d_readout.as<MkpReadOut>(),
                                                   (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
+    // records answered from another record of their name: their event lists are rebuilt from the owners' (behind every event decoder, in front of
+    // whatever consumes events: mkp_cover_reads / mkp_pileup_tiles)
+    if (c->n_dup_cons) hip_check(mkp_launch_dup_events(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+                                                       c->d_dupcons.as<MkpDupCons>(), c->d_dupsegs.as<MkpDupSeg>(), c->n_dup_cons, misc + 2), "dup events launch");
     if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_work.as<MkpWork>(), c->n_slot_class[0], c->n_slot_class[1], c->d_hdr.as<MkpReadHdr>(),
         c->d_slot_ids.as<uint32_t>(), c->n_slot_class[2],
                                               c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
@@ -654,6 +746,7 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
     lap("sync");
     if (h[2] & 2u) { c->row_cap *= 2; if (c->row_cap > (1ull << 31)) throw Error(MKP_E_NOMEM, "row buffer would exceed 2^31 rows"); continue; }
     if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
+    if (h[2] & ERR_DUP_MIXED) throw Error(MKP_E_UNSUPPORTED, "records sharing a read name inside one interval are answered from the first one's calls (the reference's per-interval cache is keyed by name); here the records one of them is answered from in different intervals disagree in status or observed mod codes, which is not reproduced on the device");
     c->stats.n_rows = h[1];
     if (time_kernels) {
       float a = 0, b = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
@@ -1082,6 +1175,9 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
     if (out) fetch_rows(c, out);
   });
 }
+
+uint32_t mkp_abi_version(void) { return MKP_ABI_VERSION; }
+size_t mkp_run_report_size(void) { return sizeof(mkp_run_report); }
 
 int mkp_get_stats(const mkp_ctx* c, mkp_stats* out) { if (!c || !out) return MKP_E_INVALID; *out = c->stats; return MKP_OK; }
 

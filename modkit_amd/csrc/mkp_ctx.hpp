@@ -113,6 +113,7 @@ struct mkp_ctx {
   // slot pipeline (focus runs, mkp_slots.hip): slot positions, feature stream, per-read visit records, stream tiles;
   // reads by kernel: [fused, longer than one base window | fused | cover]
   bool slot_mode = false; uint32_t n_slot_class[3] = {0, 0, 0}; uint32_t read_ids_dec_off = 0; uint64_t cov_bytes = 0;
+  uint32_t n_dup_cons = 0; mkp::DevBuf d_dupcons, d_dupsegs;   // records answered from another record of their name (MkpDupCons / MkpDupSeg)
   mkp::DevBuf d_slot_pos, d_cov, d_visits, d_stiles, d_slot_ids, d_fdesc, d_work;
   // threshold sample, resident in HBM: keys = base << 30 | f32 bit pattern of an argmax probability; level-0 histogram per base
   mkp::ShardHost sample_shard; std::vector<MkpReadOut> sample_ro; uint64_t sample_n = 0;

@@ -235,6 +235,22 @@ struct MkpWork {             // 64 B
   uint32_t rank_off, n_calls, ml_off0, ml_off1;   // the shared rank list, the tags' ML bytes
   uint32_t rid, pad;
 };
+// Records that share a read NAME inside one interval of the reference's grid (unmarked duplicates, mates, split reads that kept the primary flag).
+// The reference keeps ONE cache entry per name and interval (ReadCache, read_cache.rs:24-43): the record asked about first — the first focus
+// column of the interval that holds a record of the name, file order within a column — is parsed; every later record of the name is answered
+// from THAT record's call map, looked up by reference position and the asking record's own read base (get_mod_call, 232-297).  The host planner
+// works out, per interval, which record owns the name (make_resident); a record that is answered from another one in some interval is a
+// CONSUMER: mkp_dup_events rebuilds its event list — its own events where it owns the name, the owner's events elsewhere, kept where its own
+// alignment shows the call's base — and the accumulate kernels then take that list as the record's own.
+struct MkpDupSeg { int32_t p_lo, p_hi; uint32_t src_off /* the owner's OWN event slice */, owner; };   // positions [p_lo, p_hi) of one consumer, ascending
+struct MkpDupCons {
+  uint32_t rid, seg_off, n_seg;
+  uint32_t own_off;    // the record's own event slice (what its decode kernel writes)
+  uint32_t eff_off, eff_cap;   // the rebuilt list
+  uint32_t out_n, out_ok, out_obs0, out_obs1;   // written by mkp_dup_events, moved into the record's header / summary by mkp_dup_apply
+  uint32_t pad[6];
+};
+#define ERR_DUP_MIXED 8u   // device error bit: the records a consumer is answered from disagree in status or observed codes (refused, not approximated)
 #define MKP_VF_OK 1u
 #define MKP_VF_REV 2u
 #define MKP_VF_GAPS 4u

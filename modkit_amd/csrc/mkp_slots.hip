@@ -679,18 +679,25 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
         }
       }
     }
+    // bytes outside [k_lo, k_hi) — the ends of the read's first and last dword in this tile — become "no feature": the first dword's (lane 0 of
+    // the first round only) once per visit, the last dword's once per round
+    uint32_t lom = kfirst < k_lo ? ~(0xffffffffu << (8u * (k_lo - kfirst))) : 0u;
     for (uint32_t k = kfirst;; k += 256u) {
-      uint32_t w = wcur;
+      uint32_t w = wcur | lom;
+      lom = 0;
       const uint32_t kn = k + 256u;
       wcur = kn < k_hi ? *reinterpret_cast<const uint32_t*>(cp + kn) : 0xffffffffu;
-      // bytes outside [k_lo, k_hi) — the ends of the read's first and last dword in this tile — become "no feature" once per dword
-      if (k < k_lo) w |= k + 4u <= k_lo ? 0xffffffffu : ~(0xffffffffu << (8u * (k_lo - k)));
       if (k + 4u > k_hi) w |= k >= k_hi ? 0xffffffffu : 0xffffffffu << (8u * (k_hi - k));
       const uint32_t lane_base = talbase + 4u * (col0 + k);
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t fb = (w >> (8u * j)) & 0xffu;
-        if (fb < 0x40u) lds_add(lane_base + 4u * j + __umul24(fb & 31u, S4), (fb & 32u) ? 0x10000u : 1u);
+        // feature byte: [0:4] counter, [5] tally strand, >= 0x40 none.  One multiply-add for the row address (the byte's column goes into the
+        // instruction's offset field), one for the increment (1 or 1 << 16)
+        const uint32_t row = (w >> (8u * j)) & 31u, st = (w >> (8u * j + 5u)) & 1u;
+        if (!(w & (0xc0u << (8u * j)))) {
+          lds_u32* col = (lds_u32*)(uintptr_t)(lane_base + __umul24(row, S4));
+          __hip_atomic_fetch_add(col + j, __umul24(st, 0xffffu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
       if (!__any(kn < k_hi)) break;
     }
@@ -872,6 +879,91 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_strea
 extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, MKP_STREAM_VB>(STREAM_PASS); }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// Records sharing a read name inside one interval (MkpDupCons / MkpDupSeg, mkp_device.h).  Rare: a handful of records per shard.
+//   mkp_dup_restore  before the decode kernels: a consumer's header points at its OWN event slice again (a re-launch on a resident shard finds
+//                    it pointing at the rebuilt list of the pass before)
+//   mkp_dup_events   after the decode kernels: one wave per consumer rebuilds its event list segment by segment.  Own segment: its events are
+//                    copied.  Foreign segment: the owner's events in the segment's positions — each is a (reference position, counter, mod
+//                    strand, base) of the OWNER's call map — are kept where the consumer's own alignment has a base at that position and the
+//                    base (read orientation) is the call's base (get_mod_call asks `calls[strand][read_base].get(position)`, read_cache.rs:232-297),
+//                    with the tally strand of the consumer's alignment (add_feature, pileup/mod.rs:238-281).
+//   mkp_dup_apply    the consumer's header / summary now describe the rebuilt list: cover / accumulate kernels take it as the record's own.
+// The observed codes and the status (skip set, read_cache.rs:272-277) are the owner's too; the accumulate kernels apply ONE set per record, so
+// owners that disagree across a consumer's segments raise ERR_DUP_MIXED (the host refuses the shard) instead of being approximated.
+extern "C" __global__ void __launch_bounds__(64) mkp_dup_restore(MkpReadHdr* __restrict__ hdrs, const MkpDupCons* __restrict__ cons, uint32_t n) {
+  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+  if (k < n) hdrs[cons[k].rid].event_off = cons[k].own_off;
+}
+extern "C" __global__ void __launch_bounds__(64) mkp_dup_apply(MkpReadHdr* __restrict__ hdrs, MkpReadOut* __restrict__ readout, const MkpDupCons* __restrict__ cons, uint32_t n) {
+  const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+  if (k >= n) return;
+  const MkpDupCons c = cons[k];
+  hdrs[c.rid].event_off = c.eff_off;
+  MkpReadOut o; o.n_events = c.out_n; o.ok = c.out_ok; o.obs[0] = c.out_obs0; o.obs[1] = c.out_obs1;
+  readout[c.rid] = o;
+}
+extern "C" __global__ void __launch_bounds__(64) mkp_dup_events(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, MkpEvent* __restrict__ events,
+                                                                const MkpReadOut* __restrict__ readout, MkpDupCons* __restrict__ cons, const MkpDupSeg* __restrict__ segs, uint32_t n, uint32_t* __restrict__ dev_err) {
+  const uint32_t ci = blockIdx.x;
+  if (ci >= n) return;
+  const int lane = lane_id();
+  const MkpDupCons c = cons[ci];
+  const MkpReadHdr h = hdrs[c.rid];
+  const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u, L = h.l_seq;
+  const uint8_t* __restrict__ seqb = seqs + h.seq_off;
+  const uint32_t* __restrict__ cg = cigar + h.cigar_off;
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0; rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
+  rw.pref = cigar_quad(cg, h.n_cigar, 0);
+  MkpEvent* __restrict__ dst = events + c.eff_off;
+  uint32_t n_out = 0, st_ok = 0, st_o0 = 0, st_o1 = 0; bool have_st = false, mixed = false, over = false;
+  for (uint32_t s = 0; s < c.n_seg; s++) {
+    const MkpDupSeg sg = segs[c.seg_off + s];
+    const MkpReadOut ro = readout[sg.owner];   // (the owner's own summary: mkp_dup_apply runs behind this kernel)
+    const uint32_t ok = ro.ok == 1u ? 1u : 0u, o0 = ok ? ro.obs[0] : 0u, o1 = ok ? ro.obs[1] : 0u;
+    if (!have_st) { st_ok = ok; st_o0 = o0; st_o1 = o1; have_st = true; } else if (ok != st_ok || o0 != st_o0 || o1 != st_o1) mixed = true;
+    const uint32_t n_src = ok ? ro.n_events : 0u;
+    const MkpEvent* __restrict__ src = events + sg.src_off;
+    const bool own = sg.owner == c.rid;
+    for (uint32_t at = event_lower_bound(src, n_src, sg.p_lo);; at += 64u) {
+      const uint32_t k = at + (uint32_t)lane;
+      MkpEvent e; e.pos = 0xffffffffu; e.info = 0;
+      if (k < n_src) e = src[k];
+      const bool in = k < n_src && (int32_t)e.pos < sg.p_hi;
+      bool keep = in;
+      if (!own) {
+        // the consumer's own alignment at the call's reference position: a base (M / = / X), and the call's base in read orientation
+        uint32_t kind = 2u, q = 0u;
+        const bool inside = in && (int32_t)e.pos >= h.ref_start && (int32_t)e.pos < h.ref_end;
+        refwin_map(rw, cg, h.n_cigar, h.ref_start, inside, (int32_t)e.pos, &kind, &q);
+        keep = false;
+        if (inside && kind == 0u && q < L) {
+          const uint32_t byte = (uint32_t)seqb[q >> 1], nib = (q & 1u) ? (byte & 15u) : (byte >> 4);
+          const int sb = nib2base(nib);
+          const uint32_t rb = sb < 0 ? 4u : (aln ? 3u - (uint32_t)sb : (uint32_t)sb);
+          keep = rb == ((e.info >> 9) & 3u);
+        }
+        // the mod strand of the owner's call (its tally strand seen from its own alignment), tallied from THIS record's alignment strand
+        const uint32_t mod_strand = ((e.info >> 8) ^ (e.info >> 11)) & 1u;
+        e.info = (e.info & ~((1u << 8) | (1u << 11))) | ((aln ^ mod_strand) << 8) | (aln << 11);
+      }
+      const unsigned long long bk = __ballot(keep);
+      const uint32_t nk = (uint32_t)__popcll(bk);
+      if (n_out + nk > c.eff_cap) { over = true; break; }
+      if (keep) dst[n_out + (uint32_t)__popcll(bk & lanemask_lt())] = e;
+      n_out += nk;
+      if (!__all(in)) break;
+    }
+    if (over) break;
+  }
+  if (lane == 0) {
+    if (mixed) atomicOr(dev_err, ERR_DUP_MIXED);
+    if (over) atomicOr(dev_err, ERR_EVENT_CAP);
+    MkpDupCons* o = cons + ci;
+    o->out_n = st_ok ? n_out : 0u; o->out_ok = st_ok; o->out_obs0 = st_o0; o->out_obs1 = st_o1;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
 // work = the fused decoder's reads [longer than one base window | the others], cover_ids = the reads of mkp_cover_reads
 extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint32_t n_long, uint32_t n_short, const MkpReadHdr* hdrs, const uint32_t* cover_ids, uint32_t n_cover, const uint32_t* cigar,
@@ -881,6 +973,18 @@ extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint
   if (n_long) MKP_FUSED_LAUNCH(mkp_decode_slots_long, work, n_long);
   if (n_short) MKP_FUSED_LAUNCH(mkp_decode_slots, work + n_long, n_short);
   if (n_cover) hipLaunchKernelGGL(mkp_cover_reads, dim3((n_cover + 3u) / 4u), dim3(256), 0, st, hdrs, n_cover, cover_ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, *prm, slot_pos, cov, visits, events, readout, dev_err);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t mkp_launch_dup_restore(hipStream_t st, MkpReadHdr* hdrs, const MkpDupCons* cons, uint32_t n) {
+  if (n) hipLaunchKernelGGL(mkp_dup_restore, dim3((n + 63u) / 64u), dim3(64), 0, st, hdrs, cons, n);
+  return hipGetLastError();
+}
+extern "C" hipError_t mkp_launch_dup_events(hipStream_t st, MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs, MkpEvent* events, MkpReadOut* readout, MkpDupCons* cons, const MkpDupSeg* segs,
+                                            uint32_t n, uint32_t* dev_err) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(mkp_dup_events, dim3(n), dim3(64), 0, st, hdrs, cigar, seqs, events, readout, cons, segs, n, dev_err);
+  hipLaunchKernelGGL(mkp_dup_apply, dim3((n + 63u) / 64u), dim3(64), 0, st, hdrs, readout, cons, n);
   return hipGetLastError();
 }
 

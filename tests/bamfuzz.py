@@ -124,7 +124,8 @@ def bam_header(contigs):
 
 
 class Fuzz:
-    def __init__(self, seed, contigs=(("ctgA", 12000), ("ctgB", 3000)), n_reads=250, mean_len=900, profile="mixed", tie_rate=0.05, weird_rate=0.08, index=None):
+    def __init__(self, seed, contigs=(("ctgA", 12000), ("ctgB", 3000)), n_reads=250, mean_len=900, profile="mixed", tie_rate=0.05, weird_rate=0.08, index=None, dup_rate=0.0):
+        self.dup_rate = dup_rate   # share of reads written as TWO primary records with one name: an unmarked duplicate, a shifted copy, or the two halves of a split read
         self.index = (seed % 3 != 2) if index is None else index   # two of three seeds write a BAI
         self.r = random.Random(seed)
         self.contigs = contigs
@@ -367,6 +368,52 @@ class Fuzz:
                     aux += aux_i("MN", len(seq))
         return start, flag, [(n, op) for n, op in cigar], seq, aux
 
+    def second_record(self, start, flag, cigar, seq, aux, name, ref_len):
+        """A second PRIMARY record with the same name (the reference keys its per-interval read cache by name, read_cache.rs:28-35): an unmarked
+        duplicate, the same alignment shifted by a few bases, or the read split in two (each half soft-clips the other's bases; the first
+        record is replaced by the first half)."""
+        kind = self.r.choice(["copy", "shift", "split"])
+        span = sum(n for n, op in cigar if op in "MDN=X")
+        if kind == "copy":
+            return [(start, flag, cigar, seq, aux, name)]
+        if kind == "shift":
+            d = self.r.randrange(1, 40)
+            return [(start + d, flag, cigar, seq, aux, name)] if start + d + span < ref_len else []
+        # split: cut at a query position inside an M run
+        qtot = sum(n for n, op in cigar if op in "MIS=X")
+        if qtot < 40:
+            return []
+        cut = self.r.randrange(15, qtot - 15)
+        a, b, q, r = [], [], 0, start
+        b_start = None
+        for n, op in cigar:
+            qn = n if op in "MIS=X" else 0
+            rn = n if op in "MDN=X" else 0
+            if q + qn <= cut or (qn == 0 and q < cut):
+                a.append((n, op)); q += qn; r += rn
+            elif q >= cut:
+                if b_start is None:
+                    if op in "DN":      # a half must not begin with a deletion / skip
+                        r += rn
+                        continue
+                    b_start = r
+                b.append((n, op)); q += qn; r += rn
+            else:                       # the cut falls inside this op
+                k1 = cut - q
+                if op in "M=X":
+                    a.append((k1, op)); b_start = r + k1; b.append((n - k1, op))
+                else:                   # inside an insertion / soft clip: give it whole to the first half
+                    a.append((n, op)); cut = q + n
+                q += qn; r += rn
+        if b_start is None or not any(op in "M=X" for _, op in a) or not any(op in "M=X" for _, op in b):
+            return []
+        while a and a[-1][1] in "DN":
+            a.pop()
+        qa = sum(n for n, op in a if op in "MIS=X")
+        a.append((qtot - qa, "S"))
+        b = [(qa, "S")] + b
+        return [("replace", a), (b_start, flag, b, seq, aux, name)]
+
     def write(self, prefix, bed=False):
         data = bam_header(self.contigs)
         k = 0
@@ -378,12 +425,22 @@ class Fuzz:
                 rd = self.make_read(self.refs[name])
                 if rd:
                     reads.append(rd)
-            reads.sort(key=lambda t: t[0])
+            named = []
             for start, flag, cigar, seq, aux in reads:
-                rec = bam_record(tid, start, flag, "read%06d" % k, cigar, seq, aux)
+                name = "read%06d" % k
+                k += 1
+                named.append((start, flag, cigar, seq, aux, name))
+                if self.dup_rate and self.r.random() < self.dup_rate and not (flag & (4 | 256 | 2048)):
+                    for extra in self.second_record(start, flag, cigar, seq, aux, name, ln):
+                        if extra[0] == "replace":
+                            named[-1] = (start, flag, extra[1], seq, aux, name)
+                        else:
+                            named.append(extra)
+            named.sort(key=lambda t: t[0])   # (stable: the first record of a name stays in front of its copy at the same start)
+            for start, flag, cigar, seq, aux, name in named:
+                rec = bam_record(tid, start, flag, name, cigar, seq, aux)
                 index.append((tid, start, sum(n for n, op in cigar if op in "MDN=X"), flag, len(data), len(rec)))
                 data += rec
-                k += 1
         offs = bgzf_write(prefix + ".bam", bytes(data))
         if self.index:   # an indexed BAM goes through the device ingest (linear-index entry points), an unindexed one through the host loader
             write_bai(prefix + ".bam.bai", len(self.contigs), offs, index)

@@ -24,7 +24,7 @@ def L():
 
 def declared_symbols():
     text = open(HEADER).read()
-    return sorted(set(re.findall(r"^(?:int|unsigned|void|const char\*)\s+(mkp_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|unsigned|void|const char\*|uint32_t|size_t)\s+(mkp_\w+)\s*\(", text, flags=re.M)))
 
 
 def test_every_declared_symbol_is_exported(L):
@@ -53,6 +53,13 @@ def test_ctypes_mirror_matches_header_layout(tmp_path):
     assert sizes[6] == ctypes.sizeof(modkit_amd.Rows)
     assert sizes[7] == ctypes.sizeof(modkit_amd.Stats)
     assert sizes[4] == 16 and sizes[3] == 32
+
+
+def test_abi_revision_and_report_size(L):
+    # a caller built against another revision of the header must be able to tell before it hands over a struct
+    m = re.search(r"#define MKP_ABI_VERSION (\d+)u", open(HEADER).read())
+    assert m and L.mkp_abi_version() == int(m.group(1)) == modkit_amd.ABI_VERSION
+    assert L.mkp_run_report_size() == ctypes.sizeof(modkit_amd.RunReport)
 
 
 def test_version_and_no_device_is_loud(L):

@@ -1,0 +1,83 @@
+"""GPU: primary records that share a read NAME inside one interval of the reference's grid.  The reference keeps one read-cache entry per
+name and interval (ReadCache, read_cache.rs:24-43): the record asked about first is parsed, every later record of the name is answered
+from THAT record's calls — by reference position and the asking record's own read base — codes and failure (get_mod_call 232-297,
+add_mod_codes_for_record 299-355).  Rounds 1-5 refused such shards; now the host works out the owner of the name per interval and
+mkp_dup_events rebuilds the later records' event lists (mkp_slots.hip).  The checker is the oracle, whose cache is keyed by name like the
+reference's.  Still refused, loudly: a record whose owners in different intervals disagree in status or observed codes."""
+import os
+import subprocess
+
+import pytest
+
+import modkit_amd
+from bamfuzz import Fuzz, aux_bc, aux_z, bam_header, bam_record, bgzf_write
+
+pytestmark = pytest.mark.gpu
+
+
+def both(oracle_bin, tmp_path, bam, flags, extra_dev=()):
+    dev, ora = str(tmp_path / "dev.bed"), str(tmp_path / "ora.bed")
+    modkit_amd.pileup([bam, dev] + flags + list(extra_dev))
+    p = subprocess.run([oracle_bin, "pileup", bam, ora] + flags, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-400:]
+    a, b = open(dev).read(), open(ora).read()
+    if a != b:
+        al, bl = a.splitlines(), b.splitlines()
+        for i in range(max(len(al), len(bl))):
+            x, y = (al[i] if i < len(al) else "<none>"), (bl[i] if i < len(bl) else "<none>")
+            assert x == y, "row %d differs\n device: %s\n oracle: %s (%d vs %d rows)" % (i, x, y, len(al), len(bl))
+    return a
+
+
+FLAGS = [
+    ["--no-filtering"],                                                   # no focus positions: mkp_pileup_tiles
+    ["--filter-threshold", "0.7", "-i", "700"],                           # several intervals per contig: owners change along a record
+    ["--cpg", "--ref", "{fa}", "--filter-threshold", "0.7"],              # slot pipeline (mkp_cover_reads for the records of a shared name)
+    ["--preset", "traditional", "--ref", "{fa}", "--filter-threshold", "0.6", "-i", "500"],
+    ["--motif", "CG", "0", "--motif", "GATC", "1", "--ref", "{fa}", "--no-filtering", "-i", "1300"],
+    ["--include-bed", "{bed}", "--filter-threshold", "0.7", "-i", "900"],
+    ["--cpg", "--ref", "{fa}", "--filter-threshold", "0.7", "--shard-bp", "2500", "-i", "400"],   # shards cut inside a contig
+]
+
+
+@pytest.mark.parametrize("fi", range(len(FLAGS)))
+@pytest.mark.parametrize("profile,seed", [("m", 3), ("hm_split", 4), ("mixed", 6)])
+def test_duplicates_shifted_copies_and_split_reads(oracle_bin, tmp_path, profile, seed, fi):
+    bam, fa, bed = Fuzz(100 + seed, profile=profile, n_reads=400, dup_rate=0.35, weird_rate=0.05 if profile == "mixed" else 0.0, index=(fi % 2 == 0)).write(str(tmp_path / "fz"), bed=True)
+    flags = [f.format(fa=fa, bed=bed) for f in FLAGS[fi]]
+    dev_only = []
+    oflags = []
+    k = 0
+    while k < len(flags):   # (--shard-bp is the device driver's knob, not a flag of the subcommand)
+        if flags[k] == "--shard-bp":
+            dev_only += flags[k:k + 2]; k += 2; continue
+        oflags.append(flags[k]); k += 1
+    out = both(oracle_bin, tmp_path, bam, oflags, dev_only)
+    assert len(out.splitlines()) > 200
+
+
+def test_two_records_one_name_follow_the_first(oracle_bin, tmp_path):
+    # (the case rounds 1-5 refused, tests/test_gpu_loud_failures.py): the second record, 30 bases further on, is answered from the first one's calls
+    seq = "ACGTCGACGTACGCGTACGATCGCGTA" * 4
+    aux = aux_z("MM", "C+m?,0,1;") + aux_bc("ML", [200, 30])
+    recs = [bam_record(0, 10, 0, "same_name", [(len(seq), "M")], seq, aux), bam_record(0, 40, 0, "same_name", [(len(seq), "M")], seq, aux)]
+    bam = str(tmp_path / "dup.bam")
+    bgzf_write(bam, bytes(bam_header([("ctg", 1000)])) + b"".join(recs))
+    out = both(oracle_bin, tmp_path, bam, ["--no-filtering"])
+    assert len(out.splitlines()) == 2   # the first record's two calls; the second record's own calls (30 bases on) are never looked at
+    # with the grid cut between them the second record is asked about first in its own interval: its calls count there
+    out2 = both(oracle_bin, tmp_path, bam, ["--no-filtering", "-i", "35"])
+    assert out2 != out and len(out2.splitlines()) > 2
+
+
+def test_owners_that_disagree_are_refused(tmp_path):
+    # record B (5hmC tag) spans two intervals; in the first it is answered from record A (5mC tag, asked first), in the second from itself:
+    # one record, two sets of observed codes -> MKP_E_UNSUPPORTED, not an approximation
+    seq = "ACGTCGACGTACGCGTACGATCGCGTA" * 8
+    a = bam_record(0, 10, 0, "same_name", [(100, "M"), (len(seq) - 100, "S")], seq, aux_z("MM", "C+m?,0,1;") + aux_bc("ML", [200, 30]))
+    b = bam_record(0, 40, 0, "same_name", [(len(seq), "M")], seq, aux_z("MM", "C+h?,0,1;") + aux_bc("ML", [200, 30]))
+    bam = str(tmp_path / "mixed.bam")
+    bgzf_write(bam, bytes(bam_header([("ctg", 1000)])) + a + b)
+    with pytest.raises(modkit_amd.MkpError) as e:
+        modkit_amd.pileup([bam, str(tmp_path / "o.bed"), "--no-filtering", "-i", "150"])
+    assert e.value.status == -3 and "read name" in str(e.value)
