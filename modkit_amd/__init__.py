@@ -76,6 +76,9 @@ def lib():
         L.mkp_histogram_resolve.argtypes = [ctypes.c_uint32, u64p, ctypes.c_uint64, f32p]
         L.mkp_percentile_from_histogram.argtypes = [ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float, f32p]
         # the structs this binding allocates mirror ONE revision of include/mkpileup.h: a library of another revision would write past them
+        if os.environ.get("MKP_LIB_PATH") and not hasattr(L, "mkp_abi_version"):
+            _lib = L   # (A/B runs against a build from before the query existed, tools/dbg/ab.sh)
+            return _lib
         L.mkp_abi_version.restype = ctypes.c_uint32
         L.mkp_run_report_size.restype = ctypes.c_size_t
         if L.mkp_abi_version() != ABI_VERSION or L.mkp_run_report_size() != ctypes.sizeof(RunReport):

@@ -431,7 +431,9 @@ void make_resident(mkp_ctx* c) {
       // LDS of mkp_pileup_stream: tallies + per slot its position and an emission word, + the row map (one thread per slot decides the rows)
       const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, ((budget_words - MKP_STREAM_ROWMAP_WORDS) / (words_per_slot + 2u)) & ~63u);
       if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
-      uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 2304u + 63u) & ~63u));   // about 2300 tiles over 512 resident workgroups (C3, round 6 kernel: 448 / 640 / 768 / 896 / 992 slots: 0.153 / 0.136 / 0.132 / 0.125 / 0.128 ms)
+      // as many slots per tile as LDS and the one-thread-per-slot emission allow, down to ~1024 tiles for small windows: a read is visited once per
+      // tile it crosses and the visits are most of the kernel (C3, round 6: 448 / 640 / 704 / 896 / 992 slots: 0.153 / 0.139 / 0.128 / 0.125 / 0.116 ms)
+      uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 1024u + 63u) & ~63u));
       if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));   // tests: many small tiles
       if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));
           // experiments

@@ -606,7 +606,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
                  uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs, uint32_t S, uint32_t tal_words) {
   const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = key_arg >> 16;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  __shared__ uint32_t next_read, run_ticket, row_base_s, row_total_s;
+  __shared__ uint32_t next_read, n_real, run_ticket, row_base_s, row_total_s;
   __shared__ uint32_t wave_tot[PILEUP_WAVES];
   __shared__ __attribute__((aligned(16))) uint32_t prm_lds[(sizeof(MkpRunParams) + 3) / 4];
   __shared__ __attribute__((aligned(16))) uint32_t combo_lds[64 * sizeof(MkpCombo) / 4];
@@ -618,7 +618,7 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   // not hang on it starts beside the ticket: the tallies are cleared at once (their size is a kernel argument), the parameter block and the
   // combos come in; the slot positions and focus bytes (needed by the emission only) are requested when the tile is known and land in LDS
   // behind the visits.  ONE barrier stands between a workgroup's start and its first visit (round 5: two, the second behind the positions).
-  if (threadIdx.x == 0) { run_ticket = atomicAdd(row_cursor, 1u); next_read = 0; }
+  if (threadIdx.x == 0) { run_ticket = atomicAdd(row_cursor, 1u); next_read = 0; n_real = 0; }
   { const uint32_t nv = tal_words >> 2; uint4* l4 = reinterpret_cast<uint4*>(lds);
     for (uint32_t k = threadIdx.x; k < nv; k += PILEUP_THREADS) l4[k] = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t k = (nv << 2) + threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0; }
@@ -657,15 +657,12 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
     const uint32_t kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
     // observed mod codes over the columns the read is in (add_mod_codes_for_record, pileup/mod.rs:831-835)
     if ((v.flags & MKP_VF_OK) && (v.obs0 | v.obs1)) {
-      if (!(v.flags & MKP_VF_GAPS)) {
-        if (lane < 2) {
-          uint32_t m = lane ? v.obs1 : v.obs0;
-          const uint32_t inc = lane ? 0x10000u : 1u;
-          while (m) {
-            const uint32_t sl = (uint32_t)__ffs((int)m) - 1u; m &= m - 1u;
-            atomicAdd(&obs[sl * S + (a - gh0)], inc);
-            if (b - gh0 < n_tslots) atomicAdd(&obs[sl * S + (b - gh0)], 0u - inc);
-          }
+      if (!(v.flags & MKP_VF_GAPS)) {   // one lane per (observed-code slot, tally strand): +1 where the read enters the tile's columns, -1 behind its last
+        const uint32_t sl = (uint32_t)lane >> 1, st = (uint32_t)lane & 1u;
+        if (sl < n_oslots && (((st ? v.obs1 : v.obs0) >> sl) & 1u)) {
+          const uint32_t inc = st ? 0x10000u : 1u, at = __umul24(sl, S) + (a - gh0);
+          atomicAdd(&obs[at], inc);
+          if (b - gh0 < n_tslots) atomicAdd(&obs[at + (b - a)], 0u - inc);
         }
       } else {   // ref-skips: the read is not in those columns (alignment.is_refskip()) — a change of state per boundary
         for (uint32_t k = k_lo + (uint32_t)lane; k <= k_hi; k += 64) {
@@ -708,25 +705,44 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
       }
     }
   };
-  // Reads are drawn FOUR at a time: their visit records and the first stream dword of each are requested before any of them is used (a visit
-  // is a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics).
-  for (;;) {
+  // The tile's candidate reads [first, last) are a superset (everything that starts before the tile's end and behind the longest read's reach:
+  // about half of them end before the tile starts, C3).  Every thread looks at one candidate — slot range only, one 8-byte load — and the ones
+  // that reach into the tile are compacted into a list in LDS (the row map's words: the emission is not running yet); the waves then draw
+  // from that list, FOUR at a time: the visit records and the first stream dword of each are requested before any of them is used (a visit is
+  // a chain ticket -> 32-byte record -> one dword per lane -> LDS atomics).  Round 6 ablation (profiles/r06_stream_ablation.txt): with the
+  // emission rewritten the visits are the kernel — 0.077 of 0.133 ms — and every empty candidate used to cost a ticket, a scalar load and its wait.
+  for (uint32_t c0 = rid_first; c0 < rid_end; c0 += PILEUP_THREADS) {
 #ifdef MKP_DEBUG
     if (prm.debug_skip & 1024u) break;   // ablation: no visits (prologue + scans + emission only)
 #endif
-    uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, VB); base = rid_first + rfl(ticket); }
-    if (base >= rid_end) break;
-    MkpVisit vv[VB]; uint32_t ww[VB];
+    if (c0 != rid_first) { __syncthreads(); if (threadIdx.x == 0) { next_read = 0; n_real = 0; } __syncthreads(); }   // (the round before is through with the list)
+    { const uint32_t cnd = c0 + threadIdx.x; bool reaches = false;
+      if (cnd < rid_end) {
+        const uint2 gr = *reinterpret_cast<const uint2*>(&visits[cnd]);   // gs0, n_sl
+        reaches = max(gr.x, gh0) < min(gr.x + gr.y, gh1);
+        if (KEYED && reaches) reaches = (visits[cnd].flags >> 8) == key_filter;   // --partition-tag: one pass per key
+      }
+      const unsigned long long bal = __ballot(reaches);
+      uint32_t w0 = 0; if (lane == 0 && bal) w0 = atomicAdd(&n_real, (uint32_t)__popcll(bal));
+      w0 = rfl(w0);
+      if (reaches) rowmap[w0 + (uint32_t)__popcll(bal & lanemask_lt())] = cnd; }
+    __syncthreads();
+    const uint32_t n_here = n_real;
+    for (;;) {
+      uint32_t base; { uint32_t ticket = 0; if (lane == 0) ticket = atomicAdd(&next_read, VB); base = rfl(ticket); }
+      if (base >= n_here) break;
+      MkpVisit vv[VB]; uint32_t ww[VB];
 #pragma unroll
-    for (uint32_t j = 0; j < VB; j++) vv[j] = visits[min(base + j, rid_end - 1u)];   // (uniform: scalar loads)
+      for (uint32_t j = 0; j < VB; j++) vv[j] = visits[rfl(rowmap[min(base + j, n_here - 1u)])];   // (uniform: scalar loads)
 #pragma unroll
-    for (uint32_t j = 0; j < VB; j++) {
-      const uint32_t a = max(vv[j].gs0, gh0), b = min(vv[j].gs0 + vv[j].n_sl, gh1);
-      const uint32_t k_lo = a - vv[j].gs0, k_hi = b - vv[j].gs0, kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
-      ww[j] = (a < b && kfirst < k_hi) ? *reinterpret_cast<const uint32_t*>(cov + vv[j].cov_off + kfirst) : 0xffffffffu;
+      for (uint32_t j = 0; j < VB; j++) {
+        const uint32_t a = max(vv[j].gs0, gh0), b = min(vv[j].gs0 + vv[j].n_sl, gh1);
+        const uint32_t k_lo = a - vv[j].gs0, k_hi = b - vv[j].gs0, kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
+        ww[j] = (a < b && kfirst < k_hi) ? *reinterpret_cast<const uint32_t*>(cov + vv[j].cov_off + kfirst) : 0xffffffffu;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < VB; j++) if (base + j < n_here) visit(vv[j], ww[j]);
     }
-#pragma unroll
-    for (uint32_t j = 0; j < VB; j++) if (base + j < rid_end) visit(vv[j], ww[j]);
   }
   // the emission's per-slot words: position and focus byte (the byte's load overlaps the barrier and the scans below)
   uint32_t my_fv = 0;

@@ -65,9 +65,13 @@ def test_two_records_one_name_follow_the_first(oracle_bin, tmp_path):
     bgzf_write(bam, bytes(bam_header([("ctg", 1000)])) + b"".join(recs))
     out = both(oracle_bin, tmp_path, bam, ["--no-filtering"])
     assert len(out.splitlines()) == 2   # the first record's two calls; the second record's own calls (30 bases on) are never looked at
-    # with the grid cut between them the second record is asked about first in its own interval: its calls count there
-    out2 = both(oracle_bin, tmp_path, bam, ["--no-filtering", "-i", "35"])
-    assert out2 != out and len(out2.splitlines()) > 2
+    # a finer grid: the first record is still asked about first in every interval the second one's calls lie in
+    assert both(oracle_bin, tmp_path, bam, ["--no-filtering", "-i", "35"]) == out
+    # the second record alone in the interval that holds its calls (the first record placed elsewhere): its own calls count
+    recs2 = [bam_record(0, 10, 0, "same_name", [(20, "M"), (len(seq) - 20, "S")], seq, aux), recs[1]]
+    bam2 = str(tmp_path / "dup2.bam")
+    bgzf_write(bam2, bytes(bam_header([("ctg", 1000)])) + b"".join(recs2))
+    assert both(oracle_bin, tmp_path, bam2, ["--no-filtering", "-i", "35"]) != both(oracle_bin, tmp_path, bam2, ["--no-filtering"])
 
 
 def test_owners_that_disagree_are_refused(tmp_path):
