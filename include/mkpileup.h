@@ -360,7 +360,12 @@ int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
  * --no-headers, --kmer-size k, --no-filtering | --filter-threshold .. | the sampling flags of the threshold estimate (-n -f -p -t
  * --sampling-interval-size), --mod-thresholds, --ignore, --edge-filter, --invert-edge-filter, --device N.  Records go out in FILE order
  * (the reference's serial path, which its golden tests pin; its indexed path emits interval batches in Rayon completion order).
- * --region, --include-bed / --exclude-bed, --motif, --num-reads, --ignore-implicit, --bgzf fail with MKP_E_UNSUPPORTED. */
+ * Round 6: --include-bed (ReferencePositionFilter::keep, src/extract/util.rs:44-69: rows are asked of the BED with the reference strand
+ * of the mod; rows without a reference position go), --region (src/extract/util.rs:126-160: steers the threshold estimate; with a BAI next
+ * to the BAM and without --ignore-index the table holds the records overlapping the region — what the reference's interval fetches
+ * return — otherwise every record of the file, as its serial scan does), --num-reads N with --ignore-index or an unindexed BAM (the first N
+ * records that reach process_record, util.rs:519-575), --ignore-index.
+ * --num-reads on an indexed BAM (the sampling schedule), --exclude-bed, --motif / --cpg, --ignore-implicit, --bgzf fail with MKP_E_UNSUPPORTED. */
 int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
 /* ---- BGZF inflate on the device as a call of its own.  On the pileup path the same kernels run inside the device ingest

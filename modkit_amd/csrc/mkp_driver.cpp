@@ -1489,7 +1489,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
   mkp_ctx* ctx = nullptr;
   struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
   try {
-    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false; size_t kmer = 5; int device = 0;
+    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false; size_t kmer = 5; int device = 0; long num_reads = -1;
     std::vector<std::string> rest;
     for (int i = 0; i < argc; i++) {
       const std::string s = argv[i];
@@ -1497,9 +1497,9 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       if (s == "--ref" || s == "--reference") ref_path = val(); else if (s == "--allow-non-primary") allow_np = true; else if (s == "--mapped-only") mapped_only = true;
       else if (s == "--pass-only" || s == "--pass") pass_only = true; else if (s == "--no-headers") no_headers = true; else if (s == "--kmer-size") kmer = std::stoul(val());
       else if (s == "--force" || s == "--suppress-progress") {} else if (s == "--device") device = std::stoi(val()); else if (s == "--stats") stats = true;
-      else if (s == "--region" || s == "--include-bed" || s == "--include-positions" || s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--num-reads" ||
-               s == "--ignore-index" || s == "--ignore-implicit" || s == "--bgzf" || s == "--cpg" || s == "--seed")
-        throw Error(MKP_E_UNSUPPORTED, "extract calls: " + s + " is outside what this library restates (whole-file, file-order table; see include/mkpileup.h)");
+      else if (s == "--num-reads") num_reads = std::stol(val()); else if (s == "--ignore-index") ignore_index = true;
+      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--ignore-implicit" || s == "--bgzf" || s == "--cpg" || s == "--seed")
+        throw Error(MKP_E_UNSUPPORTED, "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --num-reads / --ignore-index are; see include/mkpileup.h)");
       else rest.push_back(s);
     }
     if (kmer == 0 || kmer > 50) throw Error(MKP_E_INVALID, "kmer size must be less than or equal to 50");
@@ -1510,7 +1510,8 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     // unless --mapped-only (ReferencePositionFilter::only_mapped_positions, src/extract/util.rs:39-41)
     std::vector<std::string> sf;
     for (size_t i = 0; i < rest.size(); i++) if (rest[i] != a.in_bam && rest[i] != a.out_bed) sf.push_back(rest[i]);
-    if (!mapped_only) sf.push_back("--include-unmapped");
+    // (--include-bed: "specifying include-only BED outputs only mapped sites", util.rs:136-142 — positions without a reference position do not count)
+    if (!mapped_only && a.include_bed.empty()) sf.push_back("--include-unmapped");
     std::vector<const char*> sav; for (auto& x : sf) sav.push_back(x.c_str());
     mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = device;
     int rc = mkp_ctx_create(&cfg, &ctx);
@@ -1538,6 +1539,22 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     must(mkp_internal_set_extract(ctx, true));
     const BamData bd = load_bam(a.in_bam, 0, false);
     Fasta fasta; if (!ref_path.empty()) fasta = Fasta::load(ref_path);
+    // --include-bed (ReferencePositionFilter::keep, src/extract/util.rs:44-69), --region, --num-reads (src/extract/util.rs:126-160, 329-575).
+    // With an index (and without --ignore-index) the reference walks interval chunks of the targets: --region then selects the records its
+    // fetches return — every record overlapping the region, once — where the serial scan looks at every record of the file.  The reference's
+    // rows leave in the order its pool finishes the intervals; here in file order.  --num-reads: the serial path's "first N records that
+    // reach process_record"; on an indexed BAM it follows the sampling schedule, which is not restated for this subcommand.
+    BedFilter bed; const bool have_bed = !a.include_bed.empty();
+    if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t; bed = BedFilter::load(a.include_bed, c2t); }
+    bool use_index = false; { FILE* probe = fopen((a.in_bam + ".bai").c_str(), "rb"); if (probe) { fclose(probe); use_index = !ignore_index; } }
+    if (use_index && num_reads >= 0) throw Error(MKP_E_UNSUPPORTED, "extract calls: --num-reads on an indexed BAM follows the reference's sampling schedule, which is not restated for this subcommand (--ignore-index: the first N records)");
+    int64_t reg_tid = -1, reg_s = 0, reg_e = 0; const bool have_region = !a.region.empty();
+    if (have_region) {
+      std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0); const RegionSpec rg = parse_region(a.region, *src);
+      for (size_t t = 0; t < bd.ref_names.size(); t++) if (bd.ref_names[t] == rg.name) reg_tid = (int64_t)t;
+      reg_s = rg.start; reg_e = rg.end;
+    }
+    long n_sent = 0; bool done = false;
     FILE* out = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w+");
     if (!out) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
     struct Close { FILE* f; ~Close() { if (f && f != stdout) fclose(f); } } closer{out};
@@ -1548,11 +1565,17 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     static const char NT16[] = "=ACMGRSVTWYHKDBN";
     const size_t BATCH = 1 << 15;
     std::vector<MkpEvent> ev; std::vector<float> vals; std::vector<uint32_t> n_vals;
-    for (size_t r0 = 0; r0 < bd.recs.size(); r0 += BATCH) {
+    for (size_t r0 = 0; r0 < bd.recs.size() && !done; r0 += BATCH) {
       const size_t r1 = std::min(bd.recs.size(), r0 + BATCH);
       std::vector<mkp_record> recs;
       for (size_t i = r0; i < r1; i++) {   // TrackingModRecordIter (mod_bam.rs:53-122) + process_records_to_chan's --mapped-only
         const mkp_record r = view.view(bd.recs[i]);
+        if (use_index && have_region) {   // IndexedReader::fetch(tid, start, end): the records overlapping the region (one without reference span counts as one base)
+          int64_t span = 0; const uint8_t* cgp = r.data + r.l_qname;
+          for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cgp + 4 * (size_t)k, 4); const uint32_t op = w & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4; }
+          const int64_t e = (int64_t)r.pos + std::max<int64_t>(span, 1);
+          if (r.tid != reg_tid || (int64_t)r.pos >= reg_e || e <= reg_s) continue;
+        }
         if ((r.flag & (2048 | 256 | 1024)) && !allow_np) { n_skipped++; continue; }
         if (r.l_qseq <= 0) { n_failed++; continue; }
         if ((r.flag & 4) && mapped_only) { n_skipped++; continue; }
@@ -1566,6 +1589,10 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       for (size_t i = 0; i < recs.size(); i++) {
         const mkp_record& r = recs[i];
         const MkpReadHdr& h = ctx->sample_shard.hdr[i]; const MkpReadOut& ro = ctx->sample_ro[i];
+        if (done) break;
+        // --num-reads counts what reaches process_record: records whose tags parse and hold something (an unmapped record under --mapped-only
+        // never gets that far: dropped above)
+        if (ro.ok) { n_sent++; if (num_reads >= 0 && n_sent >= num_reads) done = true; }
         if (!ro.ok || !ro.n_events) { if (h.flags & MKP_RF_BAD) n_failed++; else n_skipped++; continue; }
         const bool unmapped = (r.flag & 4) != 0, rev = (r.flag & 16) != 0;
         const size_t L = (size_t)r.l_qseq;
@@ -1613,7 +1640,8 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         if (unmapped && rev) std::reverse(rows.begin(), rows.end());   // no alignment strand: ascending forward position
         bool any = false;
         for (const Row& w : rows) {
-          if (mapped_only && (unmapped || w.ref < 0)) continue;                 // filter_read_base_mod_probs (src/extract/util.rs:71-124)
+          if ((mapped_only || have_bed) && (unmapped || w.ref < 0)) continue;   // filter_read_base_mod_probs (src/extract/util.rs:71-124)
+          if (have_bed && !bed.contains((uint32_t)r.tid, (uint64_t)w.ref, (((w.info >> 2) & 1u) != 0) != rev)) continue;   // ... asked with the reference strand of the mod
           if (!primary_or_unmapped && !within(w.f)) continue;                   // iter_profiles (read_ids_to_base_mod_probs.rs:785-800)
           any = true;
           const uint32_t tb = w.info & 3u, sg = (w.info >> 2) & 1u, inferred = (w.info >> 3) & 1u, thr_cls = (w.info >> 4) & 15u, arg_cls = (w.info >> 8) & 15u;

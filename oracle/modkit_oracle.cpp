@@ -766,8 +766,21 @@ static int run_summary(const Options& o) {
 }
 
 // `modkit extract calls` (EntryExtractCalls::run, src/extract/subcommand.rs:452-761), the serial file-order path
-static int run_extract_calls(const Options& o, const ExtractOptions& xo) {
+static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
+  ExtractOptions xo = xo_in;
   BamFile bam = read_bam(o.in_bam);
+  Region region; const bool have_region = !o.region.empty();
+  if (have_region) region = parse_region(o.region, bam);
+  PositionFilter pf_store; const PositionFilter* pf = nullptr;
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& rr : get_targets(bam, have_region ? &region : nullptr)) c2t[rr.name] = rr.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store;
+    xo.include = [pf](int32_t tid, uint64_t p, bool neg) { return pf->contains(tid, p, neg); }; }
+  // With an index (and without --ignore-index) the reference walks interval chunks of the targets (util.rs:329-470): --region then selects the
+  // records the fetches of its intervals return — every record overlapping it, once (prev_end) — where the serial scan looks at every record
+  // of the file.  Its rows leave in whatever order the pool finishes the intervals; here: file order.  --num-reads with an index goes through
+  // the sampling schedule, which is not restated for this subcommand.
+  FILE* probe = fopen((o.in_bam + ".bai").c_str(), "rb"); const bool use_index = probe && !xo.ignore_index; if (probe) fclose(probe);
+  if (use_index && xo.num_reads >= 0) throw MkErr("extract calls --num-reads on an indexed BAM follows the sampling schedule: not restated (use --ignore-index for the first N records)");
+  const int region_tid = have_region ? bam.tid_of(region.name) : -1;
   EdgeFilter edge;
   if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
   CollapseMethod collapse;
@@ -778,9 +791,9 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo) {
   if (o.no_filtering) {}
   else if (!o.filter_threshold.empty()) { caller.per_mod = per_mod; parse_thresholds(o.filter_threshold, &caller); }
   else {   // get_threshold_from_options (command_utils.rs:74-134): the pileup's estimate; positions without a reference position count unless --mapped-only
-    Options so = o; so.include_unmapped = !xo.mapped_only;
+    Options so = o; so.include_unmapped = !xo.mapped_only && !pf;   // reference_position_filter.only_mapped_positions()
     caller.per_mod = per_mod;
-    auto per_base = sample_probs(bam, so, nullptr, collapse, edge, nullptr);
+    auto per_base = sample_probs(bam, so, have_region ? &region : nullptr, collapse, edge, pf);
     for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); }
   }
   std::map<std::string, std::string> ref_seqs;
@@ -789,9 +802,18 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo) {
   if (!out) throw MkErr("failed to make output file");
   if (!xo.no_headers) fputs(extract_calls_header(), out);
   uint64_t n_used = 0, n_skipped = 0, n_failed = 0, n_rows = 0;
+  long n_sent = 0;
   for (const BamRecord& r : bam.recs) {
-    std::string rows; bool skipped = false;
-    if (!extract_calls_of_record(bam, r, xo, collapse, edge, caller, ref_seqs, &rows, &skipped)) { n_failed++; continue; }
+    if (use_index && have_region) {   // IndexedReader::fetch(tid, start, end): records overlapping the region (a record without reference span counts as one base)
+      const int64_t e = (int64_t)r.pos + std::max<int64_t>((int64_t)r.ref_len(), 1);
+      if (r.tid != region_tid || r.pos >= (int64_t)region.end || e <= (int64_t)region.start) continue;
+    }
+    std::string rows; bool skipped = false, sent = false;
+    const bool ok = extract_calls_of_record(bam, r, xo, collapse, edge, caller, ref_seqs, &rows, &skipped, &sent);
+    if (sent) n_sent++;
+    const bool done = xo.num_reads >= 0 && sent && n_sent >= xo.num_reads;   // process_records_to_chan: stop once N records went to the writer
+    if (!ok) { n_failed++; if (done) break; continue; }
+    if (done) { if (skipped) n_skipped++; else { n_used++; for (char c : rows) if (c == '\n') n_rows++; fputs(rows.c_str(), out); } break; }
     if (skipped) { n_skipped++; continue; }
     n_used++; for (char c : rows) if (c == '\n') n_rows++;
     fputs(rows.c_str(), out);
@@ -828,6 +850,8 @@ int main(int argc, char** argv) {
         if (a == "--pass-only" || a == "--pass") { xo.pass_only = true; continue; }
         if (a == "--no-headers") { xo.no_headers = true; continue; }
         if (a == "--kmer-size") { xo.kmer_size = std::stoul(val()); continue; }
+        if (a == "--num-reads") { xo.num_reads = std::stol(val()); continue; }
+        if (a == "--ignore-index") { xo.ignore_index = true; continue; }
         if (a == "--force") continue;
       }
       if (o.sample_probs_cmd) {

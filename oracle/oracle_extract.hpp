@@ -15,6 +15,7 @@
 // reference's FxHashMap<(usize, Strand, DnaBase)> iteration — here: positive mod strand first.
 #pragma once
 #include <algorithm>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -64,6 +65,10 @@ struct ExtractOptions {
   std::string in_bam, out_tsv, ref_fasta;
   bool allow_non_primary = false, mapped_only = false, pass_only = false, no_headers = false;
   size_t kmer_size = 5;
+  // round 6: --num-reads (the serial path's "first N records", util.rs:519-575), --ignore-index, --include-bed (ReferencePositionFilter::keep,
+  // util.rs:44-69: the BED is asked with the REFERENCE strand of the mod; rows without a reference position go), --region (util.rs:126-160)
+  long num_reads = -1; bool ignore_index = false;
+  std::function<bool(int32_t, uint64_t, bool /*reference mod strand is '-'*/)> include;   // empty: no --include-bed
 };
 
 struct ModProfileRow {   // ModProfile (read_ids_to_base_mod_probs.rs:381-397)
@@ -76,9 +81,10 @@ static inline const char* extract_calls_header() {
 }
 
 // one record -> its rows.  Returns false when the record counts as failed (tag / CIGAR error).
+// *sent: the record reached process_record (what --num-reads counts: TrackingModRecordIter yielded it and it was not an unmapped record under --mapped-only)
 static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& r, const ExtractOptions& o, const CollapseMethod& collapse, const EdgeFilter& edge,
-                                           const ThresholdCaller& caller, const std::map<std::string, std::string>& ref_seqs, std::string* out, bool* skipped) {
-  *skipped = false;
+                                           const ThresholdCaller& caller, const std::map<std::string, std::string>& ref_seqs, std::string* out, bool* skipped, bool* sent = nullptr) {
+  *skipped = false; if (sent) *sent = false;
   const bool not_primary = (r.flag & (2048 | 256 | 1024)) != 0;                     // record_is_not_primary (util.rs:405-407)
   if (not_primary && !o.allow_non_primary) { *skipped = true; return true; }
   if (r.l_seq == 0) return false;
@@ -87,6 +93,7 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
   if (info.is_empty()) { *skipped = true; return true; }
   const bool unmapped = (r.flag & 4) != 0;
   if (unmapped && o.mapped_only) { *skipped = true; return true; }
+  if (sent) *sent = true;
   const bool rev = r.is_reverse();
   const size_t L = (size_t)r.l_seq;
   // get_soft_clipped (803-824)
@@ -128,8 +135,13 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
     }
   }
   std::stable_sort(prof.begin(), prof.end(), [&](const ModProfileRow& a, const ModProfileRow& b) { return rev ? a.query_position > b.query_position : a.query_position < b.query_position; });
-  // filter_read_base_mod_probs with --mapped-only: profiles without a reference position go
-  if (o.mapped_only) { std::vector<ModProfileRow> k; for (auto& p : prof) if (!unmapped && p.ref_position >= 0) k.push_back(p); prof.swap(k); }
+  // filter_read_base_mod_probs (util.rs:71-124): a profile with a reference position is asked of the BED (reference strand of the mod); one
+  // without goes under --mapped-only and under --include-bed (load_regions: "specifying include-only BED outputs only mapped sites")
+  if (o.mapped_only || o.include) {
+    std::vector<ModProfileRow> k;
+    for (auto& p : prof) { if (unmapped || p.ref_position < 0) continue; if (o.include && !o.include(r.tid, (uint64_t)p.ref_position, (p.strand != 0) != rev)) continue; k.push_back(p); }
+    prof.swap(k);
+  }
   if (prof.empty()) { *skipped = true; return true; }
   // iter_profiles: secondary / supplementary records only report what lies inside the alignment
   auto within = [&](size_t qp) { return L >= clip_end && qp >= clip_start && qp < L - clip_end; };

@@ -29,14 +29,21 @@ FLAG_SETS = [
     ["--allow-non-primary", "--no-filtering", "--ref", "{fa}"],
     ["-p", "0.2", "--ref", "{fa}"],
     [],
+    # round 6: --include-bed / --region / --num-reads / --ignore-index (src/extract/subcommand.rs:540-560, util.rs:126-160, 329-575)
+    ["--include-bed", "{bed}", "--no-filtering"],
+    ["--region", "ctgA:2000-7000", "--filter-threshold", "0.7"],            # indexed input: the records overlapping the region
+    ["--region", "ctgA:2000-7000", "--ignore-index", "--no-filtering"],     # serial scan: the region only steers the estimate
+    ["--num-reads", "57", "--ignore-index", "--no-filtering"],              # the first 57 records that reach process_record
+    ["--num-reads", "40", "--no-filtering"],                                # indexed: the sampling schedule — refused by both
+    ["--include-bed", "{bed}", "--region", "ctgA", "-p", "0.3", "--mapped-only"],   # estimate under BED + region
 ]
 
 
 @pytest.mark.parametrize("profile", ["m", "hm_comb", "hm_split", "hm_split_diff", "hma", "implicit", "default", "nbase", "chebi", "mixed"])
 def test_extract_calls_fuzz_vs_oracle(oracle_bin, tmp_path, profile):
-    bam, fa, bed = Fuzz(900, profile=profile, n_reads=300).write(str(tmp_path / "fz"))
+    bam, fa, bed = Fuzz(900, profile=profile, n_reads=300).write(str(tmp_path / "fz"), bed=True)
     for fi, fl in enumerate(FLAG_SETS):
-        flags = [f.format(fa=fa) for f in fl]
+        flags = [f.format(fa=fa, bed=bed) for f in fl]
         dev, ora = str(tmp_path / ("dev%d.tsv" % fi)), str(tmp_path / ("ora%d.tsv" % fi))
         p = subprocess.run([oracle_bin, "extract-calls", bam, ora] + flags, capture_output=True, text=True)
         try:
@@ -52,4 +59,4 @@ def test_extract_calls_fuzz_vs_oracle(oracle_bin, tmp_path, profile):
         for i in range(max(len(a), len(b))):
             x, y = (a[i] if i < len(a) else "<none>"), (b[i] if i < len(b) else "<none>")
             assert x == y, "profile %s flags %s row %d differs\n device: %s\n oracle: %s (%d vs %d rows)" % (profile, flags, i, x, y, len(a), len(b))
-        assert len(a) > 1
+        assert len(a) > 1 or "--include-bed" in flags
