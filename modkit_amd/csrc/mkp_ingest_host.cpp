@@ -156,7 +156,14 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
           while (got < pc.n) { const ssize_t r = ::pread(fd, dst + got, pc.n - got, (off_t)(pc.file_off + got)); if (r <= 0) { read_bad = true; return; } got += (size_t)r; }
         });
         if (read_bad) throw Error(MKP_E_IO, "read error on " + bam.path());
-        for (size_t k = 0; k < n; k++) ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, pieces[p0 + k].n, hipMemcpyHostToDevice, d->up_stream), "H2D");
+        // one copy per run of pieces that lie back to back in the staging half AND in the window (a whole round, for a window of one file range):
+        // 2 MiB copies do not reach the link's rate, 32 MiB ones do
+        for (size_t k = 0; k < n;) {
+          size_t k1 = k + 1, bytes = pieces[p0 + k].n;
+          while (k1 < n && pieces[p0 + k1 - 1].n == mkp_dev_ingest::kPiece && pieces[p0 + k1].z_off == pieces[p0 + k1 - 1].z_off + mkp_dev_ingest::kPiece) { bytes += pieces[p0 + k1].n; k1++; }
+          ok(hipMemcpyAsync(d->zin.as<uint8_t>() + pieces[p0 + k].z_off, base + k * mkp_dev_ingest::kPiece, bytes, hipMemcpyHostToDevice, d->up_stream), "H2D");
+          k = k1;
+        }
         ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
         if ((round + 1) % stage_rounds == 0 && (round + 1) / stage_rounds < n_stages) {
           const size_t j = (round + 1) / stage_rounds - 1;
