@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)  # the short run the --pmc passes profile
     ap.add_argument("--tile", type=int, default=0, help="experiments: reference positions per accumulate tile (0 = the library's plan)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl", help="nccl (= RCCL over xGMI, one GPU per rank) or gloo (tests: several ranks may share a GPU)")
+    ap.add_argument("--no-full-data", action="store_true", help="c4 / chr1: skip the extra -f 1.0 run (and, with --cpu-whole, the oracle's)")
     ap.add_argument("--skip-e2e", action="store_true", help="profiling runs: skip the sharded end-to-end pass so that every kernel launch is the full-size one the timed region repeats")
     a = ap.parse_args()
     if a.skip_e2e or a.inner:
@@ -372,7 +373,7 @@ def main():
         value = total_positions / (ms_per_step * 1e-3)
         extra_cfg = {"genome_scale": a.genome_scale, "shards": int(rep.n_shards), "timing": "multi-shard workload: value = positions / device kernel time summed over the shards of one pass (HIP events inside the library, mean over the timed passes), NOT a wall-clock bracket; walls are in tiers.end_to_end",
                      "pass_wall_ms_mean": sum(walls) / max(1, len(walls)), "kernel_ms_last_shard": {"decode": st.decode_kernel_ms, "pileup": st.pileup_kernel_ms, "gather": st.gather_kernel_ms}}
-        if a.workload in ("c4", "chr1"):   # the full-data percentile (-f 1.0) next to the default sampled threshold
+        if a.workload in ("c4", "chr1") and not a.no_full_data:   # the full-data percentile (-f 1.0) next to the default sampled threshold
             rf = run_subcommand(ctx, out_bed + ".f1", ["-f", "1.0"])
             extra_cfg["full_data_threshold_run"] = {"flag": "-f 1.0", "total_ms": rf.total_ms, "threshold_ms": rf.threshold_ms, "thresholds": {"ACGT"[i]: float(rf.threshold[i]) for i in range(4) if rf.has_threshold[i]}, "rows": int(rf.n_rows)}
         rep1, elapsed = rep, ms_per_step * 1e-3 * a.steps

@@ -183,8 +183,10 @@ int mkp_shard_begin(mkp_ctx* ctx, const mkp_shard* shard);
 int mkp_shard_add_records(mkp_ctx* ctx, const mkp_record* recs, uint32_t n);
 /* Optional, between begin and run: the ascending start positions of the reference's intervals inside the shard (the last one ends with
  * the window).  The reference keeps one read cache per interval, keyed by read NAME (src/read_cache.rs:28-35): two kept records with one
- * name interfere only when they overlap a common interval — that case is refused (MKP_E_UNSUPPORTED); mates / split alignments lying
- * in different intervals are independent reads.  Without this call the whole shard counts as one interval. */
+ * name interfere only when they overlap a common interval — there the record asked about first owns the name and the later ones are
+ * answered from its calls (get_mod_call, src/read_cache.rs:232-297), which the library reproduces (round 6; refused before); mates / split
+ * alignments lying in different intervals are independent reads.  Without this call the whole shard counts as one interval.  Still
+ * MKP_E_UNSUPPORTED: pileup-hemi with such records, and a record whose owners in different intervals disagree in status or codes. */
 int mkp_shard_set_intervals(mkp_ctx* ctx, const uint32_t* interval_starts, uint32_t n_intervals);
 int mkp_shard_run(mkp_ctx* ctx, mkp_rows* out);
 
