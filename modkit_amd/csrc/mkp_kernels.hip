@@ -1110,8 +1110,15 @@ template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECO
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<false>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 1>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast2(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 2>(DECODE_PASS); }
-extern "C" __global__ void __launch_bounds__(256) mkp_decode_sparse1(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 1>(DECODE_PASS); }
-extern "C" __global__ void __launch_bounds__(256) mkp_decode_sparse2(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 2>(DECODE_PASS); }
+// Seven waves per SIMD for the SPARSE event decoders (72 VGPRs, 94 SGPRs: the scalar file admits seven at <= 96, MI355X_MICROARCH.md
+// "Residency"; left alone the compiler takes 77 / 85 VGPRs and 106 SGPRs = six / five waves): C2 decode 0.509 -> 0.481 ms, hemi decode
+// 2.40 -> 2.28 ms; eight waves spill (0.57 / 2.60).  A/B on one box, tools/dbg/ab.sh.
+#ifndef MKP_SPARSE_WAVES
+#define MKP_SPARSE_WAVES 7
+#endif
+#define MKP_SPARSE_LB __launch_bounds__(256, MKP_SPARSE_WAVES)
+extern "C" __global__ void MKP_SPARSE_LB mkp_decode_sparse1(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 1>(DECODE_PASS); }
+extern "C" __global__ void MKP_SPARSE_LB mkp_decode_sparse2(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 2>(DECODE_PASS); }
 // the same walks in threshold-sampling mode (reads_sampler / thresholds.rs:121-159): separate kernels so profiles keep the two apart
 extern "C" __global__ void __launch_bounds__(256) mkp_sample_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<true>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_sample_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<true, 1>(DECODE_PASS); }
