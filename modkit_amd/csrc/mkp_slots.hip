@@ -493,14 +493,20 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
 // (MI355X_MICROARCH.md, "Residency and cooperative launch"), so the 105 the compiler takes when left alone admit six waves per SIMD whatever
 // the LDS and VGPR budgets say (the compiler's own occupancy figure says eight).  The short-read kernel is capped at 80 — eight waves; the
 // spilled scalars cost ~26 v_readlane / v_writelane per slot batch (+7 % VALU) against +33 % resident waves: 0.75 -> 0.70 ms on C3
-// (A/B on one box: tools/dbg/ab.sh, MKP_DECODE_SGPRS=96 gives seven waves and 0.705).  The long-read kernel keeps its 85 VGPRs (five waves).
+// (A/B on one box: tools/dbg/ab.sh, MKP_DECODE_SGPRS=96 gives seven waves and 0.705).  The long-read kernel (several slot windows per read,
+// 106 SGPRs / 79 VGPRs left alone: six waves) is bounded to seven waves — 94 SGPRs, 72 VGPRs, 12 B of scratch: C3 decode 0.694 -> 0.682 ms on
+// one box; eight waves (MKP_LONG_WAVES=8) spills enough to lose: 0.725.
 #ifndef MKP_DECODE_SGPRS
 #define MKP_DECODE_SGPRS 80
 #endif
-#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __VA_ARGS__ __launch_bounds__(256) NAME(FUSED_PARAMS(MkpRunParams)) { \
+#ifndef MKP_LONG_WAVES
+#define MKP_LONG_WAVES 7
+#endif
+#define MKP_LONG_LB __launch_bounds__(256, MKP_LONG_WAVES)
+#define MKP_SLOT_KERNEL(NAME, MULTI, ...) extern "C" __global__ void __VA_ARGS__ NAME(FUSED_PARAMS(MkpRunParams)) { \
     __shared__ __attribute__((aligned(16))) SlotLds lds_all[4]; decode_slots_body<MULTI>(FUSED_PASS, lds_all); }
-MKP_SLOT_KERNEL(mkp_decode_slots, false, __attribute__((amdgpu_num_sgpr(MKP_DECODE_SGPRS))))
-MKP_SLOT_KERNEL(mkp_decode_slots_long, true)
+MKP_SLOT_KERNEL(mkp_decode_slots, false, __attribute__((amdgpu_num_sgpr(MKP_DECODE_SGPRS))) __launch_bounds__(256))
+MKP_SLOT_KERNEL(mkp_decode_slots_long, true, MKP_LONG_LB)
 
 // ----------------------------------------------------------------------------------------------------------------------
 // mkp_cover_reads: coverage features of the reads the event-producing decode kernels handled, with their call events merged in.
