@@ -118,9 +118,12 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   std::lock_guard<std::mutex> lock(d->mu);
   auto t0 = std::chrono::steady_clock::now(); const double wait_ms = std::chrono::duration<double, std::milli>(t0 - t_lock).count(), alloc0 = mkp_tl_alloc_ms();
   std::unique_ptr<DevShard> out(new DevShard());
+  static const bool trace_laps = getenv("MKP_TRACE_PLAN") != nullptr; std::string laps; auto t_lap = t0;
+  auto lap = [&](const char* what) { if (trace_laps) { auto now = std::chrono::steady_clock::now(); char b[96]; snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::milli>(now - t_lap).count()); laps += b; t_lap = now; } };
   ShardHost& S = out->S; S.tid = (int32_t)tid; S.dev_packed = true;
   BamSource::IngestPlan plan; bam.ingest_ranges(tid, parts, &plan);
   if (plan.ranges.empty()) return out;   // nothing under the region: an empty shard
+  lap("ranges");
   auto ok = [](hipError_t e, const char* what) { if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string("device ingest: ") + what + ": " + hipGetErrorString(e)); };
   ok(hipSetDevice(d->device), "hipSetDevice");
   // ---- the compressed ranges go up piece by piece — pread into page-locked staging on all cores, async H2D behind them — on a helper
@@ -135,6 +138,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     pieces.push_back({plan.ranges[r].file_off + o, zbase[r] + o, (size_t)std::min<uint64_t>(piece_bytes, plan.ranges[r].file_len - o)});
   d->stage.ensure(2 * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece);
   const int fd = bam.fd();
+  lap("zin+staging");
   std::unique_ptr<Error> up_err; double up_ms = 0;
   // upload stages (the staged path below): stage j = rounds [j * kStageRounds, (j + 1) * kStageRounds); stage_end_z[j] = where its bytes end in zin
   const size_t n_rounds = (pieces.size() + mkp_dev_ingest::kSlots - 1) / mkp_dev_ingest::kSlots, n_stages = std::max<size_t>(1, (n_rounds + stage_rounds - 1) / stage_rounds);
@@ -197,6 +201,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     struct Drain { mkp_dev_ingest* d; int n = std::uncaught_exceptions(); ~Drain() { if (std::uncaught_exceptions() > n) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->crc_stream); } } } drain{d};   // (whatever leaves this block by exception must not leave kernels reading buffers the next ingest rewrites)
     std::vector<BamSource::IngestChain> chains; bam.ingest_chains(plan, &chains);
     const size_t nc = chains.size();
+    lap("chains");
     if (nc > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF chains; use smaller shards");
     std::vector<MkpZChain> zc(nc); std::vector<size_t> stage_c0(n_stages + 1, nc);
     { size_t j = 0; stage_c0[0] = 0;
@@ -207,6 +212,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
         while (j + 1 < n_stages && zend > stage_end_z[j]) { j++; stage_c0[j] = i; } }
       for (size_t k = j + 1; k <= n_stages; k++) stage_c0[k] = nc; }
     out->ms_plan = ms_since(t0);
+    lap("chain table");
     // the window's capacity as the layout kernel enforces it: a block that would end behind it gets no room at all (out_len 0: the inflate and
     // the CRC of its stage touch nothing), the overflow bit goes up, and the stages after it only build their tables
     const uint64_t raw_cap = g_tune.raw_cap ? g_tune.raw_cap : std::max<uint64_t>(d->raw.cap, plan.comp_total * 6 + (64ull << 20));
@@ -225,6 +231,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
       if (keep) ok(hipMemcpy(nb.p, b.p, keep, hipMemcpyDeviceToDevice), "D2D"); b.release(); b = nb; nb.p = nullptr; nb.cap = 0; };
     size_t blkbase = 0; std::vector<uint32_t> stage_nblk(n_stages, 0);
     t_inf_staged = std::chrono::steady_clock::now();
+    lap("buffers");
     for (size_t j = 0; j < n_stages; j++) {
       { std::unique_lock<std::mutex> lk(st_mu); st_cv.wait(lk, [&] { return stages_issued > j || up_finished; }); }
       if (up_err) break;
@@ -255,7 +262,9 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
       }
       blkbase += nblk;
     }
+    lap("stages issued");
     uploader.join();
+    lap("uploader joined");
     if (up_err) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->crc_stream); throw *up_err; }
     out->ms_upload = up_ms;
     // the whole table comes back for the window layout the record kernels need (entry points of the chains) and for error reports
@@ -264,6 +273,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     d2h_copy(cbase.data(), d->seg_cnt.p, (nc + n_stages + 1) * 4, d->stream);
     ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 2, d->rawcur.p, 8, hipMemcpyDeviceToHost, d->stream), "D2H");
     ok(hipStreamSynchronize(d->stream), "inflate sync");
+    lap("tables back + sync");
     for (size_t j = 0; j < n_stages; j++) if (stage_nblk[j]) { float ms = 0; if (hipEventElapsedTime(&ms, d->tev[2 * j], d->tev[2 * j + 1]) == hipSuccess) staged_kernel_ms += ms; }
     const uint32_t zerr = h_small[0];
     if (zerr & (MKP_ZE_BAD | MKP_ZE_CHAIN)) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
@@ -275,6 +285,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
           for (uint32_t k = cb[i - c0]; k < cb[i - c0 + 1]; k++) { const MkpZBlk& z = zb[base + k]; parts[i].push_back({fo + (z.coff - zbs), z.hdr, z.clen, z.isize, 0}); } }
         base += stage_nblk[j]; } }
     bam.ingest_layout(&plan, chains, parts);
+    lap("layout");
     unsigned long long cur; memcpy(&cur, h_small + 2, 8);
     staged_done = !(zerr & MKP_ZE_RAWCAP) && cur == plan.raw_total && plan.blks.size() == blkbase;   // (a window larger than the estimate: inflated again below, into an exact allocation)
     if (!staged_done) { ok(hipStreamSynchronize(d->crc_stream), "sync"); if (!(zerr & MKP_ZE_RAWCAP)) throw Error(MKP_E_DEVICE, "internal: the device's window layout differs from the host's"); g_reinflated++; }
@@ -292,6 +303,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     blks[k] = {zbase[r] + (b.coff - plan.ranges[r].file_off) + b.hdr, b.doff, b.clen, b.isize};
   }
   const std::vector<MkpSeg> segs = mkp_plan_segments<MkpSeg>(plan);
+  lap("segments");
   d->zblk.ensure(nb * sizeof(BgzfBlk)); d->zstat.ensure(nb * 4 + 16); d->raw.ensure(plan.raw_total + 64); d->segs.ensure(ns * sizeof(MkpSeg)); d->seg_cnt.ensure((ns + 1) * 4); d->tot.ensure(sizeof(MkpIngestTotals));
   const size_t small_need = nb * sizeof(BgzfBlk) + ns * sizeof(MkpSeg) + 2 * (nb * 4 + 64) + sizeof(MkpIngestTotals) + 256;
   d->small.ensure(small_need + small_need / 4);
@@ -325,6 +337,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   ok(hipMemcpyAsync(tot, d->tot.p, sizeof(MkpIngestTotals), hipMemcpyDeviceToHost, d->stream), "D2H");
   ok(hipStreamSynchronize(d->stream), "inflate sync");
   out->ms_inflate = ms_since(t_inf);
+  lap("count+sync");
   { float kms = 0; if (hipEventElapsedTime(&kms, d->kev[0], d->kev[1]) == hipSuccess) out->ms_kernel = kms + staged_kernel_ms; }   // (staged: the stages' inflate launches + the chain kernels)
   bam.bytes_inflated += plan.raw_total; bam.bytes_inflated_device += plan.raw_total;
   // whatever leaves this function early must not leave the CRC kernel reading buffers the next ingest rewrites
@@ -386,6 +399,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   check(tot->err);
   corrupt();
   out->ms_pack = ms_since(t_scan);
+  lap("parse+pack");
   // ---- digest -> what the planner reads: layout ids (this shard's own table; mkp_internal_shard_attach maps them into the context's), flags
   auto t_dig = std::chrono::steady_clock::now();
   S.n_calls = tot->n_calls; S.dev_n_ranks = tot->n_calls; S.dev_n_ml = tot->n_ml_used;
@@ -426,10 +440,11 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   S.n_events_cap = ev_cap;
   std::vector<MkpRecInfo>().swap(out->info_host);
   out->ms_digest = ms_since(t_dig);
+  lap("digest");
   out->n_blocks = nb; out->n_segments = ns; out->n_records = n_all; out->raw_bytes = plan.raw_total; out->comp_bytes = plan.comp_total;
   out->ms_total = ms_since(t0); out->ms_alloc = mkp_tl_alloc_ms() - alloc0; out->ms_wait = wait_ms;
-  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u) in %zu window(s): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f (kernels %.1f) parse+pack %.1f digest %.1f total %.1f ms, of which hipMalloc/hipFree %.1f; began at %.1f\n",
+  if (getenv("MKP_TRACE_PLAN")) fprintf(stderr, "[mkpileup ingest] tid %u [%u, %u) in %zu window(s): %zu blocks, %zu segments, %u records (%u kept), %.1f MB -> %.1f MB; plan %.1f upload %.1f inflate+chains %.1f (kernels %.1f) parse+pack %.1f digest %.1f total %.1f ms, of which hipMalloc/hipFree %.1f; began at %.1f; laps:%s\n",
       tid, beg, end, parts.size(), nb, ns, n_all, n, plan.comp_total / 1e6, plan.raw_total / 1e6, out->ms_plan, out->ms_upload, out->ms_inflate, out->ms_kernel, out->ms_pack, out->ms_digest, out->ms_total, out->ms_alloc,
-      std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count() - 1000.0 * std::floor(std::chrono::duration<double>(t0.time_since_epoch()).count() / 100.0) * 100.0);
+      std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count() - 1000.0 * std::floor(std::chrono::duration<double>(t0.time_since_epoch()).count() / 100.0) * 100.0, laps.c_str());
   return out;
 }

@@ -127,6 +127,76 @@ __device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict
   }
 }
 
+// The fused decoders' form of the same window (mkp_decode_slots*: VALU-issue bound, 42 % of their vector instructions were this mapping).
+// The window's running values live in scalar registers (read back through readfirstlane after every update: left to itself the compiler
+// carries them as vectors and advances them with v_cndmask), "nothing loaded yet" is a window of no reference bases in front of op 0 —
+// no flag, no conditional advance — and the slot step maps its lanes in a pass of straight-line code, with the loop only behind it for
+// the steps that straddle windows (the one loop of refwin_map kept every window register twice and copied 14 of them per iteration).
+struct RefWinS { uint32_t c0, q_run, Rtot, Qtot; int32_t r_run; uint32_t re, m1, m2, m3, pk[4]; uint4 pref; };
+__device__ __forceinline__ void refwin_s_init(RefWinS& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start) {
+  w.c0 = 0u - 256u; w.q_run = 0; w.r_run = ref_start; w.Rtot = 0; w.Qtot = 0; w.re = w.m1 = w.m2 = w.m3 = 0; w.pk[0] = w.pk[1] = w.pk[2] = w.pk[3] = 0;
+  w.pref = cigar_quad(cg, n_cigar, 0);
+}
+// the next 256 ops; false behind the last op
+__device__ __forceinline__ bool refwin_s_next(RefWinS& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start) {
+  w.c0 = rfl(w.c0 + 256u); w.q_run = rfl(w.q_run + w.Qtot); w.r_run = (int32_t)rfl((uint32_t)w.r_run + w.Rtot);
+  if (w.c0 >= n_cigar) { w.Rtot = 0; w.Qtot = 0; return false; }
+  const uint4 v = w.pref;
+  w.pref = cigar_quad(cg, n_cigar, w.c0 + 256u);   // requested one window ahead
+  const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+  uint32_t ql[4], rl[4], kind[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t f = (uint32_t)(MKP_CIGAR_LUT >> ((wd[j] & 15u) << 2)), len = wd[j] >> 4;
+    ql[j] = len & (0u - (f & 1u)); rl[j] = len & (0u - ((f >> 1) & 1u)); kind[j] = (f >> 2) & 3u;
+  }
+  const uint32_t qsum = ql[0] + ql[1] + ql[2] + ql[3], rsum = rl[0] + rl[1] + rl[2] + rl[3];
+  uint32_t qe;
+  if (!__any((v.x | v.y | v.z | v.w) >= (128u << 4))) {   // ops shorter than 128: both running sums fit 16 bits, one scan serves both
+    const uint32_t sc = wave_incl_scan(qsum | (rsum << 16));
+    qe = sc & 0xffffu; w.re = sc >> 16;
+  } else { qe = wave_incl_scan(qsum); w.re = wave_incl_scan(rsum); }
+  w.Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63); w.Rtot = (uint32_t)__builtin_amdgcn_readlane((int)w.re, 63);
+  uint32_t qs = w.q_run + qe - qsum, rs = w.re - rsum;   // query offset / window-relative reference offset of the lane's first op
+  const int32_t rbase = w.r_run - ref_start;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    w.pk[j] = ((uint32_t)((int32_t)qs - (rbase + (int32_t)rs)) << 2) | kind[j];
+    qs += ql[j]; rs += rl[j];
+    if (j == 0) w.m1 = rs; else if (j == 1) w.m2 = rs; else if (j == 2) w.m3 = rs;
+  }
+  return true;
+}
+// one pass over the lanes whose position lies in the loaded window
+__device__ __forceinline__ void refwin_s_pass(const RefWinS& w, int32_t ref_start, bool& pending, int32_t p, uint32_t& kind, uint32_t& q) {
+  const uint32_t rel0 = (uint32_t)(p - w.r_run);
+  const bool inw = pending && rel0 < w.Rtot;
+  if (!__any(inw)) return;
+  const uint32_t rel = inw ? rel0 : 0u;
+  uint32_t probe = 31u << 2;
+#pragma unroll
+  for (int hstep = 16; hstep >= 1; hstep >>= 1) {
+    const uint32_t vv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)probe, (int)w.re);
+    probe = vv <= rel ? probe + 4u * (uint32_t)hstep : probe - 4u * (uint32_t)hstep;
+  }
+  { const uint32_t vv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)probe, (int)w.re); probe = vv <= rel ? probe + 4u : probe; }
+  const int oa = (int)(probe & 255u);
+  const uint32_t o_m1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m1), o_m2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m2), o_m3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m3);
+  const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[0]), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[1]);
+  const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[2]), o3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[3]);
+  const uint32_t pk = rel < o_m1 ? o0 : rel < o_m2 ? o1 : rel < o_m3 ? o2 : o3;
+  if (inw) { kind = pk & 3u; q = (uint32_t)((p - ref_start) + ((int32_t)pk >> 2)); pending = false; }
+}
+__device__ __forceinline__ void refwin_s_map(RefWinS& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start, bool valid, int32_t p, uint32_t* kind_out, uint32_t* q_out) {
+  bool pending = valid; uint32_t kind = 2u, q = 0u;
+  refwin_s_pass(w, ref_start, pending, p, kind, q);
+  while (__any(pending)) {
+    if (!refwin_s_next(w, cg, n_cigar, ref_start)) break;   // (cannot happen for positions inside the span)
+    refwin_s_pass(w, ref_start, pending, p, kind, q);
+  }
+  *kind_out = kind; *q_out = q;
+}
+
 // coverage feature of a slot: NoCall(base) on the alignment strand (the base complemented on '-': get_forward_read_base,
 // pileup/mod.rs:612-624), Delete, nothing on a ref-skip, and no feature for a base that is not A/C/G/T (864-874)
 __device__ __forceinline__ uint32_t cover_feature(uint32_t kind, uint32_t nib, uint32_t aln) {
@@ -184,8 +254,7 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
     return x;
   };
   uint32_t p_next = (uint32_t)lane < n_sl ? ldo<uint32_t>(spos, 4u * (uint32_t)lane) : 0u;
-  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0; rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
-  rw.pref = cigar_quad(cg, h.n_cigar, 0);
+  RefWinS rw; refwin_s_init(rw, cg, h.n_cigar, h.ref_start);
   uint4 xpre[4];   // stored bases [0, 8192): a 16-byte vector per lane and 2048 bases
 #pragma unroll
   for (int j = 0; j < 4; j++) xpre[j] = (have_calls && 2048u * (uint32_t)j < L) ? load4(4u * (64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
@@ -356,7 +425,7 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
 #ifdef MKP_DEBUG
     if (prm.debug_skip & 64u) { kind = 0u; q = min((uint32_t)(p - h.ref_start), L - 1u); } else   // ablation: no CIGAR mapping
 #endif
-    refwin_map(rw, cg, h.n_cigar, h.ref_start, valid, p, &kind, &q);
+    refwin_s_map(rw, cg, h.n_cigar, h.ref_start, valid, p, &kind, &q);
     const bool is_match = valid && kind == 0u && q < L;
     const uint32_t byte = is_match ? (uint32_t)ldo<uint8_t>(seqb, q >> 1) : 0u;
     uint32_t call_fb = 0xffffffffu;
