@@ -40,10 +40,17 @@ struct mkp_dev_ingest {
   int device = 0; hipStream_t stream = nullptr, up_stream = nullptr, crc_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr}, inf_done = nullptr, crc_done = nullptr;
   std::vector<hipEvent_t> stage_ev;      // upload stages: recorded on up_stream behind a stage's last copy
   std::vector<hipEvent_t> tev;           // timed pairs around the inflate launches of the stages
-  static constexpr size_t kStageRounds = 4;   // an upload stage = 4 rounds of kSlots pieces = 128 MiB: inflated while the next stage is on its way up
-  DevBuf ztab, rawcur;
-  static constexpr size_t kPiece = (size_t)2 << 20, kSlots = 16;   // 64 MiB page-locked in all (allocating it is part of a fresh context's first ingest)   // upload staging: two halves of kSlots pieces
+  hipStream_t inf_stream[1] = {nullptr};   // the stages' inflate launches: off the ingest stream, whose chain walks (and the host's one sync per stage) then never wait for an inflate.
+                                           // (Two such streams, launches alternating, ran two stages side by side at half speed each — the same 76 ms for the C3 file — and with the
+                                           //  process's seventh stream the chain walks began to queue behind inflate launches: 12 ms syncs.)
+  std::vector<hipEvent_t> lay_ev;        // a stage's tables are laid out (ingest stream) -> its inflate may start
+  static constexpr size_t kStageRounds = 0;   // most rounds a stage may take; 0 = whatever has been issued (tests cap it so that a few-MB BAM goes through several stages)
+  DevBuf rawcur;
+  Pinned ztab, chain_cnt;   // the staged path's block table and chain counts: written by the chain kernels straight into page-locked host memory (1.3 MB for a chr20 window) —
+                            // as copies at the end they waited 8-47 ms on a device busy inflating (round 6 trace); the layout kernel reads the table back over the link
+  static constexpr size_t kPiece = (size_t)1 << 20, kSlots = 16;   // upload staging: two halves of kSlots pieces, 32 MiB page-locked in all (allocating it is part of a fresh context's first ingest: 0.22 ms per MiB)
   Pinned stage, small;                                             // compressed bytes on their way up; tables up / totals + status down
+  Pinned chain_host;                                               // the staged path's chain table: the chain kernels read it where it lies (a copy would queue behind the upload's 32 MiB pieces)
   DevBuf zin, zblk, zstat, raw, segs, seg_cnt, rec_off, info, sz, extra, tot, dig, parts;
   std::mutex mu;                                                   // one ingest at a time per object
   std::mutex spare_mu; std::vector<DevBuf> spares;                 // buffers the contexts handed back (mkp_internal_ingest_recycle)
@@ -76,6 +83,7 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   const int prio_mid = (prio_lo + prio_hi) / 2 != prio_hi ? (prio_lo + prio_hi) / 2 : prio_hi;   // (below the contexts' own streams, above the uploads and the CRC)
   if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_mid) != hipSuccess || hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
       hipStreamCreateWithPriority(&d->crc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
+  for (auto& st : d->inf_stream) if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
   for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + chain kernels, for the trace)
@@ -86,12 +94,15 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
 void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig, &d->parts, &d->ztab, &d->rawcur}) b->release();
+  for (DevBuf* b : {&d->zin, &d->zblk, &d->zstat, &d->raw, &d->segs, &d->seg_cnt, &d->rec_off, &d->info, &d->sz, &d->extra, &d->tot, &d->dig, &d->parts, &d->rawcur}) b->release();
+  d->ztab.release(); d->chain_cnt.release();
   for (auto& e : d->stage_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : d->tev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : d->lay_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& st : d->inf_stream) if (st) (void)hipStreamDestroy(st);
   if (d->crc_stream) (void)hipStreamDestroy(d->crc_stream);
   for (auto& b : d->spares) b.release();
-  d->stage.release(); d->small.release();
+  d->stage.release(); d->small.release(); d->chain_host.release();
   for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
   if (d->up_done) (void)hipEventDestroy(d->up_done);
   for (auto& e : d->kev) if (e) (void)hipEventDestroy(e);
@@ -131,21 +142,27 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   std::vector<uint64_t> zbase(plan.ranges.size()); uint64_t zbytes = 0;
   for (size_t r = 0; r < plan.ranges.size(); r++) { zbase[r] = zbytes; zbytes += (plan.ranges[r].file_len + 63) & ~63ull; }
   d->zin.ensure(zbytes + 64);
+  lap("zin");
   struct Piece { uint64_t file_off, z_off; size_t n; };
   std::vector<Piece> pieces;
-  const size_t piece_bytes = g_tune.piece, stage_rounds = g_tune.stage_rounds;   // (kPiece / kStageRounds unless a test shrank them)
+  static const size_t env_rounds = getenv("MKP_STAGE_ROUNDS") ? strtoull(getenv("MKP_STAGE_ROUNDS"), nullptr, 10) : 0;   // (A/B runs)
+  const size_t piece_bytes = g_tune.piece, stage_rounds = env_rounds ? env_rounds : g_tune.stage_rounds;   // (kPiece / kStageRounds unless a test shrank them)
   for (size_t r = 0; r < plan.ranges.size(); r++) for (uint64_t o = 0; o < plan.ranges[r].file_len; o += piece_bytes)
     pieces.push_back({plan.ranges[r].file_off + o, zbase[r] + o, (size_t)std::min<uint64_t>(piece_bytes, plan.ranges[r].file_len - o)});
   d->stage.ensure(2 * mkp_dev_ingest::kSlots * mkp_dev_ingest::kPiece);
   const int fd = bam.fd();
   lap("zin+staging");
   std::unique_ptr<Error> up_err; double up_ms = 0;
-  // upload stages (the staged path below): stage j = rounds [j * kStageRounds, (j + 1) * kStageRounds); stage_end_z[j] = where its bytes end in zin
-  const size_t n_rounds = (pieces.size() + mkp_dev_ingest::kSlots - 1) / mkp_dev_ingest::kSlots, n_stages = std::max<size_t>(1, (n_rounds + stage_rounds - 1) / stage_rounds);
-  std::vector<uint64_t> stage_end_z(n_stages, zbytes);
-  for (size_t j = 0; j + 1 < n_stages; j++) { const size_t last = std::min(pieces.size(), (j + 1) * stage_rounds * mkp_dev_ingest::kSlots) - 1; stage_end_z[j] = pieces[last].z_off + pieces[last].n; }
-  while (d->stage_ev.size() < n_stages) { hipEvent_t e = nullptr; ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"); d->stage_ev.push_back(e); }
-  std::mutex st_mu; std::condition_variable st_cv; size_t stages_issued = 0; bool up_finished = false;   // (an event that has not been recorded yet does not hold a stream back: the consumer waits for the record call itself)
+  // The upload goes in ROUNDS of kSlots pieces (16 MiB), an event behind each.  The staged path below cuts its STAGES as it goes: a stage is
+  // every round that has been issued when the ingest thread gets to it — so the stages grow with what the upload delivered while the stages
+  // before were inflating (C3: 16, ~30, ~100, ~120, ~190, ~250 MiB ...).  An inflate launch takes whole multiples of one block's latency
+  // (4.4 ms with 4 096 one-wave workgroups resident), so few large launches beat many equal ones: seven 128 MiB stages took 77 ms of
+  // inflate for the C3 file, one launch of everything 58 — but only after the whole 30 ms upload.  `stage_rounds` caps a stage (tests).
+  const size_t n_rounds = (pieces.size() + mkp_dev_ingest::kSlots - 1) / mkp_dev_ingest::kSlots;
+  std::vector<uint64_t> round_end_z(n_rounds, zbytes);   // where a round's bytes end in zin
+  for (size_t r = 0; r + 1 < n_rounds; r++) { const size_t last = (r + 1) * mkp_dev_ingest::kSlots - 1; round_end_z[r] = pieces[last].z_off + pieces[last].n; }
+  while (d->stage_ev.size() < n_rounds) { hipEvent_t e = nullptr; ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"); d->stage_ev.push_back(e); }
+  std::mutex st_mu; std::condition_variable st_cv; size_t rounds_issued = 0; bool up_finished = false;   // (an event that has not been recorded yet does not hold a stream back: the consumer waits for the record call itself)
   std::thread uploader([&]() {
     auto t_up = std::chrono::steady_clock::now();
     try {
@@ -169,16 +186,12 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
           k = k1;
         }
         ok(hipEventRecord(d->slot_ev[half], d->up_stream), "event");
-        if ((round + 1) % stage_rounds == 0 && (round + 1) / stage_rounds < n_stages) {
-          const size_t j = (round + 1) / stage_rounds - 1;
-          ok(hipEventRecord(d->stage_ev[j], d->up_stream), "event");
-          { std::lock_guard<std::mutex> g(st_mu); stages_issued = j + 1; } st_cv.notify_all();
-        }
+        ok(hipEventRecord(d->stage_ev[round], d->up_stream), "event");
+        { std::lock_guard<std::mutex> g(st_mu); rounds_issued = round + 1; } st_cv.notify_all();
       }
-      ok(hipEventRecord(d->stage_ev[n_stages - 1], d->up_stream), "event");
       ok(hipEventRecord(d->up_done, d->up_stream), "event");
     } catch (const Error& e) { up_err.reset(new Error(e)); }
-    { std::lock_guard<std::mutex> g(st_mu); stages_issued = n_stages; up_finished = true; } st_cv.notify_all();
+    { std::lock_guard<std::mutex> g(st_mu); up_finished = true; } st_cv.notify_all();
     up_ms = ms_since(t_up);
   });
   // (whatever way this function is left: the uploader has stopped and the copies it queued out of the page-locked staging have landed — the
@@ -189,75 +202,95 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   // MKP_HOST_BLOCK_TABLE=1 keeps the host walk (A/B runs).
   static const bool host_table = getenv("MKP_HOST_BLOCK_TABLE") && !strcmp(getenv("MKP_HOST_BLOCK_TABLE"), "1");
   if (host_table) { bam.ingest_blocks(&plan); out->ms_plan = ms_since(t0); uploader.join(); if (up_err) throw *up_err; out->ms_upload = up_ms; }
-  bool staged_done = false; double staged_kernel_ms = 0; std::chrono::steady_clock::time_point t_inf_staged;
+  bool staged_done = false; double staged_kernel_ms = 0; std::chrono::steady_clock::time_point t_inf_staged; hipEvent_t last_inf[2] = {nullptr, nullptr}; size_t staged_stages = 0; std::vector<uint32_t> staged_nblk;
   if (!host_table) {
-    // ---- the STAGED path: the window goes up in stages of 128 MiB, and a stage's blocks are found, laid out and inflated while the next
-    // stage is still on its way (round 4: whole upload, then block table, then one inflate launch — the GPU idle for the 40-90 ms of the
+    // ---- the STAGED path: the window goes up in rounds of 16 MiB, cut into stages as they arrive (above), and a stage's blocks are found, laid out
+    // and inflated while the next stage is still on its way (round 4: whole upload, then block table, then one inflate launch — the GPU idle for the 40-90 ms of the
     // upload, the host idle for the inflate).  Per stage, on the ingest stream: wait for the stage's last copy; walk its chains
     // (count -> scan; ONE host sync for the block count, which sizes the launches); write its MkpZBlk entries; mkp_bgzf_layout turns them
     // into the inflate's table behind a device-side cursor of the inflated window; inflate; CRC on a stream of its own.  The inflated
     // size is not known before the last stage: the window buffer is sized at 6 x the compressed bytes and the layout kernel reports an
     // overflow, on which the whole window is inflated again into an exact allocation (below).
-    struct Drain { mkp_dev_ingest* d; int n = std::uncaught_exceptions(); ~Drain() { if (std::uncaught_exceptions() > n) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->crc_stream); } } } drain{d};   // (whatever leaves this block by exception must not leave kernels reading buffers the next ingest rewrites)
+    struct Drain { mkp_dev_ingest* d; int n = std::uncaught_exceptions(); ~Drain() { if (std::uncaught_exceptions() > n) { (void)hipStreamSynchronize(d->stream); for (auto& st : d->inf_stream) (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(d->crc_stream); } } } drain{d};   // (whatever leaves this block by exception must not leave kernels reading buffers the next ingest rewrites)
     std::vector<BamSource::IngestChain> chains; bam.ingest_chains(plan, &chains);
     const size_t nc = chains.size();
     lap("chains");
     if (nc > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF chains; use smaller shards");
-    std::vector<MkpZChain> zc(nc); std::vector<size_t> stage_c0(n_stages + 1, nc);
-    { size_t j = 0; stage_c0[0] = 0;
-      for (size_t i = 0; i < nc; i++) { const BamSource::IngestRange& rg = plan.ranges[chains[i].range]; const uint64_t zb = zbase[chains[i].range], fo = rg.file_off;
-        MkpZChain c; c.start = zb + (chains[i].start - fo); c.stop = chains[i].stop == UINT64_MAX ? ~0ull : zb + (chains[i].stop - fo); c.range_end = zb + rg.file_len;
-        c.ce = (rg.vend >> 16) >= fo ? zb + ((rg.vend >> 16) - fo) : 0; c.ue = (uint32_t)(rg.vend & 0xffff); c.pad = 0; zc[i] = c;
-        const uint64_t zend = c.stop == ~0ull ? c.range_end : std::min<uint64_t>(c.stop, c.range_end);   // the chain reads nothing at or behind this
-        while (j + 1 < n_stages && zend > stage_end_z[j]) { j++; stage_c0[j] = i; } }
-      for (size_t k = j + 1; k <= n_stages; k++) stage_c0[k] = nc; }
+    // the chain table is written into page-locked memory and read from there by the chain kernels (115 KB for a chr20 window): as a copy it
+    // waited on the copy engine behind the upload pieces already queued — 44 ms in which no stage could start (round 6 trace)
+    d->chain_host.ensure(std::max<size_t>(nc, 1) * sizeof(MkpZChain));
+    MkpZChain* zc = (MkpZChain*)d->chain_host.p; std::vector<uint64_t> chain_zend(nc);   // chain_zend: the chain reads nothing at or behind this
+    for (size_t i = 0; i < nc; i++) { const BamSource::IngestRange& rg = plan.ranges[chains[i].range]; const uint64_t zb = zbase[chains[i].range], fo = rg.file_off;
+      MkpZChain c; c.start = zb + (chains[i].start - fo); c.stop = chains[i].stop == UINT64_MAX ? ~0ull : zb + (chains[i].stop - fo); c.range_end = zb + rg.file_len;
+      c.ce = (rg.vend >> 16) >= fo ? zb + ((rg.vend >> 16) - fo) : 0; c.ue = (uint32_t)(rg.vend & 0xffff); c.pad = 0; zc[i] = c;
+      chain_zend[i] = c.stop == ~0ull ? c.range_end : std::min<uint64_t>(c.stop, c.range_end); }
+    std::vector<size_t> stage_c0(1, 0);   // stage j = chains [stage_c0[j], stage_c0[j + 1]): those that end inside the rounds the stage took
     out->ms_plan = ms_since(t0);
     lap("chain table");
     // the window's capacity as the layout kernel enforces it: a block that would end behind it gets no room at all (out_len 0: the inflate and
     // the CRC of its stage touch nothing), the overflow bit goes up, and the stages after it only build their tables
     const uint64_t raw_cap = g_tune.raw_cap ? g_tune.raw_cap : std::max<uint64_t>(d->raw.cap, plan.comp_total * 6 + (64ull << 20));
-    d->raw.ensure(raw_cap); d->segs.ensure(nc * sizeof(MkpZChain)); d->seg_cnt.ensure((nc + n_stages + 2) * 4); d->tot.ensure(sizeof(MkpIngestTotals)); d->rawcur.ensure(16);
+    d->raw.ensure(raw_cap); lap("raw window"); d->chain_cnt.ensure((nc + n_rounds + 2) * 4); d->tot.ensure(sizeof(MkpIngestTotals)); d->rawcur.ensure(16);
     d->small.ensure(4096);
     uint32_t* h_small = (uint32_t*)d->small.p;   // [0] error bits, [1] blocks of the stage; [2..3] the cursor of the inflated window (at the end)
-    while (d->tev.size() < 2 * n_stages) { hipEvent_t e = nullptr; ok(hipEventCreate(&e), "event"); d->tev.push_back(e); }
-    h2d_copy(d->segs.p, zc.data(), nc * sizeof(MkpZChain));   // (a temporary: through the library's page-locked staging, mkp_ctx.hpp)
+    auto stage_events = [&](size_t j) {   // (created as the stages come: their number is not known ahead)
+      while (d->tev.size() < 2 * (j + 1)) { hipEvent_t e = nullptr; ok(hipEventCreate(&e), "event"); d->tev.push_back(e); }
+      while (d->lay_ev.size() < j + 1) { hipEvent_t e = nullptr; ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event"); d->lay_ev.push_back(e); } };
+    lap("small buffers + events");   // (a temporary: through the library's page-locked staging, mkp_ctx.hpp)
     ok(hipMemsetAsync(d->tot.p, 0, sizeof(MkpIngestTotals), d->stream), "memset");
     ok(hipMemsetAsync(d->rawcur.p, 0, 16, d->stream), "memset");
     size_t blk_cap = std::max<size_t>({d->zblk.cap / sizeof(BgzfBlk), d->ztab.cap / sizeof(MkpZBlk), (size_t)(plan.comp_total / 8192 + 4096)});
     d->zblk.ensure(blk_cap * sizeof(BgzfBlk)); d->ztab.ensure(blk_cap * sizeof(MkpZBlk)); d->zstat.ensure(blk_cap * 4 + 16);
     blk_cap = std::min({d->zblk.cap / sizeof(BgzfBlk), d->ztab.cap / sizeof(MkpZBlk), (d->zstat.cap - 16) / 4});
     auto grow = [&](DevBuf& b, size_t need, size_t keep) {   // (a window of unusually small blocks: the tables grow, keeping what the stages before wrote)
-      DevBuf nb; nb.ensure(need); ok(hipStreamSynchronize(d->stream), "sync"); ok(hipStreamSynchronize(d->crc_stream), "sync");
+      DevBuf nb; nb.ensure(need); ok(hipStreamSynchronize(d->stream), "sync"); for (auto& st : d->inf_stream) ok(hipStreamSynchronize(st), "sync"); ok(hipStreamSynchronize(d->crc_stream), "sync");
       if (keep) ok(hipMemcpy(nb.p, b.p, keep, hipMemcpyDeviceToDevice), "D2D"); b.release(); b = nb; nb.p = nullptr; nb.cap = 0; };
-    size_t blkbase = 0; std::vector<uint32_t> stage_nblk(n_stages, 0);
+    size_t blkbase = 0; std::vector<uint32_t> stage_nblk; std::vector<hipEvent_t> inf_end; size_t r_done = 0;
     t_inf_staged = std::chrono::steady_clock::now();
     lap("buffers");
-    for (size_t j = 0; j < n_stages; j++) {
-      { std::unique_lock<std::mutex> lk(st_mu); st_cv.wait(lk, [&] { return stages_issued > j || up_finished; }); }
-      if (up_err) break;
-      ok(hipStreamWaitEvent(d->stream, d->stage_ev[j], 0), "wait for the upload stage");
-      const size_t c0 = stage_c0[j], c1 = stage_c0[j + 1], n = c1 - c0;
-      uint32_t* cnt = d->seg_cnt.as<uint32_t>() + c0 + j;   // the stage's counts -> offsets, its total behind them
-      ok(mkp_launch_bgzf_chain_count(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>() + c0, (uint32_t)n, cnt, d->tot.as<uint32_t>()), "block table launch");
+    for (size_t j = 0; r_done < n_rounds; j++) {
+      // pacing: a stage is cut when the one before it has inflated — cut earlier it would be a smaller one (with one stage queued behind the
+      // running one, MKP_STAGE_DEPTH=2, the C3 file took 5-6 launches and 73-76 ms of inflate; so: 4 launches, 66-70 ms, ~1 ms idle between them)
+      static const size_t depth = getenv("MKP_STAGE_DEPTH") ? std::max<size_t>(1, strtoull(getenv("MKP_STAGE_DEPTH"), nullptr, 10)) : 1;   // (A/B runs)
+      if (inf_end.size() >= depth) ok(hipEventSynchronize(inf_end[inf_end.size() - depth]), "stage pacing");
+      size_t r_now;
+      { std::unique_lock<std::mutex> lk(st_mu); st_cv.wait(lk, [&] { return rounds_issued > r_done || up_finished; }); r_now = rounds_issued; }
+      if (trace_laps) { char b[64]; snprintf(b, sizeof b, " [s%zu: rounds %zu-%zu, issued", j, r_done, r_now); lap(b); }
+      if (up_err || r_now <= r_done) break;   // (the uploader stopped early: its error is reported below)
+      if (stage_rounds && r_now - r_done > stage_rounds) r_now = r_done + stage_rounds;
+      ok(hipStreamWaitEvent(d->stream, d->stage_ev[r_now - 1], 0), "wait for the upload rounds");
+      stage_events(j);
+      const uint64_t z_end = round_end_z[r_now - 1];
+      const size_t c0 = stage_c0[j]; size_t c1 = c0; while (c1 < nc && (r_now == n_rounds || chain_zend[c1] <= z_end)) c1++;
+      stage_c0.push_back(c1); stage_nblk.push_back(0); r_done = r_now;
+      const size_t n = c1 - c0;
+      uint32_t* cnt = (uint32_t*)d->chain_cnt.p + c0 + j;   // the stage's counts -> offsets, its total behind them
+      ok(mkp_launch_bgzf_chain_count(d->stream, d->zin.as<uint8_t>(), zc + c0, (uint32_t)n, cnt, d->tot.as<uint32_t>()), "block table launch");
       ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 1, cnt + n, 4, hipMemcpyDeviceToHost, d->stream), "D2H");
       ok(hipStreamSynchronize(d->stream), "block table sync");
+      lap("count");
       if (h_small[0] & (MKP_ZE_BAD | MKP_ZE_CHAIN)) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
       const bool outgrown = (h_small[0] & MKP_ZE_RAWCAP) != 0;   // an earlier stage ran out of window: the rest is inflated below, into an exact allocation
       const uint32_t nblk = h_small[1]; stage_nblk[j] = nblk;
       if (blkbase + nblk > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard window holds too many BGZF blocks; use smaller shards");
       if (blkbase + nblk > blk_cap) { const size_t want = std::max<size_t>(2 * blk_cap, blkbase + nblk + 4096);
-        grow(d->zblk, want * sizeof(BgzfBlk), blkbase * sizeof(BgzfBlk)); grow(d->ztab, want * sizeof(MkpZBlk), blkbase * sizeof(MkpZBlk)); grow(d->zstat, want * 4 + 16, blkbase * 4); blk_cap = want; }
+        grow(d->zblk, want * sizeof(BgzfBlk), blkbase * sizeof(BgzfBlk)); { Pinned nt; nt.ensure(want * sizeof(MkpZBlk)); ok(hipStreamSynchronize(d->stream), "sync"); if (blkbase) memcpy(nt.p, d->ztab.p, blkbase * sizeof(MkpZBlk)); d->ztab.release(); d->ztab = nt; } grow(d->zstat, want * 4 + 16, blkbase * 4); blk_cap = want; }
       if (!nblk) continue;
-      MkpZBlk* ztab = d->ztab.as<MkpZBlk>() + blkbase; BgzfBlk* zblk = d->zblk.as<BgzfBlk>() + blkbase; uint32_t* zst = d->zstat.as<uint32_t>() + blkbase;
-      ok(mkp_launch_bgzf_chain_write(d->stream, d->zin.as<uint8_t>(), d->segs.as<MkpZChain>() + c0, (uint32_t)n, cnt, nblk, ztab, d->tot.as<uint32_t>()), "block table launch");
+      MkpZBlk* ztab = (MkpZBlk*)d->ztab.p + blkbase; BgzfBlk* zblk = d->zblk.as<BgzfBlk>() + blkbase; uint32_t* zst = d->zstat.as<uint32_t>() + blkbase;
+      ok(mkp_launch_bgzf_chain_write(d->stream, d->zin.as<uint8_t>(), zc + c0, (uint32_t)n, cnt, nblk, ztab, d->tot.as<uint32_t>()), "block table launch");
       ok(mkp_launch_bgzf_layout(d->stream, ztab, nblk, d->rawcur.as<unsigned long long>(), raw_cap, zblk, d->tot.as<uint32_t>()), "layout launch");
       ok(hipMemsetAsync(zst, 0xff, (size_t)nblk * 4, d->stream), "memset");
-      ok(hipEventRecord(d->tev[2 * j], d->stream), "event");
-      if (!outgrown) ok(mkp_launch_inflate_auto(d->stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "inflate launch");
-      ok(hipEventRecord(d->tev[2 * j + 1], d->stream), "event");
+      // the inflate itself goes to a stream of its own: the ingest stream stays free for the next stage's chain walk, the host's one sync per
+      // stage no longer waits for an inflate, and the tables come back (and the window is laid out) while the last stages still inflate
+      hipStream_t inf = d->inf_stream[0];
+      ok(hipEventRecord(d->lay_ev[j], d->stream), "event");
+      ok(hipStreamWaitEvent(inf, d->lay_ev[j], 0), "wait for the stage's tables");
+      ok(hipEventRecord(d->tev[2 * j], inf), "event");
+      if (!outgrown) ok(mkp_launch_inflate_auto(inf, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "inflate launch");
+      ok(hipEventRecord(d->tev[2 * j + 1], inf), "event");
+      last_inf[0] = d->tev[2 * j + 1]; inf_end.push_back(d->tev[2 * j + 1]);
       if (!outgrown) {
-        ok(hipEventRecord(d->inf_done, d->stream), "event");
-        ok(hipStreamWaitEvent(d->crc_stream, d->inf_done, 0), "wait for the inflate");
+        ok(hipStreamWaitEvent(d->crc_stream, d->tev[2 * j + 1], 0), "wait for the inflate");
         ok(mkp_launch_crc32(d->crc_stream, d->zin.as<uint8_t>(), zblk, nblk, d->raw.as<uint8_t>(), zst), "crc launch");
       }
       blkbase += nblk;
@@ -265,22 +298,21 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     lap("stages issued");
     uploader.join();
     lap("uploader joined");
-    if (up_err) { (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->crc_stream); throw *up_err; }
+    if (up_err) { (void)hipStreamSynchronize(d->stream); for (auto& st : d->inf_stream) (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(d->crc_stream); throw *up_err; }
     out->ms_upload = up_ms;
     // the whole table comes back for the window layout the record kernels need (entry points of the chains) and for error reports
-    std::vector<MkpZBlk> zb(blkbase); std::vector<uint32_t> cbase(nc + n_stages + 2);
-    d2h_copy(zb.data(), d->ztab.p, blkbase * sizeof(MkpZBlk), d->stream);
-    d2h_copy(cbase.data(), d->seg_cnt.p, (nc + n_stages + 1) * 4, d->stream);
+    const MkpZBlk* zb = (const MkpZBlk*)d->ztab.p; const uint32_t* cbase_all = (const uint32_t*)d->chain_cnt.p;   // (complete behind the sync below)
     ok(hipMemcpyAsync(h_small, d->tot.p, 4, hipMemcpyDeviceToHost, d->stream), "D2H"); ok(hipMemcpyAsync(h_small + 2, d->rawcur.p, 8, hipMemcpyDeviceToHost, d->stream), "D2H");
     ok(hipStreamSynchronize(d->stream), "inflate sync");
     lap("tables back + sync");
-    for (size_t j = 0; j < n_stages; j++) if (stage_nblk[j]) { float ms = 0; if (hipEventElapsedTime(&ms, d->tev[2 * j], d->tev[2 * j + 1]) == hipSuccess) staged_kernel_ms += ms; }
+    const size_t n_stages = stage_nblk.size();
+    staged_stages = n_stages; staged_nblk = stage_nblk;
     const uint32_t zerr = h_small[0];
     if (zerr & (MKP_ZE_BAD | MKP_ZE_CHAIN)) throw Error(MKP_E_IO, "bad BGZF block in " + bam.path() + " (or the index does not match the file)");
     if (zerr & MKP_ZE_ISIZE) throw Error(MKP_E_IO, "BGZF block inflates to more than 64 KiB in " + bam.path());
     std::vector<std::vector<BamSource::IngestBlk>> parts(nc);
     { size_t base = 0;
-      for (size_t j = 0; j < n_stages; j++) { const size_t c0 = stage_c0[j], c1 = stage_c0[j + 1]; const uint32_t* cb = cbase.data() + c0 + j;
+      for (size_t j = 0; j < n_stages; j++) { const size_t c0 = stage_c0[j], c1 = stage_c0[j + 1]; const uint32_t* cb = cbase_all + c0 + j;
         for (size_t i = c0; i < c1; i++) { const uint64_t zbs = zbase[chains[i].range], fo = plan.ranges[chains[i].range].file_off; parts[i].reserve(cb[i - c0 + 1] - cb[i - c0]);
           for (uint32_t k = cb[i - c0]; k < cb[i - c0 + 1]; k++) { const MkpZBlk& z = zb[base + k]; parts[i].push_back({fo + (z.coff - zbs), z.hdr, z.clen, z.isize, 0}); } }
         base += stage_nblk[j]; } }
@@ -288,7 +320,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     lap("layout");
     unsigned long long cur; memcpy(&cur, h_small + 2, 8);
     staged_done = !(zerr & MKP_ZE_RAWCAP) && cur == plan.raw_total && plan.blks.size() == blkbase;   // (a window larger than the estimate: inflated again below, into an exact allocation)
-    if (!staged_done) { ok(hipStreamSynchronize(d->crc_stream), "sync"); if (!(zerr & MKP_ZE_RAWCAP)) throw Error(MKP_E_DEVICE, "internal: the device's window layout differs from the host's"); g_reinflated++; }
+    if (!staged_done) { for (auto& st : d->inf_stream) ok(hipStreamSynchronize(st), "sync"); ok(hipStreamSynchronize(d->crc_stream), "sync"); if (!(zerr & MKP_ZE_RAWCAP)) throw Error(MKP_E_DEVICE, "internal: the device's window layout differs from the host's"); g_reinflated++; }
     else g_staged_windows++;
   }
   bam.bytes_read += plan.comp_total;
@@ -324,7 +356,11 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
     ok(hipEventRecord(d->inf_done, d->stream), "event");
     ok(hipStreamWaitEvent(d->crc_stream, d->inf_done, 0), "wait for the inflate");
     ok(mkp_launch_crc32(d->crc_stream, d->zin.as<uint8_t>(), d->zblk.p, (uint32_t)nb, d->raw.as<uint8_t>(), d->zstat.as<uint32_t>()), "crc launch");
-  } else ok(hipEventRecord(d->kev[0], d->stream), "event");
+  } else {   // the record kernels read what the stages' inflate launches wrote
+    (void)copy_stage();   // (this thread's page-locked copy staging, needed for the digest: allocated while the last stages inflate)
+    for (hipEvent_t e : last_inf) if (e) ok(hipStreamWaitEvent(d->stream, e, 0), "wait for the inflate");
+    ok(hipEventRecord(d->kev[0], d->stream), "event");
+  }
   // ---- record chains
   MkpIngestParams P; memset(&P, 0, sizeof(P));
   P.raw_len = plan.raw_total; P.tid = (int32_t)tid; P.beg = (int32_t)std::min<uint32_t>(beg, 0x7fffffffu); P.end = (int32_t)std::min<uint32_t>(end, 0x7fffffffu); P.n_ref = (int32_t)bam.ref_names.size(); P.n_seg = (uint32_t)ns;
@@ -338,6 +374,12 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   ok(hipStreamSynchronize(d->stream), "inflate sync");
   out->ms_inflate = ms_since(t_inf);
   lap("count+sync");
+  if (staged_done) {   // the stages' inflate launches overlap (two streams): what is reported is the span from the first launch's start to the last one's end
+    size_t j0 = SIZE_MAX; float span = 0;
+    for (size_t j = 0; j < staged_stages; j++) if (staged_nblk[j]) { if (j0 == SIZE_MAX) j0 = j; float b = 0; if (hipEventElapsedTime(&b, d->tev[2 * j0], d->tev[2 * j + 1]) == hipSuccess) span = std::max(span, b);
+      if (trace_laps) { float a = 0; (void)hipEventElapsedTime(&a, d->tev[2 * j0], d->tev[2 * j]); char t[64]; snprintf(t, sizeof t, " {inflate %zu: %.1f-%.1f}", j, a, b); laps += t; } }
+    staged_kernel_ms = span;
+  }
   { float kms = 0; if (hipEventElapsedTime(&kms, d->kev[0], d->kev[1]) == hipSuccess) out->ms_kernel = kms + staged_kernel_ms; }   // (staged: the stages' inflate launches + the chain kernels)
   bam.bytes_inflated += plan.raw_total; bam.bytes_inflated_device += plan.raw_total;
   // whatever leaves this function early must not leave the CRC kernel reading buffers the next ingest rewrites
@@ -406,13 +448,14 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
   S.dev_sum2.resize(n); S.dev_name_hash2.resize(n); S.dev_win_idx.resize(n); S.so_name_hash.resize(n_so); S.so_name_hash2.resize(n_so); S.so_win_idx.resize(n_so);
   for (size_t k = 0; k < extra.size(); k += 2) S.extra_spans.push_back({extra[k], extra[k + 1]});
   std::unordered_map<uint64_t, uint16_t> by_hash; std::vector<uint8_t> recbuf;
-  uint64_t ev_cap = 0;
+  uint64_t ev_cap = 0, last_hash = 0; uint16_t last_id = 0; bool have_last = false;
   for (uint32_t j = 0; j < n_pk; j++) {
     const bool so = j >= n;
     MkpReadHdr& h = so ? S.so_hdr[j - n] : S.hdr[j];
     if (so) { S.so_name_hash[j - n] = dig[j].name_hash; S.so_name_hash2[j - n] = dig[j].name_hash2; S.so_win_idx[j - n] = (uint32_t)dig[j].win_idx; h.pad = 0; }
     else { S.name_hash[j] = dig[j].name_hash; S.dev_name_hash2[j] = dig[j].name_hash2; S.dev_win_idx[j] = (uint32_t)dig[j].win_idx; S.dev_sum2[j] = (uint8_t)(h.pad & 1u); h.pad = 0; ev_cap += h.event_cap; }
     if (!h.n_tags || (h.flags & MKP_RF_BAD)) continue;
+    if (have_last && dig[j].key_hash == last_hash) { h.layout = last_id; continue; }   // (runs of one structure: most of a file)
     auto it = by_hash.find(dig[j].key_hash);
     if (it == by_hash.end()) {
       // a structure not seen in this shard yet: its record comes back from HBM and goes through the host packer, which interns the layout
@@ -435,7 +478,7 @@ std::unique_ptr<DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const BamSo
       if (id < before) throw Error(MKP_E_DEVICE, "internal: two MM header structures share a 64-bit key hash");
       it = by_hash.emplace(dig[j].key_hash, id).first;
     }
-    h.layout = it->second;
+    h.layout = it->second; last_hash = dig[j].key_hash; last_id = it->second; have_last = true;
   }
   S.n_events_cap = ev_cap;
   std::vector<MkpRecInfo>().swap(out->info_host);

@@ -729,6 +729,7 @@ __device__ __forceinline__ uint32_t nibble_eq(uint32_t x, uint32_t pat) {
   t |= t >> 1; t |= t >> 2;
   return ~t & 0x11111111u;
 }
+__device__ __forceinline__ uint32_t rfl_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 #define MKP_SQCAP 128   // call queue of the SPARSE kernels: < 64 left over + one round of <= 64
 template <bool SAMPLE, int NT>
 __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict__ hdrs, uint32_t n_reads, const uint32_t* __restrict__ cigar,
@@ -829,9 +830,11 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   // CIGAR window: 64 ops in registers, advanced as the batches move along the read
   // (128 ops per window, two per lane: w_qe = inclusive query end of the lane's pair, w_mid = where its second op starts,
   //  w_a / w_b = (reference start - query start) << 1 | is-match of the two ops)
-  uint32_t c0 = 0, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
+  // The window's running values (first op, query / reference offsets, totals) are kept in scalar registers — read back through readfirstlane
+  // after every update; carried as vectors they were advanced with v_cndmask and copied at every loop head — and "nothing loaded yet" is an
+  // empty window in front of op 0: no flag, no conditional advance (the same rewrite as refwin_s_* of mkp_slots.hip).
+  uint32_t c0 = 0u - 128u, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
   uint32_t w_qe = 0, w_mid = 0, w_a = 0, w_b = 0, w_rtot = 0;
-  bool win_loaded = false;
   auto cigar2 = [&](uint32_t c) { uint2 r; const uint32_t k = c + 2u * (uint32_t)lane; r.x = k < h.n_cigar ? cigar[h.cigar_off + k] : 5u /*0H*/; r.y = k + 1u < h.n_cigar ? cigar[h.cigar_off + k + 1u] : 5u; return r; };
   uint2 w_pref = cigar2(0);   // the first CIGAR window, requested before the read is walked
   uint32_t qhead = 0, qcount = 0, d0 = 0;
@@ -957,32 +960,33 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
 #endif
     {
       bool pending = active;
-      for (;;) {
-        if (!win_loaded || (__any(pending && q >= wq1) && !__any(pending && q < wq1))) {
-          if (win_loaded) { c0 += 128; wq0 = wq1; wr0 += (int32_t)w_rtot; }
-          if (c0 >= h.n_cigar) break;
-          const uint2 w = w_pref;   // requested one window ahead: the load is off the mapping's dependency chain
-          w_pref = cigar2(c0 + 128u);
-          const uint32_t op0 = w.x & 15u, len0 = w.x >> 4, op1 = w.y & 15u, len1 = w.y >> 4;
-          const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
-          const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
-          w_qe = wave_incl_scan(ql0 + ql1); const uint32_t re = wave_incl_scan(rl0 + rl1);
-          w_mid = w_qe - ql1;                                                       // window-relative query offset of the second op
-          const int32_t dl0 = (wr0 + (int32_t)(re - rl0 - rl1)) - (int32_t)(wq0 + w_qe - ql0 - ql1);   // ref start - query start of the first op
-          const int32_t dl1 = (wr0 + (int32_t)(re - rl1)) - (int32_t)(wq0 + w_mid);
-          w_a = ((uint32_t)dl0 << 1) | (op_is_match(op0) ? 1u : 0u); w_b = ((uint32_t)dl1 << 1) | (op_is_match(op1) ? 1u : 0u);
-          wq1 = wq0 + (uint32_t)__builtin_amdgcn_readlane((int)w_qe, 63); w_rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
-          win_loaded = true;
-          continue;
-        }
+      auto win_next = [&]() -> bool {   // the next 128 ops; false behind the last op (cannot happen for positions inside SEQ: the packer checks the lengths)
+        c0 = rfl_u(c0 + 128u); wq0 = wq1; wr0 = (int32_t)rfl_u((uint32_t)wr0 + w_rtot);
+        if (c0 >= h.n_cigar) { w_rtot = 0; return false; }
+        const uint2 w = w_pref;   // requested one window ahead: the load is off the mapping's dependency chain
+        w_pref = cigar2(c0 + 128u);
+        const uint32_t op0 = w.x & 15u, len0 = w.x >> 4, op1 = w.y & 15u, len1 = w.y >> 4;
+        const uint32_t ql0 = op_consumes_query(op0) ? len0 : 0u, rl0 = op_consumes_ref(op0) ? len0 : 0u;
+        const uint32_t ql1 = op_consumes_query(op1) ? len1 : 0u, rl1 = op_consumes_ref(op1) ? len1 : 0u;
+        w_qe = wave_incl_scan(ql0 + ql1); const uint32_t re = wave_incl_scan(rl0 + rl1);
+        w_mid = w_qe - ql1;                                                       // window-relative query offset of the second op
+        const int32_t dl0 = (wr0 + (int32_t)(re - rl0 - rl1)) - (int32_t)(wq0 + w_qe - ql0 - ql1);   // ref start - query start of the first op
+        const int32_t dl1 = (wr0 + (int32_t)(re - rl1)) - (int32_t)(wq0 + w_mid);
+        w_a = ((uint32_t)dl0 << 1) | (op_is_match(op0) ? 1u : 0u); w_b = ((uint32_t)dl1 << 1) | (op_is_match(op1) ? 1u : 0u);
+        wq1 = wq0 + (uint32_t)__builtin_amdgcn_readlane((int)w_qe, 63); w_rtot = (uint32_t)__builtin_amdgcn_readlane((int)re, 63);
+        return true;
+      };
+      auto win_pass = [&]() {   // the lanes whose position lies in the loaded window (positions ascend from batch to batch: none lies before it)
         const bool ready = pending && q < wq1;
+        if (!__any(ready)) return;
         const uint32_t qrel = ready ? q - wq0 : 0u;
         const int oi = find_op(w_qe, qrel) & 63;
         const uint32_t o_mid = (uint32_t)__shfl((int)w_mid, oi, 64), o_a = (uint32_t)__shfl((int)w_a, oi, 64), o_b = (uint32_t)__shfl((int)w_b, oi, 64);
         const uint32_t pick = qrel < o_mid ? o_a : o_b;
         if (ready) { mapped = (pick & 1u) != 0u; rpos = (int32_t)q + ((int32_t)pick >> 1); pending = false; }
-        if (!__any(pending)) break;
-      }
+      };
+      win_pass();
+      while (__any(pending)) { if (!win_next()) break; win_pass(); }
     }
     F4 pk = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -157,12 +157,13 @@ __device__ __forceinline__ bool refwin_s_next(RefWinS& w, const uint32_t* __rest
     qe = sc & 0xffffu; w.re = sc >> 16;
   } else { qe = wave_incl_scan(qsum); w.re = wave_incl_scan(rsum); }
   w.Qtot = (uint32_t)__builtin_amdgcn_readlane((int)qe, 63); w.Rtot = (uint32_t)__builtin_amdgcn_readlane((int)w.re, 63);
-  uint32_t qs = w.q_run + qe - qsum, rs = w.re - rsum;   // query offset / window-relative reference offset of the lane's first op
-  const int32_t rbase = w.r_run - ref_start;
+  // d = query offset - (reference offset - ref_start) of the lane's op, carried op to op; rs = window-relative reference offset
+  uint32_t rs = w.re - rsum;
+  uint32_t d = (w.q_run - (uint32_t)(w.r_run - ref_start)) + (qe - qsum) - rs;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    w.pk[j] = ((uint32_t)((int32_t)qs - (rbase + (int32_t)rs)) << 2) | kind[j];
-    qs += ql[j]; rs += rl[j];
+    w.pk[j] = (d << 2) | kind[j];
+    d += ql[j] - rl[j]; rs += rl[j];
     if (j == 0) w.m1 = rs; else if (j == 1) w.m2 = rs; else if (j == 2) w.m3 = rs;
   }
   return true;
