@@ -938,6 +938,14 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
     if (prm.debug_skip & 16u) { qhead += nb; any_surviving = true; continue; }   // ablation: producer only
 #endif
     const bool active = (uint32_t)lane < nb;
+    // The descriptor words the per-call code branches on are made opaque here, once per batch: left visible as loop invariants, every
+    // uniform compare derived from them (which code a slot holds, how many codes a tag lists, ...) was hoisted out of the loop as a 64-bit
+    // lane mask, dozens of them, spilled to VGPR lanes and read back with two v_readlane each inside the loop — VALU instructions in a
+    // VALU-bound kernel; derived in place they are a few scalar instructions that live for a handful of cycles.
+    GroupRegs g0 = grp0; uint32_t kc_l = (uint32_t)kcodes0, SH_l = SH_all, sm_l = setmask_all, tmu_l[NT], tnc_l[NT];
+    asm volatile("" : "+s"(g0.misc), "+s"(g0.slots), "+s"(g0.cids), "+s"(kc_l), "+s"(SH_l), "+s"(sm_l));
+#pragma unroll
+    for (int t = 0; t < NT; t++) { tmu_l[t] = tmu[t]; tnc_l[t] = t_nc[t]; asm volatile("" : "+s"(tmu_l[t]), "+s"(tnc_l[t])); }
     const uint32_t q = active ? q_pos[qhead + lane] : 0u;
     const uint32_t jx = active ? q_j[qhead + lane] : 0u;
     const uint32_t f = rev ? (L - 1 - q) : q;  // forward (as-sequenced) position
@@ -948,7 +956,7 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
 #pragma unroll
       for (int i = 0; i < MKP_KMAX; i++) mlq[t][i] = 0;
       if (t < n_tags) {
-        const uint32_t nc = t_nc[t], base = active ? (t_ml[t] + jx * nc) : 0u;
+        const uint32_t nc = tnc_l[t], base = active ? (t_ml[t] + jx * nc) : 0u;
 #pragma unroll
         for (int i = 0; i < MKP_KMAX; i++) if ((uint32_t)i < nc) mlq[t][i] = ml[base + (active ? (uint32_t)i : 0u)];
       }
@@ -994,42 +1002,42 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
       if (t >= n_tags) break;
 #pragma unroll
       for (int i = 0; i < MKP_KMAX; i++) {
-        if ((uint32_t)i >= t_nc[t]) break;
+        if ((uint32_t)i >= tnc_l[t]) break;
         const float p = ((float)mlq[t][i] + 0.5f) / 256.0f;   // quals_to_probs (mod_bam.rs:808-816)
-        const uint32_t kk = (tmu[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
+        const uint32_t kk = (tmu_l[t] >> (4 + 4 * i)) & 15u;   // wave-uniform local code
         setk(pk, kk, true, p);
       }
     }
     if (NT > 1 && n_tags > 1) {  // combine_checked's sum test, once on the final map (partial sums of positive terms cannot exceed it)
       float s = 0.f;
 #pragma unroll
-      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (setmask_all & (1u << k2)) s = s + at(pk, k2);
+      for (int k2 = 0; k2 < MKP_KMAX; k2++) if (sm_l & (1u << k2)) s = s + at(pk, k2);
       if (active && s > 1.01f) err = true;
     }
     uint32_t ev_info = 0; float sv = 0.f; bool has_ev = false;
     if (active) {
       const bool edge_keep = !prm.edge_filter ||
           (prm.edge_inverted ? (f < prm.edge_start || f >= L - prm.edge_end) : (f >= prm.edge_start && f < L - prm.edge_end));
-      const uint32_t pv = gp0[12 + SH_all];
-      contribH |= SH_all;
+      const uint32_t pv = gp0[12 + SH_l];
+      contribH |= SH_l;
       if (trimmable && edge_keep) {
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
           if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
           if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;   // `extract calls`: the collapse left no code in the map: no profile row
           else if (keep && prm.sample_mode >= 2) {
-            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob; has_ev = true;
+            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(g0, pv, pk, collapse, &ob, (int)kc_l, &am); obs0 |= ob; has_ev = true;
             if (prm.sample_mode == 3) { ev_info |= (uint32_t)sg0 << 2; sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position (explicit tags: never inferred)
           }
-          else if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
+          else if (keep) { any_surviving = true; sv = argmax_group(g0, pv, pk, collapse, (int)kc_l); ev_info = MKP_G_TB(g0.misc); has_ev = true; }
         } else {
           any_surviving = true;
           uint32_t ob = 0;
-          const int cls = call_group(grp0, pv, pk, collapse, &ob, kcodes0);
+          const int cls = call_group(g0, pv, pk, collapse, &ob, (int)kc_l);
           const uint32_t tally = aln ^ (uint32_t)sg0;  // read_cache.rs:181-188 / FeatureVector::add_feature
           if (tally) obs1 |= ob; else obs0 |= ob;
           if (mapped) {
-            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(grp0.misc) : ((grp0.cids >> (8 * (cls - 2))) & 0xffu);
+            const uint32_t cid = cls == 0 ? (uint32_t)MKP_C_FAIL : cls == 1 ? MKP_G_CIDCAN(g0.misc) : ((g0.cids >> (8 * (cls - 2))) & 0xffu);
             ev_info = cid | (tally << 8) | ((uint32_t)b0 << 9) | (aln << 11) | (1u << 12);
             has_ev = true;
           }

@@ -8,8 +8,10 @@ for F in "" "-f 1.0"; do
   T=$(echo $F | tr -d ' -.'); 
   ( time timeout 300 modkit_amd/csrc/mkpileup pileup $P.bam /tmp/chr1_dev$T.bed --cpg --ref $P.fa --stats $F ) > /dev/null 2> $OUT/dev$T.err; echo "device [$F] rc $?"; grep -E "rows=|ahead=|real" $OUT/dev$T.err | cut -c1-330
 done
-for F in "" "-f 1.0"; do
+# (the oracle's own -f 1.0 run does not finish in 700 s at this size: only with FULL_ORACLE=1)
+for F in "" ${FULL_ORACLE:+"-f 1.0"}; do
   T=$(echo $F | tr -d ' -.');
   ( time timeout ${ORACLE_TIMEOUT:-600} oracle/modkit_oracle pileup $P.bam /tmp/chr1_ora$T.bed --cpg --ref $P.fa --oracle-workers 16 $F ) > /dev/null 2> $OUT/ora$T.err; echo "oracle [$F] rc $?"; grep -E "rows=|real" $OUT/ora$T.err | cut -c1-300
   sha256sum /tmp/chr1_dev$T.bed /tmp/chr1_ora$T.bed | tee -a $OUT/sha.txt
 done
+sha256sum /tmp/chr1_dev.bed /tmp/chr1_devf10.bed | tee -a $OUT/sha.txt
