@@ -857,8 +857,9 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
 
   for (;;) {
     if (err) break;
-    if (qcount - qhead < 64u && (step_loaded || d0 < nd)) {
-      // ---- producer
+    // ---- producer: a loop of its own — the steps and rank batches that refill the queue touch none of the consumer's state, and as
+    // iterations of the one outer loop each of them went through that loop's head with all of it
+    while (qcount - qhead < 64u && (step_loaded || d0 < nd)) {
       // the next 64 ranks at the cursor are requested first: the flag / scan work below hides the load
       uint32_t e; bool valid;
       if (!rev) { const uint32_t i = t_cur + lane; valid = i < t_n; e = valid ? ranks[t_off + i] : 0xffffffffu; }
@@ -929,7 +930,6 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         cum += st_cntT; d0 += 512; step_loaded = false;
         if (rev ? (t_cur == 0u) : (t_cur == t_n)) d0 = nd;
       }
-      continue;
     }
     if (qcount == qhead) break;
     // ---- consumer: up to 64 queued calls, in read order
@@ -1122,11 +1122,13 @@ template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECO
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_reads(DECODE_PARAMS(MkpRunParams)) { decode_general_entry<false>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast1(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 1>(DECODE_PASS); }
 extern "C" __global__ void __launch_bounds__(256) mkp_decode_fast2(DECODE_PARAMS(MkpRunParams)) { decode_fast_entry<false, 2>(DECODE_PASS); }
-// Seven waves per SIMD for the SPARSE event decoders (72 VGPRs, 94 SGPRs: the scalar file admits seven at <= 96, MI355X_MICROARCH.md
-// "Residency"; left alone the compiler takes 77 / 85 VGPRs and 106 SGPRs = six / five waves): C2 decode 0.509 -> 0.481 ms, hemi decode
-// 2.40 -> 2.28 ms; eight waves spill (0.57 / 2.60).  A/B on one box, tools/dbg/ab.sh.
+// Waves per SIMD of the SPARSE event decoders.  Left alone the compiler took 77 / 85 VGPRs and 106 SGPRs = six / five waves; seven
+// (72 VGPRs, <= 96 SGPRs: the scalar file admits seven, MI355X_MICROARCH.md "Residency") gave C2 decode 0.509 -> 0.481 ms, hemi 2.40 -> 2.28,
+// and eight spilled (0.57 / 2.60).  Since the producer runs as a loop of its own and the consumer's descriptor words are opaque (both
+// in decode_read_sparse) the kernels need 59 / 60 VGPRs, and EIGHT waves (<= 64 VGPRs, <= 80 SGPRs) win: C2 decode 0.428 -> 0.405 ms, hemi
+// decode 1.955 -> 1.859 (0.452 / 2.03 before both changes).  A/B on one box, tools/dbg/ab.sh.
 #ifndef MKP_SPARSE_WAVES
-#define MKP_SPARSE_WAVES 7
+#define MKP_SPARSE_WAVES 8
 #endif
 #define MKP_SPARSE_LB __launch_bounds__(256, MKP_SPARSE_WAVES)
 extern "C" __global__ void MKP_SPARSE_LB mkp_decode_sparse1(DECODE_PARAMS(MkpRunParams)) { decode_sparse_entry<false, 1>(DECODE_PASS); }
