@@ -103,7 +103,10 @@ struct RowWriter {
     if (n_rows == 0) return;
     const unsigned n_thr = n_rows >= 65536 ? HostPool::host_cpus() : 1u;
     // a large shard goes to the writer thread in pieces: the first piece is on its way to the file while the next is formatted
-    const uint64_t n_pieces = n_rows >= (1u << 20) ? 4 : 1;
+    // (C3's 2.77 M rows = 190 MB on the GPU box's 16 CPUs, tools/dbg/writer_bench.cpp: 1 piece 59 ms — 10 of formatting, then 49 of pwrite —
+    //  2 pieces 35, 4 pieces 39-46, 8 pieces 37-41, 16 pieces 32-34)
+    static const uint64_t env_pieces = getenv("MKP_WRITE_PIECES") ? strtoull(getenv("MKP_WRITE_PIECES"), nullptr, 10) : 0;   // (experiments)
+    const uint64_t n_pieces = n_rows >= (1u << 20) ? (env_pieces ? env_pieces : 16) : 1;
     for (uint64_t pc = 0; pc < n_pieces; pc++) {
       const uint64_t p_lo = n_rows * pc / n_pieces, p_n = n_rows * (pc + 1) / n_pieces - p_lo;
       std::vector<TextBuf> bufs(n_thr);
