@@ -881,7 +881,7 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
   // the context's stream runs the short kernels a caller waits for — sampling rounds, the pileup pass — often beside an ingest that fills the
   // chip for tens of milliseconds: it goes first when workgroup slots free up
   { int plo = 0, phi = 0;
-    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamDefault, phi) != hipSuccess) { delete c; return MKP_E_DEVICE; } }
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess || pooled_stream_create(&c->stream, c->device, hipStreamDefault, phi) != hipSuccess) { delete c; return MKP_E_DEVICE; } c->stream_prio = phi; }
   // timing events between the kernels of a pass: no system-scope fence when they are recorded (its cache write-back and invalidation sat
   // between the decoder and the kernel that reads what it just wrote; nothing on the host looks at device memory through these events)
   for (auto& e : c->ev) if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { delete c; return MKP_E_DEVICE; }
@@ -899,7 +899,7 @@ void mkp_ctx_destroy(mkp_ctx* c) {
   c->h_rows.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->h_words) (void)hipHostFree(c->h_words);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  pooled_stream_release(c->stream, c->device, hipStreamDefault, c->stream_prio);   // (drained, then parked for the next context: mkp_ctx.hpp)
   delete c;
 }
 

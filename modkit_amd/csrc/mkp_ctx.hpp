@@ -4,6 +4,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <mutex>
+#include <vector>
 
 #include "mkp_pack.hpp"
 
@@ -30,6 +32,27 @@ inline void hip_check(hipError_t e, const char* what) {
   if (e != hipSuccess) throw Error(MKP_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Streams are recycled process-wide.  Creating one costs 8-10 ms on this stack (an HSA queue each: tools/dbg/api_cost.hip), and a context with
+// its ingest object holds five of them, a thread's copy staging one more: 45-60 ms of every fresh context, before its first byte moves.
+// A destroyed context hands its (drained) streams back; the next one of the same device, flags and priority takes them.  The pool is never
+// torn down (the runtime may be gone by the time static destructors run).
+struct StreamPool {
+  struct Item { int dev; unsigned flags; int prio; hipStream_t st; };
+  std::mutex mu; std::vector<Item> free;
+  static StreamPool& get() { static StreamPool* p = new StreamPool(); return *p; }
+};
+inline hipError_t pooled_stream_create(hipStream_t* out, int dev, unsigned flags, int prio) {
+  { StreamPool& P = StreamPool::get(); std::lock_guard<std::mutex> g(P.mu);
+    for (size_t i = 0; i < P.free.size(); i++) if (P.free[i].dev == dev && P.free[i].flags == flags && P.free[i].prio == prio) { *out = P.free[i].st; P.free.erase(P.free.begin() + (ptrdiff_t)i); return hipSuccess; } }
+  return hipStreamCreateWithPriority(out, flags, prio);
+}
+inline void pooled_stream_release(hipStream_t st, int dev, unsigned flags, int prio) {
+  if (!st) return;
+  if (hipStreamSynchronize(st) != hipSuccess) { (void)hipStreamDestroy(st); return; }   // (a stream that reports an error is not kept)
+  StreamPool& P = StreamPool::get(); std::lock_guard<std::mutex> g(P.mu);
+  if (P.free.size() < 64) P.free.push_back({dev, flags, prio, st}); else (void)hipStreamDestroy(st);
+}
+
 // Host -> device copies of plan data (read headers, work records, focus bytes, tiles) go through page-locked staging owned by the library.
 // Handed a large PAGEABLE buffer, the HIP runtime pins the caller's pages in place (a userptr mapping) for the DMA; when that memory is
 // later freed or remapped — the planner's vectors are temporaries — the kernel driver evicts every queue of the process and restores
@@ -39,15 +62,15 @@ inline void hip_check(hipError_t e, const char* what) {
 struct H2DStage {
   static constexpr size_t kHalf = 8u << 20;
   uint8_t* p = nullptr; hipStream_t st = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; int dev = -1;
-  ~H2DStage() { if (st) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(st); } if (p) (void)hipHostFree(p); }
+  ~H2DStage() { if (st) { for (auto& e : ev) if (e) (void)hipEventDestroy(e); pooled_stream_release(st, dev, hipStreamNonBlocking, 0); } if (p) (void)hipHostFree(p); }
 };
 inline H2DStage& copy_stage() {   // this thread's staging, its stream and events on the current device
   static thread_local H2DStage S;
   int dev = 0; hip_check(hipGetDevice(&dev), "hipGetDevice");
   if (!S.p && hipHostMalloc(reinterpret_cast<void**>(&S.p), 2 * H2DStage::kHalf, hipHostMallocPortable) != hipSuccess) { S.p = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc of the copy staging failed"); }
   if (S.dev != dev) {   // the stream and events belong to a device
-    if (S.st) { for (auto& e : S.ev) if (e) (void)hipEventDestroy(e); (void)hipStreamDestroy(S.st); S.st = nullptr; S.ev[0] = S.ev[1] = nullptr; }
-    hip_check(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking), "hipStreamCreate");
+    if (S.st) { for (auto& e : S.ev) if (e) (void)hipEventDestroy(e); pooled_stream_release(S.st, S.dev, hipStreamNonBlocking, 0); S.st = nullptr; S.ev[0] = S.ev[1] = nullptr; }
+    hip_check(pooled_stream_create(&S.st, dev, hipStreamNonBlocking, 0), "hipStreamCreate");
     for (auto& e : S.ev) hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     S.dev = dev;
   }
@@ -102,7 +125,7 @@ inline double ms_since(std::chrono::steady_clock::time_point t0) { return std::c
 }  // namespace mkp
 
 struct mkp_ctx {
-  int device = 0; hipStream_t stream = nullptr; std::string err; mkp_config cfg;
+  int device = 0; int stream_prio = 0; hipStream_t stream = nullptr; std::string err; mkp_config cfg;
   mkp::CallerCfg caller; bool caller_set = false;
   mkp::Packer packer; mkp::ShardHost shard; mkp::LayoutTables tables; bool shard_open = false, resident = false;
   mkp::PodVec<uint8_t> focus; bool has_focus = false; std::vector<mkp_motif_combo> combos;   // (focus: a byte per position of the shard window, copied on all cores)

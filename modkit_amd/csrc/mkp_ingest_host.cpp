@@ -37,7 +37,7 @@ uint64_t fnv64(const std::string& s) { uint64_t h = 1469598103934665603ull; for 
 }  // namespace
 
 struct mkp_dev_ingest {
-  int device = 0; hipStream_t stream = nullptr, up_stream = nullptr, crc_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr}, inf_done = nullptr, crc_done = nullptr;
+  int device = 0, prio_mid = 0, prio_lo = 0; hipStream_t stream = nullptr, up_stream = nullptr, crc_stream = nullptr; hipEvent_t slot_ev[2] = {nullptr, nullptr}, up_done = nullptr, kev[2] = {nullptr, nullptr}, inf_done = nullptr, crc_done = nullptr;
   std::vector<hipEvent_t> stage_ev;      // upload stages: recorded on up_stream behind a stage's last copy
   std::vector<hipEvent_t> tev;           // timed pairs around the inflate launches of the stages
   hipStream_t inf_stream[1] = {nullptr};   // the stages' inflate launches: off the ingest stream, whose chain walks (and the host's one sync per stage) then never wait for an inflate.
@@ -81,9 +81,10 @@ mkp_dev_ingest* mkp_internal_ingest_create(int device) {
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) return nullptr;
   const int prio_mid = (prio_lo + prio_hi) / 2 != prio_hi ? (prio_lo + prio_hi) / 2 : prio_hi;   // (below the contexts' own streams, above the uploads and the CRC)
-  if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, prio_mid) != hipSuccess || hipStreamCreateWithPriority(&d->up_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-      hipStreamCreateWithPriority(&d->crc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
-  for (auto& st : d->inf_stream) if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
+  d->prio_mid = prio_mid; d->prio_lo = prio_lo;   // (streams come from the process-wide pool: 8-10 ms each to create, mkp_ctx.hpp)
+  if (pooled_stream_create(&d->stream, device, hipStreamNonBlocking, prio_mid) != hipSuccess || pooled_stream_create(&d->up_stream, device, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+      pooled_stream_create(&d->crc_stream, device, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
+  for (auto& st : d->inf_stream) if (pooled_stream_create(&st, device, hipStreamNonBlocking, prio_lo) != hipSuccess) return nullptr;
   for (auto& e : d->slot_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&d->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (auto& e : d->kev) if (hipEventCreate(&e) != hipSuccess) return nullptr;   // (timed: the inflate + chain kernels, for the trace)
@@ -99,8 +100,8 @@ void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   for (auto& e : d->stage_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : d->tev) if (e) (void)hipEventDestroy(e);
   for (auto& e : d->lay_ev) if (e) (void)hipEventDestroy(e);
-  for (auto& st : d->inf_stream) if (st) (void)hipStreamDestroy(st);
-  if (d->crc_stream) (void)hipStreamDestroy(d->crc_stream);
+  for (auto& st : d->inf_stream) pooled_stream_release(st, d->device, hipStreamNonBlocking, d->prio_lo);
+  pooled_stream_release(d->crc_stream, d->device, hipStreamNonBlocking, d->prio_lo);
   for (auto& b : d->spares) b.release();
   d->stage.release(); d->small.release(); d->chain_host.release();
   for (auto& e : d->slot_ev) if (e) (void)hipEventDestroy(e);
@@ -108,8 +109,8 @@ void mkp_internal_ingest_destroy(mkp_dev_ingest* d) {
   for (auto& e : d->kev) if (e) (void)hipEventDestroy(e);
   if (d->inf_done) (void)hipEventDestroy(d->inf_done);
   if (d->crc_done) (void)hipEventDestroy(d->crc_done);
-  if (d->stream) (void)hipStreamDestroy(d->stream);
-  if (d->up_stream) (void)hipStreamDestroy(d->up_stream);
+  pooled_stream_release(d->stream, d->device, hipStreamNonBlocking, d->prio_mid);
+  pooled_stream_release(d->up_stream, d->device, hipStreamNonBlocking, d->prio_lo);
   delete d;
 }
 
