@@ -327,13 +327,18 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
         for (int j = 0; j < 4; j++) x[j] = (i0 + 64u * (uint32_t)j < nwords) ? load4(dbase + 4u * (i0 + 64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (i0 + 64u * (uint32_t)j < nwords) {
-          const uint32_t wi = i0 + 64u * (uint32_t)j + (uint32_t)lane;
-          const uint32_t Fw = flags4(x[j]), c = wi < nwords ? (uint32_t)__popc(Fw) : 0u;   // (a window of 416 words ends inside a vector: the words behind it belong to the next window)
-          const uint32_t inc = wave_incl_scan(c);
-          if (wi < nwords) { W.F[wi] = Fw; W.P[wi] = (uint16_t)(carry + inc - c); }
-          carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      for (int jp = 0; jp < 4; jp += 2) {   // two vectors per prefix sum: a word holds at most 32 occurrences, 64 words 2 048 — both running counts fit 16 bits
+        if (i0 + 64u * (uint32_t)jp < nwords) {
+          const bool has1 = i0 + 64u * (uint32_t)(jp + 1) < nwords;   // (uniform)
+          const uint32_t wi0 = i0 + 64u * (uint32_t)jp + (uint32_t)lane, wi1 = wi0 + 64u;
+          const uint32_t Fw0 = flags4(x[jp]), c0 = wi0 < nwords ? (uint32_t)__popc(Fw0) : 0u;   // (a window of 416 words ends inside a vector: the words behind it belong to the next window)
+          uint32_t Fw1 = 0, c1 = 0;
+          if (has1) { Fw1 = flags4(x[jp + 1]); c1 = wi1 < nwords ? (uint32_t)__popc(Fw1) : 0u; }
+          const uint32_t sc = wave_incl_scan(c0 | (c1 << 16));
+          const uint32_t tot01 = (uint32_t)__builtin_amdgcn_readlane((int)sc, 63), tot0 = tot01 & 0xffffu;
+          if (wi0 < nwords) { W.F[wi0] = Fw0; W.P[wi0] = (uint16_t)(carry + (sc & 0xffffu) - c0); }
+          if (has1 && wi1 < nwords) { W.F[wi1] = Fw1; W.P[wi1] = (uint16_t)(carry + tot0 + (sc >> 16) - c1); }
+          carry += tot0 + (tot01 >> 16);
         }
       }
     }
@@ -537,14 +542,14 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
     const uint32_t nib = (q & 1u) ? (byte & 15u) : (byte >> 4);
     uint32_t fb = cover_feature(valid ? kind : 2u, nib, aln);
     if (valid && kind == 0u && q >= L) fb = MKP_FB_NONE;   // (a CIGAR longer than SEQ is refused by the packer)
-    if (call_fb != 0xffffffffu) { fb = call_fb; n_callfeat++; }
+    { const bool cf = call_fb != 0xffffffffu; if (cf) fb = call_fb; n_callfeat += (uint32_t)__popcll(__ballot(cf)); }   // (a scalar count: no per-lane counter, no scan at the end)
     if (valid) cov[h.cov_off + i] = (uint8_t)fb;
     gaps = gaps || (valid && fb == MKP_FB_NONE);
   }
   gaps = __any(gaps);
   const bool ok = have_calls;
   const uint32_t tally = aln ^ sg0u, ob_const = fmisc >> 16;
-  const uint32_t n_cf = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(n_callfeat), 63);
+  const uint32_t n_cf = n_callfeat;
   if (lane == 0) {
     // (what the records below need of the work record is read again here rather than held in scalar registers through the slot loop)
     const MkpWork* hp = work + widx; asm volatile("" : "+s"(hp));

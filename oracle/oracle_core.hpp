@@ -688,4 +688,51 @@ static inline float percentile_linear_interp(const std::vector<float>& xs, float
   return a + b;
 }
 
+// rand 0.8.5 `StdRng` as RecordSampler uses it (src/reads_sampler/record_sampler.rs:29-38 `StdRng::seed_from_u64`, 80-86 `gen_bool`).
+// The crate is a dependency (Cargo.toml:42 `rand = "0.8.5"`, which pulls rand_chacha 0.3.1 / rand_core 0.6.4), not in /root/reference:
+// restated from its published algorithm —
+//   * rand_core `SeedableRng::seed_from_u64`: the 32 seed bytes are eight PCG32 (XSH-RR) outputs of an LCG over the u64, little endian;
+//   * `StdRng` = `ChaCha12Rng`: djb ChaCha, 12 rounds, 256-bit key = the seed, 64-bit block counter (words 12-13) from 0, 64-bit stream
+//     id (words 14-15) 0; the block buffer hands out the keystream's u32 words in order, a u64 = (next word) | (word after) << 32;
+//   * `Rng::gen_bool(p)` = `Bernoulli::new(p).sample`: p == 1 is always true without a draw, otherwise one u64 < (p * 2^64) as u64.
+// Pinned: the block function against the published zero-key keystreams at 20 and 12 rounds (tests/test_oracle_unit_kats.py).  Unpinned:
+// the seed expansion and the Bernoulli draw (no reference fixture depends on a seeded sample).
+struct ChaChaBlocks {
+  uint32_t key[8] = {0}; uint64_t counter = 0; int rounds = 12;
+  static inline uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+  void block(uint32_t out[16]) {
+    uint32_t st[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; i++) st[4 + i] = key[i];
+    st[12] = (uint32_t)counter; st[13] = (uint32_t)(counter >> 32); st[14] = 0; st[15] = 0;
+    uint32_t x[16]; for (int i = 0; i < 16; i++) x[i] = st[i];
+    auto qr = [&](int a, int b, int c, int d) {
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7); };
+    for (int r = 0; r < rounds; r += 2) { qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+                                          qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14); }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + st[i];
+    counter++;
+  }
+};
+struct StdRng {
+  ChaChaBlocks cc; uint32_t buf[16]; int idx = 16;
+  static StdRng seed_from_u64(uint64_t state) {
+    StdRng r;
+    for (int i = 0; i < 8; i++) {
+      state = state * 6364136223846793005ull + 11634580027462260723ull;
+      const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+      r.cc.key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));   // (the bytes are stored little endian and read back as LE words)
+    }
+    return r;
+  }
+  uint32_t next_u32() { if (idx == 16) { cc.block(buf); idx = 0; } return buf[idx++]; }
+  uint64_t next_u64() { const uint64_t lo = next_u32(); return lo | ((uint64_t)next_u32() << 32); }
+  bool gen_bool(double p) {
+    if (!(p >= 0.0 && p <= 1.0)) throw MkErr("Bernoulli: p outside [0, 1]");
+    if (p == 1.0) return true;
+    const uint64_t p_int = (uint64_t)(p * 18446744073709551616.0);
+    return next_u64() < p_int;
+  }
+};
+
 }  // namespace mko
