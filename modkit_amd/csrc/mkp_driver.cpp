@@ -21,6 +21,7 @@
 #include "mkp_ingest_host.hpp"
 #include "mkp_focus.hpp"
 #include "mkp_writer.hpp"
+#include "mkp_rand.hpp"
 
 using namespace mkp;
 
@@ -62,6 +63,7 @@ struct BedGraphOut {
 struct Args {
   std::string in_bam, out_bed, region, sample_region, include_bed, ignore, ref_fasta, edge_filter, preset;
   uint32_t max_depth = 8000, interval_size = 100000, sampling_interval_size = 1000000;
+  bool have_seed = false; uint64_t seed = 0;   // --seed
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
@@ -249,11 +251,14 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   struct TakeState { size_t used = 0, n_reads_out = 0; };
   // the sampler's verdict on candidates cand[lo, hi) whose value counts are nv[0 ..): mask[k] = 1 where the read's values enter the sample
   auto decide = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen,
-      TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask) {
+      TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask, SeededSampler* draws = nullptr, double frac = 1.0) {
     for (size_t i = lo; i < hi; i++) {
       if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
       const size_t k = i - lo;
       if (skip && (*skip)[i]) continue;
+      // check_sample_frac (record_sampler.rs:80-86): one draw per record the iterator yields, before anything else is looked at.  Only the
+      // unmapped leg draws, and there (no edge filter, no BED, no alignment) "the tags parse and hold a position" == "a value is left"
+      if (draws && nv[k] != 0 && !draws->keep(frac)) continue;
       std::string name = batch.name(cand[i]);
       // with_mod_base_info drops reads whose tags fail or are empty before the sampler is asked; a read that parses
       // but keeps no position is asked, not counted, and not recorded
@@ -276,7 +281,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
   };
   auto take = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen,
-      TakeState* ts, const std::vector<uint8_t>* skip = nullptr) {
+      TakeState* ts, const std::vector<uint8_t>* skip = nullptr, SeededSampler* draws = nullptr, double frac = 1.0) {
     size_t next = from;
     while (next < cand.size() && (limit < 0 || ts->used < (size_t)limit)) {
       size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - ts->used));
@@ -284,7 +289,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       std::vector<std::pair<const RecSet*, size_t>> which; which.reserve(hi - next); for (size_t i = next; i < hi; i++) which.push_back({&batch, cand[i]});
       std::vector<uint32_t> nv; sample_round(which, tid, mapped_contig, &nv);
       std::vector<uint8_t> mask(which.size(), 0);
-      decide(batch, cand, next, hi, nv.data(), limit, interval_seen, ts, skip, mask.data());
+      decide(batch, cand, next, hi, nv.data(), limit, interval_seen, ts, skip, mask.data(), draws, frac);
       int rc = mkp_internal_sample_take(ctx, mask);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       next = hi;
@@ -429,10 +434,14 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     long limit;
     if (!a.have_frac) limit = (long)(a.num_reads > taken.size() ? a.num_reads - taken.size() : 0);
     else if (a.sampling_frac >= 1.0) limit = -1;
-    else { if (!cand.empty()) throw Error(MKP_E_UNSUPPORTED,
-        "unmapped-read sampling with --sampling-frac < 1 depends on rand::StdRng (record_sampler.rs:80-86): not reproducible");
-    limit = -1; }
-    std::set<std::string> seen; TakeState ts; take(batch, cand, 0, limit, 0, false, &seen, &ts);
+    else limit = -1;
+    // RecordSampler::new_from_options (record_sampler.rs:51-61): a fraction < 1 is a Bernoulli draw per record from StdRng — seeded by
+    // --seed, else from entropy (no two runs of the reference agree: refused, --seed makes it a function of the input)
+    const bool draws = a.have_frac && a.sampling_frac < 1.0;
+    if (draws && !cand.empty() && !a.have_seed) throw Error(MKP_E_UNSUPPORTED,
+        "unmapped-read sampling with --sampling-frac < 1 draws from an entropy-seeded rand::StdRng (record_sampler.rs:29-38): give --seed");
+    SeededSampler rng(a.seed);
+    std::set<std::string> seen; TakeState ts; take(batch, cand, 0, limit, 0, false, &seen, &ts, nullptr, draws ? &rng : nullptr, a.sampling_frac);
   }
 }
 
@@ -1163,7 +1172,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     if (hemi && (s == "-o" || s == "--out-bed")) { a.out_bed = val(); continue; }
     if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
     else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
-    else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath" || s == "--seed") val();
+    else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath") val();
+    else if (s == "--seed") { a.have_seed = true; a.seed = std::stoull(val()); }
     else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true;
         a.sampling_frac = std::stod(val()); }
     else if (s == "--no-filtering") a.no_filtering = true; else if (s == "-p" || s == "--filter-percentile") a.filter_percentile = std::stof(val());

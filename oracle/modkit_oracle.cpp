@@ -324,6 +324,7 @@ struct Options {
   uint32_t max_depth = 8000, interval_size = 100000, sampling_interval_size = 1000000;
   size_t threads = 4, num_reads = 10042; bool have_chunk = false; size_t chunk_size = 0;
   bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
+  bool have_seed = false; uint64_t seed = 0;   // --seed (RecordSampler::new_sample_frac, record_sampler.rs:29-38)
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false;
   bool invert_edge = false, mixed_delim = false, with_header = false;
@@ -423,7 +424,7 @@ struct SampledProbs {
 struct SampleCtx { const BamFile* bam; const CollapseMethod* collapse; const EdgeFilter* edge; const PositionFilter* pf; bool only_mapped; bool keep_calls = false; };
 
 // process_records (223-362) over an iterator of records; limit: -1 = passthrough, else first-N
-static SampledProbs process_records(const std::vector<const BamRecord*>& recs, long limit, const SampleCtx& cx) {
+static SampledProbs process_records(const std::vector<const BamRecord*>& recs, long limit, const SampleCtx& cx, StdRng* rng = nullptr, double frac = 1.0) {
   SampledProbs out; size_t used = 0;
   for (const BamRecord* rp : recs) {
     const BamRecord& r = *rp;
@@ -434,6 +435,7 @@ static SampledProbs process_records(const std::vector<const BamRecord*>& recs, l
     if (info.is_empty()) continue;
     if ((cx.only_mapped || cx.edge->active) && (r.flag & 4)) continue;
     if (limit >= 0 && used >= (size_t)limit) break;  // RecordSampler::ask -> Done
+    if (rng && !rng->gen_bool(frac)) continue;        // check_sample_frac (record_sampler.rs:80-86): one draw per record the iterator yields -> Skip
     std::unordered_map<size_t, uint64_t> pairs;
     if (cx.only_mapped) {
       size_t q = 0; uint64_t rpos = (uint64_t)r.pos; size_t L = (size_t)r.l_seq;
@@ -541,8 +543,13 @@ static SampledProbs sample_reads(const BamFile& bam, const Options& o, const Reg
     long limit;
     if (!o.have_frac) limit = (long)(o.num_reads > agg.len() ? o.num_reads - agg.len() : 0);
     else if (o.sampling_frac >= 1.0) limit = -1;
-    else { if (!un.empty()) throw MkErr("unmapped-read sampling with --sampling-frac < 1 uses rand::StdRng: parity unpinned, unsupported"); limit = -1; }
-    agg.merge(process_records(un, limit, cx));
+    else limit = -1;
+    // new_from_options (record_sampler.rs:51-61): --num-reads -> first N; --sampling-frac -> a Bernoulli draw per record from StdRng,
+    // seeded by --seed; without --seed the reference seeds from entropy and no two runs agree: refused here as by the product
+    const bool draws = o.have_frac && o.sampling_frac < 1.0;
+    if (draws && !un.empty() && !o.have_seed) throw MkErr("unmapped-read sampling with --sampling-frac < 1 draws from an entropy-seeded rand::StdRng: give --seed");
+    StdRng rng = StdRng::seed_from_u64(o.seed);
+    agg.merge(process_records(un, limit, cx, draws ? &rng : nullptr, o.sampling_frac));
   }
   return agg;
 }
@@ -866,7 +873,7 @@ int main(int argc, char** argv) {
       else if (a == "-t" || a == "--threads") o.threads = std::stoul(val()); else if (a == "-i" || a == "--interval-size") o.interval_size = (uint32_t)std::stoul(val());
       else if (a == "--chunk-size") { o.have_chunk = true; o.chunk_size = std::stoul(val()); }
       else if (a == "-n" || a == "--num-reads") o.num_reads = std::stoul(val()); else if (a == "-f" || a == "--sampling-frac") { o.have_frac = true; o.sampling_frac = std::stod(val()); }
-      else if (a == "--seed") val(); else if (a == "--no-filtering") o.no_filtering = true; else if (a == "-p" || a == "--filter-percentile") o.filter_percentile = std::stof(val());
+      else if (a == "--seed") { o.have_seed = true; o.seed = std::stoull(val()); } else if (a == "--no-filtering") o.no_filtering = true; else if (a == "-p" || a == "--filter-percentile") o.filter_percentile = std::stof(val());
       else if (a == "--filter-threshold") o.filter_threshold.push_back(val()); else if (a == "--mod-thresholds" || a == "--mod-threshold") o.mod_thresholds.push_back(val());
       else if (a == "--sample-region") o.sample_region = val(); else if (a == "--sampling-interval-size") o.sampling_interval_size = (uint32_t)std::stoul(val());
       else if (a == "--include-bed" || a == "--include-positions") o.include_bed = val(); else if (a == "--include-unmapped") o.include_unmapped = true;

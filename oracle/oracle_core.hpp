@@ -13,6 +13,7 @@
 //   rustc-hash 1.1 FxHasher + hashbrown       (iteration order of small maps)
 //   rust-lapper 1.1                           (merge_overlaps / find)
 //   bio 1.0 fasta::IndexedReader              (fetch/read)
+//   rand 0.8.5 StdRng (rand_chacha 0.3 ChaCha12, rand_core 0.6 seed_from_u64, Bernoulli)   (--seed with --sampling-frac < 1)
 //
 // Parity unpinned by any reference fixture (derived from code only): ties in
 // mod-code probability, >=3 codes per base, ChEBI ordering (derived Ord: Code <

@@ -72,3 +72,56 @@ def test_fuzzed_percentiles_match_oracle(oracle_bin, tmp_path, profile):
                 assert got[b]["n"] == want[b]["n"] and [f32bits(v) for v in got[b]["percentiles"].values()] == [f32bits(v) for v in want[b]["percentiles"]]
     finally:
         ctx.close()
+
+
+def unmapped_tail_bam(prefix, n_mapped=30, n_unmapped=600, seed=11):
+    """A few mapped reads (fewer than 100 sampled records: reads_sampler/mod.rs:89-90 then always turns to the unmapped ones) and a tail of
+    records without coordinates, each with a `C+m?` tag; every tenth record carries no tags (the iterator never offers it to the sampler)."""
+    import random
+    from bamfuzz import aux_bc, aux_z, bam_header, bam_record, bgzf_write, write_bai
+    r = random.Random(seed)
+    contigs = [("ctg", 6000)]
+    data = bytearray(bam_header(contigs))
+    index = []
+
+    def one(tid, pos, flag, k):
+        n = r.randrange(60, 220)
+        seq = "".join(r.choice("ACGT") for _ in range(n))
+        ncalls = min(seq.count("C"), r.randrange(1, 12))
+        aux = b"" if (k % 10 == 9 or ncalls == 0) else aux_z("MM", "C+m?," + ",".join("0" for _ in range(ncalls)) + ";") + aux_bc("ML", [r.randrange(256) for _ in range(ncalls)])
+        cigar = [(n, "M")] if tid >= 0 else []
+        rec = bam_record(tid, pos, flag, "r%05d" % k, cigar, seq, aux)
+        index.append((tid, pos, n if tid >= 0 else 0, flag, len(data), len(rec)))
+        data.extend(rec)
+
+    starts = sorted(r.randrange(0, 5000) for _ in range(n_mapped))
+    for k, s in enumerate(starts):
+        one(0, s, 0, k)
+    for k in range(n_unmapped):
+        one(-1, -1, 4, n_mapped + k)
+    offs = bgzf_write(prefix + ".bam", bytes(data))
+    write_bai(prefix + ".bam.bai", 1, offs, index)
+    return prefix + ".bam"
+
+
+def test_seeded_fraction_of_the_unmapped_reads(oracle_bin, tmp_path):
+    # `-f 0.4 --seed S` (record_sampler.rs:29-38, 80-86): the unmapped records that enter the sample follow StdRng's draws — the same on
+    # both sides, different from seed to seed, and refused without a seed (the reference would seed from entropy)
+    bam = unmapped_tail_bam(str(tmp_path / "un"))
+    qs = [0.1, 0.5, 0.9]
+    ctx = modkit_amd.Context()
+    try:
+        ns = []
+        for flags in (["-f", "0.4", "--seed", "7"], ["-f", "0.4", "--seed", "8"], ["-f", "0.05", "--seed", "123456789012"], ["-f", "0.999", "--seed", "0"], ["--no-sampling"]):
+            want = oracle_table(oracle_bin, bam, flags, qs)
+            got = ctx.sample_probs(bam, qs, flags)
+            assert want is not None and set(got) == set(want) == {"C"}
+            assert got["C"]["n"] == want["C"]["n"]
+            assert [f32bits(v) for v in got["C"]["percentiles"].values()] == [f32bits(v) for v in want["C"]["percentiles"]]
+            ns.append(got["C"]["n"])
+        assert ns[0] != ns[1] and ns[2] < ns[0] < ns[3] <= ns[4]
+        assert oracle_table(oracle_bin, bam, ["-f", "0.4"], qs) is None
+        with pytest.raises(modkit_amd.MkpError):
+            ctx.sample_probs(bam, qs, ["-f", "0.4"])
+    finally:
+        ctx.close()
