@@ -143,7 +143,7 @@ typedef struct {
   double decode_kernel_ms, pileup_kernel_ms, gather_kernel_ms;
   uint64_t n_reads, n_events, n_rows, n_tiles, n_positions;
   uint64_t alg_bytes_decode, alg_bytes_pileup; /* SURVEY.md §8(d) algorithmic bytes of the decode and pileup kernels */
-  double rows_kernel_ms;                       /* always 0: rows are emitted by the aggregation kernels straight from LDS (kept for layout compatibility) */
+  double rows_kernel_ms; /* always 0: rows are emitted by the aggregation kernels straight from LDS (kept for layout compatibility) */
   uint64_t alg_bytes_rows;                     /* 44 B per row */
   /* focus runs on the slot pipeline: feature-stream bytes (one per read and focus position in its span) and
    * SURVEY §8(d)'s literal B_agg = 8 B per coverage / call event + 44 B per row for the aggregation kernel */
@@ -235,7 +235,8 @@ typedef struct {
   double grid_wait_ms;          /* the threshold estimate waiting for the reference FASTA and the interval grid (not part of threshold_ms) */
   double callback_ms;           /* mkp_pileup_run_cb: inside the caller's threshold callback (all-reduce / broadcast; not part of threshold_ms) */
   double ingest_kernel_ms;      /* device ingest, summed over the shards: the inflate launch + record chains (HIP events) */
-  double ingest_upload_ms, ingest_table_ms, ingest_pack_ms;   /* ... the uploads, the block tables, parse + scans + pack incl. their syncs (host clocks) */
+  double ingest_upload_ms, ingest_table_ms, ingest_pack_ms;
+    /* ... the uploads, the block tables, parse + scans + pack incl. their syncs (host clocks) */
   uint64_t ingest_comp_bytes, ingest_raw_bytes, ingest_blocks, ingest_records;   /* compressed bytes uploaded, bytes they inflated to */
 } mkp_run_report;
 int mkp_pileup_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run_report* report);

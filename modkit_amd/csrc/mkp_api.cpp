@@ -13,26 +13,36 @@
 using namespace mkp;
 
 extern "C" {
-hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[7]*/, const uint32_t*, const uint8_t*,
+hipError_t mkp_launch_decode(hipStream_t, const MkpReadHdr*, const uint32_t* /*read ids by class*/, const uint32_t* /*n_class[7]*/, const uint32_t*,
+    const uint8_t*,
     const MkpTagRef*, const uint32_t*,
                              const uint8_t*, const MkpLayout*, const MkpRunParams*, MkpEvent*, MkpReadOut*, uint32_t*, const uint8_t*, float*);
 hipError_t mkp_pileup_set_lds(uint32_t accum_bytes);
-hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*, const MkpEvent*,
+hipError_t mkp_launch_pileup(hipStream_t, uint32_t /*LDS bytes*/, int /*focus mode*/, const MkpReadHdr*, const uint32_t*, const uint8_t*,
+    const MkpEvent*,
     const MkpReadOut*, const MkpTile*, uint32_t,
-                             const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/,
-                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
-hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*, const uint32_t* /*cover read ids*/,
+                             const MkpRunParams* /*device*/, const uint32_t* /*slot bitmap*/, const uint8_t* /*focus bytes*/, const MkpCombo*,
+                                 const MkpRowsDev*, uint32_t* /*row cursor*/,
+                             uint32_t* /*tile row offsets*/, uint32_t* /*tile row counts*/, const uint32_t* /*chunk offsets*/,
+                                 uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/);
+hipError_t mkp_launch_slots(hipStream_t, const MkpWork* /*fused reads: long | short*/, uint32_t, uint32_t, const MkpReadHdr*,
+    const uint32_t* /*cover read ids*/,
     uint32_t, const uint32_t*, const uint8_t*, const MkpTagRef*,
-                            const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*, const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
+                            const uint32_t*, const uint8_t*, const MkpLayout*, const MkpFusedDesc*, const MkpRunParams*,
+                                const uint32_t* /*slot positions*/, uint8_t* /*feature stream*/, MkpVisit*, MkpEvent*, MkpReadOut*, uint32_t*);
 hipError_t mkp_stream_set_lds(uint32_t bytes);
 hipError_t mkp_launch_dup_restore(hipStream_t, MkpReadHdr*, const MkpDupCons*, uint32_t);
-hipError_t mkp_launch_dup_events(hipStream_t, MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, MkpDupCons*, const MkpDupSeg*, uint32_t, uint32_t* /*error bits*/);
+hipError_t mkp_launch_dup_events(hipStream_t, MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, MkpDupCons*, const MkpDupSeg*,
+    uint32_t, uint32_t* /*error bits*/);
 hipError_t mkp_launch_stream(hipStream_t, uint32_t /*LDS bytes*/, const MkpVisit*, const uint8_t*, const MkpEvent*, const MkpSTile*, uint32_t,
     const MkpRunParams* /*device*/, const uint32_t* /*slot positions*/,
-                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*, uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, uint32_t /*motif combos*/, uint32_t /*row runs of the launch sequence*/,
+                             const uint8_t* /*focus bytes*/, const MkpCombo*, const MkpRowsDev*, uint32_t* /*row cursor*/, uint32_t*, uint32_t*,
+                                 uint32_t* /*error bits*/, uint32_t /*key filter*/, uint32_t /*key pass*/, uint32_t /*motif combos*/,
+                                 uint32_t /*row runs of the launch sequence*/,
                              uint32_t /*slot capacity of a tile*/, uint32_t /*tally words per slot*/);
 hipError_t mkp_launch_gather(hipStream_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t, uint32_t*, const MkpRowsDev*, const MkpRowsDev*);
-hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t, const uint32_t* /*slot bitmap*/,
+hipError_t mkp_launch_hemi_failed(hipStream_t, const MkpReadHdr*, const uint32_t*, const uint8_t*, MkpEvent*, MkpReadOut*, uint32_t,
+    const uint32_t* /*slot bitmap*/,
     const uint32_t* /*interval starts*/,
                                   uint32_t, int32_t, int32_t, uint32_t* /*error bits*/);
 }
@@ -86,7 +96,8 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   auto class_of = [&](size_t i) -> int {
     const MkpReadHdr& h = S.hdr[i];
     auto same = [&](uint32_t t0, uint32_t t1) { const MkpTagRef &a = S.tagref[h.tag_off + t0], &b = S.tagref[h.tag_off + t1];
-        if (S.dev_packed) return t1 == t0 + 1 && b.pad != 0;   // compared on the device while the lists were written (only neighbours are ever asked about)
+        // compared on the device while the lists were written (only neighbours are ever asked about)
+        if (S.dev_packed) return t1 == t0 + 1 && b.pad != 0;
         return a.n == b.n && (a.n == 0 || memcmp(&S.ranks[a.rank_off], &S.ranks[b.rank_off], 4 * (size_t)a.n) == 0); };
     if ((h.flags & MKP_RF_BAD) || !h.n_tags || h.layout >= T.dev.size()) return 4;
     const MkpLayout& L = T.dev[h.layout];
@@ -109,10 +120,12 @@ void class_ids(const ShardHost& S, const LayoutTables& T, std::vector<uint32_t>*
   host_parallel(S.hdr.size(), 4096, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) cl[i] = (uint8_t)class_of(i); });
   std::vector<uint32_t> cls[7];
   for (size_t i = 0; i < cl.size(); i++) cls[cl[i]].push_back((uint32_t)i);
-  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) stable_sort_desc(cls[c], [&](uint32_t x) { return S.hdr[x].l_seq; }); });
+  host_parallel(7, 1, [&](size_t lo, size_t hi) { for (size_t c = lo; c < hi; c++) stable_sort_desc(cls[c], [&](uint32_t x) { return S.hdr[x].l_seq;
+    }); });
   ids->clear();
   for (int c = 0; c < 5; c++) { n_class[c] = (uint32_t)cls[c].size(); ids->insert(ids->end(), cls[c].begin(), cls[c].end()); }
-  for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r); ids->push_back(r | 0x80000000u); } }
+  for (int c = 5; c < 7; c++) { n_class[c] = 2u * (uint32_t)cls[c].size(); for (uint32_t r : cls[c]) { ids->push_back(r);
+      ids->push_back(r | 0x80000000u); } }
 }
 
 // MkpFusedDesc of a layout whose tags form one explicit-mode group (decode class SPARSE): the walk of
@@ -136,7 +149,8 @@ MkpFusedDesc fused_desc(const MkpLayout& D) {
   f.nc = (uint32_t)D.tags[0].n_codes | ((D.n_tags > 1 ? (uint32_t)D.tags[1].n_codes : 0u) << 8);
   f.thr_can = G.thr_can;
   // the thresholds of the integer caller: least T with T / 2048 >= threshold (exact in double: a float times 2^11)
-  auto i_of = [](float thr) -> int32_t { if (!(thr == thr)) return INT32_MAX; const double t = std::ceil((double)thr * 2048.0); return (int32_t)std::max(-1073741824.0, std::min(1073741824.0, t)); };
+  auto i_of = [](float thr) -> int32_t { if (!(thr == thr)) return INT32_MAX; const double t = std::ceil((double)thr * 2048.0); return (int32_t)std::max(-1073741824.0,
+      std::min(1073741824.0, t)); };
   for (uint32_t i = 0; i < MKP_KMAX; i++) f.i_thr[i] = i_of(f.it_thr[i]);
   f.i_can = i_of(f.thr_can);
   f.misc |= 1u << 6;
@@ -146,7 +160,8 @@ MkpFusedDesc fused_desc(const MkpLayout& D) {
     f.col = 1u; f.n_other = (float)n_pre;
     for (uint32_t t = 0; t < D.n_tags; t++) for (uint32_t k = 0; k < D.tags[t].n_codes; k++)
       if ((int)((D.tagmap[t][b0] >> (4 + 4 * k)) & 15u) == x) f.col |= (t | (k << 1)) << 1;
-    if (n_pre == 1 || n_pre == 2 || n_pre == 4) f.col |= (n_pre == 1 ? 0u : n_pre == 2 ? 1u : 2u) << 5; else col_exact = false;   // (a share over three codes is rounded: the f32 walk stays)
+    // (a share over three codes is rounded: the f32 walk stays)
+    if (n_pre == 1 || n_pre == 2 || n_pre == 4) f.col |= (n_pre == 1 ? 0u : n_pre == 2 ? 1u : 2u) << 5; else col_exact = false;
   }
   if (col_exact) f.misc |= 1u << 7;
   return f;
@@ -174,10 +189,12 @@ void depth_guard(const ShardHost& S, uint32_t max_depth) {
   for (auto& h : S.hdr) { st.push_back(h.ref_start); en.push_back(std::max(h.ref_end, h.ref_start + 1)); }
   for (auto& x : S.extra_spans) { st.push_back(x.first); en.push_back(std::max(x.second, x.first + 1)); }
   // (alignment starts and ends are non-negative: they sort as unsigned)
-  { std::vector<uint32_t> a(st.begin(), st.end()), b(en.begin(), en.end()); if (!std::is_sorted(a.begin(), a.end())) sort_u32(a); sort_u32(b); std::copy(a.begin(), a.end(), st.begin()); std::copy(b.begin(), b.end(), en.begin()); }
+  { std::vector<uint32_t> a(st.begin(), st.end()), b(en.begin(), en.end()); if (!std::is_sorted(a.begin(), a.end())) sort_u32(a); sort_u32(b);
+    std::copy(a.begin(), a.end(), st.begin()); std::copy(b.begin(), b.end(), en.begin()); }
   size_t j = 0, cur = 0, best = 0;
   for (size_t i = 0; i < n; i++) { while (j < n && en[j] <= st[i]) { j++; cur--; } cur++; best = std::max(best, cur); }
-  if (best > 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
+  if (best > 65535) throw Error(MKP_E_UNSUPPORTED,
+      "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
   if (best > max_depth) throw Error(MKP_E_UNSUPPORTED,
       "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
 }
@@ -194,7 +211,8 @@ hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void
   return mkp_launch_inflate_wave4(st, in, blks, n, out, status, 4);
 }
 namespace {
-hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) { return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
+hipError_t launch_inflate(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status) {
+  return mkp_launch_inflate_auto(st, in, blks, n, out, status); }
 
 // slot bitmap of a focus window (bit p - win_start + margin set where position p owns a tally column), its running popcount per word and —
 // slot pipeline — the slot positions.  Depends on the focus bytes only.
@@ -206,16 +224,21 @@ void window_slots(mkp_ctx* c, bool hemi, bool stream, std::vector<uint32_t>& slo
   const uint8_t* fz = c->focus.data();
   // pileup-hemi: only the positions with a positive-strand motif hit own a column (positions_to_motifs.get(pos), duplex.rs:289-296)
   uint8_t hemi_ok[64]; for (size_t k = 0; k < 64; k++) hemi_ok[k] = (k < c->combos.size() && c->combos[k].n_pos > 0) ? 1 : 0;
-  host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {   // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
+  // pieces are multiples of 32 positions and the margin is 64: no two pieces share a word
+  host_parallel((size_t)win, (size_t)1 << 20, [&](size_t lo, size_t hi) {
     for (size_t p = lo; p < hi; p++) if (hemi ? ((fz[p] & 1u) && hemi_ok[fz[p] >> 2]) : (fz[p] & 3u)) { const size_t b = p + MKP_SLOTBM_MARGIN;
         slotbm[b >> 5] |= 1u << (b & 31); }
   });
   wpfx.assign(nwords + 1, 0);
   {   // running popcount over the bitmap words: block sums on all cores, a short serial pass over the blocks, then the blocks again
     const size_t blk = (size_t)1 << 16, nblk = (nwords + blk - 1) / blk; std::vector<uint32_t> bsum(nblk + 1, 0);
-    host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t t = 0; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) t += (uint32_t)__builtin_popcount(slotbm[w]); bsum[b + 1] = t; } });
+    host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t t = 0;
+        for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) t += (uint32_t)__builtin_popcount(slotbm[w]);
+        bsum[b + 1] = t; } });
     for (size_t b = 0; b < nblk; b++) bsum[b + 1] += bsum[b];
-    host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t run = bsum[b]; for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) { wpfx[w] = run; run += (uint32_t)__builtin_popcount(slotbm[w]); } } });
+    host_parallel(nblk, 1, [&](size_t lo, size_t hi) { for (size_t b = lo; b < hi; b++) { uint32_t run = bsum[b];
+        for (size_t w = b * blk; w < std::min(nwords, (b + 1) * blk); w++) { wpfx[w] = run;
+          run += (uint32_t)__builtin_popcount(slotbm[w]); } } });
     wpfx[nwords] = bsum[nblk];
   }
   slot_pos_h.clear();
@@ -254,7 +277,8 @@ void make_resident(mkp_ctx* c) {
         const uint64_t kk = i < S.hdr.size() ? S.hdr[i].flags >> MKP_RF_KEY_SHIFT : 0u;   // per partition key: tallies of different keys never meet
         size_t at = (size_t)((hh * 0x9e3779b97f4a7c15ull) >> 20) & (cap - 1);
         for (;;) { if (!used[at]) { used[at] = 1; tab[at] = hh; key[at] = kk; who[at] = (uint32_t)i; break; }
-                   if (tab[at] == hh && key[at] == kk) { std::lock_guard<std::mutex> g(dmu); dups.push_back({who[at], (uint32_t)i}); break; } at = (at + 1) & (cap - 1); } }
+                   if (tab[at] == hh && key[at] == kk) { std::lock_guard<std::mutex> g(dmu); dups.push_back({who[at], (uint32_t)i}); break;
+                     } at = (at + 1) & (cap - 1); } }
     } });
     // The reference keys its read cache by NAME, one cache per interval (read_cache.rs:28-35, pileup/mod.rs:718-760): two kept records
     // with one name meet only if they overlap a common interval — then the later one is answered from the earlier one's calls, which the
@@ -263,12 +287,15 @@ void make_resident(mkp_ctx* c) {
     // Every pair of records of one name is judged (three records A, B, C: the table above names (A, B) and (A, C); B and C can meet too).
     // A record that lies wholly outside the shard window — a halo record of the fetch — belongs to none of its intervals.
     std::map<uint32_t, std::vector<uint32_t>> groups;
-    for (auto& d : dups) { if (d.first >= S.hdr.size() || d.second >= S.hdr.size()) continue; auto& g = groups[d.first]; if (g.empty()) g.push_back(d.first); g.push_back(d.second); }
+    for (auto& d : dups) { if (d.first >= S.hdr.size() || d.second >= S.hdr.size()) continue; auto& g = groups[d.first];
+      if (g.empty()) g.push_back(d.first);
+      g.push_back(d.second); }
     auto iv_range = [&](const MkpReadHdr& h, int64_t* a, int64_t* b) -> bool {   // false: outside the window
       const int64_t s0 = h.ref_start, e0 = std::max<int64_t>(h.ref_end, (int64_t)h.ref_start + 1);
       if (e0 <= (int64_t)S.win_start || s0 >= (int64_t)S.win_end) return false;
       if (c->iv_starts.empty()) { *a = 0; *b = 0; return true; }
-      auto idx = [&](int64_t p) { return (int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1; };
+      auto idx = [&](int64_t p) {
+        return (int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1; };
       *a = std::max<int64_t>(idx(std::max<int64_t>(s0, S.win_start)), 0); *b = std::max<int64_t>(idx(std::min<int64_t>(e0, S.win_end) - 1), 0);
       return true;
     };
@@ -277,7 +304,9 @@ void make_resident(mkp_ctx* c) {
       std::vector<std::pair<int64_t, int64_t>> rg; rg.reserve(g.size());
       for (uint32_t r : g) { int64_t a, b; if (iv_range(S.hdr[r], &a, &b)) rg.push_back({a, b}); }
       bool meet = false;
-      for (size_t x = 0; x < rg.size() && !meet; x++) for (size_t y = x + 1; y < rg.size(); y++) if (rg[x].first <= rg[y].second && rg[y].first <= rg[x].second) { meet = true; break; }
+      for (size_t x = 0; x < rg.size() && !meet; x++) for (size_t y = x + 1; y < rg.size(); y++) if (rg[x].first <= rg[y].second
+          && rg[y].first <= rg[x].second) {
+        meet = true; break; }
       if (!meet) continue;
       // pileup-hemi keys its DuplexReadCache by name as well (read_cache.rs:368-468); that form is not reproduced
       if (c->hemi) throw Error(MKP_E_UNSUPPORTED,
@@ -287,19 +316,23 @@ void make_resident(mkp_ctx* c) {
   }
   lap("duplicate-name check");
   // caller tables over the layouts this shard's reads use (not whatever the packer has interned before)
-  { std::vector<uint8_t> used(c->packer.layouts.size(), 0); for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1;
+  { std::vector<uint8_t> used(c->packer.layouts.size(), 0);
+    for (auto& h : S.hdr) if (!(h.flags & MKP_RF_BAD) && h.n_tags && h.layout < used.size()) used[h.layout] = 1;
       c->tables.build(c->packer.layouts, c->caller, &used); }
   MkpRunParams& P = c->prm; memset(&P, 0, sizeof(P));
   P.win_start = S.win_start; P.win_end = S.win_end;
   P.n_counters = c->tables.n_counters; P.n_slots = (uint32_t)c->tables.st.slots.size(); P.n_pb = (uint32_t)c->tables.st.can_pbs.size();
-  P.numeric_mode = c->caller.numeric_mode; P.combine_strands = c->caller.combine_strands; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
-  P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = c->caller.force_allow; P.max_depth = c->caller.max_depth;
+  P.numeric_mode = c->caller.numeric_mode; P.combine_strands = c->caller.combine_strands; P.edge_filter = c->caller.edge;
+    P.edge_start = c->caller.edge_start;
+  P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = c->caller.force_allow;
+    P.max_depth = c->caller.max_depth;
   P.has_focus = c->has_focus; P.n_combos = (uint32_t)c->combos.size();
 #ifdef MKP_DEBUG
   if (const char* dbg = getenv("MKP_DEBUG_SKIP")) P.debug_skip = (uint32_t)strtoul(dbg, nullptr, 0);
 #endif
   for (int b = 0; b < 4; b++) { P.can_of_pb[b] = 0xff; P.pb_of_can[b] = 0; }
-  for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) { P.can_of_pb[c->tables.st.can_pbs[k]] = (uint8_t)k; P.pb_of_can[k] = (uint8_t)c->tables.st.can_pbs[k]; }
+  for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) { P.can_of_pb[c->tables.st.can_pbs[k]] = (uint8_t)k;
+    P.pb_of_can[k] = (uint8_t)c->tables.st.can_pbs[k]; }
   std::vector<int> order(P.n_slots); for (uint32_t i = 0; i < P.n_slots; i++) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { const MkpSlot &x = c->tables.st.slots[(size_t)a],
       &y = c->tables.st.slots[(size_t)b]; return x.code_repr != y.code_repr ? x.code_repr < y.code_repr : x.pb < y.pb; });
@@ -318,7 +351,8 @@ void make_resident(mkp_ctx* c) {
     for (size_t k = 0; k < c->tables.st.can_pbs.size(); k++) {
       const int pb = c->tables.st.can_pbs[k];
       std::vector<int> mine; for (size_t i = 0; i < c->tables.st.slots.size(); i++) if (c->tables.st.slots[i].pb == pb) mine.push_back((int)i);
-      std::sort(mine.begin(), mine.end(), [&](int x, int y) { return c->tables.st.slots[(size_t)x].code_repr < c->tables.st.slots[(size_t)y].code_repr; });
+      std::sort(mine.begin(), mine.end(), [&](int x, int y) {
+        return c->tables.st.slots[(size_t)x].code_repr < c->tables.st.slots[(size_t)y].code_repr; });
       const bool comb = P.numeric_mode == 1;   // DuplexModCall::into_combined: every modified element becomes the base's any-mod code
       const uint32_t nel = comb ? (mine.empty() ? 1u : 2u) : 1u + (uint32_t)mine.size();
       if (nel > MKP_KMAX + 1) throw Error(MKP_E_UNSUPPORTED, "more mod codes on one base than a pileup-hemi pattern block holds");
@@ -337,7 +371,8 @@ void make_resident(mkp_ctx* c) {
     if (c->hemi_iv.empty()) c->hemi_iv.push_back((uint32_t)S.win_start);
     if (!std::is_sorted(c->hemi_iv.begin(), c->hemi_iv.end())) throw Error(MKP_E_INVALID, "interval starts must ascend");
     for (auto& h : S.hdr) {
-      auto iv_of = [&](int64_t p) { return (int64_t)(std::upper_bound(c->hemi_iv.begin(), c->hemi_iv.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->hemi_iv.begin()); };
+      auto iv_of = [&](int64_t p) {
+        return (int64_t)(std::upper_bound(c->hemi_iv.begin(), c->hemi_iv.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->hemi_iv.begin()); };
       const int64_t need = iv_of((int64_t)h.ref_end - 1) - iv_of(h.ref_start) + 1;
       h.event_cap = (uint32_t)std::max<int64_t>(h.event_cap, need);
     }
@@ -374,7 +409,8 @@ void make_resident(mkp_ctx* c) {
       h.event_cap = std::max(h.event_cap, (uint32_t)need);
     } }
   { uint64_t off = 0;   // event slices laid out again (capacities may have grown above)
-    for (auto& h : S.hdr) { if (off > 0xfffffff0ull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
+    for (auto& h : S.hdr) {
+      if (off > 0xfffffff0ull - h.event_cap) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
         h.event_off = (uint32_t)off; off += h.event_cap; }
     S.n_events_cap = off; }
   P.readout_b_off = (uint32_t)S.hdr.size();
@@ -419,7 +455,8 @@ void make_resident(mkp_ctx* c) {
       const int64_t lo_clamp = (int64_t)S.win_start - MKP_SLOTBM_MARGIN, hi_clamp = (int64_t)S.win_end + MKP_SLOTBM_MARGIN;
       auto crank = [&](int64_t p) { return rank(std::min(std::max(p, lo_clamp), hi_clamp)); };
       const uint32_t total = wpfx[nwords];
-      host_parallel(S.hdr.size(), 8192, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { MkpReadHdr& h = S.hdr[i]; const uint32_t a = crank(h.ref_start), b = std::max(a, crank(h.ref_end)); h.gs0 = a; h.n_sl = b - a; h.pad = 0; } });
+      host_parallel(S.hdr.size(), 8192, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { MkpReadHdr& h = S.hdr[i];
+          const uint32_t a = crank(h.ref_start), b = std::max(a, crank(h.ref_end)); h.gs0 = a; h.n_sl = b - a; h.pad = 0; } });
       uint64_t off = 0;
       for (auto& h : S.hdr) {   // (the stream offsets are a running sum: serial, but nothing else is left in the loop)
         h.cov_off = (uint32_t)off;
@@ -432,10 +469,13 @@ void make_resident(mkp_ctx* c) {
       const uint32_t Smax = std::min<uint32_t>(MKP_PILEUP_THREADS, ((budget_words - MKP_STREAM_ROWMAP_WORDS) / (words_per_slot + 2u)) & ~63u);
       if (Smax < 128) throw Error(MKP_E_UNSUPPORTED, "too many counters for one LDS tile");
       // as many slots per tile as LDS and the one-thread-per-slot emission allow, down to ~1024 tiles for small windows: a read is visited once per
-      // tile it crosses and the visits are most of the kernel (C3, round 6: 448 / 640 / 704 / 896 / 992 slots: 0.153 / 0.139 / 0.128 / 0.125 / 0.116 ms)
+      // tile it crosses and the visits are most of the kernel (C3, round 6: 448 / 640 / 704 / 896 / 992 slots: 0.153 / 0.139 / 0.128 / 0.125 / 0.116
+      // ms)
       uint32_t Te = std::min<uint32_t>(Smax - 2 * MKP_HALO, std::max<uint32_t>(256u, (total / 1024u + 63u) & ~63u));
-      if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));   // tests: many small tiles
-      if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));
+      // tests: many small tiles
+      if (c->cfg.tile_positions) Te = std::max<uint32_t>(32u, std::min<uint32_t>(Smax - 2 * MKP_HALO, c->cfg.tile_positions / 4u));
+      if (const char* e = getenv("MKP_STREAM_TILE")) Te = std::max<uint32_t>(32u,
+          std::min<uint32_t>(Smax - 2 * MKP_HALO, (uint32_t)strtoul(e, nullptr, 10)));
           // experiments
       uint32_t most = 0;
       for (uint32_t g0 = 0; g0 < total; g0 += Te) {
@@ -488,7 +528,8 @@ void make_resident(mkp_ctx* c) {
     }
     tiles.swap(kept);
   }
-  if (stream) {   // slot tiles: reads are coordinate sorted, so their first slots ascend; the prefix-max of their slot ends bounds the first candidate
+  // slot tiles: reads are coordinate sorted, so their first slots ascend; the prefix-max of their slot ends bounds the first candidate
+  if (stream) {
     std::vector<uint32_t> pmax(n); uint32_t m = 0;
     for (size_t i = 0; i < n; i++) { m = std::max(m, S.hdr[i].gs0 + S.hdr[i].n_sl); pmax[i] = m; }
     size_t first = 0, last = 0; std::vector<MkpSTile> kept;
@@ -511,16 +552,20 @@ void make_resident(mkp_ctx* c) {
     auto cigar_of = [&](uint32_t r) {
       const MkpReadHdr& h = S.hdr[r]; std::vector<uint32_t> cg(h.n_cigar);
       if (!S.dev_packed) { for (uint32_t k = 0; k < h.n_cigar; k++) cg[k] = S.cigar[h.cigar_off + k]; }
-      else if (h.n_cigar) { hip_check(hipSetDevice(c->device), "hipSetDevice"); d2h_copy(cg.data(), c->d_cigar.as<uint32_t>() + h.cigar_off, (size_t)h.n_cigar * 4, c->stream); }
+      else if (h.n_cigar) { hip_check(hipSetDevice(c->device), "hipSetDevice");
+        d2h_copy(cg.data(), c->d_cigar.as<uint32_t>() + h.cigar_off, (size_t)h.n_cigar * 4, c->stream); }
       return cg;
     };
     const int64_t W0 = S.win_start, W1 = S.win_end;
     auto iv_bounds = [&](int64_t k, int64_t* a, int64_t* b) {   // interval k of the shard's grid, clipped to the window
       if (c->iv_starts.empty()) { *a = W0; *b = W1; return; }
-      *a = std::max<int64_t>(W0, k == 0 ? W0 : (int64_t)c->iv_starts[(size_t)k]); *b = (size_t)k + 1 < c->iv_starts.size() ? std::min<int64_t>(W1, (int64_t)c->iv_starts[(size_t)k + 1]) : W1;
+      *a = std::max<int64_t>(W0, k == 0 ? W0 : (int64_t)c->iv_starts[(size_t)k]);
+        *b = (size_t)k + 1 < c->iv_starts.size() ? std::min<int64_t>(W1, (int64_t)c->iv_starts[(size_t)k + 1]) : W1;
     };
     auto iv_index = [&](int64_t p) -> int64_t { if (c->iv_starts.empty()) return 0;
-      return std::max<int64_t>((int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(), (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1, 0); };
+      return std::max<int64_t>((int64_t)(std::upper_bound(c->iv_starts.begin(), c->iv_starts.end(),
+          (uint32_t)std::max<int64_t>(p, 0)) - c->iv_starts.begin()) - 1, 0);
+        };
     uint64_t ev_off = S.n_events_cap;
     for (auto& g : dup_groups) {
       struct Mem { uint32_t r; int64_t beg, end; std::vector<std::pair<int64_t, int64_t>> skips; };
@@ -529,15 +574,20 @@ void make_resident(mkp_ctx* c) {
         const MkpReadHdr& h = S.hdr[r]; Mem m; m.r = r; m.beg = h.ref_start; m.end = std::max<int64_t>(h.ref_end, (int64_t)h.ref_start + 1);
         if (m.end <= W0 || m.beg >= W1) continue;   // a halo record of the fetch: in none of the shard's intervals
         int64_t p = h.ref_start;
-        for (uint32_t w : cigar_of(r)) { const uint32_t op = w & 15u, len = w >> 4; if (op == 3u) m.skips.push_back({p, p + len}); if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) p += len; }
+        for (uint32_t w : cigar_of(r)) { const uint32_t op = w & 15u, len = w >> 4; if (op == 3u) m.skips.push_back({p, p + len});
+          if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) p += len;
+          }
         ms.push_back(std::move(m)); dup_member[r] = 1;
       }
       // first column of [lo, hi) in which member m is asked about: a focus position that is not inside one of its reference skips
       auto first_col = [&](const Mem& m, int64_t lo, int64_t hi) -> int64_t {
         lo = std::max(lo, m.beg); hi = std::min(hi, m.end);
-        auto in_skip = [&](int64_t p, int64_t* e) { for (auto& sk : m.skips) if (p >= sk.first && p < sk.second) { *e = sk.second; return true; } return false; };
+        auto in_skip = [&](int64_t p, int64_t* e) {
+          for (auto& sk : m.skips) if (p >= sk.first && p < sk.second) { *e = sk.second; return true; }
+          return false; };
         if (!c->has_focus) { int64_t p = lo, e; while (p < hi && in_skip(p, &e)) p = e; return p < hi ? p : -1; }
-        for (size_t k = (size_t)(std::lower_bound(slot_pos_h.begin(), slot_pos_h.end(), (uint32_t)std::max<int64_t>(lo, 0)) - slot_pos_h.begin()); k < slot_pos_h.size() && (int64_t)slot_pos_h[k] < hi; k++) {
+        for (size_t k = (size_t)(std::lower_bound(slot_pos_h.begin(), slot_pos_h.end(),
+            (uint32_t)std::max<int64_t>(lo, 0)) - slot_pos_h.begin()); k < slot_pos_h.size() && (int64_t)slot_pos_h[k] < hi; k++) {
           int64_t e; if (!in_skip((int64_t)slot_pos_h[k], &e)) return (int64_t)slot_pos_h[k]; }
         return -1;
       };
@@ -559,7 +609,8 @@ void make_resident(mkp_ctx* c) {
       for (size_t x = 0; x < ms.size(); x++) {
         bool foreign = false; for (auto& sg : segs_of[x]) if (sg.owner != ms[x].r) foreign = true;
         if (!foreign) continue;   // asked about first wherever it shows up: an ordinary record (whose events others may read)
-        MkpDupCons dc; memset(&dc, 0, sizeof(dc)); dc.rid = ms[x].r; dc.seg_off = (uint32_t)dup_segs.size(); dc.n_seg = (uint32_t)segs_of[x].size(); dc.own_off = S.hdr[ms[x].r].event_off;
+        MkpDupCons dc; memset(&dc, 0, sizeof(dc)); dc.rid = ms[x].r; dc.seg_off = (uint32_t)dup_segs.size(); dc.n_seg = (uint32_t)segs_of[x].size();
+          dc.own_off = S.hdr[ms[x].r].event_off;
         uint64_t cap = 0; for (auto& sg : segs_of[x]) { cap += S.hdr[sg.owner].event_cap; dup_segs.push_back(sg); }
         if (ev_off + cap > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
         dc.eff_off = (uint32_t)ev_off; dc.eff_cap = (uint32_t)cap; ev_off += cap;
@@ -584,16 +635,20 @@ void make_resident(mkp_ctx* c) {
       //  behind the fused reads of the class list, where the decode launch starts)
       if (!dup_groups.empty()) {
         std::vector<uint32_t> keep, f0, f1; const uint32_t n0 = c->n_class[0], n01 = c->n_class[0] + c->n_class[1]; uint32_t k0 = 0;
-        for (uint32_t k = 0; k < n01; k++) { const uint32_t r = class_list[k]; if (dup_member[r]) (k < n0 ? f0 : f1).push_back(r); else { keep.push_back(r); if (k < n0) k0++; } }
-        std::vector<uint32_t> nl(keep); nl.insert(nl.end(), f0.begin(), f0.end()); nl.insert(nl.end(), f1.begin(), f1.end()); nl.insert(nl.end(), class_list.begin() + n01, class_list.end());
-        class_list.swap(nl); c->n_class[0] = k0; c->n_class[1] = (uint32_t)keep.size() - k0; dup_forced[0] = (uint32_t)f0.size(); dup_forced[1] = (uint32_t)f1.size();
+        for (uint32_t k = 0; k < n01; k++) { const uint32_t r = class_list[k]; if (dup_member[r]) (k < n0 ? f0 : f1).push_back(r); else {
+            keep.push_back(r); if (k < n0) k0++; } }
+        std::vector<uint32_t> nl(keep); nl.insert(nl.end(), f0.begin(), f0.end()); nl.insert(nl.end(), f1.begin(), f1.end());
+          nl.insert(nl.end(), class_list.begin() + n01, class_list.end());
+        class_list.swap(nl); c->n_class[0] = k0; c->n_class[1] = (uint32_t)keep.size() - k0; dup_forced[0] = (uint32_t)f0.size();
+          dup_forced[1] = (uint32_t)f1.size();
       }
       const uint32_t nf = c->n_class[0] + c->n_class[1];
       for (uint32_t k = 0; k < nf; k++) is_fused[class_list[k]] = 1;
       // one list for both SPARSE classes, longest first; the reads of more than one base window (mkp_decode_slots_long) lead it
       slot_ids.resize(nf);
       auto longer = [&](uint32_t x, uint32_t y) { return S.hdr[x].l_seq > S.hdr[y].l_seq; };
-      std::merge(class_list.begin(), class_list.begin() + c->n_class[0], class_list.begin() + c->n_class[0], class_list.begin() + nf, slot_ids.begin(), longer);
+      std::merge(class_list.begin(), class_list.begin() + c->n_class[0], class_list.begin() + c->n_class[0], class_list.begin() + nf,
+          slot_ids.begin(), longer);
       uint32_t n_long = 0; while (n_long < nf && S.hdr[slot_ids[n_long]].l_seq > MKP_SLOT_WB) n_long++;
       c->n_slot_class[0] = n_long; c->n_slot_class[1] = nf - n_long;
       c->read_ids_dec_off = nf; c->n_class[0] = dup_forced[0]; c->n_class[1] = dup_forced[1];
@@ -614,13 +669,15 @@ void make_resident(mkp_ctx* c) {
   auto t1 = std::chrono::steady_clock::now();
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   upload(c->d_hdr, S.hdr);
-  if (!S.dev_packed) { upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml); }
+  if (!S.dev_packed) { upload(c->d_cigar, S.cigar); upload(c->d_chunk, S.chunk_pfx); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref);
+    upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml); }
   // (device ingest: those arrays were written in HBM by mkp_ingest_pack and handed over by mkp_internal_shard_attach)
   lap("upload: packed reads");
   upload(c->d_layouts, c->tables.dev); upload(c->d_tiles, tiles);
   upload(c->d_read_ids, class_list);
   if (c->has_focus && preplanned) { /* focus bytes, combos, slot bitmap and slot positions went up with the pre-plan */ }
-  else if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16); c->d_combos.ensure(64);
+  else if (c->has_focus) { upload(c->d_focus, c->focus); upload(c->d_combos, c->combos); upload(c->d_slotbm, slotbm); } else { c->d_focus.ensure(16);
+    c->d_combos.ensure(64);
       c->d_slotbm.ensure(16); }
   c->d_events.ensure(std::max<uint64_t>(S.n_events_cap, 1) * sizeof(MkpEvent));
   if (c->n_dup_cons) { upload(c->d_dupcons, dup_cons); upload(c->d_dupsegs, dup_segs); }
@@ -636,17 +693,20 @@ void make_resident(mkp_ctx* c) {
       host_parallel(nf, 8192, [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; k++) {
           const MkpReadHdr& h = S.hdr[slot_ids[k]]; MkpWork& w = work[k]; memset(&w, 0, sizeof(w));
-          w.ref_start = h.ref_start; w.l_seq = h.l_seq; w.n_cigar = h.n_cigar; w.cigar_off = h.cigar_off; w.seq_off = h.seq_off; w.flags = h.flags; w.gs0 = h.gs0;
+          w.ref_start = h.ref_start; w.l_seq = h.l_seq; w.n_cigar = h.n_cigar; w.cigar_off = h.cigar_off; w.seq_off = h.seq_off; w.flags = h.flags;
+            w.gs0 = h.gs0;
               w.n_sl = h.n_sl;
           w.cov_off = h.cov_off; w.n_tags = h.n_tags; w.layout = h.layout; w.rid = slot_ids[k];
-          if (!(h.flags & MKP_RF_BAD) && h.n_tags) { const MkpTagRef& t0 = S.tagref[h.tag_off]; w.rank_off = t0.rank_off; w.n_calls = t0.n; w.ml_off0 = t0.ml_off;
+          if (!(h.flags & MKP_RF_BAD) && h.n_tags) { const MkpTagRef& t0 = S.tagref[h.tag_off]; w.rank_off = t0.rank_off; w.n_calls = t0.n;
+            w.ml_off0 = t0.ml_off;
               if (h.n_tags > 1) w.ml_off1 = S.tagref[h.tag_off + 1].ml_off; }
         }
       });
       upload(c->d_work, work);
       std::vector<uint32_t> cover(slot_ids.begin() + nf, slot_ids.end()); upload(c->d_slot_ids, cover);
     }
-    { std::vector<MkpFusedDesc> fd(c->tables.dev.size()); for (size_t i = 0; i < fd.size(); i++) fd[i] = fused_desc(c->tables.dev[i]); upload(c->d_fdesc, fd); }
+    { std::vector<MkpFusedDesc> fd(c->tables.dev.size()); for (size_t i = 0; i < fd.size(); i++) fd[i] = fused_desc(c->tables.dev[i]);
+      upload(c->d_fdesc, fd); }
     c->d_cov.ensure(c->cov_bytes + 256); c->d_visits.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpVisit));
     hip_check(mkp_stream_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS, stream)");
   }
@@ -654,7 +714,8 @@ void make_resident(mkp_ctx* c) {
   // partition keys present in this shard: one accumulate pass each
   c->key_passes.clear();
   if (c->partition_tags.empty()) c->key_passes.push_back(MKP_NO_KEY_FILTER);
-  else { std::vector<uint8_t> seen(c->key_names.size(), 0); for (auto& h : S.hdr) { const uint32_t k = h.flags >> MKP_RF_KEY_SHIFT; if (k < seen.size()) seen[k] = 1;
+  else { std::vector<uint8_t> seen(c->key_names.size(), 0); for (auto& h : S.hdr) { const uint32_t k = h.flags >> MKP_RF_KEY_SHIFT;
+      if (k < seen.size()) seen[k] = 1;
       } for (uint32_t k = 0; k < seen.size(); k++) if (seen[k]) c->key_passes.push_back(k); if (c->key_passes.empty()) c->key_passes.push_back(0); }
   hip_check(mkp_pileup_set_lds(c->lds_bytes), "hipFuncSetAttribute(max dynamic LDS)");
   hip_check(hipDeviceSynchronize(), "upload sync");
@@ -664,7 +725,8 @@ void make_resident(mkp_ctx* c) {
   // algorithmic bytes
   uint64_t b_reads = 0; for (auto& h : S.hdr) b_reads += 16 + 4ull * h.n_cigar + (h.l_seq + 1) / 2;
   c->stats.n_reads = S.hdr.size(); c->stats.n_tiles = c->n_tiles; c->stats.n_positions = (uint64_t)win;
-  c->stats.alg_bytes_decode = b_reads + (S.dev_packed ? S.dev_n_ranks : S.ranks.size()) * 2ull + (S.dev_packed ? S.dev_n_ml : S.ml.size());  // + 8*events added after the run
+  // + 8*events added after the run
+  c->stats.alg_bytes_decode = b_reads + (S.dev_packed ? S.dev_n_ranks : S.ranks.size()) * 2ull + (S.dev_packed ? S.dev_n_ml : S.ml.size());
   c->stats.alg_bytes_pileup = b_reads;                                          // + 8*events + 44*rows added after the run
   c->stats.slot_pipeline = stream ? 1u : 0u; c->stats.stream_bytes = 0; c->stats.alg_bytes_agg_survey = 0;
   if (stream) {
@@ -688,72 +750,101 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
   }
   const bool trace = time_kernels && getenv("MKP_TRACE_PLAN") != nullptr;
   auto t_rk = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) { if (trace) { auto now = std::chrono::steady_clock::now(); fprintf(stderr, "[mkpileup plan]   kernels: %-20s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_rk).count()); t_rk = now; } };
+  auto lap = [&](const char* what) { if (trace) { auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[mkpileup plan]   kernels: %-20s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_rk).count()); t_rk = now;
+    } };
   const uint32_t n_runs = c->n_tiles * (uint32_t)c->key_passes.size();   // row runs: one per (key pass, tile), ordered by key then genome
   // (slot pipeline: row_off holds the runs' 64-bit look-back words behind a 64-byte header — the pass's cursor / total / error words — so that
   //  ONE memset readies a pass: between two kernels of a 1 ms step every extra fill or copy is a 5-10 us launch of its own)
-  c->d_tile_row_off.ensure(64 + (size_t)(n_runs + 1) * 8); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4); c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);
+  c->d_tile_row_off.ensure(64 + (size_t)(n_runs + 1) * 8); c->d_tile_row_cnt.ensure((size_t)(n_runs + 1) * 4);
+    c->d_tile_dst.ensure((size_t)(n_runs + 1) * 4);
   for (;;) {
     P.row_capacity = (uint32_t)c->row_cap;
     c->rows_src = carve_rows(c->d_rows_src, c->row_cap); c->rows_dst = carve_rows(c->d_rows_dst, c->row_cap);
     lap("row buffers");
-    if (trace) { hip_check(hipStreamSynchronize(c->stream), "sync"); lap("stream drained"); }   // (trace runs: what the stream still had queued shows up here, not in the kernels' sync)
-    uint32_t* misc = c->d_tile_row_off.as<uint32_t>();  // [0] row cursor / tile ticket, [1] total rows, [2] error bits; the look-back words (slot pipeline) or row offsets start at +16 dwords
+    // (trace runs: what the stream still had queued shows up here, not in the kernels' sync)
+    if (trace) { hip_check(hipStreamSynchronize(c->stream), "sync"); lap("stream drained"); }
+    // [0] row cursor / tile ticket, [1] total rows, [2] error bits; the look-back words (slot pipeline) or row offsets start at +16 dwords
+    uint32_t* misc = c->d_tile_row_off.as<uint32_t>();
     uint32_t* row_off = misc + 16;
     // rows leave mkp_pileup_stream in genome order (look-back over the runs): the words start at zero, the number of runs is a kernel argument
     hip_check(hipMemsetAsync(misc, 0, c->slot_mode ? 64 + (size_t)(n_runs + 1) * 8 : 64, c->stream), "memset");
     c->d_prm.ensure(sizeof(MkpRunParams));
-    if (c->prm_uploaded.size() != sizeof(MkpRunParams) || c->prm_uploaded_to != c->d_prm.p || memcmp(c->prm_uploaded.data(), &P, sizeof(MkpRunParams)) != 0) {   // (re-launches on a resident shard: unchanged)
-      c->prm_uploaded.assign(reinterpret_cast<const uint8_t*>(&P), reinterpret_cast<const uint8_t*>(&P) + sizeof(MkpRunParams)); c->prm_uploaded_to = c->d_prm.p;
+    // (re-launches on a resident shard: unchanged)
+    if (c->prm_uploaded.size() != sizeof(MkpRunParams) || c->prm_uploaded_to != c->d_prm.p
+        || memcmp(c->prm_uploaded.data(), &P, sizeof(MkpRunParams)) != 0) {
+      c->prm_uploaded.assign(reinterpret_cast<const uint8_t*>(&P), reinterpret_cast<const uint8_t*>(&P) + sizeof(MkpRunParams));
+        c->prm_uploaded_to = c->d_prm.p;
       hip_check(hipMemcpyAsync(c->d_prm.p, c->prm_uploaded.data(), sizeof(MkpRunParams), hipMemcpyHostToDevice, c->stream), "params H2D");
     }
     if (time_kernels) hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    if (c->n_dup_cons) hip_check(mkp_launch_dup_restore(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_dupcons.as<MkpDupCons>(), c->n_dup_cons), "dup restore launch");
-    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class, c->d_cigar.as<uint32_t>(),
+    if (c->n_dup_cons) hip_check(mkp_launch_dup_restore(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_dupcons.as<MkpDupCons>(), c->n_dup_cons),
+        "dup restore launch");
+    hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>() + c->read_ids_dec_off, c->n_class,
+        c->d_cigar.as<uint32_t>(),
         c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
-                                c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
-    if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(),
+                                c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(),
+                                    c->d_readout.as<MkpReadOut>(), misc + 2, c->d_focus.as<uint8_t>(), nullptr), "decode launch");
+    if (c->hemi) hip_check(mkp_launch_hemi_failed(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
+        c->d_events.as<MkpEvent>(),
         c->d_readout.as<MkpReadOut>(),
-                                                  (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(), (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
+                                                  (uint32_t)c->shard.hdr.size(), c->d_slotbm.as<uint32_t>(), c->d_hemi_iv.as<uint32_t>(),
+                                                      (uint32_t)c->hemi_iv.size(), P.win_start, P.win_end, misc + 2), "hemi failed-reads launch");
     // records answered from another record of their name: their event lists are rebuilt from the owners' (behind every event decoder, in front of
     // whatever consumes events: mkp_cover_reads / mkp_pileup_tiles)
-    if (c->n_dup_cons) hip_check(mkp_launch_dup_events(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                                       c->d_dupcons.as<MkpDupCons>(), c->d_dupsegs.as<MkpDupSeg>(), c->n_dup_cons, misc + 2), "dup events launch");
-    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_work.as<MkpWork>(), c->n_slot_class[0], c->n_slot_class[1], c->d_hdr.as<MkpReadHdr>(),
+    if (c->n_dup_cons) hip_check(mkp_launch_dup_events(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
+        c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+                                                       c->d_dupcons.as<MkpDupCons>(), c->d_dupsegs.as<MkpDupSeg>(), c->n_dup_cons, misc + 2),
+                                                           "dup events launch");
+    if (c->slot_mode) hip_check(mkp_launch_slots(c->stream, c->d_work.as<MkpWork>(), c->n_slot_class[0], c->n_slot_class[1],
+        c->d_hdr.as<MkpReadHdr>(),
         c->d_slot_ids.as<uint32_t>(), c->n_slot_class[2],
                                               c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(), c->d_tagref.as<MkpTagRef>(),
-                                              c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), c->d_fdesc.as<MkpFusedDesc>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(), c->d_visits.as<MkpVisit>(),
+                                              c->d_ranks.as<uint32_t>(), c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(),
+                                                  c->d_fdesc.as<MkpFusedDesc>(), &P, c->d_slot_pos.as<uint32_t>(), c->d_cov.as<uint8_t>(),
+                                                  c->d_visits.as<MkpVisit>(),
                                               c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2), "slot decode launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     for (uint32_t kp = 0; kp < c->key_passes.size(); kp++)   // one pass per partition key present (a single unfiltered pass without --partition-tag)
-      if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(), c->d_events.as<MkpEvent>(),
+      if (c->slot_mode) hip_check(mkp_launch_stream(c->stream, c->lds_bytes, c->d_visits.as<MkpVisit>(), c->d_cov.as<uint8_t>(),
+          c->d_events.as<MkpEvent>(),
           c->d_stiles.as<MkpSTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(),
-                                                 c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc, row_off, c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
-                                                 c->key_passes[kp], kp, (uint32_t)c->combos.size(), n_runs, P.slot_cap, P.n_counters + P.n_slots), "stream pileup launch");
-      else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(), c->d_cigar.as<uint32_t>(),
+                                                 c->d_slot_pos.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src,
+                                                     misc, row_off, c->d_tile_row_cnt.as<uint32_t>(), misc + 2,
+                                                 c->key_passes[kp], kp, (uint32_t)c->combos.size(), n_runs, P.slot_cap, P.n_counters + P.n_slots),
+                                                     "stream pileup launch");
+      else hip_check(mkp_launch_pileup(c->stream, c->lds_bytes, c->hemi ? 2 : c->has_focus ? 1 : 0, c->d_hdr.as<MkpReadHdr>(),
+          c->d_cigar.as<uint32_t>(),
           c->d_seq.as<uint8_t>(), c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
-                                  c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(), c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
-                                  row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp), "pileup launch");
+                                  c->d_tiles.as<MkpTile>(), c->n_tiles, c->d_prm.as<MkpRunParams>(), c->d_slotbm.as<uint32_t>(),
+                                      c->d_focus.as<uint8_t>(), c->d_combos.as<MkpCombo>(), &c->rows_src, misc,
+                                  row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_chunk.as<uint32_t>(), misc + 2, c->key_passes[kp], kp),
+                                      "pileup launch");
     if (time_kernels) hip_check(hipEventRecord(c->ev[2], c->stream), "event");
     if (c->slot_mode) c->rows_dst = c->rows_src;   // already in genome order
     else hip_check(mkp_launch_gather(c->stream, row_off, c->d_tile_row_cnt.as<uint32_t>(), c->d_tile_dst.as<uint32_t>(), n_runs, misc + 1,
         &c->rows_src, &c->rows_dst), "gather launch");
     if (time_kernels && !c->slot_mode) hip_check(hipEventRecord(c->ev[3], c->stream), "event");
     lap("launches");
-    if (trace && time_kernels) { hip_check(hipEventSynchronize(c->ev[0]), "sync"); lap("first event reached"); hip_check(hipEventSynchronize(c->ev[2]), "sync"); lap("kernels done (event)"); }
-    if (!c->h_words && hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 64, hipHostMallocDefault) != hipSuccess) { c->h_words = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); }
+    if (trace && time_kernels) { hip_check(hipEventSynchronize(c->ev[0]), "sync"); lap("first event reached");
+      hip_check(hipEventSynchronize(c->ev[2]), "sync"); lap("kernels done (event)"); }
+    if (!c->h_words && hipHostMalloc(reinterpret_cast<void**>(&c->h_words), 64, hipHostMallocDefault) != hipSuccess) { c->h_words = nullptr;
+      throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); }
     uint32_t* h = c->h_words;
     hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
     hip_check(hipStreamSynchronize(c->stream), "kernel sync");
     lap("sync");
     if (h[2] & 2u) { c->row_cap *= 2; if (c->row_cap > (1ull << 31)) throw Error(MKP_E_NOMEM, "row buffer would exceed 2^31 rows"); continue; }
     if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
-    if (h[2] & ERR_DUP_MIXED) throw Error(MKP_E_UNSUPPORTED, "records sharing a read name inside one interval are answered from the first one's calls (the reference's per-interval cache is keyed by name); here the records one of them is answered from in different intervals disagree in status or observed mod codes, which is not reproduced on the device");
+    if (h[2] & ERR_DUP_MIXED) throw Error(MKP_E_UNSUPPORTED,
+        "records sharing a read name inside one interval are answered from the first one's calls (the reference's per-interval cache is keyed by name); here the records one of them is answered from in different intervals disagree in status or observed mod codes, which is not reproduced on the device");
     c->stats.n_rows = h[1];
     if (time_kernels) {
-      float a = 0, b = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event"); hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
+      float a = 0, b = 0, d = 0; hip_check(hipEventElapsedTime(&a, c->ev[0], c->ev[1]), "event");
+        hip_check(hipEventElapsedTime(&b, c->ev[1], c->ev[2]), "event");
       if (!c->slot_mode) hip_check(hipEventElapsedTime(&d, c->ev[2], c->ev[3]), "event");   // (the slot pipeline has no gather pass)
-      c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = d; c->stats.kernel_ms = a + b + d;
+      c->stats.decode_kernel_ms = a; c->stats.pileup_kernel_ms = b; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = d;
+        c->stats.kernel_ms = a + b + d;
     }
     return;
   }
@@ -762,10 +853,12 @@ void run_kernels(mkp_ctx* c, bool time_kernels) {
 // row columns and per-read outcome counts, device -> host
 void fetch_row_columns(mkp_ctx* c) {
   const uint64_t n = c->stats.n_rows;
-  const uint32_t* src[11] = {c->rows_dst.pos, c->rows_dst.info, c->rows_dst.code, c->rows_dst.n_valid, c->rows_dst.n_mod, c->rows_dst.n_can, c->rows_dst.n_other,
+  const uint32_t* src[11] = {c->rows_dst.pos, c->rows_dst.info, c->rows_dst.code, c->rows_dst.n_valid, c->rows_dst.n_mod, c->rows_dst.n_can,
+      c->rows_dst.n_other,
                              c->rows_dst.n_del, c->rows_dst.n_fail, c->rows_dst.n_diff, c->rows_dst.n_nocall};
   c->h_rows.ensure(std::max<uint64_t>(n, 1));
-  if (n) { for (int k = 0; k < 11; k++) hip_check(hipMemcpyAsync(c->h_rows.col[k], src[k], n * 4, hipMemcpyDeviceToHost, c->stream), "rows D2H"); hip_check(hipStreamSynchronize(c->stream), "rows D2H sync"); }
+  if (n) { for (int k = 0; k < 11; k++) hip_check(hipMemcpyAsync(c->h_rows.col[k], src[k], n * 4, hipMemcpyDeviceToHost, c->stream), "rows D2H");
+    hip_check(hipStreamSynchronize(c->stream), "rows D2H sync"); }
   std::vector<MkpReadOut> ro(c->shard.hdr.size());
   d2h_copy(ro.data(), c->d_readout.p, ro.size() * sizeof(MkpReadOut), c->stream);
   c->n_ok = 0; c->n_bad = 0; uint64_t ev = 0;
@@ -798,16 +891,19 @@ void fetch_rows(mkp_ctx* c, mkp_rows* out) {
   fetch_row_columns(c);
   const uint64_t n = c->stats.n_rows;
   c->h_strand.resize(n); c->h_motif.resize(n); c->h_key.resize(n);
-  host_parallel(n, (size_t)1 << 17, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { const uint32_t inf = c->h_rows.col[1][i]; c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1;
+  host_parallel(n, (size_t)1 << 17, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) { const uint32_t inf = c->h_rows.col[1][i];
+      c->h_strand[i] = "+-."[inf & 3u]; c->h_motif[i] = (int32_t)((inf >> 8) & 0xffu) - 1;
       c->h_key[i] = inf >> 16; } });
   c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
   c->stats.d2h_ms = ms_since(t0);
   if (out) {
-    out->n_rows = n; out->pos = c->h_rows.col[0]; out->strand = c->h_strand.data(); out->code_repr = c->h_rows.col[2]; out->motif_idx = c->h_motif.data();
+    out->n_rows = n; out->pos = c->h_rows.col[0]; out->strand = c->h_strand.data(); out->code_repr = c->h_rows.col[2];
+      out->motif_idx = c->h_motif.data();
     out->n_valid = c->h_rows.col[3]; out->n_mod = c->h_rows.col[4]; out->n_canonical = c->h_rows.col[5]; out->n_other = c->h_rows.col[6];
     out->n_delete = c->h_rows.col[7]; out->n_fail = c->h_rows.col[8]; out->n_diff = c->h_rows.col[9]; out->n_nocall = c->h_rows.col[10];
     out->processed_records = c->n_ok; out->skipped_records = c->n_bad;
-    out->partition_key = c->h_key.data(); out->n_partition_keys = (uint32_t)c->key_name_ptrs.size(); out->partition_key_names = c->key_name_ptrs.data();
+    out->partition_key = c->h_key.data(); out->n_partition_keys = (uint32_t)c->key_name_ptrs.size();
+      out->partition_key_names = c->key_name_ptrs.data();
   }
 }
 
@@ -817,7 +913,8 @@ bool aux_stringable(const mkp_record& r, const char* tag, std::string* out) {
   const size_t fixed = (size_t)r.l_qname + 4 * (size_t)r.n_cigar + ((size_t)std::max(r.l_qseq, 0) + 1) / 2 + (size_t)std::max(r.l_qseq, 0);
   if (fixed > (size_t)r.l_data) return false;
   const uint8_t* a = r.data + fixed; const uint8_t* e = r.data + r.l_data;
-  auto width = [](uint8_t ty) -> int { switch (ty) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4;
+  auto width = [](uint8_t ty) -> int { switch (ty) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2;
+      case 'i': case 'I': case 'f': return 4;
       case 'd': return 8; default: return -1; } };
   while (a + 3 <= e) {
     const uint8_t ty = a[2]; const uint8_t* v = a + 3; const uint8_t* nx;
@@ -881,7 +978,9 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
   // the context's stream runs the short kernels a caller waits for — sampling rounds, the pileup pass — often beside an ingest that fills the
   // chip for tens of milliseconds: it goes first when workgroup slots free up
   { int plo = 0, phi = 0;
-    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess || pooled_stream_create(&c->stream, c->device, hipStreamDefault, phi) != hipSuccess) { delete c; return MKP_E_DEVICE; } c->stream_prio = phi; }
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&plo, &phi) != hipSuccess
+        || pooled_stream_create(&c->stream, c->device, hipStreamDefault, phi) != hipSuccess) {
+      delete c; return MKP_E_DEVICE; } c->stream_prio = phi; }
   // timing events between the kernels of a pass: no system-scope fence when they are recorded (its cache write-back and invalidation sat
   // between the decoder and the kernel that reads what it just wrote; nothing on the host looks at device memory through these events)
   for (auto& e : c->ev) if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) { delete c; return MKP_E_DEVICE; }
@@ -893,8 +992,12 @@ int mkp_ctx_create(const mkp_config* cfg, mkp_ctx** out) {
 void mkp_ctx_destroy(mkp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout, &c->d_focus, &c->d_combos, &c->d_tiles,
-                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take, &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv, &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout, &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask, &c->d_hist64}) b->release();
+  for (DevBuf* b : {&c->d_vals, &c->d_hdr, &c->d_cigar, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml, &c->d_layouts, &c->d_events, &c->d_readout,
+      &c->d_focus, &c->d_combos, &c->d_tiles,
+                    &c->d_slotbm, &c->d_prm, &c->d_read_ids, &c->d_chunk, &c->d_store, &c->d_hist0, &c->d_hist1, &c->d_sample_cursor, &c->d_take,
+                        &c->d_tile_row_off, &c->d_tile_row_cnt, &c->d_tile_dst, &c->d_misc, &c->d_rows_src, &c->d_rows_dst, &c->d_hemi_iv,
+                        &c->d_slot_pos, &c->d_cov, &c->d_visits, &c->d_stiles, &c->d_slot_ids, &c->d_fdesc, &c->d_work, &c->d_zin, &c->d_zout,
+                        &c->d_zblk, &c->d_zstat, &c->d_summary, &c->d_bedmask, &c->d_hist64}) b->release();
   mkp_internal_ingest_destroy(c->ingest); c->ingest = nullptr;
   c->h_rows.release();
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -912,7 +1015,8 @@ int mkp_set_caller(mkp_ctx* c, const mkp_caller* k) {
     CallerCfg cc; cc.default_threshold = k->default_threshold;
     for (int b = 0; b < 4; b++) { cc.per_base[b] = k->per_base_threshold[b]; cc.has_per_base[b] = k->has_per_base[b] != 0; }
     for (uint32_t i = 0; i < k->n_per_mod; i++) cc.per_mod[k->per_mod[i].code_repr] = k->per_mod[i].threshold;
-    cc.numeric_mode = k->numeric_mode; cc.collapse_code = k->collapse_code; cc.edge = k->edge_filter != 0; cc.edge_start = k->edge_start; cc.edge_end = k->edge_end;
+    cc.numeric_mode = k->numeric_mode; cc.collapse_code = k->collapse_code; cc.edge = k->edge_filter != 0; cc.edge_start = k->edge_start;
+      cc.edge_end = k->edge_end;
     cc.edge_inverted = k->edge_inverted != 0; cc.force_allow = k->force_allow_implicit != 0; cc.combine_strands = k->combine_strands != 0;
     cc.max_depth = k->max_depth ? k->max_depth : 8000;
     c->caller = cc; c->caller_set = true; c->resident = false;
@@ -991,24 +1095,28 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
     // supplementary records are not tallied but htslib buffers them (BAM_DEF_MASK lets 0x800 through): their spans count for the max-depth guard
     for (uint32_t i = 0; i < n; i++) {
       const mkp_record& r = recs[i];
-      if (r.tid != tid || !(r.flag & 2048) || (r.flag & (4 | 256 | 512 | 1024)) || !r.n_cigar || !r.data || (uint64_t)r.l_qname + 4ull * r.n_cigar > (uint64_t)std::max(r.l_data,
+      if (r.tid != tid || !(r.flag & 2048) || (r.flag & (4 | 256 | 512 | 1024)) || !r.n_cigar || !r.data
+          || (uint64_t)r.l_qname + 4ull * r.n_cigar > (uint64_t)std::max(r.l_data,
           0)) continue;
       int64_t len = 0; for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, r.data + r.l_qname + 4 * (size_t)k, 4);
           if ((0x18du >> (w & 15u)) & 1u) len += w >> 4; }
       c->shard.extra_spans.push_back({r.pos, (int32_t)std::min<int64_t>((int64_t)r.pos + std::max<int64_t>(len, 1), INT32_MAX)});
     }
-    if (!c->partition_tags.empty()) {   // PartitionKey per kept record (parse_tags_from_record, pileup/mod.rs:626-643): values joined by '_', "missing" for an absent tag
+    // PartitionKey per kept record (parse_tags_from_record, pileup/mod.rs:626-643): values joined by '_', "missing" for an absent tag
+    if (!c->partition_tags.empty()) {
       size_t at = hdr_before;
       for (uint32_t i = 0; i < n; i++) {
         const mkp_record& r = recs[i];
         if (!(r.tid == tid && Packer::keep(r))) continue;
         if (at >= c->shard.hdr.size()) throw Error(MKP_E_INVALID, "internal: packer dropped a kept record");
         std::string key; bool any = false;
-        for (size_t t = 0; t < c->partition_tags.size(); t++) { std::string v; const bool got = aux_stringable(r, c->partition_tags[t].c_str(), &v); any |= got;
+        for (size_t t = 0; t < c->partition_tags.size(); t++) { std::string v; const bool got = aux_stringable(r, c->partition_tags[t].c_str(), &v);
+          any |= got;
             if (t) key += '_'; key += got ? v : std::string("missing"); }
         uint32_t id = 0;
         if (any) { auto it = std::find(c->key_names.begin() + 1, c->key_names.end(), key); id = (uint32_t)(it - c->key_names.begin());
-            if (it == c->key_names.end()) { if (c->key_names.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65534 partition keys in one shard");
+            if (it == c->key_names.end()) {
+              if (c->key_names.size() >= 65535) throw Error(MKP_E_UNSUPPORTED, "more than 65534 partition keys in one shard");
             c->key_names.push_back(key); } }
         c->shard.hdr[at].flags |= id << MKP_RF_KEY_SHIFT;
         at++;
@@ -1022,10 +1130,13 @@ int mkp_shard_add_records(mkp_ctx* c, const mkp_record* recs, uint32_t n) {
 
 }   // extern "C"
 namespace {
-void adopt_layouts(mkp_ctx* c, DevShard* sh) {   // the shard's own layout ids -> the context's table (shared with the threshold sampler); once per shard
+// the shard's own layout ids -> the context's table (shared with the threshold sampler); once per shard
+void adopt_layouts(mkp_ctx* c, DevShard* sh) {
   if (sh->layouts_adopted) return;
   const std::vector<uint16_t> map = c->packer.adopt(sh->layouts);
-  for (auto* hv : {&sh->S.hdr, &sh->S.so_hdr}) for (auto& h : *hv) if (h.n_tags && !(h.flags & MKP_RF_BAD)) { if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range"); h.layout = map[h.layout]; }
+  for (auto* hv : {&sh->S.hdr, &sh->S.so_hdr}) for (auto& h : *hv) if (h.n_tags && !(h.flags & MKP_RF_BAD)) {
+    if (h.layout >= map.size()) throw Error(MKP_E_DEVICE, "internal: device ingest layout id out of range");
+    h.layout = map[h.layout]; }
   sh->layouts_adopted = true;
 }
 }  // namespace
@@ -1034,7 +1145,8 @@ int mkp_internal_sample_bind(mkp_ctx* c, DevShard* sh) {
   return guarded(c, [&]() {
     if (!sh->bound) adopt_layouts(c, sh);
     std::swap(c->shard, sh->S);
-    std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref); std::swap(c->d_ranks, sh->d_ranks); std::swap(c->d_ml, sh->d_ml);
+    std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref);
+      std::swap(c->d_ranks, sh->d_ranks); std::swap(c->d_ml, sh->d_ml);
     sh->bound = !sh->bound;
     c->shard_open = sh->bound; c->resident = false; c->wplan.valid = false;
     if (sh->bound) for (DevBuf* b : {&c->d_cigar, &c->d_chunk, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml}) b->ensure(16);
@@ -1054,9 +1166,11 @@ int mkp_internal_shard_attach(mkp_ctx* c, DevShard* sh) {
     adopt_layouts(c, sh);
     const int32_t tid = c->shard.tid, ws = c->shard.win_start, we = c->shard.win_end;
     c->shard = std::move(sh->S); c->shard.tid = tid; c->shard.win_start = ws; c->shard.win_end = we; c->shard.dev_packed = true;
-    std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref); std::swap(c->d_ranks, sh->d_ranks);
+    std::swap(c->d_cigar, sh->d_cigar); std::swap(c->d_chunk, sh->d_chunk); std::swap(c->d_seq, sh->d_seq); std::swap(c->d_tagref, sh->d_tagref);
+      std::swap(c->d_ranks, sh->d_ranks);
         std::swap(c->d_ml, sh->d_ml);
-    for (DevBuf* b : {&c->d_cigar, &c->d_chunk, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml}) b->ensure(16);   // (an empty shard: the kernels still take valid pointers)
+    // (an empty shard: the kernels still take valid pointers)
+    for (DevBuf* b : {&c->d_cigar, &c->d_chunk, &c->d_seq, &c->d_tagref, &c->d_ranks, &c->d_ml}) b->ensure(16);
     c->resident = false; c->row_cap = 0;
     c->stats.pack_ms += ms_since(t0);
   });
@@ -1102,13 +1216,17 @@ int mkp_batch_run(mkp_ctx* c, const mkp_shard* ivs, uint32_t n_ivs, const mkp_re
     struct Slice { uint64_t lo, hi, processed, skipped; }; std::vector<Slice> slice(n_ivs, Slice{0, 0, 0, 0});
     mkp_stats acc; memset(&acc, 0, sizeof(acc));
     for (uint32_t i0 = 0; i0 < n_ivs;) {
-      // a group: intervals i0 .. i1-1 follow each other on one contig with the same kind of focus (with partition keys every interval runs alone: rows come grouped by key)
+      // a group: intervals i0 .. i1-1 follow each other on one contig with the same kind of focus (with partition keys every interval runs alone:
+      // rows come grouped by key)
       uint32_t i1 = i0 + 1;
-      while (c->partition_tags.empty() && i1 < n_ivs && ivs[i1].tid == ivs[i0].tid && ivs[i1].start == ivs[i1 - 1].end && (ivs[i1].focus != nullptr) == (ivs[i0].focus != nullptr) &&
+      while (c->partition_tags.empty() && i1 < n_ivs && ivs[i1].tid == ivs[i0].tid && ivs[i1].start == ivs[i1 - 1].end
+          && (ivs[i1].focus != nullptr) == (ivs[i0].focus != nullptr) &&
              ivs[i1].combos == ivs[i0].combos && ivs[i1].n_combos == ivs[i0].n_combos && (uint64_t)ivs[i1].end - ivs[i0].start <= (1ull << 27)) i1++;
       mkp_shard sh = ivs[i0]; sh.end = ivs[i1 - 1].end;
       std::vector<uint8_t> focus;
-      if (sh.focus && i1 > i0 + 1) { focus.resize((size_t)(sh.end - sh.start)); for (uint32_t k = i0; k < i1; k++) memcpy(focus.data() + (ivs[k].start - sh.start), ivs[k].focus, (size_t)(ivs[k].end - ivs[k].start)); sh.focus = focus.data(); }
+      if (sh.focus && i1 > i0 + 1) { focus.resize((size_t)(sh.end - sh.start));
+        for (uint32_t k = i0; k < i1; k++) memcpy(focus.data() + (ivs[k].start - sh.start), ivs[k].focus, (size_t)(ivs[k].end - ivs[k].start));
+        sh.focus = focus.data(); }
       int rc = mkp_shard_begin(c, &sh); if (rc != MKP_OK) throw Error(rc, c->err);
       c->iv_starts.clear(); for (uint32_t k = i0; k < i1; k++) c->iv_starts.push_back(ivs[k].start);   // the duplicate-name rule is per interval
       // the group's records: its contig, starting before the window's end (the packer drops the other contigs itself; a record that ends
@@ -1121,28 +1239,36 @@ int mkp_batch_run(mkp_ctx* c, const mkp_shard* ivs, uint32_t n_ivs, const mkp_re
       rc = mkp_shard_run(c, &rows); if (rc != MKP_OK) throw Error(rc, c->err);
       // rows are in genome order (by key first with partition tags: then the group is one interval): cut at the interval ends
       const uint64_t base = c->batch_cols[0].size();
-      const uint32_t* src[11] = {rows.pos, nullptr, rows.code_repr, rows.n_valid, rows.n_mod, rows.n_canonical, rows.n_other, rows.n_delete, rows.n_fail, rows.n_diff, rows.n_nocall};
+      const uint32_t* src[11] = {rows.pos, nullptr, rows.code_repr, rows.n_valid, rows.n_mod, rows.n_canonical, rows.n_other, rows.n_delete,
+          rows.n_fail, rows.n_diff, rows.n_nocall};
       for (int k = 0; k < 11; k++) if (src[k]) c->batch_cols[k].insert(c->batch_cols[k].end(), src[k], src[k] + rows.n_rows);
-      c->batch_strand.insert(c->batch_strand.end(), rows.strand, rows.strand + rows.n_rows); c->batch_motif.insert(c->batch_motif.end(), rows.motif_idx, rows.motif_idx + rows.n_rows);
+      c->batch_strand.insert(c->batch_strand.end(), rows.strand, rows.strand + rows.n_rows);
+        c->batch_motif.insert(c->batch_motif.end(), rows.motif_idx, rows.motif_idx + rows.n_rows);
       c->batch_key.insert(c->batch_key.end(), rows.partition_key, rows.partition_key + rows.n_rows);
       uint64_t at = 0;
       for (uint32_t k = i0; k < i1; k++) {
         uint64_t e = at; if (i1 == i0 + 1) e = rows.n_rows; else while (e < rows.n_rows && rows.pos[e] < ivs[k].end) e++;
         slice[k] = {base + at, base + e, k == i0 ? rows.processed_records : 0, k == i0 ? rows.skipped_records : 0}; at = e;
       }
-      acc.pack_ms += c->stats.pack_ms; acc.h2d_ms += c->stats.h2d_ms; acc.kernel_ms += c->stats.kernel_ms; acc.d2h_ms += c->stats.d2h_ms; acc.n_rows += c->stats.n_rows; acc.n_reads += c->stats.n_reads;
+      acc.pack_ms += c->stats.pack_ms; acc.h2d_ms += c->stats.h2d_ms; acc.kernel_ms += c->stats.kernel_ms; acc.d2h_ms += c->stats.d2h_ms;
+        acc.n_rows += c->stats.n_rows; acc.n_reads += c->stats.n_reads;
       i0 = i1;
     }
     c->key_name_ptrs.clear(); for (auto& k : c->key_names) c->key_name_ptrs.push_back(k.c_str());
     for (uint32_t k = 0; k < n_ivs; k++) {
       mkp_rows& o = out[k]; memset(&o, 0, sizeof(o)); const Slice& sl = slice[k]; const uint64_t lo = sl.lo;
-      o.n_rows = sl.hi - sl.lo; o.pos = c->batch_cols[0].data() + lo; o.strand = c->batch_strand.data() + lo; o.code_repr = c->batch_cols[2].data() + lo; o.motif_idx = c->batch_motif.data() + lo;
-      o.n_valid = c->batch_cols[3].data() + lo; o.n_mod = c->batch_cols[4].data() + lo; o.n_canonical = c->batch_cols[5].data() + lo; o.n_other = c->batch_cols[6].data() + lo;
-      o.n_delete = c->batch_cols[7].data() + lo; o.n_fail = c->batch_cols[8].data() + lo; o.n_diff = c->batch_cols[9].data() + lo; o.n_nocall = c->batch_cols[10].data() + lo;
+      o.n_rows = sl.hi - sl.lo; o.pos = c->batch_cols[0].data() + lo; o.strand = c->batch_strand.data() + lo;
+        o.code_repr = c->batch_cols[2].data() + lo; o.motif_idx = c->batch_motif.data() + lo;
+      o.n_valid = c->batch_cols[3].data() + lo; o.n_mod = c->batch_cols[4].data() + lo; o.n_canonical = c->batch_cols[5].data() + lo;
+        o.n_other = c->batch_cols[6].data() + lo;
+      o.n_delete = c->batch_cols[7].data() + lo; o.n_fail = c->batch_cols[8].data() + lo; o.n_diff = c->batch_cols[9].data() + lo;
+        o.n_nocall = c->batch_cols[10].data() + lo;
       o.processed_records = sl.processed; o.skipped_records = sl.skipped;
-      o.partition_key = c->batch_key.data() + lo; o.n_partition_keys = (uint32_t)c->key_name_ptrs.size(); o.partition_key_names = c->key_name_ptrs.data();
+      o.partition_key = c->batch_key.data() + lo; o.n_partition_keys = (uint32_t)c->key_name_ptrs.size();
+        o.partition_key_names = c->key_name_ptrs.data();
     }
-    c->stats.pack_ms = acc.pack_ms; c->stats.h2d_ms = acc.h2d_ms; c->stats.kernel_ms = acc.kernel_ms; c->stats.d2h_ms = acc.d2h_ms;   // the batch's sums (the other fields: its last group)
+    // the batch's sums (the other fields: its last group)
+    c->stats.pack_ms = acc.pack_ms; c->stats.h2d_ms = acc.h2d_ms; c->stats.kernel_ms = acc.kernel_ms; c->stats.d2h_ms = acc.d2h_ms;
   });
 }
 
@@ -1169,10 +1295,13 @@ int mkp_shard_rerun(mkp_ctx* c, uint32_t iters, mkp_rows* out) {
   if (!c) return MKP_E_INVALID;
   return guarded(c, [&]() {
     if (!c->resident) throw Error(MKP_E_INVALID, "no resident shard: call mkp_shard_run once first");
-    if (c->resident_hemi && out) throw Error(MKP_E_INVALID, "the resident shard ran as pileup-hemi: pass out = NULL here and read rows with mkp_hemi_shard_run");
+    if (c->resident_hemi && out) throw Error(MKP_E_INVALID,
+        "the resident shard ran as pileup-hemi: pass out = NULL here and read rows with mkp_hemi_shard_run");
     double d = 0, p = 0, g = 0;
-    for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms; g += c->stats.gather_kernel_ms; }
-    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = 0; c->stats.gather_kernel_ms = g / iters;
+    for (uint32_t i = 0; i < iters; i++) { run_kernels(c, true); d += c->stats.decode_kernel_ms; p += c->stats.pileup_kernel_ms;
+      g += c->stats.gather_kernel_ms; }
+    if (iters) { c->stats.decode_kernel_ms = d / iters; c->stats.pileup_kernel_ms = p / iters; c->stats.rows_kernel_ms = 0;
+      c->stats.gather_kernel_ms = g / iters;
         c->stats.kernel_ms = (d + p + g) / iters; }
     if (out) fetch_rows(c, out);
   });
@@ -1203,7 +1332,8 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
       uint16_t xlen; memcpy(&xlen, bgzf + o + 10, 2);
       uint64_t x = o + 12; const uint64_t xe = x + xlen; uint32_t bsize = 0; bool found = false;
       if (xe > n_bytes) throw Error(MKP_E_IO, "bad BGZF block");
-      while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, bgzf + x + 2, 2); if (bgzf[x] == 'B' && bgzf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b;
+      while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, bgzf + x + 2, 2); if (bgzf[x] == 'B' && bgzf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) {
+          uint16_t b;
           memcpy(&b, bgzf + x + 4, 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (uint64_t)sl; }
       if (!found || o + bsize > n_bytes || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block");
       uint32_t crc, isize; memcpy(&crc, bgzf + o + bsize - 8, 4); memcpy(&isize, bgzf + o + bsize - 4, 4);
@@ -1213,13 +1343,15 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
     }
     if (blks.size() > 0xffffffffull) throw Error(MKP_E_UNSUPPORTED, "too many BGZF blocks");
     hip_check(hipSetDevice(c->device), "hipSetDevice");
-    c->d_zin.ensure(std::max<uint64_t>(n_bytes, 16)); c->d_zout.ensure(std::max<uint64_t>(total, 16)); c->d_zblk.ensure(std::max<size_t>(blks.size(), 1) * sizeof(Blk));
+    c->d_zin.ensure(std::max<uint64_t>(n_bytes, 16)); c->d_zout.ensure(std::max<uint64_t>(total, 16));
+      c->d_zblk.ensure(std::max<size_t>(blks.size(), 1) * sizeof(Blk));
         c->d_zstat.ensure(std::max<size_t>(blks.size(), 1) * 4);
     h2d_copy(c->d_zin.p, bgzf, n_bytes);   // (caller memory and a temporary: through the library's page-locked staging, mkp_ctx.hpp)
     h2d_copy(c->d_zblk.p, blks.data(), blks.size() * sizeof(Blk));
     hip_check(hipMemsetAsync(c->d_zstat.p, 0xff, std::max<size_t>(blks.size(), 1) * 4, c->stream), "memset");
     hip_check(hipEventRecord(c->ev[0], c->stream), "event");
-    hip_check(launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(), c->d_zstat.as<uint32_t>()),
+    hip_check(launch_inflate(c->stream, c->d_zin.as<uint8_t>(), c->d_zblk.p, (uint32_t)blks.size(), c->d_zout.as<uint8_t>(),
+        c->d_zstat.as<uint32_t>()),
         "inflate launch");
     hip_check(hipEventRecord(c->ev[1], c->stream), "event");
     std::vector<uint32_t> st(blks.size());
@@ -1245,7 +1377,9 @@ int mkp_bgzf_inflate(mkp_ctx* c, const uint8_t* bgzf, uint64_t n_bytes, const ui
 // prefetch thread while the shard in hand uses the context's stream.
 struct PinnedBuf {   // page-locked host staging: pageable copies of a window's 270 MB ran at under 3 GB/s
   void* p = nullptr; size_t cap = 0;
-  void ensure(size_t n) { if (n <= cap) return; release(); const size_t want = n + n / 8 + 4096; if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); } cap = want; }
+  void ensure(size_t n) { if (n <= cap) return; release(); const size_t want = n + n / 8 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr;
+      throw Error(MKP_E_NOMEM, "hipHostMalloc failed"); } cap = want; }
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 struct mkp_dev_inflater { int device = 0; hipStream_t stream = nullptr; DevBuf zin, zout, zblk, zstat; PinnedBuf pin_in, pin_out; std::mutex mu; };
@@ -1257,7 +1391,8 @@ mkp_dev_inflater* mkp_internal_inflater_create(int device) {
 }
 void mkp_internal_inflater_destroy(mkp_dev_inflater* d) {
   if (!d) return;
-  (void)hipSetDevice(d->device); d->zin.release(); d->zout.release(); d->zblk.release(); d->zstat.release(); d->pin_in.release(); d->pin_out.release();
+  (void)hipSetDevice(d->device); d->zin.release(); d->zout.release(); d->zblk.release(); d->zstat.release(); d->pin_in.release();
+    d->pin_out.release();
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
 }
@@ -1272,7 +1407,8 @@ bool mkp_internal_device_inflate(void* user, const InflateJob& j) {
     d->pin_in.ensure(j.comp_len + j.n_blks * sizeof(InflateBlk)); d->pin_out.ensure(j.dtotal + j.n_blks * 4);
     // file pages -> pinned (all cores, behind the foreground work), one H2D; inflate; one D2H into pinned; pinned -> the window's buffer
     uint8_t* pin = (uint8_t*)d->pin_in.p; const size_t piece = (size_t)4 << 20;
-    HostPool::get().parallel((j.comp_len + piece - 1) / piece, [&](size_t i) { const size_t lo = i * piece, n = std::min(piece, j.comp_len - lo); memcpy(pin + lo, j.comp + lo, n); });
+    HostPool::get().parallel((j.comp_len + piece - 1) / piece, [&](size_t i) { const size_t lo = i * piece, n = std::min(piece, j.comp_len - lo);
+      memcpy(pin + lo, j.comp + lo, n); });
     memcpy(pin + j.comp_len, j.blks, j.n_blks * sizeof(InflateBlk));
     ok(hipMemcpyAsync(d->zin.p, pin, j.comp_len, hipMemcpyHostToDevice, d->stream));
     ok(hipMemcpyAsync(d->zblk.p, pin + j.comp_len, j.n_blks * sizeof(InflateBlk), hipMemcpyHostToDevice, d->stream));
@@ -1283,12 +1419,15 @@ bool mkp_internal_device_inflate(void* user, const InflateJob& j) {
     ok(hipMemcpyAsync(pout + j.dtotal, d->zstat.p, j.n_blks * 4, hipMemcpyDeviceToHost, d->stream));
     ok(hipStreamSynchronize(d->stream));
     const uint32_t* st = (const uint32_t*)(pout + j.dtotal);   // (dtotal is a sum of block sizes; the status words may sit unaligned)
-    for (size_t i = 0; i < j.n_blks; i++) { uint32_t v; memcpy(&v, (const uint8_t*)st + 4 * i, 4); if (v != 0) return false; }   // the host decoder takes the window and names the error
-    HostPool::get().parallel((j.dtotal + piece - 1) / piece, [&](size_t i) { const size_t lo = i * piece, n = std::min(piece, j.dtotal - lo); memcpy(j.dst + lo, pout + lo, n); });
+    // the host decoder takes the window and names the error
+    for (size_t i = 0; i < j.n_blks; i++) { uint32_t v; memcpy(&v, (const uint8_t*)st + 4 * i, 4); if (v != 0) return false; }
+    HostPool::get().parallel((j.dtotal + piece - 1) / piece, [&](size_t i) { const size_t lo = i * piece, n = std::min(piece, j.dtotal - lo);
+      memcpy(j.dst + lo, pout + lo, n); });
     // the blocks' CRC32s (trailer word behind each payload), as the host decoder checks them: a mismatch hands the window to the host path,
     // which names the error
     std::atomic<bool> crc_bad{false};
-    HostPool::get().parallel((j.n_blks + 63) / 64, [&](size_t g) { for (size_t i = g * 64; i < std::min(j.n_blks, (g + 1) * 64); i++) { const InflateBlk& b = j.blks[i];
+    HostPool::get().parallel((j.n_blks + 63) / 64, [&](size_t g) { for (size_t i = g * 64; i < std::min(j.n_blks, (g + 1) * 64); i++) {
+        const InflateBlk& b = j.blks[i];
         uint32_t want; memcpy(&want, j.comp + b.in_off + b.in_len, 4); if (crc32_of(j.dst + b.out_off, b.out_len) != want) crc_bad = true; } });
     if (crc_bad) return false;
     return true;
@@ -1304,9 +1443,11 @@ int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_ta
     const uint32_t cg = (l_seq << 4) | 0u; data.insert(data.end(), (const uint8_t*)&cg, (const uint8_t*)&cg + 4);
     data.insert(data.end(), (l_seq + 1) / 2, 0x11); data.insert(data.end(), l_seq, 0xff);
     data.push_back('M'); data.push_back('M'); data.push_back('Z'); data.insert(data.end(), mm, mm + strlen(mm) + 1);
-    data.push_back('M'); data.push_back('L'); data.push_back('B'); data.push_back('C'); data.insert(data.end(), (const uint8_t*)&n_ml, (const uint8_t*)&n_ml + 4);
+    data.push_back('M'); data.push_back('L'); data.push_back('B'); data.push_back('C');
+      data.insert(data.end(), (const uint8_t*)&n_ml, (const uint8_t*)&n_ml + 4);
         data.insert(data.end(), n_ml, 0);
-    mkp_record r; memset(&r, 0, sizeof(r)); r.tid = 0; r.pos = 0; r.l_qname = 2; r.n_cigar = 1; r.l_qseq = (int32_t)l_seq; r.l_data = (int32_t)data.size();
+    mkp_record r; memset(&r, 0, sizeof(r)); r.tid = 0; r.pos = 0; r.l_qname = 2; r.n_cigar = 1; r.l_qseq = (int32_t)l_seq;
+      r.l_data = (int32_t)data.size();
         r.data = data.data();
     Packer pk; ShardHost S; S.tid = 0; pk.add(r, S);
     if (S.hdr.empty() || (S.hdr[0].flags & MKP_RF_BAD)) return MKP_E_INVALID;
@@ -1325,7 +1466,8 @@ int mkp_host_mm_ranks(const char* mm, uint32_t l_seq, uint32_t n_ml, mkp_host_ta
 
 int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_out) {
   if (!code_reprs || !order_out || n > 14) return MKP_E_INVALID;
-  try { FxOrder m; for (uint32_t i = 0; i < n; i++) m.insert(code_reprs[i], (int)i); auto c = m.codes(); for (size_t i = 0; i < c.size(); i++) order_out[i] = c[i];
+  try { FxOrder m; for (uint32_t i = 0; i < n; i++) m.insert(code_reprs[i], (int)i); auto c = m.codes();
+    for (size_t i = 0; i < c.size(); i++) order_out[i] = c[i];
       return (int)c.size(); }
   catch (...) { return MKP_E_INVALID; }
 }
@@ -1334,10 +1476,12 @@ int mkp_host_map_order(const uint32_t* code_reprs, uint32_t n, uint32_t* order_o
 
 // ---- threshold sampling on the device (decode kernels in sampling mode; the values stay in HBM)
 extern "C" {
-hipError_t mkp_launch_sample_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const float*, const MkpEvent*, uint32_t*,
+hipError_t mkp_launch_sample_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const float*, const MkpEvent*,
+    uint32_t*,
     unsigned long long, unsigned long long*, uint32_t*, uint32_t*);
 hipError_t mkp_launch_sample_hist1(hipStream_t, const uint32_t*, unsigned long long, uint32_t, uint32_t, uint32_t*);
-hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const MkpEvent*, unsigned long long*,
+hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const MkpReadOut*, const uint8_t*, uint32_t, const MkpEvent*,
+    unsigned long long*,
     unsigned long long*);
 }
 
@@ -1346,15 +1490,19 @@ hipError_t mkp_launch_summary_accumulate(hipStream_t, const MkpReadHdr*, const M
 namespace {
 // the sampling pass over the packed reads of S (host-packed: everything goes up; resident: the arrays of the attached shard are in HBM
 // already and S.hdr is the round's selection of its headers)
-void sample_decode(mkp_ctx* c, ShardHost& S, bool resident, const uint8_t* bedmask, bool only_mapped, size_t n_expected, std::vector<uint32_t>* n_vals) {
+void sample_decode(mkp_ctx* c, ShardHost& S, bool resident, const uint8_t* bedmask, bool only_mapped, size_t n_expected,
+    std::vector<uint32_t>* n_vals) {
   c->tables.build(c->packer.layouts, c->caller);
   MkpRunParams P; memset(&P, 0, sizeof(P));
-  P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge; P.edge_start = c->caller.edge_start;
-  P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1; P.sample_mode = c->extract_mode ? 3 : c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
+  P.win_start = S.win_start; P.win_end = S.win_end; P.numeric_mode = c->caller.numeric_mode; P.edge_filter = c->caller.edge;
+    P.edge_start = c->caller.edge_start;
+  P.edge_end = c->caller.edge_end; P.edge_inverted = c->caller.edge_inverted; P.force_allow = 1;
+    P.sample_mode = c->extract_mode ? 3 : c->summary_mode ? 2 : 1; P.only_mapped = only_mapped;
       P.has_focus = bedmask != nullptr;
   hip_check(hipSetDevice(c->device), "hipSetDevice");
   upload(c->d_hdr, S.hdr);
-  if (!resident) { upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks); upload(c->d_ml, S.ml); }
+  if (!resident) { upload(c->d_cigar, S.cigar); upload(c->d_seq, S.seq); upload(c->d_tagref, S.tagref); upload(c->d_ranks, S.ranks);
+    upload(c->d_ml, S.ml); }
   upload(c->d_layouts, c->tables.dev);
   { std::vector<uint32_t> ids; class_ids(S, c->tables, &ids, c->n_class, false); upload(c->d_read_ids, ids); }
   // the --include-bed mask of the contig: one upload per contig and sampling session, not per round (a 25 MB mask per round was most of
@@ -1368,16 +1516,20 @@ void sample_decode(mkp_ctx* c, ShardHost& S, bool resident, const uint8_t* bedma
     d_mask = c->d_bedmask.as<uint8_t>();
   } else { c->d_focus.ensure(16); d_mask = c->d_focus.as<uint8_t>(); }
   const uint64_t cap = std::max<uint64_t>(S.n_events_cap, 1);
-  c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float)); c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
+  c->d_events.ensure(cap * sizeof(MkpEvent)); c->d_vals.ensure(cap * sizeof(float));
+    c->d_readout.ensure(std::max<size_t>(S.hdr.size(), 1) * sizeof(MkpReadOut));
       c->d_misc.ensure(64);
   uint32_t* misc = c->d_misc.as<uint32_t>();
   hip_check(hipMemsetAsync(misc, 0, 16, c->stream), "memset");
-  hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(), c->d_seq.as<uint8_t>(),
+  hip_check(mkp_launch_decode(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_read_ids.as<uint32_t>(), c->n_class, c->d_cigar.as<uint32_t>(),
+      c->d_seq.as<uint8_t>(),
       c->d_tagref.as<MkpTagRef>(), c->d_ranks.as<uint32_t>(),
-                              c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(), misc + 2, d_mask, c->d_vals.as<float>()), "decode(sample) launch");
+                              c->d_ml.as<uint8_t>(), c->d_layouts.as<MkpLayout>(), &P, c->d_events.as<MkpEvent>(), c->d_readout.as<MkpReadOut>(),
+                                  misc + 2, d_mask, c->d_vals.as<float>()), "decode(sample) launch");
   uint32_t h[4]; hip_check(hipMemcpyAsync(h, misc, 16, hipMemcpyDeviceToHost, c->stream), "D2H");
   c->sample_ro.resize(S.hdr.size());
-  if (!S.hdr.empty()) hip_check(hipMemcpyAsync(c->sample_ro.data(), c->d_readout.p, S.hdr.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost, c->stream), "D2H");
+  if (!S.hdr.empty()) hip_check(hipMemcpyAsync(c->sample_ro.data(), c->d_readout.p, S.hdr.size() * sizeof(MkpReadOut), hipMemcpyDeviceToHost,
+      c->stream), "D2H");
   hip_check(hipStreamSynchronize(c->stream), "sample sync");
   if (h[2] & 1u) throw Error(MKP_E_DEVICE, "internal: event segment overflow");
   if (S.hdr.size() != n_expected) throw Error(MKP_E_INVALID, "internal: sampler packed a different number of records");
@@ -1391,7 +1543,8 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
                         uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals) {
   if (!c || !n_vals) return MKP_E_INVALID;
   return guarded(c, [&]() {
-    if (c->shard.dev_packed) { c->shard.clear(); c->shard_open = false; c->resident = false; }   // a device-packed shard of an earlier run: its HBM arrays are about to be reused
+    // a device-packed shard of an earlier run: its HBM arrays are about to be reused
+    if (c->shard.dev_packed) { c->shard.clear(); c->shard_open = false; c->resident = false; }
     ShardHost& S = c->sample_shard; S.clear(); S.tid = tid; S.win_start = (int32_t)win_start; S.win_end = (int32_t)win_end;
     pack_records(c->packer, S, recs, n, [](const mkp_record&) { return true; });
     sample_decode(c, S, false, bedmask, only_mapped, n, n_vals);
@@ -1400,7 +1553,8 @@ int mkp_internal_sample(mkp_ctx* c, int32_t tid, uint32_t win_start, uint32_t wi
 
 // The same pass over reads of the shard the device ingest attached (mkp_internal_shard_attach): `reads` index that shard's records; their
 // CIGARs, bases and tags are in HBM already, only the round's headers (with their slices of the event buffer) go up.
-int mkp_internal_sample_resident(mkp_ctx* c, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const uint32_t* reads, uint32_t n, bool only_mapped, std::vector<uint32_t>* n_vals) {
+int mkp_internal_sample_resident(mkp_ctx* c, uint32_t win_start, uint32_t win_end, const uint8_t* bedmask, const uint32_t* reads, uint32_t n,
+    bool only_mapped, std::vector<uint32_t>* n_vals) {
   if (!c || !n_vals || (!reads && n)) return MKP_E_INVALID;
   return guarded(c, [&]() {
     ShardHost& R = c->shard;
@@ -1470,14 +1624,17 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
       if (!c->d_summary.p) throw Error(MKP_E_INVALID, "internal: summary table not set up");
       c->d_take.ensure(std::max<size_t>(n, 16));
       hip_check(hipMemcpyAsync(c->d_take.p, take.data(), n, hipMemcpyHostToDevice, c->stream), "H2D");
-      hip_check(mkp_launch_summary_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n,
+      hip_check(mkp_launch_summary_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(),
+          (uint32_t)n,
           c->d_events.as<MkpEvent>(),
-                                              c->d_summary.as<unsigned long long>(), c->d_summary.as<unsigned long long>() + 128), "summary accumulate launch");
+                                              c->d_summary.as<unsigned long long>(), c->d_summary.as<unsigned long long>() + 128),
+                                                  "summary accumulate launch");
       hip_check(hipStreamSynchronize(c->stream), "summary accumulate sync");
       return;
     }
     if (!c->d_hist0.p) { c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4); c->d_sample_cursor.ensure(16);
-        hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset"); hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
+        hip_check(hipMemsetAsync(c->d_hist0.p, 0, 4 * 65536 * 4, c->stream), "memset");
+          hip_check(hipMemsetAsync(c->d_sample_cursor.p, 0, 16, c->stream), "memset"); }
     const uint64_t need = c->sample_n + add;
     // the device histograms count in 32 bits: with 2^32 or more sampled values one bin could wrap (ML bytes put most values on a handful
     // of f32 patterns) — refused rather than estimated wrongly
@@ -1493,15 +1650,18 @@ int mkp_internal_sample_take(mkp_ctx* c, const std::vector<uint8_t>& take) {
     uint32_t* misc = c->d_misc.as<uint32_t>();
     hip_check(mkp_launch_sample_accumulate(c->stream, c->d_hdr.as<MkpReadHdr>(), c->d_readout.as<MkpReadOut>(), c->d_take.as<uint8_t>(), (uint32_t)n,
         c->d_vals.as<float>(), c->d_events.as<MkpEvent>(),
-                                           c->d_store.as<uint32_t>(), c->d_store.cap / 4, c->d_sample_cursor.as<unsigned long long>(), c->d_hist0.as<uint32_t>(), misc + 2), "sample accumulate launch");
+                                           c->d_store.as<uint32_t>(), c->d_store.cap / 4, c->d_sample_cursor.as<unsigned long long>(),
+                                               c->d_hist0.as<uint32_t>(), misc + 2), "sample accumulate launch");
     hip_check(hipStreamSynchronize(c->stream), "sample accumulate sync");
     c->sample_n = need;
   });
 }
 
 namespace {
-void require_sample(mkp_ctx* c) { if (!c->d_hist0.p) { hip_check(hipSetDevice(c->device), "hipSetDevice"); c->d_hist0.ensure(4 * 65536 * 4); c->d_hist1.ensure(65536 * 4);
-    c->d_sample_cursor.ensure(16); hip_check(hipMemset(c->d_hist0.p, 0, 4 * 65536 * 4), "memset"); hip_check(hipMemset(c->d_sample_cursor.p, 0, 16), "memset"); } }
+void require_sample(mkp_ctx* c) { if (!c->d_hist0.p) { hip_check(hipSetDevice(c->device), "hipSetDevice"); c->d_hist0.ensure(4 * 65536 * 4);
+    c->d_hist1.ensure(65536 * 4);
+    c->d_sample_cursor.ensure(16); hip_check(hipMemset(c->d_hist0.p, 0, 4 * 65536 * 4), "memset");
+      hip_check(hipMemset(c->d_sample_cursor.p, 0, 16), "memset"); } }
 }
 
 extern "C" {
@@ -1541,12 +1701,17 @@ namespace {
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 // the HIP runtime this library is bound to (its device pointers mean something to that copy only): a process that also imports torch
 // can hold a second copy of the ROCm libraries, with a librccl of its own next to it
-std::string hip_runtime_path() { Dl_info i; if (dladdr((void*)&hipGetDeviceCount, &i) && i.dli_fname) return std::string(i.dli_fname); return std::string(); }
+std::string hip_runtime_path() { Dl_info i; if (dladdr((void*)&hipGetDeviceCount, &i) && i.dli_fname) return std::string(i.dli_fname);
+  return std::string(); }
 nccl_allreduce_fn rccl_allreduce() {
   static nccl_allreduce_fn fn = []() -> nccl_allreduce_fn {
     const char* forced = getenv("MKP_RCCL_LIB");   // (the library the caller made its communicator with)
-    std::string beside = hip_runtime_path(); { const size_t sl = beside.rfind('/'); beside = sl == std::string::npos ? std::string("librccl.so.1") : beside.substr(0, sl + 1) + "librccl.so.1"; }
-    for (const char* name : {forced ? forced : beside.c_str(), beside.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f; } }
+    std::string beside = hip_runtime_path(); { const size_t sl = beside.rfind('/');
+      beside = sl == std::string::npos ? std::string("librccl.so.1") : beside.substr(0, sl + 1) + "librccl.so.1"; }
+    for (const char* name : {forced ? forced : beside.c_str(), beside.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+        "/opt/rocm/lib/librccl.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { if (void* f = dlsym(h, "ncclAllReduce")) return (nccl_allreduce_fn)f;
+      } }
     return nullptr; }();
   return fn;
 }
@@ -1596,11 +1761,13 @@ int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint6
   if (n < 2 || !(q >= 0.0f) || q > 1.0f) return MKP_E_THRESHOLD;
   uint64_t want[2];
   if (q == 1.0f) want[0] = want[1] = n - 1;
-  else { const float l = (float)(n - 1), lq = l * q; want[0] = (uint64_t)floorf(lq); want[1] = (uint64_t)ceilf(lq); if (want[1] > n - 1) want[1] = n - 1;
+  else { const float l = (float)(n - 1), lq = l * q; want[0] = (uint64_t)floorf(lq); want[1] = (uint64_t)ceilf(lq);
+    if (want[1] > n - 1) want[1] = n - 1;
       if (want[0] > n - 1) want[0] = n - 1; }
   for (int k = 0; k < 2; k++) {
     uint64_t cum = 0; bool found = false;
-    for (uint32_t b = 0; b < 65536 && !found; b++) { if (want[k] < cum + hist0[b]) { bins[k] = b; ranks_in_bin[k] = want[k] - cum; found = true; } cum += hist0[b]; }
+    for (uint32_t b = 0; b < 65536 && !found; b++) { if (want[k] < cum + hist0[b]) { bins[k] = b; ranks_in_bin[k] = want[k] - cum; found = true;
+      } cum += hist0[b]; }
     if (!found) return MKP_E_THRESHOLD;
   }
   return MKP_OK;
@@ -1609,7 +1776,8 @@ int mkp_histogram_locate(const uint64_t* hist0, float q, uint32_t bins[2], uint6
 int mkp_histogram_resolve(uint32_t prefix, const uint64_t* hist1, uint64_t rank_in_bin, float* value) {
   if (!hist1 || !value || prefix > 0xffffu) return MKP_E_INVALID;
   uint64_t cum = 0;
-  for (uint32_t b = 0; b < 65536; b++) { if (rank_in_bin < cum + hist1[b]) { const uint32_t bits = (prefix << 16) | b; memcpy(value, &bits, 4); return MKP_OK;
+  for (uint32_t b = 0; b < 65536; b++) { if (rank_in_bin < cum + hist1[b]) { const uint32_t bits = (prefix << 16) | b; memcpy(value, &bits, 4);
+      return MKP_OK;
       } cum += hist1[b]; }
   return MKP_E_THRESHOLD;
 }

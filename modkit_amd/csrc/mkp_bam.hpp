@@ -56,7 +56,8 @@ class HostPool {
     cpu_set_t set; if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, (unsigned)std::max(1, CPU_COUNT(&set)));
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota|max> <period>"
       char q[32]; unsigned long long period = 0;
-      if (fscanf(f, "%31s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min(n, (unsigned)std::max(1ull, (strtoull(q, nullptr, 10) + period - 1) / period));
+      if (fscanf(f, "%31s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min(n,
+          (unsigned)std::max(1ull, (strtoull(q, nullptr, 10) + period - 1) / period));
       fclose(f);
     } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
       long long quota = -1, period = 0; if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g);
@@ -83,10 +84,12 @@ class HostPool {
     if (job.failed.load()) std::rethrow_exception(job.error);
   }
  private:
-  struct Job { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}, skipped{0}; std::atomic<bool> failed{false}; std::exception_ptr error; std::mutex emu; };
+  struct Job { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0},
+      skipped{0}; std::atomic<bool> failed{false}; std::exception_ptr error; std::mutex emu; };
   static void run_one(Job* job, size_t i) {   // never lets an exception escape: the first one is kept for the caller, the index counts as done
     try { if (!job->failed.load()) job->fn(i); }
-    catch (...) { std::lock_guard<std::mutex> lk(job->emu); if (!job->failed.load()) { job->error = std::current_exception(); job->failed.store(true); } }
+    catch (...) { std::lock_guard<std::mutex> lk(job->emu); if (!job->failed.load()) { job->error = std::current_exception(); job->failed.store(true);
+      } }
     job->done.fetch_add(1);
   }
   std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_, done_cv_; std::deque<Job*> jobs_; bool stop_ = false;
@@ -102,7 +105,8 @@ class HostPool {
       { std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
           if (stop_) return;
-          for (Job* j : jobs_) { const size_t k = j->next.fetch_add(1); if (k < j->n) { job = j; i = k; break; } }   // claimed under the lock: the job cannot be retired in between
+          // claimed under the lock: the job cannot be retired in between
+          for (Job* j : jobs_) { const size_t k = j->next.fetch_add(1); if (k < j->n) { job = j; i = k; break; } }
           if (job) break;
           cv_.wait(lk);
         } }
@@ -126,30 +130,37 @@ struct ByteBuf {
   uint8_t* p = nullptr; size_t n = 0, cap = 0; bool heap = false;
   ByteBuf() = default;
   ByteBuf(ByteBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), heap(o.heap) { o.p = nullptr; o.n = o.cap = 0; }
-  ByteBuf& operator=(ByteBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; heap = o.heap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+  ByteBuf& operator=(ByteBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; heap = o.heap; o.p = nullptr;
+      o.n = o.cap = 0; } return *this; }
   ByteBuf(const ByteBuf&) = delete; ByteBuf& operator=(const ByteBuf&) = delete;
   ~ByteBuf() { release(); }
   // Large mappings are recycled through a process-wide spare list: a shard's inflated windows are ~1 GB, and unmapping them after the
   // pack (~45 ms per shard, the address-space lock held against every other thread's faults) plus faulting fresh ones for the next
-  // shard cost more than the copy itself.  At most spare_limit() bytes stay parked (recycled mappings are not zeroed: callers write what they read, including the 8 spare bytes behind a window); trim_spares() (BamSource destructor) returns them.
+  // shard cost more than the copy itself.  At most spare_limit() bytes stay parked (recycled mappings are not zeroed: callers write what they read,
+  // including the 8 spare bytes behind a window); trim_spares() (BamSource destructor) returns them.
   struct Spares { std::mutex mu; std::vector<std::pair<uint8_t*, size_t>> free; size_t bytes = 0; };
   static Spares& spares() { static Spares s; return s; }
   // at most 6 GiB parked, and never more than a quarter of what this process may use (the cgroup's memory limit where there is one):
   // parked mappings are resident pages nobody is using
   static size_t spare_limit() {
     static const size_t lim = []() { size_t v = (size_t)6 << 30;
-      if (FILE* f = fopen("/sys/fs/cgroup/memory.max", "r")) { char q[64]; if (fscanf(f, "%63s", q) == 1 && strcmp(q, "max") != 0) { const unsigned long long m = strtoull(q, nullptr, 10); if (m) v = std::min<size_t>(v, (size_t)(m / 4)); } fclose(f); }
-      else if (FILE* g = fopen("/sys/fs/cgroup/memory/memory.limit_in_bytes", "r")) { unsigned long long m = 0; if (fscanf(g, "%llu", &m) == 1 && m && m < (1ull << 60)) v = std::min<size_t>(v, (size_t)(m / 4)); fclose(g); }
+      if (FILE* f = fopen("/sys/fs/cgroup/memory.max", "r")) { char q[64]; if (fscanf(f, "%63s", q) == 1 && strcmp(q, "max") != 0) {
+          const unsigned long long m = strtoull(q, nullptr, 10); if (m) v = std::min<size_t>(v, (size_t)(m / 4)); } fclose(f); }
+      else if (FILE* g = fopen("/sys/fs/cgroup/memory/memory.limit_in_bytes", "r")) { unsigned long long m = 0;
+        if (fscanf(g, "%llu", &m) == 1 && m && m < (1ull << 60)) v = std::min<size_t>(v, (size_t)(m / 4));
+        fclose(g); }
       return v; }();
     return lim;
   }
-  static void trim_spares() { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu); for (auto& f : s.free) munmap(f.first, f.second); s.free.clear(); s.bytes = 0; }
+  static void trim_spares() { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu); for (auto& f : s.free) munmap(f.first, f.second);
+    s.free.clear(); s.bytes = 0; }
   void release() {
     if (p) {
       if (heap) free(p);
       else {
         Spares& s = spares(); bool parked = false;
-        { std::lock_guard<std::mutex> g(s.mu); if (s.bytes + cap <= spare_limit() && s.free.size() < 64) { s.free.push_back({p, cap}); s.bytes += cap; parked = true; } }
+        { std::lock_guard<std::mutex> g(s.mu); if (s.bytes + cap <= spare_limit() && s.free.size() < 64) { s.free.push_back({p, cap}); s.bytes += cap;
+            parked = true; } }
         if (!parked) munmap(p, cap);
       }
     }
@@ -158,13 +169,18 @@ struct ByteBuf {
   // small buffers come from the heap: many threads mapping, faulting and unmapping small regions serialise on the address-space lock
   void alloc(size_t bytes) {
     release();
-    if (bytes < (32u << 20)) { p = (uint8_t*)malloc(std::max<size_t>(bytes, 1)); if (!p) throw Error(MKP_E_NOMEM, "out of host memory for the decompressed BAM"); n = cap = bytes; heap = true; return; }
+    if (bytes < (32u << 20)) { p = (uint8_t*)malloc(std::max<size_t>(bytes, 1));
+      if (!p) throw Error(MKP_E_NOMEM, "out of host memory for the decompressed BAM");
+      n = cap = bytes; heap = true; return; }
     // sizes in 32 MiB steps: the windows of one file inflate to similar sizes and then land in the same step
     const size_t want = (std::max<size_t>(bytes, 1) + (32u << 20) - 1) & ~(size_t)((32u << 20) - 1);
-    { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu);   // the smallest parked mapping that holds it without wasting more than its size again
+    // the smallest parked mapping that holds it without wasting more than its size again
+    { Spares& s = spares(); std::lock_guard<std::mutex> g(s.mu);
       size_t best = SIZE_MAX;
-      for (size_t i = 0; i < s.free.size(); i++) if (s.free[i].second >= want && s.free[i].second <= 2 * want && (best == SIZE_MAX || s.free[i].second < s.free[best].second)) best = i;
-      if (best != SIZE_MAX) { p = s.free[best].first; cap = s.free[best].second; n = bytes; s.bytes -= cap; s.free.erase(s.free.begin() + (ptrdiff_t)best); return; }
+      for (size_t i = 0; i < s.free.size(); i++) if (s.free[i].second >= want && s.free[i].second <= 2 * want
+          && (best == SIZE_MAX || s.free[i].second < s.free[best].second)) best = i;
+      if (best != SIZE_MAX) { p = s.free[best].first; cap = s.free[best].second; n = bytes; s.bytes -= cap;
+        s.free.erase(s.free.begin() + (ptrdiff_t)best); return; }
       // nothing parked fits: the parked ones belong to a shape of work that is over; give them back so that the peak follows the shard in hand
       for (auto& f : s.free) munmap(f.first, f.second);
       s.free.clear(); s.bytes = 0; }
@@ -257,7 +273,8 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0, bo
     uint16_t xlen; memcpy(&xlen, &comp[o + 10], 2);
     size_t x = o + 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
     if (xe > comp.size()) throw Error(MKP_E_IO, "bad BGZF block in " + path);
-    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &comp[x + 2], 2); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b; memcpy(&b, &comp[x + 4], 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (size_t)sl; }
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &comp[x + 2], 2); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t b;
+        memcpy(&b, &comp[x + 4], 2); bsize = (uint32_t)b + 1; found = true; } x += 4 + (size_t)sl; }
     if (!found || o + bsize > comp.size() || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path);
     uint32_t isize; memcpy(&isize, &comp[o + bsize - 4], 4);
     blks.push_back({o + 12 + xlen, bsize - xlen - 20, dtotal, isize});
@@ -266,8 +283,11 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0, bo
   BamData bd; bd.raw.alloc(dtotal);
   if (!threads) threads = HostPool::host_cpus();
   std::atomic<size_t> next{0}; std::atomic<bool> bad{false};
-  auto work = [&]() { for (;;) { size_t i = next++; if (i >= blks.size()) break; if (!blks[i].dlen) continue; try { inflate_block(&comp[blks[i].coff], blks[i].clen, &bd.raw[blks[i].doff], blks[i].dlen); } catch (...) { bad = true; } } };
-  if (threads <= 1 || blks.size() < 4) work(); else { std::vector<std::thread> th; for (unsigned t = 0; t < threads; t++) th.emplace_back(work); for (auto& t : th) t.join(); }
+  auto work = [&]() { for (;;) { size_t i = next++; if (i >= blks.size()) break; if (!blks[i].dlen) continue; try {
+        inflate_block(&comp[blks[i].coff], blks[i].clen, &bd.raw[blks[i].doff], blks[i].dlen); } catch (...) { bad = true; } } };
+  if (threads <= 1 || blks.size() < 4) work(); else { std::vector<std::thread> th; for (unsigned t = 0; t < threads; t++) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    }
   if (bad) throw Error(MKP_E_IO, "corrupt BGZF data in " + path);
   const ByteBuf& d = bd.raw; o = 0;
   auto need = [&](size_t n) { if (o + n > d.size()) throw Error(MKP_E_IO, "truncated BAM " + path); };
@@ -292,11 +312,14 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0, bo
     memcpy(&e.tid, &d[o], 4); memcpy(&e.pos, &d[o + 4], 4);
     uint8_t lq = d[o + 8]; uint16_t nc; memcpy(&nc, &d[o + 12], 2); memcpy(&e.flag, &d[o + 14], 2);
     int32_t lseq; memcpy(&lseq, &d[o + 16], 4);
-    if (lseq < 0 || (uint64_t)32 + lq + 4ull * nc + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) throw Error(MKP_E_IO, "corrupt BAM record");
-    if (e.tid < -1 || e.tid >= n_ref || e.pos < -1 || e.pos >= 0x7ffffff0) throw Error(MKP_E_IO, "corrupt BAM record: reference id or position out of range");
+    if (lseq < 0 || (uint64_t)32 + lq + 4ull * nc + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) throw Error(MKP_E_IO,
+        "corrupt BAM record");
+    if (e.tid < -1 || e.tid >= n_ref || e.pos < -1 || e.pos >= 0x7ffffff0) throw Error(MKP_E_IO,
+        "corrupt BAM record: reference id or position out of range");
     e.reflen = 0; e.end = e.pos + 1;
     // fetches assume a coordinate-sorted file (reference ids ascending, unplaced records last, positions ascending inside a reference)
-    if (require_sorted && !bd.recs.empty()) { const BamIndexEntry& q = bd.recs.back(); const uint32_t ta = (uint32_t)q.tid, tb = (uint32_t)e.tid;   // -1 sorts last as unsigned
+    // -1 sorts last as unsigned
+    if (require_sorted && !bd.recs.empty()) { const BamIndexEntry& q = bd.recs.back(); const uint32_t ta = (uint32_t)q.tid, tb = (uint32_t)e.tid;
       if (tb < ta || (tb == ta && e.tid >= 0 && e.pos < q.pos)) throw Error(MKP_E_INVALID, "the BAM is not coordinate sorted: " + path); }
     bd.recs.push_back(e); o += (size_t)bs;
   }
@@ -307,19 +330,24 @@ static inline BamData load_bam(const std::string& path, unsigned threads = 0, bo
         BamIndexEntry& e = bd.recs[i];
         const uint8_t* c = &d[e.off]; uint16_t nc; memcpy(&nc, c + 12, 2);
         const uint8_t* cg = c + 32 + c[8]; int64_t rl = 0;
-        for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4; }
+        for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); uint32_t op = w & 15;
+          if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4;
+          }
         if ((int64_t)e.pos + rl > 0x7ffffff0ll) { span_bad = true; rl = 0; }   // alignment runs past 2^31: corrupt record
         e.reflen = (int32_t)rl; e.end = e.pos + (rl > 0 ? (int32_t)rl : 1);
       }
     };
     const unsigned nt = n >= 4096 ? threads : 1u;
     if (nt <= 1) span(0, n);
-    else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(span, n * t / nt, n * (t + 1) / nt); for (auto& t : th) t.join(); }
+    else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(span, n * t / nt, n * (t + 1) / nt);
+      for (auto& t : th) t.join();
+      }
     if (span_bad) throw Error(MKP_E_IO, "corrupt BAM record: alignment runs past 2^31");
   }
   bd.tid_first.assign(bd.ref_names.size() + 1, bd.recs.size());
   for (size_t i = bd.recs.size(); i-- > 0;) { int t = bd.recs[i].tid; if (t >= 0 && (size_t)t < bd.ref_names.size()) bd.tid_first[(size_t)t] = i; }
-  for (size_t t = bd.ref_names.size(); t-- > 0;) if (bd.tid_first[t] == bd.recs.size() && t + 1 <= bd.ref_names.size()) bd.tid_first[t] = bd.tid_first[t + 1];
+  for (size_t t = bd.ref_names.size(); t-- > 0;) if (bd.tid_first[t] == bd.recs.size()
+      && t + 1 <= bd.ref_names.size()) bd.tid_first[t] = bd.tid_first[t + 1];
   return bd;
 }
 
@@ -360,7 +388,9 @@ static inline bool index_record(const uint8_t* d, size_t o, int32_t bs, int32_t 
   if (lseq < 0 || (uint64_t)32 + lq + 4ull * nc + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) return false;
   if (e->tid < -1 || e->tid >= n_ref || e->pos < -1 || e->pos >= 0x7ffffff0) return false;
   const uint8_t* cg = d + o + 32 + lq; int64_t rl = 0;
-  for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); const uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4; }
+  for (uint16_t k = 0; k < nc; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); const uint32_t op = w & 15;
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4;
+    }
   if ((int64_t)e->pos + rl > 0x7ffffff0ll) return false;
   e->reflen = (int32_t)rl; e->end = e->pos + (rl > 0 ? (int32_t)rl : 1);
   return true;
@@ -368,14 +398,18 @@ static inline bool index_record(const uint8_t* d, size_t o, int32_t bs, int32_t 
 
 struct BaiIndex {
   struct Chunk { uint64_t beg, end; };
-  struct Ref { std::map<uint32_t, std::vector<Chunk>> bins; std::vector<uint64_t> lin; uint64_t mapped = 0, unmapped = 0, off_beg = 0, off_end = 0; bool has_counts = false; };
+  struct Ref { std::map<uint32_t, std::vector<Chunk>> bins; std::vector<uint64_t> lin; uint64_t mapped = 0, unmapped = 0, off_beg = 0,
+      off_end = 0; bool has_counts = false; };
   std::vector<Ref> refs; uint64_t no_coor = 0; bool has_no_coor = false;
   static bool load(const std::string& path, BaiIndex* out) {
     FILE* f = fopen(path.c_str(), "rb"); if (!f) return false;
-    std::vector<uint8_t> b; { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize((size_t)std::max(n, 0l)); if (n > 0 && fread(b.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); return false; } }
+    std::vector<uint8_t> b; { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); b.resize((size_t)std::max(n, 0l));
+      if (n > 0 && fread(b.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f);
+        return false; } }
     fclose(f);
     size_t o = 0; auto need = [&](size_t n) { if (o + n > b.size()) throw Error(MKP_E_IO, "truncated BAM index " + path); };
-    auto u32 = [&]() { need(4); uint32_t v; memcpy(&v, &b[o], 4); o += 4; return v; }; auto u64 = [&]() { need(8); uint64_t v; memcpy(&v, &b[o], 8); o += 8; return v; };
+    auto u32 = [&]() { need(4); uint32_t v; memcpy(&v, &b[o], 4); o += 4; return v; }; auto u64 = [&]() { need(8); uint64_t v; memcpy(&v, &b[o], 8);
+      o += 8; return v; };
     need(4); if (memcmp(b.data(), "BAI\1", 4) != 0) throw Error(MKP_E_IO, "not a BAI index: " + path); o = 4;
     const uint32_t n_ref = u32(); if (n_ref > (1u << 24)) throw Error(MKP_E_IO, "corrupt BAM index " + path);
     out->refs.assign(n_ref, Ref());
@@ -383,7 +417,9 @@ struct BaiIndex {
       Ref& R = out->refs[r]; const uint32_t n_bin = u32();
       for (uint32_t k = 0; k < n_bin; k++) {
         const uint32_t bin = u32(), n_chunk = u32(); need((size_t)n_chunk * 16);
-        if (bin == 37450 && n_chunk == 2) { R.off_beg = u64(); R.off_end = u64(); R.mapped = u64(); R.unmapped = u64(); R.has_counts = true; continue; }   // htslib's metadata pseudo-bin
+        // htslib's metadata pseudo-bin
+        if (bin == 37450 && n_chunk == 2) { R.off_beg = u64(); R.off_end = u64(); R.mapped = u64(); R.unmapped = u64(); R.has_counts = true; continue;
+          }
         std::vector<Chunk>& v = R.bins[bin]; for (uint32_t c = 0; c < n_chunk; c++) { Chunk ch; ch.beg = u64(); ch.end = u64(); v.push_back(ch); }
       }
       const uint32_t n_intv = u32(); need((size_t)n_intv * 8); R.lin.resize(n_intv); for (uint32_t i = 0; i < n_intv; i++) R.lin[i] = u64();
@@ -408,21 +444,33 @@ struct BaiIndex {
     // coordinate sorted), so the first chunk of that window's own bin ends the search — what htslib gets by stopping at the first
     // record with pos >= end, known here before anything is read (the device ingest uploads whole ranges; a sparse BED asks for hundreds)
     uint64_t max_off = UINT64_MAX;   // (the smallest chunk start of that bin: the BAI format does not promise a bin's chunks sorted)
-    for (int64_t w = ((end - 1) >> 14) + 1, tries = 0; tries < 256 && w < (1 << 15); w++, tries++) { auto it = R.bins.find((uint32_t)(4681 + w)); if (it != R.bins.end() && !it->second.empty()) { max_off = UINT64_MAX; for (auto& ck : it->second) max_off = std::min<uint64_t>(max_off, ck.beg); break; } }
-    for (uint32_t b : bins) { auto it = R.bins.find(b); if (it == R.bins.end()) continue; for (auto c : it->second) if (c.end > min_off && c.beg < max_off) { c.end = std::min(c.end, max_off); out.push_back(c); } }
+    for (int64_t w = ((end - 1) >> 14) + 1, tries = 0; tries < 256 && w < (1 << 15); w++, tries++) { auto it = R.bins.find((uint32_t)(4681 + w));
+      if (it != R.bins.end() && !it->second.empty()) { max_off = UINT64_MAX;
+        for (auto& ck : it->second) max_off = std::min<uint64_t>(max_off, ck.beg);
+        break; } }
+    for (uint32_t b : bins) { auto it = R.bins.find(b); if (it == R.bins.end()) continue;
+      for (auto c : it->second) if (c.end > min_off && c.beg < max_off) { c.end = std::min(c.end, max_off);
+        out.push_back(c); } }
     std::sort(out.begin(), out.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
     // chunks are record-granular and those of neighbouring bins interleave in the file: ranges that overlap, touch, or lie within
     // one block (64 KiB compressed) of each other are read as one — the records in between belong to other bins of the same
     // region or are dropped by the position test, and reading through the gap beats re-reading the same blocks chunk by chunk
-    std::vector<Chunk> m; for (auto& c : out) { if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end); else m.push_back(c); }
+    std::vector<Chunk> m; for (auto& c : out) {
+      if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end);
+      else m.push_back(c);
+      }
     return m;
   }
   // the same for several disjoint ascending windows of one reference at once (a shard made of BED spans): one merged list
   std::vector<Chunk> query_parts(uint32_t tid, const std::vector<std::pair<int64_t, int64_t>>& parts) const {
     if (parts.size() == 1) return query(tid, parts[0].first, parts[0].second);
-    std::vector<Chunk> all; for (auto& pr : parts) { const std::vector<Chunk> q = query(tid, pr.first, pr.second); all.insert(all.end(), q.begin(), q.end()); }
+    std::vector<Chunk> all; for (auto& pr : parts) { const std::vector<Chunk> q = query(tid, pr.first, pr.second);
+      all.insert(all.end(), q.begin(), q.end()); }
     std::sort(all.begin(), all.end(), [](const Chunk& a, const Chunk& b) { return a.beg < b.beg; });
-    std::vector<Chunk> m; for (auto& c : all) { if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end); else m.push_back(c); }
+    std::vector<Chunk> m; for (auto& c : all) {
+      if (!m.empty() && (c.beg >> 16) <= (m.back().end >> 16) + (1u << 16)) m.back().end = std::max(m.back().end, c.end);
+      else m.push_back(c);
+      }
     return m;
   }
 };
@@ -462,7 +510,9 @@ class BamSource {
       // an index without htslib's per-reference counts (metadata pseudo-bins) cannot drive the sampling schedule: load the file instead
       bool complete = s->bai_.has_no_coor; for (auto& R : s->bai_.refs) if (!R.has_counts && !R.bins.empty()) complete = false;
       if (!complete) { close(s->fd_); s->fd_ = -1; s->ref_names.clear(); s->ref_lens.clear(); s->bai_ = BaiIndex(); }
-      else { uint64_t n = s->bai_.no_coor; for (auto& R : s->bai_.refs) n += R.mapped + R.unmapped; if (n) s->avg_rec_bytes_ = (double)s->fsize_ / (double)n; }
+      else { uint64_t n = s->bai_.no_coor; for (auto& R : s->bai_.refs) n += R.mapped + R.unmapped;
+        if (n) s->avg_rec_bytes_ = (double)s->fsize_ / (double)n;
+        }
     }
     if (s->fd_ < 0) {
       s->resident_ = load_bam(path, s->threads_); s->ref_names = s->resident_.ref_names; s->ref_lens = s->resident_.ref_lens;
@@ -494,7 +544,8 @@ class BamSource {
   void fetch_parts(uint32_t tid, const FetchParts& parts, BamBatch* out) const {
     out->clear();
     if (tid >= ref_names.size() || parts.empty()) return;
-    if (parts.size() == 1) { fetch(tid, (uint32_t)std::max<int64_t>(parts[0].first, 0), (uint32_t)std::min<int64_t>(parts[0].second, 0xffffffffll), out); return; }
+    if (parts.size() == 1) {
+      fetch(tid, (uint32_t)std::max<int64_t>(parts[0].first, 0), (uint32_t)std::min<int64_t>(parts[0].second, 0xffffffffll), out); return; }
     const int64_t beg = parts.front().first, end = parts.back().second;
     if (!indexed()) {
       const BamData& bam = resident_; out->base = bam.raw.data();
@@ -514,7 +565,9 @@ class BamSource {
     out->clear();
     if (!indexed()) { out->base = resident_.raw.data(); for (auto& e : resident_.recs) if (e.tid < 0) out->recs.push_back(e); return; }
     uint64_t from = first_record_voff_;
-    for (auto& R : bai_.refs) { for (auto& kv : R.bins) for (auto& c : kv.second) from = std::max(from, c.end); if (R.has_counts) from = std::max(from, R.off_end); }
+    for (auto& R : bai_.refs) { for (auto& kv : R.bins) for (auto& c : kv.second) from = std::max(from, c.end);
+      if (R.has_counts) from = std::max(from, R.off_end);
+      }
     std::vector<BaiIndex::Chunk> ch(1); ch[0].beg = from; ch[0].end = fsize_ << 16;
     read_chunks(ch, -1, 0, 0, out, SIZE_MAX);
   }
@@ -522,9 +575,12 @@ class BamSource {
   // per-reference counts as htslib's idxstats gives them (sampling_schedule.rs:685-710)
   void counts(std::vector<uint64_t>* mapped, std::vector<uint64_t>* unmapped, uint64_t* no_coor) const {
     mapped->assign(ref_names.size(), 0); unmapped->assign(ref_names.size(), 0); *no_coor = 0;
-    if (!indexed()) { for (auto& r : resident_.recs) { if (r.tid < 0) (*no_coor)++; else if (r.flag & 4) (*unmapped)[(size_t)r.tid]++; else (*mapped)[(size_t)r.tid]++; } return; }
+    if (!indexed()) { for (auto& r : resident_.recs) { if (r.tid < 0) (*no_coor)++; else if (r.flag & 4) (*unmapped)[(size_t)r.tid]++;
+        else (*mapped)[(size_t)r.tid]++;
+      } return; }
     bool complete = bai_.has_no_coor; for (auto& R : bai_.refs) if (!R.has_counts && !R.bins.empty()) complete = false;
-    if (!complete) throw Error(MKP_E_UNSUPPORTED, "the BAM index carries no per-reference read counts (metadata pseudo-bin): re-index the file with samtools index");
+    if (!complete) throw Error(MKP_E_UNSUPPORTED,
+        "the BAM index carries no per-reference read counts (metadata pseudo-bin): re-index the file with samtools index");
     for (size_t t = 0; t < bai_.refs.size(); t++) { (*mapped)[t] = bai_.refs[t].mapped; (*unmapped)[t] = bai_.refs[t].unmapped; }
     *no_coor = bai_.no_coor;
   }
@@ -533,7 +589,8 @@ class BamSource {
   // (tid, pos) for a sorted file, so differences measure the bytes under a reference range.  Without an index: a base-pair
   // coordinate over the concatenated references (shards are then balanced by length).
   uint64_t offset_at(uint32_t tid, uint64_t pos) const {
-    if (!indexed()) { uint64_t o = 0; for (uint32_t t = 0; t < tid && t < ref_lens.size(); t++) o += ref_lens[t]; return o + std::min<uint64_t>(pos, tid < ref_lens.size() ? ref_lens[tid] : 0); }
+    if (!indexed()) { uint64_t o = 0; for (uint32_t t = 0; t < tid && t < ref_lens.size(); t++) o += ref_lens[t];
+      return o + std::min<uint64_t>(pos, tid < ref_lens.size() ? ref_lens[tid] : 0); }
     if (tid >= bai_.refs.size()) return fsize_;
     // references without records take the offset of the next one that has any
     for (uint32_t t = tid; t < bai_.refs.size(); t++) {
@@ -551,12 +608,15 @@ class BamSource {
   // ranges holding the region's BGZF blocks, the block table with each block's place in the inflated window, and the record starts the
   // index knows (chunk starts + the 16 kb linear index) from which the device walks the `block_size` chains in parallel.
   struct IngestBlk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
-  struct IngestRange { uint64_t file_off = 0, file_len = 0, vbeg = 0, vend = 0; size_t blk0 = 0, blk1 = 0; uint64_t raw_start = 0, raw_limit = 0; size_t entry0 = 0, entry1 = 0; };
-  struct IngestPlan { uint32_t tid = 0; std::vector<IngestRange> ranges; std::vector<IngestBlk> blks; std::vector<uint64_t> entries; uint64_t raw_total = 0, comp_total = 0; };
+  struct IngestRange { uint64_t file_off = 0, file_len = 0, vbeg = 0, vend = 0; size_t blk0 = 0, blk1 = 0; uint64_t raw_start = 0, raw_limit = 0;
+    size_t entry0 = 0, entry1 = 0; };
+  struct IngestPlan { uint32_t tid = 0; std::vector<IngestRange> ranges; std::vector<IngestBlk> blks; std::vector<uint64_t> entries; uint64_t raw_total = 0,
+      comp_total = 0; };
   int fd() const { return fd_; }
   const std::string& path() const { return path_; }
   // phase 1: the file ranges (what has to go up) — the chunk list of the index and one header read at each chunk's end block
-  void ingest_ranges(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const { ingest_ranges(tid, FetchParts{{(int64_t)beg, (int64_t)end}}, out); }
+  void ingest_ranges(uint32_t tid, uint32_t beg, uint32_t end, IngestPlan* out) const {
+    ingest_ranges(tid, FetchParts{{(int64_t)beg, (int64_t)end}}, out); }
   void ingest_ranges(uint32_t tid, const FetchParts& parts, IngestPlan* out) const {
     *out = IngestPlan(); out->tid = tid;
     if (!indexed() || tid >= ref_names.size() || parts.empty() || parts.back().second <= parts.front().first) return;
@@ -577,7 +637,8 @@ class BamSource {
   // phase 2: block table, window layout, entry points.  The table is walked in CHAINS — runs of blocks between block starts the index
   // knows (every chunk boundary of the reference's bins, every linear-index offset) — by the device over the uploaded bytes
   // (mkp_ingest_host.cpp; round 5: 54 000 preads of the host walk below were the longest step of a whole-contig ingest) or by the host pool.
-  struct IngestChain { size_t range; uint64_t start, stop; };   // file offsets; stop = the next known block start inside the range, UINT64_MAX for the range's last chain
+  // file offsets; stop = the next known block start inside the range, UINT64_MAX for the range's last chain
+  struct IngestChain { size_t range; uint64_t start, stop; };
   void ingest_chains(const IngestPlan& plan, std::vector<IngestChain>* out) const {
     out->clear();
     const uint32_t tid = plan.tid; if (tid >= bai_.refs.size()) return;
@@ -590,7 +651,8 @@ class BamSource {
       const IngestRange& rg = plan.ranges[r]; const uint64_t cb = rg.file_off, range_end = cb + rg.file_len;
       const size_t first = out->size();
       out->push_back({r, cb, UINT64_MAX});
-      for (auto it = std::upper_bound(known_all.begin(), known_all.end(), cb); it != known_all.end() && *it < range_end; ++it) { out->back().stop = *it; out->push_back({r, *it, UINT64_MAX}); }
+      for (auto it = std::upper_bound(known_all.begin(), known_all.end(), cb); it != known_all.end() && *it < range_end; ++it) {
+        out->back().stop = *it; out->push_back({r, *it, UINT64_MAX}); }
       (void)first;
     }
   }
@@ -602,8 +664,11 @@ class BamSource {
     uint64_t c = ch.start;
     try {
       std::vector<uint8_t> hb(600); Blk b; bool have = false;
-      auto read_at = [&](uint64_t off, size_t n) { n = (size_t)std::min<uint64_t>(n, range_end > off ? range_end - off : 0); hb.resize(n); size_t got = 0;
-        while (got < n) { const ssize_t r = ::pread(fd_, hb.data() + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; } };
+      auto read_at = [&](uint64_t off, size_t n) { n = (size_t)std::min<uint64_t>(n, range_end > off ? range_end - off : 0); hb.resize(n);
+        size_t got = 0;
+        while (got < n) { const ssize_t r = ::pread(fd_, hb.data() + got, n - got, (off_t)(off + got));
+          if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_);
+          got += (size_t)r; } };
       for (;;) {
         if (c >= stop || c > ce || (c == ce && ue == 0) || c + 18 > range_end) break;
         if (!have) { read_at(c, 600); if (!block_at_header(hb, c, &b)) break; }
@@ -615,10 +680,13 @@ class BamSource {
         uint32_t isize; memcpy(&isize, hb.data() + 4, 4);
         blks->push_back({c, b.hdr, b.clen, isize, 0});
         c = next; have = false;
-        if (hb.size() >= 8 + 18 && !(c >= stop || c > ce || (c == ce && ue == 0))) { Blk nb; if (block_at_header(hb.data() + 8, hb.size() - 8, c, &nb)) { b = nb; have = true; } }
+        if (hb.size() >= 8 + 18 && !(c >= stop || c > ce || (c == ce && ue == 0))) { Blk nb;
+          if (block_at_header(hb.data() + 8, hb.size() - 8, c, &nb)) { b = nb;
+            have = true; } }
       }
     } catch (...) { return false; }
-    return !(stop != UINT64_MAX && c != stop && !(c > ce || (c == ce && ue == 0)));   // the chain of block sizes must land on the block start the index names
+    // the chain of block sizes must land on the block start the index names
+    return !(stop != UINT64_MAX && c != stop && !(c > ce || (c == ce && ue == 0)));
   }
   // window layout and entry points from the chains' blocks (parts[i] = the blocks of chain i, in file order)
   void ingest_layout(IngestPlan* out, const std::vector<IngestChain>& chains, std::vector<std::vector<IngestBlk>>& parts) const {
@@ -628,7 +696,9 @@ class BamSource {
       IngestRange& rg = out->ranges[r];
       const uint64_t cb = rg.file_off, ce = rg.vend >> 16, ue = rg.vend & 0xffff; const uint32_t ub = (uint32_t)(rg.vbeg & 0xffff);
       rg.blk0 = out->blks.size(); const uint64_t d0 = out->raw_total; uint64_t expect = cb;
-      for (; ci < chains.size() && chains[ci].range == r; ci++) for (auto& b : parts[ci]) { if (b.coff != expect) throw Error(MKP_E_IO, "the BAM index does not match the file: " + path_ + ".bai"); b.doff = out->raw_total; out->raw_total += b.isize; expect = b.coff + b.hdr + b.clen + 8; out->blks.push_back(b); }
+      for (; ci < chains.size() && chains[ci].range == r; ci++) for (auto& b : parts[ci]) {
+        if (b.coff != expect) throw Error(MKP_E_IO, "the BAM index does not match the file: " + path_ + ".bai");
+        b.doff = out->raw_total; out->raw_total += b.isize; expect = b.coff + b.hdr + b.clen + 8; out->blks.push_back(b); }
       rg.blk1 = out->blks.size();
       if (rg.blk1 == rg.blk0 || expect != cb + rg.file_len) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
       rg.raw_start = d0 + ub; rg.raw_limit = out->raw_total;
@@ -641,7 +711,8 @@ class BamSource {
         last_v = v;
         const uint64_t vc = v >> 16; size_t lo = rg.blk0, hi = rg.blk1;
         while (lo < hi) { const size_t mid = (lo + hi) / 2; if (out->blks[mid].coff < vc) lo = mid + 1; else hi = mid; }
-        if (lo >= rg.blk1 || out->blks[lo].coff != vc || (v & 0xffff) >= out->blks[lo].isize) continue;   // not a block start of this range: the chain does without it
+        // not a block start of this range: the chain does without it
+        if (lo >= rg.blk1 || out->blks[lo].coff != vc || (v & 0xffff) >= out->blks[lo].isize) continue;
         const uint64_t at = out->blks[lo].doff + (v & 0xffff);
         if (at > out->entries.back() && at + 4 <= rg.raw_limit) out->entries.push_back(at);
       }
@@ -663,7 +734,9 @@ class BamSource {
   double avg_rec_bytes_ = 0;   // compressed bytes per record over the whole file (indexed source: the index's counts)
 
   void pread_all(uint64_t off, uint8_t* dst, size_t n) const {
-    size_t got = 0; while (got < n) { const ssize_t r = ::pread(fd_, dst + got, n - got, (off_t)(off + got)); if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_); got += (size_t)r; }
+    size_t got = 0; while (got < n) { const ssize_t r = ::pread(fd_, dst + got, n - got, (off_t)(off + got));
+      if (r <= 0) throw Error(MKP_E_IO, "read error on " + path_);
+      got += (size_t)r; }
     bytes_read += n;
   }
   struct Blk { uint64_t coff; uint32_t hdr, clen, isize; uint64_t doff; };
@@ -676,7 +749,8 @@ class BamSource {
     const uint8_t& operator[](size_t i) const { return p[i]; }
   };
   void map_window(uint64_t off, size_t n, Window* w) const {
-    if (n < (16u << 20)) { w->copy.resize(n); pread_all(off, w->copy.data(), n); w->p = w->copy.data(); w->n = n; return; }   // small: a plain read (no mapping churn)
+    // small: a plain read (no mapping churn)
+    if (n < (16u << 20)) { w->copy.resize(n); pread_all(off, w->copy.data(), n); w->p = w->copy.data(); w->n = n; return; }
     const uint64_t page = 4096, a0 = off & ~(page - 1);
     w->map_len = (size_t)(off - a0) + n;
     w->map = mmap(nullptr, w->map_len, PROT_READ, MAP_PRIVATE, fd_, (off_t)a0);
@@ -692,7 +766,8 @@ class BamSource {
     uint16_t xlen; memcpy(&xlen, &buf[o + 10], 2);
     size_t x = o + 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
     if (xe > buf.size()) return false;
-    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &buf[x + 2], 2); if (buf[x] == 'B' && buf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t v; memcpy(&v, &buf[x + 4], 2); bsize = (uint32_t)v + 1; found = true; } x += 4 + (size_t)sl; }
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &buf[x + 2], 2); if (buf[x] == 'B' && buf[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t v;
+        memcpy(&v, &buf[x + 4], 2); bsize = (uint32_t)v + 1; found = true; } x += 4 + (size_t)sl; }
     if (!found || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path_);
     if (o + bsize > buf.size()) return false;
     b->coff = coff; b->hdr = 12u + xlen; b->clen = bsize - xlen - 20u; memcpy(&b->isize, &buf[o + bsize - 4], 4); b->doff = 0;
@@ -707,7 +782,8 @@ class BamSource {
     uint16_t xlen; memcpy(&xlen, &hb[10], 2);
     size_t x = 12, xe = x + xlen; uint32_t bsize = 0; bool found = false;
     if (xe > hn) return false;
-    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &hb[x + 2], 2); if (hb[x] == 'B' && hb[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t v; memcpy(&v, &hb[x + 4], 2); bsize = (uint32_t)v + 1; found = true; } x += 4 + (size_t)sl; }
+    while (x + 4 <= xe) { uint16_t sl; memcpy(&sl, &hb[x + 2], 2); if (hb[x] == 'B' && hb[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { uint16_t v;
+        memcpy(&v, &hb[x + 4], 2); bsize = (uint32_t)v + 1; found = true; } x += 4 + (size_t)sl; }
     if (!found || bsize < (uint32_t)xlen + 20u) throw Error(MKP_E_IO, "bad BGZF block in " + path_);
     b->coff = coff; b->hdr = 12u + xlen; b->clen = bsize - xlen - 20u; b->isize = 0; b->doff = 0;
     return true;
@@ -733,7 +809,8 @@ class BamSource {
     for (int32_t i = 0; i < n_ref; i++) {
       ensure(o + 4); int32_t ln; memcpy(&ln, &d[o], 4); if (ln <= 0) throw Error(MKP_E_IO, "corrupt BAM header: reference name length");
       ensure(o + 4 + (size_t)ln + 4);
-      ref_names.push_back(std::string((const char*)&d[o + 4], (size_t)ln - 1)); uint32_t lr; memcpy(&lr, &d[o + 4 + (size_t)ln], 4); ref_lens.push_back(lr); o += 8 + (size_t)ln;
+      ref_names.push_back(std::string((const char*)&d[o + 4], (size_t)ln - 1)); uint32_t lr; memcpy(&lr, &d[o + 4 + (size_t)ln], 4);
+        ref_lens.push_back(lr); o += 8 + (size_t)ln;
     }
     // virtual offset of the first record: `o` bytes into the inflated stream
     uint64_t acc = 0; first_record_voff_ = coff << 16;
@@ -741,38 +818,45 @@ class BamSource {
   }
 
   // inflate the blocks under the (merged, ascending) virtual-offset ranges and index their records that pass the region test
-  void read_chunks(const std::vector<BaiIndex::Chunk>& chunks, int32_t tid, int64_t beg, int64_t end, BamBatch* out, size_t max_records, const FetchParts* parts = nullptr) const {
+  void read_chunks(const std::vector<BaiIndex::Chunk>& chunks, int32_t tid, int64_t beg, int64_t end, BamBatch* out, size_t max_records,
+      const FetchParts* parts = nullptr) const {
     const int32_t n_ref = (int32_t)ref_names.size();
     // groups of chunks are processed until enough records are in hand; each group: pread, block walk, parallel inflate, record scan
     bool stop = false;
     for (size_t ci = 0; ci < chunks.size() && !stop; ci++) {
-      uint64_t cb = chunks[ci].beg >> 16; const uint64_t ce = chunks[ci].end >> 16, ue = chunks[ci].end & 0xffff; uint32_t ub = (uint32_t)(chunks[ci].beg & 0xffff);
+      uint64_t cb = chunks[ci].beg >> 16; const uint64_t ce = chunks[ci].end >> 16, ue = chunks[ci].end & 0xffff;
+        uint32_t ub = (uint32_t)(chunks[ci].beg & 0xffff);
       // a bounded window of compressed bytes at a time (a chunk may be the whole contig): 64 MiB, or — when the caller wants only
       // the first records of the region — 4 MiB growing to that
       // (heads: sized from the file's mean compressed record — index counts over file size — plus slack for the records of the first
       // chunk that end before the region; a fixed 2 MiB start was short for 10 kb reads and its doubling then inflated 2.4x what was needed)
       uint64_t window = max_records == SIZE_MAX ? (64u << 20) : avg_rec_bytes_ > 0
-          ? std::min<uint64_t>(64u << 20, std::max<uint64_t>(256u << 10, (uint64_t)((double)max_records * avg_rec_bytes_ * 1.2) + (192u << 10))) : (2u << 20);
+          ? std::min<uint64_t>(64u << 20, std::max<uint64_t>(256u << 10, (uint64_t)((double)max_records * avg_rec_bytes_ * 1.2) + (192u << 10)))
+              : (2u << 20);
       while (cb < fsize_ && (cb < ce || (cb == ce && ue > 0)) && !stop) {
         const uint64_t want_end = std::min<uint64_t>(fsize_, std::min<uint64_t>(ce + (1u << 16) + 64, cb + window));
         const bool window_at_max = window >= (64u << 20) || want_end < cb + window;   // this window cannot be made larger
         window = std::min<uint64_t>(window * 2, 64u << 20);
         Window buf; map_window(cb, (size_t)(want_end - cb), &buf);
         std::vector<Blk> blks; uint64_t c = cb, dtotal = 0;
-        for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; b.doff = dtotal; dtotal += b.isize; blks.push_back(b); c += b.hdr + b.clen + 8; }
+        for (;;) { Blk b; if (c > ce || (c == ce && ue == 0) || !block_at(buf, cb, c, &b)) break; b.doff = dtotal; dtotal += b.isize;
+          blks.push_back(b); c += b.hdr + b.clen + 8; }
         if (blks.empty()) throw Error(MKP_E_IO, "truncated BGZF block in " + path_);
         ByteBuf d; d.alloc((size_t)dtotal + 8);
         bool on_device = false;
         if (dev_inflate && dtotal >= (32u << 20)) {   // big windows only: a sampler's 2 MiB head is not worth a round trip
           std::vector<InflateBlk> jb(blks.size());
-          for (size_t i = 0; i < blks.size(); i++) jb[i] = {(unsigned long long)((blks[i].coff - cb) + blks[i].hdr), (unsigned long long)blks[i].doff, blks[i].clen, blks[i].isize};
+          for (size_t i = 0; i < blks.size(); i++) jb[i] = {(unsigned long long)((blks[i].coff - cb) + blks[i].hdr), (unsigned long long)blks[i].doff,
+              blks[i].clen, blks[i].isize};
           InflateJob job{&buf[0], buf.size(), jb.data(), jb.size(), d.data(), (size_t)dtotal};
           on_device = dev_inflate(dev_inflate_user, job);
           if (on_device) bytes_inflated_device += dtotal;
         }
         if (!on_device)
         { std::atomic<bool> bad{false};
-          HostPool::get().parallel(blks.size(), [&](size_t i) { if (!blks[i].isize) return; try { inflate_block(&buf[(size_t)(blks[i].coff - cb) + blks[i].hdr], blks[i].clen, &d[(size_t)blks[i].doff], blks[i].isize); } catch (...) { bad = true; } });
+          HostPool::get().parallel(blks.size(), [&](size_t i) { if (!blks[i].isize) return; try {
+              inflate_block(&buf[(size_t)(blks[i].coff - cb) + blks[i].hdr], blks[i].clen, &d[(size_t)blks[i].doff], blks[i].isize); } catch (...) {
+              bad = true; } });
           if (bad) throw Error(MKP_E_IO, "corrupt BGZF data in " + path_); }
         bytes_inflated += dtotal;
         // records: from `ub` in the first block to the chunk end (or the end of this window's last complete record)
@@ -793,12 +877,16 @@ class BamSource {
         }
         std::vector<BamIndexEntry> all(starts.size()); std::atomic<bool> rec_bad{false};
         { const size_t grain = 512, pieces = (starts.size() + grain - 1) / grain;
-          HostPool::get().parallel(pieces, [&](size_t pc) { for (size_t i = pc * grain; i < std::min(starts.size(), (pc + 1) * grain); i++) { int32_t bs; memcpy(&bs, &d[(size_t)starts[i]], 4); if (!index_record(d.data(), (size_t)starts[i] + 4, bs, n_ref, &all[i])) rec_bad = true; } }); }
+          HostPool::get().parallel(pieces, [&](size_t pc) { for (size_t i = pc * grain; i < std::min(starts.size(), (pc + 1) * grain); i++) {
+              int32_t bs; memcpy(&bs, &d[(size_t)starts[i]], 4);
+              if (!index_record(d.data(), (size_t)starts[i] + 4, bs, n_ref, &all[i])) rec_bad = true;
+            } }); }
         if (rec_bad) throw Error(MKP_E_IO, "corrupt BAM record");
         std::vector<BamIndexEntry> recs;
         for (size_t i = 0; i < all.size(); i++) {
           const BamIndexEntry& e = all[i];
-          if (tid >= 0) { if (e.tid != tid || (int64_t)e.pos >= end) { if (e.tid > tid || e.tid < 0 || (e.tid == tid && (int64_t)e.pos >= end)) { stop = true; break; } continue; } if ((int64_t)e.end <= beg) continue; if (parts && !overlaps_parts(*parts, e.pos, e.end)) continue; }
+          if (tid >= 0) { if (e.tid != tid || (int64_t)e.pos >= end) { if (e.tid > tid || e.tid < 0 || (e.tid == tid && (int64_t)e.pos >= end)) {
+                stop = true; break; } continue; } if ((int64_t)e.end <= beg) continue; if (parts && !overlaps_parts(*parts, e.pos, e.end)) continue; }
           else if (e.tid >= 0) continue;
           recs.push_back(e);
           if (recs.size() + out->recs.size() >= max_records) { stop = true; break; }
@@ -812,7 +900,8 @@ class BamSource {
         // next window starts at the block holding the first unconsumed byte
         size_t bi = blks.size() - 1; while (bi > 0 && blks[bi].doff > consumed) bi--;
         // no progress: the same first record again.  A larger window may hold it; the largest one did not
-        if (blks[bi].coff == cb && consumed - blks[bi].doff == ub && window_at_max) throw Error(MKP_E_IO, "BAM record larger than the ingest window (corrupt block_size?)");
+        if (blks[bi].coff == cb && consumed - blks[bi].doff == ub && window_at_max) throw Error(MKP_E_IO,
+            "BAM record larger than the ingest window (corrupt block_size?)");
         cb = blks[bi].coff; ub = (uint32_t)(consumed - blks[bi].doff);
       }
     }
@@ -827,7 +916,8 @@ struct FastaSeq {
   std::unique_ptr<char[]> mem; size_t n = 0;
   FastaSeq() = default;
   FastaSeq(FastaSeq&&) = default; FastaSeq& operator=(FastaSeq&&) = default;
-  FastaSeq& operator=(const std::string& s) { mem.reset(); n = 0; if (!s.empty()) memcpy(grow(s.size()), s.data(), s.size()); return *this; }   // (test harnesses fill a contig from a string)
+  // (test harnesses fill a contig from a string)
+  FastaSeq& operator=(const std::string& s) { mem.reset(); n = 0; if (!s.empty()) memcpy(grow(s.size()), s.data(), s.size()); return *this; }
   size_t size() const { return n; }
   const char* data() const { return mem.get(); }
   char* grow(size_t extra) {   // room for `extra` more bytes; returns where they go (what was there is kept: a name that comes twice)
@@ -843,14 +933,18 @@ struct Fasta {
   static std::map<std::string, std::string> load_serial(const std::string& path) {
     std::map<std::string, std::string> f; FILE* fp = fopen(path.c_str(), "rb");
     if (!fp) throw Error(MKP_E_IO, "cannot open fasta " + path);
-    std::string buf; { fseek(fp, 0, SEEK_END); const long n = ftell(fp); fseek(fp, 0, SEEK_SET); buf.resize((size_t)std::max(n, 0l)); if (n > 0 && fread(&buf[0], 1, (size_t)n, fp) != (size_t)n) { fclose(fp); throw Error(MKP_E_IO, "short read on fasta " + path); } }
+    std::string buf; { fseek(fp, 0, SEEK_END); const long n = ftell(fp); fseek(fp, 0, SEEK_SET); buf.resize((size_t)std::max(n, 0l));
+      if (n > 0 && fread(&buf[0], 1, (size_t)n, fp) != (size_t)n) { fclose(fp);
+        throw Error(MKP_E_IO, "short read on fasta " + path); } }
     fclose(fp);
     std::string* cur = nullptr; size_t o = 0; const size_t n = buf.size();
     while (o < n) {
       const char* nl = (const char*)memchr(buf.data() + o, '\n', n - o); size_t e = nl ? (size_t)(nl - buf.data()) : n, le = e;
       if (le > o && buf[le - 1] == '\r') le--;
       if (le > o) {
-        if (buf[o] == '>') { std::string name(buf.data() + o + 1, le - o - 1); const size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name.resize(sp); cur = &f[name]; }
+        if (buf[o] == '>') { std::string name(buf.data() + o + 1, le - o - 1); const size_t sp = name.find_first_of(" \t");
+          if (sp != std::string::npos) name.resize(sp);
+          cur = &f[name]; }
         else if (cur) cur->append(buf.data() + o, le - o);
       }
       o = e + 1;
@@ -887,7 +981,9 @@ struct Fasta {
       std::string name(buf + o + 1, le - o - 1); { const size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name.resize(sp); }
       const size_t b0 = std::min(n, e + 1);
       size_t b1 = b0;   // the body ends at the next '>' that starts a line
-      for (;;) { const char* g = b1 < n ? (const char*)memchr(buf + b1, '>', n - b1) : nullptr; if (!g) { b1 = n; break; } b1 = (size_t)(g - buf); if (b1 == b0 || buf[b1 - 1] == '\n') break; b1++; }
+      for (;;) { const char* g = b1 < n ? (const char*)memchr(buf + b1, '>', n - b1) : nullptr; if (!g) { b1 = n; break; } b1 = (size_t)(g - buf);
+        if (b1 == b0 || buf[b1 - 1] == '\n') break;
+        b1++; }
       FastaSeq& dst = f.seqs[name];
       if (b1 > b0) {
         const size_t piece = (size_t)1 << 20, np = (b1 - b0 + piece - 1) / piece;

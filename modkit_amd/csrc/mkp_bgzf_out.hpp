@@ -23,7 +23,8 @@ static const size_t MKP_BGZF_BLOCK = 0xff00;   // uncompressed bytes per block, 
 static inline uint32_t bgzf_block(const uint8_t* text, size_t n, std::vector<uint8_t>* out, int level = 6) {
   const size_t at = out->size(); out->resize(at + n + n / 8 + 64);
   z_stream zs; memset(&zs, 0, sizeof(zs));
-  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { out->resize(at); throw std::runtime_error("bgzf: deflateInit2 failed"); }
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { out->resize(at);
+    throw std::runtime_error("bgzf: deflateInit2 failed"); }
   zs.next_in = const_cast<Bytef*>(text); zs.avail_in = (uInt)n; zs.next_out = out->data() + at + 18; zs.avail_out = (uInt)(out->size() - at - 26);
   const int rc = deflate(&zs, Z_FINISH); const size_t clen = zs.total_out; deflateEnd(&zs);
   if (rc != Z_STREAM_END || clen + 26 > 65536) { out->resize(at); throw std::runtime_error("bgzf: block does not compress into 64 KiB"); }
@@ -47,8 +48,10 @@ struct BgzfPiece {
     size_t i = 0, off = 0;
     while (i < n_lines) {
       size_t j = i, bytes = 0;
-      while (j < n_lines && bytes + line_len[j] <= MKP_BGZF_BLOCK) { lines.push_back({pos[j], (uint32_t)block_csize.size(), (uint32_t)bytes, line_len[j]}); bytes += line_len[j]; j++; }
-      if (j == i) { lines.push_back({pos[j], (uint32_t)block_csize.size(), 0u, line_len[j]}); bytes = line_len[j]; j++; }   // (a line longer than a block cannot happen for bedMethyl rows)
+      while (j < n_lines && bytes + line_len[j] <= MKP_BGZF_BLOCK) {
+        lines.push_back({pos[j], (uint32_t)block_csize.size(), (uint32_t)bytes, line_len[j]}); bytes += line_len[j]; j++; }
+      // (a line longer than a block cannot happen for bedMethyl rows)
+      if (j == i) { lines.push_back({pos[j], (uint32_t)block_csize.size(), 0u, line_len[j]}); bytes = line_len[j]; j++; }
       const uint32_t cs = bgzf_block(reinterpret_cast<const uint8_t*>(text) + off, bytes, &comp);
       block_csize.push_back(cs); block_usize.push_back((uint32_t)bytes);
       off += bytes; i = j;
@@ -60,7 +63,8 @@ class BgzfTabixSink {
  public:
   FILE* f = nullptr; std::string index_path; bool failed = false;
   uint64_t file_off = 0;
-  struct Ref { std::string name; std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lidx; uint64_t first = 0, last = 0, n = 0; };
+  struct Ref { std::string name; std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lidx; uint64_t first = 0,
+      last = 0, n = 0; };
   std::vector<Ref> refs;
   static uint32_t reg2bin(int64_t beg, int64_t end) {  // SAM spec 5.3
     --end;
@@ -100,14 +104,16 @@ class BgzfTabixSink {
     std::vector<uint8_t> ix; auto put = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; ix.insert(ix.end(), b, b + n); };
     auto i32 = [&](int32_t v) { put(&v, 4); }; auto u32 = [&](uint32_t v) { put(&v, 4); }; auto u64 = [&](uint64_t v) { put(&v, 8); };
     put("TBI\1", 4); i32((int32_t)refs.size());
-    i32(0x10000); i32(1); i32(2); i32(3); i32('#'); i32(0);   // `tabix -p bed`: TBX_UCSC, sequence / begin / end columns, comment character, lines to skip
+    // `tabix -p bed`: TBX_UCSC, sequence / begin / end columns, comment character, lines to skip
+    i32(0x10000); i32(1); i32(2); i32(3); i32('#'); i32(0);
     std::string names; for (auto& r : refs) { names += r.name; names.push_back('\0'); }
     i32((int32_t)names.size()); put(names.data(), names.size());
     for (auto& r : refs) {
       i32((int32_t)r.bins.size() + 1);
       for (auto& kv : r.bins) { u32(kv.first); i32((int32_t)kv.second.size()); for (auto& c : kv.second) { u64(c.first); u64(c.second); } }
       u32(37450); i32(2); u64(r.first); u64(r.last); u64(r.n); u64(0);   // htslib's pseudo-bin: the contig's extent in the file and its line count
-      for (size_t w = r.lidx.size(); w-- > 1;) if (r.lidx[w - 1] == 0) r.lidx[w - 1] = r.lidx[w];   // empty windows take the next window's offset, as htslib fills them
+      // empty windows take the next window's offset, as htslib fills them
+      for (size_t w = r.lidx.size(); w-- > 1;) if (r.lidx[w - 1] == 0) r.lidx[w - 1] = r.lidx[w];
       i32((int32_t)r.lidx.size()); for (uint64_t v : r.lidx) u64(v);
     }
     u64(0);   // n_no_coor

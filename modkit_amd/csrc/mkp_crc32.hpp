@@ -29,8 +29,10 @@ __attribute__((target("pclmul,sse4.1"))) static inline uint32_t crc32_fold_pclmu
   x0 = _mm_load_si128((const __m128i*)k1k2);
   p += 64; n -= 64;
   while (n >= 64) {   // four 128-bit lanes folded 512 bits forward per step
-    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00); x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11); x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00); x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+      x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11); x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+      x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
     y5 = _mm_loadu_si128((const __m128i*)(p + 0x00)); y6 = _mm_loadu_si128((const __m128i*)(p + 0x10));
     y7 = _mm_loadu_si128((const __m128i*)(p + 0x20)); y8 = _mm_loadu_si128((const __m128i*)(p + 0x30));
     x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);

@@ -34,7 +34,8 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 }
 
 // BAM 4-bit code -> A,C,G,T = 0..3, anything else -1 (DnaBase::parse, mod_base_code.rs:188-196)
-__device__ __forceinline__ int nib2base(uint32_t n) { const int x = (int)__ffs((int)n) - 1; return (n & (n - 1u)) ? -1 : x; }  // one-hot nibble -> bit index; 0 -> -1
+// one-hot nibble -> bit index; 0 -> -1
+__device__ __forceinline__ int nib2base(uint32_t n) { const int x = (int)__ffs((int)n) - 1; return (n & (n - 1u)) ? -1 : x; }
 __device__ __forceinline__ uint32_t seq_nibble(const uint8_t* __restrict__ s, uint32_t q) {
   uint32_t b = s[q >> 1];
   return (q & 1u) ? (b & 15u) : (b >> 4);
@@ -56,7 +57,8 @@ __device__ __forceinline__ int find_op(uint32_t incl, uint32_t j) {
 }
 
 __device__ __forceinline__ uint32_t sel4(const uint32_t* a, int x) { return x == 0 ? a[0] : x == 1 ? a[1] : x == 2 ? a[2] : a[3]; }
-__device__ __forceinline__ unsigned long long sel4b(const unsigned long long* a, int x) { return x == 0 ? a[0] : x == 1 ? a[1] : x == 2 ? a[2] : a[3]; }
+__device__ __forceinline__ unsigned long long sel4b(const unsigned long long* a, int x) { return x == 0 ? a[0] : x == 1 ? a[1] : x == 2 ? a[2] : a[3];
+  }
 
 __device__ __forceinline__ int find_rank(const uint32_t* __restrict__ a, uint32_t n, uint32_t key) {
   uint32_t lo = 0, hi = n;
@@ -71,18 +73,23 @@ __device__ __forceinline__ int find_rank(const uint32_t* __restrict__ a, uint32_
 // demoted to scratch memory by the compiler (a select chain over array elements becomes an indexed load), which put
 // scratch loads into the per-call path.  With scalars the selects stay v_cndmask.
 struct F4 { float v0, v1, v2, v3; };
-__device__ __forceinline__ float& at(F4& f, int k) { return k == 0 ? f.v0 : k == 1 ? f.v1 : k == 2 ? f.v2 : f.v3; }   // k is a compile-time constant at every call site (unrolled loops)
+// k is a compile-time constant at every call site (unrolled loops)
+__device__ __forceinline__ float& at(F4& f, int k) { return k == 0 ? f.v0 : k == 1 ? f.v1 : k == 2 ? f.v2 : f.v3; }
 __device__ __forceinline__ float at(const F4& f, int k) { return k == 0 ? f.v0 : k == 1 ? f.v1 : k == 2 ? f.v2 : f.v3; }
 __device__ __forceinline__ float getk(const F4& p, int k) {   // OR of masked bit patterns: cannot be folded into an indexed (scratch) load
-  const uint32_t r = (k == 0 ? __float_as_uint(p.v0) : 0u) | (k == 1 ? __float_as_uint(p.v1) : 0u) | (k == 2 ? __float_as_uint(p.v2) : 0u) | (k == 3 ? __float_as_uint(p.v3) : 0u);
+  const uint32_t r = (k == 0 ? __float_as_uint(p.v0) : 0u) | (k == 1 ? __float_as_uint(p.v1) : 0u) | (k == 2 ? __float_as_uint(p.v2) : 0u) | (k == 3
+      ? __float_as_uint(p.v3) : 0u);
   return __uint_as_float(r);
 }
 // p[kk] = cond ? v : p[kk], as bit-field inserts under an all-ones / all-zeros mask (again: nothing the compiler can turn into an indexed store)
-__device__ __forceinline__ float bsel(bool c, float a, float b) { const uint32_t m = c ? 0xffffffffu : 0u; return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m)); }
+__device__ __forceinline__ float bsel(bool c, float a, float b) { const uint32_t m = c ? 0xffffffffu : 0u;
+  return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m)); }
 __device__ __forceinline__ void setk(F4& p, uint32_t kk, bool cond, float v) {
-  p.v0 = bsel(cond && kk == 0u, v, p.v0); p.v1 = bsel(cond && kk == 1u, v, p.v1); p.v2 = bsel(cond && kk == 2u, v, p.v2); p.v3 = bsel(cond && kk == 3u, v, p.v3);
+  p.v0 = bsel(cond && kk == 0u, v, p.v0); p.v1 = bsel(cond && kk == 1u, v, p.v1); p.v2 = bsel(cond && kk == 2u, v, p.v2);
+    p.v3 = bsel(cond && kk == 3u, v, p.v3);
 }
-__device__ __forceinline__ void addk(F4& p, int k, float v) { p.v0 = k == 0 ? p.v0 + v : p.v0; p.v1 = k == 1 ? p.v1 + v : p.v1; p.v2 = k == 2 ? p.v2 + v : p.v2; p.v3 = k == 3 ? p.v3 + v : p.v3; }
+__device__ __forceinline__ void addk(F4& p, int k, float v) { p.v0 = k == 0 ? p.v0 + v : p.v0; p.v1 = k == 1 ? p.v1 + v : p.v1;
+  p.v2 = k == 2 ? p.v2 + v : p.v2; p.v3 = k == 3 ? p.v3 + v : p.v3; }
 
 // ----------------------------------------------------------------------------------------------
 // One (mod strand, base) group descriptor as the lane sees it (fetched from the LDS copy of the layout).
@@ -108,7 +115,8 @@ __device__ __forceinline__ void collapse_redistribute(const GroupRegs& g, uint32
   const float n_other = (float)(present ? n_pre : n_pre + 1);  // other_mods.len() + 1
   const float redistribute = marginal / n_other;
 #pragma unroll
-  for (int i = 0; i < MKP_KMAX; i++) { if (i >= kmax) break; const int kq = (int)((pv >> (8 + 2 * i)) & 3u); addk(pk, (i < n_pre && kq != x) ? kq : -1, redistribute); }
+  for (int i = 0; i < MKP_KMAX; i++) { if (i >= kmax) break; const int kq = (int)((pv >> (8 + 2 * i)) & 3u);
+    addk(pk, (i < n_pre && kq != x) ? kq : -1, redistribute); }
 }
 
 // BaseModProbs -> BaseModCall: MultipleThresholdModCaller::call (threshold_mod_caller.rs:28-63).
@@ -162,7 +170,8 @@ __device__ __forceinline__ float argmax_group(const GroupRegs& g, uint32_t pv, F
 // Returns the sample "event" info: [0:1] canonical base, [4:7] thresholded class, [8:11] argmax class; class 0 = Filtered,
 // 1 = Canonical, 2 + s = Modified(code of global slot s).  *obs gets the slots of the codes in the map (observed_mods).
 // *amax (optional): the probability of the argmax call (`extract calls`: call_prob)
-__device__ __forceinline__ uint32_t summary_info(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX, float* amax = nullptr) {
+__device__ __forceinline__ uint32_t summary_info(const GroupRegs& g, uint32_t pv, F4& pk, bool collapse, uint32_t* obs, int kmax = MKP_KMAX,
+    float* amax = nullptr) {
   if (collapse) collapse_redistribute(g, pv, pk, kmax);
   const int n_post = (int)((pv >> 3) & 7u);
   float s = 0.0f, best = 0.0f; bool have = false; int bk = 0;
@@ -191,7 +200,9 @@ struct GState { F4 pk; uint32_t H, setmask; };
 __device__ __forceinline__ bool merge_tag(GState& S, const F4& ts, uint32_t seen, uint32_t mi) {
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) { if (S.setmask & (1u << k)) at(S.pk, k) = at(S.pk, k) + at(ts, k); else at(S.pk, k) = at(ts, k); }
+  for (int k = 0; k < MKP_KMAX; k++) if (seen & (1u << k)) { if (S.setmask & (1u << k)) at(S.pk, k) = at(S.pk, k) + at(ts, k);
+    else at(S.pk, k) = at(ts, k);
+    }
   S.setmask |= seen;
   if (S.H) {
     float s = 0.f;

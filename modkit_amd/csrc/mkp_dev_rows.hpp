@@ -5,11 +5,13 @@
 
 struct RowAcc { uint32_t n_valid, n_mod, n_can, n_other, n_del, n_fail, n_diff, n_nocall; };
 
-struct TileView {   // packed tallies of a tile in LDS: [counter | observed-code slot][S], '+' tally in the low, '-' in the high 16 bits; column = tally slot
+// packed tallies of a tile in LDS: [counter | observed-code slot][S], '+' tally in the low, '-' in the high 16 bits; column = tally slot
+struct TileView {
   const uint32_t* pk;
   uint32_t W, n_counters;
   __device__ __forceinline__ uint32_t c(uint32_t s, uint32_t cid, uint32_t i) const { return (pk[cid * W + i] >> (16u * s)) & 0xffffu; }
-  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const { return (int32_t)((pk[(n_counters + sl) * W + i] >> (16u * s)) & 0xffffu); }
+  __device__ __forceinline__ int32_t o(uint32_t s, uint32_t sl, uint32_t i) const {
+    return (int32_t)((pk[(n_counters + sl) * W + i] >> (16u * s)) & 0xffffu); }
 };
 
 // one (strand tally, primary base) row of FeatureVector::add_tally_to_counts (pileup/mod.rs:283-410);
@@ -41,7 +43,8 @@ __device__ __forceinline__ bool tally_row(const TV& tv, const MkpRunParams& prm,
 template <bool WRITE, class TV, class SlotOf>
 __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& prm, const uint8_t* __restrict__ focus,
                                             const MkpCombo* combos, int32_t p, uint32_t i, const MkpRowsDev& rows,
-                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */, SlotOf slot_of, uint32_t key = 0) {
+                                            uint32_t wr, uint32_t fv /* this position's focus byte (3 when there is no focus) */, SlotOf slot_of,
+                                                uint32_t key = 0) {
   const uint32_t rule = fv & 3u, combo = fv >> 2;
   if (!rule) return 0;
   uint32_t n = 0;
@@ -127,7 +130,8 @@ __device__ __forceinline__ uint32_t rows_at(const TV& tv, const MkpRunParams& pr
 // writer's order: primary base, then pattern — writers.rs:196-207).  The pattern goes out as its two element indices
 // (rows.code = a | b << 8), the primary base in rows.info; the host turns the elements into mod codes.
 template <bool WRITE>
-__device__ __forceinline__ uint32_t hemi_rows_at(const uint32_t* __restrict__ tal, uint32_t S, const MkpRunParams& prm, int32_t p, uint32_t i, const MkpRowsDev& rows, uint32_t wr) {
+__device__ __forceinline__ uint32_t hemi_rows_at(const uint32_t* __restrict__ tal, uint32_t S, const MkpRunParams& prm, int32_t p, uint32_t i,
+    const MkpRowsDev& rows, uint32_t wr) {
   uint32_t tot[4], n = 0;
   for (int pb = 0; pb < 4; pb++) {
     tot[pb] = 0;
@@ -157,15 +161,19 @@ __device__ __forceinline__ uint32_t hemi_rows_at(const uint32_t* __restrict__ ta
 // Row emission, row-major (round 6): MkpRunParams resolved once per workgroup into a small table (the "row program"), existence of a
 // row decided from a handful of tallies, one thread per ROW filling and storing it (mkp_pileup_stream, mkp_pileup_tiles).
 struct StreamProg {
-  uint32_t n_groups;       // row candidates per strand (or per motif when strands combine): observed-code slots in row order, or the four primary bases (--combine-mods)
+  // row candidates per strand (or per motif when strands combine): observed-code slots in row order, or the four primary bases (--combine-mods)
+  uint32_t n_groups;
   uint32_t totmask;        // counters that add up to a column's total (all but Delete and Filtered)
   uint32_t modmask[4];     // primary base -> the counters of its mod codes
   uint32_t code[16];       // group -> code of its rows
-  uint32_t info[16];       // group -> [0:1] primary base, [2:6] observed-code slot + 1 (0: a --combine-mods row), [7:11] counter of the code, [12:16] counter of
-                           //          Canonical(base), [17] the base has one, [18] first group of its code (strand combining adds up the groups of a code)
+  // group -> [0:1] primary base, [2:6] observed-code slot + 1 (0: a --combine-mods row), [7:11] counter of the code, [12:16] counter of
+  uint32_t info[16];
+                           //          Canonical(base), [17] the base has one, [18] first group of its code (strand combining adds up the groups of a
+                           //          code)
 };
 
-__device__ __forceinline__ uint32_t col_get(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t k) { return (tal[k * S + i] >> (16u * s)) & 0xffffu; }
+__device__ __forceinline__ uint32_t col_get(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t k) {
+  return (tal[k * S + i] >> (16u * s)) & 0xffffu; }
 __device__ __forceinline__ uint32_t col_sum(const uint32_t* __restrict__ tal, uint32_t S, uint32_t i, uint32_t s, uint32_t mask) {
   uint32_t t = 0;
   while (mask) { const uint32_t k = (uint32_t)__ffs((int)mask) - 1u; mask &= mask - 1u; t += col_get(tal, S, i, s, k); }
@@ -173,7 +181,8 @@ __device__ __forceinline__ uint32_t col_sum(const uint32_t* __restrict__ tal, ui
 }
 // does (strand tally s, column i, group g) yield a row — add_tally_to_counts's early returns (pileup/mod.rs:283-410): the primary base has
 // filtered coverage, and (per-code rows) the code was observed in a record over this column
-__device__ __forceinline__ bool stream_row_exists(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g) {
+__device__ __forceinline__ bool stream_row_exists(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, const StreamProg& P, uint32_t s,
+    uint32_t i, uint32_t g) {
   const uint32_t inf = P.info[g];
   if (!((inf >> 17) & 1u)) return false;
   const uint32_t cov = col_get(tal, S, i, s, (inf >> 12) & 31u) + col_sum(tal, S, i, s, P.modmask[inf & 3u]);
@@ -182,7 +191,8 @@ __device__ __forceinline__ bool stream_row_exists(const uint32_t* __restrict__ t
   return !osl || col_get(tal, S, i, s, n_counters + osl - 1u) != 0u;
 }
 // the row itself, added into `r`
-__device__ __forceinline__ void stream_row_add(const uint32_t* __restrict__ tal, uint32_t S, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g, RowAcc& r) {
+__device__ __forceinline__ void stream_row_add(const uint32_t* __restrict__ tal, uint32_t S, const StreamProg& P, uint32_t s, uint32_t i, uint32_t g,
+    RowAcc& r) {
   const uint32_t inf = P.info[g], pb = inf & 3u;
   const uint32_t n_can = col_get(tal, S, i, s, (inf >> 12) & 31u), mods = col_sum(tal, S, i, s, P.modmask[pb]);
   const uint32_t n_mod = ((inf >> 2) & 31u) ? col_get(tal, S, i, s, (inf >> 7) & 31u) : mods;
@@ -202,10 +212,12 @@ __device__ __forceinline__ void rowprog_build(const MkpRunParams& prm, uint32_t 
     const uint32_t sl = combine_mods ? 0u : prm.slot_order[g], pb = combine_mods ? g : prm.slots[sl].pb, ck = prm.can_of_pb[pb];
     code = combine_mods ? (uint32_t)"ACGT"[g] : prm.slots[sl].code_repr;
     const bool first = combine_mods || g == 0u || prm.slots[prm.slot_order[g - 1u]].code_repr != code;
-    inf = pb | ((combine_mods ? 0u : sl + 1u) << 2) | ((combine_mods ? 0u : (uint32_t)prm.slots[sl].cid) << 7) | (((MKP_C_CAN + ck) & 31u) << 12) | ((ck != 0xffu ? 1u : 0u) << 17) | ((first ? 1u : 0u) << 18);
+    inf = pb | ((combine_mods ? 0u : sl + 1u) << 2) | ((combine_mods ? 0u
+        : (uint32_t)prm.slots[sl].cid) << 7) | (((MKP_C_CAN + ck) & 31u) << 12) | ((ck != 0xffu ? 1u : 0u) << 17) | ((first ? 1u : 0u) << 18);
   }
   prog.code[g] = code; prog.info[g] = inf;
-  if (g < 4u) { uint32_t m = 0; for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == g) m |= 1u << prm.slots[t].cid; prog.modmask[g] = m; }
+  if (g < 4u) { uint32_t m = 0; for (uint32_t t = 0; t < prm.n_slots; t++) if (prm.slots[t].pb == g) m |= 1u << prm.slots[t].cid; prog.modmask[g] = m;
+    }
   if (g == 0u) { prog.n_groups = ng; prog.totmask = ((1u << n_counters) - 1u) & ~((1u << MKP_C_DEL) | (1u << MKP_C_FAIL)); }
 }
 
@@ -219,16 +231,20 @@ __device__ __forceinline__ void rowprog_build(const MkpRunParams& prm, uint32_t 
 // the threads scatter (column, strand, group) words into `rowmap` (LDS, `map_words` dwords: the accumulate phase's per-wave scratch, dead
 // by now) and then every thread fills and stores whole rows.  Existence is evaluated twice (count, scatter) — a handful of LDS reads —
 // instead of keeping a mask per column.  (Rounds 1-5: the interpreter of rows_at three times per column, 119 spilled registers.)
-__device__ __forceinline__ void emit_dense_rows(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, uint32_t n_tslots, int32_t T0h, const MkpTile& tl, uint32_t run, uint32_t key,
-                                                const MkpRunParams& prm, StreamProg& prog, uint32_t* __restrict__ rowmap, uint32_t map_words, uint32_t* __restrict__ rows_base,
-                                                uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
+__device__ __forceinline__ void emit_dense_rows(const uint32_t* __restrict__ tal, uint32_t S, uint32_t n_counters, uint32_t n_tslots, int32_t T0h,
+    const MkpTile& tl, uint32_t run, uint32_t key,
+                                                const MkpRunParams& prm, StreamProg& prog, uint32_t* __restrict__ rowmap, uint32_t map_words,
+                                                    uint32_t* __restrict__ rows_base,
+                                                uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off,
+                                                    uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
                                                 uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* row_total_p) {
   const int lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   rowprog_build(prm, n_counters, prog);
   __syncthreads();
   const StreamProg& P = prog;
-  const uint32_t n_groups = prm.combine_strands ? 0u : P.n_groups;   // (strands combine at motif positions only: a run without focus positions has none)
+  // (strands combine at motif positions only: a run without focus positions has none)
+  const uint32_t n_groups = prm.combine_strands ? 0u : P.n_groups;
   const uint32_t per = (n_tslots + PILEUP_THREADS - 1u) / PILEUP_THREADS;
   const uint32_t i0 = min(n_tslots, threadIdx.x * per), i1 = min(n_tslots, i0 + per);
   auto in_rows = [&](uint32_t i) { const int32_t p = T0h + (int32_t)i; return p >= tl.r0 && p < tl.r1; };
@@ -250,7 +266,8 @@ __device__ __forceinline__ void emit_dense_rows(const uint32_t* __restrict__ tal
   }
   MkpRowsDev rows;
   { const size_t cap = prm.row_capacity; uint32_t* q = rows_base;
-    rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap; rows.n_other = q + 6 * cap;
+    rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap;
+      rows.n_other = q + 6 * cap;
     rows.n_del = q + 7 * cap; rows.n_fail = q + 8 * cap; rows.n_diff = q + 9 * cap; rows.n_nocall = q + 10 * cap; }
   for (uint32_t r0 = 0; r0 < tile_rows; r0 += map_words) {
     if (r0) __syncthreads();   // the round before has read the map
@@ -282,7 +299,8 @@ __device__ __forceinline__ void emit_dense_rows(const uint32_t* __restrict__ tal
 // LDS byte addresses as integers: a tally update is then `lane base + 256*window + row*4*S`, two VALU instructions
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
-__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) {
+  __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // first index in the position-sorted event list `ev[0..n)` whose pos is >= key: 64-way probes, two dependent
 // loads for up to 4096 events instead of a 12-step bisection
@@ -316,7 +334,8 @@ template <bool FOCUS> struct SlotMap {
     const uint32_t lb = (uint32_t)(p - lbase), w = lb >> 5;
     return pfx[w] + (uint32_t)__popc(bm[w] & ((1u << (lb & 31u)) - 1u));
   }
-  __device__ __forceinline__ bool is_slot(int32_t p) const { if (!FOCUS) return true; const uint32_t lb = (uint32_t)(p - lbase); return (bm[lb >> 5] >> (lb & 31u)) & 1u; }
+  __device__ __forceinline__ bool is_slot(int32_t p) const { if (!FOCUS) return true; const uint32_t lb = (uint32_t)(p - lbase);
+    return (bm[lb >> 5] >> (lb & 31u)) & 1u; }
   __device__ __forceinline__ int32_t pos_of(uint32_t c) const { return FOCUS ? fpos[c] : T0h + (int32_t)c; }
 };
 
@@ -334,7 +353,8 @@ __device__ __forceinline__ uint32_t lookback_reserve_wave(unsigned long long* __
   uint32_t excl = 0;
   for (long long hi = (long long)run - 1; hi >= 0;) {
     const long long idx = hi - lane;
-    const unsigned long long v = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);   // (before the first run: everything so far = 0)
+    // (before the first run: everything so far = 0)
+    const unsigned long long v = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
     const uint32_t flag = (uint32_t)(v >> 62);
     const unsigned long long m2 = __ballot(flag == 2u), m0 = __ballot(flag == 0u);
     const uint32_t first2 = m2 ? (uint32_t)__builtin_ctzll(m2) : 64u, first0 = m0 ? (uint32_t)__builtin_ctzll(m0) : 64u;
@@ -351,16 +371,20 @@ __device__ __forceinline__ uint32_t lookback_reserve_wave(unsigned long long* __
 }
 
 template <bool FOCUS, bool HEMI, class SM, bool ORDERED = false>
-__device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SM sm, uint32_t n_tslots, MkpTile tl, uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
-                                            const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
+__device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal, SM sm, uint32_t n_tslots, MkpTile tl,
+    uint32_t tix /* row-run index: key pass * tiles + tile */, uint32_t key, const MkpRunParams* __restrict__ prmp,
+                                            const uint8_t* __restrict__ focus, const MkpCombo* combos_l, uint32_t* __restrict__ rows_base,
+                                                uint32_t* __restrict__ row_cursor,
                                             uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt, uint32_t* __restrict__ dev_err,
-                                            uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p, uint32_t n_runs = 0 /* ORDERED: runs of the launch sequence */) {
+                                            uint32_t* wave_tot, uint32_t* row_base_p, uint32_t* scan_carry_p,
+                                                uint32_t n_runs = 0 /* ORDERED: runs of the launch sequence */) {
   const MkpRunParams& prm = *prmp;
   const int lane = lane_id();
   const uint32_t wave = threadIdx.x >> 6;
   MkpRowsDev rows;
   { const size_t cap = prm.row_capacity; uint32_t* p = rows_base;
-    rows.pos = p; rows.info = p + cap; rows.code = p + 2 * cap; rows.n_valid = p + 3 * cap; rows.n_mod = p + 4 * cap; rows.n_can = p + 5 * cap; rows.n_other = p + 6 * cap;
+    rows.pos = p; rows.info = p + cap; rows.code = p + 2 * cap; rows.n_valid = p + 3 * cap; rows.n_mod = p + 4 * cap; rows.n_can = p + 5 * cap;
+      rows.n_other = p + 6 * cap;
     rows.n_del = p + 7 * cap; rows.n_fail = p + 8 * cap; rows.n_diff = p + 9 * cap; rows.n_nocall = p + 10 * cap; }
   TileView tv; tv.pk = tal; tv.W = prm.slot_cap; tv.n_counters = prm.n_counters;
   auto slot_of = [&](int32_t q) { return sm.rank(q); };
@@ -374,7 +398,8 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       p = sm.pos_of(i);
       if (p >= tl.r0 && p < tl.r1) {
         if (HEMI) cnt = hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0);
-        else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+        else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u;
+          cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
       }
     }
     const uint32_t inc2 = wave_incl_scan(cnt);
@@ -384,9 +409,13 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       uint32_t s = 0;
       for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) s += wave_tot[w2];
       uint32_t base;
-      if (ORDERED) {   // tile_row_off = the runs' look-back words (two dwords each); n_runs = number of runs (a kernel argument), row_cursor[1] = total rows, written by the last run
+      // tile_row_off = the runs' look-back words (two dwords each); n_runs = number of runs (a kernel argument), row_cursor[1] = total rows, written
+      // by the last run
+      if (ORDERED) {
 #ifdef MKP_DEBUG
-        if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (threadIdx.x == 0) b0 = atomicAdd(row_cursor + 1, s); base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); } else   // ablation: no look-back (rows in completion order)
+        // ablation: no look-back (rows in completion order)
+        if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (threadIdx.x == 0) b0 = atomicAdd(row_cursor + 1, s);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0); } else
 #endif
         {
         base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), tix, s);
@@ -402,7 +431,8 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
     if (*scan_carry_p != 0xffffffffu && cnt) {
       uint32_t woff = *row_base_p + inc2 - cnt;
       for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
-      if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, woff); else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, woff, fv, slot_of, key);
+      if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, woff);
+        else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, woff, fv, slot_of, key);
     }
     return;
   }
@@ -435,7 +465,8 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
         p = sm.pos_of(i);
         if (p >= tl.r0 && p < tl.r1) {
           if (HEMI) cnt = hemi_rows_at<false>(tal, prm.slot_cap, prm, p, i, rows, 0);
-          else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u; cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
+          else { fv = prm.has_focus ? (uint32_t)focus[p - prm.win_start] : 3u;
+            cnt = rows_at<false>(tv, prm, focus, combos_l, p, i, rows, 0, fv, slot_of); }
         }
       }
       const uint32_t inc2 = wave_incl_scan(cnt);
@@ -444,7 +475,9 @@ __device__ __forceinline__ void emit_tile_rows(const uint32_t* __restrict__ tal,
       __syncthreads();
       uint32_t woff = *scan_carry_p;
       for (uint32_t w2 = 0; w2 < wave; w2++) woff += wave_tot[w2];
-      if (cnt) { if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, row_base + woff + inc2 - cnt); else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of, key); }
+      if (cnt) { if (HEMI) hemi_rows_at<true>(tal, prm.slot_cap, prm, p, i, rows, row_base + woff + inc2 - cnt);
+        else rows_at<true>(tv, prm, focus, combos_l, p, i, rows, row_base + woff + inc2 - cnt, fv, slot_of, key);
+        }
       __syncthreads();
       if (threadIdx.x == PILEUP_THREADS - 1) *scan_carry_p = woff + inc2;
     }

@@ -242,7 +242,8 @@ struct MkpWork {             // 64 B
 // works out, per interval, which record owns the name (make_resident); a record that is answered from another one in some interval is a
 // CONSUMER: mkp_dup_events rebuilds its event list — its own events where it owns the name, the owner's events elsewhere, kept where its own
 // alignment shows the call's base — and the accumulate kernels then take that list as the record's own.
-struct MkpDupSeg { int32_t p_lo, p_hi; uint32_t src_off /* the owner's OWN event slice */, owner; };   // positions [p_lo, p_hi) of one consumer, ascending
+// positions [p_lo, p_hi) of one consumer, ascending
+struct MkpDupSeg { int32_t p_lo, p_hi; uint32_t src_off /* the owner's OWN event slice */, owner; };
 struct MkpDupCons {
   uint32_t rid, seg_off, n_seg;
   uint32_t own_off;    // the record's own event slice (what its decode kernel writes)

@@ -42,21 +42,30 @@ struct BedGraphOut {
     for (uint64_t i = 0; i < r.n_rows; i++) {
       std::string name;
       if (!prefix.empty()) name = prefix + "_";
-      if (groupings) { const uint32_t k = r.partition_key ? r.partition_key[i] : 0u; name += (k < r.n_partition_keys ? r.partition_key_names[k] : "not_found"); name += "_"; }
+      if (groupings) { const uint32_t k = r.partition_key ? r.partition_key[i] : 0u;
+        name += (k < r.n_partition_keys ? r.partition_key_names[k] : "not_found"); name += "_"; }
       const uint32_t code = r.code_repr[i];
       if (code & 0x80000000u) name += std::to_string(code & 0x7fffffffu); else name += (char)code;
-      if (r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) { name += "_"; for (char ch : labels[(size_t)r.motif_idx[i]]) if (ch != ',') name += ch; }
+      if (r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) { name += "_";
+        for (char ch : labels[(size_t)r.motif_idx[i]]) if (ch != ',') name += ch;
+        }
       name += r.strand[i] == '+' ? "_positive" : r.strand[i] == '-' ? "_negative" : r.strand[i] == '.' ? "_combined" : "__unknown";
       File& fl = files[name];
-      if (!fl.f) { const std::string path = dir + "/" + name + ".bedgraph"; fl.f = fopen(path.c_str(), "w"); if (!fl.f) throw Error(MKP_E_IO, "failed to make output file " + path); }
+      if (!fl.f) { const std::string path = dir + "/" + name + ".bedgraph"; fl.f = fopen(path.c_str(), "w");
+        if (!fl.f) throw Error(MKP_E_IO, "failed to make output file " + path);
+        }
       const float frac = (float)r.n_mod[i] / (float)r.n_valid[i];
       const int k = snprintf(line, sizeof(line), "\t%u\t%u\t%s\t%u\n", r.pos[i], r.pos[i] + 1, f32_display(frac).c_str(), r.n_valid[i]);
       fl.buf += chrom; fl.buf.append(line, (size_t)k);
-      if (fl.buf.size() > ((size_t)1 << 20)) { if (fwrite(fl.buf.data(), 1, fl.buf.size(), fl.f) != fl.buf.size()) throw Error(MKP_E_IO, "write error in " + dir); fl.buf.clear(); }
+      if (fl.buf.size() > ((size_t)1 << 20)) {
+        if (fwrite(fl.buf.data(), 1, fl.buf.size(), fl.f) != fl.buf.size()) throw Error(MKP_E_IO, "write error in " + dir);
+        fl.buf.clear(); }
       n++;
     }
   }
-  void finish() { for (auto& kv : files) { File& fl = kv.second; if (fl.f) { if (!fl.buf.empty() && fwrite(fl.buf.data(), 1, fl.buf.size(), fl.f) != fl.buf.size()) throw Error(MKP_E_IO, "write error in " + dir); fclose(fl.f); fl.f = nullptr; } } }
+  void finish() { for (auto& kv : files) { File& fl = kv.second; if (fl.f) {
+        if (!fl.buf.empty() && fwrite(fl.buf.data(), 1, fl.buf.size(), fl.f) != fl.buf.size()) throw Error(MKP_E_IO, "write error in " + dir);
+        fclose(fl.f); fl.f = nullptr; } } }
   ~BedGraphOut() { for (auto& kv : files) if (kv.second.f) fclose(kv.second.f); }
 };
 
@@ -66,16 +75,22 @@ struct Args {
   bool have_seed = false; uint64_t seed = 0;   // --seed
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
-  bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false, mixed_delim = false, with_header = false;
+  bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false,
+      mixed_delim = false, with_header = false;
   int device = 0; uint32_t rank = 0, world = 1;
-      uint64_t shard_bp = 0, shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
+      uint64_t shard_bp = 0,
+          shard_bytes = 256ull << 20 /* BAM bytes per shard (indexed input): bounds host memory, and the next shard inflates while this one is packed and run */;
       bool no_index = false; uint32_t tile = 0; bool stats = false, plan_only = false; uint32_t rerun = 0, plan_pack_min = 1024;
   bool hemi = false;   /* `pileup-hemi` (DuplexModBamPileup, subcommand.rs:827-1514) */
-  mkp_threshold_fn thr_cb = nullptr; void* thr_cb_user = nullptr;   /* mkp_pileup_run_cb: the pass thresholds come from the caller (multi-GPU: all-reduced histograms / a broadcast) */
+  mkp_threshold_fn thr_cb = nullptr; void* thr_cb_user = nullptr;
+    /* mkp_pileup_run_cb: the pass thresholds come from the caller (multi-GPU: all-reduced histograms / a broadcast) */
   uint64_t hbm_budget_mb = 0;   /* --hbm-budget-mb: device memory the shards ingested ahead may hold (0: 55 % of the device) */
-  bool device_inflate = false;   /* inflate the shards' BGZF windows on the GPU (mkp_inflate_wave4.hip) instead of the host pool, records back to the host packer */
-  bool host_ingest = false, shard_bytes_set = false;   /* --host-ingest (or MKP_HOST_INGEST=1): inflate, cut and pack the shards on the host instead of the device (mkp_ingest.hip) */
-  bool bedgraph = false;   /* --bedgraph: the output path is a directory of <code>[_<motif>]_<strand>.bedgraph files (BedGraphWriter, writers.rs:264-381) */
+  bool device_inflate = false;
+    /* inflate the shards' BGZF windows on the GPU (mkp_inflate_wave4.hip) instead of the host pool, records back to the host packer */
+  bool host_ingest = false, shard_bytes_set = false;
+    /* --host-ingest (or MKP_HOST_INGEST=1): inflate, cut and pack the shards on the host instead of the device (mkp_ingest.hip) */
+  bool bedgraph = false;
+    /* --bedgraph: the output path is a directory of <code>[_<motif>]_<strand>.bedgraph files (BedGraphWriter, writers.rs:264-381) */
   bool bgzf = false;   /* write the bedMethyl as BGZF + a .tbi index (what `bgzip` + `tabix -p bed` make of the reference's output) */
 };
 
@@ -90,12 +105,15 @@ uint64_t peak_rss_kb() {   // VmHWM of this process (--stats)
 RegionSpec parse_region(const std::string& raw, const BamSource& bam) {  // Region::parse_str (util.rs:463-524)
   auto bad = [&]() { return Error(MKP_E_INVALID, "invalid region, " + raw + ", should be 'chrom' or 'chrom:start-stop'"); };
   size_t c = raw.find(':');
-  if (c == std::string::npos) { int tid = bam.tid_of(raw); if (tid < 0) throw Error(MKP_E_INVALID, "contig-missing"); return {raw, 0, bam.ref_lens[(size_t)tid]}; }
+  if (c == std::string::npos) { int tid = bam.tid_of(raw); if (tid < 0) throw Error(MKP_E_INVALID, "contig-missing");
+    return {raw, 0, bam.ref_lens[(size_t)tid]}; }
   if (raw.find(':', c + 1) != std::string::npos) throw bad();
   std::string se = raw.substr(c + 1); std::vector<uint32_t> v; size_t s = 0;
   for (;;) { size_t d = se.find('-', s); std::string part = se.substr(s, d == std::string::npos ? std::string::npos : d - s), cl;
-      for (char ch : part) if (ch != ',') cl += ch; if (cl.empty()) throw bad(); uint64_t x = 0; for (char ch : cl) { if (ch < '0' || ch > '9') throw bad();
-      x = x * 10 + (uint64_t)(ch - '0'); if (x > 0xffffffffull) throw bad(); } v.push_back((uint32_t)x); if (d == std::string::npos) break; s = d + 1; }
+      for (char ch : part) if (ch != ',') cl += ch; if (cl.empty()) throw bad(); uint64_t x = 0; for (char ch : cl) {
+        if (ch < '0' || ch > '9') throw bad();
+      x = x * 10 + (uint64_t)(ch - '0'); if (x > 0xffffffffull) throw bad(); } v.push_back((uint32_t)x); if (d == std::string::npos) break; s = d + 1;
+        }
   if (v.size() != 2 || v[1] <= v[0]) throw bad();
   return {raw.substr(0, c), v[0], v[1]};
 }
@@ -109,7 +127,8 @@ bool parse_code(const std::string& s, uint32_t* out) {  // ModCodeRepr::parse (m
 
 std::vector<Contig> targets(const BamSource& bam, const RegionSpec* r) {  // get_targets (util.rs:409-446)
   std::vector<Contig> out;
-  for (size_t t = 0; t < bam.ref_names.size(); t++) { if (r) { if (bam.ref_names[t] == r->name) out.push_back({(uint32_t)t, r->start, r->end - r->start,
+  for (size_t t = 0; t < bam.ref_names.size(); t++) { if (r) {
+      if (bam.ref_names[t] == r->name) out.push_back({(uint32_t)t, r->start, r->end - r->start,
       bam.ref_names[t]}); } else out.push_back({(uint32_t)t, 0, bam.ref_lens[t], bam.ref_names[t]}); }
   return out;
 }
@@ -139,15 +158,19 @@ SampleTimes g_sample_times;   // --stats: where the threshold estimate's time we
 // attached to the context covers the contig — indices into that shard's digest (every kept record is a candidate; names are compared
 // through their two 64-bit hashes; the reads' bases and tags are in HBM already, mkp_internal_sample_resident).
 struct RecSet {
-  std::unique_ptr<BamBatch> b; bool complete = false; const ShardHost* S = nullptr; std::vector<uint32_t> idx;   // complete: nothing was left out for a later fetch; resident: index < S->hdr.size() = a kept read, above = sampler-only read (index - hdr.size())
+  // complete: nothing was left out for a later fetch; resident: index < S->hdr.size() = a kept read, above = sampler-only read (index - hdr.size())
+  std::unique_ptr<BamBatch> b; bool complete = false; const ShardHost* S = nullptr; std::vector<uint32_t> idx;
   size_t size() const { return S ? idx.size() : b->recs.size(); }
   bool truncated(size_t cap) const { return !S && !complete && b->recs.size() >= cap; }
   std::string name(size_t i) const {
-    if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size(); char key[16]; memcpy(key, k < n ? &S->name_hash[k] : &S->so_name_hash[k - n], 8); memcpy(key + 8, k < n ? &S->dev_name_hash2[k] : &S->so_name_hash2[k - n], 8);
+    if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size(); char key[16];
+      memcpy(key, k < n ? &S->name_hash[k] : &S->so_name_hash[k - n], 8);
+      memcpy(key + 8, k < n ? &S->dev_name_hash2[k] : &S->so_name_hash2[k - n], 8);
       return std::string(key, 16); }
     return b->qname(b->recs[i]);
   }
-  int32_t pos(size_t i) const { if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size(); return k < n ? S->hdr[k].ref_start : S->so_hdr[k - n].ref_start; } return b->recs[i].pos; }
+  int32_t pos(size_t i) const { if (S) { const uint32_t k = idx[i]; const size_t n = S->hdr.size();
+      return k < n ? S->hdr[k].ref_start : S->so_hdr[k - n].ref_start; } return b->recs[i].pos; }
   bool candidate(size_t i, bool drop_unmapped) const {
     if (S) return true;
     const BamIndexEntry& e = b->recs[i];
@@ -159,7 +182,8 @@ struct RecSet {
 // `resident_of` (optional): the device-packed shard holding contig `tid`, bound to the context (mkp_internal_sample_bind) — the estimate then
 // samples from HBM; called whenever the schedule moves to another contig.
 using ResidentOf = std::function<const ShardHost*(uint32_t tid)>;
-void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf, const ResidentOf& resident_of = ResidentOf()) {
+void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf,
+    const ResidentOf& resident_of = ResidentOf()) {
   const bool only_mapped = !a.include_unmapped;
   const bool sharded = a.world > 1;
   const bool resident_mode = (bool)resident_of;
@@ -170,19 +194,23 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     if (res && res_tid == tid) return;
     res = resident_of(tid); res_tid = tid;
     if (!res || (int32_t)tid != res->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
-    res_pmax.resize(res->hdr.size()); int32_t m = INT32_MIN; for (size_t i = 0; i < res->hdr.size(); i++) { m = std::max(m, std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1)); res_pmax[i] = m; }
+    res_pmax.resize(res->hdr.size()); int32_t m = INT32_MIN; for (size_t i = 0; i < res->hdr.size(); i++) {
+      m = std::max(m, std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1)); res_pmax[i] = m; }
   };
   auto fetch_set = [&](uint32_t tid, uint32_t s, uint32_t e, size_t cap) {
     RecSet r;
     if (resident_mode) {
       use_contig(tid);
       r.S = res;
-      const size_t first = (size_t)(std::upper_bound(res_pmax.begin(), res_pmax.end(), (int32_t)std::min<uint32_t>(s, 0x7fffffffu)) - res_pmax.begin());
-      for (size_t i = first; i < res->hdr.size() && (int64_t)res->hdr[i].ref_start < (int64_t)e; i++) if ((int64_t)std::max(res->hdr[i].ref_end, res->hdr[i].ref_start + 1) > (int64_t)s) r.idx.push_back((uint32_t)i);
+      const size_t first = (size_t)(std::upper_bound(res_pmax.begin(), res_pmax.end(),
+          (int32_t)std::min<uint32_t>(s, 0x7fffffffu)) - res_pmax.begin());
+      for (size_t i = first; i < res->hdr.size() && (int64_t)res->hdr[i].ref_start < (int64_t)e; i++) if ((int64_t)std::max(res->hdr[i].ref_end,
+          res->hdr[i].ref_start + 1) > (int64_t)s) r.idx.push_back((uint32_t)i);
       // the sampler-only records of the window (QC-fail ...: few), merged in by their place in the file
       bool any_so = false;
       for (size_t k = 0; k < res->so_hdr.size(); k++) { const MkpReadHdr& h = res->so_hdr[k];
-        if ((int64_t)h.ref_start < (int64_t)e && (int64_t)std::max(h.ref_end, h.ref_start + 1) > (int64_t)s) { r.idx.push_back((uint32_t)(res->hdr.size() + k)); any_so = true; } }
+        if ((int64_t)h.ref_start < (int64_t)e && (int64_t)std::max(h.ref_end, h.ref_start + 1) > (int64_t)s) {
+          r.idx.push_back((uint32_t)(res->hdr.size() + k)); any_so = true; } }
       if (any_so) { const size_t n = res->hdr.size(); auto wi = [&](uint32_t k) { return k < n ? res->dev_win_idx[k] : res->so_win_idx[k - n]; };
         std::stable_sort(r.idx.begin(), r.idx.end(), [&](uint32_t x, uint32_t y) { return wi(x) < wi(y); }); }
       return r;
@@ -194,7 +222,9 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       // the estimate inflate every sampling interval whole), all of them: there is no head to extend afterwards.  A record of the interval
       // meets a span inside it, or reaches a span outside it — then it crosses the interval's first or last position.
       std::vector<Span> sp;
-      for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue; for (auto& x : it->second) if (x.e > s && x.s < e) sp.push_back({std::max<uint64_t>(x.s, s), std::min<uint64_t>(x.e, e)}); }
+      for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
+        for (auto& x : it->second) if (x.e > s && x.s < e) sp.push_back({std::max<uint64_t>(x.s, s), std::min<uint64_t>(x.e, e)});
+        }
       sp.push_back({s, (uint64_t)s + 1}); if (e > s + 1) sp.push_back({(uint64_t)e - 1, e});
       std::sort(sp.begin(), sp.end(), [](const Span& x, const Span& y) { return x.s < y.s; });
       merge_spans(sp);
@@ -219,7 +249,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         quota[(uint32_t)kv.first] = q; }
   } else {  // from_num_reads (171-273)
     const float total = (float)total_u; size_t sum = 0;
-    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q; q.n = std::min<size_t>((size_t)ceilf((float)a.num_reads * ((float)kv.second / total)), (size_t)kv.second);
+    for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q;
+      q.n = std::min<size_t>((size_t)ceilf((float)a.num_reads * ((float)kv.second / total)), (size_t)kv.second);
         sum += q.n; quota[(uint32_t)kv.first] = q; }
     if (!only_mapped) sum += (size_t)ceilf((float)a.num_reads * ((float)st.unmapped / total));
     size_t floor = 1;
@@ -232,7 +263,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   const size_t batch_size = (size_t)floorf((float)a.threads * 1.5f);
   std::vector<Contig> contigs; for (auto& c : targets(bam, region)) if (quota.count(c.tid)) contigs.push_back(c);
   std::map<uint32_t, uint32_t> contig_size; for (auto& c : contigs) contig_size[c.tid] = c.length;
-  std::map<uint32_t, uint64_t> contig_base, contig_start; uint64_t grid_bp = 0; for (auto& c : contigs) { contig_base[c.tid] = grid_bp; contig_start[c.tid] = c.start;
+  std::map<uint32_t, uint64_t> contig_base, contig_start; uint64_t grid_bp = 0; for (auto& c : contigs) { contig_base[c.tid] = grid_bp;
+    contig_start[c.tid] = c.start;
       grid_bp += c.length; }
   std::set<std::string> taken; std::map<uint32_t, size_t> sampled_so_far;
   std::map<uint32_t, std::vector<uint8_t>> bedmasks;
@@ -250,7 +282,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   // `skip` (rank-sharded mode): candidates an earlier interval already took.  State across calls: used / n_reads_out.
   struct TakeState { size_t used = 0, n_reads_out = 0; };
   // the sampler's verdict on candidates cand[lo, hi) whose value counts are nv[0 ..): mask[k] = 1 where the read's values enter the sample
-  auto decide = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit, std::set<std::string>* interval_seen,
+  auto decide = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t lo, size_t hi, const uint32_t* nv, long limit,
+      std::set<std::string>* interval_seen,
       TakeState* ts, const std::vector<uint8_t>* skip, uint8_t* mask, SeededSampler* draws = nullptr, double frac = 1.0) {
     for (size_t i = lo; i < hi; i++) {
       if (limit >= 0 && ts->used >= (size_t)limit) break;   // RecordSampler::ask -> Done
@@ -276,17 +309,20 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     int rc;
     if (resident_mode) { std::vector<uint32_t> ids; ids.reserve(which.size()); for (auto& w : which) ids.push_back(w.first->idx[w.second]);
       rc = mkp_internal_sample_resident(ctx, ws, we, mask, ids.data(), (uint32_t)ids.size(), only_mapped, nv); }
-    else { std::vector<mkp_record> recs; recs.reserve(which.size()); for (auto& w : which) recs.push_back(w.first->b->view(w.first->b->recs[w.second]));
+    else { std::vector<mkp_record> recs; recs.reserve(which.size());
+      for (auto& w : which) recs.push_back(w.first->b->view(w.first->b->recs[w.second]));
       rc = mkp_internal_sample(ctx, mapped_contig ? (int32_t)tid : -1, ws, we, mask, recs.data(), (uint32_t)recs.size(), only_mapped, nv); }
     if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
   };
-  auto take = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig, std::set<std::string>* interval_seen,
+  auto take = [&](const RecSet& batch, const std::vector<size_t>& cand, size_t from, long limit, uint32_t tid, bool mapped_contig,
+      std::set<std::string>* interval_seen,
       TakeState* ts, const std::vector<uint8_t>* skip = nullptr, SeededSampler* draws = nullptr, double frac = 1.0) {
     size_t next = from;
     while (next < cand.size() && (limit < 0 || ts->used < (size_t)limit)) {
       size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - ts->used));
       size_t hi = std::min(cand.size(), next + want);
-      std::vector<std::pair<const RecSet*, size_t>> which; which.reserve(hi - next); for (size_t i = next; i < hi; i++) which.push_back({&batch, cand[i]});
+      std::vector<std::pair<const RecSet*, size_t>> which; which.reserve(hi - next);
+        for (size_t i = next; i < hi; i++) which.push_back({&batch, cand[i]});
       std::vector<uint32_t> nv; sample_round(which, tid, mapped_contig, &nv);
       std::vector<uint8_t> mask(which.size(), 0);
       decide(batch, cand, next, hi, nv.data(), limit, interval_seen, ts, skip, mask.data(), draws, frac);
@@ -304,18 +340,23 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
     struct Iv { uint32_t tid, start, end; };
     std::vector<std::vector<Iv>> groups;  // MultiChromCoordinates in feeder order
     { std::vector<Iv> batch; uint32_t blen = 0;
-      for (auto& c : contigs) for (uint32_t p = c.start; p < c.end();) { uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.sampling_interval_size, c.end());
-          batch.push_back({c.tid, p, e}); blen += e - p; if (blen >= a.sampling_interval_size) { groups.push_back(batch); batch.clear(); blen = 0; } p = e; }
+      for (auto& c : contigs) for (uint32_t p = c.start; p < c.end();) {
+        uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.sampling_interval_size, c.end());
+          batch.push_back({c.tid, p, e}); blen += e - p; if (blen >= a.sampling_interval_size) { groups.push_back(batch); batch.clear(); blen = 0;
+            } p = e; }
       if (!batch.empty()) groups.push_back(batch); }
     for (size_t g0 = 0; g0 < groups.size(); g0 += std::max<size_t>(batch_size, 1)) {
-      std::vector<Iv> all; for (size_t g = g0; g < std::min(groups.size(), g0 + std::max<size_t>(batch_size, 1)); g++) for (auto& iv : groups[g]) all.push_back(iv);
+      std::vector<Iv> all;
+        for (size_t g = g0; g < std::min(groups.size(), g0 + std::max<size_t>(batch_size, 1)); g++) for (auto& iv : groups[g]) all.push_back(iv);
       std::stable_sort(all.begin(), all.end(), [](const Iv& x, const Iv& y) { return x.tid != y.tid ? x.tid < y.tid : x.start < y.start; });
       // accumulate_sample_counts (sampling_schedule.rs:440-615)
       std::map<uint32_t, uint32_t> len_per; for (auto& iv : all) len_per[iv.tid] += iv.end - iv.start;
       std::map<uint32_t, Quota> per_chrom;
-      for (auto& kv : len_per) { auto cs = contig_size.find(kv.first); auto q = quota.find(kv.first); if (cs == contig_size.end() || q == quota.end()) continue;
+      for (auto& kv : len_per) { auto cs = contig_size.find(kv.first); auto q = quota.find(kv.first);
+        if (cs == contig_size.end() || q == quota.end()) continue;
           size_t so_far = sampled_so_far.count(kv.first) ? sampled_so_far[kv.first] : 0; float f = (float)kv.second / (float)cs->second;
-        if (q->second.all) per_chrom[kv.first] = q->second; else if (q->second.n > so_far) { Quota x; x.n = (size_t)ceilf(f * (float)(q->second.n - so_far));
+        if (q->second.all) per_chrom[kv.first] = q->second; else if (q->second.n > so_far) { Quota x;
+          x.n = (size_t)ceilf(f * (float)(q->second.n - so_far));
             per_chrom[kv.first] = x; } }
       struct G { Iv iv; Quota q; }; std::vector<G> grouped; bool have_slack = false; Iv slack{0, 0, 0}; size_t slack_n = 0;
       auto merged = [](const Iv& x, const Iv& y) { return Iv{x.tid, std::min(x.start, y.start), std::max(x.end, y.end)}; };
@@ -324,10 +365,13 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         if (pc->second.all) { grouped.push_back({iv, pc->second}); continue; }
         float f = (float)(iv.end - iv.start) / (float)len_per[iv.tid]; size_t x = (size_t)ceilf((float)pc->second.n * f); Quota qx; qx.n = x;
         if (x < 50) {
-          if (have_slack) { if (slack.tid == iv.tid) { Iv m = merged(slack, iv); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot; } else { Quota q;
-              q.n = tot; grouped.push_back({m, q}); have_slack = false; } } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); slack = iv; slack_n = x; } }
+          if (have_slack) { if (slack.tid == iv.tid) { Iv m = merged(slack, iv); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot;
+              } else { Quota q;
+              q.n = tot; grouped.push_back({m, q}); have_slack = false; } } else { Quota q; q.n = slack_n; grouped.push_back({slack, q}); slack = iv;
+                slack_n = x; } }
           else { have_slack = true; slack = iv; slack_n = x; }
-        } else if (have_slack) { have_slack = false; if (slack.tid == iv.tid) { Quota q; q.n = slack_n + x; grouped.push_back({merged(slack, iv), q}); } else { Quota q;
+        } else if (have_slack) { have_slack = false; if (slack.tid == iv.tid) { Quota q; q.n = slack_n + x; grouped.push_back({merged(slack, iv), q});
+          } else { Quota q;
             q.n = slack_n; grouped.push_back({slack, q}); grouped.push_back({iv, qx}); } }
         else grouped.push_back({iv, qx});
       }
@@ -346,9 +390,11 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         mine.push_back(gi);
       }
       auto cap_of = [&](const G& g) { return g.q.all ? SIZE_MAX : 2 * g.q.n + 128; };
-      auto head_of = [&](size_t gi) { return std::unique_ptr<RecSet>(new RecSet(fetch_set(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, cap_of(grouped[gi])))); };
+      auto head_of = [&](size_t gi) {
+        return std::unique_ptr<RecSet>(new RecSet(fetch_set(grouped[gi].iv.tid, grouped[gi].iv.start, grouped[gi].iv.end, cap_of(grouped[gi])))); };
       auto skip_for = [&](const G& g, const RecSet& batch, const std::vector<size_t>& cand, std::vector<uint8_t>* skip) {
-        skip->assign(cand.size(), 0);   // rank-sharded mode: a read that reaches back into an earlier processed interval of this contig was taken there
+        // rank-sharded mode: a read that reaches back into an earlier processed interval of this contig was taken there
+        skip->assign(cand.size(), 0);
         for (size_t i = 0; i < cand.size(); i++) {
           const int64_t e_pos = batch.pos(cand[i]);
           for (int64_t s1 = g.iv.start; s1 > (int64_t)contig_start[g.iv.tid] && e_pos < s1;) {   // grid intervals before this one, nearest first
@@ -367,14 +413,16 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
         if (!truncated || (limit >= 0 && ts->used >= (size_t)limit)) return;
         const size_t done = head->size();
         head.reset();
-        const RecSet whole = fetch_set(g.iv.tid, g.iv.start, g.iv.end, SIZE_MAX);   // the head was not enough: the whole interval, records already seen skipped
+        // the head was not enough: the whole interval, records already seen skipped
+        const RecSet whole = fetch_set(g.iv.tid, g.iv.start, g.iv.end, SIZE_MAX);
         std::vector<size_t> cand; candidates(whole, &cand);
         std::vector<uint8_t> skip; if (sharded) skip_for(g, whole, cand, &skip);
         size_t from = 0; while (from < cand.size() && cand[from] < done) from++;
         take(whole, cand, from, limit, g.iv.tid, true, seen, ts, sharded ? &skip : nullptr);
       };
       // run_batch (reads_sampler/mod.rs:259-338).  The count-based schedule needs only the head of every interval: the heads of up to
-      // 8 consecutive intervals of one contig (32 when they are scans of a resident shard's digest) are fetched concurrently and decoded in ONE device round; the sampler's first-N logic
+      // 8 consecutive intervals of one contig (32 when they are scans of a resident shard's digest) are fetched concurrently and decoded in ONE
+      // device round; the sampler's first-N logic
       // then runs over them in interval order.  An interval its head does not satisfy is finished sequentially before the
       // following ones are judged (their reads may already be taken by it), and the remaining heads are decoded again.
       struct Pending { size_t gi; std::unique_ptr<RecSet> head; std::vector<size_t> cand; std::vector<uint8_t> skip; size_t n_first = 0; std::set<std::string> seen;
@@ -382,9 +430,12 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       for (size_t mi = 0; mi < mine.size();) {
         const G& g0 = grouped[mine[mi]];
         size_t mj = mi + 1;
-        if (!g0.q.all) while (mj < mine.size() && mj - mi < (resident_mode ? 32u : 8u) && !grouped[mine[mj]].q.all && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;   // (resident: a head is a scan of the digest — more intervals per device round)
+        // (resident: a head is a scan of the digest — more intervals per device round)
+        if (!g0.q.all) while (mj < mine.size() && mj - mi < (resident_mode ? 32u : 8u) && !grouped[mine[mj]].q.all
+            && grouped[mine[mj]].iv.tid == g0.iv.tid) mj++;
         std::vector<std::future<std::unique_ptr<RecSet>>> futs;
-        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(resident_mode ? std::launch::deferred : std::launch::async, head_of, mine[k]));   // (resident: a scan of the digest, no fetch to overlap)
+        // (resident: a scan of the digest, no fetch to overlap)
+        for (size_t k = mi; k < mj; k++) futs.push_back(std::async(resident_mode ? std::launch::deferred : std::launch::async, head_of, mine[k]));
         std::vector<Pending> pend(mj - mi);
         for (size_t k = mi; k < mj; k++) {
           Pending& P = pend[k - mi]; P.gi = mine[k];
@@ -393,7 +444,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
           const G& g = grouped[P.gi];
           P.n_first = g.q.all ? 0 : std::min(P.cand.size(), std::max<size_t>(256, 2 * g.q.n));
         }
-        if (g0.q.all) { finish_interval(g0, pend[0].head, pend[0].cand, 0, pend[0].skip, &pend[0].seen, &pend[0].ts); batch_counts[g0.iv.tid] += pend[0].ts.n_reads_out;
+        if (g0.q.all) { finish_interval(g0, pend[0].head, pend[0].cand, 0, pend[0].skip, &pend[0].seen, &pend[0].ts);
+          batch_counts[g0.iv.tid] += pend[0].ts.n_reads_out;
             mi = mj; continue; }
         for (size_t k0 = 0; k0 < pend.size();) {
           std::vector<std::pair<const RecSet*, size_t>> recs; std::vector<size_t> at(pend.size() + 1, 0);
@@ -428,7 +480,8 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
       for (auto& kv : batch_counts) sampled_so_far[kv.first] += kv.second;
     }
   }
-  if ((sched_unmapped || taken.size() < 100) && !only_mapped && a.rank == 0) {  // reads_sampler/mod.rs:89-125 (rank-sharded: rank 0 takes the unmapped reads)
+  // reads_sampler/mod.rs:89-125 (rank-sharded: rank 0 takes the unmapped reads)
+  if ((sched_unmapped || taken.size() < 100) && !only_mapped && a.rank == 0) {
     RecSet batch; batch.b.reset(new BamBatch()); bam.fetch_unmapped(batch.b.get());
     std::vector<size_t> cand; candidates(batch, &cand);
     long limit;
@@ -474,11 +527,13 @@ void sample_resident_full(mkp_ctx* ctx, const BamSource& bam, const BedFilter* b
     g_sample_times.fetch_ms += ms_since(t_f);
     if (!S || (int32_t)fs.tid != S->tid) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
     const size_t n = S->hdr.size(), n_so = S->so_hdr.size();
-    auto owned = [&](const MkpReadHdr& h) { const int64_t pos = h.ref_start, end = std::max(h.ref_end, h.ref_start + 1); return pos >= fs.own_from && pos < fs.ext_hi && end > fs.ext_lo; };
+    auto owned = [&](const MkpReadHdr& h) { const int64_t pos = h.ref_start, end = std::max(h.ref_end, h.ref_start + 1);
+      return pos >= fs.own_from && pos < fs.ext_hi && end > fs.ext_lo; };
     std::vector<uint32_t> ids; ids.reserve(n + n_so);
     for (size_t i = 0; i < n; i++) if (owned(S->hdr[i])) ids.push_back((uint32_t)i);
     { bool any_so = false; for (size_t k = 0; k < n_so; k++) if (owned(S->so_hdr[k])) { ids.push_back((uint32_t)(n + k)); any_so = true; }
-      if (any_so) { auto wi = [&](uint32_t k) { return k < n ? S->dev_win_idx[k] : S->so_win_idx[k - n]; }; std::stable_sort(ids.begin(), ids.end(), [&](uint32_t x, uint32_t y) { return wi(x) < wi(y); }); } }
+      if (any_so) { auto wi = [&](uint32_t k) { return k < n ? S->dev_win_idx[k] : S->so_win_idx[k - n]; };
+        std::stable_sort(ids.begin(), ids.end(), [&](uint32_t x, uint32_t y) { return wi(x) < wi(y); }); } }
     const uint8_t* mask = bedmask_for(fs.tid);
     for (size_t at = 0; at < ids.size();) {
       const size_t hi = std::min(ids.size(), at + ((size_t)1 << 18));
@@ -491,7 +546,8 @@ void sample_resident_full(mkp_ctx* ctx, const BamSource& bam, const BedFilter* b
       std::vector<uint8_t> take(hi - at, 0);
       for (size_t i = at; i < hi; i++) {
         if (nv[i - at] == 0) continue;   // a read that keeps no position is asked, not counted and not recorded
-        const uint32_t k = ids[i]; NameKey key{k < n ? S->name_hash[k] : S->so_name_hash[k - n], k < n ? S->dev_name_hash2[k] : S->so_name_hash2[k - n]};
+        const uint32_t k = ids[i];
+          NameKey key{k < n ? S->name_hash[k] : S->so_name_hash[k - n], k < n ? S->dev_name_hash2[k] : S->so_name_hash2[k - n]};
         if (taken.insert(key).second) take[i - at] = 1;
       }
       g_sample_times.decide_ms += ms_since(t_h);
@@ -517,10 +573,14 @@ void thresholds_from_sample(mkp_ctx* ctx, float q, float thr[4], uint8_t has[4],
     float y[2];
     for (int k = 0; k < 2; k++) {
       if (k == 1 && bins[1] == bins[0] && rk[1] == rk[0]) { y[1] = y[0]; break; }
-      if (k == 0 || bins[1] != bins[0]) { rc = mkp_histogram_get(ctx, b, 1, bins[k], h1.data()); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx)); }
-      rc = mkp_histogram_resolve(bins[k], h1.data(), rk[k], &y[k]); if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "internal: histogram levels disagree");
+      if (k == 0 || bins[1] != bins[0]) { rc = mkp_histogram_get(ctx, b, 1, bins[k], h1.data());
+        if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+        }
+      rc = mkp_histogram_resolve(bins[k], h1.data(), rk[k], &y[k]);
+        if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "internal: histogram levels disagree");
     }
-    float t; rc = mkp_percentile_from_histogram(n, q, y[0], y[1], &t); if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(n));
+    float t; rc = mkp_percentile_from_histogram(n, q, y[0], y[1], &t);
+      if (rc != MKP_OK) throw Error(MKP_E_THRESHOLD, "not enough datapoints, got " + std::to_string(n));
     thr[b] = t; has[b] = 1;
     if (verbose) fprintf(stderr, "[mkpileup] threshold %c %.9g (n=%llu)\n", "ACGT"[b], (double)t, (unsigned long long)n);
   }
@@ -568,13 +628,16 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
   std::vector<Contig> records = targets(bam, have_region ? &region : nullptr);
   BedFilter bed_store; const BedFilter* bf = nullptr;
-  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t);
+  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid;
+    bed_store = BedFilter::load(a.include_bed, c2t);
       bf = &bed_store; }
   if (idxstats(bam, have_region ? &region : nullptr, bf).mapped == 0) throw Error(MKP_E_INVALID,
       "did not find any mapped reads, perform alignment first or use modkit extract and/or modkit summary to inspect unaligned modBAMs");
   if (a.filter_percentile > 1.0f) throw Error(MKP_E_INVALID, "filter percentile must be <= 1.0");
-  if (a.combine_strands && !(a.cpg || !a.motif_parts.empty())) throw Error(MKP_E_INVALID, "need to specify either --motif or --cpg to combine strands");
-  if (a.hemi) {  // subcommand.rs:1247-1276: one motif, --cpg or --motif (a clap argument group: not both), palindromic; the reference FASTA is required
+  if (a.combine_strands && !(a.cpg || !a.motif_parts.empty())) throw Error(MKP_E_INVALID,
+      "need to specify either --motif or --cpg to combine strands");
+  // subcommand.rs:1247-1276: one motif, --cpg or --motif (a clap argument group: not both), palindromic; the reference FASTA is required
+  if (a.hemi) {
     if (!a.cpg && a.motif_parts.empty()) throw Error(MKP_E_INVALID, "either --cpg or a --motif must be provided for pileup-hemi");
     if (a.cpg && !a.motif_parts.empty()) throw Error(MKP_E_INVALID, "the argument '--cpg' cannot be used with '--motif'");
     if (a.motif_parts.size() > 2) throw Error(MKP_E_INVALID, "motif arg should be length 2, eg. CG 0");
@@ -584,7 +647,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; combine_strands = true; }
   else if (!a.preset.empty()) throw Error(MKP_E_INVALID, "unknown preset " + a.preset);
   else if (a.combine_mods) kc.numeric_mode = 1;
-  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2;
+  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore);
+    kc.numeric_mode = 2;
       kc.collapse_code = code; }
   kc.combine_strands = combine_strands;
   if (a.hemi) combine_strands = true;
@@ -595,7 +659,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (!a.motif_parts.empty()) {  // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
     if (!a.preset.empty()) throw Error(MKP_E_INVALID, "cannot use presets and motifs together");
     std::vector<std::string> parts = a.motif_parts;
-    for (size_t i = 0; i + 1 < parts.size(); i += 2) for (size_t j = i + 2; j + 1 < parts.size(); j += 2) if (parts[i] == parts[j] && parts[i + 1] == parts[j + 1]) throw Error(MKP_E_INVALID,
+    for (size_t i = 0; i + 1 < parts.size(); i += 2) for (size_t j = i + 2; j + 1 < parts.size(); j += 2) if (parts[i] == parts[j]
+        && parts[i + 1] == parts[j + 1]) throw Error(MKP_E_INVALID,
         "cannot have the same motif more than once");
     if (a.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true;
         if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
@@ -606,7 +671,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (a.ref_fasta.empty()) throw Error(MKP_E_INVALID, "reference fasta is required for using --motif or --cpg options");
     if (combine_strands) for (auto& m : fb.motifs) if (!m.palindrome) throw Error(MKP_E_INVALID,
         a.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
-    fasta_load = std::async(std::launch::async, [&]() { return Fasta::load(a.ref_fasta); });   // joined where the grid walk needs it: the device ingest of the first shard starts meanwhile
+    // joined where the grid walk needs it: the device ingest of the first shard starts meanwhile
+    fasta_load = std::async(std::launch::async, [&]() { return Fasta::load(a.ref_fasta); });
   }
   mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = a.device; cfg.tile_positions = a.tile;
   mkp_ctx* ctx = ext_ctx;
@@ -616,7 +682,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   auto must = [&](int r) { if (r != MKP_OK) throw Error(r, mkp_last_error(ctx)); };
   // --device-inflate (or MKP_DEVICE_INFLATE=1): the shard windows' BGZF blocks are inflated on the GPU; destroyed after the last fetch (declared
   // before everything that fetches, so it outlives the prefetch threads on every path out of here)
-  struct InflaterGuard { mkp_dev_inflater* d = nullptr; BamSource* src = nullptr; ~InflaterGuard() { if (src) { src->dev_inflate = nullptr; src->dev_inflate_user = nullptr; } mkp_internal_inflater_destroy(d); } } inflater;
+  struct InflaterGuard { mkp_dev_inflater* d = nullptr; BamSource* src = nullptr; ~InflaterGuard() { if (src) { src->dev_inflate = nullptr;
+        src->dev_inflate_user = nullptr; } mkp_internal_inflater_destroy(d); } } inflater;
   if ((a.device_inflate || (getenv("MKP_DEVICE_INFLATE") && !strcmp(getenv("MKP_DEVICE_INFLATE"), "1"))) && !a.plan_only && bam.indexed()) {
     inflater.d = mkp_internal_inflater_create(a.device);
     if (!inflater.d) throw Error(MKP_E_DEVICE, "--device-inflate: cannot create a stream on the device");
@@ -636,7 +703,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // 2^27 positions per shard keeps the per-shard focus / slot buffers small
   // BAM bytes per shard: the device ingest's inflate pays a fixed latency per launch and HBM holds the window many times over — 1 GiB of
   // compressed blocks at a time; the host path keeps 256 MiB (its inflated window lives in host memory)
-  const bool dev_ingest_plan = !a.no_index && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !a.device_inflate && !(getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1"));
+  const bool dev_ingest_plan = !a.no_index && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !a.device_inflate
+      && !(getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1"));
   const uint64_t shard_bytes = (a.shard_bytes_set || !dev_ingest_plan) ? a.shard_bytes : (1ull << 30);
   auto shard_cut = [&](const Contig& rec, const std::vector<Interval>& ivs, size_t i0, uint64_t* bp_out) {   // -> one past the shard's last interval
     size_t i1 = i0; uint64_t bp = 0; const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
@@ -650,14 +718,17 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   struct ShardInput { std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev; };
   const bool host_ingest_env = getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1");
   const bool dev_ingest = bam.indexed() && !a.plan_only && !a.host_ingest && a.partition_tags.empty() && !inflater.d && !host_ingest_env;
-  if (dev_ingest && !ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
+  if (dev_ingest && !ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device);
+    if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device");
+    }
   double ingest_ms[5] = {0, 0, 0, 0, 0}, ingest_kernel_ms = 0; uint64_t ingest_blocks = 0, ingest_records = 0, ingest_comp = 0, ingest_raw = 0;
   // the records of a shard: those overlapping any of its windows (one window, or the BED spans of a merged shard), each +- the halo
   auto fetch_windows = [&](uint32_t tid, const std::vector<std::pair<uint32_t, uint32_t>>& wins, mkp_dev_ingest* ing = nullptr) {
     ShardInput in; FetchParts parts;
     for (auto& w : wins) { const int64_t lo = w.first > MKP_HALO ? (int64_t)w.first - MKP_HALO : 0, hi = (int64_t)w.second + MKP_HALO;
       if (!parts.empty() && lo <= parts.back().second) parts.back().second = std::max(parts.back().second, hi); else parts.push_back({lo, hi}); }
-    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ing ? ing : ctx->ingest, bam, tid, parts); return in; }   // foreground: the upload feeds the GPU's longest job of the run
+    // foreground: the upload feeds the GPU's longest job of the run
+    if (dev_ingest) { in.dev = mkp_internal_ingest_run(ing ? ing : ctx->ingest, bam, tid, parts); return in; }
     HostPool::background() = true; in.batch.reset(new BamBatch()); bam.fetch_parts(tid, parts, in.batch.get()); return in; };
   auto fetch_range = [&](uint32_t tid, uint32_t s0, uint32_t s1) { return fetch_windows(tid, {{s0, s1}}); };
   // compressed bytes a set of fetch windows stands for (the index's 16 kb granularity: a short window costs at least its blocks)
@@ -682,22 +753,26 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // other on a worker thread, and stay packed in HBM (288 GB hold a 30x genome's packed reads) — the threshold estimate then samples from
   // them (every contig's interval heads are scans of a digest, no second read of the file), and the pileup pass finds its shards already
   // there.  Budget: the compressed bytes under the shards; beyond it the shards are fetched as the loop reaches them (host sampler).
-  struct Ahead { size_t rec0 = 0, rec1 = 0; uint32_t tid = 0, s0 = 0, s1 = 0; std::vector<std::pair<uint32_t, uint32_t>> wins; ShardInput in; bool ready = false; std::exception_ptr err; uint64_t bytes = 0, est = 0; };
+  struct Ahead { size_t rec0 = 0, rec1 = 0; uint32_t tid = 0, s0 = 0, s1 = 0; std::vector<std::pair<uint32_t,
+      uint32_t>> wins; ShardInput in; bool ready = false; std::exception_ptr err; uint64_t bytes = 0, est = 0; };
   // Several shards are in flight at once, each on an ingest object of its own (its streams, staging and scratch): one shard's inflate is a
   // launch that fills a fraction of the chip for most of its time, and its host half (pread into staging) leaves the GPU idle —
   // shards side by side fill both.  What they may hold is bounded by an HBM BUDGET (round 5; round 4 had an all-or-nothing 24 GiB gate on
   // the compressed size): a shard is admitted — in plan order — while the estimated bytes of the admitted, not yet consumed shards fit the
   // budget (one shard is always admitted), and the shard loop gives a shard's bytes back when it is through with it.  A run whose shards
   // fit together keeps them all (and may sample its threshold estimate from them); a larger one streams.
-  std::vector<Ahead> ahead; std::mutex amu; std::condition_variable acv; std::vector<std::thread> aworkers; std::atomic<bool> astop{false}; std::atomic<size_t> anext{0};
+  std::vector<Ahead> ahead; std::mutex amu; std::condition_variable acv; std::vector<std::thread> aworkers; std::atomic<bool> astop{false};
+    std::atomic<size_t> anext{0};
   size_t admit_next = 0; uint64_t hbm_used = 0, hbm_budget = 0, ahead_est_total = 0;   // (under amu)
   std::vector<mkp_dev_ingest*> aingest;
   struct FreeIngest { std::vector<mkp_dev_ingest*>* v; ~FreeIngest() { for (auto* d : *v) mkp_internal_ingest_destroy(d); } } free_ingest{&aingest};
-  struct JoinAhead { std::vector<std::thread>* t; std::atomic<bool>* stop; std::condition_variable* cv; ~JoinAhead() { stop->store(true); cv->notify_all(); for (auto& x : *t) if (x.joinable()) x.join(); } } join_ahead{&aworkers, &astop, &acv};
+  struct JoinAhead { std::vector<std::thread>* t; std::atomic<bool>* stop; std::condition_variable* cv; ~JoinAhead() { stop->store(true);
+      cv->notify_all(); for (auto& x : *t) if (x.joinable()) x.join(); } } join_ahead{&aworkers, &astop, &acv};
   if (dev_ingest) {
     uint64_t mb = a.hbm_budget_mb; if (const char* e = getenv("MKP_HBM_BUDGET_MB")) mb = strtoull(e, nullptr, 10);
     if (mb) hbm_budget = mb << 20;
-    else { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) tot = (size_t)64 << 30; hbm_budget = (uint64_t)((double)tot * 0.55); }
+    else { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) tot = (size_t)64 << 30;
+      hbm_budget = (uint64_t)((double)tot * 0.55); }
   }
   // packed arrays of a shard ~ 1.9 x its compressed blocks on ONT-like data (SEQ nibbles + CIGAR words + 5 bytes per call; names and
   // qualities are not kept), the inflated window of the ingest object in flight on top: 2.5 x as the estimate
@@ -727,18 +802,25 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
     });
   };
-  auto ahead_release = [&](size_t k) { { std::lock_guard<std::mutex> g(amu); hbm_used -= std::min(hbm_used, ahead[k].est); } acv.notify_all(); };   // the shard loop is through with shard k
+  // the shard loop is through with shard k
+  auto ahead_release = [&](size_t k) { { std::lock_guard<std::mutex> g(amu); hbm_used -= std::min(hbm_used, ahead[k].est); } acv.notify_all(); };
   // the fetch windows of a shard made of BED records [r0, r1) of one contig: the BED spans inside them (rows exist at BED positions only,
   // so only records reaching a span matter), not the records, which run from one span to the next
   auto bed_windows = [&](size_t r0, size_t r1) {
     std::vector<std::pair<uint32_t, uint32_t>> w; const uint32_t tid = records[r0].tid; std::vector<Span> sp;
     for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
-      for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, records[r0].start), hi = std::min<uint64_t>(x.e, records[r1 - 1].end()); if (lo < hi) sp.push_back({lo, hi}); } }
+      for (auto& x : it->second) {
+        const uint64_t lo = std::max<uint64_t>(x.s, records[r0].start), hi = std::min<uint64_t>(x.e, records[r1 - 1].end());
+        if (lo < hi) sp.push_back({lo, hi});
+        } }
     merge_spans(sp);
     // keep what lies inside the records (sorted, disjoint): one sweep
     { std::vector<Span> in; size_t r = r0;
       for (auto& x : sp) { while (r < r1 && records[r].end() <= x.s) r++;
-        for (size_t q = r; q < r1 && records[q].start < x.e; q++) { const uint64_t lo = std::max<uint64_t>(x.s, records[q].start), hi = std::min<uint64_t>(x.e, records[q].end()); if (lo < hi) in.push_back({lo, hi}); } }
+        for (size_t q = r; q < r1 && records[q].start < x.e; q++) {
+          const uint64_t lo = std::max<uint64_t>(x.s, records[q].start), hi = std::min<uint64_t>(x.e, records[q].end());
+          if (lo < hi) in.push_back({lo, hi});
+          } }
       sp.swap(in); merge_spans(sp); } for (auto& x : sp) w.push_back({(uint32_t)x.s, (uint32_t)x.e});
     return w;
   };
@@ -749,14 +831,16 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       Ahead A; A.rec0 = r0; A.rec1 = r1; A.tid = records[r0].tid; A.s0 = records[r0].start; A.s1 = records[r1 - 1].end();
       if (bf) A.wins = bed_windows(r0, r1); else A.wins.push_back({A.s0, A.s1});
       A.bytes = bf ? win_bytes(A.tid, A.wins) : bam.offset_at(A.tid, A.s1) - bam.offset_at(A.tid, A.s0);
-      if ((uint64_t)A.s1 - A.s0 > shard_bp || A.bytes > shard_bytes || (bf && r1 - r0 > 65536) || records[r0].length == 0 || A.wins.empty()) fits = false;
+      if ((uint64_t)A.s1 - A.s0 > shard_bp || A.bytes > shard_bytes || (bf && r1 - r0 > 65536) || records[r0].length == 0
+          || A.wins.empty()) fits = false;
       total += A.bytes; ahead.push_back(std::move(A)); r0 = r1;
     }
     (void)total;
     if (!fits) ahead.clear();   // a contig larger than a shard: the shards are cut on the grid and ingested ahead once the plan is known (below)
     start_ahead();
   }
-  auto ahead_wait = [&](size_t k) -> Ahead& { std::unique_lock<std::mutex> lk(amu); acv.wait(lk, [&] { return ahead[k].ready; }); if (ahead[k].err) std::rethrow_exception(ahead[k].err); return ahead[k]; };
+  auto ahead_wait = [&](size_t k) -> Ahead& { std::unique_lock<std::mutex> lk(amu); acv.wait(lk,
+      [&] { return ahead[k].ready; }); if (ahead[k].err) std::rethrow_exception(ahead[k].err); return ahead[k]; };
   if (fasta_load.valid()) { fasta = fasta_load.get(); fb.fasta = &fasta; mark("reference FASTA loaded"); }
   std::future<void> early_walk;
   if (fb.has_focus() && a.world == 1 && !a.plan_only && a.filter_threshold.empty() && !a.no_filtering)
@@ -764,7 +848,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       auto t_focus = std::chrono::steady_clock::now();
       for (size_t ri = 0; ri < records.size(); ri++) {
         grid_of[ri] = fb.walk(records[ri], a.interval_size, &focus_of[ri]); grid_done[ri] = 1; focus_done[ri] = 1;
-        if (ri == 0 && !early_whole && !bf && ahead.empty() && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {   // (--include-bed: the first shard is a merge of records, known only with the plan)
+        // (--include-bed: the first shard is a merge of records, known only with the plan)
+        if (ri == 0 && !early_whole && !bf && ahead.empty() && !grid_of[0].empty() && !getenv("MKP_NO_EARLY_FETCH")) {
           uint64_t bp; const size_t i1 = shard_cut(records[0], grid_of[0], 0, &bp);
           early_s0 = grid_of[0][0].start; early_s1 = grid_of[0][i1 - 1].end; early_set = true;
           early_fetch = std::async(std::launch::async, fetch_range, records[0].tid, early_s0, early_s1);
@@ -779,7 +864,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   struct ShardPart { size_t rec; uint32_t s0, s1; };
   struct ShardPlan { size_t rec; uint32_t s0, s1; uint64_t bp; std::vector<uint32_t> iv_starts; /* pileup-hemi: starts of the shard's intervals */
                      std::vector<ShardPart> parts; /* --include-bed: the BED-span records merged into this shard (empty: one window) */
-                     int64_t own_from = INT64_MIN; /* full-data sampling from the shards: reads starting before this position lie in the previous shard of the contig too, and are sampled there */ };
+                     int64_t own_from = INT64_MIN;
+                       /* full-data sampling from the shards: reads starting before this position lie in the previous shard of the contig too, and are sampled there */ };
   std::vector<ShardPlan> plan;
   // what every rank's shards would hold in HBM if they were all ingested ahead (est_of of each shard's bytes under the index), computed by
   // every rank for every rank: the one thing a rank of a multi-GPU run may base a choice on that the other ranks must make the same way
@@ -795,10 +881,13 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       const uint64_t off_lo = records.empty() ? 0 : bam.offset_at(records.front().tid,
           records.front().start), off_hi = records.empty() ? 0 : bam.offset_at(records.back().tid, records.back().end());
       bool have_prev = false; uint32_t prev_tid = 0; int64_t prev_fetch_hi = 0;   // the shard before, over ALL ranks' shards: where its fetch ends
-      auto last_window_end = [&](uint32_t tid, uint32_t w0, uint32_t w1) -> int64_t {   // end of the last fetch window of a shard [w0, w1) (plan_windows below, before the halo)
+      // end of the last fetch window of a shard [w0, w1) (plan_windows below, before the halo)
+      auto last_window_end = [&](uint32_t tid, uint32_t w0, uint32_t w1) -> int64_t {
         if (!bf) return w1;
         uint64_t last = 0; for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
-          for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, w0), hi = std::min<uint64_t>(x.e, w1); if (lo < hi) last = std::max(last, hi); } }
+          for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, w0), hi = std::min<uint64_t>(x.e, w1);
+            if (lo < hi) last = std::max(last, hi);
+            } }
         return last ? (int64_t)last : (int64_t)w0 + 1;
       };
       for (size_t ri = 0; ri < records.size(); ri++) {
@@ -814,8 +903,10 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           uint64_t bp = 0; const size_t i1 = shard_cut(rec, ivs, i0, &bp); const uint64_t o0 = bam.offset_at(rec.tid, ivs[i0].start);
           const uint32_t s0 = ivs[i0].start, s1 = ivs[i1 - 1].end;
           const uint64_t mid = (o0 + bam.offset_at(rec.tid, s1)) / 2;
-          const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1, (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
-          std::vector<uint32_t> iv_starts; for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);   // the shard's intervals (pileup-hemi: per-interval NoCalls; always: the duplicate-name rule)
+          const uint32_t owner = off_hi > off_lo ? (uint32_t)std::min<uint64_t>(a.world - 1,
+              (mid > off_lo ? mid - off_lo : 0) * a.world / (off_hi - off_lo)) : 0;
+          // the shard's intervals (pileup-hemi: per-interval NoCalls; always: the duplicate-name rule)
+          std::vector<uint32_t> iv_starts; for (size_t k = i0; k < i1; k++) iv_starts.push_back(ivs[k].start);
           i0 = i1;
           const int64_t own_from = have_prev && prev_tid == rec.tid ? prev_fetch_hi : INT64_MIN;
           have_prev = true; prev_tid = rec.tid; prev_fetch_hi = last_window_end(rec.tid, s0, s1) + MKP_HALO;
@@ -833,10 +924,13 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       for (auto& sp : plan) {
         const uint32_t tid = records[sp.rec].tid;
         const uint64_t sp_bytes = bam.indexed() ? bam.offset_at(tid, sp.s1) - bam.offset_at(tid, sp.s0) + (1u << 16) : 0;
-        const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1 && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp && (bytes + sp_bytes <= shard_bytes || !ahead.empty() /* its spans were sized when it was ingested ahead */) &&
+        const bool join = !merged.empty() && records[merged.back().rec].tid == tid && sp.s0 >= merged.back().s1
+            && (uint64_t)sp.s1 - merged.back().s0 <= shard_bp
+            && (bytes + sp_bytes <= shard_bytes || !ahead.empty() /* its spans were sized when it was ingested ahead */) &&
                           merged.back().parts.size() < 65536;
         if (!join) { ShardPlan m = sp; m.parts.assign(1, {sp.rec, sp.s0, sp.s1}); merged.push_back(std::move(m)); bytes = sp_bytes; continue; }
-        ShardPlan& m = merged.back(); m.s1 = sp.s1; m.bp += sp.bp; m.iv_starts.insert(m.iv_starts.end(), sp.iv_starts.begin(), sp.iv_starts.end()); m.parts.push_back({sp.rec, sp.s0, sp.s1}); bytes += sp_bytes;
+        ShardPlan& m = merged.back(); m.s1 = sp.s1; m.bp += sp.bp; m.iv_starts.insert(m.iv_starts.end(), sp.iv_starts.begin(), sp.iv_starts.end());
+          m.parts.push_back({sp.rec, sp.s0, sp.s1}); bytes += sp_bytes;
       }
       for (auto& m : merged) if (m.parts.size() == 1) m.parts.clear();
       plan.swap(merged);
@@ -850,7 +944,9 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     if (!bf) { w.push_back({sp.s0, sp.s1}); return w; }
     const uint32_t tid = records[sp.rec].tid; std::vector<Span> spn;
     auto clip = [&](uint32_t a0, uint32_t a1) { for (auto* m : {&bf->pos, &bf->neg}) { auto it = m->find(tid); if (it == m->end()) continue;
-        for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, a0), hi = std::min<uint64_t>(x.e, a1); if (lo < hi) spn.push_back({lo, hi}); } } };
+        for (auto& x : it->second) { const uint64_t lo = std::max<uint64_t>(x.s, a0), hi = std::min<uint64_t>(x.e, a1);
+          if (lo < hi) spn.push_back({lo, hi});
+          } } };
     if (sp.parts.empty()) clip(sp.s0, sp.s1); else for (auto& pt : sp.parts) clip(pt.s0, pt.s1);
     merge_spans(spn); for (auto& x : spn) w.push_back({(uint32_t)x.s, (uint32_t)x.e});
     if (w.empty()) w.push_back({sp.s0, sp.s0 + 1});   // (no BED position inside: nothing to fetch but an empty window)
@@ -861,14 +957,16 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // workers, same budget as the contig list above
   auto ahead_from_plan = [&]() {
     if (!dev_ingest || !ahead.empty() || plan.empty()) return;
-    for (auto& sp : plan) { Ahead A; A.rec0 = sp.rec; A.rec1 = sp.rec + 1; A.tid = records[sp.rec].tid; A.s0 = sp.s0; A.s1 = sp.s1; A.wins = plan_windows(sp);
+    for (auto& sp : plan) { Ahead A; A.rec0 = sp.rec; A.rec1 = sp.rec + 1; A.tid = records[sp.rec].tid; A.s0 = sp.s0; A.s1 = sp.s1;
+      A.wins = plan_windows(sp);
       A.bytes = bf ? win_bytes(A.tid, A.wins) : bam.offset_at(A.tid, A.s1) - bam.offset_at(A.tid, A.s0) + (1u << 16); ahead.push_back(std::move(A)); }
     start_ahead();
   };
   // thresholds (subcommand.rs:615-638)
   kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
   double thr_ms = 0, fetch_wait_early_ms = 0, grid_wait_ms = 0, callback_ms = 0;
-  ShardInput early_in; bool early_in_ready = false, pre_attached = false; std::unique_ptr<DevShard> pre_dev;   // the first shard's records, taken before the loop
+  // the first shard's records, taken before the loop
+  ShardInput early_in; bool early_in_ready = false, pre_attached = false; std::unique_ptr<DevShard> pre_dev;
   const bool full_mode = a.have_frac && a.sampling_frac >= 1.0;
   const bool want_estimate = a.filter_threshold.empty() && !a.no_filtering && !a.plan_only;
   const bool resident_ok = !have_sregion && !a.include_unmapped && !getenv("MKP_NO_RESIDENT_SAMPLING");
@@ -877,7 +975,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   // The plan comes before the thresholds — and its shards go ahead — when nothing is gained by waiting for them: several ranks (a rank needs
   // its own shards whatever the thresholds turn out to be, and the others' estimate or all-reduce is time to ingest in), thresholds given,
   // or a full-data estimate, which samples from the shards themselves.
-  if (dev_ingest && !early_whole && ahead.empty() && !getenv("MKP_NO_AHEAD") && (a.world > 1 || !want_estimate || (full_mode && resident_ok))) { build_plan(); ahead_from_plan(); }
+  if (dev_ingest && !early_whole && ahead.empty() && !getenv("MKP_NO_AHEAD") && (a.world > 1 || !want_estimate || (full_mode && resident_ok))) {
+    build_plan(); ahead_from_plan(); }
   if (!a.filter_threshold.empty()) parse_base_thresholds(a.filter_threshold, &kc);
   else if (a.no_filtering || a.plan_only) { kc.n_per_mod = 0; }  // MultipleThresholdModCaller::new_passthrough
   else {
@@ -899,12 +998,15 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     // instead of fetching, inflating and packing interval heads on the host next to the ingest.
     const ShardHost* resident = nullptr;
     if (early_whole && !have_sregion && !a.include_unmapped && !getenv("MKP_NO_RESIDENT_SAMPLING")) {
-      bool only_this = true; { const IdxStats stx = idxstats(bam, sr, bf); for (auto& kv : stx.mapped_by_tid) if (kv.second && kv.first != (int64_t)records[0].tid) only_this = false; }
+      bool only_this = true; { const IdxStats stx = idxstats(bam, sr, bf);
+        for (auto& kv : stx.mapped_by_tid) if (kv.second && kv.first != (int64_t)records[0].tid) only_this = false;
+        }
       if (only_this) {
         mark("resident sampling: waiting for the grid");
         auto t_gw = std::chrono::steady_clock::now();
         if (early_walk.valid()) early_walk.get();
-        else if (!grid_done[0]) { auto t_focus = std::chrono::steady_clock::now(); grid_of[0] = fb.walk(records[0], a.interval_size, fb.has_focus() ? &focus_of[0] : nullptr); grid_done[0] = 1;
+        else if (!grid_done[0]) { auto t_focus = std::chrono::steady_clock::now();
+          grid_of[0] = fb.walk(records[0], a.interval_size, fb.has_focus() ? &focus_of[0] : nullptr); grid_done[0] = 1;
           if (fb.has_focus()) focus_done[0] = 1; focus_ms += ms_since(t_focus); }
         grid_wait_ms += ms_since(t_gw);
         const std::vector<Interval>& ivs = grid_of[0]; uint64_t bp = 0;
@@ -912,9 +1014,11 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
           // the shard is begun and everything of its plan that needs the window alone (slot bitmap, slot positions, their uploads) is
           // made now, while the ingest is still running
           mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)records[0].tid; sh.start = early_s0; sh.end = early_s1;
-          if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+          if (fb.has_focus()) { sh.focus = focus_of[0].data() + (early_s0 - records[0].start); sh.combos = fb.combos.data();
+            sh.n_combos = (uint32_t)fb.combos.size(); }
           must(mkp_shard_begin(ctx, &sh));
-          { std::vector<uint32_t> st; st.reserve(ivs.size()); for (auto& iv : ivs) st.push_back(iv.start); must(mkp_shard_set_intervals(ctx, st.data(), (uint32_t)st.size())); }
+          { std::vector<uint32_t> st; st.reserve(ivs.size()); for (auto& iv : ivs) st.push_back(iv.start);
+            must(mkp_shard_set_intervals(ctx, st.data(), (uint32_t)st.size())); }
           if (fb.has_focus() && !a.hemi) must(mkp_internal_shard_preplan(ctx));
           auto t_w = std::chrono::steady_clock::now();
           mark("resident sampling: waiting for the ingest");
@@ -938,12 +1042,15 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       Ahead& A = ahead_wait(k);
       fetch_wait_early_ms += ms_since(t_w);
       if (!A.in.dev) throw Error(MKP_E_INVALID, "internal: shard ingested ahead without device records");
-      if (bound != A.in.dev.get()) { if (bound) must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; must(mkp_internal_sample_bind(ctx, A.in.dev.get())); bound = A.in.dev.get(); }
+      if (bound != A.in.dev.get()) { if (bound) must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr;
+        must(mkp_internal_sample_bind(ctx, A.in.dev.get())); bound = A.in.dev.get(); }
       return &ctx->shard;
     };
-    const bool ahead_fits = !ahead.empty() && ahead_est_total <= hbm_budget;   // every shard stays in HBM until the loop takes it: the sample can come from them
+    // every shard stays in HBM until the loop takes it: the sample can come from them
+    const bool ahead_fits = !ahead.empty() && ahead_est_total <= hbm_budget;
     // the extent the sampler covers on a contig: the region, or all of it
-    auto ext_of = [&](uint32_t tid, int64_t* lo, int64_t* hi) { if (have_region) { *lo = region.start; *hi = region.end; } else { *lo = 0; *hi = bam.ref_lens[tid]; } };
+    auto ext_of = [&](uint32_t tid, int64_t* lo, int64_t* hi) { if (have_region) { *lo = region.start; *hi = region.end; } else { *lo = 0;
+        *hi = bam.ref_lens[tid]; } };
     // Several ranks in the full-data mode (mkp_pileup_run_cb): the ranks' samples are summed by the caller, so every rank must cut the reads the
     // same way — by shard ownership (own_from) when the shards are the source, by sampling intervals when the host reader is.  The two cuts do
     // not coincide, so the choice is one every rank arrives at alike without talking: the shards are the source iff EVERY rank's shards fit
@@ -957,19 +1064,25 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       // full-data mode: the shards themselves are the sample's source, whatever their cut — with several ranks (mkp_pileup_run_cb) each
       // rank its own, the caller sums the histograms
       std::vector<FullShard> fs;
-      if (resident) { FullShard f; f.tid = records[0].tid; f.own_from = INT64_MIN; ext_of(f.tid, &f.ext_lo, &f.ext_hi); f.bind = [&]() { return resident; }; fs.push_back(std::move(f)); }
-      else for (size_t k = 0; k < ahead.size(); k++) { FullShard f; f.tid = ahead[k].tid; f.own_from = ahead_whole_contigs ? INT64_MIN : plan[k].own_from; ext_of(f.tid, &f.ext_lo, &f.ext_hi);
+      if (resident) { FullShard f; f.tid = records[0].tid; f.own_from = INT64_MIN; ext_of(f.tid, &f.ext_lo, &f.ext_hi); f.bind = [&]() {
+          return resident; }; fs.push_back(std::move(f)); }
+      else for (size_t k = 0; k < ahead.size(); k++) { FullShard f; f.tid = ahead[k].tid;
+        f.own_from = ahead_whole_contigs ? INT64_MIN : plan[k].own_from; ext_of(f.tid, &f.ext_lo, &f.ext_hi);
           f.bind = [&, k]() { return bind_ahead(k); }; fs.push_back(std::move(f)); }
       sample_resident_full(ctx, bam, bf, fs);
       resident_used = true;
-      if (a.stats) fprintf(stderr, "[mkpileup] full-data threshold sample taken from %zu resident shard(s)%s\n", fs.size(), a.world > 1 ? " of this rank" : "");
+      if (a.stats) fprintf(stderr, "[mkpileup] full-data threshold sample taken from %zu resident shard(s)%s\n", fs.size(),
+          a.world > 1 ? " of this rank" : "");
     } else {
     if (resident) resident_of = [&](uint32_t) { return resident; };
     else if (ahead_fits && ahead_whole_contigs && resident_ok && a.world == 1) {
       // every contig the schedule can visit must be among the shards ingested ahead
       std::map<uint32_t, size_t> by_tid; for (size_t k = 0; k < ahead.size(); k++) by_tid[ahead[k].tid] = k;
-      bool covered = true; { const IdxStats stx = idxstats(bam, sr, bf); for (auto& kv : stx.mapped_by_tid) if (kv.second && !by_tid.count((uint32_t)kv.first)) covered = false; }
-      // (a region run: the one record is the region; a BED run: a contig's shard holds the records reaching its BED spans, which are the only ones that can yield a value)
+      bool covered = true; { const IdxStats stx = idxstats(bam, sr, bf);
+        for (auto& kv : stx.mapped_by_tid) if (kv.second && !by_tid.count((uint32_t)kv.first)) covered = false;
+        }
+      // (a region run: the one record is the region; a BED run: a contig's shard holds the records reaching its BED spans, which are the only ones
+      // that can yield a value)
       if (covered) resident_of = [&, by_tid](uint32_t tid) -> const ShardHost* {
         auto it = by_tid.find(tid); if (it == by_tid.end()) throw Error(MKP_E_INVALID, "internal: resident sampling outside the ingested contigs");
         return bind_ahead(it->second);
@@ -979,16 +1092,19 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
     // sampling intervals through the host reader, as round 4 did)
     sample_probabilities(ctx, bam, (a.thr_cb && full_mode) ? a : as, sr, bf, resident_of);
     if (resident_of) resident_used = true;
-    if (a.stats && resident_of && !resident) fprintf(stderr, "[mkpileup] threshold estimate sampled from %zu shards ingested ahead (resident)\n", ahead.size());
+    if (a.stats && resident_of && !resident) fprintf(stderr, "[mkpileup] threshold estimate sampled from %zu shards ingested ahead (resident)\n",
+        ahead.size());
     }
     if (bound) { must(mkp_internal_sample_bind(ctx, bound)); bound = nullptr; }
     mark("schedule walked, sample in HBM");
-    if (a.stats) fprintf(stderr, "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n",
+    if (a.stats) fprintf(stderr,
+        "[mkpileup] threshold sampling: head fetch wait %.1f ms, device rounds %llu (%llu reads) %.1f ms, first-N logic %.1f ms\n",
         g_sample_times.fetch_ms, (unsigned long long)g_sample_times.rounds, (unsigned long long)g_sample_times.reads, g_sample_times.device_ms,
         g_sample_times.decide_ms);
     }
     { float thr[4] = {0, 0, 0, 0}; uint8_t has[4] = {0, 0, 0, 0};
-      if (a.thr_cb) { auto t_cb = std::chrono::steady_clock::now(); const int rc = a.thr_cb(a.thr_cb_user, ctx, cb_supplies ? 0 : 1, thr, has); callback_ms = ms_since(t_cb);
+      if (a.thr_cb) { auto t_cb = std::chrono::steady_clock::now(); const int rc = a.thr_cb(a.thr_cb_user, ctx, cb_supplies ? 0 : 1, thr, has);
+        callback_ms = ms_since(t_cb);
         if (rc != MKP_OK) throw Error(rc, "the threshold callback failed"); mark("thresholds from the callback"); }
       else thresholds_from_sample(ctx, a.filter_percentile, thr, has, a.stats);
       for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; } }
@@ -997,20 +1113,24 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   mark("thresholds done");
   if (!a.plan_only) must(mkp_set_caller(ctx, &kc));
   if (early_walk.valid()) early_walk.get();   // rethrows what the walk threw
-  // --partition-tag: the output path is a directory with one bedMethyl per key, `[<prefix>_]<key>.bed` (PartitioningBedMethylWriter, writers.rs:1005-1082)
+  // --partition-tag: the output path is a directory with one bedMethyl per key, `[<prefix>_]<key>.bed` (PartitioningBedMethylWriter,
+  // writers.rs:1005-1082)
   const bool partitioned = !a.partition_tags.empty();
   std::map<std::string, std::unique_ptr<RowWriter>> key_writers;
   BedGraphOut bg;
   if (a.bedgraph) {   // (subcommand.rs:328-363: no header, no mixed delimiters; the path is a directory)
-    if (a.with_header || a.mixed_delim || a.bgzf || a.hemi || a.plan_only) throw Error(MKP_E_INVALID, "--bedgraph cannot be combined with --with-header, --mixed-delim, --bgzf or --plan-only");
+    if (a.with_header || a.mixed_delim || a.bgzf || a.hemi || a.plan_only) throw Error(MKP_E_INVALID,
+        "--bedgraph cannot be combined with --with-header, --mixed-delim, --bgzf or --plan-only");
     if (a.out_bed.empty() || a.out_bed == "-" || a.out_bed == "stdout") throw Error(MKP_E_INVALID, "--bedgraph needs an output directory");
-    if (partitioned) { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
+    if (partitioned) { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str());
+      must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
     if (mkdir(a.out_bed.c_str(), 0777) != 0 && errno != EEXIST) throw Error(MKP_E_IO, "failed to make output directory " + a.out_bed);
     bg.dir = a.out_bed; bg.prefix = a.prefix; bg.groupings = partitioned; bg.labels = wr.labels;
   } else if (partitioned) {
     if (a.with_header) throw Error(MKP_E_INVALID, "--with-header cannot be combined with --partition-tag");
     if (a.plan_only) throw Error(MKP_E_INVALID, "--plan-only has no partitioned form");
-    { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str()); must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
+    { std::vector<const char*> tp; for (auto& t : a.partition_tags) tp.push_back(t.c_str());
+      must(mkp_set_partition_tags(ctx, tp.data(), (uint32_t)tp.size())); }
     if (mkdir(a.out_bed.c_str(), 0777) != 0 && errno != EEXIST) throw Error(MKP_E_IO, "failed to make output directory " + a.out_bed);
   } else {
   wr.f = (a.out_bed == "-" || a.out_bed == "stdout" || (a.hemi && a.out_bed.empty())) ? stdout : fopen(a.out_bed.c_str(), "w+");
@@ -1035,37 +1155,52 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
   if (a.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n",
       wr.f);
   build_plan();
-  if (ahead.empty() && plan.size() > 1 && !getenv("MKP_NO_AHEAD")) ahead_from_plan();   // (thresholds known before the plan: the shards go ahead of the loop from here)
+  // (thresholds known before the plan: the shards go ahead of the loop from here)
+  if (ahead.empty() && plan.size() > 1 && !getenv("MKP_NO_AHEAD")) ahead_from_plan();
   // shards that were ingested ahead: same contig, same hull, same windows
   std::vector<long> plan_ahead(plan.size(), -1);
   for (size_t pi = 0; pi < plan.size(); pi++) for (size_t k = 0; k < ahead.size(); k++)
-    if (ahead[k].tid == records[plan[pi].rec].tid && ahead[k].s0 == plan[pi].s0 && ahead[k].s1 == plan[pi].s1 && ahead[k].wins == plan_windows(plan[pi])) { plan_ahead[pi] = (long)k; break; }
+    if (ahead[k].tid == records[plan[pi].rec].tid && ahead[k].s0 == plan[pi].s0 && ahead[k].s1 == plan[pi].s1
+        && ahead[k].wins == plan_windows(plan[pi])) {
+      plan_ahead[pi] = (long)k; break; }
   // double buffering: the next shard's blocks are read and inflated while this one is packed, run and written
   std::future<ShardInput> next_batch;
   const bool early_match = early_set && !plan.empty() && plan[0].rec == 0 && plan[0].s0 == early_s0 && plan[0].s1 == early_s1;
-  if (pre_attached && !(early_match && plan.size() == 1)) throw Error(MKP_E_INVALID, "internal: the shard attached for resident sampling is not the plan's");
-  if (pre_attached || !ahead.empty()) { fetch_wait_ms += fetch_wait_early_ms; }   // (what the estimate waited for shards ingested ahead is load time too)
-  else if (early_match && early_in_ready) { fetch_wait_ms += fetch_wait_early_ms; next_batch = std::async(std::launch::deferred, [&]() { return std::move(early_in); }); }
+  if (pre_attached && !(early_match && plan.size() == 1)) throw Error(MKP_E_INVALID,
+      "internal: the shard attached for resident sampling is not the plan's");
+  // (what the estimate waited for shards ingested ahead is load time too)
+  if (pre_attached || !ahead.empty()) { fetch_wait_ms += fetch_wait_early_ms; }
+  else if (early_match && early_in_ready) { fetch_wait_ms += fetch_wait_early_ms; next_batch = std::async(std::launch::deferred, [&]() {
+      return std::move(early_in); }); }
   else if (early_match && early_fetch.valid()) next_batch = std::move(early_fetch);
-  else { if (early_fetch.valid()) early_fetch.wait(); if (!plan.empty() && plan_ahead[0] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[0]); }
+  else { if (early_fetch.valid()) early_fetch.wait();
+    if (!plan.empty() && plan_ahead[0] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[0]);
+    }
   for (size_t pi = 0; pi < plan.size(); pi++) {
     const ShardPlan& sp = plan[pi]; const Contig& rec = records[sp.rec]; const uint32_t s0 = sp.s0, s1 = sp.s1; const uint64_t bp = sp.bp;
     std::unique_ptr<BamBatch> batch; std::unique_ptr<DevShard> dev;
     const bool attached_already = pre_attached && pi == 0;
-    struct Release { decltype(ahead_release)& rel; long k; ~Release() { if (k >= 0) rel((size_t)k); } } release_shard{ahead_release, plan_ahead[pi]};   // the shard's bytes go back to the budget when this iteration is over
+    // the shard's bytes go back to the budget when this iteration is over
+    struct Release { decltype(ahead_release)& rel; long k; ~Release() { if (k >= 0) rel((size_t)k); } } release_shard{ahead_release, plan_ahead[pi]};
     if (attached_already) dev = std::move(pre_dev);
-    else if (plan_ahead[pi] >= 0) { auto t_f = std::chrono::steady_clock::now(); Ahead& A = ahead_wait((size_t)plan_ahead[pi]); batch = std::move(A.in.batch); dev = std::move(A.in.dev); fetch_wait_ms += ms_since(t_f); }
-    else { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev); fetch_wait_ms += ms_since(t_f); }
-    if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack; ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
+    else if (plan_ahead[pi] >= 0) { auto t_f = std::chrono::steady_clock::now(); Ahead& A = ahead_wait((size_t)plan_ahead[pi]);
+      batch = std::move(A.in.batch); dev = std::move(A.in.dev); fetch_wait_ms += ms_since(t_f); }
+    else { auto t_f = std::chrono::steady_clock::now(); ShardInput in = next_batch.get(); batch = std::move(in.batch); dev = std::move(in.dev);
+      fetch_wait_ms += ms_since(t_f); }
+    if (dev) { ingest_ms[0] += dev->ms_plan; ingest_ms[1] += dev->ms_upload; ingest_ms[2] += dev->ms_inflate; ingest_ms[3] += dev->ms_pack;
+      ingest_ms[4] += dev->ms_digest; ingest_blocks += dev->n_blocks;
                ingest_records += dev->n_records; ingest_kernel_ms += dev->ms_kernel; ingest_comp += dev->comp_bytes; ingest_raw += dev->raw_bytes; }
     if (pi + 1 < plan.size() && plan_ahead[pi + 1] < 0) next_batch = std::async(std::launch::async, fetch_shard, plan[pi + 1]);
     std::vector<uint8_t> merged_focus;   // a merged shard: its records' focus bytes at their places in the hull, zero in between
     if (hf) for (size_t k = 0; k < std::max<size_t>(sp.parts.size(), 1); k++) { const size_t ri = sp.parts.empty() ? sp.rec : sp.parts[k].rec;
-      if (!focus_done[ri]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(records[ri], a.interval_size, &focus_of[ri]); focus_done[ri] = 1; focus_ms += ms_since(t_focus); } }
+      if (!focus_done[ri]) { auto t_focus = std::chrono::steady_clock::now(); fb.walk(records[ri], a.interval_size, &focus_of[ri]);
+        focus_done[ri] = 1; focus_ms += ms_since(t_focus); } }
     if (sp.rec > 0 && (pi == 0 || plan[pi - 1].rec != sp.rec)) for (size_t r2 = 0; r2 < sp.rec; r2++) { std::vector<uint8_t>().swap(focus_of[r2]);
         }   // earlier contigs are done
     if (hf && !sp.parts.empty()) { merged_focus.assign((size_t)(s1 - s0), 0);
-      for (auto& pt : sp.parts) memcpy(merged_focus.data() + (pt.s0 - s0), focus_of[pt.rec].data() + (pt.s0 - records[pt.rec].start), (size_t)(pt.s1 - pt.s0)); }
+      for (auto& pt : sp.parts) memcpy(merged_focus.data() + (pt.s0 - s0), focus_of[pt.rec].data() + (pt.s0 - records[pt.rec].start),
+          (size_t)(pt.s1 - pt.s0));
+        }
     const std::vector<uint8_t>& focus = focus_of[sp.rec];
     std::vector<mkp_record> recs; if (batch) { recs.reserve(batch->recs.size()); for (auto& e : batch->recs) recs.push_back(batch->view(e)); }
     {
@@ -1074,21 +1209,27 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         Packer pk; pk.pieces.swap(kept_pieces); ShardHost S; S.tid = (int32_t)rec.tid; S.win_start = (int32_t)s0; S.win_end = (int32_t)s1;
         const int32_t tid = (int32_t)rec.tid; auto t_pk = std::chrono::steady_clock::now();
         // --plan-pack-min N: records from which the packer runs on all cores (0 = always; default as in mkp_shard_add_records)
-        pack_records(pk, S, recs.data(), (uint32_t)recs.size(), [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r); }, a.plan_pack_min);
+        pack_records(pk, S, recs.data(), (uint32_t)recs.size(), [tid](const mkp_record& r) { return r.tid == tid && Packer::keep(r);
+          }, a.plan_pack_min);
         pack_ms += ms_since(t_pk); kept_pieces.swap(pk.pieces);
         // digest of everything the packer hands to the device: a parallel pack must equal the sequential one byte for byte
         uint64_t dg = 1469598103934665603ull;
-        auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { dg ^= b[i]; dg *= 1099511628211ull; } };
-        mix(S.hdr.data(), S.hdr.size() * sizeof(MkpReadHdr)); mix(S.cigar.data(), S.cigar.size() * 4); mix(S.chunk_pfx.data(), S.chunk_pfx.size() * 4);
+        auto mix = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < n; i++) { dg ^= b[i];
+            dg *= 1099511628211ull; } };
+        mix(S.hdr.data(), S.hdr.size() * sizeof(MkpReadHdr)); mix(S.cigar.data(), S.cigar.size() * 4);
+          mix(S.chunk_pfx.data(), S.chunk_pfx.size() * 4);
             mix(S.seq.data(), S.seq.size());
         mix(S.tagref.data(), S.tagref.size() * sizeof(MkpTagRef)); mix(S.ranks.data(), S.ranks.size() * 4); mix(S.ml.data(), S.ml.size());
             mix(S.name_hash.data(), S.name_hash.size() * 8);
         for (auto& k : pk.layout_keys) mix(k.data(), k.size());
-        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\t%016llx\n", rec.name.c_str(), s0, s1, S.hdr.size(), (unsigned long long)S.n_calls, (unsigned long long)dg); positions += bp;
+        fprintf(wr.f, "%s\t%u\t%u\t%zu\t%llu\t%016llx\n", rec.name.c_str(), s0, s1, S.hdr.size(), (unsigned long long)S.n_calls,
+            (unsigned long long)dg);
+          positions += bp;
             continue;
       }
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = (int32_t)rec.tid; sh.start = s0; sh.end = s1;
-      if (hf) { sh.focus = sp.parts.empty() ? focus.data() + (s0 - rec.start) : merged_focus.data(); sh.combos = fb.combos.data(); sh.n_combos = (uint32_t)fb.combos.size(); }
+      if (hf) { sh.focus = sp.parts.empty() ? focus.data() + (s0 - rec.start) : merged_focus.data(); sh.combos = fb.combos.data();
+        sh.n_combos = (uint32_t)fb.combos.size(); }
       mark("shard blocks in hand");
       if (attached_already) dev.reset();   // begun and attached before the threshold estimate, which sampled from it
       else {
@@ -1117,7 +1258,8 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
         else if (!partitioned) wr.write(rec.name, rows);
         else for (uint64_t i0r = 0; i0r < rows.n_rows;) {   // rows come grouped by key: one slice per key
           uint64_t i1r = i0r; while (i1r < rows.n_rows && rows.partition_key[i1r] == rows.partition_key[i0r]) i1r++;
-          mkp_rows v = rows; v.n_rows = i1r - i0r; v.pos += i0r; v.strand += i0r; v.code_repr += i0r; v.motif_idx += i0r; v.n_valid += i0r; v.n_mod += i0r;
+          mkp_rows v = rows; v.n_rows = i1r - i0r; v.pos += i0r; v.strand += i0r; v.code_repr += i0r; v.motif_idx += i0r; v.n_valid += i0r;
+            v.n_mod += i0r;
               v.n_canonical += i0r; v.n_other += i0r;
           v.n_delete += i0r; v.n_fail += i0r; v.n_diff += i0r; v.n_nocall += i0r; v.partition_key += i0r;
           const uint32_t k = rows.partition_key[i0r];
@@ -1128,35 +1270,47 @@ int run(const Args& a, mkp_ctx* ext_ctx, mkp_run_report* rep) {
       }
       n_shards++;
       mark("shard run, rows with the writer");
-      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms; row_ms += st.rows_kernel_ms;
+      mkp_stats st; mkp_get_stats(ctx, &st); kernel_ms += st.kernel_ms; dec_ms += st.decode_kernel_ms; pil_ms += st.pileup_kernel_ms;
+        row_ms += st.rows_kernel_ms;
           pack_ms += st.pack_ms; h2d_ms += st.h2d_ms; d2h_ms += st.d2h_ms;
       positions += bp; processed += rows.processed_records; skipped += rows.skipped_records;
     }
   }
   load_ms += fetch_wait_ms;   // what the shard loop waited for blocks to be read and inflated (the rest overlapped with pack / run / write)
-  { auto t_w = std::chrono::steady_clock::now(); bg.finish(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f); } write_ms += ms_since(t_w); }
+  { auto t_w = std::chrono::steady_clock::now(); bg.finish(); wr.finish(); for (auto& kv : key_writers) { kv.second->finish(); fclose(kv.second->f);
+    } write_ms += ms_since(t_w); }
   if (wr.f && wr.f != stdout) fclose(wr.f);
   mark("output closed");
   if (rep) {
     memset(rep, 0, sizeof(*rep));
-    rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms; rep->kernel_ms = kernel_ms;
+    rep->load_ms = load_ms; rep->threshold_ms = thr_ms; rep->focus_ms = focus_ms; rep->pack_ms = pack_ms; rep->h2d_ms = h2d_ms;
+      rep->kernel_ms = kernel_ms;
         rep->d2h_ms = d2h_ms; rep->write_ms = write_ms;
     rep->total_ms = ms_since(t_all); rep->n_rows = wr.n; rep->n_positions = positions; rep->n_shards = n_shards; rep->processed_records = processed;
         rep->skipped_records = skipped;
     for (int b = 0; b < 4; b++) { rep->threshold[b] = kc.per_base_threshold[b]; rep->has_threshold[b] = kc.has_per_base[b]; }
-    rep->grid_wait_ms = grid_wait_ms; rep->callback_ms = callback_ms; rep->ingest_kernel_ms = ingest_kernel_ms; rep->ingest_upload_ms = ingest_ms[1]; rep->ingest_table_ms = ingest_ms[0];
-    rep->ingest_pack_ms = ingest_ms[3]; rep->ingest_comp_bytes = ingest_comp; rep->ingest_raw_bytes = ingest_raw; rep->ingest_blocks = ingest_blocks; rep->ingest_records = ingest_records;
+    rep->grid_wait_ms = grid_wait_ms; rep->callback_ms = callback_ms; rep->ingest_kernel_ms = ingest_kernel_ms; rep->ingest_upload_ms = ingest_ms[1];
+      rep->ingest_table_ms = ingest_ms[0];
+    rep->ingest_pack_ms = ingest_ms[3]; rep->ingest_comp_bytes = ingest_comp; rep->ingest_raw_bytes = ingest_raw; rep->ingest_blocks = ingest_blocks;
+      rep->ingest_records = ingest_records;
   }
   if (a.stats) fprintf(stderr,
       "[mkpileup] rows=%llu positions=%llu processed~%llu skipped~%llu load_ms=%.1f threshold_ms=%.1f focus_ms=%.1f pack_ms=%.1f h2d_ms=%.1f kernel_ms=%.3f (decode %.3f pileup %.3f rows %.3f) d2h_ms=%.1f write_ms=%.1f total_ms=%.1f shards=%llu indexed=%d bam_bytes_read=%llu bam_bytes_inflated=%llu (on the device %llu) peak_rss_kb=%llu\n",
-                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms, thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
-                       (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(), (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)bam.bytes_inflated_device.load(), (unsigned long long)peak_rss_kb());
+                       (unsigned long long)wr.n, (unsigned long long)positions, (unsigned long long)processed, (unsigned long long)skipped, load_ms,
+                           thr_ms, focus_ms, pack_ms, h2d_ms, kernel_ms, dec_ms, pil_ms, row_ms, d2h_ms, write_ms, ms_since(t_all),
+                       (unsigned long long)n_shards, bam.indexed() ? 1 : 0, (unsigned long long)bam.bytes_read.load(),
+                           (unsigned long long)bam.bytes_inflated.load(), (unsigned long long)bam.bytes_inflated_device.load(),
+                           (unsigned long long)peak_rss_kb());
   if (a.stats) {   // every MKP_* variable that is set: they pick kernels and paths and would otherwise leave no trace in a measurement
     std::string ov; for (char** e = ::environ; e && *e; e++) if (!strncmp(*e, "MKP_", 4)) { ov += ' '; ov += *e; }
-    fprintf(stderr, "[mkpileup] ingest=%s resident_sampling=%d ahead=%zu shards (estimated %.0f MB, HBM budget %.0f MB) rank=%u/%u env overrides:%s\n", dev_ingest ? "device" : "host", (pre_attached || resident_used) ? 1 : 0,
+    fprintf(stderr,
+        "[mkpileup] ingest=%s resident_sampling=%d ahead=%zu shards (estimated %.0f MB, HBM budget %.0f MB) rank=%u/%u env overrides:%s\n",
+        dev_ingest ? "device" : "host", (pre_attached || resident_used) ? 1 : 0,
         ahead.size(), (double)ahead_est_total / 1048576.0, (double)hbm_budget / 1048576.0, a.rank, a.world, ov.empty() ? " none" : ov.c_str());
   }
-  if (a.stats && dev_ingest) fprintf(stderr, "[mkpileup] device ingest: %llu BGZF blocks, %llu records; block plan %.1f ms, upload %.1f, inflate + CRC + chains %.1f, parse + pack %.1f, digest %.1f (overlapped with the threshold estimate / the shard in hand)\n",
+  if (a.stats
+      && dev_ingest) fprintf(stderr,
+      "[mkpileup] device ingest: %llu BGZF blocks, %llu records; block plan %.1f ms, upload %.1f, inflate + CRC + chains %.1f, parse + pack %.1f, digest %.1f (overlapped with the threshold estimate / the shard in hand)\n",
       (unsigned long long)ingest_blocks, (unsigned long long)ingest_records, ingest_ms[0], ingest_ms[1], ingest_ms[2], ingest_ms[3], ingest_ms[4]);
   return MKP_OK;
 }
@@ -1167,11 +1321,13 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
   for (int i = 0; i < argc; i++) {
     std::string s = argv[i];
     auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
-    if (hemi && (s == "--preset" || s == "--combine-strands" || s == "--with-header" || s == "--header" || s == "--partition-tag" || s == "--prefix" || s == "--bedgraph" || s == "--plan-only"))
+    if (hemi && (s == "--preset" || s == "--combine-strands" || s == "--with-header" || s == "--header" || s == "--partition-tag" || s == "--prefix"
+        || s == "--bedgraph" || s == "--plan-only"))
       throw Error(MKP_E_INVALID, "unexpected argument '" + s + "' for pileup-hemi");
     if (hemi && (s == "-o" || s == "--out-bed")) { a.out_bed = val(); continue; }
     if (s == "--region") a.region = val(); else if (s == "--max-depth") a.max_depth = (uint32_t)std::stoul(val());
-    else if (s == "-t" || s == "--threads") a.threads = std::stoul(val()); else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
+    else if (s == "-t" || s == "--threads") a.threads = std::stoul(val());
+      else if (s == "-i" || s == "--interval-size") a.interval_size = (uint32_t)std::stoul(val());
     else if (s == "--chunk-size" || s == "--queue-size" || s == "--log-filepath") val();
     else if (s == "--seed") { a.have_seed = true; a.seed = std::stoull(val()); }
     else if (s == "-n" || s == "--num-reads") a.num_reads = std::stoul(val()); else if (s == "-f" || s == "--sampling-frac") { a.have_frac = true;
@@ -1179,11 +1335,13 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (s == "--no-filtering") a.no_filtering = true; else if (s == "-p" || s == "--filter-percentile") a.filter_percentile = std::stof(val());
     else if (s == "--filter-threshold") a.filter_threshold.push_back(val());
         else if (s == "--mod-thresholds" || s == "--mod-threshold") a.mod_thresholds.push_back(val());
-    else if (s == "--sample-region") a.sample_region = val(); else if (s == "--sampling-interval-size") a.sampling_interval_size = (uint32_t)std::stoul(val());
+    else if (s == "--sample-region") a.sample_region = val();
+      else if (s == "--sampling-interval-size") a.sampling_interval_size = (uint32_t)std::stoul(val());
     else if (s == "--include-bed" || s == "--include-positions") a.include_bed = val(); else if (s == "--include-unmapped") a.include_unmapped = true;
     else if (s == "--ignore") a.ignore = val(); else if (s == "--force-allow-implicit") a.force_allow = true;
     else if (s == "--motif") { a.motif_parts.push_back(val()); a.motif_parts.push_back(val()); } else if (s == "--cpg") a.cpg = true;
-    else if (s == "--ref" || s == "-r") a.ref_fasta = val(); else if (s == "--mask" || s == "-k") a.mask = true; else if (s == "--preset") a.preset = val();
+    else if (s == "--ref" || s == "-r") a.ref_fasta = val(); else if (s == "--mask" || s == "-k") a.mask = true;
+      else if (s == "--preset") a.preset = val();
     else if (s == "--combine-mods") a.combine_mods = true; else if (s == "--combine-strands") a.combine_strands = true;
     else if (s == "--edge-filter") a.edge_filter = val(); else if (s == "--invert-edge-filter") a.invert_edge = true;
     else if (s == "--only-tabs" || s == "--suppress-progress") {} else if (s == "--mixed-delim") a.mixed_delim = true;
@@ -1192,7 +1350,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
         else if (s == "--gpus-world") a.world = (uint32_t)std::stoul(val());
     else if (s == "--plan-only") a.plan_only = true; else if (s == "--plan-pack-min") a.plan_pack_min = (uint32_t)std::stoul(val());
         else if (s == "--rerun") a.rerun = (uint32_t)std::stoul(val()); else if (s == "--shard-bp") a.shard_bp = std::stoull(val());
-        else if (s == "--shard-bytes") { a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); a.shard_bytes_set = true; } else if (s == "--no-index") a.no_index = true;
+        else if (s == "--shard-bytes") { a.shard_bytes = std::max<uint64_t>(1, std::stoull(val())); a.shard_bytes_set = true;
+          } else if (s == "--no-index") a.no_index = true;
         else if (s == "--device-inflate") a.device_inflate = true; else if (s == "--host-ingest") a.host_ingest = true;
         else if (s == "--hbm-budget-mb") a.hbm_budget_mb = std::stoull(val());
         else if (s == "--tile") a.tile = (uint32_t)std::stoul(val()); else if (s == "--stats") a.stats = true;
@@ -1202,8 +1361,10 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
     else if (!s.empty() && s[0] == '-' && s != "-") throw Error(MKP_E_INVALID, "unknown flag " + s);
     else pos.push_back(s);
   }
-  if (need_positional && hemi) { if (pos.size() != 1) throw Error(MKP_E_INVALID, "usage: <in.bam> -o <out.bed> [flags of `modkit pileup-hemi`]"); a.in_bam = pos[0]; }
-  else if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]"); a.in_bam = pos[0];
+  if (need_positional && hemi) { if (pos.size() != 1) throw Error(MKP_E_INVALID, "usage: <in.bam> -o <out.bed> [flags of `modkit pileup-hemi`]");
+    a.in_bam = pos[0]; }
+  else if (need_positional) { if (pos.size() != 2) throw Error(MKP_E_INVALID, "usage: <in.bam> <out.bed> [flags of `modkit pileup`]");
+    a.in_bam = pos[0];
       a.out_bed = pos[1]; }
   else if (!pos.empty()) throw Error(MKP_E_INVALID, "unexpected positional argument " + pos[0]);
   if (a.world == 0 || a.rank >= a.world) throw Error(MKP_E_INVALID, "bad --gpus-rank/--gpus-world");
@@ -1212,7 +1373,8 @@ void parse_args(int argc, const char* const* argv, Args* out, bool need_position
 }  // namespace
 
 // (tests) the --bedgraph writer alone: rows in, files out — no device involved
-extern "C" int mkp_internal_bedgraph_write(const char* dir, const char* prefix, int groupings, const char* const* motif_labels, uint32_t n_labels, const char* chrom, const mkp_rows* rows) {
+extern "C" int mkp_internal_bedgraph_write(const char* dir, const char* prefix, int groupings, const char* const* motif_labels, uint32_t n_labels,
+    const char* chrom, const mkp_rows* rows) {
   if (!dir || !chrom || !rows) return MKP_E_INVALID;
   try {
     BedGraphOut bg; bg.dir = dir; bg.prefix = prefix ? prefix : ""; bg.groupings = groupings != 0;
@@ -1279,7 +1441,8 @@ namespace {
 // the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
 void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out, const mkp_caller* thresholds = nullptr) {
   Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
-  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, HostPool::host_cpus())),
+  std::unique_ptr<BamSource> src = BamSource::open(a.in_bam,
+      std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, HostPool::host_cpus())),
       !a.no_index);   // inflate threads: --threads only steers the sampling schedule
   const BamSource& bam = *src;
   RegionSpec region, sregion; const bool hr = !a.region.empty(), hs = !a.sample_region.empty();
@@ -1289,17 +1452,21 @@ void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
   mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
   if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(',');
       if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10);
-      kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr,
+      kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10);
+        } else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr,
       10); }
   if (a.preset == "traditional") { kc.numeric_mode = 2; kc.collapse_code = 'h'; }
-  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2;
+  else if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore);
+    kc.numeric_mode = 2;
       kc.collapse_code = code; }
   std::vector<Contig> records = targets(bam, hr ? &region : nullptr);
   BedFilter bed_store; const BedFilter* bf = nullptr;
-  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid; bed_store = BedFilter::load(a.include_bed, c2t);
+  if (!a.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : records) c2t[r.name] = r.tid;
+    bed_store = BedFilter::load(a.include_bed, c2t);
       bf = &bed_store; }
   if (thresholds) { kc.default_threshold = thresholds->default_threshold; kc.per_mod = thresholds->per_mod; kc.n_per_mod = thresholds->n_per_mod;
-                    for (int b = 0; b < 4; b++) { kc.per_base_threshold[b] = thresholds->per_base_threshold[b]; kc.has_per_base[b] = thresholds->has_per_base[b]; } }
+                    for (int b = 0; b < 4; b++) { kc.per_base_threshold[b] = thresholds->per_base_threshold[b];
+                      kc.has_per_base[b] = thresholds->has_per_base[b]; } }
   int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
   sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
   if (q_out) *q_out = a.filter_percentile;
@@ -1326,7 +1493,8 @@ extern "C" int mkp_estimate_thresholds(mkp_ctx* ctx, const char* bam_path, int a
 // `modkit sample-probs` (SampleModBaseProbs::run, src/commands.rs:680-887), the percentiles table: the schedule's sample, per canonical
 // base the requested percentiles of the argmax probabilities (Percentiles::new -> percentile_linear_interp).  The subcommand's own
 // flag names: -i is the sampling interval (default 1 000 000), unmapped reads are sampled unless --only-mapped (or --include-bed).
-extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, const float* percentiles, uint32_t n_percentiles,
+extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, const float* percentiles,
+    uint32_t n_percentiles,
                                 float* values /* [4][n_percentiles], bases A,C,G,T */, uint8_t has[4], uint64_t n_values[4]) {
   if (!ctx || !bam_path || (!percentiles && n_percentiles) || !values || !has || !n_values) return MKP_E_INVALID;
   try {
@@ -1337,7 +1505,8 @@ extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, co
       else if (s == "--no-sampling") { tr.push_back("-f"); tr.push_back("1.0"); }
       else if (s == "--only-mapped") only_mapped = true;
       else if (s == "--include-bed" || s == "--include-positions") { only_mapped = true; tr.push_back(s); }
-      else if (s == "-p" || s == "--percentiles" || s == "--filter-percentile") throw Error(MKP_E_INVALID, "percentiles are an argument of this call, not a flag");
+      else if (s == "-p" || s == "--percentiles" || s == "--filter-percentile") throw Error(MKP_E_INVALID,
+          "percentiles are an argument of this call, not a flag");
       else tr.push_back(s);
     }
     if (!have_i) { tr.push_back("--sampling-interval-size"); tr.push_back("1000000"); }
@@ -1387,7 +1556,8 @@ extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const c
         if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID,
         "encountered illegal per-mod threshold: " + raw);
         per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
-    if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kt); kt.per_mod = per_mod.data(); kt.n_per_mod = (uint32_t)per_mod.size(); }
+    if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kt); kt.per_mod = per_mod.data();
+      kt.n_per_mod = (uint32_t)per_mod.size(); }
     else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
     else {
       int rc = mkp_histogram_begin(ctx); if (rc != MKP_OK) return rc;
@@ -1406,16 +1576,19 @@ extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const c
     for (uint32_t b = 0; b < 4; b++) {
       out->reads_with_mod_calls[b] = t[128 + b]; out->threshold[b] = kt.per_base_threshold[b]; out->has_threshold[b] = kt.has_per_base[b];
       if (!t[128 + b]) continue;
-      auto row = [&](uint32_t code, uint32_t cls) { ctx->h_sum_base.push_back((uint8_t)b); ctx->h_sum_code.push_back(code); ctx->h_sum_pass.push_back(t[b * 32 + cls]);
+      auto row = [&](uint32_t code, uint32_t cls) { ctx->h_sum_base.push_back((uint8_t)b); ctx->h_sum_code.push_back(code);
+        ctx->h_sum_pass.push_back(t[b * 32 + cls]);
           ctx->h_sum_fail.push_back(t[b * 32 + 16 + cls]); };
       row(MKP_HEMI_CANONICAL, 1);
       std::vector<std::pair<uint32_t, uint32_t>> codes;
-      for (size_t si = 0; si < slots.size() && si < 14; si++) if (slots[si].pb == b && ((obs >> si) & 1ull)) codes.push_back({slots[si].code_repr, (uint32_t)si});
+      for (size_t si = 0; si < slots.size() && si < 14; si++) if (slots[si].pb == b
+          && ((obs >> si) & 1ull)) codes.push_back({slots[si].code_repr, (uint32_t)si});
       std::sort(codes.begin(), codes.end());
       for (auto& cs : codes) row(cs.first, 2 + cs.second);
     }
     out->total_reads_used = t[128 + 4];
-    out->n_rows = (uint32_t)ctx->h_sum_base.size(); out->base = ctx->h_sum_base.data(); out->code_repr = ctx->h_sum_code.data(); out->pass_count = ctx->h_sum_pass.data();
+    out->n_rows = (uint32_t)ctx->h_sum_base.size(); out->base = ctx->h_sum_base.data(); out->code_repr = ctx->h_sum_code.data();
+      out->pass_count = ctx->h_sum_pass.data();
         out->fail_count = ctx->h_sum_fail.data();
     return MKP_OK;
   } catch (const Error& e) { ctx->err = e.what(); return e.status; }
@@ -1437,8 +1610,11 @@ extern "C" int mkp_process_region(mkp_ctx* ctx, const char* bam_path, const mkp_
     std::unique_ptr<BamSource> src = BamSource::open(bam_path, 0);
     const bool host_ingest_env = getenv("MKP_HOST_INGEST") && !strcmp(getenv("MKP_HOST_INGEST"), "1");
     if (src->indexed() && ctx->partition_tags.empty() && !host_ingest_env && shard->tid >= 0 && shard->end > shard->start) {
-      if (!ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device); if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device"); }
-      std::unique_ptr<DevShard> dev = mkp_internal_ingest_run(ctx->ingest, *src, (uint32_t)shard->tid, shard->start > MKP_HALO ? (uint32_t)shard->start - MKP_HALO : 0u, (uint32_t)shard->end + MKP_HALO);
+      if (!ctx->ingest) { ctx->ingest = mkp_internal_ingest_create(ctx->device);
+        if (!ctx->ingest) throw Error(MKP_E_DEVICE, "device ingest: cannot create streams on the device");
+        }
+      std::unique_ptr<DevShard> dev = mkp_internal_ingest_run(ctx->ingest, *src, (uint32_t)shard->tid,
+          shard->start > MKP_HALO ? (uint32_t)shard->start - MKP_HALO : 0u, (uint32_t)shard->end + MKP_HALO);
       int rc = mkp_shard_begin(ctx, shard); if (rc != MKP_OK) return rc;
       rc = mkp_internal_shard_attach(ctx, dev.get()); mkp_internal_ingest_recycle(ctx->ingest, dev.get()); if (rc != MKP_OK) return rc;
       return mkp_shard_run(ctx, out);
@@ -1472,14 +1648,17 @@ std::string f32_display(float v) {
   std::string digits; for (char c : mant) if (c != '.') digits.push_back(c);
   while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
   std::string out;
-  if (ex >= 0) { if ((int)digits.size() <= ex + 1) out = digits + std::string((size_t)(ex + 1 - (int)digits.size()), '0'); else out = digits.substr(0, (size_t)ex + 1) + "." + digits.substr((size_t)ex + 1); }
+  if (ex >= 0) { if ((int)digits.size() <= ex + 1) out = digits + std::string((size_t)(ex + 1 - (int)digits.size()), '0');
+    else out = digits.substr(0, (size_t)ex + 1) + "." + digits.substr((size_t)ex + 1);
+    }
   else out = "0." + std::string((size_t)(-ex - 1), '0') + digits;
   return neg ? "-" + out : out;
 }
 char comp_char(char c) {   // bio::alphabets::dna::revcomp
   switch (c) {
     case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N';
-    case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K'; case 'B': return 'V'; case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D';
+    case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K'; case 'B': return 'V'; case 'V': return 'B';
+      case 'D': return 'H'; case 'H': return 'D';
     default: return c;
   }
 }
@@ -1499,21 +1678,28 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
   mkp_ctx* ctx = nullptr;
   struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
   try {
-    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false; size_t kmer = 5; int device = 0; long num_reads = -1;
+    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false;
+      size_t kmer = 5; int device = 0; long num_reads = -1;
     std::vector<std::string> rest;
     for (int i = 0; i < argc; i++) {
       const std::string s = argv[i];
       auto val = [&]() { if (i + 1 >= argc) throw Error(MKP_E_INVALID, "missing value for " + s); return std::string(argv[++i]); };
-      if (s == "--ref" || s == "--reference") ref_path = val(); else if (s == "--allow-non-primary") allow_np = true; else if (s == "--mapped-only") mapped_only = true;
-      else if (s == "--pass-only" || s == "--pass") pass_only = true; else if (s == "--no-headers") no_headers = true; else if (s == "--kmer-size") kmer = std::stoul(val());
-      else if (s == "--force" || s == "--suppress-progress") {} else if (s == "--device") device = std::stoi(val()); else if (s == "--stats") stats = true;
+      if (s == "--ref" || s == "--reference") ref_path = val(); else if (s == "--allow-non-primary") allow_np = true;
+        else if (s == "--mapped-only") mapped_only = true;
+      else if (s == "--pass-only" || s == "--pass") pass_only = true; else if (s == "--no-headers") no_headers = true;
+        else if (s == "--kmer-size") kmer = std::stoul(val());
+      else if (s == "--force" || s == "--suppress-progress") {} else if (s == "--device") device = std::stoi(val());
+        else if (s == "--stats") stats = true;
       else if (s == "--num-reads") num_reads = std::stol(val()); else if (s == "--ignore-index") ignore_index = true;
-      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--ignore-implicit" || s == "--bgzf" || s == "--cpg" || s == "--seed")
-        throw Error(MKP_E_UNSUPPORTED, "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --num-reads / --ignore-index are; see include/mkpileup.h)");
+      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--ignore-implicit" || s == "--bgzf"
+          || s == "--cpg" || s == "--seed")
+        throw Error(MKP_E_UNSUPPORTED,
+            "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --num-reads / --ignore-index are; see include/mkpileup.h)");
       else rest.push_back(s);
     }
     if (kmer == 0 || kmer > 50) throw Error(MKP_E_INVALID, "kmer size must be less than or equal to 50");
-    if (pass_only && std::find(rest.begin(), rest.end(), "--no-filtering") != rest.end()) throw Error(MKP_E_INVALID, "the argument '--no-filtering' cannot be used with '--pass-only'");
+    if (pass_only && std::find(rest.begin(), rest.end(), "--no-filtering") != rest.end()) throw Error(MKP_E_INVALID,
+        "the argument '--no-filtering' cannot be used with '--pass-only'");
     std::vector<const char*> av; for (auto& x : rest) av.push_back(x.c_str());
     Args a; parse_args((int)av.size(), av.data(), &a, true);
     // the flags of the threshold estimate (get_threshold_from_options, command_utils.rs:74-134): calls without a reference position count
@@ -1530,9 +1716,11 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     mkp_caller kc; memset(&kc, 0, sizeof(kc)); kc.max_depth = a.max_depth;
     std::vector<mkp_mod_threshold> per_mod;
     for (auto& raw : a.mod_thresholds) { size_t c = raw.find(':'); uint32_t code;
-      if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID, "encountered illegal per-mod threshold: " + raw);
+      if (c == std::string::npos || raw.find(':', c + 1) != std::string::npos || !parse_code(raw.substr(0, c), &code)) throw Error(MKP_E_INVALID,
+          "encountered illegal per-mod threshold: " + raw);
       per_mod.push_back({code, strtof(raw.c_str() + c + 1, nullptr)}); }
-    if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kc); kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size(); }
+    if (!a.filter_threshold.empty()) { parse_base_thresholds(a.filter_threshold, &kc); kc.per_mod = per_mod.data();
+      kc.n_per_mod = (uint32_t)per_mod.size(); }
     else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
     else {
       must(mkp_histogram_begin(ctx));
@@ -1542,9 +1730,11 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();
     }
     if (!a.edge_filter.empty()) { kc.edge_filter = 1; kc.edge_inverted = a.invert_edge; size_t c = a.edge_filter.find(',');
-      if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); }
+      if (c != std::string::npos) { kc.edge_start = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10);
+        kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str() + c + 1, nullptr, 10); }
       else kc.edge_start = kc.edge_end = (uint32_t)strtoul(a.edge_filter.c_str(), nullptr, 10); }
-    if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore); kc.numeric_mode = 2; kc.collapse_code = code; }
+    if (!a.ignore.empty()) { uint32_t code; if (!parse_code(a.ignore, &code)) throw Error(MKP_E_INVALID, "failed to parse mod code " + a.ignore);
+      kc.numeric_mode = 2; kc.collapse_code = code; }
     must(mkp_set_caller(ctx, &kc));
     must(mkp_internal_set_extract(ctx, true));
     const BamData bd = load_bam(a.in_bam, 0, false);
@@ -1555,9 +1745,11 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     // rows leave in the order its pool finishes the intervals; here in file order.  --num-reads: the serial path's "first N records that
     // reach process_record"; on an indexed BAM it follows the sampling schedule, which is not restated for this subcommand.
     BedFilter bed; const bool have_bed = !a.include_bed.empty();
-    if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t; bed = BedFilter::load(a.include_bed, c2t); }
+    if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;
+      bed = BedFilter::load(a.include_bed, c2t); }
     bool use_index = false; { FILE* probe = fopen((a.in_bam + ".bai").c_str(), "rb"); if (probe) { fclose(probe); use_index = !ignore_index; } }
-    if (use_index && num_reads >= 0) throw Error(MKP_E_UNSUPPORTED, "extract calls: --num-reads on an indexed BAM follows the reference's sampling schedule, which is not restated for this subcommand (--ignore-index: the first N records)");
+    if (use_index && num_reads >= 0) throw Error(MKP_E_UNSUPPORTED,
+        "extract calls: --num-reads on an indexed BAM follows the reference's sampling schedule, which is not restated for this subcommand (--ignore-index: the first N records)");
     int64_t reg_tid = -1, reg_s = 0, reg_e = 0; const bool have_region = !a.region.empty();
     if (have_region) {
       std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0); const RegionSpec rg = parse_region(a.region, *src);
@@ -1580,9 +1772,12 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       std::vector<mkp_record> recs;
       for (size_t i = r0; i < r1; i++) {   // TrackingModRecordIter (mod_bam.rs:53-122) + process_records_to_chan's --mapped-only
         const mkp_record r = view.view(bd.recs[i]);
-        if (use_index && have_region) {   // IndexedReader::fetch(tid, start, end): the records overlapping the region (one without reference span counts as one base)
+        // IndexedReader::fetch(tid, start, end): the records overlapping the region (one without reference span counts as one base)
+        if (use_index && have_region) {
           int64_t span = 0; const uint8_t* cgp = r.data + r.l_qname;
-          for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cgp + 4 * (size_t)k, 4); const uint32_t op = w & 15u; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4; }
+          for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cgp + 4 * (size_t)k, 4); const uint32_t op = w & 15u;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += w >> 4;
+            }
           const int64_t e = (int64_t)r.pos + std::max<int64_t>(span, 1);
           if (r.tid != reg_tid || (int64_t)r.pos >= reg_e || e <= reg_s) continue;
         }
@@ -1610,9 +1805,11 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         auto cig = [&](uint32_t k) { uint32_t w; memcpy(&w, cg + 4 * (size_t)k, 4); return w; };
         size_t sc_start = 0, sc_end = 0; bool cigar_ok = true;   // get_soft_clipped (read_ids_to_base_mod_probs.rs:803-824)
         if (!unmapped) {
-          bool broke = false; for (uint32_t k = 0; k < r.n_cigar; k++) { const uint32_t w = cig(k); if ((w & 15u) == 4u) sc_start += w >> 4; else { broke = true; break; } }
+          bool broke = false; for (uint32_t k = 0; k < r.n_cigar; k++) { const uint32_t w = cig(k); if ((w & 15u) == 4u) sc_start += w >> 4; else {
+              broke = true; break; } }
           if (!broke) cigar_ok = false;
-          broke = false; for (uint32_t k = r.n_cigar; k-- > 0;) { const uint32_t w = cig(k); if ((w & 15u) == 4u) sc_end += w >> 4; else { broke = true; break; } }
+          broke = false; for (uint32_t k = r.n_cigar; k-- > 0;) { const uint32_t w = cig(k); if ((w & 15u) == 4u) sc_end += w >> 4; else {
+              broke = true; break; } }
           if (!broke) cigar_ok = false;
         }
         if (!cigar_ok) { n_failed++; continue; }
@@ -1620,7 +1817,10 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         auto within = [&](size_t qp) { return L >= clip_end && qp >= clip_start && qp < L - clip_end; };
         // forward sequence and qualities
         std::string fwd(L, 'N');
-        for (size_t k = 0; k < L; k++) { const uint8_t b = sq[k >> 1]; const char c = NT16[(k & 1) ? (b & 15) : (b >> 4)]; if (rev) fwd[L - 1 - k] = comp_char(c); else fwd[k] = c; }
+        for (size_t k = 0; k < L; k++) { const uint8_t b = sq[k >> 1]; const char c = NT16[(k & 1) ? (b & 15) : (b >> 4)];
+          if (rev) fwd[L - 1 - k] = comp_char(c);
+          else fwd[k] = c;
+          }
         const std::string chrom = (!unmapped && r.tid >= 0 && (size_t)r.tid < bd.ref_names.size()) ? bd.ref_names[(size_t)r.tid] : std::string();
         const bool have_chrom = !unmapped && r.tid >= 0 && (size_t)r.tid < bd.ref_names.size();
         const FastaSeq* ref_seq = have_chrom ? fasta.get(chrom) : nullptr;
@@ -1635,7 +1835,9 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           const size_t f = e.pos, q = rev ? L - 1 - f : f;
           long ref = -1;
           if (!unmapped) {
-            if (q < q_at) { ck = 0; q_at = 0; r_at = r.pos; }   // an event behind the walk (the kernels emit a record's events in stored order; should that ever change, start over instead of underflowing)
+            // an event behind the walk (the kernels emit a record's events in stored order; should that ever change, start over instead of
+            // underflowing)
+            if (q < q_at) { ck = 0; q_at = 0; r_at = r.pos; }
             while (ck < r.n_cigar) {
               const uint32_t w = cig(ck), op = w & 15u, len = w >> 4;
               const bool cq = op == 0 || op == 1 || op == 4 || op == 7 || op == 8, cr = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
@@ -1651,32 +1853,40 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         bool any = false;
         for (const Row& w : rows) {
           if ((mapped_only || have_bed) && (unmapped || w.ref < 0)) continue;   // filter_read_base_mod_probs (src/extract/util.rs:71-124)
-          if (have_bed && !bed.contains((uint32_t)r.tid, (uint64_t)w.ref, (((w.info >> 2) & 1u) != 0) != rev)) continue;   // ... asked with the reference strand of the mod
+          // ... asked with the reference strand of the mod
+          if (have_bed && !bed.contains((uint32_t)r.tid, (uint64_t)w.ref, (((w.info >> 2) & 1u) != 0) != rev)) continue;
           if (!primary_or_unmapped && !within(w.f)) continue;                   // iter_profiles (read_ids_to_base_mod_probs.rs:785-800)
           any = true;
-          const uint32_t tb = w.info & 3u, sg = (w.info >> 2) & 1u, inferred = (w.info >> 3) & 1u, thr_cls = (w.info >> 4) & 15u, arg_cls = (w.info >> 8) & 15u;
+          const uint32_t tb = w.info & 3u, sg = (w.info >> 2) & 1u, inferred = (w.info >> 3) & 1u, thr_cls = (w.info >> 4) & 15u,
+              arg_cls = (w.info >> 8) & 15u;
           const bool filtered = thr_cls == 0;
           if (filtered && pass_only) continue;
           std::string code = "-";
-          if (arg_cls >= 2) { const uint32_t cr = arg_cls - 2 < slots.size() ? slots[arg_cls - 2].code_repr : 0u; code = (cr & 0x80000000u) ? std::to_string(cr & 0x7fffffffu) : std::string(1, (char)cr); }
+          if (arg_cls >= 2) { const uint32_t cr = arg_cls - 2 < slots.size() ? slots[arg_cls - 2].code_repr : 0u;
+            code = (cr & 0x80000000u) ? std::to_string(cr & 0x7fffffffu) : std::string(1, (char)cr); }
           std::string qk = kmer_at(fwd.data(), L, w.f, kmer);
           if (sg) { std::string t; for (size_t k = qk.size(); k-- > 0;) t.push_back(qk[k] == '-' ? '-' : comp_char(qk[k])); qk.swap(t); }
           std::string rk = ".";
           if (w.ref >= 0 && ref_seq) rk = kmer_at(ref_seq->data(), ref_seq->size(), (size_t)w.ref, kmer);
           const unsigned bq = ql[rev ? L - 1 - w.f : w.f];
           char line[1200];
-          const int ln = snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n", qname.c_str(), w.f, w.ref >= 0 ? w.ref : -1L,
-                   have_chrom ? chrom.c_str() : ".", sg ? '-' : '+', unmapped ? '.' : (rev ? '-' : '+'), unmapped ? '.' : ((sg != 0) != rev ? '-' : '+'), clip_start, clip_end, L,
-                   f32_display(w.p).c_str(), code.c_str(), bq, rk.c_str(), qk.c_str(), "ACGT"[tb], "ACGT"[sg ? 3 - tb : tb], filtered ? "true" : "false", inferred ? "true" : "false",
+          const int ln = snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n",
+              qname.c_str(), w.f, w.ref >= 0 ? w.ref : -1L,
+                   have_chrom ? chrom.c_str() : ".", sg ? '-' : '+', unmapped ? '.' : (rev ? '-' : '+'),
+                       unmapped ? '.' : ((sg != 0) != rev ? '-' : '+'), clip_start, clip_end, L,
+                   f32_display(w.p).c_str(), code.c_str(), bq, rk.c_str(), qk.c_str(), "ACGT"[tb], "ACGT"[sg ? 3 - tb : tb],
+                       filtered ? "true" : "false", inferred ? "true" : "false",
                    (have_chrom && within(w.f)) ? "true" : "false", (unsigned)r.flag);
-          if (ln < 0 || (size_t)ln >= sizeof(line)) throw Error(MKP_E_UNSUPPORTED, "extract calls: a row is longer than " + std::to_string(sizeof(line)) + " bytes (read or contig name of unusual length)");
+          if (ln < 0 || (size_t)ln >= sizeof(line)) throw Error(MKP_E_UNSUPPORTED,
+              "extract calls: a row is longer than " + std::to_string(sizeof(line)) + " bytes (read or contig name of unusual length)");
           text.append(line, (size_t)ln); n_rows++;
         }
         if (any) n_used++; else n_skipped++;
       }
       if (!text.empty() && fwrite(text.data(), 1, text.size(), out) != text.size()) throw Error(MKP_E_IO, "write error on " + a.out_bed);
     }
-    if (stats) fprintf(stderr, "[mkpileup] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used, (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);
+    if (stats) fprintf(stderr, "[mkpileup] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used,
+        (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);
     return MKP_OK;
   } catch (const Error& e) { return fail(e.status, e.what()); }
   catch (const std::exception& e) { return fail(MKP_E_INVALID, e.what()); }

@@ -38,7 +38,8 @@ inline char* put_pct2(char* p, float pct) {
 
 // one row; `name` = mod code (or `code,MOTIF,offset`); returns the end of the written text (at most ~200 bytes + chrom + name)
 inline char* format_row(char* p, const char* chrom, size_t chrom_n, const char* name, size_t name_n, char sp, uint32_t pos, char strand,
-                        uint32_t n_valid, uint32_t n_mod, uint32_t n_can, uint32_t n_other, uint32_t n_del, uint32_t n_fail, uint32_t n_diff, uint32_t n_nocall) {
+                        uint32_t n_valid, uint32_t n_mod, uint32_t n_can, uint32_t n_other, uint32_t n_del, uint32_t n_fail, uint32_t n_diff,
+                            uint32_t n_nocall) {
   memcpy(p, chrom, chrom_n); p += chrom_n; *p++ = '\t';
   // start, end and the coverage appear twice in a row (columns 2-3 = 7-8, 5 = 10): converted once, copied the second time
   char* const se = p; p = put_u32(p, pos); *p++ = '\t'; p = put_u32(p, pos + 1u); *p++ = '\t'; const size_t se_n = (size_t)(p - se);

@@ -35,7 +35,8 @@ static inline bool build_table(const uint8_t* lens, int n, int root, uint32_t* t
   for (int i = 0; i < n; i++) count[lens[i]]++;
   count[0] = 0;
   int left = 1; uint32_t next_code[16]; uint32_t code = 0;
-  for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return false; code = (code + (uint32_t)count[l - 1]) << 1; next_code[l] = code; }
+  for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return false; code = (code + (uint32_t)count[l - 1]) << 1;
+    next_code[l] = code; }
   const bool incomplete = left > 0;
   if (incomplete) {   // zlib's rule (inftrees.c): only "no codes at all" or "one code of one bit", and never for literal/length
     int longest = 0; for (int l = 1; l <= 15; l++) if (count[l]) longest = l;
@@ -52,7 +53,10 @@ static inline bool build_table(const uint8_t* lens, int n, int root, uint32_t* t
   if (any_long) {
     uint16_t prefixes[320]; int n_prefixes = 0;   // first-level slots that lead to a second-level table (at most one per long code)
     memset(submax, 0, root_size);
-    for (int s = 0; s < n; s++) if (lens[s] > root) { const uint32_t p = codes[s] & (root_size - 1); if (!submax[p]) prefixes[n_prefixes++] = (uint16_t)p; if (lens[s] > submax[p]) submax[p] = lens[s]; }
+    for (int s = 0; s < n; s++) if (lens[s] > root) { const uint32_t p = codes[s] & (root_size - 1);
+      if (!submax[p]) prefixes[n_prefixes++] = (uint16_t)p;
+      if (lens[s] > submax[p]) submax[p] = lens[s];
+      }
     for (int k = 0; k < n_prefixes; k++) {
       const uint32_t p = prefixes[k], sb = (uint32_t)submax[p] - (uint32_t)root;
       if (used + (1u << sb) > cap) return false;
@@ -90,9 +94,11 @@ static inline void pair_literals(uint32_t* tab) {
   }
 }
 
-static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227,
+    258};
 static const uint8_t LEN_XB[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
+    6145, 8193, 12289, 16385, 24577};
 static const uint8_t DIST_XB[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
 static inline uint32_t lit_entry(int s) {
@@ -140,7 +146,8 @@ static inline bool inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t
       uint32_t len, nlen; if (!take(16, &len) || !take(16, &nlen) || (len ^ 0xffffu) != nlen) return false;
       // bytes still in the bit buffer first, then straight from the input
       while (len && bc >= 8) { if (out >= out_end) return false; *out++ = (uint8_t)bb; bb >>= 8; bc -= 8; len--; }
-      if (len) { if (bc != 0) return false; if ((size_t)(in_end - in) < len || (size_t)(out_end - out) < len) return false; memcpy(out, in, len); in += len; out += len; }
+      if (len) { if (bc != 0) return false; if ((size_t)(in_end - in) < len || (size_t)(out_end - out) < len) return false; memcpy(out, in, len);
+        in += len; out += len; }
       if (final_blk) break; else continue;
     } else if (type == 1) { if (!fixed.ok) return false; T = &fixed.t; }
     else if (type == 2) {
@@ -154,9 +161,12 @@ static inline bool inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t
       uint32_t cltab[128];   // 7-bit single-level table of the code-length code
       { int count[8] = {0}; for (int i = 0; i < 19; i++) count[cl[i]]++; count[0] = 0;
         int left = 1; uint32_t next_code[8], code = 0;
-        for (int l = 1; l <= 7; l++) { left = (left << 1) - count[l]; if (left < 0) return false; code = (code + (uint32_t)count[l - 1]) << 1; next_code[l] = code; }
+        for (int l = 1; l <= 7; l++) { left = (left << 1) - count[l]; if (left < 0) return false; code = (code + (uint32_t)count[l - 1]) << 1;
+          next_code[l] = code; }
         if (left > 0) memset(cltab, 0, sizeof(cltab));
-        for (int s = 0; s < 19; s++) if (cl[s]) { const uint32_t r = rev_bits(next_code[cl[s]]++, cl[s]); for (uint32_t k = r; k < 128; k += 1u << cl[s]) cltab[k] = 0x80000000u | ((uint32_t)s << 8) | cl[s]; } }
+        for (int s = 0; s < 19; s++) if (cl[s]) { const uint32_t r = rev_bits(next_code[cl[s]]++, cl[s]);
+          for (uint32_t k = r; k < 128; k += 1u << cl[s]) cltab[k] = 0x80000000u | ((uint32_t)s << 8) | cl[s];
+          } }
       uint8_t lens[288 + 32]; uint32_t at = 0; const uint32_t total = hlit + hdist;
       while (at < total) {
         if (bc < 14) { refill_slow(); }
@@ -172,7 +182,8 @@ static inline bool inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t
         memset(lens + at, fill, rep); at += rep;
       }
       if (lens[256] == 0) return false;   // no end-of-block code
-      uint8_t ll[288], dl[32]; memcpy(ll, lens, hlit); memset(ll + hlit, 0, 288 - hlit); memcpy(dl, lens + hlit, hdist); memset(dl + hdist, 0, 32 - hdist);
+      uint8_t ll[288], dl[32]; memcpy(ll, lens, hlit); memset(ll + hlit, 0, 288 - hlit); memcpy(dl, lens + hlit, hdist);
+        memset(dl + hdist, 0, 32 - hdist);
       if (!build_table(ll, 288, LIT_BITS, dyn.lit, LIT_CAP, false, lit_entry)) return false;
       pair_literals(dyn.lit);
       if (!build_table(dl, 32, DIST_BITS, dyn.dist, DIST_CAP, true, dist_entry)) return false;   // one or no distance code is a legal incomplete code
@@ -202,17 +213,20 @@ static inline bool inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t
         bb >>= (e & 0xffu); bc -= (e & 0xffu);
         if (e & F_EOB) { eob = true; break; }
         {
-          const uint32_t lxb = (e >> 8) & 15u; const uint32_t len = ((e >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << lxb) - 1u)); bb >>= lxb; bc -= lxb;
+          const uint32_t lxb = (e >> 8) & 15u; const uint32_t len = ((e >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << lxb) - 1u)); bb >>= lxb;
+            bc -= lxb;
           if (len > 258) return false;
           uint32_t d = dt[bb & DMASK];
           if (d & F_SUB) { bb >>= DIST_BITS; bc -= DIST_BITS; d = dt[((d >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
           if (!d) return false;
           bb >>= (d & 0xffu); bc -= (d & 0xffu);
-          const uint32_t dxb = (d >> 8) & 15u; const uint32_t dist = ((d >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << dxb) - 1u)); bb >>= dxb; bc -= dxb;
+          const uint32_t dxb = (d >> 8) & 15u; const uint32_t dist = ((d >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << dxb) - 1u)); bb >>= dxb;
+            bc -= dxb;
           if (dist > (size_t)(out - dst) || dist > 32768u) return false;
           MKP_REFILL(); e = lt[bb & LMASK];   // the next symbol's entry is on its way while the match is copied
           const uint8_t* from = out - dist; uint8_t* const stop = out + len;
-          if (dist >= 8) {   // 16 bytes without a test (most matches are shorter: no loop branch to mispredict), word by word so that dist < 16 reads what it just wrote
+          // 16 bytes without a test (most matches are shorter: no loop branch to mispredict), word by word so that dist < 16 reads what it just wrote
+          if (dist >= 8) {
             uint64_t w; memcpy(&w, from, 8); memcpy(out, &w, 8); memcpy(&w, from + 8, 8); memcpy(out + 8, &w, 8);
             if (len > 16) { from += 16; out += 16; do { memcpy(&w, from, 8); memcpy(out, &w, 8); from += 8; out += 8; } while (out < stop); }
           }
@@ -235,10 +249,12 @@ static inline bool inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t
       for (;;) {
         refill_slow();
         uint32_t e = lt[bb & LMASK];
-        if (e & F_SUB) { if (bc < (uint32_t)LIT_BITS) return false; bb >>= LIT_BITS; bc -= LIT_BITS; e = lt[((e >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))]; }
+        if (e & F_SUB) { if (bc < (uint32_t)LIT_BITS) return false; bb >>= LIT_BITS; bc -= LIT_BITS;
+          e = lt[((e >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))]; }
         if (!e || (e & 0xffu) > bc) return false;
         bb >>= (e & 0xffu); bc -= (e & 0xffu);
-        if (e & F_LIT) { const uint32_t nl = 1u + ((e >> 11) & 1u); if ((size_t)(out_end - out) < nl) return false; out[0] = (uint8_t)(e >> 12); if (nl == 2) out[1] = (uint8_t)(e >> 20);
+        if (e & F_LIT) { const uint32_t nl = 1u + ((e >> 11) & 1u); if ((size_t)(out_end - out) < nl) return false; out[0] = (uint8_t)(e >> 12);
+          if (nl == 2) out[1] = (uint8_t)(e >> 20);
           out += nl; continue; }
         if (e & F_EOB) break;
         refill_slow();
@@ -246,7 +262,8 @@ static inline bool inflate(const uint8_t* src, size_t clen, uint8_t* dst, size_t
         const uint32_t len = ((e >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << lxb) - 1u)); bb >>= lxb; bc -= lxb;
         if (len > 258) return false;
         uint32_t d = dt[bb & DMASK];
-        if (d & F_SUB) { if (bc < (uint32_t)DIST_BITS) return false; bb >>= DIST_BITS; bc -= DIST_BITS; d = dt[((d >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
+        if (d & F_SUB) { if (bc < (uint32_t)DIST_BITS) return false; bb >>= DIST_BITS; bc -= DIST_BITS;
+          d = dt[((d >> 12) & 0xffffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))]; }
         if (!d || (d & 0xffu) > bc) return false;
         bb >>= (d & 0xffu); bc -= (d & 0xffu);
         refill_slow();

@@ -13,7 +13,8 @@
 namespace {
 // RFC 1951 §3.2.5 as arithmetic: length symbols 257..285 (ls = symbol - 257), distance symbols 0..29
 MKP_TOK_HD uint32_t len_extra(int ls) { return (ls < 8 || ls == 28) ? 0u : (uint32_t)(ls >> 2) - 1u; }
-MKP_TOK_HD uint32_t len_base(int ls) { return ls < 8 ? 3u + (uint32_t)ls : ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << ((uint32_t)(ls >> 2) - 1u)); }
+MKP_TOK_HD uint32_t len_base(int ls) {
+  return ls < 8 ? 3u + (uint32_t)ls : ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << ((uint32_t)(ls >> 2) - 1u)); }
 MKP_TOK_HD uint32_t dist_extra(int ds) { return ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u; }
 MKP_TOK_HD uint32_t dist_base(int ds) { return ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << ((uint32_t)(ds >> 1) - 1u)); }
 
@@ -34,7 +35,8 @@ MKP_TOK_HD uint16_t mkp_w4_lit_entry(uint32_t l, uint32_t sym) {
   const int ls = (int)sym - 257;
   return (uint16_t)(l | 16u | ((len_base(ls) - 3u) << 5) | (len_extra(ls) << 13));
 }
-MKP_TOK_HD uint16_t mkp_w4_dist_entry(uint32_t l, uint32_t ds) { return ds >= 30u ? (uint16_t)0 : (uint16_t)(l | (ds << 4) | (dist_extra((int)ds) << 9)); }
+MKP_TOK_HD uint16_t mkp_w4_dist_entry(uint32_t l, uint32_t ds) {
+  return ds >= 30u ? (uint16_t)0 : (uint16_t)(l | (ds << 4) | (dist_extra((int)ds) << 9)); }
 MKP_TOK_HD uint16_t mkp_w4_plain_entry(uint32_t l, uint32_t sym) { return (uint16_t)(l | (sym << 4)); }   // (the code-length code)
 
 // What lane k reports for bit position pos + k: nx = the bits the token takes if the pass can place it as it is (a literal, or a match of at

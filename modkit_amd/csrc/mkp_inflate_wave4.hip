@@ -60,11 +60,15 @@ struct Spec4Lds {   // 6 144 bytes + the ring: 10 240 with a 4 KiB ring = sixtee
 // direct table + canonical lists from lens[0, n): all lanes.  ENC(code length, symbol) = the table entry.  Returns 0 complete, > 0
 // incomplete, < 0 over-subscribed.
 template <class ENC>
-__device__ __forceinline__ int build(const uint8_t* lens, int n, uint16_t* tab, uint32_t tab_bits, uint16_t* count, uint16_t* syms, int lane, ENC enc) {
+__device__ __forceinline__ int build(const uint8_t* lens, int n, uint16_t* tab, uint32_t tab_bits, uint16_t* count, uint16_t* syms, int lane,
+    ENC enc) {
   if (lane < 16) count[lane] = 0;
   for (uint32_t i = (uint32_t)lane; i < (1u << tab_bits); i += 64u) tab[i] = 0;
   LDS_SYNC();
-  for (int s = lane; s < n; s += 64) { const uint32_t l = lens[s]; if (l) atomicAdd(reinterpret_cast<uint32_t*>(count) + (l >> 1), (l & 1u) ? 0x10000u : 1u); }   // two u16 counters per dword
+  // two u16 counters per dword
+  for (int s = lane; s < n; s += 64) { const uint32_t l = lens[s];
+    if (l) atomicAdd(reinterpret_cast<uint32_t*>(count) + (l >> 1), (l & 1u) ? 0x10000u : 1u);
+    }
   LDS_SYNC();
   uint32_t next_code[16], offs[16]; int left = 1; uint32_t code = 0, off = 0; uint32_t used = 0;
   next_code[0] = 0; offs[0] = 0;
@@ -101,9 +105,12 @@ __device__ __forceinline__ uint32_t cl_order(int i) {
 template <uint32_t RINGSZ>
 __device__ __forceinline__ void flush_ring(const uint8_t* ring, uint8_t* __restrict__ o, uint32_t from, uint32_t to, int lane) {
   uint32_t a = from;
-  if (a & 15u) { const uint32_t head = min(to, (a + 15u) & ~15u); for (uint32_t k = a + (uint32_t)lane; k < head; k += 64u) o[k] = ring[k & (RINGSZ - 1u)]; a = head; }
+  if (a & 15u) { const uint32_t head = min(to, (a + 15u) & ~15u);
+    for (uint32_t k = a + (uint32_t)lane; k < head; k += 64u) o[k] = ring[k & (RINGSZ - 1u)];
+    a = head; }
   const uint32_t units = (to - a) >> 4;
-  for (uint32_t u = (uint32_t)lane; u < units; u += 64u) { const uint32_t at = a + 16u * u; uint4 v = *reinterpret_cast<const uint4*>(ring + (at & (RINGSZ - 1u))); __builtin_memcpy(o + at, &v, 16); }
+  for (uint32_t u = (uint32_t)lane; u < units; u += 64u) { const uint32_t at = a + 16u * u;
+    uint4 v = *reinterpret_cast<const uint4*>(ring + (at & (RINGSZ - 1u))); __builtin_memcpy(o + at, &v, 16); }
   for (uint32_t k = a + 16u * units + (uint32_t)lane; k < to; k += 64u) o[k] = ring[k & (RINGSZ - 1u)];
 }
 
@@ -156,7 +163,8 @@ struct Hdr {
     const uint32_t v = (uint32_t)(cb >> (pos - cpos)) & ((1u << k) - 1u);
     pos += k; return v;
   }
-  __device__ __forceinline__ uint32_t peek16(In2& in, uint32_t pos, int lane) { if (pos + 16u > cpos + 64u) load(in, pos, lane); return (uint32_t)(cb >> (pos - cpos)) & 0xffffu; }
+  __device__ __forceinline__ uint32_t peek16(In2& in, uint32_t pos, int lane) { if (pos + 16u > cpos + 64u) load(in, pos, lane);
+    return (uint32_t)(cb >> (pos - cpos)) & 0xffffu; }
 };
 
 // canonical decode (RFC 1951 §3.2.2) of the code starting at the low end of `bits`; returns the symbol or -1, its length in *l
@@ -207,7 +215,8 @@ __device__ __forceinline__ OneTok one_token(const In2& in, const LDS& L, uint32_
 // takes its bytes from the flushed output (always flushed: the unflushed tail is at most a quarter + one pass + one long match), one
 // agent-scope load for all such lanes of a pass.
 template <uint32_t RINGSZ, bool FARM>
-__device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+__device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks,
+    uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
   __shared__ __attribute__((aligned(16))) Spec4Lds<RINGSZ> L;
   constexpr uint32_t RING = RINGSZ, FLQ = RINGSZ >= 32768u ? RINGSZ / 2u : RINGSZ / 4u, NEAR = RINGSZ - 128u;
   const uint32_t bi = blockIdx.x;
@@ -251,11 +260,13 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
         LDS_SYNC();
         for (int idx = 0; idx < ncode; idx++) { const uint32_t v = h.get(in, pos, 3, lane); if (lane == 0) L.lens[cl_order(idx)] = (uint8_t)v; }
         LDS_SYNC();
-        if (build(L.lens, 19, L.dist, DIST_BITS, L.dcount, L.dsym, lane, mkp_w4_plain_entry) != 0) { err = 3; break; }   // the code-length code, in the distance table's storage; must be complete
+        // the code-length code, in the distance table's storage; must be complete
+        if (build(L.lens, 19, L.dist, DIST_BITS, L.dcount, L.dsym, lane, mkp_w4_plain_entry) != 0) { err = 3; break; }
         __builtin_amdgcn_wave_barrier();
         int idx = 0;
         while (idx < nlen + ndist) {
-          const uint32_t e = sgpr(L.dist[h.peek16(in, pos, lane) & ((1u << DIST_BITS) - 1u)]);   // (a code-length code has at most 7 bits: always in the table)
+          // (a code-length code has at most 7 bits: always in the table)
+          const uint32_t e = sgpr(L.dist[h.peek16(in, pos, lane) & ((1u << DIST_BITS) - 1u)]);
           if (!(e & 15u)) { err = 4; break; }
           pos += (e & 15u);
           const int sym = (int)(e >> 4);
@@ -289,7 +300,8 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
           if (e1 < 0 || (e1 > 0 && !(used1 == 1u && sgpr(L.lcount[1]) == 1u))) { err = 3; break; } }
         const int e2 = build(L.lens + 288, ndist_codes, L.dist, DIST_BITS, L.dcount, L.dsym, lane, mkp_w4_dist_entry);
         uint32_t used2 = 0; for (int l = 1; l <= 15; l++) used2 += sgpr(L.dcount[l]);
-        if (e2 < 0 || (e2 > 0 && !(used2 == 1u && sgpr(L.dcount[1]) == 1u))) { err = 3; break; }   // incomplete distance code: only a single one-bit code
+        // incomplete distance code: only a single one-bit code
+        if (e2 < 0 || (e2 > 0 && !(used2 == 1u && sgpr(L.dcount[1]) == 1u))) { err = 3; break; }
       }
       LDS_SYNC();   // (lens is dead from here on: its storage is the passes' head slots)
       // tokens until end of block (§3.2.5), 64 bit positions per pass
@@ -303,16 +315,20 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
         // which carries i past every in-range value: one compare per token
         uint32_t i = 0; unsigned long long chain = 0;
         do { chain |= 1ull << i; i += (uint32_t)__builtin_amdgcn_readlane((int)t.nx, (int)i); } while (i < 64u);
-        uint32_t stop_nx = 0;   // i = bit offset of the first position beyond the chain; stop_nx = what that position reported, if the walk stopped on it
-        if (i >= MKP_NX_STOP) { i = 63u - (uint32_t)__builtin_clzll(chain); chain &= ~(1ull << i); stop_nx = (uint32_t)__builtin_amdgcn_readlane((int)t.nx, (int)i); }
+        // i = bit offset of the first position beyond the chain; stop_nx = what that position reported, if the walk stopped on it
+        uint32_t stop_nx = 0;
+        if (i >= MKP_NX_STOP) { i = 63u - (uint32_t)__builtin_clzll(chain); chain &= ~(1ull << i);
+          stop_nx = (uint32_t)__builtin_amdgcn_readlane((int)t.nx, (int)i); }
         const bool in_chain = (chain >> lane) & 1ull;
         const uint32_t ol = in_chain ? t.ol : 0u;
         const uint32_t incl = wave_incl_scan(ol), excl = incl - ol;
-        // the pass takes the longest prefix of the chain that fits 64 output lanes, the block's size, and whose distances reach no further than the output so far
+        // the pass takes the longest prefix of the chain that fits 64 output lanes, the block's size, and whose distances reach no further than the
+        // output so far
         const bool ok = incl <= 64u && w + incl <= cap && ((t.desc & LITERAL) || t.desc <= w + excl);
         const unsigned long long rej = __builtin_amdgcn_ballot_w64(in_chain && !ok);
         unsigned long long acc = chain; uint32_t adv = i, n_out; bool special;
-        if (rej) { const uint32_t first = (uint32_t)__builtin_ctzll(rej); acc = chain & ((1ull << first) - 1ull); adv = first; n_out = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)first); special = first == 0u; }
+        if (rej) { const uint32_t first = (uint32_t)__builtin_ctzll(rej); acc = chain & ((1ull << first) - 1ull); adv = first;
+          n_out = (uint32_t)__builtin_amdgcn_readlane((int)excl, (int)first); special = first == 0u; }
         else { n_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63); special = i < 64u; }
         if (n_out) {
           // byte j -> its token: descriptors dropped at the tokens' first output lanes, then "the nearest non-empty slot at or below j"
@@ -322,7 +338,8 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
           const uint32_t hv = L.hd[lane];
           const unsigned long long heads = __builtin_amdgcn_ballot_w64(hv != 0u);
           const uint32_t mhi = (uint32_t)(heads >> 32) & le_hi, mlo = (uint32_t)heads & le_lo;
-          const uint32_t hj = mhi ? 63u - (uint32_t)__builtin_clz(mhi) : 31u - (uint32_t)__builtin_clz(mlo | 1u);   // (lane 0 is a head whenever n_out > 0)
+          // (lane 0 is a head whenever n_out > 0)
+          const uint32_t hj = mhi ? 63u - (uint32_t)__builtin_clz(mhi) : 31u - (uint32_t)__builtin_clz(mlo | 1u);
           const uint32_t desc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(hj << 2), (int)hv);
           uint32_t sv = (uint32_t)lane < n_out ? mkp_w4_source(desc, (uint32_t)lane, w, M, NEAR, FARM) : LITERAL;
           // bytes produced earlier in this pass: follow the references until every lane names a literal, the ring or the flushed output
@@ -331,7 +348,9 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
             if ((sv & (LITERAL | MKP_SV_INPASS)) == MKP_SV_INPASS) sv = other;
           }
           uint32_t r_ = L.ring[sv & M];
-          if (FARM) { const bool far_ = (sv & (LITERAL | MKP_SV_FAR)) == MKP_SV_FAR; if (__builtin_amdgcn_ballot_w64(far_)) { if (far_) r_ = far_byte(o + (sv & 0xfffffu)); } }
+          if (FARM) { const bool far_ = (sv & (LITERAL | MKP_SV_FAR)) == MKP_SV_FAR; if (__builtin_amdgcn_ballot_w64(far_)) {
+              if (far_) r_ = far_byte(o + (sv & 0xfffffu));
+            } }
           if ((uint32_t)lane < n_out) L.ring[(w + (uint32_t)lane) & M] = (uint8_t)((sv & LITERAL) ? sv : r_);
           w += n_out;
         }
@@ -363,13 +382,15 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
               for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) L.ring[(w + k2) & M] = v;
             } else {   // the source cycle, lane k at k mod dist: one division, then steps of 64 mod dist
               const uint32_t step = 64u % dist; uint32_t r = (uint32_t)lane % dist;
-              for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) { L.ring[(w + k2) & M] = L.ring[(src0 + r) & M]; r += step; r -= r >= dist ? dist : 0u; }
+              for (uint32_t k2 = (uint32_t)lane; k2 < len; k2 += 64u) { L.ring[(w + k2) & M] = L.ring[(src0 + r) & M]; r += step;
+                r -= r >= dist ? dist : 0u; }
             }
             w += len;
           }
         }
         // a quarter of the ring is complete: it goes out in one coalesced sweep, long before the write position comes round to it again
-        if ((w & ~(FLQ - 1u)) > flushed) { const uint32_t upto = w & ~(FLQ - 1u); LDS_SYNC(); flush_ring<RINGSZ>(L.ring, o, flushed, upto, lane); flushed = upto;
+        if ((w & ~(FLQ - 1u)) > flushed) { const uint32_t upto = w & ~(FLQ - 1u); LDS_SYNC(); flush_ring<RINGSZ>(L.ring, o, flushed, upto, lane);
+          flushed = upto;
           if (FARM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
       }
     } else { err = 2; break; }
@@ -382,23 +403,29 @@ __device__ __forceinline__ void inflate_wave_par(const uint8_t* __restrict__ in_
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-mkp_inflate_wave4(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+mkp_inflate_wave4(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out,
+    uint32_t* __restrict__ status) {
   inflate_wave_par<4096u, true>(in_bytes, blocks, n_blocks, out, status);
 }
-// ring-size variants for A/B runs (MKP_INFLATE_KERNEL=wave4_8k | wave4_2k): 8 KiB = 11 waves per CU and fewer far reads, 2 KiB = more of them (and no more waves: 16 per CU is the VGPR limit)
+// ring-size variants for A/B runs (MKP_INFLATE_KERNEL=wave4_8k | wave4_2k): 8 KiB = 11 waves per CU and fewer far reads, 2 KiB = more of them (and no
+// more waves: 16 per CU is the VGPR limit)
 extern "C" __global__ void __launch_bounds__(64)
-mkp_inflate_wave4_8k(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+mkp_inflate_wave4_8k(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out,
+    uint32_t* __restrict__ status) {
   inflate_wave_par<8192u, true>(in_bytes, blocks, n_blocks, out, status);
 }
 extern "C" __global__ void __launch_bounds__(64)
-mkp_inflate_wave4_2k(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status) {
+mkp_inflate_wave4_2k(const uint8_t* __restrict__ in_bytes, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out,
+    uint32_t* __restrict__ status) {
   inflate_wave_par<2048u, true>(in_bytes, blocks, n_blocks, out, status);
 }
 
-extern "C" hipError_t mkp_launch_inflate_wave4(hipStream_t st, const uint8_t* in, const void* blocks, uint32_t n_blocks, uint8_t* out, uint32_t* status, int variant) {
+extern "C" hipError_t mkp_launch_inflate_wave4(hipStream_t st, const uint8_t* in, const void* blocks, uint32_t n_blocks, uint8_t* out,
+    uint32_t* status, int variant) {
   if (!n_blocks) return hipSuccess;
   if (variant == 8) hipLaunchKernelGGL(mkp_inflate_wave4_8k, dim3(n_blocks), dim3(64), 0, st, in, (const MkpBgzfBlock*)blocks, n_blocks, out, status);
-  else if (variant == 2) hipLaunchKernelGGL(mkp_inflate_wave4_2k, dim3(n_blocks), dim3(64), 0, st, in, (const MkpBgzfBlock*)blocks, n_blocks, out, status);
+  else if (variant == 2) hipLaunchKernelGGL(mkp_inflate_wave4_2k, dim3(n_blocks), dim3(64), 0, st, in, (const MkpBgzfBlock*)blocks, n_blocks, out,
+      status);
   else hipLaunchKernelGGL(mkp_inflate_wave4, dim3(n_blocks), dim3(64), 0, st, in, (const MkpBgzfBlock*)blocks, n_blocks, out, status);
   return hipGetLastError();
 }

@@ -50,7 +50,8 @@ __device__ __forceinline__ uint32_t crc_slice(const uint8_t* __restrict__ p, uin
   uint32_t k = 0;
   for (; k + 4u <= nd; k += 4u) {
     uint4 nx; __builtin_memcpy(&nx, q + k + 4u, 16);
-    const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, off), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, off), d2 = __builtin_amdgcn_alignbyte(w.w, w.z, off), d3 = __builtin_amdgcn_alignbyte(nx.x, w.w, off);
+    const uint32_t d0 = __builtin_amdgcn_alignbyte(w.y, w.x, off), d1 = __builtin_amdgcn_alignbyte(w.z, w.y, off),
+        d2 = __builtin_amdgcn_alignbyte(w.w, w.z, off), d3 = __builtin_amdgcn_alignbyte(nx.x, w.w, off);
     c ^= d0; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
     c ^= d1; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
     c ^= d2; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24];
@@ -59,9 +60,11 @@ __device__ __forceinline__ uint32_t crc_slice(const uint8_t* __restrict__ p, uin
   }
   // up to three dwords and three bytes left, all inside w and the dword behind it
   const uint32_t e = q[k + 4u];
-  const uint32_t r[4] = {__builtin_amdgcn_alignbyte(w.y, w.x, off), __builtin_amdgcn_alignbyte(w.z, w.y, off), __builtin_amdgcn_alignbyte(w.w, w.z, off), __builtin_amdgcn_alignbyte(e, w.w, off)};
+  const uint32_t r[4] = {__builtin_amdgcn_alignbyte(w.y, w.x, off), __builtin_amdgcn_alignbyte(w.z, w.y, off),
+      __builtin_amdgcn_alignbyte(w.w, w.z, off), __builtin_amdgcn_alignbyte(e, w.w, off)};
   uint32_t j = 0;
-  for (; k < nd; k++, j++) { const uint32_t d = j == 0 ? r[0] : j == 1 ? r[1] : r[2]; c ^= d; c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24]; }
+  for (; k < nd; k++, j++) { const uint32_t d = j == 0 ? r[0] : j == 1 ? r[1] : r[2]; c ^= d;
+    c = T[768u + (c & 0xffu)] ^ T[512u + ((c >> 8) & 0xffu)] ^ T[256u + ((c >> 16) & 0xffu)] ^ T[c >> 24]; }
   uint32_t tail = j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
   for (uint32_t b = 0; b < (n & 3u); b++) { c = T[(c ^ tail) & 0xffu] ^ (c >> 8); tail >>= 8; }
   return c;
@@ -69,24 +72,28 @@ __device__ __forceinline__ uint32_t crc_slice(const uint8_t* __restrict__ p, uin
 }  // namespace
 
 extern "C" __global__ void __launch_bounds__(256)
-mkp_crc32_blocks(const uint8_t* __restrict__ zin, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, const uint8_t* __restrict__ raw, uint32_t* __restrict__ status) {
+mkp_crc32_blocks(const uint8_t* __restrict__ zin, const MkpBgzfBlock* __restrict__ blocks, uint32_t n_blocks, const uint8_t* __restrict__ raw,
+    uint32_t* __restrict__ status) {
   __shared__ uint32_t T[1024];   // T[0..255]: the byte table; T[256 k + i] = the CRC register after byte i followed by k zero bytes
   { uint32_t c = threadIdx.x; for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ MKP_CRC_POLY : c >> 1; T[threadIdx.x] = c; }
   __syncthreads();
-  for (uint32_t k = 1; k < 4u; k++) { const uint32_t v = T[256u * (k - 1u) + threadIdx.x]; T[256u * k + threadIdx.x] = (v >> 8) ^ T[v & 0xffu]; __syncthreads(); }
+  for (uint32_t k = 1; k < 4u; k++) { const uint32_t v = T[256u * (k - 1u) + threadIdx.x]; T[256u * k + threadIdx.x] = (v >> 8) ^ T[v & 0xffu];
+    __syncthreads(); }
   const uint32_t bi = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (bi >= n_blocks) return;
   const MkpBgzfBlock bk = blocks[bi];
   const uint32_t len = bk.out_len;
   const uint32_t S = (len / 64u) & ~3u;                 // slice of lanes 1..63 (<= 1024)
   const uint32_t first = len - 63u * S;                 // lane 0
-  uint32_t c = crc_slice(raw + bk.out_off + (lane ? first + (lane - 1u) * S : 0u), lane ? S : first, lane ? 0u : 0xffffffffu, T);   // the conditioning (initial all-ones) belongs to the first slice only
+  // the conditioning (initial all-ones) belongs to the first slice only
+  uint32_t c = crc_slice(raw + bk.out_off + (lane ? first + (lane - 1u) * S : 0u), lane ? S : first, lane ? 0u : 0xffffffffu, T);
   // join: at level L lanes with bit L clear hold a left operand whose right neighbour covers S << L bytes
   for (uint32_t L = 0; L < 6u; L++) {
     const uint32_t sh = kXpow.v[L][S >> 2];
     const uint32_t other = (uint32_t)__shfl_xor((int)c, 1 << L);
     const bool left = ((lane >> L) & 1u) == 0u;
-    c = gf2_mulmod(left ? c : other, sh) ^ (left ? other : c);   // both lanes of a pair now hold the pair's CRC; only lanes with the low L+1 bits clear matter from here on
+    // both lanes of a pair now hold the pair's CRC; only lanes with the low L+1 bits clear matter from here on
+    c = gf2_mulmod(left ? c : other, sh) ^ (left ? other : c);
   }
   if (lane == 0) {
     uint32_t want; __builtin_memcpy(&want, zin + bk.in_off + bk.in_len, 4);
@@ -113,7 +120,8 @@ __device__ __forceinline__ unsigned long long block_scan_inplace(uint32_t* __res
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
     if (lane == 63u) wtot[wv] = incl;
     __syncthreads();
-    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x; } tile_total = run; }
+    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x;
+      } tile_total = run; }
     __syncthreads();
     unsigned long long run = carry + wtot[wv] + incl - mine;
 #pragma unroll
@@ -136,7 +144,8 @@ mkp_bgzf_chain_scan(uint32_t* __restrict__ cnt, uint32_t n, uint32_t* err) {
   if (threadIdx.x == 0) { if (total > 0xfffffff0ull) { atomicOr(err, MKP_ZE_BAD); cnt[n] = 0; } else cnt[n] = (uint32_t)total; }
 }
 extern "C" __global__ void __launch_bounds__(256)
-mkp_bgzf_chain_write(const uint8_t* __restrict__ z, const MkpZChain* __restrict__ chains, uint32_t n, const uint32_t* __restrict__ base, uint32_t cap, MkpZBlk* __restrict__ out, uint32_t* err) {
+mkp_bgzf_chain_write(const uint8_t* __restrict__ z, const MkpZChain* __restrict__ chains, uint32_t n, const uint32_t* __restrict__ base, uint32_t cap,
+    MkpZBlk* __restrict__ out, uint32_t* err) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (base[i + 1] > cap) { atomicOr(err, MKP_ZE_BAD); return; }
@@ -147,7 +156,8 @@ mkp_bgzf_chain_write(const uint8_t* __restrict__ z, const MkpZChain* __restrict_
 // window — an exclusive scan of ISIZE behind *raw_cursor, which moves on by the stage's total.  One workgroup.  A block that claims more than
 // 64 KiB, or a window that would not fit raw_cap, raises the error bits (the host then falls back to an exact allocation).
 extern "C" __global__ void __launch_bounds__(1024)
-mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap, MkpBgzfBlock* __restrict__ out, uint32_t* err) {
+mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap,
+    MkpBgzfBlock* __restrict__ out, uint32_t* err) {
   __shared__ unsigned long long wtot[16];
   __shared__ unsigned long long tile_total;
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
@@ -162,7 +172,8 @@ mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* 
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d); if ((int)lane >= d) incl += o; }
     if (lane == 63u) wtot[wv] = incl;
     __syncthreads();
-    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x; } tile_total = run; }
+    if (t == 0) { unsigned long long run = 0; for (uint32_t k = 0; k < 16u; k++) { const unsigned long long x = wtot[k]; wtot[k] = run; run += x;
+      } tile_total = run; }
     __syncthreads();
     if (i < n) {
       MkpBgzfBlock b; b.in_off = z.coff + z.hdr; b.out_off = base0 + carry + wtot[wv] + incl - z.isize; b.in_len = z.clen; b.out_len = z.isize;
@@ -178,7 +189,8 @@ mkp_bgzf_layout(const MkpZBlk* __restrict__ zb, uint32_t n, unsigned long long* 
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, uint32_t* __restrict__ seg_cnt, MkpIngestTotals* tot) {
+mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, uint32_t* __restrict__ seg_cnt,
+    MkpIngestTotals* tot) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_seg) return;
   seg_cnt[i] = ingest_walk_segment(raw, P.raw_len, segs[i], nullptr, &tot->err);
@@ -188,20 +200,24 @@ mkp_ingest_count(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSe
 extern "C" __global__ void __launch_bounds__(1024)
 mkp_ingest_scan_segs(uint32_t* __restrict__ seg_cnt, uint32_t n, MkpIngestTotals* tot) {
   const unsigned long long total = block_scan_inplace(seg_cnt, n);
-  if (threadIdx.x == 0) { if (total > 0xfffffff0ull) { atomicOr(&tot->err, MKP_IE_TABLE); tot->n_all = 0; } else tot->n_all = (uint32_t)total; seg_cnt[n] = (uint32_t)total; }
+  if (threadIdx.x == 0) { if (total > 0xfffffff0ull) { atomicOr(&tot->err, MKP_IE_TABLE); tot->n_all = 0; } else tot->n_all = (uint32_t)total;
+    seg_cnt[n] = (uint32_t)total; }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-mkp_ingest_write(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, const uint32_t* __restrict__ seg_base, unsigned long long* __restrict__ rec_off, MkpIngestTotals* tot) {
+mkp_ingest_write(const uint8_t* __restrict__ raw, MkpIngestParams P, const MkpSeg* __restrict__ segs, const uint32_t* __restrict__ seg_base,
+    unsigned long long* __restrict__ rec_off, MkpIngestTotals* tot) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_seg) return;
   if ((unsigned long long)seg_base[i + 1] > (unsigned long long)P.rec_cap) { atomicOr(&tot->err, MKP_IE_TABLE); return; }
   ingest_walk_segment(raw, P.raw_len, segs[i], rec_off + seg_base[i], &tot->err);
 }
 
-// per record: checks, region test, aux walk; sizes of the packed ones into sz[6][rec_cap] (kept, CIGAR words, chunk pairs, SEQ bytes, ML bytes, sampler-only)
+// per record: checks, region test, aux walk; sizes of the packed ones into sz[6][rec_cap] (kept, CIGAR words, chunk pairs, SEQ bytes, ML bytes,
+// sampler-only)
 extern "C" __global__ void __launch_bounds__(256)
-mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const int32_t* __restrict__ parts, const unsigned long long* __restrict__ rec_off, MkpRecInfo* __restrict__ info,
+mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const int32_t* __restrict__ parts,
+    const unsigned long long* __restrict__ rec_off, MkpRecInfo* __restrict__ info,
                  uint32_t* __restrict__ sz, int32_t* __restrict__ extra, MkpIngestTotals* tot) {
   const uint32_t n = min(tot->n_all, P.rec_cap);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -215,7 +231,8 @@ mkp_ingest_parse(const uint8_t* __restrict__ raw, MkpIngestParams P, const int32
     sz[4 * (size_t)P.rec_cap + i] = pk ? R.ml_n : 0u;
     sz[5 * (size_t)P.rec_cap + i] = R.kind == 3 ? 1u : 0u;
     if (R.kind == 2) { const uint32_t at = atomicAdd(&tot->n_extra, 1u); extra[2 * (size_t)at] = R.pos;
-      const long long e = (long long)R.pos + (R.reflen > 0 ? R.reflen : 1); extra[2 * (size_t)at + 1] = (int32_t)(e > 0x7fffffffll ? 0x7fffffffll : e); }
+      const long long e = (long long)R.pos + (R.reflen > 0 ? R.reflen : 1);
+        extra[2 * (size_t)at + 1] = (int32_t)(e > 0x7fffffffll ? 0x7fffffffll : e); }
   }
 }
 
@@ -226,7 +243,10 @@ mkp_ingest_scan_sizes(uint32_t* __restrict__ sz, uint32_t rec_cap, MkpIngestTota
   const unsigned long long total = block_scan_inplace(sz + (size_t)q * rec_cap, n);
   if (threadIdx.x == 0) {
     if (total > 0xfffffff0ull) atomicOr(&tot->err, MKP_IE_4G);
-    if (q == 0) tot->n_kept = (uint32_t)total; else if (q == 1) tot->cigar_words = total; else if (q == 2) tot->chunk_pairs = total; else if (q == 3) tot->seq_bytes = total; else if (q == 4) tot->ml_bytes = total; else tot->n_sample_only = (uint32_t)total;
+    if (q == 0) tot->n_kept = (uint32_t)total; else if (q == 1) tot->cigar_words = total; else if (q == 2) tot->chunk_pairs = total;
+      else if (q == 3) tot->seq_bytes = total;
+      else if (q == 4) tot->ml_bytes = total;
+      else tot->n_sample_only = (uint32_t)total;
   }
 }
 
@@ -239,7 +259,8 @@ mkp_ingest_pack(const uint8_t* __restrict__ raw, uint32_t rec_cap, const MkpRecI
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const MkpRecInfo R = info[i];
     if (R.kind != 1 && R.kind != 3) continue;
-    const uint32_t j = R.kind == 1 ? sz[i] : tot->n_kept + sz[5 * (size_t)rec_cap + i];   // headers: the kept records in file order, then the sampler-only ones
+    // headers: the kept records in file order, then the sampler-only ones
+    const uint32_t j = R.kind == 1 ? sz[i] : tot->n_kept + sz[5 * (size_t)rec_cap + i];
     ingest_pack_record(raw, R, i, j, sz[(size_t)rec_cap + i], sz[2 * (size_t)rec_cap + i], sz[3 * (size_t)rec_cap + i], sz[4 * (size_t)rec_cap + i],
                        hdr, chunk_pfx, tagref, ranks, dig, tot);
   }
@@ -274,11 +295,13 @@ hipError_t mkp_launch_bgzf_chain_count(hipStream_t st, const uint8_t* z, const M
   hipLaunchKernelGGL(mkp_bgzf_chain_scan, dim3(1), dim3(1024), 0, st, cnt, n, err);
   return hipGetLastError();
 }
-hipError_t mkp_launch_bgzf_chain_write(hipStream_t st, const uint8_t* z, const MkpZChain* chains, uint32_t n, const uint32_t* base, uint32_t cap, MkpZBlk* out, uint32_t* err) {
+hipError_t mkp_launch_bgzf_chain_write(hipStream_t st, const uint8_t* z, const MkpZChain* chains, uint32_t n, const uint32_t* base, uint32_t cap,
+    MkpZBlk* out, uint32_t* err) {
   if (n) hipLaunchKernelGGL(mkp_bgzf_chain_write, dim3((n + 255u) / 256u), dim3(256), 0, st, z, chains, n, base, cap, out, err);
   return hipGetLastError();
 }
-hipError_t mkp_launch_bgzf_layout(hipStream_t st, const MkpZBlk* zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap, void* out, uint32_t* err) {
+hipError_t mkp_launch_bgzf_layout(hipStream_t st, const MkpZBlk* zb, uint32_t n, unsigned long long* raw_cursor, unsigned long long raw_cap,
+    void* out, uint32_t* err) {
   hipLaunchKernelGGL(mkp_bgzf_layout, dim3(1), dim3(1024), 0, st, zb, n, raw_cursor, raw_cap, (MkpBgzfBlock*)out, err);
   return hipGetLastError();
 }
@@ -287,12 +310,14 @@ hipError_t mkp_launch_crc32(hipStream_t st, const uint8_t* zin, const void* bloc
   hipLaunchKernelGGL(mkp_crc32_blocks, dim3((n_blocks + 3u) / 4u), dim3(256), 0, st, zin, (const MkpBgzfBlock*)blocks, n_blocks, raw, status);
   return hipGetLastError();
 }
-hipError_t mkp_launch_ingest_count(hipStream_t st, const uint8_t* raw, const MkpIngestParams* P, const MkpSeg* segs, uint32_t* seg_cnt, MkpIngestTotals* tot) {
+hipError_t mkp_launch_ingest_count(hipStream_t st, const uint8_t* raw, const MkpIngestParams* P, const MkpSeg* segs, uint32_t* seg_cnt,
+    MkpIngestTotals* tot) {
   if (P->n_seg) hipLaunchKernelGGL(mkp_ingest_count, dim3((P->n_seg + 255u) / 256u), dim3(256), 0, st, raw, *P, segs, seg_cnt, tot);
   hipLaunchKernelGGL(mkp_ingest_scan_segs, dim3(1), dim3(1024), 0, st, seg_cnt, P->n_seg, tot);
   return hipGetLastError();
 }
-hipError_t mkp_launch_ingest_parse(hipStream_t st, const uint8_t* raw, const MkpIngestParams* P, const int32_t* parts, const MkpSeg* segs, const uint32_t* seg_base, unsigned long long* rec_off,
+hipError_t mkp_launch_ingest_parse(hipStream_t st, const uint8_t* raw, const MkpIngestParams* P, const int32_t* parts, const MkpSeg* segs,
+    const uint32_t* seg_base, unsigned long long* rec_off,
                                    MkpRecInfo* info, uint32_t* sz, int32_t* extra, MkpIngestTotals* tot) {
   if (P->n_seg) hipLaunchKernelGGL(mkp_ingest_write, dim3((P->n_seg + 255u) / 256u), dim3(256), 0, st, raw, *P, segs, seg_base, rec_off, tot);
   const uint32_t grid = P->rec_cap ? (uint32_t)((P->rec_cap + 255u) / 256u < 8192u ? (P->rec_cap + 255u) / 256u : 8192u) : 1u;
@@ -300,8 +325,10 @@ hipError_t mkp_launch_ingest_parse(hipStream_t st, const uint8_t* raw, const Mkp
   hipLaunchKernelGGL(mkp_ingest_scan_sizes, dim3(6), dim3(1024), 0, st, sz, P->rec_cap, tot);
   return hipGetLastError();
 }
-hipError_t mkp_launch_ingest_pack(hipStream_t st, const uint8_t* raw, uint32_t rec_cap, const MkpRecInfo* info, const uint32_t* sz, MkpReadHdr* hdr, uint32_t* cigar,
-                                  uint32_t* chunk_pfx, uint8_t* seq, MkpTagRef* tagref, uint32_t* ranks, uint8_t* ml, MkpRecDigest* dig, MkpIngestTotals* tot) {
+hipError_t mkp_launch_ingest_pack(hipStream_t st, const uint8_t* raw, uint32_t rec_cap, const MkpRecInfo* info, const uint32_t* sz, MkpReadHdr* hdr,
+    uint32_t* cigar,
+                                  uint32_t* chunk_pfx, uint8_t* seq, MkpTagRef* tagref, uint32_t* ranks, uint8_t* ml, MkpRecDigest* dig,
+                                      MkpIngestTotals* tot) {
   const uint32_t grid = rec_cap ? (uint32_t)((rec_cap + 255u) / 256u < 8192u ? (rec_cap + 255u) / 256u : 8192u) : 1u;
   hipLaunchKernelGGL(mkp_ingest_pack, dim3(grid), dim3(256), 0, st, raw, rec_cap, info, sz, hdr, chunk_pfx, tagref, ranks, dig, tot);
   const uint32_t cgrid = rec_cap ? (uint32_t)((rec_cap + 3u) / 4u < 16384u ? (rec_cap + 3u) / 4u : 16384u) : 1u;

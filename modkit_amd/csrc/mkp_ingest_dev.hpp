@@ -38,14 +38,16 @@
 #define MKP_IE_TAGS 256u         // more than 8 MM tags in one read
 #define MKP_IE_4G 512u           // packed shard exceeds 4 GiB of one array
 
-struct MkpSeg { unsigned long long start, stop; uint32_t exact, pad; };   // records starting in [start, stop - 3); exact: the chain must land on `stop`
+// records starting in [start, stop - 3); exact: the chain must land on `stop`
+struct MkpSeg { unsigned long long start, stop; uint32_t exact, pad; };
 
 struct MkpIngestParams {
   unsigned long long raw_len;   // bytes of the inflated window
   int32_t tid, beg, end;        // region test of the fetch: records of `tid` with pos < end and endpos > beg
   int32_t n_ref;
   uint32_t n_seg, rec_cap;
-  uint32_t n_parts, pad;        // > 1: the fetch is the union of n_parts windows (ascending, disjoint {beg, end} pairs, passed next to the params); beg / end is their hull
+  // > 1: the fetch is the union of n_parts windows (ascending, disjoint {beg, end} pairs, passed next to the params); beg / end is their hull
+  uint32_t n_parts, pad;
 };
 
 // one record of the window after mkp_ingest_parse
@@ -53,7 +55,8 @@ struct MkpRecInfo {             // 48 B
   unsigned long long core;      // offset of the 32-byte core in the window (block_size sits 4 bytes before it)
   int32_t pos, reflen;
   uint32_t l_seq, bs;           // block_size
-  uint16_t n_cigar, flag; uint8_t l_qname, kind, pad0, pad1;   // kind: 0 dropped, 1 kept, 2 span only (supplementary: max-depth guard), 3 sampler-only
+  // kind: 0 dropped, 1 kept, 2 span only (supplementary: max-depth guard), 3 sampler-only
+  uint16_t n_cigar, flag; uint8_t l_qname, kind, pad0, pad1;
   uint32_t mm, ml, mn;          // offsets of the aux values' TYPE bytes from the core (0 = absent): MM|Mm, ML|Ml, MN
   uint32_t ml_n;                // elements of the ML array when it is B:C
 };
@@ -86,7 +89,8 @@ MKP_IDEV uint16_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p,
 // ---- BGZF block table (BamSource::ingest_walk_chain_host on the uploaded bytes).  One thread walks one chain: the blocks from a block
 // start the index knows to the next one.  Offsets are positions in the uploaded buffer `z` (the window's file ranges, each 64-byte aligned).
 // Pass 1 (out == nullptr) counts, pass 2 writes {offset, header bytes, payload bytes, ISIZE}.
-struct MkpZChain { unsigned long long start, stop, range_end, ce; uint32_t ue, pad; };   // stop: the next known block start (~0: none); ce / ue: block offset and in-block offset of the chunk's end
+// stop: the next known block start (~0: none); ce / ue: block offset and in-block offset of the chunk's end
+struct MkpZChain { unsigned long long start, stop, range_end, ce; uint32_t ue, pad; };
 struct MkpZBlk { unsigned long long coff; uint32_t hdr, clen, isize, pad; };
 #define MKP_ZE_BAD 1u      // not BGZF, or a block without a usable BC field
 #define MKP_ZE_CHAIN 2u    // the chain of block sizes misses the block start the index names
@@ -96,11 +100,14 @@ MKP_IDEV uint32_t ingest_walk_blocks(const uint8_t* z, const MkpZChain ch, MkpZB
   unsigned long long c = ch.start; uint32_t n = 0;
   for (;;) {
     if (c >= ch.stop || c > ch.ce || (c == ch.ce && ch.ue == 0) || c + 18 > ch.range_end) break;
-    const uint8_t* hb = z + c; const unsigned long long hn = ch.range_end - c < 600ull ? ch.range_end - c : 600ull;   // (the host reads 600 bytes of header at most)
+    // (the host reads 600 bytes of header at most)
+    const uint8_t* hb = z + c; const unsigned long long hn = ch.range_end - c < 600ull ? ch.range_end - c : 600ull;
     if (hb[0] != 31 || hb[1] != 139 || !(hb[3] & 4)) { MKP_ATOMIC_OR(err, MKP_ZE_BAD); return n; }
-    const uint32_t xlen = ld_u16(hb + 10); unsigned long long x = 12; const unsigned long long xe = 12ull + xlen; uint32_t bsize = 0; bool found = false;
+    const uint32_t xlen = ld_u16(hb + 10); unsigned long long x = 12; const unsigned long long xe = 12ull + xlen; uint32_t bsize = 0;
+      bool found = false;
     if (xe > hn) break;
-    while (x + 4 <= xe) { const uint32_t sl = ld_u16(hb + x + 2); if (hb[x] == 'B' && hb[x + 1] == 'C' && sl == 2 && x + 6 <= xe) { bsize = (uint32_t)ld_u16(hb + x + 4) + 1u; found = true; } x += 4ull + sl; }
+    while (x + 4 <= xe) { const uint32_t sl = ld_u16(hb + x + 2); if (hb[x] == 'B' && hb[x + 1] == 'C' && sl == 2 && x + 6 <= xe) {
+        bsize = (uint32_t)ld_u16(hb + x + 4) + 1u; found = true; } x += 4ull + sl; }
     if (!found || bsize < xlen + 20u) { MKP_ATOMIC_OR(err, MKP_ZE_BAD); return n; }
     const uint32_t hdr = 12u + xlen, clen = bsize - xlen - 20u;
     const unsigned long long next = c + hdr + clen + 8ull;
@@ -135,21 +142,26 @@ MKP_IDEV bool ingest_overlaps_parts(const int32_t* parts, uint32_t n, long long 
   while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if ((long long)parts[2 * mid + 1] > pos) hi = mid; else lo = mid + 1; }
   return lo < n && (long long)parts[2 * lo] < end;
 }
-MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, const MkpIngestParams& P, const int32_t* parts, MkpRecInfo* out, uint32_t* err) {
+MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, const MkpIngestParams& P, const int32_t* parts, MkpRecInfo* out,
+    uint32_t* err) {
   MkpRecInfo R; R.core = o + 4; R.kind = 0; R.pad0 = R.pad1 = 0; R.mm = R.ml = R.mn = 0; R.ml_n = 0;
   const uint8_t* c = raw + o + 4;
   const int32_t bs = ld_i32(raw + o); R.bs = (uint32_t)bs;
   const int32_t tid = ld_i32(c); R.pos = ld_i32(c + 4);
   R.l_qname = c[8]; R.n_cigar = ld_u16(c + 12); R.flag = ld_u16(c + 14);
   const int32_t lseq = ld_i32(c + 16); R.l_seq = (uint32_t)lseq; R.reflen = 0;
-  const unsigned long long fixed = 32ull + R.l_qname + 4ull * R.n_cigar + ((unsigned long long)(lseq < 0 ? 0 : lseq) + 1) / 2 + (unsigned long long)(lseq < 0 ? 0 : lseq);
-  if (lseq < 0 || fixed > (unsigned long long)bs || tid < -1 || tid >= P.n_ref || R.pos < -1 || R.pos >= 0x7ffffff0) { MKP_ATOMIC_OR(err, MKP_IE_CORRUPT); *out = R; return; }
+  const unsigned long long fixed = 32ull + R.l_qname + 4ull * R.n_cigar + ((unsigned long long)(lseq < 0 ? 0
+      : lseq) + 1) / 2 + (unsigned long long)(lseq < 0 ? 0 : lseq);
+  if (lseq < 0 || fixed > (unsigned long long)bs || tid < -1 || tid >= P.n_ref || R.pos < -1 || R.pos >= 0x7ffffff0) {
+    MKP_ATOMIC_OR(err, MKP_IE_CORRUPT); *out = R; return; }
   const uint8_t* cg = c + 32 + R.l_qname; long long rl = 0;
-  for (uint32_t k = 0; k < R.n_cigar; k++) { const uint32_t w = ld_u32(cg + 4 * k); if ((0x18du >> (w & 15u)) & 1u) rl += w >> 4; }   // M D N = X consume the reference
+  // M D N = X consume the reference
+  for (uint32_t k = 0; k < R.n_cigar; k++) { const uint32_t w = ld_u32(cg + 4 * k); if ((0x18du >> (w & 15u)) & 1u) rl += w >> 4; }
   if ((long long)R.pos + rl > 0x7ffffff0ll) { MKP_ATOMIC_OR(err, MKP_IE_CORRUPT); *out = R; return; }
   R.reflen = (int32_t)rl;
   const long long endpos = (long long)R.pos + (rl > 0 ? rl : 1);
-  const bool in_region = tid == P.tid && (long long)R.pos < (long long)P.end && endpos > (long long)P.beg && (P.n_parts < 2 || ingest_overlaps_parts(parts, P.n_parts, R.pos, endpos));
+  const bool in_region = tid == P.tid && (long long)R.pos < (long long)P.end && endpos > (long long)P.beg
+      && (P.n_parts < 2 || ingest_overlaps_parts(parts, P.n_parts, R.pos, endpos));
   if (!in_region) { *out = R; return; }
   const bool masked = (R.flag & (4u | 256u | 512u | 1024u)) != 0;
   if (!masked && (R.flag & 2048u) && R.n_cigar) { R.kind = 2; *out = R; return; }
@@ -170,9 +182,11 @@ MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, cons
       case 's': case 'S': len = 2; break;
       case 'i': case 'I': case 'f': len = 4; break;
       case 'd': len = 8; break;
-      case 'Z': case 'H': { uint32_t k = v; while (k < aux_n && a[k]) k++; len = (unsigned long long)(k - v) + 1; break; }   // (no terminator: runs past the end, malformed below)
+      // (no terminator: runs past the end, malformed below)
+      case 'Z': case 'H': { uint32_t k = v; while (k < aux_n && a[k]) k++; len = (unsigned long long)(k - v) + 1; break; }
       case 'B': { if (v + 5 > aux_n) { q = aux_n; len = 0; missing = -1; break; } const uint8_t st = a[v]; const uint32_t cnt = ld_u32(a + v + 1);
-                  const uint32_t es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u; len = 5ull + (unsigned long long)es * cnt; break; }
+                  const uint32_t es = (st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u; len = 5ull + (unsigned long long)es * cnt;
+                    break; }
       default: missing = -1; len = 0; break;
     }
     if (missing < 0) break;
@@ -191,7 +205,8 @@ MKP_IDEV void ingest_parse_record(const uint8_t* raw, unsigned long long o, cons
 
 // sizes a kept record takes in the packed arrays (scanned into offsets before mkp_ingest_pack)
 MKP_IDEV uint32_t ingest_seq_bytes(uint32_t l_seq) { return (((l_seq + 1u) / 2u) + 3u) & ~3u; }
-MKP_IDEV uint32_t ingest_chunk_pairs(uint32_t n_cigar) { return n_cigar ? (n_cigar + 63u) / 64u : 1u; }   // (a record without a CIGAR is packed with one soft clip over its bases, as Packer::add does)
+// (a record without a CIGAR is packed with one soft clip over its bases, as Packer::add does)
+MKP_IDEV uint32_t ingest_chunk_pairs(uint32_t n_cigar) { return n_cigar ? (n_cigar + 63u) / 64u : 1u; }
 MKP_IDEV uint32_t ingest_cigar_words(uint32_t n_cigar) { return n_cigar ? n_cigar : 1u; }
 
 // what the packer's tokeniser leaves for one record
@@ -213,7 +228,8 @@ MKP_IDEV void fnv_decimal(unsigned long long* h, uint32_t v) {   // the digits s
 // Packer::tokenise (mkp_pack.hpp) for one record: MM header structure -> key hash, delta lists -> cumulative ranks (the ML bytes are moved
 // by ingest_copy_record).  ranks: the record's slice (capacity ml_n); tagref: MKP_MAX_TAGS entries; rank_base / ml_base: their offsets in the shard.
 // false = the read only contributes coverage (tag error).  `err` collects the conditions the host packer throws on.
-MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* ranks, MkpTagRef* tagref, uint32_t rank_base, uint32_t ml_base, MkpTokOut* out, uint32_t* err) {
+MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* ranks, MkpTagRef* tagref, uint32_t rank_base, uint32_t ml_base,
+    MkpTokOut* out, uint32_t* err) {
   out->n_tags = 0; out->n_calls = 0; out->ml_used = 0; out->cap = 0; out->key_hash = 1469598103934665603ull; out->sum2 = 0;
   if (!R.mm || !R.ml) return false;
   if (c[R.mm] != 'Z') return false;
@@ -240,11 +256,13 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
       const uint8_t* p = s; const uint8_t* he = s; while (he < e && *he != ',') he++;
       uint32_t fb; bool neg; uint32_t mode = 2; uint32_t codes[MKP_KMAX + 1]; uint32_t n_codes = 0;
       if (p >= he) return false;
-      switch (*p) { case 'A': fb = 0; break; case 'C': fb = 1; break; case 'G': fb = 2; break; case 'T': case 'U': fb = 3; break; case 'N': fb = 4; break; default: return false; }
+      switch (*p) { case 'A': fb = 0; break; case 'C': fb = 1; break; case 'G': fb = 2; break; case 'T': case 'U': fb = 3; break; case 'N': fb = 4;
+        break; default: return false; }
       p++; if (p >= he) return false;
       if (*p == '+') neg = false; else if (*p == '-') neg = true; else return false;
       p++; bool chebi = false; uint32_t offset = 2;
-      if (p < he && *p >= '0' && *p <= '9') { unsigned long long v = 0; while (p < he && *p >= '0' && *p <= '9') { v = v * 10 + (unsigned long long)(*p - '0'); if (v > 0x7fffffffull) return false; p++; offset++; }
+      if (p < he && *p >= '0' && *p <= '9') { unsigned long long v = 0; while (p < he && *p >= '0' && *p <= '9') {
+          v = v * 10 + (unsigned long long)(*p - '0'); if (v > 0x7fffffffull) return false; p++; offset++; }
         codes[n_codes++] = 0x80000000u | (uint32_t)v; chebi = true; }
       for (; p < he; p++) {
         if (*p == '?' || *p == '.') { mode = *p == '?' ? 0u : 1u; offset++; }
@@ -266,7 +284,8 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
           if (!first) { if (d >= e || MKP_CH(d) != ',') break; d++; }
           while (d < e && ingest_ws(MKP_CH(d))) d++;
           if (!(d < e && MKP_CH(d) >= '0' && MKP_CH(d) <= '9')) { if (first) return false; d = save; break; }
-          unsigned long long v = 0; while (d < e) { const uint8_t ch = MKP_CH(d); if (ch < '0' || ch > '9') break; v = v * 10 + (unsigned long long)(ch - '0'); if (v > 0xffffffffull) return false; d++; }
+          unsigned long long v = 0; while (d < e) { const uint8_t ch = MKP_CH(d); if (ch < '0' || ch > '9') break;
+            v = v * 10 + (unsigned long long)(ch - '0'); if (v > 0xffffffffull) return false; d++; }
           while (d < e && ingest_ws(MKP_CH(d))) d++;
           acc = first ? v : acc + v + 1;   // sum(d + 1) - 1
           if (acc >= (fb == 4 ? (unsigned long long)R.l_seq : 0xffffffffull)) { if (fb == 4 || acc >= 0xffffffffull) return false; }
@@ -304,7 +323,9 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
   // term is (2q + 1) / 512, so the f32 sum is exact and the test is "the numerators reach 518"
   if (n_hdr == 2 && tagref[1].pad) {
     const uint32_t n = tagref[0].n; const uint8_t* m0 = mlp + 6; const uint8_t* m1 = mlp + 6 + (tagref[1].ml_off - ml_base); bool bad = false;
-    for (uint32_t j = 0; j < n && !bad; j++) { uint32_t num = 0; for (uint32_t i = 0; i < nc[0]; i++) num += 2u * m0[j * nc[0] + i] + 1u; for (uint32_t i = 0; i < nc[1]; i++) num += 2u * m1[j * nc[1] + i] + 1u; bad = num >= 518u; }
+    for (uint32_t j = 0; j < n && !bad; j++) { uint32_t num = 0; for (uint32_t i = 0; i < nc[0]; i++) num += 2u * m0[j * nc[0] + i] + 1u;
+      for (uint32_t i = 0; i < nc[1]; i++) num += 2u * m1[j * nc[1] + i] + 1u;
+      bad = num >= 518u; }
     out->sum2 = bad ? 1u : 0u;
   }
   out->n_tags = n_hdr; out->n_calls = (uint32_t)calls; out->ml_used = (uint32_t)pointer;
@@ -313,11 +334,14 @@ MKP_IDEV bool ingest_tokenise(const uint8_t* c, const MkpRecInfo& R, uint32_t* r
 }
 
 // per-record digest the host plans with (next to the record's MkpReadHdr and tag table)
-struct MkpRecDigest { unsigned long long name_hash, key_hash, name_hash2, win_idx; };   // name_hash2: a second, independent hash of the read name (128 bits identify a name in the sampler's sets); win_idx: the record's place in the window (file order across kept and sampler-only records)
+// name_hash2: a second, independent hash of the read name (128 bits identify a name in the sampler's sets); win_idx: the record's place in the window
+// (file order across kept and sampler-only records)
+struct MkpRecDigest { unsigned long long name_hash, key_hash, name_hash2, win_idx; };
 
 // Packer::add for one kept record, the serial half (one thread): chunk prefixes of the CIGAR, name hashes, the tags; writes the header with
 // the offsets the scan gave.  The bulk copies are ingest_copy_record's.
-MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t win_idx, uint32_t j, uint32_t cigar_off, uint32_t chunk_off, uint32_t seq_off, uint32_t ml_off,
+MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t win_idx, uint32_t j, uint32_t cigar_off, uint32_t chunk_off,
+    uint32_t seq_off, uint32_t ml_off,
                                  MkpReadHdr* hdr, uint32_t* chunk_pfx, MkpTagRef* tagref, uint32_t* ranks, MkpRecDigest* dig, MkpIngestTotals* tot) {
   const uint8_t* c = raw + R.core;
   const uint8_t* cg = c + 32 + R.l_qname;
@@ -330,12 +354,14 @@ MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32
     if ((0x18du >> op) & 1u) reflen += w >> 4;
     if ((0x193u >> op) & 1u) qlen += w >> 4;   // M I S = X consume the query
   }
-  if (R.n_cigar == 0) { chunk_pfx[2 * chunk_off] = 0; chunk_pfx[2 * chunk_off + 1] = 0; qlen = R.l_seq; }   // sampler-only record without alignment ops
+  // sampler-only record without alignment ops
+  if (R.n_cigar == 0) { chunk_pfx[2 * chunk_off] = 0; chunk_pfx[2 * chunk_off + 1] = 0; qlen = R.l_seq; }
   if (qlen != (long long)R.l_seq) MKP_ATOMIC_OR(&tot->err, MKP_IE_QLEN);
   if (qlen >= (1 << 26) || reflen >= (1 << 26)) MKP_ATOMIC_OR(&tot->err, MKP_IE_SPAN);
   h.ref_start = R.pos; h.ref_end = R.pos + (int32_t)reflen; h.l_seq = R.l_seq; h.n_cigar = ingest_cigar_words(R.n_cigar);
   h.flags = (R.flag & 16u) ? MKP_RF_REVERSE : 0u;
-  { unsigned long long hh = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull; for (int i = 0; i + 1 < (int)R.l_qname; i++) { hh ^= c[32 + i]; hh *= 1099511628211ull; h2 = (h2 ^ c[32 + i]) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 29; }
+  { unsigned long long hh = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull; for (int i = 0; i + 1 < (int)R.l_qname; i++) { hh ^= c[32 + i];
+      hh *= 1099511628211ull; h2 = (h2 ^ c[32 + i]) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 29; }
     dig[j].name_hash = hh; dig[j].name_hash2 = h2; dig[j].win_idx = win_idx; }
   MkpTokOut t;
   for (uint32_t k = 0; k < MKP_MAX_TAGS; k++) { MkpTagRef z; z.rank_off = 0; z.n = 0; z.ml_off = 0; z.pad = 0; tagref[h.tag_off + k] = z; }
@@ -344,7 +370,8 @@ MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32
   if (t.cap > 0xfffffff0ull) { MKP_ATOMIC_OR(&tot->err, MKP_IE_4G); t.cap = 0; }
   h.n_tags = (uint16_t)t.n_tags; h.layout = 0;
   h.event_off = 0; h.event_cap = (uint32_t)t.cap;
-  h.gs0 = 0; h.n_sl = 0; h.cov_off = 0; h.pad = t.sum2;   // pad: bit 0 = the two tags' probabilities of some call add up to more than 1.01 (the planner moves it into flags)
+  // pad: bit 0 = the two tags' probabilities of some call add up to more than 1.01 (the planner moves it into flags)
+  h.gs0 = 0; h.n_sl = 0; h.cov_off = 0; h.pad = t.sum2;
   dig[j].key_hash = t.key_hash;
   hdr[j] = h;
   if (t.n_calls) MKP_ATOMIC_ADD64(&tot->n_calls, (unsigned long long)t.n_calls);
@@ -354,7 +381,8 @@ MKP_IDEV void ingest_pack_record(const uint8_t* raw, const MkpRecInfo& R, uint32
 // Packer::add for one kept record, the bulk half: CIGAR words, SEQ bytes (zero-padded to a dword), the ML array — by `nlanes` lanes that
 // share the record (a wave on the device; the test harness calls it lane after lane).  No lane reads what another wrote.  The whole B:C
 // array is moved (the record's slice has room for it; the tags only ever point at the bytes their calls use).
-MKP_IDEV void ingest_copy_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t cigar_off, uint32_t seq_off, uint32_t ml_off, uint32_t* cigar, uint8_t* seq, uint8_t* ml,
+MKP_IDEV void ingest_copy_record(const uint8_t* raw, const MkpRecInfo& R, uint32_t cigar_off, uint32_t seq_off, uint32_t ml_off, uint32_t* cigar,
+    uint8_t* seq, uint8_t* ml,
                                  uint32_t lane, uint32_t nlanes) {
   const uint8_t* c = raw + R.core;
   const uint8_t* cg = c + 32 + R.l_qname;

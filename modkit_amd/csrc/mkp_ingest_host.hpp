@@ -23,11 +23,13 @@ struct DevShard {
 // chain segments of a plan: from every known record start to the next one (the chain must land on it), the last of a range to the range's limit
 template <class Seg> inline std::vector<Seg> mkp_plan_segments(const mkp::BamSource::IngestPlan& plan) {
   std::vector<Seg> segs(plan.entries.size());
-  for (auto& rg : plan.ranges) for (size_t k = rg.entry0; k < rg.entry1; k++) { Seg s; s.start = plan.entries[k]; s.exact = k + 1 < rg.entry1 ? 1u : 0u; s.stop = s.exact ? plan.entries[k + 1] : rg.raw_limit; s.pad = 0; segs[k] = s; }
+  for (auto& rg : plan.ranges) for (size_t k = rg.entry0; k < rg.entry1; k++) { Seg s; s.start = plan.entries[k];
+    s.exact = k + 1 < rg.entry1 ? 1u : 0u; s.stop = s.exact ? plan.entries[k + 1] : rg.raw_limit; s.pad = 0; segs[k] = s; }
   return segs;
 }
 
-// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block (speculative token decode) below 28 000 blocks, one thread per block (second edition) from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
+// the BGZF inflate kernel for a launch of n blocks (mkp_api.cpp): one wave per block (speculative token decode) below 28 000 blocks, one thread per
+// block (second edition) from there; MKP_INFLATE_KERNEL=wave|thread|thread2 forces one
 hipError_t mkp_launch_inflate_auto(hipStream_t st, const uint8_t* in, const void* blks, uint32_t n, uint8_t* out, uint32_t* status);
 
 mkp_dev_ingest* mkp_internal_ingest_create(int device);
@@ -35,7 +37,8 @@ void mkp_internal_ingest_destroy(mkp_dev_ingest* d);
 // the indexed fetch of [beg, end) on `tid` — every record overlapping it — inflated, cut, filtered and packed on the device; throws mkp::Error
 // (several windows — ascending, disjoint: a shard made of BED spans — select the union of their fetches, every record once)
 std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const mkp::BamSource& bam, uint32_t tid, const mkp::FetchParts& parts);
-inline std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const mkp::BamSource& bam, uint32_t tid, uint32_t beg, uint32_t end) {
+inline std::unique_ptr<mkp::DevShard> mkp_internal_ingest_run(mkp_dev_ingest* d, const mkp::BamSource& bam, uint32_t tid, uint32_t beg,
+    uint32_t end) {
   return mkp_internal_ingest_run(d, bam, tid, mkp::FetchParts{{(int64_t)beg, (int64_t)end}});
 }
 // the shard begun with mkp_shard_begin takes these records instead of mkp_shard_add_records: device arrays swapped into the context

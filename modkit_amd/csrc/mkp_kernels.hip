@@ -51,7 +51,8 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
                  const uint8_t* __restrict__ seqs, const MkpTagRef* __restrict__ tagref, const uint32_t* __restrict__ ranks,
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
-                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, const uint32_t* __restrict__ read_ids, uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4) {
+                 const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, const uint32_t* __restrict__ read_ids,
+                     uint32_t* __restrict__ lds_layouts, uint32_t (*__restrict__ lds_marks)[64], const uint8_t* __restrict__ pdep4) {
   const int lane = lane_id();
   // wave-uniform values are made provably uniform (readfirstlane) so they live in SGPRs and load through the scalar cache
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -160,7 +161,8 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
     for (int j = 0; j < NB; j++) {
       m8[j] = 0; incl[j] = 0; cnt[j] = 0;
       if ((uint32_t)j < nb) {
-        m8[j] = match8(xl, (int)sbase[j]) & vmask; incl[j] = wave_incl_scan((uint32_t)__popc(m8[j])); cnt[j] = (uint32_t)__builtin_amdgcn_readlane((int)incl[j], 63);
+        m8[j] = match8(xl, (int)sbase[j]) & vmask; incl[j] = wave_incl_scan((uint32_t)__popc(m8[j]));
+          cnt[j] = (uint32_t)__builtin_amdgcn_readlane((int)incl[j], 63);
         if ((implslots >> j) & 1u) U |= m8[j];
       }
     }
@@ -180,8 +182,11 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
       const uint32_t kbase = dsc.fb == 4 ? qa : selN<NB>(cum, sj), ktot = dsc.fb == 4 ? L : selN<NB>(tot, sj);
       for (;;) {
         uint32_t e; bool hit; uint32_t nh;
-        if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
-        else { const uint32_t i = t_cur[t] - 64u + lane; const bool valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }  // an entry >= whi is past the last occurrence: never consumed -> error at the end
+        if (!rev) { const uint32_t i = t_cur[t] + lane; const bool valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu;
+          hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
+        // an entry >= whi is past the last occurrence: never consumed -> error at the end
+        else { const uint32_t i = t_cur[t] - 64u + lane; const bool valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u;
+          hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }
         if (nh == 0) break;
         // chunk-relative stored ordinal of the call's base (specific-base tags) or stored position (`N` tags): one bit in LDS
         const uint32_t ib = (rev ? (ktot - 1u - e) : e) - kbase;
@@ -319,11 +324,14 @@ __device__ __forceinline__ void decode_read_body(const MkpReadHdr* __restrict__ 
           if (!trimmable || !edge_keep) continue;
           if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
             bool keep = !prm.only_mapped || mapped;
-            if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
+            if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end
+                && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg)) & 1u);
             if (!keep) continue;
             any_surviving = true;
-            if (prm.sample_mode >= 2) {   // 2 `summary`: thresholded + argmax class; 3 `extract calls`: + forward position, mod strand, inferred, call_prob
-              if (prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) continue;   // the collapse left no code in the map: no profile row (iter_probs is empty)
+            // 2 `summary`: thresholded + argmax class; 3 `extract calls`: + forward position, mod strand, inferred, call_prob
+            if (prm.sample_mode >= 2) {
+              // the collapse left no code in the map: no profile row (iter_probs is empty)
+              if (prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) continue;
               uint32_t ob = 0; float am = 0.f; uint32_t inf = summary_info(gr, pv, spk, collapse, &ob, MKP_KMAX, &am);
               if (prm.sample_mode == 3) { inf |= ((uint32_t)sg << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); ev_pos = (int32_t)f; }
               sv[ev_cnt] = prm.sample_mode == 3 ? am : 0.f; ev_info[ev_cnt++] = inf; obs0 |= ob; continue;
@@ -401,7 +409,8 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
                  const uint8_t* __restrict__ ml, const MkpLayout* __restrict__ layouts, const MkpRunParams& prm,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t* __restrict__ dev_err,
                  const uint8_t* __restrict__ bedmask, float* __restrict__ sample_vals, uint32_t* __restrict__ lds_layouts,
-                 const uint32_t* __restrict__ read_ids, uint32_t* __restrict__ lds_ord, const uint8_t* __restrict__ pdep4, uint32_t* __restrict__ lds_queue) {
+                 const uint32_t* __restrict__ read_ids, uint32_t* __restrict__ lds_ord, const uint8_t* __restrict__ pdep4,
+                     uint32_t* __restrict__ lds_queue) {
   static_assert(NT <= 2, "the call queue holds two ML indices per entry");
   const int lane = lane_id();
   const uint32_t wib = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -413,7 +422,8 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   if ((h.flags & MKP_RF_BAD) || h.n_tags == 0) { if (lane == 0) readout[rid] = out; return; }
   uint32_t* __restrict__ lds_lay = lds_layouts + wib * MKP_LAYOUT_DWORDS;
   uint32_t* __restrict__ ordb = lds_ord + wib * (NT * MKP_ORD_WORDS);   // [NT][MKP_ORD_WORDS] ordinal bitmaps of the step
-  uint32_t* __restrict__ q_pos = lds_queue + wib * ((1 + NT) * MKP_QCAP);   // queue, SoA: stored position, ML call index of tag 0 / 1 (~0 = not listed)
+  // queue, SoA: stored position, ML call index of tag 0 / 1 (~0 = not listed)
+  uint32_t* __restrict__ q_pos = lds_queue + wib * ((1 + NT) * MKP_QCAP);
   uint32_t* __restrict__ q_j0 = q_pos + MKP_QCAP;
   uint32_t* __restrict__ q_j1 = q_pos + (NT > 1 ? 2 : 1) * MKP_QCAP;
   { const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(&layouts[h.layout]);
@@ -429,9 +439,11 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
   const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
   GroupRegs grp0 = load_group(gp0);
   grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
-  grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
+  grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids);
+    grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
 #pragma unroll
-  for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
+  for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr,
+      kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
   grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
   const uint32_t impl0 = MKP_G_IMPL(grp0.misc);
   const int kcodes0 = (int)((grp0.misc >> 20) & 7u);   // codes of the group: bounds every per-code loop
@@ -526,7 +538,8 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
             else if (!rev) { const uint32_t i = t_cur[t] + lane; valid = i < t_n[t]; e = valid ? ranks[t_off[t] + i] : 0xffffffffu; }
             else { const uint32_t i = t_cur[t] - 64u + lane; valid = (int32_t)i >= 0 && i < t_cur[t]; e = valid ? ranks[t_off[t] + i] : 0u; }
             if (!rev) { hit = valid && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] += nh; }
-            else { hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }   // an entry >= whi is past the last occurrence: never consumed -> error at the end
+            // an entry >= whi is past the last occurrence: never consumed -> error at the end
+            else { hit = valid && e >= wlo && e < whi; nh = (uint32_t)__popcll(__ballot(hit)); t_cur[t] -= nh; }
             if (nh == 0) break;
             const uint32_t ib = (rev ? (tot - 1u - e) : e) - cum;   // step-relative stored ordinal of the called base (< 1024)
             if (hit) atomicOr(&ordb[t * MKP_ORD_WORDS + (ib >> 5)], 1u << (ib & 31u));
@@ -657,11 +670,15 @@ __device__ __forceinline__ void decode_read_fast(const MkpReadHdr* __restrict__ 
       if (trimmable && edge_keep) {
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
-          if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;   // `extract calls`: the collapse left no code in the map: no profile row
+          if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end
+              && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
+          // `extract calls`: the collapse left no code in the map: no profile row
+          if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;
           else if (keep && prm.sample_mode >= 2) {
-            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob; has_ev = true;
-            if (prm.sample_mode == 3) { ev_info |= ((uint32_t)sg0 << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position
+            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(grp0, pv, pk, collapse, &ob, kcodes0, &am); obs0 |= ob;
+              has_ev = true;
+            // `extract calls`: the event carries the forward position
+            if (prm.sample_mode == 3) { ev_info |= ((uint32_t)sg0 << 2) | ((pat == MKP_PAT_INFERRED ? 1u : 0u) << 3); sv = am; rpos = (int32_t)f; }
           }
           else if (keep) { any_surviving = true; sv = argmax_group(grp0, pv, pk, collapse, kcodes0); ev_info = MKP_G_TB(grp0.misc); has_ev = true; }
         } else {
@@ -777,9 +794,11 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   const uint32_t* gp0 = lds_lay + MKP_LAYOUT_GROUP_DW + (sg0 * 4 + b0) * 32;
   GroupRegs grp0 = load_group(gp0);
   grp0.misc = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.misc); grp0.slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.slots);
-  grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids); grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
+  grp0.cids = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.cids);
+    grp0.member_tags = (uint32_t)__builtin_amdgcn_readfirstlane((int)grp0.member_tags);
 #pragma unroll
-  for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr, kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
+  for (int kq = 0; kq < MKP_KMAX; kq++) at(grp0.thr,
+      kq) = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(at(grp0.thr, kq))));
   grp0.thr_can = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(grp0.thr_can)));
   const int kcodes0 = (int)((grp0.misc >> 20) & 7u);   // codes of the group: bounds every per-code loop
   uint32_t t_ml[NT], t_nc[NT], tmu[NT], codes_t[NT];
@@ -835,12 +854,14 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
   // empty window in front of op 0: no flag, no conditional advance (the same rewrite as refwin_s_* of mkp_slots.hip).
   uint32_t c0 = 0u - 128u, wq0 = 0, wq1 = 0; int32_t wr0 = h.ref_start;
   uint32_t w_qe = 0, w_mid = 0, w_a = 0, w_b = 0, w_rtot = 0;
-  auto cigar2 = [&](uint32_t c) { uint2 r; const uint32_t k = c + 2u * (uint32_t)lane; r.x = k < h.n_cigar ? cigar[h.cigar_off + k] : 5u /*0H*/; r.y = k + 1u < h.n_cigar ? cigar[h.cigar_off + k + 1u] : 5u; return r; };
+  auto cigar2 = [&](uint32_t c) { uint2 r; const uint32_t k = c + 2u * (uint32_t)lane; r.x = k < h.n_cigar ? cigar[h.cigar_off + k] : 5u /*0H*/;
+    r.y = k + 1u < h.n_cigar ? cigar[h.cigar_off + k + 1u] : 5u; return r; };
   uint2 w_pref = cigar2(0);   // the first CIGAR window, requested before the read is walked
   uint32_t qhead = 0, qcount = 0, d0 = 0;
   // the next step's SEQ dwords (eight per lane = 64 bases, two 16-byte loads) are always in flight; SEQ buffers end with
   // slack, so whole vectors are loaded and the dwords past the read are discarded when the flags are made
-  const uint4* __restrict__ seqv = reinterpret_cast<const uint4*>(seqw);   // reads start 4-byte aligned: vector loads may be unaligned (fine on global memory)
+  // reads start 4-byte aligned: vector loads may be unaligned (fine on global memory)
+  const uint4* __restrict__ seqv = reinterpret_cast<const uint4*>(seqw);
   uint4 xa = make_uint4(0, 0, 0, 0), xb = make_uint4(0, 0, 0, 0);
   auto load_step = [&](uint32_t dstep) {
     const uint32_t d = dstep + 8u * (uint32_t)lane;
@@ -899,13 +920,15 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
           const uint32_t n_left = qcount - qhead;
           const bool mv = (uint32_t)lane < n_left;
           const uint32_t a = mv ? q_pos[qhead + lane] : 0u, b = mv ? q_j[qhead + lane] : 0u;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           if (mv) { q_pos[lane] = a; q_j[lane] = b; }
           qcount = n_left; qhead = 0;
         }
         const uint32_t ib = hit ? ((rev ? (tot - 1u - e) : e) - cum) : 0u;   // step-relative stored ordinal of the called base (< cntT)
         const int owner = find_op(st_incl, ib) & 63;                          // the lane whose 64 bases hold that occurrence
-        const uint32_t o_excl = (uint32_t)__shfl((int)st_excl, owner, 64), o_lo = (uint32_t)__shfl((int)st_cumlo, owner, 64), o_hi = (uint32_t)__shfl((int)st_cumhi, owner, 64);
+        const uint32_t o_excl = (uint32_t)__shfl((int)st_excl, owner, 64), o_lo = (uint32_t)__shfl((int)st_cumlo, owner, 64),
+            o_hi = (uint32_t)__shfl((int)st_cumhi, owner, 64);
         const uint32_t k = ib - o_excl;                                       // occurrence inside the owner's 64 bases
         // dword: the last of the 8 running counts that is <= k (SWAR: byte i of t keeps 0x80 where count_i > k; counts < 128)
         const uint32_t kk1 = (k + 1u) * 0x01010101u;
@@ -921,7 +944,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         cc = Fw & 1u;                         if (r >= cc) { bpos += 1u; }
         // read order: forward reads hit on the low lanes with ascending positions, reverse reads on the high lanes with descending ones
         const uint32_t slot = qcount + (uint32_t)__popcll(rev ? (hb & ~lanemask_le()) : (hb & lanemask_lt()));
-        if (hit) { q_pos[slot] = 8u * (d0 + 8u * (uint32_t)owner + jd) + bpos; q_j[slot] = rev ? (t_cur - 64u + (uint32_t)lane) : (t_cur + (uint32_t)lane); }
+        if (hit) { q_pos[slot] = 8u * (d0 + 8u * (uint32_t)owner + jd) + bpos;
+          q_j[slot] = rev ? (t_cur - 64u + (uint32_t)lane) : (t_cur + (uint32_t)lane); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         qcount += nh;
         if (rev) t_cur -= nh; else t_cur += nh;
@@ -968,7 +992,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
 #endif
     {
       bool pending = active;
-      auto win_next = [&]() -> bool {   // the next 128 ops; false behind the last op (cannot happen for positions inside SEQ: the packer checks the lengths)
+      // the next 128 ops; false behind the last op (cannot happen for positions inside SEQ: the packer checks the lengths)
+      auto win_next = [&]() -> bool {
         c0 = rfl_u(c0 + 128u); wq0 = wq1; wr0 = (int32_t)rfl_u((uint32_t)wr0 + w_rtot);
         if (c0 >= h.n_cigar) { w_rtot = 0; return false; }
         const uint2 w = w_pref;   // requested one window ahead: the load is off the mapping's dependency chain
@@ -989,7 +1014,8 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
         if (!__any(ready)) return;
         const uint32_t qrel = ready ? q - wq0 : 0u;
         const int oi = find_op(w_qe, qrel) & 63;
-        const uint32_t o_mid = (uint32_t)__shfl((int)w_mid, oi, 64), o_a = (uint32_t)__shfl((int)w_a, oi, 64), o_b = (uint32_t)__shfl((int)w_b, oi, 64);
+        const uint32_t o_mid = (uint32_t)__shfl((int)w_mid, oi, 64), o_a = (uint32_t)__shfl((int)w_a, oi, 64),
+            o_b = (uint32_t)__shfl((int)w_b, oi, 64);
         const uint32_t pick = qrel < o_mid ? o_a : o_b;
         if (ready) { mapped = (pick & 1u) != 0u; rpos = (int32_t)q + ((int32_t)pick >> 1); pending = false; }
       };
@@ -1023,11 +1049,15 @@ __device__ __forceinline__ void decode_read_sparse(const MkpReadHdr* __restrict_
       if (trimmable && edge_keep) {
         if (SAMPLE) {  // SeqPosBaseModProbs::filter_positions (read_ids_to_base_mod_probs.rs:966-1070)
           bool keep = !prm.only_mapped || mapped;
-          if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
-          if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;   // `extract calls`: the collapse left no code in the map: no profile row
+          if (prm.has_focus) keep = keep && mapped && rpos >= prm.win_start && rpos < prm.win_end
+              && ((bedmask[rpos - prm.win_start] >> (aln ^ (uint32_t)sg0)) & 1u);
+          // `extract calls`: the collapse left no code in the map: no profile row
+          if (keep && prm.sample_mode == 3 && ((pv >> 3) & 7u) == 0u) any_surviving = true;
           else if (keep && prm.sample_mode >= 2) {
-            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(g0, pv, pk, collapse, &ob, (int)kc_l, &am); obs0 |= ob; has_ev = true;
-            if (prm.sample_mode == 3) { ev_info |= (uint32_t)sg0 << 2; sv = am; rpos = (int32_t)f; }   // `extract calls`: the event carries the forward position (explicit tags: never inferred)
+            any_surviving = true; uint32_t ob = 0; float am = 0.f; ev_info = summary_info(g0, pv, pk, collapse, &ob, (int)kc_l, &am); obs0 |= ob;
+              has_ev = true;
+            // `extract calls`: the event carries the forward position (explicit tags: never inferred)
+            if (prm.sample_mode == 3) { ev_info |= (uint32_t)sg0 << 2; sv = am; rpos = (int32_t)f; }
           }
           else if (keep) { any_surviving = true; sv = argmax_group(g0, pv, pk, collapse, (int)kc_l); ev_info = MKP_G_TB(g0.misc); has_ev = true; }
         } else {
@@ -1106,7 +1136,8 @@ template <bool SAMPLE, int NT> __device__ __forceinline__ void decode_sparse_ent
   __shared__ uint32_t lds_queue[4][2 * MKP_SQCAP];
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
   __shared__ __attribute__((aligned(16))) uint32_t lds_flags[4][512];
-  decode_read_sparse<SAMPLE, NT>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals, &lds_layouts[0][0], read_ids, &lds_queue[0][0], &lds_flags[0][0]);
+  decode_read_sparse<SAMPLE, NT>(hdrs, n_reads, cigar, seqs, tagref, ranks, ml, layouts, prm, events, readout, dev_err, bedmask, sample_vals,
+      &lds_layouts[0][0], read_ids, &lds_queue[0][0], &lds_flags[0][0]);
 }
 template <bool SAMPLE> __device__ __forceinline__ void decode_general_entry(DECODE_PARAMS(const MkpRunParams&)) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_layouts[4][MKP_LAYOUT_DWORDS];
@@ -1161,10 +1192,13 @@ extern "C" __global__ void __launch_bounds__(256) mkp_sample_sparse2(DECODE_PARA
 // HEMI (pileup-hemi, duplex.rs:241-339): the tally columns are the '+' motif positions; a read's '+' tally call at such a position
 // and its '-' tally call at the partner position form one pattern count; everything else about the walk is the focus kernel's.
 template <bool FOCUS, int UNROLL, bool KEYED, bool HEMI = false>
-__device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
+__device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar,
+    const uint8_t* __restrict__ seqs,
                  const MkpEvent* __restrict__ events, const MkpReadOut* __restrict__ readout, const MkpTile* __restrict__ tiles, uint32_t n_tiles,
-                 const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos,
-                 uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ tile_row_cnt,
+                 const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slotbm, const uint8_t* __restrict__ focus,
+                     const MkpCombo* __restrict__ combos,
+                 uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor, uint32_t* __restrict__ tile_row_off,
+                     uint32_t* __restrict__ tile_row_cnt,
                  const uint2* __restrict__ chunk_pfx, uint32_t* __restrict__ dev_err, uint32_t key_arg) {
   // --partition-tag (KEYED kernels): low 16 bits = the key this pass tallies, high 16 bits = index of the pass; otherwise unused
   const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = KEYED ? (key_arg >> 16) : 0u;
@@ -1222,7 +1256,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   const int32_t T0h = tl.r0 - MKP_HALO, T1h = tl.r1 + MKP_HALO;
   // zero the tallies and the per-wave scratch (the focus arrays are rewritten below)
   for (uint32_t k = threadIdx.x; k < tal_words; k += PILEUP_THREADS) lds[k] = 0;
-  for (uint32_t k = threadIdx.x; k < PILEUP_WAVES * wave_words; k += PILEUP_THREADS) lds[tal_words + focus_total + k] = FOCUS ? 3u : 0u;   // focus: kind 3 = no base
+  // focus: kind 3 = no base
+  for (uint32_t k = threadIdx.x; k < PILEUP_WAVES * wave_words; k += PILEUP_THREADS) lds[tal_words + focus_total + k] = FOCUS ? 3u : 0u;
   if (threadIdx.x == 0) { next_read = tl.first; scan_carry = 0; }
   SlotMap<FOCUS> sm; sm.bm = fbm; sm.pfx = fpfx; sm.fpos = fpos; sm.T0h = T0h; sm.lbase = T0h;
   uint32_t n_tslots = (uint32_t)(T1h - T0h);   // tally columns in use
@@ -1298,7 +1333,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
       }
     }
     // the first chunk's CIGAR words are requested now, ahead of the event work; every later chunk is requested one chunk ahead
-    auto load2 = [&](uint32_t c) { uint2 r; const uint32_t i = c + 2u * (uint32_t)lane; r.x = i < h.n_cigar ? cigar[h.cigar_off + i] : 5u; r.y = i + 1u < h.n_cigar ? cigar[h.cigar_off + i + 1u] : 5u; return r; };
+    auto load2 = [&](uint32_t c) { uint2 r; const uint32_t i = c + 2u * (uint32_t)lane; r.x = i < h.n_cigar ? cigar[h.cigar_off + i] : 5u;
+      r.y = i + 1u < h.n_cigar ? cigar[h.cigar_off + i + 1u] : 5u; return r; };
     uint32_t w_next = 5u; uint2 w2_next = make_uint2(5u, 5u);   // focus kernel: two ops per lane
     if (FOCUS) w2_next = load2(c_first); else w_next = (c_first + (uint32_t)lane < h.n_cigar) ? cigar[h.cigar_off + c_first + lane] : 5u;
     // observed mod codes: +1 over the read's span (add_mod_codes_for_record, pileup/mod.rs:831-835)
@@ -1320,7 +1356,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
         const MkpEvent* __restrict__ ev = events + h.event_off;
         const uint32_t lo = h.ref_start >= T0h ? 0u : event_lower_bound(ev, ro.n_events, T0h);
         const int32_t hoff = prm.hemi_off;
-        auto pb_of = [](uint32_t info) { const uint32_t b = (info >> 9) & 3u; return (((info >> 11) ^ (info >> 8)) & 1u) ? 3u - b : b; };   // threshold base of the call (read_cache.rs:147-150)
+        // threshold base of the call (read_cache.rs:147-150)
+        auto pb_of = [](uint32_t info) { const uint32_t b = (info >> 9) & 3u; return (((info >> 11) ^ (info >> 8)) & 1u) ? 3u - b : b; };
         for (uint32_t k = lo + lane;; k += 64) {
           bool in = k < ro.n_events;
           MkpEvent e; e.pos = 0; e.info = 0;
@@ -1344,7 +1381,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
               }
               if (binfo != 0xffffffffu && q >= 0) {
                 const uint32_t elA = prm.hemi_el[e.info & 0xffu], elB = prm.hemi_el[binfo & 0xffu];
-                const uint32_t cid = (elA == 0xffu || elB == 0xffu) ? (uint32_t)MKP_H_FAIL + pbA : (uint32_t)prm.hemi_pat_base[pbA] + elA * prm.hemi_nel[pbA] + elB;
+                const uint32_t cid = (elA == 0xffu || elB == 0xffu) ? (uint32_t)MKP_H_FAIL + pbA
+                    : (uint32_t)prm.hemi_pat_base[pbA] + elA * prm.hemi_nel[pbA] + elB;
                 atomicAdd(&tal[cid * S + i], 1u);
                 atomicAdd(&tal[(MKP_H_NC + pbA) * S + i], 0u - 1u);
               }
@@ -1406,7 +1444,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
             const uint32_t kind0 = op_is_match(op0) ? 0u : (op0 == 2 ? 1u : 2u), kind1 = op_is_match(op1) ? 0u : (op1 == 2 ? 1u : 2u);
             const uint32_t pk0 = ((uint32_t)((int32_t)qs0 - (rs0 - h.ref_start) + (1 << 26)) << 5) | (kind0 << 3);  // q = (pos - ref_start) + D
             const uint32_t pk1 = ((uint32_t)((int32_t)qs1 - (rs1 - h.ref_start) + (1 << 26)) << 5) | (kind1 << 3);
-            if (!HEMI && ro.ok && __any((op0 == 3 && rl0 > 0) || (op1 == 3 && rl1 > 0))) {  // ref-skips: the read is not in these columns (alignment.is_refskip())
+            // ref-skips: the read is not in these columns (alignment.is_refskip())
+            if (!HEMI && ro.ok && __any((op0 == 3 && rl0 > 0) || (op1 == 3 && rl1 > 0))) {
               for (int j = 0; j < 2; j++) {
                 const bool skipop = j ? (op1 == 3 && rl1 > 0) : (op0 == 3 && rl0 > 0);
                 const int32_t a0 = j ? rs1 : rs0, b0 = a0 + (int32_t)(j ? rl1 : rl0);
@@ -1428,7 +1467,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
               const int32_t p = valid ? fpos[c] : c_lo;
               const uint32_t rel = (uint32_t)(p - r_run);
               const int ol = find_op(re, rel) & 63;
-              const uint32_t o_mid = (uint32_t)__shfl((int)mid, ol, 64), o_pk0 = (uint32_t)__shfl((int)pk0, ol, 64), o_pk1 = (uint32_t)__shfl((int)pk1, ol, 64);
+              const uint32_t o_mid = (uint32_t)__shfl((int)mid, ol, 64), o_pk0 = (uint32_t)__shfl((int)pk0, ol, 64),
+                  o_pk1 = (uint32_t)__shfl((int)pk1, ol, 64);
               const uint32_t my_pk = rel < o_mid ? o_pk0 : o_pk1;
               const uint32_t qq = (uint32_t)p + qbase + (my_pk >> 5);
               if (valid) qk[c - rs_a] = (qq << 2) | ((my_pk >> 3) & 3u);
@@ -1475,7 +1515,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
         const uint32_t nref = (uint32_t)__popcll(refbal);
         const uint32_t ci = (uint32_t)__popcll(refbal & lanemask_lt());
         const uint32_t kind = op_is_match(op) ? 0u : (op == 2 ? 1u : 2u);
-        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);  // q = (pos - ref_start) + D; kind sits where it ORs into the row
+        // q = (pos - ref_start) + D; kind sits where it ORs into the row
+        const uint32_t pk = ((uint32_t)((int32_t)qs - (rs - h.ref_start) + (1 << 26)) << 5) | (kind << 3);
         if (covers) comp[ci] = make_uint2(sa, pk);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1507,7 +1548,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
           for (int j = 0; j < UNROLL; j++) Wd[j] = *reinterpret_cast<const uint2*>(bm + 2u * kk[j]);
 #pragma unroll
           for (int j = 0; j < UNROLL; j++) {
-            if (FOCUS) pp[j] = (64u * kk[j] + (uint32_t)lane < n_tslots) ? *(const __attribute__((address_space(3))) int32_t*)(uintptr_t)(fposbase + 256u * kk[j]) : T0h;
+            if (FOCUS) pp[j] = (64u * kk[j] + (uint32_t)lane < n_tslots)
+                ? *(const __attribute__((address_space(3))) int32_t*)(uintptr_t)(fposbase + 256u * kk[j]) : T0h;
             else pp[j] = T0h + (int32_t)(64u * kk[j]) + lane;
           }
 #pragma unroll
@@ -1517,7 +1559,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
           }
 #pragma unroll
           for (int j = 0; j < UNROLL; j++)
-            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(Wd[j].y, __builtin_amdgcn_mbcnt_lo(Wd[j].x, 0u))) << 2), (int)c_pk);
+            pkv[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx[j] + __builtin_amdgcn_mbcnt_hi(Wd[j].y,
+                __builtin_amdgcn_mbcnt_lo(Wd[j].x, 0u))) << 2), (int)c_pk);
 #pragma unroll
           for (int j = 0; j < UNROLL; j++) {
             qq[j] = (uint32_t)pp[j] + qbase + (pkv[j] >> 5);
@@ -1558,7 +1601,8 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
           const uint32_t t = ((v[j] >> 2) & 1u) | aln2;
           const uint32_t rowt = (uint32_t)lut[(t << 8) | byte[j]];
           const uint32_t a0 = lds_addr(tal) + 4u * (rs_a + i);
-          if (kind == 0u && rowt < 8u && (!HEMI || ro.ok)) lds_add(a0 + __umul24(rowt, TS4), inc);   // hemi: a failed record gives no feature (its one NoCall came in as an event)
+          // hemi: a failed record gives no feature (its one NoCall came in as an event)
+          if (kind == 0u && rowt < 8u && (!HEMI || ro.ok)) lds_add(a0 + __umul24(rowt, TS4), inc);
           if (kind == 1u) lds_add(a0 + __umul24((uint32_t)MKP_C_DEL, TS4), inc);   // alignment.is_del()
           if (i < nsl) qk[i] = 3u;   // left clean for the wave's next read
         }
@@ -1583,10 +1627,13 @@ __device__ __forceinline__ void pileup_tiles_body(const MkpReadHdr* __restrict__
   // rows of the tile straight from LDS: count, reserve, write (slot order = position order).  One tile per workgroup: nothing of
   // the accumulate phase is live here and nothing of this phase is live there, so neither raises the other's register count
   if (dbg & 4u) {}
-  else if (!FOCUS && !HEMI)   // dense tiles: row-major emission; the row map lives in the per-wave scratch of the accumulate phase (dead behind the barrier above)
-    emit_dense_rows(tal, S, n_counters, n_tslots, T0h, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, prm, rowprog, lds + tal_words + focus_total, min(8192u, PILEUP_WAVES * wave_words),
+  // dense tiles: row-major emission; the row map lives in the per-wave scratch of the accumulate phase (dead behind the barrier above)
+  else if (!FOCUS && !HEMI)
+    emit_dense_rows(tal, S, n_counters, n_tslots, T0h, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, prm, rowprog,
+        lds + tal_words + focus_total, min(8192u, PILEUP_WAVES * wave_words),
                     rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
-  else emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base, row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
+  else emit_tile_rows<FOCUS, HEMI>(tal, sm, n_tslots, tl, KEYED ? key_run * n_tiles + tix : tix, key_filter, &prm, focus, combos_l, rows_base,
+      row_cursor, tile_row_off, tile_row_cnt, dev_err, wave_tot, &row_base, &scan_carry);
   }
 }
 
@@ -1601,15 +1648,18 @@ extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles
 // (focus positions — --cpg / --motif / --include-bed — go through the slot pipeline of mkp_slots.hip; the FOCUS instantiation of this body
 // serves pileup-hemi below)
 // --partition-tag: the same kernel tallying only the reads of one partition key per launch
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_keyed(PILEUP_PARAMS) { pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_keyed(PILEUP_PARAMS) {
+  pileup_tiles_body<false, 4, true>(PILEUP_PASS); }
 // pileup-hemi: the focus kernel with duplex pattern tallies
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_hemi(PILEUP_PARAMS) { pileup_tiles_body<true, 1, false, true>(PILEUP_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_tiles_hemi(PILEUP_PARAMS) {
+  pileup_tiles_body<true, 1, false, true>(PILEUP_PASS); }
 
 // Duplex reads decoded one group per wave (decode_read_sparse): interleave the two position-sorted event lists of a read into the
 // front of its slice and combine the two summaries.  The record fails if either group failed (add_record returns at the first
 // error, read_cache.rs:111-211) and counts as "no modified base information" if neither group added anything.
 extern "C" __global__ void __launch_bounds__(256)
-mkp_merge_duplex(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ read_ids, uint32_t n, const MkpTagRef* __restrict__ tagref, const MkpLayout* __restrict__ layouts,
+mkp_merge_duplex(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ read_ids, uint32_t n, const MkpTagRef* __restrict__ tagref,
+    const MkpLayout* __restrict__ layouts,
                  MkpEvent* __restrict__ events, MkpReadOut* __restrict__ readout, uint32_t roff) {
   const uint32_t lane = (uint32_t)lane_id();
   const uint32_t widx = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -1652,7 +1702,8 @@ mkp_merge_duplex(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
     place(eA, nA, eB, nB, 0u);
     place(eB, nB, eA, nA, 1u);
     out.ok = 1; out.n_events = nA + nB;
-    out.obs[0] = (a.ok == 1u ? a.obs[0] : 0u) | (b.ok == 1u ? b.obs[0] : 0u); out.obs[1] = (a.ok == 1u ? a.obs[1] : 0u) | (b.ok == 1u ? b.obs[1] : 0u);
+    out.obs[0] = (a.ok == 1u ? a.obs[0] : 0u) | (b.ok == 1u ? b.obs[0] : 0u);
+      out.obs[1] = (a.ok == 1u ? a.obs[1] : 0u) | (b.ok == 1u ? b.obs[1] : 0u);
   }
   if (lane == 0) readout[rid] = out;
 }
@@ -1664,8 +1715,10 @@ mkp_merge_duplex(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict
 // covers with an A/C/G/T base (not a deletion or ref-skip).  One thread per record writes those as events into the record's own
 // (unused) event slice, where mkp_pileup_tiles_hemi picks them up.  iv_start = ascending starts of the shard's intervals.
 extern "C" __global__ void __launch_bounds__(256)
-mkp_hemi_failed_reads(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, MkpEvent* __restrict__ events,
-                      MkpReadOut* __restrict__ readout, uint32_t n_reads, const uint32_t* __restrict__ slotbm, const uint32_t* __restrict__ iv_start, uint32_t n_iv,
+mkp_hemi_failed_reads(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs,
+    MkpEvent* __restrict__ events,
+                      MkpReadOut* __restrict__ readout, uint32_t n_reads, const uint32_t* __restrict__ slotbm, const uint32_t* __restrict__ iv_start,
+                          uint32_t n_iv,
                       int32_t win_start, int32_t win_end, uint32_t* __restrict__ dev_err) {
   const uint32_t rid = blockIdx.x * 256u + threadIdx.x;
   if (rid >= n_reads) return;
@@ -1792,7 +1845,9 @@ mkp_sample_accumulate(const MkpReadHdr* __restrict__ hdrs, const MkpReadOut* __r
     }
   }
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < 4u * MKP_HIST_LDS; k += 256) { const uint32_t c = (&lh[0][0])[k]; if (c) atomicAdd(&hist0[(k / MKP_HIST_LDS) * 65536u + MKP_HIST_LO + (k % MKP_HIST_LDS)], c); }
+  for (uint32_t k = threadIdx.x; k < 4u * MKP_HIST_LDS; k += 256) { const uint32_t c = (&lh[0][0])[k];
+    if (c) atomicAdd(&hist0[(k / MKP_HIST_LDS) * 65536u + MKP_HIST_LO + (k % MKP_HIST_LDS)], c);
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -1808,8 +1863,10 @@ mkp_sample_hist1(const uint32_t* __restrict__ store, unsigned long long n, uint3
 // summary_info; filtered calls are counted under their argmax class), reads_with[base] = taken reads with a call on that base,
 // reads_with[4] = taken reads with any call, reads_with[5] = OR of the reads' observed-code slot masks.
 extern "C" __global__ void __launch_bounds__(256)
-mkp_summary_accumulate(const MkpReadHdr* __restrict__ hdrs, const MkpReadOut* __restrict__ readout, const uint8_t* __restrict__ take, uint32_t n_reads,
-                       const MkpEvent* __restrict__ events, unsigned long long* __restrict__ table /*[4][2][16]*/, unsigned long long* __restrict__ reads_with /*[6]*/) {
+mkp_summary_accumulate(const MkpReadHdr* __restrict__ hdrs, const MkpReadOut* __restrict__ readout, const uint8_t* __restrict__ take,
+    uint32_t n_reads,
+                       const MkpEvent* __restrict__ events, unsigned long long* __restrict__ table /*[4][2][16]*/,
+                           unsigned long long* __restrict__ reads_with /*[6]*/) {
   __shared__ uint32_t lt[128];
   __shared__ uint32_t lr[6];
   for (uint32_t k = threadIdx.x; k < 128; k += 256) lt[k] = 0;
@@ -1832,14 +1889,16 @@ mkp_summary_accumulate(const MkpReadHdr* __restrict__ hdrs, const MkpReadOut* __
       }
     }
     bases = wave_or(bases);
-    if (lane == 0) { for (uint32_t b = 0; b < 4; b++) if (bases & (1u << b)) atomicAdd(&lr[b], 1u); atomicAdd(&lr[4], 1u); atomicOr(&lr[5], ro.obs[0] | ro.obs[1]); }
+    if (lane == 0) { for (uint32_t b = 0; b < 4; b++) if (bases & (1u << b)) atomicAdd(&lr[b], 1u); atomicAdd(&lr[4], 1u);
+      atomicOr(&lr[5], ro.obs[0] | ro.obs[1]); }
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < 128; k += 256) if (lt[k]) atomicAdd(&table[k], (unsigned long long)lt[k]);
   if (threadIdx.x < 5 && lr[threadIdx.x]) atomicAdd(&reads_with[threadIdx.x], (unsigned long long)lr[threadIdx.x]);
   if (threadIdx.x == 5 && lr[5]) atomicOr(&reads_with[5], (unsigned long long)lr[5]);
 }
-extern "C" hipError_t mkp_launch_summary_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take, uint32_t n_reads, const MkpEvent* events,
+extern "C" hipError_t mkp_launch_summary_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take,
+    uint32_t n_reads, const MkpEvent* events,
                                                     unsigned long long* table, unsigned long long* reads_with) {
   if (!n_reads) return hipSuccess;
   const uint32_t grid = std::min<uint32_t>((n_reads + 3u) / 4u, 1024u);
@@ -1847,14 +1906,18 @@ extern "C" hipError_t mkp_launch_summary_accumulate(hipStream_t st, const MkpRea
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_launch_sample_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take, uint32_t n_reads, const float* vals,
-                                                   const MkpEvent* events, uint32_t* store, unsigned long long store_cap, unsigned long long* store_cursor, uint32_t* hist0, uint32_t* dev_err) {
+extern "C" hipError_t mkp_launch_sample_accumulate(hipStream_t st, const MkpReadHdr* hdrs, const MkpReadOut* readout, const uint8_t* take,
+    uint32_t n_reads, const float* vals,
+                                                   const MkpEvent* events, uint32_t* store, unsigned long long store_cap,
+                                                       unsigned long long* store_cursor, uint32_t* hist0, uint32_t* dev_err) {
   if (!n_reads) return hipSuccess;
   const uint32_t grid = std::min<uint32_t>((n_reads + 3u) / 4u, 1024u);
-  hipLaunchKernelGGL(mkp_sample_accumulate, dim3(grid), dim3(256), 0, st, hdrs, readout, take, n_reads, vals, events, store, store_cap, store_cursor, hist0, dev_err);
+  hipLaunchKernelGGL(mkp_sample_accumulate, dim3(grid), dim3(256), 0, st, hdrs, readout, take, n_reads, vals, events, store, store_cap, store_cursor,
+      hist0, dev_err);
   return hipGetLastError();
 }
-extern "C" hipError_t mkp_launch_sample_hist1(hipStream_t st, const uint32_t* store, unsigned long long n, uint32_t base, uint32_t prefix, uint32_t* hist1) {
+extern "C" hipError_t mkp_launch_sample_hist1(hipStream_t st, const uint32_t* store, unsigned long long n, uint32_t base, uint32_t prefix,
+    uint32_t* hist1) {
   if (!n) return hipSuccess;
   const uint32_t grid = (uint32_t)std::min<unsigned long long>((n + 255u) / 256u, 4096ull);
   hipLaunchKernelGGL(mkp_sample_hist1, dim3(grid), dim3(256), 0, st, store, n, base, prefix, hist1);
@@ -1864,7 +1927,8 @@ extern "C" hipError_t mkp_launch_sample_hist1(hipStream_t st, const uint32_t* st
 // ----------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
 // read_ids = [SPARSE one tag | SPARSE two tags | FAST one tag | FAST two tags | all other reads], n_class = the five list lengths
-extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* read_ids, const uint32_t* n_class /* [7] */, const uint32_t* cigar, const uint8_t* seqs,
+extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* read_ids, const uint32_t* n_class /* [7] */,
+    const uint32_t* cigar, const uint8_t* seqs,
                                         const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts,
                                         const MkpRunParams* prm, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err,
                                         const uint8_t* bedmask, float* sample_vals) {
@@ -1876,15 +1940,25 @@ extern "C" hipError_t mkp_launch_decode(hipStream_t st, const MkpReadHdr* hdrs, 
       dim3 grid((n + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
       if (cls >= 5) {   // duplex reads, listed once per group (never in sampling mode): SPARSE decode per group, then the merge
         if (prm->sample_mode) return hipErrorInvalidValue;
-        if (cls == 5) hipLaunchKernelGGL(mkp_decode_sparse1, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids);
-        else hipLaunchKernelGGL(mkp_decode_sparse2, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids);
+        if (cls == 5) hipLaunchKernelGGL(mkp_decode_sparse1, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events,
+            readout, dev_err, bedmask, sample_vals, ids);
+        else hipLaunchKernelGGL(mkp_decode_sparse2, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout,
+            dev_err, bedmask, sample_vals, ids);
         hipLaunchKernelGGL(mkp_merge_duplex, grid, block, 0, st, hdrs, ids, n, tagref, layouts, events, readout, prm->readout_b_off);
         ids += n;
         continue;
       }
 #define MKP_DECODE_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, st, hdrs, n, cigar, seqs, tagref, ranks, ml, layouts, *prm, events, readout, dev_err, bedmask, sample_vals, ids)
-      if (prm->sample_mode) { if (cls == 0) MKP_DECODE_LAUNCH(mkp_sample_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_sample_sparse2); else if (cls == 2) MKP_DECODE_LAUNCH(mkp_sample_fast1); else if (cls == 3) MKP_DECODE_LAUNCH(mkp_sample_fast2); else MKP_DECODE_LAUNCH(mkp_sample_reads); }
-      else { if (cls == 0) MKP_DECODE_LAUNCH(mkp_decode_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_decode_sparse2); else if (cls == 2) MKP_DECODE_LAUNCH(mkp_decode_fast1); else if (cls == 3) MKP_DECODE_LAUNCH(mkp_decode_fast2); else MKP_DECODE_LAUNCH(mkp_decode_reads); }
+      if (prm->sample_mode) { if (cls == 0) MKP_DECODE_LAUNCH(mkp_sample_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_sample_sparse2);
+        else if (cls == 2) MKP_DECODE_LAUNCH(mkp_sample_fast1);
+        else if (cls == 3) MKP_DECODE_LAUNCH(mkp_sample_fast2);
+        else MKP_DECODE_LAUNCH(mkp_sample_reads);
+        }
+      else { if (cls == 0) MKP_DECODE_LAUNCH(mkp_decode_sparse1); else if (cls == 1) MKP_DECODE_LAUNCH(mkp_decode_sparse2);
+        else if (cls == 2) MKP_DECODE_LAUNCH(mkp_decode_fast1);
+        else if (cls == 3) MKP_DECODE_LAUNCH(mkp_decode_fast2);
+        else MKP_DECODE_LAUNCH(mkp_decode_reads);
+        }
     }
     ids += n;
   }
@@ -1900,10 +1974,14 @@ extern "C" hipError_t mkp_pileup_set_lds(uint32_t accum_bytes) {
   return hipSuccess;
 }
 
-extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int focus_mode, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs,
-                                        const MkpEvent* events, const MkpReadOut* readout, const MkpTile* tiles, uint32_t n_tiles, const MkpRunParams* prm_dev,
-                                        const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot) {
+extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int focus_mode, const MkpReadHdr* hdrs, const uint32_t* cigar,
+    const uint8_t* seqs,
+                                        const MkpEvent* events, const MkpReadOut* readout, const MkpTile* tiles, uint32_t n_tiles,
+                                            const MkpRunParams* prm_dev,
+                                        const uint32_t* slotbm, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows,
+                                            uint32_t* row_cursor,
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, const uint32_t* chunk_pfx, uint32_t* dev_err,
+                                            uint32_t key_filter, uint32_t key_slot) {
   if (!n_tiles) return hipSuccess;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;
   const uint32_t key_arg = keyed ? ((key_filter & 0xffffu) | (key_slot << 16)) : 0u;
@@ -1917,10 +1995,13 @@ extern "C" hipError_t mkp_launch_pileup(hipStream_t st, uint32_t lds_bytes, int 
   return hipGetLastError();
 }
 
-extern "C" hipError_t mkp_launch_hemi_failed(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs, MkpEvent* events, MkpReadOut* readout, uint32_t n_reads,
-                                             const uint32_t* slotbm, const uint32_t* iv_start, uint32_t n_iv, int32_t win_start, int32_t win_end, uint32_t* dev_err) {
+extern "C" hipError_t mkp_launch_hemi_failed(hipStream_t st, const MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs, MkpEvent* events,
+    MkpReadOut* readout, uint32_t n_reads,
+                                             const uint32_t* slotbm, const uint32_t* iv_start, uint32_t n_iv, int32_t win_start, int32_t win_end,
+                                                 uint32_t* dev_err) {
   if (!n_reads) return hipSuccess;
-  hipLaunchKernelGGL(mkp_hemi_failed_reads, dim3((n_reads + 255u) / 256u), dim3(256), 0, st, hdrs, cigar, seqs, events, readout, n_reads, slotbm, iv_start, n_iv, win_start, win_end, dev_err);
+  hipLaunchKernelGGL(mkp_hemi_failed_reads, dim3((n_reads + 255u) / 256u), dim3(256), 0, st, hdrs, cigar, seqs, events, readout, n_reads, slotbm,
+      iv_start, n_iv, win_start, win_end, dev_err);
   return hipGetLastError();
 }
 

@@ -35,7 +35,8 @@ class FxOrder {
   struct B { bool used = false; uint32_t code = 0; int tag = 0; };
   std::vector<B> b_; size_t n_ = 0;
   static size_t capacity(size_t nb) { return nb == 0 ? 0 : (nb < 8 ? nb - 1 : nb / 8 * 7); }
-  static size_t buckets_for(size_t cap) { if (cap < 4) return 4; if (cap < 8) return 8; size_t adj = cap * 8 / 7, p = 1; while (p < adj) p <<= 1; return p; }
+  static size_t buckets_for(size_t cap) { if (cap < 4) return 4; if (cap < 8) return 8; size_t adj = cap * 8 / 7, p = 1; while (p < adj) p <<= 1;
+    return p; }
   static uint64_t hash(uint32_t code_repr) {
     auto add = [](uint64_t h, uint64_t w) { return (((h << 5) | (h >> 59)) ^ w) * 0x517cc1b727220a95ull; };
     bool chebi = (code_repr & 0x80000000u) != 0;
@@ -64,7 +65,9 @@ struct CallerCfg {  // mkp_caller, owned copy
 
 struct SlotTable {
   std::vector<MkpSlot> slots; std::vector<int> can_pbs;  // primary bases having a CAN counter
-  int find_slot(int pb, uint32_t code) const { for (size_t i = 0; i < slots.size(); i++) if (slots[i].pb == pb && slots[i].code_repr == code) return (int)i; return -1; }
+  int find_slot(int pb, uint32_t code) const {
+    for (size_t i = 0; i < slots.size(); i++) if (slots[i].pb == pb && slots[i].code_repr == code) return (int)i;
+    return -1; }
   int find_can(int pb) const { for (size_t i = 0; i < can_pbs.size(); i++) if (can_pbs[i] == pb) return (int)i; return -1; }
 };
 
@@ -96,12 +99,15 @@ struct LayoutTables {
       if (mem.empty()) continue;
       int pb = (sg && !cc.read_base_caller) ? 3 - b : b;  // threshold_base (read_cache.rs:147-150)
       if (st.find_can(pb) < 0) st.can_pbs.push_back(pb);
-      for (uint32_t c : uni) { if (collapse && c == cc.collapse_code) continue; if (st.find_slot(pb, c) < 0) { MkpSlot s; memset(&s, 0, sizeof(s)); s.code_repr = c; s.pb = (uint8_t)pb; st.slots.push_back(s); } }
+      for (uint32_t c : uni) { if (collapse && c == cc.collapse_code) continue; if (st.find_slot(pb, c) < 0) { MkpSlot s; memset(&s, 0, sizeof(s));
+          s.code_repr = c; s.pb = (uint8_t)pb; st.slots.push_back(s); } }
     }
-    if (st.slots.size() > MKP_MAX_SLOTS) throw Error(MKP_E_UNSUPPORTED, "more than " + std::to_string(MKP_MAX_SLOTS) + " distinct (base, mod code) pairs in one run");
+    if (st.slots.size() > MKP_MAX_SLOTS) throw Error(MKP_E_UNSUPPORTED,
+        "more than " + std::to_string(MKP_MAX_SLOTS) + " distinct (base, mod code) pairs in one run");
     std::sort(st.can_pbs.begin(), st.can_pbs.end());
     n_counters = 6 + (uint32_t)st.can_pbs.size() + (uint32_t)st.slots.size();
-    for (size_t i = 0; i < st.slots.size(); i++) { st.slots[i].cid = (uint8_t)(6 + st.can_pbs.size() + i); st.slots[i].can_cid = (uint8_t)(6 + st.find_can(st.slots[i].pb)); }
+    for (size_t i = 0; i < st.slots.size(); i++) { st.slots[i].cid = (uint8_t)(6 + st.can_pbs.size() + i);
+      st.slots[i].can_cid = (uint8_t)(6 + st.find_can(st.slots[i].pb)); }
     // pass 2: per-layout tables
     for (size_t li = 0; li < layouts.size(); li++) {
       const LayoutHost& L = layouts[li];
@@ -110,19 +116,25 @@ struct LayoutTables {
       D.n_tags = (uint8_t)L.tags.size();
       { bool fast = !L.tags.empty(); std::vector<uint32_t> seen_codes;
         for (auto& th : L.tags) { if (th.fb == 4 || th.fb != L.tags[0].fb || th.neg != L.tags[0].neg || th.codes.empty()) fast = false;
-          for (uint32_t c : th.codes) { if (std::find(seen_codes.begin(), seen_codes.end(), c) != seen_codes.end()) fast = false; seen_codes.push_back(c); } }
+          for (uint32_t c : th.codes) { if (std::find(seen_codes.begin(), seen_codes.end(), c) != seen_codes.end()) fast = false;
+            seen_codes.push_back(c); } }
         D.fast = fast ? 1 : 0;
         // duplex: a leading run of tags on one (strand, base) and the rest on another one, different base, at most two tags each and no
         // code listed twice inside a group (`C+h?;C+m?;G-h?;G-m?`, `C+hm?;G-hm?`): each group decodes like a single-group read
         if (!fast && L.tags.size() >= 2 && L.tags.size() <= 4) {
           size_t nA = 1; while (nA < L.tags.size() && L.tags[nA].fb == L.tags[0].fb && L.tags[nA].neg == L.tags[0].neg) nA++;
-          bool ok = nA < L.tags.size() && nA <= 2 && L.tags.size() - nA <= 2 && L.tags[0].fb < 4 && L.tags[nA].fb < 4 && L.tags[nA].fb != L.tags[0].fb;
+          bool ok = nA < L.tags.size() && nA <= 2 && L.tags.size() - nA <= 2 && L.tags[0].fb < 4 && L.tags[nA].fb < 4
+              && L.tags[nA].fb != L.tags[0].fb;
           for (size_t t = nA; ok && t < L.tags.size(); t++) ok = L.tags[t].fb == L.tags[nA].fb && L.tags[t].neg == L.tags[nA].neg;
-          for (size_t g = 0; ok && g < 2; g++) { std::vector<uint32_t> seen; for (size_t t = g ? nA : 0; t < (g ? L.tags.size() : nA); t++) { if (L.tags[t].codes.empty()) ok = false; for (uint32_t c : L.tags[t].codes) { if (std::find(seen.begin(), seen.end(), c) != seen.end()) ok = false; seen.push_back(c); } } }
+          for (size_t g = 0; ok && g < 2; g++) { std::vector<uint32_t> seen; for (size_t t = g ? nA : 0; t < (g ? L.tags.size() : nA); t++) {
+              if (L.tags[t].codes.empty()) ok = false;
+              for (uint32_t c : L.tags[t].codes) { if (std::find(seen.begin(), seen.end(), c) != seen.end()) ok = false;
+                seen.push_back(c); } } }
           if (ok) { D.fast = 2; D.pad = (uint8_t)nA; }
         } }
       for (size_t t = 0; t < L.tags.size(); t++) {
-        D.tags[t].fb = L.tags[t].fb; D.tags[t].neg = L.tags[t].neg; D.tags[t].mode = L.tags[t].mode; D.tags[t].n_codes = (uint8_t)L.tags[t].codes.size();
+        D.tags[t].fb = L.tags[t].fb; D.tags[t].neg = L.tags[t].neg; D.tags[t].mode = L.tags[t].mode;
+          D.tags[t].n_codes = (uint8_t)L.tags[t].codes.size();
         if (L.tags[t].mode == 2) D.default_mask |= (uint8_t)(1u << t);
       }
       for (int sg = 0; sg < 2; sg++) for (int b = 0; b < 4; b++) {
@@ -141,7 +153,9 @@ struct LayoutTables {
           // threshold resolution (threshold_mod_caller.rs:36-43)
           float thr; auto a = cc.per_mod.find(uni[k]);
           if (a != cc.per_mod.end()) thr = a->second;
-          else { auto any = cc.per_mod.find((uint32_t)"ACGT"[pb]); if (any != cc.per_mod.end()) thr = any->second; else thr = cc.has_per_base[pb] ? cc.per_base[pb] : cc.default_threshold; }
+          else { auto any = cc.per_mod.find((uint32_t)"ACGT"[pb]); if (any != cc.per_mod.end()) thr = any->second;
+            else thr = cc.has_per_base[pb] ? cc.per_base[pb] : cc.default_threshold;
+            }
           G.thr_mod[k] = thr;
         }
         G.thr_can = cc.has_per_base[pb] ? cc.per_base[pb] : cc.default_threshold;
@@ -167,14 +181,18 @@ struct LayoutTables {
           }
           std::vector<int> pre = agg.order(); std::vector<uint32_t> prec = agg.codes();
           std::vector<int> post = pre;
-          if (collapse) { FxOrder nm; for (size_t i = 0; i < pre.size(); i++) if (prec[i] != cc.collapse_code) nm.insert(prec[i], pre[i]); post = nm.order(); }
+          if (collapse) { FxOrder nm; for (size_t i = 0; i < pre.size(); i++) if (prec[i] != cc.collapse_code) nm.insert(prec[i], pre[i]);
+            post = nm.order(); }
           uint32_t v = (uint32_t)pre.size() | ((uint32_t)post.size() << 3);
           for (size_t i = 0; i < pre.size(); i++) v |= (uint32_t)pre[i] << (8 + 2 * i);
           for (size_t i = 0; i < post.size(); i++) v |= (uint32_t)post[i] << (16 + 2 * i);
           G.pat[pat] = v;
         };
-        for (int pat = 1; pat < (1 << mem.size()); pat++) { std::vector<int> hm; for (size_t mi = 0; mi < mem.size(); mi++) if (pat & (1 << mi)) hm.push_back((int)mi); fill(pat, hm, false); }
-        if (implicit) { std::vector<int> hm; for (size_t mi = 0; mi < mem.size(); mi++) if (implicit & (1u << mi)) hm.push_back((int)mi); fill(MKP_PAT_INFERRED, hm, true); }
+        for (int pat = 1; pat < (1 << mem.size()); pat++) { std::vector<int> hm;
+          for (size_t mi = 0; mi < mem.size(); mi++) if (pat & (1 << mi)) hm.push_back((int)mi);
+          fill(pat, hm, false); }
+        if (implicit) { std::vector<int> hm; for (size_t mi = 0; mi < mem.size(); mi++) if (implicit & (1u << mi)) hm.push_back((int)mi);
+          fill(MKP_PAT_INFERRED, hm, true); }
       }
       dev.push_back(D);
     }
@@ -211,10 +229,12 @@ struct ShardHost {
   PodVec<uint32_t> ranks; PodVec<uint8_t> ml;
   uint64_t n_events_cap = 0, n_calls = 0;
   PodVec<uint64_t> name_hash;  // for duplicate-qname detection (read cache is keyed by name, read_cache.rs:28-35)
-  std::vector<std::pair<int32_t, int32_t>> extra_spans;   // reference spans of records htslib's pileup buffers but the path drops (supplementary): max-depth guard only
+  // reference spans of records htslib's pileup buffers but the path drops (supplementary): max-depth guard only
+  std::vector<std::pair<int32_t, int32_t>> extra_spans;
   // Device ingest (mkp_ingest.hip): cigar / chunk_pfx / seq / ranks / ml were written in HBM and never existed on the host; hdr, tagref
   // (MKP_MAX_TAGS entries per read, pad = "same delta list as the tag before") and name_hash are the digest the planner works from.
-  bool dev_packed = false; std::vector<uint8_t> dev_sum2;   // per read: the probability-sum test of a two-tag read (what make_resident computes from S.ml otherwise)
+  // per read: the probability-sum test of a two-tag read (what make_resident computes from S.ml otherwise)
+  bool dev_packed = false; std::vector<uint8_t> dev_sum2;
   uint64_t dev_n_ranks = 0, dev_n_ml = 0;
   std::vector<uint64_t> dev_name_hash2; std::vector<uint32_t> dev_win_idx;   // second name hash; place in the window (file order)
   // records of the window only the threshold sampler takes (QC-fail, CIGAR-less): packed behind the kept ones in the same HBM arrays; their
@@ -229,31 +249,39 @@ struct ShardHost {
     uint64_t calls = n_calls;
     for (size_t i = 0; i < ps.size(); i++) {
       const ShardHost& o = ps[i];
-      b[i + 1] = {b[i].hdr + o.hdr.size(), b[i].cigar + o.cigar.size(), b[i].chunk + o.chunk_pfx.size(), b[i].seq + o.seq.size(), b[i].tag + o.tagref.size(),
+      b[i + 1] = {b[i].hdr + o.hdr.size(), b[i].cigar + o.cigar.size(), b[i].chunk + o.chunk_pfx.size(), b[i].seq + o.seq.size(),
+          b[i].tag + o.tagref.size(),
                   b[i].rank + o.ranks.size(), b[i].ml + o.ml.size(), b[i].name + o.name_hash.size(), b[i].ev + o.n_events_cap};
       calls += o.n_calls;
     }
     const Base& e = b[ps.size()];
-    if (e.seq > 0xfffffff0ull || e.cigar > 0xfffffff0ull || e.rank > 0xfffffff0ull || e.ml > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
+    if (e.seq > 0xfffffff0ull || e.cigar > 0xfffffff0ull || e.rank > 0xfffffff0ull || e.ml > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED,
+        "shard exceeds 4 GiB of packed bases; use smaller shards");
     if (e.ev > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 Gi call events; use smaller shards");
-    hdr.resize(e.hdr); cigar.resize(e.cigar); chunk_pfx.resize(e.chunk); seq.resize(e.seq); tagref.resize(e.tag); ranks.resize(e.rank); ml.resize(e.ml); name_hash.resize(e.name);
+    hdr.resize(e.hdr); cigar.resize(e.cigar); chunk_pfx.resize(e.chunk); seq.resize(e.seq); tagref.resize(e.tag); ranks.resize(e.rank);
+      ml.resize(e.ml); name_hash.resize(e.name);
     auto place = [&](size_t i) {
       const ShardHost& o = ps[i]; const Base& at = b[i]; const std::vector<uint16_t>& lm = layout_maps[i];
       auto cp = [](auto& dst, size_t off, const auto& src) { if (!src.empty()) memcpy(dst.data() + off, src.data(), src.size() * sizeof(src[0])); };
-      cp(cigar, at.cigar, o.cigar); cp(chunk_pfx, at.chunk, o.chunk_pfx); cp(seq, at.seq, o.seq); cp(ranks, at.rank, o.ranks); cp(ml, at.ml, o.ml); cp(name_hash, at.name, o.name_hash);
+      cp(cigar, at.cigar, o.cigar); cp(chunk_pfx, at.chunk, o.chunk_pfx); cp(seq, at.seq, o.seq); cp(ranks, at.rank, o.ranks); cp(ml, at.ml, o.ml);
+        cp(name_hash, at.name, o.name_hash);
       for (size_t k = 0; k < o.hdr.size(); k++) {
         MkpReadHdr h = o.hdr[k];
-        h.cigar_off += (uint32_t)at.cigar; h.chunk_off += (uint32_t)(at.chunk / 2); h.seq_off += (uint32_t)at.seq; h.tag_off += (uint32_t)at.tag; h.event_off += (uint32_t)at.ev;
+        h.cigar_off += (uint32_t)at.cigar; h.chunk_off += (uint32_t)(at.chunk / 2); h.seq_off += (uint32_t)at.seq; h.tag_off += (uint32_t)at.tag;
+          h.event_off += (uint32_t)at.ev;
         if (h.n_tags) h.layout = lm[h.layout];
         hdr[at.hdr + k] = h;
       }
-      for (size_t k = 0; k < o.tagref.size(); k++) { MkpTagRef t = o.tagref[k]; t.rank_off += (uint32_t)at.rank; t.ml_off += (uint32_t)at.ml; tagref[at.tag + k] = t; }
+      for (size_t k = 0; k < o.tagref.size(); k++) { MkpTagRef t = o.tagref[k]; t.rank_off += (uint32_t)at.rank; t.ml_off += (uint32_t)at.ml;
+        tagref[at.tag + k] = t; }
     };
     HostPool::get().parallel(ps.size(), place);
     n_events_cap = e.ev; n_calls = calls;
   }
-  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0; name_hash.clear(); extra_spans.clear();
-               dev_packed = false; dev_sum2.clear(); dev_n_ranks = dev_n_ml = 0; dev_name_hash2.clear(); dev_win_idx.clear(); so_hdr.clear(); so_name_hash.clear(); so_name_hash2.clear(); so_win_idx.clear(); }
+  void clear() { hdr.clear(); cigar.clear(); chunk_pfx.clear(); seq.clear(); tagref.clear(); ranks.clear(); ml.clear(); n_events_cap = 0; n_calls = 0;
+    name_hash.clear(); extra_spans.clear();
+               dev_packed = false; dev_sum2.clear(); dev_n_ranks = dev_n_ml = 0; dev_name_hash2.clear(); dev_win_idx.clear(); so_hdr.clear();
+                 so_name_hash.clear(); so_name_hash2.clear(); so_win_idx.clear(); }
 };
 
 class Packer {
@@ -291,7 +319,8 @@ class Packer {
         case 'i': case 'I': case 'f': len = 4; break;
         case 'd': len = 8; break;
         case 'Z': case 'H': { size_t k = v; while (k < n && aux[k]) k++; len = k - v + 1; break; }
-        case 'B': { if (v + 5 > n) return nullptr; char st = (char)aux[v]; uint32_t c; memcpy(&c, aux + v + 1, 4); size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; len = 5 + es * (size_t)c; break; }
+        case 'B': { if (v + 5 > n) return nullptr; char st = (char)aux[v]; uint32_t c; memcpy(&c, aux + v + 1, 4); size_t es = (st == 'c'
+            || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; len = 5 + es * (size_t)c; break; }
         default: return nullptr;
       }
       if (v + len > n) return nullptr;
@@ -314,12 +343,16 @@ class Packer {
         case 's': case 'S': len = 2; break;
         case 'i': case 'I': case 'f': len = 4; break;
         case 'd': len = 8; break;
-        case 'Z': case 'H': { const void* z = v < n ? memchr(aux + v, 0, n - v) : nullptr; len = z ? (size_t)((const uint8_t*)z - (aux + v)) + 1 : n - v + 1; break; }   // (no terminator: runs past the end, malformed below)
-        case 'B': { if (v + 5 > n) return; const char st = (char)aux[v]; uint32_t c; memcpy(&c, aux + v + 1, 4); const size_t es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; len = 5 + es * (size_t)c; break; }
+        // (no terminator: runs past the end, malformed below)
+        case 'Z': case 'H': { const void* z = v < n ? memchr(aux + v, 0, n - v) : nullptr; len = z ? (size_t)((const uint8_t*)z - (aux + v)) + 1
+            : n - v + 1; break; }
+        case 'B': { if (v + 5 > n) return; const char st = (char)aux[v]; uint32_t c; memcpy(&c, aux + v + 1, 4); const size_t es = (st == 'c'
+            || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4; len = 5 + es * (size_t)c; break; }
         default: return;
       }
       if (v + len > n) return;
-      for (int k = 0; k < n_tags; k++) if (!out[k] && (char)aux[o] == tags[k][0] && (char)aux[o + 1] == tags[k][1]) { out[k] = aux + o + 2; missing--; }
+      for (int k = 0; k < n_tags; k++) if (!out[k] && (char)aux[o] == tags[k][0] && (char)aux[o + 1] == tags[k][1]) { out[k] = aux + o + 2; missing--;
+        }
       o = v + len;
     }
   }
@@ -331,7 +364,9 @@ class Packer {
 
   void add(const mkp_record& r, ShardHost& S) {
     MkpReadHdr h; memset(&h, 0, sizeof(h));
-    if (!r.data || r.l_data < 0 || r.l_qseq < 0 || (uint64_t)r.l_qname + 4ull * r.n_cigar + ((uint64_t)r.l_qseq + 1) / 2 + (uint64_t)r.l_qseq > (uint64_t)r.l_data)
+    if (!r.data
+        || r.l_data < 0
+        || r.l_qseq < 0 || (uint64_t)r.l_qname + 4ull * r.n_cigar + ((uint64_t)r.l_qseq + 1) / 2 + (uint64_t)r.l_qseq > (uint64_t)r.l_data)
       throw Error(MKP_E_INVALID, "record data shorter than its fields");
     const uint8_t* cg = r.data + r.l_qname;
     const uint8_t* sq = cg + 4 * (size_t)r.n_cigar;
@@ -341,22 +376,29 @@ class Packer {
     int64_t reflen = 0, qlen = 0;
     h.cigar_off = (uint32_t)S.cigar.size();
     uint32_t n_cigar = r.n_cigar;
-    if (n_cigar == 0) { S.cigar.push_back(((uint32_t)r.l_qseq << 4) | 4u); n_cigar = 1; qlen = r.l_qseq; }  // unaligned record (sampling only): one soft clip
+    // unaligned record (sampling only): one soft clip
+    if (n_cigar == 0) { S.cigar.push_back(((uint32_t)r.l_qseq << 4) | 4u); n_cigar = 1; qlen = r.l_qseq; }
     h.chunk_off = (uint32_t)(S.chunk_pfx.size() / 2);
     if (r.n_cigar == 0) { S.chunk_pfx.push_back(0); S.chunk_pfx.push_back(0); }
     for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cg + 4 * k, 4); S.cigar.push_back(w); uint32_t op = w & 15;
-      if ((k & 63u) == 0) { S.chunk_pfx.push_back((uint32_t)qlen); S.chunk_pfx.push_back((uint32_t)reflen); } if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += w >> 4; if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += w >> 4; }
+      if ((k & 63u) == 0) { S.chunk_pfx.push_back((uint32_t)qlen); S.chunk_pfx.push_back((uint32_t)reflen);
+        } if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += w >> 4;
+        if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += w >> 4;
+        }
     if (qlen != r.l_qseq) throw Error(MKP_E_INVALID, "CIGAR query length does not match SEQ length");
-    if (qlen >= (1 << 26) || reflen >= (1 << 26)) throw Error(MKP_E_UNSUPPORTED, "a read or its alignment spans 2^26 bases or more (the depth walk packs query offsets in 27 bits)");
+    if (qlen >= (1 << 26) || reflen >= (1 << 26)) throw Error(MKP_E_UNSUPPORTED,
+        "a read or its alignment spans 2^26 bases or more (the depth walk packs query offsets in 27 bits)");
     h.ref_start = r.pos; h.ref_end = r.pos + (int32_t)reflen; h.l_seq = (uint32_t)r.l_qseq; h.n_cigar = n_cigar;
-    if (S.seq.size() + (size_t)r.l_qseq / 2 + 8 > 0xfffffff0ull || S.cigar.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED, "shard exceeds 4 GiB of packed bases; use smaller shards");
+    if (S.seq.size() + (size_t)r.l_qseq / 2 + 8 > 0xfffffff0ull || S.cigar.size() > 0xfffffff0ull) throw Error(MKP_E_UNSUPPORTED,
+        "shard exceeds 4 GiB of packed bases; use smaller shards");
     h.seq_off = (uint32_t)S.seq.size();
     S.seq.insert(S.seq.end(), sq, sq + ((size_t)r.l_qseq + 1) / 2);
     while (S.seq.size() & 3) S.seq.push_back(0);
     h.flags = (r.flag & 16) ? MKP_RF_REVERSE : 0;
     h.tag_off = (uint32_t)S.tagref.size();
     h.event_off = (uint32_t)S.n_events_cap;
-    { uint64_t hh = 1469598103934665603ull; for (int i = 0; i + 1 < r.l_qname; i++) { hh ^= r.data[i]; hh *= 1099511628211ull; } S.name_hash.push_back(hh); }
+    { uint64_t hh = 1469598103934665603ull; for (int i = 0; i + 1 < r.l_qname; i++) { hh ^= r.data[i]; hh *= 1099511628211ull;
+      } S.name_hash.push_back(hh); }
     size_t rank_mark = S.ranks.size(), ml_mark = S.ml.size(), tag_mark = S.tagref.size();
     uint64_t cap = 0;
     if (!tokenise(r, aux, aux_n, S, &h, &cap)) {  // tag error: the read only contributes coverage (read_cache.rs:272-277)
@@ -392,7 +434,8 @@ class Packer {
         default: return false;
       }
       if ((uint64_t)v != (uint64_t)(uint32_t)r.l_qseq) return false;  // check_mn_tag_correct (mod_bam.rs:1431-1449)
-    } else if (r.flag & (256 | 1024 | 2048)) return false;             // NonPrimaryMissingMn: a secondary / supplementary / duplicate record needs MN (1444-1446)
+    // NonPrimaryMissingMn: a secondary / supplementary / duplicate record needs MN (1444-1446)
+    } else if (r.flag & (256 | 1024 | 2048)) return false;
     const char* s = (const char*)mm + 1;
     std::string key; std::vector<TagHeader> hdrs; std::vector<MkpTagRef> refs;
     uint32_t ml_base = (uint32_t)S.ml.size(); uint64_t pointer = 0; uint64_t calls = 0; bool implicit_strand[2] = {false, false};
@@ -403,15 +446,19 @@ class Packer {
         const char* p = s; const char* he = s; while (he < e && *he != ',') he++;
         TagHeader th;
         if (p >= he) return false;
-        switch (*p) { case 'A': th.fb = 0; break; case 'C': th.fb = 1; break; case 'G': th.fb = 2; break; case 'T': case 'U': th.fb = 3; break; case 'N': th.fb = 4; break; default: return false; }
+        switch (*p) { case 'A': th.fb = 0; break; case 'C': th.fb = 1; break; case 'G': th.fb = 2; break; case 'T': case 'U': th.fb = 3; break;
+          case 'N': th.fb = 4; break; default: return false; }
         p++; if (p >= he) return false;
         if (*p == '+') th.neg = false; else if (*p == '-') th.neg = true; else return false;
         p++; th.mode = 2; bool chebi = false; size_t offset = 2;
-        if (p < he && *p >= '0' && *p <= '9') { uint64_t v = 0; while (p < he && *p >= '0' && *p <= '9') { v = v * 10 + (uint64_t)(*p - '0'); if (v > 0x7fffffffull) return false; p++; offset++; } th.codes.push_back(0x80000000u | (uint32_t)v); chebi = true; }
+        if (p < he && *p >= '0' && *p <= '9') { uint64_t v = 0; while (p < he && *p >= '0' && *p <= '9') { v = v * 10 + (uint64_t)(*p - '0');
+            if (v > 0x7fffffffull) return false;
+            p++; offset++; } th.codes.push_back(0x80000000u | (uint32_t)v); chebi = true; }
         for (; p < he; p++) {
           if (*p == '?' || *p == '.') { th.mode = *p == '?' ? 0 : 1; offset++; }
           else if (*p >= '0' && *p <= '9') return false;
-          else { if (chebi) return false; if ((unsigned char)*p >= 0x80) throw Error(MKP_E_UNSUPPORTED, "non-ASCII mod code"); th.codes.push_back((uint32_t)(unsigned char)*p); offset++; }
+          else { if (chebi) return false; if ((unsigned char)*p >= 0x80) throw Error(MKP_E_UNSUPPORTED, "non-ASCII mod code");
+            th.codes.push_back((uint32_t)(unsigned char)*p); offset++; }
         }
         if (th.codes.size() > MKP_KMAX) throw Error(MKP_E_UNSUPPORTED, "more than 4 mod codes in one MM tag");
         // ---- delta list -> cumulative ranks (to_positions_specific / to_positions, mod_bam.rs:697-767)

@@ -39,7 +39,8 @@
 struct SlotLds { int32_t ck_thr[4]; uint32_t ck_off[4]; uint32_t ck_str[4]; uint32_t ck_cid[4]; uint32_t F[SL_FW]; uint32_t B[SL_FW + 2]; uint16_t P[SL_FW]; uint16_t WP[SL_FW + 2]; };
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 // flag word of a SEQ dword: bit 4n set where nibble n equals the BAM code in `pat`
 __device__ __forceinline__ uint32_t nib_eq(uint32_t x, uint32_t pat) { uint32_t t = x ^ pat; t |= t >> 1; t |= t >> 2; return ~t & 0x11111111u; }
 // the eight flags (bits 4n) gathered into bits n
@@ -59,12 +60,15 @@ struct RefWin {
   uint32_t c0, q_run, Rtot, Qtot, re, m1, m2, m3, pk[4]; int32_t r_run; uint4 pref; bool loaded;
 };
 // loads as `uniform base + 32-bit byte offset`: the address is one VALU instruction (global saddr form), not 64-bit arithmetic
-template <class T> __device__ __forceinline__ T ldo(const void* __restrict__ base, uint32_t byte_off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
+template <class T> __device__ __forceinline__ T ldo(const void* __restrict__ base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off); }
 // four CIGAR words per lane; the address is clamped to the read's last op (the buffer has slack behind it), ops past the end read as 0H
 __device__ __forceinline__ uint4 cigar_quad(const uint32_t* __restrict__ cg, uint32_t n_cigar, uint32_t c) {
   const uint32_t k = c + 4u * (uint32_t)lane_id();
   uint4 r = ldo<uint4>(cg, 4u * min(k, n_cigar - 1u));
-  if (__any(k + 4u > n_cigar)) { if (k >= n_cigar) r.x = 5u; if (k + 1u >= n_cigar) r.y = 5u; if (k + 2u >= n_cigar) r.z = 5u; if (k + 3u >= n_cigar) r.w = 5u; }
+  if (__any(k + 4u > n_cigar)) { if (k >= n_cigar) r.x = 5u; if (k + 1u >= n_cigar) r.y = 5u; if (k + 2u >= n_cigar) r.z = 5u;
+    if (k + 3u >= n_cigar) r.w = 5u;
+    }
   return r;
 }
 // per op code (MIDNSHP=X): bit 0 consumes query, bit 1 consumes reference, bits 2-3 kind
@@ -98,7 +102,8 @@ __device__ __forceinline__ void refwin_load(RefWin& w, const uint32_t* __restric
 }
 // (kind, query index) of the reference positions p (ascending over the lanes and from call to call; `valid` lanes lie inside the
 // read's reference span).  htslib pileup columns: M = X -> the base, D -> is_del, N -> is_refskip (pileup/mod.rs:783-851).
-__device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start, bool valid, int32_t p, uint32_t* kind, uint32_t* q) {
+__device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start, bool valid, int32_t p,
+    uint32_t* kind, uint32_t* q) {
   bool pending = valid; *kind = 2u; *q = 0u;
   for (;;) {
     if (!__any(pending)) break;
@@ -119,7 +124,8 @@ __device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict
     }
     { const uint32_t vv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)probe, (int)w.re); probe = vv <= rel ? probe + 4u : probe; }
     const int oa = (int)(probe & 255u);
-    const uint32_t o_m1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m1), o_m2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m2), o_m3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m3);
+    const uint32_t o_m1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m1), o_m2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m2),
+        o_m3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m3);
     const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[0]), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[1]);
     const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[2]), o3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[3]);
     const uint32_t pk = rel < o_m1 ? o0 : rel < o_m2 ? o1 : rel < o_m3 ? o2 : o3;
@@ -134,7 +140,8 @@ __device__ __forceinline__ void refwin_map(RefWin& w, const uint32_t* __restrict
 // the steps that straddle windows (the one loop of refwin_map kept every window register twice and copied 14 of them per iteration).
 struct RefWinS { uint32_t c0, q_run, Rtot, Qtot; int32_t r_run; uint32_t re, m1, m2, m3, pk[4]; uint4 pref; };
 __device__ __forceinline__ void refwin_s_init(RefWinS& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start) {
-  w.c0 = 0u - 256u; w.q_run = 0; w.r_run = ref_start; w.Rtot = 0; w.Qtot = 0; w.re = w.m1 = w.m2 = w.m3 = 0; w.pk[0] = w.pk[1] = w.pk[2] = w.pk[3] = 0;
+  w.c0 = 0u - 256u; w.q_run = 0; w.r_run = ref_start; w.Rtot = 0; w.Qtot = 0; w.re = w.m1 = w.m2 = w.m3 = 0;
+    w.pk[0] = w.pk[1] = w.pk[2] = w.pk[3] = 0;
   w.pref = cigar_quad(cg, n_cigar, 0);
 }
 // the next 256 ops; false behind the last op
@@ -182,13 +189,15 @@ __device__ __forceinline__ void refwin_s_pass(const RefWinS& w, int32_t ref_star
   }
   { const uint32_t vv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)probe, (int)w.re); probe = vv <= rel ? probe + 4u : probe; }
   const int oa = (int)(probe & 255u);
-  const uint32_t o_m1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m1), o_m2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m2), o_m3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m3);
+  const uint32_t o_m1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m1), o_m2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m2),
+      o_m3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.m3);
   const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[0]), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[1]);
   const uint32_t o2 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[2]), o3 = (uint32_t)__builtin_amdgcn_ds_bpermute(oa, (int)w.pk[3]);
   const uint32_t pk = rel < o_m1 ? o0 : rel < o_m2 ? o1 : rel < o_m3 ? o2 : o3;
   if (inw) { kind = pk & 3u; q = (uint32_t)((p - ref_start) + ((int32_t)pk >> 2)); pending = false; }
 }
-__device__ __forceinline__ void refwin_s_map(RefWinS& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start, bool valid, int32_t p, uint32_t* kind_out, uint32_t* q_out) {
+__device__ __forceinline__ void refwin_s_map(RefWinS& w, const uint32_t* __restrict__ cg, uint32_t n_cigar, int32_t ref_start, bool valid, int32_t p,
+    uint32_t* kind_out, uint32_t* q_out) {
   bool pending = valid; uint32_t kind = 2u, q = 0u;
   refwin_s_pass(w, ref_start, pending, p, kind, q);
   while (__any(pending)) {
@@ -258,7 +267,8 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
   RefWinS rw; refwin_s_init(rw, cg, h.n_cigar, h.ref_start);
   uint4 xpre[4];   // stored bases [0, 8192): a 16-byte vector per lane and 2048 bases
 #pragma unroll
-  for (int j = 0; j < 4; j++) xpre[j] = (have_calls && 2048u * (uint32_t)j < L) ? load4(4u * (64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
+  for (int j = 0; j < 4; j++) xpre[j] = (have_calls && 2048u * (uint32_t)j < L) ? load4(4u * (64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u,
+      0u, 0u, 0u);
   const uint32_t pad_nib = (L & 1u) ? ((uint32_t)seqb[L >> 1] & 15u) : 0u;   // the low nibble of the last byte is not a base when L is odd
 
   // ---- the read's one (mod strand, base) group.  The caller's walk over a call's map in iteration order is resolved once per
@@ -324,14 +334,17 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
       uint4* x = xpre;   // (the vectors requested at the top serve the first 8192 bases)
       if (!(w0 == 0 && i0 == 0)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = (i0 + 64u * (uint32_t)j < nwords) ? load4(dbase + 4u * (i0 + 64u * (uint32_t)j + (uint32_t)lane)) : make_uint4(0u, 0u, 0u, 0u);
+        for (int j = 0; j < 4; j++) x[j] = (i0 + 64u * (uint32_t)j < nwords) ? load4(dbase + 4u * (i0 + 64u * (uint32_t)j + (uint32_t)lane))
+            : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
-      for (int jp = 0; jp < 4; jp += 2) {   // two vectors per prefix sum: a word holds at most 32 occurrences, 64 words 2 048 — both running counts fit 16 bits
+      // two vectors per prefix sum: a word holds at most 32 occurrences, 64 words 2 048 — both running counts fit 16 bits
+      for (int jp = 0; jp < 4; jp += 2) {
         if (i0 + 64u * (uint32_t)jp < nwords) {
           const bool has1 = i0 + 64u * (uint32_t)(jp + 1) < nwords;   // (uniform)
           const uint32_t wi0 = i0 + 64u * (uint32_t)jp + (uint32_t)lane, wi1 = wi0 + 64u;
-          const uint32_t Fw0 = flags4(x[jp]), c0 = wi0 < nwords ? (uint32_t)__popc(Fw0) : 0u;   // (a window of 416 words ends inside a vector: the words behind it belong to the next window)
+          // (a window of 416 words ends inside a vector: the words behind it belong to the next window)
+          const uint32_t Fw0 = flags4(x[jp]), c0 = wi0 < nwords ? (uint32_t)__popc(Fw0) : 0u;
           uint32_t Fw1 = 0, c1 = 0;
           if (has1) { Fw1 = flags4(x[jp + 1]); c1 = wi1 < nwords ? (uint32_t)__popc(Fw1) : 0u; }
           const uint32_t sc = wave_incl_scan(c0 | (c1 << 16));
@@ -512,7 +525,8 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
             }
             const int32_t pc = 2048 - sum;
             if (pc >= max(i_can, best)) cid = (fmisc >> 8) & 0xffu;
-          } else {   // (a share over three codes: the f32 walk; its thresholds are read here — this is the rare path — not held in registers by every read)
+          // (a share over three codes: the f32 walk; its thresholds are read here — this is the rare path — not held in registers by every read)
+          } else {
           const MkpFusedDesc& fdr = fdesc[h.layout];
           float f_thr[MKP_KMAX]; const float thr_can = fdr.thr_can;
 #pragma unroll
@@ -542,7 +556,8 @@ __device__ __forceinline__ void decode_slots_body(FUSED_PARAMS(const MkpRunParam
     const uint32_t nib = (q & 1u) ? (byte & 15u) : (byte >> 4);
     uint32_t fb = cover_feature(valid ? kind : 2u, nib, aln);
     if (valid && kind == 0u && q >= L) fb = MKP_FB_NONE;   // (a CIGAR longer than SEQ is refused by the packer)
-    { const bool cf = call_fb != 0xffffffffu; if (cf) fb = call_fb; n_callfeat += (uint32_t)__popcll(__ballot(cf)); }   // (a scalar count: no per-lane counter, no scan at the end)
+    // (a scalar count: no per-lane counter, no scan at the end)
+    { const bool cf = call_fb != 0xffffffffu; if (cf) fb = call_fb; n_callfeat += (uint32_t)__popcll(__ballot(cf)); }
     if (valid) cov[h.cov_off + i] = (uint8_t)fb;
     gaps = gaps || (valid && fb == MKP_FB_NONE);
   }
@@ -607,7 +622,8 @@ extern "C" __global__ void __launch_bounds__(256) mkp_cover_reads(SLOT_PARAMS(Mk
   MkpEvent* __restrict__ ev = events + h.event_off;
   const uint32_t n_sl = h.n_sl, gs0 = h.gs0;
   uint8_t* __restrict__ covp = cov + h.cov_off;
-  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0; rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0;
+    rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
   rw.pref = cigar_quad(cg, h.n_cigar, 0);
   uint32_t p_next = (uint32_t)lane < n_sl ? slot_pos[gs0 + (uint32_t)lane] : 0u;
   uint32_t ec = 0, n_over = 0; bool gaps = false;
@@ -681,10 +697,13 @@ extern "C" __global__ void __launch_bounds__(256) mkp_cover_reads(SLOT_PARAMS(Mk
 //   E3  one thread per ROW fills its row from the tallies and stores it: every store instruction writes 64 consecutive rows of one column.
 // MkpRunParams is resolved once per workgroup into a small table (StreamProg) so that neither pass walks slot lists.
 template <bool KEYED, uint32_t VB /* visits drawn per ticket, their records and first stream dwords requested together */>
-__device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov, const MkpEvent* __restrict__ events,
+__device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ visits, const uint8_t* __restrict__ cov,
+    const MkpEvent* __restrict__ events,
                  const MkpSTile* __restrict__ tiles, uint32_t n_tiles, const MkpRunParams* __restrict__ prmp, const uint32_t* __restrict__ slot_pos,
-                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base, uint32_t* __restrict__ row_cursor,
-                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs, uint32_t S, uint32_t tal_words) {
+                 const uint8_t* __restrict__ focus, const MkpCombo* __restrict__ combos, uint32_t* __restrict__ rows_base,
+                     uint32_t* __restrict__ row_cursor,
+                 uint32_t* __restrict__ tile_row_off, uint32_t* __restrict__ dev_err, uint32_t key_arg, uint32_t n_combos, uint32_t n_runs,
+                     uint32_t S, uint32_t tal_words) {
   const uint32_t key_filter = KEYED ? (key_arg & 0xffffu) : 0u, key_run = key_arg >> 16;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t next_read, n_real, run_ticket, row_base_s, row_total_s;
@@ -712,7 +731,8 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   uint32_t* __restrict__ tal = lds;
   uint32_t* __restrict__ obs = lds + n_counters * S;
   int32_t* __restrict__ fpos = reinterpret_cast<int32_t*>(lds + tal_words);
-  uint32_t* __restrict__ aux = lds + tal_words + S;            // per slot: [0:7] focus byte, [8 + 6m ..] partner column of the m-th '+' motif (strand combining)
+  // per slot: [0:7] focus byte, [8 + 6m ..] partner column of the m-th '+' motif (strand combining)
+  uint32_t* __restrict__ aux = lds + tal_words + S;
   uint32_t* __restrict__ rowmap = lds + tal_words + 2u * S;
   const int lane = lane_id();
   const uint32_t wave = rfl(threadIdx.x >> 6);
@@ -738,7 +758,8 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
     const uint32_t kfirst = (k_lo & ~3u) + 4u * (uint32_t)lane;
     // observed mod codes over the columns the read is in (add_mod_codes_for_record, pileup/mod.rs:831-835)
     if ((v.flags & MKP_VF_OK) && (v.obs0 | v.obs1)) {
-      if (!(v.flags & MKP_VF_GAPS)) {   // one lane per (observed-code slot, tally strand): +1 where the read enters the tile's columns, -1 behind its last
+      // one lane per (observed-code slot, tally strand): +1 where the read enters the tile's columns, -1 behind its last
+      if (!(v.flags & MKP_VF_GAPS)) {
         const uint32_t sl = (uint32_t)lane >> 1, st = (uint32_t)lane & 1u;
         if (sl < n_oslots && (((st ? v.obs1 : v.obs0) >> sl) & 1u)) {
           const uint32_t inc = st ? 0x10000u : 1u, at = __umul24(sl, S) + (a - gh0);
@@ -796,7 +817,8 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
 #ifdef MKP_DEBUG
     if (prm.debug_skip & 1024u) break;   // ablation: no visits (prologue + scans + emission only)
 #endif
-    if (c0 != rid_first) { __syncthreads(); if (threadIdx.x == 0) { next_read = 0; n_real = 0; } __syncthreads(); }   // (the round before is through with the list)
+    // (the round before is through with the list)
+    if (c0 != rid_first) { __syncthreads(); if (threadIdx.x == 0) { next_read = 0; n_real = 0; } __syncthreads(); }
     { const uint32_t cnd = c0 + threadIdx.x; bool reaches = false;
       if (cnd < rid_end) {
         const uint2 gr = *reinterpret_cast<const uint2*>(&visits[cnd]);   // gs0, n_sl
@@ -878,7 +900,9 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
           if (delta > 0) { while (iq + 1u < n_tslots && fpos[iq + 1u] <= qpos) iq++; } else { while (iq > 0u && fpos[iq - 1u] >= qpos) iq--; }
           if (fpos[iq] == qpos) {
             const uint32_t fq = aux[iq] & 0xffu;
-            if ((fq & 2u) && (fq >> 2)) { const MkpCombo& cq = combos_l[fq >> 2]; for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx); }
+            if ((fq & 2u) && (fq >> 2)) { const MkpCombo& cq = combos_l[fq >> 2];
+              for (uint32_t k = 0; k < cq.n_neg; k++) neg_ok |= (cq.neg_ids[k] == idx);
+              }
           }
         }
         if (neg_ok) part |= ((iq - i + 32u) & 63u) << (8u + 6u * m);
@@ -886,7 +910,8 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
           if (!((P.info[g] >> 18) & 1u)) continue;   // grouped by code (BTreeMap)
           bool any = false;
           for (uint32_t gj = g; gj < n_groups && (gj == g || !((P.info[gj] >> 18) & 1u)); gj++)
-            any = any || (pos_ok && stream_row_exists(tal, S, n_counters, P, 0, i, gj)) || (neg_ok && stream_row_exists(tal, S, n_counters, P, 1, iq, gj));
+            any = any || (pos_ok && stream_row_exists(tal, S, n_counters, P, 0, i, gj))
+                || (neg_ok && stream_row_exists(tal, S, n_counters, P, 1, iq, gj));
           if (any) { em |= 1ull << (16u * m + g); cnt++; }
         }
       }
@@ -901,7 +926,8 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
   for (uint32_t w2 = 0; w2 < PILEUP_WAVES; w2++) { const uint32_t t = wave_tot[w2]; if (w2 < wave) off += t; tile_rows += t; }
   MkpRowsDev rows;
   { const size_t cap = prm.row_capacity; uint32_t* q = rows_base;
-    rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap; rows.n_other = q + 6 * cap;
+    rows.pos = q; rows.info = q + cap; rows.code = q + 2 * cap; rows.n_valid = q + 3 * cap; rows.n_mod = q + 4 * cap; rows.n_can = q + 5 * cap;
+      rows.n_other = q + 6 * cap;
     rows.n_del = q + 7 * cap; rows.n_fail = q + 8 * cap; rows.n_diff = q + 9 * cap; rows.n_nocall = q + 10 * cap; }
   for (uint32_t r0 = 0; r0 == 0u || r0 < tile_rows; r0 += MKP_STREAM_ROWMAP_WORDS) {
     if (r0) __syncthreads();   // the round before has read the map
@@ -913,14 +939,16 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
         const uint32_t mult = combine ? 1u : (sm ? mult1 : mult0);
         while (bits) {
           const uint32_t g = (uint32_t)__ffs((int)bits) - 1u; bits &= bits - 1u;
-          for (uint32_t k = 0; k < mult; k++, r++) if (r >= r0 && r < r0 + MKP_STREAM_ROWMAP_WORDS) rowmap[r - r0] = i | (g << 10) | (sm << 14) | (k << 16);
+          for (uint32_t k = 0; k < mult; k++, r++) if (r >= r0
+              && r < r0 + MKP_STREAM_ROWMAP_WORDS) rowmap[r - r0] = i | (g << 10) | (sm << 14) | (k << 16);
         }
       }
     }
     if (r0 == 0u && wave == 0u) {   // tile_row_off = the runs' look-back words (two dwords each); row_cursor[1] = total rows, written by the last run
 #ifdef MKP_DEBUG
       uint32_t base;
-      if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (lane == 0) b0 = atomicAdd(row_cursor + 1, tile_rows); base = rfl(b0); }   // ablation: no look-back (rows in completion order)
+      // ablation: no look-back (rows in completion order)
+      if (prm.debug_skip & 4096u) { uint32_t b0 = 0; if (lane == 0) b0 = atomicAdd(row_cursor + 1, tile_rows); base = rfl(b0); }
       else base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, tile_rows);
 #else
       const uint32_t base = lookback_reserve_wave(reinterpret_cast<unsigned long long*>(tile_row_off), run, tile_rows);
@@ -946,7 +974,9 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
       if (!combine) {
         stream_row_add(tal, S, P, sm, si, g, acc);
         strand = sm; motif1 = 0;
-        if (combo) { const MkpCombo& cb = combos_l[combo]; const uint32_t n_ids = sm ? cb.n_neg : cb.n_pos; if (n_ids) motif1 = (uint32_t)(sm ? cb.neg_ids[k] : cb.pos_ids[k]) + 1u; }
+        if (combo) { const MkpCombo& cb = combos_l[combo]; const uint32_t n_ids = sm ? cb.n_neg : cb.n_pos;
+          if (n_ids) motif1 = (uint32_t)(sm ? cb.neg_ids[k] : cb.pos_ids[k]) + 1u;
+          }
       } else {
         const MkpCombo& cb = combos_l[combo];
         const uint32_t pd = (ax >> (8u + 6u * sm)) & 63u, iq = si + pd - 32u;
@@ -972,8 +1002,10 @@ __device__ __forceinline__ void pileup_stream_body(const MkpVisit* __restrict__ 
 #ifndef MKP_STREAM_VB
 #define MKP_STREAM_VB 4
 #endif
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) { pileup_stream_body<false, MKP_STREAM_VB>(STREAM_PASS); }
-extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) { pileup_stream_body<true, MKP_STREAM_VB>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream(STREAM_PARAMS) {
+  pileup_stream_body<false, MKP_STREAM_VB>(STREAM_PASS); }
+extern "C" __global__ void __launch_bounds__(PILEUP_THREADS, 8) mkp_pileup_stream_keyed(STREAM_PARAMS) {
+  pileup_stream_body<true, MKP_STREAM_VB>(STREAM_PASS); }
 
 // ----------------------------------------------------------------------------------------------------------------------
 // Records sharing a read name inside one interval (MkpDupCons / MkpDupSeg, mkp_device.h).  Rare: a handful of records per shard.
@@ -991,7 +1023,8 @@ extern "C" __global__ void __launch_bounds__(64) mkp_dup_restore(MkpReadHdr* __r
   const uint32_t k = blockIdx.x * 64u + threadIdx.x;
   if (k < n) hdrs[cons[k].rid].event_off = cons[k].own_off;
 }
-extern "C" __global__ void __launch_bounds__(64) mkp_dup_apply(MkpReadHdr* __restrict__ hdrs, MkpReadOut* __restrict__ readout, const MkpDupCons* __restrict__ cons, uint32_t n) {
+extern "C" __global__ void __launch_bounds__(64) mkp_dup_apply(MkpReadHdr* __restrict__ hdrs, MkpReadOut* __restrict__ readout,
+    const MkpDupCons* __restrict__ cons, uint32_t n) {
   const uint32_t k = blockIdx.x * 64u + threadIdx.x;
   if (k >= n) return;
   const MkpDupCons c = cons[k];
@@ -999,8 +1032,10 @@ extern "C" __global__ void __launch_bounds__(64) mkp_dup_apply(MkpReadHdr* __res
   MkpReadOut o; o.n_events = c.out_n; o.ok = c.out_ok; o.obs[0] = c.out_obs0; o.obs[1] = c.out_obs1;
   readout[c.rid] = o;
 }
-extern "C" __global__ void __launch_bounds__(64) mkp_dup_events(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar, const uint8_t* __restrict__ seqs, MkpEvent* __restrict__ events,
-                                                                const MkpReadOut* __restrict__ readout, MkpDupCons* __restrict__ cons, const MkpDupSeg* __restrict__ segs, uint32_t n, uint32_t* __restrict__ dev_err) {
+extern "C" __global__ void __launch_bounds__(64) mkp_dup_events(const MkpReadHdr* __restrict__ hdrs, const uint32_t* __restrict__ cigar,
+    const uint8_t* __restrict__ seqs, MkpEvent* __restrict__ events,
+                                                                const MkpReadOut* __restrict__ readout, MkpDupCons* __restrict__ cons,
+                                                                    const MkpDupSeg* __restrict__ segs, uint32_t n, uint32_t* __restrict__ dev_err) {
   const uint32_t ci = blockIdx.x;
   if (ci >= n) return;
   const int lane = lane_id();
@@ -1009,7 +1044,8 @@ extern "C" __global__ void __launch_bounds__(64) mkp_dup_events(const MkpReadHdr
   const uint32_t aln = (h.flags & MKP_RF_REVERSE) ? 1u : 0u, L = h.l_seq;
   const uint8_t* __restrict__ seqb = seqs + h.seq_off;
   const uint32_t* __restrict__ cg = cigar + h.cigar_off;
-  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0; rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
+  RefWin rw; rw.c0 = 0; rw.q_run = 0; rw.r_run = h.ref_start; rw.Rtot = 0; rw.Qtot = 0; rw.re = rw.m1 = rw.m2 = rw.m3 = 0;
+    rw.pk[0] = rw.pk[1] = rw.pk[2] = rw.pk[3] = 0; rw.loaded = false;
   rw.pref = cigar_quad(cg, h.n_cigar, 0);
   MkpEvent* __restrict__ dst = events + c.eff_off;
   uint32_t n_out = 0, st_ok = 0, st_o0 = 0, st_o1 = 0; bool have_st = false, mixed = false, over = false;
@@ -1063,13 +1099,17 @@ extern "C" __global__ void __launch_bounds__(64) mkp_dup_events(const MkpReadHdr
 // ----------------------------------------------------------------------------------------------------------------------
 // host-side launchers (called from mkp_api.cpp)
 // work = the fused decoder's reads [longer than one base window | the others], cover_ids = the reads of mkp_cover_reads
-extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint32_t n_long, uint32_t n_short, const MkpReadHdr* hdrs, const uint32_t* cover_ids, uint32_t n_cover, const uint32_t* cigar,
-                                       const uint8_t* seqs, const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml, const MkpLayout* layouts, const MkpFusedDesc* fdesc, const MkpRunParams* prm,
-                                       const uint32_t* slot_pos, uint8_t* cov, MkpVisit* visits, MkpEvent* events, MkpReadOut* readout, uint32_t* dev_err) {
+extern "C" hipError_t mkp_launch_slots(hipStream_t st, const MkpWork* work, uint32_t n_long, uint32_t n_short, const MkpReadHdr* hdrs,
+    const uint32_t* cover_ids, uint32_t n_cover, const uint32_t* cigar,
+                                       const uint8_t* seqs, const MkpTagRef* tagref, const uint32_t* ranks, const uint8_t* ml,
+                                           const MkpLayout* layouts, const MkpFusedDesc* fdesc, const MkpRunParams* prm,
+                                       const uint32_t* slot_pos, uint8_t* cov, MkpVisit* visits, MkpEvent* events, MkpReadOut* readout,
+                                           uint32_t* dev_err) {
 #define MKP_FUSED_LAUNCH(K, W, N) hipLaunchKernelGGL(K, dim3(((N) + 3u) / 4u), dim3(256), 0, st, W, N, cigar, seqs, ranks, ml, fdesc, *prm, slot_pos, cov, visits, readout)
   if (n_long) MKP_FUSED_LAUNCH(mkp_decode_slots_long, work, n_long);
   if (n_short) MKP_FUSED_LAUNCH(mkp_decode_slots, work + n_long, n_short);
-  if (n_cover) hipLaunchKernelGGL(mkp_cover_reads, dim3((n_cover + 3u) / 4u), dim3(256), 0, st, hdrs, n_cover, cover_ids, cigar, seqs, tagref, ranks, ml, layouts, fdesc, *prm, slot_pos, cov, visits, events, readout, dev_err);
+  if (n_cover) hipLaunchKernelGGL(mkp_cover_reads, dim3((n_cover + 3u) / 4u), dim3(256), 0, st, hdrs, n_cover, cover_ids, cigar, seqs, tagref, ranks,
+      ml, layouts, fdesc, *prm, slot_pos, cov, visits, events, readout, dev_err);
   return hipGetLastError();
 }
 
@@ -1077,7 +1117,8 @@ extern "C" hipError_t mkp_launch_dup_restore(hipStream_t st, MkpReadHdr* hdrs, c
   if (n) hipLaunchKernelGGL(mkp_dup_restore, dim3((n + 63u) / 64u), dim3(64), 0, st, hdrs, cons, n);
   return hipGetLastError();
 }
-extern "C" hipError_t mkp_launch_dup_events(hipStream_t st, MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs, MkpEvent* events, MkpReadOut* readout, MkpDupCons* cons, const MkpDupSeg* segs,
+extern "C" hipError_t mkp_launch_dup_events(hipStream_t st, MkpReadHdr* hdrs, const uint32_t* cigar, const uint8_t* seqs, MkpEvent* events,
+    MkpReadOut* readout, MkpDupCons* cons, const MkpDupSeg* segs,
                                             uint32_t n, uint32_t* dev_err) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(mkp_dup_events, dim3(n), dim3(64), 0, st, hdrs, cigar, seqs, events, readout, cons, segs, n, dev_err);
@@ -1093,9 +1134,12 @@ extern "C" hipError_t mkp_stream_set_lds(uint32_t bytes) {
   return hipSuccess;
 }
 
-extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events, const MkpSTile* tiles, uint32_t n_tiles,
-                                        const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos, const MkpRowsDev* rows, uint32_t* row_cursor,
-                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot, uint32_t n_combos, uint32_t n_runs, uint32_t slot_cap, uint32_t words_per_slot) {
+extern "C" hipError_t mkp_launch_stream(hipStream_t st, uint32_t lds_bytes, const MkpVisit* visits, const uint8_t* cov, const MkpEvent* events,
+    const MkpSTile* tiles, uint32_t n_tiles,
+                                        const MkpRunParams* prm_dev, const uint32_t* slot_pos, const uint8_t* focus, const MkpCombo* combos,
+                                            const MkpRowsDev* rows, uint32_t* row_cursor,
+                                        uint32_t* tile_row_off, uint32_t* tile_row_cnt, uint32_t* dev_err, uint32_t key_filter, uint32_t key_slot,
+                                            uint32_t n_combos, uint32_t n_runs, uint32_t slot_cap, uint32_t words_per_slot) {
   if (!n_tiles) return hipSuccess;
   (void)tile_row_cnt;
   const bool keyed = key_filter != MKP_NO_KEY_FILTER;

@@ -28,12 +28,14 @@ struct RowWriter {
   std::unique_ptr<BgzfTabixSink> bz;   // --bgzf: BGZF blocks + TBI index instead of plain text
   FILE* f = nullptr; bool mixed = false; std::vector<std::string> labels; uint64_t n = 0;
   bool bz_finished = false;
-  std::thread io; std::mutex mu; std::condition_variable cv; std::deque<std::vector<TextBuf>> pending; bool closing = false, io_failed = false, io_started = false;
+  std::thread io; std::mutex mu; std::condition_variable cv; std::deque<std::vector<TextBuf>> pending;
+    bool closing = false, io_failed = false, io_started = false;
   // plain text into a seekable file goes out with pwrite from all cores (decided at the first write: what the caller wrote through `f`
   // before — a header line — is flushed and the offset taken from there)
   int pos_mode = -1; uint64_t file_off = 0;
   bool positional() {
-    if (pos_mode < 0) { pos_mode = 0; if (f && f != stdout && fflush(f) == 0) { const off_t o = ftello(f); if (o >= 0) { file_off = (uint64_t)o; pos_mode = 1; } } }
+    if (pos_mode < 0) { pos_mode = 0; if (f && f != stdout && fflush(f) == 0) { const off_t o = ftello(f); if (o >= 0) { file_off = (uint64_t)o;
+          pos_mode = 1; } } }
     return pos_mode == 1;
   }
   static size_t row_bound(size_t chrom_n) { return chrom_n + 96 + 14 * 11 + 32; }   // chrom + name + 14 numbers + separators
@@ -46,8 +48,10 @@ struct RowWriter {
       const char* p_line = p;
       char name[96]; uint32_t code = r.code_repr[i];
       int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : (name[0] = (char)code, name[1] = 0, 1);
-      if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) k += snprintf(name + k, sizeof(name) - (size_t)k, ",%s", labels[(size_t)r.motif_idx[i]].c_str());
-      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)std::min<int>(k, (int)sizeof(name) - 1), sp, r.pos[i], (char)r.strand[i], r.n_valid[i], r.n_mod[i], r.n_canonical[i], r.n_other[i],
+      if (labels.size() >= 2 && r.motif_idx[i] >= 0 && (size_t)r.motif_idx[i] < labels.size()) k += snprintf(name + k, sizeof(name) - (size_t)k,
+          ",%s", labels[(size_t)r.motif_idx[i]].c_str());
+      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)std::min<int>(k, (int)sizeof(name) - 1), sp, r.pos[i], (char)r.strand[i],
+          r.n_valid[i], r.n_mod[i], r.n_canonical[i], r.n_other[i],
                      r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
       if (bz) lens.push_back((uint32_t)(p - p_line));
     }
@@ -61,11 +65,14 @@ struct RowWriter {
     out->mem.reset(new char[(size_t)(hi - lo) * row_bound(chrom.size()) + 1]);
     char* p = out->mem.get();
     std::vector<uint32_t> lens; if (bz) lens.reserve((size_t)(hi - lo));
-    auto element = [](char* q, uint32_t code) { if (code == MKP_HEMI_CANONICAL) { *q++ = '-'; return q; } if (code & 0x80000000u) return put_u32(q, code & 0x7fffffffu); *q++ = (char)code; return q; };
+    auto element = [](char* q, uint32_t code) { if (code == MKP_HEMI_CANONICAL) { *q++ = '-'; return q;
+      } if (code & 0x80000000u) return put_u32(q, code & 0x7fffffffu); *q++ = (char)code; return q; };
     for (uint64_t i = lo; i < hi; i++) {
       const char* p_line = p;
-      char name[32]; char* q = element(name, r.pattern_pos[i]); *q++ = ','; q = element(q, r.pattern_neg[i]); *q++ = ','; *q++ = (char)r.primary_base[i];
-      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)(q - name), sp, r.pos[i], '.', r.n_valid[i], r.count[i], r.n_canonical[i], r.n_other_pattern[i],
+      char name[32]; char* q = element(name, r.pattern_pos[i]); *q++ = ','; q = element(q, r.pattern_neg[i]); *q++ = ',';
+        *q++ = (char)r.primary_base[i];
+      p = format_row(p, chrom.data(), chrom.size(), name, (size_t)(q - name), sp, r.pos[i], '.', r.n_valid[i], r.count[i], r.n_canonical[i],
+          r.n_other_pattern[i],
                      r.n_delete[i], r.n_fail[i], r.n_diff[i], r.n_nocall[i]);
       if (bz) lens.push_back((uint32_t)(p - p_line));
     }
@@ -75,7 +82,8 @@ struct RowWriter {
   void io_loop() {
     for (;;) {
       std::vector<TextBuf> job;
-      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closing || !pending.empty(); }); if (pending.empty()) return; job = std::move(pending.front()); }
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closing || !pending.empty(); }); if (pending.empty()) return;
+        job = std::move(pending.front()); }
       bool ok = true;
       if (bz) { for (auto& b : job) bz->write(b.chrom, b.piece); ok = !bz->failed; }
       else if (positional()) {
@@ -84,11 +92,14 @@ struct RowWriter {
         // mapping from all cores 120 ms: a page fault per 4 KiB of a fresh file costs more than the lock.)
         std::vector<uint64_t> at(job.size()); uint64_t o = file_off; for (size_t i = 0; i < job.size(); i++) { at[i] = o; o += job[i].n; }
         std::atomic<bool> bad{false}; const int fd = fileno(f);
-        HostPool::get().parallel(job.size(), [&](size_t i) { size_t done = 0; while (done < job[i].n) { const ssize_t w = ::pwrite(fd, job[i].mem.get() + done, job[i].n - done, (off_t)(at[i] + done)); if (w <= 0) { bad = true; return; } done += (size_t)w; } });
+        HostPool::get().parallel(job.size(), [&](size_t i) { size_t done = 0; while (done < job[i].n) {
+            const ssize_t w = ::pwrite(fd, job[i].mem.get() + done, job[i].n - done, (off_t)(at[i] + done)); if (w <= 0) { bad = true; return;
+            } done += (size_t)w; } });
         file_off = o; ok = !bad;
       }
       else for (auto& b : job) if (b.n && fwrite(b.mem.get(), 1, b.n, f) != b.n) ok = false;
-      { std::lock_guard<std::mutex> lk(mu); pending.pop_front(); if (!ok) io_failed = true; }   // popped after the write: `pending` bounds the text held in memory
+      // popped after the write: `pending` bounds the text held in memory
+      { std::lock_guard<std::mutex> lk(mu); pending.pop_front(); if (!ok) io_failed = true; }
       cv.notify_all();
     }
   }
@@ -126,7 +137,9 @@ struct RowWriter {
   void finish() {
     if (io_started) { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); io.join(); io_started = false; }
     if (io_failed) throw Error(MKP_E_IO, "short write on the bedMethyl output");
-    if (bz && !bz_finished) { bz_finished = true; bz->finish(); if (bz->failed) throw Error(MKP_E_IO, "short write on the bedMethyl output or its index"); }
+    if (bz && !bz_finished) { bz_finished = true; bz->finish();
+      if (bz->failed) throw Error(MKP_E_IO, "short write on the bedMethyl output or its index");
+      }
     if (f && pos_mode == 1) fseeko(f, (off_t)file_off, SEEK_SET);   // the stream's own position follows what pwrite put behind it
     if (f && fflush(f) != 0) throw Error(MKP_E_IO, "short write on the bedMethyl output");
   }

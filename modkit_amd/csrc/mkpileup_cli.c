@@ -18,7 +18,8 @@ int main(int argc, char** argv) {
                     "       mkpileup extract calls <in.bam> <out.tsv> [flags of `modkit extract calls`] [--device N] [--stats]\n");
     return 2;
   }
-  int rc = hemi ? mkp_pileup_hemi_main(argc - 2, (const char* const*)(argv + 2), err, sizeof(err)) : mkp_pileup_main(argc - 2, (const char* const*)(argv + 2), err, sizeof(err));
+  int rc = hemi ? mkp_pileup_hemi_main(argc - 2, (const char* const*)(argv + 2), err, sizeof(err)) : mkp_pileup_main(argc - 2,
+      (const char* const*)(argv + 2), err, sizeof(err));
   if (rc != MKP_OK) { fprintf(stderr, "Error! %s (status %d)\n", err, rc); return 1; }
   return 0;
 }

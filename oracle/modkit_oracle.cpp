@@ -24,7 +24,8 @@ struct Fasta {
     while (std::getline(in, line)) {
       if (!line.empty() && line.back() == '\r') line.pop_back();
       if (line.empty()) continue;
-      if (line[0] == '>') { name = line.substr(1); size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name = name.substr(0, sp); f.seqs[name]; }
+      if (line[0] == '>') { name = line.substr(1); size_t sp = name.find_first_of(" \t"); if (sp != std::string::npos) name = name.substr(0, sp);
+        f.seqs[name]; }
       else f.seqs[name] += line;
     }
     return f;
@@ -67,7 +68,8 @@ static Motif parse_motif(const std::string& raw, size_t offset) {  // parse_stri
   if (raw.size() < offset + 1) throw MkErr("motif not long enough for offset");
   m.info.forward_offset = offset; m.info.reverse_offset = raw.size() - (offset + 1); m.info.length = raw.size();
   // palindrome == regex strings equal (220): compare as written strings
-  auto as_regex = [](const std::vector<std::string>& cl) { std::string s; for (auto& c : cl) { if (c.size() == 1) s += c; else s += "[" + c + "]"; } return s; };
+  auto as_regex = [](const std::vector<std::string>& cl) { std::string s; for (auto& c : cl) { if (c.size() == 1) s += c; else s += "[" + c + "]";
+    } return s; };
   m.info.is_palindrome = as_regex(m.fwd_classes) == as_regex(m.rev_classes);
   return m;
 }
@@ -86,7 +88,8 @@ static std::vector<std::pair<size_t, bool>> find_motif_hits(const std::string& s
   std::vector<std::pair<size_t, bool>> hits;
   if (m.info.is_palindrome) {
     for (size_t s : find_overlapping(seq, m.fwd_classes)) {
-      if (m.info.forward_offset <= m.info.reverse_offset) { hits.push_back({s + m.info.forward_offset, false}); hits.push_back({s + m.info.reverse_offset, true}); }
+      if (m.info.forward_offset <= m.info.reverse_offset) { hits.push_back({s + m.info.forward_offset, false});
+        hits.push_back({s + m.info.reverse_offset, true}); }
       else { hits.push_back({s + m.info.reverse_offset, true}); hits.push_back({s + m.info.forward_offset, false}); }
     }
   } else if (m.info.length == 1) {
@@ -130,7 +133,8 @@ struct PositionFilter {  // position_filter.rs:20-24
       bool ps, ns;
       if (parts.size() == 3) { ps = ns = true; }
       else if (parts.size() >= 6) {
-        if (parts[5] == "+") { ps = true; ns = false; } else if (parts[5] == "-") { ps = false; ns = true; } else if (parts[5] == ".") { ps = ns = true; } else continue;
+        if (parts[5] == "+") { ps = true; ns = false; } else if (parts[5] == "-") { ps = false; ns = true; } else if (parts[5] == ".") {
+          ps = ns = true; } else continue;
       } else continue;
       auto it = chrom_to_tid.find(parts[0]);
       if (it == chrom_to_tid.end()) { warned.insert(parts[0]); continue; }
@@ -147,7 +151,8 @@ struct PositionFilter {  // position_filter.rs:20-24
 struct ReferenceRecord { uint32_t tid, start, length; std::string name; uint32_t end() const { return start + length; } };
 
 // optimize_reference_records + group_genome_intervals (position_filter.rs:103-210)
-static std::vector<ReferenceRecord> optimize_reference_records(const PositionFilter& pf, const std::vector<ReferenceRecord>& recs, uint32_t interval_size) {
+static std::vector<ReferenceRecord> optimize_reference_records(const PositionFilter& pf, const std::vector<ReferenceRecord>& recs,
+    uint32_t interval_size) {
   std::map<uint32_t, ReferenceRecord> lut; for (auto& r : recs) lut[r.tid] = r;  // later duplicates overwrite (collect into HashMap)
   std::set<uint32_t> tids; for (auto& kv : pf.pos) tids.insert(kv.first); for (auto& kv : pf.neg) tids.insert(kv.first);
   std::vector<ReferenceRecord> out;
@@ -212,7 +217,9 @@ struct MotifLookup {
       uint64_t search_end = end;
       { uint64_t qs = end >= 1 ? end - 1 : 0; for (auto& iv : ivs) if (iv.start < end && iv.stop > qs) { search_end = iv.stop; break; } }
       if (search_end < too_close || end_w >= ref_end) {
-        for (auto& ml : locs) { for (auto it = ml.locs.begin(); it != ml.locs.end();) { if ((uint64_t)it->first <= search_end) ++it; else it = ml.locs.erase(it); } }
+        for (auto& ml : locs) { for (auto it = ml.locs.begin(); it != ml.locs.end();) { if ((uint64_t)it->first <= search_end) ++it;
+            else it = ml.locs.erase(it);
+          } }
         *end_out = (uint32_t)search_end;
         return locs;
       }
@@ -222,7 +229,8 @@ struct MotifLookup {
 };
 
 // ------------------------------------------------------------ FocusPositions ctors
-static FocusPositions focus_new_motif(const std::vector<MotifLocations>& mls, const std::vector<Motif>& motifs, uint32_t start, uint32_t end) {  // interval_chunks.rs:62-202
+// interval_chunks.rs:62-202
+static FocusPositions focus_new_motif(const std::vector<MotifLocations>& mls, const std::vector<Motif>& motifs, uint32_t start, uint32_t end) {
   FocusPositions f; f.kind = FocusPositions::MOTIF;
   bool all_single = true; for (auto& m : motifs) if (m.info.length != 1) all_single = false;
   auto in_range = [&](uint32_t p) { return p >= start && p < end; };
@@ -241,8 +249,11 @@ static FocusPositions focus_new_motif(const std::vector<MotifLocations>& mls, co
       if (a < 0) return;
       for (auto& kv : mls[a].locs) {
         if (!in_range(kv.first)) continue;
-        if (t >= 0) { f.positions[kv.first] = RULE_BOTH; f.positive_motif_ids[kv.first] = {(size_t)a, (size_t)t}; f.negative_motif_ids[kv.first] = {(size_t)a, (size_t)t}; }
-        else { f.positions[kv.first] = kv.second; if (kv.second == RULE_POS) f.positive_motif_ids[kv.first] = {(size_t)a}; else if (kv.second == RULE_NEG) f.negative_motif_ids[kv.first] = {(size_t)a}; }
+        if (t >= 0) { f.positions[kv.first] = RULE_BOTH; f.positive_motif_ids[kv.first] = {(size_t)a, (size_t)t};
+          f.negative_motif_ids[kv.first] = {(size_t)a, (size_t)t}; }
+        else { f.positions[kv.first] = kv.second; if (kv.second == RULE_POS) f.positive_motif_ids[kv.first] = {(size_t)a};
+          else if (kv.second == RULE_NEG) f.negative_motif_ids[kv.first] = {(size_t)a};
+          }
       }
     };
     add("A", "T"); add("C", "G");
@@ -257,7 +268,9 @@ static FocusPositions focus_new_motif(const std::vector<MotifLocations>& mls, co
   }
   return f;
 }
-static FocusPositions focus_new_motif_combine(const std::vector<MotifLocations>& mls, const std::vector<Motif>& motifs, uint32_t start, uint32_t end) {  // 250-297
+// 250-297
+static FocusPositions focus_new_motif_combine(const std::vector<MotifLocations>& mls, const std::vector<Motif>& motifs, uint32_t start,
+    uint32_t end) {
   FocusPositions f; f.kind = FocusPositions::MOTIF_COMBINE;
   for (size_t id = 0; id < mls.size(); id++) for (auto& kv : mls[id].locs) {
     if (!(kv.first >= start && kv.first < end)) continue;
@@ -272,7 +285,8 @@ static FocusPositions focus_new_regions(const PositionFilter& pf, uint32_t tid, 
   FocusPositions f; f.kind = FocusPositions::REGIONS;
   auto clip = [&](const std::map<uint32_t, std::vector<Iv>>& m, std::vector<Iv>& out) {
     auto it = m.find(tid); if (it == m.end()) return;
-    for (auto& iv : it->second) if (iv.start < end && iv.stop > start) out.push_back({std::max<uint64_t>(iv.start, start), std::min<uint64_t>(iv.stop, end)});
+    for (auto& iv : it->second) if (iv.start < end && iv.stop > start) out.push_back({std::max<uint64_t>(iv.start, start),
+        std::min<uint64_t>(iv.stop, end)});
     lapper_merge(out);
   };
   clip(pf.pos, f.pos_intervals); clip(pf.neg, f.neg_intervals);
@@ -330,7 +344,8 @@ struct Options {
   bool invert_edge = false, mixed_delim = false, with_header = false;
   size_t workers = 1;  // oracle-only: interval-parallel std::thread workers for the CPU baseline
   bool hemi = false;   // `pileup-hemi` (DuplexModBamPileup, src/pileup/subcommand.rs:827-1514)
-  bool sample_probs_cmd = false; std::string percentiles = "0.1,0.5,0.9";   // `sample-probs` (SampleModBaseProbs, src/commands.rs:549-887): the percentiles table only
+  // `sample-probs` (SampleModBaseProbs, src/commands.rs:549-887): the percentiles table only
+  bool sample_probs_cmd = false; std::string percentiles = "0.1,0.5,0.9";
 };
 
 struct Region { std::string name; uint32_t start, end; };
@@ -339,10 +354,14 @@ static Region parse_region(const std::string& raw, const BamFile& bam) {  // uti
     size_t c = raw.find(':'); if (raw.find(':', c + 1) != std::string::npos) throw MkErr("invalid region " + raw);
     std::string name = raw.substr(0, c), se = raw.substr(c + 1);
     std::vector<std::string> parts; size_t s = 0;
-    for (;;) { size_t d = se.find('-', s); parts.push_back(se.substr(s, d == std::string::npos ? std::string::npos : d - s)); if (d == std::string::npos) break; s = d + 1; }
+    for (;;) { size_t d = se.find('-', s); parts.push_back(se.substr(s, d == std::string::npos ? std::string::npos : d - s));
+      if (d == std::string::npos) break;
+      s = d + 1; }
     if (parts.size() != 2) throw MkErr("invalid region " + raw);
     uint32_t v[2];
-    for (int i = 0; i < 2; i++) { std::string cl; for (char ch : parts[i]) if (ch != ',') cl += ch; if (cl.empty()) throw MkErr("invalid region " + raw); char* e; v[i] = (uint32_t)strtoul(cl.c_str(), &e, 10); if (*e) throw MkErr("invalid region " + raw); }
+    for (int i = 0; i < 2; i++) { std::string cl; for (char ch : parts[i]) if (ch != ',') cl += ch;
+      if (cl.empty()) throw MkErr("invalid region " + raw);
+      char* e; v[i] = (uint32_t)strtoul(cl.c_str(), &e, 10); if (*e) throw MkErr("invalid region " + raw); }
     if (v[1] <= v[0]) throw MkErr("invalid region " + raw);
     return {name, v[0], v[1]};
   }
@@ -352,7 +371,9 @@ static Region parse_region(const std::string& raw, const BamFile& bam) {  // uti
 static std::vector<ReferenceRecord> get_targets(const BamFile& bam, const Region* region) {  // util.rs:409-446
   std::vector<ReferenceRecord> out;
   for (size_t tid = 0; tid < bam.ref_names.size(); tid++) {
-    if (region) { if (bam.ref_names[tid] == region->name) out.push_back({(uint32_t)tid, region->start, region->end - region->start, bam.ref_names[tid]}); }
+    if (region) {
+      if (bam.ref_names[tid] == region->name) out.push_back({(uint32_t)tid, region->start, region->end - region->start, bam.ref_names[tid]});
+      }
     else out.push_back({(uint32_t)tid, 0, bam.ref_lens[tid], bam.ref_names[tid]});
   }
   return out;
@@ -368,7 +389,8 @@ struct IdxStats {
     std::vector<uint64_t> m(bam.ref_names.size(), 0), u(bam.ref_names.size(), 0); uint64_t nocoor = 0;
     for (auto& r : bam.recs) { if (r.tid < 0) { nocoor++; continue; } if (r.flag & 4) u[r.tid]++; else m[r.tid]++; }
     auto keep = [&](int64_t tid) { if (region) return tid == region_tid; if (pf) return pf->contains_chrom(tid); return true; };
-    for (size_t tid = 0; tid < m.size(); tid++) if (keep((int64_t)tid)) { st.mapped += m[tid]; st.unmapped += u[tid]; st.tid_mapped[(int64_t)tid] = m[tid]; }
+    for (size_t tid = 0; tid < m.size(); tid++) if (keep((int64_t)tid)) { st.mapped += m[tid]; st.unmapped += u[tid];
+      st.tid_mapped[(int64_t)tid] = m[tid]; }
     if (keep(-1)) st.unmapped += nocoor;
     return st;
   }
@@ -387,10 +409,13 @@ struct SamplingSchedule {  // sampling_schedule.rs:73-76
       size_t n = std::min<size_t>((size_t)ceilf((float)num_reads * frac), (size_t)kv.second);
       total_to_sample += n; Count c; c.n = n; s.counts[(uint32_t)kv.first] = c;
     }
-    if (include_unmapped) { float frac = (float)st.unmapped / total; total_to_sample += (size_t)ceilf((float)num_reads * frac); s.has_unmapped = true; }
+    if (include_unmapped) { float frac = (float)st.unmapped / total; total_to_sample += (size_t)ceilf((float)num_reads * frac); s.has_unmapped = true;
+      }
     size_t floor = 1;
-    while ((double)total_to_sample / (double)num_reads > 1.5) {  // pruning iterates an FxHashMap<u32,_>: order here is ascending tid (parity unpinned)
-      for (auto& kv : s.counts) { if (kv.second.n <= floor) { total_to_sample -= kv.second.n; kv.second.n = 0; } if (total_to_sample <= num_reads) break; }
+    // pruning iterates an FxHashMap<u32,_>: order here is ascending tid (parity unpinned)
+    while ((double)total_to_sample / (double)num_reads > 1.5) {
+      for (auto& kv : s.counts) { if (kv.second.n <= floor) { total_to_sample -= kv.second.n; kv.second.n = 0;
+        } if (total_to_sample <= num_reads) break; }
       total_to_sample = 0; for (auto& kv : s.counts) total_to_sample += kv.second.n;
       floor++;
     }
@@ -416,7 +441,9 @@ struct SampledProbs {
   std::map<std::string, std::map<int, std::vector<float>>> inner;
   std::map<std::string, std::map<int, std::vector<BaseModProbs>>> calls;   // `summary` only: the sampled maps themselves
   void merge(SampledProbs&& o) {  // op_mut 205-213: the first occurrence of a read id wins
-    for (auto& kv : o.inner) if (!inner.count(kv.first)) { auto c = o.calls.find(kv.first); if (c != o.calls.end()) calls.emplace(kv.first, std::move(c->second)); inner.emplace(kv.first, std::move(kv.second)); }
+    for (auto& kv : o.inner) if (!inner.count(kv.first)) { auto c = o.calls.find(kv.first);
+      if (c != o.calls.end()) calls.emplace(kv.first, std::move(c->second));
+      inner.emplace(kv.first, std::move(kv.second)); }
   }
   size_t len() const { return inner.size(); }
 };
@@ -424,7 +451,8 @@ struct SampledProbs {
 struct SampleCtx { const BamFile* bam; const CollapseMethod* collapse; const EdgeFilter* edge; const PositionFilter* pf; bool only_mapped; bool keep_calls = false; };
 
 // process_records (223-362) over an iterator of records; limit: -1 = passthrough, else first-N
-static SampledProbs process_records(const std::vector<const BamRecord*>& recs, long limit, const SampleCtx& cx, StdRng* rng = nullptr, double frac = 1.0) {
+static SampledProbs process_records(const std::vector<const BamRecord*>& recs, long limit, const SampleCtx& cx, StdRng* rng = nullptr,
+    double frac = 1.0) {
   SampledProbs out; size_t used = 0;
   for (const BamRecord* rp : recs) {
     const BamRecord& r = *rp;
@@ -440,7 +468,9 @@ static SampledProbs process_records(const std::vector<const BamRecord*>& recs, l
     if (cx.only_mapped) {
       size_t q = 0; uint64_t rpos = (uint64_t)r.pos; size_t L = (size_t)r.l_seq;
       for (uint32_t c : r.cigar) { int op = c & 15; uint32_t len = c >> 4;
-        if (op == 0 || op == 7 || op == 8) { for (uint32_t k = 0; k < len; k++) { size_t qq = q + k; if (qq < L) pairs[r.is_reverse() ? L - 1 - qq : qq] = rpos + k; } q += len; rpos += len; }
+        if (op == 0 || op == 7 || op == 8) { for (uint32_t k = 0; k < len; k++) { size_t qq = q + k;
+            if (qq < L) pairs[r.is_reverse() ? L - 1 - qq : qq] = rpos + k;
+          } q += len; rpos += len; }
         else if (op == 1 || op == 4) q += len; else if (op == 2 || op == 3) rpos += len; }
     }
     if (out.inner.count(r.qname)) continue;  // seen
@@ -453,9 +483,13 @@ static SampledProbs process_records(const std::vector<const BamRecord*>& recs, l
       for (auto& pp : kv.second.pos) {
         bool keep = !cx.edge->active || cx.edge->keep_position(pp.first, (size_t)r.l_seq);
         if (cx.only_mapped && !pairs.count(pp.first)) keep = false;
-        if (cx.pf) { auto ap = pairs.find(pp.first); bool ref_neg = (s == 1) != r.is_reverse(); if (ap == pairs.end() || !cx.pf->contains(r.tid, ap->second, ref_neg)) keep = false; }
+        if (cx.pf) { auto ap = pairs.find(pp.first); bool ref_neg = (s == 1) != r.is_reverse();
+          if (ap == pairs.end() || !cx.pf->contains(r.tid, ap->second, ref_neg)) keep = false;
+          }
         if (!keep) continue;
-        if (cx.collapse->active) { BaseModProbs c2 = collapse_redistribute(pp.second, cx.collapse->code); vals.push_back(c2.argmax_value()); if (cx.keep_calls) kept.push_back(c2); }
+        if (cx.collapse->active) { BaseModProbs c2 = collapse_redistribute(pp.second, cx.collapse->code); vals.push_back(c2.argmax_value());
+          if (cx.keep_calls) kept.push_back(c2);
+          }
         else { vals.push_back(pp.second.argmax_value()); if (cx.keep_calls) kept.push_back(pp.second); }
       }
       if (vals.empty()) continue;
@@ -504,7 +538,8 @@ static SampledProbs sample_reads(const BamFile& bam, const Options& o, const Reg
       }
       struct G { ChromCoordinates cc; Count c; };
       std::vector<G> grouped; bool have_slack = false; ChromCoordinates slack; size_t slack_n = 0;
-      auto merge_cc = [](const ChromCoordinates& a, const ChromCoordinates& b) { ChromCoordinates m = a; m.start = std::min(a.start, b.start); m.end = std::max(a.end, b.end); return m; };
+      auto merge_cc = [](const ChromCoordinates& a, const ChromCoordinates& b) { ChromCoordinates m = a; m.start = std::min(a.start, b.start);
+        m.end = std::max(a.end, b.end); return m; };
       for (auto& cc : all) {
         auto pc = per_chrom.find(cc.tid); if (pc == per_chrom.end()) continue;
         float f = (float)cc.len() / (float)len_per_chrom[cc.tid];
@@ -512,7 +547,8 @@ static SampledProbs sample_reads(const BamFile& bam, const Options& o, const Reg
         size_t x = (size_t)ceilf((float)pc->second.n * f);
         if (x < 50) {
           if (have_slack) {
-            if (slack.tid == cc.tid) { ChromCoordinates m = merge_cc(slack, cc); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot; } else { Count c; c.n = tot; grouped.push_back({m, c}); have_slack = false; } }
+            if (slack.tid == cc.tid) { ChromCoordinates m = merge_cc(slack, cc); size_t tot = x + slack_n; if (tot < 50) { slack = m; slack_n = tot;
+              } else { Count c; c.n = tot; grouped.push_back({m, c}); have_slack = false; } }
             else { Count c; c.n = slack_n; grouped.push_back({slack, c}); slack = cc; slack_n = x; }
           } else { have_slack = true; slack = cc; slack_n = x; }
         } else {
@@ -547,7 +583,9 @@ static SampledProbs sample_reads(const BamFile& bam, const Options& o, const Reg
     // new_from_options (record_sampler.rs:51-61): --num-reads -> first N; --sampling-frac -> a Bernoulli draw per record from StdRng,
     // seeded by --seed; without --seed the reference seeds from entropy and no two runs agree: refused here as by the product
     const bool draws = o.have_frac && o.sampling_frac < 1.0;
-    if (draws && !un.empty() && !o.have_seed) throw MkErr("unmapped-read sampling with --sampling-frac < 1 draws from an entropy-seeded rand::StdRng: give --seed");
+    if (draws
+        && !un.empty()
+        && !o.have_seed) throw MkErr("unmapped-read sampling with --sampling-frac < 1 draws from an entropy-seeded rand::StdRng: give --seed");
     StdRng rng = StdRng::seed_from_u64(o.seed);
     agg.merge(process_records(un, limit, cx, draws ? &rng : nullptr, o.sampling_frac));
   }
@@ -573,32 +611,37 @@ static void parse_thresholds(const std::vector<std::string>& raws, ThresholdCall
       int b = base_from_char(raw[0]); if (b < 0) throw MkErr("failed to parse base");
       if (c->per_base.count(b)) throw MkErr("repeated threshold for base");
       c->per_base[b] = strtof(raw.c_str() + col + 1, nullptr);
-    } else { if (have_default) throw MkErr("default threshold encountered more than once"); have_default = true; c->default_threshold = strtof(raw.c_str(), nullptr); }
+    } else { if (have_default) throw MkErr("default threshold encountered more than once"); have_default = true;
+      c->default_threshold = strtof(raw.c_str(), nullptr); }
   }
 }
 
 // BedMethylWriter::write_feature_counts (writers.rs:87-156)
-static void write_rows(FILE* f, const std::string& chrom, const std::map<uint32_t, std::vector<Row>>& rows, bool mixed, const std::vector<std::string>& labels, uint64_t* n_rows) {
+static void write_rows(FILE* f, const std::string& chrom, const std::map<uint32_t, std::vector<Row>>& rows, bool mixed,
+    const std::vector<std::string>& labels, uint64_t* n_rows) {
   char sp = mixed ? ' ' : '\t';
   for (auto& kv : rows) for (const Row& r : kv.second) {
     std::string name = code_str(r.code);
     if (labels.size() >= 2 && r.motif_idx >= 0 && (size_t)r.motif_idx < labels.size()) name += "," + labels[r.motif_idx];
     float pct = r.frac * 100.0f;
-    fprintf(f, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos, r.pos + 1, name.c_str(), r.cov, r.strand, r.pos,
+    fprintf(f, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos, r.pos + 1, name.c_str(),
+        r.cov, r.strand, r.pos,
             r.pos + 1, r.cov, sp, (double)pct, sp, r.n_mod, sp, r.n_can, sp, r.n_other, sp, r.n_delete, sp, r.n_fail, sp, r.n_diff, sp, r.n_nocall);
     (*n_rows)++;
   }
 }
 
 // PileupWriter<DuplexModBasePileup> for BedMethylWriter (writers.rs:185-258)
-static void write_duplex_rows(FILE* f, const std::string& chrom, const std::map<uint32_t, std::vector<DuplexRow>>& rows, bool mixed, uint64_t* n_rows) {
+static void write_duplex_rows(FILE* f, const std::string& chrom, const std::map<uint32_t, std::vector<DuplexRow>>& rows, bool mixed,
+    uint64_t* n_rows) {
   char sp = mixed ? ' ' : '\t';
   auto el = [](ModCode c) { return c == 0 ? std::string("-") : code_str(c); };
   for (auto& kv : rows) for (const DuplexRow& r : kv.second) {
     uint32_t cov = r.count + r.n_other;
     float pct = ((float)r.count / (float)cov) * 100.0f;
     std::string name = el(r.pat[0]) + "," + el(r.pat[1]) + "," + std::string(1, r.base);
-    fprintf(f, "%s\t%u\t%u\t%s\t%u\t.\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos, r.pos + 1, name.c_str(), cov, r.pos, r.pos + 1,
+    fprintf(f, "%s\t%u\t%u\t%s\t%u\t.\t%u\t%u\t255,0,0\t%u%c%.2f%c%u%c%u%c%u%c%u%c%u%c%u%c%u\n", chrom.c_str(), r.pos, r.pos + 1, name.c_str(), cov,
+        r.pos, r.pos + 1,
             cov, sp, (double)pct, sp, r.count, sp, r.n_can, sp, r.n_other, sp, r.n_delete, sp, r.n_fail, sp, r.n_diff, sp, r.n_nocall);
     (*n_rows)++;
   }
@@ -615,14 +658,18 @@ static int run_pileup(const Options& o) {
   if (!o.edge_filter.empty()) {  // parse_edge_filter_input (command_utils.rs:243-277)
     po.edge_filter.active = true; po.edge_filter.inverted = o.invert_edge;
     size_t c = o.edge_filter.find(',');
-    if (c != std::string::npos) { po.edge_filter.start = strtoul(o.edge_filter.c_str(), nullptr, 10); po.edge_filter.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); }
+    if (c != std::string::npos) { po.edge_filter.start = strtoul(o.edge_filter.c_str(), nullptr, 10);
+      po.edge_filter.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); }
     else po.edge_filter.start = po.edge_filter.end = strtoul(o.edge_filter.c_str(), nullptr, 10);
   }
   std::map<ModCode, float> per_mod;
-  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc; if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code"); per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
+  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc;
+    if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code");
+    per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
   std::vector<ReferenceRecord> reference_records = get_targets(bam, have_region ? &region : nullptr);
   PositionFilter pf_store; const PositionFilter* pf = nullptr;
-  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid;
+    pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
   if (IdxStats::make(bam, have_region ? &region : nullptr, pf).mapped == 0) throw MkErr("did not find any mapped reads");
   size_t chunk_size = o.have_chunk ? o.chunk_size : (size_t)floorf((float)o.threads * 1.5f);
   if (o.filter_percentile > 1.0f) throw MkErr("filter percentile must be <= 1.0");
@@ -634,16 +681,20 @@ static int run_pileup(const Options& o) {
     if (o.ref_fasta.empty()) throw MkErr("--ref is required");
   }
   CollapseMethod thr_collapse; bool combine_strands = o.combine_strands || o.hemi;  // the feeder runs with combine_strands = true (1383-1390)
-  if (o.preset == "traditional") { po.numeric = NUM_COLLAPSE; po.collapse.active = true; po.collapse.code = code_char('h'); combine_strands = true; thr_collapse = po.collapse; }
+  if (o.preset == "traditional") { po.numeric = NUM_COLLAPSE; po.collapse.active = true; po.collapse.code = code_char('h'); combine_strands = true;
+    thr_collapse = po.collapse; }
   else if (!o.preset.empty()) throw MkErr("unknown preset");
   else if (o.combine_mods) po.numeric = NUM_COMBINE;
-  else if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); po.numeric = NUM_COLLAPSE; po.collapse.active = true; po.collapse.code = mc; thr_collapse = po.collapse; }
+  else if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); po.numeric = NUM_COLLAPSE;
+    po.collapse.active = true; po.collapse.code = mc; thr_collapse = po.collapse; }
   po.combine_strands = combine_strands;
   std::vector<Motif> motifs; bool have_motifs = false;
   if (!o.motif_parts.empty()) {  // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
     if (!o.preset.empty()) throw MkErr("cannot use presets and motifs together");
     std::vector<std::string> parts = o.motif_parts;
-    if (o.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true; if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
+    if (o.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true;
+      if (!has) { parts.push_back("CG");
+        parts.push_back("0"); } }
     for (size_t i = 0; i + 1 < parts.size(); i += 2) motifs.push_back(parse_motif(parts[i], strtoul(parts[i + 1].c_str(), nullptr, 10)));
     have_motifs = true;
   } else if (o.preset == "traditional" || o.cpg) { motifs.push_back(parse_motif("CG", 0)); have_motifs = true; }
@@ -651,8 +702,10 @@ static int run_pileup(const Options& o) {
   MotifLookup lookup; const MotifLookup* lk = nullptr;
   if (have_motifs) {
     if (o.ref_fasta.empty()) throw MkErr("reference fasta is required for using --motif or --cpg options");
-    if (combine_strands) for (auto& m : motifs) if (!m.info.is_palindrome) throw MkErr(o.hemi ? "motif must be palindromic for pileup-hemi" : "cannot combine strands with a motif that is not a palindrome");
-    lookup.fasta = Fasta::load(o.ref_fasta); lookup.mask = o.mask; lookup.motifs = motifs; for (auto& m : motifs) lookup.longest = std::max<uint64_t>(lookup.longest, m.info.length);
+    if (combine_strands) for (auto& m : motifs) if (!m.info.is_palindrome) throw MkErr(o.hemi ? "motif must be palindromic for pileup-hemi"
+        : "cannot combine strands with a motif that is not a palindrome");
+    lookup.fasta = Fasta::load(o.ref_fasta); lookup.mask = o.mask; lookup.motifs = motifs;
+      for (auto& m : motifs) lookup.longest = std::max<uint64_t>(lookup.longest, m.info.length);
     lk = &lookup;
   }
   ThresholdCaller caller; caller.per_mod = per_mod;
@@ -661,21 +714,25 @@ static int run_pileup(const Options& o) {
   else {
     const Region* sr = have_sregion ? &sregion : (have_region ? &region : nullptr);
     auto per_base = sample_probs(bam, o, sr, thr_collapse, po.edge_filter, pf);
-    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); }
-    for (auto& kv : caller.per_base) fprintf(stderr, "[oracle] threshold %c %.9g (n=%zu)\n", base_char(kv.first), (double)kv.second, per_base[kv.first].size());
+    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end());
+      caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); }
+    for (auto& kv : caller.per_base) fprintf(stderr, "[oracle] threshold %c %.9g (n=%zu)\n", base_char(kv.first), (double)kv.second,
+        per_base[kv.first].size());
   }
   auto t_thr = std::chrono::steady_clock::now();
   if (pf) reference_records = optimize_reference_records(*pf, reference_records, o.interval_size);
   FILE* out = (o.out_bed.empty() || o.out_bed == "-" || o.out_bed == "stdout") ? stdout : fopen(o.out_bed.c_str(), "w");
   if (!out) throw MkErr("failed to make output file");
-  if (o.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n", out);
+  if (o.with_header) fputs("chrom\tchromStart\tchromEnd\tname\tscore\tstrand\tthickStart\tthickEnd\tcolor\tvalid_coverage\tpercent_modified\tcount_modified\tcount_canonical\tcount_other_mod\tcount_delete\tcount_fail\tcount_diff\tcount_nocall\n",
+      out);
   uint64_t n_rows = 0, n_positions = 0, n_proc = 0, n_skip = 0;
   if (!reference_records.empty()) {
     Feeder feeder(reference_records, chunk_size, o.interval_size, combine_strands, lk, pf);
     std::vector<MultiChromCoordinates> super_batch;
     while (feeder.next_batch(&super_batch)) {
       std::vector<const ChromCoordinates*> work; for (auto& m : super_batch) for (auto& c : m) work.push_back(&c);
-      std::vector<IntervalResult> results(work.size()); std::vector<DuplexIntervalResult> dresults(o.hemi ? work.size() : 0); std::vector<std::string> errs(work.size());
+      std::vector<IntervalResult> results(work.size()); std::vector<DuplexIntervalResult> dresults(o.hemi ? work.size() : 0);
+        std::vector<std::string> errs(work.size());
       auto job = [&](size_t i) {
         try {
           if (o.hemi) dresults[i] = process_region_duplex(bam, work[i]->tid, work[i]->start, work[i]->end, caller, po, work[i]->focus);
@@ -683,11 +740,16 @@ static int run_pileup(const Options& o) {
         } catch (const MkErr& e) { errs[i] = e.what(); }
       };
       if (o.workers <= 1) for (size_t i = 0; i < work.size(); i++) job(i);
-      else { std::vector<std::thread> th; std::atomic<size_t> nxt{0}; for (size_t w = 0; w < o.workers; w++) th.emplace_back([&]() { for (;;) { size_t i = nxt++; if (i >= work.size()) break; job(i); } }); for (auto& t : th) t.join(); }
+      else { std::vector<std::thread> th; std::atomic<size_t> nxt{0}; for (size_t w = 0; w < o.workers; w++) th.emplace_back([&]() { for (;;) {
+            size_t i = nxt++; if (i >= work.size()) break; job(i); } }); for (auto& t : th) t.join(); }
       for (size_t i = 0; i < work.size(); i++) {
-        if (!errs[i].empty()) { fprintf(stderr, "[oracle] interval error: %s\n", errs[i].c_str()); if (errs[i].find("max-depth") != std::string::npos) throw MkErr(errs[i]); continue; }
-        if (o.hemi) { write_duplex_rows(out, bam.ref_names[work[i]->tid], dresults[i].rows, o.mixed_delim, &n_rows); n_proc += dresults[i].processed; n_skip += dresults[i].skipped; }
-        else { write_rows(out, bam.ref_names[work[i]->tid], results[i].rows, o.mixed_delim, labels, &n_rows); n_proc += results[i].processed; n_skip += results[i].skipped; }
+        if (!errs[i].empty()) { fprintf(stderr, "[oracle] interval error: %s\n", errs[i].c_str());
+          if (errs[i].find("max-depth") != std::string::npos) throw MkErr(errs[i]);
+          continue; }
+        if (o.hemi) { write_duplex_rows(out, bam.ref_names[work[i]->tid], dresults[i].rows, o.mixed_delim, &n_rows); n_proc += dresults[i].processed;
+          n_skip += dresults[i].skipped; }
+        else { write_rows(out, bam.ref_names[work[i]->tid], results[i].rows, o.mixed_delim, labels, &n_rows); n_proc += results[i].processed;
+          n_skip += results[i].skipped; }
         n_positions += work[i]->len();
       }
     }
@@ -695,8 +757,10 @@ static int run_pileup(const Options& o) {
   if (out != stdout) fclose(out);
   auto t1 = std::chrono::steady_clock::now();
   auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-  fprintf(stderr, "[oracle] rows=%llu positions=%llu processed~%llu skipped~%llu load_s=%.3f threshold_s=%.3f pileup_s=%.3f total_s=%.3f\n", (unsigned long long)n_rows,
-          (unsigned long long)n_positions, (unsigned long long)n_proc, (unsigned long long)n_skip, sec(t0, t_load), sec(t_load, t_thr), sec(t_thr, t1), sec(t0, t1));
+  fprintf(stderr, "[oracle] rows=%llu positions=%llu processed~%llu skipped~%llu load_s=%.3f threshold_s=%.3f pileup_s=%.3f total_s=%.3f\n",
+      (unsigned long long)n_rows,
+          (unsigned long long)n_positions, (unsigned long long)n_proc, (unsigned long long)n_skip, sec(t0, t_load), sec(t_load, t_thr),
+              sec(t_thr, t1), sec(t0, t1));
   return 0;
 }
 
@@ -708,19 +772,27 @@ static int run_sample_probs(const Options& o) {
   Region region; const bool have_region = !o.region.empty();
   if (have_region) region = parse_region(o.region, bam);
   EdgeFilter edge;
-  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
+  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) {
+      edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10);
+    } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
   CollapseMethod collapse;
-  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true; collapse.code = mc; }
+  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true;
+    collapse.code = mc; }
   std::vector<ReferenceRecord> reference_records = get_targets(bam, have_region ? &region : nullptr);
   PositionFilter pf_store; const PositionFilter* pf = nullptr;
-  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid;
+    pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
   auto per_base = sample_probs(bam, o, have_region ? &region : nullptr, collapse, edge, pf);
-  std::vector<float> qs; { size_t a = 0; while (a <= o.percentiles.size()) { size_t c = o.percentiles.find(',', a); if (c == std::string::npos) c = o.percentiles.size(); if (c > a) qs.push_back(strtof(o.percentiles.substr(a, c - a).c_str(), nullptr)); a = c + 1; } }
+  std::vector<float> qs; { size_t a = 0; while (a <= o.percentiles.size()) { size_t c = o.percentiles.find(',', a);
+      if (c == std::string::npos) c = o.percentiles.size();
+      if (c > a) qs.push_back(strtof(o.percentiles.substr(a, c - a).c_str(), nullptr));
+      a = c + 1; } }
   FILE* out = (o.out_bed.empty() || o.out_bed == "-") ? stdout : fopen(o.out_bed.c_str(), "w");
   if (!out) throw MkErr("failed to make output file");
   for (auto& kv : per_base) {
     std::sort(kv.second.begin(), kv.second.end());
-    for (float q : qs) fprintf(out, "%c\t%.9g\t%.9g\t%zu\n", base_char(kv.first), (double)q, (double)percentile_linear_interp(kv.second, q), kv.second.size());
+    for (float q : qs) fprintf(out, "%c\t%.9g\t%.9g\t%zu\n", base_char(kv.first), (double)q, (double)percentile_linear_interp(kv.second, q),
+        kv.second.size());
   }
   if (out != stdout) fclose(out);
   return 0;
@@ -734,20 +806,28 @@ static int run_summary(const Options& o) {
   Region region; const bool have_region = !o.region.empty();
   if (have_region) region = parse_region(o.region, bam);
   EdgeFilter edge;
-  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
+  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) {
+      edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10);
+    } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
   CollapseMethod collapse;
-  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true; collapse.code = mc; }
+  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true;
+    collapse.code = mc; }
   std::map<ModCode, float> per_mod;
-  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc; if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code"); per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
+  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc;
+    if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code");
+    per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
   std::vector<ReferenceRecord> reference_records = get_targets(bam, have_region ? &region : nullptr);
   PositionFilter pf_store; const PositionFilter* pf = nullptr;
-  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& r : reference_records) c2t[r.name] = r.tid;
+    pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store; }
   SampledProbs agg = sample_reads(bam, o, have_region ? &region : nullptr, collapse, edge, pf, true);
   ThresholdCaller caller;
   if (!o.filter_threshold.empty()) { caller.per_mod = per_mod; parse_thresholds(o.filter_threshold, &caller); }
   else if (o.no_filtering) {}
-  else { caller.per_mod = per_mod; auto per_base = flatten_probs(agg); for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); } }
-  std::map<int, uint64_t> reads_with; std::map<int, std::map<ModCode, uint64_t>> pass, fail; std::map<int, std::set<ModCode>> observed;   // code 0 = canonical
+  else { caller.per_mod = per_mod; auto per_base = flatten_probs(agg); for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end());
+      caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); } }
+  // code 0 = canonical
+  std::map<int, uint64_t> reads_with; std::map<int, std::map<ModCode, uint64_t>> pass, fail; std::map<int, std::set<ModCode>> observed;
   for (auto& rk : agg.calls) for (auto& bk : rk.second) {
     const int base = bk.first; reads_with[base]++;
     for (const BaseModProbs& bmp : bk.second) {
@@ -766,7 +846,8 @@ static int run_summary(const Options& o) {
     const int b = kv.first;
     std::vector<ModCode> codes(observed[b].begin(), observed[b].end()); std::sort(codes.begin(), codes.end());
     fprintf(out, "row\t%c\t-\t%llu\t%llu\n", base_char(b), (unsigned long long)pass[b][0], (unsigned long long)fail[b][0]);
-    for (ModCode c : codes) fprintf(out, "row\t%c\t%s\t%llu\t%llu\n", base_char(b), code_str(c).c_str(), (unsigned long long)pass[b][c], (unsigned long long)fail[b][c]);
+    for (ModCode c : codes) fprintf(out, "row\t%c\t%s\t%llu\t%llu\n", base_char(b), code_str(c).c_str(), (unsigned long long)pass[b][c],
+        (unsigned long long)fail[b][c]);
   }
   if (out != stdout) fclose(out);
   return 0;
@@ -779,39 +860,52 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
   Region region; const bool have_region = !o.region.empty();
   if (have_region) region = parse_region(o.region, bam);
   PositionFilter pf_store; const PositionFilter* pf = nullptr;
-  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& rr : get_targets(bam, have_region ? &region : nullptr)) c2t[rr.name] = rr.tid; pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store;
+  if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t;
+    for (auto& rr : get_targets(bam, have_region ? &region : nullptr)) c2t[rr.name] = rr.tid;
+    pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store;
     xo.include = [pf](int32_t tid, uint64_t p, bool neg) { return pf->contains(tid, p, neg); }; }
   // With an index (and without --ignore-index) the reference walks interval chunks of the targets (util.rs:329-470): --region then selects the
   // records the fetches of its intervals return — every record overlapping it, once (prev_end) — where the serial scan looks at every record
   // of the file.  Its rows leave in whatever order the pool finishes the intervals; here: file order.  --num-reads with an index goes through
   // the sampling schedule, which is not restated for this subcommand.
   FILE* probe = fopen((o.in_bam + ".bai").c_str(), "rb"); const bool use_index = probe && !xo.ignore_index; if (probe) fclose(probe);
-  if (use_index && xo.num_reads >= 0) throw MkErr("extract calls --num-reads on an indexed BAM follows the sampling schedule: not restated (use --ignore-index for the first N records)");
+  if (use_index
+      && xo.num_reads >= 0) throw MkErr("extract calls --num-reads on an indexed BAM follows the sampling schedule: not restated (use --ignore-index for the first N records)");
   const int region_tid = have_region ? bam.tid_of(region.name) : -1;
   EdgeFilter edge;
-  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) { edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10); } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
+  if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) {
+      edge.start = strtoul(o.edge_filter.c_str(), nullptr, 10); edge.end = strtoul(o.edge_filter.c_str() + c + 1, nullptr, 10);
+    } else edge.start = edge.end = strtoul(o.edge_filter.c_str(), nullptr, 10); }
   CollapseMethod collapse;
-  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true; collapse.code = mc; }
+  if (!o.ignore.empty()) { ModCode mc; if (!parse_mod_code(o.ignore, &mc)) throw MkErr("failed to parse mod code"); collapse.active = true;
+    collapse.code = mc; }
   std::map<ModCode, float> per_mod;
-  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc; if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code"); per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
+  for (auto& raw : o.mod_thresholds) { size_t c = raw.find(':'); if (c == std::string::npos) throw MkErr("illegal per-mod threshold"); ModCode mc;
+    if (!parse_mod_code(raw.substr(0, c), &mc)) throw MkErr("failed to parse mod code");
+    per_mod[mc] = strtof(raw.c_str() + c + 1, nullptr); }
   ThresholdCaller caller;
   if (o.no_filtering) {}
   else if (!o.filter_threshold.empty()) { caller.per_mod = per_mod; parse_thresholds(o.filter_threshold, &caller); }
-  else {   // get_threshold_from_options (command_utils.rs:74-134): the pileup's estimate; positions without a reference position count unless --mapped-only
+  // get_threshold_from_options (command_utils.rs:74-134): the pileup's estimate; positions without a reference position count unless --mapped-only
+  else {
     Options so = o; so.include_unmapped = !xo.mapped_only && !pf;   // reference_position_filter.only_mapped_positions()
     caller.per_mod = per_mod;
     auto per_base = sample_probs(bam, so, have_region ? &region : nullptr, collapse, edge, pf);
-    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end()); caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); }
+    for (auto& kv : per_base) { std::sort(kv.second.begin(), kv.second.end());
+      caller.per_base[kv.first] = percentile_linear_interp(kv.second, o.filter_percentile); }
   }
   std::map<std::string, std::string> ref_seqs;
-  if (!xo.ref_fasta.empty()) { Fasta fa = Fasta::load(xo.ref_fasta); for (auto& kv : fa.seqs) if (bam.tid_of(kv.first) >= 0) ref_seqs[kv.first] = kv.second; }
+  if (!xo.ref_fasta.empty()) { Fasta fa = Fasta::load(xo.ref_fasta);
+    for (auto& kv : fa.seqs) if (bam.tid_of(kv.first) >= 0) ref_seqs[kv.first] = kv.second;
+    }
   FILE* out = (xo.out_tsv.empty() || xo.out_tsv == "-" || xo.out_tsv == "stdout") ? stdout : fopen(xo.out_tsv.c_str(), "w");
   if (!out) throw MkErr("failed to make output file");
   if (!xo.no_headers) fputs(extract_calls_header(), out);
   uint64_t n_used = 0, n_skipped = 0, n_failed = 0, n_rows = 0;
   long n_sent = 0;
   for (const BamRecord& r : bam.recs) {
-    if (use_index && have_region) {   // IndexedReader::fetch(tid, start, end): records overlapping the region (a record without reference span counts as one base)
+    // IndexedReader::fetch(tid, start, end): records overlapping the region (a record without reference span counts as one base)
+    if (use_index && have_region) {
       const int64_t e = (int64_t)r.pos + std::max<int64_t>((int64_t)r.ref_len(), 1);
       if (r.tid != region_tid || r.pos >= (int64_t)region.end || e <= (int64_t)region.start) continue;
     }
@@ -826,13 +920,16 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
     fputs(rows.c_str(), out);
   }
   if (out != stdout) fclose(out);
-  fprintf(stderr, "[oracle] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used, (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);
+  fprintf(stderr, "[oracle] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used, (unsigned long long)n_rows,
+      (unsigned long long)n_skipped, (unsigned long long)n_failed);
   return 0;
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs" && std::string(argv[1]) != "summary" && std::string(argv[1]) != "extract-calls")) {
-    fprintf(stderr, "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n"
+  if (argc < 2 || (std::string(argv[1]) != "pileup" && std::string(argv[1]) != "pileup-hemi" && std::string(argv[1]) != "sample-probs"
+      && std::string(argv[1]) != "summary" && std::string(argv[1]) != "extract-calls")) {
+    fprintf(stderr,
+        "usage: modkit_oracle pileup <in.bam> <out.bed> [flags as `modkit pileup`]\n       modkit_oracle pileup-hemi <in.bam> -o <out.bed> [flags as `modkit pileup-hemi`]\n"
                     "       modkit_oracle sample-probs <in.bam> [-o table.tsv] [-p 0.1,0.5,0.9] [sampling flags of `modkit sample-probs`]\n"
                     "       modkit_oracle summary <in.bam> [-o counts.tsv] [flags of `modkit summary`]\n"
                     "       modkit_oracle extract-calls <in.bam> <out.tsv> [--ref fa] [--allow-non-primary] [--mapped-only] [--pass-only] [threshold / sampling flags of `modkit extract calls`]\n");
@@ -843,12 +940,14 @@ int main(int argc, char** argv) {
   o.hemi = std::string(argv[1]) == "pileup-hemi";
   const bool summary_cmd = std::string(argv[1]) == "summary";
   o.sample_probs_cmd = std::string(argv[1]) == "sample-probs" || summary_cmd;
-  if (o.sample_probs_cmd) { o.include_unmapped = true; o.sampling_interval_size = 1000000; }   // --only-mapped is off by default; -i is the sampling interval
+  // --only-mapped is off by default; -i is the sampling interval
+  if (o.sample_probs_cmd) { o.include_unmapped = true; o.sampling_interval_size = 1000000; }
   try {
     for (int i = 2; i < argc; i++) {
       std::string a = argv[i];
       auto val = [&]() { if (i + 1 >= argc) throw MkErr("missing value for " + a); return std::string(argv[++i]); };
-      if (o.hemi && (a == "--preset" || a == "--combine-strands" || a == "--with-header" || a == "--header")) throw MkErr("unknown flag " + a + " for pileup-hemi");
+      if (o.hemi && (a == "--preset" || a == "--combine-strands" || a == "--with-header"
+          || a == "--header")) throw MkErr("unknown flag " + a + " for pileup-hemi");
       if (o.hemi && (a == "-o" || a == "--out-bed")) { o.out_bed = val(); continue; }
       if (extract_cmd) {
         if (a == "--ref" || a == "--reference") { xo.ref_fasta = val(); continue; }
@@ -870,26 +969,37 @@ int main(int argc, char** argv) {
         if (a == "--no-sampling") { o.have_frac = true; o.sampling_frac = 1.0; continue; }
       }
       if (a == "--region") o.region = val(); else if (a == "--max-depth") o.max_depth = (uint32_t)std::stoul(val());
-      else if (a == "-t" || a == "--threads") o.threads = std::stoul(val()); else if (a == "-i" || a == "--interval-size") o.interval_size = (uint32_t)std::stoul(val());
+      else if (a == "-t" || a == "--threads") o.threads = std::stoul(val());
+        else if (a == "-i" || a == "--interval-size") o.interval_size = (uint32_t)std::stoul(val());
       else if (a == "--chunk-size") { o.have_chunk = true; o.chunk_size = std::stoul(val()); }
-      else if (a == "-n" || a == "--num-reads") o.num_reads = std::stoul(val()); else if (a == "-f" || a == "--sampling-frac") { o.have_frac = true; o.sampling_frac = std::stod(val()); }
-      else if (a == "--seed") { o.have_seed = true; o.seed = std::stoull(val()); } else if (a == "--no-filtering") o.no_filtering = true; else if (a == "-p" || a == "--filter-percentile") o.filter_percentile = std::stof(val());
-      else if (a == "--filter-threshold") o.filter_threshold.push_back(val()); else if (a == "--mod-thresholds" || a == "--mod-threshold") o.mod_thresholds.push_back(val());
-      else if (a == "--sample-region") o.sample_region = val(); else if (a == "--sampling-interval-size") o.sampling_interval_size = (uint32_t)std::stoul(val());
-      else if (a == "--include-bed" || a == "--include-positions") o.include_bed = val(); else if (a == "--include-unmapped") o.include_unmapped = true;
+      else if (a == "-n" || a == "--num-reads") o.num_reads = std::stoul(val()); else if (a == "-f" || a == "--sampling-frac") { o.have_frac = true;
+        o.sampling_frac = std::stod(val()); }
+      else if (a == "--seed") { o.have_seed = true; o.seed = std::stoull(val()); } else if (a == "--no-filtering") o.no_filtering = true;
+        else if (a == "-p" || a == "--filter-percentile") o.filter_percentile = std::stof(val());
+      else if (a == "--filter-threshold") o.filter_threshold.push_back(val());
+        else if (a == "--mod-thresholds" || a == "--mod-threshold") o.mod_thresholds.push_back(val());
+      else if (a == "--sample-region") o.sample_region = val();
+        else if (a == "--sampling-interval-size") o.sampling_interval_size = (uint32_t)std::stoul(val());
+      else if (a == "--include-bed" || a == "--include-positions") o.include_bed = val();
+        else if (a == "--include-unmapped") o.include_unmapped = true;
       else if (a == "--ignore") o.ignore = val(); else if (a == "--force-allow-implicit") o.force_allow = true;
       else if (a == "--motif") { o.motif_parts.push_back(val()); o.motif_parts.push_back(val()); } else if (a == "--cpg") o.cpg = true;
-      else if (a == "--ref" || a == "-r") o.ref_fasta = val(); else if (a == "--mask" || a == "-k") o.mask = true; else if (a == "--preset") o.preset = val();
+      else if (a == "--ref" || a == "-r") o.ref_fasta = val(); else if (a == "--mask" || a == "-k") o.mask = true;
+        else if (a == "--preset") o.preset = val();
       else if (a == "--combine-mods") o.combine_mods = true; else if (a == "--combine-strands") o.combine_strands = true;
       else if (a == "--edge-filter") o.edge_filter = val(); else if (a == "--invert-edge-filter") o.invert_edge = true;
-      else if (a == "--only-tabs") {} else if (a == "--mixed-delim") o.mixed_delim = true; else if (a == "--with-header" || a == "--header") o.with_header = true;
+      else if (a == "--only-tabs") {} else if (a == "--mixed-delim") o.mixed_delim = true;
+        else if (a == "--with-header" || a == "--header") o.with_header = true;
       else if (a == "--suppress-progress") {} else if (a == "--oracle-workers") o.workers = std::stoul(val());
       else if (a == "--partition-tag" || a == "--bedgraph" || a == "--prefix") throw MkErr(a + " is not restated by the oracle");
       else if (!a.empty() && a[0] == '-' && a != "-") throw MkErr("unknown flag " + a);
       else pos.push_back(a);
     }
-    if (extract_cmd) { if (pos.size() != 2) throw MkErr("need <in.bam> <out.tsv>"); o.in_bam = pos[0]; xo.in_bam = pos[0]; xo.out_tsv = pos[1]; return run_extract_calls(o, xo); }
-    if (o.sample_probs_cmd) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; if (!o.include_bed.empty()) o.include_unmapped = false; return summary_cmd ? run_summary(o) : run_sample_probs(o); }
+    if (extract_cmd) { if (pos.size() != 2) throw MkErr("need <in.bam> <out.tsv>"); o.in_bam = pos[0]; xo.in_bam = pos[0]; xo.out_tsv = pos[1];
+      return run_extract_calls(o, xo); }
+    if (o.sample_probs_cmd) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0];
+      if (!o.include_bed.empty()) o.include_unmapped = false;
+      return summary_cmd ? run_summary(o) : run_sample_probs(o); }
     if (o.hemi) { if (pos.size() != 1) throw MkErr("need <in.bam>"); o.in_bam = pos[0]; }
     else { if (pos.size() != 2) throw MkErr("need <in.bam> <out.bed>"); o.in_bam = pos[0]; o.out_bed = pos[1]; }
     return run_pileup(o);

@@ -217,7 +217,9 @@ template <class F> static inline void oracle_parallel_for(size_t n, F f) {
 static inline std::vector<uint8_t> read_bgzf_all(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) throw MkErr("cannot open " + path);
-  std::vector<uint8_t> comp; { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); comp.resize((size_t)n); if (n && fread(comp.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); throw MkErr("read error " + path); } }
+  std::vector<uint8_t> comp; { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); comp.resize((size_t)n);
+    if (n && fread(comp.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f);
+      throw MkErr("read error " + path); } }
   fclose(f);
   struct Blk { size_t off, clen; uint32_t isize; uint64_t uoff; };
   std::vector<Blk> blks; size_t o = 0; uint64_t u = 0; bool ok = true;
@@ -225,7 +227,9 @@ static inline std::vector<uint8_t> read_bgzf_all(const std::string& path) {
     if (o + 18 > comp.size() || comp[o] != 31 || comp[o + 1] != 139 || !(comp[o + 3] & 4)) { ok = false; break; }
     const size_t xlen = comp[o + 10] | (comp[o + 11] << 8); size_t x = o + 12, xe = x + xlen; int bsize = -1;
     if (xe > comp.size()) { ok = false; break; }
-    while (x + 4 <= xe) { const size_t sl = comp[x + 2] | (comp[x + 3] << 8); if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2 && x + 6 <= xe) bsize = comp[x + 4] | (comp[x + 5] << 8); x += 4 + sl; }
+    while (x + 4 <= xe) { const size_t sl = comp[x + 2] | (comp[x + 3] << 8);
+      if (comp[x] == 'B' && comp[x + 1] == 'C' && sl == 2 && x + 6 <= xe) bsize = comp[x + 4] | (comp[x + 5] << 8);
+      x += 4 + sl; }
     if (bsize < 0 || o + (size_t)bsize + 1 > comp.size() || (size_t)bsize + 1 < xlen + 20) { ok = false; break; }
     const size_t total = (size_t)bsize + 1; uint32_t isize; memcpy(&isize, &comp[o + total - 4], 4);
     blks.push_back({o + 12 + xlen, total - xlen - 20, isize, u}); u += isize; o += total;
@@ -262,7 +266,8 @@ static inline BamFile read_bam(const std::string& path) {
   }
   // record boundaries first (sequential, cheap), then the records themselves on all cores
   std::vector<std::pair<size_t, size_t>> spans;
-  while (o + 4 <= d.size()) { int32_t bs = i32(); if (bs < 32) throw MkErr("corrupt BAM record"); need((size_t)bs); spans.push_back({o, o + (size_t)bs}); o += (size_t)bs; }
+  while (o + 4 <= d.size()) { int32_t bs = i32(); if (bs < 32) throw MkErr("corrupt BAM record"); need((size_t)bs);
+    spans.push_back({o, o + (size_t)bs}); o += (size_t)bs; }
   bf.recs.resize(spans.size());
   static const char* NT16 = "=ACMGRSVTWYHKDBN";
   std::atomic<bool> bad{false};

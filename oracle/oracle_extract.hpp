@@ -81,9 +81,12 @@ static inline const char* extract_calls_header() {
 }
 
 // one record -> its rows.  Returns false when the record counts as failed (tag / CIGAR error).
-// *sent: the record reached process_record (what --num-reads counts: TrackingModRecordIter yielded it and it was not an unmapped record under --mapped-only)
-static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& r, const ExtractOptions& o, const CollapseMethod& collapse, const EdgeFilter& edge,
-                                           const ThresholdCaller& caller, const std::map<std::string, std::string>& ref_seqs, std::string* out, bool* skipped, bool* sent = nullptr) {
+// *sent: the record reached process_record (what --num-reads counts: TrackingModRecordIter yielded it and it was not an unmapped record under
+// --mapped-only)
+static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& r, const ExtractOptions& o, const CollapseMethod& collapse,
+    const EdgeFilter& edge,
+                                           const ThresholdCaller& caller, const std::map<std::string, std::string>& ref_seqs, std::string* out,
+                                               bool* skipped, bool* sent = nullptr) {
   *skipped = false; if (sent) *sent = false;
   const bool not_primary = (r.flag & (2048 | 256 | 1024)) != 0;                     // record_is_not_primary (util.rs:405-407)
   if (not_primary && !o.allow_non_primary) { *skipped = true; return true; }
@@ -101,7 +104,8 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
   if (!unmapped) {
     bool broke = false; for (uint32_t c : r.cigar) { if ((c & 15u) == 4u) sc_start += c >> 4; else { broke = true; break; } }
     if (!broke) return false;
-    broke = false; for (size_t i = r.cigar.size(); i-- > 0;) { const uint32_t c = r.cigar[i]; if ((c & 15u) == 4u) sc_end += c >> 4; else { broke = true; break; } }
+    broke = false; for (size_t i = r.cigar.size(); i-- > 0;) { const uint32_t c = r.cigar[i]; if ((c & 15u) == 4u) sc_end += c >> 4; else {
+        broke = true; break; } }
     if (!broke) return false;
   }
   const size_t clip_start = rev ? sc_end : sc_start, clip_end = rev ? sc_start : sc_end;
@@ -131,15 +135,19 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
     }
     for (auto& pp : sp.pos) {
       const BaseModProbs bmp = collapse.active ? collapse_redistribute(pp.second, collapse.code) : pp.second;
-      bmp.probs.for_each([&](ModCode c, float p) { prof.push_back({pp.first, fwd_to_ref[pp.first < L ? pp.first : 0], p, c, bmp.inferred, sg, base}); });
+      bmp.probs.for_each([&](ModCode c, float p) { prof.push_back({pp.first, fwd_to_ref[pp.first < L ? pp.first : 0], p, c, bmp.inferred, sg, base});
+        });
     }
   }
-  std::stable_sort(prof.begin(), prof.end(), [&](const ModProfileRow& a, const ModProfileRow& b) { return rev ? a.query_position > b.query_position : a.query_position < b.query_position; });
+  std::stable_sort(prof.begin(), prof.end(), [&](const ModProfileRow& a, const ModProfileRow& b) {
+    return rev ? a.query_position > b.query_position : a.query_position < b.query_position; });
   // filter_read_base_mod_probs (util.rs:71-124): a profile with a reference position is asked of the BED (reference strand of the mod); one
   // without goes under --mapped-only and under --include-bed (load_regions: "specifying include-only BED outputs only mapped sites")
   if (o.mapped_only || o.include) {
     std::vector<ModProfileRow> k;
-    for (auto& p : prof) { if (unmapped || p.ref_position < 0) continue; if (o.include && !o.include(r.tid, (uint64_t)p.ref_position, (p.strand != 0) != rev)) continue; k.push_back(p); }
+    for (auto& p : prof) { if (unmapped || p.ref_position < 0) continue;
+      if (o.include && !o.include(r.tid, (uint64_t)p.ref_position, (p.strand != 0) != rev)) continue;
+      k.push_back(p); }
     prof.swap(k);
   }
   if (prof.empty()) { *skipped = true; return true; }
@@ -170,7 +178,8 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
     bool any_inferred = false; for (auto* p : g.rows) any_inferred |= p->inferred;
     std::vector<ModCode> all(codes_of_base[g.base].begin(), codes_of_base[g.base].end()); std::sort(all.begin(), all.end());
     if (any_inferred) { bmp.inferred = true; for (ModCode c : all) { float prev; bmp.probs.insert(c, 0.0f, &prev); } }
-    else { for (auto* p : g.rows) { float prev; bmp.probs.insert(p->code, p->q_mod, &prev); } for (ModCode c : all) if (bmp.probs.find(c) < 0) { float prev; bmp.probs.insert(c, 0.0f, &prev); } }
+    else { for (auto* p : g.rows) { float prev; bmp.probs.insert(p->code, p->q_mod, &prev); } for (ModCode c : all) if (bmp.probs.find(c) < 0) {
+        float prev; bmp.probs.insert(c, 0.0f, &prev); } }
     const bool filtered = caller.call(g.base, bmp).kind == BaseModCall::FILTERED;
     if (filtered && o.pass_only) continue;
     const BaseModCall am = argmax_call(bmp);
@@ -180,13 +189,17 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
     const char ref_mod_strand = unmapped ? '.' : ((g.strand != 0) != rev ? '-' : '+');
     std::string qk = kmer_at(fwd, g.qp, o.kmer_size); if (g.strand) qk = kmer_revcomp(qk);
     std::string rk = ".";
-    if (ref_pos >= 0) { auto it = ref_seqs.find(chrom.empty() ? "." : chrom); if (it != ref_seqs.end()) rk = kmer_at(it->second, (size_t)ref_pos, o.kmer_size); }
+    if (ref_pos >= 0) { auto it = ref_seqs.find(chrom.empty() ? "." : chrom);
+      if (it != ref_seqs.end()) rk = kmer_at(it->second, (size_t)ref_pos, o.kmer_size);
+      }
     const uint8_t bq = g.qp < quals.size() ? quals[g.qp] : 0;
     const bool within_aln = have_chrom && within(g.qp);
     char line[1024];
-    snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n", r.qname.c_str(), g.qp, ref_pos >= 0 ? ref_pos : -1L,
+    snprintf(line, sizeof(line), "%s\t%zu\t%ld\t%s\t%c\t%c\t%c\t%zu\t%zu\t%zu\t%s\t%s\t%u\t%s\t%s\t%c\t%c\t%s\t%s\t%s\t%u\n", r.qname.c_str(), g.qp,
+        ref_pos >= 0 ? ref_pos : -1L,
              have_chrom ? chrom.c_str() : ".", mod_strand, ref_strand, ref_mod_strand, clip_start, clip_end, L, f32_display(am.p).c_str(),
-             am.kind == BaseModCall::CANONICAL ? "-" : code_str(am.code).c_str(), (unsigned)bq, rk.c_str(), qk.c_str(), base_char(g.base), base_char(g.strand ? complement(g.base) : g.base),
+             am.kind == BaseModCall::CANONICAL ? "-" : code_str(am.code).c_str(), (unsigned)bq, rk.c_str(), qk.c_str(), base_char(g.base),
+                 base_char(g.strand ? complement(g.base) : g.base),
              filtered ? "true" : "false", bmp.inferred ? "true" : "false", within_aln ? "true" : "false", (unsigned)r.flag);
     out->append(line);
   }

@@ -78,7 +78,8 @@ struct FocusPositions {
     return nullptr;
   }
   const std::vector<size_t>* get_negative_ids(uint32_t pos) const {  // 395-408
-    if (kind == MOTIF || kind == MOTIF_COMBINE) { auto it = negative_motif_ids.find(pos); return it == negative_motif_ids.end() ? nullptr : &it->second; }
+    if (kind == MOTIF || kind == MOTIF_COMBINE) { auto it = negative_motif_ids.find(pos);
+      return it == negative_motif_ids.end() ? nullptr : &it->second; }
     return nullptr;
   }
 };
@@ -367,8 +368,12 @@ static inline IntervalResult process_region(const BamFile& bam, uint32_t tid, ui
       int read_base = aln_neg ? complement(x) : x;
       const BaseModCall* pc = nullptr; const BaseModCall* nc = nullptr;
       if (e) {  // get_mod_call (read_cache.rs:232-297)
-        if (e->have_pos && e->have_calls[0][read_base]) { auto it = e->calls[0][read_base].find((uint64_t)P); if (it != e->calls[0][read_base].end()) pc = &it->second; }
-        if (e->have_neg && e->have_calls[1][read_base]) { auto it = e->calls[1][read_base].find((uint64_t)P); if (it != e->calls[1][read_base].end()) nc = &it->second; }
+        if (e->have_pos && e->have_calls[0][read_base]) { auto it = e->calls[0][read_base].find((uint64_t)P);
+          if (it != e->calls[0][read_base].end()) pc = &it->second;
+          }
+        if (e->have_neg && e->have_calls[1][read_base]) { auto it = e->calls[1][read_base].find((uint64_t)P);
+          if (it != e->calls[1][read_base].end()) nc = &it->second;
+          }
       }
       auto feat = [&](const BaseModCall& c, int pb, bool rs_neg) {  // Feature::from_base_mod_call 38-51
         if (c.kind == BaseModCall::FILTERED) add_feature(1, pb, 0, rs_neg);
@@ -430,7 +435,8 @@ static inline DuplexIntervalResult process_region_duplex(const BamFile& bam, uin
     if (mit == focus.positive_motifs.end()) return;
     const MotifInfo& motif = mit->second[0].first;
     // DuplexFeatureVector (duplex.rs:90-122): kind 0 = ModCall(pattern), 1 = Filtered, 2 = NoCall; key (kind, base, a, b)
-    struct Key { int kind; int base; ModCode a, b; bool operator<(const Key& o) const { return std::tie(kind, base, a, b) < std::tie(o.kind, o.base, o.a, o.b); } };
+    struct Key { int kind; int base; ModCode a, b; bool operator<(const Key& o) const {
+        return std::tie(kind, base, a, b) < std::tie(o.kind, o.base, o.a, o.b); } };
     std::map<Key, uint32_t> counts;
     uint32_t n_delete = 0;
     for (size_t ai : active) {

@@ -31,7 +31,8 @@ static uint8_t* bgzf_inflate_all(const uint8_t* c, size_t n, size_t* out_n) {
   while (o + 18 <= n) {
     if (c[o] != 31 || c[o + 1] != 139) die("not BGZF");
     size_t xlen = c[o + 10] | (c[o + 11] << 8), x = o + 12, xe = x + xlen; int bsize = -1;
-    while (x + 4 <= xe) { size_t sl = c[x + 2] | (c[x + 3] << 8); if (c[x] == 'B' && c[x + 1] == 'C' && sl == 2) bsize = c[x + 4] | (c[x + 5] << 8); x += 4 + sl; }
+    while (x + 4 <= xe) { size_t sl = c[x + 2] | (c[x + 3] << 8); if (c[x] == 'B' && c[x + 1] == 'C' && sl == 2) bsize = c[x + 4] | (c[x + 5] << 8);
+      x += 4 + sl; }
     if (bsize < 0) die("BGZF block without BC field");
     size_t total = (size_t)bsize + 1; uint32_t isize; memcpy(&isize, c + o + total - 4, 4);
     if (len + isize > cap) { cap = (len + isize) * 2; out = (uint8_t*)realloc(out, cap); if (!out) die("oom"); }
@@ -57,7 +58,8 @@ static contig_t* read_fasta(const char* path, int* n_out) {
     size_t j = i + 1, k = 0; while (j < n && b[j] != '\n' && b[j] != ' ' && b[j] != '\t' && k < 255) c->name[k++] = (char)b[j++];
     while (j < n && b[j] != '\n') j++;
     c->seq = (char*)malloc(n - j + 1); size_t l = 0;
-    for (j++; j < n && b[j] != '>'; j++) if (b[j] != '\n' && b[j] != '\r') { char ch = (char)b[j]; if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32); c->seq[l++] = ch; }
+    for (j++; j < n && b[j] != '>'; j++) if (b[j] != '\n' && b[j] != '\r') { char ch = (char)b[j]; if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+      c->seq[l++] = ch; }
     c->len = l; i = j;
   }
   free(b); *n_out = nc; return cs;
@@ -108,16 +110,20 @@ int main(int argc, char** argv) {
   size_t o = 4; int32_t l_text; memcpy(&l_text, d + o, 4); o += 4 + (size_t)l_text;
   int32_t n_ref; memcpy(&n_ref, d + o, 4); o += 4;
   char (*names)[256] = calloc((size_t)n_ref, 256); uint32_t* lens = calloc((size_t)n_ref, 4);
-  for (int i = 0; i < n_ref; i++) { int32_t ln; memcpy(&ln, d + o, 4); o += 4; memcpy(names[i], d + o, (size_t)(ln < 255 ? ln : 255)); o += (size_t)ln; memcpy(&lens[i], d + o, 4); o += 4; }
+  for (int i = 0; i < n_ref; i++) { int32_t ln; memcpy(&ln, d + o, 4); o += 4; memcpy(names[i], d + o, (size_t)(ln < 255 ? ln : 255));
+    o += (size_t)ln; memcpy(&lens[i], d + o, 4); o += 4; }
   /* records: views + reference ends */
   size_t cap = 1024, nr = 0; mkp_record* recs = malloc(cap * sizeof(*recs)); int32_t* ends = malloc(cap * 4);
   while (o + 4 <= n) {
     int32_t bs; memcpy(&bs, d + o, 4); const uint8_t* r = d + o + 4; o += 4 + (size_t)bs;
     if (nr == cap) { cap *= 2; recs = realloc(recs, cap * sizeof(*recs)); ends = realloc(ends, cap * 4); }
     mkp_record v; memset(&v, 0, sizeof(v));
-    memcpy(&v.tid, r, 4); memcpy(&v.pos, r + 4, 4); v.l_qname = r[8]; uint16_t nc; memcpy(&nc, r + 12, 2); v.n_cigar = nc; memcpy(&v.flag, r + 14, 2); memcpy(&v.l_qseq, r + 16, 4);
+    memcpy(&v.tid, r, 4); memcpy(&v.pos, r + 4, 4); v.l_qname = r[8]; uint16_t nc; memcpy(&nc, r + 12, 2); v.n_cigar = nc; memcpy(&v.flag, r + 14, 2);
+      memcpy(&v.l_qseq, r + 16, 4);
     v.l_data = bs - 32; v.data = r + 32;
-    int64_t rl = 0; for (uint32_t k = 0; k < v.n_cigar; k++) { uint32_t w; memcpy(&w, v.data + v.l_qname + 4 * k, 4); uint32_t op = w & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4; }
+    int64_t rl = 0; for (uint32_t k = 0; k < v.n_cigar; k++) { uint32_t w; memcpy(&w, v.data + v.l_qname + 4 * k, 4); uint32_t op = w & 15;
+      if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += w >> 4;
+      }
     ends[nr] = v.pos + (int32_t)(rl > 0 ? rl : 1); recs[nr++] = v;
   }
   int n_contigs = 0; contig_t* fa = NULL; motif_t motifs[2]; int n_motifs = 0;
@@ -141,12 +147,15 @@ int main(int argc, char** argv) {
   mkp_record* batch = malloc(nr * sizeof(*batch) + sizeof(*batch));
   for (int tid = 0; tid < n_ref; tid++) {
     const char* seq = NULL;
-    if (n_motifs) { for (int c = 0; c < n_contigs; c++) if (strcmp(fa[c].name, names[tid]) == 0) { if (fa[c].len < lens[tid]) die("FASTA contig shorter than BAM header says"); seq = fa[c].seq; } if (!seq) die("contig missing from FASTA"); }
+    if (n_motifs) { for (int c = 0; c < n_contigs; c++) if (strcmp(fa[c].name, names[tid]) == 0) {
+        if (fa[c].len < lens[tid]) die("FASTA contig shorter than BAM header says");
+        seq = fa[c].seq; } if (!seq) die("contig missing from FASTA"); }
     while (first < nr && recs[first].tid >= 0 && recs[first].tid < tid) first++;
     size_t lo = first;
     if (file_seam && lens[tid] > 0) {
       mkp_shard sh; memset(&sh, 0, sizeof(sh)); sh.tid = tid; sh.start = 0; sh.end = lens[tid];
-      if (n_motifs) { build_focus(seq, 0, lens[tid], motifs, n_motifs, focus, &combos); sh.focus = focus; sh.combos = combos.c; sh.n_combos = combos.n; }
+      if (n_motifs) { build_focus(seq, 0, lens[tid], motifs, n_motifs, focus, &combos); sh.focus = focus; sh.combos = combos.c;
+        sh.n_combos = combos.n; }
       mkp_rows rows; memset(&rows, 0, sizeof(rows));
       double ta = now_s();
       if (mkp_process_region(ctx, argv[1], &sh, &rows) != MKP_OK) die(mkp_last_error(ctx));
@@ -154,10 +163,13 @@ int main(int argc, char** argv) {
       for (uint64_t i = 0; i < rows.n_rows; i++) {
         char name[64]; uint32_t code = rows.code_repr[i];
         int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
-        if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + k, sizeof(name) - (size_t)k, ",%s,%d", motifs[rows.motif_idx[i]].pat, motifs[rows.motif_idx[i]].off);
+        if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + k, sizeof(name) - (size_t)k, ",%s,%d", motifs[rows.motif_idx[i]].pat,
+            motifs[rows.motif_idx[i]].off);
         float frac = (float)rows.n_mod[i] / (float)rows.n_valid[i];
-        fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1, name, rows.n_valid[i], (char)rows.strand[i],
-                rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i], rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
+        fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1,
+            name, rows.n_valid[i], (char)rows.strand[i],
+                rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i],
+                    rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
       }
       total_rows += rows.n_rows;
       continue;
@@ -168,7 +180,8 @@ int main(int argc, char** argv) {
       for (; nb_iv < per_batch && s < lens[tid]; nb_iv++) {
         uint32_t e = s + interval < lens[tid] ? s + interval : lens[tid];
         memset(&ivs[nb_iv], 0, sizeof(ivs[nb_iv])); ivs[nb_iv].tid = tid; ivs[nb_iv].start = s; ivs[nb_iv].end = e;
-        if (n_motifs) { build_focus(seq, s, e, motifs, n_motifs, focus + (size_t)nb_iv * interval, &combos); ivs[nb_iv].focus = focus + (size_t)nb_iv * interval; ivs[nb_iv].combos = combos.c; }
+        if (n_motifs) { build_focus(seq, s, e, motifs, n_motifs, focus + (size_t)nb_iv * interval, &combos);
+          ivs[nb_iv].focus = focus + (size_t)nb_iv * interval; ivs[nb_iv].combos = combos.c; }
         s = e;
       }
       for (uint32_t k = 0; k < nb_iv; k++) if (n_motifs) ivs[k].n_combos = combos.n;   /* one table for the batch */
@@ -184,10 +197,13 @@ int main(int argc, char** argv) {
         for (uint64_t i = 0; i < rows.n_rows; i++) {
           char name[64]; uint32_t code = rows.code_repr[i];
           int kk = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
-          if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + kk, sizeof(name) - (size_t)kk, ",%s,%d", motifs[rows.motif_idx[i]].pat, motifs[rows.motif_idx[i]].off);
+          if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + kk, sizeof(name) - (size_t)kk, ",%s,%d", motifs[rows.motif_idx[i]].pat,
+              motifs[rows.motif_idx[i]].off);
           float frac = (float)rows.n_mod[i] / (float)rows.n_valid[i];
-          fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1, name, rows.n_valid[i], (char)rows.strand[i],
-                  rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i], rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
+          fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1,
+              name, rows.n_valid[i], (char)rows.strand[i],
+                  rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i],
+                      rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
         }
         total_rows += rows.n_rows;
       }
@@ -210,17 +226,21 @@ int main(int argc, char** argv) {
       for (uint64_t i = 0; i < rows.n_rows; i++) {
         char name[64]; uint32_t code = rows.code_repr[i];
         int k = (code & 0x80000000u) ? snprintf(name, sizeof(name), "%u", code & 0x7fffffffu) : snprintf(name, sizeof(name), "%c", (char)code);
-        if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + k, sizeof(name) - (size_t)k, ",%s,%d", motifs[rows.motif_idx[i]].pat, motifs[rows.motif_idx[i]].off);
+        if (n_motifs >= 2 && rows.motif_idx[i] >= 0) snprintf(name + k, sizeof(name) - (size_t)k, ",%s,%d", motifs[rows.motif_idx[i]].pat,
+            motifs[rows.motif_idx[i]].off);
         float frac = (float)rows.n_mod[i] / (float)rows.n_valid[i];
-        fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1, name, rows.n_valid[i], (char)rows.strand[i],
-                rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i], rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
+        fprintf(out, "%s\t%u\t%u\t%s\t%u\t%c\t%u\t%u\t255,0,0\t%u\t%.2f\t%u\t%u\t%u\t%u\t%u\t%u\t%u\n", names[tid], rows.pos[i], rows.pos[i] + 1,
+            name, rows.n_valid[i], (char)rows.strand[i],
+                rows.pos[i], rows.pos[i] + 1, rows.n_valid[i], (double)(frac * 100.0f), rows.n_mod[i], rows.n_canonical[i], rows.n_other[i],
+                    rows.n_delete[i], rows.n_fail[i], rows.n_diff[i], rows.n_nocall[i]);
       }
       total_rows += rows.n_rows;
     }
   }
   fclose(out);
   double wall = now_s() - t0;
-  fprintf(stderr, "[abi_client] per_batch=%u intervals=%llu rows=%llu api_s=%.3f wall_s=%.3f rows_per_s_api=%.0f\n", per_batch, (unsigned long long)n_calls, (unsigned long long)total_rows, t_api, wall, t_api > 0 ? (double)total_rows / t_api : 0.0);
+  fprintf(stderr, "[abi_client] per_batch=%u intervals=%llu rows=%llu api_s=%.3f wall_s=%.3f rows_per_s_api=%.0f\n", per_batch,
+      (unsigned long long)n_calls, (unsigned long long)total_rows, t_api, wall, t_api > 0 ? (double)total_rows / t_api : 0.0);
   mkp_ctx_destroy(ctx);
   return 0;
 }

@@ -40,7 +40,8 @@ int build(const uint8_t* lens, int n, uint16_t* tab, uint32_t tab_bits, uint16_t
   for (int s = 0; s < n; s++) if (lens[s]) count[lens[s]]++;
   uint32_t next_code[16], offs[16]; int left = 1; uint32_t code = 0, off = 0, used = 0;
   next_code[0] = 0; offs[0] = 0;
-  for (int l = 1; l <= 15; l++) { const uint32_t c = count[l]; left = left * 2 - (int)c; code = (code + (l > 1 ? count[l - 1] : 0u)) << 1; next_code[l] = code; offs[l] = off; off += c; used += c; }
+  for (int l = 1; l <= 15; l++) { const uint32_t c = count[l]; left = left * 2 - (int)c; code = (code + (l > 1 ? count[l - 1] : 0u)) << 1;
+    next_code[l] = code; offs[l] = off; off += c; used += c; }
   if (left < 0) return left;
   if (used == 0) return 0;
   for (int s = 0; s < n; s++) {
@@ -60,7 +61,8 @@ uint32_t cl_order(int i) { static const uint8_t o[19] = {16, 17, 18, 0, 8, 7, 9,
 struct In2 {
   const uint8_t* p; uint32_t n, lo; uint32_t pf[W]; uint32_t* w;
   uint64_t refills = 0, seeks = 0;
-  uint32_t load_word(uint32_t off) const { uint32_t v = 0; for (uint32_t k = 0; k < 4u; k++) if (off + k < n) v |= (uint32_t)p[off + k] << (8u * k); return v; }
+  uint32_t load_word(uint32_t off) const { uint32_t v = 0; for (uint32_t k = 0; k < 4u; k++) if (off + k < n) v |= (uint32_t)p[off + k] << (8u * k);
+    return v; }
   void seek(uint32_t byte) {
     lo = byte & ~255u; seeks++;
     for (uint32_t k = 0; k < INW / 64u; k++) for (uint32_t lane = 0; lane < W; lane++) w[(((lo >> 2) + 64u * k) + lane) & (INW - 1u)] = load_word(lo + 256u * k + 4u * lane);
@@ -86,7 +88,8 @@ struct In2 {
 struct Hdr {
   unsigned long long cb; uint32_t cpos;
   void load(In2& in, uint32_t pos) { in.ensure(pos); cb = in.peek(pos); cpos = pos; }
-  uint32_t get(In2& in, uint32_t& pos, uint32_t k) { if (pos + k > cpos + 64u) load(in, pos); const uint32_t v = (uint32_t)(cb >> (pos - cpos)) & ((1u << k) - 1u); pos += k; return v; }
+  uint32_t get(In2& in, uint32_t& pos, uint32_t k) { if (pos + k > cpos + 64u) load(in, pos);
+    const uint32_t v = (uint32_t)(cb >> (pos - cpos)) & ((1u << k) - 1u); pos += k; return v; }
   uint32_t peek16(In2& in, uint32_t pos) { if (pos + 16u > cpos + 64u) load(in, pos); return (uint32_t)(cb >> (pos - cpos)) & 0xffffu; }
 };
 int canon_sym(uint32_t bits, const uint16_t* count, const uint16_t* syms, uint32_t* l) {
@@ -126,7 +129,8 @@ OneTok one_token(const In2& in, const Lds& L, uint32_t q) {
   return r;
 }
 
-struct Stats { uint64_t far_reads = 0, far_passes = 0, out_passes = 0, out_bytes = 0, passes = 0, tokens = 0, slow = 0, slow_eob = 0, slow_lit = 0, slow_match = 0, slow_long = 0, slow_direct = 0, cut_full = 0, cut_other = 0, jump_passes = 0, jump_rounds = 0, refills = 0, seeks = 0; } g_stats;
+struct Stats { uint64_t far_reads = 0, far_passes = 0, out_passes = 0, out_bytes = 0, passes = 0, tokens = 0, slow = 0, slow_eob = 0, slow_lit = 0,
+    slow_match = 0, slow_long = 0, slow_direct = 0, cut_full = 0, cut_other = 0, jump_passes = 0, jump_rounds = 0, refills = 0, seeks = 0; } g_stats;
 
 // the kernel, one block; returns the status, fills `out` (cap bytes)
 uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t cap) {
@@ -204,7 +208,8 @@ uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
         MkpTok4 t[W];
         for (uint32_t lane = 0; lane < W; lane++) {
           const uint32_t b0 = 4u * ((pos + lane) >> 5);   // the window must hold what is read: bytes [4 * (q >> 5), + 12)
-          if (b0 < in.lo || b0 + 12u > in.lo + 4u * INW) { fprintf(stderr, "window miss: byte %u, window [%u, %u)\n", b0, in.lo, in.lo + 4u * INW); exit(3); }
+          if (b0 < in.lo || b0 + 12u > in.lo + 4u * INW) { fprintf(stderr, "window miss: byte %u, window [%u, %u)\n", b0, in.lo, in.lo + 4u * INW);
+            exit(3); }
           uint32_t lo, hi; mkp_tok_window2(L.inw, pos + lane, &lo, &hi);
           t[lane] = mkp_tok_decode4(lo, hi, L.lit, L.dist);
         }
@@ -216,20 +221,23 @@ uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
         if (i >= MKP_NX_STOP) { i = 63u - (uint32_t)__builtin_clzll(chain); chain &= ~(1ull << i); stop_nx = t[i].nx; }
         // prefix sum of the output lengths over the chain
         uint32_t ol[W], incl[W], excl[W]; uint32_t run = 0;
-        for (uint32_t lane = 0; lane < W; lane++) { ol[lane] = ((chain >> lane) & 1ull) ? t[lane].ol : 0u; run += ol[lane]; incl[lane] = run; excl[lane] = run - ol[lane]; }
+        for (uint32_t lane = 0; lane < W; lane++) { ol[lane] = ((chain >> lane) & 1ull) ? t[lane].ol : 0u; run += ol[lane]; incl[lane] = run;
+          excl[lane] = run - ol[lane]; }
         unsigned long long rej = 0; bool rej_full = false;
         for (uint32_t lane = 0; lane < W; lane++) {
           const bool ok = incl[lane] <= 64u && w + incl[lane] <= cap && ((t[lane].desc & LITERAL) || t[lane].desc <= w + excl[lane]);
           if (((chain >> lane) & 1ull) && !ok) { if (!rej) rej_full = incl[lane] > 64u; rej |= 1ull << lane; }
         }
         unsigned long long acc = chain; uint32_t adv = i, n_out; bool special;
-        if (rej) { const uint32_t first = (uint32_t)__builtin_ctzll(rej); acc = chain & ((1ull << first) - 1ull); adv = first; n_out = excl[first]; special = first == 0u; if (rej_full) g_stats.cut_full++; else g_stats.cut_other++; }
+        if (rej) { const uint32_t first = (uint32_t)__builtin_ctzll(rej); acc = chain & ((1ull << first) - 1ull); adv = first; n_out = excl[first];
+          special = first == 0u; if (rej_full) g_stats.cut_full++; else g_stats.cut_other++; }
         else { n_out = incl[63]; special = i < 64u; }
         g_stats.tokens += (uint64_t)__builtin_popcountll(acc);
         if (n_out) {
           g_stats.out_passes++; g_stats.out_bytes += n_out;
           for (uint32_t lane = 0; lane < W; lane++) L.hd[lane] = 0;
-          for (uint32_t lane = 0; lane < W; lane++) if ((acc >> lane) & 1ull) { if (L.hd[excl[lane]]) { fprintf(stderr, "head slot %u taken twice\n", excl[lane]); exit(3); } L.hd[excl[lane]] = t[lane].desc; }
+          for (uint32_t lane = 0; lane < W; lane++) if ((acc >> lane) & 1ull) { if (L.hd[excl[lane]]) {
+              fprintf(stderr, "head slot %u taken twice\n", excl[lane]); exit(3); } L.hd[excl[lane]] = t[lane].desc; }
           unsigned long long heads = 0; for (uint32_t lane = 0; lane < W; lane++) if (L.hd[lane]) heads |= 1ull << lane;
           if (!(heads & 1ull)) { fprintf(stderr, "no head at lane 0\n"); exit(3); }
           uint32_t sv[W];
@@ -255,7 +263,8 @@ uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
           for (uint32_t lane = 0; lane < n_out; lane++) {
             if ((sv[lane] & (LITERAL | MKP_SV_FAR)) == MKP_SV_FAR) { r[lane] = far_byte(sv[lane] & 0xfffffu); anyfar = true; }
             else if (!(sv[lane] & LITERAL)) {   // a ring read: the position it names must be a byte already written and not yet overwritten
-              // the lane knows the ring index only; what it stands for is w + lane - dist of its token, checked through the result below (zlib comparison)
+              // the lane knows the ring index only; what it stands for is w + lane - dist of its token, checked through the result below (zlib
+              // comparison)
             }
           }
           if (anyfar) g_stats.far_passes++;
@@ -269,7 +278,8 @@ uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
           if (!rej && (stop_nx & (MKP_NX_STOP - 1u))) {
             k.err = 0; k.kind = MKP_TK_MATCH; k.bits = stop_nx & (MKP_NX_STOP - 1u); k.val = t[adv].ol; k.dist = t[adv].desc; g_stats.slow_direct++;
             const OneTok chk = one_token(in, L, pos);   // (the lane's answer must be the wave's)
-            if (chk.err || chk.kind != k.kind || chk.bits != k.bits || chk.val != k.val || chk.dist != k.dist) { fprintf(stderr, "lane-decoded long match differs from one_token\n"); exit(3); }
+            if (chk.err || chk.kind != k.kind || chk.bits != k.bits || chk.val != k.val || chk.dist != k.dist) {
+              fprintf(stderr, "lane-decoded long match differs from one_token\n"); exit(3); }
           } else k = one_token(in, L, pos);
           if (k.err) { err = k.err; break; }
           pos += k.bits;
@@ -287,10 +297,12 @@ uint32_t wave4_block(const uint8_t* inp, uint32_t in_len, uint8_t* o, uint32_t c
             for (uint32_t k0 = 0; k0 < len; k0 += 64u) {   // lanes in steps of 64: all loads of a step before its stores
               uint8_t v[W];
               for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) {
-                uint32_t r = (k2 - k0) % dist; const uint32_t step = 64u % dist;   // the kernel's walk of the source cycle: lane mod dist, then steps of 64 mod dist
+                // the kernel's walk of the source cycle: lane mod dist, then steps of 64 mod dist
+                uint32_t r = (k2 - k0) % dist; const uint32_t step = 64u % dist;
                 for (uint32_t q = 0; q < k0; q += 64u) { r += step; r -= r >= dist ? dist : 0u; }
                 if (r != k2 % dist) { fprintf(stderr, "cycle walk off\n"); exit(3); }
-                v[k2 - k0] = (FARM && dist > NEAR) ? (uint8_t)far_byte(src0 + k2) : dist >= len ? L.ring[(src0 + k2) & M] : dist == 1u ? L.ring[src0 & M] : L.ring[(src0 + r) & M];
+                v[k2 - k0] = (FARM && dist > NEAR) ? (uint8_t)far_byte(src0 + k2) : dist >= len ? L.ring[(src0 + k2) & M] : dist == 1u
+                    ? L.ring[src0 & M] : L.ring[(src0 + r) & M];
               }
               for (uint32_t k2 = k0; k2 < k0 + 64u && k2 < len; k2++) L.ring[(w + k2) & M] = v[k2 - k0];
             }
@@ -338,7 +350,8 @@ std::vector<uint8_t> slurp(const char* path) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (getenv("RING")) { RING = (uint32_t)atoi(getenv("RING")); FARM = RING < 32768u; if (RING < 1024u || RING > RING_MAX || (RING & (RING - 1u))) { fprintf(stderr, "RING must be a power of two in [1024, 32768]\n"); return 2; } }
+  if (getenv("RING")) { RING = (uint32_t)atoi(getenv("RING")); FARM = RING < 32768u; if (RING < 1024u || RING > RING_MAX || (RING & (RING - 1u))) {
+      fprintf(stderr, "RING must be a power of two in [1024, 32768]\n"); return 2; } }
   if (argc < 3) { fprintf(stderr, "usage: inflate_wave4_emul bgzf FILE... | corpus FILE\n"); return 2; }
   const std::string mode = argv[1];
   uint64_t blocks = 0, bytes = 0, accepted = 0, rejected = 0;
@@ -346,7 +359,10 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> a(cap + 64, 0xAA), b(cap + 64, 0xBB);
     const uint32_t st = wave4_block(inp, in_len, a.data(), cap);
     const int zr = zlib_block(inp, in_len, b.data(), cap);
-    if ((st == 0) != (zr == 0)) { fprintf(stderr, "%s @%llu: kernel status %u, zlib %s (in %u bytes, out %u)\n", what, (unsigned long long)at, st, zr == 0 ? "accepts" : "rejects", in_len, cap); exit(1); }
+    if ((st == 0) != (zr == 0)) {
+      fprintf(stderr, "%s @%llu: kernel status %u, zlib %s (in %u bytes, out %u)\n", what, (unsigned long long)at, st,
+          zr == 0 ? "accepts" : "rejects", in_len, cap);
+      exit(1); }
     if (st == 0 && memcmp(a.data(), b.data(), cap) != 0) {
       uint32_t k = 0; while (k < cap && a[k] == b[k]) k++;
       fprintf(stderr, "%s @%llu: output differs at byte %u of %u\n", what, (unsigned long long)at, k, cap); exit(1);
@@ -360,7 +376,9 @@ int main(int argc, char** argv) {
       while (off + 18 <= d.size()) {
         if (d[off] != 0x1f || d[off + 1] != 0x8b) { fprintf(stderr, "%s: not BGZF at %zu\n", argv[f], off); return 2; }
         const uint32_t xlen = d[off + 10] | (d[off + 11] << 8);
-        uint32_t bsize = 0; for (uint32_t x = 0; x + 4 <= xlen;) { const uint8_t* e = &d[off + 12 + x]; const uint32_t sl = e[2] | (e[3] << 8); if (e[0] == 'B' && e[1] == 'C') bsize = (e[4] | (e[5] << 8)) + 1u; x += 4 + sl; }
+        uint32_t bsize = 0; for (uint32_t x = 0; x + 4 <= xlen;) { const uint8_t* e = &d[off + 12 + x]; const uint32_t sl = e[2] | (e[3] << 8);
+          if (e[0] == 'B' && e[1] == 'C') bsize = (e[4] | (e[5] << 8)) + 1u;
+          x += 4 + sl; }
         if (!bsize || off + bsize > d.size()) { fprintf(stderr, "%s: bad block at %zu\n", argv[f], off); return 2; }
         const uint32_t hdr = 12 + xlen, clen = bsize - hdr - 8;
         uint32_t isize; memcpy(&isize, &d[off + bsize - 4], 4);
@@ -378,11 +396,17 @@ int main(int argc, char** argv) {
       off += in_len;
     }
   } else return 2;
-  printf("ok %llu %llu %llu %llu\n", (unsigned long long)blocks, (unsigned long long)bytes, (unsigned long long)accepted, (unsigned long long)rejected);
-  fprintf(stderr, "ring %u: far reads %llu in %llu passes; passes %llu (%.2f tokens, %.1f bytes each; %llu with output) cut by the 64-byte limit %llu, by size / distance %llu; in-pass jumps in %llu passes (%.2f rounds); special %llu (eob %llu lit %llu match %llu of which > 64 bytes %llu, lane-decoded %llu) refills %llu seeks %llu\n",
-          RING, (unsigned long long)g_stats.far_reads, (unsigned long long)g_stats.far_passes, (unsigned long long)g_stats.passes, g_stats.passes ? (double)g_stats.tokens / (double)g_stats.passes : 0.0,
-          g_stats.passes ? (double)g_stats.out_bytes / (double)g_stats.passes : 0.0, (unsigned long long)g_stats.out_passes, (unsigned long long)g_stats.cut_full, (unsigned long long)g_stats.cut_other,
-          (unsigned long long)g_stats.jump_passes, g_stats.jump_passes ? (double)g_stats.jump_rounds / (double)g_stats.jump_passes : 0.0, (unsigned long long)g_stats.slow, (unsigned long long)g_stats.slow_eob,
-          (unsigned long long)g_stats.slow_lit, (unsigned long long)g_stats.slow_match, (unsigned long long)g_stats.slow_long, (unsigned long long)g_stats.slow_direct, (unsigned long long)g_stats.refills, (unsigned long long)g_stats.seeks);
+  printf("ok %llu %llu %llu %llu\n", (unsigned long long)blocks, (unsigned long long)bytes, (unsigned long long)accepted,
+      (unsigned long long)rejected);
+  fprintf(stderr,
+      "ring %u: far reads %llu in %llu passes; passes %llu (%.2f tokens, %.1f bytes each; %llu with output) cut by the 64-byte limit %llu, by size / distance %llu; in-pass jumps in %llu passes (%.2f rounds); special %llu (eob %llu lit %llu match %llu of which > 64 bytes %llu, lane-decoded %llu) refills %llu seeks %llu\n",
+          RING, (unsigned long long)g_stats.far_reads, (unsigned long long)g_stats.far_passes, (unsigned long long)g_stats.passes,
+              g_stats.passes ? (double)g_stats.tokens / (double)g_stats.passes : 0.0,
+          g_stats.passes ? (double)g_stats.out_bytes / (double)g_stats.passes : 0.0, (unsigned long long)g_stats.out_passes,
+              (unsigned long long)g_stats.cut_full, (unsigned long long)g_stats.cut_other,
+          (unsigned long long)g_stats.jump_passes, g_stats.jump_passes ? (double)g_stats.jump_rounds / (double)g_stats.jump_passes : 0.0,
+              (unsigned long long)g_stats.slow, (unsigned long long)g_stats.slow_eob,
+          (unsigned long long)g_stats.slow_lit, (unsigned long long)g_stats.slow_match, (unsigned long long)g_stats.slow_long,
+              (unsigned long long)g_stats.slow_direct, (unsigned long long)g_stats.refills, (unsigned long long)g_stats.seeks);
   return 0;
 }

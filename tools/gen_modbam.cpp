@@ -33,14 +33,17 @@
 struct Rng {
   uint64_t s;
   explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
-  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
   double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
   uint32_t below(uint32_t n) { return (uint32_t)(uni() * n); }
   double normal() { double u = uni(), v = uni(); if (u < 1e-300) u = 1e-300; return std::sqrt(-2.0 * std::log(u)) * std::cos(6.283185307179586 * v); }
   double gamma(double a) {  // Marsaglia-Tsang
     if (a < 1.0) { double u = uni(); if (u < 1e-300) u = 1e-300; return gamma(a + 1.0) * std::pow(u, 1.0 / a); }
     double d = a - 1.0 / 3.0, c = 1.0 / std::sqrt(9.0 * d);
-    for (;;) { double x = normal(), v = 1.0 + c * x; if (v <= 0) continue; v = v * v * v; double u = uni(); if (u < 1e-300) u = 1e-300; if (std::log(u) < 0.5 * x * x + d - d * v + d * std::log(v)) return d * v; }
+    for (;;) { double x = normal(), v = 1.0 + c * x; if (v <= 0) continue; v = v * v * v; double u = uni(); if (u < 1e-300) u = 1e-300;
+      if (std::log(u) < 0.5 * x * x + d - d * v + d * std::log(v)) return d * v;
+      }
   }
 };
 
@@ -48,9 +51,12 @@ static const char ACGT[4] = {'A', 'C', 'G', 'T'};
 static inline char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
 static inline uint8_t nib(char c) { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; }
 
-struct Out { std::vector<uint8_t> d; void put(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; d.insert(d.end(), b, b + n); } void i32(int32_t v) { put(&v, 4); } void u32(uint32_t v) { put(&v, 4); } void u16(uint16_t v) { put(&v, 2); } void u8(uint8_t v) { d.push_back(v); } };
+struct Out { std::vector<uint8_t> d; void put(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; d.insert(d.end(), b, b + n);
+  } void i32(int32_t v) { put(&v, 4); } void u32(uint32_t v) { put(&v, 4); } void u16(uint16_t v) { put(&v, 2); } void u8(uint8_t v) {
+    d.push_back(v); } };
 
-static double site_beta(uint64_t seed, uint32_t tid, uint32_t pos) { Rng r(seed ^ ((uint64_t)tid << 40) ^ pos); double x = r.gamma(0.3), y = r.gamma(0.3); return x / (x + y); }
+static double site_beta(uint64_t seed, uint32_t tid, uint32_t pos) { Rng r(seed ^ ((uint64_t)tid << 40) ^ pos);
+  double x = r.gamma(0.3), y = r.gamma(0.3); return x / (x + y); }
 
 template <class F> static void parallel_for(size_t n, unsigned threads, F f) {
   std::atomic<size_t> next{0};
@@ -66,7 +72,8 @@ struct Stream {
   uint64_t size() const { return start.back(); }
   void gather(uint64_t off, size_t len, uint8_t* dst) const {
     size_t i = (size_t)(std::upper_bound(start.begin(), start.end(), off) - start.begin()) - 1;
-    while (len) { const size_t o = (size_t)(off - start[i]), n = std::min(len, pieces[i]->size() - o); memcpy(dst, pieces[i]->data() + o, n); dst += n; off += n; len -= n; i++; }
+    while (len) { const size_t o = (size_t)(off - start[i]), n = std::min(len, pieces[i]->size() - o); memcpy(dst, pieces[i]->data() + o, n);
+      dst += n; off += n; len -= n; i++; }
   }
 };
 static const size_t BGZF_BS = 0xff00;
@@ -108,15 +115,22 @@ static inline uint32_t reg2bin(int64_t beg, int64_t end) {  // SAM spec 5.3
 struct RecIdx { int32_t tid; uint32_t pos, end; uint16_t flag; uint64_t off; uint32_t size; };  // off/size: block_size field included
 
 int main(int argc, char** argv) {
-  std::string out = "synth", style = "m", ptag; uint32_t ptag_k = 0; std::vector<std::pair<std::string, uint32_t>> contigs; uint64_t n_reads = 1000, seed = 1; double mean_len = 4000, sigma = 0.6; uint32_t min_len = 500, max_len = 50000;
+  std::string out = "synth", style = "m", ptag; uint32_t ptag_k = 0; std::vector<std::pair<std::string, uint32_t>> contigs;
+    uint64_t n_reads = 1000, seed = 1; double mean_len = 4000, sigma = 0.6; uint32_t min_len = 500, max_len = 50000;
   bool depleted = false; unsigned threads = std::max(1u, std::thread::hardware_concurrency());
   for (int i = 1; i < argc; i++) {
-    std::string a = argv[i]; auto val = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return std::string(argv[++i]); };
-    if (a == "--out") out = val(); else if (a == "--contig") { std::string v = val(); size_t c = v.find(':'); contigs.push_back({v.substr(0, c), (uint32_t)strtoul(v.c_str() + c + 1, nullptr, 10)}); }
-    else if (a == "--reads") n_reads = strtoull(val().c_str(), nullptr, 10); else if (a == "--seed") seed = strtoull(val().c_str(), nullptr, 10); else if (a == "--style") style = val();
-    else if (a == "--mean-len") mean_len = atof(val().c_str()); else if (a == "--sigma") sigma = atof(val().c_str()); else if (a == "--min-len") min_len = (uint32_t)atoi(val().c_str()); else if (a == "--max-len") max_len = (uint32_t)atoi(val().c_str());
+    std::string a = argv[i]; auto val = [&]() { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2);
+      } return std::string(argv[++i]); };
+    if (a == "--out") out = val(); else if (a == "--contig") { std::string v = val(); size_t c = v.find(':');
+      contigs.push_back({v.substr(0, c), (uint32_t)strtoul(v.c_str() + c + 1, nullptr, 10)}); }
+    else if (a == "--reads") n_reads = strtoull(val().c_str(), nullptr, 10); else if (a == "--seed") seed = strtoull(val().c_str(), nullptr, 10);
+      else if (a == "--style") style = val();
+    else if (a == "--mean-len") mean_len = atof(val().c_str()); else if (a == "--sigma") sigma = atof(val().c_str());
+      else if (a == "--min-len") min_len = (uint32_t)atoi(val().c_str());
+      else if (a == "--max-len") max_len = (uint32_t)atoi(val().c_str());
     else if (a == "--cpg-depleted") depleted = true; else if (a == "--threads") threads = (unsigned)atoi(val().c_str());
-    else if (a == "--partition-tag") { std::string v = val(); size_t c = v.find(':'); if (c != 2) { fprintf(stderr, "--partition-tag wants XX:K\n"); return 2; } ptag = v.substr(0, 2); ptag_k = (uint32_t)atoi(v.c_str() + 3); }
+    else if (a == "--partition-tag") { std::string v = val(); size_t c = v.find(':'); if (c != 2) { fprintf(stderr, "--partition-tag wants XX:K\n");
+        return 2; } ptag = v.substr(0, 2); ptag_k = (uint32_t)atoi(v.c_str() + 3); }
     else { fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (contigs.empty()) contigs.push_back({"synth5m", 5000000});
@@ -133,13 +147,16 @@ int main(int argc, char** argv) {
     refs[t] = std::move(s);
   });
   { FILE* fa = fopen((out + ".fa").c_str(), "w"), *fai = fopen((out + ".fa.fai").c_str(), "w"); uint64_t off = 0; std::string line;
-    for (size_t t = 0; t < contigs.size(); t++) { off += (uint64_t)fprintf(fa, ">%s\n", contigs[t].first.c_str()); fprintf(fai, "%s\t%u\t%llu\t60\t61\n", contigs[t].first.c_str(), contigs[t].second, (unsigned long long)off);
+    for (size_t t = 0; t < contigs.size(); t++) { off += (uint64_t)fprintf(fa, ">%s\n", contigs[t].first.c_str());
+      fprintf(fai, "%s\t%u\t%llu\t60\t61\n", contigs[t].first.c_str(), contigs[t].second, (unsigned long long)off);
       std::string buf; buf.reserve((size_t)contigs[t].second + contigs[t].second / 60 + 2);
-      for (uint32_t i = 0; i < contigs[t].second; i += 60) { uint32_t n = std::min(60u, contigs[t].second - i); buf.append(&refs[t][i], n); buf.push_back('\n'); off += n + 1; }
+      for (uint32_t i = 0; i < contigs[t].second; i += 60) { uint32_t n = std::min(60u, contigs[t].second - i); buf.append(&refs[t][i], n);
+        buf.push_back('\n'); off += n + 1; }
       fwrite(buf.data(), 1, buf.size(), fa); }
     fclose(fa); fclose(fai); }
   // ---- BAM header
-  Out hdr; std::string text = "@HD\tVN:1.6\tSO:coordinate\n"; for (auto& c : contigs) text += "@SQ\tSN:" + c.first + "\tLN:" + std::to_string(c.second) + "\n";
+  Out hdr; std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+    for (auto& c : contigs) text += "@SQ\tSN:" + c.first + "\tLN:" + std::to_string(c.second) + "\n";
   hdr.put("BAM\1", 4); hdr.i32((int32_t)text.size()); hdr.put(text.data(), text.size()); hdr.i32((int32_t)contigs.size());
   for (auto& c : contigs) { hdr.i32((int32_t)c.first.size() + 1); hdr.put(c.first.c_str(), c.first.size() + 1); hdr.i32((int32_t)c.second); }
   // ---- read plans (sequential generator: cheap), coordinate sorted per contig
@@ -147,53 +164,74 @@ int main(int argc, char** argv) {
   std::vector<Plan> plan;
   { Rng r(seed + 1);
     for (size_t tid = 0; tid < contigs.size(); tid++) {
-      const uint32_t G = contigs[tid].second; const uint64_t n_here = (uint64_t)((double)n_reads * G / (double)total_len + 0.5); const size_t at = plan.size();
-      for (uint64_t k = 0; k < n_here; k++) { double l = std::exp(std::log(mean_len) + sigma * r.normal()); uint32_t L = (uint32_t)std::min<double>(std::max<double>(std::floor(l + 0.5), min_len), max_len); if (L + 2 > G) L = G > 2 ? G - 2 : 1; plan.push_back({(uint32_t)tid, r.below(G - L), L}); }
+      const uint32_t G = contigs[tid].second; const uint64_t n_here = (uint64_t)((double)n_reads * G / (double)total_len + 0.5);
+        const size_t at = plan.size();
+      for (uint64_t k = 0; k < n_here; k++) { double l = std::exp(std::log(mean_len) + sigma * r.normal());
+        uint32_t L = (uint32_t)std::min<double>(std::max<double>(std::floor(l + 0.5), min_len), max_len); if (L + 2 > G) L = G > 2 ? G - 2 : 1;
+        plan.push_back({(uint32_t)tid, r.below(G - L), L}); }
       std::stable_sort(plan.begin() + (std::ptrdiff_t)at, plan.end(), [](const Plan& a, const Plan& b) { return a.start < b.start; });
     } }
   // ---- reads, in blocks of 128 built in parallel; every read has its own generator
   const size_t RB = 128, nblocks = (plan.size() + RB - 1) / RB; const uint64_t beta_seed = seed + 2;
-  std::vector<Out> blk(nblocks); std::vector<std::vector<RecIdx>> blk_idx(nblocks); std::vector<uint64_t> blk_aligned(nblocks, 0), blk_calls(nblocks, 0);
+  std::vector<Out> blk(nblocks); std::vector<std::vector<RecIdx>> blk_idx(nblocks);
+    std::vector<uint64_t> blk_aligned(nblocks, 0), blk_calls(nblocks, 0);
   std::atomic<bool> bad{false};
   parallel_for(nblocks, threads, [&](size_t bi) {
-    Out& bam = blk[bi]; std::vector<uint32_t> cigar; std::string seq, fwd; std::vector<uint32_t> qref;  // qref: reference position of each query base or ~0
+    // qref: reference position of each query base or ~0
+    Out& bam = blk[bi]; std::vector<uint32_t> cigar; std::string seq, fwd; std::vector<uint32_t> qref;
     for (size_t rid = bi * RB; rid < std::min(plan.size(), (bi + 1) * RB); rid++) {
       const Plan& pl = plan[rid]; const std::string& ref = refs[pl.tid]; const uint32_t tid = pl.tid;
       Rng r((seed + 7) * 0x2545F4914F6CDD1Dull + rid);
       cigar.clear(); seq.clear(); qref.clear();
-      auto push = [&](uint32_t n, uint32_t op) { if (!n) return; if (!cigar.empty() && (cigar.back() & 15) == op) cigar.back() += n << 4; else cigar.push_back((n << 4) | op); };
+      auto push = [&](uint32_t n, uint32_t op) { if (!n) return; if (!cigar.empty() && (cigar.back() & 15) == op) cigar.back() += n << 4;
+        else cigar.push_back((n << 4) | op);
+        };
       uint32_t sc = r.below(51); push(sc, 4); for (uint32_t i = 0; i < sc; i++) { seq.push_back(ACGT[r.below(4)]); qref.push_back(~0u); }
       uint32_t p = pl.start, end = pl.start + pl.len; bool first = true;
       while (p < end) {
         double x = first ? 1.0 : r.uni(); first = false;
-        if (x < 0.015) { uint32_t n = 1; while (r.uni() < 1.0 / 3.0) n++; push(n, 1); for (uint32_t i = 0; i < n; i++) { seq.push_back(ACGT[r.below(4)]); qref.push_back(~0u); } }
-        else if (x < 0.03) { uint32_t n = 1; while (r.uni() < 1.0 / 3.0) n++; if (p + n >= end) n = 1; if (p + n < end) { push(n, 2); p += n; } else { push(1, 0); seq.push_back(ref[p]); qref.push_back(p); p++; } }
+        if (x < 0.015) { uint32_t n = 1; while (r.uni() < 1.0 / 3.0) n++; push(n, 1); for (uint32_t i = 0; i < n; i++) {
+            seq.push_back(ACGT[r.below(4)]); qref.push_back(~0u); } }
+        else if (x < 0.03) { uint32_t n = 1; while (r.uni() < 1.0 / 3.0) n++; if (p + n >= end) n = 1; if (p + n < end) { push(n, 2); p += n; } else {
+            push(1, 0); seq.push_back(ref[p]); qref.push_back(p); p++; } }
         else if (x < 0.05) { char b = ACGT[r.below(4)]; if (b == ref[p]) b = comp(b); push(1, 0); seq.push_back(b); qref.push_back(p); p++; }
         else { push(1, 0); seq.push_back(ref[p]); qref.push_back(p); p++; }
       }
-      while (!cigar.empty() && (cigar.back() & 15) == 1) { uint32_t n = cigar.back() >> 4; cigar.pop_back(); seq.resize(seq.size() - n); qref.resize(qref.size() - n); }
+      while (!cigar.empty() && (cigar.back() & 15) == 1) { uint32_t n = cigar.back() >> 4; cigar.pop_back(); seq.resize(seq.size() - n);
+        qref.resize(qref.size() - n); }
       uint32_t ec = r.below(51); push(ec, 4); for (uint32_t i = 0; i < ec; i++) { seq.push_back(ACGT[r.below(4)]); qref.push_back(~0u); }
       const bool rev = r.uni() < 0.5; const uint32_t L = (uint32_t)seq.size();
       uint16_t flag = rev ? 16 : 0; double fx = r.uni(); bool need_mn = false;
-      if (fx < 0.01) { flag |= 256; need_mn = true; } else if (fx < 0.02) flag |= 1024; else if (fx < 0.03) { flag |= 2048; need_mn = true; } else if (fx < 0.035) flag |= 512;
+      if (fx < 0.01) { flag |= 256; need_mn = true; } else if (fx < 0.02) flag |= 1024; else if (fx < 0.03) { flag |= 2048; need_mn = true;
+        } else if (fx < 0.035) flag |= 512;
       // as-sequenced read and its calls
       fwd.resize(L); for (uint32_t i = 0; i < L; i++) fwd[i] = rev ? comp(seq[L - 1 - i]) : seq[i];
-      auto site = [&](uint32_t f) -> double { uint32_t q = rev ? L - 1 - f : f; uint32_t rp = qref[q]; return rp == ~0u ? 0.5 : site_beta(beta_seed, tid, rev ? rp - 1 : rp); };
-      auto qual = [&](bool meth) -> uint8_t { if (r.uni() < 0.1) return (uint8_t)r.below(256); int v = (int)std::floor(std::fabs(r.normal() * 25.0)); if (v > 255) v = 255; return (uint8_t)(meth ? 255 - v : v); };
+      auto site = [&](uint32_t f) -> double { uint32_t q = rev ? L - 1 - f : f; uint32_t rp = qref[q];
+        return rp == ~0u ? 0.5 : site_beta(beta_seed, tid, rev ? rp - 1 : rp); };
+      auto qual = [&](bool meth) -> uint8_t { if (r.uni() < 0.1) return (uint8_t)r.below(256); int v = (int)std::floor(std::fabs(r.normal() * 25.0)); if (v > 255) v = 255; return (uint8_t)(meth
+          ? 255 - v : v); };
       std::string mm; std::vector<uint8_t> ml; char num[16];
-      std::vector<uint32_t> cpos; std::string deltas; { uint32_t skipped = 0; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'C') { if (f + 1 < L && fwd[f + 1] == 'G') { cpos.push_back(f); snprintf(num, sizeof(num), ",%u", skipped); deltas += num; skipped = 0; } else skipped++; } }
+      std::vector<uint32_t> cpos; std::string deltas; { uint32_t skipped = 0; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'C') {
+          if (f + 1 < L && fwd[f + 1] == 'G') { cpos.push_back(f);
+            snprintf(num, sizeof(num), ",%u", skipped); deltas += num; skipped = 0; } else skipped++; } }
       if (style == "duplex") {
         // duplex basecalls: the read's own strand as C+h / C+m at its CpG C's, the opposite strand as G-h / G-m at the G's of the same
         // CpGs; the two strands of a site are drawn independently from the site's methylation level (mostly concordant, some hemi)
-        std::vector<uint32_t> gpos; std::string gdeltas; { uint32_t skipped = 0; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'G') { if (f > 0 && fwd[f - 1] == 'C') { gpos.push_back(f); snprintf(num, sizeof(num), ",%u", skipped); gdeltas += num; skipped = 0; } else skipped++; } }
-        auto gsite = [&](uint32_t f) -> double { uint32_t q = rev ? L - 1 - f : f; uint32_t rp = qref[q]; return rp == ~0u ? 0.5 : site_beta(beta_seed, tid, rev ? rp : rp - 1); };
+        std::vector<uint32_t> gpos; std::string gdeltas; { uint32_t skipped = 0; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'G') {
+            if (f > 0 && fwd[f - 1] == 'C') { gpos.push_back(f);
+              snprintf(num, sizeof(num), ",%u", skipped); gdeltas += num; skipped = 0; } else skipped++; } }
+        auto gsite = [&](uint32_t f) -> double { uint32_t q = rev ? L - 1 - f : f; uint32_t rp = qref[q];
+          return rp == ~0u ? 0.5 : site_beta(beta_seed, tid, rev ? rp : rp - 1); };
         std::vector<uint8_t> hv[2], mv[2];
         for (int sd = 0; sd < 2; sd++) for (uint32_t f : (sd ? gpos : cpos)) {
-          double b = sd ? gsite(f) : site(f); bool meth = r.uni() < b; uint8_t qm = qual(meth); uint32_t rest = 255u - qm; uint8_t qh = (uint8_t)(r.uni() < 0.15 ? r.below(rest + 1) : r.below(rest / 4 + 1));
+          double b = sd ? gsite(f) : site(f); bool meth = r.uni() < b; uint8_t qm = qual(meth); uint32_t rest = 255u - qm;
+            uint8_t qh = (uint8_t)(r.uni() < 0.15 ? r.below(rest + 1) : r.below(rest / 4 + 1));
           hv[sd].push_back(qh); mv[sd].push_back(qm);
         }
-        if (rid & 1) { mm = "C+hm?" + deltas + ";G-hm?" + gdeltas + ";"; for (int sd = 0; sd < 2; sd++) for (size_t i = 0; i < hv[sd].size(); i++) { ml.push_back(hv[sd][i]); ml.push_back(mv[sd][i]); } }
-        else { mm = "C+h?" + deltas + ";C+m?" + deltas + ";G-h?" + gdeltas + ";G-m?" + gdeltas + ";"; for (int sd = 0; sd < 2; sd++) { ml.insert(ml.end(), hv[sd].begin(), hv[sd].end()); ml.insert(ml.end(), mv[sd].begin(), mv[sd].end()); } }
+        if (rid & 1) { mm = "C+hm?" + deltas + ";G-hm?" + gdeltas + ";"; for (int sd = 0; sd < 2; sd++) for (size_t i = 0; i < hv[sd].size(); i++) {
+            ml.push_back(hv[sd][i]); ml.push_back(mv[sd][i]); } }
+        else { mm = "C+h?" + deltas + ";C+m?" + deltas + ";G-h?" + gdeltas + ";G-m?" + gdeltas + ";"; for (int sd = 0; sd < 2; sd++) {
+            ml.insert(ml.end(), hv[sd].begin(), hv[sd].end()); ml.insert(ml.end(), mv[sd].begin(), mv[sd].end()); } }
         blk_calls[bi] += gpos.size();
       } else {
       const bool hm = style == "hm" || style == "hma";
@@ -201,14 +239,16 @@ int main(int argc, char** argv) {
       else {
         std::vector<uint8_t> hv, mv;
         for (uint32_t f : cpos) {
-          double b = site(f); bool meth = r.uni() < b; uint8_t qm = qual(meth); uint32_t rest = 255u - qm; uint8_t qh = (uint8_t)(r.uni() < 0.15 ? r.below(rest + 1) : r.below(rest / 4 + 1));
+          double b = site(f); bool meth = r.uni() < b; uint8_t qm = qual(meth); uint32_t rest = 255u - qm;
+            uint8_t qh = (uint8_t)(r.uni() < 0.15 ? r.below(rest + 1) : r.below(rest / 4 + 1));
           if (r.uni() < 0.02) { qm = qh = (uint8_t)r.below(128); }  // forced tie
           hv.push_back(qh); mv.push_back(qm);
         }
         const bool combined = style == "hm" && (rid & 1);
         if (combined) { mm = "C+hm?" + deltas + ";"; for (size_t i = 0; i < hv.size(); i++) { ml.push_back(hv[i]); ml.push_back(mv[i]); } }
         else { mm = "C+h?" + deltas + ";C+m?" + deltas + ";"; ml.insert(ml.end(), hv.begin(), hv.end()); ml.insert(ml.end(), mv.begin(), mv.end()); }
-        if (style == "hma") { mm += "A+a?"; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'A') { mm += ",0"; ml.push_back(qual(r.uni() < 0.05)); } mm += ";"; }
+        if (style == "hma") { mm += "A+a?"; for (uint32_t f = 0; f < L; f++) if (fwd[f] == 'A') { mm += ",0"; ml.push_back(qual(r.uni() < 0.05));
+          } mm += ";"; }
       }
       }
       blk_calls[bi] += cpos.size();
@@ -216,7 +256,8 @@ int main(int argc, char** argv) {
       char qn[32]; int lq = snprintf(qn, sizeof(qn), "r%09llu", (unsigned long long)rid) + 1;
       size_t at = bam.d.size(); bam.i32(0);
       const uint32_t rend = pl.start + pl.len;
-      bam.i32((int32_t)tid); bam.i32((int32_t)pl.start); bam.u8((uint8_t)lq); bam.u8(60); bam.u16((uint16_t)reg2bin(pl.start, rend)); bam.u16((uint16_t)cigar.size()); bam.u16(flag); bam.i32((int32_t)L); bam.i32(-1); bam.i32(-1); bam.i32(0);
+      bam.i32((int32_t)tid); bam.i32((int32_t)pl.start); bam.u8((uint8_t)lq); bam.u8(60); bam.u16((uint16_t)reg2bin(pl.start, rend));
+        bam.u16((uint16_t)cigar.size()); bam.u16(flag); bam.i32((int32_t)L); bam.i32(-1); bam.i32(-1); bam.i32(0);
       bam.put(qn, (size_t)lq); bam.put(cigar.data(), cigar.size() * 4);
       for (uint32_t i = 0; i < L; i += 2) bam.u8((uint8_t)((nib(seq[i]) << 4) | (i + 1 < L ? nib(seq[i + 1]) : 0)));
       bam.d.insert(bam.d.end(), L, 0xff);
@@ -240,7 +281,8 @@ int main(int argc, char** argv) {
     fwrite("BAI\1", 1, 4, f); w32((uint32_t)contigs.size());
     size_t bi = 0, ri = 0;   // cursor over (block, record) in file order
     for (size_t tid = 0; tid < contigs.size(); tid++) {
-      std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin; uint64_t n_mapped = 0, n_unmapped = 0, off_beg = ~0ull, off_end = 0;
+      std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins; std::vector<uint64_t> lin;
+        uint64_t n_mapped = 0, n_unmapped = 0, off_beg = ~0ull, off_end = 0;
       for (; bi < nblocks; bi++, ri = 0) {
         bool stop = false;
         for (; ri < blk_idx[bi].size(); ri++) {
@@ -262,7 +304,8 @@ int main(int argc, char** argv) {
     w64(0);  // n_no_coor
     fclose(f); }
   uint64_t aligned = 0, calls = 0; for (size_t i = 0; i < nblocks; i++) { aligned += blk_aligned[i]; calls += blk_calls[i]; }
-  printf("{\"reads\": %llu, \"aligned_bases\": %llu, \"cpg_calls\": %llu, \"bam_bytes_uncompressed\": %llu, \"genome\": %llu}\n", (unsigned long long)plan.size(), (unsigned long long)aligned, (unsigned long long)calls,
+  printf("{\"reads\": %llu, \"aligned_bases\": %llu, \"cpg_calls\": %llu, \"bam_bytes_uncompressed\": %llu, \"genome\": %llu}\n",
+      (unsigned long long)plan.size(), (unsigned long long)aligned, (unsigned long long)calls,
          (unsigned long long)st.size(), (unsigned long long)total_len);
   return 0;
 }

@@ -12,7 +12,8 @@
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 extern "C" __global__ void calib_stream16(const uint4* __restrict__ p, size_t n16, uint32_t* sink) {
   uint32_t acc = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { uint4 v = p[i];
+    acc += v.x ^ v.y ^ v.z ^ v.w; }
   if (acc == 0x12345678u) *sink = acc;
 }
 template <int STRIDE> __device__ void byte_walk(const uint8_t* __restrict__ p, size_t n, uint32_t* sink) {
@@ -23,7 +24,8 @@ template <int STRIDE> __device__ void byte_walk(const uint8_t* __restrict__ p, s
 extern "C" __global__ void calib_byte_s32(const uint8_t* __restrict__ p, size_t n, uint32_t* sink) { byte_walk<32>(p, n, sink); }
 extern "C" __global__ void calib_byte_s24(const uint8_t* __restrict__ p, size_t n, uint32_t* sink) { byte_walk<24>(p, n, sink); }
 extern "C" __global__ void calib_write16(uint4* __restrict__ p, size_t n16) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4((uint32_t)i, 1u, 2u, 3u);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4((uint32_t)i, 1u, 2u,
+      3u);
 }
 int main() {
   const size_t bytes = 1ull << 30;
