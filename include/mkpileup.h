@@ -68,7 +68,7 @@ typedef struct {
   uint32_t edge_start, edge_end, edge_inverted;
   uint32_t force_allow_implicit;
   uint32_t combine_strands;
-  uint32_t max_depth;      /* columns deeper than this fail loudly (htslib maxcnt is not restated) */
+  uint32_t max_depth;      /* htslib's maxcnt: a shard in which bam_plp_push would drop a record under this cap fails loudly */
 } mkp_caller;
 
 /* One alignment record = the fields of htslib's bam1_t the path reads

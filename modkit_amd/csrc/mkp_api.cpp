@@ -178,25 +178,59 @@ template <class F> void host_parallel(size_t n, size_t grain, F f) {   // f(lo, 
   HostPool::get().parallel(pieces, [&](size_t i) { f(i * grain, std::min(n, (i + 1) * grain)); });
 }
 
-// htslib's pileup engine stops buffering reads once more than max_depth of them overlap (bam_plp_push, maxcnt); which reads it
-// would drop is not restated, so a shard in which that could happen is refused.  The population is htslib's: every record
-// passing BAM_DEF_MASK (kept reads and supplementary ones), by reference span (ref-skips included).  While no position has
-// more than max_depth such records over it, nothing is ever dropped and the device result is exact.
-void depth_guard(const ShardHost& S, uint32_t max_depth) {
+// htslib's pileup engine (bam_plp_push; `set_max_depth` = bam_plp_set_maxcnt, pileup/mod.rs:755-759) refuses a record when it starts
+// where the last buffered record started and the buffer — the records that end at or behind that position, plus the list's tail node —
+// holds more than max_depth entries (`iter->pos == b->core.pos && iter->mp->cnt > iter->maxcnt`); the first record of a start is always
+// taken, so depth alone drops nothing.  Every interval of the reference's grid is a fetch with an iterator of its own over the records
+// that overlap it.  Dropping per (record, interval) is not reproduced on the device; what is decided here, exactly, is whether ANY
+// record would be dropped: an interval [a, e) and a start b shared by two or more of its records with
+//     #{records of the interval: start <= b and end >= b}  >  max_depth        (end > a where b <= a: the fetch's own condition).
+// If there is none, htslib keeps every record at any depth and the device result is exact (up to the tallies' 65 535).  The population
+// is htslib's: every record passing BAM_DEF_MASK (kept reads and supplementary ones), by reference span (ref-skips included).
+void depth_guard(const ShardHost& S, uint32_t max_depth, const std::vector<uint32_t>& iv_starts) {
   const size_t n = S.hdr.size() + S.extra_spans.size();
   if (n <= max_depth) return;
-  std::vector<int32_t> st, en; st.reserve(n); en.reserve(n);
-  for (auto& h : S.hdr) { st.push_back(h.ref_start); en.push_back(std::max(h.ref_end, h.ref_start + 1)); }
-  for (auto& x : S.extra_spans) { st.push_back(x.first); en.push_back(std::max(x.second, x.first + 1)); }
-  // (alignment starts and ends are non-negative: they sort as unsigned)
-  { std::vector<uint32_t> a(st.begin(), st.end()), b(en.begin(), en.end()); if (!std::is_sorted(a.begin(), a.end())) sort_u32(a); sort_u32(b);
-    std::copy(a.begin(), a.end(), st.begin()); std::copy(b.begin(), b.end(), en.begin()); }
+  std::vector<std::pair<uint32_t, uint32_t>> sp; sp.reserve(n);   // (start, end), starts ascending (alignment starts and ends are non-negative)
+  for (auto& h : S.hdr) sp.push_back({(uint32_t)h.ref_start, (uint32_t)std::max(h.ref_end, h.ref_start + 1)});
+  for (auto& x : S.extra_spans) sp.push_back({(uint32_t)x.first, (uint32_t)std::max(x.second, x.first + 1)});
+  if (!std::is_sorted(sp.begin(), sp.end(), [](auto& x, auto& y) { return x.first < y.first; }))
+    std::stable_sort(sp.begin(), sp.end(), [](auto& x, auto& y) { return x.first < y.first; });
+  std::vector<uint32_t> en(n); for (size_t i = 0; i < n; i++) en[i] = sp[i].second;
+  sort_u32(en);
   size_t j = 0, cur = 0, best = 0;
-  for (size_t i = 0; i < n; i++) { while (j < n && en[j] <= st[i]) { j++; cur--; } cur++; best = std::max(best, cur); }
+  for (size_t i = 0; i < n; i++) { while (j < n && en[j] <= sp[i].first) { j++; cur--; } cur++; best = std::max(best, cur); }
   if (best > 65535) throw Error(MKP_E_UNSUPPORTED,
       "more than 65535 reads over one position: columns this deep are outside the device path (16-bit packed tallies)");
-  if (best > max_depth) throw Error(MKP_E_UNSUPPORTED,
-      "a pileup column is deeper than max_depth (" + std::to_string(best) + " records over one position); htslib's maxcnt read-dropping is not reproduced");
+  auto refuse = [&](uint32_t b, size_t held) {
+    throw Error(MKP_E_UNSUPPORTED, "htslib would drop records here: " + std::to_string(held) + " buffered records at position " + std::to_string(b) +
+        ", where several records start, exceed max_depth (" + std::to_string(max_depth) + "); bam_plp_push's maxcnt read dropping is not reproduced"); };
+  auto ends_below = [&](uint32_t v) { return (size_t)(std::lower_bound(en.begin(), en.end(), v) - en.begin()); };   // #{end < v}
+  // interval starts of the shard (none given: the shard is one interval)
+  std::vector<uint32_t> A; A.push_back((uint32_t)std::max(S.win_start, 0));
+  for (size_t k = 1; k < iv_starts.size(); k++) if (iv_starts[k] > A.back()) A.push_back(iv_starts[k]);
+  // (1) starts b inside an interval (a <= b): the interval's fetch holds every record with start <= b <= end
+  for (size_t i = 0; i < n;) {
+    size_t r = i; while (r < n && sp[r].first == sp[i].first) r++;
+    const uint32_t b = sp[i].first;
+    if (r - i >= 2 && b >= A[0]) {
+      const bool on_start = std::binary_search(A.begin(), A.end(), b);   // b == a: records that end AT a are not fetched
+      const size_t held = r - (on_start ? ends_below(b + 1) : ends_below(b));
+      if (held > max_depth) refuse(b, held);
+    }
+    i = r;
+  }
+  // (2) starts in front of an interval's start a: among the records with start < a < end
+  for (uint32_t a : A) {
+    const size_t before = (size_t)(std::lower_bound(sp.begin(), sp.end(), a, [](auto& x, uint32_t v) { return x.first < v; }) - sp.begin());
+    if (before - std::min(before, ends_below(a + 1)) <= max_depth) continue;
+    size_t held = 0;
+    for (size_t i = 0; i < before;) {
+      size_t r = i, m = 0; while (r < before && sp[r].first == sp[i].first) { m += sp[r].second > a; r++; }
+      held += m;
+      if (m >= 2 && held > max_depth) refuse(sp[i].first, held);
+      i = r;
+    }
+  }
 }
 
 // BGZF inflate on the device: mkp_inflate_wave4, one wave per block — speculative token decode, a scalar walk that only marks the chain,
@@ -417,7 +451,7 @@ void make_resident(mkp_ctx* c) {
   lap("decode classes + event slices");
   const size_t n = S.hdr.size();
   for (size_t i = 1; i < n; i++) if (S.hdr[i].ref_start < S.hdr[i - 1].ref_start) throw Error(MKP_E_INVALID, "records must be coordinate sorted");
-  depth_guard(S, c->caller.max_depth);
+  depth_guard(S, c->caller.max_depth, c->iv_starts);
   lap("sortedness + depth guard");
 
   // ---- tile plan.  The accumulate kernel runs two 1024-thread workgroups per CU, each holding one tile in LDS: 76 KiB per

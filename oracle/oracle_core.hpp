@@ -17,7 +17,7 @@
 //
 // Parity unpinned by any reference fixture (derived from code only): ties in
 // mod-code probability, >=3 codes per base, ChEBI ordering (derived Ord: Code <
-// ChEbi, src/mod_base_code.rs:105), max_depth overflow, QC-fail reads, N CIGAR
+// ChEbi, src/mod_base_code.rs:105), max_depth read dropping (bam_plp_push, restated in oracle_pileup.hpp), QC-fail reads, N CIGAR
 // ops, boundary-CpG loss, schedule pruning order (sampling_schedule.rs:225).
 #pragma once
 #include <zlib.h>

@@ -2,6 +2,7 @@
 // Per-interval pileup: ReadCache, htslib pileup columns, tallies, row decode,
 // strand combine.  Follows /root/reference/src/read_cache.rs and src/pileup/mod.rs.
 #pragma once
+#include <queue>
 #include "oracle_core.hpp"
 #include <tuple>
 
@@ -283,11 +284,26 @@ struct ReadSpan {
 template <class ColFn>
 static inline void sweep_columns(const BamFile& bam, uint32_t tid, uint32_t start, uint32_t end, uint32_t max_depth, ColFn&& col) {
   std::vector<ReadSpan> spans;
+  // bam_plp_push's maxcnt rule (htslib sam.c, the engine behind rust-htslib 0.46's `pileup()`; `set_max_depth` = bam_plp_set_maxcnt,
+  // pileup/mod.rs:755-759) — htslib is not in /root/reference: restated from its published source, parity unpinned.  A record is refused
+  // when `iter->tid == b->core.tid && iter->pos == b->core.pos && iter->mp->cnt > iter->maxcnt`.  Between two pushes the iterator has
+  // walked every column in front of the last buffered record's start P and sits ON P (`max_pos > pos` ends the walk), and a column's
+  // walk frees the nodes with `end <= column`; so the test only ever fires for a record that starts where the last BUFFERED record
+  // started, and `cnt` is then 1 (the list's empty tail node) + the buffered records that end at or behind P.  The first record of every
+  // start is therefore always taken, whatever the depth; a fetch starts a fresh iterator, so the verdict is per interval.
+  std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> ends;   // buffered records' end positions
+  bool have_last = false; int64_t last_beg = 0;
   for (const BamRecord& r : bam.recs) {
     if (r.tid != (int32_t)tid) continue;
     if ((int64_t)r.pos >= (int64_t)end) continue;
     if ((int64_t)r.end_pos() <= (int64_t)start) continue;
     if (r.flag & (4 | 256 | 512 | 1024)) continue;
+    {
+      const int64_t b = r.pos, e = std::max<int64_t>(r.end_pos(), b + 1);
+      while (!ends.empty() && ends.top() < b) ends.pop();
+      if (have_last && last_beg == b && 1 + ends.size() > (size_t)max_depth) continue;   // refused: never seen by any column
+      ends.push(e); have_last = true; last_beg = b;
+    }
     int32_t rl = r.ref_len();
     if (rl <= 0) continue;
     ReadSpan sp; sp.rec = &r; sp.beg = r.pos; sp.end = r.pos + rl; sp.state.assign((size_t)rl, -2);
@@ -316,8 +332,6 @@ static inline void sweep_columns(const BamFile& bam, uint32_t tid, uint32_t star
       if (P + 1 < (int64_t)start) P = (int64_t)start - 1;
       continue;
     }
-    if (active.size() > max_depth)
-      throw MkErr("depth exceeds --max-depth: htslib maxcnt semantics are not restated (parity unpinned)");
     col((uint32_t)P, spans, active);
   }
 }

@@ -1,5 +1,5 @@
 """GPU: inputs outside the device path's coverage must fail loudly (MKP_E_UNSUPPORTED), never fall back or silently
-diverge from the reference: columns deeper than --max-depth (htslib's read dropping is not restated) and flags whose handling lives in
+diverge from the reference: piles in which htslib would drop records under --max-depth (the dropping is restated in the oracle only; tests/test_gpu_max_depth.py) and flags whose handling lives in
 the reference's Rust writers.  (Two kept records sharing a read name in one interval — refused through round 5 — are reproduced now:
 tests/test_gpu_dup_names.py.)"""
 import os
