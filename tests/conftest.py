@@ -22,3 +22,8 @@ def oracle_bin():
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
         subprocess.check_call(["make", "-C", d, "modkit_oracle"])
     return exe
+
+
+# MKP_SOAK_SHIFT=n moves the seeds of the fuzzed suites (hemi, extract, ingest, duplicate names, summary) by 1000 n for one-off soak runs
+# on the GPU box (`profiles/*_soak.txt`); 0 = the seeds the suite pins.  test_gpu_parity_fuzz.py has MKP_FUZZ_SEEDS / MKP_FUZZ_PROFILE_SEEDS.
+SOAK = 1000 * int(os.environ.get("MKP_SOAK_SHIFT", "0"))

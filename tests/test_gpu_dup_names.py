@@ -9,6 +9,8 @@ import subprocess
 
 import pytest
 
+from conftest import SOAK
+
 import modkit_amd
 from bamfuzz import Fuzz, aux_bc, aux_z, bam_header, bam_record, bgzf_write
 
@@ -43,7 +45,7 @@ FLAGS = [
 @pytest.mark.parametrize("fi", range(len(FLAGS)))
 @pytest.mark.parametrize("profile,seed", [("m", 3), ("hm_split", 4), ("mixed", 6)])
 def test_duplicates_shifted_copies_and_split_reads(oracle_bin, tmp_path, profile, seed, fi):
-    bam, fa, bed = Fuzz(100 + seed, profile=profile, n_reads=400, dup_rate=0.35, weird_rate=0.05 if profile == "mixed" else 0.0, index=(fi % 2 == 0)).write(str(tmp_path / "fz"), bed=True)
+    bam, fa, bed = Fuzz(100 + seed + SOAK, profile=profile, n_reads=400, dup_rate=0.35, weird_rate=0.05 if profile == "mixed" else 0.0, index=(fi % 2 == 0)).write(str(tmp_path / "fz"), bed=True)
     flags = [f.format(fa=fa, bed=bed) for f in FLAGS[fi]]
     dev_only = []
     oflags = []
@@ -52,7 +54,12 @@ def test_duplicates_shifted_copies_and_split_reads(oracle_bin, tmp_path, profile
         if flags[k] == "--shard-bp":
             dev_only += flags[k:k + 2]; k += 2; continue
         oflags.append(flags[k]); k += 1
-    out = both(oracle_bin, tmp_path, bam, oflags, dev_only)
+    try:
+        out = both(oracle_bin, tmp_path, bam, oflags, dev_only)
+    except modkit_amd.MkpError as e:
+        if SOAK and e.status == -3 and "disagree" in str(e):   # (soak seeds may build the one constellation that is refused by design)
+            pytest.skip("owners disagree across intervals: refused by design")
+        raise
     assert len(out.splitlines()) > 200
 
 

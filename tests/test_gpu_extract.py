@@ -5,6 +5,8 @@ import subprocess
 
 import pytest
 
+from conftest import SOAK
+
 import modkit_amd
 from bamfuzz import Fuzz
 from pileup_cases import EXTRACT_CALLS_CASES, REF, fixture
@@ -41,7 +43,7 @@ FLAG_SETS = [
 
 @pytest.mark.parametrize("profile", ["m", "hm_comb", "hm_split", "hm_split_diff", "hma", "implicit", "default", "nbase", "chebi", "mixed"])
 def test_extract_calls_fuzz_vs_oracle(oracle_bin, tmp_path, profile):
-    bam, fa, bed = Fuzz(900, profile=profile, n_reads=300).write(str(tmp_path / "fz"), bed=True)
+    bam, fa, bed = Fuzz(900 + SOAK, profile=profile, n_reads=300).write(str(tmp_path / "fz"), bed=True)
     for fi, fl in enumerate(FLAG_SETS):
         flags = [f.format(fa=fa, bed=bed) for f in fl]
         dev, ora = str(tmp_path / ("dev%d.tsv" % fi)), str(tmp_path / ("ora%d.tsv" % fi))

@@ -8,6 +8,8 @@ import subprocess
 
 import pytest
 
+from conftest import SOAK
+
 import modkit_amd
 from bamfuzz import Fuzz
 from test_host_ingest import gen
@@ -54,7 +56,7 @@ FLAGS = [
 @pytest.mark.parametrize("fi", range(len(FLAGS)))
 @pytest.mark.parametrize("profile", ["mixed", "hm_split", "duplex"])
 def test_device_ingest_equals_host_ingest_and_oracle(oracle_bin, tmp_path, profile, fi):
-    bam, fa, bed = Fuzz(31 + fi, profile=profile, n_reads=500, weird_rate=0.15, index=True).write(str(tmp_path / "fz"), bed=True)
+    bam, fa, bed = Fuzz(31 + fi + SOAK, profile=profile, n_reads=500, weird_rate=0.15, index=True).write(str(tmp_path / "fz"), bed=True)
     flags = [f.format(fa=fa, bed=bed) for f in FLAGS[fi]]
     dev, host, _ = both(tmp_path, "pileup", bam, flags)
     assert dev == host

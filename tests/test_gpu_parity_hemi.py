@@ -6,6 +6,8 @@ import subprocess
 
 import pytest
 
+from conftest import SOAK
+
 import modkit_amd
 from bamfuzz import Fuzz
 from pileup_cases import HEMI_BAM, HEMI_GOLDEN_CASES, fixture, hemi_reference_fasta
@@ -92,7 +94,7 @@ FUZZ_FLAGS = [
 @pytest.mark.parametrize("profile", ["duplex", "duplex_hm", "duplex_split", "duplex_chebi", "duplex_3codes", "mixed"])
 @pytest.mark.parametrize("fi", range(len(FUZZ_FLAGS)))
 def test_fuzz_hemi(oracle_bin, tmp_path, profile, fi):
-    bam, fa, bed = Fuzz(4200 + fi, profile=profile, n_reads=300, tie_rate=0.1).write(str(tmp_path / "fz"), bed=True)
+    bam, fa, bed = Fuzz(4200 + fi + SOAK, profile=profile, n_reads=300, tie_rate=0.1).write(str(tmp_path / "fz"), bed=True)
     flags = [f.format(bed=bed) for f in FUZZ_FLAGS[fi]] + ["-r", fa]
     run_both(oracle_bin, tmp_path, bam, flags, extra_dev=["--tile", "256"] if fi % 2 else [])
 

@@ -5,6 +5,8 @@ import struct
 
 import pytest
 
+from conftest import SOAK
+
 import modkit_amd
 from bamfuzz import Fuzz
 from pileup_cases import BC, BED, fixture
@@ -70,7 +72,7 @@ def test_summary_implicit_calls_on_device(oracle_bin):
 
 @pytest.mark.parametrize("profile", ["hm_split", "hma", "duplex_hm", "chebi", "implicit", "mixed"])
 def test_fuzzed_summary_matches_oracle(oracle_bin, tmp_path, profile):
-    bam, _, _ = Fuzz(1212, profile=profile, n_reads=400, tie_rate=0.15).write(str(tmp_path / "fz"))
+    bam, _, _ = Fuzz(1212 + SOAK, profile=profile, n_reads=400, tie_rate=0.15).write(str(tmp_path / "fz"))
     ctx = modkit_amd.Context()
     try:
         for flags in ([], ["--only-mapped", "-n", "150", "-i", "3000", "-p", "0.25"], ["--no-sampling", "--filter-threshold", "0.75"], ["--no-sampling", "--no-filtering"]):
