@@ -19,8 +19,12 @@ def oracle_bin():
     d = os.path.join(ROOT, "oracle")
     exe = os.path.join(d, "modkit_oracle")
     srcs = [os.path.join(d, f) for f in ("modkit_oracle.cpp", "oracle_core.hpp", "oracle_pileup.hpp")]
-    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
-        subprocess.check_call(["make", "-C", d, "modkit_oracle"])
+    # (under pytest-xdist several workers come through here at once: one builds, the others wait — never run a binary that is being written)
+    import fcntl
+    with open(os.path.join(d, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+            subprocess.check_call(["make", "-C", d, "modkit_oracle"])
     return exe
 
 
