@@ -73,6 +73,7 @@ struct Args {
   std::string in_bam, out_bed, region, sample_region, include_bed, ignore, ref_fasta, edge_filter, preset;
   uint32_t max_depth = 8000, interval_size = 100000, sampling_interval_size = 1000000;
   bool have_seed = false; uint64_t seed = 0;   // --seed
+  bool serial_sampler = false;   // sample-probs / summary / extract calls on a BAM that has no index file (reads_sampler/mod.rs:129-158)
   size_t threads = 4, num_reads = 10042; bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts, partition_tags; std::string prefix;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false, invert_edge = false,
@@ -179,6 +180,80 @@ struct RecSet {
   }
 };
 
+// what `bam::IndexedReader::from_path` finds (htslib: <bam>.bai, <bam>.csi, or the extension replaced)
+bool bam_index_file_exists(const std::string& path) {
+  std::vector<std::string> c = {path + ".bai", path + ".csi"};
+  if (path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0) { c.push_back(path.substr(0, path.size() - 4) + ".bai");
+    c.push_back(path.substr(0, path.size() - 4) + ".csi"); }
+  for (auto& f : c) { FILE* p = fopen(f.c_str(), "rb"); if (p) { fclose(p); return true; } }
+  return false;
+}
+
+// The sampler of a BAM WITHOUT an index (reads_sampler/mod.rs:129-158; `bam::IndexedReader::from_path(..).is_ok()` decides, so an index
+// ignored by `extract calls --ignore-index` still counts as one): no schedule — one pass over the file in file order, mapped and unmapped
+// records alike, under RecordSampler::new_from_options (record_sampler.rs:51-61): the first --num-reads records that yield values, or with
+// --sampling-frac one `gen_bool` per record the tag iterator yields (StdRng, --seed).  A region is an error there, as it is here.
+// Records go to the sampling kernels contig by contig (a round has one reference window and one BED mask); the sampler's state — reads
+// used, names seen — runs across the whole file.
+void sample_serial(mkp_ctx* ctx, const BamSource& bam, const Args& a, const RegionSpec* region, const BedFilter* bf) {
+  if (region) throw Error(MKP_E_INVALID, "cannot use region without indexed BAM");
+  const bool only_mapped = !a.include_unmapped;
+  const bool draws = a.have_frac && a.sampling_frac < 1.0;
+  if (a.have_frac && a.sampling_frac > 1.0) throw Error(MKP_E_INVALID, "sample fraction must be <= 1");
+  if (draws && !a.have_seed) throw Error(MKP_E_UNSUPPORTED,
+      "--sampling-frac < 1 on a BAM without an index draws from an entropy-seeded rand::StdRng (record_sampler.rs:29-38): give --seed");
+  // a draw is taken for every record whose tags parse and hold a position, whether or not a value survives the filters; the kernels report
+  // surviving values only — the two coincide while nothing can remove a record's every position
+  if (draws && (only_mapped || bf || !a.edge_filter.empty())) throw Error(MKP_E_UNSUPPORTED,
+      "--sampling-frac < 1 on a BAM without an index together with --only-mapped / --include-bed / --edge-filter: which records consume a draw is not reproduced");
+  SeededSampler rng(a.seed);
+  const long limit = a.have_frac ? -1 : (long)a.num_reads;
+  std::set<std::string> seen; size_t used = 0;
+  std::map<uint32_t, std::vector<uint8_t>> masks;   // --include-bed: bit 0 / 1 = the position is listed for the '+' / '-' strand
+  auto mask_of = [&](uint32_t tid) -> const uint8_t* {
+    if (!bf) return nullptr;
+    auto it = masks.find(tid); if (it != masks.end()) return it->second.data();
+    std::vector<uint8_t> m(bam.ref_lens[tid], 0);
+    auto mark = [&](const std::map<uint32_t, std::vector<Span>>& mp, uint8_t bit) { auto f = mp.find(tid); if (f == mp.end()) return;
+        for (auto& x : f->second) for (uint64_t q = x.s; q < std::min<uint64_t>(x.e, m.size()); q++) m[q] |= bit; };
+    mark(bf->pos, 1); mark(bf->neg, 2);
+    return masks.emplace(tid, std::move(m)).first->second.data();
+  };
+  auto round = [&](const RecSet& set, int64_t tid) {
+    const BamBatch& b = *set.b;
+    std::vector<size_t> cand;
+    for (size_t i = 0; i < set.size(); i++) if (set.candidate(i, only_mapped || !a.edge_filter.empty())) cand.push_back(i);
+    const bool mapped = tid >= 0;
+    const uint8_t* mask = mapped ? mask_of((uint32_t)tid) : nullptr;
+    for (size_t next = 0; next < cand.size() && (limit < 0 || used < (size_t)limit);) {
+      const size_t want = limit < 0 ? std::min<size_t>(cand.size() - next, 1u << 18) : std::max<size_t>(256, 2 * ((size_t)limit - used));
+      const size_t hi = std::min(cand.size(), next + want);
+      std::vector<mkp_record> recs; recs.reserve(hi - next); for (size_t i = next; i < hi; i++) recs.push_back(b.view(b.recs[cand[i]]));
+      std::vector<uint32_t> nv;
+      int rc = mkp_internal_sample(ctx, mapped ? (int32_t)tid : -1, 0, mapped ? bam.ref_lens[(size_t)tid] : 1, mask, recs.data(), (uint32_t)recs.size(),
+          only_mapped, &nv);
+      if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+      std::vector<uint8_t> keep(recs.size(), 0);
+      for (size_t i = next; i < hi; i++) {
+        if (limit >= 0 && used >= (size_t)limit) break;                               // RecordSampler::ask -> Done
+        const size_t k = i - next;
+        if (draws && nv[k] != 0 && !rng.keep(a.sampling_frac)) continue;               // check_sample_frac -> Skip
+        std::string name = set.name(cand[i]);
+        if (seen.count(name) || nv[k] == 0) continue;                                 // seen(); a record that keeps no value is not recorded
+        seen.insert(name); used++; keep[k] = 1;
+      }
+      rc = mkp_internal_sample_take(ctx, keep);
+      if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+      next = hi;
+    }
+  };
+  for (size_t t = 0; t < bam.ref_names.size() && (limit < 0 || used < (size_t)limit); t++) {
+    RecSet set; set.b.reset(new BamBatch()); bam.fetch((uint32_t)t, 0, std::max<uint32_t>(bam.ref_lens[t], 1u), set.b.get());
+    round(set, (int64_t)t);
+  }
+  if (limit < 0 || used < (size_t)limit) { RecSet set; set.b.reset(new BamBatch()); bam.fetch_unmapped(set.b.get()); round(set, -1); }
+}
+
 // `resident_of` (optional): the device-packed shard holding contig `tid`, bound to the context (mkp_internal_sample_bind) — the estimate then
 // samples from HBM; called whenever the schedule moves to another contig.
 using ResidentOf = std::function<const ShardHost*(uint32_t tid)>;
@@ -236,6 +311,7 @@ void sample_probabilities(mkp_ctx* ctx, const BamSource& bam, const Args& a, con
   };
   mkp_internal_bedmask_reset(ctx);
   struct MaskSession { mkp_ctx* c; ~MaskSession() { mkp_internal_bedmask_reset(c); } } mask_session{ctx};   // the host masks below die with this call
+  if (a.serial_sampler) { sample_serial(ctx, bam, a, region, bf); return; }
   if (sharded && !(a.have_frac && a.sampling_frac >= 1.0)) throw Error(MKP_E_UNSUPPORTED,
       "rank-sharded threshold sampling needs the full-data mode (-f 1.0): the count-based schedule carries quotas from interval to interval");
   IdxStats st = idxstats(bam, region, bf);
@@ -1439,7 +1515,8 @@ extern "C" int mkp_pileup_run_cb(mkp_ctx* ctx, int argc, const char* const* argv
 // (-n -f -p -t --sampling-interval-size --region --sample-region --include-bed --include-unmapped --edge-filter --ignore --preset).
 namespace {
 // the sampling half of get_threshold_from_options: parse the sampling flags, set the caller's collapse / edge filter, walk the schedule
-void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out, const mkp_caller* thresholds = nullptr) {
+void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, float* q_out, const mkp_caller* thresholds = nullptr,
+    bool serial_without_index = false /* sample-probs / summary / extract calls: the reference's own choice (reads_sampler/mod.rs:47) */) {
   Args a; parse_args(argc, argv, &a, false); a.in_bam = bam_path;
   std::unique_ptr<BamSource> src = BamSource::open(a.in_bam,
       std::max(std::max<unsigned>((unsigned)a.threads, 1u), std::min(32u, HostPool::host_cpus())),
@@ -1468,6 +1545,7 @@ void sample_bam(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
                     for (int b = 0; b < 4; b++) { kc.per_base_threshold[b] = thresholds->per_base_threshold[b];
                       kc.has_per_base[b] = thresholds->has_per_base[b]; } }
   int rc = mkp_set_caller(ctx, &kc); if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
+  a.serial_sampler = serial_without_index && a.world <= 1 && !bam_index_file_exists(a.in_bam);
   sample_probabilities(ctx, bam, a, hs ? &sregion : (hr ? &region : nullptr), bf);
   if (q_out) *q_out = a.filter_percentile;
 }
@@ -1513,7 +1591,7 @@ extern "C" int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, co
     if (!only_mapped) tr.push_back("--include-unmapped");
     std::vector<const char*> av; for (auto& x : tr) av.push_back(x.c_str());
     int rc = mkp_histogram_begin(ctx); if (rc != MKP_OK) return rc;
-    sample_bam(ctx, bam_path, (int)av.size(), av.data(), nullptr);
+    sample_bam(ctx, bam_path, (int)av.size(), av.data(), nullptr, nullptr, true);
     for (int b = 0; b < 4; b++) { has[b] = 0; n_values[b] = 0; }
     for (uint32_t k = 0; k < n_percentiles; k++) {
       const float q = percentiles[k];
@@ -1561,14 +1639,14 @@ extern "C" int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const c
     else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
     else {
       int rc = mkp_histogram_begin(ctx); if (rc != MKP_OK) return rc;
-      float q = 0.1f; sample_bam(ctx, bam_path, (int)av.size(), av.data(), &q);
+      float q = 0.1f; sample_bam(ctx, bam_path, (int)av.size(), av.data(), &q, nullptr, true);
       float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, q, thr, has, false);
       for (int b = 0; b < 4; b++) if (has[b]) { kt.has_per_base[b] = 1; kt.per_base_threshold[b] = thr[b]; }
       kt.per_mod = per_mod.data(); kt.n_per_mod = (uint32_t)per_mod.size();
     }
     ctx->summary_mode = true;
     int rc = mkp_internal_summary_begin(ctx); if (rc != MKP_OK) return rc;
-    sample_bam(ctx, bam_path, (int)av.size(), av.data(), nullptr, &kt);
+    sample_bam(ctx, bam_path, (int)av.size(), av.data(), nullptr, &kt, true);
     uint64_t t[134]; std::vector<MkpSlot> slots;
     rc = mkp_internal_summary_get(ctx, t, &slots); if (rc != MKP_OK) return rc;
     ctx->h_sum_base.clear(); ctx->h_sum_code.clear(); ctx->h_sum_pass.clear(); ctx->h_sum_fail.clear();
@@ -1724,7 +1802,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     else if (a.no_filtering) { /* MultipleThresholdModCaller::new_passthrough */ }
     else {
       must(mkp_histogram_begin(ctx));
-      float q = 0.1f; sample_bam(ctx, a.in_bam.c_str(), (int)sav.size(), sav.data(), &q);
+      float q = 0.1f; sample_bam(ctx, a.in_bam.c_str(), (int)sav.size(), sav.data(), &q, nullptr, true);
       float thr[4]; uint8_t has[4]; thresholds_from_sample(ctx, q, thr, has, false);
       for (int b = 0; b < 4; b++) if (has[b]) { kc.has_per_base[b] = 1; kc.per_base_threshold[b] = thr[b]; }
       kc.per_mod = per_mod.data(); kc.n_per_mod = (uint32_t)per_mod.size();

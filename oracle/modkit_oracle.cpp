@@ -339,6 +339,7 @@ struct Options {
   size_t threads = 4, num_reads = 10042; bool have_chunk = false; size_t chunk_size = 0;
   bool have_frac = false; double sampling_frac = 0; bool no_filtering = false; float filter_percentile = 0.1f;
   bool have_seed = false; uint64_t seed = 0;   // --seed (RecordSampler::new_sample_frac, record_sampler.rs:29-38)
+  bool serial_sampler = false;   // sample-probs / summary / extract calls: a BAM without an index is sampled serially (reads_sampler/mod.rs:129-158)
   std::vector<std::string> filter_threshold, mod_thresholds, motif_parts;
   bool include_unmapped = false, force_allow = false, cpg = false, mask = false, combine_mods = false, combine_strands = false;
   bool invert_edge = false, mixed_delim = false, with_header = false;
@@ -508,9 +509,27 @@ static std::vector<const BamRecord*> fetch(const BamFile& bam, uint32_t tid, uin
 }
 
 // get_sampled_read_ids_to_base_mod_probs + sample_reads_base_mod_calls_over_regions (reads_sampler/mod.rs:30-257)
+// bam::IndexedReader::from_path(..).is_ok() (reads_sampler/mod.rs:47): htslib finds <bam>.bai, <bam>.csi or the extension replaced
+static bool bam_has_index(const std::string& path) {
+  std::vector<std::string> c = {path + ".bai", path + ".csi"};
+  if (path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0) { c.push_back(path.substr(0, path.size() - 4) + ".bai"); c.push_back(path.substr(0, path.size() - 4) + ".csi"); }
+  for (auto& f : c) { FILE* p = fopen(f.c_str(), "rb"); if (p) { fclose(p); return true; } }
+  return false;
+}
 static SampledProbs sample_reads(const BamFile& bam, const Options& o, const Region* region, const CollapseMethod& collapse,
                                  const EdgeFilter& edge, const PositionFilter* pf, bool keep_calls) {
   bool only_mapped = !o.include_unmapped;
+  if (o.serial_sampler && !bam_has_index(o.in_bam)) {
+    // no index next to the BAM (reads_sampler/mod.rs:129-158): one pass over the file in file order — mapped and unmapped records alike —
+    // under RecordSampler::new_from_options: the first --num-reads records that yield values, or a Bernoulli draw per record
+    if (region) throw MkErr("cannot use region without indexed BAM");
+    SampleCtx cx{&bam, &collapse, &edge, pf, only_mapped, keep_calls};
+    std::vector<const BamRecord*> all; all.reserve(bam.recs.size()); for (auto& r : bam.recs) all.push_back(&r);
+    const bool draws = o.have_frac && o.sampling_frac < 1.0;
+    if (draws && !o.have_seed) throw MkErr("--sampling-frac < 1 on a BAM without an index draws from an entropy-seeded rand::StdRng: give --seed");
+    StdRng rng = StdRng::seed_from_u64(o.seed);
+    return process_records(all, o.have_frac ? -1 : (long)o.num_reads, cx, draws ? &rng : nullptr, o.sampling_frac);
+  }
   IdxStats st = IdxStats::make(bam, region, pf);
   SamplingSchedule sched = o.have_frac ? SamplingSchedule::from_sample_frac(st, (float)o.sampling_frac, !only_mapped)
                                        : SamplingSchedule::from_num_reads(st, o.num_reads, !only_mapped);
@@ -861,7 +880,7 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
   if (have_region) region = parse_region(o.region, bam);
   PositionFilter pf_store; const PositionFilter* pf = nullptr;
   if (!o.include_bed.empty()) { std::map<std::string, uint32_t> c2t;
-    for (auto& rr : get_targets(bam, have_region ? &region : nullptr)) c2t[rr.name] = rr.tid;
+    for (auto& rr : get_targets(bam, nullptr)) c2t[rr.name] = rr.tid;   // name_to_tid of the whole header (subcommand.rs:514-517), not of --region
     pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store;
     xo.include = [pf](int32_t tid, uint64_t p, bool neg) { return pf->contains(tid, p, neg); }; }
   // With an index (and without --ignore-index) the reference walks interval chunks of the targets (util.rs:329-470): --region then selects the
@@ -940,6 +959,7 @@ int main(int argc, char** argv) {
   o.hemi = std::string(argv[1]) == "pileup-hemi";
   const bool summary_cmd = std::string(argv[1]) == "summary";
   o.sample_probs_cmd = std::string(argv[1]) == "sample-probs" || summary_cmd;
+  o.serial_sampler = o.sample_probs_cmd || extract_cmd;   // (`pileup` needs an index in the reference; here it keeps the schedule over scanned counts)
   // --only-mapped is off by default; -i is the sampling interval
   if (o.sample_probs_cmd) { o.include_unmapped = true; o.sampling_interval_size = 1000000; }
   try {

@@ -9,6 +9,7 @@ import pytest
 import modkit_amd
 from bamfuzz import Fuzz
 from pileup_cases import BC, BED, fixture
+from sampler_cases import unmapped_tail_bam
 
 pytestmark = pytest.mark.gpu
 
@@ -74,36 +75,6 @@ def test_fuzzed_percentiles_match_oracle(oracle_bin, tmp_path, profile):
         ctx.close()
 
 
-def unmapped_tail_bam(prefix, n_mapped=30, n_unmapped=600, seed=11):
-    """A few mapped reads (fewer than 100 sampled records: reads_sampler/mod.rs:89-90 then always turns to the unmapped ones) and a tail of
-    records without coordinates, each with a `C+m?` tag; every tenth record carries no tags (the iterator never offers it to the sampler)."""
-    import random
-    from bamfuzz import aux_bc, aux_z, bam_header, bam_record, bgzf_write, write_bai
-    r = random.Random(seed)
-    contigs = [("ctg", 6000)]
-    data = bytearray(bam_header(contigs))
-    index = []
-
-    def one(tid, pos, flag, k):
-        n = r.randrange(60, 220)
-        seq = "".join(r.choice("ACGT") for _ in range(n))
-        ncalls = min(seq.count("C"), r.randrange(1, 12))
-        aux = b"" if (k % 10 == 9 or ncalls == 0) else aux_z("MM", "C+m?," + ",".join("0" for _ in range(ncalls)) + ";") + aux_bc("ML", [r.randrange(256) for _ in range(ncalls)])
-        cigar = [(n, "M")] if tid >= 0 else []
-        rec = bam_record(tid, pos, flag, "r%05d" % k, cigar, seq, aux)
-        index.append((tid, pos, n if tid >= 0 else 0, flag, len(data), len(rec)))
-        data.extend(rec)
-
-    starts = sorted(r.randrange(0, 5000) for _ in range(n_mapped))
-    for k, s in enumerate(starts):
-        one(0, s, 0, k)
-    for k in range(n_unmapped):
-        one(-1, -1, 4, n_mapped + k)
-    offs = bgzf_write(prefix + ".bam", bytes(data))
-    write_bai(prefix + ".bam.bai", 1, offs, index)
-    return prefix + ".bam"
-
-
 def test_seeded_fraction_of_the_unmapped_reads(oracle_bin, tmp_path):
     # `-f 0.4 --seed S` (record_sampler.rs:29-38, 80-86): the unmapped records that enter the sample follow StdRng's draws — the same on
     # both sides, different from seed to seed, and refused without a seed (the reference would seed from entropy)
@@ -123,5 +94,32 @@ def test_seeded_fraction_of_the_unmapped_reads(oracle_bin, tmp_path):
         assert oracle_table(oracle_bin, bam, ["-f", "0.4"], qs) is None
         with pytest.raises(modkit_amd.MkpError):
             ctx.sample_probs(bam, qs, ["-f", "0.4"])
+    finally:
+        ctx.close()
+
+
+def test_a_bam_without_an_index_is_sampled_serially(oracle_bin, tmp_path):
+    # reads_sampler/mod.rs:129-158: no schedule — the file in file order under RecordSampler (first N records that yield values, or one seeded
+    # draw per record); a region is an error
+    bam = unmapped_tail_bam(str(tmp_path / "ser"), n_mapped=260, n_unmapped=200, index=False, contig_len=40000)
+    qs = [0.1, 0.5, 0.9]
+    ctx = modkit_amd.Context()
+    try:
+        ns = []
+        for flags in (["-n", "40"], ["-n", "300"], ["-n", "40", "--only-mapped"], [], ["-f", "0.3", "--seed", "5"], ["-f", "0.3", "--seed", "6"], ["--no-sampling"],
+                      ["-n", "100", "--ignore", "m"]):
+            want = oracle_table(oracle_bin, bam, flags, qs)
+            got = ctx.sample_probs(bam, qs, flags)
+            assert want is not None and set(got) == set(want) == {"C"}, flags
+            assert got["C"]["n"] == want["C"]["n"], flags
+            assert [f32bits(v) for v in got["C"]["percentiles"].values()] == [f32bits(v) for v in want["C"]["percentiles"]], flags
+            ns.append(got["C"]["n"])
+        assert ns[0] < ns[1] < ns[6] and ns[3] == ns[6] and ns[4] != ns[5]
+        for flags in (["--region", "ctg"], ["-f", "0.3"]):    # the reference's own errors: a region needs an index; an entropy seed has no answer
+            assert oracle_table(oracle_bin, bam, flags, qs) is None
+            with pytest.raises(modkit_amd.MkpError):
+                ctx.sample_probs(bam, qs, flags)
+        with pytest.raises(modkit_amd.MkpError):             # which records consume a draw under a position filter is not reproduced: refused
+            ctx.sample_probs(bam, qs, ["-f", "0.3", "--seed", "5", "--only-mapped"])
     finally:
         ctx.close()
