@@ -331,7 +331,12 @@ int mkp_pileup_hemi_run(mkp_ctx* ctx, int argc, const char* const* argv, mkp_run
  * src/thresholds.rs:17-38).  argv = the subcommand's sampling flags (-n -f --no-sampling --region -i --include-bed --only-mapped
  * --ignore --edge-filter --invert-edge-filter -t); values[b * n_percentiles + k] for bases A,C,G,T; has[b] = 0 when the sample holds
  * no call on base b; n_values[b] = sampled calls on base b.  A base with fewer than two values fails with MKP_E_THRESHOLD, as the
- * reference does.  (The histogram / plot outputs of the subcommand are outside this path.) */
+ * reference does.  (The histogram / plot outputs of the subcommand are outside this path.)
+ * A BAM without an index file takes the reference's serial branch (src/reads_sampler/mod.rs:129-158), as mkp_summary and the estimate of
+ * mkp_extract_calls_main do: no schedule, the file in file order under RecordSampler — the first -n records that yield values, or with
+ * -f < 1 one `gen_bool` per record from rand's StdRng, which needs --seed (src/reads_sampler/record_sampler.rs:29-38, 80-86; without a
+ * seed the reference draws from entropy: MKP_E_UNSUPPORTED); --region is then an error, as in the reference.  With an index, -f < 1 only
+ * draws for the records without coordinates (--seed again). */
 int mkp_sample_probs(mkp_ctx* ctx, const char* bam_path, int argc, const char* const* argv, const float* percentiles, uint32_t n_percentiles,
                      float* values, uint8_t has[4], uint64_t n_values[4]);
 
