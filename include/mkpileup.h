@@ -373,7 +373,10 @@ int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
  * to the BAM and without --ignore-index the table holds the records overlapping the region — what the reference's interval fetches
  * return — otherwise every record of the file, as its serial scan does), --num-reads N with --ignore-index or an unindexed BAM (the first N
  * records that reach process_record, util.rs:519-575), --ignore-index.
- * --num-reads on an indexed BAM (the sampling schedule), --exclude-bed, --motif / --cpg, --ignore-implicit, --bgzf fail with MKP_E_UNSUPPORTED. */
+ * --num-reads N on an indexed BAM follows the reference's sampling schedule (run_extract_reads, src/extract/util.rs:329-470;
+ * SamplingSchedule::from_num_reads + get_record_sampler, src/reads_sampler/sampling_schedule.rs:171-273, 417-438): one sampler per interval
+ * of the feeder, then the records without coordinates; rows in interval order.
+ * --num-reads with --include-bed on an indexed BAM, --exclude-bed, --motif / --cpg, --ignore-implicit, --bgzf fail with MKP_E_UNSUPPORTED. */
 int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
 /* ---- BGZF inflate on the device as a call of its own.  On the pileup path the same kernels run inside the device ingest

@@ -147,6 +147,26 @@ IdxStats idxstats(const BamSource& bam, const RegionSpec* region, const BedFilte
 }
 
 struct Quota { bool all = false; size_t n = 0; };
+// SamplingSchedule::from_num_reads (sampling_schedule.rs:171-273): per contig ceil(N * its share of the reads), capped by its count; while the
+// sum overshoots N by more than half, contigs at or under a rising floor are dropped (the reference walks an FxHashMap there; ascending tid
+// here — order unpinned)
+std::map<uint32_t, Quota> quota_from_num_reads(const IdxStats& st, size_t num_reads, bool include_unmapped) {
+  const uint64_t total_u = include_unmapped ? st.mapped + st.unmapped : st.mapped;
+  if (total_u == 0) throw Error(MKP_E_THRESHOLD, "zero reads found in bam index");
+  std::map<uint32_t, Quota> quota;
+  const float total = (float)total_u; size_t sum = 0;
+  for (auto& kv : st.mapped_by_tid) if (kv.second) { Quota q;
+    q.n = std::min<size_t>((size_t)ceilf((float)num_reads * ((float)kv.second / total)), (size_t)kv.second);
+    sum += q.n; quota[(uint32_t)kv.first] = q; }
+  if (include_unmapped) sum += (size_t)ceilf((float)num_reads * ((float)st.unmapped / total));
+  size_t floor = 1;
+  while ((double)sum / (double)num_reads > 1.5) {
+    for (auto& kv : quota) { if (kv.second.n <= floor) { sum -= kv.second.n; kv.second.n = 0; } if (sum <= num_reads) break; }
+    sum = 0; for (auto& kv : quota) sum += kv.second.n; floor++;
+  }
+  for (auto it = quota.begin(); it != quota.end();) { if (!it->second.all && it->second.n == 0) it = quota.erase(it); else ++it; }
+  return quota;
+}
 struct SampleTimes { double fetch_ms = 0, device_ms = 0, decide_ms = 0; uint64_t rounds = 0, reads = 0; };
 SampleTimes g_sample_times;   // --stats: where the threshold estimate's time went (last run in this process)
 
@@ -230,7 +250,8 @@ void sample_serial(mkp_ctx* ctx, const BamSource& bam, const Args& a, const Regi
       const size_t hi = std::min(cand.size(), next + want);
       std::vector<mkp_record> recs; recs.reserve(hi - next); for (size_t i = next; i < hi; i++) recs.push_back(b.view(b.recs[cand[i]]));
       std::vector<uint32_t> nv;
-      int rc = mkp_internal_sample(ctx, mapped ? (int32_t)tid : -1, 0, mapped ? bam.ref_lens[(size_t)tid] : 1, mask, recs.data(), (uint32_t)recs.size(),
+      int rc = mkp_internal_sample(ctx, mapped ? (int32_t)tid : -1, 0, mapped ? bam.ref_lens[(size_t)tid] : 1, mask, recs.data(),
+          (uint32_t)recs.size(),
           only_mapped, &nv);
       if (rc != MKP_OK) throw Error(rc, mkp_last_error(ctx));
       std::vector<uint8_t> keep(recs.size(), 0);
@@ -1821,18 +1842,58 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     // With an index (and without --ignore-index) the reference walks interval chunks of the targets: --region then selects the records its
     // fetches return — every record overlapping the region, once — where the serial scan looks at every record of the file.  The reference's
     // rows leave in the order its pool finishes the intervals; here in file order.  --num-reads: the serial path's "first N records that
-    // reach process_record"; on an indexed BAM it follows the sampling schedule, which is not restated for this subcommand.
+    // reach process_record"; on an indexed BAM it follows the sampling schedule (below).
     BedFilter bed; const bool have_bed = !a.include_bed.empty();
     if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;
       bed = BedFilter::load(a.include_bed, c2t); }
     bool use_index = false; { FILE* probe = fopen((a.in_bam + ".bai").c_str(), "rb"); if (probe) { fclose(probe); use_index = !ignore_index; } }
-    if (use_index && num_reads >= 0) throw Error(MKP_E_UNSUPPORTED,
-        "extract calls: --num-reads on an indexed BAM follows the reference's sampling schedule, which is not restated for this subcommand (--ignore-index: the first N records)");
+    const bool scheduled = use_index && num_reads >= 0;
+    if (scheduled && have_bed) throw Error(MKP_E_UNSUPPORTED,
+        "extract calls: --num-reads with --include-bed on an indexed BAM walks the BED-optimised intervals of the sampling schedule, which is not restated for this subcommand (--ignore-index: the first N records)");
     int64_t reg_tid = -1, reg_s = 0, reg_e = 0; const bool have_region = !a.region.empty();
     if (have_region) {
       std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0); const RegionSpec rg = parse_region(a.region, *src);
       for (size_t t = 0; t < bd.ref_names.size(); t++) if (bd.ref_names[t] == rg.name) reg_tid = (int64_t)t;
       reg_s = rg.start; reg_e = rg.end;
+    }
+    // --num-reads with an index (run_extract_reads, src/extract/util.rs:329-470; subcommand.rs:662-683): SamplingSchedule::from_num_reads over the
+    // index counts; every interval of the feeder — threads * 1.5 groups of >= --interval-size bases per super batch — has a RecordSampler
+    // of its own: ceil(contig count * interval length / length of the whole super batch) records (get_record_sampler, sampling_schedule.rs:
+    // 417-438).  An interval's records are the ones its fetch returns that do not start in front of the previous interval's end — in a
+    // sorted file: the records that start inside it (the first interval of a region also takes the records reaching into it) — and it takes
+    // the first that many whose process_record succeeds.  Then the records without coordinates, unless a region / --mapped-only excludes
+    // them: the first (N - used) that reach process_record.  Rows leave in interval order (the reference: in pool order).
+    struct IvQuota { long nr; long used; };   // nr < 0: every record (CountOrSample::All does not arise from --num-reads)
+    std::map<uint32_t, std::vector<IvQuota>> iv_quota;   // per contig with reads: its intervals from the contig's (region's) start
+    std::map<uint32_t, uint32_t> iv_origin;
+    const bool include_unmapped_reads = !have_region && !mapped_only;   // load_regions (util.rs:136-155)
+    size_t aligned_used = 0;
+    if (scheduled) {
+      std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0);
+      RegionSpec rg; if (have_region) rg = parse_region(a.region, *src);
+      const IdxStats st = idxstats(*src, have_region ? &rg : nullptr, nullptr);
+      const std::map<uint32_t, Quota> quota = quota_from_num_reads(st, (size_t)num_reads, include_unmapped_reads);
+      const size_t batch_size = std::max<size_t>((size_t)floorf((float)a.threads * 1.5f), 1);
+      struct Iv { uint32_t tid, start, end; };
+      std::vector<std::vector<Iv>> groups;   // MultiChromCoordinates in feeder order (interval_chunks.rs:563-643)
+      { std::vector<Iv> g; uint32_t glen = 0;
+        for (auto& c : targets(*src, have_region ? &rg : nullptr)) {
+          iv_origin[c.tid] = c.start;
+          for (uint32_t p = c.start; p < c.end();) { const uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.interval_size, c.end());
+            g.push_back({c.tid, p, e}); glen += e - p;
+            if (glen >= a.interval_size) { groups.push_back(g); g.clear(); glen = 0; }
+            p = e; } }
+        if (!g.empty()) groups.push_back(g); }
+      for (size_t g0 = 0; g0 < groups.size(); g0 += batch_size) {
+        uint64_t total_len = 0;
+        for (size_t g = g0; g < std::min(groups.size(), g0 + batch_size); g++) for (auto& iv : groups[g]) total_len += iv.end - iv.start;
+        for (size_t g = g0; g < std::min(groups.size(), g0 + batch_size); g++) for (auto& iv : groups[g]) {
+          auto q = quota.find(iv.tid);
+          const long nr = q == quota.end() ? 0 /* chrom_has_reads: never fetched */
+              : (long)std::ceil((double)q->second.n * ((double)(iv.end - iv.start) / (double)(uint32_t)total_len));
+          iv_quota[iv.tid].push_back({q == quota.end() ? -2 : nr, 0});
+        }
+      }
     }
     long n_sent = 0; bool done = false;
     FILE* out = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w+");
@@ -1859,9 +1920,17 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           const int64_t e = (int64_t)r.pos + std::max<int64_t>(span, 1);
           if (r.tid != reg_tid || (int64_t)r.pos >= reg_e || e <= reg_s) continue;
         }
+        if (scheduled && r.tid < 0) {   // the schedule's last leg: process_records_to_chan(.., only_mapped = false, allow_non_primary = false, ..)
+          if (!include_unmapped_reads) continue;
+          if (r.flag & (2048 | 256 | 1024)) { n_skipped++; continue; }
+          if (r.l_qseq <= 0) { n_failed++; continue; }
+          recs.push_back(r); continue;
+        }
+        if (scheduled && !have_region && r.tid >= 0 && (size_t)r.tid < bd.ref_lens.size() && (int64_t)r.pos >= (int64_t)bd.ref_lens[(size_t)r.tid])
+          continue;   // (starts behind its contig: no interval fetches it)
         if ((r.flag & (2048 | 256 | 1024)) && !allow_np) { n_skipped++; continue; }
         if (r.l_qseq <= 0) { n_failed++; continue; }
-        if ((r.flag & 4) && mapped_only) { n_skipped++; continue; }
+        if ((r.flag & 4) && mapped_only && !scheduled) { n_skipped++; continue; }   // (the schedule's samplers never ask about mapping)
         recs.push_back(r);
       }
       if (recs.empty()) continue;
@@ -1875,8 +1944,31 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         if (done) break;
         // --num-reads counts what reaches process_record: records whose tags parse and hold something (an unmapped record under --mapped-only
         // never gets that far: dropped above)
+        if (scheduled && r.tid >= 0) {
+          auto qi = iv_quota.find((uint32_t)r.tid); if (qi == iv_quota.end() || qi->second.empty()) continue;
+          const uint32_t origin = iv_origin[(uint32_t)r.tid];
+          const size_t idx = std::min<size_t>((int64_t)r.pos < (int64_t)origin ? 0 : ((size_t)r.pos - origin) / a.interval_size,
+              qi->second.size() - 1);
+          IvQuota& Q = qi->second[idx];
+          if (Q.nr == -2) continue;                                                        // the schedule holds nothing for this contig
+          if (!ro.ok) { if (h.flags & MKP_RF_BAD) n_failed++; else n_skipped++; continue; }  // TrackingModRecordIter never offers it
+          if (Q.nr >= 0 && Q.used >= Q.nr) continue;                                       // RecordSampler::ask -> Done
+          bool clips_ok = true;                                                            // process_record's own failure: get_soft_clipped
+          if (!(r.flag & 4)) { const uint8_t* cgp = r.data + r.l_qname; bool other = false;
+            for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cgp + 4 * (size_t)k, 4); if ((w & 15u) != 4u) { other = true; break; } }
+            clips_ok = other; }
+          if (!clips_ok) { n_failed++; continue; }
+          Q.used++; aligned_used++;
+          if (mapped_only && (r.flag & 4)) continue;                                       // every row of an unmapped record lacks a reference position
+          if (!ro.n_events) continue;
+        } else if (scheduled) {
+          const long n_un = num_reads > (long)aligned_used ? num_reads - (long)aligned_used : 0;
+          if (ro.ok) { n_sent++; if (n_sent >= n_un) done = true; }   // (looked at after the record went to the writer: N = 0 lets one through)
+          if (!ro.ok || !ro.n_events) { if (h.flags & MKP_RF_BAD) n_failed++; else n_skipped++; continue; }
+        } else {
         if (ro.ok) { n_sent++; if (num_reads >= 0 && n_sent >= num_reads) done = true; }
         if (!ro.ok || !ro.n_events) { if (h.flags & MKP_RF_BAD) n_failed++; else n_skipped++; continue; }
+        }
         const bool unmapped = (r.flag & 4) != 0, rev = (r.flag & 16) != 0;
         const size_t L = (size_t)r.l_qseq;
         const uint8_t* cg = r.data + r.l_qname; const uint8_t* sq = cg + 4 * (size_t)r.n_cigar; const uint8_t* ql = sq + (L + 1) / 2;

@@ -512,7 +512,8 @@ static std::vector<const BamRecord*> fetch(const BamFile& bam, uint32_t tid, uin
 // bam::IndexedReader::from_path(..).is_ok() (reads_sampler/mod.rs:47): htslib finds <bam>.bai, <bam>.csi or the extension replaced
 static bool bam_has_index(const std::string& path) {
   std::vector<std::string> c = {path + ".bai", path + ".csi"};
-  if (path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0) { c.push_back(path.substr(0, path.size() - 4) + ".bai"); c.push_back(path.substr(0, path.size() - 4) + ".csi"); }
+  if (path.size() > 4 && path.compare(path.size() - 4, 4, ".bam") == 0) { c.push_back(path.substr(0, path.size() - 4) + ".bai");
+    c.push_back(path.substr(0, path.size() - 4) + ".csi"); }
   for (auto& f : c) { FILE* p = fopen(f.c_str(), "rb"); if (p) { fclose(p); return true; } }
   return false;
 }
@@ -886,10 +887,13 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
   // With an index (and without --ignore-index) the reference walks interval chunks of the targets (util.rs:329-470): --region then selects the
   // records the fetches of its intervals return — every record overlapping it, once (prev_end) — where the serial scan looks at every record
   // of the file.  Its rows leave in whatever order the pool finishes the intervals; here: file order.  --num-reads with an index goes through
-  // the sampling schedule, which is not restated for this subcommand.
+  // the sampling schedule (`scheduled` below).
   FILE* probe = fopen((o.in_bam + ".bai").c_str(), "rb"); const bool use_index = probe && !xo.ignore_index; if (probe) fclose(probe);
-  if (use_index
-      && xo.num_reads >= 0) throw MkErr("extract calls --num-reads on an indexed BAM follows the sampling schedule: not restated (use --ignore-index for the first N records)");
+  // --num-reads with an index: the sampling schedule per interval (below).  Together with --include-bed the intervals are the BED-optimised
+  // reference records, which the device driver does not restate for this subcommand: refused on both sides.
+  const bool scheduled = use_index && xo.num_reads >= 0;
+  if (scheduled
+      && pf) throw MkErr("extract calls --num-reads with --include-bed on an indexed BAM: not restated (use --ignore-index for the first N records)");
   const int region_tid = have_region ? bam.tid_of(region.name) : -1;
   EdgeFilter edge;
   if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) {
@@ -922,6 +926,64 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
   if (!xo.no_headers) fputs(extract_calls_header(), out);
   uint64_t n_used = 0, n_skipped = 0, n_failed = 0, n_rows = 0;
   long n_sent = 0;
+  if (scheduled) {
+    // run_extract_reads with an index and --num-reads (src/extract/util.rs:329-470, subcommand.rs:662-683): SamplingSchedule::from_num_reads
+    // over the index counts; every interval of the feeder (threads * 1.5 groups per super batch, no BED here) gets a RecordSampler of its
+    // own — ceil(chrom count * interval length / length of the whole super batch) records (get_record_sampler, sampling_schedule.rs:417-438) —
+    // and takes, of the records its fetch returns that do not start in front of the previous interval's end (`cut`), the first that many
+    // whose process_record succeeds (ReadsBaseModProfile::process_records, read_ids_to_base_mod_probs.rs:884-945).  Then, unless a region /
+    // --mapped-only excludes them, the records without coordinates: the first (N - used) that reach process_record.  The reference's
+    // rows leave in pool order; here in interval order.
+    const bool include_unmapped_reads = !have_region && !xo.mapped_only;   // load_regions (util.rs:136-155), no BED / motif here
+    IdxStats st = IdxStats::make(bam, have_region ? &region : nullptr, nullptr);
+    SamplingSchedule sched = SamplingSchedule::from_num_reads(st, (size_t)xo.num_reads, include_unmapped_reads);
+    Feeder feeder(get_targets(bam, have_region ? &region : nullptr), (size_t)floorf((float)o.threads * 1.5f), o.interval_size, false, nullptr,
+        nullptr);
+    ExtractOptions xs = xo; xs.ask_unmapped = true;   // (this path never drops a record for being unmapped: its rows go with the position filter)
+    std::vector<MultiChromCoordinates> super_batch; bool have_prev = false; uint32_t prev_tid = 0, prev_end = 0; size_t aligned_used = 0;
+    auto emit = [&](const std::string& rows) { n_used++; for (char c : rows) if (c == '\n') n_rows++; fputs(rows.c_str(), out); };
+    while (feeder.next_batch(&super_batch)) {
+      uint64_t total_len = 0; for (auto& m : super_batch) for (auto& c : m) total_len += c.len();
+      for (auto& m : super_batch) for (auto& cc : m) {
+        const bool cut = have_prev && prev_tid == cc.tid; const uint32_t cut_at = prev_end;
+        have_prev = true; prev_tid = cc.tid; prev_end = cc.end;
+        auto sc = sched.counts.find(cc.tid); if (sc == sched.counts.end()) continue;   // chrom_has_reads
+        long nr = -1;
+        if (sc->second.k == Count::COUNT) nr = (long)ceil((double)sc->second.n * ((double)(cc.end - cc.start) / (double)(uint32_t)total_len));
+        long used = 0;
+        for (const BamRecord* rp : fetch(bam, cc.tid, cc.start, cc.end)) {
+          const BamRecord& r = *rp;
+          if (cut && (int64_t)r.pos < (int64_t)cut_at) continue;
+          std::string rows; bool skipped = false, sent = false;
+          const bool ok = extract_calls_of_record(bam, r, xs, collapse, edge, caller, ref_seqs, &rows, &skipped, &sent);
+          if (!sent) { if (!ok) n_failed++; else n_skipped++; continue; }   // TrackingModRecordIter never offers it
+          if (nr >= 0 && used >= nr) break;                                   // RecordSampler::ask -> Done
+          if (!ok) { n_failed++; continue; }
+          used++; aligned_used++;
+          if (xo.mapped_only && (r.flag & 4)) continue;                       // every row of an unmapped record lacks a reference position
+          emit(rows);
+        }
+      }
+    }
+    if (include_unmapped_reads) {
+      const long n_un = (long)((size_t)xo.num_reads > aligned_used ? (size_t)xo.num_reads - aligned_used : 0);
+      ExtractOptions xu = xo; xu.allow_non_primary = false; xu.mapped_only = false;
+      for (const BamRecord& r : bam.recs) {
+        if (r.tid >= 0) continue;
+        std::string rows; bool skipped = false, sent = false;
+        const bool ok = extract_calls_of_record(bam, r, xu, collapse, edge, caller, ref_seqs, &rows, &skipped, &sent);
+        if (sent) n_sent++;
+        // process_records_to_chan (util.rs:519-575) looks at its count AFTER a record went to the writer: N = 0 still lets one through
+        const bool done = sent && n_sent >= n_un;
+        if (!ok) n_failed++; else if (skipped) n_skipped++; else emit(rows);
+        if (done) break;
+      }
+    }
+    if (out != stdout) fclose(out);
+    fprintf(stderr, "[oracle] extract calls (scheduled): reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used,
+        (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);
+    return 0;
+  }
   for (const BamRecord& r : bam.recs) {
     // IndexedReader::fetch(tid, start, end): records overlapping the region (a record without reference span counts as one base)
     if (use_index && have_region) {
@@ -959,7 +1021,8 @@ int main(int argc, char** argv) {
   o.hemi = std::string(argv[1]) == "pileup-hemi";
   const bool summary_cmd = std::string(argv[1]) == "summary";
   o.sample_probs_cmd = std::string(argv[1]) == "sample-probs" || summary_cmd;
-  o.serial_sampler = o.sample_probs_cmd || extract_cmd;   // (`pileup` needs an index in the reference; here it keeps the schedule over scanned counts)
+  // (`pileup` needs an index in the reference; here it keeps the schedule over scanned counts)
+  o.serial_sampler = o.sample_probs_cmd || extract_cmd;
   // --only-mapped is off by default; -i is the sampling interval
   if (o.sample_probs_cmd) { o.include_unmapped = true; o.sampling_interval_size = 1000000; }
   try {

@@ -68,6 +68,7 @@ struct ExtractOptions {
   // round 6: --num-reads (the serial path's "first N records", util.rs:519-575), --ignore-index, --include-bed (ReferencePositionFilter::keep,
   // util.rs:44-69: the BED is asked with the REFERENCE strand of the mod; rows without a reference position go), --region (util.rs:126-160)
   long num_reads = -1; bool ignore_index = false;
+  bool ask_unmapped = false;   // the scheduled path (ReadsBaseModProfile::process_records) never asks whether a record is mapped
   std::function<bool(int32_t, uint64_t, bool /*reference mod strand is '-'*/)> include;   // empty: no --include-bed
 };
 
@@ -95,7 +96,7 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
   try { info = mod_base_info_from_record(r); } catch (const MkErr&) { return false; }
   if (info.is_empty()) { *skipped = true; return true; }
   const bool unmapped = (r.flag & 4) != 0;
-  if (unmapped && o.mapped_only) { *skipped = true; return true; }
+  if (unmapped && o.mapped_only && !o.ask_unmapped) { *skipped = true; return true; }
   if (sent) *sent = true;
   const bool rev = r.is_reverse();
   const size_t L = (size_t)r.l_seq;

@@ -36,7 +36,12 @@ FLAG_SETS = [
     ["--region", "ctgA:2000-7000", "--filter-threshold", "0.7"],            # indexed input: the records overlapping the region
     ["--region", "ctgA:2000-7000", "--ignore-index", "--no-filtering"],     # serial scan: the region only steers the estimate
     ["--num-reads", "57", "--ignore-index", "--no-filtering"],              # the first 57 records that reach process_record
-    ["--num-reads", "40", "--no-filtering"],                                # indexed: the sampling schedule — refused by both
+    ["--num-reads", "40", "--no-filtering"],                                # indexed: the sampling schedule, one RecordSampler per interval
+    ["--num-reads", "25", "-i", "700", "--region", "ctgA:1000-9000", "--filter-threshold", "0.7"],
+    ["--num-reads", "60", "--mapped-only", "-t", "2", "-i", "500", "--no-filtering"],
+    ["--num-reads", "1", "--no-filtering", "--allow-non-primary"],
+    ["--num-reads", "400", "-i", "2500", "-p", "0.25"],                     # more than the file holds: quotas capped by the index counts
+    ["--num-reads", "30", "--include-bed", "{bed}", "--no-filtering"],      # indexed + BED: the BED-optimised intervals — refused by both
     ["--include-bed", "{bed}", "--region", "ctgA", "-p", "0.3", "--mapped-only"],   # estimate under BED + region
 ]
 
