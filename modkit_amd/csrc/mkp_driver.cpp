@@ -1848,8 +1848,6 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       bed = BedFilter::load(a.include_bed, c2t); }
     bool use_index = false; { FILE* probe = fopen((a.in_bam + ".bai").c_str(), "rb"); if (probe) { fclose(probe); use_index = !ignore_index; } }
     const bool scheduled = use_index && num_reads >= 0;
-    if (scheduled && have_bed) throw Error(MKP_E_UNSUPPORTED,
-        "extract calls: --num-reads with --include-bed on an indexed BAM walks the BED-optimised intervals of the sampling schedule, which is not restated for this subcommand (--ignore-index: the first N records)");
     int64_t reg_tid = -1, reg_s = 0, reg_e = 0; const bool have_region = !a.region.empty();
     if (have_region) {
       std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0); const RegionSpec rg = parse_region(a.region, *src);
@@ -1863,22 +1861,23 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     // sorted file: the records that start inside it (the first interval of a region also takes the records reaching into it) — and it takes
     // the first that many whose process_record succeeds.  Then the records without coordinates, unless a region / --mapped-only excludes
     // them: the first (N - used) that reach process_record.  Rows leave in interval order (the reference: in pool order).
-    struct IvQuota { long nr; long used; };   // nr < 0: every record (CountOrSample::All does not arise from --num-reads)
-    std::map<uint32_t, std::vector<IvQuota>> iv_quota;   // per contig with reads: its intervals from the contig's (region's) start
-    std::map<uint32_t, uint32_t> iv_origin;
-    const bool include_unmapped_reads = !have_region && !mapped_only;   // load_regions (util.rs:136-155)
+    struct IvQuota { uint32_t start, end; long nr; long used; };   // nr == -2: the schedule holds nothing for the contig (never fetched)
+    std::map<uint32_t, std::vector<IvQuota>> iv_quota;              // per contig: the feeder's intervals, ascending and disjoint
+    const bool include_unmapped_reads = !have_region && !mapped_only && !have_bed;   // load_regions (util.rs:136-155)
     size_t aligned_used = 0;
     if (scheduled) {
       std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0);
       RegionSpec rg; if (have_region) rg = parse_region(a.region, *src);
-      const IdxStats st = idxstats(*src, have_region ? &rg : nullptr, nullptr);
+      const IdxStats st = idxstats(*src, have_region ? &rg : nullptr, have_bed ? &bed : nullptr);
       const std::map<uint32_t, Quota> quota = quota_from_num_reads(st, (size_t)num_reads, include_unmapped_reads);
       const size_t batch_size = std::max<size_t>((size_t)floorf((float)a.threads * 1.5f), 1);
       struct Iv { uint32_t tid, start, end; };
       std::vector<std::vector<Iv>> groups;   // MultiChromCoordinates in feeder order (interval_chunks.rs:563-643)
       { std::vector<Iv> g; uint32_t glen = 0;
-        for (auto& c : targets(*src, have_region ? &rg : nullptr)) {
-          iv_origin[c.tid] = c.start;
+        // (--include-bed: every run of BED spans is a reference record of its own — optimize_reference_records, util.rs:287-296)
+        std::vector<Contig> recs_t = targets(*src, have_region ? &rg : nullptr);
+        if (have_bed) recs_t = bed_contigs(bed, recs_t, a.interval_size);
+        for (auto& c : recs_t) {
           for (uint32_t p = c.start; p < c.end();) { const uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)p + a.interval_size, c.end());
             g.push_back({c.tid, p, e}); glen += e - p;
             if (glen >= a.interval_size) { groups.push_back(g); g.clear(); glen = 0; }
@@ -1891,7 +1890,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           auto q = quota.find(iv.tid);
           const long nr = q == quota.end() ? 0 /* chrom_has_reads: never fetched */
               : (long)std::ceil((double)q->second.n * ((double)(iv.end - iv.start) / (double)(uint32_t)total_len));
-          iv_quota[iv.tid].push_back({q == quota.end() ? -2 : nr, 0});
+          iv_quota[iv.tid].push_back({iv.start, iv.end, q == quota.end() ? -2 : nr, 0});
         }
       }
     }
@@ -1926,8 +1925,6 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           if (r.l_qseq <= 0) { n_failed++; continue; }
           recs.push_back(r); continue;
         }
-        if (scheduled && !have_region && r.tid >= 0 && (size_t)r.tid < bd.ref_lens.size() && (int64_t)r.pos >= (int64_t)bd.ref_lens[(size_t)r.tid])
-          continue;   // (starts behind its contig: no interval fetches it)
         if ((r.flag & (2048 | 256 | 1024)) && !allow_np) { n_skipped++; continue; }
         if (r.l_qseq <= 0) { n_failed++; continue; }
         if ((r.flag & 4) && mapped_only && !scheduled) { n_skipped++; continue; }   // (the schedule's samplers never ask about mapping)
@@ -1946,10 +1943,16 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         // never gets that far: dropped above)
         if (scheduled && r.tid >= 0) {
           auto qi = iv_quota.find((uint32_t)r.tid); if (qi == iv_quota.end() || qi->second.empty()) continue;
-          const uint32_t origin = iv_origin[(uint32_t)r.tid];
-          const size_t idx = std::min<size_t>((int64_t)r.pos < (int64_t)origin ? 0 : ((size_t)r.pos - origin) / a.interval_size,
-              qi->second.size() - 1);
-          IvQuota& Q = qi->second[idx];
+          // the interval that takes the record: the first one (feeder order) whose fetch returns it and whose `cut` — the previous interval's
+          // end — does not lie behind its start: the first interval that ends behind the record's start, if the record reaches it at all
+          int64_t rspan = 0; { const uint8_t* cgp = r.data + r.l_qname;
+            for (uint32_t k = 0; k < r.n_cigar; k++) { uint32_t w; memcpy(&w, cgp + 4 * (size_t)k, 4); const uint32_t op = w & 15u;
+              if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rspan += w >> 4; } }
+          const int64_t rend = (int64_t)r.pos + std::max<int64_t>(rspan, 1);
+          auto it = std::upper_bound(qi->second.begin(), qi->second.end(), (int64_t)r.pos,
+              [](int64_t p, const IvQuota& q) { return p < (int64_t)q.end; });
+          if (it == qi->second.end() || (int64_t)it->start >= rend) continue;
+          IvQuota& Q = *it;
           if (Q.nr == -2) continue;                                                        // the schedule holds nothing for this contig
           if (!ro.ok) { if (h.flags & MKP_RF_BAD) n_failed++; else n_skipped++; continue; }  // TrackingModRecordIter never offers it
           if (Q.nr >= 0 && Q.used >= Q.nr) continue;                                       // RecordSampler::ask -> Done

@@ -889,11 +889,8 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
   // of the file.  Its rows leave in whatever order the pool finishes the intervals; here: file order.  --num-reads with an index goes through
   // the sampling schedule (`scheduled` below).
   FILE* probe = fopen((o.in_bam + ".bai").c_str(), "rb"); const bool use_index = probe && !xo.ignore_index; if (probe) fclose(probe);
-  // --num-reads with an index: the sampling schedule per interval (below).  Together with --include-bed the intervals are the BED-optimised
-  // reference records, which the device driver does not restate for this subcommand: refused on both sides.
+  // --num-reads with an index: the sampling schedule per interval (below); with --include-bed over the BED-optimised reference records
   const bool scheduled = use_index && xo.num_reads >= 0;
-  if (scheduled
-      && pf) throw MkErr("extract calls --num-reads with --include-bed on an indexed BAM: not restated (use --ignore-index for the first N records)");
   const int region_tid = have_region ? bam.tid_of(region.name) : -1;
   EdgeFilter edge;
   if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) {
@@ -934,11 +931,12 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
     // whose process_record succeeds (ReadsBaseModProfile::process_records, read_ids_to_base_mod_probs.rs:884-945).  Then, unless a region /
     // --mapped-only excludes them, the records without coordinates: the first (N - used) that reach process_record.  The reference's
     // rows leave in pool order; here in interval order.
-    const bool include_unmapped_reads = !have_region && !xo.mapped_only;   // load_regions (util.rs:136-155), no BED / motif here
-    IdxStats st = IdxStats::make(bam, have_region ? &region : nullptr, nullptr);
+    const bool include_unmapped_reads = !have_region && !xo.mapped_only && !pf;   // load_regions (util.rs:136-155), no BED / motif here
+    IdxStats st = IdxStats::make(bam, have_region ? &region : nullptr, pf);
     SamplingSchedule sched = SamplingSchedule::from_num_reads(st, (size_t)xo.num_reads, include_unmapped_reads);
-    Feeder feeder(get_targets(bam, have_region ? &region : nullptr), (size_t)floorf((float)o.threads * 1.5f), o.interval_size, false, nullptr,
-        nullptr);
+    std::vector<ReferenceRecord> sched_records = get_targets(bam, have_region ? &region : nullptr);
+    if (pf) sched_records = optimize_reference_records(*pf, sched_records, o.interval_size);   // load_regions (util.rs:287-296)
+    Feeder feeder(sched_records, (size_t)floorf((float)o.threads * 1.5f), o.interval_size, false, nullptr, nullptr);
     ExtractOptions xs = xo; xs.ask_unmapped = true;   // (this path never drops a record for being unmapped: its rows go with the position filter)
     std::vector<MultiChromCoordinates> super_batch; bool have_prev = false; uint32_t prev_tid = 0, prev_end = 0; size_t aligned_used = 0;
     auto emit = [&](const std::string& rows) { n_used++; for (char c : rows) if (c == '\n') n_rows++; fputs(rows.c_str(), out); };

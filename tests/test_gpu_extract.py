@@ -41,7 +41,8 @@ FLAG_SETS = [
     ["--num-reads", "60", "--mapped-only", "-t", "2", "-i", "500", "--no-filtering"],
     ["--num-reads", "1", "--no-filtering", "--allow-non-primary"],
     ["--num-reads", "400", "-i", "2500", "-p", "0.25"],                     # more than the file holds: quotas capped by the index counts
-    ["--num-reads", "30", "--include-bed", "{bed}", "--no-filtering"],      # indexed + BED: the BED-optimised intervals — refused by both
+    ["--num-reads", "30", "--include-bed", "{bed}", "--no-filtering"],      # indexed + BED: the schedule over the BED-optimised reference records
+    ["--num-reads", "45", "--include-bed", "{bed}", "-i", "300", "--region", "ctgA", "--filter-threshold", "0.6"],
     ["--include-bed", "{bed}", "--region", "ctgA", "-p", "0.3", "--mapped-only"],   # estimate under BED + region
 ]
 
