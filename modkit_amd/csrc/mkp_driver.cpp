@@ -1777,7 +1777,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
   mkp_ctx* ctx = nullptr;
   struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
   try {
-    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false;
+    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false, ignore_implicit = false;
       size_t kmer = 5; int device = 0; long num_reads = -1;
     std::vector<std::string> rest;
     for (int i = 0; i < argc; i++) {
@@ -1790,7 +1790,8 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       else if (s == "--force" || s == "--suppress-progress") {} else if (s == "--device") device = std::stoi(val());
         else if (s == "--stats") stats = true;
       else if (s == "--num-reads") num_reads = std::stol(val()); else if (s == "--ignore-index") ignore_index = true;
-      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--ignore-implicit" || s == "--bgzf"
+      else if (s == "--ignore-implicit") ignore_implicit = true;
+      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--bgzf"
           || s == "--cpg" || s == "--seed")
         throw Error(MKP_E_UNSUPPORTED,
             "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --num-reads / --ignore-index are; see include/mkpileup.h)");
@@ -1848,6 +1849,9 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       bed = BedFilter::load(a.include_bed, c2t); }
     bool use_index = false; { FILE* probe = fopen((a.in_bam + ".bai").c_str(), "rb"); if (probe) { fclose(probe); use_index = !ignore_index; } }
     const bool scheduled = use_index && num_reads >= 0;
+    // --ignore-implicit: ReadBaseModProfile::remove_inferred runs in the reference's interval path only (src/extract/util.rs:413-419); its serial
+    // scan (no index, --ignore-index) takes the flag and never looks at it
+    const bool remove_inferred = ignore_implicit && use_index;
     int64_t reg_tid = -1, reg_s = 0, reg_e = 0; const bool have_region = !a.region.empty();
     if (have_region) {
       std::unique_ptr<BamSource> src = BamSource::open(a.in_bam, 0); const RegionSpec rg = parse_region(a.region, *src);
@@ -2032,6 +2036,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           any = true;
           const uint32_t tb = w.info & 3u, sg = (w.info >> 2) & 1u, inferred = (w.info >> 3) & 1u, thr_cls = (w.info >> 4) & 15u,
               arg_cls = (w.info >> 8) & 15u;
+          if (remove_inferred && inferred) continue;
           const bool filtered = thr_cls == 0;
           if (filtered && pass_only) continue;
           std::string code = "-";

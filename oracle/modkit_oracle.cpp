@@ -891,6 +891,7 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
   FILE* probe = fopen((o.in_bam + ".bai").c_str(), "rb"); const bool use_index = probe && !xo.ignore_index; if (probe) fclose(probe);
   // --num-reads with an index: the sampling schedule per interval (below); with --include-bed over the BED-optimised reference records
   const bool scheduled = use_index && xo.num_reads >= 0;
+  if (!use_index) xo.remove_inferred = false;   // process_records_to_chan (the serial scan) never removes inferred calls (util.rs:501-575)
   const int region_tid = have_region ? bam.tid_of(region.name) : -1;
   EdgeFilter edge;
   if (!o.edge_filter.empty()) { edge.active = true; edge.inverted = o.invert_edge; size_t c = o.edge_filter.find(','); if (c != std::string::npos) {
@@ -1039,6 +1040,7 @@ int main(int argc, char** argv) {
         if (a == "--kmer-size") { xo.kmer_size = std::stoul(val()); continue; }
         if (a == "--num-reads") { xo.num_reads = std::stol(val()); continue; }
         if (a == "--ignore-index") { xo.ignore_index = true; continue; }
+        if (a == "--ignore-implicit") { xo.remove_inferred = true; continue; }   // (only the interval path looks at it: cleared below without an index)
         if (a == "--force") continue;
       }
       if (o.sample_probs_cmd) {

@@ -68,6 +68,7 @@ struct ExtractOptions {
   // round 6: --num-reads (the serial path's "first N records", util.rs:519-575), --ignore-index, --include-bed (ReferencePositionFilter::keep,
   // util.rs:44-69: the BED is asked with the REFERENCE strand of the mod; rows without a reference position go), --region (util.rs:126-160)
   long num_reads = -1; bool ignore_index = false;
+  bool remove_inferred = false;   // --ignore-implicit where the reference honours it: its interval path only (util.rs:413-419)
   bool ask_unmapped = false;   // the scheduled path (ReadsBaseModProfile::process_records) never asks whether a record is mapped
   std::function<bool(int32_t, uint64_t, bool /*reference mod strand is '-'*/)> include;   // empty: no --include-bed
 };
@@ -140,6 +141,9 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
         });
     }
   }
+  if (o.remove_inferred) {   // ReadBaseModProfile::remove_inferred (read_ids_to_base_mod_probs.rs:765-775)
+    std::vector<ModProfileRow> k; for (auto& p : prof) if (!p.inferred) k.push_back(p);
+    prof.swap(k); }
   std::stable_sort(prof.begin(), prof.end(), [&](const ModProfileRow& a, const ModProfileRow& b) {
     return rev ? a.query_position > b.query_position : a.query_position < b.query_position; });
   // filter_read_base_mod_probs (util.rs:71-124): a profile with a reference position is asked of the BED (reference strand of the mod); one
