@@ -377,7 +377,8 @@ int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
  * SamplingSchedule::from_num_reads + get_record_sampler, src/reads_sampler/sampling_schedule.rs:171-273, 417-438): one sampler per interval
  * of the feeder (with --include-bed: of the BED-optimised reference records), then the records without coordinates; rows in interval order.
  * --ignore-implicit drops the inferred calls where the reference does: in its interval path (an index, no --ignore-index; util.rs:413-419) — its
- * serial scan takes the flag and never looks at it.  --exclude-bed, --motif / --cpg, --bgzf fail with MKP_E_UNSUPPORTED. */
+ * serial scan takes the flag and never looks at it.  --exclude-bed drops the rows whose reference position and reference mod strand the BED
+ * lists (ReferencePositionFilter::keep, util.rs:44-69).  --motif / --cpg, --bgzf fail with MKP_E_UNSUPPORTED. */
 int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
 /* ---- BGZF inflate on the device as a call of its own.  On the pileup path the same kernels run inside the device ingest

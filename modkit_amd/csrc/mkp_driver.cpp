@@ -1777,7 +1777,8 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
   mkp_ctx* ctx = nullptr;
   struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
   try {
-    std::string ref_path; bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false, ignore_implicit = false;
+    std::string ref_path, exclude_bed;
+      bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false, ignore_implicit = false;
       size_t kmer = 5; int device = 0; long num_reads = -1;
     std::vector<std::string> rest;
     for (int i = 0; i < argc; i++) {
@@ -1791,10 +1792,11 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         else if (s == "--stats") stats = true;
       else if (s == "--num-reads") num_reads = std::stol(val()); else if (s == "--ignore-index") ignore_index = true;
       else if (s == "--ignore-implicit") ignore_implicit = true;
-      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions" || s == "--motif" || s == "--bgzf"
+      else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions") exclude_bed = val();
+      else if (s == "--motif" || s == "--bgzf"
           || s == "--cpg" || s == "--seed")
         throw Error(MKP_E_UNSUPPORTED,
-            "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --num-reads / --ignore-index are; see include/mkpileup.h)");
+            "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --exclude-bed / --num-reads / --ignore-index / --ignore-implicit are; see include/mkpileup.h)");
       else rest.push_back(s);
     }
     if (kmer == 0 || kmer > 50) throw Error(MKP_E_INVALID, "kmer size must be less than or equal to 50");
@@ -1847,6 +1849,10 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     BedFilter bed; const bool have_bed = !a.include_bed.empty();
     if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;
       bed = BedFilter::load(a.include_bed, c2t); }
+    // --exclude-bed (load_regions, util.rs:177-187; ReferencePositionFilter::keep = include hit && !exclude hit): a row filter only
+    BedFilter exbed; const bool have_ex = !exclude_bed.empty();
+    if (have_ex) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;
+      exbed = BedFilter::load(exclude_bed, c2t); }
     bool use_index = false; { FILE* probe = fopen((a.in_bam + ".bai").c_str(), "rb"); if (probe) { fclose(probe); use_index = !ignore_index; } }
     const bool scheduled = use_index && num_reads >= 0;
     // --ignore-implicit: ReadBaseModProfile::remove_inferred runs in the reference's interval path only (src/extract/util.rs:413-419); its serial
@@ -2032,6 +2038,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
           if ((mapped_only || have_bed) && (unmapped || w.ref < 0)) continue;   // filter_read_base_mod_probs (src/extract/util.rs:71-124)
           // ... asked with the reference strand of the mod
           if (have_bed && !bed.contains((uint32_t)r.tid, (uint64_t)w.ref, (((w.info >> 2) & 1u) != 0) != rev)) continue;
+          if (have_ex && !unmapped && w.ref >= 0 && exbed.contains((uint32_t)r.tid, (uint64_t)w.ref, (((w.info >> 2) & 1u) != 0) != rev)) continue;
           if (!primary_or_unmapped && !within(w.f)) continue;                   // iter_profiles (read_ids_to_base_mod_probs.rs:785-800)
           any = true;
           const uint32_t tb = w.info & 3u, sg = (w.info >> 2) & 1u, inferred = (w.info >> 3) & 1u, thr_cls = (w.info >> 4) & 15u,

@@ -884,6 +884,11 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
     for (auto& rr : get_targets(bam, nullptr)) c2t[rr.name] = rr.tid;   // name_to_tid of the whole header (subcommand.rs:514-517), not of --region
     pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store;
     xo.include = [pf](int32_t tid, uint64_t p, bool neg) { return pf->contains(tid, p, neg); }; }
+  // --exclude-bed (load_regions, util.rs:177-187): a row filter only — neither the estimate nor the schedule looks at it
+  PositionFilter ex_store;
+  if (!xo.exclude_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& rr : get_targets(bam, nullptr)) c2t[rr.name] = rr.tid;
+    ex_store = PositionFilter::from_bed(xo.exclude_bed, c2t); const PositionFilter* ex = &ex_store;
+    xo.exclude = [ex](int32_t tid, uint64_t p, bool neg) { return ex->contains(tid, p, neg); }; }
   // With an index (and without --ignore-index) the reference walks interval chunks of the targets (util.rs:329-470): --region then selects the
   // records the fetches of its intervals return — every record overlapping it, once (prev_end) — where the serial scan looks at every record
   // of the file.  Its rows leave in whatever order the pool finishes the intervals; here: file order.  --num-reads with an index goes through
@@ -1040,7 +1045,9 @@ int main(int argc, char** argv) {
         if (a == "--kmer-size") { xo.kmer_size = std::stoul(val()); continue; }
         if (a == "--num-reads") { xo.num_reads = std::stol(val()); continue; }
         if (a == "--ignore-index") { xo.ignore_index = true; continue; }
-        if (a == "--ignore-implicit") { xo.remove_inferred = true; continue; }   // (only the interval path looks at it: cleared below without an index)
+        if (a == "--exclude-bed" || a == "-v" || a == "--exclude-positions") { xo.exclude_bed = val(); continue; }
+        // (only the interval path looks at it: cleared below without an index)
+        if (a == "--ignore-implicit") { xo.remove_inferred = true; continue; }
         if (a == "--force") continue;
       }
       if (o.sample_probs_cmd) {

@@ -62,7 +62,7 @@ static inline std::string kmer_revcomp(const std::string& k) {
 }
 
 struct ExtractOptions {
-  std::string in_bam, out_tsv, ref_fasta;
+  std::string in_bam, out_tsv, ref_fasta, exclude_bed;
   bool allow_non_primary = false, mapped_only = false, pass_only = false, no_headers = false;
   size_t kmer_size = 5;
   // round 6: --num-reads (the serial path's "first N records", util.rs:519-575), --ignore-index, --include-bed (ReferencePositionFilter::keep,
@@ -71,6 +71,7 @@ struct ExtractOptions {
   bool remove_inferred = false;   // --ignore-implicit where the reference honours it: its interval path only (util.rs:413-419)
   bool ask_unmapped = false;   // the scheduled path (ReadsBaseModProfile::process_records) never asks whether a record is mapped
   std::function<bool(int32_t, uint64_t, bool /*reference mod strand is '-'*/)> include;   // empty: no --include-bed
+  std::function<bool(int32_t, uint64_t, bool)> exclude;                                    // empty: no --exclude-bed (keep = include hit && !exclude hit)
 };
 
 struct ModProfileRow {   // ModProfile (read_ids_to_base_mod_probs.rs:381-397)
@@ -148,10 +149,14 @@ static inline bool extract_calls_of_record(const BamFile& bam, const BamRecord& 
     return rev ? a.query_position > b.query_position : a.query_position < b.query_position; });
   // filter_read_base_mod_probs (util.rs:71-124): a profile with a reference position is asked of the BED (reference strand of the mod); one
   // without goes under --mapped-only and under --include-bed (load_regions: "specifying include-only BED outputs only mapped sites")
-  if (o.mapped_only || o.include) {
+  if (o.mapped_only || o.include || o.exclude) {
+    // include_unmapped_positions (load_regions): --exclude-bed alone keeps them
+    const bool unmapped_positions_go = o.mapped_only || (bool)o.include;
     std::vector<ModProfileRow> k;
-    for (auto& p : prof) { if (unmapped || p.ref_position < 0) continue;
+    for (auto& p : prof) {
+      if (unmapped || p.ref_position < 0) { if (!unmapped_positions_go) k.push_back(p); continue; }
       if (o.include && !o.include(r.tid, (uint64_t)p.ref_position, (p.strand != 0) != rev)) continue;
+      if (o.exclude && o.exclude(r.tid, (uint64_t)p.ref_position, (p.strand != 0) != rev)) continue;
       k.push_back(p); }
     prof.swap(k);
   }

@@ -43,6 +43,8 @@ FLAG_SETS = [
     ["--num-reads", "400", "-i", "2500", "-p", "0.25"],                     # more than the file holds: quotas capped by the index counts
     ["--num-reads", "30", "--include-bed", "{bed}", "--no-filtering"],      # indexed + BED: the schedule over the BED-optimised reference records
     ["--num-reads", "45", "--include-bed", "{bed}", "-i", "300", "--region", "ctgA", "--filter-threshold", "0.6"],
+    ["--exclude-bed", "{bed}", "--no-filtering"],                           # keep = include hit && !exclude hit; rows without a reference position stay
+    ["--exclude-bed", "{bed}", "--mapped-only", "--filter-threshold", "0.7", "--num-reads", "80"],
     ["--ignore-implicit", "--no-filtering"],                                # honoured by the reference's interval path only (an index, no --ignore-index)
     ["--ignore-implicit", "--ignore-index", "--no-filtering"],              # ... and silently not by its serial scan
     ["--ignore-implicit", "--num-reads", "50", "--filter-threshold", "0.7"],
