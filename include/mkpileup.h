@@ -378,7 +378,9 @@ int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
  * of the feeder (with --include-bed: of the BED-optimised reference records), then the records without coordinates; rows in interval order.
  * --ignore-implicit drops the inferred calls where the reference does: in its interval path (an index, no --ignore-index; util.rs:413-419) — its
  * serial scan takes the flag and never looks at it.  --exclude-bed drops the rows whose reference position and reference mod strand the BED
- * lists (ReferencePositionFilter::keep, util.rs:44-69).  --motif / --cpg, --bgzf fail with MKP_E_UNSUPPORTED. */
+ * lists (ReferencePositionFilter::keep, util.rs:44-69).  --motif M off / --cpg (with --ref, --mask): the include filter becomes the motif hits
+ * over the whole contigs, intersected with --include-bed (load_regions, util.rs:157-277).  --seed goes to the estimate.  --bgzf fails with
+ * MKP_E_UNSUPPORTED. */
 int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
 /* ---- BGZF inflate on the device as a call of its own.  On the pileup path the same kernels run inside the device ingest

@@ -1777,7 +1777,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
   mkp_ctx* ctx = nullptr;
   struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
   try {
-    std::string ref_path, exclude_bed;
+    std::string ref_path, exclude_bed; std::vector<std::string> motif_parts; bool cpg = false;
       bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false, ignore_implicit = false;
       size_t kmer = 5; int device = 0; long num_reads = -1;
     std::vector<std::string> rest;
@@ -1793,10 +1793,9 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       else if (s == "--num-reads") num_reads = std::stol(val()); else if (s == "--ignore-index") ignore_index = true;
       else if (s == "--ignore-implicit") ignore_implicit = true;
       else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions") exclude_bed = val();
-      else if (s == "--motif" || s == "--bgzf"
-          || s == "--cpg" || s == "--seed")
-        throw Error(MKP_E_UNSUPPORTED,
-            "extract calls: " + s + " is outside what this library restates (file-order table; --region / --include-bed / --exclude-bed / --num-reads / --ignore-index / --ignore-implicit are; see include/mkpileup.h)");
+      else if (s == "--motif") { motif_parts.push_back(val()); motif_parts.push_back(val()); } else if (s == "--cpg") cpg = true;
+      else if (s == "--bgzf")
+        throw Error(MKP_E_UNSUPPORTED, "extract calls: " + s + " is outside what this library restates (plain-text table; see include/mkpileup.h)");
       else rest.push_back(s);
     }
     if (kmer == 0 || kmer > 50) throw Error(MKP_E_INVALID, "kmer size must be less than or equal to 50");
@@ -1806,10 +1805,53 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     Args a; parse_args((int)av.size(), av.data(), &a, true);
     // the flags of the threshold estimate (get_threshold_from_options, command_utils.rs:74-134): calls without a reference position count
     // unless --mapped-only (ReferencePositionFilter::only_mapped_positions, src/extract/util.rs:39-41)
+    const BamData bd = load_bam(a.in_bam, 0, false);
+    Fasta fasta; if (!ref_path.empty()) fasta = Fasta::load(ref_path);
+    BedFilter bed; bool have_bed = !a.include_bed.empty();
+    if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;
+      bed = BedFilter::load(a.include_bed, c2t); }
+    // --motif / --cpg (load_regions, src/extract/util.rs:157-277): the include filter becomes the motif hits over every contig of the FASTA that
+    // the header names — the whole sequence, lower case matching unless --mask — one position per hit and strand, intersected with the
+    // --include-bed positions when both are given.  From there on it IS the include filter: rows, the estimate (handed over as a BED file of
+    // its own), the schedule.
+    std::string motif_bed_path;
+    struct Unlink { std::string* p; ~Unlink() { if (!p->empty()) unlink(p->c_str()); } } unlink_motif_bed{&motif_bed_path};
+    if (cpg || !motif_parts.empty()) {
+      if (ref_path.empty()) throw Error(MKP_E_INVALID, "--motif / --cpg need --ref");
+      std::vector<std::string> parts = motif_parts;   // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
+      if (cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true;
+        if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
+      std::vector<Motif> motifs;
+      for (size_t i = 0; i + 1 < parts.size(); i += 2) motifs.push_back(Motif::parse(parts[i], std::stoul(parts[i + 1])));
+      BedFilter mf;
+      for (size_t t = 0; t < bd.ref_names.size(); t++) {
+        const FastaSeq* sq = fasta.get(bd.ref_names[t]); if (!sq) continue;
+        std::map<uint32_t, Rule> hits;
+        for (auto& m : motifs) motif_hits(sq->data(), sq->size(), m, 0, (uint32_t)t, have_bed ? &bed : nullptr, &hits, !a.mask);
+        auto& P = mf.pos[(uint32_t)t]; auto& N = mf.neg[(uint32_t)t];   // (a searched contig is in the filter even without a hit)
+        for (auto& kv : hits) { if (kv.second & R_POS) P.push_back({kv.first, (uint64_t)kv.first + 1});
+          if (kv.second & R_NEG) N.push_back({kv.first, (uint64_t)kv.first + 1}); }
+        merge_spans(P); merge_spans(N);
+      }
+      bed = std::move(mf); have_bed = true;
+      char tmpl[] = "/tmp/mkp_motif_bed_XXXXXX"; const int fd = mkstemp(tmpl);
+      if (fd < 0) throw Error(MKP_E_IO, "cannot create a temporary BED for the motif positions");
+      motif_bed_path = tmpl; FILE* bf_out = fdopen(fd, "w");
+      for (auto* mp : {&bed.pos, &bed.neg}) for (auto& kv : *mp) for (auto& x : kv.second)
+        fprintf(bf_out, "%s\t%llu\t%llu\t.\t0\t%c\n", bd.ref_names[kv.first].c_str(), (unsigned long long)x.s, (unsigned long long)x.e,
+            mp == &bed.pos ? '+' : '-');
+      fclose(bf_out);
+    }
     std::vector<std::string> sf;
-    for (size_t i = 0; i < rest.size(); i++) if (rest[i] != a.in_bam && rest[i] != a.out_bed) sf.push_back(rest[i]);
+    for (size_t i = 0; i < rest.size(); i++) {
+      if (rest[i] == a.in_bam || rest[i] == a.out_bed) continue;
+      // (the motif positions already hold the intersection with the BED: the estimate gets them as its only --include-bed)
+      if (!motif_bed_path.empty() && (rest[i] == "--include-bed" || rest[i] == "--include-positions")) { i++; continue; }
+      sf.push_back(rest[i]);
+    }
+    if (!motif_bed_path.empty()) { sf.push_back("--include-bed"); sf.push_back(motif_bed_path); }
     // (--include-bed: "specifying include-only BED outputs only mapped sites", util.rs:136-142 — positions without a reference position do not count)
-    if (!mapped_only && a.include_bed.empty()) sf.push_back("--include-unmapped");
+    if (!mapped_only && !have_bed) sf.push_back("--include-unmapped");
     std::vector<const char*> sav; for (auto& x : sf) sav.push_back(x.c_str());
     mkp_config cfg; memset(&cfg, 0, sizeof(cfg)); cfg.device = device;
     int rc = mkp_ctx_create(&cfg, &ctx);
@@ -1839,16 +1881,11 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       kc.numeric_mode = 2; kc.collapse_code = code; }
     must(mkp_set_caller(ctx, &kc));
     must(mkp_internal_set_extract(ctx, true));
-    const BamData bd = load_bam(a.in_bam, 0, false);
-    Fasta fasta; if (!ref_path.empty()) fasta = Fasta::load(ref_path);
     // --include-bed (ReferencePositionFilter::keep, src/extract/util.rs:44-69), --region, --num-reads (src/extract/util.rs:126-160, 329-575).
     // With an index (and without --ignore-index) the reference walks interval chunks of the targets: --region then selects the records its
     // fetches return — every record overlapping the region, once — where the serial scan looks at every record of the file.  The reference's
     // rows leave in the order its pool finishes the intervals; here in file order.  --num-reads: the serial path's "first N records that
     // reach process_record"; on an indexed BAM it follows the sampling schedule (below).
-    BedFilter bed; const bool have_bed = !a.include_bed.empty();
-    if (have_bed) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;
-      bed = BedFilter::load(a.include_bed, c2t); }
     // --exclude-bed (load_regions, util.rs:177-187; ReferencePositionFilter::keep = include hit && !exclude hit): a row filter only
     BedFilter exbed; const bool have_ex = !exclude_bed.empty();
     if (have_ex) { std::map<std::string, uint32_t> c2t; for (size_t t = 0; t < bd.ref_names.size(); t++) c2t[bd.ref_names[t]] = (uint32_t)t;

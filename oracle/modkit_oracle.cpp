@@ -884,6 +884,31 @@ static int run_extract_calls(const Options& o, const ExtractOptions& xo_in) {
     for (auto& rr : get_targets(bam, nullptr)) c2t[rr.name] = rr.tid;   // name_to_tid of the whole header (subcommand.rs:514-517), not of --region
     pf_store = PositionFilter::from_bed(o.include_bed, c2t); pf = &pf_store;
     xo.include = [pf](int32_t tid, uint64_t p, bool neg) { return pf->contains(tid, p, neg); }; }
+  // --motif / --cpg (load_regions, util.rs:157-277): the include filter becomes the motif hits over every contig of the FASTA that the header
+  // names (the whole sequence, upper-cased unless --mask), one position per hit and strand, intersected with the --include-bed positions when
+  // both are given; from there on it IS the include filter — rows, the estimate, the schedule ("outputs only mapped sites")
+  if (o.cpg || !o.motif_parts.empty()) {
+    if (xo.ref_fasta.empty()) throw MkErr("--motif / --cpg need --ref");
+    std::vector<std::string> parts = o.motif_parts;   // RegexMotif::from_raw_parts (motif_bed.rs:152-195)
+    if (o.cpg) { bool has = false; for (size_t i = 0; i + 1 < parts.size(); i += 2) if (parts[i] == "CG" && parts[i + 1] == "0") has = true;
+      if (!has) { parts.push_back("CG"); parts.push_back("0"); } }
+    std::vector<Motif> motifs;
+    for (size_t i = 0; i + 1 < parts.size(); i += 2) motifs.push_back(parse_motif(parts[i], strtoul(parts[i + 1].c_str(), nullptr, 10)));
+    Fasta fa = Fasta::load(xo.ref_fasta);
+    PositionFilter mf;
+    for (auto& kv : fa.seqs) {
+      const int tid = bam.tid_of(kv.first); if (tid < 0) continue;
+      std::string seq = kv.second; if (!o.mask) for (char& c : seq) c = (char)toupper((unsigned char)c);
+      auto& P = mf.pos[(uint32_t)tid]; auto& N = mf.neg[(uint32_t)tid];   // (a searched contig is in the filter even without a hit)
+      for (auto& m : motifs) for (auto& h : find_motif_hits(seq, m)) {
+        if (pf && !pf->contains(tid, h.first, h.second)) continue;
+        (h.second ? N : P).push_back({(uint64_t)h.first, (uint64_t)h.first + 1});
+      }
+      lapper_merge(P); lapper_merge(N);
+    }
+    pf_store = std::move(mf); pf = &pf_store;
+    xo.include = [pf](int32_t tid, uint64_t p, bool neg) { return pf->contains(tid, p, neg); };
+  }
   // --exclude-bed (load_regions, util.rs:177-187): a row filter only — neither the estimate nor the schedule looks at it
   PositionFilter ex_store;
   if (!xo.exclude_bed.empty()) { std::map<std::string, uint32_t> c2t; for (auto& rr : get_targets(bam, nullptr)) c2t[rr.name] = rr.tid;

@@ -43,6 +43,9 @@ FLAG_SETS = [
     ["--num-reads", "400", "-i", "2500", "-p", "0.25"],                     # more than the file holds: quotas capped by the index counts
     ["--num-reads", "30", "--include-bed", "{bed}", "--no-filtering"],      # indexed + BED: the schedule over the BED-optimised reference records
     ["--num-reads", "45", "--include-bed", "{bed}", "-i", "300", "--region", "ctgA", "--filter-threshold", "0.6"],
+    ["--cpg", "--ref", "{fa}", "--no-filtering"],                           # the include filter = the motif hits of the whole contigs (util.rs:157-277)
+    ["--motif", "CG", "0", "--motif", "GATC", "1", "--ref", "{fa}", "--include-bed", "{bed}", "-p", "0.3"],   # ... intersected with the BED; estimate under it
+    ["--cpg", "--ref", "{fa}", "--mask", "--num-reads", "40", "--filter-threshold", "0.7"],                     # ... soft-masked bases do not match; the schedule
     ["--exclude-bed", "{bed}", "--no-filtering"],                           # keep = include hit && !exclude hit; rows without a reference position stay
     ["--exclude-bed", "{bed}", "--mapped-only", "--filter-threshold", "0.7", "--num-reads", "80"],
     ["--ignore-implicit", "--no-filtering"],                                # honoured by the reference's interval path only (an index, no --ignore-index)
