@@ -379,8 +379,8 @@ int mkp_summary(mkp_ctx* ctx, const char* bam_path, int argc, const char* const*
  * --ignore-implicit drops the inferred calls where the reference does: in its interval path (an index, no --ignore-index; util.rs:413-419) — its
  * serial scan takes the flag and never looks at it.  --exclude-bed drops the rows whose reference position and reference mod strand the BED
  * lists (ReferencePositionFilter::keep, util.rs:44-69).  --motif M off / --cpg (with --ref, --mask): the include filter becomes the motif hits
- * over the whole contigs, intersected with --include-bed (load_regions, util.rs:157-277).  --seed goes to the estimate.  --bgzf fails with
- * MKP_E_UNSUPPORTED. */
+ * over the whole contigs, intersected with --include-bed (load_regions, util.rs:157-277).  --seed goes to the estimate.  --bgzf writes the table as
+ * BGZF blocks (SAM spec 4.1) closed by the EOF block. */
 int mkp_extract_calls_main(int argc, const char* const* argv, char* errbuf, size_t errbuf_len);
 
 /* ---- BGZF inflate on the device as a call of its own.  On the pileup path the same kernels run inside the device ingest

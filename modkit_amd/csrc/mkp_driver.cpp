@@ -1777,7 +1777,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
   mkp_ctx* ctx = nullptr;
   struct Guard { mkp_ctx** c; ~Guard() { if (*c) mkp_ctx_destroy(*c); } } guard{&ctx};
   try {
-    std::string ref_path, exclude_bed; std::vector<std::string> motif_parts; bool cpg = false;
+    std::string ref_path, exclude_bed; std::vector<std::string> motif_parts; bool cpg = false, bgzf = false;
       bool allow_np = false, mapped_only = false, pass_only = false, no_headers = false, stats = false, ignore_index = false, ignore_implicit = false;
       size_t kmer = 5; int device = 0; long num_reads = -1;
     std::vector<std::string> rest;
@@ -1794,8 +1794,7 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
       else if (s == "--ignore-implicit") ignore_implicit = true;
       else if (s == "--exclude-bed" || s == "-v" || s == "--exclude-positions") exclude_bed = val();
       else if (s == "--motif") { motif_parts.push_back(val()); motif_parts.push_back(val()); } else if (s == "--cpg") cpg = true;
-      else if (s == "--bgzf")
-        throw Error(MKP_E_UNSUPPORTED, "extract calls: " + s + " is outside what this library restates (plain-text table; see include/mkpileup.h)");
+      else if (s == "--bgzf") bgzf = true; else if (s == "--out-threads") val();
       else rest.push_back(s);
     }
     if (kmer == 0 || kmer > 50) throw Error(MKP_E_INVALID, "kmer size must be less than or equal to 50");
@@ -1945,8 +1944,19 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
     FILE* out = (a.out_bed == "-" || a.out_bed == "stdout") ? stdout : fopen(a.out_bed.c_str(), "w+");
     if (!out) throw Error(MKP_E_IO, "failed to make output file " + a.out_bed);
     struct Close { FILE* f; ~Close() { if (f && f != stdout) fclose(f); } } closer{out};
-    if (!no_headers) fputs("read_id\tforward_read_position\tref_position\tchrom\tmod_strand\tref_strand\tref_mod_strand\tfw_soft_clipped_start\tfw_soft_clipped_end\tread_length\tcall_prob\tcall_code\t"
-                           "base_qual\tref_kmer\tquery_kmer\tcanonical_base\tmodified_primary_base\tfail\tinferred\twithin_alignment\tflag\n", out);
+    // --bgzf (src/extract/subcommand.rs:629-660): the same table as BGZF blocks (SAM spec 4.1) cut at 0xff00 bytes, closed by the empty EOF block
+    std::vector<uint8_t> zpend, zout;
+    auto put = [&](const char* p, size_t n) {
+      if (!bgzf) { if (n && fwrite(p, 1, n, out) != n) throw Error(MKP_E_IO, "write error on " + a.out_bed); return; }
+      zpend.insert(zpend.end(), (const uint8_t*)p, (const uint8_t*)p + n);
+      size_t at = 0; zout.clear();
+      while (zpend.size() - at >= MKP_BGZF_BLOCK) { bgzf_block(zpend.data() + at, MKP_BGZF_BLOCK, &zout); at += MKP_BGZF_BLOCK; }
+      zpend.erase(zpend.begin(), zpend.begin() + (long)at);
+      if (!zout.empty() && fwrite(zout.data(), 1, zout.size(), out) != zout.size()) throw Error(MKP_E_IO, "write error on " + a.out_bed);
+    };
+    static const char EXTRACT_HEADER[] = "read_id\tforward_read_position\tref_position\tchrom\tmod_strand\tref_strand\tref_mod_strand\tfw_soft_clipped_start\tfw_soft_clipped_end\tread_length\tcall_prob\tcall_code\t"
+                                         "base_qual\tref_kmer\tquery_kmer\tcanonical_base\tmodified_primary_base\tfail\tinferred\twithin_alignment\tflag\n";
+    if (!no_headers) put(EXTRACT_HEADER, sizeof(EXTRACT_HEADER) - 1);
     BamBatch view; view.base = bd.raw.data();
     uint64_t n_used = 0, n_skipped = 0, n_failed = 0, n_rows = 0;
     static const char NT16[] = "=ACMGRSVTWYHKDBN";
@@ -2105,7 +2115,13 @@ extern "C" int mkp_extract_calls_main(int argc, const char* const* argv, char* e
         }
         if (any) n_used++; else n_skipped++;
       }
-      if (!text.empty() && fwrite(text.data(), 1, text.size(), out) != text.size()) throw Error(MKP_E_IO, "write error on " + a.out_bed);
+      put(text.data(), text.size());
+    }
+    if (bgzf) {
+      zout.clear(); if (!zpend.empty()) bgzf_block(zpend.data(), zpend.size(), &zout);
+      static const uint8_t eof_block[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      zout.insert(zout.end(), eof_block, eof_block + 28);
+      if (fwrite(zout.data(), 1, zout.size(), out) != zout.size()) throw Error(MKP_E_IO, "write error on " + a.out_bed);
     }
     if (stats) fprintf(stderr, "[mkpileup] extract calls: reads=%llu rows=%llu skipped=%llu failed=%llu\n", (unsigned long long)n_used,
         (unsigned long long)n_rows, (unsigned long long)n_skipped, (unsigned long long)n_failed);

@@ -76,3 +76,18 @@ def test_extract_calls_fuzz_vs_oracle(oracle_bin, tmp_path, profile):
             x, y = (a[i] if i < len(a) else "<none>"), (b[i] if i < len(b) else "<none>")
             assert x == y, "profile %s flags %s row %d differs\n device: %s\n oracle: %s (%d vs %d rows)" % (profile, flags, i, x, y, len(a), len(b))
         assert len(a) > 1 or "--include-bed" in flags
+
+
+def test_bgzf_table_is_the_plain_table_compressed(tmp_path):
+    # --bgzf (src/extract/subcommand.rs:629-660): the same rows as BGZF blocks — a multi-member gzip stream closed by the empty EOF block
+    import gzip
+    bam, fa, _ = Fuzz(907 + SOAK, profile="hm_split", n_reads=300).write(str(tmp_path / "fz"))
+    plain, packed = str(tmp_path / "p.tsv"), str(tmp_path / "p.tsv.gz")
+    flags = ["--filter-threshold", "0.7", "--ref", fa]
+    modkit_amd.extract_calls([bam, plain] + flags)
+    modkit_amd.extract_calls([bam, packed, "--bgzf", "--out-threads", "2"] + flags)
+    raw = open(packed, "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC"
+    assert raw[-28:] == bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    text = gzip.open(packed, "rb").read()
+    assert text == open(plain, "rb").read() and len(text) > 3 * 0xff00   # several blocks
